@@ -1,0 +1,454 @@
+/* =====================================================================
+ * TEST INFRASTRUCTURE -- CPU restatement (plain C, IEEE fp64, no FMA
+ * contraction) of the reference's B-grid EVP subcycle.  It is the checker
+ * for the HIP path and the "port" CPU baseline; it is never linked into,
+ * loaded by, or called from the product (cice_amd/, libcice_evp_hip.so).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * PARITY PIN: this file is checked bit-for-bit against the reference's own
+ * evp() compiled unmodified from /root/reference with
+ * `amdflang -O2 -ffp-contract=off` (oracle/ref/build_ref.sh) through the
+ * golden fixtures in tests/golden/ (tests/test_oracle_golden.py).
+ *
+ * Every function cites the reference lines it follows
+ * (paths relative to /root/reference/cicecore/cicedyn/).
+ *
+ * Array layout: Fortran (nx_block, ny_block, nblocks) column-major, i.e.
+ * C index  blk*nx*ny + (j-1)*nx + (i-1)  with 1-based i,j as in the reference.
+ * ===================================================================== */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* numeric constants: shared/ice_constants.F90:79-85 */
+static const double p027 = 1.0 / 36.0;  /* p027 = p055*p5  */
+static const double p055 = 1.0 / 18.0;  /* p055 = p111*p5  */
+static const double p111 = 1.0 / 9.0;
+static const double p166 = 1.0 / 6.0;
+static const double p222 = 2.0 / 9.0;
+static const double p25 = 0.25;
+static const double p333 = 1.0 / 3.0;
+static const double p5 = 0.5;
+static const double c1p5 = 1.5;
+
+enum { BND_CLOSED = 0, BND_OPEN = 1, BND_CYCLIC = 2, BND_TRIPOLE = 3, BND_TRIPOLET = 4 };
+
+typedef struct {
+    int nx_block, ny_block, nblocks, nghost;
+    int nx_global, ny_global;
+    int ew_type, ns_type;
+    /* per block, length nblocks each; 1-based local indices as in type(block)
+       (infrastructure/ice_blocks.F90:21-41) */
+    const int *ilo, *ihi, *jlo, *jhi;
+    const int *iglob0, *jglob0; /* global index of (ilo), (jlo) */
+} evp_oracle_domain;
+
+typedef struct {
+    /* set_evp_parameters: dynamics/ice_dyn_shared.F90:453-486 */
+    double arlx1i, denom1, brlx, revp, e_factor, epp2i;
+    double capping, Ktens, deltaminEVP;
+    double u0, cosw, sinw; /* ice_dyn_shared.F90:68-70,86 */
+    double rhow;           /* Icepack constant, ice_dyn_shared.F90:920 */
+} evp_oracle_params;
+
+#define IX(i, j) ((size_t)((j)-1) * nx + (size_t)((i)-1))
+
+/* ---------------------------------------------------------------------
+ * set_evp_parameters   dynamics/ice_dyn_shared.F90:453-486
+ * ------------------------------------------------------------------- */
+void evp_oracle_set_parameters(int ndte, double dt, int revised_evp, double elasticDamp,
+                               double arlx_in, double brlx_in, double e_yieldcurve,
+                               double e_plasticpot, double *out /* arlx, arlx1i, brlx, denom1,
+                               revp, epp2i, e_factor, dtei, ecci */)
+{
+    double dtei = (double)ndte / dt;
+    double epp2i = 1.0 / (e_plasticpot * e_plasticpot);
+    double e_factor = (e_yieldcurve * e_yieldcurve) / (e_plasticpot * e_plasticpot * e_plasticpot * e_plasticpot);
+    double ecci = 1.0 / (e_yieldcurve * e_yieldcurve);
+    double revp, denom1, arlx1i, arlx = arlx_in, brlx = brlx_in;
+    if (revised_evp) {
+        revp = 1.0;
+        denom1 = 1.0;
+        arlx1i = 1.0 / arlx;
+    } else {
+        revp = 0.0;
+        arlx = 2.0 * elasticDamp * (double)ndte;
+        arlx1i = 1.0 / arlx;
+        brlx = (double)ndte;
+        denom1 = 1.0 / (1.0 + arlx1i);
+    }
+    out[0] = arlx; out[1] = arlx1i; out[2] = brlx; out[3] = denom1; out[4] = revp;
+    out[5] = epp2i; out[6] = e_factor; out[7] = dtei; out[8] = ecci;
+}
+
+/* ---------------------------------------------------------------------
+ * Ghost-cell update by *semantics* of ice_HaloUpdate for the boundary types
+ * cyclic / closed / open (infrastructure/comm/serial/ice_boundary.F90:1066-1760):
+ * a ghost cell takes the value of the interior cell that holds the same global
+ * (i,j); ghost cells outside a closed/open outer boundary are left untouched
+ * when no fillValue is given (ewfillouter/nsfillouter = .false., :1176-1182)
+ * and set to `fill` when one is (:1184-1189).  Tripole: see halo_tripole below.
+ * ------------------------------------------------------------------- */
+static void gather_global(const evp_oracle_domain *d, const double *a, double *g)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    for (int b = 0; b < d->nblocks; ++b) {
+        const double *ab = a + (size_t)b * nx * ny;
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                int ig = d->iglob0[b] + (i - d->ilo[b]);
+                int jg = d->jglob0[b] + (j - d->jlo[b]);
+                g[(size_t)(jg - 1) * d->nx_global + (ig - 1)] = ab[IX(i, j)];
+            }
+    }
+}
+
+/* field_loc: 0 = center, 1 = NE corner.  field_type: 0 = scalar, 1 = vector (sign -1 over tripole). */
+void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc, int field_type,
+                            int have_fill, double fill)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const int NX = d->nx_global, NY = d->ny_global;
+    double *g = (double *)malloc(sizeof(double) * (size_t)NX * NY);
+    gather_global(d, a, g);
+    const int tripole = (d->ns_type == BND_TRIPOLE);
+    const double isign = (field_type == 1) ? -1.0 : 1.0;
+
+    if (tripole && field_loc == 1) {
+        /* u-fold, NE-corner field: the top physical row lies on the fold and is
+           degenerate; enforce symmetry by averaging the two copies
+           (ice_boundary.F90:1630-1649), then the averaged row replaces the top
+           physical row of the array (copy-out with offsets 1,1: :1632-1633,1689-1722). */
+        double *top = g + (size_t)(NY - 1) * NX;
+        for (int i = 1; i <= NX / 2 - 1; ++i) {
+            int idst = NX - i;
+            double x1 = top[i - 1], x2 = top[idst - 1];
+            double xavg = 0.5 * (x1 + isign * x2);
+            top[i - 1] = xavg;
+            top[idst - 1] = isign * xavg;
+        }
+    }
+
+    for (int b = 0; b < d->nblocks; ++b) {
+        double *ab = a + (size_t)b * nx * ny;
+        const int ilo = d->ilo[b], ihi = d->ihi[b], jlo = d->jlo[b], jhi = d->jhi[b];
+        for (int j = jlo - d->nghost; j <= jhi + d->nghost; ++j)
+            for (int i = ilo - d->nghost; i <= ihi + d->nghost; ++i) {
+                int interior = (i >= ilo && i <= ihi && j >= jlo && j <= jhi);
+                int ig = d->iglob0[b] + (i - ilo);
+                int jg = d->jglob0[b] + (j - jlo);
+                if (interior) {
+                    if (tripole && field_loc == 1 && jg == NY) /* averaged seam row written back */
+                        ab[IX(i, j)] = g[(size_t)(NY - 1) * NX + (ig - 1)];
+                    continue;
+                }
+                int outside = 0;
+                double sgn = 1.0;
+                if (ig < 1 || ig > NX) {
+                    if (d->ew_type == BND_CYCLIC) ig = (ig < 1) ? ig + NX : ig - NX;
+                    else outside = 1;
+                }
+                if (jg < 1) {
+                    if (d->ns_type == BND_CYCLIC) jg += NY;
+                    else outside = 1;
+                } else if (jg > NY) {
+                    if (d->ns_type == BND_CYCLIC) jg -= NY;
+                    else if (tripole && !outside) {
+                        /* u-fold mirror (ice_blocks.F90:423-424; ice_boundary.F90:1689-1722).
+                           center:   ghost(ig, NY+k)  <- sign * a(NX-ig+1, NY-k+1)
+                           NEcorner: ghost(ig, NY+k)  <- sign * a(NX-ig  , NY-k  )   (offsets 1,1) */
+                        int k = jg - NY;
+                        if (field_loc == 0) { ig = NX - ig + 1; jg = NY - k + 1; }
+                        else { ig = NX - ig; jg = NY - k; if (ig < 1) ig += NX; }
+                        sgn = isign;
+                    } else outside = 1;
+                }
+                if (outside) {
+                    if (have_fill) ab[IX(i, j)] = fill;
+                    continue;
+                }
+                ab[IX(i, j)] = sgn * g[(size_t)(jg - 1) * NX + (ig - 1)];
+            }
+    }
+    free(g);
+}
+
+/* ---------------------------------------------------------------------
+ * Static metric terms   dynamics/ice_dyn_shared.F90:384-388 (DminTarea),
+ * :401-424 (dxhy, dyhx + halo with fillValue=c1), :426-441 (cxp, cyp, cxm, cym)
+ * ------------------------------------------------------------------- */
+void evp_oracle_metrics(const evp_oracle_domain *d, double deltaminEVP, const double *HTE,
+                        const double *HTN, const double *tarea, double *cxp, double *cyp,
+                        double *cxm, double *cym, double *dxhy, double *dyhx, double *DminTarea)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t nb = (size_t)nx * ny;
+    for (int b = 0; b < d->nblocks; ++b) {
+        const double *hte = HTE + b * nb, *htn = HTN + b * nb;
+        for (int j = 1; j <= ny; ++j)
+            for (int i = 1; i <= nx; ++i)
+                DminTarea[b * nb + IX(i, j)] = deltaminEVP * tarea[b * nb + IX(i, j)];
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                dxhy[b * nb + IX(i, j)] = p5 * (hte[IX(i, j)] - hte[IX(i - 1, j)]);
+                dyhx[b * nb + IX(i, j)] = p5 * (htn[IX(i, j)] - htn[IX(i, j - 1)]);
+            }
+        for (int j = d->jlo[b]; j <= d->jhi[b] + 1; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b] + 1; ++i) {
+                cyp[b * nb + IX(i, j)] = (c1p5 * hte[IX(i, j)] - p5 * hte[IX(i - 1, j)]);
+                cxp[b * nb + IX(i, j)] = (c1p5 * htn[IX(i, j)] - p5 * htn[IX(i, j - 1)]);
+                cym[b * nb + IX(i, j)] = -(c1p5 * hte[IX(i - 1, j)] - p5 * hte[IX(i, j)]);
+                cxm[b * nb + IX(i, j)] = -(c1p5 * htn[IX(i, j - 1)] - p5 * htn[IX(i, j)]);
+            }
+    }
+    evp_oracle_halo_update(d, dxhy, 0, 1, 1, 1.0);
+    evp_oracle_halo_update(d, dyhx, 0, 1, 1, 1.0);
+}
+
+/* ---------------------------------------------------------------------
+ * visc_replpress   dynamics/ice_dyn_shared.F90:2446-2475
+ * ------------------------------------------------------------------- */
+static inline void visc_replpress(const evp_oracle_params *p, double strength, double DminArea,
+                                  double Delta, double *zetax2, double *etax2, double *rep_prs)
+{
+    double tmpcalc = p->capping * (strength / fmax(Delta, DminArea)) +
+                     (1.0 - p->capping) * (strength / (Delta + DminArea));
+    *zetax2 = (1.0 + p->Ktens) * tmpcalc;
+    *rep_prs = (1.0 - p->Ktens) * tmpcalc * Delta;
+    *etax2 = p->epp2i * (*zetax2);
+}
+
+/* ---------------------------------------------------------------------
+ * stress (one T-cell)   dynamics/ice_dyn_evp.F90:1539-1741
+ *   strain_rates        dynamics/ice_dyn_shared.F90:2127-2161
+ * str1..str8 are the eight planes of the reference's str(:,:,1:8).
+ * ------------------------------------------------------------------- */
+static inline void stress_cell(const evp_oracle_params *p, int nx, int i, int j,
+                               const double *uvel, const double *vvel, const double *dxT,
+                               const double *dyT, const double *dxhy, const double *dyhx,
+                               const double *cxp, const double *cyp, const double *cxm,
+                               const double *cym, const double *DminTarea, const double *strength,
+                               double *sp1, double *sp2, double *sp3, double *sp4, double *sm1,
+                               double *sm2, double *sm3, double *sm4, double *s121, double *s122,
+                               double *s123, double *s124, double *str, size_t plane)
+{
+    const size_t c = IX(i, j);
+    const double u_ij = uvel[IX(i, j)], u_im = uvel[IX(i - 1, j)], u_jm = uvel[IX(i, j - 1)],
+                 u_mm = uvel[IX(i - 1, j - 1)];
+    const double v_ij = vvel[IX(i, j)], v_im = vvel[IX(i - 1, j)], v_jm = vvel[IX(i, j - 1)],
+                 v_mm = vvel[IX(i - 1, j - 1)];
+    const double cxp_ = cxp[c], cyp_ = cyp[c], cxm_ = cxm[c], cym_ = cym[c];
+    const double dxt = dxT[c], dyt = dyT[c];
+
+    /* divergence  =  e_11 + e_22   (:2127-2134) */
+    double divune = cyp_ * u_ij - dyt * u_im + cxp_ * v_ij - dxt * v_jm;
+    double divunw = cym_ * u_im + dyt * u_ij + cxp_ * v_im - dxt * v_mm;
+    double divusw = cym_ * u_mm + dyt * u_jm + cxm_ * v_mm + dxt * v_im;
+    double divuse = cyp_ * u_jm - dyt * u_mm + cxm_ * v_jm + dxt * v_ij;
+    /* tension strain rate  =  e_11 - e_22   (:2137-2144) */
+    double tensionne = -cym_ * u_ij - dyt * u_im + cxm_ * v_ij + dxt * v_jm;
+    double tensionnw = -cyp_ * u_im + dyt * u_ij + cxm_ * v_im + dxt * v_mm;
+    double tensionsw = -cyp_ * u_mm + dyt * u_jm + cxp_ * v_mm - dxt * v_im;
+    double tensionse = -cym_ * u_jm - dyt * u_mm + cxp_ * v_jm - dxt * v_ij;
+    /* shearing strain rate  =  2*e_12   (:2147-2154) */
+    double shearne = -cym_ * v_ij - dyt * v_im - cxm_ * u_ij - dxt * u_jm;
+    double shearnw = -cyp_ * v_im + dyt * v_ij - cxm_ * u_im - dxt * u_mm;
+    double shearsw = -cyp_ * v_mm + dyt * v_jm - cxp_ * u_mm + dxt * u_im;
+    double shearse = -cym_ * v_jm - dyt * v_mm - cxp_ * u_jm + dxt * u_ij;
+    /* Delta   (:2158-2161) */
+    double Deltane = sqrt(divune * divune + p->e_factor * (tensionne * tensionne + shearne * shearne));
+    double Deltanw = sqrt(divunw * divunw + p->e_factor * (tensionnw * tensionnw + shearnw * shearnw));
+    double Deltasw = sqrt(divusw * divusw + p->e_factor * (tensionsw * tensionsw + shearsw * shearsw));
+    double Deltase = sqrt(divuse * divuse + p->e_factor * (tensionse * tensionse + shearse * shearse));
+
+    double zetax2ne, etax2ne, rep_prsne, zetax2nw, etax2nw, rep_prsnw;
+    double zetax2sw, etax2sw, rep_prssw, zetax2se, etax2se, rep_prsse;
+    visc_replpress(p, strength[c], DminTarea[c], Deltane, &zetax2ne, &etax2ne, &rep_prsne);
+    visc_replpress(p, strength[c], DminTarea[c], Deltanw, &zetax2nw, &etax2nw, &rep_prsnw);
+    visc_replpress(p, strength[c], DminTarea[c], Deltasw, &zetax2sw, &etax2sw, &rep_prssw);
+    visc_replpress(p, strength[c], DminTarea[c], Deltase, &zetax2se, &etax2se, &rep_prsse);
+
+    /* the stresses (ice_dyn_evp.F90:1585-1610); (1) NE, (2) NW, (3) SW, (4) SE */
+    const double arlx1i = p->arlx1i, revp = p->revp, denom1 = p->denom1;
+    sp1[c] = (sp1[c] * (1.0 - arlx1i * revp) + arlx1i * (zetax2ne * divune - rep_prsne)) * denom1;
+    sp2[c] = (sp2[c] * (1.0 - arlx1i * revp) + arlx1i * (zetax2nw * divunw - rep_prsnw)) * denom1;
+    sp3[c] = (sp3[c] * (1.0 - arlx1i * revp) + arlx1i * (zetax2sw * divusw - rep_prssw)) * denom1;
+    sp4[c] = (sp4[c] * (1.0 - arlx1i * revp) + arlx1i * (zetax2se * divuse - rep_prsse)) * denom1;
+
+    sm1[c] = (sm1[c] * (1.0 - arlx1i * revp) + arlx1i * etax2ne * tensionne) * denom1;
+    sm2[c] = (sm2[c] * (1.0 - arlx1i * revp) + arlx1i * etax2nw * tensionnw) * denom1;
+    sm3[c] = (sm3[c] * (1.0 - arlx1i * revp) + arlx1i * etax2sw * tensionsw) * denom1;
+    sm4[c] = (sm4[c] * (1.0 - arlx1i * revp) + arlx1i * etax2se * tensionse) * denom1;
+
+    s121[c] = (s121[c] * (1.0 - arlx1i * revp) + arlx1i * p5 * etax2ne * shearne) * denom1;
+    s122[c] = (s122[c] * (1.0 - arlx1i * revp) + arlx1i * p5 * etax2nw * shearnw) * denom1;
+    s123[c] = (s123[c] * (1.0 - arlx1i * revp) + arlx1i * p5 * etax2sw * shearsw) * denom1;
+    s124[c] = (s124[c] * (1.0 - arlx1i * revp) + arlx1i * p5 * etax2se * shearse) * denom1;
+
+    /* combinations of the stresses for the momentum equation (:1646-1689) */
+    double ssigpn = sp1[c] + sp2[c];
+    double ssigps = sp3[c] + sp4[c];
+    double ssigpe = sp1[c] + sp4[c];
+    double ssigpw = sp2[c] + sp3[c];
+    double ssigp1 = (sp1[c] + sp3[c]) * p055;
+    double ssigp2 = (sp2[c] + sp4[c]) * p055;
+
+    double ssigmn = sm1[c] + sm2[c];
+    double ssigms = sm3[c] + sm4[c];
+    double ssigme = sm1[c] + sm4[c];
+    double ssigmw = sm2[c] + sm3[c];
+    double ssigm1 = (sm1[c] + sm3[c]) * p055;
+    double ssigm2 = (sm2[c] + sm4[c]) * p055;
+
+    double ssig12n = s121[c] + s122[c];
+    double ssig12s = s123[c] + s124[c];
+    double ssig12e = s121[c] + s124[c];
+    double ssig12w = s122[c] + s123[c];
+    double ssig121 = (s121[c] + s123[c]) * p111;
+    double ssig122 = (s122[c] + s124[c]) * p111;
+
+    double csigpne = p111 * sp1[c] + ssigp2 + p027 * sp3[c];
+    double csigpnw = p111 * sp2[c] + ssigp1 + p027 * sp4[c];
+    double csigpsw = p111 * sp3[c] + ssigp2 + p027 * sp1[c];
+    double csigpse = p111 * sp4[c] + ssigp1 + p027 * sp2[c];
+
+    double csigmne = p111 * sm1[c] + ssigm2 + p027 * sm3[c];
+    double csigmnw = p111 * sm2[c] + ssigm1 + p027 * sm4[c];
+    double csigmsw = p111 * sm3[c] + ssigm2 + p027 * sm1[c];
+    double csigmse = p111 * sm4[c] + ssigm1 + p027 * sm2[c];
+
+    double csig12ne = p222 * s121[c] + ssig122 + p055 * s123[c];
+    double csig12nw = p222 * s122[c] + ssig121 + p055 * s124[c];
+    double csig12sw = p222 * s123[c] + ssig122 + p055 * s121[c];
+    double csig12se = p222 * s124[c] + ssig121 + p055 * s122[c];
+
+    double str12ew = p5 * dxt * (p333 * ssig12e + p166 * ssig12w);
+    double str12we = p5 * dxt * (p333 * ssig12w + p166 * ssig12e);
+    double str12ns = p5 * dyt * (p333 * ssig12n + p166 * ssig12s);
+    double str12sn = p5 * dyt * (p333 * ssig12s + p166 * ssig12n);
+
+    const double dxhy_ = dxhy[c], dyhx_ = dyhx[c];
+    /* for dF/dx (u momentum) (:1698-1717) */
+    double strp_tmp = p25 * dyt * (p333 * ssigpn + p166 * ssigps);
+    double strm_tmp = p25 * dyt * (p333 * ssigmn + p166 * ssigms);
+    str[0 * plane + c] = -strp_tmp - strm_tmp - str12ew + dxhy_ * (-csigpne + csigmne) + dyhx_ * csig12ne;
+    str[1 * plane + c] = strp_tmp + strm_tmp - str12we + dxhy_ * (-csigpnw + csigmnw) + dyhx_ * csig12nw;
+    strp_tmp = p25 * dyt * (p333 * ssigps + p166 * ssigpn);
+    strm_tmp = p25 * dyt * (p333 * ssigms + p166 * ssigmn);
+    str[2 * plane + c] = -strp_tmp - strm_tmp + str12ew + dxhy_ * (-csigpse + csigmse) + dyhx_ * csig12se;
+    str[3 * plane + c] = strp_tmp + strm_tmp + str12we + dxhy_ * (-csigpsw + csigmsw) + dyhx_ * csig12sw;
+    /* for dF/dy (v momentum) (:1722-1739) */
+    strp_tmp = p25 * dxt * (p333 * ssigpe + p166 * ssigpw);
+    strm_tmp = p25 * dxt * (p333 * ssigme + p166 * ssigmw);
+    str[4 * plane + c] = -strp_tmp + strm_tmp - str12ns - dyhx_ * (csigpne + csigmne) + dxhy_ * csig12ne;
+    str[5 * plane + c] = strp_tmp - strm_tmp - str12sn - dyhx_ * (csigpse + csigmse) + dxhy_ * csig12se;
+    strp_tmp = p25 * dxt * (p333 * ssigpw + p166 * ssigpe);
+    strm_tmp = p25 * dxt * (p333 * ssigmw + p166 * ssigme);
+    str[6 * plane + c] = -strp_tmp + strm_tmp + str12ns - dyhx_ * (csigpnw + csigmnw) + dxhy_ * csig12nw;
+    str[7 * plane + c] = strp_tmp - strm_tmp + str12sn - dyhx_ * (csigpsw + csigmsw) + dxhy_ * csig12sw;
+}
+
+/* ---------------------------------------------------------------------
+ * stepu (one U-cell)   dynamics/ice_dyn_shared.F90:925-966
+ * ------------------------------------------------------------------- */
+static inline void stepu_cell(const evp_oracle_params *p, int nx, int i, int j, const double *Cw,
+                              const double *aiX, const double *str, size_t plane,
+                              const double *uocn, const double *vocn, const double *waterx,
+                              const double *watery, const double *forcex, const double *forcey,
+                              const double *Umassdti, const double *fm, const double *uarear,
+                              double *strintx, double *strinty, double *taubx, double *tauby,
+                              const double *uvel_init, const double *vvel_init, double *uvel,
+                              double *vvel, const double *TbU)
+{
+    const size_t c = IX(i, j);
+    double uold = uvel[c];
+    double vold = vvel[c];
+    /* (magnitude of relative ocean current)*rhow*drag*aice */
+    double vrel = aiX[c] * p->rhow * Cw[c] *
+                  sqrt((uocn[c] - uold) * (uocn[c] - uold) + (vocn[c] - vold) * (vocn[c] - vold));
+    double taux = vrel * waterx[c];
+    double tauy = vrel * watery[c];
+    double Cb = TbU[c] / (sqrt(uold * uold + vold * vold) + p->u0);
+    double cca = (p->brlx + p->revp) * Umassdti[c] + vrel * p->cosw + Cb;
+    double ccb = fm[c] + copysign(1.0, fm[c]) * vrel * p->sinw;
+    double ab2 = cca * cca + ccb * ccb;
+    /* divergence of the internal stress tensor (:948-951) */
+    strintx[c] = uarear[c] * (str[0 * plane + IX(i, j)] + str[1 * plane + IX(i + 1, j)] +
+                              str[2 * plane + IX(i, j + 1)] + str[3 * plane + IX(i + 1, j + 1)]);
+    strinty[c] = uarear[c] * (str[4 * plane + IX(i, j)] + str[5 * plane + IX(i, j + 1)] +
+                              str[6 * plane + IX(i + 1, j)] + str[7 * plane + IX(i + 1, j + 1)]);
+    double cc1 = strintx[c] + forcex[c] + taux + Umassdti[c] * (p->brlx * uold + p->revp * uvel_init[c]);
+    double cc2 = strinty[c] + forcey[c] + tauy + Umassdti[c] * (p->brlx * vold + p->revp * vvel_init[c]);
+    uvel[c] = (cca * cc1 + ccb * cc2) / ab2;
+    vvel[c] = (cca * cc2 - ccb * cc1) / ab2;
+    taubx[c] = -uvel[c] * Cb;
+    tauby[c] = -vvel[c] * Cb;
+}
+
+/* ---------------------------------------------------------------------
+ * The subcycle loop   dynamics/ice_dyn_evp.F90:859-913
+ *   do ksub = 1,ndte { for all blocks: stress ; stepu }  ; halo(uvel,vvel) NEcorner/vector
+ * Dense sweep with masks instead of the reference's compressed index lists;
+ * the index-list contract is dyn_prep2's (ice_dyn_shared.F90:740-789):
+ *   T-cells: ilo..ihi+1 x jlo..jhi+1 where iceTmask ;  U-cells: ilo..ihi x jlo..jhi where iceUmask.
+ * Pointer table `f` (each (nx_block,ny_block,nblocks)):
+ *  0-11 stressp_1..4, stressm_1..4, stress12_1..4 (inout)
+ *  12 strength 13 cdn_ocnU 14 aiU 15 uocnU 16 vocnU 17 waterxU 18 wateryU 19 forcexU 20 forceyU
+ *  21 umassdti 22 fmU 23 strintxU 24 strintyU 25 TbU 26 taubxU 27 taubyU 28 uvel 29 vvel
+ *  30 uvel_init 31 vvel_init
+ * Static table `g`: 0 dxT 1 dyT 2 dxhy 3 dyhx 4 cxp 5 cyp 6 cxm 7 cym 8 DminTarea 9 uarear
+ * ------------------------------------------------------------------- */
+void evp_oracle_subcycle(const evp_oracle_domain *d, const evp_oracle_params *p, int ndte,
+                         double *const *f, const double *const *g, const int32_t *iceTmask,
+                         const int32_t *iceUmask)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t nb = (size_t)nx * ny;
+    double *str = (double *)malloc(sizeof(double) * 8 * nb * (size_t)d->nblocks);
+
+    for (int ksub = 0; ksub < ndte; ++ksub) {
+#pragma omp parallel
+        {
+#pragma omp for schedule(static) collapse(2)
+            for (int b = 0; b < d->nblocks; ++b)
+                for (int j = 1; j <= ny; ++j) {
+                    double *strb = str + 8 * nb * b;
+                    /* str(:,:,:) = c0   (ice_dyn_evp.F90:1537) */
+                    for (int k = 0; k < 8; ++k)
+                        memset(strb + k * nb + IX(1, j), 0, sizeof(double) * nx);
+                    if (j < d->jlo[b] || j > d->jhi[b] + 1) continue;
+                    for (int i = d->ilo[b]; i <= d->ihi[b] + 1; ++i) {
+                        if (!iceTmask[b * nb + IX(i, j)]) continue;
+                        stress_cell(p, nx, i, j, f[28] + b * nb, f[29] + b * nb, g[0] + b * nb,
+                                    g[1] + b * nb, g[2] + b * nb, g[3] + b * nb, g[4] + b * nb,
+                                    g[5] + b * nb, g[6] + b * nb, g[7] + b * nb, g[8] + b * nb,
+                                    f[12] + b * nb, f[0] + b * nb, f[1] + b * nb, f[2] + b * nb,
+                                    f[3] + b * nb, f[4] + b * nb, f[5] + b * nb, f[6] + b * nb,
+                                    f[7] + b * nb, f[8] + b * nb, f[9] + b * nb, f[10] + b * nb,
+                                    f[11] + b * nb, strb, nb);
+                    }
+                }
+            /* implicit barrier: all str planes complete before stepu reads neighbours */
+#pragma omp for schedule(static) collapse(2)
+            for (int b = 0; b < d->nblocks; ++b)
+                for (int j = 1; j <= ny; ++j) {
+                    if (j < d->jlo[b] || j > d->jhi[b]) continue;
+                    const double *strb = str + 8 * nb * b;
+                    for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                        if (!iceUmask[b * nb + IX(i, j)]) continue;
+                        stepu_cell(p, nx, i, j, f[13] + b * nb, f[14] + b * nb, strb, nb,
+                                   f[15] + b * nb, f[16] + b * nb, f[17] + b * nb, f[18] + b * nb,
+                                   f[19] + b * nb, f[20] + b * nb, f[21] + b * nb, f[22] + b * nb,
+                                   g[9] + b * nb, f[23] + b * nb, f[24] + b * nb, f[26] + b * nb,
+                                   f[27] + b * nb, f[30] + b * nb, f[31] + b * nb, f[28] + b * nb,
+                                   f[29] + b * nb, f[25] + b * nb);
+                    }
+                }
+        }
+        /* dyn_haloUpdate(uvel, vvel; field_loc_NEcorner, field_type_vector)  (:908-910) */
+        evp_oracle_halo_update(d, f[28], 1, 1, 0, 0.0);
+        evp_oracle_halo_update(d, f[29], 1, 1, 0, 0.0);
+    }
+    free(str);
+}

@@ -1,0 +1,150 @@
+"""TEST INFRASTRUCTURE -- ctypes front end of oracle/libevp_oracle.so (the CPU
+restatement of the reference EVP subcycle).  Importable only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; the product
+(cice_amd/) never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "libevp_oracle.so"
+
+BND = {"closed": 0, "open": 1, "cyclic": 2, "tripole": 3, "tripoleT": 4}
+
+# order of the dynamic-field pointer table of evp_oracle_subcycle
+DYN_FIELDS = [
+    "stressp_1", "stressp_2", "stressp_3", "stressp_4",
+    "stressm_1", "stressm_2", "stressm_3", "stressm_4",
+    "stress12_1", "stress12_2", "stress12_3", "stress12_4",
+    "strength", "cdn_ocnU", "aiU", "uocnU", "vocnU", "waterxU", "wateryU",
+    "forcexU", "forceyU", "umassdti", "fmU", "strintxU", "strintyU", "TbU",
+    "taubxU", "taubyU", "uvel", "vvel", "uvel_init", "vvel_init",
+]
+STATIC_FIELDS = ["dxT", "dyT", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "DminTarea", "uarear"]
+OUT_FIELDS = DYN_FIELDS[:12] + ["strintxU", "strintyU", "taubxU", "taubyU", "uvel", "vvel"]
+
+
+class Domain(C.Structure):
+    _fields_ = [("nx_block", C.c_int), ("ny_block", C.c_int), ("nblocks", C.c_int),
+                ("nghost", C.c_int), ("nx_global", C.c_int), ("ny_global", C.c_int),
+                ("ew_type", C.c_int), ("ns_type", C.c_int),
+                ("ilo", C.POINTER(C.c_int)), ("ihi", C.POINTER(C.c_int)),
+                ("jlo", C.POINTER(C.c_int)), ("jhi", C.POINTER(C.c_int)),
+                ("iglob0", C.POINTER(C.c_int)), ("jglob0", C.POINTER(C.c_int))]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping", "Ktens",
+                 "deltaminEVP", "u0", "cosw", "sinw", "rhow")]
+
+
+def build(force: bool = False) -> Path:
+    if force or not LIB.exists() or LIB.stat().st_mtime < (HERE / "evp_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(HERE), "-B", "libevp_oracle.so"], check=True,
+                       capture_output=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(LIB))
+        _lib.evp_oracle_subcycle.restype = None
+        _lib.evp_oracle_metrics.restype = None
+        _lib.evp_oracle_halo_update.restype = None
+        _lib.evp_oracle_set_parameters.restype = None
+    return _lib
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleDomain:
+    """Block geometry as the reference's `type(block)` holds it
+    (ice_blocks.F90:21-41): per block ilo,ihi,jlo,jhi (1-based) and the global
+    index of the first interior cell."""
+
+    def __init__(self, nx_block, ny_block, nblocks, nx_global, ny_global, ew, ns,
+                 ilo, ihi, jlo, jhi, iglob0, jglob0, nghost=1):
+        self.arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (ilo, ihi, jlo, jhi, iglob0, jglob0)]
+        self.c = Domain(nx_block, ny_block, nblocks, nghost, nx_global, ny_global,
+                        BND[ew], BND[ns], *[_ip(a) for a in self.arrs])
+        self.shape = (nblocks, ny_block, nx_block)
+
+    @classmethod
+    def from_dump(cls, d, ew, ns):
+        nxb, nyb, nblk, ngh, nxg, nyg = [int(v) for v in d["dims"][:6]]
+        bi = np.asarray(d["blkinfo"]).reshape(nblk, 8)
+        return cls(nxb, nyb, nblk, nxg, nyg, ew, ns, bi[:, 0], bi[:, 1], bi[:, 2], bi[:, 3],
+                   bi[:, 6], bi[:, 7], nghost=ngh)
+
+
+def make_params(**kw) -> Params:
+    p = Params()
+    for k, v in kw.items():
+        setattr(p, k, float(v))
+    return p
+
+
+def params_from_scalars(s) -> Params:
+    """scalars record of the reference harness dump (evp_ref_harness.F90)."""
+    return make_params(arlx1i=s[0], denom1=s[1], brlx=s[2], revp=s[3], e_factor=s[4], epp2i=s[5],
+                       capping=s[6], Ktens=s[7], deltaminEVP=s[8], u0=s[9], cosw=s[10], sinw=s[11],
+                       rhow=s[12])
+
+
+def set_parameters(ndte, dt, revised_evp=False, elasticDamp=0.36, arlx=300.0, brlx=300.0,
+                   e_yieldcurve=2.0, e_plasticpot=2.0):
+    out = np.zeros(9)
+    lib().evp_oracle_set_parameters(C.c_int(ndte), C.c_double(dt), C.c_int(int(revised_evp)),
+                                    C.c_double(elasticDamp), C.c_double(arlx), C.c_double(brlx),
+                                    C.c_double(e_yieldcurve), C.c_double(e_plasticpot), _dp(out))
+    return dict(zip(["arlx", "arlx1i", "brlx", "denom1", "revp", "epp2i", "e_factor", "dtei", "ecci"], out))
+
+
+def metrics(dom: OracleDomain, deltaminEVP, HTE, HTN, tarea):
+    names = ["cxp", "cyp", "cxm", "cym", "dxhy", "dyhx", "DminTarea"]
+    out = {n: np.zeros(dom.shape) for n in names}
+    HTE, HTN, tarea = [np.ascontiguousarray(a, dtype=np.float64) for a in (HTE, HTN, tarea)]
+    lib().evp_oracle_metrics(C.byref(dom.c), C.c_double(deltaminEVP), _dp(HTE), _dp(HTN), _dp(tarea),
+                             *[_dp(out[n]) for n in names])
+    return out
+
+
+def halo_update(dom: OracleDomain, a, field_loc="NEcorner", field_type="vector", fill=None):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    lib().evp_oracle_halo_update(C.byref(dom.c), _dp(a), C.c_int(1 if field_loc == "NEcorner" else 0),
+                                 C.c_int(1 if field_type == "vector" else 0),
+                                 C.c_int(0 if fill is None else 1), C.c_double(0.0 if fill is None else fill))
+    return a
+
+
+def subcycle(dom: OracleDomain, params: Params, ndte: int, dyn: dict, static: dict,
+             iceTmask, iceUmask) -> dict:
+    """Run ndte subcycles; `dyn` maps DYN_FIELDS -> arrays (copied, originals untouched).
+    Returns the dict of all dynamic fields after the loop."""
+    work = {k: np.array(dyn[k], dtype=np.float64, order="C", copy=True) for k in DYN_FIELDS}
+    st = {k: np.ascontiguousarray(static[k], dtype=np.float64) for k in STATIC_FIELDS}
+    tm = np.ascontiguousarray(iceTmask, dtype=np.int32)
+    um = np.ascontiguousarray(iceUmask, dtype=np.int32)
+    fptr = (C.POINTER(C.c_double) * len(DYN_FIELDS))(*[_dp(work[k]) for k in DYN_FIELDS])
+    gptr = (C.POINTER(C.c_double) * len(STATIC_FIELDS))(*[_dp(st[k]) for k in STATIC_FIELDS])
+    lib().evp_oracle_subcycle(C.byref(dom.c), C.byref(params), C.c_int(ndte), fptr, gptr,
+                              tm.ctypes.data_as(C.POINTER(C.c_int32)),
+                              um.ctypes.data_as(C.POINTER(C.c_int32)))
+    return work

@@ -1,0 +1,86 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE -- builds the *unmodified* reference hot-path modules
+# in place from /root/reference (nothing is copied into this repo) with
+# amdflang, against the build-owned Icepack interface stub, and links them
+# with the build-owned harnesses in this directory.  Outputs go ONLY to
+# oracle/_ref/ (git-ignored; travels to the GPU box with the snapshot).
+#
+# Recipe = SURVEY.md Appendix A.1 (verified compile order).
+#
+#   usage: oracle/ref/build_ref.sh [strict|fast]   (default: both)
+#     strict : -O2 -ffp-contract=off  (bitwise-comparable with oracle/evp_oracle.c)
+#     fast   : -O2                    (the reference's ordinary optimisation level)
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REPO="$(cd "$HERE/../.." && pwd)"
+REF=${CICE_REFERENCE:-/root/reference}
+OUT="$REPO/oracle/_ref"
+FC=${FC:-/opt/rocm/bin/amdflang}
+
+if [ ! -d "$REF/cicecore" ]; then
+  echo "build_ref: $REF not present (GPU box?) -- using prebuilt oracle/_ref" >&2
+  exit 0
+fi
+
+R=$REF/cicecore
+S=$R/cicedyn/infrastructure/comm/serial
+SRCS=(
+  $R/shared/ice_kinds_mod.F90 $R/shared/ice_constants.F90 $R/shared/ice_fileunits.F90
+  $S/ice_exit.F90 $S/ice_communicate.F90
+  $R/shared/ice_domain_size.F90
+  $R/cicedyn/infrastructure/ice_blocks.F90 $R/cicedyn/infrastructure/ice_memusage.F90
+  $R/shared/ice_spacecurve.F90 $R/shared/ice_distribution.F90
+  $S/ice_broadcast.F90 $S/ice_reprosum.F90 $S/ice_gather_scatter.F90
+  $S/ice_global_reductions.F90 $S/ice_boundary.F90
+  $R/cicedyn/infrastructure/ice_domain.F90
+  $S/ice_timers.F90
+  $R/cicedyn/infrastructure/ice_read_write.F90
+  $R/shared/ice_calendar.F90
+  $R/cicedyn/infrastructure/ice_grid.F90
+  $R/shared/ice_arrays_column.F90
+  $R/cicedyn/general/ice_state.F90 $R/cicedyn/general/ice_flux_bgc.F90 $R/cicedyn/general/ice_flux.F90
+  $R/cicedyn/dynamics/ice_dyn_shared.F90
+  $R/cicedyn/infrastructure/ice_restoring.F90
+  $R/cicedyn/dynamics/ice_dyn_core1d.F90
+)
+# ice_dyn_evp1d is either the reference's own (refonly) or a build-owned
+# module of the same name (capture harness / HIP drop-in): see below.
+EVP1D_REF=$R/cicedyn/dynamics/ice_dyn_evp1d.F90
+EVP=$R/cicedyn/dynamics/ice_dyn_evp.F90
+CSRCS=( $R/cicedyn/infrastructure/ice_shr_reprosum86.c $R/cicedyn/infrastructure/ice_memusage_gptl.c )
+
+build_variant () {
+  local variant=$1; shift
+  local fflags="$*"
+  local O="$OUT/obj_$variant"
+  mkdir -p "$O"
+  ( cd "$O"
+    $FC $fflags -cpp -c "$HERE/icepack_intfc_stub.F90" -o icepack_intfc.o
+    for f in "${SRCS[@]}"; do
+      b=$(basename "$f" .F90)
+      if [ ! -f "$b.o" ] || [ "$f" -nt "$b.o" ]; then
+        $FC $fflags -cpp -c "$f" -o "$b.o"
+      fi
+    done
+    for f in "${CSRCS[@]}"; do
+      b=$(basename "$f" .c)
+      [ -f "$b.o" ] || gcc -O2 -DFORTRANUNDERSCORE -c "$f" -o "$b.o"
+    done
+    COMMON=$(ls *.o | grep -v -E '^(ice_dyn_evp|ice_dyn_evp1d|evp_.*)\.o$' | tr '\n' ' ')
+
+    # (1) fixture generator: capture module stands in for ice_dyn_evp1d so that
+    #     evp() hands over every (otherwise private) subcycle input; the very
+    #     next evp() call with evp_algorithm='standard_2d' gives the golden output.
+    mkdir -p cap && cd cap
+    $FC $fflags -cpp -I.. -c "$HERE/ice_dyn_evp1d_capture.F90" -o ice_dyn_evp1d.o
+    $FC $fflags -cpp -I.. -c "$EVP" -o ice_dyn_evp.o
+    $FC $fflags -cpp -I.. -I. "$HERE/evp_ref_harness.F90" ice_dyn_evp1d.o ice_dyn_evp.o \
+        $(for o in $COMMON; do echo ../$o; done) -o "$OUT/evp_ref_harness_$variant"
+    cd ..
+  )
+  echo "built $OUT/evp_ref_harness_$variant"
+}
+
+want=${1:-both}
+if [ "$want" = strict ] || [ "$want" = both ]; then build_variant strict -O2 -ffp-contract=off; fi
+if [ "$want" = fast ]   || [ "$want" = both ]; then build_variant fast   -O2 -fopenmp; fi

@@ -1,0 +1,327 @@
+!=======================================================================
+! TEST INFRASTRUCTURE (oracle/ref) -- drives the reference's own, unmodified
+! evp() (/root/reference/cicecore/cicedyn/dynamics/ice_dyn_evp.F90:259) on a
+! self-contained grid through the reference's serial comm layer, and dumps
+!   * the static grid / metric arrays and EVP scalars,
+!   * every input of the EVP subcycle, captured at the drop-in boundary by
+!     the build-owned `ice_dyn_evp1d` capture module (evp_algorithm toggled to
+!     'shared_mem_1d' for one call that computes nothing),
+!   * the reference's outputs for exactly those inputs after nsub subcycles
+!     (evp_algorithm='standard_2d', private 2-D `stress` + public `stepu` +
+!     serial ice_HaloUpdate incl. tripole), for each nsub in nsub_list,
+!   * its own timer for the subcycle loop (timer_evp), for the CPU baseline.
+! Call order mirrors cice_init
+! (/root/reference/cicecore/drivers/standalone/cice/CICE_InitMod.F90:97-141)
+! minus everything Icepack/IO; see SURVEY.md Appendix A.3.
+!
+! Inputs: ./ice_in (only &domain_nml) and ./harness_in (&harness_nml).
+! This program is written for this repo; it contains no reference code.
+!=======================================================================
+program evp_ref_harness
+
+  use ice_kinds_mod
+  use ice_constants
+  use ice_communicate, only: init_communicate, my_task
+  use ice_fileunits, only: init_fileunits, nu_diag, nml_filename
+  use ice_domain, only: init_domain_blocks, nblocks, blocks_ice, halo_info, &
+      ew_boundary_type, ns_boundary_type, maskhalo_dyn
+  use ice_domain_size
+  use ice_blocks, only: nx_block, ny_block, block, get_block, nghost
+  use ice_boundary, only: ice_HaloUpdate
+  use ice_grid
+  use ice_state
+  use ice_flux
+  use ice_flux_bgc, only: alloc_flux_bgc
+  use ice_arrays_column, only: alloc_arrays_column, Cdn_ocn
+  use ice_timers, only: init_ice_timers, ice_timer_print_all, ice_timer_clear, &
+      timer_evp
+  use ice_calendar, only: dt, dt_dyn, ndtd
+  use ice_dyn_shared
+  use ice_dyn_evp, only: init_evp, evp
+  use ice_dyn_evp1d, only: capture_tag
+  use evp_dumpio
+  use icepack_intfc, only: icepack_query_parameters
+#if defined (_OPENMP)
+  use OMP_LIB
+#endif
+
+  implicit none
+
+  ! ---- harness namelist ------------------------------------------------
+  character(len=32)  :: grid_kind   = 'rect'      ! 'rect' | 'popfile' | 'tripolefile'
+  character(len=32)  :: kmt_kind    = 'default'   ! rectgrid kmt_type, or 'file'
+  character(len=32)  :: icecase     = 'full'      ! 'full' | 'caps' | 'patchy'
+  character(len=256) :: dumpfile    = 'dump.bin'
+  character(len=256) :: h_grid_file = 'grid.bin'
+  character(len=256) :: h_kmt_file  = 'kmt.bin'
+  real(dbl_kind)     :: h_dxrect    = 16.e5_dbl_kind   ! cm
+  real(dbl_kind)     :: h_dyrect    = 16.e5_dbl_kind   ! cm
+  real(dbl_kind)     :: h_dt        = 3600._dbl_kind
+  integer(int_kind)  :: h_ndte      = 120
+  integer(int_kind)  :: ncalls      = 1
+  integer(int_kind)  :: nsub_list(8) = -1         ! subcycle counts to dump per call (last one advances state)
+  logical            :: h_revised   = .false.
+  real(dbl_kind)     :: h_arlx      = 300._dbl_kind
+  real(dbl_kind)     :: h_brlx      = 300._dbl_kind
+  real(dbl_kind)     :: h_capping   = 1._dbl_kind
+  real(dbl_kind)     :: h_Ktens     = 0._dbl_kind
+  real(dbl_kind)     :: h_e_yield   = 2._dbl_kind
+  real(dbl_kind)     :: h_e_plast   = 2._dbl_kind
+  real(dbl_kind)     :: h_elasticDamp = 0.36_dbl_kind
+  character(len=32)  :: h_coriolis  = 'latitude'
+  logical            :: h_seabed    = .false.
+  logical            :: dump_arrays = .true.      ! .false. = timing-only run (no array dumps)
+  integer(int_kind)  :: ntiming     = 0           ! extra evp() calls, timed, after the dumps
+
+  namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
+     h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
+     h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, &
+     dump_arrays, ntiming
+
+  ! ---- locals ----------------------------------------------------------
+  integer(int_kind) :: i, j, iblk, icall, k, nsub, nl, ios, nthreads
+  type(block) :: tb
+  real(dbl_kind) :: x, y, hi, taper, rhow_l
+  real(dbl_kind), parameter :: twopi = 6.283185307179586_dbl_kind
+  real(dbl_kind), allocatable, dimension(:,:,:) :: s_u, s_v, s_sp1, s_sp2, s_sp3, s_sp4, &
+     s_sm1, s_sm2, s_sm3, s_sm4, s_s121, s_s122, s_s123, s_s124
+  integer(int_kind), allocatable :: blkinfo(:)
+  real(dbl_kind) :: scal(24)
+  character(len=16) :: tag
+  integer(kind=8) :: c0_clk, c1_clk, crate
+
+  open(unit=55, file='harness_in', status='old', iostat=ios)
+  if (ios /= 0) stop 'harness_in missing'
+  read(55, nml=harness_nml)
+  close(55)
+
+  call init_communicate
+  call init_fileunits
+  nml_filename = 'ice_in'
+
+  ncat=1; nfsd=1; nilyr=1; nslyr=1; nblyr=1
+  n_iso=0; n_aero=0; n_zaero=0; n_algae=0; n_doc=0; n_dic=0; n_don=0; n_fed=0; n_fep=0
+  nfreq=1
+
+  grid_format='bin'; grid_ice='B'; grid_atm='A'; grid_ocn='A'
+  grid_atm_thrm='T'; grid_atm_dynu='T'; grid_atm_dynv='T'
+  grid_ocn_thrm='T'; grid_ocn_dynu='T'; grid_ocn_dynv='T'
+  dxrect=h_dxrect; dyrect=h_dyrect; scale_dxdy=.false.
+  lonrefrect=-156.5_dbl_kind; latrefrect=71.35_dbl_kind
+  bathymetry_format='default'; use_bathymetry=.false.
+  if (trim(grid_kind) == 'rect') then
+     grid_type='rectangular'
+     kmt_type=trim(kmt_kind)
+  else
+     if (trim(grid_kind) == 'tripolefile') then
+        grid_type='tripole'
+     else
+        grid_type='displaced_pole'
+     endif
+     grid_file=trim(h_grid_file)
+     kmt_file=trim(h_kmt_file)
+     kmt_type='file'
+  endif
+
+  kdyn=1; ndte=h_ndte; revised_evp=h_revised; evp_algorithm='standard_2d'
+  elasticDamp=h_elasticDamp
+  e_yieldcurve=h_e_yield; e_plasticpot=h_e_plast; Ktens=h_Ktens
+  deltaminEVP=1e-11_dbl_kind; capping=h_capping
+  coriolis=trim(h_coriolis); ssh_stress='geostrophic'
+  seabed_stress=h_seabed; seabed_stress_method='LKD'
+  dyn_area_min=1e-11_dbl_kind; dyn_mass_min=1e-10_dbl_kind
+  yield_curve='ellipse'; visc_method='avg_zeta'
+  arlx=h_arlx; brlx=h_brlx
+  dt=h_dt; ndtd=1; dt_dyn=dt
+
+  call init_domain_blocks
+  call init_grid1
+  call alloc_grid
+  call alloc_arrays_column
+  call alloc_state
+  call alloc_flux_bgc
+  call alloc_flux
+  call init_ice_timers
+  call init_grid2
+  call init_evp
+
+  ! ---- fill the model state that evp() reads ----------------------------
+  do iblk = 1, nblocks
+     tb = get_block(blocks_ice(iblk), iblk)
+     do j = 1, ny_block
+     do i = 1, nx_block
+        x = (real(tb%i_glob(i),dbl_kind) - p5)/real(nx_global,dbl_kind)
+        y = (real(tb%j_glob(j),dbl_kind) - p5)/real(ny_global,dbl_kind)
+        aice(i,j,iblk) = c0; vice(i,j,iblk) = c0; vsno(i,j,iblk) = c0
+        if (tmask(i,j,iblk)) then
+           hi = c2*(c1 + 0.1_dbl_kind*sin(c2*twopi*y)*cos(twopi*x))
+           select case (trim(icecase))
+           case ('full')
+              aice(i,j,iblk) = 0.9_dbl_kind + 0.05_dbl_kind*sin(twopi*x)*cos(twopi*y)
+           case ('caps')
+              taper = (abs(y - p5) - p25)/0.05_dbl_kind
+              taper = max(c0, min(c1, taper))
+              aice(i,j,iblk) = 0.95_dbl_kind*taper
+           case ('patchy')
+              aice(i,j,iblk) = 0.85_dbl_kind + 0.1_dbl_kind*sin(twopi*x)*cos(twopi*y)
+              if (sin(5.5_dbl_kind*twopi*x)*sin(3.5_dbl_kind*twopi*y) > 0.6_dbl_kind) aice(i,j,iblk) = c0
+           case default
+              stop 'unknown icecase'
+           end select
+           vice(i,j,iblk) = hi*aice(i,j,iblk)
+           vsno(i,j,iblk) = 0.2_dbl_kind*aice(i,j,iblk)
+        endif
+        aice0(i,j,iblk)   = c1 - aice(i,j,iblk)
+        aicen(i,j,1,iblk) = aice(i,j,iblk)
+        vicen(i,j,1,iblk) = vice(i,j,iblk)
+        aice_init(i,j,iblk) = aice(i,j,iblk)
+        Cdn_ocn(i,j,iblk) = 0.00536_dbl_kind
+        uocn(i,j,iblk) =  0.2_dbl_kind*y - 0.1_dbl_kind
+        vocn(i,j,iblk) = -0.2_dbl_kind*x + 0.1_dbl_kind
+        ss_tltx(i,j,iblk) = c0; ss_tlty(i,j,iblk) = c0
+        strairxT(i,j,iblk) = aice(i,j,iblk)*0.1_dbl_kind*sin(twopi*x)*sin(p5*twopi*y)
+        strairyT(i,j,iblk) = aice(i,j,iblk)*0.1_dbl_kind*sin(p5*twopi*x)*sin(twopi*y)
+        if (h_seabed) hwater(i,j,iblk) = 8._dbl_kind + 40._dbl_kind*y   ! shallow shelf in the south
+     enddo
+     enddo
+  enddo
+  ! consistent ghosts for every boundary type (cyclic, closed, tripole)
+  call ice_HaloUpdate(aice,      halo_info, field_loc_center, field_type_scalar)
+  call ice_HaloUpdate(vice,      halo_info, field_loc_center, field_type_scalar)
+  call ice_HaloUpdate(vsno,      halo_info, field_loc_center, field_type_scalar)
+  call ice_HaloUpdate(aice0,     halo_info, field_loc_center, field_type_scalar)
+  call ice_HaloUpdate(aice_init, halo_info, field_loc_center, field_type_scalar)
+  do iblk = 1, nblocks
+     aicen(:,:,1,iblk) = aice(:,:,iblk)
+     vicen(:,:,1,iblk) = vice(:,:,iblk)
+  enddo
+
+  call icepack_query_parameters(rhow_out=rhow_l)
+
+  ! ---- static dump --------------------------------------------------------
+  call dump_begin(trim(dumpfile))
+  allocate(blkinfo(8*nblocks))
+  do iblk = 1, nblocks
+     tb = get_block(blocks_ice(iblk), iblk)
+     blkinfo(8*(iblk-1)+1:8*iblk) = (/ tb%ilo, tb%ihi, tb%jlo, tb%jhi, tb%iblock, tb%jblock, &
+                                       tb%i_glob(tb%ilo), tb%j_glob(tb%jlo) /)
+  enddo
+  nl = 0
+  do k = 1, 8
+     if (nsub_list(k) > 0) nl = nl + 1
+  enddo
+  if (nl == 0) then
+     nl = 1; nsub_list(1) = h_ndte
+  endif
+  call dump_i4_1d('dims', (/ nx_block, ny_block, nblocks, nghost, nx_global, ny_global, &
+                             h_ndte, ncalls, nl /))
+  call dump_i4_1d('blkinfo', blkinfo)
+  call dump_i4_1d('nsub_list', nsub_list(1:nl))
+  scal = c0
+  scal(1)=arlx1i; scal(2)=denom1; scal(3)=brlx; scal(4)=revp; scal(5)=e_factor; scal(6)=epp2i
+  scal(7)=capping; scal(8)=Ktens; scal(9)=deltaminEVP; scal(10)=u0; scal(11)=cosw; scal(12)=sinw
+  scal(13)=rhow_l; scal(14)=dt; scal(15)=arlx; scal(16)=dtei; scal(17)=ecci
+  call dump_r8_1d('scalars', scal)
+  if (dump_arrays) then
+     call dump_r8_3d('HTE', HTE, nblocks);       call dump_r8_3d('HTN', HTN, nblocks)
+     call dump_r8_3d('dxT', dxT, nblocks);       call dump_r8_3d('dyT', dyT, nblocks)
+     call dump_r8_3d('dxU', dxU, nblocks);       call dump_r8_3d('dyU', dyU, nblocks)
+     call dump_r8_3d('tarea', tarea, nblocks);   call dump_r8_3d('uarear', uarear, nblocks)
+     call dump_r8_3d('tarear', tarear, nblocks); call dump_r8_3d('hm', hm, nblocks)
+     call dump_r8_3d('uvm', uvm, nblocks)
+     call dump_l_3d ('tmask', tmask, nblocks);   call dump_l_3d ('umask', umask, nblocks)
+     call dump_r8_3d('cxp', cxp, nblocks);       call dump_r8_3d('cyp', cyp, nblocks)
+     call dump_r8_3d('cxm', cxm, nblocks);       call dump_r8_3d('cym', cym, nblocks)
+     call dump_r8_3d('dxhy', dxhy, nblocks);     call dump_r8_3d('dyhx', dyhx, nblocks)
+     call dump_r8_3d('DminTarea', DminTarea, nblocks)
+     call dump_r8_3d('ULAT', ULAT, nblocks)
+  endif
+
+  allocate(s_u(nx_block,ny_block,max_blocks), s_v(nx_block,ny_block,max_blocks))
+  allocate(s_sp1(nx_block,ny_block,max_blocks), s_sp2(nx_block,ny_block,max_blocks), &
+           s_sp3(nx_block,ny_block,max_blocks), s_sp4(nx_block,ny_block,max_blocks), &
+           s_sm1(nx_block,ny_block,max_blocks), s_sm2(nx_block,ny_block,max_blocks), &
+           s_sm3(nx_block,ny_block,max_blocks), s_sm4(nx_block,ny_block,max_blocks), &
+           s_s121(nx_block,ny_block,max_blocks), s_s122(nx_block,ny_block,max_blocks), &
+           s_s123(nx_block,ny_block,max_blocks), s_s124(nx_block,ny_block,max_blocks))
+
+  ! ---- evp calls ------------------------------------------------------------
+  do icall = 1, ncalls
+
+     ! (1) capture the subcycle inputs at the boundary (computes nothing)
+     write(tag,'(a,i2.2)') 'in', icall
+     capture_tag = tag
+     evp_algorithm = 'shared_mem_1d'
+     if (.not. dump_arrays) call dump_end
+     call evp(dt_dyn)
+     evp_algorithm = 'standard_2d'
+
+     ! post-prep state = the captured inputs
+     s_u = uvel; s_v = vvel
+     s_sp1 = stressp_1; s_sp2 = stressp_2; s_sp3 = stressp_3; s_sp4 = stressp_4
+     s_sm1 = stressm_1; s_sm2 = stressm_2; s_sm3 = stressm_3; s_sm4 = stressm_4
+     s_s121 = stress12_1; s_s122 = stress12_2; s_s123 = stress12_3; s_s124 = stress12_4
+
+     ! (2) the reference's answer for those inputs after nsub subcycles
+     do k = 1, nl
+        nsub = nsub_list(k)
+        uvel = s_u; vvel = s_v
+        stressp_1 = s_sp1; stressp_2 = s_sp2; stressp_3 = s_sp3; stressp_4 = s_sp4
+        stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
+        stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
+        ndte = nsub                 ! loop count only; EVP scalars were fixed by init_evp
+        call evp(dt_dyn)
+        ndte = h_ndte
+        if (dump_arrays) then
+           write(tag,'(a,i2.2,a,i4.4)') 'o', icall, 'n', nsub
+           call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)
+           call dump_r8_3d(trim(tag)//'_vvel', vvel, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_1', stressp_1, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_2', stressp_2, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_3', stressp_3, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_4', stressp_4, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_1', stressm_1, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_2', stressm_2, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_3', stressm_3, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_4', stressm_4, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_1', stress12_1, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_2', stress12_2, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_3', stress12_3, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_4', stress12_4, nblocks)
+           call dump_r8_3d(trim(tag)//'_strintxU', strintxU, nblocks)
+           call dump_r8_3d(trim(tag)//'_strintyU', strintyU, nblocks)
+           call dump_r8_3d(trim(tag)//'_taubxU', taubxU, nblocks)
+           call dump_r8_3d(trim(tag)//'_taubyU', taubyU, nblocks)
+           call dump_r8_3d(trim(tag)//'_divu', divu, nblocks)
+           call dump_r8_3d(trim(tag)//'_shear', shear, nblocks)
+           call dump_r8_3d(trim(tag)//'_vort', vort, nblocks)
+           call dump_r8_3d(trim(tag)//'_rdg_conv', rdg_conv, nblocks)
+           call dump_r8_3d(trim(tag)//'_rdg_shear', rdg_shear, nblocks)
+           call dump_r8_3d(trim(tag)//'_strocnxU', strocnxU, nblocks)
+           call dump_r8_3d(trim(tag)//'_strocnyU', strocnyU, nblocks)
+        endif
+        write(*,'(a,i3,a,i5,3es24.16)') 'call', icall, ' nsub', nsub, &
+             maxval(abs(uvel(:,:,1:nblocks))), maxval(abs(vvel(:,:,1:nblocks))), &
+             maxval(abs(stressp_1(:,:,1:nblocks)))
+     enddo
+  enddo
+  call dump_end
+
+  ! ---- timing of the reference subcycle loop (its own timer_evp) -----------
+  if (ntiming > 0) then
+     nthreads = 1
+#if defined (_OPENMP)
+     nthreads = omp_get_max_threads()
+#endif
+     call ice_timer_clear(timer_evp)
+     call system_clock(c0_clk, crate)
+     do k = 1, ntiming
+        call evp(dt_dyn)
+     enddo
+     call system_clock(c1_clk)
+     write(*,'(a,i4,a,i6,a,i4,a,es14.6)') 'TIMING threads', nthreads, ' ndte', h_ndte, &
+          ' calls', ntiming, ' wall_s_total_evp_calls', real(c1_clk-c0_clk,dbl_kind)/real(crate,dbl_kind)
+     call ice_timer_print_all(stats=.false.)
+  endif
+
+end program evp_ref_harness

@@ -1,0 +1,140 @@
+"""TEST INFRASTRUCTURE -- run the compiled reference harness (oracle/_ref) and
+read its dump.  Only tests/, tests/golden/make_golden.py, smoke() and the
+bench's cpu_baseline leg may import this module; the product never does.
+
+The harness binary is built by oracle/ref/build_ref.sh from the unmodified
+reference sources in /root/reference (in place).  It travels to the GPU box as
+a prebuilt file under oracle/_ref/, so it may be *executed* there, but nothing
+here reads /root/reference at run time.
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REF_DIR = HERE.parent / "_ref"
+
+
+def harness_path(variant: str = "strict") -> Path:
+    return REF_DIR / f"evp_ref_harness_{variant}"
+
+
+def have_ref(variant: str = "strict") -> bool:
+    p = harness_path(variant)
+    return p.exists() and os.access(p, os.X_OK)
+
+
+def read_dump(path) -> dict:
+    """Parse the record stream written by evp_dumpio (see ice_dyn_evp1d_capture.F90):
+    name(32 chars) | type code int32 (1=f64, 2=i32) | d1 d2 d3 int32 | payload (Fortran order)."""
+    out = {}
+    buf = Path(path).read_bytes()
+    off = 0
+    while off < len(buf):
+        name = buf[off:off + 32].decode("ascii").strip()
+        tcode, d1, d2, d3 = np.frombuffer(buf, dtype="<i4", count=4, offset=off + 32)
+        off += 48
+        n = int(d1) * int(d2) * int(d3)
+        dt = np.dtype("<f8") if tcode == 1 else np.dtype("<i4")
+        a = np.frombuffer(buf, dtype=dt, count=n, offset=off).copy()
+        off += n * dt.itemsize
+        if d2 == 1 and d3 == 1:
+            out[name] = a
+        else:
+            # Fortran (d1,d2,d3) column-major  ->  numpy [d3][d2][d1] C-order (i fastest)
+            out[name] = a.reshape(int(d3), int(d2), int(d1))
+    return out
+
+
+def _fmt(v):
+    if isinstance(v, bool):
+        return ".true." if v else ".false."
+    if isinstance(v, str):
+        return f"'{v}'"
+    if isinstance(v, float):
+        return repr(v).replace("e", "d") if "e" in repr(v) else repr(v) + "d0"
+    if isinstance(v, (list, tuple)):
+        return ", ".join(_fmt(x) for x in v)
+    return str(v)
+
+
+def write_pop_grid(path, ULAT, ULON, HTN_cm, HTE_cm, ANGLE=None):
+    """POP-format binary grid file read by the reference's popgrid
+    (/root/reference/cicecore/cicedyn/infrastructure/ice_grid.F90:1000-1061):
+    7 direct-access records of nx_global*ny_global float64 (native endian here):
+    ULAT ULON HTN HTE HUS HUW ANGLE.  Arrays are [ny][nx]."""
+    ny, nx = ULAT.shape
+    z = np.zeros((ny, nx))
+    recs = [ULAT, ULON, HTN_cm, HTE_cm, HTN_cm, HTE_cm, z if ANGLE is None else ANGLE]
+    with open(path, "wb") as f:
+        for r in recs:
+            f.write(np.ascontiguousarray(r, dtype="<f8").tobytes())
+
+
+def write_kmt(path, kmt):
+    with open(path, "wb") as f:
+        f.write(np.ascontiguousarray(kmt, dtype="<i4").tobytes())
+
+
+def run_harness(nx_global, ny_global, block_size_x, block_size_y, *,
+                ew="cyclic", ns="closed", maskhalo_dyn=False, variant="strict",
+                threads=1, workdir=None, grid_files=None, keep=False, timeout=3600,
+                **harness):
+    """Run one harness case, return (dump dict, stdout text)."""
+    exe = harness_path(variant)
+    if not have_ref(variant):
+        raise FileNotFoundError(f"{exe} not built (run oracle/ref/build_ref.sh)")
+    tmp = None
+    if workdir is None:
+        tmp = tempfile.TemporaryDirectory(prefix="evpref_")
+        workdir = tmp.name
+    wd = Path(workdir)
+    wd.mkdir(parents=True, exist_ok=True)
+    (wd / "ice_in").write_text(
+        "&domain_nml\n"
+        "  nprocs = 1\n"
+        f"  nx_global = {nx_global}\n  ny_global = {ny_global}\n"
+        f"  block_size_x = {block_size_x}\n  block_size_y = {block_size_y}\n"
+        "  max_blocks = -1\n  processor_shape = 'slenderX2'\n"
+        "  distribution_type = 'cartesian'\n  distribution_wght = 'blockall'\n"
+        f"  ew_boundary_type = '{ew}'\n  ns_boundary_type = '{ns}'\n"
+        f"  maskhalo_dyn = {_fmt(bool(maskhalo_dyn))}\n"
+        "  maskhalo_remap = .false.\n  maskhalo_bound = .false.\n"
+        "  add_mpi_barriers = .false.\n  debug_blocks = .false.\n/\n")
+    if grid_files is not None:
+        gpath, kpath = grid_files
+        harness.setdefault("h_grid_file", str(gpath))
+        harness.setdefault("h_kmt_file", str(kpath))
+    lines = ["&harness_nml"]
+    for k, v in harness.items():
+        lines.append(f"  {k} = {_fmt(v)}")
+    lines.append("/\n")
+    (wd / "harness_in").write_text("\n".join(lines))
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = str(threads)
+    env.setdefault("OMP_SCHEDULE", "static,1")
+    env.setdefault("OMP_STACKSIZE", "256M")
+    # one 320x384 block needs a large stack (automatic arrays in evp()): SURVEY Appendix A.3
+    cmd = f"ulimit -s unlimited 2>/dev/null; exec '{exe}'"
+    r = subprocess.run(["bash", "-c", cmd], cwd=wd, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference harness failed rc={r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}")
+    dumpname = harness.get("dumpfile", "dump.bin")
+    d = read_dump(wd / dumpname) if (wd / dumpname).exists() else {}
+    text = r.stdout
+    if tmp is not None and not keep:
+        tmp.cleanup()
+    return d, text
+
+
+def parse_timer(text, name="evp"):
+    """Pull `Timer N: <name>  T seconds` out of ice_timer_print_all output."""
+    m = re.search(r"Timer\s+\d+:\s+" + re.escape(name) + r"\s+([0-9.Ee+-]+)\s+seconds", text)
+    return float(m.group(1)) if m else None
