@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""EVP subcycle benchmark (BASELINE.json metric: EVP subcycle cell-updates/sec,
+gx1 fp64, at 1/2/4/8 GPUs; % of the HBM roofline).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one evp() call's worth of the hot path: ndte subcycles
+(stress + stepu + velocity halo, ice_dyn_evp.F90:859-913) on a resident synthetic
+state.  Workload at every N: the gx1-sized grid (320x384, fp64, ndte=120, ice on
+every ocean cell), block-decomposed over the N GPUs (strong scaling of the
+headline config; `--workload s01` selects the synthetic 3600x2400 grid).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+B_ALG = 368.0            # algorithmic bytes per cell-subcycle (32 reads + 14 writes, fp64)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="gx1", choices=["gx3", "gx1", "s01"])
+    ap.add_argument("--case", default="full", choices=["full", "caps"])
+    ap.add_argument("--ndte", type=int, default=None)
+    ap.add_argument("--strict", action="store_true", help="no-FMA build (bit-identical to the reference built -ffp-contract=off)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, case, ndte, target_s):
+    """Rank 0, N=1 only: the reference's own evp() (oracle/_ref, built from the
+    unmodified reference sources, OpenMP over 64 blocks) timed on this box's host cores
+    by its own timer_evp; falls back to the C restatement ("port") if the prebuilt
+    reference binary did not travel."""
+    from cice_amd import synth
+    spec = synth.GRIDS[workload]
+    nx, ny = spec["nx"], spec["ny"]
+    cores = len(os.sched_getaffinity(0))
+    sys.path.insert(0, str(ROOT / "oracle" / "ref"))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    try:
+        import run_ref
+        if run_ref.have_ref("fast"):
+            import tempfile
+            g = synth.make_grid(nx, ny, spec["dx0"], ns="closed")
+            td = tempfile.mkdtemp(prefix="evpcpu_")
+            run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+            run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
+            bx, by = max(nx // 8, 8), max(ny // 8, 8)
+            threads = min(cores, (nx // bx) * (ny // by))
+            # reference speed is ~1e7 cell-updates/s/core: size the sample for ~target_s
+            est = 1.0e7 * max(threads * 0.5, 1)
+            ncalls = int(max(1, min(200, target_s * est / (nx * ny * ndte))))
+            d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant="fast",
+                                         threads=threads, grid_kind="popfile", icecase=case,
+                                         grid_files=(td + "/grid.bin", td + "/kmt.bin"),
+                                         h_ndte=ndte, ncalls=1, nsub_list=[ndte], dump_arrays=False,
+                                         ntiming=ncalls, timeout=600)
+            t = run_ref.parse_timer(txt, "evp")
+            if t and t > 0:
+                return dict(value=nx * ny * ndte * ncalls / t, unit="cell-updates/s", cores=threads,
+                            kind="reference",
+                            sample=f"reference evp() standard_2d (amdflang -O2 -fopenmp), {nx}x{ny} in "
+                                   f"{(nx // bx) * (ny // by)} blocks {bx}x{by}, ndte={ndte}, {ncalls} calls, "
+                                   f"timer_evp={t:.2f}s, {threads} OpenMP threads of {cores} cores")
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] reference CPU baseline unavailable ({e}); using the C port", file=sys.stderr)
+    # port: the oracle's C restatement with OpenMP
+    import oracle
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_gpu_parity import run_oracle, synth_case
+    scal = synth.evp_scalars(ndte)
+    dc, geo, fields, tm, um = synth_case(workload, case, seed=1, bs=(max(nx // 8, 8), max(ny // 8, 8)))
+    nsub = 24
+    run_oracle(dc, geo, fields, tm, um, scal, 2)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < target_s and reps < 50:
+        run_oracle(dc, geo, fields, tm, um, scal, nsub)
+        reps += 1
+    t = time.perf_counter() - t0
+    return dict(value=nx * ny * nsub * reps / t, unit="cell-updates/s", cores=cores, kind="port",
+                sample=f"oracle/evp_oracle.c (gcc -O2 -fopenmp), {nx}x{ny}, {nsub * reps} subcycles incl. "
+                       f"setup copies, {cores} threads")
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from cice_amd import decomp, evp, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("CICE_EVP_HIP_DEVICE", str(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    spec = synth.GRIDS[a.workload]
+    nx, ny = spec["nx"], spec["ny"]
+    ndte = a.ndte or {"gx3": 120, "gx1": 120, "s01": 480}[a.workload]
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+    st = synth.make_state(g, case=a.case, seed=20260928, warm=True)
+    dc = decomp.per_rank_blocks(nx, ny, world, "cyclic", "closed")
+    geo = {k: dc.scatter(g[k], rank, fill=(1.0 if k != "uarear" else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], rank) for k in evp.FIELDS}
+    tm = dc.scatter(st["iceTmask"], rank, fill=0)
+    um = dc.scatter(st["iceUmask"], rank, fill=0)
+    n_active = int(st["iceTmask"].sum())
+
+    scal = synth.evp_scalars(ndte)
+    d, keep = evp.make_dims(dc, rank)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
+                      geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+    if world > 1:
+        uid = [core.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        core.comm_init(uid[0])
+    core.upload(fields, tm, um)
+
+    def barrier():
+        core.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        core.subcycle(ndte)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        core.subcycle(ndte)
+    core.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    dt = t1 - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-launch kernel durations by HIP events on the library's stream (rank 0's share)
+    kt = core.time_kernels(200)
+    out = core.download()
+    finite = bool(np.isfinite(out["uvel"]).all() and np.isfinite(out["stressp_1"]).all())
+    umax = float(np.abs(out["uvel"]).max())
+
+    if rank == 0:
+        cells = nx * ny
+        ms_step = 1e3 * dt / a.steps
+        value = cells * ndte * a.steps / dt
+        my_active = int((tm[:, 1:-1, 1:-1] != 0).sum())
+        t_kernel = kt["stencil_ms"] * 1e-3
+        achieved = B_ALG * my_active / t_kernel / 1e9 if t_kernel > 0 else 0.0
+        res = {
+            "metric": "EVP subcycle cell-updates/sec (gx1 fp64)" if a.workload == "gx1"
+                      else f"EVP subcycle cell-updates/sec ({a.workload} fp64)",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload} {nx}x{ny} B-grid EVP ndte={ndte}, case={a.case}, "
+                                   f"{'strict (no FMA)' if a.strict else 'fused FMA'}",
+                       "cells": cells, "active_T_cells": n_active, "ndte": ndte,
+                       "decomposition": f"{dc.proc_shape[0]}x{dc.proc_shape[1]} ranks, "
+                                        f"{dc.block_size_x}x{dc.block_size_y} cells each",
+                       "us_per_subcycle": 1e3 * ms_step / ndte, "finite": finite, "max_abs_u": umax},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "evp_subcycle_tile", "kernel_us": 1e3 * kt["stencil_ms"],
+                         "kernel_period_us": 1e3 * kt["stencil_period_ms"],
+                         "halo_kernel_us": 1e3 * kt["halo_ms"],
+                         "alg_bytes_per_launch": B_ALG * my_active,
+                         "note": "368 B x active T-cells of rank 0 per launch / HIP-event kernel time; "
+                                 "gx1 working set (45 MB) is Infinity-Cache resident",
+                         "loop_frac_all_cells": (B_ALG * cells * ndte * a.steps / dt / 1e9) / HBM_PEAK_GBS / world},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.workload, a.case, ndte, a.cpu_seconds)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    core.finalize()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

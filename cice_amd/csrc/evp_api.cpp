@@ -1,0 +1,678 @@
+// =====================================================================
+// C ABI of the MI355X-native EVP core (see include/cice_evp_hip.h) and the
+// device-state management behind it.
+//
+// HBM layout: structure-of-arrays; every field is one contiguous fp64 array
+// (nx_block, ny_block, nblocks), i fastest -- the memory image of the CICE
+// module arrays, so H2D/D2H are straight copies of blocks 1..nblocks.
+// State that the subcycle rewrites (uvel, vvel, 12 stresses) exists twice
+// (ping-pong, see evp_kernels.hip); everything else once.
+// =====================================================================
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cice_evp_hip.h"
+#include "evp_device.h"
+#include "halo_plan.h"
+
+// host arithmetic of derive_metrics must round every operation (no FMA)
+#pragma clang fp contract(off)
+
+namespace {
+
+std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code ? code : -1;
+}
+
+#define HIPC(call)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((int)e_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                              \
+    } while (0)
+
+#define NCCLC(call)                                                                              \
+    do {                                                                                         \
+        ncclResult_t r_ = (call);                                                                \
+        if (r_ != ncclSuccess)                                                                   \
+            return fail(1000 + (int)r_, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// order of the 32-entry field table == argument order of cice_evp_hip_run
+enum Field {
+    F_SIG0 = 0,   // 0..11 stressp_1..4, stressm_1..4, stress12_1..4
+    F_STRENGTH = 12, F_CW, F_AIX, F_UOCN, F_VOCN, F_WATERX, F_WATERY, F_FORCEX, F_FORCEY,
+    F_UMASSDTI, F_FM, F_STRINTX, F_STRINTY, F_TBU, F_TAUBX, F_TAUBY, F_UVEL, F_VVEL,
+    F_UVEL_INIT, F_VVEL_INIT, F_COUNT
+};
+
+struct State {
+    bool ready = false;
+    bool uploaded = false;
+    cice_evp_hip_dims d{};
+    cice_evp_hip_params prm{};
+    std::vector<int32_t> ilo, ihi, jlo, jhi, iglob0, jglob0;
+    int device = 0;
+    size_t plane = 0, n = 0;     // nx*ny, nx*ny*nblocks
+    int max_ni = 0, max_nj = 0;
+    int tyb = 5;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+
+    // device arrays
+    double *stat[10] = {};      // dxT dyT dxhy dyhx cxp cyp cxm cym DminTarea uarear
+    double *in[F_COUNT] = {};   // per-call inputs + diagnostics (entries of ping-ponged fields unused)
+    double *u[2] = {}, *v[2] = {};
+    double *sig[2][12] = {};
+    uint8_t *mask = nullptr;
+    int4 *blk = nullptr;
+    int cur = 0;
+
+    HaloPlan plan;
+    int32_t *h_local_dst = nullptr, *h_local_src = nullptr;
+    int8_t *h_local_sign = nullptr;
+    int n_local = 0;
+    // remote halo
+    ncclComm_t comm = nullptr;
+    bool have_comm = false;
+    int32_t *h_send_src = nullptr, *h_recv_dst = nullptr;
+    int8_t *h_recv_sign = nullptr;
+    double *sendbuf = nullptr, *recvbuf = nullptr;
+    int n_send = 0, n_recv = 0;
+
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, cur) -> captured loop
+    bool use_graph = true;
+
+    double t_loop_ms = 0, t_h2d_ms = 0, t_d2h_ms = 0;
+    int t_nsub = 0;
+    std::vector<uint8_t> hmask;
+};
+
+State S;
+
+const char *env(const char *k) { return std::getenv(k); }
+
+int alloc_d(double **p, size_t n)
+{
+    HIPC(hipMalloc((void **)p, n * sizeof(double)));
+    HIPC(hipMemsetAsync(*p, 0, n * sizeof(double), S.stream));
+    return 0;
+}
+
+void free_all()
+{
+    auto F = [](auto *&p) {
+        if (p) (void)hipFree((void *)p);
+        p = nullptr;
+    };
+    for (auto &p : S.stat) F(p);
+    for (auto &p : S.in) F(p);
+    for (int k = 0; k < 2; ++k) {
+        F(S.u[k]);
+        F(S.v[k]);
+        for (auto &p : S.sig[k]) F(p);
+    }
+    F(S.mask);
+    F(S.blk);
+    F(S.h_local_dst);
+    F(S.h_local_src);
+    F(S.h_local_sign);
+    F(S.h_send_src);
+    F(S.h_recv_dst);
+    F(S.h_recv_sign);
+    F(S.sendbuf);
+    F(S.recvbuf);
+    for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);
+    S.graphs.clear();
+    if (S.ev0) (void)hipEventDestroy(S.ev0);
+    if (S.ev1) (void)hipEventDestroy(S.ev1);
+    if (S.ev2) (void)hipEventDestroy(S.ev2);
+    if (S.ev3) (void)hipEventDestroy(S.ev3);
+    S.ev0 = S.ev1 = S.ev2 = S.ev3 = nullptr;
+    if (S.have_comm) (void)ncclCommDestroy(S.comm);
+    S.have_comm = false;
+    if (S.stream) (void)hipStreamDestroy(S.stream);
+    S.stream = nullptr;
+}
+
+// Copies blocks 1..nblocks of a host (nx,ny,max_blocks) array: contiguous prefix.
+int h2d(double *dst, const double *src)
+{
+    HIPC(hipMemcpyAsync(dst, src, S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    return 0;
+}
+int d2h(double *dst, const double *src)
+{
+    HIPC(hipMemcpyAsync(dst, src, S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    return 0;
+}
+
+// Static metric terms, host arithmetic in the reference's operation order
+// (init_dyn_shared, ice_dyn_shared.F90:384-388, 401-441).  dxhy/dyhx are
+// evaluated directly on the N/E ghost T-cells from the HTE/HTN ghost values
+// (which CICE defines from the global arrays, ice_grid.F90:662-666) instead of
+// through a halo update: same operands, same result for every cell that can
+// hold ice.
+int derive_metrics(const double *HTE, const double *HTN, const double *dxT, const double *dyT,
+                   const double *uarear, const double *tarea)
+{
+    const int nx = S.d.nx_block;
+    const size_t plane = S.plane;
+    std::vector<std::vector<double>> m(7, std::vector<double>(S.n, 0.0));   // cxp cyp cxm cym dxhy dyhx Dmin
+    const double p5 = 0.5, c1p5 = 1.5;
+    for (int b = 0; b < S.d.nblocks; ++b) {
+        const double *hte = HTE + b * plane, *htn = HTN + b * plane;
+        for (size_t k = 0; k < plane; ++k) m[6][b * plane + k] = S.prm.deltaminEVP * tarea[b * plane + k];
+        for (int j = S.jlo[b]; j <= S.jhi[b] + 1; ++j)
+            for (int i = S.ilo[b]; i <= S.ihi[b] + 1; ++i) {
+                const size_t c = (size_t)(j - 1) * nx + (i - 1);
+                const size_t g = b * plane + c;
+                m[0][g] = (c1p5 * htn[c] - p5 * htn[c - nx]);        // cxp
+                m[1][g] = (c1p5 * hte[c] - p5 * hte[c - 1]);         // cyp
+                m[2][g] = -(c1p5 * htn[c - nx] - p5 * htn[c]);       // cxm
+                m[3][g] = -(c1p5 * hte[c - 1] - p5 * hte[c]);        // cym
+                m[4][g] = p5 * (hte[c] - hte[c - 1]);                // dxhy
+                m[5][g] = p5 * (htn[c] - htn[c - nx]);               // dyhx
+            }
+    }
+    if (h2d(S.stat[0], dxT) || h2d(S.stat[1], dyT) || h2d(S.stat[9], uarear)) return -1;
+    const int order[7] = {4, 5, 6, 7, 2, 3, 8};   // stat slots of cxp cyp cxm cym dxhy dyhx Dmin
+    for (int k = 0; k < 7; ++k)
+        if (h2d(S.stat[order[k]], m[k].data())) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+int upload_lists()
+{
+    const HaloPlan &P = S.plan;
+    S.n_local = (int)P.local_dst.size();
+    if (S.n_local) {
+        HIPC(hipMalloc((void **)&S.h_local_dst, S.n_local * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&S.h_local_src, S.n_local * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&S.h_local_sign, S.n_local));
+        HIPC(hipMemcpy(S.h_local_dst, P.local_dst.data(), S.n_local * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(S.h_local_src, P.local_src.data(), S.n_local * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(S.h_local_sign, P.local_sign.data(), S.n_local, hipMemcpyHostToDevice));
+    }
+    std::vector<int32_t> ss, rd;
+    std::vector<int8_t> rs;
+    for (const HaloPeer &p : P.peers) {
+        ss.insert(ss.end(), p.send_src.begin(), p.send_src.end());
+        rd.insert(rd.end(), p.recv_dst.begin(), p.recv_dst.end());
+        rs.insert(rs.end(), p.recv_sign.begin(), p.recv_sign.end());
+    }
+    S.n_send = (int)ss.size();
+    S.n_recv = (int)rd.size();
+    if (S.n_send) {
+        HIPC(hipMalloc((void **)&S.h_send_src, ss.size() * sizeof(int32_t)));
+        HIPC(hipMemcpy(S.h_send_src, ss.data(), ss.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMalloc((void **)&S.sendbuf, 2 * ss.size() * sizeof(double)));
+    }
+    if (S.n_recv) {
+        HIPC(hipMalloc((void **)&S.h_recv_dst, rd.size() * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&S.h_recv_sign, rs.size()));
+        HIPC(hipMemcpy(S.h_recv_dst, rd.data(), rd.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(S.h_recv_sign, rs.data(), rs.size(), hipMemcpyHostToDevice));
+        HIPC(hipMalloc((void **)&S.recvbuf, 2 * rd.size() * sizeof(double)));
+    }
+    return 0;
+}
+
+void fill_args(EvpArgs &A, int cur, int last)
+{
+    const cice_evp_hip_params &q = S.prm;
+    A.p = {q.arlx1i, q.denom1, q.brlx, q.revp, q.e_factor, q.epp2i, q.capping, q.Ktens,
+           q.u0, q.cosw, q.sinw, q.rhow};
+    A.nx = S.d.nx_block;
+    A.ny = S.d.ny_block;
+    A.plane = S.plane;
+    A.last = last;
+    A.blk = S.blk;
+    A.mask = S.mask;
+    A.u_in = S.u[cur];
+    A.v_in = S.v[cur];
+    A.u_out = S.u[cur ^ 1];
+    A.v_out = S.v[cur ^ 1];
+    for (int k = 0; k < 12; ++k) {
+        A.sig_in[k] = S.sig[cur][k];
+        A.sig_out[k] = S.sig[cur ^ 1][k];
+    }
+    A.dxT = S.stat[0]; A.dyT = S.stat[1]; A.dxhy = S.stat[2]; A.dyhx = S.stat[3];
+    A.cxp = S.stat[4]; A.cyp = S.stat[5]; A.cxm = S.stat[6]; A.cym = S.stat[7];
+    A.DminTarea = S.stat[8]; A.uarear = S.stat[9];
+    A.strength = S.in[F_STRENGTH]; A.Cw = S.in[F_CW]; A.aiX = S.in[F_AIX];
+    A.uocn = S.in[F_UOCN]; A.vocn = S.in[F_VOCN]; A.waterx = S.in[F_WATERX];
+    A.watery = S.in[F_WATERY]; A.forcex = S.in[F_FORCEX]; A.forcey = S.in[F_FORCEY];
+    A.umassdti = S.in[F_UMASSDTI]; A.fm = S.in[F_FM]; A.TbU = S.in[F_TBU];
+    A.uvel_init = S.in[F_UVEL_INIT]; A.vvel_init = S.in[F_VVEL_INIT];
+    A.strintx = S.in[F_STRINTX]; A.strinty = S.in[F_STRINTY];
+    A.taubx = S.in[F_TAUBX]; A.tauby = S.in[F_TAUBY];
+}
+
+int cap_mode()
+{
+    if (S.prm.capping == 1.0) return 1;
+    if (S.prm.capping == 0.0) return 0;
+    return -1;
+}
+
+// velocity halo of buffer `b` (ice_dyn_evp.F90:908-910)
+int halo_uv(int b)
+{
+    evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src, (const signed char *)S.h_local_sign,
+                          S.n_local, S.stream);
+    if (!S.plan.peers.empty()) {
+        if (!S.have_comm) return fail(-2, "remote halo needed but cice_evp_hip_comm_init was not called");
+        evp_launch_halo_pack(S.u[b], S.v[b], S.h_send_src, S.sendbuf, S.n_send, S.stream);
+        size_t so = 0, ro = 0;
+        NCCLC(ncclGroupStart());
+        for (const HaloPeer &p : S.plan.peers) {
+            if (!p.send_src.empty())
+                NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream));
+            if (!p.recv_dst.empty())
+                NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream));
+            so += p.send_src.size();
+            ro += p.recv_dst.size();
+        }
+        NCCLC(ncclGroupEnd());
+        evp_launch_halo_unpack(S.u[b], S.v[b], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
+                               S.n_recv, S.stream);
+    }
+    return 0;
+}
+
+int enqueue_loop(int ndte, int cur0)
+{
+    int cur = cur0;
+    const bool strict = S.prm.strict != 0;
+    const int cap = cap_mode();
+    for (int k = 0; k < ndte; ++k) {
+        EvpArgs A;
+        fill_args(A, cur, k == ndte - 1);
+        evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, S.tyb, strict, cap, S.stream);
+        if (int rc = halo_uv(cur ^ 1)) return rc;
+        cur ^= 1;
+    }
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================
+extern "C" {
+
+int cice_evp_hip_abi_version(void) { return CICE_EVP_HIP_ABI_VERSION; }
+
+int cice_evp_hip_last_error(char *buf, int32_t buflen)
+{
+    if (buf && buflen > 0) {
+        std::strncpy(buf, g_err.c_str(), (size_t)buflen - 1);
+        buf[buflen - 1] = 0;
+    }
+    return (int)g_err.size();
+}
+
+int cice_evp_hip_finalize(void)
+{
+    if (S.stream) (void)hipStreamSynchronize(S.stream);
+    free_all();
+    S = State();
+    return 0;
+}
+
+int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *params,
+                      const double *HTE, const double *HTN, const double *dxT, const double *dyT,
+                      const double *uarear, const double *tarea)
+{
+    if (!dims || !params || !HTE || !HTN || !dxT || !dyT || !uarear || !tarea)
+        return fail(-1, "cice_evp_hip_init: null argument");
+    if (S.ready) cice_evp_hip_finalize();
+    if (dims->nghost != 1) return fail(-1, "nghost must be 1");
+    if (dims->nblocks < 1 || dims->nblocks > dims->max_blocks) return fail(-1, "bad nblocks/max_blocks");
+
+    S.d = *dims;
+    S.prm = *params;
+    const int nb = dims->nblocks;
+    S.ilo.assign(dims->ilo, dims->ilo + nb);
+    S.ihi.assign(dims->ihi, dims->ihi + nb);
+    S.jlo.assign(dims->jlo, dims->jlo + nb);
+    S.jhi.assign(dims->jhi, dims->jhi + nb);
+    S.iglob0.assign(dims->iglob0, dims->iglob0 + nb);
+    S.jglob0.assign(dims->jglob0, dims->jglob0 + nb);
+    S.d.ilo = S.ilo.data(); S.d.ihi = S.ihi.data(); S.d.jlo = S.jlo.data(); S.d.jhi = S.jhi.data();
+    S.d.iglob0 = S.iglob0.data(); S.d.jglob0 = S.jglob0.data();
+
+    if (!build_halo_plan(*dims, S.plan)) return fail(-3, "halo plan: %s", S.plan.error.c_str());
+    // the global block table is only needed while planning
+    S.d.gi0 = S.d.gj0 = S.d.gnx = S.d.gny = S.d.gowner = S.d.glocal = nullptr;
+
+    int ndev = 0;
+    HIPC(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(-4, "no HIP device");
+    int dev = 0;
+    if (env("CICE_EVP_HIP_DEVICE")) dev = std::atoi(env("CICE_EVP_HIP_DEVICE"));
+    else if (env("LOCAL_RANK")) dev = std::atoi(env("LOCAL_RANK")) % ndev;
+    else dev = dims->rank % ndev;
+    S.device = dev;
+    HIPC(hipSetDevice(dev));
+    HIPC(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    HIPC(hipEventCreate(&S.ev0));
+    HIPC(hipEventCreate(&S.ev1));
+    HIPC(hipEventCreate(&S.ev2));
+    HIPC(hipEventCreate(&S.ev3));
+
+    S.plane = (size_t)dims->nx_block * dims->ny_block;
+    S.n = S.plane * nb;
+    S.max_ni = S.max_nj = 0;
+    std::vector<int4> hb(nb);
+    for (int b = 0; b < nb; ++b) {
+        hb[b] = make_int4(S.ilo[b], S.ihi[b], S.jlo[b], S.jhi[b]);
+        S.max_ni = std::max(S.max_ni, S.ihi[b] - S.ilo[b] + 1);
+        S.max_nj = std::max(S.max_nj, S.jhi[b] - S.jlo[b] + 1);
+    }
+    S.tyb = 5;
+    if (env("CICE_EVP_HIP_TYB")) S.tyb = std::atoi(env("CICE_EVP_HIP_TYB")) == 9 ? 9 : 5;
+    S.use_graph = !(env("CICE_EVP_HIP_NOGRAPH") && std::atoi(env("CICE_EVP_HIP_NOGRAPH")));
+
+    for (auto &p : S.stat)
+        if (alloc_d(&p, S.n)) return -1;
+    for (int f = F_STRENGTH; f < F_COUNT; ++f) {
+        if (f == F_UVEL || f == F_VVEL) continue;
+        if (alloc_d(&S.in[f], S.n)) return -1;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (alloc_d(&S.u[k], S.n) || alloc_d(&S.v[k], S.n)) return -1;
+        for (auto &p : S.sig[k])
+            if (alloc_d(&p, S.n)) return -1;
+    }
+    HIPC(hipMalloc((void **)&S.mask, S.n));
+    HIPC(hipMemsetAsync(S.mask, 0, S.n, S.stream));
+    HIPC(hipMalloc((void **)&S.blk, nb * sizeof(int4)));
+    HIPC(hipMemcpy(S.blk, hb.data(), nb * sizeof(int4), hipMemcpyHostToDevice));
+    if (upload_lists()) return -1;
+    if (derive_metrics(HTE, HTN, dxT, dyT, uarear, tarea)) return -1;
+    S.hmask.resize(S.n);
+    S.ready = true;
+    S.uploaded = false;
+    S.cur = 0;
+    return 0;
+}
+
+int cice_evp_hip_set_metrics(const double *cxp, const double *cyp, const double *cxm,
+                             const double *cym, const double *dxhy, const double *dyhx,
+                             const double *DminTarea)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    const double *src[7] = {dxhy, dyhx, cxp, cyp, cxm, cym, DminTarea};   // stat slots 2..8
+    for (int k = 0; k < 7; ++k)
+        if (src[k] && h2d(S.stat[2 + k], src[k])) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const int32_t *iceUmask)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!f || !iceTmask || !iceUmask) return fail(-1, "null argument");
+    HIPC(hipEventRecord(S.ev2, S.stream));
+    S.cur = 0;
+    for (int k = 0; k < 12; ++k) {
+        if (!f[k]) return fail(-1, "null stress field %d", k);
+        if (h2d(S.sig[0][k], f[k])) return -1;
+        HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    }
+    for (int fi = F_STRENGTH; fi < F_COUNT; ++fi) {
+        if (fi == F_UVEL || fi == F_VVEL) continue;
+        if ((fi == F_UVEL_INIT || fi == F_VVEL_INIT) && !f[fi]) continue;   // only read when revp = 1
+        if (!f[fi]) return fail(-1, "null field %d", fi);
+        if (h2d(S.in[fi], f[fi])) return -1;
+    }
+    if (S.prm.revp != 0.0 && (!f[F_UVEL_INIT] || !f[F_VVEL_INIT]))
+        return fail(-1, "uvel_init/vvel_init required for revised EVP");
+    if (!f[F_UVEL] || !f[F_VVEL]) return fail(-1, "null velocity field");
+    if (h2d(S.u[0], f[F_UVEL]) || h2d(S.v[0], f[F_VVEL])) return -1;
+    HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    for (size_t k = 0; k < S.n; ++k)
+        S.hmask[k] = (uint8_t)((iceTmask[k] != 0 ? 1 : 0) | (iceUmask[k] != 0 ? 2 : 0));
+    HIPC(hipMemcpyAsync(S.mask, S.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    HIPC(hipEventRecord(S.ev3, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+    S.t_h2d_ms = ms;
+    S.uploaded = true;
+    return 0;
+}
+
+int cice_evp_hip_subcycle(int32_t ndte)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (ndte < 0) return fail(-1, "ndte < 0");
+    if (ndte == 0) return 0;
+    HIPC(hipEventRecord(S.ev0, S.stream));
+    const bool graph_ok = S.use_graph && S.plan.peers.empty();
+    if (graph_ok) {
+        const auto key = std::make_pair((int)ndte, S.cur);
+        auto it = S.graphs.find(key);
+        if (it == S.graphs.end()) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            HIPC(hipStreamBeginCapture(S.stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_loop(ndte, S.cur);
+            hipError_t e = hipStreamEndCapture(S.stream, &g);
+            if (rc) return rc;
+            if (e != hipSuccess) return fail((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            HIPC(hipGraphDestroy(g));
+            it = S.graphs.emplace(key, ge).first;
+            // the event recorded before the capture is stale for timing; re-record
+            HIPC(hipEventRecord(S.ev0, S.stream));
+        }
+        HIPC(hipGraphLaunch(it->second, S.stream));
+    } else {
+        if (int rc = enqueue_loop(ndte, S.cur)) return rc;
+    }
+    HIPC(hipEventRecord(S.ev1, S.stream));
+    S.cur ^= (ndte & 1);
+    S.t_nsub = ndte;
+    return 0;
+}
+
+int cice_evp_hip_sync(void)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+int cice_evp_hip_download(double *const *f)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    HIPC(hipEventRecord(S.ev2, S.stream));
+    for (int k = 0; k < 12; ++k)
+        if (f[k] && d2h(f[k], S.sig[S.cur][k])) return -1;
+    const int outs[4] = {F_STRINTX, F_STRINTY, F_TAUBX, F_TAUBY};
+    for (int o : outs)
+        if (f[o] && d2h(f[o], S.in[o])) return -1;
+    if (f[F_UVEL] && d2h(f[F_UVEL], S.u[S.cur])) return -1;
+    if (f[F_VVEL] && d2h(f[F_VVEL], S.v[S.cur])) return -1;
+    HIPC(hipEventRecord(S.ev3, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+    S.t_d2h_ms = ms;
+    if (S.t_nsub > 0 && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) S.t_loop_ms = ms;
+    return 0;
+}
+
+int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, double *stressp_4,
+                     double *stressm_1, double *stressm_2, double *stressm_3, double *stressm_4,
+                     double *stress12_1, double *stress12_2, double *stress12_3, double *stress12_4,
+                     const double *strength, const double *cdn_ocnU, const double *aiU,
+                     const double *uocnU, const double *vocnU, const double *waterxU,
+                     const double *wateryU, const double *forcexU, const double *forceyU,
+                     const double *umassdti, const double *fmU, double *strintxU, double *strintyU,
+                     const double *TbU, double *taubxU, double *taubyU, double *uvel, double *vvel,
+                     const double *uvel_init, const double *vvel_init, const int32_t *iceTmask,
+                     const int32_t *iceUmask, int32_t ndte)
+{
+    double *f[F_COUNT] = {stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2,
+                          stressm_3, stressm_4, stress12_1, stress12_2, stress12_3, stress12_4,
+                          (double *)strength, (double *)cdn_ocnU, (double *)aiU, (double *)uocnU,
+                          (double *)vocnU, (double *)waterxU, (double *)wateryU, (double *)forcexU,
+                          (double *)forceyU, (double *)umassdti, (double *)fmU, strintxU, strintyU,
+                          (double *)TbU, taubxU, taubyU, uvel, vvel, (double *)uvel_init,
+                          (double *)vvel_init};
+    if (int rc = cice_evp_hip_upload(f, iceTmask, iceUmask)) return rc;
+    if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
+    // only the documented outputs travel back
+    double *o[F_COUNT] = {};
+    for (int k = 0; k < 12; ++k) o[k] = f[k];
+    o[F_STRINTX] = strintxU; o[F_STRINTY] = strintyU; o[F_TAUBX] = taubxU; o[F_TAUBY] = taubyU;
+    o[F_UVEL] = uvel; o[F_VVEL] = vvel;
+    return cice_evp_hip_download(o);
+}
+
+int cice_evp_hip_get_timings(double *out, int32_t n)
+{
+    float ms = 0;
+    if (S.ready && S.t_nsub > 0 && hipEventQuery(S.ev1) == hipSuccess &&
+        hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess)
+        S.t_loop_ms = ms;
+    const double v[5] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+                         1.0 + (S.n_local > 0 ? 1.0 : 0.0) + (S.plan.peers.empty() ? 0.0 : 2.0)};
+    for (int k = 0; k < n && k < 5; ++k) out[k] = v[k];
+    return 0;
+}
+
+// Per-launch durations of the two kernels of a subcycle, measured with HIP events
+// on the library's own stream (the stream the kernels are launched on).  Works on
+// the resident state without advancing it: the launches write the ping-pong
+// "next" buffers, which the next real subcycle overwrites anyway.
+int cice_evp_hip_time_kernels(int32_t nrep, double *out3)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (nrep < 1) nrep = 1;
+    std::vector<hipEvent_t> ev(2 * (size_t)nrep + 2);
+    for (auto &e : ev) HIPC(hipEventCreate(&e));
+    const bool strict = S.prm.strict != 0;
+    const int cap = cap_mode();
+    EvpArgs A;
+    fill_args(A, S.cur, 0);
+    double sum[2] = {0, 0};
+    for (int which = 0; which < 2; ++which) {
+        for (int r = 0; r < nrep; ++r) {
+            HIPC(hipEventRecord(ev[2 * r], S.stream));
+            if (which == 0) evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, S.tyb, strict, cap, S.stream);
+            else evp_launch_halo_local(S.u[S.cur ^ 1], S.v[S.cur ^ 1], S.h_local_dst, S.h_local_src,
+                                       (const signed char *)S.h_local_sign, S.n_local, S.stream);
+            HIPC(hipEventRecord(ev[2 * r + 1], S.stream));
+        }
+        HIPC(hipStreamSynchronize(S.stream));
+        for (int r = 0; r < nrep; ++r) {
+            float ms = 0;
+            HIPC(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
+            sum[which] += ms;
+        }
+    }
+    // back-to-back period of the stencil kernel (launch gap included)
+    HIPC(hipEventRecord(ev[2 * nrep], S.stream));
+    for (int r = 0; r < nrep; ++r)
+        evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, S.tyb, strict, cap, S.stream);
+    HIPC(hipEventRecord(ev[2 * nrep + 1], S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, ev[2 * nrep], ev[2 * nrep + 1]));
+    out3[0] = sum[0] / nrep;
+    out3[1] = S.n_local > 0 ? sum[1] / nrep : 0.0;
+    out3[2] = ms / nrep;
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+int cice_evp_hip_comm_unique_id(void *id128)
+{
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCLC(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+int cice_evp_hip_comm_init(const void *id128)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    HIPC(hipSetDevice(S.device));
+    NCCLC(ncclCommInitRank(&S.comm, S.d.nranks, id, S.d.rank));
+    S.have_comm = true;
+    return 0;
+}
+
+// Host-only: build the halo plan for `dims` without touching a device (tests).
+int cice_evp_hip_plan_build(const cice_evp_hip_dims *dims)
+{
+    if (!dims) return fail(-1, "null dims");
+    if (!build_halo_plan(*dims, S.plan)) return fail(-3, "halo plan: %s", S.plan.error.c_str());
+    return 0;
+}
+
+int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_src,
+                           int32_t *local_sign, int32_t *peer_rank, int32_t *peer_nsend,
+                           int32_t *peer_nrecv, int32_t *send_src, int32_t *recv_dst)
+{
+    const HaloPlan &P = S.plan;
+    size_t ns = 0, nr = 0;
+    for (const HaloPeer &p : P.peers) {
+        ns += p.send_src.size();
+        nr += p.recv_dst.size();
+    }
+    if (counts4) {
+        counts4[0] = (int32_t)P.local_dst.size();
+        counts4[1] = (int32_t)P.peers.size();
+        counts4[2] = (int32_t)ns;
+        counts4[3] = (int32_t)nr;
+    }
+    for (size_t k = 0; k < P.local_dst.size(); ++k) {
+        if (local_dst) local_dst[k] = P.local_dst[k];
+        if (local_src) local_src[k] = P.local_src[k];
+        if (local_sign) local_sign[k] = P.local_sign[k];
+    }
+    size_t so = 0, ro = 0;
+    for (size_t q = 0; q < P.peers.size(); ++q) {
+        const HaloPeer &p = P.peers[q];
+        if (peer_rank) peer_rank[q] = p.rank;
+        if (peer_nsend) peer_nsend[q] = (int32_t)p.send_src.size();
+        if (peer_nrecv) peer_nrecv[q] = (int32_t)p.recv_dst.size();
+        if (send_src) std::copy(p.send_src.begin(), p.send_src.end(), send_src + so);
+        if (recv_dst) std::copy(p.recv_dst.begin(), p.recv_dst.end(), recv_dst + ro);
+        so += p.send_src.size();
+        ro += p.recv_dst.size();
+    }
+    return 0;
+}
+
+}  // extern "C"

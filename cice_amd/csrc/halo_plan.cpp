@@ -1,0 +1,160 @@
+#include "halo_plan.h"
+
+#include <algorithm>
+#include <map>
+
+namespace {
+
+struct Table {
+    std::vector<HaloBlock> blk;
+    // blocks of each rank ordered by local index
+    std::map<int, std::vector<int>> by_rank;
+    int find(int ig, int jg) const
+    {
+        for (size_t k = 0; k < blk.size(); ++k) {
+            const HaloBlock &b = blk[k];
+            if (ig >= b.gi0 && ig < b.gi0 + b.gnx && jg >= b.gj0 && jg < b.gj0 + b.gny) return (int)k;
+        }
+        return -1;
+    }
+};
+
+struct Src {
+    bool outside = false;   // beyond a closed/open outer boundary: ghost left untouched
+    int ig = 0, jg = 0;
+    int sign = 1;
+};
+
+// Which global cell does the ghost position (ig,jg) of an NE-corner vector field mirror?
+Src resolve(const cice_evp_hip_dims &d, int ig, int jg)
+{
+    Src s;
+    const int NX = d.nx_global, NY = d.ny_global;
+    if (ig < 1 || ig > NX) {
+        if (d.ew_boundary_type == CICE_EVP_BND_CYCLIC) ig = (ig < 1) ? ig + NX : ig - NX;
+        else s.outside = true;
+    }
+    if (jg < 1) {
+        if (d.ns_boundary_type == CICE_EVP_BND_CYCLIC) jg += NY;
+        else s.outside = true;
+    } else if (jg > NY) {
+        if (d.ns_boundary_type == CICE_EVP_BND_CYCLIC) jg -= NY;
+        else s.outside = true;   // tripole handled by the caller
+    }
+    s.ig = ig;
+    s.jg = jg;
+    return s;
+}
+
+}  // namespace
+
+bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
+{
+    plan = HaloPlan();
+    plan.nx_block = d.nx_block;
+    plan.ny_block = d.ny_block;
+    plan.nblocks = d.nblocks;
+    if (d.nghost != 1) {
+        plan.error = "nghost must be 1 (ice_blocks.F90:47)";
+        return false;
+    }
+    if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE) {
+        plan.error = "tripole north boundary not supported yet";
+        return false;
+    }
+    const int ng = d.nghost;
+    const int nx = d.nx_block, ny = d.ny_block;
+    const size_t plane = (size_t)nx * ny;
+    const int me = d.rank;
+
+    Table T;
+    if (d.gi0 != nullptr && d.nblocks_tot > 0) {
+        for (int k = 0; k < d.nblocks_tot; ++k)
+            T.blk.push_back({d.gi0[k], d.gj0[k], d.gnx[k], d.gny[k], d.gowner[k], d.glocal[k]});
+    } else {
+        if (d.nranks != 1) {
+            plan.error = "global block table required when nranks > 1";
+            return false;
+        }
+        for (int b = 0; b < d.nblocks; ++b)
+            T.blk.push_back({d.iglob0[b], d.jglob0[b], d.ihi[b] - d.ilo[b] + 1,
+                             d.jhi[b] - d.jlo[b] + 1, me, b});
+    }
+    for (size_t k = 0; k < T.blk.size(); ++k)
+        if (T.blk[k].owner >= 0) T.by_rank[T.blk[k].owner].push_back((int)k);
+    for (auto &kv : T.by_rank)
+        std::sort(kv.second.begin(), kv.second.end(),
+                  [&](int a, int b) { return T.blk[a].local < T.blk[b].local; });
+
+    // consistency of the local description with the table
+    {
+        auto it = T.by_rank.find(me);
+        const size_t nloc = (it == T.by_rank.end()) ? 0 : it->second.size();
+        if ((int)nloc != d.nblocks) {
+            plan.error = "global block table disagrees with nblocks of this rank";
+            return false;
+        }
+        for (int b = 0; b < d.nblocks; ++b) {
+            const HaloBlock &B = T.blk[it->second[b]];
+            if (d.ilo[b] != ng + 1 || d.jlo[b] != ng + 1 || B.local != b || B.gi0 != d.iglob0[b] ||
+                B.gj0 != d.jglob0[b] || B.gnx != d.ihi[b] - d.ilo[b] + 1 ||
+                B.gny != d.jhi[b] - d.jlo[b] + 1 || d.ihi[b] + ng > nx || d.jhi[b] + ng > ny) {
+                plan.error = "local block geometry inconsistent with the global block table";
+                return false;
+            }
+        }
+    }
+
+    std::map<int, HaloPeer> peers;
+
+    // Enumerate the ghost cells of every rank in one canonical order (local
+    // block index, then j, then i).  The receiver keeps entries whose source it
+    // does not own in recv lists; the owner of the source, running the very same
+    // enumeration, appends the matching cell to its send list -- so both lists
+    // have identical order without any set-up communication.
+    for (const auto &kv : T.by_rank) {
+        const int R = kv.first;
+        for (int kb : kv.second) {
+            const HaloBlock &B = T.blk[kb];
+            const int ilo = ng + 1, jlo = ng + 1, ihi = ng + B.gnx, jhi = ng + B.gny;
+            for (int j = jlo - ng; j <= jhi + ng; ++j)
+                for (int i = ilo - ng; i <= ihi + ng; ++i) {
+                    if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) continue;
+                    const Src s = resolve(d, B.gi0 + (i - ilo), B.gj0 + (j - jlo));
+                    if (s.outside) continue;
+                    const int32_t dst = (int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1));
+                    const int ks = T.find(s.ig, s.jg);
+                    if (ks < 0 || T.blk[ks].owner < 0) {
+                        // eliminated land block: reference fills with 0 (srcBlock == 0)
+                        if (R == me) {
+                            plan.local_dst.push_back(dst);
+                            plan.local_src.push_back(-1);
+                            plan.local_sign.push_back(1);
+                        }
+                        continue;
+                    }
+                    const HaloBlock &S = T.blk[ks];
+                    const int32_t src = (int32_t)((size_t)S.local * plane +
+                                                  (size_t)(ng + (s.jg - S.gj0)) * nx + (ng + (s.ig - S.gi0)));
+                    if (R == me) {
+                        if (S.owner == me) {
+                            plan.local_dst.push_back(dst);
+                            plan.local_src.push_back(src);
+                            plan.local_sign.push_back((int8_t)s.sign);
+                        } else {
+                            HaloPeer &p = peers[S.owner];
+                            p.rank = S.owner;
+                            p.recv_dst.push_back(dst);
+                            p.recv_sign.push_back((int8_t)s.sign);
+                        }
+                    } else if (S.owner == me) {
+                        HaloPeer &p = peers[R];
+                        p.rank = R;
+                        p.send_src.push_back(src);
+                    }
+                }
+        }
+    }
+    for (auto &kv : peers) plan.peers.push_back(std::move(kv.second));
+    return true;
+}

@@ -1,0 +1,240 @@
+"""Host-side front end of the MI355X-native EVP core.
+
+This mirrors, in Python, the interface CICE's evp() uses for an alternative EVP
+core (module ice_dyn_evp1d: dyn_evp1d_init / dyn_evp1d_run / dyn_evp1d_finalize,
+cicecore/cicedyn/dynamics/ice_dyn_evp1d.F90:25,73,121) on top of the C ABI in
+include/cice_evp_hip.h -- same field names, same argument meaning, fail-stop
+error behaviour (abort_ice -> EvpHipError).  The Fortran binding a CICE
+maintainer would use is cice_amd/fortran/ice_dyn_evp_hip.F90; both call exactly
+the same shared library.
+
+There is no CPU fallback: if libcice_evp_hip.so is missing or the HIP runtime
+finds no device, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libcice_evp_hip.so"
+
+BND = {"closed": 0, "open": 1, "cyclic": 2, "tripole": 3}
+
+# order of the 32-entry field table == argument order of cice_evp_hip_run
+FIELDS = [
+    "stressp_1", "stressp_2", "stressp_3", "stressp_4",
+    "stressm_1", "stressm_2", "stressm_3", "stressm_4",
+    "stress12_1", "stress12_2", "stress12_3", "stress12_4",
+    "strength", "cdn_ocnU", "aiU", "uocnU", "vocnU", "waterxU", "wateryU",
+    "forcexU", "forceyU", "umassdti", "fmU", "strintxU", "strintyU", "TbU",
+    "taubxU", "taubyU", "uvel", "vvel", "uvel_init", "vvel_init",
+]
+OUTPUTS = FIELDS[:12] + ["strintxU", "strintyU", "taubxU", "taubyU", "uvel", "vvel"]
+EXPORTS = [
+    "cice_evp_hip_abi_version", "cice_evp_hip_last_error", "cice_evp_hip_init",
+    "cice_evp_hip_set_metrics", "cice_evp_hip_run", "cice_evp_hip_finalize",
+    "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
+    "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
+    "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels",
+]
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class EvpHipError(RuntimeError):
+    """Raised where the Fortran wrapper would call abort_ice(...)."""
+
+
+class Dims(C.Structure):
+    _fields_ = [("nx_block", C.c_int32), ("ny_block", C.c_int32), ("nblocks", C.c_int32),
+                ("max_blocks", C.c_int32), ("nghost", C.c_int32), ("nx_global", C.c_int32),
+                ("ny_global", C.c_int32), ("ew_boundary_type", C.c_int32),
+                ("ns_boundary_type", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
+                ("ilo", _i32p), ("ihi", _i32p), ("jlo", _i32p), ("jhi", _i32p),
+                ("iglob0", _i32p), ("jglob0", _i32p), ("nblocks_tot", C.c_int32),
+                ("gi0", _i32p), ("gj0", _i32p), ("gnx", _i32p), ("gny", _i32p),
+                ("gowner", _i32p), ("glocal", _i32p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("ndte", C.c_int32), ("strict", C.c_int32)] + [(n, C.c_double) for n in (
+        "arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping", "Ktens",
+        "deltaminEVP", "u0", "cosw", "sinw", "rhow")]
+
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen the product library; raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise EvpHipError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(p), mode=C.RTLD_GLOBAL)
+    for name in EXPORTS:
+        getattr(lib, name).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        buf = C.create_string_buffer(1024)
+        lib.cice_evp_hip_last_error(buf, 1024)
+        raise EvpHipError(f"{what} ERROR: rc={rc}: {buf.value.decode(errors='replace')}")
+
+
+def make_dims(decomp, rank: int = 0):
+    """(Dims, keepalive) for `rank` of a cice_amd.decomp.Decomp."""
+    blks = decomp.local_blocks(rank)
+    loc = [np.array(v, dtype=np.int32) for v in (
+        [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks], [b.jhi for b in blks],
+        [b.gi0 for b in blks], [b.gj0 for b in blks])]
+    allb = decomp.blocks
+    tab = [np.array(v, dtype=np.int32) for v in (
+        [b.gi0 for b in allb], [b.gj0 for b in allb], [b.gnx for b in allb], [b.gny for b in allb],
+        [b.owner for b in allb], [b.local for b in allb])]
+    d = Dims(decomp.nx_block, decomp.ny_block, len(blks), len(blks), 1, decomp.nx_global,
+             decomp.ny_global, BND[decomp.ew], BND[decomp.ns], rank, decomp.nranks,
+             *[_ip(a) for a in loc], len(allb), *[_ip(a) for a in tab])
+    return d, (loc, tab)
+
+
+def make_params(scal: dict, strict: bool = False) -> Params:
+    p = Params()
+    p.ndte = int(scal.get("ndte", 120))
+    p.strict = 1 if strict else 0
+    for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping", "Ktens",
+              "deltaminEVP", "u0", "cosw", "sinw", "rhow"):
+        setattr(p, k, float(scal[k]))
+    return p
+
+
+class EvpHip:
+    """One EVP core per process (the library keeps a single device state, like the
+    module-level state of ice_dyn_evp1d)."""
+
+    def __init__(self, dims: Dims, params: Params, HTE, HTN, dxT, dyT, uarear, tarea, keepalive=None):
+        self.lib = load_library()
+        self._keep = keepalive
+        self.shape = (dims.nblocks, dims.ny_block, dims.nx_block)
+        arrs = [self._c(a) for a in (HTE, HTN, dxT, dyT, uarear, tarea)]
+        rc = self.lib.cice_evp_hip_init(C.byref(dims), C.byref(params), *[_dp(a) for a in arrs])
+        _check(self.lib, rc, "(dyn_evp_hip_init)")
+        self.ndte = params.ndte
+        self._open = True
+
+    # -- helpers ---------------------------------------------------------------
+    def _c(self, a, dtype=np.float64):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if a.shape != self.shape:
+            raise EvpHipError(f"array shape {a.shape} != (nblocks, ny_block, nx_block) {self.shape}")
+        return a
+
+    def set_metrics(self, **m):
+        order = ("cxp", "cyp", "cxm", "cym", "dxhy", "dyhx", "DminTarea")
+        arrs = [self._c(m[k]) if k in m and m[k] is not None else None for k in order]
+        rc = self.lib.cice_evp_hip_set_metrics(*[(_dp(a) if a is not None else None) for a in arrs])
+        _check(self.lib, rc, "(dyn_evp_hip_set_metrics)")
+
+    # -- dyn_evp1d_run equivalent ----------------------------------------------
+    def run(self, fields: dict, iceTmask, iceUmask, ndte: int | None = None) -> dict:
+        """H2D, ndte subcycles, D2H.  `fields` maps FIELDS -> arrays; the inout/out
+        ones (OUTPUTS) are updated in place in copies that are returned."""
+        work = {k: np.array(self._c(fields[k]), copy=True) for k in FIELDS
+                if k in fields and fields[k] is not None}
+        tm = self._c(iceTmask, np.int32)
+        um = self._c(iceUmask, np.int32)
+        args = [(_dp(work[k]) if k in work else None) for k in FIELDS]
+        rc = self.lib.cice_evp_hip_run(*args, _ip(tm), _ip(um), C.c_int32(self.ndte if ndte is None else ndte))
+        _check(self.lib, rc, "(dyn_evp_hip_run)")
+        return {k: work[k] for k in OUTPUTS}
+
+    # -- resident-state entry points ----------------------------------------------
+    def upload(self, fields: dict, iceTmask, iceUmask):
+        self._up = [self._c(fields[k]) if k in fields and fields[k] is not None else None for k in FIELDS]
+        tab = (_f64p * len(FIELDS))(*[(_dp(a) if a is not None else None) for a in self._up])
+        tm = self._c(iceTmask, np.int32)
+        um = self._c(iceUmask, np.int32)
+        rc = self.lib.cice_evp_hip_upload(tab, _ip(tm), _ip(um))
+        _check(self.lib, rc, "(dyn_evp_hip_upload)")
+
+    def subcycle(self, ndte: int | None = None):
+        rc = self.lib.cice_evp_hip_subcycle(C.c_int32(self.ndte if ndte is None else ndte))
+        _check(self.lib, rc, "(dyn_evp_hip_subcycle)")
+
+    def sync(self):
+        _check(self.lib, self.lib.cice_evp_hip_sync(), "(dyn_evp_hip_sync)")
+
+    def download(self) -> dict:
+        out = {k: np.zeros(self.shape) for k in OUTPUTS}
+        tab = (_f64p * len(FIELDS))(*[(_dp(out[k]) if k in out else None) for k in FIELDS])
+        rc = self.lib.cice_evp_hip_download(tab)
+        _check(self.lib, rc, "(dyn_evp_hip_download)")
+        return out
+
+    def timings(self) -> dict:
+        t = np.zeros(5)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 5)
+        return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4])
+
+    def time_kernels(self, nrep: int = 50) -> dict:
+        t = np.zeros(3)
+        _check(self.lib, self.lib.cice_evp_hip_time_kernels(C.c_int32(nrep), _dp(t)), "(time_kernels)")
+        return dict(stencil_ms=t[0], halo_ms=t[1], stencil_period_ms=t[2])
+
+    # -- RCCL ------------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(self.lib, self.lib.cice_evp_hip_comm_unique_id(buf), "(dyn_evp_hip_comm_unique_id)")
+        return buf.raw
+
+    def comm_init(self, uid: bytes):
+        assert len(uid) == 128
+        _check(self.lib, self.lib.cice_evp_hip_comm_init(C.c_char_p(uid)), "(dyn_evp_hip_comm_init)")
+
+    # -- dyn_evp1d_finalize equivalent ---------------------------------------------------
+    def finalize(self):
+        if getattr(self, "_open", False):
+            self.lib.cice_evp_hip_finalize()
+            self._open = False
+
+    def __del__(self):
+        try:
+            self.finalize()
+        except Exception:
+            pass
+
+
+def halo_plan(dims: Dims) -> dict:
+    """Host-only halo plan of `dims.rank` (no device needed): for CPU tests."""
+    lib = load_library()
+    _check(lib, lib.cice_evp_hip_plan_build(C.byref(dims)), "(plan_build)")
+    cnt = np.zeros(4, dtype=np.int32)
+    lib.cice_evp_hip_halo_plan(_ip(cnt), None, None, None, None, None, None, None, None)
+    nl, npeer, ns, nr = [int(v) for v in cnt]
+    ld, ls, lg = [np.zeros(max(nl, 1), dtype=np.int32) for _ in range(3)]
+    pr, pns, pnr = [np.zeros(max(npeer, 1), dtype=np.int32) for _ in range(3)]
+    ss = np.zeros(max(ns, 1), dtype=np.int32)
+    rd = np.zeros(max(nr, 1), dtype=np.int32)
+    lib.cice_evp_hip_halo_plan(_ip(cnt), _ip(ld), _ip(ls), _ip(lg), _ip(pr), _ip(pns), _ip(pnr), _ip(ss), _ip(rd))
+    return dict(local_dst=ld[:nl], local_src=ls[:nl], local_sign=lg[:nl], peer_rank=pr[:npeer],
+                peer_nsend=pns[:npeer], peer_nrecv=pnr[:npeer], send_src=ss[:ns], recv_dst=rd[:nr])

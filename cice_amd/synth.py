@@ -1,0 +1,165 @@
+"""Synthetic, self-contained workloads for the EVP subcycle.
+
+The real gx3/gx1/tx1 grid and forcing files live outside the reference
+repository (configuration/scripts/options/set_nml.gx1:6-12), so every size in
+BASELINE.json is generated analytically here: a curvilinear-metric global grid
+(non-zero dxhy/dyhx, cxp != cyp), a land mask with closed N/S rows and two
+"continents", and the fields that `evp()` hands to its EVP core
+(dyn_evp1d_run's argument list, ice_dyn_evp1d.F90:121-153).
+
+Global arrays are numpy [ny_global][nx_global] (i fastest), i.e. the memory
+image of Fortran (nx_global, ny_global).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+OMEGA = 7.292e-5          # shared/ice_constants.F90:23
+RHOW = 1026.0             # Icepack default, consumed at ice_dyn_shared.F90:920
+RHOI, RHOS = 917.0, 330.0
+
+# named sizes of BASELINE.json `configs`
+GRIDS = {
+    "gx3": dict(nx=100, ny=116, dx0=3.3e5, ns="closed"),
+    "gx1": dict(nx=320, ny=384, dx0=1.1e5, ns="closed"),
+    "tx1": dict(nx=360, ny=240, dx0=1.1e5, ns="tripole"),
+    "s01": dict(nx=3600, ny=2400, dx0=1.1e4, ns="closed"),   # synthetic 0.1-degree class
+}
+
+
+def make_grid(nx: int, ny: int, dx0: float = 1.1e5, dy0: float | None = None, ns: str = "closed",
+              continents: bool = True) -> dict:
+    """Global geometry: HTN/HTE [m] (N and E edge lengths of T-cells,
+    ice_grid.F90:1000-1061), ULAT/ULON [rad], kmt (1 = ocean)."""
+    dy0 = dx0 if dy0 is None else dy0
+    i = np.arange(1, nx + 1, dtype=np.float64)[None, :]
+    j = np.arange(1, ny + 1, dtype=np.float64)[:, None]
+    HTN = dx0 * (1.0 + 0.3 * np.cos(2 * np.pi * (j - 0.5) / ny)) * (1.0 + 0.05 * np.sin(2 * np.pi * i / nx))
+    HTE = dy0 * (1.0 + 0.2 * np.cos(2 * np.pi * (j - 0.5) / ny)) * (1.0 + 0.04 * np.cos(2 * np.pi * i / nx))
+    ULAT = np.deg2rad(-78.0 + 165.0 * j / ny) * np.ones((1, nx))
+    ULON = np.deg2rad(360.0 * i / nx) * np.ones((ny, 1))
+    kmt = np.ones((ny, nx), dtype=np.int32)
+    if ns == "closed":
+        kmt[:2, :] = 0
+        kmt[-2:, :] = 0          # cf. rectgrid, ice_grid.F90:2752-2755
+    else:
+        kmt[:2, :] = 0           # tripole: closed in the south only
+    if continents and nx >= 20 and ny >= 20:
+        kmt[int(0.30 * ny):int(0.55 * ny), int(0.10 * nx):int(0.30 * nx)] = 0
+        kmt[int(0.60 * ny):int(0.80 * ny), int(0.55 * nx):int(0.80 * nx)] = 0
+    return dict(nx=nx, ny=ny, ns=ns, ew="cyclic", HTN=HTN, HTE=HTE, ULAT=ULAT, ULON=ULON, kmt=kmt)
+
+
+def derive_geometry(g: dict) -> dict:
+    """dxT,dyT,dxU,dyU,tarea,uarea,uarear and masks on the global grid, by the
+    formulas of primary_grid_lengths_HTN/HTE (ice_grid.F90:3063-3280),
+    init_grid2 (:676-714) and makemask (:3382-3383); E-W cyclic."""
+    HTN, HTE = g["HTN"], g["HTE"]
+    dxU = 0.5 * (HTN + np.roll(HTN, -1, axis=1))
+    dxT = np.empty_like(HTN)
+    dxT[1:] = 0.5 * (HTN[1:] + HTN[:-1])
+    dxT[0] = 2.0 * HTN[1] - HTN[2]
+    dyT = 0.5 * (HTE + np.roll(HTE, 1, axis=1))
+    dyU = np.empty_like(HTE)
+    dyU[:-1] = 0.5 * (HTE[:-1] + HTE[1:])
+    dyU[-1] = 2.0 * HTE[-2] - HTE[-3]
+    tarea = dxT * dyT
+    uarea = dxU * dyU
+    hm = g["kmt"].astype(np.float64)
+    hm_n = np.vstack([hm[1:], np.zeros((1, hm.shape[1]))])     # (i, j+1); closed/seam row: land
+    uvm = np.minimum(np.minimum(hm, np.roll(hm, -1, axis=1)),
+                     np.minimum(hm_n, np.roll(hm_n, -1, axis=1)))
+    out = dict(g)
+    out.update(dxT=dxT, dyT=dyT, dxU=dxU, dyU=dyU, tarea=tarea, uarea=uarea,
+               uarear=np.where(uarea > 0, 1.0 / uarea, 0.0),
+               tarear=np.where(tarea > 0, 1.0 / tarea, 0.0),
+               hm=hm, uvm=uvm, tmask=hm > 0.5, umask=uvm > 0.5)
+    return out
+
+
+def make_state(g: dict, case: str = "full", dt: float = 3600.0, seed: int | None = None,
+               warm: bool = False) -> dict:
+    """Inputs of the EVP subcycle on the global grid (U-grid fields at NE corners).
+
+    case 'full' : ice on every ocean cell (headline case, every ocean cell active)
+    case 'caps' : ice only in the top/bottom 25 % of rows, tapered (~35 % active)
+    seed        : PCG64 +-1 % multiplicative perturbation of ice thickness
+    warm        : non-zero initial stresses/velocities (otherwise cold start)
+    """
+    nx, ny = g["nx"], g["ny"]
+    x = (np.arange(1, nx + 1) - 0.5)[None, :] / nx * np.ones((ny, 1))
+    y = (np.arange(1, ny + 1) - 0.5)[:, None] / ny * np.ones((1, nx))
+    tmask, umask = g["tmask"], g["umask"]
+
+    aice = np.where(tmask, 0.95 * (1.0 - 0.04 * np.sin(2 * np.pi * x) * np.cos(4 * np.pi * y)), 0.0)
+    hi = 2.0 * (1.0 + 0.1 * np.sin(4 * np.pi * y) * np.cos(2 * np.pi * x))
+    if case == "caps":
+        taper = np.clip((np.abs(y - 0.5) - 0.25) / 0.05, 0.0, 1.0)
+        aice = aice * taper
+    elif case != "full":
+        raise ValueError(case)
+    if seed is not None:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        hi = hi * (1.0 + 0.01 * (2.0 * rng.random((ny, nx)) - 1.0))
+    vice = hi * aice
+    iceT = tmask & (aice > 1e-11)
+    # Hibler-form strength (a fixture INPUT, like in the reference harness)
+    strength = np.where(iceT, 2.75e4 * vice * np.exp(-20.0 * (1.0 - aice)), 0.0)
+
+    def t2u(a):   # unweighted 4-point T -> U average (stand-in for grid_average_X2Y 'S')
+        an = np.vstack([a[1:], a[-1:]])
+        return 0.25 * (a + np.roll(a, -1, axis=1) + an + np.roll(an, -1, axis=1))
+
+    aiU = t2u(aice)
+    umass = t2u(RHOI * vice + RHOS * 0.2 * aice)
+    iceU = umask & (aiU > 1e-11) & (umass > 1e-10)
+    z = np.zeros((ny, nx))
+    uocn = 0.2 * y - 0.1                      # box2001-style currents, ice_forcing.F90:5242-5245
+    vocn = -0.2 * x + 0.1
+    fcor = 2.0 * OMEGA * np.sin(g["ULAT"])
+    fm = np.where(iceU, fcor * umass, 0.0)
+    umassdti = np.where(iceU, umass / dt, 0.0)
+    strairx = aiU * 0.1 * np.sin(2 * np.pi * x) * np.sin(np.pi * y)
+    strairy = aiU * 0.1 * np.sin(np.pi * x) * np.sin(2 * np.pi * y)
+    # geostrophic tilt, ice_dyn_shared.F90:823-826 ; waterx with cosw=1, sinw=0 (:819-820)
+    forcex = np.where(iceU, strairx - fm * vocn, 0.0)
+    forcey = np.where(iceU, strairy + fm * uocn, 0.0)
+    st = dict(
+        strength=strength, cdn_ocnU=np.full((ny, nx), 0.00536), aiU=aiU, uocnU=uocn, vocnU=vocn,
+        waterxU=np.where(iceU, uocn, 0.0), wateryU=np.where(iceU, vocn, 0.0),
+        forcexU=forcex, forceyU=forcey, umassdti=umassdti, fmU=fm, TbU=z.copy(),
+        strintxU=z.copy(), strintyU=z.copy(), taubxU=z.copy(), taubyU=z.copy(),
+        iceTmask=iceT.astype(np.int32), iceUmask=iceU.astype(np.int32),
+    )
+    if warm:
+        u0 = np.where(iceU, 0.05 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y), 0.0)
+        v0 = np.where(iceU, 0.05 * np.cos(2 * np.pi * x) * np.sin(4 * np.pi * y), 0.0)
+        s0 = np.where(iceT, -0.1 * strength * (1.0 + 0.3 * np.sin(6 * np.pi * x)), 0.0)
+    else:
+        u0, v0, s0 = z, z, z
+    st["uvel"], st["vvel"] = u0.copy(), v0.copy()
+    st["uvel_init"], st["vvel_init"] = u0.copy(), v0.copy()
+    for k, fac in (("stressp", 1.0), ("stressm", 0.1), ("stress12", 0.05)):
+        for c in range(1, 5):
+            st[f"{k}_{c}"] = s0 * fac * (1.0 + 0.01 * c)
+    return st
+
+
+def evp_scalars(ndte: int, dt: float = 3600.0, revised_evp: bool = False, elasticDamp: float = 0.36,
+                arlx: float = 300.0, brlx: float = 300.0, e_yieldcurve: float = 2.0,
+                e_plasticpot: float = 2.0, capping: float = 1.0, Ktens: float = 0.0,
+                deltaminEVP: float = 1e-11) -> dict:
+    """set_evp_parameters (ice_dyn_shared.F90:453-486) as plain host arithmetic."""
+    epp2i = 1.0 / e_plasticpot ** 2
+    e_factor = e_yieldcurve ** 2 / e_plasticpot ** 4
+    if revised_evp:
+        revp, denom1, arlx1i = 1.0, 1.0, 1.0 / arlx
+    else:
+        revp = 0.0
+        arlx = 2.0 * elasticDamp * float(ndte)
+        arlx1i = 1.0 / arlx
+        brlx = float(ndte)
+        denom1 = 1.0 / (1.0 + arlx1i)
+    return dict(ndte=ndte, arlx1i=arlx1i, denom1=denom1, brlx=brlx, revp=revp, e_factor=e_factor,
+                epp2i=epp2i, capping=capping, Ktens=Ktens, deltaminEVP=deltaminEVP,
+                u0=5e-5, cosw=1.0, sinw=0.0, rhow=RHOW)

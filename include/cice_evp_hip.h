@@ -1,0 +1,160 @@
+/* =====================================================================
+ * cice_evp_hip.h -- C ABI of the MI355X-native EVP dynamics core.
+ *
+ * Drop-in boundary: the place where CICE's evp() already hands the whole EVP
+ * subcycle to an alternative core,
+ *     call dyn_evp1d_run(stressp_1 ... iceUmask)
+ *         cicecore/cicedyn/dynamics/ice_dyn_evp.F90:846-856   (run)
+ *         cicecore/cicedyn/dynamics/ice_dyn_evp.F90:153-155   (init)
+ *     argument contract: ice_dyn_evp1d.F90:121-153
+ * and what that region computes in the standard path:
+ *     do ksub=1,ndte { stress ; stepu } ; halo(uvel,vvel)   ice_dyn_evp.F90:859-913
+ *
+ * Conventions
+ *  - every array pointer is caller-owned HOST memory laid out as Fortran
+ *    (nx_block, ny_block, max_blocks) column-major real(8) -- CICE's own
+ *    module arrays are passed straight through, no copies on the Fortran side;
+ *    only blocks 1..nblocks are touched;
+ *  - masks are Fortran logical(4) / int32: non-zero = .true.;
+ *  - all functions return 0 on success, a non-zero code otherwise, and never
+ *    exit(): the Fortran wrapper turns non-zero into abort_ice(...) as the
+ *    reference's fail-stop convention requires (comm/mpi/ice_exit.F90);
+ *    cice_evp_hip_last_error() returns the message;
+ *  - one host thread per process calls in (evp() is called outside OpenMP
+ *    regions, general/ice_step_mod.F90:1007); the library is not re-entrant.
+ * ===================================================================== */
+#ifndef CICE_EVP_HIP_H
+#define CICE_EVP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CICE_EVP_HIP_ABI_VERSION 1
+
+/* boundary types: ice_domain.F90 domain_nml ew_boundary_type / ns_boundary_type */
+enum {
+    CICE_EVP_BND_CLOSED = 0,
+    CICE_EVP_BND_OPEN = 1,
+    CICE_EVP_BND_CYCLIC = 2,
+    CICE_EVP_BND_TRIPOLE = 3 /* u-fold; ns only */
+};
+
+/* Block decomposition of this process (type(block), ice_blocks.F90:21-41;
+ * nblocks/blocks_ice, ice_domain.F90:42-78) plus -- for nranks > 1 -- the
+ * global block table every rank can build with get_block_parameter and
+ * distrb_info%blockLocation (ice_distribution.F90:24-37).                 */
+typedef struct {
+    int32_t nx_block, ny_block; /* block array extents incl. ghost cells           */
+    int32_t nblocks;            /* blocks owned by this process                   */
+    int32_t max_blocks;         /* 3rd extent of the host arrays (>= nblocks)     */
+    int32_t nghost;             /* must be 1 (ice_blocks.F90:47)                  */
+    int32_t nx_global, ny_global;
+    int32_t ew_boundary_type, ns_boundary_type;
+    int32_t rank, nranks;       /* position in the EVP process group              */
+    /* per local block, length nblocks; 1-based local indices like type(block)    */
+    const int32_t *ilo, *ihi, *jlo, *jhi;
+    const int32_t *iglob0, *jglob0; /* i_glob(ilo), j_glob(jlo)                   */
+    /* global block table, length nblocks_tot; may be NULL when nranks == 1.
+     * A block is the interior rectangle [gi0, gi0+gnx) x [gj0, gj0+gny) of the
+     * global index space owned by `gowner` (-1: eliminated land block) as its
+     * `glocal`-th local block (0-based).                                          */
+    int32_t nblocks_tot;
+    const int32_t *gi0, *gj0, *gnx, *gny, *gowner, *glocal;
+} cice_evp_hip_dims;
+
+/* EVP scalars: set_evp_parameters (ice_dyn_shared.F90:453-486), module
+ * parameters u0,cosw,sinw (:68-70), capping (ice_init.F90:1553-1558), Ktens,
+ * deltaminEVP, and rhow = icepack_query_parameters(rhow_out) (:920).           */
+typedef struct {
+    int32_t ndte;     /* default subcycle count                                     */
+    int32_t strict;   /* 1: no FMA contraction (bit-comparable with the CPU oracle
+                         and with the reference built -ffp-contract=off); 0: fused  */
+    double arlx1i, denom1, brlx, revp;
+    double e_factor, epp2i;
+    double capping, Ktens, deltaminEVP;
+    double u0, cosw, sinw;
+    double rhow;
+} cice_evp_hip_params;
+
+/* ---- life cycle --------------------------------------------------------- */
+
+/* Replaces dyn_evp1d_init (ice_dyn_evp1d.F90:73-117).  Static grid arrays are
+ * CICE's ice_grid module arrays (HTE,HTN,dxT,dyT,uarear,tarea).  Derives the
+ * metric terms of init_dyn_shared (ice_dyn_shared.F90:384-441) and uploads
+ * them; builds the halo plan; selects the device (HIP device = local rank
+ * unless CICE_EVP_HIP_DEVICE is set).                                         */
+int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *params,
+                      const double *HTE, const double *HTN, const double *dxT, const double *dyT,
+                      const double *uarear, const double *tarea);
+
+/* Optional: overwrite the derived metric terms with the caller's own arrays
+ * (ice_dyn_shared module arrays cxp,cyp,cxm,cym,dxhy,dyhx,DminTarea).         */
+int cice_evp_hip_set_metrics(const double *cxp, const double *cyp, const double *cxm,
+                             const double *cym, const double *dxhy, const double *dyhx,
+                             const double *DminTarea);
+
+/* Replaces dyn_evp1d_run (ice_dyn_evp1d.F90:121-319): H2D, `ndte` subcycles on
+ * the device, D2H.  Same argument order as the reference routine, plus
+ * uvel_init/vvel_init (ice_dyn_shared module arrays; read only when revp=1) and
+ * the subcycle count.  On exit: 12 stresses, uvel, vvel (ghost cells current),
+ * strintxU/yU, taubxU/yU hold the state after the last subcycle.              */
+int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, double *stressp_4,
+                     double *stressm_1, double *stressm_2, double *stressm_3, double *stressm_4,
+                     double *stress12_1, double *stress12_2, double *stress12_3, double *stress12_4,
+                     const double *strength, const double *cdn_ocnU, const double *aiU,
+                     const double *uocnU, const double *vocnU, const double *waterxU,
+                     const double *wateryU, const double *forcexU, const double *forceyU,
+                     const double *umassdti, const double *fmU, double *strintxU, double *strintyU,
+                     const double *TbU, double *taubxU, double *taubyU, double *uvel, double *vvel,
+                     const double *uvel_init, const double *vvel_init, const int32_t *iceTmask,
+                     const int32_t *iceUmask, int32_t ndte);
+
+int cice_evp_hip_finalize(void);
+
+/* ---- resident-state entry points (same work as _run, split in three so that
+ *      a caller can keep the state in HBM across calls) ----------------------- */
+
+/* fields: pointer table in the order of the cice_evp_hip_run arguments
+ * stressp_1 .. vvel_init (32 entries); masks as in _run.                      */
+int cice_evp_hip_upload(const double *const *fields32, const int32_t *iceTmask,
+                        const int32_t *iceUmask);
+/* ndte subcycles (stress + stepu + velocity halo) on the resident state.      */
+int cice_evp_hip_subcycle(int32_t ndte);
+/* D2H of the 18 output fields into a 32-entry table (NULL entries skipped).   */
+int cice_evp_hip_download(double *const *fields32);
+/* Block the host until all device work of this library has finished.          */
+int cice_evp_hip_sync(void);
+
+/* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */
+/* 128-byte ncclUniqueId made by rank 0 and distributed by the host program
+ * (MPI_Bcast in CICE; torch.distributed in bench.py).                          */
+int cice_evp_hip_comm_unique_id(void *id128);
+int cice_evp_hip_comm_init(const void *id128);
+
+/* ---- introspection ------------------------------------------------------------ */
+int cice_evp_hip_abi_version(void);
+int cice_evp_hip_last_error(char *buf, int32_t buflen);
+/* out[0]=last subcycle-loop ms (HIP events), [1]=H2D ms, [2]=D2H ms,
+ * [3]=subcycles in that loop, [4]=kernel launches per subcycle                 */
+int cice_evp_hip_get_timings(double *out, int32_t n);
+/* Halo plan of this rank, for tests: counts[0]=local copies, [1]=#peers,
+ * [2]=total send cells, [3]=total recv cells.  Lists may be NULL.
+ * local_dst/local_src are 0-based offsets into a (nx_block,ny_block,nblocks)
+ * array; sign is +-1 (tripole vector fold).                                    */
+/* Per-launch kernel durations by HIP events on the library's stream, state not
+ * advanced: out3[0]=fused stress+stepu kernel ms, [1]=halo gather kernel ms,
+ * [2]=back-to-back period of the fused kernel ms (launch gap included).        */
+int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
+/* Host-only: build the plan for `dims` without touching a device (CPU tests). */
+int cice_evp_hip_plan_build(const cice_evp_hip_dims *dims);
+int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_src,
+                           int32_t *local_sign, int32_t *peer_rank, int32_t *peer_nsend,
+                           int32_t *peer_nrecv, int32_t *send_src, int32_t *recv_dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CICE_EVP_HIP_H */

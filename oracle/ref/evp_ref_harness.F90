@@ -129,6 +129,7 @@ program evp_ref_harness
   deltaminEVP=1e-11_dbl_kind; capping=h_capping
   coriolis=trim(h_coriolis); ssh_stress='geostrophic'
   seabed_stress=h_seabed; seabed_stress_method='LKD'
+  k1=7.5_dbl_kind; k2=15._dbl_kind; alphab=20._dbl_kind; threshold_hw=30._dbl_kind   ! ice_in defaults
   dyn_area_min=1e-11_dbl_kind; dyn_mass_min=1e-10_dbl_kind
   yield_curve='ellipse'; visc_method='avg_zeta'
   arlx=h_arlx; brlx=h_brlx

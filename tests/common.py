@@ -1,0 +1,79 @@
+"""Shared helpers of the test-suite (test infrastructure; may use the oracle)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+import oracle  # oracle/oracle.py  (CPU restatement -- the checker)
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+GOLDEN_CASES = sorted(p.stem for p in GOLDEN.glob("*.npz"))
+
+
+class GoldenCase:
+    """A fixture made by tests/golden/make_golden.py from the compiled reference."""
+
+    def __init__(self, name):
+        self.name = name
+        z = np.load(GOLDEN / f"{name}.npz")
+        self.d = {k: z[k] for k in z.files}
+        self.ew, self.ns = str(self.d["ew"]), str(self.d["ns"])
+        dims = [int(v) for v in self.d["dims"]]
+        (self.nx_block, self.ny_block, self.nblocks, self.nghost, self.nx_global, self.ny_global,
+         self.ndte, self.ncalls, _) = dims
+        self.nsub_list = [int(v) for v in self.d["nsub_list"]]
+        self.scal = self.d["scalars"]
+        self.blk = np.asarray(self.d["blkinfo"]).reshape(self.nblocks, 8)
+
+    # --- oracle-side objects ---
+    def oracle_domain(self):
+        return oracle.OracleDomain.from_dump(self.d, self.ew, self.ns)
+
+    def oracle_params(self):
+        return oracle.params_from_scalars(self.scal)
+
+    def static(self):
+        return {k: self.d[k] for k in oracle.STATIC_FIELDS}
+
+    def inputs(self, icall=1):
+        dyn = {k: self.d[f"in{icall:02d}_{k}"] for k in oracle.DYN_FIELDS}
+        return dyn, self.d[f"in{icall:02d}_iceTmask"], self.d[f"in{icall:02d}_iceUmask"]
+
+    def expected(self, icall, nsub):
+        return {k: self.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in oracle.OUT_FIELDS}
+
+    # --- product-side objects (C ABI structs) ---
+    def scal_dict(self):
+        s = self.scal
+        return dict(ndte=self.ndte, arlx1i=s[0], denom1=s[1], brlx=s[2], revp=s[3], e_factor=s[4],
+                    epp2i=s[5], capping=s[6], Ktens=s[7], deltaminEVP=s[8], u0=s[9], cosw=s[10],
+                    sinw=s[11], rhow=s[12])
+
+    def hip_dims(self):
+        from cice_amd import evp
+        b = self.blk
+        loc = [np.ascontiguousarray(b[:, k], dtype=np.int32) for k in (0, 1, 2, 3, 6, 7)]
+        d = evp.Dims(self.nx_block, self.ny_block, self.nblocks, self.nblocks, self.nghost,
+                     self.nx_global, self.ny_global, evp.BND[self.ew], evp.BND[self.ns], 0, 1,
+                     *[a.ctypes.data_as(evp._i32p) for a in loc], 0, None, None, None, None, None, None)
+        return d, loc
+
+
+def assert_bitwise(got: dict, want: dict, what=""):
+    bad = []
+    for k, w in want.items():
+        g = got[k]
+        if not np.array_equal(g, w):
+            ne = np.argwhere(g != w)
+            bad.append(f"{k}: {len(ne)} cells differ, max|d|={np.abs(g - w).max():.3e}, first at {ne[0].tolist()}")
+    assert not bad, f"{what} not bit-identical:\n  " + "\n  ".join(bad)
+
+
+def max_rel_err(got: dict, want: dict, keys):
+    """max over fields of max|got-want| / max|want| (field-wise scale)."""
+    worst = 0.0
+    for k in keys:
+        scale = max(np.abs(want[k]).max(), 1e-300)
+        worst = max(worst, np.abs(got[k] - want[k]).max() / scale)
+    return worst

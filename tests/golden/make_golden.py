@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Runs oracle/_ref/evp_ref_harness_strict -- the reference's own evp() compiled
+unmodified from /root/reference by oracle/ref/build_ref.sh (amdflang -O2
+-ffp-contract=off) -- on small self-contained cases and freezes, per case:
+  * static grid + metric arrays and the EVP scalars,
+  * every input of the EVP subcycle captured at the drop-in boundary,
+  * the reference's outputs after nsub subcycles for several nsub.
+A fixture is data only (inputs + expected outputs).  Re-run in the development
+container (needs /root/reference for build_ref.sh):  python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle" / "ref"))
+
+import run_ref  # noqa: E402
+from cice_amd import synth  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+STATIC = ["HTE", "HTN", "dxT", "dyT", "tarea", "uarear", "cxp", "cyp", "cxm", "cym", "dxhy", "dyhx",
+          "DminTarea"]
+
+CASES = {
+    # name: (nx, ny, bx, by, ew, ns, harness kwargs)
+    "rect_cyc_2x2_full": (24, 20, 12, 10, "cyclic", "closed",
+                          dict(grid_kind="rect", icecase="full", nsub_list=[1, 10, 120], ncalls=2)),
+    "pop_cyc_1blk_patchy": (24, 20, 24, 20, "cyclic", "closed",
+                            dict(grid_kind="popfile", icecase="patchy", nsub_list=[1, 2, 120], ncalls=1)),
+    "pop_cyc_3x2pad_caps": (26, 22, 10, 12, "cyclic", "closed",
+                            dict(grid_kind="popfile", icecase="caps", nsub_list=[1, 120], ncalls=2)),
+    "pop_closed_2x2_revp": (24, 20, 12, 10, "closed", "closed",
+                            dict(grid_kind="popfile", icecase="full", nsub_list=[1, 120], ncalls=2,
+                                 h_revised=True, h_arlx=300.0, h_brlx=300.0)),
+    "pop_cyc_2x1_cap0_ktens": (24, 20, 12, 20, "cyclic", "closed",
+                               dict(grid_kind="popfile", icecase="patchy", nsub_list=[1, 120], ncalls=1,
+                                    h_capping=0.0, h_Ktens=0.2, h_e_yield=1.5, h_e_plast=2.5)),
+    "pop_cyc_2x2_seabed": (24, 20, 12, 10, "cyclic", "closed",
+                           dict(grid_kind="popfile", icecase="full", nsub_list=[1, 120], ncalls=2,
+                                h_seabed=True)),
+}
+
+
+def make_case(name, spec):
+    nx, ny, bx, by, ew, ns, kw = spec
+    kw = dict(kw)
+    grid_files = None
+    td = tempfile.mkdtemp(prefix="golden_")
+    if kw["grid_kind"] != "rect":
+        g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+        run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+        run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
+        grid_files = (td + "/grid.bin", td + "/kmt.bin")
+    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="strict", h_ndte=120,
+                                 grid_files=grid_files, **kw)
+    keep = {"dims": d["dims"], "blkinfo": d["blkinfo"], "scalars": d["scalars"],
+            "nsub_list": d["nsub_list"], "ew": np.array(ew), "ns": np.array(ns)}
+    for k in STATIC:
+        keep[k] = d[k]
+    for k, v in d.items():
+        if k.startswith("in") or (k.startswith("o") and k[1:3].isdigit()):
+            # next-tier diagnostics (deformations, dyn_finish) are kept for SURVEY §8 f-1
+            keep[k] = v
+    path = OUT / f"{name}.npz"
+    np.savez_compressed(path, **keep)
+    nact = int(d["in01_iceTmask"].sum()), int(d["in01_iceUmask"].sum())
+    print(f"{name}: {path.stat().st_size/1024:.0f} KiB, active T/U cells {nact}, "
+          f"max|u| {np.abs(d['o01n0120_uvel']).max():.4f}")
+
+
+if __name__ == "__main__":
+    if not run_ref.have_ref("strict"):
+        raise SystemExit("build the reference first: oracle/ref/build_ref.sh strict")
+    only = sys.argv[1:]
+    for name, spec in CASES.items():
+        if only and name not in only:
+            continue
+        make_case(name, spec)

@@ -1,0 +1,174 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against
+  (1) the golden fixtures frozen from the reference's own evp()     -- bit-exact in strict mode
+  (2) the CPU oracle on seeded synthetic inputs (gx3 / gx1 sizes)   -- bit-exact in strict mode
+  (3) size-independent properties at full BASELINE sizes (decomposition invariance,
+      mask invariants, strict-vs-fused tolerance).
+Tolerances (fused build, FMA contraction on): stated next to each assert."""
+import numpy as np
+import pytest
+
+import oracle
+from cice_amd import decomp, evp, synth
+from common import GOLDEN_CASES, GoldenCase, assert_bitwise, max_rel_err
+
+pytestmark = pytest.mark.gpu
+
+VEL = ["uvel", "vvel"]
+SIG = evp.FIELDS[:12]
+
+
+def hip_from_case(c: GoldenCase, strict: bool):
+    d, keep = c.hip_dims()
+    prm = evp.make_params(c.scal_dict(), strict=strict)
+    core = evp.EvpHip(d, prm, c.d["HTE"], c.d["HTN"], c.d["dxT"], c.d["dyT"], c.d["uarear"], c.d["tarea"],
+                      keepalive=keep)
+    return core
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_strict_bitwise(name):
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        for icall in range(1, c.ncalls + 1):
+            dyn, tm, um = c.inputs(icall)
+            for nsub in c.nsub_list:
+                out = core.run(dyn, tm, um, ndte=nsub)
+                assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub} (HIP strict)")
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_fused_within_tolerance(name):
+    """Fused multiply-add build vs the reference: velocities and stresses agree to
+    1e-9 relative (field max norm) after a full ndte=120 subcycle loop, 1e-12 after one."""
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=False)
+    try:
+        dyn, tm, um = c.inputs(1)
+        out1 = core.run(dyn, tm, um, ndte=1)
+        assert max_rel_err(out1, c.expected(1, 1), VEL + SIG) < 1e-12
+        outn = core.run(dyn, tm, um, ndte=c.ndte)
+        assert max_rel_err(outn, c.expected(1, c.ndte), VEL + SIG) < 1e-9
+    finally:
+        core.finalize()
+
+
+def synth_case(grid_name, case, nranks_blocks=(1, 1), seed=None, warm=False, ndte=None, bs=None):
+    spec = synth.GRIDS[grid_name]
+    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns="closed"))
+    st = synth.make_state(g, case=case, seed=seed, warm=warm)
+    nx, ny = spec["nx"], spec["ny"]
+    if bs is None:
+        bs = (nx, ny)
+    dc = decomp.Decomp(nx, ny, bs[0], bs[1], "cyclic", "closed", 1)
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+    tm = dc.scatter(st["iceTmask"], 0, fill=0)
+    um = dc.scatter(st["iceUmask"], 0, fill=0)
+    return dc, geo, fields, tm, um
+
+
+def run_hip(dc, geo, fields, tm, um, scal, strict, ndte):
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=strict), geo["HTE"], geo["HTN"], geo["dxT"],
+                      geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        return core.run(fields, tm, um, ndte=ndte)
+    finally:
+        core.finalize()
+
+
+def run_oracle(dc, geo, fields, tm, um, scal, ndte):
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    m = oracle.metrics(dom, scal["deltaminEVP"], geo["HTE"], geo["HTN"], geo["tarea"])
+    static = dict(m, dxT=geo["dxT"], dyT=geo["dyT"], uarear=geo["uarear"])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i",
+                                                      "capping", "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    out = oracle.subcycle(dom, prm, ndte, fields, static, tm, um)
+    return {k: out[k] for k in evp.OUTPUTS}
+
+
+@pytest.mark.parametrize("grid,case,bs,warm", [("gx3", "full", None, False), ("gx3", "caps", (25, 29), True),
+                                                ("gx1", "full", None, True), ("gx1", "caps", (80, 96), False)])
+def test_synthetic_vs_oracle_strict_bitwise(grid, case, bs, warm):
+    ndte = 12   # oracle finishes in seconds at gx1 size
+    dc, geo, fields, tm, um = synth_case(grid, case, seed=20260928, warm=warm, bs=bs)
+    scal = synth.evp_scalars(120)
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=ndte)
+    want = run_oracle(dc, geo, fields, tm, um, scal, ndte)
+    assert np.abs(want["uvel"]).max() > 1e-4       # the case actually moves ice
+    assert_bitwise(got, want, f"{grid}/{case} HIP strict vs oracle")
+
+
+def test_gx1_decomposition_invariance_bitwise():
+    """1 block vs 4x4 blocks vs padded 7x5-ish blocks: identical interiors, both builds
+    (the reference's own correctness criterion, ug_implementation.rst:715-716)."""
+    scal = synth.evp_scalars(120)
+    for strict in (True, False):
+        ref = None
+        for bs in (None, (80, 96), (48, 80)):
+            dc, geo, fields, tm, um = synth_case("gx1", "full", seed=1, warm=True, bs=bs)
+            out = run_hip(dc, geo, fields, tm, um, scal, strict=strict, ndte=120)
+            glob = {k: dc.gather({0: out[k]}) for k in VEL + SIG + ["strintxU", "strintyU"]}
+            if ref is None:
+                ref = glob
+            else:
+                assert_bitwise(glob, ref, f"gx1 decomposition {bs} strict={strict}")
+
+
+def test_gx1_full_run_properties():
+    """Full configs[1] size, ndte=120: finite, bounded, masked-out cells untouched,
+    fused vs strict within 1e-9 relative."""
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx1", "caps", seed=3)
+    a = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=120)
+    b = run_hip(dc, geo, fields, tm, um, scal, strict=False, ndte=120)
+    for k in evp.OUTPUTS:
+        assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all(), k
+    assert 1e-3 < np.abs(a["uvel"]).max() < 2.0
+    inter = np.zeros(dc.shape(0), bool)
+    inter[:, 1:-1, 1:-1] = True
+    offU = inter & (um == 0)
+    offT = inter & (tm == 0)
+    assert not a["uvel"][offU].any() and not a["vvel"][offU].any()
+    for k in SIG:
+        assert not a[k][offT].any()
+    assert max_rel_err(b, a, VEL + SIG) < 1e-9
+
+
+def test_resident_entry_points_equal_run():
+    c = GoldenCase("pop_cyc_3x2pad_caps")
+    core = hip_from_case(c, strict=True)
+    try:
+        dyn, tm, um = c.inputs(1)
+        core.upload(dyn, tm, um)
+        core.subcycle(60)
+        core.subcycle(59)          # odd count: ping-pong parity flips
+        core.subcycle(1)
+        core.sync()
+        out = core.download()
+        assert_bitwise(out, c.expected(1, 120), "upload/subcycle/download")
+        t = core.timings()
+        assert t["nsub"] == 1 and t["loop_ms"] >= 0.0
+    finally:
+        core.finalize()
+
+
+def test_single_rank_rccl_self_exchange():
+    """E-W cyclic single block: the RCCL communicator initialises on one rank and a
+    run with it attached still matches (no peers -> no exchange, API smoke)."""
+    c = GoldenCase("pop_cyc_1blk_patchy")
+    core = hip_from_case(c, strict=True)
+    try:
+        core.comm_init(core.comm_unique_id())
+        dyn, tm, um = c.inputs(1)
+        out = core.run(dyn, tm, um, ndte=120)
+        assert_bitwise(out, c.expected(1, 120), "with RCCL communicator")
+    finally:
+        core.finalize()

@@ -1,0 +1,77 @@
+"""CPU: the oracle (oracle/evp_oracle.c) against the golden fixtures frozen from
+the reference's own evp() (tests/golden/make_golden.py).  Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from common import GOLDEN_CASES, GoldenCase, assert_bitwise
+
+
+def test_fixtures_present():
+    assert len(GOLDEN_CASES) >= 6
+
+
+def test_evp_parameter_known_answers():
+    # set_evp_parameters (ice_dyn_shared.F90:453-486); values printed by the compiled
+    # reference for ndte=120, dt=3600
+    p = oracle.set_parameters(120, 3600.0)
+    assert p["arlx"] == 86.39999999999999
+    assert p["arlx1i"] == 1.1574074074074075e-02
+    assert p["denom1"] == 0.9885583524027459
+    assert p["brlx"] == 120.0 and p["revp"] == 0.0
+    assert p["epp2i"] == 0.25 and p["e_factor"] == 0.25
+    r = oracle.set_parameters(240, 3600.0, revised_evp=True, arlx=300.0, brlx=300.0)
+    assert r["revp"] == 1.0 and r["denom1"] == 1.0 and r["arlx1i"] == 1.0 / 300.0 and r["brlx"] == 300.0
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_scalars_match_reference(name):
+    c = GoldenCase(name)
+    s = c.scal
+    revised = s[3] == 1.0
+    e_plast = (1.0 / s[5]) ** 0.5
+    e_yield = (s[4] * e_plast ** 4) ** 0.5
+    p = oracle.set_parameters(c.ndte, s[13], revised_evp=revised, arlx=s[14], brlx=s[2],
+                              e_yieldcurve=round(e_yield, 6), e_plasticpot=round(e_plast, 6))
+    assert p["arlx1i"] == s[0] and p["denom1"] == s[1] and p["brlx"] == s[2]
+    assert p["e_factor"] == s[4] and p["epp2i"] == s[5]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_metrics_bitwise(name):
+    c = GoldenCase(name)
+    m = oracle.metrics(c.oracle_domain(), c.scal[8], c.d["HTE"], c.d["HTN"], c.d["tarea"])
+    assert_bitwise(m, {k: c.d[k] for k in m}, f"{name} metrics")
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_subcycle_bitwise(name):
+    c = GoldenCase(name)
+    dom, prm, st = c.oracle_domain(), c.oracle_params(), c.static()
+    for icall in range(1, c.ncalls + 1):
+        dyn, tm, um = c.inputs(icall)
+        for nsub in c.nsub_list:
+            out = oracle.subcycle(dom, prm, nsub, dyn, st, tm, um)
+            assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub}")
+
+
+def test_halo_known_answer_global_index():
+    """halochk method (drivers/unittest/halochk/halochk.F90:232-247): fill interiors with
+    a function of the global index, update, and check every ghost cell analytically."""
+    from cice_amd import decomp
+    for ew, ns, bx, by in (("cyclic", "closed", 7, 5), ("closed", "closed", 20, 6), ("cyclic", "cyclic", 8, 9)):
+        dc = decomp.Decomp(20, 18, bx, by, ew, ns, 1)
+        blks = dc.local_blocks(0)
+        dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), 20, 18, ew, ns,
+                                  [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                                  [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+        gi = np.arange(1, 21)[None, :] + 1000.0 * np.arange(1, 19)[:, None]
+        a = dc.scatter(gi, 0, fill=-999.0)
+        # wipe ghosts, keep interiors
+        ref = a.copy()
+        for b in blks:
+            m = np.ones((dc.ny_block, dc.nx_block), bool)
+            m[1:1 + b.gny, 1:1 + b.gnx] = False
+            a[b.local][m] = -999.0
+        oracle.halo_update(dom, a, "NEcorner", "vector")
+        assert np.array_equal(a, ref), (ew, ns)
