@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--workload", default="gx1", choices=["gx3", "gx1", "s01"])
     ap.add_argument("--case", default="full", choices=["full", "caps"])
     ap.add_argument("--ndte", type=int, default=None)
-    ap.add_argument("--strict", action="store_true", help="no-FMA build (bit-identical to the reference built -ffp-contract=off)")
+    ap.add_argument("--fused", action="store_true",
+                    help="allow FMA contraction (default: strict fp64, bit-identical to the reference built without FMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
     return ap.parse_args()
@@ -64,21 +65,29 @@ def cpu_baseline(workload, case, ndte, target_s):
             run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
             bx, by = max(nx // 8, 8), max(ny // 8, 8)
             threads = min(cores, (nx // bx) * (ny // by))
-            # reference speed is ~1e7 cell-updates/s/core: size the sample for ~target_s
-            est = 1.0e7 * max(threads * 0.5, 1)
-            ncalls = int(max(1, min(200, target_s * est / (nx * ny * ndte))))
-            d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant="fast",
-                                         threads=threads, grid_kind="popfile", icecase=case,
-                                         grid_files=(td + "/grid.bin", td + "/kmt.bin"),
-                                         h_ndte=ndte, ncalls=1, nsub_list=[ndte], dump_arrays=False,
-                                         ntiming=ncalls, timeout=600)
+            def ref_run(ncalls):
+                d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant="fast",
+                                             threads=threads, grid_kind="popfile", icecase=case,
+                                             grid_files=(td + "/grid.bin", td + "/kmt.bin"),
+                                             h_ndte=ndte, ncalls=1, nsub_list=[ndte], dump_arrays=False,
+                                             ntiming=ncalls, timeout=900)
+                return run_ref.parse_timer(txt, "evp"), txt
+            # calibrate on 2 calls, then size the sample for ~target_s of the reference's timer_evp
+            t_cal, _ = ref_run(2)
+            per_call = max(t_cal or 0.0, 1e-3) / 3.0          # timer_evp also saw the dump call
+            ncalls = int(max(2, min(2000, target_s / per_call)))
+            t, txt = ref_run(ncalls)
+            if t:
+                t *= ncalls / (ncalls + 1.0)                      # remove the untimed-loop dump call's share
             t = run_ref.parse_timer(txt, "evp")
             if t and t > 0:
                 return dict(value=nx * ny * ndte * ncalls / t, unit="cell-updates/s", cores=threads,
                             kind="reference",
-                            sample=f"reference evp() standard_2d (amdflang -O2 -fopenmp), {nx}x{ny} in "
-                                   f"{(nx // bx) * (ny // by)} blocks {bx}x{by}, ndte={ndte}, {ncalls} calls, "
-                                   f"timer_evp={t:.2f}s, {threads} OpenMP threads of {cores} cores")
+                            sample=f"reference evp() standard_2d compiled from the unmodified sources "
+                                   f"(amdflang -O2 -fopenmp), {nx}x{ny} in {(nx // bx) * (ny // by)} blocks "
+                                   f"{bx}x{by}, ndte={ndte}, {ncalls} evp() calls, its own timer_evp={t:.2f}s "
+                                   f"(subcycle loop incl. serial halo + deformations), {threads} OpenMP "
+                                   f"threads of {cores} host cores")
     except Exception as e:  # noqa: BLE001
         print(f"[bench] reference CPU baseline unavailable ({e}); using the C port", file=sys.stderr)
     # port: the oracle's C restatement with OpenMP
@@ -100,8 +109,21 @@ def cpu_baseline(workload, case, ndte, target_s):
                        f"setup copies, {cores} threads")
 
 
+def pmc_traffic(a):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes of this same command (profiles/): a timed run cannot collect counters itself."""
+    if a.workload != "gx1" or a.case != "full" or a.fused or a.gpus != 1:
+        return None
+    f = ROOT / "profiles" / "r01_gx1_pmc_traffic.json"
+    try:
+        return json.loads(f.read_text())["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     a = parse()
+    a.strict = not a.fused
     import torch
     import torch.distributed as dist
     from cice_amd import decomp, evp, synth
@@ -152,8 +174,10 @@ def main():
         core.subcycle(ndte)
     barrier()
     t0 = time.perf_counter()
+    core.mark(0)
     for _ in range(a.steps):
         core.subcycle(ndte)
+    core.mark(1)
     core.sync()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -165,7 +189,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # per-launch kernel durations by HIP events on the library's stream (rank 0's share)
+    # HIP events on the library's stream around the timed region (rank 0's share)
+    tm_ev = core.timings()
     kt = core.time_kernels(200)
     out = core.download()
     finite = bool(np.isfinite(out["uvel"]).all() and np.isfinite(out["stressp_1"]).all())
@@ -175,9 +200,14 @@ def main():
         cells = nx * ny
         ms_step = 1e3 * dt / a.steps
         value = cells * ndte * a.steps / dt
+        my_cells = sum(b.gnx * b.gny for b in dc.local_blocks(0))
         my_active = int((tm[:, 1:-1, 1:-1] != 0).sum())
-        t_kernel = kt["stencil_ms"] * 1e-3
-        achieved = B_ALG * my_active / t_kernel / 1e9 if t_kernel > 0 else 0.0
+        launches = ndte * a.steps * tm_ev["launches_per_subcycle"]
+        # average duration of one launch of the fused stress+stepu kernel: HIP events on the
+        # library's stream over the timed region / number of launches (includes launch gaps;
+        # a single kernel per subcycle on one GPU)
+        t_kernel = tm_ev["marks_ms"] * 1e-3 / (ndte * a.steps)
+        achieved = B_ALG * my_cells / t_kernel / 1e9 if t_kernel > 0 else 0.0
         res = {
             "metric": "EVP subcycle cell-updates/sec (gx1 fp64)" if a.workload == "gx1"
                       else f"EVP subcycle cell-updates/sec ({a.workload} fp64)",
@@ -185,20 +215,23 @@ def main():
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload} {nx}x{ny} B-grid EVP ndte={ndte}, case={a.case}, "
-                                   f"{'strict (no FMA)' if a.strict else 'fused FMA'}",
+                                   f"{'strict fp64 (no FMA contraction; bit-identical to the reference)' if a.strict else 'fp64 with FMA contraction'}",
                        "cells": cells, "active_T_cells": n_active, "ndte": ndte,
                        "decomposition": f"{dc.proc_shape[0]}x{dc.proc_shape[1]} ranks, "
                                         f"{dc.block_size_x}x{dc.block_size_y} cells each",
-                       "us_per_subcycle": 1e3 * ms_step / ndte, "finite": finite, "max_abs_u": umax},
+                       "us_per_subcycle": 1e3 * ms_step / ndte, "tile_variant": tm_ev["tile_variant"],
+                       "launches_per_subcycle": tm_ev["launches_per_subcycle"],
+                       "finite": finite, "max_abs_u": umax},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "evp_subcycle_tile", "kernel_us": 1e3 * kt["stencil_ms"],
-                         "kernel_period_us": 1e3 * kt["stencil_period_ms"],
-                         "halo_kernel_us": 1e3 * kt["halo_ms"],
-                         "alg_bytes_per_launch": B_ALG * my_active,
-                         "note": "368 B x active T-cells of rank 0 per launch / HIP-event kernel time; "
-                                 "gx1 working set (45 MB) is Infinity-Cache resident",
-                         "loop_frac_all_cells": (B_ALG * cells * ndte * a.steps / dt / 1e9) / HBM_PEAK_GBS / world},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a),
+                         "kernel": "evp_subcycle_tile", "kernel_us": 1e6 * t_kernel,
+                         "kernel_us_single_launch_event_pair": 1e3 * kt["stencil_ms"],
+                         "kernel_period_us_back_to_back": 1e3 * kt["stencil_period_ms"],
+                         "alg_bytes_per_launch": B_ALG * my_cells,
+                         "achieved_active_cells_only": B_ALG * my_active / t_kernel / 1e9,
+                         "note": "achieved = 368 B x grid cells of rank 0 (SURVEY 8d: all cells of the domain, "
+                                 "ice or not) / average launch duration from HIP events on the kernel's stream "
+                                 "over the timed region; the 45 MB gx1 working set is Infinity-Cache resident"},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.workload, a.case, ndte, a.cpu_seconds)

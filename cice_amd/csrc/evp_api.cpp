@@ -75,17 +75,26 @@ struct State {
     size_t plane = 0, n = 0;     // nx*ny, nx*ny*nblocks
     int max_ni = 0, max_nj = 0;
     int tyb = 5;
+    bool tyb_forced = false, tuned = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evm[2] = {nullptr, nullptr};
+    bool marked[2] = {false, false};
 
     // device arrays
     double *stat[10] = {};      // dxT dyT dxhy dyhx cxp cyp cxm cym DminTarea uarear
     double *in[F_COUNT] = {};   // per-call inputs + diagnostics (entries of ping-ponged fields unused)
     double *u[2] = {}, *v[2] = {};
     double *sig[2][12] = {};
+    double *hte = nullptr, *htn = nullptr;   // edge lengths for in-kernel metric terms
+    double *vrelfac = nullptr;               // (aiX*rhow)*Cw, rebuilt at every upload
     uint8_t *mask = nullptr;
     int4 *blk = nullptr;
     int cur = 0;
+    unsigned flags = 0;          // EVP_F_* in effect
+    unsigned flags_allowed = ~0u;
+    int *push = nullptr;         // halo push table (device)
+    int push_ni = 0, push_nj = 0;
+    bool push_ok = false;
 
     HaloPlan plan;
     int32_t *h_local_dst = nullptr, *h_local_src = nullptr;
@@ -131,6 +140,10 @@ void free_all()
         F(S.v[k]);
         for (auto &p : S.sig[k]) F(p);
     }
+    F(S.hte);
+    F(S.htn);
+    F(S.vrelfac);
+    F(S.push);
     F(S.mask);
     F(S.blk);
     F(S.h_local_dst);
@@ -147,6 +160,7 @@ void free_all()
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     if (S.ev2) (void)hipEventDestroy(S.ev2);
     if (S.ev3) (void)hipEventDestroy(S.ev3);
+    for (auto &e : S.evm) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     S.ev0 = S.ev1 = S.ev2 = S.ev3 = nullptr;
     if (S.have_comm) (void)ncclCommDestroy(S.comm);
     S.have_comm = false;
@@ -195,6 +209,11 @@ int derive_metrics(const double *HTE, const double *HTN, const double *dxT, cons
             }
     }
     if (h2d(S.stat[0], dxT) || h2d(S.stat[1], dyT) || h2d(S.stat[9], uarear)) return -1;
+    if (h2d(S.hte, HTE) || h2d(S.htn, HTN)) return -1;
+    // in-kernel metric terms need tarea == dxT*dyT bit for bit (ice_grid.F90:681)
+    bool same = true;
+    for (size_t k = 0; k < S.n && same; ++k) same = (tarea[k] == dxT[k] * dyT[k]);
+    if (same) S.flags |= EVP_F_METRICS;
     const int order[7] = {4, 5, 6, 7, 2, 3, 8};   // stat slots of cxp cyp cxm cym dxhy dyhx Dmin
     for (int k = 0; k < 7; ++k)
         if (h2d(S.stat[order[k]], m[k].data())) return -1;
@@ -238,6 +257,49 @@ int upload_lists()
     return 0;
 }
 
+// Inverse of the local part of the halo plan: for every interior edge cell the
+// ghost cells that mirror it, so that the thread producing the cell can store the
+// images itself.  Per block 2*(nj+ni) edge slots (W, E, S, N) x 2 entries; an entry is
+// dst*2 + (sign<0), or -1.  Falls back to the gather kernel if an image does not fit.
+int build_push_table()
+{
+    const HaloPlan &P = S.plan;
+    S.push_ok = false;
+    S.push_ni = S.max_ni;
+    S.push_nj = S.max_nj;
+    const int nslot = 2 * (S.push_nj + S.push_ni);
+    std::vector<int> tab((size_t)S.d.nblocks * nslot * 2, -1);
+    const int nx = S.d.nx_block;
+    bool ok = true;
+    for (size_t k = 0; k < P.local_dst.size() && ok; ++k) {
+        const int src = P.local_src[k];
+        if (src < 0) { ok = false; break; }
+        const int b = (int)(src / S.plane);
+        const int rem = (int)(src % S.plane);
+        const int j = rem / nx + 1, i = rem % nx + 1;
+        int cand[4];
+        cand[0] = (i == S.ilo[b]) ? (j - S.jlo[b]) : -1;
+        cand[1] = (i == S.ihi[b]) ? S.push_nj + (j - S.jlo[b]) : -1;
+        cand[2] = (j == S.jlo[b]) ? 2 * S.push_nj + (i - S.ilo[b]) : -1;
+        cand[3] = (j == S.jhi[b]) ? 2 * S.push_nj + S.push_ni + (i - S.ilo[b]) : -1;
+        const int enc = P.local_dst[k] * 2 + (P.local_sign[k] < 0 ? 1 : 0);
+        bool placed = false;
+        for (int e = 0; e < 4 && !placed; ++e) {
+            if (cand[e] < 0) continue;
+            for (int w = 0; w < 2 && !placed; ++w) {
+                int &slot = tab[((size_t)b * nslot + cand[e]) * 2 + w];
+                if (slot < 0) { slot = enc; placed = true; }
+            }
+        }
+        if (!placed) ok = false;
+    }
+    if (!ok || P.local_dst.empty()) return 0;
+    HIPC(hipMalloc((void **)&S.push, tab.size() * sizeof(int)));
+    HIPC(hipMemcpy(S.push, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    S.push_ok = true;
+    return 0;
+}
+
 void fill_args(EvpArgs &A, int cur, int last)
 {
     const cice_evp_hip_params &q = S.prm;
@@ -260,6 +322,11 @@ void fill_args(EvpArgs &A, int cur, int last)
     A.dxT = S.stat[0]; A.dyT = S.stat[1]; A.dxhy = S.stat[2]; A.dyhx = S.stat[3];
     A.cxp = S.stat[4]; A.cyp = S.stat[5]; A.cxm = S.stat[6]; A.cym = S.stat[7];
     A.DminTarea = S.stat[8]; A.uarear = S.stat[9];
+    A.HTE = S.hte; A.HTN = S.htn; A.deltaminEVP = q.deltaminEVP;
+    A.vrelfac = S.vrelfac;
+    A.flags = S.flags & S.flags_allowed;
+    if (!S.push_ok) A.flags &= ~EVP_F_PUSH;
+    A.push = S.push; A.push_ni = S.push_ni; A.push_nj = S.push_nj;
     A.strength = S.in[F_STRENGTH]; A.Cw = S.in[F_CW]; A.aiX = S.in[F_AIX];
     A.uocn = S.in[F_UOCN]; A.vocn = S.in[F_VOCN]; A.waterx = S.in[F_WATERX];
     A.watery = S.in[F_WATERY]; A.forcex = S.in[F_FORCEX]; A.forcey = S.in[F_FORCEY];
@@ -279,8 +346,10 @@ int cap_mode()
 // velocity halo of buffer `b` (ice_dyn_evp.F90:908-910)
 int halo_uv(int b)
 {
-    evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src, (const signed char *)S.h_local_sign,
-                          S.n_local, S.stream);
+    const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
+    if (!pushed)
+        evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src,
+                              (const signed char *)S.h_local_sign, S.n_local, S.stream);
     if (!S.plan.peers.empty()) {
         if (!S.have_comm) return fail(-2, "remote halo needed but cice_evp_hip_comm_init was not called");
         evp_launch_halo_pack(S.u[b], S.v[b], S.h_send_src, S.sendbuf, S.n_send, S.stream);
@@ -381,6 +450,8 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     HIPC(hipEventCreate(&S.ev1));
     HIPC(hipEventCreate(&S.ev2));
     HIPC(hipEventCreate(&S.ev3));
+    HIPC(hipEventCreate(&S.evm[0]));
+    HIPC(hipEventCreate(&S.evm[1]));
 
     S.plane = (size_t)dims->nx_block * dims->ny_block;
     S.n = S.plane * nb;
@@ -392,7 +463,10 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         S.max_nj = std::max(S.max_nj, S.jhi[b] - S.jlo[b] + 1);
     }
     S.tyb = 5;
-    if (env("CICE_EVP_HIP_TYB")) S.tyb = std::atoi(env("CICE_EVP_HIP_TYB")) == 9 ? 9 : 5;
+    if (env("CICE_EVP_HIP_TYB")) {
+        const int t = std::atoi(env("CICE_EVP_HIP_TYB"));   // tile height [+100: XCD-contiguous order]
+        S.tyb = (t % 100 == 9 || t % 100 == 3) ? t : 5 + 100 * (t / 100);
+    }
     S.use_graph = !(env("CICE_EVP_HIP_NOGRAPH") && std::atoi(env("CICE_EVP_HIP_NOGRAPH")));
 
     for (auto &p : S.stat)
@@ -406,13 +480,20 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         for (auto &p : S.sig[k])
             if (alloc_d(&p, S.n)) return -1;
     }
+    if (alloc_d(&S.hte, S.n) || alloc_d(&S.htn, S.n) || alloc_d(&S.vrelfac, S.n)) return -1;
+    S.flags = EVP_F_VRELFAC;
+    S.flags_allowed = ~0u;
+    if (env("CICE_EVP_HIP_FLAGS")) S.flags_allowed = (unsigned)std::strtoul(env("CICE_EVP_HIP_FLAGS"), nullptr, 0);
     HIPC(hipMalloc((void **)&S.mask, S.n));
     HIPC(hipMemsetAsync(S.mask, 0, S.n, S.stream));
     HIPC(hipMalloc((void **)&S.blk, nb * sizeof(int4)));
     HIPC(hipMemcpy(S.blk, hb.data(), nb * sizeof(int4), hipMemcpyHostToDevice));
     if (upload_lists()) return -1;
+    if (build_push_table()) return -1;
+    if (S.push_ok) S.flags |= EVP_F_PUSH;
     if (derive_metrics(HTE, HTN, dxT, dyT, uarear, tarea)) return -1;
     S.hmask.resize(S.n);
+    S.tyb_forced = env("CICE_EVP_HIP_TYB") != nullptr;
     S.ready = true;
     S.uploaded = false;
     S.cur = 0;
@@ -454,8 +535,23 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
     if (h2d(S.u[0], f[F_UVEL]) || h2d(S.v[0], f[F_VVEL])) return -1;
     HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
     HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    for (size_t k = 0; k < S.n; ++k)
-        S.hmask[k] = (uint8_t)((iceTmask[k] != 0 ? 1 : 0) | (iceUmask[k] != 0 ? 2 : 0));
+    bool water_is_ocn = true, tbu_zero = true;
+    {
+        const double *wx = f[F_WATERX], *wy = f[F_WATERY], *uo = f[F_UOCN], *vo = f[F_VOCN], *tb = f[F_TBU];
+        for (size_t k = 0; k < S.n; ++k) {
+            const bool um = iceUmask[k] != 0;
+            S.hmask[k] = (uint8_t)((iceTmask[k] != 0 ? 1 : 0) | (um ? 2 : 0));
+            if (um) {
+                // bit-for-bit identical operands (cosw=1, sinw=0: ice_dyn_shared.F90:69-70,819-820)
+                if (std::memcmp(&wx[k], &uo[k], 8) != 0 || std::memcmp(&wy[k], &vo[k], 8) != 0) water_is_ocn = false;
+                if (tb[k] != 0.0) tbu_zero = false;
+            }
+        }
+    }
+    S.flags &= ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
+    if (water_is_ocn) S.flags |= EVP_F_WATER_IS_OCN;
+    if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
+    evp_launch_vrelfac(S.in[F_AIX], S.in[F_CW], S.prm.rhow, S.vrelfac, S.n, S.stream);
     HIPC(hipMemcpyAsync(S.mask, S.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
     HIPC(hipEventRecord(S.ev3, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
@@ -463,6 +559,32 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
     HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
     S.t_h2d_ms = ms;
     S.uploaded = true;
+    if (!S.tyb_forced && !S.tuned) {
+        // pick the tile height once per init by timing a few launches of each variant on
+        // the real state (results are identical for every tile shape; only speed differs).
+        // The launches write the ping-pong "next" buffers, which the first real subcycle
+        // overwrites, so the state is not advanced.
+        const int cand[9] = {3, 5, 9, 103, 105, 109, 203, 205, 209};
+        float best = 1e30f;
+        int best_t = 5;
+        EvpArgs A;
+        fill_args(A, S.cur, 0);
+        for (int c : cand) {
+            for (int rep = 0; rep < 2; ++rep) {   // first pass warms caches / code
+                HIPC(hipEventRecord(S.ev2, S.stream));
+                for (int k = 0; k < 8; ++k)
+                    evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, c, S.prm.strict != 0, cap_mode(), S.stream);
+                HIPC(hipEventRecord(S.ev3, S.stream));
+                HIPC(hipStreamSynchronize(S.stream));
+                HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+            }
+            if (ms < best) { best = ms; best_t = c; }
+        }
+        S.tyb = best_t;
+        S.tuned = true;
+        for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);
+        S.graphs.clear();
+    }
     return 0;
 }
 
@@ -497,6 +619,17 @@ int cice_evp_hip_subcycle(int32_t ndte)
     HIPC(hipEventRecord(S.ev1, S.stream));
     S.cur ^= (ndte & 1);
     S.t_nsub = ndte;
+    return 0;
+}
+
+// Record a HIP event on the library's stream: which = 0 (begin) or 1 (end) of a caller's
+// timed region; the elapsed time is reported by cice_evp_hip_get_timings()[6].
+int cice_evp_hip_mark(int32_t which)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (which < 0 || which > 1) return fail(-1, "mark index");
+    HIPC(hipEventRecord(S.evm[which], S.stream));
+    S.marked[which] = true;
     return 0;
 }
 
@@ -561,9 +694,14 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     if (S.ready && S.t_nsub > 0 && hipEventQuery(S.ev1) == hipSuccess &&
         hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess)
         S.t_loop_ms = ms;
-    const double v[5] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
-                         1.0 + (S.n_local > 0 ? 1.0 : 0.0) + (S.plan.peers.empty() ? 0.0 : 2.0)};
-    for (int k = 0; k < n && k < 5; ++k) out[k] = v[k];
+    double marks_ms = -1.0;
+    if (S.ready && S.marked[0] && S.marked[1] && hipEventQuery(S.evm[1]) == hipSuccess &&
+        hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
+        marks_ms = ms;
+    const double v[7] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+                         1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
+                             (S.plan.peers.empty() ? 0.0 : 2.0), (double)S.tyb, marks_ms};
+    for (int k = 0; k < n && k < 7; ++k) out[k] = v[k];
     return 0;
 }
 

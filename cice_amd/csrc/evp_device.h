@@ -19,6 +19,8 @@ struct EvpArgs {
     EvpScalars p;
     int nx, ny;
     size_t plane;              // nx*ny
+    int gx, gy, ntiles;        // tile grid (filled by evp_launch_subcycle)
+    int xcdmap;                // 1: XCD-contiguous tile order
     int last;                  // write strintx/y, taubx/y (needed after the last subcycle only)
     const int4 *blk;           // per block: ilo, ihi, jlo, jhi (1-based)
     const uint8_t *mask;       // bit0 = iceTmask, bit1 = iceUmask
@@ -29,14 +31,31 @@ struct EvpArgs {
     double *sig_out[12];
     // static metric terms (init_dyn_shared, ice_dyn_shared.F90:384-441)
     const double *dxT, *dyT, *dxhy, *dyhx, *cxp, *cyp, *cxm, *cym, *DminTarea, *uarear;
+    const double *HTE, *HTN;   // for EVP_F_METRICS (metric terms recomputed per cell)
+    double deltaminEVP;
     // per-call inputs (dyn_evp1d_run argument list, ice_dyn_evp1d.F90:121-153)
     const double *strength, *Cw, *aiX, *uocn, *vocn, *waterx, *watery, *forcex, *forcey;
     const double *umassdti, *fm, *TbU, *uvel_init, *vvel_init;
+    const double *vrelfac;     // (aiX*rhow)*Cw, formed once per call (same rounding as stepu :933)
+    unsigned flags;            // EVP_F_*
+    // halo push table (see halo_plan.h): per block 2*(nj_max+ni_max) edge slots x 2 entries
+    const int *push;
+    int push_ni, push_nj;
     // diagnostics of the last subcycle
     double *strintx, *strinty, *taubx, *tauby;
 };
 
-void evp_launch_subcycle(const EvpArgs &A, int max_ni, int max_nj, int nblocks, int tyb,
+enum : unsigned {
+    EVP_F_METRICS = 1u,     // recompute cxp..DminTarea from HTE,HTN,dxT,dyT (tarea == dxT*dyT verified)
+    EVP_F_WATER_IS_OCN = 2u,// waterxU==uocnU and wateryU==vocnU bit for bit on every active U-cell
+    EVP_F_TBU_ZERO = 4u,    // TbU == 0 on every active U-cell (seabed_stress off)
+    EVP_F_VRELFAC = 8u,     // use the pre-multiplied drag factor
+    EVP_F_PUSH = 16u,       // edge U-cells also write their ghost images (halo fused into the kernel)
+};
+
+void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double *out, size_t n,
+                        hipStream_t st);
+void evp_launch_subcycle(const EvpArgs &A, int max_ni, int max_nj, int nblocks, int variant,
                          bool strict, int cap, hipStream_t st);
 void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
                            const signed char *sign, int n, hipStream_t st);

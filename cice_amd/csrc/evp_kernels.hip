@@ -1,11 +1,11 @@
 // =====================================================================
 // HIP kernels of the MI355X-native EVP subcycle (gfx950, wave64, fp64).
 //
-// One launch per subcycle: a fused stress + stepu kernel over dense masked
-// tiles (replaces the reference's two sweeps over compressed index lists,
-// ice_dyn_evp.F90:867-901), followed -- for ghost cells that cannot be folded
-// into the stencil loads -- by a tiny halo gather kernel (replaces
-// dyn_haloUpdate -> ice_HaloUpdate, ice_dyn_evp.F90:908-910).
+// One launch per subcycle on a single GPU: a fused stress + stepu kernel over
+// dense masked tiles (replaces the reference's two sweeps over compressed index
+// lists, ice_dyn_evp.F90:867-901) whose edge threads also write the ghost-cell
+// images of the velocities they produce (replaces dyn_haloUpdate ->
+// ice_HaloUpdate for on-device neighbours, ice_dyn_evp.F90:908-910).
 //
 // Jacobi semantics: stress of every T-cell uses the velocities of the
 // previous subcycle (ice_dyn_evp.F90:867-901), so u,v are ping-ponged between
@@ -15,6 +15,8 @@
 // =====================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <cstdlib>
 
 #include "evp_device.h"
 
@@ -29,6 +31,7 @@ __device__ constexpr double p222 = 2.0 / 9.0;
 __device__ constexpr double p25 = 0.25;
 __device__ constexpr double p333 = 1.0 / 3.0;
 __device__ constexpr double p5 = 0.5;
+__device__ constexpr double c1p5 = 1.5;
 
 }  // namespace
 
@@ -43,6 +46,38 @@ namespace evp_fused {
 
 namespace {
 
+template <bool STRICT> struct Math;
+template <> struct Math<true> {
+    using SI = evp_strict::StressIn;
+    using UI = evp_strict::StepuIn;
+    using UO = evp_strict::StepuOut;
+    template <int CAP>
+    static __device__ __forceinline__ void stress(const EvpScalars &p, const SI &a, double (&s)[12], double (&str)[8])
+    {
+        evp_strict::stress_cell<CAP>(p, a, s, str);
+    }
+    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_strict::stepu_cell(p, a, o); }
+    static __device__ __forceinline__ void metrics(double hte, double hte_im, double htn, double htn_jm, double dmin, SI &a)
+    {
+        evp_strict::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);
+    }
+};
+template <> struct Math<false> {
+    using SI = evp_fused::StressIn;
+    using UI = evp_fused::StepuIn;
+    using UO = evp_fused::StepuOut;
+    template <int CAP>
+    static __device__ __forceinline__ void stress(const EvpScalars &p, const SI &a, double (&s)[12], double (&str)[8])
+    {
+        evp_fused::stress_cell<CAP>(p, a, s, str);
+    }
+    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_fused::stepu_cell(p, a, o); }
+    static __device__ __forceinline__ void metrics(double hte, double hte_im, double htn, double htn_jm, double dmin, SI &a)
+    {
+        evp_fused::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);
+    }
+};
+
 // ---------------------------------------------------------------------
 // Fused stress + stepu, tile version.
 //
@@ -51,65 +86,106 @@ namespace {
 // produces the 63 x (TYB-1) U-cells at the same (i,j).  Lane = i so that every
 // array access of a wave is one contiguous 512-byte row segment.
 //
+//   phase 0  all loads of both phases are issued up front (one latency exposure)
 //   phase 1  each thread: stress update of T(i,j) -> 12 new stresses (stored by
 //            the owning tile only) and the 8 partials str(i,j,1:8) -> LDS
 //   phase 2  each thread with tx<63, ty<TYB-1: stepu of U(i,j) from
 //            str(i,j,1|5) str(i+1,j,2|7) str(i,j+1,3|6) str(i+1,j+1,4|8)
-//            (ice_dyn_shared.F90:948-951) read back from LDS
+//            (ice_dyn_shared.F90:948-951) read back from LDS; threads on a block
+//            edge also store u,v into the ghost cells that mirror their cell.
 // ---------------------------------------------------------------------
-template <int TYB, bool STRICT, int CAP>
+template <int TYB, bool STRICT, int CAP, bool PRE>
 __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
 {
+    using MM = Math<STRICT>;
     __shared__ double s_str[8][TYB][64];
 
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int bz = blockIdx.z;
+    // XCD-aware tile order: workgroup w runs on XCD w % 8 (observed dispatch rule, used
+    // for speed only).  Give every XCD one contiguous run of the tile sequence, ordered
+    // with the tile row index fastest, so that vertically adjacent tiles -- which share
+    // the T-row recomputed on the fringe -- are read through the same L2 close in time.
+    int t;
+    {
+        const int w = blockIdx.x;
+        const int per = (A.ntiles + 7) >> 3;
+        t = A.xcdmap ? (w & 7) * per + (w >> 3) : w;
+        if (t >= A.ntiles) return;
+    }
+    int bx, by;
+    if (A.xcdmap == 1) {            // column runs: vertically adjacent tiles back to back
+        by = t % A.gy;
+        bx = (t / A.gy) % A.gx;
+    } else {                        // row-major: horizontally adjacent tiles back to back
+        bx = t % A.gx;
+        by = (t / A.gx) % A.gy;
+    }
+    const int bz = t / (A.gy * A.gx);
     const int4 r = A.blk[bz];                       // ilo, ihi, jlo, jhi (1-based)
-    const int i = r.x + blockIdx.x * 63 + tx;       // 1-based local indices
-    const int j = r.z + blockIdx.y * (TYB - 1) + ty;
+    const int i = r.x + bx * 63 + tx;               // 1-based local indices
+    const int j = r.z + by * (TYB - 1) + ty;
     const int nx = A.nx;
     const size_t base = (size_t)bz * A.plane;
     const size_t c = base + (size_t)(j - 1) * nx + (i - 1);
+    const unsigned flags = A.flags;
 
     const bool inT = (i <= r.y + 1) && (j <= r.w + 1);
     unsigned m = 0;
     if (inT) m = A.mask[c];
+    const bool actT = inT && (m & 1u);
+    const bool isU = (tx < 63) && (ty < TYB - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
 
-    double str[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) str[k] = 0.0;
-
+    // ---- phase 0: loads -------------------------------------------------
     double u_ij = 0.0, v_ij = 0.0;
-    if (inT && (m & 3u)) {
+    if (actT || isU) {
         u_ij = A.u_in[c];
         v_ij = A.v_in[c];
     }
-
-    if (inT && (m & 1u)) {
-        double s[12];
+    typename MM::SI a;
+    double s[12];
+    if (actT) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) s[k] = A.sig_in[k][c];
-        if (STRICT) {
-            evp_strict::StressIn a;
-            a.u_ij = u_ij; a.v_ij = v_ij;
-            a.u_im = A.u_in[c - 1]; a.v_im = A.v_in[c - 1];
-            a.u_jm = A.u_in[c - nx]; a.v_jm = A.v_in[c - nx];
-            a.u_mm = A.u_in[c - nx - 1]; a.v_mm = A.v_in[c - nx - 1];
-            a.dxT = A.dxT[c]; a.dyT = A.dyT[c]; a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c];
-            a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
-            a.DminTarea = A.DminTarea[c]; a.strength = A.strength[c];
-            evp_strict::stress_cell<CAP>(A.p, a, s, str);
+        a.u_ij = u_ij; a.v_ij = v_ij;
+        a.u_im = A.u_in[c - 1]; a.v_im = A.v_in[c - 1];
+        a.u_jm = A.u_in[c - nx]; a.v_jm = A.v_in[c - nx];
+        a.u_mm = A.u_in[c - nx - 1]; a.v_mm = A.v_in[c - nx - 1];
+        a.dxT = A.dxT[c]; a.dyT = A.dyT[c];
+        a.strength = A.strength[c];
+    }
+    double hte = 0, hte_im = 0, htn = 0, htn_jm = 0;
+    if (actT) {
+        if (flags & EVP_F_METRICS) {
+            hte = A.HTE[c]; hte_im = A.HTE[c - 1];
+            htn = A.HTN[c]; htn_jm = A.HTN[c - nx];
         } else {
-            evp_fused::StressIn a;
-            a.u_ij = u_ij; a.v_ij = v_ij;
-            a.u_im = A.u_in[c - 1]; a.v_im = A.v_in[c - 1];
-            a.u_jm = A.u_in[c - nx]; a.v_jm = A.v_in[c - nx];
-            a.u_mm = A.u_in[c - nx - 1]; a.v_mm = A.v_in[c - nx - 1];
-            a.dxT = A.dxT[c]; a.dyT = A.dyT[c]; a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c];
+            a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c];
             a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
-            a.DminTarea = A.DminTarea[c]; a.strength = A.strength[c];
-            evp_fused::stress_cell<CAP>(A.p, a, s, str);
+            a.DminTarea = A.DminTarea[c];
         }
+    }
+    typename MM::UI q;
+    auto load_u = [&]() {
+        q.uold = u_ij; q.vold = v_ij;
+        q.vrelfac = A.vrelfac[c];
+        q.uocn = A.uocn[c]; q.vocn = A.vocn[c];
+        q.forcex = A.forcex[c]; q.forcey = A.forcey[c];
+        q.Umassdti = A.umassdti[c]; q.fm = A.fm[c]; q.uarear = A.uarear[c];
+        if (flags & EVP_F_WATER_IS_OCN) { q.waterx = q.uocn; q.watery = q.vocn; }
+        else { q.waterx = A.waterx[c]; q.watery = A.watery[c]; }
+        q.TbU = (flags & EVP_F_TBU_ZERO) ? 0.0 : A.TbU[c];
+        q.uvel_init = A.p.revp != 0.0 ? A.uvel_init[c] : 0.0;
+        q.vvel_init = A.p.revp != 0.0 ? A.vvel_init[c] : 0.0;
+    };
+    if (PRE && isU) load_u();   // PRE: momentum operands in flight during the stress phase
+
+    // ---- phase 1: stress ---------------------------------------------------
+    double str[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) str[k] = 0.0;
+    if (actT) {
+        if (flags & EVP_F_METRICS) MM::metrics(hte, hte_im, htn, htn_jm, A.deltaminEVP, a);
+        MM::template stress<CAP>(A.p, a, s, str);
         // the tile that holds this T-cell off its north/east fringe owns it; the
         // ghost row/column ihi+1 / jhi+1 has no further tile and is owned here
         const bool own = (tx < 63 || i == r.y + 1) && (ty < TYB - 1 || j == r.w + 1);
@@ -122,50 +198,53 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
     for (int k = 0; k < 8; ++k) s_str[k][ty][tx] = str[k];
     __syncthreads();
 
-    const bool isU = (tx < 63) && (ty < TYB - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
+    // ---- phase 2: momentum ----------------------------------------------------
     if (isU) {
-        if (STRICT) {
-            evp_strict::StepuIn a;
-            evp_strict::StepuOut o;
-            a.uold = u_ij; a.vold = v_ij;
-            a.Cw = A.Cw[c]; a.aiX = A.aiX[c]; a.uocn = A.uocn[c]; a.vocn = A.vocn[c];
-            a.waterx = A.waterx[c]; a.watery = A.watery[c]; a.forcex = A.forcex[c];
-            a.forcey = A.forcey[c]; a.Umassdti = A.umassdti[c]; a.fm = A.fm[c];
-            a.uarear = A.uarear[c]; a.TbU = A.TbU[c];
-            a.uvel_init = A.p.revp != 0.0 ? A.uvel_init[c] : 0.0;
-            a.vvel_init = A.p.revp != 0.0 ? A.vvel_init[c] : 0.0;
-            a.sx0 = s_str[0][ty][tx]; a.sx1 = s_str[1][ty][tx + 1];
-            a.sx2 = s_str[2][ty + 1][tx]; a.sx3 = s_str[3][ty + 1][tx + 1];
-            a.sy0 = s_str[4][ty][tx]; a.sy1 = s_str[5][ty + 1][tx];
-            a.sy2 = s_str[6][ty][tx + 1]; a.sy3 = s_str[7][ty + 1][tx + 1];
-            evp_strict::stepu_cell(A.p, a, o);
-            A.u_out[c] = o.u; A.v_out[c] = o.v;
-            if (A.last) {
-                A.strintx[c] = o.strintx; A.strinty[c] = o.strinty;
-                A.taubx[c] = o.taubx; A.tauby[c] = o.tauby;
-            }
-        } else {
-            evp_fused::StepuIn a;
-            evp_fused::StepuOut o;
-            a.uold = u_ij; a.vold = v_ij;
-            a.Cw = A.Cw[c]; a.aiX = A.aiX[c]; a.uocn = A.uocn[c]; a.vocn = A.vocn[c];
-            a.waterx = A.waterx[c]; a.watery = A.watery[c]; a.forcex = A.forcex[c];
-            a.forcey = A.forcey[c]; a.Umassdti = A.umassdti[c]; a.fm = A.fm[c];
-            a.uarear = A.uarear[c]; a.TbU = A.TbU[c];
-            a.uvel_init = A.p.revp != 0.0 ? A.uvel_init[c] : 0.0;
-            a.vvel_init = A.p.revp != 0.0 ? A.vvel_init[c] : 0.0;
-            a.sx0 = s_str[0][ty][tx]; a.sx1 = s_str[1][ty][tx + 1];
-            a.sx2 = s_str[2][ty + 1][tx]; a.sx3 = s_str[3][ty + 1][tx + 1];
-            a.sy0 = s_str[4][ty][tx]; a.sy1 = s_str[5][ty + 1][tx];
-            a.sy2 = s_str[6][ty][tx + 1]; a.sy3 = s_str[7][ty + 1][tx + 1];
-            evp_fused::stepu_cell(A.p, a, o);
-            A.u_out[c] = o.u; A.v_out[c] = o.v;
-            if (A.last) {
-                A.strintx[c] = o.strintx; A.strinty[c] = o.strinty;
-                A.taubx[c] = o.taubx; A.tauby[c] = o.tauby;
+        typename MM::UO o;
+        if (!PRE) load_u();
+        q.sx0 = s_str[0][ty][tx]; q.sx1 = s_str[1][ty][tx + 1];
+        q.sx2 = s_str[2][ty + 1][tx]; q.sx3 = s_str[3][ty + 1][tx + 1];
+        q.sy0 = s_str[4][ty][tx]; q.sy1 = s_str[5][ty + 1][tx];
+        q.sy2 = s_str[6][ty][tx + 1]; q.sy3 = s_str[7][ty + 1][tx + 1];
+        MM::stepu(A.p, q, o);
+        A.u_out[c] = o.u; A.v_out[c] = o.v;
+        if (A.last) {
+            A.strintx[c] = o.strintx; A.strinty[c] = o.strinty;
+            A.taubx[c] = o.taubx; A.tauby[c] = o.tauby;
+        }
+        if ((flags & EVP_F_PUSH) && (i == r.x || i == r.y || j == r.z || j == r.w)) {
+            // ghost images of this cell (cyclic wrap / neighbouring block on this GPU)
+            const int nslot = 2 * (A.push_nj + A.push_ni);
+            const int *tab = A.push + (size_t)bz * nslot * 2;
+            int slots[4];
+            slots[0] = (i == r.x) ? (j - r.z) : -1;
+            slots[1] = (i == r.y) ? A.push_nj + (j - r.z) : -1;
+            slots[2] = (j == r.z) ? 2 * A.push_nj + (i - r.x) : -1;
+            slots[3] = (j == r.w) ? 2 * A.push_nj + A.push_ni + (i - r.x) : -1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (slots[e] < 0) continue;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int v = tab[slots[e] * 2 + w];
+                    if (v >= 0) {
+                        const double sg = (v & 1) ? -1.0 : 1.0;
+                        A.u_out[v >> 1] = sg * o.u;
+                        A.v_out[v >> 1] = sg * o.v;
+                    }
+                }
             }
         }
     }
+}
+
+// (aiX*rhow)*Cw once per call: the leading factors of vrel in stepu
+// (ice_dyn_shared.F90:933), multiplied in the reference's order.
+__global__ void vrelfac_kernel(const double *__restrict__ aiX, const double *__restrict__ Cw,
+                               double rhow, double *__restrict__ out, size_t n)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = aiX[t] * rhow * Cw[t];
 }
 
 // ---------------------------------------------------------------------
@@ -217,7 +296,12 @@ template <int TYB>
 void launch_tile(const EvpArgs &A, dim3 grid, hipStream_t st, bool strict, int cap)
 {
     dim3 block(64, TYB);
-#define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_subcycle_tile<TYB, S, C>), grid, block, 0, st, A)
+    static const bool pre = std::getenv("CICE_EVP_HIP_PREFETCH") && std::atoi(std::getenv("CICE_EVP_HIP_PREFETCH"));
+#define EVP_LAUNCH(S, C)                                                                           \
+    do {                                                                                           \
+        if (pre) hipLaunchKernelGGL((evp_subcycle_tile<TYB, S, C, true>), grid, block, 0, st, A);  \
+        else hipLaunchKernelGGL((evp_subcycle_tile<TYB, S, C, false>), grid, block, 0, st, A);     \
+    } while (0)
     if (strict) {
         if (cap == 1) EVP_LAUNCH(true, 1);
         else if (cap == 0) EVP_LAUNCH(true, 0);
@@ -235,19 +319,29 @@ void launch_tile(const EvpArgs &A, dim3 grid, hipStream_t st, bool strict, int c
 // ---------------------------------------------------------------------
 // host-callable launchers (declared in evp_device.h)
 // ---------------------------------------------------------------------
-void evp_launch_subcycle(const EvpArgs &A, int max_ni, int max_nj, int nblocks, int tyb,
+void evp_launch_subcycle(const EvpArgs &A0, int max_ni, int max_nj, int nblocks, int variant,
                          bool strict, int cap, hipStream_t st)
 {
     // a tile produces 63 x (TYB-1) U-cells and holds one more T row/column, so
     // ceil(ni/63) x ceil(nj/(TYB-1)) tiles also cover the T-cells ihi+1 / jhi+1
-    const int gx = (max_ni + 62) / 63;
-    if (tyb == 9) {
-        dim3 grid(gx, (max_nj + 7) / 8, nblocks);
-        launch_tile<9>(A, grid, st, strict, cap);
-    } else {
-        dim3 grid(gx, (max_nj + 3) / 4, nblocks);
-        launch_tile<5>(A, grid, st, strict, cap);
-    }
+    EvpArgs A = A0;
+    int tyb = variant % 100;           // variant = tile height + 100 * (XCD-contiguous tile order)
+    A.xcdmap = variant / 100;        // 0: plain row-major, 1: XCD-chunked column runs, 2: XCD-chunked row-major
+    if (tyb != 3 && tyb != 9) tyb = 5;
+    A.gx = (max_ni + 62) / 63;
+    A.gy = (max_nj + tyb - 2) / (tyb - 1);
+    A.ntiles = A.gx * A.gy * nblocks;
+    const int per = (A.ntiles + 7) / 8;
+    dim3 grid(per * 8);
+    if (tyb == 9) launch_tile<9>(A, grid, st, strict, cap);
+    else if (tyb == 3) launch_tile<3>(A, grid, st, strict, cap);
+    else launch_tile<5>(A, grid, st, strict, cap);
+}
+
+void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double *out, size_t n,
+                        hipStream_t st)
+{
+    hipLaunchKernelGGL(vrelfac_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aiX, Cw, rhow, out, n);
 }
 
 void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,

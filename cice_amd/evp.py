@@ -39,7 +39,7 @@ EXPORTS = [
     "cice_evp_hip_set_metrics", "cice_evp_hip_run", "cice_evp_hip_finalize",
     "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
-    "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels",
+    "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark",
 ]
 
 _i32p = C.POINTER(C.c_int32)
@@ -192,9 +192,13 @@ class EvpHip:
         return out
 
     def timings(self) -> dict:
-        t = np.zeros(5)
-        self.lib.cice_evp_hip_get_timings(_dp(t), 5)
-        return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4])
+        t = np.zeros(7)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 7)
+        return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4],
+                    tile_variant=int(t[5]), marks_ms=t[6])
+
+    def mark(self, which: int):
+        _check(self.lib, self.lib.cice_evp_hip_mark(C.c_int32(which)), "(dyn_evp_hip_mark)")
 
     def time_kernels(self, nrep: int = 50) -> dict:
         t = np.zeros(3)

@@ -125,6 +125,9 @@ int cice_evp_hip_upload(const double *const *fields32, const int32_t *iceTmask,
 int cice_evp_hip_subcycle(int32_t ndte);
 /* D2H of the 18 output fields into a 32-entry table (NULL entries skipped).   */
 int cice_evp_hip_download(double *const *fields32);
+/* HIP event on the library's stream: which=0 begins, which=1 ends a caller's timed
+ * region (elapsed ms: cice_evp_hip_get_timings()[6]).                           */
+int cice_evp_hip_mark(int32_t which);
 /* Block the host until all device work of this library has finished.          */
 int cice_evp_hip_sync(void);
 
@@ -138,7 +141,9 @@ int cice_evp_hip_comm_init(const void *id128);
 int cice_evp_hip_abi_version(void);
 int cice_evp_hip_last_error(char *buf, int32_t buflen);
 /* out[0]=last subcycle-loop ms (HIP events), [1]=H2D ms, [2]=D2H ms,
- * [3]=subcycles in that loop, [4]=kernel launches per subcycle                 */
+ * [3]=subcycles in that loop, [4]=kernel launches per subcycle,
+ * [5]=tile variant in use (tile height + 100 * tile-order mode),
+ * [6]=ms between cice_evp_hip_mark(0) and cice_evp_hip_mark(1), -1 if unset                 */
 int cice_evp_hip_get_timings(double *out, int32_t n);
 /* Halo plan of this rank, for tests: counts[0]=local copies, [1]=#peers,
  * [2]=total send cells, [3]=total recv cells.  Lists may be NULL.

@@ -9,7 +9,8 @@
 #
 #   usage: oracle/ref/build_ref.sh [strict|fast]   (default: both)
 #     strict : -O2 -ffp-contract=off  (bitwise-comparable with oracle/evp_oracle.c)
-#     fast   : -O2                    (the reference's ordinary optimisation level)
+#     fast   : -O2 -fopenmp           (the reference's ordinary optimisation level; CPU baseline)
+#     fma    : -O2 -march=native -ffp-contract=fast  (only on request)
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 REPO="$(cd "$HERE/../.." && pwd)"
@@ -84,3 +85,6 @@ build_variant () {
 want=${1:-both}
 if [ "$want" = strict ] || [ "$want" = both ]; then build_variant strict -O2 -ffp-contract=off; fi
 if [ "$want" = fast ]   || [ "$want" = both ]; then build_variant fast   -O2 -fopenmp; fi
+# fma: contraction really happens (x86-64 baseline has no FMA, so "fast" == strict bit for bit);
+#      used once to measure the reference's own build-to-build spread (tolerance)
+if [ "$want" = fma ]; then build_variant fma -O2 -march=native -ffp-contract=fast; fi
