@@ -1,0 +1,277 @@
+!=======================================================================
+! ice_dyn_evp_hip -- Fortran host side of the MI355X-native EVP core.
+!
+! ISO_C_BINDING interfaces of the C ABI in include/cice_evp_hip.h plus the
+! three routines CICE's evp() needs, with the same call shape as the
+! reference's alternative EVP core (module ice_dyn_evp1d, public
+! dyn_evp1d_init / dyn_evp1d_run / dyn_evp1d_finalize,
+! cicecore/cicedyn/dynamics/ice_dyn_evp1d.F90:25,73,121):
+!
+!    call dyn_evp_hip_init                       ! ice_dyn_evp.F90:153-155
+!    call dyn_evp_hip_run(stressp_1, ..., iceUmask)   ! ice_dyn_evp.F90:846-856
+!    call dyn_evp_hip_finalize
+!
+! CICE's module arrays (nx_block,ny_block,max_blocks) are passed straight to
+! the library (sequence association, no copies).  Errors follow the
+! reference's fail-stop convention: non-zero status -> abort_ice(msg,file,line)
+! (comm/*/ice_exit.F90).  Unlike the reference's 1-d core the HIP core stays
+! block-distributed: every MPI rank drives its own GPU and the velocity halo
+! runs over RCCL; with the serial comm layer everything is on one GPU.
+!
+! This file is new code written for this repository (no reference code).
+!=======================================================================
+module ice_dyn_evp_hip
+
+  use, intrinsic :: iso_c_binding
+  use ice_kinds_mod
+  use ice_exit, only: abort_ice
+
+  implicit none
+  private
+
+  public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize
+
+  ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
+  type, bind(C) :: cice_evp_hip_dims
+     integer(c_int32_t) :: nx_block, ny_block, nblocks, max_blocks, nghost
+     integer(c_int32_t) :: nx_global, ny_global
+     integer(c_int32_t) :: ew_boundary_type, ns_boundary_type
+     integer(c_int32_t) :: rank, nranks
+     type(c_ptr) :: ilo, ihi, jlo, jhi, iglob0, jglob0
+     integer(c_int32_t) :: nblocks_tot
+     type(c_ptr) :: gi0, gj0, gnx, gny, gowner, glocal
+  end type cice_evp_hip_dims
+
+  ! mirror of cice_evp_hip_params
+  type, bind(C) :: cice_evp_hip_params
+     integer(c_int32_t) :: ndte, strict
+     real(c_double) :: arlx1i, denom1, brlx, revp, e_factor, epp2i
+     real(c_double) :: capping, Ktens, deltaminEVP, u0, cosw, sinw, rhow
+  end type cice_evp_hip_params
+
+  interface
+     integer(c_int) function cice_evp_hip_init(dims, params, HTE, HTN, dxT, dyT, uarear, tarea) &
+          bind(C, name='cice_evp_hip_init')
+       import :: c_int, c_double, cice_evp_hip_dims, cice_evp_hip_params
+       type(cice_evp_hip_dims), intent(in) :: dims
+       type(cice_evp_hip_params), intent(in) :: params
+       real(c_double), dimension(*), intent(in) :: HTE, HTN, dxT, dyT, uarear, tarea
+     end function cice_evp_hip_init
+
+     integer(c_int) function cice_evp_hip_run( &
+          stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
+          stress12_1, stress12_2, stress12_3, stress12_4, strength, cdn_ocnU, aiU, uocnU, vocnU, &
+          waterxU, wateryU, forcexU, forceyU, umassdti, fmU, strintxU, strintyU, TbU, taubxU, &
+          taubyU, uvel, vvel, uvel_init, vvel_init, iceTmask, iceUmask, ndte) &
+          bind(C, name='cice_evp_hip_run')
+       import :: c_int, c_int32_t, c_double
+       real(c_double), dimension(*), intent(inout) :: &
+          stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
+          stress12_1, stress12_2, stress12_3, stress12_4, strintxU, strintyU, taubxU, taubyU, &
+          uvel, vvel
+       real(c_double), dimension(*), intent(in) :: &
+          strength, cdn_ocnU, aiU, uocnU, vocnU, waterxU, wateryU, forcexU, forceyU, umassdti, &
+          fmU, TbU, uvel_init, vvel_init
+       integer(c_int32_t), dimension(*), intent(in) :: iceTmask, iceUmask   ! logical(4): non-zero = .true.
+       integer(c_int32_t), value :: ndte
+     end function cice_evp_hip_run
+
+     integer(c_int) function cice_evp_hip_finalize() bind(C, name='cice_evp_hip_finalize')
+       import :: c_int
+     end function cice_evp_hip_finalize
+
+     integer(c_int) function cice_evp_hip_last_error(buf, buflen) bind(C, name='cice_evp_hip_last_error')
+       import :: c_int, c_int32_t, c_char
+       character(kind=c_char), dimension(*), intent(out) :: buf
+       integer(c_int32_t), value :: buflen
+     end function cice_evp_hip_last_error
+
+     integer(c_int) function cice_evp_hip_comm_unique_id(id128) bind(C, name='cice_evp_hip_comm_unique_id')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), dimension(32), intent(out) :: id128
+     end function cice_evp_hip_comm_unique_id
+
+     integer(c_int) function cice_evp_hip_comm_init(id128) bind(C, name='cice_evp_hip_comm_init')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), dimension(32), intent(in) :: id128
+     end function cice_evp_hip_comm_init
+  end interface
+
+  logical :: initialised = .false.
+
+contains
+
+!-----------------------------------------------------------------------
+  subroutine check(rc, subname, file, line)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: subname, file
+    integer, intent(in) :: line
+    character(kind=c_char), dimension(1024) :: cbuf
+    character(len=1024) :: msg
+    integer :: n, k
+    if (rc == 0) return
+    n = cice_evp_hip_last_error(cbuf, 1024_c_int32_t)
+    msg = ' '
+    do k = 1, min(n, 1023)
+       msg(k:k) = cbuf(k)
+    enddo
+    call abort_ice(subname//' ERROR: '//trim(msg), file=file, line=line)
+  end subroutine check
+
+!-----------------------------------------------------------------------
+! Replaces dyn_evp1d_init.  Everything it needs is public module data:
+! block geometry (ice_blocks, ice_domain), static grid (ice_grid), EVP
+! scalars (ice_dyn_shared, set by set_evp_parameters), rhow (Icepack).
+  subroutine dyn_evp_hip_init
+
+    use ice_blocks, only: nx_block, ny_block, nghost, block, get_block, nblocks_tot, &
+        get_block_parameter
+    use ice_communicate, only: my_task, master_task, get_num_procs
+    use ice_broadcast, only: broadcast_array
+    use ice_domain, only: nblocks, blocks_ice, distrb_info, ew_boundary_type, ns_boundary_type
+    use ice_domain_size, only: max_blocks, nx_global, ny_global
+    use ice_grid, only: HTE, HTN, dxT, dyT, uarear, tarea
+    use ice_dyn_shared, only: ndte, arlx1i, denom1, brlx, revp, e_factor, epp2i, capping, &
+        Ktens, deltaminEVP, u0, cosw, sinw
+    use ice_fileunits, only: nu_diag
+    use icepack_intfc, only: icepack_query_parameters, icepack_warnings_flush, &
+        icepack_warnings_aborted
+
+    type(cice_evp_hip_dims) :: d
+    type(cice_evp_hip_params) :: p
+    type(block) :: tb
+    integer(c_int32_t), allocatable, target, save :: ilo(:), ihi(:), jlo(:), jhi(:), ig0(:), jg0(:), &
+        gi0(:), gj0(:), gnx(:), gny(:), gown(:), gloc(:)
+    integer(int_kind), pointer :: i_glob(:), j_glob(:)
+    integer(int_kind) :: n, lo_i, hi_i, lo_j, hi_j, nprocs
+    integer(c_int32_t) :: uid(32)
+    real(dbl_kind) :: rhow
+    character(len=*), parameter :: subname = '(dyn_evp_hip_init)'
+
+    call icepack_query_parameters(rhow_out=rhow)
+    call icepack_warnings_flush(nu_diag)
+    if (icepack_warnings_aborted()) call abort_ice(error_message=subname, file=__FILE__, line=__LINE__)
+
+    nprocs = get_num_procs()
+    if (allocated(ilo)) deallocate(ilo, ihi, jlo, jhi, ig0, jg0, gi0, gj0, gnx, gny, gown, gloc)
+    allocate(ilo(nblocks), ihi(nblocks), jlo(nblocks), jhi(nblocks), ig0(nblocks), jg0(nblocks))
+    do n = 1, nblocks
+       tb = get_block(blocks_ice(n), n)
+       ilo(n) = tb%ilo; ihi(n) = tb%ihi; jlo(n) = tb%jlo; jhi(n) = tb%jhi
+       ig0(n) = tb%i_glob(tb%ilo); jg0(n) = tb%j_glob(tb%jlo)
+    enddo
+    ! global block table: who owns which rectangle of the global index space
+    allocate(gi0(nblocks_tot), gj0(nblocks_tot), gnx(nblocks_tot), gny(nblocks_tot), &
+             gown(nblocks_tot), gloc(nblocks_tot))
+    do n = 1, nblocks_tot
+       call get_block_parameter(n, ilo=lo_i, ihi=hi_i, jlo=lo_j, jhi=hi_j, i_glob=i_glob, j_glob=j_glob)
+       gi0(n) = i_glob(lo_i); gj0(n) = j_glob(lo_j)
+       gnx(n) = hi_i - lo_i + 1; gny(n) = hi_j - lo_j + 1
+       gown(n) = distrb_info%blockLocation(n) - 1      ! 0 -> -1: eliminated land block
+       gloc(n) = distrb_info%blockLocalID(n) - 1
+    enddo
+
+    d%nx_block = nx_block; d%ny_block = ny_block; d%nblocks = nblocks; d%max_blocks = max_blocks
+    d%nghost = nghost; d%nx_global = nx_global; d%ny_global = ny_global
+    d%ew_boundary_type = bnd_code(ew_boundary_type); d%ns_boundary_type = bnd_code(ns_boundary_type)
+    d%rank = my_task; d%nranks = nprocs
+    d%ilo = c_loc(ilo); d%ihi = c_loc(ihi); d%jlo = c_loc(jlo); d%jhi = c_loc(jhi)
+    d%iglob0 = c_loc(ig0); d%jglob0 = c_loc(jg0)
+    d%nblocks_tot = nblocks_tot
+    d%gi0 = c_loc(gi0); d%gj0 = c_loc(gj0); d%gnx = c_loc(gnx); d%gny = c_loc(gny)
+    d%gowner = c_loc(gown); d%glocal = c_loc(gloc)
+
+    p%ndte = ndte; p%strict = 1
+    p%arlx1i = arlx1i; p%denom1 = denom1; p%brlx = brlx; p%revp = revp
+    p%e_factor = e_factor; p%epp2i = epp2i; p%capping = capping; p%Ktens = Ktens
+    p%deltaminEVP = deltaminEVP; p%u0 = u0; p%cosw = cosw; p%sinw = sinw; p%rhow = rhow
+
+    call check(cice_evp_hip_init(d, p, HTE, HTN, dxT, dyT, uarear, tarea), subname, __FILE__, __LINE__)
+
+    if (nprocs > 1) then
+       ! RCCL bootstrap: the master's ncclUniqueId travels over CICE's own broadcast
+       uid = 0
+       if (my_task == master_task) &
+          call check(cice_evp_hip_comm_unique_id(uid), subname, __FILE__, __LINE__)
+       call broadcast_array(uid, master_task)
+       call check(cice_evp_hip_comm_init(uid), subname, __FILE__, __LINE__)
+    endif
+    initialised = .true.
+
+  end subroutine dyn_evp_hip_init
+
+!-----------------------------------------------------------------------
+  integer(c_int32_t) function bnd_code(bnd)
+    character(len=*), intent(in) :: bnd
+    select case (trim(bnd))
+    case ('closed');  bnd_code = 0
+    case ('open');    bnd_code = 1
+    case ('cyclic');  bnd_code = 2
+    case ('tripole'); bnd_code = 3
+    case default
+       bnd_code = -1
+       call abort_ice('(dyn_evp_hip_init) ERROR: unsupported boundary type '//trim(bnd), &
+            file=__FILE__, line=__LINE__)
+    end select
+  end function bnd_code
+
+!-----------------------------------------------------------------------
+! Replaces dyn_evp1d_run: identical argument list (ice_dyn_evp1d.F90:121-153).
+! uvel_init/vvel_init (read for revised EVP only) and ndte are module data.
+  subroutine dyn_evp_hip_run(L_stressp_1 , L_stressp_2 , L_stressp_3 , L_stressp_4 , &
+                             L_stressm_1 , L_stressm_2 , L_stressm_3 , L_stressm_4 , &
+                             L_stress12_1, L_stress12_2, L_stress12_3, L_stress12_4, &
+                             L_strength,                                             &
+                             L_cdn_ocn   , L_aiu       , L_uocn      , L_vocn      , &
+                             L_waterxU   , L_wateryU   , L_forcexU   , L_forceyU   , &
+                             L_umassdti  , L_fmU       , L_strintxU  , L_strintyU  , &
+                             L_Tbu       , L_taubxU    , L_taubyU    , L_uvel      , &
+                             L_vvel      , L_icetmask  , L_iceUmask)
+
+    use ice_dyn_shared, only: ndte, uvel_init, vvel_init
+    use ice_timers, only: ice_timer_start, ice_timer_stop, timer_evp1dcore
+
+    real(kind=dbl_kind), dimension(:,:,:), intent(inout), contiguous, target :: &
+      L_stressp_1 , L_stressp_2 , L_stressp_3 , L_stressp_4 ,  &
+      L_stressm_1 , L_stressm_2 , L_stressm_3 , L_stressm_4 ,  &
+      L_stress12_1, L_stress12_2, L_stress12_3, L_stress12_4,  &
+      L_strintxU  , L_strintyU  , L_uvel      , L_vvel      ,  &
+      L_taubxU    , L_taubyU
+    real(kind=dbl_kind), dimension(:,:,:), intent(in), contiguous, target :: &
+      L_strength  ,                                            &
+      L_cdn_ocn   , L_aiu       , L_uocn     , L_vocn   ,      &
+      L_waterxU   , L_wateryU   , L_forcexU  , L_forceyU,      &
+      L_umassdti  , L_fmU       , L_Tbu
+    logical(kind=log_kind), dimension(:,:,:), intent(in), contiguous, target :: &
+      L_iceUmask  , L_iceTmask
+
+    integer(c_int32_t), pointer :: tmask_i(:), umask_i(:)
+    character(len=*), parameter :: subname = '(dyn_evp_hip_run)'
+
+    if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
+         file=__FILE__, line=__LINE__)
+
+    ! logical(log_kind) is a 4-byte Fortran logical (Icepack kinds): hand its storage
+    ! to the C side, which tests "non-zero"
+    call c_f_pointer(c_loc(L_iceTmask), tmask_i, [size(L_iceTmask)])
+    call c_f_pointer(c_loc(L_iceUmask), umask_i, [size(L_iceUmask)])
+
+    call ice_timer_start(timer_evp1dcore)
+    call check(cice_evp_hip_run( &
+         L_stressp_1, L_stressp_2, L_stressp_3, L_stressp_4, L_stressm_1, L_stressm_2, L_stressm_3, &
+         L_stressm_4, L_stress12_1, L_stress12_2, L_stress12_3, L_stress12_4, L_strength, L_cdn_ocn, &
+         L_aiu, L_uocn, L_vocn, L_waterxU, L_wateryU, L_forcexU, L_forceyU, L_umassdti, L_fmU, &
+         L_strintxU, L_strintyU, L_Tbu, L_taubxU, L_taubyU, L_uvel, L_vvel, uvel_init, vvel_init, &
+         tmask_i, umask_i, int(ndte, c_int32_t)), subname, __FILE__, __LINE__)
+    call ice_timer_stop(timer_evp1dcore)
+
+  end subroutine dyn_evp_hip_run
+
+!-----------------------------------------------------------------------
+  subroutine dyn_evp_hip_finalize
+    character(len=*), parameter :: subname = '(dyn_evp_hip_finalize)'
+    if (initialised) call check(cice_evp_hip_finalize(), subname, __FILE__, __LINE__)
+    initialised = .false.
+  end subroutine dyn_evp_hip_finalize
+
+end module ice_dyn_evp_hip

@@ -73,11 +73,28 @@ build_variant () {
     #     evp() hands over every (otherwise private) subcycle input; the very
     #     next evp() call with evp_algorithm='standard_2d' gives the golden output.
     mkdir -p cap && cd cap
-    $FC $fflags -cpp -I.. -c "$HERE/ice_dyn_evp1d_capture.F90" -o ice_dyn_evp1d.o
-    $FC $fflags -cpp -I.. -c "$EVP" -o ice_dyn_evp.o
-    $FC $fflags -cpp -I.. -I. "$HERE/evp_ref_harness.F90" ice_dyn_evp1d.o ice_dyn_evp.o \
+    $FC $fflags -cpp -I.. -c "$HERE/evp_dumpio.F90" -o evp_dumpio.o
+    $FC $fflags -cpp -I.. -I. -c "$HERE/ice_dyn_evp1d_capture.F90" -o ice_dyn_evp1d.o
+    $FC $fflags -cpp -I.. -I. -c "$EVP" -o ice_dyn_evp.o
+    $FC $fflags -cpp -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp1d.o ice_dyn_evp.o \
         $(for o in $COMMON; do echo ../$o; done) -o "$OUT/evp_ref_harness_$variant"
     cd ..
+
+    # (2) drop-in demonstration: the reference's unmodified evp() driver linked with the
+    #     build-owned `ice_dyn_evp1d` that forwards to the HIP core (cice_amd/fortran),
+    #     i.e. Option B of INTEGRATION.md.  Needs cice_amd/libcice_evp_hip.so.
+    if [ "$variant" = strict ] && [ -f "$REPO/cice_amd/libcice_evp_hip.so" ]; then
+      mkdir -p hip && cd hip
+      $FC $fflags -cpp -I.. -c "$HERE/evp_dumpio.F90" -o evp_dumpio.o
+      $FC $fflags -cpp -I.. -I. -c "$REPO/cice_amd/fortran/ice_dyn_evp_hip.F90" -o ice_dyn_evp_hip.o
+      $FC $fflags -cpp -I.. -I. -c "$REPO/cice_amd/fortran/ice_dyn_evp1d_hip.F90" -o ice_dyn_evp1d.o
+      $FC $fflags -cpp -I.. -I. -c "$EVP" -o ice_dyn_evp.o
+      $FC $fflags -cpp -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp_hip.o ice_dyn_evp1d.o ice_dyn_evp.o \
+          $(for o in $COMMON; do echo ../$o; done) \
+          -L"$REPO/cice_amd" -lcice_evp_hip -Wl,-rpath,'$ORIGIN/../../cice_amd' -o "$OUT/evp_hip_dropin_harness"
+      cd ..
+      echo "built $OUT/evp_hip_dropin_harness"
+    fi
   )
   echo "built $OUT/evp_ref_harness_$variant"
 }

@@ -38,7 +38,7 @@ program evp_ref_harness
   use ice_calendar, only: dt, dt_dyn, ndtd
   use ice_dyn_shared
   use ice_dyn_evp, only: init_evp, evp
-  use ice_dyn_evp1d, only: capture_tag
+  use ice_dyn_evp1d, only: capture_tag, dyn_evp1d_init, dyn_evp1d_finalize
   use evp_dumpio
   use icepack_intfc, only: icepack_query_parameters
 #if defined (_OPENMP)
@@ -72,11 +72,12 @@ program evp_ref_harness
   logical            :: h_seabed    = .false.
   logical            :: dump_arrays = .true.      ! .false. = timing-only run (no array dumps)
   integer(int_kind)  :: ntiming     = 0           ! extra evp() calls, timed, after the dumps
+  logical            :: hipmode     = .false.     ! drop-in check: HIP core (via ice_dyn_evp1d) vs standard_2d
 
   namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
      h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
      h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, &
-     dump_arrays, ntiming
+     dump_arrays, ntiming, hipmode
 
   ! ---- locals ----------------------------------------------------------
   integer(int_kind) :: i, j, iblk, icall, k, nsub, nl, ios, nthreads
@@ -145,6 +146,7 @@ program evp_ref_harness
   call init_ice_timers
   call init_grid2
   call init_evp
+  call dyn_evp1d_init          ! no-op in the capture build; HIP core set-up in the drop-in build
 
   ! ---- fill the model state that evp() reads ----------------------------
   do iblk = 1, nblocks
@@ -249,6 +251,13 @@ program evp_ref_harness
   ! ---- evp calls ------------------------------------------------------------
   do icall = 1, ncalls
 
+     if (hipmode) then
+        ! prep-only pass (ndte=0): applies dyn_prep2's one-off state changes (new-ice
+        ! velocities, stresses zeroed off the ice) so that both cores start identically
+        ndte = 0
+        call evp(dt_dyn)
+        ndte = h_ndte
+     else
      ! (1) capture the subcycle inputs at the boundary (computes nothing)
      write(tag,'(a,i2.2)') 'in', icall
      capture_tag = tag
@@ -256,6 +265,7 @@ program evp_ref_harness
      if (.not. dump_arrays) call dump_end
      call evp(dt_dyn)
      evp_algorithm = 'standard_2d'
+     endif
 
      ! post-prep state = the captured inputs
      s_u = uvel; s_v = vvel
@@ -271,6 +281,39 @@ program evp_ref_harness
         stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
         stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
         ndte = nsub                 ! loop count only; EVP scalars were fixed by init_evp
+        if (hipmode) then
+           ! the reference's unmodified evp() driving the HIP core through the
+           ! existing dyn_evp1d_run boundary (ice_dyn_evp.F90:846-856)
+           evp_algorithm = 'shared_mem_1d'
+           call evp(dt_dyn)
+           evp_algorithm = 'standard_2d'
+           write(tag,'(a,i2.2,a,i4.4)') 'h', icall, 'n', nsub
+           call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)
+           call dump_r8_3d(trim(tag)//'_vvel', vvel, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_1', stressp_1, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_2', stressp_2, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_3', stressp_3, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressp_4', stressp_4, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_1', stressm_1, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_2', stressm_2, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_3', stressm_3, nblocks)
+           call dump_r8_3d(trim(tag)//'_stressm_4', stressm_4, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_1', stress12_1, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_2', stress12_2, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_3', stress12_3, nblocks)
+           call dump_r8_3d(trim(tag)//'_stress12_4', stress12_4, nblocks)
+           call dump_r8_3d(trim(tag)//'_strintxU', strintxU, nblocks)
+           call dump_r8_3d(trim(tag)//'_strintyU', strintyU, nblocks)
+           call dump_r8_3d(trim(tag)//'_taubxU', taubxU, nblocks)
+           call dump_r8_3d(trim(tag)//'_taubyU', taubyU, nblocks)
+           call dump_r8_3d(trim(tag)//'_divu', divu, nblocks)
+           call dump_r8_3d(trim(tag)//'_shear', shear, nblocks)
+           call dump_r8_3d(trim(tag)//'_strocnxU', strocnxU, nblocks)
+           uvel = s_u; vvel = s_v
+           stressp_1 = s_sp1; stressp_2 = s_sp2; stressp_3 = s_sp3; stressp_4 = s_sp4
+           stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
+           stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
+        endif
         call evp(dt_dyn)
         ndte = h_ndte
         if (dump_arrays) then
@@ -307,6 +350,7 @@ program evp_ref_harness
      enddo
   enddo
   call dump_end
+  call dyn_evp1d_finalize
 
   ! ---- timing of the reference subcycle loop (its own timer_evp) -----------
   if (ntiming > 0) then

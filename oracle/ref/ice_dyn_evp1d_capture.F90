@@ -12,76 +12,6 @@
 ! then re-runs evp() with evp_algorithm='standard_2d' to obtain the golden
 ! outputs for exactly these inputs (SURVEY.md Appendix A.3, route (b)).
 !=======================================================================
-module evp_dumpio
-
-  use ice_kinds_mod
-  implicit none
-  public
-
-  integer, parameter :: dump_unit = 77
-  logical            :: dump_open = .false.
-
-contains
-
-  subroutine dump_begin(fname)
-    character(len=*), intent(in) :: fname
-    open(unit=dump_unit, file=fname, form='unformatted', access='stream', status='replace')
-    dump_open = .true.
-  end subroutine dump_begin
-
-  subroutine dump_end
-    if (dump_open) close(dump_unit)
-    dump_open = .false.
-  end subroutine dump_end
-
-  ! record = name(32 chars) | type code (1=r8, 2=i4) | d1 d2 d3 (int32) | payload
-  subroutine dump_hdr(name, tcode, d1, d2, d3)
-    character(len=*), intent(in) :: name
-    integer(int_kind), intent(in) :: tcode, d1, d2, d3
-    character(len=32) :: nm
-    nm = name
-    write(dump_unit) nm, tcode, d1, d2, d3
-  end subroutine dump_hdr
-
-  subroutine dump_r8_3d(name, a, nb)
-    character(len=*), intent(in) :: name
-    real(dbl_kind), dimension(:,:,:), intent(in) :: a
-    integer(int_kind), intent(in) :: nb          ! number of real blocks (<= size(a,3))
-    call dump_hdr(name, 1, size(a,1), size(a,2), nb)
-    write(dump_unit) a(:,:,1:nb)
-  end subroutine dump_r8_3d
-
-  subroutine dump_l_3d(name, a, nb)
-    character(len=*), intent(in) :: name
-    logical(log_kind), dimension(:,:,:), intent(in) :: a
-    integer(int_kind), intent(in) :: nb
-    integer(int_kind), allocatable :: ia(:,:,:)
-    allocate(ia(size(a,1),size(a,2),nb))
-    ia = 0
-    where (a(:,:,1:nb)) ia = 1
-    call dump_hdr(name, 2, size(a,1), size(a,2), nb)
-    write(dump_unit) ia
-    deallocate(ia)
-  end subroutine dump_l_3d
-
-  subroutine dump_i4_1d(name, a)
-    character(len=*), intent(in) :: name
-    integer(int_kind), dimension(:), intent(in) :: a
-    call dump_hdr(name, 2, size(a), 1, 1)
-    write(dump_unit) a
-  end subroutine dump_i4_1d
-
-  subroutine dump_r8_1d(name, a)
-    character(len=*), intent(in) :: name
-    real(dbl_kind), dimension(:), intent(in) :: a
-    call dump_hdr(name, 1, size(a), 1, 1)
-    write(dump_unit) a
-  end subroutine dump_r8_1d
-
-end module evp_dumpio
-
-!=======================================================================
-
 module ice_dyn_evp1d
 
   use ice_kinds_mod

@@ -22,6 +22,9 @@ REF_DIR = HERE.parent / "_ref"
 
 
 def harness_path(variant: str = "strict") -> Path:
+    if variant == "hip_dropin":
+        # the reference's unmodified evp() driver + cice_amd/fortran shim + libcice_evp_hip.so
+        return REF_DIR / "evp_hip_dropin_harness"
     return REF_DIR / f"evp_ref_harness_{variant}"
 
 

@@ -1,0 +1,57 @@
+"""GPU (-m gpu): the drop-in itself.  oracle/_ref/evp_hip_dropin_harness is the
+reference's own, unmodified evp() driver (compiled in place from the reference tree)
+linked with cice_amd/fortran/ice_dyn_evp1d_hip.F90 -- the build-owned module that
+takes the place of the reference's alternative EVP core at ice_dyn_evp.F90:846-856 --
+and libcice_evp_hip.so.  In one process it runs, from identical state, the HIP core
+(through Fortran -> ISO_C_BINDING -> C ABI -> HIP) and the reference's standard_2d
+path, and dumps both; they must be bit-identical, ghost cells included.
+
+The binary is prebuilt by oracle/ref/build_ref.sh (needs the reference tree) and
+travels to the GPU box; the test skips when it is absent."""
+import numpy as np
+import pytest
+
+import run_ref
+from cice_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = (["uvel", "vvel", "strintxU", "strintyU", "taubxU", "taubyU"] +
+          [f"stress{k}_{c}" for k in ("p", "m", "12") for c in range(1, 5)])
+# outputs of the untouched remainder of evp() (deformations, dyn_finish) fed by the HIP velocities
+DOWNSTREAM = ["divu", "shear", "strocnxU"]
+
+CASES = [
+    # nx, ny, bx, by, ew, kwargs
+    (40, 36, 20, 18, "cyclic", dict(grid_kind="rect", icecase="full")),
+    (60, 44, 20, 15, "cyclic", dict(grid_kind="popfile", icecase="patchy")),
+    (100, 116, 50, 29, "cyclic", dict(grid_kind="popfile", icecase="caps", h_seabed=True)),
+    (64, 48, 64, 48, "closed", dict(grid_kind="popfile", icecase="full", h_revised=True)),
+]
+
+
+@pytest.mark.parametrize("nx,ny,bx,by,ew,kw", CASES)
+def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw):
+    if not run_ref.have_ref("hip_dropin"):
+        pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
+    kw = dict(kw)
+    grid_files = None
+    if kw["grid_kind"] != "rect":
+        g = synth.make_grid(nx, ny, dx0=1.1e5, ns="closed")
+        run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+        run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
+        grid_files = (tmp_path / "grid.bin", tmp_path / "kmt.bin")
+    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns="closed", variant="hip_dropin", h_ndte=120,
+                                 ncalls=2, nsub_list=[1, 120], hipmode=True, grid_files=grid_files, **kw)
+    checked = 0
+    for icall in (1, 2):
+        for nsub in (1, 120):
+            for f in FIELDS + DOWNSTREAM:
+                hip = d[f"h{icall:02d}n{nsub:04d}_{f}"]
+                ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
+                assert np.array_equal(hip, ref), (
+                    f"call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
+                    f"max|d|={np.abs(hip - ref).max():.3e}")
+                checked += 1
+    assert np.abs(d["o02n0120_uvel"]).max() > 1e-3
+    assert checked == 2 * 2 * (len(FIELDS) + len(DOWNSTREAM))
