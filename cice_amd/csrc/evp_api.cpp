@@ -433,6 +433,25 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     S.d.iglob0 = S.iglob0.data(); S.d.jglob0 = S.jglob0.data();
 
     if (!build_halo_plan(*dims, S.plan)) return fail(-3, "halo plan: %s", S.plan.error.c_str());
+    if (env("CICE_EVP_HIP_SELF_EXCHANGE") && std::atoi(env("CICE_EVP_HIP_SELF_EXCHANGE")) && dims->nranks == 1) {
+        // test hook: route the on-device ghost copies through pack -> ncclSend/ncclRecv (to
+        // self) -> unpack, so that the remote-halo code path runs on a single GPU
+        HaloPeer self;
+        self.rank = dims->rank;
+        std::vector<int32_t> kd, ks;
+        std::vector<int8_t> kg;
+        for (size_t k = 0; k < S.plan.local_dst.size(); ++k) {
+            if (S.plan.local_src[k] < 0) {
+                kd.push_back(S.plan.local_dst[k]); ks.push_back(-1); kg.push_back(1);
+                continue;
+            }
+            self.send_src.push_back(S.plan.local_src[k]);
+            self.recv_dst.push_back(S.plan.local_dst[k]);
+            self.recv_sign.push_back(S.plan.local_sign[k]);
+        }
+        S.plan.local_dst = kd; S.plan.local_src = ks; S.plan.local_sign = kg;
+        S.plan.peers.push_back(self);
+    }
     // the global block table is only needed while planning
     S.d.gi0 = S.d.gj0 = S.d.gnx = S.d.gny = S.d.gowner = S.d.glocal = nullptr;
 

@@ -168,15 +168,31 @@ def test_resident_entry_points_equal_run():
         core.finalize()
 
 
-def test_single_rank_rccl_self_exchange():
-    """E-W cyclic single block: the RCCL communicator initialises on one rank and a
-    run with it attached still matches (no peers -> no exchange, API smoke)."""
-    c = GoldenCase("pop_cyc_1blk_patchy")
+@pytest.mark.parametrize("name", ["pop_cyc_1blk_patchy", "pop_cyc_3x2pad_caps"])
+def test_single_rank_rccl_self_exchange(name, monkeypatch):
+    """The remote-halo path (pack kernel -> ncclGroup{ncclSend, ncclRecv} -> unpack kernel)
+    on one GPU: CICE_EVP_HIP_SELF_EXCHANGE routes every on-device ghost copy through RCCL
+    point-to-point to the rank itself.  Same bits as the fixtures."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     try:
         core.comm_init(core.comm_unique_id())
         dyn, tm, um = c.inputs(1)
         out = core.run(dyn, tm, um, ndte=120)
-        assert_bitwise(out, c.expected(1, 120), "with RCCL communicator")
+        assert_bitwise(out, c.expected(1, 120), "halo through RCCL self send/recv")
+        assert core.timings()["launches_per_subcycle"] == 3.0
+    finally:
+        core.finalize()
+
+
+def test_remote_halo_without_communicator_fails_loudly(monkeypatch):
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    c = GoldenCase("pop_cyc_1blk_patchy")
+    core = hip_from_case(c, strict=True)
+    try:
+        dyn, tm, um = c.inputs(1)
+        with pytest.raises(evp.EvpHipError):
+            core.run(dyn, tm, um, ndte=2)
     finally:
         core.finalize()
