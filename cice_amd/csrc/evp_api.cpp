@@ -103,6 +103,10 @@ struct State {
     // remote halo
     ncclComm_t comm = nullptr;
     bool have_comm = false;
+    int32_t *h_seam_a = nullptr, *h_seam_b = nullptr, *h_seam_pole = nullptr, *h_late_dst = nullptr,
+            *h_late_src = nullptr;
+    int8_t *h_late_sign = nullptr;
+    int n_seam = 0, n_pole = 0, n_late = 0;
     int32_t *h_send_src = nullptr, *h_recv_dst = nullptr;
     int8_t *h_recv_sign = nullptr;
     double *sendbuf = nullptr, *recvbuf = nullptr;
@@ -149,6 +153,7 @@ void free_all()
     F(S.h_local_dst);
     F(S.h_local_src);
     F(S.h_local_sign);
+    F(S.h_seam_a); F(S.h_seam_b); F(S.h_seam_pole); F(S.h_late_dst); F(S.h_late_src); F(S.h_late_sign);
     F(S.h_send_src);
     F(S.h_recv_dst);
     F(S.h_recv_sign);
@@ -214,6 +219,9 @@ int derive_metrics(const double *HTE, const double *HTN, const double *dxT, cons
     bool same = true;
     for (size_t k = 0; k < S.n && same; ++k) same = (tarea[k] == dxT[k] * dyT[k]);
     if (same) S.flags |= EVP_F_METRICS;
+    // on the tripole ghost row dxhy/dyhx are mirrored interior values (halo update with sign,
+    // ice_dyn_shared.F90:412-417), not a local difference: keep them as arrays there
+    if (S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE) S.flags |= EVP_F_DXHY_ARRAY;
     const int order[7] = {4, 5, 6, 7, 2, 3, 8};   // stat slots of cxp cyp cxm cym dxhy dyhx Dmin
     for (int k = 0; k < 7; ++k)
         if (h2d(S.stat[order[k]], m[k].data())) return -1;
@@ -232,6 +240,21 @@ int upload_lists()
         HIPC(hipMemcpy(S.h_local_dst, P.local_dst.data(), S.n_local * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPC(hipMemcpy(S.h_local_src, P.local_src.data(), S.n_local * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPC(hipMemcpy(S.h_local_sign, P.local_sign.data(), S.n_local, hipMemcpyHostToDevice));
+    }
+    auto up32 = [&](const std::vector<int32_t> &v, int32_t *&dptr) -> int {
+        if (v.empty()) return 0;
+        HIPC(hipMalloc((void **)&dptr, v.size() * sizeof(int32_t)));
+        HIPC(hipMemcpy(dptr, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        return 0;
+    };
+    S.n_seam = (int)P.seam_a.size();
+    S.n_pole = (int)P.seam_pole.size();
+    S.n_late = (int)P.late_dst.size();
+    if (up32(P.seam_a, S.h_seam_a) || up32(P.seam_b, S.h_seam_b) || up32(P.seam_pole, S.h_seam_pole) ||
+        up32(P.late_dst, S.h_late_dst) || up32(P.late_src, S.h_late_src)) return -1;
+    if (S.n_late) {
+        HIPC(hipMalloc((void **)&S.h_late_sign, S.n_late));
+        HIPC(hipMemcpy(S.h_late_sign, P.late_sign.data(), S.n_late, hipMemcpyHostToDevice));
     }
     std::vector<int32_t> ss, rd;
     std::vector<int8_t> rs;
@@ -350,6 +373,10 @@ int halo_uv(int b)
     if (!pushed)
         evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src,
                               (const signed char *)S.h_local_sign, S.n_local, S.stream);
+    // tripole seam of the top physical row (all on this rank, enforced by the plan); the remote
+    // exchange below never involves seam-row cells
+    evp_launch_halo_seam(S.u[b], S.v[b], S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
+                         S.h_late_dst, S.h_late_src, (const signed char *)S.h_late_sign, S.n_late, S.stream);
     if (!S.plan.peers.empty()) {
         if (!S.have_comm) return fail(-2, "remote halo needed but cice_evp_hip_comm_init was not called");
         evp_launch_halo_pack(S.u[b], S.v[b], S.h_send_src, S.sendbuf, S.n_send, S.stream);
@@ -719,7 +746,8 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
         marks_ms = ms;
     const double v[7] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
-                             (S.plan.peers.empty() ? 0.0 : 2.0), (double)S.tyb, marks_ms};
+                             (S.plan.peers.empty() ? 0.0 : 2.0) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
+                         (double)S.tyb, marks_ms};
     for (int k = 0; k < n && k < 7; ++k) out[k] = v[k];
     return 0;
 }
@@ -828,6 +856,31 @@ int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_
         if (recv_dst) std::copy(p.recv_dst.begin(), p.recv_dst.end(), recv_dst + ro);
         so += p.send_src.size();
         ro += p.recv_dst.size();
+    }
+    return 0;
+}
+
+// Tripole part of the plan built by the last init / plan_build (tests): counts3 =
+// {pairs, poles, late copies}; lists may be NULL.
+int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,
+                           int32_t *late_dst, int32_t *late_src, int32_t *late_sign)
+{
+    const HaloPlan &P = S.plan;
+    if (counts3) {
+        counts3[0] = (int32_t)P.seam_a.size();
+        counts3[1] = (int32_t)P.seam_pole.size();
+        counts3[2] = (int32_t)P.late_dst.size();
+    }
+    for (size_t k = 0; k < P.seam_a.size(); ++k) {
+        if (seam_a) seam_a[k] = P.seam_a[k];
+        if (seam_b) seam_b[k] = P.seam_b[k];
+    }
+    for (size_t k = 0; k < P.seam_pole.size(); ++k)
+        if (seam_pole) seam_pole[k] = P.seam_pole[k];
+    for (size_t k = 0; k < P.late_dst.size(); ++k) {
+        if (late_dst) late_dst[k] = P.late_dst[k];
+        if (late_src) late_src[k] = P.late_src[k];
+        if (late_sign) late_sign[k] = P.late_sign[k];
     }
     return 0;
 }

@@ -50,7 +50,8 @@ enum : unsigned {
     EVP_F_WATER_IS_OCN = 2u,// waterxU==uocnU and wateryU==vocnU bit for bit on every active U-cell
     EVP_F_TBU_ZERO = 4u,    // TbU == 0 on every active U-cell (seabed_stress off)
     EVP_F_VRELFAC = 8u,     // use the pre-multiplied drag factor
-    EVP_F_PUSH = 16u,       // edge U-cells also write their ghost images (halo fused into the kernel)
+    EVP_F_PUSH = 16u,
+    EVP_F_DXHY_ARRAY = 32u, // with EVP_F_METRICS: dxhy, dyhx still come from their arrays (tripole ghost row)       // edge U-cells also write their ghost images (halo fused into the kernel)
 };
 
 void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double *out, size_t n,
@@ -59,6 +60,9 @@ void evp_launch_subcycle(const EvpArgs &A, int max_ni, int max_nj, int nblocks, 
                          bool strict, int cap, hipStream_t st);
 void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
                            const signed char *sign, int n, hipStream_t st);
+void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, int npair, const int *pole,
+                          int npole, const int *ldst, const int *lsrc, const signed char *lsign,
+                          int nlate, hipStream_t st);
 void evp_launch_halo_pack(const double *u, const double *v, const int *src, double *buf, int n,
                           hipStream_t st);
 void evp_launch_halo_unpack(double *u, double *v, const int *dst, const signed char *sign,

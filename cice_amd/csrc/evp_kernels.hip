@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
         if (flags & EVP_F_METRICS) {
             hte = A.HTE[c]; hte_im = A.HTE[c - 1];
             htn = A.HTN[c]; htn_jm = A.HTN[c - nx];
+            if (flags & EVP_F_DXHY_ARRAY) { a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c]; }
         } else {
             a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c];
             a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
@@ -184,7 +185,11 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
 #pragma unroll
     for (int k = 0; k < 8; ++k) str[k] = 0.0;
     if (actT) {
-        if (flags & EVP_F_METRICS) MM::metrics(hte, hte_im, htn, htn_jm, A.deltaminEVP, a);
+        if (flags & EVP_F_METRICS) {
+            const double dxhy_a = a.dxhy, dyhx_a = a.dyhx;
+            MM::metrics(hte, hte_im, htn, htn_jm, A.deltaminEVP, a);
+            if (flags & EVP_F_DXHY_ARRAY) { a.dxhy = dxhy_a; a.dyhx = dyhx_a; }
+        }
         MM::template stress<CAP>(A.p, a, s, str);
         // the tile that holds this T-cell off its north/east fringe owns it; the
         // ghost row/column ihi+1 / jhi+1 has no further tile and is owned here
@@ -269,6 +274,38 @@ __global__ void halo_local_uv(double *__restrict__ u, double *__restrict__ v,
     v[d] = vv;
 }
 
+// Tripole seam of the velocity (NE-corner, vector): one workgroup.
+//   pairs:  (x_a, x_b) <- (xavg, -xavg), xavg = 0.5*(x_a + isign*x_b), isign = -1
+//           (ice_boundary.F90:1630-1649)
+//   poles:  x <- -x  (the pole points mirror onto themselves, copy-out :1689-1722)
+//   late :  ghost copies whose source is a seam-row cell, repeated with the new values
+__global__ void halo_seam_uv(double *__restrict__ u, double *__restrict__ v,
+                             const int *__restrict__ pa, const int *__restrict__ pb, int npair,
+                             const int *__restrict__ pole, int npole,
+                             const int *__restrict__ ldst, const int *__restrict__ lsrc,
+                             const signed char *__restrict__ lsign, int nlate)
+{
+    const double isign = -1.0;
+    for (int k = threadIdx.x; k < npair; k += blockDim.x) {
+        const int a = pa[k], b = pb[k];
+        const double xu = 0.5 * (u[a] + isign * u[b]);
+        const double xv = 0.5 * (v[a] + isign * v[b]);
+        u[a] = xu; u[b] = isign * xu;
+        v[a] = xv; v[b] = isign * xv;
+    }
+    for (int k = threadIdx.x; k < npole; k += blockDim.x) {
+        const int a = pole[k];
+        u[a] = isign * u[a];
+        v[a] = isign * v[a];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nlate; k += blockDim.x) {
+        const double sg = (double)lsign[k];
+        u[ldst[k]] = sg * u[lsrc[k]];
+        v[ldst[k]] = sg * v[lsrc[k]];
+    }
+}
+
 // pack / unpack of remote halo cells (ice_boundary.F90:1260-1284, 1419-1449)
 __global__ void halo_pack_uv(const double *__restrict__ u, const double *__restrict__ v,
                              const int *__restrict__ src, double *__restrict__ buf, int n)
@@ -349,6 +386,15 @@ void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(halo_local_uv, dim3((n + 255) / 256), dim3(256), 0, st, u, v, dst, src, sign, n);
+}
+
+void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, int npair, const int *pole,
+                          int npole, const int *ldst, const int *lsrc, const signed char *lsign,
+                          int nlate, hipStream_t st)
+{
+    if (npair <= 0 && npole <= 0 && nlate <= 0) return;
+    hipLaunchKernelGGL(halo_seam_uv, dim3(1), dim3(1024), 0, st, u, v, pa, pb, npair, pole, npole, ldst,
+                       lsrc, lsign, nlate);
 }
 
 void evp_launch_halo_pack(const double *u, const double *v, const int *src, double *buf, int n,

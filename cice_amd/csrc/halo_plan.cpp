@@ -39,7 +39,16 @@ Src resolve(const cice_evp_hip_dims &d, int ig, int jg)
         else s.outside = true;
     } else if (jg > NY) {
         if (d.ns_boundary_type == CICE_EVP_BND_CYCLIC) jg -= NY;
-        else s.outside = true;   // tripole handled by the caller
+        else if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE && !s.outside) {
+            // u-fold mirror of an NE-corner vector field (ice_blocks.F90:423-424;
+            // copy-out offsets (1,1) and isign = -1, ice_boundary.F90:1555-1556,1632-1633):
+            //   ghost(ig, NY+k) <- - a(NX-ig, NY-k)
+            const int k = jg - NY;
+            ig = NX - ig;
+            if (ig < 1) ig += NX;
+            jg = NY - k;
+            s.sign = -1;
+        } else s.outside = true;
     }
     s.ig = ig;
     s.jg = jg;
@@ -58,8 +67,9 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
         plan.error = "nghost must be 1 (ice_blocks.F90:47)";
         return false;
     }
-    if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE) {
-        plan.error = "tripole north boundary not supported yet";
+    const bool tripole = d.ns_boundary_type == CICE_EVP_BND_TRIPOLE;
+    if (tripole && (d.nx_global % 2 != 0 || d.ew_boundary_type != CICE_EVP_BND_CYCLIC)) {
+        plan.error = "tripole needs an even nx_global and a cyclic east-west boundary";
         return false;
     }
     const int ng = d.nghost;
@@ -136,11 +146,23 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                     const HaloBlock &S = T.blk[ks];
                     const int32_t src = (int32_t)((size_t)S.local * plane +
                                                   (size_t)(ng + (s.jg - S.gj0)) * nx + (ng + (s.ig - S.gi0)));
+                    const bool src_on_seam = tripole && s.jg == d.ny_global;
+                    if (src_on_seam && S.owner != R && (R == me || S.owner == me)) {
+                        plan.error = "tripole: a ghost cell mirrors a seam-row cell of another rank "
+                                     "(two-phase exchange not implemented); use a rank layout that keeps "
+                                     "each seam row and its east-west neighbours on one rank (px = 1)";
+                        return false;
+                    }
                     if (R == me) {
                         if (S.owner == me) {
                             plan.local_dst.push_back(dst);
                             plan.local_src.push_back(src);
                             plan.local_sign.push_back((int8_t)s.sign);
+                            if (src_on_seam) {
+                                plan.late_dst.push_back(dst);
+                                plan.late_src.push_back(src);
+                                plan.late_sign.push_back((int8_t)s.sign);
+                            }
                         } else {
                             HaloPeer &p = peers[S.owner];
                             p.rank = S.owner;
@@ -156,5 +178,35 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
         }
     }
     for (auto &kv : peers) plan.peers.push_back(std::move(kv.second));
+
+    if (tripole) {
+        const int NX = d.nx_global, NY = d.ny_global;
+        auto offset_of = [&](int ig, int jg, int &owner) -> int32_t {
+            const int k = T.find(ig, jg);
+            if (k < 0 || T.blk[k].owner < 0) { owner = -1; return -1; }
+            const HaloBlock &B = T.blk[k];
+            owner = B.owner;
+            return (int32_t)((size_t)B.local * plane + (size_t)(ng + (jg - B.gj0)) * nx + (ng + (ig - B.gi0)));
+        };
+        for (int ig = 1; ig <= NX; ++ig) {
+            int oa = -1, ob = -1;
+            const int32_t a = offset_of(ig, NY, oa);
+            if (ig == NX / 2 || ig == NX) {
+                if (oa == me) plan.seam_pole.push_back(a);
+                continue;
+            }
+            if (ig > NX / 2 - 1) continue;      // pairs are enumerated from their low index
+            const int32_t b = offset_of(NX - ig, NY, ob);
+            if (oa != me && ob != me) continue;
+            if (oa != ob) {
+                if (oa < 0 || ob < 0) continue;  // eliminated land block on one side: nothing to average
+                plan.error = "tripole: the two halves of a seam pair live on different ranks "
+                             "(not implemented); use a rank layout with px = 1";
+                return false;
+            }
+            plan.seam_a.push_back(a);
+            plan.seam_b.push_back(b);
+        }
+    }
     return true;
 }

@@ -36,9 +36,16 @@ struct HaloPlan {
     std::vector<int32_t> local_dst, local_src;   // src = -1: fill with 0
     std::vector<int8_t> local_sign;
     std::vector<HaloPeer> peers;                  // ascending rank
-    // tripole u-fold seam of NE-corner vector fields: pairs averaged with sign flip
-    // (ice_boundary.F90:1630-1649); offsets into the local array, both local.
-    std::vector<int32_t> seam_a, seam_b;
+    // Tripole u-fold seam of NE-corner vector fields (ice_boundary.F90:1630-1649,
+    // 1689-1722).  The top physical row lies on the fold: U(i,NY) and U(NX-i,NY) are one
+    // point, so after every update the pair is replaced by (xavg, -xavg),
+    // xavg = 0.5*(x_i - x_{NX-i}), i = 1..NX/2-1; the two pole points i = NX/2, NX mirror
+    // onto themselves and change sign.  Offsets into the local array (both cells of a
+    // pair must live on this rank).  `late_*`: ghost copies whose source is a seam-row
+    // cell; they are repeated after the seam step so that they carry the averaged value.
+    std::vector<int32_t> seam_a, seam_b, seam_pole;
+    std::vector<int32_t> late_dst, late_src;
+    std::vector<int8_t> late_sign;
     std::string error;
 };
 

@@ -39,7 +39,7 @@ EXPORTS = [
     "cice_evp_hip_set_metrics", "cice_evp_hip_run", "cice_evp_hip_finalize",
     "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
-    "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark",
+    "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
 ]
 
 _i32p = C.POINTER(C.c_int32)
@@ -240,5 +240,14 @@ def halo_plan(dims: Dims) -> dict:
     ss = np.zeros(max(ns, 1), dtype=np.int32)
     rd = np.zeros(max(nr, 1), dtype=np.int32)
     lib.cice_evp_hip_halo_plan(_ip(cnt), _ip(ld), _ip(ls), _ip(lg), _ip(pr), _ip(pns), _ip(pnr), _ip(ss), _ip(rd))
+    c3 = np.zeros(3, dtype=np.int32)
+    lib.cice_evp_hip_seam_plan(_ip(c3), None, None, None, None, None, None)
+    npair, npole, nlate = [int(v) for v in c3]
+    sa, sb = [np.zeros(max(npair, 1), dtype=np.int32) for _ in range(2)]
+    sp = np.zeros(max(npole, 1), dtype=np.int32)
+    td, ts, tg = [np.zeros(max(nlate, 1), dtype=np.int32) for _ in range(3)]
+    lib.cice_evp_hip_seam_plan(_ip(c3), _ip(sa), _ip(sb), _ip(sp), _ip(td), _ip(ts), _ip(tg))
     return dict(local_dst=ld[:nl], local_src=ls[:nl], local_sign=lg[:nl], peer_rank=pr[:npeer],
-                peer_nsend=pns[:npeer], peer_nrecv=pnr[:npeer], send_src=ss[:ns], recv_dst=rd[:nr])
+                peer_nsend=pns[:npeer], peer_nrecv=pnr[:npeer], send_src=ss[:ns], recv_dst=rd[:nr],
+                seam_a=sa[:npair], seam_b=sb[:npair], seam_pole=sp[:npole],
+                late_dst=td[:nlate], late_src=ts[:nlate], late_sign=tg[:nlate])

@@ -76,6 +76,13 @@ module ice_dyn_evp_hip
        integer(c_int32_t), value :: ndte
      end function cice_evp_hip_run
 
+     integer(c_int) function cice_evp_hip_set_metrics(cxp, cyp, cxm, cym, dxhy, dyhx, DminTarea) &
+          bind(C, name='cice_evp_hip_set_metrics')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: cxp, cyp, cxm, cym, DminTarea          ! c_null_ptr = keep derived
+       real(c_double), dimension(*), intent(in) :: dxhy, dyhx
+     end function cice_evp_hip_set_metrics
+
      integer(c_int) function cice_evp_hip_finalize() bind(C, name='cice_evp_hip_finalize')
        import :: c_int
      end function cice_evp_hip_finalize
@@ -132,7 +139,7 @@ contains
     use ice_domain_size, only: max_blocks, nx_global, ny_global
     use ice_grid, only: HTE, HTN, dxT, dyT, uarear, tarea
     use ice_dyn_shared, only: ndte, arlx1i, denom1, brlx, revp, e_factor, epp2i, capping, &
-        Ktens, deltaminEVP, u0, cosw, sinw
+        Ktens, deltaminEVP, u0, cosw, sinw, dxhy, dyhx
     use ice_fileunits, only: nu_diag
     use icepack_intfc, only: icepack_query_parameters, icepack_warnings_flush, &
         icepack_warnings_aborted
@@ -187,6 +194,12 @@ contains
     p%deltaminEVP = deltaminEVP; p%u0 = u0; p%cosw = cosw; p%sinw = sinw; p%rhow = rhow
 
     call check(cice_evp_hip_init(d, p, HTE, HTN, dxT, dyT, uarear, tarea), subname, __FILE__, __LINE__)
+    if (trim(ns_boundary_type) == 'tripole') then
+       ! the north ghost row of dxhy/dyhx is a mirrored interior value (halo update with
+       ! sign, ice_dyn_shared.F90:412-417): hand over CICE's own arrays
+       call check(cice_evp_hip_set_metrics(c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, &
+            dxhy, dyhx, c_null_ptr), subname, __FILE__, __LINE__)
+    endif
 
     if (nprocs > 1) then
        ! RCCL bootstrap: the master's ncclUniqueId travels over CICE's own broadcast

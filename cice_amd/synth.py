@@ -44,6 +44,11 @@ def make_grid(nx: int, ny: int, dx0: float = 1.1e5, dy0: float | None = None, ns
         kmt[-2:, :] = 0          # cf. rectgrid, ice_grid.F90:2752-2755
     else:
         kmt[:2, :] = 0           # tripole: closed in the south only
+        # the two northern poles of a tripole grid sit on land (U points i = nx/2 and i = nx of
+        # the seam row): mask the T-cells around them, as on real tx1-type grids
+        for ic in (nx // 2, nx):
+            for di in (-1, 0, 1, 2):
+                kmt[-2:, (ic - 1 + di) % nx] = 0
     if continents and nx >= 20 and ny >= 20:
         kmt[int(0.30 * ny):int(0.55 * ny), int(0.10 * nx):int(0.30 * nx)] = 0
         kmt[int(0.60 * ny):int(0.80 * ny), int(0.55 * nx):int(0.80 * nx)] = 0

@@ -1,2 +1,2 @@
 cd /root/repo; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -8
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|differ|Error|^tests|def test" | tail -30

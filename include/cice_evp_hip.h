@@ -91,7 +91,10 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
                       const double *uarear, const double *tarea);
 
 /* Optional: overwrite the derived metric terms with the caller's own arrays
- * (ice_dyn_shared module arrays cxp,cyp,cxm,cym,dxhy,dyhx,DminTarea).         */
+ * (ice_dyn_shared module arrays cxp,cyp,cxm,cym,dxhy,dyhx,DminTarea); NULL = keep.
+ * On tripole grids pass at least dxhy,dyhx: their north ghost row is a mirrored
+ * interior value (halo update with sign, ice_dyn_shared.F90:412-417) which the library
+ * can only reproduce by local differencing when the grid is symmetric about the seam. */
 int cice_evp_hip_set_metrics(const double *cxp, const double *cyp, const double *cxm,
                              const double *cym, const double *dxhy, const double *dyhx,
                              const double *DminTarea);
@@ -158,6 +161,13 @@ int cice_evp_hip_plan_build(const cice_evp_hip_dims *dims);
 int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_src,
                            int32_t *local_sign, int32_t *peer_rank, int32_t *peer_nsend,
                            int32_t *peer_nrecv, int32_t *send_src, int32_t *recv_dst);
+
+/* Tripole (u-fold) part of the plan: counts3 = {seam pairs, pole cells, late copies}.
+ * After every velocity update the pair (a,b) of the seam row becomes (xavg, -xavg),
+ * pole cells change sign, then the late copies are (re)applied
+ * (ice_boundary.F90:1630-1649, 1689-1722).  Lists may be NULL.                  */
+int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,
+                           int32_t *late_dst, int32_t *late_src, int32_t *late_sign);
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,12 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
             top[i - 1] = xavg;
             top[idst - 1] = isign * xavg;
         }
+        /* copy-out: array(i,NY) = isign*buf(mirror(i),NY), mirror(i) = NX-i (0 -> NX).  An
+           averaged pair is returned as (xavg, isign*xavg); the two pole points i = NX/2 and
+           i = NX mirror onto themselves and simply change sign.  Ghost columns of the seam
+           row receive the same final values. */
+        top[NX / 2 - 1] = isign * top[NX / 2 - 1];
+        top[NX - 1] = isign * top[NX - 1];
     }
 
     for (int b = 0; b < d->nblocks; ++b) {
@@ -139,7 +145,7 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
                 int ig = d->iglob0[b] + (i - ilo);
                 int jg = d->jglob0[b] + (j - jlo);
                 if (interior) {
-                    if (tripole && field_loc == 1 && jg == NY) /* averaged seam row written back */
+                    if (tripole && field_loc == 1 && jg == NY) /* seam row written back */
                         ab[IX(i, j)] = g[(size_t)(NY - 1) * NX + (ig - 1)];
                     continue;
                 }
@@ -170,6 +176,38 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
                 }
                 ab[IX(i, j)] = sgn * g[(size_t)(jg - 1) * NX + (ig - 1)];
             }
+    }
+    free(g);
+}
+
+/* ---------------------------------------------------------------------
+ * Tripole symmetrisation of the stresses after the subcycle loop
+ * (dynamics/ice_dyn_evp.F90:1321-1389 -> ice_HaloUpdate_stress,
+ * infrastructure/comm/serial/ice_boundary.F90:7440-7825): the north ghost row of
+ * array1 takes the mirrored top physical row of array2 (cell-centre, scalar, u-fold:
+ * ghost(i, NY+1) <- a2(NX-i+1, NY)).  OUTSIDE the replaced region (evp() runs it on
+ * the host arrays after the core returns); restated so that whole-evp() fixtures can
+ * be compared on every cell.
+ * ------------------------------------------------------------------- */
+void evp_oracle_tripole_stress(const evp_oracle_domain *d, double *a1, const double *a2)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const int NX = d->nx_global, NY = d->ny_global;
+    if (d->ns_type != BND_TRIPOLE) return;
+    double *g = (double *)malloc(sizeof(double) * (size_t)NX * NY);
+    gather_global(d, a2, g);
+    for (int b = 0; b < d->nblocks; ++b) {
+        double *ab = a1 + (size_t)b * nx * ny;
+        const int ilo = d->ilo[b], ihi = d->ihi[b], jlo = d->jlo[b], jhi = d->jhi[b];
+        const int j = jhi + 1;
+        if (d->jglob0[b] + (j - jlo) != NY + 1) continue;
+        for (int i = ilo - d->nghost; i <= ihi + d->nghost; ++i) {
+            int ig = d->iglob0[b] + (i - ilo);
+            if (ig < 1) ig += NX;
+            if (ig > NX) ig -= NX;
+            int im = NX - ig + 1;
+            ab[IX(i, j)] = g[(size_t)(NY - 1) * NX + (im - 1)];
+        }
     }
     free(g);
 }

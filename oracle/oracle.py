@@ -134,6 +134,16 @@ def halo_update(dom: OracleDomain, a, field_loc="NEcorner", field_type="vector",
     return a
 
 
+def tripole_stress_sym(dom: OracleDomain, out: dict) -> dict:
+    """ice_HaloUpdate_stress x12 as evp() applies it after the loop (ice_dyn_evp.F90:1364-1387)."""
+    lib().evp_oracle_tripole_stress.restype = None
+    pairs = [(1, 3), (3, 1), (2, 4), (4, 2)]
+    for fam in ("stressp", "stressm", "stress12"):
+        for a, b in pairs:
+            lib().evp_oracle_tripole_stress(C.byref(dom.c), _dp(out[f"{fam}_{a}"]), _dp(out[f"{fam}_{b}"]))
+    return out
+
+
 def subcycle(dom: OracleDomain, params: Params, ndte: int, dyn: dict, static: dict,
              iceTmask, iceUmask) -> dict:
     """Run ndte subcycles; `dyn` maps DYN_FIELDS -> arrays (copied, originals untouched).

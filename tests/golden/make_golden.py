@@ -47,6 +47,14 @@ CASES = {
     "pop_cyc_2x2_seabed": (24, 20, 12, 10, "cyclic", "closed",
                            dict(grid_kind="popfile", icecase="full", nsub_list=[1, 120], ncalls=2,
                                 h_seabed=True)),
+    # tripole (u-fold) north boundary: seam-row averaging, mirrored ghost row, and -- in the
+    # expected outputs only -- evp()'s ice_HaloUpdate_stress symmetrisation after the loop
+    "trip_cyc_2x2_full": (28, 20, 14, 10, "cyclic", "tripole",
+                          dict(grid_kind="tripolefile", icecase="full", nsub_list=[1, 2, 120], ncalls=2)),
+    "trip_cyc_1blk_patchy": (24, 18, 24, 18, "cyclic", "tripole",
+                             dict(grid_kind="tripolefile", icecase="patchy", nsub_list=[1, 120], ncalls=1)),
+    "trip_cyc_4x3_caps": (32, 24, 8, 8, "cyclic", "tripole",
+                          dict(grid_kind="tripolefile", icecase="caps", nsub_list=[1, 120], ncalls=2)),
 }
 
 

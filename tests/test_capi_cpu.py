@@ -45,15 +45,27 @@ def test_compute_entry_points_fail_loudly_without_init():
 
 
 def apply_plan_single_rank(plan, a):
+    """What halo_uv() does on one GPU: local copies, tripole seam (pairs, poles), late copies."""
     flat = a.reshape(-1)
     src = plan["local_src"]
     val = np.where(src >= 0, plan["local_sign"] * flat[np.maximum(src, 0)], 0.0)
     flat[plan["local_dst"]] = val
+    if len(plan["seam_a"]):
+        xa, xb = flat[plan["seam_a"]].copy(), flat[plan["seam_b"]].copy()
+        xavg = 0.5 * (xa + (-1.0) * xb)
+        flat[plan["seam_a"]] = xavg
+        flat[plan["seam_b"]] = -1.0 * xavg
+    if len(plan["seam_pole"]):
+        flat[plan["seam_pole"]] = -1.0 * flat[plan["seam_pole"]]
+    if len(plan["late_dst"]):
+        flat[plan["late_dst"]] = plan["late_sign"] * flat[plan["late_src"]]
     return a
 
 
 @pytest.mark.parametrize("ew,ns,bx,by", [("cyclic", "closed", 7, 5), ("closed", "closed", 20, 6),
-                                         ("cyclic", "cyclic", 8, 9), ("cyclic", "closed", 20, 18)])
+                                         ("cyclic", "cyclic", 8, 9), ("cyclic", "closed", 20, 18),
+                                         ("cyclic", "tripole", 20, 18), ("cyclic", "tripole", 5, 6),
+                                         ("cyclic", "tripole", 7, 18)])
 def test_halo_plan_matches_oracle_semantics(ew, ns, bx, by):
     dc = decomp.Decomp(20, 18, bx, by, ew, ns, 1)
     d, keep = evp.make_dims(dc, 0)
@@ -69,6 +81,18 @@ def test_halo_plan_matches_oracle_semantics(ew, ns, bx, by):
     assert np.array_equal(got, want)
     # every ghost cell that has a source appears exactly once
     assert len(set(plan["local_dst"].tolist())) == len(plan["local_dst"])
+
+
+def test_tripole_plan_refuses_seam_split_across_ranks():
+    dc = decomp.Decomp(20, 18, 10, 9, "cyclic", "tripole", 2, (2, 1))   # seam row cut in x
+    d, keep = evp.make_dims(dc, 0)
+    with pytest.raises(evp.EvpHipError, match="tripole"):
+        evp.halo_plan(d)
+    dc = decomp.Decomp(20, 18, 20, 9, "cyclic", "tripole", 2, (1, 2))    # y slabs: seam on one rank
+    for r in range(2):
+        d, keep = evp.make_dims(dc, r)
+        plan = evp.halo_plan(d)
+        assert (len(plan["seam_a"]) > 0) == (r == 1)
 
 
 def test_halo_plan_rejects_bad_geometry():
