@@ -640,7 +640,9 @@ int cice_evp_hip_subcycle(int32_t ndte)
     if (ndte < 0) return fail(-1, "ndte < 0");
     if (ndte == 0) return 0;
     HIPC(hipEventRecord(S.ev0, S.stream));
-    const bool graph_ok = S.use_graph && S.plan.peers.empty();
+    // RCCL p2p inside a captured graph: opt-in (CICE_EVP_HIP_GRAPH_RCCL=1) until measured on a multi-GPU node
+    static const bool graph_rccl = env("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env("CICE_EVP_HIP_GRAPH_RCCL"));
+    const bool graph_ok = S.use_graph && (S.plan.peers.empty() || graph_rccl);
     if (graph_ok) {
         const auto key = std::make_pair((int)ndte, S.cur);
         auto it = S.graphs.find(key);

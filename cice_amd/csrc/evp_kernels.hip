@@ -125,58 +125,67 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
     const int i = r.x + bx * 63 + tx;               // 1-based local indices
     const int j = r.z + by * (TYB - 1) + ty;
     const int nx = A.nx;
-    const size_t base = (size_t)bz * A.plane;
-    const size_t c = base + (size_t)(j - 1) * nx + (i - 1);
+    // 32-bit element index (every array is far below 2^31 elements): loads become
+    // scalar-base + 32-bit-offset instead of a 64-bit address add per array
+    const int c = bz * (int)A.plane + (j - 1) * nx + (i - 1);
+    const unsigned ob = (unsigned)c * 8u;            // byte offset of this cell in every array
+    const unsigned orow = (unsigned)nx * 8u;          // one row down
+    auto LD = [](const double *p, unsigned off) -> double {
+        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + off);
+    };
+    auto ST = [](double *p, unsigned off, double v) {
+        *reinterpret_cast<double *>(reinterpret_cast<char *>(p) + off) = v;
+    };
     const unsigned flags = A.flags;
 
     const bool inT = (i <= r.y + 1) && (j <= r.w + 1);
     unsigned m = 0;
-    if (inT) m = A.mask[c];
+    if (inT) m = A.mask[(unsigned)c];
     const bool actT = inT && (m & 1u);
     const bool isU = (tx < 63) && (ty < TYB - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
 
     // ---- phase 0: loads -------------------------------------------------
     double u_ij = 0.0, v_ij = 0.0;
     if (actT || isU) {
-        u_ij = A.u_in[c];
-        v_ij = A.v_in[c];
+        u_ij = LD(A.u_in, ob);
+        v_ij = LD(A.v_in, ob);
     }
     typename MM::SI a;
     double s[12];
     if (actT) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) s[k] = A.sig_in[k][c];
+        for (int k = 0; k < 12; ++k) s[k] = LD(A.sig_in[k], ob);
         a.u_ij = u_ij; a.v_ij = v_ij;
-        a.u_im = A.u_in[c - 1]; a.v_im = A.v_in[c - 1];
-        a.u_jm = A.u_in[c - nx]; a.v_jm = A.v_in[c - nx];
-        a.u_mm = A.u_in[c - nx - 1]; a.v_mm = A.v_in[c - nx - 1];
-        a.dxT = A.dxT[c]; a.dyT = A.dyT[c];
-        a.strength = A.strength[c];
+        a.u_im = LD(A.u_in, ob - 8u); a.v_im = LD(A.v_in, ob - 8u);
+        a.u_jm = LD(A.u_in, ob - orow); a.v_jm = LD(A.v_in, ob - orow);
+        a.u_mm = LD(A.u_in, ob - orow - 8u); a.v_mm = LD(A.v_in, ob - orow - 8u);
+        a.dxT = LD(A.dxT, ob); a.dyT = LD(A.dyT, ob);
+        a.strength = LD(A.strength, ob);
     }
     double hte = 0, hte_im = 0, htn = 0, htn_jm = 0;
     if (actT) {
         if (flags & EVP_F_METRICS) {
-            hte = A.HTE[c]; hte_im = A.HTE[c - 1];
-            htn = A.HTN[c]; htn_jm = A.HTN[c - nx];
-            if (flags & EVP_F_DXHY_ARRAY) { a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c]; }
+            hte = LD(A.HTE, ob); hte_im = LD(A.HTE, ob - 8u);
+            htn = LD(A.HTN, ob); htn_jm = LD(A.HTN, ob - orow);
+            if (flags & EVP_F_DXHY_ARRAY) { a.dxhy = LD(A.dxhy, ob); a.dyhx = LD(A.dyhx, ob); }
         } else {
-            a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c];
-            a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
-            a.DminTarea = A.DminTarea[c];
+            a.dxhy = LD(A.dxhy, ob); a.dyhx = LD(A.dyhx, ob);
+            a.cxp = LD(A.cxp, ob); a.cyp = LD(A.cyp, ob); a.cxm = LD(A.cxm, ob); a.cym = LD(A.cym, ob);
+            a.DminTarea = LD(A.DminTarea, ob);
         }
     }
     typename MM::UI q;
     auto load_u = [&]() {
         q.uold = u_ij; q.vold = v_ij;
-        q.vrelfac = A.vrelfac[c];
-        q.uocn = A.uocn[c]; q.vocn = A.vocn[c];
-        q.forcex = A.forcex[c]; q.forcey = A.forcey[c];
-        q.Umassdti = A.umassdti[c]; q.fm = A.fm[c]; q.uarear = A.uarear[c];
+        q.vrelfac = LD(A.vrelfac, ob);
+        q.uocn = LD(A.uocn, ob); q.vocn = LD(A.vocn, ob);
+        q.forcex = LD(A.forcex, ob); q.forcey = LD(A.forcey, ob);
+        q.Umassdti = LD(A.umassdti, ob); q.fm = LD(A.fm, ob); q.uarear = LD(A.uarear, ob);
         if (flags & EVP_F_WATER_IS_OCN) { q.waterx = q.uocn; q.watery = q.vocn; }
-        else { q.waterx = A.waterx[c]; q.watery = A.watery[c]; }
-        q.TbU = (flags & EVP_F_TBU_ZERO) ? 0.0 : A.TbU[c];
-        q.uvel_init = A.p.revp != 0.0 ? A.uvel_init[c] : 0.0;
-        q.vvel_init = A.p.revp != 0.0 ? A.vvel_init[c] : 0.0;
+        else { q.waterx = LD(A.waterx, ob); q.watery = LD(A.watery, ob); }
+        q.TbU = (flags & EVP_F_TBU_ZERO) ? 0.0 : LD(A.TbU, ob);
+        q.uvel_init = A.p.revp != 0.0 ? LD(A.uvel_init, ob) : 0.0;
+        q.vvel_init = A.p.revp != 0.0 ? LD(A.vvel_init, ob) : 0.0;
     };
     if (PRE && isU) load_u();   // PRE: momentum operands in flight during the stress phase
 
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
         const bool own = (tx < 63 || i == r.y + 1) && (ty < TYB - 1 || j == r.w + 1);
         if (own) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) A.sig_out[k][c] = s[k];
+            for (int k = 0; k < 12; ++k) ST(A.sig_out[k], ob, s[k]);
         }
     }
 #pragma unroll
@@ -212,10 +221,10 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
         q.sy0 = s_str[4][ty][tx]; q.sy1 = s_str[5][ty + 1][tx];
         q.sy2 = s_str[6][ty][tx + 1]; q.sy3 = s_str[7][ty + 1][tx + 1];
         MM::stepu(A.p, q, o);
-        A.u_out[c] = o.u; A.v_out[c] = o.v;
+        ST(A.u_out, ob, o.u); ST(A.v_out, ob, o.v);
         if (A.last) {
-            A.strintx[c] = o.strintx; A.strinty[c] = o.strinty;
-            A.taubx[c] = o.taubx; A.tauby[c] = o.tauby;
+            ST(A.strintx, ob, o.strintx); ST(A.strinty, ob, o.strinty);
+            ST(A.taubx, ob, o.taubx); ST(A.tauby, ob, o.tauby);
         }
         if ((flags & EVP_F_PUSH) && (i == r.x || i == r.y || j == r.z || j == r.w)) {
             // ghost images of this cell (cyclic wrap / neighbouring block on this GPU)
