@@ -76,7 +76,12 @@ struct State {
     int max_ni = 0, max_nj = 0;
     int tyb = 5;
     bool tyb_forced = false, tuned = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_comm = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+    bool overlap = true;
+    // tiles that produce cells other ranks need (run first) / all other tiles, per tile variant
+    struct TileSplit { int *d_boundary = nullptr, *d_interior = nullptr; int nb = 0, ni = 0; };
+    std::map<int, TileSplit> splits;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evm[2] = {nullptr, nullptr};
     bool marked[2] = {false, false};
 
@@ -169,6 +174,16 @@ void free_all()
     S.ev0 = S.ev1 = S.ev2 = S.ev3 = nullptr;
     if (S.have_comm) (void)ncclCommDestroy(S.comm);
     S.have_comm = false;
+    for (auto &kv : S.splits) {
+        if (kv.second.d_boundary) (void)hipFree(kv.second.d_boundary);
+        if (kv.second.d_interior) (void)hipFree(kv.second.d_interior);
+    }
+    S.splits.clear();
+    if (S.ev_pack) (void)hipEventDestroy(S.ev_pack);
+    if (S.ev_halo) (void)hipEventDestroy(S.ev_halo);
+    S.ev_pack = S.ev_halo = nullptr;
+    if (S.stream_comm) (void)hipStreamDestroy(S.stream_comm);
+    S.stream_comm = nullptr;
     if (S.stream) (void)hipStreamDestroy(S.stream);
     S.stream = nullptr;
 }
@@ -332,6 +347,8 @@ void fill_args(EvpArgs &A, int cur, int last)
     A.ny = S.d.ny_block;
     A.plane = S.plane;
     A.last = last;
+    A.tile_list = nullptr;
+    A.tile_count = 0;
     A.blk = S.blk;
     A.mask = S.mask;
     A.u_in = S.u[cur];
@@ -397,18 +414,114 @@ int halo_uv(int b)
     return 0;
 }
 
+// Boundary-first + second stream pays when the interior kernel is long enough to hide the
+// exchange; on small per-rank domains the extra host calls (events, two launches) cost more
+// than they hide (measured: 50 vs 26 us per subcycle on gx1, eager).  CICE_EVP_HIP_OVERLAP=1/0 forces.
+bool use_overlap()
+{
+    const bool seam = (S.n_seam + S.n_pole + S.n_late) > 0;
+    if (!S.overlap || S.plan.peers.empty() || seam || !S.have_comm) return false;
+    if (env("CICE_EVP_HIP_OVERLAP")) return std::atoi(env("CICE_EVP_HIP_OVERLAP")) != 0;
+    size_t cells = 0;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);
+    return cells >= 400000;
+}
+
+// Which tiles of `variant` hold U-cells that some other rank mirrors (send list)?
+int get_tile_split(int variant, State::TileSplit **out)
+{
+    auto it = S.splits.find(variant);
+    if (it != S.splits.end()) { *out = &it->second; return 0; }
+    int tyb, gx, gy;
+    evp_tile_geometry(S.max_ni, S.max_nj, variant, &tyb, &gx, &gy);
+    const int ntiles = gx * gy * S.d.nblocks;
+    std::vector<char> is_b((size_t)ntiles, 0);
+    const int nx = S.d.nx_block;
+    for (const HaloPeer &p : S.plan.peers)
+        for (int32_t src : p.send_src) {
+            const int b = (int)(src / S.plane);
+            const int rem = (int)(src % S.plane);
+            const int j = rem / nx + 1, i = rem % nx + 1;
+            const int bx = (i - S.ilo[b]) / 63, by = (j - S.jlo[b]) / (tyb - 1);
+            if (bx < 0 || bx >= gx || by < 0 || by >= gy) continue;
+            is_b[((size_t)b * gy + by) * gx + bx] = 1;       // row-major tile id (xcdmap 0/2 decoding)
+        }
+    std::vector<int> lb, li;
+    for (int t = 0; t < ntiles; ++t) (is_b[t] ? lb : li).push_back(t);
+    State::TileSplit ts;
+    ts.nb = (int)lb.size();
+    ts.ni = (int)li.size();
+    if (ts.nb) {
+        HIPC(hipMalloc((void **)&ts.d_boundary, lb.size() * sizeof(int)));
+        HIPC(hipMemcpy(ts.d_boundary, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (ts.ni) {
+        HIPC(hipMalloc((void **)&ts.d_interior, li.size() * sizeof(int)));
+        HIPC(hipMemcpy(ts.d_interior, li.data(), li.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    *out = &S.splits.emplace(variant, ts).first->second;
+    return 0;
+}
+
 int enqueue_loop(int ndte, int cur0)
 {
     int cur = cur0;
     const bool strict = S.prm.strict != 0;
     const int cap = cap_mode();
+    // Boundary strips first, RCCL exchange on a second stream while the interior tiles run
+    // (the tripole seam needs every tile of the top row first, so it keeps the serial order).
+    const bool overlap = use_overlap();
+    if (!overlap) {
+        for (int k = 0; k < ndte; ++k) {
+            EvpArgs A;
+            fill_args(A, cur, k == ndte - 1);
+            evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, S.tyb, strict, cap, S.stream);
+            if (int rc = halo_uv(cur ^ 1)) return rc;
+            cur ^= 1;
+        }
+        HIPC(hipGetLastError());
+        return 0;
+    }
+    // the split kernels decode tile ids row-major: use the row-major flavour of the variant
+    const int variant = S.tyb % 100;
+    State::TileSplit *ts = nullptr;
+    if (int rc = get_tile_split(variant, &ts)) return rc;
     for (int k = 0; k < ndte; ++k) {
+        const int nxt = cur ^ 1;
         EvpArgs A;
         fill_args(A, cur, k == ndte - 1);
-        evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, S.tyb, strict, cap, S.stream);
-        if (int rc = halo_uv(cur ^ 1)) return rc;
-        cur ^= 1;
+        if (k > 0) HIPC(hipStreamWaitEvent(S.stream, S.ev_halo, 0));   // ghosts of u_in complete
+        // 1. tiles whose cells other ranks need
+        A.tile_list = ts->d_boundary; A.tile_count = ts->nb;
+        evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
+        evp_launch_halo_pack(S.u[nxt], S.v[nxt], S.h_send_src, S.sendbuf, S.n_send, S.stream);
+        HIPC(hipEventRecord(S.ev_pack, S.stream));
+        // 2. everything else, concurrently with the exchange
+        A.tile_list = ts->d_interior; A.tile_count = ts->ni;
+        evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
+        if (!(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH)))
+            evp_launch_halo_local(S.u[nxt], S.v[nxt], S.h_local_dst, S.h_local_src,
+                                  (const signed char *)S.h_local_sign, S.n_local, S.stream);
+        // 3. RCCL point-to-point over xGMI on the communication stream
+        HIPC(hipStreamWaitEvent(S.stream_comm, S.ev_pack, 0));
+        size_t so = 0, ro = 0;
+        NCCLC(ncclGroupStart());
+        for (const HaloPeer &p : S.plan.peers) {
+            if (!p.send_src.empty())
+                NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
+            if (!p.recv_dst.empty())
+                NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
+            so += p.send_src.size();
+            ro += p.recv_dst.size();
+        }
+        NCCLC(ncclGroupEnd());
+        evp_launch_halo_unpack(S.u[nxt], S.v[nxt], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
+                               S.n_recv, S.stream_comm);
+        HIPC(hipEventRecord(S.ev_halo, S.stream_comm));
+        cur = nxt;
     }
+    HIPC(hipStreamWaitEvent(S.stream, S.ev_halo, 0));   // the compute stream owns the final state
     HIPC(hipGetLastError());
     return 0;
 }
@@ -492,6 +605,10 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     S.device = dev;
     HIPC(hipSetDevice(dev));
     HIPC(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    HIPC(hipStreamCreateWithFlags(&S.stream_comm, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&S.ev_pack, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&S.ev_halo, hipEventDisableTiming));
+    S.overlap = !(env("CICE_EVP_HIP_NO_OVERLAP") && std::atoi(env("CICE_EVP_HIP_NO_OVERLAP")));
     HIPC(hipEventCreate(&S.ev0));
     HIPC(hipEventCreate(&S.ev1));
     HIPC(hipEventCreate(&S.ev2));
@@ -511,7 +628,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     S.tyb = 5;
     if (env("CICE_EVP_HIP_TYB")) {
         const int t = std::atoi(env("CICE_EVP_HIP_TYB"));   // tile height [+100: XCD-contiguous order]
-        S.tyb = (t % 100 == 9 || t % 100 == 3) ? t : 5 + 100 * (t / 100);
+        S.tyb = (t % 100 >= 2 && t % 100 <= 9) ? t : 5 + 100 * (t / 100);
     }
     S.use_graph = !(env("CICE_EVP_HIP_NOGRAPH") && std::atoi(env("CICE_EVP_HIP_NOGRAPH")));
 
@@ -649,6 +766,10 @@ int cice_evp_hip_subcycle(int32_t ndte)
         if (it == S.graphs.end()) {
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
+            if (use_overlap()) {   // device allocations are not allowed while capturing
+                State::TileSplit *ts = nullptr;
+                if (int rc = get_tile_split(S.tyb % 100, &ts)) return rc;
+            }
             HIPC(hipStreamBeginCapture(S.stream, hipStreamCaptureModeThreadLocal));
             const int rc = enqueue_loop(ndte, S.cur);
             hipError_t e = hipStreamEndCapture(S.stream, &g);

@@ -21,6 +21,8 @@ struct EvpArgs {
     size_t plane;              // nx*ny
     int gx, gy, ntiles;        // tile grid (filled by evp_launch_subcycle)
     int xcdmap;                // 1: XCD-contiguous tile order
+    const int *tile_list;      // non-NULL: run only these tiles (boundary-first / interior split)
+    int tile_count;
     int last;                  // write strintx/y, taubx/y (needed after the last subcycle only)
     const int4 *blk;           // per block: ilo, ihi, jlo, jhi (1-based)
     const uint8_t *mask;       // bit0 = iceTmask, bit1 = iceUmask
@@ -58,6 +60,8 @@ void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double
                         hipStream_t st);
 void evp_launch_subcycle(const EvpArgs &A, int max_ni, int max_nj, int nblocks, int variant,
                          bool strict, int cap, hipStream_t st);
+// tile geometry of a variant (tile height, tiles in x / y per block)
+void evp_tile_geometry(int max_ni, int max_nj, int variant, int *tyb, int *gx, int *gy);
 void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
                            const signed char *sign, int n, hipStream_t st);
 void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, int npair, const int *pole,

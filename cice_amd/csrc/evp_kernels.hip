@@ -106,7 +106,9 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
     // with the tile row index fastest, so that vertically adjacent tiles -- which share
     // the T-row recomputed on the fringe -- are read through the same L2 close in time.
     int t;
-    {
+    if (A.tile_list) {
+        t = A.tile_list[blockIdx.x];                 // explicit subset (boundary / interior tiles)
+    } else {
         const int w = blockIdx.x;
         const int per = (A.ntiles + 7) >> 3;
         t = A.xcdmap ? (w & 7) * per + (w >> 3) : w;
@@ -373,15 +375,35 @@ void evp_launch_subcycle(const EvpArgs &A0, int max_ni, int max_nj, int nblocks,
     EvpArgs A = A0;
     int tyb = variant % 100;           // variant = tile height + 100 * (XCD-contiguous tile order)
     A.xcdmap = variant / 100;        // 0: plain row-major, 1: XCD-chunked column runs, 2: XCD-chunked row-major
-    if (tyb != 3 && tyb != 9) tyb = 5;
+    if (tyb < 2 || tyb > 9) tyb = 5;
     A.gx = (max_ni + 62) / 63;
     A.gy = (max_nj + tyb - 2) / (tyb - 1);
     A.ntiles = A.gx * A.gy * nblocks;
     const int per = (A.ntiles + 7) / 8;
     dim3 grid(per * 8);
-    if (tyb == 9) launch_tile<9>(A, grid, st, strict, cap);
-    else if (tyb == 3) launch_tile<3>(A, grid, st, strict, cap);
-    else launch_tile<5>(A, grid, st, strict, cap);
+    if (A.tile_list) {
+        if (A.tile_count <= 0) return;
+        grid = dim3(A.tile_count);
+    }
+    switch (tyb) {
+    case 2: launch_tile<2>(A, grid, st, strict, cap); break;
+    case 3: launch_tile<3>(A, grid, st, strict, cap); break;
+    case 4: launch_tile<4>(A, grid, st, strict, cap); break;
+    case 6: launch_tile<6>(A, grid, st, strict, cap); break;
+    case 7: launch_tile<7>(A, grid, st, strict, cap); break;
+    case 8: launch_tile<8>(A, grid, st, strict, cap); break;
+    case 9: launch_tile<9>(A, grid, st, strict, cap); break;
+    default: launch_tile<5>(A, grid, st, strict, cap); break;
+    }
+}
+
+void evp_tile_geometry(int max_ni, int max_nj, int variant, int *tyb_out, int *gx, int *gy)
+{
+    int tyb = variant % 100;
+    if (tyb < 2 || tyb > 9) tyb = 5;
+    *tyb_out = tyb;
+    *gx = (max_ni + 62) / 63;
+    *gy = (max_nj + tyb - 2) / (tyb - 1);
 }
 
 void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double *out, size_t n,

@@ -1,6 +1,3 @@
 cd /root/repo; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|differ|Error" | tail -5
-P='import sys,json; r=json.loads(sys.stdin.read()); print(round(r["value"]/1e9,3), round(r["config"]["us_per_subcycle"],2), round(r["roofline"]["frac"],3), r["config"].get("tile_variant"))'
-for i in 1 2; do python bench.py --no-cpu-baseline 2>/dev/null | python -c "$P"; done
-python bench.py --no-cpu-baseline --fused 2>/dev/null | python -c "$P"
-python bench.py --no-cpu-baseline --workload s01 --steps 2 --warmup 1 2>/dev/null | python -c "$P"
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|differ|Error" | tail -8
+for v in "CICE_EVP_HIP_SELF_EXCHANGE=1" "CICE_EVP_HIP_SELF_EXCHANGE=1 CICE_EVP_HIP_OVERLAP=1" "CICE_EVP_HIP_SELF_EXCHANGE=1 CICE_EVP_HIP_GRAPH_RCCL=1" "CICE_EVP_HIP_SELF_EXCHANGE=1 CICE_EVP_HIP_GRAPH_RCCL=1 CICE_EVP_HIP_OVERLAP=1"; do echo "$v"; env $v timeout 120 python gpurun_selfx.py 2>&1 | grep -E "RESULT|rror" | cut -c1-80; done

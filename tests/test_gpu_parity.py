@@ -88,11 +88,13 @@ def synth_case(grid_name, case, nranks_blocks=(1, 1), seed=None, warm=False, ndt
     return dc, geo, fields, tm, um
 
 
-def run_hip(dc, geo, fields, tm, um, scal, strict, ndte):
+def run_hip(dc, geo, fields, tm, um, scal, strict, ndte, rccl_self=False):
     d, keep = evp.make_dims(dc, 0)
     core = evp.EvpHip(d, evp.make_params(scal, strict=strict), geo["HTE"], geo["HTN"], geo["dxT"],
                       geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
     try:
+        if rccl_self:
+            core.comm_init(core.comm_unique_id())
         return core.run(fields, tm, um, ndte=ndte)
     finally:
         core.finalize()
@@ -198,6 +200,20 @@ def test_single_rank_rccl_self_exchange(name, monkeypatch):
         assert core.timings()["launches_per_subcycle"] == (4.0 if c.ns == "tripole" else 3.0)
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_gx1_boundary_first_overlap_path_bitwise(overlap, monkeypatch):
+    """gx1 in 2x2 blocks with every inter-block ghost copy routed through RCCL (to self):
+    boundary tiles first + pack, exchange on the communication stream while the interior
+    tiles run, unpack -- versus the oracle, bit for bit; and the same without overlap."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_OVERLAP", "1" if overlap else "0")
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx1", "full", seed=11, warm=True, bs=(160, 192))
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12, rccl_self=True)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 12)
+    assert_bitwise(got, want, f"gx1 2x2 blocks through RCCL, overlap={overlap}")
 
 
 def test_remote_halo_without_communicator_fails_loudly(monkeypatch):
