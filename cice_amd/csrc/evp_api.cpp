@@ -92,6 +92,9 @@ struct State {
     double *sig[2][12] = {};
     double *hte = nullptr, *htn = nullptr;   // edge lengths for in-kernel metric terms
     double *vrelfac = nullptr;               // (aiX*rhow)*Cw, rebuilt at every upload
+    double *post_geo[3] = {};                // dxU dyU tarear (next tier f-1)
+    double *post_out[7] = {};                // divu shear vort rdg_conv rdg_shear strocnx strocny
+    bool have_post_geo = false;
     uint8_t *mask = nullptr;
     int4 *blk = nullptr;
     int cur = 0;
@@ -152,6 +155,8 @@ void free_all()
     F(S.hte);
     F(S.htn);
     F(S.vrelfac);
+    for (auto &p : S.post_geo) F(p);
+    for (auto &p : S.post_out) F(p);
     F(S.push);
     F(S.mask);
     F(S.blk);
@@ -799,6 +804,54 @@ int cice_evp_hip_mark(int32_t which)
     if (which < 0 || which > 1) return fail(-1, "mark index");
     HIPC(hipEventRecord(S.evm[which], S.stream));
     S.marked[which] = true;
+    return 0;
+}
+
+// ---- next tier: deformations and dyn_finish on the resident final state ----
+int cice_evp_hip_set_post_geometry(const double *dxU, const double *dyU, const double *tarear)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!dxU || !dyU || !tarear) return fail(-1, "null argument");
+    const double *src[3] = {dxU, dyU, tarear};
+    for (int k = 0; k < 3; ++k) {
+        if (!S.post_geo[k] && alloc_d(&S.post_geo[k], S.n)) return -1;
+        if (h2d(S.post_geo[k], src[k])) return -1;
+    }
+    for (auto &p : S.post_out)
+        if (!p && alloc_d(&p, S.n)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    S.have_post_geo = true;
+    return 0;
+}
+
+int cice_evp_hip_deformations(double *divu, double *shear, double *vort, double *rdg_conv, double *rdg_shear)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (!S.have_post_geo) return fail(-1, "cice_evp_hip_set_post_geometry not called");
+    EvpArgs A;
+    fill_args(A, S.cur, 0);
+    evp_launch_deformations(A, S.d.nblocks, S.prm.strict != 0, S.post_geo[0], S.post_geo[1], S.post_geo[2],
+                            S.post_out[0], S.post_out[1], S.post_out[2], S.post_out[3], S.post_out[4], S.stream);
+    double *dst[5] = {divu, shear, vort, rdg_conv, rdg_shear};
+    for (int k = 0; k < 5; ++k)
+        if (dst[k] && d2h(dst[k], S.post_out[k])) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+int cice_evp_hip_dyn_finish(double *strocnxU, double *strocnyU)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (!strocnxU || !strocnyU) return fail(-1, "null argument");
+    for (int k = 5; k < 7; ++k)
+        if (!S.post_out[k] && alloc_d(&S.post_out[k], S.n)) return -1;
+    // inout: cells outside the ice keep the caller's values (dyn_prep2 zeroes them, :776-784)
+    if (h2d(S.post_out[5], strocnxU) || h2d(S.post_out[6], strocnyU)) return -1;
+    EvpArgs A;
+    fill_args(A, S.cur, 0);
+    evp_launch_dyn_finish(A, S.d.nblocks, S.prm.strict != 0, S.post_out[5], S.post_out[6], S.stream);
+    if (d2h(strocnxU, S.post_out[5]) || d2h(strocnyU, S.post_out[6])) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
     return 0;
 }
 

@@ -60,6 +60,11 @@ void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double
                         hipStream_t st);
 void evp_launch_subcycle(const EvpArgs &A, int max_ni, int max_nj, int nblocks, int variant,
                          bool strict, int cap, hipStream_t st);
+void evp_launch_deformations(const EvpArgs &A, int nblocks, bool strict, const double *dxU, const double *dyU,
+                              const double *tarear, double *divu, double *shear, double *vort,
+                              double *rdg_conv, double *rdg_shear, hipStream_t st);
+void evp_launch_dyn_finish(const EvpArgs &A, int nblocks, bool strict, double *strocnx, double *strocny,
+                           hipStream_t st);
 // tile geometry of a variant (tile height, tiles in x / y per block)
 void evp_tile_geometry(int max_ni, int max_nj, int variant, int *tyb, int *gx, int *gy);
 void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,

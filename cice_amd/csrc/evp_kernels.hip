@@ -254,6 +254,64 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
     }
 }
 
+// ---------------------------------------------------------------------
+// Next tier (f-1): deformations and dyn_finish on the final velocities.
+// One thread per cell, row-major 2-D launch over (nx, ny, nblocks).
+// ---------------------------------------------------------------------
+template <bool STRICT>
+__global__ void deformations_kernel(EvpArgs A, const double *__restrict__ dxU, const double *__restrict__ dyU,
+                                    const double *__restrict__ tarear, double *__restrict__ divu,
+                                    double *__restrict__ shear, double *__restrict__ vort,
+                                    double *__restrict__ rdg_conv, double *__restrict__ rdg_shear)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int bz = blockIdx.z;
+    if (i > A.nx) return;
+    const int nx = A.nx;
+    const size_t c = (size_t)bz * A.plane + (size_t)(j - 1) * nx + (i - 1);
+    const int4 r = A.blk[bz];
+    double o_divu = 0, o_shear = 0, o_vort = 0, o_conv = 0, o_rshear = 0;   // zero off the ice (ice_dyn_evp.F90:385-393)
+    const bool inT = i >= r.x && i <= r.y + 1 && j >= r.z && j <= r.w + 1;
+    if (inT && (A.mask[c] & 1u)) {
+        if (STRICT) {
+            evp_strict::StressIn a; evp_strict::DeformOut o;
+            a.u_ij = A.u_in[c]; a.v_ij = A.v_in[c]; a.u_im = A.u_in[c - 1]; a.v_im = A.v_in[c - 1];
+            a.u_jm = A.u_in[c - nx]; a.v_jm = A.v_in[c - nx]; a.u_mm = A.u_in[c - nx - 1]; a.v_mm = A.v_in[c - nx - 1];
+            a.dxT = A.dxT[c]; a.dyT = A.dyT[c]; a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
+            evp_strict::deform_cell(A.p, a, tarear[c], dyU[c], dyU[c - 1], dyU[c - nx], dyU[c - nx - 1],
+                                    dxU[c], dxU[c - 1], dxU[c - nx], dxU[c - nx - 1], o);
+            o_divu = o.divu; o_shear = o.shear; o_vort = o.vort; o_conv = o.rdg_conv; o_rshear = o.rdg_shear;
+        } else {
+            evp_fused::StressIn a; evp_fused::DeformOut o;
+            a.u_ij = A.u_in[c]; a.v_ij = A.v_in[c]; a.u_im = A.u_in[c - 1]; a.v_im = A.v_in[c - 1];
+            a.u_jm = A.u_in[c - nx]; a.v_jm = A.v_in[c - nx]; a.u_mm = A.u_in[c - nx - 1]; a.v_mm = A.v_in[c - nx - 1];
+            a.dxT = A.dxT[c]; a.dyT = A.dyT[c]; a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
+            evp_fused::deform_cell(A.p, a, tarear[c], dyU[c], dyU[c - 1], dyU[c - nx], dyU[c - nx - 1],
+                                   dxU[c], dxU[c - 1], dxU[c - nx], dxU[c - nx - 1], o);
+            o_divu = o.divu; o_shear = o.shear; o_vort = o.vort; o_conv = o.rdg_conv; o_rshear = o.rdg_shear;
+        }
+    }
+    divu[c] = o_divu; shear[c] = o_shear; vort[c] = o_vort; rdg_conv[c] = o_conv; rdg_shear[c] = o_rshear;
+}
+
+template <bool STRICT>
+__global__ void dyn_finish_kernel(EvpArgs A, double *__restrict__ strocnx, double *__restrict__ strocny)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int j = blockIdx.y + 1;
+    const int bz = blockIdx.z;
+    const int4 r = A.blk[bz];
+    if (i < r.x || i > r.y || j < r.z || j > r.w) return;
+    const size_t c = (size_t)bz * A.plane + (size_t)(j - 1) * A.nx + (i - 1);
+    if (!(A.mask[c] & 2u)) return;
+    double sx, sy;
+    if (STRICT) evp_strict::finish_cell(A.p, A.Cw[c], A.aiX[c], A.uocn[c], A.vocn[c], A.u_in[c], A.v_in[c], A.fm[c], sx, sy);
+    else evp_fused::finish_cell(A.p, A.Cw[c], A.aiX[c], A.uocn[c], A.vocn[c], A.u_in[c], A.v_in[c], A.fm[c], sx, sy);
+    strocnx[c] = sx;
+    strocny[c] = sy;
+}
+
 // (aiX*rhow)*Cw once per call: the leading factors of vrel in stepu
 // (ice_dyn_shared.F90:933), multiplied in the reference's order.
 __global__ void vrelfac_kernel(const double *__restrict__ aiX, const double *__restrict__ Cw,
@@ -395,6 +453,23 @@ void evp_launch_subcycle(const EvpArgs &A0, int max_ni, int max_nj, int nblocks,
     case 9: launch_tile<9>(A, grid, st, strict, cap); break;
     default: launch_tile<5>(A, grid, st, strict, cap); break;
     }
+}
+
+void evp_launch_deformations(const EvpArgs &A, int nblocks, bool strict, const double *dxU, const double *dyU,
+                              const double *tarear, double *divu, double *shear, double *vort,
+                              double *rdg_conv, double *rdg_shear, hipStream_t st)
+{
+    dim3 grid((A.nx + 63) / 64, A.ny, nblocks), block(64);
+    if (strict) hipLaunchKernelGGL(deformations_kernel<true>, grid, block, 0, st, A, dxU, dyU, tarear, divu, shear, vort, rdg_conv, rdg_shear);
+    else hipLaunchKernelGGL(deformations_kernel<false>, grid, block, 0, st, A, dxU, dyU, tarear, divu, shear, vort, rdg_conv, rdg_shear);
+}
+
+void evp_launch_dyn_finish(const EvpArgs &A, int nblocks, bool strict, double *strocnx, double *strocny,
+                           hipStream_t st)
+{
+    dim3 grid((A.nx + 63) / 64, A.ny, nblocks), block(64);
+    if (strict) hipLaunchKernelGGL(dyn_finish_kernel<true>, grid, block, 0, st, A, strocnx, strocny);
+    else hipLaunchKernelGGL(dyn_finish_kernel<false>, grid, block, 0, st, A, strocnx, strocny);
 }
 
 void evp_tile_geometry(int max_ni, int max_nj, int variant, int *tyb_out, int *gx, int *gy)

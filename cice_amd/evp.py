@@ -40,6 +40,7 @@ EXPORTS = [
     "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
+    "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
 ]
 
 _i32p = C.POINTER(C.c_int32)
@@ -199,6 +200,23 @@ class EvpHip:
 
     def mark(self, which: int):
         _check(self.lib, self.lib.cice_evp_hip_mark(C.c_int32(which)), "(dyn_evp_hip_mark)")
+
+    # -- next tier: deformations / dyn_finish on the resident final state -----------------
+    def set_post_geometry(self, dxU, dyU, tarear):
+        a = [self._c(x) for x in (dxU, dyU, tarear)]
+        _check(self.lib, self.lib.cice_evp_hip_set_post_geometry(*[_dp(x) for x in a]), "(set_post_geometry)")
+
+    def deformations(self) -> dict:
+        names = ["divu", "shear", "vort", "rdg_conv", "rdg_shear"]
+        out = {n: np.zeros(self.shape) for n in names}
+        _check(self.lib, self.lib.cice_evp_hip_deformations(*[_dp(out[n]) for n in names]), "(deformations)")
+        return out
+
+    def dyn_finish(self, strocnxU, strocnyU) -> dict:
+        sx = np.array(self._c(strocnxU), copy=True)
+        sy = np.array(self._c(strocnyU), copy=True)
+        _check(self.lib, self.lib.cice_evp_hip_dyn_finish(_dp(sx), _dp(sy)), "(dyn_finish)")
+        return dict(strocnxU=sx, strocnyU=sy)
 
     def time_kernels(self, nrep: int = 50) -> dict:
         t = np.zeros(3)

@@ -134,6 +134,17 @@ int cice_evp_hip_mark(int32_t which);
 /* Block the host until all device work of this library has finished.          */
 int cice_evp_hip_sync(void);
 
+/* ---- next tier: the two kernels evp() runs on the final velocities ----
+ * deformations (ice_dyn_shared.F90:1756-1860, call site ice_dyn_evp.F90:920-934) and
+ * dyn_finish (ice_dyn_shared.F90:1291-1365, call site ice_dyn_evp.F90:1395-1406),
+ * computed on the device from the resident state after cice_evp_hip_subcycle/_run.
+ * set_post_geometry: ice_grid arrays dxU, dyU, tarear (once).  deformations: outputs,
+ * zero where iceTmask is false.  dyn_finish: strocnxU/yU are inout.               */
+int cice_evp_hip_set_post_geometry(const double *dxU, const double *dyU, const double *tarear);
+int cice_evp_hip_deformations(double *divu, double *shear, double *vort, double *rdg_conv,
+                              double *rdg_shear);
+int cice_evp_hip_dyn_finish(double *strocnxU, double *strocnyU);
+
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */
 /* 128-byte ncclUniqueId made by rank 0 and distributed by the host program
  * (MPI_Bcast in CICE; torch.distributed in bench.py).                          */

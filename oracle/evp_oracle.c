@@ -490,3 +490,98 @@ void evp_oracle_subcycle(const evp_oracle_domain *d, const evp_oracle_params *p,
     }
     free(str);
 }
+
+/* ---------------------------------------------------------------------
+ * "Next" tier: the two kernels evp() runs on the final
+ * velocities right after the subcycle loop.
+ *
+ * deformations   dynamics/ice_dyn_shared.F90:1756-1860
+ *   T-cells ilo..ihi+1 x jlo..jhi+1 where iceTmask (same list as stress);
+ *   the five outputs are zero elsewhere (evp() zero-fills them, ice_dyn_evp.F90:385-393).
+ * ------------------------------------------------------------------- */
+void evp_oracle_deformations(const evp_oracle_domain *d, const evp_oracle_params *p,
+                             const double *uvel, const double *vvel, const double *dxT,
+                             const double *dyT, const double *dxU, const double *dyU,
+                             const double *cxp, const double *cyp, const double *cxm,
+                             const double *cym, const double *tarear, const int32_t *iceTmask,
+                             double *vort, double *shear, double *divu, double *rdg_conv,
+                             double *rdg_shear)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t nb = (size_t)nx * ny;
+    memset(vort, 0, sizeof(double) * nb * d->nblocks);
+    memset(shear, 0, sizeof(double) * nb * d->nblocks);
+    memset(divu, 0, sizeof(double) * nb * d->nblocks);
+    memset(rdg_conv, 0, sizeof(double) * nb * d->nblocks);
+    memset(rdg_shear, 0, sizeof(double) * nb * d->nblocks);
+    for (int b = 0; b < d->nblocks; ++b) {
+        const double *u = uvel + b * nb, *v = vvel + b * nb;
+        for (int j = d->jlo[b]; j <= d->jhi[b] + 1; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b] + 1; ++i) {
+                const size_t c = b * nb + IX(i, j);
+                if (!iceTmask[c]) continue;
+                const double u_ij = u[IX(i, j)], u_im = u[IX(i - 1, j)], u_jm = u[IX(i, j - 1)],
+                             u_mm = u[IX(i - 1, j - 1)];
+                const double v_ij = v[IX(i, j)], v_im = v[IX(i - 1, j)], v_jm = v[IX(i, j - 1)],
+                             v_mm = v[IX(i - 1, j - 1)];
+                const double cxp_ = cxp[c], cyp_ = cyp[c], cxm_ = cxm[c], cym_ = cym[c];
+                const double dxt = dxT[c], dyt = dyT[c];
+                /* strain_rates, ice_dyn_shared.F90:2127-2161 */
+                double divune = cyp_ * u_ij - dyt * u_im + cxp_ * v_ij - dxt * v_jm;
+                double divunw = cym_ * u_im + dyt * u_ij + cxp_ * v_im - dxt * v_mm;
+                double divusw = cym_ * u_mm + dyt * u_jm + cxm_ * v_mm + dxt * v_im;
+                double divuse = cyp_ * u_jm - dyt * u_mm + cxm_ * v_jm + dxt * v_ij;
+                double tensionne = -cym_ * u_ij - dyt * u_im + cxm_ * v_ij + dxt * v_jm;
+                double tensionnw = -cyp_ * u_im + dyt * u_ij + cxm_ * v_im + dxt * v_mm;
+                double tensionsw = -cyp_ * u_mm + dyt * u_jm + cxp_ * v_mm - dxt * v_im;
+                double tensionse = -cym_ * u_jm - dyt * u_mm + cxp_ * v_jm - dxt * v_ij;
+                double shearne = -cym_ * v_ij - dyt * v_im - cxm_ * u_ij - dxt * u_jm;
+                double shearnw = -cyp_ * v_im + dyt * v_ij - cxm_ * u_im - dxt * u_mm;
+                double shearsw = -cyp_ * v_mm + dyt * v_jm - cxp_ * u_mm + dxt * u_im;
+                double shearse = -cym_ * v_jm - dyt * v_mm - cxp_ * u_jm + dxt * u_ij;
+                double Deltane = sqrt(divune * divune + p->e_factor * (tensionne * tensionne + shearne * shearne));
+                double Deltanw = sqrt(divunw * divunw + p->e_factor * (tensionnw * tensionnw + shearnw * shearnw));
+                double Deltasw = sqrt(divusw * divusw + p->e_factor * (tensionsw * tensionsw + shearsw * shearsw));
+                double Deltase = sqrt(divuse * divuse + p->e_factor * (tensionse * tensionse + shearse * shearse));
+                /* :1827-1849 */
+                divu[c] = p25 * (divune + divunw + divuse + divusw) * tarear[c];
+                double tmp = p25 * (Deltane + Deltanw + Deltase + Deltasw) * tarear[c];
+                rdg_conv[c] = -fmin(divu[c], 0.0);
+                rdg_shear[c] = p5 * (tmp - fabs(divu[c]));
+                double tsum = tensionne + tensionnw + tensionse + tensionsw;
+                double ssum = shearne + shearnw + shearse + shearsw;
+                shear[c] = p25 * tarear[c] * sqrt(tsum * tsum + ssum * ssum);
+                const double *dyu = dyU + b * nb, *dxu = dxU + b * nb;
+                double dvdxn = dyu[IX(i, j)] * v_ij - dyu[IX(i - 1, j)] * v_im;
+                double dvdxs = dyu[IX(i, j - 1)] * v_jm - dyu[IX(i - 1, j - 1)] * v_mm;
+                double dudye = dxu[IX(i, j)] * u_ij - dxu[IX(i, j - 1)] * u_jm;
+                double dudyw = dxu[IX(i - 1, j)] * u_im - dxu[IX(i - 1, j - 1)] * u_mm;
+                vort[c] = p5 * tarear[c] * (dvdxn + dvdxs - dudye - dudyw);
+            }
+    }
+}
+
+/* ---------------------------------------------------------------------
+ * dyn_finish   dynamics/ice_dyn_shared.F90:1291-1365
+ *   ice-ocean stress from the final velocities on U-cells where iceUmask
+ *   (ilo..ihi x jlo..jhi); strocnx/y are inout (other cells keep their value).
+ * ------------------------------------------------------------------- */
+void evp_oracle_dyn_finish(const evp_oracle_domain *d, const evp_oracle_params *p, const double *Cw,
+                           const double *uvel, const double *vvel, const double *uocn,
+                           const double *vocn, const double *aiX, const double *fm,
+                           const int32_t *iceUmask, double *strocnx, double *strocny)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t nb = (size_t)nx * ny;
+    for (int b = 0; b < d->nblocks; ++b)
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const size_t c = b * nb + IX(i, j);
+                if (!iceUmask[c]) continue;
+                double du = uocn[c] - uvel[c], dv = vocn[c] - vvel[c];
+                double vrel = p->rhow * Cw[c] * sqrt(du * du + dv * dv);
+                vrel = vrel * aiX[c];
+                strocnx[c] = vrel * ((uocn[c] - uvel[c]) * p->cosw - (vocn[c] - vvel[c]) * p->sinw * copysign(1.0, fm[c]));
+                strocny[c] = vrel * ((vocn[c] - vvel[c]) * p->cosw + (uocn[c] - uvel[c]) * p->sinw * copysign(1.0, fm[c]));
+            }
+}

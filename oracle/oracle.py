@@ -158,3 +158,30 @@ def subcycle(dom: OracleDomain, params: Params, ndte: int, dyn: dict, static: di
                               tm.ctypes.data_as(C.POINTER(C.c_int32)),
                               um.ctypes.data_as(C.POINTER(C.c_int32)))
     return work
+
+
+def deformations(dom: OracleDomain, params: Params, uvel, vvel, static: dict, geo: dict, iceTmask) -> dict:
+    """deformations (ice_dyn_shared.F90:1756-1860).  geo: dxU, dyU, tarear."""
+    lib().evp_oracle_deformations.restype = None
+    names = ["vort", "shear", "divu", "rdg_conv", "rdg_shear"]
+    out = {n: np.zeros(dom.shape) for n in names}
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in
+         (uvel, vvel, static["dxT"], static["dyT"], geo["dxU"], geo["dyU"], static["cxp"], static["cyp"],
+          static["cxm"], static["cym"], geo["tarear"])]
+    tm = np.ascontiguousarray(iceTmask, dtype=np.int32)
+    lib().evp_oracle_deformations(C.byref(dom.c), C.byref(params), *[_dp(x) for x in a],
+                                  tm.ctypes.data_as(C.POINTER(C.c_int32)), *[_dp(out[n]) for n in names])
+    return out
+
+
+def dyn_finish(dom: OracleDomain, params: Params, dyn: dict, uvel, vvel, iceUmask, strocnx, strocny) -> dict:
+    """dyn_finish (ice_dyn_shared.F90:1291-1365); strocnx/y are inout."""
+    lib().evp_oracle_dyn_finish.restype = None
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in
+         (dyn["cdn_ocnU"], uvel, vvel, dyn["uocnU"], dyn["vocnU"], dyn["aiU"], dyn["fmU"])]
+    um = np.ascontiguousarray(iceUmask, dtype=np.int32)
+    sx = np.array(strocnx, dtype=np.float64, order="C", copy=True)
+    sy = np.array(strocny, dtype=np.float64, order="C", copy=True)
+    lib().evp_oracle_dyn_finish(C.byref(dom.c), C.byref(params), *[_dp(x) for x in a],
+                                um.ctypes.data_as(C.POINTER(C.c_int32)), _dp(sx), _dp(sy))
+    return dict(strocnxU=sx, strocnyU=sy)

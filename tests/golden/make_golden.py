@@ -28,7 +28,7 @@ from cice_amd import synth  # noqa: E402
 OUT = Path(__file__).resolve().parent
 
 STATIC = ["HTE", "HTN", "dxT", "dyT", "tarea", "uarear", "cxp", "cyp", "cxm", "cym", "dxhy", "dyhx",
-          "DminTarea"]
+          "DminTarea", "dxU", "dyU", "tarear"]   # the last three: deformations (next tier f-1)
 
 CASES = {
     # name: (nx, ny, bx, by, ew, ns, harness kwargs)

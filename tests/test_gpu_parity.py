@@ -258,3 +258,25 @@ def test_tx1_size_tripole_vs_reference_harness(tmp_path):
         assert np.abs(out["uvel"]).max() > 1e-3
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_next_tier_deformations_and_dyn_finish_bitwise(name):
+    """deformations + dyn_finish computed on the device from the resident
+    final velocities, against the reference's own outputs of the same evp() call."""
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        core.set_post_geometry(c.d["dxU"], c.d["dyU"], c.d["tarear"])
+        for icall in range(1, c.ncalls + 1):
+            dyn, tm, um = c.inputs(icall)
+            nsub = c.nsub_list[-1]
+            core.upload(dyn, tm, um)
+            core.subcycle(nsub)
+            got = core.deformations()
+            z = np.zeros(core.shape)
+            got.update(core.dyn_finish(z, z))
+            want = {k: c.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in got}
+            assert_bitwise(got, want, f"{name} call {icall} deformations/dyn_finish")
+    finally:
+        core.finalize()

@@ -78,3 +78,21 @@ def test_halo_known_answer_global_index():
             a[b.local][m] = -999.0
         oracle.halo_update(dom, a, "NEcorner", "vector")
         assert np.array_equal(a, ref), (ew, ns)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_next_tier_deformations_dyn_finish_bitwise(name):
+    """the oracle's deformations / dyn_finish against the reference's outputs
+    of the same evp() call (computed from the reference's final velocities)."""
+    c = GoldenCase(name)
+    dom, prm, st = c.oracle_domain(), c.oracle_params(), c.static()
+    geo = {k: c.d[k] for k in ("dxU", "dyU", "tarear")}
+    for icall in range(1, c.ncalls + 1):
+        dyn, tm, um = c.inputs(icall)
+        for nsub in c.nsub_list:
+            tag = f"o{icall:02d}n{nsub:04d}_"
+            u, v = c.d[tag + "uvel"], c.d[tag + "vvel"]
+            got = oracle.deformations(dom, prm, u, v, st, geo, tm)
+            z = np.zeros_like(u)
+            got.update(oracle.dyn_finish(dom, prm, dyn, u, v, um, z, z))
+            assert_bitwise(got, {k: c.d[tag + k] for k in got}, f"{name} call {icall} nsub {nsub} f-1")
