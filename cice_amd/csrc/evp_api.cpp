@@ -74,7 +74,7 @@ struct State {
     int device = 0;
     size_t plane = 0, n = 0;     // nx*ny, nx*ny*nblocks
     int max_ni = 0, max_nj = 0;
-    int tyb = 5;
+    int tyb = 4;
     bool tyb_forced = false, tuned = false;
     hipStream_t stream = nullptr, stream_comm = nullptr;
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
@@ -630,7 +630,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         S.max_ni = std::max(S.max_ni, S.ihi[b] - S.ilo[b] + 1);
         S.max_nj = std::max(S.max_nj, S.jhi[b] - S.jlo[b] + 1);
     }
-    S.tyb = 5;
+    S.tyb = 4;
     if (env("CICE_EVP_HIP_TYB")) {
         const int t = std::atoi(env("CICE_EVP_HIP_TYB"));   // tile height [+100: XCD-contiguous order]
         S.tyb = (t % 100 >= 2 && t % 100 <= 9) ? t : 5 + 100 * (t / 100);
@@ -732,7 +732,9 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
         // the real state (results are identical for every tile shape; only speed differs).
         // The launches write the ping-pong "next" buffers, which the first real subcycle
         // overwrites, so the state is not advanced.
-        const int cand[9] = {3, 5, 9, 103, 105, 109, 203, 205, 209};
+        // tile heights whose wave count fills the 4 SIMDs evenly (4, 8) plus 3; odd wave counts
+        // (5, 9) leave one SIMD with twice the work and measured 1.5-2x slower
+        const int cand[9] = {4, 8, 3, 104, 108, 103, 204, 208, 203};
         float best = 1e30f;
         int best_t = 5;
         EvpArgs A;

@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo/oracle')
+import pathlib; R=str(pathlib.Path(__file__).resolve().parents[1]); sys.path[:0]=[R, R+'/tests', R+'/oracle']
 import numpy as np
 from cice_amd import evp, synth, decomp
 from test_gpu_parity import synth_case
