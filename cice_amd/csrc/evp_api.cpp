@@ -123,6 +123,16 @@ struct State {
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, cur) -> captured loop
     bool use_graph = true;
 
+    // on-chip resident subcycle (evp_resident.hip)
+    int res_mode = -1;           // -1 undecided, 0 off, 1 on
+    bool res_forced = false;
+    int *res_flags = nullptr, *res_nbr = nullptr, *res_err = nullptr;
+    double **res_tab = nullptr;  // device pointer table (EvpResident::tab)
+    double *res_scratch[4] = {}; // u,v ping-pong copies for the dry probe
+    int res_ntiles = 0;
+    bool res_launched = false;   // an un-checked launch is in flight
+    double t_res_probe_ms = 0, t_stream_probe_ms = 0;
+
     double t_loop_ms = 0, t_h2d_ms = 0, t_d2h_ms = 0;
     int t_nsub = 0;
     std::vector<uint8_t> hmask;
@@ -155,6 +165,8 @@ void free_all()
     F(S.hte);
     F(S.htn);
     F(S.vrelfac);
+    F(S.res_flags); F(S.res_nbr); F(S.res_err); F(S.res_tab);
+    for (auto &p : S.res_scratch) F(p);
     for (auto &p : S.post_geo) F(p);
     for (auto &p : S.post_out) F(p);
     F(S.push);
@@ -415,6 +427,136 @@ int halo_uv(int b)
         NCCLC(ncclGroupEnd());
         evp_launch_halo_unpack(S.u[b], S.v[b], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
                                S.n_recv, S.stream);
+    }
+    return 0;
+}
+
+// ---- on-chip resident subcycle -------------------------------------------------------
+// Host side of evp_resident.hip: which tiles exchange velocities (producers == readers by
+// symmetry: the 8 surrounding tiles, with cyclic wrap through the ghost-cell images).
+bool resident_possible()
+{
+    if (S.d.nblocks != 1 || !S.plan.peers.empty()) return false;
+    if ((S.n_seam + S.n_pole + S.n_late) > 0) return false;          // tripole seam: streaming path
+    if (S.n_local > 0 && !S.push_ok) return false;
+    return true;
+}
+
+int resident_setup()
+{
+    if (S.res_nbr) return 0;
+    const int tyb = 4;
+    const int gx = (S.max_ni + 62) / 63, gy = (S.max_nj + tyb - 2) / (tyb - 1);
+    const int ntiles = gx * gy;
+    const int nx = S.d.nx_block, ny = S.d.ny_block;
+    const int ilo = S.ilo[0], ihi = S.ihi[0], jlo = S.jlo[0], jhi = S.jhi[0];
+    // producer of every cell of the (single) block: tile id, or -1 (never written)
+    std::vector<int> prod((size_t)nx * ny, -1);
+    for (int j = jlo; j <= jhi; ++j)
+        for (int i = ilo; i <= ihi; ++i)
+            prod[(size_t)(j - 1) * nx + (i - 1)] = ((j - jlo) / (tyb - 1)) * gx + (i - ilo) / 63;
+    for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
+        if (S.plan.local_src[k] >= 0) prod[S.plan.local_dst[k]] = prod[S.plan.local_src[k]];
+    std::vector<int> nbr((size_t)ntiles * EVP_RES_NNB, -1);
+    for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+            const int t = by * gx + bx;
+            int cnt = 0;
+            // velocities read by the T-cells of this tile: i0-1..i0+63, j0-1..j0+tyb-1
+            const int i0 = ilo + bx * 63, j0 = jlo + by * (tyb - 1);
+            for (int j = j0 - 1; j <= j0 + tyb - 1; ++j)
+                for (int i = i0 - 1; i <= i0 + 63; ++i) {
+                    if (i < 1 || i > nx || j < 1 || j > ny) continue;
+                    const int p = prod[(size_t)(j - 1) * nx + (i - 1)];
+                    if (p < 0 || p == t) continue;
+                    bool seen = false;
+                    for (int e = 0; e < cnt; ++e) seen |= nbr[(size_t)t * EVP_RES_NNB + e] == p;
+                    if (seen) continue;
+                    if (cnt >= EVP_RES_NNB) return fail(-6, "resident: too many neighbour tiles");
+                    nbr[(size_t)t * EVP_RES_NNB + cnt++] = p;
+                }
+        }
+    // symmetry (a reader must also be waited for before its input is overwritten)
+    for (int t = 0; t < ntiles; ++t)
+        for (int e = 0; e < EVP_RES_NNB; ++e) {
+            const int p = nbr[(size_t)t * EVP_RES_NNB + e];
+            if (p < 0) continue;
+            bool back = false;
+            int cntp = 0;
+            for (int f = 0; f < EVP_RES_NNB; ++f) {
+                back |= nbr[(size_t)p * EVP_RES_NNB + f] == t;
+                cntp += nbr[(size_t)p * EVP_RES_NNB + f] >= 0;
+            }
+            if (!back) {
+                if (cntp >= EVP_RES_NNB) return fail(-6, "resident: too many neighbour tiles");
+                nbr[(size_t)p * EVP_RES_NNB + cntp] = t;
+            }
+        }
+    S.res_ntiles = ntiles;
+    HIPC(hipMalloc((void **)&S.res_nbr, nbr.size() * sizeof(int)));
+    HIPC(hipMemcpy(S.res_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPC(hipMalloc((void **)&S.res_flags, (size_t)ntiles * sizeof(int)));
+    HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
+    HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+    return 0;
+}
+
+// every workgroup must be resident at once: occupancy query x CUs, with a margin
+bool resident_fits()
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
+    const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed), 8);
+    const long cap = (long)per_cu * prop.multiProcessorCount;
+    return S.res_ntiles > 0 && (long)S.res_ntiles * 10 <= cap * 9;
+}
+
+int launch_resident(int ndte, int cur0, bool dry)
+{
+    EvpArgs A;
+    fill_args(A, cur0, 1);
+    EvpResident R;
+    R.ndte = ndte;
+    R.cur0 = dry ? 0 : cur0;
+    R.dry = dry ? 1 : 0;
+    R.spin_limit = 4000000u;
+    R.flags = S.res_flags;
+    R.nbr = S.res_nbr;
+    R.err = S.res_err;
+    if (dry) {
+        R.u[0] = S.res_scratch[0]; R.v[0] = S.res_scratch[1];
+        R.u[1] = S.res_scratch[2]; R.v[1] = S.res_scratch[3];
+    } else {
+        R.u[0] = S.u[0]; R.v[0] = S.v[0]; R.u[1] = S.u[1]; R.v[1] = S.v[1];
+    }
+    {
+        double *tab[28];
+        for (int k = 0; k < 12; ++k) {
+            tab[k] = S.sig[dry ? cur0 : 0][k];
+            tab[12 + k] = S.sig[dry ? cur0 : 1][k];
+        }
+        tab[24] = S.in[F_STRINTX]; tab[25] = S.in[F_STRINTY]; tab[26] = S.in[F_TAUBX]; tab[27] = S.in[F_TAUBY];
+        if (!S.res_tab) HIPC(hipMalloc((void **)&S.res_tab, sizeof tab));
+        HIPC(hipMemcpyAsync(S.res_tab, tab, sizeof tab, hipMemcpyHostToDevice, S.stream));
+        HIPC(hipStreamSynchronize(S.stream));   // `tab` is a stack array
+        R.tab = S.res_tab;
+    }
+    HIPC(hipMemsetAsync(S.res_flags, 0, (size_t)S.res_ntiles * sizeof(int), S.stream));
+    evp_launch_resident(A, R, S.max_ni, S.max_nj, S.prm.strict != 0, cap_mode(), S.stream);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+int resident_check_error()
+{
+    if (!S.res_launched) return 0;
+    S.res_launched = false;
+    int e = 0;
+    HIPC(hipMemcpy(&e, S.res_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+        S.res_mode = 0;
+        return fail(-7, "resident EVP kernel: a neighbour-flag wait timed out (workgroups not co-resident?)");
     }
     return 0;
 }
@@ -752,8 +894,46 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
         }
         S.tyb = best_t;
         S.tuned = true;
+        S.t_stream_probe_ms = best / 8.0;
         for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);
         S.graphs.clear();
+    }
+    // on-chip resident subcycle: use it when it fits and a dry probe on scratch velocities
+    // (same work, nothing written back) runs clean and faster than the streaming kernel
+    if (S.res_mode < 0) {
+        S.res_mode = 0;
+        int want = -1;
+        if (env("CICE_EVP_HIP_RESIDENT")) want = std::atoi(env("CICE_EVP_HIP_RESIDENT"));
+        if (want != 0 && resident_possible()) {
+            if (int rc = resident_setup()) { if (want == 1) return rc; }
+            else if (resident_fits()) {
+                for (auto &p : S.res_scratch)
+                    if (!p && alloc_d(&p, S.n)) return -1;
+                const int nprobe = 8;
+                float tres = 1e30f;
+                bool ok = true;
+                for (int rep = 0; rep < 2 && ok; ++rep) {
+                    HIPC(hipMemcpyAsync(S.res_scratch[0], S.u[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+                    HIPC(hipMemcpyAsync(S.res_scratch[1], S.v[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+                    HIPC(hipMemcpyAsync(S.res_scratch[2], S.u[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+                    HIPC(hipMemcpyAsync(S.res_scratch[3], S.v[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+                    HIPC(hipEventRecord(S.ev2, S.stream));
+                    if (int rc = launch_resident(nprobe, S.cur, true)) return rc;
+                    HIPC(hipEventRecord(S.ev3, S.stream));
+                    HIPC(hipStreamSynchronize(S.stream));
+                    S.res_launched = true;
+                    if (resident_check_error()) { ok = false; break; }
+                    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+                    tres = ms / nprobe;
+                }
+                S.t_res_probe_ms = ok ? tres : -1.0;
+                if (ok && (want == 1 || S.t_stream_probe_ms <= 0.0 || tres < S.t_stream_probe_ms)) S.res_mode = 1;
+            } else if (want == 1) {
+                return fail(-6, "resident EVP kernel requested but its %d workgroups cannot be co-resident", S.res_ntiles);
+            }
+        } else if (want == 1) {
+            return fail(-6, "resident EVP kernel requested but not applicable (one block per rank, no remote halo, no tripole)");
+        }
     }
     return 0;
 }
@@ -764,6 +944,14 @@ int cice_evp_hip_subcycle(int32_t ndte)
     if (ndte < 0) return fail(-1, "ndte < 0");
     if (ndte == 0) return 0;
     HIPC(hipEventRecord(S.ev0, S.stream));
+    if (S.res_mode == 1) {
+        if (int rc = launch_resident(ndte, S.cur, false)) return rc;
+        S.res_launched = true;
+        HIPC(hipEventRecord(S.ev1, S.stream));
+        S.cur ^= (ndte & 1);
+        S.t_nsub = ndte;
+        return 0;
+    }
     // RCCL p2p inside a captured graph: opt-in (CICE_EVP_HIP_GRAPH_RCCL=1) until measured on a multi-GPU node
     static const bool graph_rccl = env("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env("CICE_EVP_HIP_GRAPH_RCCL"));
     const bool graph_ok = S.use_graph && (S.plan.peers.empty() || graph_rccl);
@@ -861,12 +1049,14 @@ int cice_evp_hip_sync(void)
 {
     if (!S.ready) return fail(-1, "not initialised");
     HIPC(hipStreamSynchronize(S.stream));
-    return 0;
+    return resident_check_error();
 }
 
 int cice_evp_hip_download(double *const *f)
 {
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    HIPC(hipStreamSynchronize(S.stream));
+    if (int rc = resident_check_error()) return rc;
     HIPC(hipEventRecord(S.ev2, S.stream));
     for (int k = 0; k < 12; ++k)
         if (f[k] && d2h(f[k], S.sig[S.cur][k])) return -1;
@@ -922,11 +1112,11 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     if (S.ready && S.marked[0] && S.marked[1] && hipEventQuery(S.evm[1]) == hipSuccess &&
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
-    const double v[7] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+    const double v[9] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : 2.0) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
-                         (double)S.tyb, marks_ms};
-    for (int k = 0; k < n && k < 7; ++k) out[k] = v[k];
+                         (double)(S.res_mode == 1 ? 1000 + 4 : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms};
+    for (int k = 0; k < n && k < 9; ++k) out[k] = v[k];
     return 0;
 }
 

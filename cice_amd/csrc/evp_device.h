@@ -47,6 +47,25 @@ struct EvpArgs {
     double *strintx, *strinty, *taubx, *tauby;
 };
 
+// On-chip resident subcycle (evp_resident.hip)
+#define EVP_RES_NNB 12
+struct EvpResident {
+    int ndte;
+    int cur0;                  // which ping-pong buffer holds the input velocities
+    int dry;                   // 1: timing / residency probe on scratch velocities, nothing written back
+    unsigned spin_limit;
+    int *flags;                // [ntiles] completed subcycles per tile, zeroed before the launch
+    const int *nbr;            // [ntiles][EVP_RES_NNB] tiles this tile exchanges velocities with, -1 padded
+    int *err;                  // set non-zero when a spin gave up
+    double *u[2], *v[2];
+    // pointer table in device memory (keeps 28 pointers out of the kernel's SGPR budget):
+    // [0..11] sig buffer 0, [12..23] sig buffer 1, [24..27] strintx strinty taubx tauby
+    double *const *tab;
+};
+int evp_resident_max_blocks_per_cu(bool strict, int cap, unsigned flags);
+void evp_launch_resident(const EvpArgs &A, const EvpResident &R, int max_ni, int max_nj, bool strict,
+                         int cap, hipStream_t st);
+
 enum : unsigned {
     EVP_F_METRICS = 1u,     // recompute cxp..DminTarea from HTE,HTN,dxT,dyT (tarea == dxT*dyT verified)
     EVP_F_WATER_IS_OCN = 2u,// waterxU==uocnU and wateryU==vocnU bit for bit on every active U-cell

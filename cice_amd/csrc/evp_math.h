@@ -1,0 +1,66 @@
+// Device-side arithmetic shared by evp_kernels.hip (streaming tiles) and
+// evp_resident.hip (on-chip resident subcycle): constants, the two builds of the
+// per-cell formulas (strict / fused) and a traits struct selecting between them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "evp_device.h"
+
+namespace {
+
+// shared/ice_constants.F90:79-85
+__device__ constexpr double p027 = 1.0 / 36.0;
+__device__ constexpr double p055 = 1.0 / 18.0;
+__device__ constexpr double p111 = 1.0 / 9.0;
+__device__ constexpr double p166 = 1.0 / 6.0;
+__device__ constexpr double p222 = 2.0 / 9.0;
+__device__ constexpr double p25 = 0.25;
+__device__ constexpr double p333 = 1.0 / 3.0;
+__device__ constexpr double p5 = 0.5;
+__device__ constexpr double c1p5 = 1.5;
+
+}  // namespace
+
+#pragma clang fp contract(off)
+namespace evp_strict {
+#include "evp_cell.inc"
+}
+#pragma clang fp contract(fast)
+namespace evp_fused {
+#include "evp_cell.inc"
+}
+
+namespace {
+
+template <bool STRICT> struct Math;
+template <> struct Math<true> {
+    using SI = evp_strict::StressIn;
+    using UI = evp_strict::StepuIn;
+    using UO = evp_strict::StepuOut;
+    template <int CAP>
+    static __device__ __forceinline__ void stress(const EvpScalars &p, const SI &a, double (&s)[12], double (&str)[8])
+    {
+        evp_strict::stress_cell<CAP>(p, a, s, str);
+    }
+    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_strict::stepu_cell(p, a, o); }
+    static __device__ __forceinline__ void metrics(double hte, double hte_im, double htn, double htn_jm, double dmin, SI &a)
+    {
+        evp_strict::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);
+    }
+};
+template <> struct Math<false> {
+    using SI = evp_fused::StressIn;
+    using UI = evp_fused::StepuIn;
+    using UO = evp_fused::StepuOut;
+    template <int CAP>
+    static __device__ __forceinline__ void stress(const EvpScalars &p, const SI &a, double (&s)[12], double (&str)[8])
+    {
+        evp_fused::stress_cell<CAP>(p, a, s, str);
+    }
+    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_fused::stepu_cell(p, a, o); }
+    static __device__ __forceinline__ void metrics(double hte, double hte_im, double htn, double htn_jm, double dmin, SI &a)
+    {
+        evp_fused::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);
+    }
+};
+
+}  // namespace

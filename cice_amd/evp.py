@@ -193,10 +193,10 @@ class EvpHip:
         return out
 
     def timings(self) -> dict:
-        t = np.zeros(7)
-        self.lib.cice_evp_hip_get_timings(_dp(t), 7)
+        t = np.zeros(9)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 9)
         return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4],
-                    tile_variant=int(t[5]), marks_ms=t[6])
+                    tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8])
 
     def mark(self, which: int):
         _check(self.lib, self.lib.cice_evp_hip_mark(C.c_int32(which)), "(dyn_evp_hip_mark)")

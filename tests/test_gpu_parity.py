@@ -280,3 +280,45 @@ def test_next_tier_deformations_and_dyn_finish_bitwise(name):
             assert_bitwise(got, want, f"{name} call {icall} deformations/dyn_finish")
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("grid,case,warm", [("gx3", "full", True), ("gx1", "full", True), ("gx1", "caps", False)])
+def test_resident_kernel_bitwise(grid, case, warm, monkeypatch):
+    """The on-chip resident subcycle (one launch for all ndte subcycles, stresses and operands
+    kept in registers/LDS, velocities exchanged through L2 with neighbour flags) against the
+    oracle (12 subcycles) and against the streaming kernel (120 subcycles), bit for bit."""
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case(grid, case, seed=5, warm=warm)
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 12)
+    assert_bitwise(got, want, f"{grid}/{case} resident vs oracle")
+    res = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=121)     # odd count: parity flip
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
+    stream = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=121)
+    assert_bitwise(res, stream, f"{grid}/{case} resident vs streaming, 121 subcycles")
+    assert np.abs(res["uvel"]).max() > 1e-3
+
+
+def test_resident_kernel_golden_and_modes(monkeypatch):
+    c = GoldenCase("pop_cyc_1blk_patchy")
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", mode)
+        core = hip_from_case(c, strict=True)
+        try:
+            dyn, tm, um = c.inputs(1)
+            for nsub in c.nsub_list:
+                assert_bitwise(core.run(dyn, tm, um, ndte=nsub), c.expected(1, nsub), f"resident={mode} nsub {nsub}")
+            assert (core.timings()["tile_variant"] >= 1000) == (mode == "1")
+        finally:
+            core.finalize()
+    # multi-block domains are not eligible: forcing it fails loudly
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    c2 = GoldenCase("rect_cyc_2x2_full")
+    core = hip_from_case(c2, strict=True)
+    try:
+        dyn, tm, um = c2.inputs(1)
+        with pytest.raises(evp.EvpHipError):
+            core.run(dyn, tm, um, ndte=2)
+    finally:
+        core.finalize()
