@@ -221,6 +221,7 @@ def main():
                                         f"{dc.block_size_x}x{dc.block_size_y} cells each",
                        "us_per_subcycle": 1e3 * ms_step / ndte, "tile_variant": tm_ev["tile_variant"],
                        "launches_per_subcycle": tm_ev["launches_per_subcycle"],
+                       "autotune_probe_us": {"streaming": 1e3 * tm_ev["stream_probe_ms"], "resident": 1e3 * tm_ev["resident_probe_ms"]},
                        "finite": finite, "max_abs_u": umax},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a),

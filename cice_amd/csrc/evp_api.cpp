@@ -129,7 +129,7 @@ struct State {
     int *res_flags = nullptr, *res_nbr = nullptr, *res_err = nullptr;
     double **res_tab = nullptr;  // device pointer table (EvpResident::tab)
     double *res_scratch[4] = {}; // u,v ping-pong copies for the dry probe
-    int res_ntiles = 0;
+    int res_ntiles = 0, res_logw = 6;
     bool res_launched = false;   // an un-checked launch is in flight
     double t_res_probe_ms = 0, t_stream_probe_ms = 0;
 
@@ -442,11 +442,15 @@ bool resident_possible()
     return true;
 }
 
-int resident_setup()
+int resident_setup(int logw)
 {
-    if (S.res_nbr) return 0;
-    const int tyb = 4;
-    const int gx = (S.max_ni + 62) / 63, gy = (S.max_nj + tyb - 2) / (tyb - 1);
+    if (S.res_nbr && S.res_logw == logw) return 0;
+    if (S.res_nbr) { (void)hipFree(S.res_nbr); S.res_nbr = nullptr; }
+    if (S.res_flags) { (void)hipFree(S.res_flags); S.res_flags = nullptr; }
+    S.res_logw = logw;
+    const int W = 1 << logw, H = 256 / W;
+    int gx, gy;
+    evp_resident_geometry(S.max_ni, S.max_nj, logw, &gx, &gy);
     const int ntiles = gx * gy;
     const int nx = S.d.nx_block, ny = S.d.ny_block;
     const int ilo = S.ilo[0], ihi = S.ihi[0], jlo = S.jlo[0], jhi = S.jhi[0];
@@ -454,7 +458,7 @@ int resident_setup()
     std::vector<int> prod((size_t)nx * ny, -1);
     for (int j = jlo; j <= jhi; ++j)
         for (int i = ilo; i <= ihi; ++i)
-            prod[(size_t)(j - 1) * nx + (i - 1)] = ((j - jlo) / (tyb - 1)) * gx + (i - ilo) / 63;
+            prod[(size_t)(j - 1) * nx + (i - 1)] = ((j - jlo) / (H - 1)) * gx + (i - ilo) / (W - 1);
     for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
         if (S.plan.local_src[k] >= 0) prod[S.plan.local_dst[k]] = prod[S.plan.local_src[k]];
     std::vector<int> nbr((size_t)ntiles * EVP_RES_NNB, -1);
@@ -462,10 +466,10 @@ int resident_setup()
         for (int bx = 0; bx < gx; ++bx) {
             const int t = by * gx + bx;
             int cnt = 0;
-            // velocities read by the T-cells of this tile: i0-1..i0+63, j0-1..j0+tyb-1
-            const int i0 = ilo + bx * 63, j0 = jlo + by * (tyb - 1);
-            for (int j = j0 - 1; j <= j0 + tyb - 1; ++j)
-                for (int i = i0 - 1; i <= i0 + 63; ++i) {
+            // velocities read by the T-cells of this tile: i0-1..i0+W-1, j0-1..j0+H-1
+            const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
+            for (int j = j0 - 1; j <= j0 + H - 1; ++j)
+                for (int i = i0 - 1; i <= i0 + W - 1; ++i) {
                     if (i < 1 || i > nx || j < 1 || j > ny) continue;
                     const int p = prod[(size_t)(j - 1) * nx + (i - 1)];
                     if (p < 0 || p == t) continue;
@@ -496,8 +500,10 @@ int resident_setup()
     HIPC(hipMalloc((void **)&S.res_nbr, nbr.size() * sizeof(int)));
     HIPC(hipMemcpy(S.res_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPC(hipMalloc((void **)&S.res_flags, (size_t)ntiles * sizeof(int)));
-    HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
-    HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+    if (!S.res_err) {
+        HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
+        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+    }
     return 0;
 }
 
@@ -506,7 +512,7 @@ bool resident_fits()
 {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
-    const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed), 8);
+    const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed, S.res_logw), 8);
     const long cap = (long)per_cu * prop.multiProcessorCount;
     return S.res_ntiles > 0 && (long)S.res_ntiles * 10 <= cap * 9;
 }
@@ -520,6 +526,8 @@ int launch_resident(int ndte, int cur0, bool dry)
     R.cur0 = dry ? 0 : cur0;
     R.dry = dry ? 1 : 0;
     R.spin_limit = 4000000u;
+    R.xcdmap = env("CICE_EVP_HIP_RES_XCD") ? std::atoi(env("CICE_EVP_HIP_RES_XCD")) : 0;
+    R.dbg = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.flags = S.res_flags;
     R.nbr = S.res_nbr;
     R.err = S.res_err;
@@ -529,20 +537,23 @@ int launch_resident(int ndte, int cur0, bool dry)
     } else {
         R.u[0] = S.u[0]; R.v[0] = S.v[0]; R.u[1] = S.u[1]; R.v[1] = S.v[1];
     }
-    {
-        double *tab[28];
-        for (int k = 0; k < 12; ++k) {
-            tab[k] = S.sig[dry ? cur0 : 0][k];
-            tab[12 + k] = S.sig[dry ? cur0 : 1][k];
+    if (!S.res_tab) {
+        // three pointer tables, uploaded once: [0] real run, [1]/[2] dry probe reading sig[0]/sig[1]
+        double *tab[3][28];
+        for (int v = 0; v < 3; ++v) {
+            for (int k = 0; k < 12; ++k) {
+                tab[v][k] = S.sig[v == 0 ? 0 : v - 1][k];
+                tab[v][12 + k] = S.sig[v == 0 ? 1 : v - 1][k];
+            }
+            tab[v][24] = S.in[F_STRINTX]; tab[v][25] = S.in[F_STRINTY];
+            tab[v][26] = S.in[F_TAUBX]; tab[v][27] = S.in[F_TAUBY];
         }
-        tab[24] = S.in[F_STRINTX]; tab[25] = S.in[F_STRINTY]; tab[26] = S.in[F_TAUBX]; tab[27] = S.in[F_TAUBY];
-        if (!S.res_tab) HIPC(hipMalloc((void **)&S.res_tab, sizeof tab));
-        HIPC(hipMemcpyAsync(S.res_tab, tab, sizeof tab, hipMemcpyHostToDevice, S.stream));
-        HIPC(hipStreamSynchronize(S.stream));   // `tab` is a stack array
-        R.tab = S.res_tab;
+        HIPC(hipMalloc((void **)&S.res_tab, sizeof tab));
+        HIPC(hipMemcpy(S.res_tab, tab, sizeof tab, hipMemcpyHostToDevice));
     }
+    R.tab = S.res_tab + (dry ? 28 * (1 + cur0) : 0);
     HIPC(hipMemsetAsync(S.res_flags, 0, (size_t)S.res_ntiles * sizeof(int), S.stream));
-    evp_launch_resident(A, R, S.max_ni, S.max_nj, S.prm.strict != 0, cap_mode(), S.stream);
+    evp_launch_resident(A, R, S.max_ni, S.max_nj, S.res_logw, S.prm.strict != 0, cap_mode(), S.stream);
     HIPC(hipGetLastError());
     return 0;
 }
@@ -905,31 +916,46 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
         int want = -1;
         if (env("CICE_EVP_HIP_RESIDENT")) want = std::atoi(env("CICE_EVP_HIP_RESIDENT"));
         if (want != 0 && resident_possible()) {
-            if (int rc = resident_setup()) { if (want == 1) return rc; }
-            else if (resident_fits()) {
+            int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
+            float best = 1e30f;
+            int best_w = 0;
+            bool any_fit = false;
+            for (int logw : {5, 4, 6}) {
+                if (forced_w && logw != forced_w) continue;
+                if (resident_setup(logw)) { if (want == 1) return -6; continue; }
+                if (!resident_fits()) continue;
+                any_fit = true;
                 for (auto &p : S.res_scratch)
                     if (!p && alloc_d(&p, S.n)) return -1;
-                const int nprobe = 8;
-                float tres = 1e30f;
+                // steady-state cost per subcycle = slope between a short and a long dry run
+                // (launch, prologue and epilogue are paid once per evp() call)
+                const int nshort = 8, nlong = 40;
+                float tres = 1e30f, tl[2] = {0, 0};
                 bool ok = true;
-                for (int rep = 0; rep < 2 && ok; ++rep) {
-                    HIPC(hipMemcpyAsync(S.res_scratch[0], S.u[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-                    HIPC(hipMemcpyAsync(S.res_scratch[1], S.v[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-                    HIPC(hipMemcpyAsync(S.res_scratch[2], S.u[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-                    HIPC(hipMemcpyAsync(S.res_scratch[3], S.v[S.cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+                for (int rep = 0; rep < 3 && ok; ++rep) {
+                    const int np = (rep == 2) ? nlong : nshort;      // rep 0 warms up
+                    for (int q = 0; q < 4; ++q)
+                        HIPC(hipMemcpyAsync(S.res_scratch[q], (q & 1) ? S.v[S.cur] : S.u[S.cur], S.n * sizeof(double),
+                                            hipMemcpyDeviceToDevice, S.stream));
                     HIPC(hipEventRecord(S.ev2, S.stream));
-                    if (int rc = launch_resident(nprobe, S.cur, true)) return rc;
+                    if (int rc = launch_resident(np, S.cur, true)) return rc;
                     HIPC(hipEventRecord(S.ev3, S.stream));
                     HIPC(hipStreamSynchronize(S.stream));
                     S.res_launched = true;
                     if (resident_check_error()) { ok = false; break; }
                     HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
-                    tres = ms / nprobe;
+                    if (rep >= 1) tl[rep - 1] = ms;
                 }
-                S.t_res_probe_ms = ok ? tres : -1.0;
-                if (ok && (want == 1 || S.t_stream_probe_ms <= 0.0 || tres < S.t_stream_probe_ms)) S.res_mode = 1;
+                if (ok) tres = (tl[1] - tl[0]) / (nlong - nshort);
+                if (ok && tres < best) { best = tres; best_w = logw; }
+            }
+            S.t_res_probe_ms = best_w ? best : -1.0;
+            if (best_w && (want == 1 || S.t_stream_probe_ms <= 0.0 || best < S.t_stream_probe_ms)) {
+                if (int rc = resident_setup(best_w)) return rc;
+                S.res_mode = 1;
             } else if (want == 1) {
-                return fail(-6, "resident EVP kernel requested but its %d workgroups cannot be co-resident", S.res_ntiles);
+                return fail(-6, any_fit ? "resident EVP kernel requested but its probe failed"
+                                        : "resident EVP kernel requested but its workgroups cannot be co-resident");
             }
         } else if (want == 1) {
             return fail(-6, "resident EVP kernel requested but not applicable (one block per rank, no remote halo, no tripole)");
@@ -1115,7 +1141,7 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     const double v[9] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : 2.0) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
-                         (double)(S.res_mode == 1 ? 1000 + 4 : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms};
+                         (double)(S.res_mode == 1 ? 1000 + S.res_logw : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms};
     for (int k = 0; k < n && k < 9; ++k) out[k] = v[k];
     return 0;
 }

@@ -54,6 +54,8 @@ struct EvpResident {
     int cur0;                  // which ping-pong buffer holds the input velocities
     int dry;                   // 1: timing / residency probe on scratch velocities, nothing written back
     unsigned spin_limit;
+    int xcdmap;                // 1: contiguous band of tiles per XCD
+    int dbg;                   // experiments only: bit0 skip neighbour waits, bit1 skip store drain (WRONG results)
     int *flags;                // [ntiles] completed subcycles per tile, zeroed before the launch
     const int *nbr;            // [ntiles][EVP_RES_NNB] tiles this tile exchanges velocities with, -1 padded
     int *err;                  // set non-zero when a spin gave up
@@ -62,9 +64,11 @@ struct EvpResident {
     // [0..11] sig buffer 0, [12..23] sig buffer 1, [24..27] strintx strinty taubx tauby
     double *const *tab;
 };
-int evp_resident_max_blocks_per_cu(bool strict, int cap, unsigned flags);
-void evp_launch_resident(const EvpArgs &A, const EvpResident &R, int max_ni, int max_nj, bool strict,
-                         int cap, hipStream_t st);
+// logw: log2 of the tile width in T-cells (6, 5, 4 -> tiles of 64x4, 32x8, 16x16 T-cells)
+int evp_resident_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw);
+void evp_resident_geometry(int max_ni, int max_nj, int logw, int *gx, int *gy);
+void evp_launch_resident(const EvpArgs &A, const EvpResident &R, int max_ni, int max_nj, int logw,
+                         bool strict, int cap, hipStream_t st);
 
 enum : unsigned {
     EVP_F_METRICS = 1u,     // recompute cxp..DminTarea from HTE,HTN,dxT,dyT (tarea == dxT*dyT verified)

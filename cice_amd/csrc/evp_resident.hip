@@ -37,7 +37,7 @@ __device__ __forceinline__ void st_sc1(double *p, double v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool STRICT, int CAP>
+template <bool STRICT, int CAP, int LOGW>
 __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpResident R)
 {
     using MM = Math<STRICT>;
@@ -46,18 +46,35 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
     //   s_tc  [4][RTY][64]     T-cell constants read once per subcycle (strength, DminTarea, dxhy, dyhx)
     //   s_uc  [nu][RTY-1][64]  momentum-equation operands of the tile's U-cells (nu = 8..11)
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double(*s_str)[RTY][64] = reinterpret_cast<double(*)[RTY][64]>(smem);
-    double(*s_tc)[RTY][64] = reinterpret_cast<double(*)[RTY][64]>(smem + 4 * RTY * 64);
-    double(*s_uc)[RTY - 1][64] = reinterpret_cast<double(*)[RTY - 1][64]>(smem + 8 * RTY * 64);
+    double *s_str = smem;                  // [4][256]
+    double *s_tc = smem + 4 * 256;         // [4][256]
+    double *s_uc = smem + 8 * 256;         // [nu][256]
     __shared__ int s_bad;
 
+    // Tile = W x H T-cells, W*H = 256 (one per thread): lane -> (column, sub-row), wave -> row
+    // group.  W = 64 is one row per wave (512-byte segments); W = 32 / 16 are squarer tiles:
+    // fewer T-cells recomputed on the N/E fringe (256/(W-1)/(H-1): 1.35 / 1.18 / 1.14 per
+    // U-cell) and less waste in the last tile column.
+    constexpr int W = 1 << LOGW;
+    constexpr int H = 256 / W;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tile = blockIdx.x;
+    const int t = ty * 64 + tx;            // linear thread id == row*W + column
+    const int tcol = tx & (W - 1);
+    const int trow = t >> LOGW;
+    // workgroup w runs on XCD w % 8 (observed dispatch rule; speed only): give each XCD one
+    // contiguous band of tile rows, so that most neighbour tiles exchange velocities through
+    // the XCD's own L2 instead of across the fabric
+    int tile = blockIdx.x;
+    if (A.xcdmap) {
+        const int per = (A.ntiles + 7) >> 3;
+        tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (tile >= A.ntiles) return;
+    }
     const int bx = tile % A.gx;
     const int by = tile / A.gx;
     const int4 r = A.blk[0];
-    const int i = r.x + bx * 63 + tx;
-    const int j = r.z + by * (RTY - 1) + ty;
+    const int i = r.x + bx * (W - 1) + tcol;
+    const int j = r.z + by * (H - 1) + trow;
     const int nx = A.nx;
     const int c = (j - 1) * nx + (i - 1);
     const unsigned flags = A.flags;
@@ -68,8 +85,8 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
     unsigned m = 0;
     if (inT) m = A.mask[c];
     const bool actT = inT && (m & 1u);
-    const bool isU = (tx < 63) && (ty < RTY - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
-    const bool own = (tx < 63 || i == r.y + 1) && (ty < RTY - 1 || j == r.w + 1);
+    const bool isU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
+    const bool own = (tcol < W - 1 || i == r.y + 1) && (trow < H - 1 || j == r.w + 1);
 
     // ---- state that stays on the CU for the whole call -------------------------------------
     typename MM::SI a;
@@ -86,24 +103,24 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
             a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
             a.DminTarea = A.DminTarea[c];
         }
-        s_tc[0][ty][tx] = a.strength;
-        s_tc[1][ty][tx] = a.DminTarea;
-        s_tc[2][ty][tx] = a.dxhy;
-        s_tc[3][ty][tx] = a.dyhx;
+        s_tc[0 * 256 + t] = a.strength;
+        s_tc[1 * 256 + t] = a.DminTarea;
+        s_tc[2 * 256 + t] = a.dxhy;
+        s_tc[3 * 256 + t] = a.dyhx;
     }
     double u_own = 0.0, v_own = 0.0;
     if (isU) {
-        s_uc[0][ty][tx] = A.vrelfac[c];
-        s_uc[1][ty][tx] = A.uocn[c];
-        s_uc[2][ty][tx] = A.vocn[c];
-        s_uc[3][ty][tx] = A.forcex[c];
-        s_uc[4][ty][tx] = A.forcey[c];
-        s_uc[5][ty][tx] = A.umassdti[c];
-        s_uc[6][ty][tx] = A.fm[c];
-        s_uc[7][ty][tx] = A.uarear[c];
+        s_uc[0 * 256 + t] = A.vrelfac[c];
+        s_uc[1 * 256 + t] = A.uocn[c];
+        s_uc[2 * 256 + t] = A.vocn[c];
+        s_uc[3 * 256 + t] = A.forcex[c];
+        s_uc[4 * 256 + t] = A.forcey[c];
+        s_uc[5 * 256 + t] = A.umassdti[c];
+        s_uc[6 * 256 + t] = A.fm[c];
+        s_uc[7 * 256 + t] = A.uarear[c];
         int row = 8;
-        if (water) { s_uc[row][ty][tx] = A.waterx[c]; s_uc[row + 1][ty][tx] = A.watery[c]; row += 2; }
-        if (tbu) s_uc[row][ty][tx] = A.TbU[c];
+        if (water) { s_uc[row * 256 + t] = A.waterx[c]; s_uc[(row + 1) * 256 + t] = A.watery[c]; row += 2; }
+        if (tbu) s_uc[row * 256 + t] = A.TbU[c];
         u_own = R.u[R.cur0][c];
         v_own = R.v[R.cur0][c];
     }
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
             }
         }
     }
-    if (tx == 0 && ty == 0) s_bad = 0;
+    if (t == 0) s_bad = 0;
     __syncthreads();
 
     // ---- the subcycle loop (ice_dyn_evp.F90:859-913) ------------------------------------------
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
         double *uw = R.u[rb ^ 1];
         double *vw = R.v[rb ^ 1];
 
-        if (k > 0) {
+        if (k > 0 && !(R.dbg & 1)) {
             // wait until every tile this tile exchanges velocities with has finished
             // subcycle k-1 (a flag counts the subcycles its tile has completed)
             if (ty == 0 && tx < EVP_RES_NNB) {
@@ -170,16 +187,16 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
             a.u_im = ld_sc1(ur + c - 1); a.v_im = ld_sc1(vr + c - 1);
             a.u_jm = ld_sc1(ur + c - nx); a.v_jm = ld_sc1(vr + c - nx);
             a.u_mm = ld_sc1(ur + c - nx - 1); a.v_mm = ld_sc1(vr + c - nx - 1);
-            a.strength = s_tc[0][ty][tx]; a.DminTarea = s_tc[1][ty][tx];
-            a.dxhy = s_tc[2][ty][tx]; a.dyhx = s_tc[3][ty][tx];
+            a.strength = s_tc[0 * 256 + t]; a.DminTarea = s_tc[1 * 256 + t];
+            a.dxhy = s_tc[2 * 256 + t]; a.dyhx = s_tc[3 * 256 + t];
             MM::template stress<CAP>(A.p, a, s, str);
         }
         // partials for the U-cells of the row below go through LDS; the east neighbour's
         // partials (str 2,7) come from the next lane of the same wave
-        s_str[0][ty][tx] = str[2];
-        s_str[1][ty][tx] = str[5];
-        s_str[2][ty][tx] = str[3];
-        s_str[3][ty][tx] = str[7];
+        s_str[0 * 256 + t] = str[2];
+        s_str[1 * 256 + t] = str[5];
+        s_str[2 * 256 + t] = str[3];
+        s_str[3 * 256 + t] = str[7];
         const double sx1 = __shfl_down(str[1], 1);
         const double sy2 = __shfl_down(str[6], 1);
         __syncthreads();
@@ -188,19 +205,19 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
             typename MM::UI q;
             typename MM::UO o;
             q.uold = u_own; q.vold = v_own;
-            q.vrelfac = s_uc[0][ty][tx]; q.uocn = s_uc[1][ty][tx]; q.vocn = s_uc[2][ty][tx];
-            q.forcex = s_uc[3][ty][tx]; q.forcey = s_uc[4][ty][tx]; q.Umassdti = s_uc[5][ty][tx];
-            q.fm = s_uc[6][ty][tx]; q.uarear = s_uc[7][ty][tx];
+            q.vrelfac = s_uc[0 * 256 + t]; q.uocn = s_uc[1 * 256 + t]; q.vocn = s_uc[2 * 256 + t];
+            q.forcex = s_uc[3 * 256 + t]; q.forcey = s_uc[4 * 256 + t]; q.Umassdti = s_uc[5 * 256 + t];
+            q.fm = s_uc[6 * 256 + t]; q.uarear = s_uc[7 * 256 + t];
             int row = 8;
-            if (water) { q.waterx = s_uc[row][ty][tx]; q.watery = s_uc[row + 1][ty][tx]; row += 2; }
+            if (water) { q.waterx = s_uc[row * 256 + t]; q.watery = s_uc[(row + 1) * 256 + t]; row += 2; }
             else { q.waterx = q.uocn; q.watery = q.vocn; }
-            q.TbU = tbu ? s_uc[row][ty][tx] : 0.0;
+            q.TbU = tbu ? s_uc[row * 256 + t] : 0.0;
             q.uvel_init = A.p.revp != 0.0 ? A.uvel_init[c] : 0.0;
             q.vvel_init = A.p.revp != 0.0 ? A.vvel_init[c] : 0.0;
             q.sx0 = str[0]; q.sx1 = sx1;
-            q.sx2 = s_str[0][ty + 1][tx]; q.sx3 = s_str[2][ty + 1][tx + 1];
-            q.sy0 = str[4]; q.sy1 = s_str[1][ty + 1][tx];
-            q.sy2 = sy2; q.sy3 = s_str[3][ty + 1][tx + 1];
+            q.sx2 = s_str[0 * 256 + t + W]; q.sx3 = s_str[2 * 256 + t + W + 1];
+            q.sy0 = str[4]; q.sy1 = s_str[1 * 256 + t + W];
+            q.sy2 = sy2; q.sy3 = s_str[3 * 256 + t + W + 1];
             MM::stepu(A.p, q, o);
             u_own = o.u; v_own = o.v;
             st_sc1(uw + c, o.u);
@@ -214,9 +231,9 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
             }
         }
         // publish: all velocity stores of this workgroup are out of the CU, then the flag
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(R.dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tx == 0 && ty == 0)
+        if (t == 0)
             __hip_atomic_store(R.flags + tile, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
@@ -235,14 +252,14 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
 static size_t resident_lds_bytes(unsigned flags)
 {
     int nu = 8 + ((flags & EVP_F_WATER_IS_OCN) ? 0 : 2) + ((flags & EVP_F_TBU_ZERO) ? 0 : 1);
-    return sizeof(double) * 64 * (size_t)(8 * RTY + nu * (RTY - 1));
+    return sizeof(double) * 256 * (size_t)(8 + nu);
 }
 
-int evp_resident_max_blocks_per_cu(bool strict, int cap, unsigned flags)
+template <int LOGW>
+static int occ(bool strict, int cap, size_t lds)
 {
     int nb = 0;
-    const size_t lds = resident_lds_bytes(flags);
-#define EVP_OCC(S, C) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident_tile<S, C>, 64 * RTY, lds)
+#define EVP_OCC(S, C) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident_tile<S, C, LOGW>, 64 * RTY, lds)
     hipError_t e;
     if (strict) e = cap == 1 ? EVP_OCC(true, 1) : cap == 0 ? EVP_OCC(true, 0) : EVP_OCC(true, -1);
     else e = cap == 1 ? EVP_OCC(false, 1) : cap == 0 ? EVP_OCC(false, 0) : EVP_OCC(false, -1);
@@ -250,16 +267,25 @@ int evp_resident_max_blocks_per_cu(bool strict, int cap, unsigned flags)
     return e == hipSuccess ? nb : 0;
 }
 
-void evp_launch_resident(const EvpArgs &A0, const EvpResident &R, int max_ni, int max_nj, bool strict,
-                         int cap, hipStream_t st)
+int evp_resident_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw)
 {
-    EvpArgs A = A0;
-    A.gx = (max_ni + 62) / 63;
-    A.gy = (max_nj + RTY - 2) / (RTY - 1);
-    A.ntiles = A.gx * A.gy;
-    dim3 grid(A.ntiles), block(64, RTY);
+    const size_t lds = resident_lds_bytes(flags);
+    return logw == 4 ? occ<4>(strict, cap, lds) : logw == 5 ? occ<5>(strict, cap, lds) : occ<6>(strict, cap, lds);
+}
+
+void evp_resident_geometry(int max_ni, int max_nj, int logw, int *gx, int *gy)
+{
+    const int W = 1 << logw, H = 256 / W;
+    *gx = (max_ni + W - 2) / (W - 1);
+    *gy = (max_nj + H - 2) / (H - 1);
+}
+
+template <int LOGW>
+static void launch(const EvpArgs &A, const EvpResident &R, bool strict, int cap, hipStream_t st)
+{
+    dim3 grid(A.xcdmap ? ((A.ntiles + 7) / 8) * 8 : A.ntiles), block(64, RTY);
     const size_t lds = resident_lds_bytes(A.flags);
-#define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident_tile<S, C>), grid, block, lds, st, A, R)
+#define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident_tile<S, C, LOGW>), grid, block, lds, st, A, R)
     if (strict) {
         if (cap == 1) EVP_LAUNCH(true, 1);
         else if (cap == 0) EVP_LAUNCH(true, 0);
@@ -270,4 +296,16 @@ void evp_launch_resident(const EvpArgs &A0, const EvpResident &R, int max_ni, in
         else EVP_LAUNCH(false, -1);
     }
 #undef EVP_LAUNCH
+}
+
+void evp_launch_resident(const EvpArgs &A0, const EvpResident &R, int max_ni, int max_nj, int logw,
+                         bool strict, int cap, hipStream_t st)
+{
+    EvpArgs A = A0;
+    evp_resident_geometry(max_ni, max_nj, logw, &A.gx, &A.gy);
+    A.ntiles = A.gx * A.gy;
+    A.xcdmap = R.xcdmap;
+    if (logw == 4) launch<4>(A, R, strict, cap, st);
+    else if (logw == 5) launch<5>(A, R, strict, cap, st);
+    else launch<6>(A, R, strict, cap, st);
 }
