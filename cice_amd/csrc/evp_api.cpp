@@ -925,6 +925,7 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
                 if (resident_setup(logw)) { if (want == 1) return -6; continue; }
                 if (!resident_fits()) continue;
                 any_fit = true;
+                if (want == 1 && forced_w) { best = 0.0f; best_w = logw; break; }   // fully forced: no probe launches
                 for (auto &p : S.res_scratch)
                     if (!p && alloc_d(&p, S.n)) return -1;
                 // steady-state cost per subcycle = slope between a short and a long dry run
