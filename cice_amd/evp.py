@@ -40,7 +40,7 @@ EXPORTS = [
     "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
-    "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
+    "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
 ]
 
 _i32p = C.POINTER(C.c_int32)
@@ -155,6 +155,18 @@ class EvpHip:
         arrs = [self._c(m[k]) if k in m and m[k] is not None else None for k in order]
         rc = self.lib.cice_evp_hip_set_metrics(*[(_dp(a) if a is not None else None) for a in arrs])
         _check(self.lib, rc, "(dyn_evp_hip_set_metrics)")
+
+    def pin_host(self, *arrays):
+        """Page-lock caller-owned arrays that stay alive until finalize() (see the header)."""
+        for a in arrays:
+            _check(self.lib, self.lib.cice_evp_hip_pin_host(C.c_void_p(a.ctypes.data), C.c_int64(a.nbytes)),
+                   "(dyn_evp_hip_pin_host)")
+
+    def run_inplace(self, work: dict, tm, um, ndte: int | None = None):
+        """Like run() but directly on the caller's arrays (no copies): the Fortran call shape."""
+        args = [(_dp(work[k]) if k in work and work[k] is not None else None) for k in FIELDS]
+        rc = self.lib.cice_evp_hip_run(*args, _ip(tm), _ip(um), C.c_int32(self.ndte if ndte is None else ndte))
+        _check(self.lib, rc, "(dyn_evp_hip_run)")
 
     # -- dyn_evp1d_run equivalent ----------------------------------------------
     def run(self, fields: dict, iceTmask, iceUmask, ndte: int | None = None) -> dict:

@@ -83,6 +83,12 @@ module ice_dyn_evp_hip
        real(c_double), dimension(*), intent(in) :: dxhy, dyhx
      end function cice_evp_hip_set_metrics
 
+     integer(c_int) function cice_evp_hip_pin_host(ptr, bytes) bind(C, name='cice_evp_hip_pin_host')
+       import :: c_int, c_int64_t, c_double
+       real(c_double), dimension(*), intent(in) :: ptr
+       integer(c_int64_t), value :: bytes
+     end function cice_evp_hip_pin_host
+
      integer(c_int) function cice_evp_hip_finalize() bind(C, name='cice_evp_hip_finalize')
        import :: c_int
      end function cice_evp_hip_finalize
@@ -105,6 +111,7 @@ module ice_dyn_evp_hip
   end interface
 
   logical :: initialised = .false.
+  logical :: pinned = .false.
 
 contains
 
@@ -269,6 +276,13 @@ contains
     call c_f_pointer(c_loc(L_iceTmask), tmask_i, [size(L_iceTmask)])
     call c_f_pointer(c_loc(L_iceUmask), umask_i, [size(L_iceUmask)])
 
+    if (.not. pinned) then
+       ! CICE's module arrays live for the whole run: page-lock them once so that the
+       ! per-call H2D/D2H copies are direct DMA
+       call pin_all()
+       pinned = .true.
+    endif
+
     call ice_timer_start(timer_evp1dcore)
     call check(cice_evp_hip_run( &
          L_stressp_1, L_stressp_2, L_stressp_3, L_stressp_4, L_stressm_1, L_stressm_2, L_stressm_3, &
@@ -278,6 +292,25 @@ contains
          tmask_i, umask_i, int(ndte, c_int32_t)), subname, __FILE__, __LINE__)
     call ice_timer_stop(timer_evp1dcore)
 
+  contains
+
+    subroutine pin_one(a)
+      real(kind=dbl_kind), dimension(:,:,:), intent(in), contiguous :: a
+      integer(c_int) :: rc
+      rc = cice_evp_hip_pin_host(a, int(size(a), c_int64_t) * 8_c_int64_t)   ! best effort: a failure only costs speed
+    end subroutine pin_one
+
+    subroutine pin_all()
+      call pin_one(L_stressp_1);  call pin_one(L_stressp_2);  call pin_one(L_stressp_3);  call pin_one(L_stressp_4)
+      call pin_one(L_stressm_1);  call pin_one(L_stressm_2);  call pin_one(L_stressm_3);  call pin_one(L_stressm_4)
+      call pin_one(L_stress12_1); call pin_one(L_stress12_2); call pin_one(L_stress12_3); call pin_one(L_stress12_4)
+      call pin_one(L_strength);   call pin_one(L_cdn_ocn);    call pin_one(L_aiu);        call pin_one(L_uocn)
+      call pin_one(L_vocn);       call pin_one(L_waterxU);    call pin_one(L_wateryU);    call pin_one(L_forcexU)
+      call pin_one(L_forceyU);    call pin_one(L_umassdti);   call pin_one(L_fmU);        call pin_one(L_strintxU)
+      call pin_one(L_strintyU);   call pin_one(L_Tbu);        call pin_one(L_taubxU);     call pin_one(L_taubyU)
+      call pin_one(L_uvel);       call pin_one(L_vvel)
+    end subroutine pin_all
+
   end subroutine dyn_evp_hip_run
 
 !-----------------------------------------------------------------------
@@ -285,6 +318,7 @@ contains
     character(len=*), parameter :: subname = '(dyn_evp_hip_finalize)'
     if (initialised) call check(cice_evp_hip_finalize(), subname, __FILE__, __LINE__)
     initialised = .false.
+    pinned = .false.
   end subroutine dyn_evp_hip_finalize
 
 end module ice_dyn_evp_hip

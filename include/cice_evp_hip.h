@@ -117,6 +117,11 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
 
 int cice_evp_hip_finalize(void);
 
+/* Optional: page-lock a caller-owned host array that outlives the library's
+ * initialisation (CICE's module arrays), so that the copies of cice_evp_hip_run are
+ * direct DMA.  Idempotent per pointer; released by cice_evp_hip_finalize.          */
+int cice_evp_hip_pin_host(const void *ptr, int64_t bytes);
+
 /* ---- resident-state entry points (same work as _run, split in three so that
  *      a caller can keep the state in HBM across calls) ----------------------- */
 
