@@ -130,6 +130,13 @@ struct State {
     double **res_tab = nullptr;  // device pointer table (EvpResident::tab)
     double *res_scratch[4] = {}; // u,v ping-pong copies for the dry probe
     int res_ntiles = 0, res_logw = 6;
+    int res_gen = 1;             // 1: flags (evp_resident.hip), 2: tagged records (evp_resident2.hip)
+    int4 *res2_ring = nullptr;
+    int *res2_cnt = nullptr;
+    uint8_t *res2_pub = nullptr;
+    void *res2_rec[2] = {nullptr, nullptr};
+    int res2_logw = 0, res2_ntiles = 0;
+    unsigned res2_epoch = 0;
     bool res_launched = false;   // an un-checked launch is in flight
     double t_res_probe_ms = 0, t_stream_probe_ms = 0;
 
@@ -167,6 +174,7 @@ void free_all()
     F(S.htn);
     F(S.vrelfac);
     F(S.res_flags); F(S.res_nbr); F(S.res_err); F(S.res_tab);
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_rec[0]); F(S.res2_rec[1]);
     for (auto &p : S.res_scratch) F(p);
     for (auto &p : S.post_geo) F(p);
     for (auto &p : S.post_out) F(p);
@@ -510,6 +518,118 @@ int resident_setup(int logw)
     return 0;
 }
 
+// ---- second generation (evp_resident2.hip): ring lists and publish map of a tile shape ------
+// For every tile: the cells of its LDS velocity tile that it reads but does not produce itself
+// (ring + ghost/truncation cells), each with the record to poll and the U-cell that produces
+// it; and the map of U-cells some other tile mirrors (those publish a record each subcycle).
+// Geometry only -- independent of the ice masks.
+int resident2_setup(int logw)
+{
+    if (S.res2_ring && S.res2_logw == logw) return 0;
+    auto F = [](auto *&p) { if (p) (void)hipFree((void *)p); p = nullptr; };
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub);
+    S.res2_logw = logw;
+    const int W = 1 << logw, H = 256 / W, LW = W + 1;
+    int gx, gy;
+    evp_resident_geometry(S.max_ni, S.max_nj, logw, &gx, &gy);
+    const int ntiles = gx * gy;
+    const int nx = S.d.nx_block, ny = S.d.ny_block;
+    const int ilo = S.ilo[0], ihi = S.ihi[0], jlo = S.jlo[0], jhi = S.jhi[0];
+    std::vector<int> ghost_src((size_t)nx * ny, -1);
+    for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
+        if (S.plan.local_src[k] >= 0) ghost_src[S.plan.local_dst[k]] = S.plan.local_src[k];
+    std::vector<int4> ring((size_t)ntiles * EVP_RES2_RING, make_int4(-1, 0, -1, 0));
+    std::vector<int> cnt((size_t)ntiles, 0);
+    std::vector<uint8_t> pub((size_t)nx * ny, 0);
+    std::vector<char> seen((size_t)(H + 1) * LW);
+    for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+            const int t = by * gx + bx;
+            const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int trow = 0; trow < H; ++trow)
+                for (int tcol = 0; tcol < W; ++tcol) {
+                    const int i = i0 + tcol, j = j0 + trow;
+                    if (i > ihi + 1 || j > jhi + 1) continue;          // T-cell not computed
+                    for (int q = 0; q < 4; ++q) {
+                        const int di = -(q & 1), dj = -(q >> 1);
+                        const int pc = tcol + di, pr = trow + dj, pi = i + di, pj = j + dj;
+                        const bool interior = pi >= ilo && pi <= ihi && pj >= jlo && pj <= jhi;
+                        const bool here = interior && pc >= 0 && pc <= W - 2 && pr >= 0 && pr <= H - 2;
+                        if (here) continue;
+                        const int li = (pr + 1) * LW + (pc + 1);
+                        if (seen[li]) continue;
+                        seen[li] = 1;
+                        if (pi < 1 || pi > nx || pj < 1 || pj > ny) continue;
+                        const int cp = (pj - 1) * nx + (pi - 1);
+                        const int src = interior ? cp : ghost_src[cp];
+                        if (cnt[t] >= EVP_RES2_RING) return fail(-6, "resident2: ring list overflow");
+                        ring[(size_t)t * EVP_RES2_RING + cnt[t]++] = make_int4(cp, li, src, 0);
+                        if (interior) pub[cp] = 1;
+                    }
+                }
+        }
+    S.res2_ntiles = ntiles;
+    HIPC(hipMalloc((void **)&S.res2_ring, ring.size() * sizeof(int4)));
+    HIPC(hipMemcpy(S.res2_ring, ring.data(), ring.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPC(hipMalloc((void **)&S.res2_cnt, cnt.size() * sizeof(int)));
+    HIPC(hipMemcpy(S.res2_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPC(hipMalloc((void **)&S.res2_pub, pub.size()));
+    HIPC(hipMemcpy(S.res2_pub, pub.data(), pub.size(), hipMemcpyHostToDevice));
+    for (auto &p : S.res2_rec)
+        if (!p) {
+            HIPC(hipMalloc(&p, (size_t)nx * ny * 32));
+            HIPC(hipMemset(p, 0, (size_t)nx * ny * 32));
+        }
+    if (!S.res_err) {
+        HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
+        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+    }
+    return 0;
+}
+
+bool resident2_fits()
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
+    const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed, S.res2_logw), 8);
+    const long cap = (long)per_cu * prop.multiProcessorCount;
+    return S.res2_ntiles > 0 && (long)S.res2_ntiles * 10 <= cap * 9;
+}
+
+int resident_tables();
+
+int launch_resident2(int ndte, int cur0, bool dry)
+{
+    if (ndte >= 4096) return fail(-6, "resident2: ndte must be < 4096");
+    if (int rc = resident_tables()) return rc;
+    EvpArgs A;
+    fill_args(A, cur0, 1);
+    EvpResident2 R;
+    R.ndte = ndte;
+    R.cur0 = dry ? 0 : cur0;
+    R.dry = dry ? 1 : 0;
+    S.res2_epoch = (S.res2_epoch + 1u) & 0xFFFFFu;
+    if (S.res2_epoch == 0) S.res2_epoch = 1;
+    R.tag_base = S.res2_epoch << 12;
+    R.spin_limit = 4000000u;
+    R.err = S.res_err;
+    R.pubmap = S.res2_pub;
+    R.ring = S.res2_ring;
+    R.ring_cnt = S.res2_cnt;
+    R.rec[0] = S.res2_rec[0];
+    R.rec[1] = S.res2_rec[1];
+    if (dry) {   // inputs come from the current state, nothing is written back
+        R.u[0] = S.u[cur0]; R.v[0] = S.v[cur0]; R.u[1] = S.u[cur0]; R.v[1] = S.v[cur0];
+    } else {
+        R.u[0] = S.u[0]; R.v[0] = S.v[0]; R.u[1] = S.u[1]; R.v[1] = S.v[1];
+    }
+    R.tab = S.res_tab + (dry ? 28 * (1 + cur0) : 0);
+    evp_launch_resident2(A, R, S.max_ni, S.max_nj, S.res2_logw, S.prm.strict != 0, cap_mode(), S.stream);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
 // every workgroup must be resident at once: occupancy query x CUs, with a margin
 bool resident_fits()
 {
@@ -518,6 +638,25 @@ bool resident_fits()
     const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed, S.res_logw), 8);
     const long cap = (long)per_cu * prop.multiProcessorCount;
     return S.res_ntiles > 0 && (long)S.res_ntiles * 10 <= cap * 9;
+}
+
+int resident_tables()
+{
+    if (!S.res_tab) {
+        // three pointer tables, uploaded once: [0] real run, [1]/[2] dry probe reading sig[0]/sig[1]
+        double *tab[3][28];
+        for (int v = 0; v < 3; ++v) {
+            for (int k = 0; k < 12; ++k) {
+                tab[v][k] = S.sig[v == 0 ? 0 : v - 1][k];
+                tab[v][12 + k] = S.sig[v == 0 ? 1 : v - 1][k];
+            }
+            tab[v][24] = S.in[F_STRINTX]; tab[v][25] = S.in[F_STRINTY];
+            tab[v][26] = S.in[F_TAUBX]; tab[v][27] = S.in[F_TAUBY];
+        }
+        HIPC(hipMalloc((void **)&S.res_tab, sizeof tab));
+        HIPC(hipMemcpy(S.res_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
+    return 0;
 }
 
 int launch_resident(int ndte, int cur0, bool dry)
@@ -540,20 +679,7 @@ int launch_resident(int ndte, int cur0, bool dry)
     } else {
         R.u[0] = S.u[0]; R.v[0] = S.v[0]; R.u[1] = S.u[1]; R.v[1] = S.v[1];
     }
-    if (!S.res_tab) {
-        // three pointer tables, uploaded once: [0] real run, [1]/[2] dry probe reading sig[0]/sig[1]
-        double *tab[3][28];
-        for (int v = 0; v < 3; ++v) {
-            for (int k = 0; k < 12; ++k) {
-                tab[v][k] = S.sig[v == 0 ? 0 : v - 1][k];
-                tab[v][12 + k] = S.sig[v == 0 ? 1 : v - 1][k];
-            }
-            tab[v][24] = S.in[F_STRINTX]; tab[v][25] = S.in[F_STRINTY];
-            tab[v][26] = S.in[F_TAUBX]; tab[v][27] = S.in[F_TAUBY];
-        }
-        HIPC(hipMalloc((void **)&S.res_tab, sizeof tab));
-        HIPC(hipMemcpy(S.res_tab, tab, sizeof tab, hipMemcpyHostToDevice));
-    }
+    if (int rc = resident_tables()) return rc;
     R.tab = S.res_tab + (dry ? 28 * (1 + cur0) : 0);
     HIPC(hipMemsetAsync(S.res_flags, 0, (size_t)S.res_ntiles * sizeof(int), S.stream));
     evp_launch_resident(A, R, S.max_ni, S.max_nj, S.res_logw, S.prm.strict != 0, cap_mode(), S.stream);
@@ -919,43 +1045,54 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
         int want = -1;
         if (env("CICE_EVP_HIP_RESIDENT")) want = std::atoi(env("CICE_EVP_HIP_RESIDENT"));
         if (want != 0 && resident_possible()) {
-            int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
+            const int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
+            const int forced_g = env("CICE_EVP_HIP_RES_GEN") ? std::atoi(env("CICE_EVP_HIP_RES_GEN")) : 0;
             float best = 1e30f;
-            int best_w = 0;
-            bool any_fit = false;
-            for (int logw : {5, 4, 6}) {
-                if (forced_w && logw != forced_w) continue;
-                if (resident_setup(logw)) { if (want == 1) return -6; continue; }
-                if (!resident_fits()) continue;
-                any_fit = true;
-                if (want == 1 && forced_w) { best = 0.0f; best_w = logw; break; }   // fully forced: no probe launches
-                for (auto &p : S.res_scratch)
-                    if (!p && alloc_d(&p, S.n)) return -1;
-                // steady-state cost per subcycle = slope between a short and a long dry run
-                // (launch, prologue and epilogue are paid once per evp() call)
-                const int nshort = 8, nlong = 40;
-                float tres = 1e30f, tl[2] = {0, 0};
-                bool ok = true;
-                for (int rep = 0; rep < 3 && ok; ++rep) {
-                    const int np = (rep == 2) ? nlong : nshort;      // rep 0 warms up
-                    for (int q = 0; q < 4; ++q)
-                        HIPC(hipMemcpyAsync(S.res_scratch[q], (q & 1) ? S.v[S.cur] : S.u[S.cur], S.n * sizeof(double),
-                                            hipMemcpyDeviceToDevice, S.stream));
-                    HIPC(hipEventRecord(S.ev2, S.stream));
-                    if (int rc = launch_resident(np, S.cur, true)) return rc;
-                    HIPC(hipEventRecord(S.ev3, S.stream));
-                    HIPC(hipStreamSynchronize(S.stream));
-                    S.res_launched = true;
-                    if (resident_check_error()) { ok = false; break; }
-                    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
-                    if (rep >= 1) tl[rep - 1] = ms;
+            int best_w = 0, best_g = 0;
+            bool any_fit = false, done = false;
+            for (int gen : {2, 1}) {
+                if (done || (forced_g && gen != forced_g)) continue;
+                for (int logw : {5, 4, 6}) {
+                    if (forced_w && logw != forced_w) continue;
+                    if (gen == 1) {
+                        if (resident_setup(logw)) { if (want == 1) return -6; continue; }
+                        if (!resident_fits()) continue;
+                        for (auto &p : S.res_scratch)
+                            if (!p && alloc_d(&p, S.n)) return -1;
+                    } else {
+                        if (resident2_setup(logw)) { if (want == 1) return -6; continue; }
+                        if (!resident2_fits()) continue;
+                    }
+                    any_fit = true;
+                    if (want == 1 && forced_w && forced_g) { best = 0.0f; best_w = logw; best_g = gen; done = true; break; }
+                    // steady-state cost per subcycle = slope between a short and a long dry run
+                    // (launch, prologue and epilogue are paid once per evp() call)
+                    const int nshort = 8, nlong = 40;
+                    float tres = 1e30f, tl[2] = {0, 0};
+                    bool ok = true;
+                    for (int rep = 0; rep < 3 && ok; ++rep) {
+                        const int np = (rep == 2) ? nlong : nshort;      // rep 0 warms up
+                        if (gen == 1)
+                            for (int q = 0; q < 4; ++q)
+                                HIPC(hipMemcpyAsync(S.res_scratch[q], (q & 1) ? S.v[S.cur] : S.u[S.cur],
+                                                    S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+                        HIPC(hipEventRecord(S.ev2, S.stream));
+                        if (int rc = (gen == 1 ? launch_resident(np, S.cur, true) : launch_resident2(np, S.cur, true))) return rc;
+                        HIPC(hipEventRecord(S.ev3, S.stream));
+                        HIPC(hipStreamSynchronize(S.stream));
+                        S.res_launched = true;
+                        if (resident_check_error()) { ok = false; break; }
+                        HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+                        if (rep >= 1) tl[rep - 1] = ms;
+                    }
+                    if (ok) tres = (tl[1] - tl[0]) / (nlong - nshort);
+                    if (ok && tres < best) { best = tres; best_w = logw; best_g = gen; }
                 }
-                if (ok) tres = (tl[1] - tl[0]) / (nlong - nshort);
-                if (ok && tres < best) { best = tres; best_w = logw; }
             }
             S.t_res_probe_ms = best_w ? best : -1.0;
             if (best_w && (want == 1 || S.t_stream_probe_ms <= 0.0 || best < S.t_stream_probe_ms)) {
-                if (int rc = resident_setup(best_w)) return rc;
+                if (int rc = (best_g == 1 ? resident_setup(best_w) : resident2_setup(best_w))) return rc;
+                S.res_gen = best_g;
                 S.res_mode = 1;
             } else if (want == 1) {
                 return fail(-6, any_fit ? "resident EVP kernel requested but its probe failed"
@@ -975,7 +1112,7 @@ int cice_evp_hip_subcycle(int32_t ndte)
     if (ndte == 0) return 0;
     HIPC(hipEventRecord(S.ev0, S.stream));
     if (S.res_mode == 1) {
-        if (int rc = launch_resident(ndte, S.cur, false)) return rc;
+        if (int rc = (S.res_gen == 2 ? launch_resident2(ndte, S.cur, false) : launch_resident(ndte, S.cur, false))) return rc;
         S.res_launched = true;
         HIPC(hipEventRecord(S.ev1, S.stream));
         S.cur ^= (ndte & 1);
@@ -1164,7 +1301,7 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     const double v[9] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : 2.0) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
-                         (double)(S.res_mode == 1 ? 1000 + S.res_logw : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms};
+                         (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms};
     for (int k = 0; k < n && k < 9; ++k) out[k] = v[k];
     return 0;
 }

@@ -70,6 +70,26 @@ void evp_resident_geometry(int max_ni, int max_nj, int logw, int *gx, int *gy);
 void evp_launch_resident(const EvpArgs &A, const EvpResident &R, int max_ni, int max_nj, int logw,
                          bool strict, int cap, hipStream_t st);
 
+// second generation: tagged 16-byte records instead of flags (evp_resident2.hip)
+#define EVP_RES2_RING 256
+struct EvpResident2 {
+    int ndte;
+    int cur0;                  // ping-pong buffer holding the input velocities / stresses
+    int dry;                   // 1: residency + timing probe, nothing written back
+    unsigned tag_base;         // launch epoch << 12; a record of subcycle k carries tag_base + k
+    unsigned spin_limit;
+    int *err;
+    const uint8_t *pubmap;     // per cell: 1 = some other tile's ring mirrors this U-cell
+    const int4 *ring;          // [ntiles][EVP_RES2_RING]: x record cell, y LDS index, z producing U-cell (-1 none)
+    const int *ring_cnt;       // [ntiles]
+    void *rec[2];              // [2][ncell] x {u granule, v granule} (2 x 16 bytes), by subcycle parity
+    double *u[2], *v[2];       // plain arrays: input from [cur0], final state to both
+    double *const *tab;        // as EvpResident::tab
+};
+int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw);
+void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,
+                          bool strict, int cap, hipStream_t st);
+
 enum : unsigned {
     EVP_F_METRICS = 1u,     // recompute cxp..DminTarea from HTE,HTN,dxT,dyT (tarea == dxT*dyT verified)
     EVP_F_WATER_IS_OCN = 2u,// waterxU==uocnU and wateryU==vocnU bit for bit on every active U-cell

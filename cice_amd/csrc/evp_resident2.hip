@@ -1,0 +1,349 @@
+// =====================================================================
+// On-chip resident EVP subcycle, second generation: tagged hand-off.
+//
+// evp_resident.hip publishes a tile's velocities and then a flag; the neighbours
+// poll the flag, pass a barrier and only then load the velocities: per subcycle
+// one store drain, one flag round trip and one data round trip sit on the critical
+// path (~55 % of its time, measured with shader-clock stamps).  Here the data IS the
+// flag: a velocity that another tile needs is published as one aligned 16-byte granule
+//      { tag, value.lo, value.hi, tag }        tag = launch epoch | subcycle
+// written by ONE write-through (sc1) dwordx4 store; the reader re-reads the granule
+// (sc1, L1-bypassing) until both tags carry the subcycle it waits for -- a torn
+// granule cannot pass (MI355X_MICROARCH.md, "R2": observed untorn, checked anyway).
+// No flags, no store drain, no fences.  Velocities used inside the tile never leave
+// the CU: they live in an LDS tile with a one-cell ring; only the ring is polled
+// (<= 2(W+H) threads, one granule pair each).  Records are double-buffered by subcycle
+// parity; a tile can be at most one subcycle ahead of a neighbour, so two suffice.
+//
+// Same arithmetic, tile shapes and ownership rules as evp_resident.hip / the streaming
+// kernel => same bits.  Every spin is bounded and raises the error word.
+// =====================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "evp_math.h"
+
+namespace {
+
+constexpr int RTY = 4;   // waves per workgroup (one per SIMD)
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// two adjacent granules (u then v) of one cell, write-through / L1-bypassing
+__device__ __forceinline__ void st_rec2(void *p, v4u a, v4u b)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
+                 :
+                 : "v"(p), "v"(a), "v"(b)
+                 : "memory");
+}
+__device__ __forceinline__ void ld_rec2(const void *p, v4u &a, v4u &b)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(p)
+                 : "memory");
+}
+__device__ __forceinline__ v4u pack_rec(double x, unsigned tag)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    v4u r;
+    r.x = tag; r.y = (unsigned)bits; r.z = (unsigned)(bits >> 32); r.w = tag;
+    return r;
+}
+__device__ __forceinline__ double unpack_rec(v4u r)
+{
+    return __longlong_as_double((long long)(((unsigned long long)r.z << 32) | r.y));
+}
+
+template <bool STRICT, int CAP, int LOGW>
+__global__ __launch_bounds__(64 * RTY, 4) void evp_resident2_tile(EvpArgs A, EvpResident2 R)
+{
+    using MM = Math<STRICT>;
+    constexpr int W = 1 << LOGW;
+    constexpr int H = 256 / W;
+    constexpr int LW = W + 1;                 // LDS velocity tile: (H+1) x (W+1), origin (-1,-1)
+    constexpr int NUV = ((H + 1) * LW + 7) & ~7;
+    // LDS (dynamic): s_str[4][256] | s_tc[4][256] | s_u[NUV] | s_v[NUV] | s_uc[nu][256]
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *s_str = smem;
+    double *s_tc = smem + 4 * 256;
+    double *s_u = smem + 8 * 256;
+    double *s_v = s_u + NUV;
+    double *s_uc = s_v + NUV;
+    __shared__ int s_bad;
+
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int t = ty * 64 + tx;               // == trow*W + tcol
+    const int tcol = tx & (W - 1);
+    const int trow = t >> LOGW;
+    const int tile = blockIdx.x;
+    const int bx = tile % A.gx;
+    const int by = tile / A.gx;
+    const int4 r = A.blk[0];
+    const int i0 = r.x + bx * (W - 1), j0 = r.z + by * (H - 1);
+    const int i = i0 + tcol;
+    const int j = j0 + trow;
+    const int nx = A.nx, ny = A.ny;
+    const int c = (j - 1) * nx + (i - 1);
+    const int li = (trow + 1) * LW + (tcol + 1);   // this cell in the LDS velocity tile
+    const unsigned flags = A.flags;
+    const bool water = !(flags & EVP_F_WATER_IS_OCN);
+    const bool tbu = !(flags & EVP_F_TBU_ZERO);
+
+    const bool inT = (i <= r.y + 1) && (j <= r.w + 1);
+    unsigned m = 0;
+    if (inT) m = A.mask[c];
+    const bool actT = inT && (m & 1u);
+    const bool isU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
+    const bool own = (tcol < W - 1 || i == r.y + 1) && (trow < H - 1 || j == r.w + 1);
+    const bool pub = isU && (R.pubmap[c] != 0);   // some other tile's ring mirrors this cell
+
+    // ---- state that stays on the CU for the whole call -------------------------------------
+    typename MM::SI a;
+    double s[12];
+    if (actT) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s[k] = R.tab[R.cur0 * 12 + k][c];
+        a.dxT = A.dxT[c]; a.dyT = A.dyT[c];
+        a.strength = A.strength[c];
+        if ((flags & EVP_F_METRICS) && !(flags & EVP_F_DXHY_ARRAY)) {
+            MM::metrics(A.HTE[c], A.HTE[c - 1], A.HTN[c], A.HTN[c - nx], A.deltaminEVP, a);
+        } else {
+            a.dxhy = A.dxhy[c]; a.dyhx = A.dyhx[c];
+            a.cxp = A.cxp[c]; a.cyp = A.cyp[c]; a.cxm = A.cxm[c]; a.cym = A.cym[c];
+            a.DminTarea = A.DminTarea[c];
+        }
+        s_tc[0 * 256 + t] = a.strength;
+        s_tc[1 * 256 + t] = a.DminTarea;
+        s_tc[2 * 256 + t] = a.dxhy;
+        s_tc[3 * 256 + t] = a.dyhx;
+    }
+    if (isU) {
+        s_uc[0 * 256 + t] = A.vrelfac[c];
+        s_uc[1 * 256 + t] = A.uocn[c];
+        s_uc[2 * 256 + t] = A.vocn[c];
+        s_uc[3 * 256 + t] = A.forcex[c];
+        s_uc[4 * 256 + t] = A.forcey[c];
+        s_uc[5 * 256 + t] = A.umassdti[c];
+        s_uc[6 * 256 + t] = A.fm[c];
+        s_uc[7 * 256 + t] = A.uarear[c];
+        int row = 8;
+        if (water) { s_uc[row * 256 + t] = A.waterx[c]; s_uc[(row + 1) * 256 + t] = A.watery[c]; row += 2; }
+        if (tbu) s_uc[row * 256 + t] = A.TbU[c];
+    }
+    // the velocity tile incl. its ring starts from the input arrays (ghost cells are valid on entry)
+    {
+        const double *u0 = R.u[R.cur0], *v0 = R.v[R.cur0];
+        for (int q = t; q < (H + 1) * LW; q += 256) {
+            const int pr = q / LW - 1, pc = q % LW - 1;
+            const int gi = i0 + pc, gj = j0 + pr;
+            double uu = 0.0, vv = 0.0;
+            if (gi >= 1 && gi <= nx && gj >= 1 && gj <= ny) {
+                const int cp = (gj - 1) * nx + (gi - 1);
+                uu = u0[cp]; vv = v0[cp];
+            }
+            s_u[q] = uu; s_v[q] = vv;
+        }
+    }
+    // ghost images of this U-cell (cyclic wrap), looked up once: at most three (corner cell)
+    int img0 = -1, img1 = -1, img2 = -1;
+    if (isU && (flags & EVP_F_PUSH) && (i == r.x || i == r.y || j == r.z || j == r.w)) {
+        const int slots[4] = {(i == r.x) ? (j - r.z) : -1, (i == r.y) ? A.push_nj + (j - r.z) : -1,
+                              (j == r.z) ? 2 * A.push_nj + (i - r.x) : -1,
+                              (j == r.w) ? 2 * A.push_nj + A.push_ni + (i - r.x) : -1};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (slots[e] < 0) continue;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int v = A.push[slots[e] * 2 + w];
+                if (v < 0) continue;
+                if (img0 < 0) img0 = v;
+                else if (img1 < 0) img1 = v;
+                else img2 = v;
+            }
+        }
+    }
+    // my ring entry: which cell of the LDS ring do I refresh, from which record
+    int ring_cp = -1, ring_li = 0;
+    if (t < R.ring_cnt[tile]) {
+        const int4 e = R.ring[tile * EVP_RES2_RING + t];   // x: cell whose record is polled, y: LDS index, z: producing U-cell
+        const bool live = e.z >= 0 && (A.mask[e.z] & 2u);   // an active U-cell rewrites it every subcycle
+        if (live) { ring_cp = e.x; ring_li = e.y; }
+    }
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+
+    double u_own = 0.0, v_own = 0.0;
+    if (isU) { u_own = s_u[li]; v_own = s_v[li]; }
+    // initial records (subcycle tag 0) so that the neighbours' first ring refresh finds them
+    {
+        const unsigned tag = R.tag_base;
+        v4u *r0 = (v4u *)R.rec[0];
+        if (pub) st_rec2(r0 + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
+        if (isU) {
+            if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+            if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img1 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+            if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img2 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+        }
+    }
+
+    // ---- the subcycle loop (ice_dyn_evp.F90:859-913) ------------------------------------------
+    for (int k = 0; k < R.ndte; ++k) {
+        const unsigned want = R.tag_base + (unsigned)k;       // tag of the velocities subcycle k reads
+        const v4u *rd = (const v4u *)R.rec[k & 1];
+        v4u *wr = (v4u *)R.rec[(k & 1) ^ 1];
+
+        // refresh the ring of the velocity tile from the neighbours' records
+        if (ring_cp >= 0) {
+            v4u ra, rb;
+            unsigned spins = 0;
+            for (;;) {
+                ld_rec2(rd + 2 * (size_t)ring_cp, ra, rb);
+                if (ra.x == want && ra.w == want && rb.x == want && rb.w == want) break;
+                if (++spins > R.spin_limit ||
+                    ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(R.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_bad = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_u[ring_li] = unpack_rec(ra);
+            s_v[ring_li] = unpack_rec(rb);
+        }
+        __syncthreads();
+        if (s_bad) return;   // uniform: every thread of the workgroup leaves together
+
+        double str[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) str[e] = 0.0;
+        if (actT) {
+            a.u_ij = s_u[li]; a.v_ij = s_v[li];
+            a.u_im = s_u[li - 1]; a.v_im = s_v[li - 1];
+            a.u_jm = s_u[li - LW]; a.v_jm = s_v[li - LW];
+            a.u_mm = s_u[li - LW - 1]; a.v_mm = s_v[li - LW - 1];
+            a.strength = s_tc[0 * 256 + t]; a.DminTarea = s_tc[1 * 256 + t];
+            a.dxhy = s_tc[2 * 256 + t]; a.dyhx = s_tc[3 * 256 + t];
+            MM::template stress<CAP>(A.p, a, s, str);
+        }
+        s_str[0 * 256 + t] = str[2];
+        s_str[1 * 256 + t] = str[5];
+        s_str[2 * 256 + t] = str[3];
+        s_str[3 * 256 + t] = str[7];
+        const double sx1 = __shfl_down(str[1], 1);
+        const double sy2 = __shfl_down(str[6], 1);
+        __syncthreads();
+
+        if (isU) {
+            typename MM::UI q;
+            typename MM::UO o;
+            q.uold = u_own; q.vold = v_own;
+            q.vrelfac = s_uc[0 * 256 + t]; q.uocn = s_uc[1 * 256 + t]; q.vocn = s_uc[2 * 256 + t];
+            q.forcex = s_uc[3 * 256 + t]; q.forcey = s_uc[4 * 256 + t]; q.Umassdti = s_uc[5 * 256 + t];
+            q.fm = s_uc[6 * 256 + t]; q.uarear = s_uc[7 * 256 + t];
+            int row = 8;
+            if (water) { q.waterx = s_uc[row * 256 + t]; q.watery = s_uc[(row + 1) * 256 + t]; row += 2; }
+            else { q.waterx = q.uocn; q.watery = q.vocn; }
+            q.TbU = tbu ? s_uc[row * 256 + t] : 0.0;
+            q.uvel_init = A.p.revp != 0.0 ? A.uvel_init[c] : 0.0;
+            q.vvel_init = A.p.revp != 0.0 ? A.vvel_init[c] : 0.0;
+            q.sx0 = str[0]; q.sx1 = sx1;
+            q.sx2 = s_str[0 * 256 + t + W]; q.sx3 = s_str[2 * 256 + t + W + 1];
+            q.sy0 = str[4]; q.sy1 = s_str[1 * 256 + t + W];
+            q.sy2 = sy2; q.sy3 = s_str[3 * 256 + t + W + 1];
+            MM::stepu(A.p, q, o);
+            u_own = o.u; v_own = o.v;
+            s_u[li] = o.u; s_v[li] = o.v;            // read by the next stress phase (after the ring barrier)
+            const unsigned tag = want + 1u;
+            if (pub) st_rec2(wr + 2 * (size_t)c, pack_rec(o.u, tag), pack_rec(o.v, tag));
+            if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img0 >> 1), pack_rec(sg * o.u, tag), pack_rec(sg * o.v, tag)); }
+            if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img1 >> 1), pack_rec(sg * o.u, tag), pack_rec(sg * o.v, tag)); }
+            if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img2 >> 1), pack_rec(sg * o.u, tag), pack_rec(sg * o.v, tag)); }
+            if (k == R.ndte - 1 && !R.dry) {
+                R.tab[24][c] = o.strintx; R.tab[25][c] = o.strinty;
+                R.tab[26][c] = o.taubx; R.tab[27][c] = o.tauby;
+            }
+        }
+        // no publish step: the records carry their own tags
+    }
+
+    // ---- write the state back --------------------------------------------------------------
+    if (!R.dry) {
+        if (actT && own) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                R.tab[k][c] = s[k];
+                R.tab[12 + k][c] = s[k];
+            }
+        }
+        if (isU) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                double *uu = R.u[b], *vv = R.v[b];
+                uu[c] = u_own; vv[c] = v_own;
+                if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; uu[img0 >> 1] = sg * u_own; vv[img0 >> 1] = sg * v_own; }
+                if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; uu[img1 >> 1] = sg * u_own; vv[img1 >> 1] = sg * v_own; }
+                if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; uu[img2 >> 1] = sg * u_own; vv[img2 >> 1] = sg * v_own; }
+            }
+        }
+    }
+}
+
+size_t lds_bytes(unsigned flags, int logw)
+{
+    const int W = 1 << logw, H = 256 / W;
+    const int nuv = ((H + 1) * (W + 1) + 7) & ~7;
+    const int nu = 8 + ((flags & EVP_F_WATER_IS_OCN) ? 0 : 2) + ((flags & EVP_F_TBU_ZERO) ? 0 : 1);
+    return sizeof(double) * ((size_t)256 * (8 + nu) + 2 * (size_t)nuv);
+}
+
+template <int LOGW>
+int occ(bool strict, int cap, size_t lds)
+{
+    int nb = 0;
+#define EVP_OCC(S, C) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident2_tile<S, C, LOGW>, 64 * RTY, lds)
+    hipError_t e;
+    if (strict) e = cap == 1 ? EVP_OCC(true, 1) : cap == 0 ? EVP_OCC(true, 0) : EVP_OCC(true, -1);
+    else e = cap == 1 ? EVP_OCC(false, 1) : cap == 0 ? EVP_OCC(false, 0) : EVP_OCC(false, -1);
+#undef EVP_OCC
+    return e == hipSuccess ? nb : 0;
+}
+
+template <int LOGW>
+void launch(const EvpArgs &A, const EvpResident2 &R, bool strict, int cap, hipStream_t st)
+{
+    dim3 grid(A.ntiles), block(64, RTY);
+    const size_t lds = lds_bytes(A.flags, LOGW);
+#define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident2_tile<S, C, LOGW>), grid, block, lds, st, A, R)
+    if (strict) {
+        if (cap == 1) EVP_LAUNCH(true, 1);
+        else if (cap == 0) EVP_LAUNCH(true, 0);
+        else EVP_LAUNCH(true, -1);
+    } else {
+        if (cap == 1) EVP_LAUNCH(false, 1);
+        else if (cap == 0) EVP_LAUNCH(false, 0);
+        else EVP_LAUNCH(false, -1);
+    }
+#undef EVP_LAUNCH
+}
+
+}  // namespace
+
+int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw)
+{
+    const size_t lds = lds_bytes(flags, logw);
+    return logw == 4 ? occ<4>(strict, cap, lds) : logw == 5 ? occ<5>(strict, cap, lds) : occ<6>(strict, cap, lds);
+}
+
+void evp_launch_resident2(const EvpArgs &A0, const EvpResident2 &R, int max_ni, int max_nj, int logw,
+                          bool strict, int cap, hipStream_t st)
+{
+    EvpArgs A = A0;
+    evp_resident_geometry(max_ni, max_nj, logw, &A.gx, &A.gy);
+    A.ntiles = A.gx * A.gy;
+    if (logw == 4) launch<4>(A, R, strict, cap, st);
+    else if (logw == 5) launch<5>(A, R, strict, cap, st);
+    else launch<6>(A, R, strict, cap, st);
+}

@@ -1,3 +1,3 @@
 cd /root/repo; export TMPDIR=/tmp
-python tools/run_call_overhead.py 2>&1 | grep -E "RESULT|rror"
-timeout 900 python -m pytest tests -x -q -m gpu -k "dropin or golden_strict" 2>&1 | grep -E "passed|failed|differ|Error|rror" | tail -4
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|differ|Error|rror" | tail -6
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -E "smoke|rror"

@@ -287,17 +287,19 @@ def test_next_tier_deformations_and_dyn_finish_bitwise(name):
         core.finalize()
 
 
+@pytest.mark.parametrize("gen", ["1", "2"])
 @pytest.mark.parametrize("grid,case,warm", [("gx3", "full", True), ("gx1", "full", True), ("gx1", "caps", False)])
-def test_resident_kernel_bitwise(grid, case, warm, monkeypatch):
+def test_resident_kernel_bitwise(grid, case, warm, gen, monkeypatch):
     """The on-chip resident subcycle (one launch for all ndte subcycles, stresses and operands
     kept in registers/LDS, velocities exchanged through L2 with neighbour flags) against the
     oracle (12 subcycles) and against the streaming kernel (120 subcycles), bit for bit."""
     scal = synth.evp_scalars(120)
     dc, geo, fields, tm, um = synth_case(grid, case, seed=5, warm=warm)
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_GEN", gen)     # 1: neighbour flags, 2: tagged records
     got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12)
     want = run_oracle(dc, geo, fields, tm, um, scal, 12)
-    assert_bitwise(got, want, f"{grid}/{case} resident vs oracle")
+    assert_bitwise(got, want, f"{grid}/{case} resident gen {gen} vs oracle")
     res = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=121)     # odd count: parity flip
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
     stream = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=121)
@@ -307,8 +309,9 @@ def test_resident_kernel_bitwise(grid, case, warm, monkeypatch):
 
 def test_resident_kernel_golden_and_modes(monkeypatch):
     c = GoldenCase("pop_cyc_1blk_patchy")
-    for mode in ("1", "0"):
+    for mode, gen in (("1", "1"), ("1", "2"), ("0", "1")):
         monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", mode)
+        monkeypatch.setenv("CICE_EVP_HIP_RES_GEN", gen)
         core = hip_from_case(c, strict=True)
         try:
             dyn, tm, um = c.inputs(1)
