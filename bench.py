@@ -212,7 +212,7 @@ def main():
         t_kernel = tm_ev["marks_ms"] * 1e-3 / n_launch
         alg_bytes = B_ALG * my_cells * sub_per_launch
         achieved = alg_bytes / t_kernel / 1e9 if t_kernel > 0 else 0.0
-        kname = "evp_resident_tile" if resident else "evp_subcycle_tile"
+        kname = "evp_resident_tile" if resident else "evp_subcycle_tile"   # gen 1 (flags) and gen 2 (tagged records) share the profile key
         res = {
             "metric": "EVP subcycle cell-updates/sec (gx1 fp64)" if a.workload == "gx1"
                       else f"EVP subcycle cell-updates/sec ({a.workload} fp64)",
