@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -80,7 +81,7 @@ struct State {
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
     bool overlap = true;
     // tiles that produce cells other ranks need (run first) / all other tiles, per tile variant
-    struct TileSplit { int *d_boundary = nullptr, *d_interior = nullptr; int nb = 0, ni = 0; };
+    struct TileSplit { int *d_boundary = nullptr, *d_interior = nullptr, *d_all = nullptr; int nb = 0, ni = 0; };
     std::map<int, TileSplit> splits;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evm[2] = {nullptr, nullptr};
     bool marked[2] = {false, false};
@@ -120,6 +121,21 @@ struct State {
     double *sendbuf = nullptr, *recvbuf = nullptr;
     int n_send = 0, n_recv = 0;
 
+    // mailbox halo (evp_halo_direct.hip): peers' inboxes mapped through HIP IPC
+    struct Direct {
+        bool on = false;             // use it for the remote halo
+        bool exported = false;
+        void *mailbox = nullptr;     // [flags][seq][err][inbox x 2 parities]
+        size_t bytes = 0, inbox_off = 0;
+        std::vector<void *> opened;  // hipIpcOpenMemHandle results
+        EvpDirect *d_dx = nullptr;   // device copy of the argument block (exchange riding in the subcycle launch)
+        unsigned *d_cnt = nullptr;   // [0] boundary tiles checked in, [16] launches with a riding exchange
+        double **send_addr = nullptr;
+        unsigned *send_pstride = nullptr;
+        unsigned **peer_flag = nullptr;
+        std::string why;             // why it is off
+    } direct;
+
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, cur) -> captured loop
     bool use_graph = true;
 
@@ -149,6 +165,12 @@ struct State {
 State S;
 
 const char *env(const char *k) { return std::getenv(k); }
+
+// mailbox layout: EVP_DIRECT_MAXPEER flag lines, then seq, err, then the inbox
+constexpr size_t DIRECT_SEQ_OFF = (size_t)EVP_DIRECT_MAXPEER * EVP_DIRECT_FLAG_STRIDE * sizeof(unsigned);
+constexpr size_t DIRECT_ERR_OFF = DIRECT_SEQ_OFF + 64;
+constexpr size_t DIRECT_INBOX_OFF = DIRECT_ERR_OFF + 64;
+void fill_direct(EvpDirect &D);
 
 int alloc_d(double **p, size_t n)
 {
@@ -190,6 +212,9 @@ void free_all()
     F(S.h_recv_sign);
     F(S.sendbuf);
     F(S.recvbuf);
+    for (void *q : S.direct.opened) (void)hipIpcCloseMemHandle(q);
+    F(S.direct.mailbox); F(S.direct.d_dx); F(S.direct.d_cnt); F(S.direct.send_addr); F(S.direct.send_pstride); F(S.direct.peer_flag);
+    S.direct = State::Direct();
     for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);
     S.graphs.clear();
     if (S.ev0) (void)hipEventDestroy(S.ev0);
@@ -205,6 +230,7 @@ void free_all()
     for (auto &kv : S.splits) {
         if (kv.second.d_boundary) (void)hipFree(kv.second.d_boundary);
         if (kv.second.d_interior) (void)hipFree(kv.second.d_interior);
+        if (kv.second.d_all) (void)hipFree(kv.second.d_all);
     }
     S.splits.clear();
     if (S.ev_pack) (void)hipEventDestroy(S.ev_pack);
@@ -377,6 +403,7 @@ void fill_args(EvpArgs &A, int cur, int last)
     A.last = last;
     A.tile_list = nullptr;
     A.tile_count = 0;
+    A.dx = nullptr; A.dx_count = nullptr; A.dx_fseq = nullptr; A.dx_nb = 0;
     A.blk = S.blk;
     A.mask = S.mask;
     A.u_in = S.u[cur];
@@ -411,6 +438,29 @@ int cap_mode()
     return -1;
 }
 
+void fill_direct(EvpDirect &D)
+{
+    State::Direct &X = S.direct;
+    char *base = (char *)X.mailbox;
+    D.n_send = S.n_send;
+    D.n_recv = S.n_recv;
+    D.npeers = (int)S.plan.peers.size();
+    D.send_src = S.h_send_src;
+    D.send_addr = X.send_addr;
+    D.send_pstride = X.send_pstride;
+    D.recv_dst = S.h_recv_dst;
+    D.recv_sign = (const signed char *)S.h_recv_sign;
+    D.flags_in = (unsigned *)base;
+    D.seq = (unsigned *)(base + DIRECT_SEQ_OFF);
+    D.err = (int *)(base + DIRECT_ERR_OFF);
+    D.inbox = (double *)(base + X.inbox_off);
+    static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
+    D.timeout_ticks = (unsigned long long)(tmo_ms * 1.0e5);     // 100 MHz wall clock
+    D.peer_flag = X.peer_flag;
+    static const int dbg = env("CICE_EVP_HIP_HALO_DEBUG") ? std::atoi(env("CICE_EVP_HIP_HALO_DEBUG")) : 0;
+    D.dbg = dbg;
+}
+
 // velocity halo of buffer `b` (ice_dyn_evp.F90:908-910)
 int halo_uv(int b)
 {
@@ -422,8 +472,12 @@ int halo_uv(int b)
     // exchange below never involves seam-row cells
     evp_launch_halo_seam(S.u[b], S.v[b], S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
                          S.h_late_dst, S.h_late_src, (const signed char *)S.h_late_sign, S.n_late, S.stream);
-    if (!S.plan.peers.empty()) {
-        if (!S.have_comm) return fail(-2, "remote halo needed but cice_evp_hip_comm_init was not called");
+    if (!S.plan.peers.empty() && S.direct.on) {
+        EvpDirect D;
+        fill_direct(D);
+        evp_launch_halo_direct(D, S.u[b], S.v[b], S.stream);
+    } else if (!S.plan.peers.empty()) {
+        if (!S.have_comm) return fail(-2, "remote halo needed but neither cice_evp_hip_comm_init nor cice_evp_hip_halo_import was called");
         evp_launch_halo_pack(S.u[b], S.v[b], S.h_send_src, S.sendbuf, S.n_send, S.stream);
         size_t so = 0, ro = 0;
         NCCLC(ncclGroupStart());
@@ -701,14 +755,214 @@ int resident_check_error()
     return 0;
 }
 
+
+// ---- mailbox halo: set-up over HIP IPC (kernel: evp_halo_direct.hip) ------------------------
+// What a rank tells the others: how to map its mailbox and where each peer's entries land.
+struct HaloBlob {
+    uint32_t magic, version;
+    int32_t rank, npeers;
+    uint64_t host_id;
+    int64_t pid;
+    uint64_t base;                 // mailbox address in the exporting process
+    uint64_t inbox_off, n_recv;
+    hipIpcMemHandle_t handle;
+    struct { int32_t rank, recv_off, count, flag_idx; } peer[EVP_DIRECT_MAXPEER];
+};
+static_assert(sizeof(HaloBlob) <= CICE_EVP_HIP_HALO_BLOB, "HaloBlob must fit CICE_EVP_HIP_HALO_BLOB");
+constexpr uint32_t HALO_BLOB_MAGIC = 0x45565048u;   // "EVPH"
+
+uint64_t host_identity()
+{
+    char name[256] = {0};
+    (void)gethostname(name, sizeof name - 1);
+    uint64_t h = 1469598103934665603ull;
+    for (const char *c = name; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+    return h;
+}
+
+int direct_export(HaloBlob &B)
+{
+    State::Direct &X = S.direct;
+    const int np = (int)S.plan.peers.size();
+    if (np > EVP_DIRECT_MAXPEER) return fail(-8, "mailbox halo: %d peers > %d", np, EVP_DIRECT_MAXPEER);
+    if (!X.mailbox) {
+        X.inbox_off = DIRECT_INBOX_OFF;
+        X.bytes = X.inbox_off + 2 * 2 * (size_t)std::max(S.n_recv, 1) * sizeof(double);
+        // fine-grained: stores of another GPU become visible to loads here without a kernel boundary
+        if (hipExtMallocWithFlags(&X.mailbox, X.bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPC(hipMalloc(&X.mailbox, X.bytes));
+        }
+        HIPC(hipMemset(X.mailbox, 0, X.bytes));
+    }
+    std::memset(&B, 0, sizeof B);
+    B.magic = HALO_BLOB_MAGIC;
+    B.version = 1;
+    B.rank = S.d.rank;
+    B.npeers = np;
+    B.host_id = host_identity();
+    B.pid = (int64_t)getpid();
+    B.base = (uint64_t)(uintptr_t)X.mailbox;
+    B.inbox_off = X.inbox_off;
+    B.n_recv = (uint64_t)S.n_recv;
+    HIPC(hipIpcGetMemHandle(&B.handle, X.mailbox));
+    int ro = 0;
+    for (int q = 0; q < np; ++q) {
+        const HaloPeer &p = S.plan.peers[q];
+        B.peer[q].rank = p.rank;
+        B.peer[q].recv_off = ro;
+        B.peer[q].count = (int)p.recv_dst.size();
+        B.peer[q].flag_idx = q;
+        ro += (int)p.recv_dst.size();
+    }
+    X.exported = true;
+    return 0;
+}
+
+// Map every peer's mailbox and build the device tables.  Local decision only (no communication).
+int direct_import(const HaloBlob *blobs, int nranks)
+{
+    State::Direct &X = S.direct;
+    if (!X.exported) return fail(-8, "mailbox halo: import before export");
+    if (nranks != S.d.nranks) return fail(-8, "mailbox halo: %d blobs for %d ranks", nranks, S.d.nranks);
+    const int np = (int)S.plan.peers.size();
+    std::vector<double *> send_addr((size_t)std::max(S.n_send, 1), nullptr);
+    std::vector<unsigned> send_pstride((size_t)std::max(S.n_send, 1), 0u);
+    std::vector<unsigned *> peer_flag((size_t)std::max(np, 1));
+    std::map<int, char *> mapped;
+    size_t so = 0;
+    for (int q = 0; q < np; ++q) {
+        const HaloPeer &p = S.plan.peers[q];
+        if (p.rank < 0 || p.rank >= nranks) return fail(-8, "mailbox halo: peer rank %d out of range", p.rank);
+        const HaloBlob &B = blobs[p.rank];
+        if (B.magic != HALO_BLOB_MAGIC || B.version != 1 || B.rank != p.rank)
+            return fail(-8, "mailbox halo: bad blob of rank %d", p.rank);
+        if (B.host_id != host_identity()) return fail(-8, "mailbox halo: rank %d is on another host", p.rank);
+        int e = -1;
+        for (int k = 0; k < B.npeers; ++k)
+            if (B.peer[k].rank == S.d.rank) e = k;
+        if (e < 0 || B.peer[e].count != (int)p.send_src.size())
+            return fail(-8, "mailbox halo: rank %d expects %d cells from this rank, plan sends %d", p.rank,
+                        e < 0 ? -1 : B.peer[e].count, (int)p.send_src.size());
+        char *base = nullptr;
+        if (B.pid == (int64_t)getpid()) base = (char *)(uintptr_t)B.base;       // same process (self-exchange)
+        else if (mapped.count(p.rank)) base = mapped[p.rank];
+        else {
+            void *ptr = nullptr;
+            HIPC(hipIpcOpenMemHandle(&ptr, B.handle, hipIpcMemLazyEnablePeerAccess));
+            X.opened.push_back(ptr);
+            base = (char *)ptr;
+        }
+        mapped[p.rank] = base;
+        peer_flag[q] = (unsigned *)base + (size_t)B.peer[e].flag_idx * EVP_DIRECT_FLAG_STRIDE;
+        for (size_t k = 0; k < p.send_src.size(); ++k) {
+            send_addr[so + k] = (double *)(base + B.inbox_off) + 2 * ((size_t)B.peer[e].recv_off + k);
+            send_pstride[so + k] = (unsigned)(2 * B.n_recv);
+        }
+        so += p.send_src.size();
+    }
+    auto up = [&](auto *&dptr, const auto &v) -> int {
+        using T = typename std::remove_reference<decltype(v[0])>::type;
+        if (!dptr) HIPC(hipMalloc((void **)&dptr, v.size() * sizeof(T)));
+        HIPC(hipMemcpy((void *)dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (up(X.send_addr, send_addr) || up(X.send_pstride, send_pstride) || up(X.peer_flag, peer_flag)) return -1;
+    EvpDirect D;
+    fill_direct(D);
+    if (!X.d_dx) HIPC(hipMalloc((void **)&X.d_dx, sizeof(EvpDirect)));
+    HIPC(hipMemcpy(X.d_dx, &D, sizeof(EvpDirect), hipMemcpyHostToDevice));
+    if (!X.d_cnt) HIPC(hipMalloc((void **)&X.d_cnt, 32 * sizeof(unsigned)));
+    HIPC(hipMemset(X.d_cnt, 0, 32 * sizeof(unsigned)));
+    return 0;
+}
+
+// Probe exchange (collective): every interior cell carries its global cell number, every ghost
+// must come back holding the number of the cell it mirrors (halochk.F90:232-247's method).
+// Uses the velocity buffers before any state has been uploaded, and leaves them zeroed.
+int direct_probe()
+{
+    std::vector<double> hu(S.n, 0.0), hv(S.n, 0.0);
+    const int nx = S.d.nx_block;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        for (int j = S.jlo[b]; j <= S.jhi[b]; ++j)
+            for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
+                const size_t c = b * S.plane + (size_t)(j - 1) * nx + (i - 1);
+                const double gid = (double)((S.iglob0[b] + (i - S.ilo[b]) - 1) +
+                                            (size_t)S.d.nx_global * (S.jglob0[b] + (j - S.jlo[b]) - 1));
+                hu[c] = gid + 1.0;
+                hv[c] = -2.0 * (gid + 1.0);
+            }
+    HIPC(hipMemcpyAsync(S.u[0], hu.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.v[0], hv.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    EvpDirect D;
+    fill_direct(D);
+    for (int rep = 0; rep < 3; ++rep)           // both inbox parities, and a repeat
+        evp_launch_halo_direct(D, S.u[0], S.v[0], S.stream);
+    HIPC(hipMemcpyAsync(hu.data(), S.u[0], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipMemcpyAsync(hv.data(), S.v[0], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    int err = 0;
+    HIPC(hipMemcpyAsync(&err, D.err, sizeof(int), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemsetAsync(S.u[0], 0, S.n * sizeof(double), S.stream));
+    HIPC(hipMemsetAsync(S.v[0], 0, S.n * sizeof(double), S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    if (err) {
+        HIPC(hipMemset(D.err, 0, sizeof(int)));
+        return fail(-8, "mailbox halo probe: peer %d never signalled", S.plan.peers[err - 1].rank);
+    }
+    for (const HaloPeer &p : S.plan.peers)
+        for (size_t k = 0; k < p.recv_dst.size(); ++k) {
+            const double want = (double)p.recv_sign[k] * ((double)p.recv_gid[k] + 1.0);
+            if (hu[p.recv_dst[k]] != want || hv[p.recv_dst[k]] != -2.0 * want)
+                return fail(-8, "mailbox halo probe: ghost %d from rank %d holds %.17g, expected %.17g",
+                            (int)p.recv_dst[k], p.rank, hu[p.recv_dst[k]], want);
+        }
+    return 0;
+}
+
+int direct_check_error()
+{
+    if (!S.direct.on) return 0;
+    int e = 0;
+    HIPC(hipMemcpy(&e, (char *)S.direct.mailbox + DIRECT_ERR_OFF, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) return fail(-8, "mailbox halo: rank %d never signalled within the time-out (CICE_EVP_HIP_HALO_TIMEOUT_MS)",
+                       S.plan.peers[e - 1].rank);
+    return 0;
+}
+
+// 0 auto, 1 RCCL only, 2 mailbox required
+int halo_choice()
+{
+    const char *h = env("CICE_EVP_HIP_HALO");
+    if (!h) return 0;
+    if (!std::strcmp(h, "rccl")) return 1;
+    if (!std::strcmp(h, "direct")) return 2;
+    return 0;
+}
+
 // Boundary-first + second stream pays when the interior kernel is long enough to hide the
 // exchange; on small per-rank domains the extra host calls (events, two launches) cost more
 // than they hide (measured: 50 vs 26 us per subcycle on gx1, eager).  CICE_EVP_HIP_OVERLAP=1/0 forces.
 bool use_overlap()
 {
     const bool seam = (S.n_seam + S.n_pole + S.n_late) > 0;
-    if (!S.overlap || S.plan.peers.empty() || seam || !S.have_comm) return false;
+    if (!S.overlap || S.plan.peers.empty() || seam || !(S.have_comm || S.direct.on)) return false;
     if (env("CICE_EVP_HIP_OVERLAP")) return std::atoi(env("CICE_EVP_HIP_OVERLAP")) != 0;
+    size_t cells = 0;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);
+    return cells >= 400000;
+}
+
+// The mailbox exchange can ride in the subcycle launch (no tripole seam step in between).
+bool use_riding_exchange()
+{
+    if (!S.direct.on || S.plan.peers.empty() || (S.n_seam + S.n_pole + S.n_late) > 0) return false;
+    // Pays when the interior tiles outlast the exchange (measured, 4 x 1800x1200 blocks: 571 us
+    // riding, 598 two streams, 627 separate kernel); on a domain that is one wave of workgroups
+    // there is nothing to overlap with and the separate kernel is quicker (gx1: 20.8 vs 25 us).
+    if (env("CICE_EVP_HIP_HALO_RIDE")) return std::atoi(env("CICE_EVP_HIP_HALO_RIDE")) != 0;
     size_t cells = 0;
     for (int b = 0; b < S.d.nblocks; ++b)
         cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);
@@ -747,6 +1001,22 @@ int get_tile_split(int variant, State::TileSplit **out)
         HIPC(hipMalloc((void **)&ts.d_interior, li.size() * sizeof(int)));
         HIPC(hipMemcpy(ts.d_interior, li.data(), li.size() * sizeof(int), hipMemcpyHostToDevice));
     }
+    {   // boundary tiles first, then the rest: order of the launch that carries the exchange workgroup
+        // interior tiles in XCD-chunked order: workgroup w runs on XCD w % 8, so give each XCD one
+        // contiguous run of the (row-major) interior sequence -- neighbouring tiles share an L2
+        std::vector<int> all(lb);
+        const size_t n = li.size(), per = (n + 7) / 8, w0 = lb.size() + 1;    // +1: the exchange workgroup
+        std::vector<int> chunked;
+        for (size_t w = 0; chunked.size() < n; ++w) {
+            const size_t x = (w0 + w) & 7, q = x * per + (w >> 3);
+            if ((w >> 3) < per && q < n) chunked.push_back(li[q]);
+            if (w > 16 * (n + 8)) break;
+        }
+        if (chunked.size() != n) chunked = li;
+        all.insert(all.end(), chunked.begin(), chunked.end());
+        HIPC(hipMalloc((void **)&ts.d_all, all.size() * sizeof(int)));
+        HIPC(hipMemcpy(ts.d_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     *out = &S.splits.emplace(variant, ts).first->second;
     return 0;
 }
@@ -759,6 +1029,27 @@ int enqueue_loop(int ndte, int cur0)
     // Boundary strips first, RCCL exchange on a second stream while the interior tiles run
     // (the tripole seam needs every tile of the top row first, so it keeps the serial order).
     const bool overlap = use_overlap();
+    if (use_riding_exchange()) {
+        // mailbox halo: one launch per subcycle; the tiles other ranks wait for run first, one
+        // extra workgroup exchanges their velocities while the interior tiles are computed
+        const int variant = S.tyb % 100;
+        State::TileSplit *ts = nullptr;
+        if (int rc = get_tile_split(variant, &ts)) return rc;
+        const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
+        for (int k = 0; k < ndte; ++k) {
+            EvpArgs A;
+            fill_args(A, cur, k == ndte - 1);
+            A.tile_list = ts->d_all; A.tile_count = ts->nb + ts->ni;
+            A.dx = S.direct.d_dx; A.dx_count = S.direct.d_cnt; A.dx_fseq = S.direct.d_cnt + 16; A.dx_nb = ts->nb;
+            evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
+            if (!pushed)
+                evp_launch_halo_local(S.u[cur ^ 1], S.v[cur ^ 1], S.h_local_dst, S.h_local_src,
+                                      (const signed char *)S.h_local_sign, S.n_local, S.stream);
+            cur ^= 1;
+        }
+        HIPC(hipGetLastError());
+        return 0;
+    }
     if (!overlap) {
         for (int k = 0; k < ndte; ++k) {
             EvpArgs A;
@@ -782,7 +1073,7 @@ int enqueue_loop(int ndte, int cur0)
         // 1. tiles whose cells other ranks need
         A.tile_list = ts->d_boundary; A.tile_count = ts->nb;
         evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
-        evp_launch_halo_pack(S.u[nxt], S.v[nxt], S.h_send_src, S.sendbuf, S.n_send, S.stream);
+        if (!S.direct.on) evp_launch_halo_pack(S.u[nxt], S.v[nxt], S.h_send_src, S.sendbuf, S.n_send, S.stream);
         HIPC(hipEventRecord(S.ev_pack, S.stream));
         // 2. everything else, concurrently with the exchange
         A.tile_list = ts->d_interior; A.tile_count = ts->ni;
@@ -792,19 +1083,25 @@ int enqueue_loop(int ndte, int cur0)
                                   (const signed char *)S.h_local_sign, S.n_local, S.stream);
         // 3. RCCL point-to-point over xGMI on the communication stream
         HIPC(hipStreamWaitEvent(S.stream_comm, S.ev_pack, 0));
-        size_t so = 0, ro = 0;
-        NCCLC(ncclGroupStart());
-        for (const HaloPeer &p : S.plan.peers) {
-            if (!p.send_src.empty())
-                NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
-            if (!p.recv_dst.empty())
-                NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
-            so += p.send_src.size();
-            ro += p.recv_dst.size();
+        if (S.direct.on) {      // mailbox exchange: stores into the peers' inboxes, no library call
+            EvpDirect D;
+            fill_direct(D);
+            evp_launch_halo_direct(D, S.u[nxt], S.v[nxt], S.stream_comm);
+        } else {
+            size_t so = 0, ro = 0;
+            NCCLC(ncclGroupStart());
+            for (const HaloPeer &p : S.plan.peers) {
+                if (!p.send_src.empty())
+                    NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
+                if (!p.recv_dst.empty())
+                    NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
+                so += p.send_src.size();
+                ro += p.recv_dst.size();
+            }
+            NCCLC(ncclGroupEnd());
+            evp_launch_halo_unpack(S.u[nxt], S.v[nxt], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
+                                   S.n_recv, S.stream_comm);
         }
-        NCCLC(ncclGroupEnd());
-        evp_launch_halo_unpack(S.u[nxt], S.v[nxt], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
-                               S.n_recv, S.stream_comm);
         HIPC(hipEventRecord(S.ev_halo, S.stream_comm));
         cur = nxt;
     }
@@ -875,6 +1172,14 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
             self.send_src.push_back(S.plan.local_src[k]);
             self.recv_dst.push_back(S.plan.local_dst[k]);
             self.recv_sign.push_back(S.plan.local_sign[k]);
+            {
+                const int32_t so = S.plan.local_src[k];
+                const size_t pl = (size_t)dims->nx_block * dims->ny_block;
+                const int b = (int)(so / pl), rem = (int)(so % pl);
+                const int j = rem / dims->nx_block + 1, i = rem % dims->nx_block + 1;
+                const int ig = dims->iglob0[b] + (i - dims->ilo[b]), jg = dims->jglob0[b] + (j - dims->jlo[b]);
+                self.recv_gid.push_back((int32_t)((ig - 1) + (size_t)dims->nx_global * (jg - 1)));
+            }
         }
         S.plan.local_dst = kd; S.plan.local_src = ks; S.plan.local_sign = kg;
         S.plan.peers.push_back(self);
@@ -1121,14 +1426,14 @@ int cice_evp_hip_subcycle(int32_t ndte)
     }
     // RCCL p2p inside a captured graph: opt-in (CICE_EVP_HIP_GRAPH_RCCL=1) until measured on a multi-GPU node
     static const bool graph_rccl = env("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env("CICE_EVP_HIP_GRAPH_RCCL"));
-    const bool graph_ok = S.use_graph && (S.plan.peers.empty() || graph_rccl);
+    const bool graph_ok = S.use_graph && (S.plan.peers.empty() || graph_rccl || S.direct.on);
     if (graph_ok) {
         const auto key = std::make_pair((int)ndte, S.cur);
         auto it = S.graphs.find(key);
         if (it == S.graphs.end()) {
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
-            if (use_overlap()) {   // device allocations are not allowed while capturing
+            if (use_overlap() || use_riding_exchange()) {   // device allocations are not allowed while capturing
                 State::TileSplit *ts = nullptr;
                 if (int rc = get_tile_split(S.tyb % 100, &ts)) return rc;
             }
@@ -1235,6 +1540,7 @@ int cice_evp_hip_sync(void)
 {
     if (!S.ready) return fail(-1, "not initialised");
     HIPC(hipStreamSynchronize(S.stream));
+    if (int rc = direct_check_error()) return rc;
     return resident_check_error();
 }
 
@@ -1242,6 +1548,7 @@ int cice_evp_hip_download(double *const *f)
 {
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
     HIPC(hipStreamSynchronize(S.stream));
+    if (int rc = direct_check_error()) return rc;
     if (int rc = resident_check_error()) return rc;
     HIPC(hipEventRecord(S.ev2, S.stream));
     for (int k = 0; k < 12; ++k)
@@ -1298,11 +1605,12 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     if (S.ready && S.marked[0] && S.marked[1] && hipEventQuery(S.evm[1]) == hipSuccess &&
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
-    const double v[9] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+    const double v[10] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
-                             (S.plan.peers.empty() ? 0.0 : 2.0) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
-                         (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms};
-    for (int k = 0; k < n && k < 9; ++k) out[k] = v[k];
+                             (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
+                         (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
+                          S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0)};
+    for (int k = 0; k < n && k < 10; ++k) out[k] = v[k];
     return 0;
 }
 
@@ -1368,6 +1676,72 @@ int cice_evp_hip_comm_init(const void *id128)
     HIPC(hipSetDevice(S.device));
     NCCLC(ncclCommInitRank(&S.comm, S.d.nranks, id, S.d.rank));
     S.have_comm = true;
+    if (halo_choice() == 1) { S.direct.why = "CICE_EVP_HIP_HALO=rccl"; return 0; }
+    // Mailbox halo: every step below is followed by an agreement (all-reduce of "still fine"),
+    // so that either all ranks switch to it or all stay on RCCL.
+    const int nr = S.d.nranks;
+    char *d_blobs = nullptr;
+    int *d_ok = nullptr;
+    HIPC(hipMalloc((void **)&d_blobs, (size_t)nr * CICE_EVP_HIP_HALO_BLOB));
+    HIPC(hipMalloc((void **)&d_ok, sizeof(int)));
+    auto agree = [&](int mine, int &all) -> int {
+        HIPC(hipMemcpy(d_ok, &mine, sizeof(int), hipMemcpyHostToDevice));
+        NCCLC(ncclAllReduce(d_ok, d_ok, 1, ncclInt, ncclMin, S.comm, S.stream));
+        HIPC(hipStreamSynchronize(S.stream));
+        HIPC(hipMemcpy(&all, d_ok, sizeof(int), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    std::vector<char> mine(CICE_EVP_HIP_HALO_BLOB, 0), all((size_t)nr * CICE_EVP_HIP_HALO_BLOB, 0);
+    int ok = direct_export(*reinterpret_cast<HaloBlob *>(mine.data())) == 0, all_ok = 0;
+    std::string why = ok ? "" : g_err;
+    HIPC(hipMemcpy(d_blobs + (size_t)S.d.rank * CICE_EVP_HIP_HALO_BLOB, mine.data(), CICE_EVP_HIP_HALO_BLOB, hipMemcpyHostToDevice));
+    NCCLC(ncclAllGather(d_blobs + (size_t)S.d.rank * CICE_EVP_HIP_HALO_BLOB, d_blobs, CICE_EVP_HIP_HALO_BLOB, ncclChar, S.comm, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemcpy(all.data(), d_blobs, all.size(), hipMemcpyDeviceToHost));
+    if (ok) {
+        ok = direct_import(reinterpret_cast<const HaloBlob *>(all.data()), nr) == 0;
+        if (!ok) why = g_err;
+    }
+    if (agree(ok, all_ok)) return -1;
+    if (all_ok) {
+        ok = direct_probe() == 0;
+        if (!ok) why = g_err;
+        if (agree(ok, all_ok)) return -1;
+    }
+    (void)hipFree(d_blobs);
+    (void)hipFree(d_ok);
+    S.direct.on = all_ok != 0;
+    S.direct.why = S.direct.on ? "" : (why.empty() ? "another rank could not set it up" : why);
+    if (!S.direct.on && halo_choice() == 2)
+        return fail(-8, "CICE_EVP_HIP_HALO=direct but the mailbox halo is unavailable: %s", S.direct.why.c_str());
+    if (!S.direct.on && env("CICE_EVP_HIP_VERBOSE"))
+        std::fprintf(stderr, "[cice_evp_hip] rank %d: mailbox halo off (%s), using RCCL\n", S.d.rank, S.direct.why.c_str());
+    g_err.clear();
+    return 0;
+}
+
+int cice_evp_hip_halo_export(void *blob)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!blob) return fail(-1, "null blob");
+    HIPC(hipSetDevice(S.device));
+    std::vector<char> tmp(CICE_EVP_HIP_HALO_BLOB, 0);
+    if (int rc = direct_export(*reinterpret_cast<HaloBlob *>(tmp.data()))) return rc;
+    std::memcpy(blob, tmp.data(), CICE_EVP_HIP_HALO_BLOB);
+    return 0;
+}
+
+int cice_evp_hip_halo_import(const void *blobs, int32_t nranks)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!blobs) return fail(-1, "null blobs");
+    HIPC(hipSetDevice(S.device));
+    std::vector<HaloBlob> B((size_t)std::max(nranks, 0));
+    for (int r = 0; r < nranks; ++r)
+        std::memcpy(&B[r], (const char *)blobs + (size_t)r * CICE_EVP_HIP_HALO_BLOB, sizeof(HaloBlob));
+    if (int rc = direct_import(B.data(), nranks)) return rc;
+    if (int rc = direct_probe()) return rc;     // collective; a failure here is fatal for the caller
+    S.direct.on = true;
     return 0;
 }
 

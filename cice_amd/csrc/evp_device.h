@@ -45,6 +45,12 @@ struct EvpArgs {
     int push_ni, push_nj;
     // diagnostics of the last subcycle
     double *strintx, *strinty, *taubx, *tauby;
+    // mailbox halo riding in the launch (evp_halo_direct.h); dx == NULL: off.  tile_list then
+    // holds ALL tiles, the dx_nb boundary tiles first; workgroup dx_nb is the exchange workgroup.
+    const struct EvpDirect *dx;
+    unsigned *dx_count;        // boundary tiles checked in so far (never reset)
+    unsigned *dx_fseq;         // launches with a riding exchange so far
+    int dx_nb;
 };
 
 // On-chip resident subcycle (evp_resident.hip)
@@ -89,6 +95,26 @@ struct EvpResident2 {
 int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw);
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,
                           bool strict, int cap, hipStream_t st);
+
+// Mailbox halo between GPUs of one node (evp_halo_direct.hip)
+#define EVP_DIRECT_MAXPEER 32
+#define EVP_DIRECT_FLAG_STRIDE 16          // unsigneds: one 64-byte line per flag
+struct EvpDirect {
+    int n_send, n_recv, npeers;
+    const int *send_src;          // [n_send] local source cells, the plan's peers concatenated
+    double *const *send_addr;     // [n_send] where the entry lands in its peer's inbox (parity 0), as mapped here
+    const unsigned *send_pstride; // [n_send] doubles to the other parity of that inbox
+    const int *recv_dst;          // [n_recv] local ghost cells
+    const signed char *recv_sign;
+    double *inbox;                // own inbox [2 parities][n_recv][u,v]
+    unsigned *flags_in;           // own flag slots, one per peer, EVP_DIRECT_FLAG_STRIDE apart
+    unsigned *seq;                // exchanges completed so far
+    int *err;                     // != 0: a wait gave up (1 + index of the peer)
+    unsigned long long timeout_ticks;   // of the 100 MHz wall clock
+    int dbg;                      // timing experiments only (CICE_EVP_HIP_HALO_DEBUG): 1 no release, 2 no acquire, 4 no flags, 8 empty
+    unsigned *const *peer_flag;   // [npeers] my flag slot in the peer's mailbox as mapped here
+};
+void evp_launch_halo_direct(const EvpDirect &D, double *u, double *v, hipStream_t st);
 
 enum : unsigned {
     EVP_F_METRICS = 1u,     // recompute cxp..DminTarea from HTE,HTN,dxT,dyT (tarea == dxT*dyT verified)

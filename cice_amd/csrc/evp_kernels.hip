@@ -19,7 +19,7 @@
 #include <cstdlib>
 
 #include "evp_device.h"
-
+#include "evp_halo_direct.h"
 #include "evp_math.h"
 
 namespace {
@@ -52,7 +52,22 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
     // with the tile row index fastest, so that vertically adjacent tiles -- which share
     // the T-row recomputed on the fringe -- are read through the same L2 close in time.
     int t;
-    if (A.tile_list) {
+    bool bnd = false;                                // tile whose cells the exchange workgroup sends
+    if (A.dx) {
+        // Mailbox halo riding in this launch: tiles that produce cells other ranks mirror come
+        // first, then ONE workgroup that waits for them and runs the exchange while the
+        // interior tiles (the rest of the grid) are computed.
+        int w = blockIdx.x;
+        if (w == A.dx_nb) {
+            const unsigned target = (*A.dx_fseq + 1u) * (unsigned)A.dx_nb;
+            evp_mailbox::exchange(*A.dx, A.u_out, A.v_out, ty * 64 + tx, 64 * TYB, A.dx_count, target);
+            if (tx == 0 && ty == 0) *A.dx_fseq += 1u;
+            return;
+        }
+        bnd = w < A.dx_nb;
+        if (w > A.dx_nb) --w;
+        t = A.tile_list[w];
+    } else if (A.tile_list) {
         t = A.tile_list[blockIdx.x];                 // explicit subset (boundary / interior tiles)
     } else {
         const int w = blockIdx.x;
@@ -169,7 +184,12 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
         q.sy0 = s_str[4][ty][tx]; q.sy1 = s_str[5][ty + 1][tx];
         q.sy2 = s_str[6][ty][tx + 1]; q.sy3 = s_str[7][ty + 1][tx + 1];
         MM::stepu(A.p, q, o);
-        ST(A.u_out, ob, o.u); ST(A.v_out, ob, o.v);
+        if (bnd) {   // write-through: visible to the exchange workgroup on another XCD
+            __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(A.u_out) + ob), o.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(A.v_out) + ob), o.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ST(A.u_out, ob, o.u); ST(A.v_out, ob, o.v);
+        }
         if (A.last) {
             ST(A.strintx, ob, o.strintx); ST(A.strinty, ob, o.strinty);
             ST(A.taubx, ob, o.taubx); ST(A.tauby, ob, o.tauby);
@@ -197,6 +217,11 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
                 }
             }
         }
+    }
+    if (bnd) {       // check in: every velocity of this tile has reached memory
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tx == 0 && ty == 0) __hip_atomic_fetch_add(A.dx_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -387,7 +412,7 @@ void evp_launch_subcycle(const EvpArgs &A0, int max_ni, int max_nj, int nblocks,
     dim3 grid(per * 8);
     if (A.tile_list) {
         if (A.tile_count <= 0) return;
-        grid = dim3(A.tile_count);
+        grid = dim3(A.tile_count + (A.dx ? 1 : 0));      // + the exchange workgroup
     }
     switch (tyb) {
     case 2: launch_tile<2>(A, grid, st, strict, cap); break;

@@ -168,6 +168,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                             p.rank = S.owner;
                             p.recv_dst.push_back(dst);
                             p.recv_sign.push_back((int8_t)s.sign);
+                            p.recv_gid.push_back((int32_t)((s.ig - 1) + (size_t)d.nx_global * (s.jg - 1)));
                         }
                     } else if (S.owner == me) {
                         HaloPeer &p = peers[R];

@@ -29,6 +29,7 @@ struct HaloPeer {
     std::vector<int32_t> send_src;    // offsets into the local (nx,ny,nblocks) array
     std::vector<int32_t> recv_dst;
     std::vector<int8_t> recv_sign;
+    std::vector<int32_t> recv_gid;    // global cell number (ig-1) + NX*(jg-1) each ghost mirrors (probe exchange)
 };
 
 struct HaloPlan {

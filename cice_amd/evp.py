@@ -41,7 +41,9 @@ EXPORTS = [
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
+    "cice_evp_hip_halo_export", "cice_evp_hip_halo_import",
 ]
+HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -205,10 +207,11 @@ class EvpHip:
         return out
 
     def timings(self) -> dict:
-        t = np.zeros(9)
-        self.lib.cice_evp_hip_get_timings(_dp(t), 9)
+        t = np.zeros(10)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 10)
         return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4],
-                    tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8])
+                    tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
+                    halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])])
 
     def mark(self, which: int):
         _check(self.lib, self.lib.cice_evp_hip_mark(C.c_int32(which)), "(dyn_evp_hip_mark)")
@@ -244,6 +247,18 @@ class EvpHip:
     def comm_init(self, uid: bytes):
         assert len(uid) == 128
         _check(self.lib, self.lib.cice_evp_hip_comm_init(C.c_char_p(uid)), "(dyn_evp_hip_comm_init)")
+
+    # mailbox halo without RCCL: export -> host all-gather (rank order) -> import (collective)
+    def halo_export(self) -> bytes:
+        buf = C.create_string_buffer(HALO_BLOB)
+        _check(self.lib, self.lib.cice_evp_hip_halo_export(buf), "(dyn_evp_hip_halo_export)")
+        return buf.raw
+
+    def halo_import(self, blobs):
+        raw = b"".join(blobs)
+        assert len(raw) == HALO_BLOB * len(blobs)
+        _check(self.lib, self.lib.cice_evp_hip_halo_import(C.c_char_p(raw), C.c_int32(len(blobs))),
+               "(dyn_evp_hip_halo_import)")
 
     # -- dyn_evp1d_finalize equivalent ---------------------------------------------------
     def finalize(self):

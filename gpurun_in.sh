@@ -1,13 +1,6 @@
 cd /root/repo; export TMPDIR=/tmp
-mkdir -p gpurun_out/r1e
-python bench.py > gpurun_out/r1e/bench_gx1.json 2> gpurun_out/r1e/bench_gx1.err; cut -c1-300 gpurun_out/r1e/bench_gx1.json
-python bench.py --fused --no-cpu-baseline > gpurun_out/r1e/bench_gx1_fused.json 2>/dev/null
-python bench.py --case caps --no-cpu-baseline > gpurun_out/r1e/bench_gx1_caps.json 2>/dev/null
-python bench.py --workload gx3 --no-cpu-baseline > gpurun_out/r1e/bench_gx3.json 2>/dev/null
-V=$(python -c "import json; print(json.load(open('gpurun_out/r1e/bench_gx1.json'))['config']['tile_variant'] % 1000)")
-export CICE_EVP_HIP_RESIDENT=1 CICE_EVP_HIP_RES_GEN=2 CICE_EVP_HIP_RES_LOGW=$V
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1e/prof -o gx1 -- python bench.py --no-cpu-baseline > gpurun_out/r1e/prof_gx1.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r1e/pmc -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r1e/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r1e/pmc -o write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r1e/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/r1e/pmc -o sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r1e/pmc_sq.log 2>&1
-head -3 gpurun_out/r1e/prof/gx1_kernel_stats.csv; echo logw $V
+mkdir -p gpurun_out/r1f
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r1f/pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/r1f/pytest_gpu.log | tail -5
+export CICE_EVP_HIP_SELF_EXCHANGE=1 CICE_EVP_HIP_HALO=direct CICE_EVP_HIP_HALO_RIDE=0 CICE_EVP_HIP_OVERLAP=0
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1f/prof_mb2 -o mb -- python tools/selfx_timing.py s01 > gpurun_out/r1f/prof_mb2.log 2>&1
+head -4 gpurun_out/r1f/prof_mb2/mb_kernel_stats.csv | cut -c1-160

@@ -155,6 +155,19 @@ int cice_evp_hip_dyn_finish(double *strocnxU, double *strocnyU);
  * (MPI_Bcast in CICE; torch.distributed in bench.py).                          */
 int cice_evp_hip_comm_unique_id(void *id128);
 int cice_evp_hip_comm_init(const void *id128);
+/* Mailbox halo inside one node: neighbouring ranks store ghost values straight into each
+ * other's HIP-IPC-mapped inboxes from a kernel (plain stores over xGMI + a flag handshake),
+ * so the whole subcycle loop -- exchange included -- is one hipGraph.  Replaces the same
+ * ice_HaloUpdate round as the RCCL path (ice_dyn_evp.F90:908-910).  cice_evp_hip_comm_init
+ * sets it up by itself (handles travel through an ncclAllGather, a probe exchange of global
+ * cell numbers -- the halochk method, drivers/unittest/halochk/halochk.F90:232-247 -- must
+ * pass on every rank, else all ranks stay on RCCL).  A host without RCCL does the same by
+ * hand: every rank exports CICE_EVP_HIP_HALO_BLOB bytes, the host all-gathers them
+ * (rank order) and every rank imports the nranks blobs; import runs the probe exchange
+ * (collective).  CICE_EVP_HIP_HALO=rccl|direct overrides the choice.                      */
+#define CICE_EVP_HIP_HALO_BLOB 1024
+int cice_evp_hip_halo_export(void *blob);
+int cice_evp_hip_halo_import(const void *blobs, int32_t nranks);
 
 /* ---- introspection ------------------------------------------------------------ */
 int cice_evp_hip_abi_version(void);
@@ -162,7 +175,9 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen);
 /* out[0]=last subcycle-loop ms (HIP events), [1]=H2D ms, [2]=D2H ms,
  * [3]=subcycles in that loop, [4]=kernel launches per subcycle,
  * [5]=tile variant in use (tile height + 100 * tile-order mode),
- * [6]=ms between cice_evp_hip_mark(0) and cice_evp_hip_mark(1), -1 if unset                 */
+ * [6]=ms between cice_evp_hip_mark(0) and cice_evp_hip_mark(1), -1 if unset,
+ * [7]=streaming probe ms/subcycle, [8]=resident probe ms/subcycle,
+ * [9]=remote halo transport: 0 none, 1 RCCL p2p, 2 mailbox (direct stores over xGMI)          */
 int cice_evp_hip_get_timings(double *out, int32_t n);
 /* Halo plan of this rank, for tests: counts[0]=local copies, [1]=#peers,
  * [2]=total send cells, [3]=total recv cells.  Lists may be NULL.

@@ -4,6 +4,9 @@
   (3) size-independent properties at full BASELINE sizes (decomposition invariance,
       mask invariants, strict-vs-fused tolerance).
 Tolerances (fused build, FMA contraction on): stated next to each assert."""
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -189,36 +192,69 @@ def test_resident_entry_points_equal_run():
         core.finalize()
 
 
+@pytest.mark.parametrize("transport", ["rccl", "direct", "direct-riding"])
 @pytest.mark.parametrize("name", ["pop_cyc_1blk_patchy", "pop_cyc_3x2pad_caps", "trip_cyc_2x2_full"])
-def test_single_rank_rccl_self_exchange(name, monkeypatch):
-    """The remote-halo path (pack kernel -> ncclGroup{ncclSend, ncclRecv} -> unpack kernel)
-    on one GPU: CICE_EVP_HIP_SELF_EXCHANGE routes every on-device ghost copy through RCCL
-    point-to-point to the rank itself.  Same bits as the fixtures."""
+def test_single_rank_self_exchange(name, transport, monkeypatch):
+    """The remote-halo paths on one GPU: CICE_EVP_HIP_SELF_EXCHANGE routes every on-device
+    ghost copy through the exchange with the rank itself -- either pack kernel ->
+    ncclGroup{ncclSend, ncclRecv} -> unpack kernel (rccl), or the mailbox kernel (direct:
+    stores into the inbox + flag handshake, set up and probed by comm_init).  Same bits as
+    the fixtures."""
     monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", transport.split("-")[0])
+    # riding: the exchange workgroup travels inside the subcycle launch (default on large domains)
+    monkeypatch.setenv("CICE_EVP_HIP_HALO_RIDE", "1" if transport.endswith("riding") else "0")
     c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     try:
         core.comm_init(core.comm_unique_id())
         dyn, tm, um = c.inputs(1)
         out = core.run(dyn, tm, um, ndte=120)
-        assert_bitwise(post_evp(c, out), c.expected(1, 120), "halo through RCCL self send/recv")
-        assert core.timings()["launches_per_subcycle"] == (4.0 if c.ns == "tripole" else 3.0)
+        assert_bitwise(post_evp(c, out), c.expected(1, 120), f"halo through {transport} self exchange")
+        t = core.timings()
+        assert t["halo_transport"] == ("rccl" if transport == "rccl" else "mailbox")
+        # rccl: compute, pack, unpack; mailbox: compute, exchange -- or the exchange workgroup rides
+        # in the compute launch; a tripole grid adds the seam kernel and never rides
+        want = {"rccl": 3.0, "direct": 2.0, "direct-riding": 1.0}[transport]
+        if c.ns == "tripole":
+            want = {"rccl": 4.0, "direct": 3.0, "direct-riding": 3.0}[transport]
+        assert t["launches_per_subcycle"] == want
+        out2 = core.run(*c.inputs(1), ndte=120)        # a second call reuses graph + sequence numbers
+        assert_bitwise(post_evp(c, out2), c.expected(1, 120), f"{transport}: second call")
     finally:
         core.finalize()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_gx1_boundary_first_overlap_path_bitwise(overlap, monkeypatch):
-    """gx1 in 2x2 blocks with every inter-block ghost copy routed through RCCL (to self):
-    boundary tiles first + pack, exchange on the communication stream while the interior
-    tiles run, unpack -- versus the oracle, bit for bit; and the same without overlap."""
+def test_mailbox_halo_without_rccl(monkeypatch):
+    """Hosts without RCCL set the mailbox halo up by hand: export -> all-gather -> import
+    (which runs the global-cell-number probe exchange)."""
     monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    c = GoldenCase("pop_cyc_3x2pad_caps")
+    core = hip_from_case(c, strict=True)
+    try:
+        core.halo_import([core.halo_export()])
+        out = core.run(*c.inputs(1), ndte=120)
+        assert_bitwise(post_evp(c, out), c.expected(1, 120), "mailbox halo, manual set-up")
+        assert core.timings()["halo_transport"] == "mailbox"
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "direct", "direct-riding"])
+@pytest.mark.parametrize("overlap", [True, False])
+def test_gx1_boundary_first_overlap_path_bitwise(overlap, transport, monkeypatch):
+    """gx1 in 2x2 blocks with every inter-block ghost copy routed through the remote exchange
+    (to self): boundary tiles first, exchange on the communication stream while the interior
+    tiles run -- versus the oracle, bit for bit; and the same without overlap."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", transport.split("-")[0])
+    monkeypatch.setenv("CICE_EVP_HIP_HALO_RIDE", "1" if transport.endswith("riding") else "0")
     monkeypatch.setenv("CICE_EVP_HIP_OVERLAP", "1" if overlap else "0")
     scal = synth.evp_scalars(120)
     dc, geo, fields, tm, um = synth_case("gx1", "full", seed=11, warm=True, bs=(160, 192))
     got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12, rccl_self=True)
     want = run_oracle(dc, geo, fields, tm, um, scal, 12)
-    assert_bitwise(got, want, f"gx1 2x2 blocks through RCCL, overlap={overlap}")
+    assert_bitwise(got, want, f"gx1 2x2 blocks through {transport}, overlap={overlap}")
 
 
 def test_remote_halo_without_communicator_fails_loudly(monkeypatch):
@@ -330,3 +366,22 @@ def test_resident_kernel_golden_and_modes(monkeypatch):
             core.run(dyn, tm, um, ndte=2)
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("world,workload,shape", [(2, "gx3", ""), (4, "gx3", "2x2"), (2, "gx1", "1x2")])
+def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape):
+    """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
+    peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
+    the one GPU of this box, each owning one block; every rank's sub-domain, ghost cells
+    included, equals the single-rank run bit for bit (tools/mailbox_2proc.py)."""
+    import subprocess
+    import sys as _sys
+    root = Path(__file__).resolve().parents[1]
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29540 + world + len(workload)),
+           str(root / "tools" / "mailbox_2proc.py"), "--workload", workload, "--ndte", "24"]
+    if shape:
+        cmd += ["--shape", shape]
+    env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

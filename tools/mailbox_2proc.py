@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""N ranks as N processes on ONE GPU exchanging the velocity halo through the mailbox
+transport (HIP IPC mapped inboxes + flag handshake), bootstrapped over gloo -- the only
+multi-process GPU configuration a 1-GPU box allows (RCCL refuses two ranks on one device).
+Each rank compares its sub-domain, bit for bit, with a single-rank run of the whole domain.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+         --master-port 29533 tools/mailbox_2proc.py [--workload gx3] [--ndte 24] [--timing]
+"""
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="gx3")
+    ap.add_argument("--ndte", type=int, default=24)
+    ap.add_argument("--timing", action="store_true")
+    ap.add_argument("--shape", default="")          # e.g. 2x1
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    from cice_amd import decomp, evp, synth
+
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    os.environ["CICE_EVP_HIP_DEVICE"] = "0"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    spec = synth.GRIDS[a.workload]
+    nx, ny = spec["nx"], spec["ny"]
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+    st = synth.make_state(g, case="full", seed=7, warm=True)
+    scal = synth.evp_scalars(120)
+
+    def run(dc, r, exchange):
+        geo = {k: dc.scatter(g[k], r, fill=(1.0 if k != "uarear" else 0.0))
+               for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+        fields = {k: dc.scatter(st[k], r) for k in evp.FIELDS}
+        tm = dc.scatter(st["iceTmask"], r, fill=0)
+        um = dc.scatter(st["iceUmask"], r, fill=0)
+        d, keep = evp.make_dims(dc, r)
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"],
+                          geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+        try:
+            if exchange:
+                blobs = [None] * world
+                dist.all_gather_object(blobs, core.halo_export())
+                core.halo_import(blobs)
+            core.upload(fields, tm, um)
+            core.subcycle(a.ndte)
+            out = core.download()
+            t = None
+            if a.timing:
+                core.sync()
+                if exchange:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    core.subcycle(120)
+                core.sync()
+                t = (time.perf_counter() - t0) / 600 * 1e6
+            return out, core.timings(), t
+        finally:
+            core.finalize()
+
+    ref, _, _ = run(decomp.single_block(nx, ny, "cyclic", "closed"), 0, False)
+    shape = tuple(int(v) for v in a.shape.split("x")) if a.shape else None
+    dcN = decomp.per_rank_blocks(nx, ny, world, "cyclic", "closed", proc_shape=shape)
+    got, tim, t_us = run(dcN, rank, True)
+    assert tim["halo_transport"] == "mailbox", tim
+    bad = []
+    for k in ("uvel", "vvel", "stressp_1", "stressm_3", "stress12_4", "strintxU", "taubyU"):
+        if k not in got:
+            continue
+        want = dcN.scatter(ref[k][0][1:-1, 1:-1], rank)
+        for b in dcN.local_blocks(rank):
+            w = want[b.local][1:1 + b.gny, 1:1 + b.gnx]
+            h = got[k][b.local][1:1 + b.gny, 1:1 + b.gnx]
+            if not np.array_equal(w, h):
+                bad.append((k, float(np.abs(w - h).max())))
+        if k in ("uvel", "vvel"):      # ghost cells too (post-condition of the drop-in boundary)
+            if not np.array_equal(want, got[k]):
+                bad.append((k + " ghosts", float(np.abs(want - got[k]).max())))
+    res = [None] * world
+    dist.all_gather_object(res, (rank, bad, t_us, tim["launches_per_subcycle"]))
+    if rank == 0:
+        ok = all(not r[1] for r in res)
+        print("MAILBOX_2PROC", "OK" if ok else "FAIL", a.workload, f"world={world}", res, flush=True)
+        if not ok:
+            sys.exit(1)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,21 +1,28 @@
+"""Timing of the remote-halo transports on ONE GPU (CICE_EVP_HIP_SELF_EXCHANGE routes every
+inter-block ghost copy through the exchange with the rank itself).  Usage:
+  CICE_EVP_HIP_SELF_EXCHANGE=1 CICE_EVP_HIP_HALO=direct|rccl python tools/selfx_timing.py [gx1|s01] [bx by]"""
 import sys, os, time
 import pathlib; R=str(pathlib.Path(__file__).resolve().parents[1]); sys.path[:0]=[R, R+'/tests', R+'/oracle']
 import numpy as np
 from cice_amd import evp, synth, decomp
 from test_gpu_parity import synth_case
+wl = sys.argv[1] if len(sys.argv) > 1 else "gx1"
+bs = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else {"gx1": (320, 192), "s01": (1800, 1200)}[wl]
+ndte = {"gx1": 120, "s01": 48}[wl]
 scal = synth.evp_scalars(120)
-dc, geo, fields, tm, um = synth_case("gx1", "full", seed=1, warm=True, bs=(320,192))
+dc, geo, fields, tm, um = synth_case(wl, "full", seed=1, warm=True, bs=bs)
 d, keep = evp.make_dims(dc, 0)
 core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
 if os.environ.get("CICE_EVP_HIP_SELF_EXCHANGE"):
     core.comm_init(core.comm_unique_id())
 core.upload(fields, tm, um)
-for _ in range(2): core.subcycle(120)
+for _ in range(2): core.subcycle(ndte)
 core.sync()
 t0=time.perf_counter()
-for _ in range(10): core.subcycle(120)
+for _ in range(10): core.subcycle(ndte)
 core.sync()
 t=time.perf_counter()-t0
 out=core.download()
-print("RESULT", os.environ.get("CICE_EVP_HIP_SELF_EXCHANGE"), os.environ.get("CICE_EVP_HIP_GRAPH_RCCL"), 'us/subcycle', 1e6*t/1200, 'checksum', float(np.abs(out['uvel']).sum()), core.timings())
+tt=core.timings()
+print("RESULT", wl, bs, 'us/subcycle %.2f' % (1e6*t/(10*ndte)), 'checksum', float(np.abs(out['uvel']).sum()), tt['halo_transport'], tt['launches_per_subcycle'], tt['tile_variant'])
 core.finalize()
