@@ -116,6 +116,8 @@ struct State {
             *h_late_src = nullptr;
     int8_t *h_late_sign = nullptr;
     int n_seam = 0, n_pole = 0, n_late = 0;
+    int32_t *h_stress_dst = nullptr, *h_stress_src = nullptr;
+    int n_stress = 0;
     int32_t *h_send_src = nullptr, *h_recv_dst = nullptr;
     int8_t *h_recv_sign = nullptr;
     double *sendbuf = nullptr, *recvbuf = nullptr;
@@ -207,6 +209,7 @@ void free_all()
     F(S.h_local_src);
     F(S.h_local_sign);
     F(S.h_seam_a); F(S.h_seam_b); F(S.h_seam_pole); F(S.h_late_dst); F(S.h_late_src); F(S.h_late_sign);
+    F(S.h_stress_dst); F(S.h_stress_src);
     F(S.h_send_src);
     F(S.h_recv_dst);
     F(S.h_recv_sign);
@@ -321,6 +324,8 @@ int upload_lists()
     S.n_late = (int)P.late_dst.size();
     if (up32(P.seam_a, S.h_seam_a) || up32(P.seam_b, S.h_seam_b) || up32(P.seam_pole, S.h_seam_pole) ||
         up32(P.late_dst, S.h_late_dst) || up32(P.late_src, S.h_late_src)) return -1;
+    S.n_stress = (int)P.stress_dst.size();
+    if (up32(P.stress_dst, S.h_stress_dst) || up32(P.stress_src, S.h_stress_src)) return -1;
     if (S.n_late) {
         HIPC(hipMalloc((void **)&S.h_late_sign, S.n_late));
         HIPC(hipMemcpy(S.h_late_sign, P.late_sign.data(), S.n_late, hipMemcpyHostToDevice));
@@ -1170,6 +1175,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
                 continue;
             }
             self.send_src.push_back(S.plan.local_src[k]);
+            self.send_dst.push_back(S.plan.local_dst[k]);
             self.recv_dst.push_back(S.plan.local_dst[k]);
             self.recv_sign.push_back(S.plan.local_sign[k]);
             {
@@ -1455,6 +1461,16 @@ int cice_evp_hip_subcycle(int32_t ndte)
     HIPC(hipEventRecord(S.ev1, S.stream));
     S.cur ^= (ndte & 1);
     S.t_nsub = ndte;
+    return 0;
+}
+
+// Tripole: force the stresses symmetric across the seam on the resident state, as evp() does
+// on the host arrays after the subcycle loop (12 x ice_HaloUpdate_stress, ice_dyn_evp.F90:1321-1389).
+int cice_evp_hip_stress_halo(void)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    evp_launch_halo_stress(S.sig[S.cur], S.h_stress_dst, S.h_stress_src, S.n_stress, S.stream);
+    HIPC(hipGetLastError());
     return 0;
 }
 
@@ -1790,6 +1806,17 @@ int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_
 
 // Tripole part of the plan built by the last init / plan_build (tests): counts3 =
 // {pairs, poles, late copies}; lists may be NULL.
+int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src)
+{
+    const HaloPlan &P = S.plan;
+    if (count) *count = (int32_t)P.stress_dst.size();
+    for (size_t k = 0; k < P.stress_dst.size(); ++k) {
+        if (dst) dst[k] = P.stress_dst[k];
+        if (src) src[k] = P.stress_src[k];
+    }
+    return 0;
+}
+
 int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,
                            int32_t *late_dst, int32_t *late_src, int32_t *late_sign)
 {

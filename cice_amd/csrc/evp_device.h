@@ -141,6 +141,7 @@ void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
 void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, int npair, const int *pole,
                           int npole, const int *ldst, const int *lsrc, const signed char *lsign,
                           int nlate, hipStream_t st);
+void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src, int n, hipStream_t st);
 void evp_launch_halo_pack(const double *u, const double *v, const int *src, double *buf, int n,
                           hipStream_t st);
 void evp_launch_halo_unpack(double *u, double *v, const int *dst, const signed char *sign,

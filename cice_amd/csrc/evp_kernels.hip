@@ -346,6 +346,19 @@ __global__ void halo_seam_uv(double *__restrict__ u, double *__restrict__ v,
     }
 }
 
+// ice_HaloUpdate_stress x 12 (ice_dyn_evp.F90:1321-1389): component k of a family takes the
+// mirrored top row of its partner (1<->3, 2<->4 == index ^ 2) into its tripole ghost row.
+// Reads interior rows, writes ghost rows: the 12 updates are independent.
+struct SigTable { double *p[12]; };
+__global__ void halo_stress_sym(SigTable T, const int *__restrict__ dst, const int *__restrict__ src, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int d = dst[t], s = src[t];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T.p[k][d] = (s >= 0) ? T.p[k ^ 2][s] : 0.0;
+}
+
 // pack / unpack of remote halo cells (ice_boundary.F90:1260-1284, 1419-1449)
 __global__ void halo_pack_uv(const double *__restrict__ u, const double *__restrict__ v,
                              const int *__restrict__ src, double *__restrict__ buf, int n)
@@ -472,6 +485,14 @@ void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, in
     if (npair <= 0 && npole <= 0 && nlate <= 0) return;
     hipLaunchKernelGGL(halo_seam_uv, dim3(1), dim3(1024), 0, st, u, v, pa, pb, npair, pole, npole, ldst,
                        lsrc, lsign, nlate);
+}
+
+void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    SigTable T;
+    for (int k = 0; k < 12; ++k) T.p[k] = sig12[k];
+    hipLaunchKernelGGL(halo_stress_sym, dim3((n + 255) / 256), dim3(256), 0, st, T, dst, src, n);
 }
 
 void evp_launch_halo_pack(const double *u, const double *v, const int *src, double *buf, int n,

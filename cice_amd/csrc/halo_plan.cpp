@@ -174,6 +174,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                         HaloPeer &p = peers[R];
                         p.rank = R;
                         p.send_src.push_back(src);
+                        p.send_dst.push_back(dst);
                     }
                 }
         }
@@ -208,6 +209,36 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
             plan.seam_a.push_back(a);
             plan.seam_b.push_back(b);
         }
+        // stress symmetrisation lists (cell-centre fold: partner column NX-ig+1)
+        auto it = T.by_rank.find(me);
+        if (it != T.by_rank.end())
+            for (int kb : it->second) {
+                const HaloBlock &B = T.blk[kb];
+                if (B.gj0 + B.gny - 1 != NY) continue;            // not a top-row block
+                const int j = ng + B.gny + 1;                     // local ghost row = global NY+1
+                for (int i = 1; i <= B.gnx + 2 * ng; ++i) {
+                    int ig = B.gi0 + (i - (ng + 1));
+                    if (ig < 1) ig += NX;
+                    if (ig > NX) ig -= NX;
+                    int owner = -1;
+                    const int32_t src = offset_of(NX - ig + 1, NY, owner);
+                    if (owner >= 0 && owner != me) {
+                        plan.error = "tripole: the stress symmetrisation needs a top-row cell of another rank "
+                                     "(not implemented); use a rank layout with px = 1";
+                        return false;
+                    }
+                    plan.stress_dst.push_back((int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1)));
+                    plan.stress_src.push_back(owner < 0 ? -1 : src);
+                }
+            }
     }
+    // ghost cells whose source block was eliminated: ice_HaloUpdate_stress writes the fill value
+    // (srcBlock == 0, ice_boundary.F90:7643-7645) -- the same cells the velocity plan zero-fills
+    for (size_t k = 0; k < plan.local_dst.size(); ++k)
+        if (plan.local_src[k] < 0 && tripole) {
+            bool dup = false;
+            for (int32_t dd : plan.stress_dst) dup |= dd == plan.local_dst[k];
+            if (!dup) { plan.stress_dst.push_back(plan.local_dst[k]); plan.stress_src.push_back(-1); }
+        }
     return true;
 }

@@ -27,6 +27,7 @@ struct HaloBlock {
 struct HaloPeer {
     int rank = -1;
     std::vector<int32_t> send_src;    // offsets into the local (nx,ny,nblocks) array
+    std::vector<int32_t> send_dst;    // the ghost cell each entry fills, as an offset into the PEER's array
     std::vector<int32_t> recv_dst;
     std::vector<int8_t> recv_sign;
     std::vector<int32_t> recv_gid;    // global cell number (ig-1) + NX*(jg-1) each ghost mirrors (probe exchange)
@@ -47,6 +48,11 @@ struct HaloPlan {
     std::vector<int32_t> seam_a, seam_b, seam_pole;
     std::vector<int32_t> late_dst, late_src;
     std::vector<int8_t> late_sign;
+    // ice_HaloUpdate_stress (ice_boundary.F90:7441-7826; evp() after the subcycle loop,
+    // ice_dyn_evp.F90:1321-1389): ghost row NY+1 of a cell-centre scalar takes the mirrored top
+    // physical row of its PARTNER array, a1(ig, NY+1) <- a2(NX-ig+1, NY); ghost cells whose source
+    // block was eliminated are set to 0 (src = -1).  Offsets into the local array.
+    std::vector<int32_t> stress_dst, stress_src;
     std::string error;
 };
 

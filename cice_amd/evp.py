@@ -41,7 +41,7 @@ EXPORTS = [
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
-    "cice_evp_hip_halo_export", "cice_evp_hip_halo_import",
+    "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan",
 ]
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
 
@@ -213,6 +213,10 @@ class EvpHip:
                     tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
                     halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])])
 
+    def stress_halo(self):
+        """Tripole: 12 x ice_HaloUpdate_stress on the resident stresses (ice_dyn_evp.F90:1321-1389)."""
+        _check(self.lib, self.lib.cice_evp_hip_stress_halo(), "(dyn_evp_hip_stress_halo)")
+
     def mark(self, which: int):
         _check(self.lib, self.lib.cice_evp_hip_mark(C.c_int32(which)), "(dyn_evp_hip_mark)")
 
@@ -292,7 +296,13 @@ def halo_plan(dims: Dims) -> dict:
     sp = np.zeros(max(npole, 1), dtype=np.int32)
     td, ts, tg = [np.zeros(max(nlate, 1), dtype=np.int32) for _ in range(3)]
     lib.cice_evp_hip_seam_plan(_ip(c3), _ip(sa), _ip(sb), _ip(sp), _ip(td), _ip(ts), _ip(tg))
-    return dict(local_dst=ld[:nl], local_src=ls[:nl], local_sign=lg[:nl], peer_rank=pr[:npeer],
+    c1 = np.zeros(1, dtype=np.int32)
+    lib.cice_evp_hip_stress_plan(_ip(c1), None, None)
+    nst = int(c1[0])
+    std, sts = [np.zeros(max(nst, 1), dtype=np.int32) for _ in range(2)]
+    lib.cice_evp_hip_stress_plan(_ip(c1), _ip(std), _ip(sts))
+    return dict(stress_dst=std[:nst], stress_src=sts[:nst],
+                local_dst=ld[:nl], local_src=ls[:nl], local_sign=lg[:nl], peer_rank=pr[:npeer],
                 peer_nsend=pns[:npeer], peer_nrecv=pnr[:npeer], send_src=ss[:ns], recv_dst=rd[:nr],
                 seam_a=sa[:npair], seam_b=sb[:npair], seam_pole=sp[:npole],
                 late_dst=td[:nlate], late_src=ts[:nlate], late_sign=tg[:nlate])

@@ -145,6 +145,12 @@ int cice_evp_hip_sync(void);
  * computed on the device from the resident state after cice_evp_hip_subcycle/_run.
  * set_post_geometry: ice_grid arrays dxU, dyU, tarear (once).  deformations: outputs,
  * zero where iceTmask is false.  dyn_finish: strocnxU/yU are inout.               */
+/* stress_halo (rest of SURVEY 8 f-3): on a tripole grid, force the 12 resident stress components
+ * symmetric across the seam -- what evp() does with 12 x ice_HaloUpdate_stress on the host arrays
+ * right after the subcycle loop (ice_dyn_evp.F90:1321-1389; ice_boundary.F90:7441-7826): the
+ * ghost row NY+1 of component c takes the mirrored top physical row of its partner (1<->3, 2<->4).
+ * Call between cice_evp_hip_subcycle and cice_evp_hip_download; no-op on other grids.            */
+int cice_evp_hip_stress_halo(void);
 int cice_evp_hip_set_post_geometry(const double *dxU, const double *dyU, const double *tarear);
 int cice_evp_hip_deformations(double *divu, double *shear, double *vort, double *rdg_conv,
                               double *rdg_shear);
@@ -199,6 +205,9 @@ int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_
  * (ice_boundary.F90:1630-1649, 1689-1722).  Lists may be NULL.                  */
 int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,
                            int32_t *late_dst, int32_t *late_src, int32_t *late_sign);
+/* Lists behind cice_evp_hip_stress_halo: a1[dst] <- a2[src] for every partner pair (src = -1:
+ * fill 0, ice_boundary.F90:7643-7645).  Lists may be NULL.                                     */
+int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,33 @@ def test_halo_plan_matches_oracle_semantics(ew, ns, bx, by):
     assert len(set(plan["local_dst"].tolist())) == len(plan["local_dst"])
 
 
+@pytest.mark.parametrize("bx,by", [(20, 18), (5, 6), (7, 18), (10, 9)])
+def test_stress_symmetrisation_lists_match_oracle(bx, by):
+    """The lists behind cice_evp_hip_stress_halo (ice_HaloUpdate_stress, f-3) applied with numpy
+    == the oracle's restatement (itself pinned by the tripole fixtures of the whole evp())."""
+    dc = decomp.Decomp(20, 18, bx, by, "cyclic", "tripole", 1)
+    d, keep = evp.make_dims(dc, 0)
+    plan = evp.halo_plan(d)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), 20, 18, "cyclic", "tripole",
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    rng = np.random.default_rng(11)
+    out = {k: rng.standard_normal(dc.shape(0)) for k in evp.FIELDS[:12]}
+    want = oracle.tripole_stress_sym(dom, {k: v.copy() for k, v in out.items()})
+    names = evp.FIELDS[:12]
+    got = {k: v.copy() for k, v in out.items()}
+    dst, src = plan["stress_dst"], plan["stress_src"]
+    assert len(dst) > 0 and (src >= 0).all()
+    for k, name in enumerate(names):
+        got[name].reshape(-1)[dst] = out[names[k ^ 2]].reshape(-1)[src]     # partner: 1<->3, 2<->4
+    for name in names:
+        assert np.array_equal(got[name], want[name]), name
+    # no list on a grid without a tripole seam
+    d2, keep2 = evp.make_dims(decomp.Decomp(20, 18, bx, by, "cyclic", "closed", 1), 0)
+    assert len(evp.halo_plan(d2)["stress_dst"]) == 0
+
+
 def test_tripole_plan_refuses_seam_split_across_ranks():
     dc = decomp.Decomp(20, 18, 10, 9, "cyclic", "tripole", 2, (2, 1))   # seam row cut in x
     d, keep = evp.make_dims(dc, 0)

@@ -192,6 +192,27 @@ def test_resident_entry_points_equal_run():
         core.finalize()
 
 
+@pytest.mark.parametrize("name", [n for n in GOLDEN_CASES if n.startswith("trip")])
+def test_tripole_stress_symmetrisation_on_device(name):
+    """the 12 x ice_HaloUpdate_stress evp() applies after the loop, done on the
+    resident stresses (cice_evp_hip_stress_halo) -- the downloaded state equals the reference's
+    whole-evp() output on every cell with NO host-side step; and it changes something."""
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        for icall in range(1, c.ncalls + 1):
+            dyn, tm, um = c.inputs(icall)
+            core.upload(dyn, tm, um)
+            core.subcycle(c.ndte)
+            raw = core.download()
+            core.stress_halo()
+            out = core.download()
+            assert_bitwise(out, c.expected(icall, c.ndte), f"{name} call {icall}: device stress halo")
+            assert any(not np.array_equal(raw[k], out[k]) for k in SIG), "symmetrisation was a no-op"
+    finally:
+        core.finalize()
+
+
 @pytest.mark.parametrize("transport", ["rccl", "direct", "direct-riding"])
 @pytest.mark.parametrize("name", ["pop_cyc_1blk_patchy", "pop_cyc_3x2pad_caps", "trip_cyc_2x2_full"])
 def test_single_rank_self_exchange(name, transport, monkeypatch):
