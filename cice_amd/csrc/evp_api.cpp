@@ -128,7 +128,7 @@ struct State {
         bool on = false;             // use it for the remote halo
         bool exported = false;
         void *mailbox = nullptr;     // [flags][seq][err][inbox x 2 parities]
-        size_t bytes = 0, inbox_off = 0;
+        size_t bytes = 0, inbox_off = 0, rec_off = 0;
         std::vector<void *> opened;  // hipIpcOpenMemHandle results
         EvpDirect *d_dx = nullptr;   // device copy of the argument block (exchange riding in the subcycle launch)
         unsigned *d_cnt = nullptr;   // [0] boundary tiles checked in, [16] launches with a riding exchange
@@ -155,6 +155,13 @@ struct State {
     void *res2_rec[2] = {nullptr, nullptr};
     int res2_logw = 0, res2_ntiles = 0;
     unsigned res2_epoch = 0;
+    int res2_par = 0;            // record buffer in which the next launch starts (EvpResident2::par0)
+    bool res2_rec_owned = true;  // false: the record buffers live inside the mailbox allocation
+    // resident kernel with neighbours on other GPUs (records stored into peers' buffers over xGMI)
+    bool res_remote = false;     // agreed by all ranks at mailbox import
+    int2 *res2_rimg = nullptr;
+    void **res2_peer_rec = nullptr;
+    size_t *res2_peer_rstride = nullptr;
     bool res_launched = false;   // an un-checked launch is in flight
     double t_res_probe_ms = 0, t_stream_probe_ms = 0;
 
@@ -198,7 +205,13 @@ void free_all()
     F(S.htn);
     F(S.vrelfac);
     F(S.res_flags); F(S.res_nbr); F(S.res_err); F(S.res_tab);
-    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_rec[0]); F(S.res2_rec[1]);
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub);
+    if (S.res2_rec_owned) { F(S.res2_rec[0]); F(S.res2_rec[1]); }
+    S.res2_rec[0] = S.res2_rec[1] = nullptr;
+    S.res2_rec_owned = true;
+    S.res_remote = false;
+    S.res2_par = 0; S.res2_epoch = 0;
+    F(S.res2_rimg); F(S.res2_peer_rec); F(S.res2_peer_rstride);
     for (auto &p : S.res_scratch) F(p);
     for (auto &p : S.post_geo) F(p);
     for (auto &p : S.post_out) F(p);
@@ -504,9 +517,9 @@ int halo_uv(int b)
 // ---- on-chip resident subcycle -------------------------------------------------------
 // Host side of evp_resident.hip: which tiles exchange velocities (producers == readers by
 // symmetry: the 8 surrounding tiles, with cyclic wrap through the ghost-cell images).
-bool resident_possible()
+bool resident_possible(bool with_peers = false)
 {
-    if (S.d.nblocks != 1 || !S.plan.peers.empty()) return false;
+    if (S.d.nblocks != 1 || (!with_peers && !S.plan.peers.empty())) return false;
     if ((S.n_seam + S.n_pole + S.n_late) > 0) return false;          // tripole seam: streaming path
     if (S.n_local > 0 && !S.push_ok) return false;
     return true;
@@ -597,6 +610,8 @@ int resident2_setup(int logw)
     std::vector<int> ghost_src((size_t)nx * ny, -1);
     for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
         if (S.plan.local_src[k] >= 0) ghost_src[S.plan.local_dst[k]] = S.plan.local_src[k];
+    for (const HaloPeer &p : S.plan.peers)            // produced on another rank: -2 (always refreshed)
+        for (int32_t d : p.recv_dst) ghost_src[d] = -2;
     std::vector<int4> ring((size_t)ntiles * EVP_RES2_RING, make_int4(-1, 0, -1, 0));
     std::vector<int> cnt((size_t)ntiles, 0);
     std::vector<uint8_t> pub((size_t)nx * ny, 0);
@@ -637,6 +652,7 @@ int resident2_setup(int logw)
     HIPC(hipMemcpy(S.res2_pub, pub.data(), pub.size(), hipMemcpyHostToDevice));
     for (auto &p : S.res2_rec)
         if (!p) {
+            if (!S.res2_rec_owned) return fail(-6, "resident2: record buffers missing from the mailbox");
             HIPC(hipMalloc(&p, (size_t)nx * ny * 32));
             HIPC(hipMemset(p, 0, (size_t)nx * ny * 32));
         }
@@ -647,11 +663,13 @@ int resident2_setup(int logw)
     return 0;
 }
 
-bool resident2_fits()
+bool resident2_fits(bool remote = false)
 {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
-    const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed, S.res2_logw), 8);
+    // remote: decided before any field has been seen -> the flag combination with the largest LDS need
+    const unsigned fl = remote ? (S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO)) : (S.flags & S.flags_allowed);
+    const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res2_logw, remote), 8);
     const long cap = (long)per_cu * prop.multiProcessorCount;
     return S.res2_ntiles > 0 && (long)S.res2_ntiles * 10 <= cap * 9;
 }
@@ -671,6 +689,14 @@ int launch_resident2(int ndte, int cur0, bool dry)
     S.res2_epoch = (S.res2_epoch + 1u) & 0xFFFFFu;
     if (S.res2_epoch == 0) S.res2_epoch = 1;
     R.tag_base = S.res2_epoch << 12;
+    R.par0 = S.res2_par;
+    S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
+    R.rimg = S.res_remote ? S.res2_rimg : nullptr;
+    R.rimg_ni = S.max_ni; R.rimg_nj = S.max_nj;
+    R.peer_rec = S.res2_peer_rec;
+    R.peer_rstride = S.res2_peer_rstride;
+    static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
+    R.timeout_ticks = (unsigned long long)(tmo_ms * 1.0e5);
     R.spin_limit = 4000000u;
     R.err = S.res_err;
     R.pubmap = S.res2_pub;
@@ -755,6 +781,9 @@ int resident_check_error()
     if (e) {
         HIPC(hipMemset(S.res_err, 0, sizeof(int)));
         S.res_mode = 0;
+        if (e == 2)
+            return fail(-7, "resident EVP kernel: a record of another rank never arrived within the time-out "
+                            "(CICE_EVP_HIP_HALO_TIMEOUT_MS)");
         return fail(-7, "resident EVP kernel: a neighbour-flag wait timed out (workgroups not co-resident?)");
     }
     return 0;
@@ -770,6 +799,8 @@ struct HaloBlob {
     int64_t pid;
     uint64_t base;                 // mailbox address in the exporting process
     uint64_t inbox_off, n_recv;
+    uint64_t rec_off, rec_stride;  // record buffers of the resident kernel inside the mailbox (0: none)
+    int32_t can_res, pad_;         // this rank can run the resident kernel with remote neighbours
     hipIpcMemHandle_t handle;
     struct { int32_t rank, recv_off, count, flag_idx; } peer[EVP_DIRECT_MAXPEER];
 };
@@ -790,9 +821,19 @@ int direct_export(HaloBlob &B)
     State::Direct &X = S.direct;
     const int np = (int)S.plan.peers.size();
     if (np > EVP_DIRECT_MAXPEER) return fail(-8, "mailbox halo: %d peers > %d", np, EVP_DIRECT_MAXPEER);
+    // resident kernel across GPUs: its record buffers must be writable by the neighbours, so they
+    // live in the mailbox allocation (one IPC handle)
+    bool want_res = resident_possible(true) && !S.plan.peers.empty() &&
+                    !(env("CICE_EVP_HIP_RESIDENT") && std::atoi(env("CICE_EVP_HIP_RESIDENT")) == 0) &&
+                    !(env("CICE_EVP_HIP_RES_REMOTE") && std::atoi(env("CICE_EVP_HIP_RES_REMOTE")) == 0);
+    size_t rec_off = 0;
+    const size_t rec_stride = S.plane * 32;
     if (!X.mailbox) {
         X.inbox_off = DIRECT_INBOX_OFF;
         X.bytes = X.inbox_off + 2 * 2 * (size_t)std::max(S.n_recv, 1) * sizeof(double);
+        X.bytes = (X.bytes + 255) & ~(size_t)255;
+        if (want_res) { rec_off = X.bytes; X.bytes += 2 * rec_stride; }
+        X.rec_off = rec_off;
         // fine-grained: stores of another GPU become visible to loads here without a kernel boundary
         if (hipExtMallocWithFlags(&X.mailbox, X.bytes, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
@@ -800,7 +841,25 @@ int direct_export(HaloBlob &B)
         }
         HIPC(hipMemset(X.mailbox, 0, X.bytes));
     }
+    int can_res = 0;
+    if (want_res && X.rec_off) {
+        if (S.res2_rec_owned)
+            for (auto &q : S.res2_rec) { if (q) (void)hipFree(q); q = nullptr; }
+        S.res2_rec_owned = false;
+        S.res2_rec[0] = (char *)X.mailbox + X.rec_off;
+        S.res2_rec[1] = (char *)X.mailbox + X.rec_off + rec_stride;
+        const int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
+        for (int logw : {4, 5, 6}) {
+            if (forced_w && logw != forced_w) continue;
+            if (resident2_setup(logw)) continue;
+            if (resident2_fits(true)) { can_res = 1; break; }
+        }
+        g_err.clear();
+    }
     std::memset(&B, 0, sizeof B);
+    B.can_res = can_res;
+    B.rec_off = X.rec_off;
+    B.rec_stride = rec_stride;
     B.magic = HALO_BLOB_MAGIC;
     B.version = 1;
     B.rank = S.d.rank;
@@ -873,6 +932,45 @@ int direct_import(const HaloBlob *blobs, int nranks)
         return 0;
     };
     if (up(X.send_addr, send_addr) || up(X.send_pstride, send_pstride) || up(X.peer_flag, peer_flag)) return -1;
+    // resident kernel with neighbours on other GPUs: only if EVERY rank can run it
+    bool all_res = true;
+    for (int r = 0; r < nranks; ++r) all_res = all_res && blobs[r].magic == HALO_BLOB_MAGIC && blobs[r].can_res != 0;
+    S.res_remote = false;
+    if (all_res && np > 0) {
+        std::vector<void *> prec((size_t)np);
+        std::vector<size_t> pstr((size_t)np);
+        const int nslot = 2 * (S.max_nj + S.max_ni);
+        std::vector<int2> rimg((size_t)nslot * 2, make_int2(-1, -1));
+        const int nx = S.d.nx_block;
+        bool ok = true;
+        for (int q = 0; q < np && ok; ++q) {
+            const HaloPeer &p = S.plan.peers[q];
+            const HaloBlob &B = blobs[p.rank];
+            prec[q] = mapped[p.rank] + B.rec_off;
+            pstr[q] = (size_t)B.rec_stride;
+            for (size_t k = 0; k < p.send_src.size() && ok; ++k) {
+                const int rem = (int)(p.send_src[k] % S.plane);
+                const int j = rem / nx + 1, i = rem % nx + 1;
+                const int cand[4] = {(i == S.ilo[0]) ? (j - S.jlo[0]) : -1,
+                                     (i == S.ihi[0]) ? S.max_nj + (j - S.jlo[0]) : -1,
+                                     (j == S.jlo[0]) ? 2 * S.max_nj + (i - S.ilo[0]) : -1,
+                                     (j == S.jhi[0]) ? 2 * S.max_nj + S.max_ni + (i - S.ilo[0]) : -1};
+                bool placed = false;
+                for (int e = 0; e < 4 && !placed; ++e) {
+                    if (cand[e] < 0) continue;
+                    for (int w = 0; w < 2 && !placed; ++w) {
+                        int2 &slot = rimg[(size_t)cand[e] * 2 + w];
+                        if (slot.x < 0) { slot = make_int2(q, p.send_dst[k]); placed = true; }
+                    }
+                }
+                ok = placed;
+            }
+        }
+        if (ok) {
+            if (up(S.res2_rimg, rimg) || up(S.res2_peer_rec, prec) || up(S.res2_peer_rstride, pstr)) return -1;
+            S.res_remote = true;
+        }
+    }
     EvpDirect D;
     fill_direct(D);
     if (!X.d_dx) HIPC(hipMalloc((void **)&X.d_dx, sizeof(EvpDirect)));
@@ -1355,7 +1453,12 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
         S.res_mode = 0;
         int want = -1;
         if (env("CICE_EVP_HIP_RESIDENT")) want = std::atoi(env("CICE_EVP_HIP_RESIDENT"));
-        if (want != 0 && resident_possible()) {
+        if (want != 0 && S.res_remote && S.direct.on) {
+            // neighbours on other GPUs: tile shape fixed at export, no timing probes (every launch
+            // of this kernel is collective across ranks)
+            S.res_gen = 2;
+            S.res_mode = 1;
+        } else if (want != 0 && resident_possible()) {
             const int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
             const int forced_g = env("CICE_EVP_HIP_RES_GEN") ? std::atoi(env("CICE_EVP_HIP_RES_GEN")) : 0;
             float best = 1e30f;
@@ -1622,6 +1725,7 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
     const double v[10] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+                         S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
                          (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,

@@ -91,8 +91,16 @@ struct EvpResident2 {
     void *rec[2];              // [2][ncell] x {u granule, v granule} (2 x 16 bytes), by subcycle parity
     double *u[2], *v[2];       // plain arrays: input from [cur0], final state to both
     double *const *tab;        // as EvpResident::tab
+    int par0;                  // which of rec[0/1] holds the records of subcycle index 0 of THIS launch
+                               // (flips so that a launch never starts in the buffer the previous one ended in)
+    // neighbours on other GPUs (ring entries with z == -2 are produced there); rimg == NULL: none
+    const int2 *rimg;          // [2*(rimg_nj+rimg_ni)] edge slots x 2: {peer index, ghost cell at that peer}, x = -1 none
+    int rimg_ni, rimg_nj;
+    void *const *peer_rec;     // [npeers] the peer's record buffer (parity 0) as mapped here
+    const size_t *peer_rstride;// [npeers] bytes between the two parities of that buffer
+    unsigned long long timeout_ticks;   // bound of a wait on another rank (100 MHz wall clock)
 };
-int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw);
+int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote);
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,
                           bool strict, int cap, hipStream_t st);
 

@@ -44,6 +44,21 @@ __device__ __forceinline__ void ld_rec2(const void *p, v4u &a, v4u &b)
                  : "v"(p)
                  : "memory");
 }
+// the same at system scope: records another GPU writes into this one's buffer / this one into a peer's
+__device__ __forceinline__ void st_rec2_sys(void *p, v4u a, v4u b)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1"
+                 :
+                 : "v"(p), "v"(a), "v"(b)
+                 : "memory");
+}
+__device__ __forceinline__ void ld_rec2_sys(const void *p, v4u &a, v4u &b)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(p)
+                 : "memory");
+}
 __device__ __forceinline__ v4u pack_rec(double x, unsigned tag)
 {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
@@ -56,8 +71,13 @@ __device__ __forceinline__ double unpack_rec(v4u r)
     return __longlong_as_double((long long)(((unsigned long long)r.z << 32) | r.y));
 }
 
-template <bool STRICT, int CAP, int LOGW>
-__global__ __launch_bounds__(64 * RTY, 4) void evp_resident2_tile(EvpArgs A, EvpResident2 R)
+// REMOTE: some ghost cells mirror cells of OTHER ranks (GPUs of the same node).  Their records
+// live in this rank's record buffer and are written by the producing GPU with plain 16-byte
+// stores over xGMI (the buffer is mapped there through HIP IPC); an edge cell with remote images
+// stores its record into the peers' buffers as well.  Nothing else changes: the halo exchange is
+// a remote store plus the ring poll that is there anyway.
+template <bool STRICT, int CAP, int LOGW, bool REMOTE>
+__global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(EvpArgs A, EvpResident2 R)
 {
     using MM = Math<STRICT>;
     constexpr int W = 1 << LOGW;
@@ -98,6 +118,7 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident2_tile(EvpArgs A, Evp
     const bool isU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
     const bool own = (tcol < W - 1 || i == r.y + 1) && (trow < H - 1 || j == r.w + 1);
     const bool pub = isU && (R.pubmap[c] != 0);   // some other tile's ring mirrors this cell
+    const int par0 = R.par0;                      // record buffer of subcycle index 0 in this launch
 
     // ---- state that stays on the CU for the whole call -------------------------------------
     typename MM::SI a;
@@ -165,22 +186,74 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident2_tile(EvpArgs A, Evp
             }
         }
     }
+    // images of this U-cell on other ranks: record address (parity 0) in the peer's buffer
+    char *rp0 = nullptr, *rp1 = nullptr, *rp2 = nullptr;
+    size_t rs0 = 0, rs1 = 0, rs2 = 0;
+    if (REMOTE) {
+        const bool ownU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w);
+        if (ownU && (i == r.x || i == r.y || j == r.z || j == r.w)) {
+            const int slots[4] = {(i == r.x) ? (j - r.z) : -1, (i == r.y) ? R.rimg_nj + (j - r.z) : -1,
+                                  (j == r.z) ? 2 * R.rimg_nj + (i - r.x) : -1,
+                                  (j == r.w) ? 2 * R.rimg_nj + R.rimg_ni + (i - r.x) : -1};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (slots[e] < 0) continue;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int2 v = R.rimg[slots[e] * 2 + w];
+                    if (v.x < 0) continue;
+                    char *ptr = (char *)R.peer_rec[v.x] + 32 * (size_t)v.y;
+                    const size_t st = R.peer_rstride[v.x];
+                    if (!rp0) { rp0 = ptr; rs0 = st; }
+                    else if (!rp1) { rp1 = ptr; rs1 = st; }
+                    else { rp2 = ptr; rs2 = st; }
+                }
+            }
+        }
+    }
+    const bool rpub = REMOTE && rp0 != nullptr;    // publishes every subcycle, ice or not
     // my ring entry: which cell of the LDS ring do I refresh, from which record
     int ring_cp = -1, ring_li = 0;
+    bool ring_remote = false;
     if (t < R.ring_cnt[tile]) {
         const int4 e = R.ring[tile * EVP_RES2_RING + t];   // x: cell whose record is polled, y: LDS index, z: producing U-cell
         const bool live = e.z >= 0 && (A.mask[e.z] & 2u);   // an active U-cell rewrites it every subcycle
         if (live) { ring_cp = e.x; ring_li = e.y; }
+        if (REMOTE && e.z == -2) { ring_cp = e.x; ring_li = e.y; ring_remote = true; }   // produced on another rank
     }
+    auto publish_remote = [&](int par, double uu, double vv, unsigned tag) {
+        const v4u a = pack_rec(uu, tag), b = pack_rec(vv, tag);
+        st_rec2_sys(rp0 + (size_t)par * rs0, a, b);
+        if (rp1) st_rec2_sys(rp1 + (size_t)par * rs1, a, b);
+        if (rp2) st_rec2_sys(rp2 + (size_t)par * rs2, a, b);
+    };
+    // one poll of a record written by another rank: bounded by wall-clock time (ranks reach
+    // evp() at different moments), not by a spin count
+    auto poll_remote = [&](const v4u *rec, unsigned want, v4u &ra, v4u &rb) -> bool {
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            ld_rec2_sys(rec, ra, rb);
+            if (ra.x == want && ra.w == want && rb.x == want && rb.w == want) return true;
+            if ((++spins & 255u) == 0 &&
+                (wall_clock64() - t0 > R.timeout_ticks ||
+                 __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                atomicCAS(R.err, 0, 2);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
     if (t == 0) s_bad = 0;
     __syncthreads();
 
     double u_own = 0.0, v_own = 0.0;
-    if (isU) { u_own = s_u[li]; v_own = s_v[li]; }
+    if (isU || rpub) { u_own = s_u[li]; v_own = s_v[li]; }
     // initial records (subcycle tag 0) so that the neighbours' first ring refresh finds them
     {
         const unsigned tag = R.tag_base;
-        v4u *r0 = (v4u *)R.rec[0];
+        v4u *r0 = (v4u *)R.rec[par0 & 1];
+        if (rpub) publish_remote(par0 & 1, u_own, v_own, tag);
         if (pub) st_rec2(r0 + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
         if (isU) {
             if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
@@ -192,11 +265,16 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident2_tile(EvpArgs A, Evp
     // ---- the subcycle loop (ice_dyn_evp.F90:859-913) ------------------------------------------
     for (int k = 0; k < R.ndte; ++k) {
         const unsigned want = R.tag_base + (unsigned)k;       // tag of the velocities subcycle k reads
-        const v4u *rd = (const v4u *)R.rec[k & 1];
-        v4u *wr = (v4u *)R.rec[(k & 1) ^ 1];
+        const v4u *rd = (const v4u *)R.rec[(k + par0) & 1];
+        v4u *wr = (v4u *)R.rec[((k + par0) & 1) ^ 1];
 
         // refresh the ring of the velocity tile from the neighbours' records
-        if (ring_cp >= 0) {
+        if (REMOTE && ring_remote) {
+            v4u ra, rb;
+            if (!poll_remote(rd + 2 * (size_t)ring_cp, want, ra, rb)) s_bad = 1;
+            s_u[ring_li] = unpack_rec(ra);
+            s_v[ring_li] = unpack_rec(rb);
+        } else if (ring_cp >= 0) {
             v4u ra, rb;
             unsigned spins = 0;
             for (;;) {
@@ -266,7 +344,19 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident2_tile(EvpArgs A, Evp
                 R.tab[26][c] = o.taubx; R.tab[27][c] = o.tauby;
             }
         }
+        if (rpub) publish_remote(((k + par0) & 1) ^ 1, u_own, v_own, want + 1u);
         // no publish step: the records carry their own tags
+    }
+    // ghost cells that mirror another rank's cells: fetch the final velocities (the caller
+    // relies on current ghosts, ice_dyn_evp.F90:920-934)
+    if (REMOTE && ring_remote) {
+        v4u ra, rb;
+        const v4u *rd = (const v4u *)R.rec[(R.ndte + par0) & 1];
+        const bool ok = poll_remote(rd + 2 * (size_t)ring_cp, R.tag_base + (unsigned)R.ndte, ra, rb);
+        if (ok && !R.dry) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { R.u[b][ring_cp] = unpack_rec(ra); R.v[b][ring_cp] = unpack_rec(rb); }
+        }
     }
 
     // ---- write the state back --------------------------------------------------------------
@@ -299,11 +389,11 @@ size_t lds_bytes(unsigned flags, int logw)
     return sizeof(double) * ((size_t)256 * (8 + nu) + 2 * (size_t)nuv);
 }
 
-template <int LOGW>
+template <int LOGW, bool REMOTE>
 int occ(bool strict, int cap, size_t lds)
 {
     int nb = 0;
-#define EVP_OCC(S, C) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident2_tile<S, C, LOGW>, 64 * RTY, lds)
+#define EVP_OCC(S, C) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident2_tile<S, C, LOGW, REMOTE>, 64 * RTY, lds)
     hipError_t e;
     if (strict) e = cap == 1 ? EVP_OCC(true, 1) : cap == 0 ? EVP_OCC(true, 0) : EVP_OCC(true, -1);
     else e = cap == 1 ? EVP_OCC(false, 1) : cap == 0 ? EVP_OCC(false, 0) : EVP_OCC(false, -1);
@@ -311,12 +401,12 @@ int occ(bool strict, int cap, size_t lds)
     return e == hipSuccess ? nb : 0;
 }
 
-template <int LOGW>
+template <int LOGW, bool REMOTE>
 void launch(const EvpArgs &A, const EvpResident2 &R, bool strict, int cap, hipStream_t st)
 {
     dim3 grid(A.ntiles), block(64, RTY);
     const size_t lds = lds_bytes(A.flags, LOGW);
-#define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident2_tile<S, C, LOGW>), grid, block, lds, st, A, R)
+#define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident2_tile<S, C, LOGW, REMOTE>), grid, block, lds, st, A, R)
     if (strict) {
         if (cap == 1) EVP_LAUNCH(true, 1);
         else if (cap == 0) EVP_LAUNCH(true, 0);
@@ -331,10 +421,11 @@ void launch(const EvpArgs &A, const EvpResident2 &R, bool strict, int cap, hipSt
 
 }  // namespace
 
-int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw)
+int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote)
 {
     const size_t lds = lds_bytes(flags, logw);
-    return logw == 4 ? occ<4>(strict, cap, lds) : logw == 5 ? occ<5>(strict, cap, lds) : occ<6>(strict, cap, lds);
+    if (remote) return logw == 4 ? occ<4, true>(strict, cap, lds) : logw == 5 ? occ<5, true>(strict, cap, lds) : occ<6, true>(strict, cap, lds);
+    return logw == 4 ? occ<4, false>(strict, cap, lds) : logw == 5 ? occ<5, false>(strict, cap, lds) : occ<6, false>(strict, cap, lds);
 }
 
 void evp_launch_resident2(const EvpArgs &A0, const EvpResident2 &R, int max_ni, int max_nj, int logw,
@@ -343,7 +434,14 @@ void evp_launch_resident2(const EvpArgs &A0, const EvpResident2 &R, int max_ni, 
     EvpArgs A = A0;
     evp_resident_geometry(max_ni, max_nj, logw, &A.gx, &A.gy);
     A.ntiles = A.gx * A.gy;
-    if (logw == 4) launch<4>(A, R, strict, cap, st);
-    else if (logw == 5) launch<5>(A, R, strict, cap, st);
-    else launch<6>(A, R, strict, cap, st);
+    const bool remote = R.rimg != nullptr;
+    if (remote) {
+        if (logw == 4) launch<4, true>(A, R, strict, cap, st);
+        else if (logw == 5) launch<5, true>(A, R, strict, cap, st);
+        else launch<6, true>(A, R, strict, cap, st);
+    } else {
+        if (logw == 4) launch<4, false>(A, R, strict, cap, st);
+        else if (logw == 5) launch<5, false>(A, R, strict, cap, st);
+        else launch<6, false>(A, R, strict, cap, st);
+    }
 }

@@ -225,6 +225,7 @@ def test_single_rank_self_exchange(name, transport, monkeypatch):
     monkeypatch.setenv("CICE_EVP_HIP_HALO", transport.split("-")[0])
     # riding: the exchange workgroup travels inside the subcycle launch (default on large domains)
     monkeypatch.setenv("CICE_EVP_HIP_HALO_RIDE", "1" if transport.endswith("riding") else "0")
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")     # this test is about the exchange kernels of the streaming path
     c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     try:
@@ -389,8 +390,42 @@ def test_resident_kernel_golden_and_modes(monkeypatch):
         core.finalize()
 
 
-@pytest.mark.parametrize("world,workload,shape", [(2, "gx3", ""), (4, "gx3", "2x2"), (2, "gx1", "1x2")])
-def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape):
+@pytest.mark.parametrize("name", ["pop_cyc_1blk_patchy", "rect_cyc_2x2_full"])
+def test_resident_kernel_with_remote_neighbours_self_exchange(name, monkeypatch):
+    """The on-chip resident kernel when ghost cells mirror cells of another rank: edge cells
+    store their tagged records into the neighbour's record buffer (here: the rank itself, via
+    CICE_EVP_HIP_SELF_EXCHANGE; across GPUs the same store travels over xGMI), ring entries
+    produced remotely are polled at system scope, final ghosts are fetched after the loop.
+    Single-block fixture: resident; 2x2-block fixture: must fall back to streaming + mailbox."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        core.comm_init(core.comm_unique_id())
+        for icall in range(1, c.ncalls + 1):
+            for nsub in c.nsub_list:
+                out = core.run(*c.inputs(icall), ndte=nsub)
+                assert_bitwise(post_evp(c, out), c.expected(icall, nsub), f"{name} call {icall} nsub {nsub}")
+        resident = core.timings()["tile_variant"] >= 2000
+        assert resident == (name == "pop_cyc_1blk_patchy")
+    finally:
+        core.finalize()
+
+
+def test_resident_remote_gx3_vs_oracle(monkeypatch):
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "caps", seed=5, warm=True)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 120)
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=120, rccl_self=True)
+    assert_bitwise(got, want, "gx3 resident kernel, every ghost through remote records (to self)")
+
+
+@pytest.mark.parametrize("world,workload,shape,resident", [(2, "gx3", "", True), (4, "gx3", "2x2", True),
+                                                           (2, "gx1", "1x2", False)])
+def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
     the one GPU of this box, each owning one block; every rank's sub-domain, ghost cells
@@ -403,6 +438,13 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape):
            str(root / "tools" / "mailbox_2proc.py"), "--workload", workload, "--ndte", "24"]
     if shape:
         cmd += ["--shape", shape]
+    # gx3 pieces fit the one GPU several times over: the resident kernels of all ranks are
+    # co-resident and trade tagged records across process boundaries; gx1 halves do not fit
+    # twice, so that case pins the streaming kernel + mailbox exchange
     env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
+    if resident:
+        cmd += ["--expect-resident"]
+    else:
+        env["CICE_EVP_HIP_RESIDENT"] = "0"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

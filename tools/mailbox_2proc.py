@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--ndte", type=int, default=24)
     ap.add_argument("--timing", action="store_true")
     ap.add_argument("--shape", default="")          # e.g. 2x1
+    ap.add_argument("--expect-resident", action="store_true",
+                    help="fail unless the on-chip resident kernel with remote neighbours ran")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -92,9 +94,11 @@ def main():
             if not np.array_equal(want, got[k]):
                 bad.append((k + " ghosts", float(np.abs(want - got[k]).max())))
     res = [None] * world
-    dist.all_gather_object(res, (rank, bad, t_us, tim["launches_per_subcycle"]))
+    dist.all_gather_object(res, (rank, bad, t_us, tim["launches_per_subcycle"], tim["tile_variant"]))
     if rank == 0:
         ok = all(not r[1] for r in res)
+        if a.expect_resident:
+            ok = ok and all(r[4] >= 2000 for r in res)
         print("MAILBOX_2PROC", "OK" if ok else "FAIL", a.workload, f"world={world}", res, flush=True)
         if not ok:
             sys.exit(1)
