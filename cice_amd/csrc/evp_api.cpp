@@ -835,10 +835,9 @@ int direct_export(HaloBlob &B)
         if (want_res) { rec_off = X.bytes; X.bytes += 2 * rec_stride; }
         X.rec_off = rec_off;
         // fine-grained: stores of another GPU become visible to loads here without a kernel boundary
-        if (hipExtMallocWithFlags(&X.mailbox, X.bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPC(hipMalloc(&X.mailbox, X.bytes));
-        }
+        // (no coarse-grained fallback: without this property a peer's stores are only guaranteed
+        // to be seen at kernel boundaries, and the transport would be wrong on a real node)
+        HIPC(hipExtMallocWithFlags(&X.mailbox, X.bytes, hipDeviceMallocFinegrained));
         HIPC(hipMemset(X.mailbox, 0, X.bytes));
     }
     int can_res = 0;

@@ -443,7 +443,7 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
     # twice, so that case pins the streaming kernel + mailbox exchange
     env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
     if resident:
-        cmd += ["--expect-resident"]
+        cmd += ["--expect-resident", "--timing"]    # --timing: 5 x 120 + 7 more subcycles, launches back to back
     else:
         env["CICE_EVP_HIP_RESIDENT"] = "0"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
