@@ -159,6 +159,7 @@ struct State {
     bool res2_rec_owned = true;  // false: the record buffers live inside the mailbox allocation
     // resident kernel with neighbours on other GPUs (records stored into peers' buffers over xGMI)
     bool res_remote = false;     // agreed by all ranks at mailbox import
+    double res_timeout_ms = 0;   // > 0: overrides the wait bound of the next resident launches (probe)
     int2 *res2_rimg = nullptr;
     void **res2_peer_rec = nullptr;
     size_t *res2_peer_rstride = nullptr;
@@ -696,7 +697,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.peer_rec = S.res2_peer_rec;
     R.peer_rstride = S.res2_peer_rstride;
     static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
-    R.timeout_ticks = (unsigned long long)(tmo_ms * 1.0e5);
+    R.timeout_ticks = (unsigned long long)((S.res_timeout_ms > 0 ? S.res_timeout_ms : tmo_ms) * 1.0e5);
     R.spin_limit = 4000000u;
     R.err = S.res_err;
     R.pubmap = S.res2_pub;
@@ -947,6 +948,11 @@ int direct_import(const HaloBlob *blobs, int nranks)
             const HaloBlob &B = blobs[p.rank];
             prec[q] = mapped[p.rank] + B.rec_off;
             pstr[q] = (size_t)B.rec_stride;
+            if (env("CICE_EVP_HIP_RES_REMOTE_BREAK")) {      // test hook: records go nowhere -> the probe must fail
+                void *dummy = nullptr;
+                HIPC(hipMalloc(&dummy, 2 * (size_t)B.rec_stride));
+                prec[q] = dummy;                             // (leaked on purpose: test processes only)
+            }
             for (size_t k = 0; k < p.send_src.size() && ok; ++k) {
                 const int rem = (int)(p.send_src[k] % S.plane);
                 const int j = rem / nx + 1, i = rem % nx + 1;
@@ -1030,6 +1036,53 @@ int direct_check_error()
     HIPC(hipMemcpy(&e, (char *)S.direct.mailbox + DIRECT_ERR_OFF, sizeof(int), hipMemcpyDeviceToHost));
     if (e) return fail(-8, "mailbox halo: rank %d never signalled within the time-out (CICE_EVP_HIP_HALO_TIMEOUT_MS)",
                        S.plan.peers[e - 1].rank);
+    return 0;
+}
+
+// Probe of the resident kernel with neighbours on other GPUs (collective): no ice anywhere, every
+// interior cell holds its global cell number as "velocity"; three subcycles later every ghost that
+// mirrors another rank's cell must hold that cell's number -- carried there by tagged records only.
+int resident_remote_probe()
+{
+    std::vector<double> hu(S.n, 0.0), hv(S.n, 0.0);
+    const int nx = S.d.nx_block;
+    for (int j = S.jlo[0]; j <= S.jhi[0]; ++j)
+        for (int i = S.ilo[0]; i <= S.ihi[0]; ++i) {
+            const size_t c = (size_t)(j - 1) * nx + (i - 1);
+            const double gid = (double)((S.iglob0[0] + (i - S.ilo[0]) - 1) +
+                                        (size_t)S.d.nx_global * (S.jglob0[0] + (j - S.jlo[0]) - 1));
+            hu[c] = gid + 1.0;
+            hv[c] = -2.0 * (gid + 1.0);
+        }
+    for (int b = 0; b < 2; ++b) {
+        HIPC(hipMemcpyAsync(S.u[b], hu.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+        HIPC(hipMemcpyAsync(S.v[b], hv.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    }
+    HIPC(hipMemsetAsync(S.mask, 0, S.n, S.stream));
+    S.res_timeout_ms = 10000.0;
+    int rc = launch_resident2(3, 0, false);
+    S.res_timeout_ms = 0;
+    if (rc) return rc;
+    S.res_launched = true;
+    std::vector<double> gu(S.n), gv(S.n);
+    HIPC(hipMemcpyAsync(gu.data(), S.u[1], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipMemcpyAsync(gv.data(), S.v[0], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    rc = resident_check_error();
+    S.res_mode = -1;            // (resident_check_error parks the mode on failure; decided again at upload)
+    for (int b = 0; b < 2; ++b) {
+        HIPC(hipMemsetAsync(S.u[b], 0, S.n * sizeof(double), S.stream));
+        HIPC(hipMemsetAsync(S.v[b], 0, S.n * sizeof(double), S.stream));
+    }
+    HIPC(hipStreamSynchronize(S.stream));
+    if (rc) return rc;
+    for (const HaloPeer &p : S.plan.peers)
+        for (size_t k = 0; k < p.recv_dst.size(); ++k) {
+            const double want = (double)p.recv_sign[k] * ((double)p.recv_gid[k] + 1.0);
+            if (gu[p.recv_dst[k]] != want || gv[p.recv_dst[k]] != -2.0 * want)
+                return fail(-8, "resident kernel probe: ghost %d from rank %d holds %.17g, expected %.17g",
+                            (int)p.recv_dst[k], p.rank, gu[p.recv_dst[k]], want);
+        }
     return 0;
 }
 
@@ -1827,6 +1880,17 @@ int cice_evp_hip_comm_init(const void *id128)
         if (!ok) why = g_err;
         if (agree(ok, all_ok)) return -1;
     }
+    if (all_ok && S.res_remote) {           // resident kernel across GPUs: its own probe, same agreement
+        int res_ok = resident_remote_probe() == 0, res_all = 0;
+        const std::string why_res = res_ok ? "" : g_err;
+        if (agree(res_ok, res_all)) return -1;
+        if (!res_all) {
+            S.res_remote = false;
+            if (env("CICE_EVP_HIP_VERBOSE"))
+                std::fprintf(stderr, "[cice_evp_hip] rank %d: resident kernel across GPUs off (%s)\n", S.d.rank,
+                             why_res.empty() ? "another rank's probe failed" : why_res.c_str());
+        }
+    }
     (void)hipFree(d_blobs);
     (void)hipFree(d_ok);
     S.direct.on = all_ok != 0;
@@ -1861,6 +1925,8 @@ int cice_evp_hip_halo_import(const void *blobs, int32_t nranks)
     if (int rc = direct_import(B.data(), nranks)) return rc;
     if (int rc = direct_probe()) return rc;     // collective; a failure here is fatal for the caller
     S.direct.on = true;
+    if (S.res_remote)
+        if (int rc = resident_remote_probe()) return rc;
     return 0;
 }
 

@@ -413,6 +413,25 @@ def test_resident_kernel_with_remote_neighbours_self_exchange(name, monkeypatch)
         core.finalize()
 
 
+def test_resident_remote_probe_failure_falls_back(monkeypatch):
+    """If the records of a neighbour never arrive (test hook: they are stored into a dummy
+    buffer), the collective probe at comm_init fails after its 10 s bound and every rank falls
+    back to the streaming kernel + mailbox exchange -- results unchanged."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_REMOTE_BREAK", "1")
+    c = GoldenCase("pop_cyc_1blk_patchy")
+    core = hip_from_case(c, strict=True)
+    try:
+        core.comm_init(core.comm_unique_id())
+        out = core.run(*c.inputs(1), ndte=120)
+        assert_bitwise(post_evp(c, out), c.expected(1, 120), "fallback after a failed resident probe")
+        t = core.timings()
+        assert t["tile_variant"] < 1000 and t["halo_transport"] == "mailbox"
+    finally:
+        core.finalize()
+
+
 def test_resident_remote_gx3_vs_oracle(monkeypatch):
     monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
     monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
