@@ -467,3 +467,58 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
         env["CICE_EVP_HIP_RESIDENT"] = "0"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("kind", ["no_ice", "one_cell", "one_column", "checkerboard"])
+@pytest.mark.parametrize("resident", [False, True])
+def test_degenerate_ice_covers_vs_oracle(kind, resident, monkeypatch):
+    """Edge cases of the index-list contract (dyn_prep2, ice_dyn_shared.F90:740-789): no ice
+    point at all, a single ice cell, one column of ice, ice on every other cell -- streaming
+    and resident kernels against the oracle, bit for bit, outputs off the masks untouched."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if resident else "0")
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "full", seed=13, warm=True)
+    keepT = np.zeros_like(tm)
+    if kind == "one_cell":
+        keepT[0, 60, 50] = 1
+    elif kind == "one_column":
+        keepT[0, :, 40] = 1
+    elif kind == "checkerboard":
+        jj, ii = np.meshgrid(np.arange(tm.shape[1]), np.arange(tm.shape[2]), indexing="ij")
+        keepT[0] = (ii + jj) % 2
+    tm2 = tm * keepT
+    um2 = um * keepT
+    f2 = {k: v.copy() for k, v in fields.items()}
+    for k in SIG:                      # dyn_prep2 zeroes the stresses off the T mask (:717-730)
+        f2[k][tm2 == 0] = 0.0
+    for k in VEL:                      # and the velocities off the U mask (:776-784)
+        f2[k][um2 == 0] = 0.0
+    got = run_hip(dc, geo, f2, tm2, um2, scal, strict=True, ndte=24)
+    want = run_oracle(dc, geo, f2, tm2, um2, scal, 24)
+    assert_bitwise(got, want, f"{kind} resident={resident}")
+    if kind == "no_ice":
+        for k in VEL + SIG:
+            assert not got[k].any(), k
+
+
+def test_s01_full_size_decomposition_and_transport_invariance(monkeypatch):
+    """configs[4] size (3600x2400 = 8.6M cells), 3 subcycles: one block == 2x2 blocks with the
+    ghost copies pushed in-kernel == 2x2 blocks with every ghost copy routed through the mailbox
+    exchange riding in the subcycle launch, bit for bit (size-independent property; the
+    oracle would need minutes at this size)."""
+    scal = synth.evp_scalars(480)
+    keys = VEL + ["stressp_1", "stressm_2", "stress12_3", "strintxU"]
+    ref = None
+    for bs, selfx in ((None, False), ((1800, 1200), False), ((1800, 1200), True)):
+        if selfx:
+            monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+            monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
+        dc, geo, fields, tm, um = synth_case("s01", "full", seed=2, warm=True, bs=bs)
+        out = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=3, rccl_self=selfx)
+        glob = {k: dc.gather({0: out[k]}) for k in keys}
+        del out, fields
+        assert np.isfinite(glob["uvel"]).all() and np.abs(glob["uvel"]).max() > 1e-4
+        if ref is None:
+            ref = glob
+        else:
+            assert_bitwise(glob, ref, f"s01 blocks={bs} mailbox={selfx}")
