@@ -1975,6 +1975,21 @@ int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_
 
 // Tripole part of the plan built by the last init / plan_build (tests): counts3 =
 // {pairs, poles, late copies}; lists may be NULL.
+int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid)
+{
+    const HaloPlan &P = S.plan;
+    size_t so = 0, ro = 0;
+    for (const HaloPeer &p : P.peers) {
+        for (size_t k = 0; k < p.send_dst.size(); ++k)
+            if (send_dst) send_dst[so + k] = p.send_dst[k];
+        for (size_t k = 0; k < p.recv_gid.size(); ++k)
+            if (recv_gid) recv_gid[ro + k] = p.recv_gid[k];
+        so += p.send_dst.size();
+        ro += p.recv_gid.size();
+    }
+    return 0;
+}
+
 int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src)
 {
     const HaloPlan &P = S.plan;

@@ -205,6 +205,12 @@ int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_
  * (ice_boundary.F90:1630-1649, 1689-1722).  Lists may be NULL.                  */
 int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,
                            int32_t *late_dst, int32_t *late_src, int32_t *late_sign);
+/* What the mailbox transports use on top of cice_evp_hip_halo_plan's lists, same peer order and
+ * lengths as send_src / recv_dst: send_dst = the ghost cell each sent value fills, as an offset
+ * into the PEER's array (remote stores need it; no set-up traffic -- every rank enumerates every
+ * rank's ghosts); recv_gid = global cell number (ig-1)+nx_global*(jg-1) each received ghost mirrors
+ * (probe exchanges).  Lists may be NULL.                                                         */
+int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid);
 /* Lists behind cice_evp_hip_stress_halo: a1[dst] <- a2[src] for every partner pair (src = -1:
  * fill 0, ice_boundary.F90:7643-7645).  Lists may be NULL.                                     */
 int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src);

@@ -71,6 +71,36 @@ def _worker(rank, world, port, case, q):
         flat[plan["local_dst"]] = np.where(src >= 0, plan["local_sign"] * flat[np.maximum(src, 0)], 0.0)
         ok = bool(np.array_equal(a, want))
         nbad = int((a != want).sum())
+        # mailbox semantics: the SENDER knows where each value lands in the receiver's array
+        # (send_dst), the receiver knows which global cell each ghost mirrors (recv_gid)
+        b2 = want.copy()
+        for blk in dc.local_blocks(rank):
+            m = np.ones((dc.ny_block, dc.nx_block), bool)
+            m[1:1 + blk.gny, 1:1 + blk.gnx] = False
+            b2[blk.local][m] = -999.0
+        flat2 = b2.reshape(-1)
+        vals = torch.from_numpy(flat2[plan["send_src"]].copy())
+        dsts = torch.from_numpy(plan["send_dst"].astype(np.int64).copy())
+        rvals = torch.zeros(len(plan["recv_dst"]), dtype=torch.float64)
+        rdsts = torch.zeros(len(plan["recv_dst"]), dtype=torch.int64)
+        ops, so, ro = [], 0, 0
+        for p, ns_, nr_ in zip(plan["peer_rank"], plan["peer_nsend"], plan["peer_nrecv"]):
+            if ns_:
+                ops.append(dist.P2POp(dist.isend, vals[so:so + ns_], int(p), tag=1))
+                ops.append(dist.P2POp(dist.isend, dsts[so:so + ns_], int(p), tag=2))
+            if nr_:
+                ops.append(dist.P2POp(dist.irecv, rvals[ro:ro + nr_], int(p), tag=1))
+                ops.append(dist.P2POp(dist.irecv, rdsts[ro:ro + nr_], int(p), tag=2))
+            so += ns_
+            ro += nr_
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        flat2[rdsts.numpy()] = rvals.numpy()             # "remote store" at the sender's addresses
+        flat2[plan["local_dst"]] = np.where(src >= 0, plan["local_sign"] * flat2[np.maximum(src, 0)], 0.0)
+        ok = ok and bool(np.array_equal(b2, want)) and bool(np.array_equal(rdsts.numpy(), plan["recv_dst"]))
+        gid = plan["recv_gid"]
+        known = (gid % nx + 1) + 1000.0 * (gid // nx + 1)
+        ok = ok and bool(np.array_equal(known, want.reshape(-1)[plan["recv_dst"]]))
         q.put((rank, ok, nbad, int(len(plan["send_src"])), int(len(plan["recv_dst"]))))
     finally:
         dist.destroy_process_group()
