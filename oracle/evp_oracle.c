@@ -585,3 +585,184 @@ void evp_oracle_dyn_finish(const evp_oracle_domain *d, const evp_oracle_params *
                 strocny[c] = vrel * ((vocn[c] - vvel[c]) * p->cosw + (uocn[c] - uvel[c]) * p->sinw * copysign(1.0, fm[c]));
             }
 }
+
+/* =====================================================================
+ * Preparation phase of evp(): everything between the entry of
+ * evp() and the subcycle loop on the B grid, dynamics/ice_dyn_evp.F90:383-840,
+ * except icepack_ice_strength (Icepack) and the seabed stress factor (exp()):
+ *   dyn_prep1            ice_dyn_shared.F90:496-576
+ *   halo updates         ice_dyn_evp.F90:413-428, 466-470, 727-733
+ *   grid_average_X2Y     infrastructure/ice_grid.F90:3983-3984 ('S' T->U = X2YS 'NE' with
+ *                        tarea, hm: :4183-4204) and :3957-3958 ('F' T->U = X2YF 'NE' with
+ *                        tarea, uarea: :4650-4666)
+ *   dyn_prep2            ice_dyn_shared.F90:586-839
+ * T-grid inputs are const: their ghost cells are refreshed on private copies,
+ * as the reference refreshes them on its module arrays.
+ * ===================================================================== */
+typedef struct {
+    double dt, rhoi, rhos, gravit, dyn_area_min, dyn_mass_min, cosw, sinw;
+    int ssh_coupled;   /* ssh_stress == 'coupled' (else 'geostrophic') */
+} evp_oracle_prep_params;
+
+enum { /* indices into the T-grid input table */
+    PT_AICE = 0, PT_VICE, PT_VSNO, PT_AICE_INIT, PT_CDN_OCN, PT_UOCN, PT_VOCN, PT_SS_TLTX, PT_SS_TLTY,
+    PT_STRAIRX, PT_STRAIRY, PT_COUNT
+};
+enum { /* indices into the U-grid output table */
+    PU_AIU = 0, PU_CDN_OCNU, PU_UOCNU, PU_VOCNU, PU_UMASSDTI, PU_FM, PU_WATERX, PU_WATERY, PU_FORCEX,
+    PU_FORCEY, PU_UVEL_INIT, PU_VVEL_INIT, PU_STRTLTX, PU_STRTLTY, PU_STRAIRXU, PU_STRAIRYU,
+    PU_TMASS, PU_UMASS, PU_COUNT
+};
+
+static void avg_T2U_S(const evp_oracle_domain *d, const double *w1, const double *tarea, const double *hm,
+                      double *w2)
+{
+    const int nx = d->nx_block;
+    const size_t nb = (size_t)nx * d->ny_block;
+    memset(w2, 0, sizeof(double) * nb * d->nblocks);
+    for (int b = 0; b < d->nblocks; ++b) {
+        const double *a = w1 + b * nb, *wt = tarea + b * nb, *m = hm + b * nb;
+        double *o = w2 + b * nb;
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const double wtmp = (m[IX(i, j)] * wt[IX(i, j)] + m[IX(i + 1, j)] * wt[IX(i + 1, j)] +
+                                     m[IX(i, j + 1)] * wt[IX(i, j + 1)] + m[IX(i + 1, j + 1)] * wt[IX(i + 1, j + 1)]);
+                if (wtmp != 0.0)
+                    o[IX(i, j)] = (m[IX(i, j)] * a[IX(i, j)] * wt[IX(i, j)] +
+                                   m[IX(i + 1, j)] * a[IX(i + 1, j)] * wt[IX(i + 1, j)] +
+                                   m[IX(i, j + 1)] * a[IX(i, j + 1)] * wt[IX(i, j + 1)] +
+                                   m[IX(i + 1, j + 1)] * a[IX(i + 1, j + 1)] * wt[IX(i + 1, j + 1)]) / wtmp;
+            }
+    }
+}
+
+static void avg_T2U_F(const evp_oracle_domain *d, const double *w1, const double *tarea, const double *uarea,
+                      double *w2)
+{
+    const int nx = d->nx_block;
+    const size_t nb = (size_t)nx * d->ny_block;
+    memset(w2, 0, sizeof(double) * nb * d->nblocks);
+    for (int b = 0; b < d->nblocks; ++b) {
+        const double *a = w1 + b * nb, *wt = tarea + b * nb, *w2a = uarea + b * nb;
+        double *o = w2 + b * nb;
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i)
+                o[IX(i, j)] = p25 * (a[IX(i, j)] * wt[IX(i, j)] + a[IX(i + 1, j)] * wt[IX(i + 1, j)] +
+                                     a[IX(i, j + 1)] * wt[IX(i, j + 1)] + a[IX(i + 1, j + 1)] * wt[IX(i + 1, j + 1)]) /
+                              w2a[IX(i, j)];
+    }
+}
+
+/* sig: 12 stress arrays (inout); uvel,vvel,iceUmask,strintx/y,strocnx/y: inout; iceTmask, U: out */
+void evp_oracle_prep(const evp_oracle_domain *d, const evp_oracle_prep_params *p, const int *tmask,
+                     const int *umask, const double *hm, const double *tarea, const double *uarea,
+                     const double *fcor, const double *const *T, double *const *sig, double *uvel,
+                     double *vvel, int *iceUmask, double *strintx, double *strinty, double *strocnx,
+                     double *strocny, int *iceTmask, double *const *U)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t nb = (size_t)nx * ny, n = nb * d->nblocks;
+    double *t[PT_COUNT];
+    for (int k = 0; k < PT_COUNT; ++k) {
+        t[k] = (double *)malloc(sizeof(double) * n);
+        memcpy(t[k], T[k], sizeof(double) * n);
+    }
+    double *tmass = U[PU_TMASS], *umass = U[PU_UMASS];
+    double *maskd = (double *)malloc(sizeof(double) * n);
+    unsigned char *tmphm = (unsigned char *)malloc(n);
+
+    /* dyn_prep1 (:545-575): mass on every cell, extent mask on the physical cells */
+    for (int b = 0; b < d->nblocks; ++b) {
+        const size_t o = b * nb;
+        for (int j = 1; j <= ny; ++j)
+            for (int i = 1; i <= nx; ++i) {
+                const size_t c = o + IX(i, j);
+                tmass[c] = tmask[c] ? (p->rhoi * t[PT_VICE][c] + p->rhos * t[PT_VSNO][c]) : 0.0;
+                tmphm[c] = tmask[c] && (t[PT_AICE][c] > p->dyn_area_min) && (tmass[c] > p->dyn_mass_min);
+                iceTmask[c] = 0;
+            }
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                int any = 0;
+                for (int dj = -1; dj <= 1; ++dj)
+                    for (int di = -1; di <= 1; ++di) any |= tmphm[o + IX(i + di, j + dj)];
+                iceTmask[o + IX(i, j)] = any && tmask[o + IX(i, j)];
+            }
+    }
+    /* ice_HaloUpdate(iceTmask, center, scalar)  ice_dyn_evp.F90:413-416 */
+    for (size_t c = 0; c < n; ++c) maskd[c] = (double)iceTmask[c];
+    evp_oracle_halo_update(d, maskd, 0, 0, 0, 0.0);
+    for (size_t c = 0; c < n; ++c) iceTmask[c] = maskd[c] != 0.0;
+
+    /* halo updates of the T-grid fields (:422-428): scalars, then vectors */
+    evp_oracle_halo_update(d, tmass, 0, 0, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_AICE_INIT], 0, 0, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_CDN_OCN], 0, 0, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_UOCN], 0, 1, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_VOCN], 0, 1, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_SS_TLTX], 0, 1, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_SS_TLTY], 0, 1, 0, 0.0);
+
+    /* T -> U, state-masked (:430-436) */
+    double *ss_tltxU = (double *)malloc(sizeof(double) * n), *ss_tltyU = (double *)malloc(sizeof(double) * n);
+    avg_T2U_S(d, tmass, tarea, hm, umass);
+    avg_T2U_S(d, t[PT_AICE_INIT], tarea, hm, U[PU_AIU]);
+    avg_T2U_S(d, t[PT_CDN_OCN], tarea, hm, U[PU_CDN_OCNU]);
+    avg_T2U_S(d, t[PT_UOCN], tarea, hm, U[PU_UOCNU]);
+    avg_T2U_S(d, t[PT_VOCN], tarea, hm, U[PU_VOCNU]);
+    avg_T2U_S(d, t[PT_SS_TLTX], tarea, hm, ss_tltxU);
+    avg_T2U_S(d, t[PT_SS_TLTY], tarea, hm, ss_tltyU);
+    /* wind stress, calc_strair branch (:465-470): halo, then flux average */
+    evp_oracle_halo_update(d, t[PT_STRAIRX], 0, 1, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_STRAIRY], 0, 1, 0, 0.0);
+    avg_T2U_F(d, t[PT_STRAIRX], tarea, uarea, U[PU_STRAIRXU]);
+    avg_T2U_F(d, t[PT_STRAIRY], tarea, uarea, U[PU_STRAIRYU]);
+
+    /* dyn_prep2 (:697-838) */
+    for (int b = 0; b < d->nblocks; ++b) {
+        const size_t o = b * nb;
+        for (int j = 1; j <= ny; ++j)
+            for (int i = 1; i <= nx; ++i) {
+                const size_t c = o + IX(i, j);
+                U[PU_WATERX][c] = U[PU_WATERY][c] = U[PU_FORCEX][c] = U[PU_FORCEY][c] = U[PU_UMASSDTI][c] = 0.0;
+                if (!iceTmask[c])
+                    for (int k = 0; k < 12; ++k) sig[k][c] = 0.0;
+            }
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const size_t c = o + IX(i, j);
+                const int old = iceUmask[c];
+                iceUmask[c] = umask[c] && (U[PU_AIU][c] > p->dyn_area_min) && (umass[c] > p->dyn_mass_min);
+                if (iceUmask[c]) {
+                    if (!old) { uvel[c] = U[PU_UOCNU][c]; vvel[c] = U[PU_VOCNU][c]; }
+                } else {
+                    uvel[c] = vvel[c] = 0.0;
+                    strintx[c] = strinty[c] = strocnx[c] = strocny[c] = 0.0;
+                }
+                U[PU_UVEL_INIT][c] = uvel[c];
+                U[PU_VVEL_INIT][c] = vvel[c];
+                if (!iceUmask[c]) continue;
+                U[PU_UMASSDTI][c] = umass[c] / p->dt;
+                const double fm = fcor[c] * umass[c];
+                U[PU_FM][c] = fm;
+                const double sgn = copysign(1.0, fm);
+                U[PU_WATERX][c] = U[PU_UOCNU][c] * p->cosw - U[PU_VOCNU][c] * p->sinw * sgn;
+                U[PU_WATERY][c] = U[PU_VOCNU][c] * p->cosw + U[PU_UOCNU][c] * p->sinw * sgn;
+                if (p->ssh_coupled) {
+                    U[PU_STRTLTX][c] = -p->gravit * umass[c] * ss_tltxU[c];
+                    U[PU_STRTLTY][c] = -p->gravit * umass[c] * ss_tltyU[c];
+                } else {
+                    U[PU_STRTLTX][c] = -fm * U[PU_VOCNU][c];
+                    U[PU_STRTLTY][c] = fm * U[PU_UOCNU][c];
+                }
+                U[PU_FORCEX][c] = U[PU_STRAIRXU][c] + U[PU_STRTLTX][c];
+                U[PU_FORCEY][c] = U[PU_STRAIRYU][c] + U[PU_STRTLTY][c];
+            }
+    }
+    /* velocity halo before the loop (:729-732) */
+    evp_oracle_halo_update(d, uvel, 1, 1, 0, 0.0);
+    evp_oracle_halo_update(d, vvel, 1, 1, 0, 0.0);
+
+    for (int k = 0; k < PT_COUNT; ++k) free(t[k]);
+    free(maskd); free(tmphm); free(ss_tltxU); free(ss_tltyU);
+}

@@ -185,3 +185,44 @@ def dyn_finish(dom: OracleDomain, params: Params, dyn: dict, uvel, vvel, iceUmas
     lib().evp_oracle_dyn_finish(C.byref(dom.c), C.byref(params), *[_dp(x) for x in a],
                                 um.ctypes.data_as(C.POINTER(C.c_int32)), _dp(sx), _dp(sy))
     return dict(strocnxU=sx, strocnyU=sy)
+
+
+# ---- preparation phase of evp() ----------------------------------------------
+PREP_T = ["aice", "vice", "vsno", "aice_init", "cdn_ocn", "uocn", "vocn", "ss_tltx", "ss_tlty",
+          "strairxT", "strairyT"]
+PREP_U = ["aiU", "cdn_ocnU", "uocnU", "vocnU", "umassdti", "fmU", "waterxU", "wateryU", "forcexU",
+          "forceyU", "uvel_init", "vvel_init", "strtltxU", "strtltyU", "strairxU", "strairyU",
+          "tmass", "umass"]
+
+
+class PrepParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("dt", "rhoi", "rhos", "gravit", "dyn_area_min", "dyn_mass_min",
+                                          "cosw", "sinw")] + [("ssh_coupled", C.c_int)]
+
+
+def prep(dom: OracleDomain, pp: PrepParams, static: dict, tfields: dict, state: dict) -> dict:
+    """evp()'s preparation phase (ice_dyn_evp.F90:383-840 minus ice strength and seabed stress).
+    static: tmask, umask (int), hm, tarea, uarea, fcor_blk.  tfields: PREP_T.  state: the 12
+    stresses, uvel, vvel, iceUmask (previous), strintxU/yU, strocnxU/yU (all copied).
+    Returns every product: PREP_U, iceTmask, iceUmask and the updated state."""
+    lib().evp_oracle_prep.restype = None
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    tm, um = i32(static["tmask"]), i32(static["umask"])
+    st = [f64(static[k]) for k in ("hm", "tarea", "uarea", "fcor_blk")]
+    T = [f64(tfields[k]) for k in PREP_T]
+    out = {k: np.array(state[k], dtype=np.float64, order="C", copy=True)
+           for k in DYN_FIELDS[:12] + ["uvel", "vvel", "strintxU", "strintyU", "strocnxU", "strocnyU"]}
+    out["iceUmask"] = np.array(state["iceUmask"], dtype=np.int32, order="C", copy=True)
+    out["iceTmask"] = np.zeros(dom.shape, dtype=np.int32)
+    for k in PREP_U:
+        out[k] = np.zeros(dom.shape)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    Tptr = (C.POINTER(C.c_double) * len(T))(*[_dp(a) for a in T])
+    Sptr = (C.POINTER(C.c_double) * 12)(*[_dp(out[k]) for k in DYN_FIELDS[:12]])
+    Uptr = (C.POINTER(C.c_double) * len(PREP_U))(*[_dp(out[k]) for k in PREP_U])
+    lib().evp_oracle_prep(C.byref(dom.c), C.byref(pp), ip(tm), ip(um), *[_dp(a) for a in st], Tptr, Sptr,
+                          _dp(out["uvel"]), _dp(out["vvel"]), ip(out["iceUmask"]), _dp(out["strintxU"]),
+                          _dp(out["strintyU"]), _dp(out["strocnxU"]), _dp(out["strocnyU"]),
+                          ip(out["iceTmask"]), Uptr)
+    return out

@@ -87,7 +87,7 @@ program evp_ref_harness
   real(dbl_kind), allocatable, dimension(:,:,:) :: s_u, s_v, s_sp1, s_sp2, s_sp3, s_sp4, &
      s_sm1, s_sm2, s_sm3, s_sm4, s_s121, s_s122, s_s123, s_s124
   integer(int_kind), allocatable :: blkinfo(:)
-  real(dbl_kind) :: scal(24)
+  real(dbl_kind) :: scal(32)
   character(len=16) :: tag
   integer(kind=8) :: c0_clk, c1_clk, crate
 
@@ -224,6 +224,12 @@ program evp_ref_harness
   scal(1)=arlx1i; scal(2)=denom1; scal(3)=brlx; scal(4)=revp; scal(5)=e_factor; scal(6)=epp2i
   scal(7)=capping; scal(8)=Ktens; scal(9)=deltaminEVP; scal(10)=u0; scal(11)=cosw; scal(12)=sinw
   scal(13)=rhow_l; scal(14)=dt; scal(15)=arlx; scal(16)=dtei; scal(17)=ecci
+  ! what the pre-subcycle preparation (dyn_prep1/2, seabed stress) reads besides the fields
+  call icepack_query_parameters(rhoi_out=scal(18), rhos_out=scal(19), gravit_out=scal(20))
+  scal(21)=dyn_area_min; scal(22)=dyn_mass_min
+  scal(23)=c0; if (trim(ssh_stress) == 'coupled') scal(23)=c1
+  scal(24)=c0; if (seabed_stress) scal(24)=c1
+  scal(25)=k1; scal(26)=k2; scal(27)=alphab; scal(28)=threshold_hw; scal(29)=dt_dyn
   call dump_r8_1d('scalars', scal)
   if (dump_arrays) then
      call dump_r8_3d('HTE', HTE, nblocks);       call dump_r8_3d('HTN', HTN, nblocks)
@@ -238,6 +244,8 @@ program evp_ref_harness
      call dump_r8_3d('dxhy', dxhy, nblocks);     call dump_r8_3d('dyhx', dyhx, nblocks)
      call dump_r8_3d('DminTarea', DminTarea, nblocks)
      call dump_r8_3d('ULAT', ULAT, nblocks)
+     call dump_r8_3d('uarea', uarea, nblocks);   call dump_r8_3d('fcor_blk', fcor_blk, nblocks)
+     call dump_r8_3d('hwater', hwater, nblocks)
   endif
 
   allocate(s_u(nx_block,ny_block,max_blocks), s_v(nx_block,ny_block,max_blocks))
@@ -258,6 +266,24 @@ program evp_ref_harness
         call evp(dt_dyn)
         ndte = h_ndte
      else
+     ! (0) the model state evp() is entered with: inputs of its preparation phase (SURVEY 8 f-2)
+     if (dump_arrays) then
+        write(tag,'(a,i2.2)') 'pr', icall
+        call dump_r8_3d(trim(tag)//'_aice', aice, nblocks);       call dump_r8_3d(trim(tag)//'_vice', vice, nblocks)
+        call dump_r8_3d(trim(tag)//'_vsno', vsno, nblocks);       call dump_r8_3d(trim(tag)//'_aice_init', aice_init, nblocks)
+        call dump_r8_3d(trim(tag)//'_cdn_ocn', Cdn_ocn, nblocks)
+        call dump_r8_3d(trim(tag)//'_uocn', uocn, nblocks);       call dump_r8_3d(trim(tag)//'_vocn', vocn, nblocks)
+        call dump_r8_3d(trim(tag)//'_ss_tltx', ss_tltx, nblocks); call dump_r8_3d(trim(tag)//'_ss_tlty', ss_tlty, nblocks)
+        call dump_r8_3d(trim(tag)//'_strairxT', strairxT, nblocks); call dump_r8_3d(trim(tag)//'_strairyT', strairyT, nblocks)
+        call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks);       call dump_r8_3d(trim(tag)//'_vvel', vvel, nblocks)
+        call dump_l_3d (trim(tag)//'_iceUmask', iceUmask, nblocks)
+        call dump_r8_3d(trim(tag)//'_stressp_1', stressp_1, nblocks); call dump_r8_3d(trim(tag)//'_stressp_2', stressp_2, nblocks)
+        call dump_r8_3d(trim(tag)//'_stressp_3', stressp_3, nblocks); call dump_r8_3d(trim(tag)//'_stressp_4', stressp_4, nblocks)
+        call dump_r8_3d(trim(tag)//'_stressm_1', stressm_1, nblocks); call dump_r8_3d(trim(tag)//'_stressm_2', stressm_2, nblocks)
+        call dump_r8_3d(trim(tag)//'_stressm_3', stressm_3, nblocks); call dump_r8_3d(trim(tag)//'_stressm_4', stressm_4, nblocks)
+        call dump_r8_3d(trim(tag)//'_stress12_1', stress12_1, nblocks); call dump_r8_3d(trim(tag)//'_stress12_2', stress12_2, nblocks)
+        call dump_r8_3d(trim(tag)//'_stress12_3', stress12_3, nblocks); call dump_r8_3d(trim(tag)//'_stress12_4', stress12_4, nblocks)
+     endif
      ! (1) capture the subcycle inputs at the boundary (computes nothing)
      write(tag,'(a,i2.2)') 'in', icall
      capture_tag = tag
@@ -267,6 +293,13 @@ program evp_ref_harness
      evp_algorithm = 'standard_2d'
      endif
 
+     ! other products of the preparation phase that the subcycle boundary does not carry
+     if (dump_arrays .and. .not. hipmode) then
+        write(tag,'(a,i2.2)') 'pq', icall
+        call dump_r8_3d(trim(tag)//'_strtltxU', strtltxU, nblocks); call dump_r8_3d(trim(tag)//'_strtltyU', strtltyU, nblocks)
+        call dump_r8_3d(trim(tag)//'_strairxU', strairxU, nblocks); call dump_r8_3d(trim(tag)//'_strairyU', strairyU, nblocks)
+        call dump_r8_3d(trim(tag)//'_strocnxU', strocnxU, nblocks); call dump_r8_3d(trim(tag)//'_strocnyU', strocnyU, nblocks)
+     endif
      ! post-prep state = the captured inputs
      s_u = uvel; s_v = vvel
      s_sp1 = stressp_1; s_sp2 = stressp_2; s_sp3 = stressp_3; s_sp4 = stressp_4

@@ -40,6 +40,27 @@ class GoldenCase:
         dyn = {k: self.d[f"in{icall:02d}_{k}"] for k in oracle.DYN_FIELDS}
         return dyn, self.d[f"in{icall:02d}_iceTmask"], self.d[f"in{icall:02d}_iceUmask"]
 
+    # --- preparation phase of evp() (f-2): its inputs, parameters and captured products ---
+    def prep_static(self):
+        return {k: self.d[k] for k in ("tmask", "umask", "hm", "tarea", "uarea", "fcor_blk")}
+
+    def prep_inputs(self, icall=1):
+        """(T-grid fields, state evp() is entered with)."""
+        t = {k: self.d[f"pr{icall:02d}_{k}"] for k in oracle.PREP_T}
+        state = {k: self.d[f"pr{icall:02d}_{k}"] for k in oracle.DYN_FIELDS[:12] + ["uvel", "vvel", "iceUmask"]}
+        z = np.zeros_like(self.d["tarea"])
+        # strintxU/strocnxU enter evp() as left by the previous call; zero before the first
+        for k in ("strintxU", "strintyU"):
+            state[k] = z if icall == 1 else self.d[f"o{icall - 1:02d}n{self.nsub_list[-1]:04d}_{k}"]
+        for k in ("strocnxU", "strocnyU"):
+            state[k] = z if icall == 1 else self.d[f"o{icall - 1:02d}n{self.nsub_list[-1]:04d}_{k}"]
+        return t, state
+
+    def prep_scal_dict(self):
+        s = self.scal
+        return dict(dt=s[28], rhoi=s[17], rhos=s[18], gravit=s[19], dyn_area_min=s[20], dyn_mass_min=s[21],
+                    cosw=s[10], sinw=s[11], ssh_coupled=int(s[22]))
+
     def expected(self, icall, nsub):
         return {k: self.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in oracle.OUT_FIELDS}
 

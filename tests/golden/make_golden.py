@@ -5,7 +5,9 @@ Runs oracle/_ref/evp_ref_harness_strict -- the reference's own evp() compiled
 unmodified from /root/reference by oracle/ref/build_ref.sh (amdflang -O2
 -ffp-contract=off) -- on small self-contained cases and freezes, per case:
   * static grid + metric arrays and the EVP scalars,
-  * every input of the EVP subcycle captured at the drop-in boundary,
+  * the model state evp() is entered with (pr*: inputs of its preparation phase, f-2),
+  * every input of the EVP subcycle captured at the drop-in boundary (in*) and the other
+    products of the preparation phase (pq*),
   * the reference's outputs after nsub subcycles for several nsub.
 A fixture is data only (inputs + expected outputs).  Re-run in the development
 container (needs /root/reference for build_ref.sh):  python tests/golden/make_golden.py
@@ -28,7 +30,8 @@ from cice_amd import synth  # noqa: E402
 OUT = Path(__file__).resolve().parent
 
 STATIC = ["HTE", "HTN", "dxT", "dyT", "tarea", "uarear", "cxp", "cyp", "cxm", "cym", "dxhy", "dyhx",
-          "DminTarea", "dxU", "dyU", "tarear"]   # the last three: deformations (next tier f-1)
+          "DminTarea", "dxU", "dyU", "tarear",   # the last three: deformations (next tier f-1)
+          "uarea", "fcor_blk", "hwater", "hm", "tmask", "umask"]   # preparation phase (next tier f-2)
 
 CASES = {
     # name: (nx, ny, bx, by, ew, ns, harness kwargs)
@@ -75,7 +78,7 @@ def make_case(name, spec):
     for k in STATIC:
         keep[k] = d[k]
     for k, v in d.items():
-        if k.startswith("in") or (k.startswith("o") and k[1:3].isdigit()):
+        if k[:2] in ("in", "pr", "pq") or (k.startswith("o") and k[1:3].isdigit()):
             # next-tier diagnostics (deformations, dyn_finish) are kept for SURVEY §8 f-1
             keep[k] = v
     path = OUT / f"{name}.npz"

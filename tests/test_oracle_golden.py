@@ -58,6 +58,39 @@ def test_subcycle_bitwise(name):
             assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub}")
 
 
+PREP_PRODUCTS = ["aiU", "cdn_ocnU", "uocnU", "vocnU", "waterxU", "wateryU", "forcexU", "forceyU", "umassdti",
+                 "uvel_init", "vvel_init", "uvel", "vvel"] + oracle.DYN_FIELDS[:12]
+
+
+def check_prep_products(c, icall, out, what):
+    """Products of the preparation phase against what the reference handed to its subcycle
+    (in*: captured at the dyn_evp1d_run boundary) and left in its module arrays (pq*)."""
+    dyn, tm, um = c.inputs(icall)
+    assert np.array_equal(out["iceTmask"] != 0, tm != 0), f"{what}: iceTmask"
+    assert np.array_equal(out["iceUmask"] != 0, um != 0), f"{what}: iceUmask"
+    assert_bitwise({k: out[k] for k in PREP_PRODUCTS}, {k: dyn[k] for k in PREP_PRODUCTS}, what)
+    on = um != 0                    # fm, strtlt, strair are only defined on ice U-cells (dyn_prep2 :806-836)
+    for k, ref in (("fmU", dyn["fmU"]), ("strtltxU", c.d[f"pq{icall:02d}_strtltxU"]),
+                   ("strtltyU", c.d[f"pq{icall:02d}_strtltyU"])):
+        assert np.array_equal(out[k][on], ref[on]), f"{what}: {k}"
+    for k in ("strairxU", "strairyU"):
+        assert np.array_equal(out[k], c.d[f"pq{icall:02d}_{k}"]), f"{what}: {k}"
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_prep_bitwise(name):
+    """dyn_prep1, the T-field halos, grid_average_X2Y T->U (state and flux
+    flavours), dyn_prep2 and the pre-loop velocity halo, from the model state the reference's
+    evp() was entered with, against what it handed to its subcycle loop."""
+    c = GoldenCase(name)
+    dom = c.oracle_domain()
+    pp = oracle.PrepParams(**c.prep_scal_dict())
+    for icall in range(1, c.ncalls + 1):
+        t, state = c.prep_inputs(icall)
+        out = oracle.prep(dom, pp, c.prep_static(), t, state)
+        check_prep_products(c, icall, out, f"{name} call {icall} prep")
+
+
 def test_halo_known_answer_global_index():
     """halochk method (drivers/unittest/halochk/halochk.F90:232-247): fill interiors with
     a function of the global index, update, and check every ghost cell analytically."""
