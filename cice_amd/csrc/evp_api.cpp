@@ -118,6 +118,22 @@ struct State {
     int n_seam = 0, n_pole = 0, n_late = 0;
     int32_t *h_stress_dst = nullptr, *h_stress_src = nullptr;
     int n_stress = 0;
+    // preparation phase on the device (evp_prep.hip)
+    struct Prep {
+        bool geo = false;
+        uint8_t *tmask = nullptr, *umask = nullptr, *umask_old = nullptr, *tmphm = nullptr;
+        double *hm = nullptr, *tarea = nullptr, *uarea = nullptr, *fcor = nullptr;
+        double *t[11] = {};
+        double *tmass = nullptr, *umass = nullptr, *maskd = nullptr;
+        double *ss_tltxU = nullptr, *ss_tltyU = nullptr, *strairxU = nullptr, *strairyU = nullptr,
+               *strtltx = nullptr, *strtlty = nullptr;
+        unsigned *flagword = nullptr;
+        int32_t *c_dst = nullptr, *c_src = nullptr;
+        int8_t *c_vsign = nullptr;
+        int n_center = 0;
+        std::vector<uint8_t> h8;
+        double t_ms = 0;
+    } prep;
     int32_t *h_send_src = nullptr, *h_recv_dst = nullptr;
     int8_t *h_recv_sign = nullptr;
     double *sendbuf = nullptr, *recvbuf = nullptr;
@@ -224,6 +240,14 @@ void free_all()
     F(S.h_local_sign);
     F(S.h_seam_a); F(S.h_seam_b); F(S.h_seam_pole); F(S.h_late_dst); F(S.h_late_src); F(S.h_late_sign);
     F(S.h_stress_dst); F(S.h_stress_src);
+    {
+        State::Prep &Q = S.prep;
+        F(Q.tmask); F(Q.umask); F(Q.umask_old); F(Q.tmphm); F(Q.hm); F(Q.tarea); F(Q.uarea); F(Q.fcor);
+        for (auto &q : Q.t) F(q);
+        F(Q.tmass); F(Q.umass); F(Q.maskd); F(Q.ss_tltxU); F(Q.ss_tltyU); F(Q.strairxU); F(Q.strairyU);
+        F(Q.strtltx); F(Q.strtlty); F(Q.flagword); F(Q.c_dst); F(Q.c_src); F(Q.c_vsign);
+        S.prep = State::Prep();
+    }
     F(S.h_send_src);
     F(S.h_recv_dst);
     F(S.h_recv_sign);
@@ -1423,53 +1447,11 @@ int cice_evp_hip_set_metrics(const double *cxp, const double *cyp, const double 
     return 0;
 }
 
-int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const int32_t *iceUmask)
+// Choices made once the first state is on the device (tile shape of the streaming kernel,
+// streaming vs on-chip resident kernel); shared by cice_evp_hip_upload and cice_evp_hip_prep.
+static int tune_after_upload()
 {
-    if (!S.ready) return fail(-1, "not initialised");
-    if (!f || !iceTmask || !iceUmask) return fail(-1, "null argument");
-    HIPC(hipEventRecord(S.ev2, S.stream));
-    S.cur = 0;
-    for (int k = 0; k < 12; ++k) {
-        if (!f[k]) return fail(-1, "null stress field %d", k);
-        if (h2d(S.sig[0][k], f[k])) return -1;
-        HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    }
-    for (int fi = F_STRENGTH; fi < F_COUNT; ++fi) {
-        if (fi == F_UVEL || fi == F_VVEL) continue;
-        if ((fi == F_UVEL_INIT || fi == F_VVEL_INIT) && !f[fi]) continue;   // only read when revp = 1
-        if (!f[fi]) return fail(-1, "null field %d", fi);
-        if (h2d(S.in[fi], f[fi])) return -1;
-    }
-    if (S.prm.revp != 0.0 && (!f[F_UVEL_INIT] || !f[F_VVEL_INIT]))
-        return fail(-1, "uvel_init/vvel_init required for revised EVP");
-    if (!f[F_UVEL] || !f[F_VVEL]) return fail(-1, "null velocity field");
-    if (h2d(S.u[0], f[F_UVEL]) || h2d(S.v[0], f[F_VVEL])) return -1;
-    HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    bool water_is_ocn = true, tbu_zero = true;
-    {
-        const double *wx = f[F_WATERX], *wy = f[F_WATERY], *uo = f[F_UOCN], *vo = f[F_VOCN], *tb = f[F_TBU];
-        for (size_t k = 0; k < S.n; ++k) {
-            const bool um = iceUmask[k] != 0;
-            S.hmask[k] = (uint8_t)((iceTmask[k] != 0 ? 1 : 0) | (um ? 2 : 0));
-            if (um) {
-                // bit-for-bit identical operands (cosw=1, sinw=0: ice_dyn_shared.F90:69-70,819-820)
-                if (std::memcmp(&wx[k], &uo[k], 8) != 0 || std::memcmp(&wy[k], &vo[k], 8) != 0) water_is_ocn = false;
-                if (tb[k] != 0.0) tbu_zero = false;
-            }
-        }
-    }
-    S.flags &= ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
-    if (water_is_ocn) S.flags |= EVP_F_WATER_IS_OCN;
-    if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
-    evp_launch_vrelfac(S.in[F_AIX], S.in[F_CW], S.prm.rhow, S.vrelfac, S.n, S.stream);
-    HIPC(hipMemcpyAsync(S.mask, S.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
-    HIPC(hipEventRecord(S.ev3, S.stream));
-    HIPC(hipStreamSynchronize(S.stream));
     float ms = 0;
-    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
-    S.t_h2d_ms = ms;
-    S.uploaded = true;
     if (!S.tyb_forced && !S.tuned) {
         // pick the tile height once per init by timing a few launches of each variant on
         // the real state (results are identical for every tile shape; only speed differs).
@@ -1571,6 +1553,56 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
     return 0;
 }
 
+int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const int32_t *iceUmask)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!f || !iceTmask || !iceUmask) return fail(-1, "null argument");
+    HIPC(hipEventRecord(S.ev2, S.stream));
+    S.cur = 0;
+    for (int k = 0; k < 12; ++k) {
+        if (!f[k]) return fail(-1, "null stress field %d", k);
+        if (h2d(S.sig[0][k], f[k])) return -1;
+        HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    }
+    for (int fi = F_STRENGTH; fi < F_COUNT; ++fi) {
+        if (fi == F_UVEL || fi == F_VVEL) continue;
+        if ((fi == F_UVEL_INIT || fi == F_VVEL_INIT) && !f[fi]) continue;   // only read when revp = 1
+        if (!f[fi]) return fail(-1, "null field %d", fi);
+        if (h2d(S.in[fi], f[fi])) return -1;
+    }
+    if (S.prm.revp != 0.0 && (!f[F_UVEL_INIT] || !f[F_VVEL_INIT]))
+        return fail(-1, "uvel_init/vvel_init required for revised EVP");
+    if (!f[F_UVEL] || !f[F_VVEL]) return fail(-1, "null velocity field");
+    if (h2d(S.u[0], f[F_UVEL]) || h2d(S.v[0], f[F_VVEL])) return -1;
+    HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    bool water_is_ocn = true, tbu_zero = true;
+    {
+        const double *wx = f[F_WATERX], *wy = f[F_WATERY], *uo = f[F_UOCN], *vo = f[F_VOCN], *tb = f[F_TBU];
+        for (size_t k = 0; k < S.n; ++k) {
+            const bool um = iceUmask[k] != 0;
+            S.hmask[k] = (uint8_t)((iceTmask[k] != 0 ? 1 : 0) | (um ? 2 : 0));
+            if (um) {
+                // bit-for-bit identical operands (cosw=1, sinw=0: ice_dyn_shared.F90:69-70,819-820)
+                if (std::memcmp(&wx[k], &uo[k], 8) != 0 || std::memcmp(&wy[k], &vo[k], 8) != 0) water_is_ocn = false;
+                if (tb[k] != 0.0) tbu_zero = false;
+            }
+        }
+    }
+    S.flags &= ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
+    if (water_is_ocn) S.flags |= EVP_F_WATER_IS_OCN;
+    if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
+    evp_launch_vrelfac(S.in[F_AIX], S.in[F_CW], S.prm.rhow, S.vrelfac, S.n, S.stream);
+    HIPC(hipMemcpyAsync(S.mask, S.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    HIPC(hipEventRecord(S.ev3, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+    S.t_h2d_ms = ms;
+    S.uploaded = true;
+    return tune_after_upload();
+}
+
 int cice_evp_hip_subcycle(int32_t ndte)
 {
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
@@ -1626,6 +1658,186 @@ int cice_evp_hip_stress_halo(void)
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
     evp_launch_halo_stress(S.sig[S.cur], S.h_stress_dst, S.h_stress_src, S.n_stress, S.stream);
     HIPC(hipGetLastError());
+    return 0;
+}
+
+
+// ---- next tier: the preparation phase of evp() on the device ----------------
+int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, const double *hm,
+                                   const double *tarea, const double *uarea, const double *fcor_blk)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!tmask || !umask || !hm || !tarea || !uarea || !fcor_blk) return fail(-1, "null argument");
+    State::Prep &Q = S.prep;
+    if (S.plan.center_remote)
+        return fail(-9, "device preparation needs the T-grid halo on this rank only (one rank, or blocks whose "
+                        "neighbours are all local); keep evp()'s host preparation and use cice_evp_hip_run");
+    auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };
+    if (B(Q.tmask) || B(Q.umask) || B(Q.umask_old) || B(Q.tmphm)) return -1;
+    auto D = [&](double *&p) -> int { return p ? 0 : alloc_d(&p, S.n); };
+    if (D(Q.hm) || D(Q.tarea) || D(Q.uarea) || D(Q.fcor) || D(Q.tmass) || D(Q.umass) || D(Q.maskd) ||
+        D(Q.ss_tltxU) || D(Q.ss_tltyU) || D(Q.strairxU) || D(Q.strairyU) || D(Q.strtltx) || D(Q.strtlty)) return -1;
+    for (auto &q : Q.t)
+        if (D(q)) return -1;
+    if (!Q.flagword) HIPC(hipMalloc((void **)&Q.flagword, sizeof(unsigned)));
+    Q.h8.resize(S.n);
+    for (size_t k = 0; k < S.n; ++k) Q.h8[k] = tmask[k] != 0;
+    HIPC(hipMemcpy(Q.tmask, Q.h8.data(), S.n, hipMemcpyHostToDevice));
+    for (size_t k = 0; k < S.n; ++k) Q.h8[k] = umask[k] != 0;
+    HIPC(hipMemcpy(Q.umask, Q.h8.data(), S.n, hipMemcpyHostToDevice));
+    if (h2d(Q.hm, hm) || h2d(Q.tarea, tarea) || h2d(Q.uarea, uarea) || h2d(Q.fcor, fcor_blk)) return -1;
+    const HaloPlan &P = S.plan;
+    Q.n_center = (int)P.center_dst.size();
+    if (Q.n_center && !Q.c_dst) {
+        HIPC(hipMalloc((void **)&Q.c_dst, Q.n_center * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&Q.c_src, Q.n_center * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&Q.c_vsign, Q.n_center));
+        HIPC(hipMemcpy(Q.c_dst, P.center_dst.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.c_src, P.center_src.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.c_vsign, P.center_vsign.data(), Q.n_center, hipMemcpyHostToDevice));
+    }
+    HIPC(hipStreamSynchronize(S.stream));
+    Q.geo = true;
+    return 0;
+}
+
+int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *tfields11,
+                      const double *const *fields32, int32_t *iceTmask, int32_t *iceUmask,
+                      double *strintxU, double *strintyU, double *strocnxU, double *strocnyU)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    State::Prep &Q = S.prep;
+    if (!Q.geo) return fail(-1, "cice_evp_hip_set_prep_geometry was not called");
+    if (!pp || !tfields11 || !fields32 || !iceTmask || !iceUmask) return fail(-1, "null argument");
+    for (int k = 0; k < 11; ++k)
+        if (!tfields11[k]) return fail(-1, "null T-grid field %d", k);
+    for (int k = 0; k < 12; ++k)
+        if (!fields32[k]) return fail(-1, "null stress field %d", k);
+    if (!fields32[F_UVEL] || !fields32[F_VVEL]) return fail(-1, "null velocity field");
+    HIPC(hipEventRecord(S.ev2, S.stream));
+    S.cur = 0;
+    for (int k = 0; k < 11; ++k)
+        if (h2d(Q.t[k], tfields11[k])) return -1;
+    for (int k = 0; k < 12; ++k)
+        if (h2d(S.sig[0][k], fields32[k])) return -1;
+    if (h2d(S.u[0], fields32[F_UVEL]) || h2d(S.v[0], fields32[F_VVEL])) return -1;
+    bool tbu_zero = true;
+    if (fields32[F_TBU]) {
+        if (h2d(S.in[F_TBU], fields32[F_TBU])) return -1;
+        for (size_t k = 0; k < S.n && tbu_zero; ++k) tbu_zero = fields32[F_TBU][k] == 0.0;
+    } else {
+        HIPC(hipMemsetAsync(S.in[F_TBU], 0, S.n * sizeof(double), S.stream));
+    }
+    for (size_t k = 0; k < S.n; ++k) Q.h8[k] = iceUmask[k] != 0;
+    HIPC(hipMemcpyAsync(Q.umask_old, Q.h8.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemsetAsync(Q.flagword, 0, sizeof(unsigned), S.stream));
+    HIPC(hipEventRecord(S.ev3, S.stream));
+
+    EvpPrep P{};
+    P.nx = S.d.nx_block; P.ny = S.d.ny_block; P.plane = S.plane; P.blk = S.blk;
+    P.tmask = Q.tmask; P.umask = Q.umask; P.umask_old = Q.umask_old;
+    P.hm = Q.hm; P.tarea = Q.tarea; P.uarea = Q.uarea; P.fcor = Q.fcor;
+    for (int k = 0; k < 11; ++k) P.t[k] = Q.t[k];
+    P.tmass = Q.tmass; P.umass = Q.umass; P.maskd = Q.maskd; P.tmphm = Q.tmphm;
+    P.ss_tltxU = Q.ss_tltxU; P.ss_tltyU = Q.ss_tltyU; P.strairxU = Q.strairxU; P.strairyU = Q.strairyU;
+    P.strtltx = Q.strtltx; P.strtlty = Q.strtlty;
+    P.aiU = S.in[F_AIX]; P.cdn_ocnU = S.in[F_CW]; P.uocnU = S.in[F_UOCN]; P.vocnU = S.in[F_VOCN];
+    P.umassdti = S.in[F_UMASSDTI]; P.fm = S.in[F_FM]; P.waterx = S.in[F_WATERX]; P.watery = S.in[F_WATERY];
+    P.forcex = S.in[F_FORCEX]; P.forcey = S.in[F_FORCEY];
+    P.uvel_init = S.in[F_UVEL_INIT]; P.vvel_init = S.in[F_VVEL_INIT];
+    P.uvel = S.u[0]; P.vvel = S.v[0];
+    for (int k = 0; k < 12; ++k) P.sig[k] = S.sig[0][k];
+    P.mask = S.mask; P.flagword = Q.flagword;
+    P.dt = pp->dt; P.rhoi = pp->rhoi; P.rhos = pp->rhos; P.gravit = pp->gravit;
+    P.dyn_area_min = pp->dyn_area_min; P.dyn_mass_min = pp->dyn_mass_min;
+    P.cosw = S.prm.cosw; P.sinw = S.prm.sinw; P.ssh_coupled = pp->ssh_stress_coupled;
+
+    evp_launch_prep1(P, S.d.nblocks, S.stream);
+    auto halo = [&](std::initializer_list<std::pair<double *, bool>> arrs) {
+        EvpPrepHalo H{};
+        for (const auto &a : arrs) { H.a[H.narr] = a.first; H.is_vec[H.narr] = a.second; ++H.narr; }
+        H.dst = Q.c_dst; H.src = Q.c_src; H.vsign = (const signed char *)Q.c_vsign; H.n = Q.n_center;
+        evp_launch_halo_center(H, S.stream);
+    };
+    // ice_dyn_evp.F90:413-428: iceTmask; tmass, aice_init, cdn_ocn (scalars); uocn, vocn, ss_tltx/y (vectors)
+    halo({{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false},
+          {Q.t[5], true}, {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}});
+    halo({{Q.t[9], true}, {Q.t[10], true}});                 // :466-469 (calc_strair branch)
+    evp_launch_prep_average(P, S.d.nblocks, S.stream);
+    evp_launch_prep2(P, S.d.nblocks, S.stream);
+    // ghost velocities before the loop (:729-732): the same exchange as inside the loop
+    {
+        const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
+        if (pushed)      // the in-kernel push only exists inside the subcycle kernel: use the gather lists here
+            evp_launch_halo_local(S.u[0], S.v[0], S.h_local_dst, S.h_local_src,
+                                  (const signed char *)S.h_local_sign, S.n_local, S.stream);
+        if (int rc = halo_uv(0)) return rc;
+    }
+    for (int k = 0; k < 12; ++k)
+        HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    evp_launch_vrelfac(S.in[F_AIX], S.in[F_CW], S.prm.rhow, S.vrelfac, S.n, S.stream);
+    HIPC(hipEventRecord(S.ev1, S.stream));
+    // masks and the shortcut flag back to the host
+    unsigned flagword = 0;
+    HIPC(hipMemcpyAsync(S.hmask.data(), S.mask, S.n, hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipMemcpyAsync(&flagword, Q.flagword, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+    S.t_h2d_ms = ms;
+    HIPC(hipEventElapsedTime(&ms, S.ev3, S.ev1));
+    Q.t_ms = ms;
+    for (size_t k = 0; k < S.n; ++k) {
+        const bool um = (S.hmask[k] & 2u) != 0;
+        iceTmask[k] = (S.hmask[k] & 1u) ? 1 : 0;
+        iceUmask[k] = um ? 1 : 0;
+    }
+    // dyn_prep2 also zeroes these off the ice (:776-781); they are the caller's arrays
+    {
+        const int nx = S.d.nx_block;
+        for (int b = 0; b < S.d.nblocks; ++b)
+            for (int j = S.jlo[b]; j <= S.jhi[b]; ++j)
+                for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
+                    const size_t c = b * S.plane + (size_t)(j - 1) * nx + (i - 1);
+                    if (S.hmask[c] & 2u) continue;
+                    if (strintxU) strintxU[c] = 0.0;
+                    if (strintyU) strintyU[c] = 0.0;
+                    if (strocnxU) strocnxU[c] = 0.0;
+                    if (strocnyU) strocnyU[c] = 0.0;
+                }
+    }
+    S.flags &= ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
+    if (!(flagword & 1u)) S.flags |= EVP_F_WATER_IS_OCN;
+    if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
+    S.uploaded = true;
+    return tune_after_upload();
+}
+
+// ice strength, computed by the host (icepack_ice_strength + its halo update, ice_dyn_evp.F90:541-552,
+// 727-728) from the masks cice_evp_hip_prep returned
+int cice_evp_hip_set_strength(const double *strength)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (!strength) return fail(-1, "null argument");
+    return h2d(S.in[F_STRENGTH], strength);
+}
+
+// products of the preparation phase that stay on the device, for hosts that need them
+// (coupling diagnostics) and for the tests
+int cice_evp_hip_prep_fetch(int32_t which, double *dst)
+{
+    if (!S.ready || !S.uploaded || !S.prep.geo) return fail(-1, "no prepared state");
+    if (!dst) return fail(-1, "null argument");
+    State::Prep &Q = S.prep;
+    const double *tab[20] = {S.in[F_AIX], S.in[F_CW], S.in[F_UOCN], S.in[F_VOCN], S.in[F_UMASSDTI], S.in[F_FM],
+                             S.in[F_WATERX], S.in[F_WATERY], S.in[F_FORCEX], S.in[F_FORCEY], S.in[F_UVEL_INIT],
+                             S.in[F_VVEL_INIT], Q.strtltx, Q.strtlty, Q.strairxU, Q.strairyU, Q.tmass, Q.umass,
+                             S.u[S.cur], S.v[S.cur]};
+    if (which < 0 || which >= 20) return fail(-1, "prep_fetch: which = %d", (int)which);
+    if (d2h(dst, tab[which])) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
     return 0;
 }
 

@@ -124,6 +124,38 @@ struct EvpDirect {
 };
 void evp_launch_halo_direct(const EvpDirect &D, double *u, double *v, hipStream_t st);
 
+// Preparation phase of evp() on the device (evp_prep.hip)
+struct EvpPrep {
+    int nx, ny;
+    size_t plane;
+    const int4 *blk;
+    const uint8_t *tmask, *umask, *umask_old;
+    const double *hm, *tarea, *uarea, *fcor;
+    double *t[11];             // aice vice vsno aice_init cdn_ocn uocn vocn ss_tltx ss_tlty strairxT strairyT (device copies)
+    double *tmass, *umass, *maskd;   // maskd: iceTmask as 0/1 (halo-updated like a field)
+    uint8_t *tmphm;
+    double *ss_tltxU, *ss_tltyU, *strairxU, *strairyU, *strtltx, *strtlty;
+    double *aiU, *cdn_ocnU, *uocnU, *vocnU, *umassdti, *fm, *waterx, *watery, *forcex, *forcey;
+    double *uvel_init, *vvel_init, *uvel, *vvel;
+    double *sig[12];
+    uint8_t *mask;             // out: bit0 iceTmask, bit1 iceUmask
+    unsigned *flagword;        // out: bit0 = waterx/watery differ from uocnU/vocnU somewhere
+    double dt, rhoi, rhos, gravit, dyn_area_min, dyn_mass_min, cosw, sinw;
+    int ssh_coupled;
+};
+struct EvpPrepHalo {
+    double *a[8];
+    unsigned char is_vec[8];
+    int narr;
+    const int *dst, *src;
+    const signed char *vsign;
+    int n;
+};
+void evp_launch_prep1(const EvpPrep &P, int nblocks, hipStream_t st);
+void evp_launch_halo_center(const EvpPrepHalo &H, hipStream_t st);
+void evp_launch_prep_average(const EvpPrep &P, int nblocks, hipStream_t st);
+void evp_launch_prep2(const EvpPrep &P, int nblocks, hipStream_t st);
+
 enum : unsigned {
     EVP_F_METRICS = 1u,     // recompute cxp..DminTarea from HTE,HTN,dxT,dyT (tarea == dxT*dyT verified)
     EVP_F_WATER_IS_OCN = 2u,// waterxU==uocnU and wateryU==vocnU bit for bit on every active U-cell

@@ -1,0 +1,180 @@
+// =====================================================================
+// Preparation phase of evp() on the device: everything the
+// reference does between entering evp() and its subcycle loop on the B grid
+// (dynamics/ice_dyn_evp.F90:383-840), except icepack_ice_strength (Icepack) and
+// the seabed stress factor (calls exp(); both stay with the host):
+//   prep1a/prep1b   dyn_prep1                  ice_dyn_shared.F90:496-576
+//   halo_center     ice_HaloUpdate, centre      ice_dyn_evp.F90:413-428, 466-470
+//   prep_average    grid_average_X2Y T->U       ice_grid.F90:4183-4204 ('S'), 4650-4666 ('F')
+//   prep2           dyn_prep2                   ice_dyn_shared.F90:586-839
+// Not a hot path (once per evp() call): one thread per cell, operation order of the
+// reference, no FMA contraction in either build mode so that it is bit-identical to it.
+// =====================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "evp_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ bool cell_of(const EvpPrep &P, int &i, int &j, int &bz, size_t &c)
+{
+    i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    j = blockIdx.y + 1;
+    bz = blockIdx.z;
+    if (i > P.nx) return false;
+    c = (size_t)bz * P.plane + (size_t)(j - 1) * P.nx + (i - 1);
+    return true;
+}
+
+// dyn_prep1, first loop (:545-558): mass and the "has ice" predicate on every cell
+__global__ void prep1a(EvpPrep P)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const bool tm = P.tmask[c] != 0;
+    const double tmass = tm ? (P.rhoi * P.t[1][c] + P.rhos * P.t[2][c]) : 0.0;
+    P.tmass[c] = tmass;
+    P.tmphm[c] = (uint8_t)(tm && (P.t[0][c] > P.dyn_area_min) && (tmass > P.dyn_mass_min));
+}
+
+// dyn_prep1, second loop (:560-575): extent mask = any of the 3x3 neighbourhood, physical cells only
+__global__ void prep1b(EvpPrep P)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const int4 r = P.blk[bz];
+    double m = 0.0;
+    if (i >= r.x && i <= r.y && j >= r.z && j <= r.w && P.tmask[c]) {
+        unsigned any = 0;
+        for (int dj = -1; dj <= 1; ++dj)
+            for (int di = -1; di <= 1; ++di) any |= P.tmphm[c + (ptrdiff_t)dj * P.nx + di];
+        m = any ? 1.0 : 0.0;
+    }
+    P.maskd[c] = m;
+}
+
+// ghost cells of cell-centre fields; is_vec: the vector kinds change sign across the tripole fold
+__global__ void halo_center(EvpPrepHalo H)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= H.n) return;
+    const int d = H.dst[t], s = H.src[t];
+    const double vs = (double)H.vsign[t];
+    for (int k = 0; k < H.narr; ++k) {
+        double x = 0.0;
+        if (s >= 0) x = (H.is_vec[k] ? vs : 1.0) * H.a[k][s];
+        H.a[k][d] = x;
+    }
+}
+
+// T -> U averages on the physical cells, 0 elsewhere (work2(:,:,:) = c0 first)
+__global__ void prep_average(EvpPrep P)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const int4 r = P.blk[bz];
+    const bool in = i >= r.x && i <= r.y && j >= r.z && j <= r.w;
+    double o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (in) {
+        const size_t c1 = c + 1, c2 = c + P.nx, c3 = c + P.nx + 1;
+        const double m0 = P.hm[c], m1 = P.hm[c1], m2 = P.hm[c2], m3 = P.hm[c3];
+        const double w0 = P.tarea[c], w1 = P.tarea[c1], w2 = P.tarea[c2], w3 = P.tarea[c3];
+        const double wtmp = (m0 * w0 + m1 * w1 + m2 * w2 + m3 * w3);
+        // state-masked: tmass, aice_init, cdn_ocn, uocn, vocn, ss_tltx, ss_tlty
+        const double *src[7] = {P.tmass, P.t[3], P.t[4], P.t[5], P.t[6], P.t[7], P.t[8]};
+        if (wtmp != 0.0)
+            for (int k = 0; k < 7; ++k) {
+                const double *a = src[k];
+                o[k] = (m0 * a[c] * w0 + m1 * a[c1] * w1 + m2 * a[c2] * w2 + m3 * a[c3] * w3) / wtmp;
+            }
+        // flux: wind stress
+        for (int k = 0; k < 2; ++k) {
+            const double *a = P.t[9 + k];
+            o[7 + k] = 0.25 * (a[c] * w0 + a[c1] * w1 + a[c2] * w2 + a[c3] * w3) / P.uarea[c];
+        }
+    }
+    P.umass[c] = o[0]; P.aiU[c] = o[1]; P.cdn_ocnU[c] = o[2]; P.uocnU[c] = o[3]; P.vocnU[c] = o[4];
+    P.ss_tltxU[c] = o[5]; P.ss_tltyU[c] = o[6]; P.strairxU[c] = o[7]; P.strairyU[c] = o[8];
+}
+
+// dyn_prep2 (:697-838)
+__global__ void prep2(EvpPrep P)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const int4 r = P.blk[bz];
+    const bool iceT = P.maskd[c] != 0.0;
+    if (!iceT)
+        for (int k = 0; k < 12; ++k) P.sig[k][c] = 0.0;
+    double waterx = 0.0, watery = 0.0, forcex = 0.0, forcey = 0.0, umassdti = 0.0;
+    bool iceU = false;
+    if (i >= r.x && i <= r.y && j >= r.z && j <= r.w) {
+        const double umass = P.umass[c], aiU = P.aiU[c];
+        const bool old = P.umask_old[c] != 0;
+        iceU = P.umask[c] && (aiU > P.dyn_area_min) && (umass > P.dyn_mass_min);
+        double u = P.uvel[c], v = P.vvel[c];
+        if (iceU) {
+            if (!old) { u = P.uocnU[c]; v = P.vocnU[c]; }
+        } else {
+            u = 0.0; v = 0.0;
+        }
+        P.uvel[c] = u; P.vvel[c] = v;
+        P.uvel_init[c] = u; P.vvel_init[c] = v;
+        if (iceU) {
+            umassdti = umass / P.dt;
+            const double fm = P.fcor[c] * umass;
+            P.fm[c] = fm;
+            const double sg = copysign(1.0, fm);
+            const double uo = P.uocnU[c], vo = P.vocnU[c];
+            waterx = uo * P.cosw - vo * P.sinw * sg;
+            watery = vo * P.cosw + uo * P.sinw * sg;
+            double tx, ty;
+            if (P.ssh_coupled) {
+                tx = -P.gravit * umass * P.ss_tltxU[c];
+                ty = -P.gravit * umass * P.ss_tltyU[c];
+            } else {
+                tx = -fm * vo;
+                ty = fm * uo;
+            }
+            P.strtltx[c] = tx; P.strtlty[c] = ty;
+            forcex = P.strairxU[c] + tx;
+            forcey = P.strairyU[c] + ty;
+            // does the subcycle kernel's waterx == uocn shortcut hold bit for bit?
+            if (__double_as_longlong(waterx) != __double_as_longlong(uo) ||
+                __double_as_longlong(watery) != __double_as_longlong(vo))
+                atomicOr(P.flagword, 1u);
+        }
+    }
+    P.waterx[c] = waterx; P.watery[c] = watery; P.forcex[c] = forcex; P.forcey[c] = forcey;
+    P.umassdti[c] = umassdti;
+    P.mask[c] = (uint8_t)((iceT ? 1 : 0) | (iceU ? 2 : 0));
+}
+
+dim3 cell_grid(const EvpPrep &P, int nblocks) { return dim3((P.nx + 63) / 64, P.ny, nblocks); }
+
+}  // namespace
+
+void evp_launch_prep1(const EvpPrep &P, int nblocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(prep1a, cell_grid(P, nblocks), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(prep1b, cell_grid(P, nblocks), dim3(64), 0, st, P);
+}
+
+void evp_launch_halo_center(const EvpPrepHalo &H, hipStream_t st)
+{
+    if (H.n <= 0 || H.narr <= 0) return;
+    hipLaunchKernelGGL(halo_center, dim3((H.n + 255) / 256), dim3(256), 0, st, H);
+}
+
+void evp_launch_prep_average(const EvpPrep &P, int nblocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(prep_average, cell_grid(P, nblocks), dim3(64), 0, st, P);
+}
+
+void evp_launch_prep2(const EvpPrep &P, int nblocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(prep2, cell_grid(P, nblocks), dim3(64), 0, st, P);
+}

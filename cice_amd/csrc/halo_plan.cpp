@@ -181,6 +181,54 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
     }
     for (auto &kv : peers) plan.peers.push_back(std::move(kv.second));
 
+    // cell-centre fields: ghosts of this rank's blocks, same enumeration
+    {
+        const int NX = d.nx_global, NY = d.ny_global;
+        auto it = T.by_rank.find(me);
+        if (it != T.by_rank.end())
+            for (int kb : it->second) {
+                const HaloBlock &B = T.blk[kb];
+                const int ilo = ng + 1, jlo = ng + 1, ihi = ng + B.gnx, jhi = ng + B.gny;
+                for (int j = jlo - ng; j <= jhi + ng; ++j)
+                    for (int i = ilo - ng; i <= ihi + ng; ++i) {
+                        if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) continue;
+                        int ig = B.gi0 + (i - ilo), jg = B.gj0 + (j - jlo), sign = 1;
+                        bool outside = false;
+                        if (ig < 1 || ig > NX) {
+                            if (d.ew_boundary_type == CICE_EVP_BND_CYCLIC) ig = (ig < 1) ? ig + NX : ig - NX;
+                            else outside = true;
+                        }
+                        if (jg < 1) {
+                            if (d.ns_boundary_type == CICE_EVP_BND_CYCLIC) jg += NY;
+                            else outside = true;
+                        } else if (jg > NY) {
+                            if (d.ns_boundary_type == CICE_EVP_BND_CYCLIC) jg -= NY;
+                            else if (tripole && !outside) {
+                                const int k = jg - NY;
+                                ig = NX - ig + 1;
+                                jg = NY - k + 1;
+                                sign = -1;
+                            } else outside = true;
+                        }
+                        if (outside) continue;
+                        const int32_t dst = (int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1));
+                        const int ks = T.find(ig, jg);
+                        if (ks < 0 || T.blk[ks].owner < 0) {       // eliminated land block: 0
+                            plan.center_dst.push_back(dst);
+                            plan.center_src.push_back(-1);
+                            plan.center_vsign.push_back(1);
+                            continue;
+                        }
+                        const HaloBlock &Sb = T.blk[ks];
+                        if (Sb.owner != me) { plan.center_remote = true; continue; }
+                        plan.center_dst.push_back(dst);
+                        plan.center_src.push_back((int32_t)((size_t)Sb.local * plane +
+                                                            (size_t)(ng + (jg - Sb.gj0)) * nx + (ng + (ig - Sb.gi0))));
+                        plan.center_vsign.push_back((int8_t)sign);
+                    }
+            }
+    }
+
     if (tripole) {
         const int NX = d.nx_global, NY = d.ny_global;
         auto offset_of = [&](int ig, int jg, int &owner) -> int32_t {

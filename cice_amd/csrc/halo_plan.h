@@ -53,6 +53,14 @@ struct HaloPlan {
     // physical row of its PARTNER array, a1(ig, NY+1) <- a2(NX-ig+1, NY); ghost cells whose source
     // block was eliminated are set to 0 (src = -1).  Offsets into the local array.
     std::vector<int32_t> stress_dst, stress_src;
+    // Ghost cells of CELL-CENTRE fields (the T-grid inputs of evp()'s preparation phase,
+    // ice_dyn_evp.F90:413-428, 466-470): same as the velocity lists except across the tripole
+    // fold, where a centre cell mirrors column NX-ig+1 of row NY-k+1 (ice_boundary.F90:1689-1722,
+    // ioffset -1, joffset 0); center_vsign is the factor for vector kinds (-1 across the fold),
+    // scalars always copy.  center_remote: some source lives on another rank (not listed).
+    std::vector<int32_t> center_dst, center_src;
+    std::vector<int8_t> center_vsign;
+    bool center_remote = false;
     std::string error;
 };
 

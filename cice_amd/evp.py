@@ -42,8 +42,21 @@ EXPORTS = [
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan",
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_prep_fetch",
 ]
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
+# T-grid inputs of the preparation phase (order of cice_evp_hip_prep's tfields11) and the
+# products cice_evp_hip_prep_fetch serves (index = `which`)
+PREP_T = ["aice", "vice", "vsno", "aice_init", "cdn_ocn", "uocn", "vocn", "ss_tltx", "ss_tlty",
+          "strairxT", "strairyT"]
+PREP_FETCH = ["aiU", "cdn_ocnU", "uocnU", "vocnU", "umassdti", "fmU", "waterxU", "wateryU", "forcexU",
+              "forceyU", "uvel_init", "vvel_init", "strtltxU", "strtltyU", "strairxU", "strairyU",
+              "tmass", "umass", "uvel", "vvel"]
+
+
+class PrepParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("rhoi", C.c_double), ("rhos", C.c_double), ("gravit", C.c_double),
+                ("dyn_area_min", C.c_double), ("dyn_mass_min", C.c_double), ("ssh_stress_coupled", C.c_int32)]
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -191,6 +204,41 @@ class EvpHip:
         um = self._c(iceUmask, np.int32)
         rc = self.lib.cice_evp_hip_upload(tab, _ip(tm), _ip(um))
         _check(self.lib, rc, "(dyn_evp_hip_upload)")
+
+    # -- next tier f-2: evp()'s preparation phase on the device ---------------------------
+    def set_prep_geometry(self, tmask, umask, hm, tarea, uarea, fcor_blk):
+        tm, um = self._c(tmask, np.int32), self._c(umask, np.int32)
+        a = [self._c(x) for x in (hm, tarea, uarea, fcor_blk)]
+        _check(self.lib, self.lib.cice_evp_hip_set_prep_geometry(_ip(tm), _ip(um), *[_dp(x) for x in a]),
+               "(dyn_evp_hip_set_prep_geometry)")
+
+    def prep(self, pp: "PrepParams", tfields: dict, state: dict):
+        """state: the 12 stresses, uvel, vvel, iceUmask (previous call), optional TbU and
+        strintxU/strintyU/strocnxU/strocnyU.  Returns (iceTmask, iceUmask, zeroed dict)."""
+        t = [self._c(tfields[k]) for k in PREP_T]
+        ttab = (_f64p * 11)(*[_dp(a) for a in t])
+        f = [self._c(state[k]) if k in state and state[k] is not None and k in FIELDS[:12] + ["uvel", "vvel", "TbU"]
+             else None for k in FIELDS]
+        ftab = (_f64p * len(FIELDS))(*[(_dp(a) if a is not None else None) for a in f])
+        tm = np.zeros(self.shape, dtype=np.int32)
+        um = np.array(state["iceUmask"], dtype=np.int32, order="C", copy=True).reshape(self.shape)
+        z = {k: (np.array(state[k], dtype=np.float64, order="C", copy=True) if state.get(k) is not None else None)
+             for k in ("strintxU", "strintyU", "strocnxU", "strocnyU")}
+        rc = self.lib.cice_evp_hip_prep(C.byref(pp), ttab, ftab, _ip(tm), _ip(um),
+                                        *[(_dp(z[k]) if z[k] is not None else None)
+                                          for k in ("strintxU", "strintyU", "strocnxU", "strocnyU")])
+        _check(self.lib, rc, "(dyn_evp_hip_prep)")
+        return tm, um, z
+
+    def set_strength(self, strength):
+        a = self._c(strength)
+        _check(self.lib, self.lib.cice_evp_hip_set_strength(_dp(a)), "(dyn_evp_hip_set_strength)")
+
+    def prep_fetch(self, name: str):
+        out = np.zeros(self.shape)
+        _check(self.lib, self.lib.cice_evp_hip_prep_fetch(C.c_int32(PREP_FETCH.index(name)), _dp(out)),
+               "(dyn_evp_hip_prep_fetch)")
+        return out
 
     def subcycle(self, ndte: int | None = None):
         rc = self.lib.cice_evp_hip_subcycle(C.c_int32(self.ndte if ndte is None else ndte))

@@ -156,6 +156,39 @@ int cice_evp_hip_deformations(double *divu, double *shear, double *vort, double 
                               double *rdg_shear);
 int cice_evp_hip_dyn_finish(double *strocnxU, double *strocnyU);
 
+/* ---- next tier: the preparation phase of evp() on the device ---------------
+ * Everything evp() does between its entry and the subcycle loop on the B grid
+ * (ice_dyn_evp.F90:383-840): dyn_prep1 (ice_dyn_shared.F90:496-576), the ice_HaloUpdate calls on
+ * iceTmask and the T-grid fields (:413-428, 466-470), grid_average_X2Y T->U in its state-masked
+ * and flux flavours (ice_grid.F90:4183-4204, 4650-4666), dyn_prep2 (ice_dyn_shared.F90:586-839)
+ * and the pre-loop velocity halo (:729-732) -- except icepack_ice_strength and the seabed
+ * stress factor TbU, which the host keeps (Icepack; exp()).  Call order per evp():
+ *   cice_evp_hip_prep -> host: ice strength from the returned iceTmask -> cice_evp_hip_set_strength
+ *   -> cice_evp_hip_subcycle -> cice_evp_hip_download (+ _deformations, _dyn_finish, _stress_halo).
+ * set_prep_geometry (once): tmask, umask (logical as int32), hm, tarea, uarea (ice_grid),
+ * fcor_blk (ice_dyn_shared).  T-grid fields, in this order: aice, vice, vsno, aice_init, cdn_ocn,
+ * uocn, vocn, ss_tltx, ss_tlty, strairxT, strairyT (their ghost cells need not be current).
+ * fields32: the table of cice_evp_hip_upload; read here: the 12 stresses, uvel, vvel, TbU (NULL = 0).
+ * iceUmask: in = mask of the previous call (new ice starts at the ocean velocity), out = new mask;
+ * strintxU/strintyU/strocnxU/strocnyU (may be NULL): zeroed off the ice on the host arrays.
+ * Ranks whose T-grid halo needs another rank are refused (keep the host preparation there).   */
+typedef struct cice_evp_hip_prep_params {
+    double dt;                 /* dynamics time step (dyn_prep2's Xmass/dt)                    */
+    double rhoi, rhos, gravit; /* icepack_query_parameters                                      */
+    double dyn_area_min, dyn_mass_min;
+    int32_t ssh_stress_coupled;/* ssh_stress == 'coupled' (else 'geostrophic')                  */
+} cice_evp_hip_prep_params;
+int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, const double *hm,
+                                   const double *tarea, const double *uarea, const double *fcor_blk);
+int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *tfields11,
+                      const double *const *fields32, int32_t *iceTmask, int32_t *iceUmask,
+                      double *strintxU, double *strintyU, double *strocnxU, double *strocnyU);
+int cice_evp_hip_set_strength(const double *strength);
+/* which: 0 aiU 1 cdn_ocnU 2 uocnU 3 vocnU 4 umassdti 5 fmU 6 waterxU 7 wateryU 8 forcexU 9 forceyU
+ * 10 uvel_init 11 vvel_init 12 strtltxU 13 strtltyU 14 strairxU 15 strairyU 16 tmass 17 umass
+ * 18 uvel 19 vvel (as the subcycle loop will see them)                                          */
+int cice_evp_hip_prep_fetch(int32_t which, double *dst);
+
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */
 /* 128-byte ncclUniqueId made by rank 0 and distributed by the host program
  * (MPI_Bcast in CICE; torch.distributed in bench.py).                          */

@@ -522,3 +522,44 @@ def test_s01_full_size_decomposition_and_transport_invariance(monkeypatch):
             ref = glob
         else:
             assert_bitwise(glob, ref, f"s01 blocks={bs} mailbox={selfx}")
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_next_tier_prep_on_device_bitwise(name):
+    """evp()'s preparation phase on the device -- from the model state the
+    reference's evp() was entered with (pr*) to what it handed to its subcycle loop (in*/pq*),
+    bit for bit (both calls of a fixture: new-ice / lost-ice cells, previous masks); then the
+    whole evp(): prep -> ice strength from the host -> subcycle loop -> the reference's outputs."""
+    from test_oracle_golden import check_prep_products
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        st = c.prep_static()
+        core.set_prep_geometry(st["tmask"], st["umask"], st["hm"], st["tarea"], st["uarea"], st["fcor_blk"])
+        pp = evp.PrepParams(**{k: v for k, v in c.prep_scal_dict().items() if k not in ("cosw", "sinw", "ssh_coupled")},
+                            ssh_stress_coupled=c.prep_scal_dict()["ssh_coupled"])
+        for icall in range(1, c.ncalls + 1):
+            t, state = c.prep_inputs(icall)
+            dyn, tm_ref, um_ref = c.inputs(icall)
+            state = dict(state, TbU=dyn["TbU"])                  # seabed stress factor stays with the host
+            tm, um, z = core.prep(pp, t, state)
+            out = {k: core.prep_fetch(k) for k in evp.PREP_FETCH}
+            out.update(iceTmask=tm, iceUmask=um)
+            raw = core.download()                                # stresses after dyn_prep2's zeroing
+            out.update({k: raw[k] for k in SIG})
+            check_prep_products(c, icall, out, f"{name} call {icall} prep on device")
+            assert np.abs(out["forcexU"]).max() > 0 and np.abs(out["umassdti"]).max() > 0 and um.any() and tm.any()
+            off = um == 0
+            inter = np.zeros(tm.shape, bool)
+            inter[:, 1:-1, 1:-1] = True
+            for k in ("strintxU", "strocnxU"):
+                assert not z[k][off & inter].any()
+            # the rest of evp(): strength from the host, the loop, the reference's answer
+            core.set_strength(dyn["strength"])
+            core.subcycle(c.ndte)
+            if c.ns == "tripole":
+                core.stress_halo()
+            res = core.download()
+            assert_bitwise(res, c.expected(icall, c.ndte), f"{name} call {icall}: prep + loop on device")
+    finally:
+        core.finalize()
