@@ -1789,18 +1789,16 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     S.t_h2d_ms = ms;
     HIPC(hipEventElapsedTime(&ms, S.ev3, S.ev1));
     Q.t_ms = ms;
-    for (size_t k = 0; k < S.n; ++k) {
-        const bool um = (S.hmask[k] & 2u) != 0;
-        iceTmask[k] = (S.hmask[k] & 1u) ? 1 : 0;
-        iceUmask[k] = um ? 1 : 0;
-    }
-    // dyn_prep2 also zeroes these off the ice (:776-781); they are the caller's arrays
+    for (size_t k = 0; k < S.n; ++k) iceTmask[k] = (S.hmask[k] & 1u) ? 1 : 0;
+    // dyn_prep2 writes iceUmask on the physical cells only (:761-764) and zeroes the stress
+    // divergence / ocean stress off the ice there (:776-781); they are the caller's arrays
     {
         const int nx = S.d.nx_block;
         for (int b = 0; b < S.d.nblocks; ++b)
             for (int j = S.jlo[b]; j <= S.jhi[b]; ++j)
                 for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
                     const size_t c = b * S.plane + (size_t)(j - 1) * nx + (i - 1);
+                    iceUmask[c] = (S.hmask[c] & 2u) ? 1 : 0;
                     if (S.hmask[c] & 2u) continue;
                     if (strintxU) strintxU[c] = 0.0;
                     if (strintyU) strintyU[c] = 0.0;
@@ -1814,6 +1812,11 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     S.uploaded = true;
     return tune_after_upload();
 }
+
+// Address of a caller's array, for hosts whose language will not hand out the address of an
+// object without a TARGET-like attribute (CICE's module arrays): the Fortran shim builds the
+// pointer tables of cice_evp_hip_prep / _download with it.
+void *cice_evp_hip_addr(const void *array) { return const_cast<void *>(array); }
 
 // ice strength, computed by the host (icepack_ice_strength + its halo update, ice_dyn_evp.F90:541-552,
 // 727-728) from the masks cice_evp_hip_prep returned
@@ -1988,13 +1991,13 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     if (S.ready && S.marked[0] && S.marked[1] && hipEventQuery(S.evm[1]) == hipSuccess &&
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
-    const double v[10] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+    const double v[11] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
                          (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
-                          S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0)};
-    for (int k = 0; k < n && k < 10; ++k) out[k] = v[k];
+                          S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms};
+    for (int k = 0; k < n && k < 11; ++k) out[k] = v[k];
     return 0;
 }
 

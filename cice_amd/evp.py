@@ -43,6 +43,7 @@ EXPORTS = [
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_addr",
 ]
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
 # T-grid inputs of the preparation phase (order of cice_evp_hip_prep's tfields11) and the
@@ -98,6 +99,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib = C.CDLL(str(p), mode=C.RTLD_GLOBAL)
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
+    lib.cice_evp_hip_addr.restype = C.c_void_p        # the one entry point that does not return a status
     if path is None:
         _lib = lib
     return lib
@@ -255,11 +257,11 @@ class EvpHip:
         return out
 
     def timings(self) -> dict:
-        t = np.zeros(10)
-        self.lib.cice_evp_hip_get_timings(_dp(t), 10)
+        t = np.zeros(11)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 11)
         return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4],
                     tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
-                    halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])])
+                    halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10])
 
     def stress_halo(self):
         """Tripole: 12 x ice_HaloUpdate_stress on the resident stresses (ice_dyn_evp.F90:1321-1389)."""

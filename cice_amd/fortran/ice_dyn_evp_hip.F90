@@ -29,7 +29,7 @@ module ice_dyn_evp_hip
   implicit none
   private
 
-  public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize
+  public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body
 
   ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
   type, bind(C) :: cice_evp_hip_dims
@@ -48,6 +48,12 @@ module ice_dyn_evp_hip
      real(c_double) :: arlx1i, denom1, brlx, revp, e_factor, epp2i
      real(c_double) :: capping, Ktens, deltaminEVP, u0, cosw, sinw, rhow
   end type cice_evp_hip_params
+
+  ! mirror of cice_evp_hip_prep_params
+  type, bind(C) :: cice_evp_hip_prep_params
+     real(c_double) :: dt, rhoi, rhos, gravit, dyn_area_min, dyn_mass_min
+     integer(c_int32_t) :: ssh_stress_coupled
+  end type cice_evp_hip_prep_params
 
   interface
      integer(c_int) function cice_evp_hip_init(dims, params, HTE, HTN, dxT, dyT, uarear, tarea) &
@@ -108,6 +114,48 @@ module ice_dyn_evp_hip
        import :: c_int, c_int32_t
        integer(c_int32_t), dimension(32), intent(in) :: id128
      end function cice_evp_hip_comm_init
+
+     ! ---- wider entry points (Option A: evp() patched to hand over its whole B-grid body) ----
+     integer(c_int) function cice_evp_hip_set_prep_geometry(tmask, umask, hm, tarea, uarea, fcor_blk) &
+          bind(C, name='cice_evp_hip_set_prep_geometry')
+       import :: c_int, c_int32_t, c_double
+       integer(c_int32_t), dimension(*), intent(in) :: tmask, umask       ! logical(4) storage
+       real(c_double), dimension(*), intent(in) :: hm, tarea, uarea, fcor_blk
+     end function cice_evp_hip_set_prep_geometry
+
+     integer(c_int) function cice_evp_hip_prep(pp, tfields11, fields32, iceTmask, iceUmask, &
+          strintxU, strintyU, strocnxU, strocnyU) bind(C, name='cice_evp_hip_prep')
+       import :: c_int, c_int32_t, c_double, c_ptr, cice_evp_hip_prep_params
+       type(cice_evp_hip_prep_params), intent(in) :: pp
+       type(c_ptr), dimension(11), intent(in) :: tfields11
+       type(c_ptr), dimension(32), intent(in) :: fields32
+       integer(c_int32_t), dimension(*), intent(inout) :: iceTmask, iceUmask
+       real(c_double), dimension(*), intent(inout) :: strintxU, strintyU, strocnxU, strocnyU
+     end function cice_evp_hip_prep
+
+     type(c_ptr) function cice_evp_hip_addr(array) bind(C, name='cice_evp_hip_addr')
+       import :: c_ptr
+       type(*), dimension(*), intent(in) :: array      ! any contiguous array; no TARGET needed
+     end function cice_evp_hip_addr
+
+     integer(c_int) function cice_evp_hip_set_strength(strength) bind(C, name='cice_evp_hip_set_strength')
+       import :: c_int, c_double
+       real(c_double), dimension(*), intent(in) :: strength
+     end function cice_evp_hip_set_strength
+
+     integer(c_int) function cice_evp_hip_subcycle(ndte) bind(C, name='cice_evp_hip_subcycle')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), value :: ndte
+     end function cice_evp_hip_subcycle
+
+     integer(c_int) function cice_evp_hip_stress_halo() bind(C, name='cice_evp_hip_stress_halo')
+       import :: c_int
+     end function cice_evp_hip_stress_halo
+
+     integer(c_int) function cice_evp_hip_download(fields32) bind(C, name='cice_evp_hip_download')
+       import :: c_int, c_ptr
+       type(c_ptr), dimension(32), intent(in) :: fields32
+     end function cice_evp_hip_download
   end interface
 
   logical :: initialised = .false.
@@ -234,6 +282,93 @@ contains
             file=__FILE__, line=__LINE__)
     end select
   end function bnd_code
+
+!-----------------------------------------------------------------------
+! Option A (INTEGRATION.md): the B-grid body of evp() from its entry to the end of the subcycle
+! loop -- preparation phase (ice_dyn_evp.F90:383-840), loop (:859-913) and, on a tripole grid, the
+! stress symmetrisation (:1321-1389) -- on the device.  The caller supplies the ice strength
+! through a callback that runs between the two device phases, because icepack_ice_strength
+! needs the iceTmask the preparation produces (:541-552).  Ranks whose T-grid halo needs another
+! rank keep evp()'s host preparation (the C side refuses them).
+  subroutine dyn_evp_hip_evp_body(dt, compute_strength)
+
+    use ice_blocks, only: nx_block, ny_block
+    use ice_domain_size, only: max_blocks
+    use ice_domain, only: ns_boundary_type
+    use ice_grid, only: tmask, umask, hm, tarea, uarea
+    use ice_state, only: aice, vice, vsno, uvel, vvel, aice_init, strength
+    use ice_arrays_column, only: Cdn_ocn
+    use ice_flux, only: uocn, vocn, ss_tltx, ss_tlty, strairxT, strairyT, &
+         stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
+         stress12_1, stress12_2, stress12_3, stress12_4, strintxU, strintyU, strocnxU, strocnyU, &
+         taubxU, taubyU, TbU
+    use ice_dyn_shared, only: ndte, fcor_blk, iceTmask, iceUmask, dyn_area_min, dyn_mass_min, ssh_stress
+    use icepack_intfc, only: icepack_query_parameters
+
+    real(kind=dbl_kind), intent(in) :: dt
+    interface
+       subroutine compute_strength()    ! fills ice_flux's strength from iceTmask and halo-updates it
+       end subroutine compute_strength
+    end interface
+
+    type(cice_evp_hip_prep_params) :: pp
+    type(c_ptr) :: tf(11), f32(32), out32(32)
+    integer(c_int32_t), pointer :: tmask_i(:), umask_i(:), itm(:), ium(:)
+    integer :: nall
+    logical, save :: geometry_set = .false.
+    character(len=*), parameter :: subname = '(dyn_evp_hip_evp_body)'
+
+    if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
+         file=__FILE__, line=__LINE__)
+    nall = nx_block*ny_block*max_blocks
+    if (.not. geometry_set) then
+       ! logical(log_kind) is a 4-byte logical: the C side tests "non-zero"
+       call c_f_pointer(cice_evp_hip_addr(tmask), tmask_i, [nall])
+       call c_f_pointer(cice_evp_hip_addr(umask), umask_i, [nall])
+       call check(cice_evp_hip_set_prep_geometry(tmask_i, umask_i, hm, tarea, uarea, fcor_blk), &
+            subname, __FILE__, __LINE__)
+       geometry_set = .true.
+    endif
+    pp%dt = dt
+    call icepack_query_parameters(rhoi_out=pp%rhoi, rhos_out=pp%rhos, gravit_out=pp%gravit)
+    pp%dyn_area_min = dyn_area_min
+    pp%dyn_mass_min = dyn_mass_min
+    pp%ssh_stress_coupled = merge(1_c_int32_t, 0_c_int32_t, trim(ssh_stress) == 'coupled')
+
+    tf(1) = cice_evp_hip_addr(aice);      tf(2) = cice_evp_hip_addr(vice);     tf(3) = cice_evp_hip_addr(vsno)
+    tf(4) = cice_evp_hip_addr(aice_init); tf(5) = cice_evp_hip_addr(Cdn_ocn)
+    tf(6) = cice_evp_hip_addr(uocn);      tf(7) = cice_evp_hip_addr(vocn)
+    tf(8) = cice_evp_hip_addr(ss_tltx);   tf(9) = cice_evp_hip_addr(ss_tlty)
+    tf(10) = cice_evp_hip_addr(strairxT); tf(11) = cice_evp_hip_addr(strairyT)
+    f32 = c_null_ptr
+    f32(1) = cice_evp_hip_addr(stressp_1);  f32(2) = cice_evp_hip_addr(stressp_2)
+    f32(3) = cice_evp_hip_addr(stressp_3);  f32(4) = cice_evp_hip_addr(stressp_4)
+    f32(5) = cice_evp_hip_addr(stressm_1);  f32(6) = cice_evp_hip_addr(stressm_2)
+    f32(7) = cice_evp_hip_addr(stressm_3);  f32(8) = cice_evp_hip_addr(stressm_4)
+    f32(9) = cice_evp_hip_addr(stress12_1); f32(10) = cice_evp_hip_addr(stress12_2)
+    f32(11) = cice_evp_hip_addr(stress12_3); f32(12) = cice_evp_hip_addr(stress12_4)
+    f32(26) = cice_evp_hip_addr(TbU)    ! seabed stress factor: the host's (seabed_stress_factor_LKD/_prob)
+    f32(29) = cice_evp_hip_addr(uvel)
+    f32(30) = cice_evp_hip_addr(vvel)
+    call c_f_pointer(cice_evp_hip_addr(iceTmask), itm, [nall])
+    call c_f_pointer(cice_evp_hip_addr(iceUmask), ium, [nall])
+    call check(cice_evp_hip_prep(pp, tf, f32, itm, ium, strintxU, strintyU, strocnxU, strocnyU), &
+         subname, __FILE__, __LINE__)
+
+    call compute_strength()
+    call check(cice_evp_hip_set_strength(strength), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_subcycle(int(ndte, c_int32_t)), subname, __FILE__, __LINE__)
+    if (trim(ns_boundary_type) == 'tripole') &
+       call check(cice_evp_hip_stress_halo(), subname, __FILE__, __LINE__)
+
+    out32 = c_null_ptr
+    out32(1:12) = f32(1:12)
+    out32(24) = cice_evp_hip_addr(strintxU); out32(25) = cice_evp_hip_addr(strintyU)
+    out32(27) = cice_evp_hip_addr(taubxU);   out32(28) = cice_evp_hip_addr(taubyU)
+    out32(29) = f32(29);                     out32(30) = f32(30)
+    call check(cice_evp_hip_download(out32), subname, __FILE__, __LINE__)
+
+  end subroutine dyn_evp_hip_evp_body
 
 !-----------------------------------------------------------------------
 ! Replaces dyn_evp1d_run: identical argument list (ice_dyn_evp1d.F90:121-153).

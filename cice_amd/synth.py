@@ -168,3 +168,37 @@ def evp_scalars(ndte: int, dt: float = 3600.0, revised_evp: bool = False, elasti
     return dict(ndte=ndte, arlx1i=arlx1i, denom1=denom1, brlx=brlx, revp=revp, e_factor=e_factor,
                 epp2i=epp2i, capping=capping, Ktens=Ktens, deltaminEVP=deltaminEVP,
                 u0=5e-5, cosw=1.0, sinw=0.0, rhow=RHOW)
+
+
+def make_primary(g: dict, case: str = "full", seed: int = 1) -> dict:
+    """The model state evp() is entered with (inputs of its preparation phase), on
+    the global grid: T-grid fields aice..strairyT, the previous velocities / stresses / U mask
+    (with cells that gain and lose ice), and the static fields dyn_prep1/2 and the T->U averages
+    read.  Analytic + PCG64 noise; for parity and timing runs of cice_evp_hip_prep."""
+    nx, ny = g["nx"], g["ny"]
+    x = (np.arange(1, nx + 1) - 0.5)[None, :] / nx * np.ones((ny, 1))
+    y = (np.arange(1, ny + 1) - 0.5)[:, None] / ny * np.ones((1, nx))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tmask, umask = g["tmask"], g["umask"]
+    aice = np.where(tmask, 0.9 + 0.05 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y), 0.0)
+    if case == "caps":
+        aice = aice * np.clip((np.abs(y - 0.5) - 0.25) / 0.05, 0.0, 1.0)
+    holes = np.sin(11 * np.pi * x) * np.sin(7 * np.pi * y) > 0.8          # open water patches
+    aice = np.where(holes, 0.0, aice)
+    hi = 2.0 * (1.0 + 0.1 * np.sin(4 * np.pi * y) * np.cos(2 * np.pi * x)) * (1.0 + 0.01 * (2 * rng.random((ny, nx)) - 1))
+    vice = hi * aice
+    t = dict(aice=aice, vice=vice, vsno=0.2 * aice, aice_init=aice * (1.0 - 0.01 * rng.random((ny, nx))),
+             cdn_ocn=0.00536 * (1.0 + 0.1 * rng.random((ny, nx))), uocn=0.2 * y - 0.1, vocn=-0.2 * x + 0.1,
+             ss_tltx=1e-6 * np.sin(2 * np.pi * y), ss_tlty=1e-6 * np.cos(2 * np.pi * x),
+             strairxT=aice * 0.1 * np.sin(2 * np.pi * x) * np.sin(np.pi * y),
+             strairyT=aice * 0.1 * np.sin(np.pi * x) * np.sin(2 * np.pi * y))
+    old = umask & (rng.random((ny, nx)) > 0.1)               # previous U mask: ~10 % "new ice" cells
+    state = dict(uvel=np.where(old, 0.05 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y), 0.0),
+                 vvel=np.where(old, 0.05 * np.cos(2 * np.pi * x) * np.sin(4 * np.pi * y), 0.0),
+                 iceUmask=old.astype(np.int32))
+    for k, name in enumerate(["stressp_1", "stressp_2", "stressp_3", "stressp_4", "stressm_1", "stressm_2",
+                              "stressm_3", "stressm_4", "stress12_1", "stress12_2", "stress12_3", "stress12_4"]):
+        state[name] = np.where(tmask, -1000.0 * (1.0 + 0.1 * k) * (1.0 + 0.3 * np.sin(6 * np.pi * x)), 0.0)
+    static = dict(tmask=tmask.astype(np.int32), umask=umask.astype(np.int32), hm=g["hm"], tarea=g["tarea"],
+                  uarea=g["uarea"], fcor_blk=2.0 * OMEGA * np.sin(g["ULAT"]))
+    return dict(t=t, state=state, static=static)

@@ -184,6 +184,9 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
                       const double *const *fields32, int32_t *iceTmask, int32_t *iceUmask,
                       double *strintxU, double *strintyU, double *strocnxU, double *strocnyU);
 int cice_evp_hip_set_strength(const double *strength);
+/* Returns its argument.  Lets a Fortran host take the address of a module array that lacks the
+ * TARGET attribute (type(*), dimension(*) dummy) to fill the pointer tables above.              */
+void *cice_evp_hip_addr(const void *array);
 /* which: 0 aiU 1 cdn_ocnU 2 uocnU 3 vocnU 4 umassdti 5 fmU 6 waterxU 7 wateryU 8 forcexU 9 forceyU
  * 10 uvel_init 11 vvel_init 12 strtltxU 13 strtltyU 14 strairxU 15 strairyU 16 tmass 17 umass
  * 18 uvel 19 vvel (as the subcycle loop will see them)                                          */
@@ -216,7 +219,8 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen);
  * [5]=tile variant in use (tile height + 100 * tile-order mode),
  * [6]=ms between cice_evp_hip_mark(0) and cice_evp_hip_mark(1), -1 if unset,
  * [7]=streaming probe ms/subcycle, [8]=resident probe ms/subcycle,
- * [9]=remote halo transport: 0 none, 1 RCCL p2p, 2 mailbox (direct stores over xGMI)          */
+ * [9]=remote halo transport: 0 none, 1 RCCL p2p, 2 mailbox (direct stores over xGMI),
+ * [10]=device time of the last cice_evp_hip_prep (kernels + halos, without the copies), ms      */
 int cice_evp_hip_get_timings(double *out, int32_t n);
 /* Halo plan of this rank, for tests: counts[0]=local copies, [1]=#peers,
  * [2]=total send cells, [3]=total recv cells.  Lists may be NULL.

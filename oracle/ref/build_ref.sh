@@ -89,7 +89,7 @@ build_variant () {
       $FC $fflags -cpp -I.. -I. -c "$REPO/cice_amd/fortran/ice_dyn_evp_hip.F90" -o ice_dyn_evp_hip.o
       $FC $fflags -cpp -I.. -I. -c "$REPO/cice_amd/fortran/ice_dyn_evp1d_hip.F90" -o ice_dyn_evp1d.o
       $FC $fflags -cpp -I.. -I. -c "$EVP" -o ice_dyn_evp.o
-      $FC $fflags -cpp -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp_hip.o ice_dyn_evp1d.o ice_dyn_evp.o \
+      $FC $fflags -cpp -DHARNESS_HIP_BODY -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp_hip.o ice_dyn_evp1d.o ice_dyn_evp.o \
           $(for o in $COMMON; do echo ../$o; done) \
           -L"$REPO/cice_amd" -lcice_evp_hip -Wl,-rpath,'$ORIGIN/../../cice_amd' -o "$OUT/evp_hip_dropin_harness"
       cd ..

@@ -39,6 +39,9 @@ program evp_ref_harness
   use ice_dyn_shared
   use ice_dyn_evp, only: init_evp, evp
   use ice_dyn_evp1d, only: capture_tag, dyn_evp1d_init, dyn_evp1d_finalize
+#ifdef HARNESS_HIP_BODY
+  use ice_dyn_evp_hip, only: dyn_evp_hip_evp_body
+#endif
   use evp_dumpio
   use icepack_intfc, only: icepack_query_parameters
 #if defined (_OPENMP)
@@ -73,11 +76,12 @@ program evp_ref_harness
   logical            :: dump_arrays = .true.      ! .false. = timing-only run (no array dumps)
   integer(int_kind)  :: ntiming     = 0           ! extra evp() calls, timed, after the dumps
   logical            :: hipmode     = .false.     ! drop-in check: HIP core (via ice_dyn_evp1d) vs standard_2d
+  logical            :: hipbody     = .false.     ! with hipmode: also Option A, preparation + loop on the device
 
   namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
      h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
      h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, &
-     dump_arrays, ntiming, hipmode
+     dump_arrays, ntiming, hipmode, hipbody
 
   ! ---- locals ----------------------------------------------------------
   integer(int_kind) :: i, j, iblk, icall, k, nsub, nl, ios, nthreads
@@ -342,6 +346,36 @@ program evp_ref_harness
            call dump_r8_3d(trim(tag)//'_divu', divu, nblocks)
            call dump_r8_3d(trim(tag)//'_shear', shear, nblocks)
            call dump_r8_3d(trim(tag)//'_strocnxU', strocnxU, nblocks)
+#ifdef HARNESS_HIP_BODY
+           if (hipbody) then
+              ! Option A: evp()'s preparation phase + loop (+ tripole stress symmetrisation) through
+              ! dyn_evp_hip_evp_body, ice strength by callback -- from the same state
+              uvel = s_u; vvel = s_v
+              stressp_1 = s_sp1; stressp_2 = s_sp2; stressp_3 = s_sp3; stressp_4 = s_sp4
+              stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
+              stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
+              call dyn_evp_hip_evp_body(dt_dyn, harness_strength)
+              write(tag,'(a,i2.2,a,i4.4)') 'b', icall, 'n', nsub
+              call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)
+              call dump_r8_3d(trim(tag)//'_vvel', vvel, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressp_1', stressp_1, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressp_2', stressp_2, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressp_3', stressp_3, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressp_4', stressp_4, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressm_1', stressm_1, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressm_2', stressm_2, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressm_3', stressm_3, nblocks)
+              call dump_r8_3d(trim(tag)//'_stressm_4', stressm_4, nblocks)
+              call dump_r8_3d(trim(tag)//'_stress12_1', stress12_1, nblocks)
+              call dump_r8_3d(trim(tag)//'_stress12_2', stress12_2, nblocks)
+              call dump_r8_3d(trim(tag)//'_stress12_3', stress12_3, nblocks)
+              call dump_r8_3d(trim(tag)//'_stress12_4', stress12_4, nblocks)
+              call dump_r8_3d(trim(tag)//'_strintxU', strintxU, nblocks)
+              call dump_r8_3d(trim(tag)//'_strintyU', strintyU, nblocks)
+              call dump_r8_3d(trim(tag)//'_taubxU', taubxU, nblocks)
+              call dump_r8_3d(trim(tag)//'_taubyU', taubyU, nblocks)
+           endif
+#endif
            uvel = s_u; vvel = s_v
            stressp_1 = s_sp1; stressp_2 = s_sp2; stressp_3 = s_sp3; stressp_4 = s_sp4
            stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
@@ -401,5 +435,28 @@ program evp_ref_harness
           ' calls', ntiming, ' wall_s_total_evp_calls', real(c1_clk-c0_clk,dbl_kind)/real(crate,dbl_kind)
      call ice_timer_print_all(stats=.false.)
   endif
+
+contains
+
+  ! what evp() does for the ice strength between its preparation phase and the loop
+  ! (ice_dyn_evp.F90:541-552, 727-728): callback of dyn_evp_hip_evp_body
+  subroutine harness_strength()
+    use icepack_intfc, only: icepack_ice_strength
+    integer :: ib, ii, jj
+    type(block) :: bb
+    do ib = 1, nblocks
+       bb = get_block(blocks_ice(ib), ib)
+       strength(:,:,ib) = c0
+       do jj = bb%jlo, bb%jhi+1
+       do ii = bb%ilo, bb%ihi+1
+          if (iceTmask(ii,jj,ib)) &
+             call icepack_ice_strength(aice=aice(ii,jj,ib), vice=vice(ii,jj,ib), aice0=aice0(ii,jj,ib), &
+                                       aicen=aicen(ii,jj,:,ib), vicen=vicen(ii,jj,:,ib), &
+                                       strength=strength(ii,jj,ib))
+       enddo
+       enddo
+    enddo
+    call ice_HaloUpdate(strength, halo_info, field_loc_center, field_type_scalar)
+  end subroutine harness_strength
 
 end program evp_ref_harness

@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parents[1]
 def declared_functions():
     txt = (ROOT / "include" / "cice_evp_hip.h").read_text()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(cice_evp_hip_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(?:int|void\s*\*)\s*(cice_evp_hip_\w+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -42,7 +42,8 @@ def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw
         run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
         grid_files = (tmp_path / "grid.bin", tmp_path / "kmt.bin")
     d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns="closed", variant="hip_dropin", h_ndte=120,
-                                 ncalls=2, nsub_list=[1, 120], hipmode=True, grid_files=grid_files, **kw)
+                                 ncalls=2, nsub_list=[1, 120], hipmode=True, hipbody=True,
+                                 grid_files=grid_files, **kw)
     checked = 0
     for icall in (1, 2):
         for nsub in (1, 120):
@@ -53,5 +54,15 @@ def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw
                     f"call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
                     f"max|d|={np.abs(hip - ref).max():.3e}")
                 checked += 1
+            # Option A: the B-grid body of evp() -- preparation phase + loop --
+            # through Fortran dyn_evp_hip_evp_body -> cice_evp_hip_prep / _set_strength / _subcycle
+            # / _download, the ice strength computed by a host callback in between
+            for f in FIELDS:
+                body = d[f"b{icall:02d}n{nsub:04d}_{f}"]
+                ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
+                assert np.array_equal(body, ref), (
+                    f"Option A body, call {icall} nsub {nsub} {f}: {int((body != ref).sum())} cells differ, "
+                    f"max|d|={np.abs(body - ref).max():.3e}")
+                checked += 1
     assert np.abs(d["o02n0120_uvel"]).max() > 1e-3
-    assert checked == 2 * 2 * (len(FIELDS) + len(DOWNSTREAM))
+    assert checked == 2 * 2 * (2 * len(FIELDS) + len(DOWNSTREAM))

@@ -563,3 +563,49 @@ def test_next_tier_prep_on_device_bitwise(name):
             assert_bitwise(res, c.expected(icall, c.ndte), f"{name} call {icall}: prep + loop on device")
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("grid,bs,ssh", [("gx3", (25, 29), 0), ("gx1", None, 0), ("gx1", (80, 96), 1)])
+def test_prep_on_device_full_size_vs_oracle(grid, bs, ssh):
+    """f-2 at configs[0]/[1] sizes: synthetic model state with open-water patches, cells that
+    gain and lose ice, both ssh_stress flavours -- device preparation vs the oracle's, bit for bit."""
+    spec = synth.GRIDS[grid]
+    nx, ny = spec["nx"], spec["ny"]
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+    pr = synth.make_primary(g, "caps" if ssh else "full", seed=4)
+    dc = decomp.Decomp(nx, ny, *(bs or (nx, ny)), "cyclic", "closed", 1)
+    sc = lambda a, fill=0.0: dc.scatter(np.ascontiguousarray(a), 0, fill=fill)
+    geo = {k: sc(g[k], 1.0 if k != "uarear" else 0.0) for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    static = {k: sc(v, (1.0 if k in ("tarea", "uarea") else 0)) for k, v in pr["static"].items()}
+    t = {k: sc(v) for k, v in pr["t"].items()}
+    state = {k: sc(v) for k, v in pr["state"].items()}
+    scal = synth.evp_scalars(120)
+    ppd = dict(dt=3600.0, rhoi=917.0, rhos=330.0, gravit=9.80616, dyn_area_min=1e-11, dyn_mass_min=1e-10)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), nx, ny, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    z = np.zeros(dc.shape(0))
+    want = oracle.prep(dom, oracle.PrepParams(**ppd, cosw=scal["cosw"], sinw=scal["sinw"], ssh_coupled=ssh), static, t,
+                       dict(state, strintxU=z, strintyU=z, strocnxU=z, strocnyU=z))
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        core.set_prep_geometry(static["tmask"], static["umask"], static["hm"], static["tarea"], static["uarea"],
+                               static["fcor_blk"])
+        tm, um, _ = core.prep(evp.PrepParams(**ppd, ssh_stress_coupled=ssh), t, state)
+        assert np.array_equal(tm, want["iceTmask"]) and np.array_equal(um, want["iceUmask"])
+        assert 0 < um.sum() < um.size and (state["iceUmask"] != um).any()      # cells gained and lost ice
+        got = {k: core.prep_fetch(k) for k in evp.PREP_FETCH}
+        on = um != 0
+        for k in evp.PREP_FETCH:
+            w = want[k]
+            if k in ("fmU", "strtltxU", "strtltyU"):          # defined on ice U-cells only
+                assert np.array_equal(got[k][on], w[on]), k
+            else:
+                assert np.array_equal(got[k], w), k
+        raw = core.download()
+        assert_bitwise({k: raw[k] for k in SIG}, {k: want[k] for k in SIG}, "stresses after dyn_prep2")
+    finally:
+        core.finalize()
