@@ -504,24 +504,18 @@ void fill_direct(EvpDirect &D)
     D.dbg = dbg;
 }
 
-// velocity halo of buffer `b` (ice_dyn_evp.F90:908-910)
-int halo_uv(int b)
+// Ghost cells whose source lives on another rank, for a pair of arrays laid out like uvel/vvel
+// (the velocities of the loop; pairs of T-grid fields in the preparation phase on grids without
+// a tripole fold, where cell-centre and corner fields mirror the same cells)
+int halo_remote_pair(double *a, double *bb)
 {
-    const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
-    if (!pushed)
-        evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src,
-                              (const signed char *)S.h_local_sign, S.n_local, S.stream);
-    // tripole seam of the top physical row (all on this rank, enforced by the plan); the remote
-    // exchange below never involves seam-row cells
-    evp_launch_halo_seam(S.u[b], S.v[b], S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
-                         S.h_late_dst, S.h_late_src, (const signed char *)S.h_late_sign, S.n_late, S.stream);
     if (!S.plan.peers.empty() && S.direct.on) {
         EvpDirect D;
         fill_direct(D);
-        evp_launch_halo_direct(D, S.u[b], S.v[b], S.stream);
+        evp_launch_halo_direct(D, a, bb, S.stream);
     } else if (!S.plan.peers.empty()) {
         if (!S.have_comm) return fail(-2, "remote halo needed but neither cice_evp_hip_comm_init nor cice_evp_hip_halo_import was called");
-        evp_launch_halo_pack(S.u[b], S.v[b], S.h_send_src, S.sendbuf, S.n_send, S.stream);
+        evp_launch_halo_pack(a, bb, S.h_send_src, S.sendbuf, S.n_send, S.stream);
         size_t so = 0, ro = 0;
         NCCLC(ncclGroupStart());
         for (const HaloPeer &p : S.plan.peers) {
@@ -533,9 +527,24 @@ int halo_uv(int b)
             ro += p.recv_dst.size();
         }
         NCCLC(ncclGroupEnd());
-        evp_launch_halo_unpack(S.u[b], S.v[b], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
+        evp_launch_halo_unpack(a, bb, S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
                                S.n_recv, S.stream);
     }
+    return 0;
+}
+
+// velocity halo of buffer `b` (ice_dyn_evp.F90:908-910)
+int halo_uv(int b)
+{
+    const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
+    if (!pushed)
+        evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src,
+                              (const signed char *)S.h_local_sign, S.n_local, S.stream);
+    // tripole seam of the top physical row (all on this rank, enforced by the plan); the remote
+    // exchange below never involves seam-row cells
+    evp_launch_halo_seam(S.u[b], S.v[b], S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
+                         S.h_late_dst, S.h_late_src, (const signed char *)S.h_late_sign, S.n_late, S.stream);
+    if (int rc = halo_remote_pair(S.u[b], S.v[b])) return rc;
     return 0;
 }
 
@@ -1669,9 +1678,9 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
     if (!S.ready) return fail(-1, "not initialised");
     if (!tmask || !umask || !hm || !tarea || !uarea || !fcor_blk) return fail(-1, "null argument");
     State::Prep &Q = S.prep;
-    if (S.plan.center_remote)
-        return fail(-9, "device preparation needs the T-grid halo on this rank only (one rank, or blocks whose "
-                        "neighbours are all local); keep evp()'s host preparation and use cice_evp_hip_run");
+    if (S.plan.center_remote && S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE)
+        return fail(-9, "device preparation: the T-grid halo across ranks is not implemented for tripole grids; "
+                        "keep evp()'s host preparation and use cice_evp_hip_run on this configuration");
     auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };
     if (B(Q.tmask) || B(Q.umask) || B(Q.umask_old) || B(Q.tmphm)) return -1;
     auto D = [&](double *&p) -> int { return p ? 0 : alloc_d(&p, S.n); };
@@ -1763,6 +1772,13 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     halo({{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false},
           {Q.t[5], true}, {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}});
     halo({{Q.t[9], true}, {Q.t[10], true}});                 // :466-469 (calc_strair branch)
+    if (S.plan.center_remote) {
+        // neighbours on other ranks (no tripole fold here: centre and corner fields mirror the same
+        // cells, so the velocity exchange carries pairs of T-grid fields)
+        double *pairs[5][2] = {{Q.maskd, Q.tmass}, {Q.t[3], Q.t[4]}, {Q.t[5], Q.t[6]}, {Q.t[7], Q.t[8]}, {Q.t[9], Q.t[10]}};
+        for (auto &pr : pairs)
+            if (int rc = halo_remote_pair(pr[0], pr[1])) return rc;
+    }
     evp_launch_prep_average(P, S.d.nblocks, S.stream);
     evp_launch_prep2(P, S.d.nblocks, S.stream);
     // ghost velocities before the loop (:729-732): the same exchange as inside the loop

@@ -171,7 +171,8 @@ int cice_evp_hip_dyn_finish(double *strocnxU, double *strocnyU);
  * fields32: the table of cice_evp_hip_upload; read here: the 12 stresses, uvel, vvel, TbU (NULL = 0).
  * iceUmask: in = mask of the previous call (new ice starts at the ocean velocity), out = new mask;
  * strintxU/strintyU/strocnxU/strocnyU (may be NULL): zeroed off the ice on the host arrays.
- * Ranks whose T-grid halo needs another rank are refused (keep the host preparation there).   */
+ * On a split domain the T-grid halos use the same transport as the velocities (collective call);
+ * a split TRIPOLE domain is refused (keep the host preparation there).                         */
 typedef struct cice_evp_hip_prep_params {
     double dt;                 /* dynamics time step (dyn_prep2's Xmass/dt)                    */
     double rhoi, rhos, gravit; /* icepack_query_parameters                                      */

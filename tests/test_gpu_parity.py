@@ -443,7 +443,7 @@ def test_resident_remote_gx3_vs_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("world,workload,shape,resident", [(2, "gx3", "", True), (4, "gx3", "2x2", True),
-                                                           (2, "gx1", "1x2", False)])
+                                                           (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep")])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
@@ -461,7 +461,11 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
     # co-resident and trade tagged records across process boundaries; gx1 halves do not fit
     # twice, so that case pins the streaming kernel + mailbox exchange
     env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
-    if resident:
+    if resident == "prep":
+        # from the primary model state: evp()'s preparation phase on every rank, its T-grid halos
+        # crossing the ranks through the same transport, then the loop (f-2 on a split domain)
+        cmd += ["--prep", "--expect-resident"]
+    elif resident:
         cmd += ["--expect-resident", "--timing"]    # --timing: 5 x 120 + 7 more subcycles, launches back to back
     else:
         env["CICE_EVP_HIP_RESIDENT"] = "0"

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--ndte", type=int, default=24)
     ap.add_argument("--timing", action="store_true")
     ap.add_argument("--shape", default="")          # e.g. 2x1
+    ap.add_argument("--prep", action="store_true",
+                    help="start from the primary model state: evp()'s preparation phase on the device on every "
+                         "rank (T-grid halos across ranks through the same transport), then the loop")
     ap.add_argument("--expect-resident", action="store_true",
                     help="fail unless the on-chip resident kernel with remote neighbours ran")
     a = ap.parse_args()
@@ -42,6 +45,7 @@ def main():
     nx, ny = spec["nx"], spec["ny"]
     g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
     st = synth.make_state(g, case="full", seed=7, warm=True)
+    pr = synth.make_primary(g, "full", seed=9) if a.prep else None
     scal = synth.evp_scalars(120)
 
     def run(dc, r, exchange):
@@ -58,7 +62,20 @@ def main():
                 blobs = [None] * world
                 dist.all_gather_object(blobs, core.halo_export())
                 core.halo_import(blobs)
-            core.upload(fields, tm, um)
+            if a.prep:
+                sc = lambda x, fill=0.0: dc.scatter(np.ascontiguousarray(x), r, fill=fill)
+                static = {k: sc(v, (1.0 if k in ("tarea", "uarea") else 0)) for k, v in pr["static"].items()}
+                core.set_prep_geometry(*[static[k] for k in ("tmask", "umask", "hm", "tarea", "uarea", "fcor_blk")])
+                pp = evp.PrepParams(dt=3600.0, rhoi=917.0, rhos=330.0, gravit=9.80616, dyn_area_min=1e-11,
+                                    dyn_mass_min=1e-10, ssh_stress_coupled=0)
+                tmk, umk, _ = core.prep(pp, {k: sc(v) for k, v in pr["t"].items()},
+                                        {k: sc(v) for k, v in pr["state"].items()})
+                core.set_strength(fields["strength"])
+                extra = {k: core.prep_fetch(k) for k in ("forcexU", "umassdti", "uvel_init", "aiU")}
+                extra["iceTmask"] = tmk.astype(np.float64)
+            else:
+                core.upload(fields, tm, um)
+                extra = {}
             core.subcycle(a.ndte)
             t = None
             if a.timing:      # the same launches in the reference run: back-to-back loops are compared too
@@ -72,6 +89,7 @@ def main():
                 t = (time.perf_counter() - t0) / 600 * 1e6
                 core.subcycle(7)          # an odd count: the record-buffer parity flips between launches
             out = core.download()
+            out.update(extra)
             return out, core.timings(), t
         finally:
             core.finalize()
@@ -82,7 +100,8 @@ def main():
     got, tim, t_us = run(dcN, rank, True)
     assert tim["halo_transport"] == "mailbox", tim
     bad = []
-    for k in ("uvel", "vvel", "stressp_1", "stressm_3", "stress12_4", "strintxU", "taubyU"):
+    for k in ("uvel", "vvel", "stressp_1", "stressm_3", "stress12_4", "strintxU", "taubyU",
+              "forcexU", "umassdti", "uvel_init", "aiU", "iceTmask"):
         if k not in got:
             continue
         want = dcN.scatter(ref[k][0][1:-1, 1:-1], rank)
