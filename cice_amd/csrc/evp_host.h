@@ -1,0 +1,229 @@
+// =====================================================================
+// Host side of the MI355X-native EVP core, shared declarations: the device
+// state behind the C ABI (include/cice_evp_hip.h) and the helpers its
+// translation units call on each other.
+//   evp_api.cpp            C ABI: init / upload / subcycle / download / run / introspection
+//   evp_host_common.cpp    state, copies, static metric terms, lists, kernel arguments
+//   evp_host_loop.cpp      velocity halo, tile split, the subcycle loop as enqueued work
+//   evp_host_resident.cpp  on-chip resident kernels: set-up, launch, checks, autotuning
+//   evp_host_mailbox.cpp   mailbox halo over HIP IPC, RCCL bootstrap, probes
+//   evp_host_prep.cpp      preparation phase of evp() (f-2)
+//
+// HBM layout: structure-of-arrays; every field is one contiguous fp64 array
+// (nx_block, ny_block, nblocks), i fastest -- the memory image of the CICE
+// module arrays, so H2D/D2H are straight copies of blocks 1..nblocks.
+// State that the subcycle rewrites (uvel, vvel, 12 stresses) exists twice
+// (ping-pong, see evp_kernels.hip); everything else once.
+// =====================================================================
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cice_evp_hip.h"
+#include "evp_device.h"
+#include "halo_plan.h"
+
+namespace evp_host {
+
+extern std::string g_err;
+int fail(int code, const char *fmt, ...);
+
+#define HIPC(call)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((int)e_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                              \
+    } while (0)
+
+#define NCCLC(call)                                                                              \
+    do {                                                                                         \
+        ncclResult_t r_ = (call);                                                                \
+        if (r_ != ncclSuccess)                                                                   \
+            return fail(1000 + (int)r_, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// order of the 32-entry field table == argument order of cice_evp_hip_run
+enum Field {
+    F_SIG0 = 0,   // 0..11 stressp_1..4, stressm_1..4, stress12_1..4
+    F_STRENGTH = 12, F_CW, F_AIX, F_UOCN, F_VOCN, F_WATERX, F_WATERY, F_FORCEX, F_FORCEY,
+    F_UMASSDTI, F_FM, F_STRINTX, F_STRINTY, F_TBU, F_TAUBX, F_TAUBY, F_UVEL, F_VVEL,
+    F_UVEL_INIT, F_VVEL_INIT, F_COUNT
+};
+
+struct State {
+    bool ready = false;
+    bool uploaded = false;
+    cice_evp_hip_dims d{};
+    cice_evp_hip_params prm{};
+    std::vector<int32_t> ilo, ihi, jlo, jhi, iglob0, jglob0;
+    int device = 0;
+    size_t plane = 0, n = 0;     // nx*ny, nx*ny*nblocks
+    int max_ni = 0, max_nj = 0;
+    int tyb = 4;
+    bool tyb_forced = false, tuned = false;
+    hipStream_t stream = nullptr, stream_comm = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+    bool overlap = true;
+    // tiles that produce cells other ranks need (run first) / all other tiles, per tile variant
+    struct TileSplit { int *d_boundary = nullptr, *d_interior = nullptr, *d_all = nullptr; int nb = 0, ni = 0; };
+    std::map<int, TileSplit> splits;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evm[2] = {nullptr, nullptr};
+    bool marked[2] = {false, false};
+
+    // device arrays
+    double *stat[10] = {};      // dxT dyT dxhy dyhx cxp cyp cxm cym DminTarea uarear
+    double *in[F_COUNT] = {};   // per-call inputs + diagnostics (entries of ping-ponged fields unused)
+    double *u[2] = {}, *v[2] = {};
+    double *sig[2][12] = {};
+    double *hte = nullptr, *htn = nullptr;   // edge lengths for in-kernel metric terms
+    double *vrelfac = nullptr;               // (aiX*rhow)*Cw, rebuilt at every upload
+    double *post_geo[3] = {};                // dxU dyU tarear (next tier f-1)
+    double *post_out[7] = {};                // divu shear vort rdg_conv rdg_shear strocnx strocny
+    bool have_post_geo = false;
+    uint8_t *mask = nullptr;
+    int4 *blk = nullptr;
+    int cur = 0;
+    unsigned flags = 0;          // EVP_F_* in effect
+    unsigned flags_allowed = ~0u;
+    int *push = nullptr;         // halo push table (device)
+    int push_ni = 0, push_nj = 0;
+    bool push_ok = false;
+
+    HaloPlan plan;
+    int32_t *h_local_dst = nullptr, *h_local_src = nullptr;
+    int8_t *h_local_sign = nullptr;
+    int n_local = 0;
+    // remote halo
+    ncclComm_t comm = nullptr;
+    bool have_comm = false;
+    int32_t *h_seam_a = nullptr, *h_seam_b = nullptr, *h_seam_pole = nullptr, *h_late_dst = nullptr,
+            *h_late_src = nullptr;
+    int8_t *h_late_sign = nullptr;
+    int n_seam = 0, n_pole = 0, n_late = 0;
+    int32_t *h_stress_dst = nullptr, *h_stress_src = nullptr;
+    int n_stress = 0;
+    // preparation phase on the device (evp_prep.hip)
+    struct Prep {
+        bool geo = false;
+        uint8_t *tmask = nullptr, *umask = nullptr, *umask_old = nullptr, *tmphm = nullptr;
+        double *hm = nullptr, *tarea = nullptr, *uarea = nullptr, *fcor = nullptr;
+        double *t[11] = {};
+        double *tmass = nullptr, *umass = nullptr, *maskd = nullptr;
+        double *ss_tltxU = nullptr, *ss_tltyU = nullptr, *strairxU = nullptr, *strairyU = nullptr,
+               *strtltx = nullptr, *strtlty = nullptr;
+        unsigned *flagword = nullptr;
+        int32_t *c_dst = nullptr, *c_src = nullptr;
+        int8_t *c_vsign = nullptr;
+        int n_center = 0;
+        std::vector<uint8_t> h8;
+        double t_ms = 0;
+    } prep;
+    int32_t *h_send_src = nullptr, *h_recv_dst = nullptr;
+    int8_t *h_recv_sign = nullptr;
+    double *sendbuf = nullptr, *recvbuf = nullptr;
+    int n_send = 0, n_recv = 0;
+
+    // mailbox halo (evp_halo_direct.hip): peers' inboxes mapped through HIP IPC
+    struct Direct {
+        bool on = false;             // use it for the remote halo
+        bool exported = false;
+        void *mailbox = nullptr;     // [flags][seq][err][inbox x 2 parities]
+        size_t bytes = 0, inbox_off = 0, rec_off = 0;
+        std::vector<void *> opened;  // hipIpcOpenMemHandle results
+        EvpDirect *d_dx = nullptr;   // device copy of the argument block (exchange riding in the subcycle launch)
+        unsigned *d_cnt = nullptr;   // [0] boundary tiles checked in, [16] launches with a riding exchange
+        double **send_addr = nullptr;
+        unsigned *send_pstride = nullptr;
+        unsigned **peer_flag = nullptr;
+        std::string why;             // why it is off
+    } direct;
+
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, cur) -> captured loop
+    bool use_graph = true;
+
+    // on-chip resident subcycle (evp_resident.hip)
+    int res_mode = -1;           // -1 undecided, 0 off, 1 on
+    bool res_forced = false;
+    int *res_flags = nullptr, *res_nbr = nullptr, *res_err = nullptr;
+    double **res_tab = nullptr;  // device pointer table (EvpResident::tab)
+    double *res_scratch[4] = {}; // u,v ping-pong copies for the dry probe
+    int res_ntiles = 0, res_logw = 6;
+    int res_gen = 1;             // 1: flags (evp_resident.hip), 2: tagged records (evp_resident2.hip)
+    int4 *res2_ring = nullptr;
+    int *res2_cnt = nullptr;
+    uint8_t *res2_pub = nullptr;
+    void *res2_rec[2] = {nullptr, nullptr};
+    int res2_logw = 0, res2_ntiles = 0;
+    unsigned res2_epoch = 0;
+    int res2_par = 0;            // record buffer in which the next launch starts (EvpResident2::par0)
+    bool res2_rec_owned = true;  // false: the record buffers live inside the mailbox allocation
+    // resident kernel with neighbours on other GPUs (records stored into peers' buffers over xGMI)
+    bool res_remote = false;     // agreed by all ranks at mailbox import
+    double res_timeout_ms = 0;   // > 0: overrides the wait bound of the next resident launches (probe)
+    int2 *res2_rimg = nullptr;
+    void **res2_peer_rec = nullptr;
+    size_t *res2_peer_rstride = nullptr;
+    bool res_launched = false;   // an un-checked launch is in flight
+    double t_res_probe_ms = 0, t_stream_probe_ms = 0;
+
+    double t_loop_ms = 0, t_h2d_ms = 0, t_d2h_ms = 0;
+    int t_nsub = 0;
+    std::vector<uint8_t> hmask;
+    std::map<const void *, size_t> pinned;   // host ranges registered by cice_evp_hip_pin_host
+};
+
+extern State S;
+
+inline const char *env(const char *k) { return std::getenv(k); }
+
+// mailbox layout: EVP_DIRECT_MAXPEER flag lines, then seq, err, then the inbox
+constexpr size_t DIRECT_SEQ_OFF = (size_t)EVP_DIRECT_MAXPEER * EVP_DIRECT_FLAG_STRIDE * sizeof(unsigned);
+constexpr size_t DIRECT_ERR_OFF = DIRECT_SEQ_OFF + 64;
+constexpr size_t DIRECT_INBOX_OFF = DIRECT_ERR_OFF + 64;
+
+// evp_host_common.cpp
+int alloc_d(double **p, size_t n);
+void free_all();
+int h2d(double *dst, const double *src);
+int d2h(double *dst, const double *src);
+int derive_metrics(const double *HTE, const double *HTN, const double *dxT, const double *dyT,
+                   const double *uarear, const double *tarea);
+int upload_lists();
+int build_push_table();
+void fill_args(EvpArgs &A, int cur, int last);
+int cap_mode();
+// evp_host_loop.cpp
+void fill_direct(EvpDirect &D);
+int halo_remote_pair(double *a, double *bb);
+int halo_uv(int b);
+bool use_overlap();
+bool use_riding_exchange();
+int get_tile_split(int variant, State::TileSplit **out);
+int enqueue_loop(int ndte, int cur0);
+// evp_host_resident.cpp
+bool resident_possible(bool with_peers = false);
+int resident_setup(int logw);
+int resident2_setup(int logw);
+bool resident_fits();
+bool resident2_fits(bool remote = false);
+int resident_tables();
+int launch_resident(int ndte, int cur0, bool dry);
+int launch_resident2(int ndte, int cur0, bool dry);
+int resident_check_error();
+int tune_after_upload();
+// evp_host_mailbox.cpp
+int direct_check_error();
+
+}  // namespace evp_host

@@ -1,0 +1,308 @@
+// Host side, common part: error text, the device state, copies, static metric terms
+// (init_dyn_shared), index lists, ghost-image push table, kernel argument block.
+#include "evp_host.h"
+
+// host arithmetic of derive_metrics must round every operation (no FMA)
+#pragma clang fp contract(off)
+
+namespace evp_host {
+
+std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code ? code : -1;
+}
+
+State S;
+
+int alloc_d(double **p, size_t n)
+{
+    HIPC(hipMalloc((void **)p, n * sizeof(double)));
+    HIPC(hipMemsetAsync(*p, 0, n * sizeof(double), S.stream));
+    return 0;
+}
+
+void free_all()
+{
+    auto F = [](auto *&p) {
+        if (p) (void)hipFree((void *)p);
+        p = nullptr;
+    };
+    for (auto &p : S.stat) F(p);
+    for (auto &p : S.in) F(p);
+    for (int k = 0; k < 2; ++k) {
+        F(S.u[k]);
+        F(S.v[k]);
+        for (auto &p : S.sig[k]) F(p);
+    }
+    F(S.hte);
+    F(S.htn);
+    F(S.vrelfac);
+    F(S.res_flags); F(S.res_nbr); F(S.res_err); F(S.res_tab);
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub);
+    if (S.res2_rec_owned) { F(S.res2_rec[0]); F(S.res2_rec[1]); }
+    S.res2_rec[0] = S.res2_rec[1] = nullptr;
+    S.res2_rec_owned = true;
+    S.res_remote = false;
+    S.res2_par = 0; S.res2_epoch = 0;
+    F(S.res2_rimg); F(S.res2_peer_rec); F(S.res2_peer_rstride);
+    for (auto &p : S.res_scratch) F(p);
+    for (auto &p : S.post_geo) F(p);
+    for (auto &p : S.post_out) F(p);
+    F(S.push);
+    F(S.mask);
+    F(S.blk);
+    F(S.h_local_dst);
+    F(S.h_local_src);
+    F(S.h_local_sign);
+    F(S.h_seam_a); F(S.h_seam_b); F(S.h_seam_pole); F(S.h_late_dst); F(S.h_late_src); F(S.h_late_sign);
+    F(S.h_stress_dst); F(S.h_stress_src);
+    {
+        State::Prep &Q = S.prep;
+        F(Q.tmask); F(Q.umask); F(Q.umask_old); F(Q.tmphm); F(Q.hm); F(Q.tarea); F(Q.uarea); F(Q.fcor);
+        for (auto &q : Q.t) F(q);
+        F(Q.tmass); F(Q.umass); F(Q.maskd); F(Q.ss_tltxU); F(Q.ss_tltyU); F(Q.strairxU); F(Q.strairyU);
+        F(Q.strtltx); F(Q.strtlty); F(Q.flagword); F(Q.c_dst); F(Q.c_src); F(Q.c_vsign);
+        S.prep = State::Prep();
+    }
+    F(S.h_send_src);
+    F(S.h_recv_dst);
+    F(S.h_recv_sign);
+    F(S.sendbuf);
+    F(S.recvbuf);
+    for (void *q : S.direct.opened) (void)hipIpcCloseMemHandle(q);
+    F(S.direct.mailbox); F(S.direct.d_dx); F(S.direct.d_cnt); F(S.direct.send_addr); F(S.direct.send_pstride); F(S.direct.peer_flag);
+    S.direct = State::Direct();
+    for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);
+    S.graphs.clear();
+    if (S.ev0) (void)hipEventDestroy(S.ev0);
+    if (S.ev1) (void)hipEventDestroy(S.ev1);
+    if (S.ev2) (void)hipEventDestroy(S.ev2);
+    if (S.ev3) (void)hipEventDestroy(S.ev3);
+    for (auto &e : S.evm) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    S.ev0 = S.ev1 = S.ev2 = S.ev3 = nullptr;
+    if (S.have_comm) (void)ncclCommDestroy(S.comm);
+    S.have_comm = false;
+    for (auto &kv : S.pinned) (void)hipHostUnregister(const_cast<void *>(kv.first));
+    S.pinned.clear();
+    for (auto &kv : S.splits) {
+        if (kv.second.d_boundary) (void)hipFree(kv.second.d_boundary);
+        if (kv.second.d_interior) (void)hipFree(kv.second.d_interior);
+        if (kv.second.d_all) (void)hipFree(kv.second.d_all);
+    }
+    S.splits.clear();
+    if (S.ev_pack) (void)hipEventDestroy(S.ev_pack);
+    if (S.ev_halo) (void)hipEventDestroy(S.ev_halo);
+    S.ev_pack = S.ev_halo = nullptr;
+    if (S.stream_comm) (void)hipStreamDestroy(S.stream_comm);
+    S.stream_comm = nullptr;
+    if (S.stream) (void)hipStreamDestroy(S.stream);
+    S.stream = nullptr;
+}
+
+// Copies blocks 1..nblocks of a host (nx,ny,max_blocks) array: contiguous prefix.
+int h2d(double *dst, const double *src)
+{
+    HIPC(hipMemcpyAsync(dst, src, S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    return 0;
+}
+int d2h(double *dst, const double *src)
+{
+    HIPC(hipMemcpyAsync(dst, src, S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    return 0;
+}
+
+// Static metric terms, host arithmetic in the reference's operation order
+// (init_dyn_shared, ice_dyn_shared.F90:384-388, 401-441).  dxhy/dyhx are
+// evaluated directly on the N/E ghost T-cells from the HTE/HTN ghost values
+// (which CICE defines from the global arrays, ice_grid.F90:662-666) instead of
+// through a halo update: same operands, same result for every cell that can
+// hold ice.
+int derive_metrics(const double *HTE, const double *HTN, const double *dxT, const double *dyT,
+                   const double *uarear, const double *tarea)
+{
+    const int nx = S.d.nx_block;
+    const size_t plane = S.plane;
+    std::vector<std::vector<double>> m(7, std::vector<double>(S.n, 0.0));   // cxp cyp cxm cym dxhy dyhx Dmin
+    const double p5 = 0.5, c1p5 = 1.5;
+    for (int b = 0; b < S.d.nblocks; ++b) {
+        const double *hte = HTE + b * plane, *htn = HTN + b * plane;
+        for (size_t k = 0; k < plane; ++k) m[6][b * plane + k] = S.prm.deltaminEVP * tarea[b * plane + k];
+        for (int j = S.jlo[b]; j <= S.jhi[b] + 1; ++j)
+            for (int i = S.ilo[b]; i <= S.ihi[b] + 1; ++i) {
+                const size_t c = (size_t)(j - 1) * nx + (i - 1);
+                const size_t g = b * plane + c;
+                m[0][g] = (c1p5 * htn[c] - p5 * htn[c - nx]);        // cxp
+                m[1][g] = (c1p5 * hte[c] - p5 * hte[c - 1]);         // cyp
+                m[2][g] = -(c1p5 * htn[c - nx] - p5 * htn[c]);       // cxm
+                m[3][g] = -(c1p5 * hte[c - 1] - p5 * hte[c]);        // cym
+                m[4][g] = p5 * (hte[c] - hte[c - 1]);                // dxhy
+                m[5][g] = p5 * (htn[c] - htn[c - nx]);               // dyhx
+            }
+    }
+    if (h2d(S.stat[0], dxT) || h2d(S.stat[1], dyT) || h2d(S.stat[9], uarear)) return -1;
+    if (h2d(S.hte, HTE) || h2d(S.htn, HTN)) return -1;
+    // in-kernel metric terms need tarea == dxT*dyT bit for bit (ice_grid.F90:681)
+    bool same = true;
+    for (size_t k = 0; k < S.n && same; ++k) same = (tarea[k] == dxT[k] * dyT[k]);
+    if (same) S.flags |= EVP_F_METRICS;
+    // on the tripole ghost row dxhy/dyhx are mirrored interior values (halo update with sign,
+    // ice_dyn_shared.F90:412-417), not a local difference: keep them as arrays there
+    if (S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE) S.flags |= EVP_F_DXHY_ARRAY;
+    const int order[7] = {4, 5, 6, 7, 2, 3, 8};   // stat slots of cxp cyp cxm cym dxhy dyhx Dmin
+    for (int k = 0; k < 7; ++k)
+        if (h2d(S.stat[order[k]], m[k].data())) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+int upload_lists()
+{
+    const HaloPlan &P = S.plan;
+    S.n_local = (int)P.local_dst.size();
+    if (S.n_local) {
+        HIPC(hipMalloc((void **)&S.h_local_dst, S.n_local * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&S.h_local_src, S.n_local * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&S.h_local_sign, S.n_local));
+        HIPC(hipMemcpy(S.h_local_dst, P.local_dst.data(), S.n_local * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(S.h_local_src, P.local_src.data(), S.n_local * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(S.h_local_sign, P.local_sign.data(), S.n_local, hipMemcpyHostToDevice));
+    }
+    auto up32 = [&](const std::vector<int32_t> &v, int32_t *&dptr) -> int {
+        if (v.empty()) return 0;
+        HIPC(hipMalloc((void **)&dptr, v.size() * sizeof(int32_t)));
+        HIPC(hipMemcpy(dptr, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        return 0;
+    };
+    S.n_seam = (int)P.seam_a.size();
+    S.n_pole = (int)P.seam_pole.size();
+    S.n_late = (int)P.late_dst.size();
+    if (up32(P.seam_a, S.h_seam_a) || up32(P.seam_b, S.h_seam_b) || up32(P.seam_pole, S.h_seam_pole) ||
+        up32(P.late_dst, S.h_late_dst) || up32(P.late_src, S.h_late_src)) return -1;
+    S.n_stress = (int)P.stress_dst.size();
+    if (up32(P.stress_dst, S.h_stress_dst) || up32(P.stress_src, S.h_stress_src)) return -1;
+    if (S.n_late) {
+        HIPC(hipMalloc((void **)&S.h_late_sign, S.n_late));
+        HIPC(hipMemcpy(S.h_late_sign, P.late_sign.data(), S.n_late, hipMemcpyHostToDevice));
+    }
+    std::vector<int32_t> ss, rd;
+    std::vector<int8_t> rs;
+    for (const HaloPeer &p : P.peers) {
+        ss.insert(ss.end(), p.send_src.begin(), p.send_src.end());
+        rd.insert(rd.end(), p.recv_dst.begin(), p.recv_dst.end());
+        rs.insert(rs.end(), p.recv_sign.begin(), p.recv_sign.end());
+    }
+    S.n_send = (int)ss.size();
+    S.n_recv = (int)rd.size();
+    if (S.n_send) {
+        HIPC(hipMalloc((void **)&S.h_send_src, ss.size() * sizeof(int32_t)));
+        HIPC(hipMemcpy(S.h_send_src, ss.data(), ss.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMalloc((void **)&S.sendbuf, 2 * ss.size() * sizeof(double)));
+    }
+    if (S.n_recv) {
+        HIPC(hipMalloc((void **)&S.h_recv_dst, rd.size() * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&S.h_recv_sign, rs.size()));
+        HIPC(hipMemcpy(S.h_recv_dst, rd.data(), rd.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(S.h_recv_sign, rs.data(), rs.size(), hipMemcpyHostToDevice));
+        HIPC(hipMalloc((void **)&S.recvbuf, 2 * rd.size() * sizeof(double)));
+    }
+    return 0;
+}
+
+// Inverse of the local part of the halo plan: for every interior edge cell the
+// ghost cells that mirror it, so that the thread producing the cell can store the
+// images itself.  Per block 2*(nj+ni) edge slots (W, E, S, N) x 2 entries; an entry is
+// dst*2 + (sign<0), or -1.  Falls back to the gather kernel if an image does not fit.
+int build_push_table()
+{
+    const HaloPlan &P = S.plan;
+    S.push_ok = false;
+    S.push_ni = S.max_ni;
+    S.push_nj = S.max_nj;
+    const int nslot = 2 * (S.push_nj + S.push_ni);
+    std::vector<int> tab((size_t)S.d.nblocks * nslot * 2, -1);
+    const int nx = S.d.nx_block;
+    bool ok = true;
+    for (size_t k = 0; k < P.local_dst.size() && ok; ++k) {
+        const int src = P.local_src[k];
+        if (src < 0) { ok = false; break; }
+        const int b = (int)(src / S.plane);
+        const int rem = (int)(src % S.plane);
+        const int j = rem / nx + 1, i = rem % nx + 1;
+        int cand[4];
+        cand[0] = (i == S.ilo[b]) ? (j - S.jlo[b]) : -1;
+        cand[1] = (i == S.ihi[b]) ? S.push_nj + (j - S.jlo[b]) : -1;
+        cand[2] = (j == S.jlo[b]) ? 2 * S.push_nj + (i - S.ilo[b]) : -1;
+        cand[3] = (j == S.jhi[b]) ? 2 * S.push_nj + S.push_ni + (i - S.ilo[b]) : -1;
+        const int enc = P.local_dst[k] * 2 + (P.local_sign[k] < 0 ? 1 : 0);
+        bool placed = false;
+        for (int e = 0; e < 4 && !placed; ++e) {
+            if (cand[e] < 0) continue;
+            for (int w = 0; w < 2 && !placed; ++w) {
+                int &slot = tab[((size_t)b * nslot + cand[e]) * 2 + w];
+                if (slot < 0) { slot = enc; placed = true; }
+            }
+        }
+        if (!placed) ok = false;
+    }
+    if (!ok || P.local_dst.empty()) return 0;
+    HIPC(hipMalloc((void **)&S.push, tab.size() * sizeof(int)));
+    HIPC(hipMemcpy(S.push, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    S.push_ok = true;
+    return 0;
+}
+
+void fill_args(EvpArgs &A, int cur, int last)
+{
+    const cice_evp_hip_params &q = S.prm;
+    A.p = {q.arlx1i, q.denom1, q.brlx, q.revp, q.e_factor, q.epp2i, q.capping, q.Ktens,
+           q.u0, q.cosw, q.sinw, q.rhow};
+    A.nx = S.d.nx_block;
+    A.ny = S.d.ny_block;
+    A.plane = S.plane;
+    A.last = last;
+    A.tile_list = nullptr;
+    A.tile_count = 0;
+    A.dx = nullptr; A.dx_count = nullptr; A.dx_fseq = nullptr; A.dx_nb = 0;
+    A.blk = S.blk;
+    A.mask = S.mask;
+    A.u_in = S.u[cur];
+    A.v_in = S.v[cur];
+    A.u_out = S.u[cur ^ 1];
+    A.v_out = S.v[cur ^ 1];
+    for (int k = 0; k < 12; ++k) {
+        A.sig_in[k] = S.sig[cur][k];
+        A.sig_out[k] = S.sig[cur ^ 1][k];
+    }
+    A.dxT = S.stat[0]; A.dyT = S.stat[1]; A.dxhy = S.stat[2]; A.dyhx = S.stat[3];
+    A.cxp = S.stat[4]; A.cyp = S.stat[5]; A.cxm = S.stat[6]; A.cym = S.stat[7];
+    A.DminTarea = S.stat[8]; A.uarear = S.stat[9];
+    A.HTE = S.hte; A.HTN = S.htn; A.deltaminEVP = q.deltaminEVP;
+    A.vrelfac = S.vrelfac;
+    A.flags = S.flags & S.flags_allowed;
+    if (!S.push_ok) A.flags &= ~EVP_F_PUSH;
+    A.push = S.push; A.push_ni = S.push_ni; A.push_nj = S.push_nj;
+    A.strength = S.in[F_STRENGTH]; A.Cw = S.in[F_CW]; A.aiX = S.in[F_AIX];
+    A.uocn = S.in[F_UOCN]; A.vocn = S.in[F_VOCN]; A.waterx = S.in[F_WATERX];
+    A.watery = S.in[F_WATERY]; A.forcex = S.in[F_FORCEX]; A.forcey = S.in[F_FORCEY];
+    A.umassdti = S.in[F_UMASSDTI]; A.fm = S.in[F_FM]; A.TbU = S.in[F_TBU];
+    A.uvel_init = S.in[F_UVEL_INIT]; A.vvel_init = S.in[F_VVEL_INIT];
+    A.strintx = S.in[F_STRINTX]; A.strinty = S.in[F_STRINTY];
+    A.taubx = S.in[F_TAUBX]; A.tauby = S.in[F_TAUBY];
+}
+
+int cap_mode()
+{
+    if (S.prm.capping == 1.0) return 1;
+    if (S.prm.capping == 0.0) return 0;
+    return -1;
+}
+
+}  // namespace evp_host

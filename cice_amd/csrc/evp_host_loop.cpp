@@ -1,0 +1,243 @@
+// Host side: the velocity halo (local images, tripole seam, remote transports) and the
+// subcycle loop as enqueued work (serial, boundary-first + second stream, riding exchange).
+#include "evp_host.h"
+
+namespace evp_host {
+
+void fill_direct(EvpDirect &D)
+{
+    State::Direct &X = S.direct;
+    char *base = (char *)X.mailbox;
+    D.n_send = S.n_send;
+    D.n_recv = S.n_recv;
+    D.npeers = (int)S.plan.peers.size();
+    D.send_src = S.h_send_src;
+    D.send_addr = X.send_addr;
+    D.send_pstride = X.send_pstride;
+    D.recv_dst = S.h_recv_dst;
+    D.recv_sign = (const signed char *)S.h_recv_sign;
+    D.flags_in = (unsigned *)base;
+    D.seq = (unsigned *)(base + DIRECT_SEQ_OFF);
+    D.err = (int *)(base + DIRECT_ERR_OFF);
+    D.inbox = (double *)(base + X.inbox_off);
+    static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
+    D.timeout_ticks = (unsigned long long)(tmo_ms * 1.0e5);     // 100 MHz wall clock
+    D.peer_flag = X.peer_flag;
+    static const int dbg = env("CICE_EVP_HIP_HALO_DEBUG") ? std::atoi(env("CICE_EVP_HIP_HALO_DEBUG")) : 0;
+    D.dbg = dbg;
+}
+
+// Ghost cells whose source lives on another rank, for a pair of arrays laid out like uvel/vvel
+// (the velocities of the loop; pairs of T-grid fields in the preparation phase on grids without
+// a tripole fold, where cell-centre and corner fields mirror the same cells)
+int halo_remote_pair(double *a, double *bb)
+{
+    if (!S.plan.peers.empty() && S.direct.on) {
+        EvpDirect D;
+        fill_direct(D);
+        evp_launch_halo_direct(D, a, bb, S.stream);
+    } else if (!S.plan.peers.empty()) {
+        if (!S.have_comm) return fail(-2, "remote halo needed but neither cice_evp_hip_comm_init nor cice_evp_hip_halo_import was called");
+        evp_launch_halo_pack(a, bb, S.h_send_src, S.sendbuf, S.n_send, S.stream);
+        size_t so = 0, ro = 0;
+        NCCLC(ncclGroupStart());
+        for (const HaloPeer &p : S.plan.peers) {
+            if (!p.send_src.empty())
+                NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream));
+            if (!p.recv_dst.empty())
+                NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream));
+            so += p.send_src.size();
+            ro += p.recv_dst.size();
+        }
+        NCCLC(ncclGroupEnd());
+        evp_launch_halo_unpack(a, bb, S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
+                               S.n_recv, S.stream);
+    }
+    return 0;
+}
+
+// velocity halo of buffer `b` (ice_dyn_evp.F90:908-910)
+int halo_uv(int b)
+{
+    const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
+    if (!pushed)
+        evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src,
+                              (const signed char *)S.h_local_sign, S.n_local, S.stream);
+    // tripole seam of the top physical row (all on this rank, enforced by the plan); the remote
+    // exchange below never involves seam-row cells
+    evp_launch_halo_seam(S.u[b], S.v[b], S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
+                         S.h_late_dst, S.h_late_src, (const signed char *)S.h_late_sign, S.n_late, S.stream);
+    if (int rc = halo_remote_pair(S.u[b], S.v[b])) return rc;
+    return 0;
+}
+
+// Boundary-first + second stream pays when the interior kernel is long enough to hide the
+// exchange; on small per-rank domains the extra host calls (events, two launches) cost more
+// than they hide (measured: 50 vs 26 us per subcycle on gx1, eager).  CICE_EVP_HIP_OVERLAP=1/0 forces.
+bool use_overlap()
+{
+    const bool seam = (S.n_seam + S.n_pole + S.n_late) > 0;
+    if (!S.overlap || S.plan.peers.empty() || seam || !(S.have_comm || S.direct.on)) return false;
+    if (env("CICE_EVP_HIP_OVERLAP")) return std::atoi(env("CICE_EVP_HIP_OVERLAP")) != 0;
+    size_t cells = 0;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);
+    return cells >= 400000;
+}
+
+// The mailbox exchange can ride in the subcycle launch (no tripole seam step in between).
+bool use_riding_exchange()
+{
+    if (!S.direct.on || S.plan.peers.empty() || (S.n_seam + S.n_pole + S.n_late) > 0) return false;
+    // Pays when the interior tiles outlast the exchange (measured, 4 x 1800x1200 blocks: 571 us
+    // riding, 598 two streams, 627 separate kernel); on a domain that is one wave of workgroups
+    // there is nothing to overlap with and the separate kernel is quicker (gx1: 20.8 vs 25 us).
+    if (env("CICE_EVP_HIP_HALO_RIDE")) return std::atoi(env("CICE_EVP_HIP_HALO_RIDE")) != 0;
+    size_t cells = 0;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);
+    return cells >= 400000;
+}
+
+// Which tiles of `variant` hold U-cells that some other rank mirrors (send list)?
+int get_tile_split(int variant, State::TileSplit **out)
+{
+    auto it = S.splits.find(variant);
+    if (it != S.splits.end()) { *out = &it->second; return 0; }
+    int tyb, gx, gy;
+    evp_tile_geometry(S.max_ni, S.max_nj, variant, &tyb, &gx, &gy);
+    const int ntiles = gx * gy * S.d.nblocks;
+    std::vector<char> is_b((size_t)ntiles, 0);
+    const int nx = S.d.nx_block;
+    for (const HaloPeer &p : S.plan.peers)
+        for (int32_t src : p.send_src) {
+            const int b = (int)(src / S.plane);
+            const int rem = (int)(src % S.plane);
+            const int j = rem / nx + 1, i = rem % nx + 1;
+            const int bx = (i - S.ilo[b]) / 63, by = (j - S.jlo[b]) / (tyb - 1);
+            if (bx < 0 || bx >= gx || by < 0 || by >= gy) continue;
+            is_b[((size_t)b * gy + by) * gx + bx] = 1;       // row-major tile id (xcdmap 0/2 decoding)
+        }
+    std::vector<int> lb, li;
+    for (int t = 0; t < ntiles; ++t) (is_b[t] ? lb : li).push_back(t);
+    State::TileSplit ts;
+    ts.nb = (int)lb.size();
+    ts.ni = (int)li.size();
+    if (ts.nb) {
+        HIPC(hipMalloc((void **)&ts.d_boundary, lb.size() * sizeof(int)));
+        HIPC(hipMemcpy(ts.d_boundary, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (ts.ni) {
+        HIPC(hipMalloc((void **)&ts.d_interior, li.size() * sizeof(int)));
+        HIPC(hipMemcpy(ts.d_interior, li.data(), li.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    {   // boundary tiles first, then the rest: order of the launch that carries the exchange workgroup
+        // interior tiles in XCD-chunked order: workgroup w runs on XCD w % 8, so give each XCD one
+        // contiguous run of the (row-major) interior sequence -- neighbouring tiles share an L2
+        std::vector<int> all(lb);
+        const size_t n = li.size(), per = (n + 7) / 8, w0 = lb.size() + 1;    // +1: the exchange workgroup
+        std::vector<int> chunked;
+        for (size_t w = 0; chunked.size() < n; ++w) {
+            const size_t x = (w0 + w) & 7, q = x * per + (w >> 3);
+            if ((w >> 3) < per && q < n) chunked.push_back(li[q]);
+            if (w > 16 * (n + 8)) break;
+        }
+        if (chunked.size() != n) chunked = li;
+        all.insert(all.end(), chunked.begin(), chunked.end());
+        HIPC(hipMalloc((void **)&ts.d_all, all.size() * sizeof(int)));
+        HIPC(hipMemcpy(ts.d_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    *out = &S.splits.emplace(variant, ts).first->second;
+    return 0;
+}
+
+int enqueue_loop(int ndte, int cur0)
+{
+    int cur = cur0;
+    const bool strict = S.prm.strict != 0;
+    const int cap = cap_mode();
+    // Boundary strips first, RCCL exchange on a second stream while the interior tiles run
+    // (the tripole seam needs every tile of the top row first, so it keeps the serial order).
+    const bool overlap = use_overlap();
+    if (use_riding_exchange()) {
+        // mailbox halo: one launch per subcycle; the tiles other ranks wait for run first, one
+        // extra workgroup exchanges their velocities while the interior tiles are computed
+        const int variant = S.tyb % 100;
+        State::TileSplit *ts = nullptr;
+        if (int rc = get_tile_split(variant, &ts)) return rc;
+        const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
+        for (int k = 0; k < ndte; ++k) {
+            EvpArgs A;
+            fill_args(A, cur, k == ndte - 1);
+            A.tile_list = ts->d_all; A.tile_count = ts->nb + ts->ni;
+            A.dx = S.direct.d_dx; A.dx_count = S.direct.d_cnt; A.dx_fseq = S.direct.d_cnt + 16; A.dx_nb = ts->nb;
+            evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
+            if (!pushed)
+                evp_launch_halo_local(S.u[cur ^ 1], S.v[cur ^ 1], S.h_local_dst, S.h_local_src,
+                                      (const signed char *)S.h_local_sign, S.n_local, S.stream);
+            cur ^= 1;
+        }
+        HIPC(hipGetLastError());
+        return 0;
+    }
+    if (!overlap) {
+        for (int k = 0; k < ndte; ++k) {
+            EvpArgs A;
+            fill_args(A, cur, k == ndte - 1);
+            evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, S.tyb, strict, cap, S.stream);
+            if (int rc = halo_uv(cur ^ 1)) return rc;
+            cur ^= 1;
+        }
+        HIPC(hipGetLastError());
+        return 0;
+    }
+    // the split kernels decode tile ids row-major: use the row-major flavour of the variant
+    const int variant = S.tyb % 100;
+    State::TileSplit *ts = nullptr;
+    if (int rc = get_tile_split(variant, &ts)) return rc;
+    for (int k = 0; k < ndte; ++k) {
+        const int nxt = cur ^ 1;
+        EvpArgs A;
+        fill_args(A, cur, k == ndte - 1);
+        if (k > 0) HIPC(hipStreamWaitEvent(S.stream, S.ev_halo, 0));   // ghosts of u_in complete
+        // 1. tiles whose cells other ranks need
+        A.tile_list = ts->d_boundary; A.tile_count = ts->nb;
+        evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
+        if (!S.direct.on) evp_launch_halo_pack(S.u[nxt], S.v[nxt], S.h_send_src, S.sendbuf, S.n_send, S.stream);
+        HIPC(hipEventRecord(S.ev_pack, S.stream));
+        // 2. everything else, concurrently with the exchange
+        A.tile_list = ts->d_interior; A.tile_count = ts->ni;
+        evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
+        if (!(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH)))
+            evp_launch_halo_local(S.u[nxt], S.v[nxt], S.h_local_dst, S.h_local_src,
+                                  (const signed char *)S.h_local_sign, S.n_local, S.stream);
+        // 3. RCCL point-to-point over xGMI on the communication stream
+        HIPC(hipStreamWaitEvent(S.stream_comm, S.ev_pack, 0));
+        if (S.direct.on) {      // mailbox exchange: stores into the peers' inboxes, no library call
+            EvpDirect D;
+            fill_direct(D);
+            evp_launch_halo_direct(D, S.u[nxt], S.v[nxt], S.stream_comm);
+        } else {
+            size_t so = 0, ro = 0;
+            NCCLC(ncclGroupStart());
+            for (const HaloPeer &p : S.plan.peers) {
+                if (!p.send_src.empty())
+                    NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
+                if (!p.recv_dst.empty())
+                    NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
+                so += p.send_src.size();
+                ro += p.recv_dst.size();
+            }
+            NCCLC(ncclGroupEnd());
+            evp_launch_halo_unpack(S.u[nxt], S.v[nxt], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
+                                   S.n_recv, S.stream_comm);
+        }
+        HIPC(hipEventRecord(S.ev_halo, S.stream_comm));
+        cur = nxt;
+    }
+    HIPC(hipStreamWaitEvent(S.stream, S.ev_halo, 0));   // the compute stream owns the final state
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+}  // namespace evp_host

@@ -1,0 +1,197 @@
+// Host side of the preparation phase of evp() on the device (kernels: evp_prep.hip).
+#include "evp_host.h"
+
+using namespace evp_host;
+
+extern "C" {
+
+// ---- next tier: the preparation phase of evp() on the device ----------------
+int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, const double *hm,
+                                   const double *tarea, const double *uarea, const double *fcor_blk)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!tmask || !umask || !hm || !tarea || !uarea || !fcor_blk) return fail(-1, "null argument");
+    State::Prep &Q = S.prep;
+    if (S.plan.center_remote && S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE)
+        return fail(-9, "device preparation: the T-grid halo across ranks is not implemented for tripole grids; "
+                        "keep evp()'s host preparation and use cice_evp_hip_run on this configuration");
+    auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };
+    if (B(Q.tmask) || B(Q.umask) || B(Q.umask_old) || B(Q.tmphm)) return -1;
+    auto D = [&](double *&p) -> int { return p ? 0 : alloc_d(&p, S.n); };
+    if (D(Q.hm) || D(Q.tarea) || D(Q.uarea) || D(Q.fcor) || D(Q.tmass) || D(Q.umass) || D(Q.maskd) ||
+        D(Q.ss_tltxU) || D(Q.ss_tltyU) || D(Q.strairxU) || D(Q.strairyU) || D(Q.strtltx) || D(Q.strtlty)) return -1;
+    for (auto &q : Q.t)
+        if (D(q)) return -1;
+    if (!Q.flagword) HIPC(hipMalloc((void **)&Q.flagword, sizeof(unsigned)));
+    Q.h8.resize(S.n);
+    for (size_t k = 0; k < S.n; ++k) Q.h8[k] = tmask[k] != 0;
+    HIPC(hipMemcpy(Q.tmask, Q.h8.data(), S.n, hipMemcpyHostToDevice));
+    for (size_t k = 0; k < S.n; ++k) Q.h8[k] = umask[k] != 0;
+    HIPC(hipMemcpy(Q.umask, Q.h8.data(), S.n, hipMemcpyHostToDevice));
+    if (h2d(Q.hm, hm) || h2d(Q.tarea, tarea) || h2d(Q.uarea, uarea) || h2d(Q.fcor, fcor_blk)) return -1;
+    const HaloPlan &P = S.plan;
+    Q.n_center = (int)P.center_dst.size();
+    if (Q.n_center && !Q.c_dst) {
+        HIPC(hipMalloc((void **)&Q.c_dst, Q.n_center * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&Q.c_src, Q.n_center * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&Q.c_vsign, Q.n_center));
+        HIPC(hipMemcpy(Q.c_dst, P.center_dst.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.c_src, P.center_src.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.c_vsign, P.center_vsign.data(), Q.n_center, hipMemcpyHostToDevice));
+    }
+    HIPC(hipStreamSynchronize(S.stream));
+    Q.geo = true;
+    return 0;
+}
+
+int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *tfields11,
+                      const double *const *fields32, int32_t *iceTmask, int32_t *iceUmask,
+                      double *strintxU, double *strintyU, double *strocnxU, double *strocnyU)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    State::Prep &Q = S.prep;
+    if (!Q.geo) return fail(-1, "cice_evp_hip_set_prep_geometry was not called");
+    if (!pp || !tfields11 || !fields32 || !iceTmask || !iceUmask) return fail(-1, "null argument");
+    for (int k = 0; k < 11; ++k)
+        if (!tfields11[k]) return fail(-1, "null T-grid field %d", k);
+    for (int k = 0; k < 12; ++k)
+        if (!fields32[k]) return fail(-1, "null stress field %d", k);
+    if (!fields32[F_UVEL] || !fields32[F_VVEL]) return fail(-1, "null velocity field");
+    HIPC(hipEventRecord(S.ev2, S.stream));
+    S.cur = 0;
+    for (int k = 0; k < 11; ++k)
+        if (h2d(Q.t[k], tfields11[k])) return -1;
+    for (int k = 0; k < 12; ++k)
+        if (h2d(S.sig[0][k], fields32[k])) return -1;
+    if (h2d(S.u[0], fields32[F_UVEL]) || h2d(S.v[0], fields32[F_VVEL])) return -1;
+    bool tbu_zero = true;
+    if (fields32[F_TBU]) {
+        if (h2d(S.in[F_TBU], fields32[F_TBU])) return -1;
+        for (size_t k = 0; k < S.n && tbu_zero; ++k) tbu_zero = fields32[F_TBU][k] == 0.0;
+    } else {
+        HIPC(hipMemsetAsync(S.in[F_TBU], 0, S.n * sizeof(double), S.stream));
+    }
+    for (size_t k = 0; k < S.n; ++k) Q.h8[k] = iceUmask[k] != 0;
+    HIPC(hipMemcpyAsync(Q.umask_old, Q.h8.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemsetAsync(Q.flagword, 0, sizeof(unsigned), S.stream));
+    HIPC(hipEventRecord(S.ev3, S.stream));
+
+    EvpPrep P{};
+    P.nx = S.d.nx_block; P.ny = S.d.ny_block; P.plane = S.plane; P.blk = S.blk;
+    P.tmask = Q.tmask; P.umask = Q.umask; P.umask_old = Q.umask_old;
+    P.hm = Q.hm; P.tarea = Q.tarea; P.uarea = Q.uarea; P.fcor = Q.fcor;
+    for (int k = 0; k < 11; ++k) P.t[k] = Q.t[k];
+    P.tmass = Q.tmass; P.umass = Q.umass; P.maskd = Q.maskd; P.tmphm = Q.tmphm;
+    P.ss_tltxU = Q.ss_tltxU; P.ss_tltyU = Q.ss_tltyU; P.strairxU = Q.strairxU; P.strairyU = Q.strairyU;
+    P.strtltx = Q.strtltx; P.strtlty = Q.strtlty;
+    P.aiU = S.in[F_AIX]; P.cdn_ocnU = S.in[F_CW]; P.uocnU = S.in[F_UOCN]; P.vocnU = S.in[F_VOCN];
+    P.umassdti = S.in[F_UMASSDTI]; P.fm = S.in[F_FM]; P.waterx = S.in[F_WATERX]; P.watery = S.in[F_WATERY];
+    P.forcex = S.in[F_FORCEX]; P.forcey = S.in[F_FORCEY];
+    P.uvel_init = S.in[F_UVEL_INIT]; P.vvel_init = S.in[F_VVEL_INIT];
+    P.uvel = S.u[0]; P.vvel = S.v[0];
+    for (int k = 0; k < 12; ++k) P.sig[k] = S.sig[0][k];
+    P.mask = S.mask; P.flagword = Q.flagword;
+    P.dt = pp->dt; P.rhoi = pp->rhoi; P.rhos = pp->rhos; P.gravit = pp->gravit;
+    P.dyn_area_min = pp->dyn_area_min; P.dyn_mass_min = pp->dyn_mass_min;
+    P.cosw = S.prm.cosw; P.sinw = S.prm.sinw; P.ssh_coupled = pp->ssh_stress_coupled;
+
+    evp_launch_prep1(P, S.d.nblocks, S.stream);
+    auto halo = [&](std::initializer_list<std::pair<double *, bool>> arrs) {
+        EvpPrepHalo H{};
+        for (const auto &a : arrs) { H.a[H.narr] = a.first; H.is_vec[H.narr] = a.second; ++H.narr; }
+        H.dst = Q.c_dst; H.src = Q.c_src; H.vsign = (const signed char *)Q.c_vsign; H.n = Q.n_center;
+        evp_launch_halo_center(H, S.stream);
+    };
+    // ice_dyn_evp.F90:413-428: iceTmask; tmass, aice_init, cdn_ocn (scalars); uocn, vocn, ss_tltx/y (vectors)
+    halo({{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false},
+          {Q.t[5], true}, {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}});
+    halo({{Q.t[9], true}, {Q.t[10], true}});                 // :466-469 (calc_strair branch)
+    if (S.plan.center_remote) {
+        // neighbours on other ranks (no tripole fold here: centre and corner fields mirror the same
+        // cells, so the velocity exchange carries pairs of T-grid fields)
+        double *pairs[5][2] = {{Q.maskd, Q.tmass}, {Q.t[3], Q.t[4]}, {Q.t[5], Q.t[6]}, {Q.t[7], Q.t[8]}, {Q.t[9], Q.t[10]}};
+        for (auto &pr : pairs)
+            if (int rc = halo_remote_pair(pr[0], pr[1])) return rc;
+    }
+    evp_launch_prep_average(P, S.d.nblocks, S.stream);
+    evp_launch_prep2(P, S.d.nblocks, S.stream);
+    // ghost velocities before the loop (:729-732): the same exchange as inside the loop
+    {
+        const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
+        if (pushed)      // the in-kernel push only exists inside the subcycle kernel: use the gather lists here
+            evp_launch_halo_local(S.u[0], S.v[0], S.h_local_dst, S.h_local_src,
+                                  (const signed char *)S.h_local_sign, S.n_local, S.stream);
+        if (int rc = halo_uv(0)) return rc;
+    }
+    for (int k = 0; k < 12; ++k)
+        HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    evp_launch_vrelfac(S.in[F_AIX], S.in[F_CW], S.prm.rhow, S.vrelfac, S.n, S.stream);
+    HIPC(hipEventRecord(S.ev1, S.stream));
+    // masks and the shortcut flag back to the host
+    unsigned flagword = 0;
+    HIPC(hipMemcpyAsync(S.hmask.data(), S.mask, S.n, hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipMemcpyAsync(&flagword, Q.flagword, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+    S.t_h2d_ms = ms;
+    HIPC(hipEventElapsedTime(&ms, S.ev3, S.ev1));
+    Q.t_ms = ms;
+    for (size_t k = 0; k < S.n; ++k) iceTmask[k] = (S.hmask[k] & 1u) ? 1 : 0;
+    // dyn_prep2 writes iceUmask on the physical cells only (:761-764) and zeroes the stress
+    // divergence / ocean stress off the ice there (:776-781); they are the caller's arrays
+    {
+        const int nx = S.d.nx_block;
+        for (int b = 0; b < S.d.nblocks; ++b)
+            for (int j = S.jlo[b]; j <= S.jhi[b]; ++j)
+                for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
+                    const size_t c = b * S.plane + (size_t)(j - 1) * nx + (i - 1);
+                    iceUmask[c] = (S.hmask[c] & 2u) ? 1 : 0;
+                    if (S.hmask[c] & 2u) continue;
+                    if (strintxU) strintxU[c] = 0.0;
+                    if (strintyU) strintyU[c] = 0.0;
+                    if (strocnxU) strocnxU[c] = 0.0;
+                    if (strocnyU) strocnyU[c] = 0.0;
+                }
+    }
+    S.flags &= ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
+    if (!(flagword & 1u)) S.flags |= EVP_F_WATER_IS_OCN;
+    if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
+    S.uploaded = true;
+    return tune_after_upload();
+}
+
+// Address of a caller's array, for hosts whose language will not hand out the address of an
+// object without a TARGET-like attribute (CICE's module arrays): the Fortran shim builds the
+// pointer tables of cice_evp_hip_prep / _download with it.
+void *cice_evp_hip_addr(const void *array) { return const_cast<void *>(array); }
+
+// ice strength, computed by the host (icepack_ice_strength + its halo update, ice_dyn_evp.F90:541-552,
+// 727-728) from the masks cice_evp_hip_prep returned
+int cice_evp_hip_set_strength(const double *strength)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (!strength) return fail(-1, "null argument");
+    return h2d(S.in[F_STRENGTH], strength);
+}
+
+// products of the preparation phase that stay on the device, for hosts that need them
+// (coupling diagnostics) and for the tests
+int cice_evp_hip_prep_fetch(int32_t which, double *dst)
+{
+    if (!S.ready || !S.uploaded || !S.prep.geo) return fail(-1, "no prepared state");
+    if (!dst) return fail(-1, "null argument");
+    State::Prep &Q = S.prep;
+    const double *tab[20] = {S.in[F_AIX], S.in[F_CW], S.in[F_UOCN], S.in[F_VOCN], S.in[F_UMASSDTI], S.in[F_FM],
+                             S.in[F_WATERX], S.in[F_WATERY], S.in[F_FORCEX], S.in[F_FORCEY], S.in[F_UVEL_INIT],
+                             S.in[F_VVEL_INIT], Q.strtltx, Q.strtlty, Q.strairxU, Q.strairyU, Q.tmass, Q.umass,
+                             S.u[S.cur], S.v[S.cur]};
+    if (which < 0 || which >= 20) return fail(-1, "prep_fetch: which = %d", (int)which);
+    if (d2h(dst, tab[which])) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,388 @@
+// Host side of the on-chip resident kernels (evp_resident.hip, evp_resident2.hip): neighbour /
+// ring tables, residency checks, launches, error word, and the choices made at the first upload.
+#include "evp_host.h"
+
+namespace evp_host {
+
+// ---- on-chip resident subcycle -------------------------------------------------------
+// Host side of evp_resident.hip: which tiles exchange velocities (producers == readers by
+// symmetry: the 8 surrounding tiles, with cyclic wrap through the ghost-cell images).
+bool resident_possible(bool with_peers)
+{
+    if (S.d.nblocks != 1 || (!with_peers && !S.plan.peers.empty())) return false;
+    if ((S.n_seam + S.n_pole + S.n_late) > 0) return false;          // tripole seam: streaming path
+    if (S.n_local > 0 && !S.push_ok) return false;
+    return true;
+}
+
+int resident_setup(int logw)
+{
+    if (S.res_nbr && S.res_logw == logw) return 0;
+    if (S.res_nbr) { (void)hipFree(S.res_nbr); S.res_nbr = nullptr; }
+    if (S.res_flags) { (void)hipFree(S.res_flags); S.res_flags = nullptr; }
+    S.res_logw = logw;
+    const int W = 1 << logw, H = 256 / W;
+    int gx, gy;
+    evp_resident_geometry(S.max_ni, S.max_nj, logw, &gx, &gy);
+    const int ntiles = gx * gy;
+    const int nx = S.d.nx_block, ny = S.d.ny_block;
+    const int ilo = S.ilo[0], ihi = S.ihi[0], jlo = S.jlo[0], jhi = S.jhi[0];
+    // producer of every cell of the (single) block: tile id, or -1 (never written)
+    std::vector<int> prod((size_t)nx * ny, -1);
+    for (int j = jlo; j <= jhi; ++j)
+        for (int i = ilo; i <= ihi; ++i)
+            prod[(size_t)(j - 1) * nx + (i - 1)] = ((j - jlo) / (H - 1)) * gx + (i - ilo) / (W - 1);
+    for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
+        if (S.plan.local_src[k] >= 0) prod[S.plan.local_dst[k]] = prod[S.plan.local_src[k]];
+    std::vector<int> nbr((size_t)ntiles * EVP_RES_NNB, -1);
+    for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+            const int t = by * gx + bx;
+            int cnt = 0;
+            // velocities read by the T-cells of this tile: i0-1..i0+W-1, j0-1..j0+H-1
+            const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
+            for (int j = j0 - 1; j <= j0 + H - 1; ++j)
+                for (int i = i0 - 1; i <= i0 + W - 1; ++i) {
+                    if (i < 1 || i > nx || j < 1 || j > ny) continue;
+                    const int p = prod[(size_t)(j - 1) * nx + (i - 1)];
+                    if (p < 0 || p == t) continue;
+                    bool seen = false;
+                    for (int e = 0; e < cnt; ++e) seen |= nbr[(size_t)t * EVP_RES_NNB + e] == p;
+                    if (seen) continue;
+                    if (cnt >= EVP_RES_NNB) return fail(-6, "resident: too many neighbour tiles");
+                    nbr[(size_t)t * EVP_RES_NNB + cnt++] = p;
+                }
+        }
+    // symmetry (a reader must also be waited for before its input is overwritten)
+    for (int t = 0; t < ntiles; ++t)
+        for (int e = 0; e < EVP_RES_NNB; ++e) {
+            const int p = nbr[(size_t)t * EVP_RES_NNB + e];
+            if (p < 0) continue;
+            bool back = false;
+            int cntp = 0;
+            for (int f = 0; f < EVP_RES_NNB; ++f) {
+                back |= nbr[(size_t)p * EVP_RES_NNB + f] == t;
+                cntp += nbr[(size_t)p * EVP_RES_NNB + f] >= 0;
+            }
+            if (!back) {
+                if (cntp >= EVP_RES_NNB) return fail(-6, "resident: too many neighbour tiles");
+                nbr[(size_t)p * EVP_RES_NNB + cntp] = t;
+            }
+        }
+    S.res_ntiles = ntiles;
+    HIPC(hipMalloc((void **)&S.res_nbr, nbr.size() * sizeof(int)));
+    HIPC(hipMemcpy(S.res_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPC(hipMalloc((void **)&S.res_flags, (size_t)ntiles * sizeof(int)));
+    if (!S.res_err) {
+        HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
+        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+    }
+    return 0;
+}
+
+// ---- second generation (evp_resident2.hip): ring lists and publish map of a tile shape ------
+// For every tile: the cells of its LDS velocity tile that it reads but does not produce itself
+// (ring + ghost/truncation cells), each with the record to poll and the U-cell that produces
+// it; and the map of U-cells some other tile mirrors (those publish a record each subcycle).
+// Geometry only -- independent of the ice masks.
+int resident2_setup(int logw)
+{
+    if (S.res2_ring && S.res2_logw == logw) return 0;
+    auto F = [](auto *&p) { if (p) (void)hipFree((void *)p); p = nullptr; };
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub);
+    S.res2_logw = logw;
+    const int W = 1 << logw, H = 256 / W, LW = W + 1;
+    int gx, gy;
+    evp_resident_geometry(S.max_ni, S.max_nj, logw, &gx, &gy);
+    const int ntiles = gx * gy;
+    const int nx = S.d.nx_block, ny = S.d.ny_block;
+    const int ilo = S.ilo[0], ihi = S.ihi[0], jlo = S.jlo[0], jhi = S.jhi[0];
+    std::vector<int> ghost_src((size_t)nx * ny, -1);
+    for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
+        if (S.plan.local_src[k] >= 0) ghost_src[S.plan.local_dst[k]] = S.plan.local_src[k];
+    for (const HaloPeer &p : S.plan.peers)            // produced on another rank: -2 (always refreshed)
+        for (int32_t d : p.recv_dst) ghost_src[d] = -2;
+    std::vector<int4> ring((size_t)ntiles * EVP_RES2_RING, make_int4(-1, 0, -1, 0));
+    std::vector<int> cnt((size_t)ntiles, 0);
+    std::vector<uint8_t> pub((size_t)nx * ny, 0);
+    std::vector<char> seen((size_t)(H + 1) * LW);
+    for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+            const int t = by * gx + bx;
+            const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int trow = 0; trow < H; ++trow)
+                for (int tcol = 0; tcol < W; ++tcol) {
+                    const int i = i0 + tcol, j = j0 + trow;
+                    if (i > ihi + 1 || j > jhi + 1) continue;          // T-cell not computed
+                    for (int q = 0; q < 4; ++q) {
+                        const int di = -(q & 1), dj = -(q >> 1);
+                        const int pc = tcol + di, pr = trow + dj, pi = i + di, pj = j + dj;
+                        const bool interior = pi >= ilo && pi <= ihi && pj >= jlo && pj <= jhi;
+                        const bool here = interior && pc >= 0 && pc <= W - 2 && pr >= 0 && pr <= H - 2;
+                        if (here) continue;
+                        const int li = (pr + 1) * LW + (pc + 1);
+                        if (seen[li]) continue;
+                        seen[li] = 1;
+                        if (pi < 1 || pi > nx || pj < 1 || pj > ny) continue;
+                        const int cp = (pj - 1) * nx + (pi - 1);
+                        const int src = interior ? cp : ghost_src[cp];
+                        if (cnt[t] >= EVP_RES2_RING) return fail(-6, "resident2: ring list overflow");
+                        ring[(size_t)t * EVP_RES2_RING + cnt[t]++] = make_int4(cp, li, src, 0);
+                        if (interior) pub[cp] = 1;
+                    }
+                }
+        }
+    S.res2_ntiles = ntiles;
+    HIPC(hipMalloc((void **)&S.res2_ring, ring.size() * sizeof(int4)));
+    HIPC(hipMemcpy(S.res2_ring, ring.data(), ring.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIPC(hipMalloc((void **)&S.res2_cnt, cnt.size() * sizeof(int)));
+    HIPC(hipMemcpy(S.res2_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPC(hipMalloc((void **)&S.res2_pub, pub.size()));
+    HIPC(hipMemcpy(S.res2_pub, pub.data(), pub.size(), hipMemcpyHostToDevice));
+    for (auto &p : S.res2_rec)
+        if (!p) {
+            if (!S.res2_rec_owned) return fail(-6, "resident2: record buffers missing from the mailbox");
+            HIPC(hipMalloc(&p, (size_t)nx * ny * 32));
+            HIPC(hipMemset(p, 0, (size_t)nx * ny * 32));
+        }
+    if (!S.res_err) {
+        HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
+        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+    }
+    return 0;
+}
+
+bool resident2_fits(bool remote)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
+    // remote: decided before any field has been seen -> the flag combination with the largest LDS need
+    const unsigned fl = remote ? (S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO)) : (S.flags & S.flags_allowed);
+    const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res2_logw, remote), 8);
+    const long cap = (long)per_cu * prop.multiProcessorCount;
+    return S.res2_ntiles > 0 && (long)S.res2_ntiles * 10 <= cap * 9;
+}
+
+
+int launch_resident2(int ndte, int cur0, bool dry)
+{
+    if (ndte >= 4096) return fail(-6, "resident2: ndte must be < 4096");
+    if (int rc = resident_tables()) return rc;
+    EvpArgs A;
+    fill_args(A, cur0, 1);
+    EvpResident2 R;
+    R.ndte = ndte;
+    R.cur0 = dry ? 0 : cur0;
+    R.dry = dry ? 1 : 0;
+    S.res2_epoch = (S.res2_epoch + 1u) & 0xFFFFFu;
+    if (S.res2_epoch == 0) S.res2_epoch = 1;
+    R.tag_base = S.res2_epoch << 12;
+    R.par0 = S.res2_par;
+    S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
+    R.rimg = S.res_remote ? S.res2_rimg : nullptr;
+    R.rimg_ni = S.max_ni; R.rimg_nj = S.max_nj;
+    R.peer_rec = S.res2_peer_rec;
+    R.peer_rstride = S.res2_peer_rstride;
+    static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
+    R.timeout_ticks = (unsigned long long)((S.res_timeout_ms > 0 ? S.res_timeout_ms : tmo_ms) * 1.0e5);
+    R.spin_limit = 4000000u;
+    R.err = S.res_err;
+    R.pubmap = S.res2_pub;
+    R.ring = S.res2_ring;
+    R.ring_cnt = S.res2_cnt;
+    R.rec[0] = S.res2_rec[0];
+    R.rec[1] = S.res2_rec[1];
+    if (dry) {   // inputs come from the current state, nothing is written back
+        R.u[0] = S.u[cur0]; R.v[0] = S.v[cur0]; R.u[1] = S.u[cur0]; R.v[1] = S.v[cur0];
+    } else {
+        R.u[0] = S.u[0]; R.v[0] = S.v[0]; R.u[1] = S.u[1]; R.v[1] = S.v[1];
+    }
+    R.tab = S.res_tab + (dry ? 28 * (1 + cur0) : 0);
+    evp_launch_resident2(A, R, S.max_ni, S.max_nj, S.res2_logw, S.prm.strict != 0, cap_mode(), S.stream);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+// every workgroup must be resident at once: occupancy query x CUs, with a margin
+bool resident_fits()
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
+    const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed, S.res_logw), 8);
+    const long cap = (long)per_cu * prop.multiProcessorCount;
+    return S.res_ntiles > 0 && (long)S.res_ntiles * 10 <= cap * 9;
+}
+
+int resident_tables()
+{
+    if (!S.res_tab) {
+        // three pointer tables, uploaded once: [0] real run, [1]/[2] dry probe reading sig[0]/sig[1]
+        double *tab[3][28];
+        for (int v = 0; v < 3; ++v) {
+            for (int k = 0; k < 12; ++k) {
+                tab[v][k] = S.sig[v == 0 ? 0 : v - 1][k];
+                tab[v][12 + k] = S.sig[v == 0 ? 1 : v - 1][k];
+            }
+            tab[v][24] = S.in[F_STRINTX]; tab[v][25] = S.in[F_STRINTY];
+            tab[v][26] = S.in[F_TAUBX]; tab[v][27] = S.in[F_TAUBY];
+        }
+        HIPC(hipMalloc((void **)&S.res_tab, sizeof tab));
+        HIPC(hipMemcpy(S.res_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int launch_resident(int ndte, int cur0, bool dry)
+{
+    EvpArgs A;
+    fill_args(A, cur0, 1);
+    EvpResident R;
+    R.ndte = ndte;
+    R.cur0 = dry ? 0 : cur0;
+    R.dry = dry ? 1 : 0;
+    R.spin_limit = 4000000u;
+    R.xcdmap = env("CICE_EVP_HIP_RES_XCD") ? std::atoi(env("CICE_EVP_HIP_RES_XCD")) : 0;
+    R.dbg = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
+    R.flags = S.res_flags;
+    R.nbr = S.res_nbr;
+    R.err = S.res_err;
+    if (dry) {
+        R.u[0] = S.res_scratch[0]; R.v[0] = S.res_scratch[1];
+        R.u[1] = S.res_scratch[2]; R.v[1] = S.res_scratch[3];
+    } else {
+        R.u[0] = S.u[0]; R.v[0] = S.v[0]; R.u[1] = S.u[1]; R.v[1] = S.v[1];
+    }
+    if (int rc = resident_tables()) return rc;
+    R.tab = S.res_tab + (dry ? 28 * (1 + cur0) : 0);
+    HIPC(hipMemsetAsync(S.res_flags, 0, (size_t)S.res_ntiles * sizeof(int), S.stream));
+    evp_launch_resident(A, R, S.max_ni, S.max_nj, S.res_logw, S.prm.strict != 0, cap_mode(), S.stream);
+    HIPC(hipGetLastError());
+    return 0;
+}
+
+int resident_check_error()
+{
+    if (!S.res_launched) return 0;
+    S.res_launched = false;
+    int e = 0;
+    HIPC(hipMemcpy(&e, S.res_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+        S.res_mode = 0;
+        if (e == 2)
+            return fail(-7, "resident EVP kernel: a record of another rank never arrived within the time-out "
+                            "(CICE_EVP_HIP_HALO_TIMEOUT_MS)");
+        return fail(-7, "resident EVP kernel: a neighbour-flag wait timed out (workgroups not co-resident?)");
+    }
+    return 0;
+}
+
+
+// Choices made once the first state is on the device (tile shape of the streaming kernel,
+// streaming vs on-chip resident kernel); shared by cice_evp_hip_upload and cice_evp_hip_prep.
+int tune_after_upload()
+{
+    float ms = 0;
+    if (!S.tyb_forced && !S.tuned) {
+        // pick the tile height once per init by timing a few launches of each variant on
+        // the real state (results are identical for every tile shape; only speed differs).
+        // The launches write the ping-pong "next" buffers, which the first real subcycle
+        // overwrites, so the state is not advanced.
+        // tile heights whose wave count fills the 4 SIMDs evenly (4, 8) plus 3; odd wave counts
+        // (5, 9) leave one SIMD with twice the work and measured 1.5-2x slower
+        const int cand[9] = {4, 8, 3, 104, 108, 103, 204, 208, 203};
+        float best = 1e30f;
+        int best_t = 5;
+        EvpArgs A;
+        fill_args(A, S.cur, 0);
+        for (int c : cand) {
+            for (int rep = 0; rep < 2; ++rep) {   // first pass warms caches / code
+                HIPC(hipEventRecord(S.ev2, S.stream));
+                for (int k = 0; k < 8; ++k)
+                    evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, c, S.prm.strict != 0, cap_mode(), S.stream);
+                HIPC(hipEventRecord(S.ev3, S.stream));
+                HIPC(hipStreamSynchronize(S.stream));
+                HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+            }
+            if (ms < best) { best = ms; best_t = c; }
+        }
+        S.tyb = best_t;
+        S.tuned = true;
+        S.t_stream_probe_ms = best / 8.0;
+        for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);
+        S.graphs.clear();
+    }
+    // on-chip resident subcycle: use it when it fits and a dry probe on scratch velocities
+    // (same work, nothing written back) runs clean and faster than the streaming kernel
+    if (S.res_mode < 0) {
+        S.res_mode = 0;
+        int want = -1;
+        if (env("CICE_EVP_HIP_RESIDENT")) want = std::atoi(env("CICE_EVP_HIP_RESIDENT"));
+        if (want != 0 && S.res_remote && S.direct.on) {
+            // neighbours on other GPUs: tile shape fixed at export, no timing probes (every launch
+            // of this kernel is collective across ranks)
+            S.res_gen = 2;
+            S.res_mode = 1;
+        } else if (want != 0 && resident_possible()) {
+            const int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
+            const int forced_g = env("CICE_EVP_HIP_RES_GEN") ? std::atoi(env("CICE_EVP_HIP_RES_GEN")) : 0;
+            float best = 1e30f;
+            int best_w = 0, best_g = 0;
+            bool any_fit = false, done = false;
+            for (int gen : {2, 1}) {
+                if (done || (forced_g && gen != forced_g)) continue;
+                for (int logw : {5, 4, 6}) {
+                    if (forced_w && logw != forced_w) continue;
+                    if (gen == 1) {
+                        if (resident_setup(logw)) { if (want == 1) return -6; continue; }
+                        if (!resident_fits()) continue;
+                        for (auto &p : S.res_scratch)
+                            if (!p && alloc_d(&p, S.n)) return -1;
+                    } else {
+                        if (resident2_setup(logw)) { if (want == 1) return -6; continue; }
+                        if (!resident2_fits()) continue;
+                    }
+                    any_fit = true;
+                    if (want == 1 && forced_w && forced_g) { best = 0.0f; best_w = logw; best_g = gen; done = true; break; }
+                    // steady-state cost per subcycle = slope between a short and a long dry run
+                    // (launch, prologue and epilogue are paid once per evp() call)
+                    const int nshort = 8, nlong = 40;
+                    float tres = 1e30f, tl[2] = {0, 0};
+                    bool ok = true;
+                    for (int rep = 0; rep < 3 && ok; ++rep) {
+                        const int np = (rep == 2) ? nlong : nshort;      // rep 0 warms up
+                        if (gen == 1)
+                            for (int q = 0; q < 4; ++q)
+                                HIPC(hipMemcpyAsync(S.res_scratch[q], (q & 1) ? S.v[S.cur] : S.u[S.cur],
+                                                    S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+                        HIPC(hipEventRecord(S.ev2, S.stream));
+                        if (int rc = (gen == 1 ? launch_resident(np, S.cur, true) : launch_resident2(np, S.cur, true))) return rc;
+                        HIPC(hipEventRecord(S.ev3, S.stream));
+                        HIPC(hipStreamSynchronize(S.stream));
+                        S.res_launched = true;
+                        if (resident_check_error()) { ok = false; break; }
+                        HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+                        if (rep >= 1) tl[rep - 1] = ms;
+                    }
+                    if (ok) tres = (tl[1] - tl[0]) / (nlong - nshort);
+                    if (ok && tres < best) { best = tres; best_w = logw; best_g = gen; }
+                }
+            }
+            S.t_res_probe_ms = best_w ? best : -1.0;
+            if (best_w && (want == 1 || S.t_stream_probe_ms <= 0.0 || best < S.t_stream_probe_ms)) {
+                if (int rc = (best_g == 1 ? resident_setup(best_w) : resident2_setup(best_w))) return rc;
+                S.res_gen = best_g;
+                S.res_mode = 1;
+            } else if (want == 1) {
+                return fail(-6, any_fit ? "resident EVP kernel requested but its probe failed"
+                                        : "resident EVP kernel requested but its workgroups cannot be co-resident");
+            }
+        } else if (want == 1) {
+            return fail(-6, "resident EVP kernel requested but not applicable (one block per rank, no remote halo, no tripole)");
+        }
+    }
+    return 0;
+}
+
+}  // namespace evp_host
