@@ -54,15 +54,24 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     if (!pp || !tfields11 || !fields32 || !iceTmask || !iceUmask) return fail(-1, "null argument");
     for (int k = 0; k < 11; ++k)
         if (!tfields11[k]) return fail(-1, "null T-grid field %d", k);
-    for (int k = 0; k < 12; ++k)
-        if (!fields32[k]) return fail(-1, "null stress field %d", k);
+    // stresses: all 12 given, or all 12 NULL = keep the copy the previous call left on the device
+    // (nothing between two evp() calls touches them: ice_dyn_evp.F90 is their only writer)
+    int nsig = 0;
+    for (int k = 0; k < 12; ++k) nsig += fields32[k] != nullptr;
+    if (nsig != 0 && nsig != 12) return fail(-1, "stress fields: give all 12 or none");
+    if (nsig == 0 && !S.uploaded) return fail(-1, "no stresses on the device yet: the first call must upload them");
     if (!fields32[F_UVEL] || !fields32[F_VVEL]) return fail(-1, "null velocity field");
     HIPC(hipEventRecord(S.ev2, S.stream));
-    S.cur = 0;
     for (int k = 0; k < 11; ++k)
         if (h2d(Q.t[k], tfields11[k])) return -1;
-    for (int k = 0; k < 12; ++k)
-        if (h2d(S.sig[0][k], fields32[k])) return -1;
+    for (int k = 0; k < 12; ++k) {
+        if (nsig) {
+            if (h2d(S.sig[0][k], fields32[k])) return -1;
+        } else if (S.cur != 0) {
+            HIPC(hipMemcpyAsync(S.sig[0][k], S.sig[S.cur][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+        }
+    }
+    S.cur = 0;
     if (h2d(S.u[0], fields32[F_UVEL]) || h2d(S.v[0], fields32[F_VVEL])) return -1;
     bool tbu_zero = true;
     if (fields32[F_TBU]) {

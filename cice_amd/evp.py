@@ -249,8 +249,13 @@ class EvpHip:
     def sync(self):
         _check(self.lib, self.lib.cice_evp_hip_sync(), "(dyn_evp_hip_sync)")
 
-    def download(self) -> dict:
-        out = {k: np.zeros(self.shape) for k in OUTPUTS}
+    def download_into(self, out: dict):
+        """D2H into the caller's (ideally page-locked) arrays; fields absent from `out` stay on the device."""
+        tab = (_f64p * len(FIELDS))(*[(_dp(out[k]) if k in out else None) for k in FIELDS])
+        _check(self.lib, self.lib.cice_evp_hip_download(tab), "(dyn_evp_hip_download)")
+
+    def download(self, skip_stresses: bool = False) -> dict:
+        out = {k: np.zeros(self.shape) for k in OUTPUTS if not (skip_stresses and k in FIELDS[:12])}
         tab = (_f64p * len(FIELDS))(*[(_dp(out[k]) if k in out else None) for k in FIELDS])
         rc = self.lib.cice_evp_hip_download(tab)
         _check(self.lib, rc, "(dyn_evp_hip_download)")

@@ -169,6 +169,9 @@ int cice_evp_hip_dyn_finish(double *strocnxU, double *strocnyU);
  * fcor_blk (ice_dyn_shared).  T-grid fields, in this order: aice, vice, vsno, aice_init, cdn_ocn,
  * uocn, vocn, ss_tltx, ss_tlty, strairxT, strairyT (their ghost cells need not be current).
  * fields32: the table of cice_evp_hip_upload; read here: the 12 stresses, uvel, vvel, TbU (NULL = 0).
+ * All 12 stress pointers NULL = keep the stresses the previous call left on the device (evp() is
+ * their only writer; pair it with NULL stress entries in cice_evp_hip_download and fetch them only
+ * when a restart or history file needs them): 24 of the 49 per-call array transfers go away.
  * iceUmask: in = mask of the previous call (new ice starts at the ocean velocity), out = new mask;
  * strintxU/strintyU/strocnxU/strocnyU (may be NULL): zeroed off the ice on the host arrays.
  * On a split domain the T-grid halos use the same transport as the velocities (collective call);

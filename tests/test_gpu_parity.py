@@ -613,3 +613,36 @@ def test_prep_on_device_full_size_vs_oracle(grid, bs, ssh):
         assert_bitwise({k: raw[k] for k in SIG}, {k: want[k] for k in SIG}, "stresses after dyn_prep2")
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("name", [n for n in GOLDEN_CASES if GoldenCase(n).ncalls == 2])
+def test_stresses_stay_resident_between_calls(name):
+    """Two consecutive evp() calls with the 12 stresses never leaving the device in between
+    (NULL stress pointers in the second cice_evp_hip_prep, none downloaded after the first):
+    the second call's outputs equal the reference's second call, bit for bit."""
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        st = c.prep_static()
+        core.set_prep_geometry(st["tmask"], st["umask"], st["hm"], st["tarea"], st["uarea"], st["fcor_blk"])
+        d = c.prep_scal_dict()
+        pp = evp.PrepParams(dt=d["dt"], rhoi=d["rhoi"], rhos=d["rhos"], gravit=d["gravit"],
+                            dyn_area_min=d["dyn_area_min"], dyn_mass_min=d["dyn_mass_min"],
+                            ssh_stress_coupled=d["ssh_coupled"])
+        for icall in (1, 2):
+            t, state = c.prep_inputs(icall)
+            dyn, _, _ = c.inputs(icall)
+            state = dict(state, TbU=dyn["TbU"])
+            if icall == 2:
+                for k in SIG:
+                    del state[k]                       # keep what call 1 left on the device
+            core.prep(pp, t, state)
+            core.set_strength(dyn["strength"])
+            core.subcycle(c.ndte)
+            if c.ns == "tripole":
+                core.stress_halo()
+            res = core.download(skip_stresses=(icall == 1))
+            assert ("stressp_1" in res) == (icall == 2)
+        assert_bitwise(res, c.expected(2, c.ndte), f"{name}: call 2 with device-resident stresses")
+    finally:
+        core.finalize()

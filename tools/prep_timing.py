@@ -42,6 +42,24 @@ t0 = time.perf_counter()
 for _ in range(5):
     oracle.prep(dom, opp, static, t, st2)
 t_cpu = (time.perf_counter() - t0) / 5
+# whole evp() call through the wider entry points, PCIe included: prep -> strength -> loop -> download
+strength = sc(np.where(pr["static"]["tmask"] != 0, 2.75e4 * pr["t"]["vice"] * np.exp(-20.0 * (1.0 - pr["t"]["aice"])), 0.0))
+core.pin_host(strength)
+outbuf = {k: np.zeros(dc.shape(0)) for k in evp.OUTPUTS}
+core.pin_host(*outbuf.values())
+def whole(resident):
+    st = {k: v for k, v in state.items() if not (resident and k in evp.FIELDS[:12])}
+    dst = {k: v for k, v in outbuf.items() if not (resident and k in evp.FIELDS[:12])}
+    core.prep(pp, t, state); core.set_strength(strength); core.subcycle(120); core.download_into(outbuf)   # warm, stresses on device
+    t0 = time.perf_counter()
+    for _ in range(10):
+        core.prep(pp, t, st)
+        core.set_strength(strength)
+        core.subcycle(120)
+        core.download_into(dst)
+    return (time.perf_counter() - t0) / 10
+t_full, t_res = whole(False), whole(True)
+print("EVPCALL", wl, "prep+loop+download ms: all arrays %.3f, stresses resident %.3f" % (1e3 * t_full, 1e3 * t_res))
 print("PREP", wl, "call_ms %.3f" % (1e3 * t_call), "h2d_ms %.3f" % tim["h2d_ms"], "device_ms %.3f" % tim["prep_ms"],
       "oracle_1core_ms %.2f" % (1e3 * t_cpu))
 core.finalize()
