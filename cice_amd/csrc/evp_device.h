@@ -99,6 +99,10 @@ struct EvpResident2 {
     void *const *peer_rec;     // [npeers] the peer's record buffer (parity 0) as mapped here
     const size_t *peer_rstride;// [npeers] bytes between the two parities of that buffer
     unsigned long long timeout_ticks;   // bound of a wait on another rank (100 MHz wall clock)
+    // tripole grid (the top physical row lies on the fold); all NULL otherwise
+    const int *seam;           // [nx] per column of the fold row: partner cell * 4 + role (1 low, 2 high, 3 pole), 0 none
+    const int *img3;           // [ncell][3] ghost images of every U-cell: dst * 2 + (sign < 0), -1 none
+    void *rec_raw[2];          // records of the pre-average velocities of the fold row, by subcycle parity
 };
 int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote);
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,

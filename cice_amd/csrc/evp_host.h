@@ -172,6 +172,8 @@ struct State {
     // resident kernel with neighbours on other GPUs (records stored into peers' buffers over xGMI)
     bool res_remote = false;     // agreed by all ranks at mailbox import
     double res_timeout_ms = 0;   // > 0: overrides the wait bound of the next resident launches (probe)
+    int *res2_seam = nullptr, *res2_img3 = nullptr;   // tripole: fold-row roles, per-cell ghost images
+    void *res2_rec_raw[2] = {nullptr, nullptr};       // tripole: records of the pre-average fold-row velocities
     int2 *res2_rimg = nullptr;
     void **res2_peer_rec = nullptr;
     size_t *res2_peer_rstride = nullptr;
@@ -213,6 +215,7 @@ bool use_riding_exchange();
 int get_tile_split(int variant, State::TileSplit **out);
 int enqueue_loop(int ndte, int cur0);
 // evp_host_resident.cpp
+bool tripole_seam();
 bool resident_possible(bool with_peers = false);
 int resident_setup(int logw);
 int resident2_setup(int logw);

@@ -7,10 +7,21 @@ namespace evp_host {
 // ---- on-chip resident subcycle -------------------------------------------------------
 // Host side of evp_resident.hip: which tiles exchange velocities (producers == readers by
 // symmetry: the 8 surrounding tiles, with cyclic wrap through the ghost-cell images).
+bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0; }
+
 bool resident_possible(bool with_peers)
 {
     if (S.d.nblocks != 1 || (!with_peers && !S.plan.peers.empty())) return false;
-    if ((S.n_seam + S.n_pole + S.n_late) > 0) return false;          // tripole seam: streaming path
+    if (tripole_seam()) {
+        // tagged-record kernel only: the fold row is averaged inside the kernel, ghost images come
+        // from a per-cell table (at most three per cell, no eliminated source block)
+        std::map<int, int> nimg;
+        for (size_t k = 0; k < S.plan.local_dst.size(); ++k) {
+            if (S.plan.local_src[k] < 0) return false;
+            if (++nimg[S.plan.local_src[k]] > 3) return false;
+        }
+        return true;
+    }
     if (S.n_local > 0 && !S.push_ok) return false;
     return true;
 }
@@ -128,12 +139,39 @@ int resident2_setup(int logw)
                         const int cp = (pj - 1) * nx + (pi - 1);
                         const int src = interior ? cp : ghost_src[cp];
                         if (cnt[t] >= EVP_RES2_RING) return fail(-6, "resident2: ring list overflow");
-                        ring[(size_t)t * EVP_RES2_RING + cnt[t]++] = make_int4(cp, li, src, 0);
+                        // a cell of the tripole fold row changes every subcycle, ice or not (w = 1)
+                        const int always = (tripole_seam() && src >= 0 && src / nx + 1 == jhi) ? 1 : 0;
+                        ring[(size_t)t * EVP_RES2_RING + cnt[t]++] = make_int4(cp, li, src, always);
                         if (interior) pub[cp] = 1;
                     }
                 }
         }
     S.res2_ntiles = ntiles;
+    if (tripole_seam() && !S.res2_seam) {
+        std::vector<int> seam((size_t)nx, 0), img3((size_t)nx * ny * 3, -1);
+        auto col = [&](int32_t off) { return (int)(off % nx); };                  // 0-based column of a cell offset
+        for (size_t k = 0; k < S.plan.seam_a.size(); ++k) {
+            seam[col(S.plan.seam_a[k])] = S.plan.seam_b[k] * 4 + 1;
+            seam[col(S.plan.seam_b[k])] = S.plan.seam_a[k] * 4 + 2;
+        }
+        for (int32_t pcell : S.plan.seam_pole) seam[col(pcell)] = 3;
+        for (size_t k = 0; k < S.plan.local_dst.size(); ++k) {
+            const int src = S.plan.local_src[k];
+            const int enc = S.plan.local_dst[k] * 2 + (S.plan.local_sign[k] < 0 ? 1 : 0);
+            int e = 0;
+            while (e < 3 && img3[(size_t)src * 3 + e] >= 0) ++e;
+            if (e == 3) return fail(-6, "resident2: more than three ghost images of one cell");
+            img3[(size_t)src * 3 + e] = enc;
+        }
+        HIPC(hipMalloc((void **)&S.res2_seam, seam.size() * sizeof(int)));
+        HIPC(hipMemcpy(S.res2_seam, seam.data(), seam.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPC(hipMalloc((void **)&S.res2_img3, img3.size() * sizeof(int)));
+        HIPC(hipMemcpy(S.res2_img3, img3.data(), img3.size() * sizeof(int), hipMemcpyHostToDevice));
+        for (auto &q : S.res2_rec_raw) {
+            HIPC(hipMalloc(&q, (size_t)nx * ny * 32));
+            HIPC(hipMemset(q, 0, (size_t)nx * ny * 32));
+        }
+    }
     HIPC(hipMalloc((void **)&S.res2_ring, ring.size() * sizeof(int4)));
     HIPC(hipMemcpy(S.res2_ring, ring.data(), ring.size() * sizeof(int4), hipMemcpyHostToDevice));
     HIPC(hipMalloc((void **)&S.res2_cnt, cnt.size() * sizeof(int)));
@@ -180,6 +218,10 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.tag_base = S.res2_epoch << 12;
     R.par0 = S.res2_par;
     S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
+    R.seam = S.res2_seam;
+    R.img3 = S.res2_img3;
+    R.rec_raw[0] = S.res2_rec_raw[0];
+    R.rec_raw[1] = S.res2_rec_raw[1];
     R.rimg = S.res_remote ? S.res2_rimg : nullptr;
     R.rimg_ni = S.max_ni; R.rimg_nj = S.max_nj;
     R.peer_rec = S.res2_peer_rec;
@@ -332,6 +374,7 @@ int tune_after_upload()
             bool any_fit = false, done = false;
             for (int gen : {2, 1}) {
                 if (done || (forced_g && gen != forced_g)) continue;
+                if (gen == 1 && tripole_seam()) continue;          // the fold row is only handled by gen 2
                 for (int logw : {5, 4, 6}) {
                     if (forced_w && logw != forced_w) continue;
                     if (gen == 1) {

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     const bool actT = inT && (m & 1u);
     const bool isU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
     const bool own = (tcol < W - 1 || i == r.y + 1) && (trow < H - 1 || j == r.w + 1);
-    const bool pub = isU && (R.pubmap[c] != 0);   // some other tile's ring mirrors this cell
+    bool pub = isU && (R.pubmap[c] != 0);         // some other tile's ring mirrors this cell
     const int par0 = R.par0;                      // record buffer of subcycle index 0 in this launch
 
     // ---- state that stays on the CU for the whole call -------------------------------------
@@ -169,6 +169,23 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     }
     // ghost images of this U-cell (cyclic wrap), looked up once: at most three (corner cell)
     int img0 = -1, img1 = -1, img2 = -1;
+    // tripole seam (row jhi lies on the fold): this thread's U-cell takes part in the pair average
+    // after every momentum step, ice or not (ice_boundary.F90:1630-1649) -- role 1/2: low/high index
+    // of a pair, 3: pole point; partner = the other cell of the pair
+    const bool ownU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w);
+    int seam_role = 0, seam_partner = -1;
+    if (R.seam && ownU && j == r.w) {
+        const int sv = R.seam[i - 1];
+        seam_role = sv & 3;
+        seam_partner = sv >> 2;
+    }
+    const bool isSeam = seam_role != 0;
+    if (isSeam) pub = R.pubmap[c] != 0;
+    if (R.img3) {
+        // tripole: ghost images are not confined to the block edge (ghost row NY+1 mirrors row NY-1):
+        // per-cell table, at most three images
+        if (ownU && ((m & 2u) || isSeam)) { img0 = R.img3[3 * c]; img1 = R.img3[3 * c + 1]; img2 = R.img3[3 * c + 2]; }
+    } else
     if (isU && (flags & EVP_F_PUSH) && (i == r.x || i == r.y || j == r.z || j == r.w)) {
         const int slots[4] = {(i == r.x) ? (j - r.z) : -1, (i == r.y) ? A.push_nj + (j - r.z) : -1,
                               (j == r.z) ? 2 * A.push_nj + (i - r.x) : -1,
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     bool ring_remote = false;
     if (t < R.ring_cnt[tile]) {
         const int4 e = R.ring[tile * EVP_RES2_RING + t];   // x: cell whose record is polled, y: LDS index, z: producing U-cell
-        const bool live = e.z >= 0 && (A.mask[e.z] & 2u);   // an active U-cell rewrites it every subcycle
+        const bool live = e.z >= 0 && ((A.mask[e.z] & 2u) || e.w);   // an active U-cell (or a seam cell: w) rewrites it every subcycle
         if (live) { ring_cp = e.x; ring_li = e.y; }
         if (REMOTE && e.z == -2) { ring_cp = e.x; ring_li = e.y; ring_remote = true; }   // produced on another rank
     }
@@ -248,14 +265,14 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     __syncthreads();
 
     double u_own = 0.0, v_own = 0.0;
-    if (isU || rpub) { u_own = s_u[li]; v_own = s_v[li]; }
+    if (isU || rpub || isSeam) { u_own = s_u[li]; v_own = s_v[li]; }
     // initial records (subcycle tag 0) so that the neighbours' first ring refresh finds them
     {
         const unsigned tag = R.tag_base;
         v4u *r0 = (v4u *)R.rec[par0 & 1];
         if (rpub) publish_remote(par0 & 1, u_own, v_own, tag);
         if (pub) st_rec2(r0 + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
-        if (isU) {
+        if (isU || isSeam) {
             if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
             if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img1 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
             if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img2 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
@@ -333,16 +350,55 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             q.sy2 = sy2; q.sy3 = s_str[3 * 256 + t + W + 1];
             MM::stepu(A.p, q, o);
             u_own = o.u; v_own = o.v;
-            s_u[li] = o.u; s_v[li] = o.v;            // read by the next stress phase (after the ring barrier)
-            const unsigned tag = want + 1u;
-            if (pub) st_rec2(wr + 2 * (size_t)c, pack_rec(o.u, tag), pack_rec(o.v, tag));
-            if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img0 >> 1), pack_rec(sg * o.u, tag), pack_rec(sg * o.v, tag)); }
-            if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img1 >> 1), pack_rec(sg * o.u, tag), pack_rec(sg * o.v, tag)); }
-            if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img2 >> 1), pack_rec(sg * o.u, tag), pack_rec(sg * o.v, tag)); }
             if (k == R.ndte - 1 && !R.dry) {
                 R.tab[24][c] = o.strintx; R.tab[25][c] = o.strinty;
                 R.tab[26][c] = o.taubx; R.tab[27][c] = o.tauby;
             }
+        }
+        if (isSeam) {
+            // what the halo update does to the fold row after every subcycle: pair (a, b) <- (xavg, -xavg),
+            // xavg = 0.5*(x_a + isign*x_b), isign = -1; pole points change sign.  The partner's value of
+            // THIS subcycle travels as a tagged record of its own (rec_raw), like any other hand-off.
+            const double isign = -1.0;
+            const unsigned tag = want + 1u;
+            if (seam_role == 3) {
+                u_own = isign * u_own; v_own = isign * v_own;
+            } else {
+                v4u *rw = (v4u *)R.rec_raw[((k + par0) & 1) ^ 1];
+                st_rec2(rw + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
+                v4u ra, rb;
+                unsigned spins = 0;
+                bool ok = true;
+                for (;;) {
+                    ld_rec2(rw + 2 * (size_t)seam_partner, ra, rb);
+                    if (ra.x == tag && ra.w == tag && rb.x == tag && rb.w == tag) break;
+                    if (++spins > R.spin_limit ||
+                        ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_store(R.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (ok) {
+                    const double pu = unpack_rec(ra), pv = unpack_rec(rb);
+                    if (seam_role == 1) {
+                        u_own = 0.5 * (u_own + isign * pu);
+                        v_own = 0.5 * (v_own + isign * pv);
+                    } else {
+                        u_own = isign * (0.5 * (pu + isign * u_own));
+                        v_own = isign * (0.5 * (pv + isign * v_own));
+                    }
+                }
+            }
+        }
+        if (isU || isSeam) {
+            s_u[li] = u_own; s_v[li] = v_own;        // read by the next stress phase (after the ring barrier)
+            const unsigned tag = want + 1u;
+            if (pub) st_rec2(wr + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
+            if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+            if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img1 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+            if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img2 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
         }
         if (rpub) publish_remote(((k + par0) & 1) ^ 1, u_own, v_own, want + 1u);
         // no publish step: the records carry their own tags
@@ -368,7 +424,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                 R.tab[12 + k][c] = s[k];
             }
         }
-        if (isU) {
+        if (isU || isSeam) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 double *uu = R.u[b], *vv = R.v[b];

@@ -1,2 +1,3 @@
 cd /root/repo; export TMPDIR=/tmp
-python tools/prep_timing.py gx1 2>&1 | grep -E "PREP|EVPCALL"
+mkdir -p gpurun_out/r1l
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r1l/pytest_gpu.log 2>&1; grep -E "passed|failed|^E  .*rror" gpurun_out/r1l/pytest_gpu.log | tail -8

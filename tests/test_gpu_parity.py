@@ -291,9 +291,11 @@ def test_remote_halo_without_communicator_fails_loudly(monkeypatch):
         core.finalize()
 
 
-def test_tx1_size_tripole_vs_reference_harness(tmp_path):
+@pytest.mark.parametrize("bs", [(90, 60), (360, 240)])
+def test_tx1_size_tripole_vs_reference_harness(tmp_path, bs):
     """configs[3] size (360x240, tripole seam): inputs captured from, and outputs compared
-    with, the reference's own evp() run here by the prebuilt oracle/_ref harness."""
+    with, the reference's own evp() run here by the prebuilt oracle/_ref harness.  4x4 blocks:
+    streaming kernel + seam kernel; one block: the on-chip resident kernel with the fold inside."""
     import run_ref
     if not run_ref.have_ref("strict"):
         pytest.skip("oracle/_ref/evp_ref_harness_strict not present")
@@ -301,7 +303,7 @@ def test_tx1_size_tripole_vs_reference_harness(tmp_path):
     g = synth.make_grid(nx, ny, dx0=1.1e5, ns="tripole")
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
-    d, txt = run_ref.run_harness(nx, ny, 90, 60, ew="cyclic", ns="tripole", variant="strict", h_ndte=240,
+    d, txt = run_ref.run_harness(nx, ny, bs[0], bs[1], ew="cyclic", ns="tripole", variant="strict", h_ndte=240,
                                  ncalls=1, nsub_list=[1, 240], grid_kind="tripolefile", icecase="full",
                                  grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"))
     np.savez(tmp_path / "case.npz", **d, ew=np.array("cyclic"), ns=np.array("tripole"))
@@ -319,6 +321,7 @@ def test_tx1_size_tripole_vs_reference_harness(tmp_path):
             out = post_evp(c, core.run(dyn, tm, um, ndte=nsub))
             assert_bitwise(out, c.expected(1, nsub), f"tx1-size tripole nsub {nsub}")
         assert np.abs(out["uvel"]).max() > 1e-3
+        assert (core.timings()["tile_variant"] >= 2000) == (bs == (360, 240))
     finally:
         core.finalize()
 
@@ -442,8 +445,16 @@ def test_resident_remote_gx3_vs_oracle(monkeypatch):
     assert_bitwise(got, want, "gx3 resident kernel, every ghost through remote records (to self)")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 @pytest.mark.parametrize("world,workload,shape,resident", [(2, "gx3", "", True), (4, "gx3", "2x2", True),
-                                                           (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep")])
+                                                           (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep"),
+                                                           (2, "tx1", "1x2", True)])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
@@ -453,7 +464,7 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
     import sys as _sys
     root = Path(__file__).resolve().parents[1]
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(29540 + world + len(workload)),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            str(root / "tools" / "mailbox_2proc.py"), "--workload", workload, "--ndte", "24"]
     if shape:
         cmd += ["--shape", shape]
@@ -644,5 +655,28 @@ def test_stresses_stay_resident_between_calls(name):
             res = core.download(skip_stresses=(icall == 1))
             assert ("stressp_1" in res) == (icall == 2)
         assert_bitwise(res, c.expected(2, c.ndte), f"{name}: call 2 with device-resident stresses")
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("logw", [4, 5, 6])
+def test_resident_kernel_tripole_seam_bitwise(logw, monkeypatch):
+    """The tripole fold inside the on-chip resident kernel: after every momentum step the cells
+    of the fold row exchange their new velocities as tagged records and take the pair average
+    (poles change sign), ghost row NY+1 mirrors row NY-1 with the sign flipped -- against the
+    single-block tripole fixture from the reference, every tile shape, both calls worth of
+    subcycle counts; plus the device stress symmetrisation -> whole evp()."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_LOGW", str(logw))
+    c = GoldenCase("trip_cyc_1blk_patchy")
+    core = hip_from_case(c, strict=True)
+    try:
+        dyn, tm, um = c.inputs(1)
+        for nsub in c.nsub_list:
+            core.upload(dyn, tm, um)
+            core.subcycle(nsub)
+            core.stress_halo()
+            assert_bitwise(core.download(), c.expected(1, nsub), f"tripole resident logw={logw} nsub={nsub}")
+        assert core.timings()["tile_variant"] == 2000 + logw
     finally:
         core.finalize()

@@ -43,7 +43,8 @@ def main():
 
     spec = synth.GRIDS[a.workload]
     nx, ny = spec["nx"], spec["ny"]
-    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+    ns_bnd = spec.get("ns", "closed")          # tx1: tripole north boundary (rank layouts with px = 1 only)
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns_bnd))
     st = synth.make_state(g, case="full", seed=7, warm=True)
     pr = synth.make_primary(g, "full", seed=9) if a.prep else None
     scal = synth.evp_scalars(120)
@@ -94,9 +95,9 @@ def main():
         finally:
             core.finalize()
 
-    ref, _, _ = run(decomp.single_block(nx, ny, "cyclic", "closed"), 0, False)
+    ref, _, _ = run(decomp.single_block(nx, ny, "cyclic", ns_bnd), 0, False)
     shape = tuple(int(v) for v in a.shape.split("x")) if a.shape else None
-    dcN = decomp.per_rank_blocks(nx, ny, world, "cyclic", "closed", proc_shape=shape)
+    dcN = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns_bnd, proc_shape=shape)
     got, tim, t_us = run(dcN, rank, True)
     assert tim["halo_transport"] == "mailbox", tim
     bad = []
@@ -111,8 +112,14 @@ def main():
             if not np.array_equal(w, h):
                 bad.append((k, float(np.abs(w - h).max())))
         if k in ("uvel", "vvel"):      # ghost cells too (post-condition of the drop-in boundary)
-            if not np.array_equal(want, got[k]):
-                bad.append((k + " ghosts", float(np.abs(want - got[k]).max())))
+            w2, h2 = want.copy(), got[k].copy()
+            if ns_bnd == "tripole":    # (scatter() does not know the fold: leave the folded ghost row out)
+                for b in dcN.local_blocks(rank):
+                    if b.gj0 + b.gny - 1 == ny:
+                        w2[b.local][-1, :] = 0.0
+                        h2[b.local][-1, :] = 0.0
+            if not np.array_equal(w2, h2):
+                bad.append((k + " ghosts", float(np.abs(w2 - h2).max())))
     res = [None] * world
     dist.all_gather_object(res, (rank, bad, t_us, tim["launches_per_subcycle"], tim["tile_variant"]))
     if rank == 0:
