@@ -144,14 +144,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    def measure(workload, case, ndte, steps, warmup):
+    def measure(workload, case, ndte, steps, warmup, ns="closed"):
         """One timed pass: `warmup` untimed + `steps` timed evp() subcycle loops of `workload`,
         block-decomposed over the ranks; barrier + sync on both sides, MAX over ranks."""
         spec = synth.GRIDS[workload]
         nx, ny = spec["nx"], spec["ny"]
-        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
         st = synth.make_state(g, case=case, seed=20260928, warm=True)
-        dc = decomp.per_rank_blocks(nx, ny, world, "cyclic", "closed")
+        dc = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns)
         geo = {k: dc.scatter(g[k], rank, fill=(1.0 if k != "uarear" else 0.0))
                for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
         fields = {k: dc.scatter(st[k], rank) for k in evp.FIELDS}
@@ -213,6 +213,10 @@ def main():
     M2 = None
     if a.secondary and a.workload != "s01":
         M2 = measure("s01", "full", 480, 2, 1)
+    # one GPU only: the tripole grid of configs[3] (fold row averaged inside the resident kernel)
+    M3 = None
+    if a.secondary and a.workload == "gx1" and world == 1:
+        M3 = measure("tx1", "full", 240, 10, 2, ns="tripole")
 
     if rank == 0:
         cells = nx * ny
@@ -275,6 +279,12 @@ def main():
                 "launches_per_subcycle": M2["tm_ev"]["launches_per_subcycle"],
                 "roofline_frac_rank0": B_ALG * my2 / tk2 / 1e9 / HBM_PEAK_GBS if tk2 > 0 else None,
                 "finite": M2["finite"]}
+        if M3 is not None:
+            res["tripole"] = {
+                "workload": "tx1 360x240 tripole B-grid EVP ndte=240, case=full, one GPU",
+                "value": M3["nx"] * M3["ny"] * 240 * 10 / M3["dt"], "unit": "cell-updates/s", "steps": 10, "warmup": 2,
+                "us_per_subcycle": 1e6 * M3["dt"] / (10 * 240), "tile_variant": M3["tm_ev"]["tile_variant"],
+                "finite": M3["finite"]}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.workload, a.case, ndte, a.cpu_seconds)
         else:

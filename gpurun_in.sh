@@ -1,3 +1,4 @@
 cd /root/repo; export TMPDIR=/tmp
 mkdir -p gpurun_out/r1l
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r1l/pytest_gpu.log 2>&1; grep -E "passed|failed|^E  .*rror" gpurun_out/r1l/pytest_gpu.log | tail -8
+( time python bench.py > gpurun_out/r1l/bench_gx1.json 2> gpurun_out/r1l/bench_gx1.err ) 2>&1 | grep real; python -c "
+import json; d=json.load(open('gpurun_out/r1l/bench_gx1.json')); print(d['value'], d['config']['us_per_subcycle'], d['roofline']['frac']); print(d.get('secondary')); print(d.get('tripole')); print(d['cpu_baseline']['value'])"
