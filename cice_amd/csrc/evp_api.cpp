@@ -533,6 +533,18 @@ int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid)
     return 0;
 }
 
+int cice_evp_hip_center_plan(int32_t *count, int32_t *dst, int32_t *src, int32_t *vsign)
+{
+    const HaloPlan &P = S.plan;
+    if (count) *count = (int32_t)P.center_dst.size();
+    for (size_t k = 0; k < P.center_dst.size(); ++k) {
+        if (dst) dst[k] = P.center_dst[k];
+        if (src) src[k] = P.center_src[k];
+        if (vsign) vsign[k] = P.center_vsign[k];
+    }
+    return P.center_remote ? 1 : 0;
+}
+
 int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src)
 {
     const HaloPlan &P = S.plan;

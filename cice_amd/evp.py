@@ -41,7 +41,7 @@ EXPORTS = [
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
-    "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan",
+    "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr",
 ]
@@ -356,10 +356,15 @@ def halo_plan(dims: Dims) -> dict:
     nst = int(c1[0])
     std, sts = [np.zeros(max(nst, 1), dtype=np.int32) for _ in range(2)]
     lib.cice_evp_hip_stress_plan(_ip(c1), _ip(std), _ip(sts))
+    lib.cice_evp_hip_center_plan(_ip(c1), None, None, None)
+    ncen = int(c1[0])
+    cd, cs, cv = [np.zeros(max(ncen, 1), dtype=np.int32) for _ in range(3)]
+    center_remote = lib.cice_evp_hip_center_plan(_ip(c1), _ip(cd), _ip(cs), _ip(cv)) == 1
     sd = np.zeros(max(ns, 1), dtype=np.int32)
     rg = np.zeros(max(nr, 1), dtype=np.int32)
     lib.cice_evp_hip_peer_plan(_ip(sd), _ip(rg))
     return dict(stress_dst=std[:nst], stress_src=sts[:nst], send_dst=sd[:ns], recv_gid=rg[:nr],
+                center_dst=cd[:ncen], center_src=cs[:ncen], center_vsign=cv[:ncen], center_remote=center_remote,
                 local_dst=ld[:nl], local_src=ls[:nl], local_sign=lg[:nl], peer_rank=pr[:npeer],
                 peer_nsend=pns[:npeer], peer_nrecv=pnr[:npeer], send_src=ss[:ns], recv_dst=rd[:nr],
                 seam_a=sa[:npair], seam_b=sb[:npair], seam_pole=sp[:npole],

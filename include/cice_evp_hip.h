@@ -252,6 +252,10 @@ int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, i
  * rank's ghosts); recv_gid = global cell number (ig-1)+nx_global*(jg-1) each received ghost mirrors
  * (probe exchanges).  Lists may be NULL.                                                         */
 int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid);
+/* Ghost-cell lists of cell-centre fields (T-grid inputs of cice_evp_hip_prep) whose source is on
+ * this rank: a[dst] <- (vector kind ? vsign : 1) * a[src], src = -1: 0.  Returns 1 (not an error)
+ * when some ghost needs another rank.  Lists may be NULL.                                       */
+int cice_evp_hip_center_plan(int32_t *count, int32_t *dst, int32_t *src, int32_t *vsign);
 /* Lists behind cice_evp_hip_stress_halo: a1[dst] <- a2[src] for every partner pair (src = -1:
  * fill 0, ice_boundary.F90:7643-7645).  Lists may be NULL.                                     */
 int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src);

@@ -110,6 +110,31 @@ def test_stress_symmetrisation_lists_match_oracle(bx, by):
     assert len(evp.halo_plan(d2)["stress_dst"]) == 0
 
 
+@pytest.mark.parametrize("ew,ns,bx,by", [("cyclic", "closed", 7, 5), ("closed", "closed", 20, 6), ("cyclic", "cyclic", 8, 9),
+                                         ("cyclic", "tripole", 20, 18), ("cyclic", "tripole", 5, 6)])
+@pytest.mark.parametrize("vector", [False, True])
+def test_center_field_halo_lists_match_oracle(ew, ns, bx, by, vector):
+    """Ghost-cell lists of cell-centre fields (the T-grid halos of evp()'s preparation phase)
+    applied with numpy == the oracle's halo update for field_loc_center, scalar and vector kinds
+    (the oracle's is pinned through the prep fixtures, tripole included)."""
+    dc = decomp.Decomp(20, 18, bx, by, ew, ns, 1)
+    d, keep = evp.make_dims(dc, 0)
+    plan = evp.halo_plan(d)
+    assert not plan["center_remote"]
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), 20, 18, ew, ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    a = np.random.default_rng(3).standard_normal(dc.shape(0))
+    want = oracle.halo_update(dom, a.copy(), "center", "vector" if vector else "scalar")
+    got = a.copy()
+    flat = got.reshape(-1)
+    src = plan["center_src"]
+    sgn = plan["center_vsign"] if vector else np.ones_like(plan["center_vsign"])
+    flat[plan["center_dst"]] = np.where(src >= 0, sgn * a.reshape(-1)[np.maximum(src, 0)], 0.0)
+    assert np.array_equal(got, want)
+
+
 def test_tripole_plan_refuses_seam_split_across_ranks():
     dc = decomp.Decomp(20, 18, 10, 9, "cyclic", "tripole", 2, (2, 1))   # seam row cut in x
     d, keep = evp.make_dims(dc, 0)
