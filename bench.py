@@ -138,11 +138,19 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    # Rehearsal on a 1-GPU box (tests only): CICE_EVP_BENCH_REHEARSAL=1 runs the N ranks as N processes
+    # on device 0 over gloo, the mailbox halo bootstrapped by hand (RCCL refuses two ranks per device)
+    rehearsal = world > 1 and os.environ.get("CICE_EVP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("CICE_EVP_HIP_DEVICE", str(local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def measure(workload, case, ndte, steps, warmup, ns="closed"):
         """One timed pass: `warmup` untimed + `steps` timed evp() subcycle loops of `workload`,
@@ -165,7 +173,11 @@ def main():
         core = evp.EvpHip(d, evp.make_params(scal, strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
                           geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
         try:
-            if world > 1:
+            if world > 1 and rehearsal:
+                blobs = [None] * world
+                dist.all_gather_object(blobs, core.halo_export())
+                core.halo_import(blobs)
+            elif world > 1:
                 uid = [core.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
                 core.comm_init(uid[0])
@@ -192,7 +204,7 @@ def main():
                 dist.barrier()
             dt = t1 - t0
             if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
             # HIP events on the library's stream around the timed region (rank 0's share)

@@ -1,2 +1,3 @@
 cd /root/repo; export TMPDIR=/tmp
-python tools/hbm_triad.py 2>&1 | grep HBM
+mkdir -p gpurun_out/r1n
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "rehearsal" > gpurun_out/r1n/pytest_reh.log 2>&1; grep -E "passed|failed|^E |Error" gpurun_out/r1n/pytest_reh.log | tail -12

@@ -680,3 +680,26 @@ def test_resident_kernel_tripole_seam_bitwise(logw, monkeypatch):
         assert core.timings()["tile_variant"] == 2000 + logw
     finally:
         core.finalize()
+
+
+def test_bench_multi_rank_rehearsal():
+    """bench.py's N>1 path (decomposition, collective set-up, barrier + MAX-over-ranks timing, the
+    JSON line) rehearsed on the one GPU of this box: 2 ranks as 2 processes over gloo with the
+    mailbox halo bootstrapped by hand (CICE_EVP_BENCH_REHEARSAL=1; the driver's real N>1 runs use
+    RCCL and one GPU per rank)."""
+    import json
+    import subprocess
+    import sys as _sys
+    root = Path(__file__).resolve().parents[1]
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx3", "--no-secondary"]
+    env = dict(os.environ, CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["halo_transport"] == "mailbox" and d["config"]["finite"]
+    assert d["config"]["tile_variant"] >= 2000         # the resident kernel with remote neighbours
+    assert d["cpu_baseline"] is None and "roofline" in d
