@@ -454,7 +454,7 @@ def _free_port():
 
 @pytest.mark.parametrize("world,workload,shape,resident", [(2, "gx3", "", True), (4, "gx3", "2x2", True),
                                                            (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep"),
-                                                           (2, "tx1", "1x2", True)])
+                                                           (2, "tx1", "1x2", True), (8, "gx3", "2x4", True)])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
