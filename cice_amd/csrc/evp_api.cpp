@@ -209,6 +209,7 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
     HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
     S.t_h2d_ms = ms;
     S.uploaded = true;
+    S.res2_order_stale = true;
     return tune_after_upload();
 }
 

@@ -172,6 +172,9 @@ struct State {
     // resident kernel with neighbours on other GPUs (records stored into peers' buffers over xGMI)
     bool res_remote = false;     // agreed by all ranks at mailbox import
     double res_timeout_ms = 0;   // > 0: overrides the wait bound of the next resident launches (probe)
+    int *res2_order = nullptr;                        // launch order of the tiles (heaviest first), per upload
+    int res2_order_for = -1;                          // logw the order was built for
+    bool res2_order_stale = true;                     // masks changed since it was built
     int *res2_seam = nullptr, *res2_img3 = nullptr;   // tripole: fold-row roles, per-cell ghost images
     void *res2_rec_raw[2] = {nullptr, nullptr};       // tripole: records of the pre-average fold-row velocities
     int2 *res2_rimg = nullptr;

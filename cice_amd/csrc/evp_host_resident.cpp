@@ -203,10 +203,43 @@ bool resident2_fits(bool remote)
 }
 
 
+// Launch order of the tiles: by ice-covered T-cells, descending (see the kernel).  Rebuilt when the
+// masks or the tile shape change; CICE_EVP_HIP_RES_ORDER=0 keeps the natural order.
+int resident2_order()
+{
+    static const bool off = env("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env("CICE_EVP_HIP_RES_ORDER"));
+    if (off) return 0;
+    if (S.res2_order && !S.res2_order_stale && S.res2_order_for == S.res2_logw) return 0;
+    const int W = 1 << S.res2_logw, H = 256 / W;
+    int gx, gy;
+    evp_resident_geometry(S.max_ni, S.max_nj, S.res2_logw, &gx, &gy);
+    const int ntiles = gx * gy, nx = S.d.nx_block;
+    std::vector<std::pair<int, int>> cost((size_t)ntiles);
+    for (int t = 0; t < ntiles; ++t) {
+        const int bx = t % gx, by = t / gx;
+        const int i0 = S.ilo[0] + bx * (W - 1), j0 = S.jlo[0] + by * (H - 1);
+        int n = 0;
+        for (int j = j0; j < j0 + H && j <= S.jhi[0] + 1; ++j)
+            for (int i = i0; i < i0 + W && i <= S.ihi[0] + 1; ++i) n += S.hmask[(size_t)(j - 1) * nx + (i - 1)] & 1u;
+        cost[t] = {-n, t};
+    }
+    std::stable_sort(cost.begin(), cost.end());
+    std::vector<int> order((size_t)ntiles);
+    for (int w = 0; w < ntiles; ++w) order[w] = cost[w].second;
+    if (S.res2_order && S.res2_order_for != S.res2_logw) { (void)hipFree(S.res2_order); S.res2_order = nullptr; }
+    if (!S.res2_order) HIPC(hipMalloc((void **)&S.res2_order, order.size() * sizeof(int)));
+    HIPC(hipMemcpyAsync(S.res2_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    S.res2_order_for = S.res2_logw;
+    S.res2_order_stale = false;
+    return 0;
+}
+
 int launch_resident2(int ndte, int cur0, bool dry)
 {
     if (ndte >= 4096) return fail(-6, "resident2: ndte must be < 4096");
     if (int rc = resident_tables()) return rc;
+    if (int rc = resident2_order()) return rc;
     EvpArgs A;
     fill_args(A, cur0, 1);
     EvpResident2 R;
@@ -218,6 +251,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.tag_base = S.res2_epoch << 12;
     R.par0 = S.res2_par;
     S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
+    R.order = S.res2_order;
     R.seam = S.res2_seam;
     R.img3 = S.res2_img3;
     R.rec_raw[0] = S.res2_rec_raw[0];

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     const int t = ty * 64 + tx;               // == trow*W + tcol
     const int tcol = tx & (W - 1);
     const int trow = t >> LOGW;
-    const int tile = blockIdx.x;
+    // launch order = heaviest tiles first (host-sorted by ice-covered cells): the workgroups that
+    // end up third on a CU are then the cheap ones (land, partial edge tiles)
+    const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
     const int bx = tile % A.gx;
     const int by = tile / A.gx;
     const int4 r = A.blk[0];
