@@ -252,6 +252,8 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.par0 = S.res2_par;
     S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
     R.order = S.res2_order;
+    static const int dbg2 = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
+    R.dbg = dbg2;
     R.seam = S.res2_seam;
     R.img3 = S.res2_img3;
     R.rec_raw[0] = S.res2_rec_raw[0];

@@ -293,19 +293,19 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             if (!poll_remote(rd + 2 * (size_t)ring_cp, want, ra, rb)) s_bad = 1;
             s_u[ring_li] = unpack_rec(ra);
             s_v[ring_li] = unpack_rec(rb);
-        } else if (ring_cp >= 0) {
+        } else if (ring_cp >= 0 && !(R.dbg & 2)) {
             v4u ra, rb;
             unsigned spins = 0;
             for (;;) {
                 ld_rec2(rd + 2 * (size_t)ring_cp, ra, rb);
-                if (ra.x == want && ra.w == want && rb.x == want && rb.w == want) break;
+                if ((ra.x == want && ra.w == want && rb.x == want && rb.w == want) || (R.dbg & 1)) break;
                 if (++spins > R.spin_limit ||
                     ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     __hip_atomic_store(R.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_bad = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                if (R.dbg & 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
             }
             s_u[ring_li] = unpack_rec(ra);
             s_v[ring_li] = unpack_rec(rb);

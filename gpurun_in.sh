@@ -1,3 +1,8 @@
 cd /root/repo; export TMPDIR=/tmp
-mkdir -p gpurun_out/r1o
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r1o/pytest_gpu.log 2>&1; grep -E "passed|failed|^E  .*rror" gpurun_out/r1o/pytest_gpu.log | tail -5
+export CICE_EVP_HIP_RESIDENT=1 CICE_EVP_HIP_RES_GEN=2 CICE_EVP_HIP_RES_LOGW=4
+for D in 0 4 1 2; do
+echo "gx1 dbg=$D: $(CICE_EVP_HIP_RES_DEBUG=$D python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['us_per_subcycle'])")"
+done
+for D in 0 1 2; do
+echo "gx3 dbg=$D: $(CICE_EVP_HIP_RES_DEBUG=$D python bench.py --workload gx3 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['us_per_subcycle'])")"
+done
