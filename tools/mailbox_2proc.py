@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--ndte", type=int, default=24)
     ap.add_argument("--timing", action="store_true")
     ap.add_argument("--shape", default="")          # e.g. 2x1
+    ap.add_argument("--soak", type=int, default=0, help="N more launches of 120 subcycles before the comparison")
     ap.add_argument("--prep", action="store_true",
                     help="start from the primary model state: evp()'s preparation phase on the device on every "
                          "rank (T-grid halos across ranks through the same transport), then the loop")
@@ -89,6 +90,8 @@ def main():
                 core.sync()
                 t = (time.perf_counter() - t0) / 600 * 1e6
                 core.subcycle(7)          # an odd count: the record-buffer parity flips between launches
+            for _ in range(a.soak):
+                core.subcycle(120)
             out = core.download()
             out.update(extra)
             return out, core.timings(), t
