@@ -119,7 +119,13 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     const bool actT = inT && (m & 1u);
     const bool isU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w) && (m & 2u);
     const bool own = (tcol < W - 1 || i == r.y + 1) && (trow < H - 1 || j == r.w + 1);
-    bool pub = isU && (R.pubmap[c] != 0);         // some other tile's ring mirrors this cell
+    // Every U-cell another tile's ring mirrors publishes a record every subcycle, ice or not, and
+    // every ring entry that has a producer is polled every subcycle: a tile then cannot run more
+    // than one subcycle ahead of ANY tile that still has to read its records (the two-buffer
+    // record scheme depends on that; making either side depend on the ice mask would let a tile
+    // next to open water run ahead of its reader and overwrite a record that was never read).
+    const bool ownU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w);
+    const bool pub = ownU && (R.pubmap[c] != 0);
     const int par0 = R.par0;                      // record buffer of subcycle index 0 in this launch
 
     // ---- state that stays on the CU for the whole call -------------------------------------
@@ -174,7 +180,6 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // tripole seam (row jhi lies on the fold): this thread's U-cell takes part in the pair average
     // after every momentum step, ice or not (ice_boundary.F90:1630-1649) -- role 1/2: low/high index
     // of a pair, 3: pole point; partner = the other cell of the pair
-    const bool ownU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w);
     int seam_role = 0, seam_partner = -1;
     if (R.seam && ownU && j == r.w) {
         const int sv = R.seam[i - 1];
@@ -182,13 +187,12 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         seam_partner = sv >> 2;
     }
     const bool isSeam = seam_role != 0;
-    if (isSeam) pub = R.pubmap[c] != 0;
     if (R.img3) {
         // tripole: ghost images are not confined to the block edge (ghost row NY+1 mirrors row NY-1):
         // per-cell table, at most three images
-        if (ownU && ((m & 2u) || isSeam)) { img0 = R.img3[3 * c]; img1 = R.img3[3 * c + 1]; img2 = R.img3[3 * c + 2]; }
+        if (ownU) { img0 = R.img3[3 * c]; img1 = R.img3[3 * c + 1]; img2 = R.img3[3 * c + 2]; }
     } else
-    if (isU && (flags & EVP_F_PUSH) && (i == r.x || i == r.y || j == r.z || j == r.w)) {
+    if (ownU && (flags & EVP_F_PUSH) && (i == r.x || i == r.y || j == r.z || j == r.w)) {
         const int slots[4] = {(i == r.x) ? (j - r.z) : -1, (i == r.y) ? A.push_nj + (j - r.z) : -1,
                               (j == r.z) ? 2 * A.push_nj + (i - r.x) : -1,
                               (j == r.w) ? 2 * A.push_nj + A.push_ni + (i - r.x) : -1};
@@ -209,7 +213,6 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     char *rp0 = nullptr, *rp1 = nullptr, *rp2 = nullptr;
     size_t rs0 = 0, rs1 = 0, rs2 = 0;
     if (REMOTE) {
-        const bool ownU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w);
         if (ownU && (i == r.x || i == r.y || j == r.z || j == r.w)) {
             const int slots[4] = {(i == r.x) ? (j - r.z) : -1, (i == r.y) ? R.rimg_nj + (j - r.z) : -1,
                                   (j == r.z) ? 2 * R.rimg_nj + (i - r.x) : -1,
@@ -236,8 +239,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     bool ring_remote = false;
     if (t < R.ring_cnt[tile]) {
         const int4 e = R.ring[tile * EVP_RES2_RING + t];   // x: cell whose record is polled, y: LDS index, z: producing U-cell
-        const bool live = e.z >= 0 && ((A.mask[e.z] & 2u) || e.w);   // an active U-cell (or a seam cell: w) rewrites it every subcycle
-        if (live) { ring_cp = e.x; ring_li = e.y; }
+        if (e.z >= 0) { ring_cp = e.x; ring_li = e.y; }      // has a producer on this GPU: refreshed every subcycle
         if (REMOTE && e.z == -2) { ring_cp = e.x; ring_li = e.y; ring_remote = true; }   // produced on another rank
     }
     auto publish_remote = [&](int par, double uu, double vv, unsigned tag) {
@@ -266,15 +268,27 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     if (t == 0) s_bad = 0;
     __syncthreads();
 
+    // bound of a wait on a record of this GPU: spin count (workgroups not co-resident -> fail fast) on
+    // a rank without remote neighbours, wall-clock time otherwise
+    unsigned long long t_wait0 = 0;
+    auto gave_up = [&](unsigned spins, unsigned long long t0) -> bool {
+        if (REMOTE) {
+            if ((spins & 255u) != 0) return false;
+            return wall_clock64() - t0 > R.timeout_ticks ||
+                   __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        }
+        return spins > R.spin_limit ||
+               ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+    };
     double u_own = 0.0, v_own = 0.0;
-    if (isU || rpub || isSeam) { u_own = s_u[li]; v_own = s_v[li]; }
+    if (ownU) { u_own = s_u[li]; v_own = s_v[li]; }
     // initial records (subcycle tag 0) so that the neighbours' first ring refresh finds them
     {
         const unsigned tag = R.tag_base;
         v4u *r0 = (v4u *)R.rec[par0 & 1];
         if (rpub) publish_remote(par0 & 1, u_own, v_own, tag);
         if (pub) st_rec2(r0 + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
-        if (isU || isSeam) {
+        if (ownU) {
             if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
             if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img1 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
             if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(r0 + 2 * (size_t)(img2 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
@@ -287,6 +301,10 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         const v4u *rd = (const v4u *)R.rec[(k + par0) & 1];
         v4u *wr = (v4u *)R.rec[((k + par0) & 1) ^ 1];
 
+        if ((R.dbg & 8) && (tile & 3) == 1) {      // robustness test: every fourth tile lags by ~10 us per subcycle
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(8);
+        }
         // refresh the ring of the velocity tile from the neighbours' records
         if (REMOTE && ring_remote) {
             v4u ra, rb;
@@ -296,11 +314,13 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         } else if (ring_cp >= 0 && !(R.dbg & 2)) {
             v4u ra, rb;
             unsigned spins = 0;
+            if (REMOTE) t_wait0 = wall_clock64();
             for (;;) {
                 ld_rec2(rd + 2 * (size_t)ring_cp, ra, rb);
                 if ((ra.x == want && ra.w == want && rb.x == want && rb.w == want) || (R.dbg & 1)) break;
-                if (++spins > R.spin_limit ||
-                    ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                // a local neighbour may itself be waiting for another rank: with remote neighbours
+                // every wait is bounded by wall-clock time, not by a spin count
+                if (gave_up(++spins, t_wait0)) {
                     __hip_atomic_store(R.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_bad = 1;
                     break;
@@ -371,11 +391,11 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                 v4u ra, rb;
                 unsigned spins = 0;
                 bool ok = true;
+                if (REMOTE) t_wait0 = wall_clock64();
                 for (;;) {
                     ld_rec2(rw + 2 * (size_t)seam_partner, ra, rb);
                     if (ra.x == tag && ra.w == tag && rb.x == tag && rb.w == tag) break;
-                    if (++spins > R.spin_limit ||
-                        ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (gave_up(++spins, t_wait0)) {
                         __hip_atomic_store(R.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = false;
                         break;
@@ -394,8 +414,8 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                 }
             }
         }
-        if (isU || isSeam) {
-            s_u[li] = u_own; s_v[li] = v_own;        // read by the next stress phase (after the ring barrier)
+        if (isU || isSeam) { s_u[li] = u_own; s_v[li] = v_own; }   // read by the next stress phase (after the ring barrier)
+        if (ownU) {
             const unsigned tag = want + 1u;
             if (pub) st_rec2(wr + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
             if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }

@@ -659,6 +659,23 @@ def test_stresses_stay_resident_between_calls(name):
         core.finalize()
 
 
+@pytest.mark.parametrize("case", ["caps", "full"])
+def test_resident_kernel_survives_lagging_tiles(case, monkeypatch):
+    """The two-buffer record scheme must not depend on tiles keeping pace by luck: with every
+    fourth tile artificially delayed by 10 us per subcycle (CICE_EVP_HIP_RES_DEBUG=8) -- next to
+    open water in the 'caps' case, where a reader tile has nothing its neighbour waits for --
+    the result is still the oracle's, bit for bit, and no wait times out."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_GEN", "2")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_LOGW", "4")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_DEBUG", "8")
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", case, seed=21, warm=True)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 60)
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=60)
+    assert_bitwise(got, want, f"lagging tiles, {case}")
+
+
 @pytest.mark.parametrize("logw", [4, 5, 6])
 def test_resident_kernel_tripole_seam_bitwise(logw, monkeypatch):
     """The tripole fold inside the on-chip resident kernel: after every momentum step the cells
