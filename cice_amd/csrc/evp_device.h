@@ -91,6 +91,7 @@ struct EvpResident2 {
     void *rec[2];              // [2][ncell] x {u granule, v granule} (2 x 16 bytes), by subcycle parity
     double *u[2], *v[2];       // plain arrays: input from [cur0], final state to both
     double *const *tab;        // as EvpResident::tab
+    int nblocks;               // CICE blocks of this rank (tiles = nblocks x gx x gy)
     const int *order;          // [ntiles] tile run by workgroup w (NULL: identity)
     int dbg;                   // timing experiments only (CICE_EVP_HIP_RES_DEBUG; WRONG results): 1 no tag check, 2 no ring loads, 4 longer sleep; 8 = every fourth tile lags 10 us per subcycle (results stay right)
     int par0;                  // which of rec[0/1] holds the records of subcycle index 0 of THIS launch

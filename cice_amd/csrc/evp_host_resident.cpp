@@ -11,8 +11,9 @@ bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0; }
 
 bool resident_possible(bool with_peers)
 {
-    if (S.d.nblocks != 1 || (!with_peers && !S.plan.peers.empty())) return false;
-    if (tripole_seam()) {
+    if (!with_peers && !S.plan.peers.empty()) return false;
+    if (with_peers && S.d.nblocks != 1) return false;       // remote images are looked up per edge of ONE block
+    if (tripole_seam() || S.d.nblocks > 1) {
         // tagged-record kernel only: the fold row is averaged inside the kernel, ghost images come
         // from a per-cell table (at most three per cell, no eliminated source block)
         std::map<int, int> nimg;
@@ -105,71 +106,85 @@ int resident2_setup(int logw)
     const int W = 1 << logw, H = 256 / W, LW = W + 1;
     int gx, gy;
     evp_resident_geometry(S.max_ni, S.max_nj, logw, &gx, &gy);
-    const int ntiles = gx * gy;
+    const int nb = S.d.nblocks;
+    const int ntiles = gx * gy * nb;
     const int nx = S.d.nx_block, ny = S.d.ny_block;
-    const int ilo = S.ilo[0], ihi = S.ihi[0], jlo = S.jlo[0], jhi = S.jhi[0];
-    std::vector<int> ghost_src((size_t)nx * ny, -1);
+    const size_t plane = S.plane, ncell = S.n;
+    std::vector<int> ghost_src(ncell, -1);
     for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
         if (S.plan.local_src[k] >= 0) ghost_src[S.plan.local_dst[k]] = S.plan.local_src[k];
     for (const HaloPeer &p : S.plan.peers)            // produced on another rank: -2 (always refreshed)
         for (int32_t d : p.recv_dst) ghost_src[d] = -2;
+    std::vector<char> on_seam(ncell, 0);              // cells of the tripole fold row (change every subcycle, ice or not)
+    for (int32_t c : S.plan.seam_a) on_seam[c] = 1;
+    for (int32_t c : S.plan.seam_b) on_seam[c] = 1;
+    for (int32_t c : S.plan.seam_pole) on_seam[c] = 1;
     std::vector<int4> ring((size_t)ntiles * EVP_RES2_RING, make_int4(-1, 0, -1, 0));
     std::vector<int> cnt((size_t)ntiles, 0);
-    std::vector<uint8_t> pub((size_t)nx * ny, 0);
+    std::vector<uint8_t> pub(ncell, 0);
     std::vector<char> seen((size_t)(H + 1) * LW);
-    for (int by = 0; by < gy; ++by)
-        for (int bx = 0; bx < gx; ++bx) {
-            const int t = by * gx + bx;
-            const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
-            std::fill(seen.begin(), seen.end(), 0);
-            for (int trow = 0; trow < H; ++trow)
-                for (int tcol = 0; tcol < W; ++tcol) {
-                    const int i = i0 + tcol, j = j0 + trow;
-                    if (i > ihi + 1 || j > jhi + 1) continue;          // T-cell not computed
-                    for (int q = 0; q < 4; ++q) {
-                        const int di = -(q & 1), dj = -(q >> 1);
-                        const int pc = tcol + di, pr = trow + dj, pi = i + di, pj = j + dj;
-                        const bool interior = pi >= ilo && pi <= ihi && pj >= jlo && pj <= jhi;
-                        const bool here = interior && pc >= 0 && pc <= W - 2 && pr >= 0 && pr <= H - 2;
-                        if (here) continue;
-                        const int li = (pr + 1) * LW + (pc + 1);
-                        if (seen[li]) continue;
-                        seen[li] = 1;
-                        if (pi < 1 || pi > nx || pj < 1 || pj > ny) continue;
-                        const int cp = (pj - 1) * nx + (pi - 1);
-                        const int src = interior ? cp : ghost_src[cp];
-                        if (cnt[t] >= EVP_RES2_RING) return fail(-6, "resident2: ring list overflow");
-                        // a cell of the tripole fold row changes every subcycle, ice or not (w = 1)
-                        const int always = (tripole_seam() && src >= 0 && src / nx + 1 == jhi) ? 1 : 0;
-                        ring[(size_t)t * EVP_RES2_RING + cnt[t]++] = make_int4(cp, li, src, always);
-                        if (interior) pub[cp] = 1;
+    for (int b = 0; b < nb; ++b) {
+        const int ilo = S.ilo[b], ihi = S.ihi[b], jlo = S.jlo[b], jhi = S.jhi[b];
+        const int cb = (int)(b * plane);
+        for (int by = 0; by < gy; ++by)
+            for (int bx = 0; bx < gx; ++bx) {
+                const int t = (b * gy + by) * gx + bx;
+                const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
+                std::fill(seen.begin(), seen.end(), 0);
+                for (int trow = 0; trow < H; ++trow)
+                    for (int tcol = 0; tcol < W; ++tcol) {
+                        const int i = i0 + tcol, j = j0 + trow;
+                        if (i > ihi + 1 || j > jhi + 1) continue;          // T-cell not computed
+                        for (int q = 0; q < 4; ++q) {
+                            const int di = -(q & 1), dj = -(q >> 1);
+                            const int pc = tcol + di, pr = trow + dj, pi = i + di, pj = j + dj;
+                            const bool interior = pi >= ilo && pi <= ihi && pj >= jlo && pj <= jhi;
+                            const bool here = interior && pc >= 0 && pc <= W - 2 && pr >= 0 && pr <= H - 2;
+                            if (here) continue;
+                            const int li = (pr + 1) * LW + (pc + 1);
+                            if (seen[li]) continue;
+                            seen[li] = 1;
+                            if (pi < 1 || pi > nx || pj < 1 || pj > ny) continue;
+                            const int cp = cb + (pj - 1) * nx + (pi - 1);
+                            const int src = interior ? cp : ghost_src[cp];
+                            if (cnt[t] >= EVP_RES2_RING) return fail(-6, "resident2: ring list overflow");
+                            const int always = (src >= 0 && on_seam[src]) ? 1 : 0;
+                            ring[(size_t)t * EVP_RES2_RING + cnt[t]++] = make_int4(cp, li, src, always);
+                            if (interior) pub[cp] = 1;
+                        }
                     }
-                }
-        }
+            }
+    }
     S.res2_ntiles = ntiles;
-    if (tripole_seam() && !S.res2_seam) {
-        std::vector<int> seam((size_t)nx, 0), img3((size_t)nx * ny * 3, -1);
-        auto col = [&](int32_t off) { return (int)(off % nx); };                  // 0-based column of a cell offset
-        for (size_t k = 0; k < S.plan.seam_a.size(); ++k) {
-            seam[col(S.plan.seam_a[k])] = S.plan.seam_b[k] * 4 + 1;
-            seam[col(S.plan.seam_b[k])] = S.plan.seam_a[k] * 4 + 2;
-        }
-        for (int32_t pcell : S.plan.seam_pole) seam[col(pcell)] = 3;
+    // ghost images from a per-cell table whenever they are not confined to the edge of ONE block:
+    // tripole grids (ghost row NY+1 mirrors row NY-1) and several blocks per rank
+    if ((tripole_seam() || nb > 1) && !S.res2_img3) {
+        std::vector<int> img3(ncell * 3, -1);
         for (size_t k = 0; k < S.plan.local_dst.size(); ++k) {
             const int src = S.plan.local_src[k];
+            if (src < 0) continue;
             const int enc = S.plan.local_dst[k] * 2 + (S.plan.local_sign[k] < 0 ? 1 : 0);
             int e = 0;
             while (e < 3 && img3[(size_t)src * 3 + e] >= 0) ++e;
             if (e == 3) return fail(-6, "resident2: more than three ghost images of one cell");
             img3[(size_t)src * 3 + e] = enc;
         }
-        HIPC(hipMalloc((void **)&S.res2_seam, seam.size() * sizeof(int)));
-        HIPC(hipMemcpy(S.res2_seam, seam.data(), seam.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPC(hipMalloc((void **)&S.res2_img3, img3.size() * sizeof(int)));
         HIPC(hipMemcpy(S.res2_img3, img3.data(), img3.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (tripole_seam() && !S.res2_seam) {
+        std::vector<int> seam((size_t)nx * nb, 0);       // per block and column of the fold row
+        auto slot = [&](int32_t off) { return (size_t)(off / plane) * nx + (off % plane) % nx; };
+        for (size_t k = 0; k < S.plan.seam_a.size(); ++k) {
+            seam[slot(S.plan.seam_a[k])] = S.plan.seam_b[k] * 4 + 1;
+            seam[slot(S.plan.seam_b[k])] = S.plan.seam_a[k] * 4 + 2;
+        }
+        for (int32_t pcell : S.plan.seam_pole) seam[slot(pcell)] = 3;
+        HIPC(hipMalloc((void **)&S.res2_seam, seam.size() * sizeof(int)));
+        HIPC(hipMemcpy(S.res2_seam, seam.data(), seam.size() * sizeof(int), hipMemcpyHostToDevice));
         for (auto &q : S.res2_rec_raw) {
-            HIPC(hipMalloc(&q, (size_t)nx * ny * 32));
-            HIPC(hipMemset(q, 0, (size_t)nx * ny * 32));
+            HIPC(hipMalloc(&q, ncell * 32));
+            HIPC(hipMemset(q, 0, ncell * 32));
         }
     }
     HIPC(hipMalloc((void **)&S.res2_ring, ring.size() * sizeof(int4)));
@@ -181,8 +196,8 @@ int resident2_setup(int logw)
     for (auto &p : S.res2_rec)
         if (!p) {
             if (!S.res2_rec_owned) return fail(-6, "resident2: record buffers missing from the mailbox");
-            HIPC(hipMalloc(&p, (size_t)nx * ny * 32));
-            HIPC(hipMemset(p, 0, (size_t)nx * ny * 32));
+            HIPC(hipMalloc(&p, ncell * 32));
+            HIPC(hipMemset(p, 0, ncell * 32));
         }
     if (!S.res_err) {
         HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
@@ -213,14 +228,15 @@ int resident2_order()
     const int W = 1 << S.res2_logw, H = 256 / W;
     int gx, gy;
     evp_resident_geometry(S.max_ni, S.max_nj, S.res2_logw, &gx, &gy);
-    const int ntiles = gx * gy, nx = S.d.nx_block;
+    const int ntiles = gx * gy * S.d.nblocks, nx = S.d.nx_block;
     std::vector<std::pair<int, int>> cost((size_t)ntiles);
     for (int t = 0; t < ntiles; ++t) {
-        const int bx = t % gx, by = t / gx;
-        const int i0 = S.ilo[0] + bx * (W - 1), j0 = S.jlo[0] + by * (H - 1);
+        const int b = t / (gx * gy), bx = (t % (gx * gy)) % gx, by = (t % (gx * gy)) / gx;
+        const int i0 = S.ilo[b] + bx * (W - 1), j0 = S.jlo[b] + by * (H - 1);
         int n = 0;
-        for (int j = j0; j < j0 + H && j <= S.jhi[0] + 1; ++j)
-            for (int i = i0; i < i0 + W && i <= S.ihi[0] + 1; ++i) n += S.hmask[(size_t)(j - 1) * nx + (i - 1)] & 1u;
+        for (int j = j0; j < j0 + H && j <= S.jhi[b] + 1; ++j)
+            for (int i = i0; i < i0 + W && i <= S.ihi[b] + 1; ++i)
+                n += S.hmask[b * S.plane + (size_t)(j - 1) * nx + (i - 1)] & 1u;
         cost[t] = {-n, t};
     }
     std::stable_sort(cost.begin(), cost.end());
@@ -251,6 +267,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.tag_base = S.res2_epoch << 12;
     R.par0 = S.res2_par;
     S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
+    R.nblocks = S.d.nblocks;
     R.order = S.res2_order;
     static const int dbg2 = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.dbg = dbg2;
@@ -410,7 +427,7 @@ int tune_after_upload()
             bool any_fit = false, done = false;
             for (int gen : {2, 1}) {
                 if (done || (forced_g && gen != forced_g)) continue;
-                if (gen == 1 && tripole_seam()) continue;          // the fold row is only handled by gen 2
+                if (gen == 1 && (tripole_seam() || S.d.nblocks > 1)) continue;   // fold row / several blocks: gen 2 only
                 for (int logw : {5, 4, 6}) {
                     if (forced_w && logw != forced_w) continue;
                     if (gen == 1) {

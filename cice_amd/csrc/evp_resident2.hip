@@ -100,14 +100,17 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // launch order = heaviest tiles first (host-sorted by ice-covered cells): the workgroups that
     // end up third on a CU are then the cheap ones (land, partial edge tiles)
     const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
-    const int bx = tile % A.gx;
-    const int by = tile / A.gx;
-    const int4 r = A.blk[0];
+    const int per_blk = A.gx * A.gy;
+    const int bz = tile / per_blk;                // CICE block of this rank
+    const int bx = (tile % per_blk) % A.gx;
+    const int by = (tile % per_blk) / A.gx;
+    const int4 r = A.blk[bz];
     const int i0 = r.x + bx * (W - 1), j0 = r.z + by * (H - 1);
     const int i = i0 + tcol;
     const int j = j0 + trow;
     const int nx = A.nx, ny = A.ny;
-    const int c = (j - 1) * nx + (i - 1);
+    const int cb = bz * (int)A.plane;             // first cell of the block in every (nx, ny, nblocks) array
+    const int c = cb + (j - 1) * nx + (i - 1);
     const int li = (trow + 1) * LW + (tcol + 1);   // this cell in the LDS velocity tile
     const unsigned flags = A.flags;
     const bool water = !(flags & EVP_F_WATER_IS_OCN);
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             const int gi = i0 + pc, gj = j0 + pr;
             double uu = 0.0, vv = 0.0;
             if (gi >= 1 && gi <= nx && gj >= 1 && gj <= ny) {
-                const int cp = (gj - 1) * nx + (gi - 1);
+                const int cp = cb + (gj - 1) * nx + (gi - 1);
                 uu = u0[cp]; vv = v0[cp];
             }
             s_u[q] = uu; s_v[q] = vv;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // of a pair, 3: pole point; partner = the other cell of the pair
     int seam_role = 0, seam_partner = -1;
     if (R.seam && ownU && j == r.w) {
-        const int sv = R.seam[i - 1];
+        const int sv = R.seam[bz * nx + i - 1];
         seam_role = sv & 3;
         seam_partner = sv >> 2;
     }
@@ -511,7 +514,7 @@ void evp_launch_resident2(const EvpArgs &A0, const EvpResident2 &R, int max_ni, 
 {
     EvpArgs A = A0;
     evp_resident_geometry(max_ni, max_nj, logw, &A.gx, &A.gy);
-    A.ntiles = A.gx * A.gy;
+    A.ntiles = A.gx * A.gy * (R.nblocks > 0 ? R.nblocks : 1);
     const bool remote = R.rimg != nullptr;
     if (remote) {
         if (logw == 4) launch<4, true>(A, R, strict, cap, st);
