@@ -97,8 +97,7 @@ struct EvpResident2 {
     int par0;                  // which of rec[0/1] holds the records of subcycle index 0 of THIS launch
                                // (flips so that a launch never starts in the buffer the previous one ended in)
     // neighbours on other GPUs (ring entries with z == -2 are produced there); rimg == NULL: none
-    const int2 *rimg;          // [2*(rimg_nj+rimg_ni)] edge slots x 2: {peer index, ghost cell at that peer}, x = -1 none
-    int rimg_ni, rimg_nj;
+    const int2 *rimg;          // [ncell][3] images on other ranks: {peer index, ghost cell at that peer}, x = -1 none
     void *const *peer_rec;     // [npeers] the peer's record buffer (parity 0) as mapped here
     const size_t *peer_rstride;// [npeers] bytes between the two parities of that buffer
     unsigned long long timeout_ticks;   // bound of a wait on another rank (100 MHz wall clock)

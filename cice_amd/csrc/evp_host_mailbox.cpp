@@ -41,7 +41,7 @@ int direct_export(HaloBlob &B)
                     !(env("CICE_EVP_HIP_RESIDENT") && std::atoi(env("CICE_EVP_HIP_RESIDENT")) == 0) &&
                     !(env("CICE_EVP_HIP_RES_REMOTE") && std::atoi(env("CICE_EVP_HIP_RES_REMOTE")) == 0);
     size_t rec_off = 0;
-    const size_t rec_stride = S.plane * 32;
+    const size_t rec_stride = S.n * 32;            // one 32-byte record pair per cell of every block
     if (!X.mailbox) {
         X.inbox_off = DIRECT_INBOX_OFF;
         X.bytes = X.inbox_off + 2 * 2 * (size_t)std::max(S.n_recv, 1) * sizeof(double);
@@ -152,9 +152,7 @@ int direct_import(const HaloBlob *blobs, int nranks)
     if (all_res && np > 0) {
         std::vector<void *> prec((size_t)np);
         std::vector<size_t> pstr((size_t)np);
-        const int nslot = 2 * (S.max_nj + S.max_ni);
-        std::vector<int2> rimg((size_t)nslot * 2, make_int2(-1, -1));
-        const int nx = S.d.nx_block;
+        std::vector<int2> rimg(S.n * 3, make_int2(-1, -1));     // per cell: up to three images on other ranks
         bool ok = true;
         for (int q = 0; q < np && ok; ++q) {
             const HaloPeer &p = S.plan.peers[q];
@@ -167,21 +165,11 @@ int direct_import(const HaloBlob *blobs, int nranks)
                 prec[q] = dummy;                             // (leaked on purpose: test processes only)
             }
             for (size_t k = 0; k < p.send_src.size() && ok; ++k) {
-                const int rem = (int)(p.send_src[k] % S.plane);
-                const int j = rem / nx + 1, i = rem % nx + 1;
-                const int cand[4] = {(i == S.ilo[0]) ? (j - S.jlo[0]) : -1,
-                                     (i == S.ihi[0]) ? S.max_nj + (j - S.jlo[0]) : -1,
-                                     (j == S.jlo[0]) ? 2 * S.max_nj + (i - S.ilo[0]) : -1,
-                                     (j == S.jhi[0]) ? 2 * S.max_nj + S.max_ni + (i - S.ilo[0]) : -1};
-                bool placed = false;
-                for (int e = 0; e < 4 && !placed; ++e) {
-                    if (cand[e] < 0) continue;
-                    for (int w = 0; w < 2 && !placed; ++w) {
-                        int2 &slot = rimg[(size_t)cand[e] * 2 + w];
-                        if (slot.x < 0) { slot = make_int2(q, p.send_dst[k]); placed = true; }
-                    }
-                }
-                ok = placed;
+                const size_t c = (size_t)p.send_src[k];
+                int e = 0;
+                while (e < 3 && rimg[c * 3 + e].x >= 0) ++e;
+                if (e == 3) { ok = false; break; }
+                rimg[c * 3 + e] = make_int2(q, p.send_dst[k]);
             }
         }
         if (ok) {
@@ -259,14 +247,15 @@ int resident_remote_probe()
 {
     std::vector<double> hu(S.n, 0.0), hv(S.n, 0.0);
     const int nx = S.d.nx_block;
-    for (int j = S.jlo[0]; j <= S.jhi[0]; ++j)
-        for (int i = S.ilo[0]; i <= S.ihi[0]; ++i) {
-            const size_t c = (size_t)(j - 1) * nx + (i - 1);
-            const double gid = (double)((S.iglob0[0] + (i - S.ilo[0]) - 1) +
-                                        (size_t)S.d.nx_global * (S.jglob0[0] + (j - S.jlo[0]) - 1));
-            hu[c] = gid + 1.0;
-            hv[c] = -2.0 * (gid + 1.0);
-        }
+    for (int blk = 0; blk < S.d.nblocks; ++blk)
+        for (int j = S.jlo[blk]; j <= S.jhi[blk]; ++j)
+            for (int i = S.ilo[blk]; i <= S.ihi[blk]; ++i) {
+                const size_t c = blk * S.plane + (size_t)(j - 1) * nx + (i - 1);
+                const double gid = (double)((S.iglob0[blk] + (i - S.ilo[blk]) - 1) +
+                                            (size_t)S.d.nx_global * (S.jglob0[blk] + (j - S.jlo[blk]) - 1));
+                hu[c] = gid + 1.0;
+                hv[c] = -2.0 * (gid + 1.0);
+            }
     for (int b = 0; b < 2; ++b) {
         HIPC(hipMemcpyAsync(S.u[b], hu.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
         HIPC(hipMemcpyAsync(S.v[b], hv.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));

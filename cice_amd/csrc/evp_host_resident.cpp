@@ -12,7 +12,6 @@ bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0; }
 bool resident_possible(bool with_peers)
 {
     if (!with_peers && !S.plan.peers.empty()) return false;
-    if (with_peers && S.d.nblocks != 1) return false;       // remote images are looked up per edge of ONE block
     if (tripole_seam() || S.d.nblocks > 1) {
         // tagged-record kernel only: the fold row is averaged inside the kernel, ghost images come
         // from a per-cell table (at most three per cell, no eliminated source block)
@@ -276,7 +275,6 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.rec_raw[0] = S.res2_rec_raw[0];
     R.rec_raw[1] = S.res2_rec_raw[1];
     R.rimg = S.res_remote ? S.res2_rimg : nullptr;
-    R.rimg_ni = S.max_ni; R.rimg_nj = S.max_nj;
     R.peer_rec = S.res2_peer_rec;
     R.peer_rstride = S.res2_peer_rstride;
     static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;

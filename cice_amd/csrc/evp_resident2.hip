@@ -216,23 +216,16 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     char *rp0 = nullptr, *rp1 = nullptr, *rp2 = nullptr;
     size_t rs0 = 0, rs1 = 0, rs2 = 0;
     if (REMOTE) {
-        if (ownU && (i == r.x || i == r.y || j == r.z || j == r.w)) {
-            const int slots[4] = {(i == r.x) ? (j - r.z) : -1, (i == r.y) ? R.rimg_nj + (j - r.z) : -1,
-                                  (j == r.z) ? 2 * R.rimg_nj + (i - r.x) : -1,
-                                  (j == r.w) ? 2 * R.rimg_nj + R.rimg_ni + (i - r.x) : -1};
+        if (ownU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (slots[e] < 0) continue;
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const int2 v = R.rimg[slots[e] * 2 + w];
-                    if (v.x < 0) continue;
-                    char *ptr = (char *)R.peer_rec[v.x] + 32 * (size_t)v.y;
-                    const size_t st = R.peer_rstride[v.x];
-                    if (!rp0) { rp0 = ptr; rs0 = st; }
-                    else if (!rp1) { rp1 = ptr; rs1 = st; }
-                    else { rp2 = ptr; rs2 = st; }
-                }
+            for (int e = 0; e < 3; ++e) {
+                const int2 v = R.rimg[3 * (size_t)c + e];      // per-cell table: {peer index, ghost cell at that peer}
+                if (v.x < 0) continue;
+                char *ptr = (char *)R.peer_rec[v.x] + 32 * (size_t)v.y;
+                const size_t st = R.peer_rstride[v.x];
+                if (!rp0) { rp0 = ptr; rs0 = st; }
+                else if (!rp1) { rp1 = ptr; rs1 = st; }
+                else { rp2 = ptr; rs2 = st; }
             }
         }
     }

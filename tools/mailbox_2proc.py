@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--ndte", type=int, default=24)
     ap.add_argument("--timing", action="store_true")
     ap.add_argument("--shape", default="")          # e.g. 2x1
+    ap.add_argument("--blocks-per-rank", default="", help="e.g. 2x2: split every rank's sub-domain into CICE blocks")
     ap.add_argument("--soak", type=int, default=0, help="N more launches of 120 subcycles before the comparison")
     ap.add_argument("--prep", action="store_true",
                     help="start from the primary model state: evp()'s preparation phase on the device on every "
@@ -101,6 +102,10 @@ def main():
     ref, _, _ = run(decomp.single_block(nx, ny, "cyclic", ns_bnd), 0, False)
     shape = tuple(int(v) for v in a.shape.split("x")) if a.shape else None
     dcN = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns_bnd, proc_shape=shape)
+    if a.blocks_per_rank:
+        sx, sy = (int(v) for v in a.blocks_per_rank.split("x"))
+        dcN = decomp.Decomp(nx, ny, -(-dcN.block_size_x // sx), -(-dcN.block_size_y // sy), "cyclic", ns_bnd, world,
+                            dcN.proc_shape)
     got, tim, t_us = run(dcN, rank, True)
     assert tim["halo_transport"] == "mailbox", tim
     bad = []
