@@ -7,10 +7,12 @@ import numpy as np
 from cice_amd import evp, synth, decomp
 wl = sys.argv[1] if len(sys.argv) > 1 else "gx1"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+case = sys.argv[3] if len(sys.argv) > 3 else "full"       # "caps": ice edges (tiles next to open water)
+bs = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else None
 spec = synth.GRIDS[wl]; nx, ny = spec["nx"], spec["ny"]; ns = spec.get("ns", "closed")
 g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
-st = synth.make_state(g, case="full", seed=5, warm=True)
-dc = decomp.single_block(nx, ny, "cyclic", ns)
+st = synth.make_state(g, case=case, seed=5, warm=True)
+dc = decomp.single_block(nx, ny, "cyclic", ns) if bs is None else decomp.Decomp(nx, ny, bs[0], bs[1], "cyclic", ns, 1)
 geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k != "uarear" else 0.0)) for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
 fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
 tm = dc.scatter(st["iceTmask"], 0, fill=0); um = dc.scatter(st["iceUmask"], 0, fill=0)
@@ -38,6 +40,6 @@ for r in range(reps):
     else:
         core.subcycle(120)
 core.sync()
-print("SOAK", wl, "reps", reps, "subcycles", reps * 120, "mismatches", bad, "seconds %.1f" % (time.time() - t0), "variant", core.timings()["tile_variant"])
+print("SOAK", wl, case, bs, "reps", reps, "subcycles", reps * 120, "mismatches", bad, "seconds %.1f" % (time.time() - t0), "variant", core.timings()["tile_variant"])
 core.finalize()
 sys.exit(1 if bad else 0)
