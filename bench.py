@@ -245,7 +245,9 @@ def main():
         t_kernel = tm_ev["marks_ms"] * 1e-3 / n_launch
         alg_bytes = B_ALG * my_cells * sub_per_launch
         achieved = alg_bytes / t_kernel / 1e9 if t_kernel > 0 else 0.0
-        kname = "evp_resident_tile" if resident else "evp_subcycle_tile"   # gen 1 (flags) and gen 2 (tagged records) share the profile key
+        kname = "evp_resident_tile" if resident else "evp_subcycle_tile"   # key in profiles/r01_gx1_pmc_traffic.json
+        # the kernel as rocprofv3 names it: gen 2 (tagged records) is tile_variant 20xx, gen 1 (flags) 10xx
+        kshown = ("evp_resident2_tile" if tm_ev["tile_variant"] >= 2000 else "evp_resident_tile") if resident else kname
         res = {
             "metric": "EVP subcycle cell-updates/sec (gx1 fp64)" if a.workload == "gx1"
                       else f"EVP subcycle cell-updates/sec ({a.workload} fp64)",
@@ -264,7 +266,7 @@ def main():
                        "finite": finite, "max_abs_u": umax},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, kname),
-                         "kernel": kname, "kernel_us": 1e6 * t_kernel,
+                         "kernel": kshown, "kernel_us": 1e6 * t_kernel,
                          "subcycles_per_launch": sub_per_launch,
                          "alg_bytes_per_launch": alg_bytes,
                          "achieved_active_cells_only": B_ALG * my_active * sub_per_launch / t_kernel / 1e9,
