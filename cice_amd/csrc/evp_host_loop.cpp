@@ -89,14 +89,15 @@ bool use_overlap()
 bool use_riding_exchange()
 {
     if (!S.direct.on || S.plan.peers.empty() || (S.n_seam + S.n_pole + S.n_late) > 0) return false;
-    // Pays when the interior tiles outlast the exchange (measured, 4 x 1800x1200 blocks: 571 us
-    // riding, 598 two streams, 627 separate kernel); on a domain that is one wave of workgroups
-    // there is nothing to overlap with and the separate kernel is quicker (gx1: 20.8 vs 25 us).
+    // Pays when the interior tiles outlast the exchange (measured per subcycle, riding vs separate
+    // kernel: 4 x 1800x1200 blocks 571 vs 627 us, 720x540 27.9 vs 34.1, 720x270 19.4 vs 22.1); on a
+    // domain that is one wave of workgroups there is nothing to overlap with and the separate kernel
+    // is quicker (gx1, 2 x 320x192: 25 vs 20.8 us).
     if (env("CICE_EVP_HIP_HALO_RIDE")) return std::atoi(env("CICE_EVP_HIP_HALO_RIDE")) != 0;
     size_t cells = 0;
     for (int b = 0; b < S.d.nblocks; ++b)
         cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);
-    return cells >= 400000;
+    return cells >= 160000;
 }
 
 // Which tiles of `variant` hold U-cells that some other rank mirrors (send list)?

@@ -24,6 +24,10 @@ GRIDS = {
     "gx1": dict(nx=320, ny=384, dx0=1.1e5, ns="closed"),
     "tx1": dict(nx=360, ny=240, dx0=1.1e5, ns="tripole"),
     "s01": dict(nx=3600, ny=2400, dx0=1.1e4, ns="closed"),   # synthetic 0.1-degree class
+    # per-rank pieces of a 0.25-degree class grid (1440x1080) on 8 and 4 GPUs: sizes just beyond what
+    # the on-chip resident kernel holds (tools/selfx_timing.py: where does the riding exchange pay?)
+    "q8": dict(nx=720, ny=270, dx0=2.8e4, ns="closed"),
+    "q4": dict(nx=720, ny=540, dx0=2.8e4, ns="closed"),
 }
 
 

@@ -7,8 +7,8 @@ import numpy as np
 from cice_amd import evp, synth, decomp
 from test_gpu_parity import synth_case
 wl = sys.argv[1] if len(sys.argv) > 1 else "gx1"
-bs = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else {"gx3": (100, 116), "gx1": (320, 192), "s01": (1800, 1200)}[wl]
-ndte = {"gx3": 120, "gx1": 120, "s01": 48}[wl]
+bs = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else {"gx3": (100, 116), "gx1": (320, 192), "s01": (1800, 1200), "q8": (720, 270), "q4": (720, 540)}[wl]
+ndte = {"gx3": 120, "gx1": 120, "s01": 48, "q8": 120, "q4": 120}[wl]
 scal = synth.evp_scalars(120)
 dc, geo, fields, tm, um = synth_case(wl, "full", seed=1, warm=True, bs=bs)
 d, keep = evp.make_dims(dc, 0)
