@@ -26,7 +26,7 @@ core = make(False)
 core.upload(fields, tm, um); core.subcycle(120); want = core.download(); core.finalize()
 core = make(True)
 core.upload(fields, tm, um)
-assert core.timings()["tile_variant"] >= 2000
+assert core.timings()["tile_variant"] >= 1000   # gen 1 (10xx) or gen 2 (20xx) resident kernel
 bad = 0
 t0 = time.time()
 for r in range(reps):
