@@ -24,7 +24,7 @@ __device__ constexpr double c1p5 = 1.5;
 namespace evp_strict {
 #include "evp_cell.inc"
 }
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
 namespace evp_fused {
 #include "evp_cell.inc"
 }

@@ -131,13 +131,10 @@ def test_synthetic_vs_oracle_strict_bitwise(grid, case, bs, warm):
 def test_gx1_decomposition_invariance_bitwise(monkeypatch):
     """1 block vs 4x4 blocks vs padded 7x5-ish blocks: identical interiors (the reference's
     own correctness criterion, ug_implementation.rst:715-716).  Strict build: across kernel
-    variants too (the single block runs the on-chip resident kernel, the others the streaming
-    kernel).  Fused build: the compiler contracts differently in different kernels, so
-    bit-for-bit invariance is a property of one kernel variant (streaming here)."""
+    variants too.  Fused build: contraction is per source expression (`fp contract(on)`), the same in
+    every kernel that inlines evp_cell.inc, so the invariance holds there as well."""
     scal = synth.evp_scalars(120)
     for strict in (True, False):
-        if not strict:
-            monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
         ref = None
         for bs in (None, (80, 96), (48, 80)):
             dc, geo, fields, tm, um = synth_case("gx1", "full", seed=1, warm=True, bs=bs)
@@ -484,7 +481,19 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
         cmd += ["--expect-resident", "--timing"]    # --timing: 5 x 120 + 7 more subcycles, launches back to back
     else:
         env["CICE_EVP_HIP_RESIDENT"] = "0"
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    # Several processes time-slicing ONE GPU is a stand-in for several GPUs, not a supported
+    # configuration: a run can trip over the previous test's processes still being torn down.  One
+    # retry (with a fresh rendezvous port); every failure is kept under gpurun_out/ for inspection.
+    for attempt in (1, 2):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout:
+            break
+        try:
+            (root / "gpurun_out").mkdir(exist_ok=True)
+            (root / "gpurun_out" / f"mailbox_fail_{world}_{workload}_{shape}_{attempt}.log").write_text(r.stdout + "\n---\n" + r.stderr)
+        except OSError:
+            pass
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
     assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
@@ -744,3 +753,27 @@ def test_resident_kernel_any_block_layout_golden(name, monkeypatch):
         assert core.timings()["tile_variant"] >= 2000
     finally:
         core.finalize()
+
+
+def test_fused_mode_is_kernel_invariant(monkeypatch):
+    """Fused mode (FMA contraction per source expression): the streaming kernel, both resident
+    kernels and every tile shape give the same bits -- a reproducible fast mode, within the stated
+    tolerance of the reference (not bit-identical to it)."""
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "caps", seed=8, warm=True)
+    ref = None
+    for envs in ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_TYB": "4"}, {"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_TYB": "108"},
+                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "1", "CICE_EVP_HIP_RES_LOGW": "5"},
+                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "4"},
+                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "6"}):
+        for k in ("CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_RES_GEN", "CICE_EVP_HIP_RES_LOGW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        out = run_hip(dc, geo, fields, tm, um, scal, strict=False, ndte=120)
+        if ref is None:
+            ref = out
+        else:
+            assert_bitwise(out, ref, f"fused mode, {envs}")
+    want = run_oracle(dc, geo, fields, tm, um, scal, 120)
+    assert 0 < max_rel_err(ref, want, VEL + SIG) < 1e-6      # it IS a different arithmetic, within tolerance
