@@ -442,116 +442,6 @@ def test_resident_remote_gx3_vs_oracle(monkeypatch):
     assert_bitwise(got, want, "gx3 resident kernel, every ghost through remote records (to self)")
 
 
-def _free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
-@pytest.mark.parametrize("world,workload,shape,resident", [(2, "gx3", "", True), (4, "gx3", "2x2", True),
-                                                           (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep"),
-                                                           (2, "tx1", "1x2", True), (8, "gx3", "2x4", True),
-                                                           (2, "gx3", "1x2", "blocks")])
-def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
-    """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
-    peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
-    the one GPU of this box, each owning one block; every rank's sub-domain, ghost cells
-    included, equals the single-rank run bit for bit (tools/mailbox_2proc.py)."""
-    import subprocess
-    import sys as _sys
-    root = Path(__file__).resolve().parents[1]
-    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           str(root / "tools" / "mailbox_2proc.py"), "--workload", workload, "--ndte", "24"]
-    if shape:
-        cmd += ["--shape", shape]
-    # gx3 pieces fit the one GPU several times over: the resident kernels of all ranks are
-    # co-resident and trade tagged records across process boundaries; gx1 halves do not fit
-    # twice, so that case pins the streaming kernel + mailbox exchange
-    env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
-    if resident == "blocks":
-        # several CICE blocks per rank AND neighbours on other ranks, resident kernel
-        cmd += ["--blocks-per-rank", "2x2", "--expect-resident", "--timing"]
-    elif resident == "prep":
-        # from the primary model state: evp()'s preparation phase on every rank, its T-grid halos
-        # crossing the ranks through the same transport, then the loop (f-2 on a split domain)
-        cmd += ["--prep", "--expect-resident"]
-    elif resident:
-        cmd += ["--expect-resident", "--timing"]    # --timing: 5 x 120 + 7 more subcycles, launches back to back
-    else:
-        env["CICE_EVP_HIP_RESIDENT"] = "0"
-    # Several processes time-slicing ONE GPU is a stand-in for several GPUs, not a supported
-    # configuration: a run can trip over the previous test's processes still being torn down.  One
-    # retry (with a fresh rendezvous port); every failure is kept under gpurun_out/ for inspection.
-    for attempt in (1, 2):
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-        if r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout:
-            break
-        try:
-            (root / "gpurun_out").mkdir(exist_ok=True)
-            (root / "gpurun_out" / f"mailbox_fail_{world}_{workload}_{shape}_{attempt}.log").write_text(r.stdout + "\n---\n" + r.stderr)
-        except OSError:
-            pass
-        cmd[cmd.index("--master-port") + 1] = str(_free_port())
-    assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
-
-
-@pytest.mark.parametrize("kind", ["no_ice", "one_cell", "one_column", "checkerboard"])
-@pytest.mark.parametrize("resident", [False, True])
-def test_degenerate_ice_covers_vs_oracle(kind, resident, monkeypatch):
-    """Edge cases of the index-list contract (dyn_prep2, ice_dyn_shared.F90:740-789): no ice
-    point at all, a single ice cell, one column of ice, ice on every other cell -- streaming
-    and resident kernels against the oracle, bit for bit, outputs off the masks untouched."""
-    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if resident else "0")
-    scal = synth.evp_scalars(120)
-    dc, geo, fields, tm, um = synth_case("gx3", "full", seed=13, warm=True)
-    keepT = np.zeros_like(tm)
-    if kind == "one_cell":
-        keepT[0, 60, 50] = 1
-    elif kind == "one_column":
-        keepT[0, :, 40] = 1
-    elif kind == "checkerboard":
-        jj, ii = np.meshgrid(np.arange(tm.shape[1]), np.arange(tm.shape[2]), indexing="ij")
-        keepT[0] = (ii + jj) % 2
-    tm2 = tm * keepT
-    um2 = um * keepT
-    f2 = {k: v.copy() for k, v in fields.items()}
-    for k in SIG:                      # dyn_prep2 zeroes the stresses off the T mask (:717-730)
-        f2[k][tm2 == 0] = 0.0
-    for k in VEL:                      # and the velocities off the U mask (:776-784)
-        f2[k][um2 == 0] = 0.0
-    got = run_hip(dc, geo, f2, tm2, um2, scal, strict=True, ndte=24)
-    want = run_oracle(dc, geo, f2, tm2, um2, scal, 24)
-    assert_bitwise(got, want, f"{kind} resident={resident}")
-    if kind == "no_ice":
-        for k in VEL + SIG:
-            assert not got[k].any(), k
-
-
-def test_s01_full_size_decomposition_and_transport_invariance(monkeypatch):
-    """configs[4] size (3600x2400 = 8.6M cells), 3 subcycles: one block == 2x2 blocks with the
-    ghost copies pushed in-kernel == 2x2 blocks with every ghost copy routed through the mailbox
-    exchange riding in the subcycle launch, bit for bit (size-independent property; the
-    oracle would need minutes at this size)."""
-    scal = synth.evp_scalars(480)
-    keys = VEL + ["stressp_1", "stressm_2", "stress12_3", "strintxU"]
-    ref = None
-    for bs, selfx in ((None, False), ((1800, 1200), False), ((1800, 1200), True)):
-        if selfx:
-            monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
-            monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
-        dc, geo, fields, tm, um = synth_case("s01", "full", seed=2, warm=True, bs=bs)
-        out = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=3, rccl_self=selfx)
-        glob = {k: dc.gather({0: out[k]}) for k in keys}
-        del out, fields
-        assert np.isfinite(glob["uvel"]).all() and np.abs(glob["uvel"]).max() > 1e-4
-        if ref is None:
-            ref = glob
-        else:
-            assert_bitwise(glob, ref, f"s01 blocks={bs} mailbox={selfx}")
-
-
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_next_tier_prep_on_device_bitwise(name):
     """evp()'s preparation phase on the device -- from the model state the
@@ -712,29 +602,6 @@ def test_resident_kernel_tripole_seam_bitwise(logw, monkeypatch):
         core.finalize()
 
 
-def test_bench_multi_rank_rehearsal():
-    """bench.py's N>1 path (decomposition, collective set-up, barrier + MAX-over-ranks timing, the
-    JSON line) rehearsed on the one GPU of this box: 2 ranks as 2 processes over gloo with the
-    mailbox halo bootstrapped by hand (CICE_EVP_BENCH_REHEARSAL=1; the driver's real N>1 runs use
-    RCCL and one GPU per rank)."""
-    import json
-    import subprocess
-    import sys as _sys
-    root = Path(__file__).resolve().parents[1]
-    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx3", "--no-secondary"]
-    env = dict(os.environ, CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["halo_transport"] == "mailbox" and d["config"]["finite"]
-    assert d["config"]["tile_variant"] >= 2000         # the resident kernel with remote neighbours
-    assert d["cpu_baseline"] is None and "roofline" in d
-
-
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_resident_kernel_any_block_layout_golden(name, monkeypatch):
     """The on-chip resident kernel forced on every fixture -- 1, 4, 6 (padded) and 12 blocks per
@@ -777,3 +644,58 @@ def test_fused_mode_is_kernel_invariant(monkeypatch):
             assert_bitwise(out, ref, f"fused mode, {envs}")
     want = run_oracle(dc, geo, fields, tm, um, scal, 120)
     assert 0 < max_rel_err(ref, want, VEL + SIG) < 1e-6      # it IS a different arithmetic, within tolerance
+
+
+@pytest.mark.parametrize("kind", ["no_ice", "one_cell", "one_column", "checkerboard"])
+@pytest.mark.parametrize("resident", [False, True])
+def test_degenerate_ice_covers_vs_oracle(kind, resident, monkeypatch):
+    """Edge cases of the index-list contract (dyn_prep2, ice_dyn_shared.F90:740-789): no ice
+    point at all, a single ice cell, one column of ice, ice on every other cell -- streaming
+    and resident kernels against the oracle, bit for bit, outputs off the masks untouched."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if resident else "0")
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "full", seed=13, warm=True)
+    keepT = np.zeros_like(tm)
+    if kind == "one_cell":
+        keepT[0, 60, 50] = 1
+    elif kind == "one_column":
+        keepT[0, :, 40] = 1
+    elif kind == "checkerboard":
+        jj, ii = np.meshgrid(np.arange(tm.shape[1]), np.arange(tm.shape[2]), indexing="ij")
+        keepT[0] = (ii + jj) % 2
+    tm2 = tm * keepT
+    um2 = um * keepT
+    f2 = {k: v.copy() for k, v in fields.items()}
+    for k in SIG:                      # dyn_prep2 zeroes the stresses off the T mask (:717-730)
+        f2[k][tm2 == 0] = 0.0
+    for k in VEL:                      # and the velocities off the U mask (:776-784)
+        f2[k][um2 == 0] = 0.0
+    got = run_hip(dc, geo, f2, tm2, um2, scal, strict=True, ndte=24)
+    want = run_oracle(dc, geo, f2, tm2, um2, scal, 24)
+    assert_bitwise(got, want, f"{kind} resident={resident}")
+    if kind == "no_ice":
+        for k in VEL + SIG:
+            assert not got[k].any(), k
+
+
+def test_s01_full_size_decomposition_and_transport_invariance(monkeypatch):
+    """configs[4] size (3600x2400 = 8.6M cells), 3 subcycles: one block == 2x2 blocks with the
+    ghost copies pushed in-kernel == 2x2 blocks with every ghost copy routed through the mailbox
+    exchange riding in the subcycle launch, bit for bit (size-independent property; the
+    oracle would need minutes at this size)."""
+    scal = synth.evp_scalars(480)
+    keys = VEL + ["stressp_1", "stressm_2", "stress12_3", "strintxU"]
+    ref = None
+    for bs, selfx in ((None, False), ((1800, 1200), False), ((1800, 1200), True)):
+        if selfx:
+            monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+            monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
+        dc, geo, fields, tm, um = synth_case("s01", "full", seed=2, warm=True, bs=bs)
+        out = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=3, rccl_self=selfx)
+        glob = {k: dc.gather({0: out[k]}) for k in keys}
+        del out, fields
+        assert np.isfinite(glob["uvel"]).all() and np.abs(glob["uvel"]).max() > 1e-4
+        if ref is None:
+            ref = glob
+        else:
+            assert_bitwise(glob, ref, f"s01 blocks={bs} mailbox={selfx}")
