@@ -85,8 +85,8 @@ int resident_setup(int logw)
     HIPC(hipMemcpy(S.res_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPC(hipMalloc((void **)&S.res_flags, (size_t)ntiles * sizeof(int)));
     if (!S.res_err) {
-        HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
-        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+        HIPC(hipMalloc((void **)&S.res_err, 8 * sizeof(int)));
+        HIPC(hipMemset(S.res_err, 0, 8 * sizeof(int)));
     }
     return 0;
 }
@@ -199,8 +199,8 @@ int resident2_setup(int logw)
             HIPC(hipMemset(p, 0, ncell * 32));
         }
     if (!S.res_err) {
-        HIPC(hipMalloc((void **)&S.res_err, sizeof(int)));
-        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+        HIPC(hipMalloc((void **)&S.res_err, 8 * sizeof(int)));
+        HIPC(hipMemset(S.res_err, 0, 8 * sizeof(int)));
     }
     return 0;
 }
@@ -358,14 +358,18 @@ int resident_check_error()
 {
     if (!S.res_launched) return 0;
     S.res_launched = false;
-    int e = 0;
-    HIPC(hipMemcpy(&e, S.res_err, sizeof(int), hipMemcpyDeviceToHost));
+    int ev[8] = {0};
+    HIPC(hipMemcpy(ev, S.res_err, sizeof ev, hipMemcpyDeviceToHost));
+    const int e = ev[0];
     if (e) {
-        HIPC(hipMemset(S.res_err, 0, sizeof(int)));
+        HIPC(hipMemset(S.res_err, 0, sizeof ev));
         S.res_mode = 0;
-        if (e == 2)
-            return fail(-7, "resident EVP kernel: a record of another rank never arrived within the time-out "
-                            "(CICE_EVP_HIP_HALO_TIMEOUT_MS)");
+        if (S.res_gen == 2)
+            return fail(-7, "resident EVP kernel: a wait gave up (%s; tile %d, subcycle %d, cell %d, tag seen %#x, wanted %#x)%s",
+                        e == 1 ? "record of this GPU" : e == 2 ? "record of another rank" : e == 3 ? "fold-row partner" : "?",
+                        ev[1], ev[2], ev[3], (unsigned)ev[4], (unsigned)ev[5],
+                        e == 2 ? " -- CICE_EVP_HIP_HALO_TIMEOUT_MS bounds the wait for other ranks"
+                               : " -- workgroups not co-resident?");
         return fail(-7, "resident EVP kernel: a neighbour-flag wait timed out (workgroups not co-resident?)");
     }
     return 0;

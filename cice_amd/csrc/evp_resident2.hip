@@ -238,6 +238,13 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         if (e.z >= 0) { ring_cp = e.x; ring_li = e.y; }      // has a producer on this GPU: refreshed every subcycle
         if (REMOTE && e.z == -2) { ring_cp = e.x; ring_li = e.y; ring_remote = true; }   // produced on another rank
     }
+    // first wait that gives up records where and on what: err[0] kind (1 ring of this GPU, 2 ring of
+    // another rank, 3 fold-row partner, 4 final ghosts), [1] tile, [2] subcycle, [3] cell, [4] tag seen, [5] tag wanted
+    auto give_up_note = [&](int kind, int k, int cell, unsigned seen, unsigned wanted) {
+        if (atomicCAS(R.err, 0, kind) == 0) {
+            R.err[1] = tile; R.err[2] = k; R.err[3] = cell; R.err[4] = (int)seen; R.err[5] = (int)wanted;
+        }
+    };
     auto publish_remote = [&](int par, double uu, double vv, unsigned tag) {
         const v4u a = pack_rec(uu, tag), b = pack_rec(vv, tag);
         st_rec2_sys(rp0 + (size_t)par * rs0, a, b);
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             if ((++spins & 255u) == 0 &&
                 (wall_clock64() - t0 > R.timeout_ticks ||
                  __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                atomicCAS(R.err, 0, 2);
+                give_up_note(2, (int)(want - R.tag_base), ring_cp, ra.x, want);
                 return false;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                 // a local neighbour may itself be waiting for another rank: with remote neighbours
                 // every wait is bounded by wall-clock time, not by a spin count
                 if (gave_up(++spins, t_wait0)) {
-                    __hip_atomic_store(R.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    give_up_note(1, k, ring_cp, ra.x, want);
                     s_bad = 1;
                     break;
                 }
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                     ld_rec2(rw + 2 * (size_t)seam_partner, ra, rb);
                     if (ra.x == tag && ra.w == tag && rb.x == tag && rb.w == tag) break;
                     if (gave_up(++spins, t_wait0)) {
-                        __hip_atomic_store(R.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        give_up_note(3, k, seam_partner, ra.x, tag);
                         ok = false;
                         break;
                     }
