@@ -401,6 +401,20 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
                           (double *)vvel_init};
     if (int rc = cice_evp_hip_upload(f, iceTmask, iceUmask)) return rc;
     if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
+    if (S.res_mode == 1 && S.plan.peers.empty()) {
+        // The resident kernel assumes the GPU to itself.  If that did not hold (another process or a
+        // long kernel on the device: a wait gave up), nothing has been written back yet and the
+        // caller's inputs are intact: run the call again with the streaming kernel, and keep to it.
+        HIPC(hipStreamSynchronize(S.stream));
+        if (resident_check_error() != 0) {
+            if (env("CICE_EVP_HIP_VERBOSE"))
+                std::fprintf(stderr, "[cice_evp_hip] %s -- repeating the call with the streaming kernel\n", g_err.c_str());
+            g_err.clear();
+            ++S.res_fallbacks;
+            if (int rc = cice_evp_hip_upload(f, iceTmask, iceUmask)) return rc;
+            if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
+        }
+    }
     // only the documented outputs travel back
     double *o[F_COUNT] = {};
     for (int k = 0; k < 12; ++k) o[k] = f[k];
@@ -419,13 +433,13 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     if (S.ready && S.marked[0] && S.marked[1] && hipEventQuery(S.evm[1]) == hipSuccess &&
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
-    const double v[11] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+    const double v[12] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
                          (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
-                          S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms};
-    for (int k = 0; k < n && k < 11; ++k) out[k] = v[k];
+                          S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms, (double)S.res_fallbacks};
+    for (int k = 0; k < n && k < 12; ++k) out[k] = v[k];
     return 0;
 }
 

@@ -93,7 +93,7 @@ struct EvpResident2 {
     double *const *tab;        // as EvpResident::tab
     int nblocks;               // CICE blocks of this rank (tiles = nblocks x gx x gy)
     const int *order;          // [ntiles] tile run by workgroup w (NULL: identity)
-    int dbg;                   // timing experiments only (CICE_EVP_HIP_RES_DEBUG; WRONG results): 1 no tag check, 2 no ring loads, 4 longer sleep; 8 = every fourth tile lags 10 us per subcycle (results stay right)
+    int dbg;                   // timing experiments only (CICE_EVP_HIP_RES_DEBUG; WRONG results): 1 no tag check, 2 no ring loads, 4 longer sleep; 8 = every fourth tile lags 10 us per subcycle (results stay right); 16 = tile 1 never runs (every wait on it gives up)
     int par0;                  // which of rec[0/1] holds the records of subcycle index 0 of THIS launch
                                // (flips so that a launch never starts in the buffer the previous one ended in)
     // neighbours on other GPUs (ring entries with z == -2 are produced there); rimg == NULL: none

@@ -181,6 +181,7 @@ struct State {
     void **res2_peer_rec = nullptr;
     size_t *res2_peer_rstride = nullptr;
     bool res_launched = false;   // an un-checked launch is in flight
+    int res_fallbacks = 0;       // calls repeated with the streaming kernel after a resident launch gave up
     double t_res_probe_ms = 0, t_stream_probe_ms = 0;
 
     double t_loop_ms = 0, t_h2d_ms = 0, t_d2h_ms = 0;

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // launch order = heaviest tiles first (host-sorted by ice-covered cells): the workgroups that
     // end up third on a CU are then the cheap ones (land, partial edge tiles)
     const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
+    if ((R.dbg & 16) && tile == 1 && !R.dry) return;   // test hook: one workgroup "never becomes resident" (after the probes)
     const int per_blk = A.gx * A.gy;
     const int bz = tile / per_blk;                // CICE block of this rank
     const int bx = (tile % per_blk) % A.gx;

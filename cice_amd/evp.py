@@ -262,11 +262,11 @@ class EvpHip:
         return out
 
     def timings(self) -> dict:
-        t = np.zeros(11)
-        self.lib.cice_evp_hip_get_timings(_dp(t), 11)
+        t = np.zeros(12)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 12)
         return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4],
                     tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
-                    halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10])
+                    halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10], resident_fallbacks=int(t[11]))
 
     def stress_halo(self):
         """Tripole: 12 x ice_HaloUpdate_stress on the resident stresses (ice_dyn_evp.F90:1321-1389)."""

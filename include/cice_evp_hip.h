@@ -224,7 +224,8 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen);
  * [6]=ms between cice_evp_hip_mark(0) and cice_evp_hip_mark(1), -1 if unset,
  * [7]=streaming probe ms/subcycle, [8]=resident probe ms/subcycle,
  * [9]=remote halo transport: 0 none, 1 RCCL p2p, 2 mailbox (direct stores over xGMI),
- * [10]=device time of the last cice_evp_hip_prep (kernels + halos, without the copies), ms      */
+ * [10]=device time of the last cice_evp_hip_prep (kernels + halos, without the copies), ms,
+ * [11]=cice_evp_hip_run calls repeated with the streaming kernel after the resident one gave up  */
 int cice_evp_hip_get_timings(double *out, int32_t n);
 /* Halo plan of this rank, for tests: counts[0]=local copies, [1]=#peers,
  * [2]=total send cells, [3]=total recv cells.  Lists may be NULL.

@@ -699,3 +699,27 @@ def test_s01_full_size_decomposition_and_transport_invariance(monkeypatch):
             ref = glob
         else:
             assert_bitwise(glob, ref, f"s01 blocks={bs} mailbox={selfx}")
+
+
+def test_run_recovers_when_the_resident_kernel_cannot_be_resident(monkeypatch):
+    """cice_evp_hip_run on a GPU that is not the rank's alone: a workgroup of the resident kernel
+    never runs (test hook, real launches only -- the probes pass), the waits on its records give up
+    (bounded), nothing has been written back -- the call is repeated with the streaming kernel and
+    returns the oracle's answer; later calls stay on the streaming kernel."""
+    monkeypatch.setenv("CICE_EVP_HIP_RES_DEBUG", "16")
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "full", seed=31, warm=True)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 24)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        got = core.run(fields, tm, um, ndte=24)
+        t = core.timings()
+        assert t["resident_fallbacks"] == 1 and t["tile_variant"] < 1000, t
+        assert_bitwise(got, want, "after the fall-back")
+        got = core.run(fields, tm, um, ndte=24)
+        assert core.timings()["resident_fallbacks"] == 1
+        assert_bitwise(got, want, "next call (streaming kernel)")
+    finally:
+        core.finalize()
