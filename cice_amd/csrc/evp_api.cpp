@@ -228,7 +228,7 @@ int cice_evp_hip_subcycle(int32_t ndte)
         return 0;
     }
     // RCCL p2p inside a captured graph: opt-in (CICE_EVP_HIP_GRAPH_RCCL=1) until measured on a multi-GPU node
-    static const bool graph_rccl = env("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env("CICE_EVP_HIP_GRAPH_RCCL"));
+    const bool graph_rccl = env("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env("CICE_EVP_HIP_GRAPH_RCCL"));
     const bool graph_ok = S.use_graph && (S.plan.peers.empty() || graph_rccl || S.direct.on);
     if (graph_ok) {
         const auto key = std::make_pair((int)ndte, S.cur);

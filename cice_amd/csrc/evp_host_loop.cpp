@@ -20,10 +20,10 @@ void fill_direct(EvpDirect &D)
     D.seq = (unsigned *)(base + DIRECT_SEQ_OFF);
     D.err = (int *)(base + DIRECT_ERR_OFF);
     D.inbox = (double *)(base + X.inbox_off);
-    static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
+    const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
     D.timeout_ticks = (unsigned long long)(tmo_ms * 1.0e5);     // 100 MHz wall clock
     D.peer_flag = X.peer_flag;
-    static const int dbg = env("CICE_EVP_HIP_HALO_DEBUG") ? std::atoi(env("CICE_EVP_HIP_HALO_DEBUG")) : 0;
+    const int dbg = env("CICE_EVP_HIP_HALO_DEBUG") ? std::atoi(env("CICE_EVP_HIP_HALO_DEBUG")) : 0;
     D.dbg = dbg;
 }
 

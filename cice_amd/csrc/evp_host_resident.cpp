@@ -221,7 +221,7 @@ bool resident2_fits(bool remote)
 // masks or the tile shape change; CICE_EVP_HIP_RES_ORDER=0 keeps the natural order.
 int resident2_order()
 {
-    static const bool off = env("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env("CICE_EVP_HIP_RES_ORDER"));
+    const bool off = env("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env("CICE_EVP_HIP_RES_ORDER"));
     if (off) return 0;
     if (S.res2_order && !S.res2_order_stale && S.res2_order_for == S.res2_logw) return 0;
     const int W = 1 << S.res2_logw, H = 256 / W;
@@ -268,7 +268,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
     S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
     R.nblocks = S.d.nblocks;
     R.order = S.res2_order;
-    static const int dbg2 = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
+    const int dbg2 = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.dbg = dbg2;
     R.seam = S.res2_seam;
     R.img3 = S.res2_img3;
@@ -277,7 +277,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.rimg = S.res_remote ? S.res2_rimg : nullptr;
     R.peer_rec = S.res2_peer_rec;
     R.peer_rstride = S.res2_peer_rstride;
-    static const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
+    const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
     R.timeout_ticks = (unsigned long long)((S.res_timeout_ms > 0 ? S.res_timeout_ms : tmo_ms) * 1.0e5);
     R.spin_limit = 4000000u;
     R.err = S.res_err;
