@@ -34,7 +34,8 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
 {
     if (!dims || !params || !HTE || !HTN || !dxT || !dyT || !uarear || !tarea)
         return fail(-1, "cice_evp_hip_init: null argument");
-    if (S.ready) cice_evp_hip_finalize();
+    // also after an init that failed midway (S.ready still false): release whatever it had created
+    cice_evp_hip_finalize();
     if (dims->nghost != 1) return fail(-1, "nghost must be 1");
     if (dims->nblocks < 1 || dims->nblocks > dims->max_blocks) return fail(-1, "bad nblocks/max_blocks");
 
@@ -231,7 +232,7 @@ int cice_evp_hip_subcycle(int32_t ndte)
     const bool graph_rccl = env("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env("CICE_EVP_HIP_GRAPH_RCCL"));
     const bool graph_ok = S.use_graph && (S.plan.peers.empty() || graph_rccl || S.direct.on);
     if (graph_ok) {
-        const auto key = std::make_pair((int)ndte, S.cur);
+        const auto key = std::make_tuple((int)ndte, S.cur, S.flags & S.flags_allowed);
         auto it = S.graphs.find(key);
         if (it == S.graphs.end()) {
             hipGraph_t g = nullptr;
@@ -485,6 +486,18 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3)
     out3[1] = S.n_local > 0 ? sum[1] / nrep : 0.0;
     out3[2] = ms / nrep;
     for (auto &e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+// Per-CU record of the last resident launch (16 x 16 tiles): 2048 CUs x {lock, stamp, ice-holding waves
+// on SIMD 0..3, 0, 0}; for tools that check how evenly the workgroups spread their waves.
+int cice_evp_hip_debug_cuload(int32_t *out, int32_t n)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!S.res2_cuload) return fail(-1, "no resident launch with 16 x 16 tiles yet");
+    if (!out || n < 0 || n > 2048 * 8) return fail(-1, "bad argument");
+    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemcpy(out, S.res2_cuload, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

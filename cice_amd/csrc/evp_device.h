@@ -93,6 +93,12 @@ struct EvpResident2 {
     double *const *tab;        // as EvpResident::tab
     int nblocks;               // CICE blocks of this rank (tiles = nblocks x gx x gy)
     const int *order;          // [ntiles] tile run by workgroup w (NULL: identity)
+    // 16 x 16 tiles only (rim wave / interior waves, see evp_resident2.hip): which T-cell of the tile a
+    // thread owns, the T-cells that read ring velocities first; how many waves hold such cells / ring entries
+    const uint8_t *perm;       // [ntiles][256] cell position trow*16 + tcol of (permuted) thread index
+    const uint8_t *late_waves; // [ntiles]
+    const uint8_t *nact;       // [ntiles] chunks (64 entries of perm) that hold ice cells: the first nact
+    int *cuload;               // [2048][8] per-CU record of the launch: lock, stamp, ice-holding waves per SIMD
     int dbg;                   // timing experiments only (CICE_EVP_HIP_RES_DEBUG; WRONG results): 1 no tag check, 2 no ring loads, 4 longer sleep; 8 = every fourth tile lags 10 us per subcycle (results stay right); 16 = tile 1 never runs (every wait on it gives up)
     int par0;                  // which of rec[0/1] holds the records of subcycle index 0 of THIS launch
                                // (flips so that a launch never starts in the buffer the previous one ended in)
@@ -144,6 +150,7 @@ struct EvpPrep {
     double *aiU, *cdn_ocnU, *uocnU, *vocnU, *umassdti, *fm, *waterx, *watery, *forcex, *forcey;
     double *uvel_init, *vvel_init, *uvel, *vvel;
     double *sig[12];
+    double *strintx, *strinty, *taubx, *tauby;   // zeroed as dyn_prep2 does (:704-712 everywhere, :776-781 off the ice)
     uint8_t *mask;             // out: bit0 iceTmask, bit1 iceUmask
     unsigned *flagword;        // out: bit0 = waterx/watery differ from uocnU/vocnU somewhere
     double dt, rhoi, rhos, gravit, dyn_area_min, dyn_mass_min, cosw, sinw;

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/cice_evp_hip.h"
@@ -150,7 +151,10 @@ struct State {
         std::string why;             // why it is off
     } direct;
 
-    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, cur) -> captured loop
+    // captured loops.  A capture stores the kernel arguments BY VALUE, so everything a launch bakes in
+    // that can change between calls is part of the key: (ndte, cur) and the EVP_F_* flags in effect
+    // (TBU_ZERO / WATER_IS_OCN are re-derived from the data at every upload / prep)
+    std::map<std::tuple<int, int, unsigned>, hipGraphExec_t> graphs;
     bool use_graph = true;
 
     // on-chip resident subcycle (evp_resident.hip)
@@ -164,6 +168,11 @@ struct State {
     int4 *res2_ring = nullptr;
     int *res2_cnt = nullptr;
     uint8_t *res2_pub = nullptr;
+    // 16 x 16 tiles (rim wave / interior waves): thread -> cell map, waves that wait for the ring, chunks with ice
+    uint8_t *res2_perm = nullptr, *res2_late = nullptr, *res2_nact = nullptr;
+    int *res2_cuload = nullptr;                           // per-CU record of a launch (EvpResident2::cuload)
+    std::vector<uint8_t> res2_cls_h;                      // per tile and cell position: 0 not computed, 1 reads no ring velocity, 2 does
+    std::vector<int> res2_cnt_h;                          // ring entries per tile (host copy)
     void *res2_rec[2] = {nullptr, nullptr};
     int res2_logw = 0, res2_ntiles = 0;
     unsigned res2_epoch = 0;

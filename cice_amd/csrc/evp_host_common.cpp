@@ -46,7 +46,7 @@ void free_all()
     F(S.htn);
     F(S.vrelfac);
     F(S.res_flags); F(S.res_nbr); F(S.res_err); F(S.res_tab);
-    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub);
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact); F(S.res2_cuload);
     if (S.res2_rec_owned) { F(S.res2_rec[0]); F(S.res2_rec[1]); }
     S.res2_rec[0] = S.res2_rec[1] = nullptr;
     S.res2_rec_owned = true;
@@ -299,8 +299,15 @@ void fill_args(EvpArgs &A, int cur, int last)
     A.taubx = S.in[F_TAUBX]; A.tauby = S.in[F_TAUBY];
 }
 
+// Arithmetic variant of the kernels (template MODE, evp_math.h): 3 = capping == 1 and the reference's
+// default scalars -- classic EVP (revp == 0), Ktens == 0, cosw == 1, sinw == 0 -- whose products with
+// exactly 1.0 / sums with exactly 0.0 the kernels then leave out, bit-neutral (CICE_EVP_HIP_SIMPLE=0: off)
 int cap_mode()
 {
+    const bool simple_ok = !(env("CICE_EVP_HIP_SIMPLE") && !std::atoi(env("CICE_EVP_HIP_SIMPLE")));
+    if (simple_ok && S.prm.capping == 1.0 && S.prm.revp == 0.0 && S.prm.Ktens == 0.0 && S.prm.cosw == 1.0 &&
+        S.prm.sinw == 0.0)
+        return 3;
     if (S.prm.capping == 1.0) return 1;
     if (S.prm.capping == 0.0) return 0;
     return -1;

@@ -99,6 +99,7 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     P.uvel_init = S.in[F_UVEL_INIT]; P.vvel_init = S.in[F_VVEL_INIT];
     P.uvel = S.u[0]; P.vvel = S.v[0];
     for (int k = 0; k < 12; ++k) P.sig[k] = S.sig[0][k];
+    P.strintx = S.in[F_STRINTX]; P.strinty = S.in[F_STRINTY]; P.taubx = S.in[F_TAUBX]; P.tauby = S.in[F_TAUBY];
     P.mask = S.mask; P.flagword = Q.flagword;
     P.dt = pp->dt; P.rhoi = pp->rhoi; P.rhos = pp->rhos; P.gravit = pp->gravit;
     P.dyn_area_min = pp->dyn_area_min; P.dyn_mass_min = pp->dyn_mass_min;
@@ -185,6 +186,22 @@ int cice_evp_hip_set_strength(const double *strength)
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
     if (!strength) return fail(-1, "null argument");
     return h2d(S.in[F_STRENGTH], strength);
+}
+
+// Seabed stress factor, computed by the host AFTER the preparation (seabed_stress_factor_LKD/_prob need
+// the new iceUmask: evp() calls them between dyn_prep2 and the loop, ice_dyn_evp.F90:770-826) -- or
+// on the device by cice_evp_hip_seabed_lkd.  Re-derives the "TbU == 0 everywhere" shortcut.
+int cice_evp_hip_set_tbu(const double *TbU)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (!TbU) return fail(-1, "null argument");
+    if (h2d(S.in[F_TBU], TbU)) return -1;
+    bool zero = true;
+    for (size_t k = 0; k < S.n && zero; ++k) zero = !(S.hmask[k] & 2u) || TbU[k] == 0.0;
+    HIPC(hipStreamSynchronize(S.stream));      // the caller may reuse its array
+    S.flags &= ~EVP_F_TBU_ZERO;
+    if (zero) S.flags |= EVP_F_TBU_ZERO;
+    return 0;
 }
 
 // products of the preparation phase that stay on the device, for hosts that need them

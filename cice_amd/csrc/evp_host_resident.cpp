@@ -100,7 +100,9 @@ int resident2_setup(int logw)
 {
     if (S.res2_ring && S.res2_logw == logw) return 0;
     auto F = [](auto *&p) { if (p) (void)hipFree((void *)p); p = nullptr; };
-    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub);
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact);
+    S.res2_cls_h.clear();
+    S.res2_order_stale = true;
     S.res2_logw = logw;
     const int W = 1 << logw, H = 256 / W, LW = W + 1;
     int gx, gy;
@@ -122,6 +124,12 @@ int resident2_setup(int logw)
     std::vector<int> cnt((size_t)ntiles, 0);
     std::vector<uint8_t> pub(ncell, 0);
     std::vector<char> seen((size_t)(H + 1) * LW);
+    // 16 x 16 tiles: rim wave / interior waves (evp_resident2.hip).  cls: which T-cells of a tile read a
+    // ring velocity that has a producer (geometry); the thread -> cell permutation itself also depends
+    // on the ice mask and is built by resident2_order
+    const bool permuted = logw == 4;
+    std::vector<uint8_t> cls(permuted ? (size_t)ntiles * 256 : 0);
+    std::vector<char> ringli((size_t)(H + 1) * LW);
     for (int b = 0; b < nb; ++b) {
         const int ilo = S.ilo[b], ihi = S.ihi[b], jlo = S.jlo[b], jhi = S.jhi[b];
         const int cb = (int)(b * plane);
@@ -146,12 +154,25 @@ int resident2_setup(int logw)
                             if (pi < 1 || pi > nx || pj < 1 || pj > ny) continue;
                             const int cp = cb + (pj - 1) * nx + (pi - 1);
                             const int src = interior ? cp : ghost_src[cp];
+                            if (src == -1) continue;                   // nobody produces it: constant for the whole call
                             if (cnt[t] >= EVP_RES2_RING) return fail(-6, "resident2: ring list overflow");
                             const int always = (src >= 0 && on_seam[src]) ? 1 : 0;
                             ring[(size_t)t * EVP_RES2_RING + cnt[t]++] = make_int4(cp, li, src, always);
                             if (interior) pub[cp] = 1;
                         }
                     }
+                if (permuted) {
+                    std::fill(ringli.begin(), ringli.end(), 0);
+                    for (int e = 0; e < cnt[t]; ++e) ringli[ring[(size_t)t * EVP_RES2_RING + e].y] = 1;
+                    for (int trow = 0; trow < H; ++trow)
+                        for (int tcol = 0; tcol < W; ++tcol) {
+                            const int i = i0 + tcol, j = j0 + trow;
+                            const bool computed = i <= ihi + 1 && j <= jhi + 1;
+                            const int li = (trow + 1) * LW + (tcol + 1);
+                            const bool is_late = computed && (ringli[li] || ringli[li - 1] || ringli[li - LW] || ringli[li - LW - 1]);
+                            cls[(size_t)t * 256 + trow * W + tcol] = is_late ? 2 : computed ? 1 : 0;
+                        }
+                }
             }
     }
     S.res2_ntiles = ntiles;
@@ -192,6 +213,17 @@ int resident2_setup(int logw)
     HIPC(hipMemcpy(S.res2_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPC(hipMalloc((void **)&S.res2_pub, pub.size()));
     HIPC(hipMemcpy(S.res2_pub, pub.data(), pub.size(), hipMemcpyHostToDevice));
+    if (permuted) {
+        HIPC(hipMalloc((void **)&S.res2_perm, (size_t)ntiles * 256));
+        HIPC(hipMalloc((void **)&S.res2_late, (size_t)ntiles));
+        HIPC(hipMalloc((void **)&S.res2_nact, (size_t)ntiles));
+        if (!S.res2_cuload) {
+            HIPC(hipMalloc((void **)&S.res2_cuload, 2048 * 8 * sizeof(int)));
+            HIPC(hipMemset(S.res2_cuload, 0, 2048 * 8 * sizeof(int)));
+        }
+        S.res2_cls_h = cls;
+        S.res2_cnt_h = cnt;
+    }
     for (auto &p : S.res2_rec)
         if (!p) {
             if (!S.res2_rec_owned) return fail(-6, "resident2: record buffers missing from the mailbox");
@@ -209,38 +241,101 @@ bool resident2_fits(bool remote)
 {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
-    // remote: decided before any field has been seen -> the flag combination with the largest LDS need
-    const unsigned fl = remote ? (S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO)) : (S.flags & S.flags_allowed);
+    // Decided once, but TBU_ZERO / WATER_IS_OCN are re-derived from the data at every upload / prep and
+    // the LDS need of a workgroup grows when they drop (up to 6 KB): size with the flag combination
+    // that needs the most LDS, so that a later call can never have fewer workgroups per CU than the
+    // tile count was admitted against.
+    const unsigned fl = S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
     const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res2_logw, remote), 8);
     const long cap = (long)per_cu * prop.multiProcessorCount;
     return S.res2_ntiles > 0 && (long)S.res2_ntiles * 10 <= cap * 9;
 }
 
 
-// Launch order of the tiles: by ice-covered T-cells, descending (see the kernel).  Rebuilt when the
-// masks or the tile shape change; CICE_EVP_HIP_RES_ORDER=0 keeps the natural order.
+// What depends on the ice masks, rebuilt when they or the tile shape change:
+//  * 16 x 16 tiles: the thread -> cell permutation.  Ice cells that read ring velocities first (they
+//    and the ring poll share the wave that takes chunk 0), then the other ice cells, then the rest: a
+//    tile costs ceil(ice cells / 64) waves instead of four.
+//  * the launch order.  All tiles advance in lock step and a SIMD issues for one wave at a time, so the
+//    CU with the most ice-holding waves paces the grid.  Workgroup w lands on CU w mod #CUs (observed
+//    breadth-first placement, tools/wg_placement.hip; used for speed only): longest-processing-time
+//    assignment of tiles to CUs with the slots each CU gets, heaviest tile of a CU first.
+//    CICE_EVP_HIP_RES_ORDER=0 keeps the natural order.
 int resident2_order()
 {
-    const bool off = env("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env("CICE_EVP_HIP_RES_ORDER"));
-    if (off) return 0;
     if (S.res2_order && !S.res2_order_stale && S.res2_order_for == S.res2_logw) return 0;
     const int W = 1 << S.res2_logw, H = 256 / W;
     int gx, gy;
     evp_resident_geometry(S.max_ni, S.max_nj, S.res2_logw, &gx, &gy);
     const int ntiles = gx * gy * S.d.nblocks, nx = S.d.nx_block;
-    std::vector<std::pair<int, int>> cost((size_t)ntiles);
+    const bool permuted = !S.res2_cls_h.empty() && S.res2_logw == 4;
+    std::vector<int> cost((size_t)ntiles);        // 1024 * ice-holding waves + ice cells
+    std::vector<uint8_t> perm(permuted ? (size_t)ntiles * 256 : 0), late(permuted ? (size_t)ntiles : 0),
+                         nact(permuted ? (size_t)ntiles : 0);
     for (int t = 0; t < ntiles; ++t) {
         const int b = t / (gx * gy), bx = (t % (gx * gy)) % gx, by = (t % (gx * gy)) / gx;
         const int i0 = S.ilo[b] + bx * (W - 1), j0 = S.jlo[b] + by * (H - 1);
-        int n = 0;
-        for (int j = j0; j < j0 + H && j <= S.jhi[b] + 1; ++j)
-            for (int i = i0; i < i0 + W && i <= S.ihi[b] + 1; ++i)
-                n += S.hmask[b * S.plane + (size_t)(j - 1) * nx + (i - 1)] & 1u;
-        cost[t] = {-n, t};
+        auto ice = [&](int pos) -> bool {           // T-cell or U-cell of this position takes part in the loop
+            const int i = i0 + (pos & (W - 1)), j = j0 + pos / W;
+            if (i > S.ihi[b] + 1 || j > S.jhi[b] + 1) return false;
+            return (S.hmask[b * S.plane + (size_t)(j - 1) * nx + (i - 1)] & 3u) != 0;
+        };
+        int n = 0, waves = 0;
+        if (permuted) {
+            const uint8_t *cl = &S.res2_cls_h[(size_t)t * 256];
+            uint8_t *pm = &perm[(size_t)t * 256];
+            int k = 0, nlate = 0;
+            for (int pass = 0; pass < 3; ++pass)
+                for (int pos = 0; pos < 256; ++pos) {
+                    const bool on = cl[pos] != 0 && ice(pos);
+                    const int which = on ? (cl[pos] == 2 ? 0 : 1) : 2;
+                    if (which != pass) continue;
+                    pm[k++] = (uint8_t)pos;
+                    if (pass == 0) ++nlate;
+                    if (pass < 2) ++n;
+                }
+            waves = (n + 63) / 64;
+            nact[t] = (uint8_t)waves;
+            late[t] = (uint8_t)std::min(4, (std::max(nlate, S.res2_cnt_h[t]) + 63) / 64);
+        } else {
+            int wave_on[4] = {0, 0, 0, 0};
+            for (int pos = 0; pos < 256; ++pos)
+                if (ice(pos)) { ++n; wave_on[pos >> 6] = 1; }
+            waves = wave_on[0] + wave_on[1] + wave_on[2] + wave_on[3];
+        }
+        cost[t] = 1024 * waves + n;
     }
-    std::stable_sort(cost.begin(), cost.end());
+    if (permuted) {
+        HIPC(hipMemcpyAsync(S.res2_perm, perm.data(), perm.size(), hipMemcpyHostToDevice, S.stream));
+        HIPC(hipMemcpyAsync(S.res2_late, late.data(), late.size(), hipMemcpyHostToDevice, S.stream));
+        HIPC(hipMemcpyAsync(S.res2_nact, nact.data(), nact.size(), hipMemcpyHostToDevice, S.stream));
+    }
+    const bool off = env("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env("CICE_EVP_HIP_RES_ORDER"));
     std::vector<int> order((size_t)ntiles);
-    for (int w = 0; w < ntiles; ++w) order[w] = cost[w].second;
+    for (int w = 0; w < ntiles; ++w) order[w] = w;
+    if (!off) {
+        hipDeviceProp_t prop;
+        int ncu = 256;
+        if (hipGetDeviceProperties(&prop, S.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        std::vector<int> by_cost((size_t)ntiles);
+        for (int w = 0; w < ntiles; ++w) by_cost[w] = w;
+        std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int c) { return cost[a] > cost[c]; });
+        // CU c receives the workgroups c, c + ncu, c + 2 ncu, ...: slots[c] of them
+        std::vector<int> slots((size_t)ncu), load((size_t)ncu, 0);
+        std::vector<std::vector<int>> mine((size_t)ncu);
+        for (int c = 0; c < ncu; ++c) slots[c] = ntiles / ncu + (c < ntiles % ncu ? 1 : 0);
+        for (int tile : by_cost) {                 // heaviest first, to the least loaded CU with a free slot
+            int best = -1;                           // (ties: the CU with fewer slots, so that the CUs with one more workgroup stay light)
+            for (int c = 0; c < ncu; ++c) {
+                if ((int)mine[c].size() >= slots[c]) continue;
+                if (best < 0 || load[c] < load[best] || (load[c] == load[best] && slots[c] < slots[best])) best = c;
+            }
+            mine[best].push_back(tile);
+            load[best] += cost[tile] >> 10;
+        }
+        for (int c = 0; c < ncu; ++c)
+            for (size_t k = 0; k < mine[c].size(); ++k) order[c + (int)k * ncu] = mine[c][k];
+    }
     if (S.res2_order && S.res2_order_for != S.res2_logw) { (void)hipFree(S.res2_order); S.res2_order = nullptr; }
     if (!S.res2_order) HIPC(hipMalloc((void **)&S.res2_order, order.size() * sizeof(int)));
     HIPC(hipMemcpyAsync(S.res2_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
@@ -268,6 +363,10 @@ int launch_resident2(int ndte, int cur0, bool dry)
     S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
     R.nblocks = S.d.nblocks;
     R.order = S.res2_order;
+    R.perm = S.res2_perm;
+    R.late_waves = S.res2_late;
+    R.nact = S.res2_nact;
+    R.cuload = S.res2_cuload;
     const int dbg2 = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.dbg = dbg2;
     R.seam = S.res2_seam;
@@ -302,7 +401,8 @@ bool resident_fits()
 {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
-    const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), S.flags & S.flags_allowed, S.res_logw), 8);
+    const unsigned fl = S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);   // worst-case LDS need, see resident2_fits
+    const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res_logw), 8);
     const long cap = (long)per_cu * prop.multiProcessorCount;
     return S.res_ntiles > 0 && (long)S.res_ntiles * 10 <= cap * 9;
 }
@@ -459,7 +559,7 @@ int tune_after_upload()
                         HIPC(hipEventRecord(S.ev3, S.stream));
                         HIPC(hipStreamSynchronize(S.stream));
                         S.res_launched = true;
-                        if (resident_check_error()) { ok = false; break; }
+                        if (resident_check_error()) { ok = false; g_err.clear(); break; }   // a tolerated probe failure is not the caller's error
                         HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
                         if (rep >= 1) tl[rep - 1] = ms;
                     }

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(64 * TYB) void evp_subcycle_tile(EvpArgs A)
         q.sx2 = s_str[2][ty + 1][tx]; q.sx3 = s_str[3][ty + 1][tx + 1];
         q.sy0 = s_str[4][ty][tx]; q.sy1 = s_str[5][ty + 1][tx];
         q.sy2 = s_str[6][ty][tx + 1]; q.sy3 = s_str[7][ty + 1][tx + 1];
-        MM::stepu(A.p, q, o);
+        if (flags & EVP_F_TBU_ZERO) MM::template stepu<CAP, false>(A.p, q, o);
+        else MM::template stepu<CAP, true>(A.p, q, o);
         if (bnd) {   // write-through: visible to the exchange workgroup on another XCD
             __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(A.u_out) + ob), o.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(A.v_out) + ob), o.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -393,11 +394,13 @@ void launch_tile(const EvpArgs &A, dim3 grid, hipStream_t st, bool strict, int c
         else hipLaunchKernelGGL((evp_subcycle_tile<TYB, S, C, false>), grid, block, 0, st, A);     \
     } while (0)
     if (strict) {
-        if (cap == 1) EVP_LAUNCH(true, 1);
+        if (cap == 3) EVP_LAUNCH(true, 3);
+        else if (cap == 1) EVP_LAUNCH(true, 1);
         else if (cap == 0) EVP_LAUNCH(true, 0);
         else EVP_LAUNCH(true, -1);
     } else {
-        if (cap == 1) EVP_LAUNCH(false, 1);
+        if (cap == 3) EVP_LAUNCH(false, 3);
+        else if (cap == 1) EVP_LAUNCH(false, 1);
         else if (cap == 0) EVP_LAUNCH(false, 0);
         else EVP_LAUNCH(false, -1);
     }

@@ -36,12 +36,15 @@ template <> struct Math<true> {
     using SI = evp_strict::StressIn;
     using UI = evp_strict::StepuIn;
     using UO = evp_strict::StepuOut;
-    template <int CAP>
+    // MODE: 1 capping == 1, 0 capping == 0, -1 general capping; 3 = capping == 1 AND the reference's default
+    // scalars (revp == 0, Ktens == 0, cosw == 1, sinw == 0): products with exactly 1.0 dropped (evp_cell.inc)
+    template <int MODE>
     static __device__ __forceinline__ void stress(const EvpScalars &p, const SI &a, double (&s)[12], double (&str)[8])
     {
-        evp_strict::stress_cell<CAP>(p, a, s, str);
+        evp_strict::stress_cell<(MODE == 3 ? 1 : MODE), MODE == 3>(p, a, s, str);
     }
-    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_strict::stepu_cell(p, a, o); }
+    template <int MODE = -1, bool TBU = true>
+    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_strict::stepu_cell<MODE == 3, TBU>(p, a, o); }
     static __device__ __forceinline__ void metrics(double hte, double hte_im, double htn, double htn_jm, double dmin, SI &a)
     {
         evp_strict::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);
@@ -51,12 +54,15 @@ template <> struct Math<false> {
     using SI = evp_fused::StressIn;
     using UI = evp_fused::StepuIn;
     using UO = evp_fused::StepuOut;
-    template <int CAP>
+    // MODE: 1 capping == 1, 0 capping == 0, -1 general capping; 3 = capping == 1 AND the reference's default
+    // scalars (revp == 0, Ktens == 0, cosw == 1, sinw == 0): products with exactly 1.0 dropped (evp_cell.inc)
+    template <int MODE>
     static __device__ __forceinline__ void stress(const EvpScalars &p, const SI &a, double (&s)[12], double (&str)[8])
     {
-        evp_fused::stress_cell<CAP>(p, a, s, str);
+        evp_fused::stress_cell<(MODE == 3 ? 1 : MODE), MODE == 3>(p, a, s, str);
     }
-    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_fused::stepu_cell(p, a, o); }
+    template <int MODE = -1, bool TBU = true>
+    static __device__ __forceinline__ void stepu(const EvpScalars &p, const UI &a, UO &o) { evp_fused::stepu_cell<MODE == 3, TBU>(p, a, o); }
     static __device__ __forceinline__ void metrics(double hte, double hte_im, double htn, double htn_jm, double dmin, SI &a)
     {
         evp_fused::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);

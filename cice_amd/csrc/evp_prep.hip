@@ -111,6 +111,9 @@ __global__ void prep2(EvpPrep P)
         for (int k = 0; k < 12; ++k) P.sig[k][c] = 0.0;
     double waterx = 0.0, watery = 0.0, forcex = 0.0, forcey = 0.0, umassdti = 0.0;
     bool iceU = false;
+    // the seabed stress diagnostics are zeroed on every cell (:704-712); the subcycle writes them on
+    // ice U-cells only, so a cell that has lost its ice must not keep the previous call's value
+    P.taubx[c] = 0.0; P.tauby[c] = 0.0;
     if (i >= r.x && i <= r.y && j >= r.z && j <= r.w) {
         const double umass = P.umass[c], aiU = P.aiU[c];
         const bool old = P.umask_old[c] != 0;
@@ -120,6 +123,7 @@ __global__ void prep2(EvpPrep P)
             if (!old) { u = P.uocnU[c]; v = P.vocnU[c]; }
         } else {
             u = 0.0; v = 0.0;
+            P.strintx[c] = 0.0; P.strinty[c] = 0.0;      // :776-781
         }
         P.uvel[c] = u; P.vvel[c] = v;
         P.uvel_init[c] = u; P.vvel_init[c] = v;

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(64 * RTY, 4) void evp_resident_tile(EvpArgs A, EvpR
             q.sx2 = s_str[0 * 256 + t + W]; q.sx3 = s_str[2 * 256 + t + W + 1];
             q.sy0 = str[4]; q.sy1 = s_str[1 * 256 + t + W];
             q.sy2 = sy2; q.sy3 = s_str[3 * 256 + t + W + 1];
-            MM::stepu(A.p, q, o);
+            if (flags & EVP_F_TBU_ZERO) MM::template stepu<CAP, false>(A.p, q, o);
+            else MM::template stepu<CAP, true>(A.p, q, o);
             u_own = o.u; v_own = o.v;
             st_sc1(uw + c, o.u);
             st_sc1(vw + c, o.v);
@@ -261,8 +262,8 @@ static int occ(bool strict, int cap, size_t lds)
     int nb = 0;
 #define EVP_OCC(S, C) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident_tile<S, C, LOGW>, 64 * RTY, lds)
     hipError_t e;
-    if (strict) e = cap == 1 ? EVP_OCC(true, 1) : cap == 0 ? EVP_OCC(true, 0) : EVP_OCC(true, -1);
-    else e = cap == 1 ? EVP_OCC(false, 1) : cap == 0 ? EVP_OCC(false, 0) : EVP_OCC(false, -1);
+    if (strict) e = cap == 3 ? EVP_OCC(true, 3) : cap == 1 ? EVP_OCC(true, 1) : cap == 0 ? EVP_OCC(true, 0) : EVP_OCC(true, -1);
+    else e = cap == 3 ? EVP_OCC(false, 3) : cap == 1 ? EVP_OCC(false, 1) : cap == 0 ? EVP_OCC(false, 0) : EVP_OCC(false, -1);
 #undef EVP_OCC
     return e == hipSuccess ? nb : 0;
 }
@@ -287,11 +288,13 @@ static void launch(const EvpArgs &A, const EvpResident &R, bool strict, int cap,
     const size_t lds = resident_lds_bytes(A.flags);
 #define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident_tile<S, C, LOGW>), grid, block, lds, st, A, R)
     if (strict) {
-        if (cap == 1) EVP_LAUNCH(true, 1);
+        if (cap == 3) EVP_LAUNCH(true, 3);
+        else if (cap == 1) EVP_LAUNCH(true, 1);
         else if (cap == 0) EVP_LAUNCH(true, 0);
         else EVP_LAUNCH(true, -1);
     } else {
-        if (cap == 1) EVP_LAUNCH(false, 1);
+        if (cap == 3) EVP_LAUNCH(false, 3);
+        else if (cap == 1) EVP_LAUNCH(false, 1);
         else if (cap == 0) EVP_LAUNCH(false, 0);
         else EVP_LAUNCH(false, -1);
     }

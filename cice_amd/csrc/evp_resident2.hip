@@ -17,6 +17,18 @@
 //
 // Same arithmetic, tile shapes and ownership rules as evp_resident.hip / the streaming
 // kernel => same bits.  Every spin is bounded and raises the error word.
+//
+// Rim wave / interior waves (PERM, the 16 x 16 tile).  A subcycle of a tile is a dependent chain:
+// neighbours publish -> ring poll -> stress -> barrier -> momentum step -> publish.  Only the T-cells
+// on the rim of the tile read ring velocities (60 of 256 in a full 16 x 16 tile), and the ring has
+// at most 64 entries: a host-built permutation puts those T-cells -- and the ring poll -- into
+// wave 0, all other T-cells into waves 1-3.  Waves 1-3 start their stress update straight after the
+// barrier that ends the previous momentum step, from velocities that never left the CU, while wave 0
+// waits for the neighbours' records: the hand-off latency (about 1 us of the 5.5 us a subcycle took
+// on gx1, three tiles per CU time-sharing the SIMDs) overlaps with three quarters of the tile's
+// arithmetic instead of preceding all of it.  The lane -> cell map is arbitrary here because no
+// array access of the loop is a global one; the eight stress-divergence partials travel through LDS
+// by cell position.  Same arithmetic per cell => same bits.
 // =====================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -84,22 +96,90 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     constexpr int H = 256 / W;
     constexpr int LW = W + 1;                 // LDS velocity tile: (H+1) x (W+1), origin (-1,-1)
     constexpr int NUV = ((H + 1) * LW + 7) & ~7;
-    // LDS (dynamic): s_str[4][256] | s_tc[4][256] | s_u[NUV] | s_v[NUV] | s_uc[nu][256]
+    constexpr bool PERM = (LOGW == 4);        // rim wave / interior waves (see the header)
+    constexpr int NSTR = PERM ? 6 : 4;        // planes of stress-divergence partials that travel through LDS
+    constexpr int SW = PERM ? W + 1 : W;      // row stride of a plane (PERM: odd, a column of cells is not one bank)
+    constexpr int SP = SW * H;                // plane size
+    // LDS (dynamic): s_str[NSTR][SP] | s_tc[4][256] | s_u[NUV] | s_v[NUV] | s_uc[nu][256]
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *s_str = smem;
-    double *s_tc = smem + 4 * 256;
-    double *s_u = smem + 8 * 256;
+    double *s_tc = smem + NSTR * SP;
+    double *s_u = s_tc + 4 * 256;
     double *s_v = s_u + NUV;
     double *s_uc = s_v + NUV;
     __shared__ int s_bad;
 
+    __shared__ int s_chunk[4], s_simd[4], s_cu;
+
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int t = ty * 64 + tx;               // == trow*W + tcol
-    const int tcol = tx & (W - 1);
-    const int trow = t >> LOGW;
-    // launch order = heaviest tiles first (host-sorted by ice-covered cells): the workgroups that
-    // end up third on a CU are then the cheap ones (land, partial edge tiles)
+    const int t = ty * 64 + tx;
+    // launch order = heaviest tiles first (host-sorted by active waves, see resident2_order): the
+    // workgroups that end up third on a CU are then the cheap ones (land, partial edge tiles)
     const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
+    // PERM: which quarter ("chunk") of the tile's permuted cell list this wave takes.  The host packs
+    // the ice cells of a tile into its first chunks (a coastal tile then costs one or two waves, not
+    // four).  A SIMD issues for one wave at a time and all tiles advance in lock step, so the SIMD with
+    // the most ice-holding waves paces the whole grid: the workgroups that share a CU put their active
+    // chunks on the CU's least loaded SIMDs (the wave -> SIMD map is the hardware's: read from HW_ID;
+    // a small per-CU record under a lock, once per launch).  Speed only: any chunk -> wave map is correct.
+    int tq = t;
+    if (PERM && R.cuload && !(R.dbg & 64)) {
+        const int wave = t >> 6;
+        if ((t & 63) == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            s_simd[wave] = (int)((hw >> 4) & 3u);
+            if (wave == 0) s_cu = (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));   // XCC | SE, SH, CU
+        }
+        __syncthreads();
+        if (t == 0) {
+            int *L = R.cuload + 8 * s_cu;         // [0] lock, [1] launch stamp, [2..5] ice-holding waves per SIMD
+            const int nact = R.nact[tile];        // active chunks of this tile: 0 .. nact-1
+            int chunk_of[4] = {0, 1, 2, 3};
+            unsigned spins = 0;
+            bool locked = false;
+            while (spins++ < 200000u) {
+                if (atomicCAS(&L[0], 0, 1) == 0) { locked = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (locked) {
+                int ld[4];
+                const int stamp = __hip_atomic_load(&L[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ld[q] = stamp == (int)R.tag_base ? __hip_atomic_load(&L[2 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                bool used[4] = {false, false, false, false};
+                for (int ck = 0; ck < 4; ++ck) {      // active chunks first, each to the free wave on the least loaded SIMD
+                    int best = -1;
+                    for (int w = 0; w < 4; ++w)
+                        if (!used[w] && (best < 0 || ld[s_simd[w]] < ld[s_simd[best]])) best = w;
+                    used[best] = true;
+                    chunk_of[best] = ck;
+                    if (ck < nact) ld[s_simd[best]] += 1;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) __hip_atomic_store(&L[2 + q], ld[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&L[1], (int)R.tag_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&L[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s_chunk[w] = chunk_of[w];
+        }
+        __syncthreads();
+        tq = s_chunk[wave] * 64 + (t & 63);
+    }
+    // which T-cell of the tile this thread owns: row-major (lane = column) unless permuted
+    const int pos = PERM ? (int)R.perm[tile * 256 + tq] : t;      // == trow*W + tcol
+    const int tcol = pos & (W - 1);
+    const int trow = pos >> LOGW;
+    const int sp = trow * SW + tcol;          // this cell in a plane of s_str
+    // PERM: waves below `late_waves` hold the T-cells that read ring velocities and do the ring poll;
+    // with exactly one such wave (every 16 x 16 tile: rim <= 60 cells, ring <= 64 entries) the others
+    // never wait for it before their stress update ("split")
+    const int late_waves = PERM ? (int)R.late_waves[tile] : 4;
+    const bool split = PERM && late_waves <= 1 && !(R.dbg & 32);
     if ((R.dbg & 16) && tile == 1 && !R.dry) return;   // test hook: one workgroup "never becomes resident" (after the probes)
     const int per_blk = A.gx * A.gy;
     const int bz = tile / per_blk;                // CICE block of this rank
@@ -234,8 +314,8 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // my ring entry: which cell of the LDS ring do I refresh, from which record
     int ring_cp = -1, ring_li = 0;
     bool ring_remote = false;
-    if (t < R.ring_cnt[tile]) {
-        const int4 e = R.ring[tile * EVP_RES2_RING + t];   // x: cell whose record is polled, y: LDS index, z: producing U-cell
+    if (tq < R.ring_cnt[tile]) {     // (PERM: ring entries and the T-cells that read them share the wave that took chunk 0)
+        const int4 e = R.ring[tile * EVP_RES2_RING + tq];   // x: cell whose record is polled, y: LDS index, z: producing U-cell
         if (e.z >= 0) { ring_cp = e.x; ring_li = e.y; }      // has a producer on this GPU: refreshed every subcycle
         if (REMOTE && e.z == -2) { ring_cp = e.x; ring_li = e.y; ring_remote = true; }   // produced on another rank
     }
@@ -309,7 +389,8 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             const unsigned long long t0 = wall_clock64();
             while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(8);
         }
-        // refresh the ring of the velocity tile from the neighbours' records
+        // refresh the ring of the velocity tile from the neighbours' records (split: only wave 0 holds
+        // ring entries and T-cells that read them; nobody else waits here)
         if (REMOTE && ring_remote) {
             v4u ra, rb;
             if (!poll_remote(rd + 2 * (size_t)ring_cp, want, ra, rb)) s_bad = 1;
@@ -334,8 +415,15 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             s_u[ring_li] = unpack_rec(ra);
             s_v[ring_li] = unpack_rec(rb);
         }
-        __syncthreads();
-        if (s_bad) return;   // uniform: every thread of the workgroup leaves together
+        if (!split) {
+            __syncthreads();
+            if (s_bad) return;   // uniform: every thread of the workgroup leaves together
+        } else {
+            // ring cells are written and read by wave 0 only: LDS operations of one wave complete in order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         double str[8];
 #pragma unroll
@@ -349,13 +437,27 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             a.dxhy = s_tc[2 * 256 + t]; a.dyhx = s_tc[3 * 256 + t];
             MM::template stress<CAP>(A.p, a, s, str);
         }
-        s_str[0 * 256 + t] = str[2];
-        s_str[1 * 256 + t] = str[5];
-        s_str[2 * 256 + t] = str[3];
-        s_str[3 * 256 + t] = str[7];
-        const double sx1 = __shfl_down(str[1], 1);
-        const double sy2 = __shfl_down(str[6], 1);
-        __syncthreads();
+        double sx1, sy2;
+        if (PERM) {      // by cell position: the U-cell's thread need not sit next to its T neighbours
+            s_str[0 * SP + sp] = str[2];
+            s_str[1 * SP + sp] = str[5];
+            s_str[2 * SP + sp] = str[3];
+            s_str[3 * SP + sp] = str[7];
+            s_str[4 * SP + sp] = str[1];
+            s_str[5 * SP + sp] = str[6];
+            __syncthreads();
+            if (split && s_bad) return;   // set by wave 0 before the barrier
+            sx1 = s_str[4 * SP + sp + 1];   // (sp + 1 < SP also for the last cell of the last row: SW = W + 1)
+            sy2 = s_str[5 * SP + sp + 1];
+        } else {
+            s_str[0 * SP + sp] = str[2];
+            s_str[1 * SP + sp] = str[5];
+            s_str[2 * SP + sp] = str[3];
+            s_str[3 * SP + sp] = str[7];
+            sx1 = __shfl_down(str[1], 1);
+            sy2 = __shfl_down(str[6], 1);
+            __syncthreads();
+        }
 
         if (isU) {
             typename MM::UI q;
@@ -371,10 +473,11 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             q.uvel_init = A.p.revp != 0.0 ? A.uvel_init[c] : 0.0;
             q.vvel_init = A.p.revp != 0.0 ? A.vvel_init[c] : 0.0;
             q.sx0 = str[0]; q.sx1 = sx1;
-            q.sx2 = s_str[0 * 256 + t + W]; q.sx3 = s_str[2 * 256 + t + W + 1];
-            q.sy0 = str[4]; q.sy1 = s_str[1 * 256 + t + W];
-            q.sy2 = sy2; q.sy3 = s_str[3 * 256 + t + W + 1];
-            MM::stepu(A.p, q, o);
+            q.sx2 = s_str[0 * SP + sp + SW]; q.sx3 = s_str[2 * SP + sp + SW + 1];
+            q.sy0 = str[4]; q.sy1 = s_str[1 * SP + sp + SW];
+            q.sy2 = sy2; q.sy3 = s_str[3 * SP + sp + SW + 1];
+            if (tbu) MM::template stepu<CAP, true>(A.p, q, o);
+            else MM::template stepu<CAP, false>(A.p, q, o);
             u_own = o.u; v_own = o.v;
             if (k == R.ndte - 1 && !R.dry) {
                 R.tab[24][c] = o.strintx; R.tab[25][c] = o.strinty;
@@ -428,6 +531,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         }
         if (rpub) publish_remote(((k + par0) & 1) ^ 1, u_own, v_own, want + 1u);
         // no publish step: the records carry their own tags
+        if (split) __syncthreads();   // the tile's own new velocities are in LDS before anybody's next stress update
     }
     // ghost cells that mirror another rank's cells: fetch the final velocities (the caller
     // relies on current ghosts, ice_dyn_evp.F90:920-934)
@@ -468,7 +572,8 @@ size_t lds_bytes(unsigned flags, int logw)
     const int W = 1 << logw, H = 256 / W;
     const int nuv = ((H + 1) * (W + 1) + 7) & ~7;
     const int nu = 8 + ((flags & EVP_F_WATER_IS_OCN) ? 0 : 2) + ((flags & EVP_F_TBU_ZERO) ? 0 : 1);
-    return sizeof(double) * ((size_t)256 * (8 + nu) + 2 * (size_t)nuv);
+    const size_t nstr = logw == 4 ? 6 * (size_t)(W + 1) * H : 4 * (size_t)256;   // PERM planes: row stride W + 1
+    return sizeof(double) * (nstr + (size_t)256 * (4 + nu) + 2 * (size_t)nuv);
 }
 
 template <int LOGW, bool REMOTE>
@@ -477,8 +582,8 @@ int occ(bool strict, int cap, size_t lds)
     int nb = 0;
 #define EVP_OCC(S, C) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident2_tile<S, C, LOGW, REMOTE>, 64 * RTY, lds)
     hipError_t e;
-    if (strict) e = cap == 1 ? EVP_OCC(true, 1) : cap == 0 ? EVP_OCC(true, 0) : EVP_OCC(true, -1);
-    else e = cap == 1 ? EVP_OCC(false, 1) : cap == 0 ? EVP_OCC(false, 0) : EVP_OCC(false, -1);
+    if (strict) e = cap == 3 ? EVP_OCC(true, 3) : cap == 1 ? EVP_OCC(true, 1) : cap == 0 ? EVP_OCC(true, 0) : EVP_OCC(true, -1);
+    else e = cap == 3 ? EVP_OCC(false, 3) : cap == 1 ? EVP_OCC(false, 1) : cap == 0 ? EVP_OCC(false, 0) : EVP_OCC(false, -1);
 #undef EVP_OCC
     return e == hipSuccess ? nb : 0;
 }
@@ -490,11 +595,13 @@ void launch(const EvpArgs &A, const EvpResident2 &R, bool strict, int cap, hipSt
     const size_t lds = lds_bytes(A.flags, LOGW);
 #define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident2_tile<S, C, LOGW, REMOTE>), grid, block, lds, st, A, R)
     if (strict) {
-        if (cap == 1) EVP_LAUNCH(true, 1);
+        if (cap == 3) EVP_LAUNCH(true, 3);
+        else if (cap == 1) EVP_LAUNCH(true, 1);
         else if (cap == 0) EVP_LAUNCH(true, 0);
         else EVP_LAUNCH(true, -1);
     } else {
-        if (cap == 1) EVP_LAUNCH(false, 1);
+        if (cap == 3) EVP_LAUNCH(false, 3);
+        else if (cap == 1) EVP_LAUNCH(false, 1);
         else if (cap == 0) EVP_LAUNCH(false, 0);
         else EVP_LAUNCH(false, -1);
     }

@@ -42,8 +42,8 @@ EXPORTS = [
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_center_plan",
-    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_prep_fetch",
-    "cice_evp_hip_addr",
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_addr", "cice_evp_hip_debug_cuload",
 ]
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
 # T-grid inputs of the preparation phase (order of cice_evp_hip_prep's tfields11) and the
@@ -236,6 +236,10 @@ class EvpHip:
         a = self._c(strength)
         _check(self.lib, self.lib.cice_evp_hip_set_strength(_dp(a)), "(dyn_evp_hip_set_strength)")
 
+    def set_tbu(self, TbU):
+        a = self._c(TbU)
+        _check(self.lib, self.lib.cice_evp_hip_set_tbu(_dp(a)), "(dyn_evp_hip_set_tbu)")
+
     def prep_fetch(self, name: str):
         out = np.zeros(self.shape)
         _check(self.lib, self.lib.cice_evp_hip_prep_fetch(C.c_int32(PREP_FETCH.index(name)), _dp(out)),
@@ -291,6 +295,11 @@ class EvpHip:
         sy = np.array(self._c(strocnyU), copy=True)
         _check(self.lib, self.lib.cice_evp_hip_dyn_finish(_dp(sx), _dp(sy)), "(dyn_finish)")
         return dict(strocnxU=sx, strocnyU=sy)
+
+    def debug_cuload(self):
+        a = np.zeros((2048, 8), dtype=np.int32)
+        _check(self.lib, self.lib.cice_evp_hip_debug_cuload(_ip(a), C.c_int32(a.size)), "(debug_cuload)")
+        return a
 
     def time_kernels(self, nrep: int = 50) -> dict:
         t = np.zeros(3)

@@ -143,6 +143,11 @@ module ice_dyn_evp_hip
        real(c_double), dimension(*), intent(in) :: strength
      end function cice_evp_hip_set_strength
 
+     integer(c_int) function cice_evp_hip_set_tbu(TbU) bind(C, name='cice_evp_hip_set_tbu')
+       import :: c_int, c_double
+       real(c_double), dimension(*), intent(in) :: TbU
+     end function cice_evp_hip_set_tbu
+
      integer(c_int) function cice_evp_hip_subcycle(ndte) bind(C, name='cice_evp_hip_subcycle')
        import :: c_int, c_int32_t
        integer(c_int32_t), value :: ndte
@@ -292,17 +297,18 @@ contains
 ! rank keep evp()'s host preparation (the C side refuses them).
   subroutine dyn_evp_hip_evp_body(dt, compute_strength)
 
-    use ice_blocks, only: nx_block, ny_block
+    use ice_blocks, only: nx_block, ny_block, block, get_block
     use ice_domain_size, only: max_blocks
-    use ice_domain, only: ns_boundary_type
+    use ice_domain, only: ns_boundary_type, nblocks, blocks_ice
     use ice_grid, only: tmask, umask, hm, tarea, uarea
-    use ice_state, only: aice, vice, vsno, uvel, vvel, aice_init, strength
+    use ice_state, only: aice, vice, vsno, uvel, vvel, aice_init, strength, aicen, vicen
     use ice_arrays_column, only: Cdn_ocn
     use ice_flux, only: uocn, vocn, ss_tltx, ss_tlty, strairxT, strairyT, &
          stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
          stress12_1, stress12_2, stress12_3, stress12_4, strintxU, strintyU, strocnxU, strocnyU, &
-         taubxU, taubyU, TbU
-    use ice_dyn_shared, only: ndte, fcor_blk, iceTmask, iceUmask, dyn_area_min, dyn_mass_min, ssh_stress
+         taubxU, taubyU, TbU, hwater
+    use ice_dyn_shared, only: ndte, fcor_blk, iceTmask, iceUmask, dyn_area_min, dyn_mass_min, ssh_stress, &
+         seabed_stress, seabed_stress_method, seabed_stress_factor_LKD, seabed_stress_factor_prob
     use icepack_intfc, only: icepack_query_parameters
 
     real(kind=dbl_kind), intent(in) :: dt
@@ -314,7 +320,9 @@ contains
     type(cice_evp_hip_prep_params) :: pp
     type(c_ptr) :: tf(11), f32(32), out32(32)
     integer(c_int32_t), pointer :: tmask_i(:), umask_i(:), itm(:), ium(:)
-    integer :: nall
+    integer :: nall, iblk, i, j, nT, nU
+    integer(int_kind), allocatable :: ixT(:), jxT(:), ixU(:), jxU(:)
+    type(block) :: tb
     logical, save :: geometry_set = .false.
     character(len=*), parameter :: subname = '(dyn_evp_hip_evp_body)'
 
@@ -347,7 +355,8 @@ contains
     f32(7) = cice_evp_hip_addr(stressm_3);  f32(8) = cice_evp_hip_addr(stressm_4)
     f32(9) = cice_evp_hip_addr(stress12_1); f32(10) = cice_evp_hip_addr(stress12_2)
     f32(11) = cice_evp_hip_addr(stress12_3); f32(12) = cice_evp_hip_addr(stress12_4)
-    f32(26) = cice_evp_hip_addr(TbU)    ! seabed stress factor: the host's (seabed_stress_factor_LKD/_prob)
+    ! TbU does not travel here: dyn_prep2 zeroes it and the seabed stress factor is computed from the
+    ! NEW iceUmask afterwards (ice_dyn_evp.F90:770-826) -- below, once the preparation has returned
     f32(29) = cice_evp_hip_addr(uvel)
     f32(30) = cice_evp_hip_addr(vvel)
     call c_f_pointer(cice_evp_hip_addr(iceTmask), itm, [nall])
@@ -357,6 +366,40 @@ contains
 
     call compute_strength()
     call check(cice_evp_hip_set_strength(strength), subname, __FILE__, __LINE__)
+
+    if (seabed_stress) then
+       ! the reference's own routines on the host (exp(): libm-exact), from the masks the device
+       ! preparation returned; index lists rebuilt as dyn_prep2 builds them (ice_dyn_shared.F90:740-770)
+       allocate(ixT(nx_block*ny_block), jxT(nx_block*ny_block), ixU(nx_block*ny_block), jxU(nx_block*ny_block))
+       do iblk = 1, nblocks
+          tb = get_block(blocks_ice(iblk), iblk)
+          TbU(:,:,iblk) = 0.0_dbl_kind
+          nT = 0; nU = 0
+          do j = tb%jlo, tb%jhi+1
+          do i = tb%ilo, tb%ihi+1
+             if (iceTmask(i,j,iblk)) then
+                nT = nT + 1; ixT(nT) = i; jxT(nT) = j
+             endif
+          enddo
+          enddo
+          do j = tb%jlo, tb%jhi
+          do i = tb%ilo, tb%ihi
+             if (iceUmask(i,j,iblk)) then
+                nU = nU + 1; ixU(nU) = i; jxU(nU) = j
+             endif
+          enddo
+          enddo
+          if (trim(seabed_stress_method) == 'LKD') then
+             call seabed_stress_factor_LKD(nx_block, ny_block, nU, ixU, jxU, vice(:,:,iblk), aice(:,:,iblk), &
+                                           hwater(:,:,iblk), TbU(:,:,iblk))
+          elseif (trim(seabed_stress_method) == 'probabilistic') then
+             call seabed_stress_factor_prob(nx_block, ny_block, nT, ixT, jxT, nU, ixU, jxU, &
+                                            aicen(:,:,:,iblk), vicen(:,:,:,iblk), hwater(:,:,iblk), TbU(:,:,iblk))
+          endif
+       enddo
+       deallocate(ixT, jxT, ixU, jxU)
+       call check(cice_evp_hip_set_tbu(TbU), subname, __FILE__, __LINE__)
+    endif
     call check(cice_evp_hip_subcycle(int(ndte, c_int32_t)), subname, __FILE__, __LINE__)
     if (trim(ns_boundary_type) == 'tripole') &
        call check(cice_evp_hip_stress_halo(), subname, __FILE__, __LINE__)

@@ -188,6 +188,11 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
                       const double *const *fields32, int32_t *iceTmask, int32_t *iceUmask,
                       double *strintxU, double *strintyU, double *strocnxU, double *strocnyU);
 int cice_evp_hip_set_strength(const double *strength);
+/* Seabed stress factor TbU for the coming subcycle loop, when the host computes it: evp() does so
+ * AFTER dyn_prep2 (which zeroes it, ice_dyn_shared.F90:706) from the new iceUmask
+ * (seabed_stress_factor_LKD / _prob, ice_dyn_evp.F90:770-826), so it cannot travel with
+ * cice_evp_hip_prep.  Call between cice_evp_hip_prep and cice_evp_hip_subcycle.                  */
+int cice_evp_hip_set_tbu(const double *TbU);
 /* Returns its argument.  Lets a Fortran host take the address of a module array that lacks the
  * TARGET attribute (type(*), dimension(*) dummy) to fill the pointer tables above.              */
 void *cice_evp_hip_addr(const void *array);
@@ -235,6 +240,9 @@ int cice_evp_hip_get_timings(double *out, int32_t n);
  * advanced: out3[0]=fused stress+stepu kernel ms, [1]=halo gather kernel ms,
  * [2]=back-to-back period of the fused kernel ms (launch gap included).        */
 int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
+/* Per-CU record of the last on-chip resident launch with 16 x 16 tiles (tools): n <= 2048*8 ints, per CU
+ * (index = XCC<<8 | HW_ID[15:8]) {lock, launch stamp, ice-holding waves on SIMD 0..3, 0, 0}.        */
+int cice_evp_hip_debug_cuload(int32_t *out, int32_t n);
 /* Host-only: build the plan for `dims` without touching a device (CPU tests). */
 int cice_evp_hip_plan_build(const cice_evp_hip_dims *dims);
 int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_src,

@@ -354,6 +354,7 @@ program evp_ref_harness
               stressp_1 = s_sp1; stressp_2 = s_sp2; stressp_3 = s_sp3; stressp_4 = s_sp4
               stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
               stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
+              TbU = 777._dbl_kind       ! evp_body must not depend on what a previous evp() left here
               call dyn_evp_hip_evp_body(dt_dyn, harness_strength)
               write(tag,'(a,i2.2,a,i4.4)') 'b', icall, 'n', nsub
               call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)

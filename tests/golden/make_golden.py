@@ -47,6 +47,10 @@ CASES = {
     "pop_cyc_2x1_cap0_ktens": (24, 20, 12, 20, "cyclic", "closed",
                                dict(grid_kind="popfile", icecase="patchy", nsub_list=[1, 120], ncalls=1,
                                     h_capping=0.0, h_Ktens=0.2, h_e_yield=1.5, h_e_plast=2.5)),
+    # fractional capping: the general branch of visc_replpress (both quotients, ice_dyn_shared.F90:2469-2470)
+    "pop_cyc_2x2_cap05": (24, 20, 12, 10, "cyclic", "closed",
+                          dict(grid_kind="popfile", icecase="caps", nsub_list=[1, 120], ncalls=1,
+                               h_capping=0.5, h_Ktens=0.1)),
     "pop_cyc_2x2_seabed": (24, 20, 12, 10, "cyclic", "closed",
                            dict(grid_kind="popfile", icecase="full", nsub_list=[1, 120], ncalls=2,
                                 h_seabed=True)),

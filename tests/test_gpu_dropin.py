@@ -27,6 +27,10 @@ CASES = [
     (60, 44, 20, 15, "cyclic", dict(grid_kind="popfile", icecase="patchy")),
     (100, 116, 50, 29, "cyclic", dict(grid_kind="popfile", icecase="caps", h_seabed=True)),
     (64, 48, 64, 48, "closed", dict(grid_kind="popfile", icecase="full", h_revised=True)),
+    # tripole north boundary: fold row inside the loop and -- in the Option-A body -- the 12 x
+    # ice_HaloUpdate_stress symmetrisation on the device (cice_evp_hip_stress_halo)
+    (72, 40, 36, 20, "cyclic", dict(grid_kind="tripolefile", icecase="full", ns="tripole")),
+    (48, 36, 48, 36, "cyclic", dict(grid_kind="tripolefile", icecase="patchy", ns="tripole", h_capping=0.5)),
 ]
 
 
@@ -35,13 +39,14 @@ def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw
     if not run_ref.have_ref("hip_dropin"):
         pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
     kw = dict(kw)
+    ns = kw.pop("ns", "closed")
     grid_files = None
     if kw["grid_kind"] != "rect":
-        g = synth.make_grid(nx, ny, dx0=1.1e5, ns="closed")
+        g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
         run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
         run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
         grid_files = (tmp_path / "grid.bin", tmp_path / "kmt.bin")
-    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns="closed", variant="hip_dropin", h_ndte=120,
+    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="hip_dropin", h_ndte=120,
                                  ncalls=2, nsub_list=[1, 120], hipmode=True, hipbody=True,
                                  grid_files=grid_files, **kw)
     checked = 0

@@ -288,30 +288,37 @@ def test_remote_halo_without_communicator_fails_loudly(monkeypatch):
         core.finalize()
 
 
+def reference_case(tmp_path, nx, ny, bs, ns, nsub_list, h_ndte, icecase="full", **kw):
+    """Run the reference's own evp() (prebuilt oracle/_ref harness, strict build) at full size on
+    the box and wrap its dump as a GoldenCase: inputs captured at the drop-in boundary, outputs
+    after each subcycle count of nsub_list."""
+    import run_ref
+    if not run_ref.have_ref("strict"):
+        pytest.skip("oracle/_ref/evp_ref_harness_strict not present")
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+    run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+    run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
+    d, txt = run_ref.run_harness(nx, ny, bs[0], bs[1], ew="cyclic", ns=ns, variant="strict", h_ndte=h_ndte,
+                                 ncalls=1, nsub_list=list(nsub_list),
+                                 grid_kind="tripolefile" if ns == "tripole" else "popfile", icecase=icecase,
+                                 grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
+    np.savez(tmp_path / "case.npz", **d, ew=np.array("cyclic"), ns=np.array(ns))
+    import common
+    old = common.GOLDEN
+    common.GOLDEN = tmp_path
+    try:
+        return GoldenCase("case")
+    finally:
+        common.GOLDEN = old
+
+
 @pytest.mark.parametrize("bs", [(90, 60), (360, 240)])
 def test_tx1_size_tripole_vs_reference_harness(tmp_path, bs):
     """configs[3] size (360x240, tripole seam): inputs captured from, and outputs compared
     with, the reference's own evp() run here by the prebuilt oracle/_ref harness.  4x4 blocks and
     one block: both run the on-chip resident kernel with the fold inside (several blocks per rank:
     ghost images between blocks come from the per-cell table)."""
-    import run_ref
-    if not run_ref.have_ref("strict"):
-        pytest.skip("oracle/_ref/evp_ref_harness_strict not present")
-    nx, ny = 360, 240
-    g = synth.make_grid(nx, ny, dx0=1.1e5, ns="tripole")
-    run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
-    run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
-    d, txt = run_ref.run_harness(nx, ny, bs[0], bs[1], ew="cyclic", ns="tripole", variant="strict", h_ndte=240,
-                                 ncalls=1, nsub_list=[1, 240], grid_kind="tripolefile", icecase="full",
-                                 grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"))
-    np.savez(tmp_path / "case.npz", **d, ew=np.array("cyclic"), ns=np.array("tripole"))
-    import common
-    old = common.GOLDEN
-    common.GOLDEN = tmp_path
-    try:
-        c = GoldenCase("case")
-    finally:
-        common.GOLDEN = old
+    c = reference_case(tmp_path, 360, 240, bs, "tripole", [1, 240], 240)
     core = hip_from_case(c, strict=True)
     try:
         dyn, tm, um = c.inputs(1)
@@ -322,6 +329,44 @@ def test_tx1_size_tripole_vs_reference_harness(tmp_path, bs):
         assert core.timings()["tile_variant"] >= 2000
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("bs", [(320, 384), (80, 96)])
+def test_gx1_size_vs_reference_harness(tmp_path, bs, monkeypatch):
+    """configs[1] / configs[2] -- the headline grid at its full subcycle counts (ndte = 120 and 240)
+    against the reference ITSELF: inputs captured from, outputs compared with, the reference's own
+    evp() (unmodified sources, strict build) run here at 320x384, as one block and as 4x4 blocks.
+    Every kernel the bench can time on this grid: the autotuned default (on-chip resident, tagged
+    records, 16x16 tiles with the rim-wave split), the other tile shapes, the flags generation and
+    the streaming kernel -- all bit-identical to the reference after 120 and after 240 subcycles."""
+    c = reference_case(tmp_path, 320, 384, bs, "closed", [120, 240], 120)
+    dyn, tm, um = c.inputs(1)
+    assert tm.sum() > 100000
+    variants = [("default", {}),
+                ("resident 16x16", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "4"}),
+                ("resident 32x8", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "5"}),
+                ("streaming", {"CICE_EVP_HIP_RESIDENT": "0"})]
+    if bs == (320, 384):
+        variants.append(("resident flags", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "1"}))
+    keys = ("CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_RES_GEN", "CICE_EVP_HIP_RES_LOGW")
+    for what, envs in variants:
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        core = hip_from_case(c, strict=True)
+        try:
+            for nsub in (120, 240):
+                out = core.run(dyn, tm, um, ndte=nsub)
+                assert_bitwise(out, c.expected(1, nsub), f"gx1-size {bs} {what} nsub {nsub} vs the reference")
+            tv = core.timings()["tile_variant"]
+            if what.startswith("resident") or what == "default":
+                assert tv >= 1000, (what, tv)
+            if what == "streaming":
+                assert tv < 1000
+        finally:
+            core.finalize()
+    assert np.abs(out["uvel"]).max() > 1e-3
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -721,5 +766,69 @@ def test_run_recovers_when_the_resident_kernel_cannot_be_resident(monkeypatch):
         got = core.run(fields, tm, um, ndte=24)
         assert core.timings()["resident_fallbacks"] == 1
         assert_bitwise(got, want, "next call (streaming kernel)")
+    finally:
+        core.finalize()
+
+
+def test_graph_replay_follows_the_data_dependent_flags(monkeypatch):
+    """The captured subcycle loop stores its kernel arguments by value, incl. the EVP_F_* shortcuts
+    derived from the data (TbU == 0 everywhere, waterx == uocn): a call whose TbU is all zero followed
+    by one with seabed stress must not replay the first call's graph (the flags are part of the key)."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
+    monkeypatch.setenv("CICE_EVP_HIP_NOGRAPH", "0")
+    c = GoldenCase("pop_cyc_2x2_seabed")
+    core = hip_from_case(c, strict=True)
+    try:
+        dyn, tm, um = c.inputs(1)
+        assert np.abs(dyn["TbU"][um != 0]).max() > 0
+        d0 = dict(dyn, TbU=np.zeros_like(dyn["TbU"]), waterxU=dyn["uocnU"], wateryU=dyn["vocnU"])
+        for rep in range(2):
+            first = core.run(d0, tm, um, ndte=c.ndte)                 # bakes TBU_ZERO (+ WATER_IS_OCN) into its graph
+            out = core.run(dyn, tm, um, ndte=c.ndte)
+            assert_bitwise(out, c.expected(1, c.ndte), f"seabed call after a TbU == 0 call (rep {rep})")
+            assert not np.array_equal(first["uvel"], out["uvel"])
+        assert core.timings()["tile_variant"] < 1000
+    finally:
+        core.finalize()
+
+
+def test_prep_path_zeroes_diagnostics_where_the_ice_has_gone():
+    """dyn_prep2 zeroes taubx/tauby everywhere and strintx/strinty off the ice (ice_dyn_shared.F90:704-712,
+    776-781); the subcycle writes them on ice U-cells only.  Second call through the device preparation with
+    the ice removed from half the domain: the downloaded diagnostics are zero there (no stale values)."""
+    c = GoldenCase("pop_cyc_2x2_seabed")
+    core = hip_from_case(c, strict=True)
+    try:
+        st = c.prep_static()
+        core.set_prep_geometry(st["tmask"], st["umask"], st["hm"], st["tarea"], st["uarea"], st["fcor_blk"])
+        d = c.prep_scal_dict()
+        pp = evp.PrepParams(dt=d["dt"], rhoi=d["rhoi"], rhos=d["rhos"], gravit=d["gravit"],
+                            dyn_area_min=d["dyn_area_min"], dyn_mass_min=d["dyn_mass_min"],
+                            ssh_stress_coupled=d["ssh_coupled"])
+        t, state = c.prep_inputs(1)
+        dyn, _, _ = c.inputs(1)
+        tm, um, _ = core.prep(pp, t, state)
+        core.set_strength(dyn["strength"])
+        core.set_tbu(dyn["TbU"])
+        core.subcycle(c.ndte)
+        res1 = core.download()
+        assert_bitwise(res1, c.expected(1, c.ndte), "call 1 (prep + set_tbu + loop)")
+        had = (res1["strintxU"] != 0) & (res1["taubxU"] != 0)
+        assert had.any()
+        # call 2: no ice in the western half
+        t2 = {k: v.copy() for k, v in t.items()}
+        half = c.nx_block // 2
+        for k in ("aice", "vice", "vsno", "aice_init"):
+            t2[k][..., :half] = 0.0
+        state2 = dict(state, iceUmask=um, uvel=res1["uvel"], vvel=res1["vvel"], **{k: res1[k] for k in SIG})
+        tm2, um2, _ = core.prep(pp, t2, state2)
+        lost = had & (um2 == 0)
+        assert lost.any()
+        core.set_strength(dyn["strength"])
+        core.set_tbu(dyn["TbU"])
+        core.subcycle(c.ndte)
+        res2 = core.download()
+        for k in ("strintxU", "strintyU", "taubxU", "taubyU", "uvel", "vvel"):
+            assert not res2[k][lost].any(), f"{k}: stale values on cells that lost their ice"
     finally:
         core.finalize()

@@ -7,8 +7,8 @@ import numpy as np
 from cice_amd import evp, synth, decomp
 from test_gpu_parity import synth_case
 wl = sys.argv[1] if len(sys.argv) > 1 else "gx1"
-bs = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else {"gx3": (100, 116), "gx1": (320, 192), "s01": (1800, 1200), "q8": (720, 270), "q4": (720, 540)}[wl]
-ndte = {"gx3": 120, "gx1": 120, "s01": 48, "q8": 120, "q4": 120}[wl]
+bs = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else {"gx3": (100, 116), "gx1": (320, 192), "s01": (1800, 1200), "q8": (720, 270), "q4": (720, 540), "p2": (300, 240)}[wl]
+ndte = {"gx3": 120, "gx1": 120, "s01": 48, "q8": 120, "q4": 120, "p2": 120}[wl]
 scal = synth.evp_scalars(120)
 dc, geo, fields, tm, um = synth_case(wl, "full", seed=1, warm=True, bs=bs)
 d, keep = evp.make_dims(dc, 0)
@@ -25,4 +25,9 @@ t=time.perf_counter()-t0
 out=core.download()
 tt=core.timings()
 print("RESULT", wl, bs, 'us/subcycle %.2f' % (1e6*t/(10*ndte)), 'checksum', float(np.abs(out['uvel']).sum()), tt['halo_transport'], tt['launches_per_subcycle'], tt['tile_variant'])
+if os.environ.get("EVP_SHOW_CULOAD"):
+    a = core.debug_cuload()
+    used = a[a[:, 1] != 0][:, 2:6]
+    print("CULOAD cus", len(used), "waves/SIMD histogram", np.bincount(used.ravel(), minlength=5).tolist(),
+          "CUs by max SIMD load", np.bincount(used.max(axis=1), minlength=5).tolist())
 core.finalize()
