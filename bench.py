@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """EVP subcycle benchmark (BASELINE.json metric: EVP subcycle cell-updates/sec,
-gx1 fp64, at 1/2/4/8 GPUs; % of the HBM roofline).
+gx1 fp64, at 1/2/4/8 GPUs; % of the roofline).
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
@@ -10,10 +10,23 @@ state.  Workload at every N: the gx1-sized grid (320x384, fp64, ndte=120, ice on
 every ocean cell), block-decomposed over the N GPUs (strong scaling of the
 headline config; `--workload s01` selects the synthetic 3600x2400 grid).
 Rank 0 prints ONE JSON line.
+
+What the line carries besides the contract's fields:
+  roofline      the bound that binds the timed kernel.  On-chip resident kernel: fp64 VALU issue
+                (VALU-busy SIMD-cycles per launch from the committed rocprofv3 PMC pass of this
+                command / live kernel time / 1024 SIMDs x 2.4 GHz); the 368 B/cell figure is kept as a
+                labelled yardstick (`hbm_equivalent`).  Streaming kernel: HBM (`streaming` holds its
+                fractions on gx1 and on 3600x2400, measured live in this run, with PMC traffic).
+  verified      the state after the timed region (+ a few untimed steps up to the next checkpoint)
+                hashed and compared with tests/golden/bench_checksums.json (made by the CPU oracle).
+  cpu_baseline  the reference's own evp() timed on this box's cores (2-d path and its 1-d core), and --
+                the checker's job -- the HIP path run on the inputs the reference captured in this
+                same run, compared bit for bit with the reference's outputs (`reference_parity`).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +40,14 @@ sys.path.insert(0, str(ROOT))
 
 B_ALG = 368.0            # algorithmic bytes per cell-subcycle (32 reads + 14 writes, fp64)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+MAX_CLOCK_HZ = 2.4e9
+FP64_VALU_PEAK_TFLOPS = 78.6        # dense fp64 vector peak with FMA; 39.3 without (strict mode never contracts)
+# nominal arithmetic of one cell-subcycle counted on cice_amd/csrc/evp_cell.inc (classic EVP, capping 1): stress 376
+# mul/add + 4 sqrt + 4 div, stepu 46 mul/add + 1 sqrt + 2 div -- every operation counted as one flop
+ALG_FLOP = 433.0
+CHECKPOINTS = [1, 3, 5, 12, 23, 25, 50]     # total steps after which tests/golden/bench_checksums.json holds a hash
+VERIFY_FIELDS = ("uvel", "vvel", "stressp_1")
 
 
 def parse():
@@ -41,60 +62,119 @@ def parse():
                     help="allow FMA contraction (default: strict fp64, bit-identical to the reference built without FMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
-                    help="skip the extra 3600x2400 (0.1-degree-class) measurement reported under 'secondary'")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
+                    help="skip the extra measurements reported under 'secondary', 'tripole', 'roofline.streaming', 'per_call_ms'")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time per code path")
     return ap.parse_args()
 
 
-def cpu_baseline(workload, case, ndte, target_s):
-    """Rank 0, N=1 only: the reference's own evp() (oracle/_ref, built from the
-    unmodified reference sources, OpenMP over 64 blocks) timed on this box's host cores
-    by its own timer_evp; falls back to the C restatement ("port") if the prebuilt
-    reference binary did not travel."""
+def state_hash(glob: dict) -> str:
+    h = hashlib.sha256()
+    for k in VERIFY_FIELDS:
+        h.update(np.ascontiguousarray(glob[k], dtype="<f8").tobytes())
+    return h.hexdigest()
+
+
+def golden_key(workload, case, ndte, ns):
+    return f"{workload}/{case}/ndte{ndte}/{ns}/strict"
+
+
+def load_golden():
+    try:
+        return json.loads((ROOT / "tests" / "golden" / "bench_checksums.json").read_text())
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+def load_pmc():
+    """The newest tracked PMC summary (tools/profile_gpu.sh + tools/pmc_summary.py on this command)."""
+    files = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))
+    if not files:
+        return None, None
+    try:
+        return json.loads(files[-1].read_text()), f"profiles/{files[-1].name}"
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# cpu_baseline leg (rank 0, N = 1): the only part of this file that touches oracle/
+# ----------------------------------------------------------------------------------------------
+def cpu_baseline(workload, case, ndte, target_s, strict):
+    """The reference's own evp() (oracle/_ref: the unmodified reference sources compiled with amdflang
+    -O2 -fopenmp, linked against the Icepack interface stub) timed on this box's host cores by its own
+    timer_evp -- the standard 2-d path and the 1-d "shared_mem_1d" core -- plus, as the checker, the HIP
+    path on the very inputs the reference captured here, compared bit for bit with its outputs.
+    Falls back to the C restatement ("port") if the prebuilt reference binaries did not travel."""
     from cice_amd import synth
     spec = synth.GRIDS[workload]
     nx, ny = spec["nx"], spec["ny"]
     cores = len(os.sched_getaffinity(0))
     sys.path.insert(0, str(ROOT / "oracle" / "ref"))
     sys.path.insert(0, str(ROOT / "oracle"))
+    sys.path.insert(0, str(ROOT / "tests"))
     try:
         import run_ref
-        if run_ref.have_ref("fast"):
-            import tempfile
-            g = synth.make_grid(nx, ny, spec["dx0"], ns="closed")
-            td = tempfile.mkdtemp(prefix="evpcpu_")
-            run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
-            run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
-            bx, by = max(nx // 8, 8), max(ny // 8, 8)
-            threads = min(cores, (nx // bx) * (ny // by))
-            def ref_run(ncalls):
-                d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant="fast",
-                                             threads=threads, grid_kind="popfile", icecase=case,
-                                             grid_files=(td + "/grid.bin", td + "/kmt.bin"),
-                                             h_ndte=ndte, ncalls=1, nsub_list=[ndte], dump_arrays=False,
-                                             ntiming=ncalls, timeout=900)
-                return run_ref.parse_timer(txt, "evp"), txt
-            # calibrate on 2 calls, then size the sample for ~target_s of the reference's timer_evp
-            t_cal, _ = ref_run(2)
-            per_call = max(t_cal or 0.0, 1e-3) / 3.0          # timer_evp also saw the dump call
-            ncalls = int(max(2, min(2000, target_s / per_call)))
-            t, txt = ref_run(ncalls)
-            if t:
-                t *= ncalls / (ncalls + 1.0)                      # remove the untimed-loop dump call's share
-            t = run_ref.parse_timer(txt, "evp")
+        import tempfile
+        if not run_ref.have_ref("fast"):
+            raise FileNotFoundError("oracle/_ref/evp_ref_harness_fast")
+        g = synth.make_grid(nx, ny, spec["dx0"], ns="closed")
+        td = tempfile.mkdtemp(prefix="evpcpu_")
+        run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+        run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
+
+        def ref_run(variant, bx, by, threads, ncalls, **kw):
+            d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant=variant,
+                                         threads=threads, grid_kind="popfile", icecase=case,
+                                         grid_files=(td + "/grid.bin", td + "/kmt.bin"),
+                                         h_ndte=ndte, ncalls=1, nsub_list=[ndte], dump_arrays=False,
+                                         ntiming=ncalls, timeout=900, **kw)
+            return run_ref.parse_timer(txt, "evp")       # timer_evp is cleared before the ntiming calls
+
+        # candidates: the 2-d path is OpenMP over blocks (threads <= blocks); the 1-d core over the cell vector
+        cands = []
+        for bdiv in (8, 16):
+            bx, by = max(nx // bdiv, 8), max(ny // bdiv, 8)
+            nblk = (nx // bx) * (ny // by)
+            cands.append(dict(path="standard_2d", variant="fast", bx=bx, by=by, threads=min(cores, nblk), kw={}))
+        if run_ref.have_ref("fast1d"):      # (256 threads on its flat vector measured 40x slower than 16: try a few team sizes)
+            for th in sorted({min(cores, 16), min(cores, 64)}):
+                cands.append(dict(path="shared_mem_1d", variant="fast1d", bx=max(nx // 8, 8), by=max(ny // 8, 8),
+                                  threads=th, kw=dict(time_1d=True)))
+        results = []
+        for c in cands:
+            t_cal = ref_run(c["variant"], c["bx"], c["by"], c["threads"], 2, **c["kw"])
+            if not t_cal or t_cal <= 0:
+                continue
+            c["per_call"] = t_cal / 2.0
+            results.append(c)
+        if not results:
+            raise RuntimeError("no timing from the reference harness")
+        best2d = min((c for c in results if c["path"] == "standard_2d"), key=lambda c: c["per_call"], default=None)
+        best1d = min((c for c in results if c["path"] == "shared_mem_1d"), key=lambda c: c["per_call"], default=None)
+        timed = []
+        for c in [c for c in (best2d, best1d) if c]:
+            ncalls = int(max(2, min(2000, target_s / max(c["per_call"], 1e-4))))
+            t = ref_run(c["variant"], c["bx"], c["by"], c["threads"], ncalls, **c["kw"])
             if t and t > 0:
-                return dict(value=nx * ny * ndte * ncalls / t, unit="cell-updates/s", cores=threads,
-                            kind="reference",
-                            sample=f"reference evp() standard_2d compiled from the unmodified sources "
-                                   f"(amdflang -O2 -fopenmp), {nx}x{ny} in {(nx // bx) * (ny // by)} blocks "
-                                   f"{bx}x{by}, ndte={ndte}, {ncalls} evp() calls, its own timer_evp={t:.2f}s "
-                                   f"(subcycle loop incl. serial halo + deformations), {threads} OpenMP "
-                                   f"threads of {cores} host cores")
+                timed.append(dict(path=c["path"], value=nx * ny * ndte * ncalls / t, cores=c["threads"],
+                                  blocks=f"{(nx // c['bx']) * (ny // c['by'])} x {c['bx']}x{c['by']}",
+                                  evp_calls=ncalls, timer_evp_s=t))
+        if not timed:
+            raise RuntimeError("no timing from the reference harness")
+        top = max(timed, key=lambda r: r["value"])
+        out = dict(value=top["value"], unit="cell-updates/s", cores=top["cores"], kind="reference",
+                   sample=f"reference evp() ({top['path']}) compiled from the unmodified sources (amdflang -O2 "
+                          f"-fopenmp), {nx}x{ny} in {top['blocks']} blocks, ndte={ndte}, {top['evp_calls']} evp() calls, "
+                          f"its own timer_evp={top['timer_evp_s']:.2f}s (subcycle loop incl. serial halo + deformations), "
+                          f"{top['cores']} OpenMP threads of {cores} host cores; fastest of the code paths in `paths`",
+                   paths=timed, host_cores=cores)
+        if strict and run_ref.have_ref("strict"):
+            out["reference_parity"] = reference_parity(nx, ny, ndte, case, td)
+        return out
     except Exception as e:  # noqa: BLE001
-        print(f"[bench] reference CPU baseline unavailable ({e}); using the C port", file=sys.stderr)
+        print(f"[bench] reference CPU baseline unavailable ({type(e).__name__}: {e}); using the C port", file=sys.stderr)
     # port: the oracle's C restatement with OpenMP
-    import oracle
-    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle  # noqa: F401
     from test_gpu_parity import run_oracle, synth_case
     scal = synth.evp_scalars(ndte)
     dc, geo, fields, tm, um = synth_case(workload, case, seed=1, bs=(max(nx // 8, 8), max(ny // 8, 8)))
@@ -111,19 +191,42 @@ def cpu_baseline(workload, case, ndte, target_s):
                        f"setup copies, {cores} threads")
 
 
-def pmc_traffic(a, kernel):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes of this same command (profiles/): a timed run cannot collect counters itself."""
-    if a.workload != "gx1" or a.case != "full" or a.fused or a.gpus != 1:
-        return None
-    f = ROOT / "profiles" / "r01_gx1_pmc_traffic.json"
+def reference_parity(nx, ny, ndte, case, td):
+    """Checker: the reference's evp() (strict build) run HERE, one block, its subcycle inputs captured at
+    the drop-in boundary; the HIP path (whatever kernel the autotuner picks, i.e. the timed one) on those
+    inputs; every output field compared bit for bit with the reference's."""
+    import run_ref
+    import common
+    from common import GoldenCase
+    from cice_amd import evp
+    d, _ = run_ref.run_harness(nx, ny, nx, ny, ew="cyclic", ns="closed", variant="strict", h_ndte=ndte, ncalls=1,
+                               nsub_list=[ndte], grid_kind="popfile", icecase=case,
+                               grid_files=(td + "/grid.bin", td + "/kmt.bin"), timeout=900)
+    np.savez(td + "/case.npz", **d, ew=np.array("cyclic"), ns=np.array("closed"))
+    old = common.GOLDEN
+    common.GOLDEN = Path(td)
     try:
-        d = json.loads(f.read_text())
-        return d["per_kernel"][kernel]["hbm_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        return None
+        c = GoldenCase("case")
+    finally:
+        common.GOLDEN = old
+    dd, keep = c.hip_dims()
+    core = evp.EvpHip(dd, evp.make_params(c.scal_dict(), strict=True), c.d["HTE"], c.d["HTN"], c.d["dxT"], c.d["dyT"],
+                      c.d["uarear"], c.d["tarea"], keepalive=keep)
+    try:
+        dyn, tm, um = c.inputs(1)
+        out = core.run(dyn, tm, um, ndte=ndte)
+        tv = core.timings()["tile_variant"]
+    finally:
+        core.finalize()
+    want = c.expected(1, ndte)
+    bad = [k for k, w in want.items() if not np.array_equal(out[k], w)]
+    return dict(bitwise=not bad, fields_compared=len(want), fields_differing=bad, subcycles=ndte,
+                tile_variant=tv, max_abs_u=float(np.abs(out["uvel"]).max()),
+                how="reference evp() (strict build, 1 block) run in this leg; its captured subcycle inputs -> "
+                    "cice_evp_hip_run -> outputs vs the reference's, all 18 fields incl. ghost cells")
 
 
+# ----------------------------------------------------------------------------------------------
 def main():
     a = parse()
     a.strict = not a.fused
@@ -147,97 +250,191 @@ def main():
     os.environ.setdefault("CICE_EVP_HIP_DEVICE", str(local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("CICE_EVP_HIP_VERBOSE", "1")     # why a transport was not taken goes to stderr
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    golden = load_golden()
 
-    def measure(workload, case, ndte, steps, warmup, ns="closed"):
+    def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True):
         """One timed pass: `warmup` untimed + `steps` timed evp() subcycle loops of `workload`,
         block-decomposed over the ranks; barrier + sync on both sides, MAX over ranks."""
-        spec = synth.GRIDS[workload]
-        nx, ny = spec["nx"], spec["ny"]
-        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
-        st = synth.make_state(g, case=case, seed=20260928, warm=True)
-        dc = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns)
-        geo = {k: dc.scatter(g[k], rank, fill=(1.0 if k != "uarear" else 0.0))
-               for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
-        fields = {k: dc.scatter(st[k], rank) for k in evp.FIELDS}
-        tm = dc.scatter(st["iceTmask"], rank, fill=0)
-        um = dc.scatter(st["iceUmask"], rank, fill=0)
-        n_active = int(st["iceTmask"].sum())
-        del g, st
-
-        scal = synth.evp_scalars(ndte)
-        d, keep = evp.make_dims(dc, rank)
-        core = evp.EvpHip(d, evp.make_params(scal, strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
-                          geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+        saved = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
         try:
-            if world > 1 and rehearsal:
-                blobs = [None] * world
-                dist.all_gather_object(blobs, core.halo_export())
-                core.halo_import(blobs)
-            elif world > 1:
-                uid = [core.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                core.comm_init(uid[0])
-            core.upload(fields, tm, um)
+            spec = synth.GRIDS[workload]
+            nx, ny = spec["nx"], spec["ny"]
+            g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
+            st = synth.make_state(g, case=case, seed=20260928, warm=True)
+            dc = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns)
+            geo = {k: dc.scatter(g[k], rank, fill=(1.0 if k != "uarear" else 0.0))
+                   for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+            fields = {k: dc.scatter(st[k], rank) for k in evp.FIELDS}
+            tm = dc.scatter(st["iceTmask"], rank, fill=0)
+            um = dc.scatter(st["iceUmask"], rank, fill=0)
+            n_active = int(st["iceTmask"].sum())
+            del g, st
 
-            def barrier():
+            scal = synth.evp_scalars(ndte)
+            d, keep = evp.make_dims(dc, rank)
+            core = evp.EvpHip(d, evp.make_params(scal, strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
+                              geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+            try:
+                if world > 1 and rehearsal:
+                    blobs = [None] * world
+                    dist.all_gather_object(blobs, core.halo_export())
+                    core.halo_import(blobs)
+                elif world > 1:
+                    uid = [core.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(uid, src=0)
+                    core.comm_init(uid[0])
+                core.upload(fields, tm, um)
+
+                def barrier():
+                    core.sync()
+                    torch.cuda.synchronize()
+                    if world > 1:
+                        dist.barrier()
+
+                for _ in range(warmup):
+                    core.subcycle(ndte)
+                barrier()
+                t0 = time.perf_counter()
+                core.mark(0)
+                for _ in range(steps):
+                    core.subcycle(ndte)
+                core.mark(1)
                 core.sync()
                 torch.cuda.synchronize()
+                t1 = time.perf_counter()
                 if world > 1:
                     dist.barrier()
+                dt = t1 - t0
+                if world > 1:
+                    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt.item())
+                # HIP events on the library's stream around the timed region (rank 0's share)
+                tm_ev = core.timings()
+                kt = core.time_kernels(200)
+                # ---- what was timed, checked: continue (untimed) to the next checkpoint, hash the state ----
+                total = warmup + steps
+                key = golden_key(workload, case, ndte, ns)
+                target = next((n for n in CHECKPOINTS if n >= total and str(n) in golden.get(key, {})), None)
+                ver = dict(verified=None, why="no committed checksum for this configuration", key=key)
+                if not a.strict:
+                    ver["why"] = "fused mode is not bit-comparable with the oracle (tolerance: DESIGN.md)"
+                elif verify and target is not None:
+                    for _ in range(target - total):
+                        core.subcycle(ndte)
+                    core.sync()
+                out = core.download()
+                fallbacks = core.timings()["resident_fallbacks"]
+                if a.strict and verify and target is not None:
+                    mine = {k: out[k] for k in VERIFY_FIELDS}
+                    parts = [mine]
+                    if world > 1:
+                        parts = [None] * world
+                        dist.all_gather_object(parts, mine)
+                    if rank == 0:
+                        glob = {k: dc.gather({r: parts[r][k] for r in range(world)}) for k in VERIFY_FIELDS}
+                        want = golden[key][str(target)]
+                        got = state_hash(glob)
+                        ver = dict(verified=bool(got == want["sha256"]), total_steps=target, subcycles=target * ndte,
+                                   fields=list(VERIFY_FIELDS), sha256=got[:16], expected=want["sha256"][:16], key=key,
+                                   sum_abs_u=float(np.abs(glob["uvel"]).sum()), expected_sum_abs_u=want["sum_abs_u"],
+                                   how="sha256 over the global interior arrays after all timed launches (+ untimed steps up "
+                                       "to the checkpoint) vs tests/golden/bench_checksums.json (CPU oracle, pinned bit for "
+                                       "bit to the reference)")
+            finally:
+                core.finalize()
+            return dict(nx=nx, ny=ny, ndte=ndte, dc=dc, tm=tm, n_active=n_active, dt=dt, tm_ev=tm_ev, kt=kt,
+                        steps=steps, warmup=warmup, ver=ver, fallbacks=fallbacks,
+                        finite=bool(np.isfinite(out["uvel"]).all() and np.isfinite(out["stressp_1"]).all()),
+                        umax=float(np.abs(out["uvel"]).max()))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
 
-            for _ in range(warmup):
-                core.subcycle(ndte)
-            barrier()
+    def per_call_cost(workload, case, ndte):
+        """What CICE waits for per evp(): cice_evp_hip_run = H2D of 32 fields + loop + D2H of 18, page-locked arrays."""
+        spec = synth.GRIDS[workload]
+        nx, ny = spec["nx"], spec["ny"]
+        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+        st = synth.make_state(g, case=case, seed=20260928, warm=True)
+        dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", "closed")
+        geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k != "uarear" else 0.0)) for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+        work = {k: np.array(dc.scatter(st[k], 0), dtype=np.float64, order="C", copy=True) for k in evp.FIELDS}
+        tmc = np.ascontiguousarray(dc.scatter(st["iceTmask"], 0, fill=0), np.int32)
+        umc = np.ascontiguousarray(dc.scatter(st["iceUmask"], 0, fill=0), np.int32)
+        d, keep = evp.make_dims(dc, 0)
+        core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(ndte), strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
+                          geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+        try:
+            core.pin_host(*work.values())
+            for _ in range(2):
+                core.run_inplace(work, tmc, umc, ndte)
+            n = 10
             t0 = time.perf_counter()
-            core.mark(0)
-            for _ in range(steps):
-                core.subcycle(ndte)
-            core.mark(1)
-            core.sync()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            if world > 1:
-                dist.barrier()
-            dt = t1 - t0
-            if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
-            # HIP events on the library's stream around the timed region (rank 0's share)
-            tm_ev = core.timings()
-            kt = core.time_kernels(200)
-            out = core.download()
+            for _ in range(n):
+                core.run_inplace(work, tmc, umc, ndte)
+            t = (time.perf_counter() - t0) / n
+            tt = core.timings()
         finally:
             core.finalize()
-        return dict(nx=nx, ny=ny, ndte=ndte, dc=dc, tm=tm, n_active=n_active, dt=dt, tm_ev=tm_ev, kt=kt,
-                    finite=bool(np.isfinite(out["uvel"]).all() and np.isfinite(out["stressp_1"]).all()),
-                    umax=float(np.abs(out["uvel"]).max()))
+        return dict(cice_evp_hip_run=1e3 * t, h2d=tt["h2d_ms"], loop=tt["loop_ms"], d2h=tt["d2h_ms"],
+                    note="host wall time per call, 32 fields in / 18 out, caller's arrays page-locked once")
 
     ndte = a.ndte or {"gx3": 120, "gx1": 120, "s01": 480}[a.workload]
     M = measure(a.workload, a.case, ndte, a.steps, a.warmup)
     nx, ny, dc, tm, n_active, dt, tm_ev, kt = (M[k] for k in ("nx", "ny", "dc", "tm", "n_active", "dt", "tm_ev", "kt"))
-    finite, umax = M["finite"], M["umax"]
-    # secondary line: the 0.1-degree-class grid the strong-scaling target is stated on
-    # (extras must never cost the primary line: a failure is reported inside the JSON instead)
-    M2 = M3 = None
+    # extras must never cost the primary line: a failure is reported inside the JSON instead
+    M2 = M3 = MS = None
+    extra = {}
     extra_err = {}
     if a.secondary and a.workload != "s01":
-        try:
+        try:      # the 0.1-degree-class grid the strong-scaling target is stated on (streaming kernel, HBM-bound)
             M2 = measure("s01", "full", 480, 2, 1)
         except Exception as e:  # noqa: BLE001
             extra_err["secondary"] = f"{type(e).__name__}: {e}"[:300]
-    # one GPU only: the tripole grid of configs[3] (fold row averaged inside the resident kernel)
+    if a.secondary and world == 1 and tm_ev["tile_variant"] >= 1000:
+        try:      # the same workload through the streaming kernel: its HBM fraction next to the resident kernel's
+            MS = measure(a.workload, a.case, ndte, 5, 2, env={"CICE_EVP_HIP_RESIDENT": "0"})
+        except Exception as e:  # noqa: BLE001
+            extra_err["streaming"] = f"{type(e).__name__}: {e}"[:300]
     if a.secondary and a.workload == "gx1" and world == 1:
-        try:
+        try:      # the tripole grid of configs[3] (fold row averaged inside the resident kernel)
             M3 = measure("tx1", "full", 240, 10, 2, ns="tripole")
         except Exception as e:  # noqa: BLE001
             extra_err["tripole"] = f"{type(e).__name__}: {e}"[:300]
+        try:
+            extra["per_call_ms"] = per_call_cost(a.workload, a.case, ndte)
+        except Exception as e:  # noqa: BLE001
+            extra_err["per_call_ms"] = f"{type(e).__name__}: {e}"[:300]
 
     if rank == 0:
+        pmc, pmc_file = load_pmc()
+
+        def hbm_block(Mx, pmc_key):
+            """HBM roofline of a streaming-kernel measurement (one launch = one subcycle of rank 0's sub-domain)."""
+            my = sum(b.gnx * b.gny for b in Mx["dc"].local_blocks(0))
+            tk = Mx["tm_ev"]["marks_ms"] * 1e-3 / (Mx["steps"] * Mx["ndte"])
+            alg = B_ALG * my
+            e = (pmc or {}).get("kernels", {}).get(pmc_key) if world == 1 else None
+            traffic = e.get("hbm_bytes_per_launch") if e else None
+            blk = {"bound": "hbm", "achieved": alg / tk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": alg / tk / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": "evp_subcycle_tile",
+                   "kernel_us": 1e6 * tk, "alg_bytes_per_launch": alg, "tile_variant": Mx["tm_ev"]["tile_variant"],
+                   "launches_per_subcycle": Mx["tm_ev"]["launches_per_subcycle"]}
+            if traffic:
+                blk["measured_traffic_GBps"] = traffic / tk / 1e9
+                blk["pmc_source"] = f"{pmc_file}#{pmc_key}"
+            return blk
+
         cells = nx * ny
         ms_step = 1e3 * dt / a.steps
         value = cells * ndte * a.steps / dt
@@ -251,16 +448,56 @@ def main():
         n_launch = a.steps * (1 if resident else ndte)
         t_kernel = tm_ev["marks_ms"] * 1e-3 / n_launch
         alg_bytes = B_ALG * my_cells * sub_per_launch
-        achieved = alg_bytes / t_kernel / 1e9 if t_kernel > 0 else 0.0
-        kname = "evp_resident_tile" if resident else "evp_subcycle_tile"   # key in profiles/r01_gx1_pmc_traffic.json
-        # the kernel as rocprofv3 names it: gen 2 (tagged records) is tile_variant 20xx, gen 1 (flags) 10xx
-        kshown = ("evp_resident2_tile" if tm_ev["tile_variant"] >= 2000 else "evp_resident_tile") if resident else kname
+        kshown = ("evp_resident2_tile" if tm_ev["tile_variant"] >= 2000 else "evp_resident_tile") if resident else "evp_subcycle_tile"
+        if resident:
+            e = (pmc or {}).get("kernels", {}).get("gx1res") if (a.workload == "gx1" and a.case == "full" and a.strict and world == 1) else None
+            same = bool(e and e.get("bench_line_under_trace", {}).get("tile_variant") == tm_ev["tile_variant"])
+            busy = e.get("valu_busy_simd_cycles_per_launch") if e else None
+            peak = N_SIMD * MAX_CLOCK_HZ
+            flops = ALG_FLOP * my_active * sub_per_launch / t_kernel / 1e12
+            roof = {"bound": "fp64_valu",
+                    "achieved": (busy / t_kernel) if busy else None, "peak": peak, "unit": "VALU-busy SIMD-cycles/s",
+                    "frac": (busy / t_kernel / peak) if busy else None,
+                    "traffic": e.get("hbm_bytes_per_launch") if e else None,
+                    "kernel": kshown, "kernel_us": 1e6 * t_kernel, "subcycles_per_launch": sub_per_launch,
+                    "pmc_source": f"{pmc_file}#gx1res" if e else None, "pmc_same_tile_variant": same,
+                    "valu_busy_simd_cycles_per_launch": busy,
+                    "effective_clock_ghz_in_pmc_pass": e.get("effective_clock_ghz") if e else None,
+                    "nominal_flops": {"flop_per_active_cell_subcycle": ALG_FLOP, "achieved_TFLOPs": flops,
+                                      "peak_TFLOPs_without_fma": FP64_VALU_PEAK_TFLOPS / 2, "frac": flops / (FP64_VALU_PEAK_TFLOPS / 2)},
+                    "hbm_equivalent": {"alg_bytes_per_launch": alg_bytes, "GBps_equivalent": alg_bytes / t_kernel / 1e9,
+                                       "frac_of_hbm_peak": alg_bytes / t_kernel / 1e9 / HBM_PEAK_GBS,
+                                       "active_cells_only_GBps": B_ALG * my_active * sub_per_launch / t_kernel / 1e9,
+                                       "note": "yardstick only: 368 B x cells x subcycles / time is what a kernel that streams every "
+                                               "field once per subcycle would have to move; this kernel keeps the stresses and the "
+                                               "per-call operands in registers/LDS for all subcycles of a launch and moves `traffic` "
+                                               "bytes instead, so the figure may exceed the HBM peak -- HBM does not bound it"},
+                    "note": "frac = VALU-busy SIMD-cycles per launch (SQ_ACTIVE_INST_VALU x 4 from the committed PMC pass of "
+                            "this command, pmc_source) / live kernel time (HIP events on the kernel's stream over the timed "
+                            "region) / (1024 SIMDs x 2.4 GHz): the share of the chip's fp64 issue slots the launch used"}
+        else:
+            roof = hbm_block(M, {"gx1": "gx1str", "s01": "s01str"}.get(a.workload, ""))
+            roof["subcycles_per_launch"] = 1
+            roof["achieved_active_cells_only"] = B_ALG * my_active / t_kernel / 1e9
+            roof["note"] = ("achieved = 368 B x grid cells of rank 0 (SURVEY 8d: all cells of the domain, ice or not) / average "
+                            "launch duration from HIP events on the kernel's stream over the timed region")
+        streaming = {}
+        if MS is not None:
+            streaming[a.workload] = hbm_block(MS, {"gx1": "gx1str"}.get(a.workload, ""))
+            streaming[a.workload]["verified"] = MS["ver"].get("verified")
+            if a.workload in ("gx1", "gx3"):
+                streaming[a.workload]["note"] = "working set (45 MB on gx1) is Infinity-Cache resident: fabric requests, not DRAM"
+        if M2 is not None:
+            streaming["s01"] = hbm_block(M2, "s01str")
+        if streaming:
+            roof["streaming"] = streaming
         res = {
             "metric": "EVP subcycle cell-updates/sec (gx1 fp64)" if a.workload == "gx1"
                       else f"EVP subcycle cell-updates/sec ({a.workload} fp64)",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "verified": M["ver"].get("verified"),
             "config": {"workload": f"{a.workload} {nx}x{ny} B-grid EVP ndte={ndte}, case={a.case}, "
                                    f"{'strict fp64 (no FMA contraction; bit-identical to the reference)' if a.strict else 'fp64 with FMA contraction'}",
                        "cells": cells, "active_T_cells": n_active, "ndte": ndte,
@@ -270,26 +507,13 @@ def main():
                        "launches_per_subcycle": tm_ev["launches_per_subcycle"],
                        "halo_transport": tm_ev["halo_transport"],
                        "autotune_probe_us": {"streaming": 1e3 * tm_ev["stream_probe_ms"], "resident": 1e3 * tm_ev["resident_probe_ms"]},
-                       "finite": finite, "max_abs_u": umax},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, kname),
-                         "kernel": kshown, "kernel_us": 1e6 * t_kernel,
-                         "subcycles_per_launch": sub_per_launch,
-                         "alg_bytes_per_launch": alg_bytes,
-                         "achieved_active_cells_only": B_ALG * my_active * sub_per_launch / t_kernel / 1e9,
-                         "streaming_kernel_us_single_launch_event_pair": 1e3 * kt["stencil_ms"],
-                         "note": ("achieved = 368 B x grid cells of rank 0 (SURVEY 8d: all cells of the domain, ice or "
-                                  "not) x subcycles per launch / average launch duration from HIP events on the kernel's "
-                                  "stream over the timed region. " +
-                                  ("The resident kernel keeps stresses and per-call operands in registers/LDS for all "
-                                   "subcycles of a launch, so its real fabric traffic (`traffic`) is far below the "
-                                   "algorithmic bytes: the HBM roofline no longer bounds it." if resident else
-                                   "The 45 MB gx1 working set is Infinity-Cache resident."))},
+                       "resident_fallbacks": M["fallbacks"],
+                       "finite": M["finite"], "max_abs_u": M["umax"]},
+            "verification": M["ver"],
+            "roofline": roof,
         }
         if M2 is not None:
             c2 = M2["nx"] * M2["ny"]
-            my2 = sum(b.gnx * b.gny for b in M2["dc"].local_blocks(0))
-            tk2 = M2["tm_ev"]["marks_ms"] * 1e-3 / (2 * 480)
             res["secondary"] = {
                 "workload": f"s01 {M2['nx']}x{M2['ny']} B-grid EVP ndte=480, case=full (0.1-degree class), strong scaling",
                 "value": c2 * 480 * 2 / M2["dt"], "unit": "cell-updates/s", "steps": 2, "warmup": 1,
@@ -298,18 +522,19 @@ def main():
                                  f"{M2['dc'].block_size_x}x{M2['dc'].block_size_y} cells each",
                 "tile_variant": M2["tm_ev"]["tile_variant"], "halo_transport": M2["tm_ev"]["halo_transport"],
                 "launches_per_subcycle": M2["tm_ev"]["launches_per_subcycle"],
-                "roofline_frac_rank0": B_ALG * my2 / tk2 / 1e9 / HBM_PEAK_GBS if tk2 > 0 else None,
-                "finite": M2["finite"]}
+                "roofline_frac_rank0": streaming["s01"]["frac"],
+                "verified": M2["ver"].get("verified"), "finite": M2["finite"]}
         for k_, v_ in extra_err.items():
             res[k_] = {"error": v_}
+        res.update(extra)
         if M3 is not None:
             res["tripole"] = {
                 "workload": "tx1 360x240 tripole B-grid EVP ndte=240, case=full, one GPU",
                 "value": M3["nx"] * M3["ny"] * 240 * 10 / M3["dt"], "unit": "cell-updates/s", "steps": 10, "warmup": 2,
                 "us_per_subcycle": 1e6 * M3["dt"] / (10 * 240), "tile_variant": M3["tm_ev"]["tile_variant"],
-                "finite": M3["finite"]}
+                "verified": M3["ver"].get("verified"), "finite": M3["finite"]}
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.workload, a.case, ndte, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(a.workload, a.case, ndte, a.cpu_seconds, a.strict)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

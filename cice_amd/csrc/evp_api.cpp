@@ -210,7 +210,7 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
     HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
     S.t_h2d_ms = ms;
     S.uploaded = true;
-    S.res2_order_stale = true;
+    if (S.hmask_prev != S.hmask) { S.res2_order_stale = true; S.hmask_prev = S.hmask; }
     return tune_after_upload();
 }
 
@@ -499,6 +499,16 @@ int cice_evp_hip_debug_cuload(int32_t *out, int32_t n)
     HIPC(hipStreamSynchronize(S.stream));
     HIPC(hipMemcpy(out, S.res2_cuload, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
+}
+
+// Phase stamps of the last resident launch made with CICE_EVP_HIP_RES_PROF=1: [tiles][4 chunks][8] x u64.
+int cice_evp_hip_debug_prof(uint64_t *out, int32_t ntiles_max)
+{
+    if (!S.ready || !S.res2_prof) return fail(-1, "no profiled resident launch (CICE_EVP_HIP_RES_PROF=1, 16 x 16 tiles)");
+    if (!out || ntiles_max < S.res2_ntiles) return fail(-1, "bad argument: need room for %d tiles", S.res2_ntiles);
+    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemcpy(out, S.res2_prof, (size_t)S.res2_ntiles * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return S.res2_ntiles > 0 ? 0 : -1;
 }
 
 // Host-only: build the halo plan for `dims` without touching a device (tests).

@@ -99,7 +99,8 @@ struct EvpResident2 {
     const uint8_t *late_waves; // [ntiles]
     const uint8_t *nact;       // [ntiles] chunks (64 entries of perm) that hold ice cells: the first nact
     int *cuload;               // [2048][8] per-CU record of the launch: lock, stamp, ice-holding waves per SIMD
-    int dbg;                   // timing experiments only (CICE_EVP_HIP_RES_DEBUG; WRONG results): 1 no tag check, 2 no ring loads, 4 longer sleep; 8 = every fourth tile lags 10 us per subcycle (results stay right); 16 = tile 1 never runs (every wait on it gives up)
+    unsigned long long *prof;  // NULL, or [ntiles][4 chunks][8]: cycles per phase (tools)
+    int dbg;                   // timing experiments only (CICE_EVP_HIP_RES_DEBUG; WRONG results): 1 no tag check, 2 no ring loads, 4 longer sleep; 8 = every fourth tile lags 10 us per subcycle (results stay right); 16 = tile 1 never runs (every wait on it gives up); A/B switches, results stay right: 32 = 16 x 16 tiles without the rim-wave split, 64 = without the per-CU SIMD balancing
     int par0;                  // which of rec[0/1] holds the records of subcycle index 0 of THIS launch
                                // (flips so that a launch never starts in the buffer the previous one ended in)
     // neighbours on other GPUs (ring entries with z == -2 are produced there); rimg == NULL: none

@@ -171,6 +171,7 @@ struct State {
     // 16 x 16 tiles (rim wave / interior waves): thread -> cell map, waves that wait for the ring, chunks with ice
     uint8_t *res2_perm = nullptr, *res2_late = nullptr, *res2_nact = nullptr;
     int *res2_cuload = nullptr;                           // per-CU record of a launch (EvpResident2::cuload)
+    unsigned long long *res2_prof = nullptr;              // phase stamps (CICE_EVP_HIP_RES_PROF=1)
     std::vector<uint8_t> res2_cls_h;                      // per tile and cell position: 0 not computed, 1 reads no ring velocity, 2 does
     std::vector<int> res2_cnt_h;                          // ring entries per tile (host copy)
     void *res2_rec[2] = {nullptr, nullptr};
@@ -195,7 +196,7 @@ struct State {
 
     double t_loop_ms = 0, t_h2d_ms = 0, t_d2h_ms = 0;
     int t_nsub = 0;
-    std::vector<uint8_t> hmask;
+    std::vector<uint8_t> hmask, hmask_prev;   // masks of this / the previous upload (what depends on them is rebuilt only when they change)
     std::map<const void *, size_t> pinned;   // host ranges registered by cice_evp_hip_pin_host
 };
 

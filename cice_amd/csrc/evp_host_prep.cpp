@@ -170,7 +170,7 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     if (!(flagword & 1u)) S.flags |= EVP_F_WATER_IS_OCN;
     if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
     S.uploaded = true;
-    S.res2_order_stale = true;
+    if (S.hmask_prev != S.hmask) { S.res2_order_stale = true; S.hmask_prev = S.hmask; }
     return tune_after_upload();
 }
 

@@ -367,6 +367,12 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.late_waves = S.res2_late;
     R.nact = S.res2_nact;
     R.cuload = S.res2_cuload;
+    R.prof = nullptr;
+    if (S.res2_logw == 4 && env("CICE_EVP_HIP_RES_PROF") && std::atoi(env("CICE_EVP_HIP_RES_PROF"))) {
+        if (!S.res2_prof) HIPC(hipMalloc((void **)&S.res2_prof, (size_t)S.res2_ntiles * 32 * sizeof(unsigned long long)));
+        HIPC(hipMemsetAsync(S.res2_prof, 0, (size_t)S.res2_ntiles * 32 * sizeof(unsigned long long), S.stream));
+        R.prof = S.res2_prof;
+    }
     const int dbg2 = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.dbg = dbg2;
     R.seam = S.res2_seam;

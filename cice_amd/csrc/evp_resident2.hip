@@ -123,6 +123,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // chunks on the CU's least loaded SIMDs (the wave -> SIMD map is the hardware's: read from HW_ID;
     // a small per-CU record under a lock, once per launch).  Speed only: any chunk -> wave map is correct.
     int tq = t;
+    int cu_rank = 0;                          // how many workgroups had reached this CU before this one
     if (PERM && R.cuload && !(R.dbg & 64)) {
         const int wave = t >> 6;
         if ((t & 63) == 0) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         }
         __syncthreads();
         if (t == 0) {
-            int *L = R.cuload + 8 * s_cu;         // [0] lock, [1] launch stamp, [2..5] ice-holding waves per SIMD
+            int *L = R.cuload + 8 * s_cu;         // [0] lock, [1] launch stamp, [2..5] ice-holding waves per SIMD, [6] workgroups so far
             const int nact = R.nact[tile];        // active chunks of this tile: 0 .. nact-1
             int chunk_of[4] = {0, 1, 2, 3};
             unsigned spins = 0;
@@ -146,20 +147,26 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             if (locked) {
                 int ld[4];
                 const int stamp = __hip_atomic_load(&L[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool fresh = stamp != (int)R.tag_base;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    ld[q] = stamp == (int)R.tag_base ? __hip_atomic_load(&L[2 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    ld[q] = fresh ? 0 : __hip_atomic_load(&L[2 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int rank = fresh ? 0 : __hip_atomic_load(&L[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_simd[0] |= rank << 8;               // (the arrival rank travels to the other threads with it)
                 bool used[4] = {false, false, false, false};
                 for (int ck = 0; ck < 4; ++ck) {      // active chunks first, each to the free wave on the least loaded SIMD
                     int best = -1;
-                    for (int w = 0; w < 4; ++w)
-                        if (!used[w] && (best < 0 || ld[s_simd[w]] < ld[s_simd[best]])) best = w;
+                    for (int w = 0; w < 4; ++w) {
+                        if (used[w]) continue;
+                        if (best < 0 || ld[s_simd[w] & 3] < ld[s_simd[best] & 3]) best = w;
+                    }
                     used[best] = true;
                     chunk_of[best] = ck;
-                    if (ck < nact) ld[s_simd[best]] += 1;
+                    if (ck < nact) ld[s_simd[best] & 3] += 1;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) __hip_atomic_store(&L[2 + q], ld[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&L[6], rank + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&L[1], (int)R.tag_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&L[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -169,6 +176,10 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         }
         __syncthreads();
         tq = s_chunk[wave] * 64 + (t & 63);
+        cu_rank = s_simd[0] >> 8;
+        // (tried, no measurable effect on gx1: one s_setprio level per workgroup on all SIMDs of its CU, in
+        // either order; s_setprio 3 for the rim wave between its poll and the barrier; rim waves of the
+        // workgroups of a CU on different SIMDs; s_sleep 0/3/8 in the poll loop -- all within +-2 %)
     }
     // which T-cell of the tile this thread owns: row-major (lane = column) unless permuted
     const int pos = PERM ? (int)R.perm[tile * 256 + tq] : t;      // == trow*W + tcol
@@ -380,6 +391,18 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     }
 
     // ---- the subcycle loop (ice_dyn_evp.F90:859-913) ------------------------------------------
+    // optional phase stamps of every wave (CICE_EVP_HIP_RES_PROF=1, tools/resident_phases.py): shader cycles
+    // spent in [ring poll | stress | wait at the barrier before the momentum step | momentum step, seam,
+    // publish | wait at the barrier that ends the subcycle]
+    const bool prof = R.prof != nullptr;
+    unsigned long long pc0 = 0, pacc0 = 0, pacc1 = 0, pacc2 = 0, pacc3 = 0, pacc4 = 0;
+    if (prof) pc0 = __builtin_readcyclecounter();
+#define EVP_STAMP(acc)                                                  \
+    if (prof) {                                                         \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        acc += now_ - pc0;                                              \
+        pc0 = now_;                                                     \
+    }
     for (int k = 0; k < R.ndte; ++k) {
         const unsigned want = R.tag_base + (unsigned)k;       // tag of the velocities subcycle k reads
         const v4u *rd = (const v4u *)R.rec[(k + par0) & 1];
@@ -424,6 +447,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        EVP_STAMP(pacc0)
 
         double str[8];
 #pragma unroll
@@ -437,6 +461,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             a.dxhy = s_tc[2 * 256 + t]; a.dyhx = s_tc[3 * 256 + t];
             MM::template stress<CAP>(A.p, a, s, str);
         }
+        EVP_STAMP(pacc1)
         double sx1, sy2;
         if (PERM) {      // by cell position: the U-cell's thread need not sit next to its T neighbours
             s_str[0 * SP + sp] = str[2];
@@ -458,6 +483,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             sy2 = __shfl_down(str[6], 1);
             __syncthreads();
         }
+        EVP_STAMP(pacc2)
 
         if (isU) {
             typename MM::UI q;
@@ -531,7 +557,15 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         }
         if (rpub) publish_remote(((k + par0) & 1) ^ 1, u_own, v_own, want + 1u);
         // no publish step: the records carry their own tags
+        EVP_STAMP(pacc3)
         if (split) __syncthreads();   // the tile's own new velocities are in LDS before anybody's next stress update
+        EVP_STAMP(pacc4)
+    }
+#undef EVP_STAMP
+    if (prof && (t & 63) == 0) {
+        unsigned long long *o = R.prof + ((size_t)tile * 4 + (tq >> 6)) * 8;
+        o[0] = pacc0; o[1] = pacc1; o[2] = pacc2; o[3] = pacc3; o[4] = pacc4;
+        o[5] = (unsigned long long)cu_rank; o[6] = (unsigned long long)(t >> 6); o[7] = (unsigned long long)R.nact[tile];
     }
     // ghost cells that mirror another rank's cells: fetch the final velocities (the caller
     // relies on current ghosts, ice_dyn_evp.F90:920-934)

@@ -43,7 +43,7 @@ EXPORTS = [
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_prep_fetch",
-    "cice_evp_hip_addr", "cice_evp_hip_debug_cuload",
+    "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof",
 ]
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
 # T-grid inputs of the preparation phase (order of cice_evp_hip_prep's tfields11) and the
@@ -299,6 +299,11 @@ class EvpHip:
     def debug_cuload(self):
         a = np.zeros((2048, 8), dtype=np.int32)
         _check(self.lib, self.lib.cice_evp_hip_debug_cuload(_ip(a), C.c_int32(a.size)), "(debug_cuload)")
+        return a
+
+    def debug_prof(self, ntiles_max: int = 4096):
+        a = np.zeros((ntiles_max, 4, 8), dtype=np.uint64)
+        _check(self.lib, self.lib.cice_evp_hip_debug_prof(a.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(ntiles_max)), "(debug_prof)")
         return a
 
     def time_kernels(self, nrep: int = 50) -> dict:

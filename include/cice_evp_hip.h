@@ -243,6 +243,10 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
 /* Per-CU record of the last on-chip resident launch with 16 x 16 tiles (tools): n <= 2048*8 ints, per CU
  * (index = XCC<<8 | HW_ID[15:8]) {lock, launch stamp, ice-holding waves on SIMD 0..3, 0, 0}.        */
 int cice_evp_hip_debug_cuload(int32_t *out, int32_t n);
+/* Phase stamps of the last resident launch made under CICE_EVP_HIP_RES_PROF=1 (tools/resident_phases.py):
+ * per tile and chunk of 64 cells 8 x uint64 = shader cycles in {ring poll, stress, barrier wait, momentum
+ * step + publish, barrier wait}, arrival rank of the workgroup on its CU, hardware wave, active chunks.    */
+int cice_evp_hip_debug_prof(uint64_t *out, int32_t ntiles_max);
 /* Host-only: build the plan for `dims` without touching a device (CPU tests). */
 int cice_evp_hip_plan_build(const cice_evp_hip_dims *dims);
 int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_src,

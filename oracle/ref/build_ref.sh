@@ -80,6 +80,19 @@ build_variant () {
         $(for o in $COMMON; do echo ../$o; done) -o "$OUT/evp_ref_harness_$variant"
     cd ..
 
+    # (1b) CPU baseline of the reference's own 1-d core (evp_algorithm='shared_mem_1d', its fastest CPU
+    #      form per SURVEY 8 a11): the reference's ice_dyn_evp1d.F90, timing only, no capture
+    if [ "$variant" = fast ]; then
+      mkdir -p ref1d && cd ref1d
+      $FC $fflags -cpp -I.. -c "$HERE/evp_dumpio.F90" -o evp_dumpio.o
+      $FC $fflags -cpp -I.. -I. -c "$EVP1D_REF" -o ice_dyn_evp1d.o
+      $FC $fflags -cpp -I.. -I. -c "$EVP" -o ice_dyn_evp.o
+      $FC $fflags -cpp -DHARNESS_REF1D -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp1d.o ice_dyn_evp.o \
+          $(for o in $COMMON; do echo ../$o; done) -o "$OUT/evp_ref_harness_fast1d"
+      cd ..
+      echo "built $OUT/evp_ref_harness_fast1d"
+    fi
+
     # (2) drop-in demonstration: the reference's unmodified evp() driver linked with the
     #     build-owned `ice_dyn_evp1d` that forwards to the HIP core (cice_amd/fortran),
     #     i.e. Option B of INTEGRATION.md.  Needs cice_amd/libcice_evp_hip.so.

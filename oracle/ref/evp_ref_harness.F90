@@ -38,7 +38,13 @@ program evp_ref_harness
   use ice_calendar, only: dt, dt_dyn, ndtd
   use ice_dyn_shared
   use ice_dyn_evp, only: init_evp, evp
+#ifdef HARNESS_REF1D
+  ! timing-only build: the reference's OWN ice_dyn_evp1d (its 1-d "shared_mem_1d" EVP core,
+  ! ice_dyn_evp1d.F90 + ice_dyn_core1d.F90) instead of the capture module
+  use ice_dyn_evp1d, only: dyn_evp1d_init, dyn_evp1d_finalize
+#else
   use ice_dyn_evp1d, only: capture_tag, dyn_evp1d_init, dyn_evp1d_finalize
+#endif
 #ifdef HARNESS_HIP_BODY
   use ice_dyn_evp_hip, only: dyn_evp_hip_evp_body
 #endif
@@ -77,11 +83,12 @@ program evp_ref_harness
   integer(int_kind)  :: ntiming     = 0           ! extra evp() calls, timed, after the dumps
   logical            :: hipmode     = .false.     ! drop-in check: HIP core (via ice_dyn_evp1d) vs standard_2d
   logical            :: hipbody     = .false.     ! with hipmode: also Option A, preparation + loop on the device
+  logical            :: time_1d     = .false.     ! timing loop with evp_algorithm='shared_mem_1d' (HARNESS_REF1D build only)
 
   namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
      h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
      h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, &
-     dump_arrays, ntiming, hipmode, hipbody
+     dump_arrays, ntiming, hipmode, hipbody, time_1d
 
   ! ---- locals ----------------------------------------------------------
   integer(int_kind) :: i, j, iblk, icall, k, nsub, nl, ios, nthreads
@@ -128,6 +135,9 @@ program evp_ref_harness
      kmt_type='file'
   endif
 
+#ifdef HARNESS_REF1D
+  save_ghte_ghtn = .true.      ! the 1-d core gathers the global HTE/HTN (ice_init.F90:1464-1466 sets this for it)
+#endif
   kdyn=1; ndte=h_ndte; revised_evp=h_revised; evp_algorithm='standard_2d'
   elasticDamp=h_elasticDamp
   e_yieldcurve=h_e_yield; e_plasticpot=h_e_plast; Ktens=h_Ktens
@@ -288,6 +298,7 @@ program evp_ref_harness
         call dump_r8_3d(trim(tag)//'_stress12_1', stress12_1, nblocks); call dump_r8_3d(trim(tag)//'_stress12_2', stress12_2, nblocks)
         call dump_r8_3d(trim(tag)//'_stress12_3', stress12_3, nblocks); call dump_r8_3d(trim(tag)//'_stress12_4', stress12_4, nblocks)
      endif
+#ifndef HARNESS_REF1D
      ! (1) capture the subcycle inputs at the boundary (computes nothing)
      write(tag,'(a,i2.2)') 'in', icall
      capture_tag = tag
@@ -295,6 +306,7 @@ program evp_ref_harness
      if (.not. dump_arrays) call dump_end
      call evp(dt_dyn)
      evp_algorithm = 'standard_2d'
+#endif
      endif
 
      ! other products of the preparation phase that the subcycle boundary does not carry
@@ -425,6 +437,12 @@ program evp_ref_harness
      nthreads = 1
 #if defined (_OPENMP)
      nthreads = omp_get_max_threads()
+#endif
+#ifdef HARNESS_REF1D
+     if (time_1d) then
+        evp_algorithm = 'shared_mem_1d'
+        call evp(dt_dyn)           ! first call of the 1-d core builds its index lists: not timed
+     endif
 #endif
      call ice_timer_clear(timer_evp)
      call system_clock(c0_clk, crate)

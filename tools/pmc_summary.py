@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 output of tools/profile_gpu.sh (gpurun_out/<tag>/) to the tracked summary
+bench.py quotes: per kernel/workload pair the average launch duration of the dominant kernel
+(kernel trace), its hardware counters per launch (PMC passes), and what follows from them --
+HBM-side bytes per launch (FETCH_SIZE corrected by the factor measured on known byte counts in the
+same access width, tools/pmc_calib.hip; WRITE_SIZE likewise), VALU-busy SIMD cycles, effective clock.
+
+  python tools/pmc_summary.py gpurun_out/<tag> profiles/r02_pmc_summary.json
+"""
+from __future__ import annotations
+
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+N_SIMD = 1024            # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+N_XCD = 8
+MAX_CLOCK_HZ = 2.4e9
+
+DOMINANT = {"gx1res": "evp_resident", "gx1str": "evp_subcycle_tile", "s01str": "evp_subcycle_tile"}
+
+
+def counters(path: Path, match: str):
+    """{counter: (average per launch, launches)} and the average duration of kernels whose name contains `match`."""
+    agg, dur = defaultdict(list), []
+    kname = None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if match not in r["Kernel_Name"]:
+                continue
+            kname = r["Kernel_Name"]
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {c: (sum(v) / len(v), len(v)) for c, v in agg.items()}
+    return out, (sum(dur) / len(dur) * 1e-3 if dur else None), kname
+
+
+def kernel_stats(path: Path, match: str):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if match in r["Name"]:
+                return dict(name=r["Name"], calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) * 1e-3,
+                            min_us=float(r["MinNs"]) * 1e-3, max_us=float(r["MaxNs"]) * 1e-3)
+    return None
+
+
+def calibration(d: Path):
+    """bytes really moved / bytes the counter reports, per calibration kernel."""
+    known = {}
+    plain = d / "calib_plain.log"
+    if not plain.exists():
+        return None
+    for line in plain.read_text().splitlines():
+        m = re.match(r"CALIB (\w+) bytes_read (\d+) bytes_written (\d+)", line)
+        if m:
+            known[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    out = {}
+    for cname, idx in (("FETCH_SIZE", 0), ("WRITE_SIZE", 1)):
+        f = d / f"calib_{cname}_counter_collection.csv"
+        if not f.exists():
+            continue
+        for k, b in known.items():
+            c, _, _ = counters(f, k)
+            if cname in c and c[cname][0] > 0 and b[idx] > 0:
+                out[f"{cname}:{k}"] = b[idx] / (c[cname][0] * 1024.0)
+    return out
+
+
+def main():
+    d, dst = Path(sys.argv[1]), Path(sys.argv[2])
+    cal = calibration(d) or {}
+    # 8 B per lane coalesced, as every array access of the streaming EVP kernel
+    f_fetch = cal.get("FETCH_SIZE:calib_read8", 2.0)
+    f_write = cal.get("WRITE_SIZE:calib_write8", 1.0)
+    res = {"source": str(d), "calibration": {"measured": cal, "fetch_factor_used": f_fetch, "write_factor_used": f_write,
+                                             "note": "bytes = counter [KB] x 1024 x factor; factors from tools/pmc_calib.hip "
+                                                     "(1 GiB streams of 8 B per lane)"},
+           "kernels": {}}
+    for key, match in DOMINANT.items():
+        st = d / f"{key}_trace_kernel_stats.csv"
+        if not st.exists():
+            continue
+        entry = {"kernel_trace": kernel_stats(st, match)}
+        cnt = {}
+        for p in ("sq1", "sq2", "fetch", "write"):
+            f = d / f"{key}_{p}_counter_collection.csv"
+            if f.exists():
+                c, dur_us, kname = counters(f, match)
+                for k, (v, n) in c.items():
+                    cnt[k] = {"avg_per_launch": v, "launches": n, "pass": p, "pass_avg_us": dur_us}
+                entry["kernel"] = kname
+        entry["counters"] = cnt
+        g = lambda k: cnt[k]["avg_per_launch"] if k in cnt else None
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            entry["hbm_bytes_per_launch"] = (g("FETCH_SIZE") * f_fetch + g("WRITE_SIZE") * f_write) * 1024.0
+            entry["hbm_read_bytes_per_launch"] = g("FETCH_SIZE") * f_fetch * 1024.0
+            entry["hbm_write_bytes_per_launch"] = g("WRITE_SIZE") * f_write * 1024.0
+        if g("SQ_ACTIVE_INST_VALU") is not None:
+            # SQ_* cycle counters tick in quad-cycles (MI355X_MICROARCH.md, per-instruction constants)
+            busy = g("SQ_ACTIVE_INST_VALU") * 4.0
+            entry["valu_busy_simd_cycles_per_launch"] = busy
+            dur = cnt["SQ_ACTIVE_INST_VALU"]["pass_avg_us"] * 1e-6
+            entry["valu_busy_frac_of_max_clock_in_pmc_pass"] = busy / (N_SIMD * dur * MAX_CLOCK_HZ)
+            if g("SQ_WAVE_CYCLES"):
+                entry["wave_cycles_share"] = {k: g(k) / g("SQ_WAVE_CYCLES") for k in
+                                              ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if g(k)}
+            if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
+                entry["valu_insts_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
+        if g("GRBM_GUI_ACTIVE") is not None:
+            dur = cnt["GRBM_GUI_ACTIVE"]["pass_avg_us"] * 1e-6
+            entry["effective_clock_ghz"] = g("GRBM_GUI_ACTIVE") / N_XCD / dur * 1e-9
+        bj = d / f"{key}_bench_under_trace.json"
+        if bj.exists() and bj.read_text().strip():
+            try:
+                b = json.loads(bj.read_text())
+                entry["bench_line_under_trace"] = {"us_per_subcycle": b["config"]["us_per_subcycle"],
+                                                   "kernel_us": b["roofline"]["kernel_us"],
+                                                   "tile_variant": b["config"]["tile_variant"]}
+            except Exception:  # noqa: BLE001
+                pass
+        res["kernels"][key] = entry
+    dst.write_text(json.dumps(res, indent=1))
+    for k, e in res["kernels"].items():
+        print(k, {q: e.get(q) for q in ("hbm_bytes_per_launch", "valu_busy_simd_cycles_per_launch", "effective_clock_ghz")},
+              e["kernel_trace"])
+
+
+if __name__ == "__main__":
+    main()
