@@ -163,29 +163,39 @@ int cice_evp_hip_set_metrics(const double *cxp, const double *cyp, const double 
     return 0;
 }
 
-int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const int32_t *iceUmask)
+static int upload_impl(const double *const *f, const int32_t *iceTmask, const int32_t *iceUmask, bool keep_sig)
 {
     if (!S.ready) return fail(-1, "not initialised");
     if (!f || !iceTmask || !iceUmask) return fail(-1, "null argument");
     HIPC(hipEventRecord(S.ev2, S.stream));
-    S.cur = 0;
-    for (int k = 0; k < 12; ++k) {
-        if (!f[k]) return fail(-1, "null stress field %d", k);
-        if (h2d(S.sig[0][k], f[k])) return -1;
-        HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    CopyBatch B;
+    if (!keep_sig) {
+        S.cur = 0;
+        for (int k = 0; k < 12; ++k) {
+            if (!f[k]) return fail(-1, "null stress field %d", k);
+            B.items.push_back({S.sig[0][k], f[k]});
+        }
     }
+    const int cur = S.cur;      // keep_sig: the stresses of the previous call live in sig[cur]
     for (int fi = F_STRENGTH; fi < F_COUNT; ++fi) {
         if (fi == F_UVEL || fi == F_VVEL) continue;
         if ((fi == F_UVEL_INIT || fi == F_VVEL_INIT) && !f[fi]) continue;   // only read when revp = 1
+        // (strintx/y, taubx/y are outputs of the loop on ice U-cells only; elsewhere the caller's values -- zeroed by
+        // dyn_prep2 -- must survive the download, so they travel in as well)
         if (!f[fi]) return fail(-1, "null field %d", fi);
-        if (h2d(S.in[fi], f[fi])) return -1;
+        B.items.push_back({S.in[fi], f[fi]});
     }
     if (S.prm.revp != 0.0 && (!f[F_UVEL_INIT] || !f[F_VVEL_INIT]))
         return fail(-1, "uvel_init/vvel_init required for revised EVP");
     if (!f[F_UVEL] || !f[F_VVEL]) return fail(-1, "null velocity field");
-    if (h2d(S.u[0], f[F_UVEL]) || h2d(S.v[0], f[F_VVEL])) return -1;
-    HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    B.items.push_back({S.u[cur], f[F_UVEL]});
+    B.items.push_back({S.v[cur], f[F_VVEL]});
+    if (h2d_batch(B)) return -1;
+    if (!keep_sig)
+        for (int k = 0; k < 12; ++k)
+            HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.u[cur ^ 1], S.u[cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.v[cur ^ 1], S.v[cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
     bool water_is_ocn = true, tbu_zero = true;
     {
         const double *wx = f[F_WATERX], *wy = f[F_WATERY], *uo = f[F_UOCN], *vo = f[F_VOCN], *tb = f[F_TBU];
@@ -204,6 +214,7 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
     if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
     evp_launch_vrelfac(S.in[F_AIX], S.in[F_CW], S.prm.rhow, S.vrelfac, S.n, S.stream);
     HIPC(hipMemcpyAsync(S.mask, S.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    if (keep_sig) evp_launch_zero_sig_off_mask(S.sig[0], S.sig[1], S.mask, S.n, S.stream);
     HIPC(hipEventRecord(S.ev3, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
     float ms = 0;
@@ -212,6 +223,12 @@ int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const i
     S.uploaded = true;
     if (S.hmask_prev != S.hmask) { S.res2_order_stale = true; S.hmask_prev = S.hmask; }
     return tune_after_upload();
+}
+
+int cice_evp_hip_upload(const double *const *f, const int32_t *iceTmask, const int32_t *iceUmask)
+{
+    S.sig_valid = false;
+    return upload_impl(f, iceTmask, iceUmask, false);
 }
 
 int cice_evp_hip_subcycle(int32_t ndte)
@@ -341,13 +358,57 @@ int cice_evp_hip_pin_host(const void *ptr, int64_t bytes)
     if (!S.ready) return fail(-1, "not initialised");
     if (!ptr || bytes <= 0) return fail(-1, "bad argument");
     auto it = S.pinned.find(ptr);
-    if (it != S.pinned.end() && it->second >= (size_t)bytes) return 0;
+    if (it != S.pinned.end() && it->second.bytes >= (size_t)bytes) return 0;
     if (it != S.pinned.end()) {
         (void)hipHostUnregister(const_cast<void *>(ptr));
         S.pinned.erase(it);
     }
-    HIPC(hipHostRegister(const_cast<void *>(ptr), (size_t)bytes, hipHostRegisterDefault));
-    S.pinned[ptr] = (size_t)bytes;
+    // mapped: the device can address the range itself, so the per-call traffic becomes one gather and one
+    // scatter launch (evp_copy.hip) instead of one copy per array
+    void *dev = nullptr;
+    if (hipHostRegister(const_cast<void *>(ptr), (size_t)bytes, hipHostRegisterMapped) == hipSuccess) {
+        if (hipHostGetDevicePointer(&dev, const_cast<void *>(ptr), 0) != hipSuccess) dev = nullptr;
+    } else {
+        (void)hipGetLastError();
+        HIPC(hipHostRegister(const_cast<void *>(ptr), (size_t)bytes, hipHostRegisterDefault));
+    }
+    S.pinned[ptr] = State::Pinned{(size_t)bytes, dev};
+    return 0;
+}
+
+// Options of the per-call entry points.  CICE_EVP_HIP_OPT_STRESS_RESIDENT (1): the 12 stress components
+// stay on the device between calls of cice_evp_hip_run -- evp() is their only writer (ice_dyn_evp.F90), so
+// they are uploaded on the first call only (and after cice_evp_hip_invalidate_stresses), zeroed off
+// iceTmask on the device as dyn_prep2 does on the host, and not downloaded; the caller fetches them when
+// something else needs them (restart / history: cice_evp_hip_fetch_stresses).
+int cice_evp_hip_set_option(int32_t key, int32_t value)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (key == CICE_EVP_HIP_OPT_STRESS_RESIDENT) {
+        S.opt_sig_resident = value != 0;
+        if (!S.opt_sig_resident) S.sig_valid = false;
+        return 0;
+    }
+    return fail(-1, "unknown option %d", (int)key);
+}
+
+int cice_evp_hip_invalidate_stresses(void)
+{
+    S.sig_valid = false;
+    return 0;
+}
+
+int cice_evp_hip_fetch_stresses(double *const *sig12)
+{
+    if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (!sig12) return fail(-1, "null argument");
+    HIPC(hipStreamSynchronize(S.stream));
+    if (int rc = resident_check_error()) return rc;
+    CopyBatch B;
+    for (int k = 0; k < 12; ++k)
+        if (sig12[k]) B.items.push_back({sig12[k], S.sig[S.cur][k]});
+    if (d2h_batch(B)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
     return 0;
 }
 
@@ -366,13 +427,15 @@ int cice_evp_hip_download(double *const *f)
     if (int rc = direct_check_error()) return rc;
     if (int rc = resident_check_error()) return rc;
     HIPC(hipEventRecord(S.ev2, S.stream));
+    CopyBatch B;
     for (int k = 0; k < 12; ++k)
-        if (f[k] && d2h(f[k], S.sig[S.cur][k])) return -1;
+        if (f[k]) B.items.push_back({f[k], S.sig[S.cur][k]});
     const int outs[4] = {F_STRINTX, F_STRINTY, F_TAUBX, F_TAUBY};
     for (int o : outs)
-        if (f[o] && d2h(f[o], S.in[o])) return -1;
-    if (f[F_UVEL] && d2h(f[F_UVEL], S.u[S.cur])) return -1;
-    if (f[F_VVEL] && d2h(f[F_VVEL], S.v[S.cur])) return -1;
+        if (f[o]) B.items.push_back({f[o], S.in[o]});
+    if (f[F_UVEL]) B.items.push_back({f[F_UVEL], S.u[S.cur]});
+    if (f[F_VVEL]) B.items.push_back({f[F_VVEL], S.v[S.cur]});
+    if (d2h_batch(B)) return -1;
     HIPC(hipEventRecord(S.ev3, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
     float ms = 0;
@@ -400,9 +463,11 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
                           (double *)forceyU, (double *)umassdti, (double *)fmU, strintxU, strintyU,
                           (double *)TbU, taubxU, taubyU, uvel, vvel, (double *)uvel_init,
                           (double *)vvel_init};
-    if (int rc = cice_evp_hip_upload(f, iceTmask, iceUmask)) return rc;
+    // stresses that never left the device (CICE_EVP_HIP_OPT_STRESS_RESIDENT): no upload, dyn_prep2's zeroing on the device
+    const bool keep_sig = S.opt_sig_resident && S.sig_valid && S.uploaded;
+    if (int rc = upload_impl(f, iceTmask, iceUmask, keep_sig)) return rc;
     if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
-    if (S.res_mode == 1 && S.plan.peers.empty()) {
+    if (S.res_mode == 1 && S.plan.peers.empty() && !keep_sig) {
         // The resident kernel assumes the GPU to itself.  If that did not hold (another process or a
         // long kernel on the device: a wait gave up), nothing has been written back yet and the
         // caller's inputs are intact: run the call again with the streaming kernel, and keep to it.
@@ -412,13 +477,15 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
                 std::fprintf(stderr, "[cice_evp_hip] %s -- repeating the call with the streaming kernel\n", g_err.c_str());
             g_err.clear();
             ++S.res_fallbacks;
-            if (int rc = cice_evp_hip_upload(f, iceTmask, iceUmask)) return rc;
+            if (int rc = upload_impl(f, iceTmask, iceUmask, false)) return rc;
             if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
         }
     }
     // only the documented outputs travel back
     double *o[F_COUNT] = {};
-    for (int k = 0; k < 12; ++k) o[k] = f[k];
+    S.sig_valid = S.opt_sig_resident;
+    if (!S.opt_sig_resident)
+        for (int k = 0; k < 12; ++k) o[k] = f[k];
     o[F_STRINTX] = strintxU; o[F_STRINTY] = strintyU; o[F_TAUBX] = taubxU; o[F_TAUBY] = taubyU;
     o[F_UVEL] = uvel; o[F_VVEL] = vvel;
     return cice_evp_hip_download(o);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 // EVP scalars as the kernels see them (subset of cice_evp_hip_params)
 struct EvpScalars {
@@ -178,6 +179,18 @@ enum : unsigned {
     EVP_F_PUSH = 16u,
     EVP_F_DXHY_ARRAY = 32u, // with EVP_F_METRICS: dxhy, dyhx still come from their arrays (tripole ghost row)       // edge U-cells also write their ghost images (halo fused into the kernel)
 };
+
+// one launch for many same-sized array copies (evp_copy.hip); pointers may be device-mapped host memory
+#define EVP_COPY_MAX 40
+struct EvpCopyTab {
+    const double *src[EVP_COPY_MAX];
+    double *dst[EVP_COPY_MAX];
+    int n;                     // arrays
+    size_t len;                // doubles per array
+    int vec2;                  // every pointer 16-byte aligned: double2 accesses
+};
+void evp_launch_copy_many(const EvpCopyTab &T, hipStream_t st);
+void evp_launch_zero_sig_off_mask(double *const *sig0, double *const *sig1, const uint8_t *mask, size_t n, hipStream_t st);
 
 void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double *out, size_t n,
                         hipStream_t st);

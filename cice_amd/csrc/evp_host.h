@@ -197,7 +197,11 @@ struct State {
     double t_loop_ms = 0, t_h2d_ms = 0, t_d2h_ms = 0;
     int t_nsub = 0;
     std::vector<uint8_t> hmask, hmask_prev;   // masks of this / the previous upload (what depends on them is rebuilt only when they change)
-    std::map<const void *, size_t> pinned;   // host ranges registered by cice_evp_hip_pin_host
+    struct Pinned { size_t bytes; void *dev; };    // dev: the range as the device sees it (NULL: not mapped)
+    std::map<const void *, Pinned> pinned;         // host ranges registered by cice_evp_hip_pin_host
+    // stresses that stay on the device between calls of cice_evp_hip_run (CICE_EVP_HIP_OPT_STRESS_RESIDENT)
+    bool opt_sig_resident = false;
+    bool sig_valid = false;                        // sig[cur] holds what the caller's arrays would hold
 };
 
 extern State S;
@@ -214,6 +218,10 @@ int alloc_d(double **p, size_t n);
 void free_all();
 int h2d(double *dst, const double *src);
 int d2h(double *dst, const double *src);
+// batched variants: arrays the caller page-locked travel in ONE gather / scatter launch, the rest as copies
+struct CopyBatch { std::vector<std::pair<double *, const double *>> items; };
+int h2d_batch(CopyBatch &B);
+int d2h_batch(CopyBatch &B);
 int derive_metrics(const double *HTE, const double *HTN, const double *dxT, const double *dyT,
                    const double *uarear, const double *tarea);
 int upload_lists();

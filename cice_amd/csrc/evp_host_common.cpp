@@ -92,6 +92,7 @@ void free_all()
     if (S.have_comm) (void)ncclCommDestroy(S.comm);
     S.have_comm = false;
     for (auto &kv : S.pinned) (void)hipHostUnregister(const_cast<void *>(kv.first));
+    S.sig_valid = false;
     S.pinned.clear();
     for (auto &kv : S.splits) {
         if (kv.second.d_boundary) (void)hipFree(kv.second.d_boundary);
@@ -119,6 +120,50 @@ int d2h(double *dst, const double *src)
     HIPC(hipMemcpyAsync(dst, src, S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
     return 0;
 }
+
+// Device view of a caller's array if it lies inside a range registered (and mapped) by cice_evp_hip_pin_host
+static void *mapped_view(const void *host, size_t bytes)
+{
+    auto it = S.pinned.upper_bound(host);
+    if (it == S.pinned.begin()) return nullptr;
+    --it;
+    const char *base = (const char *)it->first;
+    if (!it->second.dev || (const char *)host < base || (const char *)host + bytes > base + it->second.bytes) return nullptr;
+    return (char *)it->second.dev + ((const char *)host - base);
+}
+
+static int run_batch(CopyBatch &B, bool to_device)
+{
+    const bool off = env("CICE_EVP_HIP_GATHER") && !std::atoi(env("CICE_EVP_HIP_GATHER"));
+    EvpCopyTab T{};
+    T.len = S.n;
+    T.vec2 = 1;
+    auto flush = [&]() {
+        if (T.n > 0) evp_launch_copy_many(T, S.stream);
+        T.n = 0;
+        T.vec2 = 1;
+    };
+    for (auto &it : B.items) {
+        double *dst = it.first;
+        const double *src = it.second;
+        const void *host = to_device ? (const void *)src : (const void *)dst;
+        void *view = off ? nullptr : mapped_view(host, S.n * sizeof(double));
+        if (!view) {
+            if (to_device ? h2d(dst, src) : d2h(dst, src)) return -1;
+            continue;
+        }
+        T.src[T.n] = to_device ? (const double *)view : src;
+        T.dst[T.n] = to_device ? dst : (double *)view;
+        if ((((uintptr_t)T.src[T.n]) | ((uintptr_t)T.dst[T.n])) & 15u) T.vec2 = 0;
+        if (++T.n == EVP_COPY_MAX) flush();
+    }
+    flush();
+    HIPC(hipGetLastError());
+    B.items.clear();
+    return 0;
+}
+int h2d_batch(CopyBatch &B) { return run_batch(B, true); }
+int d2h_batch(CopyBatch &B) { return run_batch(B, false); }
 
 // Static metric terms, host arithmetic in the reference's operation order
 // (init_dyn_shared, ice_dyn_shared.F90:384-388, 401-441).  dxhy/dyhx are

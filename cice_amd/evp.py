@@ -43,9 +43,10 @@ EXPORTS = [
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_prep_fetch",
-    "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof",
+    "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
 ]
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
+OPT_STRESS_RESIDENT = 1   # CICE_EVP_HIP_OPT_STRESS_RESIDENT
 # T-grid inputs of the preparation phase (order of cice_evp_hip_prep's tfields11) and the
 # products cice_evp_hip_prep_fetch serves (index = `which`)
 PREP_T = ["aice", "vice", "vsno", "aice_init", "cdn_ocn", "uocn", "vocn", "ss_tltx", "ss_tlty",
@@ -178,6 +179,18 @@ class EvpHip:
         for a in arrays:
             _check(self.lib, self.lib.cice_evp_hip_pin_host(C.c_void_p(a.ctypes.data), C.c_int64(a.nbytes)),
                    "(dyn_evp_hip_pin_host)")
+
+    def set_option(self, key: int, value: int):
+        _check(self.lib, self.lib.cice_evp_hip_set_option(C.c_int32(key), C.c_int32(value)), "(dyn_evp_hip_set_option)")
+
+    def fetch_stresses(self, out: dict | None = None) -> dict:
+        out = out if out is not None else {k: np.zeros(self.shape) for k in FIELDS[:12]}
+        tab = (_f64p * 12)(*[_dp(out[k]) for k in FIELDS[:12]])
+        _check(self.lib, self.lib.cice_evp_hip_fetch_stresses(tab), "(dyn_evp_hip_fetch_stresses)")
+        return out
+
+    def invalidate_stresses(self):
+        _check(self.lib, self.lib.cice_evp_hip_invalidate_stresses(), "(dyn_evp_hip_invalidate_stresses)")
 
     def run_inplace(self, work: dict, tm, um, ndte: int | None = None):
         """Like run() but directly on the caller's arrays (no copies): the Fortran call shape."""

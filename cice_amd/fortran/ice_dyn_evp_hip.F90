@@ -29,7 +29,8 @@ module ice_dyn_evp_hip
   implicit none
   private
 
-  public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body
+  public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body, &
+            dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses
 
   ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
   type, bind(C) :: cice_evp_hip_dims
@@ -157,6 +158,20 @@ module ice_dyn_evp_hip
        import :: c_int
      end function cice_evp_hip_stress_halo
 
+     integer(c_int) function cice_evp_hip_set_option(key, val) bind(C, name='cice_evp_hip_set_option')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), value :: key, val
+     end function cice_evp_hip_set_option
+
+     integer(c_int) function cice_evp_hip_fetch_stresses(sig12) bind(C, name='cice_evp_hip_fetch_stresses')
+       import :: c_int, c_ptr
+       type(c_ptr), dimension(12), intent(in) :: sig12
+     end function cice_evp_hip_fetch_stresses
+
+     integer(c_int) function cice_evp_hip_invalidate_stresses() bind(C, name='cice_evp_hip_invalidate_stresses')
+       import :: c_int
+     end function cice_evp_hip_invalidate_stresses
+
      integer(c_int) function cice_evp_hip_download(fields32) bind(C, name='cice_evp_hip_download')
        import :: c_int, c_ptr
        type(c_ptr), dimension(32), intent(in) :: fields32
@@ -165,6 +180,13 @@ module ice_dyn_evp_hip
 
   logical :: initialised = .false.
   logical :: pinned = .false.
+  ! The 12 stress components stay on the device between evp() calls (evp() is their only writer): they are
+  ! uploaded once, never downloaded by dyn_evp_hip_run, and ice_flux's arrays are STALE until
+  ! dyn_evp_hip_fetch_stresses -- which the host model calls where something else reads them (restart
+  ! write, ice_restart_driver.F90:187-200; history / principal stresses).  CICE_EVP_HIP_STRESS_RESIDENT=0
+  ! in the environment restores the copy-in/copy-out behaviour of dyn_evp1d_run.
+  logical :: stress_resident = .true.
+  logical :: on_tripole = .false.
 
 contains
 
@@ -213,6 +235,8 @@ contains
     integer(int_kind) :: n, lo_i, hi_i, lo_j, hi_j, nprocs
     integer(c_int32_t) :: uid(32)
     real(dbl_kind) :: rhow
+    character(len=16) :: envval
+    integer :: envlen, envstat
     character(len=*), parameter :: subname = '(dyn_evp_hip_init)'
 
     call icepack_query_parameters(rhow_out=rhow)
@@ -260,6 +284,12 @@ contains
        call check(cice_evp_hip_set_metrics(c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, &
             dxhy, dyhx, c_null_ptr), subname, __FILE__, __LINE__)
     endif
+
+    on_tripole = trim(ns_boundary_type) == 'tripole'
+    call get_environment_variable('CICE_EVP_HIP_STRESS_RESIDENT', envval, envlen, envstat)
+    stress_resident = .not. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '0')
+    call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
+         subname, __FILE__, __LINE__)
 
     if (nprocs > 1) then
        ! RCCL bootstrap: the master's ncclUniqueId travels over CICE's own broadcast
@@ -468,6 +498,10 @@ contains
          L_aiu, L_uocn, L_vocn, L_waterxU, L_wateryU, L_forcexU, L_forceyU, L_umassdti, L_fmU, &
          L_strintxU, L_strintyU, L_Tbu, L_taubxU, L_taubyU, L_uvel, L_vvel, uvel_init, vvel_init, &
          tmask_i, umask_i, int(ndte, c_int32_t)), subname, __FILE__, __LINE__)
+    ! stresses resident on a tripole grid: evp()'s 12 x ice_HaloUpdate_stress after the loop (ice_dyn_evp.F90:1321-1389)
+    ! act on the stale host arrays; the device copy gets the same symmetrisation here
+    if (stress_resident .and. on_tripole) &
+       call check(cice_evp_hip_stress_halo(), subname, __FILE__, __LINE__)
     call ice_timer_stop(timer_evp1dcore)
 
   contains
@@ -490,6 +524,30 @@ contains
     end subroutine pin_all
 
   end subroutine dyn_evp_hip_run
+
+!-----------------------------------------------------------------------
+! ice_flux's stress arrays <- the device copy.  Call before anything but evp() reads them (restart write,
+! history).  No-op unless the stresses are resident.
+  subroutine dyn_evp_hip_fetch_stresses
+    use ice_flux, only: stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, stressm_3, stressm_4, &
+         stress12_1, stress12_2, stress12_3, stress12_4
+    type(c_ptr) :: s12(12)
+    character(len=*), parameter :: subname = '(dyn_evp_hip_fetch_stresses)'
+    if (.not. (initialised .and. stress_resident)) return
+    s12(1) = cice_evp_hip_addr(stressp_1);  s12(2) = cice_evp_hip_addr(stressp_2)
+    s12(3) = cice_evp_hip_addr(stressp_3);  s12(4) = cice_evp_hip_addr(stressp_4)
+    s12(5) = cice_evp_hip_addr(stressm_1);  s12(6) = cice_evp_hip_addr(stressm_2)
+    s12(7) = cice_evp_hip_addr(stressm_3);  s12(8) = cice_evp_hip_addr(stressm_4)
+    s12(9) = cice_evp_hip_addr(stress12_1); s12(10) = cice_evp_hip_addr(stress12_2)
+    s12(11) = cice_evp_hip_addr(stress12_3); s12(12) = cice_evp_hip_addr(stress12_4)
+    call check(cice_evp_hip_fetch_stresses(s12), subname, __FILE__, __LINE__)
+  end subroutine dyn_evp_hip_fetch_stresses
+
+! The host changed ice_flux's stress arrays itself (restart read): the next evp() uploads them again.
+  subroutine dyn_evp_hip_invalidate_stresses
+    character(len=*), parameter :: subname = '(dyn_evp_hip_invalidate_stresses)'
+    if (initialised) call check(cice_evp_hip_invalidate_stresses(), subname, __FILE__, __LINE__)
+  end subroutine dyn_evp_hip_invalidate_stresses
 
 !-----------------------------------------------------------------------
   subroutine dyn_evp_hip_finalize

@@ -122,6 +122,19 @@ int cice_evp_hip_finalize(void);
  * direct DMA.  Idempotent per pointer; released by cice_evp_hip_finalize.          */
 int cice_evp_hip_pin_host(const void *ptr, int64_t bytes);
 
+/* Options of the per-call entry points.
+ * CICE_EVP_HIP_OPT_STRESS_RESIDENT: the 12 stress components stay on the device between calls of
+ * cice_evp_hip_run.  evp() is their only writer, so they are uploaded on the first call only (and after
+ * cice_evp_hip_invalidate_stresses, e.g. when a restart file was read into the host arrays), zeroed off
+ * iceTmask on the device as dyn_prep2 does on the host arrays (ice_dyn_shared.F90:712-727), and NOT
+ * written back: the host arrays are stale until cice_evp_hip_fetch_stresses, which a host calls where
+ * something else reads them (restart: ice_restart_driver.F90:187-200; history: principal stresses).
+ * 24 of the 50 per-call array transfers go away.                                                  */
+#define CICE_EVP_HIP_OPT_STRESS_RESIDENT 1
+int cice_evp_hip_set_option(int32_t key, int32_t value);
+int cice_evp_hip_fetch_stresses(double *const *sig12);
+int cice_evp_hip_invalidate_stresses(void);
+
 /* ---- resident-state entry points (same work as _run, split in three so that
  *      a caller can keep the state in HBM across calls) ----------------------- */
 

@@ -46,7 +46,7 @@ program evp_ref_harness
   use ice_dyn_evp1d, only: capture_tag, dyn_evp1d_init, dyn_evp1d_finalize
 #endif
 #ifdef HARNESS_HIP_BODY
-  use ice_dyn_evp_hip, only: dyn_evp_hip_evp_body
+  use ice_dyn_evp_hip, only: dyn_evp_hip_evp_body, dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses
 #endif
   use evp_dumpio
   use icepack_intfc, only: icepack_query_parameters
@@ -334,7 +334,13 @@ program evp_ref_harness
            ! the reference's unmodified evp() driving the HIP core through the
            ! existing dyn_evp1d_run boundary (ice_dyn_evp.F90:846-856)
            evp_algorithm = 'shared_mem_1d'
+#ifdef HARNESS_HIP_BODY
+           call dyn_evp_hip_invalidate_stresses     ! the harness reset ice_flux's stresses behind the core's back
+#endif
            call evp(dt_dyn)
+#ifdef HARNESS_HIP_BODY
+           call dyn_evp_hip_fetch_stresses          ! device-resident stresses: ice_flux's arrays are stale until fetched
+#endif
            evp_algorithm = 'standard_2d'
            write(tag,'(a,i2.2,a,i4.4)') 'h', icall, 'n', nsub
            call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)

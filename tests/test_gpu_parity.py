@@ -832,3 +832,45 @@ def test_prep_path_zeroes_diagnostics_where_the_ice_has_gone():
             assert not res2[k][lost].any(), f"{k}: stale values on cells that lost their ice"
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("name", ["rect_cyc_2x2_full", "pop_cyc_3x2pad_caps", "pop_cyc_2x2_seabed", "trip_cyc_2x2_full"])
+def test_run_with_page_locked_arrays_and_resident_stresses(name):
+    """The per-call path CICE would use: the caller's arrays page-locked once (cice_evp_hip_pin_host -> mapped, so
+    the 20 + 6 field transfers of a call are ONE gather and ONE scatter launch) and the 12 stresses resident on the
+    device between calls (CICE_EVP_HIP_OPT_STRESS_RESIDENT): the second call is handed NaN in the stress arrays --
+    they must be neither read nor written -- and still returns the reference's second call; the stresses fetched
+    afterwards are the reference's too (tripole: after the device-side symmetrisation)."""
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        core.set_option(evp.OPT_STRESS_RESIDENT, 1)
+        work = {k: np.zeros(core.shape) for k in evp.FIELDS}
+        core.pin_host(*work.values())
+        nonsig = [k for k in evp.OUTPUTS if k not in SIG]
+        for icall in (1, 2):
+            dyn, tm, um = c.inputs(icall)
+            for k in evp.FIELDS:
+                work[k][...] = dyn[k]
+            if icall == 2:
+                for k in SIG:
+                    work[k][...] = np.nan
+            core.run_inplace(work, np.ascontiguousarray(tm, np.int32), np.ascontiguousarray(um, np.int32), c.ndte)
+            if c.ns == "tripole":
+                core.stress_halo()
+            want = c.expected(icall, c.ndte)
+            assert_bitwise({k: work[k] for k in nonsig}, {k: want[k] for k in nonsig}, f"{name} call {icall}: pinned + resident")
+            if icall == 2:
+                assert all(np.isnan(work[k]).all() for k in SIG), "resident stresses: the host arrays must stay untouched"
+        got = core.fetch_stresses()
+        assert_bitwise(got, {k: want[k] for k in SIG}, f"{name}: stresses fetched after call 2")
+        # back to copy-in / copy-out: same answer again from call-2 inputs
+        core.set_option(evp.OPT_STRESS_RESIDENT, 0)
+        dyn, tm, um = c.inputs(2)
+        for k in evp.FIELDS:
+            work[k][...] = dyn[k]
+        core.run_inplace(work, np.ascontiguousarray(tm, np.int32), np.ascontiguousarray(um, np.int32), c.ndte)
+        out = post_evp(c, {k: work[k] for k in evp.OUTPUTS})
+        assert_bitwise(out, want, f"{name}: pinned, copy-in/copy-out")
+    finally:
+        core.finalize()
