@@ -501,13 +501,14 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     if (S.ready && S.marked[0] && S.marked[1] && hipEventQuery(S.evm[1]) == hipSuccess &&
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
-    const double v[12] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+    const double v[14] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
                          S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
                          (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
-                          S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms, (double)S.res_fallbacks};
-    for (int k = 0; k < n && k < 12; ++k) out[k] = v[k];
+                          S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms, (double)S.res_fallbacks,
+                          (double)(S.msk.on ? S.msk.n_send : S.n_send), (double)(S.msk.on ? S.msk.n_recv : S.n_recv)};
+    for (int k = 0; k < n && k < 14; ++k) out[k] = v[k];
     return 0;
 }
 

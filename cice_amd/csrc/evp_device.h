@@ -128,6 +128,8 @@ struct EvpDirect {
     const unsigned *send_pstride; // [n_send] doubles to the other parity of that inbox
     const int *recv_dst;          // [n_recv] local ghost cells
     const signed char *recv_sign;
+    const int *recv_slot;         // [n_recv] inbox slot of the entry (NULL: its index) -- masked halos keep the unmasked layout
+    int n_recv_slots;             // slots per parity of the inbox
     double *inbox;                // own inbox [2 parities][n_recv][u,v]
     unsigned *flags_in;           // own flag slots, one per peer, EVP_DIRECT_FLAG_STRIDE apart
     unsigned *seq;                // exchanges completed so far
@@ -170,6 +172,8 @@ void evp_launch_prep1(const EvpPrep &P, int nblocks, hipStream_t st);
 void evp_launch_halo_center(const EvpPrepHalo &H, hipStream_t st);
 void evp_launch_prep_average(const EvpPrep &P, int nblocks, hipStream_t st);
 void evp_launch_prep2(const EvpPrep &P, int nblocks, hipStream_t st);
+void evp_launch_seabed_lkd(const EvpPrep &P, int nblocks, const double *hwater, double *TbU, double k1, double k2,
+                           double alphab, double threshold_hw, unsigned *flagword, hipStream_t st);
 
 enum : unsigned {
     EVP_F_METRICS = 1u,     // recompute cxp..DminTarea from HTE,HTN,dxT,dyT (tarea == dxT*dyT verified)

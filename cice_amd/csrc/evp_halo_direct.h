@@ -86,7 +86,7 @@ __device__ __forceinline__ void exchange(const EvpDirect &D, double *__restrict_
     __syncthreads();
     if (!(D.dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     // 4. inbox -> ghost cells
-    const double *in = D.inbox + (size_t)par * 2 * (size_t)D.n_recv;
+    const double *in = D.inbox + (size_t)par * 2 * (size_t)D.n_recv_slots;
     for (int base = 0; base < D.n_recv; base += nthr * UNR) {
         int d[UNR];
         double sg[UNR], uu[UNR], vv[UNR];
@@ -97,8 +97,9 @@ __device__ __forceinline__ void exchange(const EvpDirect &D, double *__restrict_
             if (k < D.n_recv) {
                 d[e] = D.recv_dst[k];
                 sg[e] = (double)D.recv_sign[k];
-                uu[e] = ld_sys(in + 2 * (size_t)k);
-                vv[e] = ld_sys(in + 2 * (size_t)k + 1);
+                const size_t slot = D.recv_slot ? (size_t)D.recv_slot[k] : (size_t)k;
+                uu[e] = ld_sys(in + 2 * slot);
+                vv[e] = ld_sys(in + 2 * slot + 1);
             }
         }
 #pragma unroll

@@ -119,7 +119,7 @@ struct State {
     struct Prep {
         bool geo = false;
         uint8_t *tmask = nullptr, *umask = nullptr, *umask_old = nullptr, *tmphm = nullptr;
-        double *hm = nullptr, *tarea = nullptr, *uarea = nullptr, *fcor = nullptr;
+        double *hm = nullptr, *tarea = nullptr, *uarea = nullptr, *fcor = nullptr, *hwater = nullptr;
         double *t[11] = {};
         double *tmass = nullptr, *umass = nullptr, *maskd = nullptr;
         double *ss_tltxU = nullptr, *ss_tltyU = nullptr, *strairxU = nullptr, *strairyU = nullptr,
@@ -135,6 +135,19 @@ struct State {
     int8_t *h_recv_sign = nullptr;
     double *sendbuf = nullptr, *recvbuf = nullptr;
     int n_send = 0, n_recv = 0;
+    // masked halo of the in-loop velocity exchange (ice_HaloMask, ice_boundary.F90:889-1062): the entries whose
+    // halomask is set, compacted; the unmasked lists serve every other exchange
+    struct Masked {
+        bool on = false;
+        int n_send = 0, n_recv = 0;
+        std::vector<int> peer_nsend, peer_nrecv;
+        int32_t *send_src = nullptr, *recv_dst = nullptr, *recv_slot = nullptr;
+        int8_t *recv_sign = nullptr;
+        double **send_addr = nullptr;
+        unsigned *send_pstride = nullptr;
+        std::vector<double *> h_send_addr;        // host copies of the unmasked mailbox tables (kept at import)
+        std::vector<unsigned> h_send_pstride;
+    } msk;
 
     // mailbox halo (evp_halo_direct.hip): peers' inboxes mapped through HIP IPC
     struct Direct {
@@ -144,6 +157,7 @@ struct State {
         size_t bytes = 0, inbox_off = 0, rec_off = 0;
         std::vector<void *> opened;  // hipIpcOpenMemHandle results
         EvpDirect *d_dx = nullptr;   // device copy of the argument block (exchange riding in the subcycle launch)
+        EvpDirect *d_dx_m = nullptr; // the same with the masked lists (cice_evp_hip_halo_mask)
         unsigned *d_cnt = nullptr;   // [0] boundary tiles checked in, [16] launches with a riding exchange
         double **send_addr = nullptr;
         unsigned *send_pstride = nullptr;
@@ -230,8 +244,9 @@ void fill_args(EvpArgs &A, int cur, int last);
 int cap_mode();
 // evp_host_loop.cpp
 void fill_direct(EvpDirect &D);
-int halo_remote_pair(double *a, double *bb);
-int halo_uv(int b);
+int halo_remote_pair(double *a, double *bb, bool masked = false);
+void fill_direct(EvpDirect &D, bool masked);
+int halo_uv(int b, bool masked = false);
 bool use_overlap();
 bool use_riding_exchange();
 int get_tile_split(int variant, State::TileSplit **out);

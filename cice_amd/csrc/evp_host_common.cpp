@@ -67,7 +67,7 @@ void free_all()
     F(S.h_stress_dst); F(S.h_stress_src);
     {
         State::Prep &Q = S.prep;
-        F(Q.tmask); F(Q.umask); F(Q.umask_old); F(Q.tmphm); F(Q.hm); F(Q.tarea); F(Q.uarea); F(Q.fcor);
+        F(Q.tmask); F(Q.umask); F(Q.umask_old); F(Q.tmphm); F(Q.hm); F(Q.tarea); F(Q.uarea); F(Q.fcor); F(Q.hwater);
         for (auto &q : Q.t) F(q);
         F(Q.tmass); F(Q.umass); F(Q.maskd); F(Q.ss_tltxU); F(Q.ss_tltyU); F(Q.strairxU); F(Q.strairyU);
         F(Q.strtltx); F(Q.strtlty); F(Q.flagword); F(Q.c_dst); F(Q.c_src); F(Q.c_vsign);
@@ -76,10 +76,12 @@ void free_all()
     F(S.h_send_src);
     F(S.h_recv_dst);
     F(S.h_recv_sign);
+    F(S.msk.send_src); F(S.msk.recv_dst); F(S.msk.recv_slot); F(S.msk.recv_sign); F(S.msk.send_addr); F(S.msk.send_pstride);
+    S.msk = State::Masked();
     F(S.sendbuf);
     F(S.recvbuf);
     for (void *q : S.direct.opened) (void)hipIpcCloseMemHandle(q);
-    F(S.direct.mailbox); F(S.direct.d_dx); F(S.direct.d_cnt); F(S.direct.send_addr); F(S.direct.send_pstride); F(S.direct.peer_flag);
+    F(S.direct.mailbox); F(S.direct.d_dx); F(S.direct.d_dx_m); F(S.direct.d_cnt); F(S.direct.send_addr); F(S.direct.send_pstride); F(S.direct.peer_flag);
     S.direct = State::Direct();
     for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);
     S.graphs.clear();

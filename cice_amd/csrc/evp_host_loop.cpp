@@ -4,18 +4,23 @@
 
 namespace evp_host {
 
-void fill_direct(EvpDirect &D)
+void fill_direct(EvpDirect &D) { fill_direct(D, false); }
+
+void fill_direct(EvpDirect &D, bool masked)
 {
     State::Direct &X = S.direct;
     char *base = (char *)X.mailbox;
-    D.n_send = S.n_send;
-    D.n_recv = S.n_recv;
+    masked = masked && S.msk.on;
+    D.n_send = masked ? S.msk.n_send : S.n_send;
+    D.n_recv = masked ? S.msk.n_recv : S.n_recv;
+    D.n_recv_slots = S.n_recv;
     D.npeers = (int)S.plan.peers.size();
-    D.send_src = S.h_send_src;
-    D.send_addr = X.send_addr;
-    D.send_pstride = X.send_pstride;
-    D.recv_dst = S.h_recv_dst;
-    D.recv_sign = (const signed char *)S.h_recv_sign;
+    D.send_src = masked ? S.msk.send_src : S.h_send_src;
+    D.send_addr = masked ? S.msk.send_addr : X.send_addr;
+    D.send_pstride = masked ? S.msk.send_pstride : X.send_pstride;
+    D.recv_dst = masked ? S.msk.recv_dst : S.h_recv_dst;
+    D.recv_sign = (const signed char *)(masked ? S.msk.recv_sign : S.h_recv_sign);
+    D.recv_slot = masked ? S.msk.recv_slot : nullptr;
     D.flags_in = (unsigned *)base;
     D.seq = (unsigned *)(base + DIRECT_SEQ_OFF);
     D.err = (int *)(base + DIRECT_ERR_OFF);
@@ -30,34 +35,39 @@ void fill_direct(EvpDirect &D)
 // Ghost cells whose source lives on another rank, for a pair of arrays laid out like uvel/vvel
 // (the velocities of the loop; pairs of T-grid fields in the preparation phase on grids without
 // a tripole fold, where cell-centre and corner fields mirror the same cells)
-int halo_remote_pair(double *a, double *bb)
+// masked: the in-loop velocity exchange on the entries ice_HaloMask keeps (every other exchange -- pre-loop
+// velocities, T-grid fields -- uses the full lists, as the reference does with halo_info vs halo_info_mask)
+int halo_remote_pair(double *a, double *bb, bool masked)
 {
+    masked = masked && S.msk.on;
     if (!S.plan.peers.empty() && S.direct.on) {
         EvpDirect D;
-        fill_direct(D);
+        fill_direct(D, masked);
         evp_launch_halo_direct(D, a, bb, S.stream);
     } else if (!S.plan.peers.empty()) {
         if (!S.have_comm) return fail(-2, "remote halo needed but neither cice_evp_hip_comm_init nor cice_evp_hip_halo_import was called");
-        evp_launch_halo_pack(a, bb, S.h_send_src, S.sendbuf, S.n_send, S.stream);
-        size_t so = 0, ro = 0;
+        evp_launch_halo_pack(a, bb, masked ? S.msk.send_src : S.h_send_src, S.sendbuf, masked ? S.msk.n_send : S.n_send, S.stream);
+        size_t so = 0, ro = 0, q = 0;
         NCCLC(ncclGroupStart());
         for (const HaloPeer &p : S.plan.peers) {
-            if (!p.send_src.empty())
-                NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream));
-            if (!p.recv_dst.empty())
-                NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream));
-            so += p.send_src.size();
-            ro += p.recv_dst.size();
+            const size_t ns = masked ? (size_t)S.msk.peer_nsend[q] : p.send_src.size();
+            const size_t nr = masked ? (size_t)S.msk.peer_nrecv[q] : p.recv_dst.size();
+            if (ns) NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * ns, ncclDouble, p.rank, S.comm, S.stream));
+            if (nr) NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * nr, ncclDouble, p.rank, S.comm, S.stream));
+            so += ns;
+            ro += nr;
+            ++q;
         }
         NCCLC(ncclGroupEnd());
-        evp_launch_halo_unpack(a, bb, S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
-                               S.n_recv, S.stream);
+        evp_launch_halo_unpack(a, bb, masked ? S.msk.recv_dst : S.h_recv_dst,
+                               (const signed char *)(masked ? S.msk.recv_sign : S.h_recv_sign), S.recvbuf,
+                               masked ? S.msk.n_recv : S.n_recv, S.stream);
     }
     return 0;
 }
 
 // velocity halo of buffer `b` (ice_dyn_evp.F90:908-910)
-int halo_uv(int b)
+int halo_uv(int b, bool masked)
 {
     const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
     if (!pushed)
@@ -67,7 +77,7 @@ int halo_uv(int b)
     // exchange below never involves seam-row cells
     evp_launch_halo_seam(S.u[b], S.v[b], S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
                          S.h_late_dst, S.h_late_src, (const signed char *)S.h_late_sign, S.n_late, S.stream);
-    if (int rc = halo_remote_pair(S.u[b], S.v[b])) return rc;
+    if (int rc = halo_remote_pair(S.u[b], S.v[b], masked)) return rc;
     return 0;
 }
 
@@ -171,7 +181,7 @@ int enqueue_loop(int ndte, int cur0)
             EvpArgs A;
             fill_args(A, cur, k == ndte - 1);
             A.tile_list = ts->d_all; A.tile_count = ts->nb + ts->ni;
-            A.dx = S.direct.d_dx; A.dx_count = S.direct.d_cnt; A.dx_fseq = S.direct.d_cnt + 16; A.dx_nb = ts->nb;
+            A.dx = (S.msk.on && S.direct.d_dx_m) ? S.direct.d_dx_m : S.direct.d_dx; A.dx_count = S.direct.d_cnt; A.dx_fseq = S.direct.d_cnt + 16; A.dx_nb = ts->nb;
             evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
             if (!pushed)
                 evp_launch_halo_local(S.u[cur ^ 1], S.v[cur ^ 1], S.h_local_dst, S.h_local_src,
@@ -186,7 +196,7 @@ int enqueue_loop(int ndte, int cur0)
             EvpArgs A;
             fill_args(A, cur, k == ndte - 1);
             evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, S.tyb, strict, cap, S.stream);
-            if (int rc = halo_uv(cur ^ 1)) return rc;
+            if (int rc = halo_uv(cur ^ 1, true)) return rc;
             cur ^= 1;
         }
         HIPC(hipGetLastError());
@@ -204,7 +214,8 @@ int enqueue_loop(int ndte, int cur0)
         // 1. tiles whose cells other ranks need
         A.tile_list = ts->d_boundary; A.tile_count = ts->nb;
         evp_launch_subcycle(A, S.max_ni, S.max_nj, S.d.nblocks, variant, strict, cap, S.stream);
-        if (!S.direct.on) evp_launch_halo_pack(S.u[nxt], S.v[nxt], S.h_send_src, S.sendbuf, S.n_send, S.stream);
+        const bool mk = S.msk.on;
+        if (!S.direct.on) evp_launch_halo_pack(S.u[nxt], S.v[nxt], mk ? S.msk.send_src : S.h_send_src, S.sendbuf, mk ? S.msk.n_send : S.n_send, S.stream);
         HIPC(hipEventRecord(S.ev_pack, S.stream));
         // 2. everything else, concurrently with the exchange
         A.tile_list = ts->d_interior; A.tile_count = ts->ni;
@@ -216,22 +227,24 @@ int enqueue_loop(int ndte, int cur0)
         HIPC(hipStreamWaitEvent(S.stream_comm, S.ev_pack, 0));
         if (S.direct.on) {      // mailbox exchange: stores into the peers' inboxes, no library call
             EvpDirect D;
-            fill_direct(D);
+            fill_direct(D, true);
             evp_launch_halo_direct(D, S.u[nxt], S.v[nxt], S.stream_comm);
         } else {
-            size_t so = 0, ro = 0;
+            size_t so = 0, ro = 0, q = 0;
             NCCLC(ncclGroupStart());
             for (const HaloPeer &p : S.plan.peers) {
-                if (!p.send_src.empty())
-                    NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * p.send_src.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
-                if (!p.recv_dst.empty())
-                    NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * p.recv_dst.size(), ncclDouble, p.rank, S.comm, S.stream_comm));
-                so += p.send_src.size();
-                ro += p.recv_dst.size();
+                const size_t ns = mk ? (size_t)S.msk.peer_nsend[q] : p.send_src.size();
+                const size_t nr = mk ? (size_t)S.msk.peer_nrecv[q] : p.recv_dst.size();
+                if (ns) NCCLC(ncclSend(S.sendbuf + 2 * so, 2 * ns, ncclDouble, p.rank, S.comm, S.stream_comm));
+                if (nr) NCCLC(ncclRecv(S.recvbuf + 2 * ro, 2 * nr, ncclDouble, p.rank, S.comm, S.stream_comm));
+                so += ns;
+                ro += nr;
+                ++q;
             }
             NCCLC(ncclGroupEnd());
-            evp_launch_halo_unpack(S.u[nxt], S.v[nxt], S.h_recv_dst, (const signed char *)S.h_recv_sign, S.recvbuf,
-                                   S.n_recv, S.stream_comm);
+            evp_launch_halo_unpack(S.u[nxt], S.v[nxt], mk ? S.msk.recv_dst : S.h_recv_dst,
+                                   (const signed char *)(mk ? S.msk.recv_sign : S.h_recv_sign), S.recvbuf,
+                                   mk ? S.msk.n_recv : S.n_recv, S.stream_comm);
         }
         HIPC(hipEventRecord(S.ev_halo, S.stream_comm));
         cur = nxt;

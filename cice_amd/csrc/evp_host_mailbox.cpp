@@ -145,6 +145,8 @@ int direct_import(const HaloBlob *blobs, int nranks)
         return 0;
     };
     if (up(X.send_addr, send_addr) || up(X.send_pstride, send_pstride) || up(X.peer_flag, peer_flag)) return -1;
+    S.msk.h_send_addr = send_addr;          // kept for cice_evp_hip_halo_mask (compacted copies of these tables)
+    S.msk.h_send_pstride = send_pstride;
     // resident kernel with neighbours on other GPUs: only if EVERY rank can run it
     bool all_res = true;
     for (int r = 0; r < nranks; ++r) all_res = all_res && blobs[r].magic == HALO_BLOB_MAGIC && blobs[r].can_res != 0;
@@ -373,6 +375,70 @@ int cice_evp_hip_comm_init(const void *id128)
     if (!S.direct.on && env("CICE_EVP_HIP_VERBOSE"))
         std::fprintf(stderr, "[cice_evp_hip] rank %d: mailbox halo off (%s), using RCCL\n", S.d.rank, S.direct.why.c_str());
     g_err.clear();
+    return 0;
+}
+
+// ice_HaloMask (ice_boundary.F90:889-1062; evp() builds it when maskhalo_dyn, ice_dyn_evp.F90:739-770): a reduced
+// halo for the velocity updates INSIDE the subcycle loop.  halomask: the reference's own array -- 1 where
+// iceUmask, ghost cells updated -- so that sender (mask of the source cell, :975-985) and receiver (mask of the
+// ghost cell, :1018-1028) drop the same entries; copies inside a rank are never masked (:925-945) and messages
+// across the tripole fold are always kept (:979, 1022).  NULL = back to the full halo.  Bit-neutral: a dropped
+// ghost cell mirrors an ice-free cell, whose velocity is and stays 0 (dyn_prep2 + the full pre-loop update).
+// The on-chip resident kernel across GPUs ignores it: its records are published every subcycle, ice or not.
+int cice_evp_hip_halo_mask(const int32_t *halomask)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    State::Masked &M = S.msk;
+    for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);     // captured loops bake the list lengths in
+    S.graphs.clear();
+    if (!halomask || S.plan.peers.empty()) { M.on = false; return 0; }
+    for (const HaloPeer &p : S.plan.peers)
+        for (int8_t sg : p.recv_sign)
+            if (sg < 0) { M.on = false; return 0; }      // exchange across the tripole fold: never masked
+    std::vector<int32_t> ss, rd, rslot;
+    std::vector<int8_t> rs;
+    std::vector<double *> sa;
+    std::vector<unsigned> sp;
+    M.peer_nsend.assign(S.plan.peers.size(), 0);
+    M.peer_nrecv.assign(S.plan.peers.size(), 0);
+    size_t so = 0, ro = 0;
+    for (size_t q = 0; q < S.plan.peers.size(); ++q) {
+        const HaloPeer &p = S.plan.peers[q];
+        for (size_t k = 0; k < p.send_src.size(); ++k)
+            if (halomask[p.send_src[k]] != 0) {
+                ss.push_back(p.send_src[k]);
+                if (!M.h_send_addr.empty()) { sa.push_back(M.h_send_addr[so + k]); sp.push_back(M.h_send_pstride[so + k]); }
+                ++M.peer_nsend[q];
+            }
+        for (size_t k = 0; k < p.recv_dst.size(); ++k)
+            if (halomask[p.recv_dst[k]] != 0) {
+                rd.push_back(p.recv_dst[k]);
+                rs.push_back(p.recv_sign[k]);
+                rslot.push_back((int32_t)(ro + k));
+                ++M.peer_nrecv[q];
+            }
+        so += p.send_src.size();
+        ro += p.recv_dst.size();
+    }
+    auto up = [&](auto *&dptr, const auto &v, size_t cap) -> int {
+        using T = typename std::remove_reference<decltype(v[0])>::type;
+        if (!dptr) HIPC(hipMalloc((void **)&dptr, std::max<size_t>(cap, 1) * sizeof(T)));
+        if (!v.empty()) HIPC(hipMemcpyAsync((void *)dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, S.stream));
+        return 0;
+    };
+    if (up(M.send_src, ss, S.n_send) || up(M.recv_dst, rd, S.n_recv) || up(M.recv_slot, rslot, S.n_recv) ||
+        up(M.recv_sign, rs, S.n_recv)) return -1;
+    if (!M.h_send_addr.empty() && (up(M.send_addr, sa, S.n_send) || up(M.send_pstride, sp, S.n_send))) return -1;
+    M.n_send = (int)ss.size();
+    M.n_recv = (int)rd.size();
+    M.on = true;
+    if (S.direct.on) {
+        EvpDirect D;
+        fill_direct(D, true);
+        if (!S.direct.d_dx_m) HIPC(hipMalloc((void **)&S.direct.d_dx_m, sizeof(EvpDirect)));
+        HIPC(hipMemcpyAsync(S.direct.d_dx_m, &D, sizeof(EvpDirect), hipMemcpyHostToDevice, S.stream));
+    }
+    HIPC(hipStreamSynchronize(S.stream));
     return 0;
 }
 

@@ -204,6 +204,39 @@ int cice_evp_hip_set_tbu(const double *TbU)
     return 0;
 }
 
+// Seabed stress factor on the device, LKD method (seabed_stress_factor_LKD, ice_dyn_shared.F90:1386-1460; call
+// site ice_dyn_evp.F90:783-790): from the aice / vice the last cice_evp_hip_prep uploaded (their ghost cells are
+// refreshed here), the water depth (hwater: ice_flux, static unless the host couples it -- NULL keeps the copy
+// of the previous call) and the masks that preparation produced.  Call between _prep and _subcycle instead of
+// cice_evp_hip_set_tbu.  One device exp() per ice U-cell: <= 1 ulp from the host libm's.
+int cice_evp_hip_seabed_lkd(const double *hwater, double k1, double k2, double alphab, double threshold_hw)
+{
+    if (!S.ready || !S.uploaded || !S.prep.geo) return fail(-1, "no prepared state (cice_evp_hip_prep first)");
+    State::Prep &Q = S.prep;
+    if (S.plan.center_remote) return fail(-9, "device seabed stress factor: T-grid ghosts on other ranks are not refreshed here; "
+                                              "compute TbU on the host (cice_evp_hip_set_tbu)");
+    if (!Q.hwater) {
+        if (!hwater) return fail(-1, "hwater needed on the first call");
+        if (alloc_d(&Q.hwater, S.n)) return -1;
+    }
+    if (hwater && h2d(Q.hwater, hwater)) return -1;
+    EvpPrepHalo H{};
+    H.a[0] = Q.t[0]; H.a[1] = Q.t[1]; H.a[2] = Q.hwater; H.narr = 3;     // scalars at cell centres
+    H.dst = Q.c_dst; H.src = Q.c_src; H.vsign = (const signed char *)Q.c_vsign; H.n = Q.n_center;
+    evp_launch_halo_center(H, S.stream);
+    EvpPrep P{};
+    P.nx = S.d.nx_block; P.ny = S.d.ny_block; P.plane = S.plane; P.blk = S.blk;
+    P.t[0] = Q.t[0]; P.t[1] = Q.t[1]; P.mask = S.mask;
+    HIPC(hipMemsetAsync(Q.flagword, 0, sizeof(unsigned), S.stream));
+    evp_launch_seabed_lkd(P, S.d.nblocks, Q.hwater, S.in[F_TBU], k1, k2, alphab, threshold_hw, Q.flagword, S.stream);
+    unsigned fw = 0;
+    HIPC(hipMemcpyAsync(&fw, Q.flagword, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    S.flags &= ~EVP_F_TBU_ZERO;
+    if (!(fw & 2u)) S.flags |= EVP_F_TBU_ZERO;
+    return 0;
+}
+
 // products of the preparation phase that stay on the device, for hosts that need them
 // (coupling diagnostics) and for the tests
 int cice_evp_hip_prep_fetch(int32_t which, double *dst)
@@ -211,11 +244,11 @@ int cice_evp_hip_prep_fetch(int32_t which, double *dst)
     if (!S.ready || !S.uploaded || !S.prep.geo) return fail(-1, "no prepared state");
     if (!dst) return fail(-1, "null argument");
     State::Prep &Q = S.prep;
-    const double *tab[20] = {S.in[F_AIX], S.in[F_CW], S.in[F_UOCN], S.in[F_VOCN], S.in[F_UMASSDTI], S.in[F_FM],
+    const double *tab[21] = {S.in[F_AIX], S.in[F_CW], S.in[F_UOCN], S.in[F_VOCN], S.in[F_UMASSDTI], S.in[F_FM],
                              S.in[F_WATERX], S.in[F_WATERY], S.in[F_FORCEX], S.in[F_FORCEY], S.in[F_UVEL_INIT],
                              S.in[F_VVEL_INIT], Q.strtltx, Q.strtlty, Q.strairxU, Q.strairyU, Q.tmass, Q.umass,
-                             S.u[S.cur], S.v[S.cur]};
-    if (which < 0 || which >= 20) return fail(-1, "prep_fetch: which = %d", (int)which);
+                             S.u[S.cur], S.v[S.cur], S.in[F_TBU]};
+    if (which < 0 || which >= 21) return fail(-1, "prep_fetch: which = %d", (int)which);
     if (d2h(dst, tab[which])) return -1;
     HIPC(hipStreamSynchronize(S.stream));
     return 0;

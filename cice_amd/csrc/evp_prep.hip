@@ -157,6 +157,31 @@ __global__ void prep2(EvpPrep P)
     P.mask[c] = (uint8_t)((iceT ? 1 : 0) | (iceU ? 2 : 0));
 }
 
+// seabed_stress_factor_LKD (ice_dyn_shared.F90:1386-1460) on the ice U-cells, 0 elsewhere (dyn_prep2 zeroes
+// TbU first, :706).  exp() is the device library's (<= 1 ulp): the one operation of this file whose last
+// bit may differ from the host libm the reference calls -- tolerance stated in DESIGN.md.
+__global__ void seabed_lkd(EvpPrep P, const double *__restrict__ hwater, double *__restrict__ TbU,
+                           double k1, double k2, double alphab, double threshold_hw, unsigned *flagword)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const int4 r = P.blk[bz];
+    double tb = 0.0;
+    if (i >= r.x && i <= r.y && j >= r.z && j <= r.w && (P.mask[c] & 2u)) {
+        const size_t c1 = c + 1, c2 = c + P.nx, c3 = c + P.nx + 1;
+        // grid_neighbor_min / _max at the U point (ice_grid.F90:4974, 5005): min/max(a, b, c, d) left to right
+        const double hwu = fmin(fmin(fmin(hwater[c], hwater[c1]), hwater[c2]), hwater[c3]);
+        const double docalc = hwu < threshold_hw ? 1.0 : 0.0;
+        const double *aice = P.t[0], *vice = P.t[1];
+        const double au = fmax(fmax(fmax(aice[c], aice[c1]), aice[c2]), aice[c3]);
+        const double hu = fmax(fmax(fmax(vice[c], vice[c1]), vice[c2]), vice[c3]);
+        const double hcu = au * hwu / k1;
+        tb = docalc * k2 * fmax(0.0, (hu - hcu)) * exp(-alphab * (1.0 - au));
+        if (tb != 0.0) atomicOr(flagword, 2u);
+    }
+    TbU[c] = tb;
+}
+
 dim3 cell_grid(const EvpPrep &P, int nblocks) { return dim3((P.nx + 63) / 64, P.ny, nblocks); }
 
 }  // namespace
@@ -181,4 +206,10 @@ void evp_launch_prep_average(const EvpPrep &P, int nblocks, hipStream_t st)
 void evp_launch_prep2(const EvpPrep &P, int nblocks, hipStream_t st)
 {
     hipLaunchKernelGGL(prep2, cell_grid(P, nblocks), dim3(64), 0, st, P);
+}
+
+void evp_launch_seabed_lkd(const EvpPrep &P, int nblocks, const double *hwater, double *TbU, double k1, double k2,
+                           double alphab, double threshold_hw, unsigned *flagword, hipStream_t st)
+{
+    hipLaunchKernelGGL(seabed_lkd, cell_grid(P, nblocks), dim3(64), 0, st, P, hwater, TbU, k1, k2, alphab, threshold_hw, flagword);
 }

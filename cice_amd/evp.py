@@ -42,7 +42,7 @@ EXPORTS = [
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_center_plan",
-    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
 ]
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
@@ -54,6 +54,7 @@ PREP_T = ["aice", "vice", "vsno", "aice_init", "cdn_ocn", "uocn", "vocn", "ss_tl
 PREP_FETCH = ["aiU", "cdn_ocnU", "uocnU", "vocnU", "umassdti", "fmU", "waterxU", "wateryU", "forcexU",
               "forceyU", "uvel_init", "vvel_init", "strtltxU", "strtltyU", "strairxU", "strairyU",
               "tmass", "umass", "uvel", "vvel"]
+PREP_FETCH_MORE = {"TbU": 20}      # further products cice_evp_hip_prep_fetch serves (not made by cice_evp_hip_prep itself)
 
 
 class PrepParams(C.Structure):
@@ -253,9 +254,15 @@ class EvpHip:
         a = self._c(TbU)
         _check(self.lib, self.lib.cice_evp_hip_set_tbu(_dp(a)), "(dyn_evp_hip_set_tbu)")
 
+    def seabed_lkd(self, hwater, k1, k2, alphab, threshold_hw):
+        a = self._c(hwater) if hwater is not None else None
+        _check(self.lib, self.lib.cice_evp_hip_seabed_lkd(_dp(a) if a is not None else None, C.c_double(k1), C.c_double(k2),
+                                                           C.c_double(alphab), C.c_double(threshold_hw)), "(dyn_evp_hip_seabed_lkd)")
+
     def prep_fetch(self, name: str):
         out = np.zeros(self.shape)
-        _check(self.lib, self.lib.cice_evp_hip_prep_fetch(C.c_int32(PREP_FETCH.index(name)), _dp(out)),
+        which = PREP_FETCH_MORE[name] if name in PREP_FETCH_MORE else PREP_FETCH.index(name)
+        _check(self.lib, self.lib.cice_evp_hip_prep_fetch(C.c_int32(which), _dp(out)),
                "(dyn_evp_hip_prep_fetch)")
         return out
 
@@ -279,11 +286,17 @@ class EvpHip:
         return out
 
     def timings(self) -> dict:
-        t = np.zeros(12)
-        self.lib.cice_evp_hip_get_timings(_dp(t), 12)
+        t = np.zeros(14)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 14)
         return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4],
                     tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
-                    halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10], resident_fallbacks=int(t[11]))
+                    halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10], resident_fallbacks=int(t[11]),
+                    halo_send_cells=int(t[12]), halo_recv_cells=int(t[13]))
+
+    def halo_mask(self, halomask):
+        """ice_HaloMask for the in-loop velocity exchange; halomask None = full halo."""
+        a = self._c(halomask, np.int32) if halomask is not None else None
+        _check(self.lib, self.lib.cice_evp_hip_halo_mask(_ip(a) if a is not None else None), "(dyn_evp_hip_halo_mask)")
 
     def stress_halo(self):
         """Tripole: 12 x ice_HaloUpdate_stress on the resident stresses (ice_dyn_evp.F90:1321-1389)."""

@@ -158,6 +158,11 @@ module ice_dyn_evp_hip
        import :: c_int
      end function cice_evp_hip_stress_halo
 
+     integer(c_int) function cice_evp_hip_halo_mask(halomask) bind(C, name='cice_evp_hip_halo_mask')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), dimension(*), intent(in) :: halomask
+     end function cice_evp_hip_halo_mask
+
      integer(c_int) function cice_evp_hip_set_option(key, val) bind(C, name='cice_evp_hip_set_option')
        import :: c_int, c_int32_t
        integer(c_int32_t), value :: key, val
@@ -458,6 +463,10 @@ contains
 
     use ice_dyn_shared, only: ndte, uvel_init, vvel_init
     use ice_timers, only: ice_timer_start, ice_timer_stop, timer_evp1dcore
+    use ice_domain, only: maskhalo_dyn, halo_info
+    use ice_boundary, only: ice_HaloUpdate
+    use ice_constants, only: field_loc_center, field_type_scalar
+    use ice_communicate, only: get_num_procs
 
     real(kind=dbl_kind), dimension(:,:,:), intent(inout), contiguous, target :: &
       L_stressp_1 , L_stressp_2 , L_stressp_3 , L_stressp_4 ,  &
@@ -474,6 +483,7 @@ contains
       L_iceUmask  , L_iceTmask
 
     integer(c_int32_t), pointer :: tmask_i(:), umask_i(:)
+    integer(int_kind), allocatable, save :: halomask(:,:,:)
     character(len=*), parameter :: subname = '(dyn_evp_hip_run)'
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
@@ -489,6 +499,16 @@ contains
        ! per-call H2D/D2H copies are direct DMA
        call pin_all()
        pinned = .true.
+    endif
+
+    if (maskhalo_dyn .and. get_num_procs() > 1) then
+       ! the masked halo evp() builds for its own loop (ice_dyn_evp.F90:739-770), rebuilt here because the
+       ! reference keeps halo_info_mask private: 1 where iceUmask, ghost cells updated, handed to the core
+       if (.not. allocated(halomask)) allocate(halomask(size(L_iceUmask,1), size(L_iceUmask,2), size(L_iceUmask,3)))
+       halomask = 0
+       where (L_iceUmask) halomask = 1
+       call ice_HaloUpdate(halomask, halo_info, field_loc_center, field_type_scalar)
+       call check(cice_evp_hip_halo_mask(halomask), subname, __FILE__, __LINE__)
     endif
 
     call ice_timer_start(timer_evp1dcore)

@@ -206,12 +206,17 @@ int cice_evp_hip_set_strength(const double *strength);
  * (seabed_stress_factor_LKD / _prob, ice_dyn_evp.F90:770-826), so it cannot travel with
  * cice_evp_hip_prep.  Call between cice_evp_hip_prep and cice_evp_hip_subcycle.                  */
 int cice_evp_hip_set_tbu(const double *TbU);
+/* ... or on the device, LKD method (seabed_stress_factor_LKD, ice_dyn_shared.F90:1386-1460): k1, k2, alphab,
+ * threshold_hw are ice_dyn_shared's namelist parameters, hwater ice_flux's water depth (NULL: the copy of the
+ * previous call).  Uses the aice / vice and the masks of the last cice_evp_hip_prep.  One exp() per ice U-cell from
+ * the device's math library: TbU may differ from the host's libm result in the last bit (tolerance).  */
+int cice_evp_hip_seabed_lkd(const double *hwater, double k1, double k2, double alphab, double threshold_hw);
 /* Returns its argument.  Lets a Fortran host take the address of a module array that lacks the
  * TARGET attribute (type(*), dimension(*) dummy) to fill the pointer tables above.              */
 void *cice_evp_hip_addr(const void *array);
 /* which: 0 aiU 1 cdn_ocnU 2 uocnU 3 vocnU 4 umassdti 5 fmU 6 waterxU 7 wateryU 8 forcexU 9 forceyU
  * 10 uvel_init 11 vvel_init 12 strtltxU 13 strtltyU 14 strairxU 15 strairyU 16 tmass 17 umass
- * 18 uvel 19 vvel (as the subcycle loop will see them)                                          */
+ * 18 uvel 19 vvel 20 TbU (as the subcycle loop will see them)                                         */
 int cice_evp_hip_prep_fetch(int32_t which, double *dst);
 
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */
@@ -229,6 +234,12 @@ int cice_evp_hip_comm_init(const void *id128);
  * hand: every rank exports CICE_EVP_HIP_HALO_BLOB bytes, the host all-gathers them
  * (rank order) and every rank imports the nranks blobs; import runs the probe exchange
  * (collective).  CICE_EVP_HIP_HALO=rccl|direct overrides the choice.                      */
+/* Masked halo for the velocity updates inside the subcycle loop = ice_HaloMask (ice_boundary.F90:889-1062; built by
+ * evp() when maskhalo_dyn, ice_dyn_evp.F90:739-770).  halomask: (nx_block, ny_block, max_blocks) int32, 1 where
+ * iceUmask, ghost cells updated (the reference's own array), NULL = full halo again.  Exchanged cells whose mask is
+ * 0 are dropped on both sides; copies inside a rank and exchanges across the tripole fold are never masked.  Call
+ * once per evp() after the masks are known (collective in the sense that every rank must pass its own mask).    */
+int cice_evp_hip_halo_mask(const int32_t *halomask);
 #define CICE_EVP_HIP_HALO_BLOB 1024
 int cice_evp_hip_halo_export(void *blob);
 int cice_evp_hip_halo_import(const void *blobs, int32_t nranks);
@@ -243,7 +254,8 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen);
  * [7]=streaming probe ms/subcycle, [8]=resident probe ms/subcycle,
  * [9]=remote halo transport: 0 none, 1 RCCL p2p, 2 mailbox (direct stores over xGMI),
  * [10]=device time of the last cice_evp_hip_prep (kernels + halos, without the copies), ms,
- * [11]=cice_evp_hip_run calls repeated with the streaming kernel after the resident one gave up  */
+ * [11]=cice_evp_hip_run calls repeated with the streaming kernel after the resident one gave up,
+ * [12], [13]=cells this rank sends / receives per velocity exchange of the loop (after cice_evp_hip_halo_mask)  */
 int cice_evp_hip_get_timings(double *out, int32_t n);
 /* Halo plan of this rank, for tests: counts[0]=local copies, [1]=#peers,
  * [2]=total send cells, [3]=total recv cells.  Lists may be NULL.

@@ -766,3 +766,32 @@ void evp_oracle_prep(const evp_oracle_domain *d, const evp_oracle_prep_params *p
     for (int k = 0; k < PT_COUNT; ++k) free(t[k]);
     free(maskd); free(tmphm); free(ss_tltxU); free(ss_tltyU);
 }
+
+/* =====================================================================
+ * Seabed stress factor, LKD method: seabed_stress_factor_LKD, dynamics/ice_dyn_shared.F90:1386-1460
+ * (grid_neighbor_min / _max at the U point: infrastructure/ice_grid.F90:4974, 5005); call site
+ * ice_dyn_evp.F90:783-790, after dyn_prep2 has zeroed TbU (:706).  exp() is libm's, as in the reference.
+ * aice / vice / hwater with current ghost cells (the caller's, like the reference's module arrays).
+ * ===================================================================== */
+void evp_oracle_seabed_lkd(const evp_oracle_domain *d, double k1, double k2, double alphab, double threshold_hw,
+                           const double *aice, const double *vice, const double *hwater,
+                           const int32_t *iceUmask, double *TbU)
+{
+    const int nx = d->nx_block;
+    const size_t plane = (size_t)nx * d->ny_block;
+    for (int b = 0; b < d->nblocks; ++b) {
+        for (size_t c = b * plane; c < (b + 1) * plane; ++c) TbU[c] = 0.0;
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const size_t c = b * plane + (size_t)(j - 1) * nx + (i - 1);
+                if (!iceUmask[c]) continue;
+                const size_t c1 = c + 1, c2 = c + nx, c3 = c + nx + 1;
+                const double hwu = fmin(fmin(fmin(hwater[c], hwater[c1]), hwater[c2]), hwater[c3]);
+                const double docalc_tbu = hwu < threshold_hw ? 1.0 : 0.0;
+                const double au = fmax(fmax(fmax(aice[c], aice[c1]), aice[c2]), aice[c3]);
+                const double hu = fmax(fmax(fmax(vice[c], vice[c1]), vice[c2]), vice[c3]);
+                const double hcu = au * hwu / k1;
+                TbU[c] = docalc_tbu * k2 * fmax(0.0, (hu - hcu)) * exp(-alphab * (1.0 - au));
+            }
+    }
+}

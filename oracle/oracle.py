@@ -226,3 +226,16 @@ def prep(dom: OracleDomain, pp: PrepParams, static: dict, tfields: dict, state: 
                           _dp(out["strintyU"]), _dp(out["strocnxU"]), _dp(out["strocnyU"]),
                           ip(out["iceTmask"]), Uptr)
     return out
+
+
+def seabed_lkd(dom: OracleDomain, k1, k2, alphab, threshold_hw, aice, vice, hwater, iceUmask):
+    """seabed_stress_factor_LKD (ice_dyn_shared.F90:1386-1460): TbU on the ice U-cells, 0 elsewhere."""
+    lib().evp_oracle_seabed_lkd.restype = None
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    a, v, h = f64(aice), f64(vice), f64(hwater)
+    um = np.ascontiguousarray(iceUmask, dtype=np.int32)
+    out = np.zeros(dom.shape)
+    lib().evp_oracle_seabed_lkd(C.byref(dom.c), C.c_double(k1), C.c_double(k2), C.c_double(alphab),
+                                C.c_double(threshold_hw), _dp(a), _dp(v), _dp(h),
+                                um.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out))
+    return out

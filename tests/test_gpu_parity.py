@@ -874,3 +874,73 @@ def test_run_with_page_locked_arrays_and_resident_stresses(name):
         assert_bitwise(out, want, f"{name}: pinned, copy-in/copy-out")
     finally:
         core.finalize()
+
+
+def test_seabed_stress_factor_on_device_lkd():
+    """SURVEY 8 f-2, last piece: seabed_stress_factor_LKD on the device from the aice / vice the preparation
+    uploaded and the masks it produced.  Everything but exp() is exact; exp() is the device library's, so TbU is
+    within 2 ulp of the reference's (host libm) value and the whole evp() within 1e-9 of the reference -- bit-identical
+    wherever the two exp() agree (tolerance stated in DESIGN.md)."""
+    c = GoldenCase("pop_cyc_2x2_seabed")
+    s = c.scal
+    core = hip_from_case(c, strict=True)
+    try:
+        st = c.prep_static()
+        core.set_prep_geometry(st["tmask"], st["umask"], st["hm"], st["tarea"], st["uarea"], st["fcor_blk"])
+        d = c.prep_scal_dict()
+        pp = evp.PrepParams(dt=d["dt"], rhoi=d["rhoi"], rhos=d["rhos"], gravit=d["gravit"],
+                            dyn_area_min=d["dyn_area_min"], dyn_mass_min=d["dyn_mass_min"],
+                            ssh_stress_coupled=d["ssh_coupled"])
+        for icall in range(1, c.ncalls + 1):
+            t, state = c.prep_inputs(icall)
+            dyn, _, _ = c.inputs(icall)
+            tm, um, _ = core.prep(pp, t, state)
+            core.seabed_lkd(c.d["hwater"] if icall == 1 else None, s[24], s[25], s[26], s[27])
+            tb = core.prep_fetch("TbU")
+            ref = dyn["TbU"]
+            assert np.abs(ref).max() > 0 and np.array_equal(tb == 0, ref == 0)
+            nz = ref != 0
+            ulp = np.abs(tb[nz] - ref[nz]) / np.spacing(np.abs(ref[nz]))
+            assert ulp.max() <= 2.0, f"TbU differs from the reference by {ulp.max()} ulp"
+            core.set_strength(dyn["strength"])
+            core.subcycle(c.ndte)
+            res = core.download()
+            want = c.expected(icall, c.ndte)
+            if ulp.max() == 0:
+                assert_bitwise(res, want, f"call {icall}: device seabed factor, identical exp()")
+            assert max_rel_err(res, want, VEL + SIG + ["taubxU", "taubyU"]) < 1e-9
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "direct", "direct-riding"])
+@pytest.mark.parametrize("name", ["pop_cyc_3x2pad_caps", "pop_cyc_1blk_patchy"])
+def test_masked_halo_is_bit_neutral_and_smaller(name, transport, monkeypatch):
+    """ice_HaloMask (SURVEY 8 f-3, a6/a7 option): the velocity exchange inside the loop reduced to the cells
+    whose halomask (iceUmask with updated ghost cells, as evp() builds it) is set -- on the remote paths, here
+    reached through the self exchange.  Same bits as the full halo and as the reference; fewer cells on the wire;
+    the full lists come back with a NULL mask."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", transport.split("-")[0])
+    monkeypatch.setenv("CICE_EVP_HIP_HALO_RIDE", "1" if transport.endswith("riding") else "0")
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        core.comm_init(core.comm_unique_id())
+        dyn, tm, um = c.inputs(1)
+        full = core.timings()["halo_send_cells"]
+        hm = oracle.halo_update(c.oracle_domain(), (um != 0).astype(np.float64), field_loc="center", field_type="scalar")
+        core.halo_mask((hm != 0).astype(np.int32))
+        out = core.run(dyn, tm, um, ndte=c.ndte)
+        t = core.timings()
+        assert 0 < t["halo_send_cells"] < full and t["halo_send_cells"] == t["halo_recv_cells"], (t, full)
+        assert_bitwise(post_evp(c, out), c.expected(1, c.ndte), f"{name}: masked halo through {transport}")
+        out = core.run(dyn, tm, um, ndte=c.ndte)
+        assert_bitwise(post_evp(c, out), c.expected(1, c.ndte), f"{name}: masked halo, second call")
+        core.halo_mask(None)
+        assert core.timings()["halo_send_cells"] == full
+        out = core.run(dyn, tm, um, ndte=c.ndte)
+        assert_bitwise(post_evp(c, out), c.expected(1, c.ndte), f"{name}: full halo again")
+    finally:
+        core.finalize()

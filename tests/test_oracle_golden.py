@@ -129,3 +129,18 @@ def test_next_tier_deformations_dyn_finish_bitwise(name):
             z = np.zeros_like(u)
             got.update(oracle.dyn_finish(dom, prm, dyn, u, v, um, z, z))
             assert_bitwise(got, {k: c.d[tag + k] for k in got}, f"{name} call {icall} nsub {nsub} f-1")
+
+
+def test_seabed_lkd_bitwise():
+    """seabed_stress_factor_LKD restated (libm exp, like the reference) against the TbU the reference handed to
+    its subcycle loop on the seabed fixture: bit for bit on this machine's libm, both calls."""
+    c = GoldenCase("pop_cyc_2x2_seabed")
+    s = c.scal
+    assert s[23] == 1.0                                   # seabed_stress on
+    dom = c.oracle_domain()
+    for icall in range(1, c.ncalls + 1):
+        dyn, tm, um = c.inputs(icall)
+        tb = oracle.seabed_lkd(dom, s[24], s[25], s[26], s[27], c.d[f"pr{icall:02d}_aice"], c.d[f"pr{icall:02d}_vice"],
+                               c.d["hwater"], um)
+        assert np.abs(dyn["TbU"]).max() > 0
+        assert np.array_equal(tb, dyn["TbU"]), f"call {icall}: {int((tb != dyn['TbU']).sum())} cells differ"
