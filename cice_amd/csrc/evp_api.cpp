@@ -126,8 +126,9 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         if (f == F_UVEL || f == F_VVEL) continue;
         if (alloc_d(&S.in[f], S.n)) return -1;
     }
+    S.nuv = S.n + (size_t)S.plan.tail;          // + staging slots for raw seam values of other ranks (tripole, any layout)
     for (int k = 0; k < 2; ++k) {
-        if (alloc_d(&S.u[k], S.n) || alloc_d(&S.v[k], S.n)) return -1;
+        if (alloc_d(&S.u[k], S.nuv) || alloc_d(&S.v[k], S.nuv)) return -1;
         for (auto &p : S.sig[k])
             if (alloc_d(&p, S.n)) return -1;
     }
@@ -284,6 +285,9 @@ int cice_evp_hip_subcycle(int32_t ndte)
 int cice_evp_hip_stress_halo(void)
 {
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (S.plan.stress_remote)
+        return fail(-9, "tripole: on this rank layout the stress symmetrisation needs top-row cells of other ranks; it stays "
+                        "with the host (evp() applies it to its own arrays, ice_dyn_evp.F90:1321-1389)");
     evp_launch_halo_stress(S.sig[S.cur], S.h_stress_dst, S.h_stress_src, S.n_stress, S.stream);
     HIPC(hipGetLastError());
     return 0;
@@ -639,6 +643,18 @@ int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid)
     return 0;
 }
 
+// recv_sign of cice_evp_hip_halo_plan's recv list (-1: the ghost lies across the tripole fold), same order
+int cice_evp_hip_peer_signs(int32_t *recv_sign)
+{
+    size_t ro = 0;
+    for (const HaloPeer &p : S.plan.peers) {
+        for (size_t k = 0; k < p.recv_sign.size(); ++k)
+            if (recv_sign) recv_sign[ro + k] = p.recv_sign[k];
+        ro += p.recv_sign.size();
+    }
+    return 0;
+}
+
 int cice_evp_hip_center_plan(int32_t *count, int32_t *dst, int32_t *src, int32_t *vsign)
 {
     const HaloPlan &P = S.plan;
@@ -660,6 +676,20 @@ int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src)
         if (src) src[k] = P.stress_src[k];
     }
     return 0;
+}
+
+// General form of the seam step (any rank layout): counts2 = {entries, staging slots}; lists may be NULL.
+int cice_evp_hip_seam_fin_plan(int32_t *counts2, int32_t *dst, int32_t *a, int32_t *b, int32_t *coef)
+{
+    const HaloPlan &P = S.plan;
+    if (counts2) { counts2[0] = (int32_t)P.fin_dst.size(); counts2[1] = (int32_t)P.tail; }
+    for (size_t k = 0; k < P.fin_dst.size(); ++k) {
+        if (dst) dst[k] = P.fin_dst[k];
+        if (a) a[k] = P.fin_a[k];
+        if (b) b[k] = P.fin_b[k];
+        if (coef) coef[k] = P.fin_coef[k];
+    }
+    return P.stress_remote ? 1 : 0;
 }
 
 int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,

@@ -212,6 +212,9 @@ void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
 void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, int npair, const int *pole,
                           int npole, const int *ldst, const int *lsrc, const signed char *lsign,
                           int nlate, hipStream_t st);
+int evp_halo_seam_fin_capacity();
+void evp_launch_halo_seam_fin(double *u, double *v, const int *dst, const int *fa, const int *fb,
+                              const signed char *coef, int n, hipStream_t st);
 void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src, int n, hipStream_t st);
 void evp_launch_halo_pack(const double *u, const double *v, const int *src, double *buf, int n,
                           hipStream_t st);

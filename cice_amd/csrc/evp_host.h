@@ -113,6 +113,10 @@ struct State {
             *h_late_src = nullptr;
     int8_t *h_late_sign = nullptr;
     int n_seam = 0, n_pole = 0, n_late = 0;
+    int32_t *h_fin_dst = nullptr, *h_fin_a = nullptr, *h_fin_b = nullptr;   // general seam step (HaloPlan::fin_*)
+    int8_t *h_fin_coef = nullptr;
+    int n_fin = 0;
+    size_t nuv = 0;              // elements of a velocity buffer: n + staging slots of the seam step
     int32_t *h_stress_dst = nullptr, *h_stress_src = nullptr;
     int n_stress = 0;
     // preparation phase on the device (evp_prep.hip)

@@ -64,6 +64,7 @@ void free_all()
     F(S.h_local_src);
     F(S.h_local_sign);
     F(S.h_seam_a); F(S.h_seam_b); F(S.h_seam_pole); F(S.h_late_dst); F(S.h_late_src); F(S.h_late_sign);
+    F(S.h_fin_dst); F(S.h_fin_a); F(S.h_fin_b); F(S.h_fin_coef);
     F(S.h_stress_dst); F(S.h_stress_src);
     {
         State::Prep &Q = S.prep;
@@ -239,6 +240,13 @@ int upload_lists()
     if (S.n_late) {
         HIPC(hipMalloc((void **)&S.h_late_sign, S.n_late));
         HIPC(hipMemcpy(S.h_late_sign, P.late_sign.data(), S.n_late, hipMemcpyHostToDevice));
+    }
+    S.n_fin = (int)P.fin_dst.size();
+    if (S.n_fin > evp_halo_seam_fin_capacity()) return fail(-3, "tripole seam: %d cells to finalise on one rank (limit %d)", S.n_fin, evp_halo_seam_fin_capacity());
+    if (up32(P.fin_dst, S.h_fin_dst) || up32(P.fin_a, S.h_fin_a) || up32(P.fin_b, S.h_fin_b)) return -1;
+    if (S.n_fin) {
+        HIPC(hipMalloc((void **)&S.h_fin_coef, S.n_fin));
+        HIPC(hipMemcpy(S.h_fin_coef, P.fin_coef.data(), S.n_fin, hipMemcpyHostToDevice));
     }
     std::vector<int32_t> ss, rd;
     std::vector<int8_t> rs;

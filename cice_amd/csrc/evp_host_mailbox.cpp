@@ -193,7 +193,7 @@ int direct_import(const HaloBlob *blobs, int nranks)
 // Uses the velocity buffers before any state has been uploaded, and leaves them zeroed.
 int direct_probe()
 {
-    std::vector<double> hu(S.n, 0.0), hv(S.n, 0.0);
+    std::vector<double> hu(S.nuv, 0.0), hv(S.nuv, 0.0);      // (staging slots of the tripole seam step included)
     const int nx = S.d.nx_block;
     for (int b = 0; b < S.d.nblocks; ++b)
         for (int j = S.jlo[b]; j <= S.jhi[b]; ++j)
@@ -204,14 +204,14 @@ int direct_probe()
                 hu[c] = gid + 1.0;
                 hv[c] = -2.0 * (gid + 1.0);
             }
-    HIPC(hipMemcpyAsync(S.u[0], hu.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
-    HIPC(hipMemcpyAsync(S.v[0], hv.data(), S.n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.u[0], hu.data(), S.nuv * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.v[0], hv.data(), S.nuv * sizeof(double), hipMemcpyHostToDevice, S.stream));
     EvpDirect D;
     fill_direct(D);
     for (int rep = 0; rep < 3; ++rep)           // both inbox parities, and a repeat
         evp_launch_halo_direct(D, S.u[0], S.v[0], S.stream);
-    HIPC(hipMemcpyAsync(hu.data(), S.u[0], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
-    HIPC(hipMemcpyAsync(hv.data(), S.v[0], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipMemcpyAsync(hu.data(), S.u[0], S.nuv * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipMemcpyAsync(hv.data(), S.v[0], S.nuv * sizeof(double), hipMemcpyDeviceToHost, S.stream));
     int err = 0;
     HIPC(hipMemcpyAsync(&err, D.err, sizeof(int), hipMemcpyDeviceToHost, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
@@ -391,7 +391,7 @@ int cice_evp_hip_halo_mask(const int32_t *halomask)
     State::Masked &M = S.msk;
     for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);     // captured loops bake the list lengths in
     S.graphs.clear();
-    if (!halomask || S.plan.peers.empty()) { M.on = false; return 0; }
+    if (!halomask || S.plan.peers.empty() || S.plan.tail > 0) { M.on = false; return 0; }
     for (const HaloPeer &p : S.plan.peers)
         for (int8_t sg : p.recv_sign)
             if (sg < 0) { M.on = false; return 0; }      // exchange across the tripole fold: never masked

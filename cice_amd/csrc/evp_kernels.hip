@@ -347,6 +347,40 @@ __global__ void halo_seam_uv(double *__restrict__ u, double *__restrict__ v,
     }
 }
 
+// The same seam step for any rank layout (halo_plan.h, fin lists): every entry reads RAW values -- local cells or
+// staging slots the exchange has just filled -- and only then are the results stored (own seam cells are both
+// operands and destinations).  One workgroup; up to FIN_PER entries per thread are held in registers.
+constexpr int FIN_PER = 8;
+__global__ __launch_bounds__(1024) void halo_seam_fin(double *__restrict__ u, double *__restrict__ v,
+                                                      const int *__restrict__ dst, const int *__restrict__ fa,
+                                                      const int *__restrict__ fb, const signed char *__restrict__ coef, int n)
+{
+    const double isign = -1.0;
+    double ru[FIN_PER], rv[FIN_PER];
+#pragma unroll
+    for (int e = 0; e < FIN_PER; ++e) {
+        const int k = threadIdx.x + e * 1024;
+        ru[e] = rv[e] = 0.0;
+        if (k < n) {
+            const int a = fa[k], b = fb[k];
+            const double c = (double)coef[k];
+            if (b >= 0) {      // pair: (x_a, x_b) <- (xavg, isign*xavg), xavg = 0.5*(x_a + isign*x_b)  (ice_boundary.F90:1630-1649)
+                const double xu = 0.5 * (u[a] + isign * u[b]);
+                const double xv = 0.5 * (v[a] + isign * v[b]);
+                ru[e] = c * xu; rv[e] = c * xv;
+            } else {
+                ru[e] = c * u[a]; rv[e] = c * v[a];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < FIN_PER; ++e) {
+        const int k = threadIdx.x + e * 1024;
+        if (k < n) { u[dst[k]] = ru[e]; v[dst[k]] = rv[e]; }
+    }
+}
+
 // ice_HaloUpdate_stress x 12 (ice_dyn_evp.F90:1321-1389): component k of a family takes the
 // mirrored top row of its partner (1<->3, 2<->4 == index ^ 2) into its tripole ghost row.
 // Reads interior rows, writes ghost rows: the 12 updates are independent.
@@ -488,6 +522,15 @@ void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, in
     if (npair <= 0 && npole <= 0 && nlate <= 0) return;
     hipLaunchKernelGGL(halo_seam_uv, dim3(1), dim3(1024), 0, st, u, v, pa, pb, npair, pole, npole, ldst,
                        lsrc, lsign, nlate);
+}
+
+int evp_halo_seam_fin_capacity() { return FIN_PER * 1024; }
+
+void evp_launch_halo_seam_fin(double *u, double *v, const int *dst, const int *fa, const int *fb,
+                              const signed char *coef, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(halo_seam_fin, dim3(1), dim3(1024), 0, st, u, v, dst, fa, fb, coef, n);
 }
 
 void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src, int n, hipStream_t st)

@@ -116,6 +116,8 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
     }
 
     std::map<int, HaloPeer> peers;
+    struct GhostSeam { int R; int32_t dst; int sig; int sign; };
+    std::vector<GhostSeam> ghost_seam;           // ghost cells (of any rank) that mirror a seam-row cell, canonical order
 
     // Enumerate the ghost cells of every rank in one canonical order (local
     // block index, then j, then i).  The receiver keeps entries whose source it
@@ -147,11 +149,11 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                     const int32_t src = (int32_t)((size_t)S.local * plane +
                                                   (size_t)(ng + (s.jg - S.gj0)) * nx + (ng + (s.ig - S.gi0)));
                     const bool src_on_seam = tripole && s.jg == d.ny_global;
-                    if (src_on_seam && S.owner != R && (R == me || S.owner == me)) {
-                        plan.error = "tripole: a ghost cell mirrors a seam-row cell of another rank "
-                                     "(two-phase exchange not implemented); use a rank layout that keeps "
-                                     "each seam row and its east-west neighbours on one rank (px = 1)";
-                        return false;
+                    if (src_on_seam) {
+                        // finalised after the exchange from RAW pair values (fin lists below); the plain copy only
+                        // stays in the local lists (late_*: single-rank form of the same step)
+                        ghost_seam.push_back({R, dst, s.ig, s.sign});
+                        if (S.owner != R) continue;
                     }
                     if (R == me) {
                         if (S.owner == me) {
@@ -179,7 +181,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                 }
         }
     }
-    for (auto &kv : peers) plan.peers.push_back(std::move(kv.second));
+    for (auto &kv : peers) plan.peers.push_back(kv.second);      // (the tripole section may append staging entries and rebuilds this)
 
     // cell-centre fields: ghosts of this rank's blocks, same enumeration
     {
@@ -238,7 +240,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
             owner = B.owner;
             return (int32_t)((size_t)B.local * plane + (size_t)(ng + (jg - B.gj0)) * nx + (ng + (ig - B.gi0)));
         };
-        for (int ig = 1; ig <= NX; ++ig) {
+        for (int ig = 1; ig <= NX; ++ig) {       // pairs with both halves on this rank (single-rank form; on-chip kernel)
             int oa = -1, ob = -1;
             const int32_t a = offset_of(ig, NY, oa);
             if (ig == NX / 2 || ig == NX) {
@@ -247,16 +249,71 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
             }
             if (ig > NX / 2 - 1) continue;      // pairs are enumerated from their low index
             const int32_t b = offset_of(NX - ig, NY, ob);
-            if (oa != me && ob != me) continue;
-            if (oa != ob) {
-                if (oa < 0 || ob < 0) continue;  // eliminated land block on one side: nothing to average
-                plan.error = "tripole: the two halves of a seam pair live on different ranks "
-                             "(not implemented); use a rank layout with px = 1";
-                return false;
-            }
+            if (oa != me || ob != me) continue;
             plan.seam_a.push_back(a);
             plan.seam_b.push_back(b);
         }
+        // General form: what every rank R must finalise, and which raw seam values of other ranks it needs for
+        // that.  Every rank runs the same enumeration for every R, so that a needed value appears at the same
+        // position of R's recv list and of its owner's send list.
+        for (const auto &kv : T.by_rank) {
+            const int R = kv.first;
+            const int32_t nR = (int32_t)(plane * kv.second.size());
+            std::map<int, int32_t> slot_of;          // global column of a remote seam cell -> staging slot of R
+            int32_t next_slot = 0;
+            auto ref = [&](int ig) -> int32_t {     // offset, at R, of the RAW value of seam cell (ig, NY); -1: eliminated
+                int ow = -1;
+                const int32_t off = offset_of(ig, NY, ow);
+                if (ow < 0) return -1;
+                if (ow == R) return off;
+                auto it = slot_of.find(ig);
+                if (it != slot_of.end()) return it->second;
+                const int32_t slot = nR + next_slot++;
+                slot_of[ig] = slot;
+                if (R == me) {
+                    HaloPeer &p = peers[ow];
+                    p.rank = ow;
+                    p.recv_dst.push_back(slot);
+                    p.recv_sign.push_back(1);
+                    p.recv_gid.push_back((int32_t)((ig - 1) + (size_t)NX * (NY - 1)));
+                } else if (ow == me) {
+                    HaloPeer &p = peers[R];
+                    p.rank = R;
+                    p.send_src.push_back(off);
+                    p.send_dst.push_back(slot);
+                }
+                return slot;
+            };
+            auto finalise = [&](int32_t dst, int sig, int sign) {   // dst takes sign * (final value of seam cell sig)
+                int32_t fa, fb = -1;
+                int coef = sign;
+                if (sig == NX / 2 || sig == NX) {
+                    fa = ref(sig);
+                    coef = -sign;                                   // pole: x <- -x
+                } else {
+                    const int lo = std::min(sig, NX - sig), hi = NX - lo;
+                    const int32_t ra = ref(lo), rb = ref(hi);
+                    if (ra < 0 || rb < 0) { fa = ref(sig); }        // partner eliminated: nothing to average
+                    else { fa = ra; fb = rb; if (sig == hi) coef = -sign; }
+                }
+                if (R == me && fa >= 0) {
+                    plan.fin_dst.push_back(dst);
+                    plan.fin_a.push_back(fa);
+                    plan.fin_b.push_back(fb);
+                    plan.fin_coef.push_back((int8_t)coef);
+                }
+            };
+            for (int ig = 1; ig <= NX; ++ig) {       // R's own seam-row cells
+                int ow = -1;
+                const int32_t off = offset_of(ig, NY, ow);
+                if (ow == R) finalise(off, ig, 1);
+            }
+            for (const GhostSeam &g : ghost_seam)    // R's ghost images of seam-row cells
+                if (g.R == R) finalise(g.dst, g.sig, g.sign);
+            if (R == me) plan.tail = next_slot;
+        }
+        plan.peers.clear();
+        for (auto &kv2 : peers) plan.peers.push_back(kv2.second);
         // stress symmetrisation lists (cell-centre fold: partner column NX-ig+1)
         auto it = T.by_rank.find(me);
         if (it != T.by_rank.end())
@@ -271,9 +328,10 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                     int owner = -1;
                     const int32_t src = offset_of(NX - ig + 1, NY, owner);
                     if (owner >= 0 && owner != me) {
-                        plan.error = "tripole: the stress symmetrisation needs a top-row cell of another rank "
-                                     "(not implemented); use a rank layout with px = 1";
-                        return false;
+                        // the symmetrisation stays with the host on such layouts (evp() does it on its own arrays,
+                        // ice_dyn_evp.F90:1321-1389); cice_evp_hip_stress_halo refuses
+                        plan.stress_remote = true;
+                        continue;
                     }
                     plan.stress_dst.push_back((int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1)));
                     plan.stress_src.push_back(owner < 0 ? -1 : src);

@@ -48,6 +48,17 @@ struct HaloPlan {
     std::vector<int32_t> seam_a, seam_b, seam_pole;
     std::vector<int32_t> late_dst, late_src;
     std::vector<int8_t> late_sign;
+    // The same step for ANY rank layout (seam pairs, or a ghost cell and the seam cell it mirrors, on different
+    // ranks): one entry per cell this rank must finalise after the velocity exchange -- its own seam-row cells and
+    // its ghost images of seam-row cells.  x[dst] = coef * 0.5*(x[a] + (-1)*x[b])   (b >= 0: pair average)
+    //                                     x[dst] = coef * x[a]                     (b == -1: pole / unpaired cell)
+    // a, b are offsets of RAW values of this subcycle: local cells, or staging slots n_local + t that the exchange
+    // fills with the raw value of a seam cell of another rank (`tail` slots; they travel as extra entries of the
+    // peers' send / recv lists, after the ghost cells).  All reads precede all writes.
+    std::vector<int32_t> fin_dst, fin_a, fin_b;
+    std::vector<int8_t> fin_coef;
+    int tail = 0;
+    bool stress_remote = false;                   // the stress symmetrisation needs a top-row cell of another rank
     // ice_HaloUpdate_stress (ice_boundary.F90:7441-7826; evp() after the subcycle loop,
     // ice_dyn_evp.F90:1321-1389): ghost row NY+1 of a cell-centre scalar takes the mirrored top
     // physical row of its PARTNER array, a1(ig, NY+1) <- a2(NX-ig+1, NY); ghost cells whose source

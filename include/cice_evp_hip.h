@@ -284,12 +284,20 @@ int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_
  * (ice_boundary.F90:1630-1649, 1689-1722).  Lists may be NULL.                  */
 int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,
                            int32_t *late_dst, int32_t *late_src, int32_t *late_sign);
+/* The seam step for any rank layout (pairs, or a ghost cell and the seam cell it mirrors, on different ranks):
+ * counts2 = {entries, staging slots}.  After the velocity exchange x[dst] = coef * 0.5*(x[a] - x[b]) (b >= 0) or
+ * coef * x[a] (b = -1), a / b = local cells or staging slots n_local + t filled by the exchange with RAW seam values
+ * of other ranks (they are the last entries of the peers' send / recv lists).  Returns 1 (not an error) when the
+ * stress symmetrisation would need another rank (then cice_evp_hip_stress_halo refuses).  Lists may be NULL.   */
+int cice_evp_hip_seam_fin_plan(int32_t *counts2, int32_t *dst, int32_t *a, int32_t *b, int32_t *coef);
 /* What the mailbox transports use on top of cice_evp_hip_halo_plan's lists, same peer order and
  * lengths as send_src / recv_dst: send_dst = the ghost cell each sent value fills, as an offset
  * into the PEER's array (remote stores need it; no set-up traffic -- every rank enumerates every
  * rank's ghosts); recv_gid = global cell number (ig-1)+nx_global*(jg-1) each received ghost mirrors
  * (probe exchanges).  Lists may be NULL.                                                         */
 int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid);
+/* Factor applied to each received value (+1, or -1 for a ghost cell across the tripole fold), recv-list order. */
+int cice_evp_hip_peer_signs(int32_t *recv_sign);
 /* Ghost-cell lists of cell-centre fields (T-grid inputs of cice_evp_hip_prep) whose source is on
  * this rank: a[dst] <- (vector kind ? vsign : 1) * a[src], src = -1: 0.  Returns 1 (not an error)
  * when some ghost needs another rank.  Lists may be NULL.                                       */

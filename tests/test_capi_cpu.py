@@ -135,16 +135,51 @@ def test_center_field_halo_lists_match_oracle(ew, ns, bx, by, vector):
     assert np.array_equal(got, want)
 
 
-def test_tripole_plan_refuses_seam_split_across_ranks():
-    dc = decomp.Decomp(20, 18, 10, 9, "cyclic", "tripole", 2, (2, 1))   # seam row cut in x
+def apply_fin(plan, flat):
+    """The general seam step (any rank layout): every entry from RAW values, then all stores."""
+    a, b, c = plan["fin_a"], plan["fin_b"], plan["fin_coef"].astype(np.float64)
+    pair = b >= 0
+    res = np.where(pair, c * (0.5 * (flat[a] + (-1.0) * flat[np.maximum(b, 0)])), c * flat[a])
+    flat[plan["fin_dst"]] = res
+
+
+@pytest.mark.parametrize("bx,by", [(20, 18), (5, 6), (7, 18), (10, 9)])
+def test_general_seam_lists_equal_single_rank_form(bx, by):
+    """fin lists (the seam step for any rank layout) on one rank == local copies + pairs + poles + late copies
+    == the oracle's tripole halo update."""
+    dc = decomp.Decomp(20, 18, bx, by, "cyclic", "tripole", 1)
     d, keep = evp.make_dims(dc, 0)
-    with pytest.raises(evp.EvpHipError, match="tripole"):
-        evp.halo_plan(d)
+    plan = evp.halo_plan(d)
+    assert plan["tail"] == 0 and not plan["stress_remote"] and len(plan["fin_dst"]) >= 20
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), 20, 18, "cyclic", "tripole",
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    a = np.random.default_rng(5).standard_normal(dc.shape(0))
+    want = oracle.halo_update(dom, a.copy(), "NEcorner", "vector")
+    got = a.copy()
+    flat = got.reshape(-1)
+    src = plan["local_src"]
+    flat[plan["local_dst"]] = np.where(src >= 0, plan["local_sign"] * flat[np.maximum(src, 0)], 0.0)
+    apply_fin(plan, flat)
+    assert np.array_equal(got, want)
+
+
+def test_tripole_plan_with_the_seam_split_across_ranks():
+    """px = 2: seam pairs and the east-west neighbours of the seam row live on different ranks -- the plan now
+    carries staging slots for the raw partner values instead of refusing; y slabs keep everything local."""
+    dc = decomp.Decomp(20, 18, 10, 9, "cyclic", "tripole", 2, (2, 1))   # seam row cut in x
+    for r in range(2):
+        d, keep = evp.make_dims(dc, r)
+        plan = evp.halo_plan(d)
+        assert plan["tail"] > 0 and plan["stress_remote"] and len(plan["seam_a"]) == 0
+        n_local = dc.nx_block * dc.ny_block * len(dc.local_blocks(r))
+        assert (plan["recv_dst"] >= n_local).sum() == plan["tail"]
     dc = decomp.Decomp(20, 18, 20, 9, "cyclic", "tripole", 2, (1, 2))    # y slabs: seam on one rank
     for r in range(2):
         d, keep = evp.make_dims(dc, r)
         plan = evp.halo_plan(d)
-        assert (len(plan["seam_a"]) > 0) == (r == 1)
+        assert (len(plan["seam_a"]) > 0) == (r == 1) and plan["tail"] == 0 and not plan["stress_remote"]
 
 
 def test_halo_plan_rejects_bad_geometry():

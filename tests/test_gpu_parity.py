@@ -944,3 +944,23 @@ def test_masked_halo_is_bit_neutral_and_smaller(name, transport, monkeypatch):
         assert_bitwise(post_evp(c, out), c.expected(1, c.ndte), f"{name}: full halo again")
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("name", [n for n in GOLDEN_CASES if n.startswith("trip")])
+def test_general_seam_step_equals_the_reference(name, monkeypatch):
+    """The seam step in its any-rank-layout form (exchange first, then every seam-row cell and every ghost image
+    of one finalised from raw values: halo_seam_fin) forced on one rank -- same bits as the reference's tripole
+    halo update inside the loop, both calls."""
+    monkeypatch.setenv("CICE_EVP_HIP_SEAM_FIN", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        for icall in range(1, c.ncalls + 1):
+            dyn, tm, um = c.inputs(icall)
+            for nsub in c.nsub_list:
+                out = post_evp(c, core.run(dyn, tm, um, ndte=nsub))
+                assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub} (general seam step)")
+        assert core.timings()["tile_variant"] < 1000
+    finally:
+        core.finalize()

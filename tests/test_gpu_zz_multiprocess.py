@@ -23,12 +23,15 @@ def _free_port():
 @pytest.mark.parametrize("world,workload,shape,resident", [(2, "gx3", "", True), (4, "gx3", "2x2", True),
                                                            (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep"),
                                                            (2, "tx1", "1x2", True), (8, "gx3", "2x4", True),
-                                                           (2, "gx3", "1x2", "blocks")])
+                                                           (2, "gx3", "1x2", "blocks"),
+                                                           (2, "tx1", "2x1", False), (4, "tx1", "2x2", False)])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
     the one GPU of this box, each owning one block; every rank's sub-domain, ghost cells
-    included, equals the single-rank run bit for bit (tools/mailbox_2proc.py)."""
+    included, equals the single-rank run bit for bit (tools/mailbox_2proc.py).  The last two cases cut the
+    tripole seam row in x (px = 2): seam pairs and the seam row's east-west neighbours on different ranks, raw
+    partner values travelling into the staging slots, every seam cell finalised after the exchange."""
     import subprocess
     import sys as _sys
     root = Path(__file__).resolve().parents[1]
