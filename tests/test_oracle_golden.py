@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/evp_oracle.c) against the golden fixtures frozen from
 the reference's own evp() (tests/golden/make_golden.py).  Bit-exact."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -144,3 +146,18 @@ def test_seabed_lkd_bitwise():
                                c.d["hwater"], um)
         assert np.abs(dyn["TbU"]).max() > 0
         assert np.array_equal(tb, dyn["TbU"]), f"call {icall}: {int((tb != dyn['TbU']).sum())} cells differ"
+
+
+def test_icepack_stub_constants_are_icepack_defaults():
+    """Icepack is an un-vendored submodule; the reference build under oracle/_ref links the hot-path objects against
+    oracle/ref/icepack_intfc_stub.F90.  `tools/stub_surface.sh` (nm on those objects; output committed as
+    profiles/r02_icepack_stub_surface.txt) shows what they take from it: icepack_query_parameters, the two warning
+    hooks, icepack_init_parameters (ice_grid) and icepack_ice_strength (outside the replaced region; its result is a
+    fixture input).  The constants the path reads through icepack_query_parameters, as the compiled reference dumped
+    them into every fixture, are Icepack's documented defaults (columnphysics/icepack_parameters.F90)."""
+    surface = (Path(__file__).resolve().parents[1] / "profiles" / "r02_icepack_stub_surface.txt").read_text()
+    used = sorted(set(l.split("Picepack_")[1] for l in surface.splitlines() if "Picepack_" in l))
+    assert used == ["ice_strength", "init_parameters", "query_parameters", "warnings_aborted", "warnings_flush"], used
+    for name in GOLDEN_CASES:
+        s = GoldenCase(name).scal
+        assert (s[12], s[17], s[18], s[19]) == (1026.0, 917.0, 330.0, 9.80616), name      # rhow, rhoi, rhos, gravit

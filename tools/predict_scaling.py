@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Predicted strong-scaling curve from ONE GPU: the per-rank piece an N-way split of a workload produces is
+timed alone on the GPU with every ghost copy that would cross ranks routed through the remote-halo transport to
+the rank itself (CICE_EVP_HIP_SELF_EXCHANGE=1).  What a 1-GPU box cannot show is the xGMI hop itself; the table is
+the prediction the first real N > 1 run is to be held against.
+
+  python tools/predict_scaling.py [out.json]
+"""
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+R = str(Path(__file__).resolve().parents[1])
+sys.path[:0] = [R, R + "/tests", R + "/oracle"]
+import numpy as np
+from cice_amd import decomp, evp, synth
+
+# workload: (nx, ny, ns, ndte, {N: [(px, py), ...]})
+WORK = {
+    "gx1": (320, 384, "closed", 120, {1: [(1, 1)], 2: [(2, 1), (1, 2)], 4: [(4, 1), (2, 2)], 8: [(8, 1), (4, 2)]}),
+    "tx1": (360, 240, "tripole", 240, {1: [(1, 1)], 2: [(1, 2)], 4: [(1, 4)], 8: [(1, 8)]}),
+    "s01": (3600, 2400, "closed", 480, {1: [(1, 1)], 2: [(2, 1)], 4: [(4, 1), (2, 2)], 8: [(8, 1), (4, 2)]}),
+}
+TRANSPORTS = {
+    "resident-remote": {"CICE_EVP_HIP_HALO": "direct"},
+    "stream+mailbox": {"CICE_EVP_HIP_HALO": "direct", "CICE_EVP_HIP_RESIDENT": "0"},
+    "stream+rccl": {"CICE_EVP_HIP_HALO": "rccl", "CICE_EVP_HIP_RESIDENT": "0"},
+}
+KEYS = ["CICE_EVP_HIP_HALO", "CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_SELF_EXCHANGE"]
+
+
+def time_piece(nx, ny, ns, dx0, nsub, envs, selfx):
+    for k in KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(envs)
+    if selfx:
+        os.environ["CICE_EVP_HIP_SELF_EXCHANGE"] = "1"
+    g = synth.derive_geometry(synth.make_grid(nx, ny, dx0, ns=ns))
+    st = synth.make_state(g, case="full", seed=1, warm=True)
+    dc = decomp.Decomp(nx, ny, nx, ny, "cyclic", ns, 1)
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k != "uarear" else 0.0)) for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+    tm, um = dc.scatter(st["iceTmask"], 0, fill=0), dc.scatter(st["iceUmask"], 0, fill=0)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(120), strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        if selfx:
+            core.comm_init(core.comm_unique_id())
+        core.upload(fields, tm, um)
+        core.subcycle(nsub)
+        core.sync()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            core.subcycle(nsub)
+        core.sync()
+        t = (time.perf_counter() - t0) / (reps * nsub)
+        tt = core.timings()
+    finally:
+        core.finalize()
+    return 1e6 * t, tt
+
+
+def main():
+    out = []
+    for wl, (NX, NY, ns, ndte, layouts) in WORK.items():
+        dx0 = synth.GRIDS[wl]["dx0"]
+        for N, shapes in layouts.items():
+            for px, py in shapes:
+                nx, ny = NX // px, NY // py
+                # a piece below the top row of a tripole grid has closed north/south neighbours here; the top piece keeps the fold
+                for tname, envs in TRANSPORTS.items():
+                    if N == 1 and tname != "resident-remote":
+                        continue
+                    nsub = min(ndte, 120) if nx * ny < 500000 else 24
+                    try:
+                        us, tt = time_piece(nx, ny, ns, dx0, nsub, {} if N == 1 else envs, N > 1)
+                    except Exception as e:  # noqa: BLE001
+                        out.append(dict(workload=wl, n=N, layout=f"{px}x{py}", piece=f"{nx}x{ny}", transport=tname, error=str(e)[:200]))
+                        print("RESULT", out[-1], flush=True)
+                        continue
+                    rec = dict(workload=wl, n=N, layout=f"{px}x{py}", piece=f"{nx}x{ny}", transport=tname if N > 1 else "none",
+                               us_per_subcycle=us, tile_variant=tt["tile_variant"], halo_transport=tt["halo_transport"],
+                               launches_per_subcycle=tt["launches_per_subcycle"], halo_cells=tt["halo_send_cells"],
+                               predicted_cell_updates_per_s=NX * NY / (us * 1e-6))
+                    out.append(rec)
+                    print("RESULT", rec, flush=True)
+    if len(sys.argv) > 1:
+        Path(sys.argv[1]).write_text(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
