@@ -163,6 +163,12 @@ module ice_dyn_evp_hip
        integer(c_int32_t), dimension(*), intent(in) :: halomask
      end function cice_evp_hip_halo_mask
 
+     integer(c_int) function cice_evp_hip_seam_fin_plan(counts2, dst, a, b, coef) bind(C, name='cice_evp_hip_seam_fin_plan')
+       import :: c_int, c_int32_t, c_ptr
+       integer(c_int32_t), dimension(2), intent(out) :: counts2
+       type(c_ptr), value :: dst, a, b, coef                          ! c_null_ptr: counts only
+     end function cice_evp_hip_seam_fin_plan
+
      integer(c_int) function cice_evp_hip_set_option(key, val) bind(C, name='cice_evp_hip_set_option')
        import :: c_int, c_int32_t
        integer(c_int32_t), value :: key, val
@@ -242,6 +248,7 @@ contains
     real(dbl_kind) :: rhow
     character(len=16) :: envval
     integer :: envlen, envstat
+    integer(c_int32_t) :: cnt2(2)
     character(len=*), parameter :: subname = '(dyn_evp_hip_init)'
 
     call icepack_query_parameters(rhow_out=rhow)
@@ -293,6 +300,10 @@ contains
     on_tripole = trim(ns_boundary_type) == 'tripole'
     call get_environment_variable('CICE_EVP_HIP_STRESS_RESIDENT', envval, envlen, envstat)
     stress_resident = .not. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '0')
+    ! a rank layout that cuts the tripole seam row: the stress symmetrisation needs other ranks and stays with
+    ! evp()'s host code (ice_dyn_evp.F90:1321-1389), so the stresses must make the round trip every call
+    if (on_tripole .and. cice_evp_hip_seam_fin_plan(cnt2, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr) == 1) &
+       stress_resident = .false.
     call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
          subname, __FILE__, __LINE__)
 
