@@ -795,3 +795,239 @@ void evp_oracle_seabed_lkd(const evp_oracle_domain *d, double k1, double k2, dou
             }
     }
 }
+
+/* =====================================================================
+ * C-grid EVP subcycle: evp()'s loop for grid_ice = 'C',
+ * dynamics/ice_dyn_evp.F90:938-1099.  u lives at the east face (E), v at the north
+ * face (N); stresses at cell centres (T) and corners (U).  One subcycle =
+ *   strain_rates_U -> halo(shearU) -> stressC_T -> halo(zetax2T, etax2T, stresspT, stressmT)
+ *   -> T->U average of etax2T (or of the strength) -> stressC_U -> halo(stress12U)
+ *   -> div_stress_Ex / div_stress_Ny -> stepu_C / stepv_C -> halo(uvelE), halo(vvelN)
+ *   -> uvelN = E->N average, vvelE = N->E average (times the face masks) -> their halos
+ *   -> uvel, vvel = face -> corner averages (times uvm) -> halo.
+ *
+ * Field table `f` (in/out):
+ *   0 uvelE 1 vvelE 2 uvelN 3 vvelN 4 uvel 5 vvel 6 stresspT 7 stressmT 8 stress12T 9 stress12U
+ *  10 strintxE 11 strintyN 12 taubxE 13 taubyN 14 zetax2T 15 etax2T 16 etax2U 17 shearU 18 deltaU
+ *   (14-18 are work arrays of evp(), zeroed at its entry, :351-361; kept because the reference
+ *    keeps them and the ridging diagnostics read shearU afterwards)
+ * Input table `in`:
+ *   0 strength 1 cdn_ocnE 2 aiE 3 uocnE 4 vocnE 5 waterxE 6 forcexE 7 emassdti 8 fmE 9 uvelE_init
+ *  10 TbE 11 rheofactE 12 cdn_ocnN 13 aiN 14 uocnN 15 vocnN 16 wateryN 17 forceyN 18 nmassdti
+ *  19 fmN 20 vvelN_init 21 TbN 22 rheofactN
+ * Static table `g`:
+ *   0 dxT 1 dyT 2 dxU 3 dyU 4 dxE 5 dyE 6 dxN 7 dyN 8 uarea 9 tarea 10 earea 11 narea 12 earear
+ *  13 narear 14 epm 15 npm 16 uvm 17 hm 18 DminTarea 19 ratiodxN 20 ratiodxNr 21 ratiodyE 22 ratiodyEr
+ * ===================================================================== */
+
+/* grid_average_X2YA, the four directions the loop uses (infrastructure/ice_grid.F90:4388-4606):
+ * dir 0 'NW' (E->N), 1 'SE' (N->E), 2 'N' (E->U), 3 'E' (N->U).  The whole output array is zeroed first
+ * (:4412), interior cells with a non-zero weight sum are computed, then the result is multiplied by `mask`
+ * on every cell (ice_dyn_evp.F90:1074-1075, 1088-1089). */
+static void avg_A(const evp_oracle_domain *d, int dir, const double *w1, const double *wght, const double *mask,
+                  double *w2)
+{
+    const int nx = d->nx_block;
+    const size_t nb = (size_t)nx * d->ny_block;
+    memset(w2, 0, sizeof(double) * nb * d->nblocks);
+    for (int b = 0; b < d->nblocks; ++b) {
+        const double *a = w1 + b * nb, *w = wght + b * nb;
+        double *o = w2 + b * nb;
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                double wtmp;
+                switch (dir) {
+                case 0: /* NW */
+                    wtmp = (w[IX(i - 1, j)] + w[IX(i, j)] + w[IX(i - 1, j + 1)] + w[IX(i, j + 1)]);
+                    if (wtmp != 0.0)
+                        o[IX(i, j)] = (a[IX(i - 1, j)] * w[IX(i - 1, j)] + a[IX(i, j)] * w[IX(i, j)] +
+                                       a[IX(i - 1, j + 1)] * w[IX(i - 1, j + 1)] + a[IX(i, j + 1)] * w[IX(i, j + 1)]) / wtmp;
+                    break;
+                case 1: /* SE */
+                    wtmp = (w[IX(i, j - 1)] + w[IX(i + 1, j - 1)] + w[IX(i, j)] + w[IX(i + 1, j)]);
+                    if (wtmp != 0.0)
+                        o[IX(i, j)] = (a[IX(i, j - 1)] * w[IX(i, j - 1)] + a[IX(i + 1, j - 1)] * w[IX(i + 1, j - 1)] +
+                                       a[IX(i, j)] * w[IX(i, j)] + a[IX(i + 1, j)] * w[IX(i + 1, j)]) / wtmp;
+                    break;
+                case 2: /* N */
+                    wtmp = (w[IX(i, j)] + w[IX(i, j + 1)]);
+                    if (wtmp != 0.0)
+                        o[IX(i, j)] = (a[IX(i, j)] * w[IX(i, j)] + a[IX(i, j + 1)] * w[IX(i, j + 1)]) / wtmp;
+                    break;
+                default: /* E */
+                    wtmp = (w[IX(i, j)] + w[IX(i + 1, j)]);
+                    if (wtmp != 0.0)
+                        o[IX(i, j)] = (a[IX(i, j)] * w[IX(i, j)] + a[IX(i + 1, j)] * w[IX(i + 1, j)]) / wtmp;
+                    break;
+                }
+            }
+    }
+    const double *m = mask;
+    for (size_t k = 0; k < nb * d->nblocks; ++k) w2[k] = w2[k] * m[k];
+}
+
+void evp_oracle_cgrid_subcycle(const evp_oracle_domain *d, const evp_oracle_params *p, int ndte,
+                               int avg_strength, double *const *f, const double *const *in,
+                               const double *const *g, const int32_t *iceTmask, const int32_t *iceUmask,
+                               const int32_t *iceEmask, const int32_t *iceNmask)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t nb = (size_t)nx * ny, ntot = nb * d->nblocks;
+    double *divergU = (double *)malloc(sizeof(double) * ntot), *tensionU = (double *)malloc(sizeof(double) * ntot);
+    double *strengthU = (double *)calloc(ntot, sizeof(double));
+    const double relax = 1.0 - p->arlx1i * p->revp;      /* (c1-arlx1i*revp) */
+
+    for (int ksub = 0; ksub < ndte; ++ksub) {
+        /* ---- strain_rates_U  (ice_dyn_shared.F90:2341-2444): strain rates * area at the corners ---- */
+        memset(divergU, 0, sizeof(double) * ntot);
+        memset(tensionU, 0, sizeof(double) * ntot);
+        memset(f[17], 0, sizeof(double) * ntot);
+        memset(f[18], 0, sizeof(double) * ntot);
+        for (int b = 0; b < d->nblocks; ++b) {
+            const double *uE = f[0] + b * nb, *vE = f[1] + b * nb, *uN = f[2] + b * nb, *vN = f[3] + b * nb;
+            const double *uU = f[4] + b * nb, *vU = f[5] + b * nb;
+            const double *dxU = g[2] + b * nb, *dyU = g[3] + b * nb, *dxE = g[4] + b * nb, *dyN = g[7] + b * nb;
+            const double *epm = g[14] + b * nb, *npm = g[15] + b * nb;
+            const double *rxN = g[19] + b * nb, *rxNr = g[20] + b * nb, *ryE = g[21] + b * nb, *ryEr = g[22] + b * nb;
+            for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+                for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                    if (!iceUmask[b * nb + IX(i, j)]) continue;
+                    const size_t c = IX(i, j), e = IX(i + 1, j), n = IX(i, j + 1);
+                    double uNip1j = uN[e] * npm[e] + (npm[c] - npm[e]) * npm[c] * rxN[c] * uN[c];
+                    double uNij = uN[c] * npm[c] + (npm[e] - npm[c]) * npm[e] * rxNr[c] * uN[e];
+                    double vEijp1 = vE[n] * epm[n] + (epm[c] - epm[n]) * epm[c] * ryE[c] * vE[c];
+                    double vEij = vE[c] * epm[c] + (epm[n] - epm[c]) * epm[n] * ryEr[c] * vE[n];
+                    double dv = dyU[c] * (uNip1j - uNij) + uU[c] * (dyN[e] - dyN[c]) + dxU[c] * (vEijp1 - vEij) +
+                                vU[c] * (dxE[n] - dxE[c]);
+                    double tn = dyU[c] * (uNip1j - uNij) - uU[c] * (dyN[e] - dyN[c]) - dxU[c] * (vEijp1 - vEij) +
+                                vU[c] * (dxE[n] - dxE[c]);
+                    double uEijp1 = uE[n] * epm[n] + (epm[c] - epm[n]) * epm[c] * ryE[c] * uE[c];
+                    double uEij = uE[c] * epm[c] + (epm[n] - epm[c]) * epm[n] * ryEr[c] * uE[n];
+                    double vNip1j = vN[e] * npm[e] + (npm[c] - npm[e]) * npm[c] * rxN[c] * vN[c];
+                    double vNij = vN[c] * npm[c] + (npm[e] - npm[c]) * npm[e] * rxNr[c] * vN[e];
+                    double sh = dxU[c] * (uEijp1 - uEij) - uU[c] * (dxE[n] - dxE[c]) + dyU[c] * (vNip1j - vNij) -
+                                vU[c] * (dyN[e] - dyN[c]);
+                    divergU[b * nb + c] = dv;
+                    tensionU[b * nb + c] = tn;
+                    f[17][b * nb + c] = sh;
+                    f[18][b * nb + c] = sqrt(dv * dv + p->e_factor * (tn * tn + sh * sh));
+                }
+        }
+        evp_oracle_halo_update(d, f[17], 1, 0, 0, 0.0);      /* shearU: NE corner, scalar (ice_dyn_evp.F90:965-967) */
+
+        /* ---- stressC_T  (ice_dyn_evp.F90:1758-1880; strain_rates_Tdt ice_dyn_shared.F90:2291-2339) ---- */
+        for (int b = 0; b < d->nblocks; ++b) {
+            const double *uE = f[0] + b * nb, *vN = f[3] + b * nb, *shU = f[17] + b * nb;
+            const double *dxT = g[0] + b * nb, *dyT = g[1] + b * nb, *dyE = g[5] + b * nb, *dxN = g[6] + b * nb;
+            const double *uarea = g[8] + b * nb, *Dmin = g[18] + b * nb, *strength = in[0] + b * nb;
+            for (int j = d->jlo[b]; j <= d->jhi[b] + 1; ++j)
+                for (int i = d->ilo[b]; i <= d->ihi[b] + 1; ++i) {
+                    if (!iceTmask[b * nb + IX(i, j)]) continue;
+                    const size_t c = IX(i, j), w = IX(i - 1, j), s = IX(i, j - 1), sw = IX(i - 1, j - 1);
+                    double divT = dyE[c] * uE[c] - dyE[w] * uE[w] + dxN[c] * vN[c] - dxN[s] * vN[s];
+                    double tensionT = (dyT[c] * dyT[c]) * (uE[c] / dyE[c] - uE[w] / dyE[w]) -
+                                      (dxT[c] * dxT[c]) * (vN[c] / dxN[c] - vN[s] / dxN[s]);
+                    double uareaavgr = 1.0 / (uarea[c] + uarea[s] + uarea[sw] + uarea[w]);
+                    double shearTsqr = (shU[c] * shU[c] * uarea[c] + shU[s] * shU[s] * uarea[s] +
+                                        shU[sw] * shU[sw] * uarea[sw] + shU[w] * shU[w] * uarea[w]) * uareaavgr;
+                    double shearT = (shU[c] * uarea[c] + shU[s] * uarea[s] + shU[sw] * uarea[sw] + shU[w] * uarea[w]) *
+                                    uareaavgr;
+                    double DeltaT = sqrt(divT * divT + p->e_factor * (tensionT * tensionT + shearTsqr));
+                    double zetax2, etax2, rep_prs;
+                    visc_replpress(p, strength[c], Dmin[c], DeltaT, &zetax2, &etax2, &rep_prs);
+                    f[14][b * nb + c] = zetax2;
+                    f[15][b * nb + c] = etax2;
+                    f[6][b * nb + c] = (f[6][b * nb + c] * relax + p->arlx1i * (zetax2 * divT - rep_prs)) * p->denom1;
+                    f[7][b * nb + c] = (f[7][b * nb + c] * relax + p->arlx1i * etax2 * tensionT) * p->denom1;
+                    f[8][b * nb + c] = (f[8][b * nb + c] * relax + p->arlx1i * p5 * etax2 * shearT) * p->denom1;
+                }
+        }
+        for (int k = 14; k <= 15; ++k) evp_oracle_halo_update(d, f[k], 0, 0, 0, 0.0);   /* (:988-990) */
+        for (int k = 6; k <= 7; ++k) evp_oracle_halo_update(d, f[k], 0, 0, 0, 0.0);
+
+        /* ---- viscosity at the corners (:992-996) and stressC_U (:1898-1972) ---- */
+        if (avg_strength) avg_T2U_S(d, in[0], g[9], g[17], strengthU);
+        else avg_T2U_S(d, f[15], g[9], g[17], f[16]);
+        for (int b = 0; b < d->nblocks; ++b)
+            for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+                for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                    const size_t c = b * nb + IX(i, j);
+                    if (!iceUmask[c]) continue;
+                    double etax2U = f[16][c];
+                    if (avg_strength) {
+                        double z, r;
+                        visc_replpress(p, strengthU[c], p->deltaminEVP * g[8][c], f[18][c], &z, &etax2U, &r);
+                    }
+                    f[9][c] = (f[9][c] * relax + p->arlx1i * p5 * etax2U * f[17][c]) * p->denom1;
+                }
+        evp_oracle_halo_update(d, f[9], 1, 0, 0, 0.0);       /* stress12U (:1011-1013) */
+
+        /* ---- div_stress_Ex, div_stress_Ny (:2195-2239, :2371-2416), stepu_C, stepv_C (ice_dyn_shared.F90:1090-1290) ---- */
+        for (int b = 0; b < d->nblocks; ++b) {
+            const double *sp = f[6] + b * nb, *sm = f[7] + b * nb, *s12 = f[9] + b * nb;
+            const double *dxT = g[0] + b * nb, *dyT = g[1] + b * nb, *dxU = g[2] + b * nb, *dyU = g[3] + b * nb;
+            const double *dxE = g[4] + b * nb, *dyE = g[5] + b * nb, *dxN = g[6] + b * nb, *dyN = g[7] + b * nb;
+            for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+                for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                    const size_t c = IX(i, j), e = IX(i + 1, j), n = IX(i, j + 1), s = IX(i, j - 1), w = IX(i - 1, j);
+                    const size_t o = b * nb + c;
+                    if (iceEmask[o])
+                        f[10][o] = in[11][o] * g[12][o] *
+                                   (p5 * dyE[c] * (sp[e] - sp[c]) +
+                                    (p5 / dyE[c]) * ((dyT[e] * dyT[e]) * sm[e] - (dyT[c] * dyT[c]) * sm[c]) +
+                                    (1.0 / dxE[c]) * ((dxU[c] * dxU[c]) * s12[c] - (dxU[s] * dxU[s]) * s12[s]));
+                    if (iceNmask[o])
+                        f[11][o] = in[22][o] * g[13][o] *
+                                   (p5 * dxN[c] * (sp[n] - sp[c]) -
+                                    (p5 / dxN[c]) * ((dxT[n] * dxT[n]) * sm[n] - (dxT[c] * dxT[c]) * sm[c]) +
+                                    (1.0 / dyN[c]) * ((dyU[c] * dyU[c]) * s12[c] - (dyU[w] * dyU[w]) * s12[w]));
+                }
+        }
+        for (int b = 0; b < d->nblocks; ++b)
+            for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+                for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                    const size_t o = b * nb + IX(i, j);
+                    if (iceEmask[o]) {       /* stepu_C: u at E, with the v interpolated to E last subcycle */
+                        double uold = f[0][o], vold = f[1][o];
+                        double vrel = in[2][o] * p->rhow * in[1][o] *
+                                      sqrt((in[3][o] - uold) * (in[3][o] - uold) + (in[4][o] - vold) * (in[4][o] - vold));
+                        double taux = vrel * in[5][o];
+                        double ccc = sqrt(uold * uold + vold * vold) + p->u0;
+                        double Cb = in[10][o] / ccc;
+                        double cca = (p->brlx + p->revp) * in[7][o] + vrel * p->cosw + Cb;
+                        double ccb = in[8][o] + copysign(1.0, in[8][o]) * vrel * p->sinw;
+                        double cc1 = f[10][o] + in[6][o] + taux + in[7][o] * (p->brlx * uold + p->revp * in[9][o]);
+                        f[0][o] = (ccb * vold + cc1) / cca;
+                        f[12][o] = -f[0][o] * Cb;
+                    }
+                    if (iceNmask[o]) {       /* stepv_C: v at N, with the u interpolated to N last subcycle */
+                        double uold = f[2][o], vold = f[3][o];
+                        double vrel = in[13][o] * p->rhow * in[12][o] *
+                                      sqrt((in[14][o] - uold) * (in[14][o] - uold) + (in[15][o] - vold) * (in[15][o] - vold));
+                        double tauy = vrel * in[16][o];
+                        double ccc = sqrt(uold * uold + vold * vold) + p->u0;
+                        double Cb = in[21][o] / ccc;
+                        double cca = (p->brlx + p->revp) * in[18][o] + vrel * p->cosw + Cb;
+                        double ccb = in[19][o] + copysign(1.0, in[19][o]) * vrel * p->sinw;
+                        double cc2 = f[11][o] + in[17][o] + tauy + in[18][o] * (p->brlx * vold + p->revp * in[20][o]);
+                        f[3][o] = (-ccb * uold + cc2) / cca;
+                        f[13][o] = -f[3][o] * Cb;
+                    }
+                }
+        evp_oracle_halo_update(d, f[0], 2, 1, 0, 0.0);       /* uvelE: E face, vector (:1063-1065) */
+        evp_oracle_halo_update(d, f[3], 3, 1, 0, 0.0);       /* vvelN: N face, vector (:1066-1068) */
+
+        /* ---- the other component at each face (:1070-1082), corner velocities (:1084-1094) ---- */
+        avg_A(d, 0, f[0], g[10], g[15], f[2]);               /* uvelN = E2N(uvelE) * npm */
+        avg_A(d, 1, f[3], g[11], g[14], f[1]);               /* vvelE = N2E(vvelN) * epm */
+        evp_oracle_halo_update(d, f[2], 3, 1, 0, 0.0);
+        evp_oracle_halo_update(d, f[1], 2, 1, 0, 0.0);
+        avg_A(d, 2, f[0], g[10], g[16], f[4]);               /* uvel = E2U(uvelE) * uvm */
+        avg_A(d, 3, f[3], g[11], g[16], f[5]);               /* vvel = N2U(vvelN) * uvm */
+        evp_oracle_halo_update(d, f[4], 1, 1, 0, 0.0);
+        evp_oracle_halo_update(d, f[5], 1, 1, 0, 0.0);
+    }
+    free(divergU);
+    free(tensionU);
+    free(strengthU);
+}

@@ -239,3 +239,33 @@ def seabed_lkd(dom: OracleDomain, k1, k2, alphab, threshold_hw, aice, vice, hwat
                                 C.c_double(threshold_hw), _dp(a), _dp(v), _dp(h),
                                 um.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out))
     return out
+
+
+# ---- C-grid subcycle -----------------------------------------------------------
+C_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
+            "strintxE", "strintyN", "taubxE", "taubyN", "zetax2T", "etax2T", "etax2U", "shearU", "deltaU"]
+C_WORK = C_FIELDS[14:]       # evp() zeroes these at its entry (ice_dyn_evp.F90:351-361): absent from `state` = zeros
+C_INPUTS = ["strength", "cdn_ocnE", "aiE", "uocnE", "vocnE", "waterxE", "forcexE", "emassdti", "fmE", "uvelE_init",
+            "TbE", "rheofactE", "cdn_ocnN", "aiN", "uocnN", "vocnN", "wateryN", "forceyN", "nmassdti", "fmN",
+            "vvelN_init", "TbN", "rheofactN"]
+C_STATIC = ["dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear",
+            "narear", "epm", "npm", "uvm", "hm", "DminTarea", "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr"]
+C_MASKS = ["iceTmask", "iceUmask", "iceEmask", "iceNmask"]
+
+
+def cgrid_subcycle(dom: OracleDomain, params: Params, ndte: int, state: dict, inputs: dict, static: dict,
+                   masks: dict, visc_method: str = "avg_zeta") -> dict:
+    """evp()'s subcycle loop for grid_ice = 'C' (ice_dyn_evp.F90:938-1099).  Everything is copied; returns C_FIELDS."""
+    lib().evp_oracle_cgrid_subcycle.restype = None
+    work = {k: (np.array(state[k], dtype=np.float64, order="C", copy=True) if k in state else np.zeros(dom.shape))
+            for k in C_FIELDS}
+    inp = [np.ascontiguousarray(inputs[k], dtype=np.float64) for k in C_INPUTS]
+    st = [np.ascontiguousarray(static[k], dtype=np.float64) for k in C_STATIC]
+    mk = [np.ascontiguousarray(masks[k], dtype=np.int32) for k in C_MASKS]
+    fptr = (C.POINTER(C.c_double) * len(C_FIELDS))(*[_dp(work[k]) for k in C_FIELDS])
+    iptr = (C.POINTER(C.c_double) * len(inp))(*[_dp(a) for a in inp])
+    gptr = (C.POINTER(C.c_double) * len(st))(*[_dp(a) for a in st])
+    lib().evp_oracle_cgrid_subcycle(C.byref(dom.c), C.byref(params), C.c_int(ndte),
+                                    C.c_int(1 if visc_method == "avg_strength" else 0), fptr, iptr, gptr,
+                                    *[m.ctypes.data_as(C.POINTER(C.c_int32)) for m in mk])
+    return work

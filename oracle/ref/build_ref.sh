@@ -76,7 +76,9 @@ build_variant () {
     $FC $fflags -cpp -I.. -c "$HERE/evp_dumpio.F90" -o evp_dumpio.o
     $FC $fflags -cpp -I.. -I. -c "$HERE/ice_dyn_evp1d_capture.F90" -o ice_dyn_evp1d.o
     $FC $fflags -cpp -I.. -I. -c "$EVP" -o ice_dyn_evp.o
-    $FC $fflags -cpp -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp1d.o ice_dyn_evp.o \
+    gcc -O2 -c "$HERE/evp_peek.c" -o evp_peek.o
+    $FC $fflags -cpp -I.. -I. -c "$HERE/evp_ref_harness.F90" -o evp_ref_harness.o
+    $FC $fflags evp_ref_harness.o evp_dumpio.o evp_peek.o ice_dyn_evp1d.o ice_dyn_evp.o \
         $(for o in $COMMON; do echo ../$o; done) -o "$OUT/evp_ref_harness_$variant"
     cd ..
 
@@ -87,7 +89,9 @@ build_variant () {
       $FC $fflags -cpp -I.. -c "$HERE/evp_dumpio.F90" -o evp_dumpio.o
       $FC $fflags -cpp -I.. -I. -c "$EVP1D_REF" -o ice_dyn_evp1d.o
       $FC $fflags -cpp -I.. -I. -c "$EVP" -o ice_dyn_evp.o
-      $FC $fflags -cpp -DHARNESS_REF1D -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp1d.o ice_dyn_evp.o \
+      gcc -O2 -c "$HERE/evp_peek.c" -o evp_peek.o
+      $FC $fflags -cpp -DHARNESS_REF1D -I.. -I. -c "$HERE/evp_ref_harness.F90" -o evp_ref_harness.o
+      $FC $fflags evp_ref_harness.o evp_dumpio.o evp_peek.o ice_dyn_evp1d.o ice_dyn_evp.o \
           $(for o in $COMMON; do echo ../$o; done) -o "$OUT/evp_ref_harness_fast1d"
       cd ..
       echo "built $OUT/evp_ref_harness_fast1d"
@@ -102,7 +106,9 @@ build_variant () {
       $FC $fflags -cpp -I.. -I. -c "$REPO/cice_amd/fortran/ice_dyn_evp_hip.F90" -o ice_dyn_evp_hip.o
       $FC $fflags -cpp -I.. -I. -c "$REPO/cice_amd/fortran/ice_dyn_evp1d_hip.F90" -o ice_dyn_evp1d.o
       $FC $fflags -cpp -I.. -I. -c "$EVP" -o ice_dyn_evp.o
-      $FC $fflags -cpp -DHARNESS_HIP_BODY -I.. -I. "$HERE/evp_ref_harness.F90" evp_dumpio.o ice_dyn_evp_hip.o ice_dyn_evp1d.o ice_dyn_evp.o \
+      gcc -O2 -c "$HERE/evp_peek.c" -o evp_peek.o
+      $FC $fflags -cpp -DHARNESS_HIP_BODY -I.. -I. -c "$HERE/evp_ref_harness.F90" -o evp_ref_harness.o
+      $FC $fflags evp_ref_harness.o evp_dumpio.o evp_peek.o ice_dyn_evp_hip.o ice_dyn_evp1d.o ice_dyn_evp.o \
           $(for o in $COMMON; do echo ../$o; done) \
           -L"$REPO/cice_amd" -lcice_evp_hip -Wl,-rpath,'$ORIGIN/../../cice_amd' -o "$OUT/evp_hip_dropin_harness"
       cd ..

@@ -68,4 +68,24 @@ contains
     write(dump_unit) a
   end subroutine dump_r8_1d
 
+  ! a module-private array of ice_dyn_evp, located by evp_peek.c
+  subroutine dump_peek(name, which, n1, n2, n3, nb)
+    use, intrinsic :: iso_c_binding, only: c_ptr, c_f_pointer, c_int, c_associated
+    character(len=*), intent(in) :: name
+    integer(int_kind), intent(in) :: which, n1, n2, n3, nb
+    interface
+       function evp_peek_base(w) bind(C, name='evp_peek_base') result(p)
+         use, intrinsic :: iso_c_binding
+         integer(c_int), value :: w
+         type(c_ptr) :: p
+       end function evp_peek_base
+    end interface
+    type(c_ptr) :: p
+    real(dbl_kind), pointer :: pk(:,:,:)
+    p = evp_peek_base(int(which, c_int))
+    if (.not. c_associated(p)) stop 'evp_peek_base: unknown or unallocated array'
+    call c_f_pointer(p, pk, [n1, n2, n3])
+    call dump_r8_3d(name, pk, nb)
+  end subroutine dump_peek
+
 end module evp_dumpio

@@ -17,6 +17,88 @@
 ! Inputs: ./ice_in (only &domain_nml) and ./harness_in (&harness_nml).
 ! This program is written for this repo; it contains no reference code.
 !=======================================================================
+! C-grid capture (a module of its own: the program's internal procedures must not host-associate anything,
+! or flang builds stack trampolines for the ice-strength callback of the drop-in variant)
+module evp_cgrid_capture
+  use ice_kinds_mod
+  use ice_domain, only: nblocks
+  use ice_domain_size, only: max_blocks
+  use ice_blocks, only: nx_block, ny_block
+  use ice_state, only: uvel, vvel, uvelE, vvelE, uvelN, vvelN, strength
+  use ice_flux
+  use ice_calendar, only: dt_dyn
+  use ice_dyn_shared
+  use ice_dyn_evp, only: evp
+  use evp_dumpio
+  implicit none
+  real(dbl_kind), allocatable, dimension(:,:,:), private :: c_uE, c_vN, c_uN, c_vE, c_spT, c_smT, c_s12T, c_s12U, c_u, c_v
+contains
+
+  ! ---- C grid: the subcycle inputs are module-private; a preparation-only evp() (ndte = 0) leaves them in place,
+  !      evp_peek.c reads them; the very next evp() calls from the same state give the reference's outputs ----
+
+  subroutine cgrid_call(ic, nsub_list, nl, h_ndte)
+    integer(int_kind), intent(in) :: ic, nsub_list(:), nl, h_ndte
+    integer(int_kind) :: kk, ns
+    character(len=16) :: tg
+    if (.not. allocated(c_uE)) then
+       allocate(c_uE(nx_block,ny_block,max_blocks), c_vN(nx_block,ny_block,max_blocks), &
+                c_uN(nx_block,ny_block,max_blocks), c_vE(nx_block,ny_block,max_blocks), &
+                c_spT(nx_block,ny_block,max_blocks), c_smT(nx_block,ny_block,max_blocks), &
+                c_s12T(nx_block,ny_block,max_blocks), c_s12U(nx_block,ny_block,max_blocks), &
+                c_u(nx_block,ny_block,max_blocks), c_v(nx_block,ny_block,max_blocks))
+    endif
+    ndte = 0
+    call evp(dt_dyn)                 ! preparation only
+    ndte = h_ndte
+    write(tg,'(a,i2.2)') 'in', ic
+    ! state the loop starts from
+    call dump_r8_3d(trim(tg)//'_uvelE', uvelE, nblocks);   call dump_r8_3d(trim(tg)//'_vvelE', vvelE, nblocks)
+    call dump_r8_3d(trim(tg)//'_uvelN', uvelN, nblocks);   call dump_r8_3d(trim(tg)//'_vvelN', vvelN, nblocks)
+    call dump_r8_3d(trim(tg)//'_uvel', uvel, nblocks);     call dump_r8_3d(trim(tg)//'_vvel', vvel, nblocks)
+    call dump_r8_3d(trim(tg)//'_stresspT', stresspT, nblocks);   call dump_r8_3d(trim(tg)//'_stressmT', stressmT, nblocks)
+    call dump_r8_3d(trim(tg)//'_stress12T', stress12T, nblocks); call dump_r8_3d(trim(tg)//'_stress12U', stress12U, nblocks)
+    ! per-call inputs: public ...
+    call dump_r8_3d(trim(tg)//'_strength', strength, nblocks)
+    call dump_r8_3d(trim(tg)//'_fmE', fmE, nblocks);       call dump_r8_3d(trim(tg)//'_fmN', fmN, nblocks)
+    call dump_r8_3d(trim(tg)//'_TbE', TbE, nblocks);       call dump_r8_3d(trim(tg)//'_TbN', TbN, nblocks)
+    call dump_r8_3d(trim(tg)//'_uvelE_init', uvelE_init, nblocks); call dump_r8_3d(trim(tg)//'_vvelN_init', vvelN_init, nblocks)
+    call dump_r8_3d(trim(tg)//'_strintxE', strintxE, nblocks);     call dump_r8_3d(trim(tg)//'_strintyN', strintyN, nblocks)
+    call dump_r8_3d(trim(tg)//'_taubxE', taubxE, nblocks);         call dump_r8_3d(trim(tg)//'_taubyN', taubyN, nblocks)
+    call dump_l_3d (trim(tg)//'_iceTmask', iceTmask, nblocks);     call dump_l_3d (trim(tg)//'_iceUmask', iceUmask, nblocks)
+    call dump_l_3d (trim(tg)//'_iceEmask', iceEmask, nblocks);     call dump_l_3d (trim(tg)//'_iceNmask', iceNmask, nblocks)
+    ! ... and module-private (evp_peek.c)
+    call dump_peek(trim(tg)//'_uocnE', 1, nx_block, ny_block, max_blocks, nblocks);      call dump_peek(trim(tg)//'_vocnE', 2, nx_block, ny_block, max_blocks, nblocks);     call dump_peek(trim(tg)//'_cdn_ocnE', 3, nx_block, ny_block, max_blocks, nblocks)
+    call dump_peek(trim(tg)//'_waterxE', 4, nx_block, ny_block, max_blocks, nblocks);    call dump_peek(trim(tg)//'_forcexE', 5, nx_block, ny_block, max_blocks, nblocks);   call dump_peek(trim(tg)//'_aiE', 6, nx_block, ny_block, max_blocks, nblocks)
+    call dump_peek(trim(tg)//'_rheofactE', 7, nx_block, ny_block, max_blocks, nblocks);  call dump_peek(trim(tg)//'_emassdti', 8, nx_block, ny_block, max_blocks, nblocks)
+    call dump_peek(trim(tg)//'_uocnN', 9, nx_block, ny_block, max_blocks, nblocks);      call dump_peek(trim(tg)//'_vocnN', 10, nx_block, ny_block, max_blocks, nblocks);    call dump_peek(trim(tg)//'_cdn_ocnN', 11, nx_block, ny_block, max_blocks, nblocks)
+    call dump_peek(trim(tg)//'_wateryN', 12, nx_block, ny_block, max_blocks, nblocks);   call dump_peek(trim(tg)//'_forceyN', 13, nx_block, ny_block, max_blocks, nblocks);  call dump_peek(trim(tg)//'_aiN', 14, nx_block, ny_block, max_blocks, nblocks)
+    call dump_peek(trim(tg)//'_rheofactN', 15, nx_block, ny_block, max_blocks, nblocks); call dump_peek(trim(tg)//'_nmassdti', 16, nx_block, ny_block, max_blocks, nblocks)
+    c_uE = uvelE; c_vN = vvelN; c_uN = uvelN; c_vE = vvelE; c_u = uvel; c_v = vvel
+    c_spT = stresspT; c_smT = stressmT; c_s12T = stress12T; c_s12U = stress12U
+    do kk = 1, nl
+       ns = nsub_list(kk)
+       uvelE = c_uE; vvelN = c_vN; uvelN = c_uN; vvelE = c_vE; uvel = c_u; vvel = c_v
+       stresspT = c_spT; stressmT = c_smT; stress12T = c_s12T; stress12U = c_s12U
+       ndte = ns
+       call evp(dt_dyn)
+       ndte = h_ndte
+       write(tg,'(a,i2.2,a,i4.4)') 'o', ic, 'n', ns
+       call dump_r8_3d(trim(tg)//'_uvelE', uvelE, nblocks);   call dump_r8_3d(trim(tg)//'_vvelE', vvelE, nblocks)
+       call dump_r8_3d(trim(tg)//'_uvelN', uvelN, nblocks);   call dump_r8_3d(trim(tg)//'_vvelN', vvelN, nblocks)
+       call dump_r8_3d(trim(tg)//'_uvel', uvel, nblocks);     call dump_r8_3d(trim(tg)//'_vvel', vvel, nblocks)
+       call dump_r8_3d(trim(tg)//'_stresspT', stresspT, nblocks);   call dump_r8_3d(trim(tg)//'_stressmT', stressmT, nblocks)
+       call dump_r8_3d(trim(tg)//'_stress12T', stress12T, nblocks); call dump_r8_3d(trim(tg)//'_stress12U', stress12U, nblocks)
+       call dump_r8_3d(trim(tg)//'_strintxE', strintxE, nblocks);   call dump_r8_3d(trim(tg)//'_strintyN', strintyN, nblocks)
+       call dump_r8_3d(trim(tg)//'_taubxE', taubxE, nblocks);       call dump_r8_3d(trim(tg)//'_taubyN', taubyN, nblocks)
+       call dump_peek(trim(tg)//'_zetax2T', 17, nx_block, ny_block, max_blocks, nblocks);  call dump_peek(trim(tg)//'_etax2T', 18, nx_block, ny_block, max_blocks, nblocks);  call dump_peek(trim(tg)//'_etax2U', 19, nx_block, ny_block, max_blocks, nblocks)
+       call dump_peek(trim(tg)//'_shearU', 20, nx_block, ny_block, max_blocks, nblocks);   call dump_peek(trim(tg)//'_deltaU', 21, nx_block, ny_block, max_blocks, nblocks)
+       write(*,'(a,i3,a,i5,3es24.16)') 'Ccall', ic, ' nsub', ns, &
+            maxval(abs(uvelE(:,:,1:nblocks))), maxval(abs(vvelN(:,:,1:nblocks))), maxval(abs(stresspT(:,:,1:nblocks)))
+    enddo
+  end subroutine cgrid_call
+end module evp_cgrid_capture
+
 program evp_ref_harness
 
   use ice_kinds_mod
@@ -37,7 +119,7 @@ program evp_ref_harness
       timer_evp
   use ice_calendar, only: dt, dt_dyn, ndtd
   use ice_dyn_shared
-  use ice_dyn_evp, only: init_evp, evp
+  use ice_dyn_evp, only: init_evp, evp, ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
 #ifdef HARNESS_REF1D
   ! timing-only build: the reference's OWN ice_dyn_evp1d (its 1-d "shared_mem_1d" EVP core,
   ! ice_dyn_evp1d.F90 + ice_dyn_core1d.F90) instead of the capture module
@@ -49,6 +131,7 @@ program evp_ref_harness
   use ice_dyn_evp_hip, only: dyn_evp_hip_evp_body, dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses
 #endif
   use evp_dumpio
+  use evp_cgrid_capture, only: cgrid_call
   use icepack_intfc, only: icepack_query_parameters
 #if defined (_OPENMP)
   use OMP_LIB
@@ -84,11 +167,13 @@ program evp_ref_harness
   logical            :: hipmode     = .false.     ! drop-in check: HIP core (via ice_dyn_evp1d) vs standard_2d
   logical            :: hipbody     = .false.     ! with hipmode: also Option A, preparation + loop on the device
   logical            :: time_1d     = .false.     ! timing loop with evp_algorithm='shared_mem_1d' (HARNESS_REF1D build only)
+  character(len=8)   :: h_grid_ice  = 'B'         ! 'B' | 'C': staggering of the dynamics (C: ice_dyn_evp.F90:936-1121)
+  character(len=16)  :: h_visc_method = 'avg_zeta' ! C grid: 'avg_zeta' | 'avg_strength' (ice_dyn_evp.F90:992-996)
 
   namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
      h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
      h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, &
-     dump_arrays, ntiming, hipmode, hipbody, time_1d
+     dump_arrays, ntiming, hipmode, hipbody, time_1d, h_grid_ice, h_visc_method
 
   ! ---- locals ----------------------------------------------------------
   integer(int_kind) :: i, j, iblk, icall, k, nsub, nl, ios, nthreads
@@ -115,7 +200,7 @@ program evp_ref_harness
   n_iso=0; n_aero=0; n_zaero=0; n_algae=0; n_doc=0; n_dic=0; n_don=0; n_fed=0; n_fep=0
   nfreq=1
 
-  grid_format='bin'; grid_ice='B'; grid_atm='A'; grid_ocn='A'
+  grid_format='bin'; grid_ice=trim(h_grid_ice); grid_atm='A'; grid_ocn='A'
   grid_atm_thrm='T'; grid_atm_dynu='T'; grid_atm_dynv='T'
   grid_ocn_thrm='T'; grid_ocn_dynu='T'; grid_ocn_dynv='T'
   dxrect=h_dxrect; dyrect=h_dyrect; scale_dxdy=.false.
@@ -146,7 +231,7 @@ program evp_ref_harness
   seabed_stress=h_seabed; seabed_stress_method='LKD'
   k1=7.5_dbl_kind; k2=15._dbl_kind; alphab=20._dbl_kind; threshold_hw=30._dbl_kind   ! ice_in defaults
   dyn_area_min=1e-11_dbl_kind; dyn_mass_min=1e-10_dbl_kind
-  yield_curve='ellipse'; visc_method='avg_zeta'
+  yield_curve='ellipse'; visc_method=trim(h_visc_method)
   arlx=h_arlx; brlx=h_brlx
   dt=h_dt; ndtd=1; dt_dyn=dt
 
@@ -255,11 +340,22 @@ program evp_ref_harness
      call dump_l_3d ('tmask', tmask, nblocks);   call dump_l_3d ('umask', umask, nblocks)
      call dump_r8_3d('cxp', cxp, nblocks);       call dump_r8_3d('cyp', cyp, nblocks)
      call dump_r8_3d('cxm', cxm, nblocks);       call dump_r8_3d('cym', cym, nblocks)
-     call dump_r8_3d('dxhy', dxhy, nblocks);     call dump_r8_3d('dyhx', dyhx, nblocks)
+     if (allocated(dxhy)) then      ! B grid only (ice_dyn_shared.F90:229)
+        call dump_r8_3d('dxhy', dxhy, nblocks);     call dump_r8_3d('dyhx', dyhx, nblocks)
+     endif
      call dump_r8_3d('DminTarea', DminTarea, nblocks)
      call dump_r8_3d('ULAT', ULAT, nblocks)
      call dump_r8_3d('uarea', uarea, nblocks);   call dump_r8_3d('fcor_blk', fcor_blk, nblocks)
      call dump_r8_3d('hwater', hwater, nblocks)
+     if (trim(grid_ice) == 'C') then
+        call dump_r8_3d('dxE', dxE, nblocks);       call dump_r8_3d('dyE', dyE, nblocks)
+        call dump_r8_3d('dxN', dxN, nblocks);       call dump_r8_3d('dyN', dyN, nblocks)
+        call dump_r8_3d('earea', earea, nblocks);   call dump_r8_3d('narea', narea, nblocks)
+        call dump_r8_3d('earear', earear, nblocks); call dump_r8_3d('narear', narear, nblocks)
+        call dump_r8_3d('epm', epm, nblocks);       call dump_r8_3d('npm', npm, nblocks)
+        call dump_r8_3d('ratiodxN', ratiodxN, nblocks);   call dump_r8_3d('ratiodxNr', ratiodxNr, nblocks)
+        call dump_r8_3d('ratiodyE', ratiodyE, nblocks);   call dump_r8_3d('ratiodyEr', ratiodyEr, nblocks)
+     endif
   endif
 
   allocate(s_u(nx_block,ny_block,max_blocks), s_v(nx_block,ny_block,max_blocks))
@@ -272,6 +368,11 @@ program evp_ref_harness
 
   ! ---- evp calls ------------------------------------------------------------
   do icall = 1, ncalls
+
+     if (trim(grid_ice) == 'C') then
+        call cgrid_call(icall, nsub_list, nl, h_ndte)
+        cycle
+     endif
 
      if (hipmode) then
         ! prep-only pass (ndte=0): applies dyn_prep2's one-off state changes (new-ice

@@ -8,7 +8,8 @@ import numpy as np
 import oracle  # oracle/oracle.py  (CPU restatement -- the checker)
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-GOLDEN_CASES = sorted(p.stem for p in GOLDEN.glob("*.npz"))
+GOLDEN_CASES = sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("cgrid_"))
+CGRID_CASES = sorted(p.stem for p in GOLDEN.glob("cgrid_*.npz"))      # C-grid subcycle
 
 
 class GoldenCase:
@@ -39,6 +40,19 @@ class GoldenCase:
     def inputs(self, icall=1):
         dyn = {k: self.d[f"in{icall:02d}_{k}"] for k in oracle.DYN_FIELDS}
         return dyn, self.d[f"in{icall:02d}_iceTmask"], self.d[f"in{icall:02d}_iceUmask"]
+
+    # --- C-grid fixtures (cgrid_*): loop inputs captured after a preparation-only evp(), reference outputs ---
+    def cgrid_inputs(self, icall=1):
+        """(state, inputs, masks) of the C-grid subcycle loop; evp()'s work arrays start at zero."""
+        pre = f"in{icall:02d}_"
+        state = {k: self.d[pre + k] for k in oracle.C_FIELDS if k not in oracle.C_WORK}
+        return state, {k: self.d[pre + k] for k in oracle.C_INPUTS}, {k: self.d[pre + k] for k in oracle.C_MASKS}
+
+    def cgrid_static(self):
+        return {k: self.d[k] for k in oracle.C_STATIC}
+
+    def cgrid_expected(self, icall, nsub):
+        return {k: self.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in oracle.C_FIELDS}
 
     # --- preparation phase of evp() (f-2): its inputs, parameters and captured products ---
     def prep_static(self):

@@ -65,6 +65,49 @@ CASES = {
 }
 
 
+# C-grid subcycle: the harness captures the loop's inputs after a preparation-only evp() call
+# (module-private ones through oracle/ref/evp_peek.c) and the reference's outputs of evp() with grid_ice = 'C'
+CGRID_STATIC = ["dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear",
+                "narear", "epm", "npm", "uvm", "hm", "DminTarea", "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr"]
+CGRID_CASES = {
+    "cgrid_cyc_2x2_patchy": (24, 20, 12, 10, "cyclic", "closed",
+                             dict(icecase="patchy", nsub_list=[1, 2, 120], ncalls=2)),
+    "cgrid_closed_2x2_revp": (24, 20, 12, 10, "closed", "closed",
+                              dict(icecase="full", nsub_list=[1, 120], ncalls=2, h_revised=True, h_arlx=300.0,
+                                   h_brlx=300.0)),
+    "cgrid_cyc_3x2pad_cap05_avgstrength": (26, 22, 10, 12, "cyclic", "closed",
+                                           dict(icecase="caps", nsub_list=[1, 120], ncalls=1, h_capping=0.5,
+                                                h_Ktens=0.1, h_visc_method="avg_strength")),
+    "cgrid_cyc_1blk_seabed": (24, 20, 24, 20, "cyclic", "closed",
+                              dict(icecase="full", nsub_list=[1, 120], ncalls=1, h_seabed=True)),
+    "cgrid_cyccyc_2x2_cap0_ktens": (24, 20, 12, 10, "cyclic", "cyclic",
+                                    dict(icecase="patchy", nsub_list=[1, 120], ncalls=1, h_capping=0.0, h_Ktens=0.2,
+                                         h_e_yield=1.5, h_e_plast=2.5)),
+}
+
+
+def make_cgrid_case(name, spec):
+    nx, ny, bx, by, ew, ns, kw = spec
+    kw = dict(kw)
+    td = tempfile.mkdtemp(prefix="golden_")
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+    run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+    run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
+    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="strict", h_ndte=120, grid_kind="popfile",
+                                 grid_files=(td + "/grid.bin", td + "/kmt.bin"), h_grid_ice="C", **kw)
+    keep = {"dims": d["dims"], "blkinfo": d["blkinfo"], "scalars": d["scalars"], "nsub_list": d["nsub_list"],
+            "ew": np.array(ew), "ns": np.array(ns), "visc_method": np.array(kw.get("h_visc_method", "avg_zeta"))}
+    for k in CGRID_STATIC:
+        keep[k] = d[k]
+    for k, v in d.items():
+        if k[:2] == "in" or (k.startswith("o") and k[1:3].isdigit()):
+            keep[k] = v
+    path = OUT / f"{name}.npz"
+    np.savez_compressed(path, **keep)
+    print(f"{name}: {path.stat().st_size/1024:.0f} KiB, active T/U/E/N cells "
+          f"{[int(d['in01_ice%smask' % c].sum()) for c in 'TUEN']}, max|uE| {np.abs(d['o01n0120_uvelE']).max():.4f}")
+
+
 def make_case(name, spec):
     nx, ny, bx, by, ew, ns, kw = spec
     kw = dict(kw)
@@ -100,3 +143,7 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         make_case(name, spec)
+    for name, spec in CGRID_CASES.items():
+        if only and name not in only:
+            continue
+        make_cgrid_case(name, spec)

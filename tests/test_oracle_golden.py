@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import GOLDEN_CASES, GoldenCase, assert_bitwise
+from common import CGRID_CASES, GOLDEN_CASES, GoldenCase, assert_bitwise
 
 
 def test_fixtures_present():
@@ -131,6 +131,39 @@ def test_next_tier_deformations_dyn_finish_bitwise(name):
             z = np.zeros_like(u)
             got.update(oracle.dyn_finish(dom, prm, dyn, u, v, um, z, z))
             assert_bitwise(got, {k: c.d[tag + k] for k in got}, f"{name} call {icall} nsub {nsub} f-1")
+
+
+@pytest.mark.parametrize("name", CGRID_CASES)
+def test_cgrid_subcycle_bitwise(name):
+    """the C-grid loop of evp() (ice_dyn_evp.F90:938-1099 -- strain_rates_U, stressC_T, stressC_U,
+    div_stress_Ex/Ny, stepu_C/stepv_C, the face <-> face / face -> corner averages and the eight halo updates)
+    restated in oracle/evp_oracle.c, against the reference's own evp() with grid_ice = 'C' for every call and
+    every nsub of the fixture: all 19 arrays of the loop on every cell, ghost cells included.  The only
+    post-loop step folded into the expected values is evp()'s halo update of strintxE / strintyN (:1437-1440)."""
+    c = GoldenCase(name)
+    dom, p, static = c.oracle_domain(), c.oracle_params(), c.cgrid_static()
+    assert len(c.d["dims"]) == 9 and c.ncalls >= 1
+    for icall in range(1, c.ncalls + 1):
+        state, inputs, masks = c.cgrid_inputs(icall)
+        for nsub in c.nsub_list:
+            out = oracle.cgrid_subcycle(dom, p, nsub, state, inputs, static, masks, visc_method=str(c.d["visc_method"]))
+            for k in ("strintxE", "strintyN"):
+                oracle.halo_update(dom, out[k], "center", "vector")
+            assert_bitwise(out, c.cgrid_expected(icall, nsub), f"{name} call {icall} nsub {nsub}")
+        assert np.abs(out["uvelE"]).max() > 1e-3 and int(masks["iceEmask"].sum()) > 50
+
+
+def test_cgrid_fixtures_cover_the_options():
+    """The C-grid fixtures between them exercise: both visc_method branches, revised EVP, fractional and zero
+    capping with tensile strength, the seabed stress, padded blocks, closed and doubly cyclic boundaries."""
+    cs = [GoldenCase(n) for n in CGRID_CASES]
+    assert len(cs) >= 5
+    assert {str(c.d["visc_method"]) for c in cs} == {"avg_zeta", "avg_strength"}
+    assert any(c.scal[3] == 1.0 for c in cs) and any(c.scal[3] == 0.0 for c in cs)            # revp
+    assert any(0.0 < c.scal[6] < 1.0 for c in cs) and any(c.scal[6] == 0.0 for c in cs)       # capping
+    assert any(np.abs(c.d["in01_TbE"]).max() > 0 for c in cs)
+    assert any(c.ns == "cyclic" for c in cs) and any(c.ew == "closed" for c in cs)
+    assert any(c.nx_global % (c.nx_block - 2) for c in cs)                                     # padded blocks
 
 
 def test_seabed_lkd_bitwise():
