@@ -23,6 +23,7 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen)
 int cice_evp_hip_finalize(void)
 {
     if (S.stream) (void)hipStreamSynchronize(S.stream);
+    cgrid_free();
     free_all();
     S = State();
     return 0;

@@ -1,0 +1,301 @@
+// =====================================================================
+// C-grid EVP subcycle for gfx950: u at the east faces (E), v at the north faces (N), stresses at
+// cell centres (T) and corners (U).  Reference: evp()'s loop for grid_ice = 'C', ice_dyn_evp.F90:938-1099, with
+// strain_rates_U / strain_rates_Tdt / stepu_C / stepv_C (ice_dyn_shared.F90:2291-2444, 1090-1290), stressC_T /
+// stressC_U / div_stress_Ex / div_stress_Ny (ice_dyn_evp.F90:1758-1972, 2195-2416) and the grid_average_X2Y
+// variants the loop calls (ice_grid.F90:4159-4606).
+//
+// One subcycle is five dependent stencil phases; between two phases every cell's neighbours must be complete, so
+// each phase is one launch.  What the reference does with eight ice_HaloUpdate calls per subcycle is fused into
+// the phases: the thread that produces a cell also stores it into the ghost cells that mirror it ("images",
+// at most three: a corner cell of a doubly periodic block), so the next phase reads plain i+-1, j+-1 neighbours
+// and no halo kernel runs inside the loop.  Fields the reference never exchanges (etax2U, deltaU, stress12T,
+// strintxE/yN, taubxE/yN) are not pushed: their ghost cells end up exactly as the reference leaves them.
+//
+// fp64, strict: no FMA contraction, operations in the reference's order -- bit-identical to the reference
+// compiled with -O2 -ffp-contract=off (tests/test_gpu_cgrid.py against the committed fixtures).
+// HBM-bound on large grids (about 90 doubles moved per cell and subcycle), launch-bound on gx1-sized ones.
+// =====================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "evp_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int TX = 64, TY = 4;
+
+__device__ __forceinline__ void push(const EvpCgrid &A, size_t c, unsigned m, int field, double v)
+{
+    (void)m;
+    const int s = A.img_slot[c];
+    if (s < 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int d = A.img_dst[3 * s + k];
+        if (d >= 0) A.f[field][d] = v;
+    }
+}
+
+// visc_replpress, ice_dyn_shared.F90:2446-2475
+__device__ __forceinline__ void visc_replpress(const EvpScalars &p, double strength, double DminArea, double Delta,
+                                               double &zetax2, double &etax2, double &rep_prs)
+{
+    const double tmpcalc = p.capping * (strength / fmax(Delta, DminArea)) +
+                           (1.0 - p.capping) * (strength / (Delta + DminArea));
+    zetax2 = (1.0 + p.Ktens) * tmpcalc;
+    rep_prs = (1.0 - p.Ktens) * tmpcalc * Delta;
+    etax2 = p.epp2i * zetax2;
+}
+
+struct Cell { int i, j, b; size_t o; int4 q; bool in; };
+__device__ __forceinline__ Cell cell(const EvpCgrid &A)
+{
+    Cell c;
+    c.i = blockIdx.x * TX + threadIdx.x + 1;         // 1-based, as the reference
+    c.j = blockIdx.y * TY + threadIdx.y + 1;
+    c.b = blockIdx.z;
+    c.in = c.i <= A.nx && c.j <= A.ny;
+    c.q = A.blk[c.b];
+    c.o = (size_t)c.b * A.plane + (size_t)(c.j - 1) * A.nx + (c.i - 1);
+    return c;
+}
+
+// ---- phase 0: strain_rates_U (strain rates * area at the corners); shearU is exchanged (:965-967) ----
+__global__ __launch_bounds__(TX *TY) void cg_strain_u(EvpCgrid A)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const size_t o = c.o, e = o + 1, n = o + A.nx;
+    const unsigned m = A.mask[o];
+    if (!(m & 2u)) return;
+    const double *uE = A.f[CF_UE], *vE = A.f[CF_VE], *uN = A.f[CF_UN], *vN = A.f[CF_VN];
+    const double uU = A.f[CF_UU][o], vU = A.f[CF_VU][o];
+    const double *epm = A.g[CG_EPM], *npm = A.g[CG_NPM];
+    const double dxU = A.g[CG_DXU][o], dyU = A.g[CG_DYU][o];
+    const double ddyN = A.g[CG_DYN][e] - A.g[CG_DYN][o], ddxE = A.g[CG_DXE][n] - A.g[CG_DXE][o];
+    const double rxN = A.g[CG_RXN][o], rxNr = A.g[CG_RXNR][o], ryE = A.g[CG_RYE][o], ryEr = A.g[CG_RYER][o];
+    const double npc = npm[o], npe = npm[e], epc = epm[o], epn = epm[n];
+    const double uNip1j = uN[e] * npe + (npc - npe) * npc * rxN * uN[o];
+    const double uNij = uN[o] * npc + (npe - npc) * npe * rxNr * uN[e];
+    const double vEijp1 = vE[n] * epn + (epc - epn) * epc * ryE * vE[o];
+    const double vEij = vE[o] * epc + (epn - epc) * epn * ryEr * vE[n];
+    const double dv = dyU * (uNip1j - uNij) + uU * ddyN + dxU * (vEijp1 - vEij) + vU * ddxE;
+    const double tn = dyU * (uNip1j - uNij) - uU * ddyN - dxU * (vEijp1 - vEij) + vU * ddxE;
+    const double uEijp1 = uE[n] * epn + (epc - epn) * epc * ryE * uE[o];
+    const double uEij = uE[o] * epc + (epn - epc) * epn * ryEr * uE[n];
+    const double vNip1j = vN[e] * npe + (npc - npe) * npc * rxN * vN[o];
+    const double vNij = vN[o] * npc + (npe - npc) * npe * rxNr * vN[e];
+    const double sh = dxU * (uEijp1 - uEij) - uU * ddxE + dyU * (vNip1j - vNij) - vU * ddyN;
+    A.f[CF_SHEARU][o] = sh;
+    A.f[CF_DELTAU][o] = sqrt(dv * dv + A.p.e_factor * (tn * tn + sh * sh));
+    if (m & 16u) push(A, o, m, CF_SHEARU, sh);
+}
+
+// ---- phase 1: stressC_T on ilo..ihi+1 x jlo..jhi+1 (the reference's T list, ice_dyn_shared.F90:729-738).
+// zetax2T, etax2T, stresspT, stressmT are exchanged right after (:988-990): interior cells store and push them, the
+// extra row and column (ghost cells) only keep what is never exchanged, stress12T. ----
+__global__ __launch_bounds__(TX *TY) void cg_stress_t(EvpCgrid A)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y + 1 || c.j < c.q.z || c.j > c.q.w + 1) return;
+    const size_t o = c.o, w = o - 1, s = o - A.nx, sw = s - 1;
+    const unsigned m = A.mask[o];
+    if (!(m & 1u)) return;
+    const bool own = c.i <= c.q.y && c.j <= c.q.w;
+    const double *uE = A.f[CF_UE], *vN = A.f[CF_VN], *shU = A.f[CF_SHEARU];
+    const double *dyE = A.g[CG_DYE], *dxN = A.g[CG_DXN], *uarea = A.g[CG_UAREA];
+    const double dxT = A.g[CG_DXT][o], dyT = A.g[CG_DYT][o];
+    const double divT = dyE[o] * uE[o] - dyE[w] * uE[w] + dxN[o] * vN[o] - dxN[s] * vN[s];
+    const double tensionT = (dyT * dyT) * (uE[o] / dyE[o] - uE[w] / dyE[w]) - (dxT * dxT) * (vN[o] / dxN[o] - vN[s] / dxN[s]);
+    const double uareaavgr = 1.0 / (uarea[o] + uarea[s] + uarea[sw] + uarea[w]);
+    const double shearTsqr = (shU[o] * shU[o] * uarea[o] + shU[s] * shU[s] * uarea[s] + shU[sw] * shU[sw] * uarea[sw] +
+                              shU[w] * shU[w] * uarea[w]) * uareaavgr;
+    const double shearT = (shU[o] * uarea[o] + shU[s] * uarea[s] + shU[sw] * uarea[sw] + shU[w] * uarea[w]) * uareaavgr;
+    const double DeltaT = sqrt(divT * divT + A.p.e_factor * (tensionT * tensionT + shearTsqr));
+    double zetax2, etax2, rep_prs;
+    visc_replpress(A.p, A.in[CI_STRENGTH][o], A.g[CG_DMINT][o], DeltaT, zetax2, etax2, rep_prs);
+    const double relax = 1.0 - A.p.arlx1i * A.p.revp;
+    A.f[CF_S12T][o] = (A.f[CF_S12T][o] * relax + A.p.arlx1i * 0.5 * etax2 * shearT) * A.p.denom1;
+    if (!own) return;
+    const double sp = (A.f[CF_SP][o] * relax + A.p.arlx1i * (zetax2 * divT - rep_prs)) * A.p.denom1;
+    const double sm = (A.f[CF_SM][o] * relax + A.p.arlx1i * etax2 * tensionT) * A.p.denom1;
+    A.f[CF_ZETA][o] = zetax2;
+    A.f[CF_ETA][o] = etax2;
+    A.f[CF_SP][o] = sp;
+    A.f[CF_SM][o] = sm;
+    if (m & 16u) {
+        push(A, o, m, CF_ZETA, zetax2);
+        push(A, o, m, CF_ETA, etax2);
+        push(A, o, m, CF_SP, sp);
+        push(A, o, m, CF_SM, sm);
+    }
+}
+
+// T -> U average, grid_average_X2YS('NE', work, tarea, hm): ice_grid.F90:4190-4209
+__device__ __forceinline__ double avg_t2u(const EvpCgrid &A, const double *w1, size_t o)
+{
+    const double *hm = A.g[CG_HM], *ta = A.g[CG_TAREA];
+    const size_t e = o + 1, n = o + A.nx, ne = n + 1;
+    const double wtmp = (hm[o] * ta[o] + hm[e] * ta[e] + hm[n] * ta[n] + hm[ne] * ta[ne]);
+    if (wtmp == 0.0) return 0.0;
+    return (hm[o] * w1[o] * ta[o] + hm[e] * w1[e] * ta[e] + hm[n] * w1[n] * ta[n] + hm[ne] * w1[ne] * ta[ne]) / wtmp;
+}
+
+// ---- phase 2: viscosity at the corners (:992-996) and stressC_U; stress12U is exchanged (:1011-1013) ----
+__global__ __launch_bounds__(TX *TY) void cg_stress_u(EvpCgrid A)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const size_t o = c.o;
+    const unsigned m = A.mask[o];
+    double etax2U;
+    if (A.avg_strength) {
+        if (!(m & 2u)) return;
+        double z, r;
+        visc_replpress(A.p, A.strengthU[o], A.deltaminEVP * A.g[CG_UAREA][o], A.f[CF_DELTAU][o], z, etax2U, r);
+    } else {
+        etax2U = avg_t2u(A, A.f[CF_ETA], o);
+        A.f[CF_ETAU][o] = etax2U;                       // every interior cell, as grid_average_X2YS does
+        if (!(m & 2u)) return;
+    }
+    const double relax = 1.0 - A.p.arlx1i * A.p.revp;
+    const double s12 = (A.f[CF_S12U][o] * relax + A.p.arlx1i * 0.5 * etax2U * A.f[CF_SHEARU][o]) * A.p.denom1;
+    A.f[CF_S12U][o] = s12;
+    if (m & 16u) push(A, o, m, CF_S12U, s12);
+}
+
+// ---- phase 3: div_stress_Ex + stepu_C at E, div_stress_Ny + stepv_C at N; uvelE, vvelN are exchanged (:1063-1068) ----
+__global__ __launch_bounds__(TX *TY) void cg_step(EvpCgrid A)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const size_t o = c.o, e = o + 1, n = o + A.nx, s = o - A.nx, w = o - 1;
+    const unsigned m = A.mask[o];
+    if (!(m & 12u)) return;
+    const double *sp = A.f[CF_SP], *sm = A.f[CF_SM], *s12 = A.f[CF_S12U];
+    const double spc = sp[o], smc = sm[o], s12c = s12[o];
+    const EvpScalars &p = A.p;
+    if (m & 4u) {
+        const double *dyT = A.g[CG_DYT], *dxU = A.g[CG_DXU];
+        const double dyE = A.g[CG_DYE][o], dxE = A.g[CG_DXE][o];
+        const double strintx = A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o] *
+                               (0.5 * dyE * (sp[e] - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sm[e] - (dyT[o] * dyT[o]) * smc) +
+                                (1.0 / dxE) * ((dxU[o] * dxU[o]) * s12c - (dxU[s] * dxU[s]) * s12[s]));
+        const double uold = A.f[CF_UE][o], vold = A.f[CF_VE][o];
+        const double du = A.in[CI_UOCNE][o] - uold, dv = A.in[CI_VOCNE][o] - vold;
+        const double vrel = A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o] * sqrt(du * du + dv * dv);
+        const double taux = vrel * A.in[CI_WATERXE][o];
+        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+        const double Cb = A.in[CI_TBE][o] / ccc;
+        const double massdti = A.in[CI_EMASSDTI][o], fm = A.in[CI_FME][o];
+        const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
+        const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+        const double cc1 = strintx + A.in[CI_FORCEXE][o] + taux + massdti * (p.brlx * uold + p.revp * A.in[CI_UE_INIT][o]);
+        const double unew = (ccb * vold + cc1) / cca;
+        A.f[CF_STRX][o] = strintx;
+        A.f[CF_UE][o] = unew;
+        A.f[CF_TAUBX][o] = -unew * Cb;
+        if (m & 16u) push(A, o, m, CF_UE, unew);
+    }
+    if (m & 8u) {
+        const double *dxT = A.g[CG_DXT], *dyU = A.g[CG_DYU];
+        const double dxN = A.g[CG_DXN][o], dyN = A.g[CG_DYN][o];
+        const double strinty = A.in[CI_RHEON][o] * A.g[CG_NAREAR][o] *
+                               (0.5 * dxN * (sp[n] - spc) - (0.5 / dxN) * ((dxT[n] * dxT[n]) * sm[n] - (dxT[o] * dxT[o]) * smc) +
+                                (1.0 / dyN) * ((dyU[o] * dyU[o]) * s12c - (dyU[w] * dyU[w]) * s12[w]));
+        const double uold = A.f[CF_UN][o], vold = A.f[CF_VN][o];
+        const double du = A.in[CI_UOCNN][o] - uold, dv = A.in[CI_VOCNN][o] - vold;
+        const double vrel = A.in[CI_AIN][o] * p.rhow * A.in[CI_CWN][o] * sqrt(du * du + dv * dv);
+        const double tauy = vrel * A.in[CI_WATERYN][o];
+        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+        const double Cb = A.in[CI_TBN][o] / ccc;
+        const double massdti = A.in[CI_NMASSDTI][o], fm = A.in[CI_FMN][o];
+        const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
+        const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+        const double cc2 = strinty + A.in[CI_FORCEYN][o] + tauy + massdti * (p.brlx * vold + p.revp * A.in[CI_VN_INIT][o]);
+        const double vnew = (-ccb * uold + cc2) / cca;
+        A.f[CF_STRY][o] = strinty;
+        A.f[CF_VN][o] = vnew;
+        A.f[CF_TAUBY][o] = -vnew * Cb;
+        if (m & 16u) push(A, o, m, CF_VN, vnew);
+    }
+}
+
+// ---- phase 4: the other component at each face and the corner velocities (:1070-1094):
+// uvelN = E2N('NW', earea) * npm, vvelE = N2E('SE', narea) * epm, uvel = E2U('N', earea) * uvm,
+// vvel = N2U('E', narea) * uvm (grid_average_X2YA, ice_grid.F90:4388-4606); all four are exchanged ----
+__global__ __launch_bounds__(TX *TY) void cg_average(EvpCgrid A)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const size_t o = c.o, e = o + 1, n = o + A.nx, s = o - A.nx, w = o - 1;
+    const unsigned m = A.mask[o];
+    const double *uE = A.f[CF_UE], *vN = A.f[CF_VN], *ea = A.g[CG_EAREA], *na = A.g[CG_NAREA];
+    const double eo = ea[o], no = na[o], uo = uE[o], vo = vN[o];
+    double uN = 0.0, vE = 0.0, uU = 0.0, vU = 0.0, wtmp;
+    wtmp = (ea[w] + eo + ea[n - 1] + ea[n]);
+    if (wtmp != 0.0) uN = (uE[w] * ea[w] + uo * eo + uE[n - 1] * ea[n - 1] + uE[n] * ea[n]) / wtmp;
+    wtmp = (na[s] + na[s + 1] + no + na[e]);
+    if (wtmp != 0.0) vE = (vN[s] * na[s] + vN[s + 1] * na[s + 1] + vo * no + vN[e] * na[e]) / wtmp;
+    wtmp = (eo + ea[n]);
+    if (wtmp != 0.0) uU = (uo * eo + uE[n] * ea[n]) / wtmp;
+    wtmp = (no + na[e]);
+    if (wtmp != 0.0) vU = (vo * no + vN[e] * na[e]) / wtmp;
+    const double uvm = A.g[CG_UVM][o];
+    uN = uN * A.g[CG_NPM][o];
+    vE = vE * A.g[CG_EPM][o];
+    uU = uU * uvm;
+    vU = vU * uvm;
+    A.f[CF_UN][o] = uN;
+    A.f[CF_VE][o] = vE;
+    A.f[CF_UU][o] = uU;
+    A.f[CF_VU][o] = vU;
+    if (m & 16u) {
+        push(A, o, m, CF_UN, uN);
+        push(A, o, m, CF_VE, vE);
+        push(A, o, m, CF_UU, uU);
+        push(A, o, m, CF_VU, vU);
+    }
+}
+
+// ---- once per call: strengthU = T2U('S')(strength) for visc_method = 'avg_strength' (:993) ----
+__global__ __launch_bounds__(TX *TY) void cg_strength_u(EvpCgrid A, double *out)
+{
+    const Cell c = cell(A);
+    if (!c.in) return;
+    const bool interior = c.i >= c.q.x && c.i <= c.q.y && c.j >= c.q.z && c.j <= c.q.w;
+    out[c.o] = interior ? avg_t2u(A, A.in[CI_STRENGTH], c.o) : 0.0;
+}
+
+// ---- once per call with ndte >= 1: grid_average_X2YA zero-fills its whole output before the interior is
+// computed (ice_grid.F90:4412), so whatever uvelN, vvelE, uvel, vvel held outside the interior (ghost cells without
+// a source, padding of short blocks) is zero from the first subcycle on; ghost cells with a source are pushed ----
+__global__ __launch_bounds__(TX *TY) void cg_zero_outside(EvpCgrid A)
+{
+    const Cell c = cell(A);
+    if (!c.in) return;
+    if (c.i >= c.q.x && c.i <= c.q.y && c.j >= c.q.z && c.j <= c.q.w) return;
+    A.f[CF_UN][c.o] = 0.0;
+    A.f[CF_VE][c.o] = 0.0;
+    A.f[CF_UU][c.o] = 0.0;
+    A.f[CF_VU][c.o] = 0.0;
+}
+
+}  // namespace
+
+void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, hipStream_t st)
+{
+    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    switch (phase) {
+    case 0: hipLaunchKernelGGL(cg_strain_u, grid, block, 0, st, A); break;
+    case 1: hipLaunchKernelGGL(cg_stress_t, grid, block, 0, st, A); break;
+    case 2: hipLaunchKernelGGL(cg_stress_u, grid, block, 0, st, A); break;
+    case 3: hipLaunchKernelGGL(cg_step, grid, block, 0, st, A); break;
+    case 4: hipLaunchKernelGGL(cg_average, grid, block, 0, st, A); break;
+    case 5: hipLaunchKernelGGL(cg_strength_u, grid, block, 0, st, A, const_cast<double *>(A.strengthU)); break;
+    default: hipLaunchKernelGGL(cg_zero_outside, grid, block, 0, st, A); break;
+    }
+}

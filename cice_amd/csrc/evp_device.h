@@ -220,3 +220,40 @@ void evp_launch_halo_pack(const double *u, const double *v, const int *src, doub
                           hipStream_t st);
 void evp_launch_halo_unpack(double *u, double *v, const int *dst, const signed char *sign,
                             const double *buf, int n, hipStream_t st);
+
+// ---------------------------------------------------------------------
+// C-grid EVP subcycle (evp_cgrid.hip; reference ice_dyn_evp.F90:938-1099).  Field order of the tables =
+// include/cice_evp_hip.h (CICE_EVP_HIP_CGRID_*).
+// ---------------------------------------------------------------------
+enum { CG_NF = 19, CG_NIN = 23, CG_NG = 23 };
+enum {   // f[]
+    CF_UE = 0, CF_VE, CF_UN, CF_VN, CF_UU, CF_VU, CF_SP, CF_SM, CF_S12T, CF_S12U, CF_STRX, CF_STRY, CF_TAUBX,
+    CF_TAUBY, CF_ZETA, CF_ETA, CF_ETAU, CF_SHEARU, CF_DELTAU
+};
+enum {   // in[]
+    CI_STRENGTH = 0, CI_CWE, CI_AIE, CI_UOCNE, CI_VOCNE, CI_WATERXE, CI_FORCEXE, CI_EMASSDTI, CI_FME, CI_UE_INIT,
+    CI_TBE, CI_RHEOE, CI_CWN, CI_AIN, CI_UOCNN, CI_VOCNN, CI_WATERYN, CI_FORCEYN, CI_NMASSDTI, CI_FMN, CI_VN_INIT,
+    CI_TBN, CI_RHEON
+};
+enum {   // g[]
+    CG_DXT = 0, CG_DYT, CG_DXU, CG_DYU, CG_DXE, CG_DYE, CG_DXN, CG_DYN, CG_UAREA, CG_TAREA, CG_EAREA, CG_NAREA,
+    CG_EAREAR, CG_NAREAR, CG_EPM, CG_NPM, CG_UVM, CG_HM, CG_DMINT, CG_RXN, CG_RXNR, CG_RYE, CG_RYER
+};
+struct EvpCgrid {
+    double *f[CG_NF];
+    const double *in[CG_NIN];
+    const double *g[CG_NG];
+    const double *strengthU;      // visc_method = 'avg_strength': T->U average of the strength (once per call)
+    const uint8_t *mask;          // bit0 iceT, bit1 iceU, bit2 iceE, bit3 iceN, bit4: the cell has ghost images
+    const int *img_slot;          // per cell: row of img_dst, or -1
+    const int *img_dst;           // 3 per row: ghost cells of this rank that mirror the cell (-1: none)
+    const int4 *blk;
+    EvpScalars p;
+    double deltaminEVP;
+    int nx, ny, nblocks, avg_strength;
+    size_t plane;
+};
+// phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,
+//        4 face->face and face->corner velocity averages, 5 strengthU (once per call), 6 zero what the reference's
+//        whole-array zero fills leave zero outside the interior (uvelN, vvelE, uvel, vvel; once per call)
+void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, hipStream_t st);

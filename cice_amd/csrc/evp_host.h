@@ -8,6 +8,7 @@
 //   evp_host_resident.cpp  on-chip resident kernels: set-up, launch, checks, autotuning
 //   evp_host_mailbox.cpp   mailbox halo over HIP IPC, RCCL bootstrap, probes
 //   evp_host_prep.cpp      preparation phase of evp() (f-2)
+//   evp_host_cgrid.cpp     C-grid subcycle (f-4): state, ghost images, the loop
 //
 // HBM layout: structure-of-arrays; every field is one contiguous fp64 array
 // (nx_block, ny_block, nblocks), i fastest -- the memory image of the CICE
@@ -269,5 +270,7 @@ int resident_check_error();
 int tune_after_upload();
 // evp_host_mailbox.cpp
 int direct_check_error();
+// evp_host_cgrid.cpp
+void cgrid_free();
 
 }  // namespace evp_host

@@ -1,0 +1,238 @@
+// =====================================================================
+// C-grid EVP subcycle behind the C ABI (include/cice_evp_hip.h, cice_evp_hip_cgrid_*): device state, ghost-image
+// table, the loop as a captured graph of five launches per subcycle (evp_cgrid.hip).
+//
+// Replaces evp()'s loop for grid_ice = 'C' (ice_dyn_evp.F90:938-1099).  The caller has run the reference's own
+// preparation (dyn_prep1/2 at U, N and E points, seabed stress, the grid averages of the forcing) and hands over
+// what the loop reads; it gets back what the loop writes.  One rank, cyclic / closed / open boundaries; several
+// blocks per rank are fine (their ghost cells are images like any other).  Neighbours on other ranks and the
+// tripole fold are refused loudly (the B-grid path has both; the C-grid loop exchanges six field groups per
+// subcycle, not one).
+// =====================================================================
+#include "evp_host.h"
+
+namespace evp_host {
+
+struct CGridState {
+    bool geo = false, uploaded = false;
+    double *f[CG_NF] = {}, *in[CG_NIN] = {}, *g[CG_NG] = {};
+    double *strengthU = nullptr;
+    uint8_t *mask = nullptr;
+    int *img_slot = nullptr, *img_dst = nullptr;
+    std::vector<int> h_img_slot;
+    std::vector<uint8_t> hmask;
+    int avg_strength = 0;
+    bool first = true;           // no subcycle has run since the upload
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, first << 1 | avg_strength)
+    double t_loop_ms = 0;
+    int t_nsub = 0;
+};
+static CGridState CG;
+
+void cgrid_free()
+{
+    auto F = [](auto *&p) {
+        if (p) (void)hipFree((void *)p);
+        p = nullptr;
+    };
+    for (auto &p : CG.f) F(p);
+    for (auto &p : CG.in) F(p);
+    for (auto &p : CG.g) F(p);
+    F(CG.strengthU); F(CG.mask); F(CG.img_slot); F(CG.img_dst);
+    for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
+    CG.graphs.clear();
+    CG = CGridState();
+}
+
+static void fill(EvpCgrid &A)
+{
+    const cice_evp_hip_params &q = S.prm;
+    for (int k = 0; k < CG_NF; ++k) A.f[k] = CG.f[k];
+    for (int k = 0; k < CG_NIN; ++k) A.in[k] = CG.in[k];
+    for (int k = 0; k < CG_NG; ++k) A.g[k] = CG.g[k];
+    A.strengthU = CG.strengthU;
+    A.mask = CG.mask;
+    A.img_slot = CG.img_slot;
+    A.img_dst = CG.img_dst;
+    A.blk = S.blk;
+    A.p = {q.arlx1i, q.denom1, q.brlx, q.revp, q.e_factor, q.epp2i, q.capping, q.Ktens, q.u0, q.cosw, q.sinw, q.rhow};
+    A.deltaminEVP = q.deltaminEVP;
+    A.nx = S.d.nx_block;
+    A.ny = S.d.ny_block;
+    A.nblocks = S.d.nblocks;
+    A.avg_strength = CG.avg_strength;
+    A.plane = S.plane;
+}
+
+static void enqueue(const EvpCgrid &A, int ndte, bool first)
+{
+    for (int k = 0; k < ndte; ++k) {
+        evp_launch_cgrid_phase(A, 0, S.stream);
+        // the first strain_rates_U still reads the caller's ghost values of uvelN / vvelE
+        if (first && k == 0) evp_launch_cgrid_phase(A, 6, S.stream);
+        for (int ph = 1; ph <= 4; ++ph) evp_launch_cgrid_phase(A, ph, S.stream);
+    }
+}
+
+}  // namespace evp_host
+
+using namespace evp_host;
+
+extern "C" {
+
+int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
+{
+    if (!S.ready) return fail(-1, "not initialised");
+    if (!static23) return fail(-1, "null argument");
+    const HaloPlan &P = S.plan;
+    for (const HaloPeer &p : P.peers)
+        if (!p.send_src.empty() || !p.recv_dst.empty())
+            return fail(-4, "C-grid EVP: neighbour blocks on other ranks are not supported yet (one rank only)");
+    if (S.d.ns_boundary_type >= CICE_EVP_BND_TRIPOLE)
+        return fail(-4, "C-grid EVP: the tripole fold is not supported yet");
+    cgrid_free();
+    for (auto &p : CG.f)
+        if (alloc_d(&p, S.n)) return -1;
+    for (auto &p : CG.in)
+        if (alloc_d(&p, S.n)) return -1;
+    for (int k = 0; k < CG_NG; ++k) {
+        if (!static23[k]) return fail(-1, "null static array %d", k);
+        if (alloc_d(&CG.g[k], S.n) || h2d(CG.g[k], static23[k])) return -1;
+    }
+    if (alloc_d(&CG.strengthU, S.n)) return -1;
+    HIPC(hipMalloc((void **)&CG.mask, S.n));
+    // ghost images: for every interior cell the ghost cells of this rank that mirror it (what ice_HaloUpdate copies)
+    CG.h_img_slot.assign(S.n, -1);
+    std::vector<int> dst;
+    for (size_t k = 0; k < P.local_dst.size(); ++k) {
+        const int src = P.local_src[k];
+        if (src < 0) continue;                      // neighbour block eliminated (land): stays as the caller left it
+        int &slot = CG.h_img_slot[src];
+        if (slot < 0) {
+            slot = (int)(dst.size() / 3);
+            dst.insert(dst.end(), 3, -1);
+        }
+        int w = 0;
+        while (w < 3 && dst[3 * slot + w] >= 0) ++w;
+        if (w == 3) return fail(-4, "C-grid EVP: a cell with more than three ghost images");
+        dst[3 * slot + w] = P.local_dst[k];
+    }
+    if (dst.empty()) dst.assign(3, -1);
+    HIPC(hipMalloc((void **)&CG.img_slot, S.n * sizeof(int)));
+    HIPC(hipMalloc((void **)&CG.img_dst, dst.size() * sizeof(int)));
+    HIPC(hipMemcpyAsync(CG.img_slot, CG.h_img_slot.data(), S.n * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    CG.hmask.assign(S.n, 0);
+    CG.geo = true;
+    return 0;
+}
+
+int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const *inputs23, const int32_t *iceTmask,
+                              const int32_t *iceUmask, const int32_t *iceEmask, const int32_t *iceNmask,
+                              int32_t visc_method)
+{
+    if (!S.ready || !CG.geo) return fail(-1, "C-grid EVP: geometry not set");
+    if (!state14 || !inputs23 || !iceTmask || !iceUmask || !iceEmask || !iceNmask) return fail(-1, "null argument");
+    if (visc_method != 0 && visc_method != 1) return fail(-1, "visc_method %d (0 avg_zeta, 1 avg_strength)", visc_method);
+    CopyBatch B;
+    for (int k = 0; k < 14; ++k) {
+        if (!state14[k]) return fail(-1, "null state array %d", k);
+        B.items.push_back({CG.f[k], state14[k]});
+    }
+    for (int k = 0; k < CG_NIN; ++k) {
+        if (!inputs23[k]) return fail(-1, "null input array %d", k);
+        B.items.push_back({CG.in[k], inputs23[k]});
+    }
+    if (h2d_batch(B)) return -1;
+    // evp() zeroes its work arrays at entry (ice_dyn_evp.F90:351-361)
+    for (int k = CF_ZETA; k < CG_NF; ++k) HIPC(hipMemsetAsync(CG.f[k], 0, S.n * sizeof(double), S.stream));
+    for (size_t c = 0; c < S.n; ++c)
+        CG.hmask[c] = (uint8_t)((iceTmask[c] ? 1 : 0) | (iceUmask[c] ? 2 : 0) | (iceEmask[c] ? 4 : 0) |
+                                (iceNmask[c] ? 8 : 0) | (CG.h_img_slot[c] >= 0 ? 16 : 0));
+    HIPC(hipMemcpyAsync(CG.mask, CG.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    CG.avg_strength = visc_method;
+    if (visc_method == 1) {
+        EvpCgrid A;
+        fill(A);
+        evp_launch_cgrid_phase(A, 5, S.stream);
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(S.stream));       // hmask is reused by the next upload
+    CG.uploaded = true;
+    CG.first = true;
+    return 0;
+}
+
+int cice_evp_hip_cgrid_subcycle(int32_t ndte)
+{
+    if (!CG.uploaded) return fail(-1, "C-grid EVP: nothing uploaded");
+    if (ndte < 0) return fail(-1, "ndte < 0");
+    if (ndte == 0) return 0;
+    EvpCgrid A;
+    fill(A);
+    HIPC(hipEventRecord(S.ev0, S.stream));
+    if (S.use_graph) {
+        const std::pair<int, int> key(ndte, (CG.first ? 2 : 0) | CG.avg_strength);
+        auto it = CG.graphs.find(key);
+        if (it == CG.graphs.end()) {
+            hipGraph_t gr = nullptr;
+            hipGraphExec_t ex = nullptr;
+            HIPC(hipStreamBeginCapture(S.stream, hipStreamCaptureModeThreadLocal));
+            enqueue(A, ndte, CG.first);
+            HIPC(hipStreamEndCapture(S.stream, &gr));
+            HIPC(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(gr);
+            it = CG.graphs.emplace(key, ex).first;
+        }
+        HIPC(hipGraphLaunch(it->second, S.stream));
+    } else {
+        enqueue(A, ndte, CG.first);
+    }
+    HIPC(hipEventRecord(S.ev1, S.stream));
+    HIPC(hipGetLastError());
+    CG.first = false;
+    CG.t_nsub = ndte;
+    return 0;
+}
+
+int cice_evp_hip_cgrid_download(double *const *fields19)
+{
+    if (!CG.uploaded) return fail(-1, "C-grid EVP: nothing uploaded");
+    if (!fields19) return fail(-1, "null argument");
+    CopyBatch B;
+    for (int k = 0; k < CG_NF; ++k)
+        if (fields19[k]) B.items.push_back({fields19[k], CG.f[k]});
+    if (d2h_batch(B)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    if (CG.t_nsub && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) CG.t_loop_ms = ms;
+    return 0;
+}
+
+int cice_evp_hip_cgrid_sync(void)
+{
+    HIPC(hipStreamSynchronize(S.stream));
+    float ms = 0;
+    if (CG.t_nsub && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) CG.t_loop_ms = ms;
+    return 0;
+}
+
+int cice_evp_hip_cgrid_run(int32_t ndte, int32_t visc_method, double *const *fields19, const double *const *inputs23,
+                           const int32_t *iceTmask, const int32_t *iceUmask, const int32_t *iceEmask,
+                           const int32_t *iceNmask)
+{
+    if (cice_evp_hip_cgrid_upload(fields19, inputs23, iceTmask, iceUmask, iceEmask, iceNmask, visc_method)) return -1;
+    if (cice_evp_hip_cgrid_subcycle(ndte)) return -1;
+    return cice_evp_hip_cgrid_download(fields19);
+}
+
+int cice_evp_hip_cgrid_timings(double *out, int32_t n)
+{
+    if (!out || n < 2) return fail(-1, "need room for 2 values");
+    out[0] = CG.t_loop_ms;
+    out[1] = (double)CG.t_nsub;
+    return 0;
+}
+
+}  // extern "C"

@@ -44,7 +44,19 @@ EXPORTS = [
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
+    "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
+    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings",
 ]
+# C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
+CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
+                "strintxE", "strintyN", "taubxE", "taubyN", "zetax2T", "etax2T", "etax2U", "shearU", "deltaU"]
+CGRID_INPUTS = ["strength", "cdn_ocnE", "aiE", "uocnE", "vocnE", "waterxE", "forcexE", "emassdti", "fmE", "uvelE_init",
+                "TbE", "rheofactE", "cdn_ocnN", "aiN", "uocnN", "vocnN", "wateryN", "forceyN", "nmassdti", "fmN",
+                "vvelN_init", "TbN", "rheofactN"]
+CGRID_STATIC = ["dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear",
+                "narear", "epm", "npm", "uvm", "hm", "DminTarea", "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr"]
+CGRID_MASKS = ["iceTmask", "iceUmask", "iceEmask", "iceNmask"]
+VISC_METHOD = {"avg_zeta": 0, "avg_strength": 1}
 HALO_BLOB = 1024   # CICE_EVP_HIP_HALO_BLOB
 OPT_STRESS_RESIDENT = 1   # CICE_EVP_HIP_OPT_STRESS_RESIDENT
 # T-grid inputs of the preparation phase (order of cice_evp_hip_prep's tfields11) and the
@@ -258,6 +270,49 @@ class EvpHip:
         a = self._c(hwater) if hwater is not None else None
         _check(self.lib, self.lib.cice_evp_hip_seabed_lkd(_dp(a) if a is not None else None, C.c_double(k1), C.c_double(k2),
                                                            C.c_double(alphab), C.c_double(threshold_hw)), "(dyn_evp_hip_seabed_lkd)")
+
+    # -- C-grid subcycle -------------------------------------------
+    def cgrid_set_geometry(self, static: dict):
+        arrs = [self._c(static[k]) for k in CGRID_STATIC]
+        tab = (_f64p * len(arrs))(*[_dp(a) for a in arrs])
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_set_geometry(tab), "(dyn_evp_hip_cgrid_set_geometry)")
+
+    def cgrid_upload(self, state: dict, inputs: dict, masks: dict, visc_method: str = "avg_zeta"):
+        st = [self._c(state[k]) for k in CGRID_FIELDS[:14]]
+        inp = [self._c(inputs[k]) for k in CGRID_INPUTS]
+        mk = [self._c(masks[k], np.int32) for k in CGRID_MASKS]
+        rc = self.lib.cice_evp_hip_cgrid_upload((_f64p * 14)(*[_dp(a) for a in st]), (_f64p * len(inp))(*[_dp(a) for a in inp]),
+                                                *[_ip(m) for m in mk], C.c_int32(VISC_METHOD[visc_method]))
+        _check(self.lib, rc, "(dyn_evp_hip_cgrid_upload)")
+
+    def cgrid_subcycle(self, ndte: int):
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_subcycle(C.c_int32(ndte)), "(dyn_evp_hip_cgrid_subcycle)")
+
+    def cgrid_download(self) -> dict:
+        out = {k: np.zeros(self.shape) for k in CGRID_FIELDS}
+        tab = (_f64p * len(CGRID_FIELDS))(*[_dp(out[k]) for k in CGRID_FIELDS])
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_download(tab), "(dyn_evp_hip_cgrid_download)")
+        return out
+
+    def cgrid_run(self, ndte: int, state: dict, inputs: dict, masks: dict, visc_method: str = "avg_zeta") -> dict:
+        """cice_evp_hip_cgrid_run on copies of `state` (the Fortran call shape: arrays updated in place)."""
+        work = {k: (np.array(state[k], dtype=np.float64, order="C", copy=True) if k in state else np.zeros(self.shape))
+                for k in CGRID_FIELDS}
+        inp = [self._c(inputs[k]) for k in CGRID_INPUTS]
+        mk = [self._c(masks[k], np.int32) for k in CGRID_MASKS]
+        rc = self.lib.cice_evp_hip_cgrid_run(C.c_int32(ndte), C.c_int32(VISC_METHOD[visc_method]),
+                                             (_f64p * len(CGRID_FIELDS))(*[_dp(work[k]) for k in CGRID_FIELDS]),
+                                             (_f64p * len(inp))(*[_dp(a) for a in inp]), *[_ip(m) for m in mk])
+        _check(self.lib, rc, "(dyn_evp_hip_cgrid_run)")
+        return work
+
+    def cgrid_sync(self):
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_sync(), "(dyn_evp_hip_cgrid_sync)")
+
+    def cgrid_timings(self):
+        out = np.zeros(2)
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(2)), "(dyn_evp_hip_cgrid_timings)")
+        return dict(loop_ms=float(out[0]), nsub=int(out[1]))
 
     def prep_fetch(self, name: str):
         out = np.zeros(self.shape)

@@ -219,6 +219,37 @@ void *cice_evp_hip_addr(const void *array);
  * 18 uvel 19 vvel 20 TbU (as the subcycle loop will see them)                                         */
 int cice_evp_hip_prep_fetch(int32_t which, double *dst);
 
+/* ---- C-grid EVP subcycle (second half): evp()'s loop for grid_ice = 'C',
+ * cicedyn/dynamics/ice_dyn_evp.F90:938-1099 -- strain_rates_U, stressC_T, stressC_U, div_stress_Ex / _Ny,
+ * stepu_C / stepv_C, the E<->N and face->corner velocity averages, and the eight ice_HaloUpdate calls of every
+ * subcycle (fused into the kernels).  Call after cice_evp_hip_init (dims, scalars).  One rank; cyclic, closed or
+ * open boundaries; any number of blocks.
+ *
+ * static23 (ice_grid / ice_dyn_evp arrays, once):
+ *   dxT dyT dxU dyU dxE dyE dxN dyN uarea tarea earea narea earear narear epm npm uvm hm DminTarea
+ *   ratiodxN ratiodxNr ratiodyE ratiodyEr
+ * fields19 (in/out; entries 14..18 are evp()'s work arrays: out only, zero at entry as evp() zeroes them :351-361):
+ *   uvelE vvelE uvelN vvelN uvel vvel stresspT stressmT stress12T stress12U strintxE strintyN taubxE taubyN
+ *   zetax2T etax2T etax2U shearU deltaU
+ * inputs23 (what the reference's preparation leaves in ice_dyn_evp's module arrays):
+ *   strength cdn_ocnE aiE uocnE vocnE waterxE forcexE emassdti fmE uvelE_init TbE rheofactE
+ *   cdn_ocnN aiN uocnN vocnN wateryN forceyN nmassdti fmN vvelN_init TbN rheofactN
+ * visc_method: 0 'avg_zeta', 1 'avg_strength' (ice_dyn_evp.F90:992-996).
+ * Not done here (it is after the loop, :1437-1440): the ice_HaloUpdate of strintxE / strintyN.            */
+int cice_evp_hip_cgrid_set_geometry(const double *const *static23);
+int cice_evp_hip_cgrid_run(int32_t ndte, int32_t visc_method, double *const *fields19,
+                           const double *const *inputs23, const int32_t *iceTmask, const int32_t *iceUmask,
+                           const int32_t *iceEmask, const int32_t *iceNmask);
+/* the same in three steps (state14 = the first 14 entries of fields19) */
+int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const *inputs23,
+                              const int32_t *iceTmask, const int32_t *iceUmask, const int32_t *iceEmask,
+                              const int32_t *iceNmask, int32_t visc_method);
+int cice_evp_hip_cgrid_subcycle(int32_t ndte);
+int cice_evp_hip_cgrid_download(double *const *fields19);
+int cice_evp_hip_cgrid_sync(void);
+/* out[0] = ms of the last cgrid_subcycle (HIP events), out[1] = its ndte */
+int cice_evp_hip_cgrid_timings(double *out, int32_t n);
+
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */
 /* 128-byte ncclUniqueId made by rank 0 and distributed by the host program
  * (MPI_Bcast in CICE; torch.distributed in bench.py).                          */
