@@ -20,6 +20,15 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen)
     return (int)g_err.size();
 }
 
+int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second)
+{
+    if (ncells <= 0 || !bytes_per_second) return fail(-1, "bad argument");
+    const double sec = evp_stream_probe((size_t)ncells, 5, nullptr);
+    if (sec <= 0) return fail((int)-sec, "stream probe failed: %s", hipGetErrorString((hipError_t)(int)-sec));
+    *bytes_per_second = 46.0 * 8.0 * (double)ncells / sec;
+    return 0;
+}
+
 int cice_evp_hip_finalize(void)
 {
     if (S.stream) (void)hipStreamSynchronize(S.stream);

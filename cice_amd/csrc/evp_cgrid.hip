@@ -12,6 +12,17 @@
 // and no halo kernel runs inside the loop.  Fields the reference never exchanges (etax2U, deltaU, stress12T,
 // strintxE/yN, taubxE/yN) are not pushed: their ghost cells end up exactly as the reference leaves them.
 //
+// Two schedules.  "phases": the five phases as five launches (any visc_method).  "fused" (visc_method = avg_zeta):
+// three launches per subcycle --
+//   A  face->face / face->corner averages of the PREVIOUS subcycle's velocities recomputed where strain_rates_U
+//      needs them (own cell and the east / north neighbour), so that phase 4 disappears from the loop and runs once
+//      after it; uvelN, vvelE are stored for stepu_C / stepv_C, the corner velocities stay in registers;
+//   B  stressC_T as before;
+//   C  stressC_U recomputed at the three corners div_stress_Ex / _Ny read (own, south, west: stress12U ping-pongs
+//      between two buffers), then stepu_C / stepv_C.
+// Arrays that nothing inside the loop reads (zetax2T, etax2U, deltaU, strintxE/yN, taubxE/yN) are stored in the last
+// subcycle of a call only.  81 instead of 99 doubles moved per cell and subcycle, 3 instead of 5 launches.
+//
 // fp64, strict: no FMA contraction, operations in the reference's order -- bit-identical to the reference
 // compiled with -O2 -ffp-contract=off (tests/test_gpu_cgrid.py against the committed fixtures).
 // HBM-bound on large grids (about 90 doubles moved per cell and subcycle), launch-bound on gx1-sized ones.
@@ -64,6 +75,85 @@ __device__ __forceinline__ Cell cell(const EvpCgrid &A)
 }
 
 // ---- phase 0: strain_rates_U (strain rates * area at the corners); shearU is exchanged (:965-967) ----
+// strain_rates_U proper (ice_dyn_shared.F90:2341-2444) on values in registers
+struct StrainIn {
+    double uNo, uNe, vEo, vEn, uEo, uEn, vNo, vNe, uU, vU;
+};
+__device__ __forceinline__ void strain_u(const EvpCgrid &A, size_t o, const StrainIn &v, double &sh, double &delta)
+{
+    const size_t e = o + 1, n = o + A.nx;
+    const double *epm = A.g[CG_EPM], *npm = A.g[CG_NPM];
+    const double dxU = A.g[CG_DXU][o], dyU = A.g[CG_DYU][o];
+    const double ddyN = A.g[CG_DYN][e] - A.g[CG_DYN][o], ddxE = A.g[CG_DXE][n] - A.g[CG_DXE][o];
+    const double rxN = A.g[CG_RXN][o], rxNr = A.g[CG_RXNR][o], ryE = A.g[CG_RYE][o], ryEr = A.g[CG_RYER][o];
+    const double npc = npm[o], npe = npm[e], epc = epm[o], epn = epm[n];
+    const double uNip1j = v.uNe * npe + (npc - npe) * npc * rxN * v.uNo;
+    const double uNij = v.uNo * npc + (npe - npc) * npe * rxNr * v.uNe;
+    const double vEijp1 = v.vEn * epn + (epc - epn) * epc * ryE * v.vEo;
+    const double vEij = v.vEo * epc + (epn - epc) * epn * ryEr * v.vEn;
+    const double dv = dyU * (uNip1j - uNij) + v.uU * ddyN + dxU * (vEijp1 - vEij) + v.vU * ddxE;
+    const double tn = dyU * (uNip1j - uNij) - v.uU * ddyN - dxU * (vEijp1 - vEij) + v.vU * ddxE;
+    const double uEijp1 = v.uEn * epn + (epc - epn) * epc * ryE * v.uEo;
+    const double uEij = v.uEo * epc + (epn - epc) * epn * ryEr * v.uEn;
+    const double vNip1j = v.vNe * npe + (npc - npe) * npc * rxN * v.vNo;
+    const double vNij = v.vNo * npc + (npe - npc) * npe * rxNr * v.vNe;
+    sh = dxU * (uEijp1 - uEij) - v.uU * ddxE + dyU * (vNip1j - vNij) - v.vU * ddyN;
+    delta = sqrt(dv * dv + A.p.e_factor * (tn * tn + sh * sh));
+}
+
+// grid_average_X2YA at cell p (ice_grid.F90:4388-4606): 'NW' (E -> N), 'SE' (N -> E), 'N' (E -> U), 'E' (N -> U)
+__device__ __forceinline__ double avg_nw(const double *a, const double *w, size_t p, int nx)
+{
+    const double wtmp = (w[p - 1] + w[p] + w[p + nx - 1] + w[p + nx]);
+    if (wtmp == 0.0) return 0.0;
+    return (a[p - 1] * w[p - 1] + a[p] * w[p] + a[p + nx - 1] * w[p + nx - 1] + a[p + nx] * w[p + nx]) / wtmp;
+}
+__device__ __forceinline__ double avg_se(const double *a, const double *w, size_t p, int nx)
+{
+    const double wtmp = (w[p - nx] + w[p - nx + 1] + w[p] + w[p + 1]);
+    if (wtmp == 0.0) return 0.0;
+    return (a[p - nx] * w[p - nx] + a[p - nx + 1] * w[p - nx + 1] + a[p] * w[p] + a[p + 1] * w[p + 1]) / wtmp;
+}
+__device__ __forceinline__ double avg_2(const double *a, const double *w, size_t p, size_t q)
+{
+    const double wtmp = (w[p] + w[q]);
+    if (wtmp == 0.0) return 0.0;
+    return (a[p] * w[p] + a[q] * w[q]) / wtmp;
+}
+
+// ---- fused A: what phase 4 of the previous subcycle would have stored, recomputed where this subcycle's
+// strain_rates_U reads it.  The east / north neighbour may be a ghost cell: its value in the reference is the copy
+// of the owner's average, which the same formula gives here from the (pushed) ghost velocities and the static
+// ghost weights. ----
+__global__ __launch_bounds__(TX *TY) void cg_avg_strain(EvpCgrid A, int last)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const size_t o = c.o, e = o + 1, n = o + A.nx;
+    const unsigned m = A.mask[o];
+    const double *uE = A.f[CF_UE], *vN = A.f[CF_VN], *ea = A.g[CG_EAREA], *na = A.g[CG_NAREA];
+    const double *npm = A.g[CG_NPM], *epm = A.g[CG_EPM];
+    StrainIn v;
+    v.uNo = avg_nw(uE, ea, o, A.nx) * npm[o];
+    v.vEo = avg_se(vN, na, o, A.nx) * epm[o];
+    A.f[CF_UN][o] = v.uNo;                       // stepv_C / stepu_C of this subcycle read them (own cell)
+    A.f[CF_VE][o] = v.vEo;
+    // no early exit for cells without ice: every load below is in bounds, and issuing them all before the first
+    // wait is what matters on grids this small (two waves per SIMD); only the stores are conditional
+    const double uvm = A.g[CG_UVM][o];
+    v.uU = avg_2(uE, ea, o, n) * uvm;
+    v.vU = avg_2(vN, na, o, e) * uvm;
+    v.uNe = avg_nw(uE, ea, e, A.nx) * npm[e];
+    v.vEn = avg_se(vN, na, n, A.nx) * epm[n];
+    v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
+    double sh, delta;
+    strain_u(A, o, v, sh, delta);
+    if (!(m & 2u)) return;
+    A.f[CF_SHEARU][o] = sh;
+    if (last) A.f[CF_DELTAU][o] = delta;
+    if (m & 16u) push(A, o, m, CF_SHEARU, sh);
+}
+
 __global__ __launch_bounds__(TX *TY) void cg_strain_u(EvpCgrid A)
 {
     const Cell c = cell(A);
@@ -97,13 +187,13 @@ __global__ __launch_bounds__(TX *TY) void cg_strain_u(EvpCgrid A)
 // ---- phase 1: stressC_T on ilo..ihi+1 x jlo..jhi+1 (the reference's T list, ice_dyn_shared.F90:729-738).
 // zetax2T, etax2T, stresspT, stressmT are exchanged right after (:988-990): interior cells store and push them, the
 // extra row and column (ghost cells) only keep what is never exchanged, stress12T. ----
-__global__ __launch_bounds__(TX *TY) void cg_stress_t(EvpCgrid A)
+template <bool ALWAYS>
+__global__ __launch_bounds__(TX *TY) void cg_stress_t(EvpCgrid A, int last)
 {
     const Cell c = cell(A);
     if (!c.in || c.i < c.q.x || c.i > c.q.y + 1 || c.j < c.q.z || c.j > c.q.w + 1) return;
     const size_t o = c.o, w = o - 1, s = o - A.nx, sw = s - 1;
     const unsigned m = A.mask[o];
-    if (!(m & 1u)) return;
     const bool own = c.i <= c.q.y && c.j <= c.q.w;
     const double *uE = A.f[CF_UE], *vN = A.f[CF_VN], *shU = A.f[CF_SHEARU];
     const double *dyE = A.g[CG_DYE], *dxN = A.g[CG_DXN], *uarea = A.g[CG_UAREA];
@@ -118,16 +208,19 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_t(EvpCgrid A)
     double zetax2, etax2, rep_prs;
     visc_replpress(A.p, A.in[CI_STRENGTH][o], A.g[CG_DMINT][o], DeltaT, zetax2, etax2, rep_prs);
     const double relax = 1.0 - A.p.arlx1i * A.p.revp;
-    A.f[CF_S12T][o] = (A.f[CF_S12T][o] * relax + A.p.arlx1i * 0.5 * etax2 * shearT) * A.p.denom1;
-    if (!own) return;
+    const double s12 = (A.f[CF_S12T][o] * relax + A.p.arlx1i * 0.5 * etax2 * shearT) * A.p.denom1;
     const double sp = (A.f[CF_SP][o] * relax + A.p.arlx1i * (zetax2 * divT - rep_prs)) * A.p.denom1;
     const double sm = (A.f[CF_SM][o] * relax + A.p.arlx1i * etax2 * tensionT) * A.p.denom1;
-    A.f[CF_ZETA][o] = zetax2;
+    if (!(m & 1u)) return;                       // loads above are unconditional (in bounds), stores are not
+    A.f[CF_S12T][o] = s12;
+    if (!own) return;
+    const bool zeta = ALWAYS || last;            // zetax2T: nothing in the loop reads it
+    if (zeta) A.f[CF_ZETA][o] = zetax2;
     A.f[CF_ETA][o] = etax2;
     A.f[CF_SP][o] = sp;
     A.f[CF_SM][o] = sm;
     if (m & 16u) {
-        push(A, o, m, CF_ZETA, zetax2);
+        if (zeta) push(A, o, m, CF_ZETA, zetax2);
         push(A, o, m, CF_ETA, etax2);
         push(A, o, m, CF_SP, sp);
         push(A, o, m, CF_SM, sm);
@@ -224,6 +317,103 @@ __global__ __launch_bounds__(TX *TY) void cg_step(EvpCgrid A)
     }
 }
 
+// stress12U after this subcycle at corner p (own cell or a neighbour, possibly a ghost cell): stressC_U with the
+// T -> U average of etax2T, from the previous subcycle's value in A.s12_in; unchanged where there is no ice
+__device__ __forceinline__ double s12u_new(const EvpCgrid &A, size_t p, bool ice, double relax, double *etaU)
+{
+    const double old = A.s12_in[p];
+    const double e2 = avg_t2u(A, A.f[CF_ETA], p);
+    if (etaU) *etaU = e2;
+    const double upd = (old * relax + A.p.arlx1i * 0.5 * e2 * A.f[CF_SHEARU][p]) * A.p.denom1;
+    return ice ? upd : old;
+}
+
+// ---- fused C: phases 2 and 3 in one launch (visc_method = avg_zeta) ----
+__global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const size_t o = c.o, e = o + 1, n = o + A.nx, s = o - A.nx, w = o - 1;
+    const unsigned m = A.mask[o];
+    const double relax = 1.0 - A.p.arlx1i * A.p.revp;
+    double etaU;
+    const double s12c = s12u_new(A, o, (m & 2u) != 0, relax, &etaU);
+    const double s12s = s12u_new(A, s, (A.mask[s] & 32u) != 0, relax, nullptr);
+    const double s12w = s12u_new(A, w, (A.mask[w] & 32u) != 0, relax, nullptr);
+    const double *sp = A.f[CF_SP], *sm = A.f[CF_SM];
+    const double spc = sp[o], smc = sm[o];
+    const EvpScalars &p = A.p;
+    // both faces computed for every interior cell (all loads in bounds and issued together); stores by mask
+    double unew, vnew, strintx, strinty, taubx, tauby;
+    {
+        const double *dyT = A.g[CG_DYT], *dxU = A.g[CG_DXU];
+        const double dyE = A.g[CG_DYE][o], dxE = A.g[CG_DXE][o];
+        strintx = A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o] *
+                  (0.5 * dyE * (sp[e] - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sm[e] - (dyT[o] * dyT[o]) * smc) +
+                   (1.0 / dxE) * ((dxU[o] * dxU[o]) * s12c - (dxU[s] * dxU[s]) * s12s));
+        const double uold = A.f[CF_UE][o], vold = A.f[CF_VE][o];
+        const double du = A.in[CI_UOCNE][o] - uold, dv = A.in[CI_VOCNE][o] - vold;
+        const double vrel = A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o] * sqrt(du * du + dv * dv);
+        const double taux = vrel * A.in[CI_WATERXE][o];
+        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+        const double Cb = A.in[CI_TBE][o] / ccc;
+        const double massdti = A.in[CI_EMASSDTI][o], fm = A.in[CI_FME][o];
+        const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
+        const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+        const double cc1 = strintx + A.in[CI_FORCEXE][o] + taux + massdti * (p.brlx * uold + p.revp * A.in[CI_UE_INIT][o]);
+        unew = (ccb * vold + cc1) / cca;
+        taubx = -unew * Cb;
+    }
+    {
+        const double *dxT = A.g[CG_DXT], *dyU = A.g[CG_DYU];
+        const double dxN = A.g[CG_DXN][o], dyN = A.g[CG_DYN][o];
+        strinty = A.in[CI_RHEON][o] * A.g[CG_NAREAR][o] *
+                  (0.5 * dxN * (sp[n] - spc) - (0.5 / dxN) * ((dxT[n] * dxT[n]) * sm[n] - (dxT[o] * dxT[o]) * smc) +
+                   (1.0 / dyN) * ((dyU[o] * dyU[o]) * s12c - (dyU[w] * dyU[w]) * s12w));
+        const double uold = A.f[CF_UN][o], vold = A.f[CF_VN][o];
+        const double du = A.in[CI_UOCNN][o] - uold, dv = A.in[CI_VOCNN][o] - vold;
+        const double vrel = A.in[CI_AIN][o] * p.rhow * A.in[CI_CWN][o] * sqrt(du * du + dv * dv);
+        const double tauy = vrel * A.in[CI_WATERYN][o];
+        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+        const double Cb = A.in[CI_TBN][o] / ccc;
+        const double massdti = A.in[CI_NMASSDTI][o], fm = A.in[CI_FMN][o];
+        const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
+        const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+        const double cc2 = strinty + A.in[CI_FORCEYN][o] + tauy + massdti * (p.brlx * vold + p.revp * A.in[CI_VN_INIT][o]);
+        vnew = (-ccb * uold + cc2) / cca;
+        tauby = -vnew * Cb;
+    }
+    if (m & 2u) {
+        A.f[CF_S12U][o] = s12c;
+        if (m & 16u) push(A, o, m, CF_S12U, s12c);
+    }
+    if (last) A.f[CF_ETAU][o] = etaU;
+    if (m & 4u) {
+        A.f[CF_UE][o] = unew;
+        if (last) {
+            A.f[CF_STRX][o] = strintx;
+            A.f[CF_TAUBX][o] = taubx;
+        }
+        if (m & 16u) push(A, o, m, CF_UE, unew);
+    }
+    if (m & 8u) {
+        A.f[CF_VN][o] = vnew;
+        if (last) {
+            A.f[CF_STRY][o] = strinty;
+            A.f[CF_TAUBY][o] = tauby;
+        }
+        if (m & 16u) push(A, o, m, CF_VN, vnew);
+    }
+}
+
+// ---- copy a field into the ghost images of its interior cells (what one ice_HaloUpdate does) ----
+__global__ __launch_bounds__(TX *TY) void cg_fill_images(EvpCgrid A, int field)
+{
+    const Cell c = cell(A);
+    if (!c.in) return;
+    if (A.mask[c.o] & 16u) push(A, c.o, 16u, field, A.f[field][c.o]);
+}
+
 // ---- phase 4: the other component at each face and the corner velocities (:1070-1094):
 // uvelN = E2N('NW', earea) * npm, vvelE = N2E('SE', narea) * epm, uvel = E2U('N', earea) * uvm,
 // vvel = N2U('E', narea) * uvm (grid_average_X2YA, ice_grid.F90:4388-4606); all four are exchanged ----
@@ -286,12 +476,16 @@ __global__ __launch_bounds__(TX *TY) void cg_zero_outside(EvpCgrid A)
 
 }  // namespace
 
-void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, hipStream_t st)
+void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st)
 {
     const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
     switch (phase) {
     case 0: hipLaunchKernelGGL(cg_strain_u, grid, block, 0, st, A); break;
-    case 1: hipLaunchKernelGGL(cg_stress_t, grid, block, 0, st, A); break;
+    case 1: hipLaunchKernelGGL(cg_stress_t<true>, grid, block, 0, st, A, last); break;
+    case 10: hipLaunchKernelGGL(cg_stress_t<false>, grid, block, 0, st, A, last); break;
+    case 7: hipLaunchKernelGGL(cg_avg_strain, grid, block, 0, st, A, last); break;
+    case 8: hipLaunchKernelGGL(cg_stress_u_step, grid, block, 0, st, A, last); break;
+    case 9: hipLaunchKernelGGL(cg_fill_images, grid, block, 0, st, A, last); break;
     case 2: hipLaunchKernelGGL(cg_stress_u, grid, block, 0, st, A); break;
     case 3: hipLaunchKernelGGL(cg_step, grid, block, 0, st, A); break;
     case 4: hipLaunchKernelGGL(cg_average, grid, block, 0, st, A); break;

@@ -11,6 +11,7 @@
 // =====================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #include "evp_device.h"
 
@@ -46,7 +47,67 @@ __global__ void zero_sig_off_mask(SigTab T, const uint8_t *__restrict__ mask, si
     for (int k = 0; k < 24; ++k) T.p[k][i] = 0.0;
 }
 
+// Plain streaming with the array shape of one B-grid subcycle (30 arrays in, 16 out, 368 B per cell, every element
+// touched once, consecutive lanes on consecutive addresses, next to no arithmetic): what HBM gives a kernel of this
+// shape on this box -- the practical ceiling the streaming subcycle kernel is compared with (bench.py).
+struct StreamTab { const double *in[30]; double *out[16]; };
+__global__ __launch_bounds__(256) void stream_30_16(StreamTab T, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 30; ++k) s += T.in[k][i];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T.out[k][i] = s + k;
+}
+
 }  // namespace
+
+// returns seconds per launch (best of `reps` groups of 10), or a negative HIP error code
+double evp_stream_probe(size_t ncells, int reps, hipStream_t st)
+{
+    StreamTab T{};
+    std::vector<void *> owned;
+    auto fail = [&](hipError_t e) {
+        for (void *p : owned) (void)hipFree(p);
+        return -(double)(int)e;
+    };
+    for (auto &p : T.in) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, ncells * sizeof(double));
+        if (e != hipSuccess) return fail(e);
+        owned.push_back(q);
+        (void)hipMemsetAsync(q, 0, ncells * sizeof(double), st);
+        p = (const double *)q;
+    }
+    for (auto &p : T.out) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, ncells * sizeof(double));
+        if (e != hipSuccess) return fail(e);
+        owned.push_back(q);
+        p = (double *)q;
+    }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const unsigned grid = (unsigned)((ncells + 255) / 256);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(stream_30_16, dim3(grid), dim3(256), 0, st, T, ncells);
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        (void)hipEventRecord(e0, st);
+        for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(stream_30_16, dim3(grid), dim3(256), 0, st, T, ncells);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (void *p : owned) (void)hipFree(p);
+    return (double)best * 1e-4;
+}
 
 void evp_launch_copy_many(const EvpCopyTab &T, hipStream_t st)
 {

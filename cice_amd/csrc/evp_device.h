@@ -194,6 +194,7 @@ struct EvpCopyTab {
     int vec2;                  // every pointer 16-byte aligned: double2 accesses
 };
 void evp_launch_copy_many(const EvpCopyTab &T, hipStream_t st);
+double evp_stream_probe(size_t ncells, int reps, hipStream_t st);
 void evp_launch_zero_sig_off_mask(double *const *sig0, double *const *sig1, const uint8_t *mask, size_t n, hipStream_t st);
 
 void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double *out, size_t n,
@@ -244,7 +245,9 @@ struct EvpCgrid {
     const double *in[CG_NIN];
     const double *g[CG_NG];
     const double *strengthU;      // visc_method = 'avg_strength': T->U average of the strength (once per call)
-    const uint8_t *mask;          // bit0 iceT, bit1 iceU, bit2 iceE, bit3 iceN, bit4: the cell has ghost images
+    const uint8_t *mask;          // bit0 iceT, bit1 iceU, bit2 iceE, bit3 iceN, bit4: the cell has ghost images,
+                                  // bit5: iceU of the cell, or of the interior cell this ghost cell mirrors
+    const double *s12_in;         // fused path: stress12U ping-pong (read s12_in, write f[CF_S12U])
     const int *img_slot;          // per cell: row of img_dst, or -1
     const int *img_dst;           // 3 per row: ghost cells of this rank that mirror the cell (-1: none)
     const int4 *blk;
@@ -256,4 +259,7 @@ struct EvpCgrid {
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,
 //        4 face->face and face->corner velocity averages, 5 strengthU (once per call), 6 zero what the reference's
 //        whole-array zero fills leave zero outside the interior (uvelN, vvelE, uvel, vvel; once per call)
-void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, hipStream_t st);
+//        7 fused: averages + strain_rates_U, 8 fused: viscosity at the corners + stressC_U + div_stress + stepu_C/stepv_C,
+//        9 copy field `last` into its ghost images
+// last: the launch belongs to the last subcycle of a call (arrays nobody reads inside the loop are stored only then)
+void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st);

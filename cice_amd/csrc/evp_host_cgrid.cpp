@@ -17,13 +17,15 @@ struct CGridState {
     bool geo = false, uploaded = false;
     double *f[CG_NF] = {}, *in[CG_NIN] = {}, *g[CG_NG] = {};
     double *strengthU = nullptr;
+    double *s12alt = nullptr;    // second stress12U buffer of the fused schedule (f[CF_S12U] always holds the current one)
+    int flip = 0;                // which of the two allocations f[CF_S12U] is (part of the graph key)
     uint8_t *mask = nullptr;
     int *img_slot = nullptr, *img_dst = nullptr;
-    std::vector<int> h_img_slot;
+    std::vector<int> h_img_slot, h_img_dst;
     std::vector<uint8_t> hmask;
     int avg_strength = 0;
     bool first = true;           // no subcycle has run since the upload
-    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, first << 1 | avg_strength)
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, flip << 3 | fused << 2 | first << 1 | avg_strength)
     double t_loop_ms = 0;
     int t_nsub = 0;
 };
@@ -38,7 +40,7 @@ void cgrid_free()
     for (auto &p : CG.f) F(p);
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
-    F(CG.strengthU); F(CG.mask); F(CG.img_slot); F(CG.img_dst);
+    F(CG.strengthU); F(CG.s12alt); F(CG.mask); F(CG.img_slot); F(CG.img_dst);
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
     CG.graphs.clear();
     CG = CGridState();
@@ -51,6 +53,7 @@ static void fill(EvpCgrid &A)
     for (int k = 0; k < CG_NIN; ++k) A.in[k] = CG.in[k];
     for (int k = 0; k < CG_NG; ++k) A.g[k] = CG.g[k];
     A.strengthU = CG.strengthU;
+    A.s12_in = nullptr;
     A.mask = CG.mask;
     A.img_slot = CG.img_slot;
     A.img_dst = CG.img_dst;
@@ -64,14 +67,53 @@ static void fill(EvpCgrid &A)
     A.plane = S.plane;
 }
 
-static void enqueue(const EvpCgrid &A, int ndte, bool first)
+static bool fused_schedule()
+{
+    if (CG.avg_strength) return false;           // needs deltaU at the neighbours: five phases
+    return !(env("CICE_EVP_HIP_CGRID_FUSED") && !std::atoi(env("CICE_EVP_HIP_CGRID_FUSED")));
+}
+
+// five launches per subcycle, any visc_method
+static void enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 {
     for (int k = 0; k < ndte; ++k) {
-        evp_launch_cgrid_phase(A, 0, S.stream);
+        evp_launch_cgrid_phase(A, 0, 1, S.stream);
         // the first strain_rates_U still reads the caller's ghost values of uvelN / vvelE
-        if (first && k == 0) evp_launch_cgrid_phase(A, 6, S.stream);
-        for (int ph = 1; ph <= 4; ++ph) evp_launch_cgrid_phase(A, ph, S.stream);
+        if (first && k == 0) evp_launch_cgrid_phase(A, 6, 1, S.stream);
+        for (int ph = 1; ph <= 4; ++ph) evp_launch_cgrid_phase(A, ph, 1, S.stream);
     }
+}
+
+// three launches per subcycle + one after the loop (evp_cgrid.hip); stress12U ping-pongs, returns with the
+// current values in `cur` (the caller swaps the pointers when ndte is odd)
+static int enqueue_fused(EvpCgrid A, int ndte, bool first)
+{
+    double *cur = CG.f[CF_S12U], *other = CG.s12alt;
+    if (first) {
+        // the caller's ghost cells of stress12U are whatever dyn_prep left there (zero: iceUmask is never set on
+        // ghost cells, ice_dyn_evp.F90:683-690); the reference repairs them with the first halo update, the fused
+        // kernel recomputes neighbours from their previous value: make the previous values ghost-consistent first
+        evp_launch_cgrid_phase(A, 9, CF_S12U, S.stream);
+        HIPC(hipMemcpyAsync(other, cur, S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    }
+    for (int k = 0; k < ndte; ++k) {
+        const int last = (k == ndte - 1);
+        A.f[CF_S12U] = cur;
+        if (first && k == 0) {
+            evp_launch_cgrid_phase(A, 0, 1, S.stream);
+            evp_launch_cgrid_phase(A, 6, 1, S.stream);
+        } else {
+            evp_launch_cgrid_phase(A, 7, last, S.stream);
+        }
+        evp_launch_cgrid_phase(A, 10, last, S.stream);
+        A.s12_in = cur;
+        A.f[CF_S12U] = other;
+        evp_launch_cgrid_phase(A, 8, last, S.stream);
+        std::swap(cur, other);
+    }
+    A.f[CF_S12U] = cur;
+    evp_launch_cgrid_phase(A, 4, 1, S.stream);
+    return 0;
 }
 
 }  // namespace evp_host
@@ -99,7 +141,7 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
         if (!static23[k]) return fail(-1, "null static array %d", k);
         if (alloc_d(&CG.g[k], S.n) || h2d(CG.g[k], static23[k])) return -1;
     }
-    if (alloc_d(&CG.strengthU, S.n)) return -1;
+    if (alloc_d(&CG.strengthU, S.n) || alloc_d(&CG.s12alt, S.n)) return -1;
     HIPC(hipMalloc((void **)&CG.mask, S.n));
     // ghost images: for every interior cell the ghost cells of this rank that mirror it (what ice_HaloUpdate copies)
     CG.h_img_slot.assign(S.n, -1);
@@ -118,6 +160,7 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
         dst[3 * slot + w] = P.local_dst[k];
     }
     if (dst.empty()) dst.assign(3, -1);
+    CG.h_img_dst = dst;
     HIPC(hipMalloc((void **)&CG.img_slot, S.n * sizeof(int)));
     HIPC(hipMalloc((void **)&CG.img_dst, dst.size() * sizeof(int)));
     HIPC(hipMemcpyAsync(CG.img_slot, CG.h_img_slot.data(), S.n * sizeof(int), hipMemcpyHostToDevice, S.stream));
@@ -150,12 +193,25 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
     for (size_t c = 0; c < S.n; ++c)
         CG.hmask[c] = (uint8_t)((iceTmask[c] ? 1 : 0) | (iceUmask[c] ? 2 : 0) | (iceEmask[c] ? 4 : 0) |
                                 (iceNmask[c] ? 8 : 0) | (CG.h_img_slot[c] >= 0 ? 16 : 0));
+    // bit5: iceU of an interior cell, handed on to the ghost cells that mirror it (the caller's iceUmask is not
+    // maintained on ghost cells: dyn_prep2 sets it on ilo..ihi x jlo..jhi only, ice_dyn_shared.F90:740-745)
+    const int nx = S.d.nx_block;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        for (int j = S.jlo[b]; j <= S.jhi[b]; ++j)
+            for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
+                const size_t c = (size_t)b * S.plane + (size_t)(j - 1) * nx + (i - 1);
+                if (!(CG.hmask[c] & 2)) continue;
+                CG.hmask[c] |= 32;
+                const int slot = CG.h_img_slot[c];
+                for (int k = 0; slot >= 0 && k < 3; ++k)
+                    if (CG.h_img_dst[3 * slot + k] >= 0) CG.hmask[CG.h_img_dst[3 * slot + k]] |= 32;
+            }
     HIPC(hipMemcpyAsync(CG.mask, CG.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
     CG.avg_strength = visc_method;
     if (visc_method == 1) {
         EvpCgrid A;
         fill(A);
-        evp_launch_cgrid_phase(A, 5, S.stream);
+        evp_launch_cgrid_phase(A, 5, 1, S.stream);
     }
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(S.stream));       // hmask is reused by the next upload
@@ -171,23 +227,34 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     if (ndte == 0) return 0;
     EvpCgrid A;
     fill(A);
+    const bool fused = fused_schedule();
+    auto enqueue = [&]() -> int {
+        if (fused) return enqueue_fused(A, ndte, CG.first);
+        enqueue_phases(A, ndte, CG.first);
+        return 0;
+    };
     HIPC(hipEventRecord(S.ev0, S.stream));
     if (S.use_graph) {
-        const std::pair<int, int> key(ndte, (CG.first ? 2 : 0) | CG.avg_strength);
+        const std::pair<int, int> key(ndte, (CG.flip << 3) | (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
         auto it = CG.graphs.find(key);
         if (it == CG.graphs.end()) {
             hipGraph_t gr = nullptr;
             hipGraphExec_t ex = nullptr;
             HIPC(hipStreamBeginCapture(S.stream, hipStreamCaptureModeThreadLocal));
-            enqueue(A, ndte, CG.first);
+            const int rc = enqueue();
             HIPC(hipStreamEndCapture(S.stream, &gr));
+            if (rc) return rc;
             HIPC(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
             (void)hipGraphDestroy(gr);
             it = CG.graphs.emplace(key, ex).first;
         }
         HIPC(hipGraphLaunch(it->second, S.stream));
-    } else {
-        enqueue(A, ndte, CG.first);
+    } else if (enqueue()) {
+        return -1;
+    }
+    if (fused && (ndte & 1)) {                   // the current stress12U is in the other allocation now
+        std::swap(CG.f[CF_S12U], CG.s12alt);
+        CG.flip ^= 1;
     }
     HIPC(hipEventRecord(S.ev1, S.stream));
     HIPC(hipGetLastError());

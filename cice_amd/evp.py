@@ -45,7 +45,7 @@ EXPORTS = [
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
-    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings",
+    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -158,6 +158,14 @@ def make_params(scal: dict, strict: bool = False) -> Params:
               "deltaminEVP", "u0", "cosw", "sinw", "rhow"):
         setattr(p, k, float(scal[k]))
     return p
+
+
+def stream_probe(ncells: int) -> float:
+    """Bytes/s of a plain 30-in / 16-out streaming kernel over `ncells` elements per array (see the header)."""
+    lib = load_library()
+    out = C.c_double(0.0)
+    _check(lib, lib.cice_evp_hip_stream_probe(C.c_int64(ncells), C.byref(out)), "(dyn_evp_hip_stream_probe)")
+    return out.value
 
 
 class EvpHip:

@@ -208,3 +208,97 @@ def make_primary(g: dict, case: str = "full", seed: int = 1) -> dict:
     static = dict(tmask=tmask.astype(np.int32), umask=umask.astype(np.int32), hm=g["hm"], tarea=g["tarea"],
                   uarea=g["uarea"], fcor_blk=2.0 * OMEGA * np.sin(g["ULAT"]))
     return dict(t=t, state=state, static=static)
+
+
+# ---- C-grid workloads: what evp()'s loop for grid_ice = 'C' reads, on the global grid ----------
+def cgrid_geometry(g: dict, deltaminEVP: float = 1e-11) -> dict:
+    """`g` from derive_geometry -> the 23 static arrays of cice_evp_hip_cgrid_set_geometry (E-W cyclic, closed in
+    y).  Lengths at the faces as in ice_grid.F90 (dyE = HTE, dxN = HTN; dxE, dyN through the cell centres), face
+    masks epm / npm = both neighbouring T-cells ocean (makemask), boundary-condition ratios as init_evp builds them
+    (ice_dyn_evp.F90:232-239)."""
+    dxT, dyT, hm = g["dxT"], g["dyT"], g["hm"]
+    n = lambda a: np.vstack([a[1:], a[-1:]])                 # (i, j+1), top row repeated
+    e = lambda a: np.roll(a, -1, axis=1)                     # (i+1, j), cyclic
+    dxN, dyE = g["HTN"], g["HTE"]
+    dxE = 0.5 * (dxT + e(dxT))
+    dyN = 0.5 * (dyT + n(dyT))
+    earea, narea = dxE * dyE, dxN * dyN
+    hm_n = np.vstack([hm[1:], np.zeros((1, hm.shape[1]))])
+    epm = np.minimum(hm, e(hm))
+    npm = np.minimum(hm, hm_n)
+    rxN = -e(dxN) / dxN
+    ryE = -n(dyE) / dyE
+    return dict(dxT=dxT, dyT=dyT, dxU=g["dxU"], dyU=g["dyU"], dxE=dxE, dyE=dyE, dxN=dxN, dyN=dyN, uarea=g["uarea"],
+                tarea=g["tarea"], earea=earea, narea=narea, earear=1.0 / earea, narear=1.0 / narea, epm=epm, npm=npm,
+                uvm=g["uvm"], hm=hm, DminTarea=deltaminEVP * g["tarea"], ratiodxN=rxN, ratiodxNr=1.0 / rxN,
+                ratiodyE=ryE, ratiodyEr=1.0 / ryE)
+
+
+def cgrid_state(g: dict, cg: dict, case: str = "full", dt: float = 3600.0, seed: int | None = None,
+                warm: bool = True, seabed: bool = False) -> dict:
+    """(state14, inputs23, masks4) of the C-grid loop: the same ice cover, forcing and currents as make_state, with
+    the momentum terms at the E and N faces (two-point averages of the T-cell fields, as dyn_prep2 leaves them)."""
+    nx, ny = g["nx"], g["ny"]
+    x = (np.arange(1, nx + 1) - 0.5)[None, :] / nx * np.ones((ny, 1))
+    y = (np.arange(1, ny + 1) - 0.5)[:, None] / ny * np.ones((1, nx))
+    tmask = g["tmask"]
+    aice = np.where(tmask, 0.95 * (1.0 - 0.04 * np.sin(2 * np.pi * x) * np.cos(4 * np.pi * y)), 0.0)
+    hi = 2.0 * (1.0 + 0.1 * np.sin(4 * np.pi * y) * np.cos(2 * np.pi * x))
+    if case == "caps":
+        aice = aice * np.clip((np.abs(y - 0.5) - 0.25) / 0.05, 0.0, 1.0)
+    elif case != "full":
+        raise ValueError(case)
+    if seed is not None:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        hi = hi * (1.0 + 0.01 * (2.0 * rng.random((ny, nx)) - 1.0))
+    vice = hi * aice
+    iceT = tmask & (aice > 1e-11)
+    strength = np.where(iceT, 2.75e4 * vice * np.exp(-20.0 * (1.0 - aice)), 0.0)
+    mass = RHOI * vice + RHOS * 0.2 * aice
+    n = lambda a: np.vstack([a[1:], a[-1:]])
+    e = lambda a: np.roll(a, -1, axis=1)
+    fcor = 2.0 * OMEGA * np.sin(g["ULAT"])
+    uocn = 0.2 * y - 0.1
+    vocn = -0.2 * x + 0.1
+    z = np.zeros((ny, nx))
+    out_in, masks = {"strength": strength}, {"iceTmask": iceT.astype(np.int32)}
+    vel = {}
+    for tag, sh, pm in (("E", e, cg["epm"]), ("N", n, cg["npm"])):
+        ai = 0.5 * (aice + sh(aice))
+        ms = 0.5 * (mass + sh(mass))
+        ice = (pm > 0.5) & (ai > 1e-11) & (ms > 1e-10)
+        fm = np.where(ice, fcor * ms, 0.0)
+        strair = ai * 0.1 * (np.sin(2 * np.pi * x) * np.sin(np.pi * y) if tag == "E" else np.sin(np.pi * x) * np.sin(2 * np.pi * y))
+        masks[f"ice{tag}mask"] = ice.astype(np.int32)
+        out_in[f"cdn_ocn{tag}"] = np.full((ny, nx), 0.00536)
+        out_in[f"ai{tag}"] = ai
+        out_in[f"uocn{tag}"] = uocn
+        out_in[f"vocn{tag}"] = vocn
+        out_in[("waterxE" if tag == "E" else "wateryN")] = np.where(ice, uocn if tag == "E" else vocn, 0.0)
+        out_in[("forcexE" if tag == "E" else "forceyN")] = np.where(ice, strair + (-fm * vocn if tag == "E" else fm * uocn), 0.0)
+        out_in[("emassdti" if tag == "E" else "nmassdti")] = np.where(ice, ms / dt, 0.0)
+        out_in[f"fm{tag}"] = fm
+        out_in[f"Tb{tag}"] = np.where(ice & (y < 0.2), 0.5 * ai, 0.0) if seabed else z.copy()
+        out_in[f"rheofact{tag}"] = np.where(ice, 1.0, 0.0)
+        vel[tag] = ice
+    iceU = g["umask"] & (0.25 * (aice + e(aice) + n(aice) + e(n(aice))) > 1e-11)
+    masks["iceUmask"] = iceU.astype(np.int32)
+    if warm:
+        uE = np.where(vel["E"], 0.05 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y), 0.0)
+        vN = np.where(vel["N"], 0.05 * np.cos(2 * np.pi * x) * np.sin(4 * np.pi * y), 0.0)
+        s0 = np.where(iceT, -0.1 * strength * (1.0 + 0.3 * np.sin(6 * np.pi * x)), 0.0)
+    else:
+        uE, vN, s0 = z.copy(), z.copy(), z.copy()
+    w = lambda a: np.roll(a, 1, axis=1)
+    s = lambda a: np.vstack([a[:1], a[:-1]])
+    ea, na = cg["earea"], cg["narea"]
+    # the other component at each face and the corner velocities, by the loop's own averages
+    uN = (w(uE) * w(ea) + uE * ea + n(w(uE)) * n(w(ea)) + n(uE) * n(ea)) / (w(ea) + ea + n(w(ea)) + n(ea)) * cg["npm"]
+    vE = (s(vN) * s(na) + s(e(vN)) * s(e(na)) + vN * na + e(vN) * e(na)) / (s(na) + s(e(na)) + na + e(na)) * cg["epm"]
+    uU = (uE * ea + n(uE) * n(ea)) / (ea + n(ea)) * g["uvm"]
+    vU = (vN * na + e(vN) * e(na)) / (na + e(na)) * g["uvm"]
+    state = dict(uvelE=uE, vvelE=vE, uvelN=uN, vvelN=vN, uvel=uU, vvel=vU, stresspT=s0, stressmT=0.1 * s0,
+                 stress12T=0.05 * s0, stress12U=np.where(iceU, 0.05 * 0.25 * (s0 + e(s0) + n(s0) + e(n(s0))), 0.0),
+                 strintxE=z.copy(), strintyN=z.copy(), taubxE=z.copy(), taubyN=z.copy())
+    out_in["uvelE_init"], out_in["vvelN_init"] = uE.copy(), vN.copy()
+    return state, out_in, masks

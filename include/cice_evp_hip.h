@@ -296,6 +296,10 @@ int cice_evp_hip_get_timings(double *out, int32_t n);
  * advanced: out3[0]=fused stress+stepu kernel ms, [1]=halo gather kernel ms,
  * [2]=back-to-back period of the fused kernel ms (launch gap included).        */
 int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
+/* Measurement aid (no state needed): bytes/s of a plain streaming kernel with the array shape of one B-grid subcycle
+ * (30 fp64 arrays in, 16 out, `ncells` elements each, every element touched once) -- what HBM gives a kernel of this
+ * shape on this device; the yardstick next to the 8 TB/s pin rate in bench.py's roofline block.                   */
+int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second);
 /* Per-CU record of the last on-chip resident launch with 16 x 16 tiles (tools): n <= 2048*8 ints, per CU
  * (index = XCC<<8 | HW_ID[15:8]) {lock, launch stamp, ice-holding waves on SIMD 0..3, 0, 0}.        */
 int cice_evp_hip_debug_cuload(int32_t *out, int32_t n);

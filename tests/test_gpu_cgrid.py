@@ -84,3 +84,75 @@ def test_cgrid_refuses_what_it_does_not_do():
                                                                    {k: z.astype(np.int32) for k in evp.CGRID_MASKS})
     finally:
         core.finalize()
+
+
+def synth_cgrid(grid_name, case="full", bs=None, seed=3, seabed=False):
+    from cice_amd import decomp, synth
+    spec = synth.GRIDS[grid_name]
+    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns="closed"))
+    cg = synth.cgrid_geometry(g)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed, seabed=seabed)
+    nx, ny = spec["nx"], spec["ny"]
+    bs = bs or (nx, ny)
+    dc = decomp.Decomp(nx, ny, bs[0], bs[1], "cyclic", "closed", 1)
+    ones = ("dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear", "narear",
+            "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr")
+    static = {k: dc.scatter(cg[k], 0, fill=(1.0 if k in ones else 0.0)) for k in evp.CGRID_STATIC}
+    state = {k: dc.scatter(v, 0) for k, v in state.items()}
+    inputs = {k: dc.scatter(v, 0) for k, v in inputs.items()}
+    masks = {k: dc.scatter(v, 0, fill=0) for k, v in masks.items()}
+    return dc, g, static, state, inputs, masks
+
+
+def run_both(dc, g, static, state, inputs, masks, ndte, visc_method="avg_zeta", scal_kw=None):
+    from cice_amd import synth
+    scal = synth.evp_scalars(120, **(scal_kw or {}))
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    want = oracle.cgrid_subcycle(dom, prm, ndte, state, inputs, static, masks, visc_method=visc_method)
+    d, keep = evp.make_dims(dc, 0)
+    ua = static["uarea"]
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / ua, static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        got = core.cgrid_run(ndte, state, inputs, masks, visc_method=visc_method)
+    finally:
+        core.finalize()
+    return got, want
+
+
+@pytest.mark.parametrize("grid,bs,case,visc,seabed", [("gx3", None, "full", "avg_zeta", False),
+                                                      ("gx3", (30, 40), "caps", "avg_strength", True),   # padded blocks
+                                                      ("gx1", None, "full", "avg_zeta", True),
+                                                      ("gx1", (80, 96), "caps", "avg_zeta", False)])
+def test_cgrid_synthetic_vs_oracle_bitwise(grid, bs, case, visc, seabed):
+    """Seeded synthetic workloads at the BASELINE sizes, one block and several (padded) blocks: every array of the
+    loop equal to the oracle's, bit for bit, after 24 subcycles."""
+    args = synth_cgrid(grid, case=case, bs=bs, seabed=seabed)
+    got, want = run_both(*args, ndte=24, visc_method=visc)
+    assert_bitwise(got, want, f"C grid {grid} {bs} {case} {visc}")
+    assert np.abs(want["uvelE"]).max() > 1e-3 and np.isfinite(want["stresspT"]).all()
+    assert int(args[5]["iceEmask"].sum()) > 0.2 * args[5]["iceEmask"].size * (0.3 if case == "caps" else 1.0)
+
+
+def test_cgrid_both_schedules_agree(monkeypatch):
+    """The five-launch schedule (CICE_EVP_HIP_CGRID_FUSED=0) and the fused three-launch one give the same bits
+    (the golden tests run the default; this one pins the other against the same fixture)."""
+    c = GoldenCase("cgrid_cyccyc_2x2_cap0_ktens")
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_FUSED", "0")
+    core = cgrid_core(c)
+    try:
+        state, inputs, masks = c.cgrid_inputs(1)
+        dom = c.oracle_domain()
+        for nsub in c.nsub_list:
+            out = core.cgrid_run(nsub, state, inputs, masks)
+            for k in ("strintxE", "strintyN"):
+                oracle.halo_update(dom, out[k], "center", "vector")
+            assert_bitwise(out, c.cgrid_expected(1, nsub), f"five-phase schedule nsub {nsub}")
+    finally:
+        core.finalize()

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""C-grid EVP subcycle on the GPU: microseconds per subcycle on the named synthetic grids (HIP events around the
+captured loop).  usage: tools/cgrid_timing.py [gx1 s01 ...] [--ndte 120] [--reps 5]"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from cice_amd import decomp, evp, synth  # noqa: E402
+
+
+def case(grid, case_="full"):
+    spec = synth.GRIDS[grid]
+    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns="closed"))
+    cg = synth.cgrid_geometry(g)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case_, seed=3)
+    dc = decomp.Decomp(spec["nx"], spec["ny"], spec["nx"], spec["ny"], "cyclic", "closed", 1)
+    ones = ("dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear", "narear",
+            "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr")
+    static = {k: dc.scatter(cg[k], 0, fill=(1.0 if k in ones else 0.0)) for k in evp.CGRID_STATIC}
+    return (dc, static, {k: dc.scatter(v, 0) for k, v in state.items()}, {k: dc.scatter(v, 0) for k, v in inputs.items()},
+            {k: dc.scatter(v, 0, fill=0) for k, v in masks.items()})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("grids", nargs="*", default=["gx1"])
+    ap.add_argument("--ndte", type=int, default=120)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--case", default="full")
+    a = ap.parse_args()
+    for grid in a.grids:
+        dc, static, state, inputs, masks = case(grid, a.case)
+        d, keep = evp.make_dims(dc, 0)
+        scal = synth.evp_scalars(a.ndte)
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                          1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        try:
+            core.cgrid_set_geometry(static)
+            core.cgrid_upload(state, inputs, masks)
+            ts = []
+            for r in range(a.reps + 1):
+                core.cgrid_subcycle(a.ndte)
+                core.cgrid_sync()
+                ts.append(core.cgrid_timings()["loop_ms"])
+            best = min(ts[1:])
+            ncell = dc.nx_global * dc.ny_global
+            nact = int(masks["iceTmask"].sum())
+            print(f"CGRID {grid} {a.case}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
+                  f"{ncell / (best * 1e-3 / a.ndte):.3e} cell-updates/s, active T {nact}/{ncell}", flush=True)
+        finally:
+            core.finalize()
+
+
+if __name__ == "__main__":
+    main()
