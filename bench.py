@@ -48,6 +48,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6        # dense fp64 vector peak with FMA; 39.3 with
 ALG_FLOP = 433.0
 CHECKPOINTS = [1, 3, 5, 12, 23, 25, 50]     # total steps after which tests/golden/bench_checksums.json holds a hash
 VERIFY_FIELDS = ("uvel", "vvel", "stressp_1")
+CGRID_VERIFY_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")   # tests/golden/make_bench_checksums.py
+CGRID_B_ALG = 648.0      # C grid: 81 fp64 array touches per cell and subcycle in the fused schedule
 
 
 def parse():
@@ -170,6 +172,15 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
                    paths=timed, host_cores=cores)
         if strict and run_ref.have_ref("strict"):
             out["reference_parity"] = reference_parity(nx, ny, ndte, case, td)
+        try:      # the same code with grid_ice = 'C' (next-tier row f-4), timed the same way
+            bx, by = best2d["bx"], best2d["by"]
+            tC = ref_run("fast", bx, by, best2d["threads"], 4, h_grid_ice="C")
+            if tC and tC > 0:
+                out["cgrid"] = dict(value=nx * ny * ndte * 4 / tC, unit="cell-updates/s", cores=best2d["threads"], kind="reference",
+                                    sample=f"reference evp() with grid_ice='C', {nx}x{ny} in {(nx // bx) * (ny // by)} blocks of {bx}x{by}, "
+                                           f"ndte={ndte}, 4 calls, timer_evp={tC:.2f}s")
+        except Exception as e:  # noqa: BLE001
+            out["cgrid"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         return out
     except Exception as e:  # noqa: BLE001
         print(f"[bench] reference CPU baseline unavailable ({type(e).__name__}: {e}); using the C port", file=sys.stderr)
@@ -360,6 +371,57 @@ def main():
                 else:
                     os.environ[k] = v
 
+    def cgrid_measure(workload, case, ndte, steps, warmup):
+        """The C-grid subcycle (evp()'s loop for grid_ice = 'C') on one GPU: `steps` timed loops of
+        `ndte` subcycles on the resident state, HIP events around each captured loop; the state after warmup + steps
+        loops is hashed against the oracle's committed checksum."""
+        spec = synth.GRIDS[workload]
+        nx, ny = spec["nx"], spec["ny"]
+        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+        cg = synth.cgrid_geometry(g)
+        state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=20260928, warm=True)
+        dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", "closed")
+        static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
+        n_active = int(masks["iceTmask"].sum())
+        scal = synth.evp_scalars(ndte)
+        d, keep = evp.make_dims(dc, 0)
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                          1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        try:
+            core.cgrid_set_geometry(static)
+            core.cgrid_upload(state, inputs, masks)
+            for _ in range(warmup):
+                core.cgrid_subcycle(ndte)
+            core.cgrid_sync()
+            t0 = time.perf_counter()
+            ev_ms = 0.0
+            for _ in range(steps):
+                core.cgrid_subcycle(ndte)
+                core.cgrid_sync()
+                ev_ms += core.cgrid_timings()["loop_ms"]
+            wall = time.perf_counter() - t0
+            out = core.cgrid_download()
+        finally:
+            core.finalize()
+        h = hashlib.sha256()
+        for k in CGRID_VERIFY_FIELDS:
+            h.update(np.ascontiguousarray(dc.gather({0: out[k]}), dtype="<f8").tobytes())
+        want = golden.get(f"cgrid/{workload}/{case}/ndte{ndte}/closed/strict", {}).get(str(warmup + steps))
+        launches = 3                              # fused schedule (evp_cgrid.hip): kernels per subcycle
+        t_sub = ev_ms * 1e-3 / (steps * ndte)
+        alg = CGRID_B_ALG * nx * ny
+        return {"workload": f"{workload} {nx}x{ny} C-grid EVP ndte={ndte}, case={case}, strict fp64, one GPU",
+                "value": nx * ny * ndte * steps / wall, "unit": "cell-updates/s", "steps": steps, "warmup": warmup,
+                "us_per_subcycle": 1e6 * t_sub, "us_per_subcycle_wall": 1e6 * wall / (steps * ndte),
+                "launches_per_subcycle": launches, "active_T_cells": n_active,
+                "verified": (h.hexdigest() == want["sha256"]) if want else None,
+                "checked_against": "tests/golden/bench_checksums.json (oracle/evp_oracle.c, pinned to the reference's evp() with grid_ice='C')" if want else None,
+                "finite": bool(np.isfinite(out["uvelE"]).all()), "max_abs_uE": float(np.abs(out["uvelE"]).max()),
+                "roofline": {"bound": "hbm", "achieved": alg / t_sub / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / t_sub / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_subcycle": alg,
+                             "note": "648 B per cell and subcycle = 81 fp64 array touches of the three fused kernels "
+                                     "(DESIGN.md section 9); on gx1 the 64 MB working set is Infinity-Cache resident"}}
+
     def per_call_cost(workload, case, ndte):
         """What CICE waits for per evp(): cice_evp_hip_run = H2D of 32 fields + loop + D2H of 18, page-locked arrays."""
         spec = synth.GRIDS[workload]
@@ -417,6 +479,10 @@ def main():
             M3 = measure("tx1", "full", 240, 10, 2, ns="tripole")
         except Exception as e:  # noqa: BLE001
             extra_err["tripole"] = f"{type(e).__name__}: {e}"[:300]
+        try:      # next-tier row f-4: the C-grid subcycle on the same grid
+            extra["cgrid"] = cgrid_measure("gx1", "full", 120, 3, 1)
+        except Exception as e:  # noqa: BLE001
+            extra_err["cgrid"] = f"{type(e).__name__}: {e}"[:300]
         try:
             extra["per_call_ms"] = per_call_cost(a.workload, a.case, ndte)
         except Exception as e:  # noqa: BLE001
@@ -439,6 +505,13 @@ def main():
             if traffic:
                 blk["measured_traffic_GBps"] = traffic / tk / 1e9
                 blk["pmc_source"] = f"{pmc_file}#{pmc_key}"
+            try:      # what a plain streaming kernel of the same array shape (30 in, 16 out) reaches on this box, live
+                ceil = evp.stream_probe(my) / 1e9
+                blk["stream_ceiling"] = {"GBps": ceil, "frac_of_ceiling": alg / tk / 1e9 / ceil,
+                                         "note": "cice_evp_hip_stream_probe: 30 fp64 arrays in, 16 out, same cell count, "
+                                                 "no arithmetic; the practical HBM rate for this access shape"}
+            except Exception as e:  # noqa: BLE001
+                blk["stream_ceiling"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             return blk
 
         cells = nx * ny

@@ -30,7 +30,7 @@ module ice_dyn_evp_hip
   private
 
   public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body, &
-            dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses
+            dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses, dyn_evp_hip_cgrid_run
 
   ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
   type, bind(C) :: cice_evp_hip_dims
@@ -183,6 +183,20 @@ module ice_dyn_evp_hip
        import :: c_int
      end function cice_evp_hip_invalidate_stresses
 
+     integer(c_int) function cice_evp_hip_cgrid_set_geometry(static23) bind(C, name='cice_evp_hip_cgrid_set_geometry')
+       import :: c_int, c_ptr
+       type(c_ptr), dimension(23), intent(in) :: static23
+     end function cice_evp_hip_cgrid_set_geometry
+
+     integer(c_int) function cice_evp_hip_cgrid_run(ndte, visc_method, fields19, inputs23, iceTmask, iceUmask, &
+                                                    iceEmask, iceNmask) bind(C, name='cice_evp_hip_cgrid_run')
+       import :: c_int, c_int32_t, c_ptr
+       integer(c_int32_t), value :: ndte, visc_method
+       type(c_ptr), dimension(19), intent(in) :: fields19
+       type(c_ptr), dimension(23), intent(in) :: inputs23
+       integer(c_int32_t), dimension(*), intent(in) :: iceTmask, iceUmask, iceEmask, iceNmask
+     end function cice_evp_hip_cgrid_run
+
      integer(c_int) function cice_evp_hip_download(fields32) bind(C, name='cice_evp_hip_download')
        import :: c_int, c_ptr
        type(c_ptr), dimension(32), intent(in) :: fields32
@@ -198,6 +212,7 @@ module ice_dyn_evp_hip
   ! in the environment restores the copy-in/copy-out behaviour of dyn_evp1d_run.
   logical :: stress_resident = .true.
   logical :: on_tripole = .false.
+  logical :: cgrid_geometry_set = .false.
 
 contains
 
@@ -555,6 +570,78 @@ contains
     end subroutine pin_all
 
   end subroutine dyn_evp_hip_run
+
+!-----------------------------------------------------------------------
+! C grid (grid_ice = 'C'): replaces the subcycle loop of evp(), ice_dyn_evp.F90:938-1099 -- everything between
+! "do ksub = 1,ndte" and its "enddo" (strain_rates_U .. the last dyn_haloUpdate of uvel, vvel).  The loop's
+! operands are private module arrays of ice_dyn_evp, so the call is made from inside evp() (INTEGRATION.md has the
+! patch); ice_grid / ice_dyn_shared / ice_flux / ice_state data are taken from their modules here.
+! The arguments are exactly the private arrays the loop touches.  evp() continues with deformationsC_T and its own
+! halo update of strintxE / strintyN as before.
+  subroutine dyn_evp_hip_cgrid_run(uocnE, vocnE, cdn_ocnE, waterxE, forcexE, aiE, rheofactE, emassdti, &
+                                   uocnN, vocnN, cdn_ocnN, wateryN, forceyN, aiN, rheofactN, nmassdti, &
+                                   ratiodxN, ratiodxNr, ratiodyE, ratiodyEr,                           &
+                                   zetax2T, etax2T, etax2U, shearU, deltaU)
+
+    use ice_dyn_shared, only: ndte, visc_method, DminTarea, uvelE_init, vvelN_init, &
+                              iceTmask, iceUmask, iceEmask, iceNmask
+    use ice_grid, only: dxT, dyT, dxU, dyU, dxE, dyE, dxN, dyN, uarea, tarea, earea, narea, earear, narear, &
+                        epm, npm, uvm, hm
+    use ice_state, only: uvel, vvel, uvelE, vvelE, uvelN, vvelN, strength
+    use ice_flux, only: stresspT, stressmT, stress12T, stress12U, strintxE, strintyN, taubxE, taubyN, &
+                        fmE, fmN, TbE, TbN
+    use ice_timers, only: ice_timer_start, ice_timer_stop, timer_evp1dcore
+
+    real(kind=dbl_kind), dimension(:,:,:), intent(in), contiguous, target :: &
+      uocnE, vocnE, cdn_ocnE, waterxE, forcexE, aiE, rheofactE, emassdti, &
+      uocnN, vocnN, cdn_ocnN, wateryN, forceyN, aiN, rheofactN, nmassdti, &
+      ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
+    real(kind=dbl_kind), dimension(:,:,:), intent(inout), contiguous, target :: &
+      zetax2T, etax2T, etax2U, shearU, deltaU
+
+    type(c_ptr) :: st(23), fl(19), inp(23)
+    integer(c_int32_t), pointer :: mT(:), mU(:), mE(:), mN(:)
+    integer(c_int32_t) :: vm
+    character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_run)'
+
+    if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
+         file=__FILE__, line=__LINE__)
+    if (.not. cgrid_geometry_set) then
+       st = [cice_evp_hip_addr(dxT), cice_evp_hip_addr(dyT), cice_evp_hip_addr(dxU), cice_evp_hip_addr(dyU), &
+             cice_evp_hip_addr(dxE), cice_evp_hip_addr(dyE), cice_evp_hip_addr(dxN), cice_evp_hip_addr(dyN), &
+             cice_evp_hip_addr(uarea), cice_evp_hip_addr(tarea), cice_evp_hip_addr(earea), cice_evp_hip_addr(narea), &
+             cice_evp_hip_addr(earear), cice_evp_hip_addr(narear), cice_evp_hip_addr(epm), cice_evp_hip_addr(npm), &
+             cice_evp_hip_addr(uvm), cice_evp_hip_addr(hm), cice_evp_hip_addr(DminTarea), &
+             c_loc(ratiodxN), c_loc(ratiodxNr), c_loc(ratiodyE), c_loc(ratiodyEr)]
+       call check(cice_evp_hip_cgrid_set_geometry(st), subname, __FILE__, __LINE__)
+       cgrid_geometry_set = .true.
+    endif
+    if (trim(visc_method) == 'avg_zeta') then
+       vm = 0
+    elseif (trim(visc_method) == 'avg_strength') then
+       vm = 1
+    else
+       call abort_ice(subname//' ERROR: unknown visc_method '//trim(visc_method), file=__FILE__, line=__LINE__)
+    endif
+    fl = [cice_evp_hip_addr(uvelE), cice_evp_hip_addr(vvelE), cice_evp_hip_addr(uvelN), cice_evp_hip_addr(vvelN), &
+          cice_evp_hip_addr(uvel), cice_evp_hip_addr(vvel), cice_evp_hip_addr(stresspT), cice_evp_hip_addr(stressmT), &
+          cice_evp_hip_addr(stress12T), cice_evp_hip_addr(stress12U), cice_evp_hip_addr(strintxE), &
+          cice_evp_hip_addr(strintyN), cice_evp_hip_addr(taubxE), cice_evp_hip_addr(taubyN), &
+          c_loc(zetax2T), c_loc(etax2T), c_loc(etax2U), c_loc(shearU), c_loc(deltaU)]
+    inp = [cice_evp_hip_addr(strength), c_loc(cdn_ocnE), c_loc(aiE), c_loc(uocnE), c_loc(vocnE), c_loc(waterxE), &
+           c_loc(forcexE), c_loc(emassdti), cice_evp_hip_addr(fmE), cice_evp_hip_addr(uvelE_init), &
+           cice_evp_hip_addr(TbE), c_loc(rheofactE), c_loc(cdn_ocnN), c_loc(aiN), c_loc(uocnN), c_loc(vocnN), &
+           c_loc(wateryN), c_loc(forceyN), c_loc(nmassdti), cice_evp_hip_addr(fmN), cice_evp_hip_addr(vvelN_init), &
+           cice_evp_hip_addr(TbN), c_loc(rheofactN)]
+    call c_f_pointer(cice_evp_hip_addr(iceTmask), mT, [size(iceTmask)])
+    call c_f_pointer(cice_evp_hip_addr(iceUmask), mU, [size(iceUmask)])
+    call c_f_pointer(cice_evp_hip_addr(iceEmask), mE, [size(iceEmask)])
+    call c_f_pointer(cice_evp_hip_addr(iceNmask), mN, [size(iceNmask)])
+    call ice_timer_start(timer_evp1dcore)
+    call check(cice_evp_hip_cgrid_run(int(ndte, c_int32_t), vm, fl, inp, mT, mU, mE, mN), subname, __FILE__, __LINE__)
+    call ice_timer_stop(timer_evp1dcore)
+
+  end subroutine dyn_evp_hip_cgrid_run
 
 !-----------------------------------------------------------------------
 ! ice_flux's stress arrays <- the device copy.  Call before anything but evp() reads them (restart write,

@@ -302,3 +302,14 @@ def cgrid_state(g: dict, cg: dict, case: str = "full", dt: float = 3600.0, seed:
                  strintxE=z.copy(), strintyN=z.copy(), taubxE=z.copy(), taubyN=z.copy())
     out_in["uvelE_init"], out_in["vvelN_init"] = uE.copy(), vN.copy()
     return state, out_in, masks
+
+
+CGRID_FILL_ONE = ("dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear",
+                  "narear", "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr")
+
+
+def cgrid_scatter(dc, rank: int, cg: dict, state: dict, inputs: dict, masks: dict):
+    """Global C-grid workload -> the block arrays of `rank` (lengths and areas 1 where a ghost cell has no source)."""
+    static = {k: dc.scatter(v, rank, fill=(1.0 if k in CGRID_FILL_ONE else 0.0)) for k, v in cg.items()}
+    return (static, {k: dc.scatter(v, rank) for k, v in state.items()}, {k: dc.scatter(v, rank) for k, v in inputs.items()},
+            {k: dc.scatter(v, rank, fill=0) for k, v in masks.items()})

@@ -69,9 +69,54 @@ def run(workload):
     return f"{workload}/{case}/ndte{ndte}/{ns}/strict", res
 
 
+CGRID_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")      # bench.py CGRID_VERIFY_FIELDS
+CGRID_CONFIGS = {"gx3": ("full", 120, [1, 4]), "gx1": ("full", 120, [1, 4])}
+
+
+def cgrid_inputs(workload, case):
+    """The C-grid workload of bench.py (shared: bench.py imports nothing from here, it builds the same through synth)."""
+    spec = synth.GRIDS[workload]
+    nx, ny = spec["nx"], spec["ny"]
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+    cg = synth.cgrid_geometry(g)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=20260928, warm=True)
+    dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", "closed")
+    return dc, synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
+
+
+def run_cgrid(workload):
+    case, ndte, cps = CGRID_CONFIGS[workload]
+    dc, (static, state, inputs, masks) = cgrid_inputs(workload, case)
+    scal = synth.evp_scalars(ndte)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i",
+                                                      "capping", "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    res, done = {}, 0
+    cur = dict(state)
+    for n in cps:
+        t0 = time.time()
+        out = oracle.cgrid_subcycle(dom, prm, (n - done) * ndte, cur, inputs, static, masks)
+        done = n
+        cur = {k: out[k] for k in oracle.C_FIELDS}      # work arrays carry over too (same as the resident GPU state)
+        h = hashlib.sha256()
+        for k in CGRID_FIELDS:
+            h.update(np.ascontiguousarray(dc.gather({0: out[k]}), dtype="<f8").tobytes())
+        res[str(n)] = dict(sha256=h.hexdigest(), max_abs_uE=float(np.abs(out["uvelE"]).max()))
+        print(f"cgrid {workload} N={n}: {res[str(n)]['sha256'][:16]} max|uE| {res[str(n)]['max_abs_uE']:.6f} ({time.time() - t0:.1f} s)", flush=True)
+    return f"cgrid/{workload}/{case}/ndte{ndte}/closed/strict", res
+
+
 if __name__ == "__main__":
     allres = json.loads(OUT.read_text()) if OUT.exists() else {}
-    for w in (sys.argv[1:] or ["gx3", "gx1"]):
+    args = sys.argv[1:] or ["gx3", "gx1"]
+    for w in [x[6:] for x in args if x.startswith("cgrid:")]:
+        key, res = run_cgrid(w)
+        allres[key] = res
+        OUT.write_text(json.dumps(allres, indent=1, sort_keys=True))
+    for w in [x for x in args if not x.startswith("cgrid:")]:
         key, res = run(w)
         allres[key] = res
         OUT.write_text(json.dumps(allres, indent=1, sort_keys=True))
