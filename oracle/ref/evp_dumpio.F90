@@ -88,4 +88,23 @@ contains
     call dump_r8_3d(name, pk, nb)
   end subroutine dump_peek
 
+  ! the same array as a Fortran pointer (drop-in check of the C-grid entry: the harness hands the module-private
+  ! operands of the loop to dyn_evp_hip_cgrid_run exactly as a call from inside evp() would)
+  function peek_array(which, n1, n2, n3) result(pk)
+    use, intrinsic :: iso_c_binding, only: c_ptr, c_f_pointer, c_int, c_associated
+    integer(int_kind), intent(in) :: which, n1, n2, n3
+    real(dbl_kind), pointer :: pk(:,:,:)
+    interface
+       function evp_peek_base(w) bind(C, name='evp_peek_base') result(p)
+         use, intrinsic :: iso_c_binding
+         integer(c_int), value :: w
+         type(c_ptr) :: p
+       end function evp_peek_base
+    end interface
+    type(c_ptr) :: p
+    p = evp_peek_base(int(which, c_int))
+    if (.not. c_associated(p)) stop 'evp_peek_base: unknown or unallocated array'
+    call c_f_pointer(p, pk, [n1, n2, n3])
+  end function peek_array
+
 end module evp_dumpio

@@ -28,7 +28,10 @@ module evp_cgrid_capture
   use ice_flux
   use ice_calendar, only: dt_dyn
   use ice_dyn_shared
-  use ice_dyn_evp, only: evp
+  use ice_dyn_evp, only: evp, ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
+#ifdef HARNESS_HIP_BODY
+  use ice_dyn_evp_hip, only: dyn_evp_hip_cgrid_run
+#endif
   use evp_dumpio
   implicit none
   real(dbl_kind), allocatable, dimension(:,:,:), private :: c_uE, c_vN, c_uN, c_vE, c_spT, c_smT, c_s12T, c_s12U, c_u, c_v
@@ -37,8 +40,9 @@ contains
   ! ---- C grid: the subcycle inputs are module-private; a preparation-only evp() (ndte = 0) leaves them in place,
   !      evp_peek.c reads them; the very next evp() calls from the same state give the reference's outputs ----
 
-  subroutine cgrid_call(ic, nsub_list, nl, h_ndte)
+  subroutine cgrid_call(ic, nsub_list, nl, h_ndte, hipmode)
     integer(int_kind), intent(in) :: ic, nsub_list(:), nl, h_ndte
+    logical, intent(in) :: hipmode
     integer(int_kind) :: kk, ns
     character(len=16) :: tg
     if (.not. allocated(c_uE)) then
@@ -76,6 +80,41 @@ contains
     call dump_peek(trim(tg)//'_rheofactN', 15, nx_block, ny_block, max_blocks, nblocks); call dump_peek(trim(tg)//'_nmassdti', 16, nx_block, ny_block, max_blocks, nblocks)
     c_uE = uvelE; c_vN = vvelN; c_uN = uvelN; c_vE = vvelE; c_u = uvel; c_v = vvel
     c_spT = stresspT; c_smT = stressmT; c_s12T = stress12T; c_s12U = stress12U
+    ! (the device runs come first: the reference's last run below leaves the state the next call continues from)
+#ifdef HARNESS_HIP_BODY
+    if (hipmode) then
+       ! the HIP loop through the Fortran entry a patched evp() would call (INTEGRATION.md, C grid): same start
+       ! state, preparation by the reference (ndte = 0), then the loop on the device
+       do kk = 1, nl
+          ns = nsub_list(kk)
+          uvelE = c_uE; vvelN = c_vN; uvelN = c_uN; vvelE = c_vE; uvel = c_u; vvel = c_v
+          stresspT = c_spT; stressmT = c_smT; stress12T = c_s12T; stress12U = c_s12U
+          ndte = 0
+          call evp(dt_dyn)
+          ndte = ns
+          call dyn_evp_hip_cgrid_run( &
+               pk3(1), pk3(2), pk3(3), pk3(4), pk3(5), pk3(6), pk3(7), pk3(8), &
+               pk3(9), pk3(10), pk3(11), pk3(12), pk3(13), pk3(14), pk3(15), pk3(16), &
+               ratiodxN, ratiodxNr, ratiodyE, ratiodyEr, pk3(17), pk3(18), pk3(19), pk3(20), pk3(21))
+          ndte = h_ndte
+          write(tg,'(a,i2.2,a,i4.4)') 'h', ic, 'n', ns
+          call dump_r8_3d(trim(tg)//'_uvelE', uvelE, nblocks);   call dump_r8_3d(trim(tg)//'_vvelE', vvelE, nblocks)
+          call dump_r8_3d(trim(tg)//'_uvelN', uvelN, nblocks);   call dump_r8_3d(trim(tg)//'_vvelN', vvelN, nblocks)
+          call dump_r8_3d(trim(tg)//'_uvel', uvel, nblocks);     call dump_r8_3d(trim(tg)//'_vvel', vvel, nblocks)
+          call dump_r8_3d(trim(tg)//'_stresspT', stresspT, nblocks);   call dump_r8_3d(trim(tg)//'_stressmT', stressmT, nblocks)
+          call dump_r8_3d(trim(tg)//'_stress12T', stress12T, nblocks); call dump_r8_3d(trim(tg)//'_stress12U', stress12U, nblocks)
+          call dump_r8_3d(trim(tg)//'_strintxE', strintxE, nblocks);   call dump_r8_3d(trim(tg)//'_strintyN', strintyN, nblocks)
+          call dump_r8_3d(trim(tg)//'_taubxE', taubxE, nblocks);       call dump_r8_3d(trim(tg)//'_taubyN', taubyN, nblocks)
+          call dump_peek(trim(tg)//'_zetax2T', 17, nx_block, ny_block, max_blocks, nblocks)
+          call dump_peek(trim(tg)//'_etax2T', 18, nx_block, ny_block, max_blocks, nblocks)
+          call dump_peek(trim(tg)//'_etax2U', 19, nx_block, ny_block, max_blocks, nblocks)
+          call dump_peek(trim(tg)//'_shearU', 20, nx_block, ny_block, max_blocks, nblocks)
+          call dump_peek(trim(tg)//'_deltaU', 21, nx_block, ny_block, max_blocks, nblocks)
+          write(*,'(a,i3,a,i5,3es24.16)') 'Hcall', ic, ' nsub', ns, &
+               maxval(abs(uvelE(:,:,1:nblocks))), maxval(abs(vvelN(:,:,1:nblocks))), maxval(abs(stresspT(:,:,1:nblocks)))
+       enddo
+    endif
+#endif
     do kk = 1, nl
        ns = nsub_list(kk)
        uvelE = c_uE; vvelN = c_vN; uvelN = c_uN; vvelE = c_vE; uvel = c_u; vvel = c_v
@@ -97,6 +136,12 @@ contains
             maxval(abs(uvelE(:,:,1:nblocks))), maxval(abs(vvelN(:,:,1:nblocks))), maxval(abs(stresspT(:,:,1:nblocks)))
     enddo
   end subroutine cgrid_call
+
+  function pk3(which) result(p)
+    integer(int_kind), intent(in) :: which
+    real(dbl_kind), pointer, contiguous :: p(:,:,:)
+    p => peek_array(which, nx_block, ny_block, max_blocks)
+  end function pk3
 end module evp_cgrid_capture
 
 program evp_ref_harness
@@ -370,7 +415,7 @@ program evp_ref_harness
   do icall = 1, ncalls
 
      if (trim(grid_ice) == 'C') then
-        call cgrid_call(icall, nsub_list, nl, h_ndte)
+        call cgrid_call(icall, nsub_list, nl, h_ndte, hipmode)
         cycle
      endif
 

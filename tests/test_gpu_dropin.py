@@ -71,3 +71,46 @@ def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw
                 checked += 1
     assert np.abs(d["o02n0120_uvel"]).max() > 1e-3
     assert checked == 2 * 2 * (2 * len(FIELDS) + len(DOWNSTREAM))
+
+
+CGRID_LOOP_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
+                     "taubxE", "taubyN", "zetax2T", "etax2T", "etax2U", "shearU", "deltaU"]
+CGRID_CASES = [
+    (40, 36, 20, 18, "cyclic", dict(icecase="full")),
+    (60, 44, 20, 15, "cyclic", dict(icecase="patchy", h_visc_method="avg_strength", h_capping=0.5)),
+    (64, 48, 64, 48, "closed", dict(icecase="full", h_revised=True, h_seabed=True)),
+]
+
+
+@pytest.mark.parametrize("nx,ny,bx,by,ew,kw", CGRID_CASES)
+def test_reference_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, ew, kw):
+    """C grid: the reference's own driver and preparation (evp() with ndte = 0), then the subcycle loop through the
+    Fortran entry a patched evp() calls -- dyn_evp_hip_cgrid_run(<ice_dyn_evp's private arrays>) -> ISO_C_BINDING
+    -> cice_evp_hip_cgrid_run -> HIP -- against the reference's evp() with grid_ice = 'C' from the same state, in
+    the same process.  Every array the loop writes, every cell, ghost cells included; strintxE / strintyN on the
+    cells the loop writes (evp() halo-updates them afterwards, ice_dyn_evp.F90:1437-1440)."""
+    if not run_ref.have_ref("hip_dropin"):
+        pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns="closed")
+    run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+    run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
+    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns="closed", variant="hip_dropin", h_ndte=120, ncalls=2,
+                                 nsub_list=[1, 120], hipmode=True, h_grid_ice="C", grid_kind="popfile",
+                                 grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
+    nb = int(d["dims"][2])
+    bi = np.asarray(d["blkinfo"]).reshape(nb, 8)
+    interior = np.zeros(d["o01n0001_uvelE"].shape, bool)
+    for b in range(nb):
+        interior[b, bi[b, 2] - 1:bi[b, 3], bi[b, 0] - 1:bi[b, 1]] = True
+    checked = 0
+    for icall in (1, 2):
+        for nsub in (1, 120):
+            for f in CGRID_LOOP_FIELDS + ["strintxE", "strintyN"]:
+                hip = d[f"h{icall:02d}n{nsub:04d}_{f}"]
+                ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
+                m = interior if f.startswith("strint") else np.ones_like(interior)
+                assert np.array_equal(hip[m], ref[m]), (
+                    f"C grid call {icall} nsub {nsub} {f}: {int((hip[m] != ref[m]).sum())} cells differ, "
+                    f"max|d|={np.abs(hip - ref)[m].max():.3e}")
+                checked += 1
+    assert np.abs(d["o02n0120_uvelE"]).max() > 1e-3 and checked == 2 * 2 * (len(CGRID_LOOP_FIELDS) + 2)
