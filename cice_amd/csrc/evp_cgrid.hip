@@ -474,7 +474,24 @@ __global__ __launch_bounds__(TX *TY) void cg_zero_outside(EvpCgrid A)
     A.f[CF_VU][c.o] = 0.0;
 }
 
+// ---- ghost cells whose neighbour block was eliminated (land): ice_HaloUpdate fills them with zero at every
+// exchange (ice_boundary.F90, fill value); nothing pushes into them, so they are zeroed once, in the first subcycle ----
+__global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int c = cells[k];
+    const int fld[9] = {CF_UE, CF_VE, CF_UN, CF_VN, CF_UU, CF_VU, CF_SP, CF_SM, CF_S12U};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) A.f[fld[q]][c] = 0.0;
+}
+
 }  // namespace
+
+void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(cg_zero_cells, dim3((n + 255) / 256), dim3(256), 0, st, A, cells, n);
+}
 
 void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st)
 {

@@ -21,6 +21,8 @@ struct CGridState {
     int flip = 0;                // which of the two allocations f[CF_S12U] is (part of the graph key)
     uint8_t *mask = nullptr;
     int *img_slot = nullptr, *img_dst = nullptr;
+    int *zero_cells = nullptr;   // ghost cells of eliminated (land) neighbour blocks
+    int n_zero = 0;
     std::vector<int> h_img_slot, h_img_dst;
     std::vector<uint8_t> hmask;
     int avg_strength = 0;
@@ -40,7 +42,7 @@ void cgrid_free()
     for (auto &p : CG.f) F(p);
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
-    F(CG.strengthU); F(CG.s12alt); F(CG.mask); F(CG.img_slot); F(CG.img_dst);
+    F(CG.strengthU); F(CG.s12alt); F(CG.mask); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells);
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
     CG.graphs.clear();
     CG = CGridState();
@@ -79,7 +81,10 @@ static void enqueue_phases(const EvpCgrid &A, int ndte, bool first)
     for (int k = 0; k < ndte; ++k) {
         evp_launch_cgrid_phase(A, 0, 1, S.stream);
         // the first strain_rates_U still reads the caller's ghost values of uvelN / vvelE
-        if (first && k == 0) evp_launch_cgrid_phase(A, 6, 1, S.stream);
+        if (first && k == 0) {
+            evp_launch_cgrid_phase(A, 6, 1, S.stream);
+            evp_launch_cgrid_zero_cells(A, CG.zero_cells, CG.n_zero, S.stream);
+        }
         for (int ph = 1; ph <= 4; ++ph) evp_launch_cgrid_phase(A, ph, 1, S.stream);
     }
 }
@@ -94,6 +99,8 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         // ghost cells, ice_dyn_evp.F90:683-690); the reference repairs them with the first halo update, the fused
         // kernel recomputes neighbours from their previous value: make the previous values ghost-consistent first
         evp_launch_cgrid_phase(A, 9, CF_S12U, S.stream);
+        // (ghost cells of eliminated land blocks: zero in both buffers; no ice cell reads them before the first exchange)
+        evp_launch_cgrid_zero_cells(A, CG.zero_cells, CG.n_zero, S.stream);
         HIPC(hipMemcpyAsync(other, cur, S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
     }
     for (int k = 0; k < ndte; ++k) {
@@ -145,10 +152,13 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMalloc((void **)&CG.mask, S.n));
     // ghost images: for every interior cell the ghost cells of this rank that mirror it (what ice_HaloUpdate copies)
     CG.h_img_slot.assign(S.n, -1);
-    std::vector<int> dst;
+    std::vector<int> dst, zero;
     for (size_t k = 0; k < P.local_dst.size(); ++k) {
         const int src = P.local_src[k];
-        if (src < 0) continue;                      // neighbour block eliminated (land): stays as the caller left it
+        if (src < 0) {                              // neighbour block eliminated (land): the reference fills with zero
+            zero.push_back(P.local_dst[k]);
+            continue;
+        }
         int &slot = CG.h_img_slot[src];
         if (slot < 0) {
             slot = (int)(dst.size() / 3);
@@ -165,6 +175,11 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMalloc((void **)&CG.img_dst, dst.size() * sizeof(int)));
     HIPC(hipMemcpyAsync(CG.img_slot, CG.h_img_slot.data(), S.n * sizeof(int), hipMemcpyHostToDevice, S.stream));
     HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    CG.n_zero = (int)zero.size();
+    if (CG.n_zero) {
+        HIPC(hipMalloc((void **)&CG.zero_cells, zero.size() * sizeof(int)));
+        HIPC(hipMemcpyAsync(CG.zero_cells, zero.data(), zero.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    }
     HIPC(hipStreamSynchronize(S.stream));
     CG.hmask.assign(S.n, 0);
     CG.geo = true;
