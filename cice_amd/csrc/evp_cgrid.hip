@@ -474,6 +474,22 @@ __global__ __launch_bounds__(TX *TY) void cg_zero_outside(EvpCgrid A)
     A.f[CF_VU][c.o] = 0.0;
 }
 
+// ---- ranks > 1: iceU of interior cells as 0/1 doubles (exchanged like a field), and back into bit5 of the mask for the
+// ghost cells that mirror cells of other ranks ----
+__global__ __launch_bounds__(TX *TY) void cg_umask_to_double(EvpCgrid A, double *d)
+{
+    const Cell c = cell(A);
+    if (!c.in) return;
+    const bool interior = c.i >= c.q.x && c.i <= c.q.y && c.j >= c.q.z && c.j <= c.q.w;
+    d[c.o] = (interior && (A.mask[c.o] & 2u)) ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(TX *TY) void cg_bit5_from_double(EvpCgrid A, const double *d, uint8_t *mask)
+{
+    const Cell c = cell(A);
+    if (!c.in) return;
+    if (d[c.o] != 0.0) mask[c.o] |= 32u;
+}
+
 // ---- ghost cells whose neighbour block was eliminated (land): ice_HaloUpdate fills them with zero at every
 // exchange (ice_boundary.F90, fill value); nothing pushes into them, so they are zeroed once, in the first subcycle ----
 __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
@@ -491,6 +507,13 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st)
 {
     if (n > 0) hipLaunchKernelGGL(cg_zero_cells, dim3((n + 255) / 256), dim3(256), 0, st, A, cells, n);
+}
+
+void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStream_t st)
+{
+    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    if (!back) hipLaunchKernelGGL(cg_umask_to_double, grid, block, 0, st, A, scratch);
+    else hipLaunchKernelGGL(cg_bit5_from_double, grid, block, 0, st, A, scratch, const_cast<uint8_t *>(A.mask));
 }
 
 void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st)

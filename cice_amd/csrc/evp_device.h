@@ -263,4 +263,5 @@ struct EvpCgrid {
 //        9 copy field `last` into its ghost images
 // last: the launch belongs to the last subcycle of a call (arrays nobody reads inside the loop are stored only then)
 void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st);
+void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStream_t st);
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st);

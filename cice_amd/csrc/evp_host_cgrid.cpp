@@ -4,10 +4,11 @@
 //
 // Replaces evp()'s loop for grid_ice = 'C' (ice_dyn_evp.F90:938-1099).  The caller has run the reference's own
 // preparation (dyn_prep1/2 at U, N and E points, seabed stress, the grid averages of the forcing) and hands over
-// what the loop reads; it gets back what the loop writes.  One rank, cyclic / closed / open boundaries; several
-// blocks per rank are fine (their ghost cells are images like any other).  Neighbours on other ranks and the
-// tripole fold are refused loudly (the B-grid path has both; the C-grid loop exchanges six field groups per
-// subcycle, not one).
+// what the loop reads; it gets back what the loop writes.  Cyclic / closed / open boundaries; any number of blocks
+// per rank (their ghost cells are images like any other).  Ghost cells that mirror cells of OTHER ranks are filled
+// by the B-grid path's velocity exchange (halo_remote_pair: mailbox stores over xGMI, or RCCL point-to-point) run on
+// pairs of the loop's arrays after the launch that produces them -- the same points at which the reference calls
+// ice_HaloUpdate.  The tripole fold is refused loudly (E/N-face fold rules: not built).
 // =====================================================================
 #include "evp_host.h"
 
@@ -17,6 +18,7 @@ struct CGridState {
     bool geo = false, uploaded = false;
     double *f[CG_NF] = {}, *in[CG_NIN] = {}, *g[CG_NG] = {};
     double *strengthU = nullptr;
+    double *umaskd = nullptr;    // ranks > 1: iceU as a field, to learn the flags of ghost cells other ranks own
     double *s12alt = nullptr;    // second stress12U buffer of the fused schedule (f[CF_S12U] always holds the current one)
     int flip = 0;                // which of the two allocations f[CF_S12U] is (part of the graph key)
     uint8_t *mask = nullptr;
@@ -42,7 +44,7 @@ void cgrid_free()
     for (auto &p : CG.f) F(p);
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
-    F(CG.strengthU); F(CG.s12alt); F(CG.mask); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells);
+    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.mask); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells);
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
     CG.graphs.clear();
     CG = CGridState();
@@ -69,6 +71,14 @@ static void fill(EvpCgrid &A)
     A.plane = S.plane;
 }
 
+static bool remote() { return !S.plan.peers.empty(); }
+// ghost cells owned by other ranks, for two of the loop's arrays (no-op on one rank)
+#define XCHG(a, b)                                             \
+    do {                                                       \
+        if (remote())                                          \
+            if (int rc_ = halo_remote_pair((a), (b))) return rc_; \
+    } while (0)
+
 static bool fused_schedule()
 {
     if (CG.avg_strength) return false;           // needs deltaU at the neighbours: five phases
@@ -76,7 +86,7 @@ static bool fused_schedule()
 }
 
 // five launches per subcycle, any visc_method
-static void enqueue_phases(const EvpCgrid &A, int ndte, bool first)
+static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 {
     for (int k = 0; k < ndte; ++k) {
         evp_launch_cgrid_phase(A, 0, 1, S.stream);
@@ -85,8 +95,19 @@ static void enqueue_phases(const EvpCgrid &A, int ndte, bool first)
             evp_launch_cgrid_phase(A, 6, 1, S.stream);
             evp_launch_cgrid_zero_cells(A, CG.zero_cells, CG.n_zero, S.stream);
         }
-        for (int ph = 1; ph <= 4; ++ph) evp_launch_cgrid_phase(A, ph, 1, S.stream);
+        XCHG(A.f[CF_SHEARU], A.f[CF_SHEARU]);
+        evp_launch_cgrid_phase(A, 1, 1, S.stream);
+        XCHG(A.f[CF_ETA], A.f[CF_ZETA]);
+        XCHG(A.f[CF_SP], A.f[CF_SM]);
+        evp_launch_cgrid_phase(A, 2, 1, S.stream);
+        XCHG(A.f[CF_S12U], A.f[CF_S12U]);
+        evp_launch_cgrid_phase(A, 3, 1, S.stream);
+        XCHG(A.f[CF_UE], A.f[CF_VN]);
+        evp_launch_cgrid_phase(A, 4, 1, S.stream);
+        XCHG(A.f[CF_UN], A.f[CF_VE]);
+        XCHG(A.f[CF_UU], A.f[CF_VU]);
     }
+    return 0;
 }
 
 // three launches per subcycle + one after the loop (evp_cgrid.hip); stress12U ping-pongs, returns with the
@@ -99,6 +120,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         // ghost cells, ice_dyn_evp.F90:683-690); the reference repairs them with the first halo update, the fused
         // kernel recomputes neighbours from their previous value: make the previous values ghost-consistent first
         evp_launch_cgrid_phase(A, 9, CF_S12U, S.stream);
+        XCHG(cur, cur);
         // (ghost cells of eliminated land blocks: zero in both buffers; no ice cell reads them before the first exchange)
         evp_launch_cgrid_zero_cells(A, CG.zero_cells, CG.n_zero, S.stream);
         HIPC(hipMemcpyAsync(other, cur, S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
@@ -112,14 +134,21 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         } else {
             evp_launch_cgrid_phase(A, 7, last, S.stream);
         }
+        XCHG(A.f[CF_SHEARU], A.f[CF_SHEARU]);
         evp_launch_cgrid_phase(A, 10, last, S.stream);
+        XCHG(A.f[CF_ETA], A.f[CF_ZETA]);         // (zetax2T is stored in the last subcycle only; harmless before)
+        XCHG(A.f[CF_SP], A.f[CF_SM]);
         A.s12_in = cur;
         A.f[CF_S12U] = other;
         evp_launch_cgrid_phase(A, 8, last, S.stream);
+        XCHG(other, other);
+        XCHG(A.f[CF_UE], A.f[CF_VN]);
         std::swap(cur, other);
     }
     A.f[CF_S12U] = cur;
     evp_launch_cgrid_phase(A, 4, 1, S.stream);
+    XCHG(A.f[CF_UN], A.f[CF_VE]);
+    XCHG(A.f[CF_UU], A.f[CF_VU]);
     return 0;
 }
 
@@ -134,9 +163,6 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     if (!S.ready) return fail(-1, "not initialised");
     if (!static23) return fail(-1, "null argument");
     const HaloPlan &P = S.plan;
-    for (const HaloPeer &p : P.peers)
-        if (!p.send_src.empty() || !p.recv_dst.empty())
-            return fail(-4, "C-grid EVP: neighbour blocks on other ranks are not supported yet (one rank only)");
     if (S.d.ns_boundary_type >= CICE_EVP_BND_TRIPOLE)
         return fail(-4, "C-grid EVP: the tripole fold is not supported yet");
     cgrid_free();
@@ -149,6 +175,7 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
         if (alloc_d(&CG.g[k], S.n) || h2d(CG.g[k], static23[k])) return -1;
     }
     if (alloc_d(&CG.strengthU, S.n) || alloc_d(&CG.s12alt, S.n)) return -1;
+    if (!S.plan.peers.empty() && alloc_d(&CG.umaskd, S.n)) return -1;
     HIPC(hipMalloc((void **)&CG.mask, S.n));
     // ghost images: for every interior cell the ghost cells of this rank that mirror it (what ice_HaloUpdate copies)
     CG.h_img_slot.assign(S.n, -1);
@@ -223,6 +250,13 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
             }
     HIPC(hipMemcpyAsync(CG.mask, CG.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
     CG.avg_strength = visc_method;
+    if (remote()) {                              // bit5 of ghost cells other ranks own
+        EvpCgrid A;
+        fill(A);
+        evp_launch_cgrid_umask(A, CG.umaskd, 0, S.stream);
+        if (int rc = halo_remote_pair(CG.umaskd, CG.umaskd)) return rc;
+        evp_launch_cgrid_umask(A, CG.umaskd, 1, S.stream);
+    }
     if (visc_method == 1) {
         EvpCgrid A;
         fill(A);
@@ -245,11 +279,10 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     const bool fused = fused_schedule();
     auto enqueue = [&]() -> int {
         if (fused) return enqueue_fused(A, ndte, CG.first);
-        enqueue_phases(A, ndte, CG.first);
-        return 0;
+        return enqueue_phases(A, ndte, CG.first);
     };
     HIPC(hipEventRecord(S.ev0, S.stream));
-    if (S.use_graph) {
+    if (S.use_graph && (!remote() || S.direct.on)) {     // RCCL point-to-point is enqueued eagerly (as the B-grid loop does)
         const std::pair<int, int> key(ndte, (CG.flip << 3) | (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
         auto it = CG.graphs.find(key);
         if (it == CG.graphs.end()) {

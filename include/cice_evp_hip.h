@@ -222,8 +222,9 @@ int cice_evp_hip_prep_fetch(int32_t which, double *dst);
 /* ---- C-grid EVP subcycle (second half): evp()'s loop for grid_ice = 'C',
  * cicedyn/dynamics/ice_dyn_evp.F90:938-1099 -- strain_rates_U, stressC_T, stressC_U, div_stress_Ex / _Ny,
  * stepu_C / stepv_C, the E<->N and face->corner velocity averages, and the eight ice_HaloUpdate calls of every
- * subcycle (fused into the kernels).  Call after cice_evp_hip_init (dims, scalars).  One rank; cyclic, closed or
- * open boundaries; any number of blocks.
+ * subcycle (fused into the kernels; ghost cells owned by other ranks through the halo transport of the B-grid path).
+ * Call after cice_evp_hip_init (dims, scalars) and, for nranks > 1, cice_evp_hip_comm_init or _halo_import.
+ * Cyclic, closed or open boundaries; any number of blocks; no tripole fold yet.
  *
  * static23 (ice_grid / ice_dyn_evp arrays, once):
  *   dxT dyT dxU dyU dxE dyE dxN dyN uarea tarea earea narea earear narear epm npm uvm hm DminTarea

@@ -92,3 +92,33 @@ def test_bench_multi_rank_rehearsal():
     assert d["config"]["halo_transport"] == "mailbox" and d["config"]["finite"]
     assert d["config"]["tile_variant"] >= 2000         # the resident kernel with remote neighbours
     assert d["cpu_baseline"] is None and "roofline" in d
+
+
+@pytest.mark.parametrize("world,workload,shape,extra", [(2, "gx3", "", []), (4, "gx3", "2x2", ["--blocks-per-rank", "2x2", "--timing"]),
+                                                        (2, "gx1", "1x2", ["--visc", "avg_strength"]),
+                                                        (4, "gx1", "2x2", ["--timing"])])
+def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
+    """The C-grid subcycle split over `world` ranks (processes sharing this box's GPU): ghost cells that mirror
+    cells of other ranks are filled through the mailbox transport after every producing launch -- five exchange
+    points per subcycle in the fused schedule, seven in the five-phase one (avg_strength) -- and every rank's
+    arrays, ghost cells included, equal the single-rank run bit for bit (tools/mailbox_2proc.py --cgrid)."""
+    import subprocess
+    import sys as _sys
+    root = Path(__file__).resolve().parents[1]
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(root / "tools" / "mailbox_2proc.py"), "--cgrid", "--workload", workload, "--ndte", "24"] + extra
+    if shape:
+        cmd += ["--shape", shape]
+    env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
+    for attempt in (1, 2):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout:
+            break
+        try:
+            (root / "gpurun_out").mkdir(exist_ok=True)
+            (root / "gpurun_out" / f"cgrid_mp_fail_{world}_{workload}_{shape}_{attempt}.log").write_text(r.stdout + "\n---\n" + r.stderr)
+        except OSError:
+            pass
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -30,6 +30,10 @@ def main():
     ap.add_argument("--prep", action="store_true",
                     help="start from the primary model state: evp()'s preparation phase on the device on every "
                          "rank (T-grid halos across ranks through the same transport), then the loop")
+    ap.add_argument("--cgrid", action="store_true",
+                    help="the C-grid subcycle (cice_evp_hip_cgrid_*): ghost cells other ranks own filled through the "
+                         "same transport after every producing launch")
+    ap.add_argument("--visc", default="avg_zeta")
     ap.add_argument("--expect-resident", action="store_true",
                     help="fail unless the on-chip resident kernel with remote neighbours ran")
     a = ap.parse_args()
@@ -50,6 +54,78 @@ def main():
     st = synth.make_state(g, case="full", seed=7, warm=True)
     pr = synth.make_primary(g, "full", seed=9) if a.prep else None
     scal = synth.evp_scalars(120)
+
+    def run_cgrid(dc, r, exchange):
+        cg = synth.cgrid_geometry(g)
+        state, inputs, masks = synth.cgrid_state(g, cg, case="full", seed=7, warm=True, seabed=True)
+        static, state, inputs, masks = synth.cgrid_scatter(dc, r, cg, state, inputs, masks)
+        d, keep = evp.make_dims(dc, r)
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                          1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        try:
+            if exchange:
+                blobs = [None] * world
+                dist.all_gather_object(blobs, core.halo_export())
+                core.halo_import(blobs)
+            core.cgrid_set_geometry(static)
+            core.cgrid_upload(state, inputs, masks, visc_method=a.visc)
+            core.cgrid_subcycle(a.ndte)
+            t = None
+            if a.timing:
+                core.cgrid_sync()
+                if exchange:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    core.cgrid_subcycle(40)
+                core.cgrid_sync()
+                t = (time.perf_counter() - t0) / 120 * 1e6
+                core.cgrid_subcycle(7)
+            out = core.cgrid_download()
+            return out, core.timings(), t
+        finally:
+            core.finalize()
+
+    if a.cgrid:
+        ref = None
+        for turn in range(world):
+            if turn == rank:
+                ref, _, _ = run_cgrid(decomp.single_block(nx, ny, "cyclic", ns_bnd), 0, False)
+            dist.barrier()
+        shape = tuple(int(v) for v in a.shape.split("x")) if a.shape else None
+        dcN = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns_bnd, proc_shape=shape)
+        if a.blocks_per_rank:
+            sx, sy = (int(v) for v in a.blocks_per_rank.split("x"))
+            dcN = decomp.Decomp(nx, ny, -(-dcN.block_size_x // sx), -(-dcN.block_size_y // sy), "cyclic", ns_bnd, world,
+                                dcN.proc_shape)
+        got, tim, t_us = run_cgrid(dcN, rank, True)
+        assert tim["halo_transport"] == "mailbox", tim
+        exchanged = ("uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12U", "zetax2T",
+                     "etax2T", "shearU")
+        bad = []
+        for k in evp.CGRID_FIELDS:
+            want = dcN.scatter(ref[k][0][1:-1, 1:-1], rank)
+            for b in dcN.local_blocks(rank):
+                w = want[b.local][1:1 + b.gny, 1:1 + b.gnx]
+                h = got[k][b.local][1:1 + b.gny, 1:1 + b.gnx]
+                if not np.array_equal(w, h):
+                    bad.append((k, int((w != h).sum()), float(np.abs(w - h).max())))
+                if k in exchanged:      # ghost cells that mirror a cell (all but those beyond the closed north / south edge)
+                    j0 = 1 if b.gj0 == 1 else 0
+                    j1 = b.gny + 1 if b.gj0 + b.gny - 1 == ny else b.gny + 2
+                    w2 = want[b.local][j0:j1, 0:b.gnx + 2]
+                    h2 = got[k][b.local][j0:j1, 0:b.gnx + 2]
+                    if not np.array_equal(w2, h2):
+                        bad.append((k + " ghosts", int((w2 != h2).sum()), float(np.abs(w2 - h2).max())))
+        res = [None] * world
+        dist.all_gather_object(res, (rank, bad, t_us))
+        if rank == 0:
+            ok = all(not r[1] for r in res)
+            print("MAILBOX_2PROC", "OK" if ok else "FAIL", "cgrid", a.workload, f"world={world}", res, flush=True)
+            if not ok:
+                sys.exit(1)
+        dist.destroy_process_group()
+        return
 
     def run(dc, r, exchange):
         geo = {k: dc.scatter(g[k], r, fill=(1.0 if k != "uarear" else 0.0))

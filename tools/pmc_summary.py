@@ -122,8 +122,34 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
         res["kernels"][key] = entry
+    # C-grid subcycle (tools/cgrid_timing.py): the three kernels of the fused schedule, duration and HBM-side bytes each
+    CG = {"A_avg_strain": "cg_avg_strain", "B_stress_t": "cg_stress_t", "C_stress_u_step": "cg_stress_u_step"}
+    for key in ("cgx1", "cgs01"):
+        st = d / f"{key}_trace_kernel_stats.csv"
+        if not st.exists():
+            continue
+        entry = {}
+        for tag, match in CG.items():
+            e = {"kernel_trace": kernel_stats(st, match)}
+            for p, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+                f = d / f"{key}_{p}_counter_collection.csv"
+                if f.exists():
+                    c, dur_us, kname = counters(f, match)
+                    if cname in c:
+                        e[cname + "_KB_per_launch"] = c[cname][0]
+            if "FETCH_SIZE_KB_per_launch" in e and "WRITE_SIZE_KB_per_launch" in e:
+                e["hbm_bytes_per_launch"] = (e["FETCH_SIZE_KB_per_launch"] * f_fetch + e["WRITE_SIZE_KB_per_launch"] * f_write) * 1024.0
+            entry[tag] = e
+        tot_us = sum(e["kernel_trace"]["avg_us"] for e in entry.values() if e.get("kernel_trace"))
+        tot_b = sum(e.get("hbm_bytes_per_launch", 0.0) for e in entry.values())
+        entry["per_subcycle"] = {"kernel_us_sum": tot_us, "hbm_bytes": tot_b or None,
+                                 "hbm_GBps_over_kernel_time": (tot_b / (tot_us * 1e-6) / 1e9) if tot_b and tot_us else None}
+        res["kernels"][key] = entry
     dst.write_text(json.dumps(res, indent=1))
     for k, e in res["kernels"].items():
+        if k.startswith("cg"):
+            print(k, e["per_subcycle"], {t: v.get("kernel_trace", {}) and v["kernel_trace"].get("avg_us") for t, v in e.items() if t != "per_subcycle"})
+            continue
         print(k, {q: e.get(q) for q in ("hbm_bytes_per_launch", "valu_busy_simd_cycles_per_launch", "effective_clock_ghz")},
               e["kernel_trace"])
 
