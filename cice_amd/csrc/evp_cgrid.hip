@@ -474,6 +474,32 @@ __global__ __launch_bounds__(TX *TY) void cg_zero_outside(EvpCgrid A)
     A.f[CF_VU][c.o] = 0.0;
 }
 
+// ---- tripole fold, pass 1 (values from raw sources) and pass 2 (stores); see EvpCgFold ----
+__global__ void cg_fold_gather(EvpCgFold F)
+{
+    const int q = blockIdx.y;
+    const EvpCgFoldList &L = F.L[F.loc[q]];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= L.n) return;
+    const double *x = F.x[q];
+    const int a = L.a[k], b = L.b[k];
+    const double isign = F.isign[q];
+    const double s = L.flip[k] ? isign : 1.0;
+    const double xa = a >= 0 ? x[a] : 0.0;
+    double v;
+    if (b >= 0 || b == -2) v = s * (0.5 * (xa + isign * (b >= 0 ? x[b] : 0.0)));     // -2: partner's block eliminated (land)
+    else v = s * xa;
+    F.tmp[(size_t)q * F.maxn + k] = v;
+}
+__global__ void cg_fold_scatter(EvpCgFold F)
+{
+    const int q = blockIdx.y;
+    const EvpCgFoldList &L = F.L[F.loc[q]];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= L.n) return;
+    F.x[q][L.dst[k]] = F.tmp[(size_t)q * F.maxn + k];
+}
+
 // ---- ranks > 1: iceU of interior cells as 0/1 doubles (exchanged like a field), and back into bit5 of the mask for the
 // ghost cells that mirror cells of other ranks ----
 __global__ __launch_bounds__(TX *TY) void cg_umask_to_double(EvpCgrid A, double *d)
@@ -507,6 +533,14 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st)
 {
     if (n > 0) hipLaunchKernelGGL(cg_zero_cells, dim3((n + 255) / 256), dim3(256), 0, st, A, cells, n);
+}
+
+void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st)
+{
+    if (F.nfields <= 0 || F.maxn <= 0) return;
+    const dim3 grid((F.maxn + 255) / 256, F.nfields);
+    hipLaunchKernelGGL(cg_fold_gather, grid, dim3(256), 0, st, F);
+    hipLaunchKernelGGL(cg_fold_scatter, grid, dim3(256), 0, st, F);
 }
 
 void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStream_t st)

@@ -263,5 +263,20 @@ struct EvpCgrid {
 //        9 copy field `last` into its ghost images
 // last: the launch belongs to the last subcycle of a call (arrays nobody reads inside the loop are stored only then)
 void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st);
+// Tripole fold of the C-grid fields (u-fold; ice_boundary.F90:1626-1722): entries (dst, a, b, flip) per field location
+// -- x[dst] = s * 0.5*(x[a] + isign*x[b])  (b >= 0: a point ON the fold, averaged with its partner)
+//    x[dst] = s * x[a]                     (b < 0: a ghost cell mirroring a cell across the fold; a < 0: 0)
+// with s = flip ? isign : 1 and isign = -1 for vector kinds, +1 for scalars.  Two passes (all reads, then all writes).
+struct EvpCgFoldList { const int *dst, *a, *b; const unsigned char *flip; int n; };
+struct EvpCgFold {
+    double *x[4];              // up to four fields per step
+    int loc[4];                // their location: 0 centre, 1 NE corner, 2 E face, 3 N face
+    double isign[4];
+    int nfields;
+    EvpCgFoldList L[4];        // per location
+    double *tmp;               // nfields x max n
+    int maxn;
+};
+void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st);
 void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStream_t st);
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st);

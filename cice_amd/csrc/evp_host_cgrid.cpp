@@ -23,6 +23,11 @@ struct CGridState {
     int flip = 0;                // which of the two allocations f[CF_S12U] is (part of the graph key)
     uint8_t *mask = nullptr;
     int *img_slot = nullptr, *img_dst = nullptr;
+    // tripole fold: per field location the cells of the fold row / the ghost row beyond it and their sources
+    bool tripole = false;
+    struct Fold { int *dst = nullptr, *a = nullptr, *b = nullptr; unsigned char *flip = nullptr; int n = 0; } fold[4];
+    double *fold_tmp = nullptr;
+    int fold_maxn = 0;
     int *zero_cells = nullptr;   // ghost cells of eliminated (land) neighbour blocks
     int n_zero = 0;
     std::vector<int> h_img_slot, h_img_dst;
@@ -44,7 +49,8 @@ void cgrid_free()
     for (auto &p : CG.f) F(p);
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
-    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.mask); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells);
+    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.mask); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
+    for (auto &f : CG.fold) { F(f.dst); F(f.a); F(f.b); F(f.flip); }
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
     CG.graphs.clear();
     CG = CGridState();
@@ -79,9 +85,30 @@ static bool remote() { return !S.plan.peers.empty(); }
             if (int rc_ = halo_remote_pair((a), (b))) return rc_; \
     } while (0)
 
+// tripole: the fold step of up to four fields after the launch that produced them (what their ice_HaloUpdate does
+// at the fold: points ON it averaged with their partners, ghost row beyond it mirrored); loc 0 centre, 1 NE corner,
+// 2 E face, 3 N face; vec: vector kind (sign change across the fold)
+struct FoldField { double *x; int loc; bool vec; };
+static void fold(std::initializer_list<FoldField> fs)
+{
+    if (!CG.tripole) return;
+    EvpCgFold F{};
+    for (const FoldField &f : fs) {
+        F.x[F.nfields] = f.x;
+        F.loc[F.nfields] = f.loc;
+        F.isign[F.nfields] = f.vec ? -1.0 : 1.0;
+        ++F.nfields;
+    }
+    for (int l = 0; l < 4; ++l) F.L[l] = {CG.fold[l].dst, CG.fold[l].a, CG.fold[l].b, CG.fold[l].flip, CG.fold[l].n};
+    F.tmp = CG.fold_tmp;
+    F.maxn = CG.fold_maxn;
+    evp_launch_cgrid_fold(F, S.stream);
+}
+
 static bool fused_schedule()
 {
     if (CG.avg_strength) return false;           // needs deltaU at the neighbours: five phases
+    if (CG.tripole) return false;                // recomputing a neighbour across the fold would sum in mirrored order
     return !(env("CICE_EVP_HIP_CGRID_FUSED") && !std::atoi(env("CICE_EVP_HIP_CGRID_FUSED")));
 }
 
@@ -96,16 +123,21 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
             evp_launch_cgrid_zero_cells(A, CG.zero_cells, CG.n_zero, S.stream);
         }
         XCHG(A.f[CF_SHEARU], A.f[CF_SHEARU]);
+        fold({{A.f[CF_SHEARU], 1, false}});
         evp_launch_cgrid_phase(A, 1, 1, S.stream);
         XCHG(A.f[CF_ETA], A.f[CF_ZETA]);
         XCHG(A.f[CF_SP], A.f[CF_SM]);
+        fold({{A.f[CF_ZETA], 0, false}, {A.f[CF_ETA], 0, false}, {A.f[CF_SP], 0, false}, {A.f[CF_SM], 0, false}});
         evp_launch_cgrid_phase(A, 2, 1, S.stream);
         XCHG(A.f[CF_S12U], A.f[CF_S12U]);
+        fold({{A.f[CF_S12U], 1, false}});
         evp_launch_cgrid_phase(A, 3, 1, S.stream);
         XCHG(A.f[CF_UE], A.f[CF_VN]);
+        fold({{A.f[CF_UE], 2, true}, {A.f[CF_VN], 3, true}});
         evp_launch_cgrid_phase(A, 4, 1, S.stream);
         XCHG(A.f[CF_UN], A.f[CF_VE]);
         XCHG(A.f[CF_UU], A.f[CF_VU]);
+        fold({{A.f[CF_UN], 3, true}, {A.f[CF_VE], 2, true}, {A.f[CF_UU], 1, true}, {A.f[CF_VU], 1, true}});
     }
     return 0;
 }
@@ -152,6 +184,86 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
     return 0;
 }
 
+// Fold lists by the meaning of the cells (ice_boundary.F90:1626-1722, u-fold): for every cell of every block -- interior
+// or ghost -- in the top physical row NY (locations with points ON the fold: NE corner, N face) or in the ghost row
+// NY+1 (all locations), where its value comes from.  Sources are interior cells of this rank (raw values).
+static int build_fold_lists()
+{
+    const int NX = S.d.nx_global, NY = S.d.ny_global, nx = S.d.nx_block, ng = S.d.nghost;
+    if (NX % 2) return fail(-4, "tripole: nx_global must be even");
+    std::vector<int> owner((size_t)NX * 2, -1);              // interior cell holding global (ig, NY-1) / (ig, NY)
+    for (int b = 0; b < S.d.nblocks; ++b)
+        for (int j = S.jlo[b]; j <= S.jhi[b]; ++j) {
+            const int jg = S.jglob0[b] + (j - S.jlo[b]);
+            if (jg < NY - 1 || jg > NY) continue;
+            for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
+                const int ig = S.iglob0[b] + (i - S.ilo[b]);
+                owner[(size_t)(jg - (NY - 1)) * NX + (ig - 1)] = (int)((size_t)b * S.plane + (size_t)(j - 1) * nx + (i - 1));
+            }
+        }
+    auto own = [&](int ig, int row) {                         // row 0: NY-1, 1: NY
+        while (ig < 1) ig += NX;
+        while (ig > NX) ig -= NX;
+        return owner[(size_t)row * NX + (ig - 1)];
+    };
+    CG.fold_maxn = 0;
+    for (int loc = 0; loc < 4; ++loc) {
+        std::vector<int> dst, a, bb;
+        std::vector<unsigned char> flip;
+        for (int b = 0; b < S.d.nblocks; ++b)
+            for (int j = S.jlo[b] - ng; j <= S.jhi[b] + ng; ++j) {
+                const int jg = S.jglob0[b] + (j - S.jlo[b]);
+                if (jg != NY && jg != NY + 1) continue;
+                if (jg == NY + 1 && j <= S.jhi[b]) continue;   // (cannot happen: NY+1 is never an interior row)
+                for (int i = S.ilo[b] - ng; i <= S.ihi[b] + ng; ++i) {
+                    int ig = S.iglob0[b] + (i - S.ilo[b]);
+                    while (ig < 1) ig += NX;
+                    while (ig > NX) ig -= NX;
+                    const int d = (int)((size_t)b * S.plane + (size_t)(j - 1) * nx + (i - 1));
+                    if (jg == NY) {
+                        if (loc == 1) {                       // NE corner: pairs i <-> NX-i, poles NX/2 and NX
+                            if (ig == NX / 2 || ig == NX) { dst.push_back(d); a.push_back(own(ig, 1)); bb.push_back(-1); flip.push_back(1); }
+                            else if (ig < NX / 2) { dst.push_back(d); a.push_back(own(ig, 1)); bb.push_back(own(NX - ig, 1)); flip.push_back(0); }
+                            else { dst.push_back(d); a.push_back(own(NX - ig, 1)); bb.push_back(own(ig, 1)); flip.push_back(1); }
+                        } else if (loc == 3) {                // N face: pairs i <-> NX+1-i
+                            if (ig <= NX / 2) { dst.push_back(d); a.push_back(own(ig, 1)); bb.push_back(own(NX + 1 - ig, 1)); flip.push_back(0); }
+                            else { dst.push_back(d); a.push_back(own(NX + 1 - ig, 1)); bb.push_back(own(ig, 1)); flip.push_back(1); }
+                        }
+                        continue;                             // centre / E face: the top row is an ordinary row
+                    }
+                    // ghost row NY+1: mirror with offsets (0,0) centre, (1,1) NE corner, (1,0) E face, (0,1) N face
+                    const int is = (loc == 0 || loc == 3) ? NX - ig + 1 : NX - ig;
+                    const int row = (loc == 0 || loc == 2) ? 1 : 0;
+                    dst.push_back(d); a.push_back(own(is, row)); bb.push_back(-1); flip.push_back(1);
+                }
+            }
+        for (size_t k = 0; k < dst.size(); ++k)              // a point ON the fold whose partner's block was eliminated
+            if (!flip.empty() && bb[k] == -1 && (loc == 1 || loc == 3)) {
+                const int dj = (int)((dst[k] % S.plane) / nx) + 1, db = (int)(dst[k] / S.plane);
+                const bool seam_row = S.jglob0[db] + (dj - S.jlo[db]) == NY;
+                int ig = S.iglob0[db] + ((int)(dst[k] % nx) + 1 - S.ilo[db]);
+                while (ig < 1) ig += NX;
+                while (ig > NX) ig -= NX;
+                const bool pole = loc == 1 && (ig == NX / 2 || ig == NX);
+                if (seam_row && !pole) bb[k] = -2;
+            }
+        CGridState::Fold &Fd = CG.fold[loc];
+        Fd.n = (int)dst.size();
+        CG.fold_maxn = std::max(CG.fold_maxn, Fd.n);
+        if (!Fd.n) continue;
+        HIPC(hipMalloc((void **)&Fd.dst, dst.size() * sizeof(int)));
+        HIPC(hipMalloc((void **)&Fd.a, dst.size() * sizeof(int)));
+        HIPC(hipMalloc((void **)&Fd.b, dst.size() * sizeof(int)));
+        HIPC(hipMalloc((void **)&Fd.flip, dst.size()));
+        HIPC(hipMemcpy(Fd.dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Fd.a, a.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Fd.b, bb.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Fd.flip, flip.data(), dst.size(), hipMemcpyHostToDevice));
+    }
+    if (CG.fold_maxn) HIPC(hipMalloc((void **)&CG.fold_tmp, (size_t)4 * CG.fold_maxn * sizeof(double)));
+    return 0;
+}
+
 }  // namespace evp_host
 
 using namespace evp_host;
@@ -163,9 +275,14 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     if (!S.ready) return fail(-1, "not initialised");
     if (!static23) return fail(-1, "null argument");
     const HaloPlan &P = S.plan;
-    if (S.d.ns_boundary_type >= CICE_EVP_BND_TRIPOLE)
-        return fail(-4, "C-grid EVP: the tripole fold is not supported yet");
+    const bool tripole = S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE;
+    if (S.d.ns_boundary_type > CICE_EVP_BND_TRIPOLE) return fail(-4, "C-grid EVP: tripoleT is not supported");
+    if (tripole)
+        for (const HaloPeer &p : P.peers)
+            if (!p.send_src.empty() || !p.recv_dst.empty())
+                return fail(-4, "C-grid EVP on a tripole grid: one rank only (the fold step needs every top-row block here)");
     cgrid_free();
+    CG.tripole = tripole;
     for (auto &p : CG.f)
         if (alloc_d(&p, S.n)) return -1;
     for (auto &p : CG.in)
@@ -182,6 +299,11 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     std::vector<int> dst, zero;
     for (size_t k = 0; k < P.local_dst.size(); ++k) {
         const int src = P.local_src[k];
+        if (tripole) {       // ghost row beyond the fold: location-dependent, done by the fold step, not by an image
+            const int db = (int)(P.local_dst[k] / S.plane);
+            const int dj = (int)((P.local_dst[k] % S.plane) / S.d.nx_block) + 1;
+            if (S.jglob0[db] + (dj - S.jlo[db]) > S.d.ny_global) continue;
+        }
         if (src < 0) {                              // neighbour block eliminated (land): the reference fills with zero
             zero.push_back(P.local_dst[k]);
             continue;
@@ -202,6 +324,8 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMalloc((void **)&CG.img_dst, dst.size() * sizeof(int)));
     HIPC(hipMemcpyAsync(CG.img_slot, CG.h_img_slot.data(), S.n * sizeof(int), hipMemcpyHostToDevice, S.stream));
     HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    if (tripole)
+        if (int rc = build_fold_lists()) return rc;
     CG.n_zero = (int)zero.size();
     if (CG.n_zero) {
         HIPC(hipMalloc((void **)&CG.zero_cells, zero.size() * sizeof(int)));

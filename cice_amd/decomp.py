@@ -92,8 +92,27 @@ class Decomp:
         return (len(self.local_blocks(rank)), self.ny_block, self.nx_block)
 
     # ---- global <-> block arrays -------------------------------------------
-    def scatter(self, g: np.ndarray, rank: int = 0, fill=0.0) -> np.ndarray:
-        """Global [ny][nx] -> block array of `rank`, ghost cells included."""
+    FOLD_OFFSETS = {"center": (0, 0), "NEcorner": (1, 1), "Eface": (1, 0), "Nface": (0, 1)}
+
+    def scatter(self, g: np.ndarray, rank: int = 0, fill=0.0, fold=None) -> np.ndarray:
+        """Global [ny][nx] -> block array of `rank`, ghost cells included.  fold = (location, sign) on a tripole grid:
+        the ghost row beyond the fold takes sign * the mirrored row (u-fold, offsets per location as
+        ice_boundary.F90:1626-1683: ghost(i, NY+1) <- g(NX - i + 1 - ioff, NY - joff)); without it that row is `fill`."""
+        out = self._scatter_plain(g, rank, fill)
+        if fold is None or self.ns != "tripole":
+            return out
+        loc, sign = fold
+        ioff, joff = self.FOLD_OFFSETS[loc]
+        NX, NY = self.nx_global, self.ny_global
+        for b in self.local_blocks(rank):
+            if b.gj0 + b.gny - 1 != NY:
+                continue
+            ii = (np.arange(b.gi0 - NGHOST, b.gi0 + b.gnx + NGHOST) - 1) % NX + 1      # global i of the local columns
+            src = (NX - ii + 1 - ioff - 1) % NX                                         # 0-based mirrored column
+            out[b.local][NGHOST + b.gny, :len(ii)] = sign * g[NY - joff - 1, src]
+        return out
+
+    def _scatter_plain(self, g: np.ndarray, rank: int = 0, fill=0.0) -> np.ndarray:
         blks = self.local_blocks(rank)
         out = np.full((len(blks), self.ny_block, self.nx_block), fill, dtype=g.dtype)
         NX, NY = self.nx_global, self.ny_global

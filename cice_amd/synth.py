@@ -217,17 +217,21 @@ def cgrid_geometry(g: dict, deltaminEVP: float = 1e-11) -> dict:
     masks epm / npm = both neighbouring T-cells ocean (makemask), boundary-condition ratios as init_evp builds them
     (ice_dyn_evp.F90:232-239)."""
     dxT, dyT, hm = g["dxT"], g["dyT"], g["hm"]
-    n = lambda a: np.vstack([a[1:], a[-1:]])                 # (i, j+1), top row repeated
+    trip = g.get("ns") == "tripole"
+    # (i, j+1): beyond the top row a closed grid repeats it; a tripole grid mirrors across the fold -- cell-centre
+    # fields column NX-i+1, E-face fields column NX-i (u-fold, ice_boundary.F90:1626-1683)
+    n = lambda a: np.vstack([a[1:], a[-1:, ::-1] if trip else a[-1:]])
+    n_e = lambda a: np.vstack([a[1:], np.roll(a[-1:, ::-1], -1, axis=1) if trip else a[-1:]])
     e = lambda a: np.roll(a, -1, axis=1)                     # (i+1, j), cyclic
     dxN, dyE = g["HTN"], g["HTE"]
     dxE = 0.5 * (dxT + e(dxT))
     dyN = 0.5 * (dyT + n(dyT))
     earea, narea = dxE * dyE, dxN * dyN
-    hm_n = np.vstack([hm[1:], np.zeros((1, hm.shape[1]))])
+    hm_n = np.vstack([hm[1:], hm[-1:, ::-1] if trip else np.zeros((1, hm.shape[1]))])
     epm = np.minimum(hm, e(hm))
     npm = np.minimum(hm, hm_n)
     rxN = -e(dxN) / dxN
-    ryE = -n(dyE) / dyE
+    ryE = -n_e(dyE) / dyE
     return dict(dxT=dxT, dyT=dyT, dxU=g["dxU"], dyU=g["dyU"], dxE=dxE, dyE=dyE, dxN=dxN, dyN=dyN, uarea=g["uarea"],
                 tarea=g["tarea"], earea=earea, narea=narea, earear=1.0 / earea, narear=1.0 / narea, epm=epm, npm=npm,
                 uvm=g["uvm"], hm=hm, DminTarea=deltaminEVP * g["tarea"], ratiodxN=rxN, ratiodxNr=1.0 / rxN,
@@ -308,8 +312,26 @@ CGRID_FILL_ONE = ("dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea
                   "narear", "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr")
 
 
+CGRID_LOC = {   # where each array lives (tripole grids: which mirror rule fills its ghost row beyond the fold)
+    "NEcorner": ("dxU", "dyU", "uarea", "uvm", "uvel", "vvel", "stress12U", "iceUmask"),
+    "Eface": ("dxE", "dyE", "earea", "earear", "epm", "ratiodyE", "ratiodyEr", "uvelE", "vvelE", "strintxE", "taubxE",
+              "cdn_ocnE", "aiE", "uocnE", "vocnE", "waterxE", "forcexE", "emassdti", "fmE", "uvelE_init", "TbE", "rheofactE",
+              "iceEmask"),
+    "Nface": ("dxN", "dyN", "narea", "narear", "npm", "ratiodxN", "ratiodxNr", "uvelN", "vvelN", "strintyN", "taubyN",
+              "cdn_ocnN", "aiN", "uocnN", "vocnN", "wateryN", "forceyN", "nmassdti", "fmN", "vvelN_init", "TbN", "rheofactN",
+              "iceNmask"),
+}
+CGRID_VECTOR = ("uvel", "vvel", "uvelE", "vvelE", "uvelN", "vvelN", "strintxE", "strintyN", "taubxE", "taubyN", "uocnE", "vocnE",
+                "uocnN", "vocnN", "waterxE", "wateryN", "forcexE", "forceyN", "uvelE_init", "vvelN_init")
+
+
 def cgrid_scatter(dc, rank: int, cg: dict, state: dict, inputs: dict, masks: dict):
-    """Global C-grid workload -> the block arrays of `rank` (lengths and areas 1 where a ghost cell has no source)."""
-    static = {k: dc.scatter(v, rank, fill=(1.0 if k in CGRID_FILL_ONE else 0.0)) for k, v in cg.items()}
-    return (static, {k: dc.scatter(v, rank) for k, v in state.items()}, {k: dc.scatter(v, rank) for k, v in inputs.items()},
-            {k: dc.scatter(v, rank, fill=0) for k, v in masks.items()})
+    """Global C-grid workload -> the block arrays of `rank` (lengths and areas 1 where a ghost cell has no source; on a
+    tripole grid the ghost row beyond the fold mirrored by the rule of each array's location)."""
+    def fold(k):
+        loc = next((l for l, names in CGRID_LOC.items() if k in names), "center")
+        return (loc, -1.0 if k in CGRID_VECTOR else 1.0)
+    sc = lambda k, v, fill: dc.scatter(v, rank, fill=fill, fold=fold(k))
+    static = {k: sc(k, v, 1.0 if k in CGRID_FILL_ONE else 0.0) for k, v in cg.items()}
+    return (static, {k: sc(k, v, 0.0) for k, v in state.items()}, {k: sc(k, v, 0.0) for k, v in inputs.items()},
+            {k: sc(k, v, 0) for k, v in masks.items()})

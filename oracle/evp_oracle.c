@@ -104,7 +104,11 @@ static void gather_global(const evp_oracle_domain *d, const double *a, double *g
     }
 }
 
-/* field_loc: 0 = center, 1 = NE corner.  field_type: 0 = scalar, 1 = vector (sign -1 over tripole). */
+/* field_loc: 0 = center, 1 = NE corner, 2 = E face, 3 = N face.  field_type: 0 = scalar, 1 = vector (sign -1 over
+ * the tripole fold).  u-fold rules per location (ice_boundary.F90:1626-1683): offsets (ioffset, joffset) =
+ * center (0,0), NE corner (1,1), E face (1,0), N face (0,1); points ON the fold -- top physical row of NE-corner and
+ * N-face fields -- are forced symmetric first: NE corner pairs i <-> NX-i (i = 1..NX/2-1; i = NX/2 and NX mirror onto
+ * themselves), N face pairs i <-> NX+1-i (i = 1..NX/2). */
 void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc, int field_type,
                             int have_fill, double fill)
 {
@@ -115,6 +119,18 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
     const int tripole = (d->ns_type == BND_TRIPOLE);
     const double isign = (field_type == 1) ? -1.0 : 1.0;
 
+    if (tripole && field_loc == 3) {
+        /* N face: (:1664-1677) */
+        double *top = g + (size_t)(NY - 1) * NX;
+        for (int i = 1; i <= NX / 2; ++i) {
+            int idst = NX + 1 - i;
+            double x1 = top[i - 1], x2 = top[idst - 1];
+            double xavg = 0.5 * (x1 + isign * x2);
+            top[i - 1] = xavg;
+            top[idst - 1] = isign * xavg;
+        }
+        /* copy-out: array(i,NY) = isign*buf(NX+1-i, NY): (xavg, isign*xavg) come back as themselves */
+    }
     if (tripole && field_loc == 1) {
         /* u-fold, NE-corner field: the top physical row lies on the fold and is
            degenerate; enforce symmetry by averaging the two copies
@@ -145,7 +161,7 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
                 int ig = d->iglob0[b] + (i - ilo);
                 int jg = d->jglob0[b] + (j - jlo);
                 if (interior) {
-                    if (tripole && field_loc == 1 && jg == NY) /* seam row written back */
+                    if (tripole && (field_loc == 1 || field_loc == 3) && jg == NY) /* seam row written back */
                         ab[IX(i, j)] = g[(size_t)(NY - 1) * NX + (ig - 1)];
                     continue;
                 }
@@ -166,7 +182,11 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
                            NEcorner: ghost(ig, NY+k)  <- sign * a(NX-ig  , NY-k  )   (offsets 1,1) */
                         int k = jg - NY;
                         if (field_loc == 0) { ig = NX - ig + 1; jg = NY - k + 1; }
-                        else { ig = NX - ig; jg = NY - k; if (ig < 1) ig += NX; }
+                        else if (field_loc == 1) { ig = NX - ig; jg = NY - k; }
+                        else if (field_loc == 2) { ig = NX - ig; jg = NY - k + 1; }      /* E face: offsets (1,0) */
+                        else { ig = NX - ig + 1; jg = NY - k; }                          /* N face: offsets (0,1) */
+                        if (ig < 1) ig += NX;
+                        if (ig > NX) ig -= NX;
                         sgn = isign;
                     } else outside = 1;
                 }

@@ -128,7 +128,8 @@ def metrics(dom: OracleDomain, deltaminEVP, HTE, HTN, tarea):
 
 def halo_update(dom: OracleDomain, a, field_loc="NEcorner", field_type="vector", fill=None):
     assert a.dtype == np.float64 and a.flags.c_contiguous
-    lib().evp_oracle_halo_update(C.byref(dom.c), _dp(a), C.c_int(1 if field_loc == "NEcorner" else 0),
+    loc = {"center": 0, "NEcorner": 1, "Eface": 2, "Nface": 3}[field_loc]
+    lib().evp_oracle_halo_update(C.byref(dom.c), _dp(a), C.c_int(loc),
                                  C.c_int(1 if field_type == "vector" else 0),
                                  C.c_int(0 if fill is None else 1), C.c_double(0.0 if fill is None else fill))
     return a

@@ -83,6 +83,13 @@ CGRID_CASES = {
     "cgrid_cyccyc_2x2_cap0_ktens": (24, 20, 12, 10, "cyclic", "cyclic",
                                     dict(icecase="patchy", nsub_list=[1, 120], ncalls=1, h_capping=0.0, h_Ktens=0.2,
                                          h_e_yield=1.5, h_e_plast=2.5)),
+    # tripole (u-fold): N-face fields lie ON the fold (top row averaged pairwise), E-face / centre fields mirror across it
+    "cgrid_trip_2x2_full": (28, 20, 14, 10, "cyclic", "tripole", dict(icecase="full", nsub_list=[1, 2, 120], ncalls=2)),
+    "cgrid_trip_1blk_patchy_avgstrength": (24, 18, 24, 18, "cyclic", "tripole",
+                                           dict(icecase="patchy", nsub_list=[1, 120], ncalls=1, h_capping=0.5,
+                                                h_visc_method="avg_strength")),
+    "cgrid_trip_4x3_caps_seabed": (32, 24, 8, 8, "cyclic", "tripole",
+                                   dict(icecase="caps", nsub_list=[1, 120], ncalls=1, h_seabed=True)),
 }
 
 
@@ -93,7 +100,8 @@ def make_cgrid_case(name, spec):
     g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
     run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
-    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="strict", h_ndte=120, grid_kind="popfile",
+    d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="strict", h_ndte=120,
+                                 grid_kind=("tripolefile" if ns == "tripole" else "popfile"),
                                  grid_files=(td + "/grid.bin", td + "/kmt.bin"), h_grid_ice="C", **kw)
     keep = {"dims": d["dims"], "blkinfo": d["blkinfo"], "scalars": d["scalars"], "nsub_list": d["nsub_list"],
             "ew": np.array(ew), "ns": np.array(ns), "visc_method": np.array(kw.get("h_visc_method", "avg_zeta"))}

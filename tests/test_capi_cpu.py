@@ -188,3 +188,22 @@ def test_halo_plan_rejects_bad_geometry():
     d.nghost = 2
     with pytest.raises(evp.EvpHipError):
         evp.halo_plan(d)
+
+
+def test_decomp_fold_scatter_matches_the_halo_rules():
+    """decomp.scatter(fold=...) -- used to lay out synthetic tripole workloads -- fills the ghost row beyond the fold
+    like ice_HaloUpdate does for locations whose points are not ON the fold (centre, E face), scalars and vectors
+    (checked against the oracle's halo update, itself pinned to the reference's tripole fixtures)."""
+    from cice_amd import decomp
+    nx, ny = 24, 18
+    dc = decomp.Decomp(nx, ny, 8, 6, "cyclic", "tripole", 1)
+    ob = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(ob), nx, ny, "cyclic", "tripole", [b.ilo for b in ob],
+                              [b.ihi for b in ob], [b.jlo for b in ob], [b.jhi for b in ob], [b.gi0 for b in ob],
+                              [b.gj0 for b in ob])
+    g = np.random.default_rng(1).standard_normal((ny, nx))
+    for loc in ("center", "Eface"):
+        for kind, sg in (("scalar", 1.0), ("vector", -1.0)):
+            a = dc.scatter(g, 0, fill=0.0, fold=(loc, sg))
+            w = oracle.halo_update(dom, np.ascontiguousarray(dc.scatter(g, 0, fill=0.0)), loc, kind)
+            assert np.array_equal(a, w), (loc, kind)

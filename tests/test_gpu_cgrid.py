@@ -40,8 +40,8 @@ def test_cgrid_golden_bitwise(name):
             state, inputs, masks = c.cgrid_inputs(icall)
             for nsub in c.nsub_list:
                 out = core.cgrid_run(nsub, state, inputs, masks, visc_method=str(c.d["visc_method"]))
-                for k in ("strintxE", "strintyN"):
-                    oracle.halo_update(dom, out[k], "center", "vector")
+                oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+                oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
                 assert_bitwise(out, c.cgrid_expected(icall, nsub), f"{name} call {icall} nsub {nsub} (HIP C grid)")
     finally:
         core.finalize()
@@ -60,8 +60,8 @@ def test_cgrid_split_calls_equal_one_call():
         core.cgrid_subcycle(118)
         out = core.cgrid_download()
         dom = c.oracle_domain()
-        for k in ("strintxE", "strintyN"):
-            oracle.halo_update(dom, out[k], "center", "vector")
+        oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+        oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
         assert_bitwise(out, c.cgrid_expected(1, 120), "split calls")
         t = core.cgrid_timings()
         assert t["nsub"] == 118 and t["loop_ms"] > 0
@@ -69,19 +69,16 @@ def test_cgrid_split_calls_equal_one_call():
         core.finalize()
 
 
-def test_cgrid_refuses_what_it_does_not_do():
-    """Tripole grids and neighbours on other ranks are refused with a message, not computed wrongly."""
+def test_cgrid_fails_loudly_without_geometry():
     c = GoldenCase("trip_cyc_1blk_patchy")
     d, keep = c.hip_dims()
     core = evp.EvpHip(d, evp.make_params(c.scal_dict(), strict=True), c.d["HTE"], c.d["HTN"], c.d["dxT"], c.d["dyT"],
                       c.d["uarear"], c.d["tarea"], keepalive=keep)
     try:
         z = np.zeros(core.shape)
-        with pytest.raises(evp.EvpHipError, match="tripole"):
-            core.cgrid_set_geometry({k: z for k in evp.CGRID_STATIC})
         with pytest.raises(evp.EvpHipError, match="geometry not set"):
-            core.cgrid_subcycle(1) if False else core.cgrid_upload({k: z for k in evp.CGRID_FIELDS}, {k: z for k in evp.CGRID_INPUTS},
-                                                                   {k: z.astype(np.int32) for k in evp.CGRID_MASKS})
+            core.cgrid_upload({k: z for k in evp.CGRID_FIELDS}, {k: z for k in evp.CGRID_INPUTS},
+                              {k: z.astype(np.int32) for k in evp.CGRID_MASKS})
     finally:
         core.finalize()
 
@@ -89,18 +86,14 @@ def test_cgrid_refuses_what_it_does_not_do():
 def synth_cgrid(grid_name, case="full", bs=None, seed=3, seabed=False):
     from cice_amd import decomp, synth
     spec = synth.GRIDS[grid_name]
-    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns="closed"))
+    ns = spec.get("ns", "closed")
+    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns=ns))
     cg = synth.cgrid_geometry(g)
     state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed, seabed=seabed)
     nx, ny = spec["nx"], spec["ny"]
     bs = bs or (nx, ny)
-    dc = decomp.Decomp(nx, ny, bs[0], bs[1], "cyclic", "closed", 1)
-    ones = ("dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear", "narear",
-            "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr")
-    static = {k: dc.scatter(cg[k], 0, fill=(1.0 if k in ones else 0.0)) for k in evp.CGRID_STATIC}
-    state = {k: dc.scatter(v, 0) for k, v in state.items()}
-    inputs = {k: dc.scatter(v, 0) for k, v in inputs.items()}
-    masks = {k: dc.scatter(v, 0, fill=0) for k, v in masks.items()}
+    dc = decomp.Decomp(nx, ny, bs[0], bs[1], "cyclic", ns, 1)
+    static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
     return dc, g, static, state, inputs, masks
 
 
@@ -129,7 +122,10 @@ def run_both(dc, g, static, state, inputs, masks, ndte, visc_method="avg_zeta", 
 @pytest.mark.parametrize("grid,bs,case,visc,seabed", [("gx3", None, "full", "avg_zeta", False),
                                                       ("gx3", (30, 40), "caps", "avg_strength", True),   # padded blocks
                                                       ("gx1", None, "full", "avg_zeta", True),
-                                                      ("gx1", (80, 96), "caps", "avg_zeta", False)])
+                                                      ("gx1", (80, 96), "caps", "avg_zeta", False),
+                                                      # tripole: N faces with ice ON the fold, fold step after every phase
+                                                      ("tx1", None, "full", "avg_zeta", True),
+                                                      ("tx1", (90, 60), "full", "avg_strength", False)])
 def test_cgrid_synthetic_vs_oracle_bitwise(grid, bs, case, visc, seabed):
     """Seeded synthetic workloads at the BASELINE sizes, one block and several (padded) blocks: every array of the
     loop equal to the oracle's, bit for bit, after 24 subcycles."""
@@ -151,8 +147,8 @@ def test_cgrid_both_schedules_agree(monkeypatch):
         dom = c.oracle_domain()
         for nsub in c.nsub_list:
             out = core.cgrid_run(nsub, state, inputs, masks)
-            for k in ("strintxE", "strintyN"):
-                oracle.halo_update(dom, out[k], "center", "vector")
+            oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+            oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
             assert_bitwise(out, c.cgrid_expected(1, nsub), f"five-phase schedule nsub {nsub}")
     finally:
         core.finalize()

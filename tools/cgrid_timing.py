@@ -14,15 +14,12 @@ from cice_amd import decomp, evp, synth  # noqa: E402
 
 def case(grid, case_="full"):
     spec = synth.GRIDS[grid]
-    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns="closed"))
+    ns = spec.get("ns", "closed")
+    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns=ns))
     cg = synth.cgrid_geometry(g)
     state, inputs, masks = synth.cgrid_state(g, cg, case=case_, seed=3)
-    dc = decomp.Decomp(spec["nx"], spec["ny"], spec["nx"], spec["ny"], "cyclic", "closed", 1)
-    ones = ("dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear", "narear",
-            "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr")
-    static = {k: dc.scatter(cg[k], 0, fill=(1.0 if k in ones else 0.0)) for k in evp.CGRID_STATIC}
-    return (dc, static, {k: dc.scatter(v, 0) for k, v in state.items()}, {k: dc.scatter(v, 0) for k, v in inputs.items()},
-            {k: dc.scatter(v, 0, fill=0) for k, v in masks.items()})
+    dc = decomp.Decomp(spec["nx"], spec["ny"], spec["nx"], spec["ny"], "cyclic", ns, 1)
+    return (dc,) + synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
 
 
 def main():
