@@ -500,6 +500,29 @@ __global__ void cg_fold_scatter(EvpCgFold F)
     F.x[q][L.dst[k]] = F.tmp[(size_t)q * F.maxn + k];
 }
 
+// ---- the mask byte from the caller's four logical arrays (as 32-bit words, non-zero = true): pass 0 composes bits 0-4
+// and bit5 of interior iceU cells, pass 1 hands bit5 on to the ghost cells that mirror them (one writer per ghost) ----
+__global__ __launch_bounds__(TX *TY) void cg_mask_compose(EvpCgrid A, const int *m4, uint8_t *mask, int pass)
+{
+    const Cell c = cell(A);
+    if (!c.in) return;
+    const size_t o = c.o, n = (size_t)A.plane * A.nblocks;
+    const bool interior = c.i >= c.q.x && c.i <= c.q.y && c.j >= c.q.z && c.j <= c.q.w;
+    if (pass == 0) {
+        const unsigned u = m4[n + o] ? 2u : 0u;
+        mask[o] = (uint8_t)((m4[o] ? 1u : 0u) | u | (m4[2 * n + o] ? 4u : 0u) | (m4[3 * n + o] ? 8u : 0u) |
+                            (A.img_slot[o] >= 0 ? 16u : 0u) | ((interior && u) ? 32u : 0u));
+    } else if (interior && (mask[o] & 2u)) {
+        const int s = A.img_slot[o];
+        if (s < 0) return;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int d = A.img_dst[3 * s + k];
+            if (d >= 0) mask[d] |= 32u;
+        }
+    }
+}
+
 // ---- ranks > 1: iceU of interior cells as 0/1 doubles (exchanged like a field), and back into bit5 of the mask for the
 // ghost cells that mirror cells of other ranks ----
 __global__ __launch_bounds__(TX *TY) void cg_umask_to_double(EvpCgrid A, double *d)
@@ -533,6 +556,13 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st)
 {
     if (n > 0) hipLaunchKernelGGL(cg_zero_cells, dim3((n + 255) / 256), dim3(256), 0, st, A, cells, n);
+}
+
+void evp_launch_cgrid_mask(const EvpCgrid &A, const int *m4, hipStream_t st)
+{
+    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    hipLaunchKernelGGL(cg_mask_compose, grid, block, 0, st, A, m4, const_cast<uint8_t *>(A.mask), 0);
+    hipLaunchKernelGGL(cg_mask_compose, grid, block, 0, st, A, m4, const_cast<uint8_t *>(A.mask), 1);
 }
 
 void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st)

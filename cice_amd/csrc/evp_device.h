@@ -278,5 +278,7 @@ struct EvpCgFold {
     int maxn;
 };
 void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st);
+// m4: iceTmask | iceUmask | iceEmask | iceNmask, n 32-bit words each
+void evp_launch_cgrid_mask(const EvpCgrid &A, const int *m4, hipStream_t st);
 void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStream_t st);
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st);

@@ -31,7 +31,7 @@ struct CGridState {
     int *zero_cells = nullptr;   // ghost cells of eliminated (land) neighbour blocks
     int n_zero = 0;
     std::vector<int> h_img_slot, h_img_dst;
-    std::vector<uint8_t> hmask;
+    int32_t *mask4 = nullptr;    // the caller's four logical masks as uploaded (4 x n words)
     int avg_strength = 0;
     bool first = true;           // no subcycle has run since the upload
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, flip << 3 | fused << 2 | first << 1 | avg_strength)
@@ -49,7 +49,7 @@ void cgrid_free()
     for (auto &p : CG.f) F(p);
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
-    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.mask); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
+    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.mask); F(CG.mask4); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
     for (auto &f : CG.fold) { F(f.dst); F(f.a); F(f.b); F(f.flip); }
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
     CG.graphs.clear();
@@ -294,6 +294,7 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     if (alloc_d(&CG.strengthU, S.n) || alloc_d(&CG.s12alt, S.n)) return -1;
     if (!S.plan.peers.empty() && alloc_d(&CG.umaskd, S.n)) return -1;
     HIPC(hipMalloc((void **)&CG.mask, S.n));
+    HIPC(hipMalloc((void **)&CG.mask4, 4 * S.n * sizeof(int32_t)));
     // ghost images: for every interior cell the ghost cells of this rank that mirror it (what ice_HaloUpdate copies)
     CG.h_img_slot.assign(S.n, -1);
     std::vector<int> dst, zero;
@@ -332,7 +333,6 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
         HIPC(hipMemcpyAsync(CG.zero_cells, zero.data(), zero.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
     }
     HIPC(hipStreamSynchronize(S.stream));
-    CG.hmask.assign(S.n, 0);
     CG.geo = true;
     return 0;
 }
@@ -356,23 +356,17 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
     if (h2d_batch(B)) return -1;
     // evp() zeroes its work arrays at entry (ice_dyn_evp.F90:351-361)
     for (int k = CF_ZETA; k < CG_NF; ++k) HIPC(hipMemsetAsync(CG.f[k], 0, S.n * sizeof(double), S.stream));
-    for (size_t c = 0; c < S.n; ++c)
-        CG.hmask[c] = (uint8_t)((iceTmask[c] ? 1 : 0) | (iceUmask[c] ? 2 : 0) | (iceEmask[c] ? 4 : 0) |
-                                (iceNmask[c] ? 8 : 0) | (CG.h_img_slot[c] >= 0 ? 16 : 0));
-    // bit5: iceU of an interior cell, handed on to the ghost cells that mirror it (the caller's iceUmask is not
-    // maintained on ghost cells: dyn_prep2 sets it on ilo..ihi x jlo..jhi only, ice_dyn_shared.F90:740-745)
-    const int nx = S.d.nx_block;
-    for (int b = 0; b < S.d.nblocks; ++b)
-        for (int j = S.jlo[b]; j <= S.jhi[b]; ++j)
-            for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
-                const size_t c = (size_t)b * S.plane + (size_t)(j - 1) * nx + (i - 1);
-                if (!(CG.hmask[c] & 2)) continue;
-                CG.hmask[c] |= 32;
-                const int slot = CG.h_img_slot[c];
-                for (int k = 0; slot >= 0 && k < 3; ++k)
-                    if (CG.h_img_dst[3 * slot + k] >= 0) CG.hmask[CG.h_img_dst[3 * slot + k]] |= 32;
-            }
-    HIPC(hipMemcpyAsync(CG.mask, CG.hmask.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    // the mask byte is composed on the device from the caller's four logical arrays (bit5: iceU of an interior cell,
+    // handed on to the ghost cells that mirror it -- the caller's iceUmask is not maintained on ghost cells: dyn_prep2
+    // sets it on ilo..ihi x jlo..jhi only, ice_dyn_shared.F90:740-745)
+    {
+        const int32_t *m[4] = {iceTmask, iceUmask, iceEmask, iceNmask};
+        for (int k = 0; k < 4; ++k)
+            HIPC(hipMemcpyAsync(CG.mask4 + (size_t)k * S.n, m[k], S.n * sizeof(int32_t), hipMemcpyHostToDevice, S.stream));
+        EvpCgrid A;
+        fill(A);
+        evp_launch_cgrid_mask(A, CG.mask4, S.stream);
+    }
     CG.avg_strength = visc_method;
     if (remote()) {                              // bit5 of ghost cells other ranks own
         EvpCgrid A;
@@ -387,7 +381,7 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
         evp_launch_cgrid_phase(A, 5, 1, S.stream);
     }
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(S.stream));       // hmask is reused by the next upload
+    HIPC(hipStreamSynchronize(S.stream));       // the caller may change its arrays after this returns
     CG.uploaded = true;
     CG.first = true;
     return 0;

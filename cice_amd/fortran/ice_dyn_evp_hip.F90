@@ -183,6 +183,12 @@ module ice_dyn_evp_hip
        import :: c_int
      end function cice_evp_hip_invalidate_stresses
 
+     integer(c_int) function cice_evp_hip_pin_ptr(ptr, bytes) bind(C, name='cice_evp_hip_pin_host')
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value :: ptr
+       integer(c_int64_t), value :: bytes
+     end function cice_evp_hip_pin_ptr
+
      integer(c_int) function cice_evp_hip_cgrid_set_geometry(static23) bind(C, name='cice_evp_hip_cgrid_set_geometry')
        import :: c_int, c_ptr
        type(c_ptr), dimension(23), intent(in) :: static23
@@ -213,6 +219,7 @@ module ice_dyn_evp_hip
   logical :: stress_resident = .true.
   logical :: on_tripole = .false.
   logical :: cgrid_geometry_set = .false.
+  logical :: cgrid_pinned = .false.
 
 contains
 
@@ -602,6 +609,9 @@ contains
     type(c_ptr) :: st(23), fl(19), inp(23)
     integer(c_int32_t), pointer :: mT(:), mU(:), mE(:), mN(:)
     integer(c_int32_t) :: vm
+    integer(c_int) :: rc
+    integer(c_int64_t) :: nbytes
+    integer :: k
     character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_run)'
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
@@ -637,6 +647,18 @@ contains
     call c_f_pointer(cice_evp_hip_addr(iceUmask), mU, [size(iceUmask)])
     call c_f_pointer(cice_evp_hip_addr(iceEmask), mE, [size(iceEmask)])
     call c_f_pointer(cice_evp_hip_addr(iceNmask), mN, [size(iceNmask)])
+    if (.not. cgrid_pinned) then
+       ! the module arrays live for the whole run: page-lock them once (best effort: a failure only costs speed),
+       ! so that the per-call copies are one gather and one scatter launch over PCIe
+       nbytes = int(size(uvelE), c_int64_t) * 8_c_int64_t
+       do k = 1, 19
+          rc = cice_evp_hip_pin_ptr(fl(k), nbytes)
+       enddo
+       do k = 1, 23
+          rc = cice_evp_hip_pin_ptr(inp(k), nbytes)
+       enddo
+       cgrid_pinned = .true.
+    endif
     call ice_timer_start(timer_evp1dcore)
     call check(cice_evp_hip_cgrid_run(int(ndte, c_int32_t), vm, fl, inp, mT, mU, mE, mN), subname, __FILE__, __LINE__)
     call ice_timer_stop(timer_evp1dcore)

@@ -70,7 +70,7 @@ def run(workload):
 
 
 CGRID_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")      # bench.py CGRID_VERIFY_FIELDS
-CGRID_CONFIGS = {"gx3": ("full", 120, [1, 4]), "gx1": ("full", 120, [1, 4])}
+CGRID_CONFIGS = {"gx3": ("full", 120, [1, 4]), "gx1": ("full", 120, [1, 4]), "s01": ("full", 12, [2])}
 
 
 def cgrid_inputs(workload, case):
