@@ -160,7 +160,12 @@ __global__ __launch_bounds__(TX *TY) void cg_strain_u(EvpCgrid A)
     if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
     const size_t o = c.o, e = o + 1, n = o + A.nx;
     const unsigned m = A.mask[o];
-    if (!(m & 2u)) return;
+    if (!(m & 2u)) {
+        // strain_rates_U zero-fills shearU before computing the ice cells; on a tripole grid the fold step of the
+        // previous subcycle may have stored an average into a fold-row cell without ice
+        if (A.tripole) A.f[CF_SHEARU][o] = 0.0;
+        return;
+    }
     const double *uE = A.f[CF_UE], *vE = A.f[CF_VE], *uN = A.f[CF_UN], *vN = A.f[CF_VN];
     const double uU = A.f[CF_UU][o], vU = A.f[CF_VU][o];
     const double *epm = A.g[CG_EPM], *npm = A.g[CG_NPM];

@@ -254,6 +254,7 @@ struct EvpCgrid {
     EvpScalars p;
     double deltaminEVP;
     int nx, ny, nblocks, avg_strength;
+    int tripole;                  // the fold step writes into cells without ice: what the reference re-zeroes every subcycle is re-zeroed
     size_t plane;
 };
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,

@@ -74,6 +74,7 @@ static void fill(EvpCgrid &A)
     A.ny = S.d.ny_block;
     A.nblocks = S.d.nblocks;
     A.avg_strength = CG.avg_strength;
+    A.tripole = CG.tripole ? 1 : 0;
     A.plane = S.plane;
 }
 
