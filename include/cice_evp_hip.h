@@ -102,8 +102,10 @@ int cice_evp_hip_set_metrics(const double *cxp, const double *cyp, const double 
 /* Replaces dyn_evp1d_run (ice_dyn_evp1d.F90:121-319): H2D, `ndte` subcycles on
  * the device, D2H.  Same argument order as the reference routine, plus
  * uvel_init/vvel_init (ice_dyn_shared module arrays; read only when revp=1) and
- * the subcycle count.  On exit: 12 stresses, uvel, vvel (ghost cells current),
- * strintxU/yU, taubxU/yU hold the state after the last subcycle.              */
+ * the subcycle count.  On entry the ghost cells of uvel, vvel mirror their sources, as they do at
+ * the reference's call site (evp() halo-updates them right before the loop, ice_dyn_evp.F90:729-732):
+ * inside the loop only cells with ice are exchanged.  On exit: 12 stresses, uvel, vvel (ghost cells
+ * current), strintxU/yU, taubxU/yU hold the state after the last subcycle.      */
 int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, double *stressp_4,
                      double *stressm_1, double *stressm_2, double *stressm_3, double *stressm_4,
                      double *stress12_1, double *stress12_2, double *stress12_3, double *stress12_4,
