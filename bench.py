@@ -268,6 +268,18 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     golden = load_golden()
 
+    class AttemptFailed(RuntimeError):
+        """Some rank's device work failed (a wait gave up, a launch error): every rank leaves the attempt together."""
+
+    def agree(ok: bool) -> bool:
+        """The ranks' verdicts on the work since the last agreement, MIN over ranks.  Every rank runs the same sequence
+        of these whether or not its own work failed, so a failure never leaves ranks in different collectives."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
     def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True):
         """One timed pass: `warmup` untimed + `steps` timed evp() subcycle loops of `workload`,
         block-decomposed over the ranks; barrier + sync on both sides, MAX over ranks."""
@@ -292,35 +304,45 @@ def main():
             core = evp.EvpHip(d, evp.make_params(scal, strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
                               geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
             try:
-                if world > 1 and rehearsal:
-                    blobs = [None] * world
-                    dist.all_gather_object(blobs, core.halo_export())
-                    core.halo_import(blobs)
-                elif world > 1:
-                    uid = [core.comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(uid, src=0)
-                    core.comm_init(uid[0])
-                core.upload(fields, tm, um)
+                def setup():
+                    if world > 1 and rehearsal:
+                        blobs = [None] * world
+                        dist.all_gather_object(blobs, core.halo_export())
+                        core.halo_import(blobs)
+                    elif world > 1:
+                        uid = [core.comm_unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(uid, src=0)
+                        core.comm_init(uid[0])
+                    core.upload(fields, tm, um)
 
-                def barrier():
-                    core.sync()
-                    torch.cuda.synchronize()
-                    if world > 1:
-                        dist.barrier()
+                def sync_point(work):
+                    """`work`, then wait for the device; the barrier is an agreement on "still fine" (MIN over ranks)."""
+                    err = None
+                    try:
+                        work()
+                        core.sync()
+                        torch.cuda.synchronize()
+                    except Exception as e:  # noqa: BLE001
+                        err = e
+                    t_done = time.perf_counter()
+                    if not agree(err is None):
+                        raise AttemptFailed(f"rank {rank}: {err}" if err else f"rank {rank}: another rank failed")
+                    return t_done
 
-                for _ in range(warmup):
-                    core.subcycle(ndte)
-                barrier()
+                def warm():
+                    setup()          # (transport set-up and its probes belong to the attempt: a failure there is agreed on too)
+                    for _ in range(warmup):
+                        core.subcycle(ndte)
+
+                def timed():
+                    core.mark(0)
+                    for _ in range(steps):
+                        core.subcycle(ndte)
+                    core.mark(1)
+
+                sync_point(warm)
                 t0 = time.perf_counter()
-                core.mark(0)
-                for _ in range(steps):
-                    core.subcycle(ndte)
-                core.mark(1)
-                core.sync()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                if world > 1:
-                    dist.barrier()
+                t1 = sync_point(timed)
                 dt = t1 - t0
                 if world > 1:
                     tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -370,6 +392,32 @@ def main():
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+
+    def measure_with_fallbacks(*args, **kw):
+        """N > 1: the preferred path (whatever the library's collective start-up probes settle on) first; if some rank's
+        device work fails at run time, or the result does not verify, all ranks retry together with the on-chip resident
+        kernel off, then with RCCL point-to-point only.  What was tried is reported under `attempts`."""
+        base = dict(kw.pop("env", None) or {})
+        ladder = [({}, "library default")]
+        if world > 1:
+            ladder += [({"CICE_EVP_HIP_RESIDENT": "0"}, "streaming kernel (resident kernel across GPUs off)"),
+                       ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_HALO": "rccl"}, "streaming kernel, RCCL point-to-point only")]
+        attempts = []
+        for extra_env, label in ladder:
+            try:
+                Mx = measure(*args, env={**base, **extra_env}, **kw)
+                bad = (not Mx["finite"]) or (Mx["ver"].get("verified") is False)
+                # (verification is computed on rank 0; every rank learns the verdict)
+                if agree(not bad) or world == 1:
+                    attempts.append({"path": label, "ok": not bad})
+                    Mx["attempts"] = attempts
+                    return Mx
+                attempts.append({"path": label, "ok": False, "why": "state after the timed region does not match the committed checksum"})
+            except AttemptFailed as e:
+                attempts.append({"path": label, "ok": False, "why": str(e)[:300]})
+                if rank == 0:
+                    print(f"[bench] attempt '{label}' failed: {e}", file=sys.stderr)
+        raise RuntimeError(f"no path produced a verified result: {attempts}")
 
     def cgrid_measure(workload, case, ndte, steps, warmup):
         """The C-grid subcycle (evp()'s loop for grid_ice = 'C') on one GPU: `steps` timed loops of
@@ -464,7 +512,7 @@ def main():
         return res
 
     ndte = a.ndte or {"gx3": 120, "gx1": 120, "s01": 480}[a.workload]
-    M = measure(a.workload, a.case, ndte, a.steps, a.warmup)
+    M = measure_with_fallbacks(a.workload, a.case, ndte, a.steps, a.warmup)
     nx, ny, dc, tm, n_active, dt, tm_ev, kt = (M[k] for k in ("nx", "ny", "dc", "tm", "n_active", "dt", "tm_ev", "kt"))
     # extras must never cost the primary line: a failure is reported inside the JSON instead
     M2 = M3 = MS = None
@@ -472,7 +520,7 @@ def main():
     extra_err = {}
     if a.secondary and a.workload != "s01":
         try:      # the 0.1-degree-class grid the strong-scaling target is stated on (streaming kernel, HBM-bound)
-            M2 = measure("s01", "full", 480, 2, 1)
+            M2 = measure_with_fallbacks("s01", "full", 480, 2, 1)
         except Exception as e:  # noqa: BLE001
             extra_err["secondary"] = f"{type(e).__name__}: {e}"[:300]
     if a.secondary and world == 1 and tm_ev["tile_variant"] >= 1000:
@@ -593,7 +641,7 @@ def main():
                        "launches_per_subcycle": tm_ev["launches_per_subcycle"],
                        "halo_transport": tm_ev["halo_transport"],
                        "autotune_probe_us": {"streaming": 1e3 * tm_ev["stream_probe_ms"], "resident": 1e3 * tm_ev["resident_probe_ms"]},
-                       "resident_fallbacks": M["fallbacks"],
+                       "resident_fallbacks": M["fallbacks"], "attempts": M.get("attempts"),
                        "finite": M["finite"], "max_abs_u": M["umax"]},
             "verification": M["ver"],
             "roofline": roof,

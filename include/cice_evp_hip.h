@@ -238,7 +238,8 @@ int cice_evp_hip_prep_fetch(int32_t which, double *dst);
  *   strength cdn_ocnE aiE uocnE vocnE waterxE forcexE emassdti fmE uvelE_init TbE rheofactE
  *   cdn_ocnN aiN uocnN vocnN wateryN forceyN nmassdti fmN vvelN_init TbN rheofactN
  * visc_method: 0 'avg_zeta', 1 'avg_strength' (ice_dyn_evp.F90:992-996).
- * Not done here (it is after the loop, :1437-1440): the ice_HaloUpdate of strintxE / strintyN.            */
+ * On entry ghost cells mirror their sources, as evp()'s preparation leaves them (inside the loop only cells with ice
+ * are exchanged).  Not done here (it is after the loop, :1437-1440): the ice_HaloUpdate of strintxE / strintyN.    */
 int cice_evp_hip_cgrid_set_geometry(const double *const *static23);
 int cice_evp_hip_cgrid_run(int32_t ndte, int32_t visc_method, double *const *fields19,
                            const double *const *inputs23, const int32_t *iceTmask, const int32_t *iceUmask,

@@ -71,6 +71,27 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
     assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_bench_multi_rank_falls_back_together():
+    """bench.py at N > 1 when the preferred path fails at RUN time (test hook: one workgroup of the resident kernel
+    never shows up, so its neighbours' waits give up on both ranks): every sync point is an agreement, all ranks
+    leave the attempt together, retry with the streaming kernel and report what was tried."""
+    import json
+    import subprocess
+    import sys as _sys
+    root = Path(__file__).resolve().parents[1]
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "gx3", "--no-secondary"]
+    env = dict(os.environ, CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="3000", CICE_EVP_HIP_RES_DEBUG="16")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    att = d["config"]["attempts"]
+    assert len(att) == 2 and not att[0]["ok"] and att[1]["ok"], att
+    assert d["config"]["tile_variant"] < 1000 and d["verified"] is True and d["config"]["finite"]
+
+
 def test_bench_multi_rank_rehearsal():
     """bench.py's N>1 path (decomposition, collective set-up, barrier + MAX-over-ranks timing, the
     JSON line) rehearsed on the one GPU of this box: 2 ranks as 2 processes over gloo with the
