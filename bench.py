@@ -19,6 +19,10 @@ What the line carries besides the contract's fields:
                 fractions on gx1 and on 3600x2400, measured live in this run, with PMC traffic).
   verified      the state after the timed region (+ a few untimed steps up to the next checkpoint)
                 hashed and compared with tests/golden/bench_checksums.json (made by the CPU oracle).
+  cgrid         the C-grid subcycle on gx1 and on 3600x2400: microseconds per subcycle, verified
+                against committed oracle checksums, HBM fraction on its 648 B per cell.
+  attempts      N > 1 only: every sync point is an agreement over the ranks; a failed or unverified attempt is
+                repeated by all ranks with the resident kernel off, then with RCCL only (config.attempts).
   cpu_baseline  the reference's own evp() timed on this box's cores (2-d path and its 1-d core), and --
                 the checker's job -- the HIP path run on the inputs the reference captured in this
                 same run, compared bit for bit with the reference's outputs (`reference_parity`).
