@@ -202,11 +202,18 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
     B.items.push_back({S.u[cur], f[F_UVEL]});
     B.items.push_back({S.v[cur], f[F_VVEL]});
     if (h2d_batch(B)) return -1;
-    if (!keep_sig)
-        for (int k = 0; k < 12; ++k)
-            HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    HIPC(hipMemcpyAsync(S.u[cur ^ 1], S.u[cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    HIPC(hipMemcpyAsync(S.v[cur ^ 1], S.v[cur], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    {   // the second ping-pong copy of what was uploaded: one launch
+        EvpCopyTab T{};
+        T.len = S.n;
+        T.vec2 = 1;
+        if (!keep_sig)
+            for (int k = 0; k < 12; ++k) { T.src[T.n] = S.sig[0][k]; T.dst[T.n] = S.sig[1][k]; ++T.n; }
+        T.src[T.n] = S.u[cur]; T.dst[T.n] = S.u[cur ^ 1]; ++T.n;
+        T.src[T.n] = S.v[cur]; T.dst[T.n] = S.v[cur ^ 1]; ++T.n;
+        for (int k = 0; k < T.n; ++k)
+            if ((((uintptr_t)T.src[k]) | ((uintptr_t)T.dst[k])) & 15u) T.vec2 = 0;
+        evp_launch_copy_many(T, S.stream);
+    }
     bool water_is_ocn = true, tbu_zero = true;
     {
         const double *wx = f[F_WATERX], *wy = f[F_WATERY], *uo = f[F_UOCN], *vo = f[F_VOCN], *tb = f[F_TBU];

@@ -161,8 +161,8 @@ struct EvpPrep {
     int ssh_coupled;
 };
 struct EvpPrepHalo {
-    double *a[8];
-    unsigned char is_vec[8];
+    double *a[10];
+    unsigned char is_vec[10];
     int narr;
     const int *dst, *src;
     const signed char *vsign;
@@ -172,6 +172,8 @@ void evp_launch_prep1(const EvpPrep &P, int nblocks, hipStream_t st);
 void evp_launch_halo_center(const EvpPrepHalo &H, hipStream_t st);
 void evp_launch_prep_average(const EvpPrep &P, int nblocks, hipStream_t st);
 void evp_launch_prep2(const EvpPrep &P, int nblocks, hipStream_t st);
+void evp_launch_prep_average_prep2(const EvpPrep &P, int nblocks, hipStream_t st);
+void evp_launch_words_to_bytes(const int32_t *w, uint8_t *b, size_t n, hipStream_t st);
 void evp_launch_seabed_lkd(const EvpPrep &P, int nblocks, const double *hwater, double *TbU, double k1, double k2,
                            double alphab, double threshold_hw, unsigned *flagword, hipStream_t st);
 

@@ -124,6 +124,7 @@ struct State {
     struct Prep {
         bool geo = false;
         uint8_t *tmask = nullptr, *umask = nullptr, *umask_old = nullptr, *tmphm = nullptr;
+        int32_t *umask_old32 = nullptr;          // the caller's words as uploaded (reduced to bytes on the device)
         double *hm = nullptr, *tarea = nullptr, *uarea = nullptr, *fcor = nullptr, *hwater = nullptr;
         double *t[11] = {};
         double *tmass = nullptr, *umass = nullptr, *maskd = nullptr;

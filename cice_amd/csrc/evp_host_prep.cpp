@@ -17,6 +17,7 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
                         "keep evp()'s host preparation and use cice_evp_hip_run on this configuration");
     auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };
     if (B(Q.tmask) || B(Q.umask) || B(Q.umask_old) || B(Q.tmphm)) return -1;
+    HIPC(hipMalloc((void **)&Q.umask_old32, S.n * sizeof(int32_t)));
     auto D = [&](double *&p) -> int { return p ? 0 : alloc_d(&p, S.n); };
     if (D(Q.hm) || D(Q.tarea) || D(Q.uarea) || D(Q.fcor) || D(Q.tmass) || D(Q.umass) || D(Q.maskd) ||
         D(Q.ss_tltxU) || D(Q.ss_tltyU) || D(Q.strairxU) || D(Q.strairyU) || D(Q.strtltx) || D(Q.strtlty)) return -1;
@@ -62,26 +63,30 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     if (nsig == 0 && !S.uploaded) return fail(-1, "no stresses on the device yet: the first call must upload them");
     if (!fields32[F_UVEL] || !fields32[F_VVEL]) return fail(-1, "null velocity field");
     HIPC(hipEventRecord(S.ev2, S.stream));
-    for (int k = 0; k < 11; ++k)
-        if (h2d(Q.t[k], tfields11[k])) return -1;
+    // everything that travels in, as ONE gather launch over the arrays the caller page-locked (cice_evp_hip_pin_host)
+    CopyBatch B;
+    for (int k = 0; k < 11; ++k) B.items.push_back({Q.t[k], tfields11[k]});
     for (int k = 0; k < 12; ++k) {
         if (nsig) {
-            if (h2d(S.sig[0][k], fields32[k])) return -1;
+            B.items.push_back({S.sig[0][k], fields32[k]});
         } else if (S.cur != 0) {
             HIPC(hipMemcpyAsync(S.sig[0][k], S.sig[S.cur][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
         }
     }
     S.cur = 0;
-    if (h2d(S.u[0], fields32[F_UVEL]) || h2d(S.v[0], fields32[F_VVEL])) return -1;
+    B.items.push_back({S.u[0], fields32[F_UVEL]});
+    B.items.push_back({S.v[0], fields32[F_VVEL]});
     bool tbu_zero = true;
     if (fields32[F_TBU]) {
-        if (h2d(S.in[F_TBU], fields32[F_TBU])) return -1;
+        B.items.push_back({S.in[F_TBU], fields32[F_TBU]});
         for (size_t k = 0; k < S.n && tbu_zero; ++k) tbu_zero = fields32[F_TBU][k] == 0.0;
     } else {
         HIPC(hipMemsetAsync(S.in[F_TBU], 0, S.n * sizeof(double), S.stream));
     }
-    for (size_t k = 0; k < S.n; ++k) Q.h8[k] = iceUmask[k] != 0;
-    HIPC(hipMemcpyAsync(Q.umask_old, Q.h8.data(), S.n, hipMemcpyHostToDevice, S.stream));
+    if (h2d_batch(B)) return -1;
+    // the previous call's iceUmask: the caller's 32-bit logical words, reduced to bytes on the device
+    HIPC(hipMemcpyAsync(Q.umask_old32, iceUmask, S.n * sizeof(int32_t), hipMemcpyHostToDevice, S.stream));
+    evp_launch_words_to_bytes(Q.umask_old32, Q.umask_old, S.n, S.stream);
     HIPC(hipMemsetAsync(Q.flagword, 0, sizeof(unsigned), S.stream));
     HIPC(hipEventRecord(S.ev3, S.stream));
 
@@ -113,9 +118,9 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
         evp_launch_halo_center(H, S.stream);
     };
     // ice_dyn_evp.F90:413-428: iceTmask; tmass, aice_init, cdn_ocn (scalars); uocn, vocn, ss_tltx/y (vectors)
+    // and :466-469 (calc_strair branch): strairxT, strairyT -- one launch for all ten
     halo({{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false},
-          {Q.t[5], true}, {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}});
-    halo({{Q.t[9], true}, {Q.t[10], true}});                 // :466-469 (calc_strair branch)
+          {Q.t[5], true}, {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}, {Q.t[9], true}, {Q.t[10], true}});
     if (S.plan.center_remote) {
         // neighbours on other ranks (no tripole fold here: centre and corner fields mirror the same
         // cells, so the velocity exchange carries pairs of T-grid fields)
@@ -123,8 +128,7 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
         for (auto &pr : pairs)
             if (int rc = halo_remote_pair(pr[0], pr[1])) return rc;
     }
-    evp_launch_prep_average(P, S.d.nblocks, S.stream);
-    evp_launch_prep2(P, S.d.nblocks, S.stream);
+    evp_launch_prep_average_prep2(P, S.d.nblocks, S.stream);      // T -> U averages and dyn_prep2 in one launch
     // ghost velocities before the loop (:729-732): the same exchange as inside the loop
     {
         const bool pushed = S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH);
@@ -133,10 +137,17 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
                                   (const signed char *)S.h_local_sign, S.n_local, S.stream);
         if (int rc = halo_uv(0)) return rc;
     }
-    for (int k = 0; k < 12; ++k)
-        HIPC(hipMemcpyAsync(S.sig[1][k], S.sig[0][k], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    HIPC(hipMemcpyAsync(S.u[1], S.u[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-    HIPC(hipMemcpyAsync(S.v[1], S.v[0], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    {   // the second ping-pong copy of the state: one launch for the fourteen arrays
+        EvpCopyTab T{};
+        T.len = S.n;
+        T.vec2 = 1;
+        for (int k = 0; k < 12; ++k) { T.src[T.n] = S.sig[0][k]; T.dst[T.n] = S.sig[1][k]; ++T.n; }
+        T.src[T.n] = S.u[0]; T.dst[T.n] = S.u[1]; ++T.n;
+        T.src[T.n] = S.v[0]; T.dst[T.n] = S.v[1]; ++T.n;
+        for (int k = 0; k < T.n; ++k)
+            if ((((uintptr_t)T.src[k]) | ((uintptr_t)T.dst[k])) & 15u) T.vec2 = 0;
+        evp_launch_copy_many(T, S.stream);
+    }
     evp_launch_vrelfac(S.in[F_AIX], S.in[F_CW], S.prm.rhow, S.vrelfac, S.n, S.stream);
     HIPC(hipEventRecord(S.ev1, S.stream));
     // masks and the shortcut flag back to the host

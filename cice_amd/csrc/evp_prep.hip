@@ -40,6 +40,30 @@ __global__ void prep1a(EvpPrep P)
     P.tmphm[c] = (uint8_t)(tm && (P.t[0][c] > P.dyn_area_min) && (tmass > P.dyn_mass_min));
 }
 
+// both loops of dyn_prep1 in one launch: the "has ice" predicate of the 3 x 3 neighbourhood is recomputed from the
+// T-grid fields (same expression, same operands: ghost cells carry the caller's values in either form)
+__global__ void prep1(EvpPrep P)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const bool tm = P.tmask[c] != 0;
+    P.tmass[c] = tm ? (P.rhoi * P.t[1][c] + P.rhos * P.t[2][c]) : 0.0;
+    const int4 r = P.blk[bz];
+    double m = 0.0;
+    if (i >= r.x && i <= r.y && j >= r.z && j <= r.w && tm) {
+        bool any = false;
+        for (int dj = -1; dj <= 1; ++dj)
+            for (int di = -1; di <= 1; ++di) {
+                const size_t q = c + (ptrdiff_t)dj * P.nx + di;
+                const bool tq = P.tmask[q] != 0;
+                const double tmass = tq ? (P.rhoi * P.t[1][q] + P.rhos * P.t[2][q]) : 0.0;
+                any = any || (tq && (P.t[0][q] > P.dyn_area_min) && (tmass > P.dyn_mass_min));
+            }
+        m = any ? 1.0 : 0.0;
+    }
+    P.maskd[c] = m;
+}
+
 // dyn_prep1, second loop (:560-575): extent mask = any of the 3x3 neighbourhood, physical cells only
 __global__ void prep1b(EvpPrep P)
 {
@@ -71,10 +95,8 @@ __global__ void halo_center(EvpPrepHalo H)
 }
 
 // T -> U averages on the physical cells, 0 elsewhere (work2(:,:,:) = c0 first)
-__global__ void prep_average(EvpPrep P)
+__device__ __forceinline__ void prep_average_cell(const EvpPrep &P, int i, int j, int bz, size_t c)
 {
-    int i, j, bz; size_t c;
-    if (!cell_of(P, i, j, bz, c)) return;
     const int4 r = P.blk[bz];
     const bool in = i >= r.x && i <= r.y && j >= r.z && j <= r.w;
     double o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -99,12 +121,16 @@ __global__ void prep_average(EvpPrep P)
     P.umass[c] = o[0]; P.aiU[c] = o[1]; P.cdn_ocnU[c] = o[2]; P.uocnU[c] = o[3]; P.vocnU[c] = o[4];
     P.ss_tltxU[c] = o[5]; P.ss_tltyU[c] = o[6]; P.strairxU[c] = o[7]; P.strairyU[c] = o[8];
 }
-
-// dyn_prep2 (:697-838)
-__global__ void prep2(EvpPrep P)
+__global__ void prep_average(EvpPrep P)
 {
     int i, j, bz; size_t c;
     if (!cell_of(P, i, j, bz, c)) return;
+    prep_average_cell(P, i, j, bz, c);
+}
+
+// dyn_prep2 (:697-838)
+__device__ __forceinline__ void prep2_cell(const EvpPrep &P, int i, int j, int bz, size_t c)
+{
     const int4 r = P.blk[bz];
     const bool iceT = P.maskd[c] != 0.0;
     if (!iceT)
@@ -156,6 +182,27 @@ __global__ void prep2(EvpPrep P)
     P.umassdti[c] = umassdti;
     P.mask[c] = (uint8_t)((iceT ? 1 : 0) | (iceU ? 2 : 0));
 }
+__global__ void prep2(EvpPrep P)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    prep2_cell(P, i, j, bz, c);
+}
+// the averages of a U-cell are read back by dyn_prep2 at that very cell only: one launch, one thread does both
+// (its own stores are visible to it)
+__global__ void prep_average_prep2(EvpPrep P)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    prep_average_cell(P, i, j, bz, c);
+    prep2_cell(P, i, j, bz, c);
+}
+
+__global__ void words_to_bytes(const int32_t *__restrict__ w, uint8_t *__restrict__ b, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) b[k] = w[k] != 0;
+}
 
 // seabed_stress_factor_LKD (ice_dyn_shared.F90:1386-1460) on the ice U-cells, 0 elsewhere (dyn_prep2 zeroes
 // TbU first, :706).  exp() is the device library's (<= 1 ulp): the one operation of this file whose last
@@ -188,8 +235,15 @@ dim3 cell_grid(const EvpPrep &P, int nblocks) { return dim3((P.nx + 63) / 64, P.
 
 void evp_launch_prep1(const EvpPrep &P, int nblocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(prep1a, cell_grid(P, nblocks), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(prep1b, cell_grid(P, nblocks), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(prep1, cell_grid(P, nblocks), dim3(64), 0, st, P);
+}
+void evp_launch_prep_average_prep2(const EvpPrep &P, int nblocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(prep_average_prep2, cell_grid(P, nblocks), dim3(64), 0, st, P);
+}
+void evp_launch_words_to_bytes(const int32_t *w, uint8_t *b, size_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(words_to_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, b, n);
 }
 
 void evp_launch_halo_center(const EvpPrepHalo &H, hipStream_t st)
