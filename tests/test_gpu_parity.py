@@ -1000,3 +1000,35 @@ def test_random_independent_masks_vs_oracle(seed, grid, bs, holes, kernel, monke
     want = run_oracle(dc, geo, fields, tm, um, scal, 9)
     assert_bitwise(got, want, f"random masks seed {seed} {kernel}")
     assert np.isfinite(want["uvel"]).all()
+
+
+@pytest.mark.parametrize("kernel", ["resident", "streaming"])
+@pytest.mark.parametrize("name,seed,holes", [("trip_cyc_1blk_patchy", 21, 0.3), ("trip_cyc_2x2_full", 22, 0.5),
+                                             ("trip_cyc_4x3_caps", 23, 0.4), ("pop_cyc_3x2pad_caps", 24, 0.5)])
+def test_random_masks_on_fixture_grids_vs_oracle(name, seed, holes, kernel, monkeypatch):
+    """The reference's own grids and operands (tripole fold, several blocks, padded blocks) with random holes punched
+    into iceTmask and iceUmask independently; ghost cells made consistent the way evp() does before the loop (halo
+    update: masks as scalars, velocities as NE-corner vectors -- on the fold row that is the pairwise average).
+    Resident and streaming kernels against the oracle, bit for bit."""
+    c = GoldenCase(name)
+    dom, p, static = c.oracle_domain(), c.oracle_params(), c.static()
+    dyn, tm, um = c.inputs(1)
+    rng = np.random.default_rng(seed)
+    tmd = oracle.halo_update(dom, np.ascontiguousarray(tm * (rng.random(tm.shape) > holes), dtype=np.float64), "center", "scalar")
+    umd = oracle.halo_update(dom, np.ascontiguousarray(um * (rng.random(um.shape) > holes), dtype=np.float64), "NEcorner", "scalar")
+    tm2 = (tmd == 1.0).astype(np.int32)
+    um2 = (umd == 1.0).astype(np.int32)            # fold-row partners that disagree (average 0.5): no ice on either
+    dyn = {k: np.array(v, dtype=np.float64, copy=True) for k, v in dyn.items()}
+    for k in evp.FIELDS[:12]:
+        dyn[k] = dyn[k] * tm2
+    for k in ("uvel", "vvel", "uvel_init", "vvel_init"):
+        dyn[k] = oracle.halo_update(dom, np.ascontiguousarray(dyn[k] * um2), "NEcorner", "vector")
+    want = oracle.subcycle(dom, p, 9, dyn, static, tm2, um2)
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if kernel == "resident" else "0")
+    core = hip_from_case(c, strict=True)
+    try:
+        got = core.run(dyn, tm2, um2, ndte=9)
+        assert (core.timings()["tile_variant"] >= 1000) == (kernel == "resident")
+    finally:
+        core.finalize()
+    assert_bitwise(got, {k: want[k] for k in evp.OUTPUTS}, f"{name} random masks {kernel}")
