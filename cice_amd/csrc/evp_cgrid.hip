@@ -528,6 +528,31 @@ __global__ __launch_bounds__(TX *TY) void cg_mask_compose(EvpCgrid A, const int 
     }
 }
 
+// the same in ONE launch when the lists are short enough for one workgroup to order "all reads, then all writes" with a
+// barrier (every thread keeps to its own entries in both passes; tmp holds its values in between)
+__global__ __launch_bounds__(1024) void cg_fold_one(EvpCgFold F)
+{
+    for (int q = 0; q < F.nfields; ++q) {
+        const EvpCgFoldList &L = F.L[F.loc[q]];
+        const double *x = F.x[q];
+        const double isign = F.isign[q];
+        for (int k = threadIdx.x; k < L.n; k += 1024) {
+            const int a = L.a[k], b = L.b[k];
+            const double s = L.flip[k] ? isign : 1.0;
+            const double xa = a >= 0 ? x[a] : 0.0;
+            double v;
+            if (b >= 0 || b == -2) v = s * (0.5 * (xa + isign * (b >= 0 ? x[b] : 0.0)));
+            else v = s * xa;
+            F.tmp[(size_t)q * F.maxn + k] = v;
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < F.nfields; ++q) {
+        const EvpCgFoldList &L = F.L[F.loc[q]];
+        for (int k = threadIdx.x; k < L.n; k += 1024) F.x[q][L.dst[k]] = F.tmp[(size_t)q * F.maxn + k];
+    }
+}
+
 // ---- ranks > 1: iceU of interior cells as 0/1 doubles (exchanged like a field), and back into bit5 of the mask for the
 // ghost cells that mirror cells of other ranks ----
 __global__ __launch_bounds__(TX *TY) void cg_umask_to_double(EvpCgrid A, double *d)
@@ -573,6 +598,10 @@ void evp_launch_cgrid_mask(const EvpCgrid &A, const int *m4, hipStream_t st)
 void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st)
 {
     if (F.nfields <= 0 || F.maxn <= 0) return;
+    if (F.maxn <= 8192) {            // one workgroup, one launch
+        hipLaunchKernelGGL(cg_fold_one, dim3(1), dim3(1024), 0, st, F);
+        return;
+    }
     const dim3 grid((F.maxn + 255) / 256, F.nfields);
     hipLaunchKernelGGL(cg_fold_gather, grid, dim3(256), 0, st, F);
     hipLaunchKernelGGL(cg_fold_scatter, grid, dim3(256), 0, st, F);
