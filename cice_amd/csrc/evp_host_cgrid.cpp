@@ -278,10 +278,9 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     const HaloPlan &P = S.plan;
     const bool tripole = S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE;
     if (S.d.ns_boundary_type > CICE_EVP_BND_TRIPOLE) return fail(-4, "C-grid EVP: tripoleT is not supported");
-    if (tripole)
-        for (const HaloPeer &p : P.peers)
-            if (!p.send_src.empty() || !p.recv_dst.empty())
-                return fail(-4, "C-grid EVP on a tripole grid: one rank only (the fold step needs every top-row block here)");
+    if (tripole && P.fold_rows == 2)
+        return fail(-4, "C-grid EVP on a tripole grid: the blocks next to the fold (rows NY-1, NY) must all be on one rank "
+                        "(split the domain in y only); here they are shared with other ranks");
     cgrid_free();
     CG.tripole = tripole;
     for (auto &p : CG.f)
@@ -326,7 +325,7 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMalloc((void **)&CG.img_dst, dst.size() * sizeof(int)));
     HIPC(hipMemcpyAsync(CG.img_slot, CG.h_img_slot.data(), S.n * sizeof(int), hipMemcpyHostToDevice, S.stream));
     HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
-    if (tripole)
+    if (tripole && P.fold_rows == 1)             // (ranks without the fold rows run the same schedule with empty lists)
         if (int rc = build_fold_lists()) return rc;
     CG.n_zero = (int)zero.size();
     if (CG.n_zero) {

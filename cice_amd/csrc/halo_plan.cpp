@@ -115,6 +115,15 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
         }
     }
 
+    if (tripole) {      // owners of the blocks that hold rows NY-1 / NY
+        bool mine = false, others = false;
+        for (const HaloBlock &B : T.blk) {
+            if (B.owner < 0 || B.gj0 + B.gny - 1 < d.ny_global - 1) continue;
+            (B.owner == me ? mine : others) = true;
+        }
+        plan.fold_rows = !mine ? 0 : (others ? 2 : 1);
+    }
+
     std::map<int, HaloPeer> peers;
     struct GhostSeam { int R; int32_t dst; int sig; int sign; };
     std::vector<GhostSeam> ghost_seam;           // ghost cells (of any rank) that mirror a seam-row cell, canonical order

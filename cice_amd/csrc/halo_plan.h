@@ -59,6 +59,9 @@ struct HaloPlan {
     std::vector<int8_t> fin_coef;
     int tail = 0;
     bool stress_remote = false;                   // the stress symmetrisation needs a top-row cell of another rank
+    // tripole: which ranks hold the two physical rows next to the fold (NY-1, NY)?  0: none here, 1: all of them here,
+    // 2: shared with other ranks (the C-grid fold step then cannot be done on one rank)
+    int fold_rows = 0;
     // ice_HaloUpdate_stress (ice_boundary.F90:7441-7826; evp() after the subcycle loop,
     // ice_dyn_evp.F90:1321-1389): ghost row NY+1 of a cell-centre scalar takes the mirrored top
     // physical row of its PARTNER array, a1(ig, NY+1) <- a2(NX-ig+1, NY); ghost cells whose source

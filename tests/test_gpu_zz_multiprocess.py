@@ -117,7 +117,10 @@ def test_bench_multi_rank_rehearsal():
 
 @pytest.mark.parametrize("world,workload,shape,extra", [(2, "gx3", "", []), (4, "gx3", "2x2", ["--blocks-per-rank", "2x2", "--timing"]),
                                                         (2, "gx1", "1x2", ["--visc", "avg_strength"]),
-                                                        (4, "gx1", "2x2", ["--timing"])])
+                                                        (4, "gx1", "2x2", ["--timing"]),
+                                                        # tripole grid cut in y: the rank with the fold rows does the
+                                                        # fold steps, every rank the five-phase schedule
+                                                        (2, "tx1", "1x2", []), (3, "tx1", "1x3", ["--blocks-per-rank", "2x1"])])
 def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
     """The C-grid subcycle split over `world` ranks (processes sharing this box's GPU): ghost cells that mirror
     cells of other ranks are filled through the mailbox transport after every producing launch -- five exchange
