@@ -20,6 +20,20 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen)
     return (int)g_err.size();
 }
 
+// host only: the C-grid fold step of one location for the decomposition in `dims` (counts first, then the lists)
+int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int32_t *count, int32_t *dst, int32_t *a,
+                                 int32_t *b, int32_t *flip)
+{
+    if (!dims || !count || loc < 0 || loc > 3) return fail(-1, "bad argument");
+    if (dims->ns_boundary_type != CICE_EVP_BND_TRIPOLE) return fail(-1, "not a tripole grid");
+    FoldList L;
+    build_fold_list(*dims, loc, L);
+    *count = (int32_t)L.dst.size();
+    if (dst && a && b && flip)
+        for (size_t k = 0; k < L.dst.size(); ++k) { dst[k] = L.dst[k]; a[k] = L.a[k]; b[k] = L.b[k]; flip[k] = L.flip[k]; }
+    return 0;
+}
+
 int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second)
 {
     if (ncells <= 0 || !bytes_per_second) return fail(-1, "bad argument");

@@ -185,69 +185,19 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
     return 0;
 }
 
-// Fold lists by the meaning of the cells (ice_boundary.F90:1626-1722, u-fold): for every cell of every block -- interior
-// or ghost -- in the top physical row NY (locations with points ON the fold: NE corner, N face) or in the ghost row
-// NY+1 (all locations), where its value comes from.  Sources are interior cells of this rank (raw values).
+// Fold lists (halo_plan.cpp: build_fold_list) on the device
 static int build_fold_lists()
 {
-    const int NX = S.d.nx_global, NY = S.d.ny_global, nx = S.d.nx_block, ng = S.d.nghost;
-    if (NX % 2) return fail(-4, "tripole: nx_global must be even");
-    std::vector<int> owner((size_t)NX * 2, -1);              // interior cell holding global (ig, NY-1) / (ig, NY)
-    for (int b = 0; b < S.d.nblocks; ++b)
-        for (int j = S.jlo[b]; j <= S.jhi[b]; ++j) {
-            const int jg = S.jglob0[b] + (j - S.jlo[b]);
-            if (jg < NY - 1 || jg > NY) continue;
-            for (int i = S.ilo[b]; i <= S.ihi[b]; ++i) {
-                const int ig = S.iglob0[b] + (i - S.ilo[b]);
-                owner[(size_t)(jg - (NY - 1)) * NX + (ig - 1)] = (int)((size_t)b * S.plane + (size_t)(j - 1) * nx + (i - 1));
-            }
-        }
-    auto own = [&](int ig, int row) {                         // row 0: NY-1, 1: NY
-        while (ig < 1) ig += NX;
-        while (ig > NX) ig -= NX;
-        return owner[(size_t)row * NX + (ig - 1)];
-    };
+    if (S.d.nx_global % 2) return fail(-4, "tripole: nx_global must be even");
+    cice_evp_hip_dims d = S.d;
+    d.ilo = S.ilo.data(); d.ihi = S.ihi.data(); d.jlo = S.jlo.data(); d.jhi = S.jhi.data();
+    d.iglob0 = S.iglob0.data(); d.jglob0 = S.jglob0.data();
     CG.fold_maxn = 0;
     for (int loc = 0; loc < 4; ++loc) {
-        std::vector<int> dst, a, bb;
-        std::vector<unsigned char> flip;
-        for (int b = 0; b < S.d.nblocks; ++b)
-            for (int j = S.jlo[b] - ng; j <= S.jhi[b] + ng; ++j) {
-                const int jg = S.jglob0[b] + (j - S.jlo[b]);
-                if (jg != NY && jg != NY + 1) continue;
-                if (jg == NY + 1 && j <= S.jhi[b]) continue;   // (cannot happen: NY+1 is never an interior row)
-                for (int i = S.ilo[b] - ng; i <= S.ihi[b] + ng; ++i) {
-                    int ig = S.iglob0[b] + (i - S.ilo[b]);
-                    while (ig < 1) ig += NX;
-                    while (ig > NX) ig -= NX;
-                    const int d = (int)((size_t)b * S.plane + (size_t)(j - 1) * nx + (i - 1));
-                    if (jg == NY) {
-                        if (loc == 1) {                       // NE corner: pairs i <-> NX-i, poles NX/2 and NX
-                            if (ig == NX / 2 || ig == NX) { dst.push_back(d); a.push_back(own(ig, 1)); bb.push_back(-1); flip.push_back(1); }
-                            else if (ig < NX / 2) { dst.push_back(d); a.push_back(own(ig, 1)); bb.push_back(own(NX - ig, 1)); flip.push_back(0); }
-                            else { dst.push_back(d); a.push_back(own(NX - ig, 1)); bb.push_back(own(ig, 1)); flip.push_back(1); }
-                        } else if (loc == 3) {                // N face: pairs i <-> NX+1-i
-                            if (ig <= NX / 2) { dst.push_back(d); a.push_back(own(ig, 1)); bb.push_back(own(NX + 1 - ig, 1)); flip.push_back(0); }
-                            else { dst.push_back(d); a.push_back(own(NX + 1 - ig, 1)); bb.push_back(own(ig, 1)); flip.push_back(1); }
-                        }
-                        continue;                             // centre / E face: the top row is an ordinary row
-                    }
-                    // ghost row NY+1: mirror with offsets (0,0) centre, (1,1) NE corner, (1,0) E face, (0,1) N face
-                    const int is = (loc == 0 || loc == 3) ? NX - ig + 1 : NX - ig;
-                    const int row = (loc == 0 || loc == 2) ? 1 : 0;
-                    dst.push_back(d); a.push_back(own(is, row)); bb.push_back(-1); flip.push_back(1);
-                }
-            }
-        for (size_t k = 0; k < dst.size(); ++k)              // a point ON the fold whose partner's block was eliminated
-            if (!flip.empty() && bb[k] == -1 && (loc == 1 || loc == 3)) {
-                const int dj = (int)((dst[k] % S.plane) / nx) + 1, db = (int)(dst[k] / S.plane);
-                const bool seam_row = S.jglob0[db] + (dj - S.jlo[db]) == NY;
-                int ig = S.iglob0[db] + ((int)(dst[k] % nx) + 1 - S.ilo[db]);
-                while (ig < 1) ig += NX;
-                while (ig > NX) ig -= NX;
-                const bool pole = loc == 1 && (ig == NX / 2 || ig == NX);
-                if (seam_row && !pole) bb[k] = -2;
-            }
+        FoldList L;
+        build_fold_list(d, loc, L);
+        const std::vector<int32_t> &dst = L.dst, &a = L.a, &bb = L.b;
+        const std::vector<uint8_t> &flip = L.flip;
         CGridState::Fold &Fd = CG.fold[loc];
         Fd.n = (int)dst.size();
         CG.fold_maxn = std::max(CG.fold_maxn, Fd.n);

@@ -357,3 +357,54 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
         }
     return true;
 }
+
+
+void build_fold_list(const cice_evp_hip_dims &d, int loc, FoldList &L)
+{
+    L = FoldList();
+    const int NX = d.nx_global, NY = d.ny_global, nx = d.nx_block, ng = d.nghost;
+    const size_t plane = (size_t)nx * d.ny_block;
+    std::vector<int> owner((size_t)NX * 2, -1);              // interior cell holding global (ig, NY-1) / (ig, NY)
+    for (int b = 0; b < d.nblocks; ++b)
+        for (int j = d.jlo[b]; j <= d.jhi[b]; ++j) {
+            const int jg = d.jglob0[b] + (j - d.jlo[b]);
+            if (jg < NY - 1 || jg > NY) continue;
+            for (int i = d.ilo[b]; i <= d.ihi[b]; ++i) {
+                const int ig = d.iglob0[b] + (i - d.ilo[b]);
+                owner[(size_t)(jg - (NY - 1)) * NX + (ig - 1)] = (int)((size_t)b * plane + (size_t)(j - 1) * nx + (i - 1));
+            }
+        }
+    auto wrap = [&](int ig) {
+        while (ig < 1) ig += NX;
+        while (ig > NX) ig -= NX;
+        return ig;
+    };
+    auto own = [&](int ig, int row) { return owner[(size_t)row * NX + (wrap(ig) - 1)]; };   // row 0: NY-1, 1: NY
+    auto add = [&](int dd, int aa, int bb, int fl) { L.dst.push_back(dd); L.a.push_back(aa); L.b.push_back(bb); L.flip.push_back((uint8_t)fl); };
+    // a point ON the fold is averaged with its partner even when the partner's block was eliminated (the buffer holds 0)
+    auto pair = [&](int dd, int ia, int ib, int fl) { const int pb = own(ib, 1); add(dd, own(ia, 1), pb >= 0 ? pb : -2, fl); };
+    for (int b = 0; b < d.nblocks; ++b)
+        for (int j = d.jlo[b] - ng; j <= d.jhi[b] + ng; ++j) {
+            const int jg = d.jglob0[b] + (j - d.jlo[b]);
+            if (jg != NY && jg != NY + 1) continue;
+            for (int i = d.ilo[b] - ng; i <= d.ihi[b] + ng; ++i) {
+                const int ig = wrap(d.iglob0[b] + (i - d.ilo[b]));
+                const int dd = (int)((size_t)b * plane + (size_t)(j - 1) * nx + (i - 1));
+                if (jg == NY) {
+                    if (loc == 1) {                           // NE corner: pairs i <-> NX-i, poles NX/2 and NX
+                        if (ig == NX / 2 || ig == NX) add(dd, own(ig, 1), -1, 1);
+                        else if (ig < NX / 2) pair(dd, ig, NX - ig, 0);
+                        else pair(dd, NX - ig, ig, 1);
+                    } else if (loc == 3) {                    // N face: pairs i <-> NX+1-i
+                        if (ig <= NX / 2) pair(dd, ig, NX + 1 - ig, 0);
+                        else pair(dd, NX + 1 - ig, ig, 1);
+                    }
+                    continue;                                 // centre / E face: the top row is an ordinary row
+                }
+                // ghost row NY+1: mirror with offsets (0,0) centre, (1,1) NE corner, (1,0) E face, (0,1) N face
+                const int is = (loc == 0 || loc == 3) ? NX - ig + 1 : NX - ig;
+                const int row = (loc == 0 || loc == 2) ? 1 : 0;
+                add(dd, own(is, row), -1, 1);
+            }
+        }
+}

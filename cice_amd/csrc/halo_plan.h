@@ -80,3 +80,16 @@ struct HaloPlan {
 
 // Returns false and sets plan.error on inconsistent input.
 bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan);
+
+// C grid on a tripole (u-fold) grid: the fold step of one field location (0 centre, 1 NE corner, 2 E face, 3 N face),
+// by the meaning of the cells (ice_boundary.F90:1626-1722): one entry for every cell of every local block -- interior
+// or ghost -- in the top physical row NY (locations with points ON the fold: NE corner, N face) or in the ghost row
+// NY+1 (every location).    x[dst] = s * 0.5*(x[a] + isign*x[b])   b >= 0 (or -2: partner's block eliminated, 0)
+//                           x[dst] = s * x[a]                      b == -1 (a == -1: source eliminated, 0)
+// s = flip ? isign : 1; isign = -1 for vector kinds.  Sources are interior cells of THIS rank (the blocks holding rows
+// NY-1 and NY must all be local).  Host only.
+struct FoldList {
+    std::vector<int32_t> dst, a, b;
+    std::vector<uint8_t> flip;
+};
+void build_fold_list(const cice_evp_hip_dims &d, int loc, FoldList &L);

@@ -45,7 +45,7 @@ EXPORTS = [
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
-    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe",
+    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -158,6 +158,18 @@ def make_params(scal: dict, strict: bool = False) -> Params:
               "deltaminEVP", "u0", "cosw", "sinw", "rhow"):
         setattr(p, k, float(scal[k]))
     return p
+
+
+def cgrid_fold_plan(dims: "Dims", loc: str) -> dict:
+    """Host only: the C-grid fold step of one field location on a tripole grid (see the header)."""
+    lib = load_library()
+    code = {"center": 0, "NEcorner": 1, "Eface": 2, "Nface": 3}[loc]
+    n = C.c_int32(0)
+    _check(lib, lib.cice_evp_hip_cgrid_fold_plan(C.byref(dims), C.c_int32(code), C.byref(n), None, None, None, None), "(cgrid_fold_plan)")
+    out = {k: np.zeros(n.value, dtype=np.int32) for k in ("dst", "a", "b", "flip")}
+    _check(lib, lib.cice_evp_hip_cgrid_fold_plan(C.byref(dims), C.c_int32(code), C.byref(n), *[_ip(out[k]) for k in ("dst", "a", "b", "flip")]),
+           "(cgrid_fold_plan)")
+    return out
 
 
 def stream_probe(ncells: int) -> float:

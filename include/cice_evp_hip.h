@@ -251,6 +251,11 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
 int cice_evp_hip_cgrid_subcycle(int32_t ndte);
 int cice_evp_hip_cgrid_download(double *const *fields19);
 int cice_evp_hip_cgrid_sync(void);
+/* Host only (no device needed): the fold step of field location `loc` (0 centre, 1 NE corner, 2 E face, 3 N face) on a
+ * tripole grid -- x[dst] = s*0.5*(x[a] + isign*x[b]) (b >= 0; -2: partner eliminated) or s*x[a] (b == -1), s = flip ? isign : 1.
+ * First call with NULL lists for the count.                                                                       */
+int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int32_t *count, int32_t *dst, int32_t *a,
+                                 int32_t *b, int32_t *flip);
 /* out[0] = ms of the last cgrid_subcycle (HIP events), out[1] = its ndte */
 int cice_evp_hip_cgrid_timings(double *out, int32_t n);
 

@@ -207,3 +207,33 @@ def test_decomp_fold_scatter_matches_the_halo_rules():
             a = dc.scatter(g, 0, fill=0.0, fold=(loc, sg))
             w = oracle.halo_update(dom, np.ascontiguousarray(dc.scatter(g, 0, fill=0.0)), loc, kind)
             assert np.array_equal(a, w), (loc, kind)
+
+
+@pytest.mark.parametrize("nx,ny,bx,by", [(24, 18, 24, 18), (28, 20, 14, 10), (32, 24, 8, 8), (26, 14, 10, 5)])
+def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by):
+    """C grid on tripole grids: the host-built fold lists (cice_evp_hip_cgrid_fold_plan) applied to arbitrary block
+    arrays give, on every cell of the fold row and of the ghost row beyond it, exactly what ice_HaloUpdate gives
+    there -- all four field locations, scalar and vector kinds, 1 ... 12 blocks incl. padded ones (against the
+    oracle's halo update, pinned to the reference's tripole fixtures for every location)."""
+    from cice_amd import decomp
+    dc = decomp.Decomp(nx, ny, bx, by, "cyclic", "tripole", 1)
+    d, keep = evp.make_dims(dc, 0)
+    ob = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(ob), nx, ny, "cyclic", "tripole", [b.ilo for b in ob],
+                              [b.ihi for b in ob], [b.jlo for b in ob], [b.jhi for b in ob], [b.gi0 for b in ob],
+                              [b.gj0 for b in ob])
+    rng = np.random.default_rng(nx * 100 + ny)
+    for loc in ("center", "NEcorner", "Eface", "Nface"):
+        L = evp.cgrid_fold_plan(d, loc)
+        assert len(L["dst"]) > 0 and len(set(L["dst"].tolist())) == len(L["dst"])        # every cell once
+        on_fold = (L["b"] >= 0).sum()
+        assert (on_fold > 0) == (loc in ("NEcorner", "Nface"))
+        for kind, isign in (("scalar", 1.0), ("vector", -1.0)):
+            x = rng.standard_normal((len(ob), dc.ny_block, dc.nx_block))
+            want = oracle.halo_update(dom, x.copy(), loc, kind).reshape(-1)
+            flat = x.reshape(-1)
+            s = np.where(L["flip"] != 0, isign, 1.0)
+            xa = np.where(L["a"] >= 0, flat[np.maximum(L["a"], 0)], 0.0)
+            xb = np.where(L["b"] >= 0, flat[np.maximum(L["b"], 0)], 0.0)
+            val = np.where(L["b"] != -1, s * (0.5 * (xa + isign * xb)), s * xa)
+            assert np.array_equal(val, want[L["dst"]]), (loc, kind, int((val != want[L["dst"]]).sum()))
