@@ -268,6 +268,7 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_u(EvpCgrid A)
 // ---- phase 3: div_stress_Ex + stepu_C at E, div_stress_Ny + stepv_C at N; uvelE, vvelN are exchanged (:1063-1068) ----
 __global__ __launch_bounds__(TX *TY) void cg_step(EvpCgrid A)
 {
+    constexpr bool FAST = false;      // (the shortcuts live in the fused schedule's cg_stress_u_step<true>)
     const Cell c = cell(A);
     if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
     const size_t o = c.o, e = o + 1, n = o + A.nx, s = o - A.nx, w = o - 1;
@@ -283,11 +284,15 @@ __global__ __launch_bounds__(TX *TY) void cg_step(EvpCgrid A)
                                (0.5 * dyE * (sp[e] - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sm[e] - (dyT[o] * dyT[o]) * smc) +
                                 (1.0 / dxE) * ((dxU[o] * dxU[o]) * s12c - (dxU[s] * dxU[s]) * s12[s]));
         const double uold = A.f[CF_UE][o], vold = A.f[CF_VE][o];
-        const double du = A.in[CI_UOCNE][o] - uold, dv = A.in[CI_VOCNE][o] - vold;
-        const double vrel = A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o] * sqrt(du * du + dv * dv);
-        const double taux = vrel * A.in[CI_WATERXE][o];
-        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
-        const double Cb = A.in[CI_TBE][o] / ccc;
+        const double uocn = A.in[CI_UOCNE][o];
+        const double du = uocn - uold, dv = A.in[CI_VOCNE][o] - vold;
+        const double vrel = (FAST ? A.facE[o] : A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o]) * sqrt(du * du + dv * dv);
+        const double taux = vrel * (FAST ? uocn : A.in[CI_WATERXE][o]);
+        double Cb = 0.0;
+        if (!FAST) {
+            const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+            Cb = A.in[CI_TBE][o] / ccc;
+        }
         const double massdti = A.in[CI_EMASSDTI][o], fm = A.in[CI_FME][o];
         const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
         const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
@@ -334,6 +339,11 @@ __device__ __forceinline__ double s12u_new(const EvpCgrid &A, size_t p, bool ice
 }
 
 // ---- fused C: phases 2 and 3 in one launch (visc_method = avg_zeta) ----
+// FAST: the operands the reference's default configuration makes redundant are not read -- waterxE == uocnE and
+// wateryN == vocnN bit for bit (cosw = 1, sinw = 0), TbE = TbN = +0 (no seabed stress), rheofactE = rheofactN = 1 --
+// established per call on every ice cell (cg_call_setup); aiX*rhow*Cw comes premultiplied (same operation order).
+// Bit-neutral: x*1.0, x + (+0.0) and 0.0/c are exact, taub = -u*(+0.0) is still formed.
+template <bool FAST>
 __global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
 {
     const Cell c = cell(A);
@@ -353,15 +363,19 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
     {
         const double *dyT = A.g[CG_DYT], *dxU = A.g[CG_DXU];
         const double dyE = A.g[CG_DYE][o], dxE = A.g[CG_DXE][o];
-        strintx = A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o] *
+        strintx = (FAST ? A.g[CG_EAREAR][o] : A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o]) *
                   (0.5 * dyE * (sp[e] - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sm[e] - (dyT[o] * dyT[o]) * smc) +
                    (1.0 / dxE) * ((dxU[o] * dxU[o]) * s12c - (dxU[s] * dxU[s]) * s12s));
         const double uold = A.f[CF_UE][o], vold = A.f[CF_VE][o];
-        const double du = A.in[CI_UOCNE][o] - uold, dv = A.in[CI_VOCNE][o] - vold;
-        const double vrel = A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o] * sqrt(du * du + dv * dv);
-        const double taux = vrel * A.in[CI_WATERXE][o];
-        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
-        const double Cb = A.in[CI_TBE][o] / ccc;
+        const double uocn = A.in[CI_UOCNE][o];
+        const double du = uocn - uold, dv = A.in[CI_VOCNE][o] - vold;
+        const double vrel = (FAST ? A.facE[o] : A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o]) * sqrt(du * du + dv * dv);
+        const double taux = vrel * (FAST ? uocn : A.in[CI_WATERXE][o]);
+        double Cb = 0.0;
+        if (!FAST) {
+            const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+            Cb = A.in[CI_TBE][o] / ccc;
+        }
         const double massdti = A.in[CI_EMASSDTI][o], fm = A.in[CI_FME][o];
         const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
         const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
@@ -372,15 +386,19 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
     {
         const double *dxT = A.g[CG_DXT], *dyU = A.g[CG_DYU];
         const double dxN = A.g[CG_DXN][o], dyN = A.g[CG_DYN][o];
-        strinty = A.in[CI_RHEON][o] * A.g[CG_NAREAR][o] *
+        strinty = (FAST ? A.g[CG_NAREAR][o] : A.in[CI_RHEON][o] * A.g[CG_NAREAR][o]) *
                   (0.5 * dxN * (sp[n] - spc) - (0.5 / dxN) * ((dxT[n] * dxT[n]) * sm[n] - (dxT[o] * dxT[o]) * smc) +
                    (1.0 / dyN) * ((dyU[o] * dyU[o]) * s12c - (dyU[w] * dyU[w]) * s12w));
         const double uold = A.f[CF_UN][o], vold = A.f[CF_VN][o];
-        const double du = A.in[CI_UOCNN][o] - uold, dv = A.in[CI_VOCNN][o] - vold;
-        const double vrel = A.in[CI_AIN][o] * p.rhow * A.in[CI_CWN][o] * sqrt(du * du + dv * dv);
-        const double tauy = vrel * A.in[CI_WATERYN][o];
-        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
-        const double Cb = A.in[CI_TBN][o] / ccc;
+        const double vocn = A.in[CI_VOCNN][o];
+        const double du = A.in[CI_UOCNN][o] - uold, dv = vocn - vold;
+        const double vrel = (FAST ? A.facN[o] : A.in[CI_AIN][o] * p.rhow * A.in[CI_CWN][o]) * sqrt(du * du + dv * dv);
+        const double tauy = vrel * (FAST ? vocn : A.in[CI_WATERYN][o]);
+        double Cb = 0.0;
+        if (!FAST) {
+            const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+            Cb = A.in[CI_TBN][o] / ccc;
+        }
         const double massdti = A.in[CI_NMASSDTI][o], fm = A.in[CI_FMN][o];
         const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
         const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
@@ -409,6 +427,32 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
         }
         if (m & 16u) push(A, o, m, CF_VN, vnew);
     }
+}
+
+// ---- once per call: the leading factor of vrel, and whether the default-configuration shortcuts of cg_stress_u_step
+// <true> hold bit for bit on every ice cell ----
+__global__ __launch_bounds__(TX *TY) void cg_call_setup(EvpCgrid A, double *facE, double *facN, unsigned *flags)
+{
+    const Cell c = cell(A);
+    if (!c.in) return;
+    const size_t o = c.o;
+    facE[o] = A.in[CI_AIE][o] * A.p.rhow * A.in[CI_CWE][o];
+    facN[o] = A.in[CI_AIN][o] * A.p.rhow * A.in[CI_CWN][o];
+    if (c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const unsigned m = A.mask[o];
+    unsigned bad = 0;
+    auto bits = [](double x) { return (unsigned long long)__double_as_longlong(x); };
+    if (m & 4u) {
+        if (bits(A.in[CI_WATERXE][o]) != bits(A.in[CI_UOCNE][o])) bad |= 1u;
+        if (bits(A.in[CI_TBE][o]) != 0ull) bad |= 2u;
+        if (A.in[CI_RHEOE][o] != 1.0) bad |= 4u;
+    }
+    if (m & 8u) {
+        if (bits(A.in[CI_WATERYN][o]) != bits(A.in[CI_VOCNN][o])) bad |= 1u;
+        if (bits(A.in[CI_TBN][o]) != 0ull) bad |= 2u;
+        if (A.in[CI_RHEON][o] != 1.0) bad |= 4u;
+    }
+    if (bad) atomicOr(flags, bad);
 }
 
 // ---- copy a field into the ghost images of its interior cells (what one ice_HaloUpdate does) ----
@@ -588,6 +632,12 @@ void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hip
     if (n > 0) hipLaunchKernelGGL(cg_zero_cells, dim3((n + 255) / 256), dim3(256), 0, st, A, cells, n);
 }
 
+void evp_launch_cgrid_call_setup(const EvpCgrid &A, double *facE, double *facN, unsigned *flags, hipStream_t st)
+{
+    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    hipLaunchKernelGGL(cg_call_setup, grid, block, 0, st, A, facE, facN, flags);
+}
+
 void evp_launch_cgrid_mask(const EvpCgrid &A, const int *m4, hipStream_t st)
 {
     const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
@@ -622,7 +672,8 @@ void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t 
     case 1: hipLaunchKernelGGL(cg_stress_t<true>, grid, block, 0, st, A, last); break;
     case 10: hipLaunchKernelGGL(cg_stress_t<false>, grid, block, 0, st, A, last); break;
     case 7: hipLaunchKernelGGL(cg_avg_strain, grid, block, 0, st, A, last); break;
-    case 8: hipLaunchKernelGGL(cg_stress_u_step, grid, block, 0, st, A, last); break;
+    case 8: hipLaunchKernelGGL(cg_stress_u_step<false>, grid, block, 0, st, A, last); break;
+    case 11: hipLaunchKernelGGL(cg_stress_u_step<true>, grid, block, 0, st, A, last); break;
     case 9: hipLaunchKernelGGL(cg_fill_images, grid, block, 0, st, A, last); break;
     case 2: hipLaunchKernelGGL(cg_stress_u, grid, block, 0, st, A); break;
     case 3: hipLaunchKernelGGL(cg_step, grid, block, 0, st, A); break;

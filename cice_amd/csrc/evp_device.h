@@ -250,6 +250,7 @@ struct EvpCgrid {
     const uint8_t *mask;          // bit0 iceT, bit1 iceU, bit2 iceE, bit3 iceN, bit4: the cell has ghost images,
                                   // bit5: iceU of the cell, or of the interior cell this ghost cell mirrors
     const double *s12_in;         // fused path: stress12U ping-pong (read s12_in, write f[CF_S12U])
+    const double *facE, *facN;    // (aiE*rhow)*cdn_ocnE, (aiN*rhow)*cdn_ocnN: the leading factor of vrel, once per call
     const int *img_slot;          // per cell: row of img_dst, or -1
     const int *img_dst;           // 3 per row: ghost cells of this rank that mirror the cell (-1: none)
     const int4 *blk;
@@ -284,4 +285,7 @@ void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st);
 // m4: iceTmask | iceUmask | iceEmask | iceNmask, n 32-bit words each
 void evp_launch_cgrid_mask(const EvpCgrid &A, const int *m4, hipStream_t st);
 void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStream_t st);
+// per call: facE / facN, and which of the default-configuration shortcuts hold bit for bit on every ice cell --
+// flags bit0: waterxE != uocnE or wateryN != vocnN somewhere, bit1: a TbE / TbN that is not +0, bit2: a rheofact != 1
+void evp_launch_cgrid_call_setup(const EvpCgrid &A, double *facE, double *facN, unsigned *flags, hipStream_t st);
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st);

@@ -19,6 +19,9 @@ struct CGridState {
     double *f[CG_NF] = {}, *in[CG_NIN] = {}, *g[CG_NG] = {};
     double *strengthU = nullptr;
     double *umaskd = nullptr;    // ranks > 1: iceU as a field, to learn the flags of ghost cells other ranks own
+    double *fac[2] = {nullptr, nullptr};   // leading factor of vrel at E / N (once per call)
+    unsigned *d_flags = nullptr;
+    bool fast = false;           // the shortcuts of cg_stress_u_step<true> hold on every ice cell of this call
     double *s12alt = nullptr;    // second stress12U buffer of the fused schedule (f[CF_S12U] always holds the current one)
     int flip = 0;                // which of the two allocations f[CF_S12U] is (part of the graph key)
     uint8_t *mask = nullptr;
@@ -49,7 +52,7 @@ void cgrid_free()
     for (auto &p : CG.f) F(p);
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
-    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.mask); F(CG.mask4); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
+    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.fac[0]); F(CG.fac[1]); F(CG.d_flags); F(CG.mask); F(CG.mask4); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
     for (auto &f : CG.fold) { F(f.dst); F(f.a); F(f.b); F(f.flip); }
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
     CG.graphs.clear();
@@ -64,6 +67,8 @@ static void fill(EvpCgrid &A)
     for (int k = 0; k < CG_NG; ++k) A.g[k] = CG.g[k];
     A.strengthU = CG.strengthU;
     A.s12_in = nullptr;
+    A.facE = CG.fac[0];
+    A.facN = CG.fac[1];
     A.mask = CG.mask;
     A.img_slot = CG.img_slot;
     A.img_dst = CG.img_dst;
@@ -173,7 +178,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         XCHG(A.f[CF_SP], A.f[CF_SM]);
         A.s12_in = cur;
         A.f[CF_S12U] = other;
-        evp_launch_cgrid_phase(A, 8, last, S.stream);
+        evp_launch_cgrid_phase(A, CG.fast ? 11 : 8, last, S.stream);
         XCHG(other, other);
         XCHG(A.f[CF_UE], A.f[CF_VN]);
         std::swap(cur, other);
@@ -241,7 +246,8 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
         if (!static23[k]) return fail(-1, "null static array %d", k);
         if (alloc_d(&CG.g[k], S.n) || h2d(CG.g[k], static23[k])) return -1;
     }
-    if (alloc_d(&CG.strengthU, S.n) || alloc_d(&CG.s12alt, S.n)) return -1;
+    if (alloc_d(&CG.strengthU, S.n) || alloc_d(&CG.s12alt, S.n) || alloc_d(&CG.fac[0], S.n) || alloc_d(&CG.fac[1], S.n)) return -1;
+    HIPC(hipMalloc((void **)&CG.d_flags, sizeof(unsigned)));
     if (!S.plan.peers.empty() && alloc_d(&CG.umaskd, S.n)) return -1;
     HIPC(hipMalloc((void **)&CG.mask, S.n));
     HIPC(hipMalloc((void **)&CG.mask4, 4 * S.n * sizeof(int32_t)));
@@ -318,6 +324,14 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
         evp_launch_cgrid_mask(A, CG.mask4, S.stream);
     }
     CG.avg_strength = visc_method;
+    unsigned h_flags = ~0u;
+    {
+        EvpCgrid A;
+        fill(A);
+        HIPC(hipMemsetAsync(CG.d_flags, 0, sizeof(unsigned), S.stream));
+        evp_launch_cgrid_call_setup(A, CG.fac[0], CG.fac[1], CG.d_flags, S.stream);
+        HIPC(hipMemcpyAsync(&h_flags, CG.d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+    }
     if (remote()) {                              // bit5 of ghost cells other ranks own
         EvpCgrid A;
         fill(A);
@@ -332,6 +346,7 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
     }
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(S.stream));       // the caller may change its arrays after this returns
+    CG.fast = h_flags == 0 && !(env("CICE_EVP_HIP_CGRID_FAST") && !std::atoi(env("CICE_EVP_HIP_CGRID_FAST")));
     CG.uploaded = true;
     CG.first = true;
     return 0;
@@ -351,7 +366,7 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     };
     HIPC(hipEventRecord(S.ev0, S.stream));
     if (S.use_graph && (!remote() || S.direct.on)) {     // RCCL point-to-point is enqueued eagerly (as the B-grid loop does)
-        const std::pair<int, int> key(ndte, (CG.flip << 3) | (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
+        const std::pair<int, int> key(ndte, (CG.fast ? 16 : 0) | (CG.flip << 3) | (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
         auto it = CG.graphs.find(key);
         if (it == CG.graphs.end()) {
             hipGraph_t gr = nullptr;

@@ -214,3 +214,27 @@ def test_cgrid_random_masks_vs_oracle_bitwise(seed, nx, ny, bs, ew, ns, holes, v
     assert np.isfinite(want["uvelE"]).all() and np.isfinite(want["stresspT"]).all()
     if holes < 1.0:
         assert np.abs(want["uvelE"] - args[3]["uvelE"]).max() > 0
+
+
+def test_cgrid_default_configuration_shortcuts_are_bit_neutral(monkeypatch):
+    """cg_stress_u_step<true> (taken when waterx == uocn, Tb == +0 and rheofact == 1 hold bit for bit on every ice
+    cell of a call: the reference's default configuration) against the general kernel (CICE_EVP_HIP_CGRID_FAST=0) and
+    the fixture, same bits; a call with seabed stress must not take it (it is compared with its fixture elsewhere)."""
+    c = GoldenCase("cgrid_cyc_2x2_patchy")
+    dom = c.oracle_domain()
+    state, inputs, masks = c.cgrid_inputs(1)
+    assert np.array_equal(inputs["waterxE"][masks["iceEmask"] != 0], inputs["uocnE"][masks["iceEmask"] != 0])
+    assert not inputs["TbE"].any() and (inputs["rheofactE"][masks["iceEmask"] != 0] == 1.0).all()
+    outs = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_FAST", fast)
+        core = cgrid_core(c)
+        try:
+            out = core.cgrid_run(120, state, inputs, masks)
+        finally:
+            core.finalize()
+        oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+        oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+        assert_bitwise(out, c.cgrid_expected(1, 120), f"CICE_EVP_HIP_CGRID_FAST={fast}")
+        outs.append(out)
+    assert_bitwise(outs[0], outs[1], "shortcut vs general kernel")
