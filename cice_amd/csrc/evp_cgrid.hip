@@ -65,9 +65,27 @@ struct Cell { int i, j, b; size_t o; int4 q; bool in; };
 __device__ __forceinline__ Cell cell(const EvpCgrid &A)
 {
     Cell c;
-    c.i = blockIdx.x * TX + threadIdx.x + 1;         // 1-based, as the reference
-    c.j = blockIdx.y * TY + threadIdx.y + 1;
+    int bx = blockIdx.x, by = blockIdx.y;
     c.b = blockIdx.z;
+    if (A.xcd_rows > 0) {
+        // Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2: with the plain
+        // 2-D numbering the workgroup above and the one below always sit on different XCDs, so the rows they share are
+        // fetched twice.  1-D launch: bands of xcd_rows workgroup rows, dealt to the XCDs group after group (a group =
+        // 8 bands), short enough that a band's workgroups are resident together.
+        const int gx = (A.nx + TX - 1) / TX, gy = (A.ny + TY - 1) / TY;
+        const int R = A.xcd_rows;
+        const int ngroups = (gy + 8 * R - 1) / (8 * R);
+        const int per = gx * R * 8 * ngroups;            // workgroups per block of the domain
+        const int L = blockIdx.x;
+        c.b = L / per;
+        const int r = L - c.b * per;
+        const int k = r >> 3;
+        const int g = k / (gx * R), kk = k - g * (gx * R);
+        bx = kk % gx;
+        by = (g * 8 + (r & 7)) * R + kk / gx;
+    }
+    c.i = bx * TX + threadIdx.x + 1;                 // 1-based, as the reference
+    c.j = by * TY + threadIdx.y + 1;
     c.in = c.i <= A.nx && c.j <= A.ny;
     c.q = A.blk[c.b];
     c.o = (size_t)c.b * A.plane + (size_t)(c.j - 1) * A.nx + (c.i - 1);
@@ -632,15 +650,25 @@ void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hip
     if (n > 0) hipLaunchKernelGGL(cg_zero_cells, dim3((n + 255) / 256), dim3(256), 0, st, A, cells, n);
 }
 
+static dim3 cg_grid(const EvpCgrid &A)
+{
+    const int gx = (A.nx + TX - 1) / TX, gy = (A.ny + TY - 1) / TY;
+    if (A.xcd_rows > 0) {
+        const int ngroups = (gy + 8 * A.xcd_rows - 1) / (8 * A.xcd_rows);
+        return dim3((unsigned)(gx * A.xcd_rows * 8 * ngroups * A.nblocks), 1, 1);
+    }
+    return dim3(gx, gy, A.nblocks);
+}
+
 void evp_launch_cgrid_call_setup(const EvpCgrid &A, double *facE, double *facN, unsigned *flags, hipStream_t st)
 {
-    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    const dim3 grid = cg_grid(A), block(TX, TY);
     hipLaunchKernelGGL(cg_call_setup, grid, block, 0, st, A, facE, facN, flags);
 }
 
 void evp_launch_cgrid_mask(const EvpCgrid &A, const int *m4, hipStream_t st)
 {
-    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    const dim3 grid = cg_grid(A), block(TX, TY);
     hipLaunchKernelGGL(cg_mask_compose, grid, block, 0, st, A, m4, const_cast<uint8_t *>(A.mask), 0);
     hipLaunchKernelGGL(cg_mask_compose, grid, block, 0, st, A, m4, const_cast<uint8_t *>(A.mask), 1);
 }
@@ -659,14 +687,14 @@ void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st)
 
 void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStream_t st)
 {
-    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    const dim3 grid = cg_grid(A), block(TX, TY);
     if (!back) hipLaunchKernelGGL(cg_umask_to_double, grid, block, 0, st, A, scratch);
     else hipLaunchKernelGGL(cg_bit5_from_double, grid, block, 0, st, A, scratch, const_cast<uint8_t *>(A.mask));
 }
 
 void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st)
 {
-    const dim3 grid((A.nx + TX - 1) / TX, (A.ny + TY - 1) / TY, A.nblocks), block(TX, TY);
+    const dim3 grid = cg_grid(A), block(TX, TY);
     switch (phase) {
     case 0: hipLaunchKernelGGL(cg_strain_u, grid, block, 0, st, A); break;
     case 1: hipLaunchKernelGGL(cg_stress_t<true>, grid, block, 0, st, A, last); break;

@@ -80,6 +80,13 @@ static void fill(EvpCgrid &A)
     A.nblocks = S.d.nblocks;
     A.avg_strength = CG.avg_strength;
     A.tripole = CG.tripole ? 1 : 0;
+    {   // XCD-banded workgroup numbering (evp_cgrid.hip: cell()); CICE_EVP_HIP_CGRID_XCD=0: plain 2-D launch
+        const bool on = !(env("CICE_EVP_HIP_CGRID_XCD") && !std::atoi(env("CICE_EVP_HIP_CGRID_XCD")));
+        const int gy = (S.d.ny_block + 3) / 4;      // TY = 4 rows per workgroup
+        const int gx = (S.d.nx_block + 63) / 64;    // TX = 64
+        const int rows = env("CICE_EVP_HIP_CGRID_XCD") && std::atoi(env("CICE_EVP_HIP_CGRID_XCD")) > 1 ? std::atoi(env("CICE_EVP_HIP_CGRID_XCD")) : std::max(1, 256 / gx);
+        A.xcd_rows = on ? std::min((gy + 7) / 8, rows) : 0;
+    }
     A.plane = S.plane;
 }
 
