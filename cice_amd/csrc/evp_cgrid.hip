@@ -362,23 +362,26 @@ __device__ __forceinline__ double s12u_new(const EvpCgrid &A, size_t p, bool ice
 // established per call on every ice cell (cg_call_setup); aiX*rhow*Cw comes premultiplied (same operation order).
 // Bit-neutral: x*1.0, x + (+0.0) and 0.0/c are exact, taub = -u*(+0.0) is still formed.
 template <bool FAST>
-__global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
+__global__ __launch_bounds__(TX *TY * 2) void cg_stress_u_step(EvpCgrid A, int last)
 {
     const Cell c = cell(A);
     if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
     const size_t o = c.o, e = o + 1, n = o + A.nx, s = o - A.nx, w = o - 1;
     const unsigned m = A.mask[o];
     const double relax = 1.0 - A.p.arlx1i * A.p.revp;
+    // blockDim.z == 2: the E face and the N face of a cell in different waves (half the dependent chain per wave, twice
+    // the waves in flight: grids of gx1's size are latency-, not bandwidth-bound); blockDim.z == 1: one thread does both
+    const bool doE = blockDim.z == 1 || threadIdx.z == 0, doN = blockDim.z == 1 || threadIdx.z == 1;
     double etaU;
     const double s12c = s12u_new(A, o, (m & 2u) != 0, relax, &etaU);
-    const double s12s = s12u_new(A, s, (A.mask[s] & 32u) != 0, relax, nullptr);
-    const double s12w = s12u_new(A, w, (A.mask[w] & 32u) != 0, relax, nullptr);
+    const double s12s = doE ? s12u_new(A, s, (A.mask[s] & 32u) != 0, relax, nullptr) : 0.0;
+    const double s12w = doN ? s12u_new(A, w, (A.mask[w] & 32u) != 0, relax, nullptr) : 0.0;
     const double *sp = A.f[CF_SP], *sm = A.f[CF_SM];
     const double spc = sp[o], smc = sm[o];
     const EvpScalars &p = A.p;
     // both faces computed for every interior cell (all loads in bounds and issued together); stores by mask
-    double unew, vnew, strintx, strinty, taubx, tauby;
-    {
+    double unew = 0.0, vnew = 0.0, strintx = 0.0, strinty = 0.0, taubx = 0.0, tauby = 0.0;
+    if (doE) {
         const double *dyT = A.g[CG_DYT], *dxU = A.g[CG_DXU];
         const double dyE = A.g[CG_DYE][o], dxE = A.g[CG_DXE][o];
         strintx = (FAST ? A.g[CG_EAREAR][o] : A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o]) *
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
         unew = (ccb * vold + cc1) / cca;
         taubx = -unew * Cb;
     }
-    {
+    if (doN) {
         const double *dxT = A.g[CG_DXT], *dyU = A.g[CG_DYU];
         const double dxN = A.g[CG_DXN][o], dyN = A.g[CG_DYN][o];
         strinty = (FAST ? A.g[CG_NAREAR][o] : A.in[CI_RHEON][o] * A.g[CG_NAREAR][o]) *
@@ -424,12 +427,14 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
         vnew = (-ccb * uold + cc2) / cca;
         tauby = -vnew * Cb;
     }
-    if (m & 2u) {
-        A.f[CF_S12U][o] = s12c;
-        if (m & 16u) push(A, o, m, CF_S12U, s12c);
+    if (doE) {
+        if (m & 2u) {
+            A.f[CF_S12U][o] = s12c;
+            if (m & 16u) push(A, o, m, CF_S12U, s12c);
+        }
+        if (last) A.f[CF_ETAU][o] = etaU;
     }
-    if (last) A.f[CF_ETAU][o] = etaU;
-    if (m & 4u) {
+    if (doE && (m & 4u)) {
         A.f[CF_UE][o] = unew;
         if (last) {
             A.f[CF_STRX][o] = strintx;
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_u_step(EvpCgrid A, int last)
         }
         if (m & 16u) push(A, o, m, CF_UE, unew);
     }
-    if (m & 8u) {
+    if (doN && (m & 8u)) {
         A.f[CF_VN][o] = vnew;
         if (last) {
             A.f[CF_STRY][o] = strinty;
@@ -700,8 +705,8 @@ void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t 
     case 1: hipLaunchKernelGGL(cg_stress_t<true>, grid, block, 0, st, A, last); break;
     case 10: hipLaunchKernelGGL(cg_stress_t<false>, grid, block, 0, st, A, last); break;
     case 7: hipLaunchKernelGGL(cg_avg_strain, grid, block, 0, st, A, last); break;
-    case 8: hipLaunchKernelGGL(cg_stress_u_step<false>, grid, block, 0, st, A, last); break;
-    case 11: hipLaunchKernelGGL(cg_stress_u_step<true>, grid, block, 0, st, A, last); break;
+    case 8: hipLaunchKernelGGL(cg_stress_u_step<false>, grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last); break;
+    case 11: hipLaunchKernelGGL(cg_stress_u_step<true>, grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last); break;
     case 9: hipLaunchKernelGGL(cg_fill_images, grid, block, 0, st, A, last); break;
     case 2: hipLaunchKernelGGL(cg_stress_u, grid, block, 0, st, A); break;
     case 3: hipLaunchKernelGGL(cg_step, grid, block, 0, st, A); break;

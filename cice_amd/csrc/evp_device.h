@@ -257,6 +257,7 @@ struct EvpCgrid {
     EvpScalars p;
     double deltaminEVP;
     int nx, ny, nblocks, avg_strength;
+    int split_faces;              // fused step kernel: E and N face of a cell in different waves (small grids)
     int xcd_rows;                 // > 0: workgroup rows per XCD band (1-D launch, vertically adjacent workgroups on one XCD)
     int tripole;                  // the fold step writes into cells without ice: what the reference re-zeroes every subcycle is re-zeroed
     size_t plane;

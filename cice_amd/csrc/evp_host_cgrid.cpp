@@ -80,6 +80,10 @@ static void fill(EvpCgrid &A)
     A.nblocks = S.d.nblocks;
     A.avg_strength = CG.avg_strength;
     A.tripole = CG.tripole ? 1 : 0;
+    {   // two waves per cell in the fused step kernel while the grid is small enough to be latency-bound
+        const char *e = env("CICE_EVP_HIP_CGRID_SPLIT");
+        A.split_faces = e ? (std::atoi(e) != 0) : (S.n <= 600000);
+    }
     {   // XCD-banded workgroup numbering (evp_cgrid.hip: cell()); CICE_EVP_HIP_CGRID_XCD=0: plain 2-D launch
         const bool on = !(env("CICE_EVP_HIP_CGRID_XCD") && !std::atoi(env("CICE_EVP_HIP_CGRID_XCD")));
         const int gy = (S.d.ny_block + 3) / 4;      // TY = 4 rows per workgroup
