@@ -205,6 +205,9 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
     for (int fi = F_STRENGTH; fi < F_COUNT; ++fi) {
         if (fi == F_UVEL || fi == F_VVEL) continue;
         if ((fi == F_UVEL_INIT || fi == F_VVEL_INIT) && !f[fi]) continue;   // only read when revp = 1
+        // lean call (cice_evp_hip_run on page-locked arrays): the loop writes these four on ice U-cells only and the
+        // download writes back those cells only, so the caller's values elsewhere never need to travel
+        if (S.lean_diag && (fi == F_STRINTX || fi == F_STRINTY || fi == F_TAUBX || fi == F_TAUBY)) continue;
         // (strintx/y, taubx/y are outputs of the loop on ice U-cells only; elsewhere the caller's values -- zeroed by
         // dyn_prep2 -- must survive the download, so they travel in as well)
         if (!f[fi]) return fail(-1, "null field %d", fi);
@@ -466,8 +469,15 @@ int cice_evp_hip_download(double *const *f)
     for (int k = 0; k < 12; ++k)
         if (f[k]) B.items.push_back({f[k], S.sig[S.cur][k]});
     const int outs[4] = {F_STRINTX, F_STRINTY, F_TAUBX, F_TAUBY};
-    for (int o : outs)
-        if (f[o]) B.items.push_back({f[o], S.in[o]});
+    if (S.lean_diag) {
+        CopyBatch M;
+        for (int o : outs)
+            if (f[o]) M.items.push_back({f[o], S.in[o]});
+        if (d2h_batch_masked(M, 2u)) return -1;             // bit1: iceUmask
+    } else {
+        for (int o : outs)
+            if (f[o]) B.items.push_back({f[o], S.in[o]});
+    }
     if (f[F_UVEL]) B.items.push_back({f[F_UVEL], S.u[S.cur]});
     if (f[F_VVEL]) B.items.push_back({f[F_VVEL], S.v[S.cur]});
     if (d2h_batch(B)) return -1;
@@ -500,6 +510,14 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
                           (double *)vvel_init};
     // stresses that never left the device (CICE_EVP_HIP_OPT_STRESS_RESIDENT): no upload, dyn_prep2's zeroing on the device
     const bool keep_sig = S.opt_sig_resident && S.sig_valid && S.uploaded;
+    {
+        CopyBatch D;
+        for (double *p : {strintxU, strintyU, taubxU, taubyU})
+            if (p) D.items.push_back({p, nullptr});
+        S.lean_diag = D.items.size() == 4 && batch_mapped(D, false) &&
+                      !(env("CICE_EVP_HIP_LEAN") && !std::atoi(env("CICE_EVP_HIP_LEAN")));
+    }
+    struct LeanOff { ~LeanOff() { S.lean_diag = false; } } lean_off;      // only for the duration of this call
     if (int rc = upload_impl(f, iceTmask, iceUmask, keep_sig)) return rc;
     if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
     if (S.res_mode == 1 && S.plan.peers.empty() && !keep_sig) {

@@ -36,6 +36,17 @@ __global__ __launch_bounds__(256) void copy_many(EvpCopyTab T)
     }
 }
 
+// scatter of arrays a kernel wrote on masked cells only: the other cells of the destination keep what they hold
+__global__ __launch_bounds__(256) void copy_many_masked(EvpCopyTab T, const uint8_t *__restrict__ mask, unsigned bit)
+{
+    const int a = blockIdx.y;
+    const double *__restrict__ src = T.src[a];
+    double *__restrict__ dst = T.dst[a];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.len; i += stride)
+        if (mask[i] & bit) dst[i] = src[i];
+}
+
 struct SigTab { double *p[24]; };
 // dyn_prep2 zeroes the 12 stress components wherever iceTmask is false (ice_dyn_shared.F90:712-727) on the
 // host arrays before the loop; for stresses that never left the device the same, on both ping-pong copies
@@ -115,6 +126,13 @@ void evp_launch_copy_many(const EvpCopyTab &T, hipStream_t st)
     // enough workgroups to keep the link busy, few enough that one array is a handful of 64-KB bursts per workgroup
     const unsigned per = (unsigned)std::min<size_t>(64, (T.len / 2 + 255) / 256);
     hipLaunchKernelGGL(copy_many, dim3(per ? per : 1, T.n), dim3(256), 0, st, T);
+}
+
+void evp_launch_copy_many_masked(const EvpCopyTab &T, const uint8_t *mask, unsigned bit, hipStream_t st)
+{
+    if (T.n <= 0 || T.len == 0) return;
+    const unsigned per = (unsigned)std::min<size_t>(64, (T.len + 255) / 256);
+    hipLaunchKernelGGL(copy_many_masked, dim3(per ? per : 1, T.n), dim3(256), 0, st, T, mask, bit);
 }
 
 void evp_launch_zero_sig_off_mask(double *const *sig0, double *const *sig1, const uint8_t *mask, size_t n, hipStream_t st)

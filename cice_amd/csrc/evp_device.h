@@ -197,6 +197,7 @@ struct EvpCopyTab {
 };
 void evp_launch_copy_many(const EvpCopyTab &T, hipStream_t st);
 double evp_stream_probe(size_t ncells, int reps, hipStream_t st);
+void evp_launch_copy_many_masked(const EvpCopyTab &T, const uint8_t *mask, unsigned bit, hipStream_t st);
 void evp_launch_zero_sig_off_mask(double *const *sig0, double *const *sig1, const uint8_t *mask, size_t n, hipStream_t st);
 
 void evp_launch_vrelfac(const double *aiX, const double *Cw, double rhow, double *out, size_t n,

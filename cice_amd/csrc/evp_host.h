@@ -222,6 +222,7 @@ struct State {
     // stresses that stay on the device between calls of cice_evp_hip_run (CICE_EVP_HIP_OPT_STRESS_RESIDENT)
     bool opt_sig_resident = false;
     bool sig_valid = false;                        // sig[cur] holds what the caller's arrays would hold
+    bool lean_diag = false;                        // this call: strintx/y, taubx/y not uploaded; written back on ice U-cells only
 };
 
 extern State S;
@@ -242,6 +243,8 @@ int d2h(double *dst, const double *src);
 struct CopyBatch { std::vector<std::pair<double *, const double *>> items; };
 int h2d_batch(CopyBatch &B);
 int d2h_batch(CopyBatch &B);
+bool batch_mapped(const CopyBatch &B, bool to_device);
+int d2h_batch_masked(CopyBatch &B, unsigned bit);
 int derive_metrics(const double *HTE, const double *HTN, const double *dxT, const double *dyT,
                    const double *uarear, const double *tarea);
 int upload_lists();

@@ -165,6 +165,29 @@ static int run_batch(CopyBatch &B, bool to_device)
     B.items.clear();
     return 0;
 }
+// every host array of the batch lies in a range the caller page-locked and mapped (and the gather path is on)
+bool batch_mapped(const CopyBatch &B, bool to_device)
+{
+    if (env("CICE_EVP_HIP_GATHER") && !std::atoi(env("CICE_EVP_HIP_GATHER"))) return false;
+    for (auto &it : B.items)
+        if (!mapped_view(to_device ? (const void *)it.second : (const void *)it.first, S.n * sizeof(double))) return false;
+    return true;
+}
+// device -> mapped host arrays, only the cells whose mask byte has `bit` set (batch_mapped(B, false) must hold)
+int d2h_batch_masked(CopyBatch &B, unsigned bit)
+{
+    EvpCopyTab T{};
+    T.len = S.n;
+    for (auto &it : B.items) {
+        T.src[T.n] = it.second;
+        T.dst[T.n] = (double *)mapped_view(it.first, S.n * sizeof(double));
+        if (++T.n == EVP_COPY_MAX) { evp_launch_copy_many_masked(T, S.mask, bit, S.stream); T.n = 0; }
+    }
+    evp_launch_copy_many_masked(T, S.mask, bit, S.stream);
+    HIPC(hipGetLastError());
+    B.items.clear();
+    return 0;
+}
 int h2d_batch(CopyBatch &B) { return run_batch(B, true); }
 int d2h_batch(CopyBatch &B) { return run_batch(B, false); }
 
