@@ -12,9 +12,11 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
     if (!S.ready) return fail(-1, "not initialised");
     if (!tmask || !umask || !hm || !tarea || !uarea || !fcor_blk) return fail(-1, "null argument");
     State::Prep &Q = S.prep;
-    if (S.plan.center_remote && S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE)
-        return fail(-9, "device preparation: the T-grid halo across ranks is not implemented for tripole grids; "
-                        "keep evp()'s host preparation and use cice_evp_hip_run on this configuration");
+    // T-grid ghost cells owned by other ranks travel with the velocity exchange (same cells for centre and corner
+    // fields) -- except across the tripole fold, where centre fields mirror other cells than corner fields do
+    if (S.plan.center_fold_remote)
+        return fail(-9, "device preparation: T-grid ghost cells across the tripole fold live on other ranks here (the fold "
+                        "row is split in x); keep evp()'s host preparation and use cice_evp_hip_run on this configuration");
     auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };
     if (B(Q.tmask) || B(Q.umask) || B(Q.umask_old) || B(Q.tmphm)) return -1;
     HIPC(hipMalloc((void **)&Q.umask_old32, S.n * sizeof(int32_t)));

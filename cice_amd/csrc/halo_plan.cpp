@@ -231,7 +231,11 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                             continue;
                         }
                         const HaloBlock &Sb = T.blk[ks];
-                        if (Sb.owner != me) { plan.center_remote = true; continue; }
+                        if (Sb.owner != me) {
+                            plan.center_remote = true;
+                            if (sign < 0) plan.center_fold_remote = true;
+                            continue;
+                        }
                         plan.center_dst.push_back(dst);
                         plan.center_src.push_back((int32_t)((size_t)Sb.local * plane +
                                                             (size_t)(ng + (jg - Sb.gj0)) * nx + (ng + (ig - Sb.gi0))));

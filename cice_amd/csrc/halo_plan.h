@@ -75,6 +75,7 @@ struct HaloPlan {
     std::vector<int32_t> center_dst, center_src;
     std::vector<int8_t> center_vsign;
     bool center_remote = false;
+    bool center_fold_remote = false;              // ... and one of them lies across the tripole fold (centre mirror rule, other rank)
     std::string error;
 };
 

@@ -24,7 +24,9 @@ def _free_port():
                                                            (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep"),
                                                            (2, "tx1", "1x2", True), (8, "gx3", "2x4", True),
                                                            (2, "gx3", "1x2", "blocks"),
-                                                           (2, "tx1", "2x1", False), (4, "tx1", "2x2", False)])
+                                                           (2, "tx1", "2x1", False), (4, "tx1", "2x2", False),
+                                                           # evp()'s preparation phase on a tripole grid cut in y
+                                                           (2, "tx1", "1x2", "prep")])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
