@@ -238,3 +238,32 @@ def test_cgrid_default_configuration_shortcuts_are_bit_neutral(monkeypatch):
         assert_bitwise(out, c.cgrid_expected(1, 120), f"CICE_EVP_HIP_CGRID_FAST={fast}")
         outs.append(out)
     assert_bitwise(outs[0], outs[1], "shortcut vs general kernel")
+
+
+@pytest.mark.parametrize("transport", ["rccl", "direct"])
+@pytest.mark.parametrize("name", ["cgrid_cyc_2x2_patchy", "cgrid_cyc_3x2pad_cap05_avgstrength"])
+def test_cgrid_single_rank_self_exchange(name, transport, monkeypatch):
+    """The C-grid loop's remote-halo path on one GPU: CICE_EVP_HIP_SELF_EXCHANGE routes every ghost copy through the
+    exchange with the rank itself, so nothing is pushed and every exchange point of the schedule fills all ghost cells
+    -- through pack -> ncclGroup{ncclSend, ncclRecv} -> unpack (rccl, enqueued eagerly) or through the mailbox kernel
+    (direct, inside the captured graph).  Fused and five-phase schedules; same bits as the fixtures."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", transport)
+    c = GoldenCase(name)
+    dom = c.oracle_domain()
+    d, keep = c.hip_dims()
+    ua = c.d["uarea"]
+    core = evp.EvpHip(d, evp.make_params(c.scal_dict(), strict=True), c.d["dyE"], c.d["dxN"], c.d["dxT"], c.d["dyT"],
+                      np.where(ua > 0, 1.0 / np.where(ua > 0, ua, 1.0), 0.0), c.d["tarea"], keepalive=keep)
+    try:
+        core.comm_init(core.comm_unique_id())
+        assert core.timings()["halo_transport"] == ("rccl" if transport == "rccl" else "mailbox")
+        core.cgrid_set_geometry(c.cgrid_static())
+        state, inputs, masks = c.cgrid_inputs(1)
+        for nsub in (1, 120):
+            out = core.cgrid_run(nsub, state, inputs, masks, visc_method=str(c.d["visc_method"]))
+            oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+            oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+            assert_bitwise(out, c.cgrid_expected(1, nsub), f"{name} through {transport} self exchange, nsub {nsub}")
+    finally:
+        core.finalize()
