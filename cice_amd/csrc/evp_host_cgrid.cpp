@@ -1,6 +1,6 @@
 // =====================================================================
 // C-grid EVP subcycle behind the C ABI (include/cice_evp_hip.h, cice_evp_hip_cgrid_*): device state, ghost-image
-// table, the loop as a captured graph of five launches per subcycle (evp_cgrid.hip).
+// table, the loop as a captured graph of three (fused schedule) or five launches per subcycle (evp_cgrid.hip).
 //
 // Replaces evp()'s loop for grid_ice = 'C' (ice_dyn_evp.F90:938-1099).  The caller has run the reference's own
 // preparation (dyn_prep1/2 at U, N and E points, seabed stress, the grid averages of the forcing) and hands over
@@ -8,7 +8,8 @@
 // per rank (their ghost cells are images like any other).  Ghost cells that mirror cells of OTHER ranks are filled
 // by the B-grid path's velocity exchange (halo_remote_pair: mailbox stores over xGMI, or RCCL point-to-point) run on
 // pairs of the loop's arrays after the launch that produces them -- the same points at which the reference calls
-// ice_HaloUpdate.  The tripole fold is refused loudly (E/N-face fold rules: not built).
+// ice_HaloUpdate.  Tripole (u-fold) grids: a fold step per exchange point from host-built lists (halo_plan.cpp:
+// build_fold_list), the blocks next to the fold on one rank.
 // =====================================================================
 #include "evp_host.h"
 
