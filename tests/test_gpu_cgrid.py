@@ -267,3 +267,36 @@ def test_cgrid_single_rank_self_exchange(name, transport, monkeypatch):
             assert_bitwise(out, c.cgrid_expected(1, nsub), f"{name} through {transport} self exchange, nsub {nsub}")
     finally:
         core.finalize()
+
+
+def test_cgrid_s01_full_size_invariances(monkeypatch):
+    """The 0.1-degree-class size (3600 x 2400 = 8.6M cells), 3 subcycles -- where the oracle would need a minute per
+    run, size-independent properties instead: one block == 2 x 2 blocks with pushed ghost images == the five-launch
+    schedule == 2 x 2 blocks with every ghost cell routed through the mailbox exchange (self exchange), bit for bit
+    on every array of the loop (the bench line additionally checks this size against a committed oracle checksum)."""
+    from cice_amd import synth
+    keys = [k for k in evp.CGRID_FIELDS if k not in ("etax2U", "deltaU")]     # (never exchanged: ghost cells differ by layout)
+    ref = None
+    for bs, fused, selfx in ((None, "1", False), ((1800, 1200), "1", False), (None, "0", False), ((1800, 1200), "1", True)):
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_FUSED", fused)
+        if selfx:
+            monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+            monkeypatch.setenv("CICE_EVP_HIP_HALO", "direct")
+        dc, g, static, state, inputs, masks = synth_cgrid("s01", bs=bs, seed=2)
+        d, keep = evp.make_dims(dc, 0)
+        core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(480), strict=True), static["dyE"], static["dxN"], static["dxT"],
+                          static["dyT"], 1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        try:
+            if selfx:
+                core.comm_init(core.comm_unique_id())
+            core.cgrid_set_geometry(static)
+            out = core.cgrid_run(3, state, inputs, masks)
+        finally:
+            core.finalize()
+        glob = {k: dc.gather({0: out[k]}) for k in keys}
+        del out, static, state, inputs
+        assert np.isfinite(glob["uvelE"]).all() and np.abs(glob["uvelE"]).max() > 1e-4
+        if ref is None:
+            ref = glob
+        else:
+            assert_bitwise(glob, ref, f"C grid s01 blocks={bs} fused={fused} mailbox={selfx}")
