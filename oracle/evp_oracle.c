@@ -104,6 +104,13 @@ static void gather_global(const evp_oracle_domain *d, const double *a, double *g
     }
 }
 
+/* Test hook: when set, every halo update of this file is handed to the callback instead (array, field_loc, field_type)
+ * -- tests/test_multirank_cpu.py runs the C-grid loop on the blocks of ONE rank of a multi-rank decomposition and does
+ * the exchange itself (plan lists + torch.distributed gloo), to check lists and exchange points without a GPU. */
+typedef void (*evp_oracle_halo_cb)(double *a, int field_loc, int field_type);
+static evp_oracle_halo_cb g_halo_cb = 0;
+void evp_oracle_set_halo_callback(evp_oracle_halo_cb cb) { g_halo_cb = cb; }
+
 /* field_loc: 0 = center, 1 = NE corner, 2 = E face, 3 = N face.  field_type: 0 = scalar, 1 = vector (sign -1 over
  * the tripole fold).  u-fold rules per location (ice_boundary.F90:1626-1683): offsets (ioffset, joffset) =
  * center (0,0), NE corner (1,1), E face (1,0), N face (0,1); points ON the fold -- top physical row of NE-corner and
@@ -112,6 +119,10 @@ static void gather_global(const evp_oracle_domain *d, const double *a, double *g
 void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc, int field_type,
                             int have_fill, double fill)
 {
+    if (g_halo_cb && !have_fill) {
+        g_halo_cb(a, field_loc, field_type);
+        return;
+    }
     const int nx = d->nx_block, ny = d->ny_block;
     const int NX = d->nx_global, NY = d->ny_global;
     double *g = (double *)malloc(sizeof(double) * (size_t)NX * NY);

@@ -270,3 +270,16 @@ def cgrid_subcycle(dom: OracleDomain, params: Params, ndte: int, state: dict, in
                                     C.c_int(1 if visc_method == "avg_strength" else 0), fptr, iptr, gptr,
                                     *[m.ctypes.data_as(C.POINTER(C.c_int32)) for m in mk])
     return work
+
+
+HALO_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_int)
+_halo_cb_keep = None
+
+
+def set_halo_callback(fn):
+    """Test hook: fn(array_pointer, field_loc, field_type) replaces every halo update of the oracle (None: back to the
+    built-in one).  The pointer addresses the whole (nblocks, ny_block, nx_block) array being updated."""
+    global _halo_cb_keep
+    lib().evp_oracle_set_halo_callback.restype = None
+    _halo_cb_keep = HALO_CB(fn) if fn is not None else None
+    lib().evp_oracle_set_halo_callback(_halo_cb_keep if _halo_cb_keep is not None else C.cast(None, HALO_CB))

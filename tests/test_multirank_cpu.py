@@ -211,3 +211,114 @@ def test_two_rank_halo_exchange_known_answer(case):
     # what one rank sends the other receives
     r0, r1 = sorted(res)
     assert r0[3] == r1[4] and r0[4] == r1[3]
+
+
+CGRID_RANK_CASES = [
+    # nx, ny, bx, by, ew, nranks, proc_shape, visc_method
+    (40, 36, 20, 18, "cyclic", 2, (2, 1), "avg_zeta"),
+    (40, 36, 10, 12, "cyclic", 2, (1, 2), "avg_strength"),      # several (padded) blocks per rank
+    (44, 40, 22, 20, "closed", 4, (2, 2), "avg_zeta"),
+]
+
+
+def _cgrid_worker(rank, world, port, case, q):
+    """The C-grid subcycle loop on the blocks of ONE rank (the oracle's arithmetic, block by block), with every halo
+    update of the loop done the way the GPU path does it across ranks: ghost cells this rank owns the source of by the
+    plan's local lists, the others by a point-to-point exchange of the plan's send / recv lists (gloo here, mailbox
+    stores or RCCL on the GPUs) -- the same lists at every exchange point, whatever the field's location.  Each rank's
+    blocks, ghost cells of the exchanged fields included, must equal the single-rank run."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        from pathlib import Path
+        sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
+        import oracle
+        from cice_amd import synth
+        nx, ny, bx, by, ew, nranks, shape, visc = case
+        g = synth.make_grid(nx, ny, 1.1e5, ns="closed")
+        g["ew"] = ew
+        g = synth.derive_geometry(g)
+        cg = synth.cgrid_geometry(g)
+        st, inp, mk = synth.cgrid_state(g, cg, seed=5, seabed=True)
+        scal = synth.evp_scalars(120)
+        prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                          "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+
+        def domain(dc, r):
+            ob = dc.local_blocks(r)
+            return oracle.OracleDomain(dc.nx_block, dc.ny_block, len(ob), nx, ny, ew, "closed", [b.ilo for b in ob],
+                                       [b.ihi for b in ob], [b.jlo for b in ob], [b.jhi for b in ob],
+                                       [b.gi0 for b in ob], [b.gj0 for b in ob])
+
+        # the known answer: all blocks on one rank, the oracle's own halo update
+        one = decomp.Decomp(nx, ny, bx, by, ew, "closed", 1)
+        s1 = synth.cgrid_scatter(one, 0, cg, st, inp, mk)
+        ref = oracle.cgrid_subcycle(domain(one, 0), prm, 5, s1[1], s1[2], s1[0], s1[3], visc_method=visc)
+        # this rank's share, the exchange done here
+        dc = decomp.Decomp(nx, ny, bx, by, ew, "closed", nranks, shape)
+        d, keep = evp.make_dims(dc, rank)
+        plan = evp.halo_plan(d)
+        n = len(dc.local_blocks(rank)) * dc.ny_block * dc.nx_block
+        calls = []
+
+        def halo(aptr, loc, kind):
+            flat = np.ctypeslib.as_array(aptr, shape=(n,))
+            calls.append(loc)
+            sendbuf = torch.from_numpy(flat[plan["send_src"]].copy())
+            recvbuf = torch.zeros(len(plan["recv_dst"]), dtype=torch.float64)
+            ops, so, ro = [], 0, 0
+            for p, ns_, nr_ in zip(plan["peer_rank"], plan["peer_nsend"], plan["peer_nrecv"]):
+                if ns_:
+                    ops.append(dist.P2POp(dist.isend, sendbuf[so:so + ns_], int(p)))
+                if nr_:
+                    ops.append(dist.P2POp(dist.irecv, recvbuf[ro:ro + nr_], int(p)))
+                so += ns_
+                ro += nr_
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            src = plan["local_src"]
+            vals = np.where(src >= 0, flat[np.maximum(src, 0)], 0.0)
+            flat[plan["local_dst"]] = vals
+            flat[plan["recv_dst"]] = recvbuf.numpy()
+
+        oracle.set_halo_callback(halo)
+        try:
+            sN = synth.cgrid_scatter(dc, rank, cg, st, inp, mk)
+            got = oracle.cgrid_subcycle(domain(dc, rank), prm, 5, sN[1], sN[2], sN[0], sN[3], visc_method=visc)
+        finally:
+            oracle.set_halo_callback(None)
+        exchanged = ("uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12U", "zetax2T",
+                     "etax2T", "shearU")
+        nbad = 0
+        mine = dc.local_blocks(rank)
+        ob = one.local_blocks(0)
+        for k in oracle.C_FIELDS:
+            for b in mine:
+                kb = next(o.local for o in ob if o.gi0 == b.gi0 and o.gj0 == b.gj0)
+                if k in exchanged:
+                    nbad += int((got[k][b.local] != ref[k][kb]).sum())
+                else:
+                    nbad += int((got[k][b.local][1:1 + b.gny, 1:1 + b.gnx] != ref[k][kb][1:1 + b.gny, 1:1 + b.gnx]).sum())
+        q.put((rank, nbad, len(calls), float(np.abs(ref["uvelE"]).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", CGRID_RANK_CASES)
+def test_cgrid_loop_split_over_ranks_known_answer(case):
+    world = case[5]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cgrid_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nbad, ncalls, umax in sorted(res):
+        assert nbad == 0, f"rank {rank}: {nbad} values differ from the single-rank run"
+        assert ncalls == 5 * 12 and umax > 1e-3         # 12 fields exchanged per subcycle (eight ice_HaloUpdate calls)
