@@ -300,3 +300,27 @@ def test_cgrid_s01_full_size_invariances(monkeypatch):
             ref = glob
         else:
             assert_bitwise(glob, ref, f"C grid s01 blocks={bs} fused={fused} mailbox={selfx}")
+
+
+def test_cgrid_many_small_blocks_and_zero_subcycles():
+    """Edge cases of the layout: gx3 cut into 100 blocks of 10 x 12 cells (smaller than a 64-wide workgroup row, most
+    ghost cells images of other blocks, padded blocks at the far edges) against the oracle; and ndte = 0 hands back
+    exactly what was handed in (no launch, no ghost repair, work arrays zero as evp() leaves them at entry)."""
+    args = synth_cgrid("gx3", case="caps", bs=(10, 12), seed=9, seabed=True)
+    got, want = run_both(*args, ndte=6)
+    assert_bitwise(got, want, "100 small blocks")
+    assert args[0].nx_block == 12 and len(args[0].local_blocks(0)) == 100
+    dc, g, static, state, inputs, masks = args
+    from cice_amd import synth
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(120), strict=True), static["dyE"], static["dxN"], static["dxT"],
+                      static["dyT"], 1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        out = core.cgrid_run(0, state, inputs, masks)
+    finally:
+        core.finalize()
+    for k in evp.CGRID_FIELDS[:14]:
+        assert np.array_equal(out[k], state[k]), k
+    for k in evp.CGRID_FIELDS[14:]:
+        assert not out[k].any(), k

@@ -1032,3 +1032,16 @@ def test_random_masks_on_fixture_grids_vs_oracle(name, seed, holes, kernel, monk
     finally:
         core.finalize()
     assert_bitwise(got, {k: want[k] for k in evp.OUTPUTS}, f"{name} random masks {kernel}")
+
+
+@pytest.mark.parametrize("kernel", ["resident", "streaming"])
+def test_many_small_blocks_vs_oracle(kernel, monkeypatch):
+    """gx3 cut into 100 blocks of 10 x 12 cells (blocks smaller than any tile of either kernel, most ghost cells images
+    of other blocks, padded blocks at the far edges) against the oracle, 24 subcycles."""
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "caps", seed=41, warm=True, bs=(10, 12))
+    assert len(dc.local_blocks(0)) == 100
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if kernel == "resident" else "0")
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=24)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 24)
+    assert_bitwise(got, want, f"100 small blocks, {kernel}")
