@@ -97,9 +97,10 @@ def synth_cgrid(grid_name, case="full", bs=None, seed=3, seabed=False):
     return dc, g, static, state, inputs, masks
 
 
-def run_both(dc, g, static, state, inputs, masks, ndte, visc_method="avg_zeta", scal_kw=None):
+def run_both(dc, g, static, state, inputs, masks, ndte, visc_method="avg_zeta", scal_kw=None, scal_over=None):
     from cice_amd import synth
     scal = synth.evp_scalars(120, **(scal_kw or {}))
+    scal.update(scal_over or {})
     blks = dc.local_blocks(0)
     dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
                               [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
@@ -324,3 +325,24 @@ def test_cgrid_many_small_blocks_and_zero_subcycles():
         assert np.array_equal(out[k], state[k]), k
     for k in evp.CGRID_FIELDS[14:]:
         assert not out[k].any(), k
+
+
+@pytest.mark.parametrize("seed", [61, 62, 63, 64, 65, 66])
+def test_cgrid_random_scalars_vs_oracle(seed):
+    """Property test over the EVP scalars on the C grid: capping in {0, 1, fractional}, Ktens, yield-curve ratios,
+    classic / revised EVP, an ocean turning angle (cosw != 1, sinw != 0: no fixture has one), both visc methods, random
+    operands and masks -- against the oracle, bit for bit."""
+    rng = np.random.default_rng(seed)
+    kw = dict(capping=float(rng.choice([0.0, 1.0, rng.uniform(0.1, 0.9)])), Ktens=float(rng.choice([0.0, rng.uniform(0.05, 0.5)])),
+              e_yieldcurve=float(rng.uniform(1.2, 2.5)), e_plasticpot=float(rng.uniform(1.2, 2.5)))
+    if rng.random() < 0.5:
+        kw.update(revised_evp=True, arlx=float(rng.uniform(100, 400)), brlx=float(rng.uniform(100, 400)))
+    over = {}
+    if rng.random() < 0.6:
+        ang = np.deg2rad(rng.uniform(5.0, 25.0))
+        over = dict(cosw=float(np.cos(ang)), sinw=float(np.sin(ang)))
+    ns = "tripole" if seed % 3 == 0 else "closed"
+    args = random_cgrid_case(seed, 48, 30, (16, 10) if seed % 2 else (48, 30), "cyclic", ns, 0.3)
+    got, want = run_both(*args, ndte=6, visc_method=("avg_strength" if seed % 2 else "avg_zeta"), scal_kw=kw, scal_over=over)
+    assert_bitwise(got, want, f"C grid random scalars seed {seed}: {kw} {over} {ns}")
+    assert np.isfinite(want["uvelE"]).all()

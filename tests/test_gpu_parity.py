@@ -1045,3 +1045,38 @@ def test_many_small_blocks_vs_oracle(kernel, monkeypatch):
     got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=24)
     want = run_oracle(dc, geo, fields, tm, um, scal, 24)
     assert_bitwise(got, want, f"100 small blocks, {kernel}")
+
+
+@pytest.mark.parametrize("kernel", ["resident", "streaming"])
+@pytest.mark.parametrize("seed", [51, 52, 53, 54, 55, 56])
+def test_random_scalars_vs_oracle(seed, kernel, monkeypatch):
+    """Property test over the EVP scalars: capping in {0, 1, fractional}, Ktens, yield-curve ratios, classic / revised
+    EVP, an ocean turning angle (cosw != 1, sinw != 0 -- never the case in the reference's default set-up, so no
+    fixture has it), seabed stress on part of the domain, water stress operands that differ from the ocean currents:
+    every arithmetic variant the kernels select from the scalars and from the data (evp_math.h modes, the
+    waterx == uocn and TbU == 0 shortcuts) against the oracle, bit for bit."""
+    rng = np.random.default_rng(seed)
+    kw = dict(capping=float(rng.choice([0.0, 1.0, rng.uniform(0.1, 0.9)])), Ktens=float(rng.choice([0.0, rng.uniform(0.05, 0.5)])),
+              e_yieldcurve=float(rng.uniform(1.2, 2.5)), e_plasticpot=float(rng.uniform(1.2, 2.5)))
+    if rng.random() < 0.5:
+        kw.update(revised_evp=True, arlx=float(rng.uniform(100, 400)), brlx=float(rng.uniform(100, 400)))
+    scal = synth.evp_scalars(120, **kw)
+    if rng.random() < 0.6:
+        ang = np.deg2rad(rng.uniform(5.0, 25.0))
+        scal["cosw"], scal["sinw"] = float(np.cos(ang)), float(np.sin(ang))
+    dc, geo, fields, tm, um = synth_case("gx3", "caps" if seed % 2 else "full", seed=seed, warm=True,
+                                         bs=(None if seed % 3 else (50, 58)))
+    fields = dict(fields)
+    if rng.random() < 0.6:      # seabed stress on the southern third
+        tb = np.zeros_like(fields["TbU"])
+        tb[:, : tb.shape[1] // 3, :] = rng.uniform(0.1, 2.0)
+        fields["TbU"] = tb * um
+    if scal["sinw"] != 0.0:     # as dyn_prep2 forms them (ice_dyn_shared.F90:819-820)
+        sg = np.copysign(1.0, fields["fmU"])
+        fields["waterxU"] = (fields["uocnU"] * scal["cosw"] - fields["vocnU"] * scal["sinw"] * sg) * um
+        fields["wateryU"] = (fields["vocnU"] * scal["cosw"] + fields["uocnU"] * scal["sinw"] * sg) * um
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if kernel == "resident" else "0")
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 12)
+    assert_bitwise(got, want, f"random scalars seed {seed} {kernel}: {kw} cosw={scal['cosw']}")
+    assert np.isfinite(want["uvel"]).all()
