@@ -301,6 +301,7 @@ def main():
             tm = dc.scatter(st["iceTmask"], rank, fill=0)
             um = dc.scatter(st["iceUmask"], rank, fill=0)
             n_active = int(st["iceTmask"].sum())
+            fold_metrics = synth.bgrid_fold_metrics(dc, rank, g) if ns == "tripole" else None
             del g, st
 
             scal = synth.evp_scalars(ndte)
@@ -309,6 +310,8 @@ def main():
                               geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
             try:
                 def setup():
+                    if ns == "tripole":      # CICE's own dxhy / dyhx: their north ghost row is a sign-flipped mirror image
+                        core.set_metrics(**dict(zip(("dxhy", "dyhx"), fold_metrics)))
                     if world > 1 and rehearsal:
                         blobs = [None] * world
                         dist.all_gather_object(blobs, core.halo_export())

@@ -335,3 +335,15 @@ def cgrid_scatter(dc, rank: int, cg: dict, state: dict, inputs: dict, masks: dic
     static = {k: sc(k, v, 1.0 if k in CGRID_FILL_ONE else 0.0) for k, v in cg.items()}
     return (static, {k: sc(k, v, 0.0) for k, v in state.items()}, {k: sc(k, v, 0.0) for k, v in inputs.items()},
             {k: sc(k, v, 0) for k, v in masks.items()})
+
+
+def bgrid_fold_metrics(dc, rank: int, g: dict):
+    """dxhy, dyhx as block arrays with the ghost cells CICE gives them (ice_dyn_shared.F90:401-424: computed on the
+    physical cells, then a halo update as cell-centre VECTOR fields with fill value 1): what the Fortran shim hands to
+    cice_evp_hip_set_metrics on tripole grids, where the north ghost row is a sign-flipped mirror image."""
+    HTE, HTN = g["HTE"], g["HTN"]
+    dxhy = 0.5 * (HTE - np.roll(HTE, 1, axis=1))
+    dyhx = np.empty_like(HTN)
+    dyhx[1:] = 0.5 * (HTN[1:] - HTN[:-1])
+    dyhx[0] = 0.5 * (HTN[0] - 1.0)          # (the ghost row south of a closed boundary holds the fill value 1)
+    return (dc.scatter(dxhy, rank, fill=1.0, fold=("center", -1.0)), dc.scatter(dyhx, rank, fill=1.0, fold=("center", -1.0)))

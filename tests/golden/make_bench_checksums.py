@@ -29,6 +29,7 @@ CONFIGS = {   # workload: (case, ndte, ns, checkpoints)
     "gx3": ("full", 120, "closed", [1, 3, 5, 12, 23, 25, 50]),
     "gx1": ("full", 120, "closed", [1, 3, 5, 12, 23, 25, 50]),
     "s01": ("full", 480, "closed", [3]),
+    "tx1": ("full", 240, "tripole", [12]),
 }
 
 
@@ -49,6 +50,9 @@ def run(workload):
                               [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
                               [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
     m = oracle.metrics(dom, scal["deltaminEVP"], geo["HTE"], geo["HTN"], geo["tarea"])
+    if ns == "tripole":      # what bench.py hands to cice_evp_hip_set_metrics must be what the oracle uses
+        dxhy, dyhx = synth.bgrid_fold_metrics(dc, 0, g)
+        assert np.array_equal(dxhy, m["dxhy"]) and np.array_equal(dyhx, m["dyhx"])
     static = dict(m, dxT=geo["dxT"], dyT=geo["dyT"], uarear=geo["uarear"])
     prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i",
                                                       "capping", "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
