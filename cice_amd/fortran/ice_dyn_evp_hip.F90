@@ -30,7 +30,8 @@ module ice_dyn_evp_hip
   private
 
   public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body, &
-            dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses, dyn_evp_hip_cgrid_run
+            dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses, dyn_evp_hip_cgrid_run, &
+            dyn_evp_hip_keep_stresses_resident
 
   ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
   type, bind(C) :: cice_evp_hip_dims
@@ -211,12 +212,14 @@ module ice_dyn_evp_hip
 
   logical :: initialised = .false.
   logical :: pinned = .false.
-  ! The 12 stress components stay on the device between evp() calls (evp() is their only writer): they are
-  ! uploaded once, never downloaded by dyn_evp_hip_run, and ice_flux's arrays are STALE until
-  ! dyn_evp_hip_fetch_stresses -- which the host model calls where something else reads them (restart
-  ! write, ice_restart_driver.F90:187-200; history / principal stresses).  CICE_EVP_HIP_STRESS_RESIDENT=0
-  ! in the environment restores the copy-in/copy-out behaviour of dyn_evp1d_run.
-  logical :: stress_resident = .true.
+  ! Default = dyn_evp1d_run's contract (ice_dyn_evp1d.F90:121-135): the 12 intent(inout) stress arrays are
+  ! copied in and written back on every call, so an UNPATCHED host (restart write ice_restart_driver.F90:187-200,
+  ! history sig1/sig2/sigP, evp()'s own ice_HaloUpdate_stress on tripole grids) always reads current values.
+  ! Opt-in only: a host that has installed the two hooks (dyn_evp_hip_fetch_stresses before every reader,
+  ! dyn_evp_hip_invalidate_stresses after every writer) may call dyn_evp_hip_keep_stresses_resident(.true.)
+  ! -- or set CICE_EVP_HIP_STRESS_RESIDENT=1 -- and the stresses then stay on the device between calls.
+  logical :: stress_resident = .false.
+  logical :: stress_resident_requested = .false.
   logical :: on_tripole = .false.
   logical :: cgrid_geometry_set = .false.
   logical :: cgrid_pinned = .false.
@@ -321,7 +324,7 @@ contains
 
     on_tripole = trim(ns_boundary_type) == 'tripole'
     call get_environment_variable('CICE_EVP_HIP_STRESS_RESIDENT', envval, envlen, envstat)
-    stress_resident = .not. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '0')
+    stress_resident = stress_resident_requested .or. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '1')
     ! a rank layout that cuts the tripole seam row: the stress symmetrisation needs other ranks and stays with
     ! evp()'s host code (ice_dyn_evp.F90:1321-1389), so the stresses must make the round trip every call
     if (on_tripole .and. cice_evp_hip_seam_fin_plan(cnt2, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr) == 1) &
@@ -682,6 +685,25 @@ contains
     s12(11) = cice_evp_hip_addr(stress12_3); s12(12) = cice_evp_hip_addr(stress12_4)
     call check(cice_evp_hip_fetch_stresses(s12), subname, __FILE__, __LINE__)
   end subroutine dyn_evp_hip_fetch_stresses
+
+! Opt in to (or out of) device-resident stresses.  ONLY for hosts that call dyn_evp_hip_fetch_stresses before
+! every reader of ice_flux's stress arrays and dyn_evp_hip_invalidate_stresses after every writer; may be
+! called before or after dyn_evp_hip_init.  Switching off brings the host arrays up to date first.
+  subroutine dyn_evp_hip_keep_stresses_resident(flag)
+    logical, intent(in) :: flag
+    integer(c_int32_t) :: cnt2(2)
+    character(len=*), parameter :: subname = '(dyn_evp_hip_keep_stresses_resident)'
+    stress_resident_requested = flag
+    if (.not. initialised) return
+    if (.not. flag .and. stress_resident) call dyn_evp_hip_fetch_stresses
+    stress_resident = flag
+    if (on_tripole) then
+       if (cice_evp_hip_seam_fin_plan(cnt2, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr) == 1) &
+          stress_resident = .false.
+    endif
+    call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
+         subname, __FILE__, __LINE__)
+  end subroutine dyn_evp_hip_keep_stresses_resident
 
 ! The host changed ice_flux's stress arrays itself (restart read): the next evp() uploads them again.
   subroutine dyn_evp_hip_invalidate_stresses

@@ -173,7 +173,8 @@ program evp_ref_harness
   use ice_dyn_evp1d, only: capture_tag, dyn_evp1d_init, dyn_evp1d_finalize
 #endif
 #ifdef HARNESS_HIP_BODY
-  use ice_dyn_evp_hip, only: dyn_evp_hip_evp_body, dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses
+  use ice_dyn_evp_hip, only: dyn_evp_hip_evp_body, dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses, &
+      dyn_evp_hip_keep_stresses_resident
 #endif
   use evp_dumpio
   use evp_cgrid_capture, only: cgrid_call
@@ -211,6 +212,8 @@ program evp_ref_harness
   integer(int_kind)  :: ntiming     = 0           ! extra evp() calls, timed, after the dumps
   logical            :: hipmode     = .false.     ! drop-in check: HIP core (via ice_dyn_evp1d) vs standard_2d
   logical            :: hipbody     = .false.     ! with hipmode: also Option A, preparation + loop on the device
+  logical            :: hipresident = .false.     ! with hipmode: opt in to device-resident stresses and install the two hooks
+                                                  ! (default: NO hook is called -- the unpatched-host contract of dyn_evp1d_run)
   logical            :: time_1d     = .false.     ! timing loop with evp_algorithm='shared_mem_1d' (HARNESS_REF1D build only)
   character(len=8)   :: h_grid_ice  = 'B'         ! 'B' | 'C': staggering of the dynamics (C: ice_dyn_evp.F90:936-1121)
   character(len=16)  :: h_visc_method = 'avg_zeta' ! C grid: 'avg_zeta' | 'avg_strength' (ice_dyn_evp.F90:992-996)
@@ -218,7 +221,7 @@ program evp_ref_harness
   namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
      h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
      h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, &
-     dump_arrays, ntiming, hipmode, hipbody, time_1d, h_grid_ice, h_visc_method
+     dump_arrays, ntiming, hipmode, hipbody, hipresident, time_1d, h_grid_ice, h_visc_method
 
   ! ---- locals ----------------------------------------------------------
   integer(int_kind) :: i, j, iblk, icall, k, nsub, nl, ios, nthreads
@@ -236,6 +239,9 @@ program evp_ref_harness
   if (ios /= 0) stop 'harness_in missing'
   read(55, nml=harness_nml)
   close(55)
+#ifdef HARNESS_HIP_BODY
+  if (hipresident) call dyn_evp_hip_keep_stresses_resident(.true.)
+#endif
 
   call init_communicate
   call init_fileunits
@@ -481,11 +487,13 @@ program evp_ref_harness
            ! existing dyn_evp1d_run boundary (ice_dyn_evp.F90:846-856)
            evp_algorithm = 'shared_mem_1d'
 #ifdef HARNESS_HIP_BODY
-           call dyn_evp_hip_invalidate_stresses     ! the harness reset ice_flux's stresses behind the core's back
+           ! only a host that opted in to resident stresses has hooks to call: the harness reset ice_flux's stresses
+           ! behind the core's back.  Default: nothing -- the host arrays ARE the state, as with dyn_evp1d_run
+           if (hipresident) call dyn_evp_hip_invalidate_stresses
 #endif
            call evp(dt_dyn)
 #ifdef HARNESS_HIP_BODY
-           call dyn_evp_hip_fetch_stresses          ! device-resident stresses: ice_flux's arrays are stale until fetched
+           if (hipresident) call dyn_evp_hip_fetch_stresses   ! opted in: ice_flux's arrays are stale until fetched
 #endif
            evp_algorithm = 'standard_2d'
            write(tag,'(a,i2.2,a,i4.4)') 'h', icall, 'n', nsub

@@ -34,8 +34,16 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["no_hooks", "resident_opt_in"])
 @pytest.mark.parametrize("nx,ny,bx,by,ew,kw", CASES)
-def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw):
+def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw, resident):
+    """resident=False (the shim's default): the harness calls NO fetch / invalidate hook -- an unpatched host.  The
+    twelve intent(inout) stress arrays of dyn_evp1d_run (ice_dyn_evp1d.F90:121-135) must hold the reference's values
+    in ice_flux after every evp() call (what ice_restart_driver.F90:187-200 writes), closed and tripole grids alike
+    (on a tripole grid evp()'s own 12 x ice_HaloUpdate_stress then runs on current host arrays).
+    resident=True: the host opted in (dyn_evp_hip_keep_stresses_resident) and calls the two hooks."""
+    if resident and (nx, ny) not in ((40, 36), (72, 40), (48, 36)):
+        pytest.skip("opt-in variant: one closed-north and the two tripole cases")
     if not run_ref.have_ref("hip_dropin"):
         pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
     kw = dict(kw)
@@ -48,7 +56,7 @@ def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw
         grid_files = (tmp_path / "grid.bin", tmp_path / "kmt.bin")
     d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="hip_dropin", h_ndte=120,
                                  ncalls=2, nsub_list=[1, 120], hipmode=True, hipbody=True,
-                                 grid_files=grid_files, **kw)
+                                 hipresident=resident, grid_files=grid_files, **kw)
     checked = 0
     for icall in (1, 2):
         for nsub in (1, 120):
