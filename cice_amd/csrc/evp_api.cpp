@@ -173,6 +173,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     S.ready = true;
     S.uploaded = false;
     S.cur = 0;
+    S.fault_calls = 0;
     return 0;
 }
 
@@ -243,6 +244,18 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
                 if (tb[k] != 0.0) tbu_zero = false;
             }
         }
+    }
+    if (S.lean_diag) {
+        // bit 7: the cells the loop really writes strintx/y, taubx/y on -- iceUmask on INTERIOR cells.  A caller may
+        // hold iceUmask on ghost or padding cells too (halo-updated masks): the masked scatter of the download must
+        // not hand never-written device values back there.  Kernels test bits 0 and 1 only.
+        const int nxb = S.d.nx_block;
+        for (int b = 0; b < S.d.nblocks; ++b)
+            for (int j = S.d.jlo[b]; j <= S.d.jhi[b]; ++j)
+                for (int i = S.d.ilo[b]; i <= S.d.ihi[b]; ++i) {
+                    const size_t k = (size_t)b * S.plane + (size_t)(j - 1) * nxb + (i - 1);
+                    if (S.hmask[k] & 2u) S.hmask[k] |= 0x80u;
+                }
     }
     S.flags &= ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
     if (water_is_ocn) S.flags |= EVP_F_WATER_IS_OCN;
@@ -473,7 +486,7 @@ int cice_evp_hip_download(double *const *f)
         CopyBatch M;
         for (int o : outs)
             if (f[o]) M.items.push_back({f[o], S.in[o]});
-        if (d2h_batch_masked(M, 2u)) return -1;             // bit1: iceUmask
+        if (d2h_batch_masked(M, 0x80u)) return -1;          // bit7: interior && iceUmask = the cells the loop wrote
     } else {
         for (int o : outs)
             if (f[o]) B.items.push_back({f[o], S.in[o]});
@@ -488,6 +501,14 @@ int cice_evp_hip_download(double *const *f)
     S.t_d2h_ms = ms;
     if (S.t_nsub > 0 && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) S.t_loop_ms = ms;
     return 0;
+}
+
+// Test hook: the N-th call that reaches it reports a failure that did not happen (N = value of the variable), so
+// that recovery paths can be exercised on a healthy GPU.
+static bool fault_hook(const char *name)
+{
+    const char *e = env(name);
+    return e && ++S.fault_calls == std::atoi(e);      // counted from cice_evp_hip_init
 }
 
 int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, double *stressp_4,
@@ -519,29 +540,58 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
     }
     struct LeanOff { ~LeanOff() { S.lean_diag = false; } } lean_off;      // only for the duration of this call
     if (int rc = upload_impl(f, iceTmask, iceUmask, keep_sig)) return rc;
+    // The resident kernel assumes the GPU to itself.  If that did not hold (another process or a long kernel on the
+    // device: a wait gave up) the call is repeated with the streaming kernel, which is then kept.  Without resident
+    // stresses nothing has been written back yet and the caller's inputs are intact.  With them (keep_sig) the only
+    // copy of the pre-call stresses is sig[cur], which the resident kernel overwrites at its end (both ping-pong
+    // copies): keep a device snapshot for the replay.
+    const bool may_replay = S.res_mode == 1 && S.plan.peers.empty();
+    const int cur0 = S.cur;
+    if (may_replay && keep_sig) {
+        EvpCopyTab T{};
+        T.len = S.n;
+        T.vec2 = 1;
+        for (int k = 0; k < 12; ++k) {
+            if (!S.sig_snap[k]) HIPC(hipMalloc((void **)&S.sig_snap[k], S.n * sizeof(double)));
+            T.src[T.n] = S.sig[cur0][k]; T.dst[T.n] = S.sig_snap[k]; ++T.n;
+            if ((((uintptr_t)T.src[k]) | ((uintptr_t)T.dst[k])) & 15u) T.vec2 = 0;
+        }
+        evp_launch_copy_many(T, S.stream);
+    }
+    S.sig_valid = false;                      // until this call has succeeded
     if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
-    if (S.res_mode == 1 && S.plan.peers.empty() && !keep_sig) {
-        // The resident kernel assumes the GPU to itself.  If that did not hold (another process or a
-        // long kernel on the device: a wait gave up), nothing has been written back yet and the
-        // caller's inputs are intact: run the call again with the streaming kernel, and keep to it.
+    if (may_replay) {
         HIPC(hipStreamSynchronize(S.stream));
-        if (resident_check_error() != 0) {
+        if (resident_check_error() != 0 || fault_hook("CICE_EVP_HIP_FAULT_REPLAY")) {
             if (env("CICE_EVP_HIP_VERBOSE"))
                 std::fprintf(stderr, "[cice_evp_hip] %s -- repeating the call with the streaming kernel\n", g_err.c_str());
             g_err.clear();
             ++S.res_fallbacks;
-            if (int rc = upload_impl(f, iceTmask, iceUmask, false)) return rc;
+            S.res_mode = 0;
+            if (keep_sig) {
+                EvpCopyTab T{};
+                T.len = S.n;
+                T.vec2 = 1;
+                for (int k = 0; k < 12; ++k) {
+                    T.src[T.n] = S.sig_snap[k]; T.dst[T.n] = S.sig[cur0][k]; ++T.n;
+                    if ((((uintptr_t)T.src[k]) | ((uintptr_t)T.dst[k])) & 15u) T.vec2 = 0;
+                }
+                evp_launch_copy_many(T, S.stream);
+                S.cur = cur0;
+            }
+            if (int rc = upload_impl(f, iceTmask, iceUmask, keep_sig)) return rc;
             if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
         }
     }
     // only the documented outputs travel back
     double *o[F_COUNT] = {};
-    S.sig_valid = S.opt_sig_resident;
     if (!S.opt_sig_resident)
         for (int k = 0; k < 12; ++k) o[k] = f[k];
     o[F_STRINTX] = strintxU; o[F_STRINTY] = strintyU; o[F_TAUBX] = taubxU; o[F_TAUBY] = taubyU;
     o[F_UVEL] = uvel; o[F_VVEL] = vvel;
-    return cice_evp_hip_download(o);
+    if (int rc = cice_evp_hip_download(o)) return rc;          // incl. the error words of the kernels
+    S.sig_valid = S.opt_sig_resident;                          // only a call that succeeded leaves valid resident stresses
+    return 0;
 }
 
 int cice_evp_hip_get_timings(double *out, int32_t n)
@@ -739,6 +789,15 @@ int cice_evp_hip_seam_fin_plan(int32_t *counts2, int32_t *dst, int32_t *a, int32
         if (coef) coef[k] = P.fin_coef[k];
     }
     return P.stress_remote ? 1 : 0;
+}
+
+int cice_evp_hip_plan_flags(int32_t *flags, int32_t n)
+{
+    const HaloPlan &P = S.plan;
+    const int32_t v[5] = {P.any_fold_exchange, P.fold_rows, P.stress_remote, P.center_remote, P.center_fold_remote};
+    int32_t k = 0;
+    for (; flags && k < n && k < 5; ++k) flags[k] = v[k];
+    return k;
 }
 
 int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, int32_t *seam_pole,

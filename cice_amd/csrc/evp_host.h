@@ -89,6 +89,7 @@ struct State {
     double *in[F_COUNT] = {};   // per-call inputs + diagnostics (entries of ping-ponged fields unused)
     double *u[2] = {}, *v[2] = {};
     double *sig[2][12] = {};
+    double *sig_snap[12] = {};                     // pre-call stresses for the replay of a resident-kernel call (keep_sig)
     double *hte = nullptr, *htn = nullptr;   // edge lengths for in-kernel metric terms
     double *vrelfac = nullptr;               // (aiX*rhow)*Cw, rebuilt at every upload
     double *post_geo[3] = {};                // dxU dyU tarear (next tier f-1)
@@ -220,6 +221,7 @@ struct State {
     struct Pinned { size_t bytes; void *dev; };    // dev: the range as the device sees it (NULL: not mapped)
     std::map<const void *, Pinned> pinned;         // host ranges registered by cice_evp_hip_pin_host
     // stresses that stay on the device between calls of cice_evp_hip_run (CICE_EVP_HIP_OPT_STRESS_RESIDENT)
+    int fault_calls = 0;                           // test hook counter (fault_hook, evp_api.cpp)
     bool opt_sig_resident = false;
     bool sig_valid = false;                        // sig[cur] holds what the caller's arrays would hold
     bool lean_diag = false;                        // this call: strintx/y, taubx/y not uploaded; written back on ice U-cells only

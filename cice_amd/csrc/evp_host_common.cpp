@@ -42,6 +42,7 @@ void free_all()
         F(S.v[k]);
         for (auto &p : S.sig[k]) F(p);
     }
+    for (auto &p : S.sig_snap) F(p);
     F(S.hte);
     F(S.htn);
     F(S.vrelfac);
@@ -265,7 +266,9 @@ int upload_lists()
         HIPC(hipMemcpy(S.h_late_sign, P.late_sign.data(), S.n_late, hipMemcpyHostToDevice));
     }
     S.n_fin = (int)P.fin_dst.size();
-    if (S.n_fin > evp_halo_seam_fin_capacity()) return fail(-3, "tripole seam: %d cells to finalise on one rank (limit %d)", S.n_fin, evp_halo_seam_fin_capacity());
+    // the list is only run on layouts that split the seam row (halo_uv: general form) or when forced for tests
+    const bool fin_used = P.tail > 0 || (env("CICE_EVP_HIP_SEAM_FIN") && std::atoi(env("CICE_EVP_HIP_SEAM_FIN")));
+    if (fin_used && S.n_fin > evp_halo_seam_fin_capacity()) return fail(-3, "tripole seam: %d cells to finalise on one rank (limit %d)", S.n_fin, evp_halo_seam_fin_capacity());
     if (up32(P.fin_dst, S.h_fin_dst) || up32(P.fin_a, S.h_fin_a) || up32(P.fin_b, S.h_fin_b)) return -1;
     if (S.n_fin) {
         HIPC(hipMalloc((void **)&S.h_fin_coef, S.n_fin));

@@ -40,6 +40,10 @@ void fill_direct(EvpDirect &D, bool masked)
 int halo_remote_pair(double *a, double *bb, bool masked)
 {
     masked = masked && S.msk.on;
+    // staging slots of the split tripole seam lie BEHIND the cells of an array (offsets >= S.n): only the velocity
+    // buffers are allocated with that tail (S.nuv); any other target would be written out of bounds
+    if (S.plan.tail > 0 && !((a == S.u[0] && bb == S.v[0]) || (a == S.u[1] && bb == S.v[1])))
+        return fail(-3, "remote halo of a non-velocity array on a rank layout that splits the tripole seam row (staging slots)");
     if (!S.plan.peers.empty() && S.direct.on) {
         EvpDirect D;
         fill_direct(D, masked);

@@ -391,10 +391,12 @@ int cice_evp_hip_halo_mask(const int32_t *halomask)
     State::Masked &M = S.msk;
     for (auto &kv : S.graphs) (void)hipGraphExecDestroy(kv.second);     // captured loops bake the list lengths in
     S.graphs.clear();
-    if (!halomask || S.plan.peers.empty() || S.plan.tail > 0) { M.on = false; return 0; }
-    for (const HaloPeer &p : S.plan.peers)
-        for (int8_t sg : p.recv_sign)
-            if (sg < 0) { M.on = false; return 0; }      // exchange across the tripole fold: never masked
+    // The call is collective and both sides of every message must drop the same entries, so the on/off decision may
+    // only depend on what every rank computes alike: the plan's global flag (some rank exchanges across the tripole
+    // fold or through seam staging slots: the reference never masks those messages, ice_boundary.F90:979,1022, and
+    // here the whole in-loop exchange then stays unmasked on ALL ranks), never this rank's own lists.
+    if (!halomask || S.plan.any_fold_exchange) { M.on = false; return 0; }
+    if (S.plan.peers.empty()) { M.on = false; return 0; }           // no messages at all: nothing to agree on
     std::vector<int32_t> ss, rd, rslot;
     std::vector<int8_t> rs;
     std::vector<double *> sa;

@@ -164,6 +164,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                         ghost_seam.push_back({R, dst, s.ig, s.sign});
                         if (S.owner != R) continue;
                     }
+                    if (S.owner != R && s.sign < 0) plan.any_fold_exchange = true;
                     if (R == me) {
                         if (S.owner == me) {
                             plan.local_dst.push_back(dst);
@@ -283,6 +284,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                 if (it != slot_of.end()) return it->second;
                 const int32_t slot = nR + next_slot++;
                 slot_of[ig] = slot;
+                plan.any_fold_exchange = true;
                 if (R == me) {
                     HaloPeer &p = peers[ow];
                     p.rank = ow;

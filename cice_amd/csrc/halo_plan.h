@@ -58,6 +58,10 @@ struct HaloPlan {
     std::vector<int32_t> fin_dst, fin_a, fin_b;
     std::vector<int8_t> fin_coef;
     int tail = 0;
+    // Computed identically on EVERY rank (the enumeration below runs over all ranks): some rank's in-loop velocity
+    // exchange carries an entry across the tripole fold (sign -1 from another rank) or a staging slot.  Collective
+    // decisions (cice_evp_hip_halo_mask) must hang on this, never on a rank's own lists.
+    bool any_fold_exchange = false;
     bool stress_remote = false;                   // the stress symmetrisation needs a top-row cell of another rank
     // tripole: which ranks hold the two physical rows next to the fold (NY-1, NY)?  0: none here, 1: all of them here,
     // 2: shared with other ranks (the C-grid fold step then cannot be done on one rank)

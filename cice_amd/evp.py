@@ -42,7 +42,7 @@ EXPORTS = [
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
-    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
     "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
@@ -485,7 +485,9 @@ def halo_plan(dims: Dims) -> dict:
     nfin, tail = int(c2[0]), int(c2[1])
     fd, fa, fb, fc = [np.zeros(max(nfin, 1), dtype=np.int32) for _ in range(4)]
     lib.cice_evp_hip_seam_fin_plan(_ip(c2), _ip(fd), _ip(fa), _ip(fb), _ip(fc))
-    return dict(fin_dst=fd[:nfin], fin_a=fa[:nfin], fin_b=fb[:nfin], fin_coef=fc[:nfin], tail=tail, stress_remote=stress_remote, recv_sign=rsg[:nr],
+    fl = np.zeros(5, dtype=np.int32)
+    lib.cice_evp_hip_plan_flags(_ip(fl), 5)
+    return dict(any_fold_exchange=bool(fl[0]), fold_rows=int(fl[1]), fin_dst=fd[:nfin], fin_a=fa[:nfin], fin_b=fb[:nfin], fin_coef=fc[:nfin], tail=tail, stress_remote=stress_remote, recv_sign=rsg[:nr],
                 stress_dst=std[:nst], stress_src=sts[:nst], send_dst=sd[:ns], recv_gid=rg[:nr],
                 center_dst=cd[:ncen], center_src=cs[:ncen], center_vsign=cv[:ncen], center_remote=center_remote,
                 local_dst=ld[:nl], local_src=ls[:nl], local_sign=lg[:nl], peer_rank=pr[:npeer],

@@ -349,6 +349,11 @@ int cice_evp_hip_center_plan(int32_t *count, int32_t *dst, int32_t *src, int32_t
 /* Lists behind cice_evp_hip_stress_halo: a1[dst] <- a2[src] for every partner pair (src = -1:
  * fill 0, ice_boundary.F90:7643-7645).  Lists may be NULL.                                     */
 int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src);
+/* Flags of the plan, up to n of them: [0] some rank's in-loop velocity exchange crosses the tripole fold or uses
+ * seam staging slots -- computed identically on every rank, what collective decisions (cice_evp_hip_halo_mask)
+ * hang on; [1] fold_rows (0 none here, 1 all here, 2 shared); [2] stress symmetrisation needs another rank;
+ * [3] a cell-centre ghost needs another rank; [4] ... across the fold.  Returns the number written.           */
+int cice_evp_hip_plan_flags(int32_t *flags, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -182,6 +182,28 @@ def test_tripole_plan_with_the_seam_split_across_ranks():
         assert (len(plan["seam_a"]) > 0) == (r == 1) and plan["tail"] == 0 and not plan["stress_remote"]
 
 
+@pytest.mark.parametrize("nranks,shape", [(4, (2, 2)), (2, (2, 1)), (2, (1, 2)), (8, (4, 2))])
+def test_fold_exchange_flag_is_the_same_on_every_rank(nranks, shape):
+    """cice_evp_hip_halo_mask is collective: whether the in-loop exchange may be masked must come out alike on all
+    ranks.  On a tripole grid split in x AND y only the fold-row ranks have fold-crossing / staging entries of their
+    own; the flag is a property of the whole layout (ice_boundary.F90:979,1022: fold messages are never masked)."""
+    dc = decomp.Decomp(24, 20, 24 // shape[0], 20 // shape[1], "cyclic", "tripole", nranks, shape)
+    flags, own = [], []
+    for r in range(nranks):
+        d, keep = evp.make_dims(dc, r)
+        plan = evp.halo_plan(d)
+        flags.append(plan["any_fold_exchange"])
+        own.append(plan["tail"] > 0 or bool((plan["recv_sign"] < 0).any()))
+    assert len(set(flags)) == 1
+    assert flags[0] == any(own)
+    if shape == (2, 2):
+        assert not all(own) and flags[0]          # the case the per-rank decision got wrong
+    dc = decomp.Decomp(24, 20, 12, 10, "cyclic", "closed", 4, (2, 2))
+    for r in range(4):
+        d, keep = evp.make_dims(dc, r)
+        assert not evp.halo_plan(d)["any_fold_exchange"]
+
+
 def test_halo_plan_rejects_bad_geometry():
     dc = decomp.Decomp(20, 18, 10, 9, "cyclic", "closed", 1)
     d, keep = evp.make_dims(dc, 0)

@@ -876,6 +876,40 @@ def test_run_with_page_locked_arrays_and_resident_stresses(name):
         core.finalize()
 
 
+@pytest.mark.parametrize("name", ["pop_cyc_1blk_patchy", "rect_cyc_2x2_full", "trip_cyc_1blk_patchy"])
+def test_resident_stresses_survive_a_replayed_call(name, monkeypatch):
+    """A call of the on-chip resident kernel that gives up (GPU shared with something else) is repeated with the
+    streaming kernel.  With the 12 stresses resident on the device the host has no copy of the pre-call stresses and
+    the resident kernel has already overwritten the device copy: the library keeps a snapshot and replays from it.
+    The failure is injected AFTER the resident kernel has completed call 2 (CICE_EVP_HIP_FAULT_REPLAY=2), i.e. with
+    both ping-pong copies of the stresses overwritten -- the replayed call must still return the reference's call 2,
+    and sig_valid must not have been set by the failed attempt."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_FAULT_REPLAY", "2")
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        core.set_option(evp.OPT_STRESS_RESIDENT, 1)
+        work = {k: np.zeros(core.shape) for k in evp.FIELDS}
+        nonsig = [k for k in evp.OUTPUTS if k not in SIG]
+        for icall in (1, 2):
+            dyn, tm, um = c.inputs(icall)
+            for k in evp.FIELDS:
+                work[k][...] = dyn[k]
+            if icall == 2:
+                for k in SIG:
+                    work[k][...] = np.nan
+            core.run_inplace(work, np.ascontiguousarray(tm, np.int32), np.ascontiguousarray(um, np.int32), c.ndte)
+            if c.ns == "tripole":
+                core.stress_halo()
+            want = c.expected(icall, c.ndte)
+            assert_bitwise({k: work[k] for k in nonsig}, {k: want[k] for k in nonsig}, f"{name} call {icall}")
+        assert core.timings()["resident_fallbacks"] == 1, "the injected failure must have been replayed"
+        assert_bitwise(core.fetch_stresses(), {k: want[k] for k in SIG}, f"{name}: stresses after the replayed call")
+    finally:
+        core.finalize()
+
+
 def test_seabed_stress_factor_on_device_lkd():
     """SURVEY 8 f-2, last piece: seabed_stress_factor_LKD on the device from the aice / vice the preparation
     uploaded and the masks it produced.  Everything but exp() is exact; exp() is the device library's, so TbU is
