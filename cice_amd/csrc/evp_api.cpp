@@ -47,6 +47,7 @@ int cice_evp_hip_finalize(void)
 {
     if (S.stream) (void)hipStreamSynchronize(S.stream);
     cgrid_free();
+    march_free();
     free_all();
     S = State();
     return 0;
@@ -269,6 +270,7 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
     HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
     S.t_h2d_ms = ms;
     S.uploaded = true;
+    ++S.upload_seq;
     if (S.hmask_prev != S.hmask) { S.res2_order_stale = true; S.hmask_prev = S.hmask; }
     return tune_after_upload();
 }
@@ -290,6 +292,17 @@ int cice_evp_hip_subcycle(int32_t ndte)
         S.res_launched = true;
         HIPC(hipEventRecord(S.ev1, S.stream));
         S.cur ^= (ndte & 1);
+        S.t_nsub = ndte;
+        return 0;
+    }
+    S.march.last_call = false;
+    if (march_wanted()) {
+        // large per-rank domain: two subcycles per pass over HBM (evp_march.hip); falls back to the loop below by
+        // itself when the uploaded state does not qualify
+        const int declined0 = S.march.declined;
+        if (int rc = march_run(ndte)) return rc;
+        S.march.last_call = S.march.declined == declined0;
+        HIPC(hipEventRecord(S.ev1, S.stream));
         S.t_nsub = ndte;
         return 0;
     }
@@ -605,10 +618,10 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
     const double v[14] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
-                         S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) :
+                         S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) : S.march.last_call ? 0.5 :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
-                         (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : S.tyb), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
+                         (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : (S.march.last_call ? 3000 + S.march.seglen : S.tyb)), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
                           S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms, (double)S.res_fallbacks,
                           (double)(S.msk.on ? S.msk.n_send : S.n_send), (double)(S.msk.on ? S.msk.n_recv : S.n_recv)};
     for (int k = 0; k < n && k < 14; ++k) out[k] = v[k];
@@ -789,6 +802,15 @@ int cice_evp_hip_seam_fin_plan(int32_t *counts2, int32_t *dst, int32_t *a, int32
         if (coef) coef[k] = P.fin_coef[k];
     }
     return P.stress_remote ? 1 : 0;
+}
+
+int cice_evp_hip_march_info(int32_t *out, int32_t n)
+{
+    const State::March &M = S.march;
+    const int32_t v[7] = {M.mode, (int32_t)std::min<long>(M.passes, 0x7fffffffL), M.declined, M.nstrips, M.nseg, M.seglen,
+                          M.last_call ? 1 : 0};
+    for (int k = 0; out && k < n && k < 7; ++k) out[k] = v[k];
+    return 0;
 }
 
 int cice_evp_hip_plan_flags(int32_t *flags, int32_t n)

@@ -118,6 +118,54 @@ int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int lo
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,
                           bool strict, int cap, hipStream_t st);
 
+// Two subcycles per pass over a device-private rectangle layout (evp_march.hip, evp_host_march.cpp)
+#define EVP_MARCH_OWN 60       // output columns a 64-lane strip owns (two lanes of overlap on either side)
+#define EVP_MARCH_PAD 2        // halo columns / rows of the rectangle arrays
+struct EvpMarch {
+    EvpScalars p;
+    double deltaminEVP;
+    int ldx;                   // row stride of every rectangle array (doubles)
+    int nxr, nyr;              // cells of the rank's rectangle
+    int nstrips, nseg, seglen, nitems;
+    int wrapx;                 // the rectangle spans a cyclic E-W dimension: halo columns image owned columns
+    int last;                  // write strintx/y, taubx/y (last pass of a call)
+    unsigned flags;            // EVP_F_WATER_IS_OCN / EVP_F_TBU_ZERO
+    const uint8_t *mask;       // bit0 iceTmask, bit1 iceUmask (0 on halo elements that image nothing)
+    const double *u_in, *v_in;
+    double *u_out, *v_out;
+    const double *sig_in[12];
+    double *sig_out[12];
+    const double *dxT, *dyT, *HTE, *HTN, *uarear;
+    const double *strength, *vrelfac, *uocn, *vocn, *waterx, *watery, *forcex, *forcey, *umassdti, *fm, *TbU;
+    const double *uvel_init, *vvel_init;
+    double *strintx, *strinty, *taubx, *tauby;
+};
+struct EvpMarchGeo {
+    int nxr, nyr, ldx, rows;   // rectangle: owned cells, row stride, rows incl. halo
+    int nxb, nyb, plane;       // CICE block arrays (nx_block, ny_block, their product)
+    int nblocks;
+    int bsx, bsy, nbx, nby;    // interior size of a full block, blocks of the rank in x / y
+    int ilo;                   // first interior index of a block (nghost + 1)
+    int wrapx;
+    const int *blkid;          // [nby][nbx] local block index
+    const int2 *blk_org;       // [nblocks] rectangle coordinates of the first interior cell
+    const int4 *blk;           // [nblocks] ilo ihi jlo jhi
+};
+#define EVP_MARCH_TAB 40
+struct EvpMarchTab {
+    double *blk[EVP_MARCH_TAB];     // block-layout arrays
+    double *rect[EVP_MARCH_TAB];    // rectangle arrays
+    double *rect2[EVP_MARCH_TAB];   // gather: second copy (ping-pong partner) or NULL
+    int n;
+};
+void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st);
+void evp_launch_march_gather(const EvpMarchGeo &G, const EvpMarchTab &T, const uint8_t *mask_blk, uint8_t *mask_rect,
+                             hipStream_t st);
+void evp_launch_march_check(const EvpMarchGeo &G, const EvpMarchTab &T, const uint8_t *mask_blk, const uint8_t *mask_rect,
+                            int nuv, int nfringe, unsigned *bad, hipStream_t st);
+void evp_launch_march_scatter(const EvpMarchGeo &G, const EvpMarchTab &T, const uint8_t *mask_blk, int nuv, int nsig,
+                              hipStream_t st);
+
 // Mailbox halo between GPUs of one node (evp_halo_direct.hip)
 #define EVP_DIRECT_MAXPEER 32
 #define EVP_DIRECT_FLAG_STRIDE 16          // unsigneds: one 64-byte line per flag

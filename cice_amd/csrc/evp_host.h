@@ -221,6 +221,22 @@ struct State {
     struct Pinned { size_t bytes; void *dev; };    // dev: the range as the device sees it (NULL: not mapped)
     std::map<const void *, Pinned> pinned;         // host ranges registered by cice_evp_hip_pin_host
     // stresses that stay on the device between calls of cice_evp_hip_run (CICE_EVP_HIP_OPT_STRESS_RESIDENT)
+    // two subcycles per pass over a device-private rectangle layout (evp_march.hip, evp_host_march.cpp)
+    struct March {
+        int mode = -1;                 // -1 undecided, 0 off, 1 on
+        EvpMarchGeo G{};
+        std::vector<int> blkid_h;
+        std::vector<int2> org_h;
+        int nstrips = 0, nseg = 0, seglen = 0, nitems = 0;
+        size_t nel = 0;                // elements of a rectangle array
+        bool stat_done = false, stat_ok = false;
+        unsigned checked_seq = ~0u;    // upload_seq whose ghost-cell consistency has been verified
+        long passes = 0;               // passes run since init
+        int declined = 0;              // calls handed to the one-subcycle kernels (consistency check failed)
+        bool last_call = false;        // the last cice_evp_hip_subcycle went through this path
+        std::string why;
+    } march;
+    unsigned upload_seq = 0;                       // bumped whenever the caller hands new state / inputs to the device
     int fault_calls = 0;                           // test hook counter (fault_hook, evp_api.cpp)
     bool opt_sig_resident = false;
     bool sig_valid = false;                        // sig[cur] holds what the caller's arrays would hold
@@ -274,6 +290,10 @@ int launch_resident(int ndte, int cur0, bool dry);
 int launch_resident2(int ndte, int cur0, bool dry);
 int resident_check_error();
 int tune_after_upload();
+// evp_host_march.cpp
+bool march_wanted();
+int march_run(int ndte);
+void march_free();
 // evp_host_mailbox.cpp
 int direct_check_error();
 // evp_host_cgrid.cpp

@@ -183,6 +183,7 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     if (!(flagword & 1u)) S.flags |= EVP_F_WATER_IS_OCN;
     if (tbu_zero) S.flags |= EVP_F_TBU_ZERO;
     S.uploaded = true;
+    ++S.upload_seq;
     if (S.hmask_prev != S.hmask) { S.res2_order_stale = true; S.hmask_prev = S.hmask; }
     return tune_after_upload();
 }
@@ -198,6 +199,7 @@ int cice_evp_hip_set_strength(const double *strength)
 {
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
     if (!strength) return fail(-1, "null argument");
+    ++S.upload_seq;
     return h2d(S.in[F_STRENGTH], strength);
 }
 

@@ -42,7 +42,7 @@ EXPORTS = [
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
-    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
     "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
@@ -367,6 +367,13 @@ class EvpHip:
                     tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
                     halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10], resident_fallbacks=int(t[11]),
                     halo_send_cells=int(t[12]), halo_recv_cells=int(t[13]))
+
+    def march_info(self) -> dict:
+        """The two-subcycles-per-pass path (evp_march.hip): did it run, how is the domain cut."""
+        v = np.zeros(7, dtype=np.int32)
+        self.lib.cice_evp_hip_march_info(_ip(v), 7)
+        return dict(mode=int(v[0]), passes=int(v[1]), declined=int(v[2]), strips=int(v[3]), segments=int(v[4]),
+                    seglen=int(v[5]), last_call=bool(v[6]))
 
     def halo_mask(self, halomask):
         """ice_HaloMask for the in-loop velocity exchange; halomask None = full halo."""

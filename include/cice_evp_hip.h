@@ -308,6 +308,11 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
 /* Measurement aid (no state needed): bytes/s of a plain streaming kernel with the array shape of one B-grid subcycle
  * (30 fp64 arrays in, 16 out, `ncells` elements each, every element touched once) -- what HBM gives a kernel of this
  * shape on this device; the yardstick next to the 8 TB/s pin rate in bench.py's roofline block.                   */
+/* The two-subcycles-per-pass path for per-rank domains beyond the chip (evp_march.hip): out[0] mode (-1 undecided,
+ * 0 off, 1 on), [1] passes run since init, [2] calls it handed back to the one-subcycle kernels (the uploaded ghost
+ * values were not images of one global state), [3] strips, [4] segments, [5] rows per segment, [6] 1 = the last
+ * cice_evp_hip_subcycle ran through it.  CICE_EVP_HIP_MARCH=0/1 forces it off / on (default: from 1M cells).   */
+int cice_evp_hip_march_info(int32_t *out, int32_t n);
 int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second);
 /* Per-CU record of the last on-chip resident launch with 16 x 16 tiles (tools): n <= 2048*8 ints, per CU
  * (index = XCC<<8 | HW_ID[15:8]) {lock, launch stamp, ice-holding waves on SIMD 0..3, 0, 0}.        */

@@ -1,0 +1,197 @@
+"""GPU (-m gpu): the two-subcycles-per-pass kernel (cice_amd/csrc/evp_march.hip: one wave marches north over a strip
+of 64 columns, stress -> stepu -> stress -> stepu per row, neighbours by wave shuffles, a device-private rectangle
+layout) against the golden fixtures frozen from the reference's evp() and against the CPU oracle -- bit for bit in
+strict mode.  The path is the default from 1M cells per rank; here it is forced on small grids
+(CICE_EVP_HIP_MARCH=1, on-chip resident kernel off) with short segments so that every overlap rule is exercised:
+strips (60 owned columns of 64 lanes), segments, cyclic wrap images, several blocks per rank, padded blocks, closed
+east-west boundaries, odd subcycle counts, revised EVP / seabed stress / fractional capping (the non-LEAN variants)."""
+import numpy as np
+import pytest
+
+import oracle  # noqa: F401
+from cice_amd import decomp, evp, synth
+from common import GOLDEN_CASES, GoldenCase, assert_bitwise
+from test_gpu_parity import SIG, VEL, hip_from_case, run_hip, run_oracle, synth_case
+
+pytestmark = pytest.mark.gpu
+
+NON_TRIPOLE = [n for n in GOLDEN_CASES if not n.startswith("trip")]
+
+
+@pytest.fixture
+def march(monkeypatch):
+    monkeypatch.setenv("CICE_EVP_HIP_MARCH", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
+    return monkeypatch
+
+
+@pytest.mark.parametrize("seg", [0, 5])
+@pytest.mark.parametrize("name", NON_TRIPOLE)
+def test_march_golden_strict_bitwise(name, seg, march):
+    """Every non-tripole fixture of the reference (1 .. 6 blocks, padded blocks, cyclic and closed E-W, classic and
+    revised EVP, capping 0 / 0.5 / 1, Ktens, seabed stress), 1 / 2 / 10 / 120 subcycles, two calls."""
+    if seg:
+        march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    try:
+        for icall in range(1, c.ncalls + 1):
+            dyn, tm, um = c.inputs(icall)
+            for nsub in c.nsub_list:
+                out = core.run(dyn, tm, um, ndte=nsub)
+                assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub} (march)")
+                info = core.march_info()
+                assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0, info
+        assert core.march_info()["passes"] > 0
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("grid,case,bs,warm,seg", [("gx3", "full", None, False, 0), ("gx3", "caps", (25, 29), True, 7),
+                                                    ("gx3", "full", (50, 58), True, 16), ("gx1", "full", None, True, 0),
+                                                    ("gx1", "caps", (80, 96), False, 48)])
+def test_march_synthetic_vs_oracle_strict_bitwise(grid, case, bs, warm, seg, march):
+    """gx3 / gx1-sized synthetic grids (curvilinear metrics, land, cyclic E-W: the wrap images carry the state across
+    the seam) against the CPU oracle; 12 subcycles = 6 passes."""
+    if seg:
+        march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
+    dc, geo, fields, tm, um = synth_case(grid, case, seed=20260928, warm=warm, bs=bs)
+    scal = synth.evp_scalars(120)
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 12)
+    assert np.abs(want["uvel"]).max() > 1e-4
+    assert_bitwise(got, want, f"{grid}/{case} march vs oracle")
+
+
+def test_march_equals_streaming_kernel_at_odd_counts_and_across_calls(march):
+    """upload / subcycle(60) / subcycle(59) / subcycle(1) / download: odd counts start with one subcycle of the
+    one-subcycle kernel; the block-layout state is current after every call."""
+    c = GoldenCase("pop_cyc_3x2pad_caps")
+    core = hip_from_case(c, strict=True)
+    try:
+        dyn, tm, um = c.inputs(1)
+        core.upload(dyn, tm, um)
+        core.subcycle(60)
+        core.subcycle(59)
+        core.subcycle(1)
+        core.sync()
+        assert_bitwise(core.download(), c.expected(1, 120), "march: upload/subcycle x3/download")
+        assert core.march_info()["passes"] == 30 + 29
+    finally:
+        core.finalize()
+
+
+def test_march_fused_mode_equals_streaming_fused(march):
+    """Fused build: contraction is per source expression, so the marching kernel produces the bits of every other kernel
+    that inlines evp_cell.inc."""
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "full", seed=4, warm=True, bs=(50, 58))
+    a = run_hip(dc, geo, fields, tm, um, scal, strict=False, ndte=20)
+    march.setenv("CICE_EVP_HIP_MARCH", "0")
+    b = run_hip(dc, geo, fields, tm, um, scal, strict=False, ndte=20)
+    assert_bitwise(a, b, "fused: march vs streaming")
+
+
+@pytest.mark.parametrize("seed,grid,bs,holes", [(11, "gx3", None, 0.3), (12, "gx3", (50, 58), 0.6), (14, "gx3", None, 1.1)])
+def test_march_random_masks_vs_oracle(seed, grid, bs, holes, march):
+    """Random, mutually independent holes in iceTmask / iceUmask on the GLOBAL grid (ghost cells are images, as at the
+    reference's boundary): every mask-dependent branch of the march -- ice next to none in either direction, whole
+    strips without ice -- against the oracle."""
+    scal = synth.evp_scalars(120)
+    spec = synth.GRIDS[grid]
+    nx, ny = spec["nx"], spec["ny"]
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+    st = synth.make_state(g, case="full", seed=seed, warm=True)
+    rng = np.random.default_rng(seed)
+    tmg = (st["iceTmask"] * (rng.random((ny, nx)) > holes)).astype(np.int32)
+    umg = (st["iceUmask"] * (rng.random((ny, nx)) > holes)).astype(np.int32)
+    for k in evp.FIELDS[:12]:
+        st[k] = st[k] * tmg
+    for k in ("uvel", "vvel", "uvel_init", "vvel_init"):
+        st[k] = st[k] * umg
+    bsz = bs or (nx, ny)
+    dc = decomp.Decomp(nx, ny, bsz[0], bsz[1], "cyclic", "closed", 1)
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+    tm = dc.scatter(tmg, 0, fill=0)
+    um = dc.scatter(umg, 0, fill=0)
+    march.setenv("CICE_EVP_HIP_MARCH_SEG", "9")
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=10)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 10)
+    assert_bitwise(got, want, f"march, random masks seed {seed}")
+
+
+def test_march_declines_a_state_whose_ghost_cells_are_not_images(march):
+    """The rectangle holds every cell once; the reference keeps per-block ghost storage and computes the T-cells of the
+    north / east fringe from it.  A caller whose ghost values differ from the cells they image (here: ice punched out
+    of the east ghost column of the mask, and a ghost stress changed) gets the one-subcycle kernels -- and the
+    reference's answer for exactly that input."""
+    scal = synth.evp_scalars(120)
+    dc, geo, fields, tm, um = synth_case("gx3", "full", seed=6, warm=True, bs=(50, 58))
+    tm = tm.copy()
+    fields = {k: v.copy() for k, v in fields.items()}
+    tm[:, :, -1] = 0                      # east ghost column of every block: no longer the image of column ilo
+    fields["stressp_1"][:, 5:20, -1] *= 1.5
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        got = core.run(fields, tm, um, ndte=8)
+        info = core.march_info()
+        assert info["mode"] == 1 and info["declined"] == 1 and not info["last_call"], info
+    finally:
+        core.finalize()
+    want = run_oracle(dc, geo, fields, tm, um, scal, 8)
+    assert_bitwise(got, want, "declined call: one-subcycle kernels on the caller's own ghost values")
+
+
+def test_march_is_the_default_on_a_large_grid_and_invariant_under_the_cut():
+    """1440 x 720 (1.04M cells: above the threshold, nothing forced): the marching kernel runs by default; cutting the
+    domain into other strips' segments or into CICE blocks changes nothing (size-independent property; the oracle
+    comparison at 3600 x 2400 is bench.py's committed checksum)."""
+    import os
+    scal = synth.evp_scalars(480)
+    nx, ny = 1440, 720
+    g = synth.derive_geometry(synth.make_grid(nx, ny, 2.8e4, ns="closed"))
+    st = synth.make_state(g, case="full", seed=3, warm=True)
+    ref = None
+    for bs, seg in (((nx, ny), None), ((nx, ny), "37"), ((360, 240), None)):
+        if seg:
+            os.environ["CICE_EVP_HIP_MARCH_SEG"] = seg
+        try:
+            dc = decomp.Decomp(nx, ny, bs[0], bs[1], "cyclic", "closed", 1)
+            geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+                   for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+            fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+            tm = dc.scatter(st["iceTmask"], 0, fill=0)
+            um = dc.scatter(st["iceUmask"], 0, fill=0)
+            d, keep = evp.make_dims(dc, 0)
+            core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                              geo["uarear"], geo["tarea"], keepalive=keep)
+            try:
+                out = core.run(fields, tm, um, ndte=6)
+                info = core.march_info()
+                assert info["mode"] == 1 and info["last_call"] and info["passes"] == 3, info
+            finally:
+                core.finalize()
+        finally:
+            os.environ.pop("CICE_EVP_HIP_MARCH_SEG", None)
+        glob = {k: dc.gather({0: out[k]}) for k in VEL + SIG + ["strintxU", "taubxU"]}
+        if ref is None:
+            ref = glob
+            assert np.abs(glob["uvel"]).max() > 1e-5
+        else:
+            assert_bitwise(glob, ref, f"1440x720 cut {bs} seg {seg}")
+    # and the one-subcycle kernel gives the same bits
+    os.environ["CICE_EVP_HIP_MARCH"] = "0"
+    try:
+        dc = decomp.Decomp(nx, ny, nx, ny, "cyclic", "closed", 1)
+        geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+               for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+        fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+        out = run_hip(dc, geo, fields, dc.scatter(st["iceTmask"], 0, fill=0), dc.scatter(st["iceUmask"], 0, fill=0),
+                      scal, strict=True, ndte=6)
+    finally:
+        os.environ.pop("CICE_EVP_HIP_MARCH", None)
+    assert_bitwise({k: dc.gather({0: out[k]}) for k in ref}, ref, "1440x720: march vs one-subcycle kernel")
