@@ -118,30 +118,37 @@ int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int lo
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,
                           bool strict, int cap, hipStream_t st);
 
-// Two subcycles per pass over a device-private rectangle layout (evp_march.hip, evp_host_march.cpp)
-#define EVP_MARCH_OWN 60       // output columns a 64-lane strip owns (two lanes of overlap on either side)
-#define EVP_MARCH_PAD 2        // halo columns / rows of the rectangle arrays
+// Two subcycles per pass over a device-private strip-major layout (evp_march.hip, evp_host_march.cpp)
+#define EVP_MARCH_OWN 60       // most columns a 64-lane strip can own (two lanes of overlap on either side)
+#define EVP_MARCH_PAD 2        // halo rows below / columns of the row-major byte mask
+#define EVP_MARCH_S_NF 14      // fields per block: state (u v sig x 12), constants, optional operands, diagnostics
+#define EVP_MARCH_C_NF 13
+#define EVP_MARCH_O_NF 5
+#define EVP_MARCH_D_NF 4
+#define EVP_MARCH_NODUP 0xffffffffu
 struct EvpMarch {
     EvpScalars p;
     double deltaminEVP;
-    int ldx;                   // row stride of every rectangle array (doubles)
     int nxr, nyr;              // cells of the rank's rectangle
+    int ldx;                   // row stride of the row-major byte mask
+    int own;                   // columns a strip owns (<= EVP_MARCH_OWN)
     int nstrips, nseg, seglen, nitems;
-    int wrapx;                 // the rectangle spans a cyclic E-W dimension: halo columns image owned columns
+    int wrapx;                 // the rectangle spans a cyclic E-W dimension: strips wrap around
     int last;                  // write strintx/y, taubx/y (last pass of a call)
+    int order;                 // work item order: bit0 one contiguous run per XCD, bit1 segment index fastest
     unsigned flags;            // EVP_F_WATER_IS_OCN / EVP_F_TBU_ZERO
-    const uint8_t *mask;       // bit0 iceTmask, bit1 iceUmask (0 on halo elements that image nothing)
-    const double *u_in, *v_in;
-    double *u_out, *v_out;
-    const double *sig_in[12];
-    double *sig_out[12];
-    const double *dxT, *dyT, *HTE, *HTN, *uarear;
-    const double *strength, *vrelfac, *uocn, *vocn, *waterx, *watery, *forcex, *forcey, *umassdti, *fm, *TbU;
-    const double *uvel_init, *vvel_init;
-    double *strintx, *strinty, *taubx, *tauby;
+    const uint8_t *mask;       // row-major [rows][ldx]: bit0 iceTmask, bit1 iceUmask (0 where there is no cell)
+    // strip-major buffers: [row][strip][field][64 lanes]
+    const double *st_in;       // u v stressp_1..4 stressm_1..4 stress12_1..4
+    double *st_out;
+    const double *cst;         // dxT dyT strength HTE HTN vrelfac uocn vocn forcex forcey umassdti fm uarear
+    const double *opt;         // waterx watery TbU uvel_init vvel_init, or NULL when none of them is read
+    double *diag;              // strintx strinty taubx tauby
+    const unsigned *dup;       // [nstrips][64]: where, from the start of a state row, the duplicate of the lane's column lives
 };
 struct EvpMarchGeo {
-    int nxr, nyr, ldx, rows;   // rectangle: owned cells, row stride, rows incl. halo
+    int nxr, nyr, ldx, rows;   // rectangle: owned cells; mask row stride; rows of every buffer (nyr + halo + spare)
+    int own, nstrips;          // strips of `own` owned columns
     int nxb, nyb, plane;       // CICE block arrays (nx_block, ny_block, their product)
     int nblocks;
     int bsx, bsy, nbx, nby;    // interior size of a full block, blocks of the rank in x / y
@@ -154,8 +161,10 @@ struct EvpMarchGeo {
 #define EVP_MARCH_TAB 40
 struct EvpMarchTab {
     double *blk[EVP_MARCH_TAB];     // block-layout arrays
-    double *rect[EVP_MARCH_TAB];    // rectangle arrays
-    double *rect2[EVP_MARCH_TAB];   // gather: second copy (ping-pong partner) or NULL
+    double *pk[EVP_MARCH_TAB];      // strip-major buffer the field lives in
+    double *pk2[EVP_MARCH_TAB];     // gather: second copy (ping-pong partner) or NULL
+    int nf[EVP_MARCH_TAB];          // fields per block of that buffer
+    int slot[EVP_MARCH_TAB];        // the field's slot
     int n;
 };
 void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st);

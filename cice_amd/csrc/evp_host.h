@@ -228,7 +228,8 @@ struct State {
         std::vector<int> blkid_h;
         std::vector<int2> org_h;
         int nstrips = 0, nseg = 0, seglen = 0, nitems = 0;
-        size_t nel = 0;                // elements of a rectangle array
+        size_t nblk = 0;               // (row, strip) blocks per buffer
+        std::vector<unsigned> dup_h;   // [nstrips][64] duplicate positions (EvpMarch::dup)
         bool stat_done = false, stat_ok = false;
         unsigned checked_seq = ~0u;    // upload_seq whose ghost-cell consistency has been verified
         long passes = 0;               // passes run since init

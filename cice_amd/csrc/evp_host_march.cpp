@@ -2,12 +2,13 @@
 // Host side of the two-subcycles-per-pass kernel (evp_march.hip): the device-private rectangle layout, the
 // conversions between it and the CICE block layout, and the loop.
 //
-// Rectangle layout: all blocks of the rank assembled into ONE array per field -- (nxr + 2 halo columns each side,
-// rounded up to the strips' reach) x (nyr + 2 halo rows each side), i fastest.  Every cell of the rank exists once:
-// the reference's redundant copies (ghost cells, the T-cells of the north / east fringe every block computes for
-// itself, ice_dyn_shared.F90:740-749) are images of it.  Halo columns image owned columns when the rectangle spans a
-// cyclic E-W dimension; on closed sides their first layer holds the caller's ghost values (what stress reads there,
-// constant during the loop), everything else is 0 with mask 0.
+// Strip-major layout: all blocks of the rank are assembled into ONE rectangle of nxr x nyr cells, cut into strips of
+// `own` <= 60 columns; per (row, strip) one contiguous block [field][64 lanes] -- lanes 2 .. own+1 are the strip's own
+// columns, the others duplicate its neighbours' (or, beyond a closed side, hold the caller's ghost values / zeros).
+// Buffers: state (u, v, 12 stresses; two copies), constants of a call (13 fields), optional operands (5), diagnostics
+// (4); rows -2 .. nyr+4 (two halo rows below, two above, two spare rows the prefetch may touch, one dump row).  Every
+// cell of the rank exists once: the reference's redundant copies (ghost cells, the T-cells of the north / east fringe
+// every block computes for itself, ice_dyn_shared.F90:740-749) are images of it.  The byte mask stays row-major.
 //
 // A call of cice_evp_hip_subcycle(ndte) through this path:
 //   [ndte odd: one subcycle with the one-subcycle kernel]  gather -> consistency check (first call after an upload)
@@ -23,15 +24,18 @@ namespace evp_host {
 namespace {
 
 struct MarchBuf {
-    double *u[2] = {}, *v[2] = {}, *sig[2][12] = {};
-    double *stat[5] = {};        // dxT dyT HTE HTN uarear
-    double *in[13] = {};         // strength vrelfac uocn vocn forcex forcey umassdti fm | waterx watery TbU uvel_init vvel_init
-    double *diag[4] = {};
-    uint8_t *mask = nullptr;
-    unsigned *bad = nullptr;
+    double *st[2] = {};          // state blocks: u v sig x 12
+    double *cst = nullptr;       // dxT dyT strength HTE HTN vrelfac uocn vocn forcex forcey umassdti fm uarear
+    double *opt = nullptr;       // waterx watery TbU uvel_init vvel_init
+    double *diag = nullptr;      // strintx strinty taubx tauby
+    uint8_t *mask = nullptr;     // row-major
+    unsigned *bad = nullptr, *dup = nullptr;
     int *blkid = nullptr;
     int2 *org = nullptr;
 };
+// slots of the constants block (evp_march.hip: C_*), of the optional block (O_*)
+enum { C_DXT = 0, C_DYT, C_STRENGTH, C_HTE, C_HTN, C_VRELFAC, C_UOCN, C_VOCN, C_FORCEX, C_FORCEY, C_UMASSDTI, C_FM, C_UAREAR };
+enum { O_WATERX = 0, O_WATERY, O_TBU, O_UINIT, O_VINIT };
 MarchBuf B;
 
 template <class T> void F(T *&p)
@@ -44,14 +48,8 @@ template <class T> void F(T *&p)
 
 void march_free()
 {
-    for (int k = 0; k < 2; ++k) {
-        F(B.u[k]); F(B.v[k]);
-        for (auto &p : B.sig[k]) F(p);
-    }
-    for (auto &p : B.stat) F(p);
-    for (auto &p : B.in) F(p);
-    for (auto &p : B.diag) F(p);
-    F(B.mask); F(B.bad); F(B.blkid); F(B.org);
+    F(B.st[0]); F(B.st[1]); F(B.cst); F(B.opt); F(B.diag);
+    F(B.mask); F(B.bad); F(B.dup); F(B.blkid); F(B.org);
     S.march = State::March{};
 }
 
@@ -97,19 +95,48 @@ static bool march_geometry(std::string &why)
     if (nxr < 4 || nyr < 1) { why = "rectangle too small"; return false; }
     EvpMarchGeo &G = M.G;
     G.nxr = nxr; G.nyr = nyr;
-    M.nstrips = (nxr + EVP_MARCH_OWN - 1) / EVP_MARCH_OWN;
-    G.ldx = ((M.nstrips * EVP_MARCH_OWN + 2 * EVP_MARCH_PAD + 7) / 8) * 8;
-    G.rows = nyr + 2 * EVP_MARCH_PAD;
     G.nxb = d.nx_block; G.nyb = d.ny_block; G.plane = (int)S.plane; G.nblocks = d.nblocks;
     G.bsx = bsx; G.bsy = bsy; G.nbx = nbx; G.nby = nby;
     G.ilo = d.nghost + 1;
     G.wrapx = wrapx ? 1 : 0;
-    M.nel = (size_t)G.ldx * G.rows;
-    if (M.nel * 8 >= (1ull << 32)) { why = "rectangle beyond 32-bit byte offsets"; return false; }
-    // segments: about one round of resident waves (256 CUs x 12) so that every wave marches one long segment
+    // strips of `own` columns; every owned column may have ONE duplicate (in a neighbouring strip's overlap lanes, across
+    // the cyclic seam for the edge strips) -- the widest `own` for which that holds
+    const int own_max = env("CICE_EVP_HIP_MARCH_OWN") ? std::min(EVP_MARCH_OWN, std::max(4, std::atoi(env("CICE_EVP_HIP_MARCH_OWN")))) : EVP_MARCH_OWN;
+    bool found = false;
+    for (int own = own_max; own >= 4 && !found; --own) {
+        const int ns = (nxr + own - 1) / own;
+        // where does column c live?  owner (strip c / own, lane 2 + c % own); duplicates: every other (s, l) whose
+        // column x = s*own - 2 + l is c (modulo nxr when cyclic)
+        std::vector<unsigned> dup((size_t)ns * 64, EVP_MARCH_NODUP);
+        bool ok = true;
+        for (int sb = 0; sb < ns && ok; ++sb)
+            for (int l = 0; l < 64 && ok; ++l) {
+                int x = sb * own - 2 + l;
+                const int cnt = std::min(own, nxr - sb * own);   // columns strip sb owns: lanes 2 .. cnt+1
+                if (l >= 2 && l < 2 + cnt) continue;             // an owner
+                if (!(l < 2 || l < 4 + cnt)) continue;           // beyond the two overlap lanes: nothing reads it
+                if (wrapx) { if (x < 0) x += nxr; else if (x >= nxr) x -= nxr; }
+                if (x < 0 || x >= nxr) continue;                 // beyond a closed side: nobody writes it
+                const int so = x / own, lo = 2 + x % own;        // its owner
+                unsigned &slot = dup[(size_t)so * 64 + lo];
+                if (slot != EVP_MARCH_NODUP) { ok = false; break; }           // a second duplicate
+                slot = (unsigned)(((size_t)sb * EVP_MARCH_S_NF * 64 + l) * 8);
+            }
+        if (!ok) continue;
+        found = true;
+        G.own = own; G.nstrips = ns;
+        M.dup_h = dup;
+    }
+    if (!found) { why = "no strip width gives every column a single duplicate"; return false; }
+    M.nstrips = G.nstrips;
+    G.ldx = ((G.nstrips * G.own + 64 + 2 * EVP_MARCH_PAD + 7) / 8) * 8;
+    G.rows = nyr + EVP_MARCH_PAD + 5;          // y = -2 .. nyr+4: halo, two rows the prefetch may touch, the dump row
+    M.nblk = (size_t)G.rows * G.nstrips;
+    if (M.nblk * EVP_MARCH_S_NF * 512 >= (1ull << 32)) { why = "state buffer beyond 32-bit byte offsets"; return false; }
+    // segments: about one round of resident waves (256 CUs x 8) so that every wave marches one long segment
     int seglen = env("CICE_EVP_HIP_MARCH_SEG") ? std::atoi(env("CICE_EVP_HIP_MARCH_SEG")) : 0;
     if (seglen <= 0) {
-        const int want_seg = std::max(1, 3072 / M.nstrips);
+        const int want_seg = std::max(1, 2048 / M.nstrips);
         seglen = std::max(16, (nyr + want_seg - 1) / want_seg);
     }
     M.seglen = std::min(seglen, nyr);
@@ -121,23 +148,18 @@ static bool march_geometry(std::string &why)
 static int march_alloc()
 {
     State::March &M = S.march;
-    auto A = [&](double *&p) -> int {
+    auto A = [&](double *&p, int nf) -> int {
         if (p) return 0;
-        HIPC(hipMalloc((void **)&p, M.nel * sizeof(double)));
-        HIPC(hipMemsetAsync(p, 0, M.nel * sizeof(double), S.stream));
+        const size_t bytes = M.nblk * (size_t)nf * 512;
+        HIPC(hipMalloc((void **)&p, bytes));
+        HIPC(hipMemsetAsync(p, 0, bytes, S.stream));
         return 0;
     };
-    for (int k = 0; k < 2; ++k) {
-        if (A(B.u[k]) || A(B.v[k])) return -1;
-        for (auto &p : B.sig[k])
-            if (A(p)) return -1;
-    }
-    for (auto &p : B.stat) if (A(p)) return -1;
-    for (auto &p : B.in) if (A(p)) return -1;
-    for (auto &p : B.diag) if (A(p)) return -1;
+    if (A(B.st[0], EVP_MARCH_S_NF) || A(B.st[1], EVP_MARCH_S_NF) || A(B.cst, EVP_MARCH_C_NF) || A(B.opt, EVP_MARCH_O_NF) ||
+        A(B.diag, EVP_MARCH_D_NF)) return -1;
     if (!B.mask) {
-        HIPC(hipMalloc((void **)&B.mask, M.nel));
-        HIPC(hipMemsetAsync(B.mask, 0, M.nel, S.stream));
+        HIPC(hipMalloc((void **)&B.mask, (size_t)M.G.rows * M.G.ldx));
+        HIPC(hipMemsetAsync(B.mask, 0, (size_t)M.G.rows * M.G.ldx, S.stream));
     }
     if (!B.bad) HIPC(hipMalloc((void **)&B.bad, sizeof(unsigned)));
     if (!B.blkid) {
@@ -145,6 +167,8 @@ static int march_alloc()
         HIPC(hipMemcpy(B.blkid, M.blkid_h.data(), M.blkid_h.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPC(hipMalloc((void **)&B.org, M.org_h.size() * sizeof(int2)));
         HIPC(hipMemcpy(B.org, M.org_h.data(), M.org_h.size() * sizeof(int2), hipMemcpyHostToDevice));
+        HIPC(hipMalloc((void **)&B.dup, M.dup_h.size() * sizeof(unsigned)));
+        HIPC(hipMemcpy(B.dup, M.dup_h.data(), M.dup_h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
     M.G.blkid = B.blkid;
     M.G.blk_org = B.org;
@@ -159,20 +183,29 @@ static int read_bad(unsigned &bad)
     return 0;
 }
 
-// static fields into the rectangle, once; are their ghost values images of one global field?
+namespace {
+struct TabBuilder {
+    EvpMarchTab T{};
+    void add(double *blk, double *pk, double *pk2, int nf, int slot)
+    {
+        T.blk[T.n] = blk; T.pk[T.n] = pk; T.pk2[T.n] = pk2; T.nf[T.n] = nf; T.slot[T.n] = slot; ++T.n;
+    }
+};
+}  // namespace
+
+// static fields into the constants block, once; are their ghost values images of one global field?
 static int march_statics()
 {
     State::March &M = S.march;
-    EvpMarchTab T{};
+    TabBuilder G;
     double *src[5] = {S.stat[0], S.stat[1], S.hte, S.htn, S.stat[9]};
-    for (int k = 0; k < 5; ++k) { T.blk[k] = src[k]; T.rect[k] = B.stat[k]; T.rect2[k] = nullptr; }
-    T.n = 5;
-    evp_launch_march_gather(M.G, T, nullptr, nullptr, S.stream);
-    EvpMarchTab C{};
-    C.n = 4;               // dxT dyT (fringe) | HTE HTN (fringe + column ilo-1 / row jlo-1)
-    for (int k = 0; k < 4; ++k) { C.blk[k] = src[k]; C.rect[k] = B.stat[k]; }
+    const int slot[5] = {C_DXT, C_DYT, C_HTE, C_HTN, C_UAREAR};
+    for (int k = 0; k < 5; ++k) G.add(src[k], B.cst, nullptr, EVP_MARCH_C_NF, slot[k]);
+    evp_launch_march_gather(M.G, G.T, nullptr, nullptr, S.stream);
+    TabBuilder C;              // dxT dyT (fringe) | HTE HTN (fringe + column ilo-1 / row jlo-1)
+    for (int k = 0; k < 4; ++k) C.add(src[k], B.cst, nullptr, EVP_MARCH_C_NF, slot[k]);
     HIPC(hipMemsetAsync(B.bad, 0, sizeof(unsigned), S.stream));
-    evp_launch_march_check(M.G, C, nullptr, nullptr, 0, 2, B.bad, S.stream);
+    evp_launch_march_check(M.G, C.T, nullptr, nullptr, 0, 2, B.bad, S.stream);
     unsigned bad = 0;
     if (read_bad(bad)) return -1;
     M.stat_ok = bad == 0;
@@ -207,19 +240,19 @@ static void march_args(EvpMarch &A, int cur, int last)
     const cice_evp_hip_params &q = S.prm;
     A.p = {q.arlx1i, q.denom1, q.brlx, q.revp, q.e_factor, q.epp2i, q.capping, q.Ktens, q.u0, q.cosw, q.sinw, q.rhow};
     A.deltaminEVP = q.deltaminEVP;
-    A.ldx = M.G.ldx; A.nxr = M.G.nxr; A.nyr = M.G.nyr;
+    A.nxr = M.G.nxr; A.nyr = M.G.nyr; A.ldx = M.G.ldx; A.own = M.G.own;
     A.nstrips = M.nstrips; A.nseg = M.nseg; A.seglen = M.seglen; A.nitems = M.nitems;
     A.wrapx = M.G.wrapx;
     A.last = last;
+    A.order = env("CICE_EVP_HIP_MARCH_ORDER") ? std::atoi(env("CICE_EVP_HIP_MARCH_ORDER")) : 1;
     A.flags = S.flags & S.flags_allowed;
     A.mask = B.mask;
-    A.u_in = B.u[cur]; A.v_in = B.v[cur]; A.u_out = B.u[cur ^ 1]; A.v_out = B.v[cur ^ 1];
-    for (int k = 0; k < 12; ++k) { A.sig_in[k] = B.sig[cur][k]; A.sig_out[k] = B.sig[cur ^ 1][k]; }
-    A.dxT = B.stat[0]; A.dyT = B.stat[1]; A.HTE = B.stat[2]; A.HTN = B.stat[3]; A.uarear = B.stat[4];
-    A.strength = B.in[0]; A.vrelfac = B.in[1]; A.uocn = B.in[2]; A.vocn = B.in[3]; A.forcex = B.in[4]; A.forcey = B.in[5];
-    A.umassdti = B.in[6]; A.fm = B.in[7]; A.waterx = B.in[8]; A.watery = B.in[9]; A.TbU = B.in[10];
-    A.uvel_init = B.in[11]; A.vvel_init = B.in[12];
-    A.strintx = B.diag[0]; A.strinty = B.diag[1]; A.taubx = B.diag[2]; A.tauby = B.diag[3];
+    A.st_in = B.st[cur]; A.st_out = B.st[cur ^ 1];
+    A.cst = B.cst;
+    const bool need_opt = !(A.flags & EVP_F_WATER_IS_OCN) || !(A.flags & EVP_F_TBU_ZERO) || q.revp != 0.0;
+    A.opt = need_opt ? B.opt : nullptr;
+    A.diag = B.diag;
+    A.dup = B.dup;
 }
 
 // All ndte subcycles of a call.  Returns 0 when done (S.cur advanced like the one-subcycle loop would), < 0 on error.
@@ -249,31 +282,33 @@ int march_run(int ndte)
     const unsigned fl = S.flags & S.flags_allowed;
     // ---- gather the state and the per-call inputs ----
     {
-        EvpMarchTab T{};
-        auto add = [&](double *blk, double *rect, double *rect2) { T.blk[T.n] = blk; T.rect[T.n] = rect; T.rect2[T.n] = rect2; ++T.n; };
-        add(S.u[cur], B.u[0], B.u[1]);
-        add(S.v[cur], B.v[0], B.v[1]);
-        for (int k = 0; k < 12; ++k) add(S.sig[cur][k], B.sig[0][k], B.sig[1][k]);
-        add(S.in[F_STRENGTH], B.in[0], nullptr);
-        add(S.vrelfac, B.in[1], nullptr);
-        add(S.in[F_UOCN], B.in[2], nullptr); add(S.in[F_VOCN], B.in[3], nullptr);
-        add(S.in[F_FORCEX], B.in[4], nullptr); add(S.in[F_FORCEY], B.in[5], nullptr);
-        add(S.in[F_UMASSDTI], B.in[6], nullptr); add(S.in[F_FM], B.in[7], nullptr);
-        if (!(fl & EVP_F_WATER_IS_OCN)) { add(S.in[F_WATERX], B.in[8], nullptr); add(S.in[F_WATERY], B.in[9], nullptr); }
-        if (!(fl & EVP_F_TBU_ZERO)) add(S.in[F_TBU], B.in[10], nullptr);
-        if (S.prm.revp != 0.0) { add(S.in[F_UVEL_INIT], B.in[11], nullptr); add(S.in[F_VVEL_INIT], B.in[12], nullptr); }
-        evp_launch_march_gather(M.G, T, S.mask, B.mask, S.stream);
+        TabBuilder G;
+        G.add(S.u[cur], B.st[0], B.st[1], EVP_MARCH_S_NF, 0);
+        G.add(S.v[cur], B.st[0], B.st[1], EVP_MARCH_S_NF, 1);
+        for (int k = 0; k < 12; ++k) G.add(S.sig[cur][k], B.st[0], B.st[1], EVP_MARCH_S_NF, 2 + k);
+        G.add(S.in[F_STRENGTH], B.cst, nullptr, EVP_MARCH_C_NF, C_STRENGTH);
+        G.add(S.vrelfac, B.cst, nullptr, EVP_MARCH_C_NF, C_VRELFAC);
+        G.add(S.in[F_UOCN], B.cst, nullptr, EVP_MARCH_C_NF, C_UOCN); G.add(S.in[F_VOCN], B.cst, nullptr, EVP_MARCH_C_NF, C_VOCN);
+        G.add(S.in[F_FORCEX], B.cst, nullptr, EVP_MARCH_C_NF, C_FORCEX); G.add(S.in[F_FORCEY], B.cst, nullptr, EVP_MARCH_C_NF, C_FORCEY);
+        G.add(S.in[F_UMASSDTI], B.cst, nullptr, EVP_MARCH_C_NF, C_UMASSDTI); G.add(S.in[F_FM], B.cst, nullptr, EVP_MARCH_C_NF, C_FM);
+        if (!(fl & EVP_F_WATER_IS_OCN)) {
+            G.add(S.in[F_WATERX], B.opt, nullptr, EVP_MARCH_O_NF, O_WATERX); G.add(S.in[F_WATERY], B.opt, nullptr, EVP_MARCH_O_NF, O_WATERY);
+        }
+        if (!(fl & EVP_F_TBU_ZERO)) G.add(S.in[F_TBU], B.opt, nullptr, EVP_MARCH_O_NF, O_TBU);
+        if (S.prm.revp != 0.0) {
+            G.add(S.in[F_UVEL_INIT], B.opt, nullptr, EVP_MARCH_O_NF, O_UINIT); G.add(S.in[F_VVEL_INIT], B.opt, nullptr, EVP_MARCH_O_NF, O_VINIT);
+        }
+        evp_launch_march_gather(M.G, G.T, S.mask, B.mask, S.stream);
     }
     if (M.checked_seq != S.upload_seq) {
         // first call on this uploaded state: are the caller's ghost values images of one global state?
-        EvpMarchTab C{};
-        C.blk[0] = S.u[cur]; C.rect[0] = B.u[0];
-        C.blk[1] = S.v[cur]; C.rect[1] = B.v[0];
-        for (int k = 0; k < 12; ++k) { C.blk[2 + k] = S.sig[cur][k]; C.rect[2 + k] = B.sig[0][k]; }
-        C.blk[14] = S.in[F_STRENGTH]; C.rect[14] = B.in[0];
-        C.n = 15;
+        TabBuilder C;
+        C.add(S.u[cur], B.st[0], nullptr, EVP_MARCH_S_NF, 0);
+        C.add(S.v[cur], B.st[0], nullptr, EVP_MARCH_S_NF, 1);
+        for (int k = 0; k < 12; ++k) C.add(S.sig[cur][k], B.st[0], nullptr, EVP_MARCH_S_NF, 2 + k);
+        C.add(S.in[F_STRENGTH], B.cst, nullptr, EVP_MARCH_C_NF, C_STRENGTH);
         HIPC(hipMemsetAsync(B.bad, 0, sizeof(unsigned), S.stream));
-        evp_launch_march_check(M.G, C, S.mask, B.mask, 2, 13, B.bad, S.stream);
+        evp_launch_march_check(M.G, C.T, S.mask, B.mask, 2, 13, B.bad, S.stream);
         unsigned bad = 0;
         if (read_bad(bad)) return -1;
         if (bad) return fallback("ghost cells of the uploaded state are not images of one global state");
@@ -292,13 +327,12 @@ int march_run(int ndte)
     M.passes += npass;
     // ---- back to the block layout ----
     {
-        EvpMarchTab T{};
-        auto add = [&](double *blk, double *rect) { T.blk[T.n] = blk; T.rect[T.n] = rect; ++T.n; };
-        add(S.u[cur], B.u[rc]); add(S.v[cur], B.v[rc]);
-        for (int k = 0; k < 12; ++k) add(S.sig[cur][k], B.sig[rc][k]);
-        add(S.in[F_STRINTX], B.diag[0]); add(S.in[F_STRINTY], B.diag[1]);
-        add(S.in[F_TAUBX], B.diag[2]); add(S.in[F_TAUBY], B.diag[3]);
-        evp_launch_march_scatter(M.G, T, S.mask, 2, 12, S.stream);
+        TabBuilder T;
+        T.add(S.u[cur], B.st[rc], nullptr, EVP_MARCH_S_NF, 0); T.add(S.v[cur], B.st[rc], nullptr, EVP_MARCH_S_NF, 1);
+        for (int k = 0; k < 12; ++k) T.add(S.sig[cur][k], B.st[rc], nullptr, EVP_MARCH_S_NF, 2 + k);
+        T.add(S.in[F_STRINTX], B.diag, nullptr, EVP_MARCH_D_NF, 0); T.add(S.in[F_STRINTY], B.diag, nullptr, EVP_MARCH_D_NF, 1);
+        T.add(S.in[F_TAUBX], B.diag, nullptr, EVP_MARCH_D_NF, 2); T.add(S.in[F_TAUBY], B.diag, nullptr, EVP_MARCH_D_NF, 3);
+        evp_launch_march_scatter(M.G, T.T, S.mask, 2, 12, S.stream);
     }
     HIPC(hipGetLastError());
     S.cur = cur;            // an even number of subcycles later: same ping-pong buffer of the block layout

@@ -5,11 +5,7 @@
 // Why: the one-subcycle streaming kernel (evp_kernels.hip) already moves no byte twice and runs at the box's mixed
 // read/write streaming rate; per subcycle it must read 27 and write 14 doubles per cell.  The only way below that is
 // fewer sweeps: this kernel advances the state by TWO subcycles of the reference's loop
-// (ice_dyn_evp.F90:859-913: stress :867, stepu :889, halo :908) while touching every array once.
-//
-// Data: a device-private "rectangle" layout (evp_host_march.cpp): all blocks of the rank assembled into one array
-// per field, row stride ldx, two halo columns / rows on every side (cyclic wrap images, neighbours' cells, or zeros).
-// The CICE-layout arrays are gathered into it before the loop and scattered back after it.
+// (ice_dyn_evp.F90:859-913: stress :867, stepu :889, halo :908) while touching every field once.
 //
 // Work item = ONE WAVE marching north over a strip of 64 columns x seglen rows; lane = column.  No workgroup barrier,
 // no LDS-shared data: a workgroup is just four independent waves.
@@ -17,13 +13,21 @@
 //                         U1  stepu  of subcycle k+1 on U-row r-1    (stress divergence from T-rows r-1, r)
 //                         S2  stress of subcycle k+2 on T-row r-1    (velocities U(k+1) of rows r-2, r-1)
 //                         U2  stepu  of subcycle k+2 on U-row r-2    -> stored
-//   * neighbours in i (uvel(i-1,j), HTE(i-1,j), str(i+1,j,.)) come from the adjacent lane by wavefront shuffles,
+//   * neighbours in i (uvel(i-1,j), HTE(i-1,j), str(i+1,j,.)) come from the adjacent lane by wavefront shuffles (DPP),
 //     neighbours in j from values the wave carries from its previous row in registers;
 //   * the 12 stresses of subcycle k+1 wait for S2 in a per-wave LDS stash (2 rows x 12 x 64 doubles = 12 KB);
-//   * validity shrinks by one lane per stage: S1 lanes 1..63, U1 1..62, S2 2..62, U2 2..61 -- a strip owns 60
-//     output columns, neighbouring strips / segments recompute the overlap (1.07 x 1.06 redundant work at
-//     3600 x 2400 with 48-row segments), bit-identical by construction: same operands, same operation order
-//     (evp_cell.inc), nothing depends on scheduling.
+//   * validity shrinks by one lane per stage: S1 lanes 1..63, U1 1..62, S2 2..62, U2 2..61 -- a strip owns <= 60
+//     columns, neighbouring strips / segments recompute the overlap (1.07 x 1.06 redundant work at 3600 x 2400 with
+//     48-row segments), bit-identical by construction: same operands, same operation order (evp_cell.inc), nothing
+//     depends on scheduling.
+//
+// Data: a device-private, STRIP-MAJOR layout (evp_host_march.cpp).  Per (row, strip) one contiguous block
+// [field][64 lanes]: the state (u, v, 12 stresses: 7 KB, two copies for ping-pong), the constants of a call (dxT, dyT,
+// strength, HTE, HTN and eight momentum operands: 6.5 KB), optional operands, diagnostics.  A wave's row is then a few
+// long contiguous runs instead of 41 x 512 B scattered over 41 arrays -- measured with a copy of this access pattern
+// (tools/march_stream.hip): 5.6 TB/s packed against 2.6-4.8 TB/s for separate arrays.  The four overlap lanes of a
+// block duplicate columns its neighbours own; an owner stores its two edge columns into the neighbour's block too.
+// With a cyclic E-W dimension inside the rank the strips wrap around (lane -> column modulo nxr): no halo columns.
 // Algorithmic HBM bytes per cell and PASS: 27 reads + 14 writes = 328 B, i.e. 164 B per cell-subcycle against the
 // 368 B yardstick of SURVEY 8(d).
 // =====================================================================
@@ -36,6 +40,14 @@
 #include "evp_math.h"
 
 namespace {
+
+// field slots of the packed blocks (64 doubles = 512 bytes each)
+enum : unsigned { S_U = 0, S_V = 1, S_SIG = 2, S_NF = 14 };
+enum : unsigned { C_DXT = 0, C_DYT, C_STRENGTH, C_HTE, C_HTN, C_VRELFAC, C_UOCN, C_VOCN, C_FORCEX, C_FORCEY, C_UMASSDTI, C_FM,
+                  C_UAREAR, C_NF };
+enum : unsigned { O_WATERX = 0, O_WATERY, O_TBU, O_UINIT, O_VINIT, O_NF };
+enum : unsigned { D_NF = 4 };
+static_assert(S_NF == EVP_MARCH_S_NF && C_NF == EVP_MARCH_C_NF && O_NF == EVP_MARCH_O_NF && D_NF == EVP_MARCH_D_NF, "block sizes");
 
 // neighbour lanes: one DPP move per 32-bit half (wave_shr:1 / wave_shl:1 span all 64 lanes on gfx9-family hardware)
 __device__ __forceinline__ double lane_up(double v)       // lane l <- lane l-1 (lane 0: undefined, never used)
@@ -53,204 +65,318 @@ __device__ __forceinline__ double lane_dn(double v)       // lane l <- lane l+1 
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// What a wave needs to know about its work item; everything here is wave-uniform except lane-indexed members.
+struct Item {
+    int lane, wv, strip, Y0, Y1;
+    int xw;                 // this lane's column (wrapped into the rectangle when E-W is cyclic inside the rank)
+    bool own_x;             // the lane owns its column (stores its results)
+    unsigned lane8;         // lane * 8
+    unsigned dupd;          // byte offset, from the start of a state ROW, of the duplicate of this lane's column in a
+                            // neighbouring block (field 0); EVP_MARCH_NODUP: none
+    long blk0;              // block index of (row Y0-2, strip)
+    unsigned em0;           // mask element of (column xw, row Y0-2)
+};
+
+__device__ __forceinline__ bool march_item(const EvpMarch &A, Item &I)
+{
+    I.lane = threadIdx.x & 63;
+    I.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // workgroup -> four neighbouring strips of one segment.  order bit0: workgroups go to the XCDs round-robin (observed
+    // dispatch rule, used for speed only); give every XCD one contiguous run of the item sequence.  bit1: segment fastest.
+    int wg = blockIdx.x;
+    if (A.order & 1) {
+        const int per = (gridDim.x + 7) >> 3;
+        wg = (wg & 7) * per + (wg >> 3);
+    }
+    const int item = wg * 4 + I.wv;
+    if (item >= A.nitems) return false;                // whole waves; the kernels have no barrier
+    int seg;
+    if (A.order & 2) { seg = item % A.nseg; I.strip = item / A.nseg; }
+    else { I.strip = item % A.nstrips; seg = item / A.nstrips; }
+    const int x = I.strip * A.own - 2 + I.lane;
+    I.Y0 = seg * A.seglen;
+    I.Y1 = min(I.Y0 + A.seglen, A.nyr);
+    I.own_x = I.lane >= 2 && I.lane < 2 + A.own && x < A.nxr;
+    I.xw = x;
+    if (A.wrapx) {
+        if (I.xw < 0) I.xw += A.nxr;
+        else if (I.xw >= A.nxr) I.xw -= A.nxr;
+    }
+    I.lane8 = (unsigned)I.lane * 8u;
+    I.dupd = (unsigned)A.dup[I.strip * 64 + I.lane];
+    I.blk0 = (long)(I.Y0 - 2 + EVP_MARCH_PAD) * A.nstrips + I.strip;
+    I.em0 = (unsigned)((I.Y0 - 2 + EVP_MARCH_PAD) * A.ldx + EVP_MARCH_PAD + I.xw);
+    return true;
+}
+
+// wave-uniform row base + per-lane 32-bit byte offset: one scalar pointer per buffer, advanced once per row
+__device__ __forceinline__ double LDB(const double *rowbase, unsigned off)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(rowbase) + off);
+}
+__device__ __forceinline__ void STB(double *rowbase, unsigned off, double v)
+{
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(rowbase) + off) = v;
+}
+
 // LEAN: the host has verified waterx == uocn, watery == vocn, TbU == 0 on every ice U-cell and MODE == 3 (classic
-// EVP, revp == 0): eight momentum operands per U-cell instead of thirteen stay alive between U1 and U2.
-template <bool STRICT, int MODE, bool LEAN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void evp_march2(EvpMarch A)
+// EVP, revp == 0): the optional operands are not read.
+// ---------------------------------------------------------------------
+// Every load in flight ONE ROW AHEAD of its use (software prefetch into registers), and every
+// vector-memory instruction of the loop issued unconditionally: a lane that has nothing to load or store is pointed
+// at a spare row on top of the buffers instead of being branched around.  The point is s_waitcnt: vmcnt counts in
+// issue order, and across a conditional memory instruction the compiler has to assume the worst and drain the queue
+// -- with predicated loads, issued where they are used, the march exposed three memory latencies per row; here the only
+// wait of a row is for loads issued a whole row of arithmetic earlier (and never for the stores in between).  248
+// VGPRs: two waves per SIMD; the LDS stash (12 KB per wave) would allow three.
+// ---------------------------------------------------------------------
+template <bool STRICT, int MODE, bool LEAN, bool LAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void evp_march2p(EvpMarch A)
 {
     using MM = Math<STRICT>;
     using SI = typename MM::SI;
     using UI = typename MM::UI;
     using UO = typename MM::UO;
     __shared__ double stash[4][2][12][64];
-    // scalar base + 32-bit byte offset: one offset register serves every array (a 64-bit per-lane address per array,
-    // kept across the loop, cost 90 registers and spilled)
-    auto LD = [](const double *p, unsigned off) -> double {
-        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + off);
-    };
-    auto ST = [](double *p, unsigned off, double v) {
-        *reinterpret_cast<double *>(reinterpret_cast<char *>(p) + off) = v;
-    };
-
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wv;
-    if (item >= A.nitems) return;                      // whole waves; the kernel has no barrier
-    const int strip = item % A.nstrips, seg = item / A.nstrips;
-    const int x = strip * EVP_MARCH_OWN - 2 + lane;    // this lane's column (T-cell and U-cell of every stage)
-    const int Y0 = seg * A.seglen;
-    const int Y1 = min(Y0 + A.seglen, A.nyr);          // owned output rows [Y0, Y1)
+    Item I;
+    if (!march_item(A, I)) return;
+    const int lane = I.lane, wv = I.wv, Y0 = I.Y0, Y1 = I.Y1;
     const unsigned flags = A.flags;
     const bool water_is_ocn = LEAN || (flags & EVP_F_WATER_IS_OCN);
     const bool tbu_zero = LEAN || (flags & EVP_F_TBU_ZERO);
     const bool revised = !LEAN && A.p.revp != 0.0;
-    const bool own_x = lane >= 2 && lane <= 61 && x < A.nxr;
-    // E-W cyclic wrap inside this rank: the halo columns are images of owned columns and are kept current by the
-    // lanes that own their sources
-    int img = 0;
-    if (A.wrapx && own_x) {
-        if (x < 2) img = A.nxr;
-        else if (x >= A.nxr - 2) img = -A.nxr;
-    }
-    const unsigned rowb = (unsigned)A.ldx * 8u;                     // bytes per row
-    const int e0 = (Y0 - 2 + EVP_MARCH_PAD) * A.ldx + EVP_MARCH_PAD + x;      // element (x, Y0-2)
-    unsigned ob = (unsigned)e0 * 8u;
-    unsigned em = (unsigned)e0;                                     // element index for the byte mask
-    const int imgb = img * 8;
+    const bool own_x = I.own_x;
+    const unsigned l8 = I.lane8;
+    const size_t srow = (size_t)A.nstrips * S_NF * 64, crow = (size_t)A.nstrips * C_NF * 64, orow = (size_t)A.nstrips * O_NF * 64,
+                 drow = (size_t)A.nstrips * D_NF * 64;
+    const double *sin = A.st_in + I.blk0 * (S_NF * 64);
+    double *sout = A.st_out + I.blk0 * (S_NF * 64);
+    const double *cst = A.cst + I.blk0 * (C_NF * 64);
+    const double *opt = A.opt ? A.opt + I.blk0 * (O_NF * 64) : nullptr;
+    double *dg = A.diag + I.blk0 * (D_NF * 64);
+    unsigned em = I.em0;
+    // where lanes with nothing to do load from / store to: the top spare row of blocks, as a byte offset from the row
+    // the access is relative to (the difference is wave-uniform; recomputed from the dump row index per use)
+    const long dump_blk = (long)(A.nyr + 4 + EVP_MARCH_PAD) * A.nstrips + I.strip;
+    const double *sin_dump = A.st_in + dump_blk * (S_NF * 64);
+    double *sout_dump = A.st_out + dump_blk * (S_NF * 64);
+    const double *cst_dump = A.cst + dump_blk * (C_NF * 64);
+    const double *opt_dump = A.opt ? A.opt + dump_blk * (O_NF * 64) : nullptr;
+    double *dg_dump = A.diag + dump_blk * (D_NF * 64);
+    auto rel = [](const void *to, const void *from) -> unsigned { return (unsigned)((const char *)to - (const char *)from); };
 
-    // ---- carried state: what the rows below have left for this one ----
-    double u_p = LD(A.u_in, ob), v_p = LD(A.v_in, ob);                        // U(k), row r-1
-    double htn_p = LD(A.HTN, ob), htn_pp = 0, hte_p = 0;                 // HTN rows r-1, r-2; HTE row r-1
-    double dxT_p = 0, dyT_p = 0, strength_p = 0;                    // T-row r-1 (statics of S2)
-    unsigned m_p = 0, m_pp = 0;                                     // masks of rows r-1, r-2
-    double c1_sx0 = 0, c1_sx1 = 0, c1_sy0 = 0, c1_sy2 = 0;          // str(k+1) of T-row r-1 -> U-row r-1
-    double u1_p = 0, v1_p = 0;                                      // U(k+1), row r-2
-    double c2_sx0 = 0, c2_sx1 = 0, c2_sy0 = 0, c2_sy2 = 0;          // str(k+2) of T-row r-2 -> U-row r-2
+    struct Row { double u, v, hte, htn, s[12], dxT, dyT, strength; };
+    auto load_row = [&](const double *sr, const double *cr, unsigned mm, Row &R) {
+        R.u = LDB(sr, S_U * 512 + l8); R.v = LDB(sr, S_V * 512 + l8);
+        R.hte = LDB(cr, C_HTE * 512 + l8); R.htn = LDB(cr, C_HTN * 512 + l8);
+        const bool act = (mm & 1u) && lane >= 1;
+        const unsigned os = l8 + (act ? 0u : rel(sin_dump, sr)), oc = l8 + (act ? 0u : rel(cst_dump, cr));
+#pragma unroll
+        for (int k = 0; k < 12; ++k) R.s[k] = LDB(sr, (S_SIG + k) * 512 + os);
+        R.dxT = LDB(cr, C_DXT * 512 + oc); R.dyT = LDB(cr, C_DYT * 512 + oc); R.strength = LDB(cr, C_STRENGTH * 512 + oc);
+    };
+    auto load_us = [&](const double *cr, const double *orr, bool act, UI &w) {
+        const unsigned oc = l8 + (act ? 0u : rel(cst_dump, cr));
+        w.vrelfac = LDB(cr, C_VRELFAC * 512 + oc);
+        w.uocn = LDB(cr, C_UOCN * 512 + oc); w.vocn = LDB(cr, C_VOCN * 512 + oc);
+        w.forcex = LDB(cr, C_FORCEX * 512 + oc); w.forcey = LDB(cr, C_FORCEY * 512 + oc);
+        w.Umassdti = LDB(cr, C_UMASSDTI * 512 + oc); w.fm = LDB(cr, C_FM * 512 + oc); w.uarear = LDB(cr, C_UAREAR * 512 + oc);
+        if (!LEAN && orr) {                                                       // (uniform conditions)
+            const unsigned oo = l8 + (act ? 0u : rel(opt_dump, orr));
+            if (!water_is_ocn) { w.waterx = LDB(orr, O_WATERX * 512 + oo); w.watery = LDB(orr, O_WATERY * 512 + oo); }
+            if (!tbu_zero) w.TbU = LDB(orr, O_TBU * 512 + oo);
+            if (revised) { w.uvel_init = LDB(orr, O_UINIT * 512 + oo); w.vvel_init = LDB(orr, O_VINIT * 512 + oo); }
+        }
+    };
+    auto momentum = [&](const UI &us, double uold, double vold, double sx0, double sx1, double sx2, double sx3,
+                        double sy0, double sy1, double sy2, double sy3, UO &o) {
+        UI w = us;
+        if (water_is_ocn) { w.waterx = us.uocn; w.watery = us.vocn; }
+        if (tbu_zero) w.TbU = 0.0;
+        if (!revised) { w.uvel_init = 0.0; w.vvel_init = 0.0; }
+        w.uold = uold; w.vold = vold;
+        w.sx0 = sx0; w.sx1 = sx1; w.sx2 = sx2; w.sx3 = sx3;
+        w.sy0 = sy0; w.sy1 = sy1; w.sy2 = sy2; w.sy3 = sy3;
+        if (tbu_zero) MM::template stepu<MODE, false>(A.p, w, o);
+        else MM::template stepu<MODE, true>(A.p, w, o);
+    };
+
+    // ---- carried state ----
+    double u_p = LDB(sin, S_U * 512 + l8), v_p = LDB(sin, S_V * 512 + l8);    // U(k), row r-1
+    double htn_p = LDB(cst, C_HTN * 512 + l8), htn_pp = 0, hte_p = 0;
+    double dxT_p = 0, dyT_p = 0, strength_p = 0;
+    unsigned m_p = 0, m_pp = 0;
+    double c1_sx0 = 0, c1_sx1 = 0, c1_sy0 = 0, c1_sy2 = 0;
+    double u1_p = 0, v1_p = 0;
+    double c2_sx0 = 0, c2_sx1 = 0, c2_sy0 = 0, c2_sy2 = 0;
+    UI us_p{};                                                      // momentum operands of U-row r-2 (U1's, one row ago)
+    // in flight when the loop starts: row Y0-1, momentum operands nobody uses, the masks of rows Y0-1, Y0
+    unsigned m_n = A.mask[em + (unsigned)A.ldx], m_nn = A.mask[em + 2u * (unsigned)A.ldx];
+    Row N{};
+    UI usN{};
+    load_us(cst, opt, false, usN);
+    load_row(sin + srow, cst + crow, m_n, N);
 
     for (int r = Y0 - 1; r <= Y1 + 1; ++r) {
-        ob += rowb; em += (unsigned)A.ldx;                          // element (x, r)
-        const unsigned m = A.mask[em];
-        const double u0 = LD(A.u_in, ob), v0 = LD(A.v_in, ob);
-        const double hte = LD(A.HTE, ob), htn = LD(A.HTN, ob);
+        sin += srow; sout += srow; cst += crow; dg += drow; em += (unsigned)A.ldx;     // blocks of row r
+        if (opt) opt += orow;
+        const Row C = N;
+        const UI us = usN;                                          // momentum operands of U-row r-1
+        const unsigned m = m_n;
+        m_n = m_nn;
+        // everything the NEXT row consumes, requested now
+        {
+            const bool isU1n = (m & 2u) && lane >= 1 && lane <= 62 && r + 1 >= Y0;
+            load_us(cst, opt, isU1n, usN);                          // U-row r
+            m_nn = A.mask[em + 2u * (unsigned)A.ldx];               // (spare rows on top of the arrays)
+            load_row(sin + srow, cst + crow, m_n, N);               // row r+1
+        }
 
-        // ---- S1: stress(k+1) on T(x, r) -------------------------------------------------------
+        // ---- S1: stress(k+1) on T(x, r) ----
         const bool act1 = (m & 1u) && lane >= 1;
         double str1[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) str1[k] = 0.0;
-        double dxT = 0, dyT = 0, strength = 0;
         {
-            const double uL = lane_up(u0), vL = lane_up(v0), hteL = lane_up(hte);
+            const double uL = lane_up(C.u), vL = lane_up(C.v), hteL = lane_up(C.hte);
             const double uL_p = lane_up(u_p), vL_p = lane_up(v_p);
             if (act1) {
                 double s[12];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) s[k] = LD(A.sig_in[k], ob);
-                dxT = LD(A.dxT, ob); dyT = LD(A.dyT, ob); strength = LD(A.strength, ob);
+                for (int k = 0; k < 12; ++k) s[k] = C.s[k];
                 SI a;
-                a.dxT = dxT; a.dyT = dyT; a.strength = strength;
-                a.u_ij = u0; a.u_im = uL; a.u_jm = u_p; a.u_mm = uL_p;
-                a.v_ij = v0; a.v_im = vL; a.v_jm = v_p; a.v_mm = vL_p;
-                MM::metrics(hte, hteL, htn, htn_p, A.deltaminEVP, a);
+                a.dxT = C.dxT; a.dyT = C.dyT; a.strength = C.strength;
+                a.u_ij = C.u; a.u_im = uL; a.u_jm = u_p; a.u_mm = uL_p;
+                a.v_ij = C.v; a.v_im = vL; a.v_jm = v_p; a.v_mm = vL_p;
+                MM::metrics(C.hte, hteL, C.htn, htn_p, A.deltaminEVP, a);
                 MM::template stress<MODE>(A.p, a, s, str1);
 #pragma unroll
                 for (int k = 0; k < 12; ++k) stash[wv][r & 1][k][lane] = s[k];
             }
         }
-        // T-row r is row "j+1" of U-row r-1 and row "j" of U-row r (ice_dyn_shared.F90:948-951)
         const double n1_sx3 = lane_dn(str1[3]), n1_sy3 = lane_dn(str1[7]);
         const double t1_sx1 = lane_dn(str1[1]), t1_sy2 = lane_dn(str1[6]);
 
-        // ---- U1: stepu(k+1) on U(x, r-1) ------------------------------------------------------
-        // (U2 reads the same operands again one row later: from L2 / Infinity Cache, not from registers -- carrying
-        // them across S2 spilled 150 B per lane)
-        auto momentum = [&](unsigned eu, double uold, double vold, double sx0, double sx1, double sx2, double sx3,
-                            double sy0, double sy1, double sy2, double sy3, UO &o) {
-            UI w;
-            w.vrelfac = LD(A.vrelfac, eu);
-            w.uocn = LD(A.uocn, eu); w.vocn = LD(A.vocn, eu);
-            w.forcex = LD(A.forcex, eu); w.forcey = LD(A.forcey, eu);
-            w.Umassdti = LD(A.umassdti, eu); w.fm = LD(A.fm, eu); w.uarear = LD(A.uarear, eu);
-            if (water_is_ocn) { w.waterx = w.uocn; w.watery = w.vocn; }
-            else { w.waterx = LD(A.waterx, eu); w.watery = LD(A.watery, eu); }
-            w.TbU = tbu_zero ? 0.0 : LD(A.TbU, eu);
-            w.uvel_init = revised ? LD(A.uvel_init, eu) : 0.0;
-            w.vvel_init = revised ? LD(A.vvel_init, eu) : 0.0;
-            w.uold = uold; w.vold = vold;
-            w.sx0 = sx0; w.sx1 = sx1; w.sx2 = sx2; w.sx3 = sx3;
-            w.sy0 = sy0; w.sy1 = sy1; w.sy2 = sy2; w.sy3 = sy3;
-            if (tbu_zero) MM::template stepu<MODE, false>(A.p, w, o);
-            else MM::template stepu<MODE, true>(A.p, w, o);
-        };
-        double u1 = u_p, v1 = v_p;                                  // off the ice: the velocity stays what it is
+        // ---- U1: stepu(k+1) on U(x, r-1) ----
+        double u1 = u_p, v1 = v_p;
         const bool isU1 = (m_p & 2u) && lane >= 1 && lane <= 62 && r >= Y0;
         if (isU1) {
             UO o;
-            momentum(ob - rowb, u_p, v_p, c1_sx0, c1_sx1, str1[2], n1_sx3, c1_sy0, str1[5], c1_sy2, n1_sy3, o);
+            momentum(us, u_p, v_p, c1_sx0, c1_sx1, str1[2], n1_sx3, c1_sy0, str1[5], c1_sy2, n1_sy3, o);
             u1 = o.u; v1 = o.v;
         }
 
-        // ---- S2: stress(k+2) on T(x, r-1) -----------------------------------------------------
+        // ---- S2: stress(k+2) on T(x, r-1) ----
         const bool act2 = (m_p & 1u) && lane >= 2 && lane <= 62 && r - 1 >= Y0;
         double str2[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) str2[k] = 0.0;
+        double s2[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s2[k] = 0.0;
         {
             const double u1L = lane_up(u1), v1L = lane_up(v1), hteL_p = lane_up(hte_p);
             const double u1L_p = lane_up(u1_p), v1L_p = lane_up(v1_p);
             if (act2) {
-                double s[12];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) s[k] = stash[wv][(r - 1) & 1][k][lane];
+                for (int k = 0; k < 12; ++k) s2[k] = stash[wv][(r - 1) & 1][k][lane];
                 SI b;
                 b.dxT = dxT_p; b.dyT = dyT_p; b.strength = strength_p;
                 b.u_ij = u1; b.u_im = u1L; b.u_jm = u1_p; b.u_mm = u1L_p;
                 b.v_ij = v1; b.v_im = v1L; b.v_jm = v1_p; b.v_mm = v1L_p;
                 MM::metrics(hte_p, hteL_p, htn_p, htn_pp, A.deltaminEVP, b);
-                MM::template stress<MODE>(A.p, b, s, str2);
-                if (own_x && r - 1 < Y1) {
-                    const unsigned es = ob - rowb;
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) ST(A.sig_out[k], es, s[k]);
-                    if (img) {
-#pragma unroll
-                        for (int k = 0; k < 12; ++k) ST(A.sig_out[k], es + imgb, s[k]);
-                    }
-                }
+                MM::template stress<MODE>(A.p, b, s2, str2);
             }
+        }
+        {
+            double *rb = sout - srow - (size_t)I.strip * (S_NF * 64);            // first block of row r-1
+            const bool st = act2 && own_x && r - 1 < Y1;
+            const unsigned odump = l8 + rel(sout_dump, rb);
+            const unsigned o1 = st ? l8 + (unsigned)I.strip * (S_NF * 512) : odump;
+            const unsigned o2 = (st && I.dupd != EVP_MARCH_NODUP) ? I.dupd : odump;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) STB(rb, (S_SIG + k) * 512 + o1, s2[k]);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) STB(rb, (S_SIG + k) * 512 + o2, s2[k]);
         }
         const double n2_sx3 = lane_dn(str2[3]), n2_sy3 = lane_dn(str2[7]);
         const double t2_sx1 = lane_dn(str2[1]), t2_sy2 = lane_dn(str2[6]);
 
-        // ---- U2: stepu(k+2) on U(x, r-2) ------------------------------------------------------
+        // ---- U2: stepu(k+2) on U(x, r-2) ----
         const bool isU2 = (m_pp & 2u) && own_x && r - 2 >= Y0;
-        if (isU2) {
-            UO o;
-            momentum(ob - 2u * rowb, u1_p, v1_p, c2_sx0, c2_sx1, str2[2], n2_sx3, c2_sy0, str2[5], c2_sy2, n2_sy3, o);
-            const unsigned eo = ob - 2u * rowb;
-            ST(A.u_out, eo, o.u); ST(A.v_out, eo, o.v);
-            if (img) { ST(A.u_out, eo + imgb, o.u); ST(A.v_out, eo + imgb, o.v); }
-            if (A.last) {
-                ST(A.strintx, eo, o.strintx); ST(A.strinty, eo, o.strinty);
-                ST(A.taubx, eo, o.taubx); ST(A.tauby, eo, o.tauby);
+        UO o2;
+        o2.u = 0.0; o2.v = 0.0; o2.strintx = 0.0; o2.strinty = 0.0; o2.taubx = 0.0; o2.tauby = 0.0;
+        if (isU2)
+            momentum(us_p, u1_p, v1_p, c2_sx0, c2_sx1, str2[2], n2_sx3, c2_sy0, str2[5], c2_sy2, n2_sy3, o2);
+        {
+            double *rb = sout - 2 * srow - (size_t)I.strip * (S_NF * 64);        // first block of row r-2
+            const unsigned odump = l8 + rel(sout_dump, rb);
+            const unsigned o1 = isU2 ? l8 + (unsigned)I.strip * (S_NF * 512) : odump;
+            const unsigned od = (isU2 && I.dupd != EVP_MARCH_NODUP) ? I.dupd : odump;
+            STB(rb, S_U * 512 + o1, o2.u); STB(rb, S_V * 512 + o1, o2.v);
+            STB(rb, S_U * 512 + od, o2.u); STB(rb, S_V * 512 + od, o2.v);
+            if (LAST) {
+                double *d = dg - 2 * drow;
+                const unsigned q = l8 + (isU2 ? 0u : rel(dg_dump, d));
+                STB(d, 0 * 512 + q, o2.strintx); STB(d, 1 * 512 + q, o2.strinty);
+                STB(d, 2 * 512 + q, o2.taubx); STB(d, 3 * 512 + q, o2.tauby);
             }
         }
 
-        // ---- hand the row over to the next one ------------------------------------------------
-        u_p = u0; v_p = v0;
-        htn_pp = htn_p; htn_p = htn; hte_p = hte;
-        dxT_p = dxT; dyT_p = dyT; strength_p = strength;
+        // ---- hand the row over ----
+        u_p = C.u; v_p = C.v;
+        htn_pp = htn_p; htn_p = C.htn; hte_p = C.hte;
+        dxT_p = C.dxT; dyT_p = C.dyT; strength_p = C.strength;
         m_pp = m_p; m_p = m;
         c1_sx0 = str1[0]; c1_sx1 = t1_sx1; c1_sy0 = str1[4]; c1_sy2 = t1_sy2;
         u1_p = u1; v1_p = v1;
         c2_sx0 = str2[0]; c2_sx1 = t2_sx1; c2_sy0 = str2[4]; c2_sy2 = t2_sy2;
+        us_p = us;
     }
 }
 
 // ---------------------------------------------------------------------
-// CICE block layout <-> rectangle layout (evp_host_march.cpp owns the geometry)
+// CICE block layout <-> strip-major layout (evp_host_march.cpp owns the geometry)
 // ---------------------------------------------------------------------
+// cell (x, y) of the rectangle incl. two halo layers -> (block index of its row/strip, lane) of the strip that OWNS the
+// column (or, for halo columns of a closed side, the edge strip that holds it)
+__device__ __forceinline__ void cell_to_packed(const EvpMarchGeo &G, int x, int y, long &blk, int &lane)
+{
+    const int s = min(max(x, 0) / G.own, G.nstrips - 1);
+    lane = x - s * G.own + 2;
+    blk = (long)(y + EVP_MARCH_PAD) * G.nstrips + s;
+}
+
 struct CellMap {
-    int e;          // element of the rectangle arrays, -1: no such element
-    bool live;      // the element is a real cell of the rank's rectangle, or a halo element that images one
+    long blk; int lane;   // owner position in the packed buffers
+    int em;               // element of the row-major byte mask
+    bool ok;              // the position exists
+    bool live;            // it is a real cell of the rank's rectangle (interior, or the cell a wrap ghost images)
 };
 
-// block cell (b; i, j 1-based) -> rectangle element
-__device__ __forceinline__ CellMap block_to_rect(const EvpMarchGeo &G, int b, int i, int j)
+// block cell (b; i, j 1-based) -> packed position
+__device__ __forceinline__ CellMap block_to_packed(const EvpMarchGeo &G, int b, int i, int j)
 {
     const int2 o = G.blk_org[b];                 // rectangle coordinates of the block's first interior cell
-    const int xs = o.x + (i - G.ilo), ys = o.y + (j - G.ilo);
-    CellMap c;
-    c.e = -1;
-    c.live = false;
+    int xs = o.x + (i - G.ilo);
+    const int ys = o.y + (j - G.ilo);
+    CellMap c{};
     if (xs < -EVP_MARCH_PAD || xs >= G.nxr + EVP_MARCH_PAD || ys < -EVP_MARCH_PAD || ys >= G.nyr + EVP_MARCH_PAD) return c;
-    c.e = (ys + EVP_MARCH_PAD) * G.ldx + EVP_MARCH_PAD + xs;
-    c.live = ((xs >= 0 && xs < G.nxr) || G.wrapx) && (ys >= 0 && ys < G.nyr);
+    if (G.wrapx) {                               // a ghost cell across the cyclic seam takes the cell it images
+        if (xs < 0) xs += G.nxr;
+        else if (xs >= G.nxr) xs -= G.nxr;
+    }
+    cell_to_packed(G, xs, ys, c.blk, c.lane);
+    c.em = (ys + EVP_MARCH_PAD) * G.ldx + EVP_MARCH_PAD + xs;
+    c.ok = c.lane >= 0 && c.lane < 64;
+    c.live = c.ok && xs >= 0 && xs < G.nxr && ys >= 0 && ys < G.nyr;
     return c;
 }
 
-// rectangle element (x, y incl. halo) -> element of the block-layout arrays it takes its value from; -1: none (0).
-// inside: interior cell of a block; wrap halo: the interior cell it images; first halo layer of a closed side: the
-// ghost cell of the edge block (the caller's value there is what the reference reads, ice_dyn_evp.F90:867)
+// column x, row y of the rectangle (incl. halo) -> element of the block-layout arrays it takes its value from; -1: none
+// (0).  inside: interior cell of a block; beyond a cyclic seam: the interior cell it images; first halo layer of a
+// closed side: the ghost cell of the edge block (the caller's value there is what the reference reads,
+// ice_dyn_evp.F90:867)
 __device__ __forceinline__ int rect_to_block(const EvpMarchGeo &G, int x, int y, bool &is_cell)
 {
     int xs = x, ys = y;
@@ -265,35 +391,43 @@ __device__ __forceinline__ int rect_to_block(const EvpMarchGeo &G, int x, int y,
     return b * G.plane + (j - 1) * G.nxb + (i - 1);
 }
 
+// every lane of every block of every row (all duplicates included) <- the block-layout arrays
 __global__ __launch_bounds__(256) void march_gather(EvpMarchGeo G, EvpMarchTab T, const uint8_t *__restrict__ mask_blk,
                                                     uint8_t *__restrict__ mask_rect)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x - EVP_MARCH_PAD, y = blockIdx.y - EVP_MARCH_PAD;
-    if (x + EVP_MARCH_PAD >= G.ldx) return;
-    const int e = (y + EVP_MARCH_PAD) * G.ldx + EVP_MARCH_PAD + x;
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6), row = blockIdx.y;
+    if (s >= G.nstrips) return;
+    const int x = s * G.own - 2 + lane, y = row - EVP_MARCH_PAD;
     bool is_cell;
-    const int s = rect_to_block(G, x, y, is_cell);
+    const int src = rect_to_block(G, x, y, is_cell);
+    const size_t blk = (size_t)row * G.nstrips + s;
     for (int f = 0; f < T.n; ++f) {
-        const double v = s >= 0 ? T.blk[f][s] : 0.0;
-        T.rect[f][e] = v;
-        if (T.rect2[f]) T.rect2[f][e] = v;
+        const double v = src >= 0 ? T.blk[f][src] : 0.0;
+        const size_t e = (blk * T.nf[f] + T.slot[f]) * 64 + lane;
+        T.pk[f][e] = v;
+        if (T.pk2[f]) T.pk2[f][e] = v;
     }
-    if (mask_rect) mask_rect[e] = (s >= 0 && is_cell) ? (mask_blk[s] & 3u) : 0;
+    // the byte mask stays row-major; one lane per column writes it (the owner, or the edge strips for the halo columns)
+    if (mask_rect) {
+        const bool mine = (lane >= 2 && lane < 2 + G.own) || (s == 0 && lane < 2) || (s == G.nstrips - 1 && lane >= 2 + G.own);
+        if (mine && x + EVP_MARCH_PAD < G.ldx && x >= -EVP_MARCH_PAD)
+            mask_rect[(size_t)row * G.ldx + EVP_MARCH_PAD + x] = (src >= 0 && is_cell) ? (mask_blk[src] & 3u) : 0;
+    }
 }
 
 // Is the caller's block-layout state the image of ONE global state?  The reference computes the T-cells of the
 // north / east fringe (ihi+1, jhi+1) redundantly on every block from that block's own ghost storage
-// (ice_dyn_shared.F90:740-749) and reads ghost velocities as the caller left them; the rectangle holds every cell
-// once.  Both give the same bits iff the ghost values equal the cells they image, which CICE maintains (halo
-// updates of iceTmask, strength and the velocities before the loop; stresses evolve alike on both copies).  A
-// caller for which this does not hold (synthetic tests with independent holes in ghost masks) gets the one-
-// subcycle kernels, which keep per-block ghost storage.  `which`: 1 per-call fields, 2 static fields.
+// (ice_dyn_shared.F90:740-749) and reads ghost velocities as the caller left them; the packed layout holds every cell
+// once (plus exact duplicates).  Both give the same bits iff the ghost values equal the cells they image, which CICE
+// maintains (halo updates of iceTmask, strength and the velocities before the loop; stresses evolve alike on both
+// copies).  A caller for which this does not hold (synthetic tests with independent holes in ghost masks) gets the
+// one-subcycle kernels, which keep per-block ghost storage.
 __global__ __launch_bounds__(256) void march_check(EvpMarchGeo G, EvpMarchTab T, const uint8_t *__restrict__ mask_blk,
                                                    const uint8_t *__restrict__ mask_rect, int nuv, int nfringe,
                                                    unsigned *__restrict__ bad)
 {
-    // T.blk/T.rect: [0, nuv) compared on the whole ghost ring, [nuv, nuv + nfringe) on the fringe T-cells,
-    // the rest (HTE, HTN) on the fringe and on column ilo-1 / row jlo-1
+    // T: [0, nuv) compared on the whole ghost ring, [nuv, nuv + nfringe) on the fringe T-cells, the rest (HTE, HTN) on
+    // the fringe and on column ilo-1 / row jlo-1
     const int i = blockIdx.x * 256 + threadIdx.x + 1, j = blockIdx.y + 1, b = blockIdx.z;
     const int4 r = G.blk[b];
     if (i < r.x - 1 || i > r.y + 1 || j < r.z - 1 || j > r.w + 1) return;
@@ -301,19 +435,20 @@ __global__ __launch_bounds__(256) void march_check(EvpMarchGeo G, EvpMarchTab T,
     if (!ghost) return;
     const bool fringe = (i == r.y + 1 || j == r.w + 1) && i >= r.x && j >= r.z;
     const int s = b * G.plane + (j - 1) * G.nxb + (i - 1);
-    const CellMap c = block_to_rect(G, b, i, j);
+    const CellMap c = block_to_packed(G, b, i, j);
     unsigned nbad = 0;
     auto differs = [](double p, double q) { return __double_as_longlong(p) != __double_as_longlong(q); };
-    // velocities: every ghost cell the stress of an owned T-cell reads (closed sides too: the rectangle took the value
-    // from ONE of the ghost cells that image the position; they must all agree)
-    if (c.e >= 0)
-        for (int f = 0; f < nuv; ++f) nbad += differs(T.blk[f][s], T.rect[f][c.e]);
+    auto pk = [&](int f) { return T.pk[f][((size_t)c.blk * T.nf[f] + T.slot[f]) * 64 + c.lane]; };
+    // velocities: every ghost cell the stress of an owned T-cell reads (closed sides too: the packed layout took the
+    // value from ONE of the ghost cells that image the position; they must all agree)
+    if (c.ok)
+        for (int f = 0; f < nuv; ++f) nbad += differs(T.blk[f][s], pk(f));
     if (c.live) {
         if (fringe) {
-            for (int f = nuv; f < T.n; ++f) nbad += differs(T.blk[f][s], T.rect[f][c.e]);
-            if (mask_blk) nbad += ((mask_blk[s] ^ mask_rect[c.e]) & 1u);
+            for (int f = nuv; f < T.n; ++f) nbad += differs(T.blk[f][s], pk(f));
+            if (mask_blk) nbad += ((mask_blk[s] ^ mask_rect[c.em]) & 1u);
         } else if (i == r.x - 1 || j == r.z - 1) {
-            for (int f = nuv + nfringe; f < T.n; ++f) nbad += differs(T.blk[f][s], T.rect[f][c.e]);
+            for (int f = nuv + nfringe; f < T.n; ++f) nbad += differs(T.blk[f][s], pk(f));
         }
     } else if (fringe && mask_blk) {
         nbad += (mask_blk[s] & 1u);          // a T-cell beyond a closed boundary that the reference would compute
@@ -321,34 +456,40 @@ __global__ __launch_bounds__(256) void march_check(EvpMarchGeo G, EvpMarchTab T,
     if (nbad) atomicAdd(bad, nbad);
 }
 
-// rectangle -> block layout after the loop.  Velocities: every cell with a live source (interior, ghost images of
-// cells of this rank: what the reference's halo update leaves, ice_dyn_evp.F90:908-910); stresses: the T-cells the
-// reference updates (ilo..ihi+1 x jlo..jhi+1 where iceTmask); strintx/y, taubx/y: interior ice U-cells.
+// packed -> block layout after the loop.  Velocities: every cell with a live source (interior, ghost images of cells
+// of this rank: what the reference's halo update leaves, ice_dyn_evp.F90:908-910); stresses: the T-cells the reference
+// updates (ilo..ihi+1 x jlo..jhi+1 where iceTmask); strintx/y, taubx/y: interior ice U-cells.
 __global__ __launch_bounds__(256) void march_scatter(EvpMarchGeo G, EvpMarchTab T, const uint8_t *__restrict__ mask_blk,
                                                      int nuv, int nsig)
 {
     const int i = blockIdx.x * 256 + threadIdx.x + 1, j = blockIdx.y + 1, b = blockIdx.z;
     const int4 r = G.blk[b];
     if (i < r.x - 1 || i > r.y + 1 || j < r.z - 1 || j > r.w + 1) return;
-    const CellMap c = block_to_rect(G, b, i, j);
+    const CellMap c = block_to_packed(G, b, i, j);
     if (!c.live) return;
     const int s = b * G.plane + (j - 1) * G.nxb + (i - 1);
     const unsigned m = mask_blk[s];
-    for (int f = 0; f < nuv; ++f) T.blk[f][s] = T.rect[f][c.e];
+    auto pk = [&](int f) { return T.pk[f][((size_t)c.blk * T.nf[f] + T.slot[f]) * 64 + c.lane]; };
+    for (int f = 0; f < nuv; ++f) T.blk[f][s] = pk(f);
     if ((m & 1u) && i >= r.x && j >= r.z)
-        for (int f = nuv; f < nuv + nsig; ++f) T.blk[f][s] = T.rect[f][c.e];
+        for (int f = nuv; f < nuv + nsig; ++f) T.blk[f][s] = pk(f);
     if ((m & 2u) && i >= r.x && i <= r.y && j >= r.z && j <= r.w)
-        for (int f = nuv + nsig; f < T.n; ++f) T.blk[f][s] = T.rect[f][c.e];
+        for (int f = nuv + nsig; f < T.n; ++f) T.blk[f][s] = pk(f);
 }
 
 }  // namespace
 
 void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
 {
-    const dim3 grid((unsigned)((A.nitems + 3) / 4)), block(256);
+    const unsigned nwg = (unsigned)((A.nitems + 3) / 4);
+    const dim3 grid((A.order & 1) ? ((nwg + 7) / 8) * 8 : nwg), block(256);
     const bool lean = mode == 3 && (A.flags & EVP_F_WATER_IS_OCN) && (A.flags & EVP_F_TBU_ZERO) &&
                       !(std::getenv("CICE_EVP_HIP_MARCH_LEAN") && !std::atoi(std::getenv("CICE_EVP_HIP_MARCH_LEAN")));
-#define EVP_MARCH_LAUNCH(S, M, L) hipLaunchKernelGGL((evp_march2<S, M, L>), grid, block, 0, st, A)
+#define EVP_MARCH_LAUNCH(S, M, L)                                                                    \
+    do {                                                                                             \
+        if (A.last) hipLaunchKernelGGL((evp_march2p<S, M, L, true>), grid, block, 0, st, A);         \
+        else hipLaunchKernelGGL((evp_march2p<S, M, L, false>), grid, block, 0, st, A);               \
+    } while (0)
     if (strict) {
         if (lean) EVP_MARCH_LAUNCH(true, 3, true);
         else if (mode == 3) EVP_MARCH_LAUNCH(true, 3, false);
@@ -368,7 +509,7 @@ void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
 void evp_launch_march_gather(const EvpMarchGeo &G, const EvpMarchTab &T, const uint8_t *mask_blk, uint8_t *mask_rect,
                              hipStream_t st)
 {
-    hipLaunchKernelGGL(march_gather, dim3((unsigned)((G.ldx + 255) / 256), (unsigned)G.rows), dim3(256), 0, st, G, T,
+    hipLaunchKernelGGL(march_gather, dim3((unsigned)((G.nstrips + 3) / 4), (unsigned)G.rows), dim3(256), 0, st, G, T,
                        mask_blk, mask_rect);
 }
 

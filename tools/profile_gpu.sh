@@ -7,7 +7,7 @@
 # Counters are collected in their own passes, with --kernel-trace only (no --stats, no other
 # trace domain), as MI355X_MICROARCH.md "rocprofv3 PMC slots" prescribes: SQ 8 slots per pass,
 # FETCH_SIZE and WRITE_SIZE cannot share a pass, GRBM 2 slots.
-#   usage: tools/profile_gpu.sh <tag> [what ...]     what: gx1res gx1str s01str cgx1 cgs01 calib (default: all but cg*)
+#   usage: tools/profile_gpu.sh <tag> [what ...]     what: gx1res gx1str s01str s01march cgx1 cgs01 calib (default: all but cg*)
 #   cgx1 / cgs01: the three kernels of the C-grid subcycle (tools/cgrid_timing.py) -- trace + HBM-byte passes
 set -u
 TAG=${1:-prof}; shift || true
@@ -36,7 +36,8 @@ for w in $WHAT; do
   case $w in
     gx1res) run_passes gx1res "CICE_EVP_HIP_RESIDENT=1 CICE_EVP_HIP_RES_GEN=${RES_GEN:-2} CICE_EVP_HIP_RES_LOGW=${RES_LOGW:-4} CICE_EVP_HIP_TYB=4" python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary ;;
     gx1str) run_passes gx1str "CICE_EVP_HIP_RESIDENT=0 CICE_EVP_HIP_TYB=${TYB_GX1:-4}" python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary ;;
-    s01str) run_passes s01str "CICE_EVP_HIP_RESIDENT=0 CICE_EVP_HIP_TYB=${TYB_S01:-208}" python bench.py --workload s01 --ndte 24 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary ;;
+    s01march) run_passes s01march "CICE_EVP_HIP_MARCH=1 ${MARCH_ENV:-}" python bench.py --workload s01 --ndte 24 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary ;;
+    s01str) run_passes s01str "CICE_EVP_HIP_MARCH=0 CICE_EVP_HIP_RESIDENT=0 CICE_EVP_HIP_TYB=${TYB_S01:-208}" python bench.py --workload s01 --ndte 24 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary ;;
     cgx1|cgs01)
             g=gx1; [ $w = cgs01 ] && g=s01
             nd=120; [ $w = cgs01 ] && nd=12
