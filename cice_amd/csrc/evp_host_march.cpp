@@ -133,10 +133,11 @@ static bool march_geometry(std::string &why)
     G.rows = nyr + EVP_MARCH_PAD + 5;          // y = -2 .. nyr+4: halo, two rows the prefetch may touch, the dump row
     M.nblk = (size_t)G.rows * G.nstrips;
     if (M.nblk * EVP_MARCH_S_NF * 512 >= (1ull << 32)) { why = "state buffer beyond 32-bit byte offsets"; return false; }
-    // segments: about one round of resident waves (256 CUs x 8) so that every wave marches one long segment
+    // segments: one wave per SIMD (1024 of them), all resident at once -- measured at 3600 x 2400: 16 segments (960
+    // waves) 318 us per subcycle, 24 (1440: some SIMDs get two) 400, 34 (2040: two each) 378, 12 (720) 372
     int seglen = env("CICE_EVP_HIP_MARCH_SEG") ? std::atoi(env("CICE_EVP_HIP_MARCH_SEG")) : 0;
     if (seglen <= 0) {
-        const int want_seg = std::max(1, 2048 / M.nstrips);
+        const int want_seg = std::max(1, 1000 / M.nstrips);
         seglen = std::max(16, (nyr + want_seg - 1) / want_seg);
     }
     M.seglen = std::min(seglen, nyr);

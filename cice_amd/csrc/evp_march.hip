@@ -39,6 +39,10 @@
 #include "evp_device.h"
 #include "evp_math.h"
 
+#ifndef EVP_MARCH_WAVES
+#define EVP_MARCH_WAVES 2
+#endif
+
 namespace {
 
 // field slots of the packed blocks (64 doubles = 512 bytes each)
@@ -109,29 +113,45 @@ __device__ __forceinline__ bool march_item(const EvpMarch &A, Item &I)
     return true;
 }
 
-// wave-uniform row base + per-lane 32-bit byte offset: one scalar pointer per buffer, advanced once per row
-__device__ __forceinline__ double LDB(const double *rowbase, unsigned off)
+// Buffer (MUBUF) accesses: resource descriptor of the whole buffer + wave-uniform byte offset of the row (SGPR) +
+// per-lane byte offset within the row (VGPR) + the field's constant offset.  The descriptor's bounds check is what makes
+// "every memory instruction unconditional" free: a lane with nothing to load or store gets an offset beyond the buffer --
+// the hardware returns 0 / drops the store without touching memory (the range check looks at the per-lane offset only).
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+using Rsrc = __amdgpu_buffer_rsrc_t;
+constexpr unsigned OOB = 0xfffff000u;                    // + any field offset: still below 2^32, beyond every buffer
+__device__ __forceinline__ Rsrc make_rsrc(const void *p, unsigned bytes)
 {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(rowbase) + off);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ void STB(double *rowbase, unsigned off, double v)
+// field k of the block row at soff: 512 bytes per field; the instruction's immediate reaches 4095, the rest rides on soff
+__device__ __forceinline__ double FLD(Rsrc r, unsigned voff, unsigned soff, unsigned k)
 {
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(rowbase) + off) = v;
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff + (k & 7u) * 512u, soff + (k >> 3) * 4096u, 0);
+    return __longlong_as_double(((long long)v.y << 32) | v.x);
+}
+__device__ __forceinline__ void FST(Rsrc r, unsigned voff, unsigned soff, unsigned k, double x)
+{
+    const long long b = __double_as_longlong(x);
+    v2u v;
+    v.x = (unsigned)(b & 0xffffffffll);
+    v.y = (unsigned)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff + (k & 7u) * 512u, soff + (k >> 3) * 4096u, 0);
 }
 
 // LEAN: the host has verified waterx == uocn, watery == vocn, TbU == 0 on every ice U-cell and MODE == 3 (classic
 // EVP, revp == 0): the optional operands are not read.
 // ---------------------------------------------------------------------
 // Every load in flight ONE ROW AHEAD of its use (software prefetch into registers), and every
-// vector-memory instruction of the loop issued unconditionally: a lane that has nothing to load or store is pointed
-// at a spare row on top of the buffers instead of being branched around.  The point is s_waitcnt: vmcnt counts in
+// vector-memory instruction of the loop issued unconditionally: a lane that has nothing to load or store is given an
+// out-of-range offset (dropped by the buffer bounds check) instead of being branched around.  The point is s_waitcnt: vmcnt counts in
 // issue order, and across a conditional memory instruction the compiler has to assume the worst and drain the queue
 // -- with predicated loads, issued where they are used, the march exposed three memory latencies per row; here the only
 // wait of a row is for loads issued a whole row of arithmetic earlier (and never for the stores in between).  248
 // VGPRs: two waves per SIMD; the LDS stash (12 KB per wave) would allow three.
 // ---------------------------------------------------------------------
 template <bool STRICT, int MODE, bool LEAN, bool LAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void evp_march2p(EvpMarch A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EVP_MARCH_WAVES, EVP_MARCH_WAVES))) void evp_march2p(EvpMarch A)
 {
     using MM = Math<STRICT>;
     using SI = typename MM::SI;
@@ -147,45 +167,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool revised = !LEAN && A.p.revp != 0.0;
     const bool own_x = I.own_x;
     const unsigned l8 = I.lane8;
-    const size_t srow = (size_t)A.nstrips * S_NF * 64, crow = (size_t)A.nstrips * C_NF * 64, orow = (size_t)A.nstrips * O_NF * 64,
-                 drow = (size_t)A.nstrips * D_NF * 64;
-    const double *sin = A.st_in + I.blk0 * (S_NF * 64);
-    double *sout = A.st_out + I.blk0 * (S_NF * 64);
-    const double *cst = A.cst + I.blk0 * (C_NF * 64);
-    const double *opt = A.opt ? A.opt + I.blk0 * (O_NF * 64) : nullptr;
-    double *dg = A.diag + I.blk0 * (D_NF * 64);
+    const unsigned rows = (unsigned)(A.nyr + EVP_MARCH_PAD + 5);
+    const unsigned srow = (unsigned)A.nstrips * (S_NF * 512), crow = (unsigned)A.nstrips * (C_NF * 512),
+                   orow = (unsigned)A.nstrips * (O_NF * 512), drow = (unsigned)A.nstrips * (D_NF * 512);     // bytes per row of blocks
+    const Rsrc rSin = make_rsrc(A.st_in, rows * srow), rSout = make_rsrc(A.st_out, rows * srow), rC = make_rsrc(A.cst, rows * crow),
+               rO = make_rsrc(A.opt, A.opt ? rows * orow : 0u), rD = make_rsrc(A.diag, rows * drow);
+    // row offsets (uniform) of row r-... and the lane's offsets within a row of each buffer
+    const unsigned row0 = (unsigned)(Y0 - 2 + EVP_MARCH_PAD);
+    unsigned sS = row0 * srow, sC = row0 * crow, sO = row0 * orow, sD = row0 * drow;
+    const unsigned vS = (unsigned)I.strip * (S_NF * 512) + l8, vC = (unsigned)I.strip * (C_NF * 512) + l8,
+                   vO = (unsigned)I.strip * (O_NF * 512) + l8, vD = (unsigned)I.strip * (D_NF * 512) + l8;
     unsigned em = I.em0;
-    // where lanes with nothing to do load from / store to: the top spare row of blocks, as a byte offset from the row
-    // the access is relative to (the difference is wave-uniform; recomputed from the dump row index per use)
-    const long dump_blk = (long)(A.nyr + 4 + EVP_MARCH_PAD) * A.nstrips + I.strip;
-    const double *sin_dump = A.st_in + dump_blk * (S_NF * 64);
-    double *sout_dump = A.st_out + dump_blk * (S_NF * 64);
-    const double *cst_dump = A.cst + dump_blk * (C_NF * 64);
-    const double *opt_dump = A.opt ? A.opt + dump_blk * (O_NF * 64) : nullptr;
-    double *dg_dump = A.diag + dump_blk * (D_NF * 64);
-    auto rel = [](const void *to, const void *from) -> unsigned { return (unsigned)((const char *)to - (const char *)from); };
 
     struct Row { double u, v, hte, htn, s[12], dxT, dyT, strength; };
-    auto load_row = [&](const double *sr, const double *cr, unsigned mm, Row &R) {
-        R.u = LDB(sr, S_U * 512 + l8); R.v = LDB(sr, S_V * 512 + l8);
-        R.hte = LDB(cr, C_HTE * 512 + l8); R.htn = LDB(cr, C_HTN * 512 + l8);
+    auto load_row = [&](unsigned sr, unsigned cr, unsigned mm, Row &R) {          // sr, cr: row offsets
+        R.u = FLD(rSin, vS, sr, S_U); R.v = FLD(rSin, vS, sr, S_V);
+        R.hte = FLD(rC, vC, cr, C_HTE); R.htn = FLD(rC, vC, cr, C_HTN);
         const bool act = (mm & 1u) && lane >= 1;
-        const unsigned os = l8 + (act ? 0u : rel(sin_dump, sr)), oc = l8 + (act ? 0u : rel(cst_dump, cr));
+        const unsigned os = act ? vS : OOB, oc = act ? vC : OOB;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) R.s[k] = LDB(sr, (S_SIG + k) * 512 + os);
-        R.dxT = LDB(cr, C_DXT * 512 + oc); R.dyT = LDB(cr, C_DYT * 512 + oc); R.strength = LDB(cr, C_STRENGTH * 512 + oc);
+        for (int k = 0; k < 12; ++k) R.s[k] = FLD(rSin, os, sr, S_SIG + k);
+        R.dxT = FLD(rC, oc, cr, C_DXT); R.dyT = FLD(rC, oc, cr, C_DYT); R.strength = FLD(rC, oc, cr, C_STRENGTH);
     };
-    auto load_us = [&](const double *cr, const double *orr, bool act, UI &w) {
-        const unsigned oc = l8 + (act ? 0u : rel(cst_dump, cr));
-        w.vrelfac = LDB(cr, C_VRELFAC * 512 + oc);
-        w.uocn = LDB(cr, C_UOCN * 512 + oc); w.vocn = LDB(cr, C_VOCN * 512 + oc);
-        w.forcex = LDB(cr, C_FORCEX * 512 + oc); w.forcey = LDB(cr, C_FORCEY * 512 + oc);
-        w.Umassdti = LDB(cr, C_UMASSDTI * 512 + oc); w.fm = LDB(cr, C_FM * 512 + oc); w.uarear = LDB(cr, C_UAREAR * 512 + oc);
-        if (!LEAN && orr) {                                                       // (uniform conditions)
-            const unsigned oo = l8 + (act ? 0u : rel(opt_dump, orr));
-            if (!water_is_ocn) { w.waterx = LDB(orr, O_WATERX * 512 + oo); w.watery = LDB(orr, O_WATERY * 512 + oo); }
-            if (!tbu_zero) w.TbU = LDB(orr, O_TBU * 512 + oo);
-            if (revised) { w.uvel_init = LDB(orr, O_UINIT * 512 + oo); w.vvel_init = LDB(orr, O_VINIT * 512 + oo); }
+    auto load_us = [&](unsigned cr, unsigned orr, bool act, UI &w) {
+        const unsigned oc = act ? vC : OOB;
+        w.vrelfac = FLD(rC, oc, cr, C_VRELFAC);
+        w.uocn = FLD(rC, oc, cr, C_UOCN); w.vocn = FLD(rC, oc, cr, C_VOCN);
+        w.forcex = FLD(rC, oc, cr, C_FORCEX); w.forcey = FLD(rC, oc, cr, C_FORCEY);
+        w.Umassdti = FLD(rC, oc, cr, C_UMASSDTI); w.fm = FLD(rC, oc, cr, C_FM); w.uarear = FLD(rC, oc, cr, C_UAREAR);
+        if (!LEAN) {                                                              // (uniform conditions)
+            const unsigned oo = act ? vO : OOB;
+            if (!water_is_ocn) { w.waterx = FLD(rO, oo, orr, O_WATERX); w.watery = FLD(rO, oo, orr, O_WATERY); }
+            if (!tbu_zero) w.TbU = FLD(rO, oo, orr, O_TBU);
+            if (revised) { w.uvel_init = FLD(rO, oo, orr, O_UINIT); w.vvel_init = FLD(rO, oo, orr, O_VINIT); }
         }
     };
     auto momentum = [&](const UI &us, double uold, double vold, double sx0, double sx1, double sx2, double sx3,
@@ -202,8 +216,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     // ---- carried state ----
-    double u_p = LDB(sin, S_U * 512 + l8), v_p = LDB(sin, S_V * 512 + l8);    // U(k), row r-1
-    double htn_p = LDB(cst, C_HTN * 512 + l8), htn_pp = 0, hte_p = 0;
+    double u_p = FLD(rSin, vS, sS, S_U), v_p = FLD(rSin, vS, sS, S_V);        // U(k), row r-1
+    double htn_p = FLD(rC, vC, sC, C_HTN), htn_pp = 0, hte_p = 0;
     double dxT_p = 0, dyT_p = 0, strength_p = 0;
     unsigned m_p = 0, m_pp = 0;
     double c1_sx0 = 0, c1_sx1 = 0, c1_sy0 = 0, c1_sy2 = 0;
@@ -214,12 +228,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned m_n = A.mask[em + (unsigned)A.ldx], m_nn = A.mask[em + 2u * (unsigned)A.ldx];
     Row N{};
     UI usN{};
-    load_us(cst, opt, false, usN);
-    load_row(sin + srow, cst + crow, m_n, N);
+    load_us(sC, sO, false, usN);
+    load_row(sS + srow, sC + crow, m_n, N);
 
     for (int r = Y0 - 1; r <= Y1 + 1; ++r) {
-        sin += srow; sout += srow; cst += crow; dg += drow; em += (unsigned)A.ldx;     // blocks of row r
-        if (opt) opt += orow;
+        sS += srow; sC += crow; sO += orow; sD += drow; em += (unsigned)A.ldx;          // blocks of row r
         const Row C = N;
         const UI us = usN;                                          // momentum operands of U-row r-1
         const unsigned m = m_n;
@@ -227,9 +240,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // everything the NEXT row consumes, requested now
         {
             const bool isU1n = (m & 2u) && lane >= 1 && lane <= 62 && r + 1 >= Y0;
-            load_us(cst, opt, isU1n, usN);                          // U-row r
+            load_us(sC, sO, isU1n, usN);                            // U-row r
             m_nn = A.mask[em + 2u * (unsigned)A.ldx];               // (spare rows on top of the arrays)
-            load_row(sin + srow, cst + crow, m_n, N);               // row r+1
+            load_row(sS + srow, sC + crow, m_n, N);                 // row r+1
         }
 
         // ---- S1: stress(k+1) on T(x, r) ----
@@ -289,15 +302,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         {
-            double *rb = sout - srow - (size_t)I.strip * (S_NF * 64);            // first block of row r-1
+            // new stresses of T(x, r-1): into the owner's block, and -- the two columns on either edge of a strip -- into the
+            // neighbouring block that duplicates them (a second store instruction with four live lanes)
             const bool st = act2 && own_x && r - 1 < Y1;
-            const unsigned odump = l8 + rel(sout_dump, rb);
-            const unsigned o1 = st ? l8 + (unsigned)I.strip * (S_NF * 512) : odump;
-            const unsigned o2 = (st && I.dupd != EVP_MARCH_NODUP) ? I.dupd : odump;
+            const unsigned o1 = st ? vS : OOB;
+            const unsigned o2 = (st && I.dupd != EVP_MARCH_NODUP) ? I.dupd : OOB;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) STB(rb, (S_SIG + k) * 512 + o1, s2[k]);
+            for (int k = 0; k < 12; ++k) FST(rSout, o1, sS - srow, S_SIG + k, s2[k]);
 #pragma unroll
-            for (int k = 0; k < 12; ++k) STB(rb, (S_SIG + k) * 512 + o2, s2[k]);
+            for (int k = 0; k < 12; ++k) FST(rSout, o2, sS - srow, S_SIG + k, s2[k]);
         }
         const double n2_sx3 = lane_dn(str2[3]), n2_sy3 = lane_dn(str2[7]);
         const double t2_sx1 = lane_dn(str2[1]), t2_sy2 = lane_dn(str2[6]);
@@ -309,17 +322,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (isU2)
             momentum(us_p, u1_p, v1_p, c2_sx0, c2_sx1, str2[2], n2_sx3, c2_sy0, str2[5], c2_sy2, n2_sy3, o2);
         {
-            double *rb = sout - 2 * srow - (size_t)I.strip * (S_NF * 64);        // first block of row r-2
-            const unsigned odump = l8 + rel(sout_dump, rb);
-            const unsigned o1 = isU2 ? l8 + (unsigned)I.strip * (S_NF * 512) : odump;
-            const unsigned od = (isU2 && I.dupd != EVP_MARCH_NODUP) ? I.dupd : odump;
-            STB(rb, S_U * 512 + o1, o2.u); STB(rb, S_V * 512 + o1, o2.v);
-            STB(rb, S_U * 512 + od, o2.u); STB(rb, S_V * 512 + od, o2.v);
+            const unsigned o1 = isU2 ? vS : OOB;
+            const unsigned od = (isU2 && I.dupd != EVP_MARCH_NODUP) ? I.dupd : OOB;
+            FST(rSout, o1, sS - 2u * srow, S_U, o2.u); FST(rSout, o1, sS - 2u * srow, S_V, o2.v);
+            FST(rSout, od, sS - 2u * srow, S_U, o2.u); FST(rSout, od, sS - 2u * srow, S_V, o2.v);
             if (LAST) {
-                double *d = dg - 2 * drow;
-                const unsigned q = l8 + (isU2 ? 0u : rel(dg_dump, d));
-                STB(d, 0 * 512 + q, o2.strintx); STB(d, 1 * 512 + q, o2.strinty);
-                STB(d, 2 * 512 + q, o2.taubx); STB(d, 3 * 512 + q, o2.tauby);
+                const unsigned q = isU2 ? vD : OOB;
+                FST(rD, q, sD - 2u * drow, 0, o2.strintx); FST(rD, q, sD - 2u * drow, 1, o2.strinty);
+                FST(rD, q, sD - 2u * drow, 2, o2.taubx); FST(rD, q, sD - 2u * drow, 3, o2.tauby);
             }
         }
 
