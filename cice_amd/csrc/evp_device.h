@@ -154,6 +154,7 @@ struct EvpMarchGeo {
     int bsx, bsy, nbx, nby;    // interior size of a full block, blocks of the rank in x / y
     int ilo;                   // first interior index of a block (nghost + 1)
     int wrapx;
+    int gx0, gy0, nxg, nyg, ew_cyclic;   // the rectangle in the global index space (0-based), the global domain
     const int *blkid;          // [nby][nbx] local block index
     const int2 *blk_org;       // [nblocks] rectangle coordinates of the first interior cell
     const int4 *blk;           // [nblocks] ilo ihi jlo jhi
@@ -174,6 +175,11 @@ void evp_launch_march_check(const EvpMarchGeo &G, const EvpMarchTab &T, const ui
                             int nuv, int nfringe, unsigned *bad, hipStream_t st);
 void evp_launch_march_scatter(const EvpMarchGeo &G, const EvpMarchTab &T, const uint8_t *mask_blk, int nuv, int nsig,
                               hipStream_t st);
+void evp_launch_march_pack(const double *buf, int nf, const int *pos, int n, double *out, hipStream_t st);
+void evp_launch_march_unpack(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const double *in,
+                             hipStream_t st);
+void evp_launch_march_pack_mask(const uint8_t *mask, const int *idx, int n, double *out, hipStream_t st);
+void evp_launch_march_unpack_mask(uint8_t *mask, const int *idx, int n, const double *in, hipStream_t st);
 
 // Mailbox halo between GPUs of one node (evp_halo_direct.hip)
 #define EVP_DIRECT_MAXPEER 32

@@ -18,6 +18,7 @@
 // whose ghost values are not images of one global state.
 // =====================================================================
 #include "evp_host.h"
+#include "march_plan.h"
 
 namespace evp_host {
 
@@ -32,7 +33,11 @@ struct MarchBuf {
     unsigned *bad = nullptr, *dup = nullptr;
     int *blkid = nullptr;
     int2 *org = nullptr;
+    // the two-cell ring between ranks
+    int *send_pos = nullptr, *recv_pos1 = nullptr, *recv_pos2 = nullptr, *send_midx = nullptr, *recv_midx = nullptr;
+    double *sendbuf = nullptr, *recvbuf = nullptr;
 };
+MarchPlan PL;
 // slots of the constants block (evp_march.hip: C_*), of the optional block (O_*)
 enum { C_DXT = 0, C_DYT, C_STRENGTH, C_HTE, C_HTN, C_VRELFAC, C_UOCN, C_VOCN, C_FORCEX, C_FORCEY, C_UMASSDTI, C_FM, C_UAREAR };
 enum { O_WATERX = 0, O_WATERY, O_TBU, O_UINIT, O_VINIT };
@@ -50,6 +55,8 @@ void march_free()
 {
     F(B.st[0]); F(B.st[1]); F(B.cst); F(B.opt); F(B.diag);
     F(B.mask); F(B.bad); F(B.dup); F(B.blkid); F(B.org);
+    F(B.send_pos); F(B.recv_pos1); F(B.recv_pos2); F(B.send_midx); F(B.recv_midx); F(B.sendbuf); F(B.recvbuf);
+    PL = MarchPlan();
     S.march = State::March{};
 }
 
@@ -58,9 +65,11 @@ static bool march_geometry(std::string &why)
 {
     State::March &M = S.march;
     const cice_evp_hip_dims &d = S.d;
-    if (d.nranks > 1 || !S.plan.peers.empty()) { why = "several ranks"; return false; }
-    if (d.nghost != 1) { why = "nghost != 1"; return false; }
-    if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE || d.ns_boundary_type == CICE_EVP_BND_CYCLIC) { why = "north-south boundary is not closed"; return false; }
+    // the rectangles of all ranks, this rank's strips and the exchange lists: the same verdict on every rank
+    const int own_max = env("CICE_EVP_HIP_MARCH_OWN") ? std::atoi(env("CICE_EVP_HIP_MARCH_OWN")) : EVP_MARCH_OWN;
+    const bool wrap_inside = !(env("CICE_EVP_HIP_MARCH_SELFX") && std::atoi(env("CICE_EVP_HIP_MARCH_SELFX")));
+    if (!build_march_plan(d, own_max, wrap_inside, PL)) { why = PL.error; return false; }
+    if (!PL.peers.empty() && !S.have_comm) { why = "cells of other ranks needed but no RCCL communicator (cice_evp_hip_comm_init)"; return false; }
     if (!(S.flags & EVP_F_METRICS) || (S.flags & EVP_F_DXHY_ARRAY)) { why = "metric terms come from arrays"; return false; }
     if (d.nblocks < 1) { why = "no blocks"; return false; }
     // blocks must tile [gx0, gx0+nxr) x [gy0, gy0+nyr) with full blocks of bsx x bsy (the last column / row may be smaller)
@@ -90,44 +99,20 @@ static bool march_geometry(std::string &why)
         M.blkid_h[(size_t)bj * nbx + bi] = b;
         M.org_h[b] = int2{ox, oy};
     }
-    const bool wrapx = d.ew_boundary_type == CICE_EVP_BND_CYCLIC;
-    if (wrapx && nxr != d.nx_global) { why = "cyclic dimension not spanned by this rank"; return false; }
-    if (nxr < 4 || nyr < 1) { why = "rectangle too small"; return false; }
+    if (nxr != PL.me.nxr || nyr != PL.me.nyr || gx0 - 1 != PL.me.gx0 || gy0 - 1 != PL.me.gy0) { why = "local blocks disagree with the global block table"; return false; }
+    const bool wrapx = PL.wrapx;
     EvpMarchGeo &G = M.G;
     G.nxr = nxr; G.nyr = nyr;
     G.nxb = d.nx_block; G.nyb = d.ny_block; G.plane = (int)S.plane; G.nblocks = d.nblocks;
     G.bsx = bsx; G.bsy = bsy; G.nbx = nbx; G.nby = nby;
     G.ilo = d.nghost + 1;
     G.wrapx = wrapx ? 1 : 0;
-    // strips of `own` columns; every owned column may have ONE duplicate (in a neighbouring strip's overlap lanes, across
-    // the cyclic seam for the edge strips) -- the widest `own` for which that holds
-    const int own_max = env("CICE_EVP_HIP_MARCH_OWN") ? std::min(EVP_MARCH_OWN, std::max(4, std::atoi(env("CICE_EVP_HIP_MARCH_OWN")))) : EVP_MARCH_OWN;
-    bool found = false;
-    for (int own = own_max; own >= 4 && !found; --own) {
-        const int ns = (nxr + own - 1) / own;
-        // where does column c live?  owner (strip c / own, lane 2 + c % own); duplicates: every other (s, l) whose
-        // column x = s*own - 2 + l is c (modulo nxr when cyclic)
-        std::vector<unsigned> dup((size_t)ns * 64, EVP_MARCH_NODUP);
-        bool ok = true;
-        for (int sb = 0; sb < ns && ok; ++sb)
-            for (int l = 0; l < 64 && ok; ++l) {
-                int x = sb * own - 2 + l;
-                const int cnt = std::min(own, nxr - sb * own);   // columns strip sb owns: lanes 2 .. cnt+1
-                if (l >= 2 && l < 2 + cnt) continue;             // an owner
-                if (!(l < 2 || l < 4 + cnt)) continue;           // beyond the two overlap lanes: nothing reads it
-                if (wrapx) { if (x < 0) x += nxr; else if (x >= nxr) x -= nxr; }
-                if (x < 0 || x >= nxr) continue;                 // beyond a closed side: nobody writes it
-                const int so = x / own, lo = 2 + x % own;        // its owner
-                unsigned &slot = dup[(size_t)so * 64 + lo];
-                if (slot != EVP_MARCH_NODUP) { ok = false; break; }           // a second duplicate
-                slot = (unsigned)(((size_t)sb * EVP_MARCH_S_NF * 64 + l) * 8);
-            }
-        if (!ok) continue;
-        found = true;
-        G.own = own; G.nstrips = ns;
-        M.dup_h = dup;
-    }
-    if (!found) { why = "no strip width gives every column a single duplicate"; return false; }
+    G.gx0 = PL.me.gx0; G.gy0 = PL.me.gy0; G.nxg = d.nx_global; G.nyg = d.ny_global;
+    G.ew_cyclic = d.ew_boundary_type == CICE_EVP_BND_CYCLIC ? 1 : 0;
+    G.own = PL.me.own; G.nstrips = PL.me.nstrips;
+    M.dup_h.assign(PL.dup.size(), EVP_MARCH_NODUP);
+    for (size_t k = 0; k < PL.dup.size(); ++k)
+        if (PL.dup[k] >= 0) M.dup_h[k] = (unsigned)((((size_t)(PL.dup[k] >> 8)) * EVP_MARCH_S_NF * 64 + (PL.dup[k] & 255)) * 8);
     M.nstrips = G.nstrips;
     G.ldx = ((G.nstrips * G.own + 64 + 2 * EVP_MARCH_PAD + 7) / 8) * 8;
     G.rows = nyr + EVP_MARCH_PAD + 5;          // y = -2 .. nyr+4: halo, two rows the prefetch may touch, the dump row
@@ -171,15 +156,74 @@ static int march_alloc()
         HIPC(hipMalloc((void **)&B.dup, M.dup_h.size() * sizeof(unsigned)));
         HIPC(hipMemcpy(B.dup, M.dup_h.data(), M.dup_h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
+    if (PL.n_send + PL.n_recv > 0 && !B.sendbuf) {
+        std::vector<int> sp, r1, r2, sm, rm;
+        for (const MarchPeer &p : PL.peers) {
+            sp.insert(sp.end(), p.send_pos.begin(), p.send_pos.end());
+            r1.insert(r1.end(), p.recv_pos1.begin(), p.recv_pos1.end());
+            r2.insert(r2.end(), p.recv_pos2.begin(), p.recv_pos2.end());
+            for (size_t k = 0; k < p.send_pos.size(); ++k)
+                sm.push_back((int)((size_t)((p.send_pos[k] >> 6) / M.G.nstrips) * M.G.ldx + EVP_MARCH_PAD + p.send_col[k]));
+            for (size_t k = 0; k < p.recv_pos1.size(); ++k)
+                rm.push_back((int)((size_t)p.recv_row[k] * M.G.ldx + EVP_MARCH_PAD + p.recv_col[k]));
+        }
+        auto up = [&](int *&dp, const std::vector<int> &v) -> int {
+            HIPC(hipMalloc((void **)&dp, std::max<size_t>(v.size(), 1) * sizeof(int)));
+            if (!v.empty()) HIPC(hipMemcpy(dp, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+            return 0;
+        };
+        if (up(B.send_pos, sp) || up(B.recv_pos1, r1) || up(B.recv_pos2, r2) || up(B.send_midx, sm) || up(B.recv_midx, rm)) return -1;
+        HIPC(hipMalloc((void **)&B.sendbuf, std::max<size_t>(PL.n_send, 1) * EVP_MARCH_S_NF * sizeof(double)));
+        HIPC(hipMalloc((void **)&B.recvbuf, std::max<size_t>(PL.n_recv, 1) * EVP_MARCH_S_NF * sizeof(double)));
+    }
     M.G.blkid = B.blkid;
     M.G.blk_org = B.org;
     M.G.blk = S.blk;
     return 0;
 }
 
-static int read_bad(unsigned &bad)
+// The two-cell ring of one strip-major buffer (all nf fields of every halo cell) from the ranks that own the cells:
+// pack -> ncclGroupStart{ncclSend, ncclRecv per neighbour}ncclGroupEnd -> unpack (incl. the duplicates), on the
+// library's stream.  Once per PASS of two subcycles for the state, once per call for the constants and the mask.
+static int march_exchange(double *buf, double *buf2, int nf)
 {
-    HIPC(hipMemcpyAsync(&bad, B.bad, sizeof bad, hipMemcpyDeviceToHost, S.stream));
+    if (PL.peers.empty()) return 0;
+    evp_launch_march_pack(buf, nf, B.send_pos, PL.n_send, B.sendbuf, S.stream);
+    size_t so = 0, ro = 0;
+    NCCLC(ncclGroupStart());
+    for (const MarchPeer &p : PL.peers) {
+        const size_t ns = p.send_pos.size(), nr = p.recv_pos1.size();
+        if (ns) NCCLC(ncclSend(B.sendbuf + so * nf, ns * nf, ncclDouble, p.rank, S.comm, S.stream));
+        if (nr) NCCLC(ncclRecv(B.recvbuf + ro * nf, nr * nf, ncclDouble, p.rank, S.comm, S.stream));
+        so += ns; ro += nr;
+    }
+    NCCLC(ncclGroupEnd());
+    evp_launch_march_unpack(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.recvbuf, S.stream);
+    return 0;
+}
+
+static int march_exchange_mask()
+{
+    if (PL.peers.empty()) return 0;
+    evp_launch_march_pack_mask(B.mask, B.send_midx, PL.n_send, B.sendbuf, S.stream);
+    size_t so = 0, ro = 0;
+    NCCLC(ncclGroupStart());
+    for (const MarchPeer &p : PL.peers) {
+        const size_t ns = p.send_pos.size(), nr = p.recv_pos1.size();
+        if (ns) NCCLC(ncclSend(B.sendbuf + so, ns, ncclDouble, p.rank, S.comm, S.stream));
+        if (nr) NCCLC(ncclRecv(B.recvbuf + ro, nr, ncclDouble, p.rank, S.comm, S.stream));
+        so += ns; ro += nr;
+    }
+    NCCLC(ncclGroupEnd());
+    evp_launch_march_unpack_mask(B.mask, B.recv_midx, PL.n_recv, B.recvbuf, S.stream);
+    return 0;
+}
+
+// max over ranks of a device counter (the ranks must take the same path)
+static int agree_max(unsigned &v)
+{
+    if (!PL.peers.empty() && S.d.nranks > 1) NCCLC(ncclAllReduce(B.bad, B.bad, 1, ncclUint32, ncclMax, S.comm, S.stream));
+    HIPC(hipMemcpyAsync(&v, B.bad, sizeof v, hipMemcpyDeviceToHost, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
     return 0;
 }
@@ -203,12 +247,13 @@ static int march_statics()
     const int slot[5] = {C_DXT, C_DYT, C_HTE, C_HTN, C_UAREAR};
     for (int k = 0; k < 5; ++k) G.add(src[k], B.cst, nullptr, EVP_MARCH_C_NF, slot[k]);
     evp_launch_march_gather(M.G, G.T, nullptr, nullptr, S.stream);
+    if (march_exchange(B.cst, nullptr, EVP_MARCH_C_NF)) return -1;      // (the per-call slots travel too: overwritten at every call)
     TabBuilder C;              // dxT dyT (fringe) | HTE HTN (fringe + column ilo-1 / row jlo-1)
     for (int k = 0; k < 4; ++k) C.add(src[k], B.cst, nullptr, EVP_MARCH_C_NF, slot[k]);
     HIPC(hipMemsetAsync(B.bad, 0, sizeof(unsigned), S.stream));
     evp_launch_march_check(M.G, C.T, nullptr, nullptr, 0, 2, B.bad, S.stream);
     unsigned bad = 0;
-    if (read_bad(bad)) return -1;
+    if (agree_max(bad)) return -1;
     M.stat_ok = bad == 0;
     M.stat_done = true;
     return 0;
@@ -223,14 +268,31 @@ bool march_wanted()
     const int want = env("CICE_EVP_HIP_MARCH") ? std::atoi(env("CICE_EVP_HIP_MARCH")) : -1;
     if (want == 0) return false;
     std::string why;
-    if (!march_geometry(why)) {
+    bool ok = march_geometry(why);
+    if (S.d.nranks > 1 && S.have_comm) {
+        // the choice must be the same on every rank (what decides it is partly local: e.g. whether the metric terms can be
+        // recomputed from the edge lengths is verified on each rank's own cells)
+        int *dflag = nullptr;
+        int h = ok ? 1 : 0;
+        if (hipMalloc((void **)&dflag, sizeof(int)) != hipSuccess) return false;
+        bool fine = hipMemcpyAsync(dflag, &h, sizeof h, hipMemcpyHostToDevice, S.stream) == hipSuccess &&
+                    ncclAllReduce(dflag, dflag, 1, ncclInt32, ncclMin, S.comm, S.stream) == ncclSuccess &&
+                    hipMemcpyAsync(&h, dflag, sizeof h, hipMemcpyDeviceToHost, S.stream) == hipSuccess &&
+                    hipStreamSynchronize(S.stream) == hipSuccess;
+        (void)hipFree(dflag);
+        if (ok && (!fine || !h)) { ok = false; why = "another rank cannot use it"; }
+    } else if (S.d.nranks > 1) {
+        ok = false;
+        if (why.empty()) why = "several ranks without an RCCL communicator";
+    }
+    if (!ok) {
         M.why = why;
         if (env("CICE_EVP_HIP_VERBOSE")) std::fprintf(stderr, "[cice_evp_hip] two-subcycle kernel off: %s\n", why.c_str());
         return false;
     }
     // worth it when the domain is far beyond what stays on the chip (the on-chip resident kernel is chosen before this
     // is asked): from ~1M cells the strips fill the GPU
-    if (want < 0 && (long)M.G.nxr * M.G.nyr < 1000000L) { M.why = "domain below 1M cells"; return false; }
+    if (want < 0 && (long)S.d.nx_global * S.d.ny_global < 1000000L * std::max(1, (int)S.d.nranks)) { M.why = "below 1M cells per rank"; return false; }
     M.mode = 1;
     return true;
 }
@@ -300,8 +362,14 @@ int march_run(int ndte)
             G.add(S.in[F_UVEL_INIT], B.opt, nullptr, EVP_MARCH_O_NF, O_UINIT); G.add(S.in[F_VVEL_INIT], B.opt, nullptr, EVP_MARCH_O_NF, O_VINIT);
         }
         evp_launch_march_gather(M.G, G.T, S.mask, B.mask, S.stream);
+        // the two-cell ring of everything: other ranks' cells (once per call for the constants and the mask)
+        if (march_exchange(B.cst, nullptr, EVP_MARCH_C_NF)) return -1;
+        const bool need_opt = !(fl & EVP_F_WATER_IS_OCN) || !(fl & EVP_F_TBU_ZERO) || S.prm.revp != 0.0;
+        if (need_opt && march_exchange(B.opt, nullptr, EVP_MARCH_O_NF)) return -1;
+        if (march_exchange_mask()) return -1;
+        if (march_exchange(B.st[0], B.st[1], EVP_MARCH_S_NF)) return -1;
     }
-    if (M.checked_seq != S.upload_seq) {
+    if (M.checked_seq != S.upload_seq || !PL.peers.empty()) {
         // first call on this uploaded state: are the caller's ghost values images of one global state?
         TabBuilder C;
         C.add(S.u[cur], B.st[0], nullptr, EVP_MARCH_S_NF, 0);
@@ -311,8 +379,8 @@ int march_run(int ndte)
         HIPC(hipMemsetAsync(B.bad, 0, sizeof(unsigned), S.stream));
         evp_launch_march_check(M.G, C.T, S.mask, B.mask, 2, 13, B.bad, S.stream);
         unsigned bad = 0;
-        if (read_bad(bad)) return -1;
-        if (bad) return fallback("ghost cells of the uploaded state are not images of one global state");
+        if (agree_max(bad)) return -1;
+        if (bad) return fallback("ghost cells of the uploaded state are not images of one global state (here or on another rank)");
         M.checked_seq = S.upload_seq;
     }
     // ---- the passes ----
@@ -323,6 +391,7 @@ int march_run(int ndte)
         march_args(A, rc, k == npass - 1);
         evp_launch_march(A, S.prm.strict != 0, cap_mode(), S.stream);
         rc ^= 1;
+        if (march_exchange(B.st[rc], nullptr, EVP_MARCH_S_NF)) return -1;      // the ring of the new state (also feeds the way back)
     }
     HIPC(hipGetLastError());
     M.passes += npass;
@@ -341,3 +410,34 @@ int march_run(int ndte)
 }
 
 }  // namespace evp_host
+
+// Host-only: the plan of dims->rank without touching a device (CPU tests).
+extern "C" int cice_evp_hip_march_plan(const cice_evp_hip_dims *dims, int32_t own_max, int32_t wrap_inside, int32_t *geo10,
+                                       int32_t *peer_rank, int32_t *peer_nsend, int32_t *peer_nrecv, int32_t *send_pos,
+                                       int32_t *recv_pos1, int32_t *recv_pos2)
+{
+    using namespace evp_host;
+    if (!dims) return fail(-1, "null dims");
+    MarchPlan P;
+    if (!build_march_plan(*dims, own_max > 0 ? own_max : EVP_MARCH_OWN, wrap_inside != 0, P)) return fail(-3, "march plan: %s", P.error.c_str());
+    if (geo10) {
+        const int32_t g[10] = {P.me.gx0, P.me.gy0, P.me.nxr, P.me.nyr, P.me.own, P.me.nstrips, (int32_t)P.peers.size(), P.n_send,
+                               P.n_recv, P.wrapx ? 1 : 0};
+        for (int k = 0; k < 10; ++k) geo10[k] = g[k];
+    }
+    size_t so = 0, ro = 0;
+    for (size_t q = 0; q < P.peers.size(); ++q) {
+        const MarchPeer &p = P.peers[q];
+        if (peer_rank) peer_rank[q] = p.rank;
+        if (peer_nsend) peer_nsend[q] = (int32_t)p.send_pos.size();
+        if (peer_nrecv) peer_nrecv[q] = (int32_t)p.recv_pos1.size();
+        for (size_t k = 0; k < p.send_pos.size(); ++k)
+            if (send_pos) send_pos[so + k] = p.send_pos[k];
+        for (size_t k = 0; k < p.recv_pos1.size(); ++k) {
+            if (recv_pos1) recv_pos1[ro + k] = p.recv_pos1[k];
+            if (recv_pos2) recv_pos2[ro + k] = p.recv_pos2[k];
+        }
+        so += p.send_pos.size(); ro += p.recv_pos1.size();
+    }
+    return 0;
+}

@@ -379,7 +379,10 @@ __device__ __forceinline__ CellMap block_to_packed(const EvpMarchGeo &G, int b, 
     cell_to_packed(G, xs, ys, c.blk, c.lane);
     c.em = (ys + EVP_MARCH_PAD) * G.ldx + EVP_MARCH_PAD + xs;
     c.ok = c.lane >= 0 && c.lane < 64;
-    c.live = c.ok && xs >= 0 && xs < G.nxr && ys >= 0 && ys < G.nyr;
+    // live: the position holds a real cell of the GLOBAL domain -- one of this rank's, or (two-cell ring kept current by
+    // the exchange) one of another rank's
+    const int gx = G.gx0 + xs, gy = G.gy0 + ys;
+    c.live = c.ok && gy >= 0 && gy < G.nyg && ((gx >= 0 && gx < G.nxg) || G.ew_cyclic);
     return c;
 }
 
@@ -487,6 +490,46 @@ __global__ __launch_bounds__(256) void march_scatter(EvpMarchGeo G, EvpMarchTab 
         for (int f = nuv + nsig; f < T.n; ++f) T.blk[f][s] = pk(f);
 }
 
+// ---- the two-cell ring between ranks (march_plan.h): list-driven pack / unpack around ncclSend / ncclRecv ----
+__global__ __launch_bounds__(256) void march_pack(const double *__restrict__ buf, int nf, const int *__restrict__ pos, int n,
+                                                  double *__restrict__ out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * nf) return;
+    const int e = t / nf, f = t - e * nf, p = pos[e];
+    out[t] = buf[((size_t)(p >> 6) * nf + f) * 64 + (p & 63)];
+}
+__global__ __launch_bounds__(256) void march_unpack(double *__restrict__ buf, double *__restrict__ buf2, int nf,
+                                                    const int *__restrict__ pos1, const int *__restrict__ pos2, int n,
+                                                    const double *__restrict__ in)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * nf) return;
+    const int e = t / nf, f = t - e * nf;
+    const double v = in[t];
+    const int p = pos1[e], q = pos2[e];
+    const size_t e1 = ((size_t)(p >> 6) * nf + f) * 64 + (p & 63);
+    buf[e1] = v;
+    if (buf2) buf2[e1] = v;
+    if (q >= 0) {                                    // the column's duplicate in the neighbouring strip's block
+        const size_t e2 = ((size_t)(q >> 6) * nf + f) * 64 + (q & 63);
+        buf[e2] = v;
+        if (buf2) buf2[e2] = v;
+    }
+}
+__global__ __launch_bounds__(256) void march_pack_mask(const uint8_t *__restrict__ mask, const int *__restrict__ idx, int n,
+                                                       double *__restrict__ out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) out[t] = (double)mask[idx[t]];
+}
+__global__ __launch_bounds__(256) void march_unpack_mask(uint8_t *__restrict__ mask, const int *__restrict__ idx, int n,
+                                                         const double *__restrict__ in)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) mask[idx[t]] = (uint8_t)in[t];
+}
+
 }  // namespace
 
 void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
@@ -535,4 +578,22 @@ void evp_launch_march_scatter(const EvpMarchGeo &G, const EvpMarchTab &T, const 
 {
     hipLaunchKernelGGL(march_scatter, dim3((unsigned)((G.nxb + 255) / 256), (unsigned)G.nyb, (unsigned)G.nblocks),
                        dim3(256), 0, st, G, T, mask_blk, nuv, nsig);
+}
+
+void evp_launch_march_pack(const double *buf, int nf, const int *pos, int n, double *out, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(march_pack, dim3((unsigned)(((size_t)n * nf + 255) / 256)), dim3(256), 0, st, buf, nf, pos, n, out);
+}
+void evp_launch_march_unpack(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const double *in,
+                             hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(march_unpack, dim3((unsigned)(((size_t)n * nf + 255) / 256)), dim3(256), 0, st, buf, buf2, nf, pos1, pos2, n, in);
+}
+void evp_launch_march_pack_mask(const uint8_t *mask, const int *idx, int n, double *out, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(march_pack_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mask, idx, n, out);
+}
+void evp_launch_march_unpack_mask(uint8_t *mask, const int *idx, int n, const double *in, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(march_unpack_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mask, idx, n, in);
 }

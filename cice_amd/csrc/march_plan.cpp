@@ -1,0 +1,158 @@
+// Host-only geometry and exchange plan of the two-subcycles-per-pass path: see march_plan.h.
+#include "march_plan.h"
+
+#include <algorithm>
+#include <map>
+
+namespace {
+
+struct Blk { int gi0, gj0, gnx, gny, owner; };
+
+// column x of a rank's rectangle (may lie up to two cells beyond it) -> (strip, lane) that holds it
+inline void column_home(int x, int own, int nstrips, int &s, int &l)
+{
+    s = std::min(std::max(x, 0) / own, nstrips - 1);
+    l = x - s * own + 2;
+}
+
+// duplicates of the owner lanes of a rank with `nxr` columns in strips of `own`: -1, or (strip << 8) | lane.
+// false: some column would need two duplicates (then a narrower strip is tried)
+bool dup_table(int nxr, int own, bool wrapx, std::vector<int32_t> &dup)
+{
+    const int ns = (nxr + own - 1) / own;
+    dup.assign((size_t)ns * 64, -1);
+    for (int sb = 0; sb < ns; ++sb) {
+        const int cnt = std::min(own, nxr - sb * own);       // columns strip sb owns: lanes 2 .. cnt+1
+        for (int l = 0; l < 64; ++l) {
+            if (l >= 2 && l < 2 + cnt) continue;             // an owner
+            if (!(l < 2 || l < 4 + cnt)) continue;           // beyond the two overlap lanes: nothing reads it
+            int x = sb * own - 2 + l;
+            if (wrapx) { if (x < 0) x += nxr; else if (x >= nxr) x -= nxr; }
+            if (x < 0 || x >= nxr) continue;                 // a halo column beyond the rectangle: filled by the exchange
+            const int so = x / own, lo = 2 + x % own;        // its owner
+            int32_t &slot = dup[(size_t)so * 64 + lo];
+            if (slot != -1) return false;
+            slot = (sb << 8) | l;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside, MarchPlan &P)
+{
+    P = MarchPlan();
+    const int me = d.rank;
+    const int NX = d.nx_global, NY = d.ny_global;
+    if (d.nghost != 1) { P.error = "nghost != 1"; return false; }
+    if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE || d.ns_boundary_type == CICE_EVP_BND_CYCLIC) {
+        P.error = "north-south boundary is not closed";
+        return false;
+    }
+    const bool ew_cyclic = d.ew_boundary_type == CICE_EVP_BND_CYCLIC;
+    std::vector<Blk> blk;
+    if (d.gi0 != nullptr && d.nblocks_tot > 0) {
+        for (int k = 0; k < d.nblocks_tot; ++k) blk.push_back({d.gi0[k] - 1, d.gj0[k] - 1, d.gnx[k], d.gny[k], d.gowner[k]});
+    } else {
+        if (d.nranks != 1) { P.error = "global block table required when nranks > 1"; return false; }
+        for (int b = 0; b < d.nblocks; ++b)
+            blk.push_back({d.iglob0[b] - 1, d.jglob0[b] - 1, d.ihi[b] - d.ilo[b] + 1, d.jhi[b] - d.jlo[b] + 1, me});
+    }
+    // every rank's rectangle
+    const int nranks = std::max(1, (int)d.nranks);
+    P.all.assign(nranks, MarchRect());
+    std::vector<long> area(nranks, 0);
+    std::vector<int> x0(nranks, 1 << 30), y0(nranks, 1 << 30), x1(nranks, -1), y1(nranks, -1);
+    for (const Blk &b : blk) {
+        if (b.owner < 0) { P.error = "eliminated land blocks: the ranks' sub-domains are not rectangles"; return false; }
+        if (b.owner >= nranks) { P.error = "block owner out of range"; return false; }
+        area[b.owner] += (long)b.gnx * b.gny;
+        x0[b.owner] = std::min(x0[b.owner], b.gi0); y0[b.owner] = std::min(y0[b.owner], b.gj0);
+        x1[b.owner] = std::max(x1[b.owner], b.gi0 + b.gnx - 1); y1[b.owner] = std::max(y1[b.owner], b.gj0 + b.gny - 1);
+    }
+    own_max = std::min(60, std::max(4, own_max));
+    for (int r = 0; r < nranks; ++r) {
+        if (area[r] == 0) continue;
+        MarchRect &R = P.all[r];
+        R.gx0 = x0[r]; R.gy0 = y0[r]; R.nxr = x1[r] - x0[r] + 1; R.nyr = y1[r] - y0[r] + 1;
+        if ((long)R.nxr * R.nyr != area[r]) { P.error = "a rank's blocks do not tile a rectangle"; return false; }
+        if (R.nxr < 4 || R.nyr < 1) { P.error = "a rank's rectangle is too small"; return false; }
+        R.ok = true;
+    }
+    if (!P.all[me].ok) { P.error = "this rank holds no blocks"; return false; }
+    P.me = P.all[me];
+    P.wrapx = wrap_inside && ew_cyclic && P.me.nxr == NX;
+    // strips: the widest `own` for which every column of this rank has at most one duplicate
+    bool found = false;
+    for (int own = own_max; own >= 4 && !found; --own)
+        if (dup_table(P.me.nxr, own, P.wrapx, P.dup)) { P.me.own = own; found = true; }
+    if (!found) { P.error = "no strip width gives every column a single duplicate"; return false; }
+    P.me.nstrips = (P.me.nxr + P.me.own - 1) / P.me.own;
+    P.all[me] = P.me;
+
+    auto owner_of = [&](int gx, int gy) -> int {
+        for (int r = 0; r < nranks; ++r) {
+            const MarchRect &R = P.all[r];
+            if (R.ok && gx >= R.gx0 && gx < R.gx0 + R.nxr && gy >= R.gy0 && gy < R.gy0 + R.nyr) return r;
+        }
+        return -1;
+    };
+    std::map<int, MarchPeer> peers;
+    const MarchRect &M = P.me;
+    for (int D = 0; D < nranks; ++D) {
+        const MarchRect &R = P.all[D];
+        if (!R.ok) continue;
+        const bool Dwrap = wrap_inside && ew_cyclic && R.nxr == NX;       // rank D wraps inside
+        for (int y = -2; y < R.nyr + 2; ++y)
+            for (int x = -2; x < R.nxr + 2; ++x) {
+                if (x >= 0 && x < R.nxr && y >= 0 && y < R.nyr) continue;
+                int gx = R.gx0 + x;
+                const int gy = R.gy0 + y;
+                if (gy < 0 || gy >= NY) continue;                          // closed north / south
+                if (gx < 0 || gx >= NX) {
+                    if (!ew_cyclic) continue;
+                    if (Dwrap && y >= 0 && y < R.nyr) continue;            // D reads those columns from its own strips
+                    gx = (gx + NX) % NX;
+                }
+                const int S = owner_of(gx, gy);
+                if (S < 0) continue;
+                if (Dwrap && S == D && (x < 0 || x >= R.nxr)) {
+                    // corner of a rank that wraps inside: its halo ROWS are exchanged with the ranks above / below, and
+                    // the columns beyond the seam in those rows are images of columns of the same halo row -- handled
+                    // by the wrap of the strips as well (nobody stores there)
+                    continue;
+                }
+                if (D == me) {
+                    MarchPeer &p = peers[S];
+                    p.rank = S;
+                    int s, l;
+                    column_home(x, M.own, M.nstrips, s, l);
+                    const int row = y + MARCH_PLAN_PAD;
+                    p.recv_pos1.push_back((int32_t)(((long)row * M.nstrips + s) * 64 + l));
+                    int32_t p2 = -1;
+                    if (x >= 0 && x < M.nxr) {
+                        const int32_t dd = P.dup[(size_t)s * 64 + l];
+                        if (dd >= 0) p2 = (int32_t)(((long)row * M.nstrips + (dd >> 8)) * 64 + (dd & 255));
+                    }
+                    p.recv_pos2.push_back(p2);
+                    p.recv_col.push_back(x);
+                    p.recv_row.push_back(row);
+                }
+                if (S == me) {
+                    MarchPeer &p = peers[D];
+                    p.rank = D;
+                    const int xs = gx - M.gx0, ys = gy - M.gy0;            // the source cell in my rectangle
+                    const int s = xs / M.own, l = 2 + xs % M.own;
+                    p.send_pos.push_back((int32_t)(((long)(ys + MARCH_PLAN_PAD) * M.nstrips + s) * 64 + l));
+                    p.send_col.push_back(xs);
+                }
+            }
+    }
+    for (auto &kv : peers) {
+        P.n_send += (int)kv.second.send_pos.size();
+        P.n_recv += (int)kv.second.recv_pos1.size();
+        P.peers.push_back(kv.second);
+    }
+    return true;
+}

@@ -42,7 +42,7 @@ EXPORTS = [
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
-    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
     "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
@@ -452,6 +452,23 @@ class EvpHip:
             self.finalize()
         except Exception:
             pass
+
+
+def march_plan(dims: Dims, own_max: int = 0, wrap_inside: bool = True) -> dict:
+    """Host-only geometry + exchange lists of the two-subcycle path for `dims.rank` (CPU tests)."""
+    lib = load_library()
+    geo = np.zeros(10, dtype=np.int32)
+    _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), _ip(geo), None, None, None, None, None, None),
+           "(march_plan)")
+    npeer, ns, nr = int(geo[6]), int(geo[7]), int(geo[8])
+    pr, pns, pnr = [np.zeros(max(npeer, 1), dtype=np.int32) for _ in range(3)]
+    sp = np.zeros(max(ns, 1), dtype=np.int32)
+    r1, r2 = [np.zeros(max(nr, 1), dtype=np.int32) for _ in range(2)]
+    _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), _ip(geo), _ip(pr), _ip(pns), _ip(pnr), _ip(sp),
+                                            _ip(r1), _ip(r2)), "(march_plan)")
+    return dict(gx0=int(geo[0]), gy0=int(geo[1]), nxr=int(geo[2]), nyr=int(geo[3]), own=int(geo[4]), nstrips=int(geo[5]),
+                wrapx=bool(geo[9]), peer_rank=pr[:npeer], peer_nsend=pns[:npeer], peer_nrecv=pnr[:npeer], send_pos=sp[:ns],
+                recv_pos1=r1[:nr], recv_pos2=r2[:nr])
 
 
 def halo_plan(dims: Dims) -> dict:

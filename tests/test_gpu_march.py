@@ -122,6 +122,34 @@ def test_march_random_masks_vs_oracle(seed, grid, bs, holes, march):
     assert_bitwise(got, want, f"march, random masks seed {seed}")
 
 
+@pytest.mark.parametrize("grid,case,bs,seg,own", [("gx3", "full", None, 0, 0), ("gx3", "caps", (25, 29), 9, 17), ("gx1", "full", None, 40, 0)])
+def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg, own, march):
+    """Several ranks: every pass is followed by an exchange of the two-cell ring (pack -> ncclSend / ncclRecv -> unpack,
+    duplicates included; march_plan.cpp).  One GPU can run all of it by treating the cyclic seam of the domain as a rank
+    boundary -- the rank is its own east and west neighbour (CICE_EVP_HIP_MARCH_SELFX=1): no wrap inside the strips, the
+    halo columns live on what RCCL delivers.  Against the oracle, bit for bit; the list logic for 2 and 4 ranks is
+    tests/test_multirank_cpu.py::test_march_two_cell_ring_between_ranks_known_answer."""
+    march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
+    if seg:
+        march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
+    if own:
+        march.setenv("CICE_EVP_HIP_MARCH_OWN", str(own))
+    dc, geo, fields, tm, um = synth_case(grid, case, seed=8, warm=True, bs=bs)
+    scal = synth.evp_scalars(120)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        core.comm_init(core.comm_unique_id())
+        got = core.run(fields, tm, um, ndte=12)
+        info = core.march_info()
+        assert info["mode"] == 1 and info["last_call"] and info["passes"] == 6, info
+    finally:
+        core.finalize()
+    want = run_oracle(dc, geo, fields, tm, um, scal, 12)
+    assert_bitwise(got, want, f"{grid}/{case}: march, seam through RCCL")
+
+
 def test_march_declines_a_state_whose_ghost_cells_are_not_images(march):
     """The rectangle holds every cell once; the reference keeps per-block ghost storage and computes the T-cells of the
     north / east fringe from it.  A caller whose ghost values differ from the cells they image (here: ice punched out

@@ -322,3 +322,104 @@ def test_cgrid_loop_split_over_ranks_known_answer(case):
     for rank, nbad, ncalls, umax in sorted(res):
         assert nbad == 0, f"rank {rank}: {nbad} values differ from the single-rank run"
         assert ncalls == 5 * 12 and umax > 1e-3         # 12 fields exchanged per subcycle (eight ice_HaloUpdate calls)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Two-subcycles-per-pass path (cice_amd/csrc/evp_march.hip): the exchange of the TWO-cell ring between the ranks'
+# rectangles (march_plan.cpp), once per pass.  world_size-2/4 gloo processes: every rank builds its plan from the
+# global block table alone, packs, exchanges point-to-point, unpacks -- the known answer is the global cell number.
+# ---------------------------------------------------------------------------------------------------------------
+MARCH_CASES = [
+    # nx, ny, bx, by, ew, nranks, proc_shape, own_max, wrap_inside
+    (130, 40, 65, 40, "cyclic", 2, (2, 1), 60, True),      # x split: the cyclic seam and the inner cut, both between ranks
+    (130, 40, 130, 20, "cyclic", 2, (1, 2), 60, True),     # y slabs: every rank wraps inside and trades halo ROWS (duplicates!)
+    (96, 48, 48, 24, "cyclic", 4, (2, 2), 20, True),       # 2 x 2, narrow strips, corner cells from the diagonal neighbour
+    (96, 48, 24, 24, "closed", 4, (2, 2), 60, True),       # closed E-W, two blocks per rank
+    (75, 30, 75, 15, "cyclic", 2, (1, 2), 60, False),      # test hook: the cyclic seam exchanged with the rank itself
+]
+
+
+def _march_worker(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nx, ny, bx, by, ew, nranks, shape, own_max, wrap_inside = case
+        dc = decomp.Decomp(nx, ny, bx, by, ew, "closed", nranks, shape)
+        d, keep = evp.make_dims(dc, rank)
+        P = evp.march_plan(d, own_max, wrap_inside)
+        own, ns, nxr, nyr, gx0, gy0 = P["own"], P["nstrips"], P["nxr"], P["nyr"], P["gx0"], P["gy0"]
+        rows = nyr + 4
+
+        def home(x, y):            # where the rank holds column x (may lie two cells beyond the rectangle), row y
+            s = min(max(x, 0) // own, ns - 1)
+            return ((y + 2) * ns + s) * 64 + (x - s * own + 2)
+
+        buf = np.full(rows * ns * 64, -1.0)
+        for y in range(nyr):
+            for x in range(nxr):
+                buf[home(x, y)] = (gy0 + y) * nx + (gx0 + x)
+        sendbuf = torch.from_numpy(buf[P["send_pos"]].copy())
+        assert (sendbuf >= 0).all(), "a send entry that is not an owned cell"
+        recvbuf = torch.zeros(len(P["recv_pos1"]), dtype=torch.float64)
+        ops, so, ro, selfcopy = [], 0, 0, None
+        for p, ns_, nr_ in zip(P["peer_rank"], P["peer_nsend"], P["peer_nrecv"]):
+            if int(p) == rank:     # the rank itself (seam exchanged with itself): same order on both sides by construction
+                assert ns_ == nr_
+                selfcopy = (so, ro, int(ns_))
+            else:
+                if ns_:
+                    ops.append(dist.P2POp(dist.isend, sendbuf[so:so + ns_], int(p)))
+                if nr_:
+                    ops.append(dist.P2POp(dist.irecv, recvbuf[ro:ro + nr_], int(p)))
+            so += ns_
+            ro += nr_
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if selfcopy:
+            recvbuf[selfcopy[1]:selfcopy[1] + selfcopy[2]] = sendbuf[selfcopy[0]:selfcopy[0] + selfcopy[2]]
+        buf[P["recv_pos1"]] = recvbuf.numpy()
+        has2 = P["recv_pos2"] >= 0
+        buf[P["recv_pos2"][has2]] = recvbuf.numpy()[has2]
+        # known answer: every cell of the two-cell ring that exists in the global domain
+        nbad = nring = 0
+        for y in range(-2, nyr + 2):
+            for x in range(-2, nxr + 2):
+                if 0 <= x < nxr and 0 <= y < nyr:
+                    continue
+                gx, gy = gx0 + x, gy0 + y
+                if not (0 <= gy < ny):
+                    continue
+                if not (0 <= gx < nx):
+                    if ew != "cyclic":
+                        continue
+                    if P["wrapx"]:
+                        continue       # read through the wrap of the strips, never stored
+                    gx %= nx
+                nring += 1
+                nbad += int(buf[home(x, y)] != gy * nx + gx)
+        q.put((rank, nbad, nring, int(has2.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", MARCH_CASES)
+def test_march_two_cell_ring_between_ranks_known_answer(case):
+    world = case[5]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_march_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, nbad, nring, ndup in res:
+        assert nbad == 0 and nring > 0, (rank, nbad, nring)
+    if case[8] and case[6][0] == 1:        # y slabs wrapping inside: halo-row cells next to a strip edge have duplicates
+        assert all(r[3] > 0 for r in res)

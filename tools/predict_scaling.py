@@ -4,7 +4,7 @@ timed alone on the GPU with every ghost copy that would cross ranks routed throu
 the rank itself (CICE_EVP_HIP_SELF_EXCHANGE=1).  What a 1-GPU box cannot show is the xGMI hop itself; the table is
 the prediction the first real N > 1 run is to be held against.
 
-  python tools/predict_scaling.py [out.json]
+  python tools/predict_scaling.py [out.json [workload ...]]
 """
 import json
 import os
@@ -25,17 +25,23 @@ WORK = {
 }
 TRANSPORTS = {
     "resident-remote": {"CICE_EVP_HIP_HALO": "direct"},
-    "stream+mailbox": {"CICE_EVP_HIP_HALO": "direct", "CICE_EVP_HIP_RESIDENT": "0"},
-    "stream+rccl": {"CICE_EVP_HIP_HALO": "rccl", "CICE_EVP_HIP_RESIDENT": "0"},
+    "stream+mailbox": {"CICE_EVP_HIP_HALO": "direct", "CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_MARCH": "0"},
+    "stream+rccl": {"CICE_EVP_HIP_HALO": "rccl", "CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_MARCH": "0"},
+    # two subcycles per pass, the two-cell ring exchanged once per pass over RCCL send/recv (here: the E-W seam of the piece,
+    # with the rank itself -- pack, ncclGroup, unpack are those of a real run; a 4x2 piece has two more sides)
+    "march+rccl": {"CICE_EVP_HIP_HALO": "rccl", "CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_MARCH": "1", "CICE_EVP_HIP_MARCH_SELFX": "1"},
 }
-KEYS = ["CICE_EVP_HIP_HALO", "CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_SELF_EXCHANGE"]
+KEYS = ["CICE_EVP_HIP_HALO", "CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_SELF_EXCHANGE", "CICE_EVP_HIP_MARCH", "CICE_EVP_HIP_MARCH_SELFX"]
+
+
+core_info = {}
 
 
 def time_piece(nx, ny, ns, dx0, nsub, envs, selfx):
     for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(envs)
-    if selfx:
+    if selfx and "CICE_EVP_HIP_MARCH_SELFX" not in envs:
         os.environ["CICE_EVP_HIP_SELF_EXCHANGE"] = "1"
     g = synth.derive_geometry(synth.make_grid(nx, ny, dx0, ns=ns))
     st = synth.make_state(g, case="full", seed=1, warm=True)
@@ -59,6 +65,8 @@ def time_piece(nx, ny, ns, dx0, nsub, envs, selfx):
         core.sync()
         t = (time.perf_counter() - t0) / (reps * nsub)
         tt = core.timings()
+        global core_info
+        core_info = core.march_info()
     finally:
         core.finalize()
     return 1e6 * t, tt
@@ -66,7 +74,10 @@ def time_piece(nx, ny, ns, dx0, nsub, envs, selfx):
 
 def main():
     out = []
+    only = set(sys.argv[2:])
     for wl, (NX, NY, ns, ndte, layouts) in WORK.items():
+        if only and wl not in only:
+            continue
         dx0 = synth.GRIDS[wl]["dx0"]
         for N, shapes in layouts.items():
             for px, py in shapes:
@@ -74,6 +85,8 @@ def main():
                 # a piece below the top row of a tripole grid has closed north/south neighbours here; the top piece keeps the fold
                 for tname, envs in TRANSPORTS.items():
                     if N == 1 and tname != "resident-remote":
+                        continue
+                    if tname == "march+rccl" and wl != "s01":
                         continue
                     nsub = min(ndte, 120) if nx * ny < 500000 else 24
                     try:
@@ -84,7 +97,7 @@ def main():
                         continue
                     rec = dict(workload=wl, n=N, layout=f"{px}x{py}", piece=f"{nx}x{ny}", transport=tname if N > 1 else "none",
                                us_per_subcycle=us, tile_variant=tt["tile_variant"], halo_transport=tt["halo_transport"],
-                               launches_per_subcycle=tt["launches_per_subcycle"], halo_cells=tt["halo_send_cells"],
+                               launches_per_subcycle=tt["launches_per_subcycle"], halo_cells=tt["halo_send_cells"], march=core_info.get("last_call"),
                                predicted_cell_updates_per_s=NX * NY / (us * 1e-6))
                     out.append(rec)
                     print("RESULT", rec, flush=True)
