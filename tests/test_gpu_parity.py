@@ -876,7 +876,7 @@ def test_run_with_page_locked_arrays_and_resident_stresses(name):
         core.finalize()
 
 
-@pytest.mark.parametrize("name", ["pop_cyc_1blk_patchy", "rect_cyc_2x2_full", "trip_cyc_1blk_patchy"])
+@pytest.mark.parametrize("name", ["rect_cyc_2x2_full", "pop_cyc_3x2pad_caps", "trip_cyc_2x2_full"])
 def test_resident_stresses_survive_a_replayed_call(name, monkeypatch):
     """A call of the on-chip resident kernel that gives up (GPU shared with something else) is repeated with the
     streaming kernel.  With the 12 stresses resident on the device the host has no copy of the pre-call stresses and
