@@ -42,9 +42,6 @@
 #ifndef EVP_MARCH_WAVES
 #define EVP_MARCH_WAVES 2
 #endif
-#ifndef EVP_MARCH_PFD
-#define EVP_MARCH_PFD 1          // rows the loads run ahead of their use (2 needs EVP_MARCH_WAVES 1)
-#endif
 
 namespace {
 
@@ -227,23 +224,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EVP_MARCH_W
     double u1_p = 0, v1_p = 0;
     double c2_sx0 = 0, c2_sx1 = 0, c2_sy0 = 0, c2_sy2 = 0;
     UI us_p{};                                                      // momentum operands of U-row r-2 (U1's, one row ago)
-#if EVP_MARCH_PFD == 2
-    // in flight when the loop starts: rows Y0-1 and Y0, the momentum operands of U-row Y0-1, the masks of rows Y0-1 .. Y0+1
-    unsigned m_n = A.mask[em + (unsigned)A.ldx], m_nn = A.mask[em + 2u * (unsigned)A.ldx], m_n3 = A.mask[em + 3u * (unsigned)A.ldx];
-    Row N{}, N2{};
-    UI usN{}, usN2{};
-    load_us(sC, sO, false, usN);
-    load_row(sS + srow, sC + crow, m_n, N);
-    load_us(sC + crow, sO + orow, (m_n & 2u) && lane >= 1 && lane <= 62, usN2);
-    load_row(sS + 2u * srow, sC + 2u * crow, m_nn, N2);
-#else
     // in flight when the loop starts: row Y0-1, momentum operands nobody uses, the masks of rows Y0-1, Y0
     unsigned m_n = A.mask[em + (unsigned)A.ldx], m_nn = A.mask[em + 2u * (unsigned)A.ldx];
     Row N{};
     UI usN{};
     load_us(sC, sO, false, usN);
     load_row(sS + srow, sC + crow, m_n, N);
-#endif
 
     for (int r = Y0 - 1; r <= Y1 + 1; ++r) {
         sS += srow; sC += crow; sO += orow; sD += drow; em += (unsigned)A.ldx;          // blocks of row r
@@ -251,17 +237,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EVP_MARCH_W
         const UI us = usN;                                          // momentum operands of U-row r-1
         const unsigned m = m_n;
         m_n = m_nn;
-#if EVP_MARCH_PFD == 2
-        // TWO rows ahead: what row r+2 consumes is requested now (one wave per SIMD: registers are not the limit)
-        N = N2; usN = usN2;
-        m_nn = m_n3;
-        {
-            const bool isU1n = (m_n & 2u) && lane >= 1 && lane <= 62;
-            load_us(sC + crow, sO + orow, isU1n, usN2);             // U-row r+1
-            m_n3 = A.mask[em + 3u * (unsigned)A.ldx];
-            load_row(sS + 2u * srow, sC + 2u * crow, m_nn, N2);     // row r+2
-        }
-#else
         // everything the NEXT row consumes, requested now
         {
             const bool isU1n = (m & 2u) && lane >= 1 && lane <= 62 && r + 1 >= Y0;
@@ -269,7 +244,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EVP_MARCH_W
             m_nn = A.mask[em + 2u * (unsigned)A.ldx];               // (spare rows on top of the arrays)
             load_row(sS + srow, sC + crow, m_n, N);                 // row r+1
         }
-#endif
 
         // ---- S1: stress(k+1) on T(x, r) ----
         const bool act1 = (m & 1u) && lane >= 1;
