@@ -155,6 +155,7 @@ struct EvpMarchGeo {
     int ilo;                   // first interior index of a block (nghost + 1)
     int wrapx;
     int gx0, gy0, nxg, nyg, ew_cyclic;   // the rectangle in the global index space (0-based), the global domain
+    int ext_w, ext_s, nxo, nyo;          // several ranks: the rank's OWN cells are [ext_w, ext_w+nxo) x [ext_s, ext_s+nyo) of the rectangle
     const int *blkid;          // [nby][nbx] local block index
     const int2 *blk_org;       // [nblocks] rectangle coordinates of the first interior cell
     const int4 *blk;           // [nblocks] ilo ihi jlo jhi

@@ -228,6 +228,7 @@ struct State {
         std::vector<int> blkid_h;
         std::vector<int2> org_h;
         int nstrips = 0, nseg = 0, seglen = 0, nitems = 0;
+        int exch_every = 1;            // passes between two exchanges of the ring (several ranks)
         size_t nblk = 0;               // (row, strip) blocks per buffer
         std::vector<unsigned> dup_h;   // [nstrips][64] duplicate positions (EvpMarch::dup)
         bool stat_done = false, stat_ok = false;

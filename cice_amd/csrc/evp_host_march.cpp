@@ -68,7 +68,11 @@ static bool march_geometry(std::string &why)
     // the rectangles of all ranks, this rank's strips and the exchange lists: the same verdict on every rank
     const int own_max = env("CICE_EVP_HIP_MARCH_OWN") ? std::atoi(env("CICE_EVP_HIP_MARCH_OWN")) : EVP_MARCH_OWN;
     const bool wrap_inside = !(env("CICE_EVP_HIP_MARCH_SELFX") && std::atoi(env("CICE_EVP_HIP_MARCH_SELFX")));
-    if (!build_march_plan(d, own_max, wrap_inside, PL)) { why = PL.error; return false; }
+    // cells a rank holds beyond its own on every side with a neighbour: the ring is then exchanged every (ext/2 + 1)-th
+    // pass only (march_plan.h); 2 = every second pass (every fourth subcycle)
+    const int ext = env("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env("CICE_EVP_HIP_MARCH_EXT")) & ~1) : 2;
+    if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
+    M.exch_every = ext / 2 + 1;
     if (!PL.peers.empty() && !S.have_comm) { why = "cells of other ranks needed but no RCCL communicator (cice_evp_hip_comm_init)"; return false; }
     if (!(S.flags & EVP_F_METRICS) || (S.flags & EVP_F_DXHY_ARRAY)) { why = "metric terms come from arrays"; return false; }
     if (d.nblocks < 1) { why = "no blocks"; return false; }
@@ -99,10 +103,12 @@ static bool march_geometry(std::string &why)
         M.blkid_h[(size_t)bj * nbx + bi] = b;
         M.org_h[b] = int2{ox, oy};
     }
-    if (nxr != PL.me.nxr || nyr != PL.me.nyr || gx0 - 1 != PL.me.gx0 || gy0 - 1 != PL.me.gy0) { why = "local blocks disagree with the global block table"; return false; }
+    if (nxr != PL.owned.nxr || nyr != PL.owned.nyr || gx0 - 1 != PL.owned.gx0 || gy0 - 1 != PL.owned.gy0) { why = "local blocks disagree with the global block table"; return false; }
+    for (auto &o : M.org_h) { o.x += PL.ext_w; o.y += PL.ext_s; }        // block origins in the rectangle the rank HOLDS
     const bool wrapx = PL.wrapx;
     EvpMarchGeo &G = M.G;
-    G.nxr = nxr; G.nyr = nyr;
+    G.nxr = PL.me.nxr; G.nyr = PL.me.nyr;                                  // held: own cells + the redundant rim
+    G.ext_w = PL.ext_w; G.ext_s = PL.ext_s; G.nxo = nxr; G.nyo = nyr;
     G.nxb = d.nx_block; G.nyb = d.ny_block; G.plane = (int)S.plane; G.nblocks = d.nblocks;
     G.bsx = bsx; G.bsy = bsy; G.nbx = nbx; G.nby = nby;
     G.ilo = d.nghost + 1;
@@ -115,7 +121,7 @@ static bool march_geometry(std::string &why)
         if (PL.dup[k] >= 0) M.dup_h[k] = (unsigned)((((size_t)(PL.dup[k] >> 8)) * EVP_MARCH_S_NF * 64 + (PL.dup[k] & 255)) * 8);
     M.nstrips = G.nstrips;
     G.ldx = ((G.nstrips * G.own + 64 + 2 * EVP_MARCH_PAD + 7) / 8) * 8;
-    G.rows = nyr + EVP_MARCH_PAD + 5;          // y = -2 .. nyr+4: halo, two rows the prefetch may touch, the dump row
+    G.rows = G.nyr + EVP_MARCH_PAD + 5;          // y = -2 .. nyr+4: halo, two rows the prefetch may touch, the dump row
     M.nblk = (size_t)G.rows * G.nstrips;
     if (M.nblk * EVP_MARCH_S_NF * 512 >= (1ull << 32)) { why = "state buffer beyond 32-bit byte offsets"; return false; }
     // segments: one wave per SIMD (1024 of them), all resident at once -- measured at 3600 x 2400: 16 segments (960
@@ -123,10 +129,10 @@ static bool march_geometry(std::string &why)
     int seglen = env("CICE_EVP_HIP_MARCH_SEG") ? std::atoi(env("CICE_EVP_HIP_MARCH_SEG")) : 0;
     if (seglen <= 0) {
         const int want_seg = std::max(1, 1000 / M.nstrips);
-        seglen = std::max(16, (nyr + want_seg - 1) / want_seg);
+        seglen = std::max(16, (G.nyr + want_seg - 1) / want_seg);
     }
-    M.seglen = std::min(seglen, nyr);
-    M.nseg = (nyr + M.seglen - 1) / M.seglen;
+    M.seglen = std::min(seglen, G.nyr);
+    M.nseg = (G.nyr + M.seglen - 1) / M.seglen;
     M.nitems = M.nseg * M.nstrips;
     return true;
 }
@@ -391,7 +397,10 @@ int march_run(int ndte)
         march_args(A, rc, k == npass - 1);
         evp_launch_march(A, S.prm.strict != 0, cap_mode(), S.stream);
         rc ^= 1;
-        if (march_exchange(B.st[rc], nullptr, EVP_MARCH_S_NF)) return -1;      // the ring of the new state (also feeds the way back)
+        // the ring of the new state: after every exch_every-th pass (the redundant rim has been used up) and after the last
+        // one (the way back to the block layout reads the ghost cells from it)
+        if ((k + 1) % M.exch_every == 0 || k == npass - 1)
+            if (march_exchange(B.st[rc], nullptr, EVP_MARCH_S_NF)) return -1;
     }
     HIPC(hipGetLastError());
     M.passes += npass;
@@ -412,18 +421,18 @@ int march_run(int ndte)
 }  // namespace evp_host
 
 // Host-only: the plan of dims->rank without touching a device (CPU tests).
-extern "C" int cice_evp_hip_march_plan(const cice_evp_hip_dims *dims, int32_t own_max, int32_t wrap_inside, int32_t *geo10,
+extern "C" int cice_evp_hip_march_plan(const cice_evp_hip_dims *dims, int32_t own_max, int32_t wrap_inside, int32_t ext, int32_t *geo14,
                                        int32_t *peer_rank, int32_t *peer_nsend, int32_t *peer_nrecv, int32_t *send_pos,
                                        int32_t *recv_pos1, int32_t *recv_pos2)
 {
     using namespace evp_host;
     if (!dims) return fail(-1, "null dims");
     MarchPlan P;
-    if (!build_march_plan(*dims, own_max > 0 ? own_max : EVP_MARCH_OWN, wrap_inside != 0, P)) return fail(-3, "march plan: %s", P.error.c_str());
-    if (geo10) {
-        const int32_t g[10] = {P.me.gx0, P.me.gy0, P.me.nxr, P.me.nyr, P.me.own, P.me.nstrips, (int32_t)P.peers.size(), P.n_send,
-                               P.n_recv, P.wrapx ? 1 : 0};
-        for (int k = 0; k < 10; ++k) geo10[k] = g[k];
+    if (!build_march_plan(*dims, own_max > 0 ? own_max : EVP_MARCH_OWN, wrap_inside != 0, ext, P)) return fail(-3, "march plan: %s", P.error.c_str());
+    if (geo14) {
+        const int32_t g[14] = {P.me.gx0, P.me.gy0, P.me.nxr, P.me.nyr, P.me.own, P.me.nstrips, (int32_t)P.peers.size(), P.n_send,
+                               P.n_recv, P.wrapx ? 1 : 0, P.ext_w, P.ext_e, P.ext_s, P.ext_n};
+        for (int k = 0; k < 14; ++k) geo14[k] = g[k];
     }
     size_t so = 0, ro = 0;
     for (size_t q = 0; q < P.peers.size(); ++q) {

@@ -392,10 +392,10 @@ __device__ __forceinline__ CellMap block_to_packed(const EvpMarchGeo &G, int b, 
 // ice_dyn_evp.F90:867)
 __device__ __forceinline__ int rect_to_block(const EvpMarchGeo &G, int x, int y, bool &is_cell)
 {
-    int xs = x, ys = y;
-    if (G.wrapx) { if (xs < 0) xs += G.nxr; else if (xs >= G.nxr) xs -= G.nxr; }
-    is_cell = xs >= 0 && xs < G.nxr && ys >= 0 && ys < G.nyr;
-    if (xs < -1 || xs > G.nxr || ys < -1 || ys > G.nyr) return -1;
+    int xs = x - G.ext_w, ys = y - G.ext_s;          // relative to the rank's own cells
+    if (G.wrapx) { if (xs < 0) xs += G.nxo; else if (xs >= G.nxo) xs -= G.nxo; }
+    is_cell = xs >= 0 && xs < G.nxo && ys >= 0 && ys < G.nyo;
+    if (xs < -1 || xs > G.nxo || ys < -1 || ys > G.nyo) return -1;
     const int bi = min(max(xs, 0) / G.bsx, G.nbx - 1), bj = min(max(ys, 0) / G.bsy, G.nby - 1);
     const int b = G.blkid[bj * G.nbx + bi];
     if (b < 0) return -1;

@@ -40,7 +40,7 @@ bool dup_table(int nxr, int own, bool wrapx, std::vector<int32_t> &dup)
 
 }  // namespace
 
-bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside, MarchPlan &P)
+bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside, int ext, MarchPlan &P)
 {
     P = MarchPlan();
     const int me = d.rank;
@@ -81,15 +81,34 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
         R.ok = true;
     }
     if (!P.all[me].ok) { P.error = "this rank holds no blocks"; return false; }
-    P.me = P.all[me];
-    P.wrapx = wrap_inside && ew_cyclic && P.me.nxr == NX;
+    if (ext < 0 || (ext & 1)) { P.error = "ext must be even and >= 0"; return false; }
+    // the rectangle a rank holds = its own cells + ext on every side with a neighbour (the same rule for every rank)
+    struct Held { MarchRect E; int w, e, s, n; bool wrap; };
+    auto held = [&](int r) -> Held {
+        const MarchRect &R = P.all[r];
+        Held H{R, 0, 0, 0, 0, false};
+        H.wrap = wrap_inside && ew_cyclic && R.nxr == NX;                   // wraps inside: no neighbour in x
+        if (!H.wrap) {
+            if (R.gx0 > 0 || ew_cyclic) H.w = ext;
+            if (R.gx0 + R.nxr < NX || ew_cyclic) H.e = ext;
+        }
+        if (R.gy0 > 0) H.s = ext;
+        if (R.gy0 + R.nyr < NY) H.n = ext;
+        H.E.gx0 = R.gx0 - H.w; H.E.gy0 = R.gy0 - H.s;
+        H.E.nxr = R.nxr + H.w + H.e; H.E.nyr = R.nyr + H.s + H.n;
+        return H;
+    };
+    const Held HM = held(me);
+    P.owned = P.all[me];
+    P.me = HM.E;
+    P.ext_w = HM.w; P.ext_e = HM.e; P.ext_s = HM.s; P.ext_n = HM.n;
+    P.wrapx = HM.wrap;
     // strips: the widest `own` for which every column of this rank has at most one duplicate
     bool found = false;
     for (int own = own_max; own >= 4 && !found; --own)
         if (dup_table(P.me.nxr, own, P.wrapx, P.dup)) { P.me.own = own; found = true; }
     if (!found) { P.error = "no strip width gives every column a single duplicate"; return false; }
     P.me.nstrips = (P.me.nxr + P.me.own - 1) / P.me.own;
-    P.all[me] = P.me;
 
     auto owner_of = [&](int gx, int gy) -> int {
         for (int r = 0; r < nranks; ++r) {
@@ -101,28 +120,23 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
     std::map<int, MarchPeer> peers;
     const MarchRect &M = P.me;
     for (int D = 0; D < nranks; ++D) {
-        const MarchRect &R = P.all[D];
-        if (!R.ok) continue;
-        const bool Dwrap = wrap_inside && ew_cyclic && R.nxr == NX;       // rank D wraps inside
-        for (int y = -2; y < R.nyr + 2; ++y)
-            for (int x = -2; x < R.nxr + 2; ++x) {
-                if (x >= 0 && x < R.nxr && y >= 0 && y < R.nyr) continue;
-                int gx = R.gx0 + x;
-                const int gy = R.gy0 + y;
+        if (!P.all[D].ok) continue;
+        const Held HD = held(D);
+        const MarchRect &E = HD.E;                                          // what D holds; its own cells start at (HD.w, HD.s)
+        for (int y = -2; y < E.nyr + 2; ++y)
+            for (int x = -2; x < E.nxr + 2; ++x) {
+                const bool own_cell = x >= HD.w && x < E.nxr - HD.e && y >= HD.s && y < E.nyr - HD.n;
+                if (own_cell) continue;
+                int gx = E.gx0 + x;
+                const int gy = E.gy0 + y;
                 if (gy < 0 || gy >= NY) continue;                          // closed north / south
                 if (gx < 0 || gx >= NX) {
                     if (!ew_cyclic) continue;
-                    if (Dwrap && y >= 0 && y < R.nyr) continue;            // D reads those columns from its own strips
-                    gx = (gx + NX) % NX;
+                    if (HD.wrap) continue;                                 // D reads those columns through the wrap of its strips
+                    gx = ((gx % NX) + NX) % NX;
                 }
                 const int S = owner_of(gx, gy);
                 if (S < 0) continue;
-                if (Dwrap && S == D && (x < 0 || x >= R.nxr)) {
-                    // corner of a rank that wraps inside: its halo ROWS are exchanged with the ranks above / below, and
-                    // the columns beyond the seam in those rows are images of columns of the same halo row -- handled
-                    // by the wrap of the strips as well (nobody stores there)
-                    continue;
-                }
                 if (D == me) {
                     MarchPeer &p = peers[S];
                     p.rank = S;
@@ -142,7 +156,7 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
                 if (S == me) {
                     MarchPeer &p = peers[D];
                     p.rank = D;
-                    const int xs = gx - M.gx0, ys = gy - M.gy0;            // the source cell in my rectangle
+                    const int xs = gx - P.owned.gx0 + HM.w, ys = gy - P.owned.gy0 + HM.s;   // the source cell in what I hold
                     const int s = xs / M.own, l = 2 + xs % M.own;
                     p.send_pos.push_back((int32_t)(((long)(ys + MARCH_PLAN_PAD) * M.nstrips + s) * 64 + l));
                     p.send_col.push_back(xs);

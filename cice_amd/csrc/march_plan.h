@@ -39,8 +39,11 @@ struct MarchPeer {
 };
 
 struct MarchPlan {
-    MarchRect me;
-    std::vector<MarchRect> all;                  // every rank's rectangle (index = rank; ok = false: rank holds nothing)
+    MarchRect me;                                // the rectangle this rank HOLDS: its own cells plus `ext` more on every side that
+                                                 // has a neighbour (computed redundantly, so that the ring is exchanged less often)
+    MarchRect owned;                             // the cells this rank owns (gx0, gy0, nxr, nyr)
+    int ext_w = 0, ext_e = 0, ext_s = 0, ext_n = 0;
+    std::vector<MarchRect> all;                  // every rank's OWN rectangle (index = rank; ok = false: rank holds nothing)
     bool wrapx = false;                          // E-W cyclic wrap handled inside the rank (it spans the whole dimension)
     std::vector<int32_t> dup;                    // [nstrips][64]: (strip << 8) | lane of the duplicate of an owner lane's column, -1 none
     std::vector<MarchPeer> peers;                // ascending rank; may contain this rank itself (self-exchange across the seam)
@@ -50,4 +53,7 @@ struct MarchPlan {
 
 // own_max: widest strip (<= 60); wrap_inside: let a rank that spans a cyclic E-W dimension wrap internally (false: the
 // seam is exchanged like any other rank boundary -- with the rank itself; a test hook).
-bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside, MarchPlan &P);
+// ext (even, >= 0): every rank also holds -- and advances redundantly -- `ext` cells beyond its own on every side that
+// has a neighbour.  One exchange then brings the ring of ext + 2 cells around the rank's own cells up to date, and
+// ext/2 + 1 passes can follow before the next one: pass j leaves the state valid on own cells + ext - 2(j-1).
+bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside, int ext, MarchPlan &P);

@@ -454,21 +454,21 @@ class EvpHip:
             pass
 
 
-def march_plan(dims: Dims, own_max: int = 0, wrap_inside: bool = True) -> dict:
+def march_plan(dims: Dims, own_max: int = 0, wrap_inside: bool = True, ext: int = 0) -> dict:
     """Host-only geometry + exchange lists of the two-subcycle path for `dims.rank` (CPU tests)."""
     lib = load_library()
-    geo = np.zeros(10, dtype=np.int32)
-    _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), _ip(geo), None, None, None, None, None, None),
-           "(march_plan)")
+    geo = np.zeros(14, dtype=np.int32)
+    _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), ext, _ip(geo), None, None, None, None, None,
+                                            None), "(march_plan)")
     npeer, ns, nr = int(geo[6]), int(geo[7]), int(geo[8])
     pr, pns, pnr = [np.zeros(max(npeer, 1), dtype=np.int32) for _ in range(3)]
     sp = np.zeros(max(ns, 1), dtype=np.int32)
     r1, r2 = [np.zeros(max(nr, 1), dtype=np.int32) for _ in range(2)]
-    _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), _ip(geo), _ip(pr), _ip(pns), _ip(pnr), _ip(sp),
-                                            _ip(r1), _ip(r2)), "(march_plan)")
+    _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), ext, _ip(geo), _ip(pr), _ip(pns), _ip(pnr),
+                                            _ip(sp), _ip(r1), _ip(r2)), "(march_plan)")
     return dict(gx0=int(geo[0]), gy0=int(geo[1]), nxr=int(geo[2]), nyr=int(geo[3]), own=int(geo[4]), nstrips=int(geo[5]),
-                wrapx=bool(geo[9]), peer_rank=pr[:npeer], peer_nsend=pns[:npeer], peer_nrecv=pnr[:npeer], send_pos=sp[:ns],
-                recv_pos1=r1[:nr], recv_pos2=r2[:nr])
+                wrapx=bool(geo[9]), ext=tuple(int(v) for v in geo[10:14]), peer_rank=pr[:npeer], peer_nsend=pns[:npeer],
+                peer_nrecv=pnr[:npeer], send_pos=sp[:ns], recv_pos1=r1[:nr], recv_pos2=r2[:nr])
 
 
 def halo_plan(dims: Dims) -> dict:

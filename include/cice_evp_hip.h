@@ -314,11 +314,13 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
  * cice_evp_hip_subcycle ran through it.  CICE_EVP_HIP_MARCH=0/1 forces it off / on (default: from 1M cells).   */
 int cice_evp_hip_march_info(int32_t *out, int32_t n);
 /* Host-only (CPU tests): geometry and exchange lists of the two-subcycle path for dims->rank.  Every rank's sub-domain
- * must be one rectangle; the rank holds it in strips of `own` <= own_max columns (position of a cell = (storage row *
- * nstrips + strip) * 64 + lane).  geo10 = {gx0, gy0, nxr, nyr, own, nstrips, peers, cells sent, cells received, wraps
- * inside}; per peer (ascending rank; the rank itself when wrap_inside = 0 on a cyclic dimension it spans) the cells it
- * sends / receives per exchange of the two-cell ring, recv_pos2 = the duplicate position or -1.  Lists may be NULL.  */
-int cice_evp_hip_march_plan(const cice_evp_hip_dims *dims, int32_t own_max, int32_t wrap_inside, int32_t *geo10,
+ * must be one rectangle; the rank HOLDS its own cells plus `ext` (even) more on every side that has a neighbour, in strips
+ * of `own` <= own_max columns (position of a cell = (storage row * nstrips + strip) * 64 + lane), and after one exchange
+ * of the ring of ext + 2 cells ext/2 + 1 passes can follow.  geo14 = {gx0, gy0, nxr, nyr of what it holds, own, nstrips,
+ * peers, cells sent, cells received, wraps inside, ext west / east / south / north}; per peer (ascending rank; the rank
+ * itself when wrap_inside = 0 on a cyclic dimension it spans) the cells it sends / receives, recv_pos2 = the duplicate
+ * position or -1.  Lists may be NULL.                                                                                */
+int cice_evp_hip_march_plan(const cice_evp_hip_dims *dims, int32_t own_max, int32_t wrap_inside, int32_t ext, int32_t *geo14,
                             int32_t *peer_rank, int32_t *peer_nsend, int32_t *peer_nrecv, int32_t *send_pos,
                             int32_t *recv_pos1, int32_t *recv_pos2);
 int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second);

@@ -122,14 +122,18 @@ def test_march_random_masks_vs_oracle(seed, grid, bs, holes, march):
     assert_bitwise(got, want, f"march, random masks seed {seed}")
 
 
-@pytest.mark.parametrize("grid,case,bs,seg,own", [("gx3", "full", None, 0, 0), ("gx3", "caps", (25, 29), 9, 17), ("gx1", "full", None, 40, 0)])
-def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg, own, march):
+@pytest.mark.parametrize("grid,case,bs,seg,own,ext", [("gx3", "full", None, 0, 0, 2), ("gx3", "caps", (25, 29), 9, 17, 0),
+                                                       ("gx3", "caps", (50, 58), 9, 23, 4), ("gx1", "full", None, 40, 0, 2)])
+def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg, own, ext, march):
     """Several ranks: every pass is followed by an exchange of the two-cell ring (pack -> ncclSend / ncclRecv -> unpack,
     duplicates included; march_plan.cpp).  One GPU can run all of it by treating the cyclic seam of the domain as a rank
     boundary -- the rank is its own east and west neighbour (CICE_EVP_HIP_MARCH_SELFX=1): no wrap inside the strips, the
-    halo columns live on what RCCL delivers.  Against the oracle, bit for bit; the list logic for 2 and 4 ranks is
+    halo columns live on what RCCL delivers.  ext: the rank also holds (and advances redundantly) `ext` columns of its
+    neighbour -- here of itself -- on either side, so that the ring is exchanged after every (ext/2 + 1)-th pass only.
+    Against the oracle, bit for bit; the list logic for 2 and 4 ranks is
     tests/test_multirank_cpu.py::test_march_two_cell_ring_between_ranks_known_answer."""
     march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
+    march.setenv("CICE_EVP_HIP_MARCH_EXT", str(ext))
     if seg:
         march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
     if own:
@@ -141,13 +145,13 @@ def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg
                       geo["uarear"], geo["tarea"], keepalive=keep)
     try:
         core.comm_init(core.comm_unique_id())
-        got = core.run(fields, tm, um, ndte=12)
+        got = core.run(fields, tm, um, ndte=14)
         info = core.march_info()
-        assert info["mode"] == 1 and info["last_call"] and info["passes"] == 6, info
+        assert info["mode"] == 1 and info["last_call"] and info["passes"] == 7, info
     finally:
         core.finalize()
-    want = run_oracle(dc, geo, fields, tm, um, scal, 12)
-    assert_bitwise(got, want, f"{grid}/{case}: march, seam through RCCL")
+    want = run_oracle(dc, geo, fields, tm, um, scal, 14)
+    assert_bitwise(got, want, f"{grid}/{case}: march, seam through RCCL, ext {ext}")
 
 
 def test_march_declines_a_state_whose_ghost_cells_are_not_images(march):

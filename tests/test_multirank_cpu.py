@@ -330,12 +330,18 @@ def test_cgrid_loop_split_over_ranks_known_answer(case):
 # global block table alone, packs, exchanges point-to-point, unpacks -- the known answer is the global cell number.
 # ---------------------------------------------------------------------------------------------------------------
 MARCH_CASES = [
-    # nx, ny, bx, by, ew, nranks, proc_shape, own_max, wrap_inside
-    (130, 40, 65, 40, "cyclic", 2, (2, 1), 60, True),      # x split: the cyclic seam and the inner cut, both between ranks
-    (130, 40, 130, 20, "cyclic", 2, (1, 2), 60, True),     # y slabs: every rank wraps inside and trades halo ROWS (duplicates!)
-    (96, 48, 48, 24, "cyclic", 4, (2, 2), 20, True),       # 2 x 2, narrow strips, corner cells from the diagonal neighbour
-    (96, 48, 24, 24, "closed", 4, (2, 2), 60, True),       # closed E-W, two blocks per rank
-    (75, 30, 75, 15, "cyclic", 2, (1, 2), 60, False),      # test hook: the cyclic seam exchanged with the rank itself
+    # nx, ny, bx, by, ew, nranks, proc_shape, own_max, wrap_inside, ext
+    (130, 40, 65, 40, "cyclic", 2, (2, 1), 60, True, 0),      # x split: the cyclic seam and the inner cut, both between ranks
+    (130, 40, 130, 20, "cyclic", 2, (1, 2), 60, True, 0),     # y slabs: every rank wraps inside and trades halo ROWS (duplicates!)
+    (96, 48, 48, 24, "cyclic", 4, (2, 2), 20, True, 0),       # 2 x 2, narrow strips, corner cells from the diagonal neighbour
+    (96, 48, 24, 24, "closed", 4, (2, 2), 60, True, 0),       # closed E-W, two blocks per rank
+    (75, 30, 75, 15, "cyclic", 2, (1, 2), 60, False, 0),      # test hook: the cyclic seam exchanged with the rank itself
+    # ext = 2 / 4: every rank holds (and advances redundantly) a rim of its neighbours' cells; ring of ext + 2 per exchange
+    (130, 40, 65, 40, "cyclic", 2, (2, 1), 60, True, 2),
+    (130, 40, 130, 20, "cyclic", 2, (1, 2), 60, True, 2),
+    (96, 48, 48, 24, "cyclic", 4, (2, 2), 20, True, 4),
+    (96, 48, 24, 24, "closed", 4, (2, 2), 60, True, 2),
+    (75, 30, 75, 15, "cyclic", 2, (1, 2), 60, False, 2),
 ]
 
 
@@ -344,11 +350,12 @@ def _march_worker(rank, world, port, case, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        nx, ny, bx, by, ew, nranks, shape, own_max, wrap_inside = case
+        nx, ny, bx, by, ew, nranks, shape, own_max, wrap_inside, ext = case
         dc = decomp.Decomp(nx, ny, bx, by, ew, "closed", nranks, shape)
         d, keep = evp.make_dims(dc, rank)
-        P = evp.march_plan(d, own_max, wrap_inside)
-        own, ns, nxr, nyr, gx0, gy0 = P["own"], P["nstrips"], P["nxr"], P["nyr"], P["gx0"], P["gy0"]
+        P = evp.march_plan(d, own_max, wrap_inside, ext)
+        own, ns, nxr, nyr, gx0, gy0 = P["own"], P["nstrips"], P["nxr"], P["nyr"], P["gx0"], P["gy0"]   # what the rank HOLDS
+        ew_, ee_, es_, en_ = P["ext"]
         rows = nyr + 4
 
         def home(x, y):            # where the rank holds column x (may lie two cells beyond the rectangle), row y
@@ -356,9 +363,9 @@ def _march_worker(rank, world, port, case, q):
             return ((y + 2) * ns + s) * 64 + (x - s * own + 2)
 
         buf = np.full(rows * ns * 64, -1.0)
-        for y in range(nyr):
-            for x in range(nxr):
-                buf[home(x, y)] = (gy0 + y) * nx + (gx0 + x)
+        for y in range(es_, nyr - en_):              # its OWN cells
+            for x in range(ew_, nxr - ee_):
+                buf[home(x, y)] = (gy0 + y) * nx + (gx0 + x) % nx
         sendbuf = torch.from_numpy(buf[P["send_pos"]].copy())
         assert (sendbuf >= 0).all(), "a send entry that is not an owned cell"
         recvbuf = torch.zeros(len(P["recv_pos1"]), dtype=torch.float64)
@@ -386,7 +393,7 @@ def _march_worker(rank, world, port, case, q):
         nbad = nring = 0
         for y in range(-2, nyr + 2):
             for x in range(-2, nxr + 2):
-                if 0 <= x < nxr and 0 <= y < nyr:
+                if ew_ <= x < nxr - ee_ and es_ <= y < nyr - en_:
                     continue
                 gx, gy = gx0 + x, gy0 + y
                 if not (0 <= gy < ny):
@@ -421,5 +428,5 @@ def test_march_two_cell_ring_between_ranks_known_answer(case):
     assert all(p.exitcode == 0 for p in procs)
     for rank, nbad, nring, ndup in res:
         assert nbad == 0 and nring > 0, (rank, nbad, nring)
-    if case[8] and case[6][0] == 1:        # y slabs wrapping inside: halo-row cells next to a strip edge have duplicates
+    if case[8] and case[6][0] == 1 and case[9] == 0:        # y slabs wrapping inside: halo-row cells next to a strip edge have duplicates
         assert all(r[3] > 0 for r in res)

@@ -88,7 +88,7 @@ def main():
                         continue
                     if tname == "march+rccl" and wl != "s01":
                         continue
-                    nsub = min(ndte, 120) if nx * ny < 500000 else 24
+                    nsub = min(ndte, 120) if nx * ny < 500000 else 96
                     try:
                         us, tt = time_piece(nx, ny, ns, dx0, nsub, {} if N == 1 else envs, N > 1)
                     except Exception as e:  # noqa: BLE001
