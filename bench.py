@@ -408,8 +408,11 @@ def main():
         base = dict(kw.pop("env", None) or {})
         ladder = [({}, "library default")]
         if world > 1:
-            ladder += [({"CICE_EVP_HIP_RESIDENT": "0"}, "streaming kernel (resident kernel across GPUs off)"),
-                       ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_HALO": "rccl"}, "streaming kernel, RCCL point-to-point only")]
+            ladder += [({"CICE_EVP_HIP_RESIDENT": "0"}, "streaming kernels (resident kernel across GPUs off)"),
+                       ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_MARCH": "0"},
+                        "one-subcycle streaming kernel (resident kernel and two-subcycle marching kernel off)"),
+                       ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_MARCH": "0", "CICE_EVP_HIP_HALO": "rccl"},
+                        "one-subcycle streaming kernel, RCCL point-to-point only")]
         attempts = []
         for extra_env, label in ladder:
             try:

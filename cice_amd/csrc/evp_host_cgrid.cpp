@@ -96,11 +96,14 @@ static void fill(EvpCgrid &A)
 }
 
 static bool remote() { return !S.plan.peers.empty(); }
-// ghost cells owned by other ranks, for two of the loop's arrays (no-op on one rank)
+// ghost cells owned by other ranks, for two of the loop's arrays (no-op on one rank).  Every exchange inside the loop
+// goes through the masked halo when the host has handed one over (maskhalo_dyn: evp() builds it for the C grid as the
+// five-point dilation of iceTmask, ice_dyn_evp.F90:739-770, and passes halo_info_mask to every dyn_haloUpdate of the
+// loop, :965-1096); copies inside a rank -- the pushes of the kernels -- are never masked, as in ice_HaloMask.
 #define XCHG(a, b)                                             \
     do {                                                       \
         if (remote())                                          \
-            if (int rc_ = halo_remote_pair((a), (b))) return rc_; \
+            if (int rc_ = halo_remote_pair((a), (b), true)) return rc_; \
     } while (0)
 
 // tripole: the fold step of up to four fields after the launch that produced them (what their ice_HaloUpdate does

@@ -601,6 +601,12 @@ contains
     use ice_flux, only: stresspT, stressmT, stress12T, stress12U, strintxE, strintyN, taubxE, taubyN, &
                         fmE, fmN, TbE, TbN
     use ice_timers, only: ice_timer_start, ice_timer_stop, timer_evp1dcore
+    use ice_blocks, only: nx_block, ny_block, block, get_block
+    use ice_domain, only: maskhalo_dyn, halo_info, nblocks, blocks_ice
+    use ice_domain_size, only: max_blocks
+    use ice_boundary, only: ice_HaloUpdate
+    use ice_constants, only: field_loc_center, field_type_scalar
+    use ice_communicate, only: get_num_procs
 
     real(kind=dbl_kind), dimension(:,:,:), intent(in), contiguous, target :: &
       uocnE, vocnE, cdn_ocnE, waterxE, forcexE, aiE, rheofactE, emassdti, &
@@ -610,6 +616,9 @@ contains
       zetax2T, etax2T, etax2U, shearU, deltaU
 
     type(c_ptr) :: st(23), fl(19), inp(23)
+    integer(int_kind), allocatable, save :: halomask_c(:,:,:)
+    type(block) :: tb
+    integer :: i, j, iblk
     integer(c_int32_t), pointer :: mT(:), mU(:), mE(:), mN(:)
     integer(c_int32_t) :: vm
     integer(c_int) :: rc
@@ -661,6 +670,23 @@ contains
           rc = cice_evp_hip_pin_ptr(inp(k), nbytes)
        enddo
        cgrid_pinned = .true.
+    endif
+    if (maskhalo_dyn .and. get_num_procs() > 1) then
+       ! the masked halo evp() builds for the C-grid loop (ice_dyn_evp.F90:739-770: a cell and its four neighbours,
+       ! where iceTmask; ghost cells updated), rebuilt here because halo_info_mask is private to ice_dyn_evp
+       if (.not. allocated(halomask_c)) allocate(halomask_c(nx_block, ny_block, max_blocks))
+       halomask_c = 0
+       do iblk = 1, nblocks
+          tb = get_block(blocks_ice(iblk), iblk)
+          do j = tb%jlo, tb%jhi
+          do i = tb%ilo, tb%ihi
+             if (iceTmask(i,j,iblk) .or. iceTmask(i-1,j,iblk) .or. iceTmask(i+1,j,iblk) .or. &
+                 iceTmask(i,j-1,iblk) .or. iceTmask(i,j+1,iblk)) halomask_c(i,j,iblk) = 1
+          enddo
+          enddo
+       enddo
+       call ice_HaloUpdate(halomask_c, halo_info, field_loc_center, field_type_scalar)
+       call check(cice_evp_hip_halo_mask(halomask_c), subname, __FILE__, __LINE__)
     endif
     call ice_timer_start(timer_evp1dcore)
     call check(cice_evp_hip_cgrid_run(int(ndte, c_int32_t), vm, fl, inp, mT, mU, mE, mN), subname, __FILE__, __LINE__)

@@ -120,6 +120,10 @@ def test_bench_multi_rank_rehearsal():
 @pytest.mark.parametrize("world,workload,shape,extra", [(2, "gx3", "", []), (4, "gx3", "2x2", ["--blocks-per-rank", "2x2", "--timing"]),
                                                         (2, "gx1", "1x2", ["--visc", "avg_strength"]),
                                                         (4, "gx1", "2x2", ["--timing"]),
+                                                        # maskhalo_dyn for the C-grid loop: every in-loop exchange through the
+                                                        # masked halo (five-point dilation of iceTmask); ice in two caps only
+                                                        (2, "gx1", "1x2", ["--maskhalo", "--case", "caps"]),
+                                                        (4, "gx3", "2x2", ["--maskhalo", "--case", "caps", "--blocks-per-rank", "2x2"]),
                                                         # tripole grid cut in y: the rank with the fold rows does the
                                                         # fold steps, every rank the five-phase schedule
                                                         (2, "tx1", "1x2", []), (3, "tx1", "1x3", ["--blocks-per-rank", "2x1"])])
