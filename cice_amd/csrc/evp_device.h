@@ -238,6 +238,9 @@ void evp_launch_prep_average(const EvpPrep &P, int nblocks, hipStream_t st);
 void evp_launch_prep2(const EvpPrep &P, int nblocks, hipStream_t st);
 void evp_launch_prep_average_prep2(const EvpPrep &P, int nblocks, hipStream_t st);
 void evp_launch_words_to_bytes(const int32_t *w, uint8_t *b, size_t n, hipStream_t st);
+void evp_launch_seabed_prob(const EvpPrep &P, int nblocks, const double *hwater, const double *aicen, const double *vicen,
+                            int ncat, double alphab, double rhoi, double rhow, double gravit, double pi, double puny,
+                            double *Tbt, double *TbU, unsigned *flagword, hipStream_t st);
 void evp_launch_seabed_lkd(const EvpPrep &P, int nblocks, const double *hwater, double *TbU, double k1, double k2,
                            double alphab, double threshold_hw, unsigned *flagword, hipStream_t st);
 

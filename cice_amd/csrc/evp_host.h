@@ -127,6 +127,8 @@ struct State {
         uint8_t *tmask = nullptr, *umask = nullptr, *umask_old = nullptr, *tmphm = nullptr;
         int32_t *umask_old32 = nullptr;          // the caller's words as uploaded (reduced to bytes on the device)
         double *hm = nullptr, *tarea = nullptr, *uarea = nullptr, *fcor = nullptr, *hwater = nullptr;
+        double *aicen = nullptr, *vicen = nullptr, *tbt = nullptr;     // seabed_stress_factor_prob: category arrays, factor at T points
+        int ncat = 0;
         double *t[11] = {};
         double *tmass = nullptr, *umass = nullptr, *maskd = nullptr;
         double *ss_tltxU = nullptr, *ss_tltyU = nullptr, *strairxU = nullptr, *strairyU = nullptr,

@@ -252,6 +252,47 @@ int cice_evp_hip_seabed_lkd(const double *hwater, double k1, double k2, double a
     return 0;
 }
 
+// Seabed stress factor on the device, probabilistic method (seabed_stress_factor_prob, ice_dyn_shared.F90:1475-1683;
+// call site ice_dyn_evp.F90:791-800): from the category concentrations / volumes aicen, vicen (ice_state:
+// (nx_block, ny_block, ncat, max_blocks), ghost cells current as in the host model), the water depth (NULL keeps the
+// copy of the previous call) and the masks the last cice_evp_hip_prep produced.  Call between _prep and _subcycle
+// instead of cice_evp_hip_set_tbu.  exp() / log() are the device library's: TbU within a few ulp of the reference's.
+int cice_evp_hip_seabed_prob(const double *hwater, const double *aicen, const double *vicen, int32_t ncat, double alphab,
+                             double rhoi, double gravit, double pi, double puny)
+{
+    if (!S.ready || !S.uploaded || !S.prep.geo) return fail(-1, "no prepared state (cice_evp_hip_prep first)");
+    if (!aicen || !vicen || ncat < 1) return fail(-1, "bad argument");
+    State::Prep &Q = S.prep;
+    if (!Q.hwater) {
+        if (!hwater) return fail(-1, "hwater needed on the first call");
+        if (alloc_d(&Q.hwater, S.n)) return -1;
+    }
+    if (hwater && h2d(Q.hwater, hwater)) return -1;
+    if (Q.ncat != ncat) {
+        if (Q.aicen) { (void)hipFree(Q.aicen); Q.aicen = nullptr; }
+        if (Q.vicen) { (void)hipFree(Q.vicen); Q.vicen = nullptr; }
+        if (alloc_d(&Q.aicen, S.n * (size_t)ncat) || alloc_d(&Q.vicen, S.n * (size_t)ncat)) return -1;
+        Q.ncat = ncat;
+    }
+    if (!Q.tbt && alloc_d(&Q.tbt, S.n)) return -1;
+    // the caller's arrays are (nx, ny, ncat, max_blocks): blocks 1..nblocks are contiguous
+    HIPC(hipMemcpyAsync(Q.aicen, aicen, S.n * (size_t)ncat * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(Q.vicen, vicen, S.n * (size_t)ncat * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    EvpPrep P{};
+    P.nx = S.d.nx_block; P.ny = S.d.ny_block; P.plane = S.plane; P.blk = S.blk;
+    P.mask = S.mask;
+    HIPC(hipMemsetAsync(Q.flagword, 0, sizeof(unsigned), S.stream));
+    evp_launch_seabed_prob(P, S.d.nblocks, Q.hwater, Q.aicen, Q.vicen, ncat, alphab, rhoi, S.prm.rhow, gravit, pi, puny, Q.tbt,
+                           S.in[F_TBU], Q.flagword, S.stream);
+    unsigned fw = 0;
+    HIPC(hipMemcpyAsync(&fw, Q.flagword, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    S.flags &= ~EVP_F_TBU_ZERO;
+    if (!(fw & 2u)) S.flags |= EVP_F_TBU_ZERO;
+    ++S.upload_seq;
+    return 0;
+}
+
 // products of the preparation phase that stay on the device, for hosts that need them
 // (coupling diagnostics) and for the tests
 int cice_evp_hip_prep_fetch(int32_t which, double *dst)

@@ -229,6 +229,83 @@ __global__ void seabed_lkd(EvpPrep P, const double *__restrict__ hwater, double 
     TbU[c] = tb;
 }
 
+// seabed_stress_factor_prob (ice_dyn_shared.F90:1475-1683), step 1: the factor at the T point of every ice T-cell of
+// dyn_prep2's list (ilo..ihi+1 x jlo..jhi+1) with atot > 0.05 and hwater < 50 m: a log-normal ice-thickness distribution
+// (100 categories of 0.5 m) against a normal bathymetry distribution (100 categories over +-3 sigma_b).  Same expressions
+// in the same order as the reference; exp() / log() are the device library's (<= 1 ulp from the host libm's), so the
+// result is within a few ulp, not bit-identical -- tolerance stated in DESIGN.md.  aicen / vicen: (nx, ny, ncat, nblocks).
+__global__ void seabed_prob_T(EvpPrep P, const double *__restrict__ hwater, const double *__restrict__ aicen,
+                              const double *__restrict__ vicen, int ncat, double alphab, double rhoi, double rhow,
+                              double gravit, double pi, double puny, double *__restrict__ Tbt)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const int4 r = P.blk[bz];
+    double out = 0.0;
+    if (i >= r.x && i <= r.y + 1 && j >= r.z && j <= r.w + 1 && (P.mask[c] & 1u)) {
+        constexpr int NI = 100, NB = 100;
+        const double max_depth = 50.0, mu_s = 0.1, sigma_b = 2.5, c0 = 0.0, c1 = 1.0, c2 = 2.0, c3 = 3.0, c6 = 6.0, p5 = 0.5;
+        const size_t cl = c - (size_t)bz * P.plane;
+        double atot = 0.0;
+        for (int n = 0; n < ncat; ++n) atot += aicen[((size_t)bz * ncat + n) * P.plane + cl];
+        if (atot > 0.05 && hwater[c] < max_depth) {
+            const double mu_b = hwater[c];
+            const double wid_i = max_depth / NI, wid_b = c6 * sigma_b / NB;
+            double y_n[NB], P_y[NB];
+            for (int k = 1; k <= NB; ++k) {
+                y_n[k - 1] = (mu_b - c3 * sigma_b) + ((double)k - p5) * (c6 * sigma_b / NB);
+                const double dy = y_n[k - 1] - mu_b;
+                const double b_n = exp(-(dy * dy) / (c2 * (sigma_b * sigma_b))) / (sigma_b * sqrt(c2 * pi));
+                P_y[k - 1] = b_n * wid_b;
+            }
+            double m_i = 0.0, v_i = c0;
+            for (int n = 0; n < ncat; ++n) m_i += vicen[((size_t)bz * ncat + n) * P.plane + cl];
+            for (int n = 0; n < ncat; ++n) {
+                const double vc = vicen[((size_t)bz * ncat + n) * P.plane + cl], ac = aicen[((size_t)bz * ncat + n) * P.plane + cl];
+                v_i = v_i + vc * vc / (fmax(ac, puny));
+            }
+            v_i = fmax((v_i - m_i * m_i), puny);
+            const double mu_i = log(m_i / sqrt(c1 + v_i / (m_i * m_i)));
+            const double sigma_i = sqrt(log(c1 + v_i / (m_i * m_i)));
+            double x_kmax = exp(mu_i + sqrt(c2 * sigma_i) * 1.9430);
+            const double cut = wid_i * ((double)NI - p5);      // x_k(ncat_i): the loop that would lower it never runs (:1583-1589)
+            x_kmax = fmin(cut, x_kmax);
+            double tsum = 0.0;
+            for (int n = 1; n <= NI; ++n) {
+                const double x_k = wid_i * ((double)n - p5);
+                const double lx = log(x_k) - mu_i;
+                const double g_k = exp(-(lx * lx) / (c2 * (sigma_i * sigma_i))) / (x_k * sigma_i * sqrt(c2 * pi));
+                double P_x = g_k * wid_i;
+                if (x_k > x_kmax) P_x = c0;
+                int ii = 0;
+                for (int k = 0; k < NB; ++k) ii += (y_n[k] <= rhoi * x_k / rhow) ? 1 : 0;
+                double tb = c0;
+                if (ii != 0) {
+                    double sm = 0.0;
+                    for (int k = 0; k < ii; ++k) sm += P_y[k] * (rhoi * x_k - rhow * y_n[k]);
+                    tb = fmax(mu_s * gravit * P_x * sm, c0);
+                }
+                tsum += tb;
+            }
+            out = tsum * exp(-alphab * (c1 - atot));
+        }
+    }
+    Tbt[c] = out;
+}
+// step 2 (:1648-1655): TbU = grid_neighbor_max(Tbt, 'U') on the ice U-cells, 0 elsewhere (dyn_prep2 zeroed TbU, :706)
+__global__ void seabed_prob_U(EvpPrep P, const double *__restrict__ Tbt, double *__restrict__ TbU, unsigned *flagword)
+{
+    int i, j, bz; size_t c;
+    if (!cell_of(P, i, j, bz, c)) return;
+    const int4 r = P.blk[bz];
+    double tb = 0.0;
+    if (i >= r.x && i <= r.y && j >= r.z && j <= r.w && (P.mask[c] & 2u)) {
+        tb = fmax(fmax(fmax(Tbt[c], Tbt[c + 1]), Tbt[c + P.nx]), Tbt[c + P.nx + 1]);
+        if (tb != 0.0) atomicOr(flagword, 2u);
+    }
+    TbU[c] = tb;
+}
+
 dim3 cell_grid(const EvpPrep &P, int nblocks) { return dim3((P.nx + 63) / 64, P.ny, nblocks); }
 
 }  // namespace
@@ -266,4 +343,13 @@ void evp_launch_seabed_lkd(const EvpPrep &P, int nblocks, const double *hwater, 
                            double alphab, double threshold_hw, unsigned *flagword, hipStream_t st)
 {
     hipLaunchKernelGGL(seabed_lkd, cell_grid(P, nblocks), dim3(64), 0, st, P, hwater, TbU, k1, k2, alphab, threshold_hw, flagword);
+}
+
+void evp_launch_seabed_prob(const EvpPrep &P, int nblocks, const double *hwater, const double *aicen, const double *vicen,
+                            int ncat, double alphab, double rhoi, double rhow, double gravit, double pi, double puny,
+                            double *Tbt, double *TbU, unsigned *flagword, hipStream_t st)
+{
+    hipLaunchKernelGGL(seabed_prob_T, cell_grid(P, nblocks), dim3(64), 0, st, P, hwater, aicen, vicen, ncat, alphab, rhoi, rhow,
+                       gravit, pi, puny, Tbt);
+    hipLaunchKernelGGL(seabed_prob_U, cell_grid(P, nblocks), dim3(64), 0, st, P, Tbt, TbU, flagword);
 }

@@ -42,7 +42,7 @@ EXPORTS = [
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
-    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
     "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
@@ -290,6 +290,15 @@ class EvpHip:
         a = self._c(hwater) if hwater is not None else None
         _check(self.lib, self.lib.cice_evp_hip_seabed_lkd(_dp(a) if a is not None else None, C.c_double(k1), C.c_double(k2),
                                                            C.c_double(alphab), C.c_double(threshold_hw)), "(dyn_evp_hip_seabed_lkd)")
+
+    def seabed_prob(self, hwater, aicen, vicen, alphab, rhoi, gravit, pi, puny):
+        """aicen / vicen: [nblocks][ncat][ny][nx] (the memory image of ice_state's (nx, ny, ncat, blocks))."""
+        h = self._c(hwater) if hwater is not None else None
+        a = np.ascontiguousarray(aicen, dtype=np.float64)
+        v = np.ascontiguousarray(vicen, dtype=np.float64)
+        _check(self.lib, self.lib.cice_evp_hip_seabed_prob(_dp(h) if h is not None else None, _dp(a), _dp(v), C.c_int32(a.shape[1]),
+                                                            C.c_double(alphab), C.c_double(rhoi), C.c_double(gravit), C.c_double(pi),
+                                                            C.c_double(puny)), "(dyn_evp_hip_seabed_prob)")
 
     # -- C-grid subcycle (SURVEY 8 f-4) -------------------------------------------
     def cgrid_set_geometry(self, static: dict):

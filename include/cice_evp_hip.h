@@ -213,6 +213,12 @@ int cice_evp_hip_set_tbu(const double *TbU);
  * previous call).  Uses the aice / vice and the masks of the last cice_evp_hip_prep.  One exp() per ice U-cell from
  * the device's math library: TbU may differ from the host's libm result in the last bit (tolerance).  */
 int cice_evp_hip_seabed_lkd(const double *hwater, double k1, double k2, double alphab, double threshold_hw);
+/* The same for seabed_stress_method = 'probabilistic' (seabed_stress_factor_prob, ice_dyn_shared.F90:1475-1683; B grid):
+ * aicen, vicen = ice_state's category arrays (nx_block, ny_block, ncat, max_blocks) with current ghost cells; rhoi,
+ * gravit, pi, puny from icepack_query_parameters (rhow is the one given at init).  exp() / log() are the device
+ * library's: TbU within a few ulp of the reference's, not bit-identical.                                          */
+int cice_evp_hip_seabed_prob(const double *hwater, const double *aicen, const double *vicen, int32_t ncat, double alphab,
+                             double rhoi, double gravit, double pi, double puny);
 /* Returns its argument.  Lets a Fortran host take the address of a module array that lacks the
  * TARGET attribute (type(*), dimension(*) dummy) to fill the pointer tables above.              */
 void *cice_evp_hip_addr(const void *array);

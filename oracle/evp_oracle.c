@@ -828,6 +828,88 @@ void evp_oracle_seabed_lkd(const evp_oracle_domain *d, double k1, double k2, dou
 }
 
 /* =====================================================================
+ * Seabed stress factor, probabilistic method: seabed_stress_factor_prob, dynamics/ice_dyn_shared.F90:1475-1683
+ * (B grid: TbU = grid_neighbor_max(Tbt, 'U'), :1648-1655).  Per ice T-cell with atot > 0.05 and hwater < 50 m: a
+ * log-normal ice-thickness distribution (100 categories of 0.5 m) against a normal bathymetry distribution (100
+ * categories over +-3 sigma_b, sigma_b = 2.5 m); exp() / log() are libm's, as in the reference.  The loop that would
+ * cut x_kmax at the last ice-holding category (`do n = ncat,-1,1`, :1583-1589) never executes, so cut = x_k(100).
+ * aicen / vicen: (nx, ny, ncat, nblocks), i fastest.
+ * ===================================================================== */
+void evp_oracle_seabed_prob(const evp_oracle_domain *d, int ncat, double alphab, double rhoi, double rhow, double gravit,
+                            double pi, double puny, const double *aicen, const double *vicen, const double *hwater,
+                            const int32_t *iceTmask, const int32_t *iceUmask, double *TbU)
+{
+    enum { NI = 100, NB = 100 };
+    const double max_depth = 50.0, mu_s = 0.1, sigma_b = 2.5, c0 = 0.0, c1 = 1.0, c2 = 2.0, c3 = 3.0, c6 = 6.0, p5 = 0.5;
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t plane = (size_t)nx * ny;
+    double *Tbt = (double *)calloc(plane, sizeof(double));
+    for (int b = 0; b < d->nblocks; ++b) {
+        for (size_t c = 0; c < plane; ++c) Tbt[c] = 0.0;
+        /* T-cells of the list dyn_prep2 builds: ilo..ihi+1 x jlo..jhi+1 where iceTmask (ice_dyn_shared.F90:740-749) */
+        for (int j = d->jlo[b]; j <= d->jhi[b] + 1; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b] + 1; ++i) {
+                const size_t cl = (size_t)(j - 1) * nx + (i - 1), c = b * plane + cl;
+                if (!iceTmask[c]) continue;
+                double atot = 0.0;
+                for (int n = 0; n < ncat; ++n) atot += aicen[((size_t)b * ncat + n) * plane + cl];
+                if (!(atot > 0.05 && hwater[c] < max_depth)) continue;
+                const double mu_b = hwater[c];
+                const double wid_i = max_depth / NI, wid_b = c6 * sigma_b / NB;
+                double x_k[NI], y_n[NB], P_x[NI], P_y[NB];
+                for (int k = 1; k <= NI; ++k) x_k[k - 1] = wid_i * ((double)k - p5);
+                for (int k = 1; k <= NB; ++k) y_n[k - 1] = (mu_b - c3 * sigma_b) + ((double)k - p5) * (c6 * sigma_b / NB);
+                double m_i = 0.0, v_i = c0;
+                for (int n = 0; n < ncat; ++n) m_i += vicen[((size_t)b * ncat + n) * plane + cl];
+                for (int n = 0; n < ncat; ++n) {
+                    const double vc = vicen[((size_t)b * ncat + n) * plane + cl], ac = aicen[((size_t)b * ncat + n) * plane + cl];
+                    v_i = v_i + vc * vc / (fmax(ac, puny));
+                }
+                v_i = fmax((v_i - m_i * m_i), puny);
+                const double mu_i = log(m_i / sqrt(c1 + v_i / (m_i * m_i)));
+                const double sigma_i = sqrt(log(c1 + v_i / (m_i * m_i)));
+                double x_kmax = exp(mu_i + sqrt(c2 * sigma_i) * 1.9430);
+                const double cut = x_k[NI - 1];
+                x_kmax = fmin(cut, x_kmax);
+                for (int k = 0; k < NI; ++k) {
+                    const double lx = log(x_k[k]) - mu_i;
+                    const double g_k = exp(-(lx * lx) / (c2 * (sigma_i * sigma_i))) / (x_k[k] * sigma_i * sqrt(c2 * pi));
+                    P_x[k] = g_k * wid_i;
+                }
+                for (int k = 0; k < NB; ++k) {
+                    const double dy = y_n[k] - mu_b;
+                    const double b_n = exp(-(dy * dy) / (c2 * (sigma_b * sigma_b))) / (sigma_b * sqrt(c2 * pi));
+                    P_y[k] = b_n * wid_b;
+                }
+                for (int k = 0; k < NI; ++k)
+                    if (x_k[k] > x_kmax) P_x[k] = c0;
+                double tsum = 0.0;
+                for (int n = 0; n < NI; ++n) {
+                    int ii = 0;
+                    for (int k = 0; k < NB; ++k) ii += (y_n[k] <= rhoi * x_k[n] / rhow) ? 1 : 0;
+                    double tb = c0;
+                    if (ii != 0) {
+                        double sm = 0.0;
+                        for (int k = 0; k < ii; ++k) sm += P_y[k] * (rhoi * x_k[n] - rhow * y_n[k]);
+                        tb = fmax(mu_s * gravit * P_x[n] * sm, c0);
+                    }
+                    tsum += tb;
+                }
+                Tbt[cl] = tsum * exp(-alphab * (c1 - atot));
+            }
+        for (size_t c = b * plane; c < (b + 1) * plane; ++c) TbU[c] = 0.0;
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const size_t cl = (size_t)(j - 1) * nx + (i - 1), c = b * plane + cl;
+                if (!iceUmask[c]) continue;
+                /* grid_neighbor_max at the U point (ice_grid.F90:5005): max(a(i,j), a(i+1,j), a(i,j+1), a(i+1,j+1)) */
+                TbU[c] = fmax(fmax(fmax(Tbt[cl], Tbt[cl + 1]), Tbt[cl + nx]), Tbt[cl + nx + 1]);
+            }
+    }
+    free(Tbt);
+}
+
+/* =====================================================================
  * C-grid EVP subcycle: evp()'s loop for grid_ice = 'C',
  * dynamics/ice_dyn_evp.F90:938-1099.  u lives at the east face (E), v at the north
  * face (N); stresses at cell centres (T) and corners (U).  One subcycle =

@@ -242,6 +242,22 @@ def seabed_lkd(dom: OracleDomain, k1, k2, alphab, threshold_hw, aice, vice, hwat
     return out
 
 
+def seabed_prob(dom: OracleDomain, alphab, rhoi, rhow, gravit, pi, puny, aicen, vicen, hwater, iceTmask, iceUmask):
+    """seabed_stress_factor_prob (ice_dyn_shared.F90:1475-1683), B grid: TbU on the ice U-cells, 0 elsewhere.
+    aicen / vicen: [nblocks][ncat][ny][nx]."""
+    lib().evp_oracle_seabed_prob.restype = None
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    a, v, h = f64(aicen), f64(vicen), f64(hwater)
+    ncat = a.shape[1]
+    i32 = lambda m: np.ascontiguousarray(m, dtype=np.int32)
+    tm, um = i32(iceTmask), i32(iceUmask)
+    out = np.zeros(dom.shape)
+    lib().evp_oracle_seabed_prob(C.byref(dom.c), C.c_int(ncat), C.c_double(alphab), C.c_double(rhoi), C.c_double(rhow),
+                                 C.c_double(gravit), C.c_double(pi), C.c_double(puny), _dp(a), _dp(v), _dp(h),
+                                 tm.ctypes.data_as(C.POINTER(C.c_int32)), um.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out))
+    return out
+
+
 # ---- C-grid subcycle (SURVEY 8 f-4) -----------------------------------------------------------
 C_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
             "strintxE", "strintyN", "taubxE", "taubyN", "zetax2T", "etax2T", "etax2U", "shearU", "deltaU"]

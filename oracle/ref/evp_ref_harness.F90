@@ -208,6 +208,7 @@ program evp_ref_harness
   real(dbl_kind)     :: h_elasticDamp = 0.36_dbl_kind
   character(len=32)  :: h_coriolis  = 'latitude'
   logical            :: h_seabed    = .false.
+  character(len=16)  :: h_seabed_method = 'LKD'   ! 'LKD' | 'probabilistic' (seabed_stress_factor_prob, ice_dyn_shared.F90:1475-1683)
   logical            :: dump_arrays = .true.      ! .false. = timing-only run (no array dumps)
   integer(int_kind)  :: ntiming     = 0           ! extra evp() calls, timed, after the dumps
   logical            :: hipmode     = .false.     ! drop-in check: HIP core (via ice_dyn_evp1d) vs standard_2d
@@ -220,7 +221,7 @@ program evp_ref_harness
 
   namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
      h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
-     h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, &
+     h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, h_seabed_method, &
      dump_arrays, ntiming, hipmode, hipbody, hipresident, time_1d, h_grid_ice, h_visc_method
 
   ! ---- locals ----------------------------------------------------------
@@ -279,7 +280,7 @@ program evp_ref_harness
   e_yieldcurve=h_e_yield; e_plasticpot=h_e_plast; Ktens=h_Ktens
   deltaminEVP=1e-11_dbl_kind; capping=h_capping
   coriolis=trim(h_coriolis); ssh_stress='geostrophic'
-  seabed_stress=h_seabed; seabed_stress_method='LKD'
+  seabed_stress=h_seabed; seabed_stress_method=trim(h_seabed_method)
   k1=7.5_dbl_kind; k2=15._dbl_kind; alphab=20._dbl_kind; threshold_hw=30._dbl_kind   ! ice_in defaults
   dyn_area_min=1e-11_dbl_kind; dyn_mass_min=1e-10_dbl_kind
   yield_curve='ellipse'; visc_method=trim(h_visc_method)
@@ -380,6 +381,8 @@ program evp_ref_harness
   scal(23)=c0; if (trim(ssh_stress) == 'coupled') scal(23)=c1
   scal(24)=c0; if (seabed_stress) scal(24)=c1
   scal(25)=k1; scal(26)=k2; scal(27)=alphab; scal(28)=threshold_hw; scal(29)=dt_dyn
+  scal(30)=c0; if (trim(seabed_stress_method) == 'probabilistic') scal(30)=c1
+  call icepack_query_parameters(pi_out=scal(31), puny_out=scal(32))
   call dump_r8_1d('scalars', scal)
   if (dump_arrays) then
      call dump_r8_3d('HTE', HTE, nblocks);       call dump_r8_3d('HTN', HTN, nblocks)

@@ -54,6 +54,10 @@ CASES = {
     "pop_cyc_2x2_seabed": (24, 20, 12, 10, "cyclic", "closed",
                            dict(grid_kind="popfile", icecase="full", nsub_list=[1, 120], ncalls=2,
                                 h_seabed=True)),
+    # seabed stress, probabilistic method (seabed_stress_factor_prob, ice_dyn_shared.F90:1475-1683)
+    "pop_cyc_2x2_seabedprob": (24, 20, 12, 10, "cyclic", "closed",
+                               dict(grid_kind="popfile", icecase="patchy", nsub_list=[1, 120], ncalls=2,
+                                    h_seabed=True, h_seabed_method="probabilistic")),
     # tripole (u-fold) north boundary: seam-row averaging, mirrored ghost row, and -- in the
     # expected outputs only -- evp()'s ice_HaloUpdate_stress symmetrisation after the loop
     "trip_cyc_2x2_full": (28, 20, 14, 10, "cyclic", "tripole",

@@ -947,6 +947,48 @@ def test_seabed_stress_factor_on_device_lkd():
         core.finalize()
 
 
+def test_seabed_stress_factor_on_device_probabilistic():
+    """SURVEY 8 f-2 ("LKD / prob"): seabed_stress_factor_prob (ice_dyn_shared.F90:1475-1683) on the device -- per ice
+    T-cell a log-normal thickness distribution against a normal bathymetry distribution, 100 x 100 categories, then the
+    maximum over the four T-cells around a U point.  Same expressions in the same order; exp() / log() are the device
+    library's, so TbU is within 1e-12 relative of the reference's (host libm) value -- the fixture comes from the
+    reference's evp() with seabed_stress_method = 'probabilistic' -- and the whole evp() within 1e-9; bit-identical
+    where the transcendental functions agree."""
+    c = GoldenCase("pop_cyc_2x2_seabedprob")
+    s = c.scal
+    assert s[29] == 1.0                                     # the fixture ran the probabilistic method
+    core = hip_from_case(c, strict=True)
+    try:
+        st = c.prep_static()
+        core.set_prep_geometry(st["tmask"], st["umask"], st["hm"], st["tarea"], st["uarea"], st["fcor_blk"])
+        d = c.prep_scal_dict()
+        pp = evp.PrepParams(dt=d["dt"], rhoi=d["rhoi"], rhos=d["rhos"], gravit=d["gravit"],
+                            dyn_area_min=d["dyn_area_min"], dyn_mass_min=d["dyn_mass_min"],
+                            ssh_stress_coupled=d["ssh_coupled"])
+        for icall in range(1, c.ncalls + 1):
+            t, state = c.prep_inputs(icall)
+            dyn, _, _ = c.inputs(icall)
+            core.prep(pp, t, state)
+            # ncat = 1 in the reference harness: aicen(:,:,1,:) = aice, vicen(:,:,1,:) = vice
+            core.seabed_prob(c.d["hwater"] if icall == 1 else None, t["aice"][:, None], t["vice"][:, None], s[26], s[17],
+                             s[19], s[30], s[31])
+            tb = core.prep_fetch("TbU")
+            ref = dyn["TbU"]
+            assert np.abs(ref).max() > 0 and np.array_equal(tb == 0, ref == 0)
+            nz = ref != 0
+            rel = np.abs(tb[nz] - ref[nz]) / np.abs(ref[nz])
+            assert rel.max() <= 1e-12, f"TbU differs from the reference by {rel.max():.2e} relative"
+            core.set_strength(dyn["strength"])
+            core.subcycle(c.ndte)
+            res = core.download()
+            want = c.expected(icall, c.ndte)
+            if rel.max() == 0:
+                assert_bitwise(res, want, f"call {icall}: device seabed factor (prob), identical exp() / log()")
+            assert max_rel_err(res, want, VEL + SIG + ["taubxU", "taubyU"]) < 1e-9
+    finally:
+        core.finalize()
+
+
 @pytest.mark.parametrize("transport", ["rccl", "direct", "direct-riding"])
 @pytest.mark.parametrize("name", ["pop_cyc_3x2pad_caps", "pop_cyc_1blk_patchy"])
 def test_masked_halo_is_bit_neutral_and_smaller(name, transport, monkeypatch):

@@ -194,3 +194,19 @@ def test_icepack_stub_constants_are_icepack_defaults():
     for name in GOLDEN_CASES:
         s = GoldenCase(name).scal
         assert (s[12], s[17], s[18], s[19]) == (1026.0, 917.0, 330.0, 9.80616), name      # rhow, rhoi, rhos, gravit
+
+
+def test_seabed_prob_oracle_bitwise():
+    """seabed_stress_factor_prob (ice_dyn_shared.F90:1475-1683), restated in oracle/evp_oracle.c with libm's exp / log:
+    bit-identical to the TbU the reference's evp() handed to its loop (fixture made with seabed_stress_method =
+    'probabilistic'; ncat = 1 in the harness)."""
+    c = GoldenCase("pop_cyc_2x2_seabedprob")
+    s = c.scal
+    assert s[23] == 1.0 and s[29] == 1.0
+    for icall in range(1, c.ncalls + 1):
+        dyn, tm, um = c.inputs(icall)
+        t, _ = c.prep_inputs(icall)
+        tb = oracle.seabed_prob(c.oracle_domain(), s[26], s[17], s[12], s[19], s[30], s[31], t["aice"][:, None],
+                                t["vice"][:, None], c.d["hwater"], tm, um)
+        assert np.abs(dyn["TbU"]).max() > 0
+        assert np.array_equal(tb, dyn["TbU"]), f"call {icall}"
