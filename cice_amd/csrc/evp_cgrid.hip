@@ -547,6 +547,36 @@ __global__ __launch_bounds__(TX *TY) void cg_zero_outside(EvpCgrid A)
 }
 
 // ---- tripole fold, pass 1 (values from raw sources) and pass 2 (stores); see EvpCgFold ----
+// ---- deformationsC_T (ice_dyn_shared.F90:1968-2074; strain_rates_Tdtsd :2171-2243), which evp() calls right after
+// the loop (ice_dyn_evp.F90:1106-1119): on the T-cells of dyn_prep2's list, from the loop's final face velocities and
+// shearU; every other cell keeps what the array holds ----
+__global__ __launch_bounds__(TX *TY) void cg_deformations_t(EvpCgrid A, const double *__restrict__ tarear, double *__restrict__ divu,
+                                                            double *__restrict__ shear, double *__restrict__ vort,
+                                                            double *__restrict__ rdg_conv, double *__restrict__ rdg_shear)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y + 1 || c.j < c.q.z || c.j > c.q.w + 1) return;
+    const size_t o = c.o, w = o - 1, s = o - A.nx, sw = s - 1;
+    if (!(A.mask[o] & 1u)) return;
+    const double *uE = A.f[CF_UE], *vE = A.f[CF_VE], *uN = A.f[CF_UN], *vN = A.f[CF_VN], *shU = A.f[CF_SHEARU];
+    const double *dyE = A.g[CG_DYE], *dxN = A.g[CG_DXN], *uarea = A.g[CG_UAREA];
+    const double dxT = A.g[CG_DXT][o], dyT = A.g[CG_DYT][o];
+    const double divT = dyE[o] * uE[o] - dyE[w] * uE[w] + dxN[o] * vN[o] - dxN[s] * vN[s];
+    const double tensionT = (dyT * dyT) * (uE[o] / dyE[o] - uE[w] / dyE[w]) - (dxT * dxT) * (vN[o] / dxN[o] - vN[s] / dxN[s]);
+    const double shearT = (dxT * dxT) * (uN[o] / dxN[o] - uN[s] / dxN[s]) + (dyT * dyT) * (vE[o] / dyE[o] - vE[w] / dyE[w]);
+    const double shearTsqr = (shU[o] * shU[o] * uarea[o] + shU[s] * shU[s] * uarea[s] + shU[sw] * shU[sw] * uarea[sw] +
+                              shU[w] * shU[w] * uarea[w]) / (uarea[o] + uarea[s] + uarea[sw] + uarea[w]);
+    const double DeltaT = sqrt(divT * divT + A.p.e_factor * (tensionT * tensionT + shearTsqr));
+    const double tr = tarear[o];
+    const double dv = divT * tr;
+    divu[o] = dv;
+    const double tmp = DeltaT * tr;
+    rdg_conv[o] = -fmin(dv, 0.0);
+    rdg_shear[o] = 0.5 * (tmp - fabs(dv));
+    shear[o] = tr * sqrt(tensionT * tensionT + shearT * shearT);
+    vort[o] = tr * ((dyE[o] * vE[o] - dyE[w] * vE[w]) - (dxN[o] * uN[o] - dxN[s] * uN[s]));
+}
+
 __global__ void cg_fold_gather(EvpCgFold F)
 {
     const int q = blockIdx.y;
@@ -714,4 +744,10 @@ void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t 
     case 5: hipLaunchKernelGGL(cg_strength_u, grid, block, 0, st, A, const_cast<double *>(A.strengthU)); break;
     default: hipLaunchKernelGGL(cg_zero_outside, grid, block, 0, st, A); break;
     }
+}
+
+void evp_launch_cgrid_deformations(const EvpCgrid &A, const double *tarear, double *divu, double *shear, double *vort,
+                                   double *rdg_conv, double *rdg_shear, hipStream_t st)
+{
+    hipLaunchKernelGGL(cg_deformations_t, cg_grid(A), dim3(TX, TY), 0, st, A, tarear, divu, shear, vort, rdg_conv, rdg_shear);
 }

@@ -41,6 +41,7 @@ struct CGridState {
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, flip << 3 | fused << 2 | first << 1 | avg_strength)
     double t_loop_ms = 0;
     int t_nsub = 0;
+    double *tarear = nullptr, *post[5] = {};   // deformationsC_T: 1/tarea (static), divu shear vort rdg_conv rdg_shear
 };
 static CGridState CG;
 
@@ -53,6 +54,7 @@ void cgrid_free()
     for (auto &p : CG.f) F(p);
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
+    F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.fac[0]); F(CG.fac[1]); F(CG.d_flags); F(CG.mask); F(CG.mask4); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
     for (auto &f : CG.fold) { F(f.dst); F(f.a); F(f.b); F(f.flip); }
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
@@ -420,6 +422,39 @@ int cice_evp_hip_cgrid_download(double *const *fields19)
     HIPC(hipStreamSynchronize(S.stream));
     float ms = 0;
     if (CG.t_nsub && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) CG.t_loop_ms = ms;
+    return 0;
+}
+
+// deformationsC_T (ice_dyn_shared.F90:1968-2074; evp() calls it right after the C-grid loop, ice_dyn_evp.F90:1106-1119) on
+// the device, from the loop's resident final state: divu, shear, vort, rdg_conv, rdg_shear on the T-cells of dyn_prep2's
+// list; the five arrays are inout (every other cell keeps the caller's value).  tarear: ice_grid's array, taken at the
+// first call (NULL afterwards keeps it).
+int cice_evp_hip_cgrid_deformations(const double *tarear, double *divu, double *shear, double *vort, double *rdg_conv,
+                                    double *rdg_shear)
+{
+    if (!CG.uploaded) return fail(-1, "C-grid EVP: nothing uploaded");
+    double *host[5] = {divu, shear, vort, rdg_conv, rdg_shear};
+    for (double *p : host)
+        if (!p) return fail(-1, "null argument");
+    if (!CG.tarear) {
+        if (!tarear) return fail(-1, "tarear needed on the first call");
+        if (alloc_d(&CG.tarear, S.n)) return -1;
+    }
+    if (tarear && h2d(CG.tarear, tarear)) return -1;
+    CopyBatch U;
+    for (int k = 0; k < 5; ++k) {
+        if (!CG.post[k] && alloc_d(&CG.post[k], S.n)) return -1;
+        U.items.push_back({CG.post[k], host[k]});
+    }
+    if (h2d_batch(U)) return -1;
+    EvpCgrid A;
+    fill(A);
+    evp_launch_cgrid_deformations(A, CG.tarear, CG.post[0], CG.post[1], CG.post[2], CG.post[3], CG.post[4], S.stream);
+    HIPC(hipGetLastError());
+    CopyBatch D;
+    for (int k = 0; k < 5; ++k) D.items.push_back({host[k], CG.post[k]});
+    if (d2h_batch(D)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
     return 0;
 }
 

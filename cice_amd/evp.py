@@ -45,7 +45,7 @@ EXPORTS = [
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
-    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
+    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_deformations", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -316,6 +316,15 @@ class EvpHip:
 
     def cgrid_subcycle(self, ndte: int):
         _check(self.lib, self.lib.cice_evp_hip_cgrid_subcycle(C.c_int32(ndte)), "(dyn_evp_hip_cgrid_subcycle)")
+
+    def cgrid_deformations(self, tarear, prev: dict | None = None) -> dict:
+        """deformationsC_T on the resident final state of the C-grid loop; `prev`: the five inout arrays (zeros if absent)."""
+        keys = ("divu", "shear", "vort", "rdg_conv", "rdg_shear")
+        out = {k: (np.array(prev[k], dtype=np.float64, order="C", copy=True) if prev else np.zeros(self.shape)) for k in keys}
+        t = self._c(tarear) if tarear is not None else None
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_deformations(_dp(t) if t is not None else None, *[_dp(out[k]) for k in keys]),
+               "(dyn_evp_hip_cgrid_deformations)")
+        return out
 
     def cgrid_download(self) -> dict:
         out = {k: np.zeros(self.shape) for k in CGRID_FIELDS}

@@ -31,7 +31,7 @@ module ice_dyn_evp_hip
 
   public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body, &
             dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses, dyn_evp_hip_cgrid_run, &
-            dyn_evp_hip_keep_stresses_resident
+            dyn_evp_hip_keep_stresses_resident, dyn_evp_hip_cgrid_deformations
 
   ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
   type, bind(C) :: cice_evp_hip_dims
@@ -203,6 +203,13 @@ module ice_dyn_evp_hip
        type(c_ptr), dimension(23), intent(in) :: inputs23
        integer(c_int32_t), dimension(*), intent(in) :: iceTmask, iceUmask, iceEmask, iceNmask
      end function cice_evp_hip_cgrid_run
+
+     integer(c_int) function cice_evp_hip_cgrid_deformations(tarear, divu, shear, vort, rdg_conv, rdg_shear) &
+          bind(C, name='cice_evp_hip_cgrid_deformations')
+       import :: c_int, c_double
+       real(c_double), dimension(*), intent(in) :: tarear
+       real(c_double), dimension(*), intent(inout) :: divu, shear, vort, rdg_conv, rdg_shear
+     end function cice_evp_hip_cgrid_deformations
 
      integer(c_int) function cice_evp_hip_download(fields32) bind(C, name='cice_evp_hip_download')
        import :: c_int, c_ptr
@@ -693,6 +700,18 @@ contains
     call ice_timer_stop(timer_evp1dcore)
 
   end subroutine dyn_evp_hip_cgrid_run
+
+!-----------------------------------------------------------------------
+! C grid: replaces the call of deformationsC_T that follows the loop in evp() (ice_dyn_evp.F90:1106-1119): divu, shear,
+! vort, rdg_conv, rdg_shear from the final state dyn_evp_hip_cgrid_run left on the device.
+  subroutine dyn_evp_hip_cgrid_deformations
+    use ice_grid, only: tarear
+    use ice_state, only: divu, shear, vort
+    use ice_flux, only: rdg_conv, rdg_shear
+    character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_deformations)'
+    if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', file=__FILE__, line=__LINE__)
+    call check(cice_evp_hip_cgrid_deformations(tarear, divu, shear, vort, rdg_conv, rdg_shear), subname, __FILE__, __LINE__)
+  end subroutine dyn_evp_hip_cgrid_deformations
 
 !-----------------------------------------------------------------------
 ! ice_flux's stress arrays <- the device copy.  Call before anything but evp() reads them (restart write,

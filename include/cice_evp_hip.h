@@ -257,6 +257,11 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
 int cice_evp_hip_cgrid_subcycle(int32_t ndte);
 int cice_evp_hip_cgrid_download(double *const *fields19);
 int cice_evp_hip_cgrid_sync(void);
+/* deformationsC_T (ice_dyn_shared.F90:1968-2074), which evp() calls right after the C-grid loop (ice_dyn_evp.F90:1106-1119),
+ * on the device from the loop's resident final state: divu, shear, vort, rdg_conv, rdg_shear (ice_state / ice_flux arrays,
+ * inout: written on the ice T-cells of dyn_prep2's list only).  tarear = ice_grid's 1/tarea, taken at the first call.  */
+int cice_evp_hip_cgrid_deformations(const double *tarear, double *divu, double *shear, double *vort, double *rdg_conv,
+                                    double *rdg_shear);
 /* Host only (no device needed): the fold step of field location `loc` (0 centre, 1 NE corner, 2 E face, 3 N face) on a
  * tripole grid -- x[dst] = s*0.5*(x[a] + isign*x[b]) (b >= 0; -2: partner eliminated) or s*x[a] (b == -1), s = flip ? isign : 1.
  * First call with NULL lists for the count.                                                                       */

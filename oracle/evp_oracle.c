@@ -1144,3 +1144,42 @@ void evp_oracle_cgrid_subcycle(const evp_oracle_domain *d, const evp_oracle_para
     free(tensionU);
     free(strengthU);
 }
+
+
+/* =====================================================================
+ * deformationsC_T, dynamics/ice_dyn_shared.F90:1968-2074 (strain_rates_Tdtsd :2171-2243, strain_rates_Tdt :2251-2311);
+ * evp() calls it right after the C-grid loop (ice_dyn_evp.F90:1106-1119).  On the T-cells of dyn_prep2's list
+ * (ilo..ihi+1 x jlo..jhi+1 where iceTmask): divu, shear, vort, rdg_conv, rdg_shear; every other cell keeps its value.
+ * ===================================================================== */
+void evp_oracle_deformations_c_t(const evp_oracle_domain *d, double e_factor, const double *uvelE, const double *vvelE,
+                                 const double *uvelN, const double *vvelN, const double *dxN, const double *dyE,
+                                 const double *dxT, const double *dyT, const double *tarear, const double *uarea,
+                                 const double *shearU, const int32_t *iceTmask, double *vort, double *shear, double *divu,
+                                 double *rdg_conv, double *rdg_shear)
+{
+    const int nx = d->nx_block;
+    const size_t nb = (size_t)nx * d->ny_block;
+    for (int b = 0; b < d->nblocks; ++b)
+        for (int j = d->jlo[b]; j <= d->jhi[b] + 1; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b] + 1; ++i) {
+                const size_t c = b * nb + IX(i, j), w = c - 1, s = c - nx, sw = s - 1;
+                if (!iceTmask[c]) continue;
+                /* strain_rates_Tdt: divergence and tension (x area) */
+                const double divT = dyE[c] * uvelE[c] - dyE[w] * uvelE[w] + dxN[c] * vvelN[c] - dxN[s] * vvelN[s];
+                const double tensionT = (dyT[c] * dyT[c]) * (uvelE[c] / dyE[c] - uvelE[w] / dyE[w]) -
+                                        (dxT[c] * dxT[c]) * (vvelN[c] / dxN[c] - vvelN[s] / dxN[s]);
+                /* strain_rates_Tdtsd: shear at the T point from the N / E velocities */
+                const double shearT = (dxT[c] * dxT[c]) * (uvelN[c] / dxN[c] - uvelN[s] / dxN[s]) +
+                                      (dyT[c] * dyT[c]) * (vvelE[c] / dyE[c] - vvelE[w] / dyE[w]);
+                const double shearTsqr = (shearU[c] * shearU[c] * uarea[c] + shearU[s] * shearU[s] * uarea[s] +
+                                          shearU[sw] * shearU[sw] * uarea[sw] + shearU[w] * shearU[w] * uarea[w]) /
+                                         (uarea[c] + uarea[s] + uarea[sw] + uarea[w]);
+                const double DeltaT = sqrt(divT * divT + e_factor * (tensionT * tensionT + shearTsqr));
+                divu[c] = divT * tarear[c];
+                const double tmp = DeltaT * tarear[c];
+                rdg_conv[c] = -fmin(divu[c], 0.0);
+                rdg_shear[c] = 0.5 * (tmp - fabs(divu[c]));
+                shear[c] = tarear[c] * sqrt(tensionT * tensionT + shearT * shearT);
+                vort[c] = tarear[c] * ((dyE[c] * vvelE[c] - dyE[w] * vvelE[w]) - (dxN[c] * uvelN[c] - dxN[s] * uvelN[s]));
+            }
+}

@@ -288,6 +288,22 @@ def cgrid_subcycle(dom: OracleDomain, params: Params, ndte: int, state: dict, in
     return work
 
 
+def deformations_c_t(dom: OracleDomain, e_factor, fields: dict, static: dict, tarear, iceTmask, prev: dict | None = None) -> dict:
+    """deformationsC_T (ice_dyn_shared.F90:1968-2074) from the loop's final uvelE/vvelE/uvelN/vvelN/shearU; `prev`: the
+    five arrays as they were (cells off the T list keep them; zeros when absent)."""
+    lib().evp_oracle_deformations_c_t.restype = None
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    out = {k: (np.array(prev[k], dtype=np.float64, order="C", copy=True) if prev else np.zeros(dom.shape))
+           for k in ("vort", "shear", "divu", "rdg_conv", "rdg_shear")}
+    a = [f64(fields[k]) for k in ("uvelE", "vvelE", "uvelN", "vvelN")] + [f64(static[k]) for k in ("dxN", "dyE", "dxT", "dyT")] + \
+        [f64(tarear), f64(static["uarea"]), f64(fields["shearU"])]
+    tm = np.ascontiguousarray(iceTmask, dtype=np.int32)
+    lib().evp_oracle_deformations_c_t(C.byref(dom.c), C.c_double(e_factor), *[_dp(x) for x in a],
+                                      tm.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      *[_dp(out[k]) for k in ("vort", "shear", "divu", "rdg_conv", "rdg_shear")])
+    return out
+
+
 HALO_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_int)
 _halo_cb_keep = None
 

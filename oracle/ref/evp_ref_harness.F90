@@ -24,13 +24,13 @@ module evp_cgrid_capture
   use ice_domain, only: nblocks
   use ice_domain_size, only: max_blocks
   use ice_blocks, only: nx_block, ny_block
-  use ice_state, only: uvel, vvel, uvelE, vvelE, uvelN, vvelN, strength
+  use ice_state, only: uvel, vvel, uvelE, vvelE, uvelN, vvelN, strength, divu, shear, vort
   use ice_flux
   use ice_calendar, only: dt_dyn
   use ice_dyn_shared
   use ice_dyn_evp, only: evp, ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
 #ifdef HARNESS_HIP_BODY
-  use ice_dyn_evp_hip, only: dyn_evp_hip_cgrid_run
+  use ice_dyn_evp_hip, only: dyn_evp_hip_cgrid_run, dyn_evp_hip_cgrid_deformations
 #endif
   use evp_dumpio
   implicit none
@@ -110,6 +110,12 @@ contains
           call dump_peek(trim(tg)//'_etax2U', 19, nx_block, ny_block, max_blocks, nblocks)
           call dump_peek(trim(tg)//'_shearU', 20, nx_block, ny_block, max_blocks, nblocks)
           call dump_peek(trim(tg)//'_deltaU', 21, nx_block, ny_block, max_blocks, nblocks)
+          ! deformationsC_T on the device, from the state the loop left there (evp(ndte = 0) above has already filled the
+          ! five arrays from the INITIAL velocities: every list cell must be overwritten)
+          call dyn_evp_hip_cgrid_deformations
+          call dump_r8_3d(trim(tg)//'_divu', divu, nblocks);         call dump_r8_3d(trim(tg)//'_shear', shear, nblocks)
+          call dump_r8_3d(trim(tg)//'_vort', vort, nblocks)
+          call dump_r8_3d(trim(tg)//'_rdg_conv', rdg_conv, nblocks); call dump_r8_3d(trim(tg)//'_rdg_shear', rdg_shear, nblocks)
           write(*,'(a,i3,a,i5,3es24.16)') 'Hcall', ic, ' nsub', ns, &
                maxval(abs(uvelE(:,:,1:nblocks))), maxval(abs(vvelN(:,:,1:nblocks))), maxval(abs(stresspT(:,:,1:nblocks)))
        enddo
@@ -132,6 +138,10 @@ contains
        call dump_r8_3d(trim(tg)//'_taubxE', taubxE, nblocks);       call dump_r8_3d(trim(tg)//'_taubyN', taubyN, nblocks)
        call dump_peek(trim(tg)//'_zetax2T', 17, nx_block, ny_block, max_blocks, nblocks);  call dump_peek(trim(tg)//'_etax2T', 18, nx_block, ny_block, max_blocks, nblocks);  call dump_peek(trim(tg)//'_etax2U', 19, nx_block, ny_block, max_blocks, nblocks)
        call dump_peek(trim(tg)//'_shearU', 20, nx_block, ny_block, max_blocks, nblocks);   call dump_peek(trim(tg)//'_deltaU', 21, nx_block, ny_block, max_blocks, nblocks)
+       ! deformationsC_T (ice_dyn_shared.F90:1968-2074), called by evp() right after the loop (:1106-1119)
+       call dump_r8_3d(trim(tg)//'_divu', divu, nblocks);         call dump_r8_3d(trim(tg)//'_shear', shear, nblocks)
+       call dump_r8_3d(trim(tg)//'_vort', vort, nblocks)
+       call dump_r8_3d(trim(tg)//'_rdg_conv', rdg_conv, nblocks); call dump_r8_3d(trim(tg)//'_rdg_shear', rdg_shear, nblocks)
        write(*,'(a,i3,a,i5,3es24.16)') 'Ccall', ic, ' nsub', ns, &
             maxval(abs(uvelE(:,:,1:nblocks))), maxval(abs(vvelN(:,:,1:nblocks))), maxval(abs(stresspT(:,:,1:nblocks)))
     enddo

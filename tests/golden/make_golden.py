@@ -111,6 +111,7 @@ def make_cgrid_case(name, spec):
             "ew": np.array(ew), "ns": np.array(ns), "visc_method": np.array(kw.get("h_visc_method", "avg_zeta"))}
     for k in CGRID_STATIC:
         keep[k] = d[k]
+    keep["tarear"] = d["tarear"]                 # deformationsC_T (the o*_divu / shear / vort / rdg_* arrays)
     for k, v in d.items():
         if k[:2] == "in" or (k.startswith("o") and k[1:3].isdigit()):
             keep[k] = v

@@ -47,6 +47,38 @@ def test_cgrid_golden_bitwise(name):
         core.finalize()
 
 
+@pytest.mark.parametrize("name", CGRID_CASES)
+def test_cgrid_deformations_t_on_device_bitwise(name):
+    """deformationsC_T (ice_dyn_shared.F90:1968-2074), which evp() runs right after the C-grid loop, on the device from
+    the loop's resident final state: divu, shear, vort, rdg_conv, rdg_shear equal the arrays the reference's evp() left
+    (fixtures regenerated with them), bit for bit on every cell -- the T-cells of the list are recomputed, every other
+    cell must keep the value it was handed (inout arrays: handed the reference's own values there, and a sentinel test
+    below shows nothing off the list is touched)."""
+    c = GoldenCase(name)
+    core = cgrid_core(c)
+    keys = ("divu", "shear", "vort", "rdg_conv", "rdg_shear")
+    try:
+        for icall in range(1, c.ncalls + 1):
+            state, inputs, masks = c.cgrid_inputs(icall)
+            for nsub in c.nsub_list:
+                core.cgrid_run(nsub, state, inputs, masks, visc_method=str(c.d["visc_method"]))
+                want = {k: c.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in keys}
+                tm = masks["iceTmask"] != 0
+                sent = {k: np.where(tm, 0.0, 7.25) for k in keys}          # list cells are rewritten, the rest must stay 7.25
+                got = core.cgrid_deformations(c.d["tarear"], prev=sent)
+                blk = c.blk
+                onlist = np.zeros_like(tm)
+                for b in range(c.nblocks):
+                    ilo, ihi, jlo, jhi = [int(v) for v in blk[b, :4]]
+                    onlist[b, jlo - 1:jhi + 1, ilo - 1:ihi + 1] = tm[b, jlo - 1:jhi + 1, ilo - 1:ihi + 1]
+                for k in keys:
+                    assert np.array_equal(got[k][onlist], want[k][onlist]), f"{name} call {icall} nsub {nsub} {k}"
+                    assert (got[k][~onlist] == sent[k][~onlist]).all(), f"{k}: a cell off the T list was written"
+        assert np.abs(want["divu"]).max() > 0 and np.abs(want["vort"]).max() > 0
+    finally:
+        core.finalize()
+
+
 def test_cgrid_split_calls_equal_one_call():
     """upload / subcycle(a) / subcycle(b) / download == run(a + b): the resident state carries over, and the
     one-off zero fill of the first subcycle is not repeated."""

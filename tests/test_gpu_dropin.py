@@ -83,6 +83,8 @@ def test_reference_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, kw
 
 CGRID_LOOP_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
                      "taubxE", "taubyN", "zetax2T", "etax2T", "etax2U", "shearU", "deltaU"]
+# deformationsC_T on the device (dyn_evp_hip_cgrid_deformations), from the state the HIP loop left there
+CGRID_DOWNSTREAM = ["divu", "shear", "vort", "rdg_conv", "rdg_shear"]
 CGRID_CASES = [
     (40, 36, 20, 18, "cyclic", dict(icecase="full")),
     (60, 44, 20, 15, "cyclic", dict(icecase="patchy", h_visc_method="avg_strength", h_capping=0.5)),
@@ -114,7 +116,7 @@ def test_reference_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, 
     checked = 0
     for icall in (1, 2):
         for nsub in (1, 120):
-            for f in CGRID_LOOP_FIELDS + ["strintxE", "strintyN"]:
+            for f in CGRID_LOOP_FIELDS + ["strintxE", "strintyN"] + CGRID_DOWNSTREAM:
                 hip = d[f"h{icall:02d}n{nsub:04d}_{f}"]
                 ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
                 if f.startswith("strint"):     # evp()'s own halo update after the loop (on a tripole grid it also
@@ -124,4 +126,5 @@ def test_reference_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, 
                     f"C grid call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
                     f"max|d|={np.abs(hip - ref).max():.3e}")
                 checked += 1
-    assert np.abs(d["o02n0120_uvelE"]).max() > 1e-3 and checked == 2 * 2 * (len(CGRID_LOOP_FIELDS) + 2)
+    assert np.abs(d["o02n0120_uvelE"]).max() > 1e-3 and checked == 2 * 2 * (len(CGRID_LOOP_FIELDS) + 2 + len(CGRID_DOWNSTREAM))
+    assert np.abs(d["o02n0120_divu"]).max() > 0

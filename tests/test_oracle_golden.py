@@ -210,3 +210,25 @@ def test_seabed_prob_oracle_bitwise():
                                 t["vice"][:, None], c.d["hwater"], tm, um)
         assert np.abs(dyn["TbU"]).max() > 0
         assert np.array_equal(tb, dyn["TbU"]), f"call {icall}"
+
+
+@pytest.mark.parametrize("name", CGRID_CASES)
+def test_cgrid_deformations_t_oracle_bitwise(name):
+    """deformationsC_T (ice_dyn_shared.F90:1968-2074) restated in oracle/evp_oracle.c: from the reference's final face
+    velocities and shearU, the five arrays evp() leaves (divu, shear, vort, rdg_conv, rdg_shear) bit for bit."""
+    c = GoldenCase(name)
+    keys = ("vort", "shear", "divu", "rdg_conv", "rdg_shear")
+    for icall in range(1, c.ncalls + 1):
+        _, _, masks = c.cgrid_inputs(icall)
+        for nsub in c.nsub_list:
+            want = {k: c.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in keys}
+            tm = masks["iceTmask"] != 0
+            onlist = np.zeros_like(tm)                                     # dyn_prep2's T list: ilo..ihi+1 x jlo..jhi+1
+            for b in range(c.nblocks):
+                ilo, ihi, jlo, jhi = [int(v) for v in c.blk[b, :4]]
+                onlist[b, jlo - 1:jhi + 1, ilo - 1:ihi + 1] = tm[b, jlo - 1:jhi + 1, ilo - 1:ihi + 1]
+            start = {k: np.where(onlist, 123.0, want[k]) for k in keys}   # the T list must be rewritten
+            got = oracle.deformations_c_t(c.oracle_domain(), c.scal[4], c.cgrid_expected(icall, nsub), c.cgrid_static(),
+                                          c.d["tarear"], masks["iceTmask"], prev=start)
+            for k in keys:
+                assert np.array_equal(got[k], want[k]), f"{name} call {icall} nsub {nsub} {k}"
