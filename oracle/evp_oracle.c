@@ -1183,3 +1183,209 @@ void evp_oracle_deformations_c_t(const evp_oracle_domain *d, double e_factor, co
                 vort[c] = tarear[c] * ((dyE[c] * vvelE[c] - dyE[w] * vvelE[w]) - (dxN[c] * uvelN[c] - dxN[s] * uvelN[s]));
             }
 }
+
+/* =====================================================================
+ * Preparation phase of evp() for grid_ice = 'C' (dynamics/ice_dyn_evp.F90:383-735 and 770-840, calc_strair branch, ocean
+ * and atmosphere forcing on the T grid): dyn_prep1 (:383-416), the T-grid halo updates (:418-428, 471-474), the state-masked
+ * averages T -> U / E / N (:430-453; grid_average_X2YS 'NE' / 'E' / 'N', ice_grid.F90:4190-4209, 4290-4306, 4332-4348),
+ * the flux averages of the wind stress T -> N / E (:485-488; grid_average_X2YF, ice_grid.F90:4728-4782), dyn_prep2 at
+ * U, N and E points (:563-674; ice_dyn_shared.F90:697-838, rheofactX :805-811), the zeroing of the T / U stresses off the
+ * ice (:676-691), then the velocity exchanges and face -> face / face -> corner averages (:703-731).  Not here: ice
+ * strength (Icepack) and its halo update, the seabed stress factors (evp_oracle_seabed_lkd_c below).
+ *
+ * g: the 23 static arrays of evp_oracle_cgrid_subcycle (uarea 8, tarea 9, earea 10, narea 11, epm 14, npm 15, uvm 16, hm 17).
+ * masks4: tmask, umaskCD, emask, nmask.  fcor3: fcor_blk, fcorE_blk, fcorN_blk.  T: the 11 T-grid fields of evp_oracle_prep.
+ * f: the first 14 arrays of the loop's state table (inout): uvelE vvelE uvelN vvelN uvel vvel stresspT stressmT stress12T
+ * stress12U strintxE strintyN taubxE taubyN.  in: the loop's 23 per-call inputs (out; [0] strength is not touched).
+ * iceUmask, iceEmask, iceNmask: in = the previous call's, out = new; iceTmask: out.
+ * ===================================================================== */
+static void avg_T2X_S(const evp_oracle_domain *d, int dir, const double *w1, const double *wt, const double *m, double *w2)
+{
+    const int nx = d->nx_block;
+    const size_t nb = (size_t)nx * d->ny_block;
+    memset(w2, 0, sizeof(double) * nb * d->nblocks);
+    for (int b = 0; b < d->nblocks; ++b)
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const size_t c = b * nb + IX(i, j), q = dir == 2 ? c + 1 : c + nx;       /* 2: 'E' (i+1), 3: 'N' (j+1) */
+                const double wtmp = (m[c] * wt[c] + m[q] * wt[q]);
+                if (wtmp != 0.0) w2[c] = (m[c] * w1[c] * wt[c] + m[q] * w1[q] * wt[q]) / wtmp;
+            }
+}
+static void avg_T2X_F(const evp_oracle_domain *d, int dir, const double *w1, const double *wt, const double *wt2, double *w2)
+{
+    const int nx = d->nx_block;
+    const size_t nb = (size_t)nx * d->ny_block;
+    memset(w2, 0, sizeof(double) * nb * d->nblocks);
+    for (int b = 0; b < d->nblocks; ++b)
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const size_t c = b * nb + IX(i, j), q = dir == 2 ? c + 1 : c + nx;
+                w2[c] = p5 * (w1[c] * wt[c] + w1[q] * wt[q]) / wt2[c];
+            }
+}
+
+void evp_oracle_cgrid_prep(const evp_oracle_domain *d, const evp_oracle_prep_params *p, const int32_t *const *masks4,
+                           const double *const *fcor3, const double *const *g, const double *const *T, double *const *f,
+                           double *const *in, int32_t *iceTmask, int32_t *iceUmask, int32_t *iceEmask, int32_t *iceNmask)
+{
+    const int nx = d->nx_block, ny = d->ny_block;
+    const size_t nb = (size_t)nx * ny, n = nb * d->nblocks;
+    const int32_t *tmask = masks4[0];
+    const double *uarea = g[8], *tarea = g[9], *earea = g[10], *narea = g[11], *epm = g[14], *npm = g[15], *uvm = g[16],
+                 *hm = g[17];
+    const double rheo_area_min = 1e-3;                     /* ice_dyn_shared.F90:67 */
+    double *t[PT_COUNT];
+    for (int k = 0; k < PT_COUNT; ++k) {
+        t[k] = (double *)malloc(sizeof(double) * n);
+        memcpy(t[k], T[k], sizeof(double) * n);
+    }
+    double *tmass = (double *)malloc(sizeof(double) * n), *maskd = (double *)malloc(sizeof(double) * n);
+    unsigned char *tmphm = (unsigned char *)malloc(n);
+    /* dyn_prep1 */
+    for (int b = 0; b < d->nblocks; ++b) {
+        const size_t o = b * nb;
+        for (int j = 1; j <= ny; ++j)
+            for (int i = 1; i <= nx; ++i) {
+                const size_t c = o + IX(i, j);
+                tmass[c] = tmask[c] ? (p->rhoi * t[PT_VICE][c] + p->rhos * t[PT_VSNO][c]) : 0.0;
+                tmphm[c] = tmask[c] && (t[PT_AICE][c] > p->dyn_area_min) && (tmass[c] > p->dyn_mass_min);
+                iceTmask[c] = 0;
+            }
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                int any = 0;
+                for (int dj = -1; dj <= 1; ++dj)
+                    for (int di = -1; di <= 1; ++di) any |= tmphm[o + IX(i + di, j + dj)];
+                iceTmask[o + IX(i, j)] = any && tmask[o + IX(i, j)];
+            }
+    }
+    for (size_t c = 0; c < n; ++c) maskd[c] = (double)iceTmask[c];
+    evp_oracle_halo_update(d, maskd, 0, 0, 0, 0.0);
+    for (size_t c = 0; c < n; ++c) iceTmask[c] = maskd[c] != 0.0;
+    evp_oracle_halo_update(d, tmass, 0, 0, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_AICE_INIT], 0, 0, 0, 0.0);
+    evp_oracle_halo_update(d, t[PT_CDN_OCN], 0, 0, 0, 0.0);
+    for (int k = PT_UOCN; k <= PT_STRAIRY; ++k) evp_oracle_halo_update(d, t[k], 0, 1, 0, 0.0);
+
+    /* the averages: per location X in {U, E, N}: Xmass, aiX, cdn_ocnX, uocnX, vocnX, ss_tltxX, ss_tltyX, strairxX, strairyX */
+    double *A[3][9];
+    for (int L = 0; L < 3; ++L)
+        for (int k = 0; k < 9; ++k) A[L][k] = (double *)malloc(sizeof(double) * n);
+    const double *src[7] = {tmass, t[PT_AICE_INIT], t[PT_CDN_OCN], t[PT_UOCN], t[PT_VOCN], t[PT_SS_TLTX], t[PT_SS_TLTY]};
+    for (int k = 0; k < 7; ++k) {
+        avg_T2U_S(d, src[k], tarea, hm, A[0][k]);
+        avg_T2X_S(d, 2, src[k], tarea, hm, A[1][k]);
+        avg_T2X_S(d, 3, src[k], tarea, hm, A[2][k]);
+    }
+    for (int k = 0; k < 2; ++k) {
+        avg_T2U_F(d, t[PT_STRAIRX + k], tarea, uarea, A[0][7 + k]);
+        avg_T2X_F(d, 2, t[PT_STRAIRX + k], tarea, earea, A[1][7 + k]);
+        avg_T2X_F(d, 3, t[PT_STRAIRX + k], tarea, narea, A[2][7 + k]);
+    }
+    /* dyn_prep2 at U (only its mask and velocities matter to the C-grid loop), N, E */
+    double *scratch = (double *)malloc(sizeof(double) * n);       /* products of the U pass nothing reads afterwards */
+    for (int L = 0; L < 3; ++L) {
+        const int32_t *Xmask = masks4[1 + L];
+        int32_t *iceX = L == 0 ? iceUmask : (L == 1 ? iceEmask : iceNmask);
+        const double *Xmass = A[L][0], *aiX = A[L][1], *uocnX = A[L][3], *vocnX = A[L][4], *fcor = fcor3[L];
+        double *uX = L == 0 ? f[4] : (L == 1 ? f[0] : f[2]), *vX = L == 0 ? f[5] : (L == 1 ? f[1] : f[3]);
+        /* E: 1 cdn 2 ai 3 uocn 4 vocn 5 waterx 6 forcex 7 massdti 8 fm 9 u_init 10 Tb 11 rheofact; N: + 11 */
+        const int o0 = L == 1 ? 1 : 12;
+        double *cdn = L ? in[o0] : scratch, *ai = L ? in[o0 + 1] : scratch, *uo = L ? in[o0 + 2] : scratch,
+               *vo = L ? in[o0 + 3] : scratch, *water = L ? in[o0 + 4] : scratch, *force = L ? in[o0 + 5] : scratch,
+               *massdti = L ? in[o0 + 6] : scratch, *fm = L ? in[o0 + 7] : scratch, *init = L ? in[o0 + 8] : scratch,
+               *Tb = L ? in[o0 + 9] : scratch, *rheo = L ? in[o0 + 10] : scratch;
+        double *strint = L == 1 ? f[10] : (L == 2 ? f[11] : scratch), *taub = L == 1 ? f[12] : (L == 2 ? f[13] : scratch);
+        if (L) {
+            memcpy(cdn, A[L][2], sizeof(double) * n);
+            memcpy(ai, aiX, sizeof(double) * n);
+            memcpy(uo, uocnX, sizeof(double) * n);
+            memcpy(vo, vocnX, sizeof(double) * n);
+        }
+        for (int b = 0; b < d->nblocks; ++b) {
+            const size_t o = b * nb;
+            for (int j = 1; j <= ny; ++j)
+                for (int i = 1; i <= nx; ++i) {
+                    const size_t c = o + IX(i, j);
+                    water[c] = 0.0; force[c] = 0.0; massdti[c] = 0.0; Tb[c] = 0.0; taub[c] = 0.0;   /* :701-712 */
+                }
+            for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+                for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                    const size_t c = o + IX(i, j);
+                    const int old = iceX[c];
+                    iceX[c] = Xmask[c] && (aiX[c] > p->dyn_area_min) && (Xmass[c] > p->dyn_mass_min);
+                    if (iceX[c]) {
+                        if (!old) { uX[c] = uocnX[c]; vX[c] = vocnX[c]; }
+                    } else {
+                        uX[c] = vX[c] = 0.0;
+                        strint[c] = 0.0;            /* (strintyE / strintxN and the ocean stresses: not the loop's) */
+                    }
+                    init[c] = L == 2 ? vX[c] : uX[c];
+                    if (!iceX[c]) continue;
+                    rheo[c] = aiX[c] > rheo_area_min ? 1.0 : 0.0;
+                    massdti[c] = Xmass[c] / p->dt;
+                    const double fmc = fcor[c] * Xmass[c];
+                    fm[c] = fmc;
+                    const double sgn = copysign(1.0, fmc);
+                    const double wx = uocnX[c] * p->cosw - vocnX[c] * p->sinw * sgn;
+                    const double wy = vocnX[c] * p->cosw + uocnX[c] * p->sinw * sgn;
+                    double tx, ty;
+                    if (p->ssh_coupled) {
+                        tx = -p->gravit * Xmass[c] * A[L][5][c];
+                        ty = -p->gravit * Xmass[c] * A[L][6][c];
+                    } else {
+                        tx = -fmc * vocnX[c];
+                        ty = fmc * uocnX[c];
+                    }
+                    water[c] = L == 2 ? wy : wx;
+                    force[c] = L == 2 ? (A[L][8][c] + ty) : (A[L][7][c] + tx);
+                }
+        }
+    }
+    /* :676-691: T stresses off the T mask, U stresses off the U mask, on every cell (iceUmask is never set on ghosts) */
+    for (size_t c = 0; c < n; ++c) {
+        if (!iceUmask[c]) f[9][c] = 0.0;
+        if (!iceTmask[c]) f[6][c] = f[7][c] = f[8][c] = 0.0;
+    }
+    /* :703-731 */
+    evp_oracle_halo_update(d, f[0], 2, 1, 0, 0.0);
+    evp_oracle_halo_update(d, f[3], 3, 1, 0, 0.0);
+    avg_A(d, 0, f[0], earea, npm, f[2]);
+    avg_A(d, 1, f[3], narea, epm, f[1]);
+    evp_oracle_halo_update(d, f[2], 3, 1, 0, 0.0);
+    evp_oracle_halo_update(d, f[1], 2, 1, 0, 0.0);
+    avg_A(d, 2, f[0], earea, uvm, f[4]);
+    avg_A(d, 3, f[3], narea, uvm, f[5]);
+    evp_oracle_halo_update(d, f[4], 1, 1, 0, 0.0);     /* :735-738 */
+    evp_oracle_halo_update(d, f[5], 1, 1, 0, 0.0);
+    for (int k = 0; k < PT_COUNT; ++k) free(t[k]);
+    for (int L = 0; L < 3; ++L)
+        for (int k = 0; k < 9; ++k) free(A[L][k]);
+    free(tmass); free(maskd); free(tmphm); free(scratch);
+}
+
+/* seabed_stress_factor_LKD at E or N points (grid_location = 'E' / 'N', ice_dyn_shared.F90:1386-1460 with
+ * grid_neighbor_min / _max over the two T-cells sharing the face, ice_grid.F90:4975-4978, 5006-5009); call site
+ * ice_dyn_evp.F90:803-815.  dir 2: E (i, i+1), 3: N (j, j+1). */
+void evp_oracle_seabed_lkd_c(const evp_oracle_domain *d, int dir, double k1, double k2, double alphab, double threshold_hw,
+                             const double *aice, const double *vice, const double *hwater, const int32_t *iceXmask,
+                             double *TbX)
+{
+    const int nx = d->nx_block;
+    const size_t plane = (size_t)nx * d->ny_block;
+    for (int b = 0; b < d->nblocks; ++b) {
+        for (size_t c = b * plane; c < (b + 1) * plane; ++c) TbX[c] = 0.0;
+        for (int j = d->jlo[b]; j <= d->jhi[b]; ++j)
+            for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
+                const size_t c = b * plane + (size_t)(j - 1) * nx + (i - 1), q = dir == 2 ? c + 1 : c + nx;
+                if (!iceXmask[c]) continue;
+                const double hwu = fmin(hwater[c], hwater[q]);
+                const double docalc_tbu = hwu < threshold_hw ? 1.0 : 0.0;
+                const double au = fmax(aice[c], aice[q]);
+                const double hu = fmax(vice[c], vice[q]);
+                const double hcu = au * hwu / k1;
+                TbX[c] = docalc_tbu * k2 * fmax(0.0, (hu - hcu)) * exp(-alphab * (1.0 - au));
+            }
+    }
+}

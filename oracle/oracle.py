@@ -304,6 +304,55 @@ def deformations_c_t(dom: OracleDomain, e_factor, fields: dict, static: dict, ta
     return out
 
 
+C_PREP_MASKS = ["tmask", "umaskCD", "emask", "nmask"]
+C_PREP_FCOR = ["fcor_blk", "fcorE_blk", "fcorN_blk"]
+
+
+def cgrid_prep(dom: OracleDomain, pp: PrepParams, static: dict, tfields: dict, state: dict, prev_inputs: dict | None = None) -> dict:
+    """evp()'s preparation phase for grid_ice = 'C' (ice_dyn_evp.F90:383-735) minus ice strength and seabed stress.
+    static: C_STATIC + C_PREP_MASKS + C_PREP_FCOR; tfields: PREP_T; state: the first 14 of C_FIELDS (absent = zeros) and the
+    previous iceUmask / iceEmask / iceNmask; prev_inputs: C_INPUTS as the previous call left them (cells off the ice keep
+    e.g. their old fmE).  Returns the updated state, C_INPUTS[1:] and the four masks."""
+    lib().evp_oracle_cgrid_prep.restype = None
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    mk = [i32(static[k]) for k in C_PREP_MASKS]
+    fc = [f64(static[k]) for k in C_PREP_FCOR]
+    st = [f64(static[k]) for k in C_STATIC]
+    T = [f64(tfields[k]) for k in PREP_T]
+    out = {k: (np.array(state[k], dtype=np.float64, order="C", copy=True) if k in state else np.zeros(dom.shape))
+           for k in C_FIELDS[:14]}
+    for k in C_INPUTS:
+        out[k] = (np.array(prev_inputs[k], dtype=np.float64, order="C", copy=True) if prev_inputs and k in prev_inputs
+                  else np.zeros(dom.shape))
+    for k in ("iceUmask", "iceEmask", "iceNmask"):
+        out[k] = np.array(state[k], dtype=np.int32, order="C", copy=True) if k in state else np.zeros(dom.shape, dtype=np.int32)
+    out["iceTmask"] = np.zeros(dom.shape, dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    mptr = (C.POINTER(C.c_int32) * 4)(*[ip(a) for a in mk])
+    cptr = (C.POINTER(C.c_double) * 3)(*[_dp(a) for a in fc])
+    gptr = (C.POINTER(C.c_double) * len(st))(*[_dp(a) for a in st])
+    Tptr = (C.POINTER(C.c_double) * len(T))(*[_dp(a) for a in T])
+    fptr = (C.POINTER(C.c_double) * 14)(*[_dp(out[k]) for k in C_FIELDS[:14]])
+    iptr = (C.POINTER(C.c_double) * len(C_INPUTS))(*[_dp(out[k]) for k in C_INPUTS])
+    lib().evp_oracle_cgrid_prep(C.byref(dom.c), C.byref(pp), mptr, cptr, gptr, Tptr, fptr, iptr, ip(out["iceTmask"]),
+                                ip(out["iceUmask"]), ip(out["iceEmask"]), ip(out["iceNmask"]))
+    return out
+
+
+def seabed_lkd_c(dom: OracleDomain, loc: str, k1, k2, alphab, threshold_hw, aice, vice, hwater, iceXmask):
+    """seabed_stress_factor_LKD with grid_location = 'E' / 'N' (ice_dyn_shared.F90:1386-1460)."""
+    lib().evp_oracle_seabed_lkd_c.restype = None
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    a, v, h = f64(aice), f64(vice), f64(hwater)
+    xm = np.ascontiguousarray(iceXmask, dtype=np.int32)
+    out = np.zeros(dom.shape)
+    lib().evp_oracle_seabed_lkd_c(C.byref(dom.c), C.c_int({"E": 2, "N": 3}[loc]), C.c_double(k1), C.c_double(k2),
+                                  C.c_double(alphab), C.c_double(threshold_hw), _dp(a), _dp(v), _dp(h),
+                                  xm.ctypes.data_as(C.POINTER(C.c_int32)), _dp(out))
+    return out
+
+
 HALO_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_int)
 _halo_cb_keep = None
 

@@ -24,7 +24,14 @@ module evp_cgrid_capture
   use ice_domain, only: nblocks
   use ice_domain_size, only: max_blocks
   use ice_blocks, only: nx_block, ny_block
-  use ice_state, only: uvel, vvel, uvelE, vvelE, uvelN, vvelN, strength, divu, shear, vort
+  use ice_state, only: uvel, vvel, uvelE, vvelE, uvelN, vvelN, strength, divu, shear, vort, aice, vice, vsno, aice_init, &
+                       aice0, aicen, vicen
+  use ice_blocks, only: block, get_block
+  use ice_domain, only: blocks_ice, halo_info
+  use ice_boundary, only: ice_HaloUpdate
+  use ice_constants, only: field_loc_center, field_type_scalar, c0, c1
+  use ice_grid, only: tmask
+  use ice_arrays_column, only: Cdn_ocn
   use ice_flux
   use ice_calendar, only: dt_dyn
   use ice_dyn_shared
@@ -40,10 +47,11 @@ contains
   ! ---- C grid: the subcycle inputs are module-private; a preparation-only evp() (ndte = 0) leaves them in place,
   !      evp_peek.c reads them; the very next evp() calls from the same state give the reference's outputs ----
 
-  subroutine cgrid_call(ic, nsub_list, nl, h_ndte, hipmode)
+  subroutine cgrid_call(ic, nsub_list, nl, h_ndte, hipmode, evolve)
     integer(int_kind), intent(in) :: ic, nsub_list(:), nl, h_ndte
-    logical, intent(in) :: hipmode
-    integer(int_kind) :: kk, ns
+    logical, intent(in) :: hipmode, evolve
+    integer(int_kind) :: kk, ns, ib, i, j, ig, jg
+    type(block) :: tb
     character(len=16) :: tg
     if (.not. allocated(c_uE)) then
        allocate(c_uE(nx_block,ny_block,max_blocks), c_vN(nx_block,ny_block,max_blocks), &
@@ -52,6 +60,49 @@ contains
                 c_s12T(nx_block,ny_block,max_blocks), c_s12U(nx_block,ny_block,max_blocks), &
                 c_u(nx_block,ny_block,max_blocks), c_v(nx_block,ny_block,max_blocks))
     endif
+    if (evolve .and. ic == 2) then
+       ! the ice cover between two calls: some cells lose their ice, some open-water cells gain some (dyn_prep2's
+       ! "new ice starts at the ocean velocity" / "no ice: zero" branches, ice_dyn_shared.F90:747-764)
+       do ib = 1, nblocks
+          tb = get_block(blocks_ice(ib), ib)
+          do j = 1, ny_block
+          do i = 1, nx_block
+             ig = tb%i_glob(i); jg = tb%j_glob(j)
+             if (ig < 1 .or. jg < 1 .or. .not. tmask(i,j,ib)) cycle
+             if (aice(i,j,ib) > c0 .and. mod(ig + 3*jg, 7) == 0) then
+                aice(i,j,ib) = c0; vice(i,j,ib) = c0; vsno(i,j,ib) = c0
+             elseif (aice(i,j,ib) == c0 .and. mod(2*ig + jg, 3) /= 0) then
+                aice(i,j,ib) = 0.6_dbl_kind; vice(i,j,ib) = 0.9_dbl_kind; vsno(i,j,ib) = 0.05_dbl_kind
+             endif
+             aice_init(i,j,ib) = aice(i,j,ib)
+          enddo
+          enddo
+       enddo
+       call ice_HaloUpdate(aice,      halo_info, field_loc_center, field_type_scalar)
+       call ice_HaloUpdate(vice,      halo_info, field_loc_center, field_type_scalar)
+       call ice_HaloUpdate(vsno,      halo_info, field_loc_center, field_type_scalar)
+       call ice_HaloUpdate(aice_init, halo_info, field_loc_center, field_type_scalar)
+       aice0(:,:,1:nblocks) = c1 - aice(:,:,1:nblocks)
+       aicen(:,:,1,1:nblocks) = aice(:,:,1:nblocks)
+       vicen(:,:,1,1:nblocks) = vice(:,:,1:nblocks)
+    endif
+    ! what evp()'s preparation phase reads on the C grid (ice_dyn_evp.F90:383-735): the T-grid state and forcing, the
+    ! velocities / stresses / ice masks the previous call left (SURVEY 8 f-2 for grid_ice = 'C')
+    write(tg,'(a,i2.2)') 'cp', ic
+    call dump_r8_3d(trim(tg)//'_aice', aice, nblocks);       call dump_r8_3d(trim(tg)//'_vice', vice, nblocks)
+    call dump_r8_3d(trim(tg)//'_vsno', vsno, nblocks);       call dump_r8_3d(trim(tg)//'_aice_init', aice_init, nblocks)
+    call dump_r8_3d(trim(tg)//'_cdn_ocn', Cdn_ocn, nblocks)
+    call dump_r8_3d(trim(tg)//'_uocn', uocn, nblocks);       call dump_r8_3d(trim(tg)//'_vocn', vocn, nblocks)
+    call dump_r8_3d(trim(tg)//'_ss_tltx', ss_tltx, nblocks); call dump_r8_3d(trim(tg)//'_ss_tlty', ss_tlty, nblocks)
+    call dump_r8_3d(trim(tg)//'_strairxT', strairxT, nblocks); call dump_r8_3d(trim(tg)//'_strairyT', strairyT, nblocks)
+    call dump_r8_3d(trim(tg)//'_uvelE', uvelE, nblocks);   call dump_r8_3d(trim(tg)//'_vvelE', vvelE, nblocks)
+    call dump_r8_3d(trim(tg)//'_uvelN', uvelN, nblocks);   call dump_r8_3d(trim(tg)//'_vvelN', vvelN, nblocks)
+    call dump_r8_3d(trim(tg)//'_uvel', uvel, nblocks);     call dump_r8_3d(trim(tg)//'_vvel', vvel, nblocks)
+    call dump_r8_3d(trim(tg)//'_stresspT', stresspT, nblocks);   call dump_r8_3d(trim(tg)//'_stressmT', stressmT, nblocks)
+    call dump_r8_3d(trim(tg)//'_stress12T', stress12T, nblocks); call dump_r8_3d(trim(tg)//'_stress12U', stress12U, nblocks)
+    call dump_r8_3d(trim(tg)//'_strintxE', strintxE, nblocks);   call dump_r8_3d(trim(tg)//'_strintyN', strintyN, nblocks)
+    call dump_l_3d (trim(tg)//'_iceUmask', iceUmask, nblocks)
+    call dump_l_3d (trim(tg)//'_iceEmask', iceEmask, nblocks);   call dump_l_3d (trim(tg)//'_iceNmask', iceNmask, nblocks)
     ndte = 0
     call evp(dt_dyn)                 ! preparation only
     ndte = h_ndte
@@ -223,6 +274,8 @@ program evp_ref_harness
   integer(int_kind)  :: ntiming     = 0           ! extra evp() calls, timed, after the dumps
   logical            :: hipmode     = .false.     ! drop-in check: HIP core (via ice_dyn_evp1d) vs standard_2d
   logical            :: hipbody     = .false.     ! with hipmode: also Option A, preparation + loop on the device
+  logical            :: h_evolve    = .false.     ! C grid: the ice cover changes before the second call (cells gain / lose ice)
+  character(len=16)  :: h_ssh       = 'geostrophic' ! ssh_stress; 'coupled' also gives the sea surface a slope
   logical            :: hipresident = .false.     ! with hipmode: opt in to device-resident stresses and install the two hooks
                                                   ! (default: NO hook is called -- the unpatched-host contract of dyn_evp1d_run)
   logical            :: time_1d     = .false.     ! timing loop with evp_algorithm='shared_mem_1d' (HARNESS_REF1D build only)
@@ -232,7 +285,7 @@ program evp_ref_harness
   namelist /harness_nml/ grid_kind, kmt_kind, icecase, dumpfile, h_grid_file, h_kmt_file, &
      h_dxrect, h_dyrect, h_dt, h_ndte, ncalls, nsub_list, h_revised, h_arlx, h_brlx, &
      h_capping, h_Ktens, h_e_yield, h_e_plast, h_elasticDamp, h_coriolis, h_seabed, h_seabed_method, &
-     dump_arrays, ntiming, hipmode, hipbody, hipresident, time_1d, h_grid_ice, h_visc_method
+     dump_arrays, ntiming, hipmode, hipbody, hipresident, time_1d, h_grid_ice, h_visc_method, h_evolve, h_ssh
 
   ! ---- locals ----------------------------------------------------------
   integer(int_kind) :: i, j, iblk, icall, k, nsub, nl, ios, nthreads
@@ -289,7 +342,7 @@ program evp_ref_harness
   elasticDamp=h_elasticDamp
   e_yieldcurve=h_e_yield; e_plasticpot=h_e_plast; Ktens=h_Ktens
   deltaminEVP=1e-11_dbl_kind; capping=h_capping
-  coriolis=trim(h_coriolis); ssh_stress='geostrophic'
+  coriolis=trim(h_coriolis); ssh_stress=trim(h_ssh)
   seabed_stress=h_seabed; seabed_stress_method=trim(h_seabed_method)
   k1=7.5_dbl_kind; k2=15._dbl_kind; alphab=20._dbl_kind; threshold_hw=30._dbl_kind   ! ice_in defaults
   dyn_area_min=1e-11_dbl_kind; dyn_mass_min=1e-10_dbl_kind
@@ -343,6 +396,10 @@ program evp_ref_harness
         uocn(i,j,iblk) =  0.2_dbl_kind*y - 0.1_dbl_kind
         vocn(i,j,iblk) = -0.2_dbl_kind*x + 0.1_dbl_kind
         ss_tltx(i,j,iblk) = c0; ss_tlty(i,j,iblk) = c0
+        if (trim(h_ssh) == 'coupled') then
+           ss_tltx(i,j,iblk) = 2.e-6_dbl_kind*sin(twopi*x)*cos(c2*twopi*y)
+           ss_tlty(i,j,iblk) = -1.5e-6_dbl_kind*cos(twopi*x)*sin(twopi*y)
+        endif
         strairxT(i,j,iblk) = aice(i,j,iblk)*0.1_dbl_kind*sin(twopi*x)*sin(p5*twopi*y)
         strairyT(i,j,iblk) = aice(i,j,iblk)*0.1_dbl_kind*sin(p5*twopi*x)*sin(twopi*y)
         if (h_seabed) hwater(i,j,iblk) = 8._dbl_kind + 40._dbl_kind*y   ! shallow shelf in the south
@@ -419,6 +476,9 @@ program evp_ref_harness
         call dump_r8_3d('epm', epm, nblocks);       call dump_r8_3d('npm', npm, nblocks)
         call dump_r8_3d('ratiodxN', ratiodxN, nblocks);   call dump_r8_3d('ratiodxNr', ratiodxNr, nblocks)
         call dump_r8_3d('ratiodyE', ratiodyE, nblocks);   call dump_r8_3d('ratiodyEr', ratiodyEr, nblocks)
+        call dump_l_3d ('umaskCD', umaskCD, nblocks)
+        call dump_l_3d ('emask', emask, nblocks);         call dump_l_3d ('nmask', nmask, nblocks)
+        call dump_r8_3d('fcorE_blk', fcorE_blk, nblocks); call dump_r8_3d('fcorN_blk', fcorN_blk, nblocks)
      endif
   endif
 
@@ -434,7 +494,7 @@ program evp_ref_harness
   do icall = 1, ncalls
 
      if (trim(grid_ice) == 'C') then
-        call cgrid_call(icall, nsub_list, nl, h_ndte, hipmode)
+        call cgrid_call(icall, nsub_list, nl, h_ndte, hipmode, h_evolve)
         cycle
      endif
 

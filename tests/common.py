@@ -54,6 +54,26 @@ class GoldenCase:
     def cgrid_expected(self, icall, nsub):
         return {k: self.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in oracle.C_FIELDS}
 
+    # --- preparation phase on the C grid: what it reads (cp*), with the loop inputs (in*) as its expected products ---
+    def cgrid_prep_static(self):
+        st = self.cgrid_static()
+        st.update({k: self.d[k] for k in oracle.C_PREP_MASKS + oracle.C_PREP_FCOR})
+        return st
+
+    def cgrid_prep_inputs(self, icall=1):
+        """(T-grid fields, state + previous masks evp() is entered with, the loop inputs the previous call left)."""
+        pre = f"cp{icall:02d}_"
+        t = {k: self.d[pre + k] for k in oracle.PREP_T}
+        state = {k: self.d[pre + k] for k in oracle.C_FIELDS[:12]}
+        z = np.zeros_like(self.d["tarea"])
+        last = f"o{icall - 1:02d}n{self.nsub_list[-1]:04d}_"
+        for k in ("taubxE", "taubyN"):
+            state[k] = z if icall == 1 else self.d[last + k]
+        for k in ("iceUmask", "iceEmask", "iceNmask"):
+            state[k] = self.d[pre + k]
+        prev = None if icall == 1 else {k: self.d[f"in{icall - 1:02d}_{k}"] for k in oracle.C_INPUTS}
+        return t, state, prev
+
     # --- preparation phase of evp() (f-2): its inputs, parameters and captured products ---
     def prep_static(self):
         return {k: self.d[k] for k in ("tmask", "umask", "hm", "tarea", "uarea", "fcor_blk")}

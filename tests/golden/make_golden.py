@@ -73,12 +73,13 @@ CASES = {
 # (module-private ones through oracle/ref/evp_peek.c) and the reference's outputs of evp() with grid_ice = 'C'
 CGRID_STATIC = ["dxT", "dyT", "dxU", "dyU", "dxE", "dyE", "dxN", "dyN", "uarea", "tarea", "earea", "narea", "earear",
                 "narear", "epm", "npm", "uvm", "hm", "DminTarea", "ratiodxN", "ratiodxNr", "ratiodyE", "ratiodyEr"]
+CGRID_PREP_STATIC = ["tmask", "umaskCD", "emask", "nmask", "fcor_blk", "fcorE_blk", "fcorN_blk", "hwater"]
 CGRID_CASES = {
     "cgrid_cyc_2x2_patchy": (24, 20, 12, 10, "cyclic", "closed",
-                             dict(icecase="patchy", nsub_list=[1, 2, 120], ncalls=2)),
+                             dict(icecase="patchy", nsub_list=[1, 2, 120], ncalls=2, h_evolve=True)),
     "cgrid_closed_2x2_revp": (24, 20, 12, 10, "closed", "closed",
                               dict(icecase="full", nsub_list=[1, 120], ncalls=2, h_revised=True, h_arlx=300.0,
-                                   h_brlx=300.0)),
+                                   h_brlx=300.0, h_evolve=True, h_ssh="coupled")),
     "cgrid_cyc_3x2pad_cap05_avgstrength": (26, 22, 10, 12, "cyclic", "closed",
                                            dict(icecase="caps", nsub_list=[1, 120], ncalls=1, h_capping=0.5,
                                                 h_Ktens=0.1, h_visc_method="avg_strength")),
@@ -86,9 +87,10 @@ CGRID_CASES = {
                               dict(icecase="full", nsub_list=[1, 120], ncalls=1, h_seabed=True)),
     "cgrid_cyccyc_2x2_cap0_ktens": (24, 20, 12, 10, "cyclic", "cyclic",
                                     dict(icecase="patchy", nsub_list=[1, 120], ncalls=1, h_capping=0.0, h_Ktens=0.2,
-                                         h_e_yield=1.5, h_e_plast=2.5)),
+                                         h_e_yield=1.5, h_e_plast=2.5, h_ssh="coupled")),
     # tripole (u-fold): N-face fields lie ON the fold (top row averaged pairwise), E-face / centre fields mirror across it
-    "cgrid_trip_2x2_full": (28, 20, 14, 10, "cyclic", "tripole", dict(icecase="full", nsub_list=[1, 2, 120], ncalls=2)),
+    "cgrid_trip_2x2_full": (28, 20, 14, 10, "cyclic", "tripole",
+                            dict(icecase="patchy", nsub_list=[1, 2, 120], ncalls=2, h_evolve=True)),
     "cgrid_trip_1blk_patchy_avgstrength": (24, 18, 24, 18, "cyclic", "tripole",
                                            dict(icecase="patchy", nsub_list=[1, 120], ncalls=1, h_capping=0.5,
                                                 h_visc_method="avg_strength")),
@@ -112,8 +114,10 @@ def make_cgrid_case(name, spec):
     for k in CGRID_STATIC:
         keep[k] = d[k]
     keep["tarear"] = d["tarear"]                 # deformationsC_T (the o*_divu / shear / vort / rdg_* arrays)
+    for k in CGRID_PREP_STATIC:                  # the preparation phase on the C grid (cp*: what it reads per call)
+        keep[k] = d[k]
     for k, v in d.items():
-        if k[:2] == "in" or (k.startswith("o") and k[1:3].isdigit()):
+        if k[:2] in ("in", "cp") or (k.startswith("o") and k[1:3].isdigit()):
             keep[k] = v
     path = OUT / f"{name}.npz"
     np.savez_compressed(path, **keep)

@@ -232,3 +232,32 @@ def test_cgrid_deformations_t_oracle_bitwise(name):
                                           c.d["tarear"], masks["iceTmask"], prev=start)
             for k in keys:
                 assert np.array_equal(got[k], want[k]), f"{name} call {icall} nsub {nsub} {k}"
+
+
+@pytest.mark.parametrize("name", CGRID_CASES)
+def test_cgrid_prep_oracle_bitwise(name):
+    """evp()'s preparation phase for grid_ice = 'C' (ice_dyn_evp.F90:383-735: dyn_prep1, the T -> U / E / N averages,
+    dyn_prep2 at U, N and E points, the velocity averages and exchanges) restated in oracle/evp_oracle.c: from the T-grid
+    state and the previous call's velocities / stresses / masks to everything the C-grid loop reads, bit for bit -- the
+    second call of three fixtures has cells gaining and losing ice.  Seabed stress factors (LKD at E / N points) from the
+    resulting masks; the ice strength is Icepack's (taken from the fixture)."""
+    c = GoldenCase(name)
+    pp = oracle.PrepParams(**c.prep_scal_dict())
+    s = c.scal
+    for icall in range(1, c.ncalls + 1):
+        t, state, prev = c.cgrid_prep_inputs(icall)
+        got = oracle.cgrid_prep(c.oracle_domain(), pp, c.cgrid_prep_static(), t, state, prev)
+        want_state, want_in, want_masks = c.cgrid_inputs(icall)
+        if s[23] != 0.0:            # seabed stress, LKD (the only method of the C-grid fixtures)
+            for loc in "EN":
+                got["Tb" + loc] = oracle.seabed_lkd_c(c.oracle_domain(), loc, s[24], s[25], s[26], s[27], t["aice"], t["vice"],
+                                                      c.d["hwater"], got[f"ice{loc}mask"])
+            assert np.abs(want_in["TbE"]).max() > 0
+        for k in oracle.C_MASKS:
+            assert np.array_equal(got[k] != 0, want_masks[k] != 0), f"{name} call {icall} {k}"
+        # the fixture's in* arrays were captured after a complete evp(ndte = 0): the exchange of strintxE / strintyN
+        # that follows the (empty) loop has run (ice_dyn_evp.F90:1436-1440)
+        got["strintxE"] = oracle.halo_update(c.oracle_domain(), got["strintxE"], "Eface", "vector")
+        got["strintyN"] = oracle.halo_update(c.oracle_domain(), got["strintyN"], "Nface", "vector")
+        assert_bitwise(got, want_state, f"{name} call {icall} state")
+        assert_bitwise(got, {k: v for k, v in want_in.items() if k != "strength"}, f"{name} call {icall} inputs")
