@@ -241,6 +241,9 @@ void evp_launch_words_to_bytes(const int32_t *w, uint8_t *b, size_t n, hipStream
 void evp_launch_seabed_prob(const EvpPrep &P, int nblocks, const double *hwater, const double *aicen, const double *vicen,
                             int ncat, double alphab, double rhoi, double rhow, double gravit, double pi, double puny,
                             double *Tbt, double *TbU, unsigned *flagword, hipStream_t st);
+void evp_launch_seabed_prob_t(const EvpPrep &P, int nblocks, const double *hwater, const double *aicen, const double *vicen,
+                              int ncat, double alphab, double rhoi, double rhow, double gravit, double pi, double puny,
+                              double *Tbt, hipStream_t st);
 void evp_launch_seabed_lkd(const EvpPrep &P, int nblocks, const double *hwater, double *TbU, double k1, double k2,
                            double alphab, double threshold_hw, unsigned *flagword, hipStream_t st);
 
@@ -361,3 +364,28 @@ void evp_launch_cgrid_umask(const EvpCgrid &A, double *scratch, int back, hipStr
 // flags bit0: waterxE != uocnE or wateryN != vocnN somewhere, bit1: a TbE / TbN that is not +0, bit2: a rheofact != 1
 void evp_launch_cgrid_call_setup(const EvpCgrid &A, double *facE, double *facN, unsigned *flags, hipStream_t st);
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st);
+
+// Preparation phase of evp() for grid_ice = 'C' on the device (evp_cgrid_prep.hip; ice_dyn_evp.F90:430-453, 479-490,
+// 563-691): the T -> U / E / N averages and dyn_prep2 at U, N and E points in one launch, after dyn_prep1 and the T-grid
+// halo updates of the B-grid preparation (evp_prep.hip: prep1, halo_center).
+struct EvpCgPrep {
+    int nx, ny;
+    size_t plane, n;              // n = plane * nblocks (stride of the four mask words in m4)
+    const int4 *blk;
+    const double *t[11];          // T-grid fields after their halo update (order of EvpPrep::t)
+    const double *tmass, *maskd;  // dyn_prep1's products (maskd: iceTmask as 0/1, halo-updated)
+    const double *hm, *tarea, *uarea, *earea, *narea;
+    const uint8_t *xmask[3];      // umaskCD, emask, nmask
+    const double *fcor[3];        // fcor_blk, fcorE_blk, fcorN_blk
+    int32_t *m4;                  // iceTmask | iceUmask | iceEmask | iceNmask words: U/E/N in = previous call's, out = new
+    double *f[14];                // the loop's state (first 14 of CF_*)
+    double *in[CG_NIN];           // the loop's per-call inputs (CI_*; strength untouched)
+    double dt, gravit, dyn_area_min, dyn_mass_min, cosw, sinw;
+    int ssh_coupled;
+};
+void evp_launch_cgrid_prep(const EvpCgPrep &P, int nblocks, hipStream_t st);
+// seabed_stress_factor_LKD at E and N points (grid_location 'E' / 'N'): TbE, TbN from aice, vice, hwater and mask bits 2, 3
+void evp_launch_cgrid_seabed_lkd(const EvpCgPrep &P, int nblocks, const uint8_t *mask, const double *hwater, double k1, double k2,
+                                 double alphab, double threshold_hw, hipStream_t st);
+// seabed_stress_factor_prob, C-grid tail (ice_dyn_shared.F90:1656-1676): TbE / TbN = max of Tbt over the two T-cells of a face
+void evp_launch_cgrid_seabed_prob_faces(const EvpCgPrep &P, int nblocks, const uint8_t *mask, const double *Tbt, hipStream_t st);

@@ -42,6 +42,20 @@ struct CGridState {
     double t_loop_ms = 0;
     int t_nsub = 0;
     double *tarear = nullptr, *post[5] = {};   // deformationsC_T: 1/tarea (static), divu shear vort rdg_conv rdg_shear
+    // preparation phase on the device (cice_evp_hip_cgrid_prep)
+    struct Prep {
+        bool geo = false, pending = false;     // pending: prepared, cice_evp_hip_cgrid_prep_finish not yet called
+        uint8_t *tmask = nullptr, *xmask[3] = {};
+        double *fcor[3] = {}, *t[11] = {}, *tmass = nullptr, *maskd = nullptr;
+        int *c_dst = nullptr, *c_src = nullptr;
+        signed char *c_vsign = nullptr;
+        int n_center = 0;
+        double *hwater = nullptr, *tbt = nullptr, *aicen = nullptr, *vicen = nullptr;
+        int ncat = 0;
+        std::vector<int32_t> h4;               // the four mask words as they come back
+        cice_evp_hip_prep_params pp{};
+        double t_ms = 0;
+    } prep;
 };
 static CGridState CG;
 
@@ -55,6 +69,13 @@ void cgrid_free()
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
     F(CG.tarear); for (auto &p : CG.post) F(p);
+    {
+        CGridState::Prep &Q = CG.prep;
+        F(Q.tmask); for (auto &p : Q.xmask) F(p);
+        for (auto &p : Q.fcor) F(p);
+        for (auto &p : Q.t) F(p);
+        F(Q.tmass); F(Q.maskd); F(Q.c_dst); F(Q.c_src); F(Q.c_vsign); F(Q.hwater); F(Q.tbt); F(Q.aicen); F(Q.vicen);
+    }
     F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.fac[0]); F(CG.fac[1]); F(CG.d_flags); F(CG.mask); F(CG.mask4); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
     for (auto &f : CG.fold) { F(f.dst); F(f.a); F(f.b); F(f.flip); }
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
@@ -237,6 +258,8 @@ static int build_fold_lists()
     return 0;
 }
 
+int finish_upload(int32_t visc_method);
+
 }  // namespace evp_host
 
 using namespace evp_host;
@@ -327,8 +350,6 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
         B.items.push_back({CG.in[k], inputs23[k]});
     }
     if (h2d_batch(B)) return -1;
-    // evp() zeroes its work arrays at entry (ice_dyn_evp.F90:351-361)
-    for (int k = CF_ZETA; k < CG_NF; ++k) HIPC(hipMemsetAsync(CG.f[k], 0, S.n * sizeof(double), S.stream));
     // the mask byte is composed on the device from the caller's four logical arrays (bit5: iceU of an interior cell,
     // handed on to the ghost cells that mirror it -- the caller's iceUmask is not maintained on ghost cells: dyn_prep2
     // sets it on ilo..ihi x jlo..jhi only, ice_dyn_shared.F90:740-745)
@@ -340,6 +361,18 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
         fill(A);
         evp_launch_cgrid_mask(A, CG.mask4, S.stream);
     }
+    return finish_upload(visc_method);
+}
+
+}  // extern "C"
+
+namespace evp_host {
+// what follows the arrival of the loop's inputs, however they arrived (cice_evp_hip_cgrid_upload: from the host;
+// cice_evp_hip_cgrid_prep: computed here)
+int finish_upload(int32_t visc_method)
+{
+    // evp() zeroes its work arrays at entry (ice_dyn_evp.F90:351-361)
+    for (int k = CF_ZETA; k < CG_NF; ++k) HIPC(hipMemsetAsync(CG.f[k], 0, S.n * sizeof(double), S.stream));
     CG.avg_strength = visc_method;
     unsigned h_flags = ~0u;
     {
@@ -368,6 +401,9 @@ int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const 
     CG.first = true;
     return 0;
 }
+}  // namespace evp_host
+
+extern "C" {
 
 int cice_evp_hip_cgrid_subcycle(int32_t ndte)
 {
@@ -473,6 +509,233 @@ int cice_evp_hip_cgrid_run(int32_t ndte, int32_t visc_method, double *const *fie
     if (cice_evp_hip_cgrid_upload(fields19, inputs23, iceTmask, iceUmask, iceEmask, iceNmask, visc_method)) return -1;
     if (cice_evp_hip_cgrid_subcycle(ndte)) return -1;
     return cice_evp_hip_cgrid_download(fields19);
+}
+
+// ---- the preparation phase on the device (SURVEY 8 f-2 for grid_ice = 'C'; kernels: evp_prep.hip prep1 / halo_center,
+// evp_cgrid_prep.hip, evp_cgrid.hip cg_average) ----------------------------------------------------------------------
+int cice_evp_hip_cgrid_set_prep_geometry(const int32_t *tmask, const int32_t *umaskCD, const int32_t *emask,
+                                         const int32_t *nmask, const double *fcor_blk, const double *fcorE_blk,
+                                         const double *fcorN_blk)
+{
+    if (!S.ready || !CG.geo) return fail(-1, "C-grid EVP: geometry not set");
+    if (!tmask || !umaskCD || !emask || !nmask || !fcor_blk || !fcorE_blk || !fcorN_blk) return fail(-1, "null argument");
+    if (S.plan.center_fold_remote)
+        return fail(-9, "device preparation: T-grid ghost cells across the tripole fold live on other ranks here; keep "
+                        "evp()'s host preparation (cice_evp_hip_cgrid_run) on this configuration");
+    CGridState::Prep &Q = CG.prep;
+    std::vector<uint8_t> h8(S.n);
+    auto B = [&](uint8_t *&p, const int32_t *src) -> int {
+        if (!p) HIPC(hipMalloc((void **)&p, S.n));
+        for (size_t k = 0; k < S.n; ++k) h8[k] = src[k] != 0;
+        HIPC(hipMemcpy(p, h8.data(), S.n, hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (B(Q.tmask, tmask) || B(Q.xmask[0], umaskCD) || B(Q.xmask[1], emask) || B(Q.xmask[2], nmask)) return -1;
+    const double *fc[3] = {fcor_blk, fcorE_blk, fcorN_blk};
+    for (int k = 0; k < 3; ++k)
+        if ((!Q.fcor[k] && alloc_d(&Q.fcor[k], S.n)) || h2d(Q.fcor[k], fc[k])) return -1;
+    for (auto &p : Q.t)
+        if (!p && alloc_d(&p, S.n)) return -1;
+    if ((!Q.tmass && alloc_d(&Q.tmass, S.n)) || (!Q.maskd && alloc_d(&Q.maskd, S.n))) return -1;
+    const HaloPlan &P = S.plan;
+    Q.n_center = (int)P.center_dst.size();
+    if (Q.n_center && !Q.c_dst) {
+        HIPC(hipMalloc((void **)&Q.c_dst, Q.n_center * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&Q.c_src, Q.n_center * sizeof(int32_t)));
+        HIPC(hipMalloc((void **)&Q.c_vsign, Q.n_center));
+        HIPC(hipMemcpy(Q.c_dst, P.center_dst.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.c_src, P.center_src.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.c_vsign, P.center_vsign.data(), Q.n_center, hipMemcpyHostToDevice));
+    }
+    // the loop's inputs persist between calls as the reference's module arrays do (a cell off the ice keeps e.g. its fmE)
+    for (auto &p : CG.in) HIPC(hipMemsetAsync(p, 0, S.n * sizeof(double), S.stream));
+    HIPC(hipMemsetAsync(CG.mask4, 0, 4 * S.n * sizeof(int32_t), S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    Q.geo = true;
+    return 0;
+}
+
+static void fill_prep(EvpCgPrep &P)
+{
+    CGridState::Prep &Q = CG.prep;
+    P.nx = S.d.nx_block; P.ny = S.d.ny_block; P.plane = S.plane; P.n = S.n; P.blk = S.blk;
+    for (int k = 0; k < 11; ++k) P.t[k] = Q.t[k];
+    P.tmass = Q.tmass; P.maskd = Q.maskd;
+    P.hm = CG.g[CG_HM]; P.tarea = CG.g[CG_TAREA]; P.uarea = CG.g[CG_UAREA]; P.earea = CG.g[CG_EAREA]; P.narea = CG.g[CG_NAREA];
+    for (int k = 0; k < 3; ++k) { P.xmask[k] = Q.xmask[k]; P.fcor[k] = Q.fcor[k]; }
+    P.m4 = CG.mask4;
+    for (int k = 0; k < 14; ++k) P.f[k] = CG.f[k];
+    for (int k = 0; k < CG_NIN; ++k) P.in[k] = CG.in[k];
+    P.dt = Q.pp.dt; P.gravit = Q.pp.gravit; P.dyn_area_min = Q.pp.dyn_area_min; P.dyn_mass_min = Q.pp.dyn_mass_min;
+    P.cosw = S.prm.cosw; P.sinw = S.prm.sinw; P.ssh_coupled = Q.pp.ssh_stress_coupled;
+}
+
+int cice_evp_hip_cgrid_prep(const cice_evp_hip_prep_params *pp, const double *const *tfields11,
+                            const double *const *state12, int32_t *iceTmask, int32_t *iceUmask, int32_t *iceEmask,
+                            int32_t *iceNmask)
+{
+    if (!S.ready || !CG.geo) return fail(-1, "C-grid EVP: geometry not set");
+    CGridState::Prep &Q = CG.prep;
+    if (!Q.geo) return fail(-1, "cice_evp_hip_cgrid_set_prep_geometry was not called");
+    if (!pp || !tfields11 || !iceTmask || !iceUmask || !iceEmask || !iceNmask) return fail(-1, "null argument");
+    for (int k = 0; k < 11; ++k)
+        if (!tfields11[k]) return fail(-1, "null T-grid field %d", k);
+    // the loop's state: given, or NULL = what the previous call left on the device (evp() is its only writer)
+    int nstate = 0;
+    if (state12)
+        for (int k = 0; k < 12; ++k) nstate += state12[k] != nullptr;
+    if (nstate != 0 && nstate != 12) return fail(-1, "state arrays: give all 12 or none");
+    if (nstate == 0 && !CG.uploaded) return fail(-1, "no C-grid state on the device yet: the first call must upload it");
+    Q.pp = *pp;
+    HIPC(hipEventRecord(S.ev2, S.stream));
+    CopyBatch B;
+    for (int k = 0; k < 11; ++k) B.items.push_back({Q.t[k], tfields11[k]});
+    if (nstate)
+        for (int k = 0; k < 12; ++k) B.items.push_back({CG.f[k], state12[k]});
+    if (h2d_batch(B)) return -1;
+    {   // the previous call's ice masks at U, E, N points (ghost cells included: they travel back unchanged)
+        const int32_t *m[3] = {iceUmask, iceEmask, iceNmask};
+        for (int k = 0; k < 3; ++k)
+            HIPC(hipMemcpyAsync(CG.mask4 + (size_t)(k + 1) * S.n, m[k], S.n * sizeof(int32_t), hipMemcpyHostToDevice, S.stream));
+    }
+    HIPC(hipEventRecord(S.ev3, S.stream));
+    {   // dyn_prep1 and the T-grid halo updates: the B-grid preparation's kernels
+        EvpPrep P{};
+        P.nx = S.d.nx_block; P.ny = S.d.ny_block; P.plane = S.plane; P.blk = S.blk;
+        P.tmask = Q.tmask;
+        for (int k = 0; k < 11; ++k) P.t[k] = Q.t[k];
+        P.tmass = Q.tmass; P.maskd = Q.maskd;
+        P.rhoi = pp->rhoi; P.rhos = pp->rhos; P.dyn_area_min = pp->dyn_area_min; P.dyn_mass_min = pp->dyn_mass_min;
+        evp_launch_prep1(P, S.d.nblocks, S.stream);
+        EvpPrepHalo H{};
+        std::pair<double *, bool> arrs[10] = {{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false}, {Q.t[5], true},
+                                              {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}, {Q.t[9], true}, {Q.t[10], true}};
+        for (const auto &a : arrs) { H.a[H.narr] = a.first; H.is_vec[H.narr] = a.second; ++H.narr; }
+        H.dst = Q.c_dst; H.src = Q.c_src; H.vsign = Q.c_vsign; H.n = Q.n_center;
+        evp_launch_halo_center(H, S.stream);
+        if (S.plan.center_remote) {
+            double *pairs[5][2] = {{Q.maskd, Q.tmass}, {Q.t[3], Q.t[4]}, {Q.t[5], Q.t[6]}, {Q.t[7], Q.t[8]}, {Q.t[9], Q.t[10]}};
+            for (auto &pr : pairs)
+                if (int rc = halo_remote_pair(pr[0], pr[1])) return rc;
+        }
+    }
+    EvpCgPrep P{};
+    fill_prep(P);
+    evp_launch_cgrid_prep(P, S.d.nblocks, S.stream);
+    EvpCgrid A;
+    fill(A);
+    evp_launch_cgrid_mask(A, CG.mask4, S.stream);
+    // ice_dyn_evp.F90:703-731: exchange uvelE, vvelN; the other component at each face and the corner velocities; exchange
+    // them -- the tail of a subcycle (phase 4), on every cell (nothing is masked yet)
+    evp_launch_cgrid_phase(A, 9, CF_UE, S.stream);
+    evp_launch_cgrid_phase(A, 9, CF_VN, S.stream);
+    if (remote())
+        if (int rc = halo_remote_pair(A.f[CF_UE], A.f[CF_VN])) return rc;
+    fold({{A.f[CF_UE], 2, true}, {A.f[CF_VN], 3, true}});
+    evp_launch_cgrid_phase(A, 6, 1, S.stream);
+    evp_launch_cgrid_phase(A, 4, 1, S.stream);
+    if (remote()) {
+        if (int rc = halo_remote_pair(A.f[CF_UN], A.f[CF_VE])) return rc;
+        if (int rc = halo_remote_pair(A.f[CF_UU], A.f[CF_VU])) return rc;
+    }
+    fold({{A.f[CF_UN], 3, true}, {A.f[CF_VE], 2, true}, {A.f[CF_UU], 1, true}, {A.f[CF_VU], 1, true}});
+    HIPC(hipEventRecord(S.ev1, S.stream));
+    Q.h4.resize(4 * S.n);
+    HIPC(hipMemcpyAsync(Q.h4.data(), CG.mask4, 4 * S.n * sizeof(int32_t), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(S.stream));
+    int32_t *out[4] = {iceTmask, iceUmask, iceEmask, iceNmask};
+    for (int k = 0; k < 4; ++k) std::memcpy(out[k], Q.h4.data() + (size_t)k * S.n, S.n * sizeof(int32_t));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, S.ev3, S.ev1) == hipSuccess) Q.t_ms = ms;
+    Q.pending = true;
+    return 0;
+}
+
+// seabed stress factors TbE / TbN on the device, LKD method (seabed_stress_factor_LKD with grid_location = 'E' / 'N',
+// ice_dyn_shared.F90:1386-1460; call site ice_dyn_evp.F90:803-815), from the aice / vice of the last
+// cice_evp_hip_cgrid_prep (ghost cells as given) and the masks it produced.  Between _cgrid_prep and _cgrid_prep_finish.  One device exp() per
+// ice face: <= 1 ulp from the host libm's.
+int cice_evp_hip_cgrid_seabed_lkd(const double *hwater, double k1, double k2, double alphab, double threshold_hw)
+{
+    CGridState::Prep &Q = CG.prep;
+    if (!Q.pending) return fail(-1, "no prepared C-grid state (cice_evp_hip_cgrid_prep first)");
+    if (!Q.hwater) {
+        if (!hwater) return fail(-1, "hwater needed on the first call");
+        if (alloc_d(&Q.hwater, S.n)) return -1;
+    }
+    if (hwater && h2d(Q.hwater, hwater)) return -1;
+    // aice, vice, hwater are read at (i+1, j) / (i, j+1) as the caller handed them over, ghost cells included -- the
+    // reference reads its module arrays the same way (their ghost cells are current in the host model)
+    EvpCgPrep P{};
+    fill_prep(P);
+    evp_launch_cgrid_seabed_lkd(P, S.d.nblocks, CG.mask, Q.hwater, k1, k2, alphab, threshold_hw, S.stream);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+// ... probabilistic method (seabed_stress_factor_prob with TbE / TbN, ice_dyn_shared.F90:1475-1683; call site
+// ice_dyn_evp.F90:816-827): the T-point factor as on the B grid, then the maximum over the two T-cells of every ice face
+int cice_evp_hip_cgrid_seabed_prob(const double *hwater, const double *aicen, const double *vicen, int32_t ncat, double alphab,
+                                   double rhoi, double gravit, double pi, double puny)
+{
+    CGridState::Prep &Q = CG.prep;
+    if (!Q.pending) return fail(-1, "no prepared C-grid state (cice_evp_hip_cgrid_prep first)");
+    if (!aicen || !vicen || ncat < 1) return fail(-1, "bad argument");
+    if (!Q.hwater) {
+        if (!hwater) return fail(-1, "hwater needed on the first call");
+        if (alloc_d(&Q.hwater, S.n)) return -1;
+    }
+    if (hwater && h2d(Q.hwater, hwater)) return -1;
+    if (Q.ncat != ncat) {
+        if (Q.aicen) { (void)hipFree(Q.aicen); Q.aicen = nullptr; }
+        if (Q.vicen) { (void)hipFree(Q.vicen); Q.vicen = nullptr; }
+        if (alloc_d(&Q.aicen, S.n * (size_t)ncat) || alloc_d(&Q.vicen, S.n * (size_t)ncat)) return -1;
+        Q.ncat = ncat;
+    }
+    if (!Q.tbt && alloc_d(&Q.tbt, S.n)) return -1;
+    HIPC(hipMemcpyAsync(Q.aicen, aicen, S.n * (size_t)ncat * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(Q.vicen, vicen, S.n * (size_t)ncat * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    EvpPrep PB{};
+    PB.nx = S.d.nx_block; PB.ny = S.d.ny_block; PB.plane = S.plane; PB.blk = S.blk;
+    PB.mask = CG.mask;                         // bit0 = iceTmask in both layouts
+    evp_launch_seabed_prob_t(PB, S.d.nblocks, Q.hwater, Q.aicen, Q.vicen, ncat, alphab, rhoi, S.prm.rhow, gravit, pi, puny, Q.tbt,
+                             S.stream);
+    EvpCgPrep P{};
+    fill_prep(P);
+    evp_launch_cgrid_seabed_prob_faces(P, S.d.nblocks, CG.mask, Q.tbt, S.stream);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
+// ice strength (the host's: icepack_ice_strength + its halo update, ice_dyn_evp.F90:596-608, 727-728) and the per-call
+// set-up of the loop; cice_evp_hip_cgrid_subcycle / _download follow as after cice_evp_hip_cgrid_upload
+int cice_evp_hip_cgrid_prep_finish(const double *strength, int32_t visc_method)
+{
+    CGridState::Prep &Q = CG.prep;
+    if (!Q.pending) return fail(-1, "no prepared C-grid state (cice_evp_hip_cgrid_prep first)");
+    if (!strength) return fail(-1, "null argument");
+    if (visc_method != 0 && visc_method != 1) return fail(-1, "visc_method %d (0 avg_zeta, 1 avg_strength)", visc_method);
+    if (h2d(CG.in[CI_STRENGTH], strength)) return -1;
+    Q.pending = false;
+    return finish_upload(visc_method);
+}
+
+// what the preparation left on the device, for hosts that need it (dyn_finish at E / N points reads aiX, fmX, uocnX,
+// vocnX) and for the tests: table 0 = the loop's 19 state / work arrays, 1 = its 23 inputs
+int cice_evp_hip_cgrid_fetch(int32_t table, int32_t index, double *dst)
+{
+    if (!S.ready || !CG.geo) return fail(-1, "C-grid EVP: geometry not set");
+    if (!dst) return fail(-1, "null argument");
+    const double *src = nullptr;
+    if (table == 0 && index >= 0 && index < CG_NF) src = CG.f[index];
+    if (table == 1 && index >= 0 && index < CG_NIN) src = CG.in[index];
+    if (!src) return fail(-1, "cgrid_fetch: table %d index %d", (int)table, (int)index);
+    if (d2h(dst, src)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
 }
 
 int cice_evp_hip_cgrid_timings(double *out, int32_t n)

@@ -353,3 +353,12 @@ void evp_launch_seabed_prob(const EvpPrep &P, int nblocks, const double *hwater,
                        gravit, pi, puny, Tbt);
     hipLaunchKernelGGL(seabed_prob_U, cell_grid(P, nblocks), dim3(64), 0, st, P, Tbt, TbU, flagword);
 }
+
+// step 1 alone (the C grid takes the maximum over faces instead: evp_cgrid_prep.hip)
+void evp_launch_seabed_prob_t(const EvpPrep &P, int nblocks, const double *hwater, const double *aicen, const double *vicen,
+                              int ncat, double alphab, double rhoi, double rhow, double gravit, double pi, double puny,
+                              double *Tbt, hipStream_t st)
+{
+    hipLaunchKernelGGL(seabed_prob_T, cell_grid(P, nblocks), dim3(64), 0, st, P, hwater, aicen, vicen, ncat, alphab, rhoi, rhow,
+                       gravit, pi, puny, Tbt);
+}

@@ -40,6 +40,8 @@ EXPORTS = [
     "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
+    "cice_evp_hip_cgrid_set_prep_geometry", "cice_evp_hip_cgrid_prep", "cice_evp_hip_cgrid_seabed_lkd", "cice_evp_hip_cgrid_seabed_prob",
+    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
@@ -313,6 +315,56 @@ class EvpHip:
         rc = self.lib.cice_evp_hip_cgrid_upload((_f64p * 14)(*[_dp(a) for a in st]), (_f64p * len(inp))(*[_dp(a) for a in inp]),
                                                 *[_ip(m) for m in mk], C.c_int32(VISC_METHOD[visc_method]))
         _check(self.lib, rc, "(dyn_evp_hip_cgrid_upload)")
+
+    # -- the preparation phase on the C grid (cice_evp_hip_cgrid_prep) ---------------
+    def cgrid_set_prep_geometry(self, static: dict):
+        m = [self._c(static[k], np.int32) for k in ("tmask", "umaskCD", "emask", "nmask")]
+        f = [self._c(static[k]) for k in ("fcor_blk", "fcorE_blk", "fcorN_blk")]
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_set_prep_geometry(*[_ip(a) for a in m], *[_dp(a) for a in f]),
+               "(dyn_evp_hip_cgrid_set_prep_geometry)")
+
+    def cgrid_prep(self, pp: "PrepParams", tfields: dict, state: dict | None, masks_prev: dict) -> dict:
+        """state: the first 12 of CGRID_FIELDS as evp() is entered with them (None: keep what the device holds);
+        masks_prev: iceUmask, iceEmask, iceNmask of the previous call.  Returns the four new masks."""
+        t = [self._c(tfields[k]) for k in PREP_T]
+        ttab = (_f64p * 11)(*[_dp(a) for a in t])
+        stab = None
+        if state is not None:
+            st = [self._c(state[k]) for k in CGRID_FIELDS[:12]]
+            stab = (_f64p * 12)(*[_dp(a) for a in st])
+        out = {k: np.array(masks_prev[k], dtype=np.int32, order="C", copy=True).reshape(self.shape)
+               for k in ("iceUmask", "iceEmask", "iceNmask")}
+        out["iceTmask"] = np.zeros(self.shape, dtype=np.int32)
+        rc = self.lib.cice_evp_hip_cgrid_prep(C.byref(pp), ttab, stab, *[_ip(out[k]) for k in CGRID_MASKS])
+        _check(self.lib, rc, "(dyn_evp_hip_cgrid_prep)")
+        return out
+
+    def cgrid_seabed_lkd(self, hwater, k1, k2, alphab, threshold_hw):
+        a = self._c(hwater) if hwater is not None else None
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_seabed_lkd(_dp(a) if a is not None else None, C.c_double(k1), C.c_double(k2),
+                                                                 C.c_double(alphab), C.c_double(threshold_hw)),
+               "(dyn_evp_hip_cgrid_seabed_lkd)")
+
+    def cgrid_seabed_prob(self, hwater, aicen, vicen, alphab, rhoi, gravit, pi, puny):
+        h = self._c(hwater) if hwater is not None else None
+        a = np.ascontiguousarray(aicen, dtype=np.float64)
+        v = np.ascontiguousarray(vicen, dtype=np.float64)
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_seabed_prob(_dp(h) if h is not None else None, _dp(a), _dp(v),
+                                                                  C.c_int32(a.shape[1]), C.c_double(alphab), C.c_double(rhoi),
+                                                                  C.c_double(gravit), C.c_double(pi), C.c_double(puny)),
+               "(dyn_evp_hip_cgrid_seabed_prob)")
+
+    def cgrid_prep_finish(self, strength, visc_method: str = "avg_zeta"):
+        a = self._c(strength)
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_prep_finish(_dp(a), C.c_int32(VISC_METHOD[visc_method])),
+               "(dyn_evp_hip_cgrid_prep_finish)")
+
+    def cgrid_fetch(self, name: str):
+        """One of CGRID_FIELDS / CGRID_INPUTS as it is on the device."""
+        table, index = (0, CGRID_FIELDS.index(name)) if name in CGRID_FIELDS else (1, CGRID_INPUTS.index(name))
+        out = np.zeros(self.shape)
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_fetch(C.c_int32(table), C.c_int32(index), _dp(out)), "(dyn_evp_hip_cgrid_fetch)")
+        return out
 
     def cgrid_subcycle(self, ndte: int):
         _check(self.lib, self.lib.cice_evp_hip_cgrid_subcycle(C.c_int32(ndte)), "(dyn_evp_hip_cgrid_subcycle)")

@@ -250,6 +250,34 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23);
 int cice_evp_hip_cgrid_run(int32_t ndte, int32_t visc_method, double *const *fields19,
                            const double *const *inputs23, const int32_t *iceTmask, const int32_t *iceUmask,
                            const int32_t *iceEmask, const int32_t *iceNmask);
+/* The preparation phase of evp() for grid_ice = 'C' on the device (ice_dyn_evp.F90:383-735, calc_strair branch, forcing on the
+ * T grid): dyn_prep1, the T-grid halo updates, the state-masked / flux averages T -> U, E, N (grid_average_X2Y 'S' / 'F'),
+ * dyn_prep2 at U, N and E points, the stresses zeroed off the ice, the velocity exchanges and face -> face / face -> corner
+ * averages -- everything the loop reads except the ice strength (Icepack's) is computed where the loop will read it:
+ * 11 T-grid arrays travel in instead of 14 + 23.
+ *   cice_evp_hip_cgrid_set_prep_geometry (once, after _cgrid_set_geometry): tmask, umaskCD, emask, nmask (ice_grid logicals
+ *     as int32), fcor_blk, fcorE_blk, fcorN_blk (ice_dyn_shared)
+ *   cice_evp_hip_cgrid_prep: tfields11 as for cice_evp_hip_prep; state12 = uvelE vvelE uvelN vvelN uvel vvel stresspT
+ *     stressmT stress12T stress12U strintxE strintyN as evp() is entered with them, or NULL = what the previous call left
+ *     on the device (evp() is their only writer); iceUmask / iceEmask / iceNmask: in = the previous call's masks, out = new
+ *     (physical cells only, as dyn_prep2); iceTmask: out.  Not done for the host's copies: strintyE, strintxN and the
+ *     ocean stresses zeroed off the ice (ice_dyn_shared.F90:776-781) -- diagnostics the loop does not read.
+ *   host: ice strength from the returned iceTmask; optionally cice_evp_hip_cgrid_seabed_lkd / _prob (TbE, TbN; otherwise 0)
+ *   cice_evp_hip_cgrid_prep_finish(strength, visc_method) -> cice_evp_hip_cgrid_subcycle -> cice_evp_hip_cgrid_download
+ *   cice_evp_hip_cgrid_fetch(table, index, dst): table 0 = fields19, 1 = inputs23 as they are on the device (dyn_finish at
+ *     E / N points reads aiX, fmX, uocnX, vocnX on the host).
+ * A tripole fold row split over ranks in x is refused (centre-field mirror across the fold on another rank).          */
+int cice_evp_hip_cgrid_set_prep_geometry(const int32_t *tmask, const int32_t *umaskCD, const int32_t *emask,
+                                         const int32_t *nmask, const double *fcor_blk, const double *fcorE_blk,
+                                         const double *fcorN_blk);
+int cice_evp_hip_cgrid_prep(const cice_evp_hip_prep_params *pp, const double *const *tfields11,
+                            const double *const *state12, int32_t *iceTmask, int32_t *iceUmask, int32_t *iceEmask,
+                            int32_t *iceNmask);
+int cice_evp_hip_cgrid_seabed_lkd(const double *hwater, double k1, double k2, double alphab, double threshold_hw);
+int cice_evp_hip_cgrid_seabed_prob(const double *hwater, const double *aicen, const double *vicen, int32_t ncat, double alphab,
+                                   double rhoi, double gravit, double pi, double puny);
+int cice_evp_hip_cgrid_prep_finish(const double *strength, int32_t visc_method);
+int cice_evp_hip_cgrid_fetch(int32_t table, int32_t index, double *dst);
 /* the same in three steps (state14 = the first 14 entries of fields19) */
 int cice_evp_hip_cgrid_upload(const double *const *state14, const double *const *inputs23,
                               const int32_t *iceTmask, const int32_t *iceUmask, const int32_t *iceEmask,

@@ -378,3 +378,106 @@ def test_cgrid_random_scalars_vs_oracle(seed):
     got, want = run_both(*args, ndte=6, visc_method=("avg_strength" if seed % 2 else "avg_zeta"), scal_kw=kw, scal_over=over)
     assert_bitwise(got, want, f"C grid random scalars seed {seed}: {kw} {over} {ns}")
     assert np.isfinite(want["uvelE"]).all()
+
+
+# ---- the preparation phase of evp() on the C grid, on the device (cice_evp_hip_cgrid_prep) ----------------------------
+
+def hip_prep_params(c: GoldenCase):
+    d = c.prep_scal_dict()
+    return evp.PrepParams(dt=d["dt"], rhoi=d["rhoi"], rhos=d["rhos"], gravit=d["gravit"], dyn_area_min=d["dyn_area_min"],
+                          dyn_mass_min=d["dyn_mass_min"], ssh_stress_coupled=d["ssh_coupled"])
+
+
+def device_prep(core, c, icall, state, visc=None):
+    """cice_evp_hip_cgrid_prep -> seabed factors -> _prep_finish for call `icall` of a fixture; returns the new masks."""
+    t, st, _ = c.cgrid_prep_inputs(icall)
+    masks_prev = {k: st[k] for k in ("iceUmask", "iceEmask", "iceNmask")}
+    masks = core.cgrid_prep(hip_prep_params(c), t, state if state is not None else None, masks_prev)
+    s = c.scal
+    if s[23] != 0.0:
+        core.cgrid_seabed_lkd(c.d["hwater"], s[24], s[25], s[26], s[27])
+    core.cgrid_prep_finish(c.d[f"in{icall:02d}_strength"], visc or str(c.d["visc_method"]))
+    return masks
+
+
+@pytest.mark.parametrize("name", CGRID_CASES)
+def test_cgrid_prep_on_device_bitwise(name):
+    """Everything the C-grid loop reads, computed on the device from the T-grid state and forcing (11 arrays in instead
+    of 14 + 23) and compared with what the reference's own preparation left (the in* arrays of the fixtures): the four ice
+    masks, the 12 state arrays and 22 per-call inputs, every cell, bit for bit (TbE / TbN: the device exp(), <= 4 ulp).
+    Then the loop from that state against the reference's outputs.  Second call of three fixtures: cells gain / lose ice."""
+    c = GoldenCase(name)
+    dom = c.oracle_domain()
+    core = cgrid_core(c)
+    try:
+        core.cgrid_set_prep_geometry(c.cgrid_prep_static())
+        for icall in range(1, c.ncalls + 1):
+            _, st, _ = c.cgrid_prep_inputs(icall)
+            masks = device_prep(core, c, icall, {k: st[k] for k in oracle.C_FIELDS[:12]})
+            want_state, want_in, want_masks = c.cgrid_inputs(icall)
+            for k in oracle.C_MASKS:
+                assert np.array_equal(masks[k] != 0, want_masks[k] != 0), f"{name} call {icall} {k}"
+            got = {k: core.cgrid_fetch(k) for k in list(want_state) + [k for k in want_in if k != "strength"]}
+            oracle.halo_update(dom, got["strintxE"], "Eface", "vector")      # (the fixture's post-loop exchange, see above)
+            oracle.halo_update(dom, got["strintyN"], "Nface", "vector")
+            for k in ("TbE", "TbN"):
+                w = want_in[k]
+                assert np.allclose(got.pop(k), w, rtol=1e-15, atol=0.0), k
+            assert_bitwise(got, {k: v for k, v in {**want_state, **want_in}.items() if k in got},
+                           f"{name} call {icall} (device preparation)")
+            if c.scal[23] != 0.0:
+                continue                      # the loop below would start from TbE / TbN that may differ in the last bit
+            nsub = c.nsub_list[-1]
+            core.cgrid_subcycle(nsub)
+            out = core.cgrid_download()
+            oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+            oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+            assert_bitwise(out, c.cgrid_expected(icall, nsub), f"{name} call {icall} nsub {nsub} (device preparation + loop)")
+    finally:
+        core.finalize()
+
+
+def test_cgrid_prep_keeps_the_state_on_the_device_between_calls():
+    """Second call with state12 = NULL: the velocities and stresses the first call's loop left on the device are the ones
+    evp() would be entered with -- same inputs for the loop, same results, and nothing but the 11 T-grid arrays and the
+    strength travelled in."""
+    c = GoldenCase("cgrid_cyc_2x2_patchy")
+    dom = c.oracle_domain()
+    core = cgrid_core(c)
+    try:
+        core.cgrid_set_prep_geometry(c.cgrid_prep_static())
+        _, st, _ = c.cgrid_prep_inputs(1)
+        device_prep(core, c, 1, {k: st[k] for k in oracle.C_FIELDS[:12]})
+        nsub = c.nsub_list[-1]
+        core.cgrid_subcycle(nsub)                      # the reference's state before call 2 = after its last run of call 1
+        masks = device_prep(core, c, 2, None)
+        want_state, want_in, want_masks = c.cgrid_inputs(2)
+        for k in oracle.C_MASKS:
+            assert np.array_equal(masks[k] != 0, want_masks[k] != 0), k
+        got = {k: core.cgrid_fetch(k) for k in want_state}
+        oracle.halo_update(dom, got["strintxE"], "Eface", "vector")
+        oracle.halo_update(dom, got["strintyN"], "Nface", "vector")
+        assert_bitwise(got, want_state, "call 2 from the resident state")
+        core.cgrid_subcycle(nsub)
+        out = core.cgrid_download()
+        oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+        oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+        assert_bitwise(out, c.cgrid_expected(2, nsub), "call 2 from the resident state, loop")
+    finally:
+        core.finalize()
+
+
+def test_cgrid_prep_fails_loudly_out_of_order():
+    c = GoldenCase("cgrid_cyc_1blk_seabed")
+    core = cgrid_core(c)
+    try:
+        t, st, _ = c.cgrid_prep_inputs(1)
+        with pytest.raises(evp.EvpHipError, match="set_prep_geometry"):
+            core.cgrid_prep(hip_prep_params(c), t, {k: st[k] for k in oracle.C_FIELDS[:12]}, st)
+        core.cgrid_set_prep_geometry(c.cgrid_prep_static())
+        with pytest.raises(evp.EvpHipError, match="first call must upload"):
+            core.cgrid_prep(hip_prep_params(c), t, None, st)
+        with pytest.raises(evp.EvpHipError, match="cgrid_prep first"):
+            core.cgrid_prep_finish(c.d["in01_strength"])
+    finally:
+        core.finalize()
