@@ -835,9 +835,10 @@ void evp_oracle_seabed_lkd(const evp_oracle_domain *d, double k1, double k2, dou
  * cut x_kmax at the last ice-holding category (`do n = ncat,-1,1`, :1583-1589) never executes, so cut = x_k(100).
  * aicen / vicen: (nx, ny, ncat, nblocks), i fastest.
  * ===================================================================== */
-void evp_oracle_seabed_prob(const evp_oracle_domain *d, int ncat, double alphab, double rhoi, double rhow, double gravit,
-                            double pi, double puny, const double *aicen, const double *vicen, const double *hwater,
-                            const int32_t *iceTmask, const int32_t *iceUmask, double *TbU)
+/* loc 1: U (B grid), 2: E, 3: N (C grid, :1656-1676) */
+static void seabed_prob_at(const evp_oracle_domain *d, int loc, int ncat, double alphab, double rhoi, double rhow, double gravit,
+                           double pi, double puny, const double *aicen, const double *vicen, const double *hwater,
+                           const int32_t *iceTmask, const int32_t *iceUmask, double *TbU)
 {
     enum { NI = 100, NB = 100 };
     const double max_depth = 50.0, mu_s = 0.1, sigma_b = 2.5, c0 = 0.0, c1 = 1.0, c2 = 2.0, c3 = 3.0, c6 = 6.0, p5 = 0.5;
@@ -902,11 +903,27 @@ void evp_oracle_seabed_prob(const evp_oracle_domain *d, int ncat, double alphab,
             for (int i = d->ilo[b]; i <= d->ihi[b]; ++i) {
                 const size_t cl = (size_t)(j - 1) * nx + (i - 1), c = b * plane + cl;
                 if (!iceUmask[c]) continue;
-                /* grid_neighbor_max at the U point (ice_grid.F90:5005): max(a(i,j), a(i+1,j), a(i,j+1), a(i+1,j+1)) */
-                TbU[c] = fmax(fmax(fmax(Tbt[cl], Tbt[cl + 1]), Tbt[cl + nx]), Tbt[cl + nx + 1]);
+                /* grid_neighbor_max (ice_grid.F90:5004-5009): U max(a(i,j), a(i+1,j), a(i,j+1), a(i+1,j+1)); E, N: two cells */
+                if (loc == 1) TbU[c] = fmax(fmax(fmax(Tbt[cl], Tbt[cl + 1]), Tbt[cl + nx]), Tbt[cl + nx + 1]);
+                else TbU[c] = fmax(Tbt[cl], Tbt[loc == 2 ? cl + 1 : cl + nx]);
             }
     }
     free(Tbt);
+}
+void evp_oracle_seabed_prob(const evp_oracle_domain *d, int ncat, double alphab, double rhoi, double rhow, double gravit,
+                            double pi, double puny, const double *aicen, const double *vicen, const double *hwater,
+                            const int32_t *iceTmask, const int32_t *iceUmask, double *TbU)
+{
+    seabed_prob_at(d, 1, ncat, alphab, rhoi, rhow, gravit, pi, puny, aicen, vicen, hwater, iceTmask, iceUmask, TbU);
+}
+/* grid_ice = 'C': TbE, TbN (call site ice_dyn_evp.F90:816-827) */
+void evp_oracle_seabed_prob_c(const evp_oracle_domain *d, int ncat, double alphab, double rhoi, double rhow, double gravit,
+                              double pi, double puny, const double *aicen, const double *vicen, const double *hwater,
+                              const int32_t *iceTmask, const int32_t *iceEmask, const int32_t *iceNmask, double *TbE,
+                              double *TbN)
+{
+    seabed_prob_at(d, 2, ncat, alphab, rhoi, rhow, gravit, pi, puny, aicen, vicen, hwater, iceTmask, iceEmask, TbE);
+    seabed_prob_at(d, 3, ncat, alphab, rhoi, rhow, gravit, pi, puny, aicen, vicen, hwater, iceTmask, iceNmask, TbN);
 }
 
 /* =====================================================================

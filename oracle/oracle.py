@@ -258,6 +258,21 @@ def seabed_prob(dom: OracleDomain, alphab, rhoi, rhow, gravit, pi, puny, aicen, 
     return out
 
 
+def seabed_prob_c(dom: OracleDomain, alphab, rhoi, rhow, gravit, pi, puny, aicen, vicen, hwater, iceTmask, iceEmask, iceNmask):
+    """seabed_stress_factor_prob for grid_ice = 'C' (ice_dyn_shared.F90:1475-1683, tail :1656-1676): (TbE, TbN)."""
+    lib().evp_oracle_seabed_prob_c.restype = None
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    a, v, h = f64(aicen), f64(vicen), f64(hwater)
+    i32 = lambda m: np.ascontiguousarray(m, dtype=np.int32)
+    tm, em, nm = i32(iceTmask), i32(iceEmask), i32(iceNmask)
+    ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))
+    tbe, tbn = np.zeros(dom.shape), np.zeros(dom.shape)
+    lib().evp_oracle_seabed_prob_c(C.byref(dom.c), C.c_int(a.shape[1]), C.c_double(alphab), C.c_double(rhoi), C.c_double(rhow),
+                                   C.c_double(gravit), C.c_double(pi), C.c_double(puny), _dp(a), _dp(v), _dp(h), ip(tm), ip(em),
+                                   ip(nm), _dp(tbe), _dp(tbn))
+    return tbe, tbn
+
+
 # ---- C-grid subcycle (SURVEY 8 f-4) -----------------------------------------------------------
 C_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
             "strintxE", "strintyN", "taubxE", "taubyN", "zetax2T", "etax2T", "etax2U", "shearU", "deltaU"]

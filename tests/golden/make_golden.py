@@ -85,6 +85,10 @@ CGRID_CASES = {
                                                 h_Ktens=0.1, h_visc_method="avg_strength")),
     "cgrid_cyc_1blk_seabed": (24, 20, 24, 20, "cyclic", "closed",
                               dict(icecase="full", nsub_list=[1, 120], ncalls=1, h_seabed=True)),
+    # seabed stress, probabilistic method at E / N points (seabed_stress_factor_prob with TbE / TbN, ice_dyn_shared.F90:1656-1676)
+    "cgrid_cyc_2x2_seabedprob": (24, 20, 12, 10, "cyclic", "closed",
+                                 dict(icecase="patchy", nsub_list=[1, 120], ncalls=1, h_seabed=True,
+                                      h_seabed_method="probabilistic")),
     "cgrid_cyccyc_2x2_cap0_ktens": (24, 20, 12, 10, "cyclic", "cyclic",
                                     dict(icecase="patchy", nsub_list=[1, 120], ncalls=1, h_capping=0.0, h_Ktens=0.2,
                                          h_e_yield=1.5, h_e_plast=2.5, h_ssh="coupled")),

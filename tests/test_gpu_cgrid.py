@@ -394,7 +394,9 @@ def device_prep(core, c, icall, state, visc=None):
     masks_prev = {k: st[k] for k in ("iceUmask", "iceEmask", "iceNmask")}
     masks = core.cgrid_prep(hip_prep_params(c), t, state if state is not None else None, masks_prev)
     s = c.scal
-    if s[23] != 0.0:
+    if s[23] != 0.0 and s[29] != 0.0:          # probabilistic (one thickness category in the harness)
+        core.cgrid_seabed_prob(c.d["hwater"], t["aice"][:, None], t["vice"][:, None], s[26], s[17], s[19], s[30], s[31])
+    elif s[23] != 0.0:
         core.cgrid_seabed_lkd(c.d["hwater"], s[24], s[25], s[26], s[27])
     core.cgrid_prep_finish(c.d[f"in{icall:02d}_strength"], visc or str(c.d["visc_method"]))
     return masks
@@ -422,7 +424,9 @@ def test_cgrid_prep_on_device_bitwise(name):
             oracle.halo_update(dom, got["strintyN"], "Nface", "vector")
             for k in ("TbE", "TbN"):
                 w = want_in[k]
-                assert np.allclose(got.pop(k), w, rtol=1e-15, atol=0.0), k
+                # LKD: one exp() per face (<= 1 ulp); probabilistic: sums of 100 x 100 exp / log terms (a few ulp of the sum)
+                assert np.allclose(got.pop(k), w, rtol=1e-15 if c.scal[29] == 0.0 else 1e-12, atol=0.0), k
+                assert c.scal[23] == 0.0 or np.abs(w).max() > 0
             assert_bitwise(got, {k: v for k, v in {**want_state, **want_in}.items() if k in got},
                            f"{name} call {icall} (device preparation)")
             if c.scal[23] != 0.0:

@@ -239,7 +239,7 @@ def test_cgrid_prep_oracle_bitwise(name):
     """evp()'s preparation phase for grid_ice = 'C' (ice_dyn_evp.F90:383-735: dyn_prep1, the T -> U / E / N averages,
     dyn_prep2 at U, N and E points, the velocity averages and exchanges) restated in oracle/evp_oracle.c: from the T-grid
     state and the previous call's velocities / stresses / masks to everything the C-grid loop reads, bit for bit -- the
-    second call of three fixtures has cells gaining and losing ice.  Seabed stress factors (LKD at E / N points) from the
+    second call of three fixtures has cells gaining and losing ice.  Seabed stress factors (LKD or probabilistic, at E / N points) from the
     resulting masks; the ice strength is Icepack's (taken from the fixture)."""
     c = GoldenCase(name)
     pp = oracle.PrepParams(**c.prep_scal_dict())
@@ -248,7 +248,12 @@ def test_cgrid_prep_oracle_bitwise(name):
         t, state, prev = c.cgrid_prep_inputs(icall)
         got = oracle.cgrid_prep(c.oracle_domain(), pp, c.cgrid_prep_static(), t, state, prev)
         want_state, want_in, want_masks = c.cgrid_inputs(icall)
-        if s[23] != 0.0:            # seabed stress, LKD (the only method of the C-grid fixtures)
+        if s[23] != 0.0 and s[29] != 0.0:      # seabed stress, probabilistic (ncat = 1 in the harness)
+            got["TbE"], got["TbN"] = oracle.seabed_prob_c(c.oracle_domain(), s[26], s[17], s[12], s[19], s[30], s[31],
+                                                          t["aice"][:, None], t["vice"][:, None], c.d["hwater"],
+                                                          got["iceTmask"], got["iceEmask"], got["iceNmask"])
+            assert np.abs(want_in["TbE"]).max() > 0 and np.abs(want_in["TbN"]).max() > 0
+        elif s[23] != 0.0:                     # ... LKD
             for loc in "EN":
                 got["Tb" + loc] = oracle.seabed_lkd_c(c.oracle_domain(), loc, s[24], s[25], s[26], s[27], t["aice"], t["vice"],
                                                       c.d["hwater"], got[f"ice{loc}mask"])

@@ -139,6 +139,24 @@ def main():
                         e[cname + "_KB_per_launch"] = c[cname][0]
             if "FETCH_SIZE_KB_per_launch" in e and "WRITE_SIZE_KB_per_launch" in e:
                 e["hbm_bytes_per_launch"] = (e["FETCH_SIZE_KB_per_launch"] * f_fetch + e["WRITE_SIZE_KB_per_launch"] * f_write) * 1024.0
+            sq = {}
+            for p in ("sq1", "sq2"):
+                f = d / f"{key}_{p}_counter_collection.csv"
+                if f.exists():
+                    c, dur_us, kname = counters(f, match)
+                    sq.update({k: v for k, (v, n) in c.items()})
+                    if p == "sq1":
+                        sq["_pass_avg_us"] = dur_us
+            if sq.get("SQ_WAVE_CYCLES"):
+                e["sq"] = {"valu_insts_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"] if sq.get("SQ_WAVES") else None,
+                           "waves_per_launch": sq.get("SQ_WAVES"),
+                           "wave_cycles_share": {k: sq[k] / sq["SQ_WAVE_CYCLES"] for k in
+                                                 ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if sq.get(k)},
+                           "valu_busy_frac_of_max_clock_in_pmc_pass": sq["SQ_ACTIVE_INST_VALU"] * 4.0 /
+                                                                      (N_SIMD * sq["_pass_avg_us"] * 1e-6 * MAX_CLOCK_HZ)
+                           if sq.get("SQ_ACTIVE_INST_VALU") else None,
+                           "vmem_rd_insts_per_wave": sq["SQ_INSTS_VMEM_RD"] / sq["SQ_WAVES"] if sq.get("SQ_INSTS_VMEM_RD") and sq.get("SQ_WAVES") else None,
+                           "vmem_wr_insts_per_wave": sq["SQ_INSTS_VMEM_WR"] / sq["SQ_WAVES"] if sq.get("SQ_INSTS_VMEM_WR") and sq.get("SQ_WAVES") else None}
             entry[tag] = e
         tot_us = sum(e["kernel_trace"]["avg_us"] for e in entry.values() if e.get("kernel_trace"))
         tot_b = sum(e.get("hbm_bytes_per_launch", 0.0) for e in entry.values())

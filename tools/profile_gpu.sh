@@ -8,7 +8,7 @@
 # trace domain), as MI355X_MICROARCH.md "rocprofv3 PMC slots" prescribes: SQ 8 slots per pass,
 # FETCH_SIZE and WRITE_SIZE cannot share a pass, GRBM 2 slots.
 #   usage: tools/profile_gpu.sh <tag> [what ...]     what: gx1res gx1str s01str s01march cgx1 cgs01 calib (default: all but cg*)
-#   cgx1 / cgs01: the three kernels of the C-grid subcycle (tools/cgrid_timing.py) -- trace + HBM-byte passes
+#   cgx1 / cgs01: the three kernels of the C-grid subcycle (tools/cgrid_timing.py) -- trace, HBM-byte and SQ passes
 set -u
 TAG=${1:-prof}; shift || true
 WHAT=${*:-gx1res gx1str s01str calib}
@@ -43,7 +43,9 @@ for w in $WHAT; do
             nd=120; [ $w = cgs01 ] && nd=12
             rocprofv3 --kernel-trace --stats -d "$OUT" -o "${w}_trace" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 2 > "$OUT/${w}_trace.log" 2>&1
             rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace -d "$OUT" -o "${w}_fetch" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 1 > "$OUT/${w}_fetch.log" 2>&1
-            rocprofv3 --pmc WRITE_SIZE GRBM_COUNT --kernel-trace -d "$OUT" -o "${w}_write" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 1 > "$OUT/${w}_write.log" 2>&1 ;;
+            rocprofv3 --pmc WRITE_SIZE GRBM_COUNT --kernel-trace -d "$OUT" -o "${w}_write" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 1 > "$OUT/${w}_write.log" 2>&1
+            rocprofv3 --pmc $SQ1 --kernel-trace -d "$OUT" -o "${w}_sq1" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 1 > "$OUT/${w}_sq1.log" 2>&1
+            rocprofv3 --pmc $SQ2 --kernel-trace -d "$OUT" -o "${w}_sq2" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 1 > "$OUT/${w}_sq2.log" 2>&1 ;;
     calib)  # known byte counts in the streaming kernels' access width (8 B per lane): calibrates FETCH_SIZE / WRITE_SIZE
             hipcc --offload-arch=gfx950 -O3 tools/pmc_calib.hip -o /tmp/pmc_calib || continue
             /tmp/pmc_calib > "$OUT/calib_plain.log" 2>&1
