@@ -347,3 +347,34 @@ def bgrid_fold_metrics(dc, rank: int, g: dict):
     dyhx[1:] = 0.5 * (HTN[1:] - HTN[:-1])
     dyhx[0] = 0.5 * (HTN[0] - 1.0)          # (the ghost row south of a closed boundary holds the fill value 1)
     return (dc.scatter(dxhy, rank, fill=1.0, fold=("center", -1.0)), dc.scatter(dyhx, rank, fill=1.0, fold=("center", -1.0)))
+
+
+def cgrid_prep_inputs(g: dict, cg: dict, case: str = "full", seed: int = 5, coupled: bool = False):
+    """What evp()'s preparation phase reads on the C grid, as global [ny][nx] arrays: (tfields11, static7, masks_prev3)
+    -- the T-grid state and forcing of cgrid_state's ice cover (perturbed by `seed`), the land masks / Coriolis arrays
+    of the three velocity locations, and a previous call's ice masks that differ from the ones the preparation will
+    find (cells gain and lose ice)."""
+    nx, ny = g["nx"], g["ny"]
+    x = (np.arange(1, nx + 1) - 0.5)[None, :] / nx * np.ones((ny, 1))
+    y = (np.arange(1, ny + 1) - 0.5)[:, None] / ny * np.ones((1, nx))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tmask = g["tmask"]
+    aice = np.where(tmask, 0.95 * (1.0 - 0.04 * np.sin(2 * np.pi * x) * np.cos(4 * np.pi * y)), 0.0)
+    if case == "caps":
+        aice = aice * np.clip((np.abs(y - 0.5) - 0.25) / 0.05, 0.0, 1.0)
+    aice = np.where(rng.random((ny, nx)) < 0.03, 0.0, aice)                     # scattered open water
+    hi = 2.0 * (1.0 + 0.1 * np.sin(4 * np.pi * y) * np.cos(2 * np.pi * x)) * (1.0 + 0.01 * (2.0 * rng.random((ny, nx)) - 1.0))
+    vice = hi * aice
+    t = dict(aice=aice, vice=vice, vsno=0.2 * aice, aice_init=aice * (1.0 - 0.02 * rng.random((ny, nx))),
+             cdn_ocn=0.00536 * (1.0 + 0.1 * rng.random((ny, nx))), uocn=0.2 * y - 0.1 + 0.01 * np.sin(6 * np.pi * x),
+             vocn=-0.2 * x + 0.1 + 0.01 * np.cos(4 * np.pi * y),
+             ss_tltx=(2e-6 * np.sin(2 * np.pi * x) * np.cos(4 * np.pi * y)) if coupled else np.zeros((ny, nx)),
+             ss_tlty=(-1.5e-6 * np.cos(2 * np.pi * x) * np.sin(2 * np.pi * y)) if coupled else np.zeros((ny, nx)),
+             strairxT=aice * 0.1 * np.sin(2 * np.pi * x) * np.sin(np.pi * y),
+             strairyT=aice * 0.1 * np.sin(np.pi * x) * np.sin(2 * np.pi * y))
+    fcor = 2.0 * OMEGA * np.sin(g["ULAT"])
+    static = dict(tmask=tmask.astype(np.int32), umaskCD=g["umask"].astype(np.int32), emask=(cg["epm"] > 0.5).astype(np.int32),
+                  nmask=(cg["npm"] > 0.5).astype(np.int32), fcor_blk=fcor, fcorE_blk=0.999 * fcor, fcorN_blk=1.001 * fcor)
+    prev = {k: ((rng.random((ny, nx)) < 0.8) & (static[m] != 0)).astype(np.int32)
+            for k, m in (("iceUmask", "umaskCD"), ("iceEmask", "emask"), ("iceNmask", "nmask"))}
+    return t, static, prev

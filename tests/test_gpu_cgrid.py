@@ -485,3 +485,52 @@ def test_cgrid_prep_fails_loudly_out_of_order():
             core.cgrid_prep_finish(c.d["in01_strength"])
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("grid,bs,case,coupled", [("gx1", None, "full", False), ("gx1", (80, 96), "caps", True),
+                                                  ("tx1", (90, 60), "full", True), ("gx3", (25, 29), "caps", False)])
+def test_cgrid_prep_synthetic_vs_oracle_bitwise(grid, bs, case, coupled):
+    """The device preparation on gx1 / tx1 (tripole) / gx3-sized synthetic cases, one block and many, geostrophic and
+    coupled sea-surface tilt, previous masks that make cells gain and lose ice: the four masks, the loop's 12 state
+    arrays and 22 inputs against the oracle's restatement (itself pinned on the fixtures), every cell, bit for bit."""
+    from cice_amd import decomp, synth
+    spec = synth.GRIDS[grid]
+    nx, ny = spec["nx"], spec["ny"]
+    ns = spec.get("ns", "closed")
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
+    cg = synth.cgrid_geometry(g)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=9, warm=True)
+    t, st7, prev = synth.cgrid_prep_inputs(g, cg, case=case, seed=17, coupled=coupled)
+    bsx, bsy = bs if bs else (nx, ny)
+    dc = decomp.Decomp(nx, ny, bsx, bsy, "cyclic", ns, 1)
+    static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
+    tb = {k: dc.scatter(v, 0, fold=("center", -1.0 if k in ("uocn", "vocn", "ss_tltx", "ss_tlty", "strairxT", "strairyT") else 1.0))
+          for k, v in t.items()}
+    loc = {"umaskCD": "NEcorner", "emask": "Eface", "nmask": "Nface", "fcor_blk": "NEcorner", "fcorE_blk": "Eface", "fcorN_blk": "Nface"}
+    static.update({k: dc.scatter(v, 0, fill=0, fold=(loc.get(k, "center"), 1.0)) for k, v in st7.items()})
+    prevb = {k: dc.scatter(v, 0, fill=0) for k, v in prev.items()}
+    scal = synth.evp_scalars(120)
+    ppd = dict(dt=3600.0, rhoi=917.0, rhos=330.0, gravit=9.80616, dyn_area_min=1e-11, dyn_mass_min=1e-10)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    want = oracle.cgrid_prep(dom, oracle.PrepParams(**ppd, cosw=scal["cosw"], sinw=scal["sinw"], ssh_coupled=int(coupled)), static,
+                             tb, dict(state, **prevb))
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        core.cgrid_set_prep_geometry(static)
+        got = core.cgrid_prep(evp.PrepParams(**ppd, ssh_stress_coupled=int(coupled)), tb, state, prevb)
+        for k in oracle.C_MASKS:
+            assert np.array_equal(got[k] != 0, want[k] != 0), k
+        for k in ("iceEmask", "iceNmask"):          # the case must make faces gain and lose ice
+            new, old = want[k] != 0, prevb[k] != 0
+            assert (new & ~old).any() and (old & ~new).any(), k
+        keys = oracle.C_FIELDS[:14] + [k for k in oracle.C_INPUTS if k != "strength"]
+        assert_bitwise({k: core.cgrid_fetch(k) for k in keys}, {k: want[k] for k in keys}, f"{grid} {bs} device preparation vs oracle")
+        assert np.abs(want["forcexE"]).max() > 0 and np.abs(want["uvelN"]).max() > 0
+    finally:
+        core.finalize()

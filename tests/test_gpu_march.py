@@ -227,3 +227,24 @@ def test_march_is_the_default_on_a_large_grid_and_invariant_under_the_cut():
     finally:
         os.environ.pop("CICE_EVP_HIP_MARCH", None)
     assert_bitwise({k: dc.gather({0: out[k]}) for k in ref}, ref, "1440x720: march vs one-subcycle kernel")
+
+
+def test_s01_full_size_march_vs_oracle_bitwise():
+    """BASELINE's largest configuration (3600 x 2400 = 8.6M cells, one block, nothing forced: the marching kernel is the
+    default there) against the CPU oracle itself, 13 subcycles = one subcycle of the streaming kernel + 6 passes: every
+    output field on every cell, bit for bit.  (bench.py verifies the same workload after 3 x 480 subcycles against a
+    committed checksum of the oracle's state.)"""
+    scal = synth.evp_scalars(480)
+    dc, geo, fields, tm, um = synth_case("s01", "full", seed=2, warm=True)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 13)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        got = core.run(fields, tm, um, ndte=13)
+        info = core.march_info()
+        assert info["mode"] == 1 and info["last_call"] and info["passes"] == 6 and info["declined"] == 0, info
+    finally:
+        core.finalize()
+    assert np.abs(want["uvel"]).max() > 1e-3
+    assert_bitwise(got, want, "3600x2400 march vs oracle, 13 subcycles")
