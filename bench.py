@@ -30,6 +30,7 @@ What the line carries besides the contract's fields:
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import hashlib
 import json
 import os
@@ -481,6 +482,74 @@ def main():
                              "note": "648 B per cell and subcycle = 81 fp64 array touches of the three fused kernels "
                                      "(DESIGN.md section 9); on gx1 the 64 MB working set is Infinity-Cache resident"}}
 
+    def cgrid_per_call(workload, case, ndte):
+        """What a C-grid host waits for per evp() call, two ways: its own preparation + cice_evp_hip_cgrid_run (14 state +
+        23 input arrays and 4 masks in, 19 arrays out), or the preparation on the device (11 T-grid arrays + the ice
+        strength in, the loop's state resident between calls, 14 arrays out).  Caller's arrays page-locked."""
+        spec = synth.GRIDS[workload]
+        nx, ny = spec["nx"], spec["ny"]
+        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+        cg = synth.cgrid_geometry(g)
+        state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=20260928, warm=True)
+        t, st7, prev = synth.cgrid_prep_inputs(g, cg, case=case, seed=20260928)
+        dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", "closed")
+        static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
+        own = lambda a, dt=np.float64: np.array(a, dtype=dt, order="C", copy=True)
+        tb = {k: own(dc.scatter(v, 0)) for k, v in t.items()}
+        static.update({k: dc.scatter(v, 0, fill=0) for k, v in st7.items()})
+        d, keep = evp.make_dims(dc, 0)
+        core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(ndte), strict=True), static["dyE"], static["dxN"], static["dxT"],
+                          static["dyT"], 1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        res = {}
+        try:
+            core.cgrid_set_geometry(static)
+            core.cgrid_set_prep_geometry(static)
+            work = {k: (own(state[k]) if k in state else np.zeros(core.shape)) for k in evp.CGRID_FIELDS}
+            inp = {k: own(inputs[k]) for k in evp.CGRID_INPUTS}
+            mk = {k: own(masks[k], np.int32) for k in evp.CGRID_MASKS}
+            core.pin_host(*work.values(), *inp.values(), *tb.values())
+            ftab = (evp._f64p * 19)(*[evp._dp(work[k]) for k in evp.CGRID_FIELDS])
+            f14 = (evp._f64p * 19)(*([evp._dp(work[k]) for k in evp.CGRID_FIELDS[:14]] + [None] * 5))
+            itab = (evp._f64p * 23)(*[evp._dp(inp[k]) for k in evp.CGRID_INPUTS])
+            ttab = (evp._f64p * 11)(*[evp._dp(tb[k]) for k in evp.PREP_T])
+            s12 = (evp._f64p * 12)(*[evp._dp(work[k]) for k in evp.CGRID_FIELDS[:12]])
+            pp = evp.PrepParams(dt=3600.0, rhoi=917.0, rhos=330.0, gravit=9.80616, dyn_area_min=1e-11, dyn_mass_min=1e-10,
+                                ssh_stress_coupled=0)
+            L = core.lib
+
+            def host_prepared():
+                evp._check(L, L.cice_evp_hip_cgrid_run(ndte, 0, ftab, itab, *[evp._ip(mk[k]) for k in evp.CGRID_MASKS]), "cgrid_run")
+
+            first = [True]
+
+            def device_prepared():
+                st = s12 if first[0] else None
+                first[0] = False
+                evp._check(L, L.cice_evp_hip_cgrid_prep(C.byref(pp), ttab, st, *[evp._ip(mk[k]) for k in evp.CGRID_MASKS]), "cgrid_prep")
+                evp._check(L, L.cice_evp_hip_cgrid_prep_finish(evp._dp(inp["strength"]), 0), "cgrid_prep_finish")
+                evp._check(L, L.cice_evp_hip_cgrid_subcycle(ndte), "cgrid_subcycle")
+                evp._check(L, L.cice_evp_hip_cgrid_download(f14), "cgrid_download")
+
+            for label, fn in (("host_prepared_cgrid_run", host_prepared), ("device_prepared_state_resident", device_prepared)):
+                for _ in range(2):
+                    fn()
+                each = []
+                for _ in range(10):
+                    t1 = time.perf_counter()
+                    fn()
+                    each.append(1e3 * (time.perf_counter() - t1))
+                tt = core.cgrid_timings()
+                res[label] = dict(ms_per_call=float(np.median(each)), loop_ms=tt["loop_ms"], slowest_of_10=max(each))
+                if label.startswith("device"):
+                    res[label]["prep_kernels_ms"] = tt["prep_ms"]
+        finally:
+            core.finalize()
+        res["note"] = ("median host wall time per evp()-equivalent call over 10 calls, arrays page-locked: host_prepared = upload of 14 state "
+                       "+ 23 input arrays + 4 masks, ndte subcycles, download of 19; device_prepared = 11 T-grid arrays + strength in, "
+                       "dyn_prep1/2 and the averages on the device (prep_kernels_ms), the loop's state resident between calls, 14 arrays out "
+                       "(the host's own preparation time is NOT in the first figure: the reference spends it on top)")
+        return res
+
     def per_call_cost(workload, case, ndte):
         """What CICE waits for per evp(): cice_evp_hip_run = H2D of 32 fields + loop + D2H of 18, page-locked arrays."""
         spec = synth.GRIDS[workload]
@@ -549,6 +618,7 @@ def main():
         try:      # next-tier row f-4: the C-grid subcycle on the same grid, and on the 0.1-degree-class one (HBM-bound)
             extra["cgrid"] = cgrid_measure("gx1", "full", 120, 3, 1)
             extra["cgrid"]["s01"] = cgrid_measure("s01", "full", 12, 1, 1)
+            extra["cgrid"]["per_call_ms"] = cgrid_per_call("gx1", "full", 120)
         except Exception as e:  # noqa: BLE001
             extra_err["cgrid"] = f"{type(e).__name__}: {e}"[:300]
         try:

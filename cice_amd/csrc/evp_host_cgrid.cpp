@@ -743,6 +743,7 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     if (!out || n < 2) return fail(-1, "need room for 2 values");
     out[0] = CG.t_loop_ms;
     out[1] = (double)CG.t_nsub;
+    if (n >= 3) out[2] = CG.prep.t_ms;           // device time of the last cice_evp_hip_cgrid_prep (kernels, without the copies)
     return 0;
 }
 

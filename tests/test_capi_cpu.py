@@ -259,3 +259,20 @@ def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by):
             xb = np.where(L["b"] >= 0, flat[np.maximum(L["b"], 0)], 0.0)
             val = np.where(L["b"] != -1, s * (0.5 * (xa + isign * xb)), s * xa)
             assert np.array_equal(val, want[L["dst"]]), (loc, kind, int((val != want[L["dst"]]).sum()))
+
+
+def test_tracked_pmc_summary_feeds_the_bench_line():
+    """bench.py divides counters of the newest profiles/r*_pmc_summary.json by the live kernel time: the summary must
+    hold the entry of every kernel the roofline block quotes (a summary reduced from a partial profile directory
+    silently turned `roofline.frac` into null once)."""
+    import json
+    from pathlib import Path
+    files = sorted((Path(__file__).resolve().parents[1] / "profiles").glob("r*_pmc_summary.json"))
+    assert files, "no PMC summary tracked"
+    k = json.loads(files[-1].read_text())["kernels"]
+    for key in ("gx1res", "gx1str", "s01str", "s01march"):
+        assert key in k, f"{files[-1].name}: no entry for {key}"
+        assert k[key].get("hbm_bytes_per_launch") and k[key].get("valu_busy_simd_cycles_per_launch"), key
+        assert k[key]["kernel_trace"]["avg_us"] > 0
+    for key in ("cgx1", "cgs01"):
+        assert k[key]["per_subcycle"]["hbm_bytes"]
