@@ -710,6 +710,16 @@ int cice_evp_hip_cgrid_seabed_prob(const double *hwater, const double *aicen, co
     return 0;
 }
 
+// ... or computed by the host after the preparation (the reference's own routines, libm exp(): what the Fortran entry does)
+int cice_evp_hip_cgrid_set_tb(const double *TbE, const double *TbN)
+{
+    if (!CG.prep.pending) return fail(-1, "no prepared C-grid state (cice_evp_hip_cgrid_prep first)");
+    if (!TbE || !TbN) return fail(-1, "null argument");
+    if (h2d(CG.in[CI_TBE], TbE) || h2d(CG.in[CI_TBN], TbN)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
 // ice strength (the host's: icepack_ice_strength + its halo update, ice_dyn_evp.F90:596-608, 727-728) and the per-call
 // set-up of the loop; cice_evp_hip_cgrid_subcycle / _download follow as after cice_evp_hip_cgrid_upload
 int cice_evp_hip_cgrid_prep_finish(const double *strength, int32_t visc_method)

@@ -31,7 +31,8 @@ module ice_dyn_evp_hip
 
   public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body, &
             dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses, dyn_evp_hip_cgrid_run, &
-            dyn_evp_hip_keep_stresses_resident, dyn_evp_hip_cgrid_deformations
+            dyn_evp_hip_keep_stresses_resident, dyn_evp_hip_cgrid_deformations, dyn_evp_hip_cgrid_evp_body, &
+            dyn_evp_hip_cgrid_fetch_forcing
 
   ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
   type, bind(C) :: cice_evp_hip_dims
@@ -211,6 +212,49 @@ module ice_dyn_evp_hip
        real(c_double), dimension(*), intent(inout) :: divu, shear, vort, rdg_conv, rdg_shear
      end function cice_evp_hip_cgrid_deformations
 
+     integer(c_int) function cice_evp_hip_cgrid_set_prep_geometry(tmask, umaskCD, emask, nmask, fcor_blk, fcorE_blk, &
+                                                                  fcorN_blk) bind(C, name='cice_evp_hip_cgrid_set_prep_geometry')
+       import :: c_int, c_int32_t, c_double
+       integer(c_int32_t), dimension(*), intent(in) :: tmask, umaskCD, emask, nmask
+       real(c_double), dimension(*), intent(in) :: fcor_blk, fcorE_blk, fcorN_blk
+     end function cice_evp_hip_cgrid_set_prep_geometry
+
+     integer(c_int) function cice_evp_hip_cgrid_prep(pp, tfields11, state12, iceTmask, iceUmask, iceEmask, iceNmask) &
+          bind(C, name='cice_evp_hip_cgrid_prep')
+       import :: c_int, c_int32_t, c_ptr, cice_evp_hip_prep_params
+       type(cice_evp_hip_prep_params), intent(in) :: pp
+       type(c_ptr), dimension(11), intent(in) :: tfields11
+       type(c_ptr), dimension(12), intent(in) :: state12
+       integer(c_int32_t), dimension(*), intent(inout) :: iceTmask, iceUmask, iceEmask, iceNmask
+     end function cice_evp_hip_cgrid_prep
+
+     integer(c_int) function cice_evp_hip_cgrid_set_tb(TbE, TbN) bind(C, name='cice_evp_hip_cgrid_set_tb')
+       import :: c_int, c_double
+       real(c_double), dimension(*), intent(in) :: TbE, TbN
+     end function cice_evp_hip_cgrid_set_tb
+
+     integer(c_int) function cice_evp_hip_cgrid_prep_finish(strength, visc_method) bind(C, name='cice_evp_hip_cgrid_prep_finish')
+       import :: c_int, c_int32_t, c_double
+       real(c_double), dimension(*), intent(in) :: strength
+       integer(c_int32_t), value :: visc_method
+     end function cice_evp_hip_cgrid_prep_finish
+
+     integer(c_int) function cice_evp_hip_cgrid_subcycle(ndte) bind(C, name='cice_evp_hip_cgrid_subcycle')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), value :: ndte
+     end function cice_evp_hip_cgrid_subcycle
+
+     integer(c_int) function cice_evp_hip_cgrid_download(fields19) bind(C, name='cice_evp_hip_cgrid_download')
+       import :: c_int, c_ptr
+       type(c_ptr), dimension(19), intent(in) :: fields19
+     end function cice_evp_hip_cgrid_download
+
+     integer(c_int) function cice_evp_hip_cgrid_fetch(table, idx, dst) bind(C, name='cice_evp_hip_cgrid_fetch')
+       import :: c_int, c_int32_t, c_double
+       integer(c_int32_t), value :: table, idx
+       real(c_double), dimension(*), intent(inout) :: dst
+     end function cice_evp_hip_cgrid_fetch
+
      integer(c_int) function cice_evp_hip_download(fields32) bind(C, name='cice_evp_hip_download')
        import :: c_int, c_ptr
        type(c_ptr), dimension(32), intent(in) :: fields32
@@ -230,6 +274,7 @@ module ice_dyn_evp_hip
   logical :: on_tripole = .false.
   logical :: cgrid_geometry_set = .false.
   logical :: cgrid_pinned = .false.
+  logical :: cgrid_prep_geometry_set = .false.
 
 contains
 
@@ -622,10 +667,7 @@ contains
     real(kind=dbl_kind), dimension(:,:,:), intent(inout), contiguous, target :: &
       zetax2T, etax2T, etax2U, shearU, deltaU
 
-    type(c_ptr) :: st(23), fl(19), inp(23)
-    integer(int_kind), allocatable, save :: halomask_c(:,:,:)
-    type(block) :: tb
-    integer :: i, j, iblk
+    type(c_ptr) :: fl(19), inp(23)
     integer(c_int32_t), pointer :: mT(:), mU(:), mE(:), mN(:)
     integer(c_int32_t) :: vm
     integer(c_int) :: rc
@@ -635,23 +677,8 @@ contains
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
          file=__FILE__, line=__LINE__)
-    if (.not. cgrid_geometry_set) then
-       st = [cice_evp_hip_addr(dxT), cice_evp_hip_addr(dyT), cice_evp_hip_addr(dxU), cice_evp_hip_addr(dyU), &
-             cice_evp_hip_addr(dxE), cice_evp_hip_addr(dyE), cice_evp_hip_addr(dxN), cice_evp_hip_addr(dyN), &
-             cice_evp_hip_addr(uarea), cice_evp_hip_addr(tarea), cice_evp_hip_addr(earea), cice_evp_hip_addr(narea), &
-             cice_evp_hip_addr(earear), cice_evp_hip_addr(narear), cice_evp_hip_addr(epm), cice_evp_hip_addr(npm), &
-             cice_evp_hip_addr(uvm), cice_evp_hip_addr(hm), cice_evp_hip_addr(DminTarea), &
-             c_loc(ratiodxN), c_loc(ratiodxNr), c_loc(ratiodyE), c_loc(ratiodyEr)]
-       call check(cice_evp_hip_cgrid_set_geometry(st), subname, __FILE__, __LINE__)
-       cgrid_geometry_set = .true.
-    endif
-    if (trim(visc_method) == 'avg_zeta') then
-       vm = 0
-    elseif (trim(visc_method) == 'avg_strength') then
-       vm = 1
-    else
-       call abort_ice(subname//' ERROR: unknown visc_method '//trim(visc_method), file=__FILE__, line=__LINE__)
-    endif
+    call cgrid_ensure_geometry(ratiodxN, ratiodxNr, ratiodyE, ratiodyEr)
+    vm = cgrid_visc_method()
     fl = [cice_evp_hip_addr(uvelE), cice_evp_hip_addr(vvelE), cice_evp_hip_addr(uvelN), cice_evp_hip_addr(vvelN), &
           cice_evp_hip_addr(uvel), cice_evp_hip_addr(vvel), cice_evp_hip_addr(stresspT), cice_evp_hip_addr(stressmT), &
           cice_evp_hip_addr(stress12T), cice_evp_hip_addr(stress12U), cice_evp_hip_addr(strintxE), &
@@ -678,28 +705,243 @@ contains
        enddo
        cgrid_pinned = .true.
     endif
-    if (maskhalo_dyn .and. get_num_procs() > 1) then
-       ! the masked halo evp() builds for the C-grid loop (ice_dyn_evp.F90:739-770: a cell and its four neighbours,
-       ! where iceTmask; ghost cells updated), rebuilt here because halo_info_mask is private to ice_dyn_evp
-       if (.not. allocated(halomask_c)) allocate(halomask_c(nx_block, ny_block, max_blocks))
-       halomask_c = 0
-       do iblk = 1, nblocks
-          tb = get_block(blocks_ice(iblk), iblk)
-          do j = tb%jlo, tb%jhi
-          do i = tb%ilo, tb%ihi
-             if (iceTmask(i,j,iblk) .or. iceTmask(i-1,j,iblk) .or. iceTmask(i+1,j,iblk) .or. &
-                 iceTmask(i,j-1,iblk) .or. iceTmask(i,j+1,iblk)) halomask_c(i,j,iblk) = 1
-          enddo
-          enddo
-       enddo
-       call ice_HaloUpdate(halomask_c, halo_info, field_loc_center, field_type_scalar)
-       call check(cice_evp_hip_halo_mask(halomask_c), subname, __FILE__, __LINE__)
-    endif
+    call cgrid_halo_mask()
     call ice_timer_start(timer_evp1dcore)
     call check(cice_evp_hip_cgrid_run(int(ndte, c_int32_t), vm, fl, inp, mT, mU, mE, mN), subname, __FILE__, __LINE__)
     call ice_timer_stop(timer_evp1dcore)
 
   end subroutine dyn_evp_hip_cgrid_run
+
+!-----------------------------------------------------------------------
+! C-grid helpers: static arrays handed over once; visc_method as the C ABI's code; evp()'s masked halo for the loop
+  subroutine cgrid_ensure_geometry(ratiodxN, ratiodxNr, ratiodyE, ratiodyEr)
+    use ice_dyn_shared, only: DminTarea
+    use ice_grid, only: dxT, dyT, dxU, dyU, dxE, dyE, dxN, dyN, uarea, tarea, earea, narea, earear, narear, &
+                        epm, npm, uvm, hm
+    real(kind=dbl_kind), dimension(:,:,:), intent(in), contiguous, target :: ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
+    type(c_ptr) :: st(23)
+    character(len=*), parameter :: subname = '(dyn_evp_hip cgrid_ensure_geometry)'
+    if (cgrid_geometry_set) return
+    st = [cice_evp_hip_addr(dxT), cice_evp_hip_addr(dyT), cice_evp_hip_addr(dxU), cice_evp_hip_addr(dyU), &
+          cice_evp_hip_addr(dxE), cice_evp_hip_addr(dyE), cice_evp_hip_addr(dxN), cice_evp_hip_addr(dyN), &
+          cice_evp_hip_addr(uarea), cice_evp_hip_addr(tarea), cice_evp_hip_addr(earea), cice_evp_hip_addr(narea), &
+          cice_evp_hip_addr(earear), cice_evp_hip_addr(narear), cice_evp_hip_addr(epm), cice_evp_hip_addr(npm), &
+          cice_evp_hip_addr(uvm), cice_evp_hip_addr(hm), cice_evp_hip_addr(DminTarea), &
+          c_loc(ratiodxN), c_loc(ratiodxNr), c_loc(ratiodyE), c_loc(ratiodyEr)]
+    call check(cice_evp_hip_cgrid_set_geometry(st), subname, __FILE__, __LINE__)
+    cgrid_geometry_set = .true.
+  end subroutine cgrid_ensure_geometry
+
+  integer(c_int32_t) function cgrid_visc_method() result(vm)
+    use ice_dyn_shared, only: visc_method
+    character(len=*), parameter :: subname = '(dyn_evp_hip cgrid_visc_method)'
+    vm = 0
+    if (trim(visc_method) == 'avg_strength') then
+       vm = 1
+    elseif (trim(visc_method) /= 'avg_zeta') then
+       call abort_ice(subname//' ERROR: unknown visc_method '//trim(visc_method), file=__FILE__, line=__LINE__)
+    endif
+  end function cgrid_visc_method
+
+  subroutine cgrid_halo_mask()
+    use ice_dyn_shared, only: iceTmask
+    use ice_blocks, only: nx_block, ny_block, block, get_block
+    use ice_domain, only: maskhalo_dyn, halo_info, nblocks, blocks_ice
+    use ice_domain_size, only: max_blocks
+    use ice_boundary, only: ice_HaloUpdate
+    use ice_constants, only: field_loc_center, field_type_scalar
+    use ice_communicate, only: get_num_procs
+    integer(int_kind), allocatable, save :: halomask_c(:,:,:)
+    type(block) :: tb
+    integer :: i, j, iblk
+    character(len=*), parameter :: subname = '(dyn_evp_hip cgrid_halo_mask)'
+    if (.not. (maskhalo_dyn .and. get_num_procs() > 1)) return
+    ! the masked halo evp() builds for the C-grid loop (ice_dyn_evp.F90:739-770: a cell and its four neighbours,
+    ! where iceTmask; ghost cells updated), rebuilt here because halo_info_mask is private to ice_dyn_evp
+    if (.not. allocated(halomask_c)) allocate(halomask_c(nx_block, ny_block, max_blocks))
+    halomask_c = 0
+    do iblk = 1, nblocks
+       tb = get_block(blocks_ice(iblk), iblk)
+       do j = tb%jlo, tb%jhi
+       do i = tb%ilo, tb%ihi
+          if (iceTmask(i,j,iblk) .or. iceTmask(i-1,j,iblk) .or. iceTmask(i+1,j,iblk) .or. &
+              iceTmask(i,j-1,iblk) .or. iceTmask(i,j+1,iblk)) halomask_c(i,j,iblk) = 1
+       enddo
+       enddo
+    enddo
+    call ice_HaloUpdate(halomask_c, halo_info, field_loc_center, field_type_scalar)
+    call check(cice_evp_hip_halo_mask(halomask_c), subname, __FILE__, __LINE__)
+  end subroutine cgrid_halo_mask
+
+!-----------------------------------------------------------------------
+! C grid, wider (the C-grid counterpart of dyn_evp_hip_evp_body): replaces evp()'s preparation AND its loop for
+! grid_ice = 'C' -- ice_dyn_evp.F90:372-735 (the zeroing of the deformation diagnostics, dyn_prep1, the T-grid halo
+! updates, the T -> U / E / N averages, dyn_prep2 at U, N and E points, the velocity averages and exchanges), 770-840
+! (seabed stress factors, by the reference's own routines on the host: libm exp()) and 938-1099 (the loop).  Public
+! module data is taken from its modules; the arguments are the private arrays of ice_dyn_evp the loop hands back.
+! compute_strength: fills ice_state's strength from the new iceTmask and halo-updates it (icepack_ice_strength,
+! :596-608, 727-728).  Conditions: calc_strair = .true., ocean forcing on the T grid (grid_ocn_dynu = grid_ocn_dynv =
+! 'T').  The host's own code after the loop that reads products of the preparation (dyn_finish at E / N points: aiX,
+! fmX, uocnX, vocnX, cdn_ocnX and dyn_prep2's index lists) gets them through dyn_evp_hip_cgrid_fetch_forcing and from
+! the masks.
+  subroutine dyn_evp_hip_cgrid_evp_body(dt, compute_strength, ratiodxN, ratiodxNr, ratiodyE, ratiodyEr, &
+                                        zetax2T, etax2T, etax2U, shearU, deltaU)
+
+    use ice_blocks, only: nx_block, ny_block, block, get_block
+    use ice_domain_size, only: max_blocks
+    use ice_domain, only: nblocks, blocks_ice
+    use ice_grid, only: tmask, umaskCD, emask, nmask, grid_ocn_dynu, grid_ocn_dynv
+    use ice_state, only: aice, vice, vsno, aice_init, strength, aicen, vicen, uvel, vvel, uvelE, vvelE, uvelN, vvelN, &
+                         divu, shear, vort
+    use ice_arrays_column, only: Cdn_ocn
+    use ice_flux, only: uocn, vocn, ss_tltx, ss_tlty, strairxT, strairyT, stresspT, stressmT, stress12T, stress12U, &
+                        strintxE, strintyN, taubxE, taubyN, TbU, TbE, TbN, hwater, rdg_conv, rdg_shear
+    use ice_dyn_shared, only: ndte, fcor_blk, fcorE_blk, fcorN_blk, iceTmask, iceUmask, iceEmask, iceNmask, &
+                              dyn_area_min, dyn_mass_min, ssh_stress, seabed_stress, seabed_stress_method, &
+                              seabed_stress_factor_LKD, seabed_stress_factor_prob
+    use ice_timers, only: ice_timer_start, ice_timer_stop, timer_evp1dcore
+    use icepack_intfc, only: icepack_query_parameters
+
+    real(kind=dbl_kind), intent(in) :: dt
+    interface
+       subroutine compute_strength()
+       end subroutine compute_strength
+    end interface
+    real(kind=dbl_kind), dimension(:,:,:), intent(in), contiguous, target :: ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
+    real(kind=dbl_kind), dimension(:,:,:), intent(inout), contiguous, target :: zetax2T, etax2T, etax2U, shearU, deltaU
+
+    type(cice_evp_hip_prep_params) :: pp
+    type(c_ptr) :: tf(11), s12(12), fl(19)
+    integer(c_int32_t), pointer :: m1(:), m2(:), m3(:), m4(:), mT(:), mU(:), mE(:), mN(:)
+    integer(int_kind), allocatable :: ixT(:), jxT(:), ixE(:), jxE(:), ixN(:), jxN(:), ixU(:), jxU(:)
+    integer :: nall, iblk, i, j, nT, nE, nN, nU
+    type(block) :: tb
+    logical :: calc_strair
+    character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_evp_body)'
+
+    if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
+         file=__FILE__, line=__LINE__)
+    call icepack_query_parameters(calc_strair_out=calc_strair)
+    if (.not. calc_strair .or. trim(grid_ocn_dynu) /= 'T' .or. trim(grid_ocn_dynv) /= 'T') &
+       call abort_ice(subname//' ERROR: needs calc_strair = .true. and ocean forcing on the T grid', &
+            file=__FILE__, line=__LINE__)
+    nall = nx_block*ny_block*max_blocks
+    call cgrid_ensure_geometry(ratiodxN, ratiodxNr, ratiodyE, ratiodyEr)
+    if (.not. cgrid_prep_geometry_set) then
+       call c_f_pointer(cice_evp_hip_addr(tmask), m1, [nall])
+       call c_f_pointer(cice_evp_hip_addr(umaskCD), m2, [nall])
+       call c_f_pointer(cice_evp_hip_addr(emask), m3, [nall])
+       call c_f_pointer(cice_evp_hip_addr(nmask), m4, [nall])
+       call check(cice_evp_hip_cgrid_set_prep_geometry(m1, m2, m3, m4, fcor_blk, fcorE_blk, fcorN_blk), &
+            subname, __FILE__, __LINE__)
+       cgrid_prep_geometry_set = .true.
+    endif
+    ! ice_dyn_evp.F90:372-382
+    rdg_conv(:,:,1:nblocks) = 0.0_dbl_kind; rdg_shear(:,:,1:nblocks) = 0.0_dbl_kind
+    divu(:,:,1:nblocks) = 0.0_dbl_kind; shear(:,:,1:nblocks) = 0.0_dbl_kind; vort(:,:,1:nblocks) = 0.0_dbl_kind
+
+    pp%dt = dt
+    call icepack_query_parameters(rhoi_out=pp%rhoi, rhos_out=pp%rhos, gravit_out=pp%gravit)
+    pp%dyn_area_min = dyn_area_min
+    pp%dyn_mass_min = dyn_mass_min
+    pp%ssh_stress_coupled = merge(1_c_int32_t, 0_c_int32_t, trim(ssh_stress) == 'coupled')
+    tf(1) = cice_evp_hip_addr(aice);      tf(2) = cice_evp_hip_addr(vice);     tf(3) = cice_evp_hip_addr(vsno)
+    tf(4) = cice_evp_hip_addr(aice_init); tf(5) = cice_evp_hip_addr(Cdn_ocn)
+    tf(6) = cice_evp_hip_addr(uocn);      tf(7) = cice_evp_hip_addr(vocn)
+    tf(8) = cice_evp_hip_addr(ss_tltx);   tf(9) = cice_evp_hip_addr(ss_tlty)
+    tf(10) = cice_evp_hip_addr(strairxT); tf(11) = cice_evp_hip_addr(strairyT)
+    ! the state travels in at every call: the host's arrays stay the master copy (a host that never touches them
+    ! between two evp() calls can pass null pointers to the C ABI instead and save the copies)
+    s12 = [cice_evp_hip_addr(uvelE), cice_evp_hip_addr(vvelE), cice_evp_hip_addr(uvelN), cice_evp_hip_addr(vvelN), &
+           cice_evp_hip_addr(uvel), cice_evp_hip_addr(vvel), cice_evp_hip_addr(stresspT), cice_evp_hip_addr(stressmT), &
+           cice_evp_hip_addr(stress12T), cice_evp_hip_addr(stress12U), cice_evp_hip_addr(strintxE), &
+           cice_evp_hip_addr(strintyN)]
+    call c_f_pointer(cice_evp_hip_addr(iceTmask), mT, [nall])
+    call c_f_pointer(cice_evp_hip_addr(iceUmask), mU, [nall])
+    call c_f_pointer(cice_evp_hip_addr(iceEmask), mE, [nall])
+    call c_f_pointer(cice_evp_hip_addr(iceNmask), mN, [nall])
+    call check(cice_evp_hip_cgrid_prep(pp, tf, s12, mT, mU, mE, mN), subname, __FILE__, __LINE__)
+
+    call compute_strength()
+    call cgrid_halo_mask()
+
+    if (seabed_stress) then
+       ! the reference's own routines on the host, from the masks the device preparation returned (index lists as
+       ! dyn_prep2 builds them, ice_dyn_shared.F90:740-770; call sites ice_dyn_evp.F90:803-827)
+       allocate(ixT(nx_block*ny_block), jxT(nx_block*ny_block), ixE(nx_block*ny_block), jxE(nx_block*ny_block), &
+                ixN(nx_block*ny_block), jxN(nx_block*ny_block), ixU(nx_block*ny_block), jxU(nx_block*ny_block))
+       do iblk = 1, nblocks
+          tb = get_block(blocks_ice(iblk), iblk)
+          TbE(:,:,iblk) = 0.0_dbl_kind; TbN(:,:,iblk) = 0.0_dbl_kind
+          nT = 0; nE = 0; nN = 0; nU = 0
+          do j = tb%jlo, tb%jhi+1
+          do i = tb%ilo, tb%ihi+1
+             if (iceTmask(i,j,iblk)) then
+                nT = nT + 1; ixT(nT) = i; jxT(nT) = j
+             endif
+          enddo
+          enddo
+          do j = tb%jlo, tb%jhi
+          do i = tb%ilo, tb%ihi
+             if (iceEmask(i,j,iblk)) then
+                nE = nE + 1; ixE(nE) = i; jxE(nE) = j
+             endif
+             if (iceNmask(i,j,iblk)) then
+                nN = nN + 1; ixN(nN) = i; jxN(nN) = j
+             endif
+             if (iceUmask(i,j,iblk)) then
+                nU = nU + 1; ixU(nU) = i; jxU(nU) = j
+             endif
+          enddo
+          enddo
+          if (trim(seabed_stress_method) == 'LKD') then
+             call seabed_stress_factor_LKD(nx_block, ny_block, nE, ixE, jxE, vice(:,:,iblk), aice(:,:,iblk), &
+                                           hwater(:,:,iblk), TbE(:,:,iblk), grid_location='E')
+             call seabed_stress_factor_LKD(nx_block, ny_block, nN, ixN, jxN, vice(:,:,iblk), aice(:,:,iblk), &
+                                           hwater(:,:,iblk), TbN(:,:,iblk), grid_location='N')
+          elseif (trim(seabed_stress_method) == 'probabilistic') then
+             call seabed_stress_factor_prob(nx_block, ny_block, nT, ixT, jxT, nU, ixU, jxU, &
+                                            aicen(:,:,:,iblk), vicen(:,:,:,iblk), hwater(:,:,iblk), TbU(:,:,iblk), &
+                                            TbE(:,:,iblk), TbN(:,:,iblk), nE, ixE, jxE, nN, ixN, jxN)
+          endif
+       enddo
+       deallocate(ixT, jxT, ixE, jxE, ixN, jxN, ixU, jxU)
+       call check(cice_evp_hip_cgrid_set_tb(TbE, TbN), subname, __FILE__, __LINE__)
+    endif
+    call check(cice_evp_hip_cgrid_prep_finish(strength, cgrid_visc_method()), subname, __FILE__, __LINE__)
+
+    call ice_timer_start(timer_evp1dcore)
+    call check(cice_evp_hip_cgrid_subcycle(int(ndte, c_int32_t)), subname, __FILE__, __LINE__)
+    fl(1:12) = s12
+    fl(13) = cice_evp_hip_addr(taubxE); fl(14) = cice_evp_hip_addr(taubyN)
+    fl(15) = c_loc(zetax2T); fl(16) = c_loc(etax2T); fl(17) = c_loc(etax2U); fl(18) = c_loc(shearU); fl(19) = c_loc(deltaU)
+    call check(cice_evp_hip_cgrid_download(fl), subname, __FILE__, __LINE__)
+    call ice_timer_stop(timer_evp1dcore)
+
+  end subroutine dyn_evp_hip_cgrid_evp_body
+
+!-----------------------------------------------------------------------
+! Products of the device preparation that the host's own post-loop code reads at E and N points (dyn_finish,
+! ice_dyn_evp.F90:1404-1424): private arrays of ice_dyn_evp, so the patched evp() passes them.  fmE / fmN are public.
+  subroutine dyn_evp_hip_cgrid_fetch_forcing(cdn_ocnE, aiE, uocnE, vocnE, cdn_ocnN, aiN, uocnN, vocnN)
+    use ice_flux, only: fmE, fmN
+    use ice_dyn_shared, only: uvelE_init, vvelN_init
+    real(kind=dbl_kind), dimension(:,:,:), intent(inout), contiguous :: cdn_ocnE, aiE, uocnE, vocnE, cdn_ocnN, aiN, uocnN, vocnN
+    character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_fetch_forcing)'
+    ! indices into the loop's input table (include/cice_evp_hip.h: inputs23, 0-based)
+    call check(cice_evp_hip_cgrid_fetch(1, 1, cdn_ocnE), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 2, aiE), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 3, uocnE), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 4, vocnE), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 8, fmE), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 9, uvelE_init), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 12, cdn_ocnN), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 13, aiN), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 14, uocnN), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 15, vocnN), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 19, fmN), subname, __FILE__, __LINE__)
+    call check(cice_evp_hip_cgrid_fetch(1, 20, vvelN_init), subname, __FILE__, __LINE__)
+  end subroutine dyn_evp_hip_cgrid_fetch_forcing
 
 !-----------------------------------------------------------------------
 ! C grid: replaces the call of deformationsC_T that follows the loop in evp() (ice_dyn_evp.F90:1106-1119): divu, shear,

@@ -276,6 +276,7 @@ int cice_evp_hip_cgrid_prep(const cice_evp_hip_prep_params *pp, const double *co
 int cice_evp_hip_cgrid_seabed_lkd(const double *hwater, double k1, double k2, double alphab, double threshold_hw);
 int cice_evp_hip_cgrid_seabed_prob(const double *hwater, const double *aicen, const double *vicen, int32_t ncat, double alphab,
                                    double rhoi, double gravit, double pi, double puny);
+int cice_evp_hip_cgrid_set_tb(const double *TbE, const double *TbN);   /* seabed factors computed by the host after _cgrid_prep */
 int cice_evp_hip_cgrid_prep_finish(const double *strength, int32_t visc_method);
 int cice_evp_hip_cgrid_fetch(int32_t table, int32_t index, double *dst);
 /* the same in three steps (state14 = the first 14 entries of fields19) */

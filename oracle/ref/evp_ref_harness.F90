@@ -37,19 +37,43 @@ module evp_cgrid_capture
   use ice_dyn_shared
   use ice_dyn_evp, only: evp, ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
 #ifdef HARNESS_HIP_BODY
-  use ice_dyn_evp_hip, only: dyn_evp_hip_cgrid_run, dyn_evp_hip_cgrid_deformations
+  use ice_dyn_evp_hip, only: dyn_evp_hip_cgrid_run, dyn_evp_hip_cgrid_deformations, dyn_evp_hip_cgrid_evp_body
 #endif
   use evp_dumpio
   implicit none
   real(dbl_kind), allocatable, dimension(:,:,:), private :: c_uE, c_vN, c_uN, c_vE, c_spT, c_smT, c_s12T, c_s12U, c_u, c_v
+  ! the state evp() is entered with (before its preparation), for the device-preparation variant
+  real(dbl_kind), allocatable, dimension(:,:,:), private :: q_uE, q_vN, q_uN, q_vE, q_spT, q_smT, q_s12T, q_s12U, q_u, q_v, &
+                                                            q_sxE, q_syN
+  logical(log_kind), allocatable, dimension(:,:,:), private :: q_mU, q_mE, q_mN
 contains
+
+  ! icepack_ice_strength on the T-cells of the new iceTmask + its halo update (ice_dyn_evp.F90:596-608, 727-728):
+  ! the callback of dyn_evp_hip_cgrid_evp_body
+  subroutine cgrid_strength()
+    use icepack_intfc, only: icepack_ice_strength
+    integer :: ib, ii, jj
+    type(block) :: bb
+    do ib = 1, nblocks
+       bb = get_block(blocks_ice(ib), ib)
+       strength(:,:,ib) = c0
+       do jj = bb%jlo, bb%jhi+1
+       do ii = bb%ilo, bb%ihi+1
+          if (iceTmask(ii,jj,ib)) &
+             call icepack_ice_strength(aice=aice(ii,jj,ib), vice=vice(ii,jj,ib), aice0=aice0(ii,jj,ib), &
+                                       aicen=aicen(ii,jj,:,ib), vicen=vicen(ii,jj,:,ib), strength=strength(ii,jj,ib))
+       enddo
+       enddo
+    enddo
+    call ice_HaloUpdate(strength, halo_info, field_loc_center, field_type_scalar)
+  end subroutine cgrid_strength
 
   ! ---- C grid: the subcycle inputs are module-private; a preparation-only evp() (ndte = 0) leaves them in place,
   !      evp_peek.c reads them; the very next evp() calls from the same state give the reference's outputs ----
 
-  subroutine cgrid_call(ic, nsub_list, nl, h_ndte, hipmode, evolve)
+  subroutine cgrid_call(ic, nsub_list, nl, h_ndte, hipmode, evolve, hipprep)
     integer(int_kind), intent(in) :: ic, nsub_list(:), nl, h_ndte
-    logical, intent(in) :: hipmode, evolve
+    logical, intent(in) :: hipmode, evolve, hipprep
     integer(int_kind) :: kk, ns, ib, i, j, ig, jg
     type(block) :: tb
     character(len=16) :: tg
@@ -103,6 +127,16 @@ contains
     call dump_r8_3d(trim(tg)//'_strintxE', strintxE, nblocks);   call dump_r8_3d(trim(tg)//'_strintyN', strintyN, nblocks)
     call dump_l_3d (trim(tg)//'_iceUmask', iceUmask, nblocks)
     call dump_l_3d (trim(tg)//'_iceEmask', iceEmask, nblocks);   call dump_l_3d (trim(tg)//'_iceNmask', iceNmask, nblocks)
+    if (.not. allocated(q_uE)) then
+       allocate(q_uE(nx_block,ny_block,max_blocks), q_vN(nx_block,ny_block,max_blocks), q_uN(nx_block,ny_block,max_blocks), &
+                q_vE(nx_block,ny_block,max_blocks), q_spT(nx_block,ny_block,max_blocks), q_smT(nx_block,ny_block,max_blocks), &
+                q_s12T(nx_block,ny_block,max_blocks), q_s12U(nx_block,ny_block,max_blocks), q_u(nx_block,ny_block,max_blocks), &
+                q_v(nx_block,ny_block,max_blocks), q_sxE(nx_block,ny_block,max_blocks), q_syN(nx_block,ny_block,max_blocks), &
+                q_mU(nx_block,ny_block,max_blocks), q_mE(nx_block,ny_block,max_blocks), q_mN(nx_block,ny_block,max_blocks))
+    endif
+    q_uE = uvelE; q_vN = vvelN; q_uN = uvelN; q_vE = vvelE; q_u = uvel; q_v = vvel
+    q_spT = stresspT; q_smT = stressmT; q_s12T = stress12T; q_s12U = stress12U; q_sxE = strintxE; q_syN = strintyN
+    q_mU = iceUmask; q_mE = iceEmask; q_mN = iceNmask
     ndte = 0
     call evp(dt_dyn)                 ! preparation only
     ndte = h_ndte
@@ -140,6 +174,16 @@ contains
           ns = nsub_list(kk)
           uvelE = c_uE; vvelN = c_vN; uvelN = c_uN; vvelE = c_vE; uvel = c_u; vvel = c_v
           stresspT = c_spT; stressmT = c_smT; stress12T = c_s12T; stress12U = c_s12U
+          if (hipprep) then
+             ! the preparation on the device as well: from the state evp() was entered with (the C-grid counterpart of
+             ! dyn_evp_hip_evp_body; the reference's evp() does not run at all for this output)
+             uvelE = q_uE; vvelN = q_vN; uvelN = q_uN; vvelE = q_vE; uvel = q_u; vvel = q_v
+             stresspT = q_spT; stressmT = q_smT; stress12T = q_s12T; stress12U = q_s12U; strintxE = q_sxE; strintyN = q_syN
+             iceUmask = q_mU; iceEmask = q_mE; iceNmask = q_mN
+             ndte = ns
+             call dyn_evp_hip_cgrid_evp_body(dt_dyn, cgrid_strength, ratiodxN, ratiodxNr, ratiodyE, ratiodyEr, &
+                                             pk3(17), pk3(18), pk3(19), pk3(20), pk3(21))
+          else
           ndte = 0
           call evp(dt_dyn)
           ndte = ns
@@ -147,6 +191,7 @@ contains
                pk3(1), pk3(2), pk3(3), pk3(4), pk3(5), pk3(6), pk3(7), pk3(8), &
                pk3(9), pk3(10), pk3(11), pk3(12), pk3(13), pk3(14), pk3(15), pk3(16), &
                ratiodxN, ratiodxNr, ratiodyE, ratiodyEr, pk3(17), pk3(18), pk3(19), pk3(20), pk3(21))
+          endif
           ndte = h_ndte
           write(tg,'(a,i2.2,a,i4.4)') 'h', ic, 'n', ns
           call dump_r8_3d(trim(tg)//'_uvelE', uvelE, nblocks);   call dump_r8_3d(trim(tg)//'_vvelE', vvelE, nblocks)
@@ -494,7 +539,7 @@ program evp_ref_harness
   do icall = 1, ncalls
 
      if (trim(grid_ice) == 'C') then
-        call cgrid_call(icall, nsub_list, nl, h_ndte, hipmode, h_evolve)
+        call cgrid_call(icall, nsub_list, nl, h_ndte, hipmode, h_evolve, hipbody)
         cycle
      endif
 

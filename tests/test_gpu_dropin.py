@@ -93,16 +93,23 @@ CGRID_CASES = [
 ]
 
 
+@pytest.mark.parametrize("prep", ["reference_preparation", "device_preparation"])
 @pytest.mark.parametrize("nx,ny,bx,by,ew,kw", CGRID_CASES)
-def test_reference_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, ew, kw):
+def test_reference_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, ew, kw, prep):
     """C grid: the reference's own driver and preparation (evp() with ndte = 0), then the subcycle loop through the
     Fortran entry a patched evp() calls -- dyn_evp_hip_cgrid_run(<ice_dyn_evp's private arrays>) -> ISO_C_BINDING
     -> cice_evp_hip_cgrid_run -> HIP -- against the reference's evp() with grid_ice = 'C' from the same state, in
     the same process.  Every array the loop writes, every cell, ghost cells included; strintxE / strintyN after the
-    halo update evp() gives them once the loop is over (ice_dyn_evp.F90:1437-1440; applied here with the oracle)."""
+    halo update evp() gives them once the loop is over (ice_dyn_evp.F90:1437-1440; applied here with the oracle).
+    device_preparation: the reference's evp() does not run at all for the HIP result -- dyn_evp_hip_cgrid_evp_body does
+    the preparation (device; ice strength and seabed factors by the host's routines from the returned masks) and the
+    loop from the state evp() would be entered with; the ice cover changes between the two calls and the sea surface
+    slopes (ssh_stress = 'coupled')."""
     if not run_ref.have_ref("hip_dropin"):
         pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
     kw = dict(kw)
+    if prep == "device_preparation":
+        kw.update(hipbody=True, h_evolve=True, h_ssh="coupled")
     ns = kw.pop("ns", "closed")
     g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
