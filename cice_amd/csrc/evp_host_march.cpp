@@ -129,8 +129,10 @@ static bool march_geometry(std::string &why)
     // waves) 318 us per subcycle, 24 (1440: some SIMDs get two) 400, 34 (2040: two each) 378, 12 (720) 372
     int seglen = env("CICE_EVP_HIP_MARCH_SEG") ? std::atoi(env("CICE_EVP_HIP_MARCH_SEG")) : 0;
     if (seglen <= 0) {
+        // (medium domains, 0.45M .. 1M cells: shorter segments keep the count near 1000 -- 1080 x 720: 14-row segments 39 us
+        // per subcycle against 53 for the one-subcycle kernel; each segment recomputes ~3.5 rows of warm-up)
         const int want_seg = std::max(1, 1000 / M.nstrips);
-        seglen = std::max(16, (G.nyr + want_seg - 1) / want_seg);
+        seglen = std::max(6, (G.nyr + want_seg - 1) / want_seg);
     }
     M.seglen = std::min(seglen, G.nyr);
     M.nseg = (G.nyr + M.seglen - 1) / M.seglen;
@@ -298,8 +300,8 @@ bool march_wanted()
         return false;
     }
     // worth it when the domain is far beyond what stays on the chip (the on-chip resident kernel is chosen before this
-    // is asked): from ~1M cells the strips fill the GPU
-    if (want < 0 && (long)S.d.nx_global * S.d.ny_global < 1000000L * std::max(1, (int)S.d.nranks)) { M.why = "below 1M cells per rank"; return false; }
+    // is asked): measured against the one-subcycle kernel 24 vs 26.5 us per subcycle at 389k cells, 39 vs 53 at 778k
+    if (want < 0 && (long)S.d.nx_global * S.d.ny_global < 450000L * std::max(1, (int)S.d.nranks)) { M.why = "below 450k cells per rank"; return false; }
     M.mode = 1;
     return true;
 }

@@ -351,7 +351,7 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
 /* The two-subcycles-per-pass path for per-rank domains beyond the chip (evp_march.hip): out[0] mode (-1 undecided,
  * 0 off, 1 on), [1] passes run since init, [2] calls it handed back to the one-subcycle kernels (the uploaded ghost
  * values were not images of one global state), [3] strips, [4] segments, [5] rows per segment, [6] 1 = the last
- * cice_evp_hip_subcycle ran through it.  CICE_EVP_HIP_MARCH=0/1 forces it off / on (default: from 1M cells).   */
+ * cice_evp_hip_subcycle ran through it.  CICE_EVP_HIP_MARCH=0/1 forces it off / on (default: from 450k cells per rank).   */
 int cice_evp_hip_march_info(int32_t *out, int32_t n);
 /* Host-only (CPU tests): geometry and exchange lists of the two-subcycle path for dims->rank.  Every rank's sub-domain
  * must be one rectangle; the rank HOLDS its own cells plus `ext` (even) more on every side that has a neighbour, in strips

@@ -1,7 +1,7 @@
 """GPU (-m gpu): the two-subcycles-per-pass kernel (cice_amd/csrc/evp_march.hip: one wave marches north over a strip
 of 64 columns, stress -> stepu -> stress -> stepu per row, neighbours by wave shuffles, a device-private rectangle
 layout) against the golden fixtures frozen from the reference's evp() and against the CPU oracle -- bit for bit in
-strict mode.  The path is the default from 1M cells per rank; here it is forced on small grids
+strict mode.  The path is the default from 450k cells per rank; here it is forced on small grids
 (CICE_EVP_HIP_MARCH=1, on-chip resident kernel off) with short segments so that every overlap rule is exercised:
 strips (60 owned columns of 64 lanes), segments, cyclic wrap images, several blocks per rank, padded blocks, closed
 east-west boundaries, odd subcycle counts, revised EVP / seabed stress / fractional capping (the non-LEAN variants)."""

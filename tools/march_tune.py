@@ -1,12 +1,17 @@
-"""Two-subcycle marching kernel on 3600x2400 (or argv[1]): us per subcycle for a list of settings.
+"""Two-subcycle marching kernel on 3600x2400 (or argv[1]: a workload name or NXxNY): us per subcycle for a list of settings.
    python tools/march_tune.py [s01] "SEG=48 ORDER=0" "SEG=96 ORDER=1" ...   (CICE_EVP_HIP_MARCH_<key>)"""
 import sys, os, time
 import pathlib; R=str(pathlib.Path(__file__).resolve().parents[1]); sys.path[:0]=[R, R+'/tests', R+'/oracle']
 import numpy as np
 from cice_amd import evp, synth, decomp
 args = sys.argv[1:]
-wl = args.pop(0) if args and args[0] in synth.GRIDS else "s01"
-spec = synth.GRIDS[wl]
+import re
+if args and re.fullmatch(r"\d+x\d+", args[0]):          # any size, 0.1-degree-class spacing
+    wl = args.pop(0)
+    spec = dict(nx=int(wl.split("x")[0]), ny=int(wl.split("x")[1]), dx0=2.8e4)
+else:
+    wl = args.pop(0) if args and args[0] in synth.GRIDS else "s01"
+    spec = synth.GRIDS[wl]
 nx, ny = spec["nx"], spec["ny"]
 g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
 st = synth.make_state(g, case="full", seed=20260928, warm=True)
