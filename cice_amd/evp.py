@@ -20,7 +20,7 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libcice_evp_hip.so"
+LIB_PATH = Path(os.environ["CICE_EVP_HIP_LIBRARY"]) if os.environ.get("CICE_EVP_HIP_LIBRARY") else HERE / "libcice_evp_hip.so"   # (override: experiments)
 
 BND = {"closed": 0, "open": 1, "cyclic": 2, "tripole": 3}
 
