@@ -345,6 +345,9 @@ int cice_evp_hip_subcycle(int32_t ndte)
 int cice_evp_hip_stress_halo(void)
 {
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
+    if (S.plan.tfold)
+        return fail(-9, "tripoleT: the stress symmetrisation stays with the host (evp() applies it to its own arrays, "
+                        "ice_dyn_evp.F90:1321-1389)");
     if (S.plan.stress_remote)
         return fail(-9, "tripole: on this rank layout the stress symmetrisation needs top-row cells of other ranks; it stays "
                         "with the host (evp() applies it to its own arrays, ice_dyn_evp.F90:1321-1389)");

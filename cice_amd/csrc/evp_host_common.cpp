@@ -228,7 +228,7 @@ int derive_metrics(const double *HTE, const double *HTN, const double *dxT, cons
     if (same) S.flags |= EVP_F_METRICS;
     // on the tripole ghost row dxhy/dyhx are mirrored interior values (halo update with sign,
     // ice_dyn_shared.F90:412-417), not a local difference: keep them as arrays there
-    if (S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE) S.flags |= EVP_F_DXHY_ARRAY;
+    if (S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE || S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLET) S.flags |= EVP_F_DXHY_ARRAY;
     const int order[7] = {4, 5, 6, 7, 2, 3, 8};   // stat slots of cxp cyp cxm cym dxhy dyhx Dmin
     for (int k = 0; k < 7; ++k)
         if (h2d(S.stat[order[k]], m[k].data())) return -1;

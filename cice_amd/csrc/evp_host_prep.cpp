@@ -14,6 +14,7 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
     State::Prep &Q = S.prep;
     // T-grid ghost cells owned by other ranks travel with the velocity exchange (same cells for centre and corner
     // fields) -- except across the tripole fold, where centre fields mirror other cells than corner fields do
+    if (S.plan.tfold) return fail(-9, "device preparation: not built for tripoleT grids; keep evp()'s host preparation (cice_evp_hip_run)");
     if (S.plan.center_fold_remote)
         return fail(-9, "device preparation: T-grid ghost cells across the tripole fold live on other ranks here (the fold "
                         "row is split in x); keep evp()'s host preparation and use cice_evp_hip_run on this configuration");

@@ -12,6 +12,7 @@ bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0; }
 bool resident_possible(bool with_peers)
 {
     if (!with_peers && !S.plan.peers.empty()) return false;
+    if (S.plan.tfold) return false;           // tripoleT: the top row's images are interior cells (rewritten after the launch)
     if (S.plan.tail > 0) return false;        // tripole seam pairs across ranks: streaming kernel + exchange + seam step
     if (tripole_seam() || S.d.nblocks > 1) {
         // tagged-record kernel only: the fold row is averaged inside the kernel, ghost images come

@@ -39,7 +39,13 @@ Src resolve(const cice_evp_hip_dims &d, int ig, int jg)
         else s.outside = true;
     } else if (jg > NY) {
         if (d.ns_boundary_type == CICE_EVP_BND_CYCLIC) jg -= NY;
-        else if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE && !s.outside) {
+        else if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLET && !s.outside) {
+            // T-fold, NE-corner vector field (ice_boundary.F90:1563-1622 offsets (0, 1), copy-out :1686-1722 with the
+            // buffer addresses of :8135-8159): ghost(ig, NY+1) <- - a(NX-ig+1, NY-2)
+            ig = NX - ig + 1;
+            jg = NY - 2;
+            s.sign = -1;
+        } else if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE && !s.outside) {
             // u-fold mirror of an NE-corner vector field (ice_blocks.F90:423-424;
             // copy-out offsets (1,1) and isign = -1, ice_boundary.F90:1555-1556,1632-1633):
             //   ghost(ig, NY+k) <- - a(NX-ig, NY-k)
@@ -49,6 +55,13 @@ Src resolve(const cice_evp_hip_dims &d, int ig, int jg)
             jg = NY - k;
             s.sign = -1;
         } else s.outside = true;
+    }
+    else if (jg == NY && d.ns_boundary_type == CICE_EVP_BND_TRIPOLET && !s.outside) {
+        // ... and the top physical row itself (interior cells and their east-west ghost columns) is the image of row
+        // NY-1: a(ig, NY) <- - a(NX-ig+1, NY-1); nothing is averaged at this location
+        ig = NX - ig + 1;
+        jg = NY - 1;
+        s.sign = -1;
     }
     s.ig = ig;
     s.jg = jg;
@@ -68,8 +81,15 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
         return false;
     }
     const bool tripole = d.ns_boundary_type == CICE_EVP_BND_TRIPOLE;
-    if (tripole && (d.nx_global % 2 != 0 || d.ew_boundary_type != CICE_EVP_BND_CYCLIC)) {
+    const bool tfold = d.ns_boundary_type == CICE_EVP_BND_TRIPOLET;
+    plan.tfold = tfold;
+    if ((tripole || tfold) && (d.nx_global % 2 != 0 || d.ew_boundary_type != CICE_EVP_BND_CYCLIC)) {
         plan.error = "tripole needs an even nx_global and a cyclic east-west boundary";
+        return false;
+    }
+    if (tfold && d.nranks > 1) {
+        plan.error = "tripoleT: one rank only (the images of the top row are interior cells: no exchange may ride in the "
+                     "launch that computes them)";
         return false;
     }
     const int ng = d.nghost;
@@ -140,7 +160,9 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
             const int ilo = ng + 1, jlo = ng + 1, ihi = ng + B.gnx, jhi = ng + B.gny;
             for (int j = jlo - ng; j <= jhi + ng; ++j)
                 for (int i = ilo - ng; i <= ihi + ng; ++i) {
-                    if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) continue;
+                    const bool interior = i >= ilo && i <= ihi && j >= jlo && j <= jhi;
+                    // (tripoleT: the top physical row is a destination of the halo update as well)
+                    if (interior && !(tfold && B.gj0 + (j - jlo) == d.ny_global)) continue;
                     const Src s = resolve(d, B.gi0 + (i - ilo), B.gj0 + (j - jlo));
                     if (s.outside) continue;
                     const int32_t dst = (int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1));
@@ -220,7 +242,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                                 ig = NX - ig + 1;
                                 jg = NY - k + 1;
                                 sign = -1;
-                            } else outside = true;
+                            } else outside = true;      // (tripoleT: no centre lists -- the preparation stays with the host)
                         }
                         if (outside) continue;
                         const int32_t dst = (int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1));

@@ -78,6 +78,7 @@ struct HaloPlan {
     // scalars always copy.  center_remote: some source lives on another rank (not listed).
     std::vector<int32_t> center_dst, center_src;
     std::vector<int8_t> center_vsign;
+    bool tfold = false;                           // ns_boundary_type 'tripoleT': velocity halo only (one rank)
     bool center_remote = false;
     bool center_fold_remote = false;              // ... and one of them lies across the tripole fold (centre mirror rule, other rank)
     std::string error;

@@ -46,7 +46,8 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
     const int me = d.rank;
     const int NX = d.nx_global, NY = d.ny_global;
     if (d.nghost != 1) { P.error = "nghost != 1"; return false; }
-    if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE || d.ns_boundary_type == CICE_EVP_BND_CYCLIC) {
+    if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLE || d.ns_boundary_type == CICE_EVP_BND_TRIPOLET ||
+        d.ns_boundary_type == CICE_EVP_BND_CYCLIC) {
         P.error = "north-south boundary is not closed";
         return false;
     }

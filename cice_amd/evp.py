@@ -22,7 +22,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["CICE_EVP_HIP_LIBRARY"]) if os.environ.get("CICE_EVP_HIP_LIBRARY") else HERE / "libcice_evp_hip.so"   # (override: experiments)
 
-BND = {"closed": 0, "open": 1, "cyclic": 2, "tripole": 3}
+BND = {"closed": 0, "open": 1, "cyclic": 2, "tripole": 3, "tripoleT": 4}
 
 # order of the 32-entry field table == argument order of cice_evp_hip_run
 FIELDS = [

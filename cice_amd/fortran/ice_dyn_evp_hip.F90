@@ -367,7 +367,7 @@ contains
     p%deltaminEVP = deltaminEVP; p%u0 = u0; p%cosw = cosw; p%sinw = sinw; p%rhow = rhow
 
     call check(cice_evp_hip_init(d, p, HTE, HTN, dxT, dyT, uarear, tarea), subname, __FILE__, __LINE__)
-    if (trim(ns_boundary_type) == 'tripole') then
+    if (trim(ns_boundary_type) == 'tripole' .or. trim(ns_boundary_type) == 'tripoleT') then
        ! the north ghost row of dxhy/dyhx is a mirrored interior value (halo update with
        ! sign, ice_dyn_shared.F90:412-417): hand over CICE's own arrays
        call check(cice_evp_hip_set_metrics(c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, &
@@ -381,6 +381,8 @@ contains
     ! evp()'s host code (ice_dyn_evp.F90:1321-1389), so the stresses must make the round trip every call
     if (on_tripole .and. cice_evp_hip_seam_fin_plan(cnt2, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr) == 1) &
        stress_resident = .false.
+    ! tripoleT: the symmetrisation is not built on the device at all
+    if (trim(ns_boundary_type) == 'tripoleT') stress_resident = .false.
     call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
          subname, __FILE__, __LINE__)
 
@@ -404,6 +406,7 @@ contains
     case ('open');    bnd_code = 1
     case ('cyclic');  bnd_code = 2
     case ('tripole'); bnd_code = 3
+    case ('tripoleT'); bnd_code = 4          ! T-fold: the loop only (Option B), one rank
     case default
        bnd_code = -1
        call abort_ice('(dyn_evp_hip_init) ERROR: unsupported boundary type '//trim(bnd), &
@@ -451,6 +454,8 @@ contains
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
          file=__FILE__, line=__LINE__)
+    if (trim(ns_boundary_type) == 'tripoleT') call abort_ice(subname//' ERROR: tripoleT: the loop only '// &
+         '(dyn_evp_hip_run); keep evp()''s own preparation', file=__FILE__, line=__LINE__)
     nall = nx_block*ny_block*max_blocks
     if (.not. geometry_set) then
        ! logical(log_kind) is a 4-byte logical: the C side tests "non-zero"

@@ -39,7 +39,10 @@ enum {
     CICE_EVP_BND_CLOSED = 0,
     CICE_EVP_BND_OPEN = 1,
     CICE_EVP_BND_CYCLIC = 2,
-    CICE_EVP_BND_TRIPOLE = 3 /* u-fold; ns only */
+    CICE_EVP_BND_TRIPOLE = 3, /* u-fold; ns only */
+    CICE_EVP_BND_TRIPOLET = 4 /* T-fold ('tripoleT'); ns only; B-grid subcycle loop on one rank (cice_evp_hip_run / _upload /
+                               * _subcycle / _download): the preparation phase, the stress symmetrisation and the C grid stay
+                               * with the host there */
 };
 
 /* Block decomposition of this process (type(block), ice_blocks.F90:21-41;

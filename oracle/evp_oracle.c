@@ -18,6 +18,7 @@
  * ===================================================================== */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -128,8 +129,41 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
     double *g = (double *)malloc(sizeof(double) * (size_t)NX * NY);
     gather_global(d, a, g);
     const int tripole = (d->ns_type == BND_TRIPOLE);
+    const int tfold = (d->ns_type == BND_TRIPOLET);
     const double isign = (field_type == 1) ? -1.0 : 1.0;
 
+    if (tfold) {
+        /* tripoleT (T-fold; ice_boundary.F90:1563-1622 offsets, :1686-1722 copy-out with the addresses of :8135-8159: local
+         * column i of rows jhi and jhi+1 takes buffer column NX - iGlobal(i) + 1 - ioffset of buffer rows 3 - joffset and
+         * 2 - joffset, where buffer rows 1..3 are the global rows NY-2..NY).  NE-corner fields (offsets 0, 1; no pair
+         * averaging): the top physical row is the image of row NY-1, the ghost row that of row NY-2 --
+         *   a(i, NY) <- isign * a(NX-i+1, NY-1),   a(i, NY+1) <- isign * a(NX-i+1, NY-2)    (ghost columns included).
+         * Only that location is restated (the B-grid loop exchanges nothing else); every other ghost cell as below. */
+        if (field_loc != 1) { fprintf(stderr, "evp_oracle_halo_update: tripoleT restated for NE-corner fields only\n"); abort(); }
+        for (int b = 0; b < d->nblocks; ++b) {
+            double *ab = a + (size_t)b * nx * ny;
+            const int ilo = d->ilo[b], ihi = d->ihi[b], jlo = d->jlo[b], jhi = d->jhi[b];
+            for (int j = jlo - d->nghost; j <= jhi + d->nghost; ++j)
+                for (int i = ilo - d->nghost; i <= ihi + d->nghost; ++i) {
+                    const int interior = (i >= ilo && i <= ihi && j >= jlo && j <= jhi);
+                    int ig = d->iglob0[b] + (i - ilo);
+                    int jg = d->jglob0[b] + (j - jlo);
+                    if (ig < 1 || ig > NX) {
+                        if (d->ew_type != BND_CYCLIC) continue;
+                        ig = (ig < 1) ? ig + NX : ig - NX;
+                    }
+                    if (jg == NY || jg == NY + 1) {
+                        int is = NX - ig + 1;
+                        ab[IX(i, j)] = isign * g[(size_t)(jg == NY ? NY - 2 : NY - 3) * NX + (is - 1)];
+                        continue;
+                    }
+                    if (interior || jg < 1) continue;                    /* closed south */
+                    ab[IX(i, j)] = g[(size_t)(jg - 1) * NX + (ig - 1)];
+                }
+        }
+        free(g);
+        return;
+    }
     if (tripole && field_loc == 3) {
         /* N face: (:1664-1677) */
         double *top = g + (size_t)(NY - 1) * NX;

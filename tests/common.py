@@ -8,7 +8,8 @@ import numpy as np
 import oracle  # oracle/oracle.py  (CPU restatement -- the checker)
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-GOLDEN_CASES = sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("cgrid_"))
+GOLDEN_CASES = sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith(("cgrid_", "tript_")))
+TFOLD_CASES = sorted(p.stem for p in GOLDEN.glob("tript_*.npz"))         # ns_boundary_type = 'tripoleT' (B grid, the loop only)
 CGRID_CASES = sorted(p.stem for p in GOLDEN.glob("cgrid_*.npz"))      # C-grid subcycle
 
 
@@ -113,6 +114,18 @@ class GoldenCase:
                      self.nx_global, self.ny_global, evp.BND[self.ew], evp.BND[self.ns], 0, 1,
                      *[a.ctypes.data_as(evp._i32p) for a in loc], 0, None, None, None, None, None, None)
         return d, loc
+
+
+def tfold_untouched(c: "GoldenCase"):
+    """Cells of a tripoleT fixture that evp()'s ice_HaloUpdate_stress calls after the loop do not rewrite: everything but
+    the top physical row and the ghost row above it (ice_boundary.F90:7700-7790 with the T-fold offsets) -- the stress
+    arrays of whole-evp() fixtures are compared there; the velocities everywhere."""
+    keep = np.ones((c.nblocks, c.ny_block, c.nx_block), dtype=bool)
+    for b in range(c.nblocks):
+        jlo, jhi, jg0 = int(c.blk[b, 2]), int(c.blk[b, 3]), int(c.blk[b, 7])
+        if jg0 + (jhi - jlo) == c.ny_global:
+            keep[b, jhi - 1:, :] = False
+    return keep
 
 
 def assert_bitwise(got: dict, want: dict, what=""):

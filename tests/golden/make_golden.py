@@ -66,6 +66,12 @@ CASES = {
                              dict(grid_kind="tripolefile", icecase="patchy", nsub_list=[1, 120], ncalls=1)),
     "trip_cyc_4x3_caps": (32, 24, 8, 8, "cyclic", "tripole",
                           dict(grid_kind="tripolefile", icecase="caps", nsub_list=[1, 120], ncalls=2)),
+    # tripoleT (T-fold, ice_domain.F90:260): the fold runs through the T-cell centres of the top row; the U points of that
+    # row are images of row NY-1 (ice_boundary.F90:1563-1622: NE-corner offsets (0, 1), no pair averaging)
+    "tript_cyc_2x2_full": (28, 20, 14, 10, "cyclic", "tripoleT",
+                           dict(grid_kind="tripolefile", icecase="full", nsub_list=[1, 2, 120], ncalls=2)),
+    "tript_cyc_1blk_patchy": (24, 18, 24, 18, "cyclic", "tripoleT",
+                              dict(grid_kind="tripolefile", icecase="patchy", nsub_list=[1, 120], ncalls=1)),
 }
 
 
@@ -135,7 +141,7 @@ def make_case(name, spec):
     grid_files = None
     td = tempfile.mkdtemp(prefix="golden_")
     if kw["grid_kind"] != "rect":
-        g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+        g = synth.make_grid(nx, ny, dx0=1.1e5, ns=("tripole" if ns == "tripoleT" else ns))
         run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
         run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
         grid_files = (td + "/grid.bin", td + "/kmt.bin")

@@ -65,7 +65,10 @@ def apply_plan_single_rank(plan, a):
 @pytest.mark.parametrize("ew,ns,bx,by", [("cyclic", "closed", 7, 5), ("closed", "closed", 20, 6),
                                          ("cyclic", "cyclic", 8, 9), ("cyclic", "closed", 20, 18),
                                          ("cyclic", "tripole", 20, 18), ("cyclic", "tripole", 5, 6),
-                                         ("cyclic", "tripole", 7, 18)])
+                                         ("cyclic", "tripole", 7, 18),
+                                         # T-fold: the top physical row is a destination too (image of row NY-1)
+                                         ("cyclic", "tripoleT", 20, 18), ("cyclic", "tripoleT", 5, 6),
+                                         ("cyclic", "tripoleT", 7, 18)])
 def test_halo_plan_matches_oracle_semantics(ew, ns, bx, by):
     dc = decomp.Decomp(20, 18, bx, by, ew, ns, 1)
     d, keep = evp.make_dims(dc, 0)
@@ -276,3 +279,12 @@ def test_tracked_pmc_summary_feeds_the_bench_line():
         assert k[key]["kernel_trace"]["avg_us"] > 0
     for key in ("cgx1", "cgs01"):
         assert k[key]["per_subcycle"]["hbm_bytes"]
+
+
+def test_tripoleT_is_one_rank_only():
+    """The T-fold's images of the top row are interior cells; on several ranks the plan refuses (no exchange may ride
+    in the launch that computes them) instead of racing."""
+    dc = decomp.Decomp(24, 20, 12, 10, "cyclic", "tripoleT", 2, (2, 1))
+    d, keep = evp.make_dims(dc, 0)
+    with pytest.raises(evp.EvpHipError, match="tripoleT"):
+        evp.halo_plan(d)

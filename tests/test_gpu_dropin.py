@@ -135,3 +135,30 @@ def test_reference_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, 
                 checked += 1
     assert np.abs(d["o02n0120_uvelE"]).max() > 1e-3 and checked == 2 * 2 * (len(CGRID_LOOP_FIELDS) + 2 + len(CGRID_DOWNSTREAM))
     assert np.abs(d["o02n0120_divu"]).max() > 0
+
+
+@pytest.mark.parametrize("nx,ny,bx,by,kw", [(72, 40, 36, 20, dict(icecase="full")), (48, 36, 48, 36, dict(icecase="patchy", h_capping=0.5))])
+def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx, by, kw):
+    """ns_boundary_type = 'tripoleT' (T-fold; ice_domain.F90:260), Option B: the reference's unmodified evp() -- its own
+    preparation, its own 12 x ice_HaloUpdate_stress after the loop -- with the HIP core behind dyn_evp1d_run.  The loop's
+    velocity halo follows the T-fold rule (top U row = image of row NY-1).  Every output array of the whole evp(), every
+    cell, against the reference's standard path in the same process."""
+    if not run_ref.have_ref("hip_dropin"):
+        pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns="tripole")
+    run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+    run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
+    d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="tripoleT", variant="hip_dropin", h_ndte=120,
+                                 ncalls=2, nsub_list=[1, 120], hipmode=True, hipbody=False, grid_kind="tripolefile",
+                                 grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
+    checked = 0
+    for icall in (1, 2):
+        for nsub in (1, 120):
+            for f in FIELDS + DOWNSTREAM:
+                hip = d[f"h{icall:02d}n{nsub:04d}_{f}"]
+                ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
+                assert np.array_equal(hip, ref), (
+                    f"tripoleT call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
+                    f"max|d|={np.abs(hip - ref).max():.3e}")
+                checked += 1
+    assert np.abs(d["o02n0120_uvel"]).max() > 1e-3 and checked == 2 * 2 * (len(FIELDS) + len(DOWNSTREAM))

@@ -12,7 +12,7 @@ import pytest
 
 import oracle
 from cice_amd import decomp, evp, synth
-from common import GOLDEN_CASES, GoldenCase, assert_bitwise, max_rel_err
+from common import GOLDEN_CASES, TFOLD_CASES, GoldenCase, assert_bitwise, max_rel_err, tfold_untouched
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +25,7 @@ def hip_from_case(c: GoldenCase, strict: bool):
     prm = evp.make_params(c.scal_dict(), strict=strict)
     core = evp.EvpHip(d, prm, c.d["HTE"], c.d["HTN"], c.d["dxT"], c.d["dyT"], c.d["uarear"], c.d["tarea"],
                       keepalive=keep)
-    if c.ns == "tripole":
+    if c.ns in ("tripole", "tripoleT"):
         # as the Fortran shim does on tripole grids: CICE's own dxhy/dyhx (mirrored ghost row)
         core.set_metrics(dxhy=c.d["dxhy"], dyhx=c.d["dyhx"])
     return core
@@ -52,6 +52,33 @@ def test_golden_strict_bitwise(name):
                 out = core.run(dyn, tm, um, ndte=nsub)
                 out = post_evp(c, out)
                 assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub} (HIP strict)")
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("name", TFOLD_CASES)
+def test_golden_tripoleT_strict_bitwise(name):
+    """ns_boundary_type = 'tripoleT' (T-fold): the B-grid loop through cice_evp_hip_run against the reference's evp() --
+    the velocity halo's T-fold rule (top U row = image of row NY-1, ghost row = image of row NY-2, no pair averaging:
+    ice_boundary.F90:1563-1622, 1686-1722) runs as list copies after every subcycle launch.  Velocities and the loop's
+    diagnostics on every cell; the stresses wherever evp()'s own ice_HaloUpdate_stress calls after the loop (which stay
+    with the host on this boundary type) leave them alone.  The device preparation and symmetrisation refuse loudly."""
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    keep = tfold_untouched(c)
+    try:
+        for icall in range(1, c.ncalls + 1):
+            dyn, tm, um = c.inputs(icall)
+            for nsub in c.nsub_list:
+                out = core.run(dyn, tm, um, ndte=nsub)
+                want = c.expected(icall, nsub)
+                for k in want:
+                    sel = keep if k.startswith("stress") else np.ones_like(keep)
+                    assert np.array_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k} (HIP, tripoleT)"
+        assert core.timings()["tile_variant"] < 1000          # the streaming kernel (the resident ones are not eligible)
+        assert np.abs(want["uvel"]).max() > 1e-3
+        with pytest.raises(evp.EvpHipError, match="tripoleT"):
+            core.stress_halo()
     finally:
         core.finalize()
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import CGRID_CASES, GOLDEN_CASES, GoldenCase, assert_bitwise
+from common import TFOLD_CASES, tfold_untouched, CGRID_CASES, GOLDEN_CASES, GoldenCase, assert_bitwise
 
 
 def test_fixtures_present():
@@ -58,6 +58,26 @@ def test_subcycle_bitwise(name):
             if c.ns == "tripole":   # the fixture is a whole evp() call: + ice_HaloUpdate_stress x12
                 oracle.tripole_stress_sym(dom, out)
             assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub}")
+
+
+@pytest.mark.parametrize("name", TFOLD_CASES)
+def test_subcycle_tripoleT_bitwise(name):
+    """ns_boundary_type = 'tripoleT': the oracle's loop with the T-fold rule of the velocity halo update (the top U row is
+    the image of row NY-1, the ghost row that of row NY-2; no pair averaging) against the reference's evp(): velocities
+    and the loop's diagnostics on every cell, the stresses wherever evp()'s ice_HaloUpdate_stress calls after the loop
+    leave them alone."""
+    c = GoldenCase(name)
+    dom, prm, st = c.oracle_domain(), c.oracle_params(), c.static()
+    keep = tfold_untouched(c)
+    for icall in range(1, c.ncalls + 1):
+        dyn, tm, um = c.inputs(icall)
+        for nsub in c.nsub_list:
+            out = oracle.subcycle(dom, prm, nsub, dyn, st, tm, um)
+            want = c.expected(icall, nsub)
+            for k in want:
+                sel = keep if k.startswith("stress") else np.ones_like(keep)
+                assert np.array_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k}"
+        assert np.abs(want["uvel"]).max() > 1e-3
 
 
 PREP_PRODUCTS = ["aiU", "cdn_ocnU", "uocnU", "vocnU", "waterxU", "wateryU", "forcexU", "forceyU", "umassdti",
