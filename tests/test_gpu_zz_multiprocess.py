@@ -126,7 +126,12 @@ def test_bench_multi_rank_rehearsal():
                                                         (4, "gx3", "2x2", ["--maskhalo", "--case", "caps", "--blocks-per-rank", "2x2"]),
                                                         # tripole grid cut in y: the rank with the fold rows does the
                                                         # fold steps, every rank the five-phase schedule
-                                                        (2, "tx1", "1x2", []), (3, "tx1", "1x3", ["--blocks-per-rank", "2x1"])])
+                                                        (2, "tx1", "1x2", []), (3, "tx1", "1x3", ["--blocks-per-rank", "2x1"]),
+                                                        # the preparation phase on the device on every rank (T-grid halos and
+                                                        # the E / N velocity averages across ranks), then the loop
+                                                        (2, "gx3", "2x1", ["--prep", "--case", "caps"]),
+                                                        (4, "gx1", "2x2", ["--prep", "--blocks-per-rank", "2x1"]),
+                                                        (2, "tx1", "1x2", ["--prep"])])
 def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
     """The C-grid subcycle split over `world` ranks (processes sharing this box's GPU): ghost cells that mirror
     cells of other ranks are filled through the mailbox transport after every producing launch -- five exchange
