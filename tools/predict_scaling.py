@@ -95,7 +95,12 @@ def main():
                         out.append(dict(workload=wl, n=N, layout=f"{px}x{py}", piece=f"{nx}x{ny}", transport=tname, error=str(e)[:200]))
                         print("RESULT", out[-1], flush=True)
                         continue
-                    rec = dict(workload=wl, n=N, layout=f"{px}x{py}", piece=f"{nx}x{ny}", transport=tname if N > 1 else "none",
+                    label = tname if N > 1 else "none"
+                    if N > 1 and core_info.get("last_call") and tname != "march+rccl":
+                        # pieces beyond the chip run the two-subcycle kernel by default; the one-GPU self-exchange hook of the
+                        # one-subcycle kernels does not reach it: this row is the piece's compute time without any exchange
+                        label = "march, no exchange (compute only)"
+                    rec = dict(workload=wl, n=N, layout=f"{px}x{py}", piece=f"{nx}x{ny}", transport=label,
                                us_per_subcycle=us, tile_variant=tt["tile_variant"], halo_transport=tt["halo_transport"],
                                launches_per_subcycle=tt["launches_per_subcycle"], halo_cells=tt["halo_send_cells"], march=core_info.get("last_call"),
                                predicted_cell_updates_per_s=NX * NY / (us * 1e-6))
