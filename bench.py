@@ -93,6 +93,28 @@ def load_golden():
         return {}
 
 
+# What this chip sustains in fp64 wave64 instructions per SIMD with every SIMD busy (tools/fp64_rate_probe.hip; the clock
+# drops to ~2.0 GHz under an all-fp64 load): ns per v_mul_f64 / v_add_f64 at 1, 2, 4 waves per SIMD; v_rcp_f64 / v_sqrt_f64
+FP64_NS_PER_INST = {1: 2.40, 2: 2.15, 4: 2.00}
+FP64_NS_QUARTER_RATE = 6.9
+QUARTER_RATE_PER_CELL_SUBCYCLE = 11          # 6 IEEE divisions (one v_rcp_f64 each) + 5 square roots
+
+
+def measured_issue(e, t_kernel, sub_per_launch, active_cells):
+    """The resident kernel against the fp64 instruction throughput the chip really sustains (two ice-holding waves per SIMD)."""
+    if not e or "SQ_INSTS_VALU" not in e.get("counters", {}):
+        return None
+    insts = e["counters"]["SQ_INSTS_VALU"]["avg_per_launch"]
+    quarter = QUARTER_RATE_PER_CELL_SUBCYCLE * active_cells / 64.0 * sub_per_launch
+    t_floor = (insts * FP64_NS_PER_INST[2] + quarter * (FP64_NS_QUARTER_RATE - FP64_NS_PER_INST[2])) * 1e-9 / N_SIMD
+    return {"valu_wave_instructions_per_launch": insts, "ns_per_wave_instruction_per_simd": FP64_NS_PER_INST,
+            "ns_per_quarter_rate_instruction": FP64_NS_QUARTER_RATE, "floor_us_per_launch": 1e6 * t_floor,
+            "frac_of_measured_rate": t_floor / t_kernel, "source": "profiles/r03_fp64_rate_probe.txt (tools/fp64_rate_probe.hip)",
+            "note": "the kernel's VALU instruction count (PMC) priced at what one SIMD issues per ns with two waves on it, every SIMD "
+                    "of the chip busy -- 4 cycles per fp64 instruction at the ~2.0 GHz the chip holds under that load, not at 2.4 GHz; "
+                    "`frac` above stays on the nominal clock"}
+
+
 def load_pmc():
     """The newest tracked PMC summary (tools/profile_gpu.sh + tools/pmc_summary.py on this command)."""
     files = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))
@@ -704,6 +726,7 @@ def main():
                                                "field once per subcycle would have to move; this kernel keeps the stresses and the "
                                                "per-call operands in registers/LDS for all subcycles of a launch and moves `traffic` "
                                                "bytes instead, so the figure may exceed the HBM peak -- HBM does not bound it"},
+                    "measured_fp64_issue_rate": measured_issue(e, t_kernel, sub_per_launch, my_active),
                     "note": "frac = VALU-busy SIMD-cycles per launch (SQ_ACTIVE_INST_VALU x 4 from the committed PMC pass of "
                             "this command, pmc_source) / live kernel time (HIP events on the kernel's stream over the timed "
                             "region) / (1024 SIMDs x 2.4 GHz): the share of the chip's fp64 issue slots the launch used"}
