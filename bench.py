@@ -382,6 +382,26 @@ def main():
                 # HIP events on the library's stream around the timed region (rank 0's share)
                 tm_ev = core.timings()
                 kt = core.time_kernels(200)
+                # N > 1: every rank's view of the timed region, so that a first run on real xGMI can be read -- its own wall
+                # time, the time its stream spent between the marks, its kernel alone (no exchange: HIP events around
+                # repeated launches on scratch state), which kernel / transport it ended up with, what it sends per exchange
+                per_rank = None
+                if world > 1:
+                    mi = core.march_info()
+                    mine = dict(rank=rank, wall_ms=1e3 * (t1 - t0), stream_ms=float(tm_ev["marks_ms"]),
+                                us_per_subcycle_stream=1e3 * float(tm_ev["marks_ms"]) / (steps * ndte),
+                                kernel_alone_us_per_launch=1e3 * float(kt["stencil_ms"]), halo_kernel_us=1e3 * float(kt["halo_ms"]),
+                                back_to_back_us=1e3 * float(kt["stencil_period_ms"]),
+                                tile_variant=int(tm_ev["tile_variant"]), halo_transport=tm_ev["halo_transport"],
+                                launches_per_subcycle=float(tm_ev["launches_per_subcycle"]),
+                                halo_send_cells=int(tm_ev["halo_send_cells"]), halo_recv_cells=int(tm_ev["halo_recv_cells"]),
+                                resident_fallbacks=int(tm_ev["resident_fallbacks"]),
+                                two_subcycle_kernel=dict(ran=bool(mi["last_call"]), passes=mi["passes"], declined=mi["declined"],
+                                                         strips=mi["strips"], segments=mi["segments"], rows_per_segment=mi["seglen"]),
+                                probes_us=dict(streaming=1e3 * float(tm_ev["stream_probe_ms"]), resident=1e3 * float(tm_ev["resident_probe_ms"])),
+                                local_cells=int(sum(b.gnx * b.gny for b in dc.local_blocks(rank))))
+                    per_rank = [None] * world
+                    dist.all_gather_object(per_rank, mine)
                 # ---- what was timed, checked: continue (untimed) to the next checkpoint, hash the state ----
                 total = warmup + steps
                 key = golden_key(workload, case, ndte, ns)
@@ -413,7 +433,7 @@ def main():
                                        "bit to the reference)")
             finally:
                 core.finalize()
-            return dict(nx=nx, ny=ny, ndte=ndte, dc=dc, tm=tm, n_active=n_active, dt=dt, tm_ev=tm_ev, kt=kt,
+            return dict(nx=nx, ny=ny, ndte=ndte, dc=dc, tm=tm, n_active=n_active, dt=dt, tm_ev=tm_ev, kt=kt, per_rank=per_rank,
                         steps=steps, warmup=warmup, ver=ver, fallbacks=fallbacks,
                         finite=bool(np.isfinite(out["uvel"]).all() and np.isfinite(out["stressp_1"]).all()),
                         umax=float(np.abs(out["uvel"]).max()))
@@ -767,7 +787,7 @@ def main():
                        "launches_per_subcycle": tm_ev["launches_per_subcycle"],
                        "halo_transport": tm_ev["halo_transport"],
                        "autotune_probe_us": {"streaming": 1e3 * tm_ev["stream_probe_ms"], "resident": 1e3 * tm_ev["resident_probe_ms"]},
-                       "resident_fallbacks": M["fallbacks"], "attempts": M.get("attempts"),
+                       "resident_fallbacks": M["fallbacks"], "attempts": M.get("attempts"), "per_rank": M.get("per_rank"),
                        "finite": M["finite"], "max_abs_u": M["umax"]},
             "verification": M["ver"],
             "roofline": roof,

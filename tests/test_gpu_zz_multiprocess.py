@@ -115,6 +115,10 @@ def test_bench_multi_rank_rehearsal():
     assert d["config"]["halo_transport"] == "mailbox" and d["config"]["finite"]
     assert d["config"]["tile_variant"] >= 2000         # the resident kernel with remote neighbours
     assert d["cpu_baseline"] is None and "roofline" in d
+    # every rank's own view of the timed region (what a first run on real xGMI is read with)
+    pr = d["config"]["per_rank"]
+    assert [q["rank"] for q in pr] == [0, 1] and all(q["halo_transport"] == "mailbox" and q["halo_send_cells"] > 0 for q in pr)
+    assert all(q["stream_ms"] > 0 and q["wall_ms"] >= 0.5 * q["stream_ms"] and q["local_cells"] > 0 for q in pr)
 
 
 @pytest.mark.parametrize("world,workload,shape,extra", [(2, "gx3", "", []), (4, "gx3", "2x2", ["--blocks-per-rank", "2x2", "--timing"]),
