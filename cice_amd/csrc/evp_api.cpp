@@ -105,8 +105,20 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         S.plan.local_dst = kd; S.plan.local_src = ks; S.plan.local_sign = kg;
         S.plan.peers.push_back(self);
     }
-    // the global block table is only needed while planning
-    S.d.gi0 = S.d.gj0 = S.d.gnx = S.d.gny = S.d.gowner = S.d.glocal = nullptr;
+    // the global block table is needed again by plans built later (the two-subcycle path decides at the first
+    // cice_evp_hip_subcycle): keep a copy -- the caller's arrays need not outlive this call
+    {
+        const int32_t *src[6] = {dims->gi0, dims->gj0, dims->gnx, dims->gny, dims->gowner, dims->glocal};
+        const bool have = dims->nblocks_tot > 0 && src[0] && src[1] && src[2] && src[3] && src[4] && src[5];
+        for (int k = 0; k < 6; ++k) {
+            S.gtab[k].clear();
+            if (have) S.gtab[k].assign(src[k], src[k] + dims->nblocks_tot);
+        }
+        S.d.gi0 = have ? S.gtab[0].data() : nullptr; S.d.gj0 = have ? S.gtab[1].data() : nullptr;
+        S.d.gnx = have ? S.gtab[2].data() : nullptr; S.d.gny = have ? S.gtab[3].data() : nullptr;
+        S.d.gowner = have ? S.gtab[4].data() : nullptr; S.d.glocal = have ? S.gtab[5].data() : nullptr;
+        if (!have) S.d.nblocks_tot = 0;
+    }
 
     int ndev = 0;
     HIPC(hipGetDeviceCount(&ndev));

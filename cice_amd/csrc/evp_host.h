@@ -70,6 +70,7 @@ struct State {
     cice_evp_hip_dims d{};
     cice_evp_hip_params prm{};
     std::vector<int32_t> ilo, ihi, jlo, jhi, iglob0, jglob0;
+    std::vector<int32_t> gtab[6];   // the global block table (gi0 gj0 gnx gny gowner glocal): plans built after init need it
     int device = 0;
     size_t plane = 0, n = 0;     // nx*ny, nx*ny*nblocks
     int max_ni = 0, max_nj = 0;

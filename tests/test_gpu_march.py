@@ -248,3 +248,41 @@ def test_s01_full_size_march_vs_oracle_bitwise():
         core.finalize()
     assert np.abs(want["uvel"]).max() > 1e-3
     assert_bitwise(got, want, "3600x2400 march vs oracle, 13 subcycles")
+
+
+def test_march_plan_is_built_for_a_rank_of_several(tmp_path):
+    """The two-subcycle path decides at the first cice_evp_hip_subcycle, long after cice_evp_hip_init has returned: the
+    global block table handed to init must still be there then (it was dropped once: every multi-rank domain silently got
+    the one-subcycle kernels).  One process plays rank 0 of a 2 x 1 split without a communicator: the plan must get as far
+    as asking for one -- RCCL refuses two ranks on one device, so the exchange itself is exercised with the rank itself
+    (test_march_ring_exchanged_over_rccl_with_the_rank_itself) and on the CPU (tests/test_multirank_cpu.py)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path[:0] = ["%s", "%s/tests", "%s/oracle"]
+import numpy as np
+from cice_amd import decomp, evp, synth
+nx, ny = 240, 120
+g = synth.derive_geometry(synth.make_grid(nx, ny, 2.8e4, ns="closed"))
+st = synth.make_state(g, case="full", seed=3, warm=True)
+dc = decomp.per_rank_blocks(nx, ny, 2, "cyclic", "closed", proc_shape=(2, 1))
+geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k != "uarear" else 0.0)) for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+d, keep = evp.make_dims(dc, 0)
+core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(120), strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                  geo["uarear"], geo["tarea"], keepalive=keep)
+del keep, d                      # the caller's table is gone, as CICE's temporaries are after dyn_evp_hip_init
+import gc; gc.collect()
+try:
+    core.upload(fields, dc.scatter(st["iceTmask"], 0, fill=0), dc.scatter(st["iceUmask"], 0, fill=0))
+    core.subcycle(2)
+    core.sync()
+except evp.EvpHipError as e:
+    print("EXPECTED_ERROR", str(e)[:200])
+''' % ((str(__import__("pathlib").Path(__file__).resolve().parents[1]),) * 3)
+    import os
+    env = dict(os.environ, CICE_EVP_HIP_MARCH="1", CICE_EVP_HIP_RESIDENT="0", CICE_EVP_HIP_VERBOSE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert "global block table required" not in r.stderr, r.stderr[-1500:]
+    assert "no RCCL communicator" in r.stderr, (r.stdout[-800:], r.stderr[-1500:])
