@@ -112,6 +112,13 @@ struct State {
     // remote halo
     ncclComm_t comm = nullptr;
     bool have_comm = false;
+    // test hook (cice_evp_hip_set_test_transport): the two-subcycle path's exchanges and agreements through host
+    // buffers and caller-supplied callbacks instead of RCCL, so that its several-rank form can run as processes sharing
+    // ONE GPU (RCCL refuses two ranks per device)
+    cice_evp_hip_test_xchg_fn test_xchg = nullptr;
+    cice_evp_hip_test_reduce_fn test_reduce = nullptr;
+    void *test_user = nullptr;
+    std::vector<double> test_send, test_recv;
     int32_t *h_seam_a = nullptr, *h_seam_b = nullptr, *h_seam_pole = nullptr, *h_late_dst = nullptr,
             *h_late_src = nullptr;
     int8_t *h_late_sign = nullptr;

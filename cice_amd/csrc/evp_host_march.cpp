@@ -74,7 +74,7 @@ static bool march_geometry(std::string &why)
     const int ext = env("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env("CICE_EVP_HIP_MARCH_EXT")) & ~1) : 4;
     if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
     M.exch_every = ext / 2 + 1;
-    if (!PL.peers.empty() && !S.have_comm) { why = "cells of other ranks needed but no RCCL communicator (cice_evp_hip_comm_init)"; return false; }
+    if (!PL.peers.empty() && !S.have_comm && !S.test_xchg) { why = "cells of other ranks needed but no RCCL communicator (cice_evp_hip_comm_init)"; return false; }
     if (!(S.flags & EVP_F_METRICS) || (S.flags & EVP_F_DXHY_ARRAY)) { why = "metric terms come from arrays"; return false; }
     if (d.nblocks < 1) { why = "no blocks"; return false; }
     // blocks must tile [gx0, gx0+nxr) x [gy0, gy0+nyr) with full blocks of bsx x bsy (the last column / row may be smaller)
@@ -194,10 +194,36 @@ static int march_alloc()
 // The two-cell ring of one strip-major buffer (all nf fields of every halo cell) from the ranks that own the cells:
 // pack -> ncclGroupStart{ncclSend, ncclRecv per neighbour}ncclGroupEnd -> unpack (incl. the duplicates), on the
 // library's stream.  Once per PASS of two subcycles for the state, once per call for the constants and the mask.
+// (test hook) the same exchange through host buffers and the caller's callback
+static int hook_exchange(int nf)
+{
+    std::vector<int32_t> ranks;
+    std::vector<int64_t> ns, nr;
+    for (const MarchPeer &p : PL.peers) {
+        ranks.push_back(p.rank);
+        ns.push_back((int64_t)p.send_pos.size() * nf);
+        nr.push_back((int64_t)p.recv_pos1.size() * nf);
+    }
+    S.test_send.resize((size_t)PL.n_send * nf + 1);
+    S.test_recv.resize((size_t)PL.n_recv * nf + 1);
+    HIPC(hipMemcpyAsync(S.test_send.data(), B.sendbuf, (size_t)PL.n_send * nf * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    if (S.test_xchg(S.test_user, (int32_t)ranks.size(), ranks.data(), ns.data(), nr.data(), S.test_send.data(), S.test_recv.data()))
+        return fail(-2, "test transport: the exchange callback failed");
+    HIPC(hipMemcpyAsync(B.recvbuf, S.test_recv.data(), (size_t)PL.n_recv * nf * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
 static int march_exchange(double *buf, double *buf2, int nf)
 {
     if (PL.peers.empty()) return 0;
     evp_launch_march_pack(buf, nf, B.send_pos, PL.n_send, B.sendbuf, S.stream);
+    if (S.test_xchg) {
+        if (int rc = hook_exchange(nf)) return rc;
+        evp_launch_march_unpack(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.recvbuf, S.stream);
+        return 0;
+    }
     size_t so = 0, ro = 0;
     NCCLC(ncclGroupStart());
     for (const MarchPeer &p : PL.peers) {
@@ -215,6 +241,11 @@ static int march_exchange_mask()
 {
     if (PL.peers.empty()) return 0;
     evp_launch_march_pack_mask(B.mask, B.send_midx, PL.n_send, B.sendbuf, S.stream);
+    if (S.test_xchg) {
+        if (int rc = hook_exchange(1)) return rc;
+        evp_launch_march_unpack_mask(B.mask, B.recv_midx, PL.n_recv, B.recvbuf, S.stream);
+        return 0;
+    }
     size_t so = 0, ro = 0;
     NCCLC(ncclGroupStart());
     for (const MarchPeer &p : PL.peers) {
@@ -231,6 +262,12 @@ static int march_exchange_mask()
 // max over ranks of a device counter (the ranks must take the same path)
 static int agree_max(unsigned &v)
 {
+    if (S.test_reduce && !PL.peers.empty() && S.d.nranks > 1) {
+        HIPC(hipMemcpyAsync(&v, B.bad, sizeof v, hipMemcpyDeviceToHost, S.stream));
+        HIPC(hipStreamSynchronize(S.stream));
+        if (S.test_reduce(S.test_user, 1, &v)) return fail(-2, "test transport: the reduce callback failed");
+        return 0;
+    }
     if (!PL.peers.empty() && S.d.nranks > 1) NCCLC(ncclAllReduce(B.bad, B.bad, 1, ncclUint32, ncclMax, S.comm, S.stream));
     HIPC(hipMemcpyAsync(&v, B.bad, sizeof v, hipMemcpyDeviceToHost, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
@@ -278,7 +315,11 @@ bool march_wanted()
     if (want == 0) return false;
     std::string why;
     bool ok = march_geometry(why);
-    if (S.d.nranks > 1 && S.have_comm) {
+    if (S.d.nranks > 1 && S.test_reduce) {
+        int32_t h = ok ? 1 : 0;
+        if (S.test_reduce(S.test_user, 0, &h)) return false;
+        if (ok && !h) { ok = false; why = "another rank cannot use it"; }
+    } else if (S.d.nranks > 1 && S.have_comm) {
         // the choice must be the same on every rank (what decides it is partly local: e.g. whether the metric terms can be
         // recomputed from the edge lengths is verified on each rank's own cells)
         int *dflag = nullptr;
@@ -422,6 +463,14 @@ int march_run(int ndte)
 }
 
 }  // namespace evp_host
+
+extern "C" int cice_evp_hip_set_test_transport(cice_evp_hip_test_xchg_fn xchg, cice_evp_hip_test_reduce_fn reduce, void *user)
+{
+    using namespace evp_host;
+    if ((xchg == nullptr) != (reduce == nullptr)) return fail(-1, "test transport: give both callbacks or none");
+    S.test_xchg = xchg; S.test_reduce = reduce; S.test_user = user;
+    return 0;
+}
 
 // Host-only: the plan of dims->rank without touching a device (CPU tests).
 extern "C" int cice_evp_hip_march_plan(const cice_evp_hip_dims *dims, int32_t own_max, int32_t wrap_inside, int32_t ext, int32_t *geo14,

@@ -41,7 +41,7 @@ EXPORTS = [
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_cgrid_set_prep_geometry", "cice_evp_hip_cgrid_prep", "cice_evp_hip_cgrid_seabed_lkd", "cice_evp_hip_cgrid_seabed_prob",
-    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb",
+    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_set_test_transport",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
@@ -437,6 +437,41 @@ class EvpHip:
                     tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
                     halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10], resident_fallbacks=int(t[11]),
                     halo_send_cells=int(t[12]), halo_recv_cells=int(t[13]))
+
+    def set_test_transport(self, xchg, reduce):
+        """Test hook (see the header): xchg(peer_ranks, send_counts, recv_counts, send ndarray, recv ndarray) and
+        reduce(op, value) -> value, called on the host by the two-subcycle path instead of RCCL."""
+        XF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                         C.POINTER(C.c_double), C.POINTER(C.c_double))
+        RF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
+
+        def x_c(user, npeers, pr, sc, rc, send, recv):
+            try:
+                ranks = [pr[q] for q in range(npeers)]
+                ns = [sc[q] for q in range(npeers)]
+                nr = [rc[q] for q in range(npeers)]
+                sa = np.ctypeslib.as_array(send, shape=(max(sum(ns), 1),))
+                ra = np.ctypeslib.as_array(recv, shape=(max(sum(nr), 1),))
+                xchg(ranks, ns, nr, sa, ra)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("test transport xchg failed:", e, flush=True)
+                return 1
+
+        def r_c(user, op, ptr):
+            try:
+                if op == 0:
+                    v = C.cast(ptr, C.POINTER(C.c_int32))
+                else:
+                    v = C.cast(ptr, C.POINTER(C.c_uint32))
+                v[0] = int(reduce(int(op), int(v[0])))
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("test transport reduce failed:", e, flush=True)
+                return 1
+
+        self._test_cb = (XF(x_c), RF(r_c))
+        _check(self.lib, self.lib.cice_evp_hip_set_test_transport(self._test_cb[0], self._test_cb[1], None), "(set_test_transport)")
 
     def march_info(self) -> dict:
         """The two-subcycles-per-pass path (evp_march.hip): did it run, how is the domain cut."""

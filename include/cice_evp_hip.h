@@ -356,6 +356,15 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
  * values were not images of one global state), [3] strips, [4] segments, [5] rows per segment, [6] 1 = the last
  * cice_evp_hip_subcycle ran through it.  CICE_EVP_HIP_MARCH=0/1 forces it off / on (default: from 450k cells per rank).   */
 int cice_evp_hip_march_info(int32_t *out, int32_t n);
+/* Test hook: route the exchanges and the rank agreements of the two-subcycle path through HOST buffers and the caller's
+ * callbacks instead of RCCL (which refuses two ranks on one device), so that its several-rank form can be run as
+ * processes sharing one GPU (tools/mailbox_2proc.py --march: torch.distributed gloo underneath).  xchg: per peer q
+ * (ascending rank) send_count[q] doubles starting at send + sum of the counts before, likewise recv; returns 0.  reduce:
+ * op 0 = min of one int32, 1 = max of one uint32, in place.  NULL callbacks switch the hook off.  Not for production.  */
+typedef int (*cice_evp_hip_test_xchg_fn)(void *user, int32_t npeers, const int32_t *peer_rank, const int64_t *send_count,
+                                         const int64_t *recv_count, const double *send, double *recv);
+typedef int (*cice_evp_hip_test_reduce_fn)(void *user, int32_t op, void *value);
+int cice_evp_hip_set_test_transport(cice_evp_hip_test_xchg_fn xchg, cice_evp_hip_test_reduce_fn reduce, void *user);
 /* Host-only (CPU tests): geometry and exchange lists of the two-subcycle path for dims->rank.  Every rank's sub-domain
  * must be one rectangle; the rank HOLDS its own cells plus `ext` (even) more on every side that has a neighbour, in strips
  * of `own` <= own_max columns (position of a cell = (storage row * nstrips + strip) * 64 + lane), and after one exchange

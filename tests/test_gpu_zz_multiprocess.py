@@ -161,3 +161,32 @@ def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
             pass
         cmd[cmd.index("--master-port") + 1] = str(_free_port())
     assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("world,workload,shape,extra,ext", [(2, "gx1", "2x1", [], "4"), (2, "gx1", "1x2", ["--timing"], "2"),
+                                                            (4, "gx1", "2x2", ["--blocks-per-rank", "2x1"], "4"),
+                                                            (4, "gx1", "4x1", [], "0")])
+def test_two_subcycle_kernel_across_processes_on_one_gpu(world, workload, shape, extra, ext):
+    """The two-subcycles-per-pass path in its several-rank form, as `world` processes sharing this box's GPU: every rank
+    plans from the global block table (rectangles of all ranks, ring lists in one canonical order), holds its piece plus a
+    redundant rim, exchanges the ring every (ext/2 + 1)-th pass and agrees with the others on path and verdicts.  The
+    exchanges and agreements go through the library's test transport (host buffers + torch.distributed gloo: RCCL refuses
+    two ranks per device) -- plan, pack / unpack, schedule and kernels are the product's.  Every rank's velocities,
+    stresses and diagnostics, ghost cells of the velocities included, equal the single-rank run bit for bit; --timing
+    adds back-to-back calls and an odd subcycle count (one subcycle of the one-subcycle kernel with the mailbox halo)."""
+    import subprocess
+    import sys as _sys
+    root = Path(__file__).resolve().parents[1]
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(root / "tools" / "mailbox_2proc.py"), "--march", "--workload", workload, "--ndte", "24", "--shape", shape] + extra
+    env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000", CICE_EVP_HIP_MARCH="1", CICE_EVP_HIP_RESIDENT="0",
+               CICE_EVP_HIP_MARCH_SEG="24", CICE_EVP_HIP_MARCH_EXT=ext)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    if not (r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout):
+        try:
+            (root / "gpurun_out").mkdir(exist_ok=True)
+            (root / "gpurun_out" / f"march_mp_fail_{world}_{shape}.log").write_text(r.stdout + "\n---\n" + r.stderr)
+        except OSError:
+            pass
+    assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2500:], r.stderr[-3000:])

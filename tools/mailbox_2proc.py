@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--maskhalo", action="store_true",
                     help="with --cgrid: hand the loop the masked halo evp() builds when maskhalo_dyn (five-point dilation of "
                          "iceTmask, ice_dyn_evp.F90:739-770); ghost cells outside the mask stay stale, everything else must not change")
+    ap.add_argument("--march", action="store_true",
+                    help="force the two-subcycles-per-pass kernel on every rank; its ring exchanges and rank agreements go "
+                         "through the library's test transport (host buffers + gloo here: RCCL refuses two ranks per device)")
     ap.add_argument("--case", default="full")
     ap.add_argument("--cgrid", action="store_true",
                     help="the C-grid subcycle (cice_evp_hip_cgrid_*): ghost cells other ranks own filled through the "
@@ -187,6 +190,37 @@ def main():
                 blobs = [None] * world
                 dist.all_gather_object(blobs, core.halo_export())
                 core.halo_import(blobs)
+            if exchange and a.march:
+                def xchg(ranks, ns, nr, send, recv):
+                    ops, so, ro = [], 0, 0
+                    keepalive = []
+                    for q, n_s, n_r in zip(ranks, ns, nr):
+                        if q == rank:                       # (self-exchange across a seam this rank spans)
+                            recv[ro:ro + n_r] = send[so:so + n_s]
+                        else:
+                            if n_s:
+                                ts = torch.from_numpy(np.ascontiguousarray(send[so:so + n_s]))
+                                keepalive.append(ts)
+                                ops.append(dist.P2POp(dist.isend, ts, q))
+                            if n_r:
+                                tr = torch.empty(n_r, dtype=torch.float64)
+                                keepalive.append((tr, ro, n_r))
+                                ops.append(dist.P2POp(dist.irecv, tr, q))
+                        so += n_s
+                        ro += n_r
+                    if ops:
+                        for w in dist.batch_isend_irecv(ops):
+                            w.wait()
+                    for item in keepalive:
+                        if isinstance(item, tuple):
+                            tr, o, n = item
+                            recv[o:o + n] = tr.numpy()
+
+                def reduce(op, v):
+                    tt = torch.tensor([v], dtype=torch.int64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MIN if op == 0 else dist.ReduceOp.MAX)
+                    return int(tt.item())
+                core.set_test_transport(xchg, reduce)
             if a.prep:
                 sc = lambda x, fill=0.0: dc.scatter(np.ascontiguousarray(x), r, fill=fill)
                 static = {k: sc(v, (1.0 if k in ("tarea", "uarea") else 0)) for k, v in pr["static"].items()}
@@ -217,6 +251,7 @@ def main():
                 core.subcycle(120)
             out = core.download()
             out.update(extra)
+            out["_march"] = core.march_info()
             return out, core.timings(), t
         finally:
             core.finalize()
@@ -237,6 +272,10 @@ def main():
     got, tim, t_us = run(dcN, rank, True)
     assert tim["halo_transport"] == "mailbox", tim
     bad = []
+    if a.march:
+        mi = got["_march"]
+        if not (mi["mode"] == 1 and mi["last_call"] and mi["declined"] == 0 and mi["passes"] > 0):
+            bad.append(("two-subcycle kernel did not run", mi))
     for k in ("uvel", "vvel", "stressp_1", "stressm_3", "stress12_4", "strintxU", "taubyU",
               "forcexU", "umassdti", "uvel_init", "aiU", "iceTmask"):
         if k not in got:
