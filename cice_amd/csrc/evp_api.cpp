@@ -360,10 +360,15 @@ int cice_evp_hip_stress_halo(void)
     if (S.plan.tfold)
         return fail(-9, "tripoleT: the stress symmetrisation stays with the host (evp() applies it to its own arrays, "
                         "ice_dyn_evp.F90:1321-1389)");
-    if (S.plan.stress_remote)
-        return fail(-9, "tripole: on this rank layout the stress symmetrisation needs top-row cells of other ranks; it stays "
-                        "with the host (evp() applies it to its own arrays, ice_dyn_evp.F90:1321-1389)");
     evp_launch_halo_stress(S.sig[S.cur], S.h_stress_dst, S.h_stress_src, S.n_stress, S.stream);
+    // partners on other ranks (fold row split in x): a1's ghost row <- a2's top row through the exchange of a shifted copy
+    // (halo_plan.h); collective -- a rank without destinations of its own still serves its top row.  Scalars: factor -1.
+    if (S.plan.fold_split)
+        for (int fam = 0; fam < 12; fam += 4)
+            for (int q = fam; q < fam + 2; ++q) {
+                double *a1 = S.sig[S.cur][q], *a2 = S.sig[S.cur][q ^ 2];
+                if (int rc = fold_remote_pair(a2, a1, a1, a2, 1, -1.0, -1.0)) return rc;
+            }
     HIPC(hipGetLastError());
     return 0;
 }
@@ -792,6 +797,21 @@ int cice_evp_hip_center_plan(int32_t *count, int32_t *dst, int32_t *src, int32_t
         if (vsign) vsign[k] = P.center_vsign[k];
     }
     return P.center_remote ? 1 : 0;
+}
+
+// Lists of the shifted-copy exchange (halo_plan.h): which 0 = this rank's cells of row NY-1 where the copy is built,
+// 1 = centre-field ghost cells filled from it, 2 = ghost-row cells of the stress symmetrisation filled from it; 3 / 4 =
+// east-west ghost cells of row NY and the staging slots that hold their values after a plain exchange.
+// Returns 1 when the blocks holding row NY have more than one owner (the exchanges are collective then), else 0.
+int cice_evp_hip_fold_split_plan(int32_t which, int32_t *count, int32_t *cells)
+{
+    const HaloPlan &P = S.plan;
+    const std::vector<int32_t> &v = which == 0 ? P.fold_shift_cells : (which == 1 ? P.center_foldr_dst :
+                                    (which == 2 ? P.stress_foldr_dst : (which == 3 ? P.center_seam_dst : P.center_seam_slot)));
+    if (count) *count = (int32_t)v.size();
+    if (cells)
+        for (size_t k = 0; k < v.size(); ++k) cells[k] = v[k];
+    return P.fold_split ? 1 : 0;
 }
 
 int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src)

@@ -241,6 +241,9 @@ void evp_launch_words_to_bytes(const int32_t *w, uint8_t *b, size_t n, hipStream
 void evp_launch_seabed_prob(const EvpPrep &P, int nblocks, const double *hwater, const double *aicen, const double *vicen,
                             int ncat, double alphab, double rhoi, double rhow, double gravit, double pi, double puny,
                             double *Tbt, double *TbU, unsigned *flagword, hipStream_t st);
+void evp_launch_fold_shift2(const double *a, const double *b, double *a2, double *b2, const int *cells, int n, int nx, hipStream_t st);
+void evp_launch_fold_extract2(double *a, double *b, const double *a2, const double *b2, const int *dst, int n, double fa, double fb,
+                              hipStream_t st);
 void evp_launch_seabed_prob_t(const EvpPrep &P, int nblocks, const double *hwater, const double *aicen, const double *vicen,
                               int ncat, double alphab, double rhoi, double rhow, double gravit, double pi, double puny,
                               double *Tbt, hipStream_t st);

@@ -130,6 +130,13 @@ struct State {
     int32_t *h_stress_dst = nullptr, *h_stress_src = nullptr;
     int n_stress = 0;
     // preparation phase on the device (evp_prep.hip)
+    struct FoldX {                 // device side of HaloPlan::center_foldr_dst / stress_foldr_dst / fold_shift_cells
+        bool ready = false;
+        int32_t *cells = nullptr, *dst[2] = {nullptr, nullptr}, *seam_dst = nullptr, *seam_slot = nullptr;
+        int8_t *seam_one = nullptr;
+        int n_cells = 0, n_dst[2] = {0, 0}, n_seam = 0;
+        double *scr[2] = {nullptr, nullptr};
+    } foldx;
     struct Prep {
         bool geo = false;
         uint8_t *tmask = nullptr, *umask = nullptr, *umask_old = nullptr, *tmphm = nullptr;
@@ -283,7 +290,14 @@ void fill_args(EvpArgs &A, int cur, int last);
 int cap_mode();
 // evp_host_loop.cpp
 void fill_direct(EvpDirect &D);
-int halo_remote_pair(double *a, double *bb, bool masked = false);
+int halo_remote_pair(double *a, double *bb, bool masked = false, bool has_tail = false);
+// centre-kind fields across a tripole fold whose row is split over ranks (halo_plan.h): dstA[d] <- fa * (the exchange of the
+// shifted copy of srcA)[d] for d in the list, likewise B.  kind 0: the centre-field ghost cells of the preparation phase,
+// 1: the ghost row of the stress symmetrisation
+int fold_remote_pair(const double *srcA, const double *srcB, double *dstA, double *dstB, int kind, double fa, double fb);
+// after a plain exchange of two centre-kind arrays (with staging tail): their east-west ghost cells of row NY <- the raw
+// values the exchange left in the staging slots
+int fold_seam_ghosts(double *a, double *b);
 void fill_direct(EvpDirect &D, bool masked);
 int halo_uv(int b, bool masked = false);
 bool use_overlap();

@@ -95,6 +95,16 @@ void free_all()
     S.ev0 = S.ev1 = S.ev2 = S.ev3 = nullptr;
     if (S.have_comm) (void)ncclCommDestroy(S.comm);
     S.have_comm = false;
+    {
+        State::FoldX &F = S.foldx;
+        if (F.cells) (void)hipFree(F.cells);
+        if (F.seam_dst) (void)hipFree(F.seam_dst);
+        if (F.seam_slot) (void)hipFree(F.seam_slot);
+        if (F.seam_one) (void)hipFree(F.seam_one);
+        for (auto &p : F.dst) if (p) (void)hipFree(p);
+        for (auto &p : F.scr) if (p) (void)hipFree(p);
+        F = State::FoldX();
+    }
     for (auto &kv : S.pinned) (void)hipHostUnregister(const_cast<void *>(kv.first));
     S.sig_valid = false;
     S.pinned.clear();

@@ -37,12 +37,13 @@ void fill_direct(EvpDirect &D, bool masked)
 // a tripole fold, where cell-centre and corner fields mirror the same cells)
 // masked: the in-loop velocity exchange on the entries ice_HaloMask keeps (every other exchange -- pre-loop
 // velocities, T-grid fields -- uses the full lists, as the reference does with halo_info vs halo_info_mask)
-int halo_remote_pair(double *a, double *bb, bool masked)
+int halo_remote_pair(double *a, double *bb, bool masked, bool has_tail)
 {
     masked = masked && S.msk.on;
-    // staging slots of the split tripole seam lie BEHIND the cells of an array (offsets >= S.n): only the velocity
-    // buffers are allocated with that tail (S.nuv); any other target would be written out of bounds
-    if (S.plan.tail > 0 && !((a == S.u[0] && bb == S.v[0]) || (a == S.u[1] && bb == S.v[1])))
+    // staging slots of the split tripole seam lie BEHIND the cells of an array (offsets >= S.n): the velocity buffers are
+    // allocated with that tail (S.nuv), and so are the arrays a caller vouches for (has_tail); any other target would be
+    // written out of bounds
+    if (S.plan.tail > 0 && !has_tail && !((a == S.u[0] && bb == S.v[0]) || (a == S.u[1] && bb == S.v[1])))
         return fail(-3, "remote halo of a non-velocity array on a rank layout that splits the tripole seam row (staging slots)");
     if (!S.plan.peers.empty() && S.direct.on) {
         EvpDirect D;
@@ -66,6 +67,62 @@ int halo_remote_pair(double *a, double *bb, bool masked)
         evp_launch_halo_unpack(a, bb, masked ? S.msk.recv_dst : S.h_recv_dst,
                                (const signed char *)(masked ? S.msk.recv_sign : S.h_recv_sign), S.recvbuf,
                                masked ? S.msk.n_recv : S.n_recv, S.stream);
+    }
+    return 0;
+}
+
+static int foldx_setup();
+
+int fold_seam_ghosts(double *a, double *b)
+{
+    if (foldx_setup()) return -1;
+    State::FoldX &F = S.foldx;
+    if (F.n_seam) evp_launch_halo_local(a, b, F.seam_dst, F.seam_slot, (const signed char *)F.seam_one, F.n_seam, S.stream);
+    return 0;
+}
+
+int fold_remote_pair(const double *srcA, const double *srcB, double *dstA, double *dstB, int kind, double fa, double fb)
+{
+    if (foldx_setup()) return -1;
+    State::FoldX &F = S.foldx;
+    // every rank takes part in the exchange (its top-row cells may be somebody's sources) whether or not it has
+    // destinations of its own
+    evp_launch_fold_shift2(srcA, srcB, F.scr[0], F.scr[1], F.cells, F.n_cells, S.d.nx_block, S.stream);
+    // the whole NE-corner update of the copies: a destination's corner-rule source may sit on this rank even though its
+    // centre-rule source does not (the column next to a rank boundary)
+    evp_launch_halo_local(F.scr[0], F.scr[1], S.h_local_dst, S.h_local_src, (const signed char *)S.h_local_sign, S.n_local, S.stream);
+    if (int rc = halo_remote_pair(F.scr[0], F.scr[1], false, true)) return rc;
+    evp_launch_fold_extract2(dstA, dstB, F.scr[0], F.scr[1], F.dst[kind], F.n_dst[kind], fa, fb, S.stream);
+    return 0;
+}
+
+static int foldx_setup()
+{
+    State::FoldX &F = S.foldx;
+    if (!F.ready) {
+        const HaloPlan &P = S.plan;
+        auto up = [&](int32_t *&dp, int &n, const std::vector<int32_t> &v) -> int {
+            n = (int)v.size();
+            if (n) {
+                HIPC(hipMalloc((void **)&dp, v.size() * sizeof(int32_t)));
+                HIPC(hipMemcpy(dp, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+            return 0;
+        };
+        int n2 = 0;
+        if (up(F.cells, F.n_cells, P.fold_shift_cells) || up(F.dst[0], F.n_dst[0], P.center_foldr_dst) ||
+            up(F.dst[1], F.n_dst[1], P.stress_foldr_dst) || up(F.seam_dst, F.n_seam, P.center_seam_dst) ||
+            up(F.seam_slot, n2, P.center_seam_slot)) return -1;
+        if (F.n_seam) {
+            std::vector<int8_t> one(F.n_seam, 1);
+            HIPC(hipMalloc((void **)&F.seam_one, one.size()));
+            HIPC(hipMemcpy(F.seam_one, one.data(), one.size(), hipMemcpyHostToDevice));
+        }
+        for (auto &p : F.scr) {
+            if (alloc_d(&p, S.nuv)) return -1;
+            HIPC(hipMemsetAsync(p, 0, S.nuv * sizeof(double), S.stream));
+        }
+        F.ready = true;
     }
     return 0;
 }

@@ -15,13 +15,11 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
     // T-grid ghost cells owned by other ranks travel with the velocity exchange (same cells for centre and corner
     // fields) -- except across the tripole fold, where centre fields mirror other cells than corner fields do
     if (S.plan.tfold) return fail(-9, "device preparation: not built for tripoleT grids; keep evp()'s host preparation (cice_evp_hip_run)");
-    if (S.plan.center_fold_remote)
-        return fail(-9, "device preparation: T-grid ghost cells across the tripole fold live on other ranks here (the fold "
-                        "row is split in x); keep evp()'s host preparation and use cice_evp_hip_run on this configuration");
     auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };
     if (B(Q.tmask) || B(Q.umask) || B(Q.umask_old) || B(Q.tmphm)) return -1;
     HIPC(hipMalloc((void **)&Q.umask_old32, S.n * sizeof(int32_t)));
-    auto D = [&](double *&p) -> int { return p ? 0 : alloc_d(&p, S.n); };
+    // (with the staging tail of a split tripole seam row: these arrays go through the velocity exchange too)
+    auto D = [&](double *&p) -> int { return p ? 0 : alloc_d(&p, S.nuv); };
     if (D(Q.hm) || D(Q.tarea) || D(Q.uarea) || D(Q.fcor) || D(Q.tmass) || D(Q.umass) || D(Q.maskd) ||
         D(Q.ss_tltxU) || D(Q.ss_tltyU) || D(Q.strairxU) || D(Q.strairyU) || D(Q.strtltx) || D(Q.strtlty)) return -1;
     for (auto &q : Q.t)
@@ -128,8 +126,23 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
         // neighbours on other ranks (no tripole fold here: centre and corner fields mirror the same
         // cells, so the velocity exchange carries pairs of T-grid fields)
         double *pairs[5][2] = {{Q.maskd, Q.tmass}, {Q.t[3], Q.t[4]}, {Q.t[5], Q.t[6]}, {Q.t[7], Q.t[8]}, {Q.t[9], Q.t[10]}};
-        for (auto &pr : pairs)
-            if (int rc = halo_remote_pair(pr[0], pr[1])) return rc;
+        for (auto &pr : pairs) {
+            if (int rc = halo_remote_pair(pr[0], pr[1], false, true)) return rc;
+            if (S.plan.fold_split)       // east-west ghost cells of row NY owned elsewhere: the raw values in the staging slots
+                if (int rc = fold_seam_ghosts(pr[0], pr[1])) return rc;
+        }
+        if (S.plan.fold_split) {
+            // the plain exchange follows the NE-corner rule: ghost cells across the fold whose CENTRE-rule source is on this
+            // rank have just been overwritten with a corner-rule value from elsewhere -- the local list again (its sources
+            // are interior cells)
+            halo({{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false},
+                  {Q.t[5], true}, {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}, {Q.t[9], true}, {Q.t[10], true}});
+            // ... and where the fold row is split in x, the ghost cells whose centre-rule source lies across the fold on
+            // another rank: the exchange of a shifted copy (halo_plan.h); scalars -1 (undo the exchange's sign), vectors +1
+            const double fac[5][2] = {{-1, -1}, {-1, -1}, {1, 1}, {1, 1}, {1, 1}};
+            for (int q = 0; q < 5; ++q)
+                if (int rc = fold_remote_pair(pairs[q][0], pairs[q][1], pairs[q][0], pairs[q][1], 0, fac[q][0], fac[q][1])) return rc;
+        }
     }
     evp_launch_prep_average_prep2(P, S.d.nblocks, S.stream);      // T -> U averages and dyn_prep2 in one launch
     // ghost velocities before the loop (:729-732): the same exchange as inside the loop

@@ -306,6 +306,28 @@ __global__ void seabed_prob_U(EvpPrep P, const double *__restrict__ Tbt, double 
     TbU[c] = tb;
 }
 
+// Cell-centre fields across a tripole fold whose row is split over ranks (halo_plan.h): the shifted copies the
+// NE-corner exchange is run on -- a2[c] = a[c + nx + 1] on this rank's cells of row NY-1 -- and, after the exchange, the
+// ghost cells it filled: a[d] = fa * a2[d] (fa = -1 undoes the exchange's sign for scalar kinds, +1 keeps it for vectors)
+__global__ void fold_shift2(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ a2,
+                            double *__restrict__ b2, const int *__restrict__ cells, int n, int nx)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int c = cells[t];
+    a2[c] = a[c + nx + 1];
+    b2[c] = b[c + nx + 1];
+}
+__global__ void fold_extract2(double *__restrict__ a, double *__restrict__ b, const double *__restrict__ a2,
+                              const double *__restrict__ b2, const int *__restrict__ dst, int n, double fa, double fb)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int d = dst[t];
+    a[d] = fa * a2[d];
+    b[d] = fb * b2[d];
+}
+
 dim3 cell_grid(const EvpPrep &P, int nblocks) { return dim3((P.nx + 63) / 64, P.ny, nblocks); }
 
 }  // namespace
@@ -361,4 +383,14 @@ void evp_launch_seabed_prob_t(const EvpPrep &P, int nblocks, const double *hwate
 {
     hipLaunchKernelGGL(seabed_prob_T, cell_grid(P, nblocks), dim3(64), 0, st, P, hwater, aicen, vicen, ncat, alphab, rhoi, rhow,
                        gravit, pi, puny, Tbt);
+}
+
+void evp_launch_fold_shift2(const double *a, const double *b, double *a2, double *b2, const int *cells, int n, int nx, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(fold_shift2, dim3((n + 255) / 256), dim3(256), 0, st, a, b, a2, b2, cells, n, nx);
+}
+void evp_launch_fold_extract2(double *a, double *b, const double *a2, const double *b2, const int *dst, int n, double fa, double fb,
+                              hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(fold_extract2, dim3((n + 255) / 256), dim3(256), 0, st, a, b, a2, b2, dst, n, fa, fb);
 }

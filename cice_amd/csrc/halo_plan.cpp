@@ -142,6 +142,12 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
             (B.owner == me ? mine : others) = true;
         }
         plan.fold_rows = !mine ? 0 : (others ? 2 : 1);
+        int first = -1;
+        for (const HaloBlock &B : T.blk) {
+            if (B.owner < 0 || B.gj0 + B.gny - 1 != d.ny_global) continue;
+            if (first < 0) first = B.owner;
+            else if (B.owner != first) plan.fold_split = true;
+        }
     }
 
     std::map<int, HaloPeer> peers;
@@ -256,7 +262,10 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                         const HaloBlock &Sb = T.blk[ks];
                         if (Sb.owner != me) {
                             plan.center_remote = true;
-                            if (sign < 0) plan.center_fold_remote = true;
+                            if (sign < 0) {
+                                plan.center_fold_remote = true;
+                                plan.center_foldr_dst.push_back(dst);
+                            }
                             continue;
                         }
                         plan.center_dst.push_back(dst);
@@ -346,7 +355,13 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                 if (ow == R) finalise(off, ig, 1);
             }
             for (const GhostSeam &g : ghost_seam)    // R's ghost images of seam-row cells
-                if (g.R == R) finalise(g.dst, g.sig, g.sign);
+                if (g.R == R) {
+                    finalise(g.dst, g.sig, g.sign);
+                    if (R == me && g.sign > 0) {     // an east-west image in row NY itself: for centre fields, the raw value
+                        const int32_t slot = ref(g.sig);
+                        if (slot >= nR) { plan.center_seam_dst.push_back(g.dst); plan.center_seam_slot.push_back(slot); }
+                    }
+                }
             if (R == me) plan.tail = next_slot;
         }
         plan.peers.clear();
@@ -365,14 +380,25 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                     int owner = -1;
                     const int32_t src = offset_of(NX - ig + 1, NY, owner);
                     if (owner >= 0 && owner != me) {
-                        // the symmetrisation stays with the host on such layouts (evp() does it on its own arrays,
-                        // ice_dyn_evp.F90:1321-1389); cice_evp_hip_stress_halo refuses
+                        // partner on another rank: through the exchange of a shifted copy (halo_plan.h)
                         plan.stress_remote = true;
+                        plan.stress_foldr_dst.push_back((int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1)));
                         continue;
                     }
                     plan.stress_dst.push_back((int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1)));
                     plan.stress_src.push_back(owner < 0 ? -1 : src);
                 }
+            }
+    }
+    if (tripole) {       // where the shifted copies are built: this rank's interior cells of row NY-1 whose block also holds row NY
+        auto it = T.by_rank.find(me);
+        if (it != T.by_rank.end())
+            for (int kb : it->second) {
+                const HaloBlock &B = T.blk[kb];
+                if (B.gj0 + B.gny - 1 != d.ny_global || B.gny < 2) continue;
+                const int j = ng + B.gny - 1;                     // local row of global NY-1
+                for (int i = ng + 1; i <= ng + B.gnx; ++i)
+                    plan.fold_shift_cells.push_back((int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1)));
             }
     }
     // ghost cells whose source block was eliminated: ice_HaloUpdate_stress writes the fill value

@@ -81,6 +81,18 @@ struct HaloPlan {
     bool tfold = false;                           // ns_boundary_type 'tripoleT': velocity halo only (one rank)
     bool center_remote = false;
     bool center_fold_remote = false;              // ... and one of them lies across the tripole fold (centre mirror rule, other rank)
+    // Centre-field ghost cells of this rank whose source lies across the fold on ANOTHER rank (fold row split in x), and the
+    // same for the stress symmetrisation.  They are filled through the ordinary NE-corner exchange run on a SHIFTED copy:
+    // with a'(i, NY-1) = a(i+1, NY) on the owner, the corner rule ghost(ig, NY+1) <- -a'(NX-ig, NY-1) delivers
+    // -a(NX-ig+1, NY), the centre rule's source (sign fixed afterwards).  fold_shift_cells: this rank's interior cells of
+    // row NY-1 (the shifted copy is built there).
+    std::vector<int32_t> center_foldr_dst, stress_foldr_dst, fold_shift_cells;
+    // ... and this rank's east-west ghost cells of row NY whose source another rank owns: the velocity exchange does not
+    // fill them (images of seam-row cells are finalised from RAW values), but it brings the raw value of the source into
+    // a staging slot -- which for a cell-centre field IS the ghost value: a[dst] = a[slot] after the exchange
+    std::vector<int32_t> center_seam_dst, center_seam_slot;
+    bool fold_split = false;                      // the blocks holding row NY have more than one owner: the same on every rank
+                                                  // (the exchanges above are collective)
     std::string error;
 };
 

@@ -41,7 +41,7 @@ EXPORTS = [
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_cgrid_set_prep_geometry", "cice_evp_hip_cgrid_prep", "cice_evp_hip_cgrid_seabed_lkd", "cice_evp_hip_cgrid_seabed_prob",
-    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_set_test_transport",
+    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_set_test_transport", "cice_evp_hip_fold_split_plan",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
@@ -160,6 +160,20 @@ def make_params(scal: dict, strict: bool = False) -> Params:
               "deltaminEVP", "u0", "cosw", "sinw", "rhow"):
         setattr(p, k, float(scal[k]))
     return p
+
+
+def fold_split_plan() -> dict:
+    """Lists of the shifted-copy exchange of the plan built last (halo_plan(): cice_evp_hip_plan_build)."""
+    lib = load_library()
+    out = {}
+    for which, name in enumerate(("shift_cells", "center_dst", "stress_dst", "seam_dst", "seam_slot")):
+        n = C.c_int32(0)
+        split = lib.cice_evp_hip_fold_split_plan(C.c_int32(which), C.byref(n), None)
+        a = np.zeros(max(n.value, 1), dtype=np.int32)
+        lib.cice_evp_hip_fold_split_plan(C.c_int32(which), C.byref(n), _ip(a))
+        out[name] = a[:n.value]
+        out["fold_split"] = bool(split)
+    return out
 
 
 def cgrid_fold_plan(dims: "Dims", loc: str) -> dict:

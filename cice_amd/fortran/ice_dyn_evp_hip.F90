@@ -377,10 +377,8 @@ contains
     on_tripole = trim(ns_boundary_type) == 'tripole'
     call get_environment_variable('CICE_EVP_HIP_STRESS_RESIDENT', envval, envlen, envstat)
     stress_resident = stress_resident_requested .or. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '1')
-    ! a rank layout that cuts the tripole seam row: the stress symmetrisation needs other ranks and stays with
-    ! evp()'s host code (ice_dyn_evp.F90:1321-1389), so the stresses must make the round trip every call
-    if (on_tripole .and. cice_evp_hip_seam_fin_plan(cnt2, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr) == 1) &
-       stress_resident = .false.
+    ! (a rank layout that cuts the tripole seam row in x is fine too: cice_evp_hip_stress_halo reaches the partners on
+    ! other ranks through the velocity exchange of a shifted copy)
     ! tripoleT: the symmetrisation is not built on the device at all
     if (trim(ns_boundary_type) == 'tripoleT') stress_resident = .false.
     call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
@@ -983,16 +981,11 @@ contains
 ! called before or after dyn_evp_hip_init.  Switching off brings the host arrays up to date first.
   subroutine dyn_evp_hip_keep_stresses_resident(flag)
     logical, intent(in) :: flag
-    integer(c_int32_t) :: cnt2(2)
     character(len=*), parameter :: subname = '(dyn_evp_hip_keep_stresses_resident)'
     stress_resident_requested = flag
     if (.not. initialised) return
     if (.not. flag .and. stress_resident) call dyn_evp_hip_fetch_stresses
     stress_resident = flag
-    if (on_tripole) then
-       if (cice_evp_hip_seam_fin_plan(cnt2, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr) == 1) &
-          stress_resident = .false.
-    endif
     call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
          subname, __FILE__, __LINE__)
   end subroutine dyn_evp_hip_keep_stresses_resident

@@ -193,7 +193,8 @@ int cice_evp_hip_dyn_finish(double *strocnxU, double *strocnyU);
  * iceUmask: in = mask of the previous call (new ice starts at the ocean velocity), out = new mask;
  * strintxU/strintyU/strocnxU/strocnyU (may be NULL): zeroed off the ice on the host arrays.
  * On a split domain the T-grid halos use the same transport as the velocities (collective call);
- * a split TRIPOLE domain is refused (keep the host preparation there).                         */
+ * on a tripole domain too, whatever the rank layout (a fold row split over ranks in x: through the
+ * exchange of a shifted copy, cice_amd/csrc/halo_plan.h).                                        */
 typedef struct cice_evp_hip_prep_params {
     double dt;                 /* dynamics time step (dyn_prep2's Xmass/dt)                    */
     double rhoi, rhos, gravit; /* icepack_query_parameters                                      */
@@ -416,6 +417,12 @@ int cice_evp_hip_center_plan(int32_t *count, int32_t *dst, int32_t *src, int32_t
 /* Lists behind cice_evp_hip_stress_halo: a1[dst] <- a2[src] for every partner pair (src = -1:
  * fill 0, ice_boundary.F90:7643-7645).  Lists may be NULL.                                     */
 int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src);
+/* Lists of the shifted-copy exchange that serves centre-kind fields across a tripole fold whose row is split over ranks
+ * (cice_amd/csrc/halo_plan.h): which 0 = cells of row NY-1 where a'(c) = a(c + nx_block + 1) is built, 1 = centre-field
+ * ghost cells taken from the exchanged copy, 2 = the stress symmetrisation's; 3, 4 = east-west ghost cells of row NY
+ * owned elsewhere and the staging slots (offsets behind the array) a plain exchange leaves their values in.  Returns 1
+ * when the fold row is split.                                                                                       */
+int cice_evp_hip_fold_split_plan(int32_t which, int32_t *count, int32_t *cells);
 /* Flags of the plan, up to n of them: [0] some rank's in-loop velocity exchange crosses the tripole fold or uses
  * seam staging slots -- computed identically on every rank, what collective decisions (cice_evp_hip_halo_mask)
  * hang on; [1] fold_rows (0 none here, 1 all here, 2 shared); [2] stress symmetrisation needs another rank;

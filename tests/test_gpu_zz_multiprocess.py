@@ -26,7 +26,10 @@ def _free_port():
                                                            (2, "gx3", "1x2", "blocks"),
                                                            (2, "tx1", "2x1", False), (4, "tx1", "2x2", False),
                                                            # evp()'s preparation phase on a tripole grid cut in y
-                                                           (2, "tx1", "1x2", "prep")])
+                                                           (2, "tx1", "1x2", "prep"),
+                                                           # ... and with the fold row split in x: T-grid ghost cells across the
+                                                           # fold and the stress symmetrisation through shifted copies
+                                                           (2, "tx1", "2x1", "prep_stream"), (4, "tx1", "2x2", "prep_stream")])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
@@ -49,6 +52,9 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
     if resident == "blocks":
         # several CICE blocks per rank AND neighbours on other ranks, resident kernel
         cmd += ["--blocks-per-rank", "2x2", "--expect-resident", "--timing"]
+    elif resident == "prep_stream":
+        cmd += ["--prep"]
+        env["CICE_EVP_HIP_RESIDENT"] = "0"
     elif resident == "prep":
         # from the primary model state: evp()'s preparation phase on every rank, its T-grid halos
         # crossing the ranks through the same transport, then the loop (f-2 on a split domain)

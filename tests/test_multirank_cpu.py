@@ -114,6 +114,97 @@ def test_tripole_seam_split_across_ranks_known_answer(case):
     assert sum(r[2] for r in res) > 0 and sum(r[3] for r in res) >= case[0]      # staging slots were needed; every seam cell finalised
 
 
+def _centre_fold_worker(rank, world, port, case, q):
+    """Cell-centre fields on a tripole grid whose fold row is split over ranks: the ghost cells across the fold whose source
+    another rank owns are filled by running the NE-corner exchange on a copy shifted by one cell (halo_plan.h) -- plan
+    lists + gloo here, against the oracle's centre-rule halo update of the same global field (scalar and vector kind)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        from pathlib import Path
+        sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
+        import oracle
+        nx, ny, bx, by, nranks, shape = case
+        dc = decomp.Decomp(nx, ny, bx, by, "cyclic", "tripole", nranks, shape)
+        d, keep = evp.make_dims(dc, rank)
+        plan = evp.halo_plan(d)
+        fs = evp.fold_split_plan()
+        one = decomp.Decomp(nx, ny, bx, by, "cyclic", "tripole", 1)
+        ob = one.local_blocks(0)
+        dom = oracle.OracleDomain(one.nx_block, one.ny_block, len(ob), nx, ny, "cyclic", "tripole",
+                                  [b.ilo for b in ob], [b.ihi for b in ob], [b.jlo for b in ob], [b.jhi for b in ob],
+                                  [b.gi0 for b in ob], [b.gj0 for b in ob])
+        mine = dc.local_blocks(rank)
+
+        def exchange(flat):
+            sendbuf = torch.from_numpy(flat[plan["send_src"]].copy())
+            recvbuf = torch.zeros(len(plan["recv_dst"]), dtype=torch.float64)
+            ops, so, ro = [], 0, 0
+            for p, ns_, nr_ in zip(plan["peer_rank"], plan["peer_nsend"], plan["peer_nrecv"]):
+                if ns_:
+                    ops.append(dist.P2POp(dist.isend, sendbuf[so:so + ns_], int(p)))
+                if nr_:
+                    ops.append(dist.P2POp(dist.irecv, recvbuf[ro:ro + nr_], int(p)))
+                so += ns_
+                ro += nr_
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            flat[plan["recv_dst"]] = plan["recv_sign"] * recvbuf.numpy()
+
+        nbad = 0
+        for kind in ("scalar", "vector"):
+            glob = np.random.default_rng(23).standard_normal((ny, nx))
+            ref = oracle.halo_update(dom, np.ascontiguousarray(one.scatter(glob, 0, fill=0.0)), "center", kind)
+            a = np.ascontiguousarray(dc.scatter(glob, rank, fill=0.0))
+            for b in mine:
+                m = np.ones((dc.ny_block, dc.nx_block), bool)
+                m[1:1 + b.gny, 1:1 + b.gnx] = False
+                a[b.local][m] = 0.0
+            flat = np.concatenate([a.reshape(-1), np.zeros(plan["tail"])])
+            # 1. ghosts with a source on this rank (centre rule), 2. the plain exchange: right for every remote ghost that is
+            # not across the fold, 3. the exchange of the shifted copy for those that are
+            src = plan["center_src"]
+            vs = plan["center_vsign"] if kind == "vector" else np.ones_like(plan["center_vsign"])
+            flat[plan["center_dst"]] = np.where(src >= 0, vs * flat[np.maximum(src, 0)], 0.0)
+            exchange(flat)
+            flat[fs["seam_dst"]] = flat[fs["seam_slot"]]      # east-west ghosts of row NY owned elsewhere: raw values from the staging slots
+            flat[plan["center_dst"]] = np.where(src >= 0, vs * flat[np.maximum(src, 0)], 0.0)   # (the corner-rule exchange overwrote some)
+            cp = np.zeros_like(flat)
+            cp[fs["shift_cells"]] = flat[fs["shift_cells"] + dc.nx_block + 1]
+            ls = plan["local_src"]                            # the whole NE-corner update of the copy: local part, remote part
+            cp[plan["local_dst"]] = np.where(ls >= 0, plan["local_sign"] * cp[np.maximum(ls, 0)], 0.0)
+            exchange(cp)
+            flat[fs["center_dst"]] = (1.0 if kind == "vector" else -1.0) * cp[fs["center_dst"]]
+            got = flat[:a.size].reshape(a.shape)
+            for b in mine:
+                k = next(o.local for o in ob if o.gi0 == b.gi0 and o.gj0 == b.gj0)
+                nbad += int((got[b.local] != ref[k]).sum())
+        q.put((rank, nbad, int(len(fs["center_dst"])), int(fs["fold_split"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", TRIPOLE_CASES)
+def test_centre_fields_across_a_split_fold_known_answer(case):
+    world = case[4]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_centre_fold_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nbad, ndst, split in sorted(res):
+        assert nbad == 0, f"rank {rank}: {nbad} cells differ from the oracle's centre-rule halo update"
+        assert split == 1
+    assert sum(r[2] for r in res) > 0
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
