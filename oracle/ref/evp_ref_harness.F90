@@ -48,6 +48,35 @@ module evp_cgrid_capture
   logical(log_kind), allocatable, dimension(:,:,:), private :: q_mU, q_mE, q_mN
 contains
 
+  ! the ice cover between two calls: some cells lose their ice, some open-water cells gain some (dyn_prep2's
+  ! "new ice starts at the ocean velocity" / "no ice: zero" branches, ice_dyn_shared.F90:747-764)
+  subroutine evolve_ice()
+    integer(int_kind) :: ib, i, j, ig, jg
+    type(block) :: tb
+    do ib = 1, nblocks
+       tb = get_block(blocks_ice(ib), ib)
+       do j = 1, ny_block
+       do i = 1, nx_block
+          ig = tb%i_glob(i); jg = tb%j_glob(j)
+          if (ig < 1 .or. jg < 1 .or. .not. tmask(i,j,ib)) cycle
+          if (aice(i,j,ib) > c0 .and. (mod(ig + 3*jg, 7) == 0 .or. (ig >= 4 .and. ig <= 8 .and. jg >= 5 .and. jg <= 9))) then
+             aice(i,j,ib) = c0; vice(i,j,ib) = c0; vsno(i,j,ib) = c0
+          elseif (aice(i,j,ib) == c0 .and. mod(2*ig + jg, 3) /= 0) then
+             aice(i,j,ib) = 0.6_dbl_kind; vice(i,j,ib) = 0.9_dbl_kind; vsno(i,j,ib) = 0.05_dbl_kind
+          endif
+          aice_init(i,j,ib) = aice(i,j,ib)
+       enddo
+       enddo
+    enddo
+    call ice_HaloUpdate(aice,      halo_info, field_loc_center, field_type_scalar)
+    call ice_HaloUpdate(vice,      halo_info, field_loc_center, field_type_scalar)
+    call ice_HaloUpdate(vsno,      halo_info, field_loc_center, field_type_scalar)
+    call ice_HaloUpdate(aice_init, halo_info, field_loc_center, field_type_scalar)
+    aice0(:,:,1:nblocks) = c1 - aice(:,:,1:nblocks)
+    aicen(:,:,1,1:nblocks) = aice(:,:,1:nblocks)
+    vicen(:,:,1,1:nblocks) = vice(:,:,1:nblocks)
+  end subroutine evolve_ice
+
   ! icepack_ice_strength on the T-cells of the new iceTmask + its halo update (ice_dyn_evp.F90:596-608, 727-728):
   ! the callback of dyn_evp_hip_cgrid_evp_body
   subroutine cgrid_strength()
@@ -84,32 +113,7 @@ contains
                 c_s12T(nx_block,ny_block,max_blocks), c_s12U(nx_block,ny_block,max_blocks), &
                 c_u(nx_block,ny_block,max_blocks), c_v(nx_block,ny_block,max_blocks))
     endif
-    if (evolve .and. ic == 2) then
-       ! the ice cover between two calls: some cells lose their ice, some open-water cells gain some (dyn_prep2's
-       ! "new ice starts at the ocean velocity" / "no ice: zero" branches, ice_dyn_shared.F90:747-764)
-       do ib = 1, nblocks
-          tb = get_block(blocks_ice(ib), ib)
-          do j = 1, ny_block
-          do i = 1, nx_block
-             ig = tb%i_glob(i); jg = tb%j_glob(j)
-             if (ig < 1 .or. jg < 1 .or. .not. tmask(i,j,ib)) cycle
-             if (aice(i,j,ib) > c0 .and. mod(ig + 3*jg, 7) == 0) then
-                aice(i,j,ib) = c0; vice(i,j,ib) = c0; vsno(i,j,ib) = c0
-             elseif (aice(i,j,ib) == c0 .and. mod(2*ig + jg, 3) /= 0) then
-                aice(i,j,ib) = 0.6_dbl_kind; vice(i,j,ib) = 0.9_dbl_kind; vsno(i,j,ib) = 0.05_dbl_kind
-             endif
-             aice_init(i,j,ib) = aice(i,j,ib)
-          enddo
-          enddo
-       enddo
-       call ice_HaloUpdate(aice,      halo_info, field_loc_center, field_type_scalar)
-       call ice_HaloUpdate(vice,      halo_info, field_loc_center, field_type_scalar)
-       call ice_HaloUpdate(vsno,      halo_info, field_loc_center, field_type_scalar)
-       call ice_HaloUpdate(aice_init, halo_info, field_loc_center, field_type_scalar)
-       aice0(:,:,1:nblocks) = c1 - aice(:,:,1:nblocks)
-       aicen(:,:,1,1:nblocks) = aice(:,:,1:nblocks)
-       vicen(:,:,1,1:nblocks) = vice(:,:,1:nblocks)
-    endif
+    if (evolve .and. ic == 2) call evolve_ice()
     ! what evp()'s preparation phase reads on the C grid (ice_dyn_evp.F90:383-735): the T-grid state and forcing, the
     ! velocities / stresses / ice masks the previous call left (SURVEY 8 f-2 for grid_ice = 'C')
     write(tg,'(a,i2.2)') 'cp', ic
@@ -283,7 +287,7 @@ program evp_ref_harness
       dyn_evp_hip_keep_stresses_resident
 #endif
   use evp_dumpio
-  use evp_cgrid_capture, only: cgrid_call
+  use evp_cgrid_capture, only: cgrid_call, evolve_ice
   use icepack_intfc, only: icepack_query_parameters
 #if defined (_OPENMP)
   use OMP_LIB
@@ -542,6 +546,7 @@ program evp_ref_harness
         call cgrid_call(icall, nsub_list, nl, h_ndte, hipmode, h_evolve, hipbody)
         cycle
      endif
+     if (h_evolve .and. icall == 2) call evolve_ice()
 
      if (hipmode) then
         ! prep-only pass (ndte=0): applies dyn_prep2's one-off state changes (new-ice

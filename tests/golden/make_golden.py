@@ -58,6 +58,11 @@ CASES = {
     "pop_cyc_2x2_seabedprob": (24, 20, 12, 10, "cyclic", "closed",
                                dict(grid_kind="popfile", icecase="patchy", nsub_list=[1, 120], ncalls=2,
                                     h_seabed=True, h_seabed_method="probabilistic")),
+    # the ice cover changes between the two calls (cells gain and lose ice: dyn_prep2's new-ice / no-ice branches, :747-764)
+    # and the sea surface slopes (ssh_stress = 'coupled'): the preparation phase's inputs pr02 differ from pr01
+    "pop_cyc_2x2_evolve_coupled": (24, 20, 12, 10, "cyclic", "closed",
+                                   dict(grid_kind="popfile", icecase="patchy", nsub_list=[1, 120], ncalls=2, h_evolve=True,
+                                        h_ssh="coupled")),
     # tripole (u-fold) north boundary: seam-row averaging, mirrored ghost row, and -- in the
     # expected outputs only -- evp()'s ice_HaloUpdate_stress symmetrisation after the loop
     "trip_cyc_2x2_full": (28, 20, 14, 10, "cyclic", "tripole",
