@@ -399,7 +399,7 @@ def main():
                                 two_subcycle_kernel=dict(ran=bool(mi["last_call"]), passes=mi["passes"], declined=mi["declined"],
                                                          strips=mi["strips"], segments=mi["segments"], rows_per_segment=mi["seglen"]),
                                 probes_us=dict(streaming=1e3 * float(tm_ev["stream_probe_ms"]), resident=1e3 * float(tm_ev["resident_probe_ms"])),
-                                local_cells=int(sum(b.gnx * b.gny for b in dc.local_blocks(rank))))
+                                local_cells=int(sum(b.gnx * b.gny for b in dc.local_blocks(rank))), path=core.describe_path())
                     per_rank = [None] * world
                     dist.all_gather_object(per_rank, mine)
                 # ---- what was timed, checked: continue (untimed) to the next checkpoint, hash the state ----

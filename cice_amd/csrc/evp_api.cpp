@@ -848,6 +848,26 @@ int cice_evp_hip_march_info(int32_t *out, int32_t n)
     return 0;
 }
 
+// One line on what the last cice_evp_hip_subcycle ran and why the alternatives did not -- for logs (the Fortran shim
+// prints it once after the first call when CICE_EVP_HIP_VERBOSE is set) and for reading a first multi-GPU run.
+int cice_evp_hip_describe_path(char *buf, int32_t n)
+{
+    if (!buf || n < 2) return fail(-1, "describe_path: no buffer");
+    const State::March &M = S.march;
+    const char *kernel = S.res_mode == 1 ? (S.res_gen == 2 ? (S.res_remote ? "on-chip resident (tagged records, neighbours on other ranks)"
+                                                                          : "on-chip resident (tagged records)")
+                                                           : "on-chip resident (flags)")
+                         : (M.last_call ? "two subcycles per pass (marching)" : "one subcycle per launch (streaming)");
+    const char *transport = S.plan.peers.empty() ? "none (one rank)" : (S.direct.on ? "mailbox over HIP IPC" : (S.have_comm ? "RCCL send/recv" : "not set up"));
+    std::snprintf(buf, (size_t)n, "rank %d of %d: kernel = %s; halo transport = %s%s%s; two-subcycle path: %s%s%s; blocks %d, cells per exchange %d",
+                  (int)S.d.rank, (int)std::max(1, (int)S.d.nranks), kernel, transport,
+                  (!S.plan.peers.empty() && !S.direct.on && !S.direct.why.empty()) ? " (mailbox off: " : "",
+                  (!S.plan.peers.empty() && !S.direct.on && !S.direct.why.empty()) ? (S.direct.why + ")").c_str() : "",
+                  M.mode == 1 ? "on" : (M.mode == 0 ? "off" : "undecided"), (M.mode == 0 && !M.why.empty()) ? " -- " : "",
+                  (M.mode == 0 && !M.why.empty()) ? M.why.c_str() : "", (int)S.d.nblocks, (int)(S.msk.on ? S.msk.n_send : S.n_send));
+    return 0;
+}
+
 int cice_evp_hip_plan_flags(int32_t *flags, int32_t n)
 {
     const HaloPlan &P = S.plan;

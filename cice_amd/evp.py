@@ -41,7 +41,7 @@ EXPORTS = [
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
     "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_cgrid_set_prep_geometry", "cice_evp_hip_cgrid_prep", "cice_evp_hip_cgrid_seabed_lkd", "cice_evp_hip_cgrid_seabed_prob",
-    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_set_test_transport", "cice_evp_hip_fold_split_plan",
+    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_set_test_transport", "cice_evp_hip_fold_split_plan", "cice_evp_hip_describe_path",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
     "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
@@ -486,6 +486,11 @@ class EvpHip:
 
         self._test_cb = (XF(x_c), RF(r_c))
         _check(self.lib, self.lib.cice_evp_hip_set_test_transport(self._test_cb[0], self._test_cb[1], None), "(set_test_transport)")
+
+    def describe_path(self) -> str:
+        buf = C.create_string_buffer(600)
+        _check(self.lib, self.lib.cice_evp_hip_describe_path(buf, C.c_int32(600)), "(describe_path)")
+        return buf.value.decode(errors="replace")
 
     def march_info(self) -> dict:
         """The two-subcycles-per-pass path (evp_march.hip): did it run, how is the domain cut."""

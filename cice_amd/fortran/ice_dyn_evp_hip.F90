@@ -212,6 +212,12 @@ module ice_dyn_evp_hip
        real(c_double), dimension(*), intent(inout) :: divu, shear, vort, rdg_conv, rdg_shear
      end function cice_evp_hip_cgrid_deformations
 
+     integer(c_int) function cice_evp_hip_describe_path(buf, n) bind(C, name='cice_evp_hip_describe_path')
+       import :: c_int, c_int32_t, c_char
+       character(kind=c_char), dimension(*), intent(out) :: buf
+       integer(c_int32_t), value :: n
+     end function cice_evp_hip_describe_path
+
      integer(c_int) function cice_evp_hip_cgrid_set_prep_geometry(tmask, umaskCD, emask, nmask, fcor_blk, fcorE_blk, &
                                                                   fcorN_blk) bind(C, name='cice_evp_hip_cgrid_set_prep_geometry')
        import :: c_int, c_int32_t, c_double
@@ -614,6 +620,7 @@ contains
     if (stress_resident .and. on_tripole) &
        call check(cice_evp_hip_stress_halo(), subname, __FILE__, __LINE__)
     call ice_timer_stop(timer_evp1dcore)
+    call report_path_once()
 
   contains
 
@@ -714,6 +721,29 @@ contains
     call ice_timer_stop(timer_evp1dcore)
 
   end subroutine dyn_evp_hip_cgrid_run
+
+!-----------------------------------------------------------------------
+! With CICE_EVP_HIP_VERBOSE set: one line per rank, after the first call, on which kernel and halo transport the library
+! settled on (cice_evp_hip_describe_path) -- on the diagnostics unit of this rank's stdout
+  subroutine report_path_once()
+    use ice_communicate, only: my_task
+    logical, save :: done = .false.
+    character(kind=c_char), dimension(600) :: cbuf
+    character(len=600) :: line
+    character(len=8) :: envval
+    integer :: envlen, envstat, k
+    if (done) return
+    done = .true.
+    call get_environment_variable('CICE_EVP_HIP_VERBOSE', envval, envlen, envstat)
+    if (envstat /= 0 .or. envlen < 1) return
+    if (cice_evp_hip_describe_path(cbuf, 600_c_int32_t) /= 0) return
+    line = ' '
+    do k = 1, 600
+       if (cbuf(k) == c_null_char) exit
+       line(k:k) = cbuf(k)
+    enddo
+    write(*,'(a,i0,2a)') '(dyn_evp_hip) task ', my_task, ': ', trim(line)
+  end subroutine report_path_once
 
 !-----------------------------------------------------------------------
 ! C-grid helpers: static arrays handed over once; visc_method as the C ABI's code; evp()'s masked halo for the loop

@@ -366,6 +366,9 @@ typedef int (*cice_evp_hip_test_xchg_fn)(void *user, int32_t npeers, const int32
                                          const int64_t *recv_count, const double *send, double *recv);
 typedef int (*cice_evp_hip_test_reduce_fn)(void *user, int32_t op, void *value);
 int cice_evp_hip_set_test_transport(cice_evp_hip_test_xchg_fn xchg, cice_evp_hip_test_reduce_fn reduce, void *user);
+/* One line of text on what the last cice_evp_hip_subcycle ran (kernel, halo transport, the two-subcycle path and why it is
+ * off when it is), for logs.                                                                                       */
+int cice_evp_hip_describe_path(char *buf, int32_t n);
 /* Host-only (CPU tests): geometry and exchange lists of the two-subcycle path for dims->rank.  Every rank's sub-domain
  * must be one rectangle; the rank HOLDS its own cells plus `ext` (even) more on every side that has a neighbour, in strips
  * of `own` <= own_max columns (position of a cell = (storage row * nstrips + strip) * 64 + lane), and after one exchange

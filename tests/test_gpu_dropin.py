@@ -138,13 +138,14 @@ def test_reference_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, 
 
 
 @pytest.mark.parametrize("nx,ny,bx,by,kw", [(72, 40, 36, 20, dict(icecase="full")), (48, 36, 48, 36, dict(icecase="patchy", h_capping=0.5))])
-def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx, by, kw):
+def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx, by, kw, monkeypatch):
     """ns_boundary_type = 'tripoleT' (T-fold; ice_domain.F90:260), Option B: the reference's unmodified evp() -- its own
     preparation, its own 12 x ice_HaloUpdate_stress after the loop -- with the HIP core behind dyn_evp1d_run.  The loop's
     velocity halo follows the T-fold rule (top U row = image of row NY-1).  Every output array of the whole evp(), every
     cell, against the reference's standard path in the same process."""
     if not run_ref.have_ref("hip_dropin"):
         pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
+    monkeypatch.setenv("CICE_EVP_HIP_VERBOSE", "1")        # the shim reports once which kernel / transport the library settled on
     g = synth.make_grid(nx, ny, dx0=1.1e5, ns="tripole")
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
@@ -162,3 +163,4 @@ def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx,
                     f"max|d|={np.abs(hip - ref).max():.3e}")
                 checked += 1
     assert np.abs(d["o02n0120_uvel"]).max() > 1e-3 and checked == 2 * 2 * (len(FIELDS) + len(DOWNSTREAM))
+    assert "(dyn_evp_hip) task 0: rank 0 of 1: kernel = one subcycle per launch (streaming)" in txt, txt[-1500:]

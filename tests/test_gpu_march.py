@@ -244,6 +244,8 @@ def test_s01_full_size_march_vs_oracle_bitwise():
         got = core.run(fields, tm, um, ndte=13)
         info = core.march_info()
         assert info["mode"] == 1 and info["last_call"] and info["passes"] == 6 and info["declined"] == 0, info
+        path = core.describe_path()
+        assert "two subcycles per pass" in path and "two-subcycle path: on" in path and "one rank" in path, path
     finally:
         core.finalize()
     assert np.abs(want["uvel"]).max() > 1e-3
