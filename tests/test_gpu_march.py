@@ -288,3 +288,56 @@ except evp.EvpHipError as e:
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert "global block table required" not in r.stderr, r.stderr[-1500:]
     assert "no RCCL communicator" in r.stderr, (r.stdout[-800:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("seed", list(range(101, 113)) + [int(s) for s in __import__("os").environ.get("MARCH_SWEEP_SEEDS", "").split() if s])
+def test_march_random_geometry_vs_oracle(seed, march):
+    """Geometry sweep: random domain sizes (not multiples of the strip width), block splits with padded last blocks, strip
+    widths, segment lengths, closed / cyclic east-west boundaries, random ice holes, even and odd subcycle counts -- and,
+    on cyclic domains every other seed, the seam exchanged as a ring with a random redundant rim (the several-rank form
+    with the rank itself as neighbour).  Every output field against the oracle, bit for bit."""
+    rng = np.random.default_rng(seed)
+    nx, ny = int(rng.integers(66, 210)), int(rng.integers(30, 110))
+    ew = "cyclic" if seed % 3 else "closed"
+    nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    bsx, bsy = -(-nx // nbx), -(-ny // nby)
+    own = int(rng.choice([0, 13, 29, 47, 60]))
+    seg = int(rng.integers(5, 45))
+    ndte = int(rng.choice([6, 9, 12]))
+    selfx = ew == "cyclic" and seed % 2 == 0
+    ext = int(rng.choice([0, 2, 4, 6])) if selfx else 0
+    march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
+    if own:
+        march.setenv("CICE_EVP_HIP_MARCH_OWN", str(own))
+    if selfx:
+        march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
+        march.setenv("CICE_EVP_HIP_MARCH_EXT", str(ext))
+    g = synth.derive_geometry(synth.make_grid(nx, ny, 3.0e4, ns="closed"))
+    st = synth.make_state(g, case="full", seed=seed, warm=True)
+    holes = float(rng.choice([0.0, 0.2, 0.7]))
+    tmg = (st["iceTmask"] * (rng.random((ny, nx)) >= holes)).astype(np.int32)
+    umg = (st["iceUmask"] * (rng.random((ny, nx)) >= holes)).astype(np.int32)
+    for k in evp.FIELDS[:12]:
+        st[k] = st[k] * tmg
+    for k in ("uvel", "vvel", "uvel_init", "vvel_init"):
+        st[k] = st[k] * umg
+    dc = decomp.Decomp(nx, ny, bsx, bsy, ew, "closed", 1)
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+    tm, um = dc.scatter(tmg, 0, fill=0), dc.scatter(umg, 0, fill=0)
+    scal = synth.evp_scalars(120)
+    what = f"seed {seed}: {nx}x{ny} {ew}, blocks {bsx}x{bsy}, own {own}, seg {seg}, ndte {ndte}, selfx {selfx} ext {ext}, holes {holes}"
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        if selfx:
+            core.comm_init(core.comm_unique_id())
+        got = core.run(fields, tm, um, ndte=ndte)
+        info = core.march_info()
+        assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0 and info["passes"] == ndte // 2, (what, info)
+    finally:
+        core.finalize()
+    want = run_oracle(dc, geo, fields, tm, um, scal, ndte)
+    assert_bitwise(got, want, what)
