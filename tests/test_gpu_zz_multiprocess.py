@@ -171,7 +171,10 @@ def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
 
 @pytest.mark.parametrize("world,workload,shape,extra,ext", [(2, "gx1", "2x1", [], "4"), (2, "gx1", "1x2", ["--timing"], "2"),
                                                             (4, "gx1", "2x2", ["--blocks-per-rank", "2x1"], "4"),
-                                                            (4, "gx1", "4x1", [], "0")])
+                                                            (4, "gx1", "4x1", [], "0"),
+                                                            # pieces narrower than one strip, an odd split, a wide rim
+                                                            (2, "gx3", "2x1", [], "6"), (3, "gx3", "3x1", ["--timing"], "2"),
+                                                            (4, "gx3", "2x2", [], "6")])
 def test_two_subcycle_kernel_across_processes_on_one_gpu(world, workload, shape, extra, ext):
     """The two-subcycles-per-pass path in its several-rank form, as `world` processes sharing this box's GPU: every rank
     plans from the global block table (rectangles of all ranks, ring lists in one canonical order), holds its piece plus a
