@@ -534,3 +534,67 @@ def test_cgrid_prep_synthetic_vs_oracle_bitwise(grid, bs, case, coupled):
         assert np.abs(want["forcexE"]).max() > 0 and np.abs(want["uvelN"]).max() > 0
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("seed", list(range(201, 209)) + [int(s) for s in __import__("os").environ.get("CGRID_PREP_SWEEP_SEEDS", "").split() if s])
+def test_cgrid_prep_and_loop_random_geometry_vs_oracle(seed):
+    """Geometry sweep of the C-grid path from the T-grid state on: random domain sizes, block splits with padded last blocks,
+    closed and tripole north boundaries, geostrophic / coupled tilt, previous masks that make faces gain and lose ice --
+    device preparation against the oracle's (masks, 14 state arrays, 22 inputs), then 6 subcycles of the loop from the
+    device-prepared state against the oracle's loop from the oracle-prepared one.  Bit for bit."""
+    from cice_amd import decomp, synth
+    rng = np.random.default_rng(seed)
+    trip = seed % 3 == 0
+    nx, ny = 2 * int(rng.integers(20, 70)), int(rng.integers(24, 80))
+    nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    if trip:
+        nby = 1 if ny < 40 else nby                 # (the blocks next to the fold hold at least two rows anyway)
+    bsx, bsy = -(-nx // nbx), -(-ny // nby)
+    ns = "tripole" if trip else "closed"
+    coupled = bool(seed % 2)
+    visc = "avg_strength" if seed % 4 == 1 else "avg_zeta"
+    g = synth.derive_geometry(synth.make_grid(nx, ny, 9.0e4, ns=ns))
+    cg = synth.cgrid_geometry(g)
+    state, inputs, masks = synth.cgrid_state(g, cg, case="full", seed=seed, warm=True)
+    t, st7, prev = synth.cgrid_prep_inputs(g, cg, case="full", seed=seed + 1000, coupled=coupled)
+    dc = decomp.Decomp(nx, ny, bsx, bsy, "cyclic", ns, 1)
+    static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
+    vec = ("uocn", "vocn", "ss_tltx", "ss_tlty", "strairxT", "strairyT")
+    tb = {k: dc.scatter(v, 0, fold=("center", -1.0 if k in vec else 1.0)) for k, v in t.items()}
+    loc = {"umaskCD": "NEcorner", "emask": "Eface", "nmask": "Nface", "fcor_blk": "NEcorner", "fcorE_blk": "Eface", "fcorN_blk": "Nface"}
+    static.update({k: dc.scatter(v, 0, fill=0, fold=(loc.get(k, "center"), 1.0)) for k, v in st7.items()})
+    prevb = {k: dc.scatter(v, 0, fill=0) for k, v in prev.items()}
+    scal = synth.evp_scalars(120)
+    ppd = dict(dt=3600.0, rhoi=917.0, rhos=330.0, gravit=9.80616, dyn_area_min=1e-11, dyn_mass_min=1e-10)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    what = f"seed {seed}: {nx}x{ny} {ns}, blocks {bsx}x{bsy}, coupled {coupled}, {visc}"
+    want = oracle.cgrid_prep(dom, oracle.PrepParams(**ppd, cosw=scal["cosw"], sinw=scal["sinw"], ssh_coupled=int(coupled)), static,
+                             tb, dict(state, **prevb))
+    strength = inputs["strength"]
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    win = {k: want[k] for k in oracle.C_INPUTS}
+    win["strength"] = strength
+    wloop = oracle.cgrid_subcycle(dom, prm, 6, {k: want[k] for k in oracle.C_FIELDS[:14]}, win, static,
+                                  {k: want[k] for k in oracle.C_MASKS}, visc_method=visc)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        core.cgrid_set_prep_geometry(static)
+        got = core.cgrid_prep(evp.PrepParams(**ppd, ssh_stress_coupled=int(coupled)), tb, state, prevb)
+        for k in oracle.C_MASKS:
+            assert np.array_equal(got[k] != 0, want[k] != 0), (what, k)
+        keys = oracle.C_FIELDS[:14] + [k for k in oracle.C_INPUTS if k != "strength"]
+        assert_bitwise({k: core.cgrid_fetch(k) for k in keys}, {k: want[k] for k in keys}, what + " (preparation)")
+        core.cgrid_prep_finish(strength, visc)
+        core.cgrid_subcycle(6)
+        out = core.cgrid_download()
+        assert_bitwise(out, wloop, what + " (loop from the device-prepared state)")
+        assert np.abs(wloop["uvelE"]).max() > 1e-4
+    finally:
+        core.finalize()
