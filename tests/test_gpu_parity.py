@@ -1184,3 +1184,37 @@ def test_random_scalars_vs_oracle(seed, kernel, monkeypatch):
     want = run_oracle(dc, geo, fields, tm, um, scal, 12)
     assert_bitwise(got, want, f"random scalars seed {seed} {kernel}: {kw} cosw={scal['cosw']}")
     assert np.isfinite(want["uvel"]).all()
+
+
+@pytest.mark.parametrize("resident", ["0", "1"])
+@pytest.mark.parametrize("seed", list(range(301, 307)) + [int(s) for s in os.environ.get("BGRID_SWEEP_SEEDS", "").split() if s])
+def test_bgrid_random_geometry_vs_oracle(seed, resident, monkeypatch):
+    """Geometry sweep of the B-grid loop: random domain sizes, block splits with padded last blocks, closed / cyclic
+    east-west boundaries, random ice holes, random subcycle counts -- the one-subcycle streaming kernel and the on-chip
+    resident kernels (forced; where a layout is not eligible the library says so and streams) against the oracle."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", resident)
+    monkeypatch.setenv("CICE_EVP_HIP_MARCH", "0")
+    rng = np.random.default_rng(seed)
+    nx, ny = int(rng.integers(40, 220)), int(rng.integers(30, 160))
+    ew = "cyclic" if seed % 3 else "closed"
+    nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    bsx, bsy = -(-nx // nbx), -(-ny // nby)
+    ndte = int(rng.choice([5, 8, 24]))
+    g = synth.derive_geometry(synth.make_grid(nx, ny, 5.0e4, ns="closed"))
+    st = synth.make_state(g, case="full", seed=seed, warm=True)
+    holes = float(rng.choice([0.0, 0.3]))
+    tmg = (st["iceTmask"] * (rng.random((ny, nx)) >= holes)).astype(np.int32)
+    umg = (st["iceUmask"] * (rng.random((ny, nx)) >= holes)).astype(np.int32)
+    for k in evp.FIELDS[:12]:
+        st[k] = st[k] * tmg
+    for k in ("uvel", "vvel", "uvel_init", "vvel_init"):
+        st[k] = st[k] * umg
+    dc = decomp.Decomp(nx, ny, bsx, bsy, ew, "closed", 1)
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+    tm, um = dc.scatter(tmg, 0, fill=0), dc.scatter(umg, 0, fill=0)
+    scal = synth.evp_scalars(120)
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=ndte)
+    want = run_oracle(dc, geo, fields, tm, um, scal, ndte)
+    assert_bitwise(got, want, f"seed {seed}: {nx}x{ny} {ew}, blocks {bsx}x{bsy}, ndte {ndte}, holes {holes}, resident {resident}")
