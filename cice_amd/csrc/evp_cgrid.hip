@@ -678,6 +678,251 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
     for (int q = 0; q < 9; ++q) A.f[fld[q]][c] = 0.0;
 }
 
+
+// =====================================================================
+// One launch per subcycle (grids small enough to be launch- and latency-bound; one rank, no fold, avg_zeta).
+//
+// A workgroup of ONE_X x ONE_Y threads covers a window of the grid, one thread per position; the inner
+// (ONE_X-3) x (ONE_Y-3) positions are the cells it owns.  Three levels, two workgroup barriers, nothing leaves the chip
+// in between:
+//   S  strain_rates_U at every position of the window (from the PREVIOUS subcycle's face velocities, read from
+//      global memory around the cell itself, averages recomputed as in cg_avg_strain)              -> shearU in LDS
+//   T  stressC_T at the positions with tx, ty >= 1 (shearU of the four corners from LDS)            -> etax2T,
+//      stresspT, stressmT in LDS
+//   C  viscosity at the corners + stressC_U + div_stress + stepu_C / stepv_C on the owned cells (as cg_stress_u_step).
+// Positions outside the owned cells recompute what a neighbouring workgroup also computes, so no workgroup waits
+// for another one; what a workgroup reads of its neighbours is the previous subcycle's state only, which is why
+// uvelE, vvelN, stresspT, stressmT (and stress12U, as before) ping-pong between two buffers.
+//
+// A position is not an array cell: two steps beyond the owned cells of a block the array has ended, and one step
+// beyond them sits a ghost cell whose value in the reference is the copy of another cell's.  The table (built once by
+// the host from the halo plan) gives for every position the cell the reference's value COMES FROM -- the cell itself,
+// the interior cell a ghost cell mirrors (any block of the rank), or, for a ghost cell nothing is copied into (closed
+// boundary, eliminated neighbour block), the ghost cell itself marked "static": its arrays are read, never computed.
+// Level S and T values are computed AT that cell (its own metrics, its own array neighbours, whose ghost cells hold
+// pushed level-0 state), which is bit for bit what the owner stores and the exchange copies.
+// Arrays nothing inside the loop reads any more (shearU, etax2T and the ones listed at the top) are stored in the last
+// subcycle of a call only; stress12T of the extra row / column ihi+1, jhi+1 (ghost cells the reference also computes and
+// no exchange overwrites) is kept up by the workgroup that owns the neighbouring interior cell, with the ghost cell's own
+// metrics and history.
+// =====================================================================
+struct TStress { double zetax2, etax2, sp, sm, shearT; };
+// stressC_T at cell o (ice_dyn_evp.F90:1758-1860) with the four corner values of shearU handed in; spo, smo: previous
+__device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const double *uE, const double *vN, size_t o, double shO,
+                                            double shS, double shSW, double shW, double spo, double smo)
+{
+    const size_t w = o - 1, s = o - A.nx, sw = s - 1;
+    const double *dyE = A.g[CG_DYE], *dxN = A.g[CG_DXN], *uarea = A.g[CG_UAREA];
+    const double dxT = A.g[CG_DXT][o], dyT = A.g[CG_DYT][o];
+    const double divT = dyE[o] * uE[o] - dyE[w] * uE[w] + dxN[o] * vN[o] - dxN[s] * vN[s];
+    const double tensionT = (dyT * dyT) * (uE[o] / dyE[o] - uE[w] / dyE[w]) - (dxT * dxT) * (vN[o] / dxN[o] - vN[s] / dxN[s]);
+    const double uareaavgr = 1.0 / (uarea[o] + uarea[s] + uarea[sw] + uarea[w]);
+    const double shearTsqr = (shO * shO * uarea[o] + shS * shS * uarea[s] + shSW * shSW * uarea[sw] + shW * shW * uarea[w]) * uareaavgr;
+    TStress r;
+    r.shearT = (shO * uarea[o] + shS * uarea[s] + shSW * uarea[sw] + shW * uarea[w]) * uareaavgr;
+    const double DeltaT = sqrt(divT * divT + A.p.e_factor * (tensionT * tensionT + shearTsqr));
+    double rep_prs;
+    visc_replpress(A.p, A.in[CI_STRENGTH][o], A.g[CG_DMINT][o], DeltaT, r.zetax2, r.etax2, rep_prs);
+    const double relax = 1.0 - A.p.arlx1i * A.p.revp;
+    r.sp = (spo * relax + A.p.arlx1i * (r.zetax2 * divT - rep_prs)) * A.p.denom1;
+    r.sm = (smo * relax + A.p.arlx1i * r.etax2 * tensionT) * A.p.denom1;
+    return r;
+}
+
+template <bool FAST, int ONE_X, int ONE_Y>
+__global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, int last)
+{
+    __shared__ double s_sh[ONE_Y][ONE_X], s_un[ONE_Y][ONE_X], s_ve[ONE_Y][ONE_X];
+    __shared__ double s_eta[ONE_Y][ONE_X], s_sp[ONE_Y][ONE_X], s_sm[ONE_Y][ONE_X];
+    // workgroups go to the XCDs round-robin: XCD x gets the x-th contiguous run of the (space-ordered) window list
+    const int t = (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= T.ntiles) return;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int4 tl = T.tiles[t];                          // block, first owned i, first owned j (1-based)
+    const int4 q = A.blk[tl.x];
+    const int i = tl.y - 2 + tx, j = tl.z - 2 + ty;      // the position in the block's own numbering (may lie outside its array)
+    const int lr = T.tab[(size_t)t * (ONE_X * ONE_Y) + ty * ONE_X + tx];
+    const bool stat = lr < 0;
+    const size_t L = (size_t)(stat ? -1 - lr : lr);
+    const unsigned m = A.mask[L];
+    const bool own = tx >= 2 && tx <= ONE_X - 2 && ty >= 2 && ty <= ONE_Y - 2 && i <= q.y && j <= q.w;
+    const double *uE = T.uE_in, *vN = T.vN_in;
+    const double relax = 1.0 - A.p.arlx1i * A.p.revp;
+    const int nx = A.nx;
+
+    // ---- S ----
+    {
+        double sh, delta = 0.0, uNo = 0.0, vEo = 0.0;
+        if (stat) {
+            sh = A.f[CF_SHEARU][L];
+        } else {
+            const size_t o = L, e = o + 1, n = o + nx;
+            const double *ea = A.g[CG_EAREA], *na = A.g[CG_NAREA], *npm = A.g[CG_NPM], *epm = A.g[CG_EPM];
+            StrainIn v;
+            v.uNo = uNo = avg_nw(uE, ea, o, nx) * npm[o];
+            v.vEo = vEo = avg_se(vN, na, o, nx) * epm[o];
+            const double uvm = A.g[CG_UVM][o];
+            v.uU = avg_2(uE, ea, o, n) * uvm;
+            v.vU = avg_2(vN, na, o, e) * uvm;
+            v.uNe = avg_nw(uE, ea, e, nx) * npm[e];
+            v.vEn = avg_se(vN, na, n, nx) * epm[n];
+            v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
+            strain_u(A, o, v, sh, delta);
+            if (!(m & 2u)) sh = A.f[CF_SHEARU][o];       // strain_rates_U leaves cells without ice alone
+            else if (own && last) {
+                A.f[CF_SHEARU][o] = sh;
+                A.f[CF_DELTAU][o] = delta;
+                if (m & 16u) push(A, o, m, CF_SHEARU, sh);
+            }
+        }
+        s_sh[ty][tx] = sh;
+        s_un[ty][tx] = uNo;
+        s_ve[ty][tx] = vEo;
+    }
+    __syncthreads();
+
+    // ---- T ----
+    if (tx >= 1 && ty >= 1) {
+        const double shO = s_sh[ty][tx], shS = s_sh[ty - 1][tx], shSW = s_sh[ty - 1][tx - 1], shW = s_sh[ty][tx - 1];
+        double eta, sp = T.sp_in[L], sm = T.sm_in[L];
+        if (stat || !(m & 1u)) {
+            eta = A.f[CF_ETA][L];
+        } else {
+            const TStress r = t_stress(A, uE, vN, L, shO, shS, shSW, shW, sp, sm);
+            eta = r.etax2; sp = r.sp; sm = r.sm;
+            if (own) {
+                A.f[CF_S12T][L] = (A.f[CF_S12T][L] * relax + A.p.arlx1i * 0.5 * r.etax2 * r.shearT) * A.p.denom1;
+                A.f[CF_SP][L] = sp;
+                A.f[CF_SM][L] = sm;
+                if (last) {
+                    A.f[CF_ZETA][L] = r.zetax2;
+                    A.f[CF_ETA][L] = eta;
+                }
+                if (m & 16u) {
+                    push(A, L, m, CF_SP, sp);
+                    push(A, L, m, CF_SM, sm);
+                    if (last) {
+                        push(A, L, m, CF_ZETA, r.zetax2);
+                        push(A, L, m, CF_ETA, eta);
+                    }
+                }
+            }
+        }
+        s_eta[ty][tx] = eta;
+        s_sp[ty][tx] = sp;
+        s_sm[ty][tx] = sm;
+        // the extra row / column of the reference's T list: ghost cells; only stress12T survives the exchange
+        if ((i == q.y + 1 && j >= q.z && j <= q.w + 1) || (j == q.w + 1 && i >= q.x && i <= q.y)) {
+            const int ii = min(i, q.y), jj = min(j, q.w);
+            if (ii >= tl.y && ii <= tl.y + ONE_X - 4 && jj >= tl.z && jj <= tl.z + ONE_Y - 4) {
+                const size_t g = (size_t)tl.x * A.plane + (size_t)(j - 1) * nx + (i - 1);
+                if (A.mask[g] & 1u) {
+                    const TStress r = t_stress(A, uE, vN, g, shO, shS, shSW, shW, 0.0, 0.0);
+                    A.f[CF_S12T][g] = (A.f[CF_S12T][g] * relax + A.p.arlx1i * 0.5 * r.etax2 * r.shearT) * A.p.denom1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- C ----
+    if (!own) return;
+    {
+        const size_t o = L, e = o + 1, n = o + nx, s = o - nx, w = o - 1;
+        const double *hm = A.g[CG_HM], *ta = A.g[CG_TAREA];
+        // T -> U average of etax2T (avg_t2u) at the corners o, s, w from the values in LDS
+        auto eta_u = [&](size_t p, int px, int py) {
+            const size_t pe = p + 1, pn = p + nx, pne = pn + 1;
+            const double wtmp = (hm[p] * ta[p] + hm[pe] * ta[pe] + hm[pn] * ta[pn] + hm[pne] * ta[pne]);
+            if (wtmp == 0.0) return 0.0;
+            return (hm[p] * s_eta[py][px] * ta[p] + hm[pe] * s_eta[py][px + 1] * ta[pe] + hm[pn] * s_eta[py + 1][px] * ta[pn] +
+                    hm[pne] * s_eta[py + 1][px + 1] * ta[pne]) / wtmp;
+        };
+        auto s12u = [&](size_t p, int px, int py, bool ice, double *etaU) {
+            const double old = A.s12_in[p];
+            const double e2 = eta_u(p, px, py);
+            if (etaU) *etaU = e2;
+            const double upd = (old * relax + A.p.arlx1i * 0.5 * e2 * s_sh[py][px]) * A.p.denom1;
+            return ice ? upd : old;
+        };
+        double etaU;
+        const double s12c = s12u(o, tx, ty, (m & 2u) != 0, &etaU);
+        const double s12s = s12u(s, tx, ty - 1, (A.mask[s] & 32u) != 0, nullptr);
+        const double s12w = s12u(w, tx - 1, ty, (A.mask[w] & 32u) != 0, nullptr);
+        const double spc = s_sp[ty][tx], smc = s_sm[ty][tx];
+        const double spe = s_sp[ty][tx + 1], sme = s_sm[ty][tx + 1], spn = s_sp[ty + 1][tx], smn = s_sm[ty + 1][tx];
+        const EvpScalars &p = A.p;
+        double unew, vnew, strintx, strinty, taubx, tauby;
+        {
+            const double *dyT = A.g[CG_DYT], *dxU = A.g[CG_DXU];
+            const double dyE = A.g[CG_DYE][o], dxE = A.g[CG_DXE][o];
+            strintx = (FAST ? A.g[CG_EAREAR][o] : A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o]) *
+                      (0.5 * dyE * (spe - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sme - (dyT[o] * dyT[o]) * smc) +
+                       (1.0 / dxE) * ((dxU[o] * dxU[o]) * s12c - (dxU[s] * dxU[s]) * s12s));
+            const double uold = uE[o], vold = s_ve[ty][tx];
+            const double uocn = A.in[CI_UOCNE][o];
+            const double du = uocn - uold, dv = A.in[CI_VOCNE][o] - vold;
+            const double vrel = (FAST ? A.facE[o] : A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o]) * sqrt(du * du + dv * dv);
+            const double taux = vrel * (FAST ? uocn : A.in[CI_WATERXE][o]);
+            double Cb = 0.0;
+            if (!FAST) {
+                const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+                Cb = A.in[CI_TBE][o] / ccc;
+            }
+            const double massdti = A.in[CI_EMASSDTI][o], fm = A.in[CI_FME][o];
+            const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
+            const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+            const double cc1 = strintx + A.in[CI_FORCEXE][o] + taux + massdti * (p.brlx * uold + p.revp * A.in[CI_UE_INIT][o]);
+            unew = (ccb * vold + cc1) / cca;
+            taubx = -unew * Cb;
+        }
+        {
+            const double *dxT = A.g[CG_DXT], *dyU = A.g[CG_DYU];
+            const double dxN = A.g[CG_DXN][o], dyN = A.g[CG_DYN][o];
+            strinty = (FAST ? A.g[CG_NAREAR][o] : A.in[CI_RHEON][o] * A.g[CG_NAREAR][o]) *
+                      (0.5 * dxN * (spn - spc) - (0.5 / dxN) * ((dxT[n] * dxT[n]) * smn - (dxT[o] * dxT[o]) * smc) +
+                       (1.0 / dyN) * ((dyU[o] * dyU[o]) * s12c - (dyU[w] * dyU[w]) * s12w));
+            const double uold = s_un[ty][tx], vold = vN[o];
+            const double vocn = A.in[CI_VOCNN][o];
+            const double du = A.in[CI_UOCNN][o] - uold, dv = vocn - vold;
+            const double vrel = (FAST ? A.facN[o] : A.in[CI_AIN][o] * p.rhow * A.in[CI_CWN][o]) * sqrt(du * du + dv * dv);
+            const double tauy = vrel * (FAST ? vocn : A.in[CI_WATERYN][o]);
+            double Cb = 0.0;
+            if (!FAST) {
+                const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+                Cb = A.in[CI_TBN][o] / ccc;
+            }
+            const double massdti = A.in[CI_NMASSDTI][o], fm = A.in[CI_FMN][o];
+            const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
+            const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+            const double cc2 = strinty + A.in[CI_FORCEYN][o] + tauy + massdti * (p.brlx * vold + p.revp * A.in[CI_VN_INIT][o]);
+            vnew = (-ccb * uold + cc2) / cca;
+            tauby = -vnew * Cb;
+        }
+        if (m & 2u) {
+            A.f[CF_S12U][o] = s12c;
+            if (m & 16u) push(A, o, m, CF_S12U, s12c);
+        }
+        if (last) A.f[CF_ETAU][o] = etaU;
+        if (m & 4u) {
+            A.f[CF_UE][o] = unew;
+            if (last) {
+                A.f[CF_STRX][o] = strintx;
+                A.f[CF_TAUBX][o] = taubx;
+            }
+            if (m & 16u) push(A, o, m, CF_UE, unew);
+        }
+        if (m & 8u) {
+            A.f[CF_VN][o] = vnew;
+            if (last) {
+                A.f[CF_STRY][o] = strinty;
+                A.f[CF_TAUBY][o] = tauby;
+            }
+            if (m & 16u) push(A, o, m, CF_VN, vnew);
+        }
+    }
+}
+
 }  // namespace
 
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st)
@@ -750,4 +995,18 @@ void evp_launch_cgrid_deformations(const EvpCgrid &A, const double *tarear, doub
                                    double *rdg_conv, double *rdg_shear, hipStream_t st)
 {
     hipLaunchKernelGGL(cg_deformations_t, cg_grid(A), dim3(TX, TY), 0, st, A, tarear, divu, shear, vort, rdg_conv, rdg_shear);
+}
+
+void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st)
+{
+    const dim3 grid((unsigned)(8 * T.per_xcd)), block(T.ox, T.oy);
+#define CG_ONE(F, X, Y) hipLaunchKernelGGL((cg_one<F, X, Y>), grid, block, 0, st, A, T, last)
+    if (T.ox == 32 && T.oy == 8) {
+        if (fast) CG_ONE(true, 32, 8);
+        else CG_ONE(false, 32, 8);
+    } else {
+        if (fast) CG_ONE(true, 64, 8);
+        else CG_ONE(false, 64, 8);
+    }
+#undef CG_ONE
 }

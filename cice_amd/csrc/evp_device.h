@@ -336,6 +336,17 @@ struct EvpCgrid {
     int tripole;                  // the fold step writes into cells without ice: what the reference re-zeroes every subcycle is re-zeroed
     size_t plane;
 };
+// One launch per subcycle (evp_cgrid.hip: cg_one).  A window = ox x oy positions (one workgroup: 32 x 8 or 64 x 8), the
+// inner (ox-3) x (oy-3) of them owned cells; tab: per window and position the cell whose value the reference has there
+// (>= 0), or -1 - ghost cell for a ghost cell nothing is copied into (its arrays are read, not computed).
+struct EvpCgOne {
+    const int *tab;
+    const int4 *tiles;            // block, first owned i, first owned j (1-based), unused
+    int ntiles, per_xcd;          // windows; windows per XCD (launch = 8 * per_xcd workgroups)
+    int ox, oy;
+    const double *uE_in, *vN_in, *sp_in, *sm_in;   // previous subcycle's buffers (A.f[...] = this subcycle's)
+};
+void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,
 //        4 face->face and face->corner velocity averages, 5 strengthU (once per call), 6 zero what the reference's
 //        whole-array zero fills leave zero outside the interior (uvelN, vvelE, uvel, vvel; once per call)

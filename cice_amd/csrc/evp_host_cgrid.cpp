@@ -25,6 +25,14 @@ struct CGridState {
     bool fast = false;           // the shortcuts of cg_stress_u_step<true> hold on every ice cell of this call
     double *s12alt = nullptr;    // second stress12U buffer of the fused schedule (f[CF_S12U] always holds the current one)
     int flip = 0;                // which of the two allocations f[CF_S12U] is (part of the graph key)
+    // one launch per subcycle (evp_cgrid.hip: cg_one): window table, second buffers of uvelE, vvelN, stresspT, stressmT
+    struct One {
+        int *tab = nullptr;
+        int4 *tiles = nullptr;
+        int ntiles = 0, per_xcd = 0, ox = 0, oy = 0;
+        double *alt[4] = {};
+        int flip = 0;            // which allocation f[CF_UE], f[CF_VN], f[CF_SP], f[CF_SM] are (part of the graph key)
+    } one;
     uint8_t *mask = nullptr;
     int *img_slot = nullptr, *img_dst = nullptr;
     // tripole fold: per field location the cells of the fold row / the ghost row beyond it and their sources
@@ -41,6 +49,7 @@ struct CGridState {
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (ndte, flip << 3 | fused << 2 | first << 1 | avg_strength)
     double t_loop_ms = 0;
     int t_nsub = 0;
+    int t_one = 0;               // subcycles of the last call that ran as one launch each (cg_one)
     double *tarear = nullptr, *post[5] = {};   // deformationsC_T: 1/tarea (static), divu shear vort rdg_conv rdg_shear
     // preparation phase on the device (cice_evp_hip_cgrid_prep)
     struct Prep {
@@ -69,6 +78,8 @@ void cgrid_free()
     for (auto &p : CG.in) F(p);
     for (auto &p : CG.g) F(p);
     F(CG.tarear); for (auto &p : CG.post) F(p);
+    F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
+    CG.one = CGridState::One{};
     {
         CGridState::Prep &Q = CG.prep;
         F(Q.tmask); for (auto &p : Q.xmask) F(p);
@@ -186,11 +197,31 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
     return 0;
 }
 
+// one launch per subcycle (cg_one) for every subcycle but the first after an upload (which still reads the caller's
+// uvelN, vvelE, uvel, vvel): one rank, no fold, and a grid small enough to be latency-bound -- measured:
+// gx3 12.9 -> 10.2, 300x240 18.1 -> 14.1, gx1 23.2 -> 18.9 us per subcycle, even at 720x270, slower from 720x540 on
+// (the recomputed positions cost more than the two launches saved).  CICE_EVP_HIP_CGRID_ONE=0 / 1 switches it off / on
+// regardless of size
+static const int ONE_FIELDS[4] = {CF_UE, CF_VN, CF_SP, CF_SM};
+static bool one_launch()
+{
+    if (!CG.one.tab || remote()) return false;
+    if (const char *e = env("CICE_EVP_HIP_CGRID_ONE")) return std::atoi(e) != 0;
+    return S.n <= 160000;
+}
+static int one_subcycles(int ndte, bool first) { return one_launch() ? ndte - (first ? 1 : 0) : 0; }
+
 // three launches per subcycle + one after the loop (evp_cgrid.hip); stress12U ping-pongs, returns with the
 // current values in `cur` (the caller swaps the pointers when ndte is odd)
 static int enqueue_fused(EvpCgrid A, int ndte, bool first)
 {
     double *cur = CG.f[CF_S12U], *other = CG.s12alt;
+    const bool one = one_launch();
+    double *c4[4], *o4[4];
+    for (int q = 0; q < 4; ++q) {
+        c4[q] = CG.f[ONE_FIELDS[q]];
+        o4[q] = CG.one.alt[q];
+    }
     if (first) {
         // the caller's ghost cells of stress12U are whatever dyn_prep left there (zero: iceUmask is never set on
         // ghost cells, ice_dyn_evp.F90:683-690); the reference repairs them with the first halo update, the fused
@@ -204,6 +235,16 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
     for (int k = 0; k < ndte; ++k) {
         const int last = (k == ndte - 1);
         A.f[CF_S12U] = cur;
+        if (one && !(first && k == 0)) {
+            EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy, c4[0], c4[1], c4[2], c4[3]};
+            for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
+            A.s12_in = cur;
+            A.f[CF_S12U] = other;
+            evp_launch_cgrid_one(A, T, CG.fast ? 1 : 0, last, S.stream);
+            std::swap(cur, other);
+            for (int q = 0; q < 4; ++q) std::swap(c4[q], o4[q]);
+            continue;
+        }
         if (first && k == 0) {
             evp_launch_cgrid_phase(A, 0, 1, S.stream);
             evp_launch_cgrid_phase(A, 6, 1, S.stream);
@@ -220,8 +261,12 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         XCHG(other, other);
         XCHG(A.f[CF_UE], A.f[CF_VN]);
         std::swap(cur, other);
+        if (one && first && k == 0)          // cells no subcycle writes (no ice, ghost cells nothing is copied into): the same in both buffers
+            for (int q = 0; q < 4; ++q)
+                HIPC(hipMemcpyAsync(o4[q], c4[q], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
     }
     A.f[CF_S12U] = cur;
+    for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = c4[q];
     evp_launch_cgrid_phase(A, 4, 1, S.stream);
     XCHG(A.f[CF_UN], A.f[CF_VE]);
     XCHG(A.f[CF_UU], A.f[CF_VU]);
@@ -255,6 +300,59 @@ static int build_fold_lists()
         HIPC(hipMemcpy(Fd.flip, flip.data(), dst.size(), hipMemcpyHostToDevice));
     }
     if (CG.fold_maxn) HIPC(hipMalloc((void **)&CG.fold_tmp, (size_t)4 * CG.fold_maxn * sizeof(double)));
+    return 0;
+}
+
+// Window table of the one-launch kernel: for every position of every window the cell whose value the reference has
+// there.  Within one cell of the owned range that is the array cell itself -- interior cell, or the interior cell a ghost
+// cell mirrors (halo plan), or the ghost cell marked static (nothing is copied into it); further out the walk goes on
+// from the mirrored cell, neighbour by neighbour.
+static int build_one_tables()
+{
+    const HaloPlan &P = S.plan;
+    // the window: the smaller one where there are too few cells to give every CU a workgroup otherwise
+    // (CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 picks 32x8 / 64x8)
+    int shape = S.n <= 40000 ? 0 : 1;
+    if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::atoi(e) != 0;
+    const int nxb = S.d.nx_block, OX = shape ? 64 : 32, OY = 8;
+    std::vector<int> owner(S.n, -1);
+    for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
+    auto canon = [&](long c) -> long {
+        const int b = (int)(c / (long)S.plane);
+        const long r = c % (long)S.plane;
+        const int j = (int)(r / nxb) + 1, i = (int)(r % nxb) + 1;
+        if (i >= S.ilo[b] && i <= S.ihi[b] && j >= S.jlo[b] && j <= S.jhi[b]) return c;
+        return owner[c] >= 0 ? (long)owner[c] : -1 - c;
+    };
+    std::vector<int> tab;
+    std::vector<int4> tiles;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        for (int j0 = S.jlo[b]; j0 <= S.jhi[b]; j0 += OY - 3)
+            for (int i0 = S.ilo[b]; i0 <= S.ihi[b]; i0 += OX - 3) {
+                tiles.push_back(make_int4(b, i0, j0, 0));
+                for (int ty = 0; ty < OY; ++ty)
+                    for (int tx = 0; tx < OX; ++tx) {
+                        const int i = i0 - 2 + tx, j = j0 - 2 + ty;
+                        const int ic = std::min(std::max(i, S.ilo[b] - 1), S.ihi[b] + 1);
+                        const int jc = std::min(std::max(j, S.jlo[b] - 1), S.jhi[b] + 1);
+                        long r = canon((long)b * (long)S.plane + (long)(jc - 1) * nxb + (ic - 1));
+                        for (int dx = i - ic; dx != 0 && r >= 0; dx -= (dx > 0 ? 1 : -1)) r = canon(r + (dx > 0 ? 1 : -1));
+                        for (int dy = j - jc; dy != 0 && r >= 0; dy -= (dy > 0 ? 1 : -1)) r = canon(r + (dy > 0 ? nxb : -nxb));
+                        tab.push_back((int)r);
+                    }
+            }
+    CGridState::One &O = CG.one;
+    O.ntiles = (int)tiles.size();
+    O.ox = OX;
+    O.oy = OY;
+    O.per_xcd = (O.ntiles + 7) / 8;
+    HIPC(hipMalloc((void **)&O.tab, tab.size() * sizeof(int)));
+    HIPC(hipMalloc((void **)&O.tiles, tiles.size() * sizeof(int4)));
+    HIPC(hipMemcpyAsync(O.tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(O.tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, S.stream));
+    for (auto &p : O.alt)
+        if (alloc_d(&p, S.n)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));       // (the host vectors go out of scope)
     return 0;
 }
 
@@ -323,6 +421,8 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
     if (tripole && P.fold_rows == 1)             // (ranks without the fold rows run the same schedule with empty lists)
         if (int rc = build_fold_lists()) return rc;
+    if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3)
+        if (int rc = build_one_tables()) return rc;
     CG.n_zero = (int)zero.size();
     if (CG.n_zero) {
         HIPC(hipMalloc((void **)&CG.zero_cells, zero.size() * sizeof(int)));
@@ -419,7 +519,8 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     };
     HIPC(hipEventRecord(S.ev0, S.stream));
     if (S.use_graph && (!remote() || S.direct.on)) {     // RCCL point-to-point is enqueued eagerly (as the B-grid loop does)
-        const std::pair<int, int> key(ndte, (CG.fast ? 16 : 0) | (CG.flip << 3) | (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
+        const std::pair<int, int> key(ndte, (fused && one_launch() ? 64 : 0) | (CG.one.flip << 5) | (CG.fast ? 16 : 0) | (CG.flip << 3) |
+                                                (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
         auto it = CG.graphs.find(key);
         if (it == CG.graphs.end()) {
             hipGraph_t gr = nullptr;
@@ -440,8 +541,13 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
         std::swap(CG.f[CF_S12U], CG.s12alt);
         CG.flip ^= 1;
     }
+    if (fused && (one_subcycles(ndte, CG.first) & 1)) {      // and so are uvelE, vvelN, stresspT, stressmT
+        for (int q = 0; q < 4; ++q) std::swap(CG.f[ONE_FIELDS[q]], CG.one.alt[q]);
+        CG.one.flip ^= 1;
+    }
     HIPC(hipEventRecord(S.ev1, S.stream));
     HIPC(hipGetLastError());
+    CG.t_one = fused ? one_subcycles(ndte, CG.first) : 0;
     CG.first = false;
     CG.t_nsub = ndte;
     return 0;
@@ -754,6 +860,7 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     out[0] = CG.t_loop_ms;
     out[1] = (double)CG.t_nsub;
     if (n >= 3) out[2] = CG.prep.t_ms;           // device time of the last cice_evp_hip_cgrid_prep (kernels, without the copies)
+    if (n >= 4) out[3] = (double)CG.t_one;       // subcycles of the last call run as one launch each
     return 0;
 }
 

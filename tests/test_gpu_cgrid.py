@@ -187,6 +187,40 @@ def test_cgrid_both_schedules_agree(monkeypatch):
         core.finalize()
 
 
+@pytest.mark.parametrize("name", ["cgrid_cyccyc_2x2_cap0_ktens", "cgrid_closed_2x2_revp", "cgrid_cyc_2x2_patchy",
+                                  "cgrid_cyc_1blk_seabed"])
+@pytest.mark.parametrize("one", ["0", "1"])
+def test_cgrid_one_launch_schedule_agrees(name, one, monkeypatch):
+    """One launch per subcycle (cg_one: three levels in one workgroup, neighbours recomputed, five arrays ping-pong)
+    against the three-launch form of the fused schedule, both pinned on the reference's arrays -- in one call and in
+    split calls with odd counts (the buffers change roles between calls)."""
+    c = GoldenCase(name)
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE", one)
+    core = cgrid_core(c)
+    try:
+        state, inputs, masks = c.cgrid_inputs(1)
+        dom = c.oracle_domain()
+        nsub = max(c.nsub_list)
+        out = core.cgrid_run(nsub, state, inputs, masks)
+        t = core.cgrid_timings()
+        assert t["one_launch_subcycles"] == ((nsub - 1) if one == "1" else 0), t
+        oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+        oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+        assert_bitwise(out, c.cgrid_expected(1, nsub), f"CICE_EVP_HIP_CGRID_ONE={one} nsub {nsub}")
+        core.cgrid_upload(state, inputs, masks)
+        done = 0
+        for k in (1, 3, 2, nsub - 6):
+            core.cgrid_subcycle(k)
+            done += k
+        assert done == nsub
+        out = core.cgrid_download()
+        oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+        oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+        assert_bitwise(out, c.cgrid_expected(1, nsub), f"CICE_EVP_HIP_CGRID_ONE={one} split calls")
+    finally:
+        core.finalize()
+
+
 def random_cgrid_case(seed, nx, ny, bs, ew, ns, holes):
     """Arbitrary (not physical) operands: random positive lengths / areas, random velocities, stresses and forcing,
     and -- the point -- random, mutually independent ice masks with holes, so that every mask-dependent branch of
