@@ -56,6 +56,7 @@ CHECKPOINTS = [1, 3, 5, 12, 23, 25, 50]     # total steps after which tests/gold
 VERIFY_FIELDS = ("uvel", "vvel", "stressp_1")
 CGRID_VERIFY_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")   # tests/golden/make_bench_checksums.py
 CGRID_B_ALG = 648.0      # C grid: 81 fp64 array touches per cell and subcycle in the fused schedule
+CGRID_B_ALG_ONE = 408.0  # ... 51 in the one-launch kernel (cg_one: the default up to 600k cells, one rank, no fold)
 
 
 def parse():
@@ -502,6 +503,7 @@ def main():
                 core.cgrid_sync()
                 ev_ms += core.cgrid_timings()["loop_ms"]
             wall = time.perf_counter() - t0
+            one = core.cgrid_timings()["one_launch_subcycles"] > 0
             out = core.cgrid_download()
         finally:
             core.finalize()
@@ -509,9 +511,9 @@ def main():
         for k in CGRID_VERIFY_FIELDS:
             h.update(np.ascontiguousarray(dc.gather({0: out[k]}), dtype="<f8").tobytes())
         want = golden.get(f"cgrid/{workload}/{case}/ndte{ndte}/closed/strict", {}).get(str(warmup + steps))
-        launches = 3                              # fused schedule (evp_cgrid.hip): kernels per subcycle
+        launches = 1 if one else 3                # cg_one / the fused schedule (evp_cgrid.hip): kernels per subcycle
         t_sub = ev_ms * 1e-3 / (steps * ndte)
-        alg = CGRID_B_ALG * nx * ny
+        alg = (CGRID_B_ALG_ONE if one else CGRID_B_ALG) * nx * ny
         return {"workload": f"{workload} {nx}x{ny} C-grid EVP ndte={ndte}, case={case}, strict fp64, one GPU",
                 "value": nx * ny * ndte * steps / wall, "unit": "cell-updates/s", "steps": steps, "warmup": warmup,
                 "us_per_subcycle": 1e6 * t_sub, "us_per_subcycle_wall": 1e6 * wall / (steps * ndte),
@@ -521,8 +523,10 @@ def main():
                 "finite": bool(np.isfinite(out["uvelE"]).all()), "max_abs_uE": float(np.abs(out["uvelE"]).max()),
                 "roofline": {"bound": "hbm", "achieved": alg / t_sub / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / t_sub / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_subcycle": alg,
-                             "note": "648 B per cell and subcycle = 81 fp64 array touches of the three fused kernels "
-                                     "(DESIGN.md section 9); on gx1 the 64 MB working set is Infinity-Cache resident"}}
+                             "note": ("408 B per cell and subcycle = 51 fp64 array touches of the one-launch kernel cg_one "
+                                      "(shearU, etax2T and the T-cell stresses stay in LDS between its three levels)" if one else
+                                      "648 B per cell and subcycle = 81 fp64 array touches of the three fused kernels") +
+                                     " (DESIGN.md section 9); on gx1 the 64 MB working set is Infinity-Cache resident"}}
 
     def cgrid_per_call(workload, case, ndte):
         """What a C-grid host waits for per evp() call, two ways: its own preparation + cice_evp_hip_cgrid_run (14 state +

@@ -97,13 +97,14 @@ __device__ __forceinline__ Cell cell(const EvpCgrid &A)
 struct StrainIn {
     double uNo, uNe, vEo, vEn, uEo, uEn, vNo, vNe, uU, vU;
 };
-__device__ __forceinline__ void strain_u(const EvpCgrid &A, size_t o, const StrainIn &v, double &sh, double &delta)
+template <class GT>
+__device__ __forceinline__ void strain_u(const EvpCgrid &A, const GT &G, size_t o, const StrainIn &v, double &sh, double &delta)
 {
     const size_t e = o + 1, n = o + A.nx;
-    const double *epm = A.g[CG_EPM], *npm = A.g[CG_NPM];
-    const double dxU = A.g[CG_DXU][o], dyU = A.g[CG_DYU][o];
-    const double ddyN = A.g[CG_DYN][e] - A.g[CG_DYN][o], ddxE = A.g[CG_DXE][n] - A.g[CG_DXE][o];
-    const double rxN = A.g[CG_RXN][o], rxNr = A.g[CG_RXNR][o], ryE = A.g[CG_RYE][o], ryEr = A.g[CG_RYER][o];
+    const double *epm = G[CG_EPM], *npm = G[CG_NPM];
+    const double dxU = G[CG_DXU][o], dyU = G[CG_DYU][o];
+    const double ddyN = G[CG_DYN][e] - G[CG_DYN][o], ddxE = G[CG_DXE][n] - G[CG_DXE][o];
+    const double rxN = G[CG_RXN][o], rxNr = G[CG_RXNR][o], ryE = G[CG_RYE][o], ryEr = G[CG_RYER][o];
     const double npc = npm[o], npe = npm[e], epc = epm[o], epn = epm[n];
     const double uNip1j = v.uNe * npe + (npc - npe) * npc * rxN * v.uNo;
     const double uNij = v.uNo * npc + (npe - npc) * npe * rxNr * v.uNe;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(TX *TY) void cg_avg_strain(EvpCgrid A, int last)
     v.vEn = avg_se(vN, na, n, A.nx) * epm[n];
     v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
     double sh, delta;
-    strain_u(A, o, v, sh, delta);
+    strain_u(A, A.g, o, v, sh, delta);
     if (!(m & 2u)) return;
     A.f[CF_SHEARU][o] = sh;
     if (last) A.f[CF_DELTAU][o] = delta;
@@ -706,14 +707,21 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 // no exchange overwrites) is kept up by the workgroup that owns the neighbouring interior cell, with the ghost cell's own
 // metrics and history.
 // =====================================================================
+// array k of a table that is one allocation: base + k * stride (a scalar multiply-add where it is used, instead of
+// one kernel-argument pointer per array held in scalar registers from the top of the kernel)
+struct Slab {
+    const double *base;
+    size_t stride;
+    __device__ __forceinline__ const double *operator[](int k) const { return base + (size_t)k * stride; }
+};
 struct TStress { double zetax2, etax2, sp, sm, shearT; };
 // stressC_T at cell o (ice_dyn_evp.F90:1758-1860) with the four corner values of shearU handed in; spo, smo: previous
-__device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const double *uE, const double *vN, size_t o, double shO,
-                                            double shS, double shSW, double shW, double spo, double smo)
+__device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const Slab &G, const Slab &IN, const double *uE, const double *vN, size_t o,
+                                            double shO, double shS, double shSW, double shW, double spo, double smo)
 {
     const size_t w = o - 1, s = o - A.nx, sw = s - 1;
-    const double *dyE = A.g[CG_DYE], *dxN = A.g[CG_DXN], *uarea = A.g[CG_UAREA];
-    const double dxT = A.g[CG_DXT][o], dyT = A.g[CG_DYT][o];
+    const double *dyE = G[CG_DYE], *dxN = G[CG_DXN], *uarea = G[CG_UAREA];
+    const double dxT = G[CG_DXT][o], dyT = G[CG_DYT][o];
     const double divT = dyE[o] * uE[o] - dyE[w] * uE[w] + dxN[o] * vN[o] - dxN[s] * vN[s];
     const double tensionT = (dyT * dyT) * (uE[o] / dyE[o] - uE[w] / dyE[w]) - (dxT * dxT) * (vN[o] / dxN[o] - vN[s] / dxN[s]);
     const double uareaavgr = 1.0 / (uarea[o] + uarea[s] + uarea[sw] + uarea[w]);
@@ -722,7 +730,7 @@ __device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const double *uE,
     r.shearT = (shO * uarea[o] + shS * uarea[s] + shSW * uarea[sw] + shW * uarea[w]) * uareaavgr;
     const double DeltaT = sqrt(divT * divT + A.p.e_factor * (tensionT * tensionT + shearTsqr));
     double rep_prs;
-    visc_replpress(A.p, A.in[CI_STRENGTH][o], A.g[CG_DMINT][o], DeltaT, r.zetax2, r.etax2, rep_prs);
+    visc_replpress(A.p, IN[CI_STRENGTH][o], G[CG_DMINT][o], DeltaT, r.zetax2, r.etax2, rep_prs);
     const double relax = 1.0 - A.p.arlx1i * A.p.revp;
     r.sp = (spo * relax + A.p.arlx1i * (r.zetax2 * divT - rep_prs)) * A.p.denom1;
     r.sm = (smo * relax + A.p.arlx1i * r.etax2 * tensionT) * A.p.denom1;
@@ -747,6 +755,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     const unsigned m = A.mask[L];
     const bool own = tx >= 2 && tx <= ONE_X - 2 && ty >= 2 && ty <= ONE_Y - 2 && i <= q.y && j <= q.w;
     const double *uE = T.uE_in, *vN = T.vN_in;
+    const Slab G{T.gbase, T.stride}, IN{T.inbase, T.stride};
     const double relax = 1.0 - A.p.arlx1i * A.p.revp;
     const int nx = A.nx;
 
@@ -757,17 +766,17 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             sh = A.f[CF_SHEARU][L];
         } else {
             const size_t o = L, e = o + 1, n = o + nx;
-            const double *ea = A.g[CG_EAREA], *na = A.g[CG_NAREA], *npm = A.g[CG_NPM], *epm = A.g[CG_EPM];
+            const double *ea = G[CG_EAREA], *na = G[CG_NAREA], *npm = G[CG_NPM], *epm = G[CG_EPM];
             StrainIn v;
             v.uNo = uNo = avg_nw(uE, ea, o, nx) * npm[o];
             v.vEo = vEo = avg_se(vN, na, o, nx) * epm[o];
-            const double uvm = A.g[CG_UVM][o];
+            const double uvm = G[CG_UVM][o];
             v.uU = avg_2(uE, ea, o, n) * uvm;
             v.vU = avg_2(vN, na, o, e) * uvm;
             v.uNe = avg_nw(uE, ea, e, nx) * npm[e];
             v.vEn = avg_se(vN, na, n, nx) * epm[n];
             v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
-            strain_u(A, o, v, sh, delta);
+            strain_u(A, G, o, v, sh, delta);
             if (!(m & 2u)) sh = A.f[CF_SHEARU][o];       // strain_rates_U leaves cells without ice alone
             else if (own && last) {
                 A.f[CF_SHEARU][o] = sh;
@@ -788,7 +797,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         if (stat || !(m & 1u)) {
             eta = A.f[CF_ETA][L];
         } else {
-            const TStress r = t_stress(A, uE, vN, L, shO, shS, shSW, shW, sp, sm);
+            const TStress r = t_stress(A, G, IN, uE, vN, L, shO, shS, shSW, shW, sp, sm);
             eta = r.etax2; sp = r.sp; sm = r.sm;
             if (own) {
                 A.f[CF_S12T][L] = (A.f[CF_S12T][L] * relax + A.p.arlx1i * 0.5 * r.etax2 * r.shearT) * A.p.denom1;
@@ -817,7 +826,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             if (ii >= tl.y && ii <= tl.y + ONE_X - 4 && jj >= tl.z && jj <= tl.z + ONE_Y - 4) {
                 const size_t g = (size_t)tl.x * A.plane + (size_t)(j - 1) * nx + (i - 1);
                 if (A.mask[g] & 1u) {
-                    const TStress r = t_stress(A, uE, vN, g, shO, shS, shSW, shW, 0.0, 0.0);
+                    const TStress r = t_stress(A, G, IN, uE, vN, g, shO, shS, shSW, shW, 0.0, 0.0);
                     A.f[CF_S12T][g] = (A.f[CF_S12T][g] * relax + A.p.arlx1i * 0.5 * r.etax2 * r.shearT) * A.p.denom1;
                 }
             }
@@ -829,7 +838,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     if (!own) return;
     {
         const size_t o = L, e = o + 1, n = o + nx, s = o - nx, w = o - 1;
-        const double *hm = A.g[CG_HM], *ta = A.g[CG_TAREA];
+        const double *hm = G[CG_HM], *ta = G[CG_TAREA];
         // T -> U average of etax2T (avg_t2u) at the corners o, s, w from the values in LDS
         auto eta_u = [&](size_t p, int px, int py) {
             const size_t pe = p + 1, pn = p + nx, pne = pn + 1;
@@ -854,48 +863,48 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         const EvpScalars &p = A.p;
         double unew, vnew, strintx, strinty, taubx, tauby;
         {
-            const double *dyT = A.g[CG_DYT], *dxU = A.g[CG_DXU];
-            const double dyE = A.g[CG_DYE][o], dxE = A.g[CG_DXE][o];
-            strintx = (FAST ? A.g[CG_EAREAR][o] : A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o]) *
+            const double *dyT = G[CG_DYT], *dxU = G[CG_DXU];
+            const double dyE = G[CG_DYE][o], dxE = G[CG_DXE][o];
+            strintx = (FAST ? G[CG_EAREAR][o] : IN[CI_RHEOE][o] * G[CG_EAREAR][o]) *
                       (0.5 * dyE * (spe - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sme - (dyT[o] * dyT[o]) * smc) +
                        (1.0 / dxE) * ((dxU[o] * dxU[o]) * s12c - (dxU[s] * dxU[s]) * s12s));
             const double uold = uE[o], vold = s_ve[ty][tx];
-            const double uocn = A.in[CI_UOCNE][o];
-            const double du = uocn - uold, dv = A.in[CI_VOCNE][o] - vold;
-            const double vrel = (FAST ? A.facE[o] : A.in[CI_AIE][o] * p.rhow * A.in[CI_CWE][o]) * sqrt(du * du + dv * dv);
-            const double taux = vrel * (FAST ? uocn : A.in[CI_WATERXE][o]);
+            const double uocn = IN[CI_UOCNE][o];
+            const double du = uocn - uold, dv = IN[CI_VOCNE][o] - vold;
+            const double vrel = (FAST ? A.facE[o] : IN[CI_AIE][o] * p.rhow * IN[CI_CWE][o]) * sqrt(du * du + dv * dv);
+            const double taux = vrel * (FAST ? uocn : IN[CI_WATERXE][o]);
             double Cb = 0.0;
             if (!FAST) {
                 const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
-                Cb = A.in[CI_TBE][o] / ccc;
+                Cb = IN[CI_TBE][o] / ccc;
             }
-            const double massdti = A.in[CI_EMASSDTI][o], fm = A.in[CI_FME][o];
+            const double massdti = IN[CI_EMASSDTI][o], fm = IN[CI_FME][o];
             const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
             const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
-            const double cc1 = strintx + A.in[CI_FORCEXE][o] + taux + massdti * (p.brlx * uold + p.revp * A.in[CI_UE_INIT][o]);
+            const double cc1 = strintx + IN[CI_FORCEXE][o] + taux + massdti * (p.brlx * uold + p.revp * IN[CI_UE_INIT][o]);
             unew = (ccb * vold + cc1) / cca;
             taubx = -unew * Cb;
         }
         {
-            const double *dxT = A.g[CG_DXT], *dyU = A.g[CG_DYU];
-            const double dxN = A.g[CG_DXN][o], dyN = A.g[CG_DYN][o];
-            strinty = (FAST ? A.g[CG_NAREAR][o] : A.in[CI_RHEON][o] * A.g[CG_NAREAR][o]) *
+            const double *dxT = G[CG_DXT], *dyU = G[CG_DYU];
+            const double dxN = G[CG_DXN][o], dyN = G[CG_DYN][o];
+            strinty = (FAST ? G[CG_NAREAR][o] : IN[CI_RHEON][o] * G[CG_NAREAR][o]) *
                       (0.5 * dxN * (spn - spc) - (0.5 / dxN) * ((dxT[n] * dxT[n]) * smn - (dxT[o] * dxT[o]) * smc) +
                        (1.0 / dyN) * ((dyU[o] * dyU[o]) * s12c - (dyU[w] * dyU[w]) * s12w));
             const double uold = s_un[ty][tx], vold = vN[o];
-            const double vocn = A.in[CI_VOCNN][o];
-            const double du = A.in[CI_UOCNN][o] - uold, dv = vocn - vold;
-            const double vrel = (FAST ? A.facN[o] : A.in[CI_AIN][o] * p.rhow * A.in[CI_CWN][o]) * sqrt(du * du + dv * dv);
-            const double tauy = vrel * (FAST ? vocn : A.in[CI_WATERYN][o]);
+            const double vocn = IN[CI_VOCNN][o];
+            const double du = IN[CI_UOCNN][o] - uold, dv = vocn - vold;
+            const double vrel = (FAST ? A.facN[o] : IN[CI_AIN][o] * p.rhow * IN[CI_CWN][o]) * sqrt(du * du + dv * dv);
+            const double tauy = vrel * (FAST ? vocn : IN[CI_WATERYN][o]);
             double Cb = 0.0;
             if (!FAST) {
                 const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
-                Cb = A.in[CI_TBN][o] / ccc;
+                Cb = IN[CI_TBN][o] / ccc;
             }
-            const double massdti = A.in[CI_NMASSDTI][o], fm = A.in[CI_FMN][o];
+            const double massdti = IN[CI_NMASSDTI][o], fm = IN[CI_FMN][o];
             const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
             const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
-            const double cc2 = strinty + A.in[CI_FORCEYN][o] + tauy + massdti * (p.brlx * vold + p.revp * A.in[CI_VN_INIT][o]);
+            const double cc2 = strinty + IN[CI_FORCEYN][o] + tauy + massdti * (p.brlx * vold + p.revp * IN[CI_VN_INIT][o]);
             vnew = (-ccb * uold + cc2) / cca;
             tauby = -vnew * Cb;
         }

@@ -345,6 +345,8 @@ struct EvpCgOne {
     int ntiles, per_xcd;          // windows; windows per XCD (launch = 8 * per_xcd workgroups)
     int ox, oy;
     const double *uE_in, *vN_in, *sp_in, *sm_in;   // previous subcycle's buffers (A.f[...] = this subcycle's)
+    const double *gbase, *inbase; // the static and the per-call tables as one allocation each: array k = base + k * stride
+    size_t stride;                // (70 pointers as kernel arguments do not fit the scalar registers)
 };
 void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,

@@ -18,6 +18,7 @@ namespace evp_host {
 struct CGridState {
     bool geo = false, uploaded = false;
     double *f[CG_NF] = {}, *in[CG_NIN] = {}, *g[CG_NG] = {};
+    double *gslab = nullptr, *inslab = nullptr;   // g[k] = gslab + k * n, in[k] = inslab + k * n: one allocation per table (cg_one addresses them as base + k * stride)
     double *strengthU = nullptr;
     double *umaskd = nullptr;    // ranks > 1: iceU as a field, to learn the flags of ghost cells other ranks own
     double *fac[2] = {nullptr, nullptr};   // leading factor of vrel at E / N (once per call)
@@ -75,8 +76,9 @@ void cgrid_free()
         p = nullptr;
     };
     for (auto &p : CG.f) F(p);
-    for (auto &p : CG.in) F(p);
-    for (auto &p : CG.g) F(p);
+    F(CG.gslab); F(CG.inslab);
+    for (auto &p : CG.in) p = nullptr;
+    for (auto &p : CG.g) p = nullptr;
     F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
     CG.one = CGridState::One{};
@@ -198,8 +200,9 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 }
 
 // one launch per subcycle (cg_one) for every subcycle but the first after an upload (which still reads the caller's
-// uvelN, vvelE, uvel, vvel): one rank, no fold, and a grid small enough to be latency-bound -- measured:
-// gx3 12.9 -> 10.2, 300x240 18.1 -> 14.1, gx1 23.2 -> 18.9 us per subcycle, even at 720x270, slower from 720x540 on
+// uvelN, vvelE, uvel, vvel): one rank, no fold, and a grid on which the three launches are latency- rather than
+// bandwidth-bound -- measured, us per subcycle, three launches -> one: gx3 12.9 -> 10.0, 300x240 18.1 -> 13.5,
+// gx1 23.2 -> 18.1, 720x270 30.3 -> 25.8, 720x540 49.0 -> 42.1; 1440x1080 205.9 -> 212.6 and 3600x2400 1059 -> 1182
 // (the recomputed positions cost more than the two launches saved).  CICE_EVP_HIP_CGRID_ONE=0 / 1 switches it off / on
 // regardless of size
 static const int ONE_FIELDS[4] = {CF_UE, CF_VN, CF_SP, CF_SM};
@@ -207,7 +210,7 @@ static bool one_launch()
 {
     if (!CG.one.tab || remote()) return false;
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE")) return std::atoi(e) != 0;
-    return S.n <= 160000;
+    return S.n <= 600000;
 }
 static int one_subcycles(int ndte, bool first) { return one_launch() ? ndte - (first ? 1 : 0) : 0; }
 
@@ -236,7 +239,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         const int last = (k == ndte - 1);
         A.f[CF_S12U] = cur;
         if (one && !(first && k == 0)) {
-            EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy, c4[0], c4[1], c4[2], c4[3]};
+            EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n};
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
@@ -310,9 +313,9 @@ static int build_fold_lists()
 static int build_one_tables()
 {
     const HaloPlan &P = S.plan;
-    // the window: the smaller one where there are too few cells to give every CU a workgroup otherwise
-    // (CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 picks 32x8 / 64x8)
-    int shape = S.n <= 40000 ? 0 : 1;
+    // the window: 64x8 where it gives every CU one or two workgroups (gx1: 462), 32x8 on smaller grids (more
+    // workgroups) and on larger ones (more of them resident per CU); CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 picks 32x8 / 64x8
+    int shape = (S.n > 40000 && S.n <= 160000) ? 1 : 0;
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::atoi(e) != 0;
     const int nxb = S.d.nx_block, OX = shape ? 64 : 32, OY = 8;
     std::vector<int> owner(S.n, -1);
@@ -378,11 +381,12 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     CG.tripole = tripole;
     for (auto &p : CG.f)
         if (alloc_d(&p, S.n)) return -1;
-    for (auto &p : CG.in)
-        if (alloc_d(&p, S.n)) return -1;
+    if (alloc_d(&CG.inslab, (size_t)CG_NIN * S.n) || alloc_d(&CG.gslab, (size_t)CG_NG * S.n)) return -1;
+    for (int k = 0; k < CG_NIN; ++k) CG.in[k] = CG.inslab + (size_t)k * S.n;
     for (int k = 0; k < CG_NG; ++k) {
         if (!static23[k]) return fail(-1, "null static array %d", k);
-        if (alloc_d(&CG.g[k], S.n) || h2d(CG.g[k], static23[k])) return -1;
+        CG.g[k] = CG.gslab + (size_t)k * S.n;
+        if (h2d(CG.g[k], static23[k])) return -1;
     }
     if (alloc_d(&CG.strengthU, S.n) || alloc_d(&CG.s12alt, S.n) || alloc_d(&CG.fac[0], S.n) || alloc_d(&CG.fac[1], S.n)) return -1;
     HIPC(hipMalloc((void **)&CG.d_flags, sizeof(unsigned)));

@@ -28,6 +28,7 @@ GRIDS = {
     # the on-chip resident kernel holds (tools/selfx_timing.py: where does the riding exchange pay?)
     "q8": dict(nx=720, ny=270, dx0=2.8e4, ns="closed"),
     "q4": dict(nx=720, ny=540, dx0=2.8e4, ns="closed"),
+    "q1": dict(nx=1440, ny=1080, dx0=2.8e4, ns="closed"),    # the whole 0.25-degree class grid
     # 320 tiles of 16x16: every CU holds one or two tiles of the on-chip resident kernel (pace of a SIMD with two waves)
     "p2": dict(nx=300, ny=240, dx0=1.1e5, ns="closed"),
 }
