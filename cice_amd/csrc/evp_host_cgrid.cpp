@@ -169,6 +169,17 @@ static bool fused_schedule()
     return !(env("CICE_EVP_HIP_CGRID_FUSED") && !std::atoi(env("CICE_EVP_HIP_CGRID_FUSED")));
 }
 
+// The kernels push a cell into its ghost images only where there is ice; the reference's ice_HaloUpdate copies every
+// cell.  The difference shows once per call: a cell WITHOUT ice whose ghost images hold something else than the cell
+// itself -- a corner that lost its ice since the last step (dyn_prep2 zeroes stress12U on ilo..ihi x jlo..jhi only,
+// iceUmask is never set on ghost cells: the ghost image keeps the old stress) -- is repaired by the reference's first
+// exchange of the field.  Cells without ice do not change during a call, so one unconditional copy in the first
+// subcycle, right after the launch that produces the field, leaves every ghost cell as the reference has it.
+static void first_exchange_copies_everything(const EvpCgrid &A, std::initializer_list<int> fields)
+{
+    for (int f : fields) evp_launch_cgrid_phase(A, 9, f, S.stream);
+}
+
 // five launches per subcycle, any visc_method
 static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 {
@@ -182,10 +193,12 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
         XCHG(A.f[CF_SHEARU], A.f[CF_SHEARU]);
         fold({{A.f[CF_SHEARU], 1, false}});
         evp_launch_cgrid_phase(A, 1, 1, S.stream);
+        if (first && k == 0) first_exchange_copies_everything(A, {CF_SP, CF_SM});
         XCHG(A.f[CF_ETA], A.f[CF_ZETA]);
         XCHG(A.f[CF_SP], A.f[CF_SM]);
         fold({{A.f[CF_ZETA], 0, false}, {A.f[CF_ETA], 0, false}, {A.f[CF_SP], 0, false}, {A.f[CF_SM], 0, false}});
         evp_launch_cgrid_phase(A, 2, 1, S.stream);
+        if (first && k == 0) first_exchange_copies_everything(A, {CF_S12U});
         XCHG(A.f[CF_S12U], A.f[CF_S12U]);
         fold({{A.f[CF_S12U], 1, false}});
         evp_launch_cgrid_phase(A, 3, 1, S.stream);
@@ -256,6 +269,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         }
         XCHG(A.f[CF_SHEARU], A.f[CF_SHEARU]);
         evp_launch_cgrid_phase(A, 10, last, S.stream);
+        if (first && k == 0) first_exchange_copies_everything(A, {CF_SP, CF_SM});   // (stress12U: above, before the loop)
         XCHG(A.f[CF_ETA], A.f[CF_ZETA]);         // (zetax2T is stored in the last subcycle only; harmless before)
         XCHG(A.f[CF_SP], A.f[CF_SM]);
         A.s12_in = cur;
