@@ -104,10 +104,16 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
     P.me = HM.E;
     P.ext_w = HM.w; P.ext_e = HM.e; P.ext_s = HM.s; P.ext_n = HM.n;
     P.wrapx = HM.wrap;
-    // strips: the widest `own` for which every column of this rank has at most one duplicate
+    // strips: the widest `own` for which every column of this rank has at most one duplicate -- and the last strip
+    // holds at least two columns: with a single one, the first column BEYOND the rectangle (which the exchange fills)
+    // would sit in two strips, as overlap lane of the last but one and of the last, and a received cell has one home
+    // (column_home) plus the duplicate of a column inside the rectangle only
     bool found = false;
-    for (int own = own_max; own >= 4 && !found; --own)
+    for (int own = own_max; own >= 4 && !found; --own) {
+        const int ns = (P.me.nxr + own - 1) / own;
+        if (ns > 1 && P.me.nxr - (ns - 1) * own < 2) continue;
         if (dup_table(P.me.nxr, own, P.wrapx, P.dup)) { P.me.own = own; found = true; }
+    }
     if (!found) { P.error = "no strip width gives every column a single duplicate"; return false; }
     P.me.nstrips = (P.me.nxr + P.me.own - 1) / P.me.own;
 

@@ -433,6 +433,9 @@ MARCH_CASES = [
     (96, 48, 48, 24, "cyclic", 4, (2, 2), 20, True, 4),
     (96, 48, 24, 24, "closed", 4, (2, 2), 60, True, 2),
     (75, 30, 75, 15, "cyclic", 2, (1, 2), 60, False, 2),
+    # 61 + 2 + 2 = 65 columns held = 4 x 16 + 1: strips of 16 would leave ONE column to the last strip, and the first column
+    # beyond the rectangle would sit in two strips (found by a geometry sweep on the GPU: seed 2056) -- 15 is chosen
+    (122, 30, 61, 30, "cyclic", 2, (2, 1), 16, True, 2),
 ]
 
 
@@ -497,6 +500,12 @@ def _march_worker(rank, world, port, case, q):
                     gx %= nx
                 nring += 1
                 nbad += int(buf[home(x, y)] != gy * nx + gx)
+                # ... and in EVERY lane the kernel reads it from: the two overlap lanes on either side of every strip
+                for s_ in range(ns):
+                    cnt = min(own, nxr - s_ * own)
+                    for l in (0, 1, cnt + 2, cnt + 3):
+                        if s_ * own - 2 + l == x:
+                            nbad += int(buf[((y + 2) * ns + s_) * 64 + l] != gy * nx + gx)
         q.put((rank, nbad, nring, int(has2.sum())))
     finally:
         dist.destroy_process_group()
