@@ -742,6 +742,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
 {
     __shared__ double s_sh[ONE_Y][ONE_X], s_un[ONE_Y][ONE_X], s_ve[ONE_Y][ONE_X];
     __shared__ double s_eta[ONE_Y][ONE_X], s_sp[ONE_Y][ONE_X], s_sm[ONE_Y][ONE_X];
+    __shared__ double s_dl[ONE_Y][ONE_X];            // deltaU (visc_method = avg_strength: the corner viscosities come from it)
     // workgroups go to the XCDs round-robin: XCD x gets the x-th contiguous run of the (space-ordered) window list
     const int t = (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
     if (t >= T.ntiles) return;
@@ -787,6 +788,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         s_sh[ty][tx] = sh;
         s_un[ty][tx] = uNo;
         s_ve[ty][tx] = vEo;
+        if (A.avg_strength) s_dl[ty][tx] = delta;
     }
     __syncthreads();
 
@@ -847,9 +849,18 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             return (hm[p] * s_eta[py][px] * ta[p] + hm[pe] * s_eta[py][px + 1] * ta[pe] + hm[pn] * s_eta[py + 1][px] * ta[pn] +
                     hm[pne] * s_eta[py + 1][px + 1] * ta[pne]) / wtmp;
         };
+        // visc_method = avg_strength: viscosity from the T -> U average of the strength and the corner's own Delta
+        // (ice_dyn_evp.F90:992-996), taken AT the cell the corner's value comes from (table), as S and T are
+        auto eta_s = [&](int px, int py) {
+            const int lp = T.tab[(size_t)t * (ONE_X * ONE_Y) + py * ONE_X + px];
+            if (lp < 0) return 0.0;                    // a ghost cell nothing is copied into: its stress12U is never updated
+            double z, e2, r;
+            visc_replpress(A.p, A.strengthU[lp], A.deltaminEVP * G[CG_UAREA][lp], s_dl[py][px], z, e2, r);
+            return e2;
+        };
         auto s12u = [&](size_t p, int px, int py, bool ice, double *etaU) {
             const double old = A.s12_in[p];
-            const double e2 = eta_u(p, px, py);
+            const double e2 = A.avg_strength ? eta_s(px, py) : eta_u(p, px, py);
             if (etaU) *etaU = e2;
             const double upd = (old * relax + A.p.arlx1i * 0.5 * e2 * s_sh[py][px]) * A.p.denom1;
             return ice ? upd : old;
@@ -912,7 +923,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             A.f[CF_S12U][o] = s12c;
             if (m & 16u) push(A, o, m, CF_S12U, s12c);
         }
-        if (last) A.f[CF_ETAU][o] = etaU;
+        if (last && !A.avg_strength) A.f[CF_ETAU][o] = etaU;   // (avg_strength: the reference never stores etax2U)
         if (m & 4u) {
             A.f[CF_UE][o] = unew;
             if (last) {

@@ -162,9 +162,10 @@ static void fold(std::initializer_list<FoldField> fs)
     evp_launch_cgrid_fold(F, S.stream);
 }
 
+static bool one_launch();
 static bool fused_schedule()
 {
-    if (CG.avg_strength) return false;           // needs deltaU at the neighbours: five phases
+    if (CG.avg_strength && !one_launch()) return false;   // the three-launch kernels need deltaU at the neighbours: five phases
     if (CG.tripole) return false;                // recomputing a neighbour across the fold would sum in mirrored order
     return !(env("CICE_EVP_HIP_CGRID_FUSED") && !std::atoi(env("CICE_EVP_HIP_CGRID_FUSED")));
 }
@@ -259,6 +260,20 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
             evp_launch_cgrid_one(A, T, CG.fast ? 1 : 0, last, S.stream);
             std::swap(cur, other);
             for (int q = 0; q < 4; ++q) std::swap(c4[q], o4[q]);
+            continue;
+        }
+        if (first && k == 0 && CG.avg_strength) {
+            // (only with cg_one for the rest: fused_schedule) the first subcycle as the five launches, stress12U in place
+            evp_launch_cgrid_phase(A, 0, 1, S.stream);
+            evp_launch_cgrid_phase(A, 6, 1, S.stream);
+            evp_launch_cgrid_phase(A, 1, 1, S.stream);
+            first_exchange_copies_everything(A, {CF_SP, CF_SM});
+            evp_launch_cgrid_phase(A, 2, 1, S.stream);
+            first_exchange_copies_everything(A, {CF_S12U});
+            evp_launch_cgrid_phase(A, 3, 1, S.stream);
+            for (int q = 0; q < 4; ++q)
+                HIPC(hipMemcpyAsync(o4[q], c4[q], S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+            HIPC(hipMemcpyAsync(other, cur, S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
             continue;
         }
         if (first && k == 0) {
@@ -555,7 +570,8 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     } else if (enqueue()) {
         return -1;
     }
-    if (fused && (ndte & 1)) {                   // the current stress12U is in the other allocation now
+    if (fused && ((ndte - ((CG.first && CG.avg_strength) ? 1 : 0)) & 1)) {   // the current stress12U is in the other allocation now
+        // (every subcycle swaps the two, except a first one run as five launches: visc_method = avg_strength)
         std::swap(CG.f[CF_S12U], CG.s12alt);
         CG.flip ^= 1;
     }

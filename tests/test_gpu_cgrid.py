@@ -188,7 +188,7 @@ def test_cgrid_both_schedules_agree(monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["cgrid_cyccyc_2x2_cap0_ktens", "cgrid_closed_2x2_revp", "cgrid_cyc_2x2_patchy",
-                                  "cgrid_cyc_1blk_seabed"])
+                                  "cgrid_cyc_1blk_seabed", "cgrid_cyc_3x2pad_cap05_avgstrength"])
 @pytest.mark.parametrize("one", ["0", "1"])
 def test_cgrid_one_launch_schedule_agrees(name, one, monkeypatch):
     """One launch per subcycle (cg_one: three levels in one workgroup, neighbours recomputed, five arrays ping-pong)
@@ -201,13 +201,14 @@ def test_cgrid_one_launch_schedule_agrees(name, one, monkeypatch):
         state, inputs, masks = c.cgrid_inputs(1)
         dom = c.oracle_domain()
         nsub = max(c.nsub_list)
-        out = core.cgrid_run(nsub, state, inputs, masks)
+        visc = str(c.d["visc_method"])
+        out = core.cgrid_run(nsub, state, inputs, masks, visc_method=visc)
         t = core.cgrid_timings()
         assert t["one_launch_subcycles"] == ((nsub - 1) if one == "1" else 0), t
         oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
         oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
         assert_bitwise(out, c.cgrid_expected(1, nsub), f"CICE_EVP_HIP_CGRID_ONE={one} nsub {nsub}")
-        core.cgrid_upload(state, inputs, masks)
+        core.cgrid_upload(state, inputs, masks, visc_method=visc)
         done = 0
         for k in (1, 3, 2, nsub - 6):
             core.cgrid_subcycle(k)

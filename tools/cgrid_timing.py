@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--ndte", type=int, default=120)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--case", default="full")
+    ap.add_argument("--visc", default="avg_zeta", choices=["avg_zeta", "avg_strength"])
     a = ap.parse_args()
     for grid in a.grids:
         dc, static, state, inputs, masks = case(grid, a.case)
@@ -37,7 +38,7 @@ def main():
                           1.0 / static["uarea"], static["tarea"], keepalive=keep)
         try:
             core.cgrid_set_geometry(static)
-            core.cgrid_upload(state, inputs, masks)
+            core.cgrid_upload(state, inputs, masks, visc_method=a.visc)
             ts = []
             for r in range(a.reps + 1):
                 core.cgrid_subcycle(a.ndte)
@@ -46,7 +47,7 @@ def main():
             best = min(ts[1:])
             ncell = dc.nx_global * dc.ny_global
             nact = int(masks["iceTmask"].sum())
-            print(f"CGRID {grid} {a.case}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
+            print(f"CGRID {grid} {a.case} {a.visc}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
                   f"{ncell / (best * 1e-3 / a.ndte):.3e} cell-updates/s, active T {nact}/{ncell}", flush=True)
         finally:
             core.finalize()
