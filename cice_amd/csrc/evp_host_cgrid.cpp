@@ -224,7 +224,8 @@ static bool one_launch()
 {
     if (!CG.one.tab || remote()) return false;
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE")) return std::atoi(e) != 0;
-    return S.n <= 600000;
+    // (avg_strength: the alternative is five launches -- gx1 30.1 -> 19.3, 720x540 55.8 -> 44.7, 3600x2400 1268 -> 1182 us: any size)
+    return CG.avg_strength || S.n <= 600000;
 }
 static int one_subcycles(int ndte, bool first) { return one_launch() ? ndte - (first ? 1 : 0) : 0; }
 
