@@ -120,6 +120,26 @@ __device__ __forceinline__ void strain_u(const EvpCgrid &A, const GT &G, size_t 
     delta = sqrt(dv * dv + A.p.e_factor * (tn * tn + sh * sh));
 }
 
+// The shear alone (same operations as in strain_u): inside the loop only shearU is read -- divergence, tension and
+// Delta at the corners, and with them the averages at the east and north neighbour (uNe, vEn) and the corner's own
+// uNo, vEo, feed deltaU only, which visc_method = avg_zeta stores for the caller in the last subcycle of a call.
+template <class GT>
+__device__ __forceinline__ double shear_u(const EvpCgrid &A, const GT &G, size_t o, double uEo, double uEn, double vNo, double vNe,
+                                          double uU, double vU)
+{
+    const size_t e = o + 1, n = o + A.nx;
+    const double *epm = G[CG_EPM], *npm = G[CG_NPM];
+    const double dxU = G[CG_DXU][o], dyU = G[CG_DYU][o];
+    const double ddyN = G[CG_DYN][e] - G[CG_DYN][o], ddxE = G[CG_DXE][n] - G[CG_DXE][o];
+    const double rxN = G[CG_RXN][o], rxNr = G[CG_RXNR][o], ryE = G[CG_RYE][o], ryEr = G[CG_RYER][o];
+    const double npc = npm[o], npe = npm[e], epc = epm[o], epn = epm[n];
+    const double uEijp1 = uEn * epn + (epc - epn) * epc * ryE * uEo;
+    const double uEij = uEo * epc + (epn - epc) * epn * ryEr * uEn;
+    const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;
+    const double vNij = vNo * npc + (npe - npc) * npe * rxNr * vNe;
+    return dxU * (uEijp1 - uEij) - uU * ddxE + dyU * (vNip1j - vNij) - vU * ddyN;
+}
+
 // grid_average_X2YA at cell p (ice_grid.F90:4388-4606): 'NW' (E -> N), 'SE' (N -> E), 'N' (E -> U), 'E' (N -> U)
 __device__ __forceinline__ double avg_nw(const double *a, const double *w, size_t p, int nx)
 {
@@ -152,21 +172,26 @@ __global__ __launch_bounds__(TX *TY) void cg_avg_strain(EvpCgrid A, int last)
     const unsigned m = A.mask[o];
     const double *uE = A.f[CF_UE], *vN = A.f[CF_VN], *ea = A.g[CG_EAREA], *na = A.g[CG_NAREA];
     const double *npm = A.g[CG_NPM], *epm = A.g[CG_EPM];
-    StrainIn v;
-    v.uNo = avg_nw(uE, ea, o, A.nx) * npm[o];
-    v.vEo = avg_se(vN, na, o, A.nx) * epm[o];
-    A.f[CF_UN][o] = v.uNo;                       // stepv_C / stepu_C of this subcycle read them (own cell)
-    A.f[CF_VE][o] = v.vEo;
+    const double uNo = avg_nw(uE, ea, o, A.nx) * npm[o];
+    const double vEo = avg_se(vN, na, o, A.nx) * epm[o];
+    A.f[CF_UN][o] = uNo;                         // stepv_C / stepu_C of this subcycle read them (own cell)
+    A.f[CF_VE][o] = vEo;
     // no early exit for cells without ice: every load below is in bounds, and issuing them all before the first
     // wait is what matters on grids this small (two waves per SIMD); only the stores are conditional
     const double uvm = A.g[CG_UVM][o];
-    v.uU = avg_2(uE, ea, o, n) * uvm;
-    v.vU = avg_2(vN, na, o, e) * uvm;
-    v.uNe = avg_nw(uE, ea, e, A.nx) * npm[e];
-    v.vEn = avg_se(vN, na, n, A.nx) * epm[n];
-    v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
-    double sh, delta;
-    strain_u(A, A.g, o, v, sh, delta);
+    const double uU = avg_2(uE, ea, o, n) * uvm;
+    const double vU = avg_2(vN, na, o, e) * uvm;
+    double sh, delta = 0.0;
+    if (last) {                                  // deltaU is wanted (nothing inside the loop reads it): the whole of strain_rates_U
+        StrainIn v;
+        v.uNo = uNo; v.vEo = vEo; v.uU = uU; v.vU = vU;
+        v.uNe = avg_nw(uE, ea, e, A.nx) * npm[e];
+        v.vEn = avg_se(vN, na, n, A.nx) * epm[n];
+        v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
+        strain_u(A, A.g, o, v, sh, delta);
+    } else {
+        sh = shear_u(A, A.g, o, uE[o], uE[n], vN[o], vN[e], uU, vU);
+    }
     if (!(m & 2u)) return;
     A.f[CF_SHEARU][o] = sh;
     if (last) A.f[CF_DELTAU][o] = delta;
@@ -737,9 +762,12 @@ __device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const Slab &G, co
     return r;
 }
 
-template <bool FAST, int ONE_X, int ONE_Y>
+// MODE 0: avg_zeta, not the last subcycle of a call (shearU alone at level S); 1: avg_zeta, last subcycle (deltaU is stored);
+// 2: avg_strength (deltaU feeds the corner viscosities in every subcycle)
+template <bool FAST, int ONE_X, int ONE_Y, int MODE>
 __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, int last)
 {
+    constexpr bool AVGS = MODE == 2;
     __shared__ double s_sh[ONE_Y][ONE_X], s_un[ONE_Y][ONE_X], s_ve[ONE_Y][ONE_X];
     __shared__ double s_eta[ONE_Y][ONE_X], s_sp[ONE_Y][ONE_X], s_sm[ONE_Y][ONE_X];
     __shared__ double s_dl[ONE_Y][ONE_X];            // deltaU (visc_method = avg_strength: the corner viscosities come from it)
@@ -768,16 +796,24 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         } else {
             const size_t o = L, e = o + 1, n = o + nx;
             const double *ea = G[CG_EAREA], *na = G[CG_NAREA], *npm = G[CG_NPM], *epm = G[CG_EPM];
-            StrainIn v;
-            v.uNo = uNo = avg_nw(uE, ea, o, nx) * npm[o];
-            v.vEo = vEo = avg_se(vN, na, o, nx) * epm[o];
             const double uvm = G[CG_UVM][o];
-            v.uU = avg_2(uE, ea, o, n) * uvm;
-            v.vU = avg_2(vN, na, o, e) * uvm;
-            v.uNe = avg_nw(uE, ea, e, nx) * npm[e];
-            v.vEn = avg_se(vN, na, n, nx) * epm[n];
-            v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
-            strain_u(A, G, o, v, sh, delta);
+            if (MODE != 0) {                             // deltaU is wanted: the whole of strain_rates_U
+                StrainIn v;
+                v.uNo = uNo = avg_nw(uE, ea, o, nx) * npm[o];
+                v.vEo = vEo = avg_se(vN, na, o, nx) * epm[o];
+                v.uU = avg_2(uE, ea, o, n) * uvm;
+                v.vU = avg_2(vN, na, o, e) * uvm;
+                v.uNe = avg_nw(uE, ea, e, nx) * npm[e];
+                v.vEn = avg_se(vN, na, n, nx) * epm[n];
+                v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
+                strain_u(A, G, o, v, sh, delta);
+            } else {                                     // shearU alone: two of the six averages (four more on owned cells, for level C)
+                if (own) {
+                    uNo = avg_nw(uE, ea, o, nx) * npm[o];
+                    vEo = avg_se(vN, na, o, nx) * epm[o];
+                }
+                sh = shear_u(A, G, o, uE[o], uE[n], vN[o], vN[e], avg_2(uE, ea, o, n) * uvm, avg_2(vN, na, o, e) * uvm);
+            }
             if (!(m & 2u)) sh = A.f[CF_SHEARU][o];       // strain_rates_U leaves cells without ice alone
             else if (own && last) {
                 A.f[CF_SHEARU][o] = sh;
@@ -788,7 +824,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         s_sh[ty][tx] = sh;
         s_un[ty][tx] = uNo;
         s_ve[ty][tx] = vEo;
-        if (A.avg_strength) s_dl[ty][tx] = delta;
+        if (AVGS) s_dl[ty][tx] = delta;
     }
     __syncthreads();
 
@@ -860,7 +896,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         };
         auto s12u = [&](size_t p, int px, int py, bool ice, double *etaU) {
             const double old = A.s12_in[p];
-            const double e2 = A.avg_strength ? eta_s(px, py) : eta_u(p, px, py);
+            const double e2 = AVGS ? eta_s(px, py) : eta_u(p, px, py);
             if (etaU) *etaU = e2;
             const double upd = (old * relax + A.p.arlx1i * 0.5 * e2 * s_sh[py][px]) * A.p.denom1;
             return ice ? upd : old;
@@ -923,7 +959,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             A.f[CF_S12U][o] = s12c;
             if (m & 16u) push(A, o, m, CF_S12U, s12c);
         }
-        if (last && !A.avg_strength) A.f[CF_ETAU][o] = etaU;   // (avg_strength: the reference never stores etax2U)
+        if (last && !AVGS) A.f[CF_ETAU][o] = etaU;   // (avg_strength: the reference never stores etax2U)
         if (m & 4u) {
             A.f[CF_UE][o] = unew;
             if (last) {
@@ -1020,13 +1056,21 @@ void evp_launch_cgrid_deformations(const EvpCgrid &A, const double *tarear, doub
 void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st)
 {
     const dim3 grid((unsigned)(8 * T.per_xcd)), block(T.ox, T.oy);
-#define CG_ONE(F, X, Y) hipLaunchKernelGGL((cg_one<F, X, Y>), grid, block, 0, st, A, T, last)
+    const int mode = A.avg_strength ? 2 : (last ? 1 : 0);
+#define CG_ONE(F, X, Y, M) hipLaunchKernelGGL((cg_one<F, X, Y, M>), grid, block, 0, st, A, T, last)
+#define CG_ONE_M(F, X, Y)                 \
+    do {                                  \
+        if (mode == 0) CG_ONE(F, X, Y, 0); \
+        else if (mode == 1) CG_ONE(F, X, Y, 1); \
+        else CG_ONE(F, X, Y, 2);          \
+    } while (0)
     if (T.ox == 32 && T.oy == 8) {
-        if (fast) CG_ONE(true, 32, 8);
-        else CG_ONE(false, 32, 8);
+        if (fast) CG_ONE_M(true, 32, 8);
+        else CG_ONE_M(false, 32, 8);
     } else {
-        if (fast) CG_ONE(true, 64, 8);
-        else CG_ONE(false, 64, 8);
+        if (fast) CG_ONE_M(true, 64, 8);
+        else CG_ONE_M(false, 64, 8);
     }
+#undef CG_ONE_M
 #undef CG_ONE
 }

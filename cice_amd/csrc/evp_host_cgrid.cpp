@@ -215,8 +215,8 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 
 // one launch per subcycle (cg_one) for every subcycle but the first after an upload (which still reads the caller's
 // uvelN, vvelE, uvel, vvel): one rank, no fold, and a grid on which the three launches are latency- rather than
-// bandwidth-bound -- measured, us per subcycle, three launches -> one: gx3 12.9 -> 10.0, 300x240 18.1 -> 13.5,
-// gx1 23.2 -> 18.1, 720x270 30.3 -> 25.8, 720x540 49.0 -> 42.1; 1440x1080 205.9 -> 212.6 and 3600x2400 1059 -> 1182
+// bandwidth-bound -- measured, us per subcycle, three launches -> one: gx3 12.5 -> 9.5, 300x240 17.6 -> 12.8,
+// gx1 22.4 -> 17.6, 720x270 28.3 -> 24.6, 720x540 44.1 -> 39.3; 1440x1080 196.6 -> 199.1 and 3600x2400 1013 -> 1083
 // (the recomputed positions cost more than the two launches saved).  CICE_EVP_HIP_CGRID_ONE=0 / 1 switches it off / on
 // regardless of size
 static const int ONE_FIELDS[4] = {CF_UE, CF_VN, CF_SP, CF_SM};
@@ -224,7 +224,7 @@ static bool one_launch()
 {
     if (!CG.one.tab || remote()) return false;
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE")) return std::atoi(e) != 0;
-    // (avg_strength: the alternative is five launches -- gx1 30.1 -> 19.3, 720x540 55.8 -> 44.7, 3600x2400 1268 -> 1182 us: any size)
+    // (avg_strength: the alternative is five launches -- gx1 30.1 -> 18.6, 720x540 55.8 -> 44.7 us: any size)
     return CG.avg_strength || S.n <= 600000;
 }
 static int one_subcycles(int ndte, bool first) { return one_launch() ? ndte - (first ? 1 : 0) : 0; }
