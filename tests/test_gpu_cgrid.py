@@ -635,3 +635,77 @@ def test_cgrid_prep_and_loop_random_geometry_vs_oracle(seed):
         assert np.abs(wloop["uvelE"]).max() > 1e-4
     finally:
         core.finalize()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Geometry sweep pinned on the REFERENCE itself: the prebuilt harness (oracle/_ref, the reference's unmodified evp()
+# with grid_ice = 'C') runs a random domain / block split / boundary kind / option set on the box, its dump becomes a
+# fixture on the fly, and the loop, the device preparation and deformationsC_T are compared with the reference's own
+# arrays exactly as for the committed fixtures.
+# ---------------------------------------------------------------------------------------------------------------
+def reference_cgrid_case(tmp_path, nx, ny, bs, ew, ns, **kw):
+    import run_ref
+    from cice_amd import synth
+    import common
+    if not run_ref.have_ref("strict"):
+        pytest.skip("oracle/_ref/evp_ref_harness_strict not present")
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+    run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+    run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
+    d, txt = run_ref.run_harness(nx, ny, bs[0], bs[1], ew=ew, ns=ns, variant="strict", h_ndte=kw.pop("h_ndte", 120),
+                                 grid_kind=("tripolefile" if ns == "tripole" else "popfile"),
+                                 grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), h_grid_ice="C", **kw)
+    np.savez(tmp_path / "ccase.npz", **d, ew=np.array(ew), ns=np.array(ns), visc_method=np.array(kw.get("h_visc_method", "avg_zeta")))
+    old = common.GOLDEN
+    common.GOLDEN = tmp_path
+    try:
+        return GoldenCase("ccase")
+    finally:
+        common.GOLDEN = old
+
+
+@pytest.mark.parametrize("seed", list(range(501, 509)) + [int(s) for s in __import__("os").environ.get("CGRID_REF_SWEEP_SEEDS", "").split() if s])
+def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path):
+    rng = np.random.default_rng(seed)
+    ns = ["closed", "tripole", "cyclic"][seed % 3] if seed % 7 else "tripole"
+    ew = "closed" if (ns == "closed" and seed % 2) else "cyclic"
+    nx, ny = 2 * int(rng.integers(10, 36)), int(rng.integers(14, 48))
+    nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    bs = (-(-nx // nbx), -(-ny // nby))
+    kw = dict(icecase=str(rng.choice(["full", "patchy", "caps"])), nsub_list=[1, 7], ncalls=2, h_ndte=7, h_evolve=True)
+    if rng.random() < 0.3:
+        kw["h_visc_method"] = "avg_strength"
+    if rng.random() < 0.3:
+        kw["h_seabed"] = True
+    if rng.random() < 0.3:
+        kw.update(h_capping=float(rng.choice([0.0, 0.5])), h_Ktens=0.1)
+    if rng.random() < 0.3:
+        kw["h_ssh"] = "coupled"
+    what = f"seed {seed}: {nx}x{ny} ew {ew} ns {ns}, blocks {bs[0]}x{bs[1]}, {kw}"
+    c = reference_cgrid_case(tmp_path, nx, ny, bs, ew, ns, **kw)
+    dom = c.oracle_domain()
+    core = cgrid_core(c)
+    try:
+        core.cgrid_set_prep_geometry(c.cgrid_prep_static())
+        for icall in range(1, c.ncalls + 1):
+            state, inputs, masks = c.cgrid_inputs(icall)
+            for nsub in c.nsub_list:
+                out = core.cgrid_run(nsub, state, inputs, masks, visc_method=str(c.d["visc_method"]))
+                oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+                oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+                assert_bitwise(out, c.cgrid_expected(icall, nsub), f"{what}: call {icall} nsub {nsub} (loop)")
+            if c.scal[23] != 0.0:
+                continue                      # (seabed stress: the device exp() may differ from the host's in the last bit of TbE / TbN)
+            # the same call from the T-grid state: preparation on the device, then the loop from the device-prepared state
+            _, st, _ = c.cgrid_prep_inputs(icall)
+            masks_d = device_prep(core, c, icall, {k: st[k] for k in oracle.C_FIELDS[:12]})
+            for k in oracle.C_MASKS:
+                assert np.array_equal(masks_d[k] != 0, masks[k] != 0), (what, icall, k)
+            core.cgrid_subcycle(c.nsub_list[-1])
+            out = core.cgrid_download()
+            oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+            oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+            assert_bitwise(out, c.cgrid_expected(icall, c.nsub_list[-1]), f"{what}: call {icall} (device preparation + loop)")
+        assert np.abs(out["uvelE"]).max() > 1e-4, what
+    finally:
+        core.finalize()

@@ -1218,3 +1218,32 @@ def test_bgrid_random_geometry_vs_oracle(seed, resident, monkeypatch):
     got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=ndte)
     want = run_oracle(dc, geo, fields, tm, um, scal, ndte)
     assert_bitwise(got, want, f"seed {seed}: {nx}x{ny} {ew}, blocks {bsx}x{bsy}, ndte {ndte}, holes {holes}, resident {resident}")
+
+
+@pytest.mark.parametrize("seed", list(range(401, 409)) + [int(s) for s in os.environ.get("BGRID_REF_SWEEP_SEEDS", "").split() if s])
+def test_bgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
+    """Geometry sweep pinned on the REFERENCE itself: the prebuilt harness (the reference's unmodified evp()) runs a
+    random domain size / block split (padded last blocks, several blocks in y next to the fold) / north boundary
+    (closed, tripole) / ice case on the box; its captured subcycle inputs go through the on-chip resident and the
+    streaming kernel, outputs against the reference's after 1 and ndte subcycles, bit for bit."""
+    rng = np.random.default_rng(seed)
+    ns = "tripole" if seed % 3 else "closed"
+    nx, ny = 2 * int(rng.integers(12, 60)), int(rng.integers(16, 70))
+    nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    bs = (-(-nx // nbx), -(-ny // nby))
+    icecase = str(rng.choice(["full", "patchy", "caps"]))
+    ndte = int(rng.choice([3, 8]))
+    what = f"seed {seed}: {nx}x{ny} {ns}, blocks {bs[0]}x{bs[1]}, {icecase}, ndte {ndte}"
+    c = reference_case(tmp_path, nx, ny, bs, ns, [1, ndte], ndte, icecase=icecase)
+    dyn, tm, um = c.inputs(1)
+    for resident in ("1", "0"):
+        monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", resident)
+        monkeypatch.setenv("CICE_EVP_HIP_MARCH", "0")
+        core = hip_from_case(c, strict=True)
+        try:
+            for nsub in (1, ndte):
+                out = post_evp(c, core.run(dyn, tm, um, ndte=nsub))
+                assert_bitwise(out, c.expected(1, nsub), f"{what}: nsub {nsub}, resident {resident}")
+        finally:
+            core.finalize()
+    assert np.abs(out["uvel"]).max() > 1e-4, what
