@@ -316,7 +316,7 @@ def test_remote_halo_without_communicator_fails_loudly(monkeypatch):
         core.finalize()
 
 
-def reference_case(tmp_path, nx, ny, bs, ns, nsub_list, h_ndte, icecase="full", **kw):
+def reference_case(tmp_path, nx, ny, bs, ns, nsub_list, h_ndte, icecase="full", ncalls=1, **kw):
     """Run the reference's own evp() (prebuilt oracle/_ref harness, strict build) at full size on
     the box and wrap its dump as a GoldenCase: inputs captured at the drop-in boundary, outputs
     after each subcycle count of nsub_list."""
@@ -327,7 +327,7 @@ def reference_case(tmp_path, nx, ny, bs, ns, nsub_list, h_ndte, icecase="full", 
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
     d, txt = run_ref.run_harness(nx, ny, bs[0], bs[1], ew="cyclic", ns=ns, variant="strict", h_ndte=h_ndte,
-                                 ncalls=1, nsub_list=list(nsub_list),
+                                 ncalls=ncalls, nsub_list=list(nsub_list),
                                  grid_kind="tripolefile" if ns == "tripole" else "popfile", icecase=icecase,
                                  grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
     np.savez(tmp_path / "case.npz", **d, ew=np.array("cyclic"), ns=np.array(ns))
@@ -401,7 +401,10 @@ def test_gx1_size_vs_reference_harness(tmp_path, bs, monkeypatch):
 def test_next_tier_deformations_and_dyn_finish_bitwise(name):
     """deformations + dyn_finish computed on the device from the resident
     final velocities, against the reference's own outputs of the same evp() call."""
-    c = GoldenCase(name)
+    check_next_tier_post(GoldenCase(name), name)
+
+
+def check_next_tier_post(c, name):
     core = hip_from_case(c, strict=True)
     try:
         core.set_post_geometry(c.d["dxU"], c.d["dyU"], c.d["tarear"])
@@ -521,8 +524,11 @@ def test_next_tier_prep_on_device_bitwise(name):
     reference's evp() was entered with (pr*) to what it handed to its subcycle loop (in*/pq*),
     bit for bit (both calls of a fixture: new-ice / lost-ice cells, previous masks); then the
     whole evp(): prep -> ice strength from the host -> subcycle loop -> the reference's outputs."""
+    check_next_tier_prep(GoldenCase(name), name)
+
+
+def check_next_tier_prep(c, name):
     from test_oracle_golden import check_prep_products
-    c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     try:
         st = c.prep_static()
@@ -1234,16 +1240,24 @@ def test_bgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
     icecase = str(rng.choice(["full", "patchy", "caps"]))
     ndte = int(rng.choice([3, 8]))
     what = f"seed {seed}: {nx}x{ny} {ns}, blocks {bs[0]}x{bs[1]}, {icecase}, ndte {ndte}"
-    c = reference_case(tmp_path, nx, ny, bs, ns, [1, ndte], ndte, icecase=icecase)
-    dyn, tm, um = c.inputs(1)
-    for resident in ("1", "0"):
-        monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", resident)
-        monkeypatch.setenv("CICE_EVP_HIP_MARCH", "0")
+    c = reference_case(tmp_path, nx, ny, bs, ns, [1, ndte], ndte, icecase=icecase, ncalls=2, h_evolve=True)
+    marched = 0
+    for kernel in ("resident", "streaming") + (("march",) if ns == "closed" else ()):     # (the two-subcycle path refuses a fold)
+        monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if kernel == "resident" else "0")
+        monkeypatch.setenv("CICE_EVP_HIP_MARCH", "1" if kernel == "march" else "0")
         core = hip_from_case(c, strict=True)
         try:
-            for nsub in (1, ndte):
-                out = post_evp(c, core.run(dyn, tm, um, ndte=nsub))
-                assert_bitwise(out, c.expected(1, nsub), f"{what}: nsub {nsub}, resident {resident}")
+            for icall in (1, 2):                  # (the second call: cells have gained and lost ice)
+                dyn, tm, um = c.inputs(icall)
+                for nsub in (1, ndte):
+                    out = post_evp(c, core.run(dyn, tm, um, ndte=nsub))
+                    assert_bitwise(out, c.expected(icall, nsub), f"{what}: call {icall} nsub {nsub}, {kernel}")
+                    if kernel == "march":
+                        marched += int(core.march_info()["last_call"])
         finally:
             core.finalize()
+    assert ns != "closed" or marched >= 2, (what, marched)      # the runs did go through the two-subcycle path
     assert np.abs(out["uvel"]).max() > 1e-4, what
+    # what evp() does before and after the loop, on the device: preparation (+ loop) and deformations / dyn_finish
+    check_next_tier_prep(c, what)
+    check_next_tier_post(c, what)
