@@ -54,7 +54,11 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    spec = synth.GRIDS[a.workload]
+    if a.workload in synth.GRIDS:
+        spec = synth.GRIDS[a.workload]
+    else:                                       # "NXxNY" or "NXxNY:tripole": any size (tools/multiproc_sweep.py)
+        size, _, bnd = a.workload.partition(":")
+        spec = dict(nx=int(size.split("x")[0]), ny=int(size.split("x")[1]), dx0=1.1e5, ns=bnd or "closed")
     nx, ny = spec["nx"], spec["ny"]
     ns_bnd = spec.get("ns", "closed")          # tx1: tripole north boundary (rank layouts with px = 1 only)
     g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns_bnd))
