@@ -323,12 +323,12 @@ def reference_case(tmp_path, nx, ny, bs, ns, nsub_list, h_ndte, icecase="full", 
     import run_ref
     if not run_ref.have_ref("strict"):
         pytest.skip("oracle/_ref/evp_ref_harness_strict not present")
-    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=("tripole" if ns == "tripoleT" else ns))
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
     d, txt = run_ref.run_harness(nx, ny, bs[0], bs[1], ew="cyclic", ns=ns, variant="strict", h_ndte=h_ndte,
                                  ncalls=ncalls, nsub_list=list(nsub_list),
-                                 grid_kind="tripolefile" if ns == "tripole" else "popfile", icecase=icecase,
+                                 grid_kind="tripolefile" if ns in ("tripole", "tripoleT") else "popfile", icecase=icecase,
                                  grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
     np.savez(tmp_path / "case.npz", **d, ew=np.array("cyclic"), ns=np.array(ns))
     import common
@@ -1261,3 +1261,32 @@ def test_bgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
     # what evp() does before and after the loop, on the device: preparation (+ loop) and deformations / dyn_finish
     check_next_tier_prep(c, what)
     check_next_tier_post(c, what)
+
+
+@pytest.mark.parametrize("seed", list(range(451, 455)) + [int(s) for s in os.environ.get("TFOLD_REF_SWEEP_SEEDS", "").split() if s])
+def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
+    """ns_boundary_type = 'tripoleT' over random geometries (harness on the box, as above): the B-grid loop with the
+    T-fold's velocity halo as list copies; velocities and diagnostics everywhere, stresses wherever evp()'s own
+    ice_HaloUpdate_stress after the loop leaves them alone."""
+    rng = np.random.default_rng(seed)
+    nx, ny = 2 * int(rng.integers(12, 50)), int(rng.integers(16, 60))
+    nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    bs = (-(-nx // nbx), -(-ny // nby))
+    icecase = str(rng.choice(["full", "patchy", "caps"]))
+    ndte = int(rng.choice([3, 8]))
+    what = f"seed {seed}: {nx}x{ny} tripoleT, blocks {bs[0]}x{bs[1]}, {icecase}, ndte {ndte}"
+    c = reference_case(tmp_path, nx, ny, bs, "tripoleT", [1, ndte], ndte, icecase=icecase, ncalls=2, h_evolve=True)
+    keep = tfold_untouched(c)
+    core = hip_from_case(c, strict=True)
+    try:
+        for icall in (1, 2):
+            dyn, tm, um = c.inputs(icall)
+            for nsub in (1, ndte):
+                out = core.run(dyn, tm, um, ndte=nsub)
+                want = c.expected(icall, nsub)
+                for k in want:
+                    sel = keep if k.startswith("stress") else np.ones_like(keep)
+                    assert np.array_equal(out[k][sel], want[k][sel]), f"{what}: call {icall} nsub {nsub} {k}"
+        assert np.abs(want["uvel"]).max() > 1e-5, what
+    finally:
+        core.finalize()
