@@ -347,7 +347,7 @@ static int build_one_tables()
     // workgroups) and on larger ones (more of them resident per CU); CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 picks 32x8 / 64x8
     int shape = (S.n > 40000 && S.n <= 160000) ? 1 : 0;
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::atoi(e) != 0;
-    const int nxb = S.d.nx_block, OX = shape ? 64 : 32, OY = 8;
+    const int nxb = S.d.nx_block, OX = shape ? CG_ONE_BIG_X : 32, OY = shape ? CG_ONE_BIG_Y : 8;
     std::vector<int> owner(S.n, -1);
     for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
     auto canon = [&](long c) -> long {
