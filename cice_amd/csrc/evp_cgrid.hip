@@ -1067,9 +1067,12 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
     if (T.ox == 32 && T.oy == 8) {
         if (fast) CG_ONE_M(true, 32, 8);
         else CG_ONE_M(false, 32, 8);
+    } else if (T.oy == 8) {
+        if (fast) CG_ONE_M(true, 64, 8);
+        else CG_ONE_M(false, 64, 8);
     } else {
-        if (fast) CG_ONE_M(true, CG_ONE_BIG_X, CG_ONE_BIG_Y);
-        else CG_ONE_M(false, CG_ONE_BIG_X, CG_ONE_BIG_Y);
+        if (fast) CG_ONE_M(true, 64, 16);
+        else CG_ONE_M(false, 64, 16);
     }
 #undef CG_ONE_M
 #undef CG_ONE

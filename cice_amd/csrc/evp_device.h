@@ -336,13 +336,9 @@ struct EvpCgrid {
     int tripole;                  // the fold step writes into cells without ice: what the reference re-zeroes every subcycle is re-zeroed
     size_t plane;
 };
-// One launch per subcycle (evp_cgrid.hip: cg_one).  A window = ox x oy positions (one workgroup: 32 x 8 or 64 x 8), the
+// One launch per subcycle (evp_cgrid.hip: cg_one).  A window = ox x oy positions (one workgroup: 32 x 8, 64 x 8 or 64 x 16), the
 // inner (ox-3) x (oy-3) of them owned cells; tab: per window and position the cell whose value the reference has there
 // (>= 0), or -1 - ghost cell for a ghost cell nothing is copied into (its arrays are read, not computed).
-#ifndef CG_ONE_BIG_X
-#define CG_ONE_BIG_X 64        // the larger of the two compiled windows (the other: 32 x 8)
-#define CG_ONE_BIG_Y 8
-#endif
 struct EvpCgOne {
     const int *tab;
     const int4 *tiles;            // block, first owned i, first owned j (1-based), unused

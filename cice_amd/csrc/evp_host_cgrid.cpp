@@ -214,18 +214,16 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 }
 
 // one launch per subcycle (cg_one) for every subcycle but the first after an upload (which still reads the caller's
-// uvelN, vvelE, uvel, vvel): one rank, no fold, and a grid on which the three launches are latency- rather than
-// bandwidth-bound -- measured, us per subcycle, three launches -> one: gx3 12.5 -> 9.5, 300x240 17.6 -> 12.8,
-// gx1 22.4 -> 17.6, 720x270 28.3 -> 24.6, 720x540 44.1 -> 39.3; 1440x1080 196.6 -> 199.1 and 3600x2400 1013 -> 1083
-// (the recomputed positions cost more than the two launches saved).  CICE_EVP_HIP_CGRID_ONE=0 / 1 switches it off / on
-// regardless of size
+// uvelN, vvelE, uvel, vvel): one rank, no fold.  Measured, us per subcycle, three launches -> one:
+// gx3 12.5 -> 9.5, 300x240 17.6 -> 12.8, gx1 22.4 -> 17.6, 720x270 28.3 -> 21.9, 720x540 44.1 -> 39.3 (window shapes:
+// build_one_tables), 1440x1080 196.6 -> 185.0, 3600x2400 1013 -> 925; avg_strength against its five launches:
+// gx1 30.1 -> 18.6, 1440x1080 235 -> 191, 3600x2400 1257 -> 968.  CICE_EVP_HIP_CGRID_ONE=0 switches it off
 static const int ONE_FIELDS[4] = {CF_UE, CF_VN, CF_SP, CF_SM};
 static bool one_launch()
 {
     if (!CG.one.tab || remote()) return false;
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE")) return std::atoi(e) != 0;
-    // (avg_strength: the alternative is five launches -- gx1 30.1 -> 18.6, 720x540 55.8 -> 44.7 us: any size)
-    return CG.avg_strength || S.n <= 600000;
+    return true;
 }
 static int one_subcycles(int ndte, bool first) { return one_launch() ? ndte - (first ? 1 : 0) : 0; }
 
@@ -343,11 +341,13 @@ static int build_fold_lists()
 static int build_one_tables()
 {
     const HaloPlan &P = S.plan;
-    // the window: 64x8 where it gives every CU one or two workgroups (gx1: 462), 32x8 on smaller grids (more
-    // workgroups) and on larger ones (more of them resident per CU); CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 picks 32x8 / 64x8
-    int shape = (S.n > 40000 && S.n <= 160000) ? 1 : 0;
-    if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::atoi(e) != 0;
-    const int nxb = S.d.nx_block, OX = shape ? CG_ONE_BIG_X : 32, OY = shape ? CG_ONE_BIG_Y : 8;
+    // the window: 32x8 on the smallest grids (more workgroups than 64x8 gives), 64x8 where that gives every CU one or two
+    // workgroups (gx1: 462), 64x16 from there on -- the fewest recomputed positions and re-read rows per owned cell, which is
+    // what counts once there are several windows per CU (720x270: 24.6 / 21.9 us with 32x8 / 64x16; 3600x2400: 1083 / 1032 /
+    // 925 with 32x8 / 64x8 / 64x16).  CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 / 2 picks one
+    int shape = S.n > 160000 ? 2 : (S.n > 40000 ? 1 : 0);
+    if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::min(2, std::max(0, std::atoi(e)));
+    const int nxb = S.d.nx_block, OX = shape ? 64 : 32, OY = shape == 2 ? 16 : 8;
     std::vector<int> owner(S.n, -1);
     for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
     auto canon = [&](long c) -> long {
@@ -359,9 +359,18 @@ static int build_one_tables()
     };
     std::vector<int> tab;
     std::vector<int4> tiles;
+    // Order of the windows = order of the workgroups on an XCD (each XCD takes a contiguous run of the list).  Row by
+    // row across a wide block, the window above a window starts a whole row of windows later -- by then the 2-3 rows of
+    // operands they share have left the 4 MB L2 (3600 x 2400: 13 MB per row of windows; counters 1.39x the algorithmic
+    // bytes).  Strips of `strip` windows in x, top to bottom, put vertical neighbours into flight together.
+    // (measured the other way round: 3600 x 2400 1083 us row by row, 1171 / 1139 / 1106 / 1082 in strips of 4 / 8 / 16 / 32
+    // windows -- narrow strips cost more in DRAM locality than the shared rows save -- so row by row stays, the strips an option)
+    int strip = 1 << 20;
+    if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_STRIP")) strip = std::max(1, std::atoi(e));
     for (int b = 0; b < S.d.nblocks; ++b)
+      for (int is0 = S.ilo[b]; is0 <= S.ihi[b]; is0 += strip * (OX - 3))
         for (int j0 = S.jlo[b]; j0 <= S.jhi[b]; j0 += OY - 3)
-            for (int i0 = S.ilo[b]; i0 <= S.ihi[b]; i0 += OX - 3) {
+            for (int i0 = is0; i0 <= S.ihi[b] && i0 < is0 + strip * (OX - 3); i0 += OX - 3) {
                 tiles.push_back(make_int4(b, i0, j0, 0));
                 for (int ty = 0; ty < OY; ++ty)
                     for (int tx = 0; tx < OX; ++tx) {

@@ -189,13 +189,16 @@ def test_cgrid_both_schedules_agree(monkeypatch):
 
 @pytest.mark.parametrize("name", ["cgrid_cyccyc_2x2_cap0_ktens", "cgrid_closed_2x2_revp", "cgrid_cyc_2x2_patchy",
                                   "cgrid_cyc_1blk_seabed", "cgrid_cyc_3x2pad_cap05_avgstrength"])
-@pytest.mark.parametrize("one", ["0", "1"])
+@pytest.mark.parametrize("one", ["0", "1", "1:0", "1:2"])
 def test_cgrid_one_launch_schedule_agrees(name, one, monkeypatch):
     """One launch per subcycle (cg_one: three levels in one workgroup, neighbours recomputed, five arrays ping-pong)
     against the three-launch form of the fused schedule, both pinned on the reference's arrays -- in one call and in
     split calls with odd counts (the buffers change roles between calls)."""
     c = GoldenCase(name)
+    one, _, shape = one.partition(":")          # "1:2": the 64x16 window (the default on these small grids is 32x8)
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE", one)
+    if shape:
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", shape)
     core = cgrid_core(c)
     try:
         state, inputs, masks = c.cgrid_inputs(1)
@@ -665,7 +668,8 @@ def reference_cgrid_case(tmp_path, nx, ny, bs, ew, ns, **kw):
 
 
 @pytest.mark.parametrize("seed", list(range(501, 509)) + [int(s) for s in __import__("os").environ.get("CGRID_REF_SWEEP_SEEDS", "").split() if s])
-def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path):
+def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", str(seed % 3))      # all three windows of the one-launch kernel (32x8, 64x8, 64x16)
     rng = np.random.default_rng(seed)
     ns = ["closed", "tripole", "cyclic"][seed % 3] if seed % 7 else "tripole"
     ew = "closed" if (ns == "closed" and seed % 2) else "cyclic"
