@@ -778,7 +778,9 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     const int4 tl = T.tiles[t];                          // block, first owned i, first owned j (1-based)
     const int4 q = A.blk[tl.x];
     const int i = tl.y - 2 + tx, j = tl.z - 2 + ty;      // the position in the block's own numbering (may lie outside its array)
-    const int lr = T.tab[(size_t)t * (ONE_X * ONE_Y) + ty * ONE_X + tx];
+    // (a window whose positions are all cells of its block's array, each its own source -- nearly all of them on a large
+    // block -- is marked regular and skips the table: one dependent load less at the head of the kernel)
+    const int lr = tl.w ? (int)((size_t)tl.x * A.plane + (size_t)(j - 1) * A.nx + (i - 1)) : T.tab[(size_t)t * (ONE_X * ONE_Y) + ty * ONE_X + tx];
     const bool stat = lr < 0;
     const size_t L = (size_t)(stat ? -1 - lr : lr);
     const unsigned m = A.mask[L];

@@ -341,7 +341,7 @@ struct EvpCgrid {
 // (>= 0), or -1 - ghost cell for a ghost cell nothing is copied into (its arrays are read, not computed).
 struct EvpCgOne {
     const int *tab;
-    const int4 *tiles;            // block, first owned i, first owned j (1-based), unused
+    const int4 *tiles;            // block, first owned i, first owned j (1-based), 1 if the window is regular (no table needed)
     int ntiles, per_xcd;          // windows; windows per XCD (launch = 8 * per_xcd workgroups)
     int ox, oy;
     const double *uE_in, *vN_in, *sp_in, *sm_in;   // previous subcycle's buffers (A.f[...] = this subcycle's)

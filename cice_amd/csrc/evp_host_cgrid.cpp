@@ -216,7 +216,7 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 // one launch per subcycle (cg_one) for every subcycle but the first after an upload (which still reads the caller's
 // uvelN, vvelE, uvel, vvel): one rank, no fold.  Measured, us per subcycle, three launches -> one:
 // gx3 12.5 -> 9.5, 300x240 17.6 -> 12.8, gx1 22.4 -> 17.6, 720x270 28.3 -> 21.9, 720x540 44.1 -> 39.3 (window shapes:
-// build_one_tables), 1440x1080 196.6 -> 185.0, 3600x2400 1013 -> 925; avg_strength against its five launches:
+// build_one_tables), 1440x1080 196.6 -> 178.0, 3600x2400 1013 -> 902; avg_strength against its five launches:
 // gx1 30.1 -> 18.6, 1440x1080 235 -> 191, 3600x2400 1257 -> 968.  CICE_EVP_HIP_CGRID_ONE=0 switches it off
 static const int ONE_FIELDS[4] = {CF_UE, CF_VN, CF_SP, CF_SM};
 static bool one_launch()
@@ -372,6 +372,7 @@ static int build_one_tables()
         for (int j0 = S.jlo[b]; j0 <= S.jhi[b]; j0 += OY - 3)
             for (int i0 = is0; i0 <= S.ihi[b] && i0 < is0 + strip * (OX - 3); i0 += OX - 3) {
                 tiles.push_back(make_int4(b, i0, j0, 0));
+                bool regular = true;          // every position an array cell of this block that is its own source
                 for (int ty = 0; ty < OY; ++ty)
                     for (int tx = 0; tx < OX; ++tx) {
                         const int i = i0 - 2 + tx, j = j0 - 2 + ty;
@@ -381,7 +382,10 @@ static int build_one_tables()
                         for (int dx = i - ic; dx != 0 && r >= 0; dx -= (dx > 0 ? 1 : -1)) r = canon(r + (dx > 0 ? 1 : -1));
                         for (int dy = j - jc; dy != 0 && r >= 0; dy -= (dy > 0 ? 1 : -1)) r = canon(r + (dy > 0 ? nxb : -nxb));
                         tab.push_back((int)r);
+                        regular = regular && i >= 1 && i <= nxb && j >= 1 && j <= S.d.ny_block &&
+                                  r == (long)b * (long)S.plane + (long)(j - 1) * nxb + (i - 1);
                     }
+                tiles.back().w = regular ? 1 : 0;
             }
     CGridState::One &O = CG.one;
     O.ntiles = (int)tiles.size();
