@@ -12,13 +12,14 @@ sys.path.insert(0, str(ROOT))
 from cice_amd import decomp, evp, synth  # noqa: E402
 
 
-def case(grid, case_="full"):
+def case(grid, case_="full", bs=None):
     spec = synth.GRIDS[grid]
     ns = spec.get("ns", "closed")
     g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns=ns))
     cg = synth.cgrid_geometry(g)
     state, inputs, masks = synth.cgrid_state(g, cg, case=case_, seed=3)
-    dc = decomp.Decomp(spec["nx"], spec["ny"], spec["nx"], spec["ny"], "cyclic", ns, 1)
+    bx, by = bs if bs else (spec["nx"], spec["ny"])
+    dc = decomp.Decomp(spec["nx"], spec["ny"], bx, by, "cyclic", ns, 1)
     return (dc,) + synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
 
 
@@ -29,9 +30,10 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--case", default="full")
     ap.add_argument("--visc", default="avg_zeta", choices=["avg_zeta", "avg_strength"])
+    ap.add_argument("--bs", default="", help="block size BXxBY (default: one block)")
     a = ap.parse_args()
     for grid in a.grids:
-        dc, static, state, inputs, masks = case(grid, a.case)
+        dc, static, state, inputs, masks = case(grid, a.case, tuple(int(v) for v in a.bs.split("x")) if a.bs else None)
         d, keep = evp.make_dims(dc, 0)
         scal = synth.evp_scalars(a.ndte)
         core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
