@@ -300,7 +300,8 @@ int cice_evp_hip_cgrid_deformations(const double *tarear, double *divu, double *
  * First call with NULL lists for the count.                                                                       */
 int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int32_t *count, int32_t *dst, int32_t *a,
                                  int32_t *b, int32_t *flip);
-/* out[0] = ms of the last cgrid_subcycle (HIP events), out[1] = its ndte, [2] (n >= 3) = device ms of the last cgrid_prep */
+/* out[0] = ms of the last cgrid_subcycle (HIP events), out[1] = its ndte, [2] (n >= 3) = device ms of the last cgrid_prep,
+ * [3] (n >= 4) = how many of those subcycles ran as one launch each (the default schedule on one rank without a fold)  */
 int cice_evp_hip_cgrid_timings(double *out, int32_t n);
 
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */
