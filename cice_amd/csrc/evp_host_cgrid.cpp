@@ -347,55 +347,27 @@ static int build_one_tables()
     // 925 with 32x8 / 64x8 / 64x16).  CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 / 2 picks one
     int shape = S.n > 160000 ? 2 : (S.n > 40000 ? 1 : 0);
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::min(2, std::max(0, std::atoi(e)));
-    const int nxb = S.d.nx_block, OX = shape ? 64 : 32, OY = shape == 2 ? 16 : 8;
-    std::vector<int> owner(S.n, -1);
-    for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
-    auto canon = [&](long c) -> long {
-        const int b = (int)(c / (long)S.plane);
-        const long r = c % (long)S.plane;
-        const int j = (int)(r / nxb) + 1, i = (int)(r % nxb) + 1;
-        if (i >= S.ilo[b] && i <= S.ihi[b] && j >= S.jlo[b] && j <= S.jhi[b]) return c;
-        return owner[c] >= 0 ? (long)owner[c] : -1 - c;
-    };
-    std::vector<int> tab;
-    std::vector<int4> tiles;
-    // Order of the windows = order of the workgroups on an XCD (each XCD takes a contiguous run of the list).  Row by
-    // row across a wide block, the window above a window starts a whole row of windows later -- by then the 2-3 rows of
-    // operands they share have left the 4 MB L2 (3600 x 2400: 13 MB per row of windows; counters 1.39x the algorithmic
-    // bytes).  Strips of `strip` windows in x, top to bottom, put vertical neighbours into flight together.
-    // (measured the other way round: 3600 x 2400 1083 us row by row, 1171 / 1139 / 1106 / 1082 in strips of 4 / 8 / 16 / 32
-    // windows -- narrow strips cost more in DRAM locality than the shared rows save -- so row by row stays, the strips an option)
+    const int OX = shape ? 64 : 32, OY = shape == 2 ? 16 : 8;
+    // Order of the windows = order of the workgroups on an XCD (each XCD takes a contiguous run of the list): row by row.
+    // (Strips of a few windows in x, top to bottom, so that vertical neighbours run together and share their 2-3 common rows
+    // in L2, were measured: 3600 x 2400 1083 us row by row, 1171 / 1139 / 1106 / 1082 in strips of 4 / 8 / 16 / 32 windows --
+    // narrow strips cost more in DRAM locality than the shared rows save.  CICE_EVP_HIP_CGRID_ONE_STRIP=<n> for A/B.)
     int strip = 1 << 20;
     if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_STRIP")) strip = std::max(1, std::atoi(e));
-    for (int b = 0; b < S.d.nblocks; ++b)
-      for (int is0 = S.ilo[b]; is0 <= S.ihi[b]; is0 += strip * (OX - 3))
-        for (int j0 = S.jlo[b]; j0 <= S.jhi[b]; j0 += OY - 3)
-            for (int i0 = is0; i0 <= S.ihi[b] && i0 < is0 + strip * (OX - 3); i0 += OX - 3) {
-                tiles.push_back(make_int4(b, i0, j0, 0));
-                bool regular = true;          // every position an array cell of this block that is its own source
-                for (int ty = 0; ty < OY; ++ty)
-                    for (int tx = 0; tx < OX; ++tx) {
-                        const int i = i0 - 2 + tx, j = j0 - 2 + ty;
-                        const int ic = std::min(std::max(i, S.ilo[b] - 1), S.ihi[b] + 1);
-                        const int jc = std::min(std::max(j, S.jlo[b] - 1), S.jhi[b] + 1);
-                        long r = canon((long)b * (long)S.plane + (long)(jc - 1) * nxb + (ic - 1));
-                        for (int dx = i - ic; dx != 0 && r >= 0; dx -= (dx > 0 ? 1 : -1)) r = canon(r + (dx > 0 ? 1 : -1));
-                        for (int dy = j - jc; dy != 0 && r >= 0; dy -= (dy > 0 ? 1 : -1)) r = canon(r + (dy > 0 ? nxb : -nxb));
-                        tab.push_back((int)r);
-                        regular = regular && i >= 1 && i <= nxb && j >= 1 && j <= S.d.ny_block &&
-                                  r == (long)b * (long)S.plane + (long)(j - 1) * nxb + (i - 1);
-                    }
-                tiles.back().w = regular ? 1 : 0;
-            }
+    cice_evp_hip_dims d = S.d;
+    d.ilo = S.ilo.data(); d.ihi = S.ihi.data(); d.jlo = S.jlo.data(); d.jhi = S.jhi.data();
+    d.iglob0 = S.iglob0.data(); d.jglob0 = S.jglob0.data();
+    std::vector<int32_t> tab, tiles;
+    build_window_table(d, P, OX, OY, strip, tiles, tab);       // halo_plan.cpp (host only: CPU known-answer test)
     CGridState::One &O = CG.one;
-    O.ntiles = (int)tiles.size();
+    O.ntiles = (int)(tiles.size() / 4);
     O.ox = OX;
     O.oy = OY;
     O.per_xcd = (O.ntiles + 7) / 8;
     HIPC(hipMalloc((void **)&O.tab, tab.size() * sizeof(int)));
-    HIPC(hipMalloc((void **)&O.tiles, tiles.size() * sizeof(int4)));
+    HIPC(hipMalloc((void **)&O.tiles, tiles.size() * sizeof(int32_t)));
     HIPC(hipMemcpyAsync(O.tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
-    HIPC(hipMemcpyAsync(O.tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(O.tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice, S.stream));
     for (auto &p : O.alt)
         if (alloc_d(&p, S.n)) return -1;
     HIPC(hipStreamSynchronize(S.stream));       // (the host vectors go out of scope)

@@ -462,3 +462,44 @@ void build_fold_list(const cice_evp_hip_dims &d, int loc, FoldList &L)
             }
         }
 }
+
+void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, int OY, int strip, std::vector<int32_t> &tiles,
+                        std::vector<int32_t> &tab)
+{
+    const int nxb = d.nx_block, nyb = d.ny_block;
+    const long plane = (long)nxb * nyb;
+    std::vector<int> owner((size_t)plane * d.nblocks, -1);
+    for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
+    auto canon = [&](long c) -> long {
+        const int b = (int)(c / plane);
+        const long r = c % plane;
+        const int j = (int)(r / nxb) + 1, i = (int)(r % nxb) + 1;
+        if (i >= d.ilo[b] && i <= d.ihi[b] && j >= d.jlo[b] && j <= d.jhi[b]) return c;
+        return owner[c] >= 0 ? (long)owner[c] : -1 - c;
+    };
+    tiles.clear();
+    tab.clear();
+    strip = std::max(1, strip);
+    for (int b = 0; b < d.nblocks; ++b)
+        for (long is0 = d.ilo[b]; is0 <= d.ihi[b]; is0 += (long)strip * (OX - 3))
+            for (int j0 = d.jlo[b]; j0 <= d.jhi[b]; j0 += OY - 3)
+                for (long i0 = is0; i0 <= d.ihi[b] && i0 < is0 + (long)strip * (OX - 3); i0 += OX - 3) {
+                    bool regular = true;
+                    for (int ty = 0; ty < OY; ++ty)
+                        for (int tx = 0; tx < OX; ++tx) {
+                            const int i = (int)i0 - 2 + tx, j = j0 - 2 + ty;
+                            const int ic = std::min(std::max(i, d.ilo[b] - 1), d.ihi[b] + 1);
+                            const int jc = std::min(std::max(j, d.jlo[b] - 1), d.jhi[b] + 1);
+                            long r = canon((long)b * plane + (long)(jc - 1) * nxb + (ic - 1));
+                            for (int dx = i - ic; dx != 0 && r >= 0; dx -= (dx > 0 ? 1 : -1)) r = canon(r + (dx > 0 ? 1 : -1));
+                            for (int dy = j - jc; dy != 0 && r >= 0; dy -= (dy > 0 ? 1 : -1)) r = canon(r + (dy > 0 ? nxb : -nxb));
+                            tab.push_back((int32_t)r);
+                            regular = regular && i >= 1 && i <= nxb && j >= 1 && j <= nyb &&
+                                      r == (long)b * plane + (long)(j - 1) * nxb + (i - 1);
+                        }
+                    tiles.push_back(b);
+                    tiles.push_back((int32_t)i0);
+                    tiles.push_back(j0);
+                    tiles.push_back(regular ? 1 : 0);
+                }
+}

@@ -99,6 +99,17 @@ struct HaloPlan {
 // Returns false and sets plan.error on inconsistent input.
 bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan);
 
+// Window table of the C grid's one-launch kernel (evp_cgrid.hip: cg_one; host only).  Windows of ox x oy positions, the
+// inner (ox-3) x (oy-3) owned cells, cover every block's interior row by row (in strips of `strip` windows in x).  Per
+// window 4 ints in `tiles` -- block, first owned i, first owned j (1-based, array numbering), 1 if the window is regular
+// (every position an array cell of that block and its own source) -- and ox*oy entries in `tab`: for the position
+// (tx, ty) = cell (i0-2+tx, j0-2+ty) of the block's numbering, which may lie outside its array, the cell whose value the
+// reference has there: >= 0 an interior cell (itself, or the one a ghost cell mirrors according to the plan's local
+// copies; further out the walk continues from the mirrored cell, neighbour by neighbour, x first), or -1 - c for a ghost
+// cell c nothing is copied into (closed boundary, eliminated neighbour block): its arrays are read, never computed.
+void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &plan, int ox, int oy, int strip, std::vector<int32_t> &tiles,
+                        std::vector<int32_t> &tab);
+
 // C grid on a tripole (u-fold) grid: the fold step of one field location (0 centre, 1 NE corner, 2 E face, 3 N face),
 // by the meaning of the cells (ice_boundary.F90:1626-1722): one entry for every cell of every local block -- interior
 // or ghost -- in the top physical row NY (locations with points ON the fold: NE corner, N face) or in the ghost row

@@ -47,7 +47,7 @@ EXPORTS = [
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
-    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_deformations", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan",
+    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_deformations", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -186,6 +186,17 @@ def cgrid_fold_plan(dims: "Dims", loc: str) -> dict:
     _check(lib, lib.cice_evp_hip_cgrid_fold_plan(C.byref(dims), C.c_int32(code), C.byref(n), *[_ip(out[k]) for k in ("dst", "a", "b", "flip")]),
            "(cgrid_fold_plan)")
     return out
+
+
+def cgrid_window_plan(dims: "Dims", ox: int, oy: int) -> dict:
+    """Host only: the window table of the C grid's one-launch kernel (see the header)."""
+    lib = load_library()
+    n = C.c_int32(0)
+    _check(lib, lib.cice_evp_hip_cgrid_window_plan(C.byref(dims), C.c_int32(ox), C.c_int32(oy), C.byref(n), None, None), "(cgrid_window_plan)")
+    tiles = np.zeros((n.value, 4), dtype=np.int32)
+    tab = np.zeros((n.value, oy, ox), dtype=np.int32)
+    _check(lib, lib.cice_evp_hip_cgrid_window_plan(C.byref(dims), C.c_int32(ox), C.c_int32(oy), C.byref(n), _ip(tiles), _ip(tab)), "(cgrid_window_plan)")
+    return dict(tiles=tiles, tab=tab)
 
 
 def stream_probe(ncells: int) -> float:

@@ -300,6 +300,11 @@ int cice_evp_hip_cgrid_deformations(const double *tarear, double *divu, double *
  * First call with NULL lists for the count.                                                                       */
 int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int32_t *count, int32_t *dst, int32_t *a,
                                  int32_t *b, int32_t *flip);
+/* Host only (no device needed): the window table of the C grid's one-launch kernel for windows of ox x oy positions --
+ * per window {block, first owned i, first owned j (1-based), regular} in tiles4 and ox*oy entries in tab: the cell whose
+ * value the reference has at that position (>= 0), or -1 - c for a ghost cell c nothing is copied into.  First call with
+ * NULL arrays for the count.  (What the device kernel reads; checked on the CPU against the decomposition's global numbering.) */
+int cice_evp_hip_cgrid_window_plan(const cice_evp_hip_dims *dims, int32_t ox, int32_t oy, int32_t *ntiles, int32_t *tiles4, int32_t *tab);
 /* out[0] = ms of the last cgrid_subcycle (HIP events), out[1] = its ndte, [2] (n >= 3) = device ms of the last cgrid_prep,
  * [3] (n >= 4) = how many of those subcycles ran as one launch each (the default schedule on one rank without a fold)  */
 int cice_evp_hip_cgrid_timings(double *out, int32_t n);

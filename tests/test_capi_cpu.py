@@ -264,6 +264,65 @@ def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by):
             assert np.array_equal(val, want[L["dst"]]), (loc, kind, int((val != want[L["dst"]]).sum()))
 
 
+@pytest.mark.parametrize("nx,ny,bx,by,ew,ns", [(24, 18, 24, 18, "cyclic", "closed"), (28, 20, 14, 10, "cyclic", "closed"),
+                                               (26, 22, 10, 12, "cyclic", "cyclic"), (40, 30, 20, 10, "closed", "closed"),
+                                               (70, 37, 24, 13, "cyclic", "closed"), (9, 7, 4, 3, "cyclic", "cyclic")])
+@pytest.mark.parametrize("ox,oy", [(32, 8), (64, 16), (8, 6)])
+def test_cgrid_window_table_names_the_source_cell_of_every_position(nx, ny, bx, by, ew, ns, ox, oy):
+    """C grid, one launch per subcycle: the host-built window table (cice_evp_hip_cgrid_window_plan; what the kernel reads)
+    against the decomposition's global numbering.  A position (tx, ty) of a window is the cell (i0-2+tx, j0-2+ty) of its
+    block's numbering -- possibly a ghost cell, possibly beyond the block's array; the table must name the interior cell
+    that holds that GLOBAL cell (through periodic boundaries and into other blocks, any number of steps away), or a ghost
+    cell outside the domain where the boundary is closed.  Every interior cell is owned by exactly one window, and the
+    'regular' mark (the kernel then computes the index instead of loading it) is set exactly where the table is the identity."""
+    from cice_amd import decomp
+    dc = decomp.Decomp(nx, ny, bx, by, ew, ns, 1)
+    d, keep = evp.make_dims(dc, 0)
+    ob = dc.local_blocks(0)
+    nxb, nyb = dc.nx_block, dc.ny_block
+    plane = nxb * nyb
+    home = {}                                   # global (gi, gj) -> flat index of the interior cell that holds it
+    for k, b in enumerate(ob):
+        for j in range(b.jlo, b.jhi + 1):
+            for i in range(b.ilo, b.ihi + 1):
+                home[(b.gi0 + i - b.ilo, b.gj0 + j - b.jlo)] = k * plane + (j - 1) * nxb + (i - 1)
+    assert len(home) == nx * ny
+    P = evp.cgrid_window_plan(d, ox, oy)
+    owned = np.zeros(len(ob) * plane, dtype=int)
+    for (k, i0, j0, regular), tab in zip(P["tiles"], P["tab"]):
+        b = ob[k]
+        ident = True
+        for ty in range(oy):
+            for tx in range(ox):
+                i, j = i0 - 2 + tx, j0 - 2 + ty
+                gi, gj = b.gi0 + i - b.ilo, b.gj0 + j - b.jlo
+                if ew == "cyclic":
+                    gi = (gi - 1) % nx + 1
+                if ns == "cyclic":
+                    gj = (gj - 1) % ny + 1
+                e = int(tab[ty, tx])
+                inside = 1 <= gi <= nx and 1 <= gj <= ny
+                direct = k * plane + (j - 1) * nxb + (i - 1) if (1 <= i <= nxb and 1 <= j <= nyb) else None
+                ident = ident and direct is not None and e == direct
+                if inside:
+                    assert e == home[(gi, gj)], (k, i0, j0, tx, ty, e, home[(gi, gj)])
+                else:
+                    assert e < 0, (k, i0, j0, tx, ty, e)             # beyond a closed boundary: a ghost cell, read as it is
+                    c = -1 - e
+                    kb, r = divmod(c, plane)
+                    jc, ic = r // nxb + 1, r % nxb + 1
+                    bb = ob[kb]
+                    assert not (bb.ilo <= ic <= bb.ihi and bb.jlo <= jc <= bb.jhi)
+                    gic, gjc = bb.gi0 + ic - bb.ilo, bb.gj0 + jc - bb.jlo
+                    assert (ew != "cyclic" and not 1 <= gic <= nx) or (ns != "cyclic" and not 1 <= gjc <= ny), (c, gic, gjc)
+                if 2 <= tx <= ox - 2 and 2 <= ty <= oy - 2 and i <= b.ihi and j <= b.jhi:
+                    owned[e] += 1
+        assert bool(regular) == ident, (k, i0, j0, regular, ident)
+    interior = np.zeros(len(ob) * plane, dtype=int)
+    interior[list(home.values())] = 1
+    assert np.array_equal(owned, interior)      # every interior cell in exactly one window, nothing else owned
+
+
 def test_tracked_pmc_summary_feeds_the_bench_line():
     """bench.py divides counters of the newest profiles/r*_pmc_summary.json by the live kernel time: the summary must
     hold the entry of every kernel the roofline block quotes (a summary reduced from a partial profile directory
