@@ -12,7 +12,9 @@
 // and no halo kernel runs inside the loop.  Fields the reference never exchanges (etax2U, deltaU, stress12T,
 // strintxE/yN, taubxE/yN) are not pushed: their ghost cells end up exactly as the reference leaves them.
 //
-// Two schedules.  "phases": the five phases as five launches (any visc_method).  "fused" (visc_method = avg_zeta):
+// Three schedules.  "one" (cg_one, further down; the default on one rank without a fold): ONE launch per subcycle, the three
+// dependent levels inside a workgroup, neighbouring positions recomputed.  "phases": the five phases as five launches (any
+// visc_method; tripole grids, with a fold step after each).  "fused" (visc_method = avg_zeta; several ranks):
 // three launches per subcycle --
 //   A  face->face / face->corner averages of the PREVIOUS subcycle's velocities recomputed where strain_rates_U
 //      needs them (own cell and the east / north neighbour), so that phase 4 disappears from the loop and runs once

@@ -1,6 +1,7 @@
 // =====================================================================
 // C-grid EVP subcycle behind the C ABI (include/cice_evp_hip.h, cice_evp_hip_cgrid_*): device state, ghost-image
-// table, the loop as a captured graph of three (fused schedule) or five launches per subcycle (evp_cgrid.hip).
+// table, the loop as a captured graph of one (cg_one: one rank, no fold), three (fused schedule) or five launches per
+// subcycle (evp_cgrid.hip).
 //
 // Replaces evp()'s loop for grid_ice = 'C' (ice_dyn_evp.F90:938-1099).  The caller has run the reference's own
 // preparation (dyn_prep1/2 at U, N and E points, seabed stress, the grid averages of the forcing) and hands over
