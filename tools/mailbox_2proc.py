@@ -317,9 +317,9 @@ def main():
             w2, h2 = want.copy(), got[k].copy()
             if ns_bnd == "tripole":    # (scatter() does not know the fold: leave the folded ghost row out)
                 for b in dcN.local_blocks(rank):
-                    if b.gj0 + b.gny - 1 == ny:
-                        w2[b.local][-1, :] = 0.0
-                        h2[b.local][-1, :] = 0.0
+                    if b.gj0 + b.gny - 1 == ny:           # (row gny + 1: a padded block has spare rows above it)
+                        w2[b.local][b.gny + 1:, :] = 0.0
+                        h2[b.local][b.gny + 1:, :] = 0.0
             if not np.array_equal(w2, h2):
                 bad.append((k + " ghosts", float(np.abs(w2 - h2).max())))
     res = [None] * world
