@@ -774,7 +774,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     __shared__ double s_eta[ONE_Y][ONE_X], s_sp[ONE_Y][ONE_X], s_sm[ONE_Y][ONE_X];
     __shared__ double s_dl[ONE_Y][ONE_X];            // deltaU (visc_method = avg_strength: the corner viscosities come from it)
     // workgroups go to the XCDs round-robin: XCD x gets the x-th contiguous run of the (space-ordered) window list
-    const int t = (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
+    const int t = T.plain ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
     if (t >= T.ntiles) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int4 tl = T.tiles[t];                          // block, first owned i, first owned j (1-based)

@@ -344,6 +344,7 @@ struct EvpCgOne {
     const int4 *tiles;            // block, first owned i, first owned j (1-based), 1 if the window is regular (no table needed)
     int ntiles, per_xcd;          // windows; windows per XCD (launch = 8 * per_xcd workgroups)
     int ox, oy;
+    int plain;                    // 1: window = workgroup id (A/B switch; default: contiguous runs of the list per XCD)
     const double *uE_in, *vN_in, *sp_in, *sm_in;   // previous subcycle's buffers (A.f[...] = this subcycle's)
     const double *gbase, *inbase; // the static and the per-call tables as one allocation each: array k = base + k * stride
     size_t stride;                // (70 pointers as kernel arguments do not fit the scalar registers)

@@ -253,7 +253,8 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         const int last = (k == ndte - 1);
         A.f[CF_S12U] = cur;
         if (one && !(first && k == 0)) {
-            EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n};
+            EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy,
+                       (env("CICE_EVP_HIP_CGRID_ONE_XCD") && !std::atoi(env("CICE_EVP_HIP_CGRID_ONE_XCD"))) ? 1 : 0, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n};
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
