@@ -23,6 +23,10 @@ What the line carries besides the contract's fields:
                 against committed oracle checksums, HBM fraction on its 648 B per cell.
   attempts      N > 1 only: every sync point is an agreement over the ranks; a failed or unverified attempt is
                 repeated by all ranks with the resident kernel off, then with RCCL only (config.attempts).
+  configs2_gx1_ndte240, tripole, secondary
+                N > 1: the other BASELINE configs on the same ranks -- gx1 at ndte = 240 (library default, and forced
+                onto RCCL point-to-point), tx1 with the tripole seam (cut in y), 3600x2400 at ndte = 480 -- each
+                verified against its committed checksum, each with every rank's own view (per_rank).
   cpu_baseline  the reference's own evp() timed on this box's cores (2-d path and its 1-d core), and --
                 the checker's job -- the HIP path run on the inputs the reference captured in this
                 same run, compared bit for bit with the reference's outputs (`reference_parity`).
@@ -56,6 +60,7 @@ CHECKPOINTS = [1, 3, 5, 12, 23, 25, 50]     # total steps after which tests/gold
 VERIFY_FIELDS = ("uvel", "vvel", "stressp_1")
 CGRID_VERIFY_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")   # tests/golden/make_bench_checksums.py
 CGRID_B_ALG = 648.0      # C grid: 81 fp64 array touches per cell and subcycle in the fused schedule
+EXTRAS = ("s01", "streaming", "tripole", "cgrid", "per_call", "configs2")
 CGRID_B_ALG_ONE = 408.0  # ... 51 in the one-launch kernel (cg_one: the default up to 600k cells, one rank, no fold)
 
 
@@ -73,7 +78,15 @@ def parse():
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the extra measurements reported under 'secondary', 'tripole', 'roofline.streaming', 'per_call_ms'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time per code path")
-    return ap.parse_args()
+    ap.add_argument("--extras", default="all",
+                    help="comma list of the extra measurements to run (default all): s01, streaming, tripole, cgrid, per_call, "
+                         "configs2 (N > 1: gx1 at ndte = 240, library default and forced RCCL point-to-point)")
+    a = ap.parse_args()
+    a.extras = set(EXTRAS if a.extras == "all" else [x for x in a.extras.split(",") if x])
+    unknown = a.extras - set(EXTRAS)
+    if unknown:
+        ap.error(f"unknown --extras {sorted(unknown)} (known: {', '.join(EXTRAS)})")
+    return a
 
 
 def state_hash(glob: dict) -> str:
@@ -309,7 +322,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
-    def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True):
+    def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True, proc_shape=None):
         """One timed pass: `warmup` untimed + `steps` timed evp() subcycle loops of `workload`,
         block-decomposed over the ranks; barrier + sync on both sides, MAX over ranks."""
         saved = {k: os.environ.get(k) for k in (env or {})}
@@ -319,7 +332,7 @@ def main():
             nx, ny = spec["nx"], spec["ny"]
             g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
             st = synth.make_state(g, case=case, seed=20260928, warm=True)
-            dc = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns)
+            dc = decomp.per_rank_blocks(nx, ny, world, "cyclic", ns, proc_shape)
             geo = {k: dc.scatter(g[k], rank, fill=(1.0 if k != "uarear" else 0.0))
                    for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
             fields = {k: dc.scatter(st[k], rank) for k in evp.FIELDS}
@@ -646,27 +659,69 @@ def main():
     M2 = M3 = MS = None
     extra = {}
     extra_err = {}
-    if a.secondary and a.workload != "s01":
+    want = (lambda k: a.secondary and k in a.extras)
+
+    def rank_block(Mx, label):
+        """One extra workload at N > 1 as the JSON line reports it (rank 0 only uses it)."""
+        c = Mx["nx"] * Mx["ny"]
+        return {"workload": label, "value": c * Mx["ndte"] * Mx["steps"] / Mx["dt"], "unit": "cell-updates/s",
+                "steps": Mx["steps"], "warmup": Mx["warmup"], "ms_per_step": 1e3 * Mx["dt"] / Mx["steps"],
+                "us_per_subcycle": 1e6 * Mx["dt"] / (Mx["steps"] * Mx["ndte"]),
+                "decomposition": f"{Mx['dc'].proc_shape[0]}x{Mx['dc'].proc_shape[1]} ranks, "
+                                 f"{Mx['dc'].block_size_x}x{Mx['dc'].block_size_y} cells each",
+                "tile_variant": Mx["tm_ev"]["tile_variant"], "halo_transport": Mx["tm_ev"]["halo_transport"],
+                "launches_per_subcycle": Mx["tm_ev"]["launches_per_subcycle"],
+                "verified": Mx["ver"].get("verified"), "verification": Mx["ver"], "finite": Mx["finite"],
+                "attempts": Mx.get("attempts"), "per_rank": Mx.get("per_rank")}
+
+    if want("s01") and a.workload != "s01":
         try:      # the 0.1-degree-class grid the strong-scaling target is stated on (streaming kernel, HBM-bound)
             M2 = measure_with_fallbacks("s01", "full", 480, 2, 1)
         except Exception as e:  # noqa: BLE001
             extra_err["secondary"] = f"{type(e).__name__}: {e}"[:300]
-    if a.secondary and world == 1 and 1000 <= tm_ev["tile_variant"] < 3000:
+    if want("streaming") and world == 1 and 1000 <= tm_ev["tile_variant"] < 3000:
         try:      # the same workload through the streaming kernel: its HBM fraction next to the resident kernel's
             MS = measure(a.workload, a.case, ndte, 5, 2, env={"CICE_EVP_HIP_RESIDENT": "0"})
         except Exception as e:  # noqa: BLE001
             extra_err["streaming"] = f"{type(e).__name__}: {e}"[:300]
-    if a.secondary and a.workload == "gx1" and world == 1:
+    if want("configs2") and a.workload == "gx1" and world > 1:
+        # BASELINE configs[2]: gx1 at ndte = 240 over the N GPUs -- once on the library's default path (the on-chip kernel
+        # trading tagged records through IPC-mapped buffers when every rank fits), once forced onto what the config names:
+        # block-decomposition halo over RCCL point-to-point every subcycle (streaming kernel; the exchange on the second
+        # stream where the per-rank domain is large enough to overlap)
+        c2 = {}
+        for label, env2 in (("library_default", {}), ("rccl_point_to_point_forced", {"CICE_EVP_HIP_HALO": "rccl"})):
+            if env2 and rehearsal:
+                c2[label] = {"skipped": "rehearsal on one GPU: RCCL refuses two ranks per device"}
+                continue
+            try:
+                Mx = measure_with_fallbacks("gx1", "full", 240, 4, 1, env=env2)
+                c2[label] = rank_block(Mx, f"gx1 {Mx['nx']}x{Mx['ny']} B-grid EVP ndte=240, case=full, {world} GPUs")
+            except Exception as e:  # noqa: BLE001
+                c2[label] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        extra["configs2_gx1_ndte240"] = c2
+    if want("tripole") and a.workload == "gx1" and world > 1:
+        # BASELINE configs[3]: the tripole grid over the N GPUs, cut in y (1 x N slabs): the fold row stays on one rank, which
+        # is the layout where the on-chip kernel averages the seam pairs itself; a cut through the fold row (4 x 2) runs the
+        # streaming kernel + seam step (DESIGN.md section 8)
+        try:
+            Mx = measure_with_fallbacks("tx1", "full", 240, 10, 2, ns="tripole", proc_shape=(1, world))
+            extra["tripole"] = rank_block(Mx, f"tx1 {Mx['nx']}x{Mx['ny']} tripole B-grid EVP ndte=240, case=full, {world} GPUs")
+        except Exception as e:  # noqa: BLE001
+            extra_err["tripole"] = f"{type(e).__name__}: {e}"[:300]
+    if want("tripole") and a.workload == "gx1" and world == 1:
         try:      # the tripole grid of configs[3] (fold row averaged inside the resident kernel)
             M3 = measure("tx1", "full", 240, 10, 2, ns="tripole")
         except Exception as e:  # noqa: BLE001
             extra_err["tripole"] = f"{type(e).__name__}: {e}"[:300]
+    if want("cgrid") and a.workload == "gx1" and world == 1:
         try:      # next-tier row f-4: the C-grid subcycle on the same grid, and on the 0.1-degree-class one (HBM-bound)
             extra["cgrid"] = cgrid_measure("gx1", "full", 120, 3, 1)
             extra["cgrid"]["s01"] = cgrid_measure("s01", "full", 12, 1, 1)
             extra["cgrid"]["per_call_ms"] = cgrid_per_call("gx1", "full", 120)
         except Exception as e:  # noqa: BLE001
             extra_err["cgrid"] = f"{type(e).__name__}: {e}"[:300]
+    if want("per_call") and a.workload == "gx1" and world == 1:
         try:
             extra["per_call_ms"] = per_call_cost(a.workload, a.case, ndte)
         except Exception as e:  # noqa: BLE001

@@ -30,11 +30,13 @@ CONFIGS = {   # workload: (case, ndte, ns, checkpoints)
     "gx1": ("full", 120, "closed", [1, 3, 5, 12, 23, 25, 50]),
     "s01": ("full", 480, "closed", [3]),
     "tx1": ("full", 240, "tripole", [12]),
+    "gx1@240": ("full", 240, "closed", [3, 5, 12]),      # BASELINE configs[2]: gx1 at ndte = 240 (bench.py N > 1)
 }
 
 
 def run(workload):
     case, ndte, ns, cps = CONFIGS[workload]
+    workload = workload.split("@")[0]
     spec = synth.GRIDS[workload]
     nx, ny = spec["nx"], spec["ny"]
     g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))

@@ -104,27 +104,38 @@ def test_bench_multi_rank_rehearsal():
     """bench.py's N>1 path (decomposition, collective set-up, barrier + MAX-over-ranks timing, the
     JSON line) rehearsed on the one GPU of this box: 2 ranks as 2 processes over gloo with the
     mailbox halo bootstrapped by hand (CICE_EVP_BENCH_REHEARSAL=1; the driver's real N>1 runs use
-    RCCL and one GPU per rank)."""
+    RCCL and one GPU per rank).  The line of an N > 1 run must speak for BASELINE configs[2] (gx1 at
+    ndte = 240: library default and forced RCCL point-to-point) and configs[3] (tx1, tripole) too."""
     import json
     import subprocess
     import sys as _sys
     root = Path(__file__).resolve().parents[1]
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx3", "--no-secondary"]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx1", "--extras", "configs2,tripole"]
     env = dict(os.environ, CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["halo_transport"] == "mailbox" and d["config"]["finite"]
+    assert d["config"]["halo_transport"] == "mailbox" and d["config"]["finite"] and d["verified"] is True
     assert d["config"]["tile_variant"] >= 2000         # the resident kernel with remote neighbours
     assert d["cpu_baseline"] is None and "roofline" in d
     # every rank's own view of the timed region (what a first run on real xGMI is read with)
     pr = d["config"]["per_rank"]
     assert [q["rank"] for q in pr] == [0, 1] and all(q["halo_transport"] == "mailbox" and q["halo_send_cells"] > 0 for q in pr)
     assert all(q["stream_ms"] > 0 and q["wall_ms"] >= 0.5 * q["stream_ms"] and q["local_cells"] > 0 for q in pr)
+    # configs[2]: gx1 at ndte = 240, verified against its own committed checksum; the forced-RCCL leg cannot run here
+    c2 = d["configs2_gx1_ndte240"]
+    lib = c2["library_default"]
+    assert lib["verified"] is True and lib["finite"] and lib["tile_variant"] >= 2000 and lib["us_per_subcycle"] > 0, lib
+    assert lib["verification"]["key"] == "gx1/full/ndte240/closed/strict" and [q["rank"] for q in lib["per_rank"]] == [0, 1]
+    assert "skipped" in c2["rccl_point_to_point_forced"]
+    # configs[3]: the tripole grid cut in y, the fold row on the top rank, the on-chip kernel on both
+    tp = d["tripole"]
+    assert tp["verified"] is True and tp["finite"] and tp["decomposition"].startswith("1x2 ranks"), tp
+    assert tp["tile_variant"] >= 2000 and [q["rank"] for q in tp["per_rank"]] == [0, 1]
 
 
 @pytest.mark.parametrize("world,workload,shape,extra", [(2, "gx3", "", []), (4, "gx3", "2x2", ["--blocks-per-rank", "2x2", "--timing"]),
