@@ -21,6 +21,7 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen)
 }
 
 // host only: the C-grid fold step of one location for the decomposition in `dims` (counts first, then the lists)
+#ifdef CICE_EVP_HIP_TESTING
 int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int32_t *count, int32_t *dst, int32_t *a,
                                  int32_t *b, int32_t *flip)
 {
@@ -46,6 +47,7 @@ int cice_evp_hip_cgrid_window_plan(const cice_evp_hip_dims *dims, int32_t ox, in
     if (tab) std::copy(tb.begin(), tb.end(), tab);
     return 0;
 }
+#endif  // CICE_EVP_HIP_TESTING
 
 int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second)
 {
@@ -90,7 +92,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     S.d.iglob0 = S.iglob0.data(); S.d.jglob0 = S.jglob0.data();
 
     if (!build_halo_plan(*dims, S.plan)) return fail(-3, "halo plan: %s", S.plan.error.c_str());
-    if (env("CICE_EVP_HIP_SELF_EXCHANGE") && std::atoi(env("CICE_EVP_HIP_SELF_EXCHANGE")) && dims->nranks == 1) {
+    if (env_test("CICE_EVP_HIP_SELF_EXCHANGE") && std::atoi(env_test("CICE_EVP_HIP_SELF_EXCHANGE")) && dims->nranks == 1) {
         // test hook: route the on-device ghost copies through pack -> ncclSend/ncclRecv (to
         // self) -> unpack, so that the remote-halo code path runs on a single GPU
         HaloPeer self;
@@ -185,7 +187,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     if (alloc_d(&S.hte, S.n) || alloc_d(&S.htn, S.n) || alloc_d(&S.vrelfac, S.n)) return -1;
     S.flags = EVP_F_VRELFAC;
     S.flags_allowed = ~0u;
-    if (env("CICE_EVP_HIP_FLAGS")) S.flags_allowed = (unsigned)std::strtoul(env("CICE_EVP_HIP_FLAGS"), nullptr, 0);
+    if (env_test("CICE_EVP_HIP_FLAGS")) S.flags_allowed = (unsigned)std::strtoul(env_test("CICE_EVP_HIP_FLAGS"), nullptr, 0);
     HIPC(hipMalloc((void **)&S.mask, S.n));
     HIPC(hipMemsetAsync(S.mask, 0, S.n, S.stream));
     HIPC(hipMalloc((void **)&S.blk, nb * sizeof(int4)));
@@ -553,7 +555,7 @@ int cice_evp_hip_download(double *const *f)
 // that recovery paths can be exercised on a healthy GPU.
 static bool fault_hook(const char *name)
 {
-    const char *e = env(name);
+    const char *e = env_test(name);
     return e && ++S.fault_calls == std::atoi(e);      // counted from cice_evp_hip_init
 }
 
@@ -582,7 +584,7 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
         for (double *p : {strintxU, strintyU, taubxU, taubyU})
             if (p) D.items.push_back({p, nullptr});
         S.lean_diag = D.items.size() == 4 && batch_mapped(D, false) &&
-                      !(env("CICE_EVP_HIP_LEAN") && !std::atoi(env("CICE_EVP_HIP_LEAN")));
+                      !(env_test("CICE_EVP_HIP_LEAN") && !std::atoi(env_test("CICE_EVP_HIP_LEAN")));
     }
     struct LeanOff { ~LeanOff() { S.lean_diag = false; } } lean_off;      // only for the duration of this call
     if (int rc = upload_impl(f, iceTmask, iceUmask, keep_sig)) return rc;
@@ -627,6 +629,9 @@ int cice_evp_hip_run(double *stressp_1, double *stressp_2, double *stressp_3, do
             }
             if (int rc = upload_impl(f, iceTmask, iceUmask, keep_sig)) return rc;
             if (int rc = cice_evp_hip_subcycle(ndte)) return rc;
+            // the resident kernel is off from here on (res_mode = 0): the snapshot has no further use
+            HIPC(hipStreamSynchronize(S.stream));
+            for (auto &q : S.sig_snap) { if (q) (void)hipFree(q); q = nullptr; }
         }
     }
     // only the documented outputs travel back
@@ -706,6 +711,7 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3)
     return 0;
 }
 
+#ifdef CICE_EVP_HIP_TESTING
 // Per-CU record of the last resident launch (16 x 16 tiles): 2048 CUs x {lock, stamp, ice-holding waves
 // on SIMD 0..3, 0, 0}; for tools that check how evenly the workgroups spread their waves.
 int cice_evp_hip_debug_cuload(int32_t *out, int32_t n)
@@ -837,6 +843,7 @@ int cice_evp_hip_stress_plan(int32_t *count, int32_t *dst, int32_t *src)
     }
     return 0;
 }
+#endif  // CICE_EVP_HIP_TESTING
 
 // General form of the seam step (any rank layout): counts2 = {entries, staging slots}; lists may be NULL.
 int cice_evp_hip_seam_fin_plan(int32_t *counts2, int32_t *dst, int32_t *a, int32_t *b, int32_t *coef)
@@ -881,6 +888,7 @@ int cice_evp_hip_describe_path(char *buf, int32_t n)
     return 0;
 }
 
+#ifdef CICE_EVP_HIP_TESTING
 int cice_evp_hip_plan_flags(int32_t *flags, int32_t n)
 {
     const HaloPlan &P = S.plan;
@@ -912,5 +920,6 @@ int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, i
     }
     return 0;
 }
+#endif  // CICE_EVP_HIP_TESTING
 
 }  // extern "C"

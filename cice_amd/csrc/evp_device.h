@@ -1,6 +1,8 @@
 // Device-side argument blocks and launcher prototypes shared by
 // evp_kernels.hip (kernels) and evp_api.cpp (C ABI / state management).
 #pragma once
+// test-build-only environment switch (evp_host_common.cpp): NULL in the production library
+const char *evp_env_test(const char *key);
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>

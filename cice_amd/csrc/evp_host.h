@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/cice_evp_hip.h"
+#include "../../include/cice_evp_hip_testing.h"   // (declarations; the definitions exist under CICE_EVP_HIP_TESTING only)
 #include "evp_device.h"
 #include "halo_plan.h"
 
@@ -265,6 +266,9 @@ struct State {
 extern State S;
 
 inline const char *env(const char *k) { return std::getenv(k); }
+// experiment / fault-injection switches: read in the TEST build (-DCICE_EVP_HIP_TESTING -> libcice_evp_hip_testing.so)
+// only; in the production library they are unset whatever the process environment says (evp_host_common.cpp)
+inline const char *env_test(const char *k) { return evp_env_test(k); }
 
 // mailbox layout: EVP_DIRECT_MAXPEER flag lines, then seq, err, then the inbox
 constexpr size_t DIRECT_SEQ_OFF = (size_t)EVP_DIRECT_MAXPEER * EVP_DIRECT_FLAG_STRIDE * sizeof(unsigned);

@@ -119,14 +119,14 @@ static void fill(EvpCgrid &A)
     A.avg_strength = CG.avg_strength;
     A.tripole = CG.tripole ? 1 : 0;
     {   // two waves per cell in the fused step kernel while the grid is small enough to be latency-bound
-        const char *e = env("CICE_EVP_HIP_CGRID_SPLIT");
+        const char *e = env_test("CICE_EVP_HIP_CGRID_SPLIT");
         A.split_faces = e ? (std::atoi(e) != 0) : (S.n <= 600000);
     }
     {   // XCD-banded workgroup numbering (evp_cgrid.hip: cell()); CICE_EVP_HIP_CGRID_XCD=0: plain 2-D launch
-        const bool on = !(env("CICE_EVP_HIP_CGRID_XCD") && !std::atoi(env("CICE_EVP_HIP_CGRID_XCD")));
+        const bool on = !(env_test("CICE_EVP_HIP_CGRID_XCD") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_XCD")));
         const int gy = (S.d.ny_block + 3) / 4;      // TY = 4 rows per workgroup
         const int gx = (S.d.nx_block + 63) / 64;    // TX = 64
-        const int rows = env("CICE_EVP_HIP_CGRID_XCD") && std::atoi(env("CICE_EVP_HIP_CGRID_XCD")) > 1 ? std::atoi(env("CICE_EVP_HIP_CGRID_XCD")) : std::max(1, 256 / gx);
+        const int rows = env_test("CICE_EVP_HIP_CGRID_XCD") && std::atoi(env_test("CICE_EVP_HIP_CGRID_XCD")) > 1 ? std::atoi(env_test("CICE_EVP_HIP_CGRID_XCD")) : std::max(1, 256 / gx);
         A.xcd_rows = on ? std::min((gy + 7) / 8, rows) : 0;
     }
     A.plane = S.plane;
@@ -254,7 +254,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         A.f[CF_S12U] = cur;
         if (one && !(first && k == 0)) {
             EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy,
-                       (env("CICE_EVP_HIP_CGRID_ONE_XCD") && !std::atoi(env("CICE_EVP_HIP_CGRID_ONE_XCD"))) ? 1 : 0, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n};
+                       (env_test("CICE_EVP_HIP_CGRID_ONE_XCD") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_ONE_XCD"))) ? 1 : 0, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n};
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
@@ -348,14 +348,14 @@ static int build_one_tables()
     // what counts once there are several windows per CU (720x270: 24.6 / 21.9 us with 32x8 / 64x16; 3600x2400: 1083 / 1032 /
     // 925 with 32x8 / 64x8 / 64x16).  CICE_EVP_HIP_CGRID_ONE_SHAPE=0 / 1 / 2 picks one
     int shape = S.n > 160000 ? 2 : (S.n > 40000 ? 1 : 0);
-    if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::min(2, std::max(0, std::atoi(e)));
+    if (const char *e = env_test("CICE_EVP_HIP_CGRID_ONE_SHAPE")) shape = std::min(2, std::max(0, std::atoi(e)));
     const int OX = shape ? 64 : 32, OY = shape == 2 ? 16 : 8;
     // Order of the windows = order of the workgroups on an XCD (each XCD takes a contiguous run of the list): row by row.
     // (Strips of a few windows in x, top to bottom, so that vertical neighbours run together and share their 2-3 common rows
     // in L2, were measured: 3600 x 2400 1083 us row by row, 1171 / 1139 / 1106 / 1082 in strips of 4 / 8 / 16 / 32 windows --
     // narrow strips cost more in DRAM locality than the shared rows save.  CICE_EVP_HIP_CGRID_ONE_STRIP=<n> for A/B.)
     int strip = 1 << 20;
-    if (const char *e = env("CICE_EVP_HIP_CGRID_ONE_STRIP")) strip = std::max(1, std::atoi(e));
+    if (const char *e = env_test("CICE_EVP_HIP_CGRID_ONE_STRIP")) strip = std::max(1, std::atoi(e));
     cice_evp_hip_dims d = S.d;
     d.ilo = S.ilo.data(); d.ihi = S.ihi.data(); d.jlo = S.jlo.data(); d.jhi = S.jhi.data();
     d.iglob0 = S.iglob0.data(); d.jglob0 = S.jglob0.data();
@@ -517,7 +517,7 @@ int finish_upload(int32_t visc_method)
     }
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(S.stream));       // the caller may change its arrays after this returns
-    CG.fast = h_flags == 0 && !(env("CICE_EVP_HIP_CGRID_FAST") && !std::atoi(env("CICE_EVP_HIP_CGRID_FAST")));
+    CG.fast = h_flags == 0 && !(env_test("CICE_EVP_HIP_CGRID_FAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_FAST")));
     CG.uploaded = true;
     CG.first = true;
     return 0;

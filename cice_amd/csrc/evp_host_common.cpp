@@ -5,6 +5,12 @@
 // host arithmetic of derive_metrics must round every operation (no FMA)
 #pragma clang fp contract(off)
 
+#ifdef CICE_EVP_HIP_TESTING
+const char *evp_env_test(const char *key) { return std::getenv(key); }
+#else
+const char *evp_env_test(const char *) { return nullptr; }
+#endif
+
 namespace evp_host {
 
 std::string g_err;
@@ -148,7 +154,7 @@ static void *mapped_view(const void *host, size_t bytes)
 
 static int run_batch(CopyBatch &B, bool to_device)
 {
-    const bool off = env("CICE_EVP_HIP_GATHER") && !std::atoi(env("CICE_EVP_HIP_GATHER"));
+    const bool off = env_test("CICE_EVP_HIP_GATHER") && !std::atoi(env_test("CICE_EVP_HIP_GATHER"));
     EvpCopyTab T{};
     T.len = S.n;
     T.vec2 = 1;
@@ -179,7 +185,7 @@ static int run_batch(CopyBatch &B, bool to_device)
 // every host array of the batch lies in a range the caller page-locked and mapped (and the gather path is on)
 bool batch_mapped(const CopyBatch &B, bool to_device)
 {
-    if (env("CICE_EVP_HIP_GATHER") && !std::atoi(env("CICE_EVP_HIP_GATHER"))) return false;
+    if (env_test("CICE_EVP_HIP_GATHER") && !std::atoi(env_test("CICE_EVP_HIP_GATHER"))) return false;
     for (auto &it : B.items)
         if (!mapped_view(to_device ? (const void *)it.second : (const void *)it.first, S.n * sizeof(double))) return false;
     return true;
@@ -277,7 +283,7 @@ int upload_lists()
     }
     S.n_fin = (int)P.fin_dst.size();
     // the list is only run on layouts that split the seam row (halo_uv: general form) or when forced for tests
-    const bool fin_used = P.tail > 0 || (env("CICE_EVP_HIP_SEAM_FIN") && std::atoi(env("CICE_EVP_HIP_SEAM_FIN")));
+    const bool fin_used = P.tail > 0 || (env_test("CICE_EVP_HIP_SEAM_FIN") && std::atoi(env_test("CICE_EVP_HIP_SEAM_FIN")));
     if (fin_used && S.n_fin > evp_halo_seam_fin_capacity()) return fail(-3, "tripole seam: %d cells to finalise on one rank (limit %d)", S.n_fin, evp_halo_seam_fin_capacity());
     if (up32(P.fin_dst, S.h_fin_dst) || up32(P.fin_a, S.h_fin_a) || up32(P.fin_b, S.h_fin_b)) return -1;
     if (S.n_fin) {
@@ -395,7 +401,7 @@ void fill_args(EvpArgs &A, int cur, int last)
 // exactly 1.0 / sums with exactly 0.0 the kernels then leave out, bit-neutral (CICE_EVP_HIP_SIMPLE=0: off)
 int cap_mode()
 {
-    const bool simple_ok = !(env("CICE_EVP_HIP_SIMPLE") && !std::atoi(env("CICE_EVP_HIP_SIMPLE")));
+    const bool simple_ok = !(env_test("CICE_EVP_HIP_SIMPLE") && !std::atoi(env_test("CICE_EVP_HIP_SIMPLE")));
     if (simple_ok && S.prm.capping == 1.0 && S.prm.revp == 0.0 && S.prm.Ktens == 0.0 && S.prm.cosw == 1.0 &&
         S.prm.sinw == 0.0)
         return 3;

@@ -28,7 +28,7 @@ void fill_direct(EvpDirect &D, bool masked)
     const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
     D.timeout_ticks = (unsigned long long)(tmo_ms * 1.0e5);     // 100 MHz wall clock
     D.peer_flag = X.peer_flag;
-    const int dbg = env("CICE_EVP_HIP_HALO_DEBUG") ? std::atoi(env("CICE_EVP_HIP_HALO_DEBUG")) : 0;
+    const int dbg = env_test("CICE_EVP_HIP_HALO_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_HALO_DEBUG")) : 0;
     D.dbg = dbg;
 }
 
@@ -134,7 +134,7 @@ int halo_uv(int b, bool masked)
     if (!pushed)
         evp_launch_halo_local(S.u[b], S.v[b], S.h_local_dst, S.h_local_src,
                               (const signed char *)S.h_local_sign, S.n_local, S.stream);
-    const bool general = S.plan.tail > 0 || (env("CICE_EVP_HIP_SEAM_FIN") && std::atoi(env("CICE_EVP_HIP_SEAM_FIN")));
+    const bool general = S.plan.tail > 0 || (env_test("CICE_EVP_HIP_SEAM_FIN") && std::atoi(env_test("CICE_EVP_HIP_SEAM_FIN")));
     if (!general) {
         // tripole seam of the top physical row, every pair and every ghost image of a seam cell on this rank: the
         // remote exchange below never involves seam-row cells
@@ -157,7 +157,7 @@ bool use_overlap()
 {
     const bool seam = (S.n_seam + S.n_pole + S.n_late) > 0;
     if (!S.overlap || S.plan.peers.empty() || seam || !(S.have_comm || S.direct.on)) return false;
-    if (env("CICE_EVP_HIP_OVERLAP")) return std::atoi(env("CICE_EVP_HIP_OVERLAP")) != 0;
+    if (env_test("CICE_EVP_HIP_OVERLAP")) return std::atoi(env_test("CICE_EVP_HIP_OVERLAP")) != 0;
     size_t cells = 0;
     for (int b = 0; b < S.d.nblocks; ++b)
         cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);
@@ -172,7 +172,7 @@ bool use_riding_exchange()
     // kernel: 4 x 1800x1200 blocks 571 vs 627 us, 720x540 27.9 vs 34.1, 720x270 19.4 vs 22.1); on a
     // domain that is one wave of workgroups there is nothing to overlap with and the separate kernel
     // is quicker (gx1, 2 x 320x192: 25 vs 20.8 us).
-    if (env("CICE_EVP_HIP_HALO_RIDE")) return std::atoi(env("CICE_EVP_HIP_HALO_RIDE")) != 0;
+    if (env_test("CICE_EVP_HIP_HALO_RIDE")) return std::atoi(env_test("CICE_EVP_HIP_HALO_RIDE")) != 0;
     size_t cells = 0;
     for (int b = 0; b < S.d.nblocks; ++b)
         cells += (size_t)(S.ihi[b] - S.ilo[b] + 1) * (S.jhi[b] - S.jlo[b] + 1);

@@ -39,7 +39,7 @@ int direct_export(HaloBlob &B)
     // live in the mailbox allocation (one IPC handle)
     bool want_res = resident_possible(true) && !S.plan.peers.empty() &&
                     !(env("CICE_EVP_HIP_RESIDENT") && std::atoi(env("CICE_EVP_HIP_RESIDENT")) == 0) &&
-                    !(env("CICE_EVP_HIP_RES_REMOTE") && std::atoi(env("CICE_EVP_HIP_RES_REMOTE")) == 0);
+                    !(env_test("CICE_EVP_HIP_RES_REMOTE") && std::atoi(env_test("CICE_EVP_HIP_RES_REMOTE")) == 0);
     size_t rec_off = 0;
     const size_t rec_stride = S.n * 32;            // one 32-byte record pair per cell of every block
     if (!X.mailbox) {
@@ -161,7 +161,7 @@ int direct_import(const HaloBlob *blobs, int nranks)
             const HaloBlob &B = blobs[p.rank];
             prec[q] = mapped[p.rank] + B.rec_off;
             pstr[q] = (size_t)B.rec_stride;
-            if (env("CICE_EVP_HIP_RES_REMOTE_BREAK")) {      // test hook: records go nowhere -> the probe must fail
+            if (env_test("CICE_EVP_HIP_RES_REMOTE_BREAK")) {      // test hook: records go nowhere -> the probe must fail
                 void *dummy = nullptr;
                 HIPC(hipMalloc(&dummy, 2 * (size_t)B.rec_stride));
                 prec[q] = dummy;                             // (leaked on purpose: test processes only)

@@ -13,9 +13,10 @@
 // A call of cice_evp_hip_subcycle(ndte) through this path:
 //   [ndte odd: one subcycle with the one-subcycle kernel]  gather -> consistency check (first call after an upload)
 //   -> ndte/2 passes (ping-pong between two sets of u, v, 12 stresses) -> scatter.
-// Not eligible (the one-subcycle kernels keep running): several ranks, tripole / cyclic north-south boundary, blocks
-// that do not tile a rectangle (eliminated land blocks), metric terms handed over as arrays (tripole), a caller
-// whose ghost values are not images of one global state.
+// Not eligible (the one-subcycle kernels keep running): tripole / cyclic north-south boundary, blocks that do not tile a
+// rectangle per rank (eliminated land blocks), metric terms handed over as arrays (tripole), a rank too thin next to a
+// closed boundary for its redundant rim (march_plan.cpp), a caller whose ghost values are not images of one global
+// state.  Several ranks: the ring of ext + 2 cells travels over RCCL send / recv once per ext/2 + 1 passes (section 6).
 // =====================================================================
 #include "evp_host.h"
 #include "march_plan.h"
@@ -66,8 +67,8 @@ static bool march_geometry(std::string &why)
     State::March &M = S.march;
     const cice_evp_hip_dims &d = S.d;
     // the rectangles of all ranks, this rank's strips and the exchange lists: the same verdict on every rank
-    const int own_max = env("CICE_EVP_HIP_MARCH_OWN") ? std::atoi(env("CICE_EVP_HIP_MARCH_OWN")) : EVP_MARCH_OWN;
-    const bool wrap_inside = !(env("CICE_EVP_HIP_MARCH_SELFX") && std::atoi(env("CICE_EVP_HIP_MARCH_SELFX")));
+    const int own_max = env_test("CICE_EVP_HIP_MARCH_OWN") ? std::atoi(env_test("CICE_EVP_HIP_MARCH_OWN")) : EVP_MARCH_OWN;
+    const bool wrap_inside = !(env_test("CICE_EVP_HIP_MARCH_SELFX") && std::atoi(env_test("CICE_EVP_HIP_MARCH_SELFX")));
     // cells a rank holds beyond its own on every side with a neighbour: the ring is then exchanged every (ext/2 + 1)-th
     // pass only (march_plan.h); 4 = every third pass (every sixth subcycle).  3600 x 2400 as 4x2 pieces, one-GPU rehearsal:
     // 54.3 / 52.3 / 52.0 / 51.2 us per subcycle with ext 0 / 2 / 4 / 6 against 47.0 without any exchange
@@ -127,7 +128,7 @@ static bool march_geometry(std::string &why)
     if (M.nblk * EVP_MARCH_S_NF * 512 >= (1ull << 32)) { why = "state buffer beyond 32-bit byte offsets"; return false; }
     // segments: one wave per SIMD (1024 of them), all resident at once -- measured at 3600 x 2400: 16 segments (960
     // waves) 318 us per subcycle, 24 (1440: some SIMDs get two) 400, 34 (2040: two each) 378, 12 (720) 372
-    int seglen = env("CICE_EVP_HIP_MARCH_SEG") ? std::atoi(env("CICE_EVP_HIP_MARCH_SEG")) : 0;
+    int seglen = env_test("CICE_EVP_HIP_MARCH_SEG") ? std::atoi(env_test("CICE_EVP_HIP_MARCH_SEG")) : 0;
     if (seglen <= 0) {
         // (medium domains, 0.45M .. 1M cells: shorter segments keep the count near 1000 -- 1080 x 720: 14-row segments 39 us
         // per subcycle against 53 for the one-subcycle kernel; each segment recomputes ~3.5 rows of warm-up)
@@ -312,9 +313,11 @@ bool march_wanted()
     if (M.mode >= 0) return M.mode == 1;
     M.mode = 0;
     const int want = env("CICE_EVP_HIP_MARCH") ? std::atoi(env("CICE_EVP_HIP_MARCH")) : -1;
-    if (want == 0) return false;
+    // (a rank that was told CICE_EVP_HIP_MARCH=0 still takes part in the agreement below, voting no: an environment that
+    // differs between the ranks then switches the path off everywhere instead of leaving the others in a collective)
     std::string why;
-    bool ok = march_geometry(why);
+    bool ok = want != 0 && march_geometry(why);
+    if (want == 0) why = "CICE_EVP_HIP_MARCH=0";
     if (S.d.nranks > 1 && S.test_reduce) {
         int32_t h = ok ? 1 : 0;
         if (S.test_reduce(S.test_user, 0, &h)) return false;
@@ -357,7 +360,7 @@ static void march_args(EvpMarch &A, int cur, int last)
     A.nstrips = M.nstrips; A.nseg = M.nseg; A.seglen = M.seglen; A.nitems = M.nitems;
     A.wrapx = M.G.wrapx;
     A.last = last;
-    A.order = env("CICE_EVP_HIP_MARCH_ORDER") ? std::atoi(env("CICE_EVP_HIP_MARCH_ORDER")) : 1;
+    A.order = env_test("CICE_EVP_HIP_MARCH_ORDER") ? std::atoi(env_test("CICE_EVP_HIP_MARCH_ORDER")) : 1;
     A.flags = S.flags & S.flags_allowed;
     A.mask = B.mask;
     A.st_in = B.st[cur]; A.st_out = B.st[cur ^ 1];
@@ -390,6 +393,7 @@ int march_run(int ndte)
         if (int rc = enqueue_loop(1, cur)) return rc;
         cur ^= 1;
         --left;
+        S.cur = cur;         // the device state HAS advanced: an error further down must not leave S.cur on the old copy
     }
     if (left == 0) { S.cur = cur; return 0; }
     const unsigned fl = S.flags & S.flags_allowed;
@@ -464,6 +468,7 @@ int march_run(int ndte)
 
 }  // namespace evp_host
 
+#ifdef CICE_EVP_HIP_TESTING
 extern "C" int cice_evp_hip_set_test_transport(cice_evp_hip_test_xchg_fn xchg, cice_evp_hip_test_reduce_fn reduce, void *user)
 {
     using namespace evp_host;
@@ -502,3 +507,4 @@ extern "C" int cice_evp_hip_march_plan(const cice_evp_hip_dims *dims, int32_t ow
     }
     return 0;
 }
+#endif  // CICE_EVP_HIP_TESTING

@@ -312,7 +312,7 @@ int resident2_order()
         HIPC(hipMemcpyAsync(S.res2_late, late.data(), late.size(), hipMemcpyHostToDevice, S.stream));
         HIPC(hipMemcpyAsync(S.res2_nact, nact.data(), nact.size(), hipMemcpyHostToDevice, S.stream));
     }
-    const bool off = env("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env("CICE_EVP_HIP_RES_ORDER"));
+    const bool off = env_test("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env_test("CICE_EVP_HIP_RES_ORDER"));
     std::vector<int> order((size_t)ntiles);
     for (int w = 0; w < ntiles; ++w) order[w] = w;
     if (!off) {
@@ -370,12 +370,12 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.nact = S.res2_nact;
     R.cuload = S.res2_cuload;
     R.prof = nullptr;
-    if (S.res2_logw == 4 && env("CICE_EVP_HIP_RES_PROF") && std::atoi(env("CICE_EVP_HIP_RES_PROF"))) {
+    if (S.res2_logw == 4 && env_test("CICE_EVP_HIP_RES_PROF") && std::atoi(env_test("CICE_EVP_HIP_RES_PROF"))) {
         if (!S.res2_prof) HIPC(hipMalloc((void **)&S.res2_prof, (size_t)S.res2_ntiles * 32 * sizeof(unsigned long long)));
         HIPC(hipMemsetAsync(S.res2_prof, 0, (size_t)S.res2_ntiles * 32 * sizeof(unsigned long long), S.stream));
         R.prof = S.res2_prof;
     }
-    const int dbg2 = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
+    const int dbg2 = env_test("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.dbg = dbg2;
     R.seam = S.res2_seam;
     R.img3 = S.res2_img3;
@@ -443,8 +443,8 @@ int launch_resident(int ndte, int cur0, bool dry)
     R.cur0 = dry ? 0 : cur0;
     R.dry = dry ? 1 : 0;
     R.spin_limit = 4000000u;
-    R.xcdmap = env("CICE_EVP_HIP_RES_XCD") ? std::atoi(env("CICE_EVP_HIP_RES_XCD")) : 0;
-    R.dbg = env("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env("CICE_EVP_HIP_RES_DEBUG")) : 0;
+    R.xcdmap = env_test("CICE_EVP_HIP_RES_XCD") ? std::atoi(env_test("CICE_EVP_HIP_RES_XCD")) : 0;
+    R.dbg = env_test("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.flags = S.res_flags;
     R.nbr = S.res_nbr;
     R.err = S.res_err;

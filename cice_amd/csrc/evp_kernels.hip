@@ -421,7 +421,7 @@ template <int TYB>
 void launch_tile(const EvpArgs &A, dim3 grid, hipStream_t st, bool strict, int cap)
 {
     dim3 block(64, TYB);
-    const bool pre = std::getenv("CICE_EVP_HIP_PREFETCH") && std::atoi(std::getenv("CICE_EVP_HIP_PREFETCH"));
+    const bool pre = evp_env_test("CICE_EVP_HIP_PREFETCH") && std::atoi(evp_env_test("CICE_EVP_HIP_PREFETCH"));
 #define EVP_LAUNCH(S, C)                                                                           \
     do {                                                                                           \
         if (pre) hipLaunchKernelGGL((evp_subcycle_tile<TYB, S, C, true>), grid, block, 0, st, A);  \

@@ -537,7 +537,7 @@ void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
     const unsigned nwg = (unsigned)((A.nitems + 3) / 4);
     const dim3 grid((A.order & 1) ? ((nwg + 7) / 8) * 8 : nwg), block(256);
     const bool lean = mode == 3 && (A.flags & EVP_F_WATER_IS_OCN) && (A.flags & EVP_F_TBU_ZERO) &&
-                      !(std::getenv("CICE_EVP_HIP_MARCH_LEAN") && !std::atoi(std::getenv("CICE_EVP_HIP_MARCH_LEAN")));
+                      !(evp_env_test("CICE_EVP_HIP_MARCH_LEAN") && !std::atoi(evp_env_test("CICE_EVP_HIP_MARCH_LEAN")));
 #define EVP_MARCH_LAUNCH(S, M, L)                                                                    \
     do {                                                                                             \
         if (A.last) hipLaunchKernelGGL((evp_march2p<S, M, L, true>), grid, block, 0, st, A);         \

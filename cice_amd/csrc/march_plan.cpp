@@ -99,6 +99,21 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
         H.E.nxr = R.nxr + H.w + H.e; H.E.nyr = R.nyr + H.s + H.n;
         return H;
     };
+    // A neighbour between a rank and a CLOSED boundary must be wide enough for the rim and its two-cell ring: otherwise the
+    // held rectangle reaches past the global boundary, those positions stay zero here while the owner advances its cells
+    // from the caller's boundary ghost values (rect_to_block) -- different operands for the same cell.  Such a layout is
+    // refused (the one-subcycle kernels run it); every rank reaches the same verdict from the same table.
+    for (int r = 0; r < nranks; ++r) {
+        if (!P.all[r].ok) continue;
+        const MarchRect &R = P.all[r];
+        const int dw = R.gx0, de = NX - (R.gx0 + R.nxr), ds = R.gy0, dn = NY - (R.gy0 + R.nyr);
+        const bool thin_x = !ew_cyclic && ((dw > 0 && dw < ext + 2) || (de > 0 && de < ext + 2));
+        const bool thin_y = (ds > 0 && ds < ext + 2) || (dn > 0 && dn < ext + 2);
+        if (ext > 0 && (thin_x || thin_y)) {
+            P.error = "a rank lies closer to a closed boundary than its redundant rim + ring is wide";
+            return false;
+        }
+    }
     const Held HM = held(me);
     P.owned = P.all[me];
     P.me = HM.E;

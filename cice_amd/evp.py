@@ -21,6 +21,7 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["CICE_EVP_HIP_LIBRARY"]) if os.environ.get("CICE_EVP_HIP_LIBRARY") else HERE / "libcice_evp_hip.so"   # (override: experiments)
+LIB_TESTING_PATH = HERE / "libcice_evp_hip_testing.so"
 
 BND = {"closed": 0, "open": 1, "cyclic": 2, "tripole": 3, "tripoleT": 4}
 
@@ -39,15 +40,33 @@ EXPORTS = [
     "cice_evp_hip_set_metrics", "cice_evp_hip_run", "cice_evp_hip_finalize",
     "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
     "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
-    "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_plan", "cice_evp_hip_seam_fin_plan",
+    "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_cgrid_set_prep_geometry", "cice_evp_hip_cgrid_prep", "cice_evp_hip_cgrid_seabed_lkd", "cice_evp_hip_cgrid_seabed_prob",
-    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_set_test_transport", "cice_evp_hip_fold_split_plan", "cice_evp_hip_describe_path",
+    "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_describe_path",
     "cice_evp_hip_pin_host", "cice_evp_hip_set_post_geometry", "cice_evp_hip_deformations", "cice_evp_hip_dyn_finish",
-    "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", "cice_evp_hip_stress_plan", "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan",
-    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_plan_flags", "cice_evp_hip_march_info", "cice_evp_hip_march_plan", "cice_evp_hip_prep_fetch",
-    "cice_evp_hip_addr", "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
+    "cice_evp_hip_halo_export", "cice_evp_hip_halo_import", "cice_evp_hip_stress_halo", 
+    "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_march_info", "cice_evp_hip_prep_fetch",
+    "cice_evp_hip_addr", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
-    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_deformations", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan",
+    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_deformations", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", 
+]
+# libcice_evp_hip_testing.so only (include/cice_evp_hip_testing.h): plan introspection of the CPU tests, read-outs of the tools,
+# the test transport
+TEST_EXPORTS = [
+    "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
+    "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
+    "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan", "cice_evp_hip_stress_plan",
+    "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags",
+]
+# environment switches only the test build reads (cice_amd/csrc/evp_host.h: env_test): experiments, fault injection, routing
+# of on-device copies through the remote transports.  An EvpHip made while one of them is set uses the test build.
+TEST_ENV = [
+    "CICE_EVP_HIP_RES_REMOTE", "CICE_EVP_HIP_RES_REMOTE_BREAK", "CICE_EVP_HIP_RES_ORDER", "CICE_EVP_HIP_RES_PROF", "CICE_EVP_HIP_RES_DEBUG",
+    "CICE_EVP_HIP_RES_XCD", "CICE_EVP_HIP_MARCH_OWN", "CICE_EVP_HIP_MARCH_SELFX", "CICE_EVP_HIP_MARCH_SEG", "CICE_EVP_HIP_MARCH_ORDER",
+    "CICE_EVP_HIP_MARCH_LEAN", "CICE_EVP_HIP_CGRID_SPLIT", "CICE_EVP_HIP_CGRID_XCD", "CICE_EVP_HIP_CGRID_ONE_XCD", "CICE_EVP_HIP_CGRID_ONE_SHAPE",
+    "CICE_EVP_HIP_CGRID_ONE_STRIP", "CICE_EVP_HIP_CGRID_FAST", "CICE_EVP_HIP_HALO_DEBUG", "CICE_EVP_HIP_SEAM_FIN", "CICE_EVP_HIP_OVERLAP",
+    "CICE_EVP_HIP_HALO_RIDE", "CICE_EVP_HIP_GATHER", "CICE_EVP_HIP_SIMPLE", "CICE_EVP_HIP_SELF_EXCHANGE", "CICE_EVP_HIP_FLAGS", "CICE_EVP_HIP_LEAN",
+    "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -101,23 +120,36 @@ class Params(C.Structure):
 
 
 _lib = None
+_lib_testing = None
 
 
-def load_library(path: os.PathLike | None = None) -> C.CDLL:
-    """dlopen the product library; raises if it has not been built."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    p = Path(path) if path else LIB_PATH
+def testing_wanted() -> bool:
+    """True while the process environment holds a switch only the test build reads."""
+    return any(k in os.environ for k in TEST_ENV)
+
+
+def load_library(path: os.PathLike | None = None, testing: bool = False) -> C.CDLL:
+    """dlopen the product library (testing=True: the test build, which adds include/cice_evp_hip_testing.h); raises if it has
+    not been built.  Both may live in one process: each was linked -Bsymbolic and keeps its own device state."""
+    global _lib, _lib_testing
+    if path is None:
+        if testing and _lib_testing is not None:
+            return _lib_testing
+        if not testing and _lib is not None:
+            return _lib
+    p = Path(path) if path else (LIB_TESTING_PATH if testing else LIB_PATH)
     if not p.exists():
         raise EvpHipError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-    lib = C.CDLL(str(p), mode=C.RTLD_GLOBAL)
-    for name in EXPORTS:
+    lib = C.CDLL(str(p), mode=C.RTLD_LOCAL)
+    for name in EXPORTS + (TEST_EXPORTS if testing else []):
         getattr(lib, name).restype = C.c_int
     lib.cice_evp_hip_addr.restype = C.c_void_p        # the one entry point that does not return a status
     if path is None:
-        _lib = lib
+        if testing:
+            _lib_testing = lib
+        else:
+            _lib = lib
     return lib
 
 
@@ -164,7 +196,7 @@ def make_params(scal: dict, strict: bool = False) -> Params:
 
 def fold_split_plan() -> dict:
     """Lists of the shifted-copy exchange of the plan built last (halo_plan(): cice_evp_hip_plan_build)."""
-    lib = load_library()
+    lib = load_library(testing=True)
     out = {}
     for which, name in enumerate(("shift_cells", "center_dst", "stress_dst", "seam_dst", "seam_slot")):
         n = C.c_int32(0)
@@ -178,7 +210,7 @@ def fold_split_plan() -> dict:
 
 def cgrid_fold_plan(dims: "Dims", loc: str) -> dict:
     """Host only: the C-grid fold step of one field location on a tripole grid (see the header)."""
-    lib = load_library()
+    lib = load_library(testing=True)
     code = {"center": 0, "NEcorner": 1, "Eface": 2, "Nface": 3}[loc]
     n = C.c_int32(0)
     _check(lib, lib.cice_evp_hip_cgrid_fold_plan(C.byref(dims), C.c_int32(code), C.byref(n), None, None, None, None), "(cgrid_fold_plan)")
@@ -190,7 +222,7 @@ def cgrid_fold_plan(dims: "Dims", loc: str) -> dict:
 
 def cgrid_window_plan(dims: "Dims", ox: int, oy: int) -> dict:
     """Host only: the window table of the C grid's one-launch kernel (see the header)."""
-    lib = load_library()
+    lib = load_library(testing=True)
     n = C.c_int32(0)
     _check(lib, lib.cice_evp_hip_cgrid_window_plan(C.byref(dims), C.c_int32(ox), C.c_int32(oy), C.byref(n), None, None), "(cgrid_window_plan)")
     tiles = np.zeros((n.value, 4), dtype=np.int32)
@@ -211,8 +243,10 @@ class EvpHip:
     """One EVP core per process (the library keeps a single device state, like the
     module-level state of ice_dyn_evp1d)."""
 
-    def __init__(self, dims: Dims, params: Params, HTE, HTN, dxT, dyT, uarear, tarea, keepalive=None):
-        self.lib = load_library()
+    def __init__(self, dims: Dims, params: Params, HTE, HTN, dxT, dyT, uarear, tarea, keepalive=None, testing: bool | None = None):
+        # the product library unless the caller asks for the test build or the environment holds one of its switches
+        self.testing = testing_wanted() if testing is None else bool(testing)
+        self.lib = load_library(testing=self.testing)
         self._keep = keepalive
         self.shape = (dims.nblocks, dims.ny_block, dims.nx_block)
         arrs = [self._c(a) for a in (HTE, HTN, dxT, dyT, uarear, tarea)]
@@ -463,9 +497,14 @@ class EvpHip:
                     halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10], resident_fallbacks=int(t[11]),
                     halo_send_cells=int(t[12]), halo_recv_cells=int(t[13]))
 
+    def _need_testing(self, what):
+        if not self.testing:
+            raise EvpHipError(f"{what} exists in the test build only: EvpHip(..., testing=True)")
+
     def set_test_transport(self, xchg, reduce):
         """Test hook (see the header): xchg(peer_ranks, send_counts, recv_counts, send ndarray, recv ndarray) and
         reduce(op, value) -> value, called on the host by the two-subcycle path instead of RCCL."""
+        self._need_testing("set_test_transport")
         XF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                          C.POINTER(C.c_double), C.POINTER(C.c_double))
         RF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
@@ -540,11 +579,13 @@ class EvpHip:
         return dict(strocnxU=sx, strocnyU=sy)
 
     def debug_cuload(self):
+        self._need_testing("debug_cuload")
         a = np.zeros((2048, 8), dtype=np.int32)
         _check(self.lib, self.lib.cice_evp_hip_debug_cuload(_ip(a), C.c_int32(a.size)), "(debug_cuload)")
         return a
 
     def debug_prof(self, ntiles_max: int = 4096):
+        self._need_testing("debug_prof")
         a = np.zeros((ntiles_max, 4, 8), dtype=np.uint64)
         _check(self.lib, self.lib.cice_evp_hip_debug_prof(a.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(ntiles_max)), "(debug_prof)")
         return a
@@ -591,7 +632,7 @@ class EvpHip:
 
 def march_plan(dims: Dims, own_max: int = 0, wrap_inside: bool = True, ext: int = 0) -> dict:
     """Host-only geometry + exchange lists of the two-subcycle path for `dims.rank` (CPU tests)."""
-    lib = load_library()
+    lib = load_library(testing=True)
     geo = np.zeros(14, dtype=np.int32)
     _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), ext, _ip(geo), None, None, None, None, None,
                                             None), "(march_plan)")
@@ -608,7 +649,7 @@ def march_plan(dims: Dims, own_max: int = 0, wrap_inside: bool = True, ext: int 
 
 def halo_plan(dims: Dims) -> dict:
     """Host-only halo plan of `dims.rank` (no device needed): for CPU tests."""
-    lib = load_library()
+    lib = load_library(testing=True)
     _check(lib, lib.cice_evp_hip_plan_build(C.byref(dims)), "(plan_build)")
     cnt = np.zeros(4, dtype=np.int32)
     lib.cice_evp_hip_halo_plan(_ip(cnt), None, None, None, None, None, None, None, None)

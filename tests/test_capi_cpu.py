@@ -14,13 +14,21 @@ from cice_amd import decomp, evp
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def declared_functions():
-    txt = (ROOT / "include" / "cice_evp_hip.h").read_text()
+def declared_functions(header="cice_evp_hip.h"):
+    txt = (ROOT / "include" / header).read_text()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(?:int|void\s*\*)\s*(cice_evp_hip_\w+)\s*\(", txt)))
 
 
+def exported(lib_path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib_path)], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+
+
 def test_library_exports_every_declared_symbol():
+    """The product library exports exactly what include/cice_evp_hip.h declares -- no test hook, no introspection entry
+    point, no C++ symbol; the test build adds exactly what include/cice_evp_hip_testing.h declares."""
     lib = evp.load_library()
     names = declared_functions()
     assert len(names) >= 14
@@ -28,6 +36,31 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/cice_evp_hip.h but not exported"
     assert sorted(evp.EXPORTS) == names
     assert lib.cice_evp_hip_abi_version() == 1
+    assert exported(evp.LIB_PATH) == names
+    extra = declared_functions("cice_evp_hip_testing.h")
+    assert sorted(evp.TEST_EXPORTS) == extra and not set(extra) & set(names)
+    tlib = evp.load_library(testing=True)
+    for n in names + extra:
+        assert hasattr(tlib, n), f"{n} missing from the test build"
+    assert exported(evp.LIB_TESTING_PATH) == sorted(names + extra)
+    for n in extra:
+        assert not hasattr(lib, n), f"{n} is a test-build entry point but the product library exports it"
+
+
+def test_product_library_ignores_the_test_builds_switches():
+    """Strings of the experiment / fault-injection switches are read through env_test(), which is a constant NULL in the
+    product library: no getenv of theirs can be reached (the switch names may still appear as literals)."""
+    import subprocess
+    src = "".join(p.read_text() for p in (ROOT / "cice_amd" / "csrc").glob("*.cpp")) + \
+          "".join(p.read_text() for p in (ROOT / "cice_amd" / "csrc").glob("*.hip"))
+    for k in evp.TEST_ENV:
+        assert f'env("{k}")' not in src and f'getenv("{k}")' not in src, k
+        assert f'env_test("{k}")' in src or f'fault_hook("{k}")' in src, f"{k} listed in evp.TEST_ENV but not read by the test build"
+    kept = set(re.findall(r'(?<![_a-z])env\("(CICE_EVP_HIP_\w+)"\)', src))
+    assert not kept & set(evp.TEST_ENV)
+    assert kept <= {"CICE_EVP_HIP_" + k for k in ("DEVICE", "VERBOSE", "HALO", "HALO_TIMEOUT_MS", "RESIDENT", "MARCH", "MARCH_EXT",
+                                                  "NOGRAPH", "GRAPH_RCCL", "NO_OVERLAP", "CGRID_ONE", "CGRID_FUSED", "RES_LOGW",
+                                                  "RES_GEN", "TYB")}, kept
 
 
 def test_struct_layout_matches_header():

@@ -530,3 +530,21 @@ def test_march_two_cell_ring_between_ranks_known_answer(case):
         assert nbad == 0 and nring > 0, (rank, nbad, nring)
     if case[8] and case[6][0] == 1 and case[9] == 0:        # y slabs wrapping inside: halo-row cells next to a strip edge have duplicates
         assert all(r[3] > 0 for r in res)
+
+
+def test_march_plan_refuses_a_rank_too_thin_next_to_a_closed_boundary():
+    """ADVICE (round 3): the redundant rim + two-cell ring of a rank must not reach past a CLOSED global boundary through a
+    neighbour thinner than ext + 2 cells -- those positions would stay zero here while the owner advances the same cells
+    from the caller's boundary ghost values.  The plan refuses the layout on every rank alike (the one-subcycle kernels run
+    it); with ext = 0, a cyclic dimension, or a wide enough neighbour it is accepted."""
+    def plan(nx, bx, ew, ext, rank):
+        dc = decomp.Decomp(nx, 24, bx, 24, ew, "closed", 2, (2, 1))
+        d, keep = evp.make_dims(dc, rank)
+        return evp.march_plan(d, 0, True, ext)
+
+    for rank in (0, 1):
+        with pytest.raises(evp.EvpHipError, match="closer to a closed boundary"):
+            plan(40, 36, "closed", 4, rank)           # blocks of 36 + 4 columns: the east rank is 4 < ext + 2 wide
+        assert plan(40, 36, "closed", 0, rank)["ext"] is not None      # no redundant rim: nothing reaches past the boundary
+        assert plan(40, 36, "cyclic", 4, rank)["nxr"] > 0               # cyclic: no closed boundary in x
+        assert plan(48, 24, "closed", 4, rank)["nxr"] == 24 + 4         # 24 + 24: wide enough

@@ -187,8 +187,10 @@ def main():
         tm = dc.scatter(st["iceTmask"], r, fill=0)
         um = dc.scatter(st["iceUmask"], r, fill=0)
         d, keep = evp.make_dims(dc, r)
+        # (the test transport of --march exists in the test build only; everything else runs the product library unless the
+        # environment holds one of the test build's switches)
         core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"],
-                          geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+                          geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep, testing=(True if a.march else None))
         try:
             if exchange:
                 blobs = [None] * world

@@ -14,7 +14,7 @@ spec = synth.GRIDS[wl]
 scal = synth.evp_scalars(120)
 dc, geo, fields, tm, um = synth_case(wl, "full", seed=1, warm=True)
 d, keep = evp.make_dims(dc, 0)
-core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep, testing=True)
 core.upload(fields, tm, um)
 for _ in range(3): core.subcycle(ndte)
 core.sync()

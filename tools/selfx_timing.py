@@ -12,7 +12,7 @@ ndte = {"gx3": 120, "gx1": 120, "s01": 48, "q8": 120, "q4": 120, "p2": 120}[wl]
 scal = synth.evp_scalars(120)
 dc, geo, fields, tm, um = synth_case(wl, "full", seed=1, warm=True, bs=bs)
 d, keep = evp.make_dims(dc, 0)
-core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep, testing=True)
 if os.environ.get("CICE_EVP_HIP_SELF_EXCHANGE"):
     core.comm_init(core.comm_unique_id())
 core.upload(fields, tm, um)
