@@ -785,6 +785,28 @@ def main():
         if resident:
             e = (pmc or {}).get("kernels", {}).get("gx1res") if (a.workload == "gx1" and a.case == "full" and a.strict and world == 1) else None
             same = bool(e and e.get("bench_line_under_trace", {}).get("tile_variant") == tm_ev["tile_variant"])
+            # The committed counters may only price THIS launch if they were taken on the same kernel doing the same work:
+            # the kernel name, the wave count (tiles x 4 waves, from the tile shape the live run reports) and the VALU
+            # instructions per 64 active cells and subcycle (595 in strict mode) are checked against the live run;
+            # anything else and the counter-based figures are withheld rather than divided by a live time they do not fit.
+            pmc_refused = None
+            if e:
+                logw = tm_ev["tile_variant"] % 10
+                W, H = 1 << logw, 256 >> logw
+                live_waves = 4 * sum((-(-b.gnx // (W - 1))) * (-(-b.gny // (H - 1))) for b in dc.local_blocks(0))
+                waves = e.get("counters", {}).get("SQ_WAVES", {}).get("avg_per_launch")
+                insts = e.get("counters", {}).get("SQ_INSTS_VALU", {}).get("avg_per_launch")
+                per64 = insts / (my_active / 64.0 * sub_per_launch) if insts else None
+                if kshown not in (e.get("kernel") or ""):
+                    pmc_refused = f"committed counters are of '{e.get('kernel')}', the timed kernel is {kshown}"
+                elif not same:
+                    pmc_refused = "committed counters were taken on another tile variant"
+                elif tm_ev["tile_variant"] >= 2000 and waves != live_waves:
+                    pmc_refused = f"committed pass ran {waves} waves per launch, this run launches {live_waves}"
+                elif per64 is None or not (450.0 <= per64 <= 800.0):
+                    pmc_refused = f"committed SQ_INSTS_VALU = {per64} per 64 active cells and subcycle (expected ~595-700)"
+                if pmc_refused:
+                    e = None
             busy = e.get("valu_busy_simd_cycles_per_launch") if e else None
             peak = N_SIMD * MAX_CLOCK_HZ
             flops = ALG_FLOP * my_active * sub_per_launch / t_kernel / 1e12
@@ -793,9 +815,11 @@ def main():
                     "frac": (busy / t_kernel / peak) if busy else None,
                     "traffic": e.get("hbm_bytes_per_launch") if e else None,
                     "kernel": kshown, "kernel_us": 1e6 * t_kernel, "subcycles_per_launch": sub_per_launch,
-                    "pmc_source": f"{pmc_file}#gx1res" if e else None, "pmc_same_tile_variant": same,
+                    "pmc_source": f"{pmc_file}#gx1res" if e else None, "pmc_same_tile_variant": same, "pmc_refused": pmc_refused,
                     "valu_busy_simd_cycles_per_launch": busy,
-                    "effective_clock_ghz_in_pmc_pass": e.get("effective_clock_ghz") if e else None,
+                    # the other two readings of the same launch, side by side with `frac` (labelled; neither bounds it)
+                    "frac_of_hbm_peak_on_368B_yardstick": alg_bytes / t_kernel / 1e9 / HBM_PEAK_GBS,
+                    "frac_of_fp64_flop_peak_without_fma": flops / (FP64_VALU_PEAK_TFLOPS / 2),
                     "nominal_flops": {"flop_per_active_cell_subcycle": ALG_FLOP, "achieved_TFLOPs": flops,
                                       "peak_TFLOPs_without_fma": FP64_VALU_PEAK_TFLOPS / 2, "frac": flops / (FP64_VALU_PEAK_TFLOPS / 2)},
                     "hbm_equivalent": {"alg_bytes_per_launch": alg_bytes, "GBps_equivalent": alg_bytes / t_kernel / 1e9,
