@@ -403,6 +403,10 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         acc += now_ - pc0;                                              \
         pc0 = now_;                                                     \
     }
+    // Tried in round 4, measured on gx1 (tools/resident_phases.py), none moved the subcycle by more than
+    // 2 %: s_setprio 3 for the rim wave / 0 for interior stress / 2 for every wave's momentum step; the ring records of the
+    // next subcycle requested before the momentum step (the hand-off is on a dependency CYCLE between neighbours, not on one
+    // tile's critical path: nothing is there earlier); fine-grained / uncached memory for the record buffers; no s_sleep.
     for (int k = 0; k < R.ndte; ++k) {
         const unsigned want = R.tag_base + (unsigned)k;       // tag of the velocities subcycle k reads
         const v4u *rd = (const v4u *)R.rec[(k + par0) & 1];
@@ -565,7 +569,8 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     if (prof && (t & 63) == 0) {
         unsigned long long *o = R.prof + ((size_t)tile * 4 + (tq >> 6)) * 8;
         o[0] = pacc0; o[1] = pacc1; o[2] = pacc2; o[3] = pacc3; o[4] = pacc4;
-        o[5] = (unsigned long long)cu_rank; o[6] = (unsigned long long)(t >> 6); o[7] = (unsigned long long)R.nact[tile];
+        o[5] = (unsigned long long)cu_rank | ((unsigned long long)(PERM && R.cuload ? s_cu : 0) << 8) | ((unsigned long long)(s_simd[t >> 6] & 3) << 24);
+        o[6] = (unsigned long long)(t >> 6); o[7] = (unsigned long long)R.nact[tile];
     }
     // ghost cells that mirror another rank's cells: fetch the final velocities (the caller
     // relies on current ghosts, ice_dyn_evp.F90:920-934)
