@@ -147,6 +147,8 @@ struct EvpMarch {
     const double *opt;         // waterx watery TbU uvel_init vvel_init, or NULL when none of them is read
     double *diag;              // strintx strinty taubx tauby
     const unsigned *dup;       // [nstrips][64]: where, from the start of a state row, the duplicate of the lane's column lives
+    const int4 *items;         // NULL: item = (strip, segment) of the regular cut; else nitems explicit {strip, Y0, Y1, 0} (the
+                               // early launch of the cells other ranks are waiting for, evp_host_march.cpp)
 };
 struct EvpMarchGeo {
     int nxr, nyr, ldx, rows;   // rectangle: owned cells; mask row stride; rows of every buffer (nyr + halo + spare)

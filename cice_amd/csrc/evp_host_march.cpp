@@ -37,6 +37,10 @@ struct MarchBuf {
     // the two-cell ring between ranks
     int *send_pos = nullptr, *recv_pos1 = nullptr, *recv_pos2 = nullptr, *send_midx = nullptr, *recv_midx = nullptr;
     double *sendbuf = nullptr, *recvbuf = nullptr;
+    // the early launch of an exchange pass: work items that cover every cell other ranks receive from this one
+    int4 *band_items = nullptr;
+    int nband = 0;
+    hipEvent_t ev_in = nullptr, ev_main = nullptr, ev_done = nullptr;
 };
 MarchPlan PL;
 // slots of the constants block (evp_march.hip: C_*), of the optional block (O_*)
@@ -57,6 +61,9 @@ void march_free()
     F(B.st[0]); F(B.st[1]); F(B.cst); F(B.opt); F(B.diag);
     F(B.mask); F(B.bad); F(B.dup); F(B.blkid); F(B.org);
     F(B.send_pos); F(B.recv_pos1); F(B.recv_pos2); F(B.send_midx); F(B.recv_midx); F(B.sendbuf); F(B.recvbuf);
+    F(B.band_items);
+    B.nband = 0;
+    for (hipEvent_t *e : {&B.ev_in, &B.ev_main, &B.ev_done}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     PL = MarchPlan();
     S.march = State::March{};
 }
@@ -185,6 +192,34 @@ static int march_alloc()
         if (up(B.send_pos, sp) || up(B.recv_pos1, r1) || up(B.recv_pos2, r2) || up(B.send_midx, sm) || up(B.recv_midx, rm)) return -1;
         HIPC(hipMalloc((void **)&B.sendbuf, std::max<size_t>(PL.n_send, 1) * EVP_MARCH_S_NF * sizeof(double)));
         HIPC(hipMalloc((void **)&B.recvbuf, std::max<size_t>(PL.n_recv, 1) * EVP_MARCH_S_NF * sizeof(double)));
+        // Work items of the EARLY launch of an exchange pass (march_run): per strip the rows that hold cells some other rank
+        // receives, cut into short segments -- from the send lists themselves, so every sent cell is covered whatever the
+        // layout.  Short segments (a third of the regular length, at least 6 rows) so that the launch, the pack and the
+        // transfer end before the pass they overlap with does; each costs ~3.5 rows of warm-up like any segment.
+        const int nstr = M.G.nstrips;
+        std::vector<std::vector<char>> rows((size_t)nstr, std::vector<char>((size_t)M.G.nyr, 0));
+        for (int pos : sp) {
+            const int blk = pos >> 6, strip = blk % nstr, y = blk / nstr - EVP_MARCH_PAD;
+            if (y >= 0 && y < M.G.nyr) rows[(size_t)strip][(size_t)y] = 1;
+        }
+        int bseg = env_test("CICE_EVP_HIP_MARCH_BANDSEG") ? std::atoi(env_test("CICE_EVP_HIP_MARCH_BANDSEG")) : 0;
+        if (bseg <= 0) bseg = std::max(6, M.seglen / 3);
+        std::vector<int4> items;
+        for (int st = 0; st < nstr; ++st)
+            for (int y = 0; y < M.G.nyr;) {
+                if (!rows[(size_t)st][(size_t)y]) { ++y; continue; }
+                int y1 = y;
+                while (y1 < M.G.nyr && y1 - y < bseg && rows[(size_t)st][(size_t)y1]) ++y1;
+                items.push_back(make_int4(st, y, y1, 0));
+                y = y1;
+            }
+        B.nband = (int)items.size();
+        if (B.nband > 0) {
+            HIPC(hipMalloc((void **)&B.band_items, items.size() * sizeof(int4)));
+            HIPC(hipMemcpy(B.band_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice));
+        }
+        for (hipEvent_t *e : {&B.ev_in, &B.ev_main, &B.ev_done})
+            if (!*e) HIPC(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     M.G.blkid = B.blkid;
     M.G.blk_org = B.org;
@@ -196,7 +231,7 @@ static int march_alloc()
 // pack -> ncclGroupStart{ncclSend, ncclRecv per neighbour}ncclGroupEnd -> unpack (incl. the duplicates), on the
 // library's stream.  Once per PASS of two subcycles for the state, once per call for the constants and the mask.
 // (test hook) the same exchange through host buffers and the caller's callback
-static int hook_exchange(int nf)
+static int hook_exchange(int nf, hipStream_t st)
 {
     std::vector<int32_t> ranks;
     std::vector<int64_t> ns, nr;
@@ -207,33 +242,36 @@ static int hook_exchange(int nf)
     }
     S.test_send.resize((size_t)PL.n_send * nf + 1);
     S.test_recv.resize((size_t)PL.n_recv * nf + 1);
-    HIPC(hipMemcpyAsync(S.test_send.data(), B.sendbuf, (size_t)PL.n_send * nf * sizeof(double), hipMemcpyDeviceToHost, S.stream));
-    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemcpyAsync(S.test_send.data(), B.sendbuf, (size_t)PL.n_send * nf * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
     if (S.test_xchg(S.test_user, (int32_t)ranks.size(), ranks.data(), ns.data(), nr.data(), S.test_send.data(), S.test_recv.data()))
         return fail(-2, "test transport: the exchange callback failed");
-    HIPC(hipMemcpyAsync(B.recvbuf, S.test_recv.data(), (size_t)PL.n_recv * nf * sizeof(double), hipMemcpyHostToDevice, S.stream));
-    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemcpyAsync(B.recvbuf, S.test_recv.data(), (size_t)PL.n_recv * nf * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    return 0;
+}
+
+// pack + transfer of the ring of `buf` on stream `st` (what is left is the unpack)
+static int march_send_recv(double *buf, int nf, hipStream_t st)
+{
+    evp_launch_march_pack(buf, nf, B.send_pos, PL.n_send, B.sendbuf, st);
+    if (S.test_xchg) return hook_exchange(nf, st);
+    size_t so = 0, ro = 0;
+    NCCLC(ncclGroupStart());
+    for (const MarchPeer &p : PL.peers) {
+        const size_t ns = p.send_pos.size(), nr = p.recv_pos1.size();
+        if (ns) NCCLC(ncclSend(B.sendbuf + so * nf, ns * nf, ncclDouble, p.rank, S.comm, st));
+        if (nr) NCCLC(ncclRecv(B.recvbuf + ro * nf, nr * nf, ncclDouble, p.rank, S.comm, st));
+        so += ns; ro += nr;
+    }
+    NCCLC(ncclGroupEnd());
     return 0;
 }
 
 static int march_exchange(double *buf, double *buf2, int nf)
 {
     if (PL.peers.empty()) return 0;
-    evp_launch_march_pack(buf, nf, B.send_pos, PL.n_send, B.sendbuf, S.stream);
-    if (S.test_xchg) {
-        if (int rc = hook_exchange(nf)) return rc;
-        evp_launch_march_unpack(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.recvbuf, S.stream);
-        return 0;
-    }
-    size_t so = 0, ro = 0;
-    NCCLC(ncclGroupStart());
-    for (const MarchPeer &p : PL.peers) {
-        const size_t ns = p.send_pos.size(), nr = p.recv_pos1.size();
-        if (ns) NCCLC(ncclSend(B.sendbuf + so * nf, ns * nf, ncclDouble, p.rank, S.comm, S.stream));
-        if (nr) NCCLC(ncclRecv(B.recvbuf + ro * nf, nr * nf, ncclDouble, p.rank, S.comm, S.stream));
-        so += ns; ro += nr;
-    }
-    NCCLC(ncclGroupEnd());
+    if (int rc = march_send_recv(buf, nf, S.stream)) return rc;
     evp_launch_march_unpack(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.recvbuf, S.stream);
     return 0;
 }
@@ -243,7 +281,7 @@ static int march_exchange_mask()
     if (PL.peers.empty()) return 0;
     evp_launch_march_pack_mask(B.mask, B.send_midx, PL.n_send, B.sendbuf, S.stream);
     if (S.test_xchg) {
-        if (int rc = hook_exchange(1)) return rc;
+        if (int rc = hook_exchange(1, S.stream)) return rc;
         evp_launch_march_unpack_mask(B.mask, B.recv_midx, PL.n_recv, B.recvbuf, S.stream);
         return 0;
     }
@@ -369,6 +407,7 @@ static void march_args(EvpMarch &A, int cur, int last)
     A.opt = need_opt ? B.opt : nullptr;
     A.diag = B.diag;
     A.dup = B.dup;
+    A.items = nullptr;
 }
 
 // All ndte subcycles of a call.  Returns 0 when done (S.cur advanced like the one-subcycle loop would), < 0 on error.
@@ -438,17 +477,49 @@ int march_run(int ndte)
         M.checked_seq = S.upload_seq;
     }
     // ---- the passes ----
+    // Exchange passes (every exch_every-th and the last): the cells other ranks are waiting for are advanced FIRST, by an
+    // early launch of the same kernel over short segments on the second stream; their pack and the RCCL send / recv follow
+    // there while the pass itself -- all work items, those cells included -- runs on the compute stream: the transfer is
+    // overlapped with the pass instead of following it (ice_HaloUpdate -> RCCL point-to-point on a second HIP stream over
+    // interior compute).  Both launches store the same bits into the same cells (same kernel, same operands; a cell's
+    // result does not depend on the segment it is computed in), so the duplicate stores are harmless.  Only the unpack
+    // waits for the pass: the pass still writes its (spent) redundant rim where the received cells go.
     const int npass = left / 2;
     int rc = 0;
+    // Opt-in (CICE_EVP_HIP_MARCH_OVERLAP=1).  Measured where it could be measured -- one GPU, the ring exchanged with the rank
+    // itself, 450 x 2400 and 900 x 1200 pieces of 3600 x 2400 -- the early launch costs more than it hides: 57.7 against
+    // 51.2 us per subcycle (8 x 1 piece; 48.9 without any exchange), 55.2 against 50.7 (4 x 2 piece): two of eight strips
+    // are advanced twice, and their waves share the SIMDs with the pass they overlap.  On one GPU the transfer is a 7-us
+    // device copy; over xGMI it is 1.6 MB per neighbour and pass group, which is what the overlap is for -- bench.py
+    // --gpus N times the 3600 x 2400 block both ways so that the first run on a real node decides.
+    const bool overlap = !PL.peers.empty() && B.nband > 0 && env("CICE_EVP_HIP_MARCH_OVERLAP") && std::atoi(env("CICE_EVP_HIP_MARCH_OVERLAP"));
     for (int k = 0; k < npass; ++k) {
+        const bool exch = !PL.peers.empty() && ((k + 1) % M.exch_every == 0 || k == npass - 1);
         EvpMarch A;
         march_args(A, rc, k == npass - 1);
+        if (exch && overlap) {
+            HIPC(hipEventRecord(B.ev_in, S.stream));
+            HIPC(hipStreamWaitEvent(S.stream_comm, B.ev_in, 0));
+            EvpMarch E = A;
+            E.items = B.band_items;
+            E.nitems = B.nband;
+            E.last = 0;                                          // (the diagnostics are the pass's business)
+            evp_launch_march(E, S.prm.strict != 0, cap_mode(), S.stream_comm);
+            if (int e = march_send_recv(B.st[rc ^ 1], EVP_MARCH_S_NF, S.stream_comm)) return e;
+        }
         evp_launch_march(A, S.prm.strict != 0, cap_mode(), S.stream);
         rc ^= 1;
         // the ring of the new state: after every exch_every-th pass (the redundant rim has been used up) and after the last
         // one (the way back to the block layout reads the ghost cells from it)
-        if ((k + 1) % M.exch_every == 0 || k == npass - 1)
+        if (exch && overlap) {
+            HIPC(hipEventRecord(B.ev_main, S.stream));
+            HIPC(hipStreamWaitEvent(S.stream_comm, B.ev_main, 0));
+            evp_launch_march_unpack(B.st[rc], nullptr, EVP_MARCH_S_NF, B.recv_pos1, B.recv_pos2, PL.n_recv, B.recvbuf, S.stream_comm);
+            HIPC(hipEventRecord(B.ev_done, S.stream_comm));
+            HIPC(hipStreamWaitEvent(S.stream, B.ev_done, 0));
+        } else if (exch) {
             if (march_exchange(B.st[rc], nullptr, EVP_MARCH_S_NF)) return -1;
+        }
     }
     HIPC(hipGetLastError());
     M.passes += npass;

@@ -94,12 +94,19 @@ __device__ __forceinline__ bool march_item(const EvpMarch &A, Item &I)
     }
     const int item = wg * 4 + I.wv;
     if (item >= A.nitems) return false;                // whole waves; the kernels have no barrier
-    int seg;
-    if (A.order & 2) { seg = item % A.nseg; I.strip = item / A.nseg; }
-    else { I.strip = item % A.nstrips; seg = item / A.nstrips; }
+    if (A.items) {                                     // explicit list (wave-uniform)
+        const int4 it = A.items[item];
+        I.strip = __builtin_amdgcn_readfirstlane(it.x);
+        I.Y0 = __builtin_amdgcn_readfirstlane(it.y);
+        I.Y1 = __builtin_amdgcn_readfirstlane(it.z);
+    } else {
+        int seg;
+        if (A.order & 2) { seg = item % A.nseg; I.strip = item / A.nseg; }
+        else { I.strip = item % A.nstrips; seg = item / A.nstrips; }
+        I.Y0 = seg * A.seglen;
+        I.Y1 = min(I.Y0 + A.seglen, A.nyr);
+    }
     const int x = I.strip * A.own - 2 + I.lane;
-    I.Y0 = seg * A.seglen;
-    I.Y1 = min(I.Y0 + A.seglen, A.nyr);
     I.own_x = I.lane >= 2 && I.lane < 2 + A.own && x < A.nxr;
     I.xw = x;
     if (A.wrapx) {

@@ -66,7 +66,7 @@ TEST_ENV = [
     "CICE_EVP_HIP_MARCH_LEAN", "CICE_EVP_HIP_CGRID_SPLIT", "CICE_EVP_HIP_CGRID_XCD", "CICE_EVP_HIP_CGRID_ONE_XCD", "CICE_EVP_HIP_CGRID_ONE_SHAPE",
     "CICE_EVP_HIP_CGRID_ONE_STRIP", "CICE_EVP_HIP_CGRID_FAST", "CICE_EVP_HIP_HALO_DEBUG", "CICE_EVP_HIP_SEAM_FIN", "CICE_EVP_HIP_OVERLAP",
     "CICE_EVP_HIP_HALO_RIDE", "CICE_EVP_HIP_GATHER", "CICE_EVP_HIP_SIMPLE", "CICE_EVP_HIP_SELF_EXCHANGE", "CICE_EVP_HIP_FLAGS", "CICE_EVP_HIP_LEAN",
-    "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY",
+    "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY", "CICE_EVP_HIP_MARCH_BANDSEG",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",

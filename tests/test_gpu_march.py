@@ -122,16 +122,20 @@ def test_march_random_masks_vs_oracle(seed, grid, bs, holes, march):
     assert_bitwise(got, want, f"march, random masks seed {seed}")
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("grid,case,bs,seg,own,ext", [("gx3", "full", None, 0, 0, 2), ("gx3", "caps", (25, 29), 9, 17, 0),
                                                        ("gx3", "caps", (50, 58), 9, 23, 4), ("gx1", "full", None, 40, 0, 2)])
-def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg, own, ext, march):
+def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg, own, ext, overlap, march):
     """Several ranks: every pass is followed by an exchange of the two-cell ring (pack -> ncclSend / ncclRecv -> unpack,
     duplicates included; march_plan.cpp).  One GPU can run all of it by treating the cyclic seam of the domain as a rank
     boundary -- the rank is its own east and west neighbour (CICE_EVP_HIP_MARCH_SELFX=1): no wrap inside the strips, the
     halo columns live on what RCCL delivers.  ext: the rank also holds (and advances redundantly) `ext` columns of its
     neighbour -- here of itself -- on either side, so that the ring is exchanged after every (ext/2 + 1)-th pass only.
+    overlap = 1 (CICE_EVP_HIP_MARCH_OVERLAP): the cells the neighbour waits for are advanced first by an early launch on
+    the second stream, pack + send / recv run there while the pass itself runs on the compute stream (round 4).
     Against the oracle, bit for bit; the list logic for 2 and 4 ranks is
     tests/test_multirank_cpu.py::test_march_two_cell_ring_between_ranks_known_answer."""
+    march.setenv("CICE_EVP_HIP_MARCH_OVERLAP", str(overlap))
     march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
     march.setenv("CICE_EVP_HIP_MARCH_EXT", str(ext))
     if seg:
@@ -314,6 +318,8 @@ def test_march_random_geometry_vs_oracle(seed, march):
     if selfx:
         march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
         march.setenv("CICE_EVP_HIP_MARCH_EXT", str(ext))
+        march.setenv("CICE_EVP_HIP_MARCH_OVERLAP", str((seed // 2) % 2))       # every other of them: exchange overlapped with the pass
+        march.setenv("CICE_EVP_HIP_MARCH_BANDSEG", str(int(rng.integers(2, 12))))
     g = synth.derive_geometry(synth.make_grid(nx, ny, 3.0e4, ns="closed"))
     st = synth.make_state(g, case="full", seed=seed, warm=True)
     holes = float(rng.choice([0.0, 0.2, 0.7]))

@@ -204,7 +204,10 @@ def test_two_subcycle_kernel_across_processes_on_one_gpu(world, workload, shape,
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            str(root / "tools" / "mailbox_2proc.py"), "--march", "--workload", workload, "--ndte", "24", "--shape", shape] + extra
     env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000", CICE_EVP_HIP_MARCH="1", CICE_EVP_HIP_RESIDENT="0",
-               CICE_EVP_HIP_MARCH_SEG="24", CICE_EVP_HIP_MARCH_EXT=ext)
+               CICE_EVP_HIP_MARCH_SEG="24", CICE_EVP_HIP_MARCH_EXT=ext,
+               # every other layout with the exchange overlapped (early launch of the cells the neighbours wait for: N-S and
+               # E-W cuts, corners, several blocks per rank)
+               CICE_EVP_HIP_MARCH_OVERLAP=str(int(ext) // 2 % 2 if shape != "2x2" else 1))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     if not (r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout):
         try:
