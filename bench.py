@@ -652,6 +652,71 @@ def main():
                        "hooks (dyn_evp_hip_keep_stresses_resident): 20 fields in, 6 out, the 12 stresses stay on the device")
         return res
 
+    def per_call_option_a(workload, case, ndte):
+        """What a host that hands over the whole evp() body waits for per call (INTEGRATION.md Option A,
+        dyn_evp_hip_evp_body): cice_evp_hip_prep (11 T-grid arrays + uvel, vvel in; dyn_prep1 / T->U averages / dyn_prep2 on
+        the device; the 12 stresses resident) + the host's ice strength via _set_strength + ndte subcycles + download --
+        once as the shim does it (12 stresses + 6 outputs back: CICE's arrays current after every call), once with the
+        stresses left on the device (6 outputs back; restart / history through cice_evp_hip_fetch_stresses)."""
+        spec = synth.GRIDS[workload]
+        nx, ny = spec["nx"], spec["ny"]
+        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+        pr = synth.make_primary(g, case, seed=9)
+        st = synth.make_state(g, case=case, seed=7, warm=True)
+        dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", "closed")
+        sc = lambda x, fill=0.0: np.ascontiguousarray(dc.scatter(np.ascontiguousarray(x), 0, fill=fill))
+        geo = {k: sc(g[k], 1.0 if k != "uarear" else 0.0) for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+        d, keep = evp.make_dims(dc, 0)
+        core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(ndte), strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                          geo["uarear"], geo["tarea"], keepalive=keep)
+        lib = core.lib
+        res = {}
+        try:
+            static = {k: sc(v, (1.0 if k in ("tarea", "uarea") else 0)) for k, v in pr["static"].items()}
+            core.set_prep_geometry(*[static[k] for k in ("tmask", "umask", "hm", "tarea", "uarea", "fcor_blk")])
+            pp = evp.PrepParams(dt=3600.0, rhoi=917.0, rhos=330.0, gravit=9.80616, dyn_area_min=1e-11, dyn_mass_min=1e-10,
+                                ssh_stress_coupled=0)
+            t = {k: sc(v) for k, v in pr["t"].items()}
+            state = {k: sc(v) for k, v in pr["state"].items()}
+            strength = sc(st["strength"])
+            out = {k: np.zeros(core.shape) for k in ("strintxU", "strintyU", "taubxU", "taubyU", "uvel", "vvel")}
+            core.pin_host(*t.values(), state["uvel"], state["vvel"], strength, *out.values(), *[state[k] for k in evp.FIELDS[:12]])
+            ttab = (evp._f64p * 11)(*[evp._dp(t[k]) for k in evp.PREP_T])
+            first = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(state[k]) if k in state and k != "iceUmask" else None) for k in evp.FIELDS])
+            later = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(state[k]) if k in ("uvel", "vvel") else None) for k in evp.FIELDS])
+            tm = np.zeros(core.shape, np.int32)
+            um = np.ascontiguousarray(state["iceUmask"], np.int32)
+            o6 = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(out[k]) if k in out else None) for k in evp.FIELDS])
+            o18 = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(out[k]) if k in out else evp._dp(state[k]) if k in evp.FIELDS[:12] else None)
+                                                  for k in evp.FIELDS])
+
+            def call(tab, otab):
+                parts = [time.perf_counter()]
+                evp._check(lib, lib.cice_evp_hip_prep(C.byref(pp), ttab, tab, evp._ip(tm), evp._ip(um), None, None, None, None), "prep")
+                parts.append(time.perf_counter())
+                evp._check(lib, lib.cice_evp_hip_set_strength(evp._dp(strength)), "set_strength")
+                parts.append(time.perf_counter())
+                evp._check(lib, lib.cice_evp_hip_subcycle(C.c_int32(ndte)), "subcycle")
+                evp._check(lib, lib.cice_evp_hip_download(otab), "download")
+                parts.append(time.perf_counter())
+                return [1e3 * (y - x) for x, y in zip(parts[:-1], parts[1:])]
+
+            call(first, o18)
+            for label, otab in (("shim_default_18_arrays_back", o18), ("stresses_left_on_device_6_arrays_back", o6)):
+                call(later, otab)
+                ts = np.array([call(later, otab) for _ in range(10)])
+                med = np.median(ts, axis=0)
+                tt = core.timings()
+                res[label] = dict(ms_per_call=float(np.median(ts.sum(axis=1))), prep_call=float(med[0]), set_strength=float(med[1]),
+                                  loop_and_download=float(med[2]), slowest_of_10=float(ts.sum(axis=1).max()),
+                                  library=dict(h2d=tt["h2d_ms"], prep_kernels=tt["prep_ms"], loop=tt["loop_ms"], d2h=tt["d2h_ms"]))
+        finally:
+            core.finalize()
+        res["note"] = ("median host wall time per evp() body over 10 calls through Option A (device preparation): 13 arrays in (11 T-grid "
+                       "fields, uvel, vvel) + strength, dyn_prep1 / averages / dyn_prep2 + ndte subcycles on the device, arrays page-locked; "
+                       "the host's own ice-strength computation (Icepack) is NOT in the figure")
+        return res
+
     ndte = a.ndte or {"gx3": 120, "gx1": 120, "s01": 480}[a.workload]
     M = measure_with_fallbacks(a.workload, a.case, ndte, a.steps, a.warmup)
     nx, ny, dc, tm, n_active, dt, tm_ev, kt = (M[k] for k in ("nx", "ny", "dc", "tm", "n_active", "dt", "tm_ev", "kt"))
@@ -733,6 +798,10 @@ def main():
             extra["per_call_ms"] = per_call_cost(a.workload, a.case, ndte)
         except Exception as e:  # noqa: BLE001
             extra_err["per_call_ms"] = f"{type(e).__name__}: {e}"[:300]
+        try:
+            extra.setdefault("per_call_ms", {})["option_a_device_preparation"] = per_call_option_a(a.workload, a.case, ndte)
+        except Exception as e:  # noqa: BLE001
+            extra_err["per_call_option_a"] = f"{type(e).__name__}: {e}"[:300]
 
     if rank == 0:
         pmc, pmc_file = load_pmc()
