@@ -407,13 +407,10 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // 2 %: s_setprio 3 for the rim wave / 0 for interior stress / 2 for every wave's momentum step; the ring records of the
     // next subcycle requested before the momentum step (the hand-off is on a dependency CYCLE between neighbours, not on one
     // tile's critical path: nothing is there earlier); fine-grained / uncached memory for the record buffers; no s_sleep.
-    // Not built: two polls in flight per lane (in lock step the first poll of a ring entry always misses -- the record lands
-    // 1100-2500 cycles after the reader leaves its barrier, a poll's round trip is ~1400 -- so the record is seen after the
-    // SECOND round trip; a poll issued a few hundred cycles behind the first would see it half a round trip after it lands,
-    // ~850 cycles of the ~9700 a subcycle takes).  Three forms were compiled and read in the disassembly: inline-asm loads
-    // with "=&v" / "+v" results and a separate s_waitcnt (the compiler copies a poll's registers at the loop merge while
-    // their load is in flight), a wave-uniform loop (same copies), compiler-tracked buffer loads (s_waitcnt vmcnt(0) at the
-    // loop head).  It needs one asm block on fixed registers, compares included.
+    // Two polls in flight per lane (a second poll a few hundred cycles behind the first, each re-issued once looked at; one
+    // asm block on fixed registers, compares included -- the compiler copies a poll's registers at a loop merge while the
+    // load is in flight, in every form it was given): bit-identical, and SLOWER -- poll phase 4476 -> 5131 cycles, 4.69 ->
+    // 4.90 us per subcycle (gpurun_out/r4i): twice the poll traffic costs more than the earlier sighting saves.
     for (int k = 0; k < R.ndte; ++k) {
         const unsigned want = R.tag_base + (unsigned)k;       // tag of the velocities subcycle k reads
         const v4u *rd = (const v4u *)R.rec[(k + par0) & 1];
