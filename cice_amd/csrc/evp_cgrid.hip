@@ -605,6 +605,26 @@ __global__ __launch_bounds__(TX *TY) void cg_deformations_t(EvpCgrid A, const do
     vort[o] = tr * ((dyE[o] * vE[o] - dyE[w] * vE[w]) - (dxN[o] * uN[o] - dxN[s] * uN[s]));
 }
 
+// ---- dyn_finish at N and E points (ice_dyn_shared.F90:1291-1365; call sites ice_dyn_evp.F90:1408-1436): the ice-ocean stress
+// from the loop's final face velocities, on the cells of dyn_prep2's N / E lists; every other cell keeps what the array holds.
+// which: 0 = N points (uvelN, vvelN, cdn_ocnN, aiN, uocnN, vocnN, fmN), 1 = E points ----
+__global__ __launch_bounds__(TX *TY) void cg_dyn_finish(EvpCgrid A, int which, double *__restrict__ strocnx, double *__restrict__ strocny)
+{
+    const Cell c = cell(A);
+    if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
+    const size_t o = c.o;
+    if (!(A.mask[o] & (which ? 4u : 8u))) return;
+    const double Cw = A.in[which ? CI_CWE : CI_CWN][o], aiX = A.in[which ? CI_AIE : CI_AIN][o];
+    const double uocn = A.in[which ? CI_UOCNE : CI_UOCNN][o], vocn = A.in[which ? CI_VOCNE : CI_VOCNN][o];
+    const double fm = A.in[which ? CI_FME : CI_FMN][o];
+    const double u = A.f[which ? CF_UE : CF_UN][o], v = A.f[which ? CF_VE : CF_VN][o];
+    const double du = uocn - u, dv = vocn - v;
+    double vrel = A.p.rhow * Cw * sqrt(du * du + dv * dv);
+    vrel = vrel * aiX;
+    strocnx[o] = vrel * ((uocn - u) * A.p.cosw - (vocn - v) * A.p.sinw * copysign(1.0, fm));
+    strocny[o] = vrel * ((vocn - v) * A.p.cosw + (uocn - u) * A.p.sinw * copysign(1.0, fm));
+}
+
 __global__ void cg_fold_gather(EvpCgFold F)
 {
     const int q = blockIdx.y;
@@ -1055,6 +1075,11 @@ void evp_launch_cgrid_deformations(const EvpCgrid &A, const double *tarear, doub
                                    double *rdg_conv, double *rdg_shear, hipStream_t st)
 {
     hipLaunchKernelGGL(cg_deformations_t, cg_grid(A), dim3(TX, TY), 0, st, A, tarear, divu, shear, vort, rdg_conv, rdg_shear);
+}
+
+void evp_launch_cgrid_dyn_finish(const EvpCgrid &A, int which, double *strocnx, double *strocny, hipStream_t st)
+{
+    hipLaunchKernelGGL(cg_dyn_finish, cg_grid(A), dim3(TX, TY), 0, st, A, which, strocnx, strocny);
 }
 
 void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st)

@@ -362,6 +362,7 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 // last: the launch belongs to the last subcycle of a call (arrays nobody reads inside the loop are stored only then)
 void evp_launch_cgrid_deformations(const EvpCgrid &A, const double *tarear, double *divu, double *shear, double *vort,
                                    double *rdg_conv, double *rdg_shear, hipStream_t st);
+void evp_launch_cgrid_dyn_finish(const EvpCgrid &A, int which, double *strocnx, double *strocny, hipStream_t st);
 void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t st);
 // Tripole fold of the C-grid fields (u-fold; ice_boundary.F90:1626-1722): entries (dst, a, b, flip) per field location
 // -- x[dst] = s * 0.5*(x[a] + isign*x[b])  (b >= 0: a point ON the fold, averaged with its partner)

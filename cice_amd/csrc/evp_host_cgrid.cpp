@@ -622,6 +622,34 @@ int cice_evp_hip_cgrid_deformations(const double *tarear, double *divu, double *
     return 0;
 }
 
+// dyn_finish at N and E points (ice_dyn_shared.F90:1291-1365; evp() calls it for both after the C-grid loop,
+// ice_dyn_evp.F90:1408-1436) on the device, from the loop's resident final face velocities and the per-call operands the
+// loop already holds (cdn_ocnX, aiX, uocnX, vocnX, fmX): the four arrays are inout -- written on the cells of dyn_prep2's
+// N / E lists, every other cell keeps the caller's value.
+int cice_evp_hip_cgrid_dyn_finish(double *strocnxN, double *strocnyN, double *strocnxE, double *strocnyE)
+{
+    if (!CG.uploaded) return fail(-1, "C-grid EVP: nothing uploaded");
+    double *host[4] = {strocnxN, strocnyN, strocnxE, strocnyE};
+    for (double *p : host)
+        if (!p) return fail(-1, "null argument");
+    CopyBatch U;
+    for (int k = 0; k < 4; ++k) {
+        if (!CG.post[k] && alloc_d(&CG.post[k], S.n)) return -1;
+        U.items.push_back({CG.post[k], host[k]});
+    }
+    if (h2d_batch(U)) return -1;
+    EvpCgrid A;
+    fill(A);
+    evp_launch_cgrid_dyn_finish(A, 0, CG.post[0], CG.post[1], S.stream);
+    evp_launch_cgrid_dyn_finish(A, 1, CG.post[2], CG.post[3], S.stream);
+    HIPC(hipGetLastError());
+    CopyBatch D;
+    for (int k = 0; k < 4; ++k) D.items.push_back({host[k], CG.post[k]});
+    if (d2h_batch(D)) return -1;
+    HIPC(hipStreamSynchronize(S.stream));
+    return 0;
+}
+
 int cice_evp_hip_cgrid_sync(void)
 {
     HIPC(hipStreamSynchronize(S.stream));

@@ -48,7 +48,7 @@ EXPORTS = [
     "cice_evp_hip_set_prep_geometry", "cice_evp_hip_prep", "cice_evp_hip_set_strength", "cice_evp_hip_set_tbu", "cice_evp_hip_seabed_lkd", "cice_evp_hip_seabed_prob", "cice_evp_hip_halo_mask", "cice_evp_hip_march_info", "cice_evp_hip_prep_fetch",
     "cice_evp_hip_addr", "cice_evp_hip_set_option", "cice_evp_hip_fetch_stresses", "cice_evp_hip_invalidate_stresses",
     "cice_evp_hip_cgrid_set_geometry", "cice_evp_hip_cgrid_run", "cice_evp_hip_cgrid_upload", "cice_evp_hip_cgrid_subcycle",
-    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_deformations", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", 
+    "cice_evp_hip_cgrid_download", "cice_evp_hip_cgrid_sync", "cice_evp_hip_cgrid_deformations", "cice_evp_hip_cgrid_dyn_finish", "cice_evp_hip_cgrid_timings", "cice_evp_hip_stream_probe", 
 ]
 # libcice_evp_hip_testing.so only (include/cice_evp_hip_testing.h): plan introspection of the CPU tests, read-outs of the tools,
 # the test transport
@@ -427,6 +427,13 @@ class EvpHip:
 
     def cgrid_subcycle(self, ndte: int):
         _check(self.lib, self.lib.cice_evp_hip_cgrid_subcycle(C.c_int32(ndte)), "(dyn_evp_hip_cgrid_subcycle)")
+
+    def cgrid_dyn_finish(self, prev: dict | None = None) -> dict:
+        """dyn_finish at N and E points from the resident state; prev: the four inout arrays (default zeros)."""
+        keys = ["strocnxN", "strocnyN", "strocnxE", "strocnyE"]
+        out = {k: (np.array(self._c(prev[k]), copy=True) if prev and k in prev else np.zeros(self.shape)) for k in keys}
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_dyn_finish(*[_dp(out[k]) for k in keys]), "(dyn_evp_hip_cgrid_dyn_finish)")
+        return out
 
     def cgrid_deformations(self, tarear, prev: dict | None = None) -> dict:
         """deformationsC_T on the resident final state of the C-grid loop; `prev`: the five inout arrays (zeros if absent)."""

@@ -31,7 +31,8 @@ module ice_dyn_evp_hip
 
   public :: dyn_evp_hip_init, dyn_evp_hip_run, dyn_evp_hip_finalize, dyn_evp_hip_evp_body, &
             dyn_evp_hip_fetch_stresses, dyn_evp_hip_invalidate_stresses, dyn_evp_hip_cgrid_run, &
-            dyn_evp_hip_keep_stresses_resident, dyn_evp_hip_cgrid_deformations, dyn_evp_hip_cgrid_evp_body, &
+            dyn_evp_hip_keep_stresses_resident, dyn_evp_hip_cgrid_deformations, dyn_evp_hip_cgrid_dyn_finish, &
+            dyn_evp_hip_cgrid_evp_body, &
             dyn_evp_hip_cgrid_fetch_forcing
 
   ! mirror of cice_evp_hip_dims (include/cice_evp_hip.h)
@@ -211,6 +212,11 @@ module ice_dyn_evp_hip
        real(c_double), dimension(*), intent(in) :: tarear
        real(c_double), dimension(*), intent(inout) :: divu, shear, vort, rdg_conv, rdg_shear
      end function cice_evp_hip_cgrid_deformations
+     integer(c_int) function cice_evp_hip_cgrid_dyn_finish(strocnxN, strocnyN, strocnxE, strocnyE) &
+          bind(C, name='cice_evp_hip_cgrid_dyn_finish')
+       import :: c_int, c_double
+       real(c_double), intent(inout) :: strocnxN(*), strocnyN(*), strocnxE(*), strocnyE(*)
+     end function cice_evp_hip_cgrid_dyn_finish
 
      integer(c_int) function cice_evp_hip_describe_path(buf, n) bind(C, name='cice_evp_hip_describe_path')
        import :: c_int, c_int32_t, c_char
@@ -987,6 +993,15 @@ contains
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', file=__FILE__, line=__LINE__)
     call check(cice_evp_hip_cgrid_deformations(tarear, divu, shear, vort, rdg_conv, rdg_shear), subname, __FILE__, __LINE__)
   end subroutine dyn_evp_hip_cgrid_deformations
+
+  ! dyn_finish at N and E points (ice_dyn_evp.F90:1408-1436) on the device, from the state the C-grid loop left there:
+  ! ice_flux's strocnxN / strocnyN / strocnxE / strocnyE are written on the cells of the N / E lists.
+  subroutine dyn_evp_hip_cgrid_dyn_finish
+    use ice_flux, only: strocnxN, strocnyN, strocnxE, strocnyE
+    character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_dyn_finish)'
+    if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', file=__FILE__, line=__LINE__)
+    call check(cice_evp_hip_cgrid_dyn_finish(strocnxN, strocnyN, strocnxE, strocnyE), subname, __FILE__, __LINE__)
+  end subroutine dyn_evp_hip_cgrid_dyn_finish
 
 !-----------------------------------------------------------------------
 ! ice_flux's stress arrays <- the device copy.  Call before anything but evp() reads them (restart write,

@@ -295,6 +295,10 @@ int cice_evp_hip_cgrid_sync(void);
  * inout: written on the ice T-cells of dyn_prep2's list only).  tarear = ice_grid's 1/tarea, taken at the first call.  */
 int cice_evp_hip_cgrid_deformations(const double *tarear, double *divu, double *shear, double *vort, double *rdg_conv,
                                     double *rdg_shear);
+/* dyn_finish at N and E points (ice_dyn_shared.F90:1291-1365; ice_dyn_evp.F90:1408-1436, right after the one at U points) on
+ * the device, from the loop's resident final face velocities and the per-call operands it already holds: strocnxN, strocnyN,
+ * strocnxE, strocnyE (ice_flux arrays, inout: written on the cells of dyn_prep2's N / E lists only).                       */
+int cice_evp_hip_cgrid_dyn_finish(double *strocnxN, double *strocnyN, double *strocnxE, double *strocnyE);
 /* out[0] = ms of the last cgrid_subcycle (HIP events), out[1] = its ndte, [2] (n >= 3) = device ms of the last cgrid_prep,
  * [3] (n >= 4) = how many of those subcycles ran as one launch each (the default schedule on one rank without a fold)  */
 int cice_evp_hip_cgrid_timings(double *out, int32_t n);
