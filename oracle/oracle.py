@@ -188,6 +188,19 @@ def dyn_finish(dom: OracleDomain, params: Params, dyn: dict, uvel, vvel, iceUmas
     return dict(strocnxU=sx, strocnyU=sy)
 
 
+def dyn_finish_at(dom: OracleDomain, params: Params, Cw, aiX, uocn, vocn, fm, u, v, icemask, strocnx, strocny):
+    """dyn_finish (ice_dyn_shared.F90:1291-1365) with the operands of any staggering: evp() calls the same routine at N and E
+    points on the C grid (ice_dyn_evp.F90:1408-1436).  strocnx/y are inout; returns the two arrays."""
+    lib().evp_oracle_dyn_finish.restype = None
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (Cw, u, v, uocn, vocn, aiX, fm)]
+    m = np.ascontiguousarray(icemask, dtype=np.int32)
+    sx = np.array(strocnx, dtype=np.float64, order="C", copy=True)
+    sy = np.array(strocny, dtype=np.float64, order="C", copy=True)
+    lib().evp_oracle_dyn_finish(C.byref(dom.c), C.byref(params), *[_dp(x) for x in a],
+                                m.ctypes.data_as(C.POINTER(C.c_int32)), _dp(sx), _dp(sy))
+    return sx, sy
+
+
 # ---- preparation phase of evp() (SURVEY 8 f-2) ----------------------------------------------
 PREP_T = ["aice", "vice", "vsno", "aice_init", "cdn_ocn", "uocn", "vocn", "ss_tltx", "ss_tlty",
           "strairxT", "strairyT"]

@@ -37,7 +37,8 @@ module evp_cgrid_capture
   use ice_dyn_shared
   use ice_dyn_evp, only: evp, ratiodxN, ratiodxNr, ratiodyE, ratiodyEr
 #ifdef HARNESS_HIP_BODY
-  use ice_dyn_evp_hip, only: dyn_evp_hip_cgrid_run, dyn_evp_hip_cgrid_deformations, dyn_evp_hip_cgrid_evp_body
+  use ice_dyn_evp_hip, only: dyn_evp_hip_cgrid_run, dyn_evp_hip_cgrid_deformations, dyn_evp_hip_cgrid_evp_body, &
+       dyn_evp_hip_cgrid_dyn_finish
 #endif
   use evp_dumpio
   implicit none
@@ -216,6 +217,11 @@ contains
           call dump_r8_3d(trim(tg)//'_divu', divu, nblocks);         call dump_r8_3d(trim(tg)//'_shear', shear, nblocks)
           call dump_r8_3d(trim(tg)//'_vort', vort, nblocks)
           call dump_r8_3d(trim(tg)//'_rdg_conv', rdg_conv, nblocks); call dump_r8_3d(trim(tg)//'_rdg_shear', rdg_shear, nblocks)
+          ! dyn_finish at N and E points on the device (the arrays hold what evp(ndte = 0) computed from the INITIAL velocities:
+          ! every list cell must be overwritten)
+          call dyn_evp_hip_cgrid_dyn_finish
+          call dump_r8_3d(trim(tg)//'_strocnxN', strocnxN, nblocks); call dump_r8_3d(trim(tg)//'_strocnyN', strocnyN, nblocks)
+          call dump_r8_3d(trim(tg)//'_strocnxE', strocnxE, nblocks); call dump_r8_3d(trim(tg)//'_strocnyE', strocnyE, nblocks)
           write(*,'(a,i3,a,i5,3es24.16)') 'Hcall', ic, ' nsub', ns, &
                maxval(abs(uvelE(:,:,1:nblocks))), maxval(abs(vvelN(:,:,1:nblocks))), maxval(abs(stresspT(:,:,1:nblocks)))
        enddo
@@ -242,6 +248,9 @@ contains
        call dump_r8_3d(trim(tg)//'_divu', divu, nblocks);         call dump_r8_3d(trim(tg)//'_shear', shear, nblocks)
        call dump_r8_3d(trim(tg)//'_vort', vort, nblocks)
        call dump_r8_3d(trim(tg)//'_rdg_conv', rdg_conv, nblocks); call dump_r8_3d(trim(tg)//'_rdg_shear', rdg_shear, nblocks)
+       ! dyn_finish at N and E points (ice_dyn_evp.F90:1408-1436)
+       call dump_r8_3d(trim(tg)//'_strocnxN', strocnxN, nblocks); call dump_r8_3d(trim(tg)//'_strocnyN', strocnyN, nblocks)
+       call dump_r8_3d(trim(tg)//'_strocnxE', strocnxE, nblocks); call dump_r8_3d(trim(tg)//'_strocnyE', strocnyE, nblocks)
        write(*,'(a,i3,a,i5,3es24.16)') 'Ccall', ic, ' nsub', ns, &
             maxval(abs(uvelE(:,:,1:nblocks))), maxval(abs(vvelN(:,:,1:nblocks))), maxval(abs(stresspT(:,:,1:nblocks)))
     enddo

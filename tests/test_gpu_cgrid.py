@@ -48,6 +48,34 @@ def test_cgrid_golden_bitwise(name):
 
 
 @pytest.mark.parametrize("name", CGRID_CASES)
+def test_cgrid_dyn_finish_on_device_bitwise(name):
+    """dyn_finish at N and E points (ice_dyn_evp.F90:1408-1436), the last thing evp() computes from the C-grid loop's
+    velocities, on the device from the loop's resident final state and the operands it already holds: strocnxN / strocnyN /
+    strocnxE / strocnyE equal the arrays the reference's evp() left (fixtures regenerated with them in round 4), bit for bit
+    on the cells of dyn_prep2's N / E lists; every other cell keeps the value it was handed (sentinel)."""
+    from test_oracle_golden import cgrid_dyn_finish_lists
+    c = GoldenCase(name)
+    core = cgrid_core(c)
+    keys = ("strocnxN", "strocnyN", "strocnxE", "strocnyE")
+    try:
+        for icall in range(1, c.ncalls + 1):
+            state, inputs, masks = c.cgrid_inputs(icall)
+            lists = cgrid_dyn_finish_lists(c, masks)
+            for nsub in c.nsub_list:
+                core.cgrid_run(nsub, state, inputs, masks, visc_method=str(c.d["visc_method"]))
+                want = {k: c.d[f"o{icall:02d}n{nsub:04d}_{k}"] for k in keys}
+                sent = {k: np.where(lists[k[-1]], 0.0, 7.25) for k in keys}
+                got = core.cgrid_dyn_finish(prev=sent)
+                for k in keys:
+                    on = lists[k[-1]]
+                    assert np.array_equal(got[k][on], want[k][on]), f"{name} call {icall} nsub {nsub} {k}"
+                    assert (got[k][~on] == 7.25).all(), f"{k}: a cell off the list was written"
+        assert np.abs(want["strocnxE"]).max() > 0 and np.abs(want["strocnyN"]).max() > 0
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("name", CGRID_CASES)
 def test_cgrid_deformations_t_on_device_bitwise(name):
     """deformationsC_T (ice_dyn_shared.F90:1968-2074), which evp() runs right after the C-grid loop, on the device from
     the loop's resident final state: divu, shear, vort, rdg_conv, rdg_shear equal the arrays the reference's evp() left

@@ -254,6 +254,41 @@ def test_cgrid_deformations_t_oracle_bitwise(name):
                 assert np.array_equal(got[k], want[k]), f"{name} call {icall} nsub {nsub} {k}"
 
 
+def cgrid_dyn_finish_lists(c, masks):
+    """dyn_prep2's N / E lists: the ice faces of the interior cells (ilo..ihi x jlo..jhi)."""
+    out = {}
+    for loc in "NE":
+        m = masks[f"ice{loc}mask"] != 0
+        on = np.zeros_like(m)
+        for b in range(c.nblocks):
+            ilo, ihi, jlo, jhi = [int(v) for v in c.blk[b, :4]]
+            on[b, jlo - 1:jhi, ilo - 1:ihi] = m[b, jlo - 1:jhi, ilo - 1:ihi]
+        out[loc] = on
+    return out
+
+
+@pytest.mark.parametrize("name", CGRID_CASES)
+def test_cgrid_dyn_finish_oracle_bitwise(name):
+    """dyn_finish at N and E points (ice_dyn_shared.F90:1291-1365 with the operands of ice_dyn_evp.F90:1408-1436): from the
+    reference's final face velocities and the loop's per-call operands, strocnxN / strocnyN / strocnxE / strocnyE as evp()
+    leaves them, bit for bit; the list cells are rewritten (sentinel), every other cell keeps its value."""
+    c = GoldenCase(name)
+    for icall in range(1, c.ncalls + 1):
+        _, inputs, masks = c.cgrid_inputs(icall)
+        lists = cgrid_dyn_finish_lists(c, masks)
+        for nsub in c.nsub_list:
+            exp = c.cgrid_expected(icall, nsub)
+            for loc in "NE":
+                want = [c.d[f"o{icall:02d}n{nsub:04d}_strocn{xy}{loc}"] for xy in "xy"]
+                start = [np.where(lists[loc], 123.0, w) for w in want]
+                got = oracle.dyn_finish_at(c.oracle_domain(), c.oracle_params(), inputs[f"cdn_ocn{loc}"], inputs[f"ai{loc}"], inputs[f"uocn{loc}"],
+                                           inputs[f"vocn{loc}"], inputs[f"fm{loc}"], exp[f"uvel{loc}"], exp[f"vvel{loc}"],
+                                           masks[f"ice{loc}mask"], *start)
+                for g, w, xy in zip(got, want, "xy"):
+                    assert np.array_equal(g, w), f"{name} call {icall} nsub {nsub} strocn{xy}{loc}"
+                assert lists[loc].any() and np.abs(want[0][lists[loc]]).max() > 0
+
+
 @pytest.mark.parametrize("name", CGRID_CASES)
 def test_cgrid_prep_oracle_bitwise(name):
     """evp()'s preparation phase for grid_ice = 'C' (ice_dyn_evp.F90:383-735: dyn_prep1, the T -> U / E / N averages,
