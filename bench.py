@@ -773,11 +773,10 @@ def main():
                 c2[label] = {"error": f"{type(e).__name__}: {e}"[:300]}
         extra["configs2_gx1_ndte240"] = c2
     if want("tripole") and a.workload == "gx1" and world > 1:
-        # BASELINE configs[3]: the tripole grid over the N GPUs, cut in y (1 x N slabs): the fold row stays on one rank, which
-        # is the layout where the on-chip kernel averages the seam pairs itself; a cut through the fold row (4 x 2) runs the
-        # streaming kernel + seam step
+        # BASELINE configs[3]: the tripole grid over the N GPUs in its most square cut (8 GPUs: 4 x 2, the fold row split in
+        # x: seam partners on different ranks trade their raw records through the peers' buffers, round 4)
         try:
-            Mx = measure_with_fallbacks("tx1", "full", 240, 10, 2, ns="tripole", proc_shape=(1, world))
+            Mx = measure_with_fallbacks("tx1", "full", 240, 10, 2, ns="tripole")
             extra["tripole"] = rank_block(Mx, f"tx1 {Mx['nx']}x{Mx['ny']} tripole B-grid EVP ndte=240, case=full, {world} GPUs")
         except Exception as e:  # noqa: BLE001
             extra_err["tripole"] = f"{type(e).__name__}: {e}"[:300]

@@ -108,6 +108,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
             self.send_dst.push_back(S.plan.local_dst[k]);
             self.recv_dst.push_back(S.plan.local_dst[k]);
             self.recv_sign.push_back(S.plan.local_sign[k]);
+            self.send_sign.push_back(S.plan.local_sign[k]);
             {
                 const int32_t so = S.plan.local_src[k];
                 const size_t pl = (size_t)dims->nx_block * dims->ny_block;
@@ -118,6 +119,8 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
             }
         }
         S.plan.local_dst = kd; S.plan.local_src = ks; S.plan.local_sign = kg;
+        self.n_ghost_send = (int)self.send_src.size();
+        self.n_ghost_recv = (int)self.recv_dst.size();
         S.plan.peers.push_back(self);
     }
     // the global block table is needed again by plans built later (the two-subcycle path decides at the first

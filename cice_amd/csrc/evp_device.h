@@ -107,7 +107,7 @@ struct EvpResident2 {
     int par0;                  // which of rec[0/1] holds the records of subcycle index 0 of THIS launch
                                // (flips so that a launch never starts in the buffer the previous one ended in)
     // neighbours on other GPUs (ring entries with z == -2 are produced there); rimg == NULL: none
-    const int2 *rimg;          // [ncell][3] images on other ranks: {peer index, ghost cell at that peer}, x = -1 none
+    const int2 *rimg;          // [ncell][3] images on other ranks: {peer index | 256 if the image takes the negative, ghost cell at that peer}, x = -1 none
     void *const *peer_rec;     // [npeers] the peer's record buffer (parity 0) as mapped here
     const size_t *peer_rstride;// [npeers] bytes between the two parities of that buffer
     unsigned long long timeout_ticks;   // bound of a wait on another rank (100 MHz wall clock)
@@ -115,6 +115,12 @@ struct EvpResident2 {
     const int *seam;           // [nx] per column of the fold row: partner cell * 4 + role (1 low, 2 high, 3 pole), 0 none
     const int *img3;           // [ncell][3] ghost images of every U-cell: dst * 2 + (sign < 0), -1 none
     void *rec_raw[2];          // records of the pre-average velocities of the fold row, by subcycle parity
+    // fold row split over ranks: a seam cell whose partner lives on another rank stores its raw record into that rank's
+    // rec_raw buffer as well (slot = a staging index >= ncell there) and polls the partner's in its own buffer at the slot
+    // the seam table names (partner index >= ncell)
+    const int2 *rraw;          // [ncell][3] {peer index, slot at that peer}, x = -1 none; NULL: no split fold
+    void *const *peer_raw;     // [npeers] the peer's rec_raw buffer (parity 0) as mapped here
+    const size_t *peer_raw_stride;
 };
 int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote);
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,

@@ -179,7 +179,7 @@ struct State {
         bool on = false;             // use it for the remote halo
         bool exported = false;
         void *mailbox = nullptr;     // [flags][seq][err][inbox x 2 parities]
-        size_t bytes = 0, inbox_off = 0, rec_off = 0;
+        size_t bytes = 0, inbox_off = 0, rec_off = 0, raw_off = 0;
         std::vector<void *> opened;  // hipIpcOpenMemHandle results
         EvpDirect *d_dx = nullptr;   // device copy of the argument block (exchange riding in the subcycle launch)
         EvpDirect *d_dx_m = nullptr; // the same with the masked lists (cice_evp_hip_halo_mask)
@@ -226,6 +226,10 @@ struct State {
     bool res2_order_stale = true;                     // masks changed since it was built
     int *res2_seam = nullptr, *res2_img3 = nullptr;   // tripole: fold-row roles, per-cell ghost images
     void *res2_rec_raw[2] = {nullptr, nullptr};       // tripole: records of the pre-average fold-row velocities
+    bool res2_raw_owned = true;                       // false: they live inside the mailbox allocation (fold row split over ranks)
+    int2 *res2_rraw = nullptr;                        // EvpResident2::rraw / peer_raw / peer_raw_stride
+    void **res2_peer_raw = nullptr;
+    size_t *res2_peer_raw_stride = nullptr;
     int2 *res2_rimg = nullptr;
     void **res2_peer_rec = nullptr;
     size_t *res2_peer_rstride = nullptr;

@@ -60,7 +60,11 @@ void free_all()
     S.res_remote = false;
     S.res2_par = 0; S.res2_epoch = 0;
     F(S.res2_rimg); F(S.res2_peer_rec); F(S.res2_peer_rstride);
-    F(S.res2_order); F(S.res2_seam); F(S.res2_img3); F(S.res2_rec_raw[0]); F(S.res2_rec_raw[1]);
+    F(S.res2_order); F(S.res2_seam); F(S.res2_img3);
+    if (S.res2_raw_owned) { F(S.res2_rec_raw[0]); F(S.res2_rec_raw[1]); }
+    S.res2_rec_raw[0] = S.res2_rec_raw[1] = nullptr;
+    S.res2_raw_owned = true;
+    F(S.res2_rraw); F(S.res2_peer_raw); F(S.res2_peer_raw_stride);
     for (auto &p : S.res_scratch) F(p);
     for (auto &p : S.post_geo) F(p);
     for (auto &p : S.post_out) F(p);

@@ -14,6 +14,7 @@ struct HaloBlob {
     uint64_t base;                 // mailbox address in the exporting process
     uint64_t inbox_off, n_recv;
     uint64_t rec_off, rec_stride;  // record buffers of the resident kernel inside the mailbox (0: none)
+    uint64_t raw_off, raw_stride;  // ... and its raw seam records (tripole fold row split over ranks; 0: none)
     int32_t can_res, pad_;         // this rank can run the resident kernel with remote neighbours
     hipIpcMemHandle_t handle;
     struct { int32_t rank, recv_off, count, flag_idx; } peer[EVP_DIRECT_MAXPEER];
@@ -42,12 +43,14 @@ int direct_export(HaloBlob &B)
                     !(env_test("CICE_EVP_HIP_RES_REMOTE") && std::atoi(env_test("CICE_EVP_HIP_RES_REMOTE")) == 0);
     size_t rec_off = 0;
     const size_t rec_stride = S.n * 32;            // one 32-byte record pair per cell of every block
+    const size_t raw_stride = (S.n + (size_t)S.plan.tail) * 32;   // raw seam records: the cells + the staging slots of remote partners
     if (!X.mailbox) {
         X.inbox_off = DIRECT_INBOX_OFF;
         X.bytes = X.inbox_off + 2 * 2 * (size_t)std::max(S.n_recv, 1) * sizeof(double);
         X.bytes = (X.bytes + 255) & ~(size_t)255;
         if (want_res) { rec_off = X.bytes; X.bytes += 2 * rec_stride; }
         X.rec_off = rec_off;
+        if (want_res && S.plan.tail > 0) { X.raw_off = X.bytes; X.bytes += 2 * raw_stride; }
         // fine-grained: stores of another GPU become visible to loads here without a kernel boundary
         // (no coarse-grained fallback: without this property a peer's stores are only guaranteed
         // to be seen at kernel boundaries, and the transport would be wrong on a real node)
@@ -61,6 +64,13 @@ int direct_export(HaloBlob &B)
         S.res2_rec_owned = false;
         S.res2_rec[0] = (char *)X.mailbox + X.rec_off;
         S.res2_rec[1] = (char *)X.mailbox + X.rec_off + rec_stride;
+        if (X.raw_off) {
+            if (S.res2_raw_owned)
+                for (auto &q : S.res2_rec_raw) { if (q) (void)hipFree(q); q = nullptr; }
+            S.res2_raw_owned = false;
+            S.res2_rec_raw[0] = (char *)X.mailbox + X.raw_off;
+            S.res2_rec_raw[1] = (char *)X.mailbox + X.raw_off + raw_stride;
+        }
         const int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
         for (int logw : {4, 5, 6}) {
             if (forced_w && logw != forced_w) continue;
@@ -73,6 +83,8 @@ int direct_export(HaloBlob &B)
     B.can_res = can_res;
     B.rec_off = X.rec_off;
     B.rec_stride = rec_stride;
+    B.raw_off = X.raw_off;
+    B.raw_stride = raw_stride;
     B.magic = HALO_BLOB_MAGIC;
     B.version = 1;
     B.rank = S.d.rank;
@@ -152,30 +164,68 @@ int direct_import(const HaloBlob *blobs, int nranks)
     for (int r = 0; r < nranks; ++r) all_res = all_res && blobs[r].magic == HALO_BLOB_MAGIC && blobs[r].can_res != 0;
     S.res_remote = false;
     if (all_res && np > 0) {
-        std::vector<void *> prec((size_t)np);
-        std::vector<size_t> pstr((size_t)np);
+        std::vector<void *> prec((size_t)np), praw((size_t)np, nullptr);
+        std::vector<size_t> pstr((size_t)np), prawstr((size_t)np, 0);
         std::vector<int2> rimg(S.n * 3, make_int2(-1, -1));     // per cell: up to three images on other ranks
+        std::vector<int2> rraw;                                 // per seam cell: where its raw record goes on other ranks
+        const bool split_fold = S.plan.tail > 0 || [&] { for (const HaloPeer &p : S.plan.peers) if (p.n_ghost_send < (int)p.send_src.size() || !p.fimg_src.empty()) return true; return false; }();
+        if (split_fold) rraw.assign(S.n * 3, make_int2(-1, -1));
         bool ok = true;
+        auto add = [&](std::vector<int2> &tab, size_t c, int2 v) {
+            int e = 0;
+            while (e < 3 && tab[c * 3 + e].x >= 0) ++e;
+            if (e == 3) { ok = false; return; }
+            tab[c * 3 + e] = v;
+        };
         for (int q = 0; q < np && ok; ++q) {
             const HaloPeer &p = S.plan.peers[q];
             const HaloBlob &B = blobs[p.rank];
             prec[q] = mapped[p.rank] + B.rec_off;
             pstr[q] = (size_t)B.rec_stride;
+            if (B.raw_off) { praw[q] = mapped[p.rank] + B.raw_off; prawstr[q] = (size_t)B.raw_stride; }
             if (env_test("CICE_EVP_HIP_RES_REMOTE_BREAK")) {      // test hook: records go nowhere -> the probe must fail
                 void *dummy = nullptr;
                 HIPC(hipMalloc(&dummy, 2 * (size_t)B.rec_stride));
                 prec[q] = dummy;                             // (leaked on purpose: test processes only)
             }
-            for (size_t k = 0; k < p.send_src.size() && ok; ++k) {
+            // ghost cells of the peer: the FINAL velocity (negative across the tripole fold)
+            for (int k = 0; k < p.n_ghost_send && ok; ++k)
+                add(rimg, (size_t)p.send_src[k], make_int2(q | (p.send_sign[k] < 0 ? 256 : 0), p.send_dst[k]));
+            // ... its ghost images of this rank's seam cells likewise (after the averaging)
+            for (size_t k = 0; k < p.fimg_src.size() && ok; ++k)
+                add(rimg, (size_t)p.fimg_src[k], make_int2(q | (p.fimg_sign[k] < 0 ? 256 : 0), p.fimg_dst[k]));
+            // raw seam values: into the peer's rec_raw buffer at the staging slot it polls
+            // (the plan also sends a raw value to every rank that finalises a ghost image from it in the streaming path; the
+            // on-chip kernel delivers those images as final values, so only the rank that owns the pair partner needs it)
+            for (size_t k = (size_t)p.n_ghost_send; k < p.send_src.size() && ok; ++k) {
                 const size_t c = (size_t)p.send_src[k];
-                int e = 0;
-                while (e < 3 && rimg[c * 3 + e].x >= 0) ++e;
-                if (e == 3) { ok = false; break; }
-                rimg[c * 3 + e] = make_int2(q, p.send_dst[k]);
+                const int b = (int)(c / S.plane), i = (int)((c % S.plane) % S.d.nx_block) + 1;
+                const int ig = S.iglob0[b] + (i - S.ilo[b]);
+                const int pc = S.d.nx_global - ig, NY = S.d.ny_global;
+                int owner = -1;
+                for (size_t t = 0; t < S.gtab[0].size(); ++t)
+                    if (pc >= S.gtab[0][t] && pc < S.gtab[0][t] + S.gtab[2][t] && NY >= S.gtab[1][t] && NY < S.gtab[1][t] + S.gtab[3][t])
+                        owner = S.gtab[4][t];
+                if (owner != p.rank) continue;
+                if (!praw[q]) { ok = false; break; }
+                add(rraw, c, make_int2(q, p.send_dst[k]));
             }
+        }
+        if (env("CICE_EVP_HIP_VERBOSE") && split_fold) {
+            size_t nraw = 0, nimg = 0;
+            for (const int2 &v : rraw) nraw += v.x >= 0;
+            for (const int2 &v : rimg) nimg += v.x >= 0;
+            std::fprintf(stderr, "[cice_evp_hip] rank %d: fold row split over ranks: %zu remote images, %zu raw seam records sent, %d staging slots, tables %s\n",
+                         (int)S.d.rank, nimg, nraw, S.plan.tail, ok ? "fit" : "DO NOT FIT (more than three destinations of one cell)");
+            for (int q = 0; q < np; ++q)
+                std::fprintf(stderr, "[cice_evp_hip] rank %d: peer %d: %d ghost + %zu raw sends, %d ghost + %zu raw receives, %zu / %zu seam images out / in, raw buffer %s\n",
+                             (int)S.d.rank, S.plan.peers[q].rank, S.plan.peers[q].n_ghost_send, S.plan.peers[q].send_src.size() - S.plan.peers[q].n_ghost_send,
+                             S.plan.peers[q].n_ghost_recv, S.plan.peers[q].recv_dst.size() - S.plan.peers[q].n_ghost_recv,
+                             S.plan.peers[q].fimg_src.size(), S.plan.peers[q].fimg_recv_dst.size(), praw[q] ? "mapped" : "none");
         }
         if (ok) {
             if (up(S.res2_rimg, rimg) || up(S.res2_peer_rec, prec) || up(S.res2_peer_rstride, pstr)) return -1;
+            if (split_fold && (up(S.res2_rraw, rraw) || up(S.res2_peer_raw, praw) || up(S.res2_peer_raw_stride, prawstr))) return -1;
             S.res_remote = true;
         }
     }
@@ -272,7 +322,12 @@ int resident_remote_probe()
     HIPC(hipMemcpyAsync(gu.data(), S.u[1], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
     HIPC(hipMemcpyAsync(gv.data(), S.v[0], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
-    rc = resident_check_error();
+    {
+        const int gen = S.res_gen;
+        S.res_gen = 2;          // (the probe ran the tagged-record kernel: its error word names tile, subcycle, cell and tags)
+        rc = resident_check_error();
+        S.res_gen = gen;
+    }
     S.res_mode = -1;            // (resident_check_error parks the mode on failure; decided again at upload)
     for (int b = 0; b < 2; ++b) {
         HIPC(hipMemsetAsync(S.u[b], 0, S.n * sizeof(double), S.stream));
@@ -280,13 +335,32 @@ int resident_remote_probe()
     }
     HIPC(hipStreamSynchronize(S.stream));
     if (rc) return rc;
-    for (const HaloPeer &p : S.plan.peers)
-        for (size_t k = 0; k < p.recv_dst.size(); ++k) {
+    const int NX = S.d.nx_global, NY = S.d.ny_global;
+    for (const HaloPeer &p : S.plan.peers) {
+        for (int k = 0; k < p.n_ghost_recv; ++k) {       // (the entries behind them are staging slots of the streaming path)
             const double want = (double)p.recv_sign[k] * ((double)p.recv_gid[k] + 1.0);
             if (gu[p.recv_dst[k]] != want || gv[p.recv_dst[k]] != -2.0 * want)
                 return fail(-8, "resident kernel probe: ghost %d from rank %d holds %.17g, expected %.17g",
                             (int)p.recv_dst[k], p.rank, gu[p.recv_dst[k]], want);
         }
+        // images of seam-row cells of other ranks: the owner's value AFTER the fold step -- the pair (lo, hi = NX - lo) holds
+        // (xavg, -xavg), xavg = 0.5 * (x_lo - x_hi), from the first subcycle on; a pole point has changed sign three times
+        for (size_t k = 0; k < p.fimg_recv_dst.size(); ++k) {
+            const int col = p.fimg_recv_col[k];
+            auto val = [&](int ig) { return (double)((ig - 1) + (size_t)NX * (NY - 1)) + 1.0; };
+            double fin;
+            if (col == NX / 2 || col == NX) fin = -val(col);
+            else {
+                const int lo = std::min(col, NX - col), hi = NX - lo;
+                const double xavg = 0.5 * (val(lo) + (-1.0) * val(hi));
+                fin = col == lo ? xavg : -1.0 * xavg;
+            }
+            const double want = (double)p.fimg_recv_sign[k] * fin;
+            if (gu[p.fimg_recv_dst[k]] != want || gv[p.fimg_recv_dst[k]] != -2.0 * want)
+                return fail(-8, "resident kernel probe: ghost %d (image of seam column %d of rank %d) holds %.17g, expected %.17g",
+                            (int)p.fimg_recv_dst[k], col, p.rank, gu[p.fimg_recv_dst[k]], want);
+        }
+    }
     return 0;
 }
 

@@ -7,13 +7,17 @@ namespace evp_host {
 // ---- on-chip resident subcycle -------------------------------------------------------
 // Host side of evp_resident.hip: which tiles exchange velocities (producers == readers by
 // symmetry: the 8 surrounding tiles, with cyclic wrap through the ghost-cell images).
-bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0; }
+// (a rank of a fold row split in x may hold neither a pole point nor a pair with both halves: its seam cells are the plan's
+// general list then -- 3 x 1 and 4 x 1 cuts of tx1 showed it: two of the ranks ran without any fold handling)
+bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0 || S.plan.tail > 0 || !S.plan.fin_dst.empty(); }
 
 bool resident_possible(bool with_peers)
 {
     if (!with_peers && !S.plan.peers.empty()) return false;
     if (S.plan.tfold) return false;           // tripoleT: the top row's images are interior cells (rewritten after the launch)
-    if (S.plan.tail > 0) return false;        // tripole seam pairs across ranks: streaming kernel + exchange + seam step
+    // tripole seam pairs across ranks: with neighbours on other GPUs the partners trade their raw records through the
+    // peers' rec_raw buffers (round 4); every other caller gets the streaming kernel + exchange + seam step
+    if (S.plan.tail > 0 && !with_peers) return false;
     if (tripole_seam() || S.d.nblocks > 1) {
         // tagged-record kernel only: the fold row is averaged inside the kernel, ghost images come
         // from a per-cell table (at most three per cell, no eliminated source block)
@@ -116,8 +120,10 @@ int resident2_setup(int logw)
     std::vector<int> ghost_src(ncell, -1);
     for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
         if (S.plan.local_src[k] >= 0) ghost_src[S.plan.local_dst[k]] = S.plan.local_src[k];
-    for (const HaloPeer &p : S.plan.peers)            // produced on another rank: -2 (always refreshed)
-        for (int32_t d : p.recv_dst) ghost_src[d] = -2;
+    for (const HaloPeer &p : S.plan.peers) {          // produced on another rank: -2 (always refreshed)
+        for (int k = 0; k < p.n_ghost_recv; ++k) ghost_src[p.recv_dst[k]] = -2;     // (what follows are staging slots, not cells)
+        for (int32_t d : p.fimg_recv_dst) ghost_src[d] = -2;                        // images of seam cells: the owner's FINAL value
+    }
     std::vector<char> on_seam(ncell, 0);              // cells of the tripole fold row (change every subcycle, ice or not)
     for (int32_t c : S.plan.seam_a) on_seam[c] = 1;
     for (int32_t c : S.plan.seam_b) on_seam[c] = 1;
@@ -202,12 +208,23 @@ int resident2_setup(int logw)
             seam[slot(S.plan.seam_b[k])] = S.plan.seam_a[k] * 4 + 2;
         }
         for (int32_t pcell : S.plan.seam_pole) seam[slot(pcell)] = 3;
+        // pairs with the partner on another rank (fold row split in x): the plan's general seam list names, for each of this
+        // rank's seam cells, the RAW operands a (low column) and b (high column) -- a local cell or a staging slot >= ncell,
+        // which is where the partner's raw record lands in this rank's rec_raw buffer
+        for (size_t k = 0; k < S.plan.fin_dst.size(); ++k) {
+            const int32_t dst = S.plan.fin_dst[k], a = S.plan.fin_a[k], b = S.plan.fin_b[k];
+            if (b < 0 || (dst != a && dst != b)) continue;                   // pole / unpaired cell, or a ghost image
+            if ((size_t)a < ncell && (size_t)b < ncell) continue;            // both local: set above
+            seam[slot(dst)] = (dst == a) ? b * 4 + 1 : a * 4 + 2;
+        }
         HIPC(hipMalloc((void **)&S.res2_seam, seam.size() * sizeof(int)));
         HIPC(hipMemcpy(S.res2_seam, seam.data(), seam.size() * sizeof(int), hipMemcpyHostToDevice));
-        for (auto &q : S.res2_rec_raw) {
-            HIPC(hipMalloc(&q, ncell * 32));
-            HIPC(hipMemset(q, 0, ncell * 32));
-        }
+        for (auto &q : S.res2_rec_raw)
+            if (!q) {
+                if (!S.res2_raw_owned) return fail(-6, "resident2: raw seam records missing from the mailbox");
+                HIPC(hipMalloc(&q, (ncell + (size_t)S.plan.tail) * 32));
+                HIPC(hipMemset(q, 0, (ncell + (size_t)S.plan.tail) * 32));
+            }
     }
     HIPC(hipMalloc((void **)&S.res2_ring, ring.size() * sizeof(int4)));
     HIPC(hipMemcpy(S.res2_ring, ring.data(), ring.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -384,6 +401,9 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.rimg = S.res_remote ? S.res2_rimg : nullptr;
     R.peer_rec = S.res2_peer_rec;
     R.peer_rstride = S.res2_peer_rstride;
+    R.rraw = S.res_remote ? S.res2_rraw : nullptr;
+    R.peer_raw = S.res2_peer_raw;
+    R.peer_raw_stride = S.res2_peer_raw_stride;
     const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
     R.timeout_ticks = (unsigned long long)((S.res_timeout_ms > 0 ? S.res_timeout_ms : tmo_ms) * 1.0e5);
     R.spin_limit = 4000000u;

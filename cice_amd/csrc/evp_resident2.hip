@@ -307,20 +307,40 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // images of this U-cell on other ranks: record address (parity 0) in the peer's buffer
     char *rp0 = nullptr, *rp1 = nullptr, *rp2 = nullptr;
     size_t rs0 = 0, rs1 = 0, rs2 = 0;
+    double rg0 = 1.0, rg1 = 1.0, rg2 = 1.0;       // an image across the tripole fold takes the negative
+    // fold row split over ranks: where this seam cell's RAW record goes on other ranks
+    char *rq0 = nullptr, *rq1 = nullptr, *rq2 = nullptr;
+    size_t rqs0 = 0, rqs1 = 0, rqs2 = 0;
     if (REMOTE) {
         if (ownU) {
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
-                const int2 v = R.rimg[3 * (size_t)c + e];      // per-cell table: {peer index, ghost cell at that peer}
+                const int2 v = R.rimg[3 * (size_t)c + e];      // per-cell table: {peer index (| 256: negative), ghost cell at that peer}
                 if (v.x < 0) continue;
-                char *ptr = (char *)R.peer_rec[v.x] + 32 * (size_t)v.y;
-                const size_t st = R.peer_rstride[v.x];
-                if (!rp0) { rp0 = ptr; rs0 = st; }
-                else if (!rp1) { rp1 = ptr; rs1 = st; }
-                else { rp2 = ptr; rs2 = st; }
+                const int pe = v.x & 255;
+                char *ptr = (char *)R.peer_rec[pe] + 32 * (size_t)v.y;
+                const size_t st = R.peer_rstride[pe];
+                const double sg = (v.x & 256) ? -1.0 : 1.0;
+                if (!rp0) { rp0 = ptr; rs0 = st; rg0 = sg; }
+                else if (!rp1) { rp1 = ptr; rs1 = st; rg1 = sg; }
+                else { rp2 = ptr; rs2 = st; rg2 = sg; }
+            }
+            if (R.rraw && isSeam) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const int2 v = R.rraw[3 * (size_t)c + e];
+                    if (v.x < 0) continue;
+                    char *ptr = (char *)R.peer_raw[v.x] + 32 * (size_t)v.y;
+                    const size_t st = R.peer_raw_stride[v.x];
+                    if (!rq0) { rq0 = ptr; rqs0 = st; }
+                    else if (!rq1) { rq1 = ptr; rqs1 = st; }
+                    else { rq2 = ptr; rqs2 = st; }
+                }
             }
         }
     }
+    // the partner of a seam pair on another rank: its raw record arrives in THIS rank's rec_raw buffer at a staging slot
+    const bool seam_remote = REMOTE && isSeam && seam_role != 3 && seam_partner >= (int)(A.plane * (size_t)R.nblocks);
     const bool rpub = REMOTE && rp0 != nullptr;    // publishes every subcycle, ice or not
     // my ring entry: which cell of the LDS ring do I refresh, from which record
     int ring_cp = -1, ring_li = 0;
@@ -338,14 +358,13 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         }
     };
     auto publish_remote = [&](int par, double uu, double vv, unsigned tag) {
-        const v4u a = pack_rec(uu, tag), b = pack_rec(vv, tag);
-        st_rec2_sys(rp0 + (size_t)par * rs0, a, b);
-        if (rp1) st_rec2_sys(rp1 + (size_t)par * rs1, a, b);
-        if (rp2) st_rec2_sys(rp2 + (size_t)par * rs2, a, b);
+        st_rec2_sys(rp0 + (size_t)par * rs0, pack_rec(rg0 * uu, tag), pack_rec(rg0 * vv, tag));
+        if (rp1) st_rec2_sys(rp1 + (size_t)par * rs1, pack_rec(rg1 * uu, tag), pack_rec(rg1 * vv, tag));
+        if (rp2) st_rec2_sys(rp2 + (size_t)par * rs2, pack_rec(rg2 * uu, tag), pack_rec(rg2 * vv, tag));
     };
     // one poll of a record written by another rank: bounded by wall-clock time (ranks reach
     // evp() at different moments), not by a spin count
-    auto poll_remote = [&](const v4u *rec, unsigned want, v4u &ra, v4u &rb) -> bool {
+    auto poll_remote = [&](const v4u *rec, unsigned want, v4u &ra, v4u &rb, int kind = 2, int cell = -1) -> bool {
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
         for (;;) {
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             if ((++spins & 255u) == 0 &&
                 (wall_clock64() - t0 > R.timeout_ticks ||
                  __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                give_up_note(2, (int)(want - R.tag_base), ring_cp, ra.x, want);
+                give_up_note(kind, (int)(want - R.tag_base), cell >= 0 ? cell : ring_cp, ra.x, want);
                 return false;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -529,10 +548,21 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             } else {
                 v4u *rw = (v4u *)R.rec_raw[((k + par0) & 1) ^ 1];
                 st_rec2(rw + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
+                if (REMOTE && rq0) {       // ... and into the rec_raw buffers of the ranks that hold the partner (or an image)
+                    const int parw = ((k + par0) & 1) ^ 1;
+                    const v4u a = pack_rec(u_own, tag), b = pack_rec(v_own, tag);
+                    st_rec2_sys(rq0 + (size_t)parw * rqs0, a, b);
+                    if (rq1) st_rec2_sys(rq1 + (size_t)parw * rqs1, a, b);
+                    if (rq2) st_rec2_sys(rq2 + (size_t)parw * rqs2, a, b);
+                }
                 v4u ra, rb;
                 unsigned spins = 0;
                 bool ok = true;
                 if (REMOTE) t_wait0 = wall_clock64();
+                if (seam_remote) {
+                    ok = poll_remote(rw + 2 * (size_t)seam_partner, tag, ra, rb, 3, seam_partner);
+                    if (!ok) s_bad = 1;
+                } else
                 for (;;) {
                     ld_rec2(rw + 2 * (size_t)seam_partner, ra, rb);
                     if (ra.x == tag && ra.w == tag && rb.x == tag && rb.w == tag) break;

@@ -190,7 +190,19 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                         // finalised after the exchange from RAW pair values (fin lists below); the plain copy only
                         // stays in the local lists (late_*: single-rank form of the same step)
                         ghost_seam.push_back({R, dst, s.ig, s.sign});
-                        if (S.owner != R) continue;
+                        if (S.owner != R) {
+                            // (on-chip kernel: the owner's final value as a record of its own, see halo_plan.h)
+                            if (S.owner == me) {
+                                HaloPeer &p = peers[R];
+                                p.rank = R;
+                                p.fimg_src.push_back(src); p.fimg_dst.push_back(dst); p.fimg_sign.push_back((int8_t)s.sign);
+                            } else if (R == me) {
+                                HaloPeer &p = peers[S.owner];
+                                p.rank = S.owner;
+                                p.fimg_recv_dst.push_back(dst); p.fimg_recv_col.push_back(s.ig); p.fimg_recv_sign.push_back((int8_t)s.sign);
+                            }
+                            continue;
+                        }
                     }
                     if (S.owner != R && s.sign < 0) plan.any_fold_exchange = true;
                     if (R == me) {
@@ -215,10 +227,12 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                         p.rank = R;
                         p.send_src.push_back(src);
                         p.send_dst.push_back(dst);
+                        p.send_sign.push_back((int8_t)s.sign);
                     }
                 }
         }
     }
+    for (auto &kv : peers) { kv.second.n_ghost_send = (int)kv.second.send_src.size(); kv.second.n_ghost_recv = (int)kv.second.recv_dst.size(); }
     for (auto &kv : peers) plan.peers.push_back(kv.second);      // (the tripole section may append staging entries and rebuilds this)
 
     // cell-centre fields: ghosts of this rank's blocks, same enumeration
@@ -327,6 +341,7 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                     p.rank = R;
                     p.send_src.push_back(off);
                     p.send_dst.push_back(slot);
+                    p.send_sign.push_back(1);
                 }
                 return slot;
             };

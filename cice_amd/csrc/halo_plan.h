@@ -31,6 +31,18 @@ struct HaloPeer {
     std::vector<int32_t> recv_dst;
     std::vector<int8_t> recv_sign;
     std::vector<int32_t> recv_gid;    // global cell number (ig-1) + NX*(jg-1) each ghost mirrors (probe exchange)
+    std::vector<int8_t> send_sign;    // factor the receiver applies to entry k (= its recv_sign; +1 for raw seam entries)
+    // the first n_ghost_* entries of the send / recv lists are ghost cells; what follows (tripole fold row split over ranks)
+    // are RAW seam values travelling into staging slots n_local + t of the receiver
+    int n_ghost_send = 0, n_ghost_recv = 0;
+    // On-chip kernel with the fold row split over ranks: a ghost image of a seam-row cell takes the FINAL (averaged) value
+    // straight from the cell's owner, as one more tagged record after the owner's own averaging -- instead of being finalised
+    // from raw pair values as the streaming path does.  fimg_*: cells of this rank (seam row) with the ghost cell at the
+    // peer they feed and its sign; fimg_recv_*: this rank's ghost cells fed that way, the global column of the seam cell.
+    std::vector<int32_t> fimg_src, fimg_dst;
+    std::vector<int8_t> fimg_sign;
+    std::vector<int32_t> fimg_recv_dst, fimg_recv_col;
+    std::vector<int8_t> fimg_recv_sign;
 };
 
 struct HaloPlan {

@@ -24,12 +24,21 @@ def _free_port():
                                                            (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep"),
                                                            (2, "tx1", "1x2", True), (8, "gx3", "2x4", True),
                                                            (2, "gx3", "1x2", "blocks"),
+                                                           # fold row split in x: the on-chip kernel, seam partners on different
+                                                           # ranks trading their raw records through the peers' buffers (round 4)
+                                                           (2, "tx1", "2x1", True), (4, "tx1", "2x2", True),
+                                                           # ranks of the fold row that hold neither a pole point nor a whole pair
+                                                           # (3 x 1, 4 x 1: found two ranks running without any fold handling), and
+                                                           # the natural cut of tx1 on eight GPUs
+                                                           (3, "tx1", "3x1", True), (4, "tx1", "4x1", True), (8, "tx1", "4x2", True),
                                                            (2, "tx1", "2x1", False), (4, "tx1", "2x2", False),
                                                            # evp()'s preparation phase on a tripole grid cut in y
                                                            (2, "tx1", "1x2", "prep"),
                                                            # ... and with the fold row split in x: T-grid ghost cells across the
                                                            # fold and the stress symmetrisation through shifted copies
-                                                           (2, "tx1", "2x1", "prep_stream"), (4, "tx1", "2x2", "prep_stream")])
+                                                           (2, "tx1", "2x1", "prep_stream"), (4, "tx1", "2x2", "prep_stream"),
+                                                           # ... and the same preparation followed by the on-chip kernel
+                                                           (2, "tx1", "2x1", "prep")])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
@@ -135,9 +144,10 @@ def test_bench_multi_rank_rehearsal():
     assert lib["verified"] is True and lib["finite"] and lib["us_per_subcycle"] > 0, lib
     assert lib["verification"]["key"] == "gx1/full/ndte240/closed/strict" and [q["rank"] for q in lib["per_rank"]] == [0, 1]
     assert "skipped" in c2["rccl_point_to_point_forced"]
-    # configs[3]: the tripole grid cut in y, the fold row on the top rank, the on-chip kernel on both
+    # configs[3]: the tripole grid in its natural (most square) cut -- here 2 x 1, the fold row split in x --, the on-chip kernel
+    # on both ranks, seam partners trading raw records across the rank boundary
     tp = d["tripole"]
-    assert tp["verified"] is True and tp["finite"] and tp["decomposition"].startswith("1x2 ranks"), tp
+    assert tp["verified"] is True and tp["finite"] and tp["decomposition"].startswith("2x1 ranks"), tp     # the fold row split in x
     assert tp["tile_variant"] >= 2000 and [q["rank"] for q in tp["per_rank"]] == [0, 1]
 
 
