@@ -797,6 +797,30 @@ int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid)
     return 0;
 }
 
+// The lists the on-chip kernel uses when the tripole fold row is split over ranks (halo_plan.h): per peer (ascending rank,
+// as cice_evp_hip_halo_plan) counts4 = {ghost entries at the head of the send list, of the recv list, seam images out, in};
+// send_sign in send-list order; the seam images out as (src, dst at the peer, sign), in as (dst, global column, sign).
+int cice_evp_hip_fold_images_plan(int32_t *counts4, int32_t *send_sign, int32_t *out3, int32_t *in3)
+{
+    const HaloPlan &P = S.plan;
+    size_t q = 0, so = 0, oo = 0, io = 0;
+    for (const HaloPeer &p : P.peers) {
+        if (counts4) {
+            counts4[4 * q] = p.n_ghost_send; counts4[4 * q + 1] = p.n_ghost_recv;
+            counts4[4 * q + 2] = (int32_t)p.fimg_src.size(); counts4[4 * q + 3] = (int32_t)p.fimg_recv_dst.size();
+        }
+        for (size_t k = 0; k < p.send_sign.size(); ++k)
+            if (send_sign) send_sign[so + k] = p.send_sign[k];
+        for (size_t k = 0; k < p.fimg_src.size(); ++k)
+            if (out3) { out3[3 * (oo + k)] = p.fimg_src[k]; out3[3 * (oo + k) + 1] = p.fimg_dst[k]; out3[3 * (oo + k) + 2] = p.fimg_sign[k]; }
+        for (size_t k = 0; k < p.fimg_recv_dst.size(); ++k)
+            if (in3) { in3[3 * (io + k)] = p.fimg_recv_dst[k]; in3[3 * (io + k) + 1] = p.fimg_recv_col[k]; in3[3 * (io + k) + 2] = p.fimg_recv_sign[k]; }
+        so += p.send_sign.size(); oo += p.fimg_src.size(); io += p.fimg_recv_dst.size();
+        ++q;
+    }
+    return 0;
+}
+
 // recv_sign of cice_evp_hip_halo_plan's recv list (-1: the ghost lies across the tripole fold), same order
 int cice_evp_hip_peer_signs(int32_t *recv_sign)
 {

@@ -56,7 +56,7 @@ TEST_EXPORTS = [
     "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
     "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
     "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan", "cice_evp_hip_stress_plan",
-    "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags",
+    "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags", "cice_evp_hip_fold_images_plan",
 ]
 # environment switches only the test build reads (cice_amd/csrc/evp_host.h: env_test): experiments, fault injection, routing
 # of on-device copies through the remote transports.  An EvpHip made while one of them is set uses the test build.
@@ -692,9 +692,16 @@ def halo_plan(dims: Dims) -> dict:
     nfin, tail = int(c2[0]), int(c2[1])
     fd, fa, fb, fc = [np.zeros(max(nfin, 1), dtype=np.int32) for _ in range(4)]
     lib.cice_evp_hip_seam_fin_plan(_ip(c2), _ip(fd), _ip(fa), _ip(fb), _ip(fc))
+    c4 = np.zeros((max(npeer, 1), 4), dtype=np.int32)
+    lib.cice_evp_hip_fold_images_plan(_ip(c4), None, None, None)
+    ssg = np.zeros(max(ns, 1), dtype=np.int32)
+    fo = np.zeros((max(int(c4[:, 2].sum()), 1), 3), dtype=np.int32)
+    fi = np.zeros((max(int(c4[:, 3].sum()), 1), 3), dtype=np.int32)
+    lib.cice_evp_hip_fold_images_plan(_ip(c4), _ip(ssg), _ip(fo), _ip(fi))
     fl = np.zeros(5, dtype=np.int32)
     lib.cice_evp_hip_plan_flags(_ip(fl), 5)
-    return dict(any_fold_exchange=bool(fl[0]), fold_rows=int(fl[1]), fin_dst=fd[:nfin], fin_a=fa[:nfin], fin_b=fb[:nfin], fin_coef=fc[:nfin], tail=tail, stress_remote=stress_remote, recv_sign=rsg[:nr],
+    return dict(peer_counts4=c4[:npeer], send_sign=ssg[:ns], fimg_out=fo[:int(c4[:npeer, 2].sum())], fimg_in=fi[:int(c4[:npeer, 3].sum())],
+                any_fold_exchange=bool(fl[0]), fold_rows=int(fl[1]), fin_dst=fd[:nfin], fin_a=fa[:nfin], fin_b=fb[:nfin], fin_coef=fc[:nfin], tail=tail, stress_remote=stress_remote, recv_sign=rsg[:nr],
                 stress_dst=std[:nst], stress_src=sts[:nst], send_dst=sd[:ns], recv_gid=rg[:nr],
                 center_dst=cd[:ncen], center_src=cs[:ncen], center_vsign=cv[:ncen], center_remote=center_remote,
                 local_dst=ld[:nl], local_src=ls[:nl], local_sign=lg[:nl], peer_rank=pr[:npeer],

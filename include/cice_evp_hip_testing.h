@@ -74,6 +74,11 @@ int cice_evp_hip_seam_plan(int32_t *counts3, int32_t *seam_a, int32_t *seam_b, i
  * rank's ghosts); recv_gid = global cell number (ig-1)+nx_global*(jg-1) each received ghost mirrors
  * (probe exchanges).  Lists may be NULL.                                                         */
 int cice_evp_hip_peer_plan(int32_t *send_dst, int32_t *recv_gid);
+/* What the on-chip kernel uses when the tripole fold row is split over ranks: per peer counts4 = {ghost entries at the head
+ * of the send list, of the recv list (raw seam values for the staging slots follow them), seam images out, in}; send_sign =
+ * the factor the receiver applies, send-list order; out3 = (seam cell here, ghost cell at the peer, sign) per image the owner
+ * feeds with its FINAL value; in3 = (ghost cell here, global column of the seam cell, sign).  Lists may be NULL.        */
+int cice_evp_hip_fold_images_plan(int32_t *counts4, int32_t *send_sign, int32_t *out3, int32_t *in3);
 /* Factor applied to each received value (+1, or -1 for a ghost cell across the tripole fold), recv-list order. */
 int cice_evp_hip_peer_signs(int32_t *recv_sign);
 /* Ghost-cell lists of cell-centre fields (T-grid inputs of cice_evp_hip_prep) whose source is on

@@ -548,3 +548,77 @@ def test_march_plan_refuses_a_rank_too_thin_next_to_a_closed_boundary():
         assert plan(40, 36, "closed", 0, rank)["ext"] is not None      # no redundant rim: nothing reaches past the boundary
         assert plan(40, 36, "cyclic", 4, rank)["nxr"] > 0               # cyclic: no closed boundary in x
         assert plan(48, 24, "closed", 4, rank)["nxr"] == 24 + 4         # 24 + 24: wide enough
+
+
+@pytest.mark.parametrize("shape", [(2, 1), (3, 1), (4, 1), (2, 2), (4, 2)])
+def test_fold_row_split_over_ranks_lists_of_the_on_chip_kernel(shape):
+    """Round 4: the on-chip kernel on a tripole grid whose fold row is split in x.  Host-only consistency of what every rank
+    derives from the global block table without talking to the others:
+      * a seam cell with its pair partner on another rank polls a staging slot -- the partner's rank must send exactly that
+        column's raw value to exactly that slot (the kernel stores raw records there);
+      * every ghost image of a seam cell of another rank is fed by that rank with the right sign, same order on both sides;
+      * the send list's signs are the receiver's (remote images across the fold carry their sign on the producer's side);
+      * the first n_ghost entries of corresponding send / recv lists are ghost cells, what follows are staging slots.
+    (3 x 1, 4 x 1, 4 x 2: ranks that hold neither a pole point nor a whole pair -- the layouts that ran without fold handling
+    before tripole_seam() looked at the general seam list.)"""
+    NX, NY = 48, 20
+    px, py = shape
+    dc = decomp.per_rank_blocks(NX, NY, px * py, "cyclic", "tripole", shape)
+    nr = px * py
+    plans, ncell = {}, {}
+    for r in range(nr):
+        d, keep = evp.make_dims(dc, r)
+        plans[r] = evp.halo_plan(d)
+        ncell[r] = int(np.prod(dc.shape(r)))
+    nxb, plane = dc.nx_block, dc.nx_block * dc.ny_block
+
+    def gcol(r, c):
+        b = dc.local_blocks(r)[c // plane]
+        return b.gi0 + ((c % plane) % nxb - 1), b.gj0 + ((c % plane) // nxb - 1)
+
+    def owner(ig, jg):
+        return next(b.owner for b in dc.blocks if b.gi0 <= ig < b.gi0 + b.gnx and b.gj0 <= jg < b.gj0 + b.gny)
+
+    def peer_slices(P, q):
+        so, ro = int(P["peer_nsend"][:q].sum()), int(P["peer_nrecv"][:q].sum())
+        return slice(so, so + int(P["peer_nsend"][q])), slice(ro, ro + int(P["peer_nrecv"][q]))
+
+    npairs = nimg = 0
+    for r in range(nr):
+        P, n = plans[r], ncell[r]
+        # (1) remote pair partners
+        for dst, a, b in zip(P["fin_dst"], P["fin_a"], P["fin_b"]):
+            if b < 0 or (dst != a and dst != b) or (a < n and b < n):
+                continue
+            slot = int(b if dst == a else a)
+            ig, jg = gcol(r, int(dst))
+            assert jg == NY and slot >= n
+            o = owner(NX - ig, NY)
+            Q = plans[o]
+            q = list(Q["peer_rank"]).index(r)
+            ss, _ = peer_slices(Q, q)
+            k = [k for k in range(ss.start, ss.stop) if Q["send_dst"][k] == slot]
+            assert len(k) == 1 and k[0] - ss.start >= Q["peer_counts4"][q][0], (shape, r, ig)
+            assert gcol(o, int(Q["send_src"][k[0]])) == (NX - ig, NY)
+            npairs += 1
+        # (2) seam images and (3), (4) list heads
+        oo = io = 0
+        for q, pr in enumerate(P["peer_rank"]):
+            ss, rs = peer_slices(P, q)
+            Q = plans[int(pr)]
+            qq = list(Q["peer_rank"]).index(r)
+            sq, rq = peer_slices(Q, qq)
+            ng_s, ng_r, n_out, n_in = [int(v) for v in P["peer_counts4"][q]]
+            assert ng_s == Q["peer_counts4"][qq][1] and ng_r == Q["peer_counts4"][qq][0]
+            assert (P["send_dst"][ss][:ng_s] < ncell[int(pr)]).all() and (P["send_dst"][ss][ng_s:] >= ncell[int(pr)]).all()
+            assert np.array_equal(P["send_sign"][ss], Q["recv_sign"][rq]) and np.array_equal(P["send_dst"][ss], Q["recv_dst"][rq])
+            oq = int(Q["peer_counts4"][:qq, 3].sum())
+            mine = P["fimg_out"][oo:oo + n_out]
+            theirs = Q["fimg_in"][oq:oq + int(Q["peer_counts4"][qq][3])]
+            assert len(mine) == len(theirs)
+            for (src, dstc, sg), (d2, col, sg2) in zip(mine, theirs):
+                assert dstc == d2 and sg == sg2 and gcol(r, int(src)) == (int(col), NY)
+                nimg += 1
+            oo += n_out
+            io += n_in
+    assert npairs > 0 and nimg > 0
