@@ -656,8 +656,9 @@ def main():
         """What a host that hands over the whole evp() body waits for per call (INTEGRATION.md Option A,
         dyn_evp_hip_evp_body): cice_evp_hip_prep (11 T-grid arrays + uvel, vvel in; dyn_prep1 / T->U averages / dyn_prep2 on
         the device; the 12 stresses resident) + the host's ice strength via _set_strength + ndte subcycles + download --
-        once as the shim does it (12 stresses + 6 outputs back: CICE's arrays current after every call), once with the
-        stresses left on the device (6 outputs back; restart / history through cice_evp_hip_fetch_stresses)."""
+        once as the shim does it by default (the 12 stresses in and out with everything else: CICE's arrays current after
+        every call), once as it does for a host that opted in to resident stresses (dyn_evp_hip_keep_stresses_resident: they
+        stay on the device, 6 outputs back; restart / history through the fetch hook)."""
         spec = synth.GRIDS[workload]
         nx, ny = spec["nx"], spec["ny"]
         g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
@@ -684,6 +685,8 @@ def main():
             ttab = (evp._f64p * 11)(*[evp._dp(t[k]) for k in evp.PREP_T])
             first = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(state[k]) if k in state and k != "iceUmask" else None) for k in evp.FIELDS])
             later = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(state[k]) if k in ("uvel", "vvel") else None) for k in evp.FIELDS])
+            later_sig = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(state[k]) if k in ("uvel", "vvel") or k in evp.FIELDS[:12] else None)
+                                                        for k in evp.FIELDS])
             tm = np.zeros(core.shape, np.int32)
             um = np.ascontiguousarray(state["iceUmask"], np.int32)
             o6 = (evp._f64p * len(evp.FIELDS))(*[(evp._dp(out[k]) if k in out else None) for k in evp.FIELDS])
@@ -702,9 +705,10 @@ def main():
                 return [1e3 * (y - x) for x, y in zip(parts[:-1], parts[1:])]
 
             call(first, o18)
-            for label, otab in (("shim_default_18_arrays_back", o18), ("stresses_left_on_device_6_arrays_back", o6)):
-                call(later, otab)
-                ts = np.array([call(later, otab) for _ in range(10)])
+            for label, itab, otab in (("shim_default_stresses_in_and_out", later_sig, o18),
+                                      ("shim_resident_stresses_6_arrays_back", later, o6)):
+                call(itab, otab)
+                ts = np.array([call(itab, otab) for _ in range(10)])
                 med = np.median(ts, axis=0)
                 tt = core.timings()
                 res[label] = dict(ms_per_call=float(np.median(ts.sum(axis=1))), prep_call=float(med[0]), set_strength=float(med[1]),

@@ -283,6 +283,7 @@ module ice_dyn_evp_hip
   ! -- or set CICE_EVP_HIP_STRESS_RESIDENT=1 -- and the stresses then stay on the device between calls.
   logical :: stress_resident = .false.
   logical :: stress_resident_requested = .false.
+  logical :: body_sig_on_device = .false.   ! Option A with resident stresses: the device copy is current (dyn_evp_hip_evp_body)
   logical :: on_tripole = .false.
   logical :: cgrid_geometry_set = .false.
   logical :: cgrid_pinned = .false.
@@ -454,7 +455,8 @@ contains
     end interface
 
     type(cice_evp_hip_prep_params) :: pp
-    type(c_ptr) :: tf(11), f32(32), out32(32)
+    type(c_ptr) :: tf(11), f32(32), out32(32), s12(12)
+    logical :: sig_travel
     integer(c_int32_t), pointer :: tmask_i(:), umask_i(:), itm(:), ium(:)
     integer :: nall, iblk, i, j, nT, nU
     integer(int_kind), allocatable :: ixT(:), jxT(:), ixU(:), jxU(:)
@@ -487,12 +489,17 @@ contains
     tf(8) = cice_evp_hip_addr(ss_tltx);   tf(9) = cice_evp_hip_addr(ss_tlty)
     tf(10) = cice_evp_hip_addr(strairxT); tf(11) = cice_evp_hip_addr(strairyT)
     f32 = c_null_ptr
-    f32(1) = cice_evp_hip_addr(stressp_1);  f32(2) = cice_evp_hip_addr(stressp_2)
-    f32(3) = cice_evp_hip_addr(stressp_3);  f32(4) = cice_evp_hip_addr(stressp_4)
-    f32(5) = cice_evp_hip_addr(stressm_1);  f32(6) = cice_evp_hip_addr(stressm_2)
-    f32(7) = cice_evp_hip_addr(stressm_3);  f32(8) = cice_evp_hip_addr(stressm_4)
-    f32(9) = cice_evp_hip_addr(stress12_1); f32(10) = cice_evp_hip_addr(stress12_2)
-    f32(11) = cice_evp_hip_addr(stress12_3); f32(12) = cice_evp_hip_addr(stress12_4)
+    ! the 12 stresses travel in and out at every call (CICE's arrays current after every evp()) -- unless the host opted in to
+    ! device-resident stresses (dyn_evp_hip_keep_stresses_resident) and the device copy is current: then they stay where
+    ! evp(), their only writer, left them (cice_evp_hip_prep with NULL stress entries), 24 array transfers less per call
+    sig_travel = .not. (stress_resident .and. body_sig_on_device)
+    s12(1) = cice_evp_hip_addr(stressp_1);  s12(2) = cice_evp_hip_addr(stressp_2)
+    s12(3) = cice_evp_hip_addr(stressp_3);  s12(4) = cice_evp_hip_addr(stressp_4)
+    s12(5) = cice_evp_hip_addr(stressm_1);  s12(6) = cice_evp_hip_addr(stressm_2)
+    s12(7) = cice_evp_hip_addr(stressm_3);  s12(8) = cice_evp_hip_addr(stressm_4)
+    s12(9) = cice_evp_hip_addr(stress12_1); s12(10) = cice_evp_hip_addr(stress12_2)
+    s12(11) = cice_evp_hip_addr(stress12_3); s12(12) = cice_evp_hip_addr(stress12_4)
+    if (sig_travel) f32(1:12) = s12
     ! TbU does not travel here: dyn_prep2 zeroes it and the seabed stress factor is computed from the
     ! NEW iceUmask afterwards (ice_dyn_evp.F90:770-826) -- below, once the preparation has returned
     f32(29) = cice_evp_hip_addr(uvel)
@@ -543,7 +550,8 @@ contains
        call check(cice_evp_hip_stress_halo(), subname, __FILE__, __LINE__)
 
     out32 = c_null_ptr
-    out32(1:12) = f32(1:12)
+    if (.not. stress_resident) out32(1:12) = s12
+    body_sig_on_device = stress_resident
     out32(24) = cice_evp_hip_addr(strintxU); out32(25) = cice_evp_hip_addr(strintyU)
     out32(27) = cice_evp_hip_addr(taubxU);   out32(28) = cice_evp_hip_addr(taubyU)
     out32(29) = f32(29);                     out32(30) = f32(30)
@@ -1038,6 +1046,7 @@ contains
 ! The host changed ice_flux's stress arrays itself (restart read): the next evp() uploads them again.
   subroutine dyn_evp_hip_invalidate_stresses
     character(len=*), parameter :: subname = '(dyn_evp_hip_invalidate_stresses)'
+    body_sig_on_device = .false.
     if (initialised) call check(cice_evp_hip_invalidate_stresses(), subname, __FILE__, __LINE__)
   end subroutine dyn_evp_hip_invalidate_stresses
 

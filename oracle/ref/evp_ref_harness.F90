@@ -659,7 +659,10 @@ program evp_ref_harness
               stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
               stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
               TbU = 777._dbl_kind       ! evp_body must not depend on what a previous evp() left here
+              ! (a host that opted in to resident stresses tells the core that it rewrote them, and fetches them afterwards)
+              if (hipresident) call dyn_evp_hip_invalidate_stresses
               call dyn_evp_hip_evp_body(dt_dyn, harness_strength)
+              if (hipresident) call dyn_evp_hip_fetch_stresses
               write(tag,'(a,i2.2,a,i4.4)') 'b', icall, 'n', nsub
               call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)
               call dump_r8_3d(trim(tag)//'_vvel', vvel, nblocks)
@@ -679,6 +682,39 @@ program evp_ref_harness
               call dump_r8_3d(trim(tag)//'_strintyU', strintyU, nblocks)
               call dump_r8_3d(trim(tag)//'_taubxU', taubxU, nblocks)
               call dump_r8_3d(trim(tag)//'_taubyU', taubyU, nblocks)
+              if (hipresident) then
+                 ! resident stresses, two evp() bodies in a row: the second one neither uploads nor downloads the 12 stresses
+                 ! (they are where the first one left them); against the reference's evp() called twice from the same state
+                 uvel = s_u; vvel = s_v
+                 stressp_1 = s_sp1; stressp_2 = s_sp2; stressp_3 = s_sp3; stressp_4 = s_sp4
+                 stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
+                 stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
+                 call dyn_evp_hip_invalidate_stresses
+                 call dyn_evp_hip_evp_body(dt_dyn, harness_strength)
+                 stressp_1 = -9.e9_dbl_kind; stress12_3 = -9.e9_dbl_kind    ! stale on purpose: nobody may read the host copies now
+                 call dyn_evp_hip_evp_body(dt_dyn, harness_strength)
+                 call dyn_evp_hip_fetch_stresses
+                 write(tag,'(a,i2.2,a,i4.4)') 'c', icall, 'n', nsub
+                 call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)
+                 call dump_r8_3d(trim(tag)//'_vvel', vvel, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stressp_1', stressp_1, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stressm_2', stressm_2, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stress12_3', stress12_3, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stress12_4', stress12_4, nblocks)
+                 uvel = s_u; vvel = s_v
+                 stressp_1 = s_sp1; stressp_2 = s_sp2; stressp_3 = s_sp3; stressp_4 = s_sp4
+                 stressm_1 = s_sm1; stressm_2 = s_sm2; stressm_3 = s_sm3; stressm_4 = s_sm4
+                 stress12_1 = s_s121; stress12_2 = s_s122; stress12_3 = s_s123; stress12_4 = s_s124
+                 call evp(dt_dyn)
+                 call evp(dt_dyn)
+                 write(tag,'(a,i2.2,a,i4.4)') 'p', icall, 'n', nsub
+                 call dump_r8_3d(trim(tag)//'_uvel', uvel, nblocks)
+                 call dump_r8_3d(trim(tag)//'_vvel', vvel, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stressp_1', stressp_1, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stressm_2', stressm_2, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stress12_3', stress12_3, nblocks)
+                 call dump_r8_3d(trim(tag)//'_stress12_4', stress12_4, nblocks)
+              endif
            endif
 #endif
            uvel = s_u; vvel = s_v

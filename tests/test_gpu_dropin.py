@@ -81,6 +81,15 @@ def run_bgrid_dropin(tmp_path, nx, ny, bx, by, ew, kw, resident, ndte=120):
                     f"Option A body, call {icall} nsub {nsub} {f}: {int((body != ref).sum())} cells differ, "
                     f"max|d|={np.abs(body - ref).max():.3e}")
                 checked += 1
+            if resident:
+                # Option A with resident stresses, two bodies in a row: the second call neither uploads nor downloads the 12
+                # stresses (the host copies were overwritten with garbage in between) -- against evp() called twice
+                for f in ("uvel", "vvel", "stressp_1", "stressm_2", "stress12_3", "stress12_4"):
+                    two = d[f"c{icall:02d}n{nsub:04d}_{f}"]
+                    ref = d[f"p{icall:02d}n{nsub:04d}_{f}"]
+                    assert np.array_equal(two, ref), (
+                        f"Option A, resident stresses, second body in a row, call {icall} nsub {nsub} {f}: "
+                        f"{int((two != ref).sum())} cells differ, max|d|={np.abs(two - ref).max():.3e}")
     assert np.abs(d[f"o02n{ndte:04d}_uvel"]).max() > (1e-3 if ndte >= 100 else 1e-5)
     assert checked == 2 * 2 * (2 * len(FIELDS) + len(DOWNSTREAM))
 

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="*", default=None)
     ap.add_argument("--first", type=int, default=1)
     ap.add_argument("--count", type=int, default=12)
+    ap.add_argument("--tripole-resident", action="store_true",
+                    help="every case: the on-chip kernel on a tripole grid, the fold row split over 1 to 4 ranks in x (round 4)")
     a = ap.parse_args()
     seeds = a.seeds if a.seeds else list(range(a.first, a.first + a.count))
     nbad = 0
@@ -36,8 +38,9 @@ def main():
         mode = ["resident", "streaming", "march", "cgrid", "prep", "cgrid_prep"][seed % 6]
         trip = mode in ("resident", "streaming", "prep") and seed % 4 == 0
         world, shape = [(2, "2x1"), (2, "1x2"), (4, "2x2")][int(rng.integers(0, 3))]
-        if trip and mode == "resident":
-            shape, world = "1x2", 2                  # (the resident kernel wants the seam pairs on one rank)
+        if a.tripole_resident:
+            mode, trip = ("resident" if seed % 3 else "prep"), True
+            world, shape = [(2, "2x1"), (3, "3x1"), (4, "4x1"), (4, "2x2"), (2, "1x2"), (6, "3x2")][int(rng.integers(0, 6))]
         px, py = [int(v) for v in shape.split("x")]
         nx = 2 * px * int(rng.integers(14, 50))      # even, and the same number of columns on every rank
         ny = py * int(rng.integers(16, 60))
