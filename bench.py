@@ -322,7 +322,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
-    def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True, proc_shape=None):
+    def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True, proc_shape=None, again_env=None):
         """One timed pass: `warmup` untimed + `steps` timed evp() subcycle loops of `workload`,
         block-decomposed over the ranks; barrier + sync on both sides, MAX over ranks."""
         saved = {k: os.environ.get(k) for k in (env or {})}
@@ -344,9 +344,42 @@ def main():
 
             scal = synth.evp_scalars(ndte)
             d, keep = evp.make_dims(dc, rank)
+            # (rehearsal on one GPU: the two-subcycle path's ring exchanges go through the test build's host transport --
+            # gloo underneath -- because RCCL refuses two ranks per device; a real run uses the product library and RCCL)
             core = evp.EvpHip(d, evp.make_params(scal, strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
-                              geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep)
+                              geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep, testing=(True if rehearsal else None))
             try:
+                def rehearsal_transport():
+                    def xchg(ranks, ns_, nr_, send, recv):
+                        ops, so, ro, keepalive = [], 0, 0, []
+                        for q, n_s, n_r in zip(ranks, ns_, nr_):
+                            if q == rank:
+                                recv[ro:ro + n_r] = send[so:so + n_s]
+                            else:
+                                if n_s:
+                                    ts = torch.from_numpy(np.ascontiguousarray(send[so:so + n_s]))
+                                    keepalive.append(ts)
+                                    ops.append(dist.P2POp(dist.isend, ts, q))
+                                if n_r:
+                                    tr = torch.empty(n_r, dtype=torch.float64)
+                                    keepalive.append((tr, ro, n_r))
+                                    ops.append(dist.P2POp(dist.irecv, tr, q))
+                            so += n_s
+                            ro += n_r
+                        if ops:
+                            for w in dist.batch_isend_irecv(ops):
+                                w.wait()
+                        for item in keepalive:
+                            if isinstance(item, tuple):
+                                tr, o, n = item
+                                recv[o:o + n] = tr.numpy()
+
+                    def reduce(op, v):
+                        t = torch.tensor([v], dtype=torch.int64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MIN if op == 0 else dist.ReduceOp.MAX)
+                        return int(t.item())
+                    core.set_test_transport(xchg, reduce)
+
                 def setup():
                     if ns == "tripole":      # CICE's own dxhy / dyhx: their north ghost row is a sign-flipped mirror image
                         core.set_metrics(**dict(zip(("dxhy", "dyhx"), fold_metrics)))
@@ -354,6 +387,7 @@ def main():
                         blobs = [None] * world
                         dist.all_gather_object(blobs, core.halo_export())
                         core.halo_import(blobs)
+                        rehearsal_transport()
                     elif world > 1:
                         uid = [core.comm_unique_id() if rank == 0 else None]
                         dist.broadcast_object_list(uid, src=0)
@@ -429,6 +463,29 @@ def main():
                     core.sync()
                 out = core.download()
                 fallbacks = core.timings()["resident_fallbacks"]
+                # the same ranks, state and communicator once more under switches the library reads at every call
+                # (again_env): one untimed + `steps` timed loops continuing from where the verified run ended
+                again = None
+                if again_env:
+                    saved2 = {k: os.environ.get(k) for k in again_env}
+                    os.environ.update(again_env)
+                    try:
+                        sync_point(lambda: core.subcycle(ndte))
+                        ta = time.perf_counter()
+                        tb = sync_point(lambda: [core.subcycle(ndte) for _ in range(steps)])
+                        dta = tb - ta
+                        if world > 1:
+                            tt2 = torch.tensor([dta], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+                            dta = float(tt2.item())
+                        o2 = core.download()
+                        again = dict(dt=dta, finite=bool(np.isfinite(o2["uvel"]).all()), env=dict(again_env))
+                    finally:
+                        for k, v in saved2.items():
+                            if v is None:
+                                os.environ.pop(k, None)
+                            else:
+                                os.environ[k] = v
                 if a.strict and verify and target is not None:
                     mine = {k: out[k] for k in VERIFY_FIELDS}
                     parts = [mine]
@@ -448,7 +505,7 @@ def main():
             finally:
                 core.finalize()
             return dict(nx=nx, ny=ny, ndte=ndte, dc=dc, tm=tm, n_active=n_active, dt=dt, tm_ev=tm_ev, kt=kt, per_rank=per_rank,
-                        steps=steps, warmup=warmup, ver=ver, fallbacks=fallbacks,
+                        steps=steps, warmup=warmup, ver=ver, fallbacks=fallbacks, again=again,
                         finite=bool(np.isfinite(out["uvel"]).all() and np.isfinite(out["stressp_1"]).all()),
                         umax=float(np.abs(out["uvel"]).max()))
         finally:
@@ -746,15 +803,13 @@ def main():
     M2o = None
     if want("s01") and a.workload != "s01":
         try:      # the 0.1-degree-class grid the strong-scaling target is stated on (streaming kernel, HBM-bound)
-            M2 = measure_with_fallbacks("s01", "full", 480, 2, 1)
+            # (N > 1: timed a second time on the same ranks and state with the ring exchange overlapped with the pass -- early
+            # launch of the cells the neighbours wait for, pack + RCCL send / recv on the second stream: a loss on one GPU, meant
+            # for real xGMI; both are reported)
+            M2 = measure_with_fallbacks("s01", "full", 480, 2, 1, again_env=({"CICE_EVP_HIP_MARCH_OVERLAP": "1"} if world > 1 else None))
+            M2o = M2.get("again")
         except Exception as e:  # noqa: BLE001
             extra_err["secondary"] = f"{type(e).__name__}: {e}"[:300]
-        if world > 1 and M2 is not None:
-            try:  # the same with the ring exchange overlapped with the pass (early launch of the cells the neighbours wait for,
-                  # pack + RCCL send / recv on the second stream): a loss on one GPU, meant for real xGMI -- both are reported
-                M2o = measure_with_fallbacks("s01", "full", 480, 2, 1, env={"CICE_EVP_HIP_MARCH_OVERLAP": "1"})
-            except Exception as e:  # noqa: BLE001
-                extra_err["secondary_overlapped"] = f"{type(e).__name__}: {e}"[:300]
     if want("streaming") and world == 1 and 1000 <= tm_ev["tile_variant"] < 3000:
         try:      # the same workload through the streaming kernel: its HBM fraction next to the resident kernel's
             MS = measure(a.workload, a.case, ndte, 5, 2, env={"CICE_EVP_HIP_RESIDENT": "0"})
@@ -969,8 +1024,9 @@ def main():
                 "attempts": M2.get("attempts"), "per_rank": M2.get("per_rank")}
             if M2o is not None:
                 res["secondary"]["ring_exchange_overlapped"] = {
-                    "value": c2 * 480 * 2 / M2o["dt"], "us_per_subcycle": 1e6 * M2o["dt"] / (2 * 480),
-                    "verified": M2o["ver"].get("verified"), "tile_variant": M2o["tm_ev"]["tile_variant"],
+                    "value": c2 * 480 * 2 / M2o["dt"], "us_per_subcycle": 1e6 * M2o["dt"] / (2 * 480), "finite": M2o["finite"],
+                    "verified": None, "why_unverified": "continues from the verified run's state (no checksum that far); bit-identity of the "
+                                                        "overlapped exchange is what tests/test_gpu_march.py and the multi-process tests pin",
                     "note": "CICE_EVP_HIP_MARCH_OVERLAP=1: cells other ranks wait for advanced first on the second stream, pack + "
                             "RCCL send / recv overlapped with the pass (off by default: a loss where the transfer is a device copy)"}
         for k_, v_ in extra_err.items():

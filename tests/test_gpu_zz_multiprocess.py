@@ -121,9 +121,9 @@ def test_bench_multi_rank_rehearsal():
     root = Path(__file__).resolve().parents[1]
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx1", "--extras", "configs2,tripole"]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx1", "--extras", "configs2,tripole,s01"]
     env = dict(os.environ, CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads(lines[0])
@@ -144,6 +144,11 @@ def test_bench_multi_rank_rehearsal():
     assert lib["verified"] is True and lib["finite"] and lib["us_per_subcycle"] > 0, lib
     assert lib["verification"]["key"] == "gx1/full/ndte240/closed/strict" and [q["rank"] for q in lib["per_rank"]] == [0, 1]
     assert "skipped" in c2["rccl_point_to_point_forced"]
+    # configs[4]: 3600 x 2400 on the two-subcycle kernel (ring over the test transport), verified; and once more on the same
+    # state with the exchange overlapped with the pass
+    sec = d["secondary"]
+    assert sec["verified"] is True and sec["finite"] and sec["tile_variant"] >= 3000, sec
+    assert sec["ring_exchange_overlapped"]["finite"] and sec["ring_exchange_overlapped"]["us_per_subcycle"] > 0
     # configs[3]: the tripole grid in its natural (most square) cut -- here 2 x 1, the fold row split in x --, the on-chip kernel
     # on both ranks, seam partners trading raw records across the rank boundary
     tp = d["tripole"]
