@@ -236,7 +236,8 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
     const int cur = S.cur;      // keep_sig: the stresses of the previous call live in sig[cur]
     for (int fi = F_STRENGTH; fi < F_COUNT; ++fi) {
         if (fi == F_UVEL || fi == F_VVEL) continue;
-        if ((fi == F_UVEL_INIT || fi == F_VVEL_INIT) && !f[fi]) continue;   // only read when revp = 1
+        if ((fi == F_UVEL_INIT || fi == F_VVEL_INIT) && (!f[fi] || S.prm.revp == 0.0)) continue;   // only read when revp = 1
+        if (fi == F_WATERX || fi == F_WATERY || fi == F_TBU) continue;   // below: only where the kernels will read them
         // lean call (cice_evp_hip_run on page-locked arrays): the loop writes these four on ice U-cells only and the
         // download writes back those cells only, so the caller's values elsewhere never need to travel
         if (S.lean_diag && (fi == F_STRINTX || fi == F_STRINTY || fi == F_TAUBX || fi == F_TAUBY)) continue;
@@ -263,9 +264,13 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
             if ((((uintptr_t)T.src[k]) | ((uintptr_t)T.dst[k])) & 15u) T.vec2 = 0;
         evp_launch_copy_many(T, S.stream);
     }
+    // While that batch travels the host scans the caller's arrays for what the kernels will not read in this call:
+    // waterx / watery where they equal uocn / vocn bit for bit on every ice U-cell, TbU where it is zero there (with
+    // uvel_init / vvel_init under classic EVP: five of the 32 arrays of the default configuration stay on the host).
     bool water_is_ocn = true, tbu_zero = true;
     {
         const double *wx = f[F_WATERX], *wy = f[F_WATERY], *uo = f[F_UOCN], *vo = f[F_VOCN], *tb = f[F_TBU];
+        if (!wx || !wy || !tb) return fail(-1, "null field");
         for (size_t k = 0; k < S.n; ++k) {
             const bool um = iceUmask[k] != 0;
             S.hmask[k] = (uint8_t)((iceTmask[k] != 0 ? 1 : 0) | (um ? 2 : 0));
@@ -275,6 +280,13 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
                 if (tb[k] != 0.0) tbu_zero = false;
             }
         }
+        CopyBatch B2;
+        if (!(water_is_ocn && (S.flags_allowed & EVP_F_WATER_IS_OCN))) {
+            B2.items.push_back({S.in[F_WATERX], wx});
+            B2.items.push_back({S.in[F_WATERY], wy});
+        }
+        if (!(tbu_zero && (S.flags_allowed & EVP_F_TBU_ZERO))) B2.items.push_back({S.in[F_TBU], tb});
+        if (!B2.items.empty() && h2d_batch(B2)) return -1;
     }
     if (S.lean_diag) {
         // bit 7: the cells the loop really writes strintx/y, taubx/y on -- iceUmask on INTERIOR cells.  A caller may
