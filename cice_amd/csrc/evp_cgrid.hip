@@ -103,7 +103,7 @@ template <class GT>
 __device__ __forceinline__ void strain_u(const EvpCgrid &A, const GT &G, size_t o, const StrainIn &v, double &sh, double &delta)
 {
     const size_t e = o + 1, n = o + A.nx;
-    const double *epm = G[CG_EPM], *npm = G[CG_NPM];
+    const auto epm = G[CG_EPM], npm = G[CG_NPM];
     const double dxU = G[CG_DXU][o], dyU = G[CG_DYU][o];
     const double ddyN = G[CG_DYN][e] - G[CG_DYN][o], ddxE = G[CG_DXE][n] - G[CG_DXE][o];
     const double rxN = G[CG_RXN][o], rxNr = G[CG_RXNR][o], ryE = G[CG_RYE][o], ryEr = G[CG_RYER][o];
@@ -130,7 +130,7 @@ __device__ __forceinline__ double shear_u(const EvpCgrid &A, const GT &G, size_t
                                           double uU, double vU)
 {
     const size_t e = o + 1, n = o + A.nx;
-    const double *epm = G[CG_EPM], *npm = G[CG_NPM];
+    const auto epm = G[CG_EPM], npm = G[CG_NPM];
     const double dxU = G[CG_DXU][o], dyU = G[CG_DYU][o];
     const double ddyN = G[CG_DYN][e] - G[CG_DYN][o], ddxE = G[CG_DXE][n] - G[CG_DXE][o];
     const double rxN = G[CG_RXN][o], rxNr = G[CG_RXNR][o], ryE = G[CG_RYE][o], ryEr = G[CG_RYER][o];
@@ -143,19 +143,22 @@ __device__ __forceinline__ double shear_u(const EvpCgrid &A, const GT &G, size_t
 }
 
 // grid_average_X2YA at cell p (ice_grid.F90:4388-4606): 'NW' (E -> N), 'SE' (N -> E), 'N' (E -> U), 'E' (N -> U)
-__device__ __forceinline__ double avg_nw(const double *a, const double *w, size_t p, int nx)
+template <class W>
+__device__ __forceinline__ double avg_nw(const double *a, const W &w, size_t p, int nx)
 {
     const double wtmp = (w[p - 1] + w[p] + w[p + nx - 1] + w[p + nx]);
     if (wtmp == 0.0) return 0.0;
     return (a[p - 1] * w[p - 1] + a[p] * w[p] + a[p + nx - 1] * w[p + nx - 1] + a[p + nx] * w[p + nx]) / wtmp;
 }
-__device__ __forceinline__ double avg_se(const double *a, const double *w, size_t p, int nx)
+template <class W>
+__device__ __forceinline__ double avg_se(const double *a, const W &w, size_t p, int nx)
 {
     const double wtmp = (w[p - nx] + w[p - nx + 1] + w[p] + w[p + 1]);
     if (wtmp == 0.0) return 0.0;
     return (a[p - nx] * w[p - nx] + a[p - nx + 1] * w[p - nx + 1] + a[p] * w[p] + a[p + 1] * w[p + 1]) / wtmp;
 }
-__device__ __forceinline__ double avg_2(const double *a, const double *w, size_t p, size_t q)
+template <class W>
+__device__ __forceinline__ double avg_2(const double *a, const W &w, size_t p, size_t q)
 {
     const double wtmp = (w[p] + w[q]);
     if (wtmp == 0.0) return 0.0;
@@ -761,13 +764,69 @@ struct Slab {
     size_t stride;
     __device__ __forceinline__ const double *operator[](int k) const { return base + (size_t)k * stride; }
 };
+// The same table with 15 of its 23 arrays DERIVED from the other eight instead of loaded (cg_one is HBM-bound on large
+// grids, and nearly half of its bytes per cell are static geometry): the reference computes them once at start-up as
+//   tarea = dxT*dyT, uarea = dxU*dyU, narea = dxN*dyN, earea = dxE*dyE          (ice_grid.F90:681-684)
+//   earear = 1/earea, narear = 1/narea where the area is > 0, else 0            (ice_grid.F90:706-715)
+//   ratiodxN = -dxN(i+1,j)/dxN(i,j), ratiodyE = -dyE(i,j+1)/dyE(i,j), ratiodxNr = 1/ratiodxN, ratiodyEr = 1/ratiodyE
+//                                                                               (ice_dyn_evp.F90:235-238)
+//   DminTarea = deltaminEVP*tarea                                               (ice_dyn_shared.F90: init_dyn_shared)
+//   hm, uvm, npm, epm: land masks, 0 or 1                                       (ice_grid.F90:979, 3382-3385)
+// cice_evp_hip_cgrid_set_geometry checks every one of these identities BIT FOR BIT on the caller's arrays (all cells the
+// kernel can read) and hands out this view only if all hold, so a derived value IS the array's value; the masks travel
+// as four bits of one byte.  k is a constant at every use: the switch folds.
+struct DSlab {
+    const double *base;
+    size_t stride;
+    const uint8_t *gm;              // bit 0 epm, 1 npm, 2 uvm, 3 hm
+    int nx;
+    double dmin;
+    struct Acc {
+        const DSlab &S;
+        int k;
+        __device__ __forceinline__ double raw(int a, size_t p) const { return S.base[(size_t)a * S.stride + p]; }
+        __device__ __forceinline__ double operator[](size_t p) const
+        {
+            switch (k) {
+            case CG_TAREA: return raw(CG_DXT, p) * raw(CG_DYT, p);
+            case CG_UAREA: return raw(CG_DXU, p) * raw(CG_DYU, p);
+            case CG_NAREA: return raw(CG_DXN, p) * raw(CG_DYN, p);
+            case CG_EAREA: return raw(CG_DXE, p) * raw(CG_DYE, p);
+            case CG_EAREAR: { const double a = raw(CG_DXE, p) * raw(CG_DYE, p); return a > 0.0 ? 1.0 / a : 0.0; }
+            case CG_NAREAR: { const double a = raw(CG_DXN, p) * raw(CG_DYN, p); return a > 0.0 ? 1.0 / a : 0.0; }
+            case CG_DMINT: return S.dmin * (raw(CG_DXT, p) * raw(CG_DYT, p));
+            case CG_RXN: return -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
+            case CG_RXNR: return 1.0 / -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
+            case CG_RYE: return -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
+            case CG_RYER: return 1.0 / -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
+            case CG_EPM: return (S.gm[p] & 1u) ? 1.0 : 0.0;
+            case CG_NPM: return (S.gm[p] & 2u) ? 1.0 : 0.0;
+            case CG_UVM: return (S.gm[p] & 4u) ? 1.0 : 0.0;
+            case CG_HM: return (S.gm[p] & 8u) ? 1.0 : 0.0;
+            default: return raw(k, p);
+            }
+        }
+    };
+    __device__ __forceinline__ Acc operator[](int k) const { return Acc{*this, k}; }
+};
+template <bool GEO> struct GeoView;
+template <> struct GeoView<false> {
+    static __device__ __forceinline__ Slab make(const EvpCgrid &, const EvpCgOne &T) { return Slab{T.gbase, T.stride}; }
+};
+template <> struct GeoView<true> {
+    static __device__ __forceinline__ DSlab make(const EvpCgrid &A, const EvpCgOne &T)
+    {
+        return DSlab{T.gbase, T.stride, T.gmask, A.nx, A.deltaminEVP};
+    }
+};
 struct TStress { double zetax2, etax2, sp, sm, shearT; };
 // stressC_T at cell o (ice_dyn_evp.F90:1758-1860) with the four corner values of shearU handed in; spo, smo: previous
-__device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const Slab &G, const Slab &IN, const double *uE, const double *vN, size_t o,
+template <class GT>
+__device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const GT &G, const Slab &IN, const double *uE, const double *vN, size_t o,
                                             double shO, double shS, double shSW, double shW, double spo, double smo)
 {
     const size_t w = o - 1, s = o - A.nx, sw = s - 1;
-    const double *dyE = G[CG_DYE], *dxN = G[CG_DXN], *uarea = G[CG_UAREA];
+    const auto dyE = G[CG_DYE], dxN = G[CG_DXN], uarea = G[CG_UAREA];
     const double dxT = G[CG_DXT][o], dyT = G[CG_DYT][o];
     const double divT = dyE[o] * uE[o] - dyE[w] * uE[w] + dxN[o] * vN[o] - dxN[s] * vN[s];
     const double tensionT = (dyT * dyT) * (uE[o] / dyE[o] - uE[w] / dyE[w]) - (dxT * dxT) * (vN[o] / dxN[o] - vN[s] / dxN[s]);
@@ -786,7 +845,11 @@ __device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const Slab &G, co
 
 // MODE 0: avg_zeta, not the last subcycle of a call (shearU alone at level S); 1: avg_zeta, last subcycle (deltaU is stored);
 // 2: avg_strength (deltaU feeds the corner viscosities in every subcycle)
-template <bool FAST, int ONE_X, int ONE_Y, int MODE>
+// GEO: the derived view of the static table (DSlab above)
+// (The same 64 x 16 window on a workgroup of 512 threads, two positions per thread one after the other inside each level, so
+// that TWO workgroups in different phases share a CU where the 1024-thread one is alone: 3600 x 2400 804 us against 798,
+// avg_strength 952 against 874 -- the workgroup's phases are not what the CU waits for.  Taken out again.)
+template <bool FAST, int ONE_X, int ONE_Y, int MODE, bool GEO>
 __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, int last)
 {
     constexpr bool AVGS = MODE == 2;
@@ -808,7 +871,8 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     const unsigned m = A.mask[L];
     const bool own = tx >= 2 && tx <= ONE_X - 2 && ty >= 2 && ty <= ONE_Y - 2 && i <= q.y && j <= q.w;
     const double *uE = T.uE_in, *vN = T.vN_in;
-    const Slab G{T.gbase, T.stride}, IN{T.inbase, T.stride};
+    const Slab IN{T.inbase, T.stride};
+    const auto G = GeoView<GEO>::make(A, T);
     const double relax = 1.0 - A.p.arlx1i * A.p.revp;
     const int nx = A.nx;
 
@@ -819,7 +883,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             sh = A.f[CF_SHEARU][L];
         } else {
             const size_t o = L, e = o + 1, n = o + nx;
-            const double *ea = G[CG_EAREA], *na = G[CG_NAREA], *npm = G[CG_NPM], *epm = G[CG_EPM];
+            const auto ea = G[CG_EAREA], na = G[CG_NAREA], npm = G[CG_NPM], epm = G[CG_EPM];
             const double uvm = G[CG_UVM][o];
             if (MODE != 0) {                             // deltaU is wanted: the whole of strain_rates_U
                 StrainIn v;
@@ -900,7 +964,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     if (!own) return;
     {
         const size_t o = L, e = o + 1, n = o + nx, s = o - nx, w = o - 1;
-        const double *hm = G[CG_HM], *ta = G[CG_TAREA];
+        const auto hm = G[CG_HM], ta = G[CG_TAREA];
         // T -> U average of etax2T (avg_t2u) at the corners o, s, w from the values in LDS
         auto eta_u = [&](size_t p, int px, int py) {
             const size_t pe = p + 1, pn = p + nx, pne = pn + 1;
@@ -934,7 +998,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         const EvpScalars &p = A.p;
         double unew, vnew, strintx, strinty, taubx, tauby;
         {
-            const double *dyT = G[CG_DYT], *dxU = G[CG_DXU];
+            const auto dyT = G[CG_DYT], dxU = G[CG_DXU];
             const double dyE = G[CG_DYE][o], dxE = G[CG_DXE][o];
             strintx = (FAST ? G[CG_EAREAR][o] : IN[CI_RHEOE][o] * G[CG_EAREAR][o]) *
                       (0.5 * dyE * (spe - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sme - (dyT[o] * dyT[o]) * smc) +
@@ -957,7 +1021,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             taubx = -unew * Cb;
         }
         {
-            const double *dxT = G[CG_DXT], *dyU = G[CG_DYU];
+            const auto dxT = G[CG_DXT], dyU = G[CG_DYU];
             const double dxN = G[CG_DXN][o], dyN = G[CG_DYN][o];
             strinty = (FAST ? G[CG_NAREAR][o] : IN[CI_RHEON][o] * G[CG_NAREAR][o]) *
                       (0.5 * dxN * (spn - spc) - (0.5 / dxN) * ((dxT[n] * dxT[n]) * smn - (dxT[o] * dxT[o]) * smc) +
@@ -1086,7 +1150,11 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 {
     const dim3 grid((unsigned)(8 * T.per_xcd)), block(T.ox, T.oy);
     const int mode = A.avg_strength ? 2 : (last ? 1 : 0);
-#define CG_ONE(F, X, Y, M) hipLaunchKernelGGL((cg_one<F, X, Y, M>), grid, block, 0, st, A, T, last)
+#define CG_ONE(F, X, Y, M)                                                                       \
+    do {                                                                                         \
+        if (T.gmask) hipLaunchKernelGGL((cg_one<F, X, Y, M, true>), grid, block, 0, st, A, T, last); \
+        else hipLaunchKernelGGL((cg_one<F, X, Y, M, false>), grid, block, 0, st, A, T, last);     \
+    } while (0)
 #define CG_ONE_M(F, X, Y)                 \
     do {                                  \
         if (mode == 0) CG_ONE(F, X, Y, 0); \

@@ -358,6 +358,8 @@ struct EvpCgOne {
     const double *uE_in, *vN_in, *sp_in, *sm_in;   // previous subcycle's buffers (A.f[...] = this subcycle's)
     const double *gbase, *inbase; // the static and the per-call tables as one allocation each: array k = base + k * stride
     size_t stride;                // (70 pointers as kernel arguments do not fit the scalar registers)
+    const uint8_t *gmask;         // non-null: 15 of the 23 static arrays are derived in the kernel (identities verified by the
+                                  // host, evp_host_cgrid.cpp: derive_geometry_check); the four land masks as bits of this byte
 };
 void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,

@@ -36,6 +36,8 @@ struct CGridState {
         int flip = 0;            // which allocation f[CF_UE], f[CF_VN], f[CF_SP], f[CF_SM] are (part of the graph key)
     } one;
     uint8_t *mask = nullptr;
+    uint8_t *gmask = nullptr;    // the four land masks as bits (cg_one's derived view of the static table); null: an identity failed
+    std::string geo_why;         // ... and which one
     int *img_slot = nullptr, *img_dst = nullptr;
     // tripole fold: per field location the cells of the fold row / the ghost row beyond it and their sources
     bool tripole = false;
@@ -90,7 +92,7 @@ void cgrid_free()
         for (auto &p : Q.t) F(p);
         F(Q.tmass); F(Q.maskd); F(Q.c_dst); F(Q.c_src); F(Q.c_vsign); F(Q.hwater); F(Q.tbt); F(Q.aicen); F(Q.vicen);
     }
-    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.fac[0]); F(CG.fac[1]); F(CG.d_flags); F(CG.mask); F(CG.mask4); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
+    F(CG.strengthU); F(CG.s12alt); F(CG.umaskd); F(CG.fac[0]); F(CG.fac[1]); F(CG.d_flags); F(CG.mask); F(CG.gmask); F(CG.mask4); F(CG.img_slot); F(CG.img_dst); F(CG.zero_cells); F(CG.fold_tmp);
     for (auto &f : CG.fold) { F(f.dst); F(f.a); F(f.b); F(f.flip); }
     for (auto &kv : CG.graphs) (void)hipGraphExecDestroy(kv.second);
     CG.graphs.clear();
@@ -219,6 +221,60 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 // gx3 12.5 -> 9.5, 300x240 17.6 -> 12.8, gx1 22.4 -> 17.6, 720x270 28.3 -> 21.9, 720x540 44.1 -> 39.3 (window shapes:
 // build_one_tables), 1440x1080 196.6 -> 178.0, 3600x2400 1013 -> 902; avg_strength against its five launches:
 // gx1 30.1 -> 18.6, 1440x1080 235 -> 191, 3600x2400 1257 -> 968.  CICE_EVP_HIP_CGRID_ONE=0 switches it off
+// cg_one with 15 of its 23 static arrays derived in the kernel from the other eight (evp_cgrid.hip: DSlab): allowed when
+// every identity holds bit for bit on the caller's arrays (derive_geometry_check, once per cice_evp_hip_cgrid_set_geometry).
+// CICE_EVP_HIP_CGRID_GEO=0 keeps all 23 arrays in use.
+static bool geo_derived()
+{
+    if (!CG.gmask) return false;
+    if (const char *e = env("CICE_EVP_HIP_CGRID_GEO")) return std::atoi(e) != 0;
+    return true;
+}
+// Checks, on every cell the kernels can read (the blocks' cells with their ghost ring; the ratios and nothing else need
+// a neighbour: interior cells), that the caller's derived arrays are what the reference's start-up computes from dx / dy
+// (the list: evp_cgrid.hip above DSlab).  Compared as BITS.  Returns the four masks as bits, or an empty vector + why.
+static std::vector<uint8_t> derive_geometry_check(const double *const *g, std::string &why)
+{
+    const int nxb = S.d.nx_block;
+    std::vector<uint8_t> gm(S.n, 0);
+    auto same = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0; };
+    auto bad = [&](const char *what, int b, int i, int j) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "%s differs from the reference's start-up formula at block %d cell (%d, %d)", what, b, i, j);
+        why = buf;
+        return std::vector<uint8_t>();
+    };
+    const double dmin = S.prm.deltaminEVP;
+    for (int b = 0; b < S.d.nblocks; ++b)
+        for (int j = S.jlo[b] - 1; j <= S.jhi[b] + 1; ++j)
+            for (int i = S.ilo[b] - 1; i <= S.ihi[b] + 1; ++i) {
+                const size_t p = (size_t)b * S.plane + (size_t)(j - 1) * nxb + (i - 1);
+                const double ta = g[CG_DXT][p] * g[CG_DYT][p], ua = g[CG_DXU][p] * g[CG_DYU][p];
+                const double na = g[CG_DXN][p] * g[CG_DYN][p], ea = g[CG_DXE][p] * g[CG_DYE][p];
+                if (!same(ta, g[CG_TAREA][p])) return bad("tarea", b, i, j);
+                if (!same(ua, g[CG_UAREA][p])) return bad("uarea", b, i, j);
+                if (!same(na, g[CG_NAREA][p])) return bad("narea", b, i, j);
+                if (!same(ea, g[CG_EAREA][p])) return bad("earea", b, i, j);
+                if (!same(ea > 0.0 ? 1.0 / ea : 0.0, g[CG_EAREAR][p])) return bad("earear", b, i, j);
+                if (!same(na > 0.0 ? 1.0 / na : 0.0, g[CG_NAREAR][p])) return bad("narear", b, i, j);
+                if (!same(dmin * ta, g[CG_DMINT][p])) return bad("DminTarea", b, i, j);
+                unsigned bits = 0;
+                const int mk[4] = {CG_EPM, CG_NPM, CG_UVM, CG_HM};
+                for (int q = 0; q < 4; ++q) {
+                    const double m = g[mk[q]][p];
+                    if (same(m, 1.0)) bits |= 1u << q;
+                    else if (!same(m, 0.0)) return bad("a land mask (neither 0 nor 1)", b, i, j);
+                }
+                gm[p] = (uint8_t)bits;
+                if (i >= S.ilo[b] && i <= S.ihi[b] && j >= S.jlo[b] && j <= S.jhi[b]) {
+                    const double rx = -(g[CG_DXN][p + 1] / g[CG_DXN][p]), ry = -(g[CG_DYE][p + nxb] / g[CG_DYE][p]);
+                    if (!same(rx, g[CG_RXN][p]) || !same(1.0 / rx, g[CG_RXNR][p])) return bad("ratiodxN / ratiodxNr", b, i, j);
+                    if (!same(ry, g[CG_RYE][p]) || !same(1.0 / ry, g[CG_RYER][p])) return bad("ratiodyE / ratiodyEr", b, i, j);
+                }
+            }
+    return gm;
+}
+
 static const int ONE_FIELDS[4] = {CF_UE, CF_VN, CF_SP, CF_SM};
 static bool one_launch()
 {
@@ -254,7 +310,8 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         A.f[CF_S12U] = cur;
         if (one && !(first && k == 0)) {
             EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy,
-                       (env_test("CICE_EVP_HIP_CGRID_ONE_XCD") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_ONE_XCD"))) ? 1 : 0, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n};
+                       (env_test("CICE_EVP_HIP_CGRID_ONE_XCD") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_ONE_XCD"))) ? 1 : 0, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n,
+                       geo_derived() ? CG.gmask : nullptr};
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
@@ -442,8 +499,16 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
     if (tripole && P.fold_rows == 1)             // (ranks without the fold rows run the same schedule with empty lists)
         if (int rc = build_fold_lists()) return rc;
-    if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3)
+    if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3) {
         if (int rc = build_one_tables()) return rc;
+        const std::vector<uint8_t> gm = derive_geometry_check(static23, CG.geo_why);
+        if (!gm.empty()) {
+            HIPC(hipMalloc((void **)&CG.gmask, S.n));
+            HIPC(hipMemcpy(CG.gmask, gm.data(), S.n, hipMemcpyHostToDevice));
+        } else if (env("CICE_EVP_HIP_VERBOSE")) {
+            std::fprintf(stderr, "[cice_evp_hip] C grid: all 23 static arrays stay in use: %s\n", CG.geo_why.c_str());
+        }
+    }
     CG.n_zero = (int)zero.size();
     if (CG.n_zero) {
         HIPC(hipMalloc((void **)&CG.zero_cells, zero.size() * sizeof(int)));
@@ -540,7 +605,7 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     };
     HIPC(hipEventRecord(S.ev0, S.stream));
     if (S.use_graph && (!remote() || S.direct.on)) {     // RCCL point-to-point is enqueued eagerly (as the B-grid loop does)
-        const std::pair<int, int> key(ndte, (fused && one_launch() ? 64 : 0) | (CG.one.flip << 5) | (CG.fast ? 16 : 0) | (CG.flip << 3) |
+        const std::pair<int, int> key(ndte, (geo_derived() ? 128 : 0) | (fused && one_launch() ? 64 : 0) | (CG.one.flip << 5) | (CG.fast ? 16 : 0) | (CG.flip << 3) |
                                                 (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
         auto it = CG.graphs.find(key);
         if (it == CG.graphs.end()) {
@@ -911,6 +976,7 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     out[1] = (double)CG.t_nsub;
     if (n >= 3) out[2] = CG.prep.t_ms;           // device time of the last cice_evp_hip_cgrid_prep (kernels, without the copies)
     if (n >= 4) out[3] = (double)CG.t_one;       // subcycles of the last call run as one launch each
+    if (n >= 5) out[4] = geo_derived() ? 1.0 : 0.0;   // ... with 15 of the 23 static arrays derived in the kernel
     return 0;
 }
 

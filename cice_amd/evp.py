@@ -466,9 +466,10 @@ class EvpHip:
         _check(self.lib, self.lib.cice_evp_hip_cgrid_sync(), "(dyn_evp_hip_cgrid_sync)")
 
     def cgrid_timings(self):
-        out = np.zeros(4)
-        _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(4)), "(dyn_evp_hip_cgrid_timings)")
-        return dict(loop_ms=float(out[0]), nsub=int(out[1]), prep_ms=float(out[2]), one_launch_subcycles=int(out[3]))
+        out = np.zeros(5)
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(5)), "(dyn_evp_hip_cgrid_timings)")
+        return dict(loop_ms=float(out[0]), nsub=int(out[1]), prep_ms=float(out[2]), one_launch_subcycles=int(out[3]),
+                    geometry_derived=bool(out[4]))
 
     def prep_fetch(self, name: str):
         out = np.zeros(self.shape)

@@ -236,7 +236,7 @@ def cgrid_geometry(g: dict, deltaminEVP: float = 1e-11) -> dict:
     return dict(dxT=dxT, dyT=dyT, dxU=g["dxU"], dyU=g["dyU"], dxE=dxE, dyE=dyE, dxN=dxN, dyN=dyN, uarea=g["uarea"],
                 tarea=g["tarea"], earea=earea, narea=narea, earear=1.0 / earea, narear=1.0 / narea, epm=epm, npm=npm,
                 uvm=g["uvm"], hm=hm, DminTarea=deltaminEVP * g["tarea"], ratiodxN=rxN, ratiodxNr=1.0 / rxN,
-                ratiodyE=ryE, ratiodyEr=1.0 / ryE)
+                ratiodyE=ryE, ratiodyEr=1.0 / ryE, _deltaminEVP=np.float64(deltaminEVP))
 
 
 def cgrid_state(g: dict, cg: dict, case: str = "full", dt: float = 3600.0, seed: int | None = None,
@@ -333,7 +333,20 @@ def cgrid_scatter(dc, rank: int, cg: dict, state: dict, inputs: dict, masks: dic
         loc = next((l for l, names in CGRID_LOC.items() if k in names), "center")
         return (loc, -1.0 if k in CGRID_VECTOR else 1.0)
     sc = lambda k, v, fill: dc.scatter(v, rank, fill=fill, fold=fold(k))
-    static = {k: sc(k, v, 1.0 if k in CGRID_FILL_ONE else 0.0) for k, v in cg.items()}
+    # (DminTarea = deltaminEVP * tarea on EVERY cell of the block arrays, ghost cells without a source -- tarea 1 -- included:
+    # ice_dyn_shared.F90:385)
+    dmin = float(cg.get("_deltaminEVP", 1e-11))
+    static = {k: sc(k, v, dmin if k == "DminTarea" else (1.0 if k in CGRID_FILL_ONE else 0.0)) for k, v in cg.items()
+              if not k.startswith("_")}
+    # the boundary-condition ratios as init_evp builds them (ice_dyn_evp.F90:232-239): on the interior cells of each block,
+    # from the BLOCK arrays (ghost cells as the halo left them) -- next to a closed boundary that is the fill value 1
+    for b, blk in enumerate(dc.local_blocks(rank)):
+        js, je, is_, ie = blk.jlo - 1, blk.jhi, blk.ilo - 1, blk.ihi
+        dxN, dyE = static["dxN"][b], static["dyE"][b]
+        rx = -dxN[js:je, is_ + 1:ie + 1] / dxN[js:je, is_:ie]
+        ry = -dyE[js + 1:je + 1, is_:ie] / dyE[js:je, is_:ie]
+        static["ratiodxN"][b][js:je, is_:ie], static["ratiodxNr"][b][js:je, is_:ie] = rx, 1.0 / rx
+        static["ratiodyE"][b][js:je, is_:ie], static["ratiodyEr"][b][js:je, is_:ie] = ry, 1.0 / ry
     return (static, {k: sc(k, v, 0.0) for k, v in state.items()}, {k: sc(k, v, 0.0) for k, v in inputs.items()},
             {k: sc(k, v, 0) for k, v in masks.items()})
 

@@ -300,7 +300,10 @@ int cice_evp_hip_cgrid_deformations(const double *tarear, double *divu, double *
  * strocnxE, strocnyE (ice_flux arrays, inout: written on the cells of dyn_prep2's N / E lists only).                       */
 int cice_evp_hip_cgrid_dyn_finish(double *strocnxN, double *strocnyN, double *strocnxE, double *strocnyE);
 /* out[0] = ms of the last cgrid_subcycle (HIP events), out[1] = its ndte, [2] (n >= 3) = device ms of the last cgrid_prep,
- * [3] (n >= 4) = how many of those subcycles ran as one launch each (the default schedule on one rank without a fold)  */
+ * [3] (n >= 4) = how many of those subcycles ran as one launch each (the default schedule on one rank without a fold),
+ * [4] (n >= 5) = 1 if that kernel derives 15 of the 23 static arrays from the eight dx / dy arrays (allowed when
+ * cice_evp_hip_cgrid_set_geometry found the reference's start-up identities to hold bit for bit; CICE_EVP_HIP_CGRID_GEO=0
+ * keeps all 23 in use)  */
 int cice_evp_hip_cgrid_timings(double *out, int32_t n);
 
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */

@@ -236,6 +236,7 @@ def test_cgrid_one_launch_schedule_agrees(name, one, monkeypatch):
         out = core.cgrid_run(nsub, state, inputs, masks, visc_method=visc)
         t = core.cgrid_timings()
         assert t["one_launch_subcycles"] == ((nsub - 1) if one == "1" else 0), t
+        assert t["geometry_derived"], "the reference's own start-up arrays satisfy the identities the derived view rests on"
         oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
         oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
         assert_bitwise(out, c.cgrid_expected(1, nsub), f"CICE_EVP_HIP_CGRID_ONE={one} nsub {nsub}")
@@ -251,6 +252,85 @@ def test_cgrid_one_launch_schedule_agrees(name, one, monkeypatch):
         assert_bitwise(out, c.cgrid_expected(1, nsub), f"CICE_EVP_HIP_CGRID_ONE={one} split calls")
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("name", ["cgrid_cyccyc_2x2_cap0_ktens", "cgrid_closed_2x2_revp", "cgrid_cyc_1blk_seabed",
+                                  "cgrid_cyc_3x2pad_cap05_avgstrength"])
+@pytest.mark.parametrize("shape", ["0", "2"])
+def test_cgrid_all_static_arrays_loaded_agrees(name, shape, monkeypatch):
+    """cg_one derives 15 of its 23 static arrays from the eight dx / dy arrays by default (the other tests); with
+    CICE_EVP_HIP_CGRID_GEO=0 it loads all 23, as before: the same bits, against the reference's arrays."""
+    c = GoldenCase(name)
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_GEO", "0")
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", shape)
+    core = cgrid_core(c)
+    try:
+        state, inputs, masks = c.cgrid_inputs(1)
+        dom = c.oracle_domain()
+        nsub = max(c.nsub_list)
+        visc = str(c.d["visc_method"])
+        out = core.cgrid_run(nsub, state, inputs, masks, visc_method=visc)
+        t = core.cgrid_timings()
+        assert t["one_launch_subcycles"] == nsub - 1 and not t["geometry_derived"], t
+        oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+        oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+        assert_bitwise(out, c.cgrid_expected(1, nsub), "CICE_EVP_HIP_CGRID_GEO=0")
+    finally:
+        core.finalize()
+
+
+@pytest.mark.parametrize("what", ["DminTarea", "earear", "tarea_ghost", "ratiodyEr", "uvm"])
+def test_cgrid_derived_geometry_is_refused_when_an_identity_fails(what, capfd, monkeypatch):
+    """One static array off the reference's start-up formula by one bit in one cell (an interior cell, a ghost cell; a
+    land mask that is neither 0 nor 1): the library keeps all 23 arrays in use, says why, and still equals the oracle
+    run on the same arrays."""
+    monkeypatch.setenv("CICE_EVP_HIP_VERBOSE", "1")
+    dc, g, static, state, inputs, masks = synth_cgrid("gx3", bs=(50, 58))
+    static = {k: v.copy() for k, v in static.items()}
+    if what == "tarea_ghost":
+        static["tarea"][1, 0, 7] = np.nextafter(static["tarea"][1, 0, 7], np.inf)
+    elif what == "uvm":
+        static["uvm"][2, 20, 20] = 0.5
+    else:
+        static[what][3, 30, 25] = np.nextafter(static[what][3, 30, 25], np.inf)
+    scal = __import__("cice_amd.synth", fromlist=["x"]).evp_scalars(120)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    want = oracle.cgrid_subcycle(dom, prm, 9, state, inputs, static, masks)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        got = core.cgrid_run(9, state, inputs, masks)
+        t = core.cgrid_timings()
+    finally:
+        core.finalize()
+    assert t["one_launch_subcycles"] == 8 and not t["geometry_derived"], t
+    err = capfd.readouterr().err
+    assert "all 23 static arrays stay in use" in err and "differs from the reference's start-up formula" in err, err
+    assert_bitwise(got, want, f"identity broken: {what}")
+
+
+def test_cgrid_derived_geometry_on_the_synthetic_workloads():
+    """The bench's synthetic block arrays follow the reference's start-up formulas (cice_amd/synth.py: cgrid_scatter), ghost
+    cells included, so the bench measures the derived view -- several blocks, closed and cyclic edges."""
+    for bs in (None, (50, 58)):
+        args = synth_cgrid("gx3", bs=bs)
+        dc, static = args[0], args[2]
+        d, keep = evp.make_dims(dc, 0)
+        scal = __import__("cice_amd.synth", fromlist=["x"]).evp_scalars(120)
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                          1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        try:
+            core.cgrid_set_geometry(static)
+            assert core.cgrid_timings()["geometry_derived"], bs
+        finally:
+            core.finalize()
 
 
 def random_cgrid_case(seed, nx, ny, bs, ew, ns, holes):

@@ -49,7 +49,8 @@ def main():
             best = min(ts[1:])
             ncell = dc.nx_global * dc.ny_global
             nact = int(masks["iceTmask"].sum())
-            print(f"CGRID {grid} {a.case} {a.visc}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
+            tt = core.cgrid_timings()
+            print(f"CGRID {grid} {a.case} {a.visc} one_launch={tt['one_launch_subcycles']} geometry_derived={tt['geometry_derived']}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
                   f"{ncell / (best * 1e-3 / a.ndte):.3e} cell-updates/s, active T {nact}/{ncell}", flush=True)
         finally:
             core.finalize()
