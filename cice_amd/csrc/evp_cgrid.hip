@@ -857,6 +857,11 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     __shared__ double s_eta[ONE_Y][ONE_X], s_sp[ONE_Y][ONE_X], s_sm[ONE_Y][ONE_X];
     __shared__ double s_dl[ONE_Y][ONE_X];            // deltaU (visc_method = avg_strength: the corner viscosities come from it)
     // workgroups go to the XCDs round-robin: XCD x gets the x-th contiguous run of the (space-ordered) window list
+    // (A launch of only as many workgroups as are resident at once, each looping over several windows with the LDS arrays
+    // doubled -- the 1024-thread workgroup of the 64 x 16 window is alone on its CU, and tools/cgrid_phases.py shows the CU
+    // idle for a fifth of the time between two of them -- was built and measured: the loop keeps the ~70 array pointers
+    // alive in scalar registers that spill into vector ones, 109 -> 140 registers, one wave per SIMD less; 3600 x 2400
+    // 786 -> 937 us, gx1 16.9 -> 25.9.  Taken out.)
     const int t = T.plain ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
     if (t >= T.ntiles) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -873,6 +878,19 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     const double *uE = T.uE_in, *vN = T.vN_in;
     const Slab IN{T.inbase, T.stride};
     const auto G = GeoView<GEO>::make(A, T);
+    // (test build) phase stamps of one wave with owned cells (thread (2, 2)): 0 start, 1 / 2 before / after the first barrier,
+    // 3 / 4 the second, 5 level C's arithmetic done, 6 end; 7: XCC and CU the window ran on
+    const bool stamp = T.prof && tx == 2 && ty == 2;
+    auto mark = [&](int k) {
+        if (stamp) T.prof[(size_t)t * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    mark(0);
+    if (stamp) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        T.prof[(size_t)t * 8 + 7] = ((unsigned long long)(xcc & 15u) << 32) | hw;
+    }
     const double relax = 1.0 - A.p.arlx1i * A.p.revp;
     const int nx = A.nx;
 
@@ -914,7 +932,9 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
         s_ve[ty][tx] = vEo;
         if (AVGS) s_dl[ty][tx] = delta;
     }
+    mark(1);
     __syncthreads();
+    mark(2);
 
     // ---- T ----
     if (tx >= 1 && ty >= 1) {
@@ -958,7 +978,9 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             }
         }
     }
+    mark(3);
     __syncthreads();
+    mark(4);
 
     // ---- C ----
     if (!own) return;
@@ -1047,6 +1069,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             A.f[CF_S12U][o] = s12c;
             if (m & 16u) push(A, o, m, CF_S12U, s12c);
         }
+        mark(5);
         if (last && !AVGS) A.f[CF_ETAU][o] = etaU;   // (avg_strength: the reference never stores etax2U)
         if (m & 4u) {
             A.f[CF_UE][o] = unew;
@@ -1064,6 +1087,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
             }
             if (m & 16u) push(A, o, m, CF_VN, vnew);
         }
+        mark(6);
     }
 }
 

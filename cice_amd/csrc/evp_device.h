@@ -358,6 +358,7 @@ struct EvpCgOne {
     const double *uE_in, *vN_in, *sp_in, *sm_in;   // previous subcycle's buffers (A.f[...] = this subcycle's)
     const double *gbase, *inbase; // the static and the per-call tables as one allocation each: array k = base + k * stride
     size_t stride;                // (70 pointers as kernel arguments do not fit the scalar registers)
+    unsigned long long *prof;     // test build, CICE_EVP_HIP_CGRID_PROF=1: 8 cycle stamps per window (tools/cgrid_phases.py)
     const uint8_t *gmask;         // non-null: 15 of the 23 static arrays are derived in the kernel (identities verified by the
                                   // host, evp_host_cgrid.cpp: derive_geometry_check); the four land masks as bits of this byte
 };

@@ -33,6 +33,7 @@ struct CGridState {
         int4 *tiles = nullptr;
         int ntiles = 0, per_xcd = 0, ox = 0, oy = 0;
         double *alt[4] = {};
+        unsigned long long *prof = nullptr;   // test build: phase stamps (CICE_EVP_HIP_CGRID_PROF=1)
         int flip = 0;            // which allocation f[CF_UE], f[CF_VN], f[CF_SP], f[CF_SM] are (part of the graph key)
     } one;
     uint8_t *mask = nullptr;
@@ -79,7 +80,7 @@ void cgrid_free()
         p = nullptr;
     };
     for (auto &p : CG.f) F(p);
-    F(CG.gslab); F(CG.inslab);
+    F(CG.gslab); F(CG.inslab); F(CG.one.prof);
     for (auto &p : CG.in) p = nullptr;
     for (auto &p : CG.g) p = nullptr;
     F(CG.tarear); for (auto &p : CG.post) F(p);
@@ -311,7 +312,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         if (one && !(first && k == 0)) {
             EvpCgOne T{CG.one.tab, CG.one.tiles, CG.one.ntiles, CG.one.per_xcd, CG.one.ox, CG.one.oy,
                        (env_test("CICE_EVP_HIP_CGRID_ONE_XCD") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_ONE_XCD"))) ? 1 : 0, c4[0], c4[1], c4[2], c4[3], CG.gslab, CG.inslab, S.n,
-                       geo_derived() ? CG.gmask : nullptr};
+                       CG.one.prof, geo_derived() ? CG.gmask : nullptr};
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
@@ -429,6 +430,10 @@ static int build_one_tables()
     HIPC(hipMemcpyAsync(O.tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice, S.stream));
     for (auto &p : O.alt)
         if (alloc_d(&p, S.n)) return -1;
+    if (env_test("CICE_EVP_HIP_CGRID_PROF") && std::atoi(env_test("CICE_EVP_HIP_CGRID_PROF"))) {
+        HIPC(hipMalloc((void **)&O.prof, (size_t)O.ntiles * 8 * sizeof(unsigned long long)));
+        HIPC(hipMemsetAsync(O.prof, 0, (size_t)O.ntiles * 8 * sizeof(unsigned long long), S.stream));
+    }
     HIPC(hipStreamSynchronize(S.stream));       // (the host vectors go out of scope)
     return 0;
 }
@@ -968,6 +973,19 @@ int cice_evp_hip_cgrid_fetch(int32_t table, int32_t index, double *dst)
     HIPC(hipStreamSynchronize(S.stream));
     return 0;
 }
+
+#ifdef CICE_EVP_HIP_TESTING
+// Phase stamps of the last cg_one launch (CICE_EVP_HIP_CGRID_PROF=1 at cice_evp_hip_cgrid_set_geometry): [windows][8] x u64.
+// Returns the number of windows, < 0 on error.
+int cice_evp_hip_debug_cgrid_prof(uint64_t *out, int32_t ntiles_max)
+{
+    if (!S.ready || !CG.one.prof) return fail(-1, "no profiled one-launch kernel (CICE_EVP_HIP_CGRID_PROF=1)");
+    if (!out || ntiles_max < CG.one.ntiles) return fail(-1, "bad argument: need room for %d windows", CG.one.ntiles);
+    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemcpy(out, CG.one.prof, (size_t)CG.one.ntiles * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return CG.one.ntiles;
+}
+#endif
 
 int cice_evp_hip_cgrid_timings(double *out, int32_t n)
 {

@@ -54,7 +54,7 @@ EXPORTS = [
 # the test transport
 TEST_EXPORTS = [
     "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
-    "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
+    "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_debug_cgrid_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
     "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan", "cice_evp_hip_stress_plan",
     "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags", "cice_evp_hip_fold_images_plan",
 ]
@@ -66,7 +66,7 @@ TEST_ENV = [
     "CICE_EVP_HIP_MARCH_LEAN", "CICE_EVP_HIP_CGRID_SPLIT", "CICE_EVP_HIP_CGRID_XCD", "CICE_EVP_HIP_CGRID_ONE_XCD", "CICE_EVP_HIP_CGRID_ONE_SHAPE",
     "CICE_EVP_HIP_CGRID_ONE_STRIP", "CICE_EVP_HIP_CGRID_FAST", "CICE_EVP_HIP_HALO_DEBUG", "CICE_EVP_HIP_SEAM_FIN", "CICE_EVP_HIP_OVERLAP",
     "CICE_EVP_HIP_HALO_RIDE", "CICE_EVP_HIP_GATHER", "CICE_EVP_HIP_SIMPLE", "CICE_EVP_HIP_SELF_EXCHANGE", "CICE_EVP_HIP_FLAGS", "CICE_EVP_HIP_LEAN",
-    "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY", "CICE_EVP_HIP_MARCH_BANDSEG",
+    "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY", "CICE_EVP_HIP_MARCH_BANDSEG", "CICE_EVP_HIP_CGRID_PROF",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -597,6 +597,14 @@ class EvpHip:
         a = np.zeros((ntiles_max, 4, 8), dtype=np.uint64)
         _check(self.lib, self.lib.cice_evp_hip_debug_prof(a.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(ntiles_max)), "(debug_prof)")
         return a
+
+    def debug_cgrid_prof(self, ntiles_max: int = 1 << 16):
+        self._need_testing("debug_cgrid_prof")
+        a = np.zeros((ntiles_max, 8), dtype=np.uint64)
+        n = self.lib.cice_evp_hip_debug_cgrid_prof(a.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(ntiles_max))
+        if n < 0:
+            _check(self.lib, n, "(debug_cgrid_prof)")
+        return a[:n]
 
     def time_kernels(self, nrep: int = 50) -> dict:
         t = np.zeros(3)

@@ -56,6 +56,10 @@ int cice_evp_hip_debug_cuload(int32_t *out, int32_t n);
  * per tile and chunk of 64 cells 8 x uint64 = shader cycles in {ring poll, stress, barrier wait, momentum
  * step + publish, barrier wait}, arrival rank of the workgroup on its CU, hardware wave, active chunks.    */
 int cice_evp_hip_debug_prof(uint64_t *out, int32_t ntiles_max);
+/* C grid, one-launch kernel: 8 stamps per window of the last launch (CICE_EVP_HIP_CGRID_PROF=1 when the geometry was set):
+ * shader-clock cycles at 0 start, 1 / 2 before / after the first workgroup barrier, 3 / 4 the second, 5 level C's arithmetic
+ * done, 6 end; 7 = XCC id << 32 | HW_ID.  Returns the number of windows.  tools/cgrid_phases.py */
+int cice_evp_hip_debug_cgrid_prof(uint64_t *out, int32_t ntiles_max);
 /* Host-only: build the plan for `dims` without touching a device (CPU tests). */
 int cice_evp_hip_plan_build(const cice_evp_hip_dims *dims);
 int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_src,
