@@ -861,7 +861,8 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     // doubled -- the 1024-thread workgroup of the 64 x 16 window is alone on its CU, and tools/cgrid_phases.py shows the CU
     // idle for a fifth of the time between two of them -- was built and measured: the loop keeps the ~70 array pointers
     // alive in scalar registers that spill into vector ones, 109 -> 140 registers, one wave per SIMD less; 3600 x 2400
-    // 786 -> 937 us, gx1 16.9 -> 25.9.  Taken out.)
+    // 786 -> 937 us, gx1 16.9 -> 25.9.  Taken out.  Forcing MORE waves per SIMD with a register cap -- 80 registers for the 512-thread
+    // shapes, 64 for this one -- spills 38 / 69 registers to scratch: 3600 x 2400 1432 / 1690 us.)
     const int t = T.plain ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
     if (t >= T.ntiles) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -983,6 +984,11 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     mark(4);
 
     // ---- C ----
+    // (The two bottom rows of positions are rim: their waves have nothing left to do here.  Letting them touch the lines of the
+    // window that comes to this CU next -- one dword per 128-byte line of its 16 rows of all 29 arrays, so that the next
+    // workgroup's first loads find them on their way -- was built and measured: level S did not get shorter (14.5k cycles
+    // against 13.8k), level C more than twice as long: 3600 x 2400 1134 us against 799.  The loads are not waiting for a cold
+    // miss, the memory system is busy; more requests make it worse.)
     if (!own) return;
     {
         const size_t o = L, e = o + 1, n = o + nx, s = o - nx, w = o - 1;
