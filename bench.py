@@ -467,9 +467,9 @@ def main():
                 # the same ranks, state and communicator once more under switches the library reads at every call
                 # (again_env): one untimed + `steps` timed loops continuing from where the verified run ended
                 again = None
-                if again_env:
-                    saved2 = {k: os.environ.get(k) for k in again_env}
-                    os.environ.update(again_env)
+                for env_k in ([again_env] if isinstance(again_env, dict) else (again_env or [])):
+                    saved2 = {k: os.environ.get(k) for k in env_k}
+                    os.environ.update(env_k)
                     try:
                         sync_point(lambda: core.subcycle(ndte))
                         ta = time.perf_counter()
@@ -480,7 +480,8 @@ def main():
                             dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
                             dta = float(tt2.item())
                         o2 = core.download()
-                        again = dict(dt=dta, finite=bool(np.isfinite(o2["uvel"]).all()), env=dict(again_env))
+                        again = (again or []) + [dict(dt=dta, finite=bool(np.isfinite(o2["uvel"]).all()), env=dict(env_k),
+                                                      ring=core.march_info().get("ring"))]
                     finally:
                         for k, v in saved2.items():
                             if v is None:
@@ -814,7 +815,9 @@ def main():
             # (N > 1: timed a second time on the same ranks and state with the ring exchange overlapped with the pass -- early
             # launch of the cells the neighbours wait for, pack + RCCL send / recv on the second stream: a loss on one GPU, meant
             # for real xGMI; both are reported)
-            M2 = measure_with_fallbacks("s01", "full", 480, 2, 1, again_env=({"CICE_EVP_HIP_MARCH_OVERLAP": "1"} if world > 1 else None))
+            # ... and a third time with the ring not through RCCL but as stores into the neighbours' HIP-IPC-mapped inboxes
+            M2 = measure_with_fallbacks("s01", "full", 480, 2, 1,
+                                        again_env=([{"CICE_EVP_HIP_MARCH_OVERLAP": "1"}, {"CICE_EVP_HIP_MARCH_DIRECT": "1"}] if world > 1 else None))
             M2o = M2.get("again")
         except Exception as e:  # noqa: BLE001
             extra_err["secondary"] = f"{type(e).__name__}: {e}"[:300]
@@ -1030,13 +1033,18 @@ def main():
                 "roofline_frac_rank0": streaming["s01"]["frac"],
                 "verified": M2["ver"].get("verified"), "finite": M2["finite"],
                 "attempts": M2.get("attempts"), "per_rank": M2.get("per_rank")}
-            if M2o is not None:
-                res["secondary"]["ring_exchange_overlapped"] = {
-                    "value": c2 * 480 * 2 / M2o["dt"], "us_per_subcycle": 1e6 * M2o["dt"] / (2 * 480), "finite": M2o["finite"],
-                    "verified": None, "why_unverified": "continues from the verified run's state (no checksum that far); bit-identity of the "
-                                                        "overlapped exchange is what tests/test_gpu_march.py and the multi-process tests pin",
-                    "note": "CICE_EVP_HIP_MARCH_OVERLAP=1: cells other ranks wait for advanced first on the second stream, pack + "
-                            "RCCL send / recv overlapped with the pass (off by default: a loss where the transfer is a device copy)"}
+            for Mo in (M2o or []):
+                direct = "CICE_EVP_HIP_MARCH_DIRECT" in Mo["env"]
+                res["secondary"]["ring_exchange_direct_ipc" if direct else "ring_exchange_overlapped"] = {
+                    "value": c2 * 480 * 2 / Mo["dt"], "us_per_subcycle": 1e6 * Mo["dt"] / (2 * 480), "finite": Mo["finite"],
+                    "ring": Mo.get("ring"),
+                    "verified": None, "why_unverified": "continues from the verified run's state (no checksum that far); bit-identity of this "
+                                                        "form of the exchange is what tests/test_gpu_march.py and the multi-process tests pin",
+                    "note": ("CICE_EVP_HIP_MARCH_DIRECT=1: no RCCL -- the pack kernel stores into the neighbours' HIP-IPC-mapped inboxes, "
+                             "flags instead of send / recv (off by default: no faster where the transfer is a device copy, never measured "
+                             "over xGMI); 'ring' says whether the trial exchange let it be used") if direct else
+                            ("CICE_EVP_HIP_MARCH_OVERLAP=1: cells other ranks wait for advanced first on the second stream, pack + "
+                             "RCCL send / recv overlapped with the pass (off by default: a loss where the transfer is a device copy)")}
         for k_, v_ in extra_err.items():
             res[k_] = {"error": v_}
         res.update(extra)

@@ -531,6 +531,7 @@ int cice_evp_hip_sync(void)
     if (!S.ready) return fail(-1, "not initialised");
     HIPC(hipStreamSynchronize(S.stream));
     if (int rc = direct_check_error()) return rc;
+    if (int rc = march_direct_error()) return rc;
     return resident_check_error();
 }
 
@@ -539,6 +540,7 @@ int cice_evp_hip_download(double *const *f)
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
     HIPC(hipStreamSynchronize(S.stream));
     if (int rc = direct_check_error()) return rc;
+    if (int rc = march_direct_error()) return rc;
     if (int rc = resident_check_error()) return rc;
     HIPC(hipEventRecord(S.ev2, S.stream));
     CopyBatch B;
@@ -901,9 +903,9 @@ int cice_evp_hip_seam_fin_plan(int32_t *counts2, int32_t *dst, int32_t *a, int32
 int cice_evp_hip_march_info(int32_t *out, int32_t n)
 {
     const State::March &M = S.march;
-    const int32_t v[7] = {M.mode, (int32_t)std::min<long>(M.passes, 0x7fffffffL), M.declined, M.nstrips, M.nseg, M.seglen,
-                          M.last_call ? 1 : 0};
-    for (int k = 0; out && k < n && k < 7; ++k) out[k] = v[k];
+    const int32_t v[8] = {M.mode, (int32_t)std::min<long>(M.passes, 0x7fffffffL), M.declined, M.nstrips, M.nseg, M.seglen,
+                          M.last_call ? 1 : 0, M.direct};
+    for (int k = 0; out && k < n && k < 8; ++k) out[k] = v[k];
     return 0;
 }
 

@@ -186,8 +186,38 @@ void evp_launch_march_check(const EvpMarchGeo &G, const EvpMarchTab &T, const ui
                             int nuv, int nfringe, unsigned *bad, hipStream_t st);
 void evp_launch_march_scatter(const EvpMarchGeo &G, const EvpMarchTab &T, const uint8_t *mask_blk, int nuv, int nsig,
                               hipStream_t st);
-void evp_launch_march_pack(const double *buf, int nf, const int *pos, int n, double *out, hipStream_t st);
-void evp_launch_march_unpack(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const double *in,
+// Wire format of the ring: the peers' blocks one after the other, inside a block field by field ([f][entry]: consecutive
+// lanes take consecutive entries of ONE field -- the ring cells of a row sit next to each other in a 64-lane block of the
+// packed layout, so a wave gathers runs of 48 bytes and more instead of 64 single doubles 512 bytes apart).
+#define EVP_MARCH_DIRECT_MAXPEER 16
+struct EvpRingCuts {
+    int n;                                           // peers
+    int start[EVP_MARCH_DIRECT_MAXPEER + 1];         // entries [start[q], start[q+1]) of the list belong to peer q
+};
+void evp_launch_march_pack(const double *buf, int nf, const int *pos, int n, const EvpRingCuts &C, double *out, hipStream_t st);
+// The same ring exchange WITHOUT a communication library (ranks on the GPUs of one node): the pack kernel stores every
+// entry straight into the receiving rank's inbox -- peer memory mapped through HIP IPC, plain stores over xGMI -- and the
+// last of its workgroups raises this rank's sequence number in every peer's flag slot; the unpack kernel waits (bounded)
+// for the peers' numbers and reads its own inbox.  Inboxes are double buffered by sequence parity (a rank cannot be two
+// exchanges ahead of a neighbour: it needs that neighbour's flag to finish one).  evp_host_march.cpp: march_direct_*.
+struct EvpMarchDirect {
+    int npeers;
+    double *dst[EVP_MARCH_DIRECT_MAXPEER];           // where they land in that peer's inbox (parity 0), as mapped here
+    size_t dst_pstride[EVP_MARCH_DIRECT_MAXPEER];    // doubles to parity 1 of that inbox
+    unsigned *peer_flag[EVP_MARCH_DIRECT_MAXPEER];   // my flag slot at that peer, as mapped here
+    unsigned *flags_in;           // own flag slots, one per peer, 16 unsigneds apart
+    unsigned *count;              // workgroups of the running pack kernel that have stored their share
+    int *err;                     // != 0: a wait gave up (1 + index of the peer)
+    const double *inbox;          // own inbox [2 parities][n_recv * nf]
+    size_t inbox_pstride;         // doubles
+    unsigned long long timeout_ticks;   // of the 100 MHz wall clock
+};
+void evp_launch_march_pack_direct(const double *buf, int nf, const int *pos, int n, const EvpRingCuts &C, const EvpMarchDirect &D, unsigned seq,
+                                  hipStream_t st);
+// verify != NULL: do not unpack, compare the inbox with verify[] (what the library transport delivered) and count differences in *bad
+void evp_launch_march_unpack_direct(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const EvpRingCuts &C,
+                                    const EvpMarchDirect &D, unsigned seq, const double *verify, unsigned *bad, hipStream_t st);
+void evp_launch_march_unpack(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const EvpRingCuts &C, const double *in,
                              hipStream_t st);
 void evp_launch_march_pack_mask(const uint8_t *mask, const int *idx, int n, double *out, hipStream_t st);
 void evp_launch_march_unpack_mask(uint8_t *mask, const int *idx, int n, const double *in, hipStream_t st);

@@ -259,6 +259,9 @@ struct State {
         int declined = 0;              // calls handed to the one-subcycle kernels (consistency check failed)
         bool last_call = false;        // the last cice_evp_hip_subcycle went through this path
         std::string why;
+        int direct = -1;               // the ring between ranks as stores into HIP-IPC-mapped inboxes: -1 not tried, 0 off, 1 on, 2 being verified
+        std::string direct_why;        // ... and why it is off
+        int direct_asked = -1;         // value of CICE_EVP_HIP_MARCH_DIRECT the decision was taken on (a change re-opens it)
     } march;
     unsigned upload_seq = 0;                       // bumped whenever the caller hands new state / inputs to the device
     int fault_calls = 0;                           // test hook counter (fault_hook, evp_api.cpp)
@@ -279,6 +282,7 @@ constexpr size_t DIRECT_SEQ_OFF = (size_t)EVP_DIRECT_MAXPEER * EVP_DIRECT_FLAG_S
 constexpr size_t DIRECT_ERR_OFF = DIRECT_SEQ_OFF + 64;
 constexpr size_t DIRECT_INBOX_OFF = DIRECT_ERR_OFF + 64;
 
+uint64_t host_identity();   // evp_host_mailbox.cpp
 // evp_host_common.cpp
 int alloc_d(double **p, size_t n);
 void free_all();
@@ -328,6 +332,7 @@ int tune_after_upload();
 bool march_wanted();
 int march_run(int ndte);
 void march_free();
+int march_direct_error();     // a ring neighbour never signalled (direct exchange of the two-subcycle path)
 // evp_host_mailbox.cpp
 int direct_check_error();
 // evp_host_cgrid.cpp

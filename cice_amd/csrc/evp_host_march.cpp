@@ -41,6 +41,12 @@ struct MarchBuf {
     int4 *band_items = nullptr;
     int nband = 0;
     hipEvent_t ev_in = nullptr, ev_main = nullptr, ev_done = nullptr;
+    // the same ring as stores into the peers' HIP-IPC-mapped inboxes (march_direct_setup)
+    void *dx_area = nullptr;     // fine-grained: flag lines | count | err | inbox [2][n_recv * NF]
+    std::vector<void *> dx_mapped;
+    EvpMarchDirect dx{};
+    unsigned dx_seq = 0;
+    EvpRingCuts cut_send{}, cut_recv{};      // where each neighbour's block begins in the send / receive list
 };
 MarchPlan PL;
 // slots of the constants block (evp_march.hip: C_*), of the optional block (O_*)
@@ -63,6 +69,11 @@ void march_free()
     F(B.send_pos); F(B.recv_pos1); F(B.recv_pos2); F(B.send_midx); F(B.recv_midx); F(B.sendbuf); F(B.recvbuf);
     F(B.band_items);
     B.nband = 0;
+    for (void *m : B.dx_mapped) (void)hipIpcCloseMemHandle(m);
+    B.dx_mapped.clear();
+    F(B.dx_area);
+    B.dx = EvpMarchDirect{};
+    B.dx_seq = 0;
     for (hipEvent_t *e : {&B.ev_in, &B.ev_main, &B.ev_done}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     PL = MarchPlan();
     S.march = State::March{};
@@ -82,6 +93,7 @@ static bool march_geometry(std::string &why)
     const int ext = env("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env("CICE_EVP_HIP_MARCH_EXT")) & ~1) : 4;
     if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
     M.exch_every = ext / 2 + 1;
+    if (PL.peers.size() > (size_t)EVP_MARCH_DIRECT_MAXPEER) { why = "more ring neighbours than the exchange lists hold"; return false; }
     if (!PL.peers.empty() && !S.have_comm && !S.test_xchg) { why = "cells of other ranks needed but no RCCL communicator (cice_evp_hip_comm_init)"; return false; }
     if (!(S.flags & EVP_F_METRICS) || (S.flags & EVP_F_DXHY_ARRAY)) { why = "metric terms come from arrays"; return false; }
     if (d.nblocks < 1) { why = "no blocks"; return false; }
@@ -190,6 +202,13 @@ static int march_alloc()
             return 0;
         };
         if (up(B.send_pos, sp) || up(B.recv_pos1, r1) || up(B.recv_pos2, r2) || up(B.send_midx, sm) || up(B.recv_midx, rm)) return -1;
+        B.cut_send.n = B.cut_recv.n = (int)PL.peers.size();
+        int cs = 0, cr = 0;
+        for (size_t q = 0; q < PL.peers.size(); ++q) {
+            B.cut_send.start[q] = cs; B.cut_recv.start[q] = cr;
+            cs += (int)PL.peers[q].send_pos.size(); cr += (int)PL.peers[q].recv_pos1.size();
+        }
+        B.cut_send.start[PL.peers.size()] = cs; B.cut_recv.start[PL.peers.size()] = cr;
         HIPC(hipMalloc((void **)&B.sendbuf, std::max<size_t>(PL.n_send, 1) * EVP_MARCH_S_NF * sizeof(double)));
         HIPC(hipMalloc((void **)&B.recvbuf, std::max<size_t>(PL.n_recv, 1) * EVP_MARCH_S_NF * sizeof(double)));
         // Work items of the EARLY launch of an exchange pass (march_run): per strip the rows that hold cells some other rank
@@ -254,7 +273,7 @@ static int hook_exchange(int nf, hipStream_t st)
 // pack + transfer of the ring of `buf` on stream `st` (what is left is the unpack)
 static int march_send_recv(double *buf, int nf, hipStream_t st)
 {
-    evp_launch_march_pack(buf, nf, B.send_pos, PL.n_send, B.sendbuf, st);
+    evp_launch_march_pack(buf, nf, B.send_pos, PL.n_send, B.cut_send, B.sendbuf, st);
     if (S.test_xchg) return hook_exchange(nf, st);
     size_t so = 0, ro = 0;
     NCCLC(ncclGroupStart());
@@ -268,11 +287,215 @@ static int march_send_recv(double *buf, int nf, hipStream_t st)
     return 0;
 }
 
+static int agree_max(unsigned &v);
+
+// ---- the ring without a communication library ------------------------------------------------------------------------
+// What a rank tells each of its ring neighbours: how to map its inbox and where that neighbour's entries land in it.
+struct MarchBlob {
+    uint32_t magic, nf;
+    int32_t from, to;
+    uint64_t host_id;
+    int64_t pid;
+    uint64_t base, inbox_off, inbox_pstride, flag_off;      // bytes
+    int64_t off_cells, count;                               // where the receiver of this blob writes, how many cells are expected
+    hipIpcMemHandle_t handle;
+};
+constexpr int MARCH_BLOB_DOUBLES = 32;
+static_assert(sizeof(MarchBlob) <= MARCH_BLOB_DOUBLES * sizeof(double), "MarchBlob must fit its slot");
+constexpr uint32_t MARCH_BLOB_MAGIC = 0x4d524348u;      // "MRCH"
+
+// Collective over the ranks of the ring (every rank with march neighbours runs it in the same call): inbox + flags in
+// fine-grained memory, one blob per neighbour through the transport that is there anyway (RCCL send / recv, or the test
+// hook), map, vote.  Any rank that cannot (another host, no IPC, switched off) makes everybody stay with the library.
+static int march_direct_setup()
+{
+    State::March &M = S.march;
+    M.direct = 0;
+    const int np = (int)PL.peers.size();
+    // Opt-in (CICE_EVP_HIP_MARCH_DIRECT=1), and only if every rank asks: on one GPU (the ring exchanged with the rank itself,
+    // 450 x 2400 and 900 x 1200 pieces) it is no faster than RCCL -- 54.7 against 52.6 and 52.7 against 52.1 us per subcycle: the
+    // pack kernel's uncached 8-byte stores take as long (13.4 us) as RCCL's pack + copy kernel (6.4 + 8.3) -- and what it does over
+    // xGMI has never been measured; bench.py --gpus N times the 3600 x 2400 block this way too.
+    {
+        const bool want = env("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env("CICE_EVP_HIP_MARCH_DIRECT")) &&
+                          !(env("CICE_EVP_HIP_HALO") && !std::strcmp(env("CICE_EVP_HIP_HALO"), "rccl"));
+        unsigned no = want ? 0u : 1u;
+        HIPC(hipMemcpyAsync(B.bad, &no, sizeof no, hipMemcpyHostToDevice, S.stream));
+        if (agree_max(no)) return -1;
+        if (no) {
+            M.direct_why = want ? "not asked for on every rank" : "not asked for (CICE_EVP_HIP_MARCH_DIRECT=1)";
+            return 0;
+        }
+    }
+    bool ok = np > 0 && np <= EVP_MARCH_DIRECT_MAXPEER;
+    if (!ok) M.direct_why = "more ring neighbours than the direct exchange holds";
+    const size_t flag_bytes = (size_t)EVP_MARCH_DIRECT_MAXPEER * 64, count_off = flag_bytes, err_off = flag_bytes + 64;
+    const size_t inbox_off = flag_bytes + 128;
+    const size_t par_doubles = ((size_t)std::max(PL.n_recv, 1) * EVP_MARCH_S_NF + 31) & ~(size_t)31;
+    std::vector<double> out((size_t)np * MARCH_BLOB_DOUBLES, 0.0), in((size_t)np * MARCH_BLOB_DOUBLES, 0.0);
+    if (ok) {
+        const size_t bytes = inbox_off + 2 * par_doubles * sizeof(double);
+        if (hipExtMallocWithFlags(&B.dx_area, bytes, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(B.dx_area, 0, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+            M.direct_why = "no fine-grained device memory for the inbox";
+        }
+    }
+    hipIpcMemHandle_t handle{};
+    if (ok && hipIpcGetMemHandle(&handle, B.dx_area) != hipSuccess) {
+        (void)hipGetLastError();
+        ok = false;
+        M.direct_why = "hipIpcGetMemHandle failed";
+    }
+    size_t ro = 0;
+    for (int q = 0; q < np; ++q) {
+        MarchBlob b{};
+        b.magic = ok ? MARCH_BLOB_MAGIC : 0u;
+        b.nf = EVP_MARCH_S_NF;
+        b.from = S.d.rank; b.to = PL.peers[q].rank;
+        b.host_id = host_identity();
+        b.pid = (int64_t)getpid();
+        b.base = (uint64_t)(uintptr_t)B.dx_area;
+        b.inbox_off = inbox_off; b.inbox_pstride = par_doubles * sizeof(double); b.flag_off = (size_t)q * 64;
+        b.off_cells = (int64_t)ro; b.count = (int64_t)PL.peers[q].recv_pos1.size();
+        b.handle = handle;
+        std::memcpy(&out[(size_t)q * MARCH_BLOB_DOUBLES], &b, sizeof b);
+        ro += PL.peers[q].recv_pos1.size();
+    }
+    // the blobs travel like a ring of 32 doubles per neighbour
+    if (S.test_xchg) {
+        std::vector<int32_t> ranks;
+        std::vector<int64_t> cnt((size_t)np, MARCH_BLOB_DOUBLES);
+        for (const MarchPeer &p : PL.peers) ranks.push_back(p.rank);
+        if (S.test_xchg(S.test_user, np, ranks.data(), cnt.data(), cnt.data(), out.data(), in.data()))
+            return fail(-2, "test transport: the exchange callback failed");
+    } else {
+        double *d_out = nullptr, *d_in = nullptr;
+        const size_t nb = (size_t)np * MARCH_BLOB_DOUBLES * sizeof(double);
+        HIPC(hipMalloc((void **)&d_out, nb));
+        HIPC(hipMalloc((void **)&d_in, nb));
+        HIPC(hipMemcpyAsync(d_out, out.data(), nb, hipMemcpyHostToDevice, S.stream));
+        NCCLC(ncclGroupStart());
+        for (int q = 0; q < np; ++q) {
+            NCCLC(ncclSend(d_out + (size_t)q * MARCH_BLOB_DOUBLES, MARCH_BLOB_DOUBLES, ncclDouble, PL.peers[q].rank, S.comm, S.stream));
+            NCCLC(ncclRecv(d_in + (size_t)q * MARCH_BLOB_DOUBLES, MARCH_BLOB_DOUBLES, ncclDouble, PL.peers[q].rank, S.comm, S.stream));
+        }
+        NCCLC(ncclGroupEnd());
+        HIPC(hipMemcpyAsync(in.data(), d_in, nb, hipMemcpyDeviceToHost, S.stream));
+        HIPC(hipStreamSynchronize(S.stream));
+        (void)hipFree(d_out); (void)hipFree(d_in);
+    }
+    EvpMarchDirect D{};
+    D.npeers = np;
+    for (int q = 0; q < np && ok; ++q) {
+        MarchBlob b;
+        std::memcpy(&b, &in[(size_t)q * MARCH_BLOB_DOUBLES], sizeof b);
+        const MarchPeer &p = PL.peers[q];
+        if (b.magic != MARCH_BLOB_MAGIC) { ok = false; M.direct_why = "rank " + std::to_string(p.rank) + " cannot take part"; break; }
+        if (b.from != p.rank || b.to != S.d.rank || b.nf != EVP_MARCH_S_NF || b.count != (int64_t)p.send_pos.size()) {
+            ok = false;
+            M.direct_why = "rank " + std::to_string(p.rank) + " expects another ring from this rank than the plan sends";
+            break;
+        }
+        if (b.host_id != host_identity()) { ok = false; M.direct_why = "rank " + std::to_string(p.rank) + " is on another host"; break; }
+        char *base = nullptr;
+        if (b.pid == (int64_t)getpid()) base = (char *)(uintptr_t)b.base;       // this very process (the ring exchanged with oneself)
+        else {
+            void *ptr = nullptr;
+            if (hipIpcOpenMemHandle(&ptr, b.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = false;
+                M.direct_why = "hipIpcOpenMemHandle failed for rank " + std::to_string(p.rank);
+                break;
+            }
+            B.dx_mapped.push_back(ptr);
+            base = (char *)ptr;
+        }
+        D.dst[q] = (double *)(base + b.inbox_off) + (size_t)b.off_cells * EVP_MARCH_S_NF;
+        D.dst_pstride[q] = (size_t)(b.inbox_pstride / sizeof(double));
+        D.peer_flag[q] = (unsigned *)(base + b.flag_off);
+    }
+    if (ok) {
+        char *mine = (char *)B.dx_area;
+        D.flags_in = (unsigned *)mine;
+        D.count = (unsigned *)(mine + count_off);
+        D.err = (int *)(mine + err_off);
+        D.inbox = (const double *)(mine + inbox_off);
+        D.inbox_pstride = par_doubles;
+        const double tmo_ms = env("CICE_EVP_HIP_HALO_TIMEOUT_MS") ? std::atof(env("CICE_EVP_HIP_HALO_TIMEOUT_MS")) : 30000.0;
+        D.timeout_ticks = (unsigned long long)(tmo_ms * 1.0e5);
+        B.dx = D;
+    }
+    // everybody or nobody
+    unsigned vote = ok ? 0u : 1u;
+    HIPC(hipMemcpyAsync(B.bad, &vote, sizeof vote, hipMemcpyHostToDevice, S.stream));
+    if (agree_max(vote)) return -1;
+    if (vote && ok) M.direct_why = "another rank cannot take part";
+    M.direct = vote ? 0 : 2;         // 2: the first exchange runs both ways and compares
+    if (env("CICE_EVP_HIP_VERBOSE"))
+        std::fprintf(stderr, "[cice_evp_hip] rank %d: ring of the two-subcycle path %s%s\n", (int)S.d.rank,
+                     M.direct ? "as stores into the neighbours' HIP-IPC-mapped inboxes" : "through RCCL send / recv: ",
+                     M.direct ? "" : M.direct_why.c_str());
+    return 0;
+}
+
+int march_direct_error()
+{
+    if (S.march.direct <= 0 || !B.dx.err) return 0;
+    int e = 0;
+    HIPC(hipMemcpy(&e, B.dx.err, sizeof e, hipMemcpyDeviceToHost));
+    if (e) return fail(-8, "two-subcycle path: ring neighbour rank %d never signalled within the time-out (CICE_EVP_HIP_HALO_TIMEOUT_MS)",
+                       (e - 1 < (int)PL.peers.size()) ? PL.peers[e - 1].rank : -1);
+    return 0;
+}
+
 static int march_exchange(double *buf, double *buf2, int nf)
 {
     if (PL.peers.empty()) return 0;
+    State::March &M = S.march;
+    if (nf == EVP_MARCH_S_NF) {
+        const int asked = (env("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env("CICE_EVP_HIP_MARCH_DIRECT"))) ? 1 : 0;
+        if (M.direct >= 0 && asked != M.direct_asked) {       // (bench.py times one state both ways: the switch changed between two calls)
+            HIPC(hipStreamSynchronize(S.stream));
+            for (void *m : B.dx_mapped) (void)hipIpcCloseMemHandle(m);
+            B.dx_mapped.clear();
+            F(B.dx_area);
+            B.dx = EvpMarchDirect{};
+            B.dx_seq = 0;
+            M.direct = -1;
+        }
+        M.direct_asked = asked;
+        if (M.direct < 0)
+            if (int rc = march_direct_setup()) return rc;
+    }
+    if (nf == EVP_MARCH_S_NF && M.direct == 1) {
+        const unsigned seq = ++B.dx_seq;
+        evp_launch_march_pack_direct(buf, nf, B.send_pos, PL.n_send, B.cut_send, B.dx, seq, S.stream);
+        evp_launch_march_unpack_direct(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.cut_recv, B.dx, seq, nullptr, nullptr, S.stream);
+        return 0;
+    }
     if (int rc = march_send_recv(buf, nf, S.stream)) return rc;
-    evp_launch_march_unpack(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.recvbuf, S.stream);
+    evp_launch_march_unpack(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.cut_recv, B.recvbuf, S.stream);
+    if (nf == EVP_MARCH_S_NF && M.direct == 2) {
+        // once: the same ring through the inboxes as well, compared bit for bit with what the library delivered
+        const unsigned seq = ++B.dx_seq;
+        HIPC(hipMemsetAsync(B.bad, 0, sizeof(unsigned), S.stream));
+        evp_launch_march_pack_direct(buf, nf, B.send_pos, PL.n_send, B.cut_send, B.dx, seq, S.stream);
+        evp_launch_march_unpack_direct(buf, buf2, nf, B.recv_pos1, B.recv_pos2, PL.n_recv, B.cut_recv, B.dx, seq, B.recvbuf, B.bad, S.stream);
+        unsigned bad = 0;
+        if (agree_max(bad)) return -1;
+        int e = 0;
+        HIPC(hipMemcpy(&e, B.dx.err, sizeof e, hipMemcpyDeviceToHost));
+        unsigned tmo = e ? 1u : 0u;
+        HIPC(hipMemcpyAsync(B.bad, &tmo, sizeof tmo, hipMemcpyHostToDevice, S.stream));
+        if (agree_max(tmo)) return -1;
+        if (e) HIPC(hipMemset(B.dx.err, 0, sizeof(int)));
+        M.direct = (bad || tmo) ? 0 : 1;
+        if (!M.direct) M.direct_why = tmo ? "a neighbour never signalled in the trial exchange" : "the trial exchange delivered other bits than the library";
+        if (env("CICE_EVP_HIP_VERBOSE"))
+            std::fprintf(stderr, "[cice_evp_hip] rank %d: trial of the direct ring exchange: %s\n", (int)S.d.rank,
+                         M.direct ? "identical to RCCL, in use from now on" : M.direct_why.c_str());
+    }
     return 0;
 }
 
@@ -514,7 +737,7 @@ int march_run(int ndte)
         if (exch && overlap) {
             HIPC(hipEventRecord(B.ev_main, S.stream));
             HIPC(hipStreamWaitEvent(S.stream_comm, B.ev_main, 0));
-            evp_launch_march_unpack(B.st[rc], nullptr, EVP_MARCH_S_NF, B.recv_pos1, B.recv_pos2, PL.n_recv, B.recvbuf, S.stream_comm);
+            evp_launch_march_unpack(B.st[rc], nullptr, EVP_MARCH_S_NF, B.recv_pos1, B.recv_pos2, PL.n_recv, B.cut_recv, B.recvbuf, S.stream_comm);
             HIPC(hipEventRecord(B.ev_done, S.stream_comm));
             HIPC(hipStreamWaitEvent(S.stream, B.ev_done, 0));
         } else if (exch) {

@@ -32,6 +32,7 @@
 // 368 B yardstick of SURVEY 8(d).
 // =====================================================================
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -498,31 +499,107 @@ __global__ __launch_bounds__(256) void march_scatter(EvpMarchGeo G, EvpMarchTab 
 }
 
 // ---- the two-cell ring between ranks (march_plan.h): list-driven pack / unpack around ncclSend / ncclRecv ----
-__global__ __launch_bounds__(256) void march_pack(const double *__restrict__ buf, int nf, const int *__restrict__ pos, int n,
+// element t of the wire -> (peer q, field f, list entry e); t - C.start[q] * nf is the element's place in the peer's block
+struct RingElem { int q, f, e, local; };
+__device__ __forceinline__ RingElem ring_elem(const EvpRingCuts &C, int nf, int t)
+{
+    int q = 0;
+    while (q + 1 < C.n && t >= C.start[q + 1] * nf) ++q;
+    RingElem r;
+    r.q = q;
+    r.local = t - C.start[q] * nf;
+    const int nq = C.start[q + 1] - C.start[q];
+    r.f = r.local / nq;
+    r.e = C.start[q] + (r.local - r.f * nq);
+    return r;
+}
+__global__ __launch_bounds__(256) void march_pack(const double *__restrict__ buf, int nf, const int *__restrict__ pos, int n, EvpRingCuts C,
                                                   double *__restrict__ out)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n * nf) return;
-    const int e = t / nf, f = t - e * nf, p = pos[e];
-    out[t] = buf[((size_t)(p >> 6) * nf + f) * 64 + (p & 63)];
+    const RingElem r = ring_elem(C, nf, t);
+    const int p = pos[r.e];
+    out[t] = buf[((size_t)(p >> 6) * nf + r.f) * 64 + (p & 63)];
+}
+__device__ __forceinline__ void ring_store(double *__restrict__ buf, double *__restrict__ buf2, int nf, const int *__restrict__ pos1,
+                                           const int *__restrict__ pos2, const RingElem &r, double v)
+{
+    const int p = pos1[r.e], q = pos2[r.e];
+    const size_t e1 = ((size_t)(p >> 6) * nf + r.f) * 64 + (p & 63);
+    buf[e1] = v;
+    if (buf2) buf2[e1] = v;
+    if (q >= 0) {                                    // the column's duplicate in the neighbouring strip's block
+        const size_t e2 = ((size_t)(q >> 6) * nf + r.f) * 64 + (q & 63);
+        buf[e2] = v;
+        if (buf2) buf2[e2] = v;
+    }
 }
 __global__ __launch_bounds__(256) void march_unpack(double *__restrict__ buf, double *__restrict__ buf2, int nf,
-                                                    const int *__restrict__ pos1, const int *__restrict__ pos2, int n,
+                                                    const int *__restrict__ pos1, const int *__restrict__ pos2, int n, EvpRingCuts C,
                                                     const double *__restrict__ in)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n * nf) return;
-    const int e = t / nf, f = t - e * nf;
-    const double v = in[t];
-    const int p = pos1[e], q = pos2[e];
-    const size_t e1 = ((size_t)(p >> 6) * nf + f) * 64 + (p & 63);
-    buf[e1] = v;
-    if (buf2) buf2[e1] = v;
-    if (q >= 0) {                                    // the column's duplicate in the neighbouring strip's block
-        const size_t e2 = ((size_t)(q >> 6) * nf + f) * 64 + (q & 63);
-        buf[e2] = v;
-        if (buf2) buf2[e2] = v;
+    ring_store(buf, buf2, nf, pos1, pos2, ring_elem(C, nf, t), in[t]);
+}
+// ---- ... and without a library: stores into the peers' inboxes (evp_device.h: EvpMarchDirect) ----
+__global__ __launch_bounds__(256) void march_pack_direct(const double *__restrict__ buf, int nf, const int *__restrict__ pos, int n,
+                                                         EvpRingCuts C, EvpMarchDirect D, unsigned seq)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n * nf) {
+        const RingElem r = ring_elem(C, nf, t);
+        const int p = pos[r.e];
+        const double v = buf[((size_t)(p >> 6) * nf + r.f) * 64 + (p & 63)];
+        double *dst = D.dst[r.q] + (size_t)(seq & 1u) * D.dst_pstride[r.q] + r.local;
+        __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // The stores are write-through at system scope: once the memory system has acknowledged them (vmcnt 0) they are where a
+    // peer's loads look, whatever this GPU's caches hold -- no release FENCE here: at system scope that writes the whole L2
+    // back, once per workgroup (measured: 120 us per exchange instead of 10).  The counter lives in the same uncached
+    // memory; the workgroup that brings it to the launch's size knows every other one's stores have been acknowledged.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(D.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(D.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int q = 0; q < D.npeers; ++q) __hip_atomic_store(D.peer_flag[q], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void march_unpack_direct(double *__restrict__ buf, double *__restrict__ buf2, int nf,
+                                                           const int *__restrict__ pos1, const int *__restrict__ pos2, int n, EvpRingCuts C,
+                                                           EvpMarchDirect D, unsigned seq, const double *__restrict__ verify,
+                                                           unsigned *__restrict__ bad)
+{
+    if ((int)threadIdx.x < D.npeers && __hip_atomic_load(D.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        const unsigned *f = D.flags_in + (size_t)threadIdx.x * 16;
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(have - seq) >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0 &&
+                (wall_clock64() - t0 > D.timeout_ticks || __hip_atomic_load(D.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                atomicCAS(D.err, 0, 1 + (int)threadIdx.x);       // which peer never arrived
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    // (no acquire fence either -- it would invalidate the L2 once per workgroup: the inbox is read past the caches, after the flag)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * nf) return;
+    const double v = __hip_atomic_load(D.inbox + (size_t)(seq & 1u) * D.inbox_pstride + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (verify) {
+        if (__double_as_longlong(v) != __double_as_longlong(verify[t])) atomicAdd(bad, 1u);
+        return;
+    }
+    ring_store(buf, buf2, nf, pos1, pos2, ring_elem(C, nf, t), v);
 }
 __global__ __launch_bounds__(256) void march_pack_mask(const uint8_t *__restrict__ mask, const int *__restrict__ idx, int n,
                                                        double *__restrict__ out)
@@ -587,14 +664,26 @@ void evp_launch_march_scatter(const EvpMarchGeo &G, const EvpMarchTab &T, const 
                        dim3(256), 0, st, G, T, mask_blk, nuv, nsig);
 }
 
-void evp_launch_march_pack(const double *buf, int nf, const int *pos, int n, double *out, hipStream_t st)
+void evp_launch_march_pack(const double *buf, int nf, const int *pos, int n, const EvpRingCuts &C, double *out, hipStream_t st)
 {
-    if (n > 0) hipLaunchKernelGGL(march_pack, dim3((unsigned)(((size_t)n * nf + 255) / 256)), dim3(256), 0, st, buf, nf, pos, n, out);
+    if (n > 0) hipLaunchKernelGGL(march_pack, dim3((unsigned)(((size_t)n * nf + 255) / 256)), dim3(256), 0, st, buf, nf, pos, n, C, out);
 }
-void evp_launch_march_unpack(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const double *in,
+void evp_launch_march_unpack(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const EvpRingCuts &C, const double *in,
                              hipStream_t st)
 {
-    if (n > 0) hipLaunchKernelGGL(march_unpack, dim3((unsigned)(((size_t)n * nf + 255) / 256)), dim3(256), 0, st, buf, buf2, nf, pos1, pos2, n, in);
+    if (n > 0) hipLaunchKernelGGL(march_unpack, dim3((unsigned)(((size_t)n * nf + 255) / 256)), dim3(256), 0, st, buf, buf2, nf, pos1, pos2, n, C, in);
+}
+void evp_launch_march_pack_direct(const double *buf, int nf, const int *pos, int n, const EvpRingCuts &C, const EvpMarchDirect &D, unsigned seq,
+                                  hipStream_t st)
+{
+    const unsigned nwg = (unsigned)std::max<size_t>(1, ((size_t)n * nf + 255) / 256);      // (at least one: the flags must rise)
+    hipLaunchKernelGGL(march_pack_direct, dim3(nwg), dim3(256), 0, st, buf, nf, pos, n, C, D, seq);
+}
+void evp_launch_march_unpack_direct(double *buf, double *buf2, int nf, const int *pos1, const int *pos2, int n, const EvpRingCuts &C,
+                                    const EvpMarchDirect &D, unsigned seq, const double *verify, unsigned *bad, hipStream_t st)
+{
+    const unsigned nwg = (unsigned)std::max<size_t>(1, ((size_t)n * nf + 255) / 256);
+    hipLaunchKernelGGL(march_unpack_direct, dim3(nwg), dim3(256), 0, st, buf, buf2, nf, pos1, pos2, n, C, D, seq, verify, bad);
 }
 void evp_launch_march_pack_mask(const uint8_t *mask, const int *idx, int n, double *out, hipStream_t st)
 {

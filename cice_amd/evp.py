@@ -552,10 +552,12 @@ class EvpHip:
 
     def march_info(self) -> dict:
         """The two-subcycles-per-pass path (evp_march.hip): did it run, how is the domain cut."""
-        v = np.zeros(7, dtype=np.int32)
-        self.lib.cice_evp_hip_march_info(_ip(v), 7)
+        v = np.zeros(8, dtype=np.int32)
+        v[7] = -1
+        self.lib.cice_evp_hip_march_info(_ip(v), 8)
         return dict(mode=int(v[0]), passes=int(v[1]), declined=int(v[2]), strips=int(v[3]), segments=int(v[4]),
-                    seglen=int(v[5]), last_call=bool(v[6]))
+                    seglen=int(v[5]), last_call=bool(v[6]),
+                    ring={-1: "not set up", 0: "rccl", 1: "direct stores (HIP IPC)", 2: "direct, on trial"}.get(int(v[7]), "?"))
 
     def halo_mask(self, halomask):
         """ice_HaloMask for the in-loop velocity exchange; halomask None = full halo."""

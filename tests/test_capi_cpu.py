@@ -59,7 +59,7 @@ def test_product_library_ignores_the_test_builds_switches():
     kept = set(re.findall(r'(?<![_a-z])env\("(CICE_EVP_HIP_\w+)"\)', src))
     assert not kept & set(evp.TEST_ENV)
     assert kept <= {"CICE_EVP_HIP_" + k for k in ("DEVICE", "VERBOSE", "HALO", "HALO_TIMEOUT_MS", "RESIDENT", "MARCH", "MARCH_EXT",
-                                                  "NOGRAPH", "GRAPH_RCCL", "NO_OVERLAP", "CGRID_ONE", "CGRID_FUSED", "CGRID_GEO", "RES_LOGW", "MARCH_OVERLAP",
+                                                  "NOGRAPH", "GRAPH_RCCL", "NO_OVERLAP", "CGRID_ONE", "CGRID_FUSED", "CGRID_GEO", "RES_LOGW", "MARCH_OVERLAP", "MARCH_DIRECT",
                                                   "RES_GEN", "TYB")}, kept
 
 

@@ -122,7 +122,7 @@ def test_march_random_masks_vs_oracle(seed, grid, bs, holes, march):
     assert_bitwise(got, want, f"march, random masks seed {seed}")
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
+@pytest.mark.parametrize("overlap", [0, 1, "direct"])
 @pytest.mark.parametrize("grid,case,bs,seg,own,ext", [("gx3", "full", None, 0, 0, 2), ("gx3", "caps", (25, 29), 9, 17, 0),
                                                        ("gx3", "caps", (50, 58), 9, 23, 4), ("gx1", "full", None, 40, 0, 2)])
 def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg, own, ext, overlap, march):
@@ -133,9 +133,12 @@ def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg
     neighbour -- here of itself -- on either side, so that the ring is exchanged after every (ext/2 + 1)-th pass only.
     overlap = 1 (CICE_EVP_HIP_MARCH_OVERLAP): the cells the neighbour waits for are advanced first by an early launch on
     the second stream, pack + send / recv run there while the pass itself runs on the compute stream (round 4).
+    "direct" (CICE_EVP_HIP_MARCH_DIRECT=1): no library -- the pack kernel stores into the neighbour's inbox (here: its own),
+    flags instead of send / recv; the first exchange runs both ways and must agree bit for bit before it is used.
     Against the oracle, bit for bit; the list logic for 2 and 4 ranks is
     tests/test_multirank_cpu.py::test_march_two_cell_ring_between_ranks_known_answer."""
-    march.setenv("CICE_EVP_HIP_MARCH_OVERLAP", str(overlap))
+    march.setenv("CICE_EVP_HIP_MARCH_OVERLAP", "0" if overlap == "direct" else str(overlap))
+    march.setenv("CICE_EVP_HIP_MARCH_DIRECT", "1" if overlap == "direct" else "0")
     march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
     march.setenv("CICE_EVP_HIP_MARCH_EXT", str(ext))
     if seg:
@@ -152,6 +155,9 @@ def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg
         got = core.run(fields, tm, um, ndte=14)
         info = core.march_info()
         assert info["mode"] == 1 and info["last_call"] and info["passes"] == 7, info
+        assert info["ring"] == ("direct stores (HIP IPC)" if overlap == "direct" else "rccl"), info
+        if overlap == "direct":          # a second call: every exchange through the inboxes now
+            got = core.run(fields, tm, um, ndte=14)
     finally:
         core.finalize()
     want = run_oracle(dc, geo, fields, tm, um, scal, 14)
@@ -319,6 +325,7 @@ def test_march_random_geometry_vs_oracle(seed, march):
         march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
         march.setenv("CICE_EVP_HIP_MARCH_EXT", str(ext))
         march.setenv("CICE_EVP_HIP_MARCH_OVERLAP", str((seed // 2) % 2))       # every other of them: exchange overlapped with the pass
+        march.setenv("CICE_EVP_HIP_MARCH_DIRECT", str((seed // 4) % 2))        # ... and without RCCL (where not overlapped)
         march.setenv("CICE_EVP_HIP_MARCH_BANDSEG", str(int(rng.integers(2, 12))))
     g = synth.derive_geometry(synth.make_grid(nx, ny, 3.0e4, ns="closed"))
     st = synth.make_state(g, case="full", seed=seed, warm=True)

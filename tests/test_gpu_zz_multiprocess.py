@@ -149,6 +149,8 @@ def test_bench_multi_rank_rehearsal():
     sec = d["secondary"]
     assert sec["verified"] is True and sec["finite"] and sec["tile_variant"] >= 3000, sec
     assert sec["ring_exchange_overlapped"]["finite"] and sec["ring_exchange_overlapped"]["us_per_subcycle"] > 0
+    dx = sec["ring_exchange_direct_ipc"]
+    assert dx["finite"] and dx["us_per_subcycle"] > 0 and dx["ring"] == "direct stores (HIP IPC)", dx
     # configs[3]: the tripole grid in its natural (most square) cut -- here 2 x 1, the fold row split in x --, the on-chip kernel
     # on both ranks, seam partners trading raw records across the rank boundary
     tp = d["tripole"]
@@ -222,7 +224,10 @@ def test_two_subcycle_kernel_across_processes_on_one_gpu(world, workload, shape,
                CICE_EVP_HIP_MARCH_SEG="24", CICE_EVP_HIP_MARCH_EXT=ext,
                # every other layout with the exchange overlapped (early launch of the cells the neighbours wait for: N-S and
                # E-W cuts, corners, several blocks per rank)
-               CICE_EVP_HIP_MARCH_OVERLAP=str(int(ext) // 2 % 2 if shape != "2x2" else 1))
+               CICE_EVP_HIP_MARCH_OVERLAP=str(int(ext) // 2 % 2 if shape != "2x2" else 1),
+               # ... and the layouts that are not overlapped without a library: the pack kernel stores into the other PROCESS's inbox
+               # (HIP IPC), flags instead of send / recv, after a trial exchange that must agree with the transport's bits
+               CICE_EVP_HIP_MARCH_DIRECT=str(1 - (int(ext) // 2 % 2 if shape != "2x2" else 1)))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     if not (r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout):
         try:

@@ -293,6 +293,9 @@ def main():
         mi = got["_march"]
         if not (mi["mode"] == 1 and mi["last_call"] and mi["declined"] == 0 and mi["passes"] > 0):
             bad.append(("two-subcycle kernel did not run", mi))
+        want_ring = "direct stores (HIP IPC)" if os.environ.get("CICE_EVP_HIP_MARCH_DIRECT") == "1" and os.environ.get("CICE_EVP_HIP_MARCH_OVERLAP", "0") != "1" else None
+        if want_ring and mi["ring"] != want_ring:
+            bad.append(("ring of the two-subcycle path not exchanged through the inboxes", mi))
     for k in ("uvel", "vvel", "stressp_1", "stressm_3", "stress12_4", "strintxU", "taubyU",
               "forcexU", "umassdti", "uvel_init", "aiU", "iceTmask"):
         if k not in got:
