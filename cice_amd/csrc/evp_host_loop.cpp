@@ -156,7 +156,7 @@ int halo_uv(int b, bool masked)
 bool use_overlap()
 {
     const bool seam = (S.n_seam + S.n_pole + S.n_late) > 0;
-    if (!S.overlap || S.plan.peers.empty() || seam || !(S.have_comm || S.direct.on)) return false;
+    if (!S.overlap || S.plan.peers.empty() || seam || S.plan.tfold || !(S.have_comm || S.direct.on)) return false;
     if (env_test("CICE_EVP_HIP_OVERLAP")) return std::atoi(env_test("CICE_EVP_HIP_OVERLAP")) != 0;
     size_t cells = 0;
     for (int b = 0; b < S.d.nblocks; ++b)
@@ -167,7 +167,7 @@ bool use_overlap()
 // The mailbox exchange can ride in the subcycle launch (no tripole seam step in between).
 bool use_riding_exchange()
 {
-    if (!S.direct.on || S.plan.peers.empty() || (S.n_seam + S.n_pole + S.n_late) > 0) return false;
+    if (!S.direct.on || S.plan.peers.empty() || (S.n_seam + S.n_pole + S.n_late) > 0 || S.plan.tfold) return false;
     // Pays when the interior tiles outlast the exchange (measured per subcycle, riding vs separate
     // kernel: 4 x 1800x1200 blocks 571 vs 627 us, 720x540 27.9 vs 34.1, 720x270 19.4 vs 22.1); on a
     // domain that is one wave of workgroups there is nothing to overlap with and the separate kernel

@@ -469,7 +469,7 @@ int cice_evp_hip_halo_mask(const int32_t *halomask)
     // only depend on what every rank computes alike: the plan's global flag (some rank exchanges across the tripole
     // fold or through seam staging slots: the reference never masks those messages, ice_boundary.F90:979,1022, and
     // here the whole in-loop exchange then stays unmasked on ALL ranks), never this rank's own lists.
-    if (!halomask || S.plan.any_fold_exchange) { M.on = false; return 0; }
+    if (!halomask || S.plan.any_fold_exchange || S.plan.tfold) { M.on = false; return 0; }   // (tripoleT: interior cells of the top row are destinations too)
     if (S.plan.peers.empty()) { M.on = false; return 0; }           // no messages at all: nothing to agree on
     std::vector<int32_t> ss, rd, rslot;
     std::vector<int8_t> rs;

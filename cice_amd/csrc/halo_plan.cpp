@@ -87,11 +87,8 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
         plan.error = "tripole needs an even nx_global and a cyclic east-west boundary";
         return false;
     }
-    if (tfold && d.nranks > 1) {
-        plan.error = "tripoleT: one rank only (the images of the top row are interior cells: no exchange may ride in the "
-                     "launch that computes them)";
-        return false;
-    }
+    // (tripoleT on several ranks: the images of the top row are INTERIOR cells -- receive lists may name them; the exchange
+    // then has to follow the launch that computes them, never ride in it: evp_host_loop.cpp use_riding_exchange / use_overlap)
     const int ng = d.nghost;
     const int nx = d.nx_block, ny = d.ny_block;
     const size_t plane = (size_t)nx * ny;

@@ -417,7 +417,7 @@ contains
     case ('open');    bnd_code = 1
     case ('cyclic');  bnd_code = 2
     case ('tripole'); bnd_code = 3
-    case ('tripoleT'); bnd_code = 4          ! T-fold: the loop only (Option B), one rank
+    case ('tripoleT'); bnd_code = 4          ! T-fold: the loop only (Option B); any rank layout since round 4
     case default
        bnd_code = -1
        call abort_ice('(dyn_evp_hip_init) ERROR: unsupported boundary type '//trim(bnd), &

@@ -371,12 +371,3 @@ def test_tracked_pmc_summary_feeds_the_bench_line():
         assert k[key]["kernel_trace"]["avg_us"] > 0
     for key in ("cgx1", "cgs01"):
         assert k[key]["per_subcycle"]["hbm_bytes"]
-
-
-def test_tripoleT_is_one_rank_only():
-    """The T-fold's images of the top row are interior cells; on several ranks the plan refuses (no exchange may ride
-    in the launch that computes them) instead of racing."""
-    dc = decomp.Decomp(24, 20, 12, 10, "cyclic", "tripoleT", 2, (2, 1))
-    d, keep = evp.make_dims(dc, 0)
-    with pytest.raises(evp.EvpHipError, match="tripoleT"):
-        evp.halo_plan(d)

@@ -84,6 +84,37 @@ def test_golden_tripoleT_strict_bitwise(name):
         core.finalize()
 
 
+@pytest.mark.parametrize("transport", ["rccl", "direct", "direct-riding"])
+@pytest.mark.parametrize("name", TFOLD_CASES)
+def test_tripoleT_through_the_remote_transports(name, transport, monkeypatch):
+    """tripoleT with neighbours on other ranks (late round 4), rehearsed on one GPU: CICE_EVP_HIP_SELF_EXCHANGE routes every
+    list copy of the halo update -- those into the INTERIOR cells of the top row included -- through the exchange with the
+    rank itself: pack -> ncclSend / ncclRecv -> unpack, or the mailbox kernel.  The exchange must follow the launch that
+    computes the top row, so the request to let it ride in that launch (HALO_RIDE=1) is ignored here.  Same bits as the
+    reference's evp(); the layouts of several ranks: tests/test_multirank_cpu.py::test_tripoleT_split_over_ranks_known_answer,
+    processes on one GPU: tests/test_gpu_zz_multiprocess.py."""
+    monkeypatch.setenv("CICE_EVP_HIP_SELF_EXCHANGE", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_HALO", transport.split("-")[0])
+    monkeypatch.setenv("CICE_EVP_HIP_HALO_RIDE", "1" if transport.endswith("riding") else "0")
+    c = GoldenCase(name)
+    core = hip_from_case(c, strict=True)
+    keep = tfold_untouched(c)
+    try:
+        core.comm_init(core.comm_unique_id())
+        dyn, tm, um = c.inputs(1)
+        for nsub in c.nsub_list:
+            out = core.run(dyn, tm, um, ndte=nsub)
+            want = c.expected(1, nsub)
+            for k in want:
+                sel = keep if k.startswith("stress") else np.ones_like(keep)
+                assert np.array_equal(out[k][sel], want[k][sel]), f"{name} nsub {nsub} {k} (tripoleT through {transport})"
+        t = core.timings()
+        assert t["halo_transport"] == ("rccl" if transport == "rccl" else "mailbox") and t["tile_variant"] < 1000, t
+        assert t["launches_per_subcycle"] == (3.0 if transport == "rccl" else 2.0), t       # never 1: the exchange does not ride
+    finally:
+        core.finalize()
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_golden_fused_within_tolerance(name):
     """Fused multiply-add build vs the reference: velocities and stresses agree to

@@ -38,7 +38,14 @@ def _free_port():
                                                            # fold and the stress symmetrisation through shifted copies
                                                            (2, "tx1", "2x1", "prep_stream"), (4, "tx1", "2x2", "prep_stream"),
                                                            # ... and the same preparation followed by the on-chip kernel
-                                                           (2, "tx1", "2x1", "prep")])
+                                                           (2, "tx1", "2x1", "prep"),
+                                                           # ns_boundary_type = 'tripoleT' over several ranks (late round 4): the top
+                                                           # physical row is an image of row NY-1 -- receive lists name interior
+                                                           # cells, the exchange follows the launch (streaming kernel): the fold
+                                                           # row cut in x, in y only, both, odd sizes
+                                                           (2, "360x240:tripoleT", "2x1", False), (2, "360x240:tripoleT", "1x2", False),
+                                                           (4, "360x240:tripoleT", "2x2", False), (3, "126x60:tripoleT", "3x1", False),
+                                                           (4, "100x116:tripoleT", "4x1", False)])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share

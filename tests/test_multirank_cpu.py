@@ -114,6 +114,93 @@ def test_tripole_seam_split_across_ranks_known_answer(case):
     assert sum(r[2] for r in res) > 0 and sum(r[3] for r in res) >= case[0]      # staging slots were needed; every seam cell finalised
 
 
+TFOLD_RANK_CASES = [
+    # nx, ny, bx, by, nranks, proc_shape: ns_boundary_type = 'tripoleT' -- the top physical row is itself an image (of row NY-1)
+    (40, 24, 20, 12, 2, (2, 1)),      # the fold row cut in x
+    (40, 24, 10, 6, 2, (1, 2)),       # cut in y only, several blocks per rank
+    (36, 20, 9, 10, 4, (4, 1)),
+    (44, 20, 11, 5, 4, (2, 2)),
+]
+
+
+def _tfold_worker(rank, world, port, case, q):
+    """tripoleT split over ranks: receive lists name INTERIOR cells of the top row next to ghost cells.  The plan's lists +
+    gloo against the oracle's T-fold halo update (NE-corner vector field) of the same global field on one rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        from pathlib import Path
+        sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
+        import oracle
+        nx, ny, bx, by, nranks, shape = case
+        dc = decomp.Decomp(nx, ny, bx, by, "cyclic", "tripoleT", nranks, shape)
+        d, keep = evp.make_dims(dc, rank)
+        plan = evp.halo_plan(d)
+        one = decomp.Decomp(nx, ny, bx, by, "cyclic", "tripoleT", 1)
+        ob = one.local_blocks(0)
+        dom = oracle.OracleDomain(one.nx_block, one.ny_block, len(ob), nx, ny, "cyclic", "tripoleT",
+                                  [b.ilo for b in ob], [b.ihi for b in ob], [b.jlo for b in ob], [b.jhi for b in ob],
+                                  [b.gi0 for b in ob], [b.gj0 for b in ob])
+        glob = np.random.default_rng(29).standard_normal((ny, nx))
+        ref = oracle.halo_update(dom, np.ascontiguousarray(one.scatter(glob, 0, fill=0.0)), "NEcorner", "vector")
+        a = np.ascontiguousarray(dc.scatter(glob, rank, fill=0.0))
+        mine = dc.local_blocks(rank)
+        for b in mine:                                   # wipe the ghost cells; the interior (top row included) keeps its raw values
+            m = np.ones((dc.ny_block, dc.nx_block), bool)
+            m[1:1 + b.gny, 1:1 + b.gnx] = False
+            a[b.local][m] = 0.0
+        flat = a.reshape(-1)
+        sendbuf = torch.from_numpy(flat[plan["send_src"]].copy())
+        recvbuf = torch.zeros(len(plan["recv_dst"]), dtype=torch.float64)
+        ops, so, ro = [], 0, 0
+        for p, ns_, nr_ in zip(plan["peer_rank"], plan["peer_nsend"], plan["peer_nrecv"]):
+            if ns_:
+                ops.append(dist.P2POp(dist.isend, sendbuf[so:so + ns_], int(p)))
+            if nr_:
+                ops.append(dist.P2POp(dist.irecv, recvbuf[ro:ro + nr_], int(p)))
+            so += ns_
+            ro += nr_
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        src = plan["local_src"]
+        loc = np.where(src >= 0, plan["local_sign"] * flat[np.maximum(src, 0)], 0.0)      # (sources are rows NY-1 / NY-2: never a destination)
+        flat[plan["recv_dst"]] = plan["recv_sign"] * recvbuf.numpy()
+        flat[plan["local_dst"]] = loc
+        nbad, n_int = 0, 0
+        for b in mine:
+            k = next(o.local for o in ob if o.gi0 == b.gi0 and o.gj0 == b.gj0)
+            nbad += int((a[b.local] != ref[k]).sum())
+        plane = dc.ny_block * dc.nx_block
+        for dcell in plan["recv_dst"]:
+            jj, ii = divmod(int(dcell) % plane, dc.nx_block)
+            blk = mine[int(dcell) // plane]
+            n_int += int(1 <= jj <= blk.gny and 1 <= ii <= blk.gnx)
+        q.put((rank, nbad, n_int, int(len(plan["recv_dst"]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", TFOLD_RANK_CASES)
+def test_tripoleT_split_over_ranks_known_answer(case):
+    world = case[4]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tfold_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nbad, n_int, nrecv in sorted(res):
+        assert nbad == 0, f"rank {rank}: {nbad} cells differ from the oracle's T-fold halo update"
+    if case[5][0] > 1:       # the fold row cut in x: some rank receives into interior cells of its top row
+        assert sum(r[2] for r in res) > 0
+
+
 def _centre_fold_worker(rank, world, port, case, q):
     """Cell-centre fields on a tripole grid whose fold row is split over ranks: the ghost cells across the fold whose source
     another rank owns are filled by running the NE-corner exchange on a copy shifted by one cell (halo_plan.h) -- plan

@@ -61,7 +61,8 @@ def main():
         spec = dict(nx=int(size.split("x")[0]), ny=int(size.split("x")[1]), dx0=1.1e5, ns=bnd or "closed")
     nx, ny = spec["nx"], spec["ny"]
     ns_bnd = spec.get("ns", "closed")          # tx1: tripole north boundary (rank layouts with px = 1 only)
-    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns_bnd))
+    # ("NXxNY:tripoleT": the T-fold -- the same grid as the u-fold's; only the halo rule differs, and the top row is an image)
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=("tripole" if ns_bnd == "tripoleT" else ns_bnd)))
     st = synth.make_state(g, case="full", seed=7, warm=True)
     pr = synth.make_primary(g, "full", seed=9) if a.prep else None
     scal = synth.evp_scalars(120)
@@ -320,7 +321,7 @@ def main():
                     bad.append((k + " fold ghost row", int((w != h).sum()), float(np.abs(w - h).max())))
         if k in ("uvel", "vvel"):      # ghost cells too (post-condition of the drop-in boundary)
             w2, h2 = want.copy(), got[k].copy()
-            if ns_bnd == "tripole":    # (scatter() does not know the fold: leave the folded ghost row out)
+            if ns_bnd in ("tripole", "tripoleT"):    # (scatter() does not know the fold: leave the folded ghost row out)
                 for b in dcN.local_blocks(rank):
                     if b.gj0 + b.gny - 1 == ny:           # (row gny + 1: a padded block has spare rows above it)
                         w2[b.local][b.gny + 1:, :] = 0.0
