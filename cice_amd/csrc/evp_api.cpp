@@ -387,9 +387,17 @@ int cice_evp_hip_subcycle(int32_t ndte)
 int cice_evp_hip_stress_halo(void)
 {
     if (!S.ready || !S.uploaded) return fail(-1, "state not uploaded");
-    if (S.plan.tfold)
-        return fail(-9, "tripoleT: the stress symmetrisation stays with the host (evp() applies it to its own arrays, "
-                        "ice_dyn_evp.F90:1321-1389)");
+    if (S.plan.tfold) {
+        if (S.plan.stress_remote)
+            return fail(-9, "tripoleT: with the top row split over ranks (or next to an eliminated block) the stress symmetrisation "
+                            "stays with the host (evp() applies it to its own arrays, ice_dyn_evp.F90:1321-1389)");
+        evp_launch_halo_stress_tfold(S.sig[S.cur], S.h_stress_dst, S.h_stress_src, S.n_stress, S.h_stress_own_dst, S.h_stress_own_src,
+                                     S.n_stress_own, S.stream);
+        // the north-west corner ghost cells: both arrays of a pair, each from the other's row NY-1 (which nothing above writes)
+        evp_launch_halo_stress(S.sig[S.cur], S.h_stress_corner_dst, S.h_stress_corner_src, S.n_stress_corner, S.stream);
+        HIPC(hipGetLastError());
+        return 0;
+    }
     evp_launch_halo_stress(S.sig[S.cur], S.h_stress_dst, S.h_stress_src, S.n_stress, S.stream);
     // partners on other ranks (fold row split in x): a1's ghost row <- a2's top row through the exchange of a shifted copy
     // (halo_plan.h); collective -- a rank without destinations of its own still serves its top row.  Scalars: factor -1.
@@ -866,8 +874,12 @@ int cice_evp_hip_center_plan(int32_t *count, int32_t *dst, int32_t *src, int32_t
 int cice_evp_hip_fold_split_plan(int32_t which, int32_t *count, int32_t *cells)
 {
     const HaloPlan &P = S.plan;
+    // (5 / 6: tripoleT -- east-west ghost cells of the top row that the stress symmetrisation leaves as images of their own array,
+    // and the cells they mirror)
     const std::vector<int32_t> &v = which == 0 ? P.fold_shift_cells : (which == 1 ? P.center_foldr_dst :
-                                    (which == 2 ? P.stress_foldr_dst : (which == 3 ? P.center_seam_dst : P.center_seam_slot)));
+                                    (which == 2 ? P.stress_foldr_dst : (which == 3 ? P.center_seam_dst :
+                                    (which == 4 ? P.center_seam_slot : (which == 5 ? P.stress_own_dst : (which == 6 ? P.stress_own_src :
+                                    (which == 7 ? P.stress_corner_dst : P.stress_corner_src)))))));
     if (count) *count = (int32_t)v.size();
     if (cells)
         for (size_t k = 0; k < v.size(); ++k) cells[k] = v[k];

@@ -333,6 +333,10 @@ int evp_halo_seam_fin_capacity();
 void evp_launch_halo_seam_fin(double *u, double *v, const int *dst, const int *fa, const int *fb,
                               const signed char *coef, int n, hipStream_t st);
 void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src, int n, hipStream_t st);
+// tripoleT: the top physical row of _1 / _2 from the partner's mirrored cell, east-west ghost cells of that row of _3 / _4 from
+// their own array (halo_plan.h)
+void evp_launch_halo_stress_tfold(double *const *sig12, const int *dst, const int *src, int n, const int *odst, const int *osrc, int no,
+                                  hipStream_t st);
 void evp_launch_halo_pack(const double *u, const double *v, const int *src, double *buf, int n,
                           hipStream_t st);
 void evp_launch_halo_unpack(double *u, double *v, const int *dst, const signed char *sign,

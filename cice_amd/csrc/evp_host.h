@@ -130,6 +130,10 @@ struct State {
     size_t nuv = 0;              // elements of a velocity buffer: n + staging slots of the seam step
     int32_t *h_stress_dst = nullptr, *h_stress_src = nullptr;
     int n_stress = 0;
+    int32_t *h_stress_own_dst = nullptr, *h_stress_own_src = nullptr;     // tripoleT (halo_plan.h)
+    int n_stress_own = 0;
+    int32_t *h_stress_corner_dst = nullptr, *h_stress_corner_src = nullptr;
+    int n_stress_corner = 0;
     // preparation phase on the device (evp_prep.hip)
     struct FoldX {                 // device side of HaloPlan::center_foldr_dst / stress_foldr_dst / fold_shift_cells
         bool ready = false;

@@ -76,7 +76,7 @@ void free_all()
     F(S.h_local_sign);
     F(S.h_seam_a); F(S.h_seam_b); F(S.h_seam_pole); F(S.h_late_dst); F(S.h_late_src); F(S.h_late_sign);
     F(S.h_fin_dst); F(S.h_fin_a); F(S.h_fin_b); F(S.h_fin_coef);
-    F(S.h_stress_dst); F(S.h_stress_src);
+    F(S.h_stress_dst); F(S.h_stress_src); F(S.h_stress_own_dst); F(S.h_stress_own_src); F(S.h_stress_corner_dst); F(S.h_stress_corner_src);
     {
         State::Prep &Q = S.prep;
         F(Q.tmask); F(Q.umask); F(Q.umask_old); F(Q.umask_old32); F(Q.tmphm); F(Q.hm); F(Q.tarea); F(Q.uarea); F(Q.fcor); F(Q.hwater); F(Q.aicen); F(Q.vicen); F(Q.tbt); Q.ncat = 0;
@@ -281,6 +281,10 @@ int upload_lists()
         up32(P.late_dst, S.h_late_dst) || up32(P.late_src, S.h_late_src)) return -1;
     S.n_stress = (int)P.stress_dst.size();
     if (up32(P.stress_dst, S.h_stress_dst) || up32(P.stress_src, S.h_stress_src)) return -1;
+    S.n_stress_own = (int)P.stress_own_dst.size();
+    if (up32(P.stress_own_dst, S.h_stress_own_dst) || up32(P.stress_own_src, S.h_stress_own_src)) return -1;
+    S.n_stress_corner = (int)P.stress_corner_dst.size();
+    if (up32(P.stress_corner_dst, S.h_stress_corner_dst) || up32(P.stress_corner_src, S.h_stress_corner_src)) return -1;
     if (S.n_late) {
         HIPC(hipMalloc((void **)&S.h_late_sign, S.n_late));
         HIPC(hipMemcpy(S.h_late_sign, P.late_sign.data(), S.n_late, hipMemcpyHostToDevice));

@@ -14,6 +14,7 @@
 // tile) and needs their OLD stresses while the owner is writing the new ones.
 // =====================================================================
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -394,6 +395,27 @@ __global__ void halo_stress_sym(SigTable T, const int *__restrict__ dst, const i
     for (int k = 0; k < 12; ++k) T.p[k][d] = (s >= 0) ? T.p[k ^ 2][s] : 0.0;
 }
 
+// tripoleT (halo_plan.h): the arrays _1, _2 of each family take the partner's mirrored cell of the top physical row; the
+// east-west ghost cells of that row of _3, _4 become images of their own array.  Reads touch interior cells of _3 / _4 only,
+// which nothing here writes.
+__global__ void halo_stress_tfold(SigTable T, const int *__restrict__ dst, const int *__restrict__ src, int n,
+                                  const int *__restrict__ odst, const int *__restrict__ osrc, int no)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const int d = dst[t], s = src[t];
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            if (!(k & 2)) T.p[k][d] = (s >= 0) ? T.p[k ^ 2][s] : 0.0;
+    }
+    if (t < no) {
+        const int d = odst[t], s = osrc[t];
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            if (k & 2) T.p[k][d] = (s >= 0) ? T.p[k][s] : 0.0;
+    }
+}
+
 // pack / unpack of remote halo cells (ice_boundary.F90:1260-1284, 1419-1449)
 __global__ void halo_pack_uv(const double *__restrict__ u, const double *__restrict__ v,
                              const int *__restrict__ src, double *__restrict__ buf, int n)
@@ -539,6 +561,15 @@ void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src
     SigTable T;
     for (int k = 0; k < 12; ++k) T.p[k] = sig12[k];
     hipLaunchKernelGGL(halo_stress_sym, dim3((n + 255) / 256), dim3(256), 0, st, T, dst, src, n);
+}
+
+void evp_launch_halo_stress_tfold(double *const *sig12, const int *dst, const int *src, int n, const int *odst, const int *osrc, int no,
+                                  hipStream_t st)
+{
+    if (n <= 0 && no <= 0) return;
+    SigTable T;
+    for (int k = 0; k < 12; ++k) T.p[k] = sig12[k];
+    hipLaunchKernelGGL(halo_stress_tfold, dim3((std::max(n, no) + 255) / 256), dim3(256), 0, st, T, dst, src, n, odst, osrc, no);
 }
 
 void evp_launch_halo_pack(const double *u, const double *v, const int *src, double *buf, int n,

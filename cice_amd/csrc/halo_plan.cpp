@@ -402,6 +402,65 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
                 }
             }
     }
+    if (tfold) {         // stress symmetrisation lists of the T-fold (halo_plan.h)
+        const int NX = d.nx_global, NY = d.ny_global;
+        auto cell_of = [&](int ig, int &owner) -> int32_t {
+            const int k = T.find(ig, NY);
+            if (k < 0 || T.blk[k].owner < 0) { owner = -1; return -1; }
+            const HaloBlock &B = T.blk[k];
+            owner = B.owner;
+            return (int32_t)((size_t)B.local * plane + (size_t)(ng + (NY - B.gj0)) * nx + (ng + (ig - B.gi0)));
+        };
+        auto cell_below = [&](int ig, int &owner) -> int32_t {            // (ig, NY-1)
+            const int k = T.find(ig, NY - 1);
+            if (k < 0 || T.blk[k].owner < 0) { owner = -1; return -1; }
+            const HaloBlock &B = T.blk[k];
+            owner = B.owner;
+            return (int32_t)((size_t)B.local * plane + (size_t)(ng + (NY - 1 - B.gj0)) * nx + (ng + (ig - B.gi0)));
+        };
+        auto it = T.by_rank.find(me);
+        if (it != T.by_rank.end())
+            for (int kb : it->second) {
+                const HaloBlock &B = T.blk[kb];
+                if (B.gj0 + B.gny - 1 != NY) continue;            // not a top-row block
+                {   // the north-west corner ghost cell
+                    int ig = B.gi0 - 1;
+                    if (ig < 1) ig += NX;
+                    if (ig != NX / 2 && ig != NX) {
+                        int im = NX - ig + 2;
+                        if (im > NX) im -= NX;
+                        int owner = -1;
+                        const int32_t src = cell_below(im, owner);
+                        if (owner != me) plan.stress_remote = true;
+                        plan.stress_corner_dst.push_back((int32_t)((size_t)B.local * plane + (size_t)(ng + B.gny) * nx + (ng - 1)));
+                        plan.stress_corner_src.push_back(owner == me ? src : -1);
+                    }
+                }
+                const int j = ng + B.gny;                         // local row of global NY
+                for (int i = 1; i <= B.gnx + 2 * ng; ++i) {
+                    int ig = B.gi0 + (i - (ng + 1));
+                    if (ig < 1) ig += NX;
+                    if (ig > NX) ig -= NX;
+                    int im = NX - ig + 2;
+                    if (im > NX) im -= NX;
+                    const int32_t dst = (int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1));
+                    int owner = -1;
+                    const int32_t src = cell_of(im, owner);
+                    // (a partner on another rank, or in an eliminated land block -- where the shortcut of the call pairs does not hold:
+                    // the symmetrisation then stays with the host)
+                    if (owner != me) plan.stress_remote = true;
+                    plan.stress_dst.push_back(dst);
+                    plan.stress_src.push_back(owner == me ? src : -1);
+                    if (i <= ng || i > ng + B.gnx) {              // an east-west ghost cell: image of its own array's cell
+                        int own = -1;
+                        const int32_t s2 = cell_of(ig, own);
+                        if (own != me) plan.stress_remote = true;
+                        plan.stress_own_dst.push_back(dst);
+                        plan.stress_own_src.push_back(own == me ? s2 : -1);
+                    }
+                }
+            }
+    }
     if (tripole) {       // where the shifted copies are built: this rank's interior cells of row NY-1 whose block also holds row NY
         auto it = T.by_rank.find(me);
         if (it != T.by_rank.end())

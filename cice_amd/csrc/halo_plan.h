@@ -83,6 +83,18 @@ struct HaloPlan {
     // physical row of its PARTNER array, a1(ig, NY+1) <- a2(NX-ig+1, NY); ghost cells whose source
     // block was eliminated are set to 0 (src = -1).  Offsets into the local array.
     std::vector<int32_t> stress_dst, stress_src;
+    // tripoleT: the same twelve calls rewrite the top PHYSICAL row instead -- a1(ig, NY) <- a2(NX-ig+2, NY), east-west ghost
+    // columns of that row included, the ghost row above untouched (T-fold offsets of ice_boundary.F90:7700-7740; pinned on
+    // the reference's own arrays, tests/golden/tript_*.npz).  The calls come in pairs (a1, a2), (a2, a1) and the mirror is an
+    // involution, so the second call of a pair puts a2's interior values back where they were: what changes is a1 = the
+    // arrays _1 and _2 of each family (stress_dst / stress_src above: cell of row NY <- partner array's mirrored cell), and the
+    // east-west ghost cells of row NY of _3 and _4, which end up as plain images of their own array (stress_own_*).
+    std::vector<int32_t> stress_own_dst, stress_own_src;
+    // ... and one cell of the ghost row above: the north-west corner ghost cell of a top-row block (global column ig) takes
+    // a2(NX-ig+2, NY-1) -- in BOTH arrays of a pair, each from the other -- unless ig is NX/2 or NX (0).  Found by the geometry
+    // sweep against the reference itself (three blocks across the top row are needed to see it) and pinned there on 60 random
+    // layouts; nothing else of that row is touched.
+    std::vector<int32_t> stress_corner_dst, stress_corner_src;
     // Ghost cells of CELL-CENTRE fields (the T-grid inputs of evp()'s preparation phase,
     // ice_dyn_evp.F90:413-428, 466-470): same as the velocity lists except across the tripole
     // fold, where a centre cell mirrors column NX-ig+1 of row NY-k+1 (ice_boundary.F90:1689-1722,

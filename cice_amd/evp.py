@@ -198,7 +198,8 @@ def fold_split_plan() -> dict:
     """Lists of the shifted-copy exchange of the plan built last (halo_plan(): cice_evp_hip_plan_build)."""
     lib = load_library(testing=True)
     out = {}
-    for which, name in enumerate(("shift_cells", "center_dst", "stress_dst", "seam_dst", "seam_slot")):
+    for which, name in enumerate(("shift_cells", "center_dst", "stress_dst", "seam_dst", "seam_slot", "stress_own_dst", "stress_own_src",
+                                  "stress_corner_dst", "stress_corner_src")):
         n = C.c_int32(0)
         split = lib.cice_evp_hip_fold_split_plan(C.c_int32(which), C.byref(n), None)
         a = np.zeros(max(n.value, 1), dtype=np.int32)

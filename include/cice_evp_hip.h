@@ -42,8 +42,8 @@ enum {
     CICE_EVP_BND_TRIPOLE = 3, /* u-fold; ns only */
     CICE_EVP_BND_TRIPOLET = 4 /* T-fold ('tripoleT'); ns only; B-grid subcycle loop (cice_evp_hip_run / _upload / _subcycle /
                                * _download), any rank layout (the streaming kernel; the images of the top row are interior
-                               * cells, so the exchange always follows the launch): the preparation phase, the stress
-                               * symmetrisation and the C grid stay with the host there */
+                               * cells, so the exchange always follows the launch) and cice_evp_hip_stress_halo with the top
+                               * row on one rank: the preparation phase and the C grid stay with the host there */
 };
 
 /* Block decomposition of this process (type(block), ice_blocks.F90:21-41;

@@ -61,8 +61,9 @@ def test_golden_tripoleT_strict_bitwise(name):
     """ns_boundary_type = 'tripoleT' (T-fold): the B-grid loop through cice_evp_hip_run against the reference's evp() --
     the velocity halo's T-fold rule (top U row = image of row NY-1, ghost row = image of row NY-2, no pair averaging:
     ice_boundary.F90:1563-1622, 1686-1722) runs as list copies after every subcycle launch.  Velocities and the loop's
-    diagnostics on every cell; the stresses wherever evp()'s own ice_HaloUpdate_stress calls after the loop (which stay
-    with the host on this boundary type) leave them alone.  The device preparation and symmetrisation refuse loudly."""
+    diagnostics on every cell; the stresses wherever evp()'s own ice_HaloUpdate_stress calls after the loop leave them
+    alone (test_tripole_stress_symmetrisation_on_device applies those on the device too: every cell).  The device
+    preparation refuses loudly."""
     c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     keep = tfold_untouched(c)
@@ -78,8 +79,6 @@ def test_golden_tripoleT_strict_bitwise(name):
         assert core.timings()["tile_variant"] < 1000          # the streaming kernel (the resident ones are not eligible)
         assert "one subcycle per launch" in core.describe_path() and "two-subcycle path: off" in core.describe_path()
         assert np.abs(want["uvel"]).max() > 1e-3
-        with pytest.raises(evp.EvpHipError, match="tripoleT"):
-            core.stress_halo()
     finally:
         core.finalize()
 
@@ -248,7 +247,7 @@ def test_resident_entry_points_equal_run():
         core.finalize()
 
 
-@pytest.mark.parametrize("name", [n for n in GOLDEN_CASES if n.startswith("trip")])
+@pytest.mark.parametrize("name", [n for n in GOLDEN_CASES if n.startswith("trip")] + TFOLD_CASES)
 def test_tripole_stress_symmetrisation_on_device(name):
     """the 12 x ice_HaloUpdate_stress evp() applies after the loop, done on the
     resident stresses (cice_evp_hip_stress_halo) -- the downloaded state equals the reference's
@@ -1294,14 +1293,16 @@ def test_bgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
     check_next_tier_post(c, what)
 
 
-@pytest.mark.parametrize("seed", list(range(451, 455)) + [int(s) for s in os.environ.get("TFOLD_REF_SWEEP_SEEDS", "").split() if s])
+@pytest.mark.parametrize("seed", list(range(451, 463)) + [int(s) for s in os.environ.get("TFOLD_REF_SWEEP_SEEDS", "").split() if s])
 def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
     """ns_boundary_type = 'tripoleT' over random geometries (harness on the box, as above): the B-grid loop with the
     T-fold's velocity halo as list copies; velocities and diagnostics everywhere, stresses wherever evp()'s own
-    ice_HaloUpdate_stress after the loop leaves them alone."""
+    ice_HaloUpdate_stress after the loop leaves them alone -- and, after cice_evp_hip_stress_halo, everywhere."""
     rng = np.random.default_rng(seed)
     nx, ny = 2 * int(rng.integers(12, 50)), int(rng.integers(16, 60))
     nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    if seed >= 455:              # three to five blocks across the top row: the north-west corner cells of the symmetrisation
+        nbx = int(rng.integers(3, 6))
     bs = (-(-nx // nbx), -(-ny // nby))
     icecase = str(rng.choice(["full", "patchy", "caps"]))
     ndte = int(rng.choice([3, 8]))
@@ -1318,6 +1319,9 @@ def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
                 for k in want:
                     sel = keep if k.startswith("stress") else np.ones_like(keep)
                     assert np.array_equal(out[k][sel], want[k][sel]), f"{what}: call {icall} nsub {nsub} {k}"
+                # ... and with those twelve calls done on the device too (late round 4): every cell of every array
+                core.stress_halo()
+                assert_bitwise(core.download(), want, f"{what}: call {icall} nsub {nsub}, symmetrised on the device")
         assert np.abs(want["uvel"]).max() > 1e-5, what
     finally:
         core.finalize()

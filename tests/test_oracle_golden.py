@@ -80,6 +80,43 @@ def test_subcycle_tripoleT_bitwise(name):
         assert np.abs(want["uvel"]).max() > 1e-3
 
 
+@pytest.mark.parametrize("name", TFOLD_CASES)
+def test_tripoleT_stress_symmetrisation_lists_bitwise(name):
+    """What evp()'s twelve ice_HaloUpdate_stress calls do on a tripoleT grid, as the library's plan lists say it (host code,
+    no GPU): the top physical row of _1 / _2 of each family takes the partner array's mirrored cell, east-west ghost cells of
+    that row of _3 / _4 become images of their own array, nothing else moves.  The oracle's loop output + those lists =
+    the reference's whole-evp() stresses on EVERY cell."""
+    from cice_amd import evp
+    c = GoldenCase(name)
+    dom, prm, st = c.oracle_domain(), c.oracle_params(), c.static()
+    d, keepalive = c.hip_dims()
+    plan = evp.halo_plan(d)
+    own = evp.fold_split_plan()
+    assert not plan["stress_remote"] and len(plan["stress_dst"]) > 0 and len(own["stress_own_dst"]) > 0
+    for icall in range(1, c.ncalls + 1):
+        dyn, tm, um = c.inputs(icall)
+        nsub = c.nsub_list[-1]
+        out = oracle.subcycle(dom, prm, nsub, dyn, st, tm, um)
+        want = c.expected(icall, nsub)
+        flat = {k: out[k].reshape(-1).copy() for k in out if k.startswith("stress")}
+        new = {k: v.copy() for k, v in flat.items()}
+        for fam in ("stressp", "stressm", "stress12"):
+            for q, partner in ((1, 3), (2, 4)):
+                a1, a2 = f"{fam}_{q}", f"{fam}_{partner}"
+                src = plan["stress_src"]
+                new[a1][plan["stress_dst"]] = np.where(src >= 0, flat[a2][np.maximum(src, 0)], 0.0)
+                so = own["stress_own_src"]
+                new[a2][own["stress_own_dst"]] = np.where(so >= 0, flat[a2][np.maximum(so, 0)], 0.0)
+                sc = own["stress_corner_src"]       # (north-west corner ghost cells: none on these two fixtures -- the geometry sweep
+                new[a1][own["stress_corner_dst"]] = flat[a2][sc]      # of tests/test_gpu_parity.py has layouts with three blocks across)
+                new[a2][own["stress_corner_dst"]] = flat[a1][sc]
+        changed = 0
+        for k, v in new.items():
+            assert np.array_equal(v.reshape(want[k].shape), want[k]), f"{name} call {icall} {k}"
+            changed += int((v != flat[k]).sum())
+        assert changed > 0
+
+
 PREP_PRODUCTS = ["aiU", "cdn_ocnU", "uocnU", "vocnU", "waterxU", "wateryU", "forcexU", "forceyU", "umassdti",
                  "uvel_init", "vvel_init", "uvel", "vvel"] + oracle.DYN_FIELDS[:12]
 
