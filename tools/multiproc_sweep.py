@@ -44,7 +44,8 @@ def main():
         px, py = [int(v) for v in shape.split("x")]
         nx = 2 * px * int(rng.integers(14, 50))      # even, and the same number of columns on every rank
         ny = py * int(rng.integers(16, 60))
-        wl = f"{nx}x{ny}" + (":tripole" if trip else "")
+        tfold = (not a.tripole_resident) and mode == "streaming" and seed % 4 == 1      # ns_boundary_type = 'tripoleT' (late round 4)
+        wl = f"{nx}x{ny}" + (":tripole" if trip else (":tripoleT" if tfold else ""))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(port()), str(ROOT / "tools" / "mailbox_2proc.py"), "--workload", wl, "--shape", shape,
                "--ndte", str(int(rng.choice([6, 9, 24])))]
@@ -60,6 +61,9 @@ def main():
             env.update(CICE_EVP_HIP_MARCH="1", CICE_EVP_HIP_RESIDENT="0", CICE_EVP_HIP_MARCH_SEG=str(int(rng.integers(5, 30))))
             env["CICE_EVP_HIP_MARCH_EXT"] = str(int(rng.choice([0, 2, 4])))
             env["CICE_EVP_HIP_MARCH_OWN"] = str(int(rng.choice([13, 29, 60])))
+            form = int(rng.integers(0, 3))       # the ring through the transport / overlapped with the pass / as stores into the peers' inboxes
+            env["CICE_EVP_HIP_MARCH_OVERLAP"] = "1" if form == 1 else "0"
+            env["CICE_EVP_HIP_MARCH_DIRECT"] = "1" if form == 2 else "0"
         elif mode == "cgrid":
             cmd += ["--cgrid"] + (["--visc", "avg_strength"] if rng.random() < 0.4 else []) + (["--maskhalo"] if rng.random() < 0.4 else [])
         elif mode == "prep":
