@@ -382,6 +382,15 @@ int cice_evp_hip_subcycle(int32_t ndte)
     return 0;
 }
 
+// 1 if cice_evp_hip_stress_halo can do its job on this rank layout (tripole: always; tripoleT: the top row on one rank and no
+// eliminated block in it; other boundaries: there is nothing to do, 1), else 0 -- for a host that wants to keep the stresses
+// on the device between calls and must know whether evp()'s twelve ice_HaloUpdate_stress calls can be left to the library.
+int cice_evp_hip_stress_halo_available(void)
+{
+    if (!S.ready) return 0;
+    return (S.plan.tfold && S.plan.stress_remote) ? 0 : 1;
+}
+
 // Tripole: force the stresses symmetric across the seam on the resident state, as evp() does
 // on the host arrays after the subcycle loop (12 x ice_HaloUpdate_stress, ice_dyn_evp.F90:1321-1389).
 int cice_evp_hip_stress_halo(void)

@@ -157,6 +157,9 @@ module ice_dyn_evp_hip
        integer(c_int32_t), value :: ndte
      end function cice_evp_hip_subcycle
 
+     integer(c_int) function cice_evp_hip_stress_halo_available() bind(C, name='cice_evp_hip_stress_halo_available')
+       import :: c_int
+     end function cice_evp_hip_stress_halo_available
      integer(c_int) function cice_evp_hip_stress_halo() bind(C, name='cice_evp_hip_stress_halo')
        import :: c_int
      end function cice_evp_hip_stress_halo
@@ -392,8 +395,15 @@ contains
     stress_resident = stress_resident_requested .or. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '1')
     ! (a rank layout that cuts the tripole seam row in x is fine too: cice_evp_hip_stress_halo reaches the partners on
     ! other ranks through the velocity exchange of a shifted copy)
-    ! tripoleT: the symmetrisation is not built on the device at all
-    if (trim(ns_boundary_type) == 'tripoleT') stress_resident = .false.
+    ! tripoleT: the device does the symmetrisation where the top row lies on one rank (cice_evp_hip_stress_halo_available);
+    ! elsewhere the stresses travel every call and evp() applies it to its own arrays
+    if (trim(ns_boundary_type) == 'tripoleT') then
+       if (cice_evp_hip_stress_halo_available() == 1) then
+          on_tripole = .true.
+       else
+          stress_resident = .false.
+       endif
+    endif
     call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
          subname, __FILE__, __LINE__)
 

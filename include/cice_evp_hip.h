@@ -170,6 +170,9 @@ int cice_evp_hip_sync(void);
  * ghost row NY+1 of component c takes the mirrored top physical row of its partner (1<->3, 2<->4).
  * Call between cice_evp_hip_subcycle and cice_evp_hip_download; no-op on other grids.            */
 int cice_evp_hip_stress_halo(void);
+/* 1 if cice_evp_hip_stress_halo can do that on this rank layout (tripole: always; tripoleT: the top row on one rank and no
+ * eliminated block in it), else 0: a host that keeps the stresses resident asks before it leaves the step to the library. */
+int cice_evp_hip_stress_halo_available(void);
 int cice_evp_hip_set_post_geometry(const double *dxU, const double *dyU, const double *tarear);
 int cice_evp_hip_deformations(double *divu, double *shear, double *vort, double *rdg_conv,
                               double *rdg_shear);

@@ -207,12 +207,17 @@ def test_reference_driver_with_hip_cgrid_loop_geometry_sweep(tmp_path, seed):
                      ndte=int(rng.choice([5, 12])))
 
 
-@pytest.mark.parametrize("nx,ny,bx,by,kw", [(72, 40, 36, 20, dict(icecase="full")), (48, 36, 48, 36, dict(icecase="patchy", h_capping=0.5))])
-def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx, by, kw, monkeypatch):
+@pytest.mark.parametrize("resident", [False, True], ids=["no_hooks", "resident_opt_in"])
+@pytest.mark.parametrize("nx,ny,bx,by,kw", [(72, 40, 36, 20, dict(icecase="full")), (48, 36, 48, 36, dict(icecase="patchy", h_capping=0.5)),
+                                            (90, 30, 18, 15, dict(icecase="full"))])      # five blocks across the top row
+def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx, by, kw, resident, monkeypatch):
     """ns_boundary_type = 'tripoleT' (T-fold; ice_domain.F90:260), Option B: the reference's unmodified evp() -- its own
     preparation, its own 12 x ice_HaloUpdate_stress after the loop -- with the HIP core behind dyn_evp1d_run.  The loop's
     velocity halo follows the T-fold rule (top U row = image of row NY-1).  Every output array of the whole evp(), every
-    cell, against the reference's standard path in the same process."""
+    cell, against the reference's standard path in the same process.  resident_opt_in (late round 4): the host keeps the
+    stresses on the device between calls; evp()'s twelve ice_HaloUpdate_stress calls then act on stale host arrays and the
+    library applies the same step to the device copy (cice_evp_hip_stress_halo, T-fold rule incl. the north-west corner
+    ghost cells) -- what the fetch hook brings back must equal the reference's arrays on every cell."""
     if not run_ref.have_ref("hip_dropin"):
         pytest.skip("oracle/_ref/evp_hip_dropin_harness not built (needs the reference tree)")
     monkeypatch.setenv("CICE_EVP_HIP_VERBOSE", "1")        # the shim reports once which kernel / transport the library settled on
@@ -221,7 +226,7 @@ def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx,
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
     d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="tripoleT", variant="hip_dropin", h_ndte=120,
                                  ncalls=2, nsub_list=[1, 120], hipmode=True, hipbody=False, grid_kind="tripolefile",
-                                 grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
+                                 hipresident=resident, grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
     checked = 0
     for icall in (1, 2):
         for nsub in (1, 120):
