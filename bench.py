@@ -60,6 +60,7 @@ CHECKPOINTS = [1, 3, 5, 12, 23, 25, 50]     # total steps after which tests/gold
 VERIFY_FIELDS = ("uvel", "vvel", "stressp_1")
 CGRID_VERIFY_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")   # tests/golden/make_bench_checksums.py
 CGRID_B_ALG = 648.0      # C grid: 81 fp64 array touches per cell and subcycle in the fused schedule
+CGRID_B_ALG_GEO = 563.0  # ... 70 + three mask bytes where the fused kernels derive 15 of the 23 static arrays (as cg_one does)
 EXTRAS = ("s01", "streaming", "tripole", "cgrid", "per_call", "configs2")
 CGRID_B_ALG_ONE = 408.0  # ... 51 in the one-launch kernel (cg_one: the default on one rank without a fold)
 CGRID_B_ALG_ONE_GEO = 289.0  # ... 36 + one mask byte where cg_one derives 15 of its 23 static arrays from the 8 dx / dy arrays
@@ -576,7 +577,7 @@ def main():
                 ev_ms += core.cgrid_timings()["loop_ms"]
             wall = time.perf_counter() - t0
             one = core.cgrid_timings()["one_launch_subcycles"] > 0
-            geo = one and core.cgrid_timings()["geometry_derived"]
+            geo = core.cgrid_timings()["geometry_derived"]
             out = core.cgrid_download()
         finally:
             core.finalize()
@@ -586,7 +587,7 @@ def main():
         want = golden.get(f"cgrid/{workload}/{case}/ndte{ndte}/closed/strict", {}).get(str(warmup + steps))
         launches = 1 if one else 3                # cg_one / the fused schedule (evp_cgrid.hip): kernels per subcycle
         t_sub = ev_ms * 1e-3 / (steps * ndte)
-        alg = ((CGRID_B_ALG_ONE_GEO if geo else CGRID_B_ALG_ONE) if one else CGRID_B_ALG) * nx * ny
+        alg = ((CGRID_B_ALG_ONE_GEO if geo else CGRID_B_ALG_ONE) if one else (CGRID_B_ALG_GEO if geo else CGRID_B_ALG)) * nx * ny
         return {"workload": f"{workload} {nx}x{ny} C-grid EVP ndte={ndte}, case={case}, strict fp64, one GPU",
                 "value": nx * ny * ndte * steps / wall, "unit": "cell-updates/s", "steps": steps, "warmup": warmup,
                 "us_per_subcycle": 1e6 * t_sub, "us_per_subcycle_wall": 1e6 * wall / (steps * ndte),
@@ -601,7 +602,7 @@ def main():
                              "note": (("289 B per cell and subcycle = 36 fp64 array touches + one mask byte: the one-launch kernel cg_one with 15 "
                                        "of its 23 static arrays (areas, reciprocal areas, boundary ratios, DminTarea, land masks) derived in "
                                        "the kernel from the eight dx / dy arrays -- identities the host verified bit for bit; 408 B with all "
-                                       "51 arrays loaded (frac_on_408B_yardstick)" if geo else
+                                       "51 arrays loaded (frac_on_408B_yardstick)" if (geo and one) else
                                        "408 B per cell and subcycle = 51 fp64 array touches of the one-launch kernel cg_one") +
                                       " (shearU, etax2T and the T-cell stresses stay in LDS between its three levels)" if one else
                                       "648 B per cell and subcycle = 81 fp64 array touches of the three fused kernels") +

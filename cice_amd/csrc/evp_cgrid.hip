@@ -63,6 +63,72 @@ __device__ __forceinline__ void visc_replpress(const EvpScalars &p, double stren
     etax2 = p.epp2i * zetax2;
 }
 
+// array k of a table that is one allocation: base + k * stride (a scalar multiply-add where it is used, instead of
+// one kernel-argument pointer per array held in scalar registers from the top of the kernel)
+struct Slab {
+    const double *base;
+    size_t stride;
+    __device__ __forceinline__ const double *operator[](int k) const { return base + (size_t)k * stride; }
+};
+// The same table with 15 of its 23 arrays DERIVED from the other eight instead of loaded (cg_one is HBM-bound on large
+// grids, and nearly half of its bytes per cell are static geometry): the reference computes them once at start-up as
+//   tarea = dxT*dyT, uarea = dxU*dyU, narea = dxN*dyN, earea = dxE*dyE          (ice_grid.F90:681-684)
+//   earear = 1/earea, narear = 1/narea where the area is > 0, else 0            (ice_grid.F90:706-715)
+//   ratiodxN = -dxN(i+1,j)/dxN(i,j), ratiodyE = -dyE(i,j+1)/dyE(i,j), ratiodxNr = 1/ratiodxN, ratiodyEr = 1/ratiodyE
+//                                                                               (ice_dyn_evp.F90:235-238)
+//   DminTarea = deltaminEVP*tarea                                               (ice_dyn_shared.F90: init_dyn_shared)
+//   hm, uvm, npm, epm: land masks, 0 or 1                                       (ice_grid.F90:979, 3382-3385)
+// cice_evp_hip_cgrid_set_geometry checks every one of these identities BIT FOR BIT on the caller's arrays (all cells the
+// kernel can read) and hands out this view only if all hold, so a derived value IS the array's value; the masks travel
+// as four bits of one byte.  k is a constant at every use: the switch folds.
+struct DSlab {
+    const double *base;
+    size_t stride;
+    const uint8_t *gm;              // bit 0 epm, 1 npm, 2 uvm, 3 hm
+    int nx;
+    double dmin;
+    struct Acc {
+        const DSlab &S;
+        int k;
+        __device__ __forceinline__ double raw(int a, size_t p) const { return S.base[(size_t)a * S.stride + p]; }
+        __device__ __forceinline__ double operator[](size_t p) const
+        {
+            switch (k) {
+            case CG_TAREA: return raw(CG_DXT, p) * raw(CG_DYT, p);
+            case CG_UAREA: return raw(CG_DXU, p) * raw(CG_DYU, p);
+            case CG_NAREA: return raw(CG_DXN, p) * raw(CG_DYN, p);
+            case CG_EAREA: return raw(CG_DXE, p) * raw(CG_DYE, p);
+            case CG_EAREAR: { const double a = raw(CG_DXE, p) * raw(CG_DYE, p); return a > 0.0 ? 1.0 / a : 0.0; }
+            case CG_NAREAR: { const double a = raw(CG_DXN, p) * raw(CG_DYN, p); return a > 0.0 ? 1.0 / a : 0.0; }
+            case CG_DMINT: return S.dmin * (raw(CG_DXT, p) * raw(CG_DYT, p));
+            case CG_RXN: return -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
+            case CG_RXNR: return 1.0 / -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
+            case CG_RYE: return -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
+            case CG_RYER: return 1.0 / -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
+            case CG_EPM: return (S.gm[p] & 1u) ? 1.0 : 0.0;
+            case CG_NPM: return (S.gm[p] & 2u) ? 1.0 : 0.0;
+            case CG_UVM: return (S.gm[p] & 4u) ? 1.0 : 0.0;
+            case CG_HM: return (S.gm[p] & 8u) ? 1.0 : 0.0;
+            default: return raw(k, p);
+            }
+        }
+    };
+    __device__ __forceinline__ Acc operator[](int k) const { return Acc{*this, k}; }
+};
+// the fused (three-launch) kernels see the static table through the same two views: the kernel argument's pointer array, or
+// the derived one (A.gmask set: the arrays are one allocation, A.g[k] = A.g[0] + k * A.gstride)
+struct PtrTab {
+    const double *const *g;
+    __device__ __forceinline__ const double *operator[](int k) const { return g[k]; }
+};
+template <bool GEO> struct AGeo;
+template <> struct AGeo<false> {
+    static __device__ __forceinline__ PtrTab make(const EvpCgrid &A) { return PtrTab{A.g}; }
+};
+template <> struct AGeo<true> {
+    static __device__ __forceinline__ DSlab make(const EvpCgrid &A) { return DSlab{A.g[0], A.gstride, A.gmask, A.nx, A.deltaminEVP}; }
+};
+
 struct Cell { int i, j, b; size_t o; int4 q; bool in; };
 __device__ __forceinline__ Cell cell(const EvpCgrid &A)
 {
@@ -169,21 +235,24 @@ __device__ __forceinline__ double avg_2(const double *a, const W &w, size_t p, s
 // strain_rates_U reads it.  The east / north neighbour may be a ghost cell: its value in the reference is the copy
 // of the owner's average, which the same formula gives here from the (pushed) ghost velocities and the static
 // ghost weights. ----
+template <bool GEO>
 __global__ __launch_bounds__(TX *TY) void cg_avg_strain(EvpCgrid A, int last)
 {
     const Cell c = cell(A);
     if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
     const size_t o = c.o, e = o + 1, n = o + A.nx;
     const unsigned m = A.mask[o];
-    const double *uE = A.f[CF_UE], *vN = A.f[CF_VN], *ea = A.g[CG_EAREA], *na = A.g[CG_NAREA];
-    const double *npm = A.g[CG_NPM], *epm = A.g[CG_EPM];
+    const auto G = AGeo<GEO>::make(A);
+    const double *uE = A.f[CF_UE], *vN = A.f[CF_VN];
+    const auto ea = G[CG_EAREA], na = G[CG_NAREA];
+    const auto npm = G[CG_NPM], epm = G[CG_EPM];
     const double uNo = avg_nw(uE, ea, o, A.nx) * npm[o];
     const double vEo = avg_se(vN, na, o, A.nx) * epm[o];
     A.f[CF_UN][o] = uNo;                         // stepv_C / stepu_C of this subcycle read them (own cell)
     A.f[CF_VE][o] = vEo;
     // no early exit for cells without ice: every load below is in bounds, and issuing them all before the first
     // wait is what matters on grids this small (two waves per SIMD); only the stores are conditional
-    const double uvm = A.g[CG_UVM][o];
+    const double uvm = G[CG_UVM][o];
     const double uU = avg_2(uE, ea, o, n) * uvm;
     const double vU = avg_2(vN, na, o, e) * uvm;
     double sh, delta = 0.0;
@@ -193,9 +262,9 @@ __global__ __launch_bounds__(TX *TY) void cg_avg_strain(EvpCgrid A, int last)
         v.uNe = avg_nw(uE, ea, e, A.nx) * npm[e];
         v.vEn = avg_se(vN, na, n, A.nx) * epm[n];
         v.uEo = uE[o]; v.uEn = uE[n]; v.vNo = vN[o]; v.vNe = vN[e];
-        strain_u(A, A.g, o, v, sh, delta);
+        strain_u(A, G, o, v, sh, delta);
     } else {
-        sh = shear_u(A, A.g, o, uE[o], uE[n], vN[o], vN[e], uU, vU);
+        sh = shear_u(A, G, o, uE[o], uE[n], vN[o], vN[e], uU, vU);
     }
     if (!(m & 2u)) return;
     A.f[CF_SHEARU][o] = sh;
@@ -241,17 +310,18 @@ __global__ __launch_bounds__(TX *TY) void cg_strain_u(EvpCgrid A)
 // ---- phase 1: stressC_T on ilo..ihi+1 x jlo..jhi+1 (the reference's T list, ice_dyn_shared.F90:729-738).
 // zetax2T, etax2T, stresspT, stressmT are exchanged right after (:988-990): interior cells store and push them, the
 // extra row and column (ghost cells) only keep what is never exchanged, stress12T. ----
-template <bool ALWAYS>
+template <bool ALWAYS, bool GEO>
 __global__ __launch_bounds__(TX *TY) void cg_stress_t(EvpCgrid A, int last)
 {
+    const auto G = AGeo<GEO>::make(A);
     const Cell c = cell(A);
     if (!c.in || c.i < c.q.x || c.i > c.q.y + 1 || c.j < c.q.z || c.j > c.q.w + 1) return;
     const size_t o = c.o, w = o - 1, s = o - A.nx, sw = s - 1;
     const unsigned m = A.mask[o];
     const bool own = c.i <= c.q.y && c.j <= c.q.w;
     const double *uE = A.f[CF_UE], *vN = A.f[CF_VN], *shU = A.f[CF_SHEARU];
-    const double *dyE = A.g[CG_DYE], *dxN = A.g[CG_DXN], *uarea = A.g[CG_UAREA];
-    const double dxT = A.g[CG_DXT][o], dyT = A.g[CG_DYT][o];
+    const auto dyE = G[CG_DYE], dxN = G[CG_DXN], uarea = G[CG_UAREA];
+    const double dxT = G[CG_DXT][o], dyT = G[CG_DYT][o];
     const double divT = dyE[o] * uE[o] - dyE[w] * uE[w] + dxN[o] * vN[o] - dxN[s] * vN[s];
     const double tensionT = (dyT * dyT) * (uE[o] / dyE[o] - uE[w] / dyE[w]) - (dxT * dxT) * (vN[o] / dxN[o] - vN[s] / dxN[s]);
     const double uareaavgr = 1.0 / (uarea[o] + uarea[s] + uarea[sw] + uarea[w]);
@@ -260,7 +330,7 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_t(EvpCgrid A, int last)
     const double shearT = (shU[o] * uarea[o] + shU[s] * uarea[s] + shU[sw] * uarea[sw] + shU[w] * uarea[w]) * uareaavgr;
     const double DeltaT = sqrt(divT * divT + A.p.e_factor * (tensionT * tensionT + shearTsqr));
     double zetax2, etax2, rep_prs;
-    visc_replpress(A.p, A.in[CI_STRENGTH][o], A.g[CG_DMINT][o], DeltaT, zetax2, etax2, rep_prs);
+    visc_replpress(A.p, A.in[CI_STRENGTH][o], G[CG_DMINT][o], DeltaT, zetax2, etax2, rep_prs);
     const double relax = 1.0 - A.p.arlx1i * A.p.revp;
     const double s12 = (A.f[CF_S12T][o] * relax + A.p.arlx1i * 0.5 * etax2 * shearT) * A.p.denom1;
     const double sp = (A.f[CF_SP][o] * relax + A.p.arlx1i * (zetax2 * divT - rep_prs)) * A.p.denom1;
@@ -282,14 +352,16 @@ __global__ __launch_bounds__(TX *TY) void cg_stress_t(EvpCgrid A, int last)
 }
 
 // T -> U average, grid_average_X2YS('NE', work, tarea, hm): ice_grid.F90:4190-4209
-__device__ __forceinline__ double avg_t2u(const EvpCgrid &A, const double *w1, size_t o)
+template <class GT>
+__device__ __forceinline__ double avg_t2u_g(const EvpCgrid &A, const GT &G, const double *w1, size_t o)
 {
-    const double *hm = A.g[CG_HM], *ta = A.g[CG_TAREA];
+    const auto hm = G[CG_HM], ta = G[CG_TAREA];
     const size_t e = o + 1, n = o + A.nx, ne = n + 1;
     const double wtmp = (hm[o] * ta[o] + hm[e] * ta[e] + hm[n] * ta[n] + hm[ne] * ta[ne]);
     if (wtmp == 0.0) return 0.0;
     return (hm[o] * w1[o] * ta[o] + hm[e] * w1[e] * ta[e] + hm[n] * w1[n] * ta[n] + hm[ne] * w1[ne] * ta[ne]) / wtmp;
 }
+__device__ __forceinline__ double avg_t2u(const EvpCgrid &A, const double *w1, size_t o) { return avg_t2u_g(A, PtrTab{A.g}, w1, o); }
 
 // ---- phase 2: viscosity at the corners (:992-996) and stressC_U; stress12U is exchanged (:1011-1013) ----
 __global__ __launch_bounds__(TX *TY) void cg_stress_u(EvpCgrid A)
@@ -378,10 +450,11 @@ __global__ __launch_bounds__(TX *TY) void cg_step(EvpCgrid A)
 
 // stress12U after this subcycle at corner p (own cell or a neighbour, possibly a ghost cell): stressC_U with the
 // T -> U average of etax2T, from the previous subcycle's value in A.s12_in; unchanged where there is no ice
-__device__ __forceinline__ double s12u_new(const EvpCgrid &A, size_t p, bool ice, double relax, double *etaU)
+template <class GT>
+__device__ __forceinline__ double s12u_new(const EvpCgrid &A, const GT &G, size_t p, bool ice, double relax, double *etaU)
 {
     const double old = A.s12_in[p];
-    const double e2 = avg_t2u(A, A.f[CF_ETA], p);
+    const double e2 = avg_t2u_g(A, G, A.f[CF_ETA], p);
     if (etaU) *etaU = e2;
     const double upd = (old * relax + A.p.arlx1i * 0.5 * e2 * A.f[CF_SHEARU][p]) * A.p.denom1;
     return ice ? upd : old;
@@ -392,9 +465,10 @@ __device__ __forceinline__ double s12u_new(const EvpCgrid &A, size_t p, bool ice
 // wateryN == vocnN bit for bit (cosw = 1, sinw = 0), TbE = TbN = +0 (no seabed stress), rheofactE = rheofactN = 1 --
 // established per call on every ice cell (cg_call_setup); aiX*rhow*Cw comes premultiplied (same operation order).
 // Bit-neutral: x*1.0, x + (+0.0) and 0.0/c are exact, taub = -u*(+0.0) is still formed.
-template <bool FAST>
+template <bool FAST, bool GEO>
 __global__ __launch_bounds__(TX *TY * 2) void cg_stress_u_step(EvpCgrid A, int last)
 {
+    const auto G = AGeo<GEO>::make(A);
     const Cell c = cell(A);
     if (!c.in || c.i < c.q.x || c.i > c.q.y || c.j < c.q.z || c.j > c.q.w) return;
     const size_t o = c.o, e = o + 1, n = o + A.nx, s = o - A.nx, w = o - 1;
@@ -404,18 +478,18 @@ __global__ __launch_bounds__(TX *TY * 2) void cg_stress_u_step(EvpCgrid A, int l
     // the waves in flight: grids of gx1's size are latency-, not bandwidth-bound); blockDim.z == 1: one thread does both
     const bool doE = blockDim.z == 1 || threadIdx.z == 0, doN = blockDim.z == 1 || threadIdx.z == 1;
     double etaU;
-    const double s12c = s12u_new(A, o, (m & 2u) != 0, relax, &etaU);
-    const double s12s = doE ? s12u_new(A, s, (A.mask[s] & 32u) != 0, relax, nullptr) : 0.0;
-    const double s12w = doN ? s12u_new(A, w, (A.mask[w] & 32u) != 0, relax, nullptr) : 0.0;
+    const double s12c = s12u_new(A, G, o, (m & 2u) != 0, relax, &etaU);
+    const double s12s = doE ? s12u_new(A, G, s, (A.mask[s] & 32u) != 0, relax, nullptr) : 0.0;
+    const double s12w = doN ? s12u_new(A, G, w, (A.mask[w] & 32u) != 0, relax, nullptr) : 0.0;
     const double *sp = A.f[CF_SP], *sm = A.f[CF_SM];
     const double spc = sp[o], smc = sm[o];
     const EvpScalars &p = A.p;
     // both faces computed for every interior cell (all loads in bounds and issued together); stores by mask
     double unew = 0.0, vnew = 0.0, strintx = 0.0, strinty = 0.0, taubx = 0.0, tauby = 0.0;
     if (doE) {
-        const double *dyT = A.g[CG_DYT], *dxU = A.g[CG_DXU];
-        const double dyE = A.g[CG_DYE][o], dxE = A.g[CG_DXE][o];
-        strintx = (FAST ? A.g[CG_EAREAR][o] : A.in[CI_RHEOE][o] * A.g[CG_EAREAR][o]) *
+        const auto dyT = G[CG_DYT], dxU = G[CG_DXU];
+        const double dyE = G[CG_DYE][o], dxE = G[CG_DXE][o];
+        strintx = (FAST ? G[CG_EAREAR][o] : A.in[CI_RHEOE][o] * G[CG_EAREAR][o]) *
                   (0.5 * dyE * (sp[e] - spc) + (0.5 / dyE) * ((dyT[e] * dyT[e]) * sm[e] - (dyT[o] * dyT[o]) * smc) +
                    (1.0 / dxE) * ((dxU[o] * dxU[o]) * s12c - (dxU[s] * dxU[s]) * s12s));
         const double uold = A.f[CF_UE][o], vold = A.f[CF_VE][o];
@@ -436,9 +510,9 @@ __global__ __launch_bounds__(TX *TY * 2) void cg_stress_u_step(EvpCgrid A, int l
         taubx = -unew * Cb;
     }
     if (doN) {
-        const double *dxT = A.g[CG_DXT], *dyU = A.g[CG_DYU];
-        const double dxN = A.g[CG_DXN][o], dyN = A.g[CG_DYN][o];
-        strinty = (FAST ? A.g[CG_NAREAR][o] : A.in[CI_RHEON][o] * A.g[CG_NAREAR][o]) *
+        const auto dxT = G[CG_DXT], dyU = G[CG_DYU];
+        const double dxN = G[CG_DXN][o], dyN = G[CG_DYN][o];
+        strinty = (FAST ? G[CG_NAREAR][o] : A.in[CI_RHEON][o] * G[CG_NAREAR][o]) *
                   (0.5 * dxN * (sp[n] - spc) - (0.5 / dxN) * ((dxT[n] * dxT[n]) * sm[n] - (dxT[o] * dxT[o]) * smc) +
                    (1.0 / dyN) * ((dyU[o] * dyU[o]) * s12c - (dyU[w] * dyU[w]) * s12w));
         const double uold = A.f[CF_UN][o], vold = A.f[CF_VN][o];
@@ -757,58 +831,6 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 // no exchange overwrites) is kept up by the workgroup that owns the neighbouring interior cell, with the ghost cell's own
 // metrics and history.
 // =====================================================================
-// array k of a table that is one allocation: base + k * stride (a scalar multiply-add where it is used, instead of
-// one kernel-argument pointer per array held in scalar registers from the top of the kernel)
-struct Slab {
-    const double *base;
-    size_t stride;
-    __device__ __forceinline__ const double *operator[](int k) const { return base + (size_t)k * stride; }
-};
-// The same table with 15 of its 23 arrays DERIVED from the other eight instead of loaded (cg_one is HBM-bound on large
-// grids, and nearly half of its bytes per cell are static geometry): the reference computes them once at start-up as
-//   tarea = dxT*dyT, uarea = dxU*dyU, narea = dxN*dyN, earea = dxE*dyE          (ice_grid.F90:681-684)
-//   earear = 1/earea, narear = 1/narea where the area is > 0, else 0            (ice_grid.F90:706-715)
-//   ratiodxN = -dxN(i+1,j)/dxN(i,j), ratiodyE = -dyE(i,j+1)/dyE(i,j), ratiodxNr = 1/ratiodxN, ratiodyEr = 1/ratiodyE
-//                                                                               (ice_dyn_evp.F90:235-238)
-//   DminTarea = deltaminEVP*tarea                                               (ice_dyn_shared.F90: init_dyn_shared)
-//   hm, uvm, npm, epm: land masks, 0 or 1                                       (ice_grid.F90:979, 3382-3385)
-// cice_evp_hip_cgrid_set_geometry checks every one of these identities BIT FOR BIT on the caller's arrays (all cells the
-// kernel can read) and hands out this view only if all hold, so a derived value IS the array's value; the masks travel
-// as four bits of one byte.  k is a constant at every use: the switch folds.
-struct DSlab {
-    const double *base;
-    size_t stride;
-    const uint8_t *gm;              // bit 0 epm, 1 npm, 2 uvm, 3 hm
-    int nx;
-    double dmin;
-    struct Acc {
-        const DSlab &S;
-        int k;
-        __device__ __forceinline__ double raw(int a, size_t p) const { return S.base[(size_t)a * S.stride + p]; }
-        __device__ __forceinline__ double operator[](size_t p) const
-        {
-            switch (k) {
-            case CG_TAREA: return raw(CG_DXT, p) * raw(CG_DYT, p);
-            case CG_UAREA: return raw(CG_DXU, p) * raw(CG_DYU, p);
-            case CG_NAREA: return raw(CG_DXN, p) * raw(CG_DYN, p);
-            case CG_EAREA: return raw(CG_DXE, p) * raw(CG_DYE, p);
-            case CG_EAREAR: { const double a = raw(CG_DXE, p) * raw(CG_DYE, p); return a > 0.0 ? 1.0 / a : 0.0; }
-            case CG_NAREAR: { const double a = raw(CG_DXN, p) * raw(CG_DYN, p); return a > 0.0 ? 1.0 / a : 0.0; }
-            case CG_DMINT: return S.dmin * (raw(CG_DXT, p) * raw(CG_DYT, p));
-            case CG_RXN: return -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
-            case CG_RXNR: return 1.0 / -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
-            case CG_RYE: return -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
-            case CG_RYER: return 1.0 / -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
-            case CG_EPM: return (S.gm[p] & 1u) ? 1.0 : 0.0;
-            case CG_NPM: return (S.gm[p] & 2u) ? 1.0 : 0.0;
-            case CG_UVM: return (S.gm[p] & 4u) ? 1.0 : 0.0;
-            case CG_HM: return (S.gm[p] & 8u) ? 1.0 : 0.0;
-            default: return raw(k, p);
-            }
-        }
-    };
-    __device__ __forceinline__ Acc operator[](int k) const { return Acc{*this, k}; }
-};
 template <bool GEO> struct GeoView;
 template <> struct GeoView<false> {
     static __device__ __forceinline__ Slab make(const EvpCgrid &, const EvpCgOne &T) { return Slab{T.gbase, T.stride}; }
@@ -1151,11 +1173,24 @@ void evp_launch_cgrid_phase(const EvpCgrid &A, int phase, int last, hipStream_t 
     const dim3 grid = cg_grid(A), block(TX, TY);
     switch (phase) {
     case 0: hipLaunchKernelGGL(cg_strain_u, grid, block, 0, st, A); break;
-    case 1: hipLaunchKernelGGL(cg_stress_t<true>, grid, block, 0, st, A, last); break;
-    case 10: hipLaunchKernelGGL(cg_stress_t<false>, grid, block, 0, st, A, last); break;
-    case 7: hipLaunchKernelGGL(cg_avg_strain, grid, block, 0, st, A, last); break;
-    case 8: hipLaunchKernelGGL(cg_stress_u_step<false>, grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last); break;
-    case 11: hipLaunchKernelGGL(cg_stress_u_step<true>, grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last); break;
+    // (A.gmask set: the fused kernels derive 15 of the 23 static arrays like cg_one does; the five-phase kernels always load)
+    case 1: hipLaunchKernelGGL((cg_stress_t<true, false>), grid, block, 0, st, A, last); break;
+    case 10:
+        if (A.gmask) hipLaunchKernelGGL((cg_stress_t<false, true>), grid, block, 0, st, A, last);
+        else hipLaunchKernelGGL((cg_stress_t<false, false>), grid, block, 0, st, A, last);
+        break;
+    case 7:
+        if (A.gmask) hipLaunchKernelGGL(cg_avg_strain<true>, grid, block, 0, st, A, last);
+        else hipLaunchKernelGGL(cg_avg_strain<false>, grid, block, 0, st, A, last);
+        break;
+    case 8:
+        if (A.gmask) hipLaunchKernelGGL((cg_stress_u_step<false, true>), grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last);
+        else hipLaunchKernelGGL((cg_stress_u_step<false, false>), grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last);
+        break;
+    case 11:
+        if (A.gmask) hipLaunchKernelGGL((cg_stress_u_step<true, true>), grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last);
+        else hipLaunchKernelGGL((cg_stress_u_step<true, false>), grid, dim3(TX, TY, A.split_faces ? 2 : 1), 0, st, A, last);
+        break;
     case 9: hipLaunchKernelGGL(cg_fill_images, grid, block, 0, st, A, last); break;
     case 2: hipLaunchKernelGGL(cg_stress_u, grid, block, 0, st, A); break;
     case 3: hipLaunchKernelGGL(cg_step, grid, block, 0, st, A); break;

@@ -364,6 +364,8 @@ struct EvpCgrid {
     double *f[CG_NF];
     const double *in[CG_NIN];
     const double *g[CG_NG];
+    const uint8_t *gmask;         // non-null: the fused kernels derive 15 of the 23 static arrays (as cg_one does; the host verified the
+    size_t gstride;               // identities); the four land masks as bits; g[k] = g[0] + k * gstride
     const double *strengthU;      // visc_method = 'avg_strength': T->U average of the strength (once per call)
     const uint8_t *mask;          // bit0 iceT, bit1 iceU, bit2 iceE, bit3 iceN, bit4: the cell has ghost images,
                                   // bit5: iceU of the cell, or of the interior cell this ghost cell mirrors

@@ -100,12 +100,15 @@ void cgrid_free()
     CG = CGridState();
 }
 
+static bool geo_derived();
 static void fill(EvpCgrid &A)
 {
     const cice_evp_hip_params &q = S.prm;
     for (int k = 0; k < CG_NF; ++k) A.f[k] = CG.f[k];
     for (int k = 0; k < CG_NIN; ++k) A.in[k] = CG.in[k];
     for (int k = 0; k < CG_NG; ++k) A.g[k] = CG.g[k];
+    A.gmask = geo_derived() ? CG.gmask : nullptr;
+    A.gstride = S.n;
     A.strengthU = CG.strengthU;
     A.s12_in = nullptr;
     A.facE = CG.fac[0];
@@ -504,8 +507,9 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
     if (tripole && P.fold_rows == 1)             // (ranks without the fold rows run the same schedule with empty lists)
         if (int rc = build_fold_lists()) return rc;
-    if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3) {
+    if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3)
         if (int rc = build_one_tables()) return rc;
+    if (!tripole) {      // (the five-phase kernels of tripole grids always load all 23)
         const std::vector<uint8_t> gm = derive_geometry_check(static23, CG.geo_why);
         if (!gm.empty()) {
             HIPC(hipMalloc((void **)&CG.gmask, S.n));

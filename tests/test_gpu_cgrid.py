@@ -256,13 +256,18 @@ def test_cgrid_one_launch_schedule_agrees(name, one, monkeypatch):
 
 @pytest.mark.parametrize("name", ["cgrid_cyccyc_2x2_cap0_ktens", "cgrid_closed_2x2_revp", "cgrid_cyc_1blk_seabed",
                                   "cgrid_cyc_3x2pad_cap05_avgstrength"])
-@pytest.mark.parametrize("shape", ["0", "2"])
+@pytest.mark.parametrize("shape", ["0", "2", "three_launches"])
 def test_cgrid_all_static_arrays_loaded_agrees(name, shape, monkeypatch):
-    """cg_one derives 15 of its 23 static arrays from the eight dx / dy arrays by default (the other tests); with
-    CICE_EVP_HIP_CGRID_GEO=0 it loads all 23, as before: the same bits, against the reference's arrays."""
+    """cg_one and the three fused kernels derive 15 of the 23 static arrays from the eight dx / dy arrays by default (the other
+    tests); with CICE_EVP_HIP_CGRID_GEO=0 they load all 23, as before: the same bits, against the reference's arrays."""
     c = GoldenCase(name)
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_GEO", "0")
-    monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", shape)
+    if shape == "three_launches":
+        if str(c.d["visc_method"]) != "avg_zeta":
+            pytest.skip("avg_strength without cg_one runs the five phases, which always load")
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE", "0")
+    else:
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", shape)
     core = cgrid_core(c)
     try:
         state, inputs, masks = c.cgrid_inputs(1)
@@ -271,7 +276,7 @@ def test_cgrid_all_static_arrays_loaded_agrees(name, shape, monkeypatch):
         visc = str(c.d["visc_method"])
         out = core.cgrid_run(nsub, state, inputs, masks, visc_method=visc)
         t = core.cgrid_timings()
-        assert t["one_launch_subcycles"] == nsub - 1 and not t["geometry_derived"], t
+        assert t["one_launch_subcycles"] == (0 if shape == "three_launches" else nsub - 1) and not t["geometry_derived"], t
         oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
         oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
         assert_bitwise(out, c.cgrid_expected(1, nsub), "CICE_EVP_HIP_CGRID_GEO=0")
