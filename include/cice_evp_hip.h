@@ -168,6 +168,10 @@ int cice_evp_hip_sync(void);
  * symmetric across the seam -- what evp() does with 12 x ice_HaloUpdate_stress on the host arrays
  * right after the subcycle loop (ice_dyn_evp.F90:1321-1389; ice_boundary.F90:7441-7826): the
  * ghost row NY+1 of component c takes the mirrored top physical row of its partner (1<->3, 2<->4).
+ * On a tripoleT grid the same twelve calls (T-fold offsets, ice_boundary.F90:7697-7722) rewrite the top
+ * PHYSICAL row of components 1 and 2 from the partner's mirrored cell, leave 3 and 4 with plain images in
+ * the east-west ghost cells of that row, and touch one cell of the ghost row: the north-west corner ghost
+ * cell of every top-row block (pinned on the reference's own output).
  * Call between cice_evp_hip_subcycle and cice_evp_hip_download; no-op on other grids.            */
 int cice_evp_hip_stress_halo(void);
 /* 1 if cice_evp_hip_stress_halo can do that on this rank layout (tripole: always; tripoleT: the top row on one rank and no
