@@ -808,13 +808,18 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 // One launch per subcycle (grids small enough to be launch- and latency-bound; one rank, no fold, avg_zeta).
 //
 // A workgroup of ONE_X x ONE_Y threads covers a window of the grid, one thread per position; the inner
-// (ONE_X-3) x (ONE_Y-3) positions are the cells it owns.  Three levels, two workgroup barriers, nothing leaves the chip
+// (ONE_X-3) x (ONE_Y-3) positions are the cells it owns.  Four levels, three workgroup barriers, nothing leaves the chip
 // in between:
 //   S  strain_rates_U at every position of the window (from the PREVIOUS subcycle's face velocities, read from
 //      global memory around the cell itself, averages recomputed as in cg_avg_strain)              -> shearU in LDS
 //   T  stressC_T at the positions with tx, ty >= 1 (shearU of the four corners from LDS)            -> etax2T,
 //      stresspT, stressmT in LDS
-//   C  viscosity at the corners + stressC_U + div_stress + stepu_C / stepv_C on the owned cells (as cg_stress_u_step).
+//   U  viscosity at the corner + stressC_U at the positions with tx <= X-2, ty <= Y-2 (etax2T of the four T neighbours from
+//      LDS)                                                                                        -> stress12U in LDS
+//   C  div_stress + stepu_C / stepv_C on the owned cells (stress12U of the own, south and west corner from LDS).
+//      (Until late round 4 level C evaluated stressC_U at its three corners itself -- each corner three times per window: a
+//      fourth level costs a barrier and saves two T -> U averages or, visc_method = avg_strength, two visc_replpress per cell:
+//      3600 x 2400 avg_strength 897 -> 835 us, avg_zeta 808 -> 802, ten registers fewer.)
 // Positions outside the owned cells recompute what a neighbouring workgroup also computes, so no workgroup waits
 // for another one; what a workgroup reads of its neighbours is the previous subcycle's state only, which is why
 // uvelE, vvelN, stresspT, stressmT (and stress12U, as before) ping-pong between two buffers.
@@ -878,6 +883,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     __shared__ double s_sh[ONE_Y][ONE_X], s_un[ONE_Y][ONE_X], s_ve[ONE_Y][ONE_X];
     __shared__ double s_eta[ONE_Y][ONE_X], s_sp[ONE_Y][ONE_X], s_sm[ONE_Y][ONE_X];
     __shared__ double s_dl[ONE_Y][ONE_X];            // deltaU (visc_method = avg_strength: the corner viscosities come from it)
+    __shared__ double s_s12[ONE_Y][ONE_X];           // stress12U of this subcycle
     // workgroups go to the XCDs round-robin: XCD x gets the x-th contiguous run of the (space-ordered) window list
     // (A launch of only as many workgroups as are resident at once, each looping over several windows with the LDS arrays
     // doubled -- the 1024-thread workgroup of the 64 x 16 window is alone on its CU, and tools/cgrid_phases.py shows the CU
@@ -1011,38 +1017,39 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     // workgroup's first loads find them on their way -- was built and measured: level S did not get shorter (14.5k cycles
     // against 13.8k), level C more than twice as long: 3600 x 2400 1134 us against 799.  The loads are not waiting for a cold
     // miss, the memory system is busy; more requests make it worse.)
+    // ---- U ---- stress12U (stressC_U, with the T -> U average of etax2T or the corner's own viscosity) ONCE per position that has
+    // its four T neighbours in the window, AT the cell the position's value comes from -- what the owner stores and the
+    // exchange copies; level C reads the three corners it needs (own, south, west) from LDS instead of evaluating each itself
+    double etaU = 0.0;
+    {
+        double s12v = A.s12_in[L];
+        if (!stat && tx <= ONE_X - 2 && ty <= ONE_Y - 2) {
+            double e2;
+            if (AVGS) {
+                // visc_method = avg_strength: viscosity from the T -> U average of the strength and the corner's own Delta
+                // (ice_dyn_evp.F90:992-996)
+                double z, r;
+                visc_replpress(A.p, A.strengthU[L], A.deltaminEVP * G[CG_UAREA][L], s_dl[ty][tx], z, e2, r);
+            } else {
+                // T -> U average of etax2T (avg_t2u) from the values in LDS
+                const auto hm = G[CG_HM], ta = G[CG_TAREA];
+                const size_t pp = L, pe = pp + 1, pn = pp + nx, pne = pn + 1;
+                const double wtmp = (hm[pp] * ta[pp] + hm[pe] * ta[pe] + hm[pn] * ta[pn] + hm[pne] * ta[pne]);
+                e2 = wtmp == 0.0 ? 0.0
+                                 : (hm[pp] * s_eta[ty][tx] * ta[pp] + hm[pe] * s_eta[ty][tx + 1] * ta[pe] + hm[pn] * s_eta[ty + 1][tx] * ta[pn] +
+                                    hm[pne] * s_eta[ty + 1][tx + 1] * ta[pne]) / wtmp;
+            }
+            etaU = e2;
+            const double upd = (s12v * relax + A.p.arlx1i * 0.5 * e2 * s_sh[ty][tx]) * A.p.denom1;
+            if (m & 2u) s12v = upd;
+        }
+        s_s12[ty][tx] = s12v;
+    }
+    __syncthreads();
     if (!own) return;
     {
         const size_t o = L, e = o + 1, n = o + nx, s = o - nx, w = o - 1;
-        const auto hm = G[CG_HM], ta = G[CG_TAREA];
-        // T -> U average of etax2T (avg_t2u) at the corners o, s, w from the values in LDS
-        auto eta_u = [&](size_t p, int px, int py) {
-            const size_t pe = p + 1, pn = p + nx, pne = pn + 1;
-            const double wtmp = (hm[p] * ta[p] + hm[pe] * ta[pe] + hm[pn] * ta[pn] + hm[pne] * ta[pne]);
-            if (wtmp == 0.0) return 0.0;
-            return (hm[p] * s_eta[py][px] * ta[p] + hm[pe] * s_eta[py][px + 1] * ta[pe] + hm[pn] * s_eta[py + 1][px] * ta[pn] +
-                    hm[pne] * s_eta[py + 1][px + 1] * ta[pne]) / wtmp;
-        };
-        // visc_method = avg_strength: viscosity from the T -> U average of the strength and the corner's own Delta
-        // (ice_dyn_evp.F90:992-996), taken AT the cell the corner's value comes from (table), as S and T are
-        auto eta_s = [&](int px, int py) {
-            const int lp = T.tab[(size_t)t * (ONE_X * ONE_Y) + py * ONE_X + px];
-            if (lp < 0) return 0.0;                    // a ghost cell nothing is copied into: its stress12U is never updated
-            double z, e2, r;
-            visc_replpress(A.p, A.strengthU[lp], A.deltaminEVP * G[CG_UAREA][lp], s_dl[py][px], z, e2, r);
-            return e2;
-        };
-        auto s12u = [&](size_t p, int px, int py, bool ice, double *etaU) {
-            const double old = A.s12_in[p];
-            const double e2 = AVGS ? eta_s(px, py) : eta_u(p, px, py);
-            if (etaU) *etaU = e2;
-            const double upd = (old * relax + A.p.arlx1i * 0.5 * e2 * s_sh[py][px]) * A.p.denom1;
-            return ice ? upd : old;
-        };
-        double etaU;
-        const double s12c = s12u(o, tx, ty, (m & 2u) != 0, &etaU);
-        const double s12s = s12u(s, tx, ty - 1, (A.mask[s] & 32u) != 0, nullptr);
-        const double s12w = s12u(w, tx - 1, ty, (A.mask[w] & 32u) != 0, nullptr);
+        const double s12c = s_s12[ty][tx], s12s = s_s12[ty - 1][tx], s12w = s_s12[ty][tx - 1];
         const double spc = s_sp[ty][tx], smc = s_sm[ty][tx];
         const double spe = s_sp[ty][tx + 1], sme = s_sm[ty][tx + 1], spn = s_sp[ty + 1][tx], smn = s_sm[ty + 1][tx];
         const EvpScalars &p = A.p;
