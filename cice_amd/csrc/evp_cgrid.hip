@@ -66,6 +66,7 @@ __device__ __forceinline__ void visc_replpress(const EvpScalars &p, double stren
 // array k of a table that is one allocation: base + k * stride (a scalar multiply-add where it is used, instead of
 // one kernel-argument pointer per array held in scalar registers from the top of the kernel)
 struct Slab {
+    static constexpr bool derived = false;
     const double *base;
     size_t stride;
     __device__ __forceinline__ const double *operator[](int k) const { return base + (size_t)k * stride; }
@@ -82,6 +83,7 @@ struct Slab {
 // kernel can read) and hands out this view only if all hold, so a derived value IS the array's value; the masks travel
 // as four bits of one byte.  k is a constant at every use: the switch folds.
 struct DSlab {
+    static constexpr bool derived = true;
     const double *base;
     size_t stride;
     const uint8_t *gm;              // bit 0 epm, 1 npm, 2 uvm, 3 hm
@@ -118,6 +120,7 @@ struct DSlab {
 // the fused (three-launch) kernels see the static table through the same two views: the kernel argument's pointer array, or
 // the derived one (A.gmask set: the arrays are one allocation, A.g[k] = A.g[0] + k * A.gstride)
 struct PtrTab {
+    static constexpr bool derived = false;
     const double *const *g;
     __device__ __forceinline__ const double *operator[](int k) const { return g[k]; }
 };
@@ -172,8 +175,19 @@ __device__ __forceinline__ void strain_u(const EvpCgrid &A, const GT &G, size_t 
     const auto epm = G[CG_EPM], npm = G[CG_NPM];
     const double dxU = G[CG_DXU][o], dyU = G[CG_DYU][o];
     const double ddyN = G[CG_DYN][e] - G[CG_DYN][o], ddxE = G[CG_DXE][n] - G[CG_DXE][o];
-    const double rxN = G[CG_RXN][o], rxNr = G[CG_RXNR][o], ryE = G[CG_RYE][o], ryEr = G[CG_RYER][o];
     const double npc = npm[o], npe = npm[e], epc = epm[o], epn = epm[n];
+    // The four boundary-condition ratios only ever meet the factor (npc - npe) or (epc - epn), which is +0 away from a coast:
+    // (+0 * mask) * ratio * velocity has the same bits for ANY finite negative ratio.  With the derived view (the host has
+    // checked that every ratio is finite and negative) they are therefore worked out -- two divisions each pair -- only by
+    // the waves that hold a coastal corner; everybody else takes -1.
+    double rxN, rxNr, ryE, ryEr;
+    if (GT::derived) {
+        const bool nd = npc != npe, ed = epc != epn;
+        rxN = nd ? G[CG_RXN][o] : -1.0; rxNr = nd ? G[CG_RXNR][o] : -1.0;
+        ryE = ed ? G[CG_RYE][o] : -1.0; ryEr = ed ? G[CG_RYER][o] : -1.0;
+    } else {
+        rxN = G[CG_RXN][o]; rxNr = G[CG_RXNR][o]; ryE = G[CG_RYE][o]; ryEr = G[CG_RYER][o];
+    }
     const double uNip1j = v.uNe * npe + (npc - npe) * npc * rxN * v.uNo;
     const double uNij = v.uNo * npc + (npe - npc) * npe * rxNr * v.uNe;
     const double vEijp1 = v.vEn * epn + (epc - epn) * epc * ryE * v.vEo;
@@ -199,8 +213,19 @@ __device__ __forceinline__ double shear_u(const EvpCgrid &A, const GT &G, size_t
     const auto epm = G[CG_EPM], npm = G[CG_NPM];
     const double dxU = G[CG_DXU][o], dyU = G[CG_DYU][o];
     const double ddyN = G[CG_DYN][e] - G[CG_DYN][o], ddxE = G[CG_DXE][n] - G[CG_DXE][o];
-    const double rxN = G[CG_RXN][o], rxNr = G[CG_RXNR][o], ryE = G[CG_RYE][o], ryEr = G[CG_RYER][o];
     const double npc = npm[o], npe = npm[e], epc = epm[o], epn = epm[n];
+    // The four boundary-condition ratios only ever meet the factor (npc - npe) or (epc - epn), which is +0 away from a coast:
+    // (+0 * mask) * ratio * velocity has the same bits for ANY finite negative ratio.  With the derived view (the host has
+    // checked that every ratio is finite and negative) they are therefore worked out -- two divisions each pair -- only by
+    // the waves that hold a coastal corner; everybody else takes -1.
+    double rxN, rxNr, ryE, ryEr;
+    if (GT::derived) {
+        const bool nd = npc != npe, ed = epc != epn;
+        rxN = nd ? G[CG_RXN][o] : -1.0; rxNr = nd ? G[CG_RXNR][o] : -1.0;
+        ryE = ed ? G[CG_RYE][o] : -1.0; ryEr = ed ? G[CG_RYER][o] : -1.0;
+    } else {
+        rxN = G[CG_RXN][o]; rxNr = G[CG_RXNR][o]; ryE = G[CG_RYE][o]; ryEr = G[CG_RYER][o];
+    }
     const double uEijp1 = uEn * epn + (epc - epn) * epc * ryE * uEo;
     const double uEij = uEo * epc + (epn - epc) * epn * ryEr * uEn;
     const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;

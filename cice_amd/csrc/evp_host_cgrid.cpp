@@ -12,6 +12,8 @@
 // ice_HaloUpdate.  Tripole (u-fold) grids: a fold step per exchange point from host-built lists (halo_plan.cpp:
 // build_fold_list), the blocks next to the fold on one rank.
 // =====================================================================
+#include <cmath>
+
 #include "evp_host.h"
 
 namespace evp_host {
@@ -274,6 +276,9 @@ static std::vector<uint8_t> derive_geometry_check(const double *const *g, std::s
                     const double rx = -(g[CG_DXN][p + 1] / g[CG_DXN][p]), ry = -(g[CG_DYE][p + nxb] / g[CG_DYE][p]);
                     if (!same(rx, g[CG_RXN][p]) || !same(1.0 / rx, g[CG_RXNR][p])) return bad("ratiodxN / ratiodxNr", b, i, j);
                     if (!same(ry, g[CG_RYE][p]) || !same(1.0 / ry, g[CG_RYER][p])) return bad("ratiodyE / ratiodyEr", b, i, j);
+                    // (finite and negative: the kernels put -1 in their place wherever the factor next to them is +0)
+                    if (!(rx < 0.0 && ry < 0.0 && std::isfinite(rx) && std::isfinite(ry) && std::isfinite(1.0 / rx) && std::isfinite(1.0 / ry)))
+                        return bad("a boundary ratio (not finite and negative)", b, i, j);
                 }
             }
     return gm;
