@@ -56,8 +56,15 @@ __device__ __forceinline__ void push(const EvpCgrid &A, size_t c, unsigned m, in
 __device__ __forceinline__ void visc_replpress(const EvpScalars &p, double strength, double DminArea, double Delta,
                                                double &zetax2, double &etax2, double &rep_prs)
 {
-    const double tmpcalc = p.capping * (strength / fmax(Delta, DminArea)) +
-                           (1.0 - p.capping) * (strength / (Delta + DminArea));
+    // capping = 1 (the default, capping_method 'max'): the second quotient is multiplied by (1 - 1) = +0 and the product added --
+    // a zero of the quotient's sign, which is the first quotient's sign too, so the sum IS the first quotient, bit for bit,
+    // whenever the second one is finite (DminArea > 0 makes both denominators positive; a finite strength).  One division
+    // instead of two; any other case takes the reference's expression.
+    double tmpcalc;
+    if (p.capping == 1.0 && DminArea > 0.0 && fabs(strength) <= 1.7976931348623157e308)
+        tmpcalc = strength / fmax(Delta, DminArea);
+    else
+        tmpcalc = p.capping * (strength / fmax(Delta, DminArea)) + (1.0 - p.capping) * (strength / (Delta + DminArea));
     zetax2 = (1.0 + p.Ktens) * tmpcalc;
     rep_prs = (1.0 - p.Ktens) * tmpcalc * Delta;
     etax2 = p.epp2i * zetax2;
