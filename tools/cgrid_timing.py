@@ -11,6 +11,10 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from cice_amd import decomp, evp, synth  # noqa: E402
 
+import os  # noqa: E402
+if os.environ.get("EVP_TIMING_LIB"):          # A/B on one box: time another build of the library (e.g. the previous commit's)
+    evp.LIB_PATH = Path(os.environ["EVP_TIMING_LIB"]).resolve()
+
 
 def case(grid, case_="full", bs=None):
     spec = synth.GRIDS[grid]
