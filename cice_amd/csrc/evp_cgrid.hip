@@ -851,7 +851,8 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 //   C  div_stress + stepu_C / stepv_C on the owned cells (stress12U of the own, south and west corner from LDS).
 //      (Until late round 4 level C evaluated stressC_U at its three corners itself -- each corner three times per window: a
 //      fourth level costs a barrier and saves two T -> U averages or, visc_method = avg_strength, two visc_replpress per cell:
-//      3600 x 2400 avg_strength 897 -> 835 us, avg_zeta 808 -> 802, ten registers fewer.)
+//      same box, libraries alternating: 3600 x 2400 avg_strength 876 -> 826 us, avg_zeta 784 -> 769, gx1 17.7 -> 17.3; ten
+//      registers fewer.  Handing level T's west operands over between lanes instead of loading them: 2-4 % slower, taken out.)
 // Positions outside the owned cells recompute what a neighbouring workgroup also computes, so no workgroup waits
 // for another one; what a workgroup reads of its neighbours is the previous subcycle's state only, which is why
 // uvelE, vvelN, stresspT, stressmT (and stress12U, as before) ping-pong between two buffers.
