@@ -941,12 +941,16 @@ int cice_evp_hip_describe_path(char *buf, int32_t n)
                                                            : "on-chip resident (flags)")
                          : (M.last_call ? "two subcycles per pass (marching)" : "one subcycle per launch (streaming)");
     const char *transport = S.plan.peers.empty() ? "none (one rank)" : (S.direct.on ? "mailbox over HIP IPC" : (S.have_comm ? "RCCL send/recv" : "not set up"));
-    std::snprintf(buf, (size_t)n, "rank %d of %d: kernel = %s; halo transport = %s%s%s; two-subcycle path: %s%s%s; blocks %d, cells per exchange %d",
+    const char *ring = (M.mode == 1 && !S.plan.peers.empty())
+                           ? (M.direct == 1 ? " (ring between ranks: stores into HIP-IPC-mapped inboxes)"
+                                            : (M.direct == 2 ? " (ring between ranks: RCCL send/recv, direct stores on trial)" : " (ring between ranks: RCCL send/recv)"))
+                           : "";
+    std::snprintf(buf, (size_t)n, "rank %d of %d: kernel = %s; halo transport = %s%s%s; two-subcycle path: %s%s%s%s; blocks %d, cells per exchange %d",
                   (int)S.d.rank, (int)std::max(1, (int)S.d.nranks), kernel, transport,
                   (!S.plan.peers.empty() && !S.direct.on && !S.direct.why.empty()) ? " (mailbox off: " : "",
                   (!S.plan.peers.empty() && !S.direct.on && !S.direct.why.empty()) ? (S.direct.why + ")").c_str() : "",
                   M.mode == 1 ? "on" : (M.mode == 0 ? "off" : "undecided"), (M.mode == 0 && !M.why.empty()) ? " -- " : "",
-                  (M.mode == 0 && !M.why.empty()) ? M.why.c_str() : "", (int)S.d.nblocks, (int)(S.msk.on ? S.msk.n_send : S.n_send));
+                  (M.mode == 0 && !M.why.empty()) ? M.why.c_str() : "", ring, (int)S.d.nblocks, (int)(S.msk.on ? S.msk.n_send : S.n_send));
     return 0;
 }
 
