@@ -17,6 +17,9 @@ sys.path[:0] = [R, R + "/tests", R + "/oracle"]
 import numpy as np
 from cice_amd import decomp, evp, synth
 
+if os.environ.get("EVP_TIMING_LIB"):          # A/B on one box: time another build of the library
+    evp.LIB_PATH = Path(os.environ["EVP_TIMING_LIB"]).resolve()
+
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 flags = {a for a in sys.argv[1:] if a.startswith("--")}
 nx, ny = int(args[0]), int(args[1])
