@@ -34,6 +34,7 @@ What the line carries besides the contract's fields:
 from __future__ import annotations
 
 import argparse
+import contextlib
 import ctypes as C
 import hashlib
 import json
@@ -282,6 +283,22 @@ def reference_parity(nx, ny, ndte, case, td):
 
 
 # ----------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def quiet_interpreter():
+    """Per-call timings: collect the interpreter's garbage first (earlier measurements leave multi-GB arrays whose release
+    took 45-56 ms of one call in ten when a collection happened to fall into it) and keep the collector off meanwhile,
+    as timeit does."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def main():
     a = parse()
     a.strict = not a.fused
@@ -660,10 +677,11 @@ def main():
                 for _ in range(2):
                     fn()
                 each = []
-                for _ in range(10):
-                    t1 = time.perf_counter()
-                    fn()
-                    each.append(1e3 * (time.perf_counter() - t1))
+                with quiet_interpreter():
+                    for _ in range(10):
+                        t1 = time.perf_counter()
+                        fn()
+                        each.append(1e3 * (time.perf_counter() - t1))
                 tt = core.cgrid_timings()
                 res[label] = dict(ms_per_call=float(np.median(each)), loop_ms=tt["loop_ms"], slowest_of_10=max(each))
                 if label.startswith("device"):
@@ -700,12 +718,12 @@ def main():
                     core.run_inplace(work, tmc, umc, ndte)
                 n = 10
                 each = []
-                for _ in range(n):
-                    t1 = time.perf_counter()
-                    core.run_inplace(work, tmc, umc, ndte)
-                    each.append(1e3 * (time.perf_counter() - t1))
-                t = float(np.median(each)) * 1e-3        # median: one call in ten may pay for the interpreter releasing
-                #                                          the previous measurement's multi-GB arrays (seen: 56 ms once)
+                with quiet_interpreter():
+                    for _ in range(n):
+                        t1 = time.perf_counter()
+                        core.run_inplace(work, tmc, umc, ndte)
+                        each.append(1e3 * (time.perf_counter() - t1))
+                t = float(np.median(each)) * 1e-3
                 if os.environ.get("CICE_EVP_BENCH_DEBUG"):
                     print(f"[bench] per-call {label}: " + " ".join(f"{x:.2f}" for x in each), file=sys.stderr)
                 tt = core.timings()
@@ -775,7 +793,8 @@ def main():
             for label, itab, otab in (("shim_default_stresses_in_and_out", later_sig, o18),
                                       ("shim_resident_stresses_6_arrays_back", later, o6)):
                 call(itab, otab)
-                ts = np.array([call(itab, otab) for _ in range(10)])
+                with quiet_interpreter():
+                    ts = np.array([call(itab, otab) for _ in range(10)])
                 med = np.median(ts, axis=0)
                 tt = core.timings()
                 res[label] = dict(ms_per_call=float(np.median(ts.sum(axis=1))), prep_call=float(med[0]), set_strength=float(med[1]),
