@@ -807,6 +807,45 @@ __global__ __launch_bounds__(1024) void cg_fold_one(EvpCgFold F)
     }
 }
 
+// ... and with lists of at most PER x 1024 entries every thread keeps its entries in registers between the two passes: two
+// dependent memory round trips (indices, then operands) before the barrier instead of four (the tmp store and its reload),
+// on a launch whose whole duration is latency (tx1: five of these per subcycle)
+template <int PER>
+__global__ __launch_bounds__(1024) void cg_fold_reg(EvpCgFold F)
+{
+    double v[4 * PER];
+    int dd[4 * PER];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool on = q < F.nfields;                       // (uniform)
+        const EvpCgFoldList L = F.L[on ? F.loc[q] : 0];
+        const double *x = F.x[on ? q : 0];
+        const double isign = F.isign[on ? q : 0];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int k = u * 1024 + (int)threadIdx.x, id = q * PER + u;
+            dd[id] = -1;
+            v[id] = 0.0;
+            if (on && k < L.n) {
+                const int a = L.a[k], b = L.b[k];
+                const double s = L.flip[k] ? isign : 1.0;
+                dd[id] = L.dst[k];
+                const double xa = a >= 0 ? x[a] : 0.0;
+                if (b >= 0 || b == -2) v[id] = s * (0.5 * (xa + isign * (b >= 0 ? x[b] : 0.0)));
+                else v[id] = s * xa;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = q * PER + u;
+            if (dd[id] >= 0) F.x[q][dd[id]] = v[id];
+        }
+}
+
 // ---- ranks > 1: iceU of interior cells as 0/1 doubles (exchanged like a field), and back into bit5 of the mask for the
 // ghost cells that mirror cells of other ranks ----
 __global__ __launch_bounds__(TX *TY) void cg_umask_to_double(EvpCgrid A, double *d)
@@ -1192,6 +1231,14 @@ void evp_launch_cgrid_mask(const EvpCgrid &A, const int *m4, hipStream_t st)
 void evp_launch_cgrid_fold(const EvpCgFold &F, hipStream_t st)
 {
     if (F.nfields <= 0 || F.maxn <= 0) return;
+    if (F.maxn <= 1024) {            // one workgroup, one launch, values in registers
+        hipLaunchKernelGGL(cg_fold_reg<1>, dim3(1), dim3(1024), 0, st, F);
+        return;
+    }
+    if (F.maxn <= 2048) {
+        hipLaunchKernelGGL(cg_fold_reg<2>, dim3(1), dim3(1024), 0, st, F);
+        return;
+    }
     if (F.maxn <= 8192) {            // one workgroup, one launch
         hipLaunchKernelGGL(cg_fold_one, dim3(1), dim3(1024), 0, st, F);
         return;

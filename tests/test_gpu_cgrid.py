@@ -389,6 +389,10 @@ def random_cgrid_case(seed, nx, ny, bs, ew, ns, holes):
     (5, 64, 30, (64, 30), "cyclic", "tripole", 0.4, "avg_zeta", False),      # ice and holes ON the fold
     (6, 48, 24, (12, 8), "cyclic", "tripole", 0.5, "avg_strength", True),
     (7, 40, 30, (40, 30), "cyclic", "closed", 1.1, "avg_zeta", False),       # no ice at all
+    # fold lists of 1204 and 2404 entries per field: the two-entries-per-thread fold kernel and the one that stages in memory
+    # (the cases above and every tripole fixture take the one-entry-per-thread kernel; evp_cgrid.hip: cg_fold_reg / cg_fold_one)
+    (8, 600, 10, (600, 10), "cyclic", "tripole", 0.4, "avg_zeta", False),
+    (9, 1200, 8, (1200, 8), "cyclic", "tripole", 0.4, "avg_zeta", False),
 ])
 def test_cgrid_random_masks_vs_oracle_bitwise(seed, nx, ny, bs, ew, ns, holes, visc, revised):
     args = random_cgrid_case(seed, nx, ny, bs, ew, ns, holes)
