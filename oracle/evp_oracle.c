@@ -138,8 +138,22 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
          * 2 - joffset, where buffer rows 1..3 are the global rows NY-2..NY).  NE-corner fields (offsets 0, 1; no pair
          * averaging): the top physical row is the image of row NY-1, the ghost row that of row NY-2 --
          *   a(i, NY) <- isign * a(NX-i+1, NY-1),   a(i, NY+1) <- isign * a(NX-i+1, NY-2)    (ghost columns included).
-         * Only that location is restated (the B-grid loop exchanges nothing else); every other ghost cell as below. */
-        if (field_loc != 1) { fprintf(stderr, "evp_oracle_halo_update: tripoleT restated for NE-corner fields only\n"); abort(); }
+         * Cell-centre fields (offsets -1, 0; the preparation phase's T-grid updates, ice_dyn_evp.F90:413-428, 466-469): the top
+         * physical row lies ON the fold and is made symmetric first (:1568-1583: pairs i <-> NX-i+2 for i = 2..NX/2,
+         * xavg = 0.5*(x1 + isign*x2), stored as xavg and isign*xavg; i = 1 and i = NX/2+1 mirror onto themselves), then
+         *   a(i, NY) <- isign * avg(NX-i+2, NY),   a(i, NY+1) <- isign * a(NX-i+2, NY-1)    (column NX+1 is column 1).
+         * The face locations are not restated (nothing on this path exchanges them on a T-fold grid). */
+        if (field_loc != 1 && field_loc != 0) { fprintf(stderr, "evp_oracle_halo_update: tripoleT restated for NE-corner and centre fields only\n"); abort(); }
+        if (field_loc == 0) {
+            double *top = g + (size_t)(NY - 1) * NX;
+            for (int i = 2; i <= NX / 2; ++i) {
+                const int idst = NX - i + 2;
+                const double x1 = top[i - 1], x2 = top[idst - 1];
+                const double xavg = 0.5 * (x1 + isign * x2);
+                top[i - 1] = xavg;
+                top[idst - 1] = isign * xavg;
+            }
+        }
         for (int b = 0; b < d->nblocks; ++b) {
             double *ab = a + (size_t)b * nx * ny;
             const int ilo = d->ilo[b], ihi = d->ihi[b], jlo = d->jlo[b], jhi = d->jhi[b];
@@ -153,6 +167,12 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
                         ig = (ig < 1) ? ig + NX : ig - NX;
                     }
                     if (jg == NY || jg == NY + 1) {
+                        if (field_loc == 0) {
+                            int is = NX - ig + 2;
+                            if (is > NX) is -= NX;
+                            ab[IX(i, j)] = isign * g[(size_t)(jg == NY ? NY - 1 : NY - 2) * NX + (is - 1)];
+                            continue;
+                        }
                         int is = NX - ig + 1;
                         ab[IX(i, j)] = isign * g[(size_t)(jg == NY ? NY - 2 : NY - 3) * NX + (is - 1)];
                         continue;

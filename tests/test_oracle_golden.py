@@ -150,6 +150,20 @@ def test_prep_bitwise(name):
         check_prep_products(c, icall, out, f"{name} call {icall} prep")
 
 
+@pytest.mark.parametrize("name", TFOLD_CASES)
+def test_prep_tripoleT_bitwise(name):
+    """The same on ns_boundary_type = 'tripoleT': the T-grid halo updates of the preparation follow the T-fold rule of
+    cell-centre fields (top physical row made symmetric pair by pair, then rewritten from its mirror; ghost row from row
+    NY-1; ice_boundary.F90:1563-1583, 1686-1722) -- pinned on what the reference's evp() handed to its loop."""
+    c = GoldenCase(name)
+    dom = c.oracle_domain()
+    pp = oracle.PrepParams(**c.prep_scal_dict())
+    for icall in range(1, c.ncalls + 1):
+        t, state = c.prep_inputs(icall)
+        out = oracle.prep(dom, pp, c.prep_static(), t, state)
+        check_prep_products(c, icall, out, f"{name} call {icall} prep (tripoleT)")
+
+
 def test_halo_known_answer_global_index():
     """halochk method (drivers/unittest/halochk/halochk.F90:232-247): fill interiors with
     a function of the global index, update, and check every ghost cell analytically."""
