@@ -157,6 +157,11 @@ struct State {
         int32_t *c_dst = nullptr, *c_src = nullptr;
         int8_t *c_vsign = nullptr;
         int n_center = 0;
+        // tripoleT: the fold step of the cell-centre fields (halo_plan.h: center_tf_*)
+        int32_t *tf_dst = nullptr, *tf_a = nullptr, *tf_b = nullptr;
+        uint8_t *tf_flip = nullptr;
+        double *tf_tmp = nullptr;
+        int n_tf = 0;
         std::vector<uint8_t> h8;
         double t_ms = 0;
     } prep;

@@ -82,7 +82,7 @@ void free_all()
         F(Q.tmask); F(Q.umask); F(Q.umask_old); F(Q.umask_old32); F(Q.tmphm); F(Q.hm); F(Q.tarea); F(Q.uarea); F(Q.fcor); F(Q.hwater); F(Q.aicen); F(Q.vicen); F(Q.tbt); Q.ncat = 0;
         for (auto &q : Q.t) F(q);
         F(Q.tmass); F(Q.umass); F(Q.maskd); F(Q.ss_tltxU); F(Q.ss_tltyU); F(Q.strairxU); F(Q.strairyU);
-        F(Q.strtltx); F(Q.strtlty); F(Q.flagword); F(Q.c_dst); F(Q.c_src); F(Q.c_vsign);
+        F(Q.strtltx); F(Q.strtlty); F(Q.flagword); F(Q.c_dst); F(Q.c_src); F(Q.c_vsign); F(Q.tf_dst); F(Q.tf_a); F(Q.tf_b); F(Q.tf_flip); F(Q.tf_tmp);
         S.prep = State::Prep();
     }
     F(S.h_send_src);

@@ -14,7 +14,10 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
     State::Prep &Q = S.prep;
     // T-grid ghost cells owned by other ranks travel with the velocity exchange (same cells for centre and corner
     // fields) -- except across the tripole fold, where centre fields mirror other cells than corner fields do
-    if (S.plan.tfold) return fail(-9, "device preparation: not built for tripoleT grids; keep evp()'s host preparation (cice_evp_hip_run)");
+    // (tripoleT: the centre rule rewrites the top physical row -- a fold step of its own after the plain ghost copies, one rank)
+    if (S.plan.tfold && (S.plan.center_tf_remote || S.plan.center_remote))
+        return fail(-9, "device preparation on a tripoleT grid: the top row's mirror cells live on other ranks (or in an eliminated "
+                        "block) here; keep evp()'s host preparation (cice_evp_hip_run)");
     auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };
     if (B(Q.tmask) || B(Q.umask) || B(Q.umask_old) || B(Q.tmphm)) return -1;
     HIPC(hipMalloc((void **)&Q.umask_old32, S.n * sizeof(int32_t)));
@@ -40,6 +43,19 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
         HIPC(hipMemcpy(Q.c_dst, P.center_dst.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPC(hipMemcpy(Q.c_src, P.center_src.data(), Q.n_center * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPC(hipMemcpy(Q.c_vsign, P.center_vsign.data(), Q.n_center, hipMemcpyHostToDevice));
+    }
+    Q.n_tf = (int)P.center_tf_dst.size();
+    if (Q.n_tf && !Q.tf_dst) {
+        const size_t nb = (size_t)Q.n_tf * sizeof(int32_t);
+        HIPC(hipMalloc((void **)&Q.tf_dst, nb));
+        HIPC(hipMalloc((void **)&Q.tf_a, nb));
+        HIPC(hipMalloc((void **)&Q.tf_b, nb));
+        HIPC(hipMalloc((void **)&Q.tf_flip, (size_t)Q.n_tf));
+        HIPC(hipMalloc((void **)&Q.tf_tmp, (size_t)4 * Q.n_tf * sizeof(double)));
+        HIPC(hipMemcpy(Q.tf_dst, P.center_tf_dst.data(), nb, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.tf_a, P.center_tf_a.data(), nb, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.tf_b, P.center_tf_b.data(), nb, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(Q.tf_flip, P.center_tf_flip.data(), (size_t)Q.n_tf, hipMemcpyHostToDevice));
     }
     HIPC(hipStreamSynchronize(S.stream));
     Q.geo = true;
@@ -122,6 +138,26 @@ int cice_evp_hip_prep(const cice_evp_hip_prep_params *pp, const double *const *t
     // and :466-469 (calc_strair branch): strairxT, strairyT -- one launch for all ten
     halo({{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false},
           {Q.t[5], true}, {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}, {Q.t[9], true}, {Q.t[10], true}});
+    if (S.plan.tfold && Q.n_tf) {
+        // tripoleT: rows NY (on the fold: symmetrised, rewritten from its mirror) and NY+1 of the same ten fields, after the
+        // plain ghost copies (whose sources are rows the fold step does not write); the two-pass fold launch of the C grid
+        // (evp_cgrid.hip: cg_fold_reg / cg_fold_one), four fields at a time
+        const std::pair<double *, bool> arrs[10] = {{Q.maskd, false}, {Q.tmass, false}, {Q.t[3], false}, {Q.t[4], false}, {Q.t[5], true},
+                                                    {Q.t[6], true}, {Q.t[7], true}, {Q.t[8], true}, {Q.t[9], true}, {Q.t[10], true}};
+        for (int k0 = 0; k0 < 10; k0 += 4) {
+            EvpCgFold F{};
+            for (int k = k0; k < std::min(k0 + 4, 10); ++k) {
+                F.x[F.nfields] = arrs[k].first;
+                F.loc[F.nfields] = 0;
+                F.isign[F.nfields] = arrs[k].second ? -1.0 : 1.0;
+                ++F.nfields;
+            }
+            F.L[0] = {Q.tf_dst, Q.tf_a, Q.tf_b, Q.tf_flip, Q.n_tf};
+            F.tmp = Q.tf_tmp;
+            F.maxn = Q.n_tf;
+            evp_launch_cgrid_fold(F, S.stream);
+        }
+    }
     if (S.plan.center_remote) {
         // neighbours on other ranks (no tripole fold here: centre and corner fields mirror the same
         // cells, so the velocity exchange carries pairs of T-grid fields)

@@ -287,6 +287,43 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
             }
     }
 
+    if (tfold) {       // cell-centre fields on the T-fold: rows NY (on the fold) and NY+1 of this rank's blocks, ghost columns included
+        const int NX = d.nx_global, NY = d.ny_global;
+        auto cell_of = [&](int ig, int jg) -> int32_t {
+            const int k = T.find(ig, jg);
+            if (k < 0 || T.blk[k].owner != me) { plan.center_tf_remote = true; return -1; }
+            const HaloBlock &B = T.blk[k];
+            return (int32_t)((size_t)B.local * plane + (size_t)(ng + (jg - B.gj0)) * nx + (ng + (ig - B.gi0)));
+        };
+        auto it = T.by_rank.find(me);
+        if (it != T.by_rank.end())
+            for (int kb : it->second) {
+                const HaloBlock &B = T.blk[kb];
+                const int ilo = ng + 1, jlo = ng + 1, ihi = ng + B.gnx, jhi = ng + B.gny;
+                for (int j = jlo - ng; j <= jhi + ng; ++j) {
+                    const int jg = B.gj0 + (j - jlo);
+                    if (jg != NY && jg != NY + 1) continue;
+                    for (int i = ilo - ng; i <= ihi + ng; ++i) {
+                        int ig = B.gi0 + (i - ilo);
+                        if (ig < 1) ig += NX;
+                        if (ig > NX) ig -= NX;
+                        int m = NX - ig + 2;
+                        if (m > NX) m -= NX;
+                        int32_t a, b = -1;
+                        uint8_t flip = 1;
+                        if (jg == NY + 1) a = cell_of(m, NY - 1);
+                        else if (ig == 1 || ig == NX / 2 + 1) a = cell_of(ig, NY);
+                        else if (ig <= NX / 2) { a = cell_of(ig, NY); b = cell_of(m, NY); flip = 0; }
+                        else { a = cell_of(m, NY); b = cell_of(ig, NY); }
+                        plan.center_tf_dst.push_back((int32_t)((size_t)B.local * plane + (size_t)(j - 1) * nx + (i - 1)));
+                        plan.center_tf_a.push_back(a);
+                        plan.center_tf_b.push_back(b);
+                        plan.center_tf_flip.push_back(flip);
+                    }
+                }
+            }
+    }
+
     if (tripole) {
         const int NX = d.nx_global, NY = d.ny_global;
         auto offset_of = [&](int ig, int jg, int &owner) -> int32_t {

@@ -102,7 +102,16 @@ struct HaloPlan {
     // scalars always copy.  center_remote: some source lives on another rank (not listed).
     std::vector<int32_t> center_dst, center_src;
     std::vector<int8_t> center_vsign;
-    bool tfold = false;                           // ns_boundary_type 'tripoleT': velocity halo only (one rank)
+    bool tfold = false;                           // ns_boundary_type 'tripoleT'
+    // tripoleT, cell-centre fields (the preparation phase): the top PHYSICAL row lies on the fold -- made symmetric pair by
+    // pair (i <-> NX-i+2 for i = 2..NX/2; i = 1 and NX/2+1 mirror onto themselves) and rewritten from its mirror, east-west
+    // ghost columns included; the ghost row above takes row NY-1 at column NX-i+2 (ice_boundary.F90:1563-1583, 1686-1722).
+    // As entries of a two-pass fold step (evp_device.h: EvpCgFoldList): x[dst] = s * 0.5*(x[a] + isign*x[b]) or s * x[a]
+    // (b = -1), s = flip ? isign : 1.  center_tf_remote: an operand lives on another rank or in an eliminated block (the
+    // device preparation then stays with the host).  The lists above hold the other ghost cells (rows below NY).
+    std::vector<int32_t> center_tf_dst, center_tf_a, center_tf_b;
+    std::vector<uint8_t> center_tf_flip;
+    bool center_tf_remote = false;
     bool center_remote = false;
     bool center_fold_remote = false;              // ... and one of them lies across the tripole fold (centre mirror rule, other rank)
     // Centre-field ghost cells of this rank whose source lies across the fold on ANOTHER rank (fold row split in x), and the

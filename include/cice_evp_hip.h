@@ -42,8 +42,9 @@ enum {
     CICE_EVP_BND_TRIPOLE = 3, /* u-fold; ns only */
     CICE_EVP_BND_TRIPOLET = 4 /* T-fold ('tripoleT'); ns only; B-grid subcycle loop (cice_evp_hip_run / _upload / _subcycle /
                                * _download), any rank layout (the streaming kernel; the images of the top row are interior
-                               * cells, so the exchange always follows the launch) and cice_evp_hip_stress_halo with the top
-                               * row on one rank: the preparation phase and the C grid stay with the host there */
+                               * cells, so the exchange always follows the launch); cice_evp_hip_stress_halo and the
+                               * preparation phase (cice_evp_hip_prep: the centre rule of the T-fold rewrites the top physical
+                               * row, ice_boundary.F90:1563-1583) with the top row on one rank; the C grid stays with the host */
 };
 
 /* Block decomposition of this process (type(block), ice_blocks.F90:21-41;

@@ -62,8 +62,7 @@ def test_golden_tripoleT_strict_bitwise(name):
     the velocity halo's T-fold rule (top U row = image of row NY-1, ghost row = image of row NY-2, no pair averaging:
     ice_boundary.F90:1563-1622, 1686-1722) runs as list copies after every subcycle launch.  Velocities and the loop's
     diagnostics on every cell; the stresses wherever evp()'s own ice_HaloUpdate_stress calls after the loop leave them
-    alone (test_tripole_stress_symmetrisation_on_device applies those on the device too: every cell).  The device
-    preparation refuses loudly."""
+    alone (test_tripole_stress_symmetrisation_on_device applies those on the device too: every cell)."""
     c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     keep = tfold_untouched(c)
@@ -557,6 +556,17 @@ def test_next_tier_prep_on_device_bitwise(name):
     check_next_tier_prep(GoldenCase(name), name)
 
 
+@pytest.mark.parametrize("name", TFOLD_CASES)
+def test_next_tier_prep_on_device_tripoleT_bitwise(name):
+    """The same on ns_boundary_type = 'tripoleT' (end of round 4): the T-grid halo updates of the preparation follow the
+    T-fold rule of cell-centre fields -- the top physical row made symmetric pair by pair and rewritten from its mirror,
+    the ghost row above taken from row NY-1 -- as a two-pass fold launch after the plain ghost copies (halo_plan.h:
+    center_tf_*).  Products of the preparation against what the reference's evp() handed to its loop, bit for bit on both
+    calls of a fixture; then prep -> strength -> loop -> evp()'s own stress symmetrisation on the device: every cell."""
+    c = GoldenCase(name)
+    check_next_tier_prep(c, name)
+
+
 def check_next_tier_prep(c, name):
     from test_oracle_golden import check_prep_products
     core = hip_from_case(c, strict=True)
@@ -584,7 +594,7 @@ def check_next_tier_prep(c, name):
             # the rest of evp(): strength from the host, the loop, the reference's answer
             core.set_strength(dyn["strength"])
             core.subcycle(c.ndte)
-            if c.ns == "tripole":
+            if c.ns in ("tripole", "tripoleT"):
                 core.stress_halo()
             res = core.download()
             assert_bitwise(res, c.expected(icall, c.ndte), f"{name} call {icall}: prep + loop on device")
@@ -1325,3 +1335,5 @@ def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
         assert np.abs(want["uvel"]).max() > 1e-5, what
     finally:
         core.finalize()
+    # ... and the preparation phase on the device (T-fold rule of the cell-centre fields), then the whole evp()
+    check_next_tier_prep(c, what)
