@@ -427,7 +427,7 @@ contains
     case ('open');    bnd_code = 1
     case ('cyclic');  bnd_code = 2
     case ('tripole'); bnd_code = 3
-    case ('tripoleT'); bnd_code = 4          ! T-fold: the loop only (Option B); any rank layout since round 4
+    case ('tripoleT'); bnd_code = 4          ! T-fold: the loop on any rank layout; preparation / symmetrisation with the top row on one rank
     case default
        bnd_code = -1
        call abort_ice('(dyn_evp_hip_init) ERROR: unsupported boundary type '//trim(bnd), &
@@ -476,8 +476,8 @@ contains
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
          file=__FILE__, line=__LINE__)
-    if (trim(ns_boundary_type) == 'tripoleT') call abort_ice(subname//' ERROR: tripoleT: the loop only '// &
-         '(dyn_evp_hip_run); keep evp()''s own preparation', file=__FILE__, line=__LINE__)
+    ! (tripoleT: the library takes the preparation and the symmetrisation where the top row lies on one rank and says
+    ! so otherwise -- cice_evp_hip_set_prep_geometry / cice_evp_hip_stress_halo return an error that check() reports)
     nall = nx_block*ny_block*max_blocks
     if (.not. geometry_set) then
        ! logical(log_kind) is a 4-byte logical: the C side tests "non-zero"
@@ -556,7 +556,7 @@ contains
        call check(cice_evp_hip_set_tbu(TbU), subname, __FILE__, __LINE__)
     endif
     call check(cice_evp_hip_subcycle(int(ndte, c_int32_t)), subname, __FILE__, __LINE__)
-    if (trim(ns_boundary_type) == 'tripole') &
+    if (trim(ns_boundary_type) == 'tripole' .or. trim(ns_boundary_type) == 'tripoleT') &
        call check(cice_evp_hip_stress_halo(), subname, __FILE__, __LINE__)
 
     out32 = c_null_ptr

@@ -225,7 +225,7 @@ def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx,
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
     d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="tripoleT", variant="hip_dropin", h_ndte=120,
-                                 ncalls=2, nsub_list=[1, 120], hipmode=True, hipbody=False, grid_kind="tripolefile",
+                                 ncalls=2, nsub_list=[1, 120], hipmode=True, hipbody=True, grid_kind="tripolefile",
                                  hipresident=resident, grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
     checked = 0
     for icall in (1, 2):
@@ -237,5 +237,14 @@ def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx,
                     f"tripoleT call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
                     f"max|d|={np.abs(hip - ref).max():.3e}")
                 checked += 1
-    assert np.abs(d["o02n0120_uvel"]).max() > 1e-3 and checked == 2 * 2 * (len(FIELDS) + len(DOWNSTREAM))
+            # Option A (end of round 4): the whole B-grid body of evp() through dyn_evp_hip_evp_body -- the preparation with
+            # the T-fold rule of the cell-centre fields, the loop, the symmetrisation, all on the device
+            for f in FIELDS:
+                body = d[f"b{icall:02d}n{nsub:04d}_{f}"]
+                ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
+                assert np.array_equal(body, ref), (
+                    f"tripoleT, Option A body, call {icall} nsub {nsub} {f}: {int((body != ref).sum())} cells differ, "
+                    f"max|d|={np.abs(body - ref).max():.3e}")
+                checked += 1
+    assert np.abs(d["o02n0120_uvel"]).max() > 1e-3 and checked == 2 * 2 * (2 * len(FIELDS) + len(DOWNSTREAM))
     assert "(dyn_evp_hip) task 0: rank 0 of 1: kernel = one subcycle per launch (streaming)" in txt, txt[-1500:]
