@@ -142,12 +142,15 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
          * physical row lies ON the fold and is made symmetric first (:1568-1583: pairs i <-> NX-i+2 for i = 2..NX/2,
          * xavg = 0.5*(x1 + isign*x2), stored as xavg and isign*xavg; i = 1 and i = NX/2+1 mirror onto themselves), then
          *   a(i, NY) <- isign * avg(NX-i+2, NY),   a(i, NY+1) <- isign * a(NX-i+2, NY-1)    (column NX+1 is column 1).
-         * The face locations are not restated (nothing on this path exchanges them on a T-fold grid). */
-        if (field_loc != 1 && field_loc != 0) { fprintf(stderr, "evp_oracle_halo_update: tripoleT restated for NE-corner and centre fields only\n"); abort(); }
-        if (field_loc == 0) {
+         * E-face fields (offsets 0, 0; the C grid's uvelE, vvelE): on the fold like the centres, pairs i <-> NX+1-i for
+         * i = 1..NX/2 (:1593-1608), then a(i, NY) <- isign * avg(NX-i+1, NY), a(i, NY+1) <- isign * a(NX-i+1, NY-1).
+         * N-face fields (offsets -1, 1; vvelN, uvelN): no averaging, a(i, NY) <- isign * a(NX-i+2, NY-1),
+         * a(i, NY+1) <- isign * a(NX-i+2, NY-2). */
+        if (field_loc == 0 || field_loc == 2) {
             double *top = g + (size_t)(NY - 1) * NX;
-            for (int i = 2; i <= NX / 2; ++i) {
-                const int idst = NX - i + 2;
+            const int i0 = field_loc == 0 ? 2 : 1, off = field_loc == 0 ? 2 : 1;
+            for (int i = i0; i <= NX / 2; ++i) {
+                const int idst = NX - i + off;
                 const double x1 = top[i - 1], x2 = top[idst - 1];
                 const double xavg = 0.5 * (x1 + isign * x2);
                 top[i - 1] = xavg;
@@ -167,14 +170,11 @@ void evp_oracle_halo_update(const evp_oracle_domain *d, double *a, int field_loc
                         ig = (ig < 1) ? ig + NX : ig - NX;
                     }
                     if (jg == NY || jg == NY + 1) {
-                        if (field_loc == 0) {
-                            int is = NX - ig + 2;
-                            if (is > NX) is -= NX;
-                            ab[IX(i, j)] = isign * g[(size_t)(jg == NY ? NY - 1 : NY - 2) * NX + (is - 1)];
-                            continue;
-                        }
-                        int is = NX - ig + 1;
-                        ab[IX(i, j)] = isign * g[(size_t)(jg == NY ? NY - 2 : NY - 3) * NX + (is - 1)];
+                        /* column NX - ig + 1 - ioffset; rows 3 - joffset / 2 - joffset of the buffer (= global NY-2 .. NY) */
+                        int is = NX - ig + ((field_loc == 0 || field_loc == 3) ? 2 : 1);
+                        if (is > NX) is -= NX;
+                        const int down = (field_loc == 1 || field_loc == 3) ? 1 : 0;      /* joffset */
+                        ab[IX(i, j)] = isign * g[(size_t)((jg == NY ? NY - 1 : NY - 2) - down) * NX + (is - 1)];
                         continue;
                     }
                     if (interior || jg < 1) continue;                    /* closed south */

@@ -8,9 +8,10 @@ import numpy as np
 import oracle  # oracle/oracle.py  (CPU restatement -- the checker)
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-GOLDEN_CASES = sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith(("cgrid_", "tript_")))
+GOLDEN_CASES = sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith(("cgrid_", "tript_", "cgtript_")))
 TFOLD_CASES = sorted(p.stem for p in GOLDEN.glob("tript_*.npz"))         # ns_boundary_type = 'tripoleT' (B grid, the loop only)
 CGRID_CASES = sorted(p.stem for p in GOLDEN.glob("cgrid_*.npz"))      # C-grid subcycle
+CGRID_TFOLD_CASES = sorted(p.stem for p in GOLDEN.glob("cgtript_*.npz"))   # ... on ns_boundary_type = 'tripoleT'
 
 
 class GoldenCase:

@@ -111,6 +111,12 @@ CGRID_CASES = {
                                                 h_visc_method="avg_strength")),
     "cgrid_trip_4x3_caps_seabed": (32, 24, 8, 8, "cyclic", "tripole",
                                    dict(icecase="caps", nsub_list=[1, 120], ncalls=1, h_seabed=True)),
+    # tripoleT (T-fold): centre and E-face fields lie ON the fold (top row made symmetric pairwise and rewritten from its
+    # mirror), NE-corner and N-face fields have their top row as the image of row NY-1 (ice_boundary.F90:1563-1622)
+    "cgtript_cyc_2x2_patchy": (28, 20, 14, 10, "cyclic", "tripoleT",
+                               dict(icecase="patchy", nsub_list=[1, 2, 120], ncalls=2, h_evolve=True)),
+    "cgtript_cyc_1blk_full_avgstrength": (24, 18, 24, 18, "cyclic", "tripoleT",
+                                          dict(icecase="full", nsub_list=[1, 120], ncalls=1, h_visc_method="avg_strength")),
 }
 
 
@@ -118,11 +124,11 @@ def make_cgrid_case(name, spec):
     nx, ny, bx, by, ew, ns, kw = spec
     kw = dict(kw)
     td = tempfile.mkdtemp(prefix="golden_")
-    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=("tripole" if ns == "tripoleT" else ns))
     run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
     d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="strict", h_ndte=120,
-                                 grid_kind=("tripolefile" if ns == "tripole" else "popfile"),
+                                 grid_kind=("tripolefile" if ns in ("tripole", "tripoleT") else "popfile"),
                                  grid_files=(td + "/grid.bin", td + "/kmt.bin"), h_grid_ice="C", **kw)
     keep = {"dims": d["dims"], "blkinfo": d["blkinfo"], "scalars": d["scalars"], "nsub_list": d["nsub_list"],
             "ew": np.array(ew), "ns": np.array(ns), "visc_method": np.array(kw.get("h_visc_method", "avg_zeta"))}

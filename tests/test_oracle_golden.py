@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import TFOLD_CASES, tfold_untouched, CGRID_CASES, GOLDEN_CASES, GoldenCase, assert_bitwise
+from common import TFOLD_CASES, tfold_untouched, CGRID_CASES, CGRID_TFOLD_CASES, GOLDEN_CASES, GoldenCase, assert_bitwise
 
 
 def test_fixtures_present():
@@ -204,7 +204,7 @@ def test_next_tier_deformations_dyn_finish_bitwise(name):
             assert_bitwise(got, {k: c.d[tag + k] for k in got}, f"{name} call {icall} nsub {nsub} f-1")
 
 
-@pytest.mark.parametrize("name", CGRID_CASES)
+@pytest.mark.parametrize("name", CGRID_CASES + CGRID_TFOLD_CASES)
 def test_cgrid_subcycle_bitwise(name):
     """the C-grid loop of evp() (ice_dyn_evp.F90:938-1099 -- strain_rates_U, stressC_T, stressC_U,
     div_stress_Ex/Ny, stepu_C/stepv_C, the face <-> face / face -> corner averages and the eight halo updates)
