@@ -26,7 +26,7 @@ int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int
                                  int32_t *b, int32_t *flip)
 {
     if (!dims || !count || loc < 0 || loc > 3) return fail(-1, "bad argument");
-    if (dims->ns_boundary_type != CICE_EVP_BND_TRIPOLE) return fail(-1, "not a tripole grid");
+    if (dims->ns_boundary_type != CICE_EVP_BND_TRIPOLE && dims->ns_boundary_type != CICE_EVP_BND_TRIPOLET) return fail(-1, "not a tripole grid");
     FoldList L;
     build_fold_list(*dims, loc, L);
     *count = (int32_t)L.dst.size();

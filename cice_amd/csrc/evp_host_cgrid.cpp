@@ -44,6 +44,7 @@ struct CGridState {
     int *img_slot = nullptr, *img_dst = nullptr;
     // tripole fold: per field location the cells of the fold row / the ghost row beyond it and their sources
     bool tripole = false;
+    bool tfold = false;                  // ... of the T-fold kind (tripoleT)
     struct Fold { int *dst = nullptr, *a = nullptr, *b = nullptr; unsigned char *flip = nullptr; int n = 0; } fold[4];
     double *fold_tmp = nullptr;
     int fold_maxn = 0;
@@ -459,13 +460,16 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     if (!S.ready) return fail(-1, "not initialised");
     if (!static23) return fail(-1, "null argument");
     const HaloPlan &P = S.plan;
-    const bool tripole = S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE;
-    if (S.d.ns_boundary_type > CICE_EVP_BND_TRIPOLE) return fail(-4, "C-grid EVP: tripoleT is not supported");
+    // (tripoleT: the same five launches + fold steps; only the fold lists differ -- all four locations rewrite the top
+    // physical row there, halo_plan.cpp: build_fold_list_tfold)
+    const bool tfold = S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLET;
+    const bool tripole = S.d.ns_boundary_type == CICE_EVP_BND_TRIPOLE || tfold;
     if (tripole && P.fold_rows == 2)
-        return fail(-4, "C-grid EVP on a tripole grid: the blocks next to the fold (rows NY-1, NY) must all be on one rank "
-                        "(split the domain in y only); here they are shared with other ranks");
+        return fail(-4, "C-grid EVP on a tripole grid: the blocks next to the fold (rows NY-1, NY; tripoleT: NY-2 .. NY) must all "
+                        "be on one rank (split the domain in y only); here they are shared with other ranks");
     cgrid_free();
     CG.tripole = tripole;
+    CG.tfold = tfold;
     for (auto &p : CG.f)
         if (alloc_d(&p, S.n)) return -1;
     if (alloc_d(&CG.inslab, (size_t)CG_NIN * S.n) || alloc_d(&CG.gslab, (size_t)CG_NG * S.n)) return -1;
@@ -488,7 +492,7 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
         if (tripole) {       // ghost row beyond the fold: location-dependent, done by the fold step, not by an image
             const int db = (int)(P.local_dst[k] / S.plane);
             const int dj = (int)((P.local_dst[k] % S.plane) / S.d.nx_block) + 1;
-            if (S.jglob0[db] + (dj - S.jlo[db]) > S.d.ny_global) continue;
+            if (S.jglob0[db] + (dj - S.jlo[db]) > S.d.ny_global - (tfold ? 1 : 0)) continue;    // (tripoleT: the top physical row too)
         }
         if (src < 0) {                              // neighbour block eliminated (land): the reference fills with zero
             zero.push_back(P.local_dst[k]);
@@ -754,7 +758,7 @@ int cice_evp_hip_cgrid_set_prep_geometry(const int32_t *tmask, const int32_t *um
 {
     if (!S.ready || !CG.geo) return fail(-1, "C-grid EVP: geometry not set");
     if (!tmask || !umaskCD || !emask || !nmask || !fcor_blk || !fcorE_blk || !fcorN_blk) return fail(-1, "null argument");
-    if (S.plan.center_fold_remote)
+    if (S.plan.center_fold_remote || (S.plan.tfold && (S.plan.center_tf_remote || S.plan.center_remote)))
         return fail(-9, "device preparation: T-grid ghost cells across the tripole fold live on other ranks here; keep "
                         "evp()'s host preparation (cice_evp_hip_cgrid_run) on this configuration");
     CGridState::Prep &Q = CG.prep;
@@ -848,6 +852,13 @@ int cice_evp_hip_cgrid_prep(const cice_evp_hip_prep_params *pp, const double *co
         for (const auto &a : arrs) { H.a[H.narr] = a.first; H.is_vec[H.narr] = a.second; ++H.narr; }
         H.dst = Q.c_dst; H.src = Q.c_src; H.vsign = Q.c_vsign; H.n = Q.n_center;
         evp_launch_halo_center(H, S.stream);
+        if (CG.tfold) {
+            // tripoleT: the centre rule rewrites the top physical row (made symmetric, then mirrored) and fills the ghost row
+            // from row NY-1: the fold step of location 0, after the plain ghost copies (whose sources it does not write)
+            fold({{arrs[0].first, 0, arrs[0].second}, {arrs[1].first, 0, arrs[1].second}, {arrs[2].first, 0, arrs[2].second}, {arrs[3].first, 0, arrs[3].second}});
+            fold({{arrs[4].first, 0, arrs[4].second}, {arrs[5].first, 0, arrs[5].second}, {arrs[6].first, 0, arrs[6].second}, {arrs[7].first, 0, arrs[7].second}});
+            fold({{arrs[8].first, 0, arrs[8].second}, {arrs[9].first, 0, arrs[9].second}});
+        }
         if (S.plan.center_remote) {
             double *pairs[5][2] = {{Q.maskd, Q.tmass}, {Q.t[3], Q.t[4]}, {Q.t[5], Q.t[6]}, {Q.t[7], Q.t[8]}, {Q.t[9], Q.t[10]}};
             for (auto &pr : pairs)

@@ -132,6 +132,14 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
         }
     }
 
+    if (tfold) {        // owners of the blocks that hold rows NY-2 .. NY (the C grid's fold step reads all three)
+        bool mine = false, others = false;
+        for (const HaloBlock &B : T.blk) {
+            if (B.owner < 0 || B.gj0 + B.gny - 1 < d.ny_global - 2) continue;
+            (B.owner == me ? mine : others) = true;
+        }
+        plan.fold_rows = !mine ? 0 : (others ? 2 : 1);
+    }
     if (tripole) {      // owners of the blocks that hold rows NY-1 / NY
         bool mine = false, others = false;
         for (const HaloBlock &B : T.blk) {
@@ -521,9 +529,59 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan)
 }
 
 
+// tripoleT (T-fold; ice_boundary.F90:1563-1622 offsets and symmetrisation, :1686-1722 copy-out): rows NY and NY+1 of every
+// block, ghost columns included, take column NX-ig+1-ioffset of the rows NY-joffset and NY-1-joffset, offsets (ioffset,
+// joffset) = centre (-1, 0), NE corner (0, 1), E face (0, 0), N face (-1, 1); centre and E-face fields lie ON the fold: their
+// top row is made symmetric first (pairs i <-> NX-i+2, i = 2..NX/2, resp. i <-> NX+1-i, i = 1..NX/2) -- an entry then holds
+// the pair in the reference's order (a = the lower column) and flip says which half the destination is
+static void build_fold_list_tfold(const cice_evp_hip_dims &d, int loc, FoldList &L)
+{
+    const int NX = d.nx_global, NY = d.ny_global, nx = d.nx_block, ng = d.nghost;
+    const size_t plane = (size_t)nx * d.ny_block;
+    std::vector<int> owner((size_t)NX * 3, -1);              // interior cell holding global (ig, NY-2 .. NY)
+    for (int b = 0; b < d.nblocks; ++b)
+        for (int j = d.jlo[b]; j <= d.jhi[b]; ++j) {
+            const int jg = d.jglob0[b] + (j - d.jlo[b]);
+            if (jg < NY - 2 || jg > NY) continue;
+            for (int i = d.ilo[b]; i <= d.ihi[b]; ++i) {
+                const int ig = d.iglob0[b] + (i - d.ilo[b]);
+                owner[(size_t)(jg - (NY - 2)) * NX + (ig - 1)] = (int)((size_t)b * plane + (size_t)(j - 1) * nx + (i - 1));
+            }
+        }
+    auto wrap = [&](int ig) {
+        while (ig < 1) ig += NX;
+        while (ig > NX) ig -= NX;
+        return ig;
+    };
+    auto own = [&](int ig, int jg) { return owner[(size_t)(jg - (NY - 2)) * NX + (wrap(ig) - 1)]; };
+    const int ioff = (loc == 0 || loc == 3) ? -1 : 0, joff = (loc == 1 || loc == 3) ? 1 : 0;
+    const bool on_fold = (loc == 0 || loc == 2);
+    for (int b = 0; b < d.nblocks; ++b)
+        for (int j = d.jlo[b] - ng; j <= d.jhi[b] + ng; ++j) {
+            const int jg = d.jglob0[b] + (j - d.jlo[b]);
+            if (jg != NY && jg != NY + 1) continue;
+            for (int i = d.ilo[b] - ng; i <= d.ihi[b] + ng; ++i) {
+                const int ig = wrap(d.iglob0[b] + (i - d.ilo[b]));
+                const int dd = (int)((size_t)b * plane + (size_t)(j - 1) * nx + (i - 1));
+                const int m = wrap(NX - ig + 1 - ioff);
+                const int jsrc = (jg == NY ? NY : NY - 1) - joff;
+                int a = own(m, jsrc), bb = -1, fl = 1;
+                if (on_fold && jg == NY && m != ig) {          // a pair of the symmetrised row
+                    const int lo = std::min(ig, m), hi = std::max(ig, m);
+                    a = own(lo, NY);
+                    bb = own(hi, NY);
+                    if (bb < 0) bb = -2;                         // partner's block eliminated: the buffer holds 0
+                    fl = ig == lo ? 0 : 1;
+                }
+                L.dst.push_back(dd); L.a.push_back(a); L.b.push_back(bb); L.flip.push_back((uint8_t)fl);
+            }
+        }
+}
+
 void build_fold_list(const cice_evp_hip_dims &d, int loc, FoldList &L)
 {
     L = FoldList();
+    if (d.ns_boundary_type == CICE_EVP_BND_TRIPOLET) { build_fold_list_tfold(d, loc, L); return; }
     const int NX = d.nx_global, NY = d.ny_global, nx = d.nx_block, ng = d.nghost;
     const size_t plane = (size_t)nx * d.ny_block;
     std::vector<int> owner((size_t)NX * 2, -1);              // interior cell holding global (ig, NY-1) / (ig, NY)

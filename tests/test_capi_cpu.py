@@ -267,17 +267,20 @@ def test_decomp_fold_scatter_matches_the_halo_rules():
             assert np.array_equal(a, w), (loc, kind)
 
 
+@pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
 @pytest.mark.parametrize("nx,ny,bx,by", [(24, 18, 24, 18), (28, 20, 14, 10), (32, 24, 8, 8), (26, 14, 10, 5)])
-def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by):
+def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by, ns):
     """C grid on tripole grids: the host-built fold lists (cice_evp_hip_cgrid_fold_plan) applied to arbitrary block
     arrays give, on every cell of the fold row and of the ghost row beyond it, exactly what ice_HaloUpdate gives
     there -- all four field locations, scalar and vector kinds, 1 ... 12 blocks incl. padded ones (against the
-    oracle's halo update, pinned to the reference's tripole fixtures for every location)."""
+    oracle's halo update, pinned to the reference's tripole fixtures for every location).  tripoleT (end of round 4): the
+    T-fold lists -- every location rewrites the top physical row there, centre and E-face fields are the ones ON the fold --
+    against the oracle's T-fold update, pinned to the reference's tripoleT fixtures (B-grid loop and preparation, C-grid loop)."""
     from cice_amd import decomp
-    dc = decomp.Decomp(nx, ny, bx, by, "cyclic", "tripole", 1)
+    dc = decomp.Decomp(nx, ny, bx, by, "cyclic", ns, 1)
     d, keep = evp.make_dims(dc, 0)
     ob = dc.local_blocks(0)
-    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(ob), nx, ny, "cyclic", "tripole", [b.ilo for b in ob],
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(ob), nx, ny, "cyclic", ns, [b.ilo for b in ob],
                               [b.ihi for b in ob], [b.jlo for b in ob], [b.jhi for b in ob], [b.gi0 for b in ob],
                               [b.gj0 for b in ob])
     rng = np.random.default_rng(nx * 100 + ny)
@@ -285,7 +288,7 @@ def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by):
         L = evp.cgrid_fold_plan(d, loc)
         assert len(L["dst"]) > 0 and len(set(L["dst"].tolist())) == len(L["dst"])        # every cell once
         on_fold = (L["b"] >= 0).sum()
-        assert (on_fold > 0) == (loc in ("NEcorner", "Nface"))
+        assert (on_fold > 0) == (loc in (("NEcorner", "Nface") if ns == "tripole" else ("center", "Eface")))
         for kind, isign in (("scalar", 1.0), ("vector", -1.0)):
             x = rng.standard_normal((len(ob), dc.ny_block, dc.nx_block))
             want = oracle.halo_update(dom, x.copy(), loc, kind).reshape(-1)

@@ -7,7 +7,7 @@ import pytest
 
 import oracle
 from cice_amd import evp
-from common import CGRID_CASES, GoldenCase, assert_bitwise
+from common import CGRID_CASES, CGRID_TFOLD_CASES, GoldenCase, assert_bitwise
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +30,7 @@ def expected_loop_only(c, dom, icall, nsub):
     return c.cgrid_expected(icall, nsub)
 
 
-@pytest.mark.parametrize("name", CGRID_CASES)
+@pytest.mark.parametrize("name", CGRID_CASES + CGRID_TFOLD_CASES)
 def test_cgrid_golden_bitwise(name):
     c = GoldenCase(name)
     dom = c.oracle_domain()
@@ -47,7 +47,7 @@ def test_cgrid_golden_bitwise(name):
         core.finalize()
 
 
-@pytest.mark.parametrize("name", CGRID_CASES)
+@pytest.mark.parametrize("name", CGRID_CASES + CGRID_TFOLD_CASES)
 def test_cgrid_dyn_finish_on_device_bitwise(name):
     """dyn_finish at N and E points (ice_dyn_evp.F90:1408-1436), the last thing evp() computes from the C-grid loop's
     velocities, on the device from the loop's resident final state and the operands it already holds: strocnxN / strocnyN /
@@ -75,7 +75,7 @@ def test_cgrid_dyn_finish_on_device_bitwise(name):
         core.finalize()
 
 
-@pytest.mark.parametrize("name", CGRID_CASES)
+@pytest.mark.parametrize("name", CGRID_CASES + CGRID_TFOLD_CASES)
 def test_cgrid_deformations_t_on_device_bitwise(name):
     """deformationsC_T (ice_dyn_shared.F90:1968-2074), which evp() runs right after the C-grid loop, on the device from
     the loop's resident final state: divu, shear, vort, rdg_conv, rdg_shear equal the arrays the reference's evp() left
@@ -557,7 +557,7 @@ def device_prep(core, c, icall, state, visc=None):
     return masks
 
 
-@pytest.mark.parametrize("name", CGRID_CASES)
+@pytest.mark.parametrize("name", CGRID_CASES + CGRID_TFOLD_CASES)
 def test_cgrid_prep_on_device_bitwise(name):
     """Everything the C-grid loop reads, computed on the device from the T-grid state and forcing (11 arrays in instead
     of 14 + 23) and compared with what the reference's own preparation left (the in* arrays of the fixtures): the four ice
@@ -769,11 +769,11 @@ def reference_cgrid_case(tmp_path, nx, ny, bs, ew, ns, **kw):
     import common
     if not run_ref.have_ref("strict"):
         pytest.skip("oracle/_ref/evp_ref_harness_strict not present")
-    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=("tripole" if ns == "tripoleT" else ns))
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
     d, txt = run_ref.run_harness(nx, ny, bs[0], bs[1], ew=ew, ns=ns, variant="strict", h_ndte=kw.pop("h_ndte", 120),
-                                 grid_kind=("tripolefile" if ns == "tripole" else "popfile"),
+                                 grid_kind=("tripolefile" if ns in ("tripole", "tripoleT") else "popfile"),
                                  grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), h_grid_ice="C", **kw)
     np.savez(tmp_path / "ccase.npz", **d, ew=np.array(ew), ns=np.array(ns), visc_method=np.array(kw.get("h_visc_method", "avg_zeta")))
     old = common.GOLDEN
@@ -784,11 +784,13 @@ def reference_cgrid_case(tmp_path, nx, ny, bs, ew, ns, **kw):
         common.GOLDEN = old
 
 
-@pytest.mark.parametrize("seed", list(range(501, 509)) + [int(s) for s in __import__("os").environ.get("CGRID_REF_SWEEP_SEEDS", "").split() if s])
+@pytest.mark.parametrize("seed", list(range(501, 509)) + list(range(901, 909)) + [int(s) for s in __import__("os").environ.get("CGRID_REF_SWEEP_SEEDS", "").split() if s])
 def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", str(seed % 3))      # all three windows of the one-launch kernel (32x8, 64x8, 64x16)
     rng = np.random.default_rng(seed)
     ns = ["closed", "tripole", "cyclic"][seed % 3] if seed % 7 else "tripole"
+    if seed >= 900:
+        ns = "tripoleT"                       # (end of round 4) T-fold lists of all four locations, 1 - 3 blocks across
     ew = "closed" if (ns == "closed" and seed % 2) else "cyclic"
     nx, ny = 2 * int(rng.integers(10, 36)), int(rng.integers(14, 48))
     nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 4))
