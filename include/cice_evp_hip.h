@@ -44,7 +44,9 @@ enum {
                                * _download), any rank layout (the streaming kernel; the images of the top row are interior
                                * cells, so the exchange always follows the launch); cice_evp_hip_stress_halo and the
                                * preparation phase (cice_evp_hip_prep: the centre rule of the T-fold rewrites the top physical
-                               * row, ice_boundary.F90:1563-1583) with the top row on one rank; the C grid stays with the host */
+                               * row, ice_boundary.F90:1563-1583) with the top row on one rank; the C grid (cice_evp_hip_cgrid_*:
+                               * five launches + fold steps from the T-fold lists of the four field locations, device
+                               * preparation included) with the rows NY-2 .. NY on one rank */
 };
 
 /* Block decomposition of this process (type(block), ice_blocks.F90:21-41;

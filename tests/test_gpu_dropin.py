@@ -128,6 +128,7 @@ CGRID_CASES = [
     (60, 44, 20, 15, "cyclic", dict(icecase="patchy", h_visc_method="avg_strength", h_capping=0.5)),
     (64, 48, 64, 48, "closed", dict(icecase="full", h_revised=True, h_seabed=True)),
     (72, 40, 36, 20, "cyclic", dict(icecase="full", ns="tripole")),          # fold step after every phase
+    (72, 40, 24, 20, "cyclic", dict(icecase="patchy", ns="tripoleT")),       # T-fold lists (end of round 4), three blocks across
 ]
 
 
@@ -153,12 +154,12 @@ def run_cgrid_dropin(tmp_path, nx, ny, bx, by, ew, kw, prep, ndte=120):
     if prep == "device_preparation":
         kw.update(hipbody=True, h_evolve=True, h_ssh="coupled")
     ns = kw.pop("ns", "closed")
-    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+    g = synth.make_grid(nx, ny, dx0=1.1e5, ns=("tripole" if ns == "tripoleT" else ns))
     run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
     run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
     d, txt = run_ref.run_harness(nx, ny, bx, by, ew=ew, ns=ns, variant="hip_dropin", h_ndte=ndte, ncalls=2,
                                  nsub_list=[1, ndte], hipmode=True, h_grid_ice="C",
-                                 grid_kind=("tripolefile" if ns == "tripole" else "popfile"),
+                                 grid_kind=("tripolefile" if ns in ("tripole", "tripoleT") else "popfile"),
                                  grid_files=(tmp_path / "grid.bin", tmp_path / "kmt.bin"), **kw)
     import oracle
     dom = oracle.OracleDomain.from_dump(d, ew, ns)
