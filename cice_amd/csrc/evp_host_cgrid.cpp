@@ -758,7 +758,7 @@ int cice_evp_hip_cgrid_set_prep_geometry(const int32_t *tmask, const int32_t *um
 {
     if (!S.ready || !CG.geo) return fail(-1, "C-grid EVP: geometry not set");
     if (!tmask || !umaskCD || !emask || !nmask || !fcor_blk || !fcorE_blk || !fcorN_blk) return fail(-1, "null argument");
-    if (S.plan.center_fold_remote || (S.plan.tfold && (S.plan.center_tf_remote || S.plan.center_remote)))
+    if (S.plan.center_fold_remote || (S.plan.tfold && S.plan.center_tf_remote))
         return fail(-9, "device preparation: T-grid ghost cells across the tripole fold live on other ranks here; keep "
                         "evp()'s host preparation (cice_evp_hip_cgrid_run) on this configuration");
     CGridState::Prep &Q = CG.prep;

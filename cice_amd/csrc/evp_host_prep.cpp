@@ -15,7 +15,8 @@ int cice_evp_hip_set_prep_geometry(const int32_t *tmask, const int32_t *umask, c
     // T-grid ghost cells owned by other ranks travel with the velocity exchange (same cells for centre and corner
     // fields) -- except across the tripole fold, where centre fields mirror other cells than corner fields do
     // (tripoleT: the centre rule rewrites the top physical row -- a fold step of its own after the plain ghost copies, one rank)
-    if (S.plan.tfold && (S.plan.center_tf_remote || S.plan.center_remote))
+    // (ranks cut in y only are fine: what travels between them are plain ghost rows, the fold step stays on the top rank)
+    if (S.plan.tfold && S.plan.center_tf_remote)
         return fail(-9, "device preparation on a tripoleT grid: the top row's mirror cells live on other ranks (or in an eliminated "
                         "block) here; keep evp()'s host preparation (cice_evp_hip_run)");
     auto B = [&](uint8_t *&p) -> int { if (!p) HIPC(hipMalloc((void **)&p, S.n)); return 0; };

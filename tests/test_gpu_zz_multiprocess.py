@@ -45,7 +45,10 @@ def _free_port():
                                                            # row cut in x, in y only, both, odd sizes
                                                            (2, "360x240:tripoleT", "2x1", False), (2, "360x240:tripoleT", "1x2", False),
                                                            (4, "360x240:tripoleT", "2x2", False), (3, "126x60:tripoleT", "3x1", False),
-                                                           (4, "100x116:tripoleT", "4x1", False)])
+                                                           (4, "100x116:tripoleT", "4x1", False),
+                                                           # ... and its preparation phase on the device, ranks cut in y (end of
+                                                           # round 4: the T-fold rule of the cell-centre fields stays on the top rank)
+                                                           (2, "120x80:tripoleT", "1x2", "prep_stream")])
 def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resident):
     """The mailbox transport across PROCESS boundaries (HIP IPC handles exchanged over gloo,
     peers' inboxes mapped, flags raised from the other process's kernels): `world` ranks share
@@ -179,7 +182,9 @@ def test_bench_multi_rank_rehearsal():
                                                         # the E / N velocity averages across ranks), then the loop
                                                         (2, "gx3", "2x1", ["--prep", "--case", "caps"]),
                                                         (4, "gx1", "2x2", ["--prep", "--blocks-per-rank", "2x1"]),
-                                                        (2, "tx1", "1x2", ["--prep"])])
+                                                        (2, "tx1", "1x2", ["--prep"]),
+                                                        # tripoleT, ranks cut in y (end of round 4): T-fold lists on the top rank
+                                                        (2, "120x80:tripoleT", "1x2", []), (2, "120x80:tripoleT", "1x2", ["--prep"])])
 def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
     """The C-grid subcycle split over `world` ranks (processes sharing this box's GPU): ghost cells that mirror
     cells of other ranks are filled through the mailbox transport after every producing launch -- five exchange
