@@ -9,8 +9,8 @@
 // per rank (their ghost cells are images like any other).  Ghost cells that mirror cells of OTHER ranks are filled
 // by the B-grid path's velocity exchange (halo_remote_pair: mailbox stores over xGMI, or RCCL point-to-point) run on
 // pairs of the loop's arrays after the launch that produces them -- the same points at which the reference calls
-// ice_HaloUpdate.  Tripole (u-fold) grids: a fold step per exchange point from host-built lists (halo_plan.cpp:
-// build_fold_list), the blocks next to the fold on one rank.
+// ice_HaloUpdate.  Tripole grids, u-fold and T-fold (tripoleT): a fold step per exchange point from host-built lists
+// (halo_plan.cpp: build_fold_list / build_fold_list_tfold), the blocks next to the fold on one rank.
 // =====================================================================
 #include <cmath>
 

@@ -247,7 +247,8 @@ int cice_evp_hip_prep_fetch(int32_t which, double *dst);
  * stepu_C / stepv_C, the E<->N and face->corner velocity averages, and the eight ice_HaloUpdate calls of every
  * subcycle (fused into the kernels; ghost cells owned by other ranks through the halo transport of the B-grid path).
  * Call after cice_evp_hip_init (dims, scalars) and, for nranks > 1, cice_evp_hip_comm_init or _halo_import.
- * Cyclic, closed or open boundaries, tripole u-fold (the blocks holding rows NY-1, NY on one rank); any number of blocks.
+ * Cyclic, closed or open boundaries, tripole u-fold (the blocks holding rows NY-1, NY on one rank) and T-fold ('tripoleT',
+ * ice_boundary.F90:1563-1622; rows NY-2 .. NY on one rank); any number of blocks.
  *
  * static23 (ice_grid / ice_dyn_evp arrays, once):
  *   dxT dyT dxU dyU dxE dyE dxN dyN uarea tarea earea narea earear narear epm npm uvm hm DminTarea
