@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--count", type=int, default=12)
     ap.add_argument("--tripole-resident", action="store_true",
                     help="every case: the on-chip kernel on a tripole grid, the fold row split over 1 to 4 ranks in x (round 4)")
+    ap.add_argument("--tripoleT-next", action="store_true",
+                    help="every case: a tripoleT grid cut in y only (fold rows on the top rank) -- device preparation, C-grid loop, "
+                         "C-grid device preparation (end of round 4)")
     a = ap.parse_args()
     seeds = a.seeds if a.seeds else list(range(a.first, a.first + a.count))
     nbad = 0
@@ -41,10 +44,14 @@ def main():
         if a.tripole_resident:
             mode, trip = ("resident" if seed % 3 else "prep"), True
             world, shape = [(2, "2x1"), (3, "3x1"), (4, "4x1"), (4, "2x2"), (2, "1x2"), (6, "3x2")][int(rng.integers(0, 6))]
+        if a.tripoleT_next:
+            mode, trip = ["prep", "cgrid", "cgrid_prep"][seed % 3], False
+            world, shape = [(2, "1x2"), (3, "1x3"), (4, "1x4")][int(rng.integers(0, 3))]
         px, py = [int(v) for v in shape.split("x")]
         nx = 2 * px * int(rng.integers(14, 50))      # even, and the same number of columns on every rank
         ny = py * int(rng.integers(16, 60))
         tfold = (not a.tripole_resident) and mode == "streaming" and seed % 4 == 1      # ns_boundary_type = 'tripoleT' (late round 4)
+        tfold = tfold or a.tripoleT_next
         wl = f"{nx}x{ny}" + (":tripole" if trip else (":tripoleT" if tfold else ""))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(port()), str(ROOT / "tools" / "mailbox_2proc.py"), "--workload", wl, "--shape", shape,
@@ -68,7 +75,7 @@ def main():
             cmd += ["--cgrid"] + (["--visc", "avg_strength"] if rng.random() < 0.4 else []) + (["--maskhalo"] if rng.random() < 0.4 else [])
         elif mode == "prep":
             cmd += ["--prep"]
-            if rng.random() < 0.5:
+            if rng.random() < 0.5 or tfold:         # (tripoleT: the streaming kernel is the only one eligible anyway)
                 env["CICE_EVP_HIP_RESIDENT"] = "0"
         elif mode == "cgrid_prep":
             cmd += ["--cgrid", "--prep"]
