@@ -62,7 +62,10 @@ VERIFY_FIELDS = ("uvel", "vvel", "stressp_1")
 CGRID_VERIFY_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")   # tests/golden/make_bench_checksums.py
 CGRID_B_ALG = 648.0      # C grid: 81 fp64 array touches per cell and subcycle in the fused schedule
 CGRID_B_ALG_GEO = 563.0  # ... 70 + three mask bytes where the fused kernels derive 15 of the 23 static arrays (as cg_one does)
-EXTRAS = ("s01", "streaming", "tripole", "cgrid", "per_call", "configs2")
+EXTRAS = ("s01", "streaming", "tripole", "cgrid", "per_call", "configs2", "rccl_control", "ring_variants")
+# what a plain run measures besides the headline: everything on one GPU; at N > 1 the 3600x2400 grid on the library's default
+# path and ONE control (the headline workload forced onto RCCL point-to-point) -- the other forms are asked for by name
+EXTRAS_DEFAULT = {1: ("s01", "streaming", "tripole", "cgrid", "per_call"), 2: ("s01", "rccl_control")}
 CGRID_B_ALG_ONE = 408.0  # ... 51 in the one-launch kernel (cg_one: the default on one rank without a fold)
 CGRID_B_ALG_ONE_GEO = 289.0  # ... 36 + one mask byte where cg_one derives 15 of its 23 static arrays from the 8 dx / dy arrays
 
@@ -81,11 +84,15 @@ def parse():
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the extra measurements reported under 'secondary', 'tripole', 'roofline.streaming', 'per_call_ms'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time per code path")
-    ap.add_argument("--extras", default="all",
-                    help="comma list of the extra measurements to run (default all): s01, streaming, tripole, cgrid, per_call, "
-                         "configs2 (N > 1: gx1 at ndte = 240, library default and forced RCCL point-to-point)")
+    ap.add_argument("--extras", default="auto",
+                    help="comma list of the extra measurements to run, or 'all'.  Default ('auto') at N = 1: s01, streaming, "
+                         "tripole, cgrid, per_call; at N > 1: s01 (3600x2400 at ndte = 480, library default) and rccl_control (the "
+                         "headline workload forced onto RCCL point-to-point).  By name only, N > 1: configs2 (gx1 at ndte = 240, "
+                         "default and forced RCCL), tripole (tx1 over the ranks), ring_variants (s01 again with the ring exchange "
+                         "overlapped / as direct IPC stores)")
     a = ap.parse_args()
-    a.extras = set(EXTRAS if a.extras == "all" else [x for x in a.extras.split(",") if x])
+    a.extras = set(EXTRAS if a.extras == "all" else EXTRAS_DEFAULT[min(a.gpus, 2)] if a.extras == "auto"
+                   else [x for x in a.extras.split(",") if x])
     unknown = a.extras - set(EXTRAS)
     if unknown:
         ap.error(f"unknown --extras {sorted(unknown)} (known: {', '.join(EXTRAS)})")
@@ -275,7 +282,8 @@ def reference_parity(nx, ny, ndte, case, td):
     finally:
         core.finalize()
     want = c.expected(1, ndte)
-    bad = [k for k, w in want.items() if not np.array_equal(out[k], w)]
+    bad = [k for k, w in want.items() if not np.array_equal(np.ascontiguousarray(out[k], dtype=np.float64).view(np.uint64),
+                                                            np.ascontiguousarray(w, dtype=np.float64).view(np.uint64))]
     return dict(bitwise=not bad, fields_compared=len(want), fields_differing=bad, subcycles=ndte,
                 tile_variant=tv, max_abs_u=float(np.abs(out["uvel"]).max()),
                 how="reference evp() (strict build, 1 block) run in this leg; its captured subcycle inputs -> "
@@ -302,6 +310,16 @@ def quiet_interpreter():
 def main():
     a = parse()
     a.strict = not a.fused
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # launched bare (`python bench.py --gpus N`): become the launcher the contract names -- one rank per GPU under
+        # torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]])
     import torch
     import torch.distributed as dist
     from cice_amd import decomp, evp, synth
@@ -310,8 +328,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     # Rehearsal on a 1-GPU box (tests only): CICE_EVP_BENCH_REHEARSAL=1 runs the N ranks as N processes
     # on device 0 over gloo, the mailbox halo bootstrapped by hand (RCCL refuses two ranks per device)
@@ -341,7 +358,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
-    def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True, proc_shape=None, again_env=None):
+    def measure(workload, case, ndte, steps, warmup, ns="closed", env=None, verify=True, proc_shape=None, again_env=None, median_calls=0):
         """One timed pass: `warmup` untimed + `steps` timed evp() subcycle loops of `workload`,
         block-decomposed over the ranks; barrier + sync on both sides, MAX over ranks."""
         saved = {k: os.environ.get(k) for k in (env or {})}
@@ -469,8 +486,17 @@ def main():
                                 local_cells=int(sum(b.gnx * b.gny for b in dc.local_blocks(rank))), path=core.describe_path())
                     per_rank = [None] * world
                     dist.all_gather_object(per_rank, mine)
+                # SURVEY 8(d) asks for the median over >= 10 evp() calls next to the contract's K-step mean: the same loop again,
+                # one call at a time (HIP events of the library around each loop; one GPU only -- across ranks every step would
+                # need its own agreement)
+                each_ms = []
+                if world == 1 and median_calls:
+                    for _ in range(median_calls):
+                        core.subcycle(ndte)
+                        core.sync()
+                        each_ms.append(float(core.timings()["loop_ms"]))
                 # ---- what was timed, checked: continue (untimed) to the next checkpoint, hash the state ----
-                total = warmup + steps
+                total = warmup + steps + len(each_ms)
                 key = golden_key(workload, case, ndte, ns)
                 target = next((n for n in CHECKPOINTS if n >= total and str(n) in golden.get(key, {})), None)
                 ver = dict(verified=None, why="no committed checksum for this configuration", key=key)
@@ -525,7 +551,7 @@ def main():
             finally:
                 core.finalize()
             return dict(nx=nx, ny=ny, ndte=ndte, dc=dc, tm=tm, n_active=n_active, dt=dt, tm_ev=tm_ev, kt=kt, per_rank=per_rank,
-                        steps=steps, warmup=warmup, ver=ver, fallbacks=fallbacks, again=again,
+                        steps=steps, warmup=warmup, ver=ver, fallbacks=fallbacks, again=again, each_ms=each_ms,
                         finite=bool(np.isfinite(out["uvel"]).all() and np.isfinite(out["stressp_1"]).all()),
                         umax=float(np.abs(out["uvel"]).max()))
         finally:
@@ -808,7 +834,7 @@ def main():
         return res
 
     ndte = a.ndte or {"gx3": 120, "gx1": 120, "s01": 480}[a.workload]
-    M = measure_with_fallbacks(a.workload, a.case, ndte, a.steps, a.warmup)
+    M = measure_with_fallbacks(a.workload, a.case, ndte, a.steps, a.warmup, median_calls=(10 if a.gpus == 1 else 0))
     nx, ny, dc, tm, n_active, dt, tm_ev, kt = (M[k] for k in ("nx", "ny", "dc", "tm", "n_active", "dt", "tm_ev", "kt"))
     # extras must never cost the primary line: a failure is reported inside the JSON instead
     M2 = M3 = MS = None
@@ -837,7 +863,8 @@ def main():
             # for real xGMI; both are reported)
             # ... and a third time with the ring not through RCCL but as stores into the neighbours' HIP-IPC-mapped inboxes
             M2 = measure_with_fallbacks("s01", "full", 480, 2, 1,
-                                        again_env=([{"CICE_EVP_HIP_MARCH_OVERLAP": "1"}, {"CICE_EVP_HIP_MARCH_DIRECT": "1"}] if world > 1 else None))
+                                        again_env=([{"CICE_EVP_HIP_MARCH_OVERLAP": "1"}, {"CICE_EVP_HIP_MARCH_DIRECT": "1"}]
+                                                   if (world > 1 and "ring_variants" in a.extras) else None))
             M2o = M2.get("again")
         except Exception as e:  # noqa: BLE001
             extra_err["secondary"] = f"{type(e).__name__}: {e}"[:300]
@@ -846,6 +873,18 @@ def main():
             MS = measure(a.workload, a.case, ndte, 5, 2, env={"CICE_EVP_HIP_RESIDENT": "0"})
         except Exception as e:  # noqa: BLE001
             extra_err["streaming"] = f"{type(e).__name__}: {e}"[:300]
+    if want("rccl_control") and world > 1:
+        # the control next to the library's default path: the same workload with every remote ghost cell carried by RCCL
+        # point-to-point (ncclSend / ncclRecv per neighbour and subcycle, streaming kernel) -- what north_star names
+        if rehearsal:
+            extra["rccl_control"] = {"skipped": "rehearsal on one GPU: RCCL refuses two ranks per device"}
+        else:
+            try:
+                Mx = measure_with_fallbacks(a.workload, a.case, ndte, max(2, a.steps // 4), 1, env={"CICE_EVP_HIP_HALO": "rccl"})
+                extra["rccl_control"] = rank_block(Mx, f"{a.workload} {Mx['nx']}x{Mx['ny']} B-grid EVP ndte={ndte}, case={a.case}, {world} GPUs, "
+                                                       "halo forced onto RCCL point-to-point")
+            except Exception as e:  # noqa: BLE001
+                extra_err["rccl_control"] = f"{type(e).__name__}: {e}"[:300]
     if want("configs2") and a.workload == "gx1" and world > 1:
         # BASELINE configs[2]: gx1 at ndte = 240 over the N GPUs -- once on the library's default path (the on-chip kernel
         # trading tagged records through IPC-mapped buffers when every rank fits), once forced onto what the config names:
@@ -946,7 +985,7 @@ def main():
         n_launch = a.steps * (1 if resident else ndte)
         t_kernel = tm_ev["marks_ms"] * 1e-3 / n_launch
         alg_bytes = B_ALG * my_cells * sub_per_launch
-        kshown = ("evp_resident2_tile" if tm_ev["tile_variant"] >= 2000 else "evp_resident_tile") if resident else "evp_subcycle_tile"
+        kshown = "evp_resident2_tile" if resident else "evp_subcycle_tile"
         if resident:
             e = (pmc or {}).get("kernels", {}).get("gx1res") if (a.workload == "gx1" and a.case == "full" and a.strict and world == 1) else None
             same = bool(e and e.get("bench_line_under_trace", {}).get("tile_variant") == tm_ev["tile_variant"])
@@ -1025,6 +1064,7 @@ def main():
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "median_ms_per_step": (float(np.median(M["each_ms"])) if M.get("each_ms") else None),
             "verified": M["ver"].get("verified"),
             "config": {"workload": f"{a.workload} {nx}x{ny} B-grid EVP ndte={ndte}, case={a.case}, "
                                    f"{'strict fp64 (no FMA contraction; bit-identical to the reference)' if a.strict else 'fp64 with FMA contraction'}",

@@ -151,7 +151,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     HIPC(hipStreamCreateWithFlags(&S.stream_comm, hipStreamNonBlocking));
     HIPC(hipEventCreateWithFlags(&S.ev_pack, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&S.ev_halo, hipEventDisableTiming));
-    S.overlap = !(env("CICE_EVP_HIP_NO_OVERLAP") && std::atoi(env("CICE_EVP_HIP_NO_OVERLAP")));
+    S.overlap = !(env_test("CICE_EVP_HIP_NO_OVERLAP") && std::atoi(env_test("CICE_EVP_HIP_NO_OVERLAP")));
     HIPC(hipEventCreate(&S.ev0));
     HIPC(hipEventCreate(&S.ev1));
     HIPC(hipEventCreate(&S.ev2));
@@ -169,11 +169,11 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         S.max_nj = std::max(S.max_nj, S.jhi[b] - S.jlo[b] + 1);
     }
     S.tyb = 4;
-    if (env("CICE_EVP_HIP_TYB")) {
-        const int t = std::atoi(env("CICE_EVP_HIP_TYB"));   // tile height [+100: XCD-contiguous order]
+    if (env_test("CICE_EVP_HIP_TYB")) {
+        const int t = std::atoi(env_test("CICE_EVP_HIP_TYB"));   // tile height [+100: XCD-contiguous order]
         S.tyb = (t % 100 >= 2 && t % 100 <= 9) ? t : 5 + 100 * (t / 100);
     }
-    S.use_graph = !(env("CICE_EVP_HIP_NOGRAPH") && std::atoi(env("CICE_EVP_HIP_NOGRAPH")));
+    S.use_graph = !(env_test("CICE_EVP_HIP_NOGRAPH") && std::atoi(env_test("CICE_EVP_HIP_NOGRAPH")));
 
     for (auto &p : S.stat)
         if (alloc_d(&p, S.n)) return -1;
@@ -200,7 +200,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     if (S.push_ok) S.flags |= EVP_F_PUSH;
     if (derive_metrics(HTE, HTN, dxT, dyT, uarear, tarea)) return -1;
     S.hmask.resize(S.n);
-    S.tyb_forced = env("CICE_EVP_HIP_TYB") != nullptr;
+    S.tyb_forced = env_test("CICE_EVP_HIP_TYB") != nullptr;
     S.ready = true;
     S.uploaded = false;
     S.cur = 0;
@@ -224,6 +224,8 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
 {
     if (!S.ready) return fail(-1, "not initialised");
     if (!f || !iceTmask || !iceUmask) return fail(-1, "null argument");
+    // (every argument check comes before the first copy is enqueued)
+    if (!f[F_WATERX] || !f[F_WATERY] || !f[F_TBU]) return fail(-1, "null field (waterxU / wateryU / TbU)");
     HIPC(hipEventRecord(S.ev2, S.stream));
     CopyBatch B;
     if (!keep_sig) {
@@ -270,7 +272,6 @@ static int upload_impl(const double *const *f, const int32_t *iceTmask, const in
     bool water_is_ocn = true, tbu_zero = true;
     {
         const double *wx = f[F_WATERX], *wy = f[F_WATERY], *uo = f[F_UOCN], *vo = f[F_VOCN], *tb = f[F_TBU];
-        if (!wx || !wy || !tb) return fail(-1, "null field");
         for (size_t k = 0; k < S.n; ++k) {
             const bool um = iceUmask[k] != 0;
             S.hmask[k] = (uint8_t)((iceTmask[k] != 0 ? 1 : 0) | (um ? 2 : 0));
@@ -330,7 +331,7 @@ int cice_evp_hip_subcycle(int32_t ndte)
     if (ndte == 0) return 0;
     HIPC(hipEventRecord(S.ev0, S.stream));
     if (S.res_mode == 1) {
-        if (int rc = (S.res_gen == 2 ? launch_resident2(ndte, S.cur, false) : launch_resident(ndte, S.cur, false))) return rc;
+        if (int rc = launch_resident2(ndte, S.cur, false)) return rc;
         S.res_launched = true;
         HIPC(hipEventRecord(S.ev1, S.stream));
         S.cur ^= (ndte & 1);
@@ -349,7 +350,7 @@ int cice_evp_hip_subcycle(int32_t ndte)
         return 0;
     }
     // RCCL p2p inside a captured graph: opt-in (CICE_EVP_HIP_GRAPH_RCCL=1) until measured on a multi-GPU node
-    const bool graph_rccl = env("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env("CICE_EVP_HIP_GRAPH_RCCL"));
+    const bool graph_rccl = env_test("CICE_EVP_HIP_GRAPH_RCCL") && std::atoi(env_test("CICE_EVP_HIP_GRAPH_RCCL"));
     const bool graph_ok = S.use_graph && (S.plan.peers.empty() || graph_rccl || S.direct.on);
     if (graph_ok) {
         const auto key = std::make_tuple((int)ndte, S.cur, S.flags & S.flags_allowed);
@@ -693,7 +694,7 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
                          S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) : S.march.last_call ? 0.5 :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
-                         (double)(S.res_mode == 1 ? (S.res_gen == 2 ? 2000 + S.res2_logw : 1000 + S.res_logw) : (S.march.last_call ? 3000 + S.march.seglen : S.tyb)), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
+                         (double)(S.res_mode == 1 ? 2000 + S.res2_logw : (S.march.last_call ? 3000 + S.march.seglen : S.tyb)), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
                           S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms, (double)S.res_fallbacks,
                           (double)(S.msk.on ? S.msk.n_send : S.n_send), (double)(S.msk.on ? S.msk.n_recv : S.n_recv)};
     for (int k = 0; k < n && k < 14; ++k) out[k] = v[k];
@@ -936,9 +937,8 @@ int cice_evp_hip_describe_path(char *buf, int32_t n)
 {
     if (!buf || n < 2) return fail(-1, "describe_path: no buffer");
     const State::March &M = S.march;
-    const char *kernel = S.res_mode == 1 ? (S.res_gen == 2 ? (S.res_remote ? "on-chip resident (tagged records, neighbours on other ranks)"
-                                                                          : "on-chip resident (tagged records)")
-                                                           : "on-chip resident (flags)")
+    const char *kernel = S.res_mode == 1 ? (S.res_remote ? "on-chip resident (tagged records, neighbours on other ranks)"
+                                                       : "on-chip resident (tagged records)")
                          : (M.last_call ? "two subcycles per pass (marching)" : "one subcycle per launch (streaming)");
     const char *transport = S.plan.peers.empty() ? "none (one rank)" : (S.direct.on ? "mailbox over HIP IPC" : (S.have_comm ? "RCCL send/recv" : "not set up"));
     const char *ring = (M.mode == 1 && !S.plan.peers.empty())

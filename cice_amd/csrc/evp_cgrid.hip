@@ -58,10 +58,12 @@ __device__ __forceinline__ void visc_replpress(const EvpScalars &p, double stren
 {
     // capping = 1 (the default, capping_method 'max'): the second quotient is multiplied by (1 - 1) = +0 and the product added --
     // a zero of the quotient's sign, which is the first quotient's sign too, so the sum IS the first quotient, bit for bit,
-    // whenever the second one is finite (DminArea > 0 makes both denominators positive; a finite strength).  One division
-    // instead of two; any other case takes the reference's expression.
+    // whenever the second one is finite (DminArea > 0 makes both denominators positive; a finite strength; a Delta that is
+    // a number: with Delta = NaN the reference's sum is NaN -- 0 x NaN -- while fmax would return DminArea, so a blown-up
+    // state takes the reference's expression and stays visible).  One division instead of two; any other case takes the
+    // reference's expression.
     double tmpcalc;
-    if (p.capping == 1.0 && DminArea > 0.0 && fabs(strength) <= 1.7976931348623157e308)
+    if (p.capping == 1.0 && DminArea > 0.0 && fabs(strength) <= 1.7976931348623157e308 && Delta <= 1.7976931348623157e308)
         tmpcalc = strength / fmax(Delta, DminArea);
     else
         tmpcalc = p.capping * (strength / fmax(Delta, DminArea)) + (1.0 - p.capping) * (strength / (Delta + DminArea));

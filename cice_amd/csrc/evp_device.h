@@ -56,30 +56,9 @@ struct EvpArgs {
     int dx_nb;
 };
 
-// On-chip resident subcycle (evp_resident.hip)
-#define EVP_RES_NNB 12
-struct EvpResident {
-    int ndte;
-    int cur0;                  // which ping-pong buffer holds the input velocities
-    int dry;                   // 1: timing / residency probe on scratch velocities, nothing written back
-    unsigned spin_limit;
-    int xcdmap;                // 1: contiguous band of tiles per XCD
-    int dbg;                   // experiments only: bit0 skip neighbour waits, bit1 skip store drain (WRONG results)
-    int *flags;                // [ntiles] completed subcycles per tile, zeroed before the launch
-    const int *nbr;            // [ntiles][EVP_RES_NNB] tiles this tile exchanges velocities with, -1 padded
-    int *err;                  // set non-zero when a spin gave up
-    double *u[2], *v[2];
-    // pointer table in device memory (keeps 28 pointers out of the kernel's SGPR budget):
-    // [0..11] sig buffer 0, [12..23] sig buffer 1, [24..27] strintx strinty taubx tauby
-    double *const *tab;
-};
+// On-chip resident subcycle (evp_resident2.hip): velocities another tile needs travel as tagged 16-byte records
 // logw: log2 of the tile width in T-cells (6, 5, 4 -> tiles of 64x4, 32x8, 16x16 T-cells)
-int evp_resident_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw);
 void evp_resident_geometry(int max_ni, int max_nj, int logw, int *gx, int *gy);
-void evp_launch_resident(const EvpArgs &A, const EvpResident &R, int max_ni, int max_nj, int logw,
-                         bool strict, int cap, hipStream_t st);
-
-// second generation: tagged 16-byte records instead of flags (evp_resident2.hip)
 #define EVP_RES2_RING 256
 struct EvpResident2 {
     int ndte;
@@ -93,7 +72,9 @@ struct EvpResident2 {
     const int *ring_cnt;       // [ntiles]
     void *rec[2];              // [2][ncell] x {u granule, v granule} (2 x 16 bytes), by subcycle parity
     double *u[2], *v[2];       // plain arrays: input from [cur0], final state to both
-    double *const *tab;        // as EvpResident::tab
+    // pointer table in device memory (keeps 28 pointers out of the kernel's SGPR budget):
+    // [0..11] sig buffer 0, [12..23] sig buffer 1, [24..27] strintx strinty taubx tauby
+    double *const *tab;
     int nblocks;               // CICE blocks of this rank (tiles = nblocks x gx x gy)
     const int *order;          // [ntiles] tile run by workgroup w (NULL: identity)
     // 16 x 16 tiles only (rim wave / interior waves, see evp_resident2.hip): which T-cell of the tile a

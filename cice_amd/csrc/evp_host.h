@@ -205,14 +205,12 @@ struct State {
     std::map<std::tuple<int, int, unsigned>, hipGraphExec_t> graphs;
     bool use_graph = true;
 
-    // on-chip resident subcycle (evp_resident.hip)
+    // on-chip resident subcycle (evp_resident2.hip)
     int res_mode = -1;           // -1 undecided, 0 off, 1 on
     bool res_forced = false;
-    int *res_flags = nullptr, *res_nbr = nullptr, *res_err = nullptr;
-    double **res_tab = nullptr;  // device pointer table (EvpResident::tab)
-    double *res_scratch[4] = {}; // u,v ping-pong copies for the dry probe
-    int res_ntiles = 0, res_logw = 6;
-    int res_gen = 1;             // 1: flags (evp_resident.hip), 2: tagged records (evp_resident2.hip)
+    int *res_err = nullptr;
+    double **res_tab = nullptr;  // device pointer table (EvpResident2::tab)
+    int res_ntiles = 0;
     int4 *res2_ring = nullptr;
     int *res2_cnt = nullptr;
     uint8_t *res2_pub = nullptr;
@@ -282,9 +280,14 @@ struct State {
 extern State S;
 
 inline const char *env(const char *k) { return std::getenv(k); }
-// experiment / fault-injection switches: read in the TEST build (-DCICE_EVP_HIP_TESTING -> libcice_evp_hip_testing.so)
-// only; in the production library they are unset whatever the process environment says (evp_host_common.cpp)
-inline const char *env_test(const char *k) { return evp_env_test(k); }
+// experiment / fault-injection / A-B switches: read in the TEST build (-DCICE_EVP_HIP_TESTING -> libcice_evp_hip_testing.so)
+// only; the production library does not even carry their names (a macro, so that the literal is never emitted): what it
+// reads is DEVICE, VERBOSE, HALO, HALO_TIMEOUT_MS, RESIDENT, MARCH, CGRID_ONE, CGRID_RESIDENT (include/cice_evp_hip.h)
+#ifdef CICE_EVP_HIP_TESTING
+#define env_test(k) (std::getenv(k))
+#else
+#define env_test(k) (static_cast<const char *>(nullptr))
+#endif
 
 // mailbox layout: EVP_DIRECT_MAXPEER flag lines, then seq, err, then the inbox
 constexpr size_t DIRECT_SEQ_OFF = (size_t)EVP_DIRECT_MAXPEER * EVP_DIRECT_FLAG_STRIDE * sizeof(unsigned);
@@ -328,12 +331,9 @@ int enqueue_loop(int ndte, int cur0);
 // evp_host_resident.cpp
 bool tripole_seam();
 bool resident_possible(bool with_peers = false);
-int resident_setup(int logw);
 int resident2_setup(int logw);
-bool resident_fits();
 bool resident2_fits(bool remote = false);
 int resident_tables();
-int launch_resident(int ndte, int cur0, bool dry);
 int launch_resident2(int ndte, int cur0, bool dry);
 int resident_check_error();
 int tune_after_upload();

@@ -177,7 +177,7 @@ static bool fused_schedule()
 {
     if (CG.avg_strength && !one_launch()) return false;   // the three-launch kernels need deltaU at the neighbours: five phases
     if (CG.tripole) return false;                // recomputing a neighbour across the fold would sum in mirrored order
-    return !(env("CICE_EVP_HIP_CGRID_FUSED") && !std::atoi(env("CICE_EVP_HIP_CGRID_FUSED")));
+    return !(env_test("CICE_EVP_HIP_CGRID_FUSED") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_FUSED")));
 }
 
 // The kernels push a cell into its ghost images only where there is ice; the reference's ice_HaloUpdate copies every
@@ -234,7 +234,7 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
 static bool geo_derived()
 {
     if (!CG.gmask) return false;
-    if (const char *e = env("CICE_EVP_HIP_CGRID_GEO")) return std::atoi(e) != 0;
+    if (const char *e = env_test("CICE_EVP_HIP_CGRID_GEO")) return std::atoi(e) != 0;
     return true;
 }
 // Checks, on every cell the kernels can read (the blocks' cells with their ghost ring; the ratios and nothing else need

@@ -5,6 +5,7 @@
 // host arithmetic of derive_metrics must round every operation (no FMA)
 #pragma clang fp contract(off)
 
+// (the kernel objects are compiled once and linked into both libraries: their two switches come through this function)
 #ifdef CICE_EVP_HIP_TESTING
 const char *evp_env_test(const char *key) { return std::getenv(key); }
 #else
@@ -52,7 +53,7 @@ void free_all()
     F(S.hte);
     F(S.htn);
     F(S.vrelfac);
-    F(S.res_flags); F(S.res_nbr); F(S.res_err); F(S.res_tab);
+    F(S.res_err); F(S.res_tab);
     F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact); F(S.res2_cuload); F(S.res2_prof);
     if (S.res2_rec_owned) { F(S.res2_rec[0]); F(S.res2_rec[1]); }
     S.res2_rec[0] = S.res2_rec[1] = nullptr;
@@ -65,7 +66,6 @@ void free_all()
     S.res2_rec_raw[0] = S.res2_rec_raw[1] = nullptr;
     S.res2_raw_owned = true;
     F(S.res2_rraw); F(S.res2_peer_raw); F(S.res2_peer_raw_stride);
-    for (auto &p : S.res_scratch) F(p);
     for (auto &p : S.post_geo) F(p);
     for (auto &p : S.post_out) F(p);
     F(S.push);

@@ -71,7 +71,7 @@ int direct_export(HaloBlob &B)
             S.res2_rec_raw[0] = (char *)X.mailbox + X.raw_off;
             S.res2_rec_raw[1] = (char *)X.mailbox + X.raw_off + raw_stride;
         }
-        const int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
+        const int forced_w = env_test("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env_test("CICE_EVP_HIP_RES_LOGW")) : 0;
         for (int logw : {4, 5, 6}) {
             if (forced_w && logw != forced_w) continue;
             if (resident2_setup(logw)) continue;
@@ -322,12 +322,7 @@ int resident_remote_probe()
     HIPC(hipMemcpyAsync(gu.data(), S.u[1], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
     HIPC(hipMemcpyAsync(gv.data(), S.v[0], S.n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
-    {
-        const int gen = S.res_gen;
-        S.res_gen = 2;          // (the probe ran the tagged-record kernel: its error word names tile, subcycle, cell and tags)
-        rc = resident_check_error();
-        S.res_gen = gen;
-    }
+    rc = resident_check_error();
     S.res_mode = -1;            // (resident_check_error parks the mode on failure; decided again at upload)
     for (int b = 0; b < 2; ++b) {
         HIPC(hipMemsetAsync(S.u[b], 0, S.n * sizeof(double), S.stream));

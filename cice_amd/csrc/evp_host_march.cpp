@@ -90,7 +90,7 @@ static bool march_geometry(std::string &why)
     // cells a rank holds beyond its own on every side with a neighbour: the ring is then exchanged every (ext/2 + 1)-th
     // pass only (march_plan.h); 4 = every third pass (every sixth subcycle).  3600 x 2400 as 4x2 pieces, one-GPU rehearsal:
     // 54.3 / 52.3 / 52.0 / 51.2 us per subcycle with ext 0 / 2 / 4 / 6 against 47.0 without any exchange
-    const int ext = env("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env("CICE_EVP_HIP_MARCH_EXT")) & ~1) : 4;
+    const int ext = env_test("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env_test("CICE_EVP_HIP_MARCH_EXT")) & ~1) : 4;
     if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
     M.exch_every = ext / 2 + 1;
     if (PL.peers.size() > (size_t)EVP_MARCH_DIRECT_MAXPEER) { why = "more ring neighbours than the exchange lists hold"; return false; }
@@ -317,7 +317,7 @@ static int march_direct_setup()
     // pack kernel's uncached 8-byte stores take as long (13.4 us) as RCCL's pack + copy kernel (6.4 + 8.3) -- and what it does over
     // xGMI has never been measured; bench.py --gpus N times the 3600 x 2400 block this way too.
     {
-        const bool want = env("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env("CICE_EVP_HIP_MARCH_DIRECT")) &&
+        const bool want = env_test("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env_test("CICE_EVP_HIP_MARCH_DIRECT")) &&
                           !(env("CICE_EVP_HIP_HALO") && !std::strcmp(env("CICE_EVP_HIP_HALO"), "rccl"));
         unsigned no = want ? 0u : 1u;
         HIPC(hipMemcpyAsync(B.bad, &no, sizeof no, hipMemcpyHostToDevice, S.stream));
@@ -454,7 +454,7 @@ static int march_exchange(double *buf, double *buf2, int nf)
     if (PL.peers.empty()) return 0;
     State::March &M = S.march;
     if (nf == EVP_MARCH_S_NF) {
-        const int asked = (env("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env("CICE_EVP_HIP_MARCH_DIRECT"))) ? 1 : 0;
+        const int asked = (env_test("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env_test("CICE_EVP_HIP_MARCH_DIRECT"))) ? 1 : 0;
         if (M.direct >= 0 && asked != M.direct_asked) {       // (bench.py times one state both ways: the switch changed between two calls)
             HIPC(hipStreamSynchronize(S.stream));
             for (void *m : B.dx_mapped) (void)hipIpcCloseMemHandle(m);
@@ -715,7 +715,7 @@ int march_run(int ndte)
     // are advanced twice, and their waves share the SIMDs with the pass they overlap.  On one GPU the transfer is a 7-us
     // device copy; over xGMI it is 1.6 MB per neighbour and pass group, which is what the overlap is for -- bench.py
     // --gpus N times the 3600 x 2400 block both ways so that the first run on a real node decides.
-    const bool overlap = !PL.peers.empty() && B.nband > 0 && env("CICE_EVP_HIP_MARCH_OVERLAP") && std::atoi(env("CICE_EVP_HIP_MARCH_OVERLAP"));
+    const bool overlap = !PL.peers.empty() && B.nband > 0 && env_test("CICE_EVP_HIP_MARCH_OVERLAP") && std::atoi(env_test("CICE_EVP_HIP_MARCH_OVERLAP"));
     for (int k = 0; k < npass; ++k) {
         const bool exch = !PL.peers.empty() && ((k + 1) % M.exch_every == 0 || k == npass - 1);
         EvpMarch A;

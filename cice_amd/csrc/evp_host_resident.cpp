@@ -1,12 +1,10 @@
-// Host side of the on-chip resident kernels (evp_resident.hip, evp_resident2.hip): neighbour /
-// ring tables, residency checks, launches, error word, and the choices made at the first upload.
+// Host side of the on-chip resident kernel (evp_resident2.hip): ring tables, residency checks,
+// launches, error word, and the choices made at the first upload.
 #include "evp_host.h"
 
 namespace evp_host {
 
 // ---- on-chip resident subcycle -------------------------------------------------------
-// Host side of evp_resident.hip: which tiles exchange velocities (producers == readers by
-// symmetry: the 8 surrounding tiles, with cyclic wrap through the ghost-cell images).
 // (a rank of a fold row split in x may hold neither a pole point nor a pair with both halves: its seam cells are the plan's
 // general list then -- 3 x 1 and 4 x 1 cuts of tx1 showed it: two of the ranks ran without any fold handling)
 bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0 || S.plan.tail > 0 || !S.plan.fin_dst.empty(); }
@@ -32,72 +30,7 @@ bool resident_possible(bool with_peers)
     return true;
 }
 
-int resident_setup(int logw)
-{
-    if (S.res_nbr && S.res_logw == logw) return 0;
-    if (S.res_nbr) { (void)hipFree(S.res_nbr); S.res_nbr = nullptr; }
-    if (S.res_flags) { (void)hipFree(S.res_flags); S.res_flags = nullptr; }
-    S.res_logw = logw;
-    const int W = 1 << logw, H = 256 / W;
-    int gx, gy;
-    evp_resident_geometry(S.max_ni, S.max_nj, logw, &gx, &gy);
-    const int ntiles = gx * gy;
-    const int nx = S.d.nx_block, ny = S.d.ny_block;
-    const int ilo = S.ilo[0], ihi = S.ihi[0], jlo = S.jlo[0], jhi = S.jhi[0];
-    // producer of every cell of the (single) block: tile id, or -1 (never written)
-    std::vector<int> prod((size_t)nx * ny, -1);
-    for (int j = jlo; j <= jhi; ++j)
-        for (int i = ilo; i <= ihi; ++i)
-            prod[(size_t)(j - 1) * nx + (i - 1)] = ((j - jlo) / (H - 1)) * gx + (i - ilo) / (W - 1);
-    for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
-        if (S.plan.local_src[k] >= 0) prod[S.plan.local_dst[k]] = prod[S.plan.local_src[k]];
-    std::vector<int> nbr((size_t)ntiles * EVP_RES_NNB, -1);
-    for (int by = 0; by < gy; ++by)
-        for (int bx = 0; bx < gx; ++bx) {
-            const int t = by * gx + bx;
-            int cnt = 0;
-            // velocities read by the T-cells of this tile: i0-1..i0+W-1, j0-1..j0+H-1
-            const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
-            for (int j = j0 - 1; j <= j0 + H - 1; ++j)
-                for (int i = i0 - 1; i <= i0 + W - 1; ++i) {
-                    if (i < 1 || i > nx || j < 1 || j > ny) continue;
-                    const int p = prod[(size_t)(j - 1) * nx + (i - 1)];
-                    if (p < 0 || p == t) continue;
-                    bool seen = false;
-                    for (int e = 0; e < cnt; ++e) seen |= nbr[(size_t)t * EVP_RES_NNB + e] == p;
-                    if (seen) continue;
-                    if (cnt >= EVP_RES_NNB) return fail(-6, "resident: too many neighbour tiles");
-                    nbr[(size_t)t * EVP_RES_NNB + cnt++] = p;
-                }
-        }
-    // symmetry (a reader must also be waited for before its input is overwritten)
-    for (int t = 0; t < ntiles; ++t)
-        for (int e = 0; e < EVP_RES_NNB; ++e) {
-            const int p = nbr[(size_t)t * EVP_RES_NNB + e];
-            if (p < 0) continue;
-            bool back = false;
-            int cntp = 0;
-            for (int f = 0; f < EVP_RES_NNB; ++f) {
-                back |= nbr[(size_t)p * EVP_RES_NNB + f] == t;
-                cntp += nbr[(size_t)p * EVP_RES_NNB + f] >= 0;
-            }
-            if (!back) {
-                if (cntp >= EVP_RES_NNB) return fail(-6, "resident: too many neighbour tiles");
-                nbr[(size_t)p * EVP_RES_NNB + cntp] = t;
-            }
-        }
-    S.res_ntiles = ntiles;
-    HIPC(hipMalloc((void **)&S.res_nbr, nbr.size() * sizeof(int)));
-    HIPC(hipMemcpy(S.res_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPC(hipMalloc((void **)&S.res_flags, (size_t)ntiles * sizeof(int)));
-    if (!S.res_err) {
-        HIPC(hipMalloc((void **)&S.res_err, 8 * sizeof(int)));
-        HIPC(hipMemset(S.res_err, 0, 8 * sizeof(int)));
-    }
-    return 0;
-}
-
-// ---- second generation (evp_resident2.hip): ring lists and publish map of a tile shape ------
+// ---- evp_resident2.hip: ring lists and publish map of a tile shape ------
 // For every tile: the cells of its LDS velocity tile that it reads but does not produce itself
 // (ring + ghost/truncation cells), each with the record to poll and the U-cell that produces
 // it; and the map of U-cells some other tile mirrors (those publish a record each subcycle).
@@ -424,17 +357,6 @@ int launch_resident2(int ndte, int cur0, bool dry)
     return 0;
 }
 
-// every workgroup must be resident at once: occupancy query x CUs, with a margin
-bool resident_fits()
-{
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
-    const unsigned fl = S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);   // worst-case LDS need, see resident2_fits
-    const int per_cu = std::min(evp_resident_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res_logw), 8);
-    const long cap = (long)per_cu * prop.multiProcessorCount;
-    return S.res_ntiles > 0 && (long)S.res_ntiles * 10 <= cap * 9;
-}
-
 int resident_tables()
 {
     if (!S.res_tab) {
@@ -454,34 +376,6 @@ int resident_tables()
     return 0;
 }
 
-int launch_resident(int ndte, int cur0, bool dry)
-{
-    EvpArgs A;
-    fill_args(A, cur0, 1);
-    EvpResident R;
-    R.ndte = ndte;
-    R.cur0 = dry ? 0 : cur0;
-    R.dry = dry ? 1 : 0;
-    R.spin_limit = 4000000u;
-    R.xcdmap = env_test("CICE_EVP_HIP_RES_XCD") ? std::atoi(env_test("CICE_EVP_HIP_RES_XCD")) : 0;
-    R.dbg = env_test("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_RES_DEBUG")) : 0;
-    R.flags = S.res_flags;
-    R.nbr = S.res_nbr;
-    R.err = S.res_err;
-    if (dry) {
-        R.u[0] = S.res_scratch[0]; R.v[0] = S.res_scratch[1];
-        R.u[1] = S.res_scratch[2]; R.v[1] = S.res_scratch[3];
-    } else {
-        R.u[0] = S.u[0]; R.v[0] = S.v[0]; R.u[1] = S.u[1]; R.v[1] = S.v[1];
-    }
-    if (int rc = resident_tables()) return rc;
-    R.tab = S.res_tab + (dry ? 28 * (1 + cur0) : 0);
-    HIPC(hipMemsetAsync(S.res_flags, 0, (size_t)S.res_ntiles * sizeof(int), S.stream));
-    evp_launch_resident(A, R, S.max_ni, S.max_nj, S.res_logw, S.prm.strict != 0, cap_mode(), S.stream);
-    HIPC(hipGetLastError());
-    return 0;
-}
-
 int resident_check_error()
 {
     if (!S.res_launched) return 0;
@@ -492,13 +386,11 @@ int resident_check_error()
     if (e) {
         HIPC(hipMemset(S.res_err, 0, sizeof ev));
         S.res_mode = 0;
-        if (S.res_gen == 2)
-            return fail(-7, "resident EVP kernel: a wait gave up (%s; tile %d, subcycle %d, cell %d, tag seen %#x, wanted %#x)%s",
-                        e == 1 ? "record of this GPU" : e == 2 ? "record of another rank" : e == 3 ? "fold-row partner" : "?",
-                        ev[1], ev[2], ev[3], (unsigned)ev[4], (unsigned)ev[5],
-                        e == 2 ? " -- CICE_EVP_HIP_HALO_TIMEOUT_MS bounds the wait for other ranks"
-                               : " -- workgroups not co-resident?");
-        return fail(-7, "resident EVP kernel: a neighbour-flag wait timed out (workgroups not co-resident?)");
+        return fail(-7, "resident EVP kernel: a wait gave up (%s; tile %d, subcycle %d, cell %d, tag seen %#x, wanted %#x)%s",
+                    e == 1 ? "record of this GPU" : e == 2 ? "record of another rank" : e == 3 ? "fold-row partner" : "?",
+                    ev[1], ev[2], ev[3], (unsigned)ev[4], (unsigned)ev[5],
+                    e == 2 ? " -- CICE_EVP_HIP_HALO_TIMEOUT_MS bounds the wait for other ranks"
+                           : " -- workgroups not co-resident?");
     }
     return 0;
 }
@@ -547,58 +439,40 @@ int tune_after_upload()
         if (want != 0 && S.res_remote && S.direct.on) {
             // neighbours on other GPUs: tile shape fixed at export, no timing probes (every launch
             // of this kernel is collective across ranks)
-            S.res_gen = 2;
             S.res_mode = 1;
         } else if (want != 0 && resident_possible()) {
-            const int forced_w = env("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env("CICE_EVP_HIP_RES_LOGW")) : 0;
-            const int forced_g = env("CICE_EVP_HIP_RES_GEN") ? std::atoi(env("CICE_EVP_HIP_RES_GEN")) : 0;
+            const int forced_w = env_test("CICE_EVP_HIP_RES_LOGW") ? std::atoi(env_test("CICE_EVP_HIP_RES_LOGW")) : 0;
             float best = 1e30f;
-            int best_w = 0, best_g = 0;
-            bool any_fit = false, done = false;
-            for (int gen : {2, 1}) {
-                if (done || (forced_g && gen != forced_g)) continue;
-                if (gen == 1 && (tripole_seam() || S.d.nblocks > 1)) continue;   // fold row / several blocks: gen 2 only
-                for (int logw : {5, 4, 6}) {
-                    if (forced_w && logw != forced_w) continue;
-                    if (gen == 1) {
-                        if (resident_setup(logw)) { if (want == 1) return -6; continue; }
-                        if (!resident_fits()) continue;
-                        for (auto &p : S.res_scratch)
-                            if (!p && alloc_d(&p, S.n)) return -1;
-                    } else {
-                        if (resident2_setup(logw)) { if (want == 1) return -6; continue; }
-                        if (!resident2_fits()) continue;
-                    }
-                    any_fit = true;
-                    if (want == 1 && forced_w && forced_g) { best = 0.0f; best_w = logw; best_g = gen; done = true; break; }
-                    // steady-state cost per subcycle = slope between a short and a long dry run
-                    // (launch, prologue and epilogue are paid once per evp() call)
-                    const int nshort = 8, nlong = 40;
-                    float tres = 1e30f, tl[2] = {0, 0};
-                    bool ok = true;
-                    for (int rep = 0; rep < 3 && ok; ++rep) {
-                        const int np = (rep == 2) ? nlong : nshort;      // rep 0 warms up
-                        if (gen == 1)
-                            for (int q = 0; q < 4; ++q)
-                                HIPC(hipMemcpyAsync(S.res_scratch[q], (q & 1) ? S.v[S.cur] : S.u[S.cur],
-                                                    S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
-                        HIPC(hipEventRecord(S.ev2, S.stream));
-                        if (int rc = (gen == 1 ? launch_resident(np, S.cur, true) : launch_resident2(np, S.cur, true))) return rc;
-                        HIPC(hipEventRecord(S.ev3, S.stream));
-                        HIPC(hipStreamSynchronize(S.stream));
-                        S.res_launched = true;
-                        if (resident_check_error()) { ok = false; g_err.clear(); break; }   // a tolerated probe failure is not the caller's error
-                        HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
-                        if (rep >= 1) tl[rep - 1] = ms;
-                    }
-                    if (ok) tres = (tl[1] - tl[0]) / (nlong - nshort);
-                    if (ok && tres < best) { best = tres; best_w = logw; best_g = gen; }
+            int best_w = 0;
+            bool any_fit = false;
+            for (int logw : {5, 4, 6}) {
+                if (forced_w && logw != forced_w) continue;
+                if (resident2_setup(logw)) { if (want == 1) return -6; continue; }
+                if (!resident2_fits()) continue;
+                any_fit = true;
+                if (want == 1 && forced_w) { best = 0.0f; best_w = logw; break; }
+                // steady-state cost per subcycle = slope between a short and a long dry run
+                // (launch, prologue and epilogue are paid once per evp() call)
+                const int nshort = 8, nlong = 40;
+                float tres = 1e30f, tl[2] = {0, 0};
+                bool ok = true;
+                for (int rep = 0; rep < 3 && ok; ++rep) {
+                    const int np = (rep == 2) ? nlong : nshort;      // rep 0 warms up
+                    HIPC(hipEventRecord(S.ev2, S.stream));
+                    if (int rc = launch_resident2(np, S.cur, true)) return rc;
+                    HIPC(hipEventRecord(S.ev3, S.stream));
+                    HIPC(hipStreamSynchronize(S.stream));
+                    S.res_launched = true;
+                    if (resident_check_error()) { ok = false; g_err.clear(); break; }   // a tolerated probe failure is not the caller's error
+                    HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+                    if (rep >= 1) tl[rep - 1] = ms;
                 }
+                if (ok) tres = (tl[1] - tl[0]) / (nlong - nshort);
+                if (ok && tres < best) { best = tres; best_w = logw; }
             }
             S.t_res_probe_ms = best_w ? best : -1.0;
             if (best_w && (want == 1 || S.t_stream_probe_ms <= 0.0 || best < S.t_stream_probe_ms)) {
-                if (int rc = (best_g == 1 ? resident_setup(best_w) : resident2_setup(best_w))) return rc;
-                S.res_gen = best_g;
+                if (int rc = resident2_setup(best_w)) return rc;
                 S.res_mode = 1;
             } else if (want == 1) {
                 return fail(-6, any_fit ? "resident EVP kernel requested but its probe failed"

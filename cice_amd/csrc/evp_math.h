@@ -1,5 +1,5 @@
 // Device-side arithmetic shared by evp_kernels.hip (streaming tiles) and
-// evp_resident.hip (on-chip resident subcycle): constants, the two builds of the
+// evp_resident2.hip (on-chip resident subcycle): constants, the two builds of the
 // per-cell formulas (strict / fused) and a traits struct selecting between them.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,11 +1,10 @@
 // =====================================================================
-// On-chip resident EVP subcycle, second generation: tagged hand-off.
+// On-chip resident EVP subcycle: tagged hand-off.
 //
-// evp_resident.hip publishes a tile's velocities and then a flag; the neighbours
-// poll the flag, pass a barrier and only then load the velocities: per subcycle
-// one store drain, one flag round trip and one data round trip sit on the critical
-// path (~55 % of its time, measured with shader-clock stamps).  Here the data IS the
-// flag: a velocity that another tile needs is published as one aligned 16-byte granule
+// (A first generation, retired in round 5, published a tile's velocities and then a flag; the
+// neighbours polled the flag, passed a barrier and only then loaded the velocities: per subcycle
+// one store drain, one flag round trip and one data round trip sat on the critical path,
+// ~55 % of its time by shader-clock stamps.)  Here the data IS the flag: a velocity that another tile needs is published as one aligned 16-byte granule
 //      { tag, value.lo, value.hi, tag }        tag = launch epoch | subcycle
 // written by ONE write-through (sc1) dwordx4 store; the reader re-reads the granule
 // (sc1, L1-bypassing) until both tags carry the subcycle it waits for -- a torn
@@ -15,8 +14,7 @@
 // (<= 2(W+H) threads, one granule pair each).  Records are double-buffered by subcycle
 // parity; a tile can be at most one subcycle ahead of a neighbour, so two suffice.
 //
-// Same arithmetic, tile shapes and ownership rules as evp_resident.hip / the streaming
-// kernel => same bits.  Every spin is bounded and raises the error word.
+// Same arithmetic and ownership rules as the streaming kernel => same bits.  Every spin is bounded and raises the error word.
 //
 // Rim wave / interior waves (PERM, the 16 x 16 tile).  A subcycle of a tile is a dependent chain:
 // neighbours publish -> ring poll -> stress -> barrier -> momentum step -> publish.  Only the T-cells
@@ -32,6 +30,17 @@
 // =====================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+// Debug hooks (lagging tiles, a workgroup that never shows up, A/B switches) and the per-phase cycle stamps exist in the
+// TEST build's object of this file only (-DCICE_EVP_HIP_TESTING, linked into libcice_evp_hip_testing.so): the product
+// kernel does not test R.dbg / R.prof at all.
+#ifdef CICE_EVP_HIP_TESTING
+#define RES_DBG(R) ((R).dbg)
+#define RES_PROF(R) ((R).prof != nullptr)
+#else
+#define RES_DBG(R) 0
+#define RES_PROF(R) false
+#endif
 
 #include "evp_math.h"
 
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // a small per-CU record under a lock, once per launch).  Speed only: any chunk -> wave map is correct.
     int tq = t;
     int cu_rank = 0;                          // how many workgroups had reached this CU before this one
-    if (PERM && R.cuload && !(R.dbg & 64)) {
+    if (PERM && R.cuload && !(RES_DBG(R) & 64)) {
         const int wave = t >> 6;
         if ((t & 63) == 0) {
             unsigned hw, xcc;
@@ -190,8 +199,8 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // with exactly one such wave (every 16 x 16 tile: rim <= 60 cells, ring <= 64 entries) the others
     // never wait for it before their stress update ("split")
     const int late_waves = PERM ? (int)R.late_waves[tile] : 4;
-    const bool split = PERM && late_waves <= 1 && !(R.dbg & 32);
-    if ((R.dbg & 16) && tile == 1 && !R.dry) return;   // test hook: one workgroup "never becomes resident" (after the probes)
+    const bool split = PERM && late_waves <= 1 && !(RES_DBG(R) & 32);
+    if ((RES_DBG(R) & 16) && tile == 1 && !R.dry) return;   // test hook: one workgroup "never becomes resident" (after the probes)
     const int per_blk = A.gx * A.gy;
     const int bz = tile / per_blk;                // CICE block of this rank
     const int bx = (tile % per_blk) % A.gx;
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // optional phase stamps of every wave (CICE_EVP_HIP_RES_PROF=1, tools/resident_phases.py): shader cycles
     // spent in [ring poll | stress | wait at the barrier before the momentum step | momentum step, seam,
     // publish | wait at the barrier that ends the subcycle]
-    const bool prof = R.prof != nullptr;
+    const bool prof = RES_PROF(R);
     unsigned long long pc0 = 0, pacc0 = 0, pacc1 = 0, pacc2 = 0, pacc3 = 0, pacc4 = 0;
     if (prof) pc0 = __builtin_readcyclecounter();
 #define EVP_STAMP(acc)                                                  \
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         const v4u *rd = (const v4u *)R.rec[(k + par0) & 1];
         v4u *wr = (v4u *)R.rec[((k + par0) & 1) ^ 1];
 
-        if ((R.dbg & 8) && (tile & 3) == 1) {      // robustness test: every fourth tile lags by ~10 us per subcycle
+        if ((RES_DBG(R) & 8) && (tile & 3) == 1) {      // robustness test: every fourth tile lags by ~10 us per subcycle
             const unsigned long long t0 = wall_clock64();
             while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(8);
         }
@@ -446,13 +455,13 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             if (!poll_remote(rd + 2 * (size_t)ring_cp, want, ra, rb)) s_bad = 1;
             s_u[ring_li] = unpack_rec(ra);
             s_v[ring_li] = unpack_rec(rb);
-        } else if (ring_cp >= 0 && !(R.dbg & 2)) {
+        } else if (ring_cp >= 0 && !(RES_DBG(R) & 2)) {
             v4u ra, rb;
             unsigned spins = 0;
             if (REMOTE) t_wait0 = wall_clock64();
             for (;;) {
                 ld_rec2(rd + 2 * (size_t)ring_cp, ra, rb);
-                if ((ra.x == want && ra.w == want && rb.x == want && rb.w == want) || (R.dbg & 1)) break;
+                if ((ra.x == want && ra.w == want && rb.x == want && rb.w == want) || (RES_DBG(R) & 1)) break;
                 // a local neighbour may itself be waiting for another rank: with remote neighbours
                 // every wait is bounded by wall-clock time, not by a spin count
                 if (gave_up(++spins, t_wait0)) {
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                     s_bad = 1;
                     break;
                 }
-                if (R.dbg & 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
+                if (RES_DBG(R) & 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
             }
             s_u[ring_li] = unpack_rec(ra);
             s_v[ring_li] = unpack_rec(rb);
@@ -682,6 +691,13 @@ void launch(const EvpArgs &A, const EvpResident2 &R, bool strict, int cap, hipSt
 }
 
 }  // namespace
+
+void evp_resident_geometry(int max_ni, int max_nj, int logw, int *gx, int *gy)
+{
+    const int W = 1 << logw, H = 256 / W;
+    *gx = (max_ni + W - 2) / (W - 1);
+    *gy = (max_nj + H - 2) / (H - 1);
+}
 
 int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote)
 {

@@ -62,11 +62,14 @@ TEST_EXPORTS = [
 # of on-device copies through the remote transports.  An EvpHip made while one of them is set uses the test build.
 TEST_ENV = [
     "CICE_EVP_HIP_RES_REMOTE", "CICE_EVP_HIP_RES_REMOTE_BREAK", "CICE_EVP_HIP_RES_ORDER", "CICE_EVP_HIP_RES_PROF", "CICE_EVP_HIP_RES_DEBUG",
-    "CICE_EVP_HIP_RES_XCD", "CICE_EVP_HIP_MARCH_OWN", "CICE_EVP_HIP_MARCH_SELFX", "CICE_EVP_HIP_MARCH_SEG", "CICE_EVP_HIP_MARCH_ORDER",
+    "CICE_EVP_HIP_MARCH_OWN", "CICE_EVP_HIP_MARCH_SELFX", "CICE_EVP_HIP_MARCH_SEG", "CICE_EVP_HIP_MARCH_ORDER",
     "CICE_EVP_HIP_MARCH_LEAN", "CICE_EVP_HIP_CGRID_SPLIT", "CICE_EVP_HIP_CGRID_XCD", "CICE_EVP_HIP_CGRID_ONE_XCD", "CICE_EVP_HIP_CGRID_ONE_SHAPE",
     "CICE_EVP_HIP_CGRID_ONE_STRIP", "CICE_EVP_HIP_CGRID_FAST", "CICE_EVP_HIP_HALO_DEBUG", "CICE_EVP_HIP_SEAM_FIN", "CICE_EVP_HIP_OVERLAP",
     "CICE_EVP_HIP_HALO_RIDE", "CICE_EVP_HIP_GATHER", "CICE_EVP_HIP_SIMPLE", "CICE_EVP_HIP_SELF_EXCHANGE", "CICE_EVP_HIP_FLAGS", "CICE_EVP_HIP_LEAN",
     "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY", "CICE_EVP_HIP_MARCH_BANDSEG", "CICE_EVP_HIP_CGRID_PROF",
+    # A/B switches of kernels and transports (forced tile shapes, schedules the default never picks, the ring exchange's other forms)
+    "CICE_EVP_HIP_NO_OVERLAP", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_NOGRAPH", "CICE_EVP_HIP_GRAPH_RCCL", "CICE_EVP_HIP_RES_LOGW",
+    "CICE_EVP_HIP_MARCH_EXT", "CICE_EVP_HIP_MARCH_DIRECT", "CICE_EVP_HIP_MARCH_OVERLAP", "CICE_EVP_HIP_CGRID_FUSED", "CICE_EVP_HIP_CGRID_GEO",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",

@@ -390,22 +390,9 @@ contains
             dxhy, dyhx, c_null_ptr), subname, __FILE__, __LINE__)
     endif
 
-    on_tripole = trim(ns_boundary_type) == 'tripole'
     call get_environment_variable('CICE_EVP_HIP_STRESS_RESIDENT', envval, envlen, envstat)
-    stress_resident = stress_resident_requested .or. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '1')
-    ! (a rank layout that cuts the tripole seam row in x is fine too: cice_evp_hip_stress_halo reaches the partners on
-    ! other ranks through the velocity exchange of a shifted copy)
-    ! tripoleT: the device does the symmetrisation where the top row lies on one rank (cice_evp_hip_stress_halo_available);
-    ! elsewhere the stresses travel every call and evp() applies it to its own arrays
-    if (trim(ns_boundary_type) == 'tripoleT') then
-       if (cice_evp_hip_stress_halo_available() == 1) then
-          on_tripole = .true.
-       else
-          stress_resident = .false.
-       endif
-    endif
-    call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
-         subname, __FILE__, __LINE__)
+    call settle_stress_residency(stress_resident_requested .or. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '1'), &
+         .false.)
 
     if (nprocs > 1) then
        ! RCCL bootstrap: the master's ncclUniqueId travels over CICE's own broadcast
@@ -1022,6 +1009,37 @@ contains
   end subroutine dyn_evp_hip_cgrid_dyn_finish
 
 !-----------------------------------------------------------------------
+! The one place that decides whether the stresses stay on the device (dyn_evp_hip_init and
+! dyn_evp_hip_keep_stresses_resident both come here).  Resident stresses on a tripole / tripoleT grid need the device to
+! do what evp()'s twelve ice_HaloUpdate_stress calls do on the host arrays (ice_dyn_evp.F90:1321-1389), and every rank
+! must reach the same verdict: tripole -- always possible; tripoleT -- only where cice_evp_hip_stress_halo_available()
+! says so on EVERY rank (MIN over the ranks: one rank with its top row split falls back, so all do, and
+! dyn_evp_hip_fetch_stresses / restart behaviour never depends on the rank).  explicit = the host asked for it after
+! initialisation: a request that cannot be honoured aborts instead of silently leaving the device copy unsymmetrised.
+  subroutine settle_stress_residency(want, explicit)
+    use ice_domain, only: ns_boundary_type, distrb_info
+    use ice_global_reductions, only: global_minval
+    logical, intent(in) :: want, explicit
+    integer (kind=int_kind) :: avail
+    character(len=*), parameter :: subname = '(settle_stress_residency)'
+    on_tripole = trim(ns_boundary_type) == 'tripole'
+    stress_resident = want
+    if (trim(ns_boundary_type) == 'tripoleT') then
+       avail = cice_evp_hip_stress_halo_available()
+       avail = global_minval(avail, distrb_info)
+       if (avail == 1) then
+          on_tripole = .true.
+       else if (want .and. explicit) then
+          call abort_ice(subname//' ERROR: device-resident stresses need the tripoleT fold row on one rank'// &
+               ' (cice_evp_hip_stress_halo_available() == 0 on some rank)', file=__FILE__, line=__LINE__)
+       else
+          stress_resident = .false.
+       endif
+    endif
+    call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
+         subname, __FILE__, __LINE__)
+  end subroutine settle_stress_residency
+
 ! ice_flux's stress arrays <- the device copy.  Call before anything but evp() reads them (restart write,
 ! history).  No-op unless the stresses are resident.
   subroutine dyn_evp_hip_fetch_stresses
@@ -1048,9 +1066,7 @@ contains
     stress_resident_requested = flag
     if (.not. initialised) return
     if (.not. flag .and. stress_resident) call dyn_evp_hip_fetch_stresses
-    stress_resident = flag
-    call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
-         subname, __FILE__, __LINE__)
+    call settle_stress_residency(flag, .true.)
   end subroutine dyn_evp_hip_keep_stresses_resident
 
 ! The host changed ice_flux's stress arrays itself (restart read): the next evp() uploads them again.

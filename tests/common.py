@@ -129,13 +129,27 @@ def tfold_untouched(c: "GoldenCase"):
     return keep
 
 
+def bits_equal(a, b) -> bool:
+    """Bit-for-bit equality: fp64 arrays are compared as their 64-bit patterns, so +0.0 and -0.0 differ and a NaN equals
+    only the same NaN (np.array_equal compares values: it lets a sign-of-zero difference through).  Other dtypes: values."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype == np.float64 and b.dtype == np.float64:
+        return bool(np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64)))
+    return bool(np.array_equal(a, b))
+
+
 def assert_bitwise(got: dict, want: dict, what=""):
     bad = []
     for k, w in want.items():
         g = got[k]
-        if not np.array_equal(g, w):
-            ne = np.argwhere(g != w)
-            bad.append(f"{k}: {len(ne)} cells differ, max|d|={np.abs(g - w).max():.3e}, first at {ne[0].tolist()}")
+        if not bits_equal(g, w):
+            gb, wb = (np.ascontiguousarray(x, dtype=np.float64).view(np.uint64) for x in (g, w))
+            ne = np.argwhere(gb != wb)
+            nz = int(((g == w) & (gb != wb)).sum())
+            bad.append(f"{k}: {len(ne)} cells differ ({nz} of them only in the sign of zero), max|d|={np.nanmax(np.abs(g - w)):.3e}, "
+                       f"first at {ne[0].tolist()}")
     assert not bad, f"{what} not bit-identical:\n  " + "\n  ".join(bad)
 
 

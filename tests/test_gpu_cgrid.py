@@ -7,7 +7,7 @@ import pytest
 
 import oracle
 from cice_amd import evp
-from common import CGRID_CASES, CGRID_TFOLD_CASES, GoldenCase, assert_bitwise
+from common import CGRID_CASES, CGRID_TFOLD_CASES, GoldenCase, assert_bitwise, bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -68,7 +68,7 @@ def test_cgrid_dyn_finish_on_device_bitwise(name):
                 got = core.cgrid_dyn_finish(prev=sent)
                 for k in keys:
                     on = lists[k[-1]]
-                    assert np.array_equal(got[k][on], want[k][on]), f"{name} call {icall} nsub {nsub} {k}"
+                    assert bits_equal(got[k][on], want[k][on]), f"{name} call {icall} nsub {nsub} {k}"
                     assert (got[k][~on] == 7.25).all(), f"{k}: a cell off the list was written"
         assert np.abs(want["strocnxE"]).max() > 0 and np.abs(want["strocnyN"]).max() > 0
     finally:
@@ -100,7 +100,7 @@ def test_cgrid_deformations_t_on_device_bitwise(name):
                     ilo, ihi, jlo, jhi = [int(v) for v in blk[b, :4]]
                     onlist[b, jlo - 1:jhi + 1, ilo - 1:ihi + 1] = tm[b, jlo - 1:jhi + 1, ilo - 1:ihi + 1]
                 for k in keys:
-                    assert np.array_equal(got[k][onlist], want[k][onlist]), f"{name} call {icall} nsub {nsub} {k}"
+                    assert bits_equal(got[k][onlist], want[k][onlist]), f"{name} call {icall} nsub {nsub} {k}"
                     assert (got[k][~onlist] == sent[k][~onlist]).all(), f"{k}: a cell off the T list was written"
         assert np.abs(want["divu"]).max() > 0 and np.abs(want["vort"]).max() > 0
     finally:
@@ -411,7 +411,7 @@ def test_cgrid_default_configuration_shortcuts_are_bit_neutral(monkeypatch):
     c = GoldenCase("cgrid_cyc_2x2_patchy")
     dom = c.oracle_domain()
     state, inputs, masks = c.cgrid_inputs(1)
-    assert np.array_equal(inputs["waterxE"][masks["iceEmask"] != 0], inputs["uocnE"][masks["iceEmask"] != 0])
+    assert bits_equal(inputs["waterxE"][masks["iceEmask"] != 0], inputs["uocnE"][masks["iceEmask"] != 0])
     assert not inputs["TbE"].any() and (inputs["rheofactE"][masks["iceEmask"] != 0] == 1.0).all()
     outs = []
     for fast in ("1", "0"):
@@ -509,7 +509,7 @@ def test_cgrid_many_small_blocks_and_zero_subcycles():
     finally:
         core.finalize()
     for k in evp.CGRID_FIELDS[:14]:
-        assert np.array_equal(out[k], state[k]), k
+        assert bits_equal(out[k], state[k]), k
     for k in evp.CGRID_FIELDS[14:]:
         assert not out[k].any(), k
 
@@ -573,7 +573,7 @@ def test_cgrid_prep_on_device_bitwise(name):
             masks = device_prep(core, c, icall, {k: st[k] for k in oracle.C_FIELDS[:12]})
             want_state, want_in, want_masks = c.cgrid_inputs(icall)
             for k in oracle.C_MASKS:
-                assert np.array_equal(masks[k] != 0, want_masks[k] != 0), f"{name} call {icall} {k}"
+                assert bits_equal(masks[k] != 0, want_masks[k] != 0), f"{name} call {icall} {k}"
             got = {k: core.cgrid_fetch(k) for k in list(want_state) + [k for k in want_in if k != "strength"]}
             oracle.halo_update(dom, got["strintxE"], "Eface", "vector")      # (the fixture's post-loop exchange, see above)
             oracle.halo_update(dom, got["strintyN"], "Nface", "vector")
@@ -612,7 +612,7 @@ def test_cgrid_prep_keeps_the_state_on_the_device_between_calls():
         masks = device_prep(core, c, 2, None)
         want_state, want_in, want_masks = c.cgrid_inputs(2)
         for k in oracle.C_MASKS:
-            assert np.array_equal(masks[k] != 0, want_masks[k] != 0), k
+            assert bits_equal(masks[k] != 0, want_masks[k] != 0), k
         got = {k: core.cgrid_fetch(k) for k in want_state}
         oracle.halo_update(dom, got["strintxE"], "Eface", "vector")
         oracle.halo_update(dom, got["strintyN"], "Nface", "vector")
@@ -680,7 +680,7 @@ def test_cgrid_prep_synthetic_vs_oracle_bitwise(grid, bs, case, coupled):
         core.cgrid_set_prep_geometry(static)
         got = core.cgrid_prep(evp.PrepParams(**ppd, ssh_stress_coupled=int(coupled)), tb, state, prevb)
         for k in oracle.C_MASKS:
-            assert np.array_equal(got[k] != 0, want[k] != 0), k
+            assert bits_equal(got[k] != 0, want[k] != 0), k
         for k in ("iceEmask", "iceNmask"):          # the case must make faces gain and lose ice
             new, old = want[k] != 0, prevb[k] != 0
             assert (new & ~old).any() and (old & ~new).any(), k
@@ -745,7 +745,7 @@ def test_cgrid_prep_and_loop_random_geometry_vs_oracle(seed):
         core.cgrid_set_prep_geometry(static)
         got = core.cgrid_prep(evp.PrepParams(**ppd, ssh_stress_coupled=int(coupled)), tb, state, prevb)
         for k in oracle.C_MASKS:
-            assert np.array_equal(got[k] != 0, want[k] != 0), (what, k)
+            assert bits_equal(got[k] != 0, want[k] != 0), (what, k)
         keys = oracle.C_FIELDS[:14] + [k for k in oracle.C_INPUTS if k != "strength"]
         assert_bitwise({k: core.cgrid_fetch(k) for k in keys}, {k: want[k] for k in keys}, what + " (preparation)")
         core.cgrid_prep_finish(strength, visc)
@@ -823,7 +823,7 @@ def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
             _, st, _ = c.cgrid_prep_inputs(icall)
             masks_d = device_prep(core, c, icall, {k: st[k] for k in oracle.C_FIELDS[:12]})
             for k in oracle.C_MASKS:
-                assert np.array_equal(masks_d[k] != 0, masks[k] != 0), (what, icall, k)
+                assert bits_equal(masks_d[k] != 0, masks[k] != 0), (what, icall, k)
             core.cgrid_subcycle(c.nsub_list[-1])
             out = core.cgrid_download()
             oracle.halo_update(dom, out["strintxE"], "Eface", "vector")

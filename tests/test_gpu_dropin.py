@@ -13,6 +13,7 @@ import pytest
 
 import run_ref
 from cice_amd import synth
+from common import bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +68,7 @@ def run_bgrid_dropin(tmp_path, nx, ny, bx, by, ew, kw, resident, ndte=120):
             for f in FIELDS + DOWNSTREAM:
                 hip = d[f"h{icall:02d}n{nsub:04d}_{f}"]
                 ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
-                assert np.array_equal(hip, ref), (
+                assert bits_equal(hip, ref), (
                     f"call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
                     f"max|d|={np.abs(hip - ref).max():.3e}")
                 checked += 1
@@ -77,7 +78,7 @@ def run_bgrid_dropin(tmp_path, nx, ny, bx, by, ew, kw, resident, ndte=120):
             for f in FIELDS:
                 body = d[f"b{icall:02d}n{nsub:04d}_{f}"]
                 ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
-                assert np.array_equal(body, ref), (
+                assert bits_equal(body, ref), (
                     f"Option A body, call {icall} nsub {nsub} {f}: {int((body != ref).sum())} cells differ, "
                     f"max|d|={np.abs(body - ref).max():.3e}")
                 checked += 1
@@ -87,7 +88,7 @@ def run_bgrid_dropin(tmp_path, nx, ny, bx, by, ew, kw, resident, ndte=120):
                 for f in ("uvel", "vvel", "stressp_1", "stressm_2", "stress12_3", "stress12_4"):
                     two = d[f"c{icall:02d}n{nsub:04d}_{f}"]
                     ref = d[f"p{icall:02d}n{nsub:04d}_{f}"]
-                    assert np.array_equal(two, ref), (
+                    assert bits_equal(two, ref), (
                         f"Option A, resident stresses, second body in a row, call {icall} nsub {nsub} {f}: "
                         f"{int((two != ref).sum())} cells differ, max|d|={np.abs(two - ref).max():.3e}")
     assert np.abs(d[f"o02n{ndte:04d}_uvel"]).max() > (1e-3 if ndte >= 100 else 1e-5)
@@ -177,7 +178,7 @@ def run_cgrid_dropin(tmp_path, nx, ny, bx, by, ew, kw, prep, ndte=120):
                     # compared on the faces dyn_finish writes)
                     on = d[f"in{icall:02d}_ice{f[-1]}mask"] != 0
                     hip, ref = np.where(on, hip, 0.0), np.where(on, ref, 0.0)
-                assert np.array_equal(hip, ref), (
+                assert bits_equal(hip, ref), (
                     f"C grid call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
                     f"max|d|={np.abs(hip - ref).max():.3e}")
                 checked += 1
@@ -234,7 +235,7 @@ def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx,
             for f in FIELDS + DOWNSTREAM:
                 hip = d[f"h{icall:02d}n{nsub:04d}_{f}"]
                 ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
-                assert np.array_equal(hip, ref), (
+                assert bits_equal(hip, ref), (
                     f"tripoleT call {icall} nsub {nsub} {f}: {int((hip != ref).sum())} cells differ, "
                     f"max|d|={np.abs(hip - ref).max():.3e}")
                 checked += 1
@@ -243,7 +244,7 @@ def test_reference_driver_with_hip_core_on_a_tripoleT_grid(tmp_path, nx, ny, bx,
             for f in FIELDS:
                 body = d[f"b{icall:02d}n{nsub:04d}_{f}"]
                 ref = d[f"o{icall:02d}n{nsub:04d}_{f}"]
-                assert np.array_equal(body, ref), (
+                assert bits_equal(body, ref), (
                     f"tripoleT, Option A body, call {icall} nsub {nsub} {f}: {int((body != ref).sum())} cells differ, "
                     f"max|d|={np.abs(body - ref).max():.3e}")
                 checked += 1

@@ -12,7 +12,7 @@ import pytest
 
 import oracle
 from cice_amd import decomp, evp, synth
-from common import GOLDEN_CASES, TFOLD_CASES, GoldenCase, assert_bitwise, max_rel_err, tfold_untouched
+from common import GOLDEN_CASES, TFOLD_CASES, GoldenCase, assert_bitwise, max_rel_err, tfold_untouched, bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +74,7 @@ def test_golden_tripoleT_strict_bitwise(name):
                 want = c.expected(icall, nsub)
                 for k in want:
                     sel = keep if k.startswith("stress") else np.ones_like(keep)
-                    assert np.array_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k} (HIP, tripoleT)"
+                    assert bits_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k} (HIP, tripoleT)"
         assert core.timings()["tile_variant"] < 1000          # the streaming kernel (the resident ones are not eligible)
         assert "one subcycle per launch" in core.describe_path() and "two-subcycle path: off" in core.describe_path()
         assert np.abs(want["uvel"]).max() > 1e-3
@@ -105,7 +105,7 @@ def test_tripoleT_through_the_remote_transports(name, transport, monkeypatch):
             want = c.expected(1, nsub)
             for k in want:
                 sel = keep if k.startswith("stress") else np.ones_like(keep)
-                assert np.array_equal(out[k][sel], want[k][sel]), f"{name} nsub {nsub} {k} (tripoleT through {transport})"
+                assert bits_equal(out[k][sel], want[k][sel]), f"{name} nsub {nsub} {k} (tripoleT through {transport})"
         t = core.timings()
         assert t["halo_transport"] == ("rccl" if transport == "rccl" else "mailbox") and t["tile_variant"] < 1000, t
         assert t["launches_per_subcycle"] == (3.0 if transport == "rccl" else 2.0), t       # never 1: the exchange does not ride
@@ -262,7 +262,7 @@ def test_tripole_stress_symmetrisation_on_device(name):
             core.stress_halo()
             out = core.download()
             assert_bitwise(out, c.expected(icall, c.ndte), f"{name} call {icall}: device stress halo")
-            assert any(not np.array_equal(raw[k], out[k]) for k in SIG), "symmetrisation was a no-op"
+            assert any(not bits_equal(raw[k], out[k]) for k in SIG), "symmetrisation was a no-op"
     finally:
         core.finalize()
 
@@ -394,18 +394,16 @@ def test_gx1_size_vs_reference_harness(tmp_path, bs, monkeypatch):
     against the reference ITSELF: inputs captured from, outputs compared with, the reference's own
     evp() (unmodified sources, strict build) run here at 320x384, as one block and as 4x4 blocks.
     Every kernel the bench can time on this grid: the autotuned default (on-chip resident, tagged
-    records, 16x16 tiles with the rim-wave split), the other tile shapes, the flags generation and
+    records, 16x16 tiles with the rim-wave split), the other tile shapes and
     the streaming kernel -- all bit-identical to the reference after 120 and after 240 subcycles."""
     c = reference_case(tmp_path, 320, 384, bs, "closed", [120, 240], 120)
     dyn, tm, um = c.inputs(1)
     assert tm.sum() > 100000
     variants = [("default", {}),
-                ("resident 16x16", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "4"}),
-                ("resident 32x8", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "5"}),
+                ("resident 16x16", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_LOGW": "4"}),
+                ("resident 32x8", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_LOGW": "5"}),
                 ("streaming", {"CICE_EVP_HIP_RESIDENT": "0"})]
-    if bs == (320, 384):
-        variants.append(("resident flags", {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "1"}))
-    keys = ("CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_RES_GEN", "CICE_EVP_HIP_RES_LOGW")
+    keys = ("CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_RES_LOGW")
     for what, envs in variants:
         for k in keys:
             monkeypatch.delenv(k, raising=False)
@@ -451,19 +449,17 @@ def check_next_tier_post(c, name):
         core.finalize()
 
 
-@pytest.mark.parametrize("gen", ["1", "2"])
 @pytest.mark.parametrize("grid,case,warm", [("gx3", "full", True), ("gx1", "full", True), ("gx1", "caps", False)])
-def test_resident_kernel_bitwise(grid, case, warm, gen, monkeypatch):
+def test_resident_kernel_bitwise(grid, case, warm, monkeypatch):
     """The on-chip resident subcycle (one launch for all ndte subcycles, stresses and operands
-    kept in registers/LDS, velocities exchanged through L2 with neighbour flags) against the
+    kept in registers/LDS, velocities exchanged through L2 as tagged records) against the
     oracle (12 subcycles) and against the streaming kernel (120 subcycles), bit for bit."""
     scal = synth.evp_scalars(120)
     dc, geo, fields, tm, um = synth_case(grid, case, seed=5, warm=warm)
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
-    monkeypatch.setenv("CICE_EVP_HIP_RES_GEN", gen)     # 1: neighbour flags, 2: tagged records
     got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12)
     want = run_oracle(dc, geo, fields, tm, um, scal, 12)
-    assert_bitwise(got, want, f"{grid}/{case} resident gen {gen} vs oracle")
+    assert_bitwise(got, want, f"{grid}/{case} resident vs oracle")
     res = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=121)     # odd count: parity flip
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "0")
     stream = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=121)
@@ -473,9 +469,8 @@ def test_resident_kernel_bitwise(grid, case, warm, gen, monkeypatch):
 
 def test_resident_kernel_golden_and_modes(monkeypatch):
     c = GoldenCase("pop_cyc_1blk_patchy")
-    for mode, gen in (("1", "1"), ("1", "2"), ("0", "1")):
+    for mode in ("1", "0"):
         monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", mode)
-        monkeypatch.setenv("CICE_EVP_HIP_RES_GEN", gen)
         core = hip_from_case(c, strict=True)
         try:
             dyn, tm, um = c.inputs(1)
@@ -632,16 +627,16 @@ def test_prep_on_device_full_size_vs_oracle(grid, bs, ssh):
         core.set_prep_geometry(static["tmask"], static["umask"], static["hm"], static["tarea"], static["uarea"],
                                static["fcor_blk"])
         tm, um, _ = core.prep(evp.PrepParams(**ppd, ssh_stress_coupled=ssh), t, state)
-        assert np.array_equal(tm, want["iceTmask"]) and np.array_equal(um, want["iceUmask"])
+        assert bits_equal(tm, want["iceTmask"]) and bits_equal(um, want["iceUmask"])
         assert 0 < um.sum() < um.size and (state["iceUmask"] != um).any()      # cells gained and lost ice
         got = {k: core.prep_fetch(k) for k in evp.PREP_FETCH}
         on = um != 0
         for k in evp.PREP_FETCH:
             w = want[k]
             if k in ("fmU", "strtltxU", "strtltyU"):          # defined on ice U-cells only
-                assert np.array_equal(got[k][on], w[on]), k
+                assert bits_equal(got[k][on], w[on]), k
             else:
-                assert np.array_equal(got[k], w), k
+                assert bits_equal(got[k], w), k
         raw = core.download()
         assert_bitwise({k: raw[k] for k in SIG}, {k: want[k] for k in SIG}, "stresses after dyn_prep2")
     finally:
@@ -688,7 +683,6 @@ def test_resident_kernel_survives_lagging_tiles(case, monkeypatch):
     open water in the 'caps' case, where a reader tile has nothing its neighbour waits for --
     the result is still the oracle's, bit for bit, and no wait times out."""
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
-    monkeypatch.setenv("CICE_EVP_HIP_RES_GEN", "2")
     monkeypatch.setenv("CICE_EVP_HIP_RES_LOGW", "4")
     monkeypatch.setenv("CICE_EVP_HIP_RES_DEBUG", "8")
     scal = synth.evp_scalars(120)
@@ -727,7 +721,6 @@ def test_resident_kernel_any_block_layout_golden(name, monkeypatch):
     rank, cyclic / closed / tripole: tiles of different blocks trade records through the per-cell
     ghost-image table.  Bit-identical to the reference, both calls, every subcycle count."""
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
-    monkeypatch.setenv("CICE_EVP_HIP_RES_GEN", "2")
     c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     try:
@@ -749,10 +742,10 @@ def test_fused_mode_is_kernel_invariant(monkeypatch):
     dc, geo, fields, tm, um = synth_case("gx3", "caps", seed=8, warm=True)
     ref = None
     for envs in ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_TYB": "4"}, {"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_TYB": "108"},
-                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "1", "CICE_EVP_HIP_RES_LOGW": "5"},
-                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "4"},
-                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_GEN": "2", "CICE_EVP_HIP_RES_LOGW": "6"}):
-        for k in ("CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_RES_GEN", "CICE_EVP_HIP_RES_LOGW"):
+                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_LOGW": "5"},
+                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_LOGW": "4"},
+                 {"CICE_EVP_HIP_RESIDENT": "1", "CICE_EVP_HIP_RES_LOGW": "6"}):
+        for k in ("CICE_EVP_HIP_RESIDENT", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_RES_LOGW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in envs.items():
             monkeypatch.setenv(k, v)
@@ -860,7 +853,7 @@ def test_graph_replay_follows_the_data_dependent_flags(monkeypatch):
             first = core.run(d0, tm, um, ndte=c.ndte)                 # bakes TBU_ZERO (+ WATER_IS_OCN) into its graph
             out = core.run(dyn, tm, um, ndte=c.ndte)
             assert_bitwise(out, c.expected(1, c.ndte), f"seabed call after a TbU == 0 call (rep {rep})")
-            assert not np.array_equal(first["uvel"], out["uvel"])
+            assert not bits_equal(first["uvel"], out["uvel"])
         assert core.timings()["tile_variant"] < 1000
     finally:
         core.finalize()
@@ -1006,7 +999,7 @@ def test_seabed_stress_factor_on_device_lkd():
             core.seabed_lkd(c.d["hwater"] if icall == 1 else None, s[24], s[25], s[26], s[27])
             tb = core.prep_fetch("TbU")
             ref = dyn["TbU"]
-            assert np.abs(ref).max() > 0 and np.array_equal(tb == 0, ref == 0)
+            assert np.abs(ref).max() > 0 and bits_equal(tb == 0, ref == 0)
             nz = ref != 0
             ulp = np.abs(tb[nz] - ref[nz]) / np.spacing(np.abs(ref[nz]))
             assert ulp.max() <= 2.0, f"TbU differs from the reference by {ulp.max()} ulp"
@@ -1048,7 +1041,7 @@ def test_seabed_stress_factor_on_device_probabilistic():
                              s[19], s[30], s[31])
             tb = core.prep_fetch("TbU")
             ref = dyn["TbU"]
-            assert np.abs(ref).max() > 0 and np.array_equal(tb == 0, ref == 0)
+            assert np.abs(ref).max() > 0 and bits_equal(tb == 0, ref == 0)
             nz = ref != 0
             rel = np.abs(tb[nz] - ref[nz]) / np.abs(ref[nz])
             assert rel.max() <= 1e-12, f"TbU differs from the reference by {rel.max():.2e} relative"
@@ -1328,7 +1321,7 @@ def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
                 want = c.expected(icall, nsub)
                 for k in want:
                     sel = keep if k.startswith("stress") else np.ones_like(keep)
-                    assert np.array_equal(out[k][sel], want[k][sel]), f"{what}: call {icall} nsub {nsub} {k}"
+                    assert bits_equal(out[k][sel], want[k][sel]), f"{what}: call {icall} nsub {nsub} {k}"
                 # ... and with those twelve calls done on the device too (late round 4): every cell of every array
                 core.stress_halo()
                 assert_bitwise(core.download(), want, f"{what}: call {icall} nsub {nsub}, symmetrised on the device")

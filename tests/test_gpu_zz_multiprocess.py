@@ -119,6 +119,32 @@ def test_bench_multi_rank_falls_back_together():
     assert d["config"]["tile_variant"] < 1000 and d["verified"] is True and d["config"]["finite"]
 
 
+def test_bench_self_launches_when_started_bare():
+    """The literal command the driver may type, no launcher around it: `python bench.py --gpus 2 --steps 2 --warmup 1`.  bench.py
+    re-executes itself under torch.distributed.run (one rank per GPU; here both ranks on the one GPU, CICE_EVP_BENCH_REHEARSAL=1)
+    and rank 0 prints exactly one JSON line: the gx1 N-rank figure on top, the 3600x2400 grid under `secondary` with the ranks'
+    own views, the forced-RCCL control named (it cannot run with two ranks on one device), no CPU-baseline leg."""
+    import json
+    import subprocess
+    import sys as _sys
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
+    r = subprocess.run([_sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=root,
+                       capture_output=True, text=True, timeout=1500, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["verified"] is True
+    assert d["metric"].startswith("EVP subcycle cell-updates/sec (gx1") and d["cpu_baseline"] is None
+    assert [q["rank"] for q in d["config"]["per_rank"]] == [0, 1]
+    assert all(q["halo_transport"] in ("mailbox", "rccl") for q in d["config"]["per_rank"])
+    sec = d["secondary"]
+    assert sec["verified"] is True and sec["finite"] and sec["value"] > 0 and [q["rank"] for q in sec["per_rank"]] == [0, 1]
+    assert "ring_exchange_overlapped" not in sec and "configs2_gx1_ndte240" not in d and "tripole" not in d
+    assert "skipped" in d["rccl_control"]
+
+
 def test_bench_multi_rank_rehearsal():
     """bench.py's N>1 path (decomposition, collective set-up, barrier + MAX-over-ranks timing, the
     JSON line) rehearsed on the one GPU of this box: 2 ranks as 2 processes over gloo with the
@@ -131,7 +157,7 @@ def test_bench_multi_rank_rehearsal():
     root = Path(__file__).resolve().parents[1]
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx1", "--extras", "configs2,tripole,s01"]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx1", "--extras", "configs2,tripole,s01,ring_variants"]
     env = dict(os.environ, CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]

@@ -17,6 +17,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from cice_amd import decomp, evp
+from common import bits_equal
 
 CASES = [
     # nx, ny, bx, by, ew, ns, nranks, proc_shape
@@ -334,7 +335,7 @@ def _worker(rank, world, port, case, q):
         flat[plan["recv_dst"]] = recvbuf.numpy()
         src = plan["local_src"]
         flat[plan["local_dst"]] = np.where(src >= 0, plan["local_sign"] * flat[np.maximum(src, 0)], 0.0)
-        ok = bool(np.array_equal(a, want))
+        ok = bool(bits_equal(a, want))
         nbad = int((a != want).sum())
         # mailbox semantics: the SENDER knows where each value lands in the receiver's array
         # (send_dst), the receiver knows which global cell each ghost mirrors (recv_gid)
@@ -362,10 +363,10 @@ def _worker(rank, world, port, case, q):
             w.wait()
         flat2[rdsts.numpy()] = rvals.numpy()             # "remote store" at the sender's addresses
         flat2[plan["local_dst"]] = np.where(src >= 0, plan["local_sign"] * flat2[np.maximum(src, 0)], 0.0)
-        ok = ok and bool(np.array_equal(b2, want)) and bool(np.array_equal(rdsts.numpy(), plan["recv_dst"]))
+        ok = ok and bool(bits_equal(b2, want)) and bool(bits_equal(rdsts.numpy(), plan["recv_dst"]))
         gid = plan["recv_gid"]
         known = (gid % nx + 1) + 1000.0 * (gid // nx + 1)
-        ok = ok and bool(np.array_equal(known, want.reshape(-1)[plan["recv_dst"]]))
+        ok = ok and bool(bits_equal(known, want.reshape(-1)[plan["recv_dst"]]))
         q.put((rank, ok, nbad, int(len(plan["send_src"])), int(len(plan["recv_dst"]))))
     finally:
         dist.destroy_process_group()
@@ -698,7 +699,7 @@ def test_fold_row_split_over_ranks_lists_of_the_on_chip_kernel(shape):
             ng_s, ng_r, n_out, n_in = [int(v) for v in P["peer_counts4"][q]]
             assert ng_s == Q["peer_counts4"][qq][1] and ng_r == Q["peer_counts4"][qq][0]
             assert (P["send_dst"][ss][:ng_s] < ncell[int(pr)]).all() and (P["send_dst"][ss][ng_s:] >= ncell[int(pr)]).all()
-            assert np.array_equal(P["send_sign"][ss], Q["recv_sign"][rq]) and np.array_equal(P["send_dst"][ss], Q["recv_dst"][rq])
+            assert bits_equal(P["send_sign"][ss], Q["recv_sign"][rq]) and bits_equal(P["send_dst"][ss], Q["recv_dst"][rq])
             oq = int(Q["peer_counts4"][:qq, 3].sum())
             mine = P["fimg_out"][oo:oo + n_out]
             theirs = Q["fimg_in"][oq:oq + int(Q["peer_counts4"][qq][3])]

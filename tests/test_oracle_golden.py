@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import TFOLD_CASES, tfold_untouched, CGRID_CASES, CGRID_TFOLD_CASES, GOLDEN_CASES, GoldenCase, assert_bitwise
+from common import TFOLD_CASES, tfold_untouched, CGRID_CASES, CGRID_TFOLD_CASES, GOLDEN_CASES, GoldenCase, assert_bitwise, bits_equal
 
 
 def test_fixtures_present():
@@ -76,7 +76,7 @@ def test_subcycle_tripoleT_bitwise(name):
             want = c.expected(icall, nsub)
             for k in want:
                 sel = keep if k.startswith("stress") else np.ones_like(keep)
-                assert np.array_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k}"
+                assert bits_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k}"
         assert np.abs(want["uvel"]).max() > 1e-3
 
 
@@ -112,7 +112,7 @@ def test_tripoleT_stress_symmetrisation_lists_bitwise(name):
                 new[a2][own["stress_corner_dst"]] = flat[a1][sc]
         changed = 0
         for k, v in new.items():
-            assert np.array_equal(v.reshape(want[k].shape), want[k]), f"{name} call {icall} {k}"
+            assert bits_equal(v.reshape(want[k].shape), want[k]), f"{name} call {icall} {k}"
             changed += int((v != flat[k]).sum())
         assert changed > 0
 
@@ -125,15 +125,15 @@ def check_prep_products(c, icall, out, what):
     """Products of the preparation phase against what the reference handed to its subcycle
     (in*: captured at the dyn_evp1d_run boundary) and left in its module arrays (pq*)."""
     dyn, tm, um = c.inputs(icall)
-    assert np.array_equal(out["iceTmask"] != 0, tm != 0), f"{what}: iceTmask"
-    assert np.array_equal(out["iceUmask"] != 0, um != 0), f"{what}: iceUmask"
+    assert bits_equal(out["iceTmask"] != 0, tm != 0), f"{what}: iceTmask"
+    assert bits_equal(out["iceUmask"] != 0, um != 0), f"{what}: iceUmask"
     assert_bitwise({k: out[k] for k in PREP_PRODUCTS}, {k: dyn[k] for k in PREP_PRODUCTS}, what)
     on = um != 0                    # fm, strtlt, strair are only defined on ice U-cells (dyn_prep2 :806-836)
     for k, ref in (("fmU", dyn["fmU"]), ("strtltxU", c.d[f"pq{icall:02d}_strtltxU"]),
                    ("strtltyU", c.d[f"pq{icall:02d}_strtltyU"])):
-        assert np.array_equal(out[k][on], ref[on]), f"{what}: {k}"
+        assert bits_equal(out[k][on], ref[on]), f"{what}: {k}"
     for k in ("strairxU", "strairyU"):
-        assert np.array_equal(out[k], c.d[f"pq{icall:02d}_{k}"]), f"{what}: {k}"
+        assert bits_equal(out[k], c.d[f"pq{icall:02d}_{k}"]), f"{what}: {k}"
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -183,7 +183,7 @@ def test_halo_known_answer_global_index():
             m[1:1 + b.gny, 1:1 + b.gnx] = False
             a[b.local][m] = -999.0
         oracle.halo_update(dom, a, "NEcorner", "vector")
-        assert np.array_equal(a, ref), (ew, ns)
+        assert bits_equal(a, ref), (ew, ns)
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -249,7 +249,7 @@ def test_seabed_lkd_bitwise():
         tb = oracle.seabed_lkd(dom, s[24], s[25], s[26], s[27], c.d[f"pr{icall:02d}_aice"], c.d[f"pr{icall:02d}_vice"],
                                c.d["hwater"], um)
         assert np.abs(dyn["TbU"]).max() > 0
-        assert np.array_equal(tb, dyn["TbU"]), f"call {icall}: {int((tb != dyn['TbU']).sum())} cells differ"
+        assert bits_equal(tb, dyn["TbU"]), f"call {icall}: {int((tb != dyn['TbU']).sum())} cells differ"
 
 
 def test_icepack_stub_constants_are_icepack_defaults():
@@ -280,7 +280,7 @@ def test_seabed_prob_oracle_bitwise():
         tb = oracle.seabed_prob(c.oracle_domain(), s[26], s[17], s[12], s[19], s[30], s[31], t["aice"][:, None],
                                 t["vice"][:, None], c.d["hwater"], tm, um)
         assert np.abs(dyn["TbU"]).max() > 0
-        assert np.array_equal(tb, dyn["TbU"]), f"call {icall}"
+        assert bits_equal(tb, dyn["TbU"]), f"call {icall}"
 
 
 @pytest.mark.parametrize("name", CGRID_CASES)
@@ -302,7 +302,7 @@ def test_cgrid_deformations_t_oracle_bitwise(name):
             got = oracle.deformations_c_t(c.oracle_domain(), c.scal[4], c.cgrid_expected(icall, nsub), c.cgrid_static(),
                                           c.d["tarear"], masks["iceTmask"], prev=start)
             for k in keys:
-                assert np.array_equal(got[k], want[k]), f"{name} call {icall} nsub {nsub} {k}"
+                assert bits_equal(got[k], want[k]), f"{name} call {icall} nsub {nsub} {k}"
 
 
 def cgrid_dyn_finish_lists(c, masks):
@@ -336,7 +336,7 @@ def test_cgrid_dyn_finish_oracle_bitwise(name):
                                            inputs[f"vocn{loc}"], inputs[f"fm{loc}"], exp[f"uvel{loc}"], exp[f"vvel{loc}"],
                                            masks[f"ice{loc}mask"], *start)
                 for g, w, xy in zip(got, want, "xy"):
-                    assert np.array_equal(g, w), f"{name} call {icall} nsub {nsub} strocn{xy}{loc}"
+                    assert bits_equal(g, w), f"{name} call {icall} nsub {nsub} strocn{xy}{loc}"
                 assert lists[loc].any() and np.abs(want[0][lists[loc]]).max() > 0
 
 
@@ -365,7 +365,7 @@ def test_cgrid_prep_oracle_bitwise(name):
                                                       c.d["hwater"], got[f"ice{loc}mask"])
             assert np.abs(want_in["TbE"]).max() > 0
         for k in oracle.C_MASKS:
-            assert np.array_equal(got[k] != 0, want_masks[k] != 0), f"{name} call {icall} {k}"
+            assert bits_equal(got[k] != 0, want_masks[k] != 0), f"{name} call {icall} {k}"
         # the fixture's in* arrays were captured after a complete evp(ndte = 0): the exchange of strintxE / strintyN
         # that follows the (empty) loop has run (ice_dyn_evp.F90:1436-1440)
         got["strintxE"] = oracle.halo_update(c.oracle_domain(), got["strintxE"], "Eface", "vector")

@@ -35,7 +35,7 @@ run_passes () {   # name, env assignments (string), command...
 
 for w in $WHAT; do
   case $w in
-    gx1res) run_passes gx1res "CICE_EVP_HIP_RESIDENT=1 CICE_EVP_HIP_RES_GEN=${RES_GEN:-2} CICE_EVP_HIP_RES_LOGW=${RES_LOGW:-4} CICE_EVP_HIP_TYB=4" python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary ;;
+    gx1res) run_passes gx1res "CICE_EVP_HIP_RESIDENT=1 CICE_EVP_HIP_RES_LOGW=${RES_LOGW:-4} CICE_EVP_HIP_TYB=4" python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary ;;
     gx1str) run_passes gx1str "CICE_EVP_HIP_RESIDENT=0 CICE_EVP_HIP_TYB=${TYB_GX1:-4}" python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary ;;
     s01march) run_passes s01march "CICE_EVP_HIP_MARCH=1 ${MARCH_ENV:-}" python bench.py --workload s01 --ndte 96 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary ;;
     s01str) run_passes s01str "CICE_EVP_HIP_MARCH=0 CICE_EVP_HIP_RESIDENT=0 CICE_EVP_HIP_TYB=${TYB_S01:-208}" python bench.py --workload s01 --ndte 24 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary ;;

@@ -3,7 +3,7 @@ CICE_EVP_HIP_RES_PROF=1 (16 x 16 tiles).  Usage: python tools/resident_phases.py
 import os, sys, pathlib
 R = str(pathlib.Path(__file__).resolve().parents[1]); sys.path[:0] = [R, R + "/tests", R + "/oracle"]
 os.environ["CICE_EVP_HIP_RES_PROF"] = "1"
-os.environ.setdefault("CICE_EVP_HIP_RESIDENT", "1"); os.environ.setdefault("CICE_EVP_HIP_RES_GEN", "2")
+os.environ.setdefault("CICE_EVP_HIP_RESIDENT", "1")
 os.environ.setdefault("CICE_EVP_HIP_RES_LOGW", "4"); os.environ.setdefault("CICE_EVP_HIP_TYB", "4")
 import numpy as np
 from cice_amd import evp, synth
