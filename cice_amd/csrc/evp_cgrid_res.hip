@@ -1,0 +1,511 @@
+// =====================================================================
+// C-grid EVP subcycle, on-chip resident (round 5): ALL subcycles of a call in ONE launch for domains that fit the chip
+// (gx1, tx1-sized: up to ~130k cells on one rank).  Reference: evp()'s loop for grid_ice = 'C', ice_dyn_evp.F90:936-1121
+// (strain_rates_U ice_dyn_shared.F90:2341-2444, stressC_T :1758, stressC_U :1898, div_stress_Ex / _Ny :2195-2416,
+// stepu_C / stepv_C ice_dyn_shared.F90:1090, 1189, the grid_average_X2Y variants ice_grid.F90:4388-4606).
+//
+// cg_one (evp_cgrid.hip) is one launch per subcycle: every level of every subcycle fetches its operands from L2 /
+// Infinity Cache again and a subcycle is four dependent memory round trips (18 us on gx1, 0.24 of the HBM roof although
+// nothing needs to move).  Here the B grid's answer (evp_resident2.hip): the state and the operands of a window stay in
+// registers and LDS for the whole call, and the only thing that travels between workgroups is the new face velocity of the
+// cells another window's rim mirrors -- one aligned 32-byte record {tag, uvelE, tag | tag, vvelN, tag} per cell and subcycle,
+// written with write-through stores and polled (L1-bypassing) by the reader until both tags carry the subcycle it waits for.
+//
+// Window = 16 x 16 positions, one thread each, the inner 13 x 13 owned (cg_one's window, same table of source cells:
+// halo_plan.cpp build_window_table with one extra row / column).  Levels as in cg_one, separated by workgroup barriers:
+//   S  strain_rates_U (shearU alone except for deltaU in the last subcycle) at every position
+//   T  stressC_T at tx, ty >= 1          U  corner viscosity + stressC_U at tx, ty <= 14
+//   C  div_stress + stepu_C / stepv_C on the owned cells; publish.
+// Rim positions recompute what the neighbouring window computes AND keep their own copy of its history (stresspT, stressmT,
+// stress12U in registers): same arithmetic on the same inputs => same bits, so the velocities are the only hand-off.
+// A position's operands are those of the cell its value comes from (the table); a neighbour's are the window neighbour's --
+// the host has verified that every ghost cell's static arrays equal its source's bit for bit (cgres_geometry_images_ok),
+// else this kernel is not used.
+//
+// Lock step: every position outside the owned range that has a producer is polled every subcycle, every cell some other
+// window mirrors publishes every subcycle, ice or not (geometry only, never the masks): a window cannot run more than one
+// subcycle ahead of a window that still reads its records, so two record buffers (subcycle parity) suffice.  Every spin is
+// bounded and raises the error word.  fp64, strict: no FMA contraction, the reference's operation order.
+// =====================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "evp_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int X = 16, Y = 16, LW = X + 1, NP = LW * (Y + 1);
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void st_rec2(void *p, v4u a, v4u b)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
+                 :
+                 : "v"(p), "v"(a), "v"(b)
+                 : "memory");
+}
+__device__ __forceinline__ void ld_rec2(const void *p, v4u &a, v4u &b)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(p)
+                 : "memory");
+}
+__device__ __forceinline__ v4u pack_rec(double x, unsigned tag)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    v4u r;
+    r.x = tag; r.y = (unsigned)bits; r.z = (unsigned)(bits >> 32); r.w = tag;
+    return r;
+}
+__device__ __forceinline__ double unpack_rec(v4u r)
+{
+    return __longlong_as_double((long long)(((unsigned long long)r.z << 32) | r.y));
+}
+
+// visc_replpress, ice_dyn_shared.F90:2446-2475 (the one-division form for capping = 1: see evp_cgrid.hip)
+__device__ __forceinline__ void visc_replpress(const EvpScalars &p, double strength, double DminArea, double Delta,
+                                               double &zetax2, double &etax2, double &rep_prs)
+{
+    double tmpcalc;
+    if (p.capping == 1.0 && DminArea > 0.0 && fabs(strength) <= 1.7976931348623157e308 && Delta <= 1.7976931348623157e308)
+        tmpcalc = strength / fmax(Delta, DminArea);
+    else
+        tmpcalc = p.capping * (strength / fmax(Delta, DminArea)) + (1.0 - p.capping) * (strength / (Delta + DminArea));
+    zetax2 = (1.0 + p.Ktens) * tmpcalc;
+    rep_prs = (1.0 - p.Ktens) * tmpcalc * Delta;
+    etax2 = p.epp2i * zetax2;
+}
+
+// grid_average_X2YA with two / four weights (ice_grid.F90:4388-4606), operands already in registers
+__device__ __forceinline__ double avg2(double a0, double w0, double a1, double w1)
+{
+    const double wtmp = (w0 + w1);
+    if (wtmp == 0.0) return 0.0;
+    return (a0 * w0 + a1 * w1) / wtmp;
+}
+__device__ __forceinline__ double avg4(double a0, double w0, double a1, double w1, double a2, double w2, double a3, double w3)
+{
+    const double wtmp = (w0 + w1 + w2 + w3);
+    if (wtmp == 0.0) return 0.0;
+    return (a0 * w0 + a1 * w1 + a2 * w2 + a3 * w3) / wtmp;
+}
+
+struct TOut { double zetax2, etax2, sp, sm, shearT; };
+// stressC_T (ice_dyn_evp.F90:1758-1860); the four corner values of shearU handed in
+__device__ __forceinline__ TOut t_stress(const EvpScalars &p, double uEo, double uEw, double vNo, double vNs, double dyEo, double dyEw,
+                                         double dxNo, double dxNs, double dxT2, double dyT2, double uao, double uas, double uasw,
+                                         double uaw, double uareaavgr, double strength, double DminT, double shO, double shS,
+                                         double shSW, double shW, double spo, double smo, double relax)
+{
+    const double divT = dyEo * uEo - dyEw * uEw + dxNo * vNo - dxNs * vNs;
+    const double tensionT = (dyT2) * (uEo / dyEo - uEw / dyEw) - (dxT2) * (vNo / dxNo - vNs / dxNs);
+    const double shearTsqr = (shO * shO * uao + shS * shS * uas + shSW * shSW * uasw + shW * shW * uaw) * uareaavgr;
+    TOut r;
+    r.shearT = (shO * uao + shS * uas + shSW * uasw + shW * uaw) * uareaavgr;
+    const double DeltaT = sqrt(divT * divT + p.e_factor * (tensionT * tensionT + shearTsqr));
+    double rep_prs;
+    visc_replpress(p, strength, DminT, DeltaT, r.zetax2, r.etax2, rep_prs);
+    r.sp = (spo * relax + p.arlx1i * (r.zetax2 * divT - rep_prs)) * p.denom1;
+    r.sm = (smo * relax + p.arlx1i * r.etax2 * tensionT) * p.denom1;
+    return r;
+}
+
+__device__ __forceinline__ void push1(const EvpCgrid &A, size_t c, double *f, double v)
+{
+    const int s = A.img_slot[c];
+    if (s < 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int d = A.img_dst[3 * s + k];
+        if (d >= 0) f[d] = v;
+    }
+}
+
+__global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
+{
+    __shared__ double s_uE[NP], s_vN[NP], s_ea[NP], s_na[NP], s_dyE[NP], s_dxN[NP], s_ua[NP], s_ta[NP];
+    __shared__ double s_sh[NP], s_eta[NP], s_sp[NP], s_sm[NP], s_s12[NP];
+    __shared__ double s_pc[16][13 * 13];   // per-call operands of the momentum step, by owned cell (read at level C only)
+    __shared__ int s_src[NP];
+    __shared__ uint8_t s_gm[NP];           // land masks of the position's cell: bit0 epm, 1 npm, 2 uvm, 3 hm
+    __shared__ int s_bad;
+
+    const int t = threadIdx.x;
+    const int tx = t & (X - 1), ty = t / X;
+    const int li = ty * LW + tx;
+    const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
+    const int4 tl = R.tiles[tile];
+    const int4 q = A.blk[tl.x];
+    const int i = tl.y - 2 + tx, j = tl.z - 2 + ty;
+    const int nx = A.nx;
+    const EvpScalars &p = A.p;
+    const double relax = 1.0 - p.arlx1i * p.revp;
+    auto G = [&](int k) { return R.gbase + (size_t)k * R.stride; };
+    auto IN = [&](int k) { return R.inbase + (size_t)k * R.stride; };
+
+    // ---- the window's tiles: source cell, velocities, the operands neighbours read --------------------------------
+    for (int e = t; e < NP; e += X * Y) {
+        const int lr = R.tab[(size_t)tile * NP + e];
+        const size_t c = (size_t)(lr < 0 ? -1 - lr : lr);
+        s_src[e] = lr;
+        s_uE[e] = R.uE_in[c];
+        s_vN[e] = R.vN_in[c];
+        s_ea[e] = G(CG_EAREA)[c];
+        s_na[e] = G(CG_NAREA)[c];
+        s_dyE[e] = G(CG_DYE)[c];
+        s_dxN[e] = G(CG_DXN)[c];
+        s_ua[e] = G(CG_UAREA)[c];
+        s_ta[e] = G(CG_TAREA)[c];
+        s_gm[e] = R.gmask[c];
+    }
+    if (t == 0) s_bad = 0;
+    const int lr = R.tab[(size_t)tile * NP + li];
+    const bool stat = lr < 0;
+    const size_t L = (size_t)(stat ? -1 - lr : lr);
+    const unsigned m = A.mask[L];
+    const bool own = tx >= 2 && tx <= X - 2 && ty >= 2 && ty <= Y - 2 && i <= q.y && j <= q.w;
+    const bool compS = !stat && (m & 2u);
+    const bool compT = tx >= 1 && ty >= 1 && !stat && (m & 1u);
+    const bool compU = !stat && tx <= X - 2 && ty <= Y - 2;
+    const bool pub = own && R.pubmap[L] != 0;
+    // what a position that does not compute a level shows its neighbours: the array's value, unchanged through the loop
+    s_sh[li] = A.f[CF_SHEARU][L];
+    s_eta[li] = A.f[CF_ETA][L];
+    double sp = R.sp_in[L], sm = R.sm_in[L], s12v = R.s12_in[L];
+    s_sp[li] = sp;
+    s_sm[li] = sm;
+    s_s12[li] = s12v;
+    double s12T = own ? A.f[CF_S12T][L] : 0.0;
+    __syncthreads();
+
+    // ---- operands for the whole call: registers for what every subcycle reads first, LDS (by owned cell) for what only the
+    // momentum step reads, one word of bits for the 0 / 1 land masks -------------------------------------------------------
+    const size_t cE = (size_t)(s_src[li + 1] < 0 ? -1 - s_src[li + 1] : s_src[li + 1]);
+    const size_t cN = (size_t)(s_src[li + LW] < 0 ? -1 - s_src[li + LW] : s_src[li + LW]);
+    // mb: bit 0 epm, 1 npm, 2 uvm of the cell; 3 npm of its east, 4 epm of its north neighbour; 5-8 hm of the cell, east, north,
+    // north-east; 9 / 10: sign of revp * uvelE_init / revp * vvelN_init (revp = 0 here: the product is a zero of that sign)
+    unsigned mb;
+    {
+        const unsigned gmo = s_gm[li], gme = s_gm[li + 1], gmn = s_gm[li + LW], gmne = s_gm[li + LW + 1];
+        mb = (gmo & 7u) | ((gme & 2u) << 2) | ((gmn & 1u) << 4) | ((gmo & 8u) << 2) | ((gme & 8u) << 3) | ((gmn & 8u) << 4) | ((gmne & 8u) << 5);
+    }
+    auto bit = [&](unsigned k) -> double { return (mb >> k) & 1u ? 1.0 : 0.0; };
+    double dxU = 0.0, dyU = 0.0, ddyN = 0.0, ddxE = 0.0;
+    if (!stat) {
+        dxU = G(CG_DXU)[L]; dyU = G(CG_DYU)[L];
+        ddyN = G(CG_DYN)[cE] - G(CG_DYN)[L];
+        ddxE = G(CG_DXE)[cN] - G(CG_DXE)[L];
+    }
+    double dxT2 = 0.0, dyT2 = 0.0, uareaavgr = 0.0, strength = 0.0, DminT = 0.0;
+    if (compT) {
+        const double dxT = G(CG_DXT)[L], dyT = G(CG_DYT)[L];
+        dxT2 = dxT * dxT; dyT2 = dyT * dyT;
+        uareaavgr = 1.0 / (s_ua[li] + s_ua[li - LW] + s_ua[li - LW - 1] + s_ua[li - 1]);
+        strength = IN(CI_STRENGTH)[L];
+        DminT = G(CG_DMINT)[L];
+    }
+    double wtmpU = 0.0;
+    if (compU) wtmpU = (bit(5) * s_ta[li] + bit(6) * s_ta[li + 1] + bit(7) * s_ta[li + LW] + bit(8) * s_ta[li + LW + 1]);
+    double hdyEr = 0, dyT2e = 0, dxU2s = 0;
+    double hdxNr = 0, dxT2n = 0, dyU2w = 0;
+    const int oi = (ty - 2) * 13 + (tx - 2);         // owned cells only
+    if (own) {
+        const size_t cS = (size_t)(s_src[li - LW] < 0 ? -1 - s_src[li - LW] : s_src[li - LW]);
+        const size_t cW = (size_t)(s_src[li - 1] < 0 ? -1 - s_src[li - 1] : s_src[li - 1]);
+        const double dyE = G(CG_DYE)[L], dxE = G(CG_DXE)[L], dxN = G(CG_DXN)[L], dyN = G(CG_DYN)[L];
+        const double dyTe = G(CG_DYT)[cE], dxUs = G(CG_DXU)[cS], dxTn = G(CG_DXT)[cN], dyUw = G(CG_DYU)[cW];
+        const double dxTo = G(CG_DXT)[L], dyTo = G(CG_DYT)[L];
+        dxT2 = dxTo * dxTo; dyT2 = dyTo * dyTo;      // (compT holds the same values; an owned cell without ice still needs them)
+        s_pc[12][oi] = G(CG_EAREAR)[L]; hdyEr = 0.5 / dyE; s_pc[13][oi] = 1.0 / dxE;
+        dyT2e = dyTe * dyTe; dxU2s = dxUs * dxUs;
+        s_pc[14][oi] = G(CG_NAREAR)[L]; hdxNr = 0.5 / dxN; s_pc[15][oi] = 1.0 / dyN;
+        dxT2n = dxTn * dxTn; dyU2w = dyUw * dyUw;
+        s_pc[0][oi] = IN(CI_UOCNE)[L]; s_pc[1][oi] = IN(CI_VOCNE)[L]; s_pc[2][oi] = A.facE[L]; s_pc[3][oi] = IN(CI_EMASSDTI)[L];
+        s_pc[4][oi] = IN(CI_FME)[L]; s_pc[5][oi] = IN(CI_FORCEXE)[L];
+        s_pc[6][oi] = IN(CI_UOCNN)[L]; s_pc[7][oi] = IN(CI_VOCNN)[L]; s_pc[8][oi] = A.facN[L]; s_pc[9][oi] = IN(CI_NMASSDTI)[L];
+        s_pc[10][oi] = IN(CI_FMN)[L]; s_pc[11][oi] = IN(CI_FORCEYN)[L];
+        const double zE = p.revp * IN(CI_UE_INIT)[L], zN = p.revp * IN(CI_VN_INIT)[L];
+        mb |= (__double_as_longlong(zE) < 0 ? 1u : 0u) << 9;
+        mb |= (__double_as_longlong(zN) < 0 ? 1u : 0u) << 10;
+    }
+    // The extra row / column of the reference's T list (ghost cells ihi+1, jhi+1: of what stressC_T computes there only stress12T
+    // survives the exchange) is kept up by the window that owns the neighbouring interior cell -- by the threads of its column
+    // tx = 0 and its row ty = 0, which have no T position of their own: thread (0, ty) serves the ghost cell of column ihi+1 in
+    // row ty, thread (tx, 0) the one of row jhi+1 in column tx.  Such a thread runs level T like everybody else, at the ghost
+    // position (tli), with the ghost cell's own strength, DminTarea and history; the planes hold the static operands of the
+    // cell the position's value comes from, which equal the ghost cell's (cgres: images verified).
+    int tli = li;                  // the position level T is evaluated at
+    bool ghostT = false;
+    size_t g = 0;
+    if ((tx == 0) != (ty == 0)) {
+        // column ihi+1 (incl. the corner) / row jhi+1 as window positions
+        const int gx_ = tx == 0 ? q.y + 1 - (tl.y - 2) : tx, gy_ = tx == 0 ? ty : q.w + 1 - (tl.z - 2);
+        if (gx_ >= 1 && gx_ <= X - 1 && gy_ >= 1 && gy_ <= Y - 1) {
+            const int gi = tl.y - 2 + gx_, gj = tl.z - 2 + gy_;
+            const bool colg = gi == q.y + 1 && gj >= q.z && gj <= q.w + 1, rowg = gj == q.w + 1 && gi >= q.x && gi <= q.y;
+            if ((tx == 0 && colg) || (ty == 0 && rowg)) {
+                const int ii = min(gi, q.y), jj = min(gj, q.w);
+                if (ii >= tl.y && ii <= tl.y + X - 4 && jj >= tl.z && jj <= tl.z + Y - 4) {
+                    g = (size_t)tl.x * A.plane + (size_t)(gj - 1) * nx + (gi - 1);
+                    if (A.mask[g] & 1u) {
+                        ghostT = true;
+                        tli = gy_ * LW + gx_;
+                    }
+                }
+            }
+        }
+    }
+    if (ghostT) {
+        const double dxT = G(CG_DXT)[g], dyT = G(CG_DYT)[g];
+        dxT2 = dxT * dxT; dyT2 = dyT * dyT;
+        uareaavgr = 1.0 / (s_ua[tli] + s_ua[tli - LW] + s_ua[tli - LW - 1] + s_ua[tli - 1]);
+        strength = IN(CI_STRENGTH)[g];
+        DminT = G(CG_DMINT)[g];
+        s12T = A.f[CF_S12T][g];
+        sp = 0.0; sm = 0.0;         // (stressC_T's own stresspT / stressmT there are overwritten by the exchange: not kept)
+    }
+    const bool doT = compT || ghostT;
+    const bool keepS12T = (own && compT) || ghostT;
+
+    // ---- ring: the positions of the velocity tile this window does not produce, one or two per thread ---------------
+    // entry e of the (Y+1) x (X+1) tile is polled if it lies outside the owned range and has a producer (not static);
+    // (X, Y), the one entry no level reads, is left out
+    auto ring_src = [&](int e) -> int {
+        if (e >= NP - 1) return -1;
+        const int ex = e % LW, ey = e / LW;
+        const int gi = tl.y - 2 + ex, gj = tl.z - 2 + ey;
+        const bool mine = ex >= 2 && ex <= X - 2 && ey >= 2 && ey <= Y - 2 && gi <= q.y && gj <= q.w;
+        const int sc = s_src[e];
+        return (mine || sc < 0) ? -1 : sc;
+    };
+    const int ring0 = ring_src(t), ring1 = ring_src(t + X * Y);
+    auto give_up_note = [&](int k, int cell, unsigned seen, unsigned wanted) {
+        if (atomicCAS(R.err, 0, 1) == 0) {
+            R.err[1] = tile; R.err[2] = k; R.err[3] = cell; R.err[4] = (int)seen; R.err[5] = (int)wanted;
+        }
+    };
+    auto poll = [&](const v4u *rd, int cell, int e, unsigned want, int k) {
+        v4u ra, rb;
+        unsigned spins = 0;
+        for (;;) {
+            ld_rec2(rd + 2 * (size_t)cell, ra, rb);
+            if (ra.x == want && ra.w == want && rb.x == want && rb.w == want) break;
+            ++spins;
+            if (spins > R.spin_limit || ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                give_up_note(k, cell, ra.x, want);
+                s_bad = 1;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        s_uE[e] = unpack_rec(ra);
+        s_vN[e] = unpack_rec(rb);
+    };
+    // initial records (tag of subcycle 0) so that the neighbours' first poll finds them; also the proof that they are resident
+    if (pub) st_rec2((v4u *)R.rec[R.par0 & 1] + 2 * L, pack_rec(s_uE[li], R.tag_base), pack_rec(s_vN[li], R.tag_base));
+    __syncthreads();
+
+    // One subcycle.  LAST (a compile-time constant: the loop body proper carries none of it) = the subcycle that ends the call, in
+    // which the arrays nothing inside the loop reads are stored: shearU, deltaU, zetax2T, etax2T, etax2U, strintxE/yN, taubxE/yN.
+    // Returns false when a wait gave up (every thread of the workgroup then leaves).
+    auto subcycle = [&](auto LASTC, int k) -> bool {
+        constexpr bool LAST = decltype(LASTC)::value;
+        const unsigned want = R.tag_base + (unsigned)k;
+        const v4u *rd = (const v4u *)R.rec[(k + R.par0) & 1];
+        v4u *wr = (v4u *)R.rec[((k + R.par0) & 1) ^ 1];
+        // (the operand planes never change inside the loop: without an index the compiler cannot see through it hoists every one
+        // of their loads into registers -- which is exactly what they are in LDS to avoid)
+        int lo = li, to = tli, oo = oi;
+        asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo));
+        if (ring0 >= 0) poll(rd, ring0, t, want, k);
+        if (ring1 >= 0) poll(rd, ring1, t + X * Y, want, k);
+        __syncthreads();
+        if (s_bad) return false;
+
+        // ---- S ----
+        double uNo = 0.0, vEo = 0.0;
+        const double uEo = s_uE[li], vNo = s_vN[li];
+        if (compS || own) {
+            const double epc = bit(0), npc = bit(1), npe = bit(3), epn = bit(4);
+            const double uEn = s_uE[li + LW], vNe = s_vN[li + 1];
+            const double eao = s_ea[lo], ean = s_ea[lo + LW], nao = s_na[lo], nae = s_na[lo + 1];
+            if (own) {
+                uNo = avg4(s_uE[li - 1], s_ea[lo - 1], uEo, eao, s_uE[li + LW - 1], s_ea[lo + LW - 1], uEn, ean) * npc;
+                vEo = avg4(s_vN[li - LW], s_na[lo - LW], s_vN[li - LW + 1], s_na[lo - LW + 1], vNo, nao, vNe, nae) * epc;
+            }
+            if (compS) {
+                const double uvm = bit(2);
+                const double uU = avg2(uEo, eao, uEn, ean) * uvm;
+                const double vU = avg2(vNo, nao, vNe, nae) * uvm;
+                // The four boundary-condition ratios only ever meet the factor (npc - npe) or (epc - epn), +0 away from a coast, and
+                // (+0 * mask) * ratio * velocity has the same bits for any finite negative ratio (the host has checked that all are):
+                // -1 there; the lanes of a coastal corner work them out from the reference's start-up identities
+                // ratiodxN = -dxN(i+1,j)/dxN(i,j), ratiodyE = -dyE(i,j+1)/dyE(i,j) and their reciprocals (ice_dyn_evp.F90:235-238;
+                // verified bit for bit on the caller's arrays by derive_geometry_check)
+                double rxN = -1.0, rxNr = -1.0, ryE = -1.0, ryEr = -1.0;
+                if (npc != npe) { rxN = -(s_dxN[lo + 1] / s_dxN[lo]); rxNr = 1.0 / rxN; }
+                if (epc != epn) { ryE = -(s_dyE[lo + LW] / s_dyE[lo]); ryEr = 1.0 / ryE; }
+                const double uEijp1 = uEn * epn + (epc - epn) * epc * ryE * uEo;
+                const double uEij = uEo * epc + (epn - epc) * epn * ryEr * uEn;
+                const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;
+                const double vNij = vNo * npc + (npe - npc) * npe * rxNr * vNe;
+                const double sh = dxU * (uEijp1 - uEij) - uU * ddxE + dyU * (vNip1j - vNij) - vU * ddyN;
+                s_sh[li] = sh;
+                if (LAST && own) {       // deltaU is wanted once per call: the rest of strain_rates_U
+                    const double uNe = avg4(uEo, eao, s_uE[li + 1], s_ea[lo + 1], uEn, ean, s_uE[li + LW + 1], s_ea[lo + LW + 1]) * npe;
+                    const double vEn = avg4(vNo, nao, vNe, nae, s_vN[li + LW], s_na[lo + LW], s_vN[li + LW + 1], s_na[lo + LW + 1]) * epn;
+                    const double uNip1j = uNe * npe + (npc - npe) * npc * rxN * uNo;
+                    const double uNij = uNo * npc + (npe - npc) * npe * rxNr * uNe;
+                    const double vEijp1 = vEn * epn + (epc - epn) * epc * ryE * vEo;
+                    const double vEij = vEo * epc + (epn - epc) * epn * ryEr * vEn;
+                    const double dv = dyU * (uNip1j - uNij) + uU * ddyN + dxU * (vEijp1 - vEij) + vU * ddxE;
+                    const double tn = dyU * (uNip1j - uNij) - uU * ddyN - dxU * (vEijp1 - vEij) + vU * ddxE;
+                    const double delta = sqrt(dv * dv + p.e_factor * (tn * tn + sh * sh));
+                    if (!R.dry) {
+                        A.f[CF_SHEARU][L] = sh;
+                        A.f[CF_DELTAU][L] = delta;
+                        if (m & 16u) push1(A, L, A.f[CF_SHEARU], sh);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- T ---- (at the thread's own position, or at the ghost position it serves)
+        if (doT) {
+            const TOut r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2,
+                                    dyT2, s_ua[to], s_ua[to - LW], s_ua[to - LW - 1], s_ua[to - 1], uareaavgr, strength, DminT, s_sh[tli],
+                                    s_sh[tli - LW], s_sh[tli - LW - 1], s_sh[tli - 1], sp, sm, relax);
+            if (compT) {
+                sp = r.sp; sm = r.sm;
+                s_eta[li] = r.etax2;
+                s_sp[li] = sp;
+                s_sm[li] = sm;
+            }
+            if (keepS12T) s12T = (s12T * relax + p.arlx1i * 0.5 * r.etax2 * r.shearT) * p.denom1;
+            if (LAST && own && compT && !R.dry) {
+                A.f[CF_ZETA][L] = r.zetax2;
+                A.f[CF_ETA][L] = r.etax2;
+                if (m & 16u) {
+                    push1(A, L, A.f[CF_ZETA], r.zetax2);
+                    push1(A, L, A.f[CF_ETA], r.etax2);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- U ----
+        double etaU = 0.0;
+        if (compU) {
+            const double e2 = wtmpU == 0.0 ? 0.0
+                                           : (bit(5) * s_eta[li] * s_ta[lo] + bit(6) * s_eta[li + 1] * s_ta[lo + 1] + bit(7) * s_eta[li + LW] * s_ta[lo + LW] +
+                                              bit(8) * s_eta[li + LW + 1] * s_ta[lo + LW + 1]) / wtmpU;
+            etaU = e2;
+            const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * s_sh[li]) * p.denom1;
+            if (m & 2u) {
+                s12v = upd;
+                s_s12[li] = upd;
+            }
+        }
+        __syncthreads();
+
+        // ---- C ----
+        if (own) {
+            const double s12c = s12v, s12s = s_s12[li - LW], s12w = s_s12[li - 1];
+            const double spc = sp, smc = sm;
+            const double spe = s_sp[li + 1], sme = s_sm[li + 1], spn = s_sp[li + LW], smn = s_sm[li + LW];
+            double unew, vnew, strintx, strinty, taubx, tauby;
+            {
+                const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
+                const double zE = (mb >> 9) & 1u ? -0.0 : 0.0;         // revp * uvelE_init
+                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + hdyEr * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
+                const double uold = uEo, vold = vEo;
+                const double du = uocnE - uold, dv = vocnE - vold;
+                const double vrel = facE * sqrt(du * du + dv * dv);
+                const double taux = vrel * uocnE;
+                const double Cb = 0.0;
+                const double cca = (p.brlx + p.revp) * massE + vrel * p.cosw + Cb;
+                const double ccb = fmE + copysign(1.0, fmE) * vrel * p.sinw;
+                const double cc1 = strintx + forcexE + taux + massE * (p.brlx * uold + zE);
+                unew = (ccb * vold + cc1) / cca;
+                taubx = -unew * Cb;
+            }
+            {
+                const double uocnN = s_pc[6][oo], vocnN = s_pc[7][oo], facN = s_pc[8][oo], massN = s_pc[9][oo], fmN = s_pc[10][oo], forceyN = s_pc[11][oo];
+                const double zN = (mb >> 10) & 1u ? -0.0 : 0.0;        // revp * vvelN_init
+                strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
+                const double uold = uNo, vold = vNo;
+                const double du = uocnN - uold, dv = vocnN - vold;
+                const double vrel = facN * sqrt(du * du + dv * dv);
+                const double tauy = vrel * vocnN;
+                const double Cb = 0.0;
+                const double cca = (p.brlx + p.revp) * massN + vrel * p.cosw + Cb;
+                const double ccb = fmN + copysign(1.0, fmN) * vrel * p.sinw;
+                const double cc2 = strinty + forceyN + tauy + massN * (p.brlx * vold + zN);
+                vnew = (-ccb * uold + cc2) / cca;
+                tauby = -vnew * Cb;
+            }
+            // (nobody reads the velocity tile between the barrier above and the one after the next poll)
+            const double uout = (m & 4u) ? unew : uEo, vout = (m & 8u) ? vnew : vNo;
+            s_uE[li] = uout;
+            s_vN[li] = vout;
+            if (pub) st_rec2(wr + 2 * L, pack_rec(uout, want + 1u), pack_rec(vout, want + 1u));
+            if (LAST && !R.dry) {
+                A.f[CF_ETAU][L] = etaU;
+                if (m & 4u) { A.f[CF_STRX][L] = strintx; A.f[CF_TAUBX][L] = taubx; }
+                if (m & 8u) { A.f[CF_STRY][L] = strinty; A.f[CF_TAUBY][L] = tauby; }
+            }
+        }
+        return true;
+    };
+    for (int k = 0; k < R.nsub - 1; ++k)
+        if (!subcycle(std::false_type{}, k)) return;
+    if (!subcycle(std::true_type{}, R.nsub - 1)) return;
+
+    // ---- the state goes back (both ping-pong allocations: whichever schedule runs next finds it) -------------------
+    if (R.dry) return;
+    if (own) {
+        const double uo = s_uE[li], vo = s_vN[li];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (m & 1u) {
+                R.sp_out[b][L] = sp;
+                R.sm_out[b][L] = sm;
+                if (m & 16u) { push1(A, L, R.sp_out[b], sp); push1(A, L, R.sm_out[b], sm); }
+            }
+            if (m & 2u) {
+                R.s12_out[b][L] = s12v;
+                if (m & 16u) push1(A, L, R.s12_out[b], s12v);
+            }
+            if (m & 4u) {
+                R.uE_out[b][L] = uo;
+                if (m & 16u) push1(A, L, R.uE_out[b], uo);
+            }
+            if (m & 8u) {
+                R.vN_out[b][L] = vo;
+                if (m & 16u) push1(A, L, R.vN_out[b], vo);
+            }
+        }
+        if (m & 1u) A.f[CF_S12T][L] = s12T;
+    }
+    if (ghostT) A.f[CF_S12T][g] = s12T;
+}
+
+}  // namespace
+
+int evp_cgrid_res_max_blocks_per_cu()
+{
+    int nb = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res, X * Y, 0) == hipSuccess ? nb : 0;
+}
+
+void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st)
+{
+    hipLaunchKernelGGL(cg_res, dim3(R.ntiles), dim3(X * Y), 0, st, A, R);
+}

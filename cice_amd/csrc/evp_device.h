@@ -307,11 +307,12 @@ void evp_launch_dyn_finish(const EvpArgs &A, int nblocks, bool strict, double *s
 void evp_tile_geometry(int max_ni, int max_nj, int variant, int *tyb, int *gx, int *gy);
 void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
                            const signed char *sign, int n, hipStream_t st);
-void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, int npair, const int *pole,
+// u2, v2: the other ping-pong buffer (takes the same stores; null: none)
+void evp_launch_halo_seam(double *u, double *v, double *u2, double *v2, const int *pa, const int *pb, int npair, const int *pole,
                           int npole, const int *ldst, const int *lsrc, const signed char *lsign,
                           int nlate, hipStream_t st);
 int evp_halo_seam_fin_capacity();
-void evp_launch_halo_seam_fin(double *u, double *v, const int *dst, const int *fa, const int *fb,
+void evp_launch_halo_seam_fin(double *u, double *v, double *u2, double *v2, const int *dst, const int *fa, const int *fb,
                               const signed char *coef, int n, hipStream_t st);
 void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src, int n, hipStream_t st);
 // tripoleT: the top physical row of _1 / _2 from the partner's mirrored cell, east-west ghost cells of that row of _3 / _4 from
@@ -380,6 +381,30 @@ struct EvpCgOne {
                                   // host, evp_host_cgrid.cpp: derive_geometry_check); the four land masks as bits of this byte
 };
 void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st);
+// All subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res).  Windows of 16 x 16 positions, the inner
+// 13 x 13 owned; tab: per window the source cell of its 17 x 17 positions (one row / column more than cg_one's: what level S reads
+// of its north / east neighbour), as in EvpCgOne.  The velocities another window's rim mirrors travel as tagged 32-byte records.
+struct EvpCgRes {
+    const int *tab;               // [ntiles][17 * 17]
+    const int4 *tiles;            // block, first owned i, first owned j (1-based), unused
+    const int *order;             // [ntiles] window run by workgroup w (NULL: identity)
+    int ntiles;
+    int nsub;                     // subcycles of this launch; the last one ends the call (the once-per-call arrays are stored in it)
+    int dry;                      // 1: residency + timing probe, nothing written back
+    int par0;                     // which of rec[0/1] holds the records of subcycle index 0 of this launch
+    unsigned tag_base;            // launch epoch << 12; a record of subcycle k carries tag_base + k
+    unsigned spin_limit;
+    int *err;                     // [8] first wait that gave up: 1, window, subcycle, cell, tag seen, tag wanted
+    const uint8_t *pubmap;        // per cell: 1 = some other window's rim mirrors this cell
+    void *rec[2];                 // [2][ncell] x {uvelE granule, vvelN granule} (2 x 16 bytes), by subcycle parity
+    const double *uE_in, *vN_in, *sp_in, *sm_in, *s12_in;               // the state on entry
+    double *uE_out[2], *vN_out[2], *sp_out[2], *sm_out[2], *s12_out[2];   // ... and where it goes on exit (both allocations of each)
+    const double *gbase, *inbase; // static / per-call tables: array k = base + k * stride
+    size_t stride;
+    const uint8_t *gmask;         // the four land masks as bits (derive_geometry_check passed: required)
+};
+int evp_cgrid_res_max_blocks_per_cu();
+void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,
 //        4 face->face and face->corner velocity averages, 5 strengthU (once per call), 6 zero what the reference's
 //        whole-array zero fills leave zero outside the interior (uvelN, vvelE, uvel, vvel; once per call)

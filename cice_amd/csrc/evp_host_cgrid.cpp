@@ -38,6 +38,24 @@ struct CGridState {
         unsigned long long *prof = nullptr;   // test build: phase stamps (CICE_EVP_HIP_CGRID_PROF=1)
         int flip = 0;            // which allocation f[CF_UE], f[CF_VN], f[CF_SP], f[CF_SM] are (part of the graph key)
     } one;
+    // all subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res)
+    struct Res {
+        int *tab = nullptr;
+        int4 *tiles = nullptr;
+        int ntiles = 0;
+        uint8_t *pubmap = nullptr;
+        void *rec = nullptr;         // 2 x S.n records of 32 bytes
+        int *err = nullptr;
+        unsigned epoch = 0;
+        int par = 0;
+        bool images_ok = false;      // every ghost cell's static arrays equal its source's bit for bit
+        std::string why;             // ... or why the kernel is not eligible on this rank
+        int mode = -1;               // -1 undecided (first eligible call probes), 0 off, 1 on
+        bool launched = false;       // a launch whose error word has not been looked at
+        long cap = 0;                // windows that can be resident at once (occupancy x CUs)
+        double t_probe_ms = -1.0;    // probe: ms per subcycle
+        int last_nsub = 0;           // subcycles of the last call that ran inside it
+    } res;
     uint8_t *mask = nullptr;
     uint8_t *gmask = nullptr;    // the four land masks as bits (cg_one's derived view of the static table); null: an identity failed
     std::string geo_why;         // ... and which one
@@ -89,6 +107,8 @@ void cgrid_free()
     F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
     CG.one = CGridState::One{};
+    F(CG.res.tab); F(CG.res.tiles); F(CG.res.pubmap); F(CG.res.rec); F(CG.res.err);
+    CG.res = CGridState::Res{};
     {
         CGridState::Prep &Q = CG.prep;
         F(Q.tmask); for (auto &p : Q.xmask) F(p);
@@ -293,10 +313,14 @@ static bool one_launch()
     return true;
 }
 static int one_subcycles(int ndte, bool first) { return one_launch() ? ndte - (first ? 1 : 0) : 0; }
+static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[5], double *const alt5[5]);
+static int build_res_tables(const double *const *static23);
 
 // three launches per subcycle + one after the loop (evp_cgrid.hip); stress12U ping-pongs, returns with the
 // current values in `cur` (the caller swaps the pointers when ndte is odd)
-static int enqueue_fused(EvpCgrid A, int ndte, bool first)
+// nres > 0: the last nres subcycles of the call run inside ONE launch of the on-chip resident kernel (evp_cgrid_res.hip), which
+// reads the current allocation of each ping-pong array and leaves the final state in both
+static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
 {
     double *cur = CG.f[CF_S12U], *other = CG.s12alt;
     const bool one = one_launch();
@@ -315,7 +339,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
         evp_launch_cgrid_zero_cells(A, CG.zero_cells, CG.n_zero, S.stream);
         HIPC(hipMemcpyAsync(other, cur, S.n * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
     }
-    for (int k = 0; k < ndte; ++k) {
+    for (int k = 0; k < ndte - nres; ++k) {
         const int last = (k == ndte - 1);
         A.f[CF_S12U] = cur;
         if (one && !(first && k == 0)) {
@@ -367,6 +391,11 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first)
     }
     A.f[CF_S12U] = cur;
     for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = c4[q];
+    if (nres > 0) {
+        double *cur5[5] = {c4[0], c4[1], c4[2], c4[3], cur};
+        double *alt5[5] = {o4[0], o4[1], o4[2], o4[3], other};
+        if (int rc = res_launch(A, nres, false, cur5, alt5)) return rc;
+    }
     evp_launch_cgrid_phase(A, 4, 1, S.stream);
     XCHG(A.f[CF_UN], A.f[CF_VE]);
     XCHG(A.f[CF_UU], A.f[CF_VU]);
@@ -447,6 +476,171 @@ static int build_one_tables()
     return 0;
 }
 
+// ---- the on-chip resident kernel (evp_cgrid_res.hip) ---------------------------------------------------------------
+// Tables: cg_one's window table for 16 x 16 windows with one more row / column of positions, the map of cells some other
+// window's rim mirrors (they publish a record every subcycle), the record buffers.  And the one property of the caller's
+// static arrays the kernel relies on: it takes a NEIGHBOUR's operands from the cell the neighbouring position's value comes
+// from, where the one-launch kernels read the array neighbour of the own cell -- the same thing if every ghost cell's static
+// arrays are copies of its source's, which is checked here bit for bit on the sixteen arrays concerned (true of a grid whose
+// static fields were halo-updated, as CICE's are; false, for instance, across a tripole fold).
+static int build_res_tables(const double *const *static23)
+{
+    const HaloPlan &P = S.plan;
+    CGridState::Res &Q = CG.res;
+    Q.images_ok = true;
+    for (size_t k = 0; k < P.local_dst.size() && Q.images_ok; ++k) {
+        if (P.local_src[k] < 0) continue;
+        // (the arrays the kernel reads at a NEIGHBOUR's position: the eight lengths, the four areas, the four land masks; the
+        // reciprocal areas, DminTarea and the boundary ratios are read at the own cell only or not at all)
+        for (int a : {CG_DXT, CG_DYT, CG_DXU, CG_DYU, CG_DXE, CG_DYE, CG_DXN, CG_DYN, CG_UAREA, CG_TAREA, CG_EAREA, CG_NAREA, CG_EPM, CG_NPM,
+                      CG_UVM, CG_HM})
+            if (std::memcmp(static23[a] + P.local_dst[k], static23[a] + P.local_src[k], sizeof(double)) != 0) {
+                Q.images_ok = false;
+                Q.why = "static array " + std::to_string(a) + " differs between ghost cell " + std::to_string(P.local_dst[k]) + " and its source";
+                break;
+            }
+    }
+    if (!Q.images_ok) return 0;
+    constexpr int RX = 16, RY = 16, NPOS = (RX + 1) * (RY + 1);
+    cice_evp_hip_dims d = S.d;
+    d.ilo = S.ilo.data(); d.ihi = S.ihi.data(); d.jlo = S.jlo.data(); d.jhi = S.jhi.data();
+    d.iglob0 = S.iglob0.data(); d.jglob0 = S.jglob0.data();
+    std::vector<int32_t> tab, tiles;
+    build_window_table(d, P, RX, RY, 1 << 20, tiles, tab, 1);
+    Q.ntiles = (int)(tiles.size() / 4);
+    std::vector<uint8_t> pub(S.n, 0);
+    for (int w = 0; w < Q.ntiles; ++w) {
+        const int b = tiles[4 * w], i0 = tiles[4 * w + 1], j0 = tiles[4 * w + 2];
+        for (int e = 0; e < NPOS - 1; ++e) {
+            const int ex = e % (RX + 1), ey = e / (RX + 1);
+            const bool mine = ex >= 2 && ex <= RX - 2 && ey >= 2 && ey <= RY - 2 && i0 - 2 + ex <= S.ihi[b] && j0 - 2 + ey <= S.jhi[b];
+            const int sc = tab[(size_t)w * NPOS + e];
+            if (!mine && sc >= 0) pub[sc] = 1;
+        }
+    }
+    HIPC(hipMalloc((void **)&Q.tab, tab.size() * sizeof(int)));
+    HIPC(hipMalloc((void **)&Q.tiles, tiles.size() * sizeof(int32_t)));
+    HIPC(hipMalloc((void **)&Q.pubmap, S.n));
+    HIPC(hipMalloc((void **)&Q.rec, (size_t)2 * S.n * 32));
+    HIPC(hipMalloc((void **)&Q.err, 8 * sizeof(int)));
+    HIPC(hipMemcpy(Q.tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(Q.tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(Q.pubmap, pub.data(), S.n, hipMemcpyHostToDevice));
+    HIPC(hipMemset(Q.rec, 0, (size_t)2 * S.n * 32));
+    HIPC(hipMemset(Q.err, 0, 8 * sizeof(int)));
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, S.device));
+    Q.cap = (long)evp_cgrid_res_max_blocks_per_cu() * prop.multiProcessorCount;
+    return 0;
+}
+
+// eligible in this call: one rank, no fold, avg_zeta, the default-configuration shortcuts hold on every ice cell, the static
+// identities hold (the kernel takes -1 for a boundary ratio away from a coast), every window co-resident
+static bool res_eligible(std::string *why = nullptr)
+{
+    auto no = [&](const char *w) { if (why) *why = w; return false; };
+    const CGridState::Res &Q = CG.res;
+    if (!CG.one.tab || remote() || !fused_schedule() || !one_launch()) return no("several ranks, a tripole fold, a block too small, or the one-launch schedule switched off");
+    if (!Q.tab) return no(Q.why.empty() ? "tables not built" : Q.why.c_str());
+    if (CG.avg_strength) return no("visc_method = avg_strength");
+    if (S.prm.revp != 0.0) return no("revised EVP");     // (the kernel keeps revp * uvelE_init as the zero it is under classic EVP)
+    if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
+    if (!geo_derived()) return no("a start-up identity of the static arrays does not hold");
+    if ((long)Q.ntiles > Q.cap) return no("more windows than can be resident at once");
+    return true;
+}
+
+static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[5], double *const alt5[5])
+{
+    CGridState::Res &Q = CG.res;
+    EvpCgRes R{};
+    R.tab = Q.tab; R.tiles = Q.tiles; R.order = nullptr; R.ntiles = Q.ntiles;
+    R.nsub = nsub; R.dry = dry ? 1 : 0;
+    Q.epoch = (Q.epoch + 1u) & 0xFFFFFu;
+    if (Q.epoch == 0) Q.epoch = 1;
+    R.tag_base = Q.epoch << 12;
+    R.par0 = Q.par;
+    Q.par ^= (nsub & 1);
+    R.spin_limit = 4000000u;
+    R.err = Q.err;
+    R.pubmap = Q.pubmap;
+    R.rec[0] = Q.rec; R.rec[1] = (char *)Q.rec + (size_t)S.n * 32;
+    R.uE_in = cur5[0]; R.vN_in = cur5[1]; R.sp_in = cur5[2]; R.sm_in = cur5[3]; R.s12_in = cur5[4];
+    R.uE_out[0] = cur5[0]; R.uE_out[1] = alt5[0]; R.vN_out[0] = cur5[1]; R.vN_out[1] = alt5[1];
+    R.sp_out[0] = cur5[2]; R.sp_out[1] = alt5[2]; R.sm_out[0] = cur5[3]; R.sm_out[1] = alt5[3];
+    R.s12_out[0] = cur5[4]; R.s12_out[1] = alt5[4];
+    R.gbase = CG.gslab; R.inbase = CG.inslab; R.stride = S.n;
+    R.gmask = CG.gmask;
+    evp_launch_cgrid_res(A, R, S.stream);
+    HIPC(hipGetLastError());
+    Q.launched = true;
+    return 0;
+}
+
+static int res_check_error()
+{
+    CGridState::Res &Q = CG.res;
+    if (!Q.launched) return 0;
+    Q.launched = false;
+    int ev[8] = {0};
+    HIPC(hipMemcpy(ev, Q.err, sizeof ev, hipMemcpyDeviceToHost));
+    if (ev[0]) {
+        HIPC(hipMemset(Q.err, 0, sizeof ev));
+        Q.mode = 0;
+        return fail(-7, "resident C-grid kernel: a wait gave up (window %d, subcycle %d, cell %d, tag seen %#x, wanted %#x) -- workgroups not co-resident?",
+                    ev[1], ev[2], ev[3], (unsigned)ev[4], (unsigned)ev[5]);
+    }
+    return 0;
+}
+
+// First eligible call: a dry run (the same work on the uploaded state, nothing written back) proves that every window is
+// resident and gives the steady-state cost per subcycle.  CICE_EVP_HIP_CGRID_RESIDENT=0 / 1 forces the verdict.
+static int res_decide(const EvpCgrid &A)
+{
+    CGridState::Res &Q = CG.res;
+    if (Q.mode >= 0) return 0;
+    int want = -1;
+    if (const char *e = env("CICE_EVP_HIP_CGRID_RESIDENT")) want = std::atoi(e);
+    std::string why;
+    if (want == 0 || !res_eligible(&why)) {
+        if (want == 1) return fail(-6, "resident C-grid kernel requested but not applicable: %s", why.c_str());
+        if (env("CICE_EVP_HIP_VERBOSE") && want != 0) std::fprintf(stderr, "[cice_evp_hip] C grid: on-chip resident kernel not used: %s\n", why.c_str());
+        // (per-call conditions -- visc_method, the shortcuts -- may hold in a later call: stay undecided unless switched off)
+        if (want == 0) Q.mode = 0;
+        return 0;
+    }
+    double *cur5[5] = {CG.f[CF_UE], CG.f[CF_VN], CG.f[CF_SP], CG.f[CF_SM], CG.f[CF_S12U]};
+    double *alt5[5] = {CG.one.alt[0], CG.one.alt[1], CG.one.alt[2], CG.one.alt[3], CG.s12alt};
+    const int nshort = 8, nlong = 40;
+    float tl[2] = {0, 0}, ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        const int np = rep == 2 ? nlong : nshort;
+        HIPC(hipEventRecord(S.ev2, S.stream));
+        if (int rc = res_launch(A, np, true, cur5, alt5)) return rc;
+        HIPC(hipEventRecord(S.ev3, S.stream));
+        HIPC(hipStreamSynchronize(S.stream));
+        if (res_check_error()) {
+            if (want == 1) return -7;
+            g_err.clear();
+            Q.mode = 0;
+            if (env("CICE_EVP_HIP_VERBOSE")) std::fprintf(stderr, "[cice_evp_hip] C grid: on-chip resident kernel failed its probe, not used\n");
+            return 0;
+        }
+        HIPC(hipEventElapsedTime(&ms, S.ev2, S.ev3));
+        if (rep >= 1) tl[rep - 1] = ms;
+    }
+    Q.t_probe_ms = (tl[1] - tl[0]) / (nlong - nshort);
+    Q.mode = 1;
+    return 0;
+}
+
+static int res_subcycles(int ndte, bool first)
+{
+    if (CG.res.mode != 1 || !one_launch() || !res_eligible()) return 0;
+    const int n = ndte - (first ? 1 : 0);
+    return (n >= 3 && n <= 4000) ? n : 0;
+}
+
 int finish_upload(int32_t visc_method);
 
 }  // namespace evp_host
@@ -516,8 +710,10 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     HIPC(hipMemcpyAsync(CG.img_dst, dst.data(), dst.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
     if (tripole && P.fold_rows == 1)             // (ranks without the fold rows run the same schedule with empty lists)
         if (int rc = build_fold_lists()) return rc;
-    if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3)
+    if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3) {
         if (int rc = build_one_tables()) return rc;
+        if (int rc = build_res_tables(static23)) return rc;
+    }
     if (!tripole) {      // (the five-phase kernels of tripole grids always load all 23)
         const std::vector<uint8_t> gm = derive_geometry_check(static23, CG.geo_why);
         if (!gm.empty()) {
@@ -617,12 +813,16 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     EvpCgrid A;
     fill(A);
     const bool fused = fused_schedule();
+    if (int rc = res_check_error()) return rc;
+    if (int rc = res_decide(A)) return rc;       // (first call: the on-chip resident kernel's probe; refuses loudly when forced on a rank it cannot serve)
+    const int nres = fused ? res_subcycles(ndte, CG.first) : 0;
     auto enqueue = [&]() -> int {
-        if (fused) return enqueue_fused(A, ndte, CG.first);
+        if (fused) return enqueue_fused(A, ndte, CG.first, nres);
         return enqueue_phases(A, ndte, CG.first);
     };
     HIPC(hipEventRecord(S.ev0, S.stream));
-    if (S.use_graph && (!remote() || S.direct.on)) {     // RCCL point-to-point is enqueued eagerly (as the B-grid loop does)
+    // (the resident launch carries a fresh epoch in its arguments: enqueued eagerly, with the few launches around it)
+    if (nres == 0 && S.use_graph && (!remote() || S.direct.on)) {     // RCCL point-to-point is enqueued eagerly (as the B-grid loop does)
         const std::pair<int, int> key(ndte, (geo_derived() ? 128 : 0) | (fused && one_launch() ? 64 : 0) | (CG.one.flip << 5) | (CG.fast ? 16 : 0) | (CG.flip << 3) |
                                                 (fused ? 4 : 0) | (CG.first ? 2 : 0) | CG.avg_strength);
         auto it = CG.graphs.find(key);
@@ -641,18 +841,19 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     } else if (enqueue()) {
         return -1;
     }
-    if (fused && ((ndte - ((CG.first && CG.avg_strength) ? 1 : 0)) & 1)) {   // the current stress12U is in the other allocation now
+    if (fused && ((ndte - nres - ((CG.first && CG.avg_strength) ? 1 : 0)) & 1)) {   // the current stress12U is in the other allocation now
         // (every subcycle swaps the two, except a first one run as five launches: visc_method = avg_strength)
         std::swap(CG.f[CF_S12U], CG.s12alt);
         CG.flip ^= 1;
     }
-    if (fused && (one_subcycles(ndte, CG.first) & 1)) {      // and so are uvelE, vvelN, stresspT, stressmT
+    if (fused && ((one_subcycles(ndte, CG.first) - nres) & 1)) {      // and so are uvelE, vvelN, stresspT, stressmT
         for (int q = 0; q < 4; ++q) std::swap(CG.f[ONE_FIELDS[q]], CG.one.alt[q]);
         CG.one.flip ^= 1;
     }
     HIPC(hipEventRecord(S.ev1, S.stream));
     HIPC(hipGetLastError());
-    CG.t_one = fused ? one_subcycles(ndte, CG.first) : 0;
+    CG.t_one = fused ? one_subcycles(ndte, CG.first) - nres : 0;
+    CG.res.last_nsub = nres;
     CG.first = false;
     CG.t_nsub = ndte;
     return 0;
@@ -669,7 +870,7 @@ int cice_evp_hip_cgrid_download(double *const *fields19)
     HIPC(hipStreamSynchronize(S.stream));
     float ms = 0;
     if (CG.t_nsub && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) CG.t_loop_ms = ms;
-    return 0;
+    return res_check_error();
 }
 
 // deformationsC_T (ice_dyn_shared.F90:1968-2074; evp() calls it right after the C-grid loop, ice_dyn_evp.F90:1106-1119) on
@@ -738,7 +939,7 @@ int cice_evp_hip_cgrid_sync(void)
     HIPC(hipStreamSynchronize(S.stream));
     float ms = 0;
     if (CG.t_nsub && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) CG.t_loop_ms = ms;
-    return 0;
+    return res_check_error();
 }
 
 int cice_evp_hip_cgrid_run(int32_t ndte, int32_t visc_method, double *const *fields19, const double *const *inputs23,
@@ -1015,6 +1216,8 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     if (n >= 3) out[2] = CG.prep.t_ms;           // device time of the last cice_evp_hip_cgrid_prep (kernels, without the copies)
     if (n >= 4) out[3] = (double)CG.t_one;       // subcycles of the last call run as one launch each
     if (n >= 5) out[4] = geo_derived() ? 1.0 : 0.0;   // ... with 15 of the 23 static arrays derived in the kernel
+    if (n >= 6) out[5] = (double)CG.res.last_nsub;    // subcycles of the last call inside ONE launch of the on-chip resident kernel
+    if (n >= 7) out[6] = CG.res.t_probe_ms;           // ... and what its probe measured per subcycle, ms (-1: no probe ran)
     return 0;
 }
 

@@ -138,7 +138,7 @@ int halo_uv(int b, bool masked)
     if (!general) {
         // tripole seam of the top physical row, every pair and every ghost image of a seam cell on this rank: the
         // remote exchange below never involves seam-row cells
-        evp_launch_halo_seam(S.u[b], S.v[b], S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
+        evp_launch_halo_seam(S.u[b], S.v[b], masked ? S.u[b ^ 1] : nullptr, masked ? S.v[b ^ 1] : nullptr, S.h_seam_a, S.h_seam_b, S.n_seam, S.h_seam_pole, S.n_pole,
                              S.h_late_dst, S.h_late_src, (const signed char *)S.h_late_sign, S.n_late, S.stream);
         if (int rc = halo_remote_pair(S.u[b], S.v[b], masked)) return rc;
         return 0;
@@ -146,7 +146,7 @@ int halo_uv(int b, bool masked)
     // any rank layout: the exchange first (it also carries the RAW seam values other ranks hold into the staging
     // slots behind the arrays), then every seam cell and every ghost image of one is finalised from raw values
     if (int rc = halo_remote_pair(S.u[b], S.v[b], masked)) return rc;
-    evp_launch_halo_seam_fin(S.u[b], S.v[b], S.h_fin_dst, S.h_fin_a, S.h_fin_b, (const signed char *)S.h_fin_coef, S.n_fin, S.stream);
+    evp_launch_halo_seam_fin(S.u[b], S.v[b], masked ? S.u[b ^ 1] : nullptr, masked ? S.v[b ^ 1] : nullptr, S.h_fin_dst, S.h_fin_a, S.h_fin_b, (const signed char *)S.h_fin_coef, S.n_fin, S.stream);
     return 0;
 }
 

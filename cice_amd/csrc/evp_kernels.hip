@@ -321,7 +321,11 @@ __global__ void halo_local_uv(double *__restrict__ u, double *__restrict__ v,
 //           (ice_boundary.F90:1630-1649)
 //   poles:  x <- -x  (the pole points mirror onto themselves, copy-out :1689-1722)
 //   late :  ghost copies whose source is a seam-row cell, repeated with the new values
-__global__ void halo_seam_uv(double *__restrict__ u, double *__restrict__ v,
+// u2, v2 (may be null): the OTHER ping-pong buffer, which takes every value stored here as well.  The subcycle kernel writes
+// ice cells only, so a seam-row cell without ice would otherwise meet, in the buffer the next-but-one subcycle writes, its
+// value of two updates ago -- and a pole point changes sign with EVERY update (a zero there showed the wrong sign after
+// 4k + 2 subcycles: found when the tests began to compare bit patterns, round 5).
+__global__ void halo_seam_uv(double *__restrict__ u, double *__restrict__ v, double *__restrict__ u2, double *__restrict__ v2,
                              const int *__restrict__ pa, const int *__restrict__ pb, int npair,
                              const int *__restrict__ pole, int npole,
                              const int *__restrict__ ldst, const int *__restrict__ lsrc,
@@ -334,17 +338,22 @@ __global__ void halo_seam_uv(double *__restrict__ u, double *__restrict__ v,
         const double xv = 0.5 * (v[a] + isign * v[b]);
         u[a] = xu; u[b] = isign * xu;
         v[a] = xv; v[b] = isign * xv;
+        if (u2) { u2[a] = xu; u2[b] = isign * xu; v2[a] = xv; v2[b] = isign * xv; }
     }
     for (int k = threadIdx.x; k < npole; k += blockDim.x) {
         const int a = pole[k];
-        u[a] = isign * u[a];
-        v[a] = isign * v[a];
+        const double xu = isign * u[a], xv = isign * v[a];
+        u[a] = xu;
+        v[a] = xv;
+        if (u2) { u2[a] = xu; v2[a] = xv; }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < nlate; k += blockDim.x) {
         const double sg = (double)lsign[k];
-        u[ldst[k]] = sg * u[lsrc[k]];
-        v[ldst[k]] = sg * v[lsrc[k]];
+        const double xu = sg * u[lsrc[k]], xv = sg * v[lsrc[k]];
+        u[ldst[k]] = xu;
+        v[ldst[k]] = xv;
+        if (u2) { u2[ldst[k]] = xu; v2[ldst[k]] = xv; }
     }
 }
 
@@ -352,8 +361,8 @@ __global__ void halo_seam_uv(double *__restrict__ u, double *__restrict__ v,
 // staging slots the exchange has just filled -- and only then are the results stored (own seam cells are both
 // operands and destinations).  One workgroup; up to FIN_PER entries per thread are held in registers.
 constexpr int FIN_PER = 8;
-__global__ __launch_bounds__(1024) void halo_seam_fin(double *__restrict__ u, double *__restrict__ v,
-                                                      const int *__restrict__ dst, const int *__restrict__ fa,
+__global__ __launch_bounds__(1024) void halo_seam_fin(double *__restrict__ u, double *__restrict__ v, double *__restrict__ u2,
+                                                      double *__restrict__ v2, const int *__restrict__ dst, const int *__restrict__ fa,
                                                       const int *__restrict__ fb, const signed char *__restrict__ coef, int n)
 {
     const double isign = -1.0;
@@ -378,7 +387,10 @@ __global__ __launch_bounds__(1024) void halo_seam_fin(double *__restrict__ u, do
 #pragma unroll
     for (int e = 0; e < FIN_PER; ++e) {
         const int k = threadIdx.x + e * 1024;
-        if (k < n) { u[dst[k]] = ru[e]; v[dst[k]] = rv[e]; }
+        if (k < n) {
+            u[dst[k]] = ru[e]; v[dst[k]] = rv[e];
+            if (u2) { u2[dst[k]] = ru[e]; v2[dst[k]] = rv[e]; }      // (as in halo_seam_uv: both ping-pong buffers)
+        }
     }
 }
 
@@ -537,22 +549,22 @@ void evp_launch_halo_local(double *u, double *v, const int *dst, const int *src,
     hipLaunchKernelGGL(halo_local_uv, dim3((n + 255) / 256), dim3(256), 0, st, u, v, dst, src, sign, n);
 }
 
-void evp_launch_halo_seam(double *u, double *v, const int *pa, const int *pb, int npair, const int *pole,
+void evp_launch_halo_seam(double *u, double *v, double *u2, double *v2, const int *pa, const int *pb, int npair, const int *pole,
                           int npole, const int *ldst, const int *lsrc, const signed char *lsign,
                           int nlate, hipStream_t st)
 {
     if (npair <= 0 && npole <= 0 && nlate <= 0) return;
-    hipLaunchKernelGGL(halo_seam_uv, dim3(1), dim3(1024), 0, st, u, v, pa, pb, npair, pole, npole, ldst,
+    hipLaunchKernelGGL(halo_seam_uv, dim3(1), dim3(1024), 0, st, u, v, u2, v2, pa, pb, npair, pole, npole, ldst,
                        lsrc, lsign, nlate);
 }
 
 int evp_halo_seam_fin_capacity() { return FIN_PER * 1024; }
 
-void evp_launch_halo_seam_fin(double *u, double *v, const int *dst, const int *fa, const int *fb,
+void evp_launch_halo_seam_fin(double *u, double *v, double *u2, double *v2, const int *dst, const int *fa, const int *fb,
                               const signed char *coef, int n, hipStream_t st)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(halo_seam_fin, dim3(1), dim3(1024), 0, st, u, v, dst, fa, fb, coef, n);
+    hipLaunchKernelGGL(halo_seam_fin, dim3(1), dim3(1024), 0, st, u, v, u2, v2, dst, fa, fb, coef, n);
 }
 
 void evp_launch_halo_stress(double *const *sig12, const int *dst, const int *src, int n, hipStream_t st)

@@ -630,7 +630,7 @@ void build_fold_list(const cice_evp_hip_dims &d, int loc, FoldList &L)
 }
 
 void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, int OY, int strip, std::vector<int32_t> &tiles,
-                        std::vector<int32_t> &tab)
+                        std::vector<int32_t> &tab, int extra)
 {
     const int nxb = d.nx_block, nyb = d.ny_block;
     const long plane = (long)nxb * nyb;
@@ -651,8 +651,10 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
             for (int j0 = d.jlo[b]; j0 <= d.jhi[b]; j0 += OY - 3)
                 for (long i0 = is0; i0 <= d.ihi[b] && i0 < is0 + (long)strip * (OX - 3); i0 += OX - 3) {
                     bool regular = true;
-                    for (int ty = 0; ty < OY; ++ty)
-                        for (int tx = 0; tx < OX; ++tx) {
+                    // (extra = 1: one more row and column of positions per window, same owned range -- the on-chip resident
+                    // kernel's velocity tile, evp_cgrid_res.hip)
+                    for (int ty = 0; ty < OY + extra; ++ty)
+                        for (int tx = 0; tx < OX + extra; ++tx) {
                             const int i = (int)i0 - 2 + tx, j = j0 - 2 + ty;
                             const int ic = std::min(std::max(i, d.ilo[b] - 1), d.ihi[b] + 1);
                             const int jc = std::min(std::max(j, d.jlo[b] - 1), d.jhi[b] + 1);

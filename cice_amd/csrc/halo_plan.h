@@ -140,8 +140,9 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan);
 // reference has there: >= 0 an interior cell (itself, or the one a ghost cell mirrors according to the plan's local
 // copies; further out the walk continues from the mirrored cell, neighbour by neighbour, x first), or -1 - c for a ghost
 // cell c nothing is copied into (closed boundary, eliminated neighbour block): its arrays are read, never computed.
+// extra = 1: (ox+1) x (oy+1) positions per window, same owned range and window stride (the resident kernel's velocity tile).
 void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &plan, int ox, int oy, int strip, std::vector<int32_t> &tiles,
-                        std::vector<int32_t> &tab);
+                        std::vector<int32_t> &tab, int extra = 0);
 
 // C grid on a tripole (u-fold) grid: the fold step of one field location (0 centre, 1 NE corner, 2 E face, 3 N face),
 // by the meaning of the cells (ice_boundary.F90:1626-1722): one entry for every cell of every local block -- interior

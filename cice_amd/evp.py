@@ -53,7 +53,7 @@ EXPORTS = [
 # libcice_evp_hip_testing.so only (include/cice_evp_hip_testing.h): plan introspection of the CPU tests, read-outs of the tools,
 # the test transport
 TEST_EXPORTS = [
-    "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
+    "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_cgrid_window_plan_ext", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
     "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_debug_cgrid_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
     "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan", "cice_evp_hip_stress_plan",
     "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags", "cice_evp_hip_fold_images_plan",
@@ -224,14 +224,15 @@ def cgrid_fold_plan(dims: "Dims", loc: str) -> dict:
     return out
 
 
-def cgrid_window_plan(dims: "Dims", ox: int, oy: int) -> dict:
-    """Host only: the window table of the C grid's one-launch kernel (see the header)."""
+def cgrid_window_plan(dims: "Dims", ox: int, oy: int, extra: int = 0) -> dict:
+    """Host only: the window table of the C grid's one-launch kernel (extra = 1: of the on-chip resident one; see the header)."""
     lib = load_library(testing=True)
     n = C.c_int32(0)
-    _check(lib, lib.cice_evp_hip_cgrid_window_plan(C.byref(dims), C.c_int32(ox), C.c_int32(oy), C.byref(n), None, None), "(cgrid_window_plan)")
+    a = (C.byref(dims), C.c_int32(ox), C.c_int32(oy), C.c_int32(extra), C.byref(n))
+    _check(lib, lib.cice_evp_hip_cgrid_window_plan_ext(*a, None, None), "(cgrid_window_plan)")
     tiles = np.zeros((n.value, 4), dtype=np.int32)
-    tab = np.zeros((n.value, oy, ox), dtype=np.int32)
-    _check(lib, lib.cice_evp_hip_cgrid_window_plan(C.byref(dims), C.c_int32(ox), C.c_int32(oy), C.byref(n), _ip(tiles), _ip(tab)), "(cgrid_window_plan)")
+    tab = np.zeros((n.value, oy + extra, ox + extra), dtype=np.int32)
+    _check(lib, lib.cice_evp_hip_cgrid_window_plan_ext(*a, _ip(tiles), _ip(tab)), "(cgrid_window_plan)")
     return dict(tiles=tiles, tab=tab)
 
 
@@ -470,10 +471,10 @@ class EvpHip:
         _check(self.lib, self.lib.cice_evp_hip_cgrid_sync(), "(dyn_evp_hip_cgrid_sync)")
 
     def cgrid_timings(self):
-        out = np.zeros(5)
-        _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(5)), "(dyn_evp_hip_cgrid_timings)")
+        out = np.zeros(7)
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(7)), "(dyn_evp_hip_cgrid_timings)")
         return dict(loop_ms=float(out[0]), nsub=int(out[1]), prep_ms=float(out[2]), one_launch_subcycles=int(out[3]),
-                    geometry_derived=bool(out[4]))
+                    geometry_derived=bool(out[4]), resident_subcycles=int(out[5]), resident_probe_ms=float(out[6]))
 
     def prep_fetch(self, name: str):
         out = np.zeros(self.shape)

@@ -30,6 +30,10 @@ int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int
  * value the reference has at that position (>= 0), or -1 - c for a ghost cell c nothing is copied into.  First call with
  * NULL arrays for the count.  (What the device kernel reads; checked on the CPU against the decomposition's global numbering.) */
 int cice_evp_hip_cgrid_window_plan(const cice_evp_hip_dims *dims, int32_t ox, int32_t oy, int32_t *ntiles, int32_t *tiles4, int32_t *tab);
+/* The same with (ox + extra) x (oy + extra) positions per window, extra = 0 or 1 (same owned range and window stride): the table of the
+ * on-chip resident C-grid kernel, whose level S reads one position beyond the window to the east and north (evp_cgrid_res.hip).      */
+int cice_evp_hip_cgrid_window_plan_ext(const cice_evp_hip_dims *dims, int32_t ox, int32_t oy, int32_t extra, int32_t *ntiles,
+                                       int32_t *tiles4, int32_t *tab);
 /* Test hook: route the exchanges and the rank agreements of the two-subcycle path through HOST buffers and the caller's
  * callbacks instead of RCCL (which refuses two ranks on one device), so that its several-rank form can be run as
  * processes sharing one GPU (tools/mailbox_2proc.py --march: torch.distributed gloo underneath).  xchg: per peer q

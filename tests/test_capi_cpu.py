@@ -308,8 +308,8 @@ def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by, ns):
 @pytest.mark.parametrize("nx,ny,bx,by,ew,ns", [(24, 18, 24, 18, "cyclic", "closed"), (28, 20, 14, 10, "cyclic", "closed"),
                                                (26, 22, 10, 12, "cyclic", "cyclic"), (40, 30, 20, 10, "closed", "closed"),
                                                (70, 37, 24, 13, "cyclic", "closed"), (9, 7, 4, 3, "cyclic", "cyclic")])
-@pytest.mark.parametrize("ox,oy", [(32, 8), (64, 16), (8, 6)])
-def test_cgrid_window_table_names_the_source_cell_of_every_position(nx, ny, bx, by, ew, ns, ox, oy):
+@pytest.mark.parametrize("ox,oy,extra", [(32, 8, 0), (64, 16, 0), (8, 6, 0), (16, 16, 1)])
+def test_cgrid_window_table_names_the_source_cell_of_every_position(nx, ny, bx, by, ew, ns, ox, oy, extra):
     """C grid, one launch per subcycle: the host-built window table (cice_evp_hip_cgrid_window_plan; what the kernel reads)
     against the decomposition's global numbering.  A position (tx, ty) of a window is the cell (i0-2+tx, j0-2+ty) of its
     block's numbering -- possibly a ghost cell, possibly beyond the block's array; the table must name the interior cell
@@ -328,13 +328,14 @@ def test_cgrid_window_table_names_the_source_cell_of_every_position(nx, ny, bx, 
             for i in range(b.ilo, b.ihi + 1):
                 home[(b.gi0 + i - b.ilo, b.gj0 + j - b.jlo)] = k * plane + (j - 1) * nxb + (i - 1)
     assert len(home) == nx * ny
-    P = evp.cgrid_window_plan(d, ox, oy)
+    # (extra = 1: the on-chip resident kernel's table, one more row and column of positions per window, same owned range)
+    P = evp.cgrid_window_plan(d, ox, oy, extra)
     owned = np.zeros(len(ob) * plane, dtype=int)
     for (k, i0, j0, regular), tab in zip(P["tiles"], P["tab"]):
         b = ob[k]
         ident = True
-        for ty in range(oy):
-            for tx in range(ox):
+        for ty in range(oy + extra):
+            for tx in range(ox + extra):
                 i, j = i0 - 2 + tx, j0 - 2 + ty
                 gi, gj = b.gi0 + i - b.ilo, b.gj0 + j - b.jlo
                 if ew == "cyclic":

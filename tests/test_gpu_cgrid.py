@@ -107,6 +107,47 @@ def test_cgrid_deformations_t_on_device_bitwise(name):
         core.finalize()
 
 
+def test_cgrid_resident_kernel_bitwise(monkeypatch):
+    """The on-chip resident C-grid kernel (evp_cgrid_res.hip: all subcycles of a call but the first after an upload in ONE launch,
+    state in registers and LDS, face velocities traded between windows as tagged records) forced on: every fixture it is
+    eligible for -- one rank, no fold, avg_zeta, the default-configuration shortcuts, classic EVP -- bit-identical to the
+    reference's arrays, ghost cells included, in one call and across calls; the others must refuse loudly.  Forced off, the
+    one-launch kernel gives the same bits."""
+    ran, refused = [], []
+    for name in CGRID_CASES:
+        c = GoldenCase(name)
+        dom = c.oracle_domain()
+        for forced in ("1", "0"):
+            monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", forced)
+            core = cgrid_core(c)
+            try:
+                for icall in range(1, c.ncalls + 1):
+                    state, inputs, masks = c.cgrid_inputs(icall)
+                    for nsub in c.nsub_list:
+                        try:
+                            out = core.cgrid_run(nsub, state, inputs, masks, visc_method=str(c.d["visc_method"]))
+                        except evp.EvpHipError as e:
+                            assert forced == "1" and "not applicable" in str(e), (name, str(e))
+                            refused.append((name, str(e)))
+                            break
+                        oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+                        oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+                        assert_bitwise(out, c.cgrid_expected(icall, nsub), f"{name} call {icall} nsub {nsub} (C grid, resident {forced})")
+                        res = core.cgrid_timings()["resident_subcycles"]
+                        if forced == "1" and nsub >= 4:
+                            assert res == nsub - 1, (name, nsub, res)
+                            ran.append(name)
+                        if forced == "0":
+                            assert res == 0
+                    else:
+                        continue
+                    break
+            finally:
+                core.finalize()
+    print("resident C-grid kernel ran on:", sorted(set(ran)), "refused:", sorted(set(r[0] for r in refused)))
+    assert len(set(ran)) >= 2, (ran, refused)
+
+
 def test_cgrid_split_calls_equal_one_call():
     """upload / subcycle(a) / subcycle(b) / download == run(a + b): the resident state carries over, and the
     one-off zero fill of the first subcycle is not repeated."""

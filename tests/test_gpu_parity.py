@@ -479,14 +479,15 @@ def test_resident_kernel_golden_and_modes(monkeypatch):
             assert (core.timings()["tile_variant"] >= 1000) == (mode == "1")
         finally:
             core.finalize()
-    # multi-block domains are not eligible: forcing it fails loudly
+    # a multi-block domain runs it too (tiles are numbered over the blocks, ghost images from the per-cell table)
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
     c2 = GoldenCase("rect_cyc_2x2_full")
     core = hip_from_case(c2, strict=True)
     try:
         dyn, tm, um = c2.inputs(1)
-        with pytest.raises(evp.EvpHipError):
-            core.run(dyn, tm, um, ndte=2)
+        for nsub in c2.nsub_list:
+            assert_bitwise(core.run(dyn, tm, um, ndte=nsub), c2.expected(1, nsub), f"2x2 blocks resident nsub {nsub}")
+        assert core.timings()["tile_variant"] >= 2000
     finally:
         core.finalize()
 
