@@ -619,8 +619,11 @@ def main():
                 core.cgrid_sync()
                 ev_ms += core.cgrid_timings()["loop_ms"]
             wall = time.perf_counter() - t0
-            one = core.cgrid_timings()["one_launch_subcycles"] > 0
-            geo = core.cgrid_timings()["geometry_derived"]
+            tt_ = core.cgrid_timings()
+            one = tt_["one_launch_subcycles"] > 0
+            res_n = tt_["resident_subcycles"]
+            res_probe_us = 1e3 * tt_["resident_probe_ms"]
+            geo = tt_["geometry_derived"]
             out = core.cgrid_download()
         finally:
             core.finalize()
@@ -628,13 +631,18 @@ def main():
         for k in CGRID_VERIFY_FIELDS:
             h.update(np.ascontiguousarray(dc.gather({0: out[k]}), dtype="<f8").tobytes())
         want = golden.get(f"cgrid/{workload}/{case}/ndte{ndte}/closed/strict", {}).get(str(warmup + steps))
-        launches = 1 if one else 3                # cg_one / the fused schedule (evp_cgrid.hip): kernels per subcycle
+        # kernels per subcycle: cg_res (evp_cgrid_res.hip: every subcycle of a call but the first after an upload inside ONE launch),
+        # cg_one, or the fused schedule (evp_cgrid.hip)
+        launches = (1.0 / res_n) if res_n else (1 if one else 3)
+        one = one or bool(res_n)
         t_sub = ev_ms * 1e-3 / (steps * ndte)
         alg = ((CGRID_B_ALG_ONE_GEO if geo else CGRID_B_ALG_ONE) if one else (CGRID_B_ALG_GEO if geo else CGRID_B_ALG)) * nx * ny
         return {"workload": f"{workload} {nx}x{ny} C-grid EVP ndte={ndte}, case={case}, strict fp64, one GPU",
                 "value": nx * ny * ndte * steps / wall, "unit": "cell-updates/s", "steps": steps, "warmup": warmup,
                 "us_per_subcycle": 1e6 * t_sub, "us_per_subcycle_wall": 1e6 * wall / (steps * ndte),
                 "launches_per_subcycle": launches, "active_T_cells": n_active,
+                "kernel": ("cg_res (on-chip resident: all subcycles of a call in one launch)" if res_n else "cg_one" if one else "fused schedule, three launches"),
+                "resident_subcycles_per_call": res_n, "resident_probe_us_per_subcycle": (res_probe_us if res_n else None),
                 "verified": (h.hexdigest() == want["sha256"]) if want else None,
                 "checked_against": "tests/golden/bench_checksums.json (oracle/evp_oracle.c, pinned to the reference's evp() with grid_ice='C')" if want else None,
                 "finite": bool(np.isfinite(out["uvelE"]).all()), "max_abs_uE": float(np.abs(out["uvelE"]).max()),
@@ -649,7 +657,9 @@ def main():
                                        "408 B per cell and subcycle = 51 fp64 array touches of the one-launch kernel cg_one") +
                                       " (shearU, etax2T and the T-cell stresses stay in LDS between its three levels)" if one else
                                       "648 B per cell and subcycle = 81 fp64 array touches of the three fused kernels") +
-                                     " (DESIGN.md section 9); on gx1 the 64 MB working set is Infinity-Cache resident"}}
+                                     " (DESIGN.md section 9); on gx1 the 64 MB working set is Infinity-Cache resident" +
+                                     ("; with the on-chip resident kernel the state and operands stay in registers / LDS for the whole call and "
+                                      "HBM does not bound it: the figure is the yardstick of what a streaming kernel would have to move" if res_n else "")}}
 
     def cgrid_per_call(workload, case, ndte):
         """What a C-grid host waits for per evp() call, two ways: its own preparation + cice_evp_hip_cgrid_run (14 state +

@@ -499,6 +499,30 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 
 }  // namespace
 
+// Per call: the loop's state in pairs of ghost cells OUTSIDE the domain that the kernel treats as one position (pairs: host-built,
+// evp_host_cgrid.cpp build_res_tables) must agree bit for bit -- uvelE, vvelN, stresspT, stressmT, stress12U.  Bit 8 of *flags else.
+namespace {
+struct Five { const double *f[5]; };
+__global__ void cg_res_pair_check(Five F, const int2 *__restrict__ pairs, int n, unsigned *flags)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int2 pr = pairs[k];
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) bad |= __double_as_longlong(F.f[a][pr.x]) != __double_as_longlong(F.f[a][pr.y]);
+    if (bad) atomicOr(flags, 256u);
+}
+}  // namespace
+
+void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pairs, int n, unsigned *flags, hipStream_t st)
+{
+    if (n <= 0) return;
+    Five F;
+    for (int a = 0; a < 5; ++a) F.f[a] = five[a];
+    hipLaunchKernelGGL(cg_res_pair_check, dim3((n + 255) / 256), dim3(256), 0, st, F, pairs, n, flags);
+}
+
 int evp_cgrid_res_max_blocks_per_cu()
 {
     int nb = 0;

@@ -404,6 +404,7 @@ struct EvpCgRes {
     const uint8_t *gmask;         // the four land masks as bits (derive_geometry_check passed: required)
 };
 int evp_cgrid_res_max_blocks_per_cu();
+void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pairs, int n, unsigned *flags, hipStream_t st);
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,
 //        4 face->face and face->corner velocity averages, 5 strengthU (once per call), 6 zero what the reference's

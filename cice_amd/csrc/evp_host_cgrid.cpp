@@ -13,6 +13,7 @@
 // (halo_plan.cpp: build_fold_list / build_fold_list_tfold), the blocks next to the fold on one rank.
 // =====================================================================
 #include <cmath>
+#include <set>
 
 #include "evp_host.h"
 
@@ -49,6 +50,9 @@ struct CGridState {
         unsigned epoch = 0;
         int par = 0;
         bool images_ok = false;      // every ghost cell's static arrays equal its source's bit for bit
+        int2 *pairs = nullptr;       // (array neighbour of a position's cell, the ghost cell outside the domain the table names for the
+        int npairs = 0;              // neighbouring position) where the two differ: must hold the same values (static: checked once)
+        bool pairs_state_ok = true;  // ... and the same state in this call (checked on the device at every upload)
         std::string why;             // ... or why the kernel is not eligible on this rank
         int mode = -1;               // -1 undecided (first eligible call probes), 0 off, 1 on
         bool launched = false;       // a launch whose error word has not been looked at
@@ -107,7 +111,7 @@ void cgrid_free()
     F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
     CG.one = CGridState::One{};
-    F(CG.res.tab); F(CG.res.tiles); F(CG.res.pubmap); F(CG.res.rec); F(CG.res.err);
+    F(CG.res.tab); F(CG.res.tiles); F(CG.res.pubmap); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs);
     CG.res = CGridState::Res{};
     {
         CGridState::Prep &Q = CG.prep;
@@ -518,6 +522,43 @@ static int build_res_tables(const double *const *static23)
             if (!mine && sc >= 0) pub[sc] = 1;
         }
     }
+    // A neighbour's operands and state come from the cell the table names for the NEIGHBOURING POSITION; the one-launch kernels
+    // (and the reference) read the array neighbour of the position's own cell.  Inside the domain the two are the same cell or an
+    // image of it.  Outside a closed boundary they can be two different ghost cells (every block keeps its own): the kernel is
+    // only right if both hold the same values -- the static arrays are compared here, the loop's state at every upload.
+    {
+        std::vector<int2> pairs;
+        std::set<std::pair<int, int>> seen;
+        const int nxb = S.d.nx_block;
+        for (int w = 0; w < Q.ntiles && Q.images_ok; ++w)
+            for (int ty = 0; ty < RY; ++ty)
+                for (int tx = 0; tx < RX; ++tx) {
+                    const int a = tab[(size_t)w * NPOS + ty * (RX + 1) + tx];
+                    if (a < 0) continue;                  // a position outside the domain computes nothing
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if ((!dx && !dy) || tx + dx < 0 || ty + dy < 0) continue;
+                            const int c = tab[(size_t)w * NPOS + (ty + dy) * (RX + 1) + (tx + dx)];
+                            if (c >= 0) continue;         // inside the domain: the cell itself or an image of it
+                            const int b = a + dx + dy * nxb, g = -1 - c;
+                            if (b == g || !seen.insert({b, g}).second) continue;
+                            pairs.push_back(make_int2(b, g));
+                            for (int k : {CG_DXT, CG_DYT, CG_DXU, CG_DYU, CG_DXE, CG_DYE, CG_DXN, CG_DYN, CG_UAREA, CG_TAREA, CG_EAREA, CG_NAREA,
+                                          CG_EPM, CG_NPM, CG_UVM, CG_HM})
+                                if (std::memcmp(static23[k] + b, static23[k] + g, sizeof(double)) != 0) {
+                                    Q.images_ok = false;
+                                    Q.why = "static array " + std::to_string(k) + " differs between the ghost cells " + std::to_string(b) + " and " +
+                                            std::to_string(g) + " outside the domain";
+                                }
+                        }
+                }
+        if (!Q.images_ok) return 0;
+        Q.npairs = (int)pairs.size();
+        if (Q.npairs) {
+            HIPC(hipMalloc((void **)&Q.pairs, pairs.size() * sizeof(int2)));
+            HIPC(hipMemcpy(Q.pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice));
+        }
+    }
     HIPC(hipMalloc((void **)&Q.tab, tab.size() * sizeof(int)));
     HIPC(hipMalloc((void **)&Q.tiles, tiles.size() * sizeof(int32_t)));
     HIPC(hipMalloc((void **)&Q.pubmap, S.n));
@@ -546,6 +587,7 @@ static bool res_eligible(std::string *why = nullptr)
     if (S.prm.revp != 0.0) return no("revised EVP");     // (the kernel keeps revp * uvelE_init as the zero it is under classic EVP)
     if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
     if (!geo_derived()) return no("a start-up identity of the static arrays does not hold");
+    if (!Q.pairs_state_ok) return no("ghost cells outside the domain that the kernel treats as one position hold different state");
     if ((long)Q.ntiles > Q.cap) return no("more windows than can be resident at once");
     return true;
 }
@@ -780,6 +822,10 @@ int finish_upload(int32_t visc_method)
         fill(A);
         HIPC(hipMemsetAsync(CG.d_flags, 0, sizeof(unsigned), S.stream));
         evp_launch_cgrid_call_setup(A, CG.fac[0], CG.fac[1], CG.d_flags, S.stream);
+        if (CG.res.npairs) {
+            const double *five[5] = {CG.f[CF_UE], CG.f[CF_VN], CG.f[CF_SP], CG.f[CF_SM], CG.f[CF_S12U]};
+            evp_launch_cgrid_res_pair_check(five, CG.res.pairs, CG.res.npairs, CG.d_flags, S.stream);
+        }
         HIPC(hipMemcpyAsync(&h_flags, CG.d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
     }
     if (remote()) {                              // bit5 of ghost cells other ranks own
@@ -796,7 +842,8 @@ int finish_upload(int32_t visc_method)
     }
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(S.stream));       // the caller may change its arrays after this returns
-    CG.fast = h_flags == 0 && !(env_test("CICE_EVP_HIP_CGRID_FAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_FAST")));
+    CG.fast = (h_flags & 255u) == 0 && !(env_test("CICE_EVP_HIP_CGRID_FAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_FAST")));
+    CG.res.pairs_state_ok = (h_flags & 256u) == 0;
     CG.uploaded = true;
     CG.first = true;
     return 0;
