@@ -36,6 +36,13 @@
 
 #pragma clang fp contract(off)
 
+// per-phase cycle stamps exist in the TEST build's object of this file only (tools/cgres_phases.py)
+#ifdef CICE_EVP_HIP_TESTING
+#define CGRES_PROF(R) ((R).prof != nullptr)
+#else
+#define CGRES_PROF(R) false
+#endif
+
 namespace {
 
 constexpr int X = 16, Y = 16, LW = X + 1, NP = LW * (Y + 1);
@@ -273,39 +280,76 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const bool doT = compT || ghostT;
     const bool keepS12T = (own && compT) || ghostT;
 
-    // ---- ring: the positions of the velocity tile this window does not produce, one or two per thread ---------------
-    // entry e of the (Y+1) x (X+1) tile is polled if it lies outside the owned range and has a producer (not static);
+    // ---- ring: the positions of the velocity tile this window does not produce -- at most one per thread, dealt round-robin to
+    // the four waves (a thread with two entries polled them one after the other: two memory round trips on the critical path of
+    // every subcycle; tools/cgres_phases.py showed the wave that held them all waiting twice as long as the others).
+    // Entry e of the (Y+1) x (X+1) tile is polled if it lies outside the owned range and has a producer (not static);
     // (X, Y), the one entry no level reads, is left out
     auto ring_src = [&](int e) -> int {
-        if (e >= NP - 1) return -1;
         const int ex = e % LW, ey = e / LW;
         const int gi = tl.y - 2 + ex, gj = tl.z - 2 + ey;
         const bool mine = ex >= 2 && ex <= X - 2 && ey >= 2 && ey <= Y - 2 && gi <= q.y && gj <= q.w;
         const int sc = s_src[e];
         return (mine || sc < 0) ? -1 : sc;
     };
-    const int ring0 = ring_src(t), ring1 = ring_src(t + X * Y);
+    // All entries sit in wave 0, two per lane, both requested before either is looked at: ONE polling wave per workgroup.
+    // (Measured on gx1, tools/cgres_phases.py: the entries dealt round-robin to all four waves, one per thread -- every wave of
+    // every workgroup spinning -- 8.2 us per subcycle against 6.4 with most of them in one wave: the price of a poll sits in the
+    // consumer CU's memory queue, which the workgroups that still compute on that CU need for their own publishes.)
+    // A narrow window at a block's edge can have more than 128 entries: the rest goes to wave 1, then 2, 3 the same way.
+    int ring0 = -1, ring_e = 0, ring1 = -1, ring_e1 = 0;
+    {
+        const int r0 = (t >> 6) * 128 + (t & 63), r1 = r0 + 64;
+        int cnt = 0;
+        for (int e = 0; e < NP - 1; ++e) {
+            const int sc = ring_src(e);
+            if (sc < 0) continue;
+            if (cnt == r0) { ring0 = sc; ring_e = e; }
+            if (cnt == r1) { ring1 = sc; ring_e1 = e; }
+            ++cnt;
+        }
+    }
     auto give_up_note = [&](int k, int cell, unsigned seen, unsigned wanted) {
         if (atomicCAS(R.err, 0, 1) == 0) {
             R.err[1] = tile; R.err[2] = k; R.err[3] = cell; R.err[4] = (int)seen; R.err[5] = (int)wanted;
         }
     };
-    auto poll = [&](const v4u *rd, int cell, int e, unsigned want, int k) {
-        v4u ra, rb;
+    // both entries of a lane: four loads in flight, then the tags; an entry that has arrived is not requested again
+    auto poll2 = [&](const v4u *rd, unsigned want, int k) {
+        v4u ra, rb, rc, rd2;
+        bool need0 = ring0 >= 0, need1 = ring1 >= 0;
         unsigned spins = 0;
-        for (;;) {
-            ld_rec2(rd + 2 * (size_t)cell, ra, rb);
-            if (ra.x == want && ra.w == want && rb.x == want && rb.w == want) break;
+        while (need0 || need1) {
+            if (need0 && need1) {
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                             "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd2)
+                             : "v"(rd + 2 * (size_t)ring0), "v"(rd + 2 * (size_t)ring1)
+                             : "memory");
+            } else if (need0) {
+                ld_rec2(rd + 2 * (size_t)ring0, ra, rb);
+            } else {
+                ld_rec2(rd + 2 * (size_t)ring1, rc, rd2);
+            }
+            if (need0 && ra.x == want && ra.w == want && rb.x == want && rb.w == want) {
+                s_uE[ring_e] = unpack_rec(ra);
+                s_vN[ring_e] = unpack_rec(rb);
+                need0 = false;
+            }
+            if (need1 && rc.x == want && rc.w == want && rd2.x == want && rd2.w == want) {
+                s_uE[ring_e1] = unpack_rec(rc);
+                s_vN[ring_e1] = unpack_rec(rd2);
+                need1 = false;
+            }
+            if (!(need0 || need1)) break;
             ++spins;
             if (spins > R.spin_limit || ((spins & 255u) == 0 && __hip_atomic_load(R.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                give_up_note(k, cell, ra.x, want);
+                give_up_note(k, need0 ? ring0 : ring1, need0 ? ra.x : rc.x, want);
                 s_bad = 1;
                 return;
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (R.long_sleep) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
         }
-        s_uE[e] = unpack_rec(ra);
-        s_vN[e] = unpack_rec(rb);
     };
     // initial records (tag of subcycle 0) so that the neighbours' first poll finds them; also the proof that they are resident
     if (pub) st_rec2((v4u *)R.rec[R.par0 & 1] + 2 * L, pack_rec(s_uE[li], R.tag_base), pack_rec(s_vN[li], R.tag_base));
@@ -314,6 +358,17 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // One subcycle.  LAST (a compile-time constant: the loop body proper carries none of it) = the subcycle that ends the call, in
     // which the arrays nothing inside the loop reads are stored: shearU, deltaU, zetax2T, etax2T, etax2U, strintxE/yN, taubxE/yN.
     // Returns false when a wait gave up (every thread of the workgroup then leaves).
+    // (test build) shader cycles per phase, accumulated over the launch by one lane per wave:
+    // 0 poll | 1 barrier after it | 2 S | 3 barrier | 4 T | 5 barrier | 6 U + barrier | 7 C
+    const bool prof = CGRES_PROF(R);
+    unsigned long long pc0 = 0, pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (prof) pc0 = __builtin_readcyclecounter();
+#define CG_STAMP(q)                                                     \
+    if (prof) {                                                         \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        pacc[q] += now_ - pc0;                                          \
+        pc0 = now_;                                                     \
+    }
     auto subcycle = [&](auto LASTC, int k) -> bool {
         constexpr bool LAST = decltype(LASTC)::value;
         const unsigned want = R.tag_base + (unsigned)k;
@@ -323,10 +378,11 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // of their loads into registers -- which is exactly what they are in LDS to avoid)
         int lo = li, to = tli, oo = oi;
         asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo));
-        if (ring0 >= 0) poll(rd, ring0, t, want, k);
-        if (ring1 >= 0) poll(rd, ring1, t + X * Y, want, k);
+        if (ring0 >= 0 || ring1 >= 0) poll2(rd, want, k);
+        CG_STAMP(0)
         __syncthreads();
         if (s_bad) return false;
+        CG_STAMP(1)
 
         // ---- S ----
         double uNo = 0.0, vEo = 0.0;
@@ -375,7 +431,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 }
             }
         }
+        CG_STAMP(2)
         __syncthreads();
+        CG_STAMP(3)
 
         // ---- T ---- (at the thread's own position, or at the ghost position it serves)
         if (doT) {
@@ -398,7 +456,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 }
             }
         }
+        CG_STAMP(4)
         __syncthreads();
+        CG_STAMP(5)
 
         // ---- U ----
         double etaU = 0.0;
@@ -414,6 +474,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             }
         }
         __syncthreads();
+        CG_STAMP(6)
 
         // ---- C ----
         if (own) {
@@ -462,11 +523,18 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 if (m & 8u) { A.f[CF_STRY][L] = strinty; A.f[CF_TAUBY][L] = tauby; }
             }
         }
+        CG_STAMP(7)
         return true;
     };
     for (int k = 0; k < R.nsub - 1; ++k)
         if (!subcycle(std::false_type{}, k)) return;
     if (!subcycle(std::true_type{}, R.nsub - 1)) return;
+#undef CG_STAMP
+    if (prof && (t & 63) == 0) {
+        unsigned long long *o = R.prof + ((size_t)tile * 4 + (t >> 6)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = pacc[e];
+    }
 
     // ---- the state goes back (both ping-pong allocations: whichever schedule runs next finds it) -------------------
     if (R.dry) return;

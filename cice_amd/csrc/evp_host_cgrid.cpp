@@ -47,6 +47,7 @@ struct CGridState {
         uint8_t *pubmap = nullptr;
         void *rec = nullptr;         // 2 x S.n records of 32 bytes
         int *err = nullptr;
+        int *order = nullptr;        // A/B (test build): window run by workgroup w
         unsigned epoch = 0;
         int par = 0;
         bool images_ok = false;      // every ghost cell's static arrays equal its source's bit for bit
@@ -59,6 +60,7 @@ struct CGridState {
         long cap = 0;                // windows that can be resident at once (occupancy x CUs)
         double t_probe_ms = -1.0;    // probe: ms per subcycle
         int last_nsub = 0;           // subcycles of the last call that ran inside it
+        unsigned long long *prof = nullptr;   // test build: phase stamps (CICE_EVP_HIP_CGRID_PROF=1)
     } res;
     uint8_t *mask = nullptr;
     uint8_t *gmask = nullptr;    // the four land masks as bits (cg_one's derived view of the static table); null: an identity failed
@@ -111,7 +113,7 @@ void cgrid_free()
     F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
     CG.one = CGridState::One{};
-    F(CG.res.tab); F(CG.res.tiles); F(CG.res.pubmap); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs);
+    F(CG.res.tab); F(CG.res.tiles); F(CG.res.pubmap); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs); F(CG.res.prof); F(CG.res.order);
     CG.res = CGridState::Res{};
     {
         CGridState::Prep &Q = CG.prep;
@@ -597,6 +599,29 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     CGridState::Res &Q = CG.res;
     EvpCgRes R{};
     R.tab = Q.tab; R.tiles = Q.tiles; R.order = nullptr; R.ntiles = Q.ntiles;
+    R.long_sleep = env_test("CICE_EVP_HIP_CGRID_RES_SLEEP") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_SLEEP")) ? 1 : 0;
+    if (env_test("CICE_EVP_HIP_CGRID_RES_XCD") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_XCD"))) {
+        // A/B (test build): workgroup w runs on XCD w % 8 -- give each XCD one contiguous run of the (row-major) window list
+        if (!Q.order) {
+            std::vector<int> ord(Q.ntiles);
+            const int per = (Q.ntiles + 7) / 8;
+            std::vector<int> seq;
+            for (int x = 0; x < 8; ++x) for (int k = 0; k < per; ++k) if (x * per + k < Q.ntiles) seq.push_back(x * per + k);
+            // block w -> the (w >> 3)-th window of XCD (w & 7)'s run, where it exists; the rest fill up in order
+            std::vector<char> used(Q.ntiles, 0);
+            std::vector<int> left;
+            for (int w = 0; w < Q.ntiles; ++w) {
+                const int x = w & 7, k = w >> 3, cand = x * per + k;
+                if (k < per && cand < Q.ntiles && !used[cand]) { ord[w] = cand; used[cand] = 1; } else ord[w] = -1;
+            }
+            for (int c = 0; c < Q.ntiles; ++c) if (!used[c]) left.push_back(c);
+            size_t li = 0;
+            for (int w = 0; w < Q.ntiles; ++w) if (ord[w] < 0) ord[w] = left[li++];
+            HIPC(hipMalloc((void **)&Q.order, ord.size() * sizeof(int)));
+            HIPC(hipMemcpy(Q.order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        R.order = Q.order;
+    }
     R.nsub = nsub; R.dry = dry ? 1 : 0;
     Q.epoch = (Q.epoch + 1u) & 0xFFFFFu;
     if (Q.epoch == 0) Q.epoch = 1;
@@ -613,6 +638,9 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     R.s12_out[0] = cur5[4]; R.s12_out[1] = alt5[4];
     R.gbase = CG.gslab; R.inbase = CG.inslab; R.stride = S.n;
     R.gmask = CG.gmask;
+    if (!dry && !Q.prof && env_test("CICE_EVP_HIP_CGRID_PROF") && std::atoi(env_test("CICE_EVP_HIP_CGRID_PROF")))
+        HIPC(hipMalloc((void **)&Q.prof, (size_t)Q.ntiles * 32 * sizeof(unsigned long long)));
+    R.prof = dry ? nullptr : Q.prof;
     evp_launch_cgrid_res(A, R, S.stream);
     HIPC(hipGetLastError());
     Q.launched = true;
@@ -649,6 +677,10 @@ static int res_decide(const EvpCgrid &A)
         if (env("CICE_EVP_HIP_VERBOSE") && want != 0) std::fprintf(stderr, "[cice_evp_hip] C grid: on-chip resident kernel not used: %s\n", why.c_str());
         // (per-call conditions -- visc_method, the shortcuts -- may hold in a later call: stay undecided unless switched off)
         if (want == 0) Q.mode = 0;
+        return 0;
+    }
+    if (want == 1) {       // forced on: no probe launches (profiles see real launches only); a window that is not resident shows at the next sync
+        Q.mode = 1;
         return 0;
     }
     double *cur5[5] = {CG.f[CF_UE], CG.f[CF_VN], CG.f[CF_SP], CG.f[CF_SM], CG.f[CF_S12U]};
@@ -1245,6 +1277,15 @@ int cice_evp_hip_cgrid_fetch(int32_t table, int32_t index, double *dst)
 #ifdef CICE_EVP_HIP_TESTING
 // Phase stamps of the last cg_one launch (CICE_EVP_HIP_CGRID_PROF=1 at cice_evp_hip_cgrid_set_geometry): [windows][8] x u64.
 // Returns the number of windows, < 0 on error.
+int cice_evp_hip_debug_cgres_prof(uint64_t *out, int32_t ntiles_max)
+{
+    if (!S.ready || !CG.res.prof) return fail(-1, "no profiled resident C-grid launch (CICE_EVP_HIP_CGRID_PROF=1)");
+    if (!out || ntiles_max < CG.res.ntiles) return fail(-1, "bad argument: need room for %d windows", CG.res.ntiles);
+    HIPC(hipStreamSynchronize(S.stream));
+    HIPC(hipMemcpy(out, CG.res.prof, (size_t)CG.res.ntiles * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return CG.res.ntiles;
+}
+
 int cice_evp_hip_debug_cgrid_prof(uint64_t *out, int32_t ntiles_max)
 {
     if (!S.ready || !CG.one.prof) return fail(-1, "no profiled one-launch kernel (CICE_EVP_HIP_CGRID_PROF=1)");

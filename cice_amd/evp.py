@@ -54,7 +54,7 @@ EXPORTS = [
 # the test transport
 TEST_EXPORTS = [
     "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_cgrid_window_plan_ext", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
-    "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_debug_cgrid_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
+    "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_debug_cgrid_prof", "cice_evp_hip_debug_cgres_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
     "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan", "cice_evp_hip_stress_plan",
     "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags", "cice_evp_hip_fold_images_plan",
 ]
@@ -70,6 +70,7 @@ TEST_ENV = [
     # A/B switches of kernels and transports (forced tile shapes, schedules the default never picks, the ring exchange's other forms)
     "CICE_EVP_HIP_NO_OVERLAP", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_NOGRAPH", "CICE_EVP_HIP_GRAPH_RCCL", "CICE_EVP_HIP_RES_LOGW",
     "CICE_EVP_HIP_MARCH_EXT", "CICE_EVP_HIP_MARCH_DIRECT", "CICE_EVP_HIP_MARCH_OVERLAP", "CICE_EVP_HIP_CGRID_FUSED", "CICE_EVP_HIP_CGRID_GEO",
+    "CICE_EVP_HIP_CGRID_RES_SLEEP", "CICE_EVP_HIP_CGRID_RES_XCD",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -475,6 +476,14 @@ class EvpHip:
         _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(7)), "(dyn_evp_hip_cgrid_timings)")
         return dict(loop_ms=float(out[0]), nsub=int(out[1]), prep_ms=float(out[2]), one_launch_subcycles=int(out[3]),
                     geometry_derived=bool(out[4]), resident_subcycles=int(out[5]), resident_probe_ms=float(out[6]))
+
+    def debug_cgres_prof(self):
+        self._need_testing("debug_cgres_prof")
+        out = np.zeros((4096, 4, 8), dtype=np.uint64)
+        n = self.lib.cice_evp_hip_debug_cgres_prof(out.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(4096))
+        if n < 0:
+            _check(self.lib, n, "(debug_cgres_prof)")
+        return out[:n]
 
     def prep_fetch(self, name: str):
         out = np.zeros(self.shape)

@@ -64,6 +64,9 @@ int cice_evp_hip_debug_prof(uint64_t *out, int32_t ntiles_max);
  * shader-clock cycles at 0 start, 1 / 2 before / after the first workgroup barrier, 3 / 4 the second, 5 level C's arithmetic
  * done, 6 end; 7 = XCC id << 32 | HW_ID.  Returns the number of windows.  tools/cgrid_phases.py */
 int cice_evp_hip_debug_cgrid_prof(uint64_t *out, int32_t ntiles_max);
+/* The same for the on-chip resident C-grid kernel (cg_res): 32 values per window = 4 waves x 8 phases, shader cycles summed over the
+ * last launch: poll | barrier | S | barrier | T | barrier | U + barrier | C.  Returns the number of windows.                       */
+int cice_evp_hip_debug_cgres_prof(uint64_t *out, int32_t ntiles_max);
 /* Host-only: build the plan for `dims` without touching a device (CPU tests). */
 int cice_evp_hip_plan_build(const cice_evp_hip_dims *dims);
 int cice_evp_hip_halo_plan(int32_t *counts4, int32_t *local_dst, int32_t *local_src,

@@ -128,12 +128,12 @@ def main():
         res["kernels"][key] = entry
     # C-grid subcycle (tools/cgrid_timing.py): the three kernels of the fused schedule, duration and HBM-side bytes each
     CG = {"A_avg_strain": "cg_avg_strain", "B_stress_t": "cg_stress_t", "C_stress_u_step": "cg_stress_u_step"}
-    for key in ("cgx1", "cgs01", "cgx1one", "cgs01one"):
+    for key in ("cgx1", "cgs01", "cgx1one", "cgs01one", "cgx1res"):
         st = d / f"{key}_trace_kernel_stats.csv"
         if not st.exists():
             continue
         entry = {}
-        for tag, match in ({"one_launch": "cg_one"} if key.endswith("one") else CG).items():
+        for tag, match in ({"resident": "cg_res"} if key.endswith("res") else {"one_launch": "cg_one"} if key.endswith("one") else CG).items():
             e = {"kernel_trace": kernel_stats(st, match)}
             for p, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
                 f = d / f"{key}_{p}_counter_collection.csv"
@@ -149,6 +149,7 @@ def main():
                 if f.exists():
                     c, dur_us, kname = counters(f, match)
                     sq.update({k: v for k, (v, n) in c.items()})
+                    sq.update({k + "_launches": n for k, (v, n) in c.items()})
                     if p == "sq1":
                         sq["_pass_avg_us"] = dur_us
             if sq.get("SQ_WAVE_CYCLES"):
