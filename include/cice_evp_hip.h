@@ -315,7 +315,11 @@ int cice_evp_hip_cgrid_dyn_finish(double *strocnxN, double *strocnyN, double *st
  * [3] (n >= 4) = how many of those subcycles ran as one launch each (the default schedule on one rank without a fold),
  * [4] (n >= 5) = 1 if that kernel derives 15 of the 23 static arrays from the eight dx / dy arrays (allowed when
  * cice_evp_hip_cgrid_set_geometry found the reference's start-up identities to hold bit for bit; CICE_EVP_HIP_CGRID_GEO=0
- * keeps all 23 in use)  */
+ * keeps all 23 in use; in the test build only),
+ * [5] (n >= 6) subcycles of the last call that ran inside ONE launch of the on-chip resident kernel (evp_cgrid_res.hip: the state
+ * of a call in registers and LDS, face velocities traded between windows as tagged records; one rank, no fold, avg_zeta, classic
+ * EVP, default configuration, every window co-resident: domains up to ~130k cells; CICE_EVP_HIP_CGRID_RESIDENT=0 / 1 forbids /
+ * requires it), [6] (n >= 7) what its start-up probe measured per subcycle, ms (-1: no probe ran)  */
 int cice_evp_hip_cgrid_timings(double *out, int32_t n);
 
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */
