@@ -136,10 +136,16 @@ __device__ __forceinline__ void push1(const EvpCgrid &A, size_t c, double *f, do
 
 __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 {
-    __shared__ double s_uE[NP], s_vN[NP], s_ea[NP], s_na[NP], s_dyE[NP], s_dxN[NP], s_ua[NP], s_ta[NP];
-    __shared__ double s_sh[NP], s_eta[NP], s_sp[NP], s_sm[NP], s_s12[NP];
-    __shared__ double s_pc[16][13 * 13];   // per-call operands of the momentum step, by owned cell (read at level C only)
-    __shared__ int s_src[NP];
+    // planes a level reads one position beyond the window (velocities, the averaging weights, dyE / dxN for the boundary ratios):
+    // (Y+1) x (X+1); planes read inside the window only: Y x X, index = thread index
+    __shared__ double s_uE[NP], s_vN[NP], s_ea[NP], s_na[NP], s_dyE[NP], s_dxN[NP];
+    __shared__ double s_ua[X * Y], s_ta[X * Y], s_sh[X * Y], s_eta[X * Y], s_sp[X * Y], s_sm[X * Y], s_s12[X * Y];
+    // per-call operands of the momentum step, by owned cell (read at level C only): 0-5 uocnE vocnE facE emassdti fmE forcexE,
+    // 6-11 the same at N, 12-15 earear 1/dxE narear 1/dyN, 16-17 revp * uvelE_init, revp * vvelN_init.  The last two planes
+    // double as the table of source cells during the prologue (s_src: ints, read for the last time before they are filled)
+    __shared__ double s_pc[18][13 * 13];
+    int *const s_src = reinterpret_cast<int *>(&s_pc[16][0]);
+    static_assert(sizeof(double) * 2 * 13 * 13 >= sizeof(int) * NP, "s_src does not fit its alias");
     __shared__ uint8_t s_gm[NP];           // land masks of the position's cell: bit0 epm, 1 npm, 2 uvm, 3 hm
     __shared__ int s_bad;
 
@@ -167,8 +173,10 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         s_na[e] = G(CG_NAREA)[c];
         s_dyE[e] = G(CG_DYE)[c];
         s_dxN[e] = G(CG_DXN)[c];
-        s_ua[e] = G(CG_UAREA)[c];
-        s_ta[e] = G(CG_TAREA)[c];
+        if (e % LW < X && e / LW < Y) {
+            s_ua[(e / LW) * X + e % LW] = G(CG_UAREA)[c];
+            s_ta[(e / LW) * X + e % LW] = G(CG_TAREA)[c];
+        }
         s_gm[e] = R.gmask[c];
     }
     if (t == 0) s_bad = 0;
@@ -182,12 +190,12 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const bool compU = !stat && tx <= X - 2 && ty <= Y - 2;
     const bool pub = own && R.pubmap[L] != 0;
     // what a position that does not compute a level shows its neighbours: the array's value, unchanged through the loop
-    s_sh[li] = A.f[CF_SHEARU][L];
-    s_eta[li] = A.f[CF_ETA][L];
+    s_sh[t] = A.f[CF_SHEARU][L];
+    s_eta[t] = A.f[CF_ETA][L];
     double sp = R.sp_in[L], sm = R.sm_in[L], s12v = R.s12_in[L];
-    s_sp[li] = sp;
-    s_sm[li] = sm;
-    s_s12[li] = s12v;
+    s_sp[t] = sp;
+    s_sm[t] = sm;
+    s_s12[t] = s12v;
     double s12T = own ? A.f[CF_S12T][L] : 0.0;
     __syncthreads();
 
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const size_t cE = (size_t)(s_src[li + 1] < 0 ? -1 - s_src[li + 1] : s_src[li + 1]);
     const size_t cN = (size_t)(s_src[li + LW] < 0 ? -1 - s_src[li + LW] : s_src[li + LW]);
     // mb: bit 0 epm, 1 npm, 2 uvm of the cell; 3 npm of its east, 4 epm of its north neighbour; 5-8 hm of the cell, east, north,
-    // north-east; 9 / 10: sign of revp * uvelE_init / revp * vvelN_init (revp = 0 here: the product is a zero of that sign)
+    // north-east
     unsigned mb;
     {
         const unsigned gmo = s_gm[li], gme = s_gm[li + 1], gmn = s_gm[li + LW], gmne = s_gm[li + LW + 1];
@@ -213,15 +221,16 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     if (compT) {
         const double dxT = G(CG_DXT)[L], dyT = G(CG_DYT)[L];
         dxT2 = dxT * dxT; dyT2 = dyT * dyT;
-        uareaavgr = 1.0 / (s_ua[li] + s_ua[li - LW] + s_ua[li - LW - 1] + s_ua[li - 1]);
+        uareaavgr = 1.0 / (s_ua[t] + s_ua[t - X] + s_ua[t - X - 1] + s_ua[t - 1]);
         strength = IN(CI_STRENGTH)[L];
         DminT = G(CG_DMINT)[L];
     }
     double wtmpU = 0.0;
-    if (compU) wtmpU = (bit(5) * s_ta[li] + bit(6) * s_ta[li + 1] + bit(7) * s_ta[li + LW] + bit(8) * s_ta[li + LW + 1]);
+    if (compU) wtmpU = (bit(5) * s_ta[t] + bit(6) * s_ta[t + 1] + bit(7) * s_ta[t + X] + bit(8) * s_ta[t + X + 1]);
     double hdyEr = 0, dyT2e = 0, dxU2s = 0;
     double hdxNr = 0, dxT2n = 0, dyU2w = 0;
     const int oi = (ty - 2) * 13 + (tx - 2);         // owned cells only
+    double zE0 = 0.0, zN0 = 0.0;                     // revp * uvelE_init, revp * vvelN_init (stored once the source table is done with)
     if (own) {
         const size_t cS = (size_t)(s_src[li - LW] < 0 ? -1 - s_src[li - LW] : s_src[li - LW]);
         const size_t cW = (size_t)(s_src[li - 1] < 0 ? -1 - s_src[li - 1] : s_src[li - 1]);
@@ -237,9 +246,8 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         s_pc[4][oi] = IN(CI_FME)[L]; s_pc[5][oi] = IN(CI_FORCEXE)[L];
         s_pc[6][oi] = IN(CI_UOCNN)[L]; s_pc[7][oi] = IN(CI_VOCNN)[L]; s_pc[8][oi] = A.facN[L]; s_pc[9][oi] = IN(CI_NMASSDTI)[L];
         s_pc[10][oi] = IN(CI_FMN)[L]; s_pc[11][oi] = IN(CI_FORCEYN)[L];
-        const double zE = p.revp * IN(CI_UE_INIT)[L], zN = p.revp * IN(CI_VN_INIT)[L];
-        mb |= (__double_as_longlong(zE) < 0 ? 1u : 0u) << 9;
-        mb |= (__double_as_longlong(zN) < 0 ? 1u : 0u) << 10;
+        zE0 = p.revp * IN(CI_UE_INIT)[L];
+        zN0 = p.revp * IN(CI_VN_INIT)[L];
     }
     // The extra row / column of the reference's T list (ghost cells ihi+1, jhi+1: of what stressC_T computes there only stress12T
     // survives the exchange) is kept up by the window that owns the neighbouring interior cell -- by the threads of its column
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // row ty, thread (tx, 0) the one of row jhi+1 in column tx.  Such a thread runs level T like everybody else, at the ghost
     // position (tli), with the ghost cell's own strength, DminTarea and history; the planes hold the static operands of the
     // cell the position's value comes from, which equal the ghost cell's (cgres: images verified).
-    int tli = li;                  // the position level T is evaluated at
+    int tli = li, t6 = t;          // the position level T is evaluated at (index into the (X+1)- and the X-wide planes)
     bool ghostT = false;
     size_t g = 0;
     if ((tx == 0) != (ty == 0)) {
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                     if (A.mask[g] & 1u) {
                         ghostT = true;
                         tli = gy_ * LW + gx_;
+                        t6 = gy_ * X + gx_;
                     }
                 }
             }
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     if (ghostT) {
         const double dxT = G(CG_DXT)[g], dyT = G(CG_DYT)[g];
         dxT2 = dxT * dxT; dyT2 = dyT * dyT;
-        uareaavgr = 1.0 / (s_ua[tli] + s_ua[tli - LW] + s_ua[tli - LW - 1] + s_ua[tli - 1]);
+        uareaavgr = 1.0 / (s_ua[t6] + s_ua[t6 - X] + s_ua[t6 - X - 1] + s_ua[t6 - 1]);
         strength = IN(CI_STRENGTH)[g];
         DminT = G(CG_DMINT)[g];
         s12T = A.f[CF_S12T][g];
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             if (R.long_sleep) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
         }
     };
+    __syncthreads();               // (every thread has read the source table for the last time: its planes take their operands)
+    if (own) { s_pc[16][oi] = zE0; s_pc[17][oi] = zN0; }
     // initial records (tag of subcycle 0) so that the neighbours' first poll finds them; also the proof that they are resident
     if (pub) st_rec2((v4u *)R.rec[R.par0 & 1] + 2 * L, pack_rec(s_uE[li], R.tag_base), pack_rec(s_vN[li], R.tag_base));
     __syncthreads();
@@ -376,8 +387,8 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         v4u *wr = (v4u *)R.rec[((k + R.par0) & 1) ^ 1];
         // (the operand planes never change inside the loop: without an index the compiler cannot see through it hoists every one
         // of their loads into registers -- which is exactly what they are in LDS to avoid)
-        int lo = li, to = tli, oo = oi;
-        asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo));
+        int lo = li, to = tli, oo = oi, o6 = t, to6 = t6;
+        asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo), "+v"(o6), "+v"(to6));
         if (ring0 >= 0 || ring1 >= 0) poll2(rd, want, k);
         CG_STAMP(0)
         __syncthreads();
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;
                 const double vNij = vNo * npc + (npe - npc) * npe * rxNr * vNe;
                 const double sh = dxU * (uEijp1 - uEij) - uU * ddxE + dyU * (vNip1j - vNij) - vU * ddyN;
-                s_sh[li] = sh;
+                s_sh[t] = sh;
                 if (LAST && own) {       // deltaU is wanted once per call: the rest of strain_rates_U
                     const double uNe = avg4(uEo, eao, s_uE[li + 1], s_ea[lo + 1], uEn, ean, s_uE[li + LW + 1], s_ea[lo + LW + 1]) * npe;
                     const double vEn = avg4(vNo, nao, vNe, nae, s_vN[li + LW], s_na[lo + LW], s_vN[li + LW + 1], s_na[lo + LW + 1]) * epn;
@@ -438,13 +449,13 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // ---- T ---- (at the thread's own position, or at the ghost position it serves)
         if (doT) {
             const TOut r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2,
-                                    dyT2, s_ua[to], s_ua[to - LW], s_ua[to - LW - 1], s_ua[to - 1], uareaavgr, strength, DminT, s_sh[tli],
-                                    s_sh[tli - LW], s_sh[tli - LW - 1], s_sh[tli - 1], sp, sm, relax);
+                                    dyT2, s_ua[to6], s_ua[to6 - X], s_ua[to6 - X - 1], s_ua[to6 - 1], uareaavgr, strength, DminT, s_sh[t6],
+                                    s_sh[t6 - X], s_sh[t6 - X - 1], s_sh[t6 - 1], sp, sm, relax);
             if (compT) {
                 sp = r.sp; sm = r.sm;
-                s_eta[li] = r.etax2;
-                s_sp[li] = sp;
-                s_sm[li] = sm;
+                s_eta[t] = r.etax2;
+                s_sp[t] = sp;
+                s_sm[t] = sm;
             }
             if (keepS12T) s12T = (s12T * relax + p.arlx1i * 0.5 * r.etax2 * r.shearT) * p.denom1;
             if (LAST && own && compT && !R.dry) {
@@ -464,13 +475,13 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         double etaU = 0.0;
         if (compU) {
             const double e2 = wtmpU == 0.0 ? 0.0
-                                           : (bit(5) * s_eta[li] * s_ta[lo] + bit(6) * s_eta[li + 1] * s_ta[lo + 1] + bit(7) * s_eta[li + LW] * s_ta[lo + LW] +
-                                              bit(8) * s_eta[li + LW + 1] * s_ta[lo + LW + 1]) / wtmpU;
+                                           : (bit(5) * s_eta[t] * s_ta[o6] + bit(6) * s_eta[t + 1] * s_ta[o6 + 1] + bit(7) * s_eta[t + X] * s_ta[o6 + X] +
+                                              bit(8) * s_eta[t + X + 1] * s_ta[o6 + X + 1]) / wtmpU;
             etaU = e2;
-            const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * s_sh[li]) * p.denom1;
+            const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * s_sh[t]) * p.denom1;
             if (m & 2u) {
                 s12v = upd;
-                s_s12[li] = upd;
+                s_s12[t] = upd;
             }
         }
         __syncthreads();
@@ -478,13 +489,13 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 
         // ---- C ----
         if (own) {
-            const double s12c = s12v, s12s = s_s12[li - LW], s12w = s_s12[li - 1];
+            const double s12c = s12v, s12s = s_s12[t - X], s12w = s_s12[t - 1];
             const double spc = sp, smc = sm;
-            const double spe = s_sp[li + 1], sme = s_sm[li + 1], spn = s_sp[li + LW], smn = s_sm[li + LW];
+            const double spe = s_sp[t + 1], sme = s_sm[t + 1], spn = s_sp[t + X], smn = s_sm[t + X];
             double unew, vnew, strintx, strinty, taubx, tauby;
             {
                 const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
-                const double zE = (mb >> 9) & 1u ? -0.0 : 0.0;         // revp * uvelE_init
+                const double zE = s_pc[16][oo];                        // revp * uvelE_init
                 strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + hdyEr * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
                 const double uold = uEo, vold = vEo;
                 const double du = uocnE - uold, dv = vocnE - vold;
@@ -499,7 +510,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             }
             {
                 const double uocnN = s_pc[6][oo], vocnN = s_pc[7][oo], facN = s_pc[8][oo], massN = s_pc[9][oo], fmN = s_pc[10][oo], forceyN = s_pc[11][oo];
-                const double zN = (mb >> 10) & 1u ? -0.0 : 0.0;        // revp * vvelN_init
+                const double zN = s_pc[17][oo];                        // revp * vvelN_init
                 strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
                 const double uold = uNo, vold = vNo;
                 const double du = uocnN - uold, dv = vocnN - vold;

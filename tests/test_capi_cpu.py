@@ -378,5 +378,7 @@ def test_tracked_pmc_summary_feeds_the_bench_line():
         assert key in k, f"{files[-1].name}: no entry for {key}"
         assert k[key].get("hbm_bytes_per_launch") and k[key].get("valu_busy_simd_cycles_per_launch"), key
         assert k[key]["kernel_trace"]["avg_us"] > 0
-    for key in ("cgx1", "cgs01"):
-        assert k[key]["per_subcycle"]["hbm_bytes"]
+    # C grid: the kernels the bench line's cgrid block runs by default (round 5: the on-chip resident kernel on gx1, one launch
+    # per subcycle on 3600 x 2400)
+    for key in ("cgx1res", "cgs01one"):
+        assert k[key]["per_subcycle"]["hbm_bytes"], key

@@ -826,6 +826,43 @@ def reference_cgrid_case(tmp_path, nx, ny, bs, ew, ns, **kw):
         common.GOLDEN = old
 
 
+@pytest.mark.parametrize("bs", [(320, 384), (160, 192)])
+def test_cgrid_gx1_size_vs_reference_harness(tmp_path, bs, monkeypatch):
+    """The C-grid loop at BASELINE's gx1 size (320 x 384, ndte = 120) against the reference ITSELF: operands captured from,
+    outputs compared with, the reference's own evp() with grid_ice = 'C' (unmodified sources, strict build) run here on the
+    box, as one block and as 2 x 2 blocks.  Every schedule that can run this grid: the default (the on-chip resident kernel
+    cg_res where it is eligible: all subcycles of a call but the first in one launch), forced one launch per subcycle (cg_one),
+    forced three launches -- bit-identical on all 19 arrays, ghost cells included, after 120 subcycles and after 7."""
+    c = reference_cgrid_case(tmp_path, 320, 384, bs, "cyclic", "closed", icecase="full", nsub_list=[7, 120], ncalls=1, h_ndte=120)
+    dom = c.oracle_domain()
+    state, inputs, masks = c.cgrid_inputs(1)
+    assert (masks["iceTmask"] != 0).sum() > 80000
+    ran_resident = False
+    for what, envs in (("default", {}), ("one launch per subcycle", {"CICE_EVP_HIP_CGRID_RESIDENT": "0"}),
+                       ("three launches", {"CICE_EVP_HIP_CGRID_RESIDENT": "0", "CICE_EVP_HIP_CGRID_ONE": "0"})):
+        for k in ("CICE_EVP_HIP_CGRID_RESIDENT", "CICE_EVP_HIP_CGRID_ONE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        core = cgrid_core(c)
+        try:
+            for nsub in (120, 7):
+                out = core.cgrid_run(nsub, state, inputs, masks, visc_method=str(c.d["visc_method"]))
+                oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
+                oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
+                assert_bitwise(out, c.cgrid_expected(1, nsub), f"gx1-size C grid {bs} {what} nsub {nsub} vs the reference")
+                t = core.cgrid_timings()
+                if what == "default":
+                    ran_resident = ran_resident or t["resident_subcycles"] == nsub - 1
+                else:
+                    assert t["resident_subcycles"] == 0
+        finally:
+            core.finalize()
+    assert np.abs(out["uvelE"]).max() > 1e-3
+    if bs == (320, 384):
+        assert ran_resident, "one block of 320 x 384 on one rank is what the resident kernel is for"
+
+
 @pytest.mark.parametrize("seed", list(range(501, 509)) + list(range(901, 909)) + [int(s) for s in __import__("os").environ.get("CGRID_REF_SWEEP_SEEDS", "").split() if s])
 def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", str(seed % 3))      # all three windows of the one-launch kernel (32x8, 64x8, 64x16)
