@@ -636,12 +636,36 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
     const long plane = (long)nxb * nyb;
     std::vector<int> owner((size_t)plane * d.nblocks, -1);
     for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
-    auto canon = [&](long c) -> long {
-        const int b = (int)(c / plane);
-        const long r = c % plane;
-        const int j = (int)(r / nxb) + 1, i = (int)(r % nxb) + 1;
-        if (i >= d.ilo[b] && i <= d.ihi[b] && j >= d.jlo[b] && j <= d.jhi[b]) return c;
-        return owner[c] >= 0 ? (long)owner[c] : -1 - c;
+    auto interior = [&](int b, int i, int j) { return i >= d.ilo[b] && i <= d.ihi[b] && j >= d.jlo[b] && j <= d.jhi[b]; };
+    // The cell a position's value comes from: start at the nearest interior cell of the window's block and walk, x first, then
+    // y, one array cell at a time.  Stepping onto a ghost cell that mirrors an interior cell continues FROM that interior cell
+    // (through periodic boundaries and into other blocks); a ghost cell nothing is copied into (closed boundary, eliminated
+    // neighbour) is an array cell like any other and the walk goes on through it while it stays inside the block's array --
+    // so a position outside the domain names the ghost cell that IS the array neighbour of the cells next to it (a position
+    // reached through a periodic wrap used to name the block's own corner ghost cell instead: the same "outside", but not the
+    // cell the reference reads there, and its static arrays need not agree -- round 5, the on-chip resident C-grid kernel).
+    auto walk = [&](int b, int i, int j, int ti, int tj) -> long {     // from interior (b, i, j) by (ti, tj) steps
+        bool stat = false;
+        auto step = [&](int di, int dj) {
+            const int ni = i + di, nj = j + dj;
+            if (ni < 1 || ni > nxb || nj < 1 || nj > nyb) return;      // (beyond the array: stay -- two steps outside a closed boundary)
+            i = ni; j = nj;
+            if (interior(b, i, j)) { stat = false; return; }
+            const long c = (long)b * plane + (long)(j - 1) * nxb + (i - 1);
+            if (owner[c] >= 0) {
+                const long o = owner[c];
+                b = (int)(o / plane);
+                j = (int)((o % plane) / nxb) + 1;
+                i = (int)((o % plane) % nxb) + 1;
+                stat = false;
+            } else {
+                stat = true;
+            }
+        };
+        for (; ti != 0; ti -= (ti > 0 ? 1 : -1)) step(ti > 0 ? 1 : -1, 0);
+        for (; tj != 0; tj -= (tj > 0 ? 1 : -1)) step(0, tj > 0 ? 1 : -1);
+        const long c = (long)b * plane + (long)(j - 1) * nxb + (i - 1);
+        return stat ? -1 - c : c;
     };
     tiles.clear();
     tab.clear();
@@ -656,11 +680,9 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
                     for (int ty = 0; ty < OY + extra; ++ty)
                         for (int tx = 0; tx < OX + extra; ++tx) {
                             const int i = (int)i0 - 2 + tx, j = j0 - 2 + ty;
-                            const int ic = std::min(std::max(i, d.ilo[b] - 1), d.ihi[b] + 1);
-                            const int jc = std::min(std::max(j, d.jlo[b] - 1), d.jhi[b] + 1);
-                            long r = canon((long)b * plane + (long)(jc - 1) * nxb + (ic - 1));
-                            for (int dx = i - ic; dx != 0 && r >= 0; dx -= (dx > 0 ? 1 : -1)) r = canon(r + (dx > 0 ? 1 : -1));
-                            for (int dy = j - jc; dy != 0 && r >= 0; dy -= (dy > 0 ? 1 : -1)) r = canon(r + (dy > 0 ? nxb : -nxb));
+                            const int ic = std::min(std::max(i, d.ilo[b]), d.ihi[b]);
+                            const int jc = std::min(std::max(j, d.jlo[b]), d.jhi[b]);
+                            const long r = walk(b, ic, jc, i - ic, j - jc);
                             tab.push_back((int32_t)r);
                             regular = regular && i >= 1 && i <= nxb && j >= 1 && j <= nyb &&
                                       r == (long)b * plane + (long)(j - 1) * nxb + (i - 1);
