@@ -39,8 +39,10 @@
 // per-phase cycle stamps exist in the TEST build's object of this file only (tools/cgres_phases.py)
 #ifdef CICE_EVP_HIP_TESTING
 #define CGRES_PROF(R) ((R).prof != nullptr)
+#define CGRES_DBG(R) ((R).dbg)
 #else
 #define CGRES_PROF(R) false
+#define CGRES_DBG(R) 0
 #endif
 
 namespace {
@@ -153,6 +155,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const int tx = t & (X - 1), ty = t / X;
     const int li = ty * LW + tx;
     const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
+    // test hooks (test build only; CICE_EVP_HIP_CGRID_RES_DEBUG): 8 = every fourth window lags 10 us per subcycle (the results must not
+    // change), 16 = window 1 never shows up in a real launch (every wait on its records gives up: the caller must hear about it)
+    if ((CGRES_DBG(R) & 16) && tile == 1 && !R.dry) return;
     const int4 tl = R.tiles[tile];
     const int4 q = A.blk[tl.x];
     const int i = tl.y - 2 + tx, j = tl.z - 2 + ty;
@@ -389,6 +394,10 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // of their loads into registers -- which is exactly what they are in LDS to avoid)
         int lo = li, to = tli, oo = oi, o6 = t, to6 = t6;
         asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo), "+v"(o6), "+v"(to6));
+        if ((CGRES_DBG(R) & 8) && (tile & 3) == 1) {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(8);
+        }
         if (ring0 >= 0 || ring1 >= 0) poll2(rd, want, k);
         CG_STAMP(0)
         __syncthreads();

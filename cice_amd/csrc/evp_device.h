@@ -404,6 +404,7 @@ struct EvpCgRes {
     const uint8_t *gmask;         // the four land masks as bits (derive_geometry_check passed: required)
     unsigned long long *prof;     // test build, CICE_EVP_HIP_CGRID_PROF=1: [ntiles][4 waves][8] cycles per phase (tools/cgres_phases.py)
     int long_sleep;               // A/B (test build): 512 instead of 64 cycles between two looks at a record
+    int dbg;                      // test hooks (test build): 8 every fourth window lags, 16 window 1 never runs (real launches)
 };
 int evp_cgrid_res_max_blocks_per_cu();
 void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pairs, int n, unsigned *flags, hipStream_t st);

@@ -60,6 +60,7 @@ struct CGridState {
         long cap = 0;                // windows that can be resident at once (occupancy x CUs)
         double t_probe_ms = -1.0;    // probe: ms per subcycle
         int last_nsub = 0;           // subcycles of the last call that ran inside it
+        int fallbacks = 0;           // cice_evp_hip_cgrid_run calls repeated without it after a wait gave up
         unsigned long long *prof = nullptr;   // test build: phase stamps (CICE_EVP_HIP_CGRID_PROF=1)
     } res;
     uint8_t *mask = nullptr;
@@ -599,6 +600,7 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     EvpCgRes R{};
     R.tab = Q.tab; R.tiles = Q.tiles; R.order = nullptr; R.ntiles = Q.ntiles;
     R.long_sleep = env_test("CICE_EVP_HIP_CGRID_RES_SLEEP") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_SLEEP")) ? 1 : 0;
+    R.dbg = env_test("CICE_EVP_HIP_CGRID_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_DEBUG")) : 0;
     if (env_test("CICE_EVP_HIP_CGRID_RES_XCD") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_XCD"))) {
         // A/B (test build): workgroup w runs on XCD w % 8 -- give each XCD one contiguous run of the (row-major) window list
         if (!Q.order) {
@@ -627,7 +629,7 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     R.tag_base = Q.epoch << 12;
     R.par0 = Q.par;
     Q.par ^= (nsub & 1);
-    R.spin_limit = 4000000u;
+    R.spin_limit = (R.dbg & 16) ? 200000u : 4000000u;       // (the fault test need not wait seconds for the bound)
     R.err = Q.err;
     R.pubmap = Q.pubmap;
     R.rec[0] = Q.rec; R.rec[1] = (char *)Q.rec + (size_t)S.n * 32;
@@ -941,6 +943,10 @@ int cice_evp_hip_cgrid_download(double *const *fields19)
 {
     if (!CG.uploaded) return fail(-1, "C-grid EVP: nothing uploaded");
     if (!fields19) return fail(-1, "null argument");
+    if (CG.res.launched) {       // a resident launch whose waits gave up has written nothing back: the caller's arrays stay untouched
+        HIPC(hipStreamSynchronize(S.stream));
+        if (int rc = res_check_error()) return rc;
+    }
     CopyBatch B;
     for (int k = 0; k < CG_NF; ++k)
         if (fields19[k]) B.items.push_back({fields19[k], CG.f[k]});
@@ -948,7 +954,7 @@ int cice_evp_hip_cgrid_download(double *const *fields19)
     HIPC(hipStreamSynchronize(S.stream));
     float ms = 0;
     if (CG.t_nsub && hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) CG.t_loop_ms = ms;
-    return res_check_error();
+    return 0;
 }
 
 // deformationsC_T (ice_dyn_shared.F90:1968-2074; evp() calls it right after the C-grid loop, ice_dyn_evp.F90:1106-1119) on
@@ -1026,7 +1032,19 @@ int cice_evp_hip_cgrid_run(int32_t ndte, int32_t visc_method, double *const *fie
 {
     if (cice_evp_hip_cgrid_upload(fields19, inputs23, iceTmask, iceUmask, iceEmask, iceNmask, visc_method)) return -1;
     if (cice_evp_hip_cgrid_subcycle(ndte)) return -1;
-    return cice_evp_hip_cgrid_download(fields19);
+    const int rc = cice_evp_hip_cgrid_download(fields19);
+    if (rc == -7) {
+        // The on-chip resident kernel gave up (a window was not resident: the GPU is not this rank's alone).  Its waits are
+        // bounded, a launch that gives up writes nothing back and the download has not touched the caller's arrays: the call
+        // is repeated from them with the per-subcycle kernels, which later calls use too (the verdict is kept).
+        ++CG.res.fallbacks;
+        if (env("CICE_EVP_HIP_VERBOSE")) std::fprintf(stderr, "[cice_evp_hip] C grid: %s -- repeating the call without the resident kernel\n", g_err.c_str());
+        g_err.clear();
+        if (cice_evp_hip_cgrid_upload(fields19, inputs23, iceTmask, iceUmask, iceEmask, iceNmask, visc_method)) return -1;
+        if (cice_evp_hip_cgrid_subcycle(ndte)) return -1;
+        return cice_evp_hip_cgrid_download(fields19);
+    }
+    return rc;
 }
 
 // ---- the preparation phase on the device (SURVEY 8 f-2 for grid_ice = 'C'; kernels: evp_prep.hip prep1 / halo_center,
@@ -1305,6 +1323,7 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     if (n >= 5) out[4] = geo_derived() ? 1.0 : 0.0;   // ... with 15 of the 23 static arrays derived in the kernel
     if (n >= 6) out[5] = (double)CG.res.last_nsub;    // subcycles of the last call inside ONE launch of the on-chip resident kernel
     if (n >= 7) out[6] = CG.res.t_probe_ms;           // ... and what its probe measured per subcycle, ms (-1: no probe ran)
+    if (n >= 8) out[7] = (double)CG.res.fallbacks;    // cice_evp_hip_cgrid_run calls repeated without it after one of its waits gave up
     return 0;
 }
 

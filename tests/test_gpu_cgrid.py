@@ -148,6 +148,52 @@ def test_cgrid_resident_kernel_bitwise(monkeypatch):
     assert len(set(ran)) >= 1, (ran, refused)
 
 
+@pytest.mark.parametrize("case", ["caps", "full"])
+def test_cgrid_resident_kernel_survives_lagging_windows(case, monkeypatch):
+    """The two-buffer record scheme of the resident C-grid kernel must not depend on windows keeping pace by luck: with every
+    fourth window delayed by 10 us per subcycle (test build, CICE_EVP_HIP_CGRID_RES_DEBUG=8) -- next to open water in the 'caps'
+    case -- the result is still the oracle's, bit for bit, and no wait gives up.  Revised EVP rides along in the 'full' case."""
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_RES_DEBUG", "8")
+    dc, g, static, state, inputs, masks = synth_cgrid("gx3", case=case, seed=23)
+    got, want = run_both(dc, g, static, state, inputs, masks, 40, scal_kw=(dict(revised_evp=True) if case == "full" else None))
+    assert_bitwise(got, want, f"C grid, resident kernel with lagging windows, {case}")
+    assert np.abs(want["uvelE"]).max() > 1e-4
+
+
+def test_cgrid_run_recovers_when_a_window_is_not_resident(monkeypatch):
+    """cice_evp_hip_cgrid_run on a GPU that is not the rank's alone: one window of the resident kernel never shows up (test
+    hook, real launches only), the waits on its records give up (bounded), nothing is written back, the download leaves the
+    caller's arrays alone -- the call is repeated with the per-subcycle kernels and returns the oracle's answer; later calls
+    stay off the resident kernel."""
+    from cice_amd import synth
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_RES_DEBUG", "16")
+    dc, g, static, state, inputs, masks = synth_cgrid("gx3", case="full", seed=29)
+    scal = synth.evp_scalars(120)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    want = oracle.cgrid_subcycle(dom, prm, 24, state, inputs, static, masks, visc_method="avg_zeta")
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        got = core.cgrid_run(24, state, inputs, masks)
+        t = core.cgrid_timings()
+        assert t["resident_fallbacks"] == 1 and t["resident_subcycles"] == 0, t
+        assert_bitwise(got, want, "C grid after the fall-back")
+        got = core.cgrid_run(24, state, inputs, masks)
+        t = core.cgrid_timings()
+        assert t["resident_fallbacks"] == 1 and t["resident_subcycles"] == 0, t
+        assert_bitwise(got, want, "C grid, next call")
+    finally:
+        core.finalize()
+
+
 def test_cgrid_split_calls_equal_one_call():
     """upload / subcycle(a) / subcycle(b) / download == run(a + b): the resident state carries over, and the
     one-off zero fill of the first subcycle is not repeated."""
