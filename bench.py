@@ -844,7 +844,7 @@ def main():
         return res
 
     ndte = a.ndte or {"gx3": 120, "gx1": 120, "s01": 480}[a.workload]
-    M = measure_with_fallbacks(a.workload, a.case, ndte, a.steps, a.warmup, median_calls=(10 if a.gpus == 1 else 0))
+    M = measure_with_fallbacks(a.workload, a.case, ndte, a.steps, a.warmup, median_calls=(10 if (a.gpus == 1 and a.workload != "s01") else 0))
     nx, ny, dc, tm, n_active, dt, tm_ev, kt = (M[k] for k in ("nx", "ny", "dc", "tm", "n_active", "dt", "tm_ev", "kt"))
     # extras must never cost the primary line: a failure is reported inside the JSON instead
     M2 = M3 = MS = None

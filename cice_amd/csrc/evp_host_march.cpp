@@ -151,7 +151,9 @@ static bool march_geometry(std::string &why)
     if (seglen <= 0) {
         // (medium domains, 0.45M .. 1M cells: shorter segments keep the count near 1000 -- 1080 x 720: 14-row segments 39 us
         // per subcycle against 53 for the one-subcycle kernel; each segment recomputes ~3.5 rows of warm-up)
-        const int want_seg = std::max(1, 1000 / M.nstrips);
+        // (as many segments as fit 1024 waves: 3600 x 2400 has 60 strips -- 17 segments = 1020 waves = 255 workgroups, one per CU,
+        // 302.8 us per subcycle; 16 segments (960 waves, 16 CUs idle) 310.1; 18 (1080: some SIMDs get two) 472 -- round 5, same box)
+        const int want_seg = std::max(1, 1024 / M.nstrips);
         seglen = std::max(6, (G.nyr + want_seg - 1) / want_seg);
     }
     M.seglen = std::min(seglen, G.nyr);
@@ -453,6 +455,17 @@ static int march_exchange(double *buf, double *buf2, int nf)
 {
     if (PL.peers.empty()) return 0;
     State::March &M = S.march;
+#ifndef CICE_EVP_HIP_TESTING
+    // Product build: the ring goes through RCCL send / recv; its direct-store form is a switch of the test build (until a
+    // multi-GPU node has ranked the two), so there is nothing to vote on -- and no collective that a rank without ring
+    // neighbours would miss.
+    M.direct = 0;
+    M.direct_why = "test build only";
+#else
+    // Test build.  The switch is read at every state exchange and a change re-opens the set-up, which is COLLECTIVE over the
+    // ranks that have ring neighbours (blobs, a vote): every such rank must see the same value at the same exchange -- the
+    // tests and bench.py's ring_variants set it in all processes alike.  Mutually exclusive with CICE_EVP_HIP_MARCH_OVERLAP
+    // (the overlapped path ignores it).
     if (nf == EVP_MARCH_S_NF) {
         const int asked = (env_test("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env_test("CICE_EVP_HIP_MARCH_DIRECT"))) ? 1 : 0;
         if (M.direct >= 0 && asked != M.direct_asked) {       // (bench.py times one state both ways: the switch changed between two calls)
@@ -468,6 +481,7 @@ static int march_exchange(double *buf, double *buf2, int nf)
         if (M.direct < 0)
             if (int rc = march_direct_setup()) return rc;
     }
+#endif
     if (nf == EVP_MARCH_S_NF && M.direct == 1) {
         const unsigned seq = ++B.dx_seq;
         evp_launch_march_pack_direct(buf, nf, B.send_pos, PL.n_send, B.cut_send, B.dx, seq, S.stream);
