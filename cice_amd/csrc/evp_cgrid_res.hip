@@ -136,6 +136,10 @@ __device__ __forceinline__ void push1(const EvpCgrid &A, size_t c, double *f, do
     }
 }
 
+// AVGS: visc_method = 'avg_strength' -- the corner viscosities come from the T -> U average of the strength (A.strengthU, once
+// per call) and the corner's own Delta (ice_dyn_evp.F90:992-996), so level S works out the whole of strain_rates_U in every
+// subcycle and hands deltaU to level U through the plane etax2T travels in otherwise.
+template <bool AVGS>
 __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 {
     // planes a level reads one position beyond the window (velocities, the averaging weights, dyE / dxN for the boundary ratios):
@@ -230,8 +234,11 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         strength = IN(CI_STRENGTH)[L];
         DminT = G(CG_DMINT)[L];
     }
-    double wtmpU = 0.0;
-    if (compU) wtmpU = (bit(5) * s_ta[t] + bit(6) * s_ta[t + 1] + bit(7) * s_ta[t + X] + bit(8) * s_ta[t + X + 1]);
+    double wtmpU = 0.0, strU = 0.0;      // avg_zeta: the sum of the weights of the T -> U average; AVGS: DminUarea, strengthU
+    if (compU) {
+        if (AVGS) { wtmpU = A.deltaminEVP * G(CG_UAREA)[L]; strU = A.strengthU[L]; }
+        else wtmpU = (bit(5) * s_ta[t] + bit(6) * s_ta[t + 1] + bit(7) * s_ta[t + X] + bit(8) * s_ta[t + X + 1]);
+    }
     double hdyEr = 0, dyT2e = 0, dxU2s = 0;
     double hdxNr = 0, dxT2n = 0, dyU2w = 0;
     const int oi = (ty - 2) * 13 + (tx - 2);         // owned cells only
@@ -407,11 +414,13 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // ---- S ----
         double uNo = 0.0, vEo = 0.0;
         const double uEo = s_uE[li], vNo = s_vN[li];
+        // AVGS: deltaU in every subcycle, at every corner level U evaluates (its own uvelN / vvelE need the west / south neighbour)
+        const bool fullS = AVGS ? (compS && tx >= 1 && ty >= 1) : (LAST && own);
         if (compS || own) {
             const double epc = bit(0), npc = bit(1), npe = bit(3), epn = bit(4);
             const double uEn = s_uE[li + LW], vNe = s_vN[li + 1];
             const double eao = s_ea[lo], ean = s_ea[lo + LW], nao = s_na[lo], nae = s_na[lo + 1];
-            if (own) {
+            if (own || (AVGS && fullS)) {
                 uNo = avg4(s_uE[li - 1], s_ea[lo - 1], uEo, eao, s_uE[li + LW - 1], s_ea[lo + LW - 1], uEn, ean) * npc;
                 vEo = avg4(s_vN[li - LW], s_na[lo - LW], s_vN[li - LW + 1], s_na[lo - LW + 1], vNo, nao, vNe, nae) * epc;
             }
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double vNij = vNo * npc + (npe - npc) * npe * rxNr * vNe;
                 const double sh = dxU * (uEijp1 - uEij) - uU * ddxE + dyU * (vNip1j - vNij) - vU * ddyN;
                 s_sh[t] = sh;
-                if (LAST && own) {       // deltaU is wanted once per call: the rest of strain_rates_U
+                if (fullS) {             // deltaU is wanted (avg_zeta: once per call, for the caller): the rest of strain_rates_U
                     const double uNe = avg4(uEo, eao, s_uE[li + 1], s_ea[lo + 1], uEn, ean, s_uE[li + LW + 1], s_ea[lo + LW + 1]) * npe;
                     const double vEn = avg4(vNo, nao, vNe, nae, s_vN[li + LW], s_na[lo + LW], s_vN[li + LW + 1], s_na[lo + LW + 1]) * epn;
                     const double uNip1j = uNe * npe + (npc - npe) * npc * rxN * uNo;
@@ -443,7 +452,8 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                     const double dv = dyU * (uNip1j - uNij) + uU * ddyN + dxU * (vEijp1 - vEij) + vU * ddxE;
                     const double tn = dyU * (uNip1j - uNij) - uU * ddyN - dxU * (vEijp1 - vEij) + vU * ddxE;
                     const double delta = sqrt(dv * dv + p.e_factor * (tn * tn + sh * sh));
-                    if (!R.dry) {
+                    if (AVGS) s_eta[t] = delta;
+                    if (LAST && own && !R.dry) {
                         A.f[CF_SHEARU][L] = sh;
                         A.f[CF_DELTAU][L] = delta;
                         if (m & 16u) push1(A, L, A.f[CF_SHEARU], sh);
@@ -462,7 +472,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                                     s_sh[t6 - X], s_sh[t6 - X - 1], s_sh[t6 - 1], sp, sm, relax);
             if (compT) {
                 sp = r.sp; sm = r.sm;
-                s_eta[t] = r.etax2;
+                if (!AVGS) s_eta[t] = r.etax2;       // (AVGS: the plane holds deltaU, level U does not read etax2T)
                 s_sp[t] = sp;
                 s_sm[t] = sm;
             }
@@ -483,9 +493,15 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // ---- U ----
         double etaU = 0.0;
         if (compU) {
-            const double e2 = wtmpU == 0.0 ? 0.0
-                                           : (bit(5) * s_eta[t] * s_ta[o6] + bit(6) * s_eta[t + 1] * s_ta[o6 + 1] + bit(7) * s_eta[t + X] * s_ta[o6 + X] +
-                                              bit(8) * s_eta[t + X + 1] * s_ta[o6 + X + 1]) / wtmpU;
+            double e2;
+            if (AVGS) {
+                double z, rp;
+                visc_replpress(p, strU, wtmpU, s_eta[t], z, e2, rp);
+            } else {
+                e2 = wtmpU == 0.0 ? 0.0
+                                  : (bit(5) * s_eta[t] * s_ta[o6] + bit(6) * s_eta[t + 1] * s_ta[o6 + 1] + bit(7) * s_eta[t + X] * s_ta[o6 + X] +
+                                     bit(8) * s_eta[t + X + 1] * s_ta[o6 + X + 1]) / wtmpU;
+            }
             etaU = e2;
             const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * s_sh[t]) * p.denom1;
             if (m & 2u) {
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             s_vN[li] = vout;
             if (pub) st_rec2(wr + 2 * L, pack_rec(uout, want + 1u), pack_rec(vout, want + 1u));
             if (LAST && !R.dry) {
-                A.f[CF_ETAU][L] = etaU;
+                if (!AVGS) A.f[CF_ETAU][L] = etaU;      // (avg_strength: the reference never stores etax2U)
                 if (m & 4u) { A.f[CF_STRX][L] = strintx; A.f[CF_TAUBX][L] = taubx; }
                 if (m & 8u) { A.f[CF_STRY][L] = strinty; A.f[CF_TAUBY][L] = tauby; }
             }
@@ -613,11 +629,14 @@ void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pair
 
 int evp_cgrid_res_max_blocks_per_cu()
 {
-    int nb = 0;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res, X * Y, 0) == hipSuccess ? nb : 0;
+    int nb = 0, nb2 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false>, X * Y, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, cg_res<true>, X * Y, 0) != hipSuccess) return 0;
+    return nb < nb2 ? nb : nb2;
 }
 
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st)
 {
-    hipLaunchKernelGGL(cg_res, dim3(R.ntiles), dim3(X * Y), 0, st, A, R);
+    if (A.avg_strength) hipLaunchKernelGGL(cg_res<true>, dim3(R.ntiles), dim3(X * Y), 0, st, A, R);
+    else hipLaunchKernelGGL(cg_res<false>, dim3(R.ntiles), dim3(X * Y), 0, st, A, R);
 }

@@ -578,7 +578,7 @@ static int build_res_tables(const double *const *static23)
     return 0;
 }
 
-// eligible in this call: one rank, no fold, avg_zeta (classic or revised EVP), the default-configuration shortcuts hold on every ice cell, the static
+// eligible in this call: one rank, no fold (either visc_method, classic or revised EVP), the default-configuration shortcuts hold on every ice cell, the static
 // identities hold (the kernel takes -1 for a boundary ratio away from a coast), every window co-resident
 static bool res_eligible(std::string *why = nullptr)
 {
@@ -586,7 +586,6 @@ static bool res_eligible(std::string *why = nullptr)
     const CGridState::Res &Q = CG.res;
     if (!CG.one.tab || remote() || !fused_schedule() || !one_launch()) return no("several ranks, a tripole fold, a block too small, or the one-launch schedule switched off");
     if (!Q.tab) return no(Q.why.empty() ? "tables not built" : Q.why.c_str());
-    if (CG.avg_strength) return no("visc_method = avg_strength");
     if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
     if (!geo_derived()) return no("a start-up identity of the static arrays does not hold");
     if (!Q.pairs_state_ok) return no("ghost cells outside the domain that the kernel treats as one position hold different state");
