@@ -2,7 +2,8 @@
 """EVP subcycle benchmark (BASELINE.json metric: EVP subcycle cell-updates/sec,
 gx1 fp64, at 1/2/4/8 GPUs; % of the roofline).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run, or bare -- it then re-executes
+                                                        itself under torch.distributed.run, one rank per GPU, 127.0.0.1)
 
 A "step" is one evp() call's worth of the hot path: ndte subcycles
 (stress + stepu + velocity halo, ice_dyn_evp.F90:859-913) on a resident synthetic
@@ -19,8 +20,13 @@ What the line carries besides the contract's fields:
                 fractions on gx1 and on 3600x2400, measured live in this run, with PMC traffic).
   verified      the state after the timed region (+ a few untimed steps up to the next checkpoint)
                 hashed and compared with tests/golden/bench_checksums.json (made by the CPU oracle).
+  median_ms_per_step   N = 1: the same loop ten more times, one call at a time (HIP events of the library): SURVEY 8(d)'s median
+                next to the contract's K-step mean (`ms_per_step`, `value`).
   cgrid         the C-grid subcycle on gx1 and on 3600x2400: microseconds per subcycle, verified
-                against committed oracle checksums, HBM fraction on its 648 B per cell.
+                against committed oracle checksums; `kernel` says what ran (gx1: the on-chip resident kernel cg_res, every
+                subcycle of a call but the first after an upload in one launch; 3600x2400: one launch per subcycle, HBM
+                fraction on its 289 B per cell).
+  rccl_control  N > 1: the headline workload once more with every remote ghost cell carried by RCCL point-to-point.
   attempts      N > 1 only: every sync point is an agreement over the ranks; a failed or unverified attempt is
                 repeated by all ranks with the resident kernel off, then with RCCL only (config.attempts).
   configs2_gx1_ndte240, tripole, secondary
