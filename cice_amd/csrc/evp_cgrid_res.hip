@@ -139,19 +139,28 @@ __device__ __forceinline__ void push1(const EvpCgrid &A, size_t c, double *f, do
 // AVGS: visc_method = 'avg_strength' -- the corner viscosities come from the T -> U average of the strength (A.strengthU, once
 // per call) and the corner's own Delta (ice_dyn_evp.F90:992-996), so level S works out the whole of strain_rates_U in every
 // subcycle and hands deltaU to level U through the plane etax2T travels in otherwise.
-template <bool AVGS>
+// REVP: revised EVP (revp = 1) -- revp * uvelE_init / revp * vvelN_init are operands of the momentum step (two more planes by
+// owned cell); under classic EVP they are zeros of the initial velocity's sign and travel as two bits.
+// The planes read inside the window only are (X+1) wide like the others wherever LDS allows it (53.3 KB per workgroup for three
+// per CU): X wide they measured 3-4 % slower on one box (levels U and C: gx1 6.5 -> 6.8 us per subcycle, gx3 4.17 -> 4.30), so
+// only the variant that needs the two extra planes AND the T -> U weights (revised EVP with avg_zeta) packs them.
+template <bool AVGS, bool REVP>
 __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 {
+    constexpr int PW = (REVP && !AVGS) ? X : LW;         // row stride of the window-only planes
+    constexpr int NQ = PW * Y;
+    constexpr int NPC = REVP ? 18 : 16;
     // planes a level reads one position beyond the window (velocities, the averaging weights, dyE / dxN for the boundary ratios):
     // (Y+1) x (X+1); planes read inside the window only: Y x X, index = thread index
     __shared__ double s_uE[NP], s_vN[NP], s_ea[NP], s_na[NP], s_dyE[NP], s_dxN[NP];
-    __shared__ double s_ua[X * Y], s_ta[X * Y], s_sh[X * Y], s_eta[X * Y], s_sp[X * Y], s_sm[X * Y], s_s12[X * Y];
+    __shared__ double s_ua[NQ], s_ta[AVGS ? 1 : NQ], s_sh[NQ], s_eta[NQ], s_sp[NQ], s_sm[NQ], s_s12[NQ];
     // per-call operands of the momentum step, by owned cell (read at level C only): 0-5 uocnE vocnE facE emassdti fmE forcexE,
-    // 6-11 the same at N, 12-15 earear 1/dxE narear 1/dyN, 16-17 revp * uvelE_init, revp * vvelN_init.  The last two planes
-    // double as the table of source cells during the prologue (s_src: ints, read for the last time before they are filled)
-    __shared__ double s_pc[18][13 * 13];
-    int *const s_src = reinterpret_cast<int *>(&s_pc[16][0]);
-    static_assert(sizeof(double) * 2 * 13 * 13 >= sizeof(int) * NP, "s_src does not fit its alias");
+    // 6-11 the same at N, 12-15 earear 1/dxE narear 1/dyN, REVP: 16-17 revp * uvelE_init, revp * vvelN_init.
+    __shared__ double s_pc[NPC][13 * 13];
+    // the table of source cells lives, during the prologue, where stress12U's plane is afterwards (ints; the plane is filled once
+    // every thread has read the table for the last time)
+    int *const s_src = reinterpret_cast<int *>(&s_s12[0]);
+    static_assert(sizeof(double) * NQ >= sizeof(int) * NP, "s_src does not fit its alias");
     __shared__ uint8_t s_gm[NP];           // land masks of the position's cell: bit0 epm, 1 npm, 2 uvm, 3 hm
     __shared__ int s_bad;
 
@@ -183,8 +192,8 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         s_dyE[e] = G(CG_DYE)[c];
         s_dxN[e] = G(CG_DXN)[c];
         if (e % LW < X && e / LW < Y) {
-            s_ua[(e / LW) * X + e % LW] = G(CG_UAREA)[c];
-            s_ta[(e / LW) * X + e % LW] = G(CG_TAREA)[c];
+            s_ua[(e / LW) * PW + e % LW] = G(CG_UAREA)[c];
+            if (!AVGS) s_ta[(e / LW) * PW + e % LW] = G(CG_TAREA)[c];
         }
         s_gm[e] = R.gmask[c];
     }
@@ -199,12 +208,12 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const bool compU = !stat && tx <= X - 2 && ty <= Y - 2;
     const bool pub = own && R.pubmap[L] != 0;
     // what a position that does not compute a level shows its neighbours: the array's value, unchanged through the loop
-    s_sh[t] = A.f[CF_SHEARU][L];
-    s_eta[t] = A.f[CF_ETA][L];
+    const int pt = ty * PW + tx;         // this position in the window-only planes
+    s_sh[pt] = A.f[CF_SHEARU][L];
+    s_eta[pt] = A.f[CF_ETA][L];
     double sp = R.sp_in[L], sm = R.sm_in[L], s12v = R.s12_in[L];
-    s_sp[t] = sp;
-    s_sm[t] = sm;
-    s_s12[t] = s12v;
+    s_sp[pt] = sp;
+    s_sm[pt] = sm;
     double s12T = own ? A.f[CF_S12T][L] : 0.0;
     __syncthreads();
 
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const size_t cE = (size_t)(s_src[li + 1] < 0 ? -1 - s_src[li + 1] : s_src[li + 1]);
     const size_t cN = (size_t)(s_src[li + LW] < 0 ? -1 - s_src[li + LW] : s_src[li + LW]);
     // mb: bit 0 epm, 1 npm, 2 uvm of the cell; 3 npm of its east, 4 epm of its north neighbour; 5-8 hm of the cell, east, north,
-    // north-east
+    // north-east; classic EVP: 9 / 10 the signs of revp * uvelE_init, revp * vvelN_init
     unsigned mb;
     {
         const unsigned gmo = s_gm[li], gme = s_gm[li + 1], gmn = s_gm[li + LW], gmne = s_gm[li + LW + 1];
@@ -230,14 +239,14 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     if (compT) {
         const double dxT = G(CG_DXT)[L], dyT = G(CG_DYT)[L];
         dxT2 = dxT * dxT; dyT2 = dyT * dyT;
-        uareaavgr = 1.0 / (s_ua[t] + s_ua[t - X] + s_ua[t - X - 1] + s_ua[t - 1]);
+        uareaavgr = 1.0 / (s_ua[pt] + s_ua[pt - PW] + s_ua[pt - PW - 1] + s_ua[pt - 1]);
         strength = IN(CI_STRENGTH)[L];
         DminT = G(CG_DMINT)[L];
     }
     double wtmpU = 0.0, strU = 0.0;      // avg_zeta: the sum of the weights of the T -> U average; AVGS: DminUarea, strengthU
     if (compU) {
         if (AVGS) { wtmpU = A.deltaminEVP * G(CG_UAREA)[L]; strU = A.strengthU[L]; }
-        else wtmpU = (bit(5) * s_ta[t] + bit(6) * s_ta[t + 1] + bit(7) * s_ta[t + X] + bit(8) * s_ta[t + X + 1]);
+        else wtmpU = (bit(5) * s_ta[pt] + bit(6) * s_ta[pt + 1] + bit(7) * s_ta[pt + PW] + bit(8) * s_ta[pt + PW + 1]);
     }
     double hdyEr = 0, dyT2e = 0, dxU2s = 0;
     double hdxNr = 0, dxT2n = 0, dyU2w = 0;
@@ -260,6 +269,10 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         s_pc[10][oi] = IN(CI_FMN)[L]; s_pc[11][oi] = IN(CI_FORCEYN)[L];
         zE0 = p.revp * IN(CI_UE_INIT)[L];
         zN0 = p.revp * IN(CI_VN_INIT)[L];
+        if (!REVP) {       // classic EVP: zeros -- their signs as bits 9 / 10
+            mb |= (__double_as_longlong(zE0) < 0 ? 1u : 0u) << 9;
+            mb |= (__double_as_longlong(zN0) < 0 ? 1u : 0u) << 10;
+        }
     }
     // The extra row / column of the reference's T list (ghost cells ihi+1, jhi+1: of what stressC_T computes there only stress12T
     // survives the exchange) is kept up by the window that owns the neighbouring interior cell -- by the threads of its column
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // row ty, thread (tx, 0) the one of row jhi+1 in column tx.  Such a thread runs level T like everybody else, at the ghost
     // position (tli), with the ghost cell's own strength, DminTarea and history; the planes hold the static operands of the
     // cell the position's value comes from, which equal the ghost cell's (cgres: images verified).
-    int tli = li, t6 = t;          // the position level T is evaluated at (index into the (X+1)- and the X-wide planes)
+    int tli = li, t6 = pt;         // the position level T is evaluated at (index into the velocity tile and into the window-only planes)
     bool ghostT = false;
     size_t g = 0;
     if ((tx == 0) != (ty == 0)) {
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                     if (A.mask[g] & 1u) {
                         ghostT = true;
                         tli = gy_ * LW + gx_;
-                        t6 = gy_ * X + gx_;
+                        t6 = gy_ * PW + gx_;
                     }
                 }
             }
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     if (ghostT) {
         const double dxT = G(CG_DXT)[g], dyT = G(CG_DYT)[g];
         dxT2 = dxT * dxT; dyT2 = dyT * dyT;
-        uareaavgr = 1.0 / (s_ua[t6] + s_ua[t6 - X] + s_ua[t6 - X - 1] + s_ua[t6 - 1]);
+        uareaavgr = 1.0 / (s_ua[t6] + s_ua[t6 - PW] + s_ua[t6 - PW - 1] + s_ua[t6 - 1]);
         strength = IN(CI_STRENGTH)[g];
         DminT = G(CG_DMINT)[g];
         s12T = A.f[CF_S12T][g];
@@ -372,8 +385,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             if (R.long_sleep) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
         }
     };
-    __syncthreads();               // (every thread has read the source table for the last time: its planes take their operands)
-    if (own) { s_pc[16][oi] = zE0; s_pc[17][oi] = zN0; }
+    __syncthreads();               // (every thread has read the source table for the last time: its plane takes stress12U)
+    s_s12[pt] = s12v;
+    if (REVP && own) { s_pc[NPC - 2][oi] = zE0; s_pc[NPC - 1][oi] = zN0; }
     // initial records (tag of subcycle 0) so that the neighbours' first poll finds them; also the proof that they are resident
     if (pub) st_rec2((v4u *)R.rec[R.par0 & 1] + 2 * L, pack_rec(s_uE[li], R.tag_base), pack_rec(s_vN[li], R.tag_base));
     __syncthreads();
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         v4u *wr = (v4u *)R.rec[((k + R.par0) & 1) ^ 1];
         // (the operand planes never change inside the loop: without an index the compiler cannot see through it hoists every one
         // of their loads into registers -- which is exactly what they are in LDS to avoid)
-        int lo = li, to = tli, oo = oi, o6 = t, to6 = t6;
+        int lo = li, to = tli, oo = oi, o6 = pt, to6 = t6;
         asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo), "+v"(o6), "+v"(to6));
         if ((CGRES_DBG(R) & 8) && (tile & 3) == 1) {
             const unsigned long long t0 = wall_clock64();
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;
                 const double vNij = vNo * npc + (npe - npc) * npe * rxNr * vNe;
                 const double sh = dxU * (uEijp1 - uEij) - uU * ddxE + dyU * (vNip1j - vNij) - vU * ddyN;
-                s_sh[t] = sh;
+                s_sh[pt] = sh;
                 if (fullS) {             // deltaU is wanted (avg_zeta: once per call, for the caller): the rest of strain_rates_U
                     const double uNe = avg4(uEo, eao, s_uE[li + 1], s_ea[lo + 1], uEn, ean, s_uE[li + LW + 1], s_ea[lo + LW + 1]) * npe;
                     const double vEn = avg4(vNo, nao, vNe, nae, s_vN[li + LW], s_na[lo + LW], s_vN[li + LW + 1], s_na[lo + LW + 1]) * epn;
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                     const double dv = dyU * (uNip1j - uNij) + uU * ddyN + dxU * (vEijp1 - vEij) + vU * ddxE;
                     const double tn = dyU * (uNip1j - uNij) - uU * ddyN - dxU * (vEijp1 - vEij) + vU * ddxE;
                     const double delta = sqrt(dv * dv + p.e_factor * (tn * tn + sh * sh));
-                    if (AVGS) s_eta[t] = delta;
+                    if (AVGS) s_eta[pt] = delta;
                     if (LAST && own && !R.dry) {
                         A.f[CF_SHEARU][L] = sh;
                         A.f[CF_DELTAU][L] = delta;
@@ -468,13 +482,13 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // ---- T ---- (at the thread's own position, or at the ghost position it serves)
         if (doT) {
             const TOut r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2,
-                                    dyT2, s_ua[to6], s_ua[to6 - X], s_ua[to6 - X - 1], s_ua[to6 - 1], uareaavgr, strength, DminT, s_sh[t6],
-                                    s_sh[t6 - X], s_sh[t6 - X - 1], s_sh[t6 - 1], sp, sm, relax);
+                                    dyT2, s_ua[to6], s_ua[to6 - PW], s_ua[to6 - PW - 1], s_ua[to6 - 1], uareaavgr, strength, DminT, s_sh[t6],
+                                    s_sh[t6 - PW], s_sh[t6 - PW - 1], s_sh[t6 - 1], sp, sm, relax);
             if (compT) {
                 sp = r.sp; sm = r.sm;
-                if (!AVGS) s_eta[t] = r.etax2;       // (AVGS: the plane holds deltaU, level U does not read etax2T)
-                s_sp[t] = sp;
-                s_sm[t] = sm;
+                if (!AVGS) s_eta[pt] = r.etax2;       // (AVGS: the plane holds deltaU, level U does not read etax2T)
+                s_sp[pt] = sp;
+                s_sm[pt] = sm;
             }
             if (keepS12T) s12T = (s12T * relax + p.arlx1i * 0.5 * r.etax2 * r.shearT) * p.denom1;
             if (LAST && own && compT && !R.dry) {
@@ -496,17 +510,17 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             double e2;
             if (AVGS) {
                 double z, rp;
-                visc_replpress(p, strU, wtmpU, s_eta[t], z, e2, rp);
+                visc_replpress(p, strU, wtmpU, s_eta[pt], z, e2, rp);
             } else {
                 e2 = wtmpU == 0.0 ? 0.0
-                                  : (bit(5) * s_eta[t] * s_ta[o6] + bit(6) * s_eta[t + 1] * s_ta[o6 + 1] + bit(7) * s_eta[t + X] * s_ta[o6 + X] +
-                                     bit(8) * s_eta[t + X + 1] * s_ta[o6 + X + 1]) / wtmpU;
+                                  : (bit(5) * s_eta[pt] * s_ta[o6] + bit(6) * s_eta[pt + 1] * s_ta[o6 + 1] + bit(7) * s_eta[pt + PW] * s_ta[o6 + PW] +
+                                     bit(8) * s_eta[pt + PW + 1] * s_ta[o6 + PW + 1]) / wtmpU;
             }
             etaU = e2;
-            const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * s_sh[t]) * p.denom1;
+            const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * s_sh[pt]) * p.denom1;
             if (m & 2u) {
                 s12v = upd;
-                s_s12[t] = upd;
+                s_s12[pt] = upd;
             }
         }
         __syncthreads();
@@ -514,13 +528,13 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 
         // ---- C ----
         if (own) {
-            const double s12c = s12v, s12s = s_s12[t - X], s12w = s_s12[t - 1];
+            const double s12c = s12v, s12s = s_s12[pt - PW], s12w = s_s12[pt - 1];
             const double spc = sp, smc = sm;
-            const double spe = s_sp[t + 1], sme = s_sm[t + 1], spn = s_sp[t + X], smn = s_sm[t + X];
+            const double spe = s_sp[pt + 1], sme = s_sm[pt + 1], spn = s_sp[pt + PW], smn = s_sm[pt + PW];
             double unew, vnew, strintx, strinty, taubx, tauby;
             {
                 const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
-                const double zE = s_pc[16][oo];                        // revp * uvelE_init
+                const double zE = REVP ? s_pc[NPC - 2][oo] : ((mb >> 9) & 1u ? -0.0 : 0.0);     // revp * uvelE_init
                 strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + hdyEr * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
                 const double uold = uEo, vold = vEo;
                 const double du = uocnE - uold, dv = vocnE - vold;
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             }
             {
                 const double uocnN = s_pc[6][oo], vocnN = s_pc[7][oo], facN = s_pc[8][oo], massN = s_pc[9][oo], fmN = s_pc[10][oo], forceyN = s_pc[11][oo];
-                const double zN = s_pc[17][oo];                        // revp * vvelN_init
+                const double zN = REVP ? s_pc[NPC - 1][oo] : ((mb >> 10) & 1u ? -0.0 : 0.0);    // revp * vvelN_init
                 strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
                 const double uold = uNo, vold = vNo;
                 const double du = uocnN - uold, dv = vocnN - vold;
@@ -627,16 +641,26 @@ void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pair
     hipLaunchKernelGGL(cg_res_pair_check, dim3((n + 255) / 256), dim3(256), 0, st, F, pairs, n, flags);
 }
 
-int evp_cgrid_res_max_blocks_per_cu()
+int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised)
 {
-    int nb = 0, nb2 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false>, X * Y, 0) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, cg_res<true>, X * Y, 0) != hipSuccess) return 0;
-    return nb < nb2 ? nb : nb2;
+    int nb = 0;
+    hipError_t e;
+    if (avg_strength) e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, true>, X * Y, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, false>, X * Y, 0);
+    else e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, true>, X * Y, 0)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, false>, X * Y, 0);
+    return e == hipSuccess ? nb : 0;
 }
 
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st)
 {
-    if (A.avg_strength) hipLaunchKernelGGL(cg_res<true>, dim3(R.ntiles), dim3(X * Y), 0, st, A, R);
-    else hipLaunchKernelGGL(cg_res<false>, dim3(R.ntiles), dim3(X * Y), 0, st, A, R);
+    const dim3 grid(R.ntiles), block(X * Y);
+    const bool revised = A.p.revp != 0.0;
+    if (A.avg_strength) {
+        if (revised) hipLaunchKernelGGL((cg_res<true, true>), grid, block, 0, st, A, R);
+        else hipLaunchKernelGGL((cg_res<true, false>), grid, block, 0, st, A, R);
+    } else {
+        if (revised) hipLaunchKernelGGL((cg_res<false, true>), grid, block, 0, st, A, R);
+        else hipLaunchKernelGGL((cg_res<false, false>), grid, block, 0, st, A, R);
+    }
 }

@@ -406,7 +406,7 @@ struct EvpCgRes {
     int long_sleep;               // A/B (test build): 512 instead of 64 cycles between two looks at a record
     int dbg;                      // test hooks (test build): 8 every fourth window lags, 16 window 1 never runs (real launches)
 };
-int evp_cgrid_res_max_blocks_per_cu();
+int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised);
 void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pairs, int n, unsigned *flags, hipStream_t st);
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,

@@ -57,7 +57,7 @@ struct CGridState {
         std::string why;             // ... or why the kernel is not eligible on this rank
         int mode = -1;               // -1 undecided (first eligible call probes), 0 off, 1 on
         bool launched = false;       // a launch whose error word has not been looked at
-        long cap = 0;                // windows that can be resident at once (occupancy x CUs)
+        long cap4[4] = {};           // windows that can be resident at once (occupancy x CUs), by kernel variant (avg_strength | revised << 1)
         double t_probe_ms = -1.0;    // probe: ms per subcycle
         int last_nsub = 0;           // subcycles of the last call that ran inside it
         int fallbacks = 0;           // cice_evp_hip_cgrid_run calls repeated without it after a wait gave up
@@ -574,7 +574,7 @@ static int build_res_tables(const double *const *static23)
     HIPC(hipMemset(Q.err, 0, 8 * sizeof(int)));
     hipDeviceProp_t prop;
     HIPC(hipGetDeviceProperties(&prop, S.device));
-    Q.cap = (long)evp_cgrid_res_max_blocks_per_cu() * prop.multiProcessorCount;
+    for (int v = 0; v < 4; ++v) Q.cap4[v] = (long)evp_cgrid_res_max_blocks_per_cu(v & 1, v >> 1) * prop.multiProcessorCount;
     return 0;
 }
 
@@ -589,7 +589,7 @@ static bool res_eligible(std::string *why = nullptr)
     if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
     if (!geo_derived()) return no("a start-up identity of the static arrays does not hold");
     if (!Q.pairs_state_ok) return no("ghost cells outside the domain that the kernel treats as one position hold different state");
-    if ((long)Q.ntiles > Q.cap) return no("more windows than can be resident at once");
+    if ((long)Q.ntiles > Q.cap4[(CG.avg_strength ? 1 : 0) | (S.prm.revp != 0.0 ? 2 : 0)]) return no("more windows than can be resident at once");
     return true;
 }
 
