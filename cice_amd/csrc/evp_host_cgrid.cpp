@@ -509,6 +509,15 @@ static int build_res_tables(const double *const *static23)
     }
     if (!Q.images_ok) return 0;
     constexpr int RX = 16, RY = 16, NPOS = (RX + 1) * (RY + 1);
+    {   // a domain that can never be resident (3600 x 2400: 51k windows) gets no tables and no record buffers
+        long nw = 0;
+        for (int b = 0; b < S.d.nblocks; ++b)
+            nw += (long)((S.ihi[b] - S.ilo[b] + RX - 3) / (RX - 3)) * ((S.jhi[b] - S.jlo[b] + RY - 3) / (RY - 3));
+        if (nw > 2048) {
+            Q.why = "more windows than can ever be resident at once (" + std::to_string(nw) + ")";
+            return 0;
+        }
+    }
     cice_evp_hip_dims d = S.d;
     d.ilo = S.ilo.data(); d.ihi = S.ihi.data(); d.jlo = S.jlo.data(); d.jhi = S.jhi.data();
     d.iglob0 = S.iglob0.data(); d.jglob0 = S.jglob0.data();
