@@ -43,11 +43,17 @@ int cice_evp_hip_cgrid_window_plan(const cice_evp_hip_dims *dims, int32_t ox, in
 int cice_evp_hip_cgrid_window_plan_ext(const cice_evp_hip_dims *dims, int32_t ox, int32_t oy, int32_t extra, int32_t *ntiles, int32_t *tiles4,
                                        int32_t *tab)
 {
-    if (!dims || !ntiles || ox < 4 || oy < 4 || extra < 0 || extra > 1) return fail(-1, "bad argument");
+    if (!dims || !ntiles || ox < 4 || oy < 4 || extra < 0 || extra > 2) return fail(-1, "bad argument");
     HaloPlan P;
     if (!build_halo_plan(*dims, P)) return fail(-3, "halo plan: %s", P.error.c_str());
     std::vector<int32_t> t4, tb;
-    build_window_table(*dims, P, ox, oy, 1 << 20, t4, tb, extra);
+    if (extra == 2) {                       // the resident kernel's windows on a tripole grid (17 x 17 positions; ox, oy unused)
+        std::vector<int32_t> t2;
+        std::string why;
+        if (!build_fold_window_table(*dims, P, t4, t2, tb, why)) return fail(-5, "fold windows: %s", why.c_str());
+    } else {
+        build_window_table(*dims, P, ox, oy, 1 << 20, t4, tb, extra);
+    }
     *ntiles = (int32_t)(t4.size() / 4);
     if (tiles4) std::copy(t4.begin(), t4.end(), tiles4);
     if (tab) std::copy(tb.begin(), tb.end(), tab);

@@ -629,22 +629,27 @@ void build_fold_list(const cice_evp_hip_dims &d, int loc, FoldList &L)
         }
 }
 
-void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, int OY, int strip, std::vector<int32_t> &tiles,
-                        std::vector<int32_t> &tab, int extra)
-{
-    const int nxb = d.nx_block, nyb = d.ny_block;
-    const long plane = (long)nxb * nyb;
-    std::vector<int> owner((size_t)plane * d.nblocks, -1);
-    for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
-    auto interior = [&](int b, int i, int j) { return i >= d.ilo[b] && i <= d.ihi[b] && j >= d.jlo[b] && j <= d.jhi[b]; };
-    // The cell a position's value comes from: start at the nearest interior cell of the window's block and walk, x first, then
-    // y, one array cell at a time.  Stepping onto a ghost cell that mirrors an interior cell continues FROM that interior cell
-    // (through periodic boundaries and into other blocks); a ghost cell nothing is copied into (closed boundary, eliminated
-    // neighbour) is an array cell like any other and the walk goes on through it while it stays inside the block's array --
-    // so a position outside the domain names the ghost cell that IS the array neighbour of the cells next to it (a position
-    // reached through a periodic wrap used to name the block's own corner ghost cell instead: the same "outside", but not the
-    // cell the reference reads there, and its static arrays need not agree -- round 5, the on-chip resident C-grid kernel).
-    auto walk = [&](int b, int i, int j, int ti, int tj) -> long {     // from interior (b, i, j) by (ti, tj) steps
+namespace {
+// The cell a position's value comes from: start at the nearest interior cell of the window's block and walk, x first, then
+// y, one array cell at a time.  Stepping onto a ghost cell that mirrors an interior cell continues FROM that interior cell
+// (through periodic boundaries and into other blocks); a ghost cell nothing is copied into (closed boundary, eliminated
+// neighbour) is an array cell like any other and the walk goes on through it while it stays inside the block's array --
+// so a position outside the domain names the ghost cell that IS the array neighbour of the cells next to it (a position
+// reached through a periodic wrap used to name the block's own corner ghost cell instead: the same "outside", but not the
+// cell the reference reads there, and its static arrays need not agree -- round 5, the on-chip resident C-grid kernel).
+struct WindowWalk {
+    const cice_evp_hip_dims &d;
+    int nxb, nyb;
+    long plane;
+    std::vector<int> owner;
+    WindowWalk(const cice_evp_hip_dims &d_, const HaloPlan &P) : d(d_), nxb(d_.nx_block), nyb(d_.ny_block), plane((long)d_.nx_block * d_.ny_block)
+    {
+        owner.assign((size_t)plane * d.nblocks, -1);
+        for (size_t k = 0; k < P.local_dst.size(); ++k) owner[P.local_dst[k]] = P.local_src[k];
+    }
+    bool interior(int b, int i, int j) const { return i >= d.ilo[b] && i <= d.ihi[b] && j >= d.jlo[b] && j <= d.jhi[b]; }
+    long walk(int b, int i, int j, int ti, int tj) const               // from interior (b, i, j) by (ti, tj) steps
+    {
         bool stat = false;
         auto step = [&](int di, int dj) {
             const int ni = i + di, nj = j + dj;
@@ -666,7 +671,22 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
         for (; tj != 0; tj -= (tj > 0 ? 1 : -1)) step(0, tj > 0 ? 1 : -1);
         const long c = (long)b * plane + (long)(j - 1) * nxb + (i - 1);
         return stat ? -1 - c : c;
-    };
+    }
+    long at(int b, int i, int j) const                                 // window position (i, j) in block b's index space
+    {
+        const int ic = std::min(std::max(i, d.ilo[b]), d.ihi[b]);
+        const int jc = std::min(std::max(j, d.jlo[b]), d.jhi[b]);
+        return walk(b, ic, jc, i - ic, j - jc);
+    }
+};
+}   // namespace
+
+void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, int OY, int strip, std::vector<int32_t> &tiles,
+                        std::vector<int32_t> &tab, int extra)
+{
+    const int nxb = d.nx_block, nyb = d.ny_block;
+    const long plane = (long)nxb * nyb;
+    const WindowWalk W(d, P);
     tiles.clear();
     tab.clear();
     strip = std::max(1, strip);
@@ -680,9 +700,7 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
                     for (int ty = 0; ty < OY + extra; ++ty)
                         for (int tx = 0; tx < OX + extra; ++tx) {
                             const int i = (int)i0 - 2 + tx, j = j0 - 2 + ty;
-                            const int ic = std::min(std::max(i, d.ilo[b]), d.ihi[b]);
-                            const int jc = std::min(std::max(j, d.jlo[b]), d.jhi[b]);
-                            const long r = walk(b, ic, jc, i - ic, j - jc);
+                            const long r = W.at(b, i, j);
                             tab.push_back((int32_t)r);
                             regular = regular && i >= 1 && i <= nxb && j >= 1 && j <= nyb &&
                                       r == (long)b * plane + (long)(j - 1) * nxb + (i - 1);
@@ -692,4 +710,65 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
                     tiles.push_back(j0);
                     tiles.push_back(regular ? 1 : 0);
                 }
+}
+
+// Windows of the on-chip resident C-grid kernel on a tripole (u-fold) grid (evp_cgrid_res.hip, template variant FOLD).  17 x 17
+// positions per window, 13 x 13 owned as in build_window_table(..., extra = 1), except:
+//  * the top window row of a block that touches the fold owns the block's last (up to) 11 rows, so that the fold row NY sits
+//    at tile row tf <= 12 and three more tile rows remain; the window rows below it stop where it starts;
+//  * tile rows tf+1 .. tf+3 of those windows hold a MIRRORED mini-tile in SOURCE orientation: global rows NY-2, NY-1, NY, tile
+//    column tx <-> global column G0' + tx with G0' = NX - G0 - 15, G0 + tx = the global column of normal tile column tx.  A
+//    normal fold-row position tx then faces the E-face / corner-type source at mirrored column 15 - tx and the centre / N-face
+//    type source at 16 - tx (ice_boundary.F90:1626-1722: NX - ig for E faces and NE corners, NX - ig + 1 for centres and N
+//    faces);
+//  * tile rows above the mini-tile are unused (marked static, naming the window's first cell).
+// tiles: (block, i0, j0, flags) with flags bit 0 = fold window, bits 8-15 = tf, bits 16-31 = last owned row (block index
+// space); tiles2: (G0, NX, 0, 0).  Returns false (and says why) when a mirrored cell is not an interior cell of a block on
+// this rank -- the resident kernel then is not used.
+bool build_fold_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, std::vector<int32_t> &tiles, std::vector<int32_t> &tiles2,
+                             std::vector<int32_t> &tab, std::string &why)
+{
+    const int X = 16, OWN = 13, FOLDOWN = 11;
+    const int nxb = d.nx_block;
+    const long plane = (long)nxb * d.ny_block;
+    const int NX = d.nx_global, NY = d.ny_global;
+    const WindowWalk W(d, P);
+    tiles.clear(); tiles2.clear(); tab.clear();
+    std::vector<int32_t> cell((size_t)NX * NY, -1);                    // global (ig, jg) -> local interior cell
+    for (int b = 0; b < d.nblocks; ++b)
+        for (int j = d.jlo[b]; j <= d.jhi[b]; ++j)
+            for (int i = d.ilo[b]; i <= d.ihi[b]; ++i) {
+                const int ig = d.iglob0[b] + (i - d.ilo[b]), jg = d.jglob0[b] + (j - d.jlo[b]);
+                if (ig >= 1 && ig <= NX && jg >= 1 && jg <= NY) cell[(size_t)(jg - 1) * NX + (ig - 1)] = (int32_t)(b * plane + (long)(j - 1) * nxb + (i - 1));
+            }
+    auto wrap = [&](long ig) { ig = (ig - 1) % NX; if (ig < 0) ig += NX; return (int)ig + 1; };
+    for (int b = 0; b < d.nblocks; ++b) {
+        const bool top = d.jglob0[b] + (d.jhi[b] - d.jlo[b]) == NY;
+        const int jtop = top ? std::max(d.jlo[b], d.jhi[b] - (FOLDOWN - 1)) : d.jhi[b] + 1;   // first row of the fold windows
+        if (top && d.jhi[b] - d.jlo[b] + 1 < 3) { why = "a block at the fold has fewer than three rows"; return false; }
+        for (int j0 = d.jlo[b]; j0 <= d.jhi[b]; j0 = (j0 < jtop && j0 + OWN >= jtop) ? jtop : j0 + OWN) {
+            const bool fw = top && j0 == jtop;
+            const int jmax = fw ? d.jhi[b] : std::min(j0 + OWN - 1, jtop - 1);
+            const int tf = fw ? 2 + (d.jhi[b] - j0) : 0;
+            for (int i0 = d.ilo[b]; i0 <= d.ihi[b]; i0 += OWN) {
+                const long G0 = (long)d.iglob0[b] + (i0 - 2 - d.ilo[b]);
+                const long G0m = (long)NX - G0 - 15;
+                const int32_t dead = (int32_t)(-1 - (b * plane + (long)(j0 - 1) * nxb + (i0 - 1)));
+                for (int ty = 0; ty <= X; ++ty)
+                    for (int tx = 0; tx <= X; ++tx) {
+                        if (!fw || ty <= tf) { tab.push_back((int32_t)W.at(b, i0 - 2 + tx, j0 - 2 + ty)); continue; }
+                        if (ty > tf + 3) { tab.push_back(dead); continue; }
+                        const int jg = NY - (tf + 3 - ty), ig = wrap(G0m + tx);
+                        const int32_t c = jg >= 1 ? cell[(size_t)(jg - 1) * NX + (ig - 1)] : -1;
+                        if (c < 0) { why = "a cell mirrored across the fold is not on this rank"; return false; }
+                        tab.push_back(c);
+                    }
+                tiles.push_back(b); tiles.push_back(i0); tiles.push_back(j0);
+                tiles.push_back((fw ? 1 : 0) | (tf << 8) | (jmax << 16));
+                tiles2.push_back((int32_t)G0); tiles2.push_back(NX); tiles2.push_back(0); tiles2.push_back(0);
+            }
+            if (fw) break;
+        }
+    }
+    return true;
 }

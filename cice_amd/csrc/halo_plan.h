@@ -144,6 +144,11 @@ bool build_halo_plan(const cice_evp_hip_dims &d, HaloPlan &plan);
 void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &plan, int ox, int oy, int strip, std::vector<int32_t> &tiles,
                         std::vector<int32_t> &tab, int extra = 0);
 
+// The same for a tripole (u-fold) grid (17 x 17 positions): the top window row of the blocks at the fold carries a mirrored
+// mini-tile in source orientation above the fold row; see halo_plan.cpp.  tiles2: (G0, NX, 0, 0) per window.
+bool build_fold_window_table(const cice_evp_hip_dims &d, const HaloPlan &plan, std::vector<int32_t> &tiles, std::vector<int32_t> &tiles2,
+                             std::vector<int32_t> &tab, std::string &why);
+
 // C grid on a tripole (u-fold) grid: the fold step of one field location (0 centre, 1 NE corner, 2 E face, 3 N face),
 // by the meaning of the cells (ice_boundary.F90:1626-1722): one entry for every cell of every local block -- interior
 // or ghost -- in the top physical row NY (locations with points ON the fold: NE corner, N face) or in the ghost row

@@ -226,13 +226,14 @@ def cgrid_fold_plan(dims: "Dims", loc: str) -> dict:
 
 
 def cgrid_window_plan(dims: "Dims", ox: int, oy: int, extra: int = 0) -> dict:
-    """Host only: the window table of the C grid's one-launch kernel (extra = 1: of the on-chip resident one; see the header)."""
+    """Host only: the window table of the C grid's one-launch kernel (extra = 1: of the on-chip resident one; extra = 2: of the
+    resident one on a tripole grid, 17 x 17 positions with a mirrored mini-tile in the windows at the fold; see the header)."""
     lib = load_library(testing=True)
     n = C.c_int32(0)
     a = (C.byref(dims), C.c_int32(ox), C.c_int32(oy), C.c_int32(extra), C.byref(n))
     _check(lib, lib.cice_evp_hip_cgrid_window_plan_ext(*a, None, None), "(cgrid_window_plan)")
     tiles = np.zeros((n.value, 4), dtype=np.int32)
-    tab = np.zeros((n.value, oy + extra, ox + extra), dtype=np.int32)
+    tab = np.zeros((n.value, 17, 17) if extra == 2 else (n.value, oy + extra, ox + extra), dtype=np.int32)
     _check(lib, lib.cice_evp_hip_cgrid_window_plan_ext(*a, _ip(tiles), _ip(tab)), "(cgrid_window_plan)")
     return dict(tiles=tiles, tab=tab)
 

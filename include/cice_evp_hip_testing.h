@@ -31,7 +31,10 @@ int cice_evp_hip_cgrid_fold_plan(const cice_evp_hip_dims *dims, int32_t loc, int
  * NULL arrays for the count.  (What the device kernel reads; checked on the CPU against the decomposition's global numbering.) */
 int cice_evp_hip_cgrid_window_plan(const cice_evp_hip_dims *dims, int32_t ox, int32_t oy, int32_t *ntiles, int32_t *tiles4, int32_t *tab);
 /* The same with (ox + extra) x (oy + extra) positions per window, extra = 0 or 1 (same owned range and window stride): the table of the
- * on-chip resident C-grid kernel, whose level S reads one position beyond the window to the east and north (evp_cgrid_res.hip).      */
+ * on-chip resident C-grid kernel, whose level S reads one position beyond the window to the east and north (evp_cgrid_res.hip).
+ * extra = 2: that kernel's table on a tripole (u-fold) grid, 17 x 17 positions (ox, oy unused): the windows at the fold own up to
+ * 11 rows and carry a mirrored mini-tile above the fold row, tiles4[3] = fold flag | tf << 8 | last owned row << 16 (halo_plan.cpp:
+ * build_fold_window_table); -5 when a mirrored cell is not on this rank.                                                          */
 int cice_evp_hip_cgrid_window_plan_ext(const cice_evp_hip_dims *dims, int32_t ox, int32_t oy, int32_t extra, int32_t *ntiles,
                                        int32_t *tiles4, int32_t *tab);
 /* Test hook: route the exchanges and the rank agreements of the two-subcycle path through HOST buffers and the caller's

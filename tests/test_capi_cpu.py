@@ -305,6 +305,64 @@ def test_cgrid_fold_lists_equal_the_halo_update_at_the_fold(nx, ny, bx, by, ns):
             assert bits_equal(val, want[L["dst"]]), (loc, kind, int((val != want[L["dst"]]).sum()))
 
 
+@pytest.mark.parametrize("nx,ny,bx,by", [(24, 18, 24, 18), (28, 20, 14, 10), (40, 30, 20, 5), (72, 48, 36, 48), (60, 31, 20, 31),
+                                         (30, 40, 30, 14)])
+def test_cgrid_fold_window_table_mirrors_in_source_orientation(nx, ny, bx, by):
+    """The resident C-grid kernel's window table on a tripole (u-fold) grid (halo_plan.cpp: build_fold_window_table): the rows up
+    to the fold row name the global cell of the position, every interior cell is owned by exactly one window (owned rows end at
+    the limit in tiles[3]); in the windows at the fold the tile rows tf+1 .. tf+3 name the global rows NY-2 .. NY at columns that
+    INCREASE with tx, placed so that the normal fold-row position tx faces the source of an E-face / corner field at column
+    15 - tx (global column NX - ig) and of a centre / N-face field at 16 - tx (NX - ig + 1) -- ice_boundary.F90:1626-1722."""
+    from cice_amd import decomp
+    dc = decomp.Decomp(nx, ny, bx, by, "cyclic", "tripole", 1)
+    d, keep = evp.make_dims(dc, 0)
+    ob = dc.local_blocks(0)
+    nxb, nyb = dc.nx_block, dc.ny_block
+    plane = nxb * nyb
+    home = {}
+    for k, b in enumerate(ob):
+        for j in range(b.jlo, b.jhi + 1):
+            for i in range(b.ilo, b.ihi + 1):
+                home[(b.gi0 + i - b.ilo, b.gj0 + j - b.jlo)] = k * plane + (j - 1) * nxb + (i - 1)
+    P = evp.cgrid_window_plan(d, 16, 16, 2)
+    owned = np.zeros(len(ob) * plane, dtype=int)
+    nfold = 0
+    wrap = lambda g: (g - 1) % nx + 1
+    for (k, i0, j0, flags), tab in zip(P["tiles"], P["tab"]):
+        b = ob[k]
+        fw, tf, jmax = flags & 1, (flags >> 8) & 255, flags >> 16
+        nfold += fw
+        assert jmax <= b.jhi and (not fw or (jmax == b.jhi and b.gj0 + b.jhi - b.jlo == ny and tf == 2 + b.jhi - j0 and tf <= 12))
+        for ty in range(17):
+            for tx in range(17):
+                i, j = i0 - 2 + tx, j0 - 2 + ty
+                gi, gj = wrap(b.gi0 + i - b.ilo), b.gj0 + j - b.jlo
+                e = int(tab[ty, tx])
+                if not fw or ty <= tf:
+                    if 1 <= gj <= ny:
+                        assert e == home[(gi, gj)], (k, i0, j0, tx, ty)
+                    if 2 <= tx <= 14 and 2 <= ty <= 14 and i <= b.ihi and j <= jmax:
+                        owned[e] += 1
+                elif ty <= tf + 3:
+                    gjm = ny - (tf + 3 - ty)
+                    kk, r = divmod(e, plane)
+                    bb = ob[kk]
+                    jj, ii = r // nxb + 1, r % nxb + 1
+                    assert bb.ilo <= ii <= bb.ihi and bb.jlo <= jj <= bb.jhi and bb.gj0 + jj - bb.jlo == gjm
+                    gim = bb.gi0 + ii - bb.ilo
+                    if tx <= 15:        # the normal position 15 - tx: E-face / corner partner NX - ig (NX for ig = NX)
+                        g = wrap(b.gi0 + (i0 - 2 + 15 - tx) - b.ilo)
+                        assert gim == wrap(nx - g), (k, i0, j0, tx, ty, gim, g)
+                    g = wrap(b.gi0 + (i0 - 2 + 16 - tx) - b.ilo)   # the normal position 16 - tx: centre / N-face partner NX - ig + 1
+                    assert gim == wrap(nx - g + 1), (k, i0, j0, tx, ty, gim, g)
+                else:
+                    assert e < 0
+    interior = np.zeros(len(ob) * plane, dtype=int)
+    interior[list(home.values())] = 1
+    assert bits_equal(owned, interior)
+    assert nfold == sum(-(-(b.ihi - b.ilo + 1) // 13) for b in ob if b.gj0 + b.jhi - b.jlo == ny)
+
+
 @pytest.mark.parametrize("nx,ny,bx,by,ew,ns", [(24, 18, 24, 18, "cyclic", "closed"), (28, 20, 14, 10, "cyclic", "closed"),
                                                (26, 22, 10, 12, "cyclic", "cyclic"), (40, 30, 20, 10, "closed", "closed"),
                                                (70, 37, 24, 13, "cyclic", "closed"), (9, 7, 4, 3, "cyclic", "cyclic")])
