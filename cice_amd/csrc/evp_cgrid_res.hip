@@ -144,7 +144,17 @@ __device__ __forceinline__ void push1(const EvpCgrid &A, size_t c, double *f, do
 // The planes read inside the window only are (X+1) wide like the others wherever LDS allows it (53.3 KB per workgroup for three
 // per CU): X wide they measured 3-4 % slower on one box (levels U and C: gx1 6.5 -> 6.8 us per subcycle, gx3 4.17 -> 4.30), so
 // only the variant that needs the two extra planes AND the T -> U weights (revised EVP with avg_zeta) packs them.
-template <bool AVGS, bool REVP>
+//
+// FOLD: a tripole (u-fold) grid, ice_boundary.F90:1626-1722.  The windows at the fold (tl.w bit 0) own the rows up to the fold row NY at
+// tile row tf and hold, in the three tile rows above it, a MIRRORED mini-tile in SOURCE orientation (global rows NY-2, NY-1, NY; the table:
+// halo_plan.cpp build_fold_window_table): recomputing a ghost cell in ITS orientation would sum in another order, recomputing the cell it
+// mirrors in that cell's own orientation does not.  The two rows that face each other across the fold (tile rows tf and tf+3, "cls" 1 / 3)
+// read "north" through a remap: E-face / corner type fields at column 15 - tx of the other row, centre / N-face type at 16 - tx (N faces
+// and corners one row further), vectors with the sign changed.  Everything ON the fold (N faces and NE corners of row NY: vvelN, uvelN,
+// uvelU, vvelU, shearU, stress12U) is what the reference's halo update makes of it in every subcycle, ice or not -- the average of
+// the two raw values, x_lo and x_hi of the pair of columns: s * 0.5 * (x_lo + isign * x_hi), s = 1 for the lower column, isign for the higher
+// (evp_cgrid.hip: cg_fold_gather) -- built from both sides' raw values, which every window at the fold computes itself.
+template <bool AVGS, bool REVP, bool FOLD>
 __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 {
     constexpr int PW = (REVP && !AVGS) ? X : LW;         // row stride of the window-only planes
@@ -163,6 +173,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     static_assert(sizeof(double) * NQ >= sizeof(int) * NP, "s_src does not fit its alias");
     __shared__ uint8_t s_gm[NP];           // land masks of the position's cell: bit0 epm, 1 npm, 2 uvm, 3 hm
     __shared__ int s_bad;
+    // FOLD: raw values of the two rows at the fold, [.][0] the window's own fold row, [.][1] the mirrored one: uvelU, vvelU, uvelN, vvelE
+    // (level S), the new vvelN (level C)
+    __shared__ double s_fr[FOLD ? 5 : 1][2][LW];
 
     const int t = threadIdx.x;
     const int tx = t & (X - 1), ty = t / X;
@@ -177,6 +190,32 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const int nx = A.nx;
     const EvpScalars &p = A.p;
     const double relax = 1.0 - p.arlx1i * p.revp;
+    // FOLD: cls 0 an ordinary position, 1 the window's fold row (global row NY), 2 the mirrored rows NY-2 / NY-1, 3 the mirrored fold
+    // row, 4 unused; jmax: the last owned row (a window under the fold windows stops where they start)
+    const bool foldwin = FOLD && (tl.w & 1);
+    const int tf = FOLD ? (tl.w >> 8) & 255 : 0;
+    const int jmax = FOLD ? (tl.w >> 16) : q.w;
+    const int cls = !foldwin ? 0 : ty < tf ? 0 : ty == tf ? 1 : ty < tf + 3 ? 2 : ty == tf + 3 ? 3 : 4;
+    const bool onf = FOLD && (cls == 1 || cls == 3);
+    const int orow = cls == 1 ? tf + 3 : tf;          // the row across the fold
+    const int frow = cls == 3 ? 1 : 0;
+    // "north" of a position in a row at the fold: E-face / corner type at column 15 - tx of the other row, centre type at 16 - tx;
+    // one step east there is one column to the west (hx)
+    const int nE = onf ? orow * LW + 15 - tx : li + LW;
+    const int nC = onf ? orow * LW + 16 - tx : li + LW;
+    const int hx = onf ? -1 : 1;
+    // fb: bit 0 the corner's column is the lower one of its pair, 1 the corner is a pole (its own partner), 2 the N face's column is the
+    // lower one, 3 the same for the N face one column to the east (in tile orientation)
+    unsigned fb = 0;
+    if (onf) {
+        const int4 t2 = R.tiles2[tile];
+        const int NXg = t2.y;
+        int ig = ((cls == 1 ? t2.x + tx : NXg - t2.x - 15 + tx) - 1) % NXg;
+        if (ig < 0) ig += NXg;
+        ig += 1;
+        const int ige = ig == NXg ? 1 : ig + 1;
+        fb = (ig < NXg / 2 ? 1u : 0u) | ((ig == NXg / 2 || ig == NXg) ? 2u : 0u) | (ig <= NXg / 2 ? 4u : 0u) | (ige <= NXg / 2 ? 8u : 0u);
+    }
     auto G = [&](int k) { return R.gbase + (size_t)k * R.stride; };
     auto IN = [&](int k) { return R.inbase + (size_t)k * R.stride; };
 
@@ -202,14 +241,21 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const bool stat = lr < 0;
     const size_t L = (size_t)(stat ? -1 - lr : lr);
     const unsigned m = A.mask[L];
-    const bool own = tx >= 2 && tx <= X - 2 && ty >= 2 && ty <= Y - 2 && i <= q.y && j <= q.w;
-    const bool compS = !stat && (m & 2u);
-    const bool compT = tx >= 1 && ty >= 1 && !stat && (m & 1u);
-    const bool compU = !stat && tx <= X - 2 && ty <= Y - 2;
+    const bool own = tx >= 2 && tx <= X - 2 && ty >= 2 && ty <= Y - 2 && i <= q.y && j <= jmax;
+    // FOLD: level T and U in the mirrored rows NY-1 and NY only (row NY-2 feeds their shearU), nothing above the mini-tile
+    const bool rowTU = !foldwin || ty <= tf || ty == tf + 2 || ty == tf + 3;
+    const bool compS = !stat && (m & 2u) && cls != 4;
+    const bool compT = tx >= 1 && ty >= 1 && !stat && (m & 1u) && rowTU;
+    const bool compU = !stat && tx <= X - 2 && (foldwin ? rowTU : ty <= Y - 2);
     const bool pub = own && R.pubmap[L] != 0;
+    // FOLD: the mirrored partners of the owned cells of the fold row work out their raw vvelN too (the N-face half of level C)
+    const bool pown = FOLD && cls == 3 && tx >= 2 && tx <= X - 2;
     // what a position that does not compute a level shows its neighbours: the array's value, unchanged through the loop
+    // (a corner ON the fold without ice: strain_rates_U's zero fill, which the halo update then averages with its partner)
     const int pt = ty * PW + tx;         // this position in the window-only planes
-    s_sh[pt] = A.f[CF_SHEARU][L];
+    const int nCp = onf ? orow * PW + 16 - tx : pt + PW;     // centre type "north" / the corner's partner, in those planes
+    const int pU = onf ? orow * PW + 15 - tx : pt;
+    s_sh[pt] = (onf && !compS && !stat) ? 0.0 : A.f[CF_SHEARU][L];
     s_eta[pt] = A.f[CF_ETA][L];
     double sp = R.sp_in[L], sm = R.sm_in[L], s12v = R.s12_in[L];
     s_sp[pt] = sp;
@@ -220,13 +266,14 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // ---- operands for the whole call: registers for what every subcycle reads first, LDS (by owned cell) for what only the
     // momentum step reads, one word of bits for the 0 / 1 land masks -------------------------------------------------------
     const size_t cE = (size_t)(s_src[li + 1] < 0 ? -1 - s_src[li + 1] : s_src[li + 1]);
-    const size_t cN = (size_t)(s_src[li + LW] < 0 ? -1 - s_src[li + LW] : s_src[li + LW]);
+    // (a row at the fold: the array neighbour -- the ghost row beyond the fold holds the grid's own values)
+    const size_t cN = onf ? L + nx : (size_t)(s_src[li + LW] < 0 ? -1 - s_src[li + LW] : s_src[li + LW]);
     // mb: bit 0 epm, 1 npm, 2 uvm of the cell; 3 npm of its east, 4 epm of its north neighbour; 5-8 hm of the cell, east, north,
     // north-east; classic EVP: 9 / 10 the signs of revp * uvelE_init, revp * vvelN_init
     unsigned mb;
     {
-        const unsigned gmo = s_gm[li], gme = s_gm[li + 1], gmn = s_gm[li + LW], gmne = s_gm[li + LW + 1];
-        mb = (gmo & 7u) | ((gme & 2u) << 2) | ((gmn & 1u) << 4) | ((gmo & 8u) << 2) | ((gme & 8u) << 3) | ((gmn & 8u) << 4) | ((gmne & 8u) << 5);
+        const unsigned gmo = s_gm[li], gme = s_gm[li + 1], gmnE = s_gm[nE], gmn = s_gm[nC], gmne = s_gm[nC + hx];
+        mb = (gmo & 7u) | ((gme & 2u) << 2) | ((gmnE & 1u) << 4) | ((gmo & 8u) << 2) | ((gme & 8u) << 3) | ((gmn & 8u) << 4) | ((gmne & 8u) << 5);
     }
     auto bit = [&](unsigned k) -> double { return (mb >> k) & 1u ? 1.0 : 0.0; };
     double dxU = 0.0, dyU = 0.0, ddyN = 0.0, ddxE = 0.0;
@@ -246,11 +293,12 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     double wtmpU = 0.0, strU = 0.0;      // avg_zeta: the sum of the weights of the T -> U average; AVGS: DminUarea, strengthU
     if (compU) {
         if (AVGS) { wtmpU = A.deltaminEVP * G(CG_UAREA)[L]; strU = A.strengthU[L]; }
-        else wtmpU = (bit(5) * s_ta[pt] + bit(6) * s_ta[pt + 1] + bit(7) * s_ta[pt + PW] + bit(8) * s_ta[pt + PW + 1]);
+        else wtmpU = (bit(5) * s_ta[pt] + bit(6) * s_ta[pt + 1] + bit(7) * s_ta[nCp] + bit(8) * s_ta[nCp + hx]);
     }
     double hdyEr = 0, dyT2e = 0, dxU2s = 0;
     double hdxNr = 0, dxT2n = 0, dyU2w = 0;
-    const int oi = (ty - 2) * 13 + (tx - 2);         // owned cells only
+    // owned cells only (FOLD: the partners of the fold row's owned cells take the row of s_pc after the last owned one)
+    const int oi = (pown ? tf - 1 : ty - 2) * 13 + (tx - 2);
     double zE0 = 0.0, zN0 = 0.0;                     // revp * uvelE_init, revp * vvelN_init (stored once the source table is done with)
     if (own) {
         const size_t cS = (size_t)(s_src[li - LW] < 0 ? -1 - s_src[li - LW] : s_src[li - LW]);
@@ -274,14 +322,28 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             mb |= (__double_as_longlong(zN0) < 0 ? 1u : 0u) << 10;
         }
     }
+    if (pown) {
+        const size_t cW = (size_t)(s_src[li - 1] < 0 ? -1 - s_src[li - 1] : s_src[li - 1]);
+        const double dxN = G(CG_DXN)[L], dyN = G(CG_DYN)[L], dxTn = G(CG_DXT)[cN], dyUw = G(CG_DYU)[cW], dxTo = G(CG_DXT)[L];
+        dxT2 = dxTo * dxTo;
+        s_pc[14][oi] = G(CG_NAREAR)[L]; hdxNr = 0.5 / dxN; s_pc[15][oi] = 1.0 / dyN;
+        dxT2n = dxTn * dxTn; dyU2w = dyUw * dyUw;
+        s_pc[6][oi] = IN(CI_UOCNN)[L]; s_pc[7][oi] = IN(CI_VOCNN)[L]; s_pc[8][oi] = A.facN[L]; s_pc[9][oi] = IN(CI_NMASSDTI)[L];
+        s_pc[10][oi] = IN(CI_FMN)[L]; s_pc[11][oi] = IN(CI_FORCEYN)[L];
+        zN0 = p.revp * IN(CI_VN_INIT)[L];
+        mb |= (__double_as_longlong(zN0) < 0 ? 1u : 0u) << 10;
+    }
     // The extra row / column of the reference's T list (ghost cells ihi+1, jhi+1: of what stressC_T computes there only stress12T
     // survives the exchange) is kept up by the window that owns the neighbouring interior cell -- by the threads of its column
     // tx = 0 and its row ty = 0, which have no T position of their own: thread (0, ty) serves the ghost cell of column ihi+1 in
     // row ty, thread (tx, 0) the one of row jhi+1 in column tx.  Such a thread runs level T like everybody else, at the ghost
     // position (tli), with the ghost cell's own strength, DminTarea and history; the planes hold the static operands of the
     // cell the position's value comes from, which equal the ghost cell's (cgres: images verified).
+    // FOLD: the ghost row beyond the fold (row NY+1; the window's corner cell included) is a row of MIRRORED cells: stressC_T there
+    // reads what the halo update left in the ghost cells -- the mirrored values, in the ghost cell's orientation (foldghost, below).
     int tli = li, t6 = pt;         // the position level T is evaluated at (index into the velocity tile and into the window-only planes)
-    bool ghostT = false;
+    bool ghostT = false, foldghost = false;
+    int fgx = 0;
     size_t g = 0;
     if ((tx == 0) != (ty == 0)) {
         // column ihi+1 (incl. the corner) / row jhi+1 as window positions
@@ -291,12 +353,13 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             const bool colg = gi == q.y + 1 && gj >= q.z && gj <= q.w + 1, rowg = gj == q.w + 1 && gi >= q.x && gi <= q.y;
             if ((tx == 0 && colg) || (ty == 0 && rowg)) {
                 const int ii = min(gi, q.y), jj = min(gj, q.w);
-                if (ii >= tl.y && ii <= tl.y + X - 4 && jj >= tl.z && jj <= tl.z + Y - 4) {
+                if (ii >= tl.y && ii <= tl.y + X - 4 && jj >= tl.z && jj <= tl.z + Y - 4 && jj <= jmax) {
                     g = (size_t)tl.x * A.plane + (size_t)(gj - 1) * nx + (gi - 1);
                     if (A.mask[g] & 1u) {
                         ghostT = true;
                         tli = gy_ * LW + gx_;
                         t6 = gy_ * PW + gx_;
+                        if (foldwin && gj == q.w + 1) { foldghost = true; fgx = gx_; }
                     }
                 }
             }
@@ -305,12 +368,18 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     if (ghostT) {
         const double dxT = G(CG_DXT)[g], dyT = G(CG_DYT)[g];
         dxT2 = dxT * dxT; dyT2 = dyT * dyT;
+        if (foldghost) {        // corners of the ghost cell: NE, NW mirrored from row NY-1, SE, SW the fold row's own
+            const int po = (tf + 2) * PW + 15 - fgx, ps = tf * PW + fgx;
+            uareaavgr = 1.0 / (s_ua[po] + s_ua[ps] + s_ua[ps - 1] + s_ua[po + 1]);
+        } else
         uareaavgr = 1.0 / (s_ua[t6] + s_ua[t6 - PW] + s_ua[t6 - PW - 1] + s_ua[t6 - 1]);
         strength = IN(CI_STRENGTH)[g];
         DminT = G(CG_DMINT)[g];
         s12T = A.f[CF_S12T][g];
         sp = 0.0; sm = 0.0;         // (stressC_T's own stresspT / stressmT there are overwritten by the exchange: not kept)
     }
+    // level T in a row at the fold reads the corners ON the fold averaged: the partner of the evaluation position's own corner
+    const int pT = onf ? orow * PW + 15 - (t6 - ty * PW) : t6;
     const bool doT = compT || ghostT;
     const bool keepS12T = (own && compT) || ghostT;
 
@@ -322,7 +391,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     auto ring_src = [&](int e) -> int {
         const int ex = e % LW, ey = e / LW;
         const int gi = tl.y - 2 + ex, gj = tl.z - 2 + ey;
-        const bool mine = ex >= 2 && ex <= X - 2 && ey >= 2 && ey <= Y - 2 && gi <= q.y && gj <= q.w;
+        const bool mine = ex >= 2 && ex <= X - 2 && ey >= 2 && ey <= Y - 2 && gi <= q.y && gj <= jmax;
         const int sc = s_src[e];
         return (mine || sc < 0) ? -1 : sc;
     };
@@ -413,8 +482,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         v4u *wr = (v4u *)R.rec[((k + R.par0) & 1) ^ 1];
         // (the operand planes never change inside the loop: without an index the compiler cannot see through it hoists every one
         // of their loads into registers -- which is exactly what they are in LDS to avoid)
-        int lo = li, to = tli, oo = oi, o6 = pt, to6 = t6;
+        int lo = li, to = tli, oo = oi, o6 = pt, to6 = t6, nEo = nE, nCo = nCp;
         asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo), "+v"(o6), "+v"(to6));
+        if (FOLD) asm volatile("" : "+v"(nEo), "+v"(nCo));
         if ((CGRES_DBG(R) & 8) && (tile & 3) == 1) {
             const unsigned long long t0 = wall_clock64();
             while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(8);
@@ -430,18 +500,51 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         const double uEo = s_uE[li], vNo = s_vN[li];
         // AVGS: deltaU in every subcycle, at every corner level U evaluates (its own uvelN / vvelE need the west / south neighbour)
         const bool fullS = AVGS ? (compS && tx >= 1 && ty >= 1) : (LAST && own);
-        if (compS || own) {
+        if (FOLD) {
+            // the rows at the fold first work out the raw uvelU, vvelU, uvelN (all ON the fold) and vvelE (read across it) of their
+            // positions, every position, ice or not (the reference's averages cover every cell), for both sides to pick up
+            if (onf && !stat) {
+                const double uEn = -s_uE[nE], ean = s_ea[nEo], uEnw = -s_uE[nE + 1], eanw = s_ea[nEo + 1];
+                const double eao = s_ea[lo], nao = s_na[lo], nae = s_na[lo + 1], vNe = s_vN[li + 1];
+                const double uvm = bit(2);
+                s_fr[0][frow][tx] = avg2(uEo, eao, uEn, ean) * uvm;
+                s_fr[1][frow][tx] = avg2(vNo, nao, vNe, nae) * uvm;
+                s_fr[2][frow][tx] = tx >= 1 ? avg4(s_uE[li - 1], s_ea[lo - 1], uEo, eao, uEnw, eanw, uEn, ean) * bit(1) : 0.0;
+                s_fr[3][frow][tx] = avg4(s_vN[li - LW], s_na[lo - LW], s_vN[li - LW + 1], s_na[lo - LW + 1], vNo, nao, vNe, nae) * bit(0);
+            }
+            if (foldwin) __syncthreads();
+        }
+        // a vector ON the fold from the raw values of the pair of columns: lower column 0.5 * (x_lo - x_hi), higher column the negative
+        // of that (cg_fold_gather: s * (0.5 * (x_a + isign * x_b))); a pole is its own partner: s * x_a
+        auto fold_vec = [&](double me, double partner, bool lower) -> double {
+            const double v = 0.5 * ((lower ? me : partner) + (-1.0) * (lower ? partner : me));
+            return lower ? v : (-1.0) * v;
+        };
+        if (compS || own || pown) {
             const double epc = bit(0), npc = bit(1), npe = bit(3), epn = bit(4);
-            const double uEn = s_uE[li + LW], vNe = s_vN[li + 1];
-            const double eao = s_ea[lo], ean = s_ea[lo + LW], nao = s_na[lo], nae = s_na[lo + 1];
-            if (own || (AVGS && fullS)) {
-                uNo = avg4(s_uE[li - 1], s_ea[lo - 1], uEo, eao, s_uE[li + LW - 1], s_ea[lo + LW - 1], uEn, ean) * npc;
-                vEo = avg4(s_vN[li - LW], s_na[lo - LW], s_vN[li - LW + 1], s_na[lo - LW + 1], vNo, nao, vNe, nae) * epc;
+            const double uEn = onf ? -s_uE[nE] : s_uE[li + LW], vNe = s_vN[li + 1];
+            const double eao = s_ea[lo], ean = s_ea[FOLD ? nEo : lo + LW], nao = s_na[lo], nae = s_na[lo + 1];
+            double uU = 0.0, vU = 0.0;
+            if (onf) {
+                uNo = fold_vec(s_fr[2][frow][tx], s_fr[2][1 - frow][16 - tx], fb & 4u);
+                vEo = s_fr[3][frow][tx];
+                if (fb & 2u) { uU = (-1.0) * s_fr[0][frow][tx]; vU = (-1.0) * s_fr[1][frow][tx]; }
+                else {
+                    uU = fold_vec(s_fr[0][frow][tx], s_fr[0][1 - frow][15 - tx], fb & 1u);
+                    vU = fold_vec(s_fr[1][frow][tx], s_fr[1][1 - frow][15 - tx], fb & 1u);
+                }
+            } else {
+                if (own || (AVGS && fullS)) {
+                    uNo = avg4(s_uE[li - 1], s_ea[lo - 1], uEo, eao, s_uE[li + LW - 1], s_ea[lo + LW - 1], uEn, ean) * npc;
+                    vEo = avg4(s_vN[li - LW], s_na[lo - LW], s_vN[li - LW + 1], s_na[lo - LW + 1], vNo, nao, vNe, nae) * epc;
+                }
+                if (compS) {
+                    const double uvm = bit(2);
+                    uU = avg2(uEo, eao, uEn, ean) * uvm;
+                    vU = avg2(vNo, nao, vNe, nae) * uvm;
+                }
             }
             if (compS) {
-                const double uvm = bit(2);
-                const double uU = avg2(uEo, eao, uEn, ean) * uvm;
-                const double vU = avg2(vNo, nao, vNe, nae) * uvm;
                 // The four boundary-condition ratios only ever meet the factor (npc - npe) or (epc - epn), +0 away from a coast, and
                 // (+0 * mask) * ratio * velocity has the same bits for any finite negative ratio (the host has checked that all are):
                 // -1 there; the lanes of a coastal corner work them out from the reference's start-up identities
@@ -449,7 +552,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 // verified bit for bit on the caller's arrays by derive_geometry_check)
                 double rxN = -1.0, rxNr = -1.0, ryE = -1.0, ryEr = -1.0;
                 if (npc != npe) { rxN = -(s_dxN[lo + 1] / s_dxN[lo]); rxNr = 1.0 / rxN; }
-                if (epc != epn) { ryE = -(s_dyE[lo + LW] / s_dyE[lo]); ryEr = 1.0 / ryE; }
+                if (epc != epn) { ryE = -(s_dyE[FOLD ? nEo : lo + LW] / s_dyE[lo]); ryEr = 1.0 / ryE; }
                 const double uEijp1 = uEn * epn + (epc - epn) * epc * ryE * uEo;
                 const double uEij = uEo * epc + (epn - epc) * epn * ryEr * uEn;
                 const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;
@@ -457,8 +560,14 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double sh = dxU * (uEijp1 - uEij) - uU * ddxE + dyU * (vNip1j - vNij) - vU * ddyN;
                 s_sh[pt] = sh;
                 if (fullS) {             // deltaU is wanted (avg_zeta: once per call, for the caller): the rest of strain_rates_U
-                    const double uNe = avg4(uEo, eao, s_uE[li + 1], s_ea[lo + 1], uEn, ean, s_uE[li + LW + 1], s_ea[lo + LW + 1]) * npe;
-                    const double vEn = avg4(vNo, nao, vNe, nae, s_vN[li + LW], s_na[lo + LW], s_vN[li + LW + 1], s_na[lo + LW + 1]) * epn;
+                    double uNe, vEn;
+                    if (onf) {           // uvelN one column to the east: ON the fold as well; vvelE beyond the fold: the mirrored cell's, sign changed
+                        uNe = fold_vec(s_fr[2][frow][tx + 1], s_fr[2][1 - frow][15 - tx], fb & 8u);
+                        vEn = -s_fr[3][1 - frow][15 - tx];
+                    } else {
+                        uNe = avg4(uEo, eao, s_uE[li + 1], s_ea[lo + 1], uEn, ean, s_uE[li + LW + 1], s_ea[lo + LW + 1]) * npe;
+                        vEn = avg4(vNo, nao, vNe, nae, s_vN[li + LW], s_na[lo + LW], s_vN[li + LW + 1], s_na[lo + LW + 1]) * epn;
+                    }
                     const double uNip1j = uNe * npe + (npc - npe) * npc * rxN * uNo;
                     const double uNij = uNo * npc + (npe - npc) * npe * rxNr * uNe;
                     const double vEijp1 = vEn * epn + (epc - epn) * epc * ryE * vEo;
@@ -475,15 +584,36 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 }
             }
         }
+        // (FOLD: a corner of the fold row without ice: the zero strain_rates_U fills in, for the fold step after the launch)
+        if (FOLD && LAST && own && cls == 1 && !compS && !R.dry) A.f[CF_SHEARU][L] = 0.0;
         CG_STAMP(2)
         __syncthreads();
         CG_STAMP(3)
 
         // ---- T ---- (at the thread's own position, or at the ghost position it serves)
         if (doT) {
-            const TOut r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2,
-                                    dyT2, s_ua[to6], s_ua[to6 - PW], s_ua[to6 - PW - 1], s_ua[to6 - 1], uareaavgr, strength, DminT, s_sh[t6],
-                                    s_sh[t6 - PW], s_sh[t6 - PW - 1], s_sh[t6 - 1], sp, sm, relax);
+            TOut r;
+            if (FOLD && foldghost) {
+                // the ghost cell (i, NY+1) in its own orientation, on what the halo updates leave in its ghost neighbours: uvelE(i), uvelE(i-1)
+                // = -uvelE of row NY at the mirrored columns, vvelN(i) = -vvelN of row NY-1; vvelN south of it = the fold row's own (averaged);
+                // shearU NE, NW = row NY-1's, SE, SW = the fold row's averaged with their partners
+                const int a = (tf + 3) * LW + 15 - fgx, c = (tf + 2) * LW + 16 - fgx, d = tf * LW + fgx;
+                const int po = (tf + 2) * PW + 15 - fgx, ps = tf * PW + fgx, pp = (tf + 3) * PW + 15 - fgx;
+                int ao = a, co = c, dd = d, poo = po, pso = ps;
+                asm volatile("" : "+v"(ao), "+v"(co), "+v"(dd), "+v"(poo), "+v"(pso));
+                const double shS = 0.5 * (s_sh[ps] + s_sh[pp]), shSW = 0.5 * (s_sh[ps - 1] + s_sh[pp + 1]);
+                r = t_stress(p, -s_uE[a], -s_uE[a + 1], -s_vN[c], s_vN[d], s_dyE[ao], s_dyE[ao + 1], s_dxN[co], s_dxN[dd], dxT2, dyT2, s_ua[poo], s_ua[pso],
+                             s_ua[pso - 1], s_ua[poo + 1], uareaavgr, strength, DminT, s_sh[po], shS, shSW, s_sh[po + 1], sp, sm, relax);
+            } else {
+                double shO = s_sh[t6], shW = s_sh[t6 - 1];
+                if (onf) {               // the two corners ON the fold: averaged with their partners (scalars: 0.5 * (x_lo + x_hi))
+                    shO = 0.5 * (shO + s_sh[pT]);
+                    shW = 0.5 * (shW + s_sh[pT + 1]);
+                }
+                r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2, dyT2,
+                             s_ua[to6], s_ua[to6 - PW], s_ua[to6 - PW - 1], s_ua[to6 - 1], uareaavgr, strength, DminT, shO, s_sh[t6 - PW],
+                             s_sh[t6 - PW - 1], shW, sp, sm, relax);
+            }
             if (compT) {
                 sp = r.sp; sm = r.sm;
                 if (!AVGS) s_eta[pt] = r.etax2;       // (AVGS: the plane holds deltaU, level U does not read etax2T)
@@ -513,26 +643,34 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 visc_replpress(p, strU, wtmpU, s_eta[pt], z, e2, rp);
             } else {
                 e2 = wtmpU == 0.0 ? 0.0
-                                  : (bit(5) * s_eta[pt] * s_ta[o6] + bit(6) * s_eta[pt + 1] * s_ta[o6 + 1] + bit(7) * s_eta[pt + PW] * s_ta[o6 + PW] +
-                                     bit(8) * s_eta[pt + PW + 1] * s_ta[o6 + PW + 1]) / wtmpU;
+                                  : (bit(5) * s_eta[pt] * s_ta[o6] + bit(6) * s_eta[pt + 1] * s_ta[o6 + 1] + bit(7) * s_eta[nCp] * s_ta[FOLD ? nCo : o6 + PW] +
+                                     bit(8) * s_eta[nCp + hx] * s_ta[FOLD ? nCo + hx : o6 + PW + 1]) / wtmpU;
             }
             etaU = e2;
-            const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * s_sh[pt]) * p.denom1;
+            // (a corner ON the fold: shearU as the halo update left it -- averaged with its partner)
+            const double shU = onf ? 0.5 * (s_sh[pt] + s_sh[pU]) : s_sh[pt];
+            const double upd = (s12v * relax + p.arlx1i * 0.5 * e2 * shU) * p.denom1;
             if (m & 2u) {
                 s12v = upd;
                 s_s12[pt] = upd;
+            } else if (onf) {
+                s_s12[pt] = s12v;        // (without ice: the raw value is the history, which the average below keeps changing)
             }
         }
         __syncthreads();
+        // FOLD: stress12U ON the fold -- the history takes the average of the two raw values, ice or not
+        if (onf && compU) s12v = 0.5 * (s12v + s_s12[pU]);
         CG_STAMP(6)
 
-        // ---- C ----
-        if (own) {
-            const double s12c = s12v, s12s = s_s12[pt - PW], s12w = s_s12[pt - 1];
+        // ---- C ---- (FOLD: the mirrored partners of the fold row's owned cells run the N-face half for the raw vvelN)
+        double vout = 0.0;
+        if (own || pown) {
+            const double s12c = s12v, s12s = s_s12[pt - PW];
+            const double s12w = onf ? 0.5 * (s_s12[pt - 1] + s_s12[pU + 1]) : s_s12[pt - 1];       // (the west corner of a fold-row cell: ON the fold)
             const double spc = sp, smc = sm;
-            const double spe = s_sp[pt + 1], sme = s_sm[pt + 1], spn = s_sp[pt + PW], smn = s_sm[pt + PW];
-            double unew, vnew, strintx, strinty, taubx, tauby;
-            {
+            double unew = 0.0, vnew, strintx = 0.0, strinty, taubx = 0.0, tauby;
+            if (own) {
+                const double spe = s_sp[pt + 1], sme = s_sm[pt + 1];
                 const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
                 const double zE = REVP ? s_pc[NPC - 2][oo] : ((mb >> 9) & 1u ? -0.0 : 0.0);     // revp * uvelE_init
                 strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + hdyEr * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
@@ -548,6 +686,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 taubx = -unew * Cb;
             }
             {
+                const double spn = s_sp[nCp], smn = s_sm[nCp];
                 const double uocnN = s_pc[6][oo], vocnN = s_pc[7][oo], facN = s_pc[8][oo], massN = s_pc[9][oo], fmN = s_pc[10][oo], forceyN = s_pc[11][oo];
                 const double zN = REVP ? s_pc[NPC - 1][oo] : ((mb >> 10) & 1u ? -0.0 : 0.0);    // revp * vvelN_init
                 strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
@@ -563,14 +702,29 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 tauby = -vnew * Cb;
             }
             // (nobody reads the velocity tile between the barrier above and the one after the next poll)
-            const double uout = (m & 4u) ? unew : uEo, vout = (m & 8u) ? vnew : vNo;
-            s_uE[li] = uout;
-            s_vN[li] = vout;
-            if (pub) st_rec2(wr + 2 * L, pack_rec(uout, want + 1u), pack_rec(vout, want + 1u));
-            if (LAST && !R.dry) {
-                if (!AVGS) A.f[CF_ETAU][L] = etaU;      // (avg_strength: the reference never stores etax2U)
-                if (m & 4u) { A.f[CF_STRX][L] = strintx; A.f[CF_TAUBX][L] = taubx; }
-                if (m & 8u) { A.f[CF_STRY][L] = strinty; A.f[CF_TAUBY][L] = tauby; }
+            vout = (m & 8u) ? vnew : vNo;
+            if (onf) s_fr[4][frow][tx] = vout;        // raw: both sides of the fold, for the average below
+            if (own) {
+                const double uout = (m & 4u) ? unew : uEo;
+                s_uE[li] = uout;
+                if (!onf) {
+                    s_vN[li] = vout;
+                    if (pub) st_rec2(wr + 2 * L, pack_rec(uout, want + 1u), pack_rec(vout, want + 1u));
+                }
+                if (LAST && !R.dry) {
+                    if (!AVGS) A.f[CF_ETAU][L] = etaU;      // (avg_strength: the reference never stores etax2U)
+                    if (m & 4u) { A.f[CF_STRX][L] = strintx; A.f[CF_TAUBX][L] = taubx; }
+                    if (m & 8u) { A.f[CF_STRY][L] = strinty; A.f[CF_TAUBY][L] = tauby; }
+                }
+            }
+        }
+        if (FOLD && foldwin) {
+            // vvelN ON the fold: what the halo update makes of the two raw values, on the tile and in the record
+            __syncthreads();
+            if (own && cls == 1) {
+                const double v = fold_vec(vout, s_fr[4][1][16 - tx], fb & 4u);
+                s_vN[li] = v;
+                if (pub) st_rec2(wr + 2 * L, pack_rec(s_uE[li], want + 1u), pack_rec(v, want + 1u));
             }
         }
         CG_STAMP(7)
@@ -597,7 +751,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 R.sm_out[b][L] = sm;
                 if (m & 16u) { push1(A, L, R.sp_out[b], sp); push1(A, L, R.sm_out[b], sm); }
             }
-            if (m & 2u) {
+            if ((m & 2u) || cls == 1) {          // (ON the fold: the average changes a corner without ice too)
                 R.s12_out[b][L] = s12v;
                 if (m & 16u) push1(A, L, R.s12_out[b], s12v);
             }
@@ -605,7 +759,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 R.uE_out[b][L] = uo;
                 if (m & 16u) push1(A, L, R.uE_out[b], uo);
             }
-            if (m & 8u) {
+            if ((m & 8u) || cls == 1) {
                 R.vN_out[b][L] = vo;
                 if (m & 16u) push1(A, L, R.vN_out[b], vo);
             }
@@ -641,14 +795,21 @@ void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pair
     hipLaunchKernelGGL(cg_res_pair_check, dim3((n + 255) / 256), dim3(256), 0, st, F, pairs, n, flags);
 }
 
-int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised)
+int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold)
 {
     int nb = 0;
     hipError_t e;
-    if (avg_strength) e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, true>, X * Y, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, false>, X * Y, 0);
-    else e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, true>, X * Y, 0)
-                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, false>, X * Y, 0);
+    if (fold) {          // (tripole grids: classic EVP only)
+        if (revised) return 0;
+        e = avg_strength ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, false, true>, X * Y, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, false, true>, X * Y, 0);
+    } else if (avg_strength) {
+        e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, true, false>, X * Y, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, false, false>, X * Y, 0);
+    } else {
+        e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, true, false>, X * Y, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, false, false>, X * Y, 0);
+    }
     return e == hipSuccess ? nb : 0;
 }
 
@@ -656,11 +817,14 @@ void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st)
 {
     const dim3 grid(R.ntiles), block(X * Y);
     const bool revised = A.p.revp != 0.0;
-    if (A.avg_strength) {
-        if (revised) hipLaunchKernelGGL((cg_res<true, true>), grid, block, 0, st, A, R);
-        else hipLaunchKernelGGL((cg_res<true, false>), grid, block, 0, st, A, R);
+    if (R.fold) {
+        if (A.avg_strength) hipLaunchKernelGGL((cg_res<true, false, true>), grid, block, 0, st, A, R);
+        else hipLaunchKernelGGL((cg_res<false, false, true>), grid, block, 0, st, A, R);
+    } else if (A.avg_strength) {
+        if (revised) hipLaunchKernelGGL((cg_res<true, true, false>), grid, block, 0, st, A, R);
+        else hipLaunchKernelGGL((cg_res<true, false, false>), grid, block, 0, st, A, R);
     } else {
-        if (revised) hipLaunchKernelGGL((cg_res<false, true>), grid, block, 0, st, A, R);
-        else hipLaunchKernelGGL((cg_res<false, false>), grid, block, 0, st, A, R);
+        if (revised) hipLaunchKernelGGL((cg_res<false, true, false>), grid, block, 0, st, A, R);
+        else hipLaunchKernelGGL((cg_res<false, false, false>), grid, block, 0, st, A, R);
     }
 }

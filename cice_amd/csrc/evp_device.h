@@ -386,7 +386,9 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 // of its north / east neighbour), as in EvpCgOne.  The velocities another window's rim mirrors travel as tagged 32-byte records.
 struct EvpCgRes {
     const int *tab;               // [ntiles][17 * 17]
-    const int4 *tiles;            // block, first owned i, first owned j (1-based), unused
+    const int4 *tiles;            // block, first owned i, first owned j (1-based), fold: fold window | tf << 8 | last owned row << 16
+    const int4 *tiles2;           // fold (tripole grids): global column of tile column 0, NX, -, -   (halo_plan.cpp: build_fold_window_table)
+    int fold;                     // 1: tripole (u-fold) grid, the kernel's FOLD variant
     const int *order;             // [ntiles] window run by workgroup w (NULL: identity)
     int ntiles;
     int nsub;                     // subcycles of this launch; the last one ends the call (the once-per-call arrays are stored in it)
@@ -406,7 +408,7 @@ struct EvpCgRes {
     int long_sleep;               // A/B (test build): 512 instead of 64 cycles between two looks at a record
     int dbg;                      // test hooks (test build): 8 every fourth window lags, 16 window 1 never runs (real launches)
 };
-int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised);
+int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold);
 void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pairs, int n, unsigned *flags, hipStream_t st);
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,

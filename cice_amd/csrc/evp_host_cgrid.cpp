@@ -42,9 +42,10 @@ struct CGridState {
     // all subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res)
     struct Res {
         int *tab = nullptr;
-        int4 *tiles = nullptr;
+        int4 *tiles = nullptr, *tiles2 = nullptr;     // (tiles2: tripole grids, halo_plan.cpp build_fold_window_table)
         int ntiles = 0;
         uint8_t *pubmap = nullptr;
+        uint8_t *gmask = nullptr;    // tripole grids: the land masks as bits (elsewhere CG.gmask, which the one-launch kernels share)
         void *rec = nullptr;         // 2 x S.n records of 32 bytes
         int *err = nullptr;
         int *order = nullptr;        // A/B (test build): window run by workgroup w
@@ -114,7 +115,7 @@ void cgrid_free()
     F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
     CG.one = CGridState::One{};
-    F(CG.res.tab); F(CG.res.tiles); F(CG.res.pubmap); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs); F(CG.res.prof); F(CG.res.order);
+    F(CG.res.tab); F(CG.res.tiles); F(CG.res.tiles2); F(CG.res.pubmap); F(CG.res.gmask); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs); F(CG.res.prof); F(CG.res.order);
     CG.res = CGridState::Res{};
     {
         CGridState::Prep &Q = CG.prep;
@@ -250,6 +251,12 @@ static int enqueue_phases(const EvpCgrid &A, int ndte, bool first)
     return 0;
 }
 
+static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[5], double *const alt5[5]);
+// tripole (u-fold) on one rank: the first subcycles as five launches + fold steps, the last nres inside ONE launch of the on-chip
+// resident kernel's FOLD variant, then the fold step of everything that launch leaves (ghost row beyond the fold; the points ON the fold
+// come out averaged already, and the step leaves an averaged pair as it is) and the velocity averages after the loop
+static int enqueue_phases_resident(const EvpCgrid &A, int ndte, bool first, int nres);
+
 // one launch per subcycle (cg_one) for every subcycle but the first after an upload (which still reads the caller's
 // uvelN, vvelE, uvel, vvel): one rank, no fold.  Measured, us per subcycle, three launches -> one:
 // gx3 12.5 -> 9.5, 300x240 17.6 -> 12.8, gx1 22.4 -> 17.6, 720x270 28.3 -> 21.9, 720x540 44.1 -> 39.3 (window shapes:
@@ -267,7 +274,8 @@ static bool geo_derived()
 // Checks, on every cell the kernels can read (the blocks' cells with their ghost ring; the ratios and nothing else need
 // a neighbour: interior cells), that the caller's derived arrays are what the reference's start-up computes from dx / dy
 // (the list: evp_cgrid.hip above DSlab).  Compared as BITS.  Returns the four masks as bits, or an empty vector + why.
-static std::vector<uint8_t> derive_geometry_check(const double *const *g, std::string &why)
+// areas = false: the land masks and the boundary ratios only (what the on-chip resident kernel derives on a tripole grid).
+static std::vector<uint8_t> derive_geometry_check(const double *const *g, std::string &why, bool areas = true)
 {
     const int nxb = S.d.nx_block;
     std::vector<uint8_t> gm(S.n, 0);
@@ -285,13 +293,15 @@ static std::vector<uint8_t> derive_geometry_check(const double *const *g, std::s
                 const size_t p = (size_t)b * S.plane + (size_t)(j - 1) * nxb + (i - 1);
                 const double ta = g[CG_DXT][p] * g[CG_DYT][p], ua = g[CG_DXU][p] * g[CG_DYU][p];
                 const double na = g[CG_DXN][p] * g[CG_DYN][p], ea = g[CG_DXE][p] * g[CG_DYE][p];
-                if (!same(ta, g[CG_TAREA][p])) return bad("tarea", b, i, j);
-                if (!same(ua, g[CG_UAREA][p])) return bad("uarea", b, i, j);
-                if (!same(na, g[CG_NAREA][p])) return bad("narea", b, i, j);
-                if (!same(ea, g[CG_EAREA][p])) return bad("earea", b, i, j);
-                if (!same(ea > 0.0 ? 1.0 / ea : 0.0, g[CG_EAREAR][p])) return bad("earear", b, i, j);
-                if (!same(na > 0.0 ? 1.0 / na : 0.0, g[CG_NAREAR][p])) return bad("narear", b, i, j);
-                if (!same(dmin * ta, g[CG_DMINT][p])) return bad("DminTarea", b, i, j);
+                if (areas) {
+                    if (!same(ta, g[CG_TAREA][p])) return bad("tarea", b, i, j);
+                    if (!same(ua, g[CG_UAREA][p])) return bad("uarea", b, i, j);
+                    if (!same(na, g[CG_NAREA][p])) return bad("narea", b, i, j);
+                    if (!same(ea, g[CG_EAREA][p])) return bad("earea", b, i, j);
+                    if (!same(ea > 0.0 ? 1.0 / ea : 0.0, g[CG_EAREAR][p])) return bad("earear", b, i, j);
+                    if (!same(na > 0.0 ? 1.0 / na : 0.0, g[CG_NAREAR][p])) return bad("narear", b, i, j);
+                    if (!same(dmin * ta, g[CG_DMINT][p])) return bad("DminTarea", b, i, j);
+                }
                 unsigned bits = 0;
                 const int mk[4] = {CG_EPM, CG_NPM, CG_UVM, CG_HM};
                 for (int q = 0; q < 4; ++q) {
@@ -409,6 +419,21 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
     return 0;
 }
 
+static int enqueue_phases_resident(const EvpCgrid &A, int ndte, bool first, int nres)
+{
+    if (ndte > nres)
+        if (int rc = enqueue_phases(A, ndte - nres, first)) return rc;
+    double *cur5[5] = {CG.f[CF_UE], CG.f[CF_VN], CG.f[CF_SP], CG.f[CF_SM], CG.f[CF_S12U]};
+    double *alt5[5] = {CG.one.alt[0], CG.one.alt[1], CG.one.alt[2], CG.one.alt[3], CG.s12alt};
+    if (int rc = res_launch(A, nres, false, cur5, alt5)) return rc;
+    fold({{A.f[CF_SHEARU], 1, false}, {A.f[CF_S12U], 1, false}});
+    fold({{A.f[CF_ZETA], 0, false}, {A.f[CF_ETA], 0, false}, {A.f[CF_SP], 0, false}, {A.f[CF_SM], 0, false}});
+    fold({{A.f[CF_UE], 2, true}, {A.f[CF_VN], 3, true}});
+    evp_launch_cgrid_phase(A, 4, 1, S.stream);
+    fold({{A.f[CF_UN], 3, true}, {A.f[CF_VE], 2, true}, {A.f[CF_UU], 1, true}, {A.f[CF_VU], 1, true}});
+    return 0;
+}
+
 // Fold lists (halo_plan.cpp: build_fold_list) on the device
 static int build_fold_lists()
 {
@@ -495,8 +520,14 @@ static int build_res_tables(const double *const *static23)
     const HaloPlan &P = S.plan;
     CGridState::Res &Q = CG.res;
     Q.images_ok = true;
+    const bool tripole = CG.tripole;
     for (size_t k = 0; k < P.local_dst.size() && Q.images_ok; ++k) {
         if (P.local_src[k] < 0) continue;
+        if (tripole) {       // (the ghost row beyond the fold: by field location, below)
+            const int db = (int)(P.local_dst[k] / S.plane);
+            const int dj = (int)((P.local_dst[k] % S.plane) / S.d.nx_block) + 1;
+            if (S.jglob0[db] + (dj - S.jlo[db]) > S.d.ny_global) continue;
+        }
         // (the arrays the kernel reads at a NEIGHBOUR's position: the eight lengths, the four areas, the four land masks; the
         // reciprocal areas, DminTarea and the boundary ratios are read at the own cell only or not at all)
         for (int a : {CG_DXT, CG_DYT, CG_DXU, CG_DYU, CG_DXE, CG_DYE, CG_DXN, CG_DYN, CG_UAREA, CG_TAREA, CG_EAREA, CG_NAREA, CG_EPM, CG_NPM,
@@ -508,6 +539,31 @@ static int build_res_tables(const double *const *static23)
             }
     }
     if (!Q.images_ok) return 0;
+    cice_evp_hip_dims d = S.d;
+    d.ilo = S.ilo.data(); d.ihi = S.ihi.data(); d.jlo = S.jlo.data(); d.jhi = S.jhi.data();
+    d.iglob0 = S.iglob0.data(); d.jglob0 = S.jglob0.data();
+    if (tripole) {
+        // The kernel's FOLD variant takes the operands of a cell beyond the fold from the cell it mirrors: every ghost cell of the row
+        // NY+1 must hold, array by array, what the cell its field location maps it to holds (true of a grid whose static fields went
+        // through ice_HaloUpdate with their field_loc, as CICE's do).
+        // (only the arrays the kernel reads THROUGH the remap: tarea, hm | uarea | dyE, earea, epm | dxN; everything else of a cell beyond
+        // the fold is read from the array's own ghost row -- which need not be a mirror image: CICE computes e.g. dxE there from the ghost HTN)
+        static const int by_loc[4][4] = {{CG_TAREA, CG_HM, -1, -1}, {CG_UAREA, -1, -1, -1}, {CG_DYE, CG_EAREA, CG_EPM, -1}, {CG_DXN, -1, -1, -1}};
+        for (int loc = 0; loc < 4 && Q.images_ok; ++loc) {
+            FoldList L;
+            build_fold_list(d, loc, L);
+            for (size_t k = 0; k < L.dst.size() && Q.images_ok; ++k) {
+                if (L.b[k] != -1 || L.a[k] < 0 || L.a[k] == L.dst[k]) continue;      // (points ON the fold keep their own values)
+                for (int a : by_loc[loc])
+                    if (a >= 0 && std::memcmp(static23[a] + L.dst[k], static23[a] + L.a[k], sizeof(double)) != 0) {
+                        Q.images_ok = false;
+                        Q.why = "static array " + std::to_string(a) + " differs between the cell " + std::to_string(L.dst[k]) + " beyond the fold and the cell it mirrors";
+                        break;
+                    }
+            }
+        }
+        if (!Q.images_ok) return 0;
+    }
     constexpr int RX = 16, RY = 16, NPOS = (RX + 1) * (RY + 1);
     {   // a domain that can never be resident (3600 x 2400: 51k windows) gets no tables and no record buffers
         long nw = 0;
@@ -518,18 +574,29 @@ static int build_res_tables(const double *const *static23)
             return 0;
         }
     }
-    cice_evp_hip_dims d = S.d;
-    d.ilo = S.ilo.data(); d.ihi = S.ihi.data(); d.jlo = S.jlo.data(); d.jhi = S.jhi.data();
-    d.iglob0 = S.iglob0.data(); d.jglob0 = S.jglob0.data();
-    std::vector<int32_t> tab, tiles;
-    build_window_table(d, P, RX, RY, 1 << 20, tiles, tab, 1);
+    std::vector<int32_t> tab, tiles, tiles2;
+    if (tripole) {
+        if (!build_fold_window_table(d, P, tiles, tiles2, tab, Q.why)) return 0;
+        if ((long)tiles.size() / 4 > 2048) { Q.why = "more windows than can ever be resident at once"; return 0; }
+        // the land masks as bits, the boundary ratios' identities (the five-phase kernels of these grids load all 23 arrays: no gmask yet)
+        const std::vector<uint8_t> gm = derive_geometry_check(static23, Q.why, false);
+        if (gm.empty()) return 0;
+        HIPC(hipMalloc((void **)&Q.gmask, S.n));
+        HIPC(hipMemcpy(Q.gmask, gm.data(), S.n, hipMemcpyHostToDevice));
+        for (auto &p : CG.one.alt)
+            if (!p && alloc_d(&p, S.n)) return -1;
+    } else {
+        build_window_table(d, P, RX, RY, 1 << 20, tiles, tab, 1);
+    }
     Q.ntiles = (int)(tiles.size() / 4);
+    // the last owned row of a window, the last row of positions that matter to its owned cells (fold windows: the fold row)
+    auto jmax_of = [&](int w) { return tripole ? tiles[4 * w + 3] >> 16 : S.jhi[tiles[4 * w]]; };
     std::vector<uint8_t> pub(S.n, 0);
     for (int w = 0; w < Q.ntiles; ++w) {
         const int b = tiles[4 * w], i0 = tiles[4 * w + 1], j0 = tiles[4 * w + 2];
         for (int e = 0; e < NPOS - 1; ++e) {
             const int ex = e % (RX + 1), ey = e / (RX + 1);
-            const bool mine = ex >= 2 && ex <= RX - 2 && ey >= 2 && ey <= RY - 2 && i0 - 2 + ex <= S.ihi[b] && j0 - 2 + ey <= S.jhi[b];
+            const bool mine = ex >= 2 && ex <= RX - 2 && ey >= 2 && ey <= RY - 2 && i0 - 2 + ex <= S.ihi[b] && j0 - 2 + ey <= jmax_of(w);
             const int sc = tab[(size_t)w * NPOS + e];
             if (!mine && sc >= 0) pub[sc] = 1;
         }
@@ -542,14 +609,16 @@ static int build_res_tables(const double *const *static23)
         std::vector<int2> pairs;
         std::set<std::pair<int, int>> seen;
         const int nxb = S.d.nx_block;
-        for (int w = 0; w < Q.ntiles && Q.images_ok; ++w)
-            for (int ty = 0; ty < RY; ++ty)
+        for (int w = 0; w < Q.ntiles && Q.images_ok; ++w) {
+            // (tripole: a fold window's rows up to the fold row, the others' up to two rows beyond the last owned one)
+            const int tymax = !tripole ? RY : (tiles[4 * w + 3] & 1) ? ((tiles[4 * w + 3] >> 8) & 255) + 1 : std::min(RY, jmax_of(w) - tiles[4 * w + 2] + 5);
+            for (int ty = 0; ty < tymax; ++ty)
                 for (int tx = 0; tx < RX; ++tx) {
                     const int a = tab[(size_t)w * NPOS + ty * (RX + 1) + tx];
                     if (a < 0) continue;                  // a position outside the domain computes nothing
                     for (int dy = -1; dy <= 1; ++dy)
                         for (int dx = -1; dx <= 1; ++dx) {
-                            if ((!dx && !dy) || tx + dx < 0 || ty + dy < 0) continue;
+                            if ((!dx && !dy) || tx + dx < 0 || ty + dy < 0 || ty + dy >= tymax) continue;
                             const int c = tab[(size_t)w * NPOS + (ty + dy) * (RX + 1) + (tx + dx)];
                             if (c >= 0) continue;         // inside the domain: the cell itself or an image of it
                             const int b = a + dx + dy * nxb, g = -1 - c;
@@ -564,6 +633,7 @@ static int build_res_tables(const double *const *static23)
                                 }
                         }
                 }
+        }
         if (!Q.images_ok) return 0;
         Q.npairs = (int)pairs.size();
         if (Q.npairs) {
@@ -578,12 +648,16 @@ static int build_res_tables(const double *const *static23)
     HIPC(hipMalloc((void **)&Q.err, 8 * sizeof(int)));
     HIPC(hipMemcpy(Q.tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(Q.tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (tripole) {
+        HIPC(hipMalloc((void **)&Q.tiles2, tiles2.size() * sizeof(int32_t)));
+        HIPC(hipMemcpy(Q.tiles2, tiles2.data(), tiles2.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     HIPC(hipMemcpy(Q.pubmap, pub.data(), S.n, hipMemcpyHostToDevice));
     HIPC(hipMemset(Q.rec, 0, (size_t)2 * S.n * 32));
     HIPC(hipMemset(Q.err, 0, 8 * sizeof(int)));
     hipDeviceProp_t prop;
     HIPC(hipGetDeviceProperties(&prop, S.device));
-    for (int v = 0; v < 4; ++v) Q.cap4[v] = (long)evp_cgrid_res_max_blocks_per_cu(v & 1, v >> 1) * prop.multiProcessorCount;
+    for (int v = 0; v < 4; ++v) Q.cap4[v] = (long)evp_cgrid_res_max_blocks_per_cu(v & 1, v >> 1, tripole ? 1 : 0) * prop.multiProcessorCount;
     return 0;
 }
 
@@ -593,10 +667,15 @@ static bool res_eligible(std::string *why = nullptr)
 {
     auto no = [&](const char *w) { if (why) *why = w; return false; };
     const CGridState::Res &Q = CG.res;
-    if (!CG.one.tab || remote() || !fused_schedule() || !one_launch()) return no("several ranks, a tripole fold, a block too small, or the one-launch schedule switched off");
+    if (CG.tripole) {
+        // a u-fold on one rank, classic EVP: the kernel's FOLD variant (the first subcycle of a call runs as the five phases)
+        if (CG.tfold || remote() || S.prm.revp != 0.0) return no("a T-fold, several ranks, or revised EVP on a tripole grid");
+    } else if (!CG.one.tab || remote() || !fused_schedule() || !one_launch()) {
+        return no("several ranks, a block too small, or the one-launch schedule switched off");
+    }
     if (!Q.tab) return no(Q.why.empty() ? "tables not built" : Q.why.c_str());
     if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
-    if (!geo_derived()) return no("a start-up identity of the static arrays does not hold");
+    if (CG.tripole ? !Q.gmask : !geo_derived()) return no("a start-up identity of the static arrays does not hold");
     if (!Q.pairs_state_ok) return no("ghost cells outside the domain that the kernel treats as one position hold different state");
     if ((long)Q.ntiles > Q.cap4[(CG.avg_strength ? 1 : 0) | (S.prm.revp != 0.0 ? 2 : 0)]) return no("more windows than can be resident at once");
     return true;
@@ -607,6 +686,7 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     CGridState::Res &Q = CG.res;
     EvpCgRes R{};
     R.tab = Q.tab; R.tiles = Q.tiles; R.order = nullptr; R.ntiles = Q.ntiles;
+    R.tiles2 = Q.tiles2; R.fold = CG.tripole ? 1 : 0;
     R.long_sleep = env_test("CICE_EVP_HIP_CGRID_RES_SLEEP") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_SLEEP")) ? 1 : 0;
     R.dbg = env_test("CICE_EVP_HIP_CGRID_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_DEBUG")) : 0;
     if (env_test("CICE_EVP_HIP_CGRID_RES_XCD") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_XCD"))) {
@@ -646,7 +726,7 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     R.sp_out[0] = cur5[2]; R.sp_out[1] = alt5[2]; R.sm_out[0] = cur5[3]; R.sm_out[1] = alt5[3];
     R.s12_out[0] = cur5[4]; R.s12_out[1] = alt5[4];
     R.gbase = CG.gslab; R.inbase = CG.inslab; R.stride = S.n;
-    R.gmask = CG.gmask;
+    R.gmask = CG.tripole ? Q.gmask : CG.gmask;
     if (!dry && !Q.prof && env_test("CICE_EVP_HIP_CGRID_PROF") && std::atoi(env_test("CICE_EVP_HIP_CGRID_PROF")))
         HIPC(hipMalloc((void **)&Q.prof, (size_t)Q.ntiles * 32 * sizeof(unsigned long long)));
     R.prof = dry ? nullptr : Q.prof;
@@ -719,7 +799,7 @@ static int res_decide(const EvpCgrid &A)
 
 static int res_subcycles(int ndte, bool first)
 {
-    if (CG.res.mode != 1 || !one_launch() || !res_eligible()) return 0;
+    if (CG.res.mode != 1 || (!CG.tripole && !one_launch()) || !res_eligible()) return 0;
     const int n = ndte - (first ? 1 : 0);
     return (n >= 3 && n <= 4000) ? n : 0;
 }
@@ -797,6 +877,8 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
         if (int rc = build_one_tables()) return rc;
         if (int rc = build_res_tables(static23)) return rc;
     }
+    if (tripole && !tfold && S.plan.peers.empty() && P.fold_rows == 1 && S.d.ew_boundary_type == CICE_EVP_BND_CYCLIC)
+        if (int rc = build_res_tables(static23)) return rc;
     if (!tripole) {      // (the five-phase kernels of tripole grids always load all 23)
         const std::vector<uint8_t> gm = derive_geometry_check(static23, CG.geo_why);
         if (!gm.empty()) {
@@ -903,9 +985,10 @@ int cice_evp_hip_cgrid_subcycle(int32_t ndte)
     const bool fused = fused_schedule();
     if (int rc = res_check_error()) return rc;
     if (int rc = res_decide(A)) return rc;       // (first call: the on-chip resident kernel's probe; refuses loudly when forced on a rank it cannot serve)
-    const int nres = fused ? res_subcycles(ndte, CG.first) : 0;
+    const int nres = (fused || CG.tripole) ? res_subcycles(ndte, CG.first) : 0;
     auto enqueue = [&]() -> int {
         if (fused) return enqueue_fused(A, ndte, CG.first, nres);
+        if (nres > 0) return enqueue_phases_resident(A, ndte, CG.first, nres);
         return enqueue_phases(A, ndte, CG.first);
     };
     HIPC(hipEventRecord(S.ev0, S.stream));
