@@ -942,6 +942,9 @@ def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
                 oracle.halo_update(dom, out["strintxE"], "Eface", "vector")
                 oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
                 assert_bitwise(out, c.cgrid_expected(icall, nsub), f"{what}: call {icall} nsub {nsub} (loop)")
+                if __import__("os").environ.get("CGRID_REF_SWEEP_LOG"):      # (which kernel ran: one line per call, for sweeps by hand)
+                    with open(__import__("os").environ["CGRID_REF_SWEEP_LOG"], "a") as fh:
+                        fh.write(f"{seed} {ns} {nx}x{ny} blocks {nbx}x{nby} nsub {nsub} resident {core.cgrid_timings()['resident_subcycles']}\n")
             if c.scal[23] != 0.0:
                 continue                      # (seabed stress: the device exp() may differ from the host's in the last bit of TbE / TbN)
             # the same call from the T-grid state: preparation on the device, then the loop from the device-prepared state
