@@ -110,7 +110,7 @@ def test_cgrid_deformations_t_on_device_bitwise(name):
 def test_cgrid_resident_kernel_bitwise(monkeypatch):
     """The on-chip resident C-grid kernel (evp_cgrid_res.hip: all subcycles of a call but the first after an upload in ONE launch,
     state in registers and LDS, face velocities traded between windows as tagged records) forced on: every fixture it is
-    eligible for -- one rank, no fold, avg_zeta, the default-configuration shortcuts, classic EVP -- bit-identical to the
+    eligible for -- one rank, no T-fold, the default-configuration shortcuts, classic EVP on a tripole grid -- bit-identical to the
     reference's arrays, ghost cells included, in one call and across calls; the others must refuse loudly.  Forced off, the
     one-launch kernel gives the same bits."""
     ran, refused = [], []
@@ -146,6 +146,7 @@ def test_cgrid_resident_kernel_bitwise(monkeypatch):
                 core.finalize()
     print("resident C-grid kernel ran on:", sorted(set(ran)), "refused:", sorted(set(r[0] for r in refused)))
     assert len(set(ran)) >= 1, (ran, refused)
+    assert any(n.startswith("cgrid_trip_") for n in ran), (ran, refused)      # ... the FOLD variant among them
 
 
 @pytest.mark.parametrize("case", ["caps", "full"])
@@ -158,6 +159,59 @@ def test_cgrid_resident_kernel_survives_lagging_windows(case, monkeypatch):
     dc, g, static, state, inputs, masks = synth_cgrid("gx3", case=case, seed=23)
     got, want = run_both(dc, g, static, state, inputs, masks, 40, scal_kw=(dict(revised_evp=True) if case == "full" else None))
     assert_bitwise(got, want, f"C grid, resident kernel with lagging windows, {case}")
+    assert np.abs(want["uvelE"]).max() > 1e-4
+
+
+@pytest.mark.parametrize("bs,case,visc,lag", [(None, "full", "avg_zeta", False), ((90, 60), "caps", "avg_strength", True),
+                                              ((360, 46), "full", "avg_zeta", True), ((75, 240), "caps", "avg_zeta", False)])
+def test_cgrid_resident_kernel_on_a_tripole_grid_vs_oracle(bs, case, visc, lag, monkeypatch):
+    """tx1 (360 x 240, u-fold): the resident kernel's FOLD variant forced on -- the windows at the fold carry a mirrored mini-tile in
+    source orientation and build every value ON the fold (vvelN, uvelN, uvelU, vvelU, shearU, stress12U) from both sides' raw values
+    -- bit-identical to the oracle, ghost cells included: one block, blocks cut in both directions (the mirrored cells of a window in
+    another block; a block at the fold with fewer than eleven rows), the poles inside a window and at a window's edge; with every
+    fourth window lagging (test hook) the same bits.  The first subcycle of the call runs as the five phases."""
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "1")
+    if lag:
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_RES_DEBUG", "8")
+    from cice_amd import synth
+    dc, g, static, state, inputs, masks = synth_cgrid("tx1", case=case, bs=bs, seed=41)
+    ndte = 24
+    scal = synth.evp_scalars(120)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    want = oracle.cgrid_subcycle(dom, prm, ndte, state, inputs, static, masks, visc_method=visc)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        got = core.cgrid_run(ndte, state, inputs, masks, visc_method=visc)
+        t = core.cgrid_timings()
+        assert t["resident_subcycles"] == ndte - 1 and t["resident_fallbacks"] == 0, t
+        assert_bitwise(got, want, f"C grid, tripole, resident kernel, blocks {bs}, {case}, {visc}, lag {lag}")
+        # the same state again without an upload in between: every subcycle of the call inside the launch
+        core.cgrid_subcycle(6)
+        got2 = core.cgrid_download()
+        assert core.cgrid_timings()["resident_subcycles"] == 6
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "0")
+    finally:
+        core.finalize()
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        core.cgrid_upload(state, inputs, masks, visc_method=visc)
+        core.cgrid_subcycle(ndte)
+        core.cgrid_subcycle(6)
+        ref2 = core.cgrid_download()
+        assert core.cgrid_timings()["resident_subcycles"] == 0
+    finally:
+        core.finalize()
+    assert_bitwise(got2, ref2, "C grid, tripole: a second call on the device state, resident against five phases")
     assert np.abs(want["uvelE"]).max() > 1e-4
 
 
