@@ -22,7 +22,7 @@ What the line carries besides the contract's fields:
                 hashed and compared with tests/golden/bench_checksums.json (made by the CPU oracle).
   median_ms_per_step   N = 1: the same loop ten more times, one call at a time (HIP events of the library): SURVEY 8(d)'s median
                 next to the contract's K-step mean (`ms_per_step`, `value`).
-  cgrid         the C-grid subcycle on gx1 and on 3600x2400: microseconds per subcycle, verified
+  cgrid         the C-grid subcycle on gx1, on 3600x2400 and on the tripole grid tx1: microseconds per subcycle, verified
                 against committed oracle checksums; `kernel` says what ran (gx1: the on-chip resident kernel cg_res, every
                 subcycle of a call but the first after an upload in one launch; 3600x2400: one launch per subcycle, HBM
                 fraction on its 289 B per cell).
@@ -602,10 +602,11 @@ def main():
         loops is hashed against the oracle's committed checksum."""
         spec = synth.GRIDS[workload]
         nx, ny = spec["nx"], spec["ny"]
-        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+        ns = spec.get("ns", "closed")           # (tx1: the tripole grid of BASELINE configs[3])
+        g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
         cg = synth.cgrid_geometry(g)
         state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=20260928, warm=True)
-        dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", "closed")
+        dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", ns)
         static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
         n_active = int(masks["iceTmask"].sum())
         scal = synth.evp_scalars(ndte)
@@ -636,10 +637,10 @@ def main():
         h = hashlib.sha256()
         for k in CGRID_VERIFY_FIELDS:
             h.update(np.ascontiguousarray(dc.gather({0: out[k]}), dtype="<f8").tobytes())
-        want = golden.get(f"cgrid/{workload}/{case}/ndte{ndte}/closed/strict", {}).get(str(warmup + steps))
+        want = golden.get(f"cgrid/{workload}/{case}/ndte{ndte}/{ns}/strict", {}).get(str(warmup + steps))
         # kernels per subcycle: cg_res (evp_cgrid_res.hip: every subcycle of a call but the first after an upload inside ONE launch),
         # cg_one, or the fused schedule (evp_cgrid.hip)
-        launches = (1.0 / res_n) if res_n else (1 if one else 3)
+        launches = (1.0 / res_n) if res_n else (1 if one else 10 if ns == "tripole" else 3)
         one = one or bool(res_n)
         t_sub = ev_ms * 1e-3 / (steps * ndte)
         alg = ((CGRID_B_ALG_ONE_GEO if geo else CGRID_B_ALG_ONE) if one else (CGRID_B_ALG_GEO if geo else CGRID_B_ALG)) * nx * ny
@@ -647,7 +648,8 @@ def main():
                 "value": nx * ny * ndte * steps / wall, "unit": "cell-updates/s", "steps": steps, "warmup": warmup,
                 "us_per_subcycle": 1e6 * t_sub, "us_per_subcycle_wall": 1e6 * wall / (steps * ndte),
                 "launches_per_subcycle": launches, "active_T_cells": n_active,
-                "kernel": ("cg_res (on-chip resident: all subcycles of a call in one launch)" if res_n else "cg_one" if one else "fused schedule, three launches"),
+                "kernel": ("cg_res (on-chip resident: all subcycles of a call in one launch" + (", FOLD variant)" if ns == "tripole" else ")") if res_n else "cg_one" if one
+                           else "five phases + five fold steps" if ns == "tripole" else "fused schedule, three launches"),
                 "resident_subcycles_per_call": res_n, "resident_probe_us_per_subcycle": (res_probe_us if res_n else None),
                 "verified": (h.hexdigest() == want["sha256"]) if want else None,
                 "checked_against": "tests/golden/bench_checksums.json (oracle/evp_oracle.c, pinned to the reference's evp() with grid_ice='C')" if want else None,
@@ -934,6 +936,7 @@ def main():
         try:      # next-tier row f-4: the C-grid subcycle on the same grid, and on the 0.1-degree-class one (HBM-bound)
             extra["cgrid"] = cgrid_measure("gx1", "full", 120, 3, 1)
             extra["cgrid"]["s01"] = cgrid_measure("s01", "full", 12, 1, 1)
+            extra["cgrid"]["tx1"] = cgrid_measure("tx1", "full", 120, 3, 1)
             extra["cgrid"]["per_call_ms"] = cgrid_per_call("gx1", "full", 120)
         except Exception as e:  # noqa: BLE001
             extra_err["cgrid"] = f"{type(e).__name__}: {e}"[:300]

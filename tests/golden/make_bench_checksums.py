@@ -76,17 +76,18 @@ def run(workload):
 
 
 CGRID_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")      # bench.py CGRID_VERIFY_FIELDS
-CGRID_CONFIGS = {"gx3": ("full", 120, [1, 4]), "gx1": ("full", 120, [1, 4]), "s01": ("full", 12, [2])}
+CGRID_CONFIGS = {"gx3": ("full", 120, [1, 4]), "gx1": ("full", 120, [1, 4]), "s01": ("full", 12, [2]), "tx1": ("full", 120, [4])}
 
 
 def cgrid_inputs(workload, case):
     """The C-grid workload of bench.py (shared: bench.py imports nothing from here, it builds the same through synth)."""
     spec = synth.GRIDS[workload]
     nx, ny = spec["nx"], spec["ny"]
-    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns="closed"))
+    ns = spec.get("ns", "closed")          # (tx1: tripole)
+    g = synth.derive_geometry(synth.make_grid(nx, ny, spec["dx0"], ns=ns))
     cg = synth.cgrid_geometry(g)
     state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=20260928, warm=True)
-    dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", "closed")
+    dc = decomp.per_rank_blocks(nx, ny, 1, "cyclic", ns)
     return dc, synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
 
 
@@ -112,7 +113,7 @@ def run_cgrid(workload):
             h.update(np.ascontiguousarray(dc.gather({0: out[k]}), dtype="<f8").tobytes())
         res[str(n)] = dict(sha256=h.hexdigest(), max_abs_uE=float(np.abs(out["uvelE"]).max()))
         print(f"cgrid {workload} N={n}: {res[str(n)]['sha256'][:16]} max|uE| {res[str(n)]['max_abs_uE']:.6f} ({time.time() - t0:.1f} s)", flush=True)
-    return f"cgrid/{workload}/{case}/ndte{ndte}/closed/strict", res
+    return f"cgrid/{workload}/{case}/ndte{ndte}/{dc.ns}/strict", res
 
 
 if __name__ == "__main__":

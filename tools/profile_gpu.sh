@@ -7,9 +7,10 @@
 # Counters are collected in their own passes, with --kernel-trace only (no --stats, no other
 # trace domain), as MI355X_MICROARCH.md "rocprofv3 PMC slots" prescribes: SQ 8 slots per pass,
 # FETCH_SIZE and WRITE_SIZE cannot share a pass, GRBM 2 slots.
-#   usage: tools/profile_gpu.sh <tag> [what ...]     what: gx1res gx1str s01str s01march cgx1 cgs01 cgx1one cgx1res calib (default: all but cg*)
+#   usage: tools/profile_gpu.sh <tag> [what ...]     what: gx1res gx1str s01str s01march cgx1 cgs01 cgx1one cgx1res cgtx1res cgtx1 calib (default: all but cg*)
 #   cgx1 / cgs01: the three kernels of the C-grid subcycle (tools/cgrid_timing.py) -- trace, HBM-byte and SQ passes;
 #   cgx1one: the one-launch kernel (cg_one, the default on gx1) -- cgx1 pins the three-launch form
+#   cgtx1res / cgtx1: the tripole grid tx1 with the resident kernel's FOLD variant / as five phases + fold steps
 set -u
 TAG=${1:-prof}; shift || true
 WHAT=${*:-gx1res gx1str s01str calib}
@@ -39,12 +40,13 @@ for w in $WHAT; do
     gx1str) run_passes gx1str "CICE_EVP_HIP_RESIDENT=0 CICE_EVP_HIP_TYB=${TYB_GX1:-4}" python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary ;;
     s01march) run_passes s01march "CICE_EVP_HIP_MARCH=1 ${MARCH_ENV:-}" python bench.py --workload s01 --ndte 96 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary ;;
     s01str) run_passes s01str "CICE_EVP_HIP_MARCH=0 CICE_EVP_HIP_RESIDENT=0 CICE_EVP_HIP_TYB=${TYB_S01:-208}" python bench.py --workload s01 --ndte 24 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary ;;
-    cgx1|cgs01|cgx1one|cgs01one|cgx1res)
+    cgx1|cgs01|cgx1one|cgs01one|cgx1res|cgtx1res|cgtx1)
             g=gx1; [ $w = cgs01 ] || [ $w = cgs01one ] && g=s01
+            [ $w = cgtx1res ] || [ $w = cgtx1 ] && g=tx1
             nd=120; [ $g = s01 ] && nd=12
             export CICE_EVP_HIP_CGRID_ONE=0; [ $w = cgx1one ] || [ $w = cgs01one ] || [ $w = cgx1res ] && export CICE_EVP_HIP_CGRID_ONE=1
             # cgx1res: the on-chip resident kernel (cg_res: one launch per call); the others pin the per-subcycle kernels
-            export CICE_EVP_HIP_CGRID_RESIDENT=0; [ $w = cgx1res ] && export CICE_EVP_HIP_CGRID_RESIDENT=1
+            export CICE_EVP_HIP_CGRID_RESIDENT=0; [ $w = cgx1res ] || [ $w = cgtx1res ] && export CICE_EVP_HIP_CGRID_RESIDENT=1
             rocprofv3 --kernel-trace --stats -d "$OUT" -o "${w}_trace" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 2 > "$OUT/${w}_trace.log" 2>&1
             rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace -d "$OUT" -o "${w}_fetch" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 1 > "$OUT/${w}_fetch.log" 2>&1
             rocprofv3 --pmc WRITE_SIZE GRBM_COUNT --kernel-trace -d "$OUT" -o "${w}_write" --output-format csv -- python tools/cgrid_timing.py $g --ndte $nd --reps 1 > "$OUT/${w}_write.log" 2>&1
