@@ -128,7 +128,7 @@ def main():
         res["kernels"][key] = entry
     # C-grid subcycle (tools/cgrid_timing.py): the three kernels of the fused schedule, duration and HBM-side bytes each
     CG = {"A_avg_strain": "cg_avg_strain", "B_stress_t": "cg_stress_t", "C_stress_u_step": "cg_stress_u_step"}
-    for key in ("cgx1", "cgs01", "cgx1one", "cgs01one", "cgx1res"):
+    for key in ("cgx1", "cgs01", "cgx1one", "cgs01one", "cgx1res", "cgtx1res", "cgtx1"):
         st = d / f"{key}_trace_kernel_stats.csv"
         if not st.exists():
             continue
