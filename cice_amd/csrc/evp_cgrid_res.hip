@@ -160,6 +160,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     constexpr int PW = (REVP && !AVGS) ? X : LW;         // row stride of the window-only planes
     constexpr int NQ = PW * Y;
     constexpr int NPC = REVP ? 18 : 16;
+    constexpr bool RECOMP = false;        // FOLD: per-cell constants one operation away from an LDS plane worked out again in every subcycle (A/B)
     // planes a level reads one position beyond the window (velocities, the averaging weights, dyE / dxN for the boundary ratios):
     // (Y+1) x (X+1); planes read inside the window only: Y x X, index = thread index
     __shared__ double s_uE[NP], s_vN[NP], s_ea[NP], s_na[NP], s_dyE[NP], s_dxN[NP];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 
     const int t = threadIdx.x;
     const int tx = t & (X - 1), ty = t / X;
-    const int li = ty * LW + tx;
+    int li = ty * LW + tx;
     const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
     // test hooks (test build only; CICE_EVP_HIP_CGRID_RES_DEBUG): 8 = every fourth window lags 10 us per subcycle (the results must not
     // change), 16 = window 1 never shows up in a real launch (every wait on its records gives up: the caller must hear about it)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const bool pown = FOLD && cls == 3 && tx >= 2 && tx <= X - 2;
     // what a position that does not compute a level shows its neighbours: the array's value, unchanged through the loop
     // (a corner ON the fold without ice: strain_rates_U's zero fill, which the halo update then averages with its partner)
-    const int pt = ty * PW + tx;         // this position in the window-only planes
+    int pt = ty * PW + tx;               // this position in the window-only planes
     const int nCp = onf ? orow * PW + 16 - tx : pt + PW;     // centre type "north" / the corner's partner, in those planes
     const int pU = onf ? orow * PW + 15 - tx : pt;
     s_sh[pt] = (onf && !compS && !stat) ? 0.0 : A.f[CF_SHEARU][L];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     double hdyEr = 0, dyT2e = 0, dxU2s = 0;
     double hdxNr = 0, dxT2n = 0, dyU2w = 0;
     // owned cells only (FOLD: the partners of the fold row's owned cells take the row of s_pc after the last owned one)
-    const int oi = (pown ? tf - 1 : ty - 2) * 13 + (tx - 2);
+    int oi = (pown ? tf - 1 : ty - 2) * 13 + (tx - 2);
     double zE0 = 0.0, zN0 = 0.0;                     // revp * uvelE_init, revp * vvelN_init (stored once the source table is done with)
     if (own) {
         const size_t cS = (size_t)(s_src[li - LW] < 0 ? -1 - s_src[li - LW] : s_src[li - LW]);
@@ -379,8 +380,29 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         sp = 0.0; sm = 0.0;         // (stressC_T's own stresspT / stressmT there are overwritten by the exchange: not kept)
     }
     // level T in a row at the fold reads the corners ON the fold averaged: the partner of the evaluation position's own corner
-    const int pT = onf ? orow * PW + 15 - (t6 - ty * PW) : t6;
     const bool doT = compT || ghostT;
+    // FOLD: everything a thread knows about its place at the fold in ONE register -- bits 0-2 cls, 3 foldghost, 4 pown, 5-8 fb, 9-13 the ghost
+    // cell's column; the remapped indices are worked out from it where a level needs them (a dozen integer operations against a dozen
+    // registers held through the whole loop: the kernel has none to spare, tools/cgres_phases.py)
+    const int fpk = FOLD ? (cls | (foldghost ? 8 : 0) | (pown ? 16 : 0) | ((int)fb << 5) | (fgx << 9)) : 0;
+    struct FoldIdx { bool onf, pown, ghost; int cls, frow, nE, nCp, pU, hx, gx; unsigned fb; };
+    auto fold_idx = [&](int f) -> FoldIdx {
+        FoldIdx r;
+        if (FOLD) asm volatile("" : "+v"(f));        // (not to be hoisted out of the subcycle loop)
+        r.cls = f & 7;
+        r.onf = FOLD && (r.cls == 1 || r.cls == 3);
+        r.pown = FOLD && (f & 16);
+        r.ghost = FOLD && (f & 8);
+        r.fb = (unsigned)(f >> 5) & 15u;
+        r.gx = (f >> 9) & 31;
+        r.frow = r.cls == 3 ? 1 : 0;
+        const int orw = r.cls == 1 ? tf + 3 : tf;
+        r.nE = r.onf ? orw * LW + 15 - tx : li + LW;
+        r.nCp = r.onf ? orw * PW + 16 - tx : pt + PW;
+        r.pU = r.onf ? orw * PW + 15 - tx : pt;
+        r.hx = r.onf ? -1 : 1;
+        return r;
+    };
     const bool keepS12T = (own && compT) || ghostT;
 
     // ---- ring: the positions of the velocity tile this window does not produce -- at most one per thread, dealt round-robin to
@@ -482,9 +504,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         v4u *wr = (v4u *)R.rec[((k + R.par0) & 1) ^ 1];
         // (the operand planes never change inside the loop: without an index the compiler cannot see through it hoists every one
         // of their loads into registers -- which is exactly what they are in LDS to avoid)
-        int lo = li, to = tli, oo = oi, o6 = pt, to6 = t6, nEo = nE, nCo = nCp;
-        asm volatile("" : "+v"(lo), "+v"(to), "+v"(oo), "+v"(o6), "+v"(to6));
-        if (FOLD) asm volatile("" : "+v"(nEo), "+v"(nCo));
+        // (made opaque IN PLACE: a copy per index would cost five more registers through the whole subcycle)
+        asm volatile("" : "+v"(li), "+v"(tli), "+v"(oi), "+v"(pt), "+v"(t6));
+        const int lo = li, to = tli, oo = oi, o6 = pt, to6 = t6;
         if ((CGRES_DBG(R) & 8) && (tile & 3) == 1) {
             const unsigned long long t0 = wall_clock64();
             while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(8);
@@ -503,8 +525,10 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         if (FOLD) {
             // the rows at the fold first work out the raw uvelU, vvelU, uvelN (all ON the fold) and vvelE (read across it) of their
             // positions, every position, ice or not (the reference's averages cover every cell), for both sides to pick up
-            if (onf && !stat) {
-                const double uEn = -s_uE[nE], ean = s_ea[nEo], uEnw = -s_uE[nE + 1], eanw = s_ea[nEo + 1];
+            const FoldIdx F = fold_idx(fpk);
+            const int nE = F.nE, frow = F.frow;
+            if (F.onf && !stat) {
+                const double uEn = -s_uE[nE], ean = s_ea[nE], uEnw = -s_uE[nE + 1], eanw = s_ea[nE + 1];
                 const double eao = s_ea[lo], nao = s_na[lo], nae = s_na[lo + 1], vNe = s_vN[li + 1];
                 const double uvm = bit(2);
                 s_fr[0][frow][tx] = avg2(uEo, eao, uEn, ean) * uvm;
@@ -520,10 +544,14 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             const double v = 0.5 * ((lower ? me : partner) + (-1.0) * (lower ? partner : me));
             return lower ? v : (-1.0) * v;
         };
-        if (compS || own || pown) {
+        const FoldIdx FS = fold_idx(fpk);
+        if (compS || own || FS.pown) {
+            const bool onf = FS.onf;
+            const int nE = FS.nE, frow = FS.frow;
+            const unsigned fb = FS.fb;
             const double epc = bit(0), npc = bit(1), npe = bit(3), epn = bit(4);
             const double uEn = onf ? -s_uE[nE] : s_uE[li + LW], vNe = s_vN[li + 1];
-            const double eao = s_ea[lo], ean = s_ea[FOLD ? nEo : lo + LW], nao = s_na[lo], nae = s_na[lo + 1];
+            const double eao = s_ea[lo], ean = s_ea[FOLD ? nE : lo + LW], nao = s_na[lo], nae = s_na[lo + 1];
             double uU = 0.0, vU = 0.0;
             if (onf) {
                 uNo = fold_vec(s_fr[2][frow][tx], s_fr[2][1 - frow][16 - tx], fb & 4u);
@@ -552,7 +580,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 // verified bit for bit on the caller's arrays by derive_geometry_check)
                 double rxN = -1.0, rxNr = -1.0, ryE = -1.0, ryEr = -1.0;
                 if (npc != npe) { rxN = -(s_dxN[lo + 1] / s_dxN[lo]); rxNr = 1.0 / rxN; }
-                if (epc != epn) { ryE = -(s_dyE[FOLD ? nEo : lo + LW] / s_dyE[lo]); ryEr = 1.0 / ryE; }
+                if (epc != epn) { ryE = -(s_dyE[FOLD ? nE : lo + LW] / s_dyE[lo]); ryEr = 1.0 / ryE; }
                 const double uEijp1 = uEn * epn + (epc - epn) * epc * ryE * uEo;
                 const double uEij = uEo * epc + (epn - epc) * epn * ryEr * uEn;
                 const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;
@@ -585,7 +613,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             }
         }
         // (FOLD: a corner of the fold row without ice: the zero strain_rates_U fills in, for the fold step after the launch)
-        if (FOLD && LAST && own && cls == 1 && !compS && !R.dry) A.f[CF_SHEARU][L] = 0.0;
+        if (FOLD && LAST && own && FS.cls == 1 && !compS && !R.dry) A.f[CF_SHEARU][L] = 0.0;
         CG_STAMP(2)
         __syncthreads();
         CG_STAMP(3)
@@ -593,7 +621,9 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // ---- T ---- (at the thread's own position, or at the ghost position it serves)
         if (doT) {
             TOut r;
-            if (FOLD && foldghost) {
+            const FoldIdx FT = fold_idx(fpk);
+            if (FT.ghost) {
+                const int fgx = FT.gx;
                 // the ghost cell (i, NY+1) in its own orientation, on what the halo updates leave in its ghost neighbours: uvelE(i), uvelE(i-1)
                 // = -uvelE of row NY at the mirrored columns, vvelN(i) = -vvelN of row NY-1; vvelN south of it = the fold row's own (averaged);
                 // shearU NE, NW = row NY-1's, SE, SW = the fold row's averaged with their partners
@@ -602,17 +632,22 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 int ao = a, co = c, dd = d, poo = po, pso = ps;
                 asm volatile("" : "+v"(ao), "+v"(co), "+v"(dd), "+v"(poo), "+v"(pso));
                 const double shS = 0.5 * (s_sh[ps] + s_sh[pp]), shSW = 0.5 * (s_sh[ps - 1] + s_sh[pp + 1]);
-                r = t_stress(p, -s_uE[a], -s_uE[a + 1], -s_vN[c], s_vN[d], s_dyE[ao], s_dyE[ao + 1], s_dxN[co], s_dxN[dd], dxT2, dyT2, s_ua[poo], s_ua[pso],
-                             s_ua[pso - 1], s_ua[poo + 1], uareaavgr, strength, DminT, s_sh[po], shS, shSW, s_sh[po + 1], sp, sm, relax);
+                const double uao = s_ua[poo], uas = s_ua[pso], uasw = s_ua[pso - 1], uaw = s_ua[poo + 1];
+                r = t_stress(p, -s_uE[a], -s_uE[a + 1], -s_vN[c], s_vN[d], s_dyE[ao], s_dyE[ao + 1], s_dxN[co], s_dxN[dd], dxT2, dyT2, uao, uas, uasw, uaw,
+                             1.0 / (uao + uas + uasw + uaw), strength, DminT, s_sh[po], shS, shSW, s_sh[po + 1], sp, sm, relax);
             } else {
                 double shO = s_sh[t6], shW = s_sh[t6 - 1];
-                if (onf) {               // the two corners ON the fold: averaged with their partners (scalars: 0.5 * (x_lo + x_hi))
+                if (FT.onf) {            // the two corners ON the fold: averaged with their partners (scalars: 0.5 * (x_lo + x_hi))
+                    const int pT = (FT.cls == 1 ? tf + 3 : tf) * PW + 15 - (t6 - ty * PW);      // the partner of the evaluation position's own corner
                     shO = 0.5 * (shO + s_sh[pT]);
                     shW = 0.5 * (shW + s_sh[pT + 1]);
                 }
-                r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2, dyT2,
-                             s_ua[to6], s_ua[to6 - PW], s_ua[to6 - PW - 1], s_ua[to6 - 1], uareaavgr, strength, DminT, shO, s_sh[t6 - PW],
-                             s_sh[t6 - PW - 1], shW, sp, sm, relax);
+                // (FOLD: the few per-cell constants that are one operation away from an LDS plane are worked out again in every subcycle
+                // -- this variant has no registers to keep them in; same expression, same bits)
+                const double uao = s_ua[to6], uas = s_ua[to6 - PW], uasw = s_ua[to6 - PW - 1], uaw = s_ua[to6 - 1];
+                r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2, dyT2, uao, uas,
+                             uasw, uaw, FOLD ? 1.0 / (uao + uas + uasw + uaw) : uareaavgr, strength, DminT, shO, s_sh[t6 - PW], s_sh[t6 - PW - 1], shW, sp,
+                             sm, relax);
             }
             if (compT) {
                 sp = r.sp; sm = r.sm;
@@ -636,15 +671,19 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 
         // ---- U ----
         double etaU = 0.0;
+        const FoldIdx FU = fold_idx(fpk);
         if (compU) {
+            const bool onf = FU.onf;
+            const int nCp = FU.nCp, hx = FU.hx, pU = FU.pU;
             double e2;
             if (AVGS) {
                 double z, rp;
                 visc_replpress(p, strU, wtmpU, s_eta[pt], z, e2, rp);
             } else {
-                e2 = wtmpU == 0.0 ? 0.0
-                                  : (bit(5) * s_eta[pt] * s_ta[o6] + bit(6) * s_eta[pt + 1] * s_ta[o6 + 1] + bit(7) * s_eta[nCp] * s_ta[FOLD ? nCo : o6 + PW] +
-                                     bit(8) * s_eta[nCp + hx] * s_ta[FOLD ? nCo + hx : o6 + PW + 1]) / wtmpU;
+                const double wU = FOLD ? (bit(5) * s_ta[o6] + bit(6) * s_ta[o6 + 1] + bit(7) * s_ta[nCp] + bit(8) * s_ta[nCp + hx]) : wtmpU;
+                e2 = wU == 0.0 ? 0.0
+                                  : (bit(5) * s_eta[pt] * s_ta[o6] + bit(6) * s_eta[pt + 1] * s_ta[o6 + 1] + bit(7) * s_eta[nCp] * s_ta[FOLD ? nCp : o6 + PW] +
+                                     bit(8) * s_eta[nCp + hx] * s_ta[FOLD ? nCp + hx : o6 + PW + 1]) / wU;
             }
             etaU = e2;
             // (a corner ON the fold: shearU as the halo update left it -- averaged with its partner)
@@ -659,12 +698,15 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         }
         __syncthreads();
         // FOLD: stress12U ON the fold -- the history takes the average of the two raw values, ice or not
-        if (onf && compU) s12v = 0.5 * (s12v + s_s12[pU]);
+        if (FU.onf && compU) s12v = 0.5 * (s12v + s_s12[FU.pU]);
         CG_STAMP(6)
 
         // ---- C ---- (FOLD: the mirrored partners of the fold row's owned cells run the N-face half for the raw vvelN)
         double vout = 0.0;
-        if (own || pown) {
+        const FoldIdx FC = fold_idx(fpk);
+        if (own || FC.pown) {
+            const bool onf = FC.onf;
+            const int pU = FC.pU, nCp = FC.nCp, frow = FC.frow;
             const double s12c = s12v, s12s = s_s12[pt - PW];
             const double s12w = onf ? 0.5 * (s_s12[pt - 1] + s_s12[pU + 1]) : s_s12[pt - 1];       // (the west corner of a fold-row cell: ON the fold)
             const double spc = sp, smc = sm;
@@ -673,7 +715,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double spe = s_sp[pt + 1], sme = s_sm[pt + 1];
                 const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
                 const double zE = REVP ? s_pc[NPC - 2][oo] : ((mb >> 9) & 1u ? -0.0 : 0.0);     // revp * uvelE_init
-                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + hdyEr * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
+                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + ((FOLD && RECOMP) ? 0.5 / s_dyE[lo] : hdyEr) * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
                 const double uold = uEo, vold = vEo;
                 const double du = uocnE - uold, dv = vocnE - vold;
                 const double vrel = facE * sqrt(du * du + dv * dv);
@@ -689,7 +731,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double spn = s_sp[nCp], smn = s_sm[nCp];
                 const double uocnN = s_pc[6][oo], vocnN = s_pc[7][oo], facN = s_pc[8][oo], massN = s_pc[9][oo], fmN = s_pc[10][oo], forceyN = s_pc[11][oo];
                 const double zN = REVP ? s_pc[NPC - 1][oo] : ((mb >> 10) & 1u ? -0.0 : 0.0);    // revp * vvelN_init
-                strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
+                strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - ((FOLD && RECOMP) ? 0.5 / s_dxN[lo] : hdxNr) * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
                 const double uold = uNo, vold = vNo;
                 const double du = uocnN - uold, dv = vocnN - vold;
                 const double vrel = facN * sqrt(du * du + dv * dv);
@@ -721,8 +763,8 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         if (FOLD && foldwin) {
             // vvelN ON the fold: what the halo update makes of the two raw values, on the tile and in the record
             __syncthreads();
-            if (own && cls == 1) {
-                const double v = fold_vec(vout, s_fr[4][1][16 - tx], fb & 4u);
+            if (own && FC.cls == 1) {
+                const double v = fold_vec(vout, s_fr[4][1][16 - tx], FC.fb & 4u);
                 s_vN[li] = v;
                 if (pub) st_rec2(wr + 2 * L, pack_rec(s_uE[li], want + 1u), pack_rec(v, want + 1u));
             }
@@ -766,7 +808,10 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         }
         if (m & 1u) A.f[CF_S12T][L] = s12T;
     }
-    if (ghostT) A.f[CF_S12T][g] = s12T;
+    if (ghostT) {        // (the ghost cell's index again, from the position it was evaluated at: not worth two registers through the loop)
+        const int gx_ = tli % LW, gy_ = tli / LW;
+        A.f[CF_S12T][(size_t)tl.x * A.plane + (size_t)(tl.z - 2 + gy_ - 1) * nx + (tl.y - 2 + gx_ - 1)] = s12T;
+    }
 }
 
 }  // namespace

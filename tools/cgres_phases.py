@@ -11,10 +11,11 @@ from cice_amd import decomp, evp, synth
 ap = argparse.ArgumentParser(); ap.add_argument("grid", nargs="?", default="gx1"); ap.add_argument("--ndte", type=int, default=120)
 a = ap.parse_args()
 spec = synth.GRIDS[a.grid]
-g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns="closed"))
+ns = spec.get("ns", "closed")
+g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns=ns))
 cg = synth.cgrid_geometry(g)
 state, inputs, masks = synth.cgrid_state(g, cg, case="full", seed=3)
-dc = decomp.Decomp(spec["nx"], spec["ny"], spec["nx"], spec["ny"], "cyclic", "closed", 1)
+dc = decomp.Decomp(spec["nx"], spec["ny"], spec["nx"], spec["ny"], "cyclic", ns, 1)
 static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
 d, keep = evp.make_dims(dc, 0)
 core = evp.EvpHip(d, evp.make_params(synth.evp_scalars(a.ndte), strict=True), static["dyE"], static["dxN"], static["dxT"],
@@ -34,5 +35,10 @@ names = ["poll", "bar0", "S", "bar1", "T", "bar2", "U+bar3", "C"]
 P = P / max(n, 1)
 for w in range(4):
     print(f" wave {w}: " + "  ".join(f"{nm} {np.median(P[:, w, k]):6.0f}" for k, nm in enumerate(names)) + f"   sum {np.median(P[:, w, :].sum(axis=1)):7.0f} cycles/subcycle")
+if ns == "tripole":      # the windows at the fold (the last window row) against the rest
+    nf = -(-spec["nx"] // 13)
+    for label, Q in (("fold windows", P[-nf:]), ("other windows", P[:-nf])):
+        for w in range(4):
+            print(f" {label} wave {w}: " + "  ".join(f"{nm} {np.median(Q[:, w, k]):6.0f}" for k, nm in enumerate(names)) + f"   sum {np.median(Q[:, w, :].sum(axis=1)):7.0f}")
 tot = P.sum(axis=2)
 print(" all waves: median sum", np.median(tot), " (100 MHz?? no: shader clock; at 2.4 GHz 1 us = 2400 cycles)")
