@@ -215,14 +215,15 @@ def test_cgrid_resident_kernel_on_a_tripole_grid_vs_oracle(bs, case, visc, lag, 
     assert np.abs(want["uvelE"]).max() > 1e-4
 
 
-def test_cgrid_run_recovers_when_a_window_is_not_resident(monkeypatch):
-    """cice_evp_hip_cgrid_run on a GPU that is not the rank's alone: one window of the resident kernel never shows up (test
+@pytest.mark.parametrize("grid", ["gx3", "tx1"])
+def test_cgrid_run_recovers_when_a_window_is_not_resident(grid, monkeypatch):
+    """(gx3; tx1: the FOLD variant, the repeat runs as five phases + fold steps)  cice_evp_hip_cgrid_run on a GPU that is not the rank's alone: one window of the resident kernel never shows up (test
     hook, real launches only), the waits on its records give up (bounded), nothing is written back, the download leaves the
     caller's arrays alone -- the call is repeated with the per-subcycle kernels and returns the oracle's answer; later calls
     stay off the resident kernel."""
     from cice_amd import synth
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_RES_DEBUG", "16")
-    dc, g, static, state, inputs, masks = synth_cgrid("gx3", case="full", seed=29)
+    dc, g, static, state, inputs, masks = synth_cgrid(grid, case="full", seed=29)
     scal = synth.evp_scalars(120)
     blks = dc.local_blocks(0)
     dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
