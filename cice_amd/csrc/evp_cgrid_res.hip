@@ -160,7 +160,6 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     constexpr int PW = (REVP && !AVGS) ? X : LW;         // row stride of the window-only planes
     constexpr int NQ = PW * Y;
     constexpr int NPC = REVP ? 18 : 16;
-    constexpr bool RECOMP = false;        // FOLD: per-cell constants one operation away from an LDS plane worked out again in every subcycle (A/B)
     // planes a level reads one position beyond the window (velocities, the averaging weights, dyE / dxN for the boundary ratios):
     // (Y+1) x (X+1); planes read inside the window only: Y x X, index = thread index
     __shared__ double s_uE[NP], s_vN[NP], s_ea[NP], s_na[NP], s_dyE[NP], s_dxN[NP];
@@ -525,16 +524,30 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         if (FOLD) {
             // the rows at the fold first work out the raw uvelU, vvelU, uvelN (all ON the fold) and vvelE (read across it) of their
             // positions, every position, ice or not (the reference's averages cover every cell), for both sides to pick up
-            const FoldIdx F = fold_idx(fpk);
-            const int nE = F.nE, frow = F.frow;
-            if (F.onf && !stat) {
-                const double uEn = -s_uE[nE], ean = s_ea[nE], uEnw = -s_uE[nE + 1], eanw = s_ea[nE + 1];
-                const double eao = s_ea[lo], nao = s_na[lo], nae = s_na[lo + 1], vNe = s_vN[li + 1];
-                const double uvm = bit(2);
-                s_fr[0][frow][tx] = avg2(uEo, eao, uEn, ean) * uvm;
-                s_fr[1][frow][tx] = avg2(vNo, nao, vNe, nae) * uvm;
-                s_fr[2][frow][tx] = tx >= 1 ? avg4(s_uE[li - 1], s_ea[lo - 1], uEo, eao, uEnw, eanw, uEn, ean) * bit(1) : 0.0;
-                s_fr[3][frow][tx] = avg4(s_vN[li - LW], s_na[lo - LW], s_vN[li - LW + 1], s_na[lo - LW + 1], vNo, nao, vNe, nae) * bit(0);
+            // (4 quantities x 2 rows x 16 columns = 128 single averages, one per thread of the waves 0 and 1 -- wave 0 the two-point, wave 1
+            // the four-point ones: the threads of the two rows themselves would run the four divisions one after the other, with the
+            // rest of the workgroup waiting at the barrier: tools/cgres_phases.py tx1, level S of the fold windows 4800 cycles against 2650)
+            if (foldwin && t < 128) {
+                int tt = t;
+                asm volatile("" : "+v"(tt));             // (not to be hoisted out of the subcycle loop: registers)
+                const int r = (tt >> 4) & 1, c = tt & 15, q = (tt >> 5) & 1;
+                const int ps = (r ? tf + 3 : tf) * LW + c;            // the position ...
+                const int pn = (r ? tf : tf + 3) * LW + 15 - c;       // ... and its E-face type "north" across the fold (vectors: sign changed)
+                const unsigned gm = s_gm[ps];
+                double v;
+                if (tt < 64) {       // q = 0 uvelU = avg2(uvelE, uvelE north) * uvm, q = 1 vvelU = avg2(vvelN, vvelN east) * uvm
+                    const double a0 = q ? s_vN[ps] : s_uE[ps], w0 = q ? s_na[ps] : s_ea[ps];
+                    const double a1 = q ? s_vN[ps + 1] : -s_uE[pn], w1 = q ? s_na[ps + 1] : s_ea[pn];
+                    v = avg2(a0, w0, a1, w1) * ((gm >> 2) & 1u ? 1.0 : 0.0);
+                } else {             // q = 0 uvelN = avg4(W, O, NW, N) * npm, q = 1 vvelE = avg4(S, SE, O, E) * epm
+                    const double a0 = q ? s_vN[ps - LW] : s_uE[ps - 1], w0 = q ? s_na[ps - LW] : s_ea[ps - 1];
+                    const double a1 = q ? s_vN[ps - LW + 1] : s_uE[ps], w1 = q ? s_na[ps - LW + 1] : s_ea[ps];
+                    const double a2 = q ? s_vN[ps] : -s_uE[pn + 1], w2 = q ? s_na[ps] : s_ea[pn + 1];
+                    const double a3 = q ? s_vN[ps + 1] : -s_uE[pn], w3 = q ? s_na[ps + 1] : s_ea[pn];
+                    v = avg4(a0, w0, a1, w1, a2, w2, a3, w3) * ((gm >> (q ? 0 : 1)) & 1u ? 1.0 : 0.0);
+                    if (!q && c == 0) v = 0.0;
+                }
+                s_fr[(tt >> 6) * 2 + q][r][c] = v;
             }
             if (foldwin) __syncthreads();
         }
@@ -621,33 +634,33 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         // ---- T ---- (at the thread's own position, or at the ghost position it serves)
         if (doT) {
             TOut r;
-            const FoldIdx FT = fold_idx(fpk);
-            if (FT.ghost) {
-                const int fgx = FT.gx;
-                // the ghost cell (i, NY+1) in its own orientation, on what the halo updates leave in its ghost neighbours: uvelE(i), uvelE(i-1)
-                // = -uvelE of row NY at the mirrored columns, vvelN(i) = -vvelN of row NY-1; vvelN south of it = the fold row's own (averaged);
-                // shearU NE, NW = row NY-1's, SE, SW = the fold row's averaged with their partners
-                const int a = (tf + 3) * LW + 15 - fgx, c = (tf + 2) * LW + 16 - fgx, d = tf * LW + fgx;
-                const int po = (tf + 2) * PW + 15 - fgx, ps = tf * PW + fgx, pp = (tf + 3) * PW + 15 - fgx;
-                int ao = a, co = c, dd = d, poo = po, pso = ps;
-                asm volatile("" : "+v"(ao), "+v"(co), "+v"(dd), "+v"(poo), "+v"(pso));
-                const double shS = 0.5 * (s_sh[ps] + s_sh[pp]), shSW = 0.5 * (s_sh[ps - 1] + s_sh[pp + 1]);
-                const double uao = s_ua[poo], uas = s_ua[pso], uasw = s_ua[pso - 1], uaw = s_ua[poo + 1];
-                r = t_stress(p, -s_uE[a], -s_uE[a + 1], -s_vN[c], s_vN[d], s_dyE[ao], s_dyE[ao + 1], s_dxN[co], s_dxN[dd], dxT2, dyT2, uao, uas, uasw, uaw,
-                             1.0 / (uao + uas + uasw + uaw), strength, DminT, s_sh[po], shS, shSW, s_sh[po + 1], sp, sm, relax);
+            if (FOLD) {
+                // ONE evaluation with selected operands (the ghost cells beyond the fold are served by threads of wave 0: two branches would
+                // run one after the other there, with the workgroup waiting).  The ghost cell (i, NY+1) is evaluated in its own orientation
+                // on what the halo updates leave in its ghost neighbours: uvelE(i), uvelE(i-1) = -uvelE of row NY at the mirrored columns,
+                // vvelN(i) = -vvelN of row NY-1, vvelN south of it = the fold row's own (averaged); shearU NE, NW = row NY-1's, SE, SW = the
+                // fold row's averaged with their partners.  An ordinary position in a row at the fold: its own and its west corner averaged.
+                const FoldIdx FT = fold_idx(fpk);
+                const bool gh = FT.ghost;
+                const int gx = FT.gx;
+                const int a = (tf + 3) * LW + 15 - gx, c = (tf + 2) * LW + 16 - gx, d = tf * LW + gx;
+                const int po = (tf + 2) * PW + 15 - gx, ps = tf * PW + gx, pp = (tf + 3) * PW + 15 - gx;
+                const int iE0 = gh ? a : tli, iE1 = gh ? a + 1 : tli - 1, iN0 = gh ? c : tli, iN1 = gh ? d : tli - LW;
+                const int p0 = gh ? po : t6, p1 = gh ? ps : t6 - PW, p2 = gh ? ps - 1 : t6 - PW - 1, p3 = gh ? po + 1 : t6 - 1;
+                const int pT = (FT.cls == 1 ? tf + 3 : tf) * PW + 15 - (t6 - ty * PW);       // the partner of the evaluation position's own corner
+                const bool f0 = !gh && FT.onf;
+                double uE0 = s_uE[iE0], uE1 = s_uE[iE1], vN0 = s_vN[iN0];
+                if (gh) { uE0 = -uE0; uE1 = -uE1; vN0 = -vN0; }
+                double sh0 = s_sh[p0], sh1 = s_sh[p1], sh2 = s_sh[p2], sh3 = s_sh[p3];
+                const double x0 = s_sh[f0 ? pT : p0], x3 = s_sh[f0 ? pT + 1 : p3], x1 = s_sh[gh ? pp : p1], x2 = s_sh[gh ? pp + 1 : p2];
+                if (f0) { sh0 = 0.5 * (sh0 + x0); sh3 = 0.5 * (sh3 + x3); }
+                if (gh) { sh1 = 0.5 * (sh1 + x1); sh2 = 0.5 * (sh2 + x2); }
+                r = t_stress(p, uE0, uE1, vN0, s_vN[iN1], s_dyE[iE0], s_dyE[iE1], s_dxN[iN0], s_dxN[iN1], dxT2, dyT2, s_ua[p0], s_ua[p1], s_ua[p2], s_ua[p3],
+                             uareaavgr, strength, DminT, sh0, sh1, sh2, sh3, sp, sm, relax);
             } else {
-                double shO = s_sh[t6], shW = s_sh[t6 - 1];
-                if (FT.onf) {            // the two corners ON the fold: averaged with their partners (scalars: 0.5 * (x_lo + x_hi))
-                    const int pT = (FT.cls == 1 ? tf + 3 : tf) * PW + 15 - (t6 - ty * PW);      // the partner of the evaluation position's own corner
-                    shO = 0.5 * (shO + s_sh[pT]);
-                    shW = 0.5 * (shW + s_sh[pT + 1]);
-                }
-                // (FOLD: the few per-cell constants that are one operation away from an LDS plane are worked out again in every subcycle
-                // -- this variant has no registers to keep them in; same expression, same bits)
-                const double uao = s_ua[to6], uas = s_ua[to6 - PW], uasw = s_ua[to6 - PW - 1], uaw = s_ua[to6 - 1];
-                r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2, dyT2, uao, uas,
-                             uasw, uaw, FOLD ? 1.0 / (uao + uas + uasw + uaw) : uareaavgr, strength, DminT, shO, s_sh[t6 - PW], s_sh[t6 - PW - 1], shW, sp,
-                             sm, relax);
+                r = t_stress(p, s_uE[tli], s_uE[tli - 1], s_vN[tli], s_vN[tli - LW], s_dyE[to], s_dyE[to - 1], s_dxN[to], s_dxN[to - LW], dxT2, dyT2,
+                             s_ua[to6], s_ua[to6 - PW], s_ua[to6 - PW - 1], s_ua[to6 - 1], uareaavgr, strength, DminT, s_sh[t6], s_sh[t6 - PW],
+                             s_sh[t6 - PW - 1], s_sh[t6 - 1], sp, sm, relax);
             }
             if (compT) {
                 sp = r.sp; sm = r.sm;
@@ -715,7 +728,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double spe = s_sp[pt + 1], sme = s_sm[pt + 1];
                 const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
                 const double zE = REVP ? s_pc[NPC - 2][oo] : ((mb >> 9) & 1u ? -0.0 : 0.0);     // revp * uvelE_init
-                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + ((FOLD && RECOMP) ? 0.5 / s_dyE[lo] : hdyEr) * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
+                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + hdyEr * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
                 const double uold = uEo, vold = vEo;
                 const double du = uocnE - uold, dv = vocnE - vold;
                 const double vrel = facE * sqrt(du * du + dv * dv);
@@ -731,7 +744,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double spn = s_sp[nCp], smn = s_sm[nCp];
                 const double uocnN = s_pc[6][oo], vocnN = s_pc[7][oo], facN = s_pc[8][oo], massN = s_pc[9][oo], fmN = s_pc[10][oo], forceyN = s_pc[11][oo];
                 const double zN = REVP ? s_pc[NPC - 1][oo] : ((mb >> 10) & 1u ? -0.0 : 0.0);    // revp * vvelN_init
-                strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - ((FOLD && RECOMP) ? 0.5 / s_dxN[lo] : hdxNr) * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
+                strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
                 const double uold = uNo, vold = vNo;
                 const double du = uocnN - uold, dv = vocnN - vold;
                 const double vrel = facN * sqrt(du * du + dv * dv);
