@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "evp_device.h"
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // what a position that does not compute a level shows its neighbours: the array's value, unchanged through the loop
     // (a corner ON the fold without ice: strain_rates_U's zero fill, which the halo update then averages with its partner)
     int pt = ty * PW + tx;               // this position in the window-only planes
-    const int nCp = onf ? orow * PW + 16 - tx : pt + PW;     // centre type "north" / the corner's partner, in those planes
+    const int nCp = onf ? orow * PW + (tx ? 16 - tx : 15) : pt + PW;     // centre type "north" / the corner's partner, in those planes (tx = 0: unused)
     const int pU = onf ? orow * PW + 15 - tx : pt;
     s_sh[pt] = (onf && !compS && !stat) ? 0.0 : A.f[CF_SHEARU][L];
     s_eta[pt] = A.f[CF_ETA][L];
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         r.frow = r.cls == 3 ? 1 : 0;
         const int orw = r.cls == 1 ? tf + 3 : tf;
         r.nE = r.onf ? orw * LW + 15 - tx : li + LW;
-        r.nCp = r.onf ? orw * PW + 16 - tx : pt + PW;
+        r.nCp = r.onf ? orw * PW + (tx ? 16 - tx : 15) : pt + PW;
         r.pU = r.onf ? orw * PW + 15 - tx : pt;
         r.hx = r.onf ? -1 : 1;
         return r;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     };
     __syncthreads();               // (every thread has read the source table for the last time: its plane takes stress12U)
     s_s12[pt] = s12v;
-    if (REVP && own) { s_pc[NPC - 2][oi] = zE0; s_pc[NPC - 1][oi] = zN0; }
+    if (REVP && (own || pown)) { s_pc[NPC - 2][oi] = zE0; s_pc[NPC - 1][oi] = zN0; }
     // initial records (tag of subcycle 0) so that the neighbours' first poll finds them; also the proof that they are resident
     if (pub) st_rec2((v4u *)R.rec[R.par0 & 1] + 2 * L, pack_rec(s_uE[li], R.tag_base), pack_rec(s_vN[li], R.tag_base));
     __syncthreads();
@@ -853,22 +854,30 @@ void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pair
     hipLaunchKernelGGL(cg_res_pair_check, dim3((n + 255) / 256), dim3(256), 0, st, F, pairs, n, flags);
 }
 
-int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold)
+namespace {
+// Workgroups of one variant a CU holds at once: what the runtime says, and not more than the LDS allows when a workgroup's share is
+// rounded up to 2 KB (the revised-EVP avg_zeta FOLD variant, 54 248 B, was reported as three per CU and ran as two: its waits gave up)
+template <class K>
+int blocks_per_cu(K kernel)
 {
     int nb = 0;
-    hipError_t e;
-    if (fold) {          // (tripole grids: classic EVP only)
-        if (revised) return 0;
-        e = avg_strength ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, false, true>, X * Y, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, false, true>, X * Y, 0);
-    } else if (avg_strength) {
-        e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, true, false>, X * Y, 0)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<true, false, false>, X * Y, 0);
-    } else {
-        e = revised ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, true, false>, X * Y, 0)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cg_res<false, false, false>, X * Y, 0);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, X * Y, 0) != hipSuccess) return 0;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel)) != hipSuccess) return 0;
+    const size_t share = (fa.sharedSizeBytes + 2047) / 2048 * 2048;
+    if (share) nb = std::min<int>(nb, (int)(160 * 1024 / share));
+    return nb;
+}
+}  // namespace
+
+int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold)
+{
+    if (fold) {
+        if (avg_strength) return revised ? blocks_per_cu(cg_res<true, true, true>) : blocks_per_cu(cg_res<true, false, true>);
+        return revised ? blocks_per_cu(cg_res<false, true, true>) : blocks_per_cu(cg_res<false, false, true>);
     }
-    return e == hipSuccess ? nb : 0;
+    if (avg_strength) return revised ? blocks_per_cu(cg_res<true, true, false>) : blocks_per_cu(cg_res<true, false, false>);
+    return revised ? blocks_per_cu(cg_res<false, true, false>) : blocks_per_cu(cg_res<false, false, false>);
 }
 
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st)
@@ -876,8 +885,13 @@ void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st)
     const dim3 grid(R.ntiles), block(X * Y);
     const bool revised = A.p.revp != 0.0;
     if (R.fold) {
-        if (A.avg_strength) hipLaunchKernelGGL((cg_res<true, false, true>), grid, block, 0, st, A, R);
-        else hipLaunchKernelGGL((cg_res<false, false, true>), grid, block, 0, st, A, R);
+        if (A.avg_strength) {
+            if (revised) hipLaunchKernelGGL((cg_res<true, true, true>), grid, block, 0, st, A, R);
+            else hipLaunchKernelGGL((cg_res<true, false, true>), grid, block, 0, st, A, R);
+        } else {
+            if (revised) hipLaunchKernelGGL((cg_res<false, true, true>), grid, block, 0, st, A, R);
+            else hipLaunchKernelGGL((cg_res<false, false, true>), grid, block, 0, st, A, R);
+        }
     } else if (A.avg_strength) {
         if (revised) hipLaunchKernelGGL((cg_res<true, true, false>), grid, block, 0, st, A, R);
         else hipLaunchKernelGGL((cg_res<true, false, false>), grid, block, 0, st, A, R);

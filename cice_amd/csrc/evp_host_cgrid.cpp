@@ -668,8 +668,8 @@ static bool res_eligible(std::string *why = nullptr)
     auto no = [&](const char *w) { if (why) *why = w; return false; };
     const CGridState::Res &Q = CG.res;
     if (CG.tripole) {
-        // a u-fold on one rank, classic EVP: the kernel's FOLD variant (the first subcycle of a call runs as the five phases)
-        if (CG.tfold || remote() || S.prm.revp != 0.0) return no("a T-fold, several ranks, or revised EVP on a tripole grid");
+        // a u-fold on one rank: the kernel's FOLD variant (the first subcycle of a call runs as the five phases)
+        if (CG.tfold || remote()) return no("a T-fold, or several ranks on a tripole grid");
     } else if (!CG.one.tab || remote() || !fused_schedule() || !one_launch()) {
         return no("several ranks, a block too small, or the one-launch schedule switched off");
     }

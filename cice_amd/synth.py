@@ -31,6 +31,8 @@ GRIDS = {
     "q1": dict(nx=1440, ny=1080, dx0=2.8e4, ns="closed"),    # the whole 0.25-degree class grid
     # 320 tiles of 16x16: every CU holds one or two tiles of the on-chip resident kernel (pace of a SIMD with two waves)
     "p2": dict(nx=300, ny=240, dx0=1.1e5, ns="closed"),
+    # a small tripole grid (tests: every variant of the resident C-grid kernel's FOLD form fits with two workgroups per CU)
+    "tx3": dict(nx=100, ny=116, dx0=3.3e5, ns="tripole"),
 }
 
 

@@ -110,7 +110,7 @@ def test_cgrid_deformations_t_on_device_bitwise(name):
 def test_cgrid_resident_kernel_bitwise(monkeypatch):
     """The on-chip resident C-grid kernel (evp_cgrid_res.hip: all subcycles of a call but the first after an upload in ONE launch,
     state in registers and LDS, face velocities traded between windows as tagged records) forced on: every fixture it is
-    eligible for -- one rank, no T-fold, the default-configuration shortcuts, classic EVP on a tripole grid -- bit-identical to the
+    eligible for -- one rank, no T-fold, the default-configuration shortcuts -- bit-identical to the
     reference's arrays, ghost cells included, in one call and across calls; the others must refuse loudly.  Forced off, the
     one-launch kernel gives the same bits."""
     ran, refused = [], []
@@ -162,21 +162,27 @@ def test_cgrid_resident_kernel_survives_lagging_windows(case, monkeypatch):
     assert np.abs(want["uvelE"]).max() > 1e-4
 
 
-@pytest.mark.parametrize("bs,case,visc,lag", [(None, "full", "avg_zeta", False), ((90, 60), "caps", "avg_strength", True),
-                                              ((360, 46), "full", "avg_zeta", True), ((75, 240), "caps", "avg_zeta", False)])
-def test_cgrid_resident_kernel_on_a_tripole_grid_vs_oracle(bs, case, visc, lag, monkeypatch):
+@pytest.mark.parametrize("bs,case,visc,lag,revised", [(None, "full", "avg_zeta", False, False), ((90, 60), "caps", "avg_strength", True, False),
+                                                      ((360, 46), "full", "avg_zeta", True, False), ((75, 240), "caps", "avg_zeta", False, False),
+                                                      ((180, 120), "full", "avg_strength", False, True), (None, "caps", "avg_strength", False, True),
+                                                      # (revised EVP with avg_zeta: the variant with the most LDS holds two workgroups per CU -- a smaller grid)
+                                                      ("tx3", "full", "avg_zeta", False, True), ("tx3", "caps", "avg_zeta", True, False)])
+def test_cgrid_resident_kernel_on_a_tripole_grid_vs_oracle(bs, case, visc, lag, revised, monkeypatch):
     """tx1 (360 x 240, u-fold): the resident kernel's FOLD variant forced on -- the windows at the fold carry a mirrored mini-tile in
     source orientation and build every value ON the fold (vvelN, uvelN, uvelU, vvelU, shearU, stress12U) from both sides' raw values
     -- bit-identical to the oracle, ghost cells included: one block, blocks cut in both directions (the mirrored cells of a window in
     another block; a block at the fold with fewer than eleven rows), the poles inside a window and at a window's edge; with every
-    fourth window lagging (test hook) the same bits.  The first subcycle of the call runs as the five phases."""
+    fourth window lagging (test hook) the same bits; classic and revised EVP.  The first subcycle of the call runs as the five phases."""
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "1")
     if lag:
         monkeypatch.setenv("CICE_EVP_HIP_CGRID_RES_DEBUG", "8")
     from cice_amd import synth
-    dc, g, static, state, inputs, masks = synth_cgrid("tx1", case=case, bs=bs, seed=41)
+    grid = "tx1"
+    if bs == "tx3":
+        grid, bs = "tx3", None
+    dc, g, static, state, inputs, masks = synth_cgrid(grid, case=case, bs=bs, seed=41)
     ndte = 24
-    scal = synth.evp_scalars(120)
+    scal = synth.evp_scalars(120, **(dict(revised_evp=True) if revised else {}))
     blks = dc.local_blocks(0)
     dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
                               [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
