@@ -724,12 +724,14 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             const double s12c = s12v, s12s = s_s12[pt - PW];
             const double s12w = onf ? 0.5 * (s_s12[pt - 1] + s_s12[pU + 1]) : s_s12[pt - 1];       // (the west corner of a fold-row cell: ON the fold)
             const double spc = sp, smc = sm;
-            double unew = 0.0, vnew, strintx = 0.0, strinty, taubx = 0.0, tauby;
-            if (own) {
+            double unew, vnew, strintx, strinty, taubx, tauby;
+            // (FOLD: the partner threads run the E-face half too, on operands nobody set and for nobody to read -- one basic block with the
+            // N-face half, as in the plain variant)
+            {
                 const double spe = s_sp[pt + 1], sme = s_sm[pt + 1];
                 const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
                 const double zE = REVP ? s_pc[NPC - 2][oo] : ((mb >> 9) & 1u ? -0.0 : 0.0);     // revp * uvelE_init
-                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + hdyEr * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
+                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + (FOLD ? 0.5 / s_dyE[lo] : hdyEr) * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
                 const double uold = uEo, vold = vEo;
                 const double du = uocnE - uold, dv = vocnE - vold;
                 const double vrel = facE * sqrt(du * du + dv * dv);
