@@ -641,6 +641,25 @@ def main():
         # kernels per subcycle: cg_res (evp_cgrid_res.hip: every subcycle of a call but the first after an upload inside ONE launch),
         # cg_one, or the fused schedule (evp_cgrid.hip)
         launches = (1.0 / res_n) if res_n else (1 if one else 10 if ns == "tripole" else 3)
+        # the resident kernel is not bound by HBM: its share of the chip's fp64 issue slots, from the committed PMC pass of the same kernel
+        # on the same grid (tools/profile_gpu.sh cgx1res / cgtx1res: launches of 120 subcycles) over the live time -- withheld unless the
+        # pass ran this kernel variant with this many waves
+        issue = None
+        if res_n:
+            pmc, pmc_file = load_pmc()
+            e = ((pmc or {}).get("kernels", {}).get({"gx1": "cgx1res", "tx1": "cgtx1res"}.get(workload, ""), {}) or {}).get("resident")
+            sq = (e or {}).get("sq") or {}
+            busy, waves = sq.get("valu_busy_simd_cycles_per_launch"), sq.get("waves_per_launch")
+            live_waves = 4 * sum((-(-b.gnx // 13)) * (-(-(b.gny - (11 if ns == "tripole" and b.gj0 + b.gny - 1 == ny else 0)) // 13) +
+                                                     (1 if ns == "tripole" and b.gj0 + b.gny - 1 == ny else 0)) for b in dc.local_blocks(0))
+            want_kernel = "cg_res<false, false, true>" if ns == "tripole" else "cg_res<false, false, false>"
+            if busy and waves == live_waves and want_kernel in (e["kernel_trace"]["name"] or ""):
+                t_k = ev_ms * 1e-3 / steps            # one launch = one call of res_n subcycles
+                issue = {"bound": "fp64_valu", "frac": busy * (res_n / 120.0) / t_k / (N_SIMD * MAX_CLOCK_HZ), "unit": "share of VALU-busy SIMD-cycles",
+                         "valu_busy_simd_cycles_per_subcycle": busy / 120.0, "valu_insts_per_wave_per_subcycle": (sq.get("valu_insts_per_launch") or 0) / waves / 120.0,
+                         "pmc_source": f"{pmc_file}#{'cgtx1res' if ns == 'tripole' else 'cgx1res'}",
+                         "note": "SQ_ACTIVE_INST_VALU x 4 of the committed pass (launches of 120 subcycles) / live kernel time / (1024 SIMDs x 2.4 GHz); "
+                                 "the rest of a subcycle is the hand-off between windows (tools/cgres_phases.py)"}
         one = one or bool(res_n)
         t_sub = ev_ms * 1e-3 / (steps * ndte)
         alg = ((CGRID_B_ALG_ONE_GEO if geo else CGRID_B_ALG_ONE) if one else (CGRID_B_ALG_GEO if geo else CGRID_B_ALG)) * nx * ny
@@ -654,6 +673,7 @@ def main():
                 "verified": (h.hexdigest() == want["sha256"]) if want else None,
                 "checked_against": "tests/golden/bench_checksums.json (oracle/evp_oracle.c, pinned to the reference's evp() with grid_ice='C')" if want else None,
                 "finite": bool(np.isfinite(out["uvelE"]).all()), "max_abs_uE": float(np.abs(out["uvelE"]).max()),
+                "fp64_issue": issue,
                 "roofline": {"bound": "hbm", "achieved": alg / t_sub / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / t_sub / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_subcycle": alg,
                              "geometry_derived": bool(geo),

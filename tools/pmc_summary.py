@@ -133,7 +133,7 @@ def main():
         if not st.exists():
             continue
         entry = {}
-        for tag, match in ({"resident": "cg_res"} if key.endswith("res") else {"one_launch": "cg_one"} if key.endswith("one") else CG).items():
+        for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"one_launch": "cg_one"} if key.endswith("one") else CG).items():
             e = {"kernel_trace": kernel_stats(st, match)}
             for p, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
                 f = d / f"{key}_{p}_counter_collection.csv"
@@ -155,6 +155,8 @@ def main():
             if sq.get("SQ_WAVE_CYCLES"):
                 e["sq"] = {"valu_insts_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"] if sq.get("SQ_WAVES") else None,
                            "waves_per_launch": sq.get("SQ_WAVES"),
+                           "valu_busy_simd_cycles_per_launch": (sq["SQ_ACTIVE_INST_VALU"] * 4.0) if sq.get("SQ_ACTIVE_INST_VALU") else None,
+                           "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"),
                            "wave_cycles_share": {k: sq[k] / sq["SQ_WAVE_CYCLES"] for k in
                                                  ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if sq.get(k)},
                            "valu_busy_frac_of_max_clock_in_pmc_pass": sq["SQ_ACTIVE_INST_VALU"] * 4.0 /
