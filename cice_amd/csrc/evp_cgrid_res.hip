@@ -26,6 +26,11 @@
 // window mirrors publishes every subcycle, ice or not (geometry only, never the masks): a window cannot run more than one
 // subcycle ahead of a window that still reads its records, so two record buffers (subcycle parity) suffice.  Every spin is
 // bounded and raises the error word.  fp64, strict: no FMA contraction, the reference's operation order.
+//
+// Windows without ice do not run (per call: cg_res_live, R.order / R.live): a window none of whose positions -- rim, mirrored rows and
+// the ghost T cells it serves included -- carries ice in any of the four masks changes nothing in a call; its cells keep the values
+// every reader loaded at the start, so a reader does not poll a cell of such a window.  What is launched, and has to be co-resident, is
+// the list of windows with ice: a grid ten times the chip's size runs here when a tenth of its windows hold ice.
 // =====================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // every thread has read the table for the last time)
     int *const s_src = reinterpret_cast<int *>(&s_s12[0]);
     static_assert(sizeof(double) * NQ >= sizeof(int) * NP, "s_src does not fit its alias");
-    __shared__ uint8_t s_gm[NP];           // land masks of the position's cell: bit0 epm, 1 npm, 2 uvm, 3 hm
+    __shared__ uint8_t s_gm[NP];           // land masks of the position's cell: bit0 epm, 1 npm, 2 uvm, 3 hm; bit 4: its window runs
     __shared__ int s_bad;
     // FOLD: raw values of the two rows at the fold, [.][0] the window's own fold row, [.][1] the mirrored one: uvelU, vvelU, uvelN, vvelE
     // (level S), the new vvelN (level C)
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     const int t = threadIdx.x;
     const int tx = t & (X - 1), ty = t / X;
     int li = ty * LW + tx;
-    const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
+    const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;        // (the windows with ice of this call)
     // test hooks (test build only; CICE_EVP_HIP_CGRID_RES_DEBUG): 8 = every fourth window lags 10 us per subcycle (the results must not
     // change), 16 = window 1 never shows up in a real launch (every wait on its records gives up: the caller must hear about it)
     if ((CGRES_DBG(R) & 16) && tile == 1 && !R.dry) return;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             s_ua[(e / LW) * PW + e % LW] = G(CG_UAREA)[c];
             if (!AVGS) s_ta[(e / LW) * PW + e % LW] = G(CG_TAREA)[c];
         }
-        s_gm[e] = R.gmask[c];
+        s_gm[e] = (uint8_t)(R.gmask[c] | ((!R.live || R.live[c]) ? 16u : 0u));       // bit 4: the cell's window runs in this call
     }
     if (t == 0) s_bad = 0;
     const int lr = R.tab[(size_t)tile * NP + li];
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
         const int gi = tl.y - 2 + ex, gj = tl.z - 2 + ey;
         const bool mine = ex >= 2 && ex <= X - 2 && ey >= 2 && ey <= Y - 2 && gi <= q.y && gj <= jmax;
         const int sc = s_src[e];
-        return (mine || sc < 0) ? -1 : sc;
+        return (mine || sc < 0 || !(s_gm[e] & 16u)) ? -1 : sc;        // (a cell of a window without ice: the value loaded above stays)
     };
     // All entries sit in wave 0, two per lane, both requested before either is looked at: ONE polling wave per workgroup.
     // (Measured on gx1, tools/cgres_phases.py: the entries dealt round-robin to all four waves, one per thread -- every wave of
@@ -831,6 +836,38 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 }
 
 }  // namespace
+
+// Per call (after the mask byte is composed): which windows hold ice.  One workgroup per window: any of the four ice masks set in the
+// source cell of any position, or in any array cell of the window's footprint in its block (the ghost T cells of column ihi+1 / row
+// jhi+1 it serves are array cells there).  live_win[w] = 0 / 1; live_cell[c] = live_win of the window that owns c.
+namespace {
+__global__ __launch_bounds__(256) void cg_res_live(EvpCgrid A, const int *__restrict__ tab, const int4 *__restrict__ tiles, int fold, int *live_win,
+                                                    uint8_t *live_cell)
+{
+    const int w = blockIdx.x, t = threadIdx.x;
+    const int4 tl = tiles[w];
+    const int4 q = A.blk[tl.x];
+    int any = 0;
+    for (int e = t; e < NP; e += 256) {
+        const int lr = tab[(size_t)w * NP + e];
+        if (lr >= 0) any |= A.mask[lr] & 15u;
+        const int i = tl.y - 2 + e % LW, j = tl.z - 2 + e / LW;
+        if (i >= 1 && i <= A.nx && j >= 1 && j <= A.ny) any |= A.mask[(size_t)tl.x * A.plane + (size_t)(j - 1) * A.nx + (i - 1)] & 15u;
+    }
+    const int live = __syncthreads_or(any) ? 1 : 0;
+    if (t == 0) live_win[w] = live;
+    const int jmax = fold ? (tl.w >> 16) : q.w;
+    for (int e = t; e < NP; e += 256) {
+        const int ex = e % LW, ey = e / LW, i = tl.y - 2 + ex, j = tl.z - 2 + ey;
+        if (ex >= 2 && ex <= X - 2 && ey >= 2 && ey <= Y - 2 && i <= q.y && j <= jmax) live_cell[tab[(size_t)w * NP + e]] = (uint8_t)live;
+    }
+}
+}  // namespace
+
+void evp_launch_cgrid_res_live(const EvpCgrid &A, const int *tab, const int4 *tiles, int ntiles, int fold, int *live_win, uint8_t *live_cell, hipStream_t st)
+{
+    if (ntiles > 0) hipLaunchKernelGGL(cg_res_live, dim3(ntiles), dim3(256), 0, st, A, tab, tiles, fold, live_win, live_cell);
+}
 
 // Per call: the loop's state in pairs of ghost cells OUTSIDE the domain that the kernel treats as one position (pairs: host-built,
 // evp_host_cgrid.cpp build_res_tables) must agree bit for bit -- uvelE, vvelN, stresspT, stressmT, stress12U.  Bit 8 of *flags else.

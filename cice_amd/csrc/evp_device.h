@@ -389,8 +389,9 @@ struct EvpCgRes {
     const int4 *tiles;            // block, first owned i, first owned j (1-based), fold: fold window | tf << 8 | last owned row << 16
     const int4 *tiles2;           // fold (tripole grids): global column of tile column 0, NX, -, -   (halo_plan.cpp: build_fold_window_table)
     int fold;                     // 1: tripole (u-fold) grid, the kernel's FOLD variant
-    const int *order;             // [ntiles] window run by workgroup w (NULL: identity)
-    int ntiles;
+    const int *order;             // [ntiles] window run by workgroup w (NULL: identity): the windows that hold ice in this call
+    int ntiles;                   // ... and how many there are
+    const uint8_t *live;          // per cell: its window runs in this call (NULL: all do)
     int nsub;                     // subcycles of this launch; the last one ends the call (the once-per-call arrays are stored in it)
     int dry;                      // 1: residency + timing probe, nothing written back
     int par0;                     // which of rec[0/1] holds the records of subcycle index 0 of this launch
@@ -411,6 +412,7 @@ struct EvpCgRes {
 int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold);
 void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pairs, int n, unsigned *flags, hipStream_t st);
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st);
+void evp_launch_cgrid_res_live(const EvpCgrid &A, const int *tab, const int4 *tiles, int ntiles, int fold, int *live_win, uint8_t *live_cell, hipStream_t st);
 // phase: 0 strain_rates_U, 1 stressC_T, 2 T->U viscosity + stressC_U, 3 div_stress + stepu_C/stepv_C,
 //        4 face->face and face->corner velocity averages, 5 strengthU (once per call), 6 zero what the reference's
 //        whole-array zero fills leave zero outside the interior (uvelN, vvelE, uvel, vvel; once per call)

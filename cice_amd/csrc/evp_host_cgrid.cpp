@@ -48,7 +48,11 @@ struct CGridState {
         uint8_t *gmask = nullptr;    // tripole grids: the land masks as bits (elsewhere CG.gmask, which the one-launch kernels share)
         void *rec = nullptr;         // 2 x S.n records of 32 bytes
         int *err = nullptr;
-        int *order = nullptr;        // A/B (test build): window run by workgroup w
+        int *d_order = nullptr;      // the windows that hold ice in this call (cg_res_live at every upload), n_live of them
+        int *live_win = nullptr;     // [ntiles] 0 / 1
+        uint8_t *live_cell = nullptr;   // per cell: its window runs in this call
+        int n_live = 0;
+        std::vector<int> h_live;
         unsigned epoch = 0;
         int par = 0;
         bool images_ok = false;      // every ghost cell's static arrays equal its source's bit for bit
@@ -115,7 +119,7 @@ void cgrid_free()
     F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
     CG.one = CGridState::One{};
-    F(CG.res.tab); F(CG.res.tiles); F(CG.res.tiles2); F(CG.res.pubmap); F(CG.res.gmask); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs); F(CG.res.prof); F(CG.res.order);
+    F(CG.res.tab); F(CG.res.tiles); F(CG.res.tiles2); F(CG.res.pubmap); F(CG.res.gmask); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs); F(CG.res.prof); F(CG.res.d_order); F(CG.res.live_win); F(CG.res.live_cell);
     CG.res = CGridState::Res{};
     {
         CGridState::Prep &Q = CG.prep;
@@ -569,7 +573,7 @@ static int build_res_tables(const double *const *static23)
         long nw = 0;
         for (int b = 0; b < S.d.nblocks; ++b)
             nw += (long)((S.ihi[b] - S.ilo[b] + RX - 3) / (RX - 3)) * ((S.jhi[b] - S.jlo[b] + RY - 3) / (RY - 3));
-        if (nw > 2048) {
+        if (nw > 16384) {     // (only the windows that hold ice have to be resident, per call: cg_res_live)
             Q.why = "more windows than can ever be resident at once (" + std::to_string(nw) + ")";
             return 0;
         }
@@ -577,7 +581,7 @@ static int build_res_tables(const double *const *static23)
     std::vector<int32_t> tab, tiles, tiles2;
     if (tripole) {
         if (!build_fold_window_table(d, P, tiles, tiles2, tab, Q.why)) return 0;
-        if ((long)tiles.size() / 4 > 2048) { Q.why = "more windows than can ever be resident at once"; return 0; }
+        if ((long)tiles.size() / 4 > 16384) { Q.why = "more windows than can ever be resident at once"; return 0; }
         // the land masks as bits, the boundary ratios' identities (the five-phase kernels of these grids load all 23 arrays: no gmask yet)
         const std::vector<uint8_t> gm = derive_geometry_check(static23, Q.why, false);
         if (gm.empty()) return 0;
@@ -655,6 +659,16 @@ static int build_res_tables(const double *const *static23)
     HIPC(hipMemcpy(Q.pubmap, pub.data(), S.n, hipMemcpyHostToDevice));
     HIPC(hipMemset(Q.rec, 0, (size_t)2 * S.n * 32));
     HIPC(hipMemset(Q.err, 0, 8 * sizeof(int)));
+    {   // until the first upload says otherwise: every window runs
+        std::vector<int> ident(Q.ntiles);
+        for (int w = 0; w < Q.ntiles; ++w) ident[w] = w;
+        HIPC(hipMalloc((void **)&Q.d_order, ident.size() * sizeof(int)));
+        HIPC(hipMalloc((void **)&Q.live_win, ident.size() * sizeof(int)));
+        HIPC(hipMalloc((void **)&Q.live_cell, S.n));
+        HIPC(hipMemcpy(Q.d_order, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPC(hipMemset(Q.live_cell, 1, S.n));
+        Q.n_live = Q.ntiles;
+    }
     hipDeviceProp_t prop;
     HIPC(hipGetDeviceProperties(&prop, S.device));
     for (int v = 0; v < 4; ++v) Q.cap4[v] = (long)evp_cgrid_res_max_blocks_per_cu(v & 1, v >> 1, tripole ? 1 : 0) * prop.multiProcessorCount;
@@ -663,6 +677,7 @@ static int build_res_tables(const double *const *static23)
 
 // eligible in this call: one rank, no fold (either visc_method, classic or revised EVP), the default-configuration shortcuts hold on every ice cell, the static
 // identities hold (the kernel takes -1 for a boundary ratio away from a coast), every window co-resident
+static bool res_cull() { return !(env_test("CICE_EVP_HIP_CGRID_RES_CULL") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_CULL"))); }
 static bool res_eligible(std::string *why = nullptr)
 {
     auto no = [&](const char *w) { if (why) *why = w; return false; };
@@ -677,7 +692,8 @@ static bool res_eligible(std::string *why = nullptr)
     if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
     if (CG.tripole ? !Q.gmask : !geo_derived()) return no("a start-up identity of the static arrays does not hold");
     if (!Q.pairs_state_ok) return no("ghost cells outside the domain that the kernel treats as one position hold different state");
-    if ((long)Q.ntiles > Q.cap4[(CG.avg_strength ? 1 : 0) | (S.prm.revp != 0.0 ? 2 : 0)]) return no("more windows than can be resident at once");
+    if (Q.n_live < 1) return no("no window holds ice");
+    if ((long)(res_cull() ? Q.n_live : Q.ntiles) > Q.cap4[(CG.avg_strength ? 1 : 0) | (S.prm.revp != 0.0 ? 2 : 0)]) return no("more windows with ice than can be resident at once");
     return true;
 }
 
@@ -689,27 +705,9 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     R.tiles2 = Q.tiles2; R.fold = CG.tripole ? 1 : 0;
     R.long_sleep = env_test("CICE_EVP_HIP_CGRID_RES_SLEEP") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_SLEEP")) ? 1 : 0;
     R.dbg = env_test("CICE_EVP_HIP_CGRID_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_DEBUG")) : 0;
-    if (env_test("CICE_EVP_HIP_CGRID_RES_XCD") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_XCD"))) {
-        // A/B (test build): workgroup w runs on XCD w % 8 -- give each XCD one contiguous run of the (row-major) window list
-        if (!Q.order) {
-            std::vector<int> ord(Q.ntiles);
-            const int per = (Q.ntiles + 7) / 8;
-            std::vector<int> seq;
-            for (int x = 0; x < 8; ++x) for (int k = 0; k < per; ++k) if (x * per + k < Q.ntiles) seq.push_back(x * per + k);
-            // block w -> the (w >> 3)-th window of XCD (w & 7)'s run, where it exists; the rest fill up in order
-            std::vector<char> used(Q.ntiles, 0);
-            std::vector<int> left;
-            for (int w = 0; w < Q.ntiles; ++w) {
-                const int x = w & 7, k = w >> 3, cand = x * per + k;
-                if (k < per && cand < Q.ntiles && !used[cand]) { ord[w] = cand; used[cand] = 1; } else ord[w] = -1;
-            }
-            for (int c = 0; c < Q.ntiles; ++c) if (!used[c]) left.push_back(c);
-            size_t li = 0;
-            for (int w = 0; w < Q.ntiles; ++w) if (ord[w] < 0) ord[w] = left[li++];
-            HIPC(hipMalloc((void **)&Q.order, ord.size() * sizeof(int)));
-            HIPC(hipMemcpy(Q.order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice));
-        }
-        R.order = Q.order;
+    // the windows that hold ice in this call (finish_upload: cg_res_live); CICE_EVP_HIP_CGRID_RES_CULL=0 (test build) runs them all
+    if (res_cull()) {
+        R.order = Q.d_order; R.ntiles = Q.n_live; R.live = Q.live_cell;
     }
     R.nsub = nsub; R.dry = dry ? 1 : 0;
     Q.epoch = (Q.epoch + 1u) & 0xFFFFFu;
@@ -950,6 +948,13 @@ int finish_upload(int32_t visc_method)
             evp_launch_cgrid_res_pair_check(five, CG.res.pairs, CG.res.npairs, CG.d_flags, S.stream);
         }
         HIPC(hipMemcpyAsync(&h_flags, CG.d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+        if (CG.res.tab) {        // which windows of the resident kernel hold ice in this call
+            CGridState::Res &Q = CG.res;
+            HIPC(hipMemsetAsync(Q.live_cell, 0, S.n, S.stream));
+            evp_launch_cgrid_res_live(A, Q.tab, Q.tiles, Q.ntiles, CG.tripole ? 1 : 0, Q.live_win, Q.live_cell, S.stream);
+            Q.h_live.resize(Q.ntiles);
+            HIPC(hipMemcpyAsync(Q.h_live.data(), Q.live_win, (size_t)Q.ntiles * sizeof(int), hipMemcpyDeviceToHost, S.stream));
+        }
     }
     if (remote()) {                              // bit5 of ghost cells other ranks own
         EvpCgrid A;
@@ -967,6 +972,14 @@ int finish_upload(int32_t visc_method)
     HIPC(hipStreamSynchronize(S.stream));       // the caller may change its arrays after this returns
     CG.fast = (h_flags & 255u) == 0 && !(env_test("CICE_EVP_HIP_CGRID_FAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_FAST")));
     CG.res.pairs_state_ok = (h_flags & 256u) == 0;
+    if (CG.res.tab) {
+        CGridState::Res &Q = CG.res;
+        std::vector<int> ord;
+        for (int w = 0; w < Q.ntiles; ++w)
+            if (Q.h_live[w]) ord.push_back(w);
+        Q.n_live = (int)ord.size();
+        if (Q.n_live) HIPC(hipMemcpy(Q.d_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     CG.uploaded = true;
     CG.first = true;
     return 0;
@@ -1415,6 +1428,8 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     if (n >= 6) out[5] = (double)CG.res.last_nsub;    // subcycles of the last call inside ONE launch of the on-chip resident kernel
     if (n >= 7) out[6] = CG.res.t_probe_ms;           // ... and what its probe measured per subcycle, ms (-1: no probe ran)
     if (n >= 8) out[7] = (double)CG.res.fallbacks;    // cice_evp_hip_cgrid_run calls repeated without it after one of its waits gave up
+    if (n >= 9) out[8] = (double)CG.res.n_live;       // windows of the resident kernel that hold ice in this call (only they run) ...
+    if (n >= 10) out[9] = (double)CG.res.ntiles;      // ... of so many
     return 0;
 }
 

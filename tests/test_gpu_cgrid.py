@@ -221,6 +221,49 @@ def test_cgrid_resident_kernel_on_a_tripole_grid_vs_oracle(bs, case, visc, lag, 
     assert np.abs(want["uvelE"]).max() > 1e-4
 
 
+def test_cgrid_resident_kernel_runs_only_the_windows_with_ice(monkeypatch):
+    """720 x 270 (1176 windows: more than the chip holds) with ice on the polar caps only: the windows none of whose positions carry ice
+    do not run and are not polled (cg_res_live at every upload), the 659 that do fit the chip -- the resident kernel takes the call,
+    bit-identical to the oracle and to the same call with every window forced to run (test switch) or on the one-launch kernel."""
+    from cice_amd import synth
+    dc, g, static, state, inputs, masks = synth_cgrid("q8", case="caps", seed=47)
+    ndte = 12
+    scal = synth.evp_scalars(120)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    want = oracle.cgrid_subcycle(dom, prm, ndte, state, inputs, static, masks, visc_method="avg_zeta")
+    d, keep = evp.make_dims(dc, 0)
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                          1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        try:
+            core.cgrid_set_geometry(static)
+            out = core.cgrid_run(ndte, state, inputs, masks)
+            return out, core.cgrid_timings()
+        finally:
+            core.finalize()
+            for k in env:
+                monkeypatch.delenv(k)
+
+    got, t = run(CICE_EVP_HIP_CGRID_RESIDENT="1")
+    assert t["resident_windows"] > 768 and 0 < t["resident_windows_with_ice"] <= 768, t
+    assert t["resident_subcycles"] == ndte - 1 and t["resident_fallbacks"] == 0, t
+    assert_bitwise(got, want, "C grid, 720 x 270 caps, resident kernel on the windows with ice")
+    off, t0 = run(CICE_EVP_HIP_CGRID_RESIDENT="0")
+    assert t0["resident_subcycles"] == 0 and t0["one_launch_subcycles"] > 0
+    assert_bitwise(off, want, "C grid, 720 x 270 caps, one-launch kernel")
+    # every window forced to run: too many for the chip -- the library must say so when the kernel is demanded
+    with pytest.raises(evp.EvpHipError, match="not applicable"):
+        run(CICE_EVP_HIP_CGRID_RESIDENT="1", CICE_EVP_HIP_CGRID_RES_CULL="0")
+
+
 @pytest.mark.parametrize("grid", ["gx3", "tx1"])
 def test_cgrid_run_recovers_when_a_window_is_not_resident(grid, monkeypatch):
     """(gx3; tx1: the FOLD variant, the repeat runs as five phases + fold steps)  cice_evp_hip_cgrid_run on a GPU that is not the rank's alone: one window of the resident kernel never shows up (test
