@@ -650,8 +650,7 @@ def main():
             e = ((pmc or {}).get("kernels", {}).get({"gx1": "cgx1res", "tx1": "cgtx1res"}.get(workload, ""), {}) or {}).get("resident")
             sq = (e or {}).get("sq") or {}
             busy, waves = sq.get("valu_busy_simd_cycles_per_launch"), sq.get("waves_per_launch")
-            live_waves = 4 * sum((-(-b.gnx // 13)) * (-(-(b.gny - (11 if ns == "tripole" and b.gj0 + b.gny - 1 == ny else 0)) // 13) +
-                                                     (1 if ns == "tripole" and b.gj0 + b.gny - 1 == ny else 0)) for b in dc.local_blocks(0))
+            live_waves = 4 * tt_["resident_windows_with_ice"]         # (only the windows that hold ice are launched)
             want_kernel = "cg_res<false, false, true>" if ns == "tripole" else "cg_res<false, false, false>"
             if busy and waves == live_waves and want_kernel in (e["kernel_trace"]["name"] or ""):
                 t_k = ev_ms * 1e-3 / steps            # one launch = one call of res_n subcycles
@@ -670,6 +669,7 @@ def main():
                 "kernel": ("cg_res (on-chip resident: all subcycles of a call in one launch" + (", FOLD variant)" if ns == "tripole" else ")") if res_n else "cg_one" if one
                            else "five phases + five fold steps" if ns == "tripole" else "fused schedule, three launches"),
                 "resident_subcycles_per_call": res_n, "resident_probe_us_per_subcycle": (res_probe_us if res_n else None),
+                "resident_windows_with_ice": (tt_["resident_windows_with_ice"] if res_n else None), "resident_windows": (tt_["resident_windows"] if res_n else None),
                 "verified": (h.hexdigest() == want["sha256"]) if want else None,
                 "checked_against": "tests/golden/bench_checksums.json (oracle/evp_oracle.c, pinned to the reference's evp() with grid_ice='C')" if want else None,
                 "finite": bool(np.isfinite(out["uvelE"]).all()), "max_abs_uE": float(np.abs(out["uvelE"]).max()),
