@@ -182,12 +182,15 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
         run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
         run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
 
-        def ref_run(variant, bx, by, threads, ncalls, **kw):
+        def ref_run(variant, bx, by, threads, ncalls, nprocs=1, **kw):
+            mpi = dict(nprocs=nprocs, distribution_type="roundrobin") if nprocs > 1 else {}
             d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant=variant,
                                          threads=threads, grid_kind="popfile", icecase=case,
                                          grid_files=(td + "/grid.bin", td + "/kmt.bin"),
                                          h_ndte=ndte, ncalls=1, nsub_list=[ndte], dump_arrays=False,
-                                         ntiming=ncalls, timeout=900, **kw)
+                                         ntiming=ncalls, timeout=900, **mpi, **kw)
+            if nprocs > 1:      # the wall clock around the calls (slowest task); timer_evp prints with 0.01 s resolution
+                return run_ref.parse_wall(txt) or run_ref.parse_timer(txt, "evp")
             return run_ref.parse_timer(txt, "evp")       # timer_evp is cleared before the ntiming calls
 
         # candidates: the 2-d path is OpenMP over blocks (threads <= blocks); the 1-d core over the cell vector
@@ -200,9 +203,21 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
             for th in sorted({min(cores, 16), min(cores, 64)}):
                 cands.append(dict(path="shared_mem_1d", variant="fast1d", bx=max(nx // 8, 8), by=max(ny // 8, 8),
                                   threads=th, kw=dict(time_1d=True)))
+        # the reference's MPI path (comm/mpi compiled against the image's MPICH, oracle/ref/build_ref.sh `mpi`): one block
+        # per MPI task, as many tasks as blocks -- what north_star names as the baseline ("reference MPI/Fortran path")
+        if run_ref.have_ref("mpifast") and run_ref.have_mpiexec():
+            for (dx_, dy_) in ((4, 4), (8, 4), (8, 8), (16, 8)):
+                if dx_ * dy_ <= cores and nx % dx_ == 0 and ny % dy_ == 0:
+                    cands.append(dict(path="mpi", variant="mpifast", bx=nx // dx_, by=ny // dy_, threads=1, nprocs=dx_ * dy_, kw={}))
         results = []
         for c in cands:
-            t_cal = ref_run(c["variant"], c["bx"], c["by"], c["threads"], 2, **c["kw"])
+            try:
+                t_cal = ref_run(c["variant"], c["bx"], c["by"], c["threads"], 2, nprocs=c.get("nprocs", 1), **c["kw"])
+            except Exception as e:  # noqa: BLE001
+                if c["path"] != "mpi":
+                    raise
+                print(f"[bench] reference MPI path with {c.get('nprocs')} tasks failed ({type(e).__name__}: {str(e)[:300]})", file=sys.stderr)
+                continue
             if not t_cal or t_cal <= 0:
                 continue
             c["per_call"] = t_cal / 2.0
@@ -211,14 +226,17 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
             raise RuntimeError("no timing from the reference harness")
         best2d = min((c for c in results if c["path"] == "standard_2d"), key=lambda c: c["per_call"], default=None)
         best1d = min((c for c in results if c["path"] == "shared_mem_1d"), key=lambda c: c["per_call"], default=None)
+        bestmpi = min((c for c in results if c["path"] == "mpi"), key=lambda c: c["per_call"], default=None)
         timed = []
-        for c in [c for c in (best2d, best1d) if c]:
+        for c in [c for c in (best2d, best1d, bestmpi) if c]:
             ncalls = int(max(2, min(2000, target_s / max(c["per_call"], 1e-4))))
-            t = ref_run(c["variant"], c["bx"], c["by"], c["threads"], ncalls, **c["kw"])
+            t = ref_run(c["variant"], c["bx"], c["by"], c["threads"], ncalls, nprocs=c.get("nprocs", 1), **c["kw"])
             if t and t > 0:
-                timed.append(dict(path=c["path"], value=nx * ny * ndte * ncalls / t, cores=c["threads"],
+                timed.append(dict(path=c["path"], value=nx * ny * ndte * ncalls / t, cores=c.get("nprocs", c["threads"]),
                                   blocks=f"{(nx // c['bx']) * (ny // c['by'])} x {c['bx']}x{c['by']}",
-                                  evp_calls=ncalls, timer_evp_s=t))
+                                  evp_calls=ncalls, timer_evp_s=t,
+                                  parallelism=(f"{c['nprocs']} MPI tasks (MPICH 3.3.2, shared memory), one block each" if c["path"] == "mpi"
+                                               else f"{c['threads']} OpenMP threads")))
         if not timed:
             raise RuntimeError("no timing from the reference harness")
         top = max(timed, key=lambda r: r["value"])
@@ -226,7 +244,8 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
                    sample=f"reference evp() ({top['path']}) compiled from the unmodified sources (amdflang -O2 "
                           f"-fopenmp), {nx}x{ny} in {top['blocks']} blocks, ndte={ndte}, {top['evp_calls']} evp() calls, "
                           f"its own timer_evp={top['timer_evp_s']:.2f}s (subcycle loop incl. serial halo + deformations), "
-                          f"{top['cores']} OpenMP threads of {cores} host cores; fastest of the code paths in `paths`",
+                          f"{top['parallelism']} on {cores} host cores; fastest of the code paths in `paths` "
+                          f"(standard_2d and shared_mem_1d: comm/serial + OpenMP; mpi: the reference's comm/mpi halo, MPI_ISEND/IRECV)",
                    paths=timed, host_cores=cores)
         if strict and run_ref.have_ref("strict"):
             out["reference_parity"] = reference_parity(nx, ny, ndte, case, td)

@@ -119,6 +119,17 @@ module ice_dyn_evp_hip
        integer(c_int32_t), dimension(32), intent(in) :: id128
      end function cice_evp_hip_comm_init
 
+     integer(c_int) function cice_evp_hip_halo_export(blob) bind(C, name='cice_evp_hip_halo_export')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), intent(out) :: blob(*)
+     end function cice_evp_hip_halo_export
+
+     integer(c_int) function cice_evp_hip_halo_import(blobs, nranks) bind(C, name='cice_evp_hip_halo_import')
+       import :: c_int, c_int32_t
+       integer(c_int32_t), intent(in) :: blobs(*)
+       integer(c_int32_t), value :: nranks
+     end function cice_evp_hip_halo_import
+
      ! ---- wider entry points (Option A: evp() patched to hand over its whole B-grid body) ----
      integer(c_int) function cice_evp_hip_set_prep_geometry(tmask, umask, hm, tarea, uarea, fcor_blk) &
           bind(C, name='cice_evp_hip_set_prep_geometry')
@@ -284,6 +295,7 @@ module ice_dyn_evp_hip
   ! Opt-in only: a host that has installed the two hooks (dyn_evp_hip_fetch_stresses before every reader,
   ! dyn_evp_hip_invalidate_stresses after every writer) may call dyn_evp_hip_keep_stresses_resident(.true.)
   ! -- or set CICE_EVP_HIP_STRESS_RESIDENT=1 -- and the stresses then stay on the device between calls.
+  integer, parameter :: halo_blob_words = 256   ! CICE_EVP_HIP_HALO_BLOB (1024 bytes) as 4-byte words
   logical :: stress_resident = .false.
   logical :: stress_resident_requested = .false.
   logical :: body_sig_on_device = .false.   ! Option A with resident stresses: the device copy is current (dyn_evp_hip_evp_body)
@@ -338,6 +350,8 @@ contains
     integer(int_kind), pointer :: i_glob(:), j_glob(:)
     integer(int_kind) :: n, lo_i, hi_i, lo_j, hi_j, nprocs
     integer(c_int32_t) :: uid(32)
+    integer(int_kind) :: blob(halo_blob_words), r
+    integer(int_kind), allocatable :: blobs(:,:)
     real(dbl_kind) :: rhow
     character(len=16) :: envval
     integer :: envlen, envstat
@@ -395,12 +409,28 @@ contains
          .false.)
 
     if (nprocs > 1) then
-       ! RCCL bootstrap: the master's ncclUniqueId travels over CICE's own broadcast
-       uid = 0
-       if (my_task == master_task) &
-          call check(cice_evp_hip_comm_unique_id(uid), subname, __FILE__, __LINE__)
-       call broadcast_array(uid, master_task)
-       call check(cice_evp_hip_comm_init(uid), subname, __FILE__, __LINE__)
+       call get_environment_variable('CICE_EVP_HIP_BOOTSTRAP', envval, envlen, envstat)
+       if (envstat == 0 .and. envlen >= 5 .and. envval(1:5) == 'blobs') then
+          ! bootstrap without RCCL (ranks of one node; also several ranks sharing a GPU, which RCCL refuses): every
+          ! rank exports its HIP-IPC handles, CICE's own broadcast_array ships them -- one broadcast per rank, an
+          ! all-gather in rank order -- and every rank imports all of them (collective: runs the probe exchange)
+          allocate(blobs(halo_blob_words, nprocs))
+          do r = 0, nprocs - 1
+             blob = 0
+             if (my_task == r) call check(cice_evp_hip_halo_export(blob), subname, __FILE__, __LINE__)
+             call broadcast_array(blob, r)
+             blobs(:, r + 1) = blob
+          enddo
+          call check(cice_evp_hip_halo_import(blobs, int(nprocs, c_int32_t)), subname, __FILE__, __LINE__)
+          deallocate(blobs)
+       else
+          ! RCCL bootstrap: the master's ncclUniqueId travels over CICE's own broadcast
+          uid = 0
+          if (my_task == master_task) &
+             call check(cice_evp_hip_comm_unique_id(uid), subname, __FILE__, __LINE__)
+          call broadcast_array(uid, master_task)
+          call check(cice_evp_hip_comm_init(uid), subname, __FILE__, __LINE__)
+       endif
     endif
     initialised = .true.
 

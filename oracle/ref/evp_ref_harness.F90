@@ -267,7 +267,8 @@ program evp_ref_harness
 
   use ice_kinds_mod
   use ice_constants
-  use ice_communicate, only: init_communicate, my_task
+  use ice_communicate, only: init_communicate, my_task, get_num_procs
+  use ice_exit, only: end_run
   use ice_fileunits, only: init_fileunits, nu_diag, nml_filename
   use ice_domain, only: init_domain_blocks, nblocks, blocks_ice, halo_info, &
       ew_boundary_type, ns_boundary_type, maskhalo_dyn
@@ -366,6 +367,11 @@ program evp_ref_harness
 #endif
 
   call init_communicate
+  ! several MPI tasks (the mpi* builds under mpiexec): every task dumps its own blocks; blkinfo says where they lie
+  if (get_num_procs() > 1) then
+     write(tag,'(i0)') my_task
+     dumpfile = trim(dumpfile)//'.'//trim(tag)
+  endif
   call init_fileunits
   nml_filename = 'ice_in'
 
@@ -782,6 +788,7 @@ program evp_ref_harness
           ' calls', ntiming, ' wall_s_total_evp_calls', real(c1_clk-c0_clk,dbl_kind)/real(crate,dbl_kind)
      call ice_timer_print_all(stats=.false.)
   endif
+  call end_run                 ! MPI_Finalize in the mpi* builds (comm/mpi/ice_exit.F90), nothing in the serial ones
 
 contains
 

@@ -21,11 +21,25 @@ HERE = Path(__file__).resolve().parent
 REF_DIR = HERE.parent / "_ref"
 
 
+MPIEXEC = os.environ.get("CICE_REF_MPIEXEC", "/opt/conda/bin/mpiexec")   # the image's MPICH 3.3.2 (hydra)
+
+
 def harness_path(variant: str = "strict") -> Path:
     if variant == "hip_dropin":
         # the reference's unmodified evp() driver + cice_amd/fortran shim + libcice_evp_hip.so
         return REF_DIR / "evp_hip_dropin_harness"
+    if variant == "hip_dropin_mpi":
+        # the same with the reference's comm/mpi modules: several MPI tasks drive the shim's nprocs > 1 branch
+        return REF_DIR / "evp_hip_dropin_harness_mpi"
     return REF_DIR / f"evp_ref_harness_{variant}"
+
+
+def is_mpi_variant(variant: str) -> bool:
+    return variant.startswith("mpi") or variant.endswith("_mpi")
+
+
+def have_mpiexec() -> bool:
+    return os.path.exists(MPIEXEC) and os.access(MPIEXEC, os.X_OK)
 
 
 def have_ref(variant: str = "strict") -> bool:
@@ -88,9 +102,14 @@ def write_kmt(path, kmt):
 def run_harness(nx_global, ny_global, block_size_x, block_size_y, *,
                 ew="cyclic", ns="closed", maskhalo_dyn=False, variant="strict",
                 threads=1, workdir=None, grid_files=None, keep=False, timeout=3600,
+                nprocs=1, distribution_type="cartesian", processor_shape="slenderX2", extra_env=None,
                 **harness):
-    """Run one harness case, return (dump dict, stdout text)."""
+    """Run one harness case, return (dump dict, stdout text).  nprocs > 1 (mpi* variants, started under the image's
+    mpiexec): the reference distributes the blocks over that many MPI tasks (ice_domain.F90 init_domain_distribution)
+    and the first return value is the LIST of per-task dumps in task order (global_field() assembles them)."""
     exe = harness_path(variant)
+    if nprocs > 1 and not is_mpi_variant(variant):
+        raise ValueError("nprocs > 1 needs one of the mpi variants")
     if not have_ref(variant):
         raise FileNotFoundError(f"{exe} not built (run oracle/ref/build_ref.sh)")
     tmp = None
@@ -101,11 +120,11 @@ def run_harness(nx_global, ny_global, block_size_x, block_size_y, *,
     wd.mkdir(parents=True, exist_ok=True)
     (wd / "ice_in").write_text(
         "&domain_nml\n"
-        "  nprocs = 1\n"
+        f"  nprocs = {nprocs}\n"
         f"  nx_global = {nx_global}\n  ny_global = {ny_global}\n"
         f"  block_size_x = {block_size_x}\n  block_size_y = {block_size_y}\n"
-        "  max_blocks = -1\n  processor_shape = 'slenderX2'\n"
-        "  distribution_type = 'cartesian'\n  distribution_wght = 'blockall'\n"
+        f"  max_blocks = -1\n  processor_shape = '{processor_shape}'\n"
+        f"  distribution_type = '{distribution_type}'\n  distribution_wght = 'blockall'\n"
         f"  ew_boundary_type = '{ew}'\n  ns_boundary_type = '{ns}'\n"
         f"  maskhalo_dyn = {_fmt(bool(maskhalo_dyn))}\n"
         "  maskhalo_remap = .false.\n  maskhalo_bound = .false.\n"
@@ -124,17 +143,55 @@ def run_harness(nx_global, ny_global, block_size_x, block_size_y, *,
     env.setdefault("OMP_SCHEDULE", "static,1")
     env.setdefault("OMP_STACKSIZE", "256M")
     # one 320x384 block needs a large stack (automatic arrays in evp()): SURVEY Appendix A.3
-    cmd = f"ulimit -s unlimited 2>/dev/null; exec '{exe}'"
+    if extra_env:
+        env.update(extra_env)
+    if is_mpi_variant(variant):
+        if not have_mpiexec():
+            raise FileNotFoundError(f"{MPIEXEC} not found")
+        cmd = f"ulimit -s unlimited 2>/dev/null; exec '{MPIEXEC}' -n {nprocs} '{exe}'"
+    else:
+        cmd = f"ulimit -s unlimited 2>/dev/null; exec '{exe}'"
     r = subprocess.run(["bash", "-c", cmd], cwd=wd, env=env, capture_output=True,
                        text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"reference harness failed rc={r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}")
     dumpname = harness.get("dumpfile", "dump.bin")
-    d = read_dump(wd / dumpname) if (wd / dumpname).exists() else {}
+    if nprocs > 1:
+        d = [read_dump(wd / f"{dumpname}.{r}") if (wd / f"{dumpname}.{r}").exists() else {} for r in range(nprocs)]
+    else:
+        d = read_dump(wd / dumpname) if (wd / dumpname).exists() else {}
     text = r.stdout
     if tmp is not None and not keep:
         tmp.cleanup()
     return d, text
+
+
+def global_field(dumps, name, ghosts=False):
+    """One [ny_global][nx_global] array out of a dump (or the list of per-task dumps of an MPI run): every block's
+    interior cells put where blkinfo says they lie.  Cells no block covers (eliminated land blocks) stay NaN for
+    fp64 fields and -1 for integer ones."""
+    if isinstance(dumps, dict):
+        dumps = [dumps]
+    first = next(d for d in dumps if d)
+    nxg, nyg = int(first["dims"][4]), int(first["dims"][5])
+    sample = first[name]
+    out = np.full((nyg, nxg), np.nan) if sample.dtype == np.float64 else np.full((nyg, nxg), -1, dtype=sample.dtype)
+    for d in dumps:
+        if not d:
+            continue
+        nb = int(d["dims"][2])
+        blk = np.asarray(d["blkinfo"]).reshape(nb, 8)
+        a = d[name]
+        for b in range(nb):
+            ilo, ihi, jlo, jhi, _, _, ig0, jg0 = (int(v) for v in blk[b])
+            out[jg0 - 1:jg0 + (jhi - jlo), ig0 - 1:ig0 + (ihi - ilo)] = a[b, jlo - 1:jhi, ilo - 1:ihi]
+    return out
+
+
+def parse_wall(text):
+    """`TIMING ... wall_s_total_evp_calls T` -- every task prints one; the slowest counts."""
+    v = [float(x) for x in re.findall(r"wall_s_total_evp_calls\s+([0-9.Ee+-]+)", text)]
+    return max(v) if v else None
 
 
 def parse_timer(text, name="evp"):

@@ -1,0 +1,96 @@
+"""GPU (-m gpu): the drop-in under the reference's MPI path -- the Fortran shim's `nprocs > 1` branch executed.
+
+oracle/_ref/evp_hip_dropin_harness_mpi = the reference's unmodified evp() driver with its comm/mpi modules (compiled in
+place against the image's MPICH) + cice_amd/fortran shim + libcice_evp_hip.so, started as 2-4 MPI tasks by mpiexec.
+The reference's own init_domain_distribution deals the blocks out (cartesian and roundrobin); dyn_evp_hip_init builds
+the owner table from distrb_info%blockLocation / blockLocalID (ice_distribution.F90:24-37), ships the bootstrap data
+with CICE's own broadcast_array (comm/mpi/ice_broadcast.F90) and calls cice_evp_hip_halo_import; from then on the
+velocity halo of every subcycle travels between the tasks' kernels, not through MPI.  The box has ONE GPU, so the
+tasks share it (CICE_EVP_HIP_BOOTSTRAP=blobs: HIP-IPC mailboxes; RCCL refuses two ranks on one device) -- the stand-in
+a 1-GPU box allows, as in test_gpu_zz_multiprocess.py.  Every task's arrays after the HIP core must equal what the
+reference's standard_2d path (halo through MPI) leaves in the same task, ghost cells included, and the assembled
+global fields must equal the reference's serial build."""
+import os
+
+import numpy as np
+import pytest
+
+import run_ref
+from cice_amd import synth
+from common import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = (["uvel", "vvel", "strintxU", "strintyU", "taubxU", "taubyU"] +
+          [f"stress{k}_{c}" for k in ("p", "m", "12") for c in range(1, 5)])
+DOWNSTREAM = ["divu", "shear", "strocnxU"]
+
+CASES = [
+    # nx, ny, bx, by, ew, ns, nprocs, distribution, body (Option A too), kwargs
+    (40, 36, 20, 18, "cyclic", "closed", 2, "cartesian", False, dict(grid_kind="rect", icecase="full")),
+    (60, 44, 20, 15, "cyclic", "closed", 2, "roundrobin", False, dict(grid_kind="popfile", icecase="patchy")),
+    (100, 116, 50, 29, "closed", "closed", 4, "cartesian", False, dict(grid_kind="popfile", icecase="caps", h_seabed=True)),
+    (72, 40, 36, 20, "cyclic", "tripole", 2, "cartesian", False, dict(grid_kind="tripolefile", icecase="full")),
+    (72, 40, 18, 20, "cyclic", "tripole", 4, "roundrobin", False, dict(grid_kind="tripolefile", icecase="patchy", h_capping=0.5)),
+    (72, 40, 36, 20, "cyclic", "closed", 2, "cartesian", True, dict(grid_kind="popfile", icecase="full")),
+]
+
+
+def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24):
+    if not (run_ref.have_ref("hip_dropin_mpi") and run_ref.have_mpiexec()):
+        pytest.skip("oracle/_ref/evp_hip_dropin_harness_mpi or mpiexec not available")
+    files = None
+    if kw["grid_kind"] != "rect":
+        g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+        run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
+        run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
+        files = (tmp_path / "grid.bin", tmp_path / "kmt.bin")
+    common = dict(ew=ew, ns=ns, h_ndte=ndte, ncalls=2, nsub_list=[1, ndte], grid_files=files, **kw)
+    env = {"CICE_EVP_HIP_BOOTSTRAP": "blobs", "CICE_EVP_HIP_HALO_TIMEOUT_MS": "20000",
+           "CICE_EVP_HIP_DEVICE": "0", "CICE_EVP_HIP_VERBOSE": "1"}
+    last = None
+    for attempt in (1, 2):          # tasks time-slicing one GPU: one retry, as in test_gpu_zz_multiprocess.py
+        try:
+            par, txt = run_ref.run_harness(nx, ny, bx, by, variant="hip_dropin_mpi", nprocs=nprocs,
+                                           distribution_type=dist, hipmode=True, hipbody=body, extra_env=env,
+                                           workdir=tmp_path / f"par{attempt}", timeout=600, **common)
+            last = None
+            break
+        except RuntimeError as e:
+            last = e
+    if last is not None:
+        raise last
+    checked = 0
+    for r, d in enumerate(par):
+        for icall in (1, 2):
+            for nsub in (1, ndte):
+                for f in FIELDS + DOWNSTREAM:
+                    hip, ref = d[f"h{icall:02d}n{nsub:04d}_{f}"], d[f"o{icall:02d}n{nsub:04d}_{f}"]
+                    assert bits_equal(hip, ref), (f"task {r} call {icall} nsub {nsub} {f}: "
+                                                  f"{int((hip != ref).sum())} cells differ, max|d|={np.abs(hip - ref).max():.3e}")
+                    checked += 1
+                if body:
+                    for f in FIELDS:
+                        b, ref = d[f"b{icall:02d}n{nsub:04d}_{f}"], d[f"o{icall:02d}n{nsub:04d}_{f}"]
+                        assert bits_equal(b, ref), f"Option A body, task {r} call {icall} nsub {nsub} {f}"
+                        checked += 1
+    assert checked == nprocs * 4 * (len(FIELDS) * (2 if body else 1) + len(DOWNSTREAM))
+    # ... and the whole thing against the reference's serial build on the same domain
+    if run_ref.have_ref("strict"):
+        ser, _ = run_ref.run_harness(nx, ny, bx, by, variant="strict", workdir=tmp_path / "ser", **common)
+        for f in FIELDS:
+            k = f"n{ndte:04d}_{f}"
+            assert bits_equal(run_ref.global_field(par, "h02" + k), run_ref.global_field(ser, "o02" + k)), f
+    assert np.nanmax(np.abs(run_ref.global_field(par, f"h02n{ndte:04d}_uvel"))) > 1e-5
+    return txt
+
+
+@pytest.mark.parametrize("nx,ny,bx,by,ew,ns,nprocs,dist,body,kw", CASES)
+def test_reference_mpi_driver_with_hip_core_bitwise(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw):
+    txt = run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw)
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(f"gpurun_out/dropin_mpi_{nx}x{ny}_{nprocs}_{dist}.log", "w") as f:
+            f.write(txt[-20000:])
+    except OSError:
+        pass
