@@ -182,16 +182,16 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
         run_ref.write_pop_grid(td + "/grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
         run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
 
-        def ref_run(variant, bx, by, threads, ncalls, nprocs=1, **kw):
+        def ref_run(variant, bx, by, threads, ncalls, nprocs=1, calibrate=False, **kw):
             mpi = dict(nprocs=nprocs, distribution_type="roundrobin") if nprocs > 1 else {}
             d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant=variant,
                                          threads=threads, grid_kind="popfile", icecase=case,
                                          grid_files=(td + "/grid.bin", td + "/kmt.bin"),
                                          h_ndte=ndte, ncalls=1, nsub_list=[ndte], dump_arrays=False,
                                          ntiming=ncalls, timeout=900, **mpi, **kw)
-            if nprocs > 1:      # the wall clock around the calls (slowest task); timer_evp prints with 0.01 s resolution
-                return run_ref.parse_wall(txt) or run_ref.parse_timer(txt, "evp")
-            return run_ref.parse_timer(txt, "evp")       # timer_evp is cleared before the ntiming calls
+            if nprocs > 1 and calibrate:     # two calls: timer_evp prints with 0.01 s resolution -- the wall clock around them
+                return run_ref.parse_wall(txt)
+            return run_ref.parse_timer(txt, "evp")       # timer_evp is cleared before the ntiming calls (MPI: max over tasks)
 
         # candidates: the 2-d path is OpenMP over blocks (threads <= blocks); the 1-d core over the cell vector
         cands = []
@@ -212,7 +212,7 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
         results = []
         for c in cands:
             try:
-                t_cal = ref_run(c["variant"], c["bx"], c["by"], c["threads"], 2, nprocs=c.get("nprocs", 1), **c["kw"])
+                t_cal = ref_run(c["variant"], c["bx"], c["by"], c["threads"], 2, nprocs=c.get("nprocs", 1), calibrate=True, **c["kw"])
             except Exception as e:  # noqa: BLE001
                 if c["path"] != "mpi":
                     raise
@@ -240,13 +240,17 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
         if not timed:
             raise RuntimeError("no timing from the reference harness")
         top = max(timed, key=lambda r: r["value"])
+        build = ("amdflang -O2, comm/mpi against the image's MPICH 3.3.2; its own timer_evp, slowest task"
+                 if top["path"] == "mpi" else "amdflang -O2 -fopenmp, comm/serial; its own timer_evp")
         out = dict(value=top["value"], unit="cell-updates/s", cores=top["cores"], kind="reference",
-                   sample=f"reference evp() ({top['path']}) compiled from the unmodified sources (amdflang -O2 "
-                          f"-fopenmp), {nx}x{ny} in {top['blocks']} blocks, ndte={ndte}, {top['evp_calls']} evp() calls, "
-                          f"its own timer_evp={top['timer_evp_s']:.2f}s (subcycle loop incl. serial halo + deformations), "
+                   sample=f"reference evp() ({top['path']}) compiled from the unmodified sources ({build}), "
+                          f"{nx}x{ny} in {top['blocks']} blocks, ndte={ndte}, {top['evp_calls']} evp() calls in "
+                          f"{top['timer_evp_s']:.2f}s (subcycle loop incl. halo updates + deformations), "
                           f"{top['parallelism']} on {cores} host cores; fastest of the code paths in `paths` "
                           f"(standard_2d and shared_mem_1d: comm/serial + OpenMP; mpi: the reference's comm/mpi halo, MPI_ISEND/IRECV)",
-                   paths=timed, host_cores=cores)
+                   paths=timed, host_cores=cores,
+                   calibration=[dict(path=c["path"], tasks=c.get("nprocs", 1), threads=c["threads"],
+                                     blocks=f"{c['bx']}x{c['by']}", s_per_call=c["per_call"]) for c in results])
         if strict and run_ref.have_ref("strict"):
             out["reference_parity"] = reference_parity(nx, ny, ndte, case, td)
         try:      # the same code with grid_ice = 'C' (next-tier row f-4), timed the same way
