@@ -21,9 +21,9 @@ from common import bits_equal
 
 pytestmark = pytest.mark.gpu
 
-FIELDS = (["uvel", "vvel", "strintxU", "strintyU", "taubxU", "taubyU"] +
-          [f"stress{k}_{c}" for k in ("p", "m", "12") for c in range(1, 5)])
-DOWNSTREAM = ["divu", "shear", "strocnxU"]
+B_FIELDS = (["uvel", "vvel", "strintxU", "strintyU", "taubxU", "taubyU"] +
+            [f"stress{k}_{c}" for k in ("p", "m", "12") for c in range(1, 5)])
+B_DOWNSTREAM = ["divu", "shear", "strocnxU"]
 
 CASES = [
     # nx, ny, bx, by, ew, ns, nprocs, distribution, body (Option A too), kwargs
@@ -36,12 +36,20 @@ CASES = [
 ]
 
 
-def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24):
+CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
+                "taubxE", "taubyN", "zetax2T", "etax2T", "etax2U", "shearU", "deltaU"]
+CGRID_DOWNSTREAM = ["divu", "shear", "vort", "rdg_conv", "rdg_shear", "strocnxN", "strocnyN", "strocnxE", "strocnyE"]
+
+
+def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24, cgrid=False):
+    FIELDS, DOWNSTREAM = (CGRID_FIELDS, CGRID_DOWNSTREAM) if cgrid else (B_FIELDS, B_DOWNSTREAM)
+    if cgrid:
+        kw = dict(kw, h_grid_ice="C")
     if not (run_ref.have_ref("hip_dropin_mpi") and run_ref.have_mpiexec()):
         pytest.skip("oracle/_ref/evp_hip_dropin_harness_mpi or mpiexec not available")
     files = None
     if kw["grid_kind"] != "rect":
-        g = synth.make_grid(nx, ny, dx0=1.1e5, ns=ns)
+        g = synth.make_grid(nx, ny, dx0=1.1e5, ns=("tripole" if ns == "tripoleT" else ns))
         run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
         run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
         files = (tmp_path / "grid.bin", tmp_path / "kmt.bin")
@@ -81,8 +89,45 @@ def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24):
         for f in FIELDS:
             k = f"n{ndte:04d}_{f}"
             assert bits_equal(run_ref.global_field(par, "h02" + k), run_ref.global_field(ser, "o02" + k)), f
+    if cgrid:
+        assert np.nanmax(np.abs(run_ref.global_field(par, f"h02n{ndte:04d}_uvelE"))) > 1e-5
     assert np.nanmax(np.abs(run_ref.global_field(par, f"h02n{ndte:04d}_uvel"))) > 1e-5
     return txt
+
+
+@pytest.mark.parametrize("seed", list(range(901, 909)) + [int(s) for s in os.environ.get("DROPIN_MPI_SWEEP_SEEDS", "").split() if s])
+def test_reference_mpi_driver_with_hip_core_geometry_sweep(tmp_path, seed):
+    """Random domain sizes, block splits (padded last blocks), 2-4 MPI tasks, cartesian / roundrobin / sectrobin /
+    rake-free distributions of the reference's own making, closed / cyclic / tripole boundaries, options."""
+    rng = np.random.default_rng(seed)
+    trip = seed % 3 == 0
+    nx, ny = 2 * int(rng.integers(12, 50)), int(rng.integers(16, 60))
+    nbx, nby = int(rng.integers(2, 5)), int(rng.integers(1, 4))
+    bx, by = -(-nx // nbx), -(-ny // nby)
+    nblk = (-(-nx // bx)) * (-(-ny // by))
+    nprocs = int(rng.integers(2, min(4, nblk) + 1))
+    dist = str(rng.choice(["cartesian", "roundrobin", "sectrobin"]))
+    kw = dict(grid_kind="tripolefile" if trip else "popfile", icecase=str(rng.choice(["full", "patchy", "caps"])))
+    if rng.random() < 0.3:
+        kw["h_seabed"] = True
+    if rng.random() < 0.3:
+        kw["h_revised"] = True
+    if rng.random() < 0.3:
+        kw["h_capping"] = 0.5
+    ew = "closed" if (not trip and seed % 2) else "cyclic"
+    run_case(tmp_path, nx, ny, bx, by, ew, "tripole" if trip else "closed", nprocs, dist, False, kw, ndte=int(rng.choice([5, 12])))
+
+
+@pytest.mark.parametrize("nx,ny,bx,by,ew,ns,nprocs,dist,kw", [
+    (48, 40, 24, 20, "cyclic", "closed", 2, "cartesian", dict(grid_kind="popfile", icecase="full")),
+    (60, 44, 20, 15, "closed", "closed", 3, "roundrobin", dict(grid_kind="popfile", icecase="patchy", h_visc_method="avg_strength")),
+    (72, 40, 36, 20, "cyclic", "tripole", 2, "cartesian", dict(grid_kind="tripolefile", icecase="full")),
+])
+def test_reference_mpi_driver_with_hip_cgrid_loop_bitwise(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, kw):
+    """C grid across MPI tasks: dyn_evp_hip_cgrid_run called by every task of the reference's driver (the eight halo
+    updates of a subcycle between the tasks' kernels), against the reference's evp() with grid_ice = 'C' whose halo
+    goes through MPI -- every array the loop writes, every cell of every task, ghost cells included."""
+    run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, False, kw, cgrid=True)
 
 
 @pytest.mark.parametrize("nx,ny,bx,by,ew,ns,nprocs,dist,body,kw", CASES)
