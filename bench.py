@@ -33,7 +33,8 @@ What the line carries besides the contract's fields:
                 N > 1: the other BASELINE configs on the same ranks -- gx1 at ndte = 240 (library default, and forced
                 onto RCCL point-to-point), tx1 with the tripole seam (cut in y), 3600x2400 at ndte = 480 -- each
                 verified against its committed checksum, each with every rank's own view (per_rank).
-  cpu_baseline  the reference's own evp() timed on this box's cores (2-d path and its 1-d core), and --
+  cpu_baseline  the reference's own evp() timed on this box's cores (its MPI path under mpiexec, and its 2-d path and
+                1-d core under OpenMP; the fastest is `value`, all three are in `paths`), and --
                 the checker's job -- the HIP path run on the inputs the reference captured in this
                 same run, compared bit for bit with the reference's outputs (`reference_parity`).
 """
@@ -183,7 +184,7 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
         run_ref.write_kmt(td + "/kmt.bin", g["kmt"])
 
         def ref_run(variant, bx, by, threads, ncalls, nprocs=1, calibrate=False, **kw):
-            mpi = dict(nprocs=nprocs, distribution_type="roundrobin") if nprocs > 1 else {}
+            mpi = dict(nprocs=nprocs, distribution_type="roundrobin", mpiexec_args=kw.pop("mpiexec_args", "")) if nprocs > 1 else {}
             d, txt = run_ref.run_harness(nx, ny, bx, by, ew="cyclic", ns="closed", variant=variant,
                                          threads=threads, grid_kind="popfile", icecase=case,
                                          grid_files=(td + "/grid.bin", td + "/kmt.bin"),
@@ -208,11 +209,13 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
         if run_ref.have_ref("mpifast") and run_ref.have_mpiexec():
             for (dx_, dy_) in ((4, 4), (8, 4), (8, 8), (16, 8)):
                 if dx_ * dy_ <= cores and nx % dx_ == 0 and ny % dy_ == 0:
-                    cands.append(dict(path="mpi", variant="mpifast", bx=nx // dx_, by=ny // dy_, threads=1, nprocs=dx_ * dy_, kw={}))
+                    for bind in ("", "-bind-to core"):      # hydra leaves the tasks to the scheduler unless told otherwise
+                        cands.append(dict(path="mpi", variant="mpifast", bx=nx // dx_, by=ny // dy_, threads=1, nprocs=dx_ * dy_,
+                                          kw=dict(mpiexec_args=bind)))
         results = []
         for c in cands:
             try:
-                t_cal = ref_run(c["variant"], c["bx"], c["by"], c["threads"], 2, nprocs=c.get("nprocs", 1), calibrate=True, **c["kw"])
+                t_cal = ref_run(c["variant"], c["bx"], c["by"], c["threads"], 2, nprocs=c.get("nprocs", 1), calibrate=True, **dict(c["kw"]))
             except Exception as e:  # noqa: BLE001
                 if c["path"] != "mpi":
                     raise
@@ -230,12 +233,12 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
         timed = []
         for c in [c for c in (best2d, best1d, bestmpi) if c]:
             ncalls = int(max(2, min(2000, target_s / max(c["per_call"], 1e-4))))
-            t = ref_run(c["variant"], c["bx"], c["by"], c["threads"], ncalls, nprocs=c.get("nprocs", 1), **c["kw"])
+            t = ref_run(c["variant"], c["bx"], c["by"], c["threads"], ncalls, nprocs=c.get("nprocs", 1), **dict(c["kw"]))
             if t and t > 0:
                 timed.append(dict(path=c["path"], value=nx * ny * ndte * ncalls / t, cores=c.get("nprocs", c["threads"]),
                                   blocks=f"{(nx // c['bx']) * (ny // c['by'])} x {c['bx']}x{c['by']}",
                                   evp_calls=ncalls, timer_evp_s=t,
-                                  parallelism=(f"{c['nprocs']} MPI tasks (MPICH 3.3.2, shared memory), one block each" if c["path"] == "mpi"
+                                  parallelism=(f"{c['nprocs']} MPI tasks (MPICH 3.3.2, shared memory; mpiexec {c['kw'].get('mpiexec_args') or 'unbound'}), one block each" if c["path"] == "mpi"
                                                else f"{c['threads']} OpenMP threads")))
         if not timed:
             raise RuntimeError("no timing from the reference harness")
@@ -249,7 +252,7 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
                           f"{top['parallelism']} on {cores} host cores; fastest of the code paths in `paths` "
                           f"(standard_2d and shared_mem_1d: comm/serial + OpenMP; mpi: the reference's comm/mpi halo, MPI_ISEND/IRECV)",
                    paths=timed, host_cores=cores,
-                   calibration=[dict(path=c["path"], tasks=c.get("nprocs", 1), threads=c["threads"],
+                   calibration=[dict(path=c["path"], tasks=c.get("nprocs", 1), threads=c["threads"], mpiexec_args=c["kw"].get("mpiexec_args"),
                                      blocks=f"{c['bx']}x{c['by']}", s_per_call=c["per_call"]) for c in results])
         if strict and run_ref.have_ref("strict"):
             out["reference_parity"] = reference_parity(nx, ny, ndte, case, td)

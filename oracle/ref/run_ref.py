@@ -103,6 +103,7 @@ def run_harness(nx_global, ny_global, block_size_x, block_size_y, *,
                 ew="cyclic", ns="closed", maskhalo_dyn=False, variant="strict",
                 threads=1, workdir=None, grid_files=None, keep=False, timeout=3600,
                 nprocs=1, distribution_type="cartesian", processor_shape="slenderX2", extra_env=None,
+                mpiexec_args="",
                 **harness):
     """Run one harness case, return (dump dict, stdout text).  nprocs > 1 (mpi* variants, started under the image's
     mpiexec): the reference distributes the blocks over that many MPI tasks (ice_domain.F90 init_domain_distribution)
@@ -148,7 +149,7 @@ def run_harness(nx_global, ny_global, block_size_x, block_size_y, *,
     if is_mpi_variant(variant):
         if not have_mpiexec():
             raise FileNotFoundError(f"{MPIEXEC} not found")
-        cmd = f"ulimit -s unlimited 2>/dev/null; exec '{MPIEXEC}' -n {nprocs} '{exe}'"
+        cmd = f"ulimit -s unlimited 2>/dev/null; exec '{MPIEXEC}' {mpiexec_args} -n {nprocs} '{exe}'"
     else:
         cmd = f"ulimit -s unlimited 2>/dev/null; exec '{exe}'"
     r = subprocess.run(["bash", "-c", cmd], cwd=wd, env=env, capture_output=True,
