@@ -9,7 +9,9 @@ velocity halo of every subcycle travels between the tasks' kernels, not through 
 tasks share it (CICE_EVP_HIP_BOOTSTRAP=blobs: HIP-IPC mailboxes; RCCL refuses two ranks on one device) -- the stand-in
 a 1-GPU box allows, as in test_gpu_zz_multiprocess.py.  Every task's arrays after the HIP core must equal what the
 reference's standard_2d path (halo through MPI) leaves in the same task, ghost cells included, and the assembled
-global fields must equal the reference's serial build."""
+global fields must equal the reference's serial build.  (Named to sort after test_gpu_parity.py, like
+test_gpu_zz_multiprocess.py: several processes time-slicing one GPU must not be able to hide the single-process results
+under `pytest -x`.)"""
 import os
 
 import numpy as np
