@@ -43,7 +43,7 @@ CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", 
 CGRID_DOWNSTREAM = ["divu", "shear", "vort", "rdg_conv", "rdg_shear", "strocnxN", "strocnyN", "strocnxE", "strocnyE"]
 
 
-def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24, cgrid=False):
+def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24, cgrid=False, maskhalo=False):
     FIELDS, DOWNSTREAM = (CGRID_FIELDS, CGRID_DOWNSTREAM) if cgrid else (B_FIELDS, B_DOWNSTREAM)
     if cgrid:
         kw = dict(kw, h_grid_ice="C")
@@ -55,7 +55,7 @@ def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24, 
         run_ref.write_pop_grid(tmp_path / "grid.bin", g["ULAT"], g["ULON"], g["HTN"] * 100.0, g["HTE"] * 100.0)
         run_ref.write_kmt(tmp_path / "kmt.bin", g["kmt"])
         files = (tmp_path / "grid.bin", tmp_path / "kmt.bin")
-    common = dict(ew=ew, ns=ns, h_ndte=ndte, ncalls=2, nsub_list=[1, ndte], grid_files=files, **kw)
+    common = dict(ew=ew, ns=ns, h_ndte=ndte, ncalls=2, nsub_list=[1, ndte], grid_files=files, maskhalo_dyn=maskhalo, **kw)
     env = {"CICE_EVP_HIP_BOOTSTRAP": "blobs", "CICE_EVP_HIP_HALO_TIMEOUT_MS": "20000",
            "CICE_EVP_HIP_DEVICE": "0", "CICE_EVP_HIP_VERBOSE": "1"}
     last = None
@@ -118,6 +118,21 @@ def test_reference_mpi_driver_with_hip_core_geometry_sweep(tmp_path, seed):
         kw["h_capping"] = 0.5
     ew = "closed" if (not trip and seed % 2) else "cyclic"
     run_case(tmp_path, nx, ny, bx, by, ew, "tripole" if trip else "closed", nprocs, dist, False, kw, ndte=int(rng.choice([5, 12])))
+
+
+@pytest.mark.parametrize("cgrid", [False, True], ids=["B", "C"])
+@pytest.mark.parametrize("nx,ny,bx,by,ew,ns,nprocs,dist,kw", [
+    (60, 48, 20, 12, "cyclic", "closed", 3, "roundrobin", dict(grid_kind="popfile", icecase="caps")),
+    (72, 40, 18, 20, "cyclic", "tripole", 2, "cartesian", dict(grid_kind="tripolefile", icecase="patchy")),
+])
+def test_reference_mpi_driver_with_hip_core_masked_halo(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, kw, cgrid):
+    """maskhalo_dyn = .true. under MPI: evp() builds halo_info_mask (ice_dyn_evp.F90:739-770) and the reference's loop
+    exchanges only strips that hold ice; the shim rebuilds the same mask from iceUmask (B grid) / the dilated iceTmask (C
+    grid) with the reference's own ice_HaloUpdate across the MPI tasks and hands it to cice_evp_hip_halo_mask -- the
+    branch `maskhalo_dyn .and. get_num_procs() > 1` of dyn_evp_hip_run / cgrid_halo_mask.  Ice on part of the domain,
+    blocks without ice among the neighbours."""
+    txt = run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, False, kw, cgrid=cgrid, maskhalo=True)
+    assert "maskhalo_dyn          =      T" in txt
 
 
 @pytest.mark.parametrize("nx,ny,bx,by,ew,ns,nprocs,dist,kw", [
