@@ -84,11 +84,29 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
                       const double *HTE, const double *HTN, const double *dxT, const double *dyT,
                       const double *uarear, const double *tarea)
 {
-    if (!dims || !params || !HTE || !HTN || !dxT || !dyT || !uarear || !tarea)
-        return fail(-1, "cice_evp_hip_init: null argument");
+    if (!dims || !params) return fail(-1, "cice_evp_hip_init: null argument");
     // also after an init that failed midway (S.ready still false): release whatever it had created
     cice_evp_hip_finalize();
     if (dims->nghost != 1) return fail(-1, "nghost must be 1");
+    if (dims->nblocks == 0 && dims->nranks > 1) {
+        // no blocks on this rank (shared/ice_distribution.F90 hands a task nothing when the processor grid does not divide
+        // the block grid): a bystander of the bootstrap, see State::bystander
+        S.d = *dims;
+        S.d.ilo = S.d.ihi = S.d.jlo = S.d.jhi = S.d.iglob0 = S.d.jglob0 = nullptr;
+        S.d.gi0 = S.d.gj0 = S.d.gnx = S.d.gny = S.d.gowner = S.d.glocal = nullptr;
+        S.d.nblocks_tot = 0;
+        S.prm = *params;
+        int ndev = 0;
+        HIPC(hipGetDeviceCount(&ndev));
+        if (ndev < 1) return fail(-4, "no HIP device");
+        S.device = env("CICE_EVP_HIP_DEVICE") ? std::atoi(env("CICE_EVP_HIP_DEVICE"))
+                   : env("LOCAL_RANK") ? std::atoi(env("LOCAL_RANK")) % ndev : dims->rank % ndev;
+        HIPC(hipSetDevice(S.device));
+        HIPC(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        S.bystander = true;
+        return 0;
+    }
+    if (!HTE || !HTN || !dxT || !dyT || !uarear || !tarea) return fail(-1, "cice_evp_hip_init: null argument");
     if (dims->nblocks < 1 || dims->nblocks > dims->max_blocks) return fail(-1, "bad nblocks/max_blocks");
 
     S.d = *dims;

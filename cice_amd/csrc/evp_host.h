@@ -67,6 +67,11 @@ enum Field {
 
 struct State {
     bool ready = false;
+    // A rank that holds NO blocks (the reference allows it: a cartesian distribution whose processor grid does not divide
+    // the block grid, land-block elimination): it takes part in the bootstrap's collectives -- RCCL communicator, blob
+    // all-gather, the agreements -- and in nothing else; every other entry point refuses it ("rank holds no blocks": the
+    // host has nothing to hand over there, cice_amd/fortran skips its calls).
+    bool bystander = false;
     bool uploaded = false;
     cice_evp_hip_dims d{};
     cice_evp_hip_params prm{};

@@ -384,9 +384,22 @@ int cice_evp_hip_comm_unique_id(void *id128)
     return 0;
 }
 
+// the blob of a rank without blocks: nobody's peer, no objection to anything
+static void bystander_blob(HaloBlob &B)
+{
+    std::memset(&B, 0, sizeof B);
+    B.can_res = 1;
+    B.magic = HALO_BLOB_MAGIC;
+    B.version = 1;
+    B.rank = S.d.rank;
+    B.npeers = 0;
+    B.host_id = host_identity();
+    B.pid = (int64_t)getpid();
+}
+
 int cice_evp_hip_comm_init(const void *id128)
 {
-    if (!S.ready) return fail(-1, "not initialised");
+    if (!S.ready && !S.bystander) return fail(-1, "not initialised");
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     HIPC(hipSetDevice(S.device));
@@ -408,27 +421,32 @@ int cice_evp_hip_comm_init(const void *id128)
         return 0;
     };
     std::vector<char> mine(CICE_EVP_HIP_HALO_BLOB, 0), all((size_t)nr * CICE_EVP_HIP_HALO_BLOB, 0);
-    int ok = direct_export(*reinterpret_cast<HaloBlob *>(mine.data())) == 0, all_ok = 0;
+    int ok = 1, all_ok = 0;
+    if (S.bystander) bystander_blob(*reinterpret_cast<HaloBlob *>(mine.data()));
+    else ok = direct_export(*reinterpret_cast<HaloBlob *>(mine.data())) == 0;
     std::string why = ok ? "" : g_err;
     HIPC(hipMemcpy(d_blobs + (size_t)S.d.rank * CICE_EVP_HIP_HALO_BLOB, mine.data(), CICE_EVP_HIP_HALO_BLOB, hipMemcpyHostToDevice));
     NCCLC(ncclAllGather(d_blobs + (size_t)S.d.rank * CICE_EVP_HIP_HALO_BLOB, d_blobs, CICE_EVP_HIP_HALO_BLOB, ncclChar, S.comm, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
     HIPC(hipMemcpy(all.data(), d_blobs, all.size(), hipMemcpyDeviceToHost));
-    if (ok) {
+    if (ok && !S.bystander) {
         ok = direct_import(reinterpret_cast<const HaloBlob *>(all.data()), nr) == 0;
         if (!ok) why = g_err;
     }
     if (agree(ok, all_ok)) return -1;
     if (all_ok) {
-        ok = direct_probe() == 0;
+        ok = S.bystander ? 1 : direct_probe() == 0;
         if (!ok) why = g_err;
         if (agree(ok, all_ok)) return -1;
     }
-    if (all_ok && S.res_remote) {           // resident kernel across GPUs: its own probe, same agreement
-        int res_ok = resident_remote_probe() == 0, res_all = 0;
+    if (all_ok) {           // resident kernel across GPUs: its own probe, same agreement
+        // EVERY rank takes part in this agreement, whatever its own verdict so far: a rank without neighbours on other
+        // ranks (or without blocks) has nothing to probe and votes yes -- a vote only some ranks enter would leave the
+        // others in the all-reduce
+        int res_ok = (S.bystander || !S.res_remote) ? 1 : resident_remote_probe() == 0, res_all = 0;
         const std::string why_res = res_ok ? "" : g_err;
         if (agree(res_ok, res_all)) return -1;
-        if (!res_all) {
+        if (!res_all && S.res_remote) {
             S.res_remote = false;
             if (env("CICE_EVP_HIP_VERBOSE"))
                 std::fprintf(stderr, "[cice_evp_hip] rank %d: resident kernel across GPUs off (%s)\n", S.d.rank,
@@ -515,19 +533,22 @@ int cice_evp_hip_halo_mask(const int32_t *halomask)
 
 int cice_evp_hip_halo_export(void *blob)
 {
-    if (!S.ready) return fail(-1, "not initialised");
+    if (!S.ready && !S.bystander) return fail(-1, "not initialised");
     if (!blob) return fail(-1, "null blob");
     HIPC(hipSetDevice(S.device));
     std::vector<char> tmp(CICE_EVP_HIP_HALO_BLOB, 0);
-    if (int rc = direct_export(*reinterpret_cast<HaloBlob *>(tmp.data()))) return rc;
+    if (S.bystander) bystander_blob(*reinterpret_cast<HaloBlob *>(tmp.data()));
+    else if (int rc = direct_export(*reinterpret_cast<HaloBlob *>(tmp.data()))) return rc;
     std::memcpy(blob, tmp.data(), CICE_EVP_HIP_HALO_BLOB);
     return 0;
 }
 
 int cice_evp_hip_halo_import(const void *blobs, int32_t nranks)
 {
-    if (!S.ready) return fail(-1, "not initialised");
+    if (!S.ready && !S.bystander) return fail(-1, "not initialised");
     if (!blobs) return fail(-1, "null blobs");
+    if (S.bystander)       // nobody's peer: nothing to map, nothing to probe (the probe runs between peers)
+        return nranks == S.d.nranks ? 0 : fail(-8, "mailbox halo: %d blobs for %d ranks", nranks, S.d.nranks);
     HIPC(hipSetDevice(S.device));
     std::vector<HaloBlob> B((size_t)std::max(nranks, 0));
     for (int r = 0; r < nranks; ++r)

@@ -587,6 +587,15 @@ bool march_wanted()
     State::March &M = S.march;
     if (M.mode >= 0) return M.mode == 1;
     M.mode = 0;
+    // a rank without blocks never gets here, so the agreement below would wait for it for ever: every rank sees it in the
+    // global block table and stays off the path, without a vote
+    if (S.d.nranks > 1 && !S.gtab[4].empty()) {
+        std::vector<char> has((size_t)S.d.nranks, 0);
+        for (int o : S.gtab[4])
+            if (o >= 0 && o < S.d.nranks) has[(size_t)o] = 1;
+        for (char h : has)
+            if (!h) { M.why = "a rank holds no blocks"; return false; }
+    }
     const int want = env("CICE_EVP_HIP_MARCH") ? std::atoi(env("CICE_EVP_HIP_MARCH")) : -1;
     // (a rank that was told CICE_EVP_HIP_MARCH=0 still takes part in the agreement below, voting no: an environment that
     // differs between the ranks then switches the path off everywhere instead of leaving the others in a collective)

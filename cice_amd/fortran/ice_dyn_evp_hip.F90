@@ -288,6 +288,9 @@ module ice_dyn_evp_hip
   end interface
 
   logical :: initialised = .false.
+  ! this task holds no blocks (the reference's distributions allow it): it takes part in the bootstrap among the ranks and
+  ! nothing else -- the library keeps it as a bystander, every routine below returns at once
+  logical :: empty_rank = .false.
   logical :: pinned = .false.
   ! Default = dyn_evp1d_run's contract (ice_dyn_evp1d.F90:121-135): the 12 intent(inout) stress arrays are
   ! copied in and written back on every call, so an UNPATCHED host (restart write ice_restart_driver.F90:187-200,
@@ -364,7 +367,8 @@ contains
 
     nprocs = get_num_procs()
     if (allocated(ilo)) deallocate(ilo, ihi, jlo, jhi, ig0, jg0, gi0, gj0, gnx, gny, gown, gloc)
-    allocate(ilo(nblocks), ihi(nblocks), jlo(nblocks), jhi(nblocks), ig0(nblocks), jg0(nblocks))
+    allocate(ilo(max(nblocks,1)), ihi(max(nblocks,1)), jlo(max(nblocks,1)), jhi(max(nblocks,1)), &
+             ig0(max(nblocks,1)), jg0(max(nblocks,1)))      ! (a task without blocks still hands over valid addresses)
     do n = 1, nblocks
        tb = get_block(blocks_ice(n), n)
        ilo(n) = tb%ilo; ihi(n) = tb%ihi; jlo(n) = tb%jlo; jhi(n) = tb%jhi
@@ -397,7 +401,8 @@ contains
     p%deltaminEVP = deltaminEVP; p%u0 = u0; p%cosw = cosw; p%sinw = sinw; p%rhow = rhow
 
     call check(cice_evp_hip_init(d, p, HTE, HTN, dxT, dyT, uarear, tarea), subname, __FILE__, __LINE__)
-    if (trim(ns_boundary_type) == 'tripole' .or. trim(ns_boundary_type) == 'tripoleT') then
+    empty_rank = nblocks == 0
+    if (.not. empty_rank .and. (trim(ns_boundary_type) == 'tripole' .or. trim(ns_boundary_type) == 'tripoleT')) then
        ! the north ghost row of dxhy/dyhx is a mirrored interior value (halo update with
        ! sign, ice_dyn_shared.F90:412-417): hand over CICE's own arrays
        call check(cice_evp_hip_set_metrics(c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, &
@@ -405,6 +410,7 @@ contains
     endif
 
     call get_environment_variable('CICE_EVP_HIP_STRESS_RESIDENT', envval, envlen, envstat)
+    if (.not. empty_rank) &
     call settle_stress_residency(stress_resident_requested .or. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '1'), &
          .false.)
 
@@ -493,6 +499,10 @@ contains
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
          file=__FILE__, line=__LINE__)
+    if (empty_rank) then
+       call compute_strength()      ! (whatever the host does there among the tasks happens on this one too)
+       return
+    endif
     ! (tripoleT: the library takes the preparation and the symmetrisation where the top row lies on one rank and says
     ! so otherwise -- cice_evp_hip_set_prep_geometry / cice_evp_hip_stress_halo return an error that check() reports)
     nall = nx_block*ny_block*max_blocks
@@ -626,6 +636,7 @@ contains
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
          file=__FILE__, line=__LINE__)
+    if (empty_rank) return
 
     ! logical(log_kind) is a 4-byte Fortran logical (Icepack kinds): hand its storage
     ! to the C side, which tests "non-zero"
@@ -728,6 +739,7 @@ contains
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
          file=__FILE__, line=__LINE__)
+    if (empty_rank) return
     call cgrid_ensure_geometry(ratiodxN, ratiodxNr, ratiodyE, ratiodyEr)
     vm = cgrid_visc_method()
     fl = [cice_evp_hip_addr(uvelE), cice_evp_hip_addr(vvelE), cice_evp_hip_addr(uvelN), cice_evp_hip_addr(vvelN), &
@@ -895,6 +907,10 @@ contains
 
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', &
          file=__FILE__, line=__LINE__)
+    if (empty_rank) then
+       call compute_strength()      ! (whatever the host does there among the tasks happens on this one too)
+       return
+    endif
     call icepack_query_parameters(calc_strair_out=calc_strair)
     if (.not. calc_strair .or. trim(grid_ocn_dynu) /= 'T' .or. trim(grid_ocn_dynv) /= 'T') &
        call abort_ice(subname//' ERROR: needs calc_strair = .true. and ocean forcing on the T grid', &
@@ -1002,6 +1018,7 @@ contains
     use ice_dyn_shared, only: uvelE_init, vvelN_init
     real(kind=dbl_kind), dimension(:,:,:), intent(inout), contiguous :: cdn_ocnE, aiE, uocnE, vocnE, cdn_ocnN, aiN, uocnN, vocnN
     character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_fetch_forcing)'
+    if (empty_rank) return
     ! indices into the loop's input table (include/cice_evp_hip.h: inputs23, 0-based)
     call check(cice_evp_hip_cgrid_fetch(1, 1, cdn_ocnE), subname, __FILE__, __LINE__)
     call check(cice_evp_hip_cgrid_fetch(1, 2, aiE), subname, __FILE__, __LINE__)
@@ -1026,6 +1043,7 @@ contains
     use ice_flux, only: rdg_conv, rdg_shear
     character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_deformations)'
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', file=__FILE__, line=__LINE__)
+    if (empty_rank) return
     call check(cice_evp_hip_cgrid_deformations(tarear, divu, shear, vort, rdg_conv, rdg_shear), subname, __FILE__, __LINE__)
   end subroutine dyn_evp_hip_cgrid_deformations
 
@@ -1035,6 +1053,7 @@ contains
     use ice_flux, only: strocnxN, strocnyN, strocnxE, strocnyE
     character(len=*), parameter :: subname = '(dyn_evp_hip_cgrid_dyn_finish)'
     if (.not. initialised) call abort_ice(subname//' ERROR: dyn_evp_hip_init not called', file=__FILE__, line=__LINE__)
+    if (empty_rank) return
     call check(cice_evp_hip_cgrid_dyn_finish(strocnxN, strocnyN, strocnxE, strocnyE), subname, __FILE__, __LINE__)
   end subroutine dyn_evp_hip_cgrid_dyn_finish
 
@@ -1077,7 +1096,7 @@ contains
          stress12_1, stress12_2, stress12_3, stress12_4
     type(c_ptr) :: s12(12)
     character(len=*), parameter :: subname = '(dyn_evp_hip_fetch_stresses)'
-    if (.not. (initialised .and. stress_resident)) return
+    if (.not. (initialised .and. stress_resident) .or. empty_rank) return
     s12(1) = cice_evp_hip_addr(stressp_1);  s12(2) = cice_evp_hip_addr(stressp_2)
     s12(3) = cice_evp_hip_addr(stressp_3);  s12(4) = cice_evp_hip_addr(stressp_4)
     s12(5) = cice_evp_hip_addr(stressm_1);  s12(6) = cice_evp_hip_addr(stressm_2)
@@ -1094,7 +1113,7 @@ contains
     logical, intent(in) :: flag
     character(len=*), parameter :: subname = '(dyn_evp_hip_keep_stresses_resident)'
     stress_resident_requested = flag
-    if (.not. initialised) return
+    if (.not. initialised .or. empty_rank) return
     if (.not. flag .and. stress_resident) call dyn_evp_hip_fetch_stresses
     call settle_stress_residency(flag, .true.)
   end subroutine dyn_evp_hip_keep_stresses_resident
@@ -1103,7 +1122,7 @@ contains
   subroutine dyn_evp_hip_invalidate_stresses
     character(len=*), parameter :: subname = '(dyn_evp_hip_invalidate_stresses)'
     body_sig_on_device = .false.
-    if (initialised) call check(cice_evp_hip_invalidate_stresses(), subname, __FILE__, __LINE__)
+    if (initialised .and. .not. empty_rank) call check(cice_evp_hip_invalidate_stresses(), subname, __FILE__, __LINE__)
   end subroutine dyn_evp_hip_invalidate_stresses
 
 !-----------------------------------------------------------------------
@@ -1111,6 +1130,7 @@ contains
     character(len=*), parameter :: subname = '(dyn_evp_hip_finalize)'
     if (initialised) call check(cice_evp_hip_finalize(), subname, __FILE__, __LINE__)
     initialised = .false.
+    empty_rank = .false.
     pinned = .false.
   end subroutine dyn_evp_hip_finalize
 

@@ -69,6 +69,12 @@ def run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, body, kw, ndte=24, 
         except RuntimeError as e:
             last = e
     if last is not None:
+        try:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(f"gpurun_out/dropin_mpi_FAIL_{nx}x{ny}_{bx}x{by}_{nprocs}_{dist}_{ns}.log", "w") as f:
+                f.write(str(last)[-20000:])
+        except OSError:
+            pass
         raise last
     checked = 0
     for r, d in enumerate(par):
@@ -118,6 +124,22 @@ def test_reference_mpi_driver_with_hip_core_geometry_sweep(tmp_path, seed):
         kw["h_capping"] = 0.5
     ew = "closed" if (not trip and seed % 2) else "cyclic"
     run_case(tmp_path, nx, ny, bx, by, ew, "tripole" if trip else "closed", nprocs, dist, False, kw, ndte=int(rng.choice([5, 12])))
+
+
+@pytest.mark.parametrize("cgrid", [False, True], ids=["B", "C"])
+@pytest.mark.parametrize("nx,ny,bx,by,ew,ns,nprocs,dist,kw", [
+    (54, 52, 14, 26, "cyclic", "tripole", 3, "cartesian", dict(grid_kind="tripolefile", icecase="full")),    # 4 x 2 blocks: 4, 4, 0
+    (90, 21, 30, 21, "closed", "closed", 2, "cartesian", dict(grid_kind="popfile", icecase="patchy")),        # 3 x 1 blocks: 3, 0
+    (68, 54, 17, 27, "cyclic", "closed", 3, "cartesian", dict(grid_kind="popfile", icecase="caps", h_revised=True)),
+])
+def test_reference_mpi_driver_with_a_task_that_holds_no_blocks(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, kw, cgrid):
+    """The reference's cartesian distribution hands a task NOTHING when its processor grid does not divide the block grid
+    (ice_distribution.F90 create_distrb_cart) and carries on; so does the drop-in: the task without blocks is a bystander
+    of the bootstrap (cice_evp_hip_init with nblocks = 0, an empty blob in the all-gather) and the shim's routines
+    return at once there.  Found by the geometry sweep below (seeds 2043, 2057, 2084, 2119, 2129, 2134, 2136)."""
+    txt = run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, False, kw, cgrid=cgrid)
+    import re
+    assert re.search(r"rank \d+ of \d+", txt)
 
 
 @pytest.mark.parametrize("cgrid", [False, True], ids=["B", "C"])
