@@ -137,9 +137,9 @@ def test_reference_mpi_driver_with_a_task_that_holds_no_blocks(tmp_path, nx, ny,
     (ice_distribution.F90 create_distrb_cart) and carries on; so does the drop-in: the task without blocks is a bystander
     of the bootstrap (cice_evp_hip_init with nblocks = 0, an empty blob in the all-gather) and the shim's routines
     return at once there.  Found by the geometry sweep below (seeds 2043, 2057, 2084, 2119, 2129, 2134, 2136)."""
-    txt = run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, False, kw, cgrid=cgrid)
-    import re
-    assert re.search(r"rank \d+ of \d+", txt)
+    if cgrid and ns == "tripole":
+        pytest.skip("C grid on a tripole grid: the blocks next to the fold must lie on one rank (INTEGRATION.md); this cut splits them in x")
+    run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, False, kw, cgrid=cgrid)
 
 
 @pytest.mark.parametrize("cgrid", [False, True], ids=["B", "C"])
