@@ -92,7 +92,13 @@ typedef struct {
  * CICE's ice_grid module arrays (HTE,HTN,dxT,dyT,uarear,tarea).  Derives the
  * metric terms of init_dyn_shared (ice_dyn_shared.F90:384-441) and uploads
  * them; builds the halo plan; selects the device (HIP device = local rank
- * unless CICE_EVP_HIP_DEVICE is set).                                         */
+ * unless CICE_EVP_HIP_DEVICE is set).
+ * dims->nblocks == 0 with nranks > 1: a task the reference's distribution gave no block
+ * (shared/ice_distribution.F90; evp() then loops over nothing).  Accepted: the rank is a
+ * bystander -- cice_evp_hip_comm_unique_id / _comm_init / _halo_export / _halo_import /
+ * _finalize work and keep the other ranks' collectives complete; every other entry
+ * point refuses it, the host has nothing to hand over there.  With such a rank in the job
+ * the two-subcycle path stays off on every rank.                                  */
 int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *params,
                       const double *HTE, const double *HTN, const double *dxT, const double *dyT,
                       const double *uarear, const double *tarea);
