@@ -126,6 +126,42 @@ def test_reference_mpi_driver_with_hip_core_geometry_sweep(tmp_path, seed):
     run_case(tmp_path, nx, ny, bx, by, ew, "tripole" if trip else "closed", nprocs, dist, False, kw, ndte=int(rng.choice([5, 12])))
 
 
+@pytest.mark.parametrize("seed", list(range(3001, 3011)) + [int(s) for s in os.environ.get("DROPIN_MPI_WIDE_SEEDS", "").split() if s])
+def test_reference_mpi_driver_with_hip_core_wide_sweep(tmp_path, seed):
+    """The sweep above widened: C grid as well (closed north: across ranks the C grid wants the fold's blocks on one rank),
+    the masked halo, Option A (device preparation), tasks without blocks, spacecurve distributions."""
+    rng = np.random.default_rng(seed)
+    cgrid = bool(rng.random() < 0.4)
+    trip = (not cgrid) and seed % 3 == 0
+    nx, ny = 2 * int(rng.integers(12, 50)), int(rng.integers(16, 60))
+    nbx, nby = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    bx, by = -(-nx // nbx), -(-ny // nby)
+    nblk = (-(-nx // bx)) * (-(-ny // by))
+    if nblk < 2:
+        bx = -(-nx // 2)
+        nblk = 2 * (-(-ny // by))
+    nprocs = int(rng.integers(2, 5))
+    if nprocs > nblk:
+        nprocs = nblk
+    dist = str(rng.choice(["cartesian", "roundrobin", "sectrobin", "sectcart", "rake"]))
+    if dist == "sectcart" and (nprocs % 2 or (-(-nx // bx)) % 2):      # (create_distrb_sectcart wants an even nblocks_x)
+        dist = "cartesian"
+    kw = dict(grid_kind="tripolefile" if trip else "popfile", icecase=str(rng.choice(["full", "patchy", "caps"])))
+    if rng.random() < 0.3:
+        kw["h_seabed"] = True
+    if rng.random() < 0.3:
+        kw["h_revised"] = True
+    if rng.random() < 0.3:
+        kw["h_capping"] = 0.5
+    if cgrid and rng.random() < 0.3:
+        kw["h_visc_method"] = "avg_strength"
+    body = (not cgrid) and bool(rng.random() < 0.3)
+    maskhalo = bool(rng.random() < 0.4)
+    ew = "closed" if (not trip and seed % 2) else "cyclic"
+    run_case(tmp_path, nx, ny, bx, by, ew, "tripole" if trip else "closed", nprocs, dist, body, kw,
+             ndte=int(rng.choice([5, 12])), cgrid=cgrid, maskhalo=maskhalo)
+
+
 @pytest.mark.parametrize("cgrid", [False, True], ids=["B", "C"])
 @pytest.mark.parametrize("nx,ny,bx,by,ew,ns,nprocs,dist,kw", [
     (54, 52, 14, 26, "cyclic", "tripole", 3, "cartesian", dict(grid_kind="tripolefile", icecase="full")),    # 4 x 2 blocks: 4, 4, 0
