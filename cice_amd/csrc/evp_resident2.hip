@@ -125,6 +125,19 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // launch order = heaviest tiles first (host-sorted by active waves, see resident2_order): the
     // workgroups that end up third on a CU are then the cheap ones (land, partial edge tiles)
     const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
+    {
+        // A tile that owns no U-cell leaves at once.  The tile grid is uniform over the blocks of a rank (sized for the
+        // largest one), so a block that is a row or column shorter than the largest gets a last tile row / column that
+        // starts beyond its last U-cell: all such a tile holds is the T-row jhi+1 (or column ihi+1), which the tile below
+        // (left of) it computes and stores as well.  It would poll its neighbours' records every subcycle while nobody
+        // polls any of its own -- a reader without back-pressure on its producers: they may run two subcycles ahead of
+        // it and overwrite a record it has not read, after which it waits for ever (seen as "a wait gave up ... tag
+        // seen 0x1002, wanted 0x1000" in the probe of a 3 x 3-block decomposition whose top blocks are one row short;
+        // on a single rank the call then fell back to the streaming kernel, across ranks it failed).
+        const int pb = A.gx * A.gy;
+        const int4 rb = A.blk[tile / pb];
+        if (rb.x + ((tile % pb) % A.gx) * (W - 1) > rb.y || rb.z + ((tile % pb) / A.gx) * (H - 1) > rb.w) return;
+    }
     // PERM: which quarter ("chunk") of the tile's permuted cell list this wave takes.  The host packs
     // the ice cells of a tile into its first chunks (a coastal tile then costs one or two waves, not
     // four).  A SIMD issues for one wave at a time and all tiles advance in lock step, so the SIMD with
