@@ -1331,3 +1331,61 @@ def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
         core.finalize()
     # ... and the preparation phase on the device (T-fold rule of the cell-centre fields), then the whole evp()
     check_next_tier_prep(c, what)
+
+
+def test_resident_kernel_blocks_of_unequal_height_no_reader_without_a_reader(monkeypatch):
+    """Regression (round 5, found by the MPI drop-in sweep): 3 x 3 blocks of 24 x 16 on a 72 x 47 domain -- the top blocks are
+    one row short, the rank's tile grid is sized for the largest block, so their second tile row owns no U-cell.  Such a
+    tile used to poll its neighbours every subcycle while nobody polled it: its producers could run two subcycles ahead
+    and overwrite a record it had not read; the bounded wait then gave up and the call was silently repeated with the
+    streaming kernel.  The resident kernel is REQUIRED here (an error instead of a fall-back), several calls in a row,
+    short and long loops; no call may have been repeated, every result equals the oracle's."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    # test build: tile 2 of every block (its second tile row: the one without U-cells in the short blocks) lags by ~10 us per
+    # subcycle -- the late reader the race needs; bit 512 below brings the old behaviour back
+    monkeypatch.setenv("CICE_EVP_HIP_RES_DEBUG", "256")
+    nx, ny, bx, by = 72, 47, 24, 16
+    g = synth.derive_geometry(synth.make_grid(nx, ny, 1.1e5, ns="closed"))
+    st = synth.make_state(g, case="full", seed=901, warm=True)
+    dc = decomp.Decomp(nx, ny, bx, by, "closed", "closed", 1)
+    assert sorted({b.gny for b in dc.local_blocks(0)}) == [15, 16]
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+    tm, um = dc.scatter(st["iceTmask"], 0, fill=0), dc.scatter(st["iceUmask"], 0, fill=0)
+    scal = synth.evp_scalars(120)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        want = {n: run_oracle(dc, geo, fields, tm, um, scal, n) for n in (3, 24)}
+        for rep in range(40):
+            n = 3 if rep % 2 else 24
+            got = core.run(fields, tm, um, ndte=n)
+            assert_bitwise(got, want[n], f"call {rep}, {n} subcycles")
+        t = core.timings()
+        assert t["tile_variant"] >= 2000 and t["resident_fallbacks"] == 0, t
+    finally:
+        core.finalize()
+    # ... and the hazard itself: the same with those tiles kept (RES_DEBUG bit 512) -- the lagging reader loses its record,
+    # the bounded wait gives up; the resident entry point reports it (cice_evp_hip_run would have fallen back)
+    monkeypatch.setenv("CICE_EVP_HIP_RES_DEBUG", str(256 + 512))
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    shown = False
+    try:
+        for rep in range(6):
+            try:
+                got = core.run(fields, tm, um, ndte=24)
+            except Exception as e:  # noqa: BLE001   (the required resident kernel's probe or launch gave up)
+                shown = "gave up" in str(e) or "probe failed" in str(e) or "resident" in str(e)
+                assert shown, e
+                break
+            assert_bitwise(got, want[24], f"old behaviour, call {rep}: a fall-back still gives the right answer")
+            if core.timings()["resident_fallbacks"] >= 1:
+                shown = True
+                break
+    finally:
+        core.finalize()
+    assert shown, "a reader nobody reads was expected to lose a record when it lags (if not: the hook does not bite any more)"
