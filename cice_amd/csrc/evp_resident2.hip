@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     // launch order = heaviest tiles first (host-sorted by active waves, see resident2_order): the
     // workgroups that end up third on a CU are then the cheap ones (land, partial edge tiles)
     const int tile = R.order ? R.order[blockIdx.x] : (int)blockIdx.x;
+    bool no_ucell;
     {
         // A tile that owns no U-cell leaves at once.  The tile grid is uniform over the blocks of a rank (sized for the
         // largest one), so a block that is a row or column shorter than the largest gets a last tile row / column that
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         // on a single rank the call then fell back to the streaming kernel, across ranks it failed).
         const int pb = A.gx * A.gy;
         const int4 rb = A.blk[tile / pb];
-        // (test build, RES_DEBUG bit 512: keep them, to show the hazard -- tests/test_gpu_parity.py)
-        if (!(RES_DBG(R) & 512) && (rb.x + ((tile % pb) % A.gx) * (W - 1) > rb.y || rb.z + ((tile % pb) / A.gx) * (H - 1) > rb.w)) return;
+        // (test build, RES_DEBUG bit 512: keep them, bit 256: and let them lag -- to show the hazard, tests/test_gpu_parity.py)
+        no_ucell = rb.x + ((tile % pb) % A.gx) * (W - 1) > rb.y || rb.z + ((tile % pb) / A.gx) * (H - 1) > rb.w;
+        if (no_ucell && !(RES_DBG(R) & 512)) return;
     }
     // PERM: which quarter ("chunk") of the tile's permuted cell list this wave takes.  The host packs
     // the ice cells of a tile into its first chunks (a coastal tile then costs one or two waves, not
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         const v4u *rd = (const v4u *)R.rec[(k + par0) & 1];
         v4u *wr = (v4u *)R.rec[((k + par0) & 1) ^ 1];
 
-        if (((RES_DBG(R) & 8) && (tile & 3) == 1) || ((RES_DBG(R) & 256) && (tile & 3) == 2)) {      // robustness test: every fourth tile lags by ~10 us per subcycle
+        if (((RES_DBG(R) & 8) && (tile & 3) == 1) || ((RES_DBG(R) & 256) && no_ucell)) {      // robustness test: every fourth tile lags by ~10 us per subcycle
             const unsigned long long t0 = wall_clock64();
             while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(8);
         }

@@ -1341,9 +1341,10 @@ def test_resident_kernel_blocks_of_unequal_height_no_reader_without_a_reader(mon
     streaming kernel.  The resident kernel is REQUIRED here (an error instead of a fall-back), several calls in a row,
     short and long loops; no call may have been repeated, every result equals the oracle's."""
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
-    # test build: tile 2 of every block (its second tile row: the one without U-cells in the short blocks) lags by ~10 us per
-    # subcycle -- the late reader the race needs; bit 512 below brings the old behaviour back
-    monkeypatch.setenv("CICE_EVP_HIP_RES_DEBUG", "256")
+    # test build (the library with the debug hooks is picked because this name is set); bit 256 + 512 below bring the old
+    # behaviour back and let the tiles without U-cells lag -- the late reader the race needs
+    monkeypatch.setenv("CICE_EVP_HIP_RES_DEBUG", "0")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_LOGW", "4")     # 16 x 16 tiles (what ranks with remote neighbours use): 32 x 8 tiles happen to fit these blocks
     nx, ny, bx, by = 72, 47, 24, 16
     g = synth.derive_geometry(synth.make_grid(nx, ny, 1.1e5, ns="closed"))
     st = synth.make_state(g, case="full", seed=901, warm=True)
