@@ -155,7 +155,11 @@ def run_hip(dc, geo, fields, tm, um, scal, strict, ndte, rccl_self=False):
     try:
         if rccl_self:
             core.comm_init(core.comm_unique_id())
-        return core.run(fields, tm, um, ndte=ndte)
+        out = core.run(fields, tm, um, ndte=ndte)
+        # a call the resident kernel gave up on is repeated with the streaming kernel and still returns the right answer:
+        # nothing here injects a failure, so a repeat is a defect in hiding (round 5: the reader nobody read)
+        assert core.timings()["resident_fallbacks"] == 0, core.timings()
+        return out
     finally:
         core.finalize()
 
@@ -1234,6 +1238,8 @@ def test_bgrid_random_geometry_vs_oracle(seed, resident, monkeypatch):
     resident kernels (forced; where a layout is not eligible the library says so and streams) against the oracle."""
     monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", resident)
     monkeypatch.setenv("CICE_EVP_HIP_MARCH", "0")
+    if resident == "1" and seed % 2:
+        monkeypatch.setenv("CICE_EVP_HIP_RES_LOGW", "4")     # 16 x 16 tiles whatever the probes would pick (the shape ranks with remote neighbours use)
     rng = np.random.default_rng(seed)
     nx, ny = int(rng.integers(40, 220)), int(rng.integers(30, 160))
     ew = "cyclic" if seed % 3 else "closed"
@@ -1288,6 +1294,7 @@ def test_bgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
                     assert_bitwise(out, c.expected(icall, nsub), f"{what}: call {icall} nsub {nsub}, {kernel}")
                     if kernel == "march":
                         marched += int(core.march_info()["last_call"])
+            assert core.timings()["resident_fallbacks"] == 0, (what, kernel, core.timings())
         finally:
             core.finalize()
     assert ns != "closed" or marched >= 2, (what, marched)      # the runs did go through the two-subcycle path
