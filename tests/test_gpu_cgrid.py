@@ -1062,5 +1062,6 @@ def test_cgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
             oracle.halo_update(dom, out["strintyN"], "Nface", "vector")
             assert_bitwise(out, c.cgrid_expected(icall, c.nsub_list[-1]), f"{what}: call {icall} (device preparation + loop)")
         assert np.abs(out["uvelE"]).max() > 1e-4, what
+        assert core.cgrid_timings()["resident_fallbacks"] == 0, (what, core.cgrid_timings())     # nothing repeated in silence
     finally:
         core.finalize()
