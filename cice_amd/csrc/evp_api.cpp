@@ -70,6 +70,18 @@ int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second)
     return 0;
 }
 
+// HIP device of this rank: CICE_EVP_HIP_DEVICE, else the rank's index on its node as the launcher states it
+// (torch.distributed.run, Open MPI, MVAPICH2, MPICH / Intel MPI hydra, Slurm), else rank modulo the device count --
+// right on one node, and on several when the launcher places ranks block-wise.
+static int pick_device(int rank, int ndev)
+{
+    if (env("CICE_EVP_HIP_DEVICE")) return std::atoi(env("CICE_EVP_HIP_DEVICE"));
+    for (const char *name : {"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"})
+        if (const char *v = std::getenv(name))
+            if (*v >= '0' && *v <= '9') return std::atoi(v) % ndev;
+    return rank % ndev;
+}
+
 int cice_evp_hip_finalize(void)
 {
     if (S.stream) (void)hipStreamSynchronize(S.stream);
@@ -99,8 +111,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         int ndev = 0;
         HIPC(hipGetDeviceCount(&ndev));
         if (ndev < 1) return fail(-4, "no HIP device");
-        S.device = env("CICE_EVP_HIP_DEVICE") ? std::atoi(env("CICE_EVP_HIP_DEVICE"))
-                   : env("LOCAL_RANK") ? std::atoi(env("LOCAL_RANK")) % ndev : dims->rank % ndev;
+        S.device = pick_device(dims->rank, ndev);
         HIPC(hipSetDevice(S.device));
         HIPC(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         S.bystander = true;
@@ -171,10 +182,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
     int ndev = 0;
     HIPC(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(-4, "no HIP device");
-    int dev = 0;
-    if (env("CICE_EVP_HIP_DEVICE")) dev = std::atoi(env("CICE_EVP_HIP_DEVICE"));
-    else if (env("LOCAL_RANK")) dev = std::atoi(env("LOCAL_RANK")) % ndev;
-    else dev = dims->rank % ndev;
+    const int dev = pick_device(dims->rank, ndev);
     S.device = dev;
     HIPC(hipSetDevice(dev));
     HIPC(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
