@@ -82,6 +82,7 @@ struct EvpResident2 {
     const uint8_t *perm;       // [ntiles][256] cell position trow*16 + tcol of (permuted) thread index
     const uint8_t *late_waves; // [ntiles]
     const uint8_t *nact;       // [ntiles] chunks (64 entries of perm) that hold ice cells: the first nact
+    const uint8_t *nlate;      // [ntiles] COOP: rim T-cells with ice = the first nlate entries of perm (<= 64); NULL: the variant is off
     int *cuload;               // [2048][8] per-CU record of the launch: lock, stamp, ice-holding waves per SIMD
     unsigned long long *prof;  // NULL, or [ntiles][4 chunks][8]: cycles per phase (tools)
     int dbg;                   // timing experiments only (CICE_EVP_HIP_RES_DEBUG; WRONG results): 1 no tag check, 2 no ring loads, 4 longer sleep; 8 = every fourth tile lags 10 us per subcycle (results stay right); 16 = tile 1 never runs (every wait on it gives up); A/B switches, results stay right: 32 = 16 x 16 tiles without the rim-wave split, 64 = without the per-CU SIMD balancing
@@ -103,7 +104,8 @@ struct EvpResident2 {
     void *const *peer_raw;     // [npeers] the peer's rec_raw buffer (parity 0) as mapped here
     const size_t *peer_raw_stride;
 };
-int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote);
+int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote, bool coop = false);
+bool evp_resident2_coop_built(bool strict, int cap, int logw, bool remote);   // the rim-cells-by-corners variant exists for this combination
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,
                           bool strict, int cap, hipStream_t st);
 

@@ -65,6 +65,8 @@ enum Field {
     F_UVEL_INIT, F_VVEL_INIT, F_COUNT
 };
 
+#define EVP_RES2_COOP_DEFAULT 0      // rim T-cells by corners in the resident B-grid kernel: the product's choice where it is possible
+
 struct State {
     bool ready = false;
     // A rank that holds NO blocks (the reference allows it: a cartesian distribution whose processor grid does not divide
@@ -220,7 +222,9 @@ struct State {
     int *res2_cnt = nullptr;
     uint8_t *res2_pub = nullptr;
     // 16 x 16 tiles (rim wave / interior waves): thread -> cell map, waves that wait for the ring, chunks with ice
-    uint8_t *res2_perm = nullptr, *res2_late = nullptr, *res2_nact = nullptr;
+    uint8_t *res2_perm = nullptr, *res2_late = nullptr, *res2_nact = nullptr, *res2_nlate = nullptr;
+    int res2_coop = -1;            // rim T-cells by corners (evp_resident2.hip COOP): -1 undecided, 0 off, 1 on
+    bool res2_coop_ok = false;     // ... possible for the current tables (every tile's rim list fits 64 quads)
     int *res2_cuload = nullptr;                           // per-CU record of a launch (EvpResident2::cuload)
     unsigned long long *res2_prof = nullptr;              // phase stamps (CICE_EVP_HIP_RES_PROF=1)
     std::vector<uint8_t> res2_cls_h;                      // per tile and cell position: 0 not computed, 1 reads no ring velocity, 2 does

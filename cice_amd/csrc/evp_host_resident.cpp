@@ -39,7 +39,7 @@ int resident2_setup(int logw)
 {
     if (S.res2_ring && S.res2_logw == logw) return 0;
     auto F = [](auto *&p) { if (p) (void)hipFree((void *)p); p = nullptr; };
-    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact);
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact); F(S.res2_nlate);
     S.res2_cls_h.clear();
     S.res2_order_stale = true;
     S.res2_logw = logw;
@@ -169,6 +169,7 @@ int resident2_setup(int logw)
         HIPC(hipMalloc((void **)&S.res2_perm, (size_t)ntiles * 256));
         HIPC(hipMalloc((void **)&S.res2_late, (size_t)ntiles));
         HIPC(hipMalloc((void **)&S.res2_nact, (size_t)ntiles));
+        HIPC(hipMalloc((void **)&S.res2_nlate, (size_t)ntiles));
         if (!S.res2_cuload) {
             HIPC(hipMalloc((void **)&S.res2_cuload, 2048 * 8 * sizeof(int)));
             HIPC(hipMemset(S.res2_cuload, 0, 2048 * 8 * sizeof(int)));
@@ -223,7 +224,8 @@ int resident2_order()
     const bool permuted = !S.res2_cls_h.empty() && S.res2_logw == 4;
     std::vector<int> cost((size_t)ntiles);        // 1024 * ice-holding waves + ice cells
     std::vector<uint8_t> perm(permuted ? (size_t)ntiles * 256 : 0), late(permuted ? (size_t)ntiles : 0),
-                         nact(permuted ? (size_t)ntiles : 0);
+                         nact(permuted ? (size_t)ntiles : 0), nlt(permuted ? (size_t)ntiles : 0);
+    bool coop_ok = permuted;
     for (int t = 0; t < ntiles; ++t) {
         const int b = t / (gx * gy), bx = (t % (gx * gy)) % gx, by = (t % (gx * gy)) / gx;
         const int i0 = S.ilo[b] + bx * (W - 1), j0 = S.jlo[b] + by * (H - 1);
@@ -249,6 +251,11 @@ int resident2_order()
             waves = (n + 63) / 64;
             nact[t] = (uint8_t)waves;
             late[t] = (uint8_t)std::min(4, (std::max(nlate, S.res2_cnt_h[t]) + 63) / 64);
+            // COOP: the first 64 ice cells of the list -- every rim cell and as many of the others as the 64 quads take -- are
+            // updated by quads, so that the wave that polls the ring holds no cell of its own to update afterwards (a wave's
+            // pass through the stress update costs the same for 4 active lanes as for 64)
+            nlt[t] = (uint8_t)std::min(n, 64);
+            if (nlate > 64) coop_ok = false;
         } else {
             int wave_on[4] = {0, 0, 0, 0};
             for (int pos = 0; pos < 256; ++pos)
@@ -261,7 +268,9 @@ int resident2_order()
         HIPC(hipMemcpyAsync(S.res2_perm, perm.data(), perm.size(), hipMemcpyHostToDevice, S.stream));
         HIPC(hipMemcpyAsync(S.res2_late, late.data(), late.size(), hipMemcpyHostToDevice, S.stream));
         HIPC(hipMemcpyAsync(S.res2_nact, nact.data(), nact.size(), hipMemcpyHostToDevice, S.stream));
+        HIPC(hipMemcpyAsync(S.res2_nlate, nlt.data(), nlt.size(), hipMemcpyHostToDevice, S.stream));
     }
+    S.res2_coop_ok = coop_ok;
     const bool off = env_test("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env_test("CICE_EVP_HIP_RES_ORDER"));
     std::vector<int> order((size_t)ntiles);
     for (int w = 0; w < ntiles; ++w) order[w] = w;
@@ -318,6 +327,21 @@ int launch_resident2(int ndte, int cur0, bool dry)
     R.perm = S.res2_perm;
     R.late_waves = S.res2_late;
     R.nact = S.res2_nact;
+    // rim T-cells by corners (COOP): where the variant is built, every tile's rim list fits its 64 quads and the chip still
+    // takes all tiles at once with the variant's larger LDS share (the same rule as resident2_fits)
+    {
+        const int want = env_test("CICE_EVP_HIP_RES_COOP") ? std::atoi(env_test("CICE_EVP_HIP_RES_COOP")) : EVP_RES2_COOP_DEFAULT;
+        bool can = want != 0 && S.res2_coop_ok && S.res2_logw == 4 && !S.res_remote &&
+                   evp_resident2_coop_built(S.prm.strict != 0, cap_mode(), S.res2_logw, false);
+        if (can) {
+            hipDeviceProp_t prop;
+            const int per_cu = std::min(evp_resident2_max_blocks_per_cu(true, cap_mode(), A.flags, 4, false, true), 8);
+            can = hipGetDeviceProperties(&prop, S.device) == hipSuccess &&
+                  (long)S.res2_ntiles * 10 <= (long)per_cu * prop.multiProcessorCount * 9;
+        }
+        S.res2_coop = can ? 1 : 0;
+        R.nlate = can ? S.res2_nlate : nullptr;
+    }
     R.cuload = S.res2_cuload;
     R.prof = nullptr;
     if (S.res2_logw == 4 && env_test("CICE_EVP_HIP_RES_PROF") && std::atoi(env_test("CICE_EVP_HIP_RES_PROF"))) {

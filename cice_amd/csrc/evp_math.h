@@ -49,6 +49,24 @@ template <> struct Math<true> {
     {
         evp_strict::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);
     }
+    // stress_cell one corner per lane (evp_resident2.hip, COOP)
+    using CI = evp_strict::CornerIn;
+    template <int MODE>
+    static __device__ __forceinline__ void corner(const EvpScalars &p, const CI &c, double &sp, double &sm, double &s12)
+    {
+        evp_strict::stress_corner<(MODE == 3 ? 1 : MODE), MODE == 3>(p, c, sp, sm, s12);
+    }
+    static __device__ __forceinline__ void corner_operands(int q, double dxT, double dyT, double cxp, double cyp, double cxm, double cym,
+                                                           CI &c, double &KX, double &K12X, double &KYP, double &K12Y)
+    {
+        evp_strict::corner_operands(q, dxT, dyT, cxp, cyp, cxm, cym, c, KX, K12X, KYP, K12Y);
+    }
+    static __device__ __forceinline__ void partials(double P0, double P1, double P2, double P3, double M0, double M1, double M2, double M3,
+                                                    double T0, double T1, double T2, double T3, double KX, double K12X, double KYP,
+                                                    double K12Y, double dxhy, double dyhx, double &X, double &Y)
+    {
+        evp_strict::stress_corner_partials(P0, P1, P2, P3, M0, M1, M2, M3, T0, T1, T2, T3, KX, K12X, KYP, K12Y, dxhy, dyhx, X, Y);
+    }
 };
 template <> struct Math<false> {
     using SI = evp_fused::StressIn;
@@ -66,6 +84,24 @@ template <> struct Math<false> {
     static __device__ __forceinline__ void metrics(double hte, double hte_im, double htn, double htn_jm, double dmin, SI &a)
     {
         evp_fused::metrics_cell(hte, hte_im, htn, htn_jm, dmin, a);
+    }
+    // stress_cell one corner per lane (evp_resident2.hip, COOP)
+    using CI = evp_fused::CornerIn;
+    template <int MODE>
+    static __device__ __forceinline__ void corner(const EvpScalars &p, const CI &c, double &sp, double &sm, double &s12)
+    {
+        evp_fused::stress_corner<(MODE == 3 ? 1 : MODE), MODE == 3>(p, c, sp, sm, s12);
+    }
+    static __device__ __forceinline__ void corner_operands(int q, double dxT, double dyT, double cxp, double cyp, double cxm, double cym,
+                                                           CI &c, double &KX, double &K12X, double &KYP, double &K12Y)
+    {
+        evp_fused::corner_operands(q, dxT, dyT, cxp, cyp, cxm, cym, c, KX, K12X, KYP, K12Y);
+    }
+    static __device__ __forceinline__ void partials(double P0, double P1, double P2, double P3, double M0, double M1, double M2, double M3,
+                                                    double T0, double T1, double T2, double T3, double KX, double K12X, double KYP,
+                                                    double K12Y, double dxhy, double dyhx, double &X, double &Y)
+    {
+        evp_fused::stress_corner_partials(P0, P1, P2, P3, M0, M1, M2, M3, T0, T1, T2, T3, KX, K12X, KYP, K12Y, dxhy, dyhx, X, Y);
     }
 };
 

@@ -92,14 +92,33 @@ __device__ __forceinline__ double unpack_rec(v4u r)
     return __longlong_as_double((long long)(((unsigned long long)r.z << 32) | r.y));
 }
 
+// quad permute of a double (one DPP move per 32-bit half): lane l of every four adjacent lanes reads lane (l ^ X)
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+constexpr int QP_X1 = 0xB1, QP_X2 = 0x4E, QP_X3 = 0x1B;      // quad_perm [1,0,3,2], [2,3,0,1], [3,2,1,0]
+
 // REMOTE: some ghost cells mirror cells of OTHER ranks (GPUs of the same node).  Their records
 // live in this rank's record buffer and are written by the producing GPU with plain 16-byte
 // stores over xGMI (the buffer is mapped there through HIP IPC); an edge cell with remote images
 // stores its record into the peers' buffers as well.  Nothing else changes: the halo exchange is
 // a remote store plus the ring poll that is there anyway.
-template <bool STRICT, int CAP, int LOGW, bool REMOTE>
+// COOP (16 x 16 tiles, strict arithmetic, the default scalars -- CAP == 3 -- only): the T-cells that read ring velocities are
+// not updated by one thread each after the ring poll -- 700 instructions of one wave on the critical path of every
+// subcycle, while the other three waves of the tile wait at the barrier -- but by FOUR lanes each, one per corner, spread over
+// all four waves: a lane works out the strain rates, Delta, the viscosities and the three stresses of its corner (the corner's
+// operands and signs selected per lane, the operations and their order those of stress_cell: a - b*c == a + (-b)*c, x + y == y + x
+// bit for bit), fetches the other three corners' stresses with quad-permute moves, and forms the two stress-divergence partials
+// that carry its corner's coefficients.  The cell's stresses live three per lane in those quads for the whole call.
+template <bool STRICT, int CAP, int LOGW, bool REMOTE, bool COOP = false>
 __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(EvpArgs A, EvpResident2 R)
 {
+    static_assert(!COOP || (STRICT && CAP == 3 && LOGW == 4), "COOP: 16 x 16 tiles, strict build, default scalars");
     using MM = Math<STRICT>;
     constexpr int W = 1 << LOGW;
     constexpr int H = 256 / W;
@@ -116,6 +135,8 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     double *s_u = s_tc + 4 * 256;
     double *s_v = s_u + NUV;
     double *s_uc = s_v + NUV;
+    // COOP: per rim T-cell its ten operands (s_rc[k * 64 + g]) and the two partials its own U-cell's thread keeps (s_r04), behind s_uc
+    double *s_rc = nullptr, *s_r04 = nullptr;
     __shared__ int s_bad;
 
     __shared__ int s_chunk[4], s_simd[4], s_cu;
@@ -232,6 +253,10 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     const unsigned flags = A.flags;
     const bool water = !(flags & EVP_F_WATER_IS_OCN);
     const bool tbu = !(flags & EVP_F_TBU_ZERO);
+    if (COOP) {
+        s_rc = s_uc + (8 + (water ? 2 : 0) + (tbu ? 1 : 0)) * 256;
+        s_r04 = s_rc + 10 * 64;
+    }
 
     const bool inT = (i <= r.y + 1) && (j <= r.w + 1);
     unsigned m = 0;
@@ -247,11 +272,62 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     const bool ownU = (tcol < W - 1) && (trow < H - 1) && (i <= r.y) && (j <= r.w);
     const bool pub = ownU && (R.pubmap[c] != 0);
     const int par0 = R.par0;                      // record buffer of subcycle index 0 in this launch
+    // COOP: the first nlate entries of the tile's permuted cell list are its rim T-cells with ice (resident2_order); the
+    // thread that holds such a cell leaves its stress update to the quad g = its list index, lanes 4g .. 4g+3 of the workgroup
+    const int nlate = COOP ? (int)R.nlate[tile] : 0;
+    const bool rim_owner = COOP && tq < nlate;
+    const bool actN = actT && !rim_owner;         // this thread updates its own T-cell
+    const int g = t >> 2, qc = t & 3;             // quad, corner: 0 NE, 1 NW, 2 SW, 3 SE (the order of the stress arrays)
+    const bool quad = COOP && g < nlate;
+    int gc = 0;
+    unsigned g_vel = 0, g_out = 0;                // packed LDS indices: the three velocity cells (10 bits each), the two outputs (16 bits each)
+    bool gown = false;
+    double sr0 = 0.0, sr1 = 0.0, sr2 = 0.0;       // stressp_q, stressm_q, stress12_q of the quad's cell
+    if (quad) {
+        const int gpos = (int)R.perm[tile * 256 + g];
+        const int gcol = gpos & (W - 1), grow = gpos >> LOGW;
+        const int gi = i0 + gcol, gj = j0 + grow;
+        gc = cb + (gj - 1) * nx + (gi - 1);
+        gown = (gcol < W - 1 || gi == r.y + 1) && (grow < H - 1 || gj == r.w + 1);
+        const int gli = (grow + 1) * LW + (gcol + 1);
+        const int ij = gli, im = gli - 1, jm = gli - LW, mm = gli - LW - 1;
+        // the corner's operands: first / second velocity of the u-pair, second of the v-pair (the first is the same cell)
+        const int g_oa = qc == 0 ? ij : qc == 1 ? im : qc == 2 ? mm : jm;
+        const int g_ob = qc == 0 ? im : qc == 1 ? ij : qc == 2 ? jm : mm;
+        const int g_od = qc == 0 ? jm : qc == 1 ? mm : qc == 2 ? im : ij;
+        g_vel = (unsigned)g_oa | ((unsigned)g_ob << 10) | ((unsigned)g_od << 20);
+        // where the lane's two partials go: NE str(1), str(5) -> the cell's own thread (s_r04); NW str(2), str(7) -> planes 4, 5;
+        // SW str(4), str(8) -> planes 2, 3; SE str(3), str(6) -> planes 0, 1
+        const int gsp = grow * SW + gcol;
+        const int off04 = (int)(s_r04 - s_str);   // (indices relative to s_str: the NE lane's two go to s_r04)
+        const int g_ox = qc == 0 ? off04 + g : (qc == 1 ? 4 : qc == 2 ? 2 : 0) * SP + gsp;
+        const int g_oy = qc == 0 ? off04 + 64 + g : (qc == 1 ? 5 : qc == 2 ? 3 : 1) * SP + gsp;
+        g_out = (unsigned)g_ox | ((unsigned)g_oy << 16);
+        sr0 = R.tab[R.cur0 * 12 + qc][gc];
+        sr1 = R.tab[R.cur0 * 12 + 4 + qc][gc];
+        sr2 = R.tab[R.cur0 * 12 + 8 + qc][gc];
+        if (qc == 0) {
+            typename MM::SI b;
+            b.dxT = A.dxT[gc]; b.dyT = A.dyT[gc];
+            b.strength = A.strength[gc];
+            if ((flags & EVP_F_METRICS) && !(flags & EVP_F_DXHY_ARRAY)) {
+                MM::metrics(A.HTE[gc], A.HTE[gc - 1], A.HTN[gc], A.HTN[gc - nx], A.deltaminEVP, b);
+            } else {
+                b.dxhy = A.dxhy[gc]; b.dyhx = A.dyhx[gc];
+                b.cxp = A.cxp[gc]; b.cyp = A.cyp[gc]; b.cxm = A.cxm[gc]; b.cym = A.cym[gc];
+                b.DminTarea = A.DminTarea[gc];
+            }
+            s_rc[0 * 64 + g] = b.strength; s_rc[1 * 64 + g] = b.DminTarea;
+            s_rc[2 * 64 + g] = b.dxT; s_rc[3 * 64 + g] = b.dyT;
+            s_rc[4 * 64 + g] = b.cxp; s_rc[5 * 64 + g] = b.cyp; s_rc[6 * 64 + g] = b.cxm; s_rc[7 * 64 + g] = b.cym;
+            s_rc[8 * 64 + g] = b.dxhy; s_rc[9 * 64 + g] = b.dyhx;
+        }
+    }
 
     // ---- state that stays on the CU for the whole call -------------------------------------
     typename MM::SI a;
     double s[12];
-    if (actT) {
+    if (actN) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) s[k] = R.tab[R.cur0 * 12 + k][c];
         a.dxT = A.dxT[c]; a.dyT = A.dyT[c];
@@ -504,7 +580,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         double str[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) str[e] = 0.0;
-        if (actT) {
+        if (actN) {
             a.u_ij = s_u[li]; a.v_ij = s_v[li];
             a.u_im = s_u[li - 1]; a.v_im = s_v[li - 1];
             a.u_jm = s_u[li - LW]; a.v_jm = s_v[li - LW];
@@ -516,14 +592,44 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
         EVP_STAMP(pacc1)
         double sx1, sy2;
         if (PERM) {      // by cell position: the U-cell's thread need not sit next to its T neighbours
-            s_str[0 * SP + sp] = str[2];
-            s_str[1 * SP + sp] = str[5];
-            s_str[2 * SP + sp] = str[3];
-            s_str[3 * SP + sp] = str[7];
-            s_str[4 * SP + sp] = str[1];
-            s_str[5 * SP + sp] = str[6];
+            if (!rim_owner) {      // (COOP: a rim cell's partials come from its quad)
+                s_str[0 * SP + sp] = str[2];
+                s_str[1 * SP + sp] = str[5];
+                s_str[2 * SP + sp] = str[3];
+                s_str[3 * SP + sp] = str[7];
+                s_str[4 * SP + sp] = str[1];
+                s_str[5 * SP + sp] = str[6];
+            }
             __syncthreads();
             if (split && s_bad) return;   // set by wave 0 before the barrier
+            if (COOP) {
+                EVP_STAMP(pacc2)      // (stamps: the wait at this barrier counts as "wait B1", the quads' work as "stress")
+                // the ring is in LDS for everybody now: the rim T-cells, one corner per lane, all four waves
+                if (quad) {
+                    typename MM::CI cn;
+                    double KX, K12X, KYP, K12Y;
+                    MM::corner_operands(qc, s_rc[2 * 64 + g], s_rc[3 * 64 + g], s_rc[4 * 64 + g], s_rc[5 * 64 + g], s_rc[6 * 64 + g],
+                                        s_rc[7 * 64 + g], cn, KX, K12X, KYP, K12Y);
+                    unsigned pv = g_vel, po = g_out;
+                    asm volatile("" : "+v"(pv), "+v"(po));      // (unpacked here, every subcycle: not five registers for the whole call)
+                    const int g_oa = (int)(pv & 1023u), g_ob = (int)((pv >> 10) & 1023u), g_od = (int)(pv >> 20);
+                    cn.ua = s_u[g_oa]; cn.va = s_v[g_oa];
+                    cn.ub = s_u[g_ob]; cn.vb = s_v[g_ob];
+                    cn.ud = s_u[g_od]; cn.vd = s_v[g_od];
+                    cn.strength = s_rc[0 * 64 + g]; cn.DminTarea = s_rc[1 * 64 + g];
+                    MM::template corner<CAP>(A.p, cn, sr0, sr1, sr2);
+                    double X, Y;
+                    MM::partials(sr0, quad_perm<QP_X1>(sr0), quad_perm<QP_X2>(sr0), quad_perm<QP_X3>(sr0),
+                                 sr1, quad_perm<QP_X1>(sr1), quad_perm<QP_X2>(sr1), quad_perm<QP_X3>(sr1),
+                                 sr2, quad_perm<QP_X1>(sr2), quad_perm<QP_X2>(sr2), quad_perm<QP_X3>(sr2),
+                                 KX, K12X, KYP, K12Y, s_rc[8 * 64 + g], s_rc[9 * 64 + g], X, Y);
+                    s_str[po & 0xffffu] = X;
+                    s_str[po >> 16] = Y;
+                }
+                EVP_STAMP(pacc1)
+                __syncthreads();
+                if (rim_owner) { str[0] = s_r04[tq]; str[4] = s_r04[64 + tq]; }
+            }
             sx1 = s_str[4 * SP + sp + 1];   // (sp + 1 < SP also for the last cell of the last row: SW = W + 1)
             sy2 = s_str[5 * SP + sp + 1];
         } else {
@@ -645,12 +751,17 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
 
     // ---- write the state back --------------------------------------------------------------
     if (!R.dry) {
-        if (actT && own) {
+        if (actN && own) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 R.tab[k][c] = s[k];
                 R.tab[12 + k][c] = s[k];
             }
+        }
+        if (quad && gown) {
+            R.tab[qc][gc] = sr0; R.tab[12 + qc][gc] = sr0;
+            R.tab[4 + qc][gc] = sr1; R.tab[16 + qc][gc] = sr1;
+            R.tab[8 + qc][gc] = sr2; R.tab[20 + qc][gc] = sr2;
         }
         if (isU || isSeam) {
 #pragma unroll
@@ -665,13 +776,13 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     }
 }
 
-size_t lds_bytes(unsigned flags, int logw)
+size_t lds_bytes(unsigned flags, int logw, bool coop = false)
 {
     const int W = 1 << logw, H = 256 / W;
     const int nuv = ((H + 1) * (W + 1) + 7) & ~7;
     const int nu = 8 + ((flags & EVP_F_WATER_IS_OCN) ? 0 : 2) + ((flags & EVP_F_TBU_ZERO) ? 0 : 1);
     const size_t nstr = logw == 4 ? 6 * (size_t)(W + 1) * H : 4 * (size_t)256;   // PERM planes: row stride W + 1
-    return sizeof(double) * (nstr + (size_t)256 * (4 + nu) + 2 * (size_t)nuv);
+    return sizeof(double) * (nstr + (size_t)256 * (4 + nu) + 2 * (size_t)nuv + (coop ? 12 * (size_t)64 : 0));
 }
 
 template <int LOGW, bool REMOTE>
@@ -715,8 +826,25 @@ void evp_resident_geometry(int max_ni, int max_nj, int logw, int *gx, int *gy)
     *gy = (max_nj + H - 2) / (H - 1);
 }
 
-int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote)
+// (measured slower than one thread per rim cell wherever two or three tiles share a CU -- HISTORY.md, round 5 -- so the variant is
+// compiled into the test build only, as an A/B switch: CICE_EVP_HIP_RES_COOP=1, tools/coop_ab.py)
+#ifdef CICE_EVP_HIP_TESTING
+bool evp_resident2_coop_built(bool strict, int cap, int logw, bool remote) { return strict && cap == 3 && logw == 4 && !remote; }
+#else
+bool evp_resident2_coop_built(bool, int, int, bool) { return false; }
+#endif
+
+int evp_resident2_max_blocks_per_cu(bool strict, int cap, unsigned flags, int logw, bool remote, bool coop)
 {
+    if (coop) {
+#ifdef CICE_EVP_HIP_TESTING
+        if (!evp_resident2_coop_built(strict, cap, logw, remote)) return 0;
+        int nb = 0;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, evp_resident2_tile<true, 3, 4, false, true>, 64 * RTY, lds_bytes(flags, 4, true)) == hipSuccess ? nb : 0;
+#else
+        return 0;
+#endif
+    }
     const size_t lds = lds_bytes(flags, logw);
     if (remote) return logw == 4 ? occ<4, true>(strict, cap, lds) : logw == 5 ? occ<5, true>(strict, cap, lds) : occ<6, true>(strict, cap, lds);
     return logw == 4 ? occ<4, false>(strict, cap, lds) : logw == 5 ? occ<5, false>(strict, cap, lds) : occ<6, false>(strict, cap, lds);
@@ -729,6 +857,13 @@ void evp_launch_resident2(const EvpArgs &A0, const EvpResident2 &R, int max_ni, 
     evp_resident_geometry(max_ni, max_nj, logw, &A.gx, &A.gy);
     A.ntiles = A.gx * A.gy * (R.nblocks > 0 ? R.nblocks : 1);
     const bool remote = R.rimg != nullptr;
+#ifdef CICE_EVP_HIP_TESTING
+    if (R.nlate && evp_resident2_coop_built(strict, cap, logw, remote)) {
+        dim3 grid(A.ntiles), block(64, RTY);
+        hipLaunchKernelGGL((evp_resident2_tile<true, 3, 4, false, true>), grid, block, lds_bytes(A.flags, 4, true), st, A, R);
+        return;
+    }
+#endif
     if (remote) {
         if (logw == 4) launch<4, true>(A, R, strict, cap, st);
         else if (logw == 5) launch<5, true>(A, R, strict, cap, st);

@@ -1397,3 +1397,42 @@ def test_resident_kernel_blocks_of_unequal_height_no_reader_without_a_reader(mon
     finally:
         core.finalize()
     assert shown, "a reader nobody reads was expected to lose a record when it lags (if not: the hook does not bite any more)"
+
+
+@pytest.mark.parametrize("grid,bs", [("gx3", None), ("gx3", (50, 58)), ("gx1", None)])
+def test_resident_rim_cells_by_corners_bitwise(grid, bs, monkeypatch):
+    """The measured-and-rejected variant of the resident kernel (test build only, CICE_EVP_HIP_RES_COOP=1: the T-cells that
+    read ring velocities updated by four lanes each, one corner per lane, evp_cell.inc stress_corner / stress_corner_partials)
+    gives the bits of the one-thread-per-cell update and of the oracle -- the per-corner restatement of stress_cell is
+    exact.  (Slower wherever two or three tiles share a CU: HISTORY.md; tools/coop_ab.py is the timing side.)"""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_RES_LOGW", "4")
+    spec = synth.GRIDS[grid]
+    ns = spec.get("ns", "closed")
+    g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns=ns))
+    st = synth.make_state(g, case="caps" if bs else "full", seed=11, warm=True)
+    bs = bs or (spec["nx"], spec["ny"])
+    dc = decomp.Decomp(spec["nx"], spec["ny"], bs[0], bs[1], "cyclic", ns, 1)
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
+    tm, um = dc.scatter(st["iceTmask"], 0, fill=0), dc.scatter(st["iceUmask"], 0, fill=0)
+    scal = synth.evp_scalars(120)
+    outs = {}
+    for coop in ("0", "1"):
+        monkeypatch.setenv("CICE_EVP_HIP_RES_COOP", coop)
+        d, keep = evp.make_dims(dc, 0)
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                          geo["uarear"], geo["tarea"], keepalive=keep)
+        try:
+            for n in (1, 24, 24):        # (the third call starts from the stresses the second one left on the device)
+                outs[coop, n] = core.run(fields, tm, um, ndte=n)
+            t = core.timings()
+            assert t["tile_variant"] == 2004 and t["resident_fallbacks"] == 0, t
+        finally:
+            core.finalize()
+    for n in (1, 24):
+        assert_bitwise(outs["1", n], outs["0", n], f"{grid} {bs}: rim cells by corners vs one thread per cell, {n} subcycles")
+    if ns == "closed":
+        assert_bitwise(outs["1", 24], run_oracle(dc, geo, fields, tm, um, scal, 24), f"{grid} {bs}: rim cells by corners vs oracle")
+    assert np.abs(outs["1", 24]["uvel"]).max() > 1e-4
