@@ -368,7 +368,10 @@ int cice_evp_hip_subcycle(int32_t ndte)
     if (ndte < 0) return fail(-1, "ndte < 0");
     if (ndte == 0) return 0;
     HIPC(hipEventRecord(S.ev0, S.stream));
-    if (S.res_mode == 1) {
+    // (the tiles that hold ice must all be on the chip at once: checked against THIS call's masks -- a call with more ice than that
+    // goes through the kernels below, the next one is asked again)
+    S.res_ran = S.res_mode == 1 && resident2_fits_now();
+    if (S.res_ran) {
         if (int rc = launch_resident2(ndte, S.cur, false)) return rc;
         S.res_launched = true;
         HIPC(hipEventRecord(S.ev1, S.stream));
@@ -728,14 +731,16 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
     if (S.ready && S.marked[0] && S.marked[1] && hipEventQuery(S.evm[1]) == hipSuccess &&
         hipEventElapsedTime(&ms, S.evm[0], S.evm[1]) == hipSuccess)
         marks_ms = ms;
-    const double v[14] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
-                         S.res_mode == 1 ? 1.0 / std::max(S.t_nsub, 1) : S.march.last_call ? 0.5 :
+    const bool res = S.res_mode == 1 && S.res_ran;
+    const double v[16] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
+                         res ? 1.0 / std::max(S.t_nsub, 1) : S.march.last_call ? 0.5 :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
-                         (double)(S.res_mode == 1 ? 2000 + S.res2_logw : (S.march.last_call ? 3000 + S.march.seglen : S.tyb)), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
+                         (double)(res ? 2000 + S.res2_logw : (S.march.last_call ? 3000 + S.march.seglen : S.tyb)), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
                           S.plan.peers.empty() ? 0.0 : (S.direct.on ? 2.0 : 1.0), S.prep.t_ms, (double)S.res_fallbacks,
-                          (double)(S.msk.on ? S.msk.n_send : S.n_send), (double)(S.msk.on ? S.msk.n_recv : S.n_recv)};
-    for (int k = 0; k < n && k < 14; ++k) out[k] = v[k];
+                          (double)(S.msk.on ? S.msk.n_send : S.n_send), (double)(S.msk.on ? S.msk.n_recv : S.n_recv),
+                          (double)(res ? (S.res2_nlive > 0 ? S.res2_nlive : S.res2_ntiles) : 0), (double)(S.res_mode == 1 ? S.res2_ntiles : 0)};
+    for (int k = 0; k < n && k < 16; ++k) out[k] = v[k];
     return 0;
 }
 

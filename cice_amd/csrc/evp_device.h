@@ -77,6 +77,12 @@ struct EvpResident2 {
     double *const *tab;
     int nblocks;               // CICE blocks of this rank (tiles = nblocks x gx x gy)
     const int *order;          // [ntiles] tile run by workgroup w (NULL: identity)
+    // Only the tiles that hold ice run (one rank, no neighbours on other ranks): nlaunch workgroups, order[0 .. nlaunch-1] their
+    // tiles.  A tile without ice changes nothing in a call -- its U-cells keep the values every reader loaded at the start -- so a
+    // ring entry whose producer tile is not live is not polled (live[celltile[producer cell]]).  live == NULL: every tile runs.
+    int nlaunch;               // workgroups to launch (0: all tiles)
+    const uint8_t *live;       // [ntiles]
+    const int *celltile;       // [ncell] tile that owns the U-cell, -1 for ghost cells
     // 16 x 16 tiles only (rim wave / interior waves, see evp_resident2.hip): which T-cell of the tile a
     // thread owns, the T-cells that read ring velocities first; how many waves hold such cells / ring entries
     const uint8_t *perm;       // [ntiles][256] cell position trow*16 + tcol of (permuted) thread index

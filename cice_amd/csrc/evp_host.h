@@ -223,6 +223,13 @@ struct State {
     uint8_t *res2_pub = nullptr;
     // 16 x 16 tiles (rim wave / interior waves): thread -> cell map, waves that wait for the ring, chunks with ice
     uint8_t *res2_perm = nullptr, *res2_late = nullptr, *res2_nact = nullptr, *res2_nlate = nullptr;
+    // only the tiles that hold ice run (resident2_order): how many, which (device flags), the tile of every U-cell, the tiles
+    // that always run (cells of the tripole fold row change in every subcycle, ice or not)
+    bool res_ran = true;           // the last cice_evp_hip_subcycle ran inside the resident kernel (false: that call's ice did not fit)
+    int res2_nlive = 0;
+    uint8_t *res2_live = nullptr;
+    int *res2_celltile = nullptr;
+    std::vector<char> res2_always_h;
     int res2_coop = -1;            // rim T-cells by corners (evp_resident2.hip COOP): -1 undecided, 0 off, 1 on
     bool res2_coop_ok = false;     // ... possible for the current tables (every tile's rim list fits 64 quads)
     int *res2_cuload = nullptr;                           // per-CU record of a launch (EvpResident2::cuload)
@@ -342,6 +349,8 @@ bool tripole_seam();
 bool resident_possible(bool with_peers = false);
 int resident2_setup(int logw);
 bool resident2_fits(bool remote = false);
+bool resident2_fits_now();
+int resident2_order();
 int resident_tables();
 int launch_resident2(int ndte, int cur0, bool dry);
 int resident_check_error();

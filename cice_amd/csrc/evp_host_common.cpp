@@ -54,7 +54,7 @@ void free_all()
     F(S.htn);
     F(S.vrelfac);
     F(S.res_err); F(S.res_tab);
-    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact); F(S.res2_nlate); F(S.res2_cuload); F(S.res2_prof);
+    F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact); F(S.res2_nlate); F(S.res2_live); F(S.res2_celltile); F(S.res2_cuload); F(S.res2_prof);
     if (S.res2_rec_owned) { F(S.res2_rec[0]); F(S.res2_rec[1]); }
     S.res2_rec[0] = S.res2_rec[1] = nullptr;
     S.res2_rec_owned = true;

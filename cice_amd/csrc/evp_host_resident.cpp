@@ -40,6 +40,8 @@ int resident2_setup(int logw)
     if (S.res2_ring && S.res2_logw == logw) return 0;
     auto F = [](auto *&p) { if (p) (void)hipFree((void *)p); p = nullptr; };
     F(S.res2_ring); F(S.res2_cnt); F(S.res2_pub); F(S.res2_perm); F(S.res2_late); F(S.res2_nact); F(S.res2_nlate);
+    F(S.res2_live); F(S.res2_celltile);
+    S.res2_nlive = 0;
     S.res2_cls_h.clear();
     S.res2_order_stale = true;
     S.res2_logw = logw;
@@ -63,6 +65,8 @@ int resident2_setup(int logw)
     for (int32_t c : S.plan.seam_pole) on_seam[c] = 1;
     std::vector<int4> ring((size_t)ntiles * EVP_RES2_RING, make_int4(-1, 0, -1, 0));
     std::vector<int> cnt((size_t)ntiles, 0);
+    std::vector<int> celltile(ncell, -1);
+    std::vector<char> always((size_t)ntiles, 0);
     std::vector<uint8_t> pub(ncell, 0);
     std::vector<char> seen((size_t)(H + 1) * LW);
     // 16 x 16 tiles: rim wave / interior waves (evp_resident2.hip).  cls: which T-cells of a tile read a
@@ -79,6 +83,14 @@ int resident2_setup(int logw)
                 const int t = (b * gy + by) * gx + bx;
                 const int i0 = ilo + bx * (W - 1), j0 = jlo + by * (H - 1);
                 std::fill(seen.begin(), seen.end(), 0);
+                for (int trow = 0; trow < H - 1; ++trow)                     // the U-cells this tile owns
+                    for (int tcol = 0; tcol < W - 1; ++tcol) {
+                        const int i = i0 + tcol, j = j0 + trow;
+                        if (i > ihi || j > jhi) continue;
+                        const int cp = cb + (j - 1) * nx + (i - 1);
+                        celltile[cp] = t;
+                        if (on_seam[cp]) always[t] = 1;
+                    }
                 for (int trow = 0; trow < H; ++trow)
                     for (int tcol = 0; tcol < W; ++tcol) {
                         const int i = i0 + tcol, j = j0 + trow;
@@ -117,6 +129,11 @@ int resident2_setup(int logw)
             }
     }
     S.res2_ntiles = ntiles;
+    S.res2_always_h = always;
+    HIPC(hipMalloc((void **)&S.res2_celltile, celltile.size() * sizeof(int)));
+    HIPC(hipMemcpy(S.res2_celltile, celltile.data(), celltile.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPC(hipMalloc((void **)&S.res2_live, (size_t)ntiles));
+    HIPC(hipMemset(S.res2_live, 1, (size_t)ntiles));
     // ghost images from a per-cell table whenever they are not confined to the edge of ONE block:
     // tripole grids (ghost row NY+1 mirrors row NY-1) and several blocks per rank
     if ((tripole_seam() || nb > 1) && !S.res2_img3) {
@@ -201,9 +218,22 @@ bool resident2_fits(bool remote)
     const unsigned fl = S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
     const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res2_logw, remote), 8);
     const long cap = (long)per_cu * prop.multiProcessorCount;
-    return S.res2_ntiles > 0 && (long)S.res2_ntiles * 10 <= cap * 9;
+    // what has to be co-resident is the tiles that run: all of them with neighbours on other ranks or before the masks are
+    // known, the ones that hold ice otherwise (resident2_order)
+    const int need = (remote || !S.plan.peers.empty() || S.res2_order_stale || !S.res2_order || S.res2_order_for != S.res2_logw)
+                         ? S.res2_ntiles : std::max(S.res2_nlive, 1);
+    return S.res2_ntiles > 0 && (long)need * 10 <= cap * 9;
 }
 
+
+// the same question for the masks of the current upload (the launch order, and with it the list of tiles that run, is brought up
+// to date first); with neighbours on other ranks the answer never changes after the start-up agreement
+bool resident2_fits_now()
+{
+    if (!S.plan.peers.empty() || S.res_remote) return true;
+    if (resident_tables() || resident2_order()) { g_err.clear(); return false; }
+    return resident2_fits(false);
+}
 
 // What depends on the ice masks, rebuilt when they or the tile shape change:
 //  * 16 x 16 tiles: the thread -> cell permutation.  Ice cells that read ring velocities first (they
@@ -223,6 +253,7 @@ int resident2_order()
     const int ntiles = gx * gy * S.d.nblocks, nx = S.d.nx_block;
     const bool permuted = !S.res2_cls_h.empty() && S.res2_logw == 4;
     std::vector<int> cost((size_t)ntiles);        // 1024 * ice-holding waves + ice cells
+    std::vector<uint8_t> live((size_t)ntiles, 1);
     std::vector<uint8_t> perm(permuted ? (size_t)ntiles * 256 : 0), late(permuted ? (size_t)ntiles : 0),
                          nact(permuted ? (size_t)ntiles : 0), nlt(permuted ? (size_t)ntiles : 0);
     bool coop_ok = permuted;
@@ -263,7 +294,15 @@ int resident2_order()
             waves = wave_on[0] + wave_on[1] + wave_on[2] + wave_on[3];
         }
         cost[t] = 1024 * waves + n;
+        // runs: holds ice (T- or U-cell), or cells of the tripole fold row; every tile when other ranks read this one's
+        // records; never a tile without U-cells (it leaves at once anyway)
+        const bool no_ucell = i0 > S.ihi[b] || j0 > S.jhi[b];
+        live[t] = !no_ucell && (n > 0 || S.res2_always_h[t] || !S.plan.peers.empty()) ? 1 : 0;
     }
+    std::vector<int> run;
+    for (int t = 0; t < ntiles; ++t)
+        if (live[t]) run.push_back(t);
+    const int nrun = (int)run.size();
     if (permuted) {
         HIPC(hipMemcpyAsync(S.res2_perm, perm.data(), perm.size(), hipMemcpyHostToDevice, S.stream));
         HIPC(hipMemcpyAsync(S.res2_late, late.data(), late.size(), hipMemcpyHostToDevice, S.stream));
@@ -272,19 +311,18 @@ int resident2_order()
     }
     S.res2_coop_ok = coop_ok;
     const bool off = env_test("CICE_EVP_HIP_RES_ORDER") && !std::atoi(env_test("CICE_EVP_HIP_RES_ORDER"));
-    std::vector<int> order((size_t)ntiles);
-    for (int w = 0; w < ntiles; ++w) order[w] = w;
+    std::vector<int> order((size_t)ntiles, 0);
+    for (int w = 0; w < nrun; ++w) order[w] = run[w];
     if (!off) {
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, S.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        std::vector<int> by_cost((size_t)ntiles);
-        for (int w = 0; w < ntiles; ++w) by_cost[w] = w;
+        std::vector<int> by_cost = run;
         std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int c) { return cost[a] > cost[c]; });
         // CU c receives the workgroups c, c + ncu, c + 2 ncu, ...: slots[c] of them
         std::vector<int> slots((size_t)ncu), load((size_t)ncu, 0);
         std::vector<std::vector<int>> mine((size_t)ncu);
-        for (int c = 0; c < ncu; ++c) slots[c] = ntiles / ncu + (c < ntiles % ncu ? 1 : 0);
+        for (int c = 0; c < ncu; ++c) slots[c] = nrun / ncu + (c < nrun % ncu ? 1 : 0);
         for (int tile : by_cost) {                 // heaviest first, to the least loaded CU with a free slot
             int best = -1;                           // (ties: the CU with fewer slots, so that the CUs with one more workgroup stay light)
             for (int c = 0; c < ncu; ++c) {
@@ -300,7 +338,9 @@ int resident2_order()
     if (S.res2_order && S.res2_order_for != S.res2_logw) { (void)hipFree(S.res2_order); S.res2_order = nullptr; }
     if (!S.res2_order) HIPC(hipMalloc((void **)&S.res2_order, order.size() * sizeof(int)));
     HIPC(hipMemcpyAsync(S.res2_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    HIPC(hipMemcpyAsync(S.res2_live, live.data(), live.size(), hipMemcpyHostToDevice, S.stream));
     HIPC(hipStreamSynchronize(S.stream));
+    S.res2_nlive = nrun;
     S.res2_order_for = S.res2_logw;
     S.res2_order_stale = false;
     return 0;
@@ -324,6 +364,9 @@ int launch_resident2(int ndte, int cur0, bool dry)
     S.res2_par = (S.res2_par + ndte + 1) & 1;     // never start in the buffer the previous launch ended in
     R.nblocks = S.d.nblocks;
     R.order = S.res2_order;
+    R.nlaunch = S.res2_nlive;
+    R.live = S.plan.peers.empty() ? S.res2_live : nullptr;
+    R.celltile = S.res2_celltile;
     R.perm = S.res2_perm;
     R.late_waves = S.res2_late;
     R.nact = S.res2_nact;
@@ -337,7 +380,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
             hipDeviceProp_t prop;
             const int per_cu = std::min(evp_resident2_max_blocks_per_cu(true, cap_mode(), A.flags, 4, false, true), 8);
             can = hipGetDeviceProperties(&prop, S.device) == hipSuccess &&
-                  (long)S.res2_ntiles * 10 <= (long)per_cu * prop.multiProcessorCount * 9;
+                  (long)std::max(S.res2_nlive, 1) * 10 <= (long)per_cu * prop.multiProcessorCount * 9;
         }
         S.res2_coop = can ? 1 : 0;
         R.nlate = can ? S.res2_nlate : nullptr;
@@ -472,6 +515,7 @@ int tune_after_upload()
             for (int logw : {5, 4, 6}) {
                 if (forced_w && logw != forced_w) continue;
                 if (resident2_setup(logw)) { if (want == 1) return -6; continue; }
+                if (resident2_order()) { if (want == 1) return -6; continue; }      // (which tiles hold ice: what has to fit)
                 if (!resident2_fits()) continue;
                 any_fit = true;
                 if (want == 1 && forced_w) { best = 0.0f; best_w = logw; break; }

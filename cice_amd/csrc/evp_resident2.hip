@@ -448,7 +448,9 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
     bool ring_remote = false;
     if (tq < R.ring_cnt[tile]) {     // (PERM: ring entries and the T-cells that read them share the wave that took chunk 0)
         const int4 e = R.ring[tile * EVP_RES2_RING + tq];   // x: cell whose record is polled, y: LDS index, z: producing U-cell
-        if (e.z >= 0) { ring_cp = e.x; ring_li = e.y; }      // has a producer on this GPU: refreshed every subcycle
+        // has a producer on this GPU: refreshed every subcycle -- unless the producer's tile holds no ice and does not run
+        // (EvpResident2::live): its cells keep the values the velocity tile was filled with above
+        if (e.z >= 0 && (!R.live || R.live[R.celltile[e.z]])) { ring_cp = e.x; ring_li = e.y; }
         if (REMOTE && e.z == -2) { ring_cp = e.x; ring_li = e.y; ring_remote = true; }   // produced on another rank
     }
     // first wait that gives up records where and on what: err[0] kind (1 ring of this GPU, 2 ring of
@@ -800,7 +802,7 @@ int occ(bool strict, int cap, size_t lds)
 template <int LOGW, bool REMOTE>
 void launch(const EvpArgs &A, const EvpResident2 &R, bool strict, int cap, hipStream_t st)
 {
-    dim3 grid(A.ntiles), block(64, RTY);
+    dim3 grid(R.nlaunch > 0 ? R.nlaunch : A.ntiles), block(64, RTY);
     const size_t lds = lds_bytes(A.flags, LOGW);
 #define EVP_LAUNCH(S, C) hipLaunchKernelGGL((evp_resident2_tile<S, C, LOGW, REMOTE>), grid, block, lds, st, A, R)
     if (strict) {
@@ -859,7 +861,7 @@ void evp_launch_resident2(const EvpArgs &A0, const EvpResident2 &R, int max_ni, 
     const bool remote = R.rimg != nullptr;
 #ifdef CICE_EVP_HIP_TESTING
     if (R.nlate && evp_resident2_coop_built(strict, cap, logw, remote)) {
-        dim3 grid(A.ntiles), block(64, RTY);
+        dim3 grid(R.nlaunch > 0 ? R.nlaunch : A.ntiles), block(64, RTY);
         hipLaunchKernelGGL((evp_resident2_tile<true, 3, 4, false, true>), grid, block, lds_bytes(A.flags, 4, true), st, A, R);
         return;
     }

@@ -514,12 +514,12 @@ class EvpHip:
         return out
 
     def timings(self) -> dict:
-        t = np.zeros(14)
-        self.lib.cice_evp_hip_get_timings(_dp(t), 14)
+        t = np.zeros(16)
+        self.lib.cice_evp_hip_get_timings(_dp(t), 16)
         return dict(loop_ms=t[0], h2d_ms=t[1], d2h_ms=t[2], nsub=int(t[3]), launches_per_subcycle=t[4],
                     tile_variant=int(t[5]), marks_ms=t[6], stream_probe_ms=t[7], resident_probe_ms=t[8],
                     halo_transport={0: "none", 1: "rccl", 2: "mailbox"}[int(t[9])], prep_ms=t[10], resident_fallbacks=int(t[11]),
-                    halo_send_cells=int(t[12]), halo_recv_cells=int(t[13]))
+                    halo_send_cells=int(t[12]), halo_recv_cells=int(t[13]), resident_tiles_run=int(t[14]), resident_tiles=int(t[15]))
 
     def _need_testing(self, what):
         if not self.testing:

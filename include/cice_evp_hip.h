@@ -367,7 +367,9 @@ int cice_evp_hip_last_error(char *buf, int32_t buflen);
  * [9]=remote halo transport: 0 none, 1 RCCL p2p, 2 mailbox (direct stores over xGMI),
  * [10]=device time of the last cice_evp_hip_prep (kernels + halos, without the copies), ms,
  * [11]=cice_evp_hip_run calls repeated with the streaming kernel after the resident one gave up,
- * [12], [13]=cells this rank sends / receives per velocity exchange of the loop (after cice_evp_hip_halo_mask)  */
+ * [12], [13]=cells this rank sends / receives per velocity exchange of the loop (after cice_evp_hip_halo_mask),
+ * [14], [15]=on-chip resident kernel: tiles that ran in the last loop (only the tiles that hold ice run; 0: that loop did not
+ *            go through it, e.g. because its ice needed more tiles than the chip holds at once) / tiles of the domain  */
 int cice_evp_hip_get_timings(double *out, int32_t n);
 /* Halo plan of this rank, for tests: counts[0]=local copies, [1]=#peers,
  * [2]=total send cells, [3]=total recv cells.  Lists may be NULL.

@@ -1436,3 +1436,52 @@ def test_resident_rim_cells_by_corners_bitwise(grid, bs, monkeypatch):
     if ns == "closed":
         assert_bitwise(outs["1", 24], run_oracle(dc, geo, fields, tm, um, scal, 24), f"{grid} {bs}: rim cells by corners vs oracle")
     assert np.abs(outs["1", 24]["uvel"]).max() > 1e-4
+
+
+def test_resident_kernel_runs_only_the_tiles_with_ice(monkeypatch):
+    """Only the tiles that hold ice run (round 5, after the C grid's resident kernel): what has to be on the chip at once is the
+    ice, not the domain.  gx1 with ice on the polar caps: fewer workgroups than tiles, same bits as the oracle.  640 x 480 --
+    1419 tiles of 15 x 15 U-cells, never resident before -- with ice on the caps runs inside the resident kernel; the same
+    core handed ice EVERYWHERE does that call with the streaming kernel (its tiles do not fit the chip at once; nothing fails,
+    nothing is repeated) and the next call with the caps again inside the resident kernel."""
+    monkeypatch.setenv("CICE_EVP_HIP_MARCH", "0")
+    scal = synth.evp_scalars(120)
+    # gx1, caps
+    dc, geo, fields, tm, um = synth_case("gx1", "caps", seed=5, warm=True)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        got = core.run(fields, tm, um, ndte=12)
+        t = core.timings()
+        assert t["tile_variant"] >= 2000 and 0 < t["resident_tiles_run"] < t["resident_tiles"] and t["resident_fallbacks"] == 0, t
+        assert_bitwise(got, run_oracle(dc, geo, fields, tm, um, scal, 12), "gx1 caps, only the tiles with ice")
+    finally:
+        core.finalize()
+    # a domain whose tiles do not fit the chip, ice on the caps / everywhere / on the caps
+    nx, ny = 640, 480
+    g = synth.derive_geometry(synth.make_grid(nx, ny, 5.0e4, ns="closed"))
+    dc = decomp.Decomp(nx, ny, nx, ny, "cyclic", "closed", 1)
+    geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
+           for k in ("HTE", "HTN", "dxT", "dyT", "tarea", "uarear")}
+    cases = {}
+    for case in ("caps", "full"):
+        st = synth.make_state(g, case=case, seed=9, warm=True)
+        cases[case] = ({k: dc.scatter(st[k], 0) for k in evp.FIELDS}, dc.scatter(st["iceTmask"], 0, fill=0), dc.scatter(st["iceUmask"], 0, fill=0))
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
+                      geo["uarear"], geo["tarea"], keepalive=keep)
+    try:
+        want = {case: run_oracle(dc, geo, *cases[case], scal, 6) for case in cases}
+        ran = []
+        for case in ("caps", "full", "caps"):
+            got = core.run(*cases[case], ndte=6)
+            t = core.timings()
+            ran.append((case, t["tile_variant"], t["resident_tiles_run"], t["resident_tiles"]))
+            assert_bitwise(got, want[case], f"640 x 480 {case}: {ran}")
+            assert t["resident_fallbacks"] == 0, (ran, t)
+        assert ran[0][1] >= 2000 and 0 < ran[0][2] < ran[0][3], ran           # caps: inside the resident kernel, part of the tiles
+        assert ran[1][1] < 2000 and ran[1][2] == 0, ran                        # ice everywhere: that call streams
+        assert ran[2][1] >= 2000 and ran[2][2] == ran[0][2], ran               # ... and the next one is resident again
+    finally:
+        core.finalize()
