@@ -298,6 +298,8 @@ int resident2_order()
         // records; never a tile without U-cells (it leaves at once anyway)
         const bool no_ucell = i0 > S.ihi[b] || j0 > S.jhi[b];
         live[t] = !no_ucell && (n > 0 || S.res2_always_h[t] || !S.plan.peers.empty()) ? 1 : 0;
+        // (test build, RES_DEBUG bit 512: the tiles without U-cells run as they used to -- the hazard they were, evp_resident2.hip)
+        if (no_ucell && env_test("CICE_EVP_HIP_RES_DEBUG") && (std::atoi(env_test("CICE_EVP_HIP_RES_DEBUG")) & 512)) live[t] = 1;
     }
     std::vector<int> run;
     for (int t = 0; t < ntiles; ++t)

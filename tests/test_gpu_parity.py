@@ -1440,8 +1440,8 @@ def test_resident_rim_cells_by_corners_bitwise(grid, bs, monkeypatch):
 
 def test_resident_kernel_runs_only_the_tiles_with_ice(monkeypatch):
     """Only the tiles that hold ice run (round 5, after the C grid's resident kernel): what has to be on the chip at once is the
-    ice, not the domain.  gx1 with ice on the polar caps: fewer workgroups than tiles, same bits as the oracle.  640 x 480 --
-    1419 tiles of 15 x 15 U-cells, never resident before -- with ice on the caps runs inside the resident kernel; the same
+    ice, not the domain.  gx1 with ice on the polar caps: fewer workgroups than tiles, same bits as the oracle.  560 x 400 --
+    1026 tiles of 15 x 15 U-cells, never resident before -- with ice on the caps runs inside the resident kernel; the same
     core handed ice EVERYWHERE does that call with the streaming kernel (its tiles do not fit the chip at once; nothing fails,
     nothing is repeated) and the next call with the caps again inside the resident kernel."""
     monkeypatch.setenv("CICE_EVP_HIP_MARCH", "0")
@@ -1459,7 +1459,7 @@ def test_resident_kernel_runs_only_the_tiles_with_ice(monkeypatch):
     finally:
         core.finalize()
     # a domain whose tiles do not fit the chip, ice on the caps / everywhere / on the caps
-    nx, ny = 640, 480
+    nx, ny = 560, 400
     g = synth.derive_geometry(synth.make_grid(nx, ny, 5.0e4, ns="closed"))
     dc = decomp.Decomp(nx, ny, nx, ny, "cyclic", "closed", 1)
     geo = {k: dc.scatter(g[k], 0, fill=(1.0 if k in ("HTE", "HTN", "dxT", "dyT", "tarea") else 0.0))
@@ -1478,7 +1478,7 @@ def test_resident_kernel_runs_only_the_tiles_with_ice(monkeypatch):
             got = core.run(*cases[case], ndte=6)
             t = core.timings()
             ran.append((case, t["tile_variant"], t["resident_tiles_run"], t["resident_tiles"]))
-            assert_bitwise(got, want[case], f"640 x 480 {case}: {ran}")
+            assert_bitwise(got, want[case], f"560 x 400 {case}: {ran}")
             assert t["resident_fallbacks"] == 0, (ran, t)
         assert ran[0][1] >= 2000 and 0 < ran[0][2] < ran[0][3], ran           # caps: inside the resident kernel, part of the tiles
         assert ran[1][1] < 2000 and ran[1][2] == 0, ran                        # ice everywhere: that call streams
