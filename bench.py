@@ -69,10 +69,10 @@ VERIFY_FIELDS = ("uvel", "vvel", "stressp_1")
 CGRID_VERIFY_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")   # tests/golden/make_bench_checksums.py
 CGRID_B_ALG = 648.0      # C grid: 81 fp64 array touches per cell and subcycle in the fused schedule
 CGRID_B_ALG_GEO = 563.0  # ... 70 + three mask bytes where the fused kernels derive 15 of the 23 static arrays (as cg_one does)
-EXTRAS = ("s01", "streaming", "tripole", "cgrid", "per_call", "configs2", "rccl_control", "ring_variants")
+EXTRAS = ("s01", "streaming", "tripole", "caps", "cgrid", "per_call", "configs2", "rccl_control", "ring_variants")
 # what a plain run measures besides the headline: everything on one GPU; at N > 1 the 3600x2400 grid on the library's default
 # path and ONE control (the headline workload forced onto RCCL point-to-point) -- the other forms are asked for by name
-EXTRAS_DEFAULT = {1: ("s01", "streaming", "tripole", "cgrid", "per_call"), 2: ("s01", "rccl_control")}
+EXTRAS_DEFAULT = {1: ("s01", "streaming", "tripole", "caps", "cgrid", "per_call"), 2: ("s01", "rccl_control")}
 CGRID_B_ALG_ONE = 408.0  # ... 51 in the one-launch kernel (cg_one: the default on one rank without a fold)
 CGRID_B_ALG_ONE_GEO = 289.0  # ... 36 + one mask byte where cg_one derives 15 of its 23 static arrays from the 8 dx / dy arrays
 
@@ -978,6 +978,12 @@ def main():
             M3 = measure("tx1", "full", 240, 10, 2, ns="tripole")
         except Exception as e:  # noqa: BLE001
             extra_err["tripole"] = f"{type(e).__name__}: {e}"[:300]
+    Mcaps = None
+    if want("caps") and a.workload == "gx1" and a.case == "full" and world == 1:
+        try:      # SURVEY 8(d)'s second ice case: ice on the polar caps (the realistic cover); only the tiles that hold ice run
+            Mcaps = measure("gx1", "caps", 120, 10, 2)
+        except Exception as e:  # noqa: BLE001
+            extra_err["caps"] = f"{type(e).__name__}: {e}"[:300]
     if want("cgrid") and a.workload == "gx1" and world == 1:
         try:      # next-tier row f-4: the C-grid subcycle on the same grid, and on the 0.1-degree-class one (HBM-bound)
             extra["cgrid"] = cgrid_measure("gx1", "full", 120, 3, 1)
@@ -1179,6 +1185,16 @@ def main():
                 "value": M3["nx"] * M3["ny"] * 240 * 10 / M3["dt"], "unit": "cell-updates/s", "steps": 10, "warmup": 2,
                 "us_per_subcycle": 1e6 * M3["dt"] / (10 * 240), "tile_variant": M3["tm_ev"]["tile_variant"],
                 "verified": M3["ver"].get("verified"), "finite": M3["finite"]}
+        if Mcaps is not None:
+            tcaps = Mcaps["dt"] / (10 * 120)
+            res["caps"] = {
+                "workload": "gx1 320x384 B-grid EVP ndte=120, case=caps (ice on the polar caps: SURVEY 8(d)'s realistic cover), one GPU",
+                "value": Mcaps["nx"] * Mcaps["ny"] / tcaps, "unit": "cell-updates/s",
+                "active_cell_updates_per_s": Mcaps["n_active"] / tcaps, "active_T_cells": Mcaps["n_active"],
+                "steps": 10, "warmup": 2, "us_per_subcycle": 1e6 * tcaps, "tile_variant": Mcaps["tm_ev"]["tile_variant"],
+                "resident_tiles_run": Mcaps["tm_ev"].get("resident_tiles_run"), "resident_tiles": Mcaps["tm_ev"].get("resident_tiles"),
+                "verified": Mcaps["ver"].get("verified"), "finite": Mcaps["finite"],
+                "note": "the on-chip resident kernel launches only the tiles that hold ice"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.workload, a.case, ndte, a.cpu_seconds, a.strict)
         else:

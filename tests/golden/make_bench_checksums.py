@@ -31,6 +31,7 @@ CONFIGS = {   # workload: (case, ndte, ns, checkpoints)
     "s01": ("full", 480, "closed", [3]),
     "tx1": ("full", 240, "tripole", [12]),
     "gx1@240": ("full", 240, "closed", [3, 5, 12]),      # BASELINE configs[2]: gx1 at ndte = 240 (bench.py N > 1)
+    "gx1@caps": ("caps", 120, "closed", [12]),            # SURVEY 8(d)'s second ice case (bench.py `caps`)
 }
 
 
