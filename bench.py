@@ -22,6 +22,8 @@ What the line carries besides the contract's fields:
                 hashed and compared with tests/golden/bench_checksums.json (made by the CPU oracle).
   median_ms_per_step   N = 1: the same loop ten more times, one call at a time (HIP events of the library): SURVEY 8(d)'s median
                 next to the contract's K-step mean (`ms_per_step`, `value`).
+  caps          gx1 with ice on the polar caps only (SURVEY 8(d)'s second, realistic ice case): cell-updates/s over all cells and
+                over the cells with ice, the tiles the resident kernel ran (only the ones that hold ice), verified
   cgrid         the C-grid subcycle on gx1, on 3600x2400 and on the tripole grid tx1: microseconds per subcycle, verified
                 against committed oracle checksums; `kernel` says what ran (gx1: the on-chip resident kernel cg_res, every
                 subcycle of a call but the first after an upload in one launch; 3600x2400: one launch per subcycle, HBM
