@@ -1070,7 +1070,9 @@ def main():
             if e:
                 logw = tm_ev["tile_variant"] % 10
                 W, H = 1 << logw, 256 >> logw
-                live_waves = 4 * sum((-(-b.gnx // (W - 1))) * (-(-b.gny // (H - 1))) for b in dc.local_blocks(0))
+                # (only the tiles that hold ice run: the library reports how many; older libraries ran them all)
+                live_waves = 4 * (int(tm_ev.get("resident_tiles_run") or 0) or
+                                  sum((-(-b.gnx // (W - 1))) * (-(-b.gny // (H - 1))) for b in dc.local_blocks(0)))
                 waves = e.get("counters", {}).get("SQ_WAVES", {}).get("avg_per_launch")
                 insts = e.get("counters", {}).get("SQ_INSTS_VALU", {}).get("avg_per_launch")
                 per64 = insts / (my_active / 64.0 * sub_per_launch) if insts else None
