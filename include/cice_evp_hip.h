@@ -184,7 +184,10 @@ int cice_evp_hip_sync(void);
  * Call between cice_evp_hip_subcycle and cice_evp_hip_download; no-op on other grids.            */
 int cice_evp_hip_stress_halo(void);
 /* 1 if cice_evp_hip_stress_halo can do that on this rank layout (tripole: always; tripoleT: the top row on one rank and no
- * eliminated block in it), else 0: a host that keeps the stresses resident asks before it leaves the step to the library. */
+ * eliminated block in it), else 0: a host that keeps the stresses resident asks before it leaves the step to the library.
+ * The answer is THIS rank's (a rank without top-row blocks says 1 whatever the others say); that is sound rank by rank because
+ * the tripoleT symmetrisation on the device never crosses ranks -- a host whose restart / diagnostics code wants one answer
+ * for the whole job reduces it itself (MIN).                                                                              */
 int cice_evp_hip_stress_halo_available(void);
 int cice_evp_hip_set_post_geometry(const double *dxU, const double *dyU, const double *tarear);
 int cice_evp_hip_deformations(double *divu, double *shear, double *vort, double *rdg_conv,
