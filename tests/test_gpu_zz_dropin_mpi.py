@@ -35,6 +35,10 @@ CASES = [
     (72, 40, 36, 20, "cyclic", "tripole", 2, "cartesian", False, dict(grid_kind="tripolefile", icecase="full")),
     (72, 40, 18, 20, "cyclic", "tripole", 4, "roundrobin", False, dict(grid_kind="tripolefile", icecase="patchy", h_capping=0.5)),
     (72, 40, 36, 20, "cyclic", "closed", 2, "cartesian", True, dict(grid_kind="popfile", icecase="full")),
+    # ns_boundary_type = 'tripoleT' over MPI tasks: the fold row cut in y only, in x, five blocks across dealt round-robin
+    (72, 40, 36, 20, "cyclic", "tripoleT", 2, "cartesian", False, dict(grid_kind="tripolefile", icecase="full")),
+    (72, 40, 18, 40, "cyclic", "tripoleT", 2, "cartesian", False, dict(grid_kind="tripolefile", icecase="patchy")),
+    (90, 30, 18, 15, "cyclic", "tripoleT", 3, "roundrobin", False, dict(grid_kind="tripolefile", icecase="full", h_capping=0.5)),
 ]
 
 
