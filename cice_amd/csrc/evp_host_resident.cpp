@@ -209,15 +209,26 @@ int resident2_setup(int logw)
 
 bool resident2_fits(bool remote)
 {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
+    // (asked at every cice_evp_hip_subcycle since only the tiles with ice have to fit: the device's answer is kept per
+    // kernel variant, the question then costs a comparison)
+    struct Key { int dev, logw, strict, capm; unsigned fl; bool remote; long cap; };
+    static std::vector<Key> known;
     // Decided once, but TBU_ZERO / WATER_IS_OCN are re-derived from the data at every upload / prep and
     // the LDS need of a workgroup grows when they drop (up to 6 KB): size with the flag combination
     // that needs the most LDS, so that a later call can never have fewer workgroups per CU than the
     // tile count was admitted against.
     const unsigned fl = S.flags & S.flags_allowed & ~(EVP_F_WATER_IS_OCN | EVP_F_TBU_ZERO);
-    const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res2_logw, remote), 8);
-    const long cap = (long)per_cu * prop.multiProcessorCount;
+    long cap = -1;
+    for (const Key &k : known)
+        if (k.dev == S.device && k.logw == S.res2_logw && k.strict == (S.prm.strict != 0) && k.capm == cap_mode() && k.fl == fl && k.remote == remote)
+            cap = k.cap;
+    if (cap < 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, S.device) != hipSuccess) return false;
+        const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), fl, S.res2_logw, remote), 8);
+        cap = (long)per_cu * prop.multiProcessorCount;
+        known.push_back(Key{S.device, S.res2_logw, S.prm.strict != 0, cap_mode(), fl, remote, cap});
+    }
     // what has to be co-resident is the tiles that run: all of them with neighbours on other ranks or before the masks are
     // known, the ones that hold ice otherwise (resident2_order)
     const int need = (remote || !S.plan.peers.empty() || S.res2_order_stale || !S.res2_order || S.res2_order_for != S.res2_logw)
