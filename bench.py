@@ -265,6 +265,18 @@ def cpu_baseline(workload, case, ndte, target_s, strict):
                 out["cgrid"] = dict(value=nx * ny * ndte * 4 / tC, unit="cell-updates/s", cores=best2d["threads"], kind="reference",
                                     sample=f"reference evp() with grid_ice='C', {nx}x{ny} in {(nx // bx) * (ny // by)} blocks of {bx}x{by}, "
                                            f"ndte={ndte}, 4 calls, timer_evp={tC:.2f}s")
+            if bestmpi:      # ... and on its MPI path, with the task count that was fastest for the B grid
+                mb = dict(bestmpi["kw"])
+                tM = ref_run("mpifast", bestmpi["bx"], bestmpi["by"], 1, 16, nprocs=bestmpi["nprocs"], h_grid_ice="C", **mb)
+                if tM and tM > 0:
+                    vM = nx * ny * ndte * 16 / tM
+                    omp = out.get("cgrid")
+                    if not omp or vM > omp["value"]:
+                        out["cgrid"] = dict(value=vM, unit="cell-updates/s", cores=bestmpi["nprocs"], kind="reference",
+                                            sample=f"reference evp() with grid_ice='C' on its MPI path, {nx}x{ny} as {bestmpi['nprocs']} MPI tasks of one "
+                                                   f"{bestmpi['bx']}x{bestmpi['by']} block each (mpiexec {mb.get('mpiexec_args') or 'unbound'}), ndte={ndte}, "
+                                                   f"16 calls, timer_evp={tM:.2f}s",
+                                            openmp=omp)
         except Exception as e:  # noqa: BLE001
             out["cgrid"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         return out
