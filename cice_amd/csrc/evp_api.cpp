@@ -59,6 +59,27 @@ int cice_evp_hip_cgrid_window_plan_ext(const cice_evp_hip_dims *dims, int32_t ox
     if (tab) std::copy(tb.begin(), tb.end(), tab);
     return 0;
 }
+
+int cice_evp_hip_cgrid_window_deps(const cice_evp_hip_dims *dims, int32_t *n_windows, int32_t *n_edges, int32_t *n_oneway, int32_t *n_unsafe)
+{
+    if (!dims || !n_edges || !n_oneway || !n_unsafe) return fail(-1, "bad argument");
+    HaloPlan P;
+    if (!build_halo_plan(*dims, P)) return fail(-3, "halo plan: %s", P.error.c_str());
+    const bool tripole = dims->ns_boundary_type == CICE_EVP_BND_TRIPOLE;
+    std::vector<int32_t> t4, t2, tb;
+    if (tripole) {
+        std::string why;
+        if (!build_fold_window_table(*dims, P, t4, t2, tb, why)) return fail(-5, "fold windows: %s", why.c_str());
+    } else {
+        build_window_table(*dims, P, 16, 16, 1 << 20, t4, tb, 1);
+    }
+    int ne = 0, n1 = 0;
+    *n_unsafe = cgres_dependencies(*dims, tripole, t4, tb, nullptr, &ne, &n1);
+    *n_edges = ne;
+    *n_oneway = n1;
+    if (n_windows) *n_windows = (int32_t)(t4.size() / 4);
+    return 0;
+}
 #endif  // CICE_EVP_HIP_TESTING
 
 int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second)
@@ -733,7 +754,7 @@ int cice_evp_hip_get_timings(double *out, int32_t n)
         marks_ms = ms;
     const bool res = S.res_mode == 1 && S.res_ran;
     const double v[16] = {S.t_loop_ms, S.t_h2d_ms, S.t_d2h_ms, (double)S.t_nsub,
-                         res ? 1.0 / std::max(S.t_nsub, 1) : S.march.last_call ? 0.5 :
+                         res ? 1.0 / std::max(S.t_nsub, 1) : S.march.last_call ? (double)S.march.call_passes / std::max(S.march.call_subcycles, 1) :
                          1.0 + ((S.n_local > 0 && !(S.push_ok && (S.flags & S.flags_allowed & EVP_F_PUSH))) ? 1.0 : 0.0) +
                              (S.plan.peers.empty() ? 0.0 : (S.direct.on ? (use_riding_exchange() ? 0.0 : 1.0) : 2.0)) + ((S.n_seam + S.n_pole + S.n_late) > 0 ? 1.0 : 0.0),
                          (double)(res ? 2000 + S.res2_logw : (S.march.last_call ? 3000 + S.march.seglen : S.tyb)), marks_ms, S.t_stream_probe_ms, S.t_res_probe_ms,
@@ -968,9 +989,9 @@ int cice_evp_hip_seam_fin_plan(int32_t *counts2, int32_t *dst, int32_t *a, int32
 int cice_evp_hip_march_info(int32_t *out, int32_t n)
 {
     const State::March &M = S.march;
-    const int32_t v[8] = {M.mode, (int32_t)std::min<long>(M.passes, 0x7fffffffL), M.declined, M.nstrips, M.nseg, M.seglen,
-                          M.last_call ? 1 : 0, M.direct};
-    for (int k = 0; out && k < n && k < 8; ++k) out[k] = v[k];
+    const int32_t v[10] = {M.mode, (int32_t)std::min<long>(M.passes, 0x7fffffffL), M.declined, M.nstrips, M.nseg, M.seglen,
+                           M.last_call ? 1 : 0, M.direct, M.kpass, (int32_t)std::min<long>(M.subcycles, 0x7fffffffL)};
+    for (int k = 0; out && k < n && k < 10; ++k) out[k] = v[k];
     return 0;
 }
 
@@ -982,13 +1003,14 @@ int cice_evp_hip_describe_path(char *buf, int32_t n)
     const State::March &M = S.march;
     const char *kernel = S.res_mode == 1 ? (S.res_remote ? "on-chip resident (tagged records, neighbours on other ranks)"
                                                        : "on-chip resident (tagged records)")
-                         : (M.last_call ? "two subcycles per pass (marching)" : "one subcycle per launch (streaming)");
+                         : (M.last_call ? (M.kpass == 4 ? "four subcycles per pass (marching)" : M.kpass == 3 ? "three subcycles per pass (marching)" : "two subcycles per pass (marching)")
+                                      : "one subcycle per launch (streaming)");
     const char *transport = S.plan.peers.empty() ? "none (one rank)" : (S.direct.on ? "mailbox over HIP IPC" : (S.have_comm ? "RCCL send/recv" : "not set up"));
     const char *ring = (M.mode == 1 && !S.plan.peers.empty())
                            ? (M.direct == 1 ? " (ring between ranks: stores into HIP-IPC-mapped inboxes)"
                                             : (M.direct == 2 ? " (ring between ranks: RCCL send/recv, direct stores on trial)" : " (ring between ranks: RCCL send/recv)"))
                            : "";
-    std::snprintf(buf, (size_t)n, "rank %d of %d: kernel = %s; halo transport = %s%s%s; two-subcycle path: %s%s%s%s; blocks %d, cells per exchange %d",
+    std::snprintf(buf, (size_t)n, "rank %d of %d: kernel = %s; halo transport = %s%s%s; marching path: %s%s%s%s; blocks %d, cells per exchange %d",
                   (int)S.d.rank, (int)std::max(1, (int)S.d.nranks), kernel, transport,
                   (!S.plan.peers.empty() && !S.direct.on && !S.direct.why.empty()) ? " (mailbox off: " : "",
                   (!S.plan.peers.empty() && !S.direct.on && !S.direct.why.empty()) ? (S.direct.why + ")").c_str() : "",

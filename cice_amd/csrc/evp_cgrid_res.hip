@@ -415,12 +415,17 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // every subcycle; tools/cgres_phases.py showed the wave that held them all waiting twice as long as the others).
     // Entry e of the (Y+1) x (X+1) tile is polled if it lies outside the owned range and has a producer (not static);
     // (X, Y), the one entry no level reads, is left out
+    // ... and lies within reach of the owned cells (EVP_CGRES_REACH positions beyond the last owned column / row; the rule of
+    // halo_plan.h: cgres_in_reach, which also makes the publishers' map): a narrow window at a block's edge would otherwise poll far
+    // into windows that do not poll it back, and the two-slot record protocol needs every dependency to be mutual
+    const int last_ex = min(X - 2, 2 + q.y - tl.y), last_ey = min(Y - 2, 2 + jmax - tl.z);
     auto ring_src = [&](int e) -> int {
         const int ex = e % LW, ey = e / LW;
         const int gi = tl.y - 2 + ex, gj = tl.z - 2 + ey;
         const bool mine = ex >= 2 && ex <= X - 2 && ey >= 2 && ey <= Y - 2 && gi <= q.y && gj <= jmax;
+        const bool reach = foldwin || (ex <= last_ex + EVP_CGRES_REACH && ey <= last_ey + EVP_CGRES_REACH);
         const int sc = s_src[e];
-        return (mine || sc < 0 || !(s_gm[e] & 16u)) ? -1 : sc;        // (a cell of a window without ice: the value loaded above stays)
+        return (mine || !reach || sc < 0 || !(s_gm[e] & 16u)) ? -1 : sc;        // (a cell of a window without ice: the value loaded above stays)
     };
     // All entries sit in wave 0, two per lane, both requested before either is looked at: ONE polling wave per workgroup.
     // (Measured on gx1, tools/cgres_phases.py: the entries dealt round-robin to all four waves, one per thread -- every wave of
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     s_s12[pt] = s12v;
     if (REVP && (own || pown)) { s_pc[NPC - 2][oi] = zE0; s_pc[NPC - 1][oi] = zN0; }
     // initial records (tag of subcycle 0) so that the neighbours' first poll finds them; also the proof that they are resident
-    if (pub) st_rec2((v4u *)R.rec[R.par0 & 1] + 2 * L, pack_rec(s_uE[li], R.tag_base), pack_rec(s_vN[li], R.tag_base));
+    if (pub) st_rec2((v4u *)R.rec[R.par0 & (EVP_CGRES_SLOTS - 1)] + 2 * L, pack_rec(s_uE[li], R.tag_base), pack_rec(s_vN[li], R.tag_base));
     __syncthreads();
 
     // One subcycle.  LAST (a compile-time constant: the loop body proper carries none of it) = the subcycle that ends the call, in
@@ -505,8 +510,10 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     auto subcycle = [&](auto LASTC, int k) -> bool {
         constexpr bool LAST = decltype(LASTC)::value;
         const unsigned want = R.tag_base + (unsigned)k;
-        const v4u *rd = (const v4u *)R.rec[(k + R.par0) & 1];
-        v4u *wr = (v4u *)R.rec[((k + R.par0) & 1) ^ 1];
+        // (four slots: a window that is read without reading back may be up to three subcycles ahead of its reader -- the host has
+        // checked that it cannot be more, halo_plan.cpp: cgres_dependencies -- and still not overwrite what that reader waits for)
+        const v4u *rd = (const v4u *)R.rec[(k + R.par0) & (EVP_CGRES_SLOTS - 1)];
+        v4u *wr = (v4u *)R.rec[(k + 1 + R.par0) & (EVP_CGRES_SLOTS - 1)];
         // (the operand planes never change inside the loop: without an index the compiler cannot see through it hoists every one
         // of their loads into registers -- which is exactly what they are in LDS to avoid)
         // (made opaque IN PLACE: a copy per index would cost five more registers through the whole subcycle)
@@ -904,7 +911,11 @@ int blocks_per_cu(K kernel)
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel)) != hipSuccess) return 0;
     const size_t share = (fa.sharedSizeBytes + 2047) / 2048 * 2048;
-    if (share) nb = std::min<int>(nb, (int)(160 * 1024 / share));
+    // the CU's LDS as the device reports it (160 KB on gfx950), not a constant of this file
+    int dev = 0, lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds <= 0)
+        return 0;
+    if (share) nb = std::min<int>(nb, (int)((size_t)lds / share));
     return nb;
 }
 }  // namespace

@@ -115,9 +115,12 @@ bool evp_resident2_coop_built(bool strict, int cap, int logw, bool remote);   //
 void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, int max_nj, int logw,
                           bool strict, int cap, hipStream_t st);
 
-// Two subcycles per pass over a device-private strip-major layout (evp_march.hip, evp_host_march.cpp)
-#define EVP_MARCH_OWN 60       // most columns a 64-lane strip can own (two lanes of overlap on either side)
-#define EVP_MARCH_PAD 2        // halo rows below / columns of the row-major byte mask
+// Several (2 .. 4) subcycles per pass over a device-private strip-major layout (evp_march.hip, evp_host_march.cpp)
+#define EVP_MARCH_PAD 4        // width of the overlap: lanes on either side of a strip's own columns, halo rows below and above,
+                               // halo columns of the row-major byte mask, cells of the ring between ranks = the most subcycles
+                               // one pass can advance (validity shrinks by one cell per side and subcycle)
+#define EVP_MARCH_KMAX EVP_MARCH_PAD
+#define EVP_MARCH_OWN (64 - 2 * EVP_MARCH_PAD)       // most columns a 64-lane strip can own
 #define EVP_MARCH_S_NF 14      // fields per block: state (u v sig x 12), constants, optional operands, diagnostics
 #define EVP_MARCH_C_NF 13
 #define EVP_MARCH_O_NF 5
@@ -132,6 +135,7 @@ struct EvpMarch {
     int nstrips, nseg, seglen, nitems;
     int wrapx;                 // the rectangle spans a cyclic E-W dimension: strips wrap around
     int last;                  // write strintx/y, taubx/y (last pass of a call)
+    int kpass;                 // subcycles this pass advances the state by (2 .. EVP_MARCH_KMAX)
     int order;                 // work item order: bit0 one contiguous run per XCD, bit1 segment index fastest
     unsigned flags;            // EVP_F_WATER_IS_OCN / EVP_F_TBU_ZERO
     const uint8_t *mask;       // row-major [rows][ldx]: bit0 iceTmask, bit1 iceUmask (0 where there is no cell)
@@ -392,6 +396,9 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 // All subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res).  Windows of 16 x 16 positions, the inner
 // 13 x 13 owned; tab: per window the source cell of its 17 x 17 positions (one row / column more than cg_one's: what level S reads
 // of its north / east neighbour), as in EvpCgOne.  The velocities another window's rim mirrors travel as tagged 32-byte records.
+#define EVP_CGRES_REACH 3      // == CGRES_REACH (halo_plan.h): positions beyond the last owned column / row a resident window polls
+#define EVP_CGRES_SLOTS 4      // == CGRES_SLOTS: record slots per cell; the record of subcycle j sits in slot (j + par0) mod 4, so a window
+                               // may be up to three subcycles ahead of one that reads it (halo_plan.h: cgres_dependencies proves it is not more)
 struct EvpCgRes {
     const int *tab;               // [ntiles][17 * 17]
     const int4 *tiles;            // block, first owned i, first owned j (1-based), fold: fold window | tf << 8 | last owned row << 16
@@ -402,12 +409,12 @@ struct EvpCgRes {
     const uint8_t *live;          // per cell: its window runs in this call (NULL: all do)
     int nsub;                     // subcycles of this launch; the last one ends the call (the once-per-call arrays are stored in it)
     int dry;                      // 1: residency + timing probe, nothing written back
-    int par0;                     // which of rec[0/1] holds the records of subcycle index 0 of this launch
+    int par0;                     // which of rec[0 .. 3] holds the records of subcycle index 0 of this launch
     unsigned tag_base;            // launch epoch << 12; a record of subcycle k carries tag_base + k
     unsigned spin_limit;
     int *err;                     // [8] first wait that gave up: 1, window, subcycle, cell, tag seen, tag wanted
     const uint8_t *pubmap;        // per cell: 1 = some other window's rim mirrors this cell
-    void *rec[2];                 // [2][ncell] x {uvelE granule, vvelN granule} (2 x 16 bytes), by subcycle parity
+    void *rec[EVP_CGRES_SLOTS];   // [slots][ncell] x {uvelE granule, vvelN granule} (2 x 16 bytes), by subcycle modulo the slots
     const double *uE_in, *vN_in, *sp_in, *sm_in, *s12_in;               // the state on entry
     double *uE_out[2], *vN_out[2], *sp_out[2], *sm_out[2], *s12_out[2];   // ... and where it goes on exit (both allocations of each)
     const double *gbase, *inbase; // static / per-call tables: array k = base + k * stride

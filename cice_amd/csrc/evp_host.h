@@ -273,7 +273,11 @@ struct State {
         std::vector<int> blkid_h;
         std::vector<int2> org_h;
         int nstrips = 0, nseg = 0, seglen = 0, nitems = 0;
-        int exch_every = 1;            // passes between two exchanges of the ring (several ranks)
+        int kpass = EVP_MARCH_KMAX;    // subcycles a full pass advances the state by
+        int ring_valid = EVP_MARCH_PAD;// cells beyond the rank's own that are current after an exchange of the ring (ext + P):
+                                       // that many subcycles can follow before the next exchange
+        long subcycles = 0;            // subcycles advanced by passes since init
+        int call_passes = 0, call_subcycles = 0;   // ... of the last call (launches per subcycle for the timing read-out)
         size_t nblk = 0;               // (row, strip) blocks per buffer
         std::vector<unsigned> dup_h;   // [nstrips][64] duplicate positions (EvpMarch::dup)
         bool stat_done = false, stat_ok = false;

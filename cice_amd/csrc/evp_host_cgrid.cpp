@@ -46,7 +46,7 @@ struct CGridState {
         int ntiles = 0;
         uint8_t *pubmap = nullptr;
         uint8_t *gmask = nullptr;    // tripole grids: the land masks as bits (elsewhere CG.gmask, which the one-launch kernels share)
-        void *rec = nullptr;         // 2 x S.n records of 32 bytes
+        void *rec = nullptr;         // EVP_CGRES_SLOTS x S.n records of 32 bytes
         int *err = nullptr;
         int *d_order = nullptr;      // the windows that hold ice in this call (cg_res_live at every upload), n_live of them
         int *live_win = nullptr;     // [ntiles] 0 / 1
@@ -595,14 +595,18 @@ static int build_res_tables(const double *const *static23)
     Q.ntiles = (int)(tiles.size() / 4);
     // the last owned row of a window, the last row of positions that matter to its owned cells (fold windows: the fold row)
     auto jmax_of = [&](int w) { return tripole ? tiles[4 * w + 3] >> 16 : S.jhi[tiles[4 * w]]; };
-    std::vector<uint8_t> pub(S.n, 0);
-    for (int w = 0; w < Q.ntiles; ++w) {
-        const int b = tiles[4 * w], i0 = tiles[4 * w + 1], j0 = tiles[4 * w + 2];
-        for (int e = 0; e < NPOS - 1; ++e) {
-            const int ex = e % (RX + 1), ey = e / (RX + 1);
-            const bool mine = ex >= 2 && ex <= RX - 2 && ey >= 2 && ey <= RY - 2 && i0 - 2 + ex <= S.ihi[b] && j0 - 2 + ey <= jmax_of(w);
-            const int sc = tab[(size_t)w * NPOS + e];
-            if (!mine && sc >= 0) pub[sc] = 1;
+    // who publishes what, and is every hand-off mutual?  (halo_plan.cpp: cgres_dependencies -- the rule the kernel's ring applies)
+    static_assert(CGRES_REACH == EVP_CGRES_REACH && CGRES_SLOTS == EVP_CGRES_SLOTS, "halo_plan.h and evp_device.h must agree on the windows' ring");
+    std::vector<uint8_t> pub;
+    {
+        int n_edges = 0, n_oneway = 0;
+        const int unsafe = cgres_dependencies(d, tripole, tiles, tab, &pub, &n_edges, &n_oneway);
+        if (unsafe > 0) {
+            // a window that is read by one it cannot be held back by within three subcycles could overwrite the record slot that
+            // reader still waits for: static ineligibility (the one-launch kernel runs such a cut)
+            Q.why = std::to_string(unsafe) + " of " + std::to_string(n_edges) + " hand-offs between windows have no chain back within " +
+                    std::to_string(CGRES_SLOTS - 1) + " subcycles";
+            return 0;
         }
     }
     // A neighbour's operands and state come from the cell the table names for the NEIGHBOURING POSITION; the one-launch kernels
@@ -648,7 +652,7 @@ static int build_res_tables(const double *const *static23)
     HIPC(hipMalloc((void **)&Q.tab, tab.size() * sizeof(int)));
     HIPC(hipMalloc((void **)&Q.tiles, tiles.size() * sizeof(int32_t)));
     HIPC(hipMalloc((void **)&Q.pubmap, S.n));
-    HIPC(hipMalloc((void **)&Q.rec, (size_t)2 * S.n * 32));
+    HIPC(hipMalloc((void **)&Q.rec, (size_t)EVP_CGRES_SLOTS * S.n * 32));
     HIPC(hipMalloc((void **)&Q.err, 8 * sizeof(int)));
     HIPC(hipMemcpy(Q.tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(Q.tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -657,7 +661,7 @@ static int build_res_tables(const double *const *static23)
         HIPC(hipMemcpy(Q.tiles2, tiles2.data(), tiles2.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     HIPC(hipMemcpy(Q.pubmap, pub.data(), S.n, hipMemcpyHostToDevice));
-    HIPC(hipMemset(Q.rec, 0, (size_t)2 * S.n * 32));
+    HIPC(hipMemset(Q.rec, 0, (size_t)EVP_CGRES_SLOTS * S.n * 32));
     HIPC(hipMemset(Q.err, 0, 8 * sizeof(int)));
     {   // until the first upload says otherwise: every window runs
         std::vector<int> ident(Q.ntiles);
@@ -678,10 +682,12 @@ static int build_res_tables(const double *const *static23)
 // eligible in this call: one rank, no fold (either visc_method, classic or revised EVP), the default-configuration shortcuts hold on every ice cell, the static
 // identities hold (the kernel takes -1 for a boundary ratio away from a coast), every window co-resident
 static bool res_cull() { return !(env_test("CICE_EVP_HIP_CGRID_RES_CULL") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_CULL"))); }
-static bool res_eligible(std::string *why = nullptr)
+// per_call (may be NULL): set when what stands in the way holds for THIS call only (the call's masks, operands, state)
+static bool res_eligible(std::string *why = nullptr, bool *per_call = nullptr)
 {
     auto no = [&](const char *w) { if (why) *why = w; return false; };
     const CGridState::Res &Q = CG.res;
+    if (per_call) *per_call = false;
     if (CG.tripole) {
         // a u-fold on one rank: the kernel's FOLD variant (the first subcycle of a call runs as the five phases)
         if (CG.tfold || remote()) return no("a T-fold, or several ranks on a tripole grid");
@@ -689,8 +695,9 @@ static bool res_eligible(std::string *why = nullptr)
         return no("several ranks, a block too small, or the one-launch schedule switched off");
     }
     if (!Q.tab) return no(Q.why.empty() ? "tables not built" : Q.why.c_str());
-    if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
     if (CG.tripole ? !Q.gmask : !geo_derived()) return no("a start-up identity of the static arrays does not hold");
+    if (per_call) *per_call = true;
+    if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
     if (!Q.pairs_state_ok) return no("ghost cells outside the domain that the kernel treats as one position hold different state");
     if (Q.n_live < 1) return no("no window holds ice");
     if ((long)(res_cull() ? Q.n_live : Q.ntiles) > Q.cap4[(CG.avg_strength ? 1 : 0) | (S.prm.revp != 0.0 ? 2 : 0)]) return no("more windows with ice than can be resident at once");
@@ -714,11 +721,11 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     if (Q.epoch == 0) Q.epoch = 1;
     R.tag_base = Q.epoch << 12;
     R.par0 = Q.par;
-    Q.par ^= (nsub & 1);
+    Q.par = (Q.par + nsub) & (EVP_CGRES_SLOTS - 1);
     R.spin_limit = (R.dbg & 16) ? 200000u : 4000000u;       // (the fault test need not wait seconds for the bound)
     R.err = Q.err;
     R.pubmap = Q.pubmap;
-    R.rec[0] = Q.rec; R.rec[1] = (char *)Q.rec + (size_t)S.n * 32;
+    for (int k = 0; k < EVP_CGRES_SLOTS; ++k) R.rec[k] = (char *)Q.rec + (size_t)k * S.n * 32;
     R.uE_in = cur5[0]; R.vN_in = cur5[1]; R.sp_in = cur5[2]; R.sm_in = cur5[3]; R.s12_in = cur5[4];
     R.uE_out[0] = cur5[0]; R.uE_out[1] = alt5[0]; R.vN_out[0] = cur5[1]; R.vN_out[1] = alt5[1];
     R.sp_out[0] = cur5[2]; R.sp_out[1] = alt5[2]; R.sm_out[0] = cur5[3]; R.sm_out[1] = alt5[3];
@@ -759,8 +766,11 @@ static int res_decide(const EvpCgrid &A)
     int want = -1;
     if (const char *e = env("CICE_EVP_HIP_CGRID_RESIDENT")) want = std::atoi(e);
     std::string why;
-    if (want == 0 || !res_eligible(&why)) {
-        if (want == 1) return fail(-6, "resident C-grid kernel requested but not applicable: %s", why.c_str());
+    bool per_call = false;
+    if (want == 0 || !res_eligible(&why, &per_call)) {
+        // forced on: only what can never change (tables, geometry, rank layout) is an error; a condition of this call's masks,
+        // operands or state is a fall-back for this call, as it is once the kernel has run (res_subcycles)
+        if (want == 1 && !per_call) return fail(-6, "resident C-grid kernel requested but not applicable: %s", why.c_str());
         if (env("CICE_EVP_HIP_VERBOSE") && want != 0) std::fprintf(stderr, "[cice_evp_hip] C grid: on-chip resident kernel not used: %s\n", why.c_str());
         // (per-call conditions -- visc_method, the shortcuts -- may hold in a later call: stay undecided unless switched off)
         if (want == 0) Q.mode = 0;

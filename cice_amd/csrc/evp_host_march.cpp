@@ -1,25 +1,29 @@
 // =====================================================================
-// Host side of the two-subcycles-per-pass kernel (evp_march.hip): the device-private rectangle layout, the
+// Host side of the several-subcycles-per-pass kernel (evp_march.hip): the device-private rectangle layout, the
 // conversions between it and the CICE block layout, and the loop.
 //
 // Strip-major layout: all blocks of the rank are assembled into ONE rectangle of nxr x nyr cells, cut into strips of
-// `own` <= 60 columns; per (row, strip) one contiguous block [field][64 lanes] -- lanes 2 .. own+1 are the strip's own
-// columns, the others duplicate its neighbours' (or, beyond a closed side, hold the caller's ghost values / zeros).
+// `own` <= 56 columns; per (row, strip) one contiguous block [field][64 lanes] -- with P = EVP_MARCH_PAD = 4, lanes
+// P .. P+own-1 are the strip's own columns, the others duplicate its neighbours' (or, beyond a closed side, hold the
+// caller's ghost values / zeros).
 // Buffers: state (u, v, 12 stresses; two copies), constants of a call (13 fields), optional operands (5), diagnostics
-// (4); rows -2 .. nyr+4 (two halo rows below, two above, two spare rows the prefetch may touch, one dump row).  Every
+// (4); rows -P .. nyr+P+2 (P halo rows below, P above, two spare rows the prefetch may touch, one dump row).  Every
 // cell of the rank exists once: the reference's redundant copies (ghost cells, the T-cells of the north / east fringe
 // every block computes for itself, ice_dyn_shared.F90:740-749) are images of it.  The byte mask stays row-major.
 //
 // A call of cice_evp_hip_subcycle(ndte) through this path:
-//   [ndte odd: one subcycle with the one-subcycle kernel]  gather -> consistency check (first call after an upload)
-//   -> ndte/2 passes (ping-pong between two sets of u, v, 12 stresses) -> scatter.
+//   [ndte = 4q + 1: one subcycle with the one-subcycle kernel]  gather -> consistency check (first call after an upload)
+//   -> q passes of four subcycles and one of the remaining two or three (ping-pong between two sets of u, v, 12
+//   stresses) -> scatter.
 // Not eligible (the one-subcycle kernels keep running): tripole / cyclic north-south boundary, blocks that do not tile a
 // rectangle per rank (eliminated land blocks), metric terms handed over as arrays (tripole), a rank too thin next to a
 // closed boundary for its redundant rim (march_plan.cpp), a caller whose ghost values are not images of one global
-// state.  Several ranks: the ring of ext + 2 cells travels over RCCL send / recv once per ext/2 + 1 passes (section 6).
+// state.  Several ranks: the ring of ext + P cells travels over RCCL send / recv once per ext + P subcycles (section 6).
 // =====================================================================
 #include "evp_host.h"
 #include "march_plan.h"
+
+static_assert(MARCH_PLAN_PAD == EVP_MARCH_PAD, "march_plan.h and evp_device.h must agree on the width of the overlap");
 
 namespace evp_host {
 
@@ -87,12 +91,31 @@ static bool march_geometry(std::string &why)
     // the rectangles of all ranks, this rank's strips and the exchange lists: the same verdict on every rank
     const int own_max = env_test("CICE_EVP_HIP_MARCH_OWN") ? std::atoi(env_test("CICE_EVP_HIP_MARCH_OWN")) : EVP_MARCH_OWN;
     const bool wrap_inside = !(env_test("CICE_EVP_HIP_MARCH_SELFX") && std::atoi(env_test("CICE_EVP_HIP_MARCH_SELFX")));
-    // cells a rank holds beyond its own on every side with a neighbour: the ring is then exchanged every (ext/2 + 1)-th
-    // pass only (march_plan.h); 4 = every third pass (every sixth subcycle).  3600 x 2400 as 4x2 pieces, one-GPU rehearsal:
-    // 54.3 / 52.3 / 52.0 / 51.2 us per subcycle with ext 0 / 2 / 4 / 6 against 47.0 without any exchange
+    // cells a rank holds beyond its own on every side with a neighbour: the ring of ext + P cells is then exchanged every
+    // (ext + P)-th subcycle only (march_plan.h); 4 = after every second pass of four.  (Rounds 4-5, two subcycles per pass and a
+    // two-cell ring, 3600 x 2400 as 4x2 pieces, one-GPU rehearsal: 54.3 / 52.3 / 52.0 / 51.2 us per subcycle with ext 0 / 2 / 4 / 6
+    // against 47.0 without any exchange.)
     const int ext = env_test("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env_test("CICE_EVP_HIP_MARCH_EXT")) & ~1) : 4;
     if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
-    M.exch_every = ext / 2 + 1;
+    M.ring_valid = ext + EVP_MARCH_PAD;
+    // Subcycles per pass.  Round 6 measured what binds the kernel: a wave issues one instruction per 2.4 ns whatever it is, and a
+    // row costs ~640 instructions per level plus ~350 that do not depend on the number of levels (loads, stores, addressing); a
+    // segment of sl rows marches sl + 2K - 1.  Cost per stored row and subcycle ~ (sl + 2K - 1) / sl * (640 + 350 / K): four levels
+    // from 46 rows per segment (3600 x 2400 on one GPU: 160), three from 23, two below (its 8 x 1 pieces: ~22 rows).  Every rank
+    // must run the same passes (the ring is exchanged between them), so the rule looks at the SHORTEST segment of any rank, which
+    // every rank works out from the global block table alone.  The test build can ask for a value.
+    {
+        int slmin = 1 << 30;
+        for (const MarchRect &R : PL.all) {
+            if (!R.ok) continue;
+            const int grow = d.nranks > 1 ? 2 * ext : 0;
+            const int ns = (R.nxr + grow + EVP_MARCH_OWN - 1) / EVP_MARCH_OWN;
+            const int nseg = std::max(1, 1024 / ns);
+            slmin = std::min(slmin, std::max(6, (R.nyr + grow + nseg - 1) / nseg));
+        }
+        M.kpass = slmin >= 46 ? 4 : slmin >= 23 ? 3 : 2;
+    }
+    if (env_test("CICE_EVP_HIP_MARCH_K")) M.kpass = std::min(EVP_MARCH_KMAX, std::max(2, std::atoi(env_test("CICE_EVP_HIP_MARCH_K"))));
     if (PL.peers.size() > (size_t)EVP_MARCH_DIRECT_MAXPEER) { why = "more ring neighbours than the exchange lists hold"; return false; }
     if (!PL.peers.empty() && !S.have_comm && !S.test_xchg) { why = "cells of other ranks needed but no RCCL communicator (cice_evp_hip_comm_init)"; return false; }
     if (!(S.flags & EVP_F_METRICS) || (S.flags & EVP_F_DXHY_ARRAY)) { why = "metric terms come from arrays"; return false; }
@@ -142,7 +165,7 @@ static bool march_geometry(std::string &why)
         if (PL.dup[k] >= 0) M.dup_h[k] = (unsigned)((((size_t)(PL.dup[k] >> 8)) * EVP_MARCH_S_NF * 64 + (PL.dup[k] & 255)) * 8);
     M.nstrips = G.nstrips;
     G.ldx = ((G.nstrips * G.own + 64 + 2 * EVP_MARCH_PAD + 7) / 8) * 8;
-    G.rows = G.nyr + EVP_MARCH_PAD + 5;          // y = -2 .. nyr+4: halo, two rows the prefetch may touch, the dump row
+    G.rows = G.nyr + 2 * EVP_MARCH_PAD + 3;      // y = -P .. nyr+P+2: halo, two rows the prefetch may touch, the dump row
     M.nblk = (size_t)G.rows * G.nstrips;
     if (M.nblk * EVP_MARCH_S_NF * 512 >= (1ull << 32)) { why = "state buffer beyond 32-bit byte offsets"; return false; }
     // segments: one wave per SIMD (1024 of them), all resident at once -- measured at 3600 x 2400: 16 segments (960
@@ -644,6 +667,7 @@ static void march_args(EvpMarch &A, int cur, int last)
     A.nstrips = M.nstrips; A.nseg = M.nseg; A.seglen = M.seglen; A.nitems = M.nitems;
     A.wrapx = M.G.wrapx;
     A.last = last;
+    A.kpass = M.kpass;
     A.order = env_test("CICE_EVP_HIP_MARCH_ORDER") ? std::atoi(env_test("CICE_EVP_HIP_MARCH_ORDER")) : 1;
     A.flags = S.flags & S.flags_allowed;
     A.mask = B.mask;
@@ -674,12 +698,23 @@ int march_run(int ndte)
         return 0;
     };
     if (!M.stat_ok) return fallback("ghost values of the static grid fields are not images of one global field");
-    if (left & 1) {          // the odd one first, in the block layout
-        if (int rc = enqueue_loop(1, cur)) return rc;
-        cur ^= 1;
-        --left;
-        S.cur = cur;         // the device state HAS advanced: an error further down must not leave S.cur on the old copy
+    // ndte = q passes of kpass subcycles + one pass of the remaining 2 .. kpass-1; a single remaining subcycle goes first, through
+    // the one-subcycle kernel in the block layout
+    std::vector<int> sizes;
+    {
+        const int kp = M.kpass;
+        int q = left / kp, rem = left % kp;
+        if (rem == 1) {
+            if (int rc = enqueue_loop(1, cur)) return rc;
+            cur ^= 1;
+            --left;
+            rem = 0;
+            S.cur = cur;     // the device state HAS advanced: an error further down must not leave S.cur on the old copy
+        }
+        sizes.assign((size_t)q, kp);
+        if (rem) sizes.push_back(rem);
     }
+    M.call_passes = 0; M.call_subcycles = 0;
     if (left == 0) { S.cur = cur; return 0; }
     const unsigned fl = S.flags & S.flags_allowed;
     // ---- gather the state and the per-call inputs ----
@@ -723,15 +758,16 @@ int march_run(int ndte)
         M.checked_seq = S.upload_seq;
     }
     // ---- the passes ----
-    // Exchange passes (every exch_every-th and the last): the cells other ranks are waiting for are advanced FIRST, by an
+    // Exchange passes (the redundant rim and the ring have been used up; the last): the cells other ranks are waiting for are advanced FIRST, by an
     // early launch of the same kernel over short segments on the second stream; their pack and the RCCL send / recv follow
     // there while the pass itself -- all work items, those cells included -- runs on the compute stream: the transfer is
     // overlapped with the pass instead of following it (ice_HaloUpdate -> RCCL point-to-point on a second HIP stream over
     // interior compute).  Both launches store the same bits into the same cells (same kernel, same operands; a cell's
     // result does not depend on the segment it is computed in), so the duplicate stores are harmless.  Only the unpack
     // waits for the pass: the pass still writes its (spent) redundant rim where the received cells go.
-    const int npass = left / 2;
+    const int npass = (int)sizes.size();
     int rc = 0;
+    int valid = M.ring_valid;        // cells beyond the rank's own that hold the current state (the gather's exchange just filled them)
     // Opt-in (CICE_EVP_HIP_MARCH_OVERLAP=1).  Measured where it could be measured -- one GPU, the ring exchanged with the rank
     // itself, 450 x 2400 and 900 x 1200 pieces of 3600 x 2400 -- the early launch costs more than it hides: 57.7 against
     // 51.2 us per subcycle (8 x 1 piece; 48.9 without any exchange), 55.2 against 50.7 (4 x 2 piece): two of eight strips
@@ -740,9 +776,16 @@ int march_run(int ndte)
     // --gpus N times the 3600 x 2400 block both ways so that the first run on a real node decides.
     const bool overlap = !PL.peers.empty() && B.nband > 0 && env_test("CICE_EVP_HIP_MARCH_OVERLAP") && std::atoi(env_test("CICE_EVP_HIP_MARCH_OVERLAP"));
     for (int k = 0; k < npass; ++k) {
-        const bool exch = !PL.peers.empty() && ((k + 1) % M.exch_every == 0 || k == npass - 1);
+        // the ring of the new state travels after this pass when the next one needs more valid cells than are left, and after the
+        // last one (the way back to the block layout reads the ghost cells from it)
+        // (a pass advances the cells the rank holds -- its own + ext -- and only reads the P-cell ring around them: whatever is left of
+        // the ring afterwards is a state older)
+        valid = std::min(valid - sizes[(size_t)k], M.ring_valid - EVP_MARCH_PAD);
+        const bool exch = !PL.peers.empty() && (k == npass - 1 || valid < sizes[(size_t)k + 1]);
+        if (exch) valid = M.ring_valid;
         EvpMarch A;
         march_args(A, rc, k == npass - 1);
+        A.kpass = sizes[(size_t)k];
         if (exch && overlap) {
             HIPC(hipEventRecord(B.ev_in, S.stream));
             HIPC(hipStreamWaitEvent(S.stream_comm, B.ev_in, 0));
@@ -755,8 +798,6 @@ int march_run(int ndte)
         }
         evp_launch_march(A, S.prm.strict != 0, cap_mode(), S.stream);
         rc ^= 1;
-        // the ring of the new state: after every exch_every-th pass (the redundant rim has been used up) and after the last
-        // one (the way back to the block layout reads the ghost cells from it)
         if (exch && overlap) {
             HIPC(hipEventRecord(B.ev_main, S.stream));
             HIPC(hipStreamWaitEvent(S.stream_comm, B.ev_main, 0));
@@ -769,6 +810,8 @@ int march_run(int ndte)
     }
     HIPC(hipGetLastError());
     M.passes += npass;
+    M.subcycles += left;
+    M.call_passes = npass; M.call_subcycles = left;
     // ---- back to the block layout ----
     {
         TabBuilder T;
@@ -779,7 +822,7 @@ int march_run(int ndte)
         evp_launch_march_scatter(M.G, T.T, S.mask, 2, 12, S.stream);
     }
     HIPC(hipGetLastError());
-    S.cur = cur;            // an even number of subcycles later: same ping-pong buffer of the block layout
+    S.cur = cur;            // the passes leave the block layout's ping-pong buffer where it was: the scatter wrote the new state there
     return 0;
 }
 

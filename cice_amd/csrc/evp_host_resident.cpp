@@ -391,7 +391,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
                    evp_resident2_coop_built(S.prm.strict != 0, cap_mode(), S.res2_logw, false);
         if (can) {
             hipDeviceProp_t prop;
-            const int per_cu = std::min(evp_resident2_max_blocks_per_cu(true, cap_mode(), A.flags, 4, false, true), 8);
+            const int per_cu = std::min(evp_resident2_max_blocks_per_cu(S.prm.strict != 0, cap_mode(), A.flags, 4, false, true), 8);
             can = hipGetDeviceProperties(&prop, S.device) == hipSuccess &&
                   (long)std::max(S.res2_nlive, 1) * 10 <= (long)per_cu * prop.multiProcessorCount * 9;
         }

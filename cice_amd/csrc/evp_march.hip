@@ -1,35 +1,38 @@
 // =====================================================================
-// Two EVP subcycles per pass over HBM: the "marching" kernel (gfx950, wave64, fp64) for per-rank domains
+// Several EVP subcycles per pass over HBM: the "marching" kernel (gfx950, wave64, fp64) for per-rank domains
 // that do not fit on the chip (3600 x 2400 and the like).
 //
 // Why: the one-subcycle streaming kernel (evp_kernels.hip) already moves no byte twice and runs at the box's mixed
 // read/write streaming rate; per subcycle it must read 27 and write 14 doubles per cell.  The only way below that is
-// fewer sweeps: this kernel advances the state by TWO subcycles of the reference's loop
-// (ice_dyn_evp.F90:859-913: stress :867, stepu :889, halo :908) while touching every field once.
+// fewer sweeps: this kernel advances the state by K = 2, 3 or 4 subcycles of the reference's loop
+// (ice_dyn_evp.F90:859-913: stress :867, stepu :889, halo :908) while touching every field once.  K = 2 was rounds
+// 3-5 (0.58-0.61 of the HBM peak on its own bytes, the fp64 pipes busy half of the time: memory and arithmetic take
+// turns inside the one wave a SIMD holds); K = 4 (round 6) halves the bytes per subcycle again and makes the pass
+// arithmetic-bound -- the loads of a row have four subcycles of arithmetic to hide behind instead of two.
 //
 // Work item = ONE WAVE marching north over a strip of 64 columns x seglen rows; lane = column.  No workgroup barrier,
 // no LDS-shared data: a workgroup is just four independent waves.
-//   row r of the march:   S1  stress of subcycle k+1 on T-row r      (velocities U(k) of rows r-1, r)
-//                         U1  stepu  of subcycle k+1 on U-row r-1    (stress divergence from T-rows r-1, r)
-//                         S2  stress of subcycle k+2 on T-row r-1    (velocities U(k+1) of rows r-2, r-1)
-//                         U2  stepu  of subcycle k+2 on U-row r-2    -> stored
+//   row r of the march, level L = 1 .. K (S_L = stress of subcycle k+L, U_L = stepu of subcycle k+L):
+//                         S_L  on T-row r-(L-1)    (velocities U(k+L-1) of rows r-L, r-(L-1))
+//                         U_L  on U-row r-L        (stress divergence from T-rows r-L, r-(L-1));  U_K -> stored
 //   * neighbours in i (uvel(i-1,j), HTE(i-1,j), str(i+1,j,.)) come from the adjacent lane by wavefront shuffles (DPP),
 //     neighbours in j from values the wave carries from its previous row in registers;
-//   * the 12 stresses of subcycle k+1 wait for S2 in a per-wave LDS stash (2 rows x 12 x 64 doubles = 12 KB);
-//   * validity shrinks by one lane per stage: S1 lanes 1..63, U1 1..62, S2 2..62, U2 2..61 -- a strip owns <= 60
-//     columns, neighbouring strips / segments recompute the overlap (1.07 x 1.06 redundant work at 3600 x 2400 with
-//     48-row segments), bit-identical by construction: same operands, same operation order (evp_cell.inc), nothing
-//     depends on scheduling.
+//   * the 12 stresses of subcycle k+L wait for S_(L+1) in a per-wave LDS stash (2 rows x 12 x 64 doubles = 12 KB per
+//     level boundary: 36 KB per wave, 144 KB per workgroup at K = 4 -- one workgroup per CU, one wave per SIMD);
+//   * validity shrinks by one lane per stage: S_L lanes L..64-L, U_L lanes L..63-L -- a strip owns <= 64 - 2P = 56
+//     columns (P = EVP_MARCH_PAD = 4 lanes of overlap on either side, whatever K), neighbouring strips / segments
+//     recompute the overlap, bit-identical by construction: same operands, same operation order (evp_cell.inc),
+//     nothing depends on scheduling.
 //
 // Data: a device-private, STRIP-MAJOR layout (evp_host_march.cpp).  Per (row, strip) one contiguous block
 // [field][64 lanes]: the state (u, v, 12 stresses: 7 KB, two copies for ping-pong), the constants of a call (dxT, dyT,
 // strength, HTE, HTN and eight momentum operands: 6.5 KB), optional operands, diagnostics.  A wave's row is then a few
 // long contiguous runs instead of 41 x 512 B scattered over 41 arrays -- measured with a copy of this access pattern
-// (tools/march_stream.hip): 5.6 TB/s packed against 2.6-4.8 TB/s for separate arrays.  The four overlap lanes of a
-// block duplicate columns its neighbours own; an owner stores its two edge columns into the neighbour's block too.
+// (tools/march_stream.hip): 5.6 TB/s packed against 2.6-4.8 TB/s for separate arrays.  The 2P overlap lanes of a
+// block duplicate columns its neighbours own; an owner stores its P edge columns into the neighbour's block too.
 // With a cyclic E-W dimension inside the rank the strips wrap around (lane -> column modulo nxr): no halo columns.
-// Algorithmic HBM bytes per cell and PASS: 27 reads + 14 writes = 328 B, i.e. 164 B per cell-subcycle against the
-// 368 B yardstick of SURVEY 8(d).
+// Algorithmic HBM bytes per cell and PASS: 27 reads + 14 writes = 328 B, i.e. 82 B per cell-subcycle at K = 4 (164 at
+// K = 2) against the 368 B yardstick of SURVEY 8(d).
 // =====================================================================
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -40,11 +43,9 @@
 #include "evp_device.h"
 #include "evp_math.h"
 
-#ifndef EVP_MARCH_WAVES
-#define EVP_MARCH_WAVES 2
-#endif
-
 namespace {
+
+constexpr int PADW = EVP_MARCH_PAD;
 
 // field slots of the packed blocks (64 doubles = 512 bytes each)
 enum : unsigned { S_U = 0, S_V = 1, S_SIG = 2, S_NF = 14 };
@@ -78,8 +79,6 @@ struct Item {
     unsigned lane8;         // lane * 8
     unsigned dupd;          // byte offset, from the start of a state ROW, of the duplicate of this lane's column in a
                             // neighbouring block (field 0); EVP_MARCH_NODUP: none
-    long blk0;              // block index of (row Y0-2, strip)
-    unsigned em0;           // mask element of (column xw, row Y0-2)
 };
 
 __device__ __forceinline__ bool march_item(const EvpMarch &A, Item &I)
@@ -107,8 +106,8 @@ __device__ __forceinline__ bool march_item(const EvpMarch &A, Item &I)
         I.Y0 = seg * A.seglen;
         I.Y1 = min(I.Y0 + A.seglen, A.nyr);
     }
-    const int x = I.strip * A.own - 2 + I.lane;
-    I.own_x = I.lane >= 2 && I.lane < 2 + A.own && x < A.nxr;
+    const int x = I.strip * A.own - PADW + I.lane;
+    I.own_x = I.lane >= PADW && I.lane < PADW + A.own && x < A.nxr;
     I.xw = x;
     if (A.wrapx) {
         if (I.xw < 0) I.xw += A.nxr;
@@ -116,8 +115,6 @@ __device__ __forceinline__ bool march_item(const EvpMarch &A, Item &I)
     }
     I.lane8 = (unsigned)I.lane * 8u;
     I.dupd = (unsigned)A.dup[I.strip * 64 + I.lane];
-    I.blk0 = (long)(I.Y0 - 2 + EVP_MARCH_PAD) * A.nstrips + I.strip;
-    I.em0 = (unsigned)((I.Y0 - 2 + EVP_MARCH_PAD) * A.ldx + EVP_MARCH_PAD + I.xw);
     return true;
 }
 
@@ -155,17 +152,20 @@ __device__ __forceinline__ void FST(Rsrc r, unsigned voff, unsigned soff, unsign
 // out-of-range offset (dropped by the buffer bounds check) instead of being branched around.  The point is s_waitcnt: vmcnt counts in
 // issue order, and across a conditional memory instruction the compiler has to assume the worst and drain the queue
 // -- with predicated loads, issued where they are used, the march exposed three memory latencies per row; here the only
-// wait of a row is for loads issued a whole row of arithmetic earlier (and never for the stores in between).  248
-// VGPRs: two waves per SIMD; the LDS stash (12 KB per wave) would allow three.
+// wait of a row is for loads issued a whole row of arithmetic earlier (and never for the stores in between).
+// What a level needs of older rows -- the geometry of T-row r-(L-1), the momentum operands and masks of U-row r-L --
+// rides along in register pipelines, one stage per row.  K = 2: 248 VGPRs, two waves per SIMD allowed; K = 3, 4: one wave
+// per SIMD with the 512-entry register file (VGPRs + AGPRs) to itself.
 // ---------------------------------------------------------------------
-template <bool STRICT, int MODE, bool LEAN, bool LAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EVP_MARCH_WAVES, EVP_MARCH_WAVES))) void evp_march2p(EvpMarch A)
+template <int K, bool STRICT, int MODE, bool LEAN, bool LAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 2 ? 2 : 1, K <= 2 ? 2 : 1))) void evp_marchk(EvpMarch A)
 {
+    static_assert(K >= 2 && K <= EVP_MARCH_KMAX, "subcycles per pass");
     using MM = Math<STRICT>;
     using SI = typename MM::SI;
     using UI = typename MM::UI;
     using UO = typename MM::UO;
-    __shared__ double stash[4][2][12][64];
+    __shared__ double stash[4][K - 1][2][12][64];
     Item I;
     if (!march_item(A, I)) return;
     const int lane = I.lane, wv = I.wv, Y0 = I.Y0, Y1 = I.Y1;
@@ -175,17 +175,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EVP_MARCH_W
     const bool revised = !LEAN && A.p.revp != 0.0;
     const bool own_x = I.own_x;
     const unsigned l8 = I.lane8;
-    const unsigned rows = (unsigned)(A.nyr + EVP_MARCH_PAD + 5);
+    const unsigned rows = (unsigned)(A.nyr + 2 * PADW + 3);
     const unsigned srow = (unsigned)A.nstrips * (S_NF * 512), crow = (unsigned)A.nstrips * (C_NF * 512),
                    orow = (unsigned)A.nstrips * (O_NF * 512), drow = (unsigned)A.nstrips * (D_NF * 512);     // bytes per row of blocks
     const Rsrc rSin = make_rsrc(A.st_in, rows * srow), rSout = make_rsrc(A.st_out, rows * srow), rC = make_rsrc(A.cst, rows * crow),
                rO = make_rsrc(A.opt, A.opt ? rows * orow : 0u), rD = make_rsrc(A.diag, rows * drow);
-    // row offsets (uniform) of row r-... and the lane's offsets within a row of each buffer
-    const unsigned row0 = (unsigned)(Y0 - 2 + EVP_MARCH_PAD);
+    // row offsets (uniform) of the row below the first one of the march and the lane's offsets within a row of each buffer
+    const unsigned row0 = (unsigned)(Y0 - K + PADW);
     unsigned sS = row0 * srow, sC = row0 * crow, sO = row0 * orow, sD = row0 * drow;
     const unsigned vS = (unsigned)I.strip * (S_NF * 512) + l8, vC = (unsigned)I.strip * (C_NF * 512) + l8,
                    vO = (unsigned)I.strip * (O_NF * 512) + l8, vD = (unsigned)I.strip * (D_NF * 512) + l8;
-    unsigned em = I.em0;
+    unsigned em = row0 * (unsigned)A.ldx + (unsigned)(PADW + I.xw);      // mask element of (column xw, row Y0-K)
 
     struct Row { double u, v, hte, htn, s[12], dxT, dyT, strength; };
     auto load_row = [&](unsigned sr, unsigned cr, unsigned mm, Row &R) {          // sr, cr: row offsets
@@ -223,145 +223,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EVP_MARCH_W
         else MM::template stepu<MODE, true>(A.p, w, o);
     };
 
-    // ---- carried state ----
-    double u_p = FLD(rSin, vS, sS, S_U), v_p = FLD(rSin, vS, sS, S_V);        // U(k), row r-1
-    double htn_p = FLD(rC, vC, sC, C_HTN), htn_pp = 0, hte_p = 0;
-    double dxT_p = 0, dyT_p = 0, strength_p = 0;
-    unsigned m_p = 0, m_pp = 0;
-    double c1_sx0 = 0, c1_sx1 = 0, c1_sy0 = 0, c1_sy2 = 0;
-    double u1_p = 0, v1_p = 0;
-    double c2_sx0 = 0, c2_sx1 = 0, c2_sy0 = 0, c2_sy2 = 0;
-    UI us_p{};                                                      // momentum operands of U-row r-2 (U1's, one row ago)
-    // in flight when the loop starts: row Y0-1, momentum operands nobody uses, the masks of rows Y0-1, Y0
+    // ---- carried state (index = level; [0] of the velocities is U(k) itself) ----
+    double up[K], vp[K];                 // U(k+L) on row r-L-1: the row below the one level L+1's stress works on
+    double cs[K][4];                     // str of level L+1 on T-row r-L-1: sx0, sx1 of the lane to the east, sy0, sy2 of that lane
+    struct Geo { double hte, dxT, dyT, strength; };
+    Geo gq[K];                           // geometry of T-row r-j (gq[0] = the current row, filled per iteration)
+    double htnq[K + 1];                  // HTN of row r-j
+    UI usq[K];                           // momentum operands of U-row r-1-j
+    unsigned mk[K + 1];                  // masks of row r-j
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        up[j] = 0.0; vp[j] = 0.0;
+        cs[j][0] = cs[j][1] = cs[j][2] = cs[j][3] = 0.0;
+        gq[j] = Geo{0.0, 0.0, 0.0, 0.0};
+        htnq[j] = 0.0;
+        usq[j] = UI{};
+        mk[j] = 0u;
+    }
+    htnq[K] = 0.0; mk[K] = 0u;
+    up[0] = FLD(rSin, vS, sS, S_U); vp[0] = FLD(rSin, vS, sS, S_V);        // U(k), row Y0-K
+    htnq[0] = FLD(rC, vC, sC, C_HTN);                                       // (shifted into htnq[1] by the first iteration)
+    // in flight when the loop starts: the first row of the march, momentum operands nobody uses, the masks of that row and the next
     unsigned m_n = A.mask[em + (unsigned)A.ldx], m_nn = A.mask[em + 2u * (unsigned)A.ldx];
     Row N{};
     UI usN{};
     load_us(sC, sO, false, usN);
     load_row(sS + srow, sC + crow, m_n, N);
 
-    for (int r = Y0 - 1; r <= Y1 + 1; ++r) {
+    for (int r = Y0 - (K - 1); r <= Y1 - 1 + K; ++r) {
         sS += srow; sC += crow; sO += orow; sD += drow; em += (unsigned)A.ldx;          // blocks of row r
+        // ---- the pipelines move up one row ----
+#pragma unroll
+        for (int j = K; j >= 1; --j) { htnq[j] = htnq[j - 1]; mk[j] = mk[j - 1]; }
+#pragma unroll
+        for (int j = K - 1; j >= 1; --j) { gq[j] = gq[j - 1]; usq[j] = usq[j - 1]; }
         const Row C = N;
-        const UI us = usN;                                          // momentum operands of U-row r-1
-        const unsigned m = m_n;
+        usq[0] = usN;                                               // momentum operands of U-row r-1
+        mk[0] = m_n;
+        htnq[0] = C.htn;
+        gq[0] = Geo{C.hte, C.dxT, C.dyT, C.strength};
         m_n = m_nn;
         // everything the NEXT row consumes, requested now
         {
-            const bool isU1n = (m & 2u) && lane >= 1 && lane <= 62 && r + 1 >= Y0;
+            const bool isU1n = (mk[0] & 2u) && lane >= 1 && lane <= 62 && r + 1 >= Y0 - K + 2;
             load_us(sC, sO, isU1n, usN);                            // U-row r
             m_nn = A.mask[em + 2u * (unsigned)A.ldx];               // (spare rows on top of the arrays)
             load_row(sS + srow, sC + crow, m_n, N);                 // row r+1
         }
 
-        // ---- S1: stress(k+1) on T(x, r) ----
-        const bool act1 = (m & 1u) && lane >= 1;
-        double str1[8];
+        double cu = C.u, cv = C.v;                                  // U(k+L-1) on T-row r-(L-1), the level's "row above"
 #pragma unroll
-        for (int k = 0; k < 8; ++k) str1[k] = 0.0;
-        {
-            const double uL = lane_up(C.u), vL = lane_up(C.v), hteL = lane_up(C.hte);
-            const double uL_p = lane_up(u_p), vL_p = lane_up(v_p);
-            if (act1) {
-                double s[12];
+        for (int L = 1; L <= K; ++L) {
+            const int tr = r - (L - 1), ur = r - L;
+            // ---- S_L: stress(k+L) on T(x, tr) ----
+            const bool act = (mk[L - 1] & 1u) && lane >= L && lane <= 64 - L && tr >= Y0 - (K - L);
+            double str[8];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) s[k] = C.s[k];
-                SI a;
-                a.dxT = C.dxT; a.dyT = C.dyT; a.strength = C.strength;
-                a.u_ij = C.u; a.u_im = uL; a.u_jm = u_p; a.u_mm = uL_p;
-                a.v_ij = C.v; a.v_im = vL; a.v_jm = v_p; a.v_mm = vL_p;
-                MM::metrics(C.hte, hteL, C.htn, htn_p, A.deltaminEVP, a);
-                MM::template stress<MODE>(A.p, a, s, str1);
+            for (int k = 0; k < 8; ++k) str[k] = 0.0;
+            double s[12];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) stash[wv][r & 1][k][lane] = s[k];
+            for (int k = 0; k < 12; ++k) s[k] = 0.0;
+            {
+                const double uL = lane_up(cu), vL = lane_up(cv), hteL = lane_up(gq[L - 1].hte);
+                const double uL_p = lane_up(up[L - 1]), vL_p = lane_up(vp[L - 1]);
+                if (act) {
+                    if (L == 1) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) s[k] = C.s[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) s[k] = stash[wv][L - 2][tr & 1][k][lane];
+                    }
+                    SI a;
+                    a.dxT = gq[L - 1].dxT; a.dyT = gq[L - 1].dyT; a.strength = gq[L - 1].strength;
+                    a.u_ij = cu; a.u_im = uL; a.u_jm = up[L - 1]; a.u_mm = uL_p;
+                    a.v_ij = cv; a.v_im = vL; a.v_jm = vp[L - 1]; a.v_mm = vL_p;
+                    MM::metrics(gq[L - 1].hte, hteL, htnq[L - 1], htnq[L], A.deltaminEVP, a);
+                    MM::template stress<MODE>(A.p, a, s, str);
+                    if (L < K) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) stash[wv][L < K ? L - 1 : 0][tr & 1][k][lane] = s[k];
+                    }
+                }
             }
-        }
-        const double n1_sx3 = lane_dn(str1[3]), n1_sy3 = lane_dn(str1[7]);
-        const double t1_sx1 = lane_dn(str1[1]), t1_sy2 = lane_dn(str1[6]);
-
-        // ---- U1: stepu(k+1) on U(x, r-1) ----
-        double u1 = u_p, v1 = v_p;
-        const bool isU1 = (m_p & 2u) && lane >= 1 && lane <= 62 && r >= Y0;
-        if (isU1) {
-            UO o;
-            momentum(us, u_p, v_p, c1_sx0, c1_sx1, str1[2], n1_sx3, c1_sy0, str1[5], c1_sy2, n1_sy3, o);
-            u1 = o.u; v1 = o.v;
-        }
-
-        // ---- S2: stress(k+2) on T(x, r-1) ----
-        const bool act2 = (m_p & 1u) && lane >= 2 && lane <= 62 && r - 1 >= Y0;
-        double str2[8];
+            if (L == K) {
+                // new stresses of T(x, tr): into the owner's block, and -- the P columns on either edge of a strip -- into the
+                // neighbouring block that duplicates them (a second store instruction with few live lanes)
+                const bool st = act && own_x && tr < Y1;
+                const unsigned o1 = st ? vS : OOB;
+                const unsigned o2 = (st && I.dupd != EVP_MARCH_NODUP) ? I.dupd : OOB;
+                const unsigned so = sS - (unsigned)(K - 1) * srow;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) str2[k] = 0.0;
-        double s2[12];
+                for (int k = 0; k < 12; ++k) FST(rSout, o1, so, S_SIG + k, s[k]);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) s2[k] = 0.0;
-        {
-            const double u1L = lane_up(u1), v1L = lane_up(v1), hteL_p = lane_up(hte_p);
-            const double u1L_p = lane_up(u1_p), v1L_p = lane_up(v1_p);
-            if (act2) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) s2[k] = stash[wv][(r - 1) & 1][k][lane];
-                SI b;
-                b.dxT = dxT_p; b.dyT = dyT_p; b.strength = strength_p;
-                b.u_ij = u1; b.u_im = u1L; b.u_jm = u1_p; b.u_mm = u1L_p;
-                b.v_ij = v1; b.v_im = v1L; b.v_jm = v1_p; b.v_mm = v1L_p;
-                MM::metrics(hte_p, hteL_p, htn_p, htn_pp, A.deltaminEVP, b);
-                MM::template stress<MODE>(A.p, b, s2, str2);
+                for (int k = 0; k < 12; ++k) FST(rSout, o2, so, S_SIG + k, s[k]);
             }
-        }
-        {
-            // new stresses of T(x, r-1): into the owner's block, and -- the two columns on either edge of a strip -- into the
-            // neighbouring block that duplicates them (a second store instruction with four live lanes)
-            const bool st = act2 && own_x && r - 1 < Y1;
-            const unsigned o1 = st ? vS : OOB;
-            const unsigned o2 = (st && I.dupd != EVP_MARCH_NODUP) ? I.dupd : OOB;
-#pragma unroll
-            for (int k = 0; k < 12; ++k) FST(rSout, o1, sS - srow, S_SIG + k, s2[k]);
-#pragma unroll
-            for (int k = 0; k < 12; ++k) FST(rSout, o2, sS - srow, S_SIG + k, s2[k]);
-        }
-        const double n2_sx3 = lane_dn(str2[3]), n2_sy3 = lane_dn(str2[7]);
-        const double t2_sx1 = lane_dn(str2[1]), t2_sy2 = lane_dn(str2[6]);
+            const double n_sx3 = lane_dn(str[3]), n_sy3 = lane_dn(str[7]);
+            const double t_sx1 = lane_dn(str[1]), t_sy2 = lane_dn(str[6]);
 
-        // ---- U2: stepu(k+2) on U(x, r-2) ----
-        const bool isU2 = (m_pp & 2u) && own_x && r - 2 >= Y0;
-        UO o2;
-        o2.u = 0.0; o2.v = 0.0; o2.strintx = 0.0; o2.strinty = 0.0; o2.taubx = 0.0; o2.tauby = 0.0;
-        if (isU2)
-            momentum(us_p, u1_p, v1_p, c2_sx0, c2_sx1, str2[2], n2_sx3, c2_sy0, str2[5], c2_sy2, n2_sy3, o2);
-        {
-            const unsigned o1 = isU2 ? vS : OOB;
-            const unsigned od = (isU2 && I.dupd != EVP_MARCH_NODUP) ? I.dupd : OOB;
-            FST(rSout, o1, sS - 2u * srow, S_U, o2.u); FST(rSout, o1, sS - 2u * srow, S_V, o2.v);
-            FST(rSout, od, sS - 2u * srow, S_U, o2.u); FST(rSout, od, sS - 2u * srow, S_V, o2.v);
-            if (LAST) {
-                const unsigned q = isU2 ? vD : OOB;
-                FST(rD, q, sD - 2u * drow, 0, o2.strintx); FST(rD, q, sD - 2u * drow, 1, o2.strinty);
-                FST(rD, q, sD - 2u * drow, 2, o2.taubx); FST(rD, q, sD - 2u * drow, 3, o2.tauby);
+            // ---- U_L: stepu(k+L) on U(x, ur) ----
+            if (L < K) {
+                double nu = up[L - 1], nv = vp[L - 1];
+                const bool isU = (mk[L] & 2u) && lane >= L && lane <= 63 - L && ur >= Y0 - (K - L);
+                if (isU) {
+                    UO o;
+                    momentum(usq[L - 1], up[L - 1], vp[L - 1], cs[L - 1][0], cs[L - 1][1], str[2], n_sx3, cs[L - 1][2], str[5], cs[L - 1][3], n_sy3, o);
+                    nu = o.u; nv = o.v;
+                }
+                // hand the level's rows over: what was "above" becomes "below" for the next row
+                up[L - 1] = cu; vp[L - 1] = cv;
+                cu = nu; cv = nv;
+            } else {
+                const bool isU = (mk[L] & 2u) && own_x && ur >= Y0;
+                UO o;
+                o.u = 0.0; o.v = 0.0; o.strintx = 0.0; o.strinty = 0.0; o.taubx = 0.0; o.tauby = 0.0;
+                if (isU)
+                    momentum(usq[L - 1], up[L - 1], vp[L - 1], cs[L - 1][0], cs[L - 1][1], str[2], n_sx3, cs[L - 1][2], str[5], cs[L - 1][3], n_sy3, o);
+                const unsigned o1 = isU ? vS : OOB;
+                const unsigned od = (isU && I.dupd != EVP_MARCH_NODUP) ? I.dupd : OOB;
+                const unsigned so = sS - (unsigned)K * srow;
+                FST(rSout, o1, so, S_U, o.u); FST(rSout, o1, so, S_V, o.v);
+                FST(rSout, od, so, S_U, o.u); FST(rSout, od, so, S_V, o.v);
+                if (LAST) {
+                    const unsigned q = isU ? vD : OOB;
+                    const unsigned sd = sD - (unsigned)K * drow;
+                    FST(rD, q, sd, 0, o.strintx); FST(rD, q, sd, 1, o.strinty);
+                    FST(rD, q, sd, 2, o.taubx); FST(rD, q, sd, 3, o.tauby);
+                }
+                up[L - 1] = cu; vp[L - 1] = cv;
             }
+            cs[L - 1][0] = str[0]; cs[L - 1][1] = t_sx1; cs[L - 1][2] = str[4]; cs[L - 1][3] = t_sy2;
         }
-
-        // ---- hand the row over ----
-        u_p = C.u; v_p = C.v;
-        htn_pp = htn_p; htn_p = C.htn; hte_p = C.hte;
-        dxT_p = C.dxT; dyT_p = C.dyT; strength_p = C.strength;
-        m_pp = m_p; m_p = m;
-        c1_sx0 = str1[0]; c1_sx1 = t1_sx1; c1_sy0 = str1[4]; c1_sy2 = t1_sy2;
-        u1_p = u1; v1_p = v1;
-        c2_sx0 = str2[0]; c2_sx1 = t2_sx1; c2_sy0 = str2[4]; c2_sy2 = t2_sy2;
-        us_p = us;
     }
 }
 
 // ---------------------------------------------------------------------
+// Measured and removed (round 6, profiles/r06_march_k_sweep.txt): the same pass as a pipeline ACROSS the four waves of a workgroup
+// (wave w = level w + 1 of one work item, rows handed on through 61 KB of LDS with one workgroup barrier per row, two workgroups per
+// CU).  Bit-identical, 192 VGPRs, no register pipelines -- and 348 us per subcycle against 284 for the kernel above on the same box:
+// 760-820 instructions per level and row against 723, and the lock step of four waves costs more than two waves per SIMD win.
+// ---------------------------------------------------------------------
+// ---------------------------------------------------------------------
 // CICE block layout <-> strip-major layout (evp_host_march.cpp owns the geometry)
 // ---------------------------------------------------------------------
-// cell (x, y) of the rectangle incl. two halo layers -> (block index of its row/strip, lane) of the strip that OWNS the
+// cell (x, y) of the rectangle incl. the P halo layers -> (block index of its row/strip, lane) of the strip that OWNS the
 // column (or, for halo columns of a closed side, the edge strip that holds it)
 __device__ __forceinline__ void cell_to_packed(const EvpMarchGeo &G, int x, int y, long &blk, int &lane)
 {
     const int s = min(max(x, 0) / G.own, G.nstrips - 1);
-    lane = x - s * G.own + 2;
+    lane = x - s * G.own + PADW;
     blk = (long)(y + EVP_MARCH_PAD) * G.nstrips + s;
 }
 
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(256) void march_gather(EvpMarchGeo G, EvpMarchTab T
 {
     const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6), row = blockIdx.y;
     if (s >= G.nstrips) return;
-    const int x = s * G.own - 2 + lane, y = row - EVP_MARCH_PAD;
+    const int x = s * G.own - PADW + lane, y = row - EVP_MARCH_PAD;
     bool is_cell;
     const int src = rect_to_block(G, x, y, is_cell);
     const size_t blk = (size_t)row * G.nstrips + s;
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(256) void march_gather(EvpMarchGeo G, EvpMarchTab T
     }
     // the byte mask stays row-major; one lane per column writes it (the owner, or the edge strips for the halo columns)
     if (mask_rect) {
-        const bool mine = (lane >= 2 && lane < 2 + G.own) || (s == 0 && lane < 2) || (s == G.nstrips - 1 && lane >= 2 + G.own);
+        const bool mine = (lane >= PADW && lane < PADW + G.own) || (s == 0 && lane < PADW) || (s == G.nstrips - 1 && lane >= PADW + G.own);
         if (mine && x + EVP_MARCH_PAD < G.ldx && x >= -EVP_MARCH_PAD)
             mask_rect[(size_t)row * G.ldx + EVP_MARCH_PAD + x] = (src >= 0 && is_cell) ? (mask_blk[src] & 3u) : 0;
     }
@@ -616,16 +626,13 @@ __global__ __launch_bounds__(256) void march_unpack_mask(uint8_t *__restrict__ m
 
 }  // namespace
 
-void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
+template <int K>
+static void launch_march_k(const EvpMarch &A, bool strict, int mode, bool lean, dim3 grid, dim3 block, hipStream_t st)
 {
-    const unsigned nwg = (unsigned)((A.nitems + 3) / 4);
-    const dim3 grid((A.order & 1) ? ((nwg + 7) / 8) * 8 : nwg), block(256);
-    const bool lean = mode == 3 && (A.flags & EVP_F_WATER_IS_OCN) && (A.flags & EVP_F_TBU_ZERO) &&
-                      !(evp_env_test("CICE_EVP_HIP_MARCH_LEAN") && !std::atoi(evp_env_test("CICE_EVP_HIP_MARCH_LEAN")));
 #define EVP_MARCH_LAUNCH(S, M, L)                                                                    \
     do {                                                                                             \
-        if (A.last) hipLaunchKernelGGL((evp_march2p<S, M, L, true>), grid, block, 0, st, A);         \
-        else hipLaunchKernelGGL((evp_march2p<S, M, L, false>), grid, block, 0, st, A);               \
+        if (A.last) hipLaunchKernelGGL((evp_marchk<K, S, M, L, true>), grid, block, 0, st, A);       \
+        else hipLaunchKernelGGL((evp_marchk<K, S, M, L, false>), grid, block, 0, st, A);             \
     } while (0)
     if (strict) {
         if (lean) EVP_MARCH_LAUNCH(true, 3, true);
@@ -641,6 +648,19 @@ void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
         else EVP_MARCH_LAUNCH(false, -1, false);
     }
 #undef EVP_MARCH_LAUNCH
+}
+
+void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
+{
+    const unsigned nwg = (unsigned)((A.nitems + 3) / 4);
+    const dim3 grid((A.order & 1) ? ((nwg + 7) / 8) * 8 : nwg), block(256);
+    const bool lean = mode == 3 && (A.flags & EVP_F_WATER_IS_OCN) && (A.flags & EVP_F_TBU_ZERO) &&
+                      !(evp_env_test("CICE_EVP_HIP_MARCH_LEAN") && !std::atoi(evp_env_test("CICE_EVP_HIP_MARCH_LEAN")));
+    switch (A.kpass) {
+    case 2: launch_march_k<2>(A, strict, mode, lean, grid, block, st); break;
+    case 3: launch_march_k<3>(A, strict, mode, lean, grid, block, st); break;
+    default: launch_march_k<4>(A, strict, mode, lean, grid, block, st); break;
+    }
 }
 
 void evp_launch_march_gather(const EvpMarchGeo &G, const EvpMarchTab &T, const uint8_t *mask_blk, uint8_t *mask_rect,

@@ -712,6 +712,74 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
                 }
 }
 
+int cgres_dependencies(const cice_evp_hip_dims &d, bool tripole, const std::vector<int32_t> &tiles, const std::vector<int32_t> &tab,
+                       std::vector<uint8_t> *pub, int *n_edges, int *n_oneway)
+{
+    constexpr int RX = 16, RY = 16, LW = RX + 1, NPOS = LW * (RY + 1);
+    const int nt = (int)(tiles.size() / 4);
+    const size_t ncell = (size_t)d.nblocks * d.nx_block * d.ny_block;
+    auto jmax_of = [&](int w) { return tripole ? (int)(tiles[4 * w + 3] >> 16) : (int)d.jhi[tiles[4 * w]]; };
+    auto foldwin = [&](int w) { return tripole && (tiles[4 * w + 3] & 1); };
+    auto mine = [&](int w, int ex, int ey) {
+        const int b = tiles[4 * w], i0 = tiles[4 * w + 1], j0 = tiles[4 * w + 2];
+        return ex >= 2 && ex <= RX - 2 && ey >= 2 && ey <= RY - 2 && i0 - 2 + ex <= d.ihi[b] && j0 - 2 + ey <= jmax_of(w);
+    };
+    std::vector<int32_t> owner(ncell, -1);
+    for (int w = 0; w < nt; ++w)
+        for (int e = 0; e < NPOS; ++e)
+            if (mine(w, e % LW, e / LW)) {
+                const int sc = tab[(size_t)w * NPOS + e];
+                if (sc >= 0 && (size_t)sc < ncell) owner[(size_t)sc] = w;
+            }
+    if (pub) pub->assign(ncell, 0);
+    std::vector<std::pair<int, int>> edges;
+    for (int w = 0; w < nt; ++w) {
+        const int b = tiles[4 * w], i0 = tiles[4 * w + 1], j0 = tiles[4 * w + 2];
+        const int last_ex = std::min(RX - 2, 2 + d.ihi[b] - i0), last_ey = std::min(RY - 2, 2 + jmax_of(w) - j0);
+        for (int e = 0; e < NPOS - 1; ++e) {              // ((RX, RY), the one entry no level reads, is left out)
+            const int ex = e % LW, ey = e / LW;
+            const int sc = tab[(size_t)w * NPOS + e];
+            if (mine(w, ex, ey) || sc < 0 || !cgres_in_reach(ex, ey, last_ex, last_ey, foldwin(w))) continue;
+            if (pub) (*pub)[(size_t)sc] = 1;
+            const int p = owner[(size_t)sc];
+            if (p >= 0 && p != w) edges.emplace_back(w, p);
+        }
+    }
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    if (n_edges) *n_edges = (int)edges.size();
+    // reads[w]: the windows w reads (edges is sorted by reader)
+    std::vector<int> first((size_t)nt + 1, 0);
+    for (const auto &e : edges) ++first[(size_t)e.first + 1];
+    for (int w = 0; w < nt; ++w) first[(size_t)w + 1] += first[(size_t)w];
+    int oneway = 0, unsafe = 0;
+    std::vector<int> seen((size_t)nt, -1), frontier, next;
+    int stamp = 0;
+    for (const auto &e : edges) {
+        if (std::binary_search(edges.begin(), edges.end(), std::make_pair(e.second, e.first))) continue;
+        ++oneway;
+        // w = e.first reads p = e.second and p does not read w: is there a chain p reads ... reads w of at most CGRES_SLOTS - 1?
+        const int w = e.first, p = e.second;
+        ++stamp;
+        frontier.assign(1, p);
+        seen[(size_t)p] = stamp;
+        bool found = false;
+        for (int len = 1; len <= CGRES_SLOTS - 1 && !found && !frontier.empty(); ++len) {
+            next.clear();
+            for (int x : frontier)
+                for (int k = first[(size_t)x]; k < first[(size_t)x + 1] && !found; ++k) {
+                    const int y = edges[(size_t)k].second;
+                    if (y == w) found = true;
+                    else if (seen[(size_t)y] != stamp) { seen[(size_t)y] = stamp; next.push_back(y); }
+                }
+            frontier.swap(next);
+        }
+        if (!found) ++unsafe;
+    }
+    if (n_oneway) *n_oneway = oneway;
+    return unsafe;
+}
+
 // Windows of the on-chip resident C-grid kernel on a tripole (u-fold) grid (evp_cgrid_res.hip, template variant FOLD).  17 x 17
 // positions per window, 13 x 13 owned as in build_window_table(..., extra = 1), except:
 //  * the top window row of a block that touches the fold owns the block's last (up to) 11 rows, so that the fold row NY sits

@@ -149,6 +149,32 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &plan, int ox
 bool build_fold_window_table(const cice_evp_hip_dims &d, const HaloPlan &plan, std::vector<int32_t> &tiles, std::vector<int32_t> &tiles2,
                              std::vector<int32_t> &tab, std::string &why);
 
+// Which positions of a resident window's 17 x 17 velocity tile are hand-offs (evp_cgrid_res.hip polls them, their owner publishes
+// them): not owned, with a producing cell, and within reach of the window's owned cells -- at most CGRES_REACH positions beyond
+// the last owned column and row (an owned cell's divergence reads level U beside it, that level T one further, that the velocities
+// one further again: two; three is the kernel's own margin).  Everything further out is worked out from whatever the tile was filled
+// with and read by nobody.  Without the bound a narrow window at a block's edge (one or two owned columns) polled up to 14 columns
+// into its neighbour and beyond -- cells of a window that does not poll IT: that window could run two subcycles ahead and overwrite
+// the record slot the narrow one was still waiting for (round-5 advice).  Fold windows keep every position (their mirrored mini-tile
+// runs against the column index).
+constexpr int CGRES_REACH = 3;
+constexpr int CGRES_SLOTS = 4;             // record slots per cell, by subcycle modulo (evp_device.h: EVP_CGRES_SLOTS)
+inline bool cgres_in_reach(int ex, int ey, int last_ex, int last_ey, bool foldwin)
+{
+    return foldwin || (ex <= last_ex + CGRES_REACH && ey <= last_ey + CGRES_REACH);
+}
+// The hand-off graph of the resident windows (tiles / tab as build_window_table(..., 16, 16, ., extra = 1) or
+// build_fold_window_table made them): window w READS window p when it polls a cell p owns.  A window cannot start subcycle j + 1
+// before every window it reads has finished subcycle j, so a window p is never more than len subcycles ahead of w, len = the
+// shortest chain p reads ... reads w.  The exact-tag record protocol with CGRES_SLOTS slots per cell is safe for the hand-off
+// w reads p iff that chain is at most CGRES_SLOTS - 1 long (p's record of subcycle j is overwritten by that of j + CGRES_SLOTS):
+// 1 when the hand-off is mutual -- nearly all are --, 2 or 3 for the one-way ones of narrow windows and of fold windows whose
+// mirror images do not line up.  pub (may be NULL): [ncell] 1 = the cell is polled by some window, i.e. its owner publishes it.
+// Returns the number of UNSAFE hand-offs (no chain back within CGRES_SLOTS - 1); *n_edges, *n_oneway (may be NULL): hand-offs in
+// all, and those that are not mutual.
+int cgres_dependencies(const cice_evp_hip_dims &d, bool tripole, const std::vector<int32_t> &tiles, const std::vector<int32_t> &tab,
+                       std::vector<uint8_t> *pub, int *n_edges, int *n_oneway);
+
 // C grid on a tripole (u-fold) grid: the fold step of one field location (0 centre, 1 NE corner, 2 E face, 3 N face),
 // by the meaning of the cells (ice_boundary.F90:1626-1722): one entry for every cell of every local block -- interior
 // or ghost -- in the top physical row NY (locations with points ON the fold: NE corner, N face) or in the ghost row

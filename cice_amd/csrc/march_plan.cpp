@@ -8,11 +8,13 @@ namespace {
 
 struct Blk { int gi0, gj0, gnx, gny, owner; };
 
-// column x of a rank's rectangle (may lie up to two cells beyond it) -> (strip, lane) that holds it
+constexpr int PW = MARCH_PLAN_PAD;        // width of the overlap / the ring
+
+// column x of a rank's rectangle (may lie up to P cells beyond it) -> (strip, lane) that holds it
 inline void column_home(int x, int own, int nstrips, int &s, int &l)
 {
     s = std::min(std::max(x, 0) / own, nstrips - 1);
-    l = x - s * own + 2;
+    l = x - s * own + PW;
 }
 
 // duplicates of the owner lanes of a rank with `nxr` columns in strips of `own`: -1, or (strip << 8) | lane.
@@ -22,14 +24,14 @@ bool dup_table(int nxr, int own, bool wrapx, std::vector<int32_t> &dup)
     const int ns = (nxr + own - 1) / own;
     dup.assign((size_t)ns * 64, -1);
     for (int sb = 0; sb < ns; ++sb) {
-        const int cnt = std::min(own, nxr - sb * own);       // columns strip sb owns: lanes 2 .. cnt+1
+        const int cnt = std::min(own, nxr - sb * own);       // columns strip sb owns: lanes P .. P+cnt-1
         for (int l = 0; l < 64; ++l) {
-            if (l >= 2 && l < 2 + cnt) continue;             // an owner
-            if (!(l < 2 || l < 4 + cnt)) continue;           // beyond the two overlap lanes: nothing reads it
-            int x = sb * own - 2 + l;
+            if (l >= PW && l < PW + cnt) continue;             // an owner
+            if (!(l < PW || l < 2 * PW + cnt)) continue;       // beyond the P overlap lanes: nothing reads it
+            int x = sb * own - PW + l;
             if (wrapx) { if (x < 0) x += nxr; else if (x >= nxr) x -= nxr; }
             if (x < 0 || x >= nxr) continue;                 // a halo column beyond the rectangle: filled by the exchange
-            const int so = x / own, lo = 2 + x % own;        // its owner
+            const int so = x / own, lo = PW + x % own;        // its owner
             int32_t &slot = dup[(size_t)so * 64 + lo];
             if (slot != -1) return false;
             slot = (sb << 8) | l;
@@ -72,7 +74,7 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
         x0[b.owner] = std::min(x0[b.owner], b.gi0); y0[b.owner] = std::min(y0[b.owner], b.gj0);
         x1[b.owner] = std::max(x1[b.owner], b.gi0 + b.gnx - 1); y1[b.owner] = std::max(y1[b.owner], b.gj0 + b.gny - 1);
     }
-    own_max = std::min(60, std::max(4, own_max));
+    own_max = std::min(64 - 2 * PW, std::max(4, own_max));
     for (int r = 0; r < nranks; ++r) {
         if (area[r] == 0) continue;
         MarchRect &R = P.all[r];
@@ -99,7 +101,7 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
         H.E.nxr = R.nxr + H.w + H.e; H.E.nyr = R.nyr + H.s + H.n;
         return H;
     };
-    // A neighbour between a rank and a CLOSED boundary must be wide enough for the rim and its two-cell ring: otherwise the
+    // A neighbour between a rank and a CLOSED boundary must be wide enough for the rim and its P-cell ring: otherwise the
     // held rectangle reaches past the global boundary, those positions stay zero here while the owner advances its cells
     // from the caller's boundary ghost values (rect_to_block) -- different operands for the same cell.  Such a layout is
     // refused (the one-subcycle kernels run it); every rank reaches the same verdict from the same table.
@@ -107,9 +109,9 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
         if (!P.all[r].ok) continue;
         const MarchRect &R = P.all[r];
         const int dw = R.gx0, de = NX - (R.gx0 + R.nxr), ds = R.gy0, dn = NY - (R.gy0 + R.nyr);
-        const bool thin_x = !ew_cyclic && ((dw > 0 && dw < ext + 2) || (de > 0 && de < ext + 2));
-        const bool thin_y = (ds > 0 && ds < ext + 2) || (dn > 0 && dn < ext + 2);
-        if (ext > 0 && (thin_x || thin_y)) {
+        const bool thin_x = !ew_cyclic && ((dw > 0 && dw < ext + PW) || (de > 0 && de < ext + PW));
+        const bool thin_y = (ds > 0 && ds < ext + PW) || (dn > 0 && dn < ext + PW);
+        if (thin_x || thin_y) {
             P.error = "a rank lies closer to a closed boundary than its redundant rim + ring is wide";
             return false;
         }
@@ -120,13 +122,13 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
     P.ext_w = HM.w; P.ext_e = HM.e; P.ext_s = HM.s; P.ext_n = HM.n;
     P.wrapx = HM.wrap;
     // strips: the widest `own` for which every column of this rank has at most one duplicate -- and the last strip
-    // holds at least two columns: with a single one, the first column BEYOND the rectangle (which the exchange fills)
-    // would sit in two strips, as overlap lane of the last but one and of the last, and a received cell has one home
+    // holds at least P columns: with fewer, the first columns BEYOND the rectangle (which the exchange fills)
+    // would sit in two strips, as overlap lanes of the last but one and of the last, and a received cell has one home
     // (column_home) plus the duplicate of a column inside the rectangle only
     bool found = false;
     for (int own = own_max; own >= 4 && !found; --own) {
         const int ns = (P.me.nxr + own - 1) / own;
-        if (ns > 1 && P.me.nxr - (ns - 1) * own < 2) continue;
+        if (ns > 1 && P.me.nxr - (ns - 1) * own < PW) continue;
         if (dup_table(P.me.nxr, own, P.wrapx, P.dup)) { P.me.own = own; found = true; }
     }
     if (!found) { P.error = "no strip width gives every column a single duplicate"; return false; }
@@ -145,8 +147,8 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
         if (!P.all[D].ok) continue;
         const Held HD = held(D);
         const MarchRect &E = HD.E;                                          // what D holds; its own cells start at (HD.w, HD.s)
-        for (int y = -2; y < E.nyr + 2; ++y)
-            for (int x = -2; x < E.nxr + 2; ++x) {
+        for (int y = -PW; y < E.nyr + PW; ++y)
+            for (int x = -PW; x < E.nxr + PW; ++x) {
                 const bool own_cell = x >= HD.w && x < E.nxr - HD.e && y >= HD.s && y < E.nyr - HD.n;
                 if (own_cell) continue;
                 int gx = E.gx0 + x;
@@ -179,7 +181,7 @@ bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside,
                     MarchPeer &p = peers[D];
                     p.rank = D;
                     const int xs = gx - P.owned.gx0 + HM.w, ys = gy - P.owned.gy0 + HM.s;   // the source cell in what I hold
-                    const int s = xs / M.own, l = 2 + xs % M.own;
+                    const int s = xs / M.own, l = PW + xs % M.own;
                     p.send_pos.push_back((int32_t)(((long)(ys + MARCH_PLAN_PAD) * M.nstrips + s) * 64 + l));
                     p.send_col.push_back(xs);
                 }

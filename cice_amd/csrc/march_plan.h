@@ -1,15 +1,15 @@
-// Host-only geometry and exchange plan of the two-subcycles-per-pass path (evp_march.hip) -- pure C++, no HIP, so
+// Host-only geometry and exchange plan of the several-subcycles-per-pass path (evp_march.hip) -- pure C++, no HIP, so
 // that it can be built and tested on a machine without a GPU (tests/test_multirank_cpu.py).
 //
 // Every rank's sub-domain must be ONE rectangle of the global index space (CICE's cartesian distributions:
 // ice_distribution.F90 create_distrb_cart; any number of blocks per rank as long as they tile a rectangle).  The rank
 // holds it in the strip-major layout of evp_host_march.cpp: strips of `own` columns, per (row, strip) a block of 64
-// lanes -- lanes 2 .. own+1 own their columns, lanes 0, 1 and own+2, own+3 duplicate the neighbouring strips' edge
-// columns (or, for the first / last strip, hold the two halo columns beyond the rectangle).
+// lanes -- with P = MARCH_PLAN_PAD (4): lanes P .. P+own-1 own their columns, lanes 0 .. P-1 and P+own .. 2P+own-1 duplicate
+// the neighbouring strips' edge columns (or, for the first / last strip, hold the P halo columns beyond the rectangle).
 //
-// A pass of the marching kernel needs the state two cells beyond the rectangle on every side.  What replaces the
-// reference's ice_HaloUpdate there (ice_boundary.F90:1066-1760; one-cell ring, every subcycle) is one exchange of a
-// two-cell ring every SECOND subcycle: like build_halo_plan, the lists are derived from the meaning of a halo cell --
+// A pass of the marching kernel that advances the state by k <= P subcycles needs it k cells beyond the rectangle on
+// every side.  What replaces the reference's ice_HaloUpdate there (ice_boundary.F90:1066-1760; one-cell ring, every
+// subcycle) is one exchange of a P-cell ring every few passes: like build_halo_plan, the lists are derived from the meaning of a halo cell --
 // it images the cell with the same global index (cyclic wrap) -- by every rank for every rank, in one canonical
 // order, so that sender and receiver agree without any set-up communication.
 #pragma once
@@ -19,7 +19,7 @@
 
 #include "../../include/cice_evp_hip.h"
 
-#define MARCH_PLAN_PAD 2       // == EVP_MARCH_PAD
+#define MARCH_PLAN_PAD 4       // == EVP_MARCH_PAD (evp_device.h; evp_host_march.cpp asserts it)
 
 struct MarchRect {
     int gx0 = 0, gy0 = 0;      // global index (0-based) of the first owned cell
@@ -51,9 +51,9 @@ struct MarchPlan {
     std::string error;                           // non-empty: this domain cannot use the path (the same verdict on every rank)
 };
 
-// own_max: widest strip (<= 60); wrap_inside: let a rank that spans a cyclic E-W dimension wrap internally (false: the
-// seam is exchanged like any other rank boundary -- with the rank itself; a test hook).
+// own_max: widest strip (<= 64 - 2P = 56); wrap_inside: let a rank that spans a cyclic E-W dimension wrap internally
+// (false: the seam is exchanged like any other rank boundary -- with the rank itself; a test hook).
 // ext (even, >= 0): every rank also holds -- and advances redundantly -- `ext` cells beyond its own on every side that
-// has a neighbour.  One exchange then brings the ring of ext + 2 cells around the rank's own cells up to date, and
-// ext/2 + 1 passes can follow before the next one: pass j leaves the state valid on own cells + ext - 2(j-1).
+// has a neighbour.  One exchange then brings the ring of ext + P cells around the rank's own cells up to date, and
+// passes advancing ext + P subcycles in all can follow before the next one: every subcycle costs one cell of validity.
 bool build_march_plan(const cice_evp_hip_dims &d, int own_max, bool wrap_inside, int ext, MarchPlan &P);

@@ -53,7 +53,7 @@ EXPORTS = [
 # libcice_evp_hip_testing.so only (include/cice_evp_hip_testing.h): plan introspection of the CPU tests, read-outs of the tools,
 # the test transport
 TEST_EXPORTS = [
-    "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_cgrid_window_plan_ext", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
+    "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_cgrid_window_plan_ext", "cice_evp_hip_cgrid_window_deps", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
     "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_debug_cgrid_prof", "cice_evp_hip_debug_cgres_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
     "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan", "cice_evp_hip_stress_plan",
     "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags", "cice_evp_hip_fold_images_plan",
@@ -63,7 +63,7 @@ TEST_EXPORTS = [
 TEST_ENV = [
     "CICE_EVP_HIP_RES_REMOTE", "CICE_EVP_HIP_RES_REMOTE_BREAK", "CICE_EVP_HIP_RES_ORDER", "CICE_EVP_HIP_RES_PROF", "CICE_EVP_HIP_RES_DEBUG",
     "CICE_EVP_HIP_MARCH_OWN", "CICE_EVP_HIP_MARCH_SELFX", "CICE_EVP_HIP_MARCH_SEG", "CICE_EVP_HIP_MARCH_ORDER",
-    "CICE_EVP_HIP_MARCH_LEAN", "CICE_EVP_HIP_CGRID_SPLIT", "CICE_EVP_HIP_CGRID_XCD", "CICE_EVP_HIP_CGRID_ONE_XCD", "CICE_EVP_HIP_CGRID_ONE_SHAPE",
+    "CICE_EVP_HIP_MARCH_LEAN", "CICE_EVP_HIP_MARCH_K", "CICE_EVP_HIP_CGRID_SPLIT", "CICE_EVP_HIP_CGRID_XCD", "CICE_EVP_HIP_CGRID_ONE_XCD", "CICE_EVP_HIP_CGRID_ONE_SHAPE",
     "CICE_EVP_HIP_CGRID_ONE_STRIP", "CICE_EVP_HIP_CGRID_FAST", "CICE_EVP_HIP_HALO_DEBUG", "CICE_EVP_HIP_SEAM_FIN", "CICE_EVP_HIP_OVERLAP",
     "CICE_EVP_HIP_HALO_RIDE", "CICE_EVP_HIP_GATHER", "CICE_EVP_HIP_SIMPLE", "CICE_EVP_HIP_SELF_EXCHANGE", "CICE_EVP_HIP_FLAGS", "CICE_EVP_HIP_LEAN",
     "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY", "CICE_EVP_HIP_MARCH_BANDSEG", "CICE_EVP_HIP_CGRID_PROF",
@@ -236,6 +236,14 @@ def cgrid_window_plan(dims: "Dims", ox: int, oy: int, extra: int = 0) -> dict:
     tab = np.zeros((n.value, 17, 17) if extra == 2 else (n.value, oy + extra, ox + extra), dtype=np.int32)
     _check(lib, lib.cice_evp_hip_cgrid_window_plan_ext(*a, _ip(tiles), _ip(tab)), "(cgrid_window_plan)")
     return dict(tiles=tiles, tab=tab)
+
+
+def cgrid_window_deps(dims: "Dims") -> dict:
+    """Host only: the hand-off graph of the on-chip resident C-grid kernel's windows (see the testing header)."""
+    lib = load_library(testing=True)
+    nw, ne, n1, nu = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _check(lib, lib.cice_evp_hip_cgrid_window_deps(C.byref(dims), C.byref(nw), C.byref(ne), C.byref(n1), C.byref(nu)), "(cgrid_window_deps)")
+    return dict(windows=nw.value, edges=ne.value, oneway=n1.value, unsafe=nu.value)
 
 
 def stream_probe(ncells: int) -> float:
@@ -568,11 +576,11 @@ class EvpHip:
 
     def march_info(self) -> dict:
         """The two-subcycles-per-pass path (evp_march.hip): did it run, how is the domain cut."""
-        v = np.zeros(8, dtype=np.int32)
+        v = np.zeros(10, dtype=np.int32)
         v[7] = -1
-        self.lib.cice_evp_hip_march_info(_ip(v), 8)
+        self.lib.cice_evp_hip_march_info(_ip(v), 10)
         return dict(mode=int(v[0]), passes=int(v[1]), declined=int(v[2]), strips=int(v[3]), segments=int(v[4]),
-                    seglen=int(v[5]), last_call=bool(v[6]),
+                    seglen=int(v[5]), last_call=bool(v[6]), kpass=int(v[8]), subcycles=int(v[9]),
                     ring={-1: "not set up", 0: "rccl", 1: "direct stores (HIP IPC)", 2: "direct, on trial"}.get(int(v[7]), "?"))
 
     def halo_mask(self, halomask):

@@ -410,7 +410,7 @@ contains
     endif
 
     call get_environment_variable('CICE_EVP_HIP_STRESS_RESIDENT', envval, envlen, envstat)
-    if (.not. empty_rank) &
+    ! (every rank, also one without blocks: on tripoleT grids the verdict is a reduction over all tasks of the distribution)
     call settle_stress_residency(stress_resident_requested .or. (envstat == 0 .and. envlen > 0 .and. envval(1:1) == '1'), &
          .false.)
 
@@ -1074,7 +1074,10 @@ contains
     on_tripole = trim(ns_boundary_type) == 'tripole'
     stress_resident = want
     if (trim(ns_boundary_type) == 'tripoleT') then
-       avail = cice_evp_hip_stress_halo_available()
+       ! global_minval is an MPI_ALLREDUCE over every task of the distribution (ice_global_reductions enters it for all
+       ! my_task < numProcs): a task without blocks takes part with the neutral value, or the others would wait for it for ever
+       avail = 1
+       if (.not. empty_rank) avail = cice_evp_hip_stress_halo_available()
        avail = global_minval(avail, distrb_info)
        if (avail == 1) then
           on_tripole = .true.
@@ -1085,6 +1088,7 @@ contains
           stress_resident = .false.
        endif
     endif
+    if (.not. empty_rank) &
     call check(cice_evp_hip_set_option(1_c_int32_t, merge(1_c_int32_t, 0_c_int32_t, stress_resident)), &
          subname, __FILE__, __LINE__)
   end subroutine settle_stress_residency
@@ -1113,9 +1117,9 @@ contains
     logical, intent(in) :: flag
     character(len=*), parameter :: subname = '(dyn_evp_hip_keep_stresses_resident)'
     stress_resident_requested = flag
-    if (.not. initialised .or. empty_rank) return
-    if (.not. flag .and. stress_resident) call dyn_evp_hip_fetch_stresses
-    call settle_stress_residency(flag, .true.)
+    if (.not. initialised) return
+    if (.not. flag .and. stress_resident) call dyn_evp_hip_fetch_stresses      ! (returns at once on a task without blocks)
+    call settle_stress_residency(flag, .true.)                                  ! collective on tripoleT grids: every task
   end subroutine dyn_evp_hip_keep_stresses_resident
 
 ! The host changed ice_flux's stress arrays itself (restart read): the next evp() uploads them again.

@@ -385,12 +385,13 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
 /* Measurement aid (no state needed): bytes/s of a plain streaming kernel with the array shape of one B-grid subcycle
  * (30 fp64 arrays in, 16 out, `ncells` elements each, every element touched once) -- what HBM gives a kernel of this
  * shape on this device; the yardstick next to the 8 TB/s pin rate in bench.py's roofline block.                   */
-/* The two-subcycles-per-pass path for per-rank domains beyond the chip (evp_march.hip): out[0] mode (-1 undecided,
+/* The several-subcycles-per-pass ("marching") path for per-rank domains beyond the chip (evp_march.hip): out[0] mode (-1 undecided,
  * 0 off, 1 on), [1] passes run since init, [2] calls it handed back to the one-subcycle kernels (the uploaded ghost
  * values were not images of one global state), [3] strips, [4] segments, [5] rows per segment, [6] 1 = the last
  * cice_evp_hip_subcycle ran through it, [7] (n >= 8) how its ring travels between ranks: -1 not set up, 0 RCCL send / recv,
  * 1 stores into the neighbours' HIP-IPC-mapped inboxes (opt-in: CICE_EVP_HIP_MARCH_DIRECT=1 on every rank, inside one
- * node; in use once a trial exchange has delivered the same bits as RCCL on every rank), 2 on trial.
+ * node; in use once a trial exchange has delivered the same bits as RCCL on every rank), 2 on trial; [8] (n >= 10) subcycles
+ * a full pass advances the state by (4), [9] subcycles advanced by passes since init.
  * CICE_EVP_HIP_MARCH=0/1 forces the path off / on (default: from 450k cells per rank).   */
 int cice_evp_hip_march_info(int32_t *out, int32_t n);
 /* One line of text on what the last cice_evp_hip_subcycle ran (kernel, halo transport, the two-subcycle path and why it is

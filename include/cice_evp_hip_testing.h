@@ -37,6 +37,13 @@ int cice_evp_hip_cgrid_window_plan(const cice_evp_hip_dims *dims, int32_t ox, in
  * build_fold_window_table); -5 when a mirrored cell is not on this rank.                                                          */
 int cice_evp_hip_cgrid_window_plan_ext(const cice_evp_hip_dims *dims, int32_t ox, int32_t oy, int32_t extra, int32_t *ntiles,
                                        int32_t *tiles4, int32_t *tab);
+/* Host only: the hand-off graph of the on-chip resident C-grid kernel's windows (closed / cyclic grids: the table of extra = 1;
+ * tripole: of extra = 2).  A window depends on another when it polls a cell that one owns -- every non-owned position with a
+ * producer within 3 positions of its last owned column / row (halo_plan.h: cgres_in_reach; fold windows: every position).  n_edges:
+ * dependencies, n_oneway: those that are not mutual, n_unsafe: those of them with no chain of at most 3 dependencies back (the
+ * window read could then be four subcycles ahead of its reader and overwrite one of the kernel's four record slots per cell that
+ * the reader still waits for): the library does not use the kernel unless n_unsafe == 0.                                          */
+int cice_evp_hip_cgrid_window_deps(const cice_evp_hip_dims *dims, int32_t *n_windows, int32_t *n_edges, int32_t *n_oneway, int32_t *n_unsafe);
 /* Test hook: route the exchanges and the rank agreements of the two-subcycle path through HOST buffers and the caller's
  * callbacks instead of RCCL (which refuses two ranks on one device), so that its several-rank form can be run as
  * processes sharing one GPU (tools/mailbox_2proc.py --march: torch.distributed gloo underneath).  xchg: per peer q

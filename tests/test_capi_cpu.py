@@ -440,3 +440,77 @@ def test_tracked_pmc_summary_feeds_the_bench_line():
     # per subcycle on 3600 x 2400)
     for key in ("cgx1res", "cgs01one"):
         assert k[key]["per_subcycle"]["hbm_bytes"], key
+
+
+@pytest.mark.parametrize("nx,ny,bx,by,ew,ns", [
+    (54, 26, 27, 26, "cyclic", "closed"), (40, 27, 40, 27, "cyclic", "closed"),      # the round-5 advisor's two: 8 and 7 one-way before
+    (320, 384, 320, 384, "cyclic", "closed"), (100, 116, 50, 58, "cyclic", "closed"), (72, 40, 36, 20, "cyclic", "tripole"),
+    (320, 384, 320, 384, "cyclic", "tripole"), (320, 384, 80, 96, "cyclic", "tripole")])
+def test_cgrid_resident_window_handoffs_are_safe(nx, ny, bx, by, ew, ns):
+    """Round-5 advice: the resident C-grid kernel's exact-tag record protocol with two slots per cell assumed a window is never more
+    than one subcycle ahead of a window that reads it -- true only if every hand-off is mutual.  A narrow window at a block's edge
+    (one or two owned columns) used to poll every non-owned position of its 17 x 17 tile, far into windows that do not poll it back;
+    fold windows whose mirror images do not line up read one another one-way too.  Now (a) the ring is bounded to what the owned
+    cells can reach (halo_plan.h: cgres_in_reach), (b) there are FOUR slots per cell, and (c) the library works the graph out from
+    the kernel's own rule and uses the kernel only if every window that is read is held back by its reader through a chain of at
+    most three hand-offs (cice_evp_hip_cgrid_window_deps: unsafe == 0)."""
+    from cice_amd import decomp
+    dc = decomp.Decomp(nx, ny, bx, by, ew, ns, 1)
+    d, keep = evp.make_dims(dc, 0)
+    g = evp.cgrid_window_deps(d)
+    assert g["windows"] > 0 and g["edges"] > 0 and g["unsafe"] == 0, g
+    if ns != "tripole":
+        assert g["oneway"] == 0, g
+
+
+def test_cgrid_resident_window_handoff_graph_against_a_python_restatement():
+    """The library's hand-off graph against a restatement of the rule in Python from the window table itself, over random cuts --
+    including the few that keep one-way hand-offs: counted alike, and every one of them with a chain back of at most three."""
+    from cice_amd import decomp
+    rng = np.random.default_rng(7)
+    seen_oneway = 0
+    for _ in range(40):
+        nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        bx, by = int(rng.integers(3, 45)), int(rng.integers(3, 45))
+        nx, ny = bx * nbx - int(rng.integers(0, min(bx, 3))), by * nby - int(rng.integers(0, min(by, 3)))
+        ew, ns = str(rng.choice(["cyclic", "closed"])), str(rng.choice(["closed", "cyclic"]))
+        dc = decomp.Decomp(nx, ny, bx, by, ew, ns, 1)
+        d, keep = evp.make_dims(dc, 0)
+        ob = dc.local_blocks(0)
+        P = evp.cgrid_window_plan(d, 16, 16, 1)
+        owner = {}
+        for w, ((k, i0, j0, _), tab) in enumerate(zip(P["tiles"], P["tab"])):
+            b = ob[k]
+            for ty in range(2, 15):
+                for tx in range(2, 15):
+                    if i0 - 2 + tx <= b.ihi and j0 - 2 + ty <= b.jhi:
+                        owner[int(tab[ty, tx])] = w
+        reads = {w: set() for w in range(len(P["tiles"]))}
+        for w, ((k, i0, j0, _), tab) in enumerate(zip(P["tiles"], P["tab"])):
+            b = ob[k]
+            lx, ly = min(14, 2 + b.ihi - i0), min(14, 2 + b.jhi - j0)
+            for ty in range(17):
+                for tx in range(17):
+                    e = int(tab[ty, tx])
+                    mine = 2 <= tx <= 14 and 2 <= ty <= 14 and i0 - 2 + tx <= b.ihi and j0 - 2 + ty <= b.jhi
+                    if (tx, ty) == (16, 16) or mine or e < 0 or tx > lx + 3 or ty > ly + 3:
+                        continue
+                    if owner[e] != w:
+                        reads[w].add(owner[e])
+        edges = [(w, p) for w in reads for p in reads[w]]
+        oneway = unsafe = 0
+        for w, p in edges:
+            if w in reads[p]:
+                continue
+            oneway += 1
+            front, found = {p}, False
+            for _len in range(3):                    # a chain p reads ... reads w of at most three hand-offs
+                front = set().union(*[reads[x] for x in front]) if front else set()
+                if w in front:
+                    found = True
+                    break
+            unsafe += not found
+        g = evp.cgrid_window_deps(d)
+        assert (g["windows"], g["edges"], g["oneway"], g["unsafe"]) == (len(P["tiles"]), len(edges), oneway, unsafe), (nx, ny, bx, by, ew, ns, g, len(edges), oneway, unsafe)
+        seen_oneway += oneway > 0
+    assert seen_oneway >= 1          # (the draw holds cuts with one-way hand-offs)

@@ -1,10 +1,12 @@
-"""GPU (-m gpu): the two-subcycles-per-pass kernel (cice_amd/csrc/evp_march.hip: one wave marches north over a strip
-of 64 columns, stress -> stepu -> stress -> stepu per row, neighbours by wave shuffles, a device-private rectangle
+"""GPU (-m gpu): the several-subcycles-per-pass kernel (cice_amd/csrc/evp_march.hip: one wave marches north over a strip
+of 64 columns, (stress -> stepu) x 4 per row -- or x 2, x 3 --, neighbours by wave shuffles, a device-private rectangle
 layout) against the golden fixtures frozen from the reference's evp() and against the CPU oracle -- bit for bit in
 strict mode.  The path is the default from 450k cells per rank; here it is forced on small grids
 (CICE_EVP_HIP_MARCH=1, on-chip resident kernel off) with short segments so that every overlap rule is exercised:
-strips (60 owned columns of 64 lanes), segments, cyclic wrap images, several blocks per rank, padded blocks, closed
-east-west boundaries, odd subcycle counts, revised EVP / seabed stress / fractional capping (the non-LEAN variants)."""
+strips (<= 56 owned columns of 64 lanes), segments, cyclic wrap images, several blocks per rank, padded blocks, closed
+east-west boundaries, subcycle counts that leave 1, 2 or 3 after the passes of four, revised EVP / seabed stress /
+fractional capping (the non-LEAN variants).  CICE_EVP_HIP_MARCH_K (test build) = subcycles per full pass; by default the library
+takes four from 46 rows per segment, three from 23, two below (evp_host_march.cpp)."""
 import numpy as np
 import pytest
 
@@ -25,13 +27,22 @@ def march(monkeypatch):
     return monkeypatch
 
 
-@pytest.mark.parametrize("seg", [0, 5])
+def npasses(ndte, k=4):
+    """Passes the marching path needs for ndte subcycles: passes of k, one pass of the remaining 2 .. k-1; a single remaining
+    subcycle goes through the one-subcycle kernel (evp_host_march.cpp: march_run)."""
+    q, rem = divmod(ndte, k)
+    return q + (1 if rem >= 2 else 0)
+
+
+@pytest.mark.parametrize("seg,kpass", [(0, 4), (5, 4), (5, 3), (0, 2)])
 @pytest.mark.parametrize("name", NON_TRIPOLE)
-def test_march_golden_strict_bitwise(name, seg, march):
+def test_march_golden_strict_bitwise(name, seg, kpass, march):
     """Every non-tripole fixture of the reference (1 .. 6 blocks, padded blocks, cyclic and closed E-W, classic and
-    revised EVP, capping 0 / 0.5 / 1, Ktens, seabed stress), 1 / 2 / 10 / 120 subcycles, two calls."""
+    revised EVP, capping 0 / 0.5 / 1, Ktens, seabed stress), 1 / 2 / 10 / 120 subcycles, two calls; four (the default),
+    three and two subcycles per pass."""
     if seg:
         march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
+    march.setenv("CICE_EVP_HIP_MARCH_K", str(kpass))
     c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     try:
@@ -41,7 +52,7 @@ def test_march_golden_strict_bitwise(name, seg, march):
                 out = core.run(dyn, tm, um, ndte=nsub)
                 assert_bitwise(out, c.expected(icall, nsub), f"{name} call {icall} nsub {nsub} (march)")
                 info = core.march_info()
-                assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0, info
+                assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0 and info["kpass"] == kpass, info
         assert core.march_info()["passes"] > 0
     finally:
         core.finalize()
@@ -52,31 +63,34 @@ def test_march_golden_strict_bitwise(name, seg, march):
                                                     ("gx1", "caps", (80, 96), False, 48)])
 def test_march_synthetic_vs_oracle_strict_bitwise(grid, case, bs, warm, seg, march):
     """gx3 / gx1-sized synthetic grids (curvilinear metrics, land, cyclic E-W: the wrap images carry the state across
-    the seam) against the CPU oracle; 12 subcycles = 6 passes."""
+    the seam) against the CPU oracle; 14 subcycles = three passes of four and one of two."""
     if seg:
         march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
     dc, geo, fields, tm, um = synth_case(grid, case, seed=20260928, warm=warm, bs=bs)
     scal = synth.evp_scalars(120)
-    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=12)
-    want = run_oracle(dc, geo, fields, tm, um, scal, 12)
+    got = run_hip(dc, geo, fields, tm, um, scal, strict=True, ndte=14)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 14)
     assert np.abs(want["uvel"]).max() > 1e-4
     assert_bitwise(got, want, f"{grid}/{case} march vs oracle")
 
 
 def test_march_equals_streaming_kernel_at_odd_counts_and_across_calls(march):
-    """upload / subcycle(60) / subcycle(59) / subcycle(1) / download: odd counts start with one subcycle of the
-    one-subcycle kernel; the block-layout state is current after every call."""
+    """upload / subcycle(60) / subcycle(57) / subcycle(2) / subcycle(1) / download: 57 = 4 x 14 + 1 starts with one subcycle of
+    the one-subcycle kernel, 2 is one pass of two; the block-layout state is current after every call."""
+    march.setenv("CICE_EVP_HIP_MARCH_K", "4")          # (a grid this small gets two subcycles per pass on its own)
     c = GoldenCase("pop_cyc_3x2pad_caps")
     core = hip_from_case(c, strict=True)
     try:
         dyn, tm, um = c.inputs(1)
         core.upload(dyn, tm, um)
         core.subcycle(60)
-        core.subcycle(59)
+        core.subcycle(57)
+        core.subcycle(2)
         core.subcycle(1)
         core.sync()
-        assert_bitwise(core.download(), c.expected(1, 120), "march: upload/subcycle x3/download")
-        assert core.march_info()["passes"] == 30 + 29
+        assert_bitwise(core.download(), c.expected(1, 120), "march: upload/subcycle x4/download")
+        info = core.march_info()
+        assert info["kpass"] == 4 and info["passes"] == 15 + 14 + 1 and info["subcycles"] == 60 + 56 + 2, info
     finally:
         core.finalize()
 
@@ -126,17 +140,17 @@ def test_march_random_masks_vs_oracle(seed, grid, bs, holes, march):
 @pytest.mark.parametrize("grid,case,bs,seg,own,ext", [("gx3", "full", None, 0, 0, 2), ("gx3", "caps", (25, 29), 9, 17, 0),
                                                        ("gx3", "caps", (50, 58), 9, 23, 4), ("gx1", "full", None, 40, 0, 2)])
 def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg, own, ext, overlap, march):
-    """Several ranks: every pass is followed by an exchange of the two-cell ring (pack -> ncclSend / ncclRecv -> unpack,
+    """Several ranks: the passes are followed by an exchange of the four-cell ring (pack -> ncclSend / ncclRecv -> unpack,
     duplicates included; march_plan.cpp).  One GPU can run all of it by treating the cyclic seam of the domain as a rank
     boundary -- the rank is its own east and west neighbour (CICE_EVP_HIP_MARCH_SELFX=1): no wrap inside the strips, the
     halo columns live on what RCCL delivers.  ext: the rank also holds (and advances redundantly) `ext` columns of its
-    neighbour -- here of itself -- on either side, so that the ring is exchanged after every (ext/2 + 1)-th pass only.
+    neighbour -- here of itself -- on either side, so that the ring is exchanged every (ext + 4)-th subcycle only.
     overlap = 1 (CICE_EVP_HIP_MARCH_OVERLAP): the cells the neighbour waits for are advanced first by an early launch on
     the second stream, pack + send / recv run there while the pass itself runs on the compute stream (round 4).
     "direct" (CICE_EVP_HIP_MARCH_DIRECT=1): no library -- the pack kernel stores into the neighbour's inbox (here: its own),
     flags instead of send / recv; the first exchange runs both ways and must agree bit for bit before it is used.
     Against the oracle, bit for bit; the list logic for 2 and 4 ranks is
-    tests/test_multirank_cpu.py::test_march_two_cell_ring_between_ranks_known_answer."""
+    tests/test_multirank_cpu.py::test_march_ring_between_ranks_known_answer."""
     march.setenv("CICE_EVP_HIP_MARCH_OVERLAP", "0" if overlap == "direct" else str(overlap))
     march.setenv("CICE_EVP_HIP_MARCH_DIRECT", "1" if overlap == "direct" else "0")
     march.setenv("CICE_EVP_HIP_MARCH_SELFX", "1")
@@ -154,7 +168,7 @@ def test_march_ring_exchanged_over_rccl_with_the_rank_itself(grid, case, bs, seg
         core.comm_init(core.comm_unique_id())
         got = core.run(fields, tm, um, ndte=14)
         info = core.march_info()
-        assert info["mode"] == 1 and info["last_call"] and info["passes"] == 7, info
+        assert info["mode"] == 1 and info["last_call"] and info["passes"] == npasses(14, info["kpass"]), info
         assert info["ring"] == ("direct stores (HIP IPC)" if overlap == "direct" else "rccl"), info
         if overlap == "direct":          # a second call: every exchange through the inboxes now
             got = core.run(fields, tm, um, ndte=14)
@@ -214,7 +228,7 @@ def test_march_is_the_default_on_a_large_grid_and_invariant_under_the_cut():
             try:
                 out = core.run(fields, tm, um, ndte=6)
                 info = core.march_info()
-                assert info["mode"] == 1 and info["last_call"] and info["passes"] == 3, info
+                assert info["mode"] == 1 and info["last_call"] and info["passes"] == npasses(6, info["kpass"]), info
             finally:
                 core.finalize()
         finally:
@@ -241,25 +255,25 @@ def test_march_is_the_default_on_a_large_grid_and_invariant_under_the_cut():
 
 def test_s01_full_size_march_vs_oracle_bitwise():
     """BASELINE's largest configuration (3600 x 2400 = 8.6M cells, one block, nothing forced: the marching kernel is the
-    default there) against the CPU oracle itself, 13 subcycles = one subcycle of the streaming kernel + 6 passes: every
+    default there) against the CPU oracle itself, 15 subcycles = three passes of four + one of three: every
     output field on every cell, bit for bit.  (bench.py verifies the same workload after 3 x 480 subcycles against a
     committed checksum of the oracle's state.)"""
     scal = synth.evp_scalars(480)
     dc, geo, fields, tm, um = synth_case("s01", "full", seed=2, warm=True)
-    want = run_oracle(dc, geo, fields, tm, um, scal, 13)
+    want = run_oracle(dc, geo, fields, tm, um, scal, 15)
     d, keep = evp.make_dims(dc, 0)
     core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
                       geo["uarear"], geo["tarea"], keepalive=keep)
     try:
-        got = core.run(fields, tm, um, ndte=13)
+        got = core.run(fields, tm, um, ndte=15)
         info = core.march_info()
-        assert info["mode"] == 1 and info["last_call"] and info["passes"] == 6 and info["declined"] == 0, info
+        assert info["mode"] == 1 and info["last_call"] and info["passes"] == 4 and info["subcycles"] == 15 and info["declined"] == 0, info
         path = core.describe_path()
-        assert "two subcycles per pass" in path and "two-subcycle path: on" in path and "one rank" in path, path
+        assert "four subcycles per pass" in path and "marching path: on" in path and "one rank" in path, path
     finally:
         core.finalize()
     assert np.abs(want["uvel"]).max() > 1e-3
-    assert_bitwise(got, want, "3600x2400 march vs oracle, 13 subcycles")
+    assert_bitwise(got, want, "3600x2400 march vs oracle, 15 subcycles")
 
 
 def test_march_plan_is_built_for_a_rank_of_several(tmp_path):
@@ -313,11 +327,13 @@ def test_march_random_geometry_vs_oracle(seed, march):
     ew = "cyclic" if seed % 3 else "closed"
     nbx, nby = int(rng.integers(1, 4)), int(rng.integers(1, 3))
     bsx, bsy = -(-nx // nbx), -(-ny // nby)
-    own = int(rng.choice([0, 13, 29, 47, 60]))
+    own = int(rng.choice([0, 13, 29, 47, 56]))
     seg = int(rng.integers(5, 45))
-    ndte = int(rng.choice([6, 9, 12]))
+    ndte = int(rng.choice([6, 9, 12, 7, 15]))
+    kpass = int(rng.choice([4, 4, 3, 2]))
+    march.setenv("CICE_EVP_HIP_MARCH_K", str(kpass))
     selfx = ew == "cyclic" and seed % 2 == 0
-    ext = int(rng.choice([0, 2, 4, 6])) if selfx else 0
+    ext = int(rng.choice([0, 2, 4, 6, 8])) if selfx else 0
     march.setenv("CICE_EVP_HIP_MARCH_SEG", str(seg))
     if own:
         march.setenv("CICE_EVP_HIP_MARCH_OWN", str(own))
@@ -342,7 +358,7 @@ def test_march_random_geometry_vs_oracle(seed, march):
     fields = {k: dc.scatter(st[k], 0) for k in evp.FIELDS}
     tm, um = dc.scatter(tmg, 0, fill=0), dc.scatter(umg, 0, fill=0)
     scal = synth.evp_scalars(120)
-    what = f"seed {seed}: {nx}x{ny} {ew}, blocks {bsx}x{bsy}, own {own}, seg {seg}, ndte {ndte}, selfx {selfx} ext {ext}, holes {holes}"
+    what = f"seed {seed}: {nx}x{ny} {ew}, blocks {bsx}x{bsy}, own {own}, seg {seg}, ndte {ndte}, selfx {selfx} ext {ext}, k {kpass}, holes {holes}"
     d, keep = evp.make_dims(dc, 0)
     core = evp.EvpHip(d, evp.make_params(scal, strict=True), geo["HTE"], geo["HTN"], geo["dxT"], geo["dyT"],
                       geo["uarear"], geo["tarea"], keepalive=keep)
@@ -351,7 +367,7 @@ def test_march_random_geometry_vs_oracle(seed, march):
             core.comm_init(core.comm_unique_id())
         got = core.run(fields, tm, um, ndte=ndte)
         info = core.march_info()
-        assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0 and info["passes"] == ndte // 2, (what, info)
+        assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0 and info["passes"] == npasses(ndte, kpass), (what, info)
     finally:
         core.finalize()
     want = run_oracle(dc, geo, fields, tm, um, scal, ndte)

@@ -76,7 +76,7 @@ def test_golden_tripoleT_strict_bitwise(name):
                     sel = keep if k.startswith("stress") else np.ones_like(keep)
                     assert bits_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k} (HIP, tripoleT)"
         assert core.timings()["tile_variant"] < 1000          # the streaming kernel (the resident ones are not eligible)
-        assert "one subcycle per launch" in core.describe_path() and "two-subcycle path: off" in core.describe_path()
+        assert "one subcycle per launch" in core.describe_path() and "marching path: off" in core.describe_path()
         assert np.abs(want["uvel"]).max() > 1e-3
     finally:
         core.finalize()

@@ -171,13 +171,16 @@ def test_reference_mpi_driver_with_hip_core_wide_sweep(tmp_path, seed):
     (54, 52, 14, 26, "cyclic", "tripole", 3, "cartesian", dict(grid_kind="tripolefile", icecase="full")),    # 4 x 2 blocks: 4, 4, 0
     (90, 21, 30, 21, "closed", "closed", 2, "cartesian", dict(grid_kind="popfile", icecase="patchy")),        # 3 x 1 blocks: 3, 0
     (68, 54, 17, 27, "cyclic", "closed", 3, "cartesian", dict(grid_kind="popfile", icecase="caps", h_revised=True)),
+    # tripoleT with a blockless task (round-5 advice): settle_stress_residency's global_minval is a collective over ALL tasks
+    # of the distribution -- the task without blocks used to skip it and the others waited for ever
+    (54, 52, 14, 26, "cyclic", "tripoleT", 3, "cartesian", dict(grid_kind="tripolefile", icecase="full")),
 ])
 def test_reference_mpi_driver_with_a_task_that_holds_no_blocks(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, kw, cgrid):
     """The reference's cartesian distribution hands a task NOTHING when its processor grid does not divide the block grid
     (ice_distribution.F90 create_distrb_cart) and carries on; so does the drop-in: the task without blocks is a bystander
     of the bootstrap (cice_evp_hip_init with nblocks = 0, an empty blob in the all-gather) and the shim's routines
     return at once there.  Found by the geometry sweep below (seeds 2043, 2057, 2084, 2119, 2129, 2134, 2136)."""
-    if cgrid and ns == "tripole":
+    if cgrid and ns in ("tripole", "tripoleT"):
         pytest.skip("C grid on a tripole grid: the blocks next to the fold must lie on one rank (INTEGRATION.md); this cut splits them in x")
     run_case(tmp_path, nx, ny, bx, by, ew, ns, nprocs, dist, False, kw, cgrid=cgrid)
 

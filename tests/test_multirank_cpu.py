@@ -504,25 +504,26 @@ def test_cgrid_loop_split_over_ranks_known_answer(case):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Two-subcycles-per-pass path (cice_amd/csrc/evp_march.hip): the exchange of the TWO-cell ring between the ranks'
-# rectangles (march_plan.cpp), once per pass.  world_size-2/4 gloo processes: every rank builds its plan from the
+# Several-subcycles-per-pass path (cice_amd/csrc/evp_march.hip): the exchange of the FOUR-cell ring (P = EVP_MARCH_PAD) between
+# the ranks' rectangles (march_plan.cpp), once per pass of four.  world_size-2/4 gloo processes: every rank builds its plan from the
 # global block table alone, packs, exchanges point-to-point, unpacks -- the known answer is the global cell number.
 # ---------------------------------------------------------------------------------------------------------------
 MARCH_CASES = [
     # nx, ny, bx, by, ew, nranks, proc_shape, own_max, wrap_inside, ext
-    (130, 40, 65, 40, "cyclic", 2, (2, 1), 60, True, 0),      # x split: the cyclic seam and the inner cut, both between ranks
-    (130, 40, 130, 20, "cyclic", 2, (1, 2), 60, True, 0),     # y slabs: every rank wraps inside and trades halo ROWS (duplicates!)
+    (130, 40, 65, 40, "cyclic", 2, (2, 1), 56, True, 0),      # x split: the cyclic seam and the inner cut, both between ranks
+    (130, 40, 130, 20, "cyclic", 2, (1, 2), 56, True, 0),     # y slabs: every rank wraps inside and trades halo ROWS (duplicates!)
     (96, 48, 48, 24, "cyclic", 4, (2, 2), 20, True, 0),       # 2 x 2, narrow strips, corner cells from the diagonal neighbour
-    (96, 48, 24, 24, "closed", 4, (2, 2), 60, True, 0),       # closed E-W, two blocks per rank
-    (75, 30, 75, 15, "cyclic", 2, (1, 2), 60, False, 0),      # test hook: the cyclic seam exchanged with the rank itself
-    # ext = 2 / 4: every rank holds (and advances redundantly) a rim of its neighbours' cells; ring of ext + 2 per exchange
-    (130, 40, 65, 40, "cyclic", 2, (2, 1), 60, True, 2),
-    (130, 40, 130, 20, "cyclic", 2, (1, 2), 60, True, 2),
+    (96, 48, 24, 24, "closed", 4, (2, 2), 56, True, 0),       # closed E-W, two blocks per rank
+    (75, 30, 75, 15, "cyclic", 2, (1, 2), 56, False, 0),      # test hook: the cyclic seam exchanged with the rank itself
+    # ext = 2 / 4: every rank holds (and advances redundantly) a rim of its neighbours' cells; ring of ext + 4 per exchange
+    (130, 40, 65, 40, "cyclic", 2, (2, 1), 56, True, 2),
+    (130, 40, 130, 20, "cyclic", 2, (1, 2), 56, True, 2),
     (96, 48, 48, 24, "cyclic", 4, (2, 2), 20, True, 4),
-    (96, 48, 24, 24, "closed", 4, (2, 2), 60, True, 2),
-    (75, 30, 75, 15, "cyclic", 2, (1, 2), 60, False, 2),
-    # 61 + 2 + 2 = 65 columns held = 4 x 16 + 1: strips of 16 would leave ONE column to the last strip, and the first column
-    # beyond the rectangle would sit in two strips (found by a geometry sweep on the GPU: seed 2056) -- 15 is chosen
+    (96, 48, 24, 24, "closed", 4, (2, 2), 56, True, 2),
+    (75, 30, 75, 15, "cyclic", 2, (1, 2), 56, False, 2),
+    # 61 + 2 + 2 = 65 columns held = 4 x 16 + 1: strips of 16 would leave ONE column to the last strip, and the first columns
+    # beyond the rectangle would sit in two strips (found by a geometry sweep on the GPU: seed 2056, when the ring was two cells
+    # wide and the rule "at least two") -- the last strip keeps at least P = 4 columns: 13 is chosen (5 x 13 = 65)
     (122, 30, 61, 30, "cyclic", 2, (2, 1), 16, True, 2),
 ]
 
@@ -538,11 +539,12 @@ def _march_worker(rank, world, port, case, q):
         P = evp.march_plan(d, own_max, wrap_inside, ext)
         own, ns, nxr, nyr, gx0, gy0 = P["own"], P["nstrips"], P["nxr"], P["nyr"], P["gx0"], P["gy0"]   # what the rank HOLDS
         ew_, ee_, es_, en_ = P["ext"]
-        rows = nyr + 4
+        PW = 4                     # EVP_MARCH_PAD: overlap lanes, halo rows, cells of the ring
+        rows = nyr + 2 * PW
 
-        def home(x, y):            # where the rank holds column x (may lie two cells beyond the rectangle), row y
+        def home(x, y):            # where the rank holds column x (may lie PW cells beyond the rectangle), row y
             s = min(max(x, 0) // own, ns - 1)
-            return ((y + 2) * ns + s) * 64 + (x - s * own + 2)
+            return ((y + PW) * ns + s) * 64 + (x - s * own + PW)
 
         buf = np.full(rows * ns * 64, -1.0)
         for y in range(es_, nyr - en_):              # its OWN cells
@@ -571,10 +573,10 @@ def _march_worker(rank, world, port, case, q):
         buf[P["recv_pos1"]] = recvbuf.numpy()
         has2 = P["recv_pos2"] >= 0
         buf[P["recv_pos2"][has2]] = recvbuf.numpy()[has2]
-        # known answer: every cell of the two-cell ring that exists in the global domain
+        # known answer: every cell of the PW-cell ring that exists in the global domain
         nbad = nring = 0
-        for y in range(-2, nyr + 2):
-            for x in range(-2, nxr + 2):
+        for y in range(-PW, nyr + PW):
+            for x in range(-PW, nxr + PW):
                 if ew_ <= x < nxr - ee_ and es_ <= y < nyr - en_:
                     continue
                 gx, gy = gx0 + x, gy0 + y
@@ -588,19 +590,19 @@ def _march_worker(rank, world, port, case, q):
                     gx %= nx
                 nring += 1
                 nbad += int(buf[home(x, y)] != gy * nx + gx)
-                # ... and in EVERY lane the kernel reads it from: the two overlap lanes on either side of every strip
+                # ... and in EVERY lane the kernel reads it from: the PW overlap lanes on either side of every strip
                 for s_ in range(ns):
                     cnt = min(own, nxr - s_ * own)
-                    for l in (0, 1, cnt + 2, cnt + 3):
-                        if s_ * own - 2 + l == x:
-                            nbad += int(buf[((y + 2) * ns + s_) * 64 + l] != gy * nx + gx)
+                    for l in list(range(PW)) + list(range(cnt + PW, cnt + 2 * PW)):
+                        if s_ * own - PW + l == x:
+                            nbad += int(buf[((y + PW) * ns + s_) * 64 + l] != gy * nx + gx)
         q.put((rank, nbad, nring, int(has2.sum())))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("case", MARCH_CASES)
-def test_march_two_cell_ring_between_ranks_known_answer(case):
+def test_march_ring_between_ranks_known_answer(case):
     world = case[5]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -621,10 +623,10 @@ def test_march_two_cell_ring_between_ranks_known_answer(case):
 
 
 def test_march_plan_refuses_a_rank_too_thin_next_to_a_closed_boundary():
-    """ADVICE (round 3): the redundant rim + two-cell ring of a rank must not reach past a CLOSED global boundary through a
-    neighbour thinner than ext + 2 cells -- those positions would stay zero here while the owner advances the same cells
-    from the caller's boundary ghost values.  The plan refuses the layout on every rank alike (the one-subcycle kernels run
-    it); with ext = 0, a cyclic dimension, or a wide enough neighbour it is accepted."""
+    """ADVICE (round 3): the redundant rim + ring of a rank must not reach past a CLOSED global boundary through a
+    neighbour thinner than ext + P cells (P = 4, the width of the ring) -- those positions would stay zero here while the owner
+    advances the same cells from the caller's boundary ghost values.  The plan refuses the layout on every rank alike (the
+    one-subcycle kernels run it); with a cyclic dimension or a wide enough neighbour it is accepted."""
     def plan(nx, bx, ew, ext, rank):
         dc = decomp.Decomp(nx, 24, bx, 24, ew, "closed", 2, (2, 1))
         d, keep = evp.make_dims(dc, rank)
@@ -632,8 +634,10 @@ def test_march_plan_refuses_a_rank_too_thin_next_to_a_closed_boundary():
 
     for rank in (0, 1):
         with pytest.raises(evp.EvpHipError, match="closer to a closed boundary"):
-            plan(40, 36, "closed", 4, rank)           # blocks of 36 + 4 columns: the east rank is 4 < ext + 2 wide
-        assert plan(40, 36, "closed", 0, rank)["ext"] is not None      # no redundant rim: nothing reaches past the boundary
+            plan(40, 36, "closed", 4, rank)           # blocks of 36 + 4 columns: the east rank is 4 < ext + 4 wide
+        with pytest.raises(evp.EvpHipError, match="closer to a closed boundary|too small"):
+            plan(39, 36, "closed", 0, rank)           # 36 + 3: thinner than the ring itself
+        assert plan(40, 36, "closed", 0, rank)["ext"] is not None      # no redundant rim, four columns for a four-cell ring
         assert plan(40, 36, "cyclic", 4, rank)["nxr"] > 0               # cyclic: no closed boundary in x
         assert plan(48, 24, "closed", 4, rank)["nxr"] == 24 + 4         # 24 + 24: wide enough
 
