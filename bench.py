@@ -58,7 +58,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 B_ALG = 368.0            # algorithmic bytes per cell-subcycle (32 reads + 14 writes, fp64)
-B_PASS_MARCH = 328.0     # two-subcycle marching kernel: 27 reads + 14 writes (fp64) per cell and PASS of two subcycles
+B_PASS_MARCH = 328.0     # marching kernel: 27 reads + 14 writes (fp64) per cell and PASS of four (or three, two) subcycles
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024            # 256 CUs x 4 SIMDs
 MAX_CLOCK_HZ = 2.4e9
@@ -529,7 +529,10 @@ def main():
                                 two_subcycle_kernel=dict(ran=bool(mi["last_call"]), passes=mi["passes"], declined=mi["declined"],
                                                          strips=mi["strips"], segments=mi["segments"], rows_per_segment=mi["seglen"]),
                                 probes_us=dict(streaming=1e3 * float(tm_ev["stream_probe_ms"]), resident=1e3 * float(tm_ev["resident_probe_ms"])),
-                                local_cells=int(sum(b.gnx * b.gny for b in dc.local_blocks(rank))), path=core.describe_path())
+                                local_cells=int(sum(b.gnx * b.gny for b in dc.local_blocks(rank))), path=core.describe_path(),
+                                # what RCCL itself reports (ncclCommCount / UserRank / CuDevice) and the device's PCI bus id: "did RCCL
+                                # see N ranks on N different GPUs" without trusting a label of ours
+                                **{k: v for k, v in core.comm_info().items() if k != "have_comm"})
                     per_rank = [None] * world
                     dist.all_gather_object(per_rank, mine)
                 # SURVEY 8(d) asks for the median over >= 10 evp() calls next to the contract's K-step mean: the same loop again,
@@ -936,12 +939,13 @@ def main():
     M2o = None
     if want("s01") and a.workload != "s01":
         try:      # the 0.1-degree-class grid the strong-scaling target is stated on (streaming kernel, HBM-bound)
-            # (N > 1: timed a second time on the same ranks and state with the ring exchange overlapped with the pass -- early
-            # launch of the cells the neighbours wait for, pack + RCCL send / recv on the second stream: a loss on one GPU, meant
-            # for real xGMI; both are reported)
-            # ... and a third time with the ring not through RCCL but as stores into the neighbours' HIP-IPC-mapped inboxes
+            # (N > 1: the library's default overlaps the ring exchange with the interior of the pass -- early launch of the
+            # (strip, row) units the neighbours wait for, pack + RCCL send / recv on the second stream, everything else on the
+            # compute stream.  Timed a second time on the same ranks and state with pack, send / recv and unpack AFTER the pass
+            # (the test build's CICE_EVP_HIP_MARCH_OVERLAP=0), and a third time with the ring not through RCCL but as stores into
+            # the neighbours' HIP-IPC-mapped inboxes; all three are reported)
             M2 = measure_with_fallbacks("s01", "full", 480, 2, 1,
-                                        again_env=([{"CICE_EVP_HIP_MARCH_OVERLAP": "1"}, {"CICE_EVP_HIP_MARCH_DIRECT": "1"}]
+                                        again_env=([{"CICE_EVP_HIP_MARCH_OVERLAP": "0"}, {"CICE_EVP_HIP_MARCH_DIRECT": "1"}]
                                                    if (world > 1 and "ring_variants" in a.extras) else None))
             M2o = M2.get("again")
         except Exception as e:  # noqa: BLE001
@@ -1021,21 +1025,25 @@ def main():
 
         def hbm_block(Mx, pmc_key):
             """HBM roofline of a streaming-kernel measurement.  One-subcycle kernel: one launch = one subcycle of rank 0's
-            sub-domain, 368 B per cell.  Two-subcycle marching kernel (tile_variant >= 3000): one launch = one
-            PASS = two subcycles; its algorithmic bytes are stated per pass -- 27 fp64 reads + 14 writes per cell = 328 B --
-            and the 368 B-per-cell-subcycle figure stays in the block as the labelled yardstick."""
+            sub-domain, 368 B per cell.  Marching kernel (tile_variant >= 3000): one launch = one PASS = four
+            subcycles (three or two on short segments; the library reports launches per subcycle); its algorithmic bytes are
+            stated per pass -- 27 fp64 reads + 14 writes per cell = 328 B -- and the 368 B-per-cell-subcycle figure stays in
+            the block as the labelled yardstick.  Round 6 measured that this kernel is bound by instruction issue, not by HBM
+            (one wave per SIMD issues one instruction per ~2.4 ns whatever it is): `issue` prices the committed PMC pass's
+            instruction counts at that rate."""
             my = sum(b.gnx * b.gny for b in Mx["dc"].local_blocks(0))
             march = Mx["tm_ev"]["tile_variant"] >= 3000
             if march:
                 pmc_key = {"s01str": "s01march"}.get(pmc_key, pmc_key + "march")
-            spl = 2 if march else 1
+            lps = float(Mx["tm_ev"]["launches_per_subcycle"] or 0.0)
+            spl = (1.0 / lps if lps > 0 else 4.0) if march else 1      # subcycles per launch (mean over the call's passes)
             tk = Mx["tm_ev"]["marks_ms"] * 1e-3 / (Mx["steps"] * Mx["ndte"] / spl)
             alg = (B_PASS_MARCH if march else B_ALG) * my
             e = (pmc or {}).get("kernels", {}).get(pmc_key) if world == 1 else None
             traffic = e.get("hbm_bytes_per_launch") if e else None
             blk = {"bound": "hbm", "achieved": alg / tk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": alg / tk / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                   "kernel": "evp_march2p" if march else "evp_subcycle_tile",
+                   "kernel": "evp_marchk" if march else "evp_subcycle_tile",
                    "kernel_us": 1e6 * tk, "alg_bytes_per_launch": alg, "subcycles_per_launch": spl,
                    "tile_variant": Mx["tm_ev"]["tile_variant"],
                    "launches_per_subcycle": Mx["tm_ev"]["launches_per_subcycle"]}
@@ -1044,7 +1052,23 @@ def main():
                 blk["yardstick_368B_per_cell_subcycle"] = {
                     "GBps_equivalent": B_ALG * my * spl / tk / 1e9, "frac_of_hbm_peak": B_ALG * my * spl / tk / 1e9 / HBM_PEAK_GBS,
                     "note": "what a kernel that streams every field once per SUBCYCLE would have to move for the same result "
-                            "(SURVEY 8d); this kernel streams them once per two subcycles, so the figure may exceed the peak"}
+                            "(SURVEY 8d); this kernel streams them once per pass of several subcycles, so the figure may exceed the peak"}
+                c = (e or {}).get("counters", {})
+                kinds = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
+                if all(k in c for k in kinds) and c.get("SQ_WAVES", {}).get("avg_per_launch") and "evp_marchk" in (e.get("kernel") or ""):
+                    waves = c["SQ_WAVES"]["avg_per_launch"]
+                    n_inst = sum(c[k]["avg_per_launch"] for k in kinds)
+                    floor = n_inst / waves * FP64_NS_PER_INST[1] * 1e-9          # every wave alone on its SIMD, all in parallel
+                    blk["issue"] = {"bound": "instruction issue (one wave per SIMD)", "wave_instructions_per_launch": n_inst,
+                                    "waves_per_launch": waves, "instructions_per_wave": n_inst / waves,
+                                    "valu_share": c["SQ_INSTS_VALU"]["avg_per_launch"] / n_inst,
+                                    "ns_per_instruction_one_wave_per_simd": FP64_NS_PER_INST[1],
+                                    "floor_us_per_launch": 1e6 * floor, "frac": floor / tk,
+                                    "live_ns_per_instruction": 1e9 * tk / (n_inst / waves),
+                                    "pmc_source": f"{pmc_file}#{pmc_key}",
+                                    "note": "instructions of all kinds a wave issues per launch (committed PMC pass of this command) x "
+                                            "2.4 ns, the rate tools/fp64_rate_probe.hip measures for one wave per SIMD "
+                                            "(profiles/r03_fp64_rate_probe.txt), over the live launch time: what binds this kernel"}
             if traffic:
                 blk["measured_traffic_GBps"] = traffic / tk / 1e9
                 blk["pmc_source"] = f"{pmc_file}#{pmc_key}"
@@ -1131,7 +1155,7 @@ def main():
                 roof["note"] = ("achieved = 368 B x grid cells of rank 0 (SURVEY 8d: all cells of the domain, ice or not) / average "
                                 "launch duration from HIP events on the kernel's stream over the timed region")
             else:
-                roof["note"] = ("achieved = 328 B (27 fp64 reads + 14 writes: every field once per PASS of two subcycles) x grid "
+                roof["note"] = ("achieved = 328 B (27 fp64 reads + 14 writes: every field once per PASS of several subcycles) x grid "
                                 "cells of rank 0 / average launch duration from HIP events on the kernel's stream over the "
                                 "timed region (includes, per call, one gather and one scatter launch between the CICE block "
                                 "layout and the kernel's private layout)")
@@ -1163,7 +1187,7 @@ def main():
                        "halo_transport": tm_ev["halo_transport"],
                        "autotune_probe_us": {"streaming": 1e3 * tm_ev["stream_probe_ms"], "resident": 1e3 * tm_ev["resident_probe_ms"]},
                        "resident_fallbacks": M["fallbacks"], "attempts": M.get("attempts"), "per_rank": M.get("per_rank"),
-                       "finite": M["finite"], "max_abs_u": M["umax"]},
+                       "finite": M["finite"], "max_abs_u": M["umax"]},      # (scalars of the other workloads are added below)
             "verification": M["ver"],
             "roofline": roof,
         }
@@ -1182,7 +1206,7 @@ def main():
                 "attempts": M2.get("attempts"), "per_rank": M2.get("per_rank")}
             for Mo in (M2o or []):
                 direct = "CICE_EVP_HIP_MARCH_DIRECT" in Mo["env"]
-                res["secondary"]["ring_exchange_direct_ipc" if direct else "ring_exchange_overlapped"] = {
+                res["secondary"]["ring_exchange_direct_ipc" if direct else "ring_exchange_after_the_pass"] = {
                     "value": c2 * 480 * 2 / Mo["dt"], "us_per_subcycle": 1e6 * Mo["dt"] / (2 * 480), "finite": Mo["finite"],
                     "ring": Mo.get("ring"),
                     "verified": None, "why_unverified": "continues from the verified run's state (no checksum that far); bit-identity of this "
@@ -1190,11 +1214,25 @@ def main():
                     "note": ("CICE_EVP_HIP_MARCH_DIRECT=1: no RCCL -- the pack kernel stores into the neighbours' HIP-IPC-mapped inboxes, "
                              "flags instead of send / recv (off by default: no faster where the transfer is a device copy, never measured "
                              "over xGMI); 'ring' says whether the trial exchange let it be used") if direct else
-                            ("CICE_EVP_HIP_MARCH_OVERLAP=1: cells other ranks wait for advanced first on the second stream, pack + "
-                             "RCCL send / recv overlapped with the pass (off by default: a loss where the transfer is a device copy)")}
+                            ("CICE_EVP_HIP_MARCH_OVERLAP=0 (test build): pack, RCCL send / recv and unpack after the pass on the compute "
+                             "stream -- the form before round 6; the default advances the cells other ranks wait for first, on the second "
+                             "stream, and overlaps their transfer with the rest of the pass")}
         for k_, v_ in extra_err.items():
             res[k_] = {"error": v_}
         res.update(extra)
+        # the other workloads' headline scalars once more, flat, inside `config`: a reader that keeps only the contract's keys
+        # (the driver's record does) still sees them
+        if M2 is not None:
+            res["config"].update(s01_us_per_subcycle=res["secondary"]["us_per_subcycle"], s01_verified=res["secondary"]["verified"],
+                                 s01_subcycles_per_launch=(1.0 / M2["tm_ev"]["launches_per_subcycle"] if M2["tm_ev"]["launches_per_subcycle"] else None),
+                                 s01_frac_hbm_peak_on_328B_per_pass=streaming["s01"]["frac"],
+                                 s01_frac_issue_floor=(streaming["s01"].get("issue") or {}).get("frac"))
+        cg = res.get("cgrid") if isinstance(res.get("cgrid"), dict) else {}
+        for key in ("gx1", "tx1", "s01"):
+            v = cg if key == "gx1" else (cg.get(key) if isinstance(cg.get(key), dict) else None)      # (gx1's figures are the block itself)
+            if v and v.get("us_per_subcycle") is not None:
+                res["config"][f"cgrid_{key}_us_per_subcycle"] = v["us_per_subcycle"]
+                res["config"][f"cgrid_{key}_verified"] = v.get("verified")
         if M3 is not None:
             res["tripole"] = {
                 "workload": "tx1 360x240 tripole B-grid EVP ndte=240, case=full, one GPU",

@@ -397,6 +397,24 @@ static void bystander_blob(HaloBlob &B)
     B.pid = (int64_t)getpid();
 }
 
+int cice_evp_hip_comm_info(int32_t *out, int32_t n, char *bus_id, int32_t nb)
+{
+    int32_t v[5] = {S.have_comm ? 1 : 0, -1, -1, -1, (int32_t)S.device};
+    if (S.have_comm) {
+        int c = -1, r = -1, dv = -1;
+        NCCLC(ncclCommCount(S.comm, &c));
+        NCCLC(ncclCommUserRank(S.comm, &r));
+        NCCLC(ncclCommCuDevice(S.comm, &dv));
+        v[1] = c; v[2] = r; v[3] = dv;
+    }
+    for (int k = 0; out && k < n && k < 5; ++k) out[k] = v[k];
+    if (bus_id && nb > 0) {
+        bus_id[0] = 0;
+        if (S.ready || S.bystander) HIPC(hipDeviceGetPCIBusId(bus_id, nb, S.device));
+    }
+    return 0;
+}
+
 int cice_evp_hip_comm_init(const void *id128)
 {
     if (!S.ready && !S.bystander) return fail(-1, "not initialised");

@@ -42,8 +42,8 @@ struct MarchBuf {
     int *send_pos = nullptr, *recv_pos1 = nullptr, *recv_pos2 = nullptr, *send_midx = nullptr, *recv_midx = nullptr;
     double *sendbuf = nullptr, *recvbuf = nullptr;
     // the early launch of an exchange pass: work items that cover every cell other ranks receive from this one
-    int4 *band_items = nullptr;
-    int nband = 0;
+    int4 *band_items = nullptr, *rest_items = nullptr;      // ... and every other (strip, row) of the rectangle
+    int nband = 0, nrest = 0;
     hipEvent_t ev_in = nullptr, ev_main = nullptr, ev_done = nullptr;
     // the same ring as stores into the peers' HIP-IPC-mapped inboxes (march_direct_setup)
     void *dx_area = nullptr;     // fine-grained: flag lines | count | err | inbox [2][n_recv * NF]
@@ -71,8 +71,8 @@ void march_free()
     F(B.st[0]); F(B.st[1]); F(B.cst); F(B.opt); F(B.diag);
     F(B.mask); F(B.bad); F(B.dup); F(B.blkid); F(B.org);
     F(B.send_pos); F(B.recv_pos1); F(B.recv_pos2); F(B.send_midx); F(B.recv_midx); F(B.sendbuf); F(B.recvbuf);
-    F(B.band_items);
-    B.nband = 0;
+    F(B.band_items); F(B.rest_items);
+    B.nband = B.nrest = 0;
     for (void *m : B.dx_mapped) (void)hipIpcCloseMemHandle(m);
     B.dx_mapped.clear();
     F(B.dx_area);
@@ -239,7 +239,9 @@ static int march_alloc()
         // Work items of the EARLY launch of an exchange pass (march_run): per strip the rows that hold cells some other rank
         // receives, cut into short segments -- from the send lists themselves, so every sent cell is covered whatever the
         // layout.  Short segments (a third of the regular length, at least 6 rows) so that the launch, the pack and the
-        // transfer end before the pass they overlap with does; each costs ~3.5 rows of warm-up like any segment.
+        // transfer end before the pass they overlap with does; each costs 2K - 1 rows of warm-up like any segment.  The pass
+        // itself then runs over every OTHER (strip, row) of the rectangle (rest_items): the two launches of an exchange pass
+        // store into disjoint cells (round-4 advice: they used to overlap on the band, storing the same bits twice).
         const int nstr = M.G.nstrips;
         std::vector<std::vector<char>> rows((size_t)nstr, std::vector<char>((size_t)M.G.nyr, 0));
         for (int pos : sp) {
@@ -261,6 +263,20 @@ static int march_alloc()
         if (B.nband > 0) {
             HIPC(hipMalloc((void **)&B.band_items, items.size() * sizeof(int4)));
             HIPC(hipMemcpy(B.band_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice));
+        }
+        std::vector<int4> rest;
+        for (int st = 0; st < nstr; ++st)
+            for (int y = 0; y < M.G.nyr;) {
+                if (rows[(size_t)st][(size_t)y]) { ++y; continue; }
+                int y1 = y;
+                while (y1 < M.G.nyr && y1 - y < M.seglen && !rows[(size_t)st][(size_t)y1]) ++y1;
+                rest.push_back(make_int4(st, y, y1, 0));
+                y = y1;
+            }
+        B.nrest = (int)rest.size();
+        if (B.nrest > 0) {
+            HIPC(hipMalloc((void **)&B.rest_items, rest.size() * sizeof(int4)));
+            HIPC(hipMemcpy(B.rest_items, rest.data(), rest.size() * sizeof(int4), hipMemcpyHostToDevice));
         }
         for (hipEvent_t *e : {&B.ev_in, &B.ev_main, &B.ev_done})
             if (!*e) HIPC(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -758,23 +774,23 @@ int march_run(int ndte)
         M.checked_seq = S.upload_seq;
     }
     // ---- the passes ----
-    // Exchange passes (the redundant rim and the ring have been used up; the last): the cells other ranks are waiting for are advanced FIRST, by an
-    // early launch of the same kernel over short segments on the second stream; their pack and the RCCL send / recv follow
-    // there while the pass itself -- all work items, those cells included -- runs on the compute stream: the transfer is
-    // overlapped with the pass instead of following it (ice_HaloUpdate -> RCCL point-to-point on a second HIP stream over
-    // interior compute).  Both launches store the same bits into the same cells (same kernel, same operands; a cell's
-    // result does not depend on the segment it is computed in), so the duplicate stores are harmless.  Only the unpack
-    // waits for the pass: the pass still writes its (spent) redundant rim where the received cells go.
+    // Exchange passes (the redundant rim and the ring have been used up; the last): the (strip, row) units that hold cells other
+    // ranks are waiting for are advanced FIRST, by an early launch of the same kernel over short segments on the second stream;
+    // their pack and the RCCL send / recv follow there while the rest of the pass -- every other (strip, row), rest_items -- runs
+    // on the compute stream: the transfer is overlapped with the interior of the pass instead of following it (ice_HaloUpdate ->
+    // RCCL point-to-point on a second HIP stream over interior compute).  The two launches read the same input state and store
+    // into disjoint cells (a cell's result does not depend on the segment it is computed in).  Only the unpack waits for the
+    // pass: the pass still writes its (spent) redundant rim where the received cells go.
     const int npass = (int)sizes.size();
     int rc = 0;
     int valid = M.ring_valid;        // cells beyond the rank's own that hold the current state (the gather's exchange just filled them)
-    // Opt-in (CICE_EVP_HIP_MARCH_OVERLAP=1).  Measured where it could be measured -- one GPU, the ring exchanged with the rank
-    // itself, 450 x 2400 and 900 x 1200 pieces of 3600 x 2400 -- the early launch costs more than it hides: 57.7 against
-    // 51.2 us per subcycle (8 x 1 piece; 48.9 without any exchange), 55.2 against 50.7 (4 x 2 piece): two of eight strips
-    // are advanced twice, and their waves share the SIMDs with the pass they overlap.  On one GPU the transfer is a 7-us
-    // device copy; over xGMI it is 1.6 MB per neighbour and pass group, which is what the overlap is for -- bench.py
-    // --gpus N times the 3600 x 2400 block both ways so that the first run on a real node decides.
-    const bool overlap = !PL.peers.empty() && B.nband > 0 && env_test("CICE_EVP_HIP_MARCH_OVERLAP") && std::atoi(env_test("CICE_EVP_HIP_MARCH_OVERLAP"));
+    // The default since round 6 (the test build's CICE_EVP_HIP_MARCH_OVERLAP=0 puts pack, send / recv and unpack after the pass on
+    // the compute stream: the fallback form, and the one the direct-store ring uses).  Rounds 4-5 had it opt-in because the early
+    // launch advanced the band a SECOND time (57.7 against 51.2 us per subcycle on the 450 x 2400 piece, one GPU, ring exchanged
+    // with the rank itself); with the band taken out of the pass there is no second time.
+    const bool overlap = !PL.peers.empty() && B.nband > 0 && M.direct != 1 &&
+                         !(env_test("CICE_EVP_HIP_MARCH_OVERLAP") && !std::atoi(env_test("CICE_EVP_HIP_MARCH_OVERLAP"))) &&
+                         !(env_test("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env_test("CICE_EVP_HIP_MARCH_DIRECT")));
     for (int k = 0; k < npass; ++k) {
         // the ring of the new state travels after this pass when the next one needs more valid cells than are left, and after the
         // last one (the way back to the block layout reads the ghost cells from it)
@@ -791,12 +807,13 @@ int march_run(int ndte)
             HIPC(hipStreamWaitEvent(S.stream_comm, B.ev_in, 0));
             EvpMarch E = A;
             E.items = B.band_items;
-            E.nitems = B.nband;
-            E.last = 0;                                          // (the diagnostics are the pass's business)
+            E.nitems = B.nband;                                  // (the last pass: the band's diagnostics are this launch's business)
             evp_launch_march(E, S.prm.strict != 0, cap_mode(), S.stream_comm);
             if (int e = march_send_recv(B.st[rc ^ 1], EVP_MARCH_S_NF, S.stream_comm)) return e;
+            A.items = B.rest_items;                              // the pass itself: everything else
+            A.nitems = B.nrest;
         }
-        evp_launch_march(A, S.prm.strict != 0, cap_mode(), S.stream);
+        if (A.nitems > 0) evp_launch_march(A, S.prm.strict != 0, cap_mode(), S.stream);
         rc ^= 1;
         if (exch && overlap) {
             HIPC(hipEventRecord(B.ev_main, S.stream));

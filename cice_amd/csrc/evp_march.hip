@@ -580,10 +580,11 @@ __global__ __launch_bounds__(256) void march_pack_direct(const double *__restric
         }
     }
 }
-__global__ __launch_bounds__(256) void march_unpack_direct(double *__restrict__ buf, double *__restrict__ buf2, int nf,
-                                                           const int *__restrict__ pos1, const int *__restrict__ pos2, int n, EvpRingCuts C,
-                                                           EvpMarchDirect D, unsigned seq, const double *__restrict__ verify,
-                                                           unsigned *__restrict__ bad)
+// The wait for the peers' flags is a launch of its own, ONE wave: the unpack kernel behind it on the stream then never spins.
+// (As one kernel -- every workgroup of the unpack polling before it read its share -- a large ring filled the whole GPU with
+// spinning workgroups: harmless on a GPU of the rank's own, a deadlock until the time-out when two ranks rehearse on ONE GPU
+// and the peer's pack kernel finds no CU to run on.  Round 6: 3600 x 2400 as two processes, ring of eight cells.)
+__global__ __launch_bounds__(64) void march_wait_direct(EvpMarchDirect D, unsigned seq)
 {
     if ((int)threadIdx.x < D.npeers && __hip_atomic_load(D.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         const unsigned *f = D.flags_in + (size_t)threadIdx.x * 16;
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void march_unpack_direct(double *__restrict__ 
         for (;;) {
             const unsigned have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((int)(have - seq) >= 0) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(8);
             if ((++spins & 1023u) == 0 &&
                 (wall_clock64() - t0 > D.timeout_ticks || __hip_atomic_load(D.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                 atomicCAS(D.err, 0, 1 + (int)threadIdx.x);       // which peer never arrived
@@ -600,8 +601,13 @@ __global__ __launch_bounds__(256) void march_unpack_direct(double *__restrict__ 
             }
         }
     }
-    __syncthreads();
-    // (no acquire fence either -- it would invalidate the L2 once per workgroup: the inbox is read past the caches, after the flag)
+}
+__global__ __launch_bounds__(256) void march_unpack_direct(double *__restrict__ buf, double *__restrict__ buf2, int nf,
+                                                           const int *__restrict__ pos1, const int *__restrict__ pos2, int n, EvpRingCuts C,
+                                                           EvpMarchDirect D, unsigned seq, const double *__restrict__ verify,
+                                                           unsigned *__restrict__ bad)
+{
+    // (no acquire fence -- it would invalidate the L2 once per workgroup: the inbox is read past the caches, after the flags)
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n * nf) return;
     const double v = __hip_atomic_load(D.inbox + (size_t)(seq & 1u) * D.inbox_pstride + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -703,6 +709,7 @@ void evp_launch_march_unpack_direct(double *buf, double *buf2, int nf, const int
                                     const EvpMarchDirect &D, unsigned seq, const double *verify, unsigned *bad, hipStream_t st)
 {
     const unsigned nwg = (unsigned)std::max<size_t>(1, ((size_t)n * nf + 255) / 256);
+    hipLaunchKernelGGL(march_wait_direct, dim3(1), dim3(64), 0, st, D, seq);
     hipLaunchKernelGGL(march_unpack_direct, dim3(nwg), dim3(256), 0, st, buf, buf2, nf, pos1, pos2, n, C, D, seq, verify, bad);
 }
 void evp_launch_march_pack_mask(const uint8_t *mask, const int *idx, int n, double *out, hipStream_t st)

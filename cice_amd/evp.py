@@ -39,7 +39,7 @@ EXPORTS = [
     "cice_evp_hip_abi_version", "cice_evp_hip_last_error", "cice_evp_hip_init",
     "cice_evp_hip_set_metrics", "cice_evp_hip_run", "cice_evp_hip_finalize",
     "cice_evp_hip_upload", "cice_evp_hip_subcycle", "cice_evp_hip_download", "cice_evp_hip_sync",
-    "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_get_timings",
+    "cice_evp_hip_comm_unique_id", "cice_evp_hip_comm_init", "cice_evp_hip_comm_info", "cice_evp_hip_get_timings",
     "cice_evp_hip_time_kernels", "cice_evp_hip_mark", "cice_evp_hip_seam_fin_plan",
     "cice_evp_hip_cgrid_set_prep_geometry", "cice_evp_hip_cgrid_prep", "cice_evp_hip_cgrid_seabed_lkd", "cice_evp_hip_cgrid_seabed_prob",
     "cice_evp_hip_cgrid_prep_finish", "cice_evp_hip_cgrid_fetch", "cice_evp_hip_cgrid_set_tb", "cice_evp_hip_describe_path",
@@ -568,6 +568,14 @@ class EvpHip:
 
         self._test_cb = (XF(x_c), RF(r_c))
         _check(self.lib, self.lib.cice_evp_hip_set_test_transport(self._test_cb[0], self._test_cb[1], None), "(set_test_transport)")
+
+    def comm_info(self) -> dict:
+        """What RCCL reports about this rank's communicator, and the PCI bus id of its device."""
+        v = np.full(5, -1, dtype=np.int32)
+        buf = C.create_string_buffer(64)
+        _check(self.lib, self.lib.cice_evp_hip_comm_info(_ip(v), 5, buf, C.c_int32(64)), "(comm_info)")
+        return dict(have_comm=bool(v[0] == 1), rccl_nranks=int(v[1]), rccl_rank=int(v[2]), rccl_device=int(v[3]),
+                    hip_device=int(v[4]), device_bus_id=buf.value.decode(errors="replace"))
 
     def describe_path(self) -> str:
         buf = C.create_string_buffer(600)

@@ -339,6 +339,10 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n);
  * (MPI_Bcast in CICE; torch.distributed in bench.py).                          */
 int cice_evp_hip_comm_unique_id(void *id128);
 int cice_evp_hip_comm_init(const void *id128);
+/* What RCCL itself says about the communicator of this rank, for logs and for reading a first multi-GPU run (bench.py prints it
+ * per rank): out[0] 1 = a communicator exists, [1] ncclCommCount (ranks RCCL sees), [2] ncclCommUserRank, [3] ncclCommCuDevice,
+ * [4] the HIP device this rank runs on; bus_id (may be NULL): that device's PCI bus id ("0000:c1:00.0"), nb bytes.            */
+int cice_evp_hip_comm_info(int32_t *out, int32_t n, char *bus_id, int32_t nb);
 /* Mailbox halo inside one node: neighbouring ranks store ghost values straight into each
  * other's HIP-IPC-mapped inboxes from a kernel (plain stores over xGMI + a flag handshake),
  * so the whole subcycle loop -- exchange included -- is one hipGraph.  Replaces the same

@@ -160,3 +160,14 @@ def max_rel_err(got: dict, want: dict, keys):
         scale = max(np.abs(want[k]).max(), 1e-300)
         worst = max(worst, np.abs(got[k] - want[k]).max() / scale)
     return worst
+
+
+# The default GPU suite has to fit the driver's time limit with room to spare (round-5 review: keep it under ~8 minutes).
+# Cases that repeat a path another case already pins (another cut of the same grid, one more seed) run when
+# EVP_GPU_SUITE=full -- as the wide sweeps do through their *_SWEEP_SEEDS switches; their logs go under profiles/.
+FULL_SUITE = __import__("os").environ.get("EVP_GPU_SUITE", "") == "full"
+
+
+def wide(cases):
+    """`cases` in the full run, nothing in the default one (use inside a parametrize list: [...] + wide([...]))."""
+    return list(cases) if FULL_SUITE else []

@@ -111,8 +111,9 @@ def test_cgrid_resident_kernel_bitwise(monkeypatch):
     """The on-chip resident C-grid kernel (evp_cgrid_res.hip: all subcycles of a call but the first after an upload in ONE launch,
     state in registers and LDS, face velocities traded between windows as tagged records) forced on: every fixture it is
     eligible for -- one rank, no T-fold, the default-configuration shortcuts -- bit-identical to the
-    reference's arrays, ghost cells included, in one call and across calls; the others must refuse loudly.  Forced off, the
-    one-launch kernel gives the same bits."""
+    reference's arrays, ghost cells included, in one call and across calls; a cut it can never run refuses loudly, a call whose
+    operands stand in the way (seabed stress) falls back to the one-launch kernel.  Forced off, the one-launch kernel gives the
+    same bits."""
     ran, refused = [], []
     for name in CGRID_CASES:
         c = GoldenCase(name)
@@ -135,8 +136,14 @@ def test_cgrid_resident_kernel_bitwise(monkeypatch):
                         assert_bitwise(out, c.cgrid_expected(icall, nsub), f"{name} call {icall} nsub {nsub} (C grid, resident {forced})")
                         res = core.cgrid_timings()["resident_subcycles"]
                         if forced == "1" and nsub >= 4:
-                            assert res == nsub - 1, (name, nsub, res)
-                            ran.append(name)
+                            # forced on, the kernel runs -- or, where a condition of THIS call stands in the way (seabed stress,
+                            # waterx != uocn: the fixtures named for it), the call falls back like any later one would (round-5
+                            # advice: only static ineligibility is an error)
+                            if res == 0 and "seabed" in name:
+                                refused.append((name, "per-call condition: fell back"))
+                            else:
+                                assert res == nsub - 1, (name, nsub, res)
+                                ran.append(name)
                         if forced == "0":
                             assert res == 0
                     else:
@@ -259,9 +266,12 @@ def test_cgrid_resident_kernel_runs_only_the_windows_with_ice(monkeypatch):
     off, t0 = run(CICE_EVP_HIP_CGRID_RESIDENT="0")
     assert t0["resident_subcycles"] == 0 and t0["one_launch_subcycles"] > 0
     assert_bitwise(off, want, "C grid, 720 x 270 caps, one-launch kernel")
-    # every window forced to run: too many for the chip -- the library must say so when the kernel is demanded
-    with pytest.raises(evp.EvpHipError, match="not applicable"):
-        run(CICE_EVP_HIP_CGRID_RESIDENT="1", CICE_EVP_HIP_CGRID_RES_CULL="0")
+    # every window forced to run: too many for the chip.  Demanding the kernel does not make that an error (round-5 advice: only what
+    # can never change -- tables, geometry, rank layout -- is; how many windows a call wants resident is a condition of the call):
+    # the call goes through the one-launch kernel, as it would once the resident kernel had run
+    allw, ta = run(CICE_EVP_HIP_CGRID_RESIDENT="1", CICE_EVP_HIP_CGRID_RES_CULL="0")
+    assert ta["resident_subcycles"] == 0 and ta["one_launch_subcycles"] > 0, ta
+    assert_bitwise(allw, want, "C grid, 720 x 270 caps, resident kernel demanded with every window: fell back")
 
 
 @pytest.mark.parametrize("grid", ["gx3", "tx1"])

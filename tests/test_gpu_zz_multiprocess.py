@@ -10,6 +10,8 @@ from pathlib import Path
 
 import pytest
 
+from common import FULL_SUITE, wide
+
 pytestmark = pytest.mark.gpu
 
 
@@ -20,9 +22,12 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,workload,shape,resident", [(2, "gx3", "", True), (4, "gx3", "2x2", True),
-                                                           (2, "gx1", "1x2", False), (4, "gx3", "2x2", "prep"),
-                                                           (2, "tx1", "1x2", True), (8, "gx3", "2x4", True),
+@pytest.mark.parametrize("world,workload,shape,resident", wide([(8, "gx3", "2x4", True), (4, "tx1", "4x1", True), (4, "tx1", "2x2", False),
+                                                                (2, "tx1", "2x1", "prep_stream"), (2, "360x240:tripoleT", "1x2", False),
+                                                                (4, "100x116:tripoleT", "4x1", False), (4, "gx3", "2x2", "prep")]) + [
+                                                           (2, "gx3", "", True), (4, "gx3", "2x2", True),
+                                                           (2, "gx1", "1x2", False),
+                                                           (2, "tx1", "1x2", True),
                                                            (2, "gx3", "1x2", "blocks"),
                                                            # fold row split in x: the on-chip kernel, seam partners on different
                                                            # ranks trading their raw records through the peers' buffers (round 4)
@@ -30,22 +35,21 @@ def _free_port():
                                                            # ranks of the fold row that hold neither a pole point nor a whole pair
                                                            # (3 x 1, 4 x 1: found two ranks running without any fold handling), and
                                                            # the natural cut of tx1 on eight GPUs
-                                                           (3, "tx1", "3x1", True), (4, "tx1", "4x1", True), (8, "tx1", "4x2", True),
-                                                           (2, "tx1", "2x1", False), (4, "tx1", "2x2", False),
+                                                           (3, "tx1", "3x1", True), (8, "tx1", "4x2", True),
+                                                           (2, "tx1", "2x1", False),
                                                            # evp()'s preparation phase on a tripole grid cut in y
                                                            (2, "tx1", "1x2", "prep"),
                                                            # ... and with the fold row split in x: T-grid ghost cells across the
                                                            # fold and the stress symmetrisation through shifted copies
-                                                           (2, "tx1", "2x1", "prep_stream"), (4, "tx1", "2x2", "prep_stream"),
+                                                           (4, "tx1", "2x2", "prep_stream"),
                                                            # ... and the same preparation followed by the on-chip kernel
                                                            (2, "tx1", "2x1", "prep"),
                                                            # ns_boundary_type = 'tripoleT' over several ranks (late round 4): the top
                                                            # physical row is an image of row NY-1 -- receive lists name interior
                                                            # cells, the exchange follows the launch (streaming kernel): the fold
                                                            # row cut in x, in y only, both, odd sizes
-                                                           (2, "360x240:tripoleT", "2x1", False), (2, "360x240:tripoleT", "1x2", False),
+                                                           (2, "360x240:tripoleT", "2x1", False),
                                                            (4, "360x240:tripoleT", "2x2", False), (3, "126x60:tripoleT", "3x1", False),
-                                                           (4, "100x116:tripoleT", "4x1", False),
                                                            # ... and its preparation phase on the device, ranks cut in y (end of
                                                            # round 4: the T-fold rule of the cell-centre fields stays on the top rank)
                                                            (2, "120x80:tripoleT", "1x2", "prep_stream")])
@@ -141,7 +145,7 @@ def test_bench_self_launches_when_started_bare():
     assert all(q["halo_transport"] in ("mailbox", "rccl") for q in d["config"]["per_rank"])
     sec = d["secondary"]
     assert sec["verified"] is True and sec["finite"] and sec["value"] > 0 and [q["rank"] for q in sec["per_rank"]] == [0, 1]
-    assert "ring_exchange_overlapped" not in sec and "configs2_gx1_ndte240" not in d and "tripole" not in d
+    assert "ring_exchange_after_the_pass" not in sec and "configs2_gx1_ndte240" not in d and "tripole" not in d
     assert "skipped" in d["rccl_control"]
 
 
@@ -157,7 +161,7 @@ def test_bench_multi_rank_rehearsal():
     root = Path(__file__).resolve().parents[1]
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx1", "--extras", "configs2,tripole,s01,ring_variants"]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "gx1", "--extras", "configs2,tripole,s01" + (",ring_variants" if FULL_SUITE else "")]
     env = dict(os.environ, CICE_EVP_BENCH_REHEARSAL="1", CICE_EVP_HIP_HALO_TIMEOUT_MS="20000")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -174,6 +178,10 @@ def test_bench_multi_rank_rehearsal():
     pr = d["config"]["per_rank"]
     assert [q["rank"] for q in pr] == [0, 1] and all(q["halo_transport"] == "mailbox" and q["halo_send_cells"] > 0 for q in pr)
     assert all(q["stream_ms"] > 0 and q["wall_ms"] >= 0.5 * q["stream_ms"] and q["local_cells"] > 0 for q in pr)
+    # what RCCL itself reports per rank and the device's PCI bus id (the rehearsal has no communicator: -1, but the fields and a
+    # bus id are there; on a node rccl_nranks == N and N different bus ids are what a reader checks)
+    assert all({"rccl_nranks", "rccl_rank", "rccl_device", "hip_device", "device_bus_id"} <= set(q) for q in pr), pr
+    assert all(q["rccl_nranks"] == -1 and len(q["device_bus_id"]) >= 7 for q in pr), pr
     # configs[2]: gx1 at ndte = 240, verified against its own committed checksum; the forced-RCCL leg cannot run here
     c2 = d["configs2_gx1_ndte240"]
     lib = c2["library_default"]
@@ -184,9 +192,10 @@ def test_bench_multi_rank_rehearsal():
     # state with the exchange overlapped with the pass
     sec = d["secondary"]
     assert sec["verified"] is True and sec["finite"] and sec["tile_variant"] >= 3000, sec
-    assert sec["ring_exchange_overlapped"]["finite"] and sec["ring_exchange_overlapped"]["us_per_subcycle"] > 0
-    dx = sec["ring_exchange_direct_ipc"]
-    assert dx["finite"] and dx["us_per_subcycle"] > 0 and dx["ring"] == "direct stores (HIP IPC)", dx
+    if FULL_SUITE:      # (the other two forms of the ring on the same state; in the default run tools/mailbox_2proc.py --march pins them)
+        assert sec["ring_exchange_after_the_pass"]["finite"] and sec["ring_exchange_after_the_pass"]["us_per_subcycle"] > 0
+        dx = sec["ring_exchange_direct_ipc"]
+        assert dx["finite"] and dx["us_per_subcycle"] > 0 and dx["ring"] == "direct stores (HIP IPC)", dx
     # configs[3]: the tripole grid in its natural (most square) cut -- here 2 x 1, the fold row split in x --, the on-chip kernel
     # on both ranks, seam partners trading raw records across the rank boundary
     tp = d["tripole"]
@@ -194,23 +203,23 @@ def test_bench_multi_rank_rehearsal():
     assert tp["tile_variant"] >= 2000 and [q["rank"] for q in tp["per_rank"]] == [0, 1]
 
 
-@pytest.mark.parametrize("world,workload,shape,extra", [(2, "gx3", "", []), (4, "gx3", "2x2", ["--blocks-per-rank", "2x2", "--timing"]),
+@pytest.mark.parametrize("world,workload,shape,extra", wide([(2, "gx3", "", []), (2, "gx1", "1x2", ["--maskhalo", "--case", "caps"]),
+                                                             (2, "gx3", "2x1", ["--prep", "--case", "caps"]), (2, "120x80:tripoleT", "1x2", [])]) + [
+                                                        (4, "gx3", "2x2", ["--blocks-per-rank", "2x2", "--timing"]),
                                                         (2, "gx1", "1x2", ["--visc", "avg_strength"]),
                                                         (4, "gx1", "2x2", ["--timing"]),
                                                         # maskhalo_dyn for the C-grid loop: every in-loop exchange through the
                                                         # masked halo (five-point dilation of iceTmask); ice in two caps only
-                                                        (2, "gx1", "1x2", ["--maskhalo", "--case", "caps"]),
                                                         (4, "gx3", "2x2", ["--maskhalo", "--case", "caps", "--blocks-per-rank", "2x2"]),
                                                         # tripole grid cut in y: the rank with the fold rows does the
                                                         # fold steps, every rank the five-phase schedule
                                                         (2, "tx1", "1x2", []), (3, "tx1", "1x3", ["--blocks-per-rank", "2x1"]),
                                                         # the preparation phase on the device on every rank (T-grid halos and
                                                         # the E / N velocity averages across ranks), then the loop
-                                                        (2, "gx3", "2x1", ["--prep", "--case", "caps"]),
                                                         (4, "gx1", "2x2", ["--prep", "--blocks-per-rank", "2x1"]),
                                                         (2, "tx1", "1x2", ["--prep"]),
                                                         # tripoleT, ranks cut in y (end of round 4): T-fold lists on the top rank
-                                                        (2, "120x80:tripoleT", "1x2", []), (2, "120x80:tripoleT", "1x2", ["--prep"])])
+                                                        (2, "120x80:tripoleT", "1x2", ["--prep"])])
 def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
     """The C-grid subcycle split over `world` ranks (processes sharing this box's GPU): ghost cells that mirror
     cells of other ranks are filled through the mailbox transport after every producing launch -- five exchange
@@ -238,16 +247,16 @@ def test_cgrid_across_processes_on_one_gpu(world, workload, shape, extra):
     assert r.returncode == 0 and "MAILBOX_2PROC OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("world,workload,shape,extra,ext", [(2, "gx1", "2x1", [], "4"), (2, "gx1", "1x2", ["--timing"], "2"),
+@pytest.mark.parametrize("world,workload,shape,extra,ext", wide([(4, "gx1", "4x1", [], "0"), (2, "gx3", "2x1", [], "6")]) + [
+                                                            (2, "gx1", "2x1", [], "4"), (2, "gx1", "1x2", ["--timing"], "2"),
                                                             (4, "gx1", "2x2", ["--blocks-per-rank", "2x1"], "4"),
-                                                            (4, "gx1", "4x1", [], "0"),
                                                             # pieces narrower than one strip, an odd split, a wide rim
-                                                            (2, "gx3", "2x1", [], "6"), (3, "gx3", "3x1", ["--timing"], "2"),
-                                                            (4, "gx3", "2x2", [], "6")])
+                                                            (3, "gx3", "3x1", ["--timing"], "2"),
+                                                            (4, "gx3", "2x2", [], "8")])
 def test_two_subcycle_kernel_across_processes_on_one_gpu(world, workload, shape, extra, ext):
-    """The two-subcycles-per-pass path in its several-rank form, as `world` processes sharing this box's GPU: every rank
-    plans from the global block table (rectangles of all ranks, ring lists in one canonical order), holds its piece plus a
-    redundant rim, exchanges the ring every (ext/2 + 1)-th pass and agrees with the others on path and verdicts.  The
+    """The marching path (several subcycles per pass) in its several-rank form, as `world` processes sharing this box's GPU: every
+    rank plans from the global block table (rectangles of all ranks, ring lists in one canonical order), holds its piece plus a
+    redundant rim, exchanges the four-cell ring every (ext + 4)-th subcycle and agrees with the others on path and verdicts.  The
     exchanges and agreements go through the library's test transport (host buffers + torch.distributed gloo: RCCL refuses
     two ranks per device) -- plan, pack / unpack, schedule and kernels are the product's.  Every rank's velocities,
     stresses and diagnostics, ghost cells of the velocities included, equal the single-rank run bit for bit; --timing
@@ -260,6 +269,8 @@ def test_two_subcycle_kernel_across_processes_on_one_gpu(world, workload, shape,
            str(root / "tools" / "mailbox_2proc.py"), "--march", "--workload", workload, "--ndte", "24", "--shape", shape] + extra
     env = dict(os.environ, CICE_EVP_HIP_HALO_TIMEOUT_MS="20000", CICE_EVP_HIP_MARCH="1", CICE_EVP_HIP_RESIDENT="0",
                CICE_EVP_HIP_MARCH_SEG="24", CICE_EVP_HIP_MARCH_EXT=ext,
+               # four, three or two subcycles per pass (every rank the same: the ring is exchanged between the passes)
+               CICE_EVP_HIP_MARCH_K=str(2 + int(ext) // 2 % 3),
                # every other layout with the exchange overlapped (early launch of the cells the neighbours wait for: N-S and
                # E-W cuts, corners, several blocks per rank)
                CICE_EVP_HIP_MARCH_OVERLAP=str(int(ext) // 2 % 2 if shape != "2x2" else 1),

@@ -20,7 +20,7 @@ N_SIMD = 1024            # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 N_XCD = 8
 MAX_CLOCK_HZ = 2.4e9
 
-DOMINANT = {"gx1res": "evp_resident", "gx1str": "evp_subcycle_tile", "s01str": "evp_subcycle_tile", "s01march": "evp_march2"}
+DOMINANT = {"gx1res": "evp_resident", "gx1str": "evp_subcycle_tile", "s01str": "evp_subcycle_tile", "s01march": "evp_march"}
 
 
 def counters(path: Path, match: str):
