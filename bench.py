@@ -939,13 +939,13 @@ def main():
     M2o = None
     if want("s01") and a.workload != "s01":
         try:      # the 0.1-degree-class grid the strong-scaling target is stated on (streaming kernel, HBM-bound)
-            # (N > 1: the library's default overlaps the ring exchange with the interior of the pass -- early launch of the
-            # (strip, row) units the neighbours wait for, pack + RCCL send / recv on the second stream, everything else on the
-            # compute stream.  Timed a second time on the same ranks and state with pack, send / recv and unpack AFTER the pass
-            # (the test build's CICE_EVP_HIP_MARCH_OVERLAP=0), and a third time with the ring not through RCCL but as stores into
-            # the neighbours' HIP-IPC-mapped inboxes; all three are reported)
+            # (N > 1: timed a second time on the same ranks and state with the ring exchange overlapped with the interior of the
+            # pass (CICE_EVP_HIP_MARCH_OVERLAP=1: early launch of the (strip, row) units the neighbours wait for, pack + RCCL send /
+            # recv on the second stream, every other unit on the compute stream -- a loss on one GPU, meant for real xGMI), and a
+            # third time with the ring not through RCCL but as stores into the neighbours' HIP-IPC-mapped inboxes; all three are
+            # reported)
             M2 = measure_with_fallbacks("s01", "full", 480, 2, 1,
-                                        again_env=([{"CICE_EVP_HIP_MARCH_OVERLAP": "0"}, {"CICE_EVP_HIP_MARCH_DIRECT": "1"}]
+                                        again_env=([{"CICE_EVP_HIP_MARCH_OVERLAP": "1"}, {"CICE_EVP_HIP_MARCH_DIRECT": "1"}]
                                                    if (world > 1 and "ring_variants" in a.extras) else None))
             M2o = M2.get("again")
         except Exception as e:  # noqa: BLE001
@@ -1206,7 +1206,7 @@ def main():
                 "attempts": M2.get("attempts"), "per_rank": M2.get("per_rank")}
             for Mo in (M2o or []):
                 direct = "CICE_EVP_HIP_MARCH_DIRECT" in Mo["env"]
-                res["secondary"]["ring_exchange_direct_ipc" if direct else "ring_exchange_after_the_pass"] = {
+                res["secondary"]["ring_exchange_direct_ipc" if direct else "ring_exchange_overlapped"] = {
                     "value": c2 * 480 * 2 / Mo["dt"], "us_per_subcycle": 1e6 * Mo["dt"] / (2 * 480), "finite": Mo["finite"],
                     "ring": Mo.get("ring"),
                     "verified": None, "why_unverified": "continues from the verified run's state (no checksum that far); bit-identity of this "
@@ -1214,9 +1214,9 @@ def main():
                     "note": ("CICE_EVP_HIP_MARCH_DIRECT=1: no RCCL -- the pack kernel stores into the neighbours' HIP-IPC-mapped inboxes, "
                              "flags instead of send / recv (off by default: no faster where the transfer is a device copy, never measured "
                              "over xGMI); 'ring' says whether the trial exchange let it be used") if direct else
-                            ("CICE_EVP_HIP_MARCH_OVERLAP=0 (test build): pack, RCCL send / recv and unpack after the pass on the compute "
-                             "stream -- the form before round 6; the default advances the cells other ranks wait for first, on the second "
-                             "stream, and overlaps their transfer with the rest of the pass")}
+                            ("CICE_EVP_HIP_MARCH_OVERLAP=1: the (strip, row) units other ranks wait for advanced first on the second stream, "
+                             "pack + RCCL send / recv overlapped with the rest of the pass (off by default: a loss where the transfer is "
+                             "a device copy -- profiles/r06_ring_rank.txt)")}
         for k_, v_ in extra_err.items():
             res[k_] = {"error": v_}
         res.update(extra)

@@ -99,11 +99,13 @@ static bool march_geometry(std::string &why)
     if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
     M.ring_valid = ext + EVP_MARCH_PAD;
     // Subcycles per pass.  Round 6 measured what binds the kernel: a wave issues one instruction per 2.4 ns whatever it is, and a
-    // row costs ~640 instructions per level plus ~350 that do not depend on the number of levels (loads, stores, addressing); a
-    // segment of sl rows marches sl + 2K - 1.  Cost per stored row and subcycle ~ (sl + 2K - 1) / sl * (640 + 350 / K): four levels
-    // from 46 rows per segment (3600 x 2400 on one GPU: 160), three from 23, two below (its 8 x 1 pieces: ~22 rows).  Every rank
-    // must run the same passes (the ring is exchanged between them), so the rule looks at the SHORTEST segment of any rank, which
-    // every rank works out from the global block table alone.  The test build can ask for a value.
+    // row costs ~640 instructions per level plus ~350 that do not depend on the number of levels (loads, stores, addressing, the
+    // register pipelines); a segment of sl rows marches sl + 2K - 1, the warm-up rows with part of the levels idle.  Measured on
+    // the 8 x 1 and 4 x 2 pieces of 3600 x 2400 (22- and 20-row segments, profiles/r06_ring_rank.txt): 58.0 / 50.0 / 49.1 and
+    // 54.9 / 46.8 / 46.0 us per subcycle with two / three / four subcycles per pass; 3600 x 2400 itself (160 rows) 362 / 315 / 293.
+    // Four from 12 rows per segment, three from 8, two below.  Every rank must run the same passes (the ring is exchanged between
+    // them), so the rule looks at the SHORTEST segment of any rank, which every rank works out from the global block table alone.
+    // The test build can ask for a value.
     {
         int slmin = 1 << 30;
         for (const MarchRect &R : PL.all) {
@@ -113,7 +115,7 @@ static bool march_geometry(std::string &why)
             const int nseg = std::max(1, 1024 / ns);
             slmin = std::min(slmin, std::max(6, (R.nyr + grow + nseg - 1) / nseg));
         }
-        M.kpass = slmin >= 46 ? 4 : slmin >= 23 ? 3 : 2;
+        M.kpass = slmin >= 12 ? 4 : slmin >= 8 ? 3 : 2;
     }
     if (env_test("CICE_EVP_HIP_MARCH_K")) M.kpass = std::min(EVP_MARCH_KMAX, std::max(2, std::atoi(env_test("CICE_EVP_HIP_MARCH_K"))));
     if (PL.peers.size() > (size_t)EVP_MARCH_DIRECT_MAXPEER) { why = "more ring neighbours than the exchange lists hold"; return false; }
@@ -784,12 +786,15 @@ int march_run(int ndte)
     const int npass = (int)sizes.size();
     int rc = 0;
     int valid = M.ring_valid;        // cells beyond the rank's own that hold the current state (the gather's exchange just filled them)
-    // The default since round 6 (the test build's CICE_EVP_HIP_MARCH_OVERLAP=0 puts pack, send / recv and unpack after the pass on
-    // the compute stream: the fallback form, and the one the direct-store ring uses).  Rounds 4-5 had it opt-in because the early
-    // launch advanced the band a SECOND time (57.7 against 51.2 us per subcycle on the 450 x 2400 piece, one GPU, ring exchanged
-    // with the rank itself); with the band taken out of the pass there is no second time.
+    // Opt-in, in the PRODUCT library too (CICE_EVP_HIP_MARCH_OVERLAP=1; every rank alike): where it can be measured -- one GPU, the
+    // ring exchanged with the rank itself, profiles/r06_ring_rank.txt -- it still loses, 64.2 against 57.3 us per subcycle on the
+    // 450 x 2400 piece and 61.2 against 56.9 on 900 x 1200, although the two launches no longer advance the band twice (rounds 4-5:
+    // 57.7 against 51.2): the pass is bound by instruction issue with every SIMD holding one wave for the whole pass, so there is
+    // no idle resource to hide a transfer under, and "early" means SHORT segments for the band -- 2K - 1 rows of warm-up on 7 stored.
+    // On one GPU the transfer is a 7-us device copy; over xGMI it is 1.6 MB per neighbour every eighth subcycle, and only a node
+    // can say whether hiding that is worth 6 us per subcycle.  bench.py --gpus N --extras ring_variants times both.
     const bool overlap = !PL.peers.empty() && B.nband > 0 && M.direct != 1 &&
-                         !(env_test("CICE_EVP_HIP_MARCH_OVERLAP") && !std::atoi(env_test("CICE_EVP_HIP_MARCH_OVERLAP"))) &&
+                         env("CICE_EVP_HIP_MARCH_OVERLAP") && std::atoi(env("CICE_EVP_HIP_MARCH_OVERLAP")) &&
                          !(env_test("CICE_EVP_HIP_MARCH_DIRECT") && std::atoi(env_test("CICE_EVP_HIP_MARCH_DIRECT")));
     for (int k = 0; k < npass; ++k) {
         // the ring of the new state travels after this pass when the next one needs more valid cells than are left, and after the

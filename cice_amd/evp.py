@@ -69,7 +69,7 @@ TEST_ENV = [
     "CICE_EVP_HIP_PREFETCH", "CICE_EVP_HIP_FAULT_REPLAY", "CICE_EVP_HIP_MARCH_BANDSEG", "CICE_EVP_HIP_CGRID_PROF",
     # A/B switches of kernels and transports (forced tile shapes, schedules the default never picks, the ring exchange's other forms)
     "CICE_EVP_HIP_NO_OVERLAP", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_NOGRAPH", "CICE_EVP_HIP_GRAPH_RCCL", "CICE_EVP_HIP_RES_LOGW", "CICE_EVP_HIP_RES_COOP",
-    "CICE_EVP_HIP_MARCH_EXT", "CICE_EVP_HIP_MARCH_DIRECT", "CICE_EVP_HIP_MARCH_OVERLAP", "CICE_EVP_HIP_CGRID_FUSED", "CICE_EVP_HIP_CGRID_GEO",
+    "CICE_EVP_HIP_MARCH_EXT", "CICE_EVP_HIP_MARCH_DIRECT", "CICE_EVP_HIP_CGRID_FUSED", "CICE_EVP_HIP_CGRID_GEO",
     "CICE_EVP_HIP_CGRID_RES_SLEEP", "CICE_EVP_HIP_CGRID_RES_CULL", "CICE_EVP_HIP_CGRID_RES_DEBUG",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h

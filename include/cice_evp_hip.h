@@ -396,7 +396,9 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
  * 1 stores into the neighbours' HIP-IPC-mapped inboxes (opt-in: CICE_EVP_HIP_MARCH_DIRECT=1 on every rank, inside one
  * node; in use once a trial exchange has delivered the same bits as RCCL on every rank), 2 on trial; [8] (n >= 10) subcycles
  * a full pass advances the state by (4), [9] subcycles advanced by passes since init.
- * CICE_EVP_HIP_MARCH=0/1 forces the path off / on (default: from 450k cells per rank).   */
+ * CICE_EVP_HIP_MARCH=0/1 forces the path off / on (default: from 450k cells per rank).  Several ranks:
+ * CICE_EVP_HIP_MARCH_OVERLAP=1 (every rank alike) advances the cells other ranks wait for first, on a second stream, and
+ * overlaps their RCCL send / recv with the rest of the pass (default: pack, send / recv, unpack after the pass).        */
 int cice_evp_hip_march_info(int32_t *out, int32_t n);
 /* One line of text on what the last cice_evp_hip_subcycle ran (kernel, halo transport, the two-subcycle path and why it is
  * off when it is), for logs.                                                                                       */

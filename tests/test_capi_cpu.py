@@ -59,8 +59,8 @@ def test_product_library_ignores_the_test_builds_switches():
         assert f'env_test("{k}")' in src or f'fault_hook("{k}")' in src, f"{k} listed in evp.TEST_ENV but not read by the test build"
     kept = set(re.findall(r'(?<![_a-z])env\("(CICE_EVP_HIP_\w+)"\)', src))
     assert not kept & set(evp.TEST_ENV)
-    assert kept <= {"CICE_EVP_HIP_" + k for k in ("DEVICE", "VERBOSE", "HALO", "HALO_TIMEOUT_MS", "RESIDENT", "MARCH", "CGRID_ONE",
-                                                  "CGRID_RESIDENT")}, kept
+    assert kept <= {"CICE_EVP_HIP_" + k for k in ("DEVICE", "VERBOSE", "HALO", "HALO_TIMEOUT_MS", "RESIDENT", "MARCH", "MARCH_OVERLAP",
+                                                  "CGRID_ONE", "CGRID_RESIDENT")}, kept
     # ... and the product library does not even carry the other names (env_test is a macro that drops the literal there)
     import subprocess
     names = set(re.findall(r"CICE_EVP_HIP_[A-Z0-9_]+", subprocess.run(["strings", str(evp.LIB_PATH)], capture_output=True, text=True).stdout))

@@ -145,7 +145,7 @@ def test_bench_self_launches_when_started_bare():
     assert all(q["halo_transport"] in ("mailbox", "rccl") for q in d["config"]["per_rank"])
     sec = d["secondary"]
     assert sec["verified"] is True and sec["finite"] and sec["value"] > 0 and [q["rank"] for q in sec["per_rank"]] == [0, 1]
-    assert "ring_exchange_after_the_pass" not in sec and "configs2_gx1_ndte240" not in d and "tripole" not in d
+    assert "ring_exchange_overlapped" not in sec and "configs2_gx1_ndte240" not in d and "tripole" not in d
     assert "skipped" in d["rccl_control"]
 
 
@@ -193,7 +193,7 @@ def test_bench_multi_rank_rehearsal():
     sec = d["secondary"]
     assert sec["verified"] is True and sec["finite"] and sec["tile_variant"] >= 3000, sec
     if FULL_SUITE:      # (the other two forms of the ring on the same state; in the default run tools/mailbox_2proc.py --march pins them)
-        assert sec["ring_exchange_after_the_pass"]["finite"] and sec["ring_exchange_after_the_pass"]["us_per_subcycle"] > 0
+        assert sec["ring_exchange_overlapped"]["finite"] and sec["ring_exchange_overlapped"]["us_per_subcycle"] > 0
         dx = sec["ring_exchange_direct_ipc"]
         assert dx["finite"] and dx["us_per_subcycle"] > 0 and dx["ring"] == "direct stores (HIP IPC)", dx
     # configs[3]: the tripole grid in its natural (most square) cut -- here 2 x 1, the fold row split in x --, the on-chip kernel

@@ -60,7 +60,8 @@ def time_multiproc(wl, N, px, py, ndte=24):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("MAILBOX_2PROC")]
     if r.returncode != 0 or not line or " OK " not in line[-1]:
         raise RuntimeError((line[-1] if line else r.stdout[-300:] + r.stderr[-600:])[:400])
-    res = ast.literal_eval(line[-1][line[-1].index("["):])
+    import re
+    res = ast.literal_eval(re.sub(r"np\.float64\(([^)]*)\)", r"\1", line[-1][line[-1].index("["):]))
     return max(q[2] for q in res), res[0][4], res[0][3]
 
 
