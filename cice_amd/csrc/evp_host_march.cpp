@@ -95,8 +95,38 @@ static bool march_geometry(std::string &why)
     // (ext + P)-th subcycle only (march_plan.h); 4 = after every second pass of four.  (Rounds 4-5, two subcycles per pass and a
     // two-cell ring, 3600 x 2400 as 4x2 pieces, one-GPU rehearsal: 54.3 / 52.3 / 52.0 / 51.2 us per subcycle with ext 0 / 2 / 4 / 6
     // against 47.0 without any exchange.)
-    const int ext = env_test("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env_test("CICE_EVP_HIP_MARCH_EXT")) & ~1) : 4;
-    if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
+    int ext = env_test("CICE_EVP_HIP_MARCH_EXT") ? std::max(0, std::atoi(env_test("CICE_EVP_HIP_MARCH_EXT")) & ~1) : -1;
+    if (ext >= 0) {
+        if (!build_march_plan(d, own_max, wrap_inside, ext, PL)) { why = PL.error; return false; }
+    } else {
+        // Default (round 6): the widest rim of 12 / 8 / 4 cells that costs no rank a strip more than a rim of 4 does and at most 2 %
+        // more rows -- the exchange then comes every 16th / 12th / 8th subcycle for the same bytes per subcycle.  (The 8 x 1 pieces of
+        // 3600 x 2400: 450 + 2 x 12 = 474 columns still fit the 9 strips that 458 need; measured on one GPU, ring exchanged with the
+        // rank itself, an exchange costs ~38 us: 4.8 us per subcycle at every 8th.)  Every rank reaches the same value from the global
+        // block table; a layout the plan refuses (a rank too thin next to a closed boundary) tries the next narrower rim.
+        bool ok = false;
+        std::string first_error;
+        for (int e : {12, 8, 4, 0}) {
+            if (!build_march_plan(d, own_max, wrap_inside, e, PL)) {
+                if (first_error.empty()) first_error = PL.error;
+                continue;
+            }
+            bool fits = true;
+            const bool ew_cyc = d.ew_boundary_type == CICE_EVP_BND_CYCLIC;
+            for (const MarchRect &R : PL.all) {
+                if (!R.ok || e <= 4) continue;
+                const bool span = wrap_inside && ew_cyc && R.nxr == d.nx_global;      // wraps inside: no rim in x
+                const int w = (R.gx0 > 0 || ew_cyc) ? 1 : 0, ea = (R.gx0 + R.nxr < d.nx_global || ew_cyc) ? 1 : 0;
+                const int sn = R.gy0 > 0 ? 1 : 0, nn = R.gy0 + R.nyr < d.ny_global ? 1 : 0;
+                const int own_eff = std::min(own_max > 0 ? own_max : EVP_MARCH_OWN, EVP_MARCH_OWN);
+                const int w4 = R.nxr + (span ? 0 : 4 * (w + ea)), we = R.nxr + (span ? 0 : e * (w + ea));
+                if ((we + own_eff - 1) / own_eff > (w4 + own_eff - 1) / own_eff) fits = false;
+                if ((long)(R.nyr + e * (sn + nn)) * 100 > (long)(R.nyr + 4 * (sn + nn)) * 102) fits = false;
+            }
+            if (fits) { ext = e; ok = true; break; }
+        }
+        if (!ok) { why = first_error.empty() ? PL.error : first_error; return false; }
+    }
     M.ring_valid = ext + EVP_MARCH_PAD;
     // Subcycles per pass.  Round 6 measured what binds the kernel: a wave issues one instruction per 2.4 ns whatever it is, and a
     // row costs ~640 instructions per level plus ~350 that do not depend on the number of levels (loads, stores, addressing, the
