@@ -116,9 +116,11 @@ void evp_launch_resident2(const EvpArgs &A, const EvpResident2 &R, int max_ni, i
                           bool strict, int cap, hipStream_t st);
 
 // Several (2 .. 4) subcycles per pass over a device-private strip-major layout (evp_march.hip, evp_host_march.cpp)
+#ifndef EVP_MARCH_PAD          // (a build-time A/B: -DEVP_MARCH_PAD=3 makes three the most subcycles per pass, strips of 58)
 #define EVP_MARCH_PAD 4        // width of the overlap: lanes on either side of a strip's own columns, halo rows below and above,
                                // halo columns of the row-major byte mask, cells of the ring between ranks = the most subcycles
                                // one pass can advance (validity shrinks by one cell per side and subcycle)
+#endif
 #define EVP_MARCH_KMAX EVP_MARCH_PAD
 #define EVP_MARCH_OWN (64 - 2 * EVP_MARCH_PAD)       // most columns a 64-lane strip can own
 #define EVP_MARCH_S_NF 14      // fields per block: state (u v sig x 12), constants, optional operands, diagnostics

@@ -145,7 +145,7 @@ static bool march_geometry(std::string &why)
             const int nseg = std::max(1, 1024 / ns);
             slmin = std::min(slmin, std::max(6, (R.nyr + grow + nseg - 1) / nseg));
         }
-        M.kpass = slmin >= 12 ? 4 : slmin >= 8 ? 3 : 2;
+        M.kpass = std::min(EVP_MARCH_KMAX, slmin >= 12 ? 4 : slmin >= 8 ? 3 : 2);
     }
     if (env_test("CICE_EVP_HIP_MARCH_K")) M.kpass = std::min(EVP_MARCH_KMAX, std::max(2, std::atoi(env_test("CICE_EVP_HIP_MARCH_K"))));
     if (PL.peers.size() > (size_t)EVP_MARCH_DIRECT_MAXPEER) { why = "more ring neighbours than the exchange lists hold"; return false; }

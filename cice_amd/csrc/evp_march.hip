@@ -664,8 +664,12 @@ void evp_launch_march(const EvpMarch &A, bool strict, int mode, hipStream_t st)
                       !(evp_env_test("CICE_EVP_HIP_MARCH_LEAN") && !std::atoi(evp_env_test("CICE_EVP_HIP_MARCH_LEAN")));
     switch (A.kpass) {
     case 2: launch_march_k<2>(A, strict, mode, lean, grid, block, st); break;
+#if EVP_MARCH_KMAX >= 4
     case 3: launch_march_k<3>(A, strict, mode, lean, grid, block, st); break;
     default: launch_march_k<4>(A, strict, mode, lean, grid, block, st); break;
+#else
+    default: launch_march_k<3>(A, strict, mode, lean, grid, block, st); break;
+#endif
     }
 }
 

@@ -19,7 +19,11 @@
 
 #include "../../include/cice_evp_hip.h"
 
+#ifdef EVP_MARCH_PAD
+#define MARCH_PLAN_PAD EVP_MARCH_PAD
+#else
 #define MARCH_PLAN_PAD 4       // == EVP_MARCH_PAD (evp_device.h; evp_host_march.cpp asserts it)
+#endif
 
 struct MarchRect {
     int gx0 = 0, gy0 = 0;      // global index (0-based) of the first owned cell
