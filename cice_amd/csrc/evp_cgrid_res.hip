@@ -160,7 +160,12 @@ __device__ __forceinline__ void push1(const EvpCgrid &A, size_t c, double *f, do
 // uvelU, vvelU, shearU, stress12U) is what the reference's halo update makes of it in every subcycle, ice or not -- the average of
 // the two raw values, x_lo and x_hi of the pair of columns: s * 0.5 * (x_lo + isign * x_hi), s = 1 for the lower column, isign for the higher
 // (evp_cgrid.hip: cg_fold_gather) -- built from both sides' raw values, which every window at the fold computes itself.
-template <bool AVGS, bool REVP, bool FOLD>
+// SLOW (round 6): the call's operands do not satisfy the default-configuration short cuts -- seabed stress (TbE / TbN != 0), waterx /
+// watery other than the ocean currents (an ocean turning angle), rheofact != 1 on some ice cell.  The six operands the short cuts
+// drop are then read from their arrays at level C, every subcycle, by the thread that owns the cell (the LDS has no room for six
+// more compact planes and the registers none for six more doubles across a subcycle: they come from L2, the wait is once per
+// subcycle), and the momentum step is the general one of stepu_C / stepv_C (ice_dyn_shared.F90:1090-1283), as in cg_one<FAST = false>.
+template <bool AVGS, bool REVP, bool FOLD, bool SLOW>
 __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
 {
     constexpr int PW = (REVP && !AVGS) ? X : LW;         // row stride of the window-only planes
@@ -737,18 +742,28 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             const double s12w = onf ? 0.5 * (s_s12[pt - 1] + s_s12[pU + 1]) : s_s12[pt - 1];       // (the west corner of a fold-row cell: ON the fold)
             const double spc = sp, smc = sm;
             double unew, vnew, strintx, strinty, taubx, tauby;
+            // SLOW: the six operands the short cuts drop, from their arrays (the cell's own: L is the position's source cell)
+            double g_rheoE = 1.0, g_rheoN = 1.0, g_wxE = 0.0, g_wyN = 0.0, g_tbE = 0.0, g_tbN = 0.0;
+            if (SLOW) {
+                g_rheoE = IN(CI_RHEOE)[L]; g_rheoN = IN(CI_RHEON)[L];
+                g_wxE = IN(CI_WATERXE)[L]; g_wyN = IN(CI_WATERYN)[L];
+                g_tbE = IN(CI_TBE)[L]; g_tbN = IN(CI_TBN)[L];
+            }
             // (FOLD: the partner threads run the E-face half too, on operands nobody set and for nobody to read -- one basic block with the
             // N-face half, as in the plain variant)
             {
                 const double spe = s_sp[pt + 1], sme = s_sm[pt + 1];
                 const double uocnE = s_pc[0][oo], vocnE = s_pc[1][oo], facE = s_pc[2][oo], massE = s_pc[3][oo], fmE = s_pc[4][oo], forcexE = s_pc[5][oo];
                 const double zE = REVP ? s_pc[NPC - 2][oo] : ((mb >> 9) & 1u ? -0.0 : 0.0);     // revp * uvelE_init
-                strintx = s_pc[12][oo] * (0.5 * s_dyE[lo] * (spe - spc) + (FOLD ? 0.5 / s_dyE[lo] : hdyEr) * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s));
+                const double strintx_core = 0.5 * s_dyE[lo] * (spe - spc) + (FOLD ? 0.5 / s_dyE[lo] : hdyEr) * ((dyT2e)*sme - (dyT2)*smc) + s_pc[13][oo] * ((dxU * dxU) * s12c - (dxU2s)*s12s);
+                strintx = s_pc[12][oo] * (strintx_core);
+                if (SLOW) strintx = (g_rheoE * s_pc[12][oo]) * (strintx_core);
                 const double uold = uEo, vold = vEo;
                 const double du = uocnE - uold, dv = vocnE - vold;
                 const double vrel = facE * sqrt(du * du + dv * dv);
-                const double taux = vrel * uocnE;
-                const double Cb = 0.0;
+                const double taux = vrel * (SLOW ? g_wxE : uocnE);
+                double Cb = 0.0;
+                if (SLOW) Cb = g_tbE / (sqrt(uold * uold + vold * vold) + p.u0);
                 const double cca = (p.brlx + p.revp) * massE + vrel * p.cosw + Cb;
                 const double ccb = fmE + copysign(1.0, fmE) * vrel * p.sinw;
                 const double cc1 = strintx + forcexE + taux + massE * (p.brlx * uold + zE);
@@ -759,12 +774,14 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 const double spn = s_sp[nCp], smn = s_sm[nCp];
                 const double uocnN = s_pc[6][oo], vocnN = s_pc[7][oo], facN = s_pc[8][oo], massN = s_pc[9][oo], fmN = s_pc[10][oo], forceyN = s_pc[11][oo];
                 const double zN = REVP ? s_pc[NPC - 1][oo] : ((mb >> 10) & 1u ? -0.0 : 0.0);    // revp * vvelN_init
-                strinty = s_pc[14][oo] * (0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w));
+                const double strinty_core = 0.5 * s_dxN[lo] * (spn - spc) - hdxNr * ((dxT2n)*smn - (dxT2)*smc) + s_pc[15][oo] * ((dyU * dyU) * s12c - (dyU2w)*s12w);
+                strinty = (SLOW ? g_rheoN * s_pc[14][oo] : s_pc[14][oo]) * (strinty_core);
                 const double uold = uNo, vold = vNo;
                 const double du = uocnN - uold, dv = vocnN - vold;
                 const double vrel = facN * sqrt(du * du + dv * dv);
-                const double tauy = vrel * vocnN;
-                const double Cb = 0.0;
+                const double tauy = vrel * (SLOW ? g_wyN : vocnN);
+                double Cb = 0.0;
+                if (SLOW) Cb = g_tbN / (sqrt(uold * uold + vold * vold) + p.u0);
                 const double cca = (p.brlx + p.revp) * massN + vrel * p.cosw + Cb;
                 const double ccb = fmN + copysign(1.0, fmN) * vrel * p.sinw;
                 const double cc2 = strinty + forceyN + tauy + massN * (p.brlx * vold + zN);
@@ -920,33 +937,37 @@ int blocks_per_cu(K kernel)
 }
 }  // namespace
 
-int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold)
+int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold, int slow)
 {
-    if (fold) {
-        if (avg_strength) return revised ? blocks_per_cu(cg_res<true, true, true>) : blocks_per_cu(cg_res<true, false, true>);
-        return revised ? blocks_per_cu(cg_res<false, true, true>) : blocks_per_cu(cg_res<false, false, true>);
-    }
-    if (avg_strength) return revised ? blocks_per_cu(cg_res<true, true, false>) : blocks_per_cu(cg_res<true, false, false>);
-    return revised ? blocks_per_cu(cg_res<false, true, false>) : blocks_per_cu(cg_res<false, false, false>);
+#define CGRES_PICK(F)                                                                                                          \
+    do {                                                                                                                       \
+        if (fold) {                                                                                                            \
+            if (slow) { if (avg_strength) { if (revised) F((cg_res<true, true, true, true>)); else F((cg_res<true, false, true, true>)); }      \
+                        else { if (revised) F((cg_res<false, true, true, true>)); else F((cg_res<false, false, true, true>)); } }               \
+            else { if (avg_strength) { if (revised) F((cg_res<true, true, true, false>)); else F((cg_res<true, false, true, false>)); }         \
+                   else { if (revised) F((cg_res<false, true, true, false>)); else F((cg_res<false, false, true, false>)); } }                  \
+        } else {                                                                                                               \
+            if (slow) { if (avg_strength) { if (revised) F((cg_res<true, true, false, true>)); else F((cg_res<true, false, false, true>)); }    \
+                        else { if (revised) F((cg_res<false, true, false, true>)); else F((cg_res<false, false, false, true>)); } }             \
+            else { if (avg_strength) { if (revised) F((cg_res<true, true, false, false>)); else F((cg_res<true, false, false, false>)); }       \
+                   else { if (revised) F((cg_res<false, true, false, false>)); else F((cg_res<false, false, false, false>)); } }                \
+        }                                                                                                                      \
+    } while (0)
+    const int revised_ = revised;
+    (void)revised_;
+#define CGRES_OCC(K) return blocks_per_cu(K)
+    CGRES_PICK(CGRES_OCC);
+#undef CGRES_OCC
+    return 0;
 }
 
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st)
 {
     const dim3 grid(R.ntiles), block(X * Y);
     const bool revised = A.p.revp != 0.0;
-    if (R.fold) {
-        if (A.avg_strength) {
-            if (revised) hipLaunchKernelGGL((cg_res<true, true, true>), grid, block, 0, st, A, R);
-            else hipLaunchKernelGGL((cg_res<true, false, true>), grid, block, 0, st, A, R);
-        } else {
-            if (revised) hipLaunchKernelGGL((cg_res<false, true, true>), grid, block, 0, st, A, R);
-            else hipLaunchKernelGGL((cg_res<false, false, true>), grid, block, 0, st, A, R);
-        }
-    } else if (A.avg_strength) {
-        if (revised) hipLaunchKernelGGL((cg_res<true, true, false>), grid, block, 0, st, A, R);
-        else hipLaunchKernelGGL((cg_res<true, false, false>), grid, block, 0, st, A, R);
-    } else {
-        if (revised) hipLaunchKernelGGL((cg_res<false, true, false>), grid, block, 0, st, A, R);
-        else hipLaunchKernelGGL((cg_res<false, false, false>), grid, block, 0, st, A, R);
-    }
+    const int fold = R.fold, slow = R.slow, avg_strength = A.avg_strength;
+#define CGRES_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, A, R)
+    CGRES_PICK(CGRES_LAUNCH);
+#undef CGRES_LAUNCH
+#undef CGRES_PICK
 }

@@ -406,6 +406,7 @@ struct EvpCgRes {
     const int4 *tiles;            // block, first owned i, first owned j (1-based), fold: fold window | tf << 8 | last owned row << 16
     const int4 *tiles2;           // fold (tripole grids): global column of tile column 0, NX, -, -   (halo_plan.cpp: build_fold_window_table)
     int fold;                     // 1: tripole (u-fold) grid, the kernel's FOLD variant
+    int slow;                     // 1: the SLOW variant (seabed stress, waterx != uocn, rheofact != 1 on some ice cell: general momentum step)
     const int *order;             // [ntiles] window run by workgroup w (NULL: identity): the windows that hold ice in this call
     int ntiles;                   // ... and how many there are
     const uint8_t *live;          // per cell: its window runs in this call (NULL: all do)
@@ -426,7 +427,7 @@ struct EvpCgRes {
     int long_sleep;               // A/B (test build): 512 instead of 64 cycles between two looks at a record
     int dbg;                      // test hooks (test build): 8 every fourth window lags, 16 window 1 never runs (real launches)
 };
-int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold);
+int evp_cgrid_res_max_blocks_per_cu(int avg_strength, int revised, int fold, int slow);
 void evp_launch_cgrid_res_pair_check(const double *const *five, const int2 *pairs, int n, unsigned *flags, hipStream_t st);
 void evp_launch_cgrid_res(const EvpCgrid &A, const EvpCgRes &R, hipStream_t st);
 void evp_launch_cgrid_res_live(const EvpCgrid &A, const int *tab, const int4 *tiles, int ntiles, int fold, int *live_win, uint8_t *live_cell, hipStream_t st);

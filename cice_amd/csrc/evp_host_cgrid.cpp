@@ -62,7 +62,7 @@ struct CGridState {
         std::string why;             // ... or why the kernel is not eligible on this rank
         int mode = -1;               // -1 undecided (first eligible call probes), 0 off, 1 on
         bool launched = false;       // a launch whose error word has not been looked at
-        long cap4[4] = {};           // windows that can be resident at once (occupancy x CUs), by kernel variant (avg_strength | revised << 1)
+        long cap4[8] = {};           // windows that can be resident at once (occupancy x CUs), by kernel variant (avg_strength | revised << 1 | slow << 2)
         double t_probe_ms = -1.0;    // probe: ms per subcycle
         int last_nsub = 0;           // subcycles of the last call that ran inside it
         int fallbacks = 0;           // cice_evp_hip_cgrid_run calls repeated without it after a wait gave up
@@ -675,7 +675,7 @@ static int build_res_tables(const double *const *static23)
     }
     hipDeviceProp_t prop;
     HIPC(hipGetDeviceProperties(&prop, S.device));
-    for (int v = 0; v < 4; ++v) Q.cap4[v] = (long)evp_cgrid_res_max_blocks_per_cu(v & 1, v >> 1, tripole ? 1 : 0) * prop.multiProcessorCount;
+    for (int v = 0; v < 8; ++v) Q.cap4[v] = (long)evp_cgrid_res_max_blocks_per_cu(v & 1, (v >> 1) & 1, tripole ? 1 : 0, v >> 2) * prop.multiProcessorCount;
     return 0;
 }
 
@@ -697,10 +697,10 @@ static bool res_eligible(std::string *why = nullptr, bool *per_call = nullptr)
     if (!Q.tab) return no(Q.why.empty() ? "tables not built" : Q.why.c_str());
     if (CG.tripole ? !Q.gmask : !geo_derived()) return no("a start-up identity of the static arrays does not hold");
     if (per_call) *per_call = true;
-    if (!CG.fast) return no("waterx / watery differ from the ocean currents, seabed stress or rheofact on some ice cell");
     if (!Q.pairs_state_ok) return no("ghost cells outside the domain that the kernel treats as one position hold different state");
     if (Q.n_live < 1) return no("no window holds ice");
-    if ((long)(res_cull() ? Q.n_live : Q.ntiles) > Q.cap4[(CG.avg_strength ? 1 : 0) | (S.prm.revp != 0.0 ? 2 : 0)]) return no("more windows with ice than can be resident at once");
+    // (seabed stress, waterx / watery other than the ocean currents, rheofact != 1 on some ice cell: the kernel's SLOW variant, round 6)
+    if ((long)(res_cull() ? Q.n_live : Q.ntiles) > Q.cap4[(CG.avg_strength ? 1 : 0) | (S.prm.revp != 0.0 ? 2 : 0) | (CG.fast ? 0 : 4)]) return no("more windows with ice than can be resident at once");
     return true;
 }
 
@@ -710,6 +710,7 @@ static int res_launch(const EvpCgrid &A, int nsub, bool dry, double *const cur5[
     EvpCgRes R{};
     R.tab = Q.tab; R.tiles = Q.tiles; R.order = nullptr; R.ntiles = Q.ntiles;
     R.tiles2 = Q.tiles2; R.fold = CG.tripole ? 1 : 0;
+    R.slow = CG.fast ? 0 : 1;
     R.long_sleep = env_test("CICE_EVP_HIP_CGRID_RES_SLEEP") && std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_SLEEP")) ? 1 : 0;
     R.dbg = env_test("CICE_EVP_HIP_CGRID_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_CGRID_RES_DEBUG")) : 0;
     // the windows that hold ice in this call (finish_upload: cg_res_live); CICE_EVP_HIP_CGRID_RES_CULL=0 (test build) runs them all

@@ -16,12 +16,12 @@ if os.environ.get("EVP_TIMING_LIB"):          # A/B on one box: time another bui
     evp.LIB_PATH = Path(os.environ["EVP_TIMING_LIB"]).resolve()
 
 
-def case(grid, case_="full", bs=None):
+def case(grid, case_="full", bs=None, seabed=False):
     spec = synth.GRIDS[grid]
     ns = spec.get("ns", "closed")
     g = synth.derive_geometry(synth.make_grid(spec["nx"], spec["ny"], spec["dx0"], ns=ns))
     cg = synth.cgrid_geometry(g)
-    state, inputs, masks = synth.cgrid_state(g, cg, case=case_, seed=3)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case_, seed=3, seabed=seabed)
     bx, by = bs if bs else (spec["nx"], spec["ny"])
     dc = decomp.Decomp(spec["nx"], spec["ny"], bx, by, "cyclic", ns, 1)
     return (dc,) + synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
@@ -35,9 +35,10 @@ def main():
     ap.add_argument("--case", default="full")
     ap.add_argument("--visc", default="avg_zeta", choices=["avg_zeta", "avg_strength"])
     ap.add_argument("--bs", default="", help="block size BXxBY (default: one block)")
+    ap.add_argument("--seabed", action="store_true", help="seabed stress on shallow cells (the resident kernel's SLOW variant)")
     a = ap.parse_args()
     for grid in a.grids:
-        dc, static, state, inputs, masks = case(grid, a.case, tuple(int(v) for v in a.bs.split("x")) if a.bs else None)
+        dc, static, state, inputs, masks = case(grid, a.case, tuple(int(v) for v in a.bs.split("x")) if a.bs else None, a.seabed)
         d, keep = evp.make_dims(dc, 0)
         scal = synth.evp_scalars(a.ndte)
         core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
@@ -54,7 +55,7 @@ def main():
             ncell = dc.nx_global * dc.ny_global
             nact = int(masks["iceTmask"].sum())
             tt = core.cgrid_timings()
-            print(f"CGRID {grid} {a.case} {a.visc} one_launch={tt['one_launch_subcycles']} resident={tt['resident_subcycles']} windows_with_ice={tt['resident_windows_with_ice']}/{tt['resident_windows']} geometry_derived={tt['geometry_derived']}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
+            print(f"CGRID {grid} {a.case} {a.visc}{' seabed' if a.seabed else ''} one_launch={tt['one_launch_subcycles']} resident={tt['resident_subcycles']} windows_with_ice={tt['resident_windows_with_ice']}/{tt['resident_windows']} geometry_derived={tt['geometry_derived']}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
                   f"{ncell / (best * 1e-3 / a.ndte):.3e} cell-updates/s, active T {nact}/{ncell}", flush=True)
         finally:
             core.finalize()
