@@ -326,8 +326,8 @@ int cice_evp_hip_cgrid_dyn_finish(double *strocnxN, double *strocnyN, double *st
  * cice_evp_hip_cgrid_set_geometry found the reference's start-up identities to hold bit for bit; CICE_EVP_HIP_CGRID_GEO=0
  * keeps all 23 in use; in the test build only),
  * [5] (n >= 6) subcycles of the last call that ran inside ONE launch of the on-chip resident kernel (evp_cgrid_res.hip: the state
- * of a call in registers and LDS, face velocities traded between windows as tagged records; one rank, no T-fold, no seabed
- * stress / turning angle / rheofact, every window that holds ice co-resident: up to ~130k cells with ice everywhere, larger domains
+ * of a call in registers and LDS, face velocities traded between windows as tagged records; one rank, no T-fold, every window
+ * that holds ice co-resident -- seabed stress / an ocean turning angle / rheofact != 1 take its general momentum step --: up to ~130k cells with ice everywhere, larger domains
  * when only part of them is covered; CICE_EVP_HIP_CGRID_RESIDENT=0 / 1 forbids / requires it), [6] (n >= 7) what its start-up probe
  * measured per subcycle, ms (-1: no probe ran), [7] (n >= 8) calls of cice_evp_hip_cgrid_run that were repeated with the per-subcycle
  * kernels after one of its (bounded) waits gave up, [8], [9] (n >= 10) its windows that hold ice in this call -- only they run -- and

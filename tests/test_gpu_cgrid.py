@@ -395,6 +395,58 @@ def test_cgrid_synthetic_vs_oracle_bitwise(grid, bs, case, visc, seabed):
     assert int(args[5]["iceEmask"].sum()) > 0.2 * args[5]["iceEmask"].size * (0.3 if case == "caps" else 1.0)
 
 
+@pytest.mark.parametrize("grid,bs,visc,revised", [("gx3", None, "avg_zeta", False), ("gx3", (50, 58), "avg_strength", True),
+                                                   ("tx1", None, "avg_zeta", False), ("tx1", (90, 60), "avg_strength", True)])
+def test_cgrid_resident_kernel_general_momentum_step(grid, bs, visc, revised, monkeypatch):
+    """The resident C-grid kernel's SLOW variant (round 6): every operand the default-configuration short cuts drop is given a
+    value of its own -- seabed stress TbE / TbN on a third of the cells, rheofact 0 on a tenth, waterxE / wateryN turned against
+    the ocean currents, an ocean turning angle in the scalars -- the kernel is demanded (CICE_EVP_HIP_CGRID_RESIDENT=1) and must
+    have run all subcycles but the first; every array of the loop against the oracle, bit for bit (closed and tripole grids, one
+    block and several, both visc_methods, classic and revised EVP)."""
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "1")
+    dc, g, static, state, inputs, masks = synth_cgrid(grid, case="full", bs=bs, seed=31, seabed=True)
+    rng = np.random.default_rng(31)
+    inputs = {k: v.copy() for k, v in inputs.items()}
+    ang = np.deg2rad(17.0)
+    cw, sw = float(np.cos(ang)), float(np.sin(ang))
+    for t, wat in (("E", "waterxE"), ("N", "wateryN")):
+        shp = inputs[f"Tb{t}"].shape
+        inputs[f"rheofact{t}"] = inputs[f"rheofact{t}"] * (rng.random(shp) > 0.1)
+        inputs[f"Tb{t}"] = np.where(rng.random(shp) > 0.66, rng.uniform(0.0, 0.5, shp), 0.0) * (inputs[f"ai{t}"] > 0)
+    # the reference's waterx / watery with a turning angle (ice_dyn_shared.F90:819-820) at the E and N points
+    inputs["waterxE"] = inputs["uocnE"] * cw - inputs["vocnE"] * sw
+    inputs["wateryN"] = inputs["vocnN"] * cw + inputs["uocnN"] * sw
+    # (the ghost cells of the perturbed fields must stay images of the cells they mirror: the synthetic inputs are scattered from
+    # global fields, so redo that for the ones drawn per block above)
+    from cice_amd import synth
+    for k in ("rheofactE", "rheofactN", "TbE", "TbN"):
+        loc = next((l for l, names in synth.CGRID_LOC.items() if k in names), "center")
+        inputs[k] = dc.scatter(dc.gather({0: inputs[k]}), 0, fill=0.0, fold=(loc, 1.0))
+    kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
+    scal = synth.evp_scalars(120, **kw)
+    scal.update(cosw=cw, sinw=sw)
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    ndte = 24
+    want = oracle.cgrid_subcycle(dom, prm, ndte, state, inputs, static, masks, visc_method=visc)
+    d, keep = evp.make_dims(dc, 0)
+    core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                      1.0 / static["uarea"], static["tarea"], keepalive=keep)
+    try:
+        core.cgrid_set_geometry(static)
+        got = core.cgrid_run(ndte, state, inputs, masks, visc_method=visc)
+        t = core.cgrid_timings()
+    finally:
+        core.finalize()
+    assert t["resident_subcycles"] == ndte - 1 and t["resident_fallbacks"] == 0, t
+    assert_bitwise(got, want, f"C grid {grid} {bs} {visc}: resident kernel, general momentum step")
+    assert np.abs(want["taubxE"]).max() > 0 and np.abs(want["uvelE"]).max() > 1e-3
+
+
 def test_cgrid_both_schedules_agree(monkeypatch):
     """The five-launch schedule (CICE_EVP_HIP_CGRID_FUSED=0) and the fused three-launch one give the same bits
     (the golden tests run the default; this one pins the other against the same fixture)."""
