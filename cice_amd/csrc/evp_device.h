@@ -101,6 +101,8 @@ struct EvpResident2 {
     unsigned long long timeout_ticks;   // bound of a wait on another rank (100 MHz wall clock)
     // tripole grid (the top physical row lies on the fold); all NULL otherwise
     const int *seam;           // [nx] per column of the fold row: partner cell * 4 + role (1 low, 2 high, 3 pole), 0 none
+    int tfold;                 // 1: tripoleT (T-fold): a seam entry names the cell of row NY-1 the top-row cell is the image of (role 1);
+                               // after its momentum step the cell takes -1 x that cell's NEW value (no average: ice_boundary.F90:1686-1722)
     const int *img3;           // [ncell][3] ghost images of every U-cell: dst * 2 + (sign < 0), -1 none
     void *rec_raw[2];          // records of the pre-average velocities of the fold row, by subcycle parity
     // fold row split over ranks: a seam cell whose partner lives on another rank stores its raw record into that rank's

@@ -9,19 +9,33 @@ namespace evp_host {
 // general list then -- 3 x 1 and 4 x 1 cuts of tx1 showed it: two of the ranks ran without any fold handling)
 bool tripole_seam() { return (S.n_seam + S.n_pole + S.n_late) > 0 || S.plan.tail > 0 || !S.plan.fin_dst.empty(); }
 
+// tripoleT (T-fold), round 6: the top physical row of U-cells is the image of row NY-1 (halo_plan.cpp: resolve) -- the plan's local
+// copies whose DESTINATION is an interior cell.  The resident kernel treats such a cell like a seam cell whose new value is -1 x
+// the source cell's new value (EvpResident2::tfold); the copies are taken out of the ghost-image tables here.
+static bool tfold_image(size_t k)
+{
+    if (!S.plan.tfold) return false;
+    const int dst = S.plan.local_dst[k];
+    const int b = dst / (int)S.plane, r = dst % (int)S.plane, j = r / S.d.nx_block + 1, i = r % S.d.nx_block + 1;
+    return i >= S.ilo[b] && i <= S.ihi[b] && j >= S.jlo[b] && j <= S.jhi[b];
+}
+
 bool resident_possible(bool with_peers)
 {
     if (!with_peers && !S.plan.peers.empty()) return false;
-    if (S.plan.tfold) return false;           // tripoleT: the top row's images are interior cells (rewritten after the launch)
+    // tripoleT: the top row's images are interior cells -- inside the kernel on one rank (round 6); across ranks the streaming
+    // kernel (the images are rewritten after every launch)
+    if (S.plan.tfold && (with_peers || !S.plan.peers.empty())) return false;
     // tripole seam pairs across ranks: with neighbours on other GPUs the partners trade their raw records through the
     // peers' rec_raw buffers (round 4); every other caller gets the streaming kernel + exchange + seam step
     if (S.plan.tail > 0 && !with_peers) return false;
-    if (tripole_seam() || S.d.nblocks > 1) {
+    if (tripole_seam() || S.plan.tfold || S.d.nblocks > 1) {
         // tagged-record kernel only: the fold row is averaged inside the kernel, ghost images come
         // from a per-cell table (at most three per cell, no eliminated source block)
         std::map<int, int> nimg;
         for (size_t k = 0; k < S.plan.local_dst.size(); ++k) {
             if (S.plan.local_src[k] < 0) return false;
+            if (tfold_image(k)) continue;
             if (++nimg[S.plan.local_src[k]] > 3) return false;
         }
         return true;
@@ -54,7 +68,7 @@ int resident2_setup(int logw)
     const size_t plane = S.plane, ncell = S.n;
     std::vector<int> ghost_src(ncell, -1);
     for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
-        if (S.plan.local_src[k] >= 0) ghost_src[S.plan.local_dst[k]] = S.plan.local_src[k];
+        if (S.plan.local_src[k] >= 0 && !tfold_image(k)) ghost_src[S.plan.local_dst[k]] = S.plan.local_src[k];
     for (const HaloPeer &p : S.plan.peers) {          // produced on another rank: -2 (always refreshed)
         for (int k = 0; k < p.n_ghost_recv; ++k) ghost_src[p.recv_dst[k]] = -2;     // (what follows are staging slots, not cells)
         for (int32_t d : p.fimg_recv_dst) ghost_src[d] = -2;                        // images of seam cells: the owner's FINAL value
@@ -63,6 +77,14 @@ int resident2_setup(int logw)
     for (int32_t c : S.plan.seam_a) on_seam[c] = 1;
     for (int32_t c : S.plan.seam_b) on_seam[c] = 1;
     for (int32_t c : S.plan.seam_pole) on_seam[c] = 1;
+    // T-fold: the top-row cells and the cells they are images of change every subcycle, ice or not; the sources publish
+    std::vector<int> tfold_src;
+    for (size_t k = 0; k < S.plan.local_dst.size(); ++k)
+        if (S.plan.local_src[k] >= 0 && tfold_image(k)) {
+            on_seam[S.plan.local_dst[k]] = 1;
+            on_seam[S.plan.local_src[k]] = 1;
+            tfold_src.push_back(S.plan.local_src[k]);
+        }
     std::vector<int4> ring((size_t)ntiles * EVP_RES2_RING, make_int4(-1, 0, -1, 0));
     std::vector<int> cnt((size_t)ntiles, 0);
     std::vector<int> celltile(ncell, -1);
@@ -128,6 +150,7 @@ int resident2_setup(int logw)
                 }
             }
     }
+    for (int c : tfold_src) pub[(size_t)c] = 1;
     S.res2_ntiles = ntiles;
     S.res2_always_h = always;
     HIPC(hipMalloc((void **)&S.res2_celltile, celltile.size() * sizeof(int)));
@@ -136,11 +159,11 @@ int resident2_setup(int logw)
     HIPC(hipMemset(S.res2_live, 1, (size_t)ntiles));
     // ghost images from a per-cell table whenever they are not confined to the edge of ONE block:
     // tripole grids (ghost row NY+1 mirrors row NY-1) and several blocks per rank
-    if ((tripole_seam() || nb > 1) && !S.res2_img3) {
+    if ((tripole_seam() || S.plan.tfold || nb > 1) && !S.res2_img3) {
         std::vector<int> img3(ncell * 3, -1);
         for (size_t k = 0; k < S.plan.local_dst.size(); ++k) {
             const int src = S.plan.local_src[k];
-            if (src < 0) continue;
+            if (src < 0 || tfold_image(k)) continue;
             const int enc = S.plan.local_dst[k] * 2 + (S.plan.local_sign[k] < 0 ? 1 : 0);
             int e = 0;
             while (e < 3 && img3[(size_t)src * 3 + e] >= 0) ++e;
@@ -150,9 +173,11 @@ int resident2_setup(int logw)
         HIPC(hipMalloc((void **)&S.res2_img3, img3.size() * sizeof(int)));
         HIPC(hipMemcpy(S.res2_img3, img3.data(), img3.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    if (tripole_seam() && !S.res2_seam) {
+    if ((tripole_seam() || S.plan.tfold) && !S.res2_seam) {
         std::vector<int> seam((size_t)nx * nb, 0);       // per block and column of the fold row
         auto slot = [&](int32_t off) { return (size_t)(off / plane) * nx + (off % plane) % nx; };
+        for (size_t k = 0; k < S.plan.local_dst.size(); ++k)         // T-fold: the cell of row NY-1 a top-row cell is the image of
+            if (S.plan.local_src[k] >= 0 && tfold_image(k)) seam[slot(S.plan.local_dst[k])] = S.plan.local_src[k] * 4 + 1;
         for (size_t k = 0; k < S.plan.seam_a.size(); ++k) {
             seam[slot(S.plan.seam_a[k])] = S.plan.seam_b[k] * 4 + 1;
             seam[slot(S.plan.seam_b[k])] = S.plan.seam_a[k] * 4 + 2;
@@ -408,6 +433,7 @@ int launch_resident2(int ndte, int cur0, bool dry)
     const int dbg2 = env_test("CICE_EVP_HIP_RES_DEBUG") ? std::atoi(env_test("CICE_EVP_HIP_RES_DEBUG")) : 0;
     R.dbg = dbg2;
     R.seam = S.res2_seam;
+    R.tfold = S.plan.tfold ? 1 : 0;
     R.img3 = S.res2_img3;
     R.rec_raw[0] = S.res2_rec_raw[0];
     R.rec_raw[1] = S.res2_rec_raw[1];

@@ -17,6 +17,8 @@
 // Same arithmetic and ownership rules as the streaming kernel => same bits.  Every spin is bounded and raises the error word.
 //
 // Rim wave / interior waves (PERM, the 16 x 16 tile).  A subcycle of a tile is a dependent chain:
+// (tripoleT, round 6: a top-row U-cell is the image of a cell of row NY-1; it takes -1 x that cell's new value after its own momentum
+// step, through the record that cell publishes -- EvpResident2::tfold, the seam table names the source)
 // neighbours publish -> ring poll -> stress -> barrier -> momentum step -> publish.  Only the T-cells
 // on the rim of the tile read ring velocities (60 of 256 in a full 16 x 16 tile), and the ring has
 // at most 64 entries: a host-built permutation puts those T-cells -- and the ring poll -- into
@@ -670,13 +672,46 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                 R.tab[26][c] = o.taubx; R.tab[27][c] = o.tauby;
             }
         }
+        // T-fold: a top-row cell waits for the record of the cell it is the image of -- which may sit in the SAME wave (next to the
+        // pole columns) and publishes further down: every cell that is not such an image publishes first
+        bool published = false;
+        if (R.tfold && !isSeam) {
+            if (ownU) {
+                const unsigned tag = want + 1u;
+                if (pub) st_rec2(wr + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
+                if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+                if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img1 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+                if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img2 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
+            }
+            published = true;
+        }
         if (isSeam) {
             // what the halo update does to the fold row after every subcycle: pair (a, b) <- (xavg, -xavg),
             // xavg = 0.5*(x_a + isign*x_b), isign = -1; pole points change sign.  The partner's value of
             // THIS subcycle travels as a tagged record of its own (rec_raw), like any other hand-off.
             const double isign = -1.0;
             const unsigned tag = want + 1u;
-            if (seam_role == 3) {
+            if (R.tfold) {
+                // T-fold: the top physical row is the image of row NY-1 (a(i, NY) <- -a(NX-i+1, NY-1), nothing averaged).  The cell's own
+                // momentum step above has left its strintx / taubx; its velocity is the source cell's FINAL value of this subcycle,
+                // which that cell publishes like any velocity another tile mirrors
+                v4u ra, rb;
+                unsigned spins = 0;
+                if (REMOTE) t_wait0 = wall_clock64();
+                for (;;) {
+                    ld_rec2(wr + 2 * (size_t)seam_partner, ra, rb);
+                    if (ra.x == tag && ra.w == tag && rb.x == tag && rb.w == tag) {
+                        u_own = isign * unpack_rec(ra); v_own = isign * unpack_rec(rb);
+                        break;
+                    }
+                    if (gave_up(++spins, t_wait0)) {
+                        give_up_note(3, k, seam_partner, ra.x, tag);
+                        s_bad = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            } else if (seam_role == 3) {
                 u_own = isign * u_own; v_own = isign * v_own;
             } else {
                 v4u *rw = (v4u *)R.rec_raw[((k + par0) & 1) ^ 1];
@@ -719,7 +754,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             }
         }
         if (isU || isSeam) { s_u[li] = u_own; s_v[li] = v_own; }   // read by the next stress phase (after the ring barrier)
-        if (ownU) {
+        if (ownU && !published) {
             const unsigned tag = want + 1u;
             if (pub) st_rec2(wr + 2 * (size_t)c, pack_rec(u_own, tag), pack_rec(v_own, tag));
             if (img0 >= 0) { const double sg = (img0 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img0 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }

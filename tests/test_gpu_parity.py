@@ -57,12 +57,16 @@ def test_golden_strict_bitwise(name):
 
 
 @pytest.mark.parametrize("name", TFOLD_CASES)
-def test_golden_tripoleT_strict_bitwise(name):
+@pytest.mark.parametrize("resident", ["0", "1"])
+def test_golden_tripoleT_strict_bitwise(name, resident, monkeypatch):
     """ns_boundary_type = 'tripoleT' (T-fold): the B-grid loop through cice_evp_hip_run against the reference's evp() --
     the velocity halo's T-fold rule (top U row = image of row NY-1, ghost row = image of row NY-2, no pair averaging:
-    ice_boundary.F90:1563-1622, 1686-1722) runs as list copies after every subcycle launch.  Velocities and the loop's
+    ice_boundary.F90:1563-1622, 1686-1722) runs as list copies after every subcycle launch of the streaming kernel (resident 0), or
+    INSIDE the on-chip resident kernel (resident 1, round 6: a top-row cell takes -1 x the new value of the cell it is the image of,
+    through the record that cell publishes; its own momentum step still leaves strintx / taubx).  Velocities and the loop's
     diagnostics on every cell; the stresses wherever evp()'s own ice_HaloUpdate_stress calls after the loop leave them
     alone (test_tripole_stress_symmetrisation_on_device applies those on the device too: every cell)."""
+    monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", resident)
     c = GoldenCase(name)
     core = hip_from_case(c, strict=True)
     keep = tfold_untouched(c)
@@ -75,8 +79,11 @@ def test_golden_tripoleT_strict_bitwise(name):
                 for k in want:
                     sel = keep if k.startswith("stress") else np.ones_like(keep)
                     assert bits_equal(out[k][sel], want[k][sel]), f"{name} call {icall} nsub {nsub} {k} (HIP, tripoleT)"
-        assert core.timings()["tile_variant"] < 1000          # the streaming kernel (the resident ones are not eligible)
-        assert "one subcycle per launch" in core.describe_path() and "marching path: off" in core.describe_path()
+        if resident == "0":
+            assert core.timings()["tile_variant"] < 1000 and "one subcycle per launch" in core.describe_path()
+            assert "marching path: off" in core.describe_path()
+        else:
+            assert 2000 <= core.timings()["tile_variant"] < 3000 and "on-chip resident" in core.describe_path(), core.describe_path()
         assert np.abs(want["uvel"]).max() > 1e-3
     finally:
         core.finalize()
@@ -390,6 +397,43 @@ def test_tx1_size_tripole_vs_reference_harness(tmp_path, bs):
         assert core.timings()["tile_variant"] >= 2000
     finally:
         core.finalize()
+
+
+@pytest.mark.parametrize("bs", [(360, 240), (90, 60)])
+def test_tx1_size_tripoleT_vs_reference_harness(tmp_path, bs, monkeypatch):
+    """The same size with ns_boundary_type = 'tripoleT' (T-fold), 240 subcycles, against the reference's own evp(): the on-chip
+    resident kernel with the T-fold inside (round 6) and the streaming kernel with its list copies after every launch -- velocities
+    and diagnostics on every cell, the stresses wherever evp()'s own ice_HaloUpdate_stress calls after the loop leave them alone,
+    and every cell once cice_evp_hip_stress_halo has done those on the device.  Loop times go to gpurun_out/ for the record."""
+    c = reference_case(tmp_path, 360, 240, bs, "tripoleT", [1, 240], 240)
+    keep = tfold_untouched(c)
+    dyn, tm, um = c.inputs(1)
+    times = {}
+    for resident in ("1", "0"):
+        monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", resident)
+        core = hip_from_case(c, strict=True)
+        try:
+            for nsub in (1, 240):
+                out = core.run(dyn, tm, um, ndte=nsub)
+                want = c.expected(1, nsub)
+                for k in want:
+                    sel = keep if k.startswith("stress") else np.ones_like(keep)
+                    assert bits_equal(out[k][sel], want[k][sel]), f"tx1-size tripoleT {bs} resident {resident} nsub {nsub} {k}"
+                core.stress_halo()
+                assert_bitwise(core.download(), want, f"tx1-size tripoleT {bs} resident {resident} nsub {nsub}, symmetrised on the device")
+            core.run(dyn, tm, um, ndte=240)
+            t = core.timings()
+            assert (t["tile_variant"] >= 2000) == (resident == "1"), t
+            times[resident] = 1e3 * t["loop_ms"] / 240
+        finally:
+            core.finalize()
+    assert np.abs(out["uvel"]).max() > 1e-3
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(f"gpurun_out/tripoleT_tx1_{bs[0]}x{bs[1]}_timing.txt", "w") as f:
+            f.write(f"360x240 tripoleT, blocks {bs[0]}x{bs[1]}, 240 subcycles, us per subcycle: resident {times['1']:.2f}, streaming {times['0']:.2f}\n")
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("bs", [(320, 384), (80, 96)])
@@ -1320,6 +1364,8 @@ def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
     what = f"seed {seed}: {nx}x{ny} tripoleT, blocks {bs[0]}x{bs[1]}, {icecase}, ndte {ndte}"
     c = reference_case(tmp_path, nx, ny, bs, "tripoleT", [1, ndte], ndte, icecase=icecase, ncalls=2, h_evolve=True)
     keep = tfold_untouched(c)
+    # every other seed demands the on-chip resident kernel (the T-fold inside the kernel, round 6), the others the streaming one
+    os.environ["CICE_EVP_HIP_RESIDENT"] = str(seed % 2)        # (read at the first call; taken back in the finally below)
     core = hip_from_case(c, strict=True)
     try:
         for icall in (1, 2):
@@ -1333,8 +1379,10 @@ def test_bgrid_tripoleT_geometry_sweep_vs_reference(seed, tmp_path):
                 # ... and with those twelve calls done on the device too (late round 4): every cell of every array
                 core.stress_halo()
                 assert_bitwise(core.download(), want, f"{what}: call {icall} nsub {nsub}, symmetrised on the device")
+                assert (core.timings()["tile_variant"] >= 2000) == bool(seed % 2), (what, core.timings()["tile_variant"])
         assert np.abs(want["uvel"]).max() > 1e-5, what
     finally:
+        os.environ.pop("CICE_EVP_HIP_RESIDENT", None)
         core.finalize()
     # ... and the preparation phase on the device (T-fold rule of the cell-centre fields), then the whole evp()
     check_next_tier_prep(c, what)
