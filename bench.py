@@ -426,7 +426,7 @@ def main():
 
             scal = synth.evp_scalars(ndte)
             d, keep = evp.make_dims(dc, rank)
-            # (rehearsal on one GPU: the two-subcycle path's ring exchanges go through the test build's host transport --
+            # (rehearsal on one GPU: the marching path's ring exchanges go through the test build's host transport --
             # gloo underneath -- because RCCL refuses two ranks per device; a real run uses the product library and RCCL)
             core = evp.EvpHip(d, evp.make_params(scal, strict=a.strict), geo["HTE"], geo["HTN"], geo["dxT"],
                               geo["dyT"], geo["uarear"], geo["tarea"], keepalive=keep, testing=(True if rehearsal else None))
@@ -619,7 +619,7 @@ def main():
         if world > 1:
             ladder += [({"CICE_EVP_HIP_RESIDENT": "0"}, "streaming kernels (resident kernel across GPUs off)"),
                        ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_MARCH": "0"},
-                        "one-subcycle streaming kernel (resident kernel and two-subcycle marching kernel off)"),
+                        "one-subcycle streaming kernel (resident kernel and marching kernel off)"),
                        ({"CICE_EVP_HIP_RESIDENT": "0", "CICE_EVP_HIP_MARCH": "0", "CICE_EVP_HIP_HALO": "rccl"},
                         "one-subcycle streaming kernel, RCCL point-to-point only")]
         attempts = []

@@ -185,7 +185,7 @@ int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *
         self.n_ghost_recv = (int)self.recv_dst.size();
         S.plan.peers.push_back(self);
     }
-    // the global block table is needed again by plans built later (the two-subcycle path decides at the first
+    // the global block table is needed again by plans built later (the marching path decides at the first
     // cice_evp_hip_subcycle): keep a copy -- the caller's arrays need not outlive this call
     {
         const int32_t *src[6] = {dims->gi0, dims->gj0, dims->gnx, dims->gny, dims->gowner, dims->glocal};
@@ -402,7 +402,7 @@ int cice_evp_hip_subcycle(int32_t ndte)
     }
     S.march.last_call = false;
     if (march_wanted()) {
-        // large per-rank domain: two subcycles per pass over HBM (evp_march.hip); falls back to the loop below by
+        // large per-rank domain: several subcycles per pass over HBM (evp_march.hip); falls back to the loop below by
         // itself when the uploaded state does not qualify
         const int declined0 = S.march.declined;
         if (int rc = march_run(ndte)) return rc;

@@ -120,7 +120,7 @@ struct State {
     // remote halo
     ncclComm_t comm = nullptr;
     bool have_comm = false;
-    // test hook (cice_evp_hip_set_test_transport): the two-subcycle path's exchanges and agreements through host
+    // test hook (cice_evp_hip_set_test_transport): the marching path's exchanges and agreements through host
     // buffers and caller-supplied callbacks instead of RCCL, so that its several-rank form can run as processes sharing
     // ONE GPU (RCCL refuses two ranks per device)
     cice_evp_hip_test_xchg_fn test_xchg = nullptr;
@@ -266,7 +266,7 @@ struct State {
     struct Pinned { size_t bytes; void *dev; };    // dev: the range as the device sees it (NULL: not mapped)
     std::map<const void *, Pinned> pinned;         // host ranges registered by cice_evp_hip_pin_host
     // stresses that stay on the device between calls of cice_evp_hip_run (CICE_EVP_HIP_OPT_STRESS_RESIDENT)
-    // two subcycles per pass over a device-private rectangle layout (evp_march.hip, evp_host_march.cpp)
+    // several subcycles per pass over a device-private rectangle layout (evp_march.hip, evp_host_march.cpp)
     struct March {
         int mode = -1;                 // -1 undecided, 0 off, 1 on
         EvpMarchGeo G{};
@@ -363,7 +363,7 @@ int tune_after_upload();
 bool march_wanted();
 int march_run(int ndte);
 void march_free();
-int march_direct_error();     // a ring neighbour never signalled (direct exchange of the two-subcycle path)
+int march_direct_error();     // a ring neighbour never signalled (direct exchange of the marching path)
 // evp_host_mailbox.cpp
 int direct_check_error();
 // evp_host_cgrid.cpp

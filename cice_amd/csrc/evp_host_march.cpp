@@ -506,7 +506,7 @@ static int march_direct_setup()
     if (vote && ok) M.direct_why = "another rank cannot take part";
     M.direct = vote ? 0 : 2;         // 2: the first exchange runs both ways and compares
     if (env("CICE_EVP_HIP_VERBOSE"))
-        std::fprintf(stderr, "[cice_evp_hip] rank %d: ring of the two-subcycle path %s%s\n", (int)S.d.rank,
+        std::fprintf(stderr, "[cice_evp_hip] rank %d: ring of the marching path %s%s\n", (int)S.d.rank,
                      M.direct ? "as stores into the neighbours' HIP-IPC-mapped inboxes" : "through RCCL send / recv: ",
                      M.direct ? "" : M.direct_why.c_str());
     return 0;
@@ -517,7 +517,7 @@ int march_direct_error()
     if (S.march.direct <= 0 || !B.dx.err) return 0;
     int e = 0;
     HIPC(hipMemcpy(&e, B.dx.err, sizeof e, hipMemcpyDeviceToHost));
-    if (e) return fail(-8, "two-subcycle path: ring neighbour rank %d never signalled within the time-out (CICE_EVP_HIP_HALO_TIMEOUT_MS)",
+    if (e) return fail(-8, "marching path: ring neighbour rank %d never signalled within the time-out (CICE_EVP_HIP_HALO_TIMEOUT_MS)",
                        (e - 1 < (int)PL.peers.size()) ? PL.peers[e - 1].rank : -1);
     return 0;
 }
@@ -695,7 +695,7 @@ bool march_wanted()
     }
     if (!ok) {
         M.why = why;
-        if (env("CICE_EVP_HIP_VERBOSE")) std::fprintf(stderr, "[cice_evp_hip] two-subcycle kernel off: %s\n", why.c_str());
+        if (env("CICE_EVP_HIP_VERBOSE")) std::fprintf(stderr, "[cice_evp_hip] marching kernel off: %s\n", why.c_str());
         return false;
     }
     // worth it when the domain is far beyond what stays on the chip (the on-chip resident kernel is chosen before this
@@ -739,7 +739,7 @@ int march_run(int ndte)
     auto fallback = [&](const char *why) -> int {
         ++M.declined;
         M.why = why;
-        if (env("CICE_EVP_HIP_VERBOSE")) std::fprintf(stderr, "[cice_evp_hip] two-subcycle kernel declined this call: %s\n", why);
+        if (env("CICE_EVP_HIP_VERBOSE")) std::fprintf(stderr, "[cice_evp_hip] marching kernel declined this call: %s\n", why);
         if (left > 0)
             if (int rc = enqueue_loop(left, cur)) return rc;
         S.cur = cur ^ (left & 1);

@@ -1,4 +1,4 @@
-// Host-only geometry and exchange plan of the two-subcycles-per-pass path: see march_plan.h.
+// Host-only geometry and exchange plan of the marching path: see march_plan.h.
 #include "march_plan.h"
 
 #include <algorithm>

@@ -535,7 +535,7 @@ class EvpHip:
 
     def set_test_transport(self, xchg, reduce):
         """Test hook (see the header): xchg(peer_ranks, send_counts, recv_counts, send ndarray, recv ndarray) and
-        reduce(op, value) -> value, called on the host by the two-subcycle path instead of RCCL."""
+        reduce(op, value) -> value, called on the host by the marching path instead of RCCL."""
         self._need_testing("set_test_transport")
         XF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                          C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -583,7 +583,7 @@ class EvpHip:
         return buf.value.decode(errors="replace")
 
     def march_info(self) -> dict:
-        """The two-subcycles-per-pass path (evp_march.hip): did it run, how is the domain cut."""
+        """The marching path (evp_march.hip): did it run, how is the domain cut."""
         v = np.zeros(10, dtype=np.int32)
         v[7] = -1
         self.lib.cice_evp_hip_march_info(_ip(v), 10)
@@ -681,7 +681,7 @@ class EvpHip:
 
 
 def march_plan(dims: Dims, own_max: int = 0, wrap_inside: bool = True, ext: int = 0) -> dict:
-    """Host-only geometry + exchange lists of the two-subcycle path for `dims.rank` (CPU tests)."""
+    """Host-only geometry + exchange lists of the marching path for `dims.rank` (CPU tests)."""
     lib = load_library(testing=True)
     geo = np.zeros(14, dtype=np.int32)
     _check(lib, lib.cice_evp_hip_march_plan(C.byref(dims), own_max, int(wrap_inside), ext, _ip(geo), None, None, None, None, None,

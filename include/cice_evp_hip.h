@@ -98,7 +98,7 @@ typedef struct {
  * bystander -- cice_evp_hip_comm_unique_id / _comm_init / _halo_export / _halo_import /
  * _finalize work and keep the other ranks' collectives complete; every other entry
  * point refuses it, the host has nothing to hand over there.  With such a rank in the job
- * the two-subcycle path stays off on every rank.                                  */
+ * the marching path stays off on every rank.                                  */
 int cice_evp_hip_init(const cice_evp_hip_dims *dims, const cice_evp_hip_params *params,
                       const double *HTE, const double *HTN, const double *dxT, const double *dyT,
                       const double *uarear, const double *tarea);
@@ -400,7 +400,7 @@ int cice_evp_hip_time_kernels(int32_t nrep, double *out3);
  * CICE_EVP_HIP_MARCH_OVERLAP=1 (every rank alike) advances the cells other ranks wait for first, on a second stream, and
  * overlaps their RCCL send / recv with the rest of the pass (default: pack, send / recv, unpack after the pass).        */
 int cice_evp_hip_march_info(int32_t *out, int32_t n);
-/* One line of text on what the last cice_evp_hip_subcycle ran (kernel, halo transport, the two-subcycle path and why it is
+/* One line of text on what the last cice_evp_hip_subcycle ran (kernel, halo transport, the marching path and why it is
  * off when it is), for logs.                                                                                       */
 int cice_evp_hip_describe_path(char *buf, int32_t n);
 int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second);

@@ -5,7 +5,7 @@
  * kernels and host code, plus what tests and tools need and a production host must never find by accident:
  *   - host-only introspection of the halo / seam / marching / window plans (CPU known-answer tests),
  *   - read-outs of the resident kernel's per-CU placement record and phase stamps (tools/),
- *   - a test transport that routes the two-subcycle path's exchanges through host callbacks (several ranks as
+ *   - a test transport that routes the marching path's exchanges through host callbacks (several ranks as
  *     processes sharing ONE GPU, where RCCL refuses to run),
  *   - the experiment / fault-injection environment switches (evp_host.h: env_test) -- in the production build they
  *     read as unset.
@@ -44,7 +44,7 @@ int cice_evp_hip_cgrid_window_plan_ext(const cice_evp_hip_dims *dims, int32_t ox
  * window read could then be four subcycles ahead of its reader and overwrite one of the kernel's four record slots per cell that
  * the reader still waits for): the library does not use the kernel unless n_unsafe == 0.                                          */
 int cice_evp_hip_cgrid_window_deps(const cice_evp_hip_dims *dims, int32_t *n_windows, int32_t *n_edges, int32_t *n_oneway, int32_t *n_unsafe);
-/* Test hook: route the exchanges and the rank agreements of the two-subcycle path through HOST buffers and the caller's
+/* Test hook: route the exchanges and the rank agreements of the marching path through HOST buffers and the caller's
  * callbacks instead of RCCL (which refuses two ranks on one device), so that its several-rank form can be run as
  * processes sharing one GPU (tools/mailbox_2proc.py --march: torch.distributed gloo underneath).  xchg: per peer q
  * (ascending rank) send_count[q] doubles starting at send + sum of the counts before, likewise recv; returns 0.  reduce:
@@ -53,7 +53,7 @@ typedef int (*cice_evp_hip_test_xchg_fn)(void *user, int32_t npeers, const int32
                                          const int64_t *recv_count, const double *send, double *recv);
 typedef int (*cice_evp_hip_test_reduce_fn)(void *user, int32_t op, void *value);
 int cice_evp_hip_set_test_transport(cice_evp_hip_test_xchg_fn xchg, cice_evp_hip_test_reduce_fn reduce, void *user);
-/* Host-only (CPU tests): geometry and exchange lists of the two-subcycle path for dims->rank.  Every rank's sub-domain
+/* Host-only (CPU tests): geometry and exchange lists of the marching path for dims->rank.  Every rank's sub-domain
  * must be one rectangle; the rank HOLDS its own cells plus `ext` (even) more on every side that has a neighbour, in strips
  * of `own` <= own_max columns (position of a cell = (storage row * nstrips + strip) * 64 + lane), and after one exchange
  * of the ring of ext + 2 cells ext/2 + 1 passes can follow.  geo14 = {gx0, gy0, nxr, nyr of what it holds, own, nstrips,

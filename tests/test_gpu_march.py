@@ -277,7 +277,7 @@ def test_s01_full_size_march_vs_oracle_bitwise():
 
 
 def test_march_plan_is_built_for_a_rank_of_several(tmp_path):
-    """The two-subcycle path decides at the first cice_evp_hip_subcycle, long after cice_evp_hip_init has returned: the
+    """The marching path decides at the first cice_evp_hip_subcycle, long after cice_evp_hip_init has returned: the
     global block table handed to init must still be there then (it was dropped once: every multi-rank domain silently got
     the one-subcycle kernels).  One process plays rank 0 of a 2 x 1 split without a communicator: the plan must get as far
     as asking for one -- RCCL refuses two ranks on one device, so the exchange itself is exercised with the rank itself

@@ -1326,7 +1326,7 @@ def test_bgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
     what = f"seed {seed}: {nx}x{ny} {ns}, blocks {bs[0]}x{bs[1]}, {icecase}, ndte {ndte}"
     c = reference_case(tmp_path, nx, ny, bs, ns, [1, ndte], ndte, icecase=icecase, ncalls=2, h_evolve=True)
     marched = 0
-    for kernel in ("resident", "streaming") + (("march",) if ns == "closed" else ()):     # (the two-subcycle path refuses a fold)
+    for kernel in ("resident", "streaming") + (("march",) if ns == "closed" else ()):     # (the marching path refuses a fold)
         monkeypatch.setenv("CICE_EVP_HIP_RESIDENT", "1" if kernel == "resident" else "0")
         monkeypatch.setenv("CICE_EVP_HIP_MARCH", "1" if kernel == "march" else "0")
         core = hip_from_case(c, strict=True)
@@ -1341,7 +1341,7 @@ def test_bgrid_geometry_sweep_vs_reference(seed, tmp_path, monkeypatch):
             assert core.timings()["resident_fallbacks"] == 0, (what, kernel, core.timings())
         finally:
             core.finalize()
-    assert ns != "closed" or marched >= 2, (what, marched)      # the runs did go through the two-subcycle path
+    assert ns != "closed" or marched >= 2, (what, marched)      # the runs did go through the marching path
     assert np.abs(out["uvel"]).max() > 1e-4, what
     # what evp() does before and after the loop, on the device: preparation (+ loop) and deformations / dyn_finish
     check_next_tier_prep(c, what)

@@ -188,7 +188,7 @@ def test_bench_multi_rank_rehearsal():
     assert lib["verified"] is True and lib["finite"] and lib["us_per_subcycle"] > 0, lib
     assert lib["verification"]["key"] == "gx1/full/ndte240/closed/strict" and [q["rank"] for q in lib["per_rank"]] == [0, 1]
     assert "skipped" in c2["rccl_point_to_point_forced"]
-    # configs[4]: 3600 x 2400 on the two-subcycle kernel (ring over the test transport), verified; and once more on the same
+    # configs[4]: 3600 x 2400 on the marching kernel (ring over the test transport), verified; and once more on the same
     # state with the exchange overlapped with the pass
     sec = d["secondary"]
     assert sec["verified"] is True and sec["finite"] and sec["tile_variant"] >= 3000, sec

@@ -34,7 +34,7 @@ def main():
                     help="with --cgrid: hand the loop the masked halo evp() builds when maskhalo_dyn (five-point dilation of "
                          "iceTmask, ice_dyn_evp.F90:739-770); ghost cells outside the mask stay stale, everything else must not change")
     ap.add_argument("--march", action="store_true",
-                    help="force the two-subcycles-per-pass kernel on every rank; its ring exchanges and rank agreements go "
+                    help="force the marching kernel on every rank; its ring exchanges and rank agreements go "
                          "through the library's test transport (host buffers + gloo here: RCCL refuses two ranks per device)")
     ap.add_argument("--case", default="full")
     ap.add_argument("--cgrid", action="store_true",
@@ -293,10 +293,10 @@ def main():
     if a.march:
         mi = got["_march"]
         if not (mi["mode"] == 1 and mi["last_call"] and mi["declined"] == 0 and mi["passes"] > 0):
-            bad.append(("two-subcycle kernel did not run", mi))
+            bad.append(("marching kernel did not run", mi))
         want_ring = "direct stores (HIP IPC)" if os.environ.get("CICE_EVP_HIP_MARCH_DIRECT") == "1" and os.environ.get("CICE_EVP_HIP_MARCH_OVERLAP", "0") != "1" else None
         if want_ring and mi["ring"] != want_ring:
-            bad.append(("ring of the two-subcycle path not exchanged through the inboxes", mi))
+            bad.append(("ring of the marching path not exchanged through the inboxes", mi))
     for k in ("uvel", "vvel", "stressp_1", "stressm_3", "stress12_4", "strintxU", "taubyU",
               "forcexU", "umassdti", "uvel_init", "aiU", "iceTmask"):
         if k not in got:

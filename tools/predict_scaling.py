@@ -137,7 +137,7 @@ def main():
                         continue
                     label = tname if N > 1 else "none"
                     if N > 1 and core_info.get("last_call") and tname != "march+rccl":
-                        # pieces beyond the chip run the two-subcycle kernel by default; the one-GPU self-exchange hook of the
+                        # pieces beyond the chip run the marching kernel by default; the one-GPU self-exchange hook of the
                         # one-subcycle kernels does not reach it: this row is the piece's compute time without any exchange
                         label = "march, no exchange (compute only)"
                     rec = dict(workload=wl, n=N, layout=f"{px}x{py}", piece=f"{nx}x{ny}", transport=label,
