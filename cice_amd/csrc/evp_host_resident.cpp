@@ -23,9 +23,17 @@ static bool tfold_image(size_t k)
 bool resident_possible(bool with_peers)
 {
     if (!with_peers && !S.plan.peers.empty()) return false;
-    // tripoleT: the top row's images are interior cells -- inside the kernel on one rank (round 6); across ranks the streaming
-    // kernel (the images are rewritten after every launch)
-    if (S.plan.tfold && (with_peers || !S.plan.peers.empty())) return false;
+    // tripoleT: the top row's images are interior cells -- inside the kernel (round 6) where every cell a top-row cell of this rank
+    // is the image of lies on this rank too (one rank; several ranks cut in y only); a top row split in x has images whose sources
+    // are other ranks' cells (the receive lists name interior cells then): the streaming kernel, images rewritten after every launch
+    if (S.plan.tfold) {
+        for (const HaloPeer &p : S.plan.peers)
+            for (int k = 0; k < p.n_ghost_recv; ++k) {
+                const int dst = p.recv_dst[k];
+                const int b = dst / (int)S.plane, r = dst % (int)S.plane, j = r / S.d.nx_block + 1, i = r % S.d.nx_block + 1;
+                if (i >= S.ilo[b] && i <= S.ihi[b] && j >= S.jlo[b] && j <= S.jhi[b]) return false;
+            }
+    }
     // tripole seam pairs across ranks: with neighbours on other GPUs the partners trade their raw records through the
     // peers' rec_raw buffers (round 4); every other caller gets the streaming kernel + exchange + seam step
     if (S.plan.tail > 0 && !with_peers) return false;

@@ -683,6 +683,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
                 if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img1 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
                 if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img2 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
             }
+            if (rpub) publish_remote(((k + par0) & 1) ^ 1, u_own, v_own, want + 1u);
             published = true;
         }
         if (isSeam) {
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(64 * RTY, REMOTE ? 2 : 3) void evp_resident2_tile(E
             if (img1 >= 0) { const double sg = (img1 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img1 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
             if (img2 >= 0) { const double sg = (img2 & 1) ? -1.0 : 1.0; st_rec2(wr + 2 * (size_t)(img2 >> 1), pack_rec(sg * u_own, tag), pack_rec(sg * v_own, tag)); }
         }
-        if (rpub) publish_remote(((k + par0) & 1) ^ 1, u_own, v_own, want + 1u);
+        if (rpub && !published) publish_remote(((k + par0) & 1) ^ 1, u_own, v_own, want + 1u);
         // no publish step: the records carry their own tags
         EVP_STAMP(pacc3)
         if (split) __syncthreads();   // the tile's own new velocities are in LDS before anybody's next stress update

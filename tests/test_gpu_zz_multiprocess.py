@@ -50,6 +50,10 @@ def _free_port():
                                                            # row cut in x, in y only, both, odd sizes
                                                            (2, "360x240:tripoleT", "2x1", False),
                                                            (4, "360x240:tripoleT", "2x2", False), (3, "126x60:tripoleT", "3x1", False),
+                                                           # round 6: the T-fold INSIDE the on-chip kernel where the top row lies on one
+                                                           # rank (cut in y); a top row split in x leaves some ranks unable -- the
+                                                           # ranks agree on the streaming kernel ("auto": nothing forced)
+                                                           (2, "360x240:tripoleT", "1x2", True), (4, "360x240:tripoleT", "2x2", "auto"),
                                                            # ... and its preparation phase on the device, ranks cut in y (end of
                                                            # round 4: the T-fold rule of the cell-centre fields stays on the top rank)
                                                            (2, "120x80:tripoleT", "1x2", "prep_stream")])
@@ -82,6 +86,8 @@ def test_mailbox_halo_between_processes_on_one_gpu(world, workload, shape, resid
         # from the primary model state: evp()'s preparation phase on every rank, its T-grid halos
         # crossing the ranks through the same transport, then the loop (f-2 on a split domain)
         cmd += ["--prep", "--expect-resident"]
+    elif resident == "auto":
+        pass                                        # the library's own (collective) choice
     elif resident:
         cmd += ["--expect-resident", "--timing"]    # --timing: 5 x 120 + 7 more subcycles, launches back to back
     else:
