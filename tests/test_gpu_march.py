@@ -314,7 +314,7 @@ except evp.EvpHipError as e:
     assert "no RCCL communicator" in r.stderr, (r.stdout[-800:], r.stderr[-1500:])
 
 
-@pytest.mark.parametrize("seed", list(range(101, 113)) + [2056] + [int(s) for s in __import__("os").environ.get("MARCH_SWEEP_SEEDS", "").split() if s])
+@pytest.mark.parametrize("seed", list(range(101, 113)) + [2056, 17197] + [int(s) for s in __import__("os").environ.get("MARCH_SWEEP_SEEDS", "").split() if s])
 def test_march_random_geometry_vs_oracle(seed, march):
     """Geometry sweep: random domain sizes (not multiples of the strip width), block splits with padded last blocks, strip
     widths, segment lengths, closed / cyclic east-west boundaries, random ice holes, even and odd subcycle counts -- and,
@@ -367,7 +367,14 @@ def test_march_random_geometry_vs_oracle(seed, march):
             core.comm_init(core.comm_unique_id())
         got = core.run(fields, tm, um, ndte=ndte)
         info = core.march_info()
-        assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0 and info["passes"] == npasses(ndte, kpass), (what, info)
+        path = core.describe_path()
+        if info["mode"] == 0 and own and "no strip width" in path:
+            # a forced narrow strip on a width it cannot tile (with the cyclic wrap inside, the last strip needs eight columns -- four
+            # duplicated to either neighbour; seed 17197: 172 columns in strips of <= 13): the library says so and the streaming
+            # kernel runs; the bits are compared all the same
+            pass
+        else:
+            assert info["mode"] == 1 and info["last_call"] and info["declined"] == 0 and info["passes"] == npasses(ndte, kpass), (what, info, path)
     finally:
         core.finalize()
     want = run_oracle(dc, geo, fields, tm, um, scal, ndte)
