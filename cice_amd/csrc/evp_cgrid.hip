@@ -243,22 +243,22 @@ __device__ __forceinline__ double shear_u(const EvpCgrid &A, const GT &G, size_t
 }
 
 // grid_average_X2YA at cell p (ice_grid.F90:4388-4606): 'NW' (E -> N), 'SE' (N -> E), 'N' (E -> U), 'E' (N -> U)
-template <class W>
-__device__ __forceinline__ double avg_nw(const double *a, const W &w, size_t p, int nx)
+template <class P, class W>
+__device__ __forceinline__ double avg_nw(const P &a, const W &w, size_t p, int nx)
 {
     const double wtmp = (w[p - 1] + w[p] + w[p + nx - 1] + w[p + nx]);
     if (wtmp == 0.0) return 0.0;
     return (a[p - 1] * w[p - 1] + a[p] * w[p] + a[p + nx - 1] * w[p + nx - 1] + a[p + nx] * w[p + nx]) / wtmp;
 }
-template <class W>
-__device__ __forceinline__ double avg_se(const double *a, const W &w, size_t p, int nx)
+template <class P, class W>
+__device__ __forceinline__ double avg_se(const P &a, const W &w, size_t p, int nx)
 {
     const double wtmp = (w[p - nx] + w[p - nx + 1] + w[p] + w[p + 1]);
     if (wtmp == 0.0) return 0.0;
     return (a[p - nx] * w[p - nx] + a[p - nx + 1] * w[p - nx + 1] + a[p] * w[p] + a[p + 1] * w[p + 1]) / wtmp;
 }
-template <class W>
-__device__ __forceinline__ double avg_2(const double *a, const W &w, size_t p, size_t q)
+template <class P, class W>
+__device__ __forceinline__ double avg_2(const P &a, const W &w, size_t p, size_t q)
 {
     const double wtmp = (w[p] + w[q]);
     if (wtmp == 0.0) return 0.0;
@@ -910,6 +910,74 @@ __global__ void cg_zero_cells(EvpCgrid A, const int *cells, int n)
 // no exchange overwrites) is kept up by the workgroup that owns the neighbouring interior cell, with the ghost cell's own
 // metrics and history.
 // =====================================================================
+// The marched kernel's views (cg_strip): an array = a wave-uniform base + a 32-bit byte offset per lane, so that ONE register per
+// lane (the cell's offset) addresses every array -- in a loop over rows the compiler otherwise keeps a 64-bit per-lane address for
+// each of the ~50 arrays (250 registers, two waves per SIMD).  The tables (23 x n, 23 x n doubles) must end below 4 GB: the host checks.
+struct P32 {
+    const char *base;
+    __device__ __forceinline__ double operator[](size_t i) const { return *(const double *)(base + (size_t)((unsigned)i * 8u)); }
+};
+struct P32W {
+    char *base;
+    __device__ __forceinline__ double &operator[](size_t i) const { return *(double *)(base + (size_t)((unsigned)i * 8u)); }
+};
+struct P32K {      // array k of a table: base + (k * stride + i) * 8, the sum in 32 bits
+    const char *base;
+    unsigned koff;
+    __device__ __forceinline__ double operator[](size_t i) const { return *(const double *)(base + (size_t)((unsigned)i * 8u + koff)); }
+};
+struct Slab32 {
+    static constexpr bool derived = false;
+    const char *base;
+    unsigned stride8;
+    __device__ __forceinline__ P32K operator[](int k) const { return P32K{base, (unsigned)k * stride8}; }
+};
+struct DSlab32 {   // DSlab with 32-bit offsets
+    static constexpr bool derived = true;
+    const char *base;
+    unsigned stride8;
+    const uint8_t *gm;
+    int nx;
+    double dmin;
+    struct Acc {
+        const DSlab32 &S;
+        int k;
+        __device__ __forceinline__ double raw(int a, size_t p) const { return *(const double *)(S.base + (size_t)((unsigned)p * 8u + (unsigned)a * S.stride8)); }
+        __device__ __forceinline__ unsigned bits(size_t p) const { return S.gm[(size_t)(unsigned)p]; }
+        __device__ __forceinline__ double operator[](size_t p) const
+        {
+            switch (k) {
+            case CG_TAREA: return raw(CG_DXT, p) * raw(CG_DYT, p);
+            case CG_UAREA: return raw(CG_DXU, p) * raw(CG_DYU, p);
+            case CG_NAREA: return raw(CG_DXN, p) * raw(CG_DYN, p);
+            case CG_EAREA: return raw(CG_DXE, p) * raw(CG_DYE, p);
+            case CG_EAREAR: { const double a = raw(CG_DXE, p) * raw(CG_DYE, p); return a > 0.0 ? 1.0 / a : 0.0; }
+            case CG_NAREAR: { const double a = raw(CG_DXN, p) * raw(CG_DYN, p); return a > 0.0 ? 1.0 / a : 0.0; }
+            case CG_DMINT: return S.dmin * (raw(CG_DXT, p) * raw(CG_DYT, p));
+            case CG_RXN: return -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
+            case CG_RXNR: return 1.0 / -(raw(CG_DXN, p + 1) / raw(CG_DXN, p));
+            case CG_RYE: return -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
+            case CG_RYER: return 1.0 / -(raw(CG_DYE, p + S.nx) / raw(CG_DYE, p));
+            case CG_EPM: return (bits(p) & 1u) ? 1.0 : 0.0;
+            case CG_NPM: return (bits(p) & 2u) ? 1.0 : 0.0;
+            case CG_UVM: return (bits(p) & 4u) ? 1.0 : 0.0;
+            case CG_HM: return (bits(p) & 8u) ? 1.0 : 0.0;
+            default: return raw(k, p);
+            }
+        }
+    };
+    __device__ __forceinline__ Acc operator[](int k) const { return Acc{*this, k}; }
+};
+template <bool GEO> struct GeoView32;
+template <> struct GeoView32<false> {
+    static __device__ __forceinline__ Slab32 make(const EvpCgrid &, const EvpCgOne &T) { return Slab32{(const char *)T.gbase, (unsigned)T.stride * 8u}; }
+};
+template <> struct GeoView32<true> {
+    static __device__ __forceinline__ DSlab32 make(const EvpCgrid &A, const EvpCgOne &T)
+    {
+        return DSlab32{(const char *)T.gbase, (unsigned)T.stride * 8u, T.gmask, A.nx, A.deltaminEVP};
+    }
+};
 template <bool GEO> struct GeoView;
 template <> struct GeoView<false> {
     static __device__ __forceinline__ Slab make(const EvpCgrid &, const EvpCgOne &T) { return Slab{T.gbase, T.stride}; }
@@ -922,8 +990,8 @@ template <> struct GeoView<true> {
 };
 struct TStress { double zetax2, etax2, sp, sm, shearT; };
 // stressC_T at cell o (ice_dyn_evp.F90:1758-1860) with the four corner values of shearU handed in; spo, smo: previous
-template <class GT>
-__device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const GT &G, const Slab &IN, const double *uE, const double *vN, size_t o,
+template <class GT, class IT, class P>
+__device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const GT &G, const IT &IN, const P &uE, const P &vN, size_t o,
                                             double shO, double shS, double shSW, double shW, double spo, double smo)
 {
     const size_t w = o - 1, s = o - A.nx, sw = s - 1;
@@ -1200,6 +1268,253 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     }
 }
 
+
+// =====================================================================
+// cg_one's subcycle for the INTERIOR of a large block, marched (round 6).  cg_one's window is a workgroup of 64 x 16 positions that
+// owns 61 x 13 cells, four levels behind three barriers, every operand fetched where it is used (some 130 loads per position, most
+// of them of neighbours another lane also fetches, behind branches): on 3600 x 2400 it runs at 0.38 of the HBM peak, and what
+// it waits for is instruction issue and exposed load latency, not bytes.  Here ONE WAVE takes a strip of 64
+// positions (60 owned columns) and walks north over a segment of rows [ja, jb]; per iteration
+//   S (row j) -> T (row j) -> U (row j-1) -> C (row j-1),
+// every operand loaded ONCE per row by the lane that holds the cell, unconditionally and a whole iteration ahead of its use (33 loads
+// per row), east / west neighbours by DPP lane shifts, south neighbours and the level hand-offs carried in registers; products and
+// quotients that several neighbours use (velocity x area, hm x etax2T x tarea, uE / dyE ...) are formed once by their own lane and
+// shifted -- the same operation on the same operands, so the same bits.  No LDS, no barrier, two waves per SIMD.
+// Same arithmetic AT the same cells on the same inputs (the previous subcycle's buffers) as cg_one: which kernel owns a cell does
+// not show in its bits.  Only what the default configuration needs: the short cuts of FAST hold, visc_method = avg_zeta, the derived
+// view of the static table, not the last subcycle of a call (those run cg_one).  Only "regular" positions (interior cells of the
+// block, each its own source): the host hands this kernel the rectangle of the block that cg_one's regular windows cover and keeps
+// the windows along the block's edges for cg_one.
+// Lanes: S on 0..62 (lane 63 only loads: the east neighbour's operands), T on 1..62, U on 1..61, C -- the owned cells -- on 2..61.
+// =====================================================================
+__device__ __forceinline__ double cg_lane_up(double v)    // lane l <- lane l-1 (lane 0: undefined, never used)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double cg_lane_dn(double v)    // lane l <- lane l+1 (lane 63: undefined, never used)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ unsigned cg_lane_dn_u(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+// an array as a wave-uniform base + a 32-bit byte offset per lane: one register per lane addresses every array
+__device__ __forceinline__ double cg_ld(const void *base, unsigned off) { return *(const double *)((const char *)base + (size_t)off); }
+__device__ __forceinline__ unsigned cg_ldb(const uint8_t *base, unsigned cell) { return base[(size_t)cell]; }
+__device__ __forceinline__ void cg_st(void *base, unsigned off, double v) { *(double *)((char *)base + (size_t)off) = v; }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    // workgroups go to the XCDs round-robin: XCD x takes the x-th contiguous run of the item list (x fastest, then segments)
+    const int wg = (int)(blockIdx.x & 7u) * Z.per_xcd + (int)(blockIdx.x >> 3);
+    const int it = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
+    if (it >= Z.nitems) return;
+    const int *w = Z.items + (size_t)it * 6;               // block, column of lane 2, first and last owned row (1-based), first and last owned lane
+    const int blk = __builtin_amdgcn_readfirstlane(w[0]), col = __builtin_amdgcn_readfirstlane(w[1]);
+    const int ja = __builtin_amdgcn_readfirstlane(w[2]), jb = __builtin_amdgcn_readfirstlane(w[3]);
+    const int own_lo = __builtin_amdgcn_readfirstlane(w[4]), own_hi = __builtin_amdgcn_readfirstlane(w[5]);
+    const unsigned nx = (unsigned)A.nx, nx8 = nx * 8u;
+    const bool ownx = lane >= own_lo && lane <= own_hi;
+    const unsigned st8 = (unsigned)T.stride * 8u;
+    const void *gb = T.gbase, *ib = T.inbase;
+    const uint8_t *gm = T.gmask;
+    const EvpScalars &p = A.p;
+    const double relax = 1.0 - p.arlx1i * p.revp;
+    const double dmin = A.deltaminEVP;
+    // cell of (lane, row ja - 4): the row the first iteration calls j.  Three groups of loads run ahead of the arithmetic by
+    // different distances: A (what level S reads of the row north of its own) two rows, B (the rest of S and T) one row, C (level
+    // C's momentum operands, used one row behind) within the iteration.
+    unsigned cell = (unsigned)((size_t)blk * A.plane + (size_t)(ja - 5) * nx + (size_t)(col - 3 + lane));
+    auto G = [&](int k, unsigned off) { return cg_ld(gb, off + (unsigned)k * st8); };
+    auto I = [&](int k, unsigned off) { return cg_ld(ib, off + (unsigned)k * st8); };
+
+    // ---- registers that travel with the rows: suffix N = row j+1, 0 = row j, 1 = row j-1, 2 = row j-2 ----
+    double uEN = 0, dxEN = 0, dyEN = 0; unsigned gN = 0;                     // group A as it arrives
+    double uE0 = 0, uE1 = 0, dxE0 = 0, dyE0 = 0, ea0 = 0, dxE1 = 0, dyE1 = 0, ea1 = 0, eaNc = 0, PNc = 0;
+    unsigned g0 = 0;
+    double vN1 = 0, dxN1 = 0, dyN1 = 0, na1 = 0, Q1 = 0, DV1 = 0, VQ1 = 0, ua1 = 0, XU1 = 0, XU2 = 0, YU1 = 0, XT1 = 0, YT1 = 0, W1 = 0;
+    double sh1 = 0, SS1 = 0, SU1 = 0, un1 = 0, ve1 = 0, R1 = 0, sp1 = 0, sm1 = 0, s12_2 = 0;
+    unsigned m1 = 0;
+    // loads in flight (issued one iteration, used the next)
+    double L_uE = 0, L_dxE = 0, L_dyE = 0; unsigned L_g = 0;                 // A: row j+2
+    double L_vN = 0, L_dxN = 0, L_dyN = 0, L_dxU = 0, L_dyU = 0, L_dxT = 0, L_dyT = 0, L_str = 0, L_sp = 0, L_sm = 0, L_s12t = 0,
+           L_eta = 0, L_shu = 0;                                             // B: row j+1
+    unsigned L_m = 0, m_next = 0;                                            // ice masks: row j+2 in flight, row j+1 arrived
+
+    for (int j = ja - 4; j <= jb + 1; ++j, cell += nx) {
+        // ---- what arrived: A = row j+1, B = row j, C = row j-1 (requested during the previous iteration) ----
+        const double a_uE = L_uE, a_dxE = L_dxE, a_dyE = L_dyE; const unsigned a_g = L_g;
+        const double b_vN = L_vN, b_dxN = L_dxN, b_dyN = L_dyN, b_dxU = L_dxU, b_dyU = L_dyU, b_dxT = L_dxT, b_dyT = L_dyT,
+                     b_str = L_str, b_sp = L_sp, b_sm = L_sm, b_s12t = L_s12t, b_eta = L_eta, b_shu = L_shu;
+        const unsigned m = m_next;                          // ice masks of row j
+        m_next = L_m;
+        // ---- everything the next iteration consumes, requested now ----
+        {
+            const unsigned cN = cell + nx, cNN = cN + nx;             // rows j+1, j+2
+            const unsigned oN = cN * 8u, oNN = oN + nx8;
+            L_uE = cg_ld(T.uE_in, oNN); L_dxE = G(CG_DXE, oNN); L_dyE = G(CG_DYE, oNN); L_g = cg_ldb(gm, cNN);
+            L_m = cg_ldb(A.mask, cNN);
+            L_vN = cg_ld(T.vN_in, oN); L_dxN = G(CG_DXN, oN); L_dyN = G(CG_DYN, oN); L_dxU = G(CG_DXU, oN); L_dyU = G(CG_DYU, oN);
+            L_dxT = G(CG_DXT, oN); L_dyT = G(CG_DYT, oN); L_str = I(CI_STRENGTH, oN);
+            L_sp = cg_ld(T.sp_in, oN); L_sm = cg_ld(T.sm_in, oN); L_s12t = cg_ld(A.f[CF_S12T], oN);
+            // what cells without ice keep (read by very few lanes: the others fetch the array's first line)
+            L_eta = cg_ld(A.f[CF_ETA], (m_next & 1u) ? 0u : oN);
+            L_shu = cg_ld(A.f[CF_SHEARU], (m_next & 2u) ? 0u : oN);
+        }
+        // group C (row j-1) is used at the bottom of THIS iteration: levels S, T and U cover its latency
+        const unsigned o1 = (cell - nx) * 8u;
+        const double c_s12 = cg_ld(A.s12_in, o1);
+        const double c_uoE = I(CI_UOCNE, o1), c_voE = I(CI_VOCNE, o1), c_fcE = cg_ld(A.facE, o1), c_emE = I(CI_EMASSDTI, o1), c_fmE = I(CI_FME, o1),
+                     c_fxE = I(CI_FORCEXE, o1), c_uiE = I(CI_UE_INIT, o1);
+        const double c_voN = I(CI_VOCNN, o1), c_uoN = I(CI_UOCNN, o1), c_fcN = cg_ld(A.facN, o1), c_emN = I(CI_NMASSDTI, o1), c_fmN = I(CI_FMN, o1),
+                     c_fyN = I(CI_FORCEYN, o1), c_viN = I(CI_VN_INIT, o1);
+        // ---- rows move up: last iteration's "north" is this iteration's own row ----
+        uE1 = uE0; uE0 = uEN; uEN = a_uE;
+        dxE1 = dxE0; dyE1 = dyE0; ea1 = ea0;
+        dxE0 = dxEN; dyE0 = dyEN; ea0 = eaNc; dxEN = a_dxE; dyEN = a_dyE;
+        const double P0 = PNc;                              // uE * earea of row j: last iteration's row j+1
+        g0 = gN; gN = a_g;
+        const double eaN = dxEN * dyEN;                     // earea = dxE * dyE (ice_grid.F90:684), row j+1
+        const double PN = uEN * eaN;
+        const double vN0 = b_vN, dxN0 = b_dxN, dyN0 = b_dyN, dxU0 = b_dxU, dyU0 = b_dyU, dxT0 = b_dxT, dyT0 = b_dyT;
+        const double na0 = dxN0 * dyN0, ua0 = dxU0 * dyU0, ta0 = dxT0 * dyT0;
+        const double Q0 = vN0 * na0;
+        const double hm0 = (g0 & 8u) ? 1.0 : 0.0;
+        const double W0 = hm0 * ta0;
+
+        double sh = 0.0, uNo = 0.0, vEo = 0.0, eta = 0.0, sp = 0.0, sm = 0.0, R0 = 0.0, SS0 = 0.0, SU0 = 0.0, DV0 = 0.0, VQ0 = 0.0;
+        if (j >= ja - 2) {
+            // ---- S (row j): strain_rates_U's shear at the corner (ice_dyn_shared.F90:2341-2444), the two averages of level C ----
+            const double ea0W = cg_lane_up(ea0), eaNW = cg_lane_up(eaN), P0W = cg_lane_up(P0), PNW = cg_lane_up(PN);
+            const double na0E = cg_lane_dn(na0), Q0E = cg_lane_dn(Q0), na1E = cg_lane_dn(na1), Q1E = cg_lane_dn(Q1);
+            const double vN0E = cg_lane_dn(vN0), dyN0E = cg_lane_dn(dyN0), dxN0E = cg_lane_dn(dxN0);
+            const unsigned g0E = cg_lane_dn_u(g0);
+            const double epc = (g0 & 1u) ? 1.0 : 0.0, npc = (g0 & 2u) ? 1.0 : 0.0, uvm = (g0 & 4u) ? 1.0 : 0.0;
+            const double npe = (g0E & 2u) ? 1.0 : 0.0, epn = (gN & 1u) ? 1.0 : 0.0;
+            {
+                const double wt = (ea0 + eaN);
+                const double uU = (wt == 0.0 ? 0.0 : (P0 + PN) / wt) * uvm;          // avg_2(uE, earea, o, n)
+                const double wv = (na0 + na0E);
+                const double vU = (wv == 0.0 ? 0.0 : (Q0 + Q0E) / wv) * uvm;          // avg_2(vN, narea, o, e)
+                const double ddyN = dyN0E - dyN0, ddxE = dxEN - dxE0;
+                double rxN = -1.0, rxNr = -1.0, ryE = -1.0, ryEr = -1.0;
+                if (npc != npe) { rxN = -(dxN0E / dxN0); rxNr = 1.0 / -(dxN0E / dxN0); }
+                if (epc != epn) { ryE = -(dyEN / dyE0); ryEr = 1.0 / -(dyEN / dyE0); }
+                const double uEo = uE0, uEn = uEN, vNo = vN0, vNe = vN0E;
+                const double uEijp1 = uEn * epn + (epc - epn) * epc * ryE * uEo;
+                const double uEij = uEo * epc + (epn - epc) * epn * ryEr * uEn;
+                const double vNip1j = vNe * npe + (npc - npe) * npc * rxN * vNo;
+                const double vNij = vNo * npc + (npe - npc) * npe * rxNr * vNe;
+                sh = dxU0 * (uEijp1 - uEij) - uU * ddxE + dyU0 * (vNip1j - vNij) - vU * ddyN;
+                if (!(m & 2u)) sh = b_shu;                 // strain_rates_U leaves cells without ice alone
+            }
+            if (j >= ja && j <= jb) {                      // (owned rows: what level C reads one row behind)
+                const double wn = (ea0W + ea0 + eaNW + eaN);
+                uNo = (wn == 0.0 ? 0.0 : (P0W + P0 + PNW + PN) / wn) * npc;           // avg_nw(uE, earea, o)
+                const double ws = (na1 + na1E + na0 + na0E);
+                vEo = (ws == 0.0 ? 0.0 : (Q1 + Q1E + Q0 + Q0E) / ws) * epc;           // avg_se(vN, narea, o)
+            }
+            // ---- T (row j): stressC_T (ice_dyn_evp.F90:1758-1860) ----
+            {
+                const double DU0 = dyE0 * uE0, UQ0 = uE0 / dyE0;
+                DV0 = dxN0 * vN0; VQ0 = vN0 / dxN0;
+                SS0 = sh * sh * ua0; SU0 = sh * ua0;
+                const double DU0W = cg_lane_up(DU0), UQ0W = cg_lane_up(UQ0), ua0W = cg_lane_up(ua0), ua1W = cg_lane_up(ua1);
+                const double SS0W = cg_lane_up(SS0), SS1W = cg_lane_up(SS1), SU0W = cg_lane_up(SU0), SU1W = cg_lane_up(SU1);
+                sp = b_sp; sm = b_sm; eta = b_eta;
+                if (m & 1u) {
+                    const double divT = DU0 - DU0W + DV0 - DV1;
+                    const double tensionT = (dyT0 * dyT0) * (UQ0 - UQ0W) - (dxT0 * dxT0) * (VQ0 - VQ1);
+                    const double uareaavgr = 1.0 / (ua0 + ua1 + ua1W + ua0W);
+                    const double shearTsqr = (SS0 + SS1 + SS1W + SS0W) * uareaavgr;
+                    const double shearT = (SU0 + SU1 + SU1W + SU0W) * uareaavgr;
+                    const double DeltaT = sqrt(divT * divT + p.e_factor * (tensionT * tensionT + shearTsqr));
+                    double zetax2, etax2, rep_prs;
+                    visc_replpress(p, b_str, dmin * ta0, DeltaT, zetax2, etax2, rep_prs);
+                    eta = etax2;
+                    sp = (b_sp * relax + p.arlx1i * (zetax2 * divT - rep_prs)) * p.denom1;
+                    sm = (b_sm * relax + p.arlx1i * etax2 * tensionT) * p.denom1;
+                    if (ownx && j >= ja && j <= jb) {
+                        const unsigned o0 = cell * 8u;
+                        cg_st(A.f[CF_S12T], o0, (b_s12t * relax + p.arlx1i * 0.5 * etax2 * shearT) * p.denom1);
+                        cg_st(A.f[CF_SP], o0, sp);
+                        cg_st(A.f[CF_SM], o0, sm);
+                    }
+                }
+                R0 = hm0 * eta * ta0;                       // the position's term of the T -> U average of etax2T
+            }
+        }
+        if (j >= ja) {
+            // ---- U (row j-1): stressC_U with the T -> U average of etax2T (ice_dyn_evp.F90:1862-1972, ice_grid.F90 grid_average_X2Y 'NE') ----
+            const double W1E = cg_lane_dn(W1), W0E = cg_lane_dn(W0), R1E = cg_lane_dn(R1), R0E = cg_lane_dn(R0);
+            const double wtmp = (W1 + W1E + W0 + W0E);
+            const double e2 = wtmp == 0.0 ? 0.0 : (R1 + R1E + R0 + R0E) / wtmp;
+            double s12 = c_s12;
+            const double upd = (s12 * relax + p.arlx1i * 0.5 * e2 * sh1) * p.denom1;
+            if (m1 & 2u) s12 = upd;
+            // ---- C (row j-1): div_stress_Ex / _Ny, stepu_C / stepv_C (ice_dyn_evp.F90:2195-2416, ice_dyn_shared.F90:1090-1290) ----
+            const double s12w = cg_lane_up(s12), spe = cg_lane_dn(sp1), sme = cg_lane_dn(sm1);
+            const double YT1E = cg_lane_dn(YT1), YU1W = cg_lane_up(YU1);
+            if (j > ja && ownx) {
+                const unsigned oc = (cell - nx) * 8u;
+                const double s12c = s12, s12s = s12_2;
+                const double spc = sp1, smc = sm1, spn = sp, smn = sm;
+                double unew, vnew;
+                {
+                    const double dyE = dyE1, dxE = dxE1;
+                    const double earear = ea1 > 0.0 ? 1.0 / ea1 : 0.0;
+                    const double strintx = earear * (0.5 * dyE * (spe - spc) + (0.5 / dyE) * (YT1E * sme - YT1 * smc) +
+                                                     (1.0 / dxE) * (XU1 * s12c - XU2 * s12s));
+                    const double uold = uE1, vold = ve1;
+                    const double uocn = c_uoE;
+                    const double du = uocn - uold, dv = c_voE - vold;
+                    const double vrel = c_fcE * sqrt(du * du + dv * dv);
+                    const double taux = vrel * uocn;
+                    const double massdti = c_emE, fm = c_fmE;
+                    const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + 0.0;
+                    const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+                    const double cc1 = strintx + c_fxE + taux + massdti * (p.brlx * uold + p.revp * c_uiE);
+                    unew = (ccb * vold + cc1) / cca;
+                }
+                {
+                    const double dxN = dxN1, dyN = dyN1;
+                    const double narear = na1 > 0.0 ? 1.0 / na1 : 0.0;
+                    const double XT0 = dxT0 * dxT0;
+                    const double strinty = narear * (0.5 * dxN * (spn - spc) - (0.5 / dxN) * (XT0 * smn - XT1 * smc) +
+                                                     (1.0 / dyN) * (YU1 * s12c - YU1W * s12w));
+                    const double uold = un1, vold = vN1;
+                    const double vocn = c_voN;
+                    const double du = c_uoN - uold, dv = vocn - vold;
+                    const double vrel = c_fcN * sqrt(du * du + dv * dv);
+                    const double tauy = vrel * vocn;
+                    const double massdti = c_emN, fm = c_fmN;
+                    const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + 0.0;
+                    const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
+                    const double cc2 = strinty + c_fyN + tauy + massdti * (p.brlx * vold + p.revp * c_viN);
+                    vnew = (-ccb * uold + cc2) / cca;
+                }
+                if (m1 & 2u) cg_st(A.f[CF_S12U], oc, s12c);
+                if (m1 & 4u) cg_st(A.f[CF_UE], oc, unew);
+                if (m1 & 8u) cg_st(A.f[CF_VN], oc, vnew);
+            }
+            s12_2 = s12;
+        }
+        // ---- the rows move on ----
+        eaNc = eaN; PNc = PN;
+        vN1 = vN0; dxN1 = dxN0; dyN1 = dyN0; na1 = na0; Q1 = Q0; DV1 = DV0; VQ1 = VQ0; ua1 = ua0;
+        XU2 = XU1; XU1 = dxU0 * dxU0; YU1 = dyU0 * dyU0; XT1 = dxT0 * dxT0; YT1 = dyT0 * dyT0; W1 = W0;
+        sh1 = sh; SS1 = SS0; SU1 = SU0; un1 = uNo; ve1 = vEo; R1 = R0; sp1 = sp; sm1 = sm; m1 = m;
+    }
+}
+
 }  // namespace
 
 void evp_launch_cgrid_zero_cells(const EvpCgrid &A, const int *cells, int n, hipStream_t st)
@@ -1327,4 +1642,10 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
     }
 #undef CG_ONE_M
 #undef CG_ONE
+}
+
+void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, hipStream_t st)
+{
+    if (Z.nitems <= 0) return;
+    hipLaunchKernelGGL(cg_strip, dim3((unsigned)(8 * Z.per_xcd)), dim3(256), 0, st, A, T, Z);
 }

@@ -38,6 +38,13 @@ struct CGridState {
         double *alt[4] = {};
         unsigned long long *prof = nullptr;   // test build: phase stamps (CICE_EVP_HIP_CGRID_PROF=1)
         int flip = 0;            // which allocation f[CF_UE], f[CF_VN], f[CF_SP], f[CF_SM] are (part of the graph key)
+        // the interior of large blocks marched (evp_cgrid.hip: cg_strip): its items, and the windows cg_one keeps (the block edges)
+        int *items = nullptr;
+        int4 *tiles_e = nullptr;
+        int *tab_e = nullptr;
+        int nitems = 0, ntiles_e = 0, strip_seg = 0;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the edge windows run beside the marched kernel on the second stream
+        long strip_cells = 0;    // cells the marched kernel owns
     } one;
     // all subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res)
     struct Res {
@@ -117,7 +124,9 @@ void cgrid_free()
     for (auto &p : CG.in) p = nullptr;
     for (auto &p : CG.g) p = nullptr;
     F(CG.tarear); for (auto &p : CG.post) F(p);
-    F(CG.one.tab); F(CG.one.tiles); for (auto &p : CG.one.alt) F(p);
+    F(CG.one.tab); F(CG.one.tiles); F(CG.one.items); F(CG.one.tiles_e); F(CG.one.tab_e); for (auto &p : CG.one.alt) F(p);
+    if (CG.one.ev_fork) (void)hipEventDestroy(CG.one.ev_fork);
+    if (CG.one.ev_join) (void)hipEventDestroy(CG.one.ev_join);
     CG.one = CGridState::One{};
     F(CG.res.tab); F(CG.res.tiles); F(CG.res.tiles2); F(CG.res.pubmap); F(CG.res.gmask); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs); F(CG.res.prof); F(CG.res.d_order); F(CG.res.live_win); F(CG.res.live_cell);
     CG.res = CGridState::Res{};
@@ -370,7 +379,29 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
-            evp_launch_cgrid_one(A, T, CG.fast ? 1 : 0, last, S.stream);
+            if (CG.one.nitems > 0 && CG.fast && !CG.avg_strength && !last && T.gmask) {
+                // the interior of the blocks marched, the windows along their edges as before: both read the previous
+                // subcycle's buffers only and own disjoint cells
+                EvpCgStrip Z{CG.one.items, CG.one.nitems, ((CG.one.nitems + 3) / 4 + 7) / 8};
+                EvpCgOne E = T;
+                E.tab = CG.one.tab_e; E.tiles = CG.one.tiles_e; E.ntiles = CG.one.ntiles_e; E.per_xcd = (CG.one.ntiles_e + 7) / 8;
+                E.prof = nullptr;
+                const bool beside = E.ntiles > 0 && !(env_test("CICE_EVP_HIP_CGRID_STRIP_SERIAL") && std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_SERIAL")));
+                if (beside) {
+                    HIPC(hipEventRecord(CG.one.ev_fork, S.stream));
+                    HIPC(hipStreamWaitEvent(S.stream_comm, CG.one.ev_fork, 0));
+                    evp_launch_cgrid_one(A, E, 1, 0, S.stream_comm);
+                }
+                evp_launch_cgrid_strip(A, T, Z, S.stream);
+                if (beside) {
+                    HIPC(hipEventRecord(CG.one.ev_join, S.stream_comm));
+                    HIPC(hipStreamWaitEvent(S.stream, CG.one.ev_join, 0));
+                } else if (E.ntiles > 0) {
+                    evp_launch_cgrid_one(A, E, 1, 0, S.stream);
+                }
+            } else if (T.ntiles > 0) {
+                evp_launch_cgrid_one(A, T, CG.fast ? 1 : 0, last, S.stream);
+            }
             std::swap(cur, other);
             for (int q = 0; q < 4; ++q) std::swap(c4[q], o4[q]);
             continue;
@@ -507,6 +538,92 @@ static int build_one_tables()
     if (env_test("CICE_EVP_HIP_CGRID_PROF") && std::atoi(env_test("CICE_EVP_HIP_CGRID_PROF"))) {
         HIPC(hipMalloc((void **)&O.prof, (size_t)O.ntiles * 8 * sizeof(unsigned long long)));
         HIPC(hipMemsetAsync(O.prof, 0, (size_t)O.ntiles * 8 * sizeof(unsigned long long), S.stream));
+    }
+    // ---- the marched kernel's share (cg_strip): per block the rectangle its regular windows cover, if they form one ----
+    // default: large domains (the 64 x 16 windows), the rectangle at least half of the cells; CICE_EVP_HIP_CGRID_STRIP=0 / 1 (test
+    // build) switches it off / on wherever a regular window exists, CICE_EVP_HIP_CGRID_STRIP_SEG=<rows> sets the segment length
+    {
+        const int nt = O.ntiles, sx = OX - 3, sy = OY - 3;
+        int want = shape == 2 ? 2 : 0;              // 2: auto
+        if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP")) want = std::atoi(e) ? 1 : 0;
+        struct Zone { int b, i0, i1, j0, j1; };       // first owned column of the first / last window column, same for rows
+        std::vector<Zone> zones;
+        long zcells = 0;
+        std::vector<uint8_t> in_zone((size_t)nt, 0);
+        if ((double)S.n * 8.0 * std::max((int)CG_NG, (int)CG_NIN) >= 4294967296.0) want = 0;     // (the kernel's 32-bit offsets into the tables)
+        for (int b = 0; b < d.nblocks && want && OX == 64; ++b) {
+            int i0 = 1 << 30, i1 = -1, j0 = 1 << 30, j1 = -1, cnt = 0;
+            for (int w = 0; w < nt; ++w)
+                if (tiles[4 * w] == b && tiles[4 * w + 3]) {
+                    i0 = std::min(i0, tiles[4 * w + 1]); i1 = std::max(i1, tiles[4 * w + 1]);
+                    j0 = std::min(j0, tiles[4 * w + 2]); j1 = std::max(j1, tiles[4 * w + 2]);
+                    ++cnt;
+                }
+            if (!cnt || (i1 - i0) % sx || (j1 - j0) % sy) continue;
+            if (cnt != ((i1 - i0) / sx + 1) * ((j1 - j0) / sy + 1)) continue;       // (not a rectangle: cg_one keeps the block)
+            // (cells with ghost images -- the block's outermost interior cells -- never lie inside: the marched kernel has no pushes)
+            bool images = false;
+            for (int j = j0; j <= j1 + sy - 1 && !images; ++j)
+                for (int i = i0; i <= i1 + sx - 1 && !images; ++i)
+                    images = !CG.h_img_slot.empty() && CG.h_img_slot[(size_t)b * d.nx_block * d.ny_block + (size_t)(j - 1) * d.nx_block + (i - 1)] >= 0;
+            if (images) continue;
+            zones.push_back(Zone{b, i0, i1, j0, j1});
+            zcells += (long)(i1 - i0 + sx) * (j1 - j0 + sy);
+        }
+        long interior = 0;
+        for (int b = 0; b < d.nblocks; ++b) interior += (long)(d.ihi[b] - d.ilo[b] + 1) * (d.jhi[b] - d.jlo[b] + 1);
+        if (want == 2 && 2 * zcells < interior) zones.clear();
+        if (!zones.empty()) {
+            // strips of 60 owned columns (lanes 2 .. 61 of the wave; the last strip of a rectangle is shifted west so that its lanes
+            // stay inside it and owns what is left); segments: about two waves per SIMD resident at once over all strips
+            // (256 CUs x 8), at least 16 rows
+            constexpr int SOWN = 60;
+            long nstrips = 0, maxrows = 0;
+            for (const Zone &z : zones) { nstrips += (z.i1 - z.i0 + sx + SOWN - 1) / SOWN; maxrows = std::max<long>(maxrows, z.j1 - z.j0 + sy); }
+            // (measured, 3600 x 2400: 2006 items of 70 rows 567 us per subcycle; 2065 items -- 17 more than fit at once -- 693;
+            // 2950 x 48 597, 4720 x 30 603, 11741 x 12 624: one round of work, as long as possible)
+            const long nseg_fit = std::max<long>(1, 2048 / std::max<long>(1, nstrips));
+            int seg = (int)std::max<long>(16, (maxrows + nseg_fit - 1) / nseg_fit);
+            if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_SEG")) seg = std::max(1, std::atoi(e));
+            std::vector<int32_t> items;
+            for (const Zone &z : zones) {
+                const int rows = z.j1 - z.j0 + sy, nseg = (rows + seg - 1) / seg;
+                const int ilast = z.i1 + sx - 1;                       // last owned column of the rectangle
+                for (int k = 0; k < nseg; ++k) {
+                    // (equal segments: rows / nseg, the remainder one row each to the first ones)
+                    const int ja = z.j0 + (int)((long)rows * k / nseg), jb = z.j0 + (int)((long)rows * (k + 1) / nseg) - 1;
+                    for (int i0 = z.i0; i0 <= ilast; i0 += SOWN) {
+                        const int c = std::min(i0, std::max(z.i0, ilast - SOWN + 1));      // column of lane 2
+                        const int lo = 2 + (i0 - c), hi = std::min(61, 2 + (ilast - c));
+                        items.push_back(z.b); items.push_back(c); items.push_back(ja); items.push_back(jb);
+                        items.push_back(lo); items.push_back(hi);
+                    }
+                }
+                for (int w = 0; w < nt; ++w)
+                    if (tiles[4 * w] == z.b && tiles[4 * w + 3]) in_zone[(size_t)w] = 1;
+            }
+            std::vector<int32_t> tiles_e, tab_e;
+            const size_t per = (size_t)OX * OY;
+            for (int w = 0; w < nt; ++w)
+                if (!in_zone[(size_t)w]) {
+                    tiles_e.insert(tiles_e.end(), tiles.begin() + 4 * w, tiles.begin() + 4 * w + 4);
+                    tab_e.insert(tab_e.end(), tab.begin() + (size_t)w * per, tab.begin() + (size_t)(w + 1) * per);
+                }
+            O.nitems = (int)(items.size() / 6);
+            HIPC(hipEventCreateWithFlags(&O.ev_fork, hipEventDisableTiming));
+            HIPC(hipEventCreateWithFlags(&O.ev_join, hipEventDisableTiming));
+            O.ntiles_e = (int)(tiles_e.size() / 4);
+            O.strip_seg = seg;
+            O.strip_cells = zcells;
+            HIPC(hipMalloc((void **)&O.items, items.size() * sizeof(int32_t)));
+            HIPC(hipMemcpy(O.items, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (O.ntiles_e) {
+                HIPC(hipMalloc((void **)&O.tiles_e, tiles_e.size() * sizeof(int32_t)));
+                HIPC(hipMalloc((void **)&O.tab_e, tab_e.size() * sizeof(int32_t)));
+                HIPC(hipMemcpy(O.tiles_e, tiles_e.data(), tiles_e.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                HIPC(hipMemcpy(O.tab_e, tab_e.data(), tab_e.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+        }
     }
     HIPC(hipStreamSynchronize(S.stream));       // (the host vectors go out of scope)
     return 0;
@@ -1441,6 +1558,10 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     if (n >= 8) out[7] = (double)CG.res.fallbacks;    // cice_evp_hip_cgrid_run calls repeated without it after one of its waits gave up
     if (n >= 9) out[8] = (double)CG.res.n_live;       // windows of the resident kernel that hold ice in this call (only they run) ...
     if (n >= 10) out[9] = (double)CG.res.ntiles;      // ... of so many
+    if (n >= 11) out[10] = (double)CG.one.nitems;     // the one-launch schedule's marched kernel (cg_strip): work items (0: not in use) ...
+    if (n >= 12) out[11] = (double)CG.one.strip_cells;   // ... the cells it owns ...
+    if (n >= 13) out[12] = (double)CG.one.ntiles_e;   // ... and the windows cg_one keeps beside it
+    if (n >= 14) out[13] = (double)CG.one.strip_seg;  // ... rows per segment
     return 0;
 }
 

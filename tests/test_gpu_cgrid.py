@@ -655,6 +655,76 @@ def test_cgrid_random_masks_vs_oracle_bitwise(seed, nx, ny, bs, ew, ns, holes, v
         assert np.abs(want["uvelE"] - args[3]["uvelE"]).max() > 0
 
 
+def marched_case(seed, nx, ny, bs, case, holes, land):
+    """A synthetic workload in the default configuration (the reference's start-up identities hold for the geometry, waterx == uocn,
+    Tb == 0, rheofact == 1 on ice: what the marched kernel is for) with the branches stirred up: random land cells inside the ocean
+    (coastal corners: the boundary-condition ratios), random, mutually independent holes in the four ice masks."""
+    from cice_amd import decomp, synth
+    rng = np.random.default_rng(seed)
+    g0 = synth.make_grid(nx, ny, 2.0e4, ns="closed")
+    g0["kmt"] = g0["kmt"] * (rng.random((ny, nx)) >= land)
+    g = synth.derive_geometry(g0)
+    cg = synth.cgrid_geometry(g)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed)
+    for k in masks:
+        masks[k] = masks[k] * (rng.random((ny, nx)) >= holes).astype(np.int32)
+    for k in ("stresspT", "stressmT", "stress12T"):
+        state[k] = state[k] * masks["iceTmask"]
+    state["stress12U"] = state["stress12U"] * masks["iceUmask"]
+    dc = decomp.Decomp(nx, ny, bs[0], bs[1], "cyclic", "closed", 1)
+    return (dc, g) + synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
+
+
+@pytest.mark.parametrize("seed,nx,ny,bs,case,holes,land,revised,seg,shape", [
+    (21, 200, 48, (200, 48), "full", 0.2, 0.02, False, None, "2"),       # one block: 64 x 16 windows, default segments
+    (22, 330, 40, (330, 40), "caps", 0.4, 0.05, True, "7", "1"),         # 64 x 8 windows, segments of 7 rows, revised EVP
+    (23, 400, 64, (200, 32), "full", 0.3, 0.0, False, "5", "1"),         # 2 x 2 blocks, each with a marched interior
+    (24, 140, 90, (140, 90), "full", 1.1, 0.0, False, "1", "2"),         # no ice at all; one row per segment
+    (25, 260, 72, (260, 72), "full", 0.0, 0.1, False, "64", "2"),        # ice everywhere, many islands; one segment per strip
+    (26, 190, 50, (190, 50), "caps", 0.1, 0.01, False, "3", "2"),        # the last strip shifted west (68 columns: 60 + 8)
+])
+def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes, land, revised, seg, shape, monkeypatch):
+    """The one-launch schedule with the interior of each block marched (evp_cgrid.hip: cg_strip; the default on the 0.1-degree
+    class only) forced onto small blocks: every array of the loop equal to the oracle's, bit for bit, and equal to the windowed
+    kernel's; the last subcycle of the call (the once-per-call arrays) and the first run as before."""
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "0")
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", shape)
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP", "1")
+    if seg:
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_SEG", seg)
+    from cice_amd import synth
+    dc, _, static, state, inputs, masks = marched_case(seed, nx, ny, bs, case, holes, land)
+    kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
+    scal = synth.evp_scalars(120, **kw)
+    d, keep = evp.make_dims(dc, 0)
+
+    def run():
+        core = evp.EvpHip(d, evp.make_params(scal, strict=True), static["dyE"], static["dxN"], static["dxT"], static["dyT"],
+                          1.0 / static["uarea"], static["tarea"], keepalive=keep)
+        try:
+            core.cgrid_set_geometry(static)
+            out = core.cgrid_run(9, state, inputs, masks)
+            return out, core.cgrid_timings()
+        finally:
+            core.finalize()
+    got, tt = run()
+    assert tt["marched_items"] > 0 and tt["one_launch_subcycles"] == 8 and tt["geometry_derived"], tt
+    blks = dc.local_blocks(0)
+    dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
+                              [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
+                              [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
+    prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
+                                                      "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
+    want = oracle.cgrid_subcycle(dom, prm, 9, state, inputs, static, masks)
+    assert_bitwise(got, want, f"marched interior seed {seed}")
+    if holes < 1.0:
+        assert np.abs(want["uvelE"] - state["uvelE"]).max() > 0
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP", "0")
+    windowed, tw = run()
+    assert tw["marched_items"] == 0 and tw["one_launch_subcycles"] == 8, tw
+    assert_bitwise(got, windowed, f"marched interior against the windowed kernel, seed {seed}")
+
+
 def test_cgrid_default_configuration_shortcuts_are_bit_neutral(monkeypatch):
     """cg_stress_u_step<true> (taken when waterx == uocn, Tb == +0 and rheofact == 1 hold bit for bit on every ice
     cell of a call: the reference's default configuration) against the general kernel (CICE_EVP_HIP_CGRID_FAST=0) and

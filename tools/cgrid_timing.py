@@ -55,7 +55,7 @@ def main():
             ncell = dc.nx_global * dc.ny_global
             nact = int(masks["iceTmask"].sum())
             tt = core.cgrid_timings()
-            print(f"CGRID {grid} {a.case} {a.visc}{' seabed' if a.seabed else ''} one_launch={tt['one_launch_subcycles']} resident={tt['resident_subcycles']} windows_with_ice={tt['resident_windows_with_ice']}/{tt['resident_windows']} geometry_derived={tt['geometry_derived']}: {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
+            print(f"CGRID {grid} {a.case} {a.visc}{' seabed' if a.seabed else ''} one_launch={tt['one_launch_subcycles']} resident={tt['resident_subcycles']} windows_with_ice={tt['resident_windows_with_ice']}/{tt['resident_windows']} geometry_derived={tt['geometry_derived']} marched={tt['marched_items']} items x {tt['marched_segment_rows']} rows ({tt['marched_cells']} cells; {tt['marched_edge_windows']} windows beside): {best * 1e3 / a.ndte:.2f} us/subcycle (best of {a.reps}; first {ts[0] * 1e3 / a.ndte:.2f}), "
                   f"{ncell / (best * 1e-3 / a.ndte):.3e} cell-updates/s, active T {nact}/{ncell}", flush=True)
         finally:
             core.finalize()
