@@ -1019,7 +1019,7 @@ __device__ __forceinline__ TStress t_stress(const EvpCgrid &A, const GT &G, cons
 // that TWO workgroups in different phases share a CU where the 1024-thread one is alone: 3600 x 2400 804 us against 798,
 // avg_strength 952 against 874 -- the workgroup's phases are not what the CU waits for.  Taken out again.)
 template <bool FAST, int ONE_X, int ONE_Y, int MODE, bool GEO>
-__global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, int last)
+__device__ __forceinline__ void cg_one_window(const EvpCgrid &A, const EvpCgOne &T, int last, int t, int tx, int ty)
 {
     constexpr bool AVGS = MODE == 2;
     __shared__ double s_sh[ONE_Y][ONE_X], s_un[ONE_Y][ONE_X], s_ve[ONE_Y][ONE_X];
@@ -1033,9 +1033,7 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
     // alive in scalar registers that spill into vector ones, 109 -> 140 registers, one wave per SIMD less; 3600 x 2400
     // 786 -> 937 us, gx1 16.9 -> 25.9.  Taken out.  Forcing MORE waves per SIMD with a register cap -- 80 registers for the 512-thread
     // shapes, 64 for this one -- spills 38 / 69 registers to scratch: 3600 x 2400 1432 / 1690 us.)
-    const int t = T.plain ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
     if (t >= T.ntiles) return;
-    const int tx = threadIdx.x, ty = threadIdx.y;
     const int4 tl = T.tiles[t];                          // block, first owned i, first owned j (1-based)
     const int4 q = A.blk[tl.x];
     const int i = tl.y - 2 + tx, j = tl.z - 2 + ty;      // the position in the block's own numbering (may lie outside its array)
@@ -1269,6 +1267,14 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
 }
 
 
+template <bool FAST, int ONE_X, int ONE_Y, int MODE, bool GEO>
+__global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, int last)
+{
+    // workgroups go to the XCDs round-robin: XCD x gets the x-th contiguous run of the (space-ordered) window list
+    const int t = T.plain ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * T.per_xcd + (int)(blockIdx.x >> 3);
+    cg_one_window<FAST, ONE_X, ONE_Y, MODE, GEO>(A, T, last, t, (int)threadIdx.x, (int)threadIdx.y);
+}
+
 // =====================================================================
 // cg_one's subcycle for the INTERIOR of a large block, marched (round 6).  cg_one's window is a workgroup of 64 x 16 positions that
 // owns 61 x 13 cells, four levels behind three barriers, every operand fetched where it is used (some 130 loads per position, most
@@ -1310,8 +1316,16 @@ __device__ __forceinline__ double cg_ld(const void *base, unsigned off) { return
 __device__ __forceinline__ unsigned cg_ldb(const uint8_t *base, unsigned cell) { return base[(size_t)cell]; }
 __device__ __forceinline__ void cg_st(void *base, unsigned off, double v) { *(double *)((char *)base + (size_t)off) = v; }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z)
+// In the same launch, numbered after the marched kernel's workgroups: the windows cg_one keeps along the block's edges (E), as
+// workgroups of 256 threads (32 x 8 positions).  They take the places the first marched workgroups to finish leave, instead of a
+// launch of their own behind it (51 us on 3600 x 2400 for 2.6 % of the cells: every window a round trip of four dependent levels).
+// (The marched part is written into the kernel itself: as an inlined device function it comes out 11 registers fatter and spills.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z, EvpCgOne E)
 {
+    if ((int)blockIdx.x >= 8 * Z.per_xcd) {
+        cg_one_window<true, 32, 8, 0, true>(A, E, 0, (int)blockIdx.x - 8 * Z.per_xcd, (int)(threadIdx.x & 31u), (int)(threadIdx.x >> 5));
+        return;
+    }
     const int lane = (int)(threadIdx.x & 63u);
     // workgroups go to the XCDs round-robin: XCD x takes the x-th contiguous run of the item list (x fastest, then segments)
     const int wg = (int)(blockIdx.x & 7u) * Z.per_xcd + (int)(blockIdx.x >> 3);
@@ -1329,6 +1343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const EvpScalars &p = A.p;
     const double relax = 1.0 - p.arlx1i * p.revp;
     const double dmin = A.deltaminEVP;
+    const bool revised = p.revp != 0.0;
     // cell of (lane, row ja - 4): the row the first iteration calls j.  Three groups of loads run ahead of the arithmetic by
     // different distances: A (what level S reads of the row north of its own) two rows, B (the rest of S and T) one row, C (level
     // C's momentum operands, used one row behind) within the iteration.
@@ -1373,9 +1388,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned o1 = (cell - nx) * 8u;
         const double c_s12 = cg_ld(A.s12_in, o1);
         const double c_uoE = I(CI_UOCNE, o1), c_voE = I(CI_VOCNE, o1), c_fcE = cg_ld(A.facE, o1), c_emE = I(CI_EMASSDTI, o1), c_fmE = I(CI_FME, o1),
-                     c_fxE = I(CI_FORCEXE, o1), c_uiE = I(CI_UE_INIT, o1);
+                     c_fxE = I(CI_FORCEXE, o1);
         const double c_voN = I(CI_VOCNN, o1), c_uoN = I(CI_UOCNN, o1), c_fcN = cg_ld(A.facN, o1), c_emN = I(CI_NMASSDTI, o1), c_fmN = I(CI_FMN, o1),
-                     c_fyN = I(CI_FORCEYN, o1), c_viN = I(CI_VN_INIT, o1);
+                     c_fyN = I(CI_FORCEYN, o1);
+        // classic EVP (revp == 0): revp * uvelE_init is a zero and the initial velocities are not read (as in the B-grid kernels,
+        // evp_cell.inc: the sum keeps the add of +0; a zero of the other sign could only show where uold is -0 exactly)
+        double c_uiE = 0.0, c_viN = 0.0;
+        if (revised) { c_uiE = I(CI_UE_INIT, o1); c_viN = I(CI_VN_INIT, o1); }
         // ---- rows move up: last iteration's "north" is this iteration's own row ----
         uE1 = uE0; uE0 = uEN; uEN = a_uE;
         dxE1 = dxE0; dyE1 = dyE0; ea1 = ea0;
@@ -1644,8 +1663,12 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 #undef CG_ONE
 }
 
-void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, hipStream_t st)
+void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, hipStream_t st)
 {
     if (Z.nitems <= 0) return;
-    hipLaunchKernelGGL(cg_strip, dim3((unsigned)(8 * Z.per_xcd)), dim3(256), 0, st, A, T, Z);
+    // E: windows of 32 x 8 positions to run in the same launch (NULL: none)
+    EvpCgOne none = T;
+    none.ntiles = 0;
+    const EvpCgOne &W = (E && E->ntiles > 0) ? *E : none;
+    hipLaunchKernelGGL(cg_strip, dim3((unsigned)(8 * Z.per_xcd + W.ntiles)), dim3(256), 0, st, A, T, Z, W);
 }

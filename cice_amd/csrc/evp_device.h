@@ -404,7 +404,7 @@ struct EvpCgStrip {
     const int *items;             // x 6: block, column of lane 2, first and last owned row (1-based), first and last owned lane
     int nitems, per_xcd;          // items; workgroups (of four items) per XCD (launch = 8 * per_xcd workgroups)
 };
-void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, hipStream_t st);
+void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, hipStream_t st);
 // All subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res).  Windows of 16 x 16 positions, the inner
 // 13 x 13 owned; tab: per window the source cell of its 17 x 17 positions (one row / column more than cg_one's: what level S reads
 // of its north / east neighbour), as in EvpCgOne.  The velocities another window's rim mirrors travel as tagged 32-byte records.

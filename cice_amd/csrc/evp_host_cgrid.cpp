@@ -42,8 +42,7 @@ struct CGridState {
         int *items = nullptr;
         int4 *tiles_e = nullptr;
         int *tab_e = nullptr;
-        int nitems = 0, ntiles_e = 0, strip_seg = 0;
-        hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the edge windows run beside the marched kernel on the second stream
+        int nitems = 0, ntiles_e = 0, strip_seg = 0, ex = 0, ey = 0;   // (ex, ey: shape of the windows kept)
         long strip_cells = 0;    // cells the marched kernel owns
     } one;
     // all subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res)
@@ -125,8 +124,6 @@ void cgrid_free()
     for (auto &p : CG.g) p = nullptr;
     F(CG.tarear); for (auto &p : CG.post) F(p);
     F(CG.one.tab); F(CG.one.tiles); F(CG.one.items); F(CG.one.tiles_e); F(CG.one.tab_e); for (auto &p : CG.one.alt) F(p);
-    if (CG.one.ev_fork) (void)hipEventDestroy(CG.one.ev_fork);
-    if (CG.one.ev_join) (void)hipEventDestroy(CG.one.ev_join);
     CG.one = CGridState::One{};
     F(CG.res.tab); F(CG.res.tiles); F(CG.res.tiles2); F(CG.res.pubmap); F(CG.res.gmask); F(CG.res.rec); F(CG.res.err); F(CG.res.pairs); F(CG.res.prof); F(CG.res.d_order); F(CG.res.live_win); F(CG.res.live_cell);
     CG.res = CGridState::Res{};
@@ -385,20 +382,14 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
                 EvpCgStrip Z{CG.one.items, CG.one.nitems, ((CG.one.nitems + 3) / 4 + 7) / 8};
                 EvpCgOne E = T;
                 E.tab = CG.one.tab_e; E.tiles = CG.one.tiles_e; E.ntiles = CG.one.ntiles_e; E.per_xcd = (CG.one.ntiles_e + 7) / 8;
+                E.ox = CG.one.ex; E.oy = CG.one.ey;
                 E.prof = nullptr;
-                const bool beside = E.ntiles > 0 && !(env_test("CICE_EVP_HIP_CGRID_STRIP_SERIAL") && std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_SERIAL")));
-                if (beside) {
-                    HIPC(hipEventRecord(CG.one.ev_fork, S.stream));
-                    HIPC(hipStreamWaitEvent(S.stream_comm, CG.one.ev_fork, 0));
-                    evp_launch_cgrid_one(A, E, 1, 0, S.stream_comm);
-                }
-                evp_launch_cgrid_strip(A, T, Z, S.stream);
-                if (beside) {
-                    HIPC(hipEventRecord(CG.one.ev_join, S.stream_comm));
-                    HIPC(hipStreamWaitEvent(S.stream, CG.one.ev_join, 0));
-                } else if (E.ntiles > 0) {
-                    evp_launch_cgrid_one(A, E, 1, 0, S.stream);
-                }
+                // (the edge windows on the second stream beside the marched kernel: measured no gain, 565 us against 552 -- a
+                // 1024-thread workgroup does not fit beside the marched kernel's waves on a CU anyway)
+                // windows of 32 x 8 ride in the marched kernel's launch; other shapes (A/B) get a launch of their own behind it
+                const bool ride = E.ox == 32 && E.oy == 8 && !(env_test("CICE_EVP_HIP_CGRID_STRIP_RIDE") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_RIDE")));
+                evp_launch_cgrid_strip(A, T, Z, ride ? &E : nullptr, S.stream);
+                if (!ride && E.ntiles > 0) evp_launch_cgrid_one(A, E, 1, 0, S.stream);
             } else if (T.ntiles > 0) {
                 evp_launch_cgrid_one(A, T, CG.fast ? 1 : 0, last, S.stream);
             }
@@ -543,15 +534,27 @@ static int build_one_tables()
     // default: large domains (the 64 x 16 windows), the rectangle at least half of the cells; CICE_EVP_HIP_CGRID_STRIP=0 / 1 (test
     // build) switches it off / on wherever a regular window exists, CICE_EVP_HIP_CGRID_STRIP_SEG=<rows> sets the segment length
     {
-        const int nt = O.ntiles, sx = OX - 3, sy = OY - 3;
         int want = shape == 2 ? 2 : 0;              // 2: auto
         if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP")) want = std::atoi(e) ? 1 : 0;
+        // the windows cg_one keeps beside the marched kernel -- a frame one window deep along the block's edges -- are cut
+        // smaller than the ones it covers a whole domain with: 32 x 8 positions (29 x 5 owned), 256 threads, four workgroups per CU
+        // in one round instead of two rounds of 1024-thread ones (3600 x 2400: the frame 51 us -> see DESIGN.md section 7)
+        int eshape = 0;
+        if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_EDGE")) eshape = std::min(2, std::max(0, std::atoi(e)));
+        const int EX = eshape ? 64 : 32, EY = eshape == 2 ? 16 : 8;
+        std::vector<int32_t> etiles, etab;
+        if (want && (EX != OX || EY != OY)) {
+            build_window_table(d, P, EX, EY, 1 << 20, etiles, etab);
+            tiles.swap(etiles);
+            tab.swap(etab);
+        }
+        const int nt = (int)(tiles.size() / 4), sx = EX - 3, sy = EY - 3;
         struct Zone { int b, i0, i1, j0, j1; };       // first owned column of the first / last window column, same for rows
         std::vector<Zone> zones;
         long zcells = 0;
         std::vector<uint8_t> in_zone((size_t)nt, 0);
         if ((double)S.n * 8.0 * std::max((int)CG_NG, (int)CG_NIN) >= 4294967296.0) want = 0;     // (the kernel's 32-bit offsets into the tables)
-        for (int b = 0; b < d.nblocks && want && OX == 64; ++b) {
+        for (int b = 0; b < d.nblocks && want; ++b) {
             int i0 = 1 << 30, i1 = -1, j0 = 1 << 30, j1 = -1, cnt = 0;
             for (int w = 0; w < nt; ++w)
                 if (tiles[4 * w] == b && tiles[4 * w + 3]) {
@@ -603,16 +606,15 @@ static int build_one_tables()
                     if (tiles[4 * w] == z.b && tiles[4 * w + 3]) in_zone[(size_t)w] = 1;
             }
             std::vector<int32_t> tiles_e, tab_e;
-            const size_t per = (size_t)OX * OY;
+            const size_t per = (size_t)EX * EY;
             for (int w = 0; w < nt; ++w)
                 if (!in_zone[(size_t)w]) {
                     tiles_e.insert(tiles_e.end(), tiles.begin() + 4 * w, tiles.begin() + 4 * w + 4);
                     tab_e.insert(tab_e.end(), tab.begin() + (size_t)w * per, tab.begin() + (size_t)(w + 1) * per);
                 }
             O.nitems = (int)(items.size() / 6);
-            HIPC(hipEventCreateWithFlags(&O.ev_fork, hipEventDisableTiming));
-            HIPC(hipEventCreateWithFlags(&O.ev_join, hipEventDisableTiming));
             O.ntiles_e = (int)(tiles_e.size() / 4);
+            O.ex = EX; O.ey = EY;
             O.strip_seg = seg;
             O.strip_cells = zcells;
             HIPC(hipMalloc((void **)&O.items, items.size() * sizeof(int32_t)));

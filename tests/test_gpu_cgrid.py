@@ -692,6 +692,8 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP", "1")
     if seg:
         monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_SEG", seg)
+    if seed in (22, 23):          # the windows kept along the edges: 64 x 8 / 64 x 16 instead of 32 x 8
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_EDGE", "1" if seed == 22 else "2")
     from cice_amd import synth
     dc, _, static, state, inputs, masks = marched_case(seed, nx, ny, bs, case, holes, land)
     kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
