@@ -674,6 +674,7 @@ def main():
             res_n = tt_["resident_subcycles"]
             res_probe_us = 1e3 * tt_["resident_probe_ms"]
             geo = tt_["geometry_derived"]
+            marched = tt_["marched_items"]
             out = core.cgrid_download()
         finally:
             core.finalize()
@@ -709,8 +710,12 @@ def main():
                 "value": nx * ny * ndte * steps / wall, "unit": "cell-updates/s", "steps": steps, "warmup": warmup,
                 "us_per_subcycle": 1e6 * t_sub, "us_per_subcycle_wall": 1e6 * wall / (steps * ndte),
                 "launches_per_subcycle": launches, "active_T_cells": n_active,
-                "kernel": ("cg_res (on-chip resident: all subcycles of a call in one launch" + (", FOLD variant)" if ns == "tripole" else ")") if res_n else "cg_one" if one
+                "kernel": ("cg_res (on-chip resident: all subcycles of a call in one launch" + (", FOLD variant)" if ns == "tripole" else ")") if res_n
+                           else "cg_strip (the block's interior marched: one wave per strip of 60 columns x segment of rows) with cg_one's windows along the "
+                                "block's edges in the same launch; the last subcycle of a call: cg_one" if (one and marched) else "cg_one" if one
                            else "five phases + five fold steps" if ns == "tripole" else "fused schedule, three launches"),
+                "marched_items": marched or None, "marched_segment_rows": (tt_["marched_segment_rows"] if marched else None),
+                "marched_cells": (tt_["marched_cells"] if marched else None), "windows_beside_marched": (tt_["marched_edge_windows"] if marched else None),
                 "resident_subcycles_per_call": res_n, "resident_probe_us_per_subcycle": (res_probe_us if res_n else None),
                 "resident_windows_with_ice": (tt_["resident_windows_with_ice"] if res_n else None), "resident_windows": (tt_["resident_windows"] if res_n else None),
                 "verified": (h.hexdigest() == want["sha256"]) if want else None,
