@@ -1320,6 +1320,11 @@ __device__ __forceinline__ void cg_st(void *base, unsigned off, double v) { *(do
 // workgroups of 256 threads (32 x 8 positions).  They take the places the first marched workgroups to finish leave, instead of a
 // launch of their own behind it (51 us on 3600 x 2400 for 2.6 % of the cells: every window a round trip of four dependent levels).
 // (The marched part is written into the kernel itself: as an inlined device function it comes out 11 registers fatter and spills.)
+// LEN: the six lengths dxT, dyT, dxU, dyU, dxE, dyN are formed from dxN (= HTN) and dyE (= HTE) by the reference's start-up
+// formulas (ice_grid.F90:3063-3280: two- and four-point means; the host has verified them bit for bit on every cell the kernel
+// touches) instead of loaded: 27 loads per row instead of 33, 48 B per cell less.  (Lane 0 then lacks a west neighbour: S on 1..62,
+// T on 2..62, U on 2..61, owned cells on 3..61.)
+template <bool LEN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z, EvpCgOne E)
 {
     if ((int)blockIdx.x >= 8 * Z.per_xcd) {
@@ -1344,27 +1349,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double relax = 1.0 - p.arlx1i * p.revp;
     const double dmin = A.deltaminEVP;
     const bool revised = p.revp != 0.0;
-    // cell of (lane, row ja - 4): the row the first iteration calls j.  Three groups of loads run ahead of the arithmetic by
+    // cell of (lane, row j0): the row the first iteration calls j.  Three groups of loads run ahead of the arithmetic by
     // different distances: A (what level S reads of the row north of its own) two rows, B (the rest of S and T) one row, C (level
     // C's momentum operands, used one row behind) within the iteration.
-    unsigned cell = (unsigned)((size_t)blk * A.plane + (size_t)(ja - 5) * nx + (size_t)(col - 3 + lane));
+    // (LEN: one iteration earlier -- dxE of row ja - 2, which level S starts with, takes HTN of row ja - 3)
+    const int j0 = ja - (LEN ? 5 : 4);
+    unsigned cell = (unsigned)((size_t)blk * A.plane + (size_t)(j0 - 1) * nx + (size_t)(col - 3 + lane));
     auto G = [&](int k, unsigned off) { return cg_ld(gb, off + (unsigned)k * st8); };
     auto I = [&](int k, unsigned off) { return cg_ld(ib, off + (unsigned)k * st8); };
 
     // ---- registers that travel with the rows: suffix N = row j+1, 0 = row j, 1 = row j-1, 2 = row j-2 ----
     double uEN = 0, dxEN = 0, dyEN = 0; unsigned gN = 0;                     // group A as it arrives
+    double hN = 0, h0 = 0, h1 = 0, ehN = 0, wdyEN = 0;                       // LEN: HTN of rows j+1, j, j-1; lane-shifted HTN / HTE of row j+1
     double uE0 = 0, uE1 = 0, dxE0 = 0, dyE0 = 0, ea0 = 0, dxE1 = 0, dyE1 = 0, ea1 = 0, eaNc = 0, PNc = 0;
     unsigned g0 = 0;
     double vN1 = 0, dxN1 = 0, dyN1 = 0, na1 = 0, Q1 = 0, DV1 = 0, VQ1 = 0, ua1 = 0, XU1 = 0, XU2 = 0, YU1 = 0, XT1 = 0, YT1 = 0, W1 = 0;
     double sh1 = 0, SS1 = 0, SU1 = 0, un1 = 0, ve1 = 0, R1 = 0, sp1 = 0, sm1 = 0, s12_2 = 0;
     unsigned m1 = 0;
     // loads in flight (issued one iteration, used the next)
-    double L_uE = 0, L_dxE = 0, L_dyE = 0; unsigned L_g = 0;                 // A: row j+2
+    double L_uE = 0, L_dxE = 0, L_dyE = 0; unsigned L_g = 0;                 // A: row j+2 (LEN: L_dxE carries HTN)
     double L_vN = 0, L_dxN = 0, L_dyN = 0, L_dxU = 0, L_dyU = 0, L_dxT = 0, L_dyT = 0, L_str = 0, L_sp = 0, L_sm = 0, L_s12t = 0,
            L_eta = 0, L_shu = 0;                                             // B: row j+1
     unsigned L_m = 0, m_next = 0;                                            // ice masks: row j+2 in flight, row j+1 arrived
 
-    for (int j = ja - 4; j <= jb + 1; ++j, cell += nx) {
+    for (int j = j0; j <= jb + 1; ++j, cell += nx) {
         // ---- what arrived: A = row j+1, B = row j, C = row j-1 (requested during the previous iteration) ----
         const double a_uE = L_uE, a_dxE = L_dxE, a_dyE = L_dyE; const unsigned a_g = L_g;
         const double b_vN = L_vN, b_dxN = L_dxN, b_dyN = L_dyN, b_dxU = L_dxU, b_dyU = L_dyU, b_dxT = L_dxT, b_dyT = L_dyT,
@@ -1375,10 +1383,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const unsigned cN = cell + nx, cNN = cN + nx;             // rows j+1, j+2
             const unsigned oN = cN * 8u, oNN = oN + nx8;
-            L_uE = cg_ld(T.uE_in, oNN); L_dxE = G(CG_DXE, oNN); L_dyE = G(CG_DYE, oNN); L_g = cg_ldb(gm, cNN);
+            L_uE = cg_ld(T.uE_in, oNN); L_dxE = G(LEN ? CG_DXN : CG_DXE, oNN); L_dyE = G(CG_DYE, oNN); L_g = cg_ldb(gm, cNN);
             L_m = cg_ldb(A.mask, cNN);
-            L_vN = cg_ld(T.vN_in, oN); L_dxN = G(CG_DXN, oN); L_dyN = G(CG_DYN, oN); L_dxU = G(CG_DXU, oN); L_dyU = G(CG_DYU, oN);
-            L_dxT = G(CG_DXT, oN); L_dyT = G(CG_DYT, oN); L_str = I(CI_STRENGTH, oN);
+            L_vN = cg_ld(T.vN_in, oN); L_str = I(CI_STRENGTH, oN);
+            if (!LEN) {
+                L_dxN = G(CG_DXN, oN); L_dyN = G(CG_DYN, oN); L_dxU = G(CG_DXU, oN); L_dyU = G(CG_DYU, oN);
+                L_dxT = G(CG_DXT, oN); L_dyT = G(CG_DYT, oN);
+            }
             L_sp = cg_ld(T.sp_in, oN); L_sm = cg_ld(T.sm_in, oN); L_s12t = cg_ld(A.f[CF_S12T], oN);
             // what cells without ice keep (read by very few lanes: the others fetch the array's first line)
             L_eta = cg_ld(A.f[CF_ETA], (m_next & 1u) ? 0u : oN);
@@ -1398,12 +1409,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- rows move up: last iteration's "north" is this iteration's own row ----
         uE1 = uE0; uE0 = uEN; uEN = a_uE;
         dxE1 = dxE0; dyE1 = dyE0; ea1 = ea0;
-        dxE0 = dxEN; dyE0 = dyEN; ea0 = eaNc; dxEN = a_dxE; dyEN = a_dyE;
+        dxE0 = dxEN; dyE0 = dyEN; ea0 = eaNc; dyEN = a_dyE;
+        const double eh0 = ehN, wdyE0 = wdyEN;              // (LEN) HTN of the east, HTE of the west neighbour, row j
+        if (LEN) {
+            h1 = h0; h0 = hN; hN = a_dxE;
+            ehN = cg_lane_dn(hN); wdyEN = cg_lane_up(dyEN);
+            dxEN = 0.25 * (hN + ehN + h0 + eh0);            // dxE = mean of the four HTN around the E face (ice_grid.F90:3139-3146)
+        } else {
+            dxEN = a_dxE;
+        }
         const double P0 = PNc;                              // uE * earea of row j: last iteration's row j+1
         g0 = gN; gN = a_g;
         const double eaN = dxEN * dyEN;                     // earea = dxE * dyE (ice_grid.F90:684), row j+1
         const double PN = uEN * eaN;
-        const double vN0 = b_vN, dxN0 = b_dxN, dyN0 = b_dyN, dxU0 = b_dxU, dyU0 = b_dyU, dxT0 = b_dxT, dyT0 = b_dyT;
+        // (LEN: dxN = HTN; dyN = mean of the four HTE around the N face; dxU, dyU, dxT, dyT = two-point means, ice_grid.F90:3099, 3207, 3120, 3237)
+        const double vN0 = b_vN, dxN0 = LEN ? h0 : b_dxN, dyN0 = LEN ? 0.25 * (dyE0 + wdyE0 + dyEN + wdyEN) : b_dyN,
+                     dxU0 = LEN ? 0.5 * (h0 + eh0) : b_dxU, dyU0 = LEN ? 0.5 * (dyE0 + dyEN) : b_dyU,
+                     dxT0 = LEN ? 0.5 * (h0 + h1) : b_dxT, dyT0 = LEN ? 0.5 * (dyE0 + wdyE0) : b_dyT;
         const double na0 = dxN0 * dyN0, ua0 = dxU0 * dyU0, ta0 = dxT0 * dyT0;
         const double Q0 = vN0 * na0;
         const double hm0 = (g0 & 8u) ? 1.0 : 0.0;
@@ -1670,5 +1692,6 @@ void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStr
     EvpCgOne none = T;
     none.ntiles = 0;
     const EvpCgOne &W = (E && E->ntiles > 0) ? *E : none;
-    hipLaunchKernelGGL(cg_strip, dim3((unsigned)(8 * Z.per_xcd + W.ntiles)), dim3(256), 0, st, A, T, Z, W);
+    if (Z.lengths) hipLaunchKernelGGL(cg_strip<true>, dim3((unsigned)(8 * Z.per_xcd + W.ntiles)), dim3(256), 0, st, A, T, Z, W);
+    else hipLaunchKernelGGL(cg_strip<false>, dim3((unsigned)(8 * Z.per_xcd + W.ntiles)), dim3(256), 0, st, A, T, Z, W);
 }

@@ -403,6 +403,7 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 struct EvpCgStrip {
     const int *items;             // x 6: block, column of lane 2, first and last owned row (1-based), first and last owned lane
     int nitems, per_xcd;          // items; workgroups (of four items) per XCD (launch = 8 * per_xcd workgroups)
+    int lengths;                  // 1: dxT, dyT, dxU, dyU, dxE, dyN formed in the kernel from dxN, dyE (verified by the host); the items own lanes >= 3
 };
 void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, hipStream_t st);
 // All subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res).  Windows of 16 x 16 positions, the inner

@@ -43,6 +43,7 @@ struct CGridState {
         int4 *tiles_e = nullptr;
         int *tab_e = nullptr;
         int nitems = 0, ntiles_e = 0, strip_seg = 0, ex = 0, ey = 0;   // (ex, ey: shape of the windows kept)
+        int strip_len = 0;       // 1: the marched kernel forms six of the eight lengths from dxN, dyE
         long strip_cells = 0;    // cells the marched kernel owns
     } one;
     // all subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res)
@@ -379,7 +380,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
             if (CG.one.nitems > 0 && CG.fast && !CG.avg_strength && !last && T.gmask) {
                 // the interior of the blocks marched, the windows along their edges as before: both read the previous
                 // subcycle's buffers only and own disjoint cells
-                EvpCgStrip Z{CG.one.items, CG.one.nitems, ((CG.one.nitems + 3) / 4 + 7) / 8};
+                EvpCgStrip Z{CG.one.items, CG.one.nitems, ((CG.one.nitems + 3) / 4 + 7) / 8, CG.one.strip_len};
                 EvpCgOne E = T;
                 E.tab = CG.one.tab_e; E.tiles = CG.one.tiles_e; E.ntiles = CG.one.ntiles_e; E.per_xcd = (CG.one.ntiles_e + 7) / 8;
                 E.ox = CG.one.ex; E.oy = CG.one.ey;
@@ -494,7 +495,7 @@ static int build_fold_lists()
 // there.  Within one cell of the owned range that is the array cell itself -- interior cell, or the interior cell a ghost
 // cell mirrors (halo plan), or the ghost cell marked static (nothing is copied into it); further out the walk goes on
 // from the mirrored cell, neighbour by neighbour.
-static int build_one_tables()
+static int build_one_tables(const double *const *static23)
 {
     const HaloPlan &P = S.plan;
     // the window: 32x8 on the smallest grids (more workgroups than 64x8 gives), 64x8 where that gives every CU one or two
@@ -531,11 +532,14 @@ static int build_one_tables()
         HIPC(hipMemsetAsync(O.prof, 0, (size_t)O.ntiles * 8 * sizeof(unsigned long long), S.stream));
     }
     // ---- the marched kernel's share (cg_strip): per block the rectangle its regular windows cover, if they form one ----
-    // default: large domains (the 64 x 16 windows), the rectangle at least half of the cells; CICE_EVP_HIP_CGRID_STRIP=0 / 1 (test
+    // default: large domains (the rectangle at least a million cells and half of the rank's); CICE_EVP_HIP_CGRID_STRIP=0 / 1 (test
     // build) switches it off / on wherever a regular window exists, CICE_EVP_HIP_CGRID_STRIP_SEG=<rows> sets the segment length
     {
         int want = shape == 2 ? 2 : 0;              // 2: auto
         if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP")) want = std::atoi(e) ? 1 : 0;
+        long interior = 0;
+        for (int b = 0; b < d.nblocks; ++b) interior += (long)(d.ihi[b] - d.ilo[b] + 1) * (d.jhi[b] - d.jlo[b] + 1);
+        if (want == 2 && interior < 1000000) want = 0;
         // the windows cg_one keeps beside the marched kernel -- a frame one window deep along the block's edges -- are cut
         // smaller than the ones it covers a whole domain with: 32 x 8 positions (29 x 5 owned), 256 threads, four workgroups per CU
         // in one round instead of two rounds of 1024-thread ones (3600 x 2400: the frame 51 us -> see DESIGN.md section 7)
@@ -564,6 +568,7 @@ static int build_one_tables()
                 }
             if (!cnt || (i1 - i0) % sx || (j1 - j0) % sy) continue;
             if (cnt != ((i1 - i0) / sx + 1) * ((j1 - j0) / sy + 1)) continue;       // (not a rectangle: cg_one keeps the block)
+            if (i1 + sx - i0 < 62) continue;                                          // (narrower than a strip)
             // (cells with ghost images -- the block's outermost interior cells -- never lie inside: the marched kernel has no pushes)
             bool images = false;
             for (int j = j0; j <= j1 + sy - 1 && !images; ++j)
@@ -573,14 +578,59 @@ static int build_one_tables()
             zones.push_back(Zone{b, i0, i1, j0, j1});
             zcells += (long)(i1 - i0 + sx) * (j1 - j0 + sy);
         }
-        long interior = 0;
-        for (int b = 0; b < d.nblocks; ++b) interior += (long)(d.ihi[b] - d.ilo[b] + 1) * (d.jhi[b] - d.jlo[b] + 1);
-        if (want == 2 && 2 * zcells < interior) zones.clear();
+        // (default: where the work items fill the chip -- measured against cg_one alone: 720 x 270 48 us against 22, 720 x 540 49 against 40,
+        // 1440 x 1080 109 against 154, 3600 x 2400 513 against 794)
+        if (want == 2 && (2 * zcells < interior || zcells < 1000000)) zones.clear();
+        // The six lengths the reference's start-up forms from HTN (= dxN) and HTE (= dyE) -- dxU, dyU, dxT, dyT two-point means, dxE, dyN
+        // four-point means (ice_grid.F90:3063-3280) -- checked BIT FOR BIT on every cell the marched kernel would form them for (each
+        // rectangle with three columns and rows around it); where all hold the kernel forms them itself instead of loading them.  A
+        // grid whose lengths were made otherwise (or a rectangle that reaches a row the reference extrapolates) keeps all eight loaded.
+        bool lengths = !zones.empty() && static23 != nullptr;
+        if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_LEN")) lengths = lengths && std::atoi(e) != 0;
+        if (lengths) {
+            auto same = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0; };
+            const double *const *g = static23;
+            const int nxb = d.nx_block, nyb = d.ny_block;
+            auto holds = [&](const Zone &z) {
+                const int ia = std::max(2, z.i0 - 3), ib = std::min(nxb - 1, z.i1 + sx - 1 + 2);
+                const int ja = std::max(2, z.j0 - 2), jb = std::min(nyb - 1, z.j1 + sy - 1 + 2);
+                const double *N = g[CG_DXN], *E = g[CG_DYE];
+                for (int j = ja; j <= jb; ++j)
+                    for (int i = ia; i <= ib; ++i) {
+                        const size_t p0 = (size_t)z.b * nxb * nyb + (size_t)(j - 1) * nxb + (i - 1);
+                        if (!(same(g[CG_DXU][p0], 0.5 * (N[p0] + N[p0 + 1])) && same(g[CG_DXT][p0], 0.5 * (N[p0] + N[p0 - nxb])) &&
+                              same(g[CG_DXE][p0], 0.25 * (N[p0] + N[p0 + 1] + N[p0 - nxb] + N[p0 - nxb + 1])) &&
+                              same(g[CG_DYU][p0], 0.5 * (E[p0] + E[p0 + nxb])) && same(g[CG_DYT][p0], 0.5 * (E[p0] + E[p0 - 1])) &&
+                              same(g[CG_DYN][p0], 0.25 * (E[p0] + E[p0 - 1] + E[p0 + nxb] + E[p0 + nxb - 1]))))
+                            return false;
+                    }
+                return true;
+            };
+            // (a rectangle whose outermost window row reaches a row the reference extrapolates -- j = 1, j = ny_global -- gives that
+            // row of windows back to cg_one)
+            std::vector<Zone> cut = zones;
+            for (Zone &z : cut) {
+                bool ok = false;
+                for (int v = 0; v < 4 && !ok; ++v) {
+                    Zone t = z;
+                    if (v & 1) t.j1 -= sy;
+                    if (v & 2) t.j0 += sy;
+                    if (t.j1 < t.j0) continue;
+                    if (holds(t)) { z = t; ok = true; }
+                }
+                lengths = lengths && ok;
+            }
+            if (lengths) {
+                zones = cut;
+                zcells = 0;
+                for (const Zone &z : zones) zcells += (long)(z.i1 - z.i0 + sx) * (z.j1 - z.j0 + sy);
+            }
+        }
         if (!zones.empty()) {
-            // strips of 60 owned columns (lanes 2 .. 61 of the wave; the last strip of a rectangle is shifted west so that its lanes
-            // stay inside it and owns what is left); segments: about two waves per SIMD resident at once over all strips
-            // (256 CUs x 8), at least 16 rows
-            constexpr int SOWN = 60;
+            // strips of 60 owned columns (lanes 2 .. 61 of the wave; 59, lanes 3 .. 61, where the kernel forms the lengths; the last
+            // strip of a rectangle is shifted west so that its lanes stay inside it and owns what is left); segments: about two
+            // waves per SIMD resident at once over all strips (256 CUs x 8), at least 16 rows
+            const int LO0 = lengths ? 3 : 2, SOWN = 62 - LO0;
             long nstrips = 0, maxrows = 0;
             for (const Zone &z : zones) { nstrips += (z.i1 - z.i0 + sx + SOWN - 1) / SOWN; maxrows = std::max<long>(maxrows, z.j1 - z.j0 + sy); }
             // (measured, 3600 x 2400: 2006 items of 70 rows 567 us per subcycle; 2065 items -- 17 more than fit at once -- 693;
@@ -596,14 +646,17 @@ static int build_one_tables()
                     // (equal segments: rows / nseg, the remainder one row each to the first ones)
                     const int ja = z.j0 + (int)((long)rows * k / nseg), jb = z.j0 + (int)((long)rows * (k + 1) / nseg) - 1;
                     for (int i0 = z.i0; i0 <= ilast; i0 += SOWN) {
-                        const int c = std::min(i0, std::max(z.i0, ilast - SOWN + 1));      // column of lane 2
+                        // column of lane 2: the strip's first owned column on lane LO0, or further west if lane 61 would pass the rectangle
+                        const int c = std::min(i0 - (LO0 - 2), std::max(z.i0 - (LO0 - 2), ilast - 59));
                         const int lo = 2 + (i0 - c), hi = std::min(61, 2 + (ilast - c));
                         items.push_back(z.b); items.push_back(c); items.push_back(ja); items.push_back(jb);
                         items.push_back(lo); items.push_back(hi);
                     }
                 }
                 for (int w = 0; w < nt; ++w)
-                    if (tiles[4 * w] == z.b && tiles[4 * w + 3]) in_zone[(size_t)w] = 1;
+                    if (tiles[4 * w] == z.b && tiles[4 * w + 3] && tiles[4 * w + 1] >= z.i0 && tiles[4 * w + 1] <= z.i1 &&
+                        tiles[4 * w + 2] >= z.j0 && tiles[4 * w + 2] <= z.j1)
+                        in_zone[(size_t)w] = 1;
             }
             std::vector<int32_t> tiles_e, tab_e;
             const size_t per = (size_t)EX * EY;
@@ -615,6 +668,7 @@ static int build_one_tables()
             O.nitems = (int)(items.size() / 6);
             O.ntiles_e = (int)(tiles_e.size() / 4);
             O.ex = EX; O.ey = EY;
+            O.strip_len = lengths ? 1 : 0;
             O.strip_seg = seg;
             O.strip_cells = zcells;
             HIPC(hipMalloc((void **)&O.items, items.size() * sizeof(int32_t)));
@@ -1002,7 +1056,7 @@ int cice_evp_hip_cgrid_set_geometry(const double *const *static23)
     if (tripole && P.fold_rows == 1)             // (ranks without the fold rows run the same schedule with empty lists)
         if (int rc = build_fold_lists()) return rc;
     if (!tripole && S.plan.peers.empty() && S.d.nx_block >= 3 && S.d.ny_block >= 3) {
-        if (int rc = build_one_tables()) return rc;
+        if (int rc = build_one_tables(static23)) return rc;
         if (int rc = build_res_tables(static23)) return rc;
     }
     if (tripole && !tfold && S.plan.peers.empty() && P.fold_rows == 1 && S.d.ew_boundary_type == CICE_EVP_BND_CYCLIC)
@@ -1564,6 +1618,7 @@ int cice_evp_hip_cgrid_timings(double *out, int32_t n)
     if (n >= 12) out[11] = (double)CG.one.strip_cells;   // ... the cells it owns ...
     if (n >= 13) out[12] = (double)CG.one.ntiles_e;   // ... and the windows cg_one keeps beside it
     if (n >= 14) out[13] = (double)CG.one.strip_seg;  // ... rows per segment
+    if (n >= 15) out[14] = (double)CG.one.strip_len;  // ... 1: it forms six of the eight lengths from dxN, dyE
     return 0;
 }
 

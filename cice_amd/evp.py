@@ -71,7 +71,7 @@ TEST_ENV = [
     "CICE_EVP_HIP_NO_OVERLAP", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_NOGRAPH", "CICE_EVP_HIP_GRAPH_RCCL", "CICE_EVP_HIP_RES_LOGW", "CICE_EVP_HIP_RES_COOP",
     "CICE_EVP_HIP_MARCH_EXT", "CICE_EVP_HIP_MARCH_DIRECT", "CICE_EVP_HIP_CGRID_FUSED", "CICE_EVP_HIP_CGRID_GEO",
     "CICE_EVP_HIP_CGRID_RES_SLEEP", "CICE_EVP_HIP_CGRID_RES_CULL", "CICE_EVP_HIP_CGRID_RES_DEBUG",
-    "CICE_EVP_HIP_CGRID_STRIP", "CICE_EVP_HIP_CGRID_STRIP_SEG", "CICE_EVP_HIP_CGRID_STRIP_EDGE", "CICE_EVP_HIP_CGRID_STRIP_RIDE",
+    "CICE_EVP_HIP_CGRID_STRIP", "CICE_EVP_HIP_CGRID_STRIP_SEG", "CICE_EVP_HIP_CGRID_STRIP_EDGE", "CICE_EVP_HIP_CGRID_STRIP_RIDE", "CICE_EVP_HIP_CGRID_STRIP_LEN",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",
@@ -482,13 +482,13 @@ class EvpHip:
         _check(self.lib, self.lib.cice_evp_hip_cgrid_sync(), "(dyn_evp_hip_cgrid_sync)")
 
     def cgrid_timings(self):
-        out = np.zeros(14)
-        _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(14)), "(dyn_evp_hip_cgrid_timings)")
+        out = np.zeros(15)
+        _check(self.lib, self.lib.cice_evp_hip_cgrid_timings(_dp(out), C.c_int32(15)), "(dyn_evp_hip_cgrid_timings)")
         return dict(loop_ms=float(out[0]), nsub=int(out[1]), prep_ms=float(out[2]), one_launch_subcycles=int(out[3]),
                     geometry_derived=bool(out[4]), resident_subcycles=int(out[5]), resident_probe_ms=float(out[6]),
                     resident_fallbacks=int(out[7]), resident_windows_with_ice=int(out[8]), resident_windows=int(out[9]),
                     marched_items=int(out[10]), marched_cells=int(out[11]), marched_edge_windows=int(out[12]),
-                    marched_segment_rows=int(out[13]))
+                    marched_segment_rows=int(out[13]), marched_lengths_derived=bool(out[14]))
 
     def debug_cgres_prof(self):
         self._need_testing("debug_cgres_prof")

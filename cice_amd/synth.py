@@ -216,7 +216,9 @@ def make_primary(g: dict, case: str = "full", seed: int = 1) -> dict:
 # ---- C-grid workloads: what evp()'s loop for grid_ice = 'C' reads, on the global grid ----------
 def cgrid_geometry(g: dict, deltaminEVP: float = 1e-11) -> dict:
     """`g` from derive_geometry -> the 23 static arrays of cice_evp_hip_cgrid_set_geometry (E-W cyclic, closed in
-    y).  Lengths at the faces as in ice_grid.F90 (dyE = HTE, dxN = HTN; dxE, dyN through the cell centres), face
+    y).  Lengths at the faces as in ice_grid.F90 (dyE = HTE, dxN = HTN; dxE, dyN the four-point means of HTN, HTE around the face on closed
+    grids -- the reference's start-up formulas, which the marched C-grid kernel can then form itself --, through the cell centres on the
+    synthetic tripole grids, whose fold rows are built to mirror), face
     masks epm / npm = both neighbouring T-cells ocean (makemask), boundary-condition ratios as init_evp builds them
     (ice_dyn_evp.F90:232-239)."""
     dxT, dyT, hm = g["dxT"], g["dyT"], g["hm"]
@@ -227,8 +229,16 @@ def cgrid_geometry(g: dict, deltaminEVP: float = 1e-11) -> dict:
     n_e = lambda a: np.vstack([a[1:], np.roll(a[-1:, ::-1], -1, axis=1) if trip else a[-1:]])
     e = lambda a: np.roll(a, -1, axis=1)                     # (i+1, j), cyclic
     dxN, dyE = g["HTN"], g["HTE"]
-    dxE = 0.5 * (dxT + e(dxT))
-    dyN = 0.5 * (dyT + n(dyT))
+    if trip:
+        dxE = 0.5 * (dxT + e(dxT))
+        dyN = 0.5 * (dyT + n(dyT))
+    else:
+        # the reference's four-point means (primary_grid_lengths_HTN / _HTE, ice_grid.F90:3139-3146, 3245-3253), in its order of
+        # summation; the rows it extrapolates (j = 1, j = ny_global: land in these grids) repeat their neighbour here
+        s_ = lambda a: np.vstack([a[:1], a[:-1]])             # (i, j-1)
+        w_ = lambda a: np.roll(a, 1, axis=1)                  # (i-1, j)
+        dxE = 0.25 * (dxN + e(dxN) + s_(dxN) + e(s_(dxN)))
+        dyN = 0.25 * (dyE + w_(dyE) + n(dyE) + w_(n(dyE)))
     earea, narea = dxE * dyE, dxN * dyN
     hm_n = np.vstack([hm[1:], hm[-1:, ::-1] if trip else np.zeros((1, hm.shape[1]))])
     epm = np.minimum(hm, e(hm))

@@ -331,9 +331,10 @@ int cice_evp_hip_cgrid_dyn_finish(double *strocnxN, double *strocnyN, double *st
  * when only part of them is covered; CICE_EVP_HIP_CGRID_RESIDENT=0 / 1 forbids / requires it), [6] (n >= 7) what its start-up probe
  * measured per subcycle, ms (-1: no probe ran), [7] (n >= 8) calls of cice_evp_hip_cgrid_run that were repeated with the per-subcycle
  * kernels after one of its (bounded) waits gave up, [8], [9] (n >= 10) its windows that hold ice in this call -- only they run -- and
- * all its windows, [10] .. [13] (n >= 14) the one-launch schedule's marched kernel (evp_cgrid.hip: cg_strip -- the interior of
+ * all its windows, [10] .. [14] (n >= 15) the one-launch schedule's marched kernel (evp_cgrid.hip: cg_strip -- the interior of
  * large blocks, one wave per strip of 61 columns and segment of rows): work items (0: not in use), cells it owns, windows the
- * windowed kernel keeps beside it (the block edges), rows per segment  */
+ * windowed kernel keeps beside it (the block edges), rows per segment, 1 if it forms dxT, dyT, dxU, dyU, dxE, dyN from dxN and dyE
+ * (the reference's start-up means, verified bit for bit on the caller's arrays)  */
 int cice_evp_hip_cgrid_timings(double *out, int32_t n);
 
 /* ---- multi-GPU: RCCL point-to-point halo over xGMI ---------------------------- */

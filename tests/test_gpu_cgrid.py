@@ -709,8 +709,17 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
             return out, core.cgrid_timings()
         finally:
             core.finalize()
+    if seed == 25:                # the six lengths loaded, not formed in the kernel
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_LEN", "0")
+    if seed == 26:                # a grid whose lengths are not the reference's means: the check refuses, all eight stay loaded
+        static = dict(static)
+        static["dxT"] = static["dxT"] * (1.0 + 1e-9)
+        for k, (a, b_) in dict(tarea=("dxT", "dyT")).items():
+            static[k] = static[a] * static[b_]
+        static["DminTarea"] = scal["deltaminEVP"] * static["tarea"]
     got, tt = run()
     assert tt["marched_items"] > 0 and tt["one_launch_subcycles"] == 8 and tt["geometry_derived"], tt
+    assert tt["marched_lengths_derived"] == (seed not in (25, 26)), tt
     blks = dc.local_blocks(0)
     dom = oracle.OracleDomain(dc.nx_block, dc.ny_block, len(blks), dc.nx_global, dc.ny_global, dc.ew, dc.ns,
                               [b.ilo for b in blks], [b.ihi for b in blks], [b.jlo for b in blks],
