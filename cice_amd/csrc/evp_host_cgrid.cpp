@@ -635,7 +635,9 @@ static int build_one_tables(const double *const *static23)
             for (const Zone &z : zones) { nstrips += (z.i1 - z.i0 + sx + SOWN - 1) / SOWN; maxrows = std::max<long>(maxrows, z.j1 - z.j0 + sy); }
             // (measured, 3600 x 2400: 2006 items of 70 rows 567 us per subcycle; 2065 items -- 17 more than fit at once -- 693;
             // 2950 x 48 597, 4720 x 30 603, 11741 x 12 624: one round of work, as long as possible)
-            const long nseg_fit = std::max<long>(1, 2048 / std::max<long>(1, nstrips));
+            long slots = 2048;
+            if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_ITEMS")) slots = std::max(1, std::atoi(e));
+            const long nseg_fit = std::max<long>(1, slots / std::max<long>(1, nstrips));
             int seg = (int)std::max<long>(16, (maxrows + nseg_fit - 1) / nseg_fit);
             if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_SEG")) seg = std::max(1, std::atoi(e));
             std::vector<int32_t> items;

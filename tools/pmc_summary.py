@@ -135,7 +135,7 @@ def main():
         entry = {}
         # (one launch per subcycle: on large domains the marched kernel cg_strip -- the windows along the block edges ride in its launch --
         # and cg_one for the last subcycle of a call; elsewhere cg_one alone)
-        for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"marched": "cg_strip(", "one_launch": "cg_one"} if key.endswith("one") else CG).items():
+        for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"marched": "cg_strip<", "one_launch": "cg_one"} if key.endswith("one") else CG).items():
             if kernel_stats(st, match) is None:
                 continue
             e = {"kernel_trace": kernel_stats(st, match)}
