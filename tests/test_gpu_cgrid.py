@@ -682,6 +682,8 @@ def marched_case(seed, nx, ny, bs, case, holes, land):
     (24, 140, 90, (140, 90), "full", 1.1, 0.0, False, "1", "2"),         # no ice at all; one row per segment
     (25, 260, 72, (260, 72), "full", 0.0, 0.1, False, "64", "2"),        # ice everywhere, many islands; one segment per strip
     (26, 190, 50, (190, 50), "caps", 0.1, 0.01, False, "3", "2"),        # the last strip shifted west (68 columns: 60 + 8)
+    # the rectangle's top window row would read dyU of row ny_global, which the reference extrapolates: that row goes back to cg_one
+    (27, 200, 46, (200, 46), "full", 0.2, 0.02, False, None, "2"),
 ])
 def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes, land, revised, seg, shape, monkeypatch):
     """The one-launch schedule with the interior of each block marched (evp_cgrid.hip: cg_strip; the default on the 0.1-degree
