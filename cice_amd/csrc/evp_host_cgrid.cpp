@@ -532,14 +532,14 @@ static int build_one_tables(const double *const *static23)
         HIPC(hipMemsetAsync(O.prof, 0, (size_t)O.ntiles * 8 * sizeof(unsigned long long), S.stream));
     }
     // ---- the marched kernel's share (cg_strip): per block the rectangle its regular windows cover, if they form one ----
-    // default: large domains (the rectangle at least a million cells and half of the rank's); CICE_EVP_HIP_CGRID_STRIP=0 / 1 (test
+    // default: large domains (the rectangle at least 300 000 cells and half of the rank's); CICE_EVP_HIP_CGRID_STRIP=0 / 1 (test
     // build) switches it off / on wherever a regular window exists, CICE_EVP_HIP_CGRID_STRIP_SEG=<rows> sets the segment length
     {
         int want = shape == 2 ? 2 : 0;              // 2: auto
         if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP")) want = std::atoi(e) ? 1 : 0;
         long interior = 0;
         for (int b = 0; b < d.nblocks; ++b) interior += (long)(d.ihi[b] - d.ilo[b] + 1) * (d.jhi[b] - d.jlo[b] + 1);
-        if (want == 2 && interior < 1000000) want = 0;
+        if (want == 2 && interior < 300000) want = 0;
         // the windows cg_one keeps beside the marched kernel -- a frame one window deep along the block's edges -- are cut
         // smaller than the ones it covers a whole domain with: 32 x 8 positions (29 x 5 owned), 256 threads, four workgroups per CU
         // in one round instead of two rounds of 1024-thread ones (3600 x 2400: the frame 51 us -> see DESIGN.md section 7)
@@ -578,9 +578,9 @@ static int build_one_tables(const double *const *static23)
             zones.push_back(Zone{b, i0, i1, j0, j1});
             zcells += (long)(i1 - i0 + sx) * (j1 - j0 + sy);
         }
-        // (default: where the work items fill the chip -- measured against cg_one alone: 720 x 270 48 us against 22, 720 x 540 49 against 40,
-        // 1440 x 1080 109 against 154, 3600 x 2400 513 against 794)
-        if (want == 2 && (2 * zcells < interior || zcells < 1000000)) zones.clear();
+        // (default: where the work items fill enough of the chip -- measured against cg_one alone: 720 x 270 23-48 us (segments of 4-16 rows)
+        // against 22, 720 x 540 32 (8 rows) against 40, 1440 x 1080 95 against 154, 3600 x 2400 455-489 against 794)
+        if (want == 2 && (2 * zcells < interior || zcells < 300000)) zones.clear();
         // The six lengths the reference's start-up forms from HTN (= dxN) and HTE (= dyE) -- dxU, dyU, dxT, dyT two-point means, dxE, dyN
         // four-point means (ice_grid.F90:3063-3280) -- checked BIT FOR BIT on every cell the marched kernel would form them for (each
         // rectangle with three columns and rows around it); where all hold the kernel forms them itself instead of loading them.  A
@@ -629,7 +629,7 @@ static int build_one_tables(const double *const *static23)
         if (!zones.empty()) {
             // strips of 60 owned columns (lanes 2 .. 61 of the wave; 59, lanes 3 .. 61, where the kernel forms the lengths; the last
             // strip of a rectangle is shifted west so that its lanes stay inside it and owns what is left); segments: about two
-            // waves per SIMD resident at once over all strips (256 CUs x 8), at least 16 rows
+            // waves per SIMD resident at once over all strips (256 CUs x 8)
             const int LO0 = lengths ? 3 : 2, SOWN = 62 - LO0;
             long nstrips = 0, maxrows = 0;
             for (const Zone &z : zones) { nstrips += (z.i1 - z.i0 + sx + SOWN - 1) / SOWN; maxrows = std::max<long>(maxrows, z.j1 - z.j0 + sy); }
@@ -638,7 +638,9 @@ static int build_one_tables(const double *const *static23)
             long slots = 2048;
             if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_ITEMS")) slots = std::max(1, std::atoi(e));
             const long nseg_fit = std::max<long>(1, slots / std::max<long>(1, nstrips));
-            int seg = (int)std::max<long>(16, (maxrows + nseg_fit - 1) / nseg_fit);
+            // (shortest segment: 16 rows from a million cells -- 1440 x 1080: 1608 items of 16 rows 95 us, 1992 of 13 104 --, 8 below
+            // -- 720 x 540: 804 items of 8 rows 32 us, 408 of 16 49)
+            int seg = (int)std::max<long>(zcells >= 1000000 ? 16 : 8, (maxrows + nseg_fit - 1) / nseg_fit);
             if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_SEG")) seg = std::max(1, std::atoi(e));
             std::vector<int32_t> items;
             for (const Zone &z : zones) {
