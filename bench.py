@@ -712,7 +712,7 @@ def main():
                 "launches_per_subcycle": launches, "active_T_cells": n_active,
                 "kernel": ("cg_res (on-chip resident: all subcycles of a call in one launch" + (", FOLD variant)" if ns == "tripole" else ")") if res_n
                            else "cg_strip (the block's interior marched: one wave per strip of 60 columns x segment of rows) with cg_one's windows along the "
-                                "block's edges in the same launch; the last subcycle of a call: cg_one" if (one and marched) else "cg_one" if one
+                                "block's edges in the same launch" if (one and marched) else "cg_one" if one
                            else "five phases + five fold steps" if ns == "tripole" else "fused schedule, three launches"),
                 "marched_items": marched or None, "marched_segment_rows": (tt_["marched_segment_rows"] if marched else None),
                 "marched_cells": (tt_["marched_cells"] if marched else None), "windows_beside_marched": (tt_["marched_edge_windows"] if marched else None),

@@ -1324,11 +1324,15 @@ __device__ __forceinline__ void cg_st(void *base, unsigned off, double v) { *(do
 // formulas (ice_grid.F90:3063-3280: two- and four-point means; the host has verified them bit for bit on every cell the kernel
 // touches) instead of loaded: 27 loads per row instead of 33, 48 B per cell less.  (Lane 0 then lacks a west neighbour: S on 1..62,
 // T on 2..62, U on 2..61, owned cells on 3..61.)
-template <bool LEN>
+// LAST: the last subcycle of a call also stores what the caller reads once per call -- shearU, zetax2T, etax2T, etax2U, strintxE / yN,
+// taubxE / yN (values the subcycle forms anyway) and deltaU, for which strain_rates_U's divergence and tension are worked out too, ONE ROW
+// LATE: they take the N-face average at the east neighbour (a lane shift of the owned rows' uvelN) and the E-face average of the row to
+// the north (the next iteration's vvelE); nothing inside the loop reads deltaU with visc_method = avg_zeta.
+template <bool LEN, bool LAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z, EvpCgOne E)
 {
     if ((int)blockIdx.x >= 8 * Z.per_xcd) {
-        cg_one_window<true, 32, 8, 0, true>(A, E, 0, (int)blockIdx.x - 8 * Z.per_xcd, (int)(threadIdx.x & 31u), (int)(threadIdx.x >> 5));
+        cg_one_window<true, 32, 8, LAST ? 1 : 0, true>(A, E, LAST ? 1 : 0, (int)blockIdx.x - 8 * Z.per_xcd, (int)(threadIdx.x & 31u), (int)(threadIdx.x >> 5));
         return;
     }
     const int lane = (int)(threadIdx.x & 63u);
@@ -1366,6 +1370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double vN1 = 0, dxN1 = 0, dyN1 = 0, na1 = 0, Q1 = 0, DV1 = 0, VQ1 = 0, ua1 = 0, XU1 = 0, XU2 = 0, YU1 = 0, XT1 = 0, YT1 = 0, W1 = 0;
     double sh1 = 0, SS1 = 0, SU1 = 0, un1 = 0, ve1 = 0, R1 = 0, sp1 = 0, sm1 = 0, s12_2 = 0;
     unsigned m1 = 0;
+    double dxU1 = 0, dyU1 = 0, uU1 = 0, vU1 = 0; unsigned g1 = 0;           // LAST: what deltaU of row j-1 still needs
     // loads in flight (issued one iteration, used the next)
     double L_uE = 0, L_dxE = 0, L_dyE = 0; unsigned L_g = 0;                 // A: row j+2 (LEN: L_dxE carries HTN)
     double L_vN = 0, L_dxN = 0, L_dyN = 0, L_dxU = 0, L_dyU = 0, L_dxT = 0, L_dyT = 0, L_str = 0, L_sp = 0, L_sm = 0, L_s12t = 0,
@@ -1419,6 +1424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dxEN = a_dxE;
         }
         const double P0 = PNc;                              // uE * earea of row j: last iteration's row j+1
+        if (LAST) g1 = g0;
         g0 = gN; gN = a_g;
         const double eaN = dxEN * dyEN;                     // earea = dxE * dyE (ice_grid.F90:684), row j+1
         const double PN = uEN * eaN;
@@ -1432,6 +1438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const double W0 = hm0 * ta0;
 
         double sh = 0.0, uNo = 0.0, vEo = 0.0, eta = 0.0, sp = 0.0, sm = 0.0, R0 = 0.0, SS0 = 0.0, SU0 = 0.0, DV0 = 0.0, VQ0 = 0.0;
+        double uU0 = 0.0, vU0 = 0.0;
         if (j >= ja - 2) {
             // ---- S (row j): strain_rates_U's shear at the corner (ice_dyn_shared.F90:2341-2444), the two averages of level C ----
             const double ea0W = cg_lane_up(ea0), eaNW = cg_lane_up(eaN), P0W = cg_lane_up(P0), PNW = cg_lane_up(PN);
@@ -1456,12 +1463,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const double vNij = vNo * npc + (npe - npc) * npe * rxNr * vNe;
                 sh = dxU0 * (uEijp1 - uEij) - uU * ddxE + dyU0 * (vNip1j - vNij) - vU * ddyN;
                 if (!(m & 2u)) sh = b_shu;                 // strain_rates_U leaves cells without ice alone
+                else if (LAST && ownx && j >= ja && j <= jb) cg_st(A.f[CF_SHEARU], cell * 8u, sh);
+                uU0 = uU; vU0 = vU;
             }
-            if (j >= ja && j <= jb) {                      // (owned rows: what level C reads one row behind)
+            if (j >= ja && j <= jb + (LAST ? 1 : 0)) {     // (owned rows: what level C reads one row behind; LAST: deltaU's vvelE of the row to the north)
                 const double wn = (ea0W + ea0 + eaNW + eaN);
                 uNo = (wn == 0.0 ? 0.0 : (P0W + P0 + PNW + PN) / wn) * npc;           // avg_nw(uE, earea, o)
                 const double ws = (na1 + na1E + na0 + na0E);
                 vEo = (ws == 0.0 ? 0.0 : (Q1 + Q1E + Q0 + Q0E) / ws) * epc;           // avg_se(vN, narea, o)
+            }
+            if (LAST) {
+                // ---- deltaU of row j-1 (strain_rates_U, ice_dyn_shared.F90:2341-2444: the divergence and the tension at the corner) ----
+                const double uNe = cg_lane_dn(un1), dxN1E = cg_lane_dn(dxN1), dyN1E = cg_lane_dn(dyN1);
+                const unsigned g1E = cg_lane_dn_u(g1);
+                if (j > ja && j <= jb + 1 && ownx && (m1 & 2u)) {
+                    const double epc = (g1 & 1u) ? 1.0 : 0.0, npc = (g1 & 2u) ? 1.0 : 0.0;
+                    const double npe = (g1E & 2u) ? 1.0 : 0.0, epn = (g0 & 1u) ? 1.0 : 0.0;
+                    double rxN = -1.0, rxNr = -1.0, ryE = -1.0, ryEr = -1.0;
+                    if (npc != npe) { rxN = -(dxN1E / dxN1); rxNr = 1.0 / -(dxN1E / dxN1); }
+                    if (epc != epn) { ryE = -(dyE0 / dyE1); ryEr = 1.0 / -(dyE0 / dyE1); }
+                    const double uNo_ = un1, vEo_ = ve1, vEn = vEo;
+                    const double ddyN = dyN1E - dyN1, ddxE = dxE0 - dxE1;
+                    const double uNip1j = uNe * npe + (npc - npe) * npc * rxN * uNo_;
+                    const double uNij = uNo_ * npc + (npe - npc) * npe * rxNr * uNe;
+                    const double vEijp1 = vEn * epn + (epc - epn) * epc * ryE * vEo_;
+                    const double vEij = vEo_ * epc + (epn - epc) * epn * ryEr * vEn;
+                    const double dv = dyU1 * (uNip1j - uNij) + uU1 * ddyN + dxU1 * (vEijp1 - vEij) + vU1 * ddxE;
+                    const double tn = dyU1 * (uNip1j - uNij) - uU1 * ddyN - dxU1 * (vEijp1 - vEij) + vU1 * ddxE;
+                    cg_st(A.f[CF_DELTAU], (cell - nx) * 8u, sqrt(dv * dv + p.e_factor * (tn * tn + sh1 * sh1)));
+                }
             }
             // ---- T (row j): stressC_T (ice_dyn_evp.F90:1758-1860) ----
             {
@@ -1488,6 +1518,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         cg_st(A.f[CF_S12T], o0, (b_s12t * relax + p.arlx1i * 0.5 * etax2 * shearT) * p.denom1);
                         cg_st(A.f[CF_SP], o0, sp);
                         cg_st(A.f[CF_SM], o0, sm);
+                        if (LAST) {
+                            cg_st(A.f[CF_ZETA], o0, zetax2);
+                            cg_st(A.f[CF_ETA], o0, eta);
+                        }
                     }
                 }
                 R0 = hm0 * eta * ta0;                       // the position's term of the T -> U average of etax2T
@@ -1508,7 +1542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const unsigned oc = (cell - nx) * 8u;
                 const double s12c = s12, s12s = s12_2;
                 const double spc = sp1, smc = sm1, spn = sp, smn = sm;
-                double unew, vnew;
+                double unew, vnew, strintx_ = 0.0, strinty_ = 0.0;
                 {
                     const double dyE = dyE1, dxE = dxE1;
                     const double earear = ea1 > 0.0 ? 1.0 / ea1 : 0.0;
@@ -1524,6 +1558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
                     const double cc1 = strintx + c_fxE + taux + massdti * (p.brlx * uold + p.revp * c_uiE);
                     unew = (ccb * vold + cc1) / cca;
+                    strintx_ = strintx;
                 }
                 {
                     const double dxN = dxN1, dyN = dyN1;
@@ -1541,10 +1576,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
                     const double cc2 = strinty + c_fyN + tauy + massdti * (p.brlx * vold + p.revp * c_viN);
                     vnew = (-ccb * uold + cc2) / cca;
+                    strinty_ = strinty;
                 }
                 if (m1 & 2u) cg_st(A.f[CF_S12U], oc, s12c);
-                if (m1 & 4u) cg_st(A.f[CF_UE], oc, unew);
-                if (m1 & 8u) cg_st(A.f[CF_VN], oc, vnew);
+                if (LAST) cg_st(A.f[CF_ETAU], oc, e2);
+                if (m1 & 4u) {
+                    cg_st(A.f[CF_UE], oc, unew);
+                    if (LAST) { cg_st(A.f[CF_STRX], oc, strintx_); cg_st(A.f[CF_TAUBX], oc, -unew * 0.0); }
+                }
+                if (m1 & 8u) {
+                    cg_st(A.f[CF_VN], oc, vnew);
+                    if (LAST) { cg_st(A.f[CF_STRY], oc, strinty_); cg_st(A.f[CF_TAUBY], oc, -vnew * 0.0); }
+                }
             }
             s12_2 = s12;
         }
@@ -1553,6 +1596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         vN1 = vN0; dxN1 = dxN0; dyN1 = dyN0; na1 = na0; Q1 = Q0; DV1 = DV0; VQ1 = VQ0; ua1 = ua0;
         XU2 = XU1; XU1 = dxU0 * dxU0; YU1 = dyU0 * dyU0; XT1 = dxT0 * dxT0; YT1 = dyT0 * dyT0; W1 = W0;
         sh1 = sh; SS1 = SS0; SU1 = SU0; un1 = uNo; ve1 = vEo; R1 = R0; sp1 = sp; sm1 = sm; m1 = m;
+        if (LAST) { dxU1 = dxU0; dyU1 = dyU0; uU1 = uU0; vU1 = vU0; }
     }
 }
 
@@ -1685,13 +1729,19 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 #undef CG_ONE
 }
 
-void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, hipStream_t st)
+void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, int last, hipStream_t st)
 {
     if (Z.nitems <= 0) return;
     // E: windows of 32 x 8 positions to run in the same launch (NULL: none)
     EvpCgOne none = T;
     none.ntiles = 0;
     const EvpCgOne &W = (E && E->ntiles > 0) ? *E : none;
-    if (Z.lengths) hipLaunchKernelGGL(cg_strip<true>, dim3((unsigned)(8 * Z.per_xcd + W.ntiles)), dim3(256), 0, st, A, T, Z, W);
-    else hipLaunchKernelGGL(cg_strip<false>, dim3((unsigned)(8 * Z.per_xcd + W.ntiles)), dim3(256), 0, st, A, T, Z, W);
+    const dim3 grid((unsigned)(8 * Z.per_xcd + W.ntiles)), block(256);
+    if (Z.lengths) {
+        if (last) hipLaunchKernelGGL((cg_strip<true, true>), grid, block, 0, st, A, T, Z, W);
+        else hipLaunchKernelGGL((cg_strip<true, false>), grid, block, 0, st, A, T, Z, W);
+    } else {
+        if (last) hipLaunchKernelGGL((cg_strip<false, true>), grid, block, 0, st, A, T, Z, W);
+        else hipLaunchKernelGGL((cg_strip<false, false>), grid, block, 0, st, A, T, Z, W);
+    }
 }

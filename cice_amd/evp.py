@@ -71,7 +71,7 @@ TEST_ENV = [
     "CICE_EVP_HIP_NO_OVERLAP", "CICE_EVP_HIP_TYB", "CICE_EVP_HIP_NOGRAPH", "CICE_EVP_HIP_GRAPH_RCCL", "CICE_EVP_HIP_RES_LOGW", "CICE_EVP_HIP_RES_COOP",
     "CICE_EVP_HIP_MARCH_EXT", "CICE_EVP_HIP_MARCH_DIRECT", "CICE_EVP_HIP_CGRID_FUSED", "CICE_EVP_HIP_CGRID_GEO",
     "CICE_EVP_HIP_CGRID_RES_SLEEP", "CICE_EVP_HIP_CGRID_RES_CULL", "CICE_EVP_HIP_CGRID_RES_DEBUG",
-    "CICE_EVP_HIP_CGRID_STRIP", "CICE_EVP_HIP_CGRID_STRIP_SEG", "CICE_EVP_HIP_CGRID_STRIP_EDGE", "CICE_EVP_HIP_CGRID_STRIP_RIDE", "CICE_EVP_HIP_CGRID_STRIP_LEN", "CICE_EVP_HIP_CGRID_STRIP_ITEMS",
+    "CICE_EVP_HIP_CGRID_STRIP", "CICE_EVP_HIP_CGRID_STRIP_SEG", "CICE_EVP_HIP_CGRID_STRIP_EDGE", "CICE_EVP_HIP_CGRID_STRIP_RIDE", "CICE_EVP_HIP_CGRID_STRIP_LEN", "CICE_EVP_HIP_CGRID_STRIP_ITEMS", "CICE_EVP_HIP_CGRID_STRIP_LAST",
 ]
 # C-grid subcycle (cice_evp_hip_cgrid_*): order of the pointer tables, see include/cice_evp_hip.h
 CGRID_FIELDS = ["uvelE", "vvelE", "uvelN", "vvelN", "uvel", "vvel", "stresspT", "stressmT", "stress12T", "stress12U",

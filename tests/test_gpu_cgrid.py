@@ -688,7 +688,7 @@ def marched_case(seed, nx, ny, bs, case, holes, land):
 def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes, land, revised, seg, shape, monkeypatch):
     """The one-launch schedule with the interior of each block marched (evp_cgrid.hip: cg_strip; the default on the 0.1-degree
     class only) forced onto small blocks: every array of the loop equal to the oracle's, bit for bit, and equal to the windowed
-    kernel's; the last subcycle of the call (the once-per-call arrays) and the first run as before."""
+    kernel's -- the once-per-call arrays of the last subcycle (deltaU a row late) included; the first subcycle runs as before."""
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "0")
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", shape)
     monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP", "1")
@@ -711,6 +711,8 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
             return out, core.cgrid_timings()
         finally:
             core.finalize()
+    if seed == 21:                # the last subcycle of the call by the windowed kernel, as before
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_LAST", "0")
     if seed == 25:                # the six lengths loaded, not formed in the kernel
         monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_LEN", "0")
     if seed == 26:                # a grid whose lengths are not the reference's means: the check refuses, all eight stay loaded

@@ -133,8 +133,8 @@ def main():
         if not st.exists():
             continue
         entry = {}
-        # (one launch per subcycle: on large domains the marched kernel cg_strip -- the windows along the block edges ride in its launch --
-        # and cg_one for the last subcycle of a call; elsewhere cg_one alone)
+        # (one launch per subcycle: on large domains the marched kernel cg_strip -- the windows along the block edges ride in its launch;
+        # the first match is the instantiation for all subcycles but the last --; elsewhere cg_one alone)
         for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"marched": "cg_strip<", "one_launch": "cg_one"} if key.endswith("one") else CG).items():
             if kernel_stats(st, match) is None:
                 continue
