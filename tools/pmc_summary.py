@@ -23,13 +23,18 @@ MAX_CLOCK_HZ = 2.4e9
 DOMINANT = {"gx1res": "evp_resident", "gx1str": "evp_subcycle_tile", "s01str": "evp_subcycle_tile", "s01march": "evp_march"}
 
 
-def counters(path: Path, match: str):
+def _is(name: str, match) -> bool:
+    """`match`: a substring, or a tuple of substrings that must all occur."""
+    return all(m in name for m in (match if isinstance(match, tuple) else (match,)))
+
+
+def counters(path: Path, match):
     """{counter: (average per launch, launches)} and the average duration of kernels whose name contains `match`."""
     agg, dur = defaultdict(list), []
     kname = None
     with open(path) as f:
         for r in csv.DictReader(f):
-            if match not in r["Kernel_Name"]:
+            if not _is(r["Kernel_Name"], match):
                 continue
             kname = r["Kernel_Name"]
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -38,10 +43,10 @@ def counters(path: Path, match: str):
     return out, (sum(dur) / len(dur) * 1e-3 if dur else None), kname
 
 
-def kernel_stats(path: Path, match: str):
+def kernel_stats(path: Path, match):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if match in r["Name"]:
+            if _is(r["Name"], match):
                 return dict(name=r["Name"], calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) * 1e-3,
                             min_us=float(r["MinNs"]) * 1e-3, max_us=float(r["MaxNs"]) * 1e-3)
     return None
@@ -135,7 +140,7 @@ def main():
         entry = {}
         # (one launch per subcycle: on large domains the marched kernel cg_strip -- the windows along the block edges ride in its launch;
         # the first match is the instantiation for all subcycles but the last --; elsewhere cg_one alone)
-        for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"marched": "cg_strip<", "one_launch": "cg_one"} if key.endswith("one") else CG).items():
+        for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"marched": ("cg_strip<", ", false>("), "one_launch": "cg_one"} if key.endswith("one") else CG).items():
             if kernel_stats(st, match) is None:
                 continue
             e = {"kernel_trace": kernel_stats(st, match)}
