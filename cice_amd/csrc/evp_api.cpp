@@ -80,6 +80,37 @@ int cice_evp_hip_cgrid_window_deps(const cice_evp_hip_dims *dims, int32_t *n_win
     if (n_windows) *n_windows = (int32_t)(t4.size() / 4);
     return 0;
 }
+int cice_evp_hip_cgrid_strip_plan(const cice_evp_hip_dims *dims, int32_t ex, int32_t ey, int32_t lo0, int32_t slots, int32_t seg_min, int32_t seg,
+                                  int32_t *n_items, int32_t *items6, int32_t items_cap, int32_t *n_windows, int32_t *tiles4, uint8_t *in_zone, int32_t windows_cap,
+                                  int32_t *seg_rows)
+{
+    if (!dims || !n_items || !n_windows) return fail(-1, "bad argument");
+    HaloPlan P;
+    if (!build_halo_plan(*dims, P)) return fail(-3, "halo plan: %s", P.error.c_str());
+    std::vector<int32_t> t4, tb, it;
+    build_window_table(*dims, P, ex, ey, 1 << 20, t4, tb);
+    // (ghost images: the sources of the rank's own ghost copies)
+    std::vector<int> img((size_t)dims->nblocks * dims->nx_block * dims->ny_block, -1);
+    for (size_t k = 0; k < P.local_src.size(); ++k) img[(size_t)P.local_src[k]] = 0;
+    std::vector<StripZone> zones;
+    strip_zones(*dims, t4, ex, ey, img.data(), zones);
+    const int s = strip_items(zones, ex, ey, lo0, slots, seg_min, seg, it);
+    std::vector<uint8_t> in;
+    strip_windows(zones, t4, in);
+    *n_items = (int32_t)(it.size() / 6);
+    *n_windows = (int32_t)(t4.size() / 4);
+    if (seg_rows) *seg_rows = s;
+    if (items6) {
+        if ((size_t)items_cap * 6 < it.size()) return fail(-1, "room for %d items, there are %d", items_cap, *n_items);
+        std::copy(it.begin(), it.end(), items6);
+    }
+    if (tiles4 && in_zone) {
+        if ((size_t)windows_cap * 4 < t4.size()) return fail(-1, "room for %d windows, there are %d", windows_cap, *n_windows);
+        std::copy(t4.begin(), t4.end(), tiles4);
+        std::copy(in.begin(), in.end(), in_zone);
+    }
+    return 0;
+}
 #endif  // CICE_EVP_HIP_TESTING
 
 int cice_evp_hip_stream_probe(int64_t ncells, double *bytes_per_second)

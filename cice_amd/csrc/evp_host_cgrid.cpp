@@ -553,31 +553,13 @@ static int build_one_tables(const double *const *static23)
             tab.swap(etab);
         }
         const int nt = (int)(tiles.size() / 4), sx = EX - 3, sy = EY - 3;
-        struct Zone { int b, i0, i1, j0, j1; };       // first owned column of the first / last window column, same for rows
+        using Zone = StripZone;                        // (halo_plan.h: the planning is host-only code with a CPU test)
         std::vector<Zone> zones;
         long zcells = 0;
         std::vector<uint8_t> in_zone((size_t)nt, 0);
         if ((double)S.n * 8.0 * std::max((int)CG_NG, (int)CG_NIN) >= 4294967296.0) want = 0;     // (the kernel's 32-bit offsets into the tables)
-        for (int b = 0; b < d.nblocks && want; ++b) {
-            int i0 = 1 << 30, i1 = -1, j0 = 1 << 30, j1 = -1, cnt = 0;
-            for (int w = 0; w < nt; ++w)
-                if (tiles[4 * w] == b && tiles[4 * w + 3]) {
-                    i0 = std::min(i0, tiles[4 * w + 1]); i1 = std::max(i1, tiles[4 * w + 1]);
-                    j0 = std::min(j0, tiles[4 * w + 2]); j1 = std::max(j1, tiles[4 * w + 2]);
-                    ++cnt;
-                }
-            if (!cnt || (i1 - i0) % sx || (j1 - j0) % sy) continue;
-            if (cnt != ((i1 - i0) / sx + 1) * ((j1 - j0) / sy + 1)) continue;       // (not a rectangle: cg_one keeps the block)
-            if (i1 + sx - i0 < 62) continue;                                          // (narrower than a strip)
-            // (cells with ghost images -- the block's outermost interior cells -- never lie inside: the marched kernel has no pushes)
-            bool images = false;
-            for (int j = j0; j <= j1 + sy - 1 && !images; ++j)
-                for (int i = i0; i <= i1 + sx - 1 && !images; ++i)
-                    images = !CG.h_img_slot.empty() && CG.h_img_slot[(size_t)b * d.nx_block * d.ny_block + (size_t)(j - 1) * d.nx_block + (i - 1)] >= 0;
-            if (images) continue;
-            zones.push_back(Zone{b, i0, i1, j0, j1});
-            zcells += (long)(i1 - i0 + sx) * (j1 - j0 + sy);
-        }
+        if (want) strip_zones(d, tiles, EX, EY, CG.h_img_slot.empty() ? nullptr : CG.h_img_slot.data(), zones);
+        for (const Zone &z : zones) zcells += (long)(z.i1 - z.i0 + sx) * (z.j1 - z.j0 + sy);
         // (default: where the work items fill enough of the chip -- measured against cg_one alone: 720 x 270 23-48 us (segments of 4-16 rows)
         // against 22, 720 x 540 32 (8 rows) against 40, 1440 x 1080 95 against 154, 3600 x 2400 455-489 against 794)
         if (want == 2 && (2 * zcells < interior || zcells < 300000)) zones.clear();
@@ -630,38 +612,17 @@ static int build_one_tables(const double *const *static23)
             // strips of 60 owned columns (lanes 2 .. 61 of the wave; 59, lanes 3 .. 61, where the kernel forms the lengths; the last
             // strip of a rectangle is shifted west so that its lanes stay inside it and owns what is left); segments: about two
             // waves per SIMD resident at once over all strips (256 CUs x 8)
-            const int LO0 = lengths ? 3 : 2, SOWN = 62 - LO0;
-            long nstrips = 0, maxrows = 0;
-            for (const Zone &z : zones) { nstrips += (z.i1 - z.i0 + sx + SOWN - 1) / SOWN; maxrows = std::max<long>(maxrows, z.j1 - z.j0 + sy); }
             // (measured, 3600 x 2400: 2006 items of 70 rows 567 us per subcycle; 2065 items -- 17 more than fit at once -- 693;
-            // 2950 x 48 597, 4720 x 30 603, 11741 x 12 624: one round of work, as long as possible)
+            // 2950 x 48 597, 4720 x 30 603, 11741 x 12 624: one round of work, as long as possible.  Shortest segment: 16 rows from a
+            // million cells -- 1440 x 1080: 1608 items of 16 rows 95 us, 1992 of 13 104 --, 8 below -- 720 x 540: 804 items of 8 rows
+            // 32 us, 408 of 16 49)
             long slots = 2048;
             if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_ITEMS")) slots = std::max(1, std::atoi(e));
-            const long nseg_fit = std::max<long>(1, slots / std::max<long>(1, nstrips));
-            // (shortest segment: 16 rows from a million cells -- 1440 x 1080: 1608 items of 16 rows 95 us, 1992 of 13 104 --, 8 below
-            // -- 720 x 540: 804 items of 8 rows 32 us, 408 of 16 49)
-            int seg = (int)std::max<long>(zcells >= 1000000 ? 16 : 8, (maxrows + nseg_fit - 1) / nseg_fit);
-            if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_SEG")) seg = std::max(1, std::atoi(e));
+            int seg_forced = 0;
+            if (const char *e = env_test("CICE_EVP_HIP_CGRID_STRIP_SEG")) seg_forced = std::max(1, std::atoi(e));
             std::vector<int32_t> items;
-            for (const Zone &z : zones) {
-                const int rows = z.j1 - z.j0 + sy, nseg = (rows + seg - 1) / seg;
-                const int ilast = z.i1 + sx - 1;                       // last owned column of the rectangle
-                for (int k = 0; k < nseg; ++k) {
-                    // (equal segments: rows / nseg, the remainder one row each to the first ones)
-                    const int ja = z.j0 + (int)((long)rows * k / nseg), jb = z.j0 + (int)((long)rows * (k + 1) / nseg) - 1;
-                    for (int i0 = z.i0; i0 <= ilast; i0 += SOWN) {
-                        // column of lane 2: the strip's first owned column on lane LO0, or further west if lane 61 would pass the rectangle
-                        const int c = std::min(i0 - (LO0 - 2), std::max(z.i0 - (LO0 - 2), ilast - 59));
-                        const int lo = 2 + (i0 - c), hi = std::min(61, 2 + (ilast - c));
-                        items.push_back(z.b); items.push_back(c); items.push_back(ja); items.push_back(jb);
-                        items.push_back(lo); items.push_back(hi);
-                    }
-                }
-                for (int w = 0; w < nt; ++w)
-                    if (tiles[4 * w] == z.b && tiles[4 * w + 3] && tiles[4 * w + 1] >= z.i0 && tiles[4 * w + 1] <= z.i1 &&
-                        tiles[4 * w + 2] >= z.j0 && tiles[4 * w + 2] <= z.j1)
-                        in_zone[(size_t)w] = 1;
-            }
+            const int seg = strip_items(zones, EX, EY, lengths ? 3 : 2, slots, zcells >= 1000000 ? 16 : 8, seg_forced, items);
+            strip_windows(zones, tiles, in_zone);
             std::vector<int32_t> tiles_e, tab_e;
             const size_t per = (size_t)EX * EY;
             for (int w = 0; w < nt; ++w)

@@ -712,6 +712,70 @@ void build_window_table(const cice_evp_hip_dims &d, const HaloPlan &P, int OX, i
                 }
 }
 
+void strip_zones(const cice_evp_hip_dims &d, const std::vector<int32_t> &tiles, int ex, int ey, const int *img_slot, std::vector<StripZone> &zones)
+{
+    const int nt = (int)(tiles.size() / 4), sx = ex - 3, sy = ey - 3;
+    zones.clear();
+    for (int b = 0; b < d.nblocks; ++b) {
+        int i0 = 1 << 30, i1 = -1, j0 = 1 << 30, j1 = -1, cnt = 0;
+        for (int w = 0; w < nt; ++w)
+            if (tiles[4 * w] == b && tiles[4 * w + 3]) {
+                i0 = std::min(i0, tiles[4 * w + 1]); i1 = std::max(i1, tiles[4 * w + 1]);
+                j0 = std::min(j0, tiles[4 * w + 2]); j1 = std::max(j1, tiles[4 * w + 2]);
+                ++cnt;
+            }
+        if (!cnt || (i1 - i0) % sx || (j1 - j0) % sy) continue;
+        if (cnt != ((i1 - i0) / sx + 1) * ((j1 - j0) / sy + 1)) continue;       // (not a rectangle: cg_one keeps the block)
+        if (i1 + sx - i0 < 62) continue;                                          // (narrower than a strip)
+        // (cells with ghost images -- the block's outermost interior cells -- never lie inside: the marched kernel has no pushes)
+        bool images = false;
+        for (int j = j0; j <= j1 + sy - 1 && !images && img_slot; ++j)
+            for (int i = i0; i <= i1 + sx - 1 && !images; ++i)
+                images = img_slot[(size_t)b * d.nx_block * d.ny_block + (size_t)(j - 1) * d.nx_block + (i - 1)] >= 0;
+        if (images) continue;
+        zones.push_back(StripZone{b, i0, i1, j0, j1});
+    }
+}
+
+int strip_items(const std::vector<StripZone> &zones, int ex, int ey, int lo0, long slots, int seg_min, int seg, std::vector<int32_t> &items)
+{
+    const int sx = ex - 3, sy = ey - 3, sown = 62 - lo0;
+    items.clear();
+    long nstrips = 0, maxrows = 0;
+    for (const StripZone &z : zones) { nstrips += (z.i1 - z.i0 + sx + sown - 1) / sown; maxrows = std::max<long>(maxrows, z.j1 - z.j0 + sy); }
+    if (seg <= 0) {
+        const long nseg_fit = std::max<long>(1, slots / std::max<long>(1, nstrips));
+        seg = (int)std::max<long>(seg_min, (maxrows + nseg_fit - 1) / nseg_fit);
+    }
+    for (const StripZone &z : zones) {
+        const int rows = z.j1 - z.j0 + sy, nseg = (rows + seg - 1) / seg;
+        const int ilast = z.i1 + sx - 1;                       // last owned column of the rectangle
+        for (int k = 0; k < nseg; ++k) {
+            // (equal segments: rows / nseg, the remainder one row each to the first ones)
+            const int ja = z.j0 + (int)((long)rows * k / nseg), jb = z.j0 + (int)((long)rows * (k + 1) / nseg) - 1;
+            for (int i0 = z.i0; i0 <= ilast; i0 += sown) {
+                // column of lane 2: the strip's first owned column on lane lo0, or further west if lane 61 would pass the rectangle
+                const int c = std::min(i0 - (lo0 - 2), std::max(z.i0 - (lo0 - 2), ilast - 59));
+                const int lo = 2 + (i0 - c), hi = std::min(61, 2 + (ilast - c));
+                items.push_back(z.b); items.push_back(c); items.push_back(ja); items.push_back(jb);
+                items.push_back(lo); items.push_back(hi);
+            }
+        }
+    }
+    return seg;
+}
+
+void strip_windows(const std::vector<StripZone> &zones, const std::vector<int32_t> &tiles, std::vector<uint8_t> &in_zone)
+{
+    const int nt = (int)(tiles.size() / 4);
+    in_zone.assign((size_t)nt, 0);
+    for (const StripZone &z : zones)
+        for (int w = 0; w < nt; ++w)
+            if (tiles[4 * w] == z.b && tiles[4 * w + 3] && tiles[4 * w + 1] >= z.i0 && tiles[4 * w + 1] <= z.i1 &&
+                tiles[4 * w + 2] >= z.j0 && tiles[4 * w + 2] <= z.j1)
+                in_zone[(size_t)w] = 1;
+}
+
 int cgres_dependencies(const cice_evp_hip_dims &d, bool tripole, const std::vector<int32_t> &tiles, const std::vector<int32_t> &tab,
                        std::vector<uint8_t> *pub, int *n_edges, int *n_oneway)
 {

@@ -163,6 +163,21 @@ inline bool cgres_in_reach(int ex, int ey, int last_ex, int last_ey, bool foldwi
 {
     return foldwin || (ex <= last_ex + CGRES_REACH && ey <= last_ey + CGRES_REACH);
 }
+// ---- the marched C-grid kernel's share of a rank (evp_cgrid.hip: cg_strip) -- host only, CPU-tested ----
+// A rectangle of a block that the regular windows of a window table cover (regular: every position an interior cell of the block,
+// its own source): first owned column / row of its first and last window column / row.
+struct StripZone { int b, i0, i1, j0, j1; };
+// per block the rectangle of its regular windows, if they form one, it is at least a strip wide and none of its cells has a ghost
+// image (img_slot: per cell, < 0 = none; may be null)
+void strip_zones(const cice_evp_hip_dims &d, const std::vector<int32_t> &tiles, int ex, int ey, const int *img_slot, std::vector<StripZone> &zones);
+// work items of the rectangles, x 6 ints each: block, column of lane 2, first and last owned row, first and last owned lane.  lo0: first lane
+// that may own a column (2; 3 where the kernel forms the lengths), the last is 61; strips of 62 - lo0 columns, the last one shifted west
+// so that lane 62 stays inside the rectangle + 1; segments of `seg` rows (0: the fewest rows >= seg_min with at most `slots` items).
+// Returns the rows per segment.
+int strip_items(const std::vector<StripZone> &zones, int ex, int ey, int lo0, long slots, int seg_min, int seg, std::vector<int32_t> &items);
+// 1 for every window of `tiles` that lies inside one of the rectangles (the marched kernel owns its cells), 0: cg_one keeps it
+void strip_windows(const std::vector<StripZone> &zones, const std::vector<int32_t> &tiles, std::vector<uint8_t> &in_zone);
+
 // The hand-off graph of the resident windows (tiles / tab as build_window_table(..., 16, 16, ., extra = 1) or
 // build_fold_window_table made them): window w READS window p when it polls a cell p owns.  A window cannot start subcycle j + 1
 // before every window it reads has finished subcycle j, so a window p is never more than len subcycles ahead of w, len = the

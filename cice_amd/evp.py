@@ -53,7 +53,7 @@ EXPORTS = [
 # libcice_evp_hip_testing.so only (include/cice_evp_hip_testing.h): plan introspection of the CPU tests, read-outs of the tools,
 # the test transport
 TEST_EXPORTS = [
-    "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_cgrid_window_plan_ext", "cice_evp_hip_cgrid_window_deps", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
+    "cice_evp_hip_cgrid_fold_plan", "cice_evp_hip_cgrid_window_plan", "cice_evp_hip_cgrid_window_plan_ext", "cice_evp_hip_cgrid_window_deps", "cice_evp_hip_cgrid_strip_plan", "cice_evp_hip_set_test_transport", "cice_evp_hip_march_plan",
     "cice_evp_hip_debug_cuload", "cice_evp_hip_debug_prof", "cice_evp_hip_debug_cgrid_prof", "cice_evp_hip_debug_cgres_prof", "cice_evp_hip_plan_build", "cice_evp_hip_halo_plan", "cice_evp_hip_seam_plan",
     "cice_evp_hip_peer_plan", "cice_evp_hip_peer_signs", "cice_evp_hip_center_plan", "cice_evp_hip_stress_plan",
     "cice_evp_hip_fold_split_plan", "cice_evp_hip_plan_flags", "cice_evp_hip_fold_images_plan",
@@ -245,6 +245,20 @@ def cgrid_window_deps(dims: "Dims") -> dict:
     nw, ne, n1, nu = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
     _check(lib, lib.cice_evp_hip_cgrid_window_deps(C.byref(dims), C.byref(nw), C.byref(ne), C.byref(n1), C.byref(nu)), "(cgrid_window_deps)")
     return dict(windows=nw.value, edges=ne.value, oneway=n1.value, unsafe=nu.value)
+
+
+def cgrid_strip_plan(dims: "Dims", ex=32, ey=8, lo0=3, slots=2048, seg_min=8, seg=0) -> dict:
+    """Host only: the marched C-grid kernel's work items and the windows the windowed kernel keeps (see the testing header)."""
+    lib = load_library(testing=True)
+    ni, nw, sr = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    a = (C.byref(dims), C.c_int32(ex), C.c_int32(ey), C.c_int32(lo0), C.c_int32(slots), C.c_int32(seg_min), C.c_int32(seg))
+    _check(lib, lib.cice_evp_hip_cgrid_strip_plan(*a, C.byref(ni), None, C.c_int32(0), C.byref(nw), None, None, C.c_int32(0), C.byref(sr)), "(cgrid_strip_plan)")
+    items = np.zeros((max(ni.value, 1), 6), dtype=np.int32)
+    tiles = np.zeros((max(nw.value, 1), 4), dtype=np.int32)
+    inz = np.zeros(max(nw.value, 1), dtype=np.uint8)
+    _check(lib, lib.cice_evp_hip_cgrid_strip_plan(*a, C.byref(ni), _ip(items), C.c_int32(len(items)), C.byref(nw), _ip(tiles),
+                                                  inz.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int32(len(tiles)), C.byref(sr)), "(cgrid_strip_plan)")
+    return dict(items=items[:ni.value], tiles=tiles[:nw.value], in_zone=inz[:nw.value].astype(bool), segment_rows=sr.value)
 
 
 def stream_probe(ncells: int) -> float:

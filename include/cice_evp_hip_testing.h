@@ -44,6 +44,15 @@ int cice_evp_hip_cgrid_window_plan_ext(const cice_evp_hip_dims *dims, int32_t ox
  * window read could then be four subcycles ahead of its reader and overwrite one of the kernel's four record slots per cell that
  * the reader still waits for): the library does not use the kernel unless n_unsafe == 0.                                          */
 int cice_evp_hip_cgrid_window_deps(const cice_evp_hip_dims *dims, int32_t *n_windows, int32_t *n_edges, int32_t *n_oneway, int32_t *n_unsafe);
+/* Host only: how the one-launch C-grid schedule of large domains shares a rank's cells between the marched kernel (cg_strip) and the
+ * windowed kernel (halo_plan.h: strip_zones, strip_items, strip_windows, on the window table of ex x ey positions).  items6: per work
+ * item block, column of lane 2, first and last owned row (1-based), first and last owned lane (lane l holds column items6[1] - 2 + l);
+ * tiles4 / in_zone: the windows (block, first owned i, first owned j, regular) and 1 where the marched kernel owns the window's cells.
+ * lo0: first lane that may own a column (2, or 3 where the kernel forms the lengths); slots, seg_min, seg as in strip_items.  Pass NULL
+ * arrays to learn the counts.                                                                                                        */
+int cice_evp_hip_cgrid_strip_plan(const cice_evp_hip_dims *dims, int32_t ex, int32_t ey, int32_t lo0, int32_t slots, int32_t seg_min, int32_t seg,
+                                  int32_t *n_items, int32_t *items6, int32_t items_cap, int32_t *n_windows, int32_t *tiles4, uint8_t *in_zone, int32_t windows_cap,
+                                  int32_t *seg_rows);
 /* Test hook: route the exchanges and the rank agreements of the marching path through HOST buffers and the caller's
  * callbacks instead of RCCL (which refuses two ranks on one device), so that its several-rank form can be run as
  * processes sharing one GPU (tools/mailbox_2proc.py --march: torch.distributed gloo underneath).  xchg: per peer q

@@ -463,6 +463,49 @@ def test_cgrid_resident_window_handoffs_are_safe(nx, ny, bx, by, ew, ns):
         assert g["oneway"] == 0, g
 
 
+@pytest.mark.parametrize("nx,ny,bx,by,ew,lo0,seg", [(3600, 2400, 3600, 2400, "cyclic", 3, 0), (3600, 2400, 1800, 1200, "cyclic", 2, 0),
+                                                    (720, 540, 720, 540, "cyclic", 3, 0), (400, 64, 200, 32, "cyclic", 3, 5),
+                                                    (190, 50, 190, 50, "closed", 2, 3), (331, 47, 331, 47, "cyclic", 3, 1),
+                                                    (140, 90, 70, 90, "cyclic", 3, 0), (1000, 37, 250, 37, "closed", 2, 64)])
+def test_cgrid_marched_kernel_plan_covers_every_cell_once(nx, ny, bx, by, ew, lo0, seg):
+    """How the one-launch C-grid schedule of large domains shares a rank between the marched kernel (cg_strip) and the windowed one
+    (halo_plan.h: strip_zones / strip_items / strip_windows): every interior cell of every block is owned exactly once -- by one lane
+    of one work item, or by one window the windowed kernel keeps --, the items own exactly the cells of the windows they replace, every
+    position an item computes is an interior cell of its block and every row / column it loads lies inside the block's array."""
+    from cice_amd import decomp
+    dc = decomp.Decomp(nx, ny, bx, by, ew, "closed", 1)
+    d, keep = evp.make_dims(dc, 0)
+    ex, ey = 32, 8
+    pl = evp.cgrid_strip_plan(d, ex=ex, ey=ey, lo0=lo0, slots=2048, seg_min=8, seg=seg)
+    blks = dc.local_blocks(0)
+    own = np.zeros((len(blks), dc.ny_block + 1, dc.nx_block + 1), dtype=np.int32)      # 1-based
+    for b, c, ja, jb, lo, hi in pl["items"]:
+        B = blks[b]
+        assert lo0 <= lo <= hi <= 61 and ja <= jb
+        own[b, ja:jb + 1, c - 2 + lo:c - 2 + hi + 1] += 1
+        # computed positions: lanes 0 .. 62, rows ja - 2 .. jb + 1; loaded: lane 63 too, rows ja - 6 .. jb + 2
+        assert B.ilo <= c - 2 and c + 60 <= B.ihi and B.jlo <= ja - 2 and jb + 1 <= B.jhi, (b, c, ja, jb)
+        assert c + 61 <= dc.nx_block and ja - 6 >= 1 and jb + 2 <= dc.ny_block
+    marched = own.copy()
+    win = np.zeros_like(own)
+    for (b, i0, j0, reg), inz in zip(pl["tiles"], pl["in_zone"]):
+        B = blks[b]
+        i1, j1 = min(i0 + ex - 4, B.ihi), min(j0 + ey - 4, B.jhi)
+        (win if inz else own)[b, j0:j1 + 1, i0:i1 + 1] += 1
+        assert reg or not inz
+    for b, B in enumerate(blks):
+        inner = own[b, B.jlo:B.jhi + 1, B.ilo:B.ihi + 1]
+        assert (inner == 1).all(), f"block {b}: {int((inner != 1).sum())} interior cells not owned exactly once"
+        own[b, B.jlo:B.jhi + 1, B.ilo:B.ihi + 1] = 0
+    assert not own.any(), "a cell outside the interior is owned"
+    assert (marched == win).all(), "the work items do not own exactly the cells of the windows they replace"
+    if len(pl["items"]):
+        rows = pl["items"][:, 3] - pl["items"][:, 2] + 1
+        assert rows.max() <= pl["segment_rows"] and (seg or len(pl["items"]) <= 2048 or pl["segment_rows"] == 8)
+    if (nx, ny) == (3600, 2400) and bx == 3600:
+        assert len(pl["items"]) == 2013 and pl["segment_rows"] == 73 and int(marched.sum()) == 8525130
+
+
 def test_cgrid_resident_window_handoff_graph_against_a_python_restatement():
     """The library's hand-off graph against a restatement of the rule in Python from the window table itself, over random cuts --
     including the few that keep one-way hand-offs: counted alike, and every one of them with a chain back of at most three."""
