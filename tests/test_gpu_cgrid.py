@@ -355,7 +355,7 @@ def synth_cgrid(grid_name, case="full", bs=None, seed=3, seabed=False):
     return dc, g, static, state, inputs, masks
 
 
-def run_both(dc, g, static, state, inputs, masks, ndte, visc_method="avg_zeta", scal_kw=None, scal_over=None):
+def run_both(dc, g, static, state, inputs, masks, ndte, visc_method="avg_zeta", scal_kw=None, scal_over=None, info=None):
     from cice_amd import synth
     scal = synth.evp_scalars(120, **(scal_kw or {}))
     scal.update(scal_over or {})
@@ -373,6 +373,8 @@ def run_both(dc, g, static, state, inputs, masks, ndte, visc_method="avg_zeta", 
     try:
         core.cgrid_set_geometry(static)
         got = core.cgrid_run(ndte, state, inputs, masks, visc_method=visc_method)
+        if info is not None:
+            info.update(core.cgrid_timings())
     finally:
         core.finalize()
     return got, want
@@ -738,6 +740,48 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
     windowed, tw = run()
     assert tw["marched_items"] == 0 and tw["one_launch_subcycles"] == 8, tw
     assert_bitwise(got, windowed, f"marched interior against the windowed kernel, seed {seed}")
+
+
+@pytest.mark.parametrize("seed", [3101, 3102, 3103, 3104] + [int(s) for s in __import__("os").environ.get("CGRID_STRIP_SWEEP_SEEDS", "").split() if s])
+def test_cgrid_marched_interior_random_cuts_vs_oracle(seed, monkeypatch):
+    """A sweep over what shapes the marched kernel's plan: domain and block size (one to four blocks, padded or not, cyclic or closed
+    in x), segment length, the shape of the windows kept, lengths formed or loaded, the last subcycle marched or not, ice cover, islands,
+    classic / revised EVP -- all drawn from the seed; every array equal to the oracle's, bit for bit.  CGRID_STRIP_SWEEP_SEEDS adds seeds."""
+    rng = np.random.default_rng(seed)
+    nbx, nby = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    bx, by = int(rng.integers(130, 260)), int(rng.integers(24, 70))
+    nx, ny = nbx * bx - int(rng.integers(0, 20)) * (nbx > 1), nby * by - int(rng.integers(0, 6)) * (nby > 1)
+    case, holes, land = ("full", "caps")[int(rng.integers(0, 2))], float(rng.choice([0.0, 0.2, 0.5])), float(rng.choice([0.0, 0.03, 0.1]))
+    revised = bool(rng.integers(0, 2))
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_RESIDENT", "0")
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_ONE_SHAPE", str(int(rng.integers(1, 3))))
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP", "1")
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_EDGE", str(int(rng.choice([0, 0, 0, 1, 2]))))
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_LEN", str(int(rng.integers(0, 2))))
+    monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_LAST", str(int(rng.integers(0, 2))))
+    if rng.integers(0, 2):
+        monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_SEG", str(int(rng.integers(1, 24))))
+    from cice_amd import decomp, synth
+    g0 = synth.make_grid(nx, ny, 2.0e4, ns="closed")
+    g0["kmt"] = g0["kmt"] * (rng.random((ny, nx)) >= land)
+    g = synth.derive_geometry(g0)
+    cg = synth.cgrid_geometry(g)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed)
+    for k in masks:
+        masks[k] = masks[k] * (rng.random((ny, nx)) >= holes).astype(np.int32)
+    for k in ("stresspT", "stressmT", "stress12T"):
+        state[k] = state[k] * masks["iceTmask"]
+    state["stress12U"] = state["stress12U"] * masks["iceUmask"]
+    dc = decomp.Decomp(nx, ny, bx, by, "cyclic", "closed", 1)
+    static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
+    kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
+    info = {}
+    got, want = run_both(dc, g, static, state, inputs, masks, ndte=int(rng.integers(3, 8)), scal_kw=kw, info=info)
+    assert_bitwise(got, want, f"marched interior, random cut {seed}: {nx} x {ny} in blocks of {bx} x {by}")
+    # (windows of 64 positions along the edges leave blocks under ~190 columns without a rectangle: cg_one runs those alone)
+    assert info["marched_items"] > 0 or __import__("os").environ["CICE_EVP_HIP_CGRID_STRIP_EDGE"] != "0", info
+    print(f"STRIP_SWEEP seed {seed}: {nx} x {ny} / {bx} x {by}, items {info['marched_items']} x {info['marched_segment_rows']} rows, "
+          f"cells {info['marched_cells']}, lengths formed {info['marched_lengths_derived']}")
 
 
 def test_cgrid_default_configuration_shortcuts_are_bit_neutral(monkeypatch):
