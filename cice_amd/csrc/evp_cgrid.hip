@@ -1328,11 +1328,17 @@ __device__ __forceinline__ void cg_st(void *base, unsigned off, double v) { *(do
 // taubxE / yN (values the subcycle forms anyway) and deltaU, for which strain_rates_U's divergence and tension are worked out too, ONE ROW
 // LATE: they take the N-face average at the east neighbour (a lane shift of the owned rows' uvelN) and the E-face average of the row to
 // the north (the next iteration's vvelE); nothing inside the loop reads deltaU with visc_method = avg_zeta.
-template <bool LEN, bool LAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z, EvpCgOne E)
+// FAST (as in cg_one): the default configuration's short cuts hold on every ice cell of the call (waterx == uocn, Tb == 0, rheofact == 1);
+// without it the momentum step is the general one: ten more operands per cell (rheofact, aice x cdn_ocn in place of their per-call
+// product, waterx / watery, Tb at both faces), two more square roots and divisions.
+// (the general momentum step does not fit 256 registers, and a wave that spills to scratch waits for its prefetched rows at every
+// reload -- vmcnt counts in order: 983 us on 3600 x 2400, slower than cg_one; it gets a SIMD's register file to itself instead: 658 us
+// against cg_one's 905.  The last subcycle's instantiation, 32 bytes of scratch, is no faster that way: 754 us against 717)
+template <bool LEN, bool LAST, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 1, FAST ? 2 : 1))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z, EvpCgOne E)
 {
     if ((int)blockIdx.x >= 8 * Z.per_xcd) {
-        cg_one_window<true, 32, 8, LAST ? 1 : 0, true>(A, E, LAST ? 1 : 0, (int)blockIdx.x - 8 * Z.per_xcd, (int)(threadIdx.x & 31u), (int)(threadIdx.x >> 5));
+        cg_one_window<FAST, 32, 8, LAST ? 1 : 0, true>(A, E, LAST ? 1 : 0, (int)blockIdx.x - 8 * Z.per_xcd, (int)(threadIdx.x & 31u), (int)(threadIdx.x >> 5));
         return;
     }
     const int lane = (int)(threadIdx.x & 63u);
@@ -1403,10 +1409,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // group C (row j-1) is used at the bottom of THIS iteration: levels S, T and U cover its latency
         const unsigned o1 = (cell - nx) * 8u;
         const double c_s12 = cg_ld(A.s12_in, o1);
-        const double c_uoE = I(CI_UOCNE, o1), c_voE = I(CI_VOCNE, o1), c_fcE = cg_ld(A.facE, o1), c_emE = I(CI_EMASSDTI, o1), c_fmE = I(CI_FME, o1),
-                     c_fxE = I(CI_FORCEXE, o1);
-        const double c_voN = I(CI_VOCNN, o1), c_uoN = I(CI_UOCNN, o1), c_fcN = cg_ld(A.facN, o1), c_emN = I(CI_NMASSDTI, o1), c_fmN = I(CI_FMN, o1),
-                     c_fyN = I(CI_FORCEYN, o1);
+        const double c_uoE = I(CI_UOCNE, o1), c_voE = I(CI_VOCNE, o1), c_emE = I(CI_EMASSDTI, o1), c_fmE = I(CI_FME, o1), c_fxE = I(CI_FORCEXE, o1);
+        const double c_voN = I(CI_VOCNN, o1), c_uoN = I(CI_UOCNN, o1), c_emN = I(CI_NMASSDTI, o1), c_fmN = I(CI_FMN, o1), c_fyN = I(CI_FORCEYN, o1);
+        double c_fcE = 0.0, c_fcN = 0.0, c_aiE = 0.0, c_cwE = 0.0, c_wxE = 0.0, c_tbE = 0.0, c_rhE = 0.0, c_aiN = 0.0, c_cwN = 0.0, c_wyN = 0.0, c_tbN = 0.0, c_rhN = 0.0;
+        if (FAST) {
+            c_fcE = cg_ld(A.facE, o1); c_fcN = cg_ld(A.facN, o1);
+        } else {
+            c_aiE = I(CI_AIE, o1); c_cwE = I(CI_CWE, o1); c_wxE = I(CI_WATERXE, o1); c_tbE = I(CI_TBE, o1); c_rhE = I(CI_RHEOE, o1);
+            c_aiN = I(CI_AIN, o1); c_cwN = I(CI_CWN, o1); c_wyN = I(CI_WATERYN, o1); c_tbN = I(CI_TBN, o1); c_rhN = I(CI_RHEON, o1);
+        }
         // classic EVP (revp == 0): revp * uvelE_init is a zero and the initial velocities are not read (as in the B-grid kernels,
         // evp_cell.inc: the sum keeps the add of +0; a zero of the other sign could only show where uold is -0 exactly)
         double c_uiE = 0.0, c_viN = 0.0;
@@ -1542,51 +1553,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const unsigned oc = (cell - nx) * 8u;
                 const double s12c = s12, s12s = s12_2;
                 const double spc = sp1, smc = sm1, spn = sp, smn = sm;
-                double unew, vnew, strintx_ = 0.0, strinty_ = 0.0;
+                double unew, vnew, strintx_ = 0.0, strinty_ = 0.0, taubx_ = 0.0, tauby_ = 0.0;
                 {
                     const double dyE = dyE1, dxE = dxE1;
                     const double earear = ea1 > 0.0 ? 1.0 / ea1 : 0.0;
-                    const double strintx = earear * (0.5 * dyE * (spe - spc) + (0.5 / dyE) * (YT1E * sme - YT1 * smc) +
-                                                     (1.0 / dxE) * (XU1 * s12c - XU2 * s12s));
+                    const double strintx = (FAST ? earear : c_rhE * earear) *
+                                           (0.5 * dyE * (spe - spc) + (0.5 / dyE) * (YT1E * sme - YT1 * smc) + (1.0 / dxE) * (XU1 * s12c - XU2 * s12s));
                     const double uold = uE1, vold = ve1;
                     const double uocn = c_uoE;
                     const double du = uocn - uold, dv = c_voE - vold;
-                    const double vrel = c_fcE * sqrt(du * du + dv * dv);
-                    const double taux = vrel * uocn;
+                    const double vrel = (FAST ? c_fcE : c_aiE * p.rhow * c_cwE) * sqrt(du * du + dv * dv);
+                    const double taux = vrel * (FAST ? uocn : c_wxE);
+                    double Cb = 0.0;
+                    if (!FAST) {
+                        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+                        Cb = c_tbE / ccc;
+                    }
                     const double massdti = c_emE, fm = c_fmE;
-                    const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + 0.0;
+                    const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
                     const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
                     const double cc1 = strintx + c_fxE + taux + massdti * (p.brlx * uold + p.revp * c_uiE);
                     unew = (ccb * vold + cc1) / cca;
-                    strintx_ = strintx;
+                    strintx_ = strintx; taubx_ = -unew * Cb;
                 }
                 {
                     const double dxN = dxN1, dyN = dyN1;
                     const double narear = na1 > 0.0 ? 1.0 / na1 : 0.0;
                     const double XT0 = dxT0 * dxT0;
-                    const double strinty = narear * (0.5 * dxN * (spn - spc) - (0.5 / dxN) * (XT0 * smn - XT1 * smc) +
-                                                     (1.0 / dyN) * (YU1 * s12c - YU1W * s12w));
+                    const double strinty = (FAST ? narear : c_rhN * narear) *
+                                           (0.5 * dxN * (spn - spc) - (0.5 / dxN) * (XT0 * smn - XT1 * smc) + (1.0 / dyN) * (YU1 * s12c - YU1W * s12w));
                     const double uold = un1, vold = vN1;
                     const double vocn = c_voN;
                     const double du = c_uoN - uold, dv = vocn - vold;
-                    const double vrel = c_fcN * sqrt(du * du + dv * dv);
-                    const double tauy = vrel * vocn;
+                    const double vrel = (FAST ? c_fcN : c_aiN * p.rhow * c_cwN) * sqrt(du * du + dv * dv);
+                    const double tauy = vrel * (FAST ? vocn : c_wyN);
+                    double Cb = 0.0;
+                    if (!FAST) {
+                        const double ccc = sqrt(uold * uold + vold * vold) + p.u0;
+                        Cb = c_tbN / ccc;
+                    }
                     const double massdti = c_emN, fm = c_fmN;
-                    const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + 0.0;
+                    const double cca = (p.brlx + p.revp) * massdti + vrel * p.cosw + Cb;
                     const double ccb = fm + copysign(1.0, fm) * vrel * p.sinw;
                     const double cc2 = strinty + c_fyN + tauy + massdti * (p.brlx * vold + p.revp * c_viN);
                     vnew = (-ccb * uold + cc2) / cca;
-                    strinty_ = strinty;
+                    strinty_ = strinty; tauby_ = -vnew * Cb;
                 }
                 if (m1 & 2u) cg_st(A.f[CF_S12U], oc, s12c);
                 if (LAST) cg_st(A.f[CF_ETAU], oc, e2);
                 if (m1 & 4u) {
                     cg_st(A.f[CF_UE], oc, unew);
-                    if (LAST) { cg_st(A.f[CF_STRX], oc, strintx_); cg_st(A.f[CF_TAUBX], oc, -unew * 0.0); }
+                    if (LAST) { cg_st(A.f[CF_STRX], oc, strintx_); cg_st(A.f[CF_TAUBX], oc, taubx_); }
                 }
                 if (m1 & 8u) {
                     cg_st(A.f[CF_VN], oc, vnew);
-                    if (LAST) { cg_st(A.f[CF_STRY], oc, strinty_); cg_st(A.f[CF_TAUBY], oc, -vnew * 0.0); }
+                    if (LAST) { cg_st(A.f[CF_STRY], oc, strinty_); cg_st(A.f[CF_TAUBY], oc, tauby_); }
                 }
             }
             s12_2 = s12;
@@ -1729,7 +1750,7 @@ void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int la
 #undef CG_ONE
 }
 
-void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, int last, hipStream_t st)
+void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, int fast, int last, hipStream_t st)
 {
     if (Z.nitems <= 0) return;
     // E: windows of 32 x 8 positions to run in the same launch (NULL: none)
@@ -1737,11 +1758,15 @@ void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStr
     none.ntiles = 0;
     const EvpCgOne &W = (E && E->ntiles > 0) ? *E : none;
     const dim3 grid((unsigned)(8 * Z.per_xcd + W.ntiles)), block(256);
+#define CG_STRIP(L, X, F) hipLaunchKernelGGL((cg_strip<L, X, F>), grid, block, 0, st, A, T, Z, W)
+#define CG_STRIP_F(L, X) do { if (fast) CG_STRIP(L, X, true); else CG_STRIP(L, X, false); } while (0)
     if (Z.lengths) {
-        if (last) hipLaunchKernelGGL((cg_strip<true, true>), grid, block, 0, st, A, T, Z, W);
-        else hipLaunchKernelGGL((cg_strip<true, false>), grid, block, 0, st, A, T, Z, W);
+        if (last) CG_STRIP_F(true, true);
+        else CG_STRIP_F(true, false);
     } else {
-        if (last) hipLaunchKernelGGL((cg_strip<false, true>), grid, block, 0, st, A, T, Z, W);
-        else hipLaunchKernelGGL((cg_strip<false, false>), grid, block, 0, st, A, T, Z, W);
+        if (last) CG_STRIP_F(false, true);
+        else CG_STRIP_F(false, false);
     }
+#undef CG_STRIP_F
+#undef CG_STRIP
 }

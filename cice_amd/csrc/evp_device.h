@@ -398,14 +398,14 @@ struct EvpCgOne {
 };
 void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st);
 // The interior of a large block, marched (evp_cgrid.hip: cg_strip): one wave per item = strip of 64 positions (up to 60 owned
-// columns) x segment of rows; T carries the buffers and tables as for cg_one (its window list is not used).  Classic shape only: the
-// short cuts of FAST, visc_method = avg_zeta, the derived view of the static table (T.gmask); last: the last subcycle of a call.
+// columns) x segment of rows; T carries the buffers and tables as for cg_one (its window list is not used).  visc_method = avg_zeta and
+// the derived view of the static table (T.gmask) only; fast, last: as for cg_one.
 struct EvpCgStrip {
     const int *items;             // x 6: block, column of lane 2, first and last owned row (1-based), first and last owned lane
     int nitems, per_xcd;          // items; workgroups (of four items) per XCD (launch = 8 * per_xcd workgroups)
     int lengths;                  // 1: dxT, dyT, dxU, dyU, dxE, dyN formed in the kernel from dxN, dyE (verified by the host); the items own lanes >= 3
 };
-void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, int last, hipStream_t st);
+void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStrip &Z, const EvpCgOne *E, int fast, int last, hipStream_t st);
 // All subcycles of a call in one launch, state on the chip (evp_cgrid_res.hip: cg_res).  Windows of 16 x 16 positions, the inner
 // 13 x 13 owned; tab: per window the source cell of its 17 x 17 positions (one row / column more than cg_one's: what level S reads
 // of its north / east neighbour), as in EvpCgOne.  The velocities another window's rim mirrors travel as tagged 32-byte records.

@@ -377,7 +377,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
-            if (CG.one.nitems > 0 && CG.fast && !CG.avg_strength && T.gmask && !(last && env_test("CICE_EVP_HIP_CGRID_STRIP_LAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_LAST")))) {
+            if (CG.one.nitems > 0 && !CG.avg_strength && T.gmask && !(last && env_test("CICE_EVP_HIP_CGRID_STRIP_LAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_LAST")))) {
                 // the interior of the blocks marched, the windows along their edges as before: both read the previous
                 // subcycle's buffers only and own disjoint cells
                 EvpCgStrip Z{CG.one.items, CG.one.nitems, ((CG.one.nitems + 3) / 4 + 7) / 8, CG.one.strip_len};
@@ -389,8 +389,8 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
                 // 1024-thread workgroup does not fit beside the marched kernel's waves on a CU anyway)
                 // windows of 32 x 8 ride in the marched kernel's launch; other shapes (A/B) get a launch of their own behind it
                 const bool ride = E.ox == 32 && E.oy == 8 && !(env_test("CICE_EVP_HIP_CGRID_STRIP_RIDE") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_RIDE")));
-                evp_launch_cgrid_strip(A, T, Z, ride ? &E : nullptr, last, S.stream);
-                if (!ride && E.ntiles > 0) evp_launch_cgrid_one(A, E, 1, last, S.stream);
+                evp_launch_cgrid_strip(A, T, Z, ride ? &E : nullptr, CG.fast ? 1 : 0, last, S.stream);
+                if (!ride && E.ntiles > 0) evp_launch_cgrid_one(A, E, CG.fast ? 1 : 0, last, S.stream);
             } else if (T.ntiles > 0) {
                 evp_launch_cgrid_one(A, T, CG.fast ? 1 : 0, last, S.stream);
             }

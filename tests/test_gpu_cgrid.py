@@ -657,7 +657,17 @@ def test_cgrid_random_masks_vs_oracle_bitwise(seed, nx, ny, bs, ew, ns, holes, v
         assert np.abs(want["uvelE"] - args[3]["uvelE"]).max() > 0
 
 
-def marched_case(seed, nx, ny, bs, case, holes, land):
+def stir_momentum(inputs, masks, rng):
+    """Leave the default configuration: an ocean turning angle's waterx / watery, rheofact of 0 on some faces (seabed stress comes from
+    synth.cgrid_state(seabed=True)) -- the general momentum step of every kernel."""
+    shape = inputs["waterxE"].shape
+    inputs["waterxE"] = inputs["waterxE"] * (1.0 + 0.1 * rng.random(shape))
+    inputs["wateryN"] = inputs["wateryN"] * (1.0 - 0.1 * rng.random(shape))
+    for t in "EN":
+        inputs[f"rheofact{t}"] = inputs[f"rheofact{t}"] * (rng.random(shape) > 0.1)
+
+
+def marched_case(seed, nx, ny, bs, case, holes, land, general=False):
     """A synthetic workload in the default configuration (the reference's start-up identities hold for the geometry, waterx == uocn,
     Tb == 0, rheofact == 1 on ice: what the marched kernel is for) with the branches stirred up: random land cells inside the ocean
     (coastal corners: the boundary-condition ratios), random, mutually independent holes in the four ice masks."""
@@ -667,7 +677,9 @@ def marched_case(seed, nx, ny, bs, case, holes, land):
     g0["kmt"] = g0["kmt"] * (rng.random((ny, nx)) >= land)
     g = synth.derive_geometry(g0)
     cg = synth.cgrid_geometry(g)
-    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed, seabed=general)
+    if general:
+        stir_momentum(inputs, masks, rng)
     for k in masks:
         masks[k] = masks[k] * (rng.random((ny, nx)) >= holes).astype(np.int32)
     for k in ("stresspT", "stressmT", "stress12T"):
@@ -686,6 +698,9 @@ def marched_case(seed, nx, ny, bs, case, holes, land):
     (26, 190, 50, (190, 50), "caps", 0.1, 0.01, False, "3", "2"),        # the last strip shifted west (68 columns: 60 + 8)
     # the rectangle's top window row would read dyU of row ny_global, which the reference extrapolates: that row goes back to cg_one
     (27, 200, 46, (200, 46), "full", 0.2, 0.02, False, None, "2"),
+    # seabed stress, an ocean turning angle's waterx, rheofact = 0 on some faces: the general momentum step (classic / revised EVP)
+    (28, 280, 60, (280, 60), "full", 0.2, 0.03, False, "9", "2"),
+    (29, 300, 44, (150, 44), "caps", 0.3, 0.0, True, None, "1"),
 ])
 def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes, land, revised, seg, shape, monkeypatch):
     """The one-launch schedule with the interior of each block marched (evp_cgrid.hip: cg_strip; the default on the 0.1-degree
@@ -699,9 +714,11 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
     if seed in (22, 23):          # the windows kept along the edges: 64 x 8 / 64 x 16 instead of 32 x 8
         monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_EDGE", "1" if seed == 22 else "2")
     from cice_amd import synth
-    dc, _, static, state, inputs, masks = marched_case(seed, nx, ny, bs, case, holes, land)
+    dc, _, static, state, inputs, masks = marched_case(seed, nx, ny, bs, case, holes, land, general=seed in (28, 29))
     kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
     scal = synth.evp_scalars(120, **kw)
+    if seed in (28, 29):
+        scal.update(cosw=np.cos(0.4), sinw=np.sin(0.4))
     d, keep = evp.make_dims(dc, 0)
 
     def run():
@@ -766,7 +783,10 @@ def test_cgrid_marched_interior_random_cuts_vs_oracle(seed, monkeypatch):
     g0["kmt"] = g0["kmt"] * (rng.random((ny, nx)) >= land)
     g = synth.derive_geometry(g0)
     cg = synth.cgrid_geometry(g)
-    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed)
+    general = bool(rng.integers(0, 3) == 0)
+    state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed, seabed=general)
+    if general:
+        stir_momentum(inputs, masks, rng)
     for k in masks:
         masks[k] = masks[k] * (rng.random((ny, nx)) >= holes).astype(np.int32)
     for k in ("stresspT", "stressmT", "stress12T"):
@@ -776,12 +796,13 @@ def test_cgrid_marched_interior_random_cuts_vs_oracle(seed, monkeypatch):
     static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
     kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
     info = {}
-    got, want = run_both(dc, g, static, state, inputs, masks, ndte=int(rng.integers(3, 8)), scal_kw=kw, info=info)
+    got, want = run_both(dc, g, static, state, inputs, masks, ndte=int(rng.integers(3, 8)), scal_kw=kw, info=info,
+                         scal_over=dict(cosw=np.cos(0.3), sinw=np.sin(0.3)) if general else None)
     assert_bitwise(got, want, f"marched interior, random cut {seed}: {nx} x {ny} in blocks of {bx} x {by}")
     # (windows of 64 positions along the edges leave blocks under ~190 columns without a rectangle: cg_one runs those alone)
     assert info["marched_items"] > 0 or __import__("os").environ["CICE_EVP_HIP_CGRID_STRIP_EDGE"] != "0", info
     print(f"STRIP_SWEEP seed {seed}: {nx} x {ny} / {bx} x {by}, items {info['marched_items']} x {info['marched_segment_rows']} rows, "
-          f"cells {info['marched_cells']}, lengths formed {info['marched_lengths_derived']}")
+          f"cells {info['marched_cells']}, lengths formed {info['marched_lengths_derived']}, general momentum step {general}")
 
 
 def test_cgrid_default_configuration_shortcuts_are_bit_neutral(monkeypatch):
