@@ -1334,11 +1334,13 @@ __device__ __forceinline__ void cg_st(void *base, unsigned off, double v) { *(do
 // (the general momentum step does not fit 256 registers, and a wave that spills to scratch waits for its prefetched rows at every
 // reload -- vmcnt counts in order: 983 us on 3600 x 2400, slower than cg_one; it gets a SIMD's register file to itself instead: 658 us
 // against cg_one's 905.  The last subcycle's instantiation, 32 bytes of scratch, is no faster that way: 754 us against 717)
-template <bool LEN, bool LAST, bool FAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 1, FAST ? 2 : 1))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z, EvpCgOne E)
+// AVGS: visc_method = avg_strength -- the corner's viscosity from the T -> U average of the strength (made once per call) and the
+// corner's own Delta (ice_dyn_evp.F90:992-996): deltaU of row j-1, one row late as in LAST, arrives exactly when level U of that row runs.
+template <bool LEN, bool LAST, bool FAST, bool AVGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FAST && !AVGS) ? 2 : 1, (FAST && !AVGS) ? 2 : 1))) void cg_strip(EvpCgrid A, EvpCgOne T, EvpCgStrip Z, EvpCgOne E)
 {
     if ((int)blockIdx.x >= 8 * Z.per_xcd) {
-        cg_one_window<FAST, 32, 8, LAST ? 1 : 0, true>(A, E, LAST ? 1 : 0, (int)blockIdx.x - 8 * Z.per_xcd, (int)(threadIdx.x & 31u), (int)(threadIdx.x >> 5));
+        cg_one_window<FAST, 32, 8, AVGS ? 2 : (LAST ? 1 : 0), true>(A, E, LAST ? 1 : 0, (int)blockIdx.x - 8 * Z.per_xcd, (int)(threadIdx.x & 31u), (int)(threadIdx.x >> 5));
         return;
     }
     const int lane = (int)(threadIdx.x & 63u);
@@ -1376,7 +1378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
     double vN1 = 0, dxN1 = 0, dyN1 = 0, na1 = 0, Q1 = 0, DV1 = 0, VQ1 = 0, ua1 = 0, XU1 = 0, XU2 = 0, YU1 = 0, XT1 = 0, YT1 = 0, W1 = 0;
     double sh1 = 0, SS1 = 0, SU1 = 0, un1 = 0, ve1 = 0, R1 = 0, sp1 = 0, sm1 = 0, s12_2 = 0;
     unsigned m1 = 0;
-    double dxU1 = 0, dyU1 = 0, uU1 = 0, vU1 = 0; unsigned g1 = 0;           // LAST: what deltaU of row j-1 still needs
+    double dxU1 = 0, dyU1 = 0, uU1 = 0, vU1 = 0; unsigned g1 = 0;           // LAST, AVGS: what deltaU of row j-1 still needs
     // loads in flight (issued one iteration, used the next)
     double L_uE = 0, L_dxE = 0, L_dyE = 0; unsigned L_g = 0;                 // A: row j+2 (LEN: L_dxE carries HTN)
     double L_vN = 0, L_dxN = 0, L_dyN = 0, L_dxU = 0, L_dyU = 0, L_dxT = 0, L_dyT = 0, L_str = 0, L_sp = 0, L_sm = 0, L_s12t = 0,
@@ -1422,6 +1424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
         // evp_cell.inc: the sum keeps the add of +0; a zero of the other sign could only show where uold is -0 exactly)
         double c_uiE = 0.0, c_viN = 0.0;
         if (revised) { c_uiE = I(CI_UE_INIT, o1); c_viN = I(CI_VN_INIT, o1); }
+        const double c_strU = AVGS ? cg_ld(A.strengthU, o1) : 0.0;
         // ---- rows move up: last iteration's "north" is this iteration's own row ----
         uE1 = uE0; uE0 = uEN; uEN = a_uE;
         dxE1 = dxE0; dyE1 = dyE0; ea1 = ea0;
@@ -1435,7 +1438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
             dxEN = a_dxE;
         }
         const double P0 = PNc;                              // uE * earea of row j: last iteration's row j+1
-        if (LAST) g1 = g0;
+        if (LAST || AVGS) g1 = g0;
         g0 = gN; gN = a_g;
         const double eaN = dxEN * dyEN;                     // earea = dxE * dyE (ice_grid.F90:684), row j+1
         const double PN = uEN * eaN;
@@ -1449,7 +1452,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
         const double W0 = hm0 * ta0;
 
         double sh = 0.0, uNo = 0.0, vEo = 0.0, eta = 0.0, sp = 0.0, sm = 0.0, R0 = 0.0, SS0 = 0.0, SU0 = 0.0, DV0 = 0.0, VQ0 = 0.0;
-        double uU0 = 0.0, vU0 = 0.0;
+        double uU0 = 0.0, vU0 = 0.0, dlt = 0.0;
         if (j >= ja - 2) {
             // ---- S (row j): strain_rates_U's shear at the corner (ice_dyn_shared.F90:2341-2444), the two averages of level C ----
             const double ea0W = cg_lane_up(ea0), eaNW = cg_lane_up(eaN), P0W = cg_lane_up(P0), PNW = cg_lane_up(PN);
@@ -1477,17 +1480,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
                 else if (LAST && ownx && j >= ja && j <= jb) cg_st(A.f[CF_SHEARU], cell * 8u, sh);
                 uU0 = uU; vU0 = vU;
             }
-            if (j >= ja && j <= jb + (LAST ? 1 : 0)) {     // (owned rows: what level C reads one row behind; LAST: deltaU's vvelE of the row to the north)
+            if (j >= ja - (AVGS ? 1 : 0) && j <= jb + ((LAST || AVGS) ? 1 : 0)) {     // (owned rows: what level C reads one row behind; LAST, AVGS: what deltaU takes too)
                 const double wn = (ea0W + ea0 + eaNW + eaN);
                 uNo = (wn == 0.0 ? 0.0 : (P0W + P0 + PNW + PN) / wn) * npc;           // avg_nw(uE, earea, o)
                 const double ws = (na1 + na1E + na0 + na0E);
                 vEo = (ws == 0.0 ? 0.0 : (Q1 + Q1E + Q0 + Q0E) / ws) * epc;           // avg_se(vN, narea, o)
             }
-            if (LAST) {
+            if (LAST || AVGS) {
                 // ---- deltaU of row j-1 (strain_rates_U, ice_dyn_shared.F90:2341-2444: the divergence and the tension at the corner) ----
                 const double uNe = cg_lane_dn(un1), dxN1E = cg_lane_dn(dxN1), dyN1E = cg_lane_dn(dyN1);
                 const unsigned g1E = cg_lane_dn_u(g1);
-                if (j > ja && j <= jb + 1 && ownx && (m1 & 2u)) {
+                if (AVGS ? (j >= ja) : (j > ja && j <= jb + 1 && ownx && (m1 & 2u))) {
                     const double epc = (g1 & 1u) ? 1.0 : 0.0, npc = (g1 & 2u) ? 1.0 : 0.0;
                     const double npe = (g1E & 2u) ? 1.0 : 0.0, epn = (g0 & 1u) ? 1.0 : 0.0;
                     double rxN = -1.0, rxNr = -1.0, ryE = -1.0, ryEr = -1.0;
@@ -1501,7 +1504,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
                     const double vEij = vEo_ * epc + (epn - epc) * epn * ryEr * vEn;
                     const double dv = dyU1 * (uNip1j - uNij) + uU1 * ddyN + dxU1 * (vEijp1 - vEij) + vU1 * ddxE;
                     const double tn = dyU1 * (uNip1j - uNij) - uU1 * ddyN - dxU1 * (vEijp1 - vEij) + vU1 * ddxE;
-                    cg_st(A.f[CF_DELTAU], (cell - nx) * 8u, sqrt(dv * dv + p.e_factor * (tn * tn + sh1 * sh1)));
+                    dlt = sqrt(dv * dv + p.e_factor * (tn * tn + sh1 * sh1));
+                    if (LAST && j > ja && j <= jb + 1 && ownx && (m1 & 2u)) cg_st(A.f[CF_DELTAU], (cell - nx) * 8u, dlt);
                 }
             }
             // ---- T (row j): stressC_T (ice_dyn_evp.F90:1758-1860) ----
@@ -1540,9 +1544,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
         }
         if (j >= ja) {
             // ---- U (row j-1): stressC_U with the T -> U average of etax2T (ice_dyn_evp.F90:1862-1972, ice_grid.F90 grid_average_X2Y 'NE') ----
-            const double W1E = cg_lane_dn(W1), W0E = cg_lane_dn(W0), R1E = cg_lane_dn(R1), R0E = cg_lane_dn(R0);
-            const double wtmp = (W1 + W1E + W0 + W0E);
-            const double e2 = wtmp == 0.0 ? 0.0 : (R1 + R1E + R0 + R0E) / wtmp;
+            double e2;
+            if (AVGS) {
+                double z, r;
+                visc_replpress(p, c_strU, dmin * ua1, dlt, z, e2, r);
+            } else {
+                const double W1E = cg_lane_dn(W1), W0E = cg_lane_dn(W0), R1E = cg_lane_dn(R1), R0E = cg_lane_dn(R0);
+                const double wtmp = (W1 + W1E + W0 + W0E);
+                e2 = wtmp == 0.0 ? 0.0 : (R1 + R1E + R0 + R0E) / wtmp;
+            }
             double s12 = c_s12;
             const double upd = (s12 * relax + p.arlx1i * 0.5 * e2 * sh1) * p.denom1;
             if (m1 & 2u) s12 = upd;
@@ -1600,7 +1610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
                     strinty_ = strinty; tauby_ = -vnew * Cb;
                 }
                 if (m1 & 2u) cg_st(A.f[CF_S12U], oc, s12c);
-                if (LAST) cg_st(A.f[CF_ETAU], oc, e2);
+                if (LAST && !AVGS) cg_st(A.f[CF_ETAU], oc, e2);     // (avg_strength: the reference never stores etax2U)
                 if (m1 & 4u) {
                     cg_st(A.f[CF_UE], oc, unew);
                     if (LAST) { cg_st(A.f[CF_STRX], oc, strintx_); cg_st(A.f[CF_TAUBX], oc, taubx_); }
@@ -1617,7 +1627,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST ? 2 : 
         vN1 = vN0; dxN1 = dxN0; dyN1 = dyN0; na1 = na0; Q1 = Q0; DV1 = DV0; VQ1 = VQ0; ua1 = ua0;
         XU2 = XU1; XU1 = dxU0 * dxU0; YU1 = dyU0 * dyU0; XT1 = dxT0 * dxT0; YT1 = dyT0 * dyT0; W1 = W0;
         sh1 = sh; SS1 = SS0; SU1 = SU0; un1 = uNo; ve1 = vEo; R1 = R0; sp1 = sp; sm1 = sm; m1 = m;
-        if (LAST) { dxU1 = dxU0; dyU1 = dyU0; uU1 = uU0; vU1 = vU0; }
+        if (LAST || AVGS) { dxU1 = dxU0; dyU1 = dyU0; uU1 = uU0; vU1 = vU0; }
     }
 }
 
@@ -1758,7 +1768,8 @@ void evp_launch_cgrid_strip(const EvpCgrid &A, const EvpCgOne &T, const EvpCgStr
     none.ntiles = 0;
     const EvpCgOne &W = (E && E->ntiles > 0) ? *E : none;
     const dim3 grid((unsigned)(8 * Z.per_xcd + W.ntiles)), block(256);
-#define CG_STRIP(L, X, F) hipLaunchKernelGGL((cg_strip<L, X, F>), grid, block, 0, st, A, T, Z, W)
+#define CG_STRIP(L, X, F) do { if (A.avg_strength) hipLaunchKernelGGL((cg_strip<L, X, F, true>), grid, block, 0, st, A, T, Z, W); \
+                               else hipLaunchKernelGGL((cg_strip<L, X, F, false>), grid, block, 0, st, A, T, Z, W); } while (0)
 #define CG_STRIP_F(L, X) do { if (fast) CG_STRIP(L, X, true); else CG_STRIP(L, X, false); } while (0)
     if (Z.lengths) {
         if (last) CG_STRIP_F(true, true);

@@ -398,8 +398,8 @@ struct EvpCgOne {
 };
 void evp_launch_cgrid_one(const EvpCgrid &A, const EvpCgOne &T, int fast, int last, hipStream_t st);
 // The interior of a large block, marched (evp_cgrid.hip: cg_strip): one wave per item = strip of 64 positions (up to 60 owned
-// columns) x segment of rows; T carries the buffers and tables as for cg_one (its window list is not used).  visc_method = avg_zeta and
-// the derived view of the static table (T.gmask) only; fast, last: as for cg_one.
+// columns) x segment of rows; T carries the buffers and tables as for cg_one (its window list is not used).  The derived view of
+// the static table (T.gmask) only; fast, last, A.avg_strength: as for cg_one.
 struct EvpCgStrip {
     const int *items;             // x 6: block, column of lane 2, first and last owned row (1-based), first and last owned lane
     int nitems, per_xcd;          // items; workgroups (of four items) per XCD (launch = 8 * per_xcd workgroups)

@@ -377,7 +377,7 @@ static int enqueue_fused(EvpCgrid A, int ndte, bool first, int nres = 0)
             for (int q = 0; q < 4; ++q) A.f[ONE_FIELDS[q]] = o4[q];
             A.s12_in = cur;
             A.f[CF_S12U] = other;
-            if (CG.one.nitems > 0 && !CG.avg_strength && T.gmask && !(last && env_test("CICE_EVP_HIP_CGRID_STRIP_LAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_LAST")))) {
+            if (CG.one.nitems > 0 && T.gmask && !(last && env_test("CICE_EVP_HIP_CGRID_STRIP_LAST") && !std::atoi(env_test("CICE_EVP_HIP_CGRID_STRIP_LAST")))) {
                 // the interior of the blocks marched, the windows along their edges as before: both read the previous
                 // subcycle's buffers only and own disjoint cells
                 EvpCgStrip Z{CG.one.items, CG.one.nitems, ((CG.one.nitems + 3) / 4 + 7) / 8, CG.one.strip_len};

@@ -701,6 +701,9 @@ def marched_case(seed, nx, ny, bs, case, holes, land, general=False):
     # seabed stress, an ocean turning angle's waterx, rheofact = 0 on some faces: the general momentum step (classic / revised EVP)
     (28, 280, 60, (280, 60), "full", 0.2, 0.03, False, "9", "2"),
     (29, 300, 44, (150, 44), "caps", 0.3, 0.0, True, None, "1"),
+    # visc_method = avg_strength (deltaU, a row late, feeds the corner viscosities of every subcycle); the second with the general momentum step
+    (30, 240, 52, (240, 52), "full", 0.2, 0.03, False, None, "2"),
+    (31, 300, 40, (150, 40), "caps", 0.1, 0.02, True, "6", "2"),
 ])
 def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes, land, revised, seg, shape, monkeypatch):
     """The one-launch schedule with the interior of each block marched (evp_cgrid.hip: cg_strip; the default on the 0.1-degree
@@ -714,11 +717,12 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
     if seed in (22, 23):          # the windows kept along the edges: 64 x 8 / 64 x 16 instead of 32 x 8
         monkeypatch.setenv("CICE_EVP_HIP_CGRID_STRIP_EDGE", "1" if seed == 22 else "2")
     from cice_amd import synth
-    dc, _, static, state, inputs, masks = marched_case(seed, nx, ny, bs, case, holes, land, general=seed in (28, 29))
+    dc, _, static, state, inputs, masks = marched_case(seed, nx, ny, bs, case, holes, land, general=seed in (28, 29, 31))
     kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
     scal = synth.evp_scalars(120, **kw)
-    if seed in (28, 29):
+    if seed in (28, 29, 31):
         scal.update(cosw=np.cos(0.4), sinw=np.sin(0.4))
+    visc = "avg_strength" if seed in (30, 31) else "avg_zeta"
     d, keep = evp.make_dims(dc, 0)
 
     def run():
@@ -726,7 +730,7 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
                           1.0 / static["uarea"], static["tarea"], keepalive=keep)
         try:
             core.cgrid_set_geometry(static)
-            out = core.cgrid_run(9, state, inputs, masks)
+            out = core.cgrid_run(9, state, inputs, masks, visc_method=visc)
             return out, core.cgrid_timings()
         finally:
             core.finalize()
@@ -749,7 +753,7 @@ def test_cgrid_marched_interior_vs_oracle_bitwise(seed, nx, ny, bs, case, holes,
                               [b.jhi for b in blks], [b.gi0 for b in blks], [b.gj0 for b in blks])
     prm = oracle.make_params(**{k: scal[k] for k in ("arlx1i", "denom1", "brlx", "revp", "e_factor", "epp2i", "capping",
                                                       "Ktens", "deltaminEVP", "u0", "cosw", "sinw", "rhow")})
-    want = oracle.cgrid_subcycle(dom, prm, 9, state, inputs, static, masks)
+    want = oracle.cgrid_subcycle(dom, prm, 9, state, inputs, static, masks, visc_method=visc)
     assert_bitwise(got, want, f"marched interior seed {seed}")
     if holes < 1.0:
         assert np.abs(want["uvelE"] - state["uvelE"]).max() > 0
@@ -784,6 +788,7 @@ def test_cgrid_marched_interior_random_cuts_vs_oracle(seed, monkeypatch):
     g = synth.derive_geometry(g0)
     cg = synth.cgrid_geometry(g)
     general = bool(rng.integers(0, 3) == 0)
+    visc = ("avg_zeta", "avg_zeta", "avg_strength")[int(rng.integers(0, 3))]
     state, inputs, masks = synth.cgrid_state(g, cg, case=case, seed=seed, seabed=general)
     if general:
         stir_momentum(inputs, masks, rng)
@@ -796,13 +801,13 @@ def test_cgrid_marched_interior_random_cuts_vs_oracle(seed, monkeypatch):
     static, state, inputs, masks = synth.cgrid_scatter(dc, 0, cg, state, inputs, masks)
     kw = dict(revised_evp=True, arlx=300.0, brlx=300.0) if revised else {}
     info = {}
-    got, want = run_both(dc, g, static, state, inputs, masks, ndte=int(rng.integers(3, 8)), scal_kw=kw, info=info,
+    got, want = run_both(dc, g, static, state, inputs, masks, ndte=int(rng.integers(3, 8)), scal_kw=kw, info=info, visc_method=visc,
                          scal_over=dict(cosw=np.cos(0.3), sinw=np.sin(0.3)) if general else None)
     assert_bitwise(got, want, f"marched interior, random cut {seed}: {nx} x {ny} in blocks of {bx} x {by}")
     # (windows of 64 positions along the edges leave blocks under ~190 columns without a rectangle: cg_one runs those alone)
     assert info["marched_items"] > 0 or __import__("os").environ["CICE_EVP_HIP_CGRID_STRIP_EDGE"] != "0", info
     print(f"STRIP_SWEEP seed {seed}: {nx} x {ny} / {bx} x {by}, items {info['marched_items']} x {info['marched_segment_rows']} rows, "
-          f"cells {info['marched_cells']}, lengths formed {info['marched_lengths_derived']}, general momentum step {general}")
+          f"cells {info['marched_cells']}, lengths formed {info['marched_lengths_derived']}, general momentum step {general}, {visc}")
 
 
 def test_cgrid_default_configuration_shortcuts_are_bit_neutral(monkeypatch):
