@@ -1195,16 +1195,17 @@ def test_cgrid_gx1_size_vs_reference_harness(tmp_path, bs, monkeypatch):
     """The C-grid loop at BASELINE's gx1 size (320 x 384, ndte = 120) against the reference ITSELF: operands captured from,
     outputs compared with, the reference's own evp() with grid_ice = 'C' (unmodified sources, strict build) run here on the
     box, as one block and as 2 x 2 blocks.  Every schedule that can run this grid: the default (the on-chip resident kernel
-    cg_res where it is eligible: all subcycles of a call but the first in one launch), forced one launch per subcycle (cg_one),
-    forced three launches -- bit-identical on all 19 arrays, ghost cells included, after 120 subcycles and after 7."""
+    cg_res where it is eligible: all subcycles of a call but the first in one launch), forced one launch per subcycle (cg_one; and
+    with the interior of each block marched: cg_strip), forced three launches -- bit-identical on all 19 arrays, ghost cells included, after 120 subcycles and after 7."""
     c = reference_cgrid_case(tmp_path, 320, 384, bs, "cyclic", "closed", icecase="full", nsub_list=[7, 120], ncalls=1, h_ndte=120)
     dom = c.oracle_domain()
     state, inputs, masks = c.cgrid_inputs(1)
     assert (masks["iceTmask"] != 0).sum() > 80000
     ran_resident = False
     for what, envs in (("default", {}), ("one launch per subcycle", {"CICE_EVP_HIP_CGRID_RESIDENT": "0"}),
+                       ("one launch per subcycle, the interior marched", {"CICE_EVP_HIP_CGRID_RESIDENT": "0", "CICE_EVP_HIP_CGRID_STRIP": "1"}),
                        ("three launches", {"CICE_EVP_HIP_CGRID_RESIDENT": "0", "CICE_EVP_HIP_CGRID_ONE": "0"})):
-        for k in ("CICE_EVP_HIP_CGRID_RESIDENT", "CICE_EVP_HIP_CGRID_ONE"):
+        for k in ("CICE_EVP_HIP_CGRID_RESIDENT", "CICE_EVP_HIP_CGRID_ONE", "CICE_EVP_HIP_CGRID_STRIP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in envs.items():
             monkeypatch.setenv(k, v)
@@ -1220,6 +1221,7 @@ def test_cgrid_gx1_size_vs_reference_harness(tmp_path, bs, monkeypatch):
                     ran_resident = ran_resident or t["resident_subcycles"] == nsub - 1
                 else:
                     assert t["resident_subcycles"] == 0
+                assert (t["marched_items"] > 0) == ("marched" in what), t
         finally:
             core.finalize()
     assert np.abs(out["uvelE"]).max() > 1e-3
