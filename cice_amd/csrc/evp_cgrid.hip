@@ -1287,10 +1287,11 @@ __global__ __launch_bounds__(ONE_X *ONE_Y) void cg_one(EvpCgrid A, EvpCgOne T, i
 // quotients that several neighbours use (velocity x area, hm x etax2T x tarea, uE / dyE ...) are formed once by their own lane and
 // shifted -- the same operation on the same operands, so the same bits.  No LDS, no barrier, two waves per SIMD.
 // Same arithmetic AT the same cells on the same inputs (the previous subcycle's buffers) as cg_one: which kernel owns a cell does
-// not show in its bits.  Only what the default configuration needs: the short cuts of FAST hold, visc_method = avg_zeta, the derived
-// view of the static table, not the last subcycle of a call (those run cg_one).  Only "regular" positions (interior cells of the
-// block, each its own source): the host hands this kernel the rectangle of the block that cg_one's regular windows cover and keeps
-// the windows along the block's edges for cg_one.
+// not show in its bits.  The derived view of the static table only (else cg_one); template variants for the lengths formed in the
+// kernel (LEN), the last subcycle of a call (LAST), the general momentum step (FAST = false) and visc_method = avg_strength (AVGS),
+// described above the kernel.  Only "regular" positions (interior cells of the block, each its own source): the host hands this
+// kernel the rectangle of the block that the regular windows of 32 x 8 cover (halo_plan.cpp: strip_zones / strip_items) and keeps
+// the windows along the block's edges for cg_one -- which run as further workgroups of the same launch.
 // Lanes: S on 0..62 (lane 63 only loads: the east neighbour's operands), T on 1..62, U on 1..61, C -- the owned cells -- on 2..61.
 // =====================================================================
 __device__ __forceinline__ double cg_lane_up(double v)    // lane l <- lane l-1 (lane 0: undefined, never used)
