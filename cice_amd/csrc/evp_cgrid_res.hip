@@ -187,6 +187,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
     // FOLD: raw values of the two rows at the fold, [.][0] the window's own fold row, [.][1] the mirrored one: uvelU, vvelU, uvelN, vvelE
     // (level S), the new vvelN (level C)
     __shared__ double s_fr[FOLD ? 5 : 1][2][LW];
+    auto FR = [](int k) constexpr { return FOLD ? k : 0; };       // (planes 1 .. 4 exist in fold windows only: the accesses below are dead code elsewhere)
 
     const int t = threadIdx.x;
     const int tx = t & (X - 1), ty = t / X;
@@ -585,12 +586,12 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             const double eao = s_ea[lo], ean = s_ea[FOLD ? nE : lo + LW], nao = s_na[lo], nae = s_na[lo + 1];
             double uU = 0.0, vU = 0.0;
             if (onf) {
-                uNo = fold_vec(s_fr[2][frow][tx], s_fr[2][1 - frow][16 - tx], fb & 4u);
-                vEo = s_fr[3][frow][tx];
-                if (fb & 2u) { uU = (-1.0) * s_fr[0][frow][tx]; vU = (-1.0) * s_fr[1][frow][tx]; }
+                uNo = fold_vec(s_fr[FR(2)][frow][tx], s_fr[FR(2)][1 - frow][16 - tx], fb & 4u);
+                vEo = s_fr[FR(3)][frow][tx];
+                if (fb & 2u) { uU = (-1.0) * s_fr[0][frow][tx]; vU = (-1.0) * s_fr[FR(1)][frow][tx]; }
                 else {
                     uU = fold_vec(s_fr[0][frow][tx], s_fr[0][1 - frow][15 - tx], fb & 1u);
-                    vU = fold_vec(s_fr[1][frow][tx], s_fr[1][1 - frow][15 - tx], fb & 1u);
+                    vU = fold_vec(s_fr[FR(1)][frow][tx], s_fr[FR(1)][1 - frow][15 - tx], fb & 1u);
                 }
             } else {
                 if (own || (AVGS && fullS)) {
@@ -621,8 +622,8 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
                 if (fullS) {             // deltaU is wanted (avg_zeta: once per call, for the caller): the rest of strain_rates_U
                     double uNe, vEn;
                     if (onf) {           // uvelN one column to the east: ON the fold as well; vvelE beyond the fold: the mirrored cell's, sign changed
-                        uNe = fold_vec(s_fr[2][frow][tx + 1], s_fr[2][1 - frow][15 - tx], fb & 8u);
-                        vEn = -s_fr[3][1 - frow][15 - tx];
+                        uNe = fold_vec(s_fr[FR(2)][frow][tx + 1], s_fr[FR(2)][1 - frow][15 - tx], fb & 8u);
+                        vEn = -s_fr[FR(3)][1 - frow][15 - tx];
                     } else {
                         uNe = avg4(uEo, eao, s_uE[li + 1], s_ea[lo + 1], uEn, ean, s_uE[li + LW + 1], s_ea[lo + LW + 1]) * npe;
                         vEn = avg4(vNo, nao, vNe, nae, s_vN[li + LW], s_na[lo + LW], s_vN[li + LW + 1], s_na[lo + LW + 1]) * epn;
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             }
             // (nobody reads the velocity tile between the barrier above and the one after the next poll)
             vout = (m & 8u) ? vnew : vNo;
-            if (onf) s_fr[4][frow][tx] = vout;        // raw: both sides of the fold, for the average below
+            if (onf) s_fr[FR(4)][frow][tx] = vout;        // raw: both sides of the fold, for the average below
             if (own) {
                 const double uout = (m & 4u) ? unew : uEo;
                 s_uE[li] = uout;
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(X *Y, 3) void cg_res(EvpCgrid A, EvpCgRes R)
             // vvelN ON the fold: what the halo update makes of the two raw values, on the tile and in the record
             __syncthreads();
             if (own && FC.cls == 1) {
-                const double v = fold_vec(vout, s_fr[4][1][16 - tx], FC.fb & 4u);
+                const double v = fold_vec(vout, s_fr[FR(4)][1][16 - tx], FC.fb & 4u);
                 s_vN[li] = v;
                 if (pub) st_rec2(wr + 2 * L, pack_rec(s_uE[li], want + 1u), pack_rec(v, want + 1u));
             }
