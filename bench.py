@@ -1010,7 +1010,7 @@ def main():
     if want("cgrid") and a.workload == "gx1" and world == 1:
         try:      # next-tier row f-4: the C-grid subcycle on the same grid, and on the 0.1-degree-class one (HBM-bound)
             extra["cgrid"] = cgrid_measure("gx1", "full", 120, 3, 1)
-            extra["cgrid"]["s01"] = cgrid_measure("s01", "full", 12, 1, 1)
+            extra["cgrid"]["s01"] = cgrid_measure("s01", "full", 120, 1, 1)     # (ndte = 120 as the headline: a call's first and last subcycle weigh 1 / 120 each)
             extra["cgrid"]["tx1"] = cgrid_measure("tx1", "full", 120, 3, 1)
             extra["cgrid"]["per_call_ms"] = cgrid_per_call("gx1", "full", 120)
         except Exception as e:  # noqa: BLE001

@@ -77,7 +77,7 @@ def run(workload):
 
 
 CGRID_FIELDS = ("uvelE", "vvelN", "stresspT", "stress12U")      # bench.py CGRID_VERIFY_FIELDS
-CGRID_CONFIGS = {"gx3": ("full", 120, [1, 4]), "gx1": ("full", 120, [1, 4]), "s01": ("full", 12, [2]), "tx1": ("full", 120, [4])}
+CGRID_CONFIGS = {"gx3": ("full", 120, [1, 4]), "gx1": ("full", 120, [1, 4]), "s01": ("full", 12, [2]), "s01@120": ("full", 120, [2]), "tx1": ("full", 120, [4])}
 
 
 def cgrid_inputs(workload, case):
@@ -94,6 +94,7 @@ def cgrid_inputs(workload, case):
 
 def run_cgrid(workload):
     case, ndte, cps = CGRID_CONFIGS[workload]
+    workload = workload.split("@")[0]
     dc, (static, state, inputs, masks) = cgrid_inputs(workload, case)
     scal = synth.evp_scalars(ndte)
     blks = dc.local_blocks(0)
