@@ -770,7 +770,8 @@ def test_cgrid_marched_interior_random_cuts_vs_oracle(seed, monkeypatch):
     classic / revised EVP -- all drawn from the seed; every array equal to the oracle's, bit for bit.  CGRID_STRIP_SWEEP_SEEDS adds seeds."""
     rng = np.random.default_rng(seed)
     nbx, nby = int(rng.integers(1, 3)), int(rng.integers(1, 3))
-    bx, by = int(rng.integers(130, 260)), int(rng.integers(24, 70))
+    scale = int(__import__("os").environ.get("CGRID_STRIP_SWEEP_SCALE", "1"))       # (wide runs: larger blocks, several strips and segments)
+    bx, by = int(rng.integers(130, 260)) * scale, int(rng.integers(24, 70)) * scale
     nx, ny = nbx * bx - int(rng.integers(0, 20)) * (nbx > 1), nby * by - int(rng.integers(0, 6)) * (nby > 1)
     case, holes, land = ("full", "caps")[int(rng.integers(0, 2))], float(rng.choice([0.0, 0.2, 0.5])), float(rng.choice([0.0, 0.03, 0.1]))
     revised = bool(rng.integers(0, 2))
