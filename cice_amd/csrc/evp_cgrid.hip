@@ -12,7 +12,8 @@
 // and no halo kernel runs inside the loop.  Fields the reference never exchanges (etax2U, deltaU, stress12T,
 // strintxE/yN, taubxE/yN) are not pushed: their ghost cells end up exactly as the reference leaves them.
 //
-// Three schedules.  "one" (cg_one, further down; the default on one rank without a fold): ONE launch per subcycle, the three
+// Three schedules.  "one" (cg_one, further down; the default on one rank without a fold -- from 300 000 cells per rank with the interior
+// of every block marched by cg_strip, at the end of this file, and cg_one's windows along the block edges): ONE launch per subcycle, the three
 // dependent levels inside a workgroup, neighbouring positions recomputed.  "phases": the five phases as five launches (any
 // visc_method; tripole grids, with a fold step after each).  "fused" (visc_method = avg_zeta; several ranks):
 // three launches per subcycle --
