@@ -91,7 +91,8 @@ int cice_evp_hip_cgrid_strip_plan(const cice_evp_hip_dims *dims, int32_t ex, int
     build_window_table(*dims, P, ex, ey, 1 << 20, t4, tb);
     // (ghost images: the sources of the rank's own ghost copies)
     std::vector<int> img((size_t)dims->nblocks * dims->nx_block * dims->ny_block, -1);
-    for (size_t k = 0; k < P.local_src.size(); ++k) img[(size_t)P.local_src[k]] = 0;
+    for (size_t k = 0; k < P.local_src.size(); ++k)
+        if (P.local_src[k] >= 0) img[(size_t)P.local_src[k]] = 0;        // (-1: a ghost cell filled with 0, no source)
     std::vector<StripZone> zones;
     strip_zones(*dims, t4, ex, ey, img.data(), zones);
     const int s = strip_items(zones, ex, ey, lo0, slots, seg_min, seg, it);
