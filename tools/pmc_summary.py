@@ -24,8 +24,8 @@ DOMINANT = {"gx1res": "evp_resident", "gx1str": "evp_subcycle_tile", "s01str": "
 
 
 def _is(name: str, match) -> bool:
-    """`match`: a substring, or a tuple of substrings that must all occur."""
-    return all(m in name for m in (match if isinstance(match, tuple) else (match,)))
+    """`match`: a substring, or "re:<pattern>"."""
+    return bool(re.search(match[3:], name)) if match.startswith("re:") else match in name
 
 
 def counters(path: Path, match):
@@ -139,8 +139,8 @@ def main():
             continue
         entry = {}
         # (one launch per subcycle: on large domains the marched kernel cg_strip -- the windows along the block edges ride in its launch;
-        # the first match is the instantiation for all subcycles but the last --; elsewhere cg_one alone)
-        for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"marched": ("cg_strip<", ", false>("), "one_launch": "cg_one"} if key.endswith("one") else CG).items():
+        # matched: the instantiations with LAST = false, i.e. every subcycle of a call but the first and the last --; elsewhere cg_one alone)
+        for tag, match in ({"resident": "cg_res<"} if key.endswith("res") else {"marched": "re:cg_strip<(true|false), false,", "one_launch": "cg_one"} if key.endswith("one") else CG).items():
             if kernel_stats(st, match) is None:
                 continue
             e = {"kernel_trace": kernel_stats(st, match)}
